@@ -1,0 +1,157 @@
+/*
+ * yacht_hip.h — C ABI of libyacht_hip.so, the MI355X (gfx950) containment engine for YACHT.
+ *
+ * This is the drop-in boundary for YACHT's one data-parallel hot path: sorted-uint64
+ * FracMinHash set intersection.  The reference has no in-process FFI on this path; it
+ * crosses PROCESS boundaries with files.  Each entry point below names the
+ * reference interface it replaces (paths relative to the YACHT repo, v1.4.0):
+ *
+ *   yh_db_create        replaces  read_sketches + compute_index_from_sketches
+ *                                 (src/cpp/main.cpp:105-124, :215-246) and the per-run re-reading
+ *                                 of every reference .sig (src/yacht/hypothesis_recovery_src.py:93,154,168)
+ *   yh_overlap          replaces  `sourmash scripts multisearch` as used by
+ *                                 get_organisms_with_nonzero_overlap (hypothesis_recovery_src.py:93-113)
+ *   yh_exclusive        replaces  the set loops of get_exclusive_hashes (hypothesis_recovery_src.py:165-204)
+ *   yh_pairwise         replaces  compute_intersection_matrix(_by_sketches) (src/cpp/main.cpp:249-366)
+ *   yh_index_stats      replaces  the three statistics printed at src/cpp/main.cpp:242-244
+ *   yh_train_select     replaces  do_yacht_train (src/cpp/main.cpp:371-407)
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative YH_ERR_* code on failure;
+ *     yh_last_error() returns a thread-local, library-owned message for the last failure;
+ *   - the caller allocates and owns every buffer it passes; the library never frees caller memory;
+ *   - handles are created/destroyed in pairs; one handle must not be used from two threads at
+ *     once, distinct handles are independent;
+ *   - pointer parameters named d_* are DEVICE pointers (HBM of the handle's device); all other
+ *     pointers are host pointers;
+ *   - there is NO CPU fallback: every compute entry fails with YH_ERR_NO_DEVICE when no gfx950
+ *     device is usable.  The CPU restatement of the algorithm lives in oracle/ and is test
+ *     infrastructure only.
+ *
+ * Data model
+ *   A reference database is N sketches in CSR form: `values` holds every reference's hashes
+ *   back to back, each reference's slice STRICTLY ASCENDING (sourmash "mins" order), and
+ *   `offsets[N+1]` delimits the slices.  A sample sketch is one strictly ascending uint64 array.
+ */
+#ifndef YACHT_HIP_H
+#define YACHT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define YH_ABI_VERSION 1
+
+enum {
+    YH_OK               = 0,
+    YH_ERR_INVALID_ARG  = -1,  /* null pointer, bad size, bad handle                          */
+    YH_ERR_NO_DEVICE    = -2,  /* no usable HIP device / device id out of range               */
+    YH_ERR_HIP          = -3,  /* a HIP runtime call failed (message has the HIP error string) */
+    YH_ERR_UNSORTED     = -4,  /* a sketch is not strictly ascending                          */
+    YH_ERR_CAPACITY     = -5,  /* caller buffer too small (two-call sizing: see yh_pairwise)  */
+    YH_ERR_OOM          = -6,  /* device or host allocation failed                            */
+    YH_ERR_UNSUPPORTED  = -7   /* e.g. index not built for this handle                        */
+};
+
+/* yh_db_create flags */
+#define YH_DB_DEFAULT      0u
+#define YH_DB_NO_INDEX     1u  /* skip the shared-hash inverted index (overlap-only handle)     */
+#define YH_DB_KEEP_CSR     2u  /* keep the plain CSR resident too (needed by yh_overlap_bsearch) */
+
+typedef struct yh_db yh_db;
+
+typedef struct yh_db_info {
+    uint64_t n_refs;             /* N                                                         */
+    uint64_t n_hashes;           /* H = offsets[N]                                            */
+    uint64_t max_hash;           /* largest hash in the database (0 if H == 0)                */
+    uint32_t n_partitions;       /* P hash-range partitions of the partitioned CSR            */
+    uint32_t partition_shift;    /* partition of hash h = h >> partition_shift                */
+    uint64_t n_distinct;         /* distinct hashes over all references (index built only)    */
+    uint64_t n_shared_distinct;  /* distinct hashes present in >= 2 references ("index size") */
+    uint64_t n_shared_postings;  /* sum over shared hashes of their reference counts          */
+    uint64_t device_bytes;       /* HBM held by the handle                                    */
+    int32_t  device_id;
+    uint32_t flags;
+} yh_db_info;
+
+typedef struct yh_timing {
+    float ms_overlap_kernel;     /* last overlap tile kernel (HIP events on the handle's stream) */
+    float ms_exclusive_kernels;  /* last shared-hit + postings + finalize kernels                 */
+    float ms_pairwise_kernels;   /* last accumulate + count + emit kernels                       */
+    float ms_db_build;           /* partition + (optional) index build at create time            */
+} yh_timing;
+
+/* ---- library / device ---------------------------------------------------------------- */
+const char* yh_last_error(void);
+int yh_abi_version(void);
+int yh_device_count(int* n_devices);
+
+/* ---- database handle ------------------------------------------------------------------ */
+/* Upload a CSR reference database to `device_id`, validate ordering, build the hash-range
+ * partitioned CSR and (unless YH_DB_NO_INDEX) the shared-hash inverted index.
+ * partitions_hint = 0 chooses P from the mean sketch size.                                 */
+int yh_db_create(const uint64_t* values, const uint64_t* offsets, uint64_t n_refs,
+                 int device_id, uint32_t flags, uint32_t partitions_hint, yh_db** out);
+/* Same, but `d_values`/`d_offsets` already live in the HBM of `device_id` (not modified,
+ * not retained after return unless YH_DB_KEEP_CSR is set, in which case they are COPIED). */
+int yh_db_create_device(const uint64_t* d_values, const uint64_t* d_offsets, uint64_t n_refs,
+                        int device_id, uint32_t flags, uint32_t partitions_hint, yh_db** out);
+int yh_db_destroy(yh_db* db);
+int yh_db_get_info(yh_db* db, yh_db_info* info);
+/* Run all of the handle's work on this hipStream_t (NULL = the library's own stream).      */
+int yh_db_set_stream(yh_db* db, void* hip_stream);
+/* Block until everything queued on the handle's stream has finished.                       */
+int yh_db_synchronize(yh_db* db);
+int yh_db_get_timing(yh_db* db, yh_timing* t);
+
+/* ---- yacht run, step 1: overlap of one sample with every reference ----------------------
+ * overlap[j] = |S ∩ R_j| for j in [0, N).  Host-pointer form is synchronous and validates
+ * that the sample is strictly ascending.                                                    */
+int yh_overlap(yh_db* db, const uint64_t* sample, uint64_t n_sample, uint32_t* overlap);
+/* Device-pointer form: enqueues on the handle's stream and returns (no host sync).
+ * d_overlap[N] is overwritten.  The sample must be strictly ascending (not checked).       */
+int yh_overlap_device(yh_db* db, const uint64_t* d_sample, uint64_t n_sample, uint32_t* d_overlap);
+/* Same result through the plain one-wave-per-reference binary-search kernel (needs
+ * YH_DB_KEEP_CSR).  Kept as an independent on-device cross-check and A/B baseline.        */
+int yh_overlap_bsearch(yh_db* db, const uint64_t* sample, uint64_t n_sample, uint32_t* overlap);
+int yh_overlap_bsearch_device(yh_db* db, const uint64_t* d_sample, uint64_t n_sample, uint32_t* d_overlap);
+
+/* ---- yacht run, step 2: exclusive hashes relative to a subset ----------------------------
+ * For every j with subset_mask[j] != 0:
+ *   n_excl[j]  = |{h in R_j : h is in no other masked reference}|
+ *   n_match[j] = |{h in R_j : same condition, and h in S}|
+ * and 0 for unmasked j.  Needs the index.                                                   */
+int yh_exclusive(yh_db* db, const uint8_t* subset_mask, const uint64_t* sample, uint64_t n_sample,
+                 uint32_t* n_excl, uint32_t* n_match);
+/* Host-pointer form of the fused `yacht run` counts below: overlap, mask = (overlap > 0),
+ * exclusive counts relative to that mask.  Synchronous; validates the sample ordering.       */
+int yh_run(yh_db* db, const uint64_t* sample, uint64_t n_sample,
+           uint32_t* overlap, uint32_t* n_excl, uint32_t* n_match);
+/* Fused device-side `yacht run` counts: overlap, mask = (overlap > 0), exclusive counts.
+ * All outputs are device arrays of N uint32 (d_n_excl/d_n_match may be NULL to stop after
+ * the overlap).  Enqueues on the handle's stream, no host sync.                             */
+int yh_run_device(yh_db* db, const uint64_t* d_sample, uint64_t n_sample,
+                  uint32_t* d_overlap, uint32_t* d_n_excl, uint32_t* d_n_match);
+
+/* ---- yacht train: pairwise intersections ---------------------------------------------------
+ * Emits every ORDERED pair (i, j), i != j, row_begin <= i < row_end, both sketches non-empty,
+ * count = |R_i ∩ R_j| > 0 and !(1.0*count/|R_i| < c_thresh), sorted by (i, j).
+ * Two-call sizing: cap = 0 (or too small) stores the required length in *n_out and returns
+ * YH_ERR_CAPACITY when cap != 0 is too small, YH_OK when cap == 0.                            */
+int yh_pairwise(yh_db* db, double c_thresh, uint64_t row_begin, uint64_t row_end, uint64_t cap,
+                uint32_t* pair_i, uint32_t* pair_j, uint32_t* pair_count, uint64_t* n_out);
+/* distinct hashes, hashes seen in exactly one reference, hashes kept in the index.           */
+int yh_index_stats(yh_db* db, uint64_t* n_distinct, uint64_t* n_singletons, uint64_t* n_index);
+
+/* Greedy size-ordered selection (host).  `pair_i/pair_j` are the pairs with C(i->j) >= C,
+ * sorted by (i, j).  selected[] receives the kept reference ids in walk order.              */
+int yh_train_select(const uint32_t* sizes, uint64_t n_refs,
+                    const uint32_t* pair_i, const uint32_t* pair_j, uint64_t n_pairs,
+                    uint32_t* selected, uint64_t* n_selected);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YACHT_HIP_H */

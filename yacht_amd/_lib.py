@@ -1,0 +1,139 @@
+"""ctypes binding of libyacht_hip.so — the C ABI declared in include/yacht_hip.h.
+
+There is deliberately no fallback: if the shared library cannot be loaded, or a call reports
+that no HIP device is usable, a YachtHipError is raised.  The CPU restatement under oracle/ is
+test infrastructure and is never imported from here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+from . import build as _build
+
+YH_OK = 0
+YH_ERR_INVALID_ARG = -1
+YH_ERR_NO_DEVICE = -2
+YH_ERR_HIP = -3
+YH_ERR_UNSORTED = -4
+YH_ERR_CAPACITY = -5
+YH_ERR_OOM = -6
+YH_ERR_UNSUPPORTED = -7
+
+YH_DB_DEFAULT = 0
+YH_DB_NO_INDEX = 1
+YH_DB_KEEP_CSR = 2
+
+_ERR_NAMES = {
+    YH_ERR_INVALID_ARG: "YH_ERR_INVALID_ARG",
+    YH_ERR_NO_DEVICE: "YH_ERR_NO_DEVICE",
+    YH_ERR_HIP: "YH_ERR_HIP",
+    YH_ERR_UNSORTED: "YH_ERR_UNSORTED",
+    YH_ERR_CAPACITY: "YH_ERR_CAPACITY",
+    YH_ERR_OOM: "YH_ERR_OOM",
+    YH_ERR_UNSUPPORTED: "YH_ERR_UNSUPPORTED",
+}
+
+
+class YachtHipError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"{_ERR_NAMES.get(code, code)}: {message}")
+        self.code = code
+
+
+class DbInfo(C.Structure):
+    _fields_ = [
+        ("n_refs", C.c_uint64),
+        ("n_hashes", C.c_uint64),
+        ("max_hash", C.c_uint64),
+        ("n_partitions", C.c_uint32),
+        ("partition_shift", C.c_uint32),
+        ("n_distinct", C.c_uint64),
+        ("n_shared_distinct", C.c_uint64),
+        ("n_shared_postings", C.c_uint64),
+        ("device_bytes", C.c_uint64),
+        ("device_id", C.c_int32),
+        ("flags", C.c_uint32),
+    ]
+
+
+class Timing(C.Structure):
+    _fields_ = [
+        ("ms_overlap_kernel", C.c_float),
+        ("ms_exclusive_kernels", C.c_float),
+        ("ms_pairwise_kernels", C.c_float),
+        ("ms_db_build", C.c_float),
+    ]
+
+
+_u64p = C.POINTER(C.c_uint64)
+_u32p = C.POINTER(C.c_uint32)
+_u8p = C.POINTER(C.c_uint8)
+_vp = C.c_void_p
+
+# name -> (restype, argtypes); every symbol include/yacht_hip.h declares
+SIGNATURES = {
+    "yh_last_error": (C.c_char_p, []),
+    "yh_abi_version": (C.c_int, []),
+    "yh_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "yh_db_create": (C.c_int, [_vp, _vp, C.c_uint64, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(_vp)]),
+    "yh_db_create_device": (C.c_int, [_vp, _vp, C.c_uint64, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(_vp)]),
+    "yh_db_destroy": (C.c_int, [_vp]),
+    "yh_db_get_info": (C.c_int, [_vp, C.POINTER(DbInfo)]),
+    "yh_db_set_stream": (C.c_int, [_vp, _vp]),
+    "yh_db_synchronize": (C.c_int, [_vp]),
+    "yh_db_get_timing": (C.c_int, [_vp, C.POINTER(Timing)]),
+    "yh_overlap": (C.c_int, [_vp, _vp, C.c_uint64, _vp]),
+    "yh_overlap_device": (C.c_int, [_vp, _vp, C.c_uint64, _vp]),
+    "yh_overlap_bsearch": (C.c_int, [_vp, _vp, C.c_uint64, _vp]),
+    "yh_overlap_bsearch_device": (C.c_int, [_vp, _vp, C.c_uint64, _vp]),
+    "yh_exclusive": (C.c_int, [_vp, _vp, _vp, C.c_uint64, _vp, _vp]),
+    "yh_run": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp, _vp]),
+    "yh_run_device": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp, _vp]),
+    "yh_pairwise": (C.c_int, [_vp, C.c_double, C.c_uint64, C.c_uint64, C.c_uint64, _vp, _vp, _vp,
+                              C.POINTER(C.c_uint64)]),
+    "yh_index_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "yh_train_select": (C.c_int, [_vp, C.c_uint64, _vp, _vp, C.c_uint64, _vp, C.POINTER(C.c_uint64)]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib_path() -> str:
+    return os.environ.get("YACHT_HIP_LIB", _build.LIB_PATH)
+
+
+def load() -> C.CDLL:
+    """Load (once) and type the shared library.  Raises if it is missing or incomplete."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise YachtHipError(
+            YH_ERR_NO_DEVICE,
+            f"{path} is missing: build it with `python -m yacht_amd.build` (hipcc, gfx950). "
+            "There is no CPU fallback.",
+        )
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = the .so does not match the header
+        fn.restype = res
+        fn.argtypes = args
+    if lib.yh_abi_version() != 1:
+        raise YachtHipError(YH_ERR_INVALID_ARG, f"ABI version mismatch in {path}")
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    if rc != YH_OK:
+        msg = load().yh_last_error()
+        raise YachtHipError(rc, msg.decode("utf-8", "replace") if msg else "")
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    rc = load().yh_device_count(C.byref(n))
+    return n.value if rc == YH_OK else 0

@@ -1,0 +1,494 @@
+// yh_api.hip — the extern "C" boundary of libyacht_hip.so (declared in include/yacht_hip.h).
+#include "yh_common.h"
+
+#include <stdarg.h>
+#include <string.h>
+
+#include <algorithm>
+#include <utility>
+#include <vector>
+
+// ---- error plumbing ------------------------------------------------------------------------------
+static thread_local char g_err[1024] = "";
+
+void yh_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int yh_dmalloc(yh_db* db, void** p, size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) {
+        *p = nullptr;
+        yh_set_error("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+        return YH_ERR_OOM;
+    }
+    db->device_bytes += bytes;
+    return YH_OK;
+}
+
+static void ring_create(EventRing& r) {
+    if (r.created) return;
+    for (int i = 0; i < TIMING_RING; ++i) {
+        (void)hipEventCreate(&r.beg[i]);
+        (void)hipEventCreate(&r.end[i]);
+    }
+    r.created = true;
+}
+static void ring_destroy(EventRing& r) {
+    if (!r.created) return;
+    for (int i = 0; i < TIMING_RING; ++i) {
+        (void)hipEventDestroy(r.beg[i]);
+        (void)hipEventDestroy(r.end[i]);
+    }
+    r.created = false;
+}
+void yh_ring_record_begin(yh_db* db, EventRing& r) {
+    if (!r.created) return;
+    (void)hipEventRecord(r.beg[r.head], db->stream);
+}
+void yh_ring_record_end(yh_db* db, EventRing& r) {
+    if (!r.created) return;
+    (void)hipEventRecord(r.end[r.head], db->stream);
+    r.head = (r.head + 1) % TIMING_RING;
+    if (r.pending < TIMING_RING) ++r.pending;
+}
+// mean elapsed ms over the launches recorded since the last read (stream must be idle)
+static float ring_read(EventRing& r) {
+    if (!r.created || r.pending == 0) return 0.f;
+    double acc = 0.0;
+    int n = 0;
+    for (int k = 0; k < r.pending; ++k) {
+        const int slot = (r.head - 1 - k + 2 * TIMING_RING) % TIMING_RING;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.beg[slot], r.end[slot]) == hipSuccess) { acc += ms; ++n; }
+    }
+    r.pending = 0;
+    return n ? (float)(acc / n) : 0.f;
+}
+
+static bool db_ok(yh_db* db) {
+    if (!db) { yh_set_error("null yh_db handle"); return false; }
+    return true;
+}
+static int db_select(yh_db* db) {
+    YH_HIP(hipSetDevice(db->device));
+    return YH_OK;
+}
+
+static int ensure_sample_tmp(yh_db* db, u64 n) {
+    if (n <= db->sample_tmp_cap) return YH_OK;
+    if (db->d_sample_tmp) { (void)hipFree(db->d_sample_tmp); db->d_sample_tmp = nullptr; db->sample_tmp_cap = 0; }
+    const u64 cap = std::max<u64>(n, 1024);
+    YH_HIP(hipMalloc((void**)&db->d_sample_tmp, cap * sizeof(u64)));
+    db->sample_tmp_cap = cap;
+    return YH_OK;
+}
+
+extern "C" {
+
+const char* yh_last_error(void) { return g_err; }
+int yh_abi_version(void) { return YH_ABI_VERSION; }
+
+int yh_device_count(int* n_devices) {
+    if (!n_devices) { yh_set_error("n_devices is null"); return YH_ERR_INVALID_ARG; }
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *n_devices = 0;
+        yh_set_error("hipGetDeviceCount failed: %s", hipGetErrorString(e));
+        return YH_ERR_NO_DEVICE;
+    }
+    *n_devices = n;
+    return YH_OK;
+}
+
+static int db_create_common(const u64* values, const u64* offsets, bool on_device, u64 n_refs, int device_id,
+                            uint32_t flags, uint32_t partitions_hint, yh_db** out) {
+    if (!out) { yh_set_error("out is null"); return YH_ERR_INVALID_ARG; }
+    *out = nullptr;
+    if (!offsets) { yh_set_error("offsets is null"); return YH_ERR_INVALID_ARG; }
+    if (n_refs > 0xfffffff0ull) { yh_set_error("too many references"); return YH_ERR_INVALID_ARG; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        yh_set_error("no HIP device available (libyacht_hip has no CPU fallback)");
+        return YH_ERR_NO_DEVICE;
+    }
+    if (device_id < 0 || device_id >= ndev) {
+        yh_set_error("device_id %d out of range [0, %d)", device_id, ndev);
+        return YH_ERR_NO_DEVICE;
+    }
+    YH_HIP(hipSetDevice(device_id));
+
+    yh_db* db = new yh_db();
+    db->device = device_id;
+    db->flags = flags;
+    db->n_refs = n_refs;
+    int rc = YH_OK;
+    u64* d_values_in = nullptr;   // arrays the build reads (borrowed or temporary)
+    u64* d_offsets_in = nullptr;
+    bool own_inputs = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    do {
+        if (hipStreamCreateWithFlags(&db->own_stream, hipStreamNonBlocking) != hipSuccess) {
+            yh_set_error("hipStreamCreate failed"); rc = YH_ERR_HIP; break;
+        }
+        db->stream = db->own_stream;
+        (void)hipEventCreate(&ev0);
+        (void)hipEventCreate(&ev1);
+
+        u64 H = 0;
+        if (on_device) {
+            if (hipMemcpy(&H, offsets + n_refs, sizeof(u64), hipMemcpyDeviceToHost) != hipSuccess) {
+                yh_set_error("cannot read d_offsets[n_refs]"); rc = YH_ERR_HIP; break;
+            }
+            u64 first = 0;
+            (void)hipMemcpy(&first, offsets, sizeof(u64), hipMemcpyDeviceToHost);
+            if (first != 0) { yh_set_error("offsets[0] must be 0"); rc = YH_ERR_INVALID_ARG; break; }
+        } else {
+            if (offsets[0] != 0) { yh_set_error("offsets[0] must be 0"); rc = YH_ERR_INVALID_ARG; break; }
+            H = offsets[n_refs];
+        }
+        if (H && !values) { yh_set_error("values is null"); rc = YH_ERR_INVALID_ARG; break; }
+        db->n_hashes = H;
+
+        if (on_device) {
+            d_values_in = const_cast<u64*>(values);
+            d_offsets_in = const_cast<u64*>(offsets);
+        } else {
+            own_inputs = true;
+            if (hipMalloc((void**)&d_values_in, std::max<u64>(H, 2) * sizeof(u64)) != hipSuccess ||
+                hipMalloc((void**)&d_offsets_in, (n_refs + 1) * sizeof(u64)) != hipSuccess) {
+                yh_set_error("device allocation for the CSR upload failed"); rc = YH_ERR_OOM; break;
+            }
+            if ((H && hipMemcpy(d_values_in, values, H * sizeof(u64), hipMemcpyHostToDevice) != hipSuccess) ||
+                hipMemcpy(d_offsets_in, offsets, (n_refs + 1) * sizeof(u64), hipMemcpyHostToDevice) != hipSuccess) {
+                yh_set_error("CSR upload failed"); rc = YH_ERR_HIP; break;
+            }
+        }
+
+        (void)hipEventRecord(ev0, db->stream);
+        rc = yh_build_partitions(db, d_values_in, d_offsets_in, partitions_hint);
+        if (rc != YH_OK) break;
+        if (!(flags & YH_DB_NO_INDEX)) {
+            rc = yh_build_index(db, d_values_in, d_offsets_in);
+            if (rc != YH_OK) break;
+        }
+        (void)hipEventRecord(ev1, db->stream);
+        (void)hipEventSynchronize(ev1);
+        (void)hipEventElapsedTime(&db->ms_db_build, ev0, ev1);
+
+        const u64 N = n_refs;
+        if ((rc = yh_dmalloc(db, (void**)&db->d_mask, std::max<u64>(N, 1))) != YH_OK) break;
+        if ((rc = yh_dmalloc(db, (void**)&db->d_excl_e, std::max<u64>(N, 1) * sizeof(u32))) != YH_OK) break;
+        if ((rc = yh_dmalloc(db, (void**)&db->d_excl_m, std::max<u64>(N, 1) * sizeof(u32))) != YH_OK) break;
+        if ((rc = yh_dmalloc(db, (void**)&db->d_ovsh, std::max<u64>(N, 1) * sizeof(u32))) != YH_OK) break;
+        if ((rc = yh_dmalloc(db, (void**)&db->d_overlap_tmp, std::max<u64>(N, 1) * sizeof(u32))) != YH_OK) break;
+
+        if (flags & YH_DB_KEEP_CSR) {
+            if (own_inputs) {  // adopt the upload buffers
+                db->d_values = d_values_in;
+                db->d_offsets = d_offsets_in;
+                db->device_bytes += std::max<u64>(H, 2) * sizeof(u64) + (n_refs + 1) * sizeof(u64);
+                own_inputs = false;
+            } else {
+                if ((rc = yh_dmalloc(db, (void**)&db->d_values, std::max<u64>(H, 2) * sizeof(u64))) != YH_OK) break;
+                if ((rc = yh_dmalloc(db, (void**)&db->d_offsets, (n_refs + 1) * sizeof(u64))) != YH_OK) break;
+                if ((H && hipMemcpy(db->d_values, values, H * sizeof(u64), hipMemcpyDeviceToDevice) != hipSuccess) ||
+                    hipMemcpy(db->d_offsets, offsets, (n_refs + 1) * sizeof(u64), hipMemcpyDeviceToDevice) != hipSuccess) {
+                    yh_set_error("CSR copy failed"); rc = YH_ERR_HIP; break;
+                }
+            }
+        }
+        ring_create(db->ev_overlap);
+        ring_create(db->ev_excl);
+        ring_create(db->ev_pair);
+    } while (0);
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
+    if (own_inputs) {
+        (void)hipFree(d_values_in);
+        (void)hipFree(d_offsets_in);
+    }
+    if (rc != YH_OK) {
+        yh_db_destroy(db);
+        return rc;
+    }
+    *out = db;
+    return YH_OK;
+}
+
+int yh_db_create(const uint64_t* values, const uint64_t* offsets, uint64_t n_refs, int device_id, uint32_t flags,
+                 uint32_t partitions_hint, yh_db** out) {
+    return db_create_common((const u64*)values, (const u64*)offsets, false, n_refs, device_id, flags,
+                            partitions_hint, out);
+}
+
+int yh_db_create_device(const uint64_t* d_values, const uint64_t* d_offsets, uint64_t n_refs, int device_id,
+                        uint32_t flags, uint32_t partitions_hint, yh_db** out) {
+    return db_create_common((const u64*)d_values, (const u64*)d_offsets, true, n_refs, device_id, flags,
+                            partitions_hint, out);
+}
+
+int yh_db_destroy(yh_db* db) {
+    if (!db) return YH_OK;
+    if (db->device >= 0) (void)hipSetDevice(db->device);
+    if (db->stream) (void)hipStreamSynchronize(db->stream);
+    void* ptrs[] = {db->d_values, db->d_offsets, db->d_pvals, db->d_pbeg, db->d_pcnt, db->d_poffs, db->d_sizes,
+                    db->d_g, db->d_po, db->d_pr, db->d_pg, db->d_gbeg, db->d_gcnt, db->d_nshared, db->d_sbounds,
+                    db->d_mask, db->d_hit, db->d_excl_e, db->d_excl_m, db->d_ovsh, db->d_overlap_tmp,
+                    db->d_sample_tmp, db->d_flag};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    ring_destroy(db->ev_overlap);
+    ring_destroy(db->ev_excl);
+    ring_destroy(db->ev_pair);
+    if (db->own_stream) (void)hipStreamDestroy(db->own_stream);
+    free(db->h_pw_i);
+    free(db->h_pw_j);
+    free(db->h_pw_c);
+    delete db;
+    return YH_OK;
+}
+
+int yh_db_get_info(yh_db* db, yh_db_info* info) {
+    if (!db_ok(db)) return YH_ERR_INVALID_ARG;
+    if (!info) { yh_set_error("info is null"); return YH_ERR_INVALID_ARG; }
+    memset(info, 0, sizeof(*info));
+    info->n_refs = db->n_refs;
+    info->n_hashes = db->n_hashes;
+    info->max_hash = db->max_hash;
+    info->n_partitions = db->n_parts;
+    info->partition_shift = db->pshift;
+    info->n_distinct = db->n_distinct;
+    info->n_shared_distinct = db->n_shared;
+    info->n_shared_postings = db->n_postings;
+    info->device_bytes = db->device_bytes;
+    info->device_id = db->device;
+    info->flags = db->flags;
+    return YH_OK;
+}
+
+int yh_db_set_stream(yh_db* db, void* hip_stream) {
+    if (!db_ok(db)) return YH_ERR_INVALID_ARG;
+    YH_TRY(db_select(db));
+    YH_HIP(hipStreamSynchronize(db->stream));
+    db->stream = hip_stream ? (hipStream_t)hip_stream : db->own_stream;
+    return YH_OK;
+}
+
+int yh_db_synchronize(yh_db* db) {
+    if (!db_ok(db)) return YH_ERR_INVALID_ARG;
+    YH_TRY(db_select(db));
+    YH_HIP(hipStreamSynchronize(db->stream));
+    return YH_OK;
+}
+
+int yh_db_get_timing(yh_db* db, yh_timing* t) {
+    if (!db_ok(db)) return YH_ERR_INVALID_ARG;
+    if (!t) { yh_set_error("t is null"); return YH_ERR_INVALID_ARG; }
+    YH_TRY(db_select(db));
+    YH_HIP(hipStreamSynchronize(db->stream));
+    t->ms_overlap_kernel = ring_read(db->ev_overlap);
+    t->ms_exclusive_kernels = ring_read(db->ev_excl);
+    t->ms_pairwise_kernels = ring_read(db->ev_pair);
+    t->ms_db_build = db->ms_db_build;
+    return YH_OK;
+}
+
+// ---- overlap ---------------------------------------------------------------------------------------
+int yh_overlap_device(yh_db* db, const uint64_t* d_sample, uint64_t n_sample, uint32_t* d_overlap) {
+    if (!db_ok(db)) return YH_ERR_INVALID_ARG;
+    if (!d_overlap || (n_sample && !d_sample)) { yh_set_error("null device pointer"); return YH_ERR_INVALID_ARG; }
+    YH_TRY(db_select(db));
+    return yh_q_overlap(db, (const u64*)d_sample, n_sample, d_overlap);
+}
+
+int yh_overlap_bsearch_device(yh_db* db, const uint64_t* d_sample, uint64_t n_sample, uint32_t* d_overlap) {
+    if (!db_ok(db)) return YH_ERR_INVALID_ARG;
+    if (!d_overlap || (n_sample && !d_sample)) { yh_set_error("null device pointer"); return YH_ERR_INVALID_ARG; }
+    YH_TRY(db_select(db));
+    return yh_q_overlap_bsearch(db, (const u64*)d_sample, n_sample, d_overlap);
+}
+
+static int upload_sample(yh_db* db, const uint64_t* sample, uint64_t n_sample) {
+    if (n_sample && !sample) { yh_set_error("sample is null"); return YH_ERR_INVALID_ARG; }
+    if (yh_q_check_sorted_host((const u64*)sample, n_sample) != YH_OK) {
+        yh_set_error("the sample sketch is not strictly ascending");
+        return YH_ERR_UNSORTED;
+    }
+    YH_TRY(ensure_sample_tmp(db, n_sample));
+    if (n_sample)
+        YH_HIP(hipMemcpyAsync(db->d_sample_tmp, sample, n_sample * sizeof(u64), hipMemcpyHostToDevice, db->stream));
+    return YH_OK;
+}
+
+static int overlap_host(yh_db* db, const uint64_t* sample, uint64_t n_sample, uint32_t* overlap, bool bsearch) {
+    if (!db_ok(db)) return YH_ERR_INVALID_ARG;
+    if (!overlap && db->n_refs) { yh_set_error("overlap is null"); return YH_ERR_INVALID_ARG; }
+    YH_TRY(db_select(db));
+    YH_TRY(upload_sample(db, sample, n_sample));
+    if (bsearch) YH_TRY(yh_q_overlap_bsearch(db, db->d_sample_tmp, n_sample, db->d_overlap_tmp));
+    else YH_TRY(yh_q_overlap(db, db->d_sample_tmp, n_sample, db->d_overlap_tmp));
+    if (db->n_refs)
+        YH_HIP(hipMemcpyAsync(overlap, db->d_overlap_tmp, db->n_refs * sizeof(u32), hipMemcpyDeviceToHost, db->stream));
+    YH_HIP(hipStreamSynchronize(db->stream));
+    return YH_OK;
+}
+
+int yh_overlap(yh_db* db, const uint64_t* sample, uint64_t n_sample, uint32_t* overlap) {
+    return overlap_host(db, sample, n_sample, overlap, false);
+}
+int yh_overlap_bsearch(yh_db* db, const uint64_t* sample, uint64_t n_sample, uint32_t* overlap) {
+    return overlap_host(db, sample, n_sample, overlap, true);
+}
+
+// ---- exclusive -------------------------------------------------------------------------------------
+int yh_exclusive(yh_db* db, const uint8_t* subset_mask, const uint64_t* sample, uint64_t n_sample,
+                 uint32_t* n_excl, uint32_t* n_match) {
+    if (!db_ok(db)) return YH_ERR_INVALID_ARG;
+    const u64 N = db->n_refs;
+    if (N && (!subset_mask || !n_excl || !n_match)) { yh_set_error("null argument"); return YH_ERR_INVALID_ARG; }
+    if (!db->has_index) { yh_set_error("this handle was created with YH_DB_NO_INDEX"); return YH_ERR_UNSUPPORTED; }
+    YH_TRY(db_select(db));
+    YH_TRY(upload_sample(db, sample, n_sample));
+    if (N == 0) return YH_OK;
+    u32 *d_e = nullptr, *d_m = nullptr;
+    YH_HIP(hipMalloc((void**)&d_e, N * sizeof(u32)));
+    if (hipMalloc((void**)&d_m, N * sizeof(u32)) != hipSuccess) { (void)hipFree(d_e); yh_set_error("hipMalloc failed"); return YH_ERR_OOM; }
+    int rc = YH_OK;
+    do {
+        if (hipMemcpyAsync(db->d_mask, subset_mask, N, hipMemcpyHostToDevice, db->stream) != hipSuccess) { yh_set_error("mask upload failed"); rc = YH_ERR_HIP; break; }
+        if ((rc = yh_q_overlap(db, db->d_sample_tmp, n_sample, db->d_overlap_tmp)) != YH_OK) break;
+        if ((rc = yh_q_exclusive(db, db->d_mask, db->d_sample_tmp, n_sample, db->d_overlap_tmp, d_e, d_m)) != YH_OK) break;
+        if (hipMemcpyAsync(n_excl, d_e, N * sizeof(u32), hipMemcpyDeviceToHost, db->stream) != hipSuccess ||
+            hipMemcpyAsync(n_match, d_m, N * sizeof(u32), hipMemcpyDeviceToHost, db->stream) != hipSuccess ||
+            hipStreamSynchronize(db->stream) != hipSuccess) {
+            yh_set_error("exclusive download failed: %s", hipGetErrorString(hipGetLastError()));
+            rc = YH_ERR_HIP;
+        }
+    } while (0);
+    (void)hipFree(d_e);
+    (void)hipFree(d_m);
+    return rc;
+}
+
+int yh_run_device(yh_db* db, const uint64_t* d_sample, uint64_t n_sample, uint32_t* d_overlap,
+                  uint32_t* d_n_excl, uint32_t* d_n_match) {
+    if (!db_ok(db)) return YH_ERR_INVALID_ARG;
+    if (!d_overlap || (n_sample && !d_sample)) { yh_set_error("null device pointer"); return YH_ERR_INVALID_ARG; }
+    if ((d_n_excl == nullptr) != (d_n_match == nullptr)) { yh_set_error("pass both d_n_excl and d_n_match or neither"); return YH_ERR_INVALID_ARG; }
+    YH_TRY(db_select(db));
+    YH_TRY(yh_q_overlap(db, (const u64*)d_sample, n_sample, d_overlap));
+    if (!d_n_excl) return YH_OK;
+    YH_TRY(yh_q_mask_from_overlap(db, d_overlap, db->d_mask));
+    return yh_q_exclusive(db, db->d_mask, (const u64*)d_sample, n_sample, d_overlap, d_n_excl, d_n_match);
+}
+
+int yh_run(yh_db* db, const uint64_t* sample, uint64_t n_sample, uint32_t* overlap, uint32_t* n_excl,
+           uint32_t* n_match) {
+    if (!db_ok(db)) return YH_ERR_INVALID_ARG;
+    const u64 N = db->n_refs;
+    if (N && (!overlap || !n_excl || !n_match)) { yh_set_error("null argument"); return YH_ERR_INVALID_ARG; }
+    if (!db->has_index) { yh_set_error("this handle was created with YH_DB_NO_INDEX"); return YH_ERR_UNSUPPORTED; }
+    YH_TRY(db_select(db));
+    YH_TRY(upload_sample(db, sample, n_sample));
+    if (N == 0) return YH_OK;
+    u32 *d_e = nullptr, *d_m = nullptr;
+    YH_HIP(hipMalloc((void**)&d_e, N * sizeof(u32)));
+    if (hipMalloc((void**)&d_m, N * sizeof(u32)) != hipSuccess) { (void)hipFree(d_e); yh_set_error("hipMalloc failed"); return YH_ERR_OOM; }
+    int rc = yh_run_device(db, (const uint64_t*)db->d_sample_tmp, n_sample, db->d_overlap_tmp, d_e, d_m);
+    if (rc == YH_OK) {
+        if (hipMemcpyAsync(overlap, db->d_overlap_tmp, N * sizeof(u32), hipMemcpyDeviceToHost, db->stream) != hipSuccess ||
+            hipMemcpyAsync(n_excl, d_e, N * sizeof(u32), hipMemcpyDeviceToHost, db->stream) != hipSuccess ||
+            hipMemcpyAsync(n_match, d_m, N * sizeof(u32), hipMemcpyDeviceToHost, db->stream) != hipSuccess ||
+            hipStreamSynchronize(db->stream) != hipSuccess) {
+            yh_set_error("run download failed: %s", hipGetErrorString(hipGetLastError()));
+            rc = YH_ERR_HIP;
+        }
+    }
+    (void)hipFree(d_e);
+    (void)hipFree(d_m);
+    return rc;
+}
+
+// ---- pairwise --------------------------------------------------------------------------------------
+int yh_pairwise(yh_db* db, double c_thresh, uint64_t row_begin, uint64_t row_end, uint64_t cap, uint32_t* pair_i,
+                uint32_t* pair_j, uint32_t* pair_count, uint64_t* n_out) {
+    if (!db_ok(db)) return YH_ERR_INVALID_ARG;
+    if (!n_out) { yh_set_error("n_out is null"); return YH_ERR_INVALID_ARG; }
+    if (!(c_thresh >= 0.0 && c_thresh <= 1.0)) { yh_set_error("containment threshold must be between 0.0 and 1.0"); return YH_ERR_INVALID_ARG; }
+    YH_TRY(db_select(db));
+    if (row_end > db->n_refs) row_end = db->n_refs;
+    if (!(db->pw_valid && db->pw_c == c_thresh && db->pw_r0 == row_begin && db->pw_r1 == row_end))
+        YH_TRY(yh_q_pairwise(db, c_thresh, row_begin, row_end));
+    *n_out = db->pw_n;
+    if (cap == 0) return YH_OK;
+    if (cap < db->pw_n) { yh_set_error("pair buffers hold %llu entries, %llu needed", (u64)cap, db->pw_n); return YH_ERR_CAPACITY; }
+    if (db->pw_n && (!pair_i || !pair_j || !pair_count)) { yh_set_error("null pair buffer"); return YH_ERR_INVALID_ARG; }
+    memcpy(pair_i, db->h_pw_i, db->pw_n * sizeof(u32));
+    memcpy(pair_j, db->h_pw_j, db->pw_n * sizeof(u32));
+    memcpy(pair_count, db->h_pw_c, db->pw_n * sizeof(u32));
+    return YH_OK;
+}
+
+int yh_index_stats(yh_db* db, uint64_t* n_distinct, uint64_t* n_singletons, uint64_t* n_index) {
+    if (!db_ok(db)) return YH_ERR_INVALID_ARG;
+    if (!db->has_index) { yh_set_error("this handle was created with YH_DB_NO_INDEX"); return YH_ERR_UNSUPPORTED; }
+    if (n_distinct) *n_distinct = db->n_distinct;
+    if (n_singletons) *n_singletons = db->n_distinct - db->n_shared;
+    if (n_index) *n_index = db->n_shared;
+    return YH_OK;
+}
+
+// ---- greedy selection (host; src/cpp/main.cpp:371-407) ----------------------------------------------
+// Walk the references by ascending sketch size; drop one when a not-yet-dropped neighbour of at
+// least its size exists.  The size ordering comes from libstdc++'s std::sort with a size-only
+// comparator over {id, size} pairs in input order, exactly the reference's call: ties are
+// resolved by that (deterministic, unstable) algorithm, and using the same call is the only way
+// to resolve them identically.
+int yh_train_select(const uint32_t* sizes, uint64_t n_refs, const uint32_t* pair_i, const uint32_t* pair_j,
+                    uint64_t n_pairs, uint32_t* selected, uint64_t* n_selected) {
+    if (!n_selected || (n_refs && (!sizes || !selected)) || (n_pairs && (!pair_i || !pair_j))) {
+        yh_set_error("null argument");
+        return YH_ERR_INVALID_ARG;
+    }
+    if (n_refs > 0x7fffffffull) { yh_set_error("too many references"); return YH_ERR_INVALID_ARG; }
+    std::vector<u64> first(n_refs + 1, 0);  // neighbour lists in CSR form
+    for (u64 k = 0; k < n_pairs; ++k) {
+        if (pair_i[k] >= n_refs || pair_j[k] >= n_refs) { yh_set_error("pair index out of range"); return YH_ERR_INVALID_ARG; }
+        if (k && (pair_i[k] < pair_i[k - 1] || (pair_i[k] == pair_i[k - 1] && pair_j[k] <= pair_j[k - 1]))) {
+            yh_set_error("pairs must be sorted by (i, j) without duplicates");
+            return YH_ERR_INVALID_ARG;
+        }
+        ++first[pair_i[k] + 1];
+    }
+    for (u64 i = 0; i < n_refs; ++i) first[i + 1] += first[i];
+
+    std::vector<std::pair<int, int>> order(n_refs);
+    for (u64 i = 0; i < n_refs; ++i) order[i] = {(int)i, (int)sizes[i]};
+    std::sort(order.begin(), order.end(),
+              [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.second < b.second; });
+
+    std::vector<char> dropped(n_refs, 0);
+    u64 ns = 0;
+    for (u64 t = 0; t < n_refs; ++t) {
+        const int id = order[t].first;
+        const int sz = order[t].second;
+        bool keep = true;
+        for (u64 k = first[id]; k < first[id + 1]; ++k) {
+            const u32 o = pair_j[k];
+            if (dropped[o]) continue;
+            if ((int)sizes[o] >= sz) { keep = false; break; }
+        }
+        if (keep) selected[ns++] = (u32)id;
+        else dropped[id] = 1;
+    }
+    *n_selected = ns;
+    return YH_OK;
+}
+
+}  // extern "C"

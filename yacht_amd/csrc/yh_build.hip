@@ -1,0 +1,514 @@
+// yh_build.hip — one-time database construction on the device.
+//
+//   (1) hash-range partitioned CSR: the layout the streaming overlap kernel reads.
+//       Replaces the per-run re-reading of N .sig files (hypothesis_recovery_src.py:93,154,168).
+//   (2) shared-hash inverted index: distinct hashes that occur in >= 2 references, with their
+//       posting lists.  Same content as the reference's `hash_index` after singletons are
+//       erased (src/cpp/main.cpp:215-246), built by a stable radix sort instead of a node map.
+#include "yh_common.h"
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include <algorithm>
+#include <vector>
+
+namespace {
+
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ u32 lower_bound_u64(const u64* a, u32 n, u64 key) {
+    u32 lo = 0, hi = n;
+    while (lo < hi) {
+        u32 mid = (lo + hi) >> 1;
+        if (a[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// ---- validation + extent ----------------------------------------------------------------------
+// One wave per reference: flag[0] |= 1 if the slice is not strictly ascending; atomicMax of the
+// last element gives the database's largest hash; sizes[j] = |R_j|.
+__global__ void k_scan_refs(const u64* __restrict__ values, const u64* __restrict__ offsets, u64 n_refs,
+                            u32* __restrict__ sizes, u32* __restrict__ flag, u64* __restrict__ maxv) {
+    const u64 wave = (blockIdx.x * (u64)blockDim.x + threadIdx.x) / WAVE;
+    const u64 n_waves = ((u64)gridDim.x * blockDim.x) / WAVE;
+    const int lane = threadIdx.x & (WAVE - 1);
+    for (u64 j = wave; j < n_refs; j += n_waves) {
+        const u64 b = offsets[j], e = offsets[j + 1];
+        bool bad = e < b;
+        if (!bad) {
+            for (u64 k = b + lane; k + 1 < e; k += WAVE)
+                if (!(values[k] < values[k + 1])) bad = true;
+        }
+        if (__ballot(bad) != 0ull) {
+            if (lane == 0) atomicOr(flag, 1u);
+        }
+        if (lane == 0 && !bad) {
+            const u64 n = e - b;
+            sizes[j] = (u32)n;
+            if (n > 0xffffffffull) atomicOr(flag, 2u);
+            if (n) atomicMax(maxv, values[e - 1]);
+        }
+    }
+}
+
+// ---- partition split points --------------------------------------------------------------------
+// split[j*(P+1)+p] = number of hashes of reference j below p << pshift.
+__global__ void k_split(const u64* __restrict__ values, const u64* __restrict__ offsets, u64 n_refs, u32 P,
+                        u32 pshift, u32* __restrict__ split) {
+    const u64 total = n_refs * (u64)(P + 1);
+    for (u64 t = blockIdx.x * (u64)blockDim.x + threadIdx.x; t < total; t += (u64)gridDim.x * blockDim.x) {
+        const u64 j = t / (P + 1);
+        const u32 p = (u32)(t % (P + 1));
+        const u64 b = offsets[j];
+        const u32 n = (u32)(offsets[j + 1] - b);
+        u32 r;
+        if (p == 0) r = 0;
+        else if (p == P) r = n;
+        else r = lower_bound_u64(values + b, n, (u64)p << pshift);
+        split[t] = r;
+    }
+}
+
+// block-wide exclusive scan of one u32 per thread (blockDim.x threads, multiple of 64, <= 1024)
+__device__ __forceinline__ u32 block_excl_scan(u32 v, u32* total_out, u32* lds /* >= 17 words */) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wid = threadIdx.x / WAVE;
+    const int nw = blockDim.x / WAVE;
+    u32 inc = v;
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        u32 t = __shfl_up(inc, d, WAVE);
+        if (lane >= d) inc += t;
+    }
+    if (lane == WAVE - 1) lds[wid] = inc;
+    __syncthreads();
+    if (wid == 0) {
+        u32 w = (lane < nw) ? lds[lane] : 0;
+        u32 winc = w;
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) {
+            u32 t = __shfl_up(winc, d, WAVE);
+            if (lane >= d) winc += t;
+        }
+        if (lane < nw) lds[lane] = winc - w;  // exclusive wave prefix
+        if (lane == nw - 1) lds[16] = winc;   // block total
+    }
+    __syncthreads();
+    const u32 res = lds[wid] + inc - v;
+    *total_out = lds[16];
+    __syncthreads();
+    return res;
+}
+
+// One workgroup per partition: poffs[p][j] = sum_{j' < j} (split[j'][p+1] - split[j'][p]).
+__global__ void __launch_bounds__(1024) k_part_scan(const u32* __restrict__ split, u64 n_refs, u32 P,
+                                                    u32* __restrict__ poffs, u64* __restrict__ pcnt,
+                                                    u32* __restrict__ flag) {
+    __shared__ u32 lds[17];
+    const u32 p = blockIdx.x;
+    u32* out = poffs + (u64)p * (n_refs + 1);
+    u64 carry = 0;
+    for (u64 base = 0; base < n_refs; base += blockDim.x) {
+        const u64 j = base + threadIdx.x;
+        u32 c = 0;
+        if (j < n_refs) c = split[j * (P + 1) + p + 1] - split[j * (P + 1) + p];
+        u32 tot;
+        const u32 ex = block_excl_scan(c, &tot, lds);
+        if (j < n_refs) out[j] = (u32)(carry + ex);
+        carry += tot;
+    }
+    if (threadIdx.x == 0) {
+        out[n_refs] = (u32)carry;
+        pcnt[p] = carry;
+        if (carry > 0xffffffffull) atomicOr(flag, 4u);
+    }
+}
+
+// One wave per reference: copy each hash to its partition-major slot.
+__global__ void k_scatter(const u64* __restrict__ values, const u64* __restrict__ offsets, u64 n_refs, u32 P,
+                          u32 pshift, const u32* __restrict__ split, const u64* __restrict__ pbeg,
+                          const u32* __restrict__ poffs, u64* __restrict__ pvals) {
+    const u64 wave = (blockIdx.x * (u64)blockDim.x + threadIdx.x) / WAVE;
+    const u64 n_waves = ((u64)gridDim.x * blockDim.x) / WAVE;
+    const int lane = threadIdx.x & (WAVE - 1);
+    for (u64 j = wave; j < n_refs; j += n_waves) {
+        const u64 b = offsets[j];
+        const u32 n = (u32)(offsets[j + 1] - b);
+        const u32* sp = split + j * (P + 1);
+        for (u32 k = lane; k < n; k += WAVE) {
+            const u64 h = values[b + k];
+            const u32 p = (u32)(h >> pshift);
+            const u64 dst = pbeg[p] + poffs[(u64)p * (n_refs + 1) + j] + (k - sp[p]);
+            pvals[dst] = h;
+        }
+    }
+}
+
+// ---- index build ---------------------------------------------------------------------------------
+__global__ void k_fill_ref_ids(const u64* __restrict__ offsets, u64 n_refs, u32* __restrict__ ids) {
+    const u64 wave = (blockIdx.x * (u64)blockDim.x + threadIdx.x) / WAVE;
+    const u64 n_waves = ((u64)gridDim.x * blockDim.x) / WAVE;
+    const int lane = threadIdx.x & (WAVE - 1);
+    for (u64 j = wave; j < n_refs; j += n_waves) {
+        const u64 b = offsets[j], e = offsets[j + 1];
+        for (u64 k = b + lane; k < e; k += WAVE) ids[k] = (u32)j;
+    }
+}
+
+constexpr int IDX_THREADS = 256;
+constexpr int IDX_ITEMS = 16;
+constexpr int IDX_BLOCK = IDX_THREADS * IDX_ITEMS;
+
+struct IdxFlags {
+    bool head;    // first element of a run of equal hashes
+    bool shared;  // member of a run of length >= 2
+};
+__device__ __forceinline__ IdxFlags idx_flags(const u64* __restrict__ sk, u64 n, u64 i) {
+    const u64 h = sk[i];
+    const bool eq_prev = (i > 0) && (sk[i - 1] == h);
+    const bool eq_next = (i + 1 < n) && (sk[i + 1] == h);
+    IdxFlags f;
+    f.head = !eq_prev;
+    f.shared = eq_prev || eq_next;
+    return f;
+}
+
+// per-block counts: {distinct heads, shared heads, shared elements}
+__global__ void __launch_bounds__(IDX_THREADS) k_idx_count(const u64* __restrict__ sk, u64 n,
+                                                            u32* __restrict__ counts /* [nb][3] */) {
+    __shared__ u32 acc[3];
+    if (threadIdx.x < 3) acc[threadIdx.x] = 0;
+    __syncthreads();
+    const u64 base = (u64)blockIdx.x * IDX_BLOCK;
+    u32 c0 = 0, c1 = 0, c2 = 0;
+    for (int it = 0; it < IDX_ITEMS; ++it) {
+        const u64 i = base + (u64)it * IDX_THREADS + threadIdx.x;
+        if (i < n) {
+            const IdxFlags f = idx_flags(sk, n, i);
+            c0 += f.head;
+            c1 += f.head && f.shared;
+            c2 += f.shared;
+        }
+    }
+    atomicAdd(&acc[0], c0);
+    atomicAdd(&acc[1], c1);
+    atomicAdd(&acc[2], c2);
+    __syncthreads();
+    if (threadIdx.x < 3) counts[(u64)blockIdx.x * 3 + threadIdx.x] = acc[threadIdx.x];
+}
+
+// single workgroup: exclusive scan of the per-block counts into 64-bit bases, totals at [nb]
+__global__ void __launch_bounds__(1024) k_idx_scan_counts(const u32* __restrict__ counts, u64 nb,
+                                                          u64* __restrict__ bases /* [nb+1][3] */) {
+    __shared__ u32 lds[17];
+    u64 carry[3] = {0, 0, 0};
+    for (u64 base = 0; base < nb; base += blockDim.x) {
+        const u64 b = base + threadIdx.x;
+        for (int c = 0; c < 3; ++c) {
+            const u32 v = (b < nb) ? counts[b * 3 + c] : 0u;
+            u32 tot;
+            const u32 ex = block_excl_scan(v, &tot, lds);
+            if (b < nb) bases[b * 3 + c] = carry[c] + ex;
+            carry[c] += tot;
+        }
+    }
+    if (threadIdx.x == 0) {
+        bases[nb * 3 + 0] = carry[0];
+        bases[nb * 3 + 1] = carry[1];
+        bases[nb * 3 + 2] = carry[2];
+    }
+}
+
+// Write g[], po[], pr[], pg[] and nshared[].  Items are taken in a blocked arrangement (thread
+// t owns IDX_ITEMS consecutive sorted elements) so ranks inside the block are a plain scan.
+__global__ void __launch_bounds__(IDX_THREADS) k_idx_emit(const u64* __restrict__ sk, const u32* __restrict__ sv,
+                                                          u64 n, const u64* __restrict__ bases,
+                                                          u64* __restrict__ g, u64* __restrict__ po,
+                                                          u32* __restrict__ pr, u32* __restrict__ pg,
+                                                          u32* __restrict__ nshared) {
+    __shared__ u32 lds[17];
+    const u64 base = (u64)blockIdx.x * IDX_BLOCK + (u64)threadIdx.x * IDX_ITEMS;
+    u32 nh = 0, ns = 0;
+    u32 fl[IDX_ITEMS];
+#pragma unroll
+    for (int it = 0; it < IDX_ITEMS; ++it) {
+        const u64 i = base + it;
+        u32 f = 0;
+        if (i < n) {
+            const IdxFlags x = idx_flags(sk, n, i);
+            f = (x.shared ? 1u : 0u) | ((x.shared && x.head) ? 2u : 0u);
+        }
+        fl[it] = f;
+        ns += f & 1u;
+        nh += (f >> 1) & 1u;
+    }
+    u32 tot;
+    const u32 exh = block_excl_scan(nh, &tot, lds);
+    const u32 exs = block_excl_scan(ns, &tot, lds);
+    u64 gi = bases[(u64)blockIdx.x * 3 + 1] + exh;  // shared heads before this thread's items
+    u64 mi = bases[(u64)blockIdx.x * 3 + 2] + exs;  // shared elements before this thread's items
+#pragma unroll
+    for (int it = 0; it < IDX_ITEMS; ++it) {
+        const u64 i = base + it;
+        const u32 f = fl[it];
+        if (f & 2u) {
+            g[gi] = sk[i];
+            po[gi] = mi;
+            ++gi;
+        }
+        if (f & 1u) {
+            const u32 r = sv[i];
+            pr[mi] = r;
+            pg[mi] = (u32)(gi - 1);
+            atomicAdd(&nshared[r], 1u);
+            ++mi;
+        }
+    }
+}
+
+__global__ void k_bounds_u64(const u64* __restrict__ a, u64 n, u32 P, u32 pshift, u64* __restrict__ beg,
+                             u64* __restrict__ cnt) {
+    const u32 p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    // n can exceed 2^32 in principle; use a 64-bit search
+    auto lb = [&](u64 key) {
+        u64 lo = 0, hi = n;
+        while (lo < hi) {
+            u64 mid = (lo + hi) >> 1;
+            if (a[mid] < key) lo = mid + 1; else hi = mid;
+        }
+        return lo;
+    };
+    const u64 b = (p == 0) ? 0 : lb((u64)p << pshift);
+    const u64 e = (p + 1 == P) ? n : lb((u64)(p + 1) << pshift);
+    beg[p] = b;
+    cnt[p] = e - b;
+}
+
+inline u32 grid_for(u64 work_items, u32 block, u32 max_blocks = 16384) {
+    u64 g = (work_items + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > max_blocks) g = max_blocks;
+    return (u32)g;
+}
+
+}  // namespace
+
+// =================================================================================================
+int yh_build_partitions(yh_db* db, const u64* d_values, const u64* d_offsets, u32 parts_hint) {
+    const u64 N = db->n_refs;
+    hipStream_t st = db->stream;
+
+    YH_TRY(yh_dmalloc(db, (void**)&db->d_sizes, std::max<u64>(N, 1) * sizeof(u32)));
+    YH_TRY(yh_dmalloc(db, (void**)&db->d_flag, 16));
+    u64* d_maxv = (u64*)(db->d_flag + 2);  // 8-byte aligned slot inside the 16-byte scratch
+    YH_HIP(hipMemsetAsync(db->d_flag, 0, 16, st));
+    YH_HIP(hipMemsetAsync(db->d_sizes, 0, std::max<u64>(N, 1) * sizeof(u32), st));
+    if (N) {
+        k_scan_refs<<<grid_for(N * WAVE, 256), 256, 0, st>>>(d_values, d_offsets, N, db->d_sizes, db->d_flag,
+                                                             d_maxv);
+        YH_HIP(hipGetLastError());
+    }
+    u32 hflag[4];
+    YH_HIP(hipMemcpyAsync(hflag, db->d_flag, 16, hipMemcpyDeviceToHost, st));
+    YH_HIP(hipStreamSynchronize(st));
+    if (hflag[0] & 1u) {
+        yh_set_error("a reference sketch is not strictly ascending (or offsets are not monotone)");
+        return YH_ERR_UNSORTED;
+    }
+    if (hflag[0] & 2u) {
+        yh_set_error("a reference sketch has more than 2^32-1 hashes");
+        return YH_ERR_INVALID_ARG;
+    }
+    u64 maxv;
+    memcpy(&maxv, &hflag[2], 8);
+    db->max_hash = maxv;
+
+    // ---- choose the partitioning: P ~ mean sketch size / 16 (pieces of >= ~16 hashes keep the
+    // per-(partition, reference) offsets under ~3 % of the hash bytes), rounded down to 2^k,
+    // then the largest shift that still yields at least that many partitions.
+    const u64 H = db->n_hashes;
+    u32 target = parts_hint;
+    if (target == 0) {
+        const u64 mean = N ? H / N : 0;
+        u64 t = mean / 16;
+        if (t < 1) t = 1;
+        if (t > 16384) t = 16384;
+        u32 pw = 1;
+        while ((u64)pw * 2 <= t) pw *= 2;
+        target = pw;
+    }
+    if (target > 65536) target = 65536;
+    u32 pshift = 0;
+    u32 P = 1;
+    if (H > 0 && target > 1) {
+        int s = 63;
+        while (s > 0 && ((maxv >> s) + 1) < target) --s;
+        pshift = (u32)s;
+        P = (u32)((maxv >> pshift) + 1);
+        if (P > 131072) {  // tiny hash ranges: fall back to fewer partitions
+            while (((maxv >> pshift) + 1) > 131072) ++pshift;
+            P = (u32)((maxv >> pshift) + 1);
+        }
+    } else {
+        pshift = 63;
+        // P = 1 requires every hash >> pshift == 0; with pshift = 63 a hash >= 2^63 would map to
+        // partition 1, so use two partitions in that case.
+        P = (H > 0) ? (u32)((maxv >> pshift) + 1) : 1;
+    }
+    db->pshift = pshift;
+    db->n_parts = P;
+
+    YH_TRY(yh_dmalloc(db, (void**)&db->d_pbeg, (u64)P * sizeof(u64)));
+    YH_TRY(yh_dmalloc(db, (void**)&db->d_pcnt, (u64)P * sizeof(u64)));
+    YH_TRY(yh_dmalloc(db, (void**)&db->d_poffs, (u64)P * (N + 1) * sizeof(u32)));
+    YH_TRY(yh_dmalloc(db, (void**)&db->d_sbounds, (u64)(P + 1) * sizeof(u32)));
+
+    u32* d_split = nullptr;
+    const u64 split_bytes = std::max<u64>(N, 1) * (u64)(P + 1) * sizeof(u32);
+    YH_HIP(hipMalloc((void**)&d_split, split_bytes));
+    int rc = YH_OK;
+    std::vector<u64> h_pcnt(P), h_pbeg(P);
+    do {
+        if (N) {
+            k_split<<<grid_for(N * (u64)(P + 1), 256), 256, 0, st>>>(d_values, d_offsets, N, P, pshift, d_split);
+        }
+        k_part_scan<<<P, 1024, 0, st>>>(d_split, N, P, db->d_poffs, db->d_pcnt, db->d_flag);
+        if (hipGetLastError() != hipSuccess) { yh_set_error("partition kernels failed to launch"); rc = YH_ERR_HIP; break; }
+        if (hipMemcpyAsync(h_pcnt.data(), db->d_pcnt, (u64)P * sizeof(u64), hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipMemcpyAsync(hflag, db->d_flag, 16, hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess) {
+            yh_set_error("partition scan failed: %s", hipGetErrorString(hipGetLastError()));
+            rc = YH_ERR_HIP;
+            break;
+        }
+        if (hflag[0] & 4u) { yh_set_error("a partition holds more than 2^32-1 hashes; raise partitions_hint"); rc = YH_ERR_INVALID_ARG; break; }
+        u64 pos = 0;
+        for (u32 p = 0; p < P; ++p) {
+            h_pbeg[p] = pos;
+            pos += h_pcnt[p];
+            pos = (pos + 1) & ~1ull;  // every partition starts on a 16-byte boundary
+        }
+        db->pvals_len = pos;
+        rc = yh_dmalloc(db, (void**)&db->d_pvals, std::max<u64>(pos, 2) * sizeof(u64));
+        if (rc != YH_OK) break;
+        if (hipMemsetAsync(db->d_pvals, 0, std::max<u64>(pos, 2) * sizeof(u64), st) != hipSuccess ||
+            hipMemcpyAsync(db->d_pbeg, h_pbeg.data(), (u64)P * sizeof(u64), hipMemcpyHostToDevice, st) != hipSuccess) {
+            yh_set_error("partition upload failed");
+            rc = YH_ERR_HIP;
+            break;
+        }
+        if (N) {
+            k_scatter<<<grid_for(N * WAVE, 256), 256, 0, st>>>(d_values, d_offsets, N, P, pshift, d_split, db->d_pbeg,
+                                                               db->d_poffs, db->d_pvals);
+        }
+        if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) {
+            yh_set_error("partition scatter failed");
+            rc = YH_ERR_HIP;
+            break;
+        }
+    } while (0);
+    (void)hipFree(d_split);
+    return rc;
+}
+
+// =================================================================================================
+int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets) {
+    const u64 N = db->n_refs;
+    const u64 H = db->n_hashes;
+    hipStream_t st = db->stream;
+
+    YH_TRY(yh_dmalloc(db, (void**)&db->d_nshared, std::max<u64>(N, 1) * sizeof(u32)));
+    YH_HIP(hipMemsetAsync(db->d_nshared, 0, std::max<u64>(N, 1) * sizeof(u32), st));
+    YH_TRY(yh_dmalloc(db, (void**)&db->d_gbeg, (u64)db->n_parts * sizeof(u64)));
+    YH_TRY(yh_dmalloc(db, (void**)&db->d_gcnt, (u64)db->n_parts * sizeof(u64)));
+    YH_HIP(hipMemsetAsync(db->d_gbeg, 0, (u64)db->n_parts * sizeof(u64), st));
+    YH_HIP(hipMemsetAsync(db->d_gcnt, 0, (u64)db->n_parts * sizeof(u64), st));
+
+    db->n_distinct = 0;
+    db->n_shared = 0;
+    db->n_postings = 0;
+    if (H == 0) {
+        YH_TRY(yh_dmalloc(db, (void**)&db->d_po, sizeof(u64)));
+        YH_HIP(hipMemsetAsync(db->d_po, 0, sizeof(u64), st));
+        db->has_index = true;
+        return YH_OK;
+    }
+    if (H > 0xfffffff0ull * 2) {
+        yh_set_error("index build supports at most 2^33 hashes per device");
+        return YH_ERR_UNSUPPORTED;
+    }
+
+    u32 *d_ids = nullptr, *d_sv = nullptr, *d_counts = nullptr;
+    u64 *d_sk = nullptr, *d_bases = nullptr;
+    void* d_tmp = nullptr;
+    int rc = YH_OK;
+    const u64 nb = (H + IDX_BLOCK - 1) / IDX_BLOCK;
+#define IDX_HIP(call)                                                                         \
+    if (rc == YH_OK) {                                                                        \
+        hipError_t e__ = (call);                                                              \
+        if (e__ != hipSuccess) {                                                              \
+            yh_set_error("%s failed: %s", #call, hipGetErrorString(e__));                     \
+            rc = (e__ == hipErrorOutOfMemory) ? YH_ERR_OOM : YH_ERR_HIP;                      \
+        }                                                                                     \
+    }
+    IDX_HIP(hipMalloc((void**)&d_ids, H * sizeof(u32)));
+    IDX_HIP(hipMalloc((void**)&d_sv, H * sizeof(u32)));
+    IDX_HIP(hipMalloc((void**)&d_sk, H * sizeof(u64)));
+    IDX_HIP(hipMalloc((void**)&d_counts, nb * 3 * sizeof(u32)));
+    IDX_HIP(hipMalloc((void**)&d_bases, (nb + 1) * 3 * sizeof(u64)));
+    if (rc == YH_OK) {
+        k_fill_ref_ids<<<grid_for(N * WAVE, 256), 256, 0, st>>>(d_offsets, N, d_ids);
+        // stable LSD radix sort of (hash, reference id): equal hashes keep ascending reference order
+        unsigned end_bit = 1;
+        while (end_bit < 64 && (db->max_hash >> end_bit) != 0) ++end_bit;
+        size_t tmp_bytes = 0;
+        IDX_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, (const u64*)d_values, d_sk, (const u32*)d_ids, d_sv,
+                                          (size_t)H, 0u, end_bit, st));
+        IDX_HIP(hipMalloc(&d_tmp, std::max<size_t>(tmp_bytes, 16)));
+        IDX_HIP(rocprim::radix_sort_pairs(d_tmp, tmp_bytes, (const u64*)d_values, d_sk, (const u32*)d_ids, d_sv,
+                                          (size_t)H, 0u, end_bit, st));
+    }
+    u64 totals[3] = {0, 0, 0};
+    if (rc == YH_OK) {
+        k_idx_count<<<(u32)nb, IDX_THREADS, 0, st>>>(d_sk, H, d_counts);
+        k_idx_scan_counts<<<1, 1024, 0, st>>>(d_counts, nb, d_bases);
+        IDX_HIP(hipGetLastError());
+        IDX_HIP(hipMemcpyAsync(totals, d_bases + nb * 3, 3 * sizeof(u64), hipMemcpyDeviceToHost, st));
+        IDX_HIP(hipStreamSynchronize(st));
+    }
+    if (rc == YH_OK) {
+        db->n_distinct = totals[0];
+        db->n_shared = totals[1];
+        db->n_postings = totals[2];
+        if (db->n_shared > 0xfffffff0ull) { yh_set_error("more than 2^32 shared hashes"); rc = YH_ERR_UNSUPPORTED; }
+    }
+    if (rc == YH_OK) rc = yh_dmalloc(db, (void**)&db->d_g, std::max<u64>(db->n_shared, 2) * sizeof(u64));
+    if (rc == YH_OK) rc = yh_dmalloc(db, (void**)&db->d_po, (db->n_shared + 1) * sizeof(u64));
+    if (rc == YH_OK) rc = yh_dmalloc(db, (void**)&db->d_pr, std::max<u64>(db->n_postings, 1) * sizeof(u32));
+    if (rc == YH_OK) rc = yh_dmalloc(db, (void**)&db->d_pg, std::max<u64>(db->n_postings, 1) * sizeof(u32));
+    if (rc == YH_OK) rc = yh_dmalloc(db, (void**)&db->d_hit, std::max<u64>(db->n_shared, 1));
+    if (rc == YH_OK) {
+        IDX_HIP(hipMemsetAsync(db->d_g, 0, std::max<u64>(db->n_shared, 2) * sizeof(u64), st));
+        k_idx_emit<<<(u32)nb, IDX_THREADS, 0, st>>>(d_sk, d_sv, H, d_bases, db->d_g, db->d_po, db->d_pr, db->d_pg,
+                                                    db->d_nshared);
+        IDX_HIP(hipGetLastError());
+        IDX_HIP(hipMemcpyAsync(db->d_po + db->n_shared, &db->n_postings, sizeof(u64), hipMemcpyHostToDevice, st));
+        if (db->n_shared) {
+            k_bounds_u64<<<(db->n_parts + 255) / 256, 256, 0, st>>>(db->d_g, db->n_shared, db->n_parts, db->pshift,
+                                                                    db->d_gbeg, db->d_gcnt);
+            IDX_HIP(hipGetLastError());
+        }
+        IDX_HIP(hipStreamSynchronize(st));
+    }
+#undef IDX_HIP
+    (void)hipFree(d_ids);
+    (void)hipFree(d_sv);
+    (void)hipFree(d_sk);
+    (void)hipFree(d_counts);
+    (void)hipFree(d_bases);
+    (void)hipFree(d_tmp);
+    if (rc == YH_OK) db->has_index = true;
+    return rc;
+}

@@ -1,0 +1,141 @@
+// yh_common.h — internal declarations shared by the HIP translation units of libyacht_hip.so.
+// Not part of the public boundary (that is include/yacht_hip.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/yacht_hip.h"
+
+typedef unsigned long long u64;  // same width as uint64_t; the type HIP's 64-bit atomics take
+typedef uint32_t u32;
+typedef uint16_t u16;
+typedef uint8_t u8;
+
+static_assert(sizeof(u64) == sizeof(uint64_t), "u64 must be 64 bits");
+
+// ---- error plumbing ------------------------------------------------------------------------
+void yh_set_error(const char* fmt, ...);
+
+#define YH_HIP(call)                                                                        \
+    do {                                                                                    \
+        hipError_t e__ = (call);                                                            \
+        if (e__ != hipSuccess) {                                                            \
+            yh_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__,  \
+                         __LINE__);                                                         \
+            return (e__ == hipErrorOutOfMemory) ? YH_ERR_OOM : YH_ERR_HIP;                  \
+        }                                                                                   \
+    } while (0)
+
+#define YH_TRY(call)               \
+    do {                           \
+        int rc__ = (call);         \
+        if (rc__ != YH_OK) return rc__; \
+    } while (0)
+
+// ---- tile-lookup geometry (the roofline kernel) --------------------------------------------
+// One workgroup owns one hash-range partition's slice of the SAMPLE in LDS:
+//   S : TILE_SLOTS uint64 (sorted sample hashes of the partition + 2 sentinels)
+//   E : TILE_NB uint16 bucket directory (bucket b -> first slot whose bucket >= b)
+// 65024 + 16384 = 81408 B, so two workgroups fit the CU's 160 KiB with 1 KiB to spare.
+constexpr int TILE_SLOTS = 8128;
+constexpr int TILE_CAP = TILE_SLOTS - 2;  // sample hashes per tile
+constexpr int TILE_LGNB = 13;
+constexpr int TILE_NB = 1 << TILE_LGNB;
+constexpr int TILE_THREADS = 512;
+constexpr int TILE_UNROLL = 4;  // 16-byte vectors in flight per lane
+
+constexpr int TIMING_RING = 256;
+
+struct EventRing {
+    hipEvent_t beg[TIMING_RING];
+    hipEvent_t end[TIMING_RING];
+    int head = 0;      // next slot to record into
+    int pending = 0;   // slots recorded since the last read
+    bool created = false;
+};
+
+struct yh_db {
+    int device = -1;
+    uint32_t flags = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;  // the stream work is queued on (own_stream unless overridden)
+
+    // sizes
+    u64 n_refs = 0;
+    u64 n_hashes = 0;
+    u64 max_hash = 0;
+    u32 n_parts = 1;
+    u32 pshift = 0;
+    u64 device_bytes = 0;
+
+    // plain CSR (only with YH_DB_KEEP_CSR)
+    u64* d_values = nullptr;
+    u64* d_offsets = nullptr;
+
+    // partitioned CSR: partition-major, reference-major inside a partition
+    u64* d_pvals = nullptr;  // [pvals_len]
+    u64 pvals_len = 0;
+    u64* d_pbeg = nullptr;   // [P]   first element of partition p in d_pvals (even)
+    u64* d_pcnt = nullptr;   // [P]   element count of partition p
+    u32* d_poffs = nullptr;  // [P*(N+1)] start of reference j inside partition p (relative)
+    u32* d_sizes = nullptr;  // [N]   |R_j|
+
+    // shared-hash inverted index (hashes present in >= 2 references)
+    bool has_index = false;
+    u64 n_distinct = 0;
+    u64 n_shared = 0;    // G
+    u64 n_postings = 0;  // sum of posting-list lengths
+    u64* d_g = nullptr;      // [G]   shared hashes ascending
+    u64* d_po = nullptr;     // [G+1] posting-list offsets
+    u32* d_pr = nullptr;     // [postings] reference ids, ascending inside a list
+    u32* d_pg = nullptr;     // [postings] index of the hash each posting belongs to
+    u64* d_gbeg = nullptr;   // [P]   first shared hash of partition p in d_g
+    u64* d_gcnt = nullptr;   // [P]
+    u32* d_nshared = nullptr;  // [N] number of shared hashes in reference j
+
+    // per-query scratch (allocated once)
+    u32* d_sbounds = nullptr;  // [P+1] sample slice bounds per partition
+    u8* d_mask = nullptr;      // [N]
+    u8* d_hit = nullptr;       // [G]
+    u32* d_excl_e = nullptr;   // [N] shared hashes that are subset-exclusive
+    u32* d_excl_m = nullptr;   // [N] ... and in the sample
+    u32* d_ovsh = nullptr;     // [N] overlap restricted to shared hashes
+    u32* d_overlap_tmp = nullptr;  // [N]
+    u64* d_sample_tmp = nullptr;   // grows on demand (host-pointer entry points)
+    u64 sample_tmp_cap = 0;
+    u32* d_flag = nullptr;     // [1] generic error/flag word
+
+    // pairwise result cache (two-call sizing)
+    bool pw_valid = false;
+    double pw_c = 0.0;
+    u64 pw_r0 = 0, pw_r1 = 0;
+    u64 pw_n = 0;
+    u32* h_pw_i = nullptr;
+    u32* h_pw_j = nullptr;
+    u32* h_pw_c = nullptr;
+
+    // timing
+    EventRing ev_overlap, ev_excl, ev_pair;
+    float ms_db_build = 0.f;
+};
+
+// ---- implemented in yh_build.hip -------------------------------------------------------------
+int yh_build_partitions(yh_db* db, const u64* d_values, const u64* d_offsets, u32 parts_hint);
+int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets);
+
+// ---- implemented in yh_query.hip -------------------------------------------------------------
+int yh_q_overlap(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap);
+int yh_q_overlap_bsearch(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap);
+int yh_q_exclusive(yh_db* db, const u8* d_mask, const u64* d_sample, u64 n_sample,
+                   const u32* d_overlap, u32* d_excl, u32* d_match);
+int yh_q_mask_from_overlap(yh_db* db, const u32* d_overlap, u8* d_mask);
+int yh_q_pairwise(yh_db* db, double c_thresh, u64 r0, u64 r1);
+int yh_q_check_sorted_host(const u64* v, u64 n);
+
+// helpers (yh_api.hip)
+int yh_dmalloc(yh_db* db, void** p, size_t bytes);
+void yh_ring_record_begin(yh_db* db, EventRing& r);
+void yh_ring_record_end(yh_db* db, EventRing& r);

@@ -1,0 +1,550 @@
+// yh_query.hip — the per-query kernels of libyacht_hip.so (gfx950 / CDNA4, wave64).
+//
+//   k_tile_lookup      the streaming membership kernel (HBM-bound; DESIGN.md "K1").  Each workgroup
+//                      stages one hash-range slice of the SAMPLE in LDS (sorted hashes + a bucket
+//                      directory) and streams a contiguous chunk of reference hashes of the same
+//                      range past it with 16-byte coalesced loads.
+//   k_overlap_bsearch  one wave per reference, lanes binary-search the sample in L2; the
+//                      independent cross-check and the A/B baseline for K1.
+//   k_excl_*           subset-exclusive hash counts from the shared-hash posting lists
+//                      (the arithmetic of hypothesis_recovery_src.py:165-204).
+//   k_pair_*           pairwise intersection counts from the posting lists into a dense row block,
+//                      threshold filter and ordered compaction (src/cpp/main.cpp:249-308).
+#include "yh_common.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+namespace {
+
+constexpr int WAVE = 64;
+
+typedef u64 u64x2 __attribute__((ext_vector_type(2)));  // one 16-byte global load per lane
+
+// Blocks b and b+8 share an XCD (observed round-robin dispatch; speed only, never correctness).
+// Map the hardware block id to a logical id so that one XCD receives CONSECUTIVE logical ids:
+// the workgroups that share a partition's sample tile and offsets then share one L2.
+__device__ __forceinline__ u32 xcd_remap(u32 bid, u32 nwg) {
+    const u32 q = nwg >> 3, r = nwg & 7u;
+    const u32 xcd = bid & 7u;
+    const u32 base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (bid >> 3);
+}
+
+// ---- hit handlers -------------------------------------------------------------------------------
+// A hit is reported as (partition, position relative to the partition's first element).
+struct OverlapHit {
+    const u32* poffs;  // [P][N+1]
+    u32 n_refs;
+    u32* out;          // [N]
+    __device__ __forceinline__ void operator()(u32 p, u64 rel) const {
+        const u32* po = poffs + (u64)p * (n_refs + 1);
+        const u32 r = (u32)rel;
+        u32 lo = 0, hi = n_refs;  // first j with po[j+1] > rel
+        while (lo < hi) {
+            const u32 mid = (lo + hi) >> 1;
+            if (po[mid + 1] <= r) lo = mid + 1; else hi = mid;
+        }
+        atomicAdd(&out[lo], 1u);
+    }
+};
+struct FlagHit {
+    const u64* gbeg;  // [P]
+    u8* hit;          // [G]
+    __device__ __forceinline__ void operator()(u32 p, u64 rel) const { hit[gbeg[p] + rel] = 1; }
+};
+
+// ---- K1: streaming tile lookup -------------------------------------------------------------------
+// grid = P * chunks workgroups of TILE_THREADS; LDS 81,408 B -> two workgroups per CU.
+template <class Hit>
+__global__ void __launch_bounds__(TILE_THREADS, 4)
+k_tile_lookup(const u64* __restrict__ vals,     // hash stream, grouped by partition
+              const u64* __restrict__ pbeg,     // [P] first element of partition p
+              const u64* __restrict__ pcnt,     // [P] elements in partition p
+              const u64* __restrict__ sample,   // sorted sample hashes
+              const u32* __restrict__ sbounds,  // [P+1] sample slice of partition p
+              u32 chunks, u32 pshift, Hit hit) {
+    __shared__ __attribute__((aligned(16))) u64 S[TILE_SLOTS];
+    __shared__ u16 E[TILE_NB];
+
+    const u32 tid = threadIdx.x;
+    const u32 lid = xcd_remap(blockIdx.x, gridDim.x);
+    const u32 p = lid / chunks;
+    const u32 c = lid - p * chunks;
+
+    const u64 e0 = pbeg[p];
+    const u64 cnt = pcnt[p];
+    u64 per = (cnt + chunks - 1) / chunks;
+    per = (per + 1) & ~1ull;  // even, so every chunk of an even-based partition is 16-byte aligned
+    const u64 start = e0 + (u64)c * per;
+    const u64 end = min(e0 + cnt, start + per);
+    if (start >= end) return;
+
+    const u32 s0 = sbounds[p], s1 = sbounds[p + 1];
+    const u32 bsh = (pshift > (u32)TILE_LGNB) ? pshift - TILE_LGNB : 0u;
+
+    for (u32 sub = s0; sub < s1; sub += TILE_CAP) {
+        const u32 n = min((u32)TILE_CAP, s1 - sub);
+        if (sub != s0) __syncthreads();  // previous tile fully consumed before it is overwritten
+        // ---- stage the sample slice and its two sentinels
+        for (u32 k = tid; k < n; k += TILE_THREADS) S[k] = sample[sub + k];
+        if (tid < 2) S[n + tid] = ~0ull;
+        __syncthreads();
+        // ---- bucket directory: E[b] = first slot whose bucket is >= b  (buckets are monotone in
+        // the hash inside one partition, so the slots of a bucket are contiguous)
+        for (u32 k = tid; k < n; k += TILE_THREADS) {
+            const u32 b = (u32)(S[k] >> bsh) & (TILE_NB - 1);
+            const int bp = (k == 0) ? -1 : (int)((u32)(S[k - 1] >> bsh) & (TILE_NB - 1));
+            for (int x = bp + 1; x <= (int)b; ++x) E[x] = (u16)k;
+            if (k == n - 1)
+                for (u32 x = b + 1; x < (u32)TILE_NB; ++x) E[x] = (u16)n;
+        }
+        __syncthreads();
+
+        auto lookup = [&](u64 h, u64 pos) {
+            const u32 b = (u32)(h >> bsh) & (TILE_NB - 1);
+            u32 k = E[b];
+            u64 v = S[k];
+            while (v < h) v = S[++k];  // sentinel ~0 stops the scan
+            if (v == h && k < n) hit(p, pos - e0);
+        };
+
+        // ---- stream the chunk
+        u64 i = start;
+        if (i & 1ull) {  // unaligned head (only for streams whose partitions are not padded)
+            if (tid == 0) lookup(vals[i], i);
+            ++i;
+        }
+        const u64 nvec = (end - i) >> 1;
+        const u64x2* __restrict__ vp = reinterpret_cast<const u64x2*>(vals + i);
+        u64 v = tid;
+        for (; v + (u64)(TILE_UNROLL - 1) * TILE_THREADS < nvec; v += (u64)TILE_UNROLL * TILE_THREADS) {
+            u64x2 x[TILE_UNROLL];
+#pragma unroll
+            for (int u = 0; u < TILE_UNROLL; ++u) x[u] = __builtin_nontemporal_load(&vp[v + (u64)u * TILE_THREADS]);
+#pragma unroll
+            for (int u = 0; u < TILE_UNROLL; ++u) {
+                const u64 pos = i + 2 * (v + (u64)u * TILE_THREADS);
+                lookup(x[u].x, pos);
+                lookup(x[u].y, pos + 1);
+            }
+        }
+        for (; v < nvec; v += TILE_THREADS) {
+            const u64x2 x = __builtin_nontemporal_load(&vp[v]);
+            const u64 pos = i + 2 * v;
+            lookup(x.x, pos);
+            lookup(x.y, pos + 1);
+        }
+        if (((end - i) & 1ull) && tid == 0) lookup(vals[end - 1], end - 1);
+    }
+}
+
+// sample slice bounds per partition: sbounds[p] = |{s in S : s < p << pshift}|
+__global__ void k_sample_bounds(const u64* __restrict__ sample, u32 n, u32 P, u32 pshift, u32* __restrict__ sb) {
+    const u32 p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p > P) return;
+    // Sample hashes at or above P << pshift cannot be in the database and must stay out of the
+    // last partition's tile (their bucket numbers would wrap), so sb[P] is a real bound too.
+    const bool wraps = (pshift > 0) && (((u64)p >> (64 - pshift)) != 0);  // p << pshift >= 2^64
+    u32 r;
+    if (p == 0) r = 0;
+    else if (wraps) r = n;
+    else {
+        const u64 key = (u64)p << pshift;
+        u32 lo = 0, hi = n;
+        while (lo < hi) {
+            const u32 mid = (lo + hi) >> 1;
+            if (sample[mid] < key) lo = mid + 1; else hi = mid;
+        }
+        r = lo;
+    }
+    sb[p] = r;
+}
+
+// ---- cross-check kernel: one wave per reference over the plain CSR -------------------------------
+__global__ void __launch_bounds__(256) k_overlap_bsearch(const u64* __restrict__ values,
+                                                         const u64* __restrict__ offsets, u64 n_refs,
+                                                         const u64* __restrict__ sample, u64 n_sample,
+                                                         u32* __restrict__ overlap) {
+    const u64 wave = (blockIdx.x * (u64)blockDim.x + threadIdx.x) / WAVE;
+    const u64 n_waves = ((u64)gridDim.x * blockDim.x) / WAVE;
+    const int lane = threadIdx.x & (WAVE - 1);
+    for (u64 j = wave; j < n_refs; j += n_waves) {
+        const u64 b = offsets[j], e = offsets[j + 1];
+        u32 total = 0;
+        for (u64 k0 = b; k0 < e; k0 += WAVE) {
+            const u64 k = k0 + lane;
+            bool hit = false;
+            if (k < e) {
+                const u64 h = values[k];
+                u64 lo = 0, hi = n_sample;
+                while (lo < hi) {
+                    const u64 mid = (lo + hi) >> 1;
+                    if (sample[mid] < h) lo = mid + 1; else hi = mid;
+                }
+                hit = (lo < n_sample) && (sample[lo] == h);
+            }
+            total += (u32)__popcll(__ballot(hit));
+        }
+        if (lane == 0) overlap[j] = total;
+    }
+}
+
+// ---- exclusive counts -----------------------------------------------------------------------------
+__global__ void k_mask_from_overlap(const u32* __restrict__ ov, u64 n, u8* __restrict__ mask) {
+    const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (i < n) mask[i] = ov[i] ? 1 : 0;
+}
+
+// One thread per shared hash.  c = masked references holding it.
+//   c == 1            -> the hash is exclusive to that reference inside the subset
+//   hash in sample    -> every masked holder's "shared overlap" grows by one
+__global__ void k_excl_postings(u64 G, const u64* __restrict__ po, const u32* __restrict__ pr,
+                                const u8* __restrict__ mask, const u8* __restrict__ hit, u32* __restrict__ ex_e,
+                                u32* __restrict__ ex_m, u32* __restrict__ ovsh) {
+    for (u64 gi = blockIdx.x * (u64)blockDim.x + threadIdx.x; gi < G; gi += (u64)gridDim.x * blockDim.x) {
+        const u64 b = po[gi], e = po[gi + 1];
+        const bool in_sample = hit[gi] != 0;
+        u32 c = 0, rstar = 0;
+        for (u64 k = b; k < e; ++k) {
+            const u32 r = pr[k];
+            if (mask[r]) {
+                ++c;
+                rstar = r;
+                if (in_sample) atomicAdd(&ovsh[r], 1u);
+            }
+        }
+        if (c == 1) {
+            atomicAdd(&ex_e[rstar], 1u);
+            if (in_sample) atomicAdd(&ex_m[rstar], 1u);
+        }
+    }
+}
+
+// e_j = (hashes of j that no other reference of the whole database has) + ex_e[j]
+// m_j = (overlap_j - overlap restricted to database-shared hashes)      + ex_m[j]
+__global__ void k_excl_final(u64 n, const u8* __restrict__ mask, const u32* __restrict__ sizes,
+                             const u32* __restrict__ nshared, const u32* __restrict__ overlap,
+                             const u32* __restrict__ ex_e, const u32* __restrict__ ex_m,
+                             const u32* __restrict__ ovsh, u32* __restrict__ out_e, u32* __restrict__ out_m) {
+    const u64 j = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    u32 e = 0, m = 0;
+    if (mask[j]) {
+        e = sizes[j] - nshared[j] + ex_e[j];
+        m = overlap[j] - ovsh[j] + ex_m[j];
+    }
+    out_e[j] = e;
+    out_m[j] = m;
+}
+
+// ---- pairwise -------------------------------------------------------------------------------------
+// One thread per posting (a = its reference): for every other reference b of the same hash,
+// M[a - r0][b] += 1.  Integer atomics: the result does not depend on arrival order.
+__global__ void k_pair_accum(u64 n_post, const u32* __restrict__ pr, const u32* __restrict__ pg,
+                             const u64* __restrict__ po, u64 r0, u64 r1, u64 n_refs, u32* __restrict__ M) {
+    for (u64 k = blockIdx.x * (u64)blockDim.x + threadIdx.x; k < n_post; k += (u64)gridDim.x * blockDim.x) {
+        const u32 a = pr[k];
+        if (a < r0 || a >= r1) continue;
+        const u32 gi = pg[k];
+        const u64 b = po[gi], e = po[gi + 1];
+        u32* row = M + (u64)(a - r0) * n_refs;
+        for (u64 q = b; q < e; ++q) {
+            const u32 o = pr[q];
+            if (o != a) atomicAdd(&row[o], 1u);
+        }
+    }
+}
+
+__device__ __forceinline__ bool pair_keep(u32 cnt, u32 i, u32 j, const u32* __restrict__ sizes, double c_relaxed) {
+    if (cnt == 0 || i == j) return false;
+    const u32 si = sizes[i], sj = sizes[j];
+    if (si == 0 || sj == 0) return false;
+    // relaxed device-side filter; the exact `!(1.0*cnt/|R_i| < C)` of main.cpp:297-303 is applied
+    // on the host to the survivors, so no decision depends on device floating point
+    return !((double)cnt / (double)si < c_relaxed);
+}
+
+// one wave per row: count survivors
+__global__ void __launch_bounds__(256) k_pair_count(const u32* __restrict__ M, u64 r0, u64 r1, u64 n_refs,
+                                                    const u32* __restrict__ sizes, double c_relaxed,
+                                                    u32* __restrict__ rowcnt) {
+    const u64 wave = (blockIdx.x * (u64)blockDim.x + threadIdx.x) / WAVE;
+    const u64 n_waves = ((u64)gridDim.x * blockDim.x) / WAVE;
+    const int lane = threadIdx.x & (WAVE - 1);
+    for (u64 i = r0 + wave; i < r1; i += n_waves) {
+        const u32* row = M + (i - r0) * n_refs;
+        u32 c = 0;
+        for (u64 j0 = 0; j0 < n_refs; j0 += WAVE) {
+            const u64 j = j0 + lane;
+            const bool keep = (j < n_refs) && pair_keep(row[j], (u32)i, (u32)j, sizes, c_relaxed);
+            c += (u32)__popcll(__ballot(keep));
+        }
+        if (lane == 0) rowcnt[i - r0] = c;
+    }
+}
+
+__global__ void __launch_bounds__(1024) k_scan_u32_to_u64(const u32* __restrict__ in, u64 n, u64* __restrict__ out) {
+    // single workgroup; out[n] = total
+    __shared__ u64 wsum[17];
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wid = threadIdx.x / WAVE;
+    const int nw = blockDim.x / WAVE;
+    u64 carry = 0;
+    for (u64 base = 0; base < n; base += blockDim.x) {
+        const u64 i = base + threadIdx.x;
+        const u64 v = (i < n) ? in[i] : 0;
+        u64 inc = v;
+#pragma unroll
+        for (int d = 1; d < WAVE; d <<= 1) {
+            const u64 t = __shfl_up(inc, d, WAVE);
+            if (lane >= d) inc += t;
+        }
+        if (lane == WAVE - 1) wsum[wid] = inc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            u64 acc = 0;
+            for (int w = 0; w < nw; ++w) { const u64 t = wsum[w]; wsum[w] = acc; acc += t; }
+            wsum[16] = acc;
+        }
+        __syncthreads();
+        if (i < n) out[i] = carry + wsum[wid] + inc - v;
+        carry += wsum[16];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[n] = carry;
+}
+
+// one wave per row: ordered compaction (j ascending inside a row, rows ascending)
+__global__ void __launch_bounds__(256) k_pair_emit(const u32* __restrict__ M, u64 r0, u64 r1, u64 n_refs,
+                                                   const u32* __restrict__ sizes, double c_relaxed,
+                                                   const u64* __restrict__ rowoff, u32* __restrict__ out_i,
+                                                   u32* __restrict__ out_j, u32* __restrict__ out_c) {
+    const u64 wave = (blockIdx.x * (u64)blockDim.x + threadIdx.x) / WAVE;
+    const u64 n_waves = ((u64)gridDim.x * blockDim.x) / WAVE;
+    const int lane = threadIdx.x & (WAVE - 1);
+    for (u64 i = r0 + wave; i < r1; i += n_waves) {
+        const u32* row = M + (i - r0) * n_refs;
+        u64 w = rowoff[i - r0];
+        for (u64 j0 = 0; j0 < n_refs; j0 += WAVE) {
+            const u64 j = j0 + lane;
+            u32 cnt = 0;
+            bool keep = false;
+            if (j < n_refs) {
+                cnt = row[j];
+                keep = pair_keep(cnt, (u32)i, (u32)j, sizes, c_relaxed);
+            }
+            const u64 bal = __ballot(keep);
+            if (keep) {
+                const u64 dst = w + __popcll(bal & ((1ull << lane) - 1ull));
+                out_i[dst] = (u32)i;
+                out_j[dst] = (u32)j;
+                out_c[dst] = cnt;
+            }
+            w += __popcll(bal);
+        }
+    }
+}
+
+inline u32 grid_for(u64 work_items, u32 block, u32 max_blocks = 16384) {
+    u64 g = (work_items + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > max_blocks) g = max_blocks;
+    return (u32)g;
+}
+
+// chunks per partition so the grid is ~16 workgroups per CU (8 rounds of 2 resident per CU)
+inline u32 choose_chunks(u32 P, u64 elems) {
+    const u32 target_wgs = 256 * 16;
+    u32 c = (target_wgs + P - 1) / P;
+    // never cut chunks below ~16 KiB of hashes per workgroup per tile load
+    const u64 per_part = P ? elems / P : 0;
+    const u64 max_c = std::max<u64>(1, per_part / 2048);
+    if (c > max_c) c = (u32)max_c;
+    if (c < 1) c = 1;
+    return c;
+}
+
+}  // namespace
+
+// =================================================================================================
+int yh_q_check_sorted_host(const u64* v, u64 n) {
+    for (u64 i = 1; i < n; ++i)
+        if (!(v[i - 1] < v[i])) return YH_ERR_UNSORTED;
+    return YH_OK;
+}
+
+int yh_q_overlap(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap) {
+    hipStream_t st = db->stream;
+    const u64 N = db->n_refs;
+    if (n_sample > 0xfffffff0ull) { yh_set_error("sample larger than 2^32-16 hashes"); return YH_ERR_INVALID_ARG; }
+    YH_HIP(hipMemsetAsync(d_overlap, 0, std::max<u64>(N, 1) * sizeof(u32), st));
+    if (N == 0 || db->n_hashes == 0 || n_sample == 0) return YH_OK;
+    const u32 P = db->n_parts;
+    k_sample_bounds<<<(P + 1 + 255) / 256, 256, 0, st>>>(d_sample, (u32)n_sample, P, db->pshift, db->d_sbounds);
+    const u32 chunks = choose_chunks(P, db->n_hashes);
+    OverlapHit hit{db->d_poffs, (u32)N, d_overlap};
+    yh_ring_record_begin(db, db->ev_overlap);
+    k_tile_lookup<OverlapHit><<<P * chunks, TILE_THREADS, 0, st>>>(db->d_pvals, db->d_pbeg, db->d_pcnt, d_sample,
+                                                                   db->d_sbounds, chunks, db->pshift, hit);
+    yh_ring_record_end(db, db->ev_overlap);
+    YH_HIP(hipGetLastError());
+    return YH_OK;
+}
+
+int yh_q_overlap_bsearch(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap) {
+    if (!db->d_values) { yh_set_error("yh_overlap_bsearch needs a handle created with YH_DB_KEEP_CSR"); return YH_ERR_UNSUPPORTED; }
+    hipStream_t st = db->stream;
+    const u64 N = db->n_refs;
+    YH_HIP(hipMemsetAsync(d_overlap, 0, std::max<u64>(N, 1) * sizeof(u32), st));
+    if (N == 0) return YH_OK;
+    k_overlap_bsearch<<<grid_for(N * WAVE, 256, 8192), 256, 0, st>>>(db->d_values, db->d_offsets, N, d_sample, n_sample,
+                                                                     d_overlap);
+    YH_HIP(hipGetLastError());
+    return YH_OK;
+}
+
+int yh_q_mask_from_overlap(yh_db* db, const u32* d_overlap, u8* d_mask) {
+    const u64 N = db->n_refs;
+    if (N == 0) return YH_OK;
+    k_mask_from_overlap<<<grid_for(N, 256, 1u << 22), 256, 0, db->stream>>>(d_overlap, N, d_mask);
+    YH_HIP(hipGetLastError());
+    return YH_OK;
+}
+
+// d_overlap must hold the overlap of the SAME sample (yh_q_overlap output).
+int yh_q_exclusive(yh_db* db, const u8* d_mask, const u64* d_sample, u64 n_sample, const u32* d_overlap,
+                   u32* d_excl, u32* d_match) {
+    if (!db->has_index) { yh_set_error("this handle was created with YH_DB_NO_INDEX"); return YH_ERR_UNSUPPORTED; }
+    hipStream_t st = db->stream;
+    const u64 N = db->n_refs;
+    if (N == 0) return YH_OK;
+    const u64 G = db->n_shared;
+    YH_HIP(hipMemsetAsync(db->d_excl_e, 0, N * sizeof(u32), st));
+    YH_HIP(hipMemsetAsync(db->d_excl_m, 0, N * sizeof(u32), st));
+    YH_HIP(hipMemsetAsync(db->d_ovsh, 0, N * sizeof(u32), st));
+    yh_ring_record_begin(db, db->ev_excl);
+    if (G) {
+        YH_HIP(hipMemsetAsync(db->d_hit, 0, G, st));
+        if (n_sample) {
+            // membership of every shared hash in the sample: the same tile kernel over d_g.
+            // d_sbounds still holds this sample's slice bounds (written by yh_q_overlap).
+            const u32 P = db->n_parts;
+            const u32 chunks = choose_chunks(P, G);
+            FlagHit fh{db->d_gbeg, db->d_hit};
+            k_tile_lookup<FlagHit><<<P * chunks, TILE_THREADS, 0, st>>>(db->d_g, db->d_gbeg, db->d_gcnt, d_sample,
+                                                                        db->d_sbounds, chunks, db->pshift, fh);
+        }
+        k_excl_postings<<<grid_for(G, 256, 8192), 256, 0, st>>>(G, db->d_po, db->d_pr, d_mask, db->d_hit, db->d_excl_e,
+                                                                db->d_excl_m, db->d_ovsh);
+    }
+    k_excl_final<<<grid_for(N, 256, 1u << 22), 256, 0, st>>>(N, d_mask, db->d_sizes, db->d_nshared, d_overlap,
+                                                             db->d_excl_e, db->d_excl_m, db->d_ovsh, d_excl, d_match);
+    yh_ring_record_end(db, db->ev_excl);
+    YH_HIP(hipGetLastError());
+    return YH_OK;
+}
+
+// Fills the handle's host-side pair cache (h_pw_*) for rows [r0, r1).
+int yh_q_pairwise(yh_db* db, double c_thresh, u64 r0, u64 r1) {
+    if (!db->has_index) { yh_set_error("this handle was created with YH_DB_NO_INDEX"); return YH_ERR_UNSUPPORTED; }
+    hipStream_t st = db->stream;
+    const u64 N = db->n_refs;
+    free(db->h_pw_i); free(db->h_pw_j); free(db->h_pw_c);
+    db->h_pw_i = db->h_pw_j = db->h_pw_c = nullptr;
+    db->pw_n = 0;
+    db->pw_valid = false;
+    if (r1 > N) r1 = N;
+    if (r0 >= r1) { db->pw_valid = true; db->pw_c = c_thresh; db->pw_r0 = r0; db->pw_r1 = r1; return YH_OK; }
+
+    // dense row blocks of at most ~32 GiB of int32 counts
+    const u64 budget = 32ull << 30;
+    u64 rows_per_block = std::max<u64>(1, budget / (N * sizeof(u32)));
+    if (rows_per_block > r1 - r0) rows_per_block = r1 - r0;
+    const double c_relaxed = c_thresh * (1.0 - 1e-9) - 1e-300;
+
+    u32 *d_M = nullptr, *d_rowcnt = nullptr, *d_oi = nullptr, *d_oj = nullptr, *d_oc = nullptr;
+    u64* d_rowoff = nullptr;
+    std::vector<u32> hi, hj, hc;
+    int rc = YH_OK;
+#define PW_HIP(call)                                                                          \
+    if (rc == YH_OK) {                                                                        \
+        hipError_t e__ = (call);                                                              \
+        if (e__ != hipSuccess) {                                                              \
+            yh_set_error("%s failed: %s", #call, hipGetErrorString(e__));                     \
+            rc = (e__ == hipErrorOutOfMemory) ? YH_ERR_OOM : YH_ERR_HIP;                      \
+        }                                                                                     \
+    }
+    PW_HIP(hipMalloc((void**)&d_M, rows_per_block * N * sizeof(u32)));
+    PW_HIP(hipMalloc((void**)&d_rowcnt, rows_per_block * sizeof(u32)));
+    PW_HIP(hipMalloc((void**)&d_rowoff, (rows_per_block + 1) * sizeof(u64)));
+    yh_ring_record_begin(db, db->ev_pair);
+    for (u64 b0 = r0; b0 < r1 && rc == YH_OK; b0 += rows_per_block) {
+        const u64 b1 = std::min(r1, b0 + rows_per_block);
+        const u64 rows = b1 - b0;
+        PW_HIP(hipMemsetAsync(d_M, 0, rows * N * sizeof(u32), st));
+        if (rc == YH_OK && db->n_postings) {
+            k_pair_accum<<<grid_for(db->n_postings, 256, 1u << 20), 256, 0, st>>>(db->n_postings, db->d_pr, db->d_pg,
+                                                                                  db->d_po, b0, b1, N, d_M);
+        }
+        if (rc == YH_OK) {
+            k_pair_count<<<grid_for(rows * WAVE, 256, 8192), 256, 0, st>>>(d_M, b0, b1, N, db->d_sizes, c_relaxed,
+                                                                           d_rowcnt);
+            k_scan_u32_to_u64<<<1, 1024, 0, st>>>(d_rowcnt, rows, d_rowoff);
+        }
+        PW_HIP(hipGetLastError());
+        u64 n_out = 0;
+        PW_HIP(hipMemcpyAsync(&n_out, d_rowoff + rows, sizeof(u64), hipMemcpyDeviceToHost, st));
+        PW_HIP(hipStreamSynchronize(st));
+        if (rc == YH_OK && n_out) {
+            PW_HIP(hipMalloc((void**)&d_oi, n_out * sizeof(u32)));
+            PW_HIP(hipMalloc((void**)&d_oj, n_out * sizeof(u32)));
+            PW_HIP(hipMalloc((void**)&d_oc, n_out * sizeof(u32)));
+            if (rc == YH_OK) {
+                k_pair_emit<<<grid_for(rows * WAVE, 256, 8192), 256, 0, st>>>(d_M, b0, b1, N, db->d_sizes, c_relaxed,
+                                                                              d_rowoff, d_oi, d_oj, d_oc);
+            }
+            PW_HIP(hipGetLastError());
+            const size_t base = hi.size();
+            hi.resize(base + n_out); hj.resize(base + n_out); hc.resize(base + n_out);
+            PW_HIP(hipMemcpyAsync(hi.data() + base, d_oi, n_out * sizeof(u32), hipMemcpyDeviceToHost, st));
+            PW_HIP(hipMemcpyAsync(hj.data() + base, d_oj, n_out * sizeof(u32), hipMemcpyDeviceToHost, st));
+            PW_HIP(hipMemcpyAsync(hc.data() + base, d_oc, n_out * sizeof(u32), hipMemcpyDeviceToHost, st));
+            PW_HIP(hipStreamSynchronize(st));
+            (void)hipFree(d_oi); (void)hipFree(d_oj); (void)hipFree(d_oc);
+            d_oi = d_oj = d_oc = nullptr;
+        }
+    }
+    yh_ring_record_end(db, db->ev_pair);
+#undef PW_HIP
+    (void)hipFree(d_M); (void)hipFree(d_rowcnt); (void)hipFree(d_rowoff);
+    (void)hipFree(d_oi); (void)hipFree(d_oj); (void)hipFree(d_oc);
+    if (rc != YH_OK) return rc;
+
+    // exact host-side filter (main.cpp:297-303): keep iff !(1.0*count/|R_i| < C)
+    std::vector<u32> hsizes(N);
+    YH_HIP(hipMemcpy(hsizes.data(), db->d_sizes, N * sizeof(u32), hipMemcpyDeviceToHost));
+    size_t w = 0;
+    for (size_t k = 0; k < hi.size(); ++k) {
+        const double cij = 1.0 * hc[k] / hsizes[hi[k]];
+        if (cij < c_thresh) continue;
+        hi[w] = hi[k]; hj[w] = hj[k]; hc[w] = hc[k];
+        ++w;
+    }
+    db->pw_n = w;
+    db->h_pw_i = (u32*)malloc(std::max<size_t>(w, 1) * sizeof(u32));
+    db->h_pw_j = (u32*)malloc(std::max<size_t>(w, 1) * sizeof(u32));
+    db->h_pw_c = (u32*)malloc(std::max<size_t>(w, 1) * sizeof(u32));
+    if (!db->h_pw_i || !db->h_pw_j || !db->h_pw_c) { yh_set_error("host allocation failed"); return YH_ERR_OOM; }
+    memcpy(db->h_pw_i, hi.data(), w * sizeof(u32));
+    memcpy(db->h_pw_j, hj.data(), w * sizeof(u32));
+    memcpy(db->h_pw_c, hc.data(), w * sizeof(u32));
+    db->pw_valid = true;
+    db->pw_c = c_thresh;
+    db->pw_r0 = r0;
+    db->pw_r1 = r1;
+    return YH_OK;
+}

@@ -1,0 +1,192 @@
+"""RefDB — Python handle over the HIP containment engine (libyacht_hip.so).
+
+A RefDB is a reference-sketch database resident in one GPU's HBM.  It answers the three
+questions of YACHT's hot path:
+
+    overlap(sample)              |S ∩ R_j| for every reference       (R1, `yacht run`)
+    exclusive(mask, sample)      subset-exclusive hash counts         (R2, `yacht run`)
+    pairwise(c_thresh)           above-threshold reference pairs      (T2-T4, `yacht train`)
+
+numpy arrays in, numpy arrays out; all arithmetic happens in the HIP kernels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import YH_DB_DEFAULT, YH_DB_KEEP_CSR, YH_DB_NO_INDEX, YachtHipError  # noqa: F401
+
+
+def pack_csr(sketches: Sequence[np.ndarray]) -> Tuple[np.ndarray, np.ndarray]:
+    """Pack a list of ascending uint64 hash arrays into (values, offsets)."""
+    offsets = np.zeros(len(sketches) + 1, dtype=np.uint64)
+    if len(sketches):
+        offsets[1:] = np.cumsum([len(s) for s in sketches], dtype=np.uint64)
+    if len(sketches) and int(offsets[-1]):
+        values = np.concatenate([np.asarray(s, dtype=np.uint64) for s in sketches])
+    else:
+        values = np.zeros(0, dtype=np.uint64)
+    return np.ascontiguousarray(values, dtype=np.uint64), offsets
+
+
+def _as_u64(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.uint64)
+
+
+def _ptr(a: Optional[np.ndarray]) -> C.c_void_p:
+    return C.c_void_p(0 if a is None else a.ctypes.data)
+
+
+class RefDB:
+    """Reference sketches in HBM: hash-range partitioned CSR + shared-hash inverted index."""
+
+    def __init__(self, values, offsets, device: int = 0, flags: int = YH_DB_DEFAULT, partitions_hint: int = 0):
+        self._h = C.c_void_p(0)
+        lib = _lib.load()
+        values = _as_u64(values)
+        offsets = _as_u64(offsets)
+        if offsets.ndim != 1 or offsets.size < 1:
+            raise ValueError("offsets must be a 1-D array of length n_refs + 1")
+        if int(offsets[-1]) != values.size:
+            raise ValueError("offsets[-1] must equal len(values)")
+        h = C.c_void_p(0)
+        _lib.check(lib.yh_db_create(_ptr(values), _ptr(offsets), offsets.size - 1, device, flags, partitions_hint,
+                                    C.byref(h)))
+        self._h = h
+        self._lib = lib
+        self.n_refs = offsets.size - 1
+        self.sizes = np.diff(offsets).astype(np.uint32)
+
+    @classmethod
+    def from_sketches(cls, sketches: Sequence[np.ndarray], **kw) -> "RefDB":
+        values, offsets = pack_csr(sketches)
+        return cls(values, offsets, **kw)
+
+    @classmethod
+    def from_device(cls, d_values: int, d_offsets: int, n_refs: int, sizes: Optional[np.ndarray] = None,
+                    device: int = 0, flags: int = YH_DB_DEFAULT, partitions_hint: int = 0) -> "RefDB":
+        """Build from CSR arrays that already live in this device's HBM (raw device addresses)."""
+        self = cls.__new__(cls)
+        self._h = C.c_void_p(0)
+        lib = _lib.load()
+        h = C.c_void_p(0)
+        _lib.check(lib.yh_db_create_device(C.c_void_p(d_values), C.c_void_p(d_offsets), n_refs, device, flags,
+                                           partitions_hint, C.byref(h)))
+        self._h = h
+        self._lib = lib
+        self.n_refs = n_refs
+        self.sizes = sizes
+        return self
+
+    # ---- lifetime ---------------------------------------------------------------------------
+    def close(self) -> None:
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            self._lib.yh_db_destroy(h)
+            self._h = C.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # ---- metadata ---------------------------------------------------------------------------
+    def info(self) -> dict:
+        inf = _lib.DbInfo()
+        _lib.check(self._lib.yh_db_get_info(self._h, C.byref(inf)))
+        return {name: getattr(inf, name) for name, _ in inf._fields_}
+
+    def timing(self) -> dict:
+        t = _lib.Timing()
+        _lib.check(self._lib.yh_db_get_timing(self._h, C.byref(t)))
+        return {name: getattr(t, name) for name, _ in t._fields_}
+
+    def index_stats(self) -> Tuple[int, int, int]:
+        """(distinct hashes, hashes in exactly one reference, hashes kept in the index)."""
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        _lib.check(self._lib.yh_index_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def set_stream(self, hip_stream: int) -> None:
+        _lib.check(self._lib.yh_db_set_stream(self._h, C.c_void_p(hip_stream)))
+
+    def synchronize(self) -> None:
+        _lib.check(self._lib.yh_db_synchronize(self._h))
+
+    # ---- yacht run ---------------------------------------------------------------------------
+    def overlap(self, sample, method: str = "tile") -> np.ndarray:
+        sample = _as_u64(sample)
+        out = np.zeros(self.n_refs, dtype=np.uint32)
+        fn = self._lib.yh_overlap if method == "tile" else self._lib.yh_overlap_bsearch
+        _lib.check(fn(self._h, _ptr(sample), sample.size, _ptr(out)))
+        return out
+
+    def exclusive(self, mask, sample) -> Tuple[np.ndarray, np.ndarray]:
+        sample = _as_u64(sample)
+        mask = np.ascontiguousarray(np.asarray(mask) != 0, dtype=np.uint8)
+        if mask.size != self.n_refs:
+            raise ValueError("mask must have one entry per reference")
+        e = np.zeros(self.n_refs, dtype=np.uint32)
+        m = np.zeros(self.n_refs, dtype=np.uint32)
+        _lib.check(self._lib.yh_exclusive(self._h, _ptr(mask), _ptr(sample), sample.size, _ptr(e), _ptr(m)))
+        return e, m
+
+    def run_counts(self, sample) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """overlap, and exclusive counts relative to the references with overlap > 0."""
+        sample = _as_u64(sample)
+        ov = np.zeros(self.n_refs, dtype=np.uint32)
+        e = np.zeros(self.n_refs, dtype=np.uint32)
+        m = np.zeros(self.n_refs, dtype=np.uint32)
+        _lib.check(self._lib.yh_run(self._h, _ptr(sample), sample.size, _ptr(ov), _ptr(e), _ptr(m)))
+        return ov, e, m
+
+    # device-pointer forms (async on the handle's stream; raw addresses, e.g. tensor.data_ptr())
+    def overlap_device(self, d_sample: int, n_sample: int, d_overlap: int) -> None:
+        _lib.check(self._lib.yh_overlap_device(self._h, C.c_void_p(d_sample), n_sample, C.c_void_p(d_overlap)))
+
+    def overlap_bsearch_device(self, d_sample: int, n_sample: int, d_overlap: int) -> None:
+        _lib.check(self._lib.yh_overlap_bsearch_device(self._h, C.c_void_p(d_sample), n_sample,
+                                                       C.c_void_p(d_overlap)))
+
+    def run_device(self, d_sample: int, n_sample: int, d_overlap: int, d_excl: int = 0, d_match: int = 0) -> None:
+        _lib.check(self._lib.yh_run_device(self._h, C.c_void_p(d_sample), n_sample, C.c_void_p(d_overlap),
+                                           C.c_void_p(d_excl), C.c_void_p(d_match)))
+
+    # ---- yacht train -------------------------------------------------------------------------
+    def pairwise(self, c_thresh: float, row_begin: int = 0, row_end: Optional[int] = None):
+        """Ordered pairs (i, j, |R_i ∩ R_j|) with !(count/|R_i| < c_thresh), sorted by (i, j)."""
+        if row_end is None:
+            row_end = self.n_refs
+        n = C.c_uint64(0)
+        _lib.check(self._lib.yh_pairwise(self._h, c_thresh, row_begin, row_end, 0, None, None, None, C.byref(n)))
+        cap = max(int(n.value), 1)
+        pi = np.zeros(cap, dtype=np.uint32)
+        pj = np.zeros(cap, dtype=np.uint32)
+        pc = np.zeros(cap, dtype=np.uint32)
+        _lib.check(self._lib.yh_pairwise(self._h, c_thresh, row_begin, row_end, cap, _ptr(pi), _ptr(pj), _ptr(pc),
+                                         C.byref(n)))
+        k = int(n.value)
+        return pi[:k], pj[:k], pc[:k]
+
+
+def train_select(sizes, pair_i, pair_j) -> np.ndarray:
+    """Greedy size-ordered dedup (src/cpp/main.cpp:371-407): kept reference ids in walk order."""
+    lib = _lib.load()
+    sizes = np.ascontiguousarray(sizes, dtype=np.uint32)
+    pair_i = np.ascontiguousarray(pair_i, dtype=np.uint32)
+    pair_j = np.ascontiguousarray(pair_j, dtype=np.uint32)
+    sel = np.zeros(max(sizes.size, 1), dtype=np.uint32)
+    n = C.c_uint64(0)
+    _lib.check(lib.yh_train_select(_ptr(sizes), sizes.size, _ptr(pair_i), _ptr(pair_j), pair_i.size, _ptr(sel),
+                                   C.byref(n)))
+    return sel[: int(n.value)]
