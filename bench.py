@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""bench.py — containment queries/sec of the `yacht run` hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one pass of the device-side `yacht run` counts over one sample sketch:
+overlap of the sample with every reference of the rank's shard (tile-lookup kernel, R1),
+mask = overlap > 0, subset-exclusive hash counts (R2), and — for N > 1 — one RCCL all-gather of
+the per-reference counts.  Inputs are resident in HBM before the timed region.
+
+Workload (config.workload): BASELINE.json configs[2] — GTDB-rs214-representatives scale,
+85 205 synthetic reference sketches (k=31, scaled=1000, sizes LogNormal(ln 3300, 0.6) in
+[300, 15000]) per GPU against one ~1 M-hash sample; the metric "ref-sketch containment
+queries/sec" counts one (sample, reference) intersection as one query.  N > 1 is weak scaling:
+every rank holds its own 85 205-reference shard of an N x 85 205 database, the sample is
+replicated, and no collective sits on the data path except the final gather of counts.
+
+Rank 0 prints ONE JSON line (contract in the task statement) carrying `roofline` for the
+dominant kernel (k_tile_lookup<OverlapHit>) and `cpu_baseline` (the oracle's C++ restatement,
+all host cores, same workload, also used as the full-size bit-exact parity check).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="gtdb_rs214_scale", choices=["gtdb_rs214_scale", "config2_1000refs"])
+    ap.add_argument("--refs", type=int, default=0, help="override references per GPU (testing only)")
+    ap.add_argument("--sample-hashes", type=int, default=1_000_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg (and its parity check)")
+    ap.add_argument("--overlap-only", action="store_true", help="time R1 only (diagnostic; not the reported metric)")
+    ap.add_argument("--seed", type=int, default=1002)
+    return ap.parse_args()
+
+
+def main() -> int:
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
+                  file=sys.stderr)
+        return 2
+    if not torch.cuda.is_available():
+        print("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)", file=sys.stderr)
+        return 2
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from yacht_amd import build, synth
+    from yacht_amd.engine import RefDB
+
+    if not os.path.exists(build.LIB_PATH):
+        build.build_lib()
+
+    # ---- synthetic workload, generated in HBM ---------------------------------------------------------
+    if args.workload == "gtdb_rs214_scale":
+        n_refs = args.refs or 85_205
+        values, offsets, sample = synth.config3_device(seed=args.seed + 7919 * rank, n_refs=n_refs,
+                                                       n_sample=args.sample_hashes, device=str(dev))
+        workload = f"GTDB-rs214-scale synthetic: {n_refs} refs/GPU k=31 scaled=1000 vs 1 sample"
+    else:
+        n_refs = args.refs or 1000
+        values, offsets, sample = synth.config3_device(seed=args.seed + 7919 * rank, n_refs=n_refs,
+                                                       n_sample=args.sample_hashes, device=str(dev), median=5000.0,
+                                                       sigma=0.35, lo=500, hi=20000, cluster_frac=0.0, n_present=50)
+        workload = f"configs[1]: {n_refs} refs/GPU (~5000 hashes) vs 1 sample"
+    if world > 1:  # the sample is replicated: every rank queries rank 0's sample
+        n_s = torch.tensor([sample.numel()], device=dev, dtype=torch.int64)
+        dist.broadcast(n_s, 0)
+        if rank != 0:
+            sample = torch.empty(int(n_s.item()), device=dev, dtype=torch.int64)
+        dist.broadcast(sample, 0)
+    H = int(values.numel())
+    n_sample = int(sample.numel())
+    torch.cuda.synchronize()
+
+    db = RefDB.from_device(values.data_ptr(), offsets.data_ptr(), n_refs, device=local_rank)
+    info = db.info()
+    stream = torch.cuda.current_stream()
+    db.set_stream(stream.cuda_stream)
+
+    counts = torch.zeros((3, n_refs), device=dev, dtype=torch.int32)  # overlap, n_excl, n_match (uint32 bits)
+    gathered = torch.zeros((world, 3, n_refs), device=dev, dtype=torch.int32) if world > 1 else None
+    p_sample, p_ov = sample.data_ptr(), counts[0].data_ptr()
+    p_e, p_m = (0, 0) if args.overlap_only else (counts[1].data_ptr(), counts[2].data_ptr())
+
+    def step():
+        db.run_device(p_sample, n_sample, p_ov, p_e, p_m)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, counts)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    db.timing()  # drop the warm-up launches from the kernel-duration ring
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    timing = db.timing()  # mean over the (up to 256) most recent launches of the timed region
+
+    ms_per_step = 1e3 * elapsed / args.steps
+    total_refs = n_refs * world
+    value = total_refs / (elapsed / args.steps)
+
+    # ---- roofline of the dominant kernel (overlap tile lookup) -----------------------------------------
+    # algorithmic bytes per launch: every reference hash and sample hash once,
+    # the CSR offsets once, one count per reference.
+    alg_bytes = 8 * (H + n_sample) + 8 * (n_refs + 1) + 4 * n_refs
+    k_ms = float(timing["ms_overlap_kernel"])
+    achieved = (alg_bytes / 1e9) / (k_ms / 1e3) if k_ms > 0 else 0.0
+    roofline = {
+        "bound": "hbm",
+        "kernel": "k_tile_lookup<OverlapHit>",
+        "achieved": round(achieved, 1),
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 4),
+        "traffic": None,
+        "algorithmic_bytes_per_launch": alg_bytes,
+        "kernel_ms_avg": round(k_ms, 4),
+        "exclusive_kernels_ms_avg": round(float(timing["ms_exclusive_kernels"]), 4),
+    }
+    traffic_file = os.path.join(ROOT, "profiles", "traffic_r01.json")
+    if os.path.exists(traffic_file):  # HBM bytes per launch from the rocprofv3 --pmc passes (profiles/README.md)
+        try:
+            with open(traffic_file) as f:
+                tr = json.load(f)
+            if tr.get("n_hashes") == H:
+                roofline["traffic"] = tr.get("hbm_bytes_per_launch")
+        except Exception:
+            pass
+
+    # ---- CPU baseline + full-size parity (rank 0, its own shard) ---------------------------------------
+    cpu_baseline = None
+    parity = None
+    if rank == 0 and not args.no_cpu_baseline:
+        from oracle import oracle  # the checker; never the thing measured as `value`
+
+        h_values = values.cpu().numpy().view(np.uint64)
+        h_offsets = offsets.cpu().numpy().view(np.uint64)
+        h_sample = sample.cpu().numpy().view(np.uint64)
+        cores = oracle.hardware_threads()
+        t0 = time.perf_counter()
+        want_ov = oracle.overlap(h_values, h_offsets, h_sample, threads=cores)
+        t_ov = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        want_e, want_m = oracle.exclusive(h_values, h_offsets, want_ov > 0, h_sample)
+        t_ex = time.perf_counter() - t0
+        got = counts.cpu().numpy().view(np.uint32)
+        parity = bool(np.array_equal(got[0], want_ov))
+        if not args.overlap_only:
+            parity = parity and bool(np.array_equal(got[1], want_e)) and bool(np.array_equal(got[2], want_m))
+        t_cpu = t_ov if args.overlap_only else t_ov + t_ex
+        cpu_baseline = {
+            "value": round(n_refs / t_cpu, 1),
+            "unit": "queries/s",
+            "cores": cores,
+            "kind": "port",
+            "sample": f"whole rank-0 workload once ({n_refs} refs, {H} hashes): overlap {t_ov:.2f} s on {cores} "
+                      f"threads + exclusive {t_ex:.2f} s on 1 thread",
+        }
+
+    if rank == 0:
+        out = {
+            "metric": "ref-sketch containment queries/sec (yacht run)",
+            "value": round(value, 1),
+            "unit": "queries/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u64",
+            "data": "synthetic",
+            "config": {
+                "workload": workload,
+                "refs_per_gpu": n_refs,
+                "ref_hashes_per_gpu": H,
+                "sample_hashes": n_sample,
+                "partitions": info["n_partitions"],
+                "shared_hashes": info["n_shared_distinct"],
+                "step": "overlap" if args.overlap_only else "overlap + exclusive counts" + (" + all_gather" if world > 1 else ""),
+                "parallelism": f"refs sharded x{world}",
+            },
+            "roofline": roofline,
+            "cpu_baseline": cpu_baseline,
+            "parity_bit_exact": parity,
+        }
+        print(json.dumps(out), flush=True)
+    db.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0 and parity is False:
+        print("bench.py: GPU counts differ from the CPU oracle", file=sys.stderr)
+        return 1
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

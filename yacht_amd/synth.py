@@ -121,3 +121,79 @@ def config4(seed: int = 1003, n_clusters: int = 2000, size: int = 5000):
     refs = clustered_refs(rng, n_clusters, (1.0, 0.9, 0.5, 0.25, 0.1), size)
     values, offsets = pack(refs)
     return values, offsets
+
+
+# ---- device-side generation (torch is plumbing here: it only makes the synthetic input) ----------------
+def config3_device(seed: int = 1002, n_refs: int = 85_205, n_sample: int = 1_000_000, device: str = "cuda:0",
+                   cluster_frac: float = 0.10, n_present: int = 200, median: float = 3300.0, sigma: float = 0.6,
+                   lo: int = 300, hi: int = 15000, scaled: int = 1000):
+    """configs[2] (GTDB rs214 representatives scale) generated directly in HBM.
+
+    Returns (values int64[H], offsets int64[N+1], sample int64[|S|]) as torch tensors on
+    `device`; all hashes are < 2**63 for scaled >= 2, so the int64 bit patterns ARE the uint64
+    hashes.  Same distribution family as config3_like (sizes LogNormal, ~cluster_frac of the
+    genomes in clusters of 2-8 sharing 10-95 % of a parent, sample = n_present genomes at
+    coverage Beta(0.5, 2) + uniform noise), different random stream.
+    """
+    import torch
+
+    assert scaled >= 2
+    mh = max_hash_for_scaled(scaled)
+    rng = np.random.default_rng(seed)
+    sizes = lognormal_sizes(rng, n_refs, median, sigma, lo, hi)
+    # cluster structure on the host (N-sized): parent[j] = j for founders / singletons
+    parent = np.arange(n_refs, dtype=np.int64)
+    share = np.zeros(n_refs, dtype=np.float64)
+    j = 0
+    while j < n_refs:
+        if rng.random() < cluster_frac / 4.0 and j + 2 <= n_refs:
+            k = int(min(rng.integers(2, 9), n_refs - j))
+            parent[j + 1 : j + k] = j
+            share[j + 1 : j + k] = rng.uniform(0.10, 0.95, size=k - 1)
+            j += k
+        else:
+            j += 1
+    offsets_np = np.zeros(n_refs + 1, dtype=np.int64)
+    offsets_np[1:] = np.cumsum(sizes)
+    H = int(offsets_np[-1])
+
+    dev = torch.device(device)
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    offsets = torch.from_numpy(offsets_np).to(dev)
+    sizes_t = torch.from_numpy(sizes).to(dev)
+    seg = torch.repeat_interleave(torch.arange(n_refs, device=dev, dtype=torch.int32), sizes_t)
+    vals = torch.randint(0, mh, (H,), generator=g, device=dev, dtype=torch.int64)
+    # cluster members copy the founder's hash at the same slot with probability share[j]
+    par_t = torch.from_numpy(parent).to(dev)
+    share_t = torch.from_numpy(share).to(dev)
+    seg64 = seg.long()
+    pos = torch.arange(H, device=dev, dtype=torch.int64) - offsets[seg64]
+    pj = par_t[seg64]
+    take = (torch.rand(H, generator=g, device=dev, dtype=torch.float64) < share_t[seg64]) & (pos < sizes_t[pj])
+    src = offsets[pj] + pos
+    vals = torch.where(take, vals[src.clamp_(0, H - 1)], vals)
+    del pos, pj, take, src, seg64
+    # order: by hash, then stably by reference -> each reference's slice ascending
+    vals, perm = torch.sort(vals)
+    seg = seg[perm]
+    del perm
+    seg, perm2 = torch.sort(seg, stable=True)
+    vals = vals[perm2]
+    del perm2
+    # (astronomically rare) equal neighbours inside one reference: nudge the second one up
+    dup = (vals[1:] == vals[:-1]) & (seg[1:] == seg[:-1])
+    if bool(dup.any()):
+        vals[1:] += dup.long()
+    # sample
+    present = rng.choice(n_refs, size=min(n_present, n_refs), replace=False)
+    cov = np.zeros(n_refs, dtype=np.float64)
+    cov[present] = rng.beta(0.5, 2.0, size=present.size)
+    cov_t = torch.from_numpy(cov).to(dev)
+    keep = torch.rand(H, generator=g, device=dev, dtype=torch.float64) < cov_t[seg.long()]
+    picked = vals[keep]
+    del keep, seg
+    n_noise = max(n_sample - int(picked.numel()), 0)
+    noise = torch.randint(0, mh, (n_noise,), generator=g, device=dev, dtype=torch.int64)
+    sample = torch.unique(torch.cat([picked, noise]))  # sorted ascending, distinct
+    return vals.contiguous(), offsets.contiguous(), sample.contiguous()
