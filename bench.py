@@ -48,6 +48,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg (and its parity check)")
     ap.add_argument("--overlap-only", action="store_true", help="time R1 only (diagnostic; not the reported metric)")
     ap.add_argument("--seed", type=int, default=1002)
+    ap.add_argument("--present", type=int, default=200, help="genomes present in the sample (diagnostic)")
     return ap.parse_args()
 
 
@@ -83,7 +84,8 @@ def main() -> int:
     if args.workload == "gtdb_rs214_scale":
         n_refs = args.refs or 85_205
         values, offsets, sample = synth.config3_device(seed=args.seed + 7919 * rank, n_refs=n_refs,
-                                                       n_sample=args.sample_hashes, device=str(dev))
+                                                       n_sample=args.sample_hashes, device=str(dev),
+                                                       n_present=args.present)
         workload = f"GTDB-rs214-scale synthetic: {n_refs} refs/GPU k=31 scaled=1000 vs 1 sample"
     else:
         n_refs = args.refs or 1000
@@ -105,6 +107,10 @@ def main() -> int:
     info = db.info()
     stream = torch.cuda.current_stream()
     db.set_stream(stream.cuda_stream)
+    # largest per-partition slice of the sample (one LDS tile holds 4094 hashes; larger slices
+    # make the kernel re-stream that partition once per extra tile)
+    part_of = (sample >> info["partition_shift"]) if info["partition_shift"] < 63 else torch.zeros_like(sample)
+    max_slice = int(torch.bincount(part_of.clamp_(0, info["n_partitions"])).max().item()) if n_sample else 0
 
     counts = torch.zeros((3, n_refs), device=dev, dtype=torch.int32)  # overlap, n_excl, n_match (uint32 bits)
     gathered = torch.zeros((world, 3, n_refs), device=dev, dtype=torch.int32) if world > 1 else None
@@ -219,6 +225,7 @@ def main() -> int:
                 "ref_hashes_per_gpu": H,
                 "sample_hashes": n_sample,
                 "partitions": info["n_partitions"],
+                "max_sample_slice": max_slice,
                 "shared_hashes": info["n_shared_distinct"],
                 "step": "overlap" if args.overlap_only else "overlap + exclusive counts" + (" + all_gather" if world > 1 else ""),
                 "parallelism": f"refs sharded x{world}",

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Summarize rocprofv3 CSV output of scripts/profile_bench.sh (kernel stats + PMC means per kernel)."""
+import collections
+import csv
+import glob
+import os
+import sys
+
+root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out"
+OURS = ("k_tile_lookup", "k_resolve_hits", "k_excl", "k_sample_bounds", "k_mask_from", "k_pair", "k_overlap_bsearch",
+        "k_scan_u32", "k_idx", "k_split", "k_part_scan", "k_scatter", "k_scan_refs", "k_fill", "k_bounds")
+
+
+def short(name: str) -> str:
+    name = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    for tag in ("<OverlapHit>", "<FlagHit>"):
+        if "k_tile_lookup" in name and tag[1:-1] in name:
+            return "k_tile_lookup" + tag
+    return name.split("(")[0][:60]
+
+
+stats = glob.glob(os.path.join(root, "prof_stats", "*", "*_kernel_stats.csv"))
+if stats:
+    print("== kernel stats (ours) ==")
+    print(f"{'kernel':42s} {'calls':>6s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'total_ms':>9s}")
+    for r in csv.DictReader(open(stats[0])):
+        if any(t in r["Name"] for t in OURS):
+            print(f"{short(r['Name']):42s} {r['Calls']:>6s} {float(r['AverageNs'])/1e3:10.2f} "
+                  f"{float(r['MinNs'])/1e3:10.2f} {float(r['MaxNs'])/1e3:10.2f} {float(r['TotalDurationNs'])/1e6:9.3f}")
+
+for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
+    files = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))
+    if not files:
+        continue
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(files[0])):
+        if any(t in r["Kernel_Name"] for t in ("k_tile_lookup", "k_resolve_hits", "k_excl_postings")):
+            acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    print(f"== {os.path.basename(d)} (mean per launch) ==")
+    for k, v in acc.items():
+        print("  " + k)
+        for c, vals in sorted(v.items()):
+            print(f"     {c:28s} n={len(vals):3d} mean={sum(vals)/len(vals):.6g}")

@@ -64,6 +64,21 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
     return LIB_PATH
 
 
+def build_variant(name: str, defines: dict, verbose: bool = False) -> str:
+    """Tuning aid: build lib/libyacht_hip_<name>.so with -D overrides of the YH_* macros in
+    csrc/yh_common.h.  Select it at run time with YACHT_HIP_LIB=<path>."""
+    os.makedirs(LIB_DIR, exist_ok=True)
+    hipcc = _hipcc()
+    out = os.path.join(LIB_DIR, f"libyacht_hip_{name}.so")
+    flags = [f"-D{k}={v}" for k, v in defines.items()]
+    srcs = [os.path.join(CSRC, s) for s in LIB_SOURCES]
+    if verbose:
+        print("hipcc variant", name, " ".join(flags), flush=True)
+    _run([hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result",
+          f"-I{os.path.join(REPO_DIR, 'include')}", *flags, *srcs, "-o", out])
+    return out
+
+
 def build_exe(force: bool = False, verbose: bool = False) -> str:
     """run_yacht_train_core: same argv / files contract as the reference executable."""
     build_lib(force=force, verbose=verbose)

@@ -325,14 +325,17 @@ int yh_build_partitions(yh_db* db, const u64* d_values, const u64* d_offsets, u3
     memcpy(&maxv, &hflag[2], 8);
     db->max_hash = maxv;
 
-    // ---- choose the partitioning: P ~ mean sketch size / 16 (pieces of >= ~16 hashes keep the
-    // per-(partition, reference) offsets under ~3 % of the hash bytes), rounded down to 2^k,
-    // then the largest shift that still yields at least that many partitions.
+    // ---- choose the partitioning: P ~ mean sketch size / YH_PIECE_TARGET, rounded down to 2^k,
+    // then the largest shift that still yields at least that many partitions.  With pieces of
+    // 4-8 hashes the per-(partition, reference) offsets cost 6-12 % of the hash bytes (they are
+    // only read when a hit is resolved), and a 1 M-hash sample fills the 4094-slot LDS tiles of a
+    // GTDB-like database (mean sketch ~4 000 hashes -> 526 partitions) only half: a slice that
+    // does not fit one tile makes the kernel stream that partition again.
     const u64 H = db->n_hashes;
     u32 target = parts_hint;
     if (target == 0) {
         const u64 mean = N ? H / N : 0;
-        u64 t = mean / 16;
+        u64 t = mean / YH_PIECE_TARGET;
         if (t < 1) t = 1;
         if (t > 16384) t = 16384;
         u32 pw = 1;

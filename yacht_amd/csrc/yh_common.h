@@ -35,17 +35,50 @@ void yh_set_error(const char* fmt, ...);
         if (rc__ != YH_OK) return rc__; \
     } while (0)
 
-// ---- tile-lookup geometry (the roofline kernel) --------------------------------------------
-// One workgroup owns one hash-range partition's slice of the SAMPLE in LDS:
-//   S : TILE_SLOTS uint64 (sorted sample hashes of the partition + 2 sentinels)
-//   E : TILE_NB uint16 bucket directory (bucket b -> first slot whose bucket >= b)
-// 65024 + 16384 = 81408 B, so two workgroups fit the CU's 160 KiB with 1 KiB to spare.
-constexpr int TILE_SLOTS = 8128;
+// ---- tile-lookup geometry (the roofline kernel, k_tile_lookup in yh_query.hip) -----------------
+// One workgroup stages one hash-range partition's slice of the SAMPLE in LDS:
+//   BM : 2^TILE_LGBM-bit membership bitmap              (32,768 B)
+//   S  : TILE_SLOTS uint64 sorted hashes + 2 sentinels  (32,768 B)
+//   E  : TILE_NB uint16 bucket directory                ( 8,192 B)
+// 73,728 B per workgroup -> two workgroups fit the CU's 160 KiB.
+// (the YH_* macros exist so tuning variants can be built side by side: build.py build_variant)
+#ifndef YH_TILE_SLOTS
+#define YH_TILE_SLOTS 4096
+#endif
+#ifndef YH_TILE_LGNB
+#define YH_TILE_LGNB 12
+#endif
+#ifndef YH_TILE_LGBM
+#define YH_TILE_LGBM 18
+#endif
+#ifndef YH_TILE_THREADS
+#define YH_TILE_THREADS 512
+#endif
+#ifndef YH_TILE_UNROLL
+#define YH_TILE_UNROLL 4
+#endif
+#ifndef YH_TILE_WAVES_PER_SIMD
+#define YH_TILE_WAVES_PER_SIMD 4
+#endif
+// mean sketch size / YH_PIECE_TARGET = number of hash-range partitions aimed for at build time
+#ifndef YH_PIECE_TARGET
+#define YH_PIECE_TARGET 4
+#endif
+constexpr int TILE_SLOTS = YH_TILE_SLOTS;
 constexpr int TILE_CAP = TILE_SLOTS - 2;  // sample hashes per tile
-constexpr int TILE_LGNB = 13;
+constexpr int TILE_LGNB = YH_TILE_LGNB;
 constexpr int TILE_NB = 1 << TILE_LGNB;
-constexpr int TILE_THREADS = 512;
-constexpr int TILE_UNROLL = 4;  // 16-byte vectors in flight per lane
+constexpr int TILE_LGBM = YH_TILE_LGBM;
+constexpr int TILE_BM_WORDS = (1 << TILE_LGBM) / 32;
+constexpr int TILE_THREADS = YH_TILE_THREADS;
+constexpr int TILE_UNROLL = YH_TILE_UNROLL;  // 16-byte vectors in flight per lane
+static_assert(TILE_SLOTS <= 65536, "directory entries are uint16 slot numbers");
+// hits parked in LDS until the next tile switch (8 B each); 960 keeps two workgroups per CU
+#ifndef YH_TILE_QCAP
+#define YH_TILE_QCAP 960
+#endif
+constexpr int TILE_QCAP = YH_TILE_QCAP;
+static_assert(TILE_UNROLL * 2 <= 32, "candidate masks are 32-bit");
 
 constexpr int TIMING_RING = 256;
 
@@ -107,6 +140,11 @@ struct yh_db {
     u64* d_sample_tmp = nullptr;   // grows on demand (host-pointer entry points)
     u64 sample_tmp_cap = 0;
     u32* d_flag = nullptr;     // [1] generic error/flag word
+    u64* d_hitq = nullptr;     // [hitq_wgs][hitq_cap] deferred overlap hits (partition << 32 | position)
+    u32* d_hitq_cnt = nullptr; // [hitq_wgs]
+    u32 hitq_wgs = 0, hitq_cap = 0;
+    u32* d_reps = nullptr;     // [R][N] replicated overlap counters
+    u64 reps_cap = 0;
 
     // pairwise result cache (two-call sizing)
     bool pw_valid = false;

@@ -36,109 +36,282 @@ __device__ __forceinline__ u32 xcd_remap(u32 bid, u32 nwg) {
 
 // ---- hit handlers -------------------------------------------------------------------------------
 // A hit is reported as (partition, position relative to the partition's first element).
+// Resolving a position to its reference is a 17-step dependent search through L2 (~3 us) during
+// which the rest of the wave idles, and even a single global store per hit delays the wave's next
+// `s_waitcnt vmcnt(0)` by a memory round trip.  So the streaming kernel only appends the hit to a
+// small queue in LDS; the queue is copied to the workgroup's segment of a queue in HBM at tile
+// switches and at the end, and k_resolve_hits turns that queue into counts with every lane busy.
+// Counts go to R replicas (workgroup id mod R) that k_reduce_replicas sums: a present genome
+// collects hundreds of hits and same-address atomics serialize in L2.  A hit is resolved in place
+// only when a queue overflows (samples made almost entirely of database hashes).
+struct HitCtx {
+    u32* q_fill;  // LDS: entries in the workgroup's LDS queue
+    u64* q;       // LDS queue
+    u32 wg;       // logical workgroup id
+};
+
+__device__ __forceinline__ u32 resolve_ref(const u32* __restrict__ po, u32 n_refs, u32 rel) {
+    u32 lo = 0, hi = n_refs;  // first j with po[j+1] > rel
+    while (lo < hi) {
+        const u32 mid = (lo + hi) >> 1;
+        if (po[mid + 1] <= rel) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
 struct OverlapHit {
+    static constexpr bool kQueued = true;
     const u32* poffs;  // [P][N+1]
     u32 n_refs;
-    u32* out;          // [N]
-    __device__ __forceinline__ void operator()(u32 p, u64 rel) const {
-        const u32* po = poffs + (u64)p * (n_refs + 1);
-        const u32 r = (u32)rel;
-        u32 lo = 0, hi = n_refs;  // first j with po[j+1] > rel
-        while (lo < hi) {
-            const u32 mid = (lo + hi) >> 1;
-            if (po[mid + 1] <= r) lo = mid + 1; else hi = mid;
-        }
-        atomicAdd(&out[lo], 1u);
+    u32* reps;         // [R][N] replicated counters
+    u32 rep_mask;      // R - 1 (R a power of two)
+    u64* queue;        // [wgs][qcap]  (partition << 32 | rel)
+    u32 qcap;
+    __device__ __forceinline__ void count(u32 wg, u32 p, u32 rel) const {
+        const u32 j = resolve_ref(poffs + (u64)p * (n_refs + 1), n_refs, rel);
+        atomicAdd(&reps[(u64)(wg & rep_mask) * n_refs + j], 1u);
+    }
+    __device__ __forceinline__ void operator()(const HitCtx& c, u32 p, u64 rel) const {
+        const u32 slot = atomicAdd(c.q_fill, 1u);
+        if (slot < (u32)TILE_QCAP) c.q[slot] = ((u64)p << 32) | (u64)(u32)rel;
+        else count(c.wg, p, (u32)rel);
     }
 };
 struct FlagHit {
+    static constexpr bool kQueued = false;
     const u64* gbeg;  // [P]
     u8* hit;          // [G]
-    __device__ __forceinline__ void operator()(u32 p, u64 rel) const { hit[gbeg[p] + rel] = 1; }
+    __device__ __forceinline__ void operator()(const HitCtx&, u32 p, u64 rel) const { hit[gbeg[p] + rel] = 1; }
+    __device__ __forceinline__ void count(u32, u32, u32) const {}
 };
 
+// one workgroup per queue segment: position -> reference -> replicated count
+__global__ void __launch_bounds__(256) k_resolve_hits(const u32* __restrict__ qcount, OverlapHit hit) {
+    const u32 wg = blockIdx.x;
+    const u32 cnt = qcount[wg];
+    const u64* q = hit.queue + (u64)wg * hit.qcap;
+    for (u32 e = threadIdx.x; e < cnt; e += blockDim.x) {
+        const u64 x = q[e];
+        hit.count(wg, (u32)(x >> 32), (u32)x);
+    }
+}
+
+__global__ void k_reduce_replicas(const u32* __restrict__ reps, u32 R, u64 n, u32* __restrict__ out) {
+    const u64 j = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    u32 acc = 0;
+    for (u32 r = 0; r < R; ++r) acc += reps[(u64)r * n + j];
+    out[j] = acc;
+}
+
 // ---- K1: streaming tile lookup -------------------------------------------------------------------
-// grid = P * chunks workgroups of TILE_THREADS; LDS 81,408 B -> two workgroups per CU.
+// The hash stream `vals` is grouped by hash-range partition.  The grid is sized to the machine
+// (two resident workgroups per CU), every workgroup takes an equal contiguous slice [w0, w1) of
+// the whole stream and, for each partition that slice touches, stages that partition's slice of
+// the SAMPLE in LDS as three structures:
+//   BM : bitmap of 2^TILE_LGBM bits, bit (h mod 2^TILE_LGBM) set for every sample hash h
+//   S  : the sorted sample hashes of the partition + 2 sentinels (~0)
+//   E  : bucket directory, E[b] = first slot of S whose bucket is >= b
+// It then streams its reference hashes past them: 16-byte coalesced non-temporal loads, software
+// pipelined one batch ahead.  Every hash costs ONE LDS read (its bitmap word; all reads of a
+// batch in flight together).  With <= 4094 sample hashes per tile ~1.5 % of the misses survive
+// the bitmap; survivors and true members are then looked up exactly (directory -> slot -> next
+// slots) by the few lanes that hold one.  LDS 73,728 B -> two workgroups (16 waves) per CU.
+template <bool HI>
+__device__ __forceinline__ u32 bucket_of(u64 h, u32 bsh) {
+    // HI: the bucket bits lie entirely in the upper dword (bsh >= 32): one v_bfe_u32
+    if (HI) return ((u32)(h >> 32) >> (bsh - 32)) & (TILE_NB - 1);
+    return (u32)(h >> bsh) & (TILE_NB - 1);
+}
+__device__ __forceinline__ u32 bm_index(u64 h) { return (u32)h & ((1u << TILE_LGBM) - 1u); }
+
+template <bool HI, class Hit>
+__device__ __forceinline__ void tile_stream(const u64* __restrict__ vals, u64 start, u64 end, u64 e0, u32 p, u32 n,
+                                            u32 bsh, const u64* S, const u16* E, const u32* BM, const Hit& hit,
+                                            const HitCtx& ctx) {
+    constexpr int U = TILE_UNROLL;
+    constexpr int B = 2 * U;
+    const u32 tid = threadIdx.x;
+
+    // exact membership through the directory; reports a hit at stream position `pos`
+    auto lookup1 = [&](u64 h, u64 pos) {
+        u32 k = E[bucket_of<HI>(h, bsh)];
+        u64 v = S[k];
+        while (v < h) v = S[++k];  // sentinel ~0 stops the scan
+#if defined(YH_ABLATE) && YH_ABLATE == 3  // timing-only build: hits found but not recorded
+        if (v == h && k < n && pos == 0x7fffffffffffffffull) hit(ctx, p, pos - e0);
+        return;
+#endif
+        if (v == h && k < n) hit(ctx, p, pos - e0);
+    };
+
+    u64 i = start;
+    if (i & 1ull) {  // unaligned head (streams whose partitions are not padded to 16 bytes)
+        if (tid == 0) lookup1(vals[i], i);
+        ++i;
+    }
+    const u64 nvec = (end - i) >> 1;
+    if (nvec) {
+        const u64x2* __restrict__ vp = reinterpret_cast<const u64x2*>(vals + i);
+        const u64 last = nvec - 1;
+        u64x2 cur[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) cur[u] = __builtin_nontemporal_load(&vp[min((u64)tid + (u64)u * TILE_THREADS, last)]);
+        for (u64 v = tid; v < nvec; v += (u64)U * TILE_THREADS) {
+            // ---- prefetch the next batch (clamped indices: a few harmless re-reads at the very end)
+            u64x2 nxt[U];
+            const u64 vn = v + (u64)U * TILE_THREADS;
+#pragma unroll
+            for (int u = 0; u < U; ++u) nxt[u] = __builtin_nontemporal_load(&vp[min(vn + (u64)u * TILE_THREADS, last)]);
+
+            u64 h[B];
+            u32 valid = 0;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                h[2 * u] = cur[u].x;
+                h[2 * u + 1] = cur[u].y;
+                if (v + (u64)u * TILE_THREADS < nvec) valid |= 3u << (2 * u);
+            }
+#if defined(YH_ABLATE) && YH_ABLATE == 1  // timing-only build: stream, no lookups (results are wrong)
+            {
+                u64 acc = 0;
+#pragma unroll
+                for (int b = 0; b < B; ++b) acc ^= h[b];
+                if (acc == 0x0123456789abcdefull && valid) hit(ctx, p, 0);
+#pragma unroll
+                for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+                continue;
+            }
+#endif
+            // ---- one bitmap word per hash, all B reads in flight together
+            u32 w[B];
+#pragma unroll
+            for (int b = 0; b < B; ++b) w[b] = BM[bm_index(h[b]) >> 5];
+            u32 cand = 0;
+#pragma unroll
+            for (int b = 0; b < B; ++b) cand |= ((w[b] >> (bm_index(h[b]) & 31u)) & 1u) << b;
+            cand &= valid;
+#if defined(YH_ABLATE) && YH_ABLATE == 2  // timing-only build: bitmap only (results are wrong)
+            if (cand == 0xffffffffu) hit(ctx, p, 0);
+            cand = 0;
+#endif
+            // ---- rare: exact lookup of the candidates this lane holds (usually none or one)
+            while (cand) {
+                const u32 b = (u32)__ffs((int)cand) - 1u;
+                cand &= cand - 1u;
+                u64 hb = h[0];
+#pragma unroll
+                for (int j = 1; j < B; ++j) hb = (b == (u32)j) ? h[j] : hb;
+                const u64 pos = i + 2 * (v + (u64)(b >> 1) * TILE_THREADS) + (b & 1u);
+                lookup1(hb, pos);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+        }
+    }
+    if (((end - i) & 1ull) && tid == 0) lookup1(vals[end - 1], end - 1);
+}
+
 template <class Hit>
-__global__ void __launch_bounds__(TILE_THREADS, 4)
+__global__ void __launch_bounds__(TILE_THREADS, YH_TILE_WAVES_PER_SIMD)
 k_tile_lookup(const u64* __restrict__ vals,     // hash stream, grouped by partition
-              const u64* __restrict__ pbeg,     // [P] first element of partition p
+              const u64* __restrict__ pbeg,     // [P] first element of partition p (ascending)
               const u64* __restrict__ pcnt,     // [P] elements in partition p
+              u32 P, u64 total_len,             // stream length including inter-partition padding
               const u64* __restrict__ sample,   // sorted sample hashes
               const u32* __restrict__ sbounds,  // [P+1] sample slice of partition p
-              u32 chunks, u32 pshift, Hit hit) {
+              u32 pshift, u32* __restrict__ qcount, Hit hit) {
     __shared__ __attribute__((aligned(16))) u64 S[TILE_SLOTS];
+    __shared__ __attribute__((aligned(16))) u32 BM[TILE_BM_WORDS];
     __shared__ u16 E[TILE_NB];
+    __shared__ u64 Q[Hit::kQueued ? TILE_QCAP : 1];  // hits waiting to be flushed to HBM
+    __shared__ u32 q_fill;                            // entries in Q (may exceed TILE_QCAP: overflow)
+    __shared__ u32 g_fill;                            // entries already flushed to this workgroup's segment
 
     const u32 tid = threadIdx.x;
     const u32 lid = xcd_remap(blockIdx.x, gridDim.x);
-    const u32 p = lid / chunks;
-    const u32 c = lid - p * chunks;
-
-    const u64 e0 = pbeg[p];
-    const u64 cnt = pcnt[p];
-    u64 per = (cnt + chunks - 1) / chunks;
-    per = (per + 1) & ~1ull;  // even, so every chunk of an even-based partition is 16-byte aligned
-    const u64 start = e0 + (u64)c * per;
-    const u64 end = min(e0 + cnt, start + per);
-    if (start >= end) return;
-
-    const u32 s0 = sbounds[p], s1 = sbounds[p + 1];
-    const u32 bsh = (pshift > (u32)TILE_LGNB) ? pshift - TILE_LGNB : 0u;
-
-    for (u32 sub = s0; sub < s1; sub += TILE_CAP) {
-        const u32 n = min((u32)TILE_CAP, s1 - sub);
-        if (sub != s0) __syncthreads();  // previous tile fully consumed before it is overwritten
-        // ---- stage the sample slice and its two sentinels
-        for (u32 k = tid; k < n; k += TILE_THREADS) S[k] = sample[sub + k];
-        if (tid < 2) S[n + tid] = ~0ull;
+    u64 per = (total_len + gridDim.x - 1) / gridDim.x;
+    per = (per + 1) & ~1ull;  // even: slices of an even-based stream stay 16-byte aligned
+    const u64 w0 = (u64)lid * per;
+    const u64 w1 = min(total_len, w0 + per);
+    const HitCtx ctx{&q_fill, Q, lid};
+    if (threadIdx.x == 0) { q_fill = 0; g_fill = 0; }  // visible to all after the first barrier
+    if (w0 >= w1) {
+        if (Hit::kQueued && threadIdx.x == 0) qcount[lid] = 0;
+        return;
+    }
+    // copy the LDS queue to this workgroup's HBM segment (entries past its capacity are resolved
+    // here); called by all threads, between streaming phases
+    auto flush = [&]() {
+        if (!Hit::kQueued) return;
         __syncthreads();
-        // ---- bucket directory: E[b] = first slot whose bucket is >= b  (buckets are monotone in
-        // the hash inside one partition, so the slots of a bucket are contiguous)
-        for (u32 k = tid; k < n; k += TILE_THREADS) {
-            const u32 b = (u32)(S[k] >> bsh) & (TILE_NB - 1);
-            const int bp = (k == 0) ? -1 : (int)((u32)(S[k - 1] >> bsh) & (TILE_NB - 1));
-            for (int x = bp + 1; x <= (int)b; ++x) E[x] = (u16)k;
-            if (k == n - 1)
-                for (u32 x = b + 1; x < (u32)TILE_NB; ++x) E[x] = (u16)n;
-        }
-        __syncthreads();
-
-        auto lookup = [&](u64 h, u64 pos) {
-            const u32 b = (u32)(h >> bsh) & (TILE_NB - 1);
-            u32 k = E[b];
-            u64 v = S[k];
-            while (v < h) v = S[++k];  // sentinel ~0 stops the scan
-            if (v == h && k < n) hit(p, pos - e0);
-        };
-
-        // ---- stream the chunk
-        u64 i = start;
-        if (i & 1ull) {  // unaligned head (only for streams whose partitions are not padded)
-            if (tid == 0) lookup(vals[i], i);
-            ++i;
-        }
-        const u64 nvec = (end - i) >> 1;
-        const u64x2* __restrict__ vp = reinterpret_cast<const u64x2*>(vals + i);
-        u64 v = tid;
-        for (; v + (u64)(TILE_UNROLL - 1) * TILE_THREADS < nvec; v += (u64)TILE_UNROLL * TILE_THREADS) {
-            u64x2 x[TILE_UNROLL];
-#pragma unroll
-            for (int u = 0; u < TILE_UNROLL; ++u) x[u] = __builtin_nontemporal_load(&vp[v + (u64)u * TILE_THREADS]);
-#pragma unroll
-            for (int u = 0; u < TILE_UNROLL; ++u) {
-                const u64 pos = i + 2 * (v + (u64)u * TILE_THREADS);
-                lookup(x[u].x, pos);
-                lookup(x[u].y, pos + 1);
+        const u32 f = min(q_fill, (u32)TILE_QCAP);
+        const u32 g0 = g_fill;
+        if constexpr (Hit::kQueued) {
+            for (u32 e = threadIdx.x; e < f; e += TILE_THREADS) {
+                const u64 x = Q[e];
+                if (g0 + e < hit.qcap) hit.queue[(u64)lid * hit.qcap + g0 + e] = x;
+                else hit.count(lid, (u32)(x >> 32), (u32)x);
             }
         }
-        for (; v < nvec; v += TILE_THREADS) {
-            const u64x2 x = __builtin_nontemporal_load(&vp[v]);
-            const u64 pos = i + 2 * v;
-            lookup(x.x, pos);
-            lookup(x.y, pos + 1);
+        __syncthreads();
+        if (threadIdx.x == 0) { q_fill = 0; g_fill = g0 + f; }
+        __syncthreads();
+    };
+
+    // last partition that starts at or before w0
+    u32 p;
+    {
+        u32 lo = 0, hi = P;
+        while (lo < hi) {
+            const u32 mid = (lo + hi) >> 1;
+            if (pbeg[mid] <= w0) lo = mid + 1; else hi = mid;
         }
-        if (((end - i) & 1ull) && tid == 0) lookup(vals[end - 1], end - 1);
+        p = lo ? lo - 1 : 0;
+    }
+    const u32 bsh = (pshift > (u32)TILE_LGNB) ? pshift - TILE_LGNB : 0u;
+    bool first = true;
+    for (; p < P; ++p) {
+        const u64 e0 = pbeg[p];
+        if (e0 >= w1) break;
+        const u64 start = max(w0, e0), end = min(w1, e0 + pcnt[p]);
+        if (start >= end) continue;
+        const u32 s0 = sbounds[p], s1 = sbounds[p + 1];
+        for (u32 sub = s0; sub < s1; sub += TILE_CAP) {
+            const u32 n = min((u32)TILE_CAP, s1 - sub);
+            if (!first) {
+                flush();          // drains the hit queue; its barriers also guarantee that the previous
+                __syncthreads();  // tile is fully consumed before it is overwritten
+            }
+            first = false;
+            // ---- clear the bitmap, stage the sample slice and its two sentinels
+            {
+                uint4* bm4 = reinterpret_cast<uint4*>(BM);
+                for (u32 k = tid; k < TILE_BM_WORDS / 4; k += TILE_THREADS) bm4[k] = make_uint4(0, 0, 0, 0);
+            }
+            for (u32 k = tid; k < n; k += TILE_THREADS) S[k] = sample[sub + k];
+            if (tid < 2) S[n + tid] = ~0ull;
+            __syncthreads();
+            // ---- bitmap bits and bucket directory (buckets are monotone in the hash inside one
+            // partition, so the slots of a bucket are contiguous)
+            for (u32 k = tid; k < n; k += TILE_THREADS) {
+                const u64 hk = S[k];
+                const u32 bi = bm_index(hk);
+                atomicOr(&BM[bi >> 5], 1u << (bi & 31u));
+                const u32 b = (u32)(hk >> bsh) & (TILE_NB - 1);
+                const int bp = (k == 0) ? -1 : (int)((u32)(S[k - 1] >> bsh) & (TILE_NB - 1));
+                for (int x = bp + 1; x <= (int)b; ++x) E[x] = (u16)k;
+                if (k == n - 1)
+                    for (u32 x = b + 1; x < (u32)TILE_NB; ++x) E[x] = (u16)n;
+            }
+            __syncthreads();
+            if (bsh >= 32) tile_stream<true>(vals, start, end, e0, p, n, bsh, S, E, BM, hit, ctx);
+            else tile_stream<false>(vals, start, end, e0, p, n, bsh, S, E, BM, hit, ctx);
+        }
+    }
+    flush();
+    if constexpr (Hit::kQueued) {
+        if (tid == 0) qcount[lid] = min(g_fill, hit.qcap);
     }
 }
 
@@ -356,16 +529,19 @@ inline u32 grid_for(u64 work_items, u32 block, u32 max_blocks = 16384) {
     return (u32)g;
 }
 
-// chunks per partition so the grid is ~16 workgroups per CU (8 rounds of 2 resident per CU)
-inline u32 choose_chunks(u32 P, u64 elems) {
-    const u32 target_wgs = 256 * 16;
-    u32 c = (target_wgs + P - 1) / P;
-    // never cut chunks below ~16 KiB of hashes per workgroup per tile load
-    const u64 per_part = P ? elems / P : 0;
-    const u64 max_c = std::max<u64>(1, per_part / 2048);
-    if (c > max_c) c = (u32)max_c;
-    if (c < 1) c = 1;
-    return c;
+// Workgroups for the tile kernel: YH_TILE_WGS (default 8 per CU on a 256-CU part, two of them
+// resident at a time: four rounds even out the tail), never so many that a workgroup gets less
+// than 256 KiB of stream per tile it has to stage.
+inline u32 tile_grid(u64 stream_len) {
+    static int wgs_env = -1;
+    if (wgs_env < 0) {
+        const char* e = getenv("YH_TILE_WGS");
+        wgs_env = (e && atoi(e) > 0) ? atoi(e) : 2048;
+    }
+    u64 g = (u64)wgs_env;
+    const u64 max_g = std::max<u64>(1, stream_len / 32768);  // a tile set-up must pay for itself
+    if (g > max_g) g = max_g;
+    return (u32)g;
 }
 
 }  // namespace
@@ -385,12 +561,38 @@ int yh_q_overlap(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap) {
     if (N == 0 || db->n_hashes == 0 || n_sample == 0) return YH_OK;
     const u32 P = db->n_parts;
     k_sample_bounds<<<(P + 1 + 255) / 256, 256, 0, st>>>(d_sample, (u32)n_sample, P, db->pshift, db->d_sbounds);
-    const u32 chunks = choose_chunks(P, db->n_hashes);
-    OverlapHit hit{db->d_poffs, (u32)N, d_overlap};
+    // hit queue: one segment per workgroup, 1/16 of its stream slice (at least 4096 entries)
+    const u32 wgs = tile_grid(db->pvals_len);
+    const u64 per_wg = (db->pvals_len + wgs - 1) / wgs;
+    const u64 qcap64 = std::min<u64>(std::max<u64>(4096, per_wg / 16), 1u << 24);
+    const u32 qcap = (u32)qcap64;
+    if (db->hitq_wgs < wgs || db->hitq_cap < qcap) {
+        YH_HIP(hipStreamSynchronize(st));
+        if (db->d_hitq) { (void)hipFree(db->d_hitq); db->d_hitq = nullptr; }
+        if (db->d_hitq_cnt) { (void)hipFree(db->d_hitq_cnt); db->d_hitq_cnt = nullptr; }
+        db->hitq_wgs = db->hitq_cap = 0;
+        YH_HIP(hipMalloc((void**)&db->d_hitq, (u64)wgs * qcap * sizeof(u64)));
+        YH_HIP(hipMalloc((void**)&db->d_hitq_cnt, (u64)wgs * sizeof(u32)));
+        db->hitq_wgs = wgs;
+        db->hitq_cap = qcap;
+    }
+    // replicated counters: R * N * 4 bytes, at most ~8 MiB
+    u32 R = 32;
+    while (R > 1 && (u64)R * N > (2u << 20)) R >>= 1;
+    if (db->reps_cap < (u64)R * N) {
+        YH_HIP(hipStreamSynchronize(st));
+        if (db->d_reps) { (void)hipFree(db->d_reps); db->d_reps = nullptr; db->reps_cap = 0; }
+        YH_HIP(hipMalloc((void**)&db->d_reps, (u64)R * N * sizeof(u32)));
+        db->reps_cap = (u64)R * N;
+    }
+    YH_HIP(hipMemsetAsync(db->d_reps, 0, (u64)R * N * sizeof(u32), st));
+    OverlapHit hit{db->d_poffs, (u32)N, db->d_reps, R - 1, db->d_hitq, db->hitq_cap};
     yh_ring_record_begin(db, db->ev_overlap);
-    k_tile_lookup<OverlapHit><<<P * chunks, TILE_THREADS, 0, st>>>(db->d_pvals, db->d_pbeg, db->d_pcnt, d_sample,
-                                                                   db->d_sbounds, chunks, db->pshift, hit);
+    k_tile_lookup<OverlapHit><<<wgs, TILE_THREADS, 0, st>>>(db->d_pvals, db->d_pbeg, db->d_pcnt, P, db->pvals_len,
+                                                            d_sample, db->d_sbounds, db->pshift, db->d_hitq_cnt, hit);
     yh_ring_record_end(db, db->ev_overlap);
+    k_resolve_hits<<<wgs, 256, 0, st>>>(db->d_hitq_cnt, hit);
+    k_reduce_replicas<<<(u32)((N + 255) / 256), 256, 0, st>>>(db->d_reps, R, N, d_overlap);
     YH_HIP(hipGetLastError());
     return YH_OK;
 }
@@ -433,10 +635,9 @@ int yh_q_exclusive(yh_db* db, const u8* d_mask, const u64* d_sample, u64 n_sampl
             // membership of every shared hash in the sample: the same tile kernel over d_g.
             // d_sbounds still holds this sample's slice bounds (written by yh_q_overlap).
             const u32 P = db->n_parts;
-            const u32 chunks = choose_chunks(P, G);
             FlagHit fh{db->d_gbeg, db->d_hit};
-            k_tile_lookup<FlagHit><<<P * chunks, TILE_THREADS, 0, st>>>(db->d_g, db->d_gbeg, db->d_gcnt, d_sample,
-                                                                        db->d_sbounds, chunks, db->pshift, fh);
+            k_tile_lookup<FlagHit><<<tile_grid(G), TILE_THREADS, 0, st>>>(db->d_g, db->d_gbeg, db->d_gcnt, P, G, d_sample,
+                                                                          db->d_sbounds, db->pshift, nullptr, fh);
         }
         k_excl_postings<<<grid_for(G, 256, 8192), 256, 0, st>>>(G, db->d_po, db->d_pr, d_mask, db->d_hit, db->d_excl_e,
                                                                 db->d_excl_m, db->d_ovsh);
