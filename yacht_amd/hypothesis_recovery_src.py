@@ -1,0 +1,245 @@
+"""`yacht run` hot loops on the HIP engine — the counterpart of the reference's
+src/yacht/hypothesis_recovery_src.py, same function names / arguments / return shapes:
+
+  get_organisms_with_nonzero_overlap   (reference :30-113)  multisearch subprocess  -> RefDB.overlap
+  get_exclusive_hashes                 (reference :116-206) Python set loops        -> RefDB.exclusive
+  get_alt_mut_rate / single_hyp_test   (reference :209-306) same scipy arithmetic, plus a vectorised
+                                                            hyp_test_batch used by hypothesis_recovery
+  hypothesis_recovery                  (reference :309-417) same orchestration and result columns
+
+The reference re-opens every reference .sig three times per run (multisearch, then twice in
+get_exclusive_hashes); here the selected references are packed once into a RefDB (cached next to
+the training output as `yacht_hip_db.npz`) and stay resident in HBM for both steps.
+"""
+from __future__ import annotations
+
+import glob
+import os
+import shutil
+import sys
+import warnings
+import zipfile
+from multiprocessing import Pool
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import pandas as pd
+from scipy.special import betaincinv
+from scipy.stats import binom
+
+from . import sigio
+from .engine import RefDB, pack_csr
+from .utils import decompress_all_sig_files, logger
+
+warnings.filterwarnings("ignore")
+
+SIG_SUFFIX = ".sig"
+DB_CACHE_NAME = "yacht_hip_db.npz"
+
+GIVEN_COLUMNS = [
+    "in_sample_est",
+    "p_vals",
+    "num_exclusive_kmers_to_genome",
+    "num_exclusive_kmers_to_genome_coverage",
+    "num_matches",
+    "acceptance_threshold_with_coverage",
+    "actual_confidence_with_coverage",
+    "alt_confidence_mut_rate_with_coverage",
+]
+
+# one resident database per (genome dir, md5 list): get_organisms_with_nonzero_overlap builds it,
+# get_exclusive_hashes finds it again
+_DB_CACHE: Dict[Tuple[str, Tuple[str, ...]], RefDB] = {}
+
+
+def _read_mins(path: str) -> np.ndarray:
+    return sigio.read_mins_first_signature(path)
+
+
+def load_reference_csr(md5sums: List[str], path_to_genome_temp_dir: str, ksize: int, num_threads: int = 1):
+    """(values, offsets) of `{dir}/signatures/{md5}.sig` for every md5, in order.  A packed copy
+    is kept in `{dir}/yacht_hip_db.npz` and reused while the md5 list matches."""
+    cache = os.path.join(path_to_genome_temp_dir, DB_CACHE_NAME)
+    if os.path.exists(cache):
+        try:
+            with np.load(cache, allow_pickle=False) as z:
+                if int(z["ksize"]) == int(ksize) and list(z["md5sums"]) == list(md5sums):
+                    return z["values"], z["offsets"]
+        except Exception:
+            pass
+    paths = [os.path.join(path_to_genome_temp_dir, "signatures", m + SIG_SUFFIX) for m in md5sums]
+    if num_threads > 1 and len(paths) > 256:
+        with Pool(min(num_threads, os.cpu_count() or 1)) as p:
+            sketches = p.map(_read_mins, paths, chunksize=64)
+    else:
+        sketches = [_read_mins(p) for p in paths]
+    sketches = [s if (s.size < 2 or bool(np.all(s[1:] > s[:-1]))) else np.unique(s) for s in sketches]
+    values, offsets = pack_csr(sketches)
+    try:
+        np.savez(cache, values=values, offsets=offsets, md5sums=np.array(md5sums, dtype="U32"), ksize=np.int64(ksize))
+    except OSError:
+        pass  # read-only training directory: just do not cache
+    return values, offsets
+
+
+def get_reference_db(manifest: pd.DataFrame, path_to_genome_temp_dir: str, ksize: int, num_threads: int = 1,
+                     device: int = 0) -> RefDB:
+    md5s = tuple(manifest["md5sum"].to_list())
+    key = (os.path.abspath(path_to_genome_temp_dir), md5s)
+    db = _DB_CACHE.get(key)
+    if db is None:
+        values, offsets = load_reference_csr(list(md5s), path_to_genome_temp_dir, ksize, num_threads)
+        db = RefDB(values, offsets, device=device)
+        _DB_CACHE.clear()  # one database resident at a time
+        _DB_CACHE[key] = db
+    return db
+
+
+def release_reference_dbs() -> None:
+    for db in _DB_CACHE.values():
+        db.close()
+    _DB_CACHE.clear()
+
+
+def _sample_mins(sample_sig) -> np.ndarray:
+    mh = sample_sig.minhash
+    mins = getattr(mh, "mins", None)
+    if mins is None:  # duck-typed signature (e.g. a sourmash object): hashes is a mapping
+        mins = np.fromiter((int(h) for h in mh.hashes), dtype=np.uint64)
+        mins.sort()
+    return np.asarray(mins, dtype=np.uint64)
+
+
+def get_organisms_with_nonzero_overlap(manifest: pd.DataFrame, sample_file: str, scale: int, ksize: int,
+                                       num_threads: int, path_to_genome_temp_dir: str,
+                                       path_to_sample_temp_dir: str) -> List[str]:
+    """Names of the manifest's organisms that share at least one hash with the sample
+    (reference :30-113; there: `sourmash scripts multisearch ... -t 0`, `match_name` column)."""
+    logger.info("Unzipping the sample signature zip file")
+    with zipfile.ZipFile(sample_file, "r") as z:
+        z.extractall(path_to_sample_temp_dir)
+    gz = glob.glob(f"{path_to_sample_temp_dir}/signatures/*.sig.gz")
+    logger.info(f"Decompressing {len(gz)} .sig.gz files using {num_threads} threads.")
+    decompress_all_sig_files(gz, num_threads)
+
+    # the same two list files the reference hands to multisearch (kept for tooling that reads them)
+    sample_sigs = [os.path.join(path_to_sample_temp_dir, "signatures", f)
+                   for f in os.listdir(os.path.join(path_to_sample_temp_dir, "signatures"))]
+    pd.DataFrame(sample_sigs).to_csv(os.path.join(path_to_sample_temp_dir, "sample_sig_file.txt"), header=False,
+                                     index=False)
+    organism_sigs = [os.path.join(path_to_genome_temp_dir, "signatures", m + SIG_SUFFIX) for m in manifest["md5sum"]]
+    pd.DataFrame(organism_sigs).to_csv(os.path.join(path_to_sample_temp_dir, "organism_sig_file.txt"), header=False,
+                                       index=False)
+
+    sigs = []
+    for path in sample_sigs:
+        sigs += sigio.load_file_as_signatures(path, ksize=ksize)
+    result_csv = os.path.join(path_to_sample_temp_dir, "sample_multisearch_result.csv")
+    rows = []
+    if sigs and len(manifest):
+        db = get_reference_db(manifest, path_to_genome_temp_dir, ksize, num_threads)
+        names = manifest["organism_name"].to_list()
+        md5s = manifest["md5sum"].to_list()
+        sizes = db.sizes
+        for q in sigs:
+            overlap = db.overlap(q.minhash.mins)
+            nq = len(q.minhash)
+            for j in np.flatnonzero(overlap):
+                ov = int(overlap[j])
+                rows.append((q.name, q.md5sum(), names[j], md5s[j], ov / nq if nq else 0.0,
+                             max(ov / nq if nq else 0.0, ov / int(sizes[j])), ov / (nq + int(sizes[j]) - ov), ov))
+    if not rows:
+        open(result_csv, "w").close()
+        print("ERROR: Multisearch file is empty. Likely there are no microorganisms in your sample, or something went wrong",
+              flush=True)
+        sys.exit(0)
+    res = pd.DataFrame(rows, columns=["query_name", "query_md5", "match_name", "match_md5", "containment",
+                                      "max_containment", "jaccard", "intersect_hashes"])
+    res.to_csv(result_csv, index=False)
+    return res.drop_duplicates().reset_index(drop=True)["match_name"].to_list()
+
+
+def get_exclusive_hashes(manifest: pd.DataFrame, nontrivial_organism_names: List[str], sample_sig, ksize: int,
+                         path_to_genome_temp_dir: str) -> Tuple[List[Tuple[int, int]], pd.DataFrame]:
+    """For the manifest rows whose organism_name is listed: (#hashes no other listed row has,
+    #of those present in the sample), and the sub-manifest (reference :116-206)."""
+    selected = manifest["organism_name"].isin(nontrivial_organism_names).to_numpy()
+    sub_manifest = manifest.loc[selected, :].reset_index(drop=True)
+    if not selected.any():
+        return [], sub_manifest
+    db = get_reference_db(manifest, path_to_genome_temp_dir, ksize)
+    n_excl, n_match = db.exclusive(selected, _sample_mins(sample_sig))
+    rows = np.flatnonzero(selected)
+    return [(int(n_excl[j]), int(n_match[j])) for j in rows], sub_manifest
+
+
+def get_alt_mut_rate(nu: int, thresh: int, ksize: int, significance: float = 0.99) -> float:
+    """Mutation rate at which the false-positive rate would equal `significance`
+    (reference :209-230): inverse regularized incomplete beta, NaN -> -1."""
+    mut = 1 - (1 - betaincinv(nu - thresh, 1 + thresh, significance)) ** (1 / ksize)
+    return -1.0 if np.isnan(mut) else mut
+
+
+def hyp_test_batch(n_excl, n_match, ksize: int, significance: float = 0.99, ani_thresh: float = 0.95,
+                   min_coverage: float = 1):
+    """single_hyp_test over arrays: one scipy call per quantity instead of one process-pool task
+    per organism (reference :393-408).  Returns the eight result columns as arrays."""
+    e = np.asarray(n_excl, dtype=np.int64)
+    m = np.asarray(n_match, dtype=np.int64)
+    p = ani_thresh ** ksize
+    n_cov = np.array([int(x * min_coverage) for x in e.tolist()], dtype=np.int64)  # int(): truncation, as the reference
+    thr = binom.ppf(1 - significance, n_cov, p)
+    conf = 1 - binom.cdf(thr, n_cov, p)
+    with np.errstate(all="ignore"):
+        alt = 1 - (1 - betaincinv(n_cov - thr, 1 + thr, significance)) ** (1 / ksize)
+    alt = np.where(np.isnan(alt), -1.0, alt)
+    p_val = np.where(m <= n_cov, binom.cdf(m, n_cov, p), 1.0)
+    present = (m >= thr) & (m != 0)
+    return present, p_val, e, n_cov, m, thr, conf, alt
+
+
+def single_hyp_test(exclusive_hashes_info_org: Tuple[int, int], ksize: int, significance: float = 0.99,
+                    ani_thresh: float = 0.95, min_coverage: int = 1):
+    """Binomial presence test for one organism (reference :233-306); returns the same 8-tuple:
+    (in_sample_est, p_val, n_exclusive, n_exclusive_at_coverage, n_matches, threshold, confidence,
+    alt_mut_rate)."""
+    n_excl, n_match = exclusive_hashes_info_org
+    p = ani_thresh ** ksize
+    n_cov = int(n_excl * min_coverage)
+    thr = binom.ppf(1 - significance, n_cov, p)
+    conf = 1 - binom.cdf(thr, n_cov, p)
+    alt = get_alt_mut_rate(n_cov, thr, ksize, significance=significance)
+    p_val = binom.cdf(n_match, n_cov, p) if n_match <= n_cov else 1.0
+    present = (n_match >= thr) and (n_match != 0)
+    return present, p_val, n_excl, n_cov, n_match, thr, conf, alt
+
+
+def hypothesis_recovery(manifest: pd.DataFrame, sample_info_set, path_to_genome_temp_dir: str,
+                        min_coverage_list: List[float], scale: int, ksize: int, significance: float = 0.99,
+                        ani_thresh: float = 0.95, num_threads: int = 16):
+    """One DataFrame per min_coverage: the sub-manifest of overlapping organisms joined with the
+    eight hypothesis-test columns (reference :309-417)."""
+    sample_file, sample_sig = sample_info_set
+    sample_dir = os.path.dirname(sample_file)
+    sample_name = os.path.basename(sample_file).replace(".sig.zip", "")
+    path_to_sample_temp_dir = os.path.join(sample_dir, f"sample_{sample_name}_intermediate_files")
+    if os.path.exists(path_to_sample_temp_dir):
+        logger.info(f"Removing existing temporary directory: {path_to_sample_temp_dir}")
+        shutil.rmtree(path_to_sample_temp_dir)
+    os.makedirs(path_to_sample_temp_dir)
+
+    names = get_organisms_with_nonzero_overlap(manifest, sample_file, scale, ksize, num_threads,
+                                               path_to_genome_temp_dir, path_to_sample_temp_dir)
+    info, manifest = get_exclusive_hashes(manifest, names, sample_sig, ksize, path_to_genome_temp_dir)
+    n_excl = np.array([x[0] for x in info], dtype=np.int64)
+    n_match = np.array([x[1] for x in info], dtype=np.int64)
+
+    out = []
+    for min_coverage in min_coverage_list:
+        logger.info(f"Computing hypothesis recovery for min_coverage={min_coverage}")
+        cols = hyp_test_batch(n_excl, n_match, ksize, significance, ani_thresh, min_coverage)
+        results = pd.DataFrame({name: col for name, col in zip(GIVEN_COLUMNS, cols)}, columns=GIVEN_COLUMNS)
+        results["in_sample_est"] = results["in_sample_est"].astype(bool)
+        manifest["min_coverage"] = min_coverage
+        out.append(pd.concat([manifest, results], axis=1))
+    return out

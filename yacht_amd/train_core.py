@@ -1,0 +1,111 @@
+"""In-process `run_yacht_train_core`: the reference executable's contract (src/cpp/main.cpp) with
+the comparison done by the HIP engine.
+
+    run(file_list, working_directory, output_filename, threads, passes, containment_threshold)
+
+reads the same inputs (a text file with one sketch path per line, each sketch a sourmash JSON
+whose FIRST signature's "mins" are used, main.cpp:74-78,127-139) and leaves the same outputs:
+
+  * `<output_filename>`: the selected sketch paths, one per line, in the greedy walk's order
+    (main.cpp:409-418);
+  * `<working_directory>/<pass>_<thread id, 3 digits>.txt`: lines `i,j,jaccard,C(i in j),C(j in i)`
+    for every kept ordered pair, rows split over passes and threads exactly as main.cpp:318-349
+    splits them, numbers printed as C++ iostream prints doubles (6 significant digits).
+
+Nothing here computes intersections on the CPU: counts come from RefDB.pairwise and the selection
+from the library's yh_train_select.
+"""
+from __future__ import annotations
+
+import math
+import os
+from multiprocessing import Pool
+from typing import List, Sequence, Tuple
+
+import numpy as np
+
+from . import sigio
+from .engine import RefDB, pack_csr, train_select
+
+
+def format_pair_line(i: int, j: int, count: int, size_i: int, size_j: int) -> str:
+    """One comparison line (main.cpp:296-305); %g is iostream's default double formatting."""
+    jaccard = 1.0 * count / (size_i + size_j - count)
+    c_ij = 1.0 * count / size_i
+    c_ji = 1.0 * count / size_j
+    return "%d,%d,%g,%g,%g" % (i, j, jaccard, c_ij, c_ji)
+
+
+def row_ranges(n: int, threads: int, passes: int) -> List[Tuple[int, int, int, int]]:
+    """(pass, thread, row_begin, row_end) in the reference's split (main.cpp:318-349)."""
+    out = []
+    per_pass = math.ceil(1.0 * n / passes) if passes else n
+    for p in range(passes):
+        start = p * per_pass
+        end = n if p == passes - 1 else (p + 1) * per_pass
+        rows = end - start
+        chunk = rows // threads if rows > 0 else 0
+        for t in range(threads):
+            a = start + t * chunk
+            b = end if t == threads - 1 else start + (t + 1) * chunk
+            out.append((p, t, a, b))
+    return out
+
+
+def read_sketch_list(file_list: str) -> List[str]:
+    with open(file_list) as f:
+        return [line.rstrip("\n") for line in f]
+
+
+def _read_one(path: str) -> np.ndarray:
+    mins = sigio.read_mins_first_signature(path)
+    if mins.size > 1 and not bool(np.all(mins[1:] > mins[:-1])):
+        mins = np.unique(mins)  # sourmash writes ascending, unique mins; tolerate other writers
+    return mins
+
+
+def read_sketches(paths: Sequence[str], threads: int = 1) -> List[np.ndarray]:
+    if threads > 1 and len(paths) > 256:
+        with Pool(min(threads, os.cpu_count() or 1)) as p:
+            return p.map(_read_one, paths, chunksize=64)
+    return [_read_one(p) for p in paths]
+
+
+def run(file_list: str, working_directory: str, output_filename: str, threads: int = 1, passes: int = 1,
+        containment_threshold: float = 0.9, device: int = 0, verbose: bool = False) -> dict:
+    if threads < 1:
+        raise ValueError("number of threads must be at least 1")
+    if passes < 1:
+        raise ValueError("number of passes must be at least 1")
+    if containment_threshold < 0.0 or containment_threshold > 1.0:
+        raise ValueError("containment threshold must be between 0.0 and 1.0")
+    paths = read_sketch_list(file_list)
+    sketches = read_sketches(paths, threads)
+    n = len(sketches)
+    empty = [i for i, s in enumerate(sketches) if s.size == 0]
+    values, offsets = pack_csr(sketches)
+    sizes = np.diff(offsets).astype(np.uint32)
+    with RefDB(values, offsets, device=device) as db:
+        stats = db.index_stats()
+        pi, pj, pc = db.pairwise(float(containment_threshold))
+    if verbose:
+        print(f"Total number of sketches to read: {n}")
+        print(f"Number of empty sketches: {len(empty)}")
+        print(f"Total number of distinct hashes: {stats[0]}")
+        print(f"Total number of distinct hashes that appear in only one sketch: {stats[1]}")
+        print(f"Size of the index: {stats[2]}")
+
+    # comparison files, split like the reference's (pass, thread) row blocks
+    starts = np.searchsorted(pi, np.arange(n + 1), side="left")
+    for (p, t, a, b) in row_ranges(n, threads, passes):
+        with open(os.path.join(working_directory, f"{p}_{t:03d}.txt"), "w") as f:
+            lo, hi = (int(starts[a]), int(starts[b])) if b > a else (0, 0)
+            for k in range(lo, hi):
+                i, j = int(pi[k]), int(pj[k])
+                f.write(format_pair_line(i, j, int(pc[k]), int(sizes[i]), int(sizes[j])) + "\n")
+
+    selected = train_select(sizes, pi, pj)
+    with open(output_filename, "w") as f:
+        for g in selected:
+            f.write(paths[int(g)] + "\n")
+    return {"n": n, "empty": empty, "stats": stats, "n_pairs": int(pi.size), "selected": selected.tolist()}

@@ -1,0 +1,142 @@
+"""Host-side helpers of the hot path — the counterpart of the reference's src/yacht/utils.py
+(:31-221) with the same function names, arguments, return shapes and error behaviour, so that
+callers (and tests) written against the reference read the same here.
+
+What differs is underneath: signatures are read by yacht_amd.sigio (no sourmash), and
+run_yacht_train_core calls the HIP engine through the C ABI instead of shelling out to the
+`run_yacht_train_core` executable (reference utils.py:143-147).
+"""
+from __future__ import annotations
+
+import gzip
+import logging
+import os
+import shutil
+import sys
+from glob import glob
+from multiprocessing import Pool
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import pandas as pd
+
+from . import sigio, train_core
+
+logger = logging.getLogger("yacht_amd")
+if not logger.handlers:
+    _h = logging.StreamHandler(sys.stdout)
+    _h.setFormatter(logging.Formatter("%(asctime)s - %(levelname)s - %(message)s", "%Y-%m-%d %H:%M:%S"))
+    logger.addHandler(_h)
+    logger.setLevel(logging.INFO)
+    logger.propagate = False
+
+COL_NOT_FOUND_ERROR = "Column not found: {}"
+FILE_LOCATION = os.path.dirname(os.path.realpath(__file__))
+__version__ = "1.4.0"  # the reference interface version mirrored here
+
+
+def load_signature_with_ksize(filename: str, ksize: int) -> sigio.Signature:
+    """Exactly one non-empty signature of the given k-mer size, else ValueError
+    (reference utils.py:31-51, same messages)."""
+    sketches = sigio.load_file_as_signatures(filename, ksize=ksize)
+    if len(sketches) != 1:
+        raise ValueError(f"Expected exactly one signature with ksize {ksize} in {filename}, found {len(sketches)}")
+    if len(sketches[0].minhash) == 0:
+        raise ValueError(
+            "Empty sketch in signature. This may be due to too high of a scale factor, please reduce it, eg. --scaled=1, and try again."
+        )
+    return sketches[0]
+
+
+def get_num_kmers(minhash_mean_abundance: Optional[float], minhash_hashes_len: int, minhash_scaled: int,
+                  scale: bool = True) -> int:
+    """Estimated total k-mers: mean abundance (1 when not tracked) x sketch size [x scaled]
+    (reference utils.py:54-75)."""
+    num_kmers = minhash_mean_abundance * minhash_hashes_len if minhash_mean_abundance else minhash_hashes_len
+    if scale:
+        num_kmers *= minhash_scaled
+    return int(np.round(num_kmers))
+
+
+def check_file_existence(file_path: str, error_description: str) -> None:
+    if not os.path.exists(file_path):
+        raise ValueError(error_description)
+
+
+def get_info_from_single_sig(sig_file: str, ksize: int):
+    """(path, name, md5sum, mean abundance, sketch size, scaled) or None with a warning
+    (reference utils.py:89-110)."""
+    try:
+        sig = load_signature_with_ksize(sig_file, ksize)
+        return (sig_file, sig.name, sig.md5sum(), sig.minhash.mean_abundance, len(sig.minhash), sig.minhash.scaled)
+    except Exception:
+        logger.warning(f"CANNOT extract the relevant info from the signature file: {sig_file}")
+        return None
+
+
+def collect_signature_info(num_threads: int, ksize: int, path_to_temp_dir: str) -> Dict[str, Tuple]:
+    """name -> (md5sum, mean abundance, sketch size, scaled, path) for every file under
+    {path_to_temp_dir}/signatures, in os.listdir order (reference utils.py:201-221)."""
+    sig_dir = os.path.join(path_to_temp_dir, "signatures")
+    jobs = [(os.path.join(sig_dir, f), ksize) for f in os.listdir(sig_dir)]
+    if num_threads > 1 and len(jobs) > 64:
+        with Pool(num_threads) as p:
+            signatures = p.starmap(get_info_from_single_sig, jobs)
+    else:
+        signatures = [get_info_from_single_sig(*j) for j in jobs]
+    return {sig[1]: (sig[2], sig[3], sig[4], sig[5], sig[0]) for sig in signatures if sig}
+
+
+def _gunzip_one(path: str) -> None:
+    with gzip.open(path, "rb") as f_in, open(path[: -len(".gz")], "wb") as f_out:
+        shutil.copyfileobj(f_in, f_out)
+    os.remove(path)
+
+
+def decompress_all_sig_files(sig_files: List[str], num_threads: int) -> None:
+    """gunzip every *.sig.gz next to itself and delete the .gz (reference utils.py:499-509)."""
+    if num_threads > 1 and len(sig_files) > 64:
+        with Pool(num_threads) as p:
+            p.map(_gunzip_one, sig_files)
+    else:
+        for f in sig_files:
+            _gunzip_one(f)
+
+
+def run_yacht_train_core(num_threads: int, ani_thresh: float, ksize: int, path_to_temp_dir: str,
+                         sig_info_dict: Dict[str, Tuple], num_genome_threshold: int = 1000000,
+                         device: int = 0) -> pd.DataFrame:
+    """Find the references related above `ani_thresh` and keep one per neighbourhood
+    (reference utils.py:112-197).  Same files are left behind: training_sig_files.tsv,
+    selected_result.tsv, comparison_files/<pass>_<thread>.txt; same manifest columns returned."""
+    sig_dir = os.path.join(path_to_temp_dir, "signatures")
+    sig_files = [os.path.join(sig_dir, f) for f in os.listdir(sig_dir)]
+    sig_files_path = os.path.join(path_to_temp_dir, "training_sig_files.tsv")
+    pd.DataFrame(sig_files).to_csv(sig_files_path, header=False, index=False)
+
+    containment_thresh = ani_thresh ** ksize
+    total = len(sig_files)
+    passes = 1 if total <= num_genome_threshold else int(total / num_genome_threshold) + 1
+    selected_path = os.path.join(path_to_temp_dir, "selected_result.tsv")
+    logger.info(f"Running comparison on device {device}: -t {num_threads} -c {containment_thresh} -p {passes} "
+                f"{sig_files_path} {path_to_temp_dir} {selected_path}")
+    try:
+        train_core.run(sig_files_path, path_to_temp_dir, selected_path, threads=num_threads, passes=passes,
+                       containment_threshold=containment_thresh, device=device)
+    except Exception as exc:  # the reference raises ValueError on a non-zero exit code
+        raise ValueError(f"Error running comparison algorithm: {exc}") from exc
+
+    os.makedirs(os.path.join(path_to_temp_dir, "comparison_files"), exist_ok=True)
+    for file in glob(os.path.join(path_to_temp_dir, "*.txt")):
+        shutil.move(file, os.path.join(path_to_temp_dir, "comparison_files"))
+
+    selected_sig_files = pd.read_csv(selected_path, sep="\t", header=None)[0].to_list()
+    path_to_name = {sig_info_dict[name][-1]: name for name in sig_info_dict}
+    selected_names = set(path_to_name[p] for p in selected_sig_files)
+
+    rows = []
+    for name, (md5sum, mean_abund, n_hashes, scaled, _path) in sig_info_dict.items():
+        if name in selected_names:
+            rows.append((name, md5sum, n_hashes, get_num_kmers(mean_abund, n_hashes, scaled, False), scaled))
+    return pd.DataFrame(rows, columns=["organism_name", "md5sum", "num_unique_kmers_in_genome_sketch",
+                                       "num_total_kmers_in_genome_sketch", "genome_scale_factor"])
