@@ -227,6 +227,8 @@ def main() -> int:
                 "partitions": info["n_partitions"],
                 "max_sample_slice": max_slice,
                 "shared_hashes": info["n_shared_distinct"],
+                "db_build_ms": round(float(timing["ms_db_build"]), 2),
+                "db_hbm_bytes": info["device_bytes"],
                 "step": "overlap" if args.overlap_only else "overlap + exclusive counts" + (" + all_gather" if world > 1 else ""),
                 "parallelism": f"refs sharded x{world}",
             },
