@@ -49,6 +49,8 @@ def parse_args():
     ap.add_argument("--overlap-only", action="store_true", help="time R1 only (diagnostic; not the reported metric)")
     ap.add_argument("--seed", type=int, default=1002)
     ap.add_argument("--present", type=int, default=200, help="genomes present in the sample (diagnostic)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to test the N>1 logic)")
+    ap.add_argument("--share-gpu", action="store_true", help="testing: all ranks use cuda:0 (1-GPU box, gloo backend)")
     return ap.parse_args()
 
 
@@ -68,11 +70,16 @@ def main() -> int:
     if not torch.cuda.is_available():
         print("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)", file=sys.stderr)
         return 2
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     from yacht_amd import build, synth
     from yacht_amd.engine import RefDB
@@ -105,22 +112,28 @@ def main() -> int:
 
     db = RefDB.from_device(values.data_ptr(), offsets.data_ptr(), n_refs, device=local_rank)
     info = db.info()
-    stream = torch.cuda.current_stream()
+    # Everything of the timed region runs on ONE explicit stream: the library's kernels are queued
+    # on it (a null handle — torch's default stream — would mean "the library's own stream"), and
+    # RCCL orders the all-gather after whatever is on torch's current stream.
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
     db.set_stream(stream.cuda_stream)
+    assert stream.cuda_stream != 0
     # largest per-partition slice of the sample (one LDS tile holds 4094 hashes; larger slices
     # make the kernel re-stream that partition once per extra tile)
     part_of = (sample >> info["partition_shift"]) if info["partition_shift"] < 63 else torch.zeros_like(sample)
     max_slice = int(torch.bincount(part_of.clamp_(0, info["n_partitions"])).max().item()) if n_sample else 0
 
     counts = torch.zeros((3, n_refs), device=dev, dtype=torch.int32)  # overlap, n_excl, n_match (uint32 bits)
-    gathered = torch.zeros((world, 3, n_refs), device=dev, dtype=torch.int32) if world > 1 else None
+    gathered = torch.zeros((world * 3, n_refs), device=dev, dtype=torch.int32) if world > 1 else None  # concatenation layout
     p_sample, p_ov = sample.data_ptr(), counts[0].data_ptr()
     p_e, p_m = (0, 0) if args.overlap_only else (counts[1].data_ptr(), counts[2].data_ptr())
 
     def step():
-        db.run_device(p_sample, n_sample, p_ov, p_e, p_m)
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, counts)
+        with torch.cuda.stream(stream):
+            db.run_device(p_sample, n_sample, p_ov, p_e, p_m)
+            if world > 1:
+                dist.all_gather_into_tensor(gathered, counts)
 
     def fence():
         torch.cuda.synchronize()
@@ -142,6 +155,8 @@ def main() -> int:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     timing = db.timing()  # mean over the (up to 256) most recent launches of the timed region
+    if world > 1:  # the gathered block of this rank must be this rank's counts (stream ordering check)
+        assert bool(torch.equal(gathered.view(world, 3, n_refs)[rank], counts)), "all-gather ran ahead of the kernels"
 
     ms_per_step = 1e3 * elapsed / args.steps
     total_refs = n_refs * world
