@@ -135,6 +135,31 @@ int yh_run(yh_db* db, const uint64_t* sample, uint64_t n_sample,
 int yh_run_device(yh_db* db, const uint64_t* d_sample, uint64_t n_sample,
                   uint32_t* d_overlap, uint32_t* d_n_excl, uint32_t* d_n_match);
 
+/* ---- references spread over several GPUs: exact exclusive counts --------------------------------
+ * Each rank holds (a) a handle over its shard of the REFERENCES for the overlap kernel and (b) a
+ * posting-list handle over its range of the HASH space, built from the (hash, global reference
+ * id) pairs every rank sent it (yacht_amd/dist.py does the exchange with torch.distributed).
+ *   yh_db_create_from_pairs       (b): pairs already in HBM; partition_shift/max_hash as reported
+ *                                 by the reference shards' yh_db_get_info (use the global maximum)
+ *   yh_exclusive_partial_device   partial sums over this handle's posting lists for a mask over
+ *                                 ALL references: ex_e (hashes with exactly one masked holder),
+ *                                 ex_m (those also in the sample), ovsh (sample hashes among the
+ *                                 database-shared hashes, per masked holder); summed over ranks
+ *   yh_db_nshared_device          per-reference count of hashes of this handle's range that
+ *                                 another reference also holds; summed over ranks
+ *   yh_exclusive_finalize_device  n_excl = size - nshared + ex_e, n_match = overlap - ovsh + ex_m
+ *                                 for masked references, 0 otherwise (all arrays of length n)   */
+int yh_db_create_from_pairs(const uint64_t* d_hashes, const uint32_t* d_refs, uint64_t n_pairs,
+                            uint64_t n_refs_total, int device_id, uint32_t partition_shift, uint64_t max_hash,
+                            yh_db** out);
+int yh_exclusive_partial_device(yh_db* db, const uint8_t* d_mask, const uint64_t* d_sample, uint64_t n_sample,
+                                uint32_t* d_ex_e, uint32_t* d_ex_m, uint32_t* d_ovsh);
+int yh_db_nshared_device(yh_db* db, uint32_t* d_out);
+int yh_exclusive_finalize_device(yh_db* db, uint64_t n, const uint8_t* d_mask, const uint32_t* d_sizes,
+                                 const uint32_t* d_nshared, const uint32_t* d_overlap, const uint32_t* d_ex_e,
+                                 const uint32_t* d_ex_m, const uint32_t* d_ovsh, uint32_t* d_n_excl,
+                                 uint32_t* d_n_match);
+
 /* ---- yacht train: pairwise intersections ---------------------------------------------------
  * Emits every ORDERED pair (i, j), i != j, row_begin <= i < row_end, both sketches non-empty,
  * count = |R_i ∩ R_j| > 0 and !(1.0*count/|R_i| < c_thresh), sorted by (i, j).

@@ -91,6 +91,11 @@ SIGNATURES = {
     "yh_exclusive": (C.c_int, [_vp, _vp, _vp, C.c_uint64, _vp, _vp]),
     "yh_run": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp, _vp]),
     "yh_run_device": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp, _vp]),
+    "yh_db_create_from_pairs": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64, C.c_int, C.c_uint32, C.c_uint64,
+                                          C.POINTER(_vp)]),
+    "yh_exclusive_partial_device": (C.c_int, [_vp, _vp, _vp, C.c_uint64, _vp, _vp, _vp]),
+    "yh_db_nshared_device": (C.c_int, [_vp, _vp]),
+    "yh_exclusive_finalize_device": (C.c_int, [_vp, C.c_uint64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "yh_pairwise": (C.c_int, [_vp, C.c_double, C.c_uint64, C.c_uint64, C.c_uint64, _vp, _vp, _vp,
                               C.POINTER(C.c_uint64)]),
     "yh_index_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),

@@ -174,7 +174,7 @@ static int db_create_common(const u64* values, const u64* offsets, bool on_devic
         rc = yh_build_partitions(db, d_values_in, d_offsets_in, partitions_hint);
         if (rc != YH_OK) break;
         if (!(flags & YH_DB_NO_INDEX)) {
-            rc = yh_build_index(db, d_values_in, d_offsets_in);
+            rc = yh_build_index(db, d_values_in, d_offsets_in, nullptr);
             if (rc != YH_OK) break;
         }
         (void)hipEventRecord(ev1, db->stream);
@@ -231,6 +231,80 @@ int yh_db_create_device(const uint64_t* d_values, const uint64_t* d_offsets, uin
                         uint32_t flags, uint32_t partitions_hint, yh_db** out) {
     return db_create_common((const u64*)d_values, (const u64*)d_offsets, true, n_refs, device_id, flags,
                             partitions_hint, out);
+}
+
+// Posting-list-only handle from ready-made (hash, reference id) pairs that already live in HBM:
+// the hash-range shard of a database whose references are spread over several GPUs
+// (yacht_amd/dist.py).  It answers yh_exclusive_partial_device / yh_db_nshared_device only.
+int yh_db_create_from_pairs(const uint64_t* d_hashes, const uint32_t* d_refs, uint64_t n_pairs,
+                            uint64_t n_refs_total, int device_id, uint32_t partition_shift, uint64_t max_hash,
+                            yh_db** out) {
+    if (!out) { yh_set_error("out is null"); return YH_ERR_INVALID_ARG; }
+    *out = nullptr;
+    if (n_pairs && (!d_hashes || !d_refs)) { yh_set_error("null pair arrays"); return YH_ERR_INVALID_ARG; }
+    if (n_refs_total > 0xfffffff0ull || partition_shift > 63) { yh_set_error("bad size"); return YH_ERR_INVALID_ARG; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        yh_set_error("no HIP device available (libyacht_hip has no CPU fallback)");
+        return YH_ERR_NO_DEVICE;
+    }
+    if (device_id < 0 || device_id >= ndev) { yh_set_error("device_id %d out of range", device_id); return YH_ERR_NO_DEVICE; }
+    YH_HIP(hipSetDevice(device_id));
+    const u64 nparts = (max_hash >> partition_shift) + 1;
+    if (nparts > (1ull << 24)) { yh_set_error("partition_shift too small for max_hash"); return YH_ERR_INVALID_ARG; }
+    yh_db* db = new yh_db();
+    db->device = device_id;
+    db->flags = 0;
+    db->n_refs = n_refs_total;
+    db->n_hashes = n_pairs;
+    db->max_hash = max_hash;
+    db->pshift = partition_shift;
+    db->n_parts = (u32)nparts;
+    int rc = YH_OK;
+    do {
+        if (hipStreamCreateWithFlags(&db->own_stream, hipStreamNonBlocking) != hipSuccess) { yh_set_error("hipStreamCreate failed"); rc = YH_ERR_HIP; break; }
+        db->stream = db->own_stream;
+        if ((rc = yh_dmalloc(db, (void**)&db->d_sbounds, (u64)(db->n_parts + 1) * sizeof(u32))) != YH_OK) break;
+        if ((rc = yh_dmalloc(db, (void**)&db->d_flag, 16)) != YH_OK) break;
+        if ((rc = yh_build_index(db, (const u64*)d_hashes, nullptr, d_refs)) != YH_OK) break;
+        ring_create(db->ev_excl);
+    } while (0);
+    if (rc != YH_OK) { yh_db_destroy(db); return rc; }
+    *out = db;
+    return YH_OK;
+}
+
+int yh_exclusive_partial_device(yh_db* db, const uint8_t* d_mask, const uint64_t* d_sample, uint64_t n_sample,
+                                uint32_t* d_ex_e, uint32_t* d_ex_m, uint32_t* d_ovsh) {
+    if (!db_ok(db)) return YH_ERR_INVALID_ARG;
+    if (db->n_refs && (!d_mask || !d_ex_e || !d_ex_m || !d_ovsh)) { yh_set_error("null device pointer"); return YH_ERR_INVALID_ARG; }
+    YH_TRY(db_select(db));
+    yh_ring_record_begin(db, db->ev_excl);
+    YH_TRY(yh_q_exclusive_partial(db, d_mask, (const u64*)d_sample, n_sample, d_ex_e, d_ex_m, d_ovsh, true));
+    yh_ring_record_end(db, db->ev_excl);
+    return YH_OK;
+}
+
+int yh_db_nshared_device(yh_db* db, uint32_t* d_out) {
+    if (!db_ok(db)) return YH_ERR_INVALID_ARG;
+    if (!db->has_index) { yh_set_error("this handle was created with YH_DB_NO_INDEX"); return YH_ERR_UNSUPPORTED; }
+    YH_TRY(db_select(db));
+    if (db->n_refs)
+        YH_HIP(hipMemcpyAsync(d_out, db->d_nshared, db->n_refs * sizeof(u32), hipMemcpyDeviceToDevice, db->stream));
+    return YH_OK;
+}
+
+int yh_exclusive_finalize_device(yh_db* db, uint64_t n, const uint8_t* d_mask, const uint32_t* d_sizes,
+                                 const uint32_t* d_nshared, const uint32_t* d_overlap, const uint32_t* d_ex_e,
+                                 const uint32_t* d_ex_m, const uint32_t* d_ovsh, uint32_t* d_n_excl,
+                                 uint32_t* d_n_match) {
+    if (!db_ok(db)) return YH_ERR_INVALID_ARG;
+    if (n && (!d_mask || !d_sizes || !d_nshared || !d_overlap || !d_ex_e || !d_ex_m || !d_ovsh || !d_n_excl || !d_n_match)) {
+        yh_set_error("null device pointer");
+        return YH_ERR_INVALID_ARG;
+    }
+    YH_TRY(db_select(db));
+    return yh_q_exclusive_final(db, n, d_mask, d_sizes, d_nshared, d_overlap, d_ex_e, d_ex_m, d_ovsh, d_n_excl, d_n_match);
 }
 
 int yh_db_destroy(yh_db* db) {

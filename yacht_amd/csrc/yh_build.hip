@@ -417,7 +417,7 @@ int yh_build_partitions(yh_db* db, const u64* d_values, const u64* d_offsets, u3
 }
 
 // =================================================================================================
-int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets) {
+int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, const u32* d_pair_ids) {
     const u64 N = db->n_refs;
     const u64 H = db->n_hashes;
     hipStream_t st = db->stream;
@@ -456,21 +456,23 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets) {
             rc = (e__ == hipErrorOutOfMemory) ? YH_ERR_OOM : YH_ERR_HIP;                      \
         }                                                                                     \
     }
-    IDX_HIP(hipMalloc((void**)&d_ids, H * sizeof(u32)));
+    if (!d_pair_ids) IDX_HIP(hipMalloc((void**)&d_ids, H * sizeof(u32)));
     IDX_HIP(hipMalloc((void**)&d_sv, H * sizeof(u32)));
     IDX_HIP(hipMalloc((void**)&d_sk, H * sizeof(u64)));
     IDX_HIP(hipMalloc((void**)&d_counts, nb * 3 * sizeof(u32)));
     IDX_HIP(hipMalloc((void**)&d_bases, (nb + 1) * 3 * sizeof(u64)));
     if (rc == YH_OK) {
-        k_fill_ref_ids<<<grid_for(N * WAVE, 256), 256, 0, st>>>(d_offsets, N, d_ids);
-        // stable LSD radix sort of (hash, reference id): equal hashes keep ascending reference order
+        if (!d_pair_ids) k_fill_ref_ids<<<grid_for(N * WAVE, 256), 256, 0, st>>>(d_offsets, N, d_ids);
+        const u32* ids_src = d_pair_ids ? d_pair_ids : d_ids;
+        // stable LSD radix sort of (hash, reference id): equal hashes keep their input order
+        // (ascending reference for CSR input)
         unsigned end_bit = 1;
         while (end_bit < 64 && (db->max_hash >> end_bit) != 0) ++end_bit;
         size_t tmp_bytes = 0;
-        IDX_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, (const u64*)d_values, d_sk, (const u32*)d_ids, d_sv,
+        IDX_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, (const u64*)d_values, d_sk, ids_src, d_sv,
                                           (size_t)H, 0u, end_bit, st));
         IDX_HIP(hipMalloc(&d_tmp, std::max<size_t>(tmp_bytes, 16)));
-        IDX_HIP(rocprim::radix_sort_pairs(d_tmp, tmp_bytes, (const u64*)d_values, d_sk, (const u32*)d_ids, d_sv,
+        IDX_HIP(rocprim::radix_sort_pairs(d_tmp, tmp_bytes, (const u64*)d_values, d_sk, ids_src, d_sv,
                                           (size_t)H, 0u, end_bit, st));
     }
     u64 totals[3] = {0, 0, 0};

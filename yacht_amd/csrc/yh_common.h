@@ -162,13 +162,20 @@ struct yh_db {
 
 // ---- implemented in yh_build.hip -------------------------------------------------------------
 int yh_build_partitions(yh_db* db, const u64* d_values, const u64* d_offsets, u32 parts_hint);
-int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets);
+// d_pair_ids == nullptr: reference ids come from d_offsets (CSR); otherwise (d_values[i], d_pair_ids[i]) are
+// ready-made (hash, reference) pairs and d_offsets is unused.
+int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, const u32* d_pair_ids);
 
 // ---- implemented in yh_query.hip -------------------------------------------------------------
 int yh_q_overlap(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap);
 int yh_q_overlap_bsearch(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap);
 int yh_q_exclusive(yh_db* db, const u8* d_mask, const u64* d_sample, u64 n_sample,
                    const u32* d_overlap, u32* d_excl, u32* d_match);
+int yh_q_exclusive_partial(yh_db* db, const u8* d_mask, const u64* d_sample, u64 n_sample, u32* d_ex_e, u32* d_ex_m,
+                           u32* d_ovsh, bool own_bounds);
+int yh_q_exclusive_final(yh_db* db, u64 n, const u8* d_mask, const u32* d_sizes, const u32* d_nshared,
+                         const u32* d_overlap, const u32* d_ex_e, const u32* d_ex_m, const u32* d_ovsh, u32* d_excl,
+                         u32* d_match);
 int yh_q_mask_from_overlap(yh_db* db, const u32* d_overlap, u8* d_mask);
 int yh_q_pairwise(yh_db* db, double c_thresh, u64 r0, u64 r1);
 int yh_q_check_sorted_host(const u64* v, u64 n);

@@ -554,6 +554,7 @@ int yh_q_check_sorted_host(const u64* v, u64 n) {
 }
 
 int yh_q_overlap(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap) {
+    if (!db->d_pvals) { yh_set_error("this handle holds posting lists only (yh_db_create_from_pairs)"); return YH_ERR_UNSUPPORTED; }
     hipStream_t st = db->stream;
     const u64 N = db->n_refs;
     if (n_sample > 0xfffffff0ull) { yh_set_error("sample larger than 2^32-16 hashes"); return YH_ERR_INVALID_ARG; }
@@ -618,40 +619,67 @@ int yh_q_mask_from_overlap(yh_db* db, const u32* d_overlap, u8* d_mask) {
 }
 
 // d_overlap must hold the overlap of the SAME sample (yh_q_overlap output).
-int yh_q_exclusive(yh_db* db, const u8* d_mask, const u64* d_sample, u64 n_sample, const u32* d_overlap,
-                   u32* d_excl, u32* d_match) {
+// Partial exclusive sums of this handle's posting lists for an arbitrary mask over ITS reference
+// numbering: ex_e / ex_m / ovsh (see k_excl_postings).  `own_bounds`: compute the sample's slice
+// bounds here (a handle whose overlap kernel did not just run on the same sample).
+int yh_q_exclusive_partial(yh_db* db, const u8* d_mask, const u64* d_sample, u64 n_sample, u32* d_ex_e, u32* d_ex_m,
+                           u32* d_ovsh, bool own_bounds) {
     if (!db->has_index) { yh_set_error("this handle was created with YH_DB_NO_INDEX"); return YH_ERR_UNSUPPORTED; }
     hipStream_t st = db->stream;
     const u64 N = db->n_refs;
     if (N == 0) return YH_OK;
+    if (n_sample > 0xfffffff0ull) { yh_set_error("sample larger than 2^32-16 hashes"); return YH_ERR_INVALID_ARG; }
     const u64 G = db->n_shared;
-    YH_HIP(hipMemsetAsync(db->d_excl_e, 0, N * sizeof(u32), st));
-    YH_HIP(hipMemsetAsync(db->d_excl_m, 0, N * sizeof(u32), st));
-    YH_HIP(hipMemsetAsync(db->d_ovsh, 0, N * sizeof(u32), st));
-    yh_ring_record_begin(db, db->ev_excl);
+    YH_HIP(hipMemsetAsync(d_ex_e, 0, N * sizeof(u32), st));
+    YH_HIP(hipMemsetAsync(d_ex_m, 0, N * sizeof(u32), st));
+    YH_HIP(hipMemsetAsync(d_ovsh, 0, N * sizeof(u32), st));
     if (G) {
         YH_HIP(hipMemsetAsync(db->d_hit, 0, G, st));
         if (n_sample) {
-            // membership of every shared hash in the sample: the same tile kernel over d_g.
-            // d_sbounds still holds this sample's slice bounds (written by yh_q_overlap).
             const u32 P = db->n_parts;
+            if (own_bounds)
+                k_sample_bounds<<<(P + 1 + 255) / 256, 256, 0, st>>>(d_sample, (u32)n_sample, P, db->pshift, db->d_sbounds);
+            // membership of every shared hash in the sample: the same tile kernel over d_g
             FlagHit fh{db->d_gbeg, db->d_hit};
             k_tile_lookup<FlagHit><<<tile_grid(G), TILE_THREADS, 0, st>>>(db->d_g, db->d_gbeg, db->d_gcnt, P, G, d_sample,
                                                                           db->d_sbounds, db->pshift, nullptr, fh);
         }
-        k_excl_postings<<<grid_for(G, 256, 8192), 256, 0, st>>>(G, db->d_po, db->d_pr, d_mask, db->d_hit, db->d_excl_e,
-                                                                db->d_excl_m, db->d_ovsh);
+        k_excl_postings<<<grid_for(G, 256, 8192), 256, 0, st>>>(G, db->d_po, db->d_pr, d_mask, db->d_hit, d_ex_e, d_ex_m,
+                                                                d_ovsh);
     }
-    k_excl_final<<<grid_for(N, 256, 1u << 22), 256, 0, st>>>(N, d_mask, db->d_sizes, db->d_nshared, d_overlap,
-                                                             db->d_excl_e, db->d_excl_m, db->d_ovsh, d_excl, d_match);
-    yh_ring_record_end(db, db->ev_excl);
     YH_HIP(hipGetLastError());
+    return YH_OK;
+}
+
+int yh_q_exclusive_final(yh_db* db, u64 n, const u8* d_mask, const u32* d_sizes, const u32* d_nshared,
+                         const u32* d_overlap, const u32* d_ex_e, const u32* d_ex_m, const u32* d_ovsh, u32* d_excl,
+                         u32* d_match) {
+    if (n == 0) return YH_OK;
+    k_excl_final<<<grid_for(n, 256, 1u << 22), 256, 0, db->stream>>>(n, d_mask, d_sizes, d_nshared, d_overlap, d_ex_e,
+                                                                      d_ex_m, d_ovsh, d_excl, d_match);
+    YH_HIP(hipGetLastError());
+    return YH_OK;
+}
+
+// d_overlap must hold the overlap of the SAME sample (yh_q_overlap output on this handle, which
+// also left the sample's slice bounds in d_sbounds).
+int yh_q_exclusive(yh_db* db, const u8* d_mask, const u64* d_sample, u64 n_sample, const u32* d_overlap,
+                   u32* d_excl, u32* d_match) {
+    if (!db->has_index) { yh_set_error("this handle was created with YH_DB_NO_INDEX"); return YH_ERR_UNSUPPORTED; }
+    if (!db->d_pvals) { yh_set_error("this handle holds posting lists only"); return YH_ERR_UNSUPPORTED; }
+    if (db->n_refs == 0) return YH_OK;
+    yh_ring_record_begin(db, db->ev_excl);
+    YH_TRY(yh_q_exclusive_partial(db, d_mask, d_sample, n_sample, db->d_excl_e, db->d_excl_m, db->d_ovsh, false));
+    YH_TRY(yh_q_exclusive_final(db, db->n_refs, d_mask, db->d_sizes, db->d_nshared, d_overlap, db->d_excl_e,
+                                db->d_excl_m, db->d_ovsh, d_excl, d_match));
+    yh_ring_record_end(db, db->ev_excl);
     return YH_OK;
 }
 
 // Fills the handle's host-side pair cache (h_pw_*) for rows [r0, r1).
 int yh_q_pairwise(yh_db* db, double c_thresh, u64 r0, u64 r1) {
     if (!db->has_index) { yh_set_error("this handle was created with YH_DB_NO_INDEX"); return YH_ERR_UNSUPPORTED; }
+    if (!db->d_pvals) { yh_set_error("this handle holds posting lists only"); return YH_ERR_UNSUPPORTED; }
     hipStream_t st = db->stream;
     const u64 N = db->n_refs;
     free(db->h_pw_i); free(db->h_pw_j); free(db->h_pw_c);
