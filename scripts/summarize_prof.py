@@ -7,7 +7,7 @@ import os
 import sys
 
 root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out"
-OURS = ("k_tile_lookup", "k_resolve_hits", "k_excl", "k_sample_bounds", "k_mask_from", "k_pair", "k_overlap_bsearch",
+OURS = ("k_tile_lookup", "k_resolve_hits", "k_excl", "k_prep", "k_mask_bits", "k_reduce_replicas", "k_sample_bounds", "k_mask_from", "k_pair", "k_overlap_bsearch",
         "k_scan_u32", "k_idx", "k_split", "k_part_scan", "k_scatter", "k_scan_refs", "k_fill", "k_bounds")
 
 
@@ -41,3 +41,21 @@ for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
         print("  " + k)
         for c, vals in sorted(v.items()):
             print(f"     {c:28s} n={len(vals):3d} mean={sum(vals)/len(vals):.6g}")
+
+# ---- timeline of the last complete step (kernel trace): start offset, duration, gap to the previous kernel
+trace = glob.glob(os.path.join(root, "prof_stats", "*", "*_kernel_trace.csv"))
+if trace:
+    rows = list(csv.DictReader(open(trace[0])))
+    rows = [r for r in rows if any(t in r["Kernel_Name"] for t in OURS) or "Memset" in r["Kernel_Name"] or "fill" in r["Kernel_Name"].lower()]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    idx = [i for i, r in enumerate(rows) if "k_prep" in r["Kernel_Name"]]
+    if len(idx) >= 3:
+        a, b = idx[-2], idx[-1]
+        t0 = int(rows[a]["Start_Timestamp"])
+        prev_end = t0
+        print("== timeline of one step (us) ==")
+        for r in rows[a:b]:
+            s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+            print(f"  +{(s - t0)/1e3:8.2f}  dur {(e - s)/1e3:8.2f}  gap {(s - prev_end)/1e3:7.2f}  {short(r['Kernel_Name'])}")
+            prev_end = e
+        print(f"  step span {(int(rows[b]['Start_Timestamp']) - t0)/1e3:.2f} us")

@@ -183,9 +183,10 @@ static int db_create_common(const u64* values, const u64* offsets, bool on_devic
 
         const u64 N = n_refs;
         if ((rc = yh_dmalloc(db, (void**)&db->d_mask, std::max<u64>(N, 1))) != YH_OK) break;
-        if ((rc = yh_dmalloc(db, (void**)&db->d_excl_e, std::max<u64>(N, 1) * sizeof(u32))) != YH_OK) break;
-        if ((rc = yh_dmalloc(db, (void**)&db->d_excl_m, std::max<u64>(N, 1) * sizeof(u32))) != YH_OK) break;
-        if ((rc = yh_dmalloc(db, (void**)&db->d_ovsh, std::max<u64>(N, 1) * sizeof(u32))) != YH_OK) break;
+        if ((rc = yh_dmalloc(db, (void**)&db->d_excl_e, 3 * std::max<u64>(N, 1) * sizeof(u32) + 16)) != YH_OK) break;
+        db->d_excl_m = db->d_excl_e + N;
+        db->d_ovsh = db->d_excl_e + 2 * N;
+        if ((rc = yh_dmalloc(db, (void**)&db->d_maskbits, ((N + 255) / 256) * 32 + 16)) != YH_OK) break;  // whole 256-thread blocks write it
         if ((rc = yh_dmalloc(db, (void**)&db->d_overlap_tmp, std::max<u64>(N, 1) * sizeof(u32))) != YH_OK) break;
 
         if (flags & YH_DB_KEEP_CSR) {
@@ -266,6 +267,7 @@ int yh_db_create_from_pairs(const uint64_t* d_hashes, const uint32_t* d_refs, ui
         db->stream = db->own_stream;
         if ((rc = yh_dmalloc(db, (void**)&db->d_sbounds, (u64)(db->n_parts + 1) * sizeof(u32))) != YH_OK) break;
         if ((rc = yh_dmalloc(db, (void**)&db->d_flag, 16)) != YH_OK) break;
+        if ((rc = yh_dmalloc(db, (void**)&db->d_maskbits, ((n_refs_total + 255) / 256) * 32 + 16)) != YH_OK) break;
         if ((rc = yh_build_index(db, (const u64*)d_hashes, nullptr, d_refs)) != YH_OK) break;
         ring_create(db->ev_excl);
     } while (0);
@@ -280,7 +282,8 @@ int yh_exclusive_partial_device(yh_db* db, const uint8_t* d_mask, const uint64_t
     if (db->n_refs && (!d_mask || !d_ex_e || !d_ex_m || !d_ovsh)) { yh_set_error("null device pointer"); return YH_ERR_INVALID_ARG; }
     YH_TRY(db_select(db));
     yh_ring_record_begin(db, db->ev_excl);
-    YH_TRY(yh_q_exclusive_partial(db, d_mask, (const u64*)d_sample, n_sample, d_ex_e, d_ex_m, d_ovsh, true));
+    YH_TRY(yh_q_exclusive_partial(db, d_mask, (const u64*)d_sample, n_sample, d_ex_e, d_ex_m, d_ovsh, true, false,
+                                  nullptr));
     yh_ring_record_end(db, db->ev_excl);
     return YH_OK;
 }
@@ -312,8 +315,8 @@ int yh_db_destroy(yh_db* db) {
     if (db->device >= 0) (void)hipSetDevice(db->device);
     if (db->stream) (void)hipStreamSynchronize(db->stream);
     void* ptrs[] = {db->d_values, db->d_offsets, db->d_pvals, db->d_pbeg, db->d_pcnt, db->d_poffs, db->d_sizes,
-                    db->d_g, db->d_po, db->d_pr, db->d_pg, db->d_gbeg, db->d_gcnt, db->d_nshared, db->d_sbounds,
-                    db->d_mask, db->d_hit, db->d_excl_e, db->d_excl_m, db->d_ovsh, db->d_overlap_tmp,
+                    db->d_g, db->d_po, db->d_pr, db->d_pg, db->d_gbeg, db->d_gcnt, db->d_nshared, db->d_pq, db->d_pq_count, db->d_sbounds,
+                    db->d_mask, db->d_maskbits, db->d_hit, db->d_excl_e, db->d_overlap_tmp,
                     db->d_sample_tmp, db->d_flag, db->d_hitq, db->d_hitq_cnt, db->d_reps};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -378,7 +381,7 @@ int yh_overlap_device(yh_db* db, const uint64_t* d_sample, uint64_t n_sample, ui
     if (!db_ok(db)) return YH_ERR_INVALID_ARG;
     if (!d_overlap || (n_sample && !d_sample)) { yh_set_error("null device pointer"); return YH_ERR_INVALID_ARG; }
     YH_TRY(db_select(db));
-    return yh_q_overlap(db, (const u64*)d_sample, n_sample, d_overlap);
+    return yh_q_overlap(db, (const u64*)d_sample, n_sample, d_overlap, false, false);
 }
 
 int yh_overlap_bsearch_device(yh_db* db, const uint64_t* d_sample, uint64_t n_sample, uint32_t* d_overlap) {
@@ -406,7 +409,7 @@ static int overlap_host(yh_db* db, const uint64_t* sample, uint64_t n_sample, ui
     YH_TRY(db_select(db));
     YH_TRY(upload_sample(db, sample, n_sample));
     if (bsearch) YH_TRY(yh_q_overlap_bsearch(db, db->d_sample_tmp, n_sample, db->d_overlap_tmp));
-    else YH_TRY(yh_q_overlap(db, db->d_sample_tmp, n_sample, db->d_overlap_tmp));
+    else YH_TRY(yh_q_overlap(db, db->d_sample_tmp, n_sample, db->d_overlap_tmp, false, false));
     if (db->n_refs)
         YH_HIP(hipMemcpyAsync(overlap, db->d_overlap_tmp, db->n_refs * sizeof(u32), hipMemcpyDeviceToHost, db->stream));
     YH_HIP(hipStreamSynchronize(db->stream));
@@ -436,8 +439,8 @@ int yh_exclusive(yh_db* db, const uint8_t* subset_mask, const uint64_t* sample, 
     int rc = YH_OK;
     do {
         if (hipMemcpyAsync(db->d_mask, subset_mask, N, hipMemcpyHostToDevice, db->stream) != hipSuccess) { yh_set_error("mask upload failed"); rc = YH_ERR_HIP; break; }
-        if ((rc = yh_q_overlap(db, db->d_sample_tmp, n_sample, db->d_overlap_tmp)) != YH_OK) break;
-        if ((rc = yh_q_exclusive(db, db->d_mask, db->d_sample_tmp, n_sample, db->d_overlap_tmp, d_e, d_m)) != YH_OK) break;
+        if ((rc = yh_q_overlap(db, db->d_sample_tmp, n_sample, db->d_overlap_tmp, true, false)) != YH_OK) break;
+        if ((rc = yh_q_exclusive(db, db->d_mask, db->d_sample_tmp, n_sample, db->d_overlap_tmp, d_e, d_m, true, nullptr)) != YH_OK) break;
         if (hipMemcpyAsync(n_excl, d_e, N * sizeof(u32), hipMemcpyDeviceToHost, db->stream) != hipSuccess ||
             hipMemcpyAsync(n_match, d_m, N * sizeof(u32), hipMemcpyDeviceToHost, db->stream) != hipSuccess ||
             hipStreamSynchronize(db->stream) != hipSuccess) {
@@ -456,10 +459,10 @@ int yh_run_device(yh_db* db, const uint64_t* d_sample, uint64_t n_sample, uint32
     if (!d_overlap || (n_sample && !d_sample)) { yh_set_error("null device pointer"); return YH_ERR_INVALID_ARG; }
     if ((d_n_excl == nullptr) != (d_n_match == nullptr)) { yh_set_error("pass both d_n_excl and d_n_match or neither"); return YH_ERR_INVALID_ARG; }
     YH_TRY(db_select(db));
-    YH_TRY(yh_q_overlap(db, (const u64*)d_sample, n_sample, d_overlap));
+    YH_TRY(yh_q_overlap(db, (const u64*)d_sample, n_sample, d_overlap, d_n_excl != nullptr, d_n_excl != nullptr));
     if (!d_n_excl) return YH_OK;
-    YH_TRY(yh_q_mask_from_overlap(db, d_overlap, db->d_mask));
-    return yh_q_exclusive(db, db->d_mask, (const u64*)d_sample, n_sample, d_overlap, d_n_excl, d_n_match);
+    return yh_q_exclusive(db, db->d_mask, (const u64*)d_sample, n_sample, d_overlap, d_n_excl, d_n_match, true,
+                          db->d_maskbits);
 }
 
 int yh_run(yh_db* db, const uint64_t* sample, uint64_t n_sample, uint32_t* overlap, uint32_t* n_excl,

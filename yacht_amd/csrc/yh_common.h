@@ -80,6 +80,8 @@ static_assert(TILE_SLOTS <= 65536, "directory entries are uint16 slot numbers");
 constexpr int TILE_QCAP = YH_TILE_QCAP;
 static_assert(TILE_UNROLL * 2 <= 32, "candidate masks are 32-bit");
 
+constexpr int EXCL_QBLOCKS = 4096;  // workgroups (= queue segments) of k_excl_collect / k_excl_apply
+
 constexpr int TIMING_RING = 256;
 
 struct EventRing {
@@ -128,14 +130,17 @@ struct yh_db {
     u64* d_gbeg = nullptr;   // [P]   first shared hash of partition p in d_g
     u64* d_gcnt = nullptr;   // [P]
     u32* d_nshared = nullptr;  // [N] number of shared hashes in reference j
+    u32* d_pq = nullptr;       // [postings] queue of postings that belong to masked references (per query)
+    u32* d_pq_count = nullptr; // [EXCL_QBLOCKS] fill of each workgroup's queue segment
 
     // per-query scratch (allocated once)
     u32* d_sbounds = nullptr;  // [P+1] sample slice bounds per partition
     u8* d_mask = nullptr;      // [N]
+    u32* d_maskbits = nullptr; // [ceil(N/64)*2] the same mask as bits
     u8* d_hit = nullptr;       // [G]
-    u32* d_excl_e = nullptr;   // [N] shared hashes that are subset-exclusive
-    u32* d_excl_m = nullptr;   // [N] ... and in the sample
-    u32* d_ovsh = nullptr;     // [N] overlap restricted to shared hashes
+    u32* d_excl_e = nullptr;   // [N] shared hashes that are subset-exclusive   } one allocation of 3N words,
+    u32* d_excl_m = nullptr;   // [N] ... and in the sample                      } zeroed together
+    u32* d_ovsh = nullptr;     // [N] overlap restricted to shared hashes        }
     u32* d_overlap_tmp = nullptr;  // [N]
     u64* d_sample_tmp = nullptr;   // grows on demand (host-pointer entry points)
     u64 sample_tmp_cap = 0;
@@ -167,12 +172,12 @@ int yh_build_partitions(yh_db* db, const u64* d_values, const u64* d_offsets, u3
 int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, const u32* d_pair_ids);
 
 // ---- implemented in yh_query.hip -------------------------------------------------------------
-int yh_q_overlap(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap);
+int yh_q_overlap(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap, bool flag_shared, bool make_mask);
 int yh_q_overlap_bsearch(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap);
 int yh_q_exclusive(yh_db* db, const u8* d_mask, const u64* d_sample, u64 n_sample,
-                   const u32* d_overlap, u32* d_excl, u32* d_match);
+                   const u32* d_overlap, u32* d_excl, u32* d_match, bool hit_ready, const u32* d_maskbits);
 int yh_q_exclusive_partial(yh_db* db, const u8* d_mask, const u64* d_sample, u64 n_sample, u32* d_ex_e, u32* d_ex_m,
-                           u32* d_ovsh, bool own_bounds);
+                           u32* d_ovsh, bool own_bounds, bool hit_ready, const u32* d_maskbits);
 int yh_q_exclusive_final(yh_db* db, u64 n, const u8* d_mask, const u32* d_sizes, const u32* d_nshared,
                          const u32* d_overlap, const u32* d_ex_e, const u32* d_ex_m, const u32* d_ovsh, u32* d_excl,
                          u32* d_match);

@@ -85,6 +85,17 @@ struct FlagHit {
     __device__ __forceinline__ void count(u32, u32, u32) const {}
 };
 
+// Optional second stream of the tile kernel: the database-shared hashes `g` (grouped by the same
+// partitions).  A workgroup that has partition p's tile staged also tests its proportional share
+// of g's partition-p slice and flags the members (`hit[]`, read by the exclusive-count kernels):
+// no extra launch and no extra tile set-ups for R2's membership pass.
+struct SideStream {
+    const u64* g;     // nullptr: no side stream
+    const u64* gbeg;  // [P]
+    const u64* gcnt;  // [P]
+    u8* hit;          // [G]
+};
+
 // one workgroup per queue segment: position -> reference -> replicated count
 __global__ void __launch_bounds__(256) k_resolve_hits(const u32* __restrict__ qcount, OverlapHit hit) {
     const u32 wg = blockIdx.x;
@@ -96,12 +107,66 @@ __global__ void __launch_bounds__(256) k_resolve_hits(const u32* __restrict__ qc
     }
 }
 
-__global__ void k_reduce_replicas(const u32* __restrict__ reps, u32 R, u64 n, u32* __restrict__ out) {
+// overlap[j] = sum of the replicas; optionally also the subset mask "overlap > 0" as bytes and as
+// bits (one ballot per wave: references 64w .. 64w+63 -> two words)
+__global__ void __launch_bounds__(256) k_reduce_replicas(const u32* __restrict__ reps, u32 R, u64 n,
+                                                         u32* __restrict__ out, u8* __restrict__ mask,
+                                                         u32* __restrict__ maskbits) {
     const u64 j = blockIdx.x * (u64)blockDim.x + threadIdx.x;
-    if (j >= n) return;
     u32 acc = 0;
-    for (u32 r = 0; r < R; ++r) acc += reps[(u64)r * n + j];
-    out[j] = acc;
+    if (j < n) {
+        for (u32 r = 0; r < R; ++r) acc += reps[(u64)r * n + j];
+        out[j] = acc;
+        if (mask) mask[j] = acc ? 1 : 0;
+    }
+    if (maskbits) {
+        const u64 bal = __ballot(acc != 0);
+        if ((threadIdx.x & 63) == 0) {
+            maskbits[(j >> 5)] = (u32)bal;
+            maskbits[(j >> 5) + 1] = (u32)(bal >> 32);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_mask_bits(const u8* __restrict__ mask, u64 n, u32* __restrict__ maskbits) {
+    const u64 j = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    const u64 bal = __ballot(j < n && mask[j] != 0);
+    if ((threadIdx.x & 63) == 0) {
+        maskbits[(j >> 5)] = (u32)bal;
+        maskbits[(j >> 5) + 1] = (u32)(bal >> 32);
+    }
+}
+
+// One launch in front of the streaming kernel: the sample's slice bounds per partition, and the
+// zeroing of every buffer the step accumulates into (instead of one fill kernel per buffer).
+struct ZeroList {
+    uint4* p[4];
+    u64 n16[4];  // 16-byte units
+};
+__global__ void __launch_bounds__(256) k_prep(const u64* __restrict__ sample, u32 n, u32 P, u32 pshift,
+                                              u32* __restrict__ sb, ZeroList z) {
+    const u64 t = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    const u64 nt = (u64)gridDim.x * blockDim.x;
+    if (t <= P) {
+        const u32 p = (u32)t;
+        const bool wraps = (pshift > 0) && (((u64)p >> (64 - pshift)) != 0);  // p << pshift >= 2^64
+        u32 r;
+        if (p == 0) r = 0;
+        else if (wraps) r = n;
+        else {
+            const u64 key = (u64)p << pshift;
+            u32 lo = 0, hi = n;
+            while (lo < hi) {
+                const u32 mid = (lo + hi) >> 1;
+                if (sample[mid] < key) lo = mid + 1; else hi = mid;
+            }
+            r = lo;
+        }
+        sb[p] = r;
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+        for (u64 i = t; i < z.n16[b]; i += nt) z.p[b][i] = make_uint4(0, 0, 0, 0);
 }
 
 // ---- K1: streaming tile lookup -------------------------------------------------------------------
@@ -220,7 +285,7 @@ k_tile_lookup(const u64* __restrict__ vals,     // hash stream, grouped by parti
               u32 P, u64 total_len,             // stream length including inter-partition padding
               const u64* __restrict__ sample,   // sorted sample hashes
               const u32* __restrict__ sbounds,  // [P+1] sample slice of partition p
-              u32 pshift, u32* __restrict__ qcount, Hit hit) {
+              u32 pshift, u32* __restrict__ qcount, Hit hit, SideStream side) {
     __shared__ __attribute__((aligned(16))) u64 S[TILE_SLOTS];
     __shared__ __attribute__((aligned(16))) u32 BM[TILE_BM_WORDS];
     __shared__ u16 E[TILE_NB];
@@ -307,6 +372,15 @@ k_tile_lookup(const u64* __restrict__ vals,     // hash stream, grouped by parti
             __syncthreads();
             if (bsh >= 32) tile_stream<true>(vals, start, end, e0, p, n, bsh, S, E, BM, hit, ctx);
             else tile_stream<false>(vals, start, end, e0, p, n, bsh, S, E, BM, hit, ctx);
+            if (side.g) {  // this workgroup's share of the shared hashes of partition p
+                const u64 cnt = pcnt[p], gc = side.gcnt[p], g0 = side.gbeg[p];
+                const u64 gs = g0 + gc * (start - e0) / cnt, ge = g0 + gc * (end - e0) / cnt;
+                if (gs < ge) {
+                    const FlagHit fh{side.gbeg, side.hit};
+                    if (bsh >= 32) tile_stream<true>(side.g, gs, ge, g0, p, n, bsh, S, E, BM, fh, ctx);
+                    else tile_stream<false>(side.g, gs, ge, g0, p, n, bsh, S, E, BM, fh, ctx);
+                }
+            }
         }
     }
     flush();
@@ -372,28 +446,89 @@ __global__ void k_mask_from_overlap(const u32* __restrict__ ov, u64 n, u8* __res
     if (i < n) mask[i] = ov[i] ? 1 : 0;
 }
 
-// One thread per shared hash.  c = masked references holding it.
-//   c == 1            -> the hash is exclusive to that reference inside the subset
-//   hash in sample    -> every masked holder's "shared overlap" grows by one
-__global__ void k_excl_postings(u64 G, const u64* __restrict__ po, const u32* __restrict__ pr,
-                                const u8* __restrict__ mask, const u8* __restrict__ hit, u32* __restrict__ ex_e,
-                                u32* __restrict__ ex_m, u32* __restrict__ ovsh) {
-    for (u64 gi = blockIdx.x * (u64)blockDim.x + threadIdx.x; gi < G; gi += (u64)gridDim.x * blockDim.x) {
-        const u64 b = po[gi], e = po[gi + 1];
-        const bool in_sample = hit[gi] != 0;
-        u32 c = 0, rstar = 0;
-        for (u64 k = b; k < e; ++k) {
-            const u32 r = pr[k];
-            if (mask[r]) {
-                ++c;
-                rstar = r;
-                if (in_sample) atomicAdd(&ovsh[r], 1u);
+// Exclusive sums from the posting lists, in two launches.
+//
+// k_excl_collect: one coalesced pass over pr[] (four postings per lane per step, mask probes as
+// BITS: N/8 bytes stay resident in every CU's L1, while random byte reads of an N-byte mask pulled
+// one cache line per posting through L2).  Postings of masked references are only COLLECTED:
+// appended to a per-workgroup LDS list and flushed to a queue in HBM with one atomic per workgroup.
+// (~1 % of the postings belong to masked references, which is about every second wave; walking the
+// dependent chain below right there left 1-2 lanes per wave busy for several microseconds.)
+//
+// k_excl_apply: one lane per collected posting (r holds shared hash g), all lanes busy:
+//   c = masked holders of g;  c == 1 -> g is exclusive to r inside the subset (ex_e, and ex_m
+//   when g is in the sample);  g in the sample -> r's "shared overlap" grows by one (ovsh).
+constexpr int EXCL_BLOCK = 256;
+// Workgroup b owns the contiguous vectors [b*chunk, (b+1)*chunk) of pr[] (a vector = 4 postings)
+// and the queue segment that starts at posting index 4*b*chunk: even if every posting of its range
+// is collected the segment cannot overflow, so there is no global counter (10^4 atomics on one word
+// cost ~120 us) and no zeroing; qcount[b] is written by every workgroup.
+__global__ void __launch_bounds__(EXCL_BLOCK) k_excl_collect(u64 n_post, u64 chunk, const u32* __restrict__ pr,
+                                                             const u32* __restrict__ maskbits,
+                                                             u32* __restrict__ queue, u32* __restrict__ qcount) {
+    __shared__ u32 lq[EXCL_BLOCK * 4];
+    __shared__ u32 lfill;
+    if (threadIdx.x == 0) lfill = 0;
+    __syncthreads();
+    auto masked = [&](u32 r) -> bool { return (maskbits[r >> 5] >> (r & 31u)) & 1u; };
+    const u64 n4 = n_post >> 2;
+    const uint4* __restrict__ pr4 = reinterpret_cast<const uint4*>(pr);
+    const u64 v_begin = (u64)blockIdx.x * chunk;
+    const u64 v_end = min(n4 + 1, v_begin + chunk);  // vector n4 stands for the 0-3 trailing postings
+    u32* seg = queue + 4 * v_begin;
+    u32 done = 0;  // entries already flushed to seg (same value in every thread)
+    for (u64 v0 = v_begin; v0 < v_end; v0 += EXCL_BLOCK) {
+        const u64 v = v0 + threadIdx.x;
+        if (v < v_end && v < n4) {
+            const uint4 r = pr4[v];
+            const bool m0 = masked(r.x), m1 = masked(r.y), m2 = masked(r.z), m3 = masked(r.w);
+            const u32 cnt = (u32)m0 + (u32)m1 + (u32)m2 + (u32)m3;
+            if (cnt) {
+                u32 slot = atomicAdd(&lfill, cnt);
+                const u32 k = (u32)(4 * v);
+                if (m0) lq[slot++] = k;
+                if (m1) lq[slot++] = k + 1;
+                if (m2) lq[slot++] = k + 2;
+                if (m3) lq[slot++] = k + 3;
             }
+        } else if (v < v_end && v == n4) {
+            for (u64 k = n4 << 2; k < n_post; ++k)
+                if (masked(pr[k])) lq[atomicAdd(&lfill, 1u)] = (u32)k;
+        }
+        __syncthreads();
+        const u32 f = lfill;
+        for (u32 e = threadIdx.x; e < f; e += EXCL_BLOCK) seg[done + e] = lq[e];
+        done += f;
+        __syncthreads();
+        if (threadIdx.x == 0) lfill = 0;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) qcount[blockIdx.x] = done;
+}
+
+__global__ void __launch_bounds__(EXCL_BLOCK) k_excl_apply(const u32* __restrict__ queue, const u32* __restrict__ qcount,
+                                                           u64 chunk, const u64* __restrict__ po,
+                                                           const u32* __restrict__ pr, const u32* __restrict__ pg,
+                                                           const u32* __restrict__ maskbits, const u8* __restrict__ hit,
+                                                           u32* __restrict__ ex_e, u32* __restrict__ ex_m,
+                                                           u32* __restrict__ ovsh) {
+    const u32 n = qcount[blockIdx.x];
+    const u32* seg = queue + 4 * (u64)blockIdx.x * chunk;
+    for (u32 e = threadIdx.x; e < n; e += EXCL_BLOCK) {
+        const u32 k = seg[e];
+        const u32 r = pr[k];
+        const u32 gi = pg[k];
+        const bool in_sample = hit[gi] != 0;
+        u32 c = 0;
+        for (u64 q = po[gi], qe = po[gi + 1]; q < qe; ++q) {
+            const u32 o = pr[q];
+            c += (maskbits[o >> 5] >> (o & 31u)) & 1u;
         }
         if (c == 1) {
-            atomicAdd(&ex_e[rstar], 1u);
-            if (in_sample) atomicAdd(&ex_m[rstar], 1u);
+            atomicAdd(&ex_e[r], 1u);
+            if (in_sample) atomicAdd(&ex_m[r], 1u);
         }
+        if (in_sample) atomicAdd(&ovsh[r], 1u);
     }
 }
 
@@ -553,15 +688,26 @@ int yh_q_check_sorted_host(const u64* v, u64 n) {
     return YH_OK;
 }
 
-int yh_q_overlap(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap) {
+// flag_shared: also flag which database-shared hashes are in the sample (db->d_hit), fused into the
+// same launch; yh_q_exclusive_partial(..., hit_ready = true) then skips its own membership pass.
+int yh_q_overlap(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap, bool flag_shared, bool make_mask) {
     if (!db->d_pvals) { yh_set_error("this handle holds posting lists only (yh_db_create_from_pairs)"); return YH_ERR_UNSUPPORTED; }
     hipStream_t st = db->stream;
     const u64 N = db->n_refs;
     if (n_sample > 0xfffffff0ull) { yh_set_error("sample larger than 2^32-16 hashes"); return YH_ERR_INVALID_ARG; }
-    YH_HIP(hipMemsetAsync(d_overlap, 0, std::max<u64>(N, 1) * sizeof(u32), st));
-    if (N == 0 || db->n_hashes == 0 || n_sample == 0) return YH_OK;
+    const bool with_index = flag_shared && db->has_index;
+    flag_shared = with_index && db->n_shared > 0;
+    if (N == 0 || db->n_hashes == 0 || n_sample == 0) {  // nothing can match: all-zero results
+        YH_HIP(hipMemsetAsync(d_overlap, 0, std::max<u64>(N, 1) * sizeof(u32), st));
+        if (flag_shared) YH_HIP(hipMemsetAsync(db->d_hit, 0, db->n_shared, st));
+        if (with_index && N) YH_HIP(hipMemsetAsync(db->d_excl_e, 0, 3 * N * sizeof(u32), st));
+        if (make_mask && N) {
+            YH_HIP(hipMemsetAsync(db->d_mask, 0, N, st));
+            YH_HIP(hipMemsetAsync(db->d_maskbits, 0, ((N + 255) / 256) * 32, st));
+        }
+        return YH_OK;
+    }
     const u32 P = db->n_parts;
-    k_sample_bounds<<<(P + 1 + 255) / 256, 256, 0, st>>>(d_sample, (u32)n_sample, P, db->pshift, db->d_sbounds);
     // hit queue: one segment per workgroup, 1/16 of its stream slice (at least 4096 entries)
     const u32 wgs = tile_grid(db->pvals_len);
     const u64 per_wg = (db->pvals_len + wgs - 1) / wgs;
@@ -583,17 +729,27 @@ int yh_q_overlap(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap) {
     if (db->reps_cap < (u64)R * N) {
         YH_HIP(hipStreamSynchronize(st));
         if (db->d_reps) { (void)hipFree(db->d_reps); db->d_reps = nullptr; db->reps_cap = 0; }
-        YH_HIP(hipMalloc((void**)&db->d_reps, (u64)R * N * sizeof(u32)));
+        YH_HIP(hipMalloc((void**)&db->d_reps, (u64)R * N * sizeof(u32) + 16));
         db->reps_cap = (u64)R * N;
     }
-    YH_HIP(hipMemsetAsync(db->d_reps, 0, (u64)R * N * sizeof(u32), st));
+    // one launch: sample slice bounds + zero the replicas, the shared-hash flags and the exclusive sums
+    ZeroList z{};
+    z.p[0] = reinterpret_cast<uint4*>(db->d_reps);
+    z.n16[0] = ((u64)R * N * sizeof(u32) + 15) / 16;
+    if (flag_shared) { z.p[1] = reinterpret_cast<uint4*>(db->d_hit); z.n16[1] = (db->n_shared + 15) / 16; }
+    if (with_index) { z.p[2] = reinterpret_cast<uint4*>(db->d_excl_e); z.n16[2] = (3 * N * sizeof(u32) + 15) / 16; }
+    k_prep<<<1024, 256, 0, st>>>(d_sample, (u32)n_sample, P, db->pshift, db->d_sbounds, z);
     OverlapHit hit{db->d_poffs, (u32)N, db->d_reps, R - 1, db->d_hitq, db->hitq_cap};
     yh_ring_record_begin(db, db->ev_overlap);
+    const SideStream side = flag_shared ? SideStream{db->d_g, db->d_gbeg, db->d_gcnt, db->d_hit}
+                                        : SideStream{nullptr, nullptr, nullptr, nullptr};
     k_tile_lookup<OverlapHit><<<wgs, TILE_THREADS, 0, st>>>(db->d_pvals, db->d_pbeg, db->d_pcnt, P, db->pvals_len,
-                                                            d_sample, db->d_sbounds, db->pshift, db->d_hitq_cnt, hit);
+                                                            d_sample, db->d_sbounds, db->pshift, db->d_hitq_cnt, hit,
+                                                            side);
     yh_ring_record_end(db, db->ev_overlap);
     k_resolve_hits<<<wgs, 256, 0, st>>>(db->d_hitq_cnt, hit);
-    k_reduce_replicas<<<(u32)((N + 255) / 256), 256, 0, st>>>(db->d_reps, R, N, d_overlap);
+    k_reduce_replicas<<<(u32)((N + 255) / 256), 256, 0, st>>>(db->d_reps, R, N, d_overlap, make_mask ? db->d_mask : nullptr,
+                                                             make_mask ? db->d_maskbits : nullptr);
     YH_HIP(hipGetLastError());
     return YH_OK;
 }
@@ -623,29 +779,43 @@ int yh_q_mask_from_overlap(yh_db* db, const u32* d_overlap, u8* d_mask) {
 // numbering: ex_e / ex_m / ovsh (see k_excl_postings).  `own_bounds`: compute the sample's slice
 // bounds here (a handle whose overlap kernel did not just run on the same sample).
 int yh_q_exclusive_partial(yh_db* db, const u8* d_mask, const u64* d_sample, u64 n_sample, u32* d_ex_e, u32* d_ex_m,
-                           u32* d_ovsh, bool own_bounds) {
+                           u32* d_ovsh, bool own_bounds, bool hit_ready, const u32* d_maskbits) {
     if (!db->has_index) { yh_set_error("this handle was created with YH_DB_NO_INDEX"); return YH_ERR_UNSUPPORTED; }
     hipStream_t st = db->stream;
     const u64 N = db->n_refs;
     if (N == 0) return YH_OK;
     if (n_sample > 0xfffffff0ull) { yh_set_error("sample larger than 2^32-16 hashes"); return YH_ERR_INVALID_ARG; }
     const u64 G = db->n_shared;
-    YH_HIP(hipMemsetAsync(d_ex_e, 0, N * sizeof(u32), st));
-    YH_HIP(hipMemsetAsync(d_ex_m, 0, N * sizeof(u32), st));
-    YH_HIP(hipMemsetAsync(d_ovsh, 0, N * sizeof(u32), st));
+    if (!hit_ready) {  // (the fused path zeroed these in k_prep)
+        YH_HIP(hipMemsetAsync(d_ex_e, 0, N * sizeof(u32), st));
+        YH_HIP(hipMemsetAsync(d_ex_m, 0, N * sizeof(u32), st));
+        YH_HIP(hipMemsetAsync(d_ovsh, 0, N * sizeof(u32), st));
+    }
+    if (!d_maskbits) {  // mask supplied as bytes by the caller
+        k_mask_bits<<<(u32)((N + 255) / 256), 256, 0, st>>>(d_mask, N, db->d_maskbits);
+        d_maskbits = db->d_maskbits;
+    }
     if (G) {
-        YH_HIP(hipMemsetAsync(db->d_hit, 0, G, st));
-        if (n_sample) {
+        if (!hit_ready) YH_HIP(hipMemsetAsync(db->d_hit, 0, G, st));
+        if (n_sample && !hit_ready) {
             const u32 P = db->n_parts;
             if (own_bounds)
                 k_sample_bounds<<<(P + 1 + 255) / 256, 256, 0, st>>>(d_sample, (u32)n_sample, P, db->pshift, db->d_sbounds);
             // membership of every shared hash in the sample: the same tile kernel over d_g
             FlagHit fh{db->d_gbeg, db->d_hit};
-            k_tile_lookup<FlagHit><<<tile_grid(G), TILE_THREADS, 0, st>>>(db->d_g, db->d_gbeg, db->d_gcnt, P, G, d_sample,
-                                                                          db->d_sbounds, db->pshift, nullptr, fh);
+            k_tile_lookup<FlagHit><<<tile_grid(G), TILE_THREADS, 0, st>>>(
+                db->d_g, db->d_gbeg, db->d_gcnt, P, G, d_sample, db->d_sbounds, db->pshift, nullptr, fh,
+                SideStream{nullptr, nullptr, nullptr, nullptr});
         }
-        k_excl_postings<<<grid_for(G, 256, 8192), 256, 0, st>>>(G, db->d_po, db->d_pr, d_mask, db->d_hit, d_ex_e, d_ex_m,
-                                                                d_ovsh);
+        {
+            const u64 vecs = (db->n_postings >> 2) + 1;
+            const u32 blocks = (u32)std::min<u64>(EXCL_QBLOCKS, (vecs + EXCL_BLOCK - 1) / EXCL_BLOCK);
+            const u64 chunk = (vecs + blocks - 1) / blocks;
+            k_excl_collect<<<blocks, EXCL_BLOCK, 0, st>>>(db->n_postings, chunk, db->d_pr, d_maskbits, db->d_pq,
+                                                          db->d_pq_count);
+            k_excl_apply<<<blocks, EXCL_BLOCK, 0, st>>>(db->d_pq, db->d_pq_count, chunk, db->d_po, db->d_pr, db->d_pg,
+                                                        d_maskbits, db->d_hit, d_ex_e, d_ex_m, d_ovsh);
+        }
     }
     YH_HIP(hipGetLastError());
     return YH_OK;
@@ -664,12 +834,13 @@ int yh_q_exclusive_final(yh_db* db, u64 n, const u8* d_mask, const u32* d_sizes,
 // d_overlap must hold the overlap of the SAME sample (yh_q_overlap output on this handle, which
 // also left the sample's slice bounds in d_sbounds).
 int yh_q_exclusive(yh_db* db, const u8* d_mask, const u64* d_sample, u64 n_sample, const u32* d_overlap,
-                   u32* d_excl, u32* d_match) {
+                   u32* d_excl, u32* d_match, bool hit_ready, const u32* d_maskbits) {
     if (!db->has_index) { yh_set_error("this handle was created with YH_DB_NO_INDEX"); return YH_ERR_UNSUPPORTED; }
     if (!db->d_pvals) { yh_set_error("this handle holds posting lists only"); return YH_ERR_UNSUPPORTED; }
     if (db->n_refs == 0) return YH_OK;
     yh_ring_record_begin(db, db->ev_excl);
-    YH_TRY(yh_q_exclusive_partial(db, d_mask, d_sample, n_sample, db->d_excl_e, db->d_excl_m, db->d_ovsh, false));
+    YH_TRY(yh_q_exclusive_partial(db, d_mask, d_sample, n_sample, db->d_excl_e, db->d_excl_m, db->d_ovsh, false,
+                                  hit_ready, d_maskbits));
     YH_TRY(yh_q_exclusive_final(db, db->n_refs, d_mask, db->d_sizes, db->d_nshared, d_overlap, db->d_excl_e,
                                 db->d_excl_m, db->d_ovsh, d_excl, d_match));
     yh_ring_record_end(db, db->ev_excl);
