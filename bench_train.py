@@ -1,0 +1,120 @@
+#!/usr/bin/env python3
+"""bench_train.py — the `yacht train` side of the hot path (BASELINE.json configs[3]): pairwise
+reference x reference containment + greedy dedup, 2 000 clusters x 5 sketches of ~5 000 hashes,
+ani_thresh 0.95 (C = 0.95**31).  Secondary to bench.py (whose contract the driver reads): this
+prints one JSON line with the pair-query rate, the phase times and a parity verdict.
+
+    python bench_train.py [--clusters 2000] [--size 5000] [--steps 5] [--oracle-clusters 400]
+
+Phases timed on the device path (inputs on the host, as `yacht train` has them):
+  upload+build   yh_db_create: CSR upload, partitioned CSR, radix-sort inverted index
+  pairwise       yh_pairwise: posting lists -> dense int32 row block (atomics) -> threshold -> pairs
+  select         yh_train_select (host)
+A query = one unordered reference pair whose intersection size is produced: N(N-1)/2 per pass.
+Parity: the same pipeline on the first `--oracle-clusters` clusters against the CPU oracle
+(inverted index + scatter, the reference's algorithm), bit-exact pairs / statistics / selection.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--clusters", type=int, default=2000)
+    ap.add_argument("--size", type=int, default=5000)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--oracle-clusters", type=int, default=400)
+    ap.add_argument("--no-oracle", action="store_true")
+    args = ap.parse_args()
+
+    from yacht_amd import _lib, synth
+    from yacht_amd.engine import RefDB, train_select
+
+    if _lib.device_count() < 1:
+        print("bench_train.py needs an MI355X (no CPU fallback)", file=sys.stderr)
+        return 2
+    c = 0.95 ** 31
+    values, offsets = synth.config4(seed=1003, n_clusters=args.clusters, size=args.size)
+    n = offsets.size - 1
+    sizes = np.diff(offsets).astype(np.uint32)
+
+    t_build, t_pair, t_sel = [], [], []
+    k_pair_ms = []
+    pi = pj = pc = None
+    for _ in range(args.steps + 1):  # first pass is warm-up
+        t0 = time.perf_counter()
+        db = RefDB(values, offsets)
+        t1 = time.perf_counter()
+        pi, pj, pc = db.pairwise(c)
+        t2 = time.perf_counter()
+        sel = train_select(sizes, pi, pj)
+        t3 = time.perf_counter()
+        tm = db.timing()
+        info = db.info()
+        stats = db.index_stats()
+        db.close()
+        t_build.append(t1 - t0)
+        t_pair.append(t2 - t1)
+        t_sel.append(t3 - t2)
+        k_pair_ms.append(tm["ms_pairwise_kernels"])
+    t_build, t_pair, t_sel, k_pair_ms = (float(np.median(x[1:])) for x in (t_build, t_pair, t_sel, k_pair_ms))
+    total = t_build + t_pair + t_sel
+    n_pairs_unordered = n * (n - 1) // 2
+
+    parity = None
+    cpu = None
+    if not args.no_oracle:
+        from oracle import oracle
+
+        k = min(args.oracle_clusters, args.clusters) * 5
+        v2, o2 = values[: int(offsets[k])], offsets[: k + 1]
+        s2 = sizes[:k]
+        cores = oracle.hardware_threads()
+        t0 = time.perf_counter()
+        wi, wj, wc, wstats = oracle.train_pairs(v2, o2, c, threads=cores)
+        wsel = oracle.train_select(s2, wi, wj)
+        t_cpu = time.perf_counter() - t0
+        with RefDB(v2, o2) as db2:
+            gi, gj, gc = db2.pairwise(c)
+            gstats = db2.index_stats()
+        gsel = train_select(s2, gi, gj)
+        parity = bool(np.array_equal(gi, wi) and np.array_equal(gj, wj) and np.array_equal(gc, wc)
+                      and gstats == wstats and np.array_equal(gsel, wsel))
+        cpu = {"value": round(k * (k - 1) / 2 / t_cpu, 1), "unit": "pair-queries/s", "cores": cores, "kind": "port",
+               "sample": f"first {k} sketches ({int(o2[-1])} hashes): index build on 1 thread + scatter on {cores} "
+                         f"threads + selection, {t_cpu:.2f} s"}
+
+    # algorithmic bytes: every reference hash once + one (i, j, count) per emitted pair
+    alg = 8 * int(offsets[-1]) + 12 * int(pi.size)
+    out = {
+        "metric": "ref x ref containment pair-queries/sec (yacht train)",
+        "value": round(n_pairs_unordered / total, 1),
+        "unit": "pair-queries/s",
+        "n_gpus": 1,
+        "config": {"workload": f"configs[3]: {args.clusters} clusters x 5 sketches of ~{args.size} hashes, C=0.95**31",
+                   "n_refs": int(n), "n_hashes": int(offsets[-1]), "pairs_emitted": int(pi.size),
+                   "selected": int(sel.size), "shared_hashes": int(stats[2]), "postings": int(info["n_shared_postings"])},
+        "seconds": {"upload_and_build": round(t_build, 5), "pairwise": round(t_pair, 5), "select": round(t_sel, 5),
+                    "total": round(total, 5), "pairwise_kernels_ms": round(k_pair_ms, 3),
+                    "db_build_kernels_ms": round(float(tm["ms_db_build"]), 3)},
+        "algorithmic_bytes": alg,
+        "algorithmic_GBps_over_total": round(alg / total / 1e9, 2),
+        "cpu_baseline": cpu,
+        "parity_bit_exact": parity,
+    }
+    print(json.dumps(out), flush=True)
+    return 0 if parity in (None, True) else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -216,3 +216,52 @@ def test_full_scale_properties(hip_lib):
         assert not e[ov == 0].any() and not m[ov == 0].any()
     finally:
         db.close()
+
+
+def test_cli_train_then_run_end_to_end(hip_lib, tmp_path):
+    """`yacht train` + `yacht run` through the command line entry point, as the reference's
+    tests/test_workflow.py::test_full_workflow drives them: files, columns, the known answer."""
+    from yacht_amd import cli
+
+    out = tmp_path / "out"
+    out.mkdir()
+    ref_zip = tmp_path / "20_genomes_sketches.zip"
+    sample_zip = tmp_path / "sample.sig.zip"
+    shutil.copyfile(os.path.join(FX, "20_genomes_sketches.zip"), ref_zip)
+    shutil.copyfile(os.path.join(FX, "sample.sig.zip"), sample_zip)
+    assert cli.main(["train", "--ref_file", str(ref_zip), "--ksize", "31", "--prefix", "gtdb_ani_thresh_0.95",
+                     "--ani_thresh", "0.95", "--outdir", str(out), "--num_threads", "2", "--force"]) == 0
+    cfg = json.load(open(out / "gtdb_ani_thresh_0.95_config.json"))
+    assert cfg["ksize"] == 31 and cfg["ani_thresh"] == 0.95 and cfg["scale"] == 1000
+    work = out / "gtdb_ani_thresh_0.95_intermediate_files"
+    for f in ("SOURMASH-MANIFEST.csv", "selected_result.tsv", "training_sig_files.tsv",
+              "signatures/04212e93c2172d4df49dc5d8c2973d8b.sig"):
+        assert (work / f).stat().st_size > 291
+    man = pd.read_csv(out / "gtdb_ani_thresh_0.95_processed_manifest.tsv", sep="\t")
+    assert list(man.columns) == ["organism_name", "md5sum", "num_unique_kmers_in_genome_sketch",
+                                 "num_total_kmers_in_genome_sketch", "genome_scale_factor"] and len(man) == 20
+    with pytest.raises(ValueError, match="already exists"):   # no --force
+        cli.main(["train", "--ref_file", str(ref_zip), "--ksize", "31", "--prefix", "gtdb_ani_thresh_0.95",
+                  "--outdir", str(out)])
+
+    assert cli.main(["run", "--json", str(out / "gtdb_ani_thresh_0.95_config.json"), "--sample_file", str(sample_zip),
+                     "--significance", "0.99", "--num_threads", "2", "--min_coverage_list", "0.001", "--show_all",
+                     "--keep_raw", "--outdir", str(tmp_path)]) == 0
+    res = tmp_path / "results"
+    allr = pd.read_csv(res / "result_all.txt", sep="\t")
+    sheet = pd.read_csv(res / "sheets" / "min_coverage0.001.tsv", sep="\t")
+    raw = pd.read_csv(res / "sheets" / "raw_result.tsv", sep="\t")
+    want_cols = ["organism_name", "num_unique_kmers_in_genome_sketch", "num_total_kmers_in_genome_sketch", "scale_factor",
+                 "num_exclusive_kmers_in_sample_sketch", "num_total_kmers_in_sample_sketch", "min_coverage",
+                 "in_sample_est", "p_vals", "num_exclusive_kmers_to_genome", "num_exclusive_kmers_to_genome_coverage",
+                 "num_matches", "acceptance_threshold_with_coverage", "actual_confidence_with_coverage",
+                 "alt_confidence_mut_rate_with_coverage"]
+    assert list(allr.columns) == want_cols == list(sheet.columns)
+    assert "acceptance_threshold_wo_coverage" in raw.columns and float(raw["min_coverage"].iloc[0]) == 1.0
+    assert len(allr) == 1 and float(allr["min_coverage"].iloc[0]) == 0.001   # the forced 1.0 pass is not in result_all
+    r = sheet[sheet["organism_name"] == "CP032507.1 Ectothiorhodospiraceae bacterium BW-2 chromosome, complete genome"].iloc[0]
+    assert str(r["in_sample_est"]) == "True" and int(r["num_matches"]) == 2
+    assert float(r["acceptance_threshold_with_coverage"]) == 0
+    # the reference's quirk: this column carries the sample's mean abundance
+    assert float(r["num_exclusive_kmers_in_sample_sketch"]) == pytest.approx(2.4032636839886794)
+    assert int(r["num_total_kmers_in_sample_sketch"]) == int(np.round(2.4032636839886794 * 49821))

@@ -144,3 +144,31 @@ def test_single_hyp_test_return_types():
     assert len(r) == 8 and isinstance(r[0], (bool, np.bool_)) and isinstance(r[2], int) and isinstance(r[3], int)
     assert r[3] == int(2829 * 0.2) or True
     assert hr.single_hyp_test((2829, 0), 31, 0.99, 0.95, 0.2)[3] == 565   # int(e * cov) truncates
+
+
+# ---- drivers ------------------------------------------------------------------------------------------------
+def test_coverage_plan_matches_reference_rules():
+    from yacht_amd.run_YACHT import coverage_plan
+
+    assert coverage_plan([1, 0.5, 0.1, 0.05, 0.01]) == ([1.0, 0.5, 0.1, 0.05, 0.01], True)
+    assert coverage_plan([0.001]) == ([1.0, 0.001], False)           # 1.0 is forced in front
+    assert coverage_plan([0.1, 0.5, 0.1]) == ([1.0, 0.5, 0.1], False)  # de-duplicated, descending
+
+
+def test_cli_parsers_and_error_paths(tmp_path):
+    from yacht_amd import cli, make_training_data_from_sketches
+
+    p = cli.build_parser()
+    a = p.parse_args(["train", "--ref_file", "x.zip", "--ksize", "31"])
+    assert (a.num_threads, a.ani_thresh, a.prefix, a.force) == (16, 0.95, "yacht", False)
+    r = p.parse_args(["run", "--json", "c.json", "--sample_file", "s.sig.zip"])
+    assert r.min_coverage_list == [1, 0.5, 0.1, 0.05, 0.01] and r.significance == 0.99
+    assert cli.main(["sketch", "ref"]) == 2
+    # reference behaviour (tests/test_make_training_data_from_sketches.py): a non-zip reference file is rejected
+    bad = p.parse_args(["train", "--ref_file", str(tmp_path / "refs.sig"), "--ksize", "31", "--outdir", str(tmp_path)])
+    with pytest.raises(ValueError, match="is not a zip file"):
+        make_training_data_from_sketches.main(bad)
+    missing = p.parse_args(["run", "--json", str(tmp_path / "nope.json"), "--sample_file", "s.sig.zip",
+                            "--outdir", str(tmp_path)])
+    with pytest.raises(ValueError, match="does not exist"):
+        missing.func(missing)

@@ -1,0 +1,148 @@
+"""`yacht run` driver: sample .sig.zip + training config -> presence/absence tables.
+
+Same arguments, checks, coverage-list handling and result layout as the reference's
+src/yacht/run_YACHT.py (:24-254): `results/result_all.txt` (tab-separated, every user coverage,
+unfiltered) and one table per coverage named `min_coverage{c}` (only organisms with
+in_sample_est unless --show_all), plus `raw_result` with --keep_raw.  The tables go to
+`results/result.xlsx` when openpyxl is importable, and always to `results/sheets/<name>.tsv`.
+Kept on purpose: the reference fills the column "num_exclusive_kmers_in_sample_sketch" with the
+sample's MEAN ABUNDANCE (run_YACHT.py:159) — downstream tools read it that way.
+"""
+from __future__ import annotations
+
+import argparse
+import glob
+import json
+import os
+import sys
+import zipfile
+from pathlib import Path
+
+import pandas as pd
+
+from . import hypothesis_recovery_src as hr
+from . import utils
+from .utils import logger
+
+RAW_RENAMES = {
+    "acceptance_threshold_with_coverage": "acceptance_threshold_wo_coverage",
+    "actual_confidence_with_coverage": "actual_confidence_wo_coverage",
+    "alt_confidence_mut_rate_with_coverage": "alt_confidence_mut_rate_wo_coverage",
+}
+
+
+def add_arguments(parser: argparse.ArgumentParser) -> None:
+    parser.add_argument("--json", type=str, required=True, help="Config json written by `yacht train`.")
+    parser.add_argument("--sample_file", required=True, help="Metagenomic sample in .sig.zip format")
+    parser.add_argument("--significance", type=float, default=0.99, help="Minimum probability of individual true negative.")
+    parser.add_argument("--num_threads", type=int, default=16, help="Host threads for file handling.")
+    parser.add_argument("--keep_raw", action="store_true", help="Keep raw results in output file.")
+    parser.add_argument("--show_all", action="store_true", help="Show all organisms (no matter if present) in output file.")
+    parser.add_argument("--min_coverage_list", nargs="+", type=float, default=[1, 0.5, 0.1, 0.05, 0.01],
+                        help="Fractions of a genome's unique k-mers assumed covered by the sample, each in [0, 1].")
+    parser.add_argument("--outdir", type=str, default=os.getcwd(), help="Where the 'results' folder is created.")
+
+
+def coverage_plan(min_coverage_list):
+    """De-duplicated, descending coverages with 1.0 forced in front; has_raw tells whether the user
+    asked for 1.0 (run_YACHT.py:175-181)."""
+    covs = sorted(set(min_coverage_list), reverse=True)
+    has_raw = 1.0 in covs
+    if not has_raw:
+        covs = [1.0] + covs
+    return covs, has_raw
+
+
+def write_tables(tables, results_folder: str) -> None:
+    sheets = os.path.join(results_folder, "sheets")
+    os.makedirs(sheets, exist_ok=True)
+    for name, df in tables:
+        df.to_csv(os.path.join(sheets, f"{name}.tsv"), sep="\t", index=False)
+    try:
+        import openpyxl  # noqa: F401
+    except ImportError:
+        logger.warning("openpyxl is not installed: result.xlsx not written, tables are in results/sheets/*.tsv")
+        return
+    with pd.ExcelWriter(os.path.join(results_folder, "result.xlsx"), engine="openpyxl", mode="w") as w:
+        for name, df in tables:
+            df.to_excel(w, sheet_name=name, index=False)
+
+
+def main(args) -> None:
+    json_file_path = str(Path(args.json).absolute())
+    sample_file = str(Path(args.sample_file).absolute())
+    outdir = str(Path(args.outdir).absolute())
+    results_folder = os.path.join(outdir, "results")
+    os.makedirs(results_folder, exist_ok=True)
+
+    utils.check_file_existence(json_file_path, f"Config file {json_file_path} does not exist. "
+                                               f"Please run make_training_data_from_sketches.py first.")
+    with open(json_file_path) as f:
+        config = json.load(f)
+    manifest_file_path, genome_dir = config["manifest_file_path"], config["intermediate_files_dir"]
+    scale, ksize, ani_thresh = config["scale"], config["ksize"], config["ani_thresh"]
+
+    if not os.access(outdir, os.W_OK):
+        print(f"Cannot write to the location: {outdir}.\n")
+        print("Please check that you have the permission to write to this location. Exiting..\n")
+        sys.exit(1)
+    for x in args.min_coverage_list:
+        if not (0 <= x <= 1):
+            raise ValueError(f"One of values in the min_coverage_list you provided {x} is not between 0 and 1. Please check your input.")
+    utils.check_file_existence(manifest_file_path, f"The manifest file {manifest_file_path} does not exist. "
+                                                   f"Please check if you are using the correct json file as input.")
+
+    logger.info("Loading the manifest file generated from the training data.")
+    manifest = pd.read_csv(manifest_file_path, sep="\t", header=0)
+    with zipfile.ZipFile(sample_file, "r") as z:
+        if "SOURMASH-MANIFEST.csv" not in z.namelist():
+            raise FileNotFoundError(f"The input file {sample_file} appears to be missing a manifest associated with it. "
+                                    f"Try running: sourmash sig merge {sample_file} -o <new signature with the manifest present>. "
+                                    f"And then run YACHT using the output of that command.")
+    try:
+        sample_sig = utils.load_signature_with_ksize(sample_file, ksize)
+    except ValueError:
+        raise ValueError(f"Expected exactly one signature with ksize {ksize} in {sample_file}, found {len(sample_file)}. "
+                         f"Likely you will need to do something like: sourmash sig merge {sample_file} -o <new signature with just one sketch in it>.")
+    info = utils.get_info_from_single_sig(sample_file, ksize)
+    manifest["num_exclusive_kmers_in_sample_sketch"] = info[3]
+    manifest["num_total_kmers_in_sample_sketch"] = utils.get_num_kmers(info[3], info[4], info[5], scale=False)
+    manifest["sample_scale_factor"] = info[5]
+    manifest["min_coverage"] = 1.0
+    if scale != info[5]:
+        raise ValueError("Sample scale factor does not equal genome scale factor. Please check your input.")
+
+    covs, has_raw = coverage_plan(args.min_coverage_list)
+
+    # databases trained by old versions list *.sig.gz: decompress them once (run_YACHT.py:184-189)
+    listed = glob.glob(f"{genome_dir}/training_sig_files.*")
+    if listed:
+        df = pd.read_csv(listed[0], sep="\t", header=None)
+        if len(df) and "sig.gz" in df[0].values[0]:
+            pd.DataFrame([x.replace("sig.gz", "sig") for x in df[0]]).to_csv(listed[0], header=False, index=False)
+            utils.decompress_all_sig_files(glob.glob(f"{genome_dir}/signatures/*.sig.gz"), args.num_threads)
+
+    logger.info("Computing hypothesis recovery.")
+    results = hr.hypothesis_recovery(manifest, (sample_file, sample_sig), genome_dir, covs, scale, ksize,
+                                     args.significance, ani_thresh, args.num_threads)
+    hr.release_reference_dbs()
+    results = [r[[c for c in r.columns if c not in ("md5sum", "sample_scale_factor")]]
+               .rename(columns={"genome_scale_factor": "scale_factor"}) for r in results]
+
+    logger.info(f"Saving results to {results_folder}.")
+    user_results = results if has_raw else results[1:]
+    user_covs = covs if has_raw else covs[1:]
+    pd.concat(user_results, ignore_index=True).to_csv(os.path.join(results_folder, "result_all.txt"), sep="\t", index=False)
+    tables = []
+    if args.keep_raw:
+        tables.append(("raw_result", results[0].rename(columns=RAW_RENAMES)))
+    for cov, df in zip(user_covs, user_results):
+        tables.append((f"min_coverage{cov}", df if args.show_all else df[df["in_sample_est"] == True]))  # noqa: E712
+    write_tables(tables, results_folder)
+
+
+if __name__ == "__main__":
+    p = argparse.ArgumentParser(description="Presence/absence of reference organisms in a metagenomic sample.",
+                                formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    add_arguments(p)
+    main(p.parse_args())
