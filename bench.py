@@ -49,6 +49,7 @@ def parse_args():
     ap.add_argument("--overlap-only", action="store_true", help="time R1 only (diagnostic; not the reported metric)")
     ap.add_argument("--seed", type=int, default=1002)
     ap.add_argument("--present", type=int, default=200, help="genomes present in the sample (diagnostic)")
+    ap.add_argument("--no-indexed", action="store_true", help="skip the extra measurement of the sample-driven path")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to test the N>1 logic)")
     ap.add_argument("--share-gpu", action="store_true", help="testing: all ranks use cuda:0 (1-GPU box, gloo backend)")
     return ap.parse_args()
@@ -82,7 +83,7 @@ def main() -> int:
             dist.init_process_group(args.backend)
 
     from yacht_amd import build, synth
-    from yacht_amd.engine import RefDB
+    from yacht_amd.engine import RefDB, YH_DB_DEFAULT, YH_DB_FULL_INDEX
 
     if not os.path.exists(build.LIB_PATH):
         build.build_lib()
@@ -110,7 +111,8 @@ def main() -> int:
     n_sample = int(sample.numel())
     torch.cuda.synchronize()
 
-    db = RefDB.from_device(values.data_ptr(), offsets.data_ptr(), n_refs, device=local_rank)
+    db = RefDB.from_device(values.data_ptr(), offsets.data_ptr(), n_refs, device=local_rank,
+                           flags=YH_DB_DEFAULT if args.no_indexed else YH_DB_FULL_INDEX)
     info = db.info()
     # Everything of the timed region runs on ONE explicit stream: the library's kernels are queued
     # on it (a null handle — torch's default stream — would mean "the library's own stream"), and
@@ -157,6 +159,43 @@ def main() -> int:
     timing = db.timing()  # mean over the (up to 256) most recent launches of the timed region
     if world > 1:  # the gathered block of this rank must be this rank's counts (stream ordering check)
         assert bool(torch.equal(gathered.view(world, 3, n_refs)[rank], counts)), "all-gather ran ahead of the kernels"
+
+    # ---- extra: the same step through the sample-driven path (work ~ |S| instead of streaming the
+    # database).  Not the reported `value` this round: the headline stays on the streaming kernel
+    # the north star describes; both are exact and both are checked against the oracle below.
+    indexed = None
+    counts_idx = None
+    if not args.no_indexed and not args.overlap_only:
+        counts_idx = torch.zeros((3, n_refs), device=dev, dtype=torch.int32)
+        pi0, pi1, pi2 = (counts_idx[k].data_ptr() for k in range(3))
+
+        def step_idx():
+            with torch.cuda.stream(stream):
+                db.run_indexed_device(p_sample, n_sample, pi0, pi1, pi2)
+                if world > 1:
+                    dist.all_gather_into_tensor(gathered, counts_idx)
+
+        for _ in range(args.warmup):
+            step_idx()
+        fence()
+        db.timing()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step_idx()
+        fence()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        tm_idx = db.timing()
+        indexed = {"ms_per_step": round(1e3 * el / args.steps, 4),
+                   "value": round(n_refs * world / (el / args.steps), 1), "unit": "queries/s",
+                   "lookup_kernel_ms_avg": round(float(tm_idx["ms_overlap_kernel"]), 4),
+                   "exclusive_kernels_ms_avg": round(float(tm_idx["ms_exclusive_kernels"]), 4),
+                   "note": "k_index_lookup: one lane per sample hash through the distinct-hash directory "
+                           "(YH_DB_FULL_INDEX); equals the streaming path bit for bit"}
+        indexed["equals_streaming_path"] = bool(torch.equal(counts_idx, counts))
 
     ms_per_step = 1e3 * elapsed / args.steps
     total_refs = n_refs * world
@@ -250,12 +289,16 @@ def main() -> int:
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
             "parity_bit_exact": parity,
+            "indexed_path": indexed,
         }
         print(json.dumps(out), flush=True)
     db.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0 and indexed is not None and not indexed["equals_streaming_path"]:
+        print("bench.py: indexed path differs from the streaming path", file=sys.stderr)
+        return 1
     if rank == 0 and parity is False:
         print("bench.py: GPU counts differ from the CPU oracle", file=sys.stderr)
         return 1

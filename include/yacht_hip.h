@@ -59,6 +59,8 @@ enum {
 #define YH_DB_DEFAULT      0u
 #define YH_DB_NO_INDEX     1u  /* skip the shared-hash inverted index (overlap-only handle)     */
 #define YH_DB_KEEP_CSR     2u  /* keep the plain CSR resident too (needed by yh_overlap_bsearch) */
+#define YH_DB_FULL_INDEX   4u  /* also keep a directory of EVERY distinct hash (+12 B per distinct
+                                  hash): enables the sample-driven yh_*_indexed_device queries      */
 
 typedef struct yh_db yh_db;
 
@@ -117,6 +119,13 @@ int yh_overlap_device(yh_db* db, const uint64_t* d_sample, uint64_t n_sample, ui
  * YH_DB_KEEP_CSR).  Kept as an independent on-device cross-check and A/B baseline.        */
 int yh_overlap_bsearch(yh_db* db, const uint64_t* sample, uint64_t n_sample, uint32_t* overlap);
 int yh_overlap_bsearch_device(yh_db* db, const uint64_t* d_sample, uint64_t n_sample, uint32_t* d_overlap);
+
+/* Sample-driven forms (need YH_DB_FULL_INDEX): one lane per SAMPLE hash looks it up in a directory
+ * of the database's distinct hashes, so the work is proportional to |S| instead of streaming every
+ * reference hash.  Same results as yh_overlap_device / yh_run_device.                          */
+int yh_overlap_indexed_device(yh_db* db, const uint64_t* d_sample, uint64_t n_sample, uint32_t* d_overlap);
+int yh_run_indexed_device(yh_db* db, const uint64_t* d_sample, uint64_t n_sample,
+                          uint32_t* d_overlap, uint32_t* d_n_excl, uint32_t* d_n_match);
 
 /* ---- yacht run, step 2: exclusive hashes relative to a subset ----------------------------
  * For every j with subset_mask[j] != 0:

@@ -24,6 +24,7 @@ YH_ERR_UNSUPPORTED = -7
 YH_DB_DEFAULT = 0
 YH_DB_NO_INDEX = 1
 YH_DB_KEEP_CSR = 2
+YH_DB_FULL_INDEX = 4
 
 _ERR_NAMES = {
     YH_ERR_INVALID_ARG: "YH_ERR_INVALID_ARG",
@@ -88,6 +89,8 @@ SIGNATURES = {
     "yh_overlap_device": (C.c_int, [_vp, _vp, C.c_uint64, _vp]),
     "yh_overlap_bsearch": (C.c_int, [_vp, _vp, C.c_uint64, _vp]),
     "yh_overlap_bsearch_device": (C.c_int, [_vp, _vp, C.c_uint64, _vp]),
+    "yh_overlap_indexed_device": (C.c_int, [_vp, _vp, C.c_uint64, _vp]),
+    "yh_run_indexed_device": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp, _vp]),
     "yh_exclusive": (C.c_int, [_vp, _vp, _vp, C.c_uint64, _vp, _vp]),
     "yh_run": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp, _vp]),
     "yh_run_device": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp, _vp]),

@@ -315,7 +315,7 @@ int yh_db_destroy(yh_db* db) {
     if (db->device >= 0) (void)hipSetDevice(db->device);
     if (db->stream) (void)hipStreamSynchronize(db->stream);
     void* ptrs[] = {db->d_values, db->d_offsets, db->d_pvals, db->d_pbeg, db->d_pcnt, db->d_poffs, db->d_sizes,
-                    db->d_g, db->d_po, db->d_pr, db->d_pg, db->d_gbeg, db->d_gcnt, db->d_nshared, db->d_pq, db->d_pq_count, db->d_sbounds,
+                    db->d_g, db->d_po, db->d_pr, db->d_pg, db->d_gbeg, db->d_gcnt, db->d_nshared, db->d_pq, db->d_pq_count, db->d_dh, db->d_dref, db->d_dir, db->d_sbounds,
                     db->d_mask, db->d_maskbits, db->d_hit, db->d_excl_e, db->d_overlap_tmp,
                     db->d_sample_tmp, db->d_flag, db->d_hitq, db->d_hitq_cnt, db->d_reps};
     for (void* p : ptrs)
@@ -382,6 +382,23 @@ int yh_overlap_device(yh_db* db, const uint64_t* d_sample, uint64_t n_sample, ui
     if (!d_overlap || (n_sample && !d_sample)) { yh_set_error("null device pointer"); return YH_ERR_INVALID_ARG; }
     YH_TRY(db_select(db));
     return yh_q_overlap(db, (const u64*)d_sample, n_sample, d_overlap, false, false);
+}
+
+int yh_overlap_indexed_device(yh_db* db, const uint64_t* d_sample, uint64_t n_sample, uint32_t* d_overlap) {
+    if (!db_ok(db)) return YH_ERR_INVALID_ARG;
+    if (!d_overlap || (n_sample && !d_sample)) { yh_set_error("null device pointer"); return YH_ERR_INVALID_ARG; }
+    YH_TRY(db_select(db));
+    return yh_q_overlap_indexed(db, (const u64*)d_sample, n_sample, d_overlap, false);
+}
+
+int yh_run_indexed_device(yh_db* db, const uint64_t* d_sample, uint64_t n_sample, uint32_t* d_overlap,
+                          uint32_t* d_n_excl, uint32_t* d_n_match) {
+    if (!db_ok(db)) return YH_ERR_INVALID_ARG;
+    if (!d_overlap || !d_n_excl || !d_n_match || (n_sample && !d_sample)) { yh_set_error("null device pointer"); return YH_ERR_INVALID_ARG; }
+    YH_TRY(db_select(db));
+    YH_TRY(yh_q_overlap_indexed(db, (const u64*)d_sample, n_sample, d_overlap, true));
+    return yh_q_exclusive(db, db->d_mask, (const u64*)d_sample, n_sample, d_overlap, d_n_excl, d_n_match, true,
+                          db->d_maskbits);
 }
 
 int yh_overlap_bsearch_device(yh_db* db, const uint64_t* d_sample, uint64_t n_sample, uint32_t* d_overlap) {

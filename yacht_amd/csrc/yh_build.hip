@@ -226,10 +226,13 @@ __global__ void __launch_bounds__(IDX_THREADS) k_idx_emit(const u64* __restrict_
                                                           u64 n, const u64* __restrict__ bases,
                                                           u64* __restrict__ g, u64* __restrict__ po,
                                                           u32* __restrict__ pr, u32* __restrict__ pg,
-                                                          u32* __restrict__ nshared) {
+                                                          u32* __restrict__ nshared,
+                                                          u64* __restrict__ dh, u32* __restrict__ dref) {
+    // dh/dref (optional): every DISTINCT hash ascending, with its single holder, or
+    // 0x80000000 | (index into g) when several references hold it
     __shared__ u32 lds[17];
     const u64 base = (u64)blockIdx.x * IDX_BLOCK + (u64)threadIdx.x * IDX_ITEMS;
-    u32 nh = 0, ns = 0;
+    u32 nh = 0, ns = 0, nd = 0;
     u32 fl[IDX_ITEMS];
 #pragma unroll
     for (int it = 0; it < IDX_ITEMS; ++it) {
@@ -237,15 +240,18 @@ __global__ void __launch_bounds__(IDX_THREADS) k_idx_emit(const u64* __restrict_
         u32 f = 0;
         if (i < n) {
             const IdxFlags x = idx_flags(sk, n, i);
-            f = (x.shared ? 1u : 0u) | ((x.shared && x.head) ? 2u : 0u);
+            f = (x.shared ? 1u : 0u) | ((x.shared && x.head) ? 2u : 0u) | (x.head ? 4u : 0u);
         }
         fl[it] = f;
         ns += f & 1u;
         nh += (f >> 1) & 1u;
+        nd += (f >> 2) & 1u;
     }
     u32 tot;
     const u32 exh = block_excl_scan(nh, &tot, lds);
     const u32 exs = block_excl_scan(ns, &tot, lds);
+    const u32 exd = dh ? block_excl_scan(nd, &tot, lds) : 0u;
+    u64 di = bases[(u64)blockIdx.x * 3 + 0] + exd;  // distinct hashes before this thread's items
     u64 gi = bases[(u64)blockIdx.x * 3 + 1] + exh;  // shared heads before this thread's items
     u64 mi = bases[(u64)blockIdx.x * 3 + 2] + exs;  // shared elements before this thread's items
 #pragma unroll
@@ -257,6 +263,11 @@ __global__ void __launch_bounds__(IDX_THREADS) k_idx_emit(const u64* __restrict_
             po[gi] = mi;
             ++gi;
         }
+        if (dh && (f & 4u)) {
+            dh[di] = sk[i];
+            dref[di] = (f & 2u) ? (0x80000000u | (u32)(gi - 1)) : sv[i];
+            ++di;
+        }
         if (f & 1u) {
             const u32 r = sv[i];
             pr[mi] = r;
@@ -264,6 +275,17 @@ __global__ void __launch_bounds__(IDX_THREADS) k_idx_emit(const u64* __restrict_
             atomicAdd(&nshared[r], 1u);
             ++mi;
         }
+    }
+}
+
+// Directory over the distinct hashes: dir[b] = first index whose bucket (hash >> dshift) is >= b.
+__global__ void k_dir_build(const u64* __restrict__ dh, u64 D, u32 dshift, u32 NB, u32* __restrict__ dir) {
+    for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < D; i += (u64)gridDim.x * blockDim.x) {
+        const u64 b = dh[i] >> dshift;
+        const long long bp = i ? (long long)(dh[i - 1] >> dshift) : -1;
+        for (long long x = bp + 1; x <= (long long)b; ++x) dir[x] = (u32)i;
+        if (i == D - 1)
+            for (u64 x = b + 1; x <= NB; ++x) dir[x] = (u32)D;
     }
 }
 
@@ -500,8 +522,27 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, const u
     if (rc == YH_OK) rc = yh_dmalloc(db, (void**)&db->d_pq_count, EXCL_QBLOCKS * sizeof(u32));
     if (rc == YH_OK) {
         IDX_HIP(hipMemsetAsync(db->d_g, 0, std::max<u64>(db->n_shared, 2) * sizeof(u64), st));
-        k_idx_emit<<<(u32)nb, IDX_THREADS, 0, st>>>(d_sk, d_sv, H, d_bases, db->d_g, db->d_po, db->d_pr, db->d_pg,
-                                                    db->d_nshared);
+        const bool full = (db->flags & YH_DB_FULL_INDEX) != 0;
+        if (full) {
+            if (db->n_distinct > 0x7ffffff0ull) { yh_set_error("more than 2^31 distinct hashes"); rc = YH_ERR_UNSUPPORTED; }
+            // ~4 distinct hashes per directory bucket
+            u32 lg = 4;
+            while (lg < 30 && (4ull << lg) < db->n_distinct) ++lg;
+            unsigned bits = 1;
+            while (bits < 64 && (db->max_hash >> bits) != 0) ++bits;
+            db->dir_shift = bits > lg ? bits - lg : 0;
+            db->dir_nb = (u32)((db->max_hash >> db->dir_shift) + 1);
+            if (rc == YH_OK) rc = yh_dmalloc(db, (void**)&db->d_dh, std::max<u64>(db->n_distinct, 2) * sizeof(u64));
+            if (rc == YH_OK) rc = yh_dmalloc(db, (void**)&db->d_dref, std::max<u64>(db->n_distinct, 2) * sizeof(u32));
+            if (rc == YH_OK) rc = yh_dmalloc(db, (void**)&db->d_dir, ((u64)db->dir_nb + 2) * sizeof(u32));
+        }
+        if (rc == YH_OK)
+            k_idx_emit<<<(u32)nb, IDX_THREADS, 0, st>>>(d_sk, d_sv, H, d_bases, db->d_g, db->d_po, db->d_pr, db->d_pg,
+                                                        db->d_nshared, full ? db->d_dh : nullptr,
+                                                        full ? db->d_dref : nullptr);
+        if (rc == YH_OK && full)
+            k_dir_build<<<grid_for(db->n_distinct, 256), 256, 0, st>>>(db->d_dh, db->n_distinct, db->dir_shift, db->dir_nb,
+                                                                       db->d_dir);
         IDX_HIP(hipGetLastError());
         IDX_HIP(hipMemcpyAsync(db->d_po + db->n_shared, &db->n_postings, sizeof(u64), hipMemcpyHostToDevice, st));
         if (db->n_shared) {

@@ -130,6 +130,12 @@ struct yh_db {
     u64* d_gbeg = nullptr;   // [P]   first shared hash of partition p in d_g
     u64* d_gcnt = nullptr;   // [P]
     u32* d_nshared = nullptr;  // [N] number of shared hashes in reference j
+
+    // full distinct-hash directory (only with YH_DB_FULL_INDEX): the sample-driven overlap path
+    u64* d_dh = nullptr;       // [D] every distinct hash, ascending
+    u32* d_dref = nullptr;     // [D] its single holder, or 0x80000000 | index into d_g
+    u32* d_dir = nullptr;      // [dir_nb + 1] first index of d_dh whose (hash >> dir_shift) >= bucket
+    u32 dir_shift = 0, dir_nb = 0;
     u32* d_pq = nullptr;       // [postings] queue of postings that belong to masked references (per query)
     u32* d_pq_count = nullptr; // [EXCL_QBLOCKS] fill of each workgroup's queue segment
 
@@ -174,6 +180,7 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, const u
 // ---- implemented in yh_query.hip -------------------------------------------------------------
 int yh_q_overlap(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap, bool flag_shared, bool make_mask);
 int yh_q_overlap_bsearch(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap);
+int yh_q_overlap_indexed(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap, bool for_exclusive);
 int yh_q_exclusive(yh_db* db, const u8* d_mask, const u64* d_sample, u64 n_sample,
                    const u32* d_overlap, u32* d_excl, u32* d_match, bool hit_ready, const u32* d_maskbits);
 int yh_q_exclusive_partial(yh_db* db, const u8* d_mask, const u64* d_sample, u64 n_sample, u32* d_ex_e, u32* d_ex_m,

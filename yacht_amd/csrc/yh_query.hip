@@ -440,6 +440,41 @@ __global__ void __launch_bounds__(256) k_overlap_bsearch(const u64* __restrict__
     }
 }
 
+// ---- sample-driven overlap through the distinct-hash directory (YH_DB_FULL_INDEX) ----------------
+// One lane per SAMPLE hash: directory bucket -> a short ascending scan of the distinct hashes ->
+// its holder (or the posting list of a shared hash) -> replicated counters.  Work is proportional
+// to |S|, not to the database: ~3 dependent memory round trips per sample hash instead of
+// streaming every reference hash.  Also flags the shared hashes found (hit[], for R2).
+__global__ void __launch_bounds__(256) k_index_lookup(const u64* __restrict__ sample, u64 n,
+                                                      const u64* __restrict__ dh, const u32* __restrict__ dref,
+                                                      const u32* __restrict__ dir, u32 dshift, u32 NB,
+                                                      const u64* __restrict__ po, const u32* __restrict__ pr,
+                                                      u32* __restrict__ reps, u32 rep_mask, u64 n_refs,
+                                                      u8* __restrict__ hit) {
+    u32* my = reps + (u64)(blockIdx.x & rep_mask) * n_refs;
+    for (u64 t = blockIdx.x * (u64)blockDim.x + threadIdx.x; t < n; t += (u64)gridDim.x * blockDim.x) {
+        const u64 h = sample[t];
+        const u64 b = h >> dshift;
+        if (b >= NB) continue;  // above the database's largest hash
+        u32 i = dir[b];
+        const u32 e = dir[b + 1];
+        u64 v = 0;
+        for (; i < e; ++i) {
+            v = dh[i];
+            if (v >= h) break;
+        }
+        if (i >= e || v != h) continue;
+        const u32 r = dref[i];
+        if (!(r & 0x80000000u)) {
+            atomicAdd(&my[r], 1u);
+        } else {
+            const u32 gi = r & 0x7fffffffu;
+            if (hit) hit[gi] = 1;
+            for (u64 q = po[gi], qe = po[gi + 1]; q < qe; ++q) atomicAdd(&my[pr[q]], 1u);
+        }
+    }
+}
+
 // ---- exclusive counts -----------------------------------------------------------------------------
 __global__ void k_mask_from_overlap(const u32* __restrict__ ov, u64 n, u8* __restrict__ mask) {
     const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
@@ -750,6 +785,44 @@ int yh_q_overlap(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap, b
     k_resolve_hits<<<wgs, 256, 0, st>>>(db->d_hitq_cnt, hit);
     k_reduce_replicas<<<(u32)((N + 255) / 256), 256, 0, st>>>(db->d_reps, R, N, d_overlap, make_mask ? db->d_mask : nullptr,
                                                              make_mask ? db->d_maskbits : nullptr);
+    YH_HIP(hipGetLastError());
+    return YH_OK;
+}
+
+// overlap (and, with for_exclusive, the shared-hash flags, the subset mask and zeroed exclusive
+// accumulators) through the directory; same outputs as yh_q_overlap(..., flag_shared, make_mask)
+int yh_q_overlap_indexed(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap, bool for_exclusive) {
+    if (!(db->flags & YH_DB_FULL_INDEX) || !db->has_index) {
+        yh_set_error("this handle was created without YH_DB_FULL_INDEX");
+        return YH_ERR_UNSUPPORTED;
+    }
+    hipStream_t st = db->stream;
+    const u64 N = db->n_refs;
+    if (N == 0) return YH_OK;
+    u32 R = 32;
+    while (R > 1 && (u64)R * N > (2u << 20)) R >>= 1;
+    if (db->reps_cap < (u64)R * N) {
+        YH_HIP(hipStreamSynchronize(st));
+        if (db->d_reps) { (void)hipFree(db->d_reps); db->d_reps = nullptr; db->reps_cap = 0; }
+        YH_HIP(hipMalloc((void**)&db->d_reps, (u64)R * N * sizeof(u32) + 16));
+        db->reps_cap = (u64)R * N;
+    }
+    ZeroList z{};
+    z.p[0] = reinterpret_cast<uint4*>(db->d_reps);
+    z.n16[0] = ((u64)R * N * sizeof(u32) + 15) / 16;
+    if (for_exclusive && db->n_shared) { z.p[1] = reinterpret_cast<uint4*>(db->d_hit); z.n16[1] = (db->n_shared + 15) / 16; }
+    if (for_exclusive) { z.p[2] = reinterpret_cast<uint4*>(db->d_excl_e); z.n16[2] = (3 * N * sizeof(u32) + 15) / 16; }
+    k_prep<<<1024, 256, 0, st>>>(d_sample, (u32)0, 0u, db->pshift, db->d_sbounds, z);
+    yh_ring_record_begin(db, db->ev_overlap);
+    if (n_sample && db->n_distinct)
+        k_index_lookup<<<grid_for(n_sample, 256, 4096), 256, 0, st>>>(d_sample, n_sample, db->d_dh, db->d_dref, db->d_dir,
+                                                                      db->dir_shift, db->dir_nb, db->d_po, db->d_pr,
+                                                                      db->d_reps, R - 1, N,
+                                                                      (for_exclusive && db->n_shared) ? db->d_hit : nullptr);
+    yh_ring_record_end(db, db->ev_overlap);
+    k_reduce_replicas<<<(u32)((N + 255) / 256), 256, 0, st>>>(db->d_reps, R, N, d_overlap,
+                                                             for_exclusive ? db->d_mask : nullptr,
+                                                             for_exclusive ? db->d_maskbits : nullptr);
     YH_HIP(hipGetLastError());
     return YH_OK;
 }

@@ -17,7 +17,7 @@ from typing import Optional, Sequence, Tuple
 import numpy as np
 
 from . import _lib
-from ._lib import YH_DB_DEFAULT, YH_DB_KEEP_CSR, YH_DB_NO_INDEX, YachtHipError  # noqa: F401
+from ._lib import YH_DB_DEFAULT, YH_DB_FULL_INDEX, YH_DB_KEEP_CSR, YH_DB_NO_INDEX, YachtHipError  # noqa: F401
 
 
 def pack_csr(sketches: Sequence[np.ndarray]) -> Tuple[np.ndarray, np.ndarray]:
@@ -188,6 +188,13 @@ class RefDB:
     def overlap_bsearch_device(self, d_sample: int, n_sample: int, d_overlap: int) -> None:
         _lib.check(self._lib.yh_overlap_bsearch_device(self._h, C.c_void_p(d_sample), n_sample,
                                                        C.c_void_p(d_overlap)))
+
+    def overlap_indexed_device(self, d_sample: int, n_sample: int, d_overlap: int) -> None:
+        _lib.check(self._lib.yh_overlap_indexed_device(self._h, C.c_void_p(d_sample), n_sample, C.c_void_p(d_overlap)))
+
+    def run_indexed_device(self, d_sample: int, n_sample: int, d_overlap: int, d_excl: int, d_match: int) -> None:
+        _lib.check(self._lib.yh_run_indexed_device(self._h, C.c_void_p(d_sample), n_sample, C.c_void_p(d_overlap),
+                                                   C.c_void_p(d_excl), C.c_void_p(d_match)))
 
     def run_device(self, d_sample: int, n_sample: int, d_overlap: int, d_excl: int = 0, d_match: int = 0) -> None:
         _lib.check(self._lib.yh_run_device(self._h, C.c_void_p(d_sample), n_sample, C.c_void_p(d_overlap),
