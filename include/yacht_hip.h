@@ -185,6 +185,17 @@ int yh_train_select(const uint32_t* sizes, uint64_t n_refs,
                     const uint32_t* pair_i, const uint32_t* pair_j, uint64_t n_pairs,
                     uint32_t* selected, uint64_t* n_selected);
 
+/* ---- sketching (next to the path: SURVEY.md §8f N2) --------------------------------------------
+ * DNA FracMinHash as `sourmash sketch dna -p k=K,scaled=S,abund` defines it (the reference shells
+ * out to it: sketch_ref_genomes.py:25,61, sketch_sample.py:32,49): every length-`ksize` window of
+ * `seq` made only of A/C/G/T (either case; any other byte, e.g. a record separator, breaks the
+ * window) -> canonical k-mer -> first 64 bits of MurmurHash3_x64_128 with `seed` (sourmash: 42)
+ * -> kept iff <= max_hash (sourmash: floor((2^64-1)/scaled)).  hashes_out receives the kept
+ * hashes unsorted WITH duplicates (sort + count them for mins/abundances); *n_out their number;
+ * YH_ERR_CAPACITY (with *n_out set) when cap is too small, cap = 0 only counts.               */
+int yh_sketch_dna(const uint8_t* seq, uint64_t n_bytes, int ksize, uint64_t seed, uint64_t max_hash,
+                  int device_id, uint64_t cap, uint64_t* hashes_out, uint64_t* n_out);
+
 #ifdef __cplusplus
 }
 #endif

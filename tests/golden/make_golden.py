@@ -231,7 +231,8 @@ def copy_fixtures() -> None:
     os.makedirs(fx, exist_ok=True)
     for rel in ("tests/testdata/20_genomes_sketches.zip", "tests/testdata/sample.sig.zip",
                 "tests/testdata_bug_YAC13/extract_empty_hash.sig.zip",
-                "tests/unittests_data/test_collect_signature_info_data.json"):
+                "tests/unittests_data/test_collect_signature_info_data.json",
+                "demo/ref_genomes/GCF_018918235.1_genomic.fna.gz", "demo/ref_genomes/GCF_018918045.1_genomic.fna.gz"):
         dst = os.path.join(fx, os.path.basename(rel))
         shutil.copyfile(os.path.join(REF, rel), dst)
         os.chmod(dst, 0o644)

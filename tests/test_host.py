@@ -163,7 +163,9 @@ def test_cli_parsers_and_error_paths(tmp_path):
     assert (a.num_threads, a.ani_thresh, a.prefix, a.force) == (16, 0.95, "yacht", False)
     r = p.parse_args(["run", "--json", "c.json", "--sample_file", "s.sig.zip"])
     assert r.min_coverage_list == [1, 0.5, 0.1, 0.05, 0.01] and r.significance == 0.99
-    assert cli.main(["sketch", "ref"]) == 2
+    assert cli.main(["download", "demo"]) == 2
+    k = p.parse_args(["sketch", "ref", "--infile", "g.fa", "--outfile", "o.zip"])
+    assert (k.kmer, k.scaled) == (31, 1000)
     # reference behaviour (tests/test_make_training_data_from_sketches.py): a non-zip reference file is rejected
     bad = p.parse_args(["train", "--ref_file", str(tmp_path / "refs.sig"), "--ksize", "31", "--outdir", str(tmp_path)])
     with pytest.raises(ValueError, match="is not a zip file"):

@@ -102,6 +102,8 @@ SIGNATURES = {
     "yh_pairwise": (C.c_int, [_vp, C.c_double, C.c_uint64, C.c_uint64, C.c_uint64, _vp, _vp, _vp,
                               C.POINTER(C.c_uint64)]),
     "yh_index_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "yh_sketch_dna": (C.c_int, [_vp, C.c_uint64, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_uint64, _vp,
+                                C.POINTER(C.c_uint64)]),
     "yh_train_select": (C.c_int, [_vp, C.c_uint64, _vp, _vp, C.c_uint64, _vp, C.POINTER(C.c_uint64)]),
 }
 

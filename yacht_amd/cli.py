@@ -1,7 +1,8 @@
 """`yacht` command line for the hot-path commands: `yacht train` and `yacht run`
 (reference src/yacht/__init__.py:54-136 dispatches the same sub-commands to the same
-add_arguments/main pairs).  The reference's other sub-commands (sketch, download, convert) wrap
-third-party tools or the network and are out of this repository's scope.
+add_arguments/main pairs), plus `yacht sketch ref|sample` on the HIP sketcher.  The reference's
+other sub-commands (download, convert) need the network / NCBI taxonomy tools and are out of this
+repository's scope.
 
     python -m yacht_amd train --ref_file refs.sig.zip --ksize 31 --ani_thresh 0.95 --prefix db --outdir out
     python -m yacht_amd run --json out/db_config.json --sample_file sample.sig.zip --min_coverage_list 1 0.1 --outdir out
@@ -11,10 +12,10 @@ from __future__ import annotations
 import argparse
 import sys
 
-from . import make_training_data_from_sketches, run_YACHT
+from . import make_training_data_from_sketches, run_YACHT, sketch
 from .utils import __version__
 
-OUT_OF_SCOPE = ("sketch", "download", "convert")
+OUT_OF_SCOPE = ("download", "convert")
 
 
 def build_parser() -> argparse.ArgumentParser:
@@ -29,6 +30,14 @@ def build_parser() -> argparse.ArgumentParser:
                          formatter_class=argparse.ArgumentDefaultsHelpFormatter)
     run_YACHT.add_arguments(run)
     run.set_defaults(func=run_YACHT.main)
+    sk = sub.add_parser("sketch", description="Sketch genomes or a sample (DNA FracMinHash, sourmash format)")
+    sk_sub = sk.add_subparsers(dest="sketch_command")
+    ref = sk_sub.add_parser("ref", description="Sketch reference genomes")
+    sketch.add_ref_arguments(ref)
+    ref.set_defaults(func=sketch.main_ref)
+    smp = sk_sub.add_parser("sample", description="Sketch a metagenomic sample")
+    sketch.add_sample_arguments(smp)
+    smp.set_defaults(func=sketch.main_sample)
     for name in OUT_OF_SCOPE:
         sub.add_parser(name, add_help=False)
     return parser
