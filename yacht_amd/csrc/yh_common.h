@@ -188,7 +188,6 @@ int yh_q_exclusive_partial(yh_db* db, const u8* d_mask, const u64* d_sample, u64
 int yh_q_exclusive_final(yh_db* db, u64 n, const u8* d_mask, const u32* d_sizes, const u32* d_nshared,
                          const u32* d_overlap, const u32* d_ex_e, const u32* d_ex_m, const u32* d_ovsh, u32* d_excl,
                          u32* d_match);
-int yh_q_mask_from_overlap(yh_db* db, const u32* d_overlap, u8* d_mask);
 int yh_q_pairwise(yh_db* db, double c_thresh, u64 r0, u64 r1);
 int yh_q_check_sorted_host(const u64* v, u64 n);
 

@@ -1,15 +1,22 @@
 // yh_query.hip — the per-query kernels of libyacht_hip.so (gfx950 / CDNA4, wave64).
 //
-//   k_tile_lookup      the streaming membership kernel (HBM-bound; DESIGN.md "K1").  Each workgroup
-//                      stages one hash-range slice of the SAMPLE in LDS (sorted hashes + a bucket
-//                      directory) and streams a contiguous chunk of reference hashes of the same
-//                      range past it with 16-byte coalesced loads.
-//   k_overlap_bsearch  one wave per reference, lanes binary-search the sample in L2; the
-//                      independent cross-check and the A/B baseline for K1.
+//   k_prep             sample slice bounds per partition + zeroing of every accumulator of a step
+//   k_tile_lookup      the streaming membership kernel (HBM-bound; DESIGN.md "K1"): each workgroup
+//                      stages one hash-range slice of the SAMPLE in LDS (bitmap + sorted hashes +
+//                      bucket directory) and streams reference hashes of the same range past it
+//                      with 16-byte coalesced loads; hits are queued, not resolved
+//   k_resolve_hits     queued hit positions -> references -> replicated counters
+//   k_reduce_replicas  overlap counts (+ the subset mask as bytes and bits)
+//   k_index_lookup     sample-driven alternative to k_tile_lookup (YH_DB_FULL_INDEX)
+//   k_overlap_bsearch  one wave per reference, lanes binary-search the sample in L2: independent
+//                      cross-check and A/B baseline
 //   k_excl_*           subset-exclusive hash counts from the shared-hash posting lists
-//                      (the arithmetic of hypothesis_recovery_src.py:165-204).
+//                      (the arithmetic of hypothesis_recovery_src.py:165-204)
 //   k_pair_*           pairwise intersection counts from the posting lists into a dense row block,
-//                      threshold filter and ordered compaction (src/cpp/main.cpp:249-308).
+//                      threshold filter and ordered compaction (src/cpp/main.cpp:249-308)
+//
+// Timing-only ablation builds (-DYH_ABLATE=1|2|3, see build.py build_variant) compile parts of
+// k_tile_lookup out; their results are wrong by construction and they are never shipped.
 #include "yh_common.h"
 
 #include <stdlib.h>
@@ -389,28 +396,6 @@ k_tile_lookup(const u64* __restrict__ vals,     // hash stream, grouped by parti
     }
 }
 
-// sample slice bounds per partition: sbounds[p] = |{s in S : s < p << pshift}|
-__global__ void k_sample_bounds(const u64* __restrict__ sample, u32 n, u32 P, u32 pshift, u32* __restrict__ sb) {
-    const u32 p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p > P) return;
-    // Sample hashes at or above P << pshift cannot be in the database and must stay out of the
-    // last partition's tile (their bucket numbers would wrap), so sb[P] is a real bound too.
-    const bool wraps = (pshift > 0) && (((u64)p >> (64 - pshift)) != 0);  // p << pshift >= 2^64
-    u32 r;
-    if (p == 0) r = 0;
-    else if (wraps) r = n;
-    else {
-        const u64 key = (u64)p << pshift;
-        u32 lo = 0, hi = n;
-        while (lo < hi) {
-            const u32 mid = (lo + hi) >> 1;
-            if (sample[mid] < key) lo = mid + 1; else hi = mid;
-        }
-        r = lo;
-    }
-    sb[p] = r;
-}
-
 // ---- cross-check kernel: one wave per reference over the plain CSR -------------------------------
 __global__ void __launch_bounds__(256) k_overlap_bsearch(const u64* __restrict__ values,
                                                          const u64* __restrict__ offsets, u64 n_refs,
@@ -476,11 +461,6 @@ __global__ void __launch_bounds__(256) k_index_lookup(const u64* __restrict__ sa
 }
 
 // ---- exclusive counts -----------------------------------------------------------------------------
-__global__ void k_mask_from_overlap(const u32* __restrict__ ov, u64 n, u8* __restrict__ mask) {
-    const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
-    if (i < n) mask[i] = ov[i] ? 1 : 0;
-}
-
 // Exclusive sums from the posting lists, in two launches.
 //
 // k_excl_collect: one coalesced pass over pr[] (four postings per lane per step, mask probes as
@@ -839,14 +819,6 @@ int yh_q_overlap_bsearch(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_ov
     return YH_OK;
 }
 
-int yh_q_mask_from_overlap(yh_db* db, const u32* d_overlap, u8* d_mask) {
-    const u64 N = db->n_refs;
-    if (N == 0) return YH_OK;
-    k_mask_from_overlap<<<grid_for(N, 256, 1u << 22), 256, 0, db->stream>>>(d_overlap, N, d_mask);
-    YH_HIP(hipGetLastError());
-    return YH_OK;
-}
-
 // d_overlap must hold the overlap of the SAME sample (yh_q_overlap output).
 // Partial exclusive sums of this handle's posting lists for an arbitrary mask over ITS reference
 // numbering: ex_e / ex_m / ovsh (see k_excl_postings).  `own_bounds`: compute the sample's slice
@@ -873,7 +845,7 @@ int yh_q_exclusive_partial(yh_db* db, const u8* d_mask, const u64* d_sample, u64
         if (n_sample && !hit_ready) {
             const u32 P = db->n_parts;
             if (own_bounds)
-                k_sample_bounds<<<(P + 1 + 255) / 256, 256, 0, st>>>(d_sample, (u32)n_sample, P, db->pshift, db->d_sbounds);
+                k_prep<<<(P + 1 + 255) / 256, 256, 0, st>>>(d_sample, (u32)n_sample, P, db->pshift, db->d_sbounds, ZeroList{});
             // membership of every shared hash in the sample: the same tile kernel over d_g
             FlagHit fh{db->d_gbeg, db->d_hit};
             k_tile_lookup<FlagHit><<<tile_grid(G), TILE_THREADS, 0, st>>>(
