@@ -93,6 +93,33 @@ def main() -> int:
         cpu = {"value": round(k * (k - 1) / 2 / t_cpu, 1), "unit": "pair-queries/s", "cores": cores, "kind": "port",
                "sample": f"first {k} sketches ({int(o2[-1])} hashes): index build on 1 thread + scatter on {cores} "
                          f"threads + selection, {t_cpu:.2f} s"}
+        # the GENUINE reference executable (oracle/_ref, built from /root/reference/src/cpp/main.cpp in the
+        # build container and shipped as a binary): timed on the same sketches, and its files compared
+        # with the HIP path's results
+        if oracle.have_ref_exe():
+            import re
+            import tempfile
+
+            from yacht_amd.train_core import format_pair_line
+
+            refs2 = [v2[int(o2[j]):int(o2[j + 1])] for j in range(k)]
+            with tempfile.TemporaryDirectory() as d:
+                t0 = time.perf_counter()
+                rsel, rlines, rout = oracle.run_ref_exe(refs2, c, d, threads=min(cores, 64))
+                t_ref = time.perf_counter() - t0
+            phases = {m.group(1): int(m.group(2)) for m in re.finditer(r"Time taken to ([a-z ]+): (\d+) milliseconds", rout)}
+            core_s = sum(phases.get(x, 0) for x in ("build index", "compute intersection matrix", "do yacht train")) / 1e3
+            glines = [format_pair_line(int(i), int(j), int(cc), int(s2[i]), int(s2[j])) for i, j, cc in zip(gi, gj, gc)]
+            same = bool(rsel == gsel.tolist() and rlines == glines)
+            parity = parity and same
+            cpu = {"value": round(k * (k - 1) / 2 / core_s, 1), "unit": "pair-queries/s", "cores": min(cores, 64),
+                   "kind": "reference",
+                   "sample": f"reference run_yacht_train_core -t {min(cores, 64)} on the first {k} sketches: index "
+                             f"{phases.get('build index', 0)} ms + matrix {phases.get('compute intersection matrix', 0)} ms "
+                             f"+ selection {phases.get('do yacht train', 0)} ms (file reading {phases.get('read all sketches', 0)} ms "
+                             f"not counted; whole process incl. writing the JSON inputs {t_ref:.1f} s)",
+                   "outputs_equal_hip_path": same,
+                   "port_value": round(k * (k - 1) / 2 / t_cpu, 1)}
 
     # algorithmic bytes: every reference hash once + one (i, j, count) per emitted pair
     alg = 8 * int(offsets[-1]) + 12 * int(pi.size)

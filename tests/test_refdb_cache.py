@@ -1,0 +1,55 @@
+"""The packed reference set written by `yacht train` and memory-mapped by `yacht run`."""
+import glob
+import json
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+from yacht_amd import refdb_cache
+
+FX = os.path.join(os.path.dirname(__file__), "golden", "fixtures")
+
+
+def test_cache_roundtrip_and_keying(tmp_path):
+    values = np.arange(10, dtype=np.uint64)
+    offsets = np.array([0, 3, 3, 10], dtype=np.uint64)
+    md5s = ["a", "b", "c"]
+    assert refdb_cache.save(str(tmp_path), md5s, 31, values, offsets)
+    v, o = refdb_cache.load(str(tmp_path), md5s, 31)
+    assert isinstance(v, np.memmap) and np.array_equal(v, values) and np.array_equal(o, offsets)
+    assert refdb_cache.load(str(tmp_path), md5s, 21) is None            # other k-mer size
+    assert refdb_cache.load(str(tmp_path), ["a", "c", "b"], 31) is None  # other row order
+    assert refdb_cache.load(str(tmp_path / "nope"), md5s, 31) is None
+    sv, so = refdb_cache.subset(values, offsets, [2, 0])
+    assert sv.tolist() == [3, 4, 5, 6, 7, 8, 9, 0, 1, 2] and so.tolist() == [0, 7, 10]
+
+
+@pytest.mark.gpu
+def test_run_uses_the_packed_db_not_the_sig_files(hip_lib, tmp_path):
+    """After `yacht train`, `yacht run` works with the signature JSON files gone: it reads the
+    packed arrays only."""
+    import pandas as pd
+
+    from yacht_amd import cli
+
+    out = tmp_path / "out"
+    out.mkdir()
+    ref_zip, sample_zip = tmp_path / "refs.zip", tmp_path / "sample.sig.zip"
+    shutil.copyfile(os.path.join(FX, "20_genomes_sketches.zip"), ref_zip)
+    shutil.copyfile(os.path.join(FX, "sample.sig.zip"), sample_zip)
+    assert cli.main(["train", "--ref_file", str(ref_zip), "--ksize", "31", "--prefix", "db", "--outdir", str(out),
+                     "--num_threads", "1"]) == 0
+    work = out / "db_intermediate_files"
+    meta = json.load(open(work / refdb_cache.DIR_NAME / "meta.json"))
+    man = pd.read_csv(out / "db_processed_manifest.tsv", sep="\t")
+    assert meta["md5sums"] == man["md5sum"].to_list() and meta["ksize"] == 31
+    offsets = np.load(work / refdb_cache.DIR_NAME / "offsets.npy")
+    assert np.diff(offsets).tolist() == man["num_unique_kmers_in_genome_sketch"].to_list()
+    for f in glob.glob(str(work / "signatures" / "*.sig")):
+        os.remove(f)
+    assert cli.main(["run", "--json", str(out / "db_config.json"), "--sample_file", str(sample_zip),
+                     "--min_coverage_list", "0.001", "--outdir", str(tmp_path), "--num_threads", "1"]) == 0
+    res = pd.read_csv(tmp_path / "results" / "result_all.txt", sep="\t")
+    assert len(res) == 1 and int(res["num_matches"].iloc[0]) == 2 and bool(res["in_sample_est"].iloc[0])

@@ -8,8 +8,8 @@ src/yacht/hypothesis_recovery_src.py, same function names / arguments / return s
   hypothesis_recovery                  (reference :309-417) same orchestration and result columns
 
 The reference re-opens every reference .sig three times per run (multisearch, then twice in
-get_exclusive_hashes); here the selected references are packed once into a RefDB (cached next to
-the training output as `yacht_hip_db.npz`) and stay resident in HBM for both steps.
+get_exclusive_hashes); here the selected references come packed (refdb_cache: written by `yacht train`,
+memory-mapped here) and stay resident in HBM as one RefDB for both steps.
 """
 from __future__ import annotations
 
@@ -27,14 +27,14 @@ import pandas as pd
 from scipy.special import betaincinv
 from scipy.stats import binom
 
-from . import sigio
+from . import refdb_cache, sigio
 from .engine import RefDB, pack_csr
 from .utils import decompress_all_sig_files, logger
 
 warnings.filterwarnings("ignore")
 
 SIG_SUFFIX = ".sig"
-DB_CACHE_NAME = "yacht_hip_db.npz"
+DB_CACHE_NAME = refdb_cache.DIR_NAME
 
 GIVEN_COLUMNS = [
     "in_sample_est",
@@ -57,16 +57,12 @@ def _read_mins(path: str) -> np.ndarray:
 
 
 def load_reference_csr(md5sums: List[str], path_to_genome_temp_dir: str, ksize: int, num_threads: int = 1):
-    """(values, offsets) of `{dir}/signatures/{md5}.sig` for every md5, in order.  A packed copy
-    is kept in `{dir}/yacht_hip_db.npz` and reused while the md5 list matches."""
-    cache = os.path.join(path_to_genome_temp_dir, DB_CACHE_NAME)
-    if os.path.exists(cache):
-        try:
-            with np.load(cache, allow_pickle=False) as z:
-                if int(z["ksize"]) == int(ksize) and list(z["md5sums"]) == list(md5sums):
-                    return z["values"], z["offsets"]
-        except Exception:
-            pass
+    """(values, offsets) of `{dir}/signatures/{md5}.sig` for every md5, in order: the packed copy
+    under `{dir}/yacht_hip_db/` when it matches, else parsed from the signature files (and packed
+    for the next run)."""
+    cached = refdb_cache.load(path_to_genome_temp_dir, md5sums, ksize)
+    if cached is not None:
+        return cached
     paths = [os.path.join(path_to_genome_temp_dir, "signatures", m + SIG_SUFFIX) for m in md5sums]
     if num_threads > 1 and len(paths) > 256:
         with Pool(min(num_threads, os.cpu_count() or 1)) as p:
@@ -75,10 +71,7 @@ def load_reference_csr(md5sums: List[str], path_to_genome_temp_dir: str, ksize: 
         sketches = [_read_mins(p) for p in paths]
     sketches = [s if (s.size < 2 or bool(np.all(s[1:] > s[:-1]))) else np.unique(s) for s in sketches]
     values, offsets = pack_csr(sketches)
-    try:
-        np.savez(cache, values=values, offsets=offsets, md5sums=np.array(md5sums, dtype="U32"), ksize=np.int64(ksize))
-    except OSError:
-        pass  # read-only training directory: just do not cache
+    refdb_cache.save(path_to_genome_temp_dir, md5sums, ksize, values, offsets)
     return values, offsets
 
 

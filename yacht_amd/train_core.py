@@ -108,4 +108,5 @@ def run(file_list: str, working_directory: str, output_filename: str, threads: i
     with open(output_filename, "w") as f:
         for g in selected:
             f.write(paths[int(g)] + "\n")
-    return {"n": n, "empty": empty, "stats": stats, "n_pairs": int(pi.size), "selected": selected.tolist()}
+    return {"n": n, "empty": empty, "stats": stats, "n_pairs": int(pi.size), "selected": selected.tolist(),
+            "paths": paths, "values": values, "offsets": offsets}

@@ -20,7 +20,7 @@ from typing import Dict, List, Optional, Tuple
 import numpy as np
 import pandas as pd
 
-from . import sigio, train_core
+from . import refdb_cache, sigio, train_core
 
 logger = logging.getLogger("yacht_amd")
 if not logger.handlers:
@@ -121,8 +121,8 @@ def run_yacht_train_core(num_threads: int, ani_thresh: float, ksize: int, path_t
     logger.info(f"Running comparison on device {device}: -t {num_threads} -c {containment_thresh} -p {passes} "
                 f"{sig_files_path} {path_to_temp_dir} {selected_path}")
     try:
-        train_core.run(sig_files_path, path_to_temp_dir, selected_path, threads=num_threads, passes=passes,
-                       containment_threshold=containment_thresh, device=device)
+        core = train_core.run(sig_files_path, path_to_temp_dir, selected_path, threads=num_threads, passes=passes,
+                              containment_threshold=containment_thresh, device=device)
     except Exception as exc:  # the reference raises ValueError on a non-zero exit code
         raise ValueError(f"Error running comparison algorithm: {exc}") from exc
 
@@ -138,5 +138,12 @@ def run_yacht_train_core(num_threads: int, ani_thresh: float, ksize: int, path_t
     for name, (md5sum, mean_abund, n_hashes, scaled, _path) in sig_info_dict.items():
         if name in selected_names:
             rows.append((name, md5sum, n_hashes, get_num_kmers(mean_abund, n_hashes, scaled, False), scaled))
-    return pd.DataFrame(rows, columns=["organism_name", "md5sum", "num_unique_kmers_in_genome_sketch",
-                                       "num_total_kmers_in_genome_sketch", "genome_scale_factor"])
+    manifest = pd.DataFrame(rows, columns=["organism_name", "md5sum", "num_unique_kmers_in_genome_sketch",
+                                           "num_total_kmers_in_genome_sketch", "genome_scale_factor"])
+    # the selected sketches, packed in manifest order, for `yacht run` (refdb_cache)
+    row_of_path = {p: i for i, p in enumerate(core["paths"])}
+    name_to_path = {name: info[-1] for name, info in sig_info_dict.items()}
+    keep = [row_of_path[name_to_path[name]] for name in manifest["organism_name"]]
+    values, offsets = refdb_cache.subset(core["values"], core["offsets"], keep)
+    refdb_cache.save(path_to_temp_dir, manifest["md5sum"].to_list(), ksize, values, offsets)
+    return manifest
