@@ -565,19 +565,25 @@ __global__ void k_excl_final(u64 n, const u8* __restrict__ mask, const u32* __re
 }
 
 // ---- pairwise -------------------------------------------------------------------------------------
+// Only references that hold at least one shared hash can be in a pair, so the dense count block is
+// indexed by COMPACT ids (cid[ref], ascending with the reference id; rid[] maps back): a
+// dereplicated database of 85 205 genomes has ~8 000 such references (0.3 GB instead of 29 GB).
+//
 // One thread per posting (a = its reference): for every other reference b of the same hash,
-// M[a - r0][b] += 1.  Integer atomics: the result does not depend on arrival order.
+// M[cid[a] - c0][cid[b]] += 1.  Integer atomics: the result does not depend on arrival order.
 __global__ void k_pair_accum(u64 n_post, const u32* __restrict__ pr, const u32* __restrict__ pg,
-                             const u64* __restrict__ po, u64 r0, u64 r1, u64 n_refs, u32* __restrict__ M) {
+                             const u64* __restrict__ po, const u32* __restrict__ cid, u64 c0, u64 c1, u64 n_c,
+                             u32* __restrict__ M) {
     for (u64 k = blockIdx.x * (u64)blockDim.x + threadIdx.x; k < n_post; k += (u64)gridDim.x * blockDim.x) {
         const u32 a = pr[k];
-        if (a < r0 || a >= r1) continue;
+        const u32 ca = cid[a];
+        if (ca < c0 || ca >= c1) continue;
         const u32 gi = pg[k];
         const u64 b = po[gi], e = po[gi + 1];
-        u32* row = M + (u64)(a - r0) * n_refs;
+        u32* row = M + (u64)(ca - c0) * n_c;
         for (u64 q = b; q < e; ++q) {
             const u32 o = pr[q];
-            if (o != a) atomicAdd(&row[o], 1u);
+            if (o != a) atomicAdd(&row[cid[o]], 1u);
         }
     }
 }
@@ -593,8 +599,8 @@ __device__ __forceinline__ bool pair_keep(u32 cnt, u32 i, u32 j, const u32* __re
 
 // one wave per row: count survivors
 __global__ void __launch_bounds__(256) k_pair_count(const u32* __restrict__ M, u64 r0, u64 r1, u64 n_refs,
-                                                    const u32* __restrict__ sizes, double c_relaxed,
-                                                    u32* __restrict__ rowcnt) {
+                                                    const u32* __restrict__ rid, const u32* __restrict__ sizes,
+                                                    double c_relaxed, u32* __restrict__ rowcnt) {
     const u64 wave = (blockIdx.x * (u64)blockDim.x + threadIdx.x) / WAVE;
     const u64 n_waves = ((u64)gridDim.x * blockDim.x) / WAVE;
     const int lane = threadIdx.x & (WAVE - 1);
@@ -603,7 +609,7 @@ __global__ void __launch_bounds__(256) k_pair_count(const u32* __restrict__ M, u
         u32 c = 0;
         for (u64 j0 = 0; j0 < n_refs; j0 += WAVE) {
             const u64 j = j0 + lane;
-            const bool keep = (j < n_refs) && pair_keep(row[j], (u32)i, (u32)j, sizes, c_relaxed);
+            const bool keep = (j < n_refs) && pair_keep(row[j], rid[i], rid[j], sizes, c_relaxed);
             c += (u32)__popcll(__ballot(keep));
         }
         if (lane == 0) rowcnt[i - r0] = c;
@@ -643,7 +649,8 @@ __global__ void __launch_bounds__(1024) k_scan_u32_to_u64(const u32* __restrict_
 
 // one wave per row: ordered compaction (j ascending inside a row, rows ascending)
 __global__ void __launch_bounds__(256) k_pair_emit(const u32* __restrict__ M, u64 r0, u64 r1, u64 n_refs,
-                                                   const u32* __restrict__ sizes, double c_relaxed,
+                                                   const u32* __restrict__ rid, const u32* __restrict__ sizes,
+                                                   double c_relaxed,
                                                    const u64* __restrict__ rowoff, u32* __restrict__ out_i,
                                                    u32* __restrict__ out_j, u32* __restrict__ out_c) {
     const u64 wave = (blockIdx.x * (u64)blockDim.x + threadIdx.x) / WAVE;
@@ -658,13 +665,13 @@ __global__ void __launch_bounds__(256) k_pair_emit(const u32* __restrict__ M, u6
             bool keep = false;
             if (j < n_refs) {
                 cnt = row[j];
-                keep = pair_keep(cnt, (u32)i, (u32)j, sizes, c_relaxed);
+                keep = pair_keep(cnt, rid[i], rid[j], sizes, c_relaxed);
             }
             const u64 bal = __ballot(keep);
             if (keep) {
                 const u64 dst = w + __popcll(bal & ((1ull << lane) - 1ull));
-                out_i[dst] = (u32)i;
-                out_j[dst] = (u32)j;
+                out_i[dst] = rid[i];
+                out_j[dst] = rid[j];
                 out_c[dst] = cnt;
             }
             w += __popcll(bal);
@@ -905,13 +912,27 @@ int yh_q_pairwise(yh_db* db, double c_thresh, u64 r0, u64 r1) {
     if (r1 > N) r1 = N;
     if (r0 >= r1) { db->pw_valid = true; db->pw_c = c_thresh; db->pw_r0 = r0; db->pw_r1 = r1; return YH_OK; }
 
-    // dense row blocks of at most ~32 GiB of int32 counts
+    // compact ids of the references that hold a shared hash (ascending with the reference id)
+    std::vector<u32> h_nsh(N), h_cid(N), h_rid;
+    YH_HIP(hipMemcpyAsync(h_nsh.data(), db->d_nshared, N * sizeof(u32), hipMemcpyDeviceToHost, st));
+    YH_HIP(hipStreamSynchronize(st));
+    for (u64 j = 0; j < N; ++j) {
+        if (h_nsh[j]) { h_cid[j] = (u32)h_rid.size(); h_rid.push_back((u32)j); }
+        else h_cid[j] = 0xffffffffu;
+    }
+    const u64 NC = h_rid.size();
+    const u64 c_begin = std::lower_bound(h_rid.begin(), h_rid.end(), (u32)r0) - h_rid.begin();
+    const u64 c_end = std::lower_bound(h_rid.begin(), h_rid.end(), (u32)std::min<u64>(r1, 0xffffffffull)) - h_rid.begin();
+    if (NC == 0 || c_begin >= c_end) { db->pw_valid = true; db->pw_c = c_thresh; db->pw_r0 = r0; db->pw_r1 = r1; return YH_OK; }
+
+    // dense row blocks (compact rows x compact columns) of at most ~32 GiB of int32 counts
     const u64 budget = 32ull << 30;
-    u64 rows_per_block = std::max<u64>(1, budget / (N * sizeof(u32)));
-    if (rows_per_block > r1 - r0) rows_per_block = r1 - r0;
+    u64 rows_per_block = std::max<u64>(1, budget / (NC * sizeof(u32)));
+    if (rows_per_block > c_end - c_begin) rows_per_block = c_end - c_begin;
     const double c_relaxed = c_thresh * (1.0 - 1e-9) - 1e-300;
 
     u32 *d_M = nullptr, *d_rowcnt = nullptr, *d_oi = nullptr, *d_oj = nullptr, *d_oc = nullptr;
+    u32 *d_cid = nullptr, *d_rid = nullptr;
     u64* d_rowoff = nullptr;
     std::vector<u32> hi, hj, hc;
     int rc = YH_OK;
@@ -923,20 +944,24 @@ int yh_q_pairwise(yh_db* db, double c_thresh, u64 r0, u64 r1) {
             rc = (e__ == hipErrorOutOfMemory) ? YH_ERR_OOM : YH_ERR_HIP;                      \
         }                                                                                     \
     }
-    PW_HIP(hipMalloc((void**)&d_M, rows_per_block * N * sizeof(u32)));
+    PW_HIP(hipMalloc((void**)&d_M, rows_per_block * NC * sizeof(u32)));
     PW_HIP(hipMalloc((void**)&d_rowcnt, rows_per_block * sizeof(u32)));
     PW_HIP(hipMalloc((void**)&d_rowoff, (rows_per_block + 1) * sizeof(u64)));
+    PW_HIP(hipMalloc((void**)&d_cid, N * sizeof(u32)));
+    PW_HIP(hipMalloc((void**)&d_rid, NC * sizeof(u32)));
+    PW_HIP(hipMemcpyAsync(d_cid, h_cid.data(), N * sizeof(u32), hipMemcpyHostToDevice, st));
+    PW_HIP(hipMemcpyAsync(d_rid, h_rid.data(), NC * sizeof(u32), hipMemcpyHostToDevice, st));
     yh_ring_record_begin(db, db->ev_pair);
-    for (u64 b0 = r0; b0 < r1 && rc == YH_OK; b0 += rows_per_block) {
-        const u64 b1 = std::min(r1, b0 + rows_per_block);
+    for (u64 b0 = c_begin; b0 < c_end && rc == YH_OK; b0 += rows_per_block) {
+        const u64 b1 = std::min(c_end, b0 + rows_per_block);
         const u64 rows = b1 - b0;
-        PW_HIP(hipMemsetAsync(d_M, 0, rows * N * sizeof(u32), st));
+        PW_HIP(hipMemsetAsync(d_M, 0, rows * NC * sizeof(u32), st));
         if (rc == YH_OK && db->n_postings) {
             k_pair_accum<<<grid_for(db->n_postings, 256, 1u << 20), 256, 0, st>>>(db->n_postings, db->d_pr, db->d_pg,
-                                                                                  db->d_po, b0, b1, N, d_M);
+                                                                                  db->d_po, d_cid, b0, b1, NC, d_M);
         }
         if (rc == YH_OK) {
-            k_pair_count<<<grid_for(rows * WAVE, 256, 8192), 256, 0, st>>>(d_M, b0, b1, N, db->d_sizes, c_relaxed,
+            k_pair_count<<<grid_for(rows * WAVE, 256, 8192), 256, 0, st>>>(d_M, b0, b1, NC, d_rid, db->d_sizes, c_relaxed,
                                                                            d_rowcnt);
             k_scan_u32_to_u64<<<1, 1024, 0, st>>>(d_rowcnt, rows, d_rowoff);
         }
@@ -949,8 +974,8 @@ int yh_q_pairwise(yh_db* db, double c_thresh, u64 r0, u64 r1) {
             PW_HIP(hipMalloc((void**)&d_oj, n_out * sizeof(u32)));
             PW_HIP(hipMalloc((void**)&d_oc, n_out * sizeof(u32)));
             if (rc == YH_OK) {
-                k_pair_emit<<<grid_for(rows * WAVE, 256, 8192), 256, 0, st>>>(d_M, b0, b1, N, db->d_sizes, c_relaxed,
-                                                                              d_rowoff, d_oi, d_oj, d_oc);
+                k_pair_emit<<<grid_for(rows * WAVE, 256, 8192), 256, 0, st>>>(d_M, b0, b1, NC, d_rid, db->d_sizes,
+                                                                              c_relaxed, d_rowoff, d_oi, d_oj, d_oc);
             }
             PW_HIP(hipGetLastError());
             const size_t base = hi.size();
@@ -967,6 +992,7 @@ int yh_q_pairwise(yh_db* db, double c_thresh, u64 r0, u64 r1) {
 #undef PW_HIP
     (void)hipFree(d_M); (void)hipFree(d_rowcnt); (void)hipFree(d_rowoff);
     (void)hipFree(d_oi); (void)hipFree(d_oj); (void)hipFree(d_oc);
+    (void)hipFree(d_cid); (void)hipFree(d_rid);
     if (rc != YH_OK) return rc;
 
     // exact host-side filter (main.cpp:297-303): keep iff !(1.0*count/|R_i| < C)
