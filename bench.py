@@ -50,6 +50,7 @@ def parse_args():
     ap.add_argument("--seed", type=int, default=1002)
     ap.add_argument("--present", type=int, default=200, help="genomes present in the sample (diagnostic)")
     ap.add_argument("--no-indexed", action="store_true", help="skip the extra measurement of the sample-driven path")
+    ap.add_argument("--sync-gather", action="store_true", help="N>1: blocking all-gather inside every step (no overlap)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to test the N>1 logic)")
     ap.add_argument("--share-gpu", action="store_true", help="testing: all ranks use cuda:0 (1-GPU box, gloo backend)")
     return ap.parse_args()
@@ -126,16 +127,39 @@ def main() -> int:
     part_of = (sample >> info["partition_shift"]) if info["partition_shift"] < 63 else torch.zeros_like(sample)
     max_slice = int(torch.bincount(part_of.clamp_(0, info["n_partitions"])).max().item()) if n_sample else 0
 
-    counts = torch.zeros((3, n_refs), device=dev, dtype=torch.int32)  # overlap, n_excl, n_match (uint32 bits)
-    gathered = torch.zeros((world * 3, n_refs), device=dev, dtype=torch.int32) if world > 1 else None  # concatenation layout
-    p_sample, p_ov = sample.data_ptr(), counts[0].data_ptr()
-    p_e, p_m = (0, 0) if args.overlap_only else (counts[1].data_ptr(), counts[2].data_ptr())
+    # Two sets of count buffers: the all-gather of sample k (async, on RCCL's stream, ordered after
+    # sample k's kernels) overlaps the kernels of sample k+1; a buffer set is reused only after the
+    # collective that reads it has completed (work.wait() = stream-level wait, no host block on RCCL).
+    NBUF = 2 if world > 1 and not args.sync_gather else 1
+    counts_b = [torch.zeros((3, n_refs), device=dev, dtype=torch.int32) for _ in range(NBUF)]  # overlap, n_excl, n_match
+    gathered_b = [torch.zeros((world * 3, n_refs), device=dev, dtype=torch.int32) if world > 1 else None
+                  for _ in range(NBUF)]  # concatenation layout
+    pending = [None] * NBUF
+    p_sample = sample.data_ptr()
+    state = {"i": 0}
 
     def step():
+        b = state["i"] % NBUF
+        state["i"] += 1
+        c = counts_b[b]
         with torch.cuda.stream(stream):
-            db.run_device(p_sample, n_sample, p_ov, p_e, p_m)
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
+            db.run_device(p_sample, n_sample, c[0].data_ptr(), 0 if args.overlap_only else c[1].data_ptr(),
+                          0 if args.overlap_only else c[2].data_ptr())
             if world > 1:
-                dist.all_gather_into_tensor(gathered, counts)
+                if NBUF > 1:
+                    pending[b] = dist.all_gather_into_tensor(gathered_b[b], c, async_op=True)
+                else:
+                    dist.all_gather_into_tensor(gathered_b[b], c)
+
+    def drain():
+        with torch.cuda.stream(stream):
+            for b in range(NBUF):
+                if pending[b] is not None:
+                    pending[b].wait()
+                    pending[b] = None
 
     def fence():
         torch.cuda.synchronize()
@@ -145,11 +169,13 @@ def main() -> int:
 
     for _ in range(args.warmup):
         step()
+    drain()
     fence()
     db.timing()  # drop the warm-up launches from the kernel-duration ring
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    drain()
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -157,8 +183,12 @@ def main() -> int:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     timing = db.timing()  # mean over the (up to 256) most recent launches of the timed region
-    if world > 1:  # the gathered block of this rank must be this rank's counts (stream ordering check)
-        assert bool(torch.equal(gathered.view(world, 3, n_refs)[rank], counts)), "all-gather ran ahead of the kernels"
+    last = (state["i"] - 1) % NBUF
+    counts, gathered = counts_b[last], gathered_b[last]
+    if world > 1:  # every buffer set: the gathered block of this rank must be this rank's counts
+        for b in range(NBUF):
+            assert bool(torch.equal(gathered_b[b].view(world, 3, n_refs)[rank], counts_b[b])), \
+                "all-gather ran ahead of the kernels"
 
     # ---- extra: the same step through the sample-driven path (work ~ |S| instead of streaming the
     # database).  Not the reported `value` this round: the headline stays on the streaming kernel
@@ -173,7 +203,7 @@ def main() -> int:
             with torch.cuda.stream(stream):
                 db.run_indexed_device(p_sample, n_sample, pi0, pi1, pi2)
                 if world > 1:
-                    dist.all_gather_into_tensor(gathered, counts_idx)
+                    dist.all_gather_into_tensor(gathered, counts_idx)  # (this extra measurement keeps the blocking form)
 
         for _ in range(args.warmup):
             step_idx()
@@ -283,7 +313,7 @@ def main() -> int:
                 "shared_hashes": info["n_shared_distinct"],
                 "db_build_ms": round(float(timing["ms_db_build"]), 2),
                 "db_hbm_bytes": info["device_bytes"],
-                "step": "overlap" if args.overlap_only else "overlap + exclusive counts" + (" + all_gather" if world > 1 else ""),
+                "step": "overlap" if args.overlap_only else "overlap + exclusive counts" + ((" + all_gather" + ("" if args.sync_gather else " (overlapped with the next sample)")) if world > 1 else ""),
                 "parallelism": f"refs sharded x{world}",
             },
             "roofline": roofline,
