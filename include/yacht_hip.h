@@ -127,6 +127,16 @@ int yh_overlap_indexed_device(yh_db* db, const uint64_t* d_sample, uint64_t n_sa
 int yh_run_indexed_device(yh_db* db, const uint64_t* d_sample, uint64_t n_sample,
                           uint32_t* d_overlap, uint32_t* d_n_excl, uint32_t* d_n_match);
 
+/* Many samples against one resident database in one pass (needs
+ * YH_DB_FULL_INDEX; the reference runs one sample per process, run_YACHT.py:150).  `samples` holds
+ * n_samples (1..64) sketches back to back, each strictly ascending, delimited by
+ * sample_offsets[n_samples + 1]; outputs are [n_samples][N] row-major.  For every sample the three
+ * rows equal what yh_run returns for it alone.  total_hashes = sample_offsets[n_samples].       */
+int yh_run_batch(yh_db* db, const uint64_t* samples, const uint64_t* sample_offsets, uint32_t n_samples,
+                 uint32_t* overlap, uint32_t* n_excl, uint32_t* n_match);
+int yh_run_batch_device(yh_db* db, const uint64_t* d_samples, const uint64_t* d_sample_offsets, uint32_t n_samples,
+                        uint64_t total_hashes, uint32_t* d_overlap, uint32_t* d_n_excl, uint32_t* d_n_match);
+
 /* ---- yacht run, step 2: exclusive hashes relative to a subset ----------------------------
  * For every j with subset_mask[j] != 0:
  *   n_excl[j]  = |{h in R_j : h is in no other masked reference}|

@@ -91,6 +91,8 @@ SIGNATURES = {
     "yh_overlap_bsearch_device": (C.c_int, [_vp, _vp, C.c_uint64, _vp]),
     "yh_overlap_indexed_device": (C.c_int, [_vp, _vp, C.c_uint64, _vp]),
     "yh_run_indexed_device": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp, _vp]),
+    "yh_run_batch": (C.c_int, [_vp, _vp, _vp, C.c_uint32, _vp, _vp, _vp]),
+    "yh_run_batch_device": (C.c_int, [_vp, _vp, _vp, C.c_uint32, C.c_uint64, _vp, _vp, _vp]),
     "yh_exclusive": (C.c_int, [_vp, _vp, _vp, C.c_uint64, _vp, _vp]),
     "yh_run": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp, _vp]),
     "yh_run_device": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp, _vp]),

@@ -315,9 +315,9 @@ int yh_db_destroy(yh_db* db) {
     if (db->device >= 0) (void)hipSetDevice(db->device);
     if (db->stream) (void)hipStreamSynchronize(db->stream);
     void* ptrs[] = {db->d_values, db->d_offsets, db->d_pvals, db->d_pbeg, db->d_pcnt, db->d_poffs, db->d_sizes,
-                    db->d_g, db->d_po, db->d_pr, db->d_pg, db->d_gbeg, db->d_gcnt, db->d_nshared, db->d_pq, db->d_pq_count, db->d_dh, db->d_dref, db->d_dir, db->d_sbounds,
+                    db->d_g, db->d_po, db->d_pr, db->d_pg, db->d_gbeg, db->d_gcnt, db->d_nshared, db->d_pq, db->d_pq_count, db->d_dh, db->d_dref, db->d_dir, db->d_bkt, db->d_pkeys, db->d_gkeys, db->d_sbounds,
                     db->d_mask, db->d_maskbits, db->d_hit, db->d_excl_e, db->d_overlap_tmp,
-                    db->d_sample_tmp, db->d_flag, db->d_hitq, db->d_hitq_cnt, db->d_reps};
+                    db->d_sample_tmp, db->d_flag, db->d_hitq, db->d_hitq_cnt, db->d_reps, db->d_batch};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     ring_destroy(db->ev_overlap);
@@ -399,6 +399,61 @@ int yh_run_indexed_device(yh_db* db, const uint64_t* d_sample, uint64_t n_sample
     YH_TRY(yh_q_overlap_indexed(db, (const u64*)d_sample, n_sample, d_overlap, true));
     return yh_q_exclusive(db, db->d_mask, (const u64*)d_sample, n_sample, d_overlap, d_n_excl, d_n_match, true,
                           db->d_maskbits);
+}
+
+int yh_run_batch_device(yh_db* db, const uint64_t* d_samples, const uint64_t* d_sample_offsets, uint32_t n_samples,
+                        uint64_t total_hashes, uint32_t* d_overlap, uint32_t* d_n_excl, uint32_t* d_n_match) {
+    if (!db_ok(db)) return YH_ERR_INVALID_ARG;
+    if (!d_sample_offsets || !d_overlap || !d_n_excl || !d_n_match || (total_hashes && !d_samples)) {
+        yh_set_error("null device pointer");
+        return YH_ERR_INVALID_ARG;
+    }
+    YH_TRY(db_select(db));
+    return yh_q_run_batch(db, (const u64*)d_samples, (const u64*)d_sample_offsets, n_samples, total_hashes, d_overlap,
+                          d_n_excl, d_n_match);
+}
+
+int yh_run_batch(yh_db* db, const uint64_t* samples, const uint64_t* sample_offsets, uint32_t n_samples,
+                 uint32_t* overlap, uint32_t* n_excl, uint32_t* n_match) {
+    if (!db_ok(db)) return YH_ERR_INVALID_ARG;
+    if (!sample_offsets || n_samples < 1 || n_samples > 64) { yh_set_error("1..64 samples and their offsets"); return YH_ERR_INVALID_ARG; }
+    const u64 total = sample_offsets[n_samples];
+    const u64 N = db->n_refs;
+    if (sample_offsets[0] != 0 || (total && !samples) || (N && (!overlap || !n_excl || !n_match))) {
+        yh_set_error("bad sample arrays or null output");
+        return YH_ERR_INVALID_ARG;
+    }
+    for (uint32_t s = 0; s < n_samples; ++s) {
+        if (sample_offsets[s + 1] < sample_offsets[s] ||
+            yh_q_check_sorted_host((const u64*)samples + sample_offsets[s], sample_offsets[s + 1] - sample_offsets[s]) != YH_OK) {
+            yh_set_error("sample %u is not strictly ascending", s);
+            return YH_ERR_UNSORTED;
+        }
+    }
+    YH_TRY(db_select(db));
+    if (N == 0) return YH_OK;
+    const u64 BN = (u64)n_samples * N;
+    u64 *d_s = nullptr, *d_o = nullptr;
+    u32* d_out = nullptr;
+    int rc = YH_OK;
+    do {
+        if (hipMalloc((void**)&d_s, std::max<u64>(total, 2) * sizeof(u64)) != hipSuccess ||
+            hipMalloc((void**)&d_o, (u64)(n_samples + 1) * sizeof(u64)) != hipSuccess ||
+            hipMalloc((void**)&d_out, 3 * BN * sizeof(u32)) != hipSuccess) { yh_set_error("hipMalloc failed"); rc = YH_ERR_OOM; break; }
+        if ((total && hipMemcpyAsync(d_s, samples, total * sizeof(u64), hipMemcpyHostToDevice, db->stream) != hipSuccess) ||
+            hipMemcpyAsync(d_o, sample_offsets, (u64)(n_samples + 1) * sizeof(u64), hipMemcpyHostToDevice, db->stream) != hipSuccess) {
+            yh_set_error("sample upload failed"); rc = YH_ERR_HIP; break;
+        }
+        if ((rc = yh_q_run_batch(db, d_s, d_o, n_samples, total, d_out, d_out + BN, d_out + 2 * BN)) != YH_OK) break;
+        if (hipMemcpyAsync(overlap, d_out, BN * sizeof(u32), hipMemcpyDeviceToHost, db->stream) != hipSuccess ||
+            hipMemcpyAsync(n_excl, d_out + BN, BN * sizeof(u32), hipMemcpyDeviceToHost, db->stream) != hipSuccess ||
+            hipMemcpyAsync(n_match, d_out + 2 * BN, BN * sizeof(u32), hipMemcpyDeviceToHost, db->stream) != hipSuccess ||
+            hipStreamSynchronize(db->stream) != hipSuccess) {
+            yh_set_error("batch download failed: %s", hipGetErrorString(hipGetLastError())); rc = YH_ERR_HIP;
+        }
+    } while (0);
+    (void)hipFree(d_s); (void)hipFree(d_o); (void)hipFree(d_out);
+    return rc;
 }
 
 int yh_overlap_bsearch_device(yh_db* db, const uint64_t* d_sample, uint64_t n_sample, uint32_t* d_overlap) {

@@ -289,6 +289,33 @@ __global__ void k_dir_build(const u64* __restrict__ dh, u64 D, u32 dshift, u32 N
     }
 }
 
+// Bucket table over the distinct hashes (layout: YhDirView in yh_common.h).  One thread per distinct
+// hash: its slot is the number of predecessors in the same bucket (buckets are contiguous runs of
+// the sorted array); the last hash of a run writes the bucket's header.  The table is zeroed first.
+__global__ void k_bkt_build(const u64* __restrict__ dh, const u32* __restrict__ dref, u64 D, u32 lsh, u64 nb,
+                            u32* __restrict__ bkt) {
+    for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < D; i += (u64)gridDim.x * blockDim.x) {
+        const u64 h = dh[i];
+        const u64 b = yh_bucket_of(h, lsh, nb);
+        u32 r = 0;
+        while (r < 6 && i > r && yh_bucket_of(dh[i - 1 - r], lsh, nb) == b) ++r;
+        u32* w = bkt + 16 * b;
+        if (r < 5) {
+            w[2 * r] = (u32)h;
+            w[2 * r + 1] = (u32)(h >> 32);
+            w[10 + r] = dref[i];
+        }
+        if (i + 1 == D || yh_bucket_of(dh[i + 1], lsh, nb) != b) w[15] = (r + 1 > 5) ? YH_BKT_OVERFLOW : r + 1;
+    }
+}
+
+// 32-bit keys of a hash array: inside one hash-range partition the bits above pshift are constant,
+// so (u32)(h >> kshift) orders and (almost always) identifies the hashes of a partition.
+__global__ void k_make_keys(const u64* __restrict__ v, u64 n, u32 kshift, u32* __restrict__ keys) {
+    for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x)
+        keys[i] = (u32)(v[i] >> kshift);
+}
+
 __global__ void k_bounds_u64(const u64* __restrict__ a, u64 n, u32 P, u32 pshift, u64* __restrict__ beg,
                              u64* __restrict__ cnt) {
     const u32 p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -413,7 +440,7 @@ int yh_build_partitions(yh_db* db, const u64* d_values, const u64* d_offsets, u3
         for (u32 p = 0; p < P; ++p) {
             h_pbeg[p] = pos;
             pos += h_pcnt[p];
-            pos = (pos + 1) & ~1ull;  // every partition starts on a 16-byte boundary
+            pos = (pos + 3) & ~3ull;  // every partition starts on a 16-byte boundary of the 32-bit key stream
         }
         db->pvals_len = pos;
         rc = yh_dmalloc(db, (void**)&db->d_pvals, std::max<u64>(pos, 2) * sizeof(u64));
@@ -427,6 +454,13 @@ int yh_build_partitions(yh_db* db, const u64* d_values, const u64* d_offsets, u3
         if (N) {
             k_scatter<<<grid_for(N * WAVE, 256), 256, 0, st>>>(d_values, d_offsets, N, P, pshift, d_split, db->d_pbeg,
                                                                db->d_poffs, db->d_pvals);
+        }
+        db->kshift = pshift > 32 ? pshift - 32 : 0;
+        const char* wide = getenv("YH_WIDE_KEYS");
+        if (!(wide && wide[0] == '1')) {
+            rc = yh_dmalloc(db, (void**)&db->d_pkeys, (pos + 8) * sizeof(u32));
+            if (rc != YH_OK) break;
+            k_make_keys<<<grid_for(pos + 1, 256), 256, 0, st>>>(db->d_pvals, pos, db->kshift, db->d_pkeys);
         }
         if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) {
             yh_set_error("partition scatter failed");
@@ -535,6 +569,13 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, const u
             if (rc == YH_OK) rc = yh_dmalloc(db, (void**)&db->d_dh, std::max<u64>(db->n_distinct, 2) * sizeof(u64));
             if (rc == YH_OK) rc = yh_dmalloc(db, (void**)&db->d_dref, std::max<u64>(db->n_distinct, 2) * sizeof(u32));
             if (rc == YH_OK) rc = yh_dmalloc(db, (void**)&db->d_dir, ((u64)db->dir_nb + 2) * sizeof(u32));
+            const char* nob = getenv("YH_NO_BUCKETS");
+            if (rc == YH_OK && db->n_distinct && !(nob && nob[0] == '1')) {
+                db->bkt_nb = (db->n_distinct + 1) / 2;
+                db->bkt_lsh = 64 - bits;
+                rc = yh_dmalloc(db, (void**)&db->d_bkt, db->bkt_nb * 64);
+                if (rc == YH_OK) IDX_HIP(hipMemsetAsync(db->d_bkt, 0, db->bkt_nb * 64, st));
+            }
         }
         if (rc == YH_OK)
             k_idx_emit<<<(u32)nb, IDX_THREADS, 0, st>>>(d_sk, d_sv, H, d_bases, db->d_g, db->d_po, db->d_pr, db->d_pg,
@@ -543,8 +584,16 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, const u
         if (rc == YH_OK && full)
             k_dir_build<<<grid_for(db->n_distinct, 256), 256, 0, st>>>(db->d_dh, db->n_distinct, db->dir_shift, db->dir_nb,
                                                                        db->d_dir);
+        if (rc == YH_OK && full && db->d_bkt)
+            k_bkt_build<<<grid_for(db->n_distinct, 256), 256, 0, st>>>(db->d_dh, db->d_dref, db->n_distinct, db->bkt_lsh,
+                                                                       db->bkt_nb, reinterpret_cast<u32*>(db->d_bkt));
         IDX_HIP(hipGetLastError());
         IDX_HIP(hipMemcpyAsync(db->d_po + db->n_shared, &db->n_postings, sizeof(u64), hipMemcpyHostToDevice, st));
+        if (db->n_shared && db->d_pkeys && rc == YH_OK) {
+            rc = yh_dmalloc(db, (void**)&db->d_gkeys, (db->n_shared + 8) * sizeof(u32));
+            if (rc == YH_OK)
+                k_make_keys<<<grid_for(db->n_shared, 256), 256, 0, st>>>(db->d_g, db->n_shared, db->kshift, db->d_gkeys);
+        }
         if (db->n_shared) {
             k_bounds_u64<<<(db->n_parts + 255) / 256, 256, 0, st>>>(db->d_g, db->n_shared, db->n_parts, db->pshift,
                                                                     db->d_gbeg, db->d_gcnt);

@@ -136,6 +136,12 @@ struct yh_db {
     u32* d_dref = nullptr;     // [D] its single holder, or 0x80000000 | index into d_g
     u32* d_dir = nullptr;      // [dir_nb + 1] first index of d_dh whose (hash >> dir_shift) >= bucket
     u32 dir_shift = 0, dir_nb = 0;
+    u32* d_pkeys = nullptr;    // [pvals_len] 32-bit keys of d_pvals: (u32)(hash >> kshift); the stream K1 reads
+    u32* d_gkeys = nullptr;    // [n_shared] the same keys of d_g
+    u32 kshift = 0;            // pshift - 32 when pshift > 32, else 0 (keys then carry every in-partition bit)
+    uint4* d_bkt = nullptr;    // [bkt_nb] 64-byte buckets over the distinct hashes (YhDirView below)
+    u64 bkt_nb = 0;
+    u32 bkt_lsh = 0;
     u32* d_pq = nullptr;       // [postings] queue of postings that belong to masked references (per query)
     u32* d_pq_count = nullptr; // [EXCL_QBLOCKS] fill of each workgroup's queue segment
 
@@ -156,6 +162,8 @@ struct yh_db {
     u32 hitq_wgs = 0, hitq_cap = 0;
     u32* d_reps = nullptr;     // [R][N] replicated overlap counters
     u64 reps_cap = 0;
+    void* d_batch = nullptr;   // scratch of the batched run: hit words, mask words, shared overlaps
+    u64 batch_cap = 0;
 
     // pairwise result cache (two-call sizing)
     bool pw_valid = false;
@@ -180,7 +188,64 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, const u
 // ---- implemented in yh_query.hip -------------------------------------------------------------
 int yh_q_overlap(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap, bool flag_shared, bool make_mask);
 int yh_q_overlap_bsearch(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap);
+// ---- the distinct-hash directory as the lookup kernels see it -------------------------------------
+// Primary structure: a table of 64-byte buckets, bucket(h) = floor(h * bkt_nb / 2^bits(max_hash))
+// (monotone in h, ~2 distinct hashes per bucket).  A bucket is 16 words = one HBM sector:
+//   w[0..9] five hashes (lo, hi) ascending, w[10..14] their dref words, w[15] = entries used, or
+//   YH_BKT_OVERFLOW when more than five hashes fall into it (~1.7 % of the buckets).
+// One random sector read answers a lookup; overflowing buckets fall back to the two-level
+// directory (dir -> dh -> dref, three dependent reads), which is also the whole path when the
+// table is absent (YH_NO_BUCKETS=1 at creation, for A/B timing).
+#define YH_BKT_OVERFLOW 0xffffffffu
+#define YH_DIR_NONE 0xffffffffu
+#if defined(__HIPCC__)
+__device__ __forceinline__ u64 yh_bucket_of(u64 h, u32 lsh, u64 nb) { return __umul64hi(h << lsh, nb); }
+
+struct YhDirView {
+    const u64* dh;
+    const u32* dref;
+    const u32* dir;
+    const uint4* bkt;
+    u64 bkt_nb, max_hash;
+    u32 dshift, NB, bkt_lsh;
+
+    __device__ __forceinline__ u32 find_slow(u64 h) const {
+        const u64 b = h >> dshift;
+        if (b >= NB) return YH_DIR_NONE;
+        u32 i = dir[b];
+        const u32 e = dir[b + 1];
+        u64 v = 0;
+        for (; i < e; ++i) {
+            v = dh[i];
+            if (v >= h) break;
+        }
+        return (i < e && v == h) ? dref[i] : YH_DIR_NONE;
+    }
+    // dref word of h (holder id, or 0x80000000 | shared-hash index), YH_DIR_NONE when h is not in the database
+    __device__ __forceinline__ u32 find(u64 h) const {
+        if (h > max_hash) return YH_DIR_NONE;
+        if (!bkt) return find_slow(h);
+        const uint4* p = bkt + 4 * yh_bucket_of(h, bkt_lsh, bkt_nb);
+        const uint4 a = p[0], b = p[1], c = p[2], d = p[3];
+        if (d.w == YH_BKT_OVERFLOW) return find_slow(h);
+        const u32 lo = (u32)h, hi = (u32)(h >> 32);
+        u32 r = YH_DIR_NONE;
+        if (d.w > 0 && a.x == lo && a.y == hi) r = c.z;
+        if (d.w > 1 && a.z == lo && a.w == hi) r = c.w;
+        if (d.w > 2 && b.x == lo && b.y == hi) r = d.x;
+        if (d.w > 3 && b.z == lo && b.w == hi) r = d.y;
+        if (d.w > 4 && c.x == lo && c.y == hi) r = d.z;
+        return r;
+    }
+};
+inline YhDirView yh_dir_view(const yh_db* db) {
+    return YhDirView{db->d_dh, db->d_dref, db->d_dir, db->d_bkt, db->bkt_nb, db->max_hash, db->dir_shift, db->dir_nb, db->bkt_lsh};
+}
+#endif
+
 int yh_q_overlap_indexed(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap, bool for_exclusive);
+int yh_q_run_batch(yh_db* db, const u64* d_samples, const u64* d_soff, u32 n_samples, u64 total_hashes,
+                   u32* d_overlap, u32* d_excl, u32* d_match);
 int yh_q_exclusive(yh_db* db, const u8* d_mask, const u64* d_sample, u64 n_sample,
                    const u32* d_overlap, u32* d_excl, u32* d_match, bool hit_ready, const u32* d_maskbits);
 int yh_q_exclusive_partial(yh_db* db, const u8* d_mask, const u64* d_sample, u64 n_sample, u32* d_ex_e, u32* d_ex_m,

@@ -396,6 +396,249 @@ k_tile_lookup(const u64* __restrict__ vals,     // hash stream, grouped by parti
     }
 }
 
+// ---- K1 over 32-bit keys --------------------------------------------------------------------------
+// Inside a partition the bits above pshift are constant, so the stream only needs the next 32 bits
+// below them: key = (u32)(h >> kshift), kshift = max(pshift, 32) - 32.  k_tile_lookup32 is the tile
+// kernel over the key arrays (d_pkeys, d_gkeys): HALF the bytes per reference hash.  Keys order the
+// hashes of a partition, so the tile structures work unchanged (S holds the sample's keys); what a
+// key cannot do when kshift > 0 is tell apart two hashes that differ only in their low kshift
+// bits.  So a key match is a CANDIDATE (one per ~2^21 reference hashes at rs214 scale is false):
+// it is queued like a hit and k_resolve_hits32 confirms it against the full 64-bit arrays
+// (d_pvals / d_g, read at the few queued positions only) and the sample before counting.
+// Differences to the 64-bit kernel, all because the stream is no longer the only bottleneck:
+//   * 4 keys per 16-byte load; the bitmap is a blocked Bloom filter, two bits of one word per key
+//     (word from key bits 5..17, bits from 0..4 and 18..22): one LDS read as before, ~10x fewer
+//     false candidates per wave;
+//   * the side stream's hits are queued too (tagged), not flagged in place: flagging needs the
+//     64-bit confirmation.
+// Tiles of one partition may split a run of equal keys; a match at slot 0 of a tile whose
+// predecessor ended with the same key was already reported there and is skipped (skip0).
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+
+struct NarrowHit {
+    static constexpr bool kQueued = true;
+    const u32* poffs;  // [P][N+1]
+    u32 n_refs;
+    u32* reps;
+    u32 rep_mask;
+    u64* queue;        // [wgs][qcap]  (tag << 63 | partition << 32 | rel)
+    u32 qcap;
+    const u64* vals;   // d_pvals
+    const u64* pbeg;
+    const u64* g;      // d_g (side stream), may be null
+    const u64* gbeg;
+    u8* hitflag;       // [G]
+    const u64* sample;
+    const u32* sbounds;
+    u32 exact;         // kshift == 0: a key match is a hash match
+
+    __device__ __forceinline__ bool member(u32 p, u64 h) const {
+        if (exact) return true;
+        u32 lo = sbounds[p];
+        const u32 end = sbounds[p + 1];
+        u32 hi = end;
+        while (lo < hi) {
+            const u32 mid = lo + ((hi - lo) >> 1);
+            if (sample[mid] < h) lo = mid + 1; else hi = mid;
+        }
+        return lo < end && sample[lo] == h;
+    }
+    __device__ __forceinline__ void count(u32 wg, u32 ptag, u32 rel) const {
+        const u32 p = ptag & 0x7fffffffu;
+        if (ptag >> 31) {
+            const u64 k = gbeg[p] + rel;
+            if (member(p, g[k])) hitflag[k] = 1;
+            return;
+        }
+        if (!member(p, vals[pbeg[p] + rel])) return;
+        const u32 j = resolve_ref(poffs + (u64)p * (n_refs + 1), n_refs, rel);
+        atomicAdd(&reps[(u64)(wg & rep_mask) * n_refs + j], 1u);
+    }
+    __device__ __forceinline__ void operator()(const HitCtx& c, u32 ptag, u64 rel) const {
+        const u32 slot = atomicAdd(c.q_fill, 1u);
+        if (slot < (u32)TILE_QCAP) c.q[slot] = ((u64)ptag << 32) | (u64)(u32)rel;
+        else count(c.wg, ptag, (u32)rel);
+    }
+};
+
+__global__ void __launch_bounds__(256) k_resolve_hits32(const u32* __restrict__ qcount, NarrowHit hit) {
+    const u32 wg = blockIdx.x;
+    const u32 cnt = qcount[wg];
+    const u64* q = hit.queue + (u64)wg * hit.qcap;
+    for (u32 e = threadIdx.x; e < cnt; e += blockDim.x) {
+        const u64 x = q[e];
+        hit.count(wg, (u32)(x >> 32), (u32)x);
+    }
+}
+
+__device__ __forceinline__ u32 bloom_mask(u32 key) { return (1u << (key & 31u)) | (1u << ((key >> 18) & 31u)); }
+__device__ __forceinline__ u32 bloom_word(u32 key) { return (key >> 5) & (u32)(TILE_BM_WORDS - 1); }
+
+__device__ __forceinline__ void tile_stream32(const u32* __restrict__ keys, u64 start, u64 end, u64 e0, u32 ptag, u32 n,
+                                              u32 ksh, bool skip0, const u32* S, const u16* E, const u32* BM,
+                                              const NarrowHit& hit, const HitCtx& ctx) {
+    constexpr int U = TILE_UNROLL;
+    constexpr int B = 4 * U;
+    const u32 tid = threadIdx.x;
+
+    auto lookup1 = [&](u32 key, u64 pos) {
+        u32 k = E[(key >> ksh) & (TILE_NB - 1)];
+        u32 v = S[k];
+        while (v < key) v = S[++k];  // sentinel 0xffffffff stops the scan
+        if (v == key && k < n && !(skip0 && k == 0)) hit(ctx, ptag, pos - e0);
+    };
+
+    u64 i = start;
+    {  // unaligned head
+        const u64 head = min((u64)((4 - (i & 3ull)) & 3ull), end - i);
+        if (tid < head) lookup1(keys[i + tid], i + tid);
+        i += head;
+    }
+    const u64 nvec = (end - i) >> 2;
+    if (nvec) {
+        const u32x4* __restrict__ vp = reinterpret_cast<const u32x4*>(keys + i);
+        const u64 last = nvec - 1;
+        u32x4 cur[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) cur[u] = __builtin_nontemporal_load(&vp[min((u64)tid + (u64)u * TILE_THREADS, last)]);
+        for (u64 v = tid; v < nvec; v += (u64)U * TILE_THREADS) {
+            u32x4 nxt[U];
+            const u64 vn = v + (u64)U * TILE_THREADS;
+#pragma unroll
+            for (int u = 0; u < U; ++u) nxt[u] = __builtin_nontemporal_load(&vp[min(vn + (u64)u * TILE_THREADS, last)]);
+
+            u32 h[B];
+            u32 valid = 0;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                h[4 * u] = cur[u].x;
+                h[4 * u + 1] = cur[u].y;
+                h[4 * u + 2] = cur[u].z;
+                h[4 * u + 3] = cur[u].w;
+                if (v + (u64)u * TILE_THREADS < nvec) valid |= 15u << (4 * u);
+            }
+            u32 w[B];
+#pragma unroll
+            for (int b = 0; b < B; ++b) w[b] = BM[bloom_word(h[b])];
+            u32 cand = 0;
+#pragma unroll
+            for (int b = 0; b < B; ++b) cand |= (((w[b] >> (h[b] & 31u)) & (w[b] >> ((h[b] >> 18) & 31u))) & 1u) << b;
+            cand &= valid;
+            while (cand) {  // rare: exact lookup of the candidates this lane holds
+                const u32 b = (u32)__ffs((int)cand) - 1u;
+                cand &= cand - 1u;
+                u32 hb = h[0];
+#pragma unroll
+                for (int j = 1; j < B; ++j) hb = (b == (u32)j) ? h[j] : hb;
+                const u64 pos = i + 4 * (v + (u64)(b >> 2) * TILE_THREADS) + (b & 3u);
+                lookup1(hb, pos);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+        }
+    }
+    {  // tail
+        const u64 tail = (end - i) & 3ull;
+        if (tid < tail) lookup1(keys[end - tail + tid], end - tail + tid);
+    }
+}
+
+__global__ void __launch_bounds__(TILE_THREADS, YH_TILE_WAVES_PER_SIMD)
+k_tile_lookup32(const u32* __restrict__ keys,     // key stream, grouped by partition (d_pkeys)
+                const u64* __restrict__ pbeg, const u64* __restrict__ pcnt, u32 P, u64 total_len,
+                const u64* __restrict__ sample, const u32* __restrict__ sbounds, u32 pshift, u32 kshift,
+                u32* __restrict__ qcount, NarrowHit hit,
+                const u32* __restrict__ gkeys,    // side stream (keys of d_g) or nullptr
+                const u64* __restrict__ gcnt) {
+    __shared__ __attribute__((aligned(16))) u32 S[TILE_SLOTS];
+    __shared__ __attribute__((aligned(16))) u32 BM[TILE_BM_WORDS];
+    __shared__ u16 E[TILE_NB];
+    __shared__ u64 Q[TILE_QCAP];
+    __shared__ u32 q_fill;
+    __shared__ u32 g_fill;
+
+    const u32 tid = threadIdx.x;
+    const u32 lid = xcd_remap(blockIdx.x, gridDim.x);
+    u64 per = (total_len + gridDim.x - 1) / gridDim.x;
+    per = (per + 3) & ~3ull;  // slices stay 16-byte aligned
+    const u64 w0 = (u64)lid * per;
+    const u64 w1 = min(total_len, w0 + per);
+    const HitCtx ctx{&q_fill, Q, lid};
+    if (tid == 0) { q_fill = 0; g_fill = 0; }
+    if (w0 >= w1) {
+        if (tid == 0) qcount[lid] = 0;
+        return;
+    }
+    auto flush = [&]() {
+        __syncthreads();
+        const u32 f = min(q_fill, (u32)TILE_QCAP);
+        const u32 g0 = g_fill;
+        for (u32 e = tid; e < f; e += TILE_THREADS) {
+            const u64 x = Q[e];
+            if (g0 + e < hit.qcap) hit.queue[(u64)lid * hit.qcap + g0 + e] = x;
+            else hit.count(lid, (u32)(x >> 32), (u32)x);
+        }
+        __syncthreads();
+        if (tid == 0) { q_fill = 0; g_fill = g0 + f; }
+        __syncthreads();
+    };
+
+    u32 p;
+    {
+        u32 lo = 0, hi = P;
+        while (lo < hi) {
+            const u32 mid = (lo + hi) >> 1;
+            if (pbeg[mid] <= w0) lo = mid + 1; else hi = mid;
+        }
+        p = lo ? lo - 1 : 0;
+    }
+    // bucket bits: the TILE_LGNB bits just below pshift, seen from the key
+    const u32 bsh = (pshift > (u32)TILE_LGNB) ? pshift - TILE_LGNB : 0u;
+    const u32 ksh = bsh - min(bsh, kshift);
+    bool first = true;
+    for (; p < P; ++p) {
+        const u64 e0 = pbeg[p];
+        if (e0 >= w1) break;
+        const u64 start = max(w0, e0), end = min(w1, e0 + pcnt[p]);
+        if (start >= end) continue;
+        const u32 s0 = sbounds[p], s1 = sbounds[p + 1];
+        for (u32 sub = s0; sub < s1; sub += TILE_CAP) {
+            const u32 n = min((u32)TILE_CAP, s1 - sub);
+            if (!first) {
+                flush();
+                __syncthreads();
+            }
+            first = false;
+            {
+                uint4* bm4 = reinterpret_cast<uint4*>(BM);
+                for (u32 k = tid; k < TILE_BM_WORDS / 4; k += TILE_THREADS) bm4[k] = make_uint4(0, 0, 0, 0);
+            }
+            for (u32 k = tid; k < n; k += TILE_THREADS) S[k] = (u32)(sample[sub + k] >> kshift);
+            if (tid < 2) S[n + tid] = 0xffffffffu;
+            const bool skip0 = (sub > s0) && ((u32)(sample[sub - 1] >> kshift) == (u32)(sample[sub] >> kshift));
+            __syncthreads();
+            for (u32 k = tid; k < n; k += TILE_THREADS) {
+                const u32 key = S[k];
+                atomicOr(&BM[bloom_word(key)], bloom_mask(key));
+                const u32 b = (key >> ksh) & (TILE_NB - 1);
+                const int bp = (k == 0) ? -1 : (int)((S[k - 1] >> ksh) & (TILE_NB - 1));
+                for (int x = bp + 1; x <= (int)b; ++x) E[x] = (u16)k;
+                if (k == n - 1)
+                    for (u32 x = b + 1; x < (u32)TILE_NB; ++x) E[x] = (u16)n;
+            }
+            __syncthreads();
+            tile_stream32(keys, start, end, e0, p, n, ksh, skip0, S, E, BM, hit, ctx);
+            if (gkeys) {  // this workgroup's share of the shared hashes of partition p
+                const u64 cnt = pcnt[p], gc = gcnt[p], g0 = hit.gbeg[p];
+                const u64 gs = g0 + gc * (start - e0) / cnt, ge = g0 + gc * (end - e0) / cnt;
+                if (gs < ge) tile_stream32(gkeys, gs, ge, g0, p | 0x80000000u, n, ksh, skip0, S, E, BM, hit, ctx);
+            }
+        }
+    }
+    flush();
+    if (tid == 0) qcount[lid] = min(g_fill, hit.qcap);
+}
+
 // ---- cross-check kernel: one wave per reference over the plain CSR -------------------------------
 __global__ void __launch_bounds__(256) k_overlap_bsearch(const u64* __restrict__ values,
                                                          const u64* __restrict__ offsets, u64 n_refs,
@@ -430,26 +673,14 @@ __global__ void __launch_bounds__(256) k_overlap_bsearch(const u64* __restrict__
 // its holder (or the posting list of a shared hash) -> replicated counters.  Work is proportional
 // to |S|, not to the database: ~3 dependent memory round trips per sample hash instead of
 // streaming every reference hash.  Also flags the shared hashes found (hit[], for R2).
-__global__ void __launch_bounds__(256) k_index_lookup(const u64* __restrict__ sample, u64 n,
-                                                      const u64* __restrict__ dh, const u32* __restrict__ dref,
-                                                      const u32* __restrict__ dir, u32 dshift, u32 NB,
+__global__ void __launch_bounds__(256) k_index_lookup(const u64* __restrict__ sample, u64 n, const YhDirView dv,
                                                       const u64* __restrict__ po, const u32* __restrict__ pr,
                                                       u32* __restrict__ reps, u32 rep_mask, u64 n_refs,
                                                       u8* __restrict__ hit) {
     u32* my = reps + (u64)(blockIdx.x & rep_mask) * n_refs;
     for (u64 t = blockIdx.x * (u64)blockDim.x + threadIdx.x; t < n; t += (u64)gridDim.x * blockDim.x) {
-        const u64 h = sample[t];
-        const u64 b = h >> dshift;
-        if (b >= NB) continue;  // above the database's largest hash
-        u32 i = dir[b];
-        const u32 e = dir[b + 1];
-        u64 v = 0;
-        for (; i < e; ++i) {
-            v = dh[i];
-            if (v >= h) break;
-        }
-        if (i >= e || v != h) continue;
-        const u32 r = dref[i];
+        const u32 r = dv.find(sample[t]);
+        if (r == YH_DIR_NONE) continue;
         if (!(r & 0x80000000u)) {
             atomicAdd(&my[r], 1u);
         } else {
@@ -761,6 +992,21 @@ int yh_q_overlap(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap, b
     if (flag_shared) { z.p[1] = reinterpret_cast<uint4*>(db->d_hit); z.n16[1] = (db->n_shared + 15) / 16; }
     if (with_index) { z.p[2] = reinterpret_cast<uint4*>(db->d_excl_e); z.n16[2] = (3 * N * sizeof(u32) + 15) / 16; }
     k_prep<<<1024, 256, 0, st>>>(d_sample, (u32)n_sample, P, db->pshift, db->d_sbounds, z);
+    if (db->d_pkeys) {  // the 32-bit key stream (default); YH_WIDE_KEYS=1 at creation keeps the 64-bit kernel
+        const bool side = flag_shared && db->d_gkeys;
+        NarrowHit nh{db->d_poffs, (u32)N, db->d_reps, R - 1, db->d_hitq, db->hitq_cap, db->d_pvals, db->d_pbeg,
+                     side ? db->d_g : nullptr, db->d_gbeg, db->d_hit, d_sample, db->d_sbounds, db->kshift == 0 ? 1u : 0u};
+        yh_ring_record_begin(db, db->ev_overlap);
+        k_tile_lookup32<<<wgs, TILE_THREADS, 0, st>>>(db->d_pkeys, db->d_pbeg, db->d_pcnt, P, db->pvals_len, d_sample,
+                                                      db->d_sbounds, db->pshift, db->kshift, db->d_hitq_cnt, nh,
+                                                      side ? db->d_gkeys : nullptr, db->d_gcnt);
+        yh_ring_record_end(db, db->ev_overlap);
+        k_resolve_hits32<<<wgs, 256, 0, st>>>(db->d_hitq_cnt, nh);
+        k_reduce_replicas<<<(u32)((N + 255) / 256), 256, 0, st>>>(db->d_reps, R, N, d_overlap, make_mask ? db->d_mask : nullptr,
+                                                                 make_mask ? db->d_maskbits : nullptr);
+        YH_HIP(hipGetLastError());
+        return YH_OK;
+    }
     OverlapHit hit{db->d_poffs, (u32)N, db->d_reps, R - 1, db->d_hitq, db->hitq_cap};
     yh_ring_record_begin(db, db->ev_overlap);
     const SideStream side = flag_shared ? SideStream{db->d_g, db->d_gbeg, db->d_gcnt, db->d_hit}
@@ -802,8 +1048,7 @@ int yh_q_overlap_indexed(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_ov
     k_prep<<<1024, 256, 0, st>>>(d_sample, (u32)0, 0u, db->pshift, db->d_sbounds, z);
     yh_ring_record_begin(db, db->ev_overlap);
     if (n_sample && db->n_distinct)
-        k_index_lookup<<<grid_for(n_sample, 256, 4096), 256, 0, st>>>(d_sample, n_sample, db->d_dh, db->d_dref, db->d_dir,
-                                                                      db->dir_shift, db->dir_nb, db->d_po, db->d_pr,
+        k_index_lookup<<<grid_for(n_sample, 256, 4096), 256, 0, st>>>(d_sample, n_sample, yh_dir_view(db), db->d_po, db->d_pr,
                                                                       db->d_reps, R - 1, N,
                                                                       (for_exclusive && db->n_shared) ? db->d_hit : nullptr);
     yh_ring_record_end(db, db->ev_overlap);
@@ -1017,5 +1262,179 @@ int yh_q_pairwise(yh_db* db, double c_thresh, u64 r0, u64 r1) {
     db->pw_c = c_thresh;
     db->pw_r0 = r0;
     db->pw_r1 = r1;
+    return YH_OK;
+}
+
+// =================================================================================================
+// Batched `yacht run`: up to 64 samples against the resident database in one pass
+// =================================================================================================
+// Samples are looked up through the distinct-hash directory (k_index_lookup's scheme), one lane per
+// sample hash of ANY sample.  Per-sample state is carried as 64-bit words: hitword[g] = samples that
+// contain shared hash g, maskword[r] = samples that overlap reference r.  Exclusivity of a shared
+// hash for all samples at once is bit-sliced counting over its holders' mask words:
+//     ones ^= w, twos |= (ones_before & w)   ->   held by exactly one masked reference = ones & ~twos.
+namespace {
+
+__global__ void __launch_bounds__(256) k_batch_lookup(const u64* __restrict__ samples, const u64* __restrict__ soff,
+                                                      u32 n_samples, const YhDirView dv, const u64* __restrict__ po,
+                                                      const u32* __restrict__ pr, u64 n_refs,
+                                                      u32* __restrict__ overlap /* [B][N] */, u64* __restrict__ hitword,
+                                                      u64 n_chunks, u64 chunk_mul) {
+    __shared__ u64 off[65];
+    if (threadIdx.x <= n_samples) off[threadIdx.x] = soff[threadIdx.x];
+    __syncthreads();
+    const u64 total = off[n_samples];
+    // 256-hash chunks are visited in a multiplicative permutation (chunk_mul coprime to n_chunks), so
+    // that the workgroups resident at any moment work on ALL samples: a sample's hits land on its few
+    // hundred present references, and same-address atomics serialize (~11 ns each on this part)
+    for (u64 c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+        const u64 t = ((c * chunk_mul) % n_chunks) * 256 + threadIdx.x;
+        if (t >= total) continue;
+        u32 lo = 0, hi = n_samples;  // sample of position t: last s with off[s] <= t
+        while (hi - lo > 1) {
+            const u32 mid = (lo + hi) >> 1;
+            if (off[mid] <= t) lo = mid; else hi = mid;
+        }
+        const u32 s = lo;
+        const u32 r = dv.find(samples[t]);
+        if (r == YH_DIR_NONE) continue;
+        u32* row = overlap + (u64)s * n_refs;
+        if (!(r & 0x80000000u)) {
+            atomicAdd(&row[r], 1u);
+        } else {
+            const u32 gi = r & 0x7fffffffu;
+            atomicOr((unsigned long long*)&hitword[gi], 1ull << s);
+            for (u64 q = po[gi], qe = po[gi + 1]; q < qe; ++q) atomicAdd(&row[pr[q]], 1u);
+        }
+    }
+}
+
+// maskword[r] = samples with overlap > 0; anybits = "some sample overlaps r" (for k_excl_collect)
+__global__ void __launch_bounds__(256) k_batch_maskwords(const u32* __restrict__ overlap, u32 n_samples, u64 n_refs,
+                                                         u64* __restrict__ maskword, u32* __restrict__ anybits) {
+    const u64 r = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    u64 w = 0;
+    if (r < n_refs)
+        for (u32 s = 0; s < n_samples; ++s) w |= (u64)(overlap[(u64)s * n_refs + r] != 0) << s;
+    if (r < n_refs) maskword[r] = w;
+    const u64 bal = __ballot(w != 0);
+    if ((threadIdx.x & 63) == 0) {
+        anybits[(r >> 5)] = (u32)bal;
+        anybits[(r >> 5) + 1] = (u32)(bal >> 32);
+    }
+}
+
+__global__ void __launch_bounds__(EXCL_BLOCK) k_batch_apply(const u32* __restrict__ queue, const u32* __restrict__ qcount,
+                                                            u64 chunk, const u64* __restrict__ po,
+                                                            const u32* __restrict__ pr, const u32* __restrict__ pg,
+                                                            const u64* __restrict__ maskword,
+                                                            const u64* __restrict__ hitword, u64 n_refs,
+                                                            u32* __restrict__ ex_e, u32* __restrict__ ex_m,
+                                                            u32* __restrict__ ovsh /* each [B][N] */) {
+    const u32 n = qcount[blockIdx.x];
+    const u32* seg = queue + 4 * (u64)blockIdx.x * chunk;
+    for (u32 e = threadIdx.x; e < n; e += EXCL_BLOCK) {
+        const u32 k = seg[e];
+        const u32 r = pr[k];
+        const u32 gi = pg[k];
+        const u64 wr = maskword[r];
+        const u64 hw = hitword[gi];
+        u64 ones = 0, twos = 0;
+        for (u64 q = po[gi], qe = po[gi + 1]; q < qe; ++q) {
+            const u64 w = maskword[pr[q]];
+            twos |= ones & w;
+            ones ^= w;
+        }
+        u64 excl = ones & ~twos & wr;  // samples in which r is the only masked holder of g
+        while (excl) {
+            const u32 s = (u32)__ffsll((long long)excl) - 1u;
+            excl &= excl - 1;
+            atomicAdd(&ex_e[(u64)s * n_refs + r], 1u);
+            if ((hw >> s) & 1ull) atomicAdd(&ex_m[(u64)s * n_refs + r], 1u);
+        }
+        u64 sh = wr & hw;  // samples that contain g and overlap r
+        while (sh) {
+            const u32 s = (u32)__ffsll((long long)sh) - 1u;
+            sh &= sh - 1;
+            atomicAdd(&ovsh[(u64)s * n_refs + r], 1u);
+        }
+    }
+}
+
+// in place: ex_e -> n_excl, ex_m -> n_match for every (sample, reference)
+__global__ void __launch_bounds__(256) k_batch_final(u32 n_samples, u64 n_refs, const u32* __restrict__ sizes,
+                                                     const u32* __restrict__ nshared, const u32* __restrict__ overlap,
+                                                     const u32* __restrict__ ovsh, u32* __restrict__ ex_e,
+                                                     u32* __restrict__ ex_m) {
+    const u64 total = (u64)n_samples * n_refs;
+    for (u64 t = blockIdx.x * (u64)blockDim.x + threadIdx.x; t < total; t += (u64)gridDim.x * blockDim.x) {
+        const u64 r = t % n_refs;
+        const u32 ov = overlap[t];
+        if (ov) {
+            ex_e[t] = sizes[r] - nshared[r] + ex_e[t];
+            ex_m[t] = ov - ovsh[t] + ex_m[t];
+        } else {
+            ex_e[t] = 0;
+            ex_m[t] = 0;
+        }
+    }
+}
+
+}  // namespace
+
+int yh_q_run_batch(yh_db* db, const u64* d_samples, const u64* d_soff, u32 n_samples, u64 total_hashes,
+                   u32* d_overlap, u32* d_excl, u32* d_match) {
+    if (!(db->flags & YH_DB_FULL_INDEX) || !db->has_index) {
+        yh_set_error("yh_run_batch needs a handle created with YH_DB_FULL_INDEX");
+        return YH_ERR_UNSUPPORTED;
+    }
+    if (n_samples < 1 || n_samples > 64) { yh_set_error("1..64 samples per batch"); return YH_ERR_INVALID_ARG; }
+    hipStream_t st = db->stream;
+    const u64 N = db->n_refs;
+    if (N == 0) return YH_OK;
+    const u64 BN = (u64)n_samples * N;
+    const u64 G = db->n_shared;
+    // scratch: ovsh [B][N] u32, hitword [G] u64, maskword [N] u64 (kept on the handle, grown on demand)
+    const u64 need = BN * sizeof(u32) + (G + N + 2) * sizeof(u64) + 64;
+    if (db->batch_cap < need) {
+        YH_HIP(hipStreamSynchronize(st));
+        if (db->d_batch) { (void)hipFree(db->d_batch); db->d_batch = nullptr; db->batch_cap = 0; }
+        YH_HIP(hipMalloc((void**)&db->d_batch, need));
+        db->batch_cap = need;
+    }
+    u64* d_hitword = reinterpret_cast<u64*>(db->d_batch);
+    u64* d_maskword = d_hitword + G + 1;
+    u32* d_ovsh = reinterpret_cast<u32*>(d_maskword + N + 1);
+    YH_HIP(hipMemsetAsync(d_overlap, 0, BN * sizeof(u32), st));
+    YH_HIP(hipMemsetAsync(d_excl, 0, BN * sizeof(u32), st));
+    YH_HIP(hipMemsetAsync(d_match, 0, BN * sizeof(u32), st));
+    YH_HIP(hipMemsetAsync(db->d_batch, 0, need, st));
+    yh_ring_record_begin(db, db->ev_overlap);
+    if (total_hashes && db->n_distinct) {
+        const u64 n_chunks = (total_hashes + 255) / 256;
+        if (n_chunks >> 32) { yh_set_error("batch too large"); return YH_ERR_INVALID_ARG; }
+        u64 mul = (u64)((double)n_chunks * 0.6180339887) | 1;  // golden-ratio stride, made coprime
+        auto gcd = [](u64 a, u64 b) { while (b) { const u64 t = a % b; a = b; b = t; } return a; };
+        while (gcd(mul, n_chunks) != 1) mul += 2;
+        k_batch_lookup<<<(u32)std::min<u64>(n_chunks, 8192), 256, 0, st>>>(d_samples, d_soff, n_samples, yh_dir_view(db),
+                                                                           db->d_po, db->d_pr, N, d_overlap, d_hitword,
+                                                                           n_chunks, mul);
+    }
+    yh_ring_record_end(db, db->ev_overlap);
+    yh_ring_record_begin(db, db->ev_excl);
+    k_batch_maskwords<<<(u32)((N + 255) / 256), 256, 0, st>>>(d_overlap, n_samples, N, d_maskword, db->d_maskbits);
+    if (G && db->n_postings) {
+        const u64 vecs = (db->n_postings >> 2) + 1;
+        const u32 blocks = (u32)std::min<u64>(EXCL_QBLOCKS, (vecs + EXCL_BLOCK - 1) / EXCL_BLOCK);
+        const u64 chunk = (vecs + blocks - 1) / blocks;
+        k_excl_collect<<<blocks, EXCL_BLOCK, 0, st>>>(db->n_postings, chunk, db->d_pr, db->d_maskbits, db->d_pq,
+                                                      db->d_pq_count);
+        k_batch_apply<<<blocks, EXCL_BLOCK, 0, st>>>(db->d_pq, db->d_pq_count, chunk, db->d_po, db->d_pr, db->d_pg,
+                                                     d_maskword, d_hitword, N, d_excl, d_match, d_ovsh);
+    }
+    k_batch_final<<<grid_for(BN, 256, 8192), 256, 0, st>>>(n_samples, N, db->d_sizes, db->d_nshared, d_overlap, d_ovsh,
+                                                           d_excl, d_match);
+    yh_ring_record_end(db, db->ev_excl);
+    YH_HIP(hipGetLastError());
     return YH_OK;
 }

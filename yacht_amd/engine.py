@@ -181,6 +181,21 @@ class RefDB:
         _lib.check(self._lib.yh_run(self._h, _ptr(sample), sample.size, _ptr(ov), _ptr(e), _ptr(m)))
         return ov, e, m
 
+    def run_batch(self, samples: Sequence[np.ndarray]) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """run_counts for up to 64 samples in one pass (needs YH_DB_FULL_INDEX): three uint32
+        arrays of shape [len(samples), n_refs]."""
+        values, offsets = pack_csr(samples)
+        b = len(samples)
+        out = [np.zeros((b, self.n_refs), dtype=np.uint32) for _ in range(3)]
+        _lib.check(self._lib.yh_run_batch(self._h, _ptr(values), _ptr(offsets), b, *(_ptr(a) for a in out)))
+        return out[0], out[1], out[2]
+
+    def run_batch_device(self, d_samples: int, d_offsets: int, n_samples: int, total_hashes: int, d_overlap: int,
+                         d_excl: int, d_match: int) -> None:
+        _lib.check(self._lib.yh_run_batch_device(self._h, C.c_void_p(d_samples), C.c_void_p(d_offsets), n_samples,
+                                                 total_hashes, C.c_void_p(d_overlap), C.c_void_p(d_excl),
+                                                 C.c_void_p(d_match)))
+
     # device-pointer forms (async on the handle's stream; raw addresses, e.g. tensor.data_ptr())
     def overlap_device(self, d_sample: int, n_sample: int, d_overlap: int) -> None:
         _lib.check(self._lib.yh_overlap_device(self._h, C.c_void_p(d_sample), n_sample, C.c_void_p(d_overlap)))
