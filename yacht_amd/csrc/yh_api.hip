@@ -315,7 +315,7 @@ int yh_db_destroy(yh_db* db) {
     if (db->device >= 0) (void)hipSetDevice(db->device);
     if (db->stream) (void)hipStreamSynchronize(db->stream);
     void* ptrs[] = {db->d_values, db->d_offsets, db->d_pvals, db->d_pbeg, db->d_pcnt, db->d_poffs, db->d_sizes,
-                    db->d_g, db->d_po, db->d_pr, db->d_pg, db->d_gbeg, db->d_gcnt, db->d_nshared, db->d_pq, db->d_pq_count, db->d_dh, db->d_dref, db->d_dir, db->d_bkt, db->d_pkeys, db->d_gkeys, db->d_sbounds,
+                    db->d_g, db->d_po, db->d_pr, db->d_pg, db->d_gbeg, db->d_gcnt, db->d_nshared, db->d_pq, db->d_pq_count, db->d_dh, db->d_dref, db->d_dir, db->d_bkt, db->d_pkeys, db->d_pref, db->d_gkeys, db->d_rpo, db->d_rg, db->d_chunks, db->d_sbounds,
                     db->d_mask, db->d_maskbits, db->d_hit, db->d_excl_e, db->d_overlap_tmp,
                     db->d_sample_tmp, db->d_flag, db->d_hitq, db->d_hitq_cnt, db->d_reps, db->d_batch};
     for (void* p : ptrs)
@@ -512,7 +512,14 @@ int yh_exclusive(yh_db* db, const uint8_t* subset_mask, const uint64_t* sample, 
     do {
         if (hipMemcpyAsync(db->d_mask, subset_mask, N, hipMemcpyHostToDevice, db->stream) != hipSuccess) { yh_set_error("mask upload failed"); rc = YH_ERR_HIP; break; }
         if ((rc = yh_q_overlap(db, db->d_sample_tmp, n_sample, db->d_overlap_tmp, true, false)) != YH_OK) break;
-        if ((rc = yh_q_exclusive(db, db->d_mask, db->d_sample_tmp, n_sample, db->d_overlap_tmp, d_e, d_m, true, nullptr)) != YH_OK) break;
+        {   // most references masked: the coalesced pass over all postings beats the per-chunk walk
+            u64 masked = 0;
+            for (u64 j = 0; j < N; ++j) masked += subset_mask[j] != 0;
+            db->excl_prefer_stream = masked * 8 > N;
+        }
+        rc = yh_q_exclusive(db, db->d_mask, db->d_sample_tmp, n_sample, db->d_overlap_tmp, d_e, d_m, true, nullptr);
+        db->excl_prefer_stream = false;
+        if (rc != YH_OK) break;
         if (hipMemcpyAsync(n_excl, d_e, N * sizeof(u32), hipMemcpyDeviceToHost, db->stream) != hipSuccess ||
             hipMemcpyAsync(n_match, d_m, N * sizeof(u32), hipMemcpyDeviceToHost, db->stream) != hipSuccess ||
             hipStreamSynchronize(db->stream) != hipSuccess) {

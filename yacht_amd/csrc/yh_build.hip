@@ -8,6 +8,7 @@
 #include "yh_common.h"
 
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 #include <algorithm>
 #include <vector>
@@ -128,7 +129,8 @@ __global__ void __launch_bounds__(1024) k_part_scan(const u32* __restrict__ spli
 // One wave per reference: copy each hash to its partition-major slot.
 __global__ void k_scatter(const u64* __restrict__ values, const u64* __restrict__ offsets, u64 n_refs, u32 P,
                           u32 pshift, const u32* __restrict__ split, const u64* __restrict__ pbeg,
-                          const u32* __restrict__ poffs, u64* __restrict__ pvals) {
+                          const u32* __restrict__ poffs, u64* __restrict__ pvals, u32 kshift,
+                          u32* __restrict__ pkeys, u32* __restrict__ pref) {
     const u64 wave = (blockIdx.x * (u64)blockDim.x + threadIdx.x) / WAVE;
     const u64 n_waves = ((u64)gridDim.x * blockDim.x) / WAVE;
     const int lane = threadIdx.x & (WAVE - 1);
@@ -141,6 +143,10 @@ __global__ void k_scatter(const u64* __restrict__ values, const u64* __restrict_
             const u32 p = (u32)(h >> pshift);
             const u64 dst = pbeg[p] + poffs[(u64)p * (n_refs + 1) + j] + (k - sp[p]);
             pvals[dst] = h;
+            if (pkeys) {
+                pkeys[dst] = (u32)(h >> kshift);
+                pref[dst] = (u32)j;
+            }
         }
     }
 }
@@ -316,6 +322,33 @@ __global__ void k_make_keys(const u64* __restrict__ v, u64 n, u32 kshift, u32* _
         keys[i] = (u32)(v[i] >> kshift);
 }
 
+// ---- reference-major chunk view of the postings ---------------------------------------------------
+__global__ void k_chunk_counts(const u32* __restrict__ nshared, u64 n, u32* __restrict__ cc) {
+    const u64 r = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (r < n) cc[r] = (nshared[r] + 63u) >> 6;
+}
+__global__ void k_fill_rg(u64 n_post, const u32* __restrict__ pr, const u32* __restrict__ pg,
+                          const u32* __restrict__ rpo, u32* __restrict__ cursor, u32* __restrict__ rg) {
+    for (u64 k = blockIdx.x * (u64)blockDim.x + threadIdx.x; k < n_post; k += (u64)gridDim.x * blockDim.x) {
+        const u32 r = pr[k];
+        rg[rpo[r] + atomicAdd(&cursor[r], 1u)] = pg[k];  // order inside a reference is irrelevant (sums)
+    }
+}
+// record = reference | first posting << 32; key = (the chunk's number inside its reference, a hash of
+// the reference).  The records are then sorted by that key: neighbours in the final order belong to
+// different references, and related references (adjacent ids, often masked together) are apart.
+__global__ void k_fill_chunks(u64 n, const u32* __restrict__ rpo, const u32* __restrict__ cpo, u64* __restrict__ chunks,
+                              u64* __restrict__ ckey) {
+    const u64 r = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const u32 b = rpo[r], e = rpo[r + 1];
+    u32 c = cpo[r], i = 0;
+    for (u32 k = b; k < e; k += 64, ++c, ++i) {
+        chunks[c] = (u64)r | ((u64)k << 32);
+        ckey[c] = ((u64)i << 32) | (u64)((u32)r * 2654435761u);
+    }
+}
+
 __global__ void k_bounds_u64(const u64* __restrict__ a, u64 n, u32 P, u32 pshift, u64* __restrict__ beg,
                              u64* __restrict__ cnt) {
     const u32 p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -451,16 +484,18 @@ int yh_build_partitions(yh_db* db, const u64* d_values, const u64* d_offsets, u3
             rc = YH_ERR_HIP;
             break;
         }
-        if (N) {
-            k_scatter<<<grid_for(N * WAVE, 256), 256, 0, st>>>(d_values, d_offsets, N, P, pshift, d_split, db->d_pbeg,
-                                                               db->d_poffs, db->d_pvals);
-        }
         db->kshift = pshift > 32 ? pshift - 32 : 0;
         const char* wide = getenv("YH_WIDE_KEYS");
         if (!(wide && wide[0] == '1')) {
             rc = yh_dmalloc(db, (void**)&db->d_pkeys, (pos + 8) * sizeof(u32));
+            if (rc == YH_OK) rc = yh_dmalloc(db, (void**)&db->d_pref, (pos + 8) * sizeof(u32));
             if (rc != YH_OK) break;
-            k_make_keys<<<grid_for(pos + 1, 256), 256, 0, st>>>(db->d_pvals, pos, db->kshift, db->d_pkeys);
+            if (hipMemsetAsync(db->d_pkeys, 0, (pos + 8) * sizeof(u32), st) != hipSuccess ||
+                hipMemsetAsync(db->d_pref, 0, (pos + 8) * sizeof(u32), st) != hipSuccess) { yh_set_error("memset failed"); rc = YH_ERR_HIP; break; }
+        }
+        if (N) {
+            k_scatter<<<grid_for(N * WAVE, 256), 256, 0, st>>>(d_values, d_offsets, N, P, pshift, d_split, db->d_pbeg,
+                                                               db->d_poffs, db->d_pvals, db->kshift, db->d_pkeys, db->d_pref);
         }
         if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) {
             yh_set_error("partition scatter failed");
@@ -593,6 +628,57 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, const u
             rc = yh_dmalloc(db, (void**)&db->d_gkeys, (db->n_shared + 8) * sizeof(u32));
             if (rc == YH_OK)
                 k_make_keys<<<grid_for(db->n_shared, 256), 256, 0, st>>>(db->d_g, db->n_shared, db->kshift, db->d_gkeys);
+        }
+        if (rc == YH_OK && db->n_postings && N) {
+            u32 *d_cc = nullptr, *d_cpo = nullptr, *d_cur = nullptr;
+            void* d_st = nullptr;
+            size_t st_bytes = 0;
+            rc = yh_dmalloc(db, (void**)&db->d_rpo, (N + 1) * sizeof(u32));
+            if (rc == YH_OK) rc = yh_dmalloc(db, (void**)&db->d_rg, db->n_postings * sizeof(u32));
+            IDX_HIP(hipMalloc((void**)&d_cc, N * sizeof(u32)));
+            IDX_HIP(hipMalloc((void**)&d_cpo, (N + 1) * sizeof(u32)));
+            IDX_HIP(hipMalloc((void**)&d_cur, N * sizeof(u32)));
+            IDX_HIP(rocprim::inclusive_scan(nullptr, st_bytes, db->d_nshared, db->d_rpo + 1, N, rocprim::plus<u32>(), st));
+            IDX_HIP(hipMalloc(&d_st, st_bytes + 256));
+            IDX_HIP(hipMemsetAsync(db->d_rpo, 0, sizeof(u32), st));
+            IDX_HIP(hipMemsetAsync(d_cpo, 0, sizeof(u32), st));
+            IDX_HIP(hipMemsetAsync(d_cur, 0, N * sizeof(u32), st));
+            IDX_HIP(rocprim::inclusive_scan(d_st, st_bytes, db->d_nshared, db->d_rpo + 1, N, rocprim::plus<u32>(), st));
+            if (rc == YH_OK) k_chunk_counts<<<(u32)((N + 255) / 256), 256, 0, st>>>(db->d_nshared, N, d_cc);
+            IDX_HIP(rocprim::inclusive_scan(d_st, st_bytes, d_cc, d_cpo + 1, N, rocprim::plus<u32>(), st));
+            u32 n_chunks = 0;
+            IDX_HIP(hipMemcpyAsync(&n_chunks, d_cpo + N, sizeof(u32), hipMemcpyDeviceToHost, st));
+            IDX_HIP(hipStreamSynchronize(st));
+            db->n_chunks = n_chunks;
+            if (rc == YH_OK) rc = yh_dmalloc(db, (void**)&db->d_chunks, ((u64)n_chunks + 64) * sizeof(uint2));
+            u64* d_crec = nullptr;
+            u64 *d_ck = nullptr, *d_ck2 = nullptr;
+            void* d_st2 = nullptr;
+            size_t st2_bytes = 0;
+            IDX_HIP(hipMalloc((void**)&d_crec, std::max<u64>(n_chunks, 1) * sizeof(u64)));
+            IDX_HIP(hipMalloc((void**)&d_ck, std::max<u64>(n_chunks, 1) * sizeof(u64)));
+            IDX_HIP(hipMalloc((void**)&d_ck2, std::max<u64>(n_chunks, 1) * sizeof(u64)));
+            if (rc == YH_OK) {
+                k_fill_rg<<<grid_for(db->n_postings, 256), 256, 0, st>>>(db->n_postings, db->d_pr, db->d_pg, db->d_rpo, d_cur,
+                                                                         db->d_rg);
+                k_fill_chunks<<<(u32)((N + 255) / 256), 256, 0, st>>>(N, db->d_rpo, d_cpo, d_crec, d_ck);
+            }
+            IDX_HIP(hipGetLastError());
+            if (n_chunks) {
+                u64* out = reinterpret_cast<u64*>(db->d_chunks);
+                IDX_HIP(rocprim::radix_sort_pairs(nullptr, st2_bytes, d_ck, d_ck2, d_crec, out, n_chunks, 0, 64, st));
+                IDX_HIP(hipMalloc(&d_st2, st2_bytes + 256));
+                IDX_HIP(rocprim::radix_sort_pairs(d_st2, st2_bytes, d_ck, d_ck2, d_crec, out, n_chunks, 0, 64, st));
+            }
+            IDX_HIP(hipStreamSynchronize(st));
+            (void)hipFree(d_crec);
+            (void)hipFree(d_ck);
+            (void)hipFree(d_ck2);
+            (void)hipFree(d_st2);
+            (void)hipFree(d_cc);
+            (void)hipFree(d_cpo);
+            (void)hipFree(d_cur);
+            (void)hipFree(d_st);
         }
         if (db->n_shared) {
             k_bounds_u64<<<(db->n_parts + 255) / 256, 256, 0, st>>>(db->d_g, db->n_shared, db->n_parts, db->pshift,

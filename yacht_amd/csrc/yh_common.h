@@ -57,6 +57,10 @@ void yh_set_error(const char* fmt, ...);
 #ifndef YH_TILE_UNROLL
 #define YH_TILE_UNROLL 4
 #endif
+// the same for the 32-bit key kernel (4 keys per vector): 2 measured 3-5 % faster than 4, 1 slower
+#ifndef YH_TILE_UNROLL32
+#define YH_TILE_UNROLL32 2
+#endif
 #ifndef YH_TILE_WAVES_PER_SIMD
 #define YH_TILE_WAVES_PER_SIMD 4
 #endif
@@ -79,6 +83,8 @@ static_assert(TILE_SLOTS <= 65536, "directory entries are uint16 slot numbers");
 #endif
 constexpr int TILE_QCAP = YH_TILE_QCAP;
 static_assert(TILE_UNROLL * 2 <= 32, "candidate masks are 32-bit");
+constexpr int TILE_UNROLL32 = YH_TILE_UNROLL32;
+static_assert(TILE_UNROLL32 * 4 <= 32, "candidate masks are 32-bit");
 
 constexpr int EXCL_QBLOCKS = 4096;  // workgroups (= queue segments) of k_excl_collect / k_excl_apply
 
@@ -136,7 +142,15 @@ struct yh_db {
     u32* d_dref = nullptr;     // [D] its single holder, or 0x80000000 | index into d_g
     u32* d_dir = nullptr;      // [dir_nb + 1] first index of d_dh whose (hash >> dir_shift) >= bucket
     u32 dir_shift = 0, dir_nb = 0;
+    // reference-major view of the postings, cut into chunks of <= 64 (one wave each): the
+    // exclusive pass visits only the chunks of masked references instead of streaming pr[]
+    u32* d_rpo = nullptr;      // [N + 1] first posting of reference r in d_rg
+    u32* d_rg = nullptr;       // [n_postings] shared-hash index, grouped by reference
+    uint2* d_chunks = nullptr; // [n_chunks] (reference, first posting in d_rg)
+    u32 n_chunks = 0;
+    bool excl_prefer_stream = false;  // set by the host-mask entry point when most references are masked
     u32* d_pkeys = nullptr;    // [pvals_len] 32-bit keys of d_pvals: (u32)(hash >> kshift); the stream K1 reads
+    u32* d_pref = nullptr;     // [pvals_len] reference id of every stream position
     u32* d_gkeys = nullptr;    // [n_shared] the same keys of d_g
     u32 kshift = 0;            // pshift - 32 when pshift > 32, else 0 (keys then carry every in-partition bit)
     uint4* d_bkt = nullptr;    // [bkt_nb] 64-byte buckets over the distinct hashes (YhDirView below)

@@ -405,6 +405,8 @@ k_tile_lookup(const u64* __restrict__ vals,     // hash stream, grouped by parti
 // bits.  So a key match is a CANDIDATE (one per ~2^21 reference hashes at rs214 scale is false):
 // it is queued like a hit and k_resolve_hits32 confirms it against the full 64-bit arrays
 // (d_pvals / d_g, read at the few queued positions only) and the sample before counting.
+// (Confirming at the end of each workgroup instead of in a second launch was tried: the step time
+// stayed the same, the streaming kernel just absorbed the 20 us.)
 // Differences to the 64-bit kernel, all because the stream is no longer the only bottleneck:
 //   * 4 keys per 16-byte load; the bitmap is a blocked Bloom filter, two bits of one word per key
 //     (word from key bits 5..17, bits from 0..4 and 18..22): one LDS read as before, ~10x fewer
@@ -415,69 +417,108 @@ k_tile_lookup(const u64* __restrict__ vals,     // hash stream, grouped by parti
 // predecessor ended with the same key was already reported there and is skipped (skip0).
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 
+// A queued candidate: x = side << 63 | position in the stream (d_pkeys / d_gkeys index),
+// y = index of the first sample hash with the same key.  Confirming it takes the 64-bit hash at
+// that position, the sample from y on (equal keys are consecutive; almost always one read) and,
+// for the main stream, the reference id stored per stream position (d_pref): three independent
+// reads, no search.
 struct NarrowHit {
-    static constexpr bool kQueued = true;
-    const u32* poffs;  // [P][N+1]
     u32 n_refs;
     u32* reps;
     u32 rep_mask;
-    u64* queue;        // [wgs][qcap]  (tag << 63 | partition << 32 | rel)
+    u64x2* queue;      // [wgs][qcap]
     u32 qcap;
     const u64* vals;   // d_pvals
-    const u64* pbeg;
+    const u32* pref;   // d_pref: reference of every stream position
     const u64* g;      // d_g (side stream), may be null
-    const u64* gbeg;
     u8* hitflag;       // [G]
     const u64* sample;
-    const u32* sbounds;
+    u32 n_sample;
     u32 exact;         // kshift == 0: a key match is a hash match
 
-    __device__ __forceinline__ bool member(u32 p, u64 h) const {
+    // true when candidate x is a real member of the sample (the 64-bit hashes agree)
+    __device__ __forceinline__ bool confirm(u64 x, u32 sidx) const {
         if (exact) return true;
-        u32 lo = sbounds[p];
-        const u32 end = sbounds[p + 1];
-        u32 hi = end;
-        while (lo < hi) {
-            const u32 mid = lo + ((hi - lo) >> 1);
-            if (sample[mid] < h) lo = mid + 1; else hi = mid;
-        }
-        return lo < end && sample[lo] == h;
+        const u64 pos = x & 0x7fffffffffffffffull;
+        const u64 h = (x >> 63) ? g[pos] : vals[pos];
+        u32 i = sidx;
+        u64 s = sample[i];
+        while (s < h && ++i < n_sample) s = sample[i];
+        return s == h;
     }
-    __device__ __forceinline__ void count(u32 wg, u32 ptag, u32 rel) const {
-        const u32 p = ptag & 0x7fffffffu;
-        if (ptag >> 31) {
-            const u64 k = gbeg[p] + rel;
-            if (member(p, g[k])) hitflag[k] = 1;
-            return;
-        }
-        if (!member(p, vals[pbeg[p] + rel])) return;
-        const u32 j = resolve_ref(poffs + (u64)p * (n_refs + 1), n_refs, rel);
-        atomicAdd(&reps[(u64)(wg & rep_mask) * n_refs + j], 1u);
-    }
-    __device__ __forceinline__ void operator()(const HitCtx& c, u32 ptag, u64 rel) const {
-        const u32 slot = atomicAdd(c.q_fill, 1u);
-        if (slot < (u32)TILE_QCAP) c.q[slot] = ((u64)ptag << 32) | (u64)(u32)rel;
-        else count(c.wg, ptag, (u32)rel);
+    __device__ __forceinline__ void count(u32 wg, u64 x, u32 sidx) const {
+        if (!confirm(x, sidx)) return;
+        const u64 pos = x & 0x7fffffffffffffffull;
+        if (x >> 63) hitflag[pos] = 1;
+        else atomicAdd(&reps[(u64)(wg & rep_mask) * n_refs + pref[pos]], 1u);
     }
 };
-
-__global__ void __launch_bounds__(256) k_resolve_hits32(const u32* __restrict__ qcount, NarrowHit hit) {
-    const u32 wg = blockIdx.x;
-    const u32 cnt = qcount[wg];
-    const u64* q = hit.queue + (u64)wg * hit.qcap;
-    for (u32 e = threadIdx.x; e < cnt; e += blockDim.x) {
-        const u64 x = q[e];
-        hit.count(wg, (u32)(x >> 32), (u32)x);
+struct HitCtx32 {
+    u32* q_fill;
+    u64x2* q;
+    u32 wg;
+};
+__device__ __forceinline__ void push_hit(const NarrowHit& hit, const HitCtx32& c, u64 x, u32 sidx) {
+    const u32 slot = atomicAdd(c.q_fill, 1u);
+    if (slot < (u32)TILE_QCAP) {
+        u64x2 e;
+        e.x = x;
+        e.y = sidx;
+        c.q[slot] = e;
+    } else {
+        hit.count(c.wg, x, sidx);
     }
 }
 
-__device__ __forceinline__ u32 bloom_mask(u32 key) { return (1u << (key & 31u)) | (1u << ((key >> 18) & 31u)); }
+// One workgroup per queue segment: confirm, then count (or flag) with every lane busy.  A
+// workgroup's candidates come from one contiguous slice of the partition-major, reference-major
+// stream, i.e. from few references with several hits each; they are summed in a small LDS table
+// first and leave as one global atomic per (workgroup, reference).
+constexpr int RES_SLOTS = 1024;
+__global__ void __launch_bounds__(256) k_resolve_hits32(const u32* __restrict__ qcount, NarrowHit hit) {
+    __shared__ u32 tkey[RES_SLOTS];  // reference + 1, 0 = empty
+    __shared__ u32 tcnt[RES_SLOTS];
+    const u32 wg = blockIdx.x;
+    const u32 cnt = qcount[wg];
+    if (cnt == 0) return;
+    for (u32 k = threadIdx.x; k < RES_SLOTS; k += blockDim.x) { tkey[k] = 0; tcnt[k] = 0; }
+    __syncthreads();
+    const u64x2* q = hit.queue + (u64)wg * hit.qcap;
+    u32* my = hit.reps + (u64)(wg & hit.rep_mask) * hit.n_refs;
+    for (u32 e = threadIdx.x; e < cnt; e += blockDim.x) {
+        const u64x2 x = q[e];
+        if (!hit.confirm(x.x, (u32)x.y)) continue;
+        const u64 pos = x.x & 0x7fffffffffffffffull;
+        if (x.x >> 63) { hit.hitflag[pos] = 1; continue; }
+        const u32 r = hit.pref[pos];
+        u32 slot = (r * 2654435761u) >> (32 - 10);
+        bool done = false;
+        for (int probe = 0; probe < 8 && !done; ++probe, slot = (slot + 1) & (RES_SLOTS - 1)) {
+            const u32 old = atomicCAS(&tkey[slot], 0u, r + 1);
+            if (old == 0 || old == r + 1) { atomicAdd(&tcnt[slot], 1u); done = true; }
+        }
+        if (!done) atomicAdd(&my[r], 1u);  // crowded table: count directly
+    }
+    __syncthreads();
+    for (u32 k = threadIdx.x; k < RES_SLOTS; k += blockDim.x)
+        if (tkey[k]) atomicAdd(&my[tkey[k] - 1], tcnt[k]);
+}
+
+#ifndef YH_BLOOM2
+#define YH_BLOOM2 1
+#endif
+__device__ __forceinline__ u32 bloom_mask(u32 key) {
+    return YH_BLOOM2 ? (1u << (key & 31u)) | (1u << ((key >> 18) & 31u)) : (1u << (key & 31u));
+}
+__device__ __forceinline__ u32 bloom_test(u32 w, u32 key) {
+    return YH_BLOOM2 ? ((w >> (key & 31u)) & (w >> ((key >> 18) & 31u))) & 1u : (w >> (key & 31u)) & 1u;
+}
 __device__ __forceinline__ u32 bloom_word(u32 key) { return (key >> 5) & (u32)(TILE_BM_WORDS - 1); }
 
-__device__ __forceinline__ void tile_stream32(const u32* __restrict__ keys, u64 start, u64 end, u64 e0, u32 ptag, u32 n,
+__device__ __forceinline__ void tile_stream32(const u32* __restrict__ keys, u64 start, u64 end, u64 tag, u32 sub, u32 n,
                                               u32 ksh, bool skip0, const u32* S, const u16* E, const u32* BM,
-                                              const NarrowHit& hit, const HitCtx& ctx) {
-    constexpr int U = TILE_UNROLL;
+                                              const NarrowHit& hit, const HitCtx32& ctx) {
+    constexpr int U = TILE_UNROLL32;
     constexpr int B = 4 * U;
     const u32 tid = threadIdx.x;
 
@@ -485,7 +526,7 @@ __device__ __forceinline__ void tile_stream32(const u32* __restrict__ keys, u64 
         u32 k = E[(key >> ksh) & (TILE_NB - 1)];
         u32 v = S[k];
         while (v < key) v = S[++k];  // sentinel 0xffffffff stops the scan
-        if (v == key && k < n && !(skip0 && k == 0)) hit(ctx, ptag, pos - e0);
+        if (v == key && k < n && !(skip0 && k == 0)) push_hit(hit, ctx, tag | pos, sub + k);
     };
 
     u64 i = start;
@@ -522,7 +563,7 @@ __device__ __forceinline__ void tile_stream32(const u32* __restrict__ keys, u64 
             for (int b = 0; b < B; ++b) w[b] = BM[bloom_word(h[b])];
             u32 cand = 0;
 #pragma unroll
-            for (int b = 0; b < B; ++b) cand |= (((w[b] >> (h[b] & 31u)) & (w[b] >> ((h[b] >> 18) & 31u))) & 1u) << b;
+            for (int b = 0; b < B; ++b) cand |= bloom_test(w[b], h[b]) << b;
             cand &= valid;
             while (cand) {  // rare: exact lookup of the candidates this lane holds
                 const u32 b = (u32)__ffs((int)cand) - 1u;
@@ -549,11 +590,11 @@ k_tile_lookup32(const u32* __restrict__ keys,     // key stream, grouped by part
                 const u64* __restrict__ sample, const u32* __restrict__ sbounds, u32 pshift, u32 kshift,
                 u32* __restrict__ qcount, NarrowHit hit,
                 const u32* __restrict__ gkeys,    // side stream (keys of d_g) or nullptr
-                const u64* __restrict__ gcnt) {
+                const u64* __restrict__ gbeg, const u64* __restrict__ gcnt) {
     __shared__ __attribute__((aligned(16))) u32 S[TILE_SLOTS];
     __shared__ __attribute__((aligned(16))) u32 BM[TILE_BM_WORDS];
     __shared__ u16 E[TILE_NB];
-    __shared__ u64 Q[TILE_QCAP];
+    __shared__ u64x2 Q[TILE_QCAP];
     __shared__ u32 q_fill;
     __shared__ u32 g_fill;
 
@@ -563,7 +604,7 @@ k_tile_lookup32(const u32* __restrict__ keys,     // key stream, grouped by part
     per = (per + 3) & ~3ull;  // slices stay 16-byte aligned
     const u64 w0 = (u64)lid * per;
     const u64 w1 = min(total_len, w0 + per);
-    const HitCtx ctx{&q_fill, Q, lid};
+    const HitCtx32 ctx{&q_fill, Q, lid};
     if (tid == 0) { q_fill = 0; g_fill = 0; }
     if (w0 >= w1) {
         if (tid == 0) qcount[lid] = 0;
@@ -574,9 +615,9 @@ k_tile_lookup32(const u32* __restrict__ keys,     // key stream, grouped by part
         const u32 f = min(q_fill, (u32)TILE_QCAP);
         const u32 g0 = g_fill;
         for (u32 e = tid; e < f; e += TILE_THREADS) {
-            const u64 x = Q[e];
+            const u64x2 x = Q[e];
             if (g0 + e < hit.qcap) hit.queue[(u64)lid * hit.qcap + g0 + e] = x;
-            else hit.count(lid, (u32)(x >> 32), (u32)x);
+            else hit.count(lid, x.x, (u32)x.y);
         }
         __syncthreads();
         if (tid == 0) { q_fill = 0; g_fill = g0 + f; }
@@ -627,11 +668,11 @@ k_tile_lookup32(const u32* __restrict__ keys,     // key stream, grouped by part
                     for (u32 x = b + 1; x < (u32)TILE_NB; ++x) E[x] = (u16)n;
             }
             __syncthreads();
-            tile_stream32(keys, start, end, e0, p, n, ksh, skip0, S, E, BM, hit, ctx);
+            tile_stream32(keys, start, end, 0ull, sub, n, ksh, skip0, S, E, BM, hit, ctx);
             if (gkeys) {  // this workgroup's share of the shared hashes of partition p
-                const u64 cnt = pcnt[p], gc = gcnt[p], g0 = hit.gbeg[p];
+                const u64 cnt = pcnt[p], gc = gcnt[p], g0 = gbeg[p];
                 const u64 gs = g0 + gc * (start - e0) / cnt, ge = g0 + gc * (end - e0) / cnt;
-                if (gs < ge) tile_stream32(gkeys, gs, ge, g0, p | 0x80000000u, n, ksh, skip0, S, E, BM, hit, ctx);
+                if (gs < ge) tile_stream32(gkeys, gs, ge, 1ull << 63, sub, n, ksh, skip0, S, E, BM, hit, ctx);
             }
         }
     }
@@ -778,6 +819,62 @@ __global__ void __launch_bounds__(EXCL_BLOCK) k_excl_apply(const u32* __restrict
     }
 }
 
+// The same sums without the pass over pr[]: the reference-major view of the postings is cut into
+// chunks of <= 64 (d_chunks), stored so that neighbouring records belong to DIFFERENT references
+// (sorted by the chunk's number inside its reference).  A wave tests 64 records at once (one
+// coalesced load, one mask bit each) and walks only the chunks of masked references, every lane
+// on one posting: holder lists four at a time, ballots, three sums per chunk.  A heavy reference's
+// chunks are spread over as many waves.  (With most references masked the streaming pair above is
+// ~3x faster: its reads are coalesced.)
+__global__ void __launch_bounds__(256) k_excl_chunks(u32 n_chunks, const uint2* __restrict__ chunks,
+                                                     const u32* __restrict__ rpo, const u32* __restrict__ rg,
+                                                     const u64* __restrict__ po, const u32* __restrict__ pr,
+                                                     const u32* __restrict__ maskbits, const u8* __restrict__ hit,
+                                                     u32* __restrict__ ex_e, u32* __restrict__ ex_m,
+                                                     u32* __restrict__ ovsh) {
+    const u32 lane = threadIdx.x & 63u;
+    const u32 c = (u32)((blockIdx.x * (u64)blockDim.x + threadIdx.x));  // this lane's record
+    uint2 mine = make_uint2(0u, 0u);
+    bool want = false;
+    if (c < n_chunks) {
+        mine = chunks[c];
+        want = (maskbits[mine.x >> 5] >> (mine.x & 31u)) & 1u;
+    }
+    u64 todo = __ballot(want);
+    while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const u32 r = (u32)__shfl((int)mine.x, src);
+        const u32 k = (u32)__shfl((int)mine.y, src) + lane;
+        bool e = false, m = false, o = false;
+        if (k < rpo[r + 1]) {
+            const u32 gi = rg[k];
+            const u64 q0 = po[gi], q1 = po[gi + 1];
+            const bool in_sample = hit[gi] != 0;
+            u32 cnt = 0;
+            for (u64 q = q0; q < q1; q += 4) {  // holders four at a time: the loads of a step are independent
+                u32 h[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) h[t] = pr[min(q + t, q1 - 1)];
+                u32 mw[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) mw[t] = maskbits[h[t] >> 5];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) cnt += (q + t < q1) ? ((mw[t] >> (h[t] & 31u)) & 1u) : 0u;
+            }
+            e = (cnt == 1);
+            m = e && in_sample;
+            o = in_sample;
+        }
+        const u32 ne = (u32)__popcll(__ballot(e)), nm = (u32)__popcll(__ballot(m)), no = (u32)__popcll(__ballot(o));
+        if (lane == 0) {
+            if (ne) atomicAdd(&ex_e[r], ne);
+            if (nm) atomicAdd(&ex_m[r], nm);
+            if (no) atomicAdd(&ovsh[r], no);
+        }
+    }
+}
+
 // e_j = (hashes of j that no other reference of the whole database has) + ex_e[j]
 // m_j = (overlap_j - overlap restricted to database-shared hashes)      + ex_m[j]
 __global__ void k_excl_final(u64 n, const u8* __restrict__ mask, const u32* __restrict__ sizes,
@@ -917,14 +1014,15 @@ inline u32 grid_for(u64 work_items, u32 block, u32 max_blocks = 16384) {
     return (u32)g;
 }
 
-// Workgroups for the tile kernel: YH_TILE_WGS (default 8 per CU on a 256-CU part, two of them
-// resident at a time: four rounds even out the tail), never so many that a workgroup gets less
-// than 256 KiB of stream per tile it has to stage.
+// Workgroups for the tile kernel: YH_TILE_WGS (default 512 = the two resident workgroups of each
+// of the 256 CUs, one round: with the 4-byte key stream the tile set-ups of further rounds cost
+// more than the tail they even out; measured 0.236 ms at 256-512, 0.246-0.253 ms at 1024-2048),
+// never so many that a workgroup gets less than 128 KiB of stream per tile it has to stage.
 inline u32 tile_grid(u64 stream_len) {
     static int wgs_env = -1;
     if (wgs_env < 0) {
         const char* e = getenv("YH_TILE_WGS");
-        wgs_env = (e && atoi(e) > 0) ? atoi(e) : 2048;
+        wgs_env = (e && atoi(e) > 0) ? atoi(e) : 512;
     }
     u64 g = (u64)wgs_env;
     const u64 max_g = std::max<u64>(1, stream_len / 32768);  // a tile set-up must pay for itself
@@ -971,7 +1069,7 @@ int yh_q_overlap(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap, b
         if (db->d_hitq) { (void)hipFree(db->d_hitq); db->d_hitq = nullptr; }
         if (db->d_hitq_cnt) { (void)hipFree(db->d_hitq_cnt); db->d_hitq_cnt = nullptr; }
         db->hitq_wgs = db->hitq_cap = 0;
-        YH_HIP(hipMalloc((void**)&db->d_hitq, (u64)wgs * qcap * sizeof(u64)));
+        YH_HIP(hipMalloc((void**)&db->d_hitq, (u64)wgs * qcap * 2 * sizeof(u64)));  // 16-byte entries (key stream)
         YH_HIP(hipMalloc((void**)&db->d_hitq_cnt, (u64)wgs * sizeof(u32)));
         db->hitq_wgs = wgs;
         db->hitq_cap = qcap;
@@ -994,12 +1092,12 @@ int yh_q_overlap(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap, b
     k_prep<<<1024, 256, 0, st>>>(d_sample, (u32)n_sample, P, db->pshift, db->d_sbounds, z);
     if (db->d_pkeys) {  // the 32-bit key stream (default); YH_WIDE_KEYS=1 at creation keeps the 64-bit kernel
         const bool side = flag_shared && db->d_gkeys;
-        NarrowHit nh{db->d_poffs, (u32)N, db->d_reps, R - 1, db->d_hitq, db->hitq_cap, db->d_pvals, db->d_pbeg,
-                     side ? db->d_g : nullptr, db->d_gbeg, db->d_hit, d_sample, db->d_sbounds, db->kshift == 0 ? 1u : 0u};
+        NarrowHit nh{(u32)N, db->d_reps, R - 1, reinterpret_cast<u64x2*>(db->d_hitq), db->hitq_cap, db->d_pvals, db->d_pref,
+                     side ? db->d_g : nullptr, db->d_hit, d_sample, (u32)n_sample, db->kshift == 0 ? 1u : 0u};
         yh_ring_record_begin(db, db->ev_overlap);
         k_tile_lookup32<<<wgs, TILE_THREADS, 0, st>>>(db->d_pkeys, db->d_pbeg, db->d_pcnt, P, db->pvals_len, d_sample,
                                                       db->d_sbounds, db->pshift, db->kshift, db->d_hitq_cnt, nh,
-                                                      side ? db->d_gkeys : nullptr, db->d_gcnt);
+                                                      side ? db->d_gkeys : nullptr, db->d_gbeg, db->d_gcnt);
         yh_ring_record_end(db, db->ev_overlap);
         k_resolve_hits32<<<wgs, 256, 0, st>>>(db->d_hitq_cnt, nh);
         k_reduce_replicas<<<(u32)((N + 255) / 256), 256, 0, st>>>(db->d_reps, R, N, d_overlap, make_mask ? db->d_mask : nullptr,
@@ -1104,7 +1202,12 @@ int yh_q_exclusive_partial(yh_db* db, const u8* d_mask, const u64* d_sample, u64
                 db->d_g, db->d_gbeg, db->d_gcnt, P, G, d_sample, db->d_sbounds, db->pshift, nullptr, fh,
                 SideStream{nullptr, nullptr, nullptr, nullptr});
         }
-        {
+        static const bool stream_env = [] { const char* e = getenv("YH_EXCL_STREAM"); return e && e[0] == '1'; }();
+        if (db->d_chunks && !stream_env && !db->excl_prefer_stream) {
+            if (db->n_chunks)
+                k_excl_chunks<<<(db->n_chunks + 255) / 256, 256, 0, st>>>(db->n_chunks, db->d_chunks, db->d_rpo, db->d_rg, db->d_po,
+                                                                     db->d_pr, d_maskbits, db->d_hit, d_ex_e, d_ex_m, d_ovsh);
+        } else {
             const u64 vecs = (db->n_postings >> 2) + 1;
             const u32 blocks = (u32)std::min<u64>(EXCL_QBLOCKS, (vecs + EXCL_BLOCK - 1) / EXCL_BLOCK);
             const u64 chunk = (vecs + blocks - 1) / blocks;
