@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""HBM traffic per launch of k_tile_lookup32 (the dominant kernel) from the rocprofv3 --pmc passes.
+"""HBM traffic per launch of k_tile_lookup_keys (the dominant kernel) from the rocprofv3 --pmc passes.
 
     python scripts/make_traffic_json.py gpurun_out profiles/traffic_r01.json <n_hashes>
 
@@ -27,11 +27,11 @@ def mean_counter(d, counter, kernel_tag):
     return sum(vals) / len(vals), len(vals)
 
 
-fetch_kib, nf = mean_counter("pmc_fetch", "FETCH_SIZE", "k_tile_lookup32")
-write_kib, nw = mean_counter("pmc_write", "WRITE_SIZE", "k_tile_lookup32")
+fetch_kib, nf = mean_counter("pmc_fetch", "FETCH_SIZE", "k_tile_lookup_keys")
+write_kib, nw = mean_counter("pmc_write", "WRITE_SIZE", "k_tile_lookup_keys")
 hbm = 2.0 * fetch_kib * 1024.0 + write_kib * 1024.0
 json.dump({
-    "kernel": "k_tile_lookup32",
+    "kernel": "k_tile_lookup_keys",
     "n_hashes": n_hashes,
     "FETCH_SIZE_KiB_mean": fetch_kib, "launches_fetch": nf,
     "WRITE_SIZE_KiB_mean": write_kib, "launches_write": nw,

@@ -144,7 +144,11 @@ __global__ void k_scatter(const u64* __restrict__ values, const u64* __restrict_
             const u64 dst = pbeg[p] + poffs[(u64)p * (n_refs + 1) + j] + (k - sp[p]);
             pvals[dst] = h;
             if (pkeys) {
-                pkeys[dst] = (u32)(h >> kshift);
+                const u32 key = (u32)(h >> kshift) & KEY_MASK;
+                u8* kb = reinterpret_cast<u8*>(pkeys);
+                kb[yh_key_byte_addr(dst, 0)] = (u8)key;
+                kb[yh_key_byte_addr(dst, 1)] = (u8)(key >> 8);
+                kb[yh_key_byte_addr(dst, 2)] = (u8)(key >> 16);
                 pref[dst] = (u32)j;
             }
         }
@@ -319,7 +323,7 @@ __global__ void k_bkt_build(const u64* __restrict__ dh, const u32* __restrict__ 
 // so (u32)(h >> kshift) orders and (almost always) identifies the hashes of a partition.
 __global__ void k_make_keys(const u64* __restrict__ v, u64 n, u32 kshift, u32* __restrict__ keys) {
     for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x)
-        keys[i] = (u32)(v[i] >> kshift);
+        keys[i] = (u32)(v[i] >> kshift) & KEY_MASK;
 }
 
 // ---- reference-major chunk view of the postings ---------------------------------------------------
@@ -473,7 +477,7 @@ int yh_build_partitions(yh_db* db, const u64* d_values, const u64* d_offsets, u3
         for (u32 p = 0; p < P; ++p) {
             h_pbeg[p] = pos;
             pos += h_pcnt[p];
-            pos = (pos + 3) & ~3ull;  // every partition starts on a 16-byte boundary of the 32-bit key stream
+            pos = (pos + (KEY_BLOCK - 1)) & ~(u64)(KEY_BLOCK - 1);  // every partition starts on a key-block boundary
         }
         db->pvals_len = pos;
         rc = yh_dmalloc(db, (void**)&db->d_pvals, std::max<u64>(pos, 2) * sizeof(u64));
@@ -484,13 +488,14 @@ int yh_build_partitions(yh_db* db, const u64* d_values, const u64* d_offsets, u3
             rc = YH_ERR_HIP;
             break;
         }
-        db->kshift = pshift > 32 ? pshift - 32 : 0;
+        db->kshift = pshift > (u32)KEY_BITS ? pshift - KEY_BITS : 0;
         const char* wide = getenv("YH_WIDE_KEYS");
         if (!(wide && wide[0] == '1')) {
-            rc = yh_dmalloc(db, (void**)&db->d_pkeys, (pos + 8) * sizeof(u32));
+            const u64 key_bytes = (pos / KEY_BLOCK) * KEY_BLOCK_BYTES + 256;
+            rc = yh_dmalloc(db, (void**)&db->d_pkeys, key_bytes);
             if (rc == YH_OK) rc = yh_dmalloc(db, (void**)&db->d_pref, (pos + 8) * sizeof(u32));
             if (rc != YH_OK) break;
-            if (hipMemsetAsync(db->d_pkeys, 0, (pos + 8) * sizeof(u32), st) != hipSuccess ||
+            if (hipMemsetAsync(db->d_pkeys, 0, key_bytes, st) != hipSuccess ||
                 hipMemsetAsync(db->d_pref, 0, (pos + 8) * sizeof(u32), st) != hipSuccess) { yh_set_error("memset failed"); rc = YH_ERR_HIP; break; }
         }
         if (N) {

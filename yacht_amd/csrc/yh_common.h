@@ -65,8 +65,10 @@ void yh_set_error(const char* fmt, ...);
 #define YH_TILE_WAVES_PER_SIMD 4
 #endif
 // mean sketch size / YH_PIECE_TARGET = number of hash-range partitions aimed for at build time
+// (2 -> P = 1049 at rs214 scale: ~950 sample hashes per tile; measured K1 0.182 ms against 0.192 ms
+// at 4 / P = 525 and 0.253 ms at 8 / P = 263: fewer sample keys per tile = fewer candidates)
 #ifndef YH_PIECE_TARGET
-#define YH_PIECE_TARGET 4
+#define YH_PIECE_TARGET 2
 #endif
 constexpr int TILE_SLOTS = YH_TILE_SLOTS;
 constexpr int TILE_CAP = TILE_SLOTS - 2;  // sample hashes per tile
@@ -83,6 +85,23 @@ static_assert(TILE_SLOTS <= 65536, "directory entries are uint16 slot numbers");
 #endif
 constexpr int TILE_QCAP = YH_TILE_QCAP;
 static_assert(TILE_UNROLL * 2 <= 32, "candidate masks are 32-bit");
+// The key stream K1 reads: KEY_BITS-bit keys, bit-packed, in blocks of KEY_BLOCK keys laid out so
+// that a wave reads one block with three fully coalesced 16-byte loads per lane:
+//   lane l holds keys 16l .. 16l+15 of the block = 48 bytes = pieces 0..2,
+//   piece u of lane l lives at byte  block*3072 + (u*64 + l)*16.
+// Partitions start on block boundaries (pvals / pref use the same, unswizzled, positions).
+constexpr int KEY_BITS = 24;
+constexpr u32 KEY_MASK = (1u << KEY_BITS) - 1u;
+constexpr int KEY_BLOCK = 1024;
+constexpr int KEY_BLOCK_BYTES = KEY_BLOCK * KEY_BITS / 8;  // 3072
+#if defined(__HIPCC__)
+__host__ __device__ inline u64 yh_key_byte_addr(u64 pos, u32 byte_of_key) {
+    const u64 blk = pos >> 10;
+    const u32 within = (u32)(pos & 1023u), lane = within >> 4, k = within & 15u;
+    const u32 j = 3u * k + byte_of_key;  // byte inside the lane's 48
+    return blk * (u64)KEY_BLOCK_BYTES + ((u64)(j >> 4) * 64u + lane) * 16u + (j & 15u);
+}
+#endif
 constexpr int TILE_UNROLL32 = YH_TILE_UNROLL32;
 static_assert(TILE_UNROLL32 * 4 <= 32, "candidate masks are 32-bit");
 
@@ -149,10 +168,10 @@ struct yh_db {
     uint2* d_chunks = nullptr; // [n_chunks] (reference, first posting in d_rg)
     u32 n_chunks = 0;
     bool excl_prefer_stream = false;  // set by the host-mask entry point when most references are masked
-    u32* d_pkeys = nullptr;    // [pvals_len] 32-bit keys of d_pvals: (u32)(hash >> kshift); the stream K1 reads
+    u32* d_pkeys = nullptr;    // packed KEY_BITS-bit keys of d_pvals, (hash >> kshift) & KEY_MASK: the stream K1 reads
     u32* d_pref = nullptr;     // [pvals_len] reference id of every stream position
-    u32* d_gkeys = nullptr;    // [n_shared] the same keys of d_g
-    u32 kshift = 0;            // pshift - 32 when pshift > 32, else 0 (keys then carry every in-partition bit)
+    u32* d_gkeys = nullptr;    // [n_shared] the same keys of d_g, one per 32-bit word
+    u32 kshift = 0;            // pshift - KEY_BITS when pshift > KEY_BITS, else 0 (keys then carry every in-partition bit)
     uint4* d_bkt = nullptr;    // [bkt_nb] 64-byte buckets over the distinct hashes (YhDirView below)
     u64 bkt_nb = 0;
     u32 bkt_lsh = 0;
@@ -174,6 +193,7 @@ struct yh_db {
     u64* d_hitq = nullptr;     // [hitq_wgs][hitq_cap] deferred overlap hits (partition << 32 | position)
     u32* d_hitq_cnt = nullptr; // [hitq_wgs]
     u32 hitq_wgs = 0, hitq_cap = 0;
+    u32* d_wg_first = nullptr; // [hitq_wgs] first partition of each workgroup's slice of the key stream
     u32* d_reps = nullptr;     // [R][N] replicated overlap counters
     u64 reps_cap = 0;
     void* d_batch = nullptr;   // scratch of the batched run: hit words, mask words, shared overlaps

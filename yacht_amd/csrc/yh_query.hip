@@ -396,23 +396,25 @@ k_tile_lookup(const u64* __restrict__ vals,     // hash stream, grouped by parti
     }
 }
 
-// ---- K1 over 32-bit keys --------------------------------------------------------------------------
-// Inside a partition the bits above pshift are constant, so the stream only needs the next 32 bits
-// below them: key = (u32)(h >> kshift), kshift = max(pshift, 32) - 32.  k_tile_lookup32 is the tile
-// kernel over the key arrays (d_pkeys, d_gkeys): HALF the bytes per reference hash.  Keys order the
-// hashes of a partition, so the tile structures work unchanged (S holds the sample's keys); what a
-// key cannot do when kshift > 0 is tell apart two hashes that differ only in their low kshift
-// bits.  So a key match is a CANDIDATE (one per ~2^21 reference hashes at rs214 scale is false):
-// it is queued like a hit and k_resolve_hits32 confirms it against the full 64-bit arrays
-// (d_pvals / d_g, read at the few queued positions only) and the sample before counting.
-// (Confirming at the end of each workgroup instead of in a second launch was tried: the step time
-// stayed the same, the streaming kernel just absorbed the 20 us.)
-// Differences to the 64-bit kernel, all because the stream is no longer the only bottleneck:
-//   * 4 keys per 16-byte load; the bitmap is a blocked Bloom filter, two bits of one word per key
-//     (word from key bits 5..17, bits from 0..4 and 18..22): one LDS read as before, ~10x fewer
-//     false candidates per wave;
-//   * the side stream's hits are queued too (tagged), not flagged in place: flagging needs the
-//     64-bit confirmation.
+// ---- K1 over packed keys ----------------------------------------------------------------------------
+// Inside a partition the bits above pshift are constant, so the stream only needs the KEY_BITS (24)
+// bits below them: key = (h >> kshift) & KEY_MASK, kshift = max(pshift, 24) - 24.  k_tile_lookup_keys
+// is the tile kernel over the packed key stream (d_pkeys): 3 bytes per reference hash instead of 8.
+// Keys order the hashes of a partition, so the tile structures work unchanged (S holds the sample's
+// keys); what a key cannot do when kshift > 0 is tell apart two hashes that differ only in their
+// low kshift bits.  So a key match is a CANDIDATE (at rs214 scale ~40 000 per launch are false,
+// against ~130 000 true hits): it is queued like a hit and k_resolve_hits32 confirms it against the
+// full 64-bit arrays (d_pvals / d_g, read at the queued positions only) and the sample before
+// counting.  (Confirming at the end of each workgroup instead of in a second launch was tried: the
+// step time stayed the same, the streaming kernel just absorbed the 20 us.)
+// The kernel is bound by HBM alone: running its filter stage twice per key changed its time by < 3 %
+// (timing-only build), which is why fewer bytes per key pay even at more instructions per key.
+//   * one wave reads a 1024-key block with three coalesced 16-byte loads per lane (layout:
+//     yh_common.h), the next block's loads in flight while this one is tested;
+//   * the bitmap is a blocked Bloom filter, two bits of one word per key (word from key bits 5..17,
+//     bits from 0..4 and 18..22): one LDS read per key, ~0.07 % of the misses survive it;
+//   * the side stream (shared hashes, d_gkeys, one key per 32-bit word, 1.6 % of the bytes) goes
+//     through tile_stream32; its hits are queued too (tagged): flagging needs the confirmation.
 // Tiles of one partition may split a run of equal keys; a match at slot 0 of a tile whose
 // predecessor ended with the same key was already reported there and is skipped (skip0).
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
@@ -584,13 +586,88 @@ __device__ __forceinline__ void tile_stream32(const u32* __restrict__ keys, u64 
     }
 }
 
+// first[lid] = last partition that starts at or before workgroup lid's slice (sample-independent:
+// computed once per handle instead of a 10-step dependent search at the start of every workgroup)
+__global__ void k_wg_first(const u64* __restrict__ pbeg, u32 P, u64 total_len, u32 wgs, u32* __restrict__ first) {
+    const u32 lid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lid >= wgs) return;
+    u64 per = (total_len + wgs - 1) / wgs;
+    per = (per + (KEY_BLOCK - 1)) & ~(u64)(KEY_BLOCK - 1);
+    const u64 w0 = (u64)lid * per;
+    u32 lo = 0, hi = P;
+    while (lo < hi) {
+        const u32 mid = (lo + hi) >> 1;
+        if (pbeg[mid] <= w0) lo = mid + 1; else hi = mid;
+    }
+    first[lid] = lo ? lo - 1 : 0;
+}
+
+// The main stream: packed 24-bit keys, one 1024-key block per wave and step (layout: yh_common.h).
+// `start` is a block boundary (partition starts and slice starts are); keys at positions >= end of
+// the last block are masked out.
+__device__ __forceinline__ void tile_stream24(const u32x4* __restrict__ pk, u64 start, u64 end, u32 sub, u32 n, u32 ksh,
+                                              bool skip0, const u32* S, const u16* E, const u32* BM, const NarrowHit& hit,
+                                              const HitCtx32& ctx, u32x4 c0, u32x4 c1, u32x4 c2) {
+    constexpr u32 WAVES = TILE_THREADS / 64;
+    constexpr int B = 16;
+    const u32 lane = threadIdx.x & 63u;
+    const u64 b1 = (end + (KEY_BLOCK - 1)) >> 10;
+    u64 blk = (start >> 10) + (threadIdx.x >> 6);
+    if (blk >= b1) return;
+
+    auto lookup1 = [&](u32 key, u64 pos) {
+        u32 k = E[(key >> ksh) & (TILE_NB - 1)];
+        u32 v = S[k];
+        while (v < key) v = S[++k];  // sentinel 0xffffffff stops the scan
+        if (v == key && k < n && !(skip0 && k == 0)) push_hit(hit, ctx, pos, sub + k);
+    };
+
+    // one block ahead (two blocks ahead measured the same: the kernel is not latency-bound)
+    // (c0..c2 = this wave's first block, loaded by the caller BEFORE it staged the tile)
+    auto addr = [&](u64 bk) { return pk + min(bk, b1 - 1) * 192 + lane; };  // clamped: a harmless re-read at the end
+    for (; blk < b1; blk += WAVES) {
+        const u32x4* pn = addr(blk + WAVES);
+        const u32x4 n0 = __builtin_nontemporal_load(pn), n1 = __builtin_nontemporal_load(pn + 64),
+                    n2 = __builtin_nontemporal_load(pn + 128);
+        const u32 W[12] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y, c2.z, c2.w};
+        u32 h[B];  // bits >= 24 of h[] may hold the next key's low byte: the filter only reads bits 0..22
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            h[4 * q] = W[3 * q];
+            h[4 * q + 1] = __builtin_amdgcn_alignbit(W[3 * q + 1], W[3 * q], 24);
+            h[4 * q + 2] = __builtin_amdgcn_alignbit(W[3 * q + 2], W[3 * q + 1], 16);
+            h[4 * q + 3] = W[3 * q + 2] >> 8;
+        }
+        const u64 pos0 = (blk << 10) + 16u * lane;
+        const u32 valid = pos0 >= end ? 0u : (end - pos0 >= 16 ? 0xffffu : (1u << (u32)(end - pos0)) - 1u);
+        u32 w[B];
+#pragma unroll
+        for (int b = 0; b < B; ++b) w[b] = BM[bloom_word(h[b])];
+        u32 cand = 0;
+#pragma unroll
+        for (int b = 0; b < B; ++b) cand |= bloom_test(w[b], h[b]) << b;
+        cand &= valid;
+        while (cand) {  // rare: exact lookup of the candidates this lane holds
+            const u32 b = (u32)__ffs((int)cand) - 1u;
+            cand &= cand - 1u;
+            u32 hb = h[0];
+#pragma unroll
+            for (int j = 1; j < B; ++j) hb = (b == (u32)j) ? h[j] : hb;
+            lookup1(hb & KEY_MASK, pos0 + b);
+        }
+        c0 = n0;
+        c1 = n1;
+        c2 = n2;
+    }
+}
+
 __global__ void __launch_bounds__(TILE_THREADS, YH_TILE_WAVES_PER_SIMD)
-k_tile_lookup32(const u32* __restrict__ keys,     // key stream, grouped by partition (d_pkeys)
+k_tile_lookup_keys(const u32x4* __restrict__ keys,  // packed key stream, grouped by partition (d_pkeys)
                 const u64* __restrict__ pbeg, const u64* __restrict__ pcnt, u32 P, u64 total_len,
                 const u64* __restrict__ sample, const u32* __restrict__ sbounds, u32 pshift, u32 kshift,
                 u32* __restrict__ qcount, NarrowHit hit,
                 const u32* __restrict__ gkeys,    // side stream (keys of d_g) or nullptr
-                const u64* __restrict__ gbeg, const u64* __restrict__ gcnt) {
+                const u64* __restrict__ gbeg, const u64* __restrict__ gcnt, const u32* __restrict__ wg_first) {
     __shared__ __attribute__((aligned(16))) u32 S[TILE_SLOTS];
     __shared__ __attribute__((aligned(16))) u32 BM[TILE_BM_WORDS];
     __shared__ u16 E[TILE_NB];
@@ -601,7 +678,7 @@ k_tile_lookup32(const u32* __restrict__ keys,     // key stream, grouped by part
     const u32 tid = threadIdx.x;
     const u32 lid = xcd_remap(blockIdx.x, gridDim.x);
     u64 per = (total_len + gridDim.x - 1) / gridDim.x;
-    per = (per + 3) & ~3ull;  // slices stay 16-byte aligned
+    per = (per + (KEY_BLOCK - 1)) & ~(u64)(KEY_BLOCK - 1);  // slices are whole key blocks
     const u64 w0 = (u64)lid * per;
     const u64 w1 = min(total_len, w0 + per);
     const HitCtx32 ctx{&q_fill, Q, lid};
@@ -624,15 +701,7 @@ k_tile_lookup32(const u32* __restrict__ keys,     // key stream, grouped by part
         __syncthreads();
     };
 
-    u32 p;
-    {
-        u32 lo = 0, hi = P;
-        while (lo < hi) {
-            const u32 mid = (lo + hi) >> 1;
-            if (pbeg[mid] <= w0) lo = mid + 1; else hi = mid;
-        }
-        p = lo ? lo - 1 : 0;
-    }
+    u32 p = wg_first[lid];
     // bucket bits: the TILE_LGNB bits just below pshift, seen from the key
     const u32 bsh = (pshift > (u32)TILE_LGNB) ? pshift - TILE_LGNB : 0u;
     const u32 ksh = bsh - min(bsh, kshift);
@@ -645,6 +714,15 @@ k_tile_lookup32(const u32* __restrict__ keys,     // key stream, grouped by part
         const u32 s0 = sbounds[p], s1 = sbounds[p + 1];
         for (u32 sub = s0; sub < s1; sub += TILE_CAP) {
             const u32 n = min((u32)TILE_CAP, s1 - sub);
+            // this wave's first block of the stream: in flight while the tile is staged
+            u32x4 c0, c1, c2;
+            {
+                const u64 bl = min((start >> 10) + (tid >> 6), ((end + (KEY_BLOCK - 1)) >> 10) - 1);
+                const u32x4* pb = keys + bl * 192 + (tid & 63u);
+                c0 = __builtin_nontemporal_load(pb);
+                c1 = __builtin_nontemporal_load(pb + 64);
+                c2 = __builtin_nontemporal_load(pb + 128);
+            }
             if (!first) {
                 flush();
                 __syncthreads();
@@ -654,9 +732,9 @@ k_tile_lookup32(const u32* __restrict__ keys,     // key stream, grouped by part
                 uint4* bm4 = reinterpret_cast<uint4*>(BM);
                 for (u32 k = tid; k < TILE_BM_WORDS / 4; k += TILE_THREADS) bm4[k] = make_uint4(0, 0, 0, 0);
             }
-            for (u32 k = tid; k < n; k += TILE_THREADS) S[k] = (u32)(sample[sub + k] >> kshift);
+            for (u32 k = tid; k < n; k += TILE_THREADS) S[k] = (u32)(sample[sub + k] >> kshift) & KEY_MASK;
             if (tid < 2) S[n + tid] = 0xffffffffu;
-            const bool skip0 = (sub > s0) && ((u32)(sample[sub - 1] >> kshift) == (u32)(sample[sub] >> kshift));
+            const bool skip0 = (sub > s0) && (((u32)(sample[sub - 1] >> kshift) & KEY_MASK) == ((u32)(sample[sub] >> kshift) & KEY_MASK));
             __syncthreads();
             for (u32 k = tid; k < n; k += TILE_THREADS) {
                 const u32 key = S[k];
@@ -668,7 +746,7 @@ k_tile_lookup32(const u32* __restrict__ keys,     // key stream, grouped by part
                     for (u32 x = b + 1; x < (u32)TILE_NB; ++x) E[x] = (u16)n;
             }
             __syncthreads();
-            tile_stream32(keys, start, end, 0ull, sub, n, ksh, skip0, S, E, BM, hit, ctx);
+            tile_stream24(keys, start, end, sub, n, ksh, skip0, S, E, BM, hit, ctx, c0, c1, c2);
             if (gkeys) {  // this workgroup's share of the shared hashes of partition p
                 const u64 cnt = pcnt[p], gc = gcnt[p], g0 = gbeg[p];
                 const u64 gs = g0 + gc * (start - e0) / cnt, ge = g0 + gc * (end - e0) / cnt;
@@ -1073,6 +1151,9 @@ int yh_q_overlap(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap, b
         YH_HIP(hipMalloc((void**)&db->d_hitq_cnt, (u64)wgs * sizeof(u32)));
         db->hitq_wgs = wgs;
         db->hitq_cap = qcap;
+        if (db->d_wg_first) { (void)hipFree(db->d_wg_first); db->d_wg_first = nullptr; }
+        YH_HIP(hipMalloc((void**)&db->d_wg_first, (u64)wgs * sizeof(u32)));
+        k_wg_first<<<(wgs + 255) / 256, 256, 0, st>>>(db->d_pbeg, db->n_parts, db->pvals_len, wgs, db->d_wg_first);
     }
     // replicated counters: R * N * 4 bytes, at most ~8 MiB
     u32 R = 32;
@@ -1095,9 +1176,9 @@ int yh_q_overlap(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap, b
         NarrowHit nh{(u32)N, db->d_reps, R - 1, reinterpret_cast<u64x2*>(db->d_hitq), db->hitq_cap, db->d_pvals, db->d_pref,
                      side ? db->d_g : nullptr, db->d_hit, d_sample, (u32)n_sample, db->kshift == 0 ? 1u : 0u};
         yh_ring_record_begin(db, db->ev_overlap);
-        k_tile_lookup32<<<wgs, TILE_THREADS, 0, st>>>(db->d_pkeys, db->d_pbeg, db->d_pcnt, P, db->pvals_len, d_sample,
+        k_tile_lookup_keys<<<wgs, TILE_THREADS, 0, st>>>(reinterpret_cast<const u32x4*>(db->d_pkeys), db->d_pbeg, db->d_pcnt, P, db->pvals_len, d_sample,
                                                       db->d_sbounds, db->pshift, db->kshift, db->d_hitq_cnt, nh,
-                                                      side ? db->d_gkeys : nullptr, db->d_gbeg, db->d_gcnt);
+                                                      side ? db->d_gkeys : nullptr, db->d_gbeg, db->d_gcnt, db->d_wg_first);
         yh_ring_record_end(db, db->ev_overlap);
         k_resolve_hits32<<<wgs, 256, 0, st>>>(db->d_hitq_cnt, nh);
         k_reduce_replicas<<<(u32)((N + 255) / 256), 256, 0, st>>>(db->d_reps, R, N, d_overlap, make_mask ? db->d_mask : nullptr,
