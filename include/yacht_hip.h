@@ -106,6 +106,9 @@ int yh_db_get_info(yh_db* db, yh_db_info* info);
 int yh_db_set_stream(yh_db* db, void* hip_stream);
 /* Block until everything queued on the handle's stream has finished.                       */
 int yh_db_synchronize(yh_db* db);
+/* Mean kernel durations (HIP events on the handle's stream) over the launches recorded since the
+ * previous call; synchronizes the stream.  Event records are barrier packets inside the step, so
+ * only every YH_TIMING_EVERY-th launch (environment, default 8; 1 = all, 0 = none) is recorded. */
 int yh_db_get_timing(yh_db* db, yh_timing* t);
 
 /* ---- yacht run, step 1: overlap of one sample with every reference ----------------------

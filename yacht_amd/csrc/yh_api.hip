@@ -46,12 +46,28 @@ static void ring_destroy(EventRing& r) {
     }
     r.created = false;
 }
+// Every event record is a barrier packet between two kernels of the step (~1-2 us each), so the
+// rings sample: YH_TIMING_EVERY=n records every n-th launch of a ring (default 8, 1 = all, 0 = none;
+// measured step time at rs214 scale: 0.237 ms recording every launch, 0.227 every 4th, 0.224 never).
+static int timing_every() {
+    static int every = -1;
+    if (every < 0) {
+        const char* e = getenv("YH_TIMING_EVERY");
+        every = e ? atoi(e) : 8;
+        if (every < 0) every = 0;
+    }
+    return every;
+}
 void yh_ring_record_begin(yh_db* db, EventRing& r) {
     if (!r.created) return;
+    const int every = timing_every();
+    r.armed = every > 0 && (r.calls++ % (unsigned)every) == 0;
+    if (!r.armed) return;
     (void)hipEventRecord(r.beg[r.head], db->stream);
 }
 void yh_ring_record_end(yh_db* db, EventRing& r) {
-    if (!r.created) return;
+    if (!r.created || !r.armed) return;
+    r.armed = false;
     (void)hipEventRecord(r.end[r.head], db->stream);
     r.head = (r.head + 1) % TIMING_RING;
     if (r.pending < TIMING_RING) ++r.pending;

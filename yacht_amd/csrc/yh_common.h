@@ -114,6 +114,8 @@ struct EventRing {
     hipEvent_t end[TIMING_RING];
     int head = 0;      // next slot to record into
     int pending = 0;   // slots recorded since the last read
+    unsigned calls = 0;  // launches seen (the ring samples every n-th, see yh_ring_record_begin)
+    bool armed = false;  // the current begin/end pair is being recorded
     bool created = false;
 };
 
