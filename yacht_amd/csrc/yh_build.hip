@@ -412,16 +412,19 @@ int yh_build_partitions(yh_db* db, const u64* d_values, const u64* d_offsets, u3
     db->max_hash = maxv;
 
     // ---- choose the partitioning: P ~ mean sketch size / YH_PIECE_TARGET, rounded down to 2^k,
-    // then the largest shift that still yields at least that many partitions.  With pieces of
-    // 4-8 hashes the per-(partition, reference) offsets cost 6-12 % of the hash bytes (they are
-    // only read when a hit is resolved), and a 1 M-hash sample fills the 4094-slot LDS tiles of a
-    // GTDB-like database (mean sketch ~4 000 hashes -> 526 partitions) only half: a slice that
-    // does not fit one tile makes the kernel stream that partition again.
+    // then the largest shift that still yields at least that many partitions.  Sketch size is the
+    // stand-in for the sample size the database will see (both follow `scaled`): a 1 M-hash sample
+    // puts ~950 keys into each 4094-slot LDS tile of a GTDB-like database (mean sketch ~4 000
+    // hashes -> 1 049 partitions); fewer keys per tile = fewer candidates, and a slice that does
+    // not fit one tile makes the kernel stream that partition again.  The other side: every
+    // (workgroup, partition) pair costs a tile set-up of a few microseconds, so a partition must
+    // hold at least 2^18 keys (a small database of large sketches would otherwise spend its time
+    // staging tiles: 6 000 sketches of 39 000 hashes ran at 1.8 TB/s with 20 972 partitions).
     const u64 H = db->n_hashes;
     u32 target = parts_hint;
     if (target == 0) {
         const u64 mean = N ? H / N : 0;
-        u64 t = mean / YH_PIECE_TARGET;
+        u64 t = std::min<u64>(mean / YH_PIECE_TARGET, std::max<u64>(H >> 18, 64));  // (64: room for large samples on small databases)
         if (t < 1) t = 1;
         if (t > 16384) t = 16384;
         u32 pw = 1;
