@@ -605,15 +605,23 @@ __global__ void k_wg_first(const u64* __restrict__ pbeg, u32 P, u64 total_len, u
 // The main stream: packed 24-bit keys, one 1024-key block per wave and step (layout: yh_common.h).
 // `start` is a block boundary (partition starts and slice starts are); keys at positions >= end of
 // the last block are masked out.
+// Every FLUSH_ROUNDS rounds (one round = one block per wave) the workgroup meets at a barrier and
+// drains the candidate queue if it is half full: a sample made mostly of database hashes queues
+// several candidates per thousand keys, and a full queue means resolving them in place.
+template <class Flush>
 __device__ __forceinline__ void tile_stream24(const u32x4* __restrict__ pk, u64 start, u64 end, u32 sub, u32 n, u32 ksh,
                                               bool skip0, const u32* S, const u16* E, const u32* BM, const NarrowHit& hit,
-                                              const HitCtx32& ctx, u32x4 c0, u32x4 c1, u32x4 c2) {
+                                              const HitCtx32& ctx, u32x4 c0, u32x4 c1, u32x4 c2, const Flush& flush) {
     constexpr u32 WAVES = TILE_THREADS / 64;
+#ifndef YH_FLUSH_ROUNDS
+#define YH_FLUSH_ROUNDS 8
+#endif
+    constexpr u32 FLUSH_ROUNDS = YH_FLUSH_ROUNDS;
     constexpr int B = 16;
     const u32 lane = threadIdx.x & 63u;
     const u64 b1 = (end + (KEY_BLOCK - 1)) >> 10;
     u64 blk = (start >> 10) + (threadIdx.x >> 6);
-    if (blk >= b1) return;
+    u32 round = 0;
 
     auto lookup1 = [&](u32 key, u64 pos) {
         u32 k = E[(key >> ksh) & (TILE_NB - 1)];
@@ -625,7 +633,14 @@ __device__ __forceinline__ void tile_stream24(const u32x4* __restrict__ pk, u64 
     // one block ahead (two blocks ahead measured the same: the kernel is not latency-bound)
     // (c0..c2 = this wave's first block, loaded by the caller BEFORE it staged the tile)
     auto addr = [&](u64 bk) { return pk + min(bk, b1 - 1) * 192 + lane; };  // clamped: a harmless re-read at the end
-    for (; blk < b1; blk += WAVES) {
+    for (u64 base = start >> 10; base < b1; base += WAVES, blk += WAVES) {  // the same trip count in every wave
+        if ((++round % FLUSH_ROUNDS) == 0) {
+            __syncthreads();
+            const u32 fill = *ctx.q_fill;
+            __syncthreads();  // nobody queues before everybody has read: the decision is uniform
+            if (fill >= (u32)TILE_QCAP / 2) flush();
+        }
+        if (blk >= b1) continue;
         const u32x4* pn = addr(blk + WAVES);
         const u32x4 n0 = __builtin_nontemporal_load(pn), n1 = __builtin_nontemporal_load(pn + 64),
                     n2 = __builtin_nontemporal_load(pn + 128);
@@ -746,7 +761,7 @@ k_tile_lookup_keys(const u32x4* __restrict__ keys,  // packed key stream, groupe
                     for (u32 x = b + 1; x < (u32)TILE_NB; ++x) E[x] = (u16)n;
             }
             __syncthreads();
-            tile_stream24(keys, start, end, sub, n, ksh, skip0, S, E, BM, hit, ctx, c0, c1, c2);
+            tile_stream24(keys, start, end, sub, n, ksh, skip0, S, E, BM, hit, ctx, c0, c1, c2, flush);
             if (gkeys) {  // this workgroup's share of the shared hashes of partition p
                 const u64 cnt = pcnt[p], gc = gcnt[p], g0 = gbeg[p];
                 const u64 gs = g0 + gc * (start - e0) / cnt, ge = g0 + gc * (end - e0) / cnt;
