@@ -1,22 +1,29 @@
 // yh_query.hip — the per-query kernels of libyacht_hip.so (gfx950 / CDNA4, wave64).
 //
-//   k_prep             sample slice bounds per partition + zeroing of every accumulator of a step
-//   k_tile_lookup      the streaming membership kernel (HBM-bound; DESIGN.md "K1"): each workgroup
-//                      stages one hash-range slice of the SAMPLE in LDS (bitmap + sorted hashes +
-//                      bucket directory) and streams reference hashes of the same range past it
-//                      with 16-byte coalesced loads; hits are queued, not resolved
-//   k_resolve_hits     queued hit positions -> references -> replicated counters
-//   k_reduce_replicas  overlap counts (+ the subset mask as bytes and bits)
-//   k_index_lookup     sample-driven alternative to k_tile_lookup (YH_DB_FULL_INDEX)
-//   k_overlap_bsearch  one wave per reference, lanes binary-search the sample in L2: independent
-//                      cross-check and A/B baseline
-//   k_excl_*           subset-exclusive hash counts from the shared-hash posting lists
-//                      (the arithmetic of hypothesis_recovery_src.py:165-204)
-//   k_pair_*           pairwise intersection counts from the posting lists into a dense row block,
-//                      threshold filter and ordered compaction (src/cpp/main.cpp:249-308)
+//   k_prep               sample slice bounds per partition + zeroing of every accumulator of a step
+//   k_tile_lookup_keys   the streaming membership kernel (HBM-bound; DESIGN.md "K1"): each workgroup
+//                        stages one hash-range slice of the SAMPLE in LDS (Bloom-filter bitmap +
+//                        sorted keys + bucket directory) and streams the packed 24-bit keys of the
+//                        reference hashes of that range past it; key matches are queued as candidates
+//   k_resolve_hits32     candidates -> confirmed against the 64-bit hashes -> summed per reference
+//                        in LDS -> replicated counters
+//   k_reduce_replicas    overlap counts (+ the subset mask as bytes and bits)
+//   k_tile_lookup<Hit>   the same tile kernel over the 64-bit hashes (YH_WIDE_KEYS=1, and the
+//                        stand-alone shared-hash membership pass of posting-only handles)
+//   k_index_lookup       sample-driven alternative (YH_DB_FULL_INDEX): one lane per sample hash
+//                        through the 64-byte bucket table / distinct-hash directory
+//   k_batch_*            up to 64 samples per pass through the same directory; exclusivity for all
+//                        samples at once by bit-sliced counting over 64-bit sample masks
+//   k_overlap_bsearch    one wave per reference, lanes binary-search the sample in L2: independent
+//                        cross-check and A/B baseline
+//   k_excl_chunks        subset-exclusive hash counts from the reference-major chunk view of the
+//   k_excl_collect/apply shared-hash posting lists (or from a pass over all postings), k_excl_final
+//                        (the arithmetic of hypothesis_recovery_src.py:165-204)
+//   k_pair_*             pairwise intersection counts from the posting lists into a dense row block,
+//                        threshold filter and ordered compaction (src/cpp/main.cpp:249-308)
 //
 // Timing-only ablation builds (-DYH_ABLATE=1|2|3, see build.py build_variant) compile parts of
-// k_tile_lookup out; their results are wrong by construction and they are never shipped.
+// the 64-bit k_tile_lookup out; their results are wrong by construction and they are never shipped.
 #include "yh_common.h"
 
 #include <stdlib.h>
