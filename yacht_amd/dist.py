@@ -1,4 +1,4 @@
-"""Sharding of the `yacht run` path over the GPUs of one node: one process per GPU,
+"""Sharding of the `yacht run` and `yacht train` paths over the GPUs of one node: one process per GPU,
 torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in CPU tests).
 
 The path partitions by REFERENCE: every rank holds a contiguous range of the
@@ -69,6 +69,54 @@ def sharded_overlap(sample: np.ndarray, compute_local: Callable[[np.ndarray], np
     local = np.ascontiguousarray(compute_local(sample), dtype=np.uint32)
     t = torch.from_numpy(local.view(np.int32)).to(device).unsqueeze(0)
     return gather_counts(t, plan, group=group)[0].cpu().numpy().view(np.uint32)
+
+
+# ======================================================================================================
+# `yacht train` over ranks: rows of the pairwise matrix (BASELINE.json configs[3], "tiled across GPUs")
+# ======================================================================================================
+# Every rank holds the whole reference set (10^4-10^5 sketches fit one GPU many times over) and
+# computes the ordered pairs (i, j) whose row i lies in its block: RefDB.pairwise(c, row_begin,
+# row_end).  The work of a row is the number of postings its reference takes part in, so blocks are
+# cut by cumulative `nshared`, not by row count.  The pair lists (a few hundred kB) are all-gathered
+# once; selection (yh_train_select) then runs on the concatenated list, identically on every rank.
+def pair_row_plan(nshared: np.ndarray, world: int) -> List[Tuple[int, int]]:
+    """Contiguous row blocks [(begin, end)] per rank with about equal sums of nshared (+1 per row)."""
+    w = np.asarray(nshared, dtype=np.int64) + 1
+    n = int(w.size)
+    cum = np.concatenate([[0], np.cumsum(w)])
+    cuts = [0]
+    for r in range(1, world):
+        j = int(np.searchsorted(cum, (int(cum[-1]) * r) // world, side="left"))
+        cuts.append(min(max(j, cuts[-1]), n))
+    cuts.append(n)
+    return [(cuts[r], cuts[r + 1]) for r in range(world)]
+
+
+def sharded_pairwise(compute_rows: Callable[[int, int], Tuple[np.ndarray, np.ndarray, np.ndarray]],
+                     plan: Sequence[Tuple[int, int]], device="cpu", group=None):
+    """All pairs of the database, rows ascending, from per-rank row blocks.  `compute_rows(b, e)`
+    returns this rank's (i, j, count) with b <= i < e, sorted by (i, j) (RefDB.pairwise).  Two
+    collectives: the list lengths, then the lists padded to the longest."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    assert len(plan) == world
+    b, e = plan[rank]
+    pi, pj, pc = compute_rows(b, e) if e > b else (np.zeros(0, np.uint32),) * 3
+    mine = torch.from_numpy(np.stack([np.asarray(x, dtype=np.int64) for x in (pi, pj, pc)], axis=0)).to(device)
+    n_mine = torch.tensor([mine.shape[1]], dtype=torch.int64, device=device)
+    lens = [torch.zeros_like(n_mine) for _ in range(world)]
+    dist.all_gather(lens, n_mine, group=group)
+    lens = [int(x.item()) for x in lens]
+    n_max = max(lens) if lens else 0
+    padded = torch.zeros((3, max(n_max, 1)), dtype=torch.int64, device=device)
+    padded[:, : mine.shape[1]] = mine
+    out = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(out, padded, group=group)
+    allp = torch.cat([out[r][:, : lens[r]] for r in range(world)], dim=1).cpu().numpy()
+    return allp[0].astype(np.uint32), allp[1].astype(np.uint32), allp[2].astype(np.uint32)
 
 
 # ======================================================================================================
