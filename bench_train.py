@@ -38,7 +38,7 @@ def main() -> int:
     args = ap.parse_args()
 
     from yacht_amd import _lib, synth
-    from yacht_amd.engine import RefDB, train_select
+    from yacht_amd.engine import YH_DB_PAIRWISE_ONLY, RefDB, train_select
 
     if _lib.device_count() < 1:
         print("bench_train.py needs an MI355X (no CPU fallback)", file=sys.stderr)
@@ -53,7 +53,7 @@ def main() -> int:
     pi = pj = pc = None
     for _ in range(args.steps + 1):  # first pass is warm-up
         t0 = time.perf_counter()
-        db = RefDB(values, offsets)
+        db = RefDB(values, offsets, flags=YH_DB_PAIRWISE_ONLY)  # what `yacht train` creates (train_core.py)
         t1 = time.perf_counter()
         pi, pj, pc = db.pairwise(c)
         t2 = time.perf_counter()

@@ -61,6 +61,9 @@ enum {
 #define YH_DB_KEEP_CSR     2u  /* keep the plain CSR resident too (needed by yh_overlap_bsearch) */
 #define YH_DB_FULL_INDEX   4u  /* also keep a directory of EVERY distinct hash (+12 B per distinct
                                   hash): enables the sample-driven yh_*_indexed_device queries      */
+#define YH_DB_PAIRWISE_ONLY 8u /* `yacht train` handle: validated sizes + the inverted index only
+                                  (yh_pairwise, yh_index_stats); no streaming layout, so the
+                                  overlap / exclusive / run queries return YH_ERR_UNSUPPORTED        */
 
 typedef struct yh_db yh_db;
 

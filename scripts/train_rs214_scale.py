@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
 from yacht_amd import synth  # noqa: E402
-from yacht_amd.engine import RefDB, train_select  # noqa: E402
+from yacht_amd.engine import YH_DB_PAIRWISE_ONLY, RefDB, train_select  # noqa: E402
 
 n_refs = int(sys.argv[1]) if len(sys.argv) > 1 else 85_205
 values, offsets, _sample = synth.config3_device(seed=1002, n_refs=n_refs, n_sample=1000, device="cuda:0")
@@ -24,7 +24,7 @@ c = 0.95 ** 31
 res = []
 for it in range(3):
     t0 = time.perf_counter()
-    db = RefDB.from_device(values.data_ptr(), offsets.data_ptr(), n_refs)
+    db = RefDB.from_device(values.data_ptr(), offsets.data_ptr(), n_refs, flags=YH_DB_PAIRWISE_ONLY)
     t1 = time.perf_counter()
     pi, pj, pc = db.pairwise(c)
     t2 = time.perf_counter()

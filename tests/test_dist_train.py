@@ -95,3 +95,22 @@ def test_row_blocks_on_the_hip_engine(hip_lib):
             dist.destroy_process_group()
     assert np.array_equal(gi, wi) and np.array_equal(gj, wj) and np.array_equal(gc, wc)
     assert np.array_equal(train_select(sizes, gi, gj), oracle.train_select(sizes, wi, wj))
+
+
+@pytest.mark.gpu
+def test_pairwise_only_handle(hip_lib):
+    """YH_DB_PAIRWISE_ONLY: same pairs and index statistics as a full handle, no sample queries."""
+    from oracle import oracle
+    from yacht_amd import _lib
+    from yacht_amd.engine import YH_DB_PAIRWISE_ONLY, RefDB
+
+    values, offsets, c = _case()
+    wi, wj, wc, wstats = oracle.train_pairs(values, offsets, c)
+    with RefDB(values, offsets, flags=YH_DB_PAIRWISE_ONLY) as db:
+        gi, gj, gc = db.pairwise(c)
+        assert np.array_equal(gi, wi) and np.array_equal(gj, wj) and np.array_equal(gc, wc)
+        assert db.index_stats() == wstats
+        with pytest.raises(_lib.YachtHipError):
+            db.overlap(np.unique(values)[:100])
+        with pytest.raises(_lib.YachtHipError):
+            db.run_counts(np.unique(values)[:100])

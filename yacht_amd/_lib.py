@@ -25,6 +25,7 @@ YH_DB_DEFAULT = 0
 YH_DB_NO_INDEX = 1
 YH_DB_KEEP_CSR = 2
 YH_DB_FULL_INDEX = 4
+YH_DB_PAIRWISE_ONLY = 8
 
 _ERR_NAMES = {
     YH_ERR_INVALID_ARG: "YH_ERR_INVALID_ARG",

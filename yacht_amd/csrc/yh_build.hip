@@ -452,10 +452,11 @@ int yh_build_partitions(yh_db* db, const u64* d_values, const u64* d_offsets, u3
     db->pshift = pshift;
     db->n_parts = P;
 
+    YH_TRY(yh_dmalloc(db, (void**)&db->d_sbounds, (u64)(P + 1) * sizeof(u32)));
+    if (db->flags & YH_DB_PAIRWISE_ONLY) return YH_OK;  // `yacht train` handle: validated sizes + the index, no streaming layout
     YH_TRY(yh_dmalloc(db, (void**)&db->d_pbeg, (u64)P * sizeof(u64)));
     YH_TRY(yh_dmalloc(db, (void**)&db->d_pcnt, (u64)P * sizeof(u64)));
     YH_TRY(yh_dmalloc(db, (void**)&db->d_poffs, (u64)P * (N + 1) * sizeof(u32)));
-    YH_TRY(yh_dmalloc(db, (void**)&db->d_sbounds, (u64)(P + 1) * sizeof(u32)));
 
     u32* d_split = nullptr;
     const u64 split_bytes = std::max<u64>(N, 1) * (u64)(P + 1) * sizeof(u32);
@@ -637,7 +638,7 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, const u
             if (rc == YH_OK)
                 k_make_keys<<<grid_for(db->n_shared, 256), 256, 0, st>>>(db->d_g, db->n_shared, db->kshift, db->d_gkeys);
         }
-        if (rc == YH_OK && db->n_postings && N) {
+        if (rc == YH_OK && db->n_postings && N && !(db->flags & YH_DB_PAIRWISE_ONLY)) {
             u32 *d_cc = nullptr, *d_cpo = nullptr, *d_cur = nullptr;
             void* d_st = nullptr;
             size_t st_bytes = 0;

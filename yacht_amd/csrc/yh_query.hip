@@ -1142,7 +1142,7 @@ int yh_q_check_sorted_host(const u64* v, u64 n) {
 // flag_shared: also flag which database-shared hashes are in the sample (db->d_hit), fused into the
 // same launch; yh_q_exclusive_partial(..., hit_ready = true) then skips its own membership pass.
 int yh_q_overlap(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap, bool flag_shared, bool make_mask) {
-    if (!db->d_pvals) { yh_set_error("this handle holds posting lists only (yh_db_create_from_pairs)"); return YH_ERR_UNSUPPORTED; }
+    if (!db->d_pvals) { yh_set_error("this handle has no streaming layout (yh_db_create_from_pairs or YH_DB_PAIRWISE_ONLY)"); return YH_ERR_UNSUPPORTED; }
     hipStream_t st = db->stream;
     const u64 N = db->n_refs;
     if (n_sample > 0xfffffff0ull) { yh_set_error("sample larger than 2^32-16 hashes"); return YH_ERR_INVALID_ARG; }
@@ -1353,7 +1353,10 @@ int yh_q_exclusive(yh_db* db, const u8* d_mask, const u64* d_sample, u64 n_sampl
 // Fills the handle's host-side pair cache (h_pw_*) for rows [r0, r1).
 int yh_q_pairwise(yh_db* db, double c_thresh, u64 r0, u64 r1) {
     if (!db->has_index) { yh_set_error("this handle was created with YH_DB_NO_INDEX"); return YH_ERR_UNSUPPORTED; }
-    if (!db->d_pvals) { yh_set_error("this handle holds posting lists only"); return YH_ERR_UNSUPPORTED; }
+    if (!db->d_pvals && !(db->flags & YH_DB_PAIRWISE_ONLY)) {  // (from_pairs handles carry no sketch sizes)
+        yh_set_error("this handle holds posting lists only");
+        return YH_ERR_UNSUPPORTED;
+    }
     hipStream_t st = db->stream;
     const u64 N = db->n_refs;
     free(db->h_pw_i); free(db->h_pw_j); free(db->h_pw_c);

@@ -17,7 +17,8 @@ from typing import Optional, Sequence, Tuple
 import numpy as np
 
 from . import _lib
-from ._lib import YH_DB_DEFAULT, YH_DB_FULL_INDEX, YH_DB_KEEP_CSR, YH_DB_NO_INDEX, YachtHipError  # noqa: F401
+from ._lib import (YH_DB_DEFAULT, YH_DB_FULL_INDEX, YH_DB_KEEP_CSR, YH_DB_NO_INDEX, YH_DB_PAIRWISE_ONLY,  # noqa: F401
+                   YachtHipError)
 
 
 def pack_csr(sketches: Sequence[np.ndarray]) -> Tuple[np.ndarray, np.ndarray]:

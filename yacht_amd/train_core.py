@@ -25,7 +25,7 @@ from typing import List, Sequence, Tuple
 import numpy as np
 
 from . import sigio
-from .engine import RefDB, pack_csr, train_select
+from .engine import YH_DB_PAIRWISE_ONLY, RefDB, pack_csr, train_select
 
 
 def format_pair_line(i: int, j: int, count: int, size_i: int, size_j: int) -> str:
@@ -85,7 +85,7 @@ def run(file_list: str, working_directory: str, output_filename: str, threads: i
     empty = [i for i, s in enumerate(sketches) if s.size == 0]
     values, offsets = pack_csr(sketches)
     sizes = np.diff(offsets).astype(np.uint32)
-    with RefDB(values, offsets, device=device) as db:
+    with RefDB(values, offsets, device=device, flags=YH_DB_PAIRWISE_ONLY) as db:
         stats = db.index_stats()
         pi, pj, pc = db.pairwise(float(containment_threshold))
     if verbose:
