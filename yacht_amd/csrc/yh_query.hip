@@ -672,9 +672,14 @@ __device__ __forceinline__ void tile_stream24(const u32x4* __restrict__ pk, u64 
         while (cand) {  // rare: exact lookup of the candidates this lane holds
             const u32 b = (u32)__ffs((int)cand) - 1u;
             cand &= cand - 1u;
-            u32 hb = h[0];
-#pragma unroll
-            for (int j = 1; j < B; ++j) hb = (b == (u32)j) ? h[j] : hb;
+            // key b of this lane: its group of four keys = three words, then one funnel shift
+            const u32 q = b >> 2, k = b & 3u;
+            const u32 g0 = q == 0 ? W[0] : q == 1 ? W[3] : q == 2 ? W[6] : W[9];
+            const u32 g1 = q == 0 ? W[1] : q == 1 ? W[4] : q == 2 ? W[7] : W[10];
+            const u32 g2 = q == 0 ? W[2] : q == 1 ? W[5] : q == 2 ? W[8] : W[11];
+            const u32 lo = k < 2 ? g0 : (k == 2 ? g1 : g2);
+            const u32 hi = k < 2 ? g1 : (k == 2 ? g2 : 0u);
+            const u32 hb = __builtin_amdgcn_alignbit(hi, lo, (24u * k) & 31u);
             lookup1(hb & KEY_MASK, pos0 + b);
         }
         c0 = n0;
