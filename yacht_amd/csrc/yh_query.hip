@@ -513,14 +513,23 @@ __global__ void __launch_bounds__(256) k_resolve_hits32(const u32* __restrict__ 
         if (tkey[k]) atomicAdd(&my[tkey[k] - 1], tcnt[k]);
 }
 
-#ifndef YH_BLOOM2
-#define YH_BLOOM2 1
+#ifndef YH_BLOOM_BITS
+#define YH_BLOOM_BITS 2
 #endif
+// bit positions inside the filter word: key bits 0..4, key bits 18..22, and (3-bit variant) a
+// multiplicative hash of the low 24 key bits
+__device__ __forceinline__ u32 bloom_b3(u32 key) { return ((key << 8) * 0x9e3779b1u) >> 27; }
 __device__ __forceinline__ u32 bloom_mask(u32 key) {
-    return YH_BLOOM2 ? (1u << (key & 31u)) | (1u << ((key >> 18) & 31u)) : (1u << (key & 31u));
+    u32 m = 1u << (key & 31u);
+    if (YH_BLOOM_BITS >= 2) m |= 1u << ((key >> 18) & 31u);
+    if (YH_BLOOM_BITS >= 3) m |= 1u << bloom_b3(key);
+    return m;
 }
 __device__ __forceinline__ u32 bloom_test(u32 w, u32 key) {
-    return YH_BLOOM2 ? ((w >> (key & 31u)) & (w >> ((key >> 18) & 31u))) & 1u : (w >> (key & 31u)) & 1u;
+    u32 t = w >> (key & 31u);
+    if (YH_BLOOM_BITS >= 2) t &= w >> ((key >> 18) & 31u);
+    if (YH_BLOOM_BITS >= 3) t &= w >> bloom_b3(key);
+    return t & 1u;
 }
 __device__ __forceinline__ u32 bloom_word(u32 key) { return (key >> 5) & (u32)(TILE_BM_WORDS - 1); }
 
