@@ -418,8 +418,8 @@ k_tile_lookup(const u64* __restrict__ vals,     // hash stream, grouped by parti
 // (timing-only build), which is why fewer bytes per key pay even at more instructions per key.
 //   * one wave reads a 1024-key block with three coalesced 16-byte loads per lane (layout:
 //     yh_common.h), the next block's loads in flight while this one is tested;
-//   * the bitmap is a blocked Bloom filter, two bits of one word per key (word from key bits 5..17,
-//     bits from 0..4 and 18..22): one LDS read per key, ~0.07 % of the misses survive it;
+//   * the bitmap is a blocked Bloom filter, two bits of one word per key (word from key bits 2..14,
+//     bits from 15..19 and 19..23): one LDS read per key, ~0.04 % of the misses survive it;
 //   * the side stream (shared hashes, d_gkeys, one key per 32-bit word, 1.6 % of the bytes) goes
 //     through tile_stream32; its hits are queued too (tagged): flagging needs the confirmation.
 // Tiles of one partition may split a run of equal keys; a match at slot 0 of a tile whose
@@ -516,22 +516,30 @@ __global__ void __launch_bounds__(256) k_resolve_hits32(const u32* __restrict__ 
 #ifndef YH_BLOOM_BITS
 #define YH_BLOOM_BITS 2
 #endif
-// bit positions inside the filter word: key bits 0..4, key bits 18..22, and (3-bit variant) a
-// multiplicative hash of the low 24 key bits
+// Filter word = key bits 2..14 (so that the LDS byte address is one AND of the key), bit positions
+// inside the word = key bits 15..19 and 19..23 (shift amounts: the hardware reads 5 bits).  With
+// YH_BLOOM_LOWWORD=0: word = bits 5..17, bits 0..4 and 18..22 (one more instruction per key).
+#ifndef YH_BLOOM_LOWWORD
+#define YH_BLOOM_LOWWORD 1
+#endif
+__device__ __forceinline__ u32 bloom_s1(u32 key) { return YH_BLOOM_LOWWORD ? key >> 15 : key; }
+__device__ __forceinline__ u32 bloom_s2(u32 key) { return YH_BLOOM_LOWWORD ? key >> 19 : key >> 18; }
 __device__ __forceinline__ u32 bloom_b3(u32 key) { return ((key << 8) * 0x9e3779b1u) >> 27; }
 __device__ __forceinline__ u32 bloom_mask(u32 key) {
-    u32 m = 1u << (key & 31u);
-    if (YH_BLOOM_BITS >= 2) m |= 1u << ((key >> 18) & 31u);
+    u32 m = 1u << (bloom_s1(key) & 31u);
+    if (YH_BLOOM_BITS >= 2) m |= 1u << (bloom_s2(key) & 31u);
     if (YH_BLOOM_BITS >= 3) m |= 1u << bloom_b3(key);
     return m;
 }
 __device__ __forceinline__ u32 bloom_test(u32 w, u32 key) {
-    u32 t = w >> (key & 31u);
-    if (YH_BLOOM_BITS >= 2) t &= w >> ((key >> 18) & 31u);
+    u32 t = w >> (bloom_s1(key) & 31u);
+    if (YH_BLOOM_BITS >= 2) t &= w >> (bloom_s2(key) & 31u);
     if (YH_BLOOM_BITS >= 3) t &= w >> bloom_b3(key);
     return t & 1u;
 }
-__device__ __forceinline__ u32 bloom_word(u32 key) { return (key >> 5) & (u32)(TILE_BM_WORDS - 1); }
+__device__ __forceinline__ u32 bloom_word(u32 key) {
+    return YH_BLOOM_LOWWORD ? (key >> 2) & (u32)(TILE_BM_WORDS - 1) : (key >> 5) & (u32)(TILE_BM_WORDS - 1);
+}
 
 __device__ __forceinline__ void tile_stream32(const u32* __restrict__ keys, u64 start, u64 end, u64 tag, u32 sub, u32 n,
                                               u32 ksh, bool skip0, const u32* S, const u16* E, const u32* BM,
