@@ -1,0 +1,56 @@
+"""The hash-sorted delta stream (YH_STREAM=delta at handle creation) must give the same counts as the
+default layout and the oracle.  The layout is chosen per process, so the cases run in a child."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r"""
+import sys
+import numpy as np
+sys.path.insert(0, %r)
+from oracle import oracle
+from yacht_amd import synth
+from yacht_amd.engine import RefDB
+from tests.test_gpu_keys import _colliding_case
+
+def check(values, offsets, sample, **kw):
+    with RefDB(values, offsets, **kw) as db:
+        ov, e, m = db.run_counts(sample)
+        ov_only = db.overlap(sample)
+    w_ov = oracle.overlap(values, offsets, sample)
+    mask = (w_ov > 0).astype(np.uint8)
+    w_e, w_m = oracle.exclusive(values, offsets, mask, sample)
+    assert np.array_equal(ov, w_ov) and np.array_equal(ov_only, w_ov)
+    assert np.array_equal(e, np.where(mask, w_e, 0)) and np.array_equal(m, np.where(mask, w_m, 0))
+
+v, o, s = _colliding_case()
+check(v, o, s)
+with RefDB(v, o, flags=1) as db_noidx:       # YH_DB_NO_INDEX: the stream without the inverted index
+    assert np.array_equal(db_noidx.overlap(s), oracle.overlap(v, o, s))
+v, o, s = synth.config2(seed=5)
+check(v, o, s)
+v, o = synth.config4(seed=6, n_clusters=40, size=500)   # many equal hashes: runs of delta 0
+rng = np.random.default_rng(1)
+s = np.unique(np.concatenate([rng.choice(v, 4000), rng.integers(0, 2**63, 3000, dtype=np.uint64)]))
+check(v, o, s)
+# full-range hashes, a gap far above 255 truncated units, an empty reference, a one-hash database
+refs = [np.array([0, 1, 2**40, 2**63, 2**64 - 1], dtype=np.uint64), np.zeros(0, np.uint64),
+        np.array([5, 2**40, 2**40 + 1], dtype=np.uint64)]
+offs = np.concatenate([[0], np.cumsum([len(r) for r in refs])]).astype(np.uint64)
+check(np.concatenate(refs), offs, np.array([0, 5, 2**40, 2**64 - 1], dtype=np.uint64))
+check(np.array([77], dtype=np.uint64), np.array([0, 1], dtype=np.uint64), np.array([3, 77, 99], dtype=np.uint64))
+print("delta stream ok")
+"""
+
+
+def test_delta_stream_layout_matches_oracle(hip_lib):
+    env = dict(os.environ, YH_STREAM="delta")
+    r = subprocess.run([sys.executable, "-c", CHILD % ROOT], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "delta stream ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

@@ -189,7 +189,7 @@ static int db_create_common(const u64* values, const u64* offsets, bool on_devic
         (void)hipEventRecord(ev0, db->stream);
         rc = yh_build_partitions(db, d_values_in, d_offsets_in, partitions_hint);
         if (rc != YH_OK) break;
-        if (!(flags & YH_DB_NO_INDEX)) {
+        if (!(flags & YH_DB_NO_INDEX) || yh_use_delta_stream()) {  // (the delta stream comes out of the same sort)
             rc = yh_build_index(db, d_values_in, d_offsets_in, nullptr);
             if (rc != YH_OK) break;
         }
@@ -272,6 +272,7 @@ int yh_db_create_from_pairs(const uint64_t* d_hashes, const uint32_t* d_refs, ui
     yh_db* db = new yh_db();
     db->device = device_id;
     db->flags = 0;
+    db->posting_only = true;
     db->n_refs = n_refs_total;
     db->n_hashes = n_pairs;
     db->max_hash = max_hash;
@@ -333,7 +334,8 @@ int yh_db_destroy(yh_db* db) {
     void* ptrs[] = {db->d_values, db->d_offsets, db->d_pvals, db->d_pbeg, db->d_pcnt, db->d_poffs, db->d_sizes,
                     db->d_g, db->d_po, db->d_pr, db->d_pg, db->d_gbeg, db->d_gcnt, db->d_nshared, db->d_pq, db->d_pq_count, db->d_dh, db->d_dref, db->d_dir, db->d_bkt, db->d_pkeys, db->d_pref, db->d_gkeys, db->d_rpo, db->d_rg, db->d_chunks, db->d_sbounds,
                     db->d_mask, db->d_maskbits, db->d_hit, db->d_excl_e, db->d_overlap_tmp,
-                    db->d_sample_tmp, db->d_flag, db->d_hitq, db->d_hitq_cnt, db->d_wg_first, db->d_reps, db->d_batch};
+                    db->d_sample_tmp, db->d_flag, db->d_hitq, db->d_hitq_cnt, db->d_wg_first, db->d_reps, db->d_batch,
+                    db->d_sdelta, db->d_shdr, db->d_svals, db->d_sref, db->d_sgidx, db->d_wg_key, db->d_wg_sb};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     ring_destroy(db->ev_overlap);

@@ -9,6 +9,8 @@
 
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
 
 #include <algorithm>
 #include <vector>
@@ -237,7 +239,8 @@ __global__ void __launch_bounds__(IDX_THREADS) k_idx_emit(const u64* __restrict_
                                                           u64* __restrict__ g, u64* __restrict__ po,
                                                           u32* __restrict__ pr, u32* __restrict__ pg,
                                                           u32* __restrict__ nshared,
-                                                          u64* __restrict__ dh, u32* __restrict__ dref) {
+                                                          u64* __restrict__ dh, u32* __restrict__ dref,
+                                                          u32* __restrict__ elem_g) {
     // dh/dref (optional): every DISTINCT hash ascending, with its single holder, or
     // 0x80000000 | (index into g) when several references hold it
     __shared__ u32 lds[17];
@@ -285,6 +288,43 @@ __global__ void __launch_bounds__(IDX_THREADS) k_idx_emit(const u64* __restrict_
             atomicAdd(&nshared[r], 1u);
             ++mi;
         }
+        if (elem_g && i < n) elem_g[i] = (f & 1u) ? (u32)(gi - 1) : STREAM_NONE;  // shared-hash index of every sorted element
+    }
+}
+
+// ---- hash-sorted delta stream (layout: yh_common.h) ------------------------------------------------
+// c[i] = 1 + fillers in front of sorted element i; an inclusive scan of c gives position + 1.
+struct StreamCount {
+    const u64* sk;
+    u32 sshift;
+    __device__ u64 operator()(u64 i) const {
+        if (i == 0) return 1;
+        const u64 d = (sk[i] >> sshift) - (sk[i - 1] >> sshift);
+        return 1 + (d ? (d - 1) / 255 : 0);
+    }
+};
+__global__ void k_stream_scatter(const u64* __restrict__ sk, const u32* __restrict__ sv, const u32* __restrict__ elem_g,
+                                 u64 n, u32 sshift, const u64* __restrict__ pos1 /* position + 1 */,
+                                 u8* __restrict__ sdelta, u64* __restrict__ svals, u32* __restrict__ sref,
+                                 u32* __restrict__ sgidx, u64* __restrict__ hdr) {
+    for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+        const u64 h = sk[i], t = h >> sshift, pos = pos1[i] - 1;
+        u32 own = 0;
+        if (i) {
+            const u64 tp = sk[i - 1] >> sshift, ppos = pos1[i - 1] - 1;
+            const u64 nfill = pos - ppos - 1;
+            for (u64 f = 1; f <= nfill; ++f) {  // (arrays are pre-set: hash 0, no reference)
+                const u64 q = ppos + f;
+                sdelta[q] = 255;
+                if ((q & (STREAM_BLOCK - 1)) == 0) hdr[q >> 10] = tp + 255 * f;
+            }
+            own = (u32)(t - tp - 255 * nfill);
+        }
+        sdelta[pos] = (u8)own;
+        svals[pos] = h;
+        sref[pos] = sv[i];
+        if (sgidx) sgidx[pos] = elem_g ? elem_g[i] : STREAM_NONE;
+        if ((pos & (STREAM_BLOCK - 1)) == 0) hdr[pos >> 10] = t;
     }
 }
 
@@ -454,6 +494,7 @@ int yh_build_partitions(yh_db* db, const u64* d_values, const u64* d_offsets, u3
 
     YH_TRY(yh_dmalloc(db, (void**)&db->d_sbounds, (u64)(P + 1) * sizeof(u32)));
     if (db->flags & YH_DB_PAIRWISE_ONLY) return YH_OK;  // `yacht train` handle: validated sizes + the index, no streaming layout
+    if (yh_use_delta_stream()) return YH_OK;  // the streaming layout is the hash-sorted delta stream (yh_build_index)
     YH_TRY(yh_dmalloc(db, (void**)&db->d_pbeg, (u64)P * sizeof(u64)));
     YH_TRY(yh_dmalloc(db, (void**)&db->d_pcnt, (u64)P * sizeof(u64)));
     YH_TRY(yh_dmalloc(db, (void**)&db->d_poffs, (u64)P * (N + 1) * sizeof(u32)));
@@ -516,6 +557,67 @@ int yh_build_partitions(yh_db* db, const u64* d_values, const u64* d_offsets, u3
     return rc;
 }
 
+bool yh_use_delta_stream() {
+    static const bool on = [] {
+        const char* s = getenv("YH_STREAM");  // "delta": the hash-sorted delta stream instead of the packed 24-bit keys
+        const char* w = getenv("YH_WIDE_KEYS");
+        return s && strcmp(s, "delta") == 0 && !(w && w[0] == '1');
+    }();
+    return on;
+}
+
+// The hash-sorted delta stream from the sorted (hash, reference) pairs (layout: yh_common.h).
+static int build_stream(yh_db* db, const u64* d_sk, const u32* d_sv, const u32* d_elem_g, u64 H) {
+    hipStream_t st = db->stream;
+    if (H == 0) return YH_OK;
+    u32 s = 0;  // mean truncated gap in [32, 64): ~1 % fillers, ~|S|/48 key-only candidates per query
+    while (s < 63 && ((db->max_hash >> (s + 1)) / H) >= 32) ++s;
+    db->sshift = s;
+    u64* d_pos = nullptr;
+    void* d_tmp = nullptr;
+    size_t tmp_bytes = 0;
+    int rc = YH_OK;
+#define ST_HIP(call)                                                                          \
+    if (rc == YH_OK) {                                                                        \
+        hipError_t e__ = (call);                                                              \
+        if (e__ != hipSuccess) {                                                              \
+            yh_set_error("%s failed: %s", #call, hipGetErrorString(e__));                     \
+            rc = (e__ == hipErrorOutOfMemory) ? YH_ERR_OOM : YH_ERR_HIP;                      \
+        }                                                                                     \
+    }
+    auto counts = rocprim::make_transform_iterator(rocprim::counting_iterator<u64>(0), StreamCount{d_sk, s});
+    ST_HIP(hipMalloc((void**)&d_pos, H * sizeof(u64)));
+    ST_HIP(rocprim::inclusive_scan(nullptr, tmp_bytes, counts, d_pos, (size_t)H, rocprim::plus<u64>(), st));
+    ST_HIP(hipMalloc(&d_tmp, tmp_bytes + 256));
+    ST_HIP(rocprim::inclusive_scan(d_tmp, tmp_bytes, counts, d_pos, (size_t)H, rocprim::plus<u64>(), st));
+    u64 L = 0;
+    ST_HIP(hipMemcpyAsync(&L, d_pos + (H - 1), sizeof(u64), hipMemcpyDeviceToHost, st));
+    ST_HIP(hipStreamSynchronize(st));
+    if (rc == YH_OK) {
+        db->slen = (L + (STREAM_BLOCK - 1)) & ~(u64)(STREAM_BLOCK - 1);
+        const u64 nblk = db->slen / STREAM_BLOCK;
+        rc = yh_dmalloc(db, (void**)&db->d_sdelta, db->slen + 64);
+        if (rc == YH_OK) rc = yh_dmalloc(db, (void**)&db->d_shdr, (nblk + 2) * sizeof(u64));
+        if (rc == YH_OK) rc = yh_dmalloc(db, (void**)&db->d_svals, db->slen * sizeof(u64));
+        if (rc == YH_OK) rc = yh_dmalloc(db, (void**)&db->d_sref, db->slen * sizeof(u32));
+        if (rc == YH_OK && d_elem_g) rc = yh_dmalloc(db, (void**)&db->d_sgidx, db->slen * sizeof(u32));
+        ST_HIP(hipMemsetAsync(db->d_sdelta, 0, db->slen + 64, st));
+        ST_HIP(hipMemsetAsync(db->d_shdr, 0xff, (nblk + 2) * sizeof(u64), st));
+        ST_HIP(hipMemsetAsync(db->d_svals, 0, db->slen * sizeof(u64), st));
+        ST_HIP(hipMemsetAsync(db->d_sref, 0xff, db->slen * sizeof(u32), st));
+        if (db->d_sgidx) ST_HIP(hipMemsetAsync(db->d_sgidx, 0xff, db->slen * sizeof(u32), st));
+        if (rc == YH_OK)
+            k_stream_scatter<<<grid_for(H, 256), 256, 0, st>>>(d_sk, d_sv, d_elem_g, H, s, d_pos, db->d_sdelta, db->d_svals,
+                                                              db->d_sref, db->d_sgidx, db->d_shdr);
+        ST_HIP(hipGetLastError());
+        ST_HIP(hipStreamSynchronize(st));
+    }
+#undef ST_HIP
+    (void)hipFree(d_pos);
+    (void)hipFree(d_tmp);
+    return rc;
+}
+
 // =================================================================================================
 int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, const u32* d_pair_ids) {
     const u64 N = db->n_refs;
@@ -535,7 +637,7 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, const u
     if (H == 0) {
         YH_TRY(yh_dmalloc(db, (void**)&db->d_po, sizeof(u64)));
         YH_HIP(hipMemsetAsync(db->d_po, 0, sizeof(u64), st));
-        db->has_index = true;
+        db->has_index = !(db->flags & YH_DB_NO_INDEX);
         return YH_OK;
     }
     if (H > 0xfffffff0ull * 2) {
@@ -575,6 +677,19 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, const u
         IDX_HIP(rocprim::radix_sort_pairs(d_tmp, tmp_bytes, (const u64*)d_values, d_sk, ids_src, d_sv,
                                           (size_t)H, 0u, end_bit, st));
     }
+    const bool want_stream = !d_pair_ids && yh_use_delta_stream() && !(db->flags & YH_DB_PAIRWISE_ONLY);
+    if (rc == YH_OK && (db->flags & YH_DB_NO_INDEX)) {  // overlap-only handle: the stream and nothing else
+        if (want_stream) rc = build_stream(db, d_sk, d_sv, nullptr, H);
+        (void)hipFree(d_ids);
+        (void)hipFree(d_sv);
+        (void)hipFree(d_sk);
+        (void)hipFree(d_counts);
+        (void)hipFree(d_bases);
+        (void)hipFree(d_tmp);
+        return rc;
+    }
+    u32* d_elem_g = nullptr;
+    if (want_stream) IDX_HIP(hipMalloc((void**)&d_elem_g, H * sizeof(u32)));
     u64 totals[3] = {0, 0, 0};
     if (rc == YH_OK) {
         k_idx_count<<<(u32)nb, IDX_THREADS, 0, st>>>(d_sk, H, d_counts);
@@ -624,7 +739,8 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, const u
         if (rc == YH_OK)
             k_idx_emit<<<(u32)nb, IDX_THREADS, 0, st>>>(d_sk, d_sv, H, d_bases, db->d_g, db->d_po, db->d_pr, db->d_pg,
                                                         db->d_nshared, full ? db->d_dh : nullptr,
-                                                        full ? db->d_dref : nullptr);
+                                                        full ? db->d_dref : nullptr, d_elem_g);
+        if (rc == YH_OK && want_stream) rc = build_stream(db, d_sk, d_sv, d_elem_g, H);
         if (rc == YH_OK && full)
             k_dir_build<<<grid_for(db->n_distinct, 256), 256, 0, st>>>(db->d_dh, db->n_distinct, db->dir_shift, db->dir_nb,
                                                                        db->d_dir);
@@ -697,6 +813,7 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, const u
         IDX_HIP(hipStreamSynchronize(st));
     }
 #undef IDX_HIP
+    (void)hipFree(d_elem_g);
     (void)hipFree(d_ids);
     (void)hipFree(d_sv);
     (void)hipFree(d_sk);

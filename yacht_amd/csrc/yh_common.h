@@ -102,6 +102,8 @@ __host__ __device__ inline u64 yh_key_byte_addr(u64 pos, u32 byte_of_key) {
     return blk * (u64)KEY_BLOCK_BYTES + ((u64)(j >> 4) * 64u + lane) * 16u + (j & 15u);
 }
 #endif
+constexpr int STREAM_BLOCK = 1024;          // elements per block of the delta stream = 16 per lane
+constexpr u32 STREAM_NONE = 0xffffffffu;
 constexpr int TILE_UNROLL32 = YH_TILE_UNROLL32;
 static_assert(TILE_UNROLL32 * 4 <= 32, "candidate masks are 32-bit");
 
@@ -169,7 +171,23 @@ struct yh_db {
     u32* d_rg = nullptr;       // [n_postings] shared-hash index, grouped by reference
     uint2* d_chunks = nullptr; // [n_chunks] (reference, first posting in d_rg)
     u32 n_chunks = 0;
+    bool posting_only = false;        // yh_db_create_from_pairs: posting lists of a hash range, no sketches
     bool excl_prefer_stream = false;  // set by the host-mask entry point when most references are masked
+    // hash-sorted delta stream (YH_STREAM=delta; DESIGN.md "K1"): every (hash, reference)
+    // pair of the database in ascending hash order, the hash truncated to t = hash >> sshift so that
+    // consecutive t differ by ~50 on average, one BYTE per element = t minus its predecessor's t.
+    // A gap above 255 is bridged by filler elements (delta 255, no reference).  Blocks of
+    // STREAM_BLOCK elements; s_hdr[b] = t of block b's first element (its own delta byte is unused).
+    u8* d_sdelta = nullptr;    // [slen]
+    u64* d_shdr = nullptr;     // [slen / STREAM_BLOCK + 1], last = ~0
+    u64* d_svals = nullptr;    // [slen] the 64-bit hash of every position (0 for fillers): read at candidates only
+    u32* d_sref = nullptr;     // [slen] its reference (STREAM_NONE for fillers)
+    u32* d_sgidx = nullptr;    // [slen] index into d_g when the hash is shared, else STREAM_NONE (with the index)
+    u64 slen = 0;              // multiple of STREAM_BLOCK
+    u32 sshift = 0;
+    u64* d_wg_key = nullptr;   // [wgs + 1] first t of each workgroup's block range (sample-independent)
+    u32* d_wg_sb = nullptr;    // [2 * wgs] per query: the sample range [lo, hi) of each workgroup
+    u32 wg_key_n = 0;
     u32* d_pkeys = nullptr;    // packed KEY_BITS-bit keys of d_pvals, (hash >> kshift) & KEY_MASK: the stream K1 reads
     u32* d_pref = nullptr;     // [pvals_len] reference id of every stream position
     u32* d_gkeys = nullptr;    // [n_shared] the same keys of d_g, one per 32-bit word
@@ -220,6 +238,7 @@ int yh_build_partitions(yh_db* db, const u64* d_values, const u64* d_offsets, u3
 // d_pair_ids == nullptr: reference ids come from d_offsets (CSR); otherwise (d_values[i], d_pair_ids[i]) are
 // ready-made (hash, reference) pairs and d_offsets is unused.
 int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, const u32* d_pair_ids);
+bool yh_use_delta_stream();  // YH_STREAM=delta at handle creation (default: partition-major packed 24-bit keys)
 
 // ---- implemented in yh_query.hip -------------------------------------------------------------
 int yh_q_overlap(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap, bool flag_shared, bool make_mask);

@@ -802,6 +802,323 @@ k_tile_lookup_keys(const u32x4* __restrict__ keys,  // packed key stream, groupe
     if (tid == 0) qcount[lid] = min(g_fill, hit.qcap);
 }
 
+// ---- K1 over the hash-sorted delta stream ------------------------------------------------------------
+// The stream (yh_common.h) is every (hash, reference) pair in ascending hash order, the hashes
+// truncated to t = hash >> sshift and stored as ONE BYTE per element, the difference to the previous
+// element.  Both sides being sorted, the lookup is a merge: a wave takes a block of 1024 elements
+// (16 bytes per lane, one coalesced load), rebuilds where its lanes' key spans start with byte sums
+// (v_sad_u8) and one wave scan, and then lets the FEW sample keys that fall into the block's key
+// range probe it -- ~3 per block for a 10^6-hash sample against 3.3 x 10^8 hashes -- instead of
+// testing every stream key against the sample.  A probe that equals an element's t is a candidate
+// (stream position, sample index); k_resolve_stream confirms it against the 64-bit hash of that
+// position, so truncation collisions (~|S|/48 per query) and filler elements never count.
+// A workgroup owns a contiguous range of blocks = a range of t; the sample hashes of that range are
+// staged in LDS (sorted t values + a bucket directory) -- if there are none the range is not read.
+constexpr int ST_SLOTS = 4096;          // sample keys per tile
+constexpr int ST_PAD = 64 + 2;          // readable sentinels behind the last key (a wave reads 64 slots at once)
+constexpr int ST_CAP = ST_SLOTS - ST_PAD;
+
+struct StreamHit {
+    u32 n_refs;
+    u32* reps;
+    u32 rep_mask;
+    u64x2* queue;      // [wgs][qcap]: x = stream position, y = sample index
+    u32 qcap;
+    const u64* svals;
+    const u32* sref;
+    const u32* sgidx;  // may be null (handle without index)
+    u8* hitflag;       // may be null (overlap only)
+    const u64* sample;
+
+    __device__ __forceinline__ bool confirm(u64 pos, u32 sidx, u32& ref) const {
+        if (svals[pos] != sample[sidx]) return false;
+        ref = sref[pos];
+        if (ref == STREAM_NONE) return false;
+        if (hitflag) {
+            const u32 g = sgidx[pos];
+            if (g != STREAM_NONE) hitflag[g] = 1;
+        }
+        return true;
+    }
+    __device__ __forceinline__ void count(u32 wg, u64 pos, u32 sidx) const {
+        u32 r;
+        if (confirm(pos, sidx, r)) atomicAdd(&reps[(u64)(wg & rep_mask) * n_refs + r], 1u);
+    }
+};
+__device__ __forceinline__ void push_hit(const StreamHit& hit, const HitCtx32& c, u64 pos, u32 sidx) {
+    const u32 slot = atomicAdd(c.q_fill, 1u);
+    if (slot < (u32)TILE_QCAP) {
+        u64x2 e;
+        e.x = pos;
+        e.y = sidx;
+        c.q[slot] = e;
+    } else {
+        hit.count(c.wg, pos, sidx);
+    }
+}
+
+// one workgroup per queue segment: confirm, sum per reference in LDS, one global atomic per (workgroup, reference)
+__global__ void __launch_bounds__(256) k_resolve_stream(const u32* __restrict__ qcount, StreamHit hit) {
+    __shared__ u32 tkey[RES_SLOTS];  // reference + 1, 0 = empty
+    __shared__ u32 tcnt[RES_SLOTS];
+    const u32 wg = blockIdx.x;
+    const u32 cnt = qcount[wg];
+    if (cnt == 0) return;
+    for (u32 k = threadIdx.x; k < RES_SLOTS; k += blockDim.x) { tkey[k] = 0; tcnt[k] = 0; }
+    __syncthreads();
+    const u64x2* q = hit.queue + (u64)wg * hit.qcap;
+    u32* my = hit.reps + (u64)(wg & hit.rep_mask) * hit.n_refs;
+    for (u32 e = threadIdx.x; e < cnt; e += blockDim.x) {
+        const u64x2 x = q[e];
+        u32 r;
+        if (!hit.confirm(x.x, (u32)x.y, r)) continue;
+        u32 slot = (r * 2654435761u) >> (32 - 10);
+        bool done = false;
+        for (int probe = 0; probe < 8 && !done; ++probe, slot = (slot + 1) & (RES_SLOTS - 1)) {
+            const u32 old = atomicCAS(&tkey[slot], 0u, r + 1);
+            if (old == 0 || old == r + 1) { atomicAdd(&tcnt[slot], 1u); done = true; }
+        }
+        if (!done) atomicAdd(&my[r], 1u);
+    }
+    __syncthreads();
+    for (u32 k = threadIdx.x; k < RES_SLOTS; k += blockDim.x)
+        if (tkey[k]) atomicAdd(&my[tkey[k] - 1], tcnt[k]);
+}
+
+// wg_key[w] = t of the first element of workgroup w's block range (~0 past the end): sample-independent
+__global__ void k_wg_key(const u64* __restrict__ hdr, u64 nblk, u32 wgs, u64* __restrict__ wg_key) {
+    const u32 w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w > wgs) return;
+    const u64 per = (nblk + wgs - 1) / wgs;
+    wg_key[w] = hdr[min((u64)w * per, nblk)];
+}
+
+// per query: each workgroup's sample range [lo, hi) = sample hashes with wg_key[w] <= t <= wg_key[w + 1]
+// (inclusive on both sides: equal keys may sit on either side of a range boundary), + the zeroing
+__global__ void __launch_bounds__(256) k_prep_stream(const u64* __restrict__ sample, u32 n, const u64* __restrict__ wg_key,
+                                                     u32 wgs, u32 sshift, u32* __restrict__ wg_sb, ZeroList z) {
+    const u64 t = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    const u64 nt = (u64)gridDim.x * blockDim.x;
+    if (t < 2ull * wgs) {
+        const u32 w = (u32)(t >> 1);
+        const bool upper = (t & 1) != 0;
+        const u64 key = wg_key[w + (upper ? 1 : 0)];
+        u32 lo = 0, hi = n;
+        while (lo < hi) {  // lower: first trunc >= key; upper: first trunc > key
+            const u32 mid = lo + ((hi - lo) >> 1);
+            const u64 v = sample[mid] >> sshift;
+            if (upper ? (v <= key) : (v < key)) lo = mid + 1; else hi = mid;
+        }
+        wg_sb[t] = lo;
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+        for (u64 i = t; i < z.n16[b]; i += nt) z.p[b][i] = make_uint4(0, 0, 0, 0);
+}
+
+// A wave reads the stream in super-blocks of STREAM_PF consecutive blocks (8 KB of delta bytes per
+// wave and request, the next super-block in flight while this one is probed: one block per request
+// left the kernel waiting on memory latency, 0.235 ms instead of ~0.08 ms at rs214 scale).
+#ifndef YH_STREAM_PF
+#define YH_STREAM_PF 4
+#endif
+constexpr int STREAM_PF = YH_STREAM_PF;
+
+template <class Flush>
+__device__ __forceinline__ void stream_blocks(const u32x4* __restrict__ deltas, const u64* __restrict__ hdr, u64 bl0,
+                                              u64 bl1, u32 sub, u32 n, u64 Klo, u64 Khi, u32 dsh, const u64* S,
+                                              const u16* E, const StreamHit& hit, const HitCtx32& ctx,
+                                              const Flush& flush) {
+    constexpr u32 WAVES = TILE_THREADS / 64;
+    constexpr u32 FLUSH_ROUNDS = 2;  // super-steps between two looks at the candidate queue
+    constexpr int PF = STREAM_PF;
+    const u32 lane = threadIdx.x & 63u;
+    const u64 last_blk = bl1 - 1;
+
+    // one block: the sample keys inside [base, last key of the block] probe its 1024 elements
+    auto probe_block = [&](u64 b, const u32x4 d, u64 base, u64 next) {
+        if (next < Klo || base > Khi) return;  // no sample key of the tile can lie in [base, next]
+        const u32 first_d = lane ? (d.x & 0xffu) : 0u;  // (a block's first delta byte is not used)
+        const u32 w0 = lane ? d.x : (d.x & 0xffffff00u);
+        const u32 tot = __builtin_amdgcn_sad_u8(w0, 0u, 0u) + __builtin_amdgcn_sad_u8(d.y, 0u, 0u) +
+                        __builtin_amdgcn_sad_u8(d.z, 0u, 0u) + __builtin_amdgcn_sad_u8(d.w, 0u, 0u);
+        // inclusive wave scan of the lanes' byte sums, DPP only (gfx9: row_shr 1/2/4/8 inside the rows of 16,
+        // then row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3)
+        int v = (int)tot;
+        v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+        const u32 incl = (u32)v;
+        const u32 lo = incl - tot + first_d;  // this lane's 16 elements hold the keys base + [lo, incl]
+        const u64 blk_last = base + (u32)__builtin_amdgcn_readlane(v, 63);
+        u32 k = (base <= Klo) ? 0u : (u32)E[(base - Klo) >> dsh];  // a slot at or before the first key >= base
+        for (;;) {  // 64 sample slots at a time; the keys inside the block are a run of lanes [c, c + np)
+            const u64 sk = S[k + lane];  // (ST_PAD sentinels ~0 behind the last key keep this in bounds)
+            const u64 ge = __ballot(sk >= base);
+            if (!ge) { k += 64; continue; }
+            const u64 in = __ballot(sk >= base && sk <= blk_last && k + lane < n);
+            const u32 c = (u32)__builtin_ctzll(ge);
+            const u32 np = (u32)__popcll(in);
+            const u32 rel = (u32)(sk - base);
+            // pass 1 (cheap, per probe): which probe, if any, falls into this lane's span
+            u32 myr = STREAM_NONE, myp = 0, more = 0;
+            for (u32 p = 0; p < np; ++p) {
+                const u32 r = (u32)__builtin_amdgcn_readlane((int)rel, (int)__builtin_amdgcn_readfirstlane((int)(c + p)));
+                const bool inspan = r >= lo && r <= incl;
+                more |= (inspan && myr != STREAM_NONE) ? 1u : 0u;
+                myp = (inspan && myr == STREAM_NONE) ? p : myp;
+                myr = (inspan && myr == STREAM_NONE) ? r : myr;
+            }
+            // pass 2 (once per block): the lanes that hold a probe compare their 16 keys with it
+            if (myr != STREAM_NONE) {
+                const u32 W[4] = {w0, d.y, d.z, d.w};
+                u32 cs = incl - tot, match = 0;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    cs += (W[j >> 2] >> (8 * (j & 3))) & 0xffu;
+                    match |= (cs == myr ? 1u : 0u) << j;
+                }
+                while (match) {  // (equal keys: several elements may match)
+                    const u32 j = (u32)__ffs((int)match) - 1u;
+                    match &= match - 1u;
+                    push_hit(hit, ctx, (b << 10) + 16u * lane + j, sub + k + c + myp);
+                }
+            }
+            if (__ballot(more != 0)) {  // rare: a lane's span holds several probes -- the remaining ones, one by one
+                for (u32 p = 0; p < np; ++p) {
+                    const u32 r = (u32)__builtin_amdgcn_readlane((int)rel, (int)__builtin_amdgcn_readfirstlane((int)(c + p)));
+                    if (more && p > myp && r >= lo && r <= incl) {
+                        const u32 W[4] = {w0, d.y, d.z, d.w};
+                        u32 cs = incl - tot;
+#pragma unroll 1
+                        for (int j = 0; j < 16; ++j) {
+                            cs += (W[j >> 2] >> (8 * (j & 3))) & 0xffu;
+                            if (cs == r) push_hit(hit, ctx, (b << 10) + 16u * lane + (u32)j, sub + k + c + p);
+                        }
+                    }
+                }
+            }
+            if (c + np < 64) break;  // the run ended inside these 64 slots
+            k += 64;
+        }
+    };
+    // loads of super-block sb (blocks sb*PF + i, clamped into the range: harmless re-reads at the end)
+    auto load_super = [&](u64 sb, u32x4 (&d)[PF], u64& h) {
+        const u64 b0 = bl0 + sb * PF;
+#pragma unroll
+        for (int i = 0; i < PF; ++i) d[i] = __builtin_nontemporal_load(deltas + min(b0 + i, last_blk) * 64 + lane);
+        h = hdr[min(b0 + min((u64)lane, (u64)PF), bl1)];  // lanes 0..PF hold the PF + 1 headers
+    };
+    const u64 n_super = (bl1 - bl0 + PF - 1) / PF;
+    u64 sb = threadIdx.x >> 6;
+    u32 round = 0;
+    u32x4 cur[PF];
+    u64 hcur = 0;
+    if (sb < n_super) load_super(sb, cur, hcur);
+    for (u64 it = 0; it < n_super; it += WAVES, sb += WAVES) {  // the same trip count in every wave
+        if ((++round % FLUSH_ROUNDS) == 0) {
+            __syncthreads();
+            const u32 fill = *ctx.q_fill;
+            __syncthreads();  // nobody queues before everybody has read: the decision is uniform
+            if (fill >= (u32)TILE_QCAP / 2) flush();
+        }
+        if (sb >= n_super) continue;
+        u32x4 nxt[PF];
+        u64 hnxt;
+        load_super(min(sb + WAVES, n_super - 1), nxt, hnxt);
+        const u32 hlo = (u32)hcur, hhi = (u32)(hcur >> 32);
+#pragma unroll 1
+        for (int i = 0; i < PF; ++i) {  // (not unrolled: one copy of the probe code, the block's registers picked by i)
+            const u64 b = bl0 + sb * PF + i;
+            if (b >= bl1) break;
+            const int ui = __builtin_amdgcn_readfirstlane(i);
+            u32x4 d = cur[0];
+#pragma unroll
+            for (int q = 1; q < PF; ++q) d = (ui == q) ? cur[q] : d;
+            const u64 base = ((u64)(u32)__builtin_amdgcn_readlane((int)hhi, ui) << 32) | (u32)__builtin_amdgcn_readlane((int)hlo, ui);
+            const u64 next = ((u64)(u32)__builtin_amdgcn_readlane((int)hhi, ui + 1) << 32) | (u32)__builtin_amdgcn_readlane((int)hlo, ui + 1);
+            probe_block(b, d, base, next);
+        }
+#pragma unroll
+        for (int i = 0; i < PF; ++i) cur[i] = nxt[i];
+        hcur = hnxt;
+    }
+}
+
+__global__ void __launch_bounds__(TILE_THREADS, YH_TILE_WAVES_PER_SIMD)
+k_stream_lookup(const u32x4* __restrict__ deltas, const u64* __restrict__ hdr, u64 nblk,
+                const u64* __restrict__ sample, const u32* __restrict__ wg_sb, u32 sshift,
+                u32* __restrict__ qcount, StreamHit hit) {
+    __shared__ __attribute__((aligned(16))) u64 S[ST_SLOTS];
+    __shared__ u16 E[TILE_NB];
+    __shared__ u64x2 Q[TILE_QCAP];
+    __shared__ u32 q_fill;
+    __shared__ u32 g_fill;
+
+    const u32 tid = threadIdx.x;
+    const u32 lid = xcd_remap(blockIdx.x, gridDim.x);
+    const u64 per = (nblk + gridDim.x - 1) / gridDim.x;
+    const u64 B0 = min((u64)lid * per, nblk), B1 = min(nblk, B0 + per);
+    const HitCtx32 ctx{&q_fill, Q, lid};
+    if (tid == 0) { q_fill = 0; g_fill = 0; }
+    const u32 s0 = wg_sb[2 * lid], s1 = wg_sb[2 * lid + 1];
+    if (B0 >= B1 || s0 >= s1) {  // no blocks, or no sample hash in this range of t: nothing to read
+        if (tid == 0) qcount[lid] = 0;
+        return;
+    }
+    auto flush = [&]() {
+        __syncthreads();
+        const u32 f = min(q_fill, (u32)TILE_QCAP);
+        const u32 g0 = g_fill;
+        for (u32 e = tid; e < f; e += TILE_THREADS) {
+            const u64x2 x = Q[e];
+            if (g0 + e < hit.qcap) hit.queue[(u64)lid * hit.qcap + g0 + e] = x;
+            else hit.count(lid, x.x, (u32)x.y);
+        }
+        __syncthreads();
+        if (tid == 0) { q_fill = 0; g_fill = g0 + f; }
+        __syncthreads();
+    };
+    bool first = true;
+    for (u32 sub = s0; sub < s1; sub += ST_CAP) {
+        const u32 n = min((u32)ST_CAP, s1 - sub);
+        if (!first) {
+            flush();
+            __syncthreads();
+        }
+        first = false;
+        for (u32 k = tid; k < n; k += TILE_THREADS) S[k] = sample[sub + k] >> sshift;
+        for (u32 k = n + tid; k < n + ST_PAD; k += TILE_THREADS) S[k] = ~0ull;
+        __syncthreads();
+        const u64 Klo = S[0], Khi = S[n - 1];
+        const u64 span = Khi - Klo;
+        const u32 dsh = (span >> TILE_LGNB) ? (u32)(64 - __builtin_clzll(span)) - TILE_LGNB : 0u;  // (span >> dsh) < TILE_NB
+        for (u32 k = tid; k < n; k += TILE_THREADS) {
+            const u32 bk = (u32)((S[k] - Klo) >> dsh);
+            const int bp = (k == 0) ? -1 : (int)((S[k - 1] - Klo) >> dsh);
+            for (int x = bp + 1; x <= (int)bk; ++x) E[x] = (u16)k;
+            if (k == n - 1)
+                for (u32 x = bk + 1; x < (u32)TILE_NB; ++x) E[x] = (u16)n;
+        }
+        __syncthreads();
+        u64 bl0 = B0, bl1 = B1;
+        if (s1 - s0 > (u32)ST_CAP) {  // several tiles: each covers a contiguous sub-range of the blocks
+            u64 lo = B0, hi = B1;     // first block whose NEXT header is >= Klo
+            while (lo < hi) { const u64 mid = (lo + hi) >> 1; if (hdr[mid + 1] < Klo) lo = mid + 1; else hi = mid; }
+            bl0 = lo;
+            lo = bl0; hi = B1;        // first block whose header is > Khi
+            while (lo < hi) { const u64 mid = (lo + hi) >> 1; if (hdr[mid] <= Khi) lo = mid + 1; else hi = mid; }
+            bl1 = lo;
+        }
+        stream_blocks(deltas, hdr, bl0, bl1, sub, n, Klo, Khi, dsh, S, E, hit, ctx, flush);
+    }
+    flush();
+    if (tid == 0) qcount[lid] = min(g_fill, hit.qcap);
+}
+
 // ---- cross-check kernel: one wave per reference over the plain CSR -------------------------------
 __global__ void __launch_bounds__(256) k_overlap_bsearch(const u64* __restrict__ values,
                                                          const u64* __restrict__ offsets, u64 n_refs,
@@ -1163,8 +1480,65 @@ int yh_q_check_sorted_host(const u64* v, u64 n) {
 
 // flag_shared: also flag which database-shared hashes are in the sample (db->d_hit), fused into the
 // same launch; yh_q_exclusive_partial(..., hit_ready = true) then skips its own membership pass.
+// overlap through the hash-sorted delta stream (the default layout)
+static int yh_q_overlap_stream(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap, bool flag_shared,
+                               bool with_index, bool make_mask) {
+    hipStream_t st = db->stream;
+    const u64 N = db->n_refs;
+    const u64 nblk = db->slen / STREAM_BLOCK;
+    u32 wgs = tile_grid(db->slen);
+    if ((u64)wgs > nblk) wgs = (u32)std::max<u64>(nblk, 1);
+    const u64 per_wg = (db->slen + wgs - 1) / wgs;
+    const u32 qcap = (u32)std::min<u64>(std::max<u64>(4096, per_wg / 16), 1u << 24);
+    if (db->hitq_wgs < wgs || db->hitq_cap < qcap) {
+        YH_HIP(hipStreamSynchronize(st));
+        if (db->d_hitq) { (void)hipFree(db->d_hitq); db->d_hitq = nullptr; }
+        if (db->d_hitq_cnt) { (void)hipFree(db->d_hitq_cnt); db->d_hitq_cnt = nullptr; }
+        db->hitq_wgs = db->hitq_cap = 0;
+        YH_HIP(hipMalloc((void**)&db->d_hitq, (u64)wgs * qcap * 2 * sizeof(u64)));
+        YH_HIP(hipMalloc((void**)&db->d_hitq_cnt, (u64)wgs * sizeof(u32)));
+        db->hitq_wgs = wgs;
+        db->hitq_cap = qcap;
+    }
+    if (db->wg_key_n != wgs) {  // the first t of every workgroup's block range: once per handle
+        YH_HIP(hipStreamSynchronize(st));
+        if (db->d_wg_key) { (void)hipFree(db->d_wg_key); db->d_wg_key = nullptr; }
+        if (db->d_wg_sb) { (void)hipFree(db->d_wg_sb); db->d_wg_sb = nullptr; }
+        YH_HIP(hipMalloc((void**)&db->d_wg_key, ((u64)wgs + 2) * sizeof(u64)));
+        YH_HIP(hipMalloc((void**)&db->d_wg_sb, 2ull * wgs * sizeof(u32) + 16));
+        k_wg_key<<<(wgs + 256) / 256, 256, 0, st>>>(db->d_shdr, nblk, wgs, db->d_wg_key);
+        db->wg_key_n = wgs;
+    }
+    u32 R = 32;
+    while (R > 1 && (u64)R * N > (2u << 20)) R >>= 1;
+    if (db->reps_cap < (u64)R * N) {
+        YH_HIP(hipStreamSynchronize(st));
+        if (db->d_reps) { (void)hipFree(db->d_reps); db->d_reps = nullptr; db->reps_cap = 0; }
+        YH_HIP(hipMalloc((void**)&db->d_reps, (u64)R * N * sizeof(u32) + 16));
+        db->reps_cap = (u64)R * N;
+    }
+    ZeroList z{};
+    z.p[0] = reinterpret_cast<uint4*>(db->d_reps);
+    z.n16[0] = ((u64)R * N * sizeof(u32) + 15) / 16;
+    if (flag_shared) { z.p[1] = reinterpret_cast<uint4*>(db->d_hit); z.n16[1] = (db->n_shared + 15) / 16; }
+    if (with_index) { z.p[2] = reinterpret_cast<uint4*>(db->d_excl_e); z.n16[2] = (3 * N * sizeof(u32) + 15) / 16; }
+    k_prep_stream<<<1024, 256, 0, st>>>(d_sample, (u32)n_sample, db->d_wg_key, wgs, db->sshift, db->d_wg_sb, z);
+    const bool flags_too = flag_shared && db->d_sgidx;
+    StreamHit sh{(u32)N, db->d_reps, R - 1, reinterpret_cast<u64x2*>(db->d_hitq), db->hitq_cap, db->d_svals, db->d_sref,
+                 db->d_sgidx, flags_too ? db->d_hit : nullptr, d_sample};
+    yh_ring_record_begin(db, db->ev_overlap);
+    k_stream_lookup<<<wgs, TILE_THREADS, 0, st>>>(reinterpret_cast<const u32x4*>(db->d_sdelta), db->d_shdr, nblk, d_sample,
+                                                  db->d_wg_sb, db->sshift, db->d_hitq_cnt, sh);
+    yh_ring_record_end(db, db->ev_overlap);
+    k_resolve_stream<<<wgs, 256, 0, st>>>(db->d_hitq_cnt, sh);
+    k_reduce_replicas<<<(u32)((N + 255) / 256), 256, 0, st>>>(db->d_reps, R, N, d_overlap, make_mask ? db->d_mask : nullptr,
+                                                             make_mask ? db->d_maskbits : nullptr);
+    YH_HIP(hipGetLastError());
+    return YH_OK;
+}
+
 int yh_q_overlap(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap, bool flag_shared, bool make_mask) {
-    if (!db->d_pvals) { yh_set_error("this handle has no streaming layout (yh_db_create_from_pairs or YH_DB_PAIRWISE_ONLY)"); return YH_ERR_UNSUPPORTED; }
+    if (db->posting_only || (db->flags & YH_DB_PAIRWISE_ONLY)) { yh_set_error("this handle has no streaming layout (yh_db_create_from_pairs or YH_DB_PAIRWISE_ONLY)"); return YH_ERR_UNSUPPORTED; }
     hipStream_t st = db->stream;
     const u64 N = db->n_refs;
     if (n_sample > 0xfffffff0ull) { yh_set_error("sample larger than 2^32-16 hashes"); return YH_ERR_INVALID_ARG; }
@@ -1180,6 +1554,7 @@ int yh_q_overlap(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap, b
         }
         return YH_OK;
     }
+    if (db->d_sdelta) return yh_q_overlap_stream(db, d_sample, n_sample, d_overlap, flag_shared, with_index, make_mask);
     const u32 P = db->n_parts;
     // hit queue: one segment per workgroup, 1/16 of its stream slice (at least 4096 entries)
     const u32 wgs = tile_grid(db->pvals_len);
@@ -1361,7 +1736,7 @@ int yh_q_exclusive_final(yh_db* db, u64 n, const u8* d_mask, const u32* d_sizes,
 int yh_q_exclusive(yh_db* db, const u8* d_mask, const u64* d_sample, u64 n_sample, const u32* d_overlap,
                    u32* d_excl, u32* d_match, bool hit_ready, const u32* d_maskbits) {
     if (!db->has_index) { yh_set_error("this handle was created with YH_DB_NO_INDEX"); return YH_ERR_UNSUPPORTED; }
-    if (!db->d_pvals) { yh_set_error("this handle holds posting lists only"); return YH_ERR_UNSUPPORTED; }
+    if (db->posting_only || (db->flags & YH_DB_PAIRWISE_ONLY)) { yh_set_error("this handle holds posting lists only"); return YH_ERR_UNSUPPORTED; }
     if (db->n_refs == 0) return YH_OK;
     yh_ring_record_begin(db, db->ev_excl);
     YH_TRY(yh_q_exclusive_partial(db, d_mask, d_sample, n_sample, db->d_excl_e, db->d_excl_m, db->d_ovsh, false,
@@ -1375,7 +1750,7 @@ int yh_q_exclusive(yh_db* db, const u8* d_mask, const u64* d_sample, u64 n_sampl
 // Fills the handle's host-side pair cache (h_pw_*) for rows [r0, r1).
 int yh_q_pairwise(yh_db* db, double c_thresh, u64 r0, u64 r1) {
     if (!db->has_index) { yh_set_error("this handle was created with YH_DB_NO_INDEX"); return YH_ERR_UNSUPPORTED; }
-    if (!db->d_pvals && !(db->flags & YH_DB_PAIRWISE_ONLY)) {  // (from_pairs handles carry no sketch sizes)
+    if (db->posting_only) {  // (from_pairs handles carry no sketch sizes)
         yh_set_error("this handle holds posting lists only");
         return YH_ERR_UNSUPPORTED;
     }
