@@ -7,7 +7,7 @@ import os
 import sys
 
 root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out"
-OURS = ("k_tile_lookup", "k_resolve_hits", "k_excl", "k_prep", "k_mask_bits", "k_reduce_replicas", "k_sample_bounds", "k_mask_from", "k_pair", "k_overlap_bsearch",
+OURS = ("k_tile_lookup", "k_stream_lookup", "k_resolve_stream", "k_wg_", "k_batch", "k_index_lookup", "k_resolve_hits", "k_excl", "k_prep", "k_mask_bits", "k_reduce_replicas", "k_sample_bounds", "k_mask_from", "k_pair", "k_overlap_bsearch",
         "k_scan_u32", "k_idx", "k_split", "k_part_scan", "k_scatter", "k_scan_refs", "k_fill", "k_bounds")
 
 

@@ -894,22 +894,34 @@ __global__ void k_wg_key(const u64* __restrict__ hdr, u64 nblk, u32 wgs, u64* __
 }
 
 // per query: each workgroup's sample range [lo, hi) = sample hashes with wg_key[w] <= t <= wg_key[w + 1]
-// (inclusive on both sides: equal keys may sit on either side of a range boundary), + the zeroing
+// (inclusive on both sides: equal keys may sit on either side of a range boundary), + the zeroing.
+// One WAVE per bound, 64-ary search: 3 dependent rounds of 64 parallel probes + a final one instead
+// of 20 dependent reads (11 -> 5 us at 2 x 512 bounds over a 10^6-hash sample).
 __global__ void __launch_bounds__(256) k_prep_stream(const u64* __restrict__ sample, u32 n, const u64* __restrict__ wg_key,
                                                      u32 wgs, u32 sshift, u32* __restrict__ wg_sb, ZeroList z) {
     const u64 t = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     const u64 nt = (u64)gridDim.x * blockDim.x;
-    if (t < 2ull * wgs) {
-        const u32 w = (u32)(t >> 1);
-        const bool upper = (t & 1) != 0;
-        const u64 key = wg_key[w + (upper ? 1 : 0)];
-        u32 lo = 0, hi = n;
-        while (lo < hi) {  // lower: first trunc >= key; upper: first trunc > key
-            const u32 mid = lo + ((hi - lo) >> 1);
-            const u64 v = sample[mid] >> sshift;
-            if (upper ? (v <= key) : (v < key)) lo = mid + 1; else hi = mid;
+    const u64 gw = t >> 6;
+    const u32 lane = threadIdx.x & 63u;
+    if (gw < 2ull * wgs) {
+        const bool upper = (gw & 1) != 0;  // lower bound: first trunc >= key; upper bound: first trunc > key
+        const u64 key = wg_key[(gw >> 1) + (upper ? 1 : 0)];
+        auto pred = [&](u32 i) { const u64 v = sample[i] >> sshift; return upper ? (v <= key) : (v < key); };
+        u32 lo = 0, hi = n;  // the answer (first index whose pred is false) lies in [lo, hi]
+        while (hi - lo > 64) {
+            const u32 step = (hi - lo + 63) / 64;
+            const u64 q = (u64)lo + (u64)(lane + 1) * step - 1;  // probe positions, ascending
+            const bool p = q < hi && pred((u32)q);
+            const u32 cnt = (u32)__popcll(__ballot(p));  // pred is monotone: the true lanes are 0..cnt-1
+            const u64 nlo = (u64)lo + (u64)cnt * step;
+            const u64 nhi = (u64)lo + (u64)(cnt + 1) * step - 1;  // pred is false there (or it is past hi)
+            hi = (u32)min((u64)hi, nhi);
+            lo = (u32)min(nlo, (u64)hi);
         }
-        wg_sb[t] = lo;
+        const u32 i = lo + lane;
+        const bool p = i < hi && pred(i);
+        const u32 ans = lo + (u32)__popcll(__ballot(p));
+        if (lane == 0) wg_sb[gw] = ans;
     }
 #pragma unroll
     for (int b = 0; b < 4; ++b)
@@ -917,99 +929,42 @@ __global__ void __launch_bounds__(256) k_prep_stream(const u64* __restrict__ sam
 }
 
 // A wave reads the stream in super-blocks of STREAM_PF consecutive blocks (8 KB of delta bytes per
-// wave and request, the next super-block in flight while this one is probed: one block per request
-// left the kernel waiting on memory latency, 0.235 ms instead of ~0.08 ms at rs214 scale).
+// wave and request, the next super-block in flight while this one is probed).  Per super-block:
+//   1. every block's lane spans: byte sums (v_sad_u8) + a DPP wave scan, written to LDS (INC);
+//   2. the sample keys inside the super-block's key range, ONE PER LANE: which block (8 scalar
+//      compares), which lane of it (6-step binary search in INC), that lane's 16 delta bytes again
+//      (a 16-byte read that hits L2) and a 16-step compare.
+// Probing lane-parallel over 8192 elements instead of once per 1024 is what takes the kernel from
+// 0.19 instructions per element (one probe at a time, three lanes busy) to ~0.04.
 #ifndef YH_STREAM_PF
-#define YH_STREAM_PF 4
+#define YH_STREAM_PF 8
 #endif
 constexpr int STREAM_PF = YH_STREAM_PF;
+static_assert(STREAM_PF >= 1 && STREAM_PF <= 15, "headers of a super-block live in lanes 0..PF");
+
+__device__ __forceinline__ u64 readlane_u64(u64 v, int l) {
+    return ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(v >> 32), l) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)v, l);
+}
 
 template <class Flush>
 __device__ __forceinline__ void stream_blocks(const u32x4* __restrict__ deltas, const u64* __restrict__ hdr, u64 bl0,
                                               u64 bl1, u32 sub, u32 n, u64 Klo, u64 Khi, u32 dsh, const u64* S,
-                                              const u16* E, const StreamHit& hit, const HitCtx32& ctx,
-                                              const Flush& flush) {
+                                              const u16* E, u32* INCw, u32* HBw, const StreamHit& hit,
+                                              const HitCtx32& ctx, const Flush& flush) {
     constexpr u32 WAVES = TILE_THREADS / 64;
-    constexpr u32 FLUSH_ROUNDS = 2;  // super-steps between two looks at the candidate queue
+#ifndef YH_STREAM_FLUSH
+#define YH_STREAM_FLUSH 2
+#endif
+    constexpr u32 FLUSH_ROUNDS = YH_STREAM_FLUSH;  // super-steps between two looks at the candidate queue
     constexpr int PF = STREAM_PF;
     const u32 lane = threadIdx.x & 63u;
     const u64 last_blk = bl1 - 1;
 
-    // one block: the sample keys inside [base, last key of the block] probe its 1024 elements
-    auto probe_block = [&](u64 b, const u32x4 d, u64 base, u64 next) {
-        if (next < Klo || base > Khi) return;  // no sample key of the tile can lie in [base, next]
-        const u32 first_d = lane ? (d.x & 0xffu) : 0u;  // (a block's first delta byte is not used)
-        const u32 w0 = lane ? d.x : (d.x & 0xffffff00u);
-        const u32 tot = __builtin_amdgcn_sad_u8(w0, 0u, 0u) + __builtin_amdgcn_sad_u8(d.y, 0u, 0u) +
-                        __builtin_amdgcn_sad_u8(d.z, 0u, 0u) + __builtin_amdgcn_sad_u8(d.w, 0u, 0u);
-        // inclusive wave scan of the lanes' byte sums, DPP only (gfx9: row_shr 1/2/4/8 inside the rows of 16,
-        // then row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3)
-        int v = (int)tot;
-        v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
-        v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
-        v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
-        v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
-        v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
-        v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
-        const u32 incl = (u32)v;
-        const u32 lo = incl - tot + first_d;  // this lane's 16 elements hold the keys base + [lo, incl]
-        const u64 blk_last = base + (u32)__builtin_amdgcn_readlane(v, 63);
-        u32 k = (base <= Klo) ? 0u : (u32)E[(base - Klo) >> dsh];  // a slot at or before the first key >= base
-        for (;;) {  // 64 sample slots at a time; the keys inside the block are a run of lanes [c, c + np)
-            const u64 sk = S[k + lane];  // (ST_PAD sentinels ~0 behind the last key keep this in bounds)
-            const u64 ge = __ballot(sk >= base);
-            if (!ge) { k += 64; continue; }
-            const u64 in = __ballot(sk >= base && sk <= blk_last && k + lane < n);
-            const u32 c = (u32)__builtin_ctzll(ge);
-            const u32 np = (u32)__popcll(in);
-            const u32 rel = (u32)(sk - base);
-            // pass 1 (cheap, per probe): which probe, if any, falls into this lane's span
-            u32 myr = STREAM_NONE, myp = 0, more = 0;
-            for (u32 p = 0; p < np; ++p) {
-                const u32 r = (u32)__builtin_amdgcn_readlane((int)rel, (int)__builtin_amdgcn_readfirstlane((int)(c + p)));
-                const bool inspan = r >= lo && r <= incl;
-                more |= (inspan && myr != STREAM_NONE) ? 1u : 0u;
-                myp = (inspan && myr == STREAM_NONE) ? p : myp;
-                myr = (inspan && myr == STREAM_NONE) ? r : myr;
-            }
-            // pass 2 (once per block): the lanes that hold a probe compare their 16 keys with it
-            if (myr != STREAM_NONE) {
-                const u32 W[4] = {w0, d.y, d.z, d.w};
-                u32 cs = incl - tot, match = 0;
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    cs += (W[j >> 2] >> (8 * (j & 3))) & 0xffu;
-                    match |= (cs == myr ? 1u : 0u) << j;
-                }
-                while (match) {  // (equal keys: several elements may match)
-                    const u32 j = (u32)__ffs((int)match) - 1u;
-                    match &= match - 1u;
-                    push_hit(hit, ctx, (b << 10) + 16u * lane + j, sub + k + c + myp);
-                }
-            }
-            if (__ballot(more != 0)) {  // rare: a lane's span holds several probes -- the remaining ones, one by one
-                for (u32 p = 0; p < np; ++p) {
-                    const u32 r = (u32)__builtin_amdgcn_readlane((int)rel, (int)__builtin_amdgcn_readfirstlane((int)(c + p)));
-                    if (more && p > myp && r >= lo && r <= incl) {
-                        const u32 W[4] = {w0, d.y, d.z, d.w};
-                        u32 cs = incl - tot;
-#pragma unroll 1
-                        for (int j = 0; j < 16; ++j) {
-                            cs += (W[j >> 2] >> (8 * (j & 3))) & 0xffu;
-                            if (cs == r) push_hit(hit, ctx, (b << 10) + 16u * lane + (u32)j, sub + k + c + p);
-                        }
-                    }
-                }
-            }
-            if (c + np < 64) break;  // the run ended inside these 64 slots
-            k += 64;
-        }
-    };
     // loads of super-block sb (blocks sb*PF + i, clamped into the range: harmless re-reads at the end)
     auto load_super = [&](u64 sb, u32x4 (&d)[PF], u64& h) {
         const u64 b0 = bl0 + sb * PF;
 #pragma unroll
-        for (int i = 0; i < PF; ++i) d[i] = __builtin_nontemporal_load(deltas + min(b0 + i, last_blk) * 64 + lane);
+        for (int i = 0; i < PF; ++i) d[i] = deltas[min(b0 + i, last_blk) * 64 + lane];
         h = hdr[min(b0 + min((u64)lane, (u64)PF), bl1)];  // lanes 0..PF hold the PF + 1 headers
     };
     const u64 n_super = (bl1 - bl0 + PF - 1) / PF;
@@ -1029,18 +984,96 @@ __device__ __forceinline__ void stream_blocks(const u32x4* __restrict__ deltas, 
         u32x4 nxt[PF];
         u64 hnxt;
         load_super(min(sb + WAVES, n_super - 1), nxt, hnxt);
-        const u32 hlo = (u32)hcur, hhi = (u32)(hcur >> 32);
-#pragma unroll 1
-        for (int i = 0; i < PF; ++i) {  // (not unrolled: one copy of the probe code, the block's registers picked by i)
-            const u64 b = bl0 + sb * PF + i;
-            if (b >= bl1) break;
-            const int ui = __builtin_amdgcn_readfirstlane(i);
-            u32x4 d = cur[0];
+        const u64 b0 = bl0 + sb * PF;
+        const int nvalid = (int)min((u64)PF, bl1 - b0);
+        const u64 base0 = readlane_u64(hcur, 0);
+        const u64 endkey = readlane_u64(hcur, nvalid);  // first key behind the super-block
+#if defined(YH_STREAM_ABLATE) && YH_STREAM_ABLATE == 1  // timing-only: loads, nothing else
+        {
+            u32 acc = 0;
 #pragma unroll
-            for (int q = 1; q < PF; ++q) d = (ui == q) ? cur[q] : d;
-            const u64 base = ((u64)(u32)__builtin_amdgcn_readlane((int)hhi, ui) << 32) | (u32)__builtin_amdgcn_readlane((int)hlo, ui);
-            const u64 next = ((u64)(u32)__builtin_amdgcn_readlane((int)hhi, ui + 1) << 32) | (u32)__builtin_amdgcn_readlane((int)hlo, ui + 1);
-            probe_block(b, d, base, next);
+            for (int i = 0; i < PF; ++i) acc ^= cur[i].x ^ cur[i].y ^ cur[i].z ^ cur[i].w;
+            if (acc == 0x12345678u && base0 == 77) push_hit(hit, ctx, b0, sub);
+        }
+        if (true) {} else
+#endif
+        if (!(endkey < Klo || base0 > Khi)) {           // some sample key of the tile can lie inside
+            if (lane <= (u32)PF) HBw[lane] = ((int)lane < nvalid) ? (u32)(hcur - base0) : 0xffffffffu;
+            u32 hl[PF];  // last key of block i relative to base0 (scalar); invalid blocks: ~0
+            u32 last_rel = 0;
+#pragma unroll
+            for (int i = 0; i < PF; ++i) {
+                const u32x4 d = cur[i];
+                const u32 w0 = lane ? d.x : (d.x & 0xffffff00u);  // (a block's first delta byte is not used)
+                const u32 tot = __builtin_amdgcn_sad_u8(w0, 0u, 0u) + __builtin_amdgcn_sad_u8(d.y, 0u, 0u) +
+                                __builtin_amdgcn_sad_u8(d.z, 0u, 0u) + __builtin_amdgcn_sad_u8(d.w, 0u, 0u);
+                // inclusive wave scan, DPP only (gfx9: row_shr 1/2/4/8 inside the rows of 16, then
+                // row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3)
+                int v = (int)tot;
+                v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+                v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+                v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+                v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+                v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+                v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+                INCw[i * 64 + lane] = (u32)v;
+                const u32 hb = (u32)(readlane_u64(hcur, i) - base0);
+                hl[i] = (i < nvalid) ? hb + (u32)__builtin_amdgcn_readlane(v, 63) : 0xffffffffu;
+                if (i < nvalid) last_rel = hl[i];
+            }
+            const u64 sb_last = base0 + last_rel;
+            u32 k = (base0 <= Klo) ? 0u : (u32)E[(base0 - Klo) >> dsh];  // a slot at or before the first key >= base0
+#if defined(YH_STREAM_ABLATE) && YH_STREAM_ABLATE == 2  // timing-only: + lane spans
+            if (k == 0x12345678u && sb_last == 77 && INCw[lane] == 5) push_hit(hit, ctx, b0, sub);
+            if (true) {} else
+#endif
+            for (;;) {  // 64 sample slots at a time; the keys inside the super-block are a run of lanes
+                const u64 sk = S[k + lane];  // (ST_PAD sentinels ~0 behind the last key keep this in bounds)
+                const u64 ge = __ballot(sk >= base0);
+                if (!ge) { k += 64; continue; }
+                const bool in = sk >= base0 && sk <= sb_last && k + lane < n;
+                const u32 c = (u32)__builtin_ctzll(ge);
+                const u32 np = (u32)__popcll(__ballot(in));
+#if defined(YH_STREAM_ABLATE) && YH_STREAM_ABLATE == 3  // timing-only: + finding the probes
+                if (in && sk == 0x1234567812345678ull) push_hit(hit, ctx, b0, sub);
+                if (true) {} else
+#endif
+                if (in) {  // one probe per lane
+                    const u32 rel = (u32)(sk - base0);
+                    u32 f = 0;  // first block whose last key is >= the probe
+#pragma unroll
+                    for (int i = 0; i < PF; ++i) f += (hl[i] < rel) ? 1u : 0u;
+                    while (f < (u32)PF) {  // (a run of equal keys may continue into the next block)
+                        const u32 hb = HBw[f];
+                        if (hb > rel) break;
+                        const u32 r = rel - hb;
+                        const u32* inc = INCw + f * 64;
+                        u32 t = 0;  // first lane whose last key is >= r  (inc[63] = the block's last key >= r)
+#pragma unroll
+                        for (int st = 32; st >= 1; st >>= 1) t += (inc[t + st - 1] < r) ? (u32)st : 0u;
+                        for (;;) {  // that lane's 16 elements, then the following lanes while the run of equal keys lasts
+                            const u32x4 w = deltas[(b0 + f) * 64 + t];
+                            const u32 W[4] = {t ? w.x : (w.x & 0xffffff00u), w.y, w.z, w.w};
+                            u32 cs = t ? inc[t - 1] : 0u, match = 0;
+#pragma unroll
+                            for (int j = 0; j < 16; ++j) {
+                                cs += (W[j >> 2] >> (8 * (j & 3))) & 0xffu;
+                                match |= (cs == r ? 1u : 0u) << j;
+                            }
+                            while (match) {
+                                const u32 j = (u32)__ffs((int)match) - 1u;
+                                match &= match - 1u;
+                                push_hit(hit, ctx, ((b0 + f) << 10) + 16u * t + j, sub + k + lane);
+                            }
+                            if (cs != r || t == 63) break;
+                            ++t;
+                        }
+                        ++f;
+                    }
+                }
+                if (c + np < 64) break;  // the run of inside keys ended within these 64 slots
+                k += 64;
+            }
         }
 #pragma unroll
         for (int i = 0; i < PF; ++i) cur[i] = nxt[i];
@@ -1055,6 +1088,8 @@ k_stream_lookup(const u32x4* __restrict__ deltas, const u64* __restrict__ hdr, u
     __shared__ __attribute__((aligned(16))) u64 S[ST_SLOTS];
     __shared__ u16 E[TILE_NB];
     __shared__ u64x2 Q[TILE_QCAP];
+    __shared__ u32 INC[TILE_THREADS / 64][STREAM_PF * 64];  // per wave: the lane-inclusive key sums of a super-block
+    __shared__ u32 HB[TILE_THREADS / 64][16];               // per wave: first key of each of its blocks, relative
     __shared__ u32 q_fill;
     __shared__ u32 g_fill;
 
@@ -1113,7 +1148,7 @@ k_stream_lookup(const u32x4* __restrict__ deltas, const u64* __restrict__ hdr, u
             while (lo < hi) { const u64 mid = (lo + hi) >> 1; if (hdr[mid] <= Khi) lo = mid + 1; else hi = mid; }
             bl1 = lo;
         }
-        stream_blocks(deltas, hdr, bl0, bl1, sub, n, Klo, Khi, dsh, S, E, hit, ctx, flush);
+        stream_blocks(deltas, hdr, bl0, bl1, sub, n, Klo, Khi, dsh, S, E, INC[tid >> 6], HB[tid >> 6], hit, ctx, flush);
     }
     flush();
     if (tid == 0) qcount[lid] = min(g_fill, hit.qcap);
