@@ -5,7 +5,7 @@
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 A "step" is one pass of the device-side `yacht run` counts over one sample sketch:
-overlap of the sample with every reference of the rank's shard (tile-lookup kernel, R1),
+overlap of the sample with every reference of the rank's shard (streaming lookup kernel, R1),
 mask = overlap > 0, subset-exclusive hash counts (R2), and — for N > 1 — one RCCL all-gather of
 the per-reference counts.  Inputs are resident in HBM before the timed region.
 
@@ -17,7 +17,7 @@ every rank holds its own 85 205-reference shard of an N x 85 205 database, the s
 replicated, and no collective sits on the data path except the final gather of counts.
 
 Rank 0 prints ONE JSON line (contract in the task statement) carrying `roofline` for the
-dominant kernel (k_tile_lookup_keys) and `cpu_baseline` (the oracle's C++ restatement,
+dominant kernel (k_stream_lookup) and `cpu_baseline` (the oracle's C++ restatement,
 all host cores, same workload, also used as the full-size bit-exact parity check).
 """
 from __future__ import annotations
@@ -231,35 +231,39 @@ def main() -> int:
     total_refs = n_refs * world
     value = total_refs / (elapsed / args.steps)
 
-    # ---- roofline of the dominant kernel (the tile lookup over the packed key stream) -------------------
-    # Bytes one launch has to move in this layout: a 3-byte key per reference hash (the stream) and the
-    # 8-byte sample hashes staged once.  `achieved` is that figure over the measured duration: the
-    # physical HBM rate the kernel sustains, comparable with `peak` and with `traffic` (PMC).
-    # SURVEY.md §8d's one-touch formula (8 B per reference hash: 8(H+|S|) + 8(N+1) + 4N) is reported
-    # beside it; it exceeds the peak because the kernel no longer reads 8 bytes per hash.
-    keyed = bool(info.get("key_stream", 1)) and os.environ.get("YH_WIDE_KEYS", "0") != "1"
+    # ---- roofline of the dominant kernel (the streaming lookup) ------------------------------------------
+    # Bytes one launch HAS to move in the layout the kernel reads (yh_db_info.stream_bytes: one delta
+    # byte per (hash, reference) pair + an 8-byte header per 1024 for the default hash-sorted delta
+    # stream; 3 bytes per pair for YH_STREAM=keys; 8 for YH_WIDE_KEYS=1) plus the 8-byte sample hashes
+    # staged once.  `achieved` is that figure over the measured duration: the physical HBM rate the
+    # kernel sustains, comparable with `peak` and with `traffic` (PMC).  SURVEY.md 8d's one-touch
+    # formula (8 B per reference hash: 8(H+|S|) + 8(N+1) + 4N) is reported beside it; it exceeds the
+    # peak because the kernel does not read 8 bytes per hash any more.
+    layout = int(info.get("stream_layout", 0))
+    kernel_name = {1: "k_stream_lookup", 2: "k_tile_lookup_keys", 3: "k_tile_lookup<OverlapHit>"}.get(layout, "?")
     survey_bytes = 8 * (H + n_sample) + 8 * (n_refs + 1) + 4 * n_refs
-    alg_bytes = (3 * H + 8 * n_sample) if keyed else survey_bytes
+    alg_bytes = int(info.get("stream_bytes", 0)) + 8 * n_sample
     k_ms = float(timing["ms_overlap_kernel"])
     achieved = (alg_bytes / 1e9) / (k_ms / 1e3) if k_ms > 0 else 0.0
     survey_rate = (survey_bytes / 1e9) / (k_ms / 1e3) if k_ms > 0 else 0.0
     roofline = {
         "bound": "hbm",
-        "kernel": "k_tile_lookup_keys" if keyed else "k_tile_lookup<OverlapHit>",
+        "kernel": kernel_name,
         "achieved": round(achieved, 1),
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4),
         "traffic": None,
         "algorithmic_bytes_per_launch": alg_bytes,
-        "bytes_per_ref_hash": 3 if keyed else 8,
+        "bytes_per_ref_hash": round(int(info.get("stream_bytes", 0)) / max(H, 1), 4),
         "kernel_ms_avg": round(k_ms, 4),
         "exclusive_kernels_ms_avg": round(float(timing["ms_exclusive_kernels"]), 4),
         "survey_formula": {"bytes_per_launch": survey_bytes, "GBps": round(survey_rate, 1),
                            "frac": round(survey_rate / HBM_PEAK_GBS, 4),
-                           "note": "8 B per reference hash as SURVEY.md 8d counts; the kernel streams 3-byte keys"},
+                           "note": "8 B per reference hash as SURVEY.md 8d counts; the kernel streams "
+                                   f"{round(int(info.get('stream_bytes', 0)) / max(H, 1), 3)} B per hash"},
     }
-    traffic_file = os.path.join(ROOT, "profiles", "traffic_r01.json")
+    traffic_file = os.path.join(ROOT, "profiles", "traffic_r01.json")  # written by scripts/make_traffic_json.py
     if os.path.exists(traffic_file):  # HBM bytes per launch from the rocprofv3 --pmc passes (profiles/README.md)
         try:
             with open(traffic_file) as f:

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define YH_ABI_VERSION 1
+#define YH_ABI_VERSION 2
 
 enum {
     YH_OK               = 0,
@@ -79,7 +79,17 @@ typedef struct yh_db_info {
     uint64_t device_bytes;       /* HBM held by the handle                                    */
     int32_t  device_id;
     uint32_t flags;
+    uint32_t stream_layout;      /* what the streaming overlap kernel reads: YH_STREAM_*      */
+    uint32_t stream_shift;       /* delta stream: stream key = hash >> stream_shift           */
+    uint64_t stream_bytes;       /* bytes of that array = HBM bytes one query has to stream   */
 } yh_db_info;
+
+/* yh_db_info.stream_layout */
+#define YH_STREAM_NONE   0u  /* posting-only / pairwise-only handle                              */
+#define YH_STREAM_DELTA  1u  /* default: all (hash, reference) pairs in hash order, one delta BYTE
+                                per pair (+ an 8-byte header per 1024) -- k_stream_lookup            */
+#define YH_STREAM_KEYS24 2u  /* YH_STREAM=keys: partition-major packed 24-bit keys -- k_tile_lookup_keys */
+#define YH_STREAM_WIDE   3u  /* YH_WIDE_KEYS=1: partition-major 64-bit hashes -- k_tile_lookup     */
 
 typedef struct yh_timing {
     float ms_overlap_kernel;     /* last overlap tile kernel (HIP events on the handle's stream) */

@@ -21,6 +21,7 @@ def short(name: str) -> str:
 
 stats = glob.glob(os.path.join(root, "prof_stats", "*", "*_kernel_stats.csv"))
 if stats:
+    stats.sort(key=os.path.getmtime, reverse=True)
     print("== kernel stats (ours) ==")
     print(f"{'kernel':42s} {'calls':>6s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'total_ms':>9s}")
     for r in csv.DictReader(open(stats[0])):
@@ -33,8 +34,9 @@ for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
     if not files:
         continue
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
-    for r in csv.DictReader(open(files[0])):
-        if any(t in r["Kernel_Name"] for t in ("k_tile_lookup", "k_resolve_hits", "k_excl_postings")):
+    files.sort(key=os.path.getmtime)
+    for r in csv.DictReader(open(files[-1])):
+        if any(t in r["Kernel_Name"] for t in ("k_tile_lookup", "k_stream_lookup", "k_resolve_stream", "k_resolve_hits", "k_excl_chunks")):
             acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
     print(f"== {os.path.basename(d)} (mean per launch) ==")
     for k, v in acc.items():
@@ -45,6 +47,7 @@ for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
 # ---- timeline of the last complete step (kernel trace): start offset, duration, gap to the previous kernel
 trace = glob.glob(os.path.join(root, "prof_stats", "*", "*_kernel_trace.csv"))
 if trace:
+    trace.sort(key=os.path.getmtime, reverse=True)
     rows = list(csv.DictReader(open(trace[0])))
     rows = [r for r in rows if any(t in r["Kernel_Name"] for t in OURS) or "Memset" in r["Kernel_Name"] or "fill" in r["Kernel_Name"].lower()]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))

@@ -1,5 +1,6 @@
-"""The hash-sorted delta stream (YH_STREAM=delta at handle creation) must give the same counts as the
-default layout and the oracle.  The layout is chosen per process, so the cases run in a child."""
+"""Both streaming layouts -- the hash-sorted delta stream (default) and the partition-major packed
+24-bit keys (YH_STREAM=keys at handle creation) -- must give the oracle's counts on the same edge cases.
+The layout is chosen per process, so the cases run in a child."""
 import os
 import subprocess
 import sys
@@ -20,8 +21,11 @@ from yacht_amd import synth
 from yacht_amd.engine import RefDB
 from tests.test_gpu_keys import _colliding_case
 
+WANT_LAYOUT = int(sys.argv[1])
+
 def check(values, offsets, sample, **kw):
     with RefDB(values, offsets, **kw) as db:
+        assert db.info()["stream_layout"] == WANT_LAYOUT, db.info()
         ov, e, m = db.run_counts(sample)
         ov_only = db.overlap(sample)
     w_ov = oracle.overlap(values, offsets, sample)
@@ -46,11 +50,23 @@ refs = [np.array([0, 1, 2**40, 2**63, 2**64 - 1], dtype=np.uint64), np.zeros(0, 
 offs = np.concatenate([[0], np.cumsum([len(r) for r in refs])]).astype(np.uint64)
 check(np.concatenate(refs), offs, np.array([0, 5, 2**40, 2**64 - 1], dtype=np.uint64))
 check(np.array([77], dtype=np.uint64), np.array([0, 1], dtype=np.uint64), np.array([3, 77, 99], dtype=np.uint64))
-print("delta stream ok")
+print("stream layout ok")
 """
 
 
-def test_delta_stream_layout_matches_oracle(hip_lib):
-    env = dict(os.environ, YH_STREAM="delta")
-    r = subprocess.run([sys.executable, "-c", CHILD % ROOT], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0 and "delta stream ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+@pytest.mark.parametrize("name,layout", [("delta", 1), ("keys", 2)])
+def test_stream_layout_matches_oracle(hip_lib, name, layout):
+    env = dict(os.environ, YH_STREAM=name)
+    env.pop("YH_WIDE_KEYS", None)
+    r = subprocess.run([sys.executable, "-c", CHILD % ROOT, str(layout)], env=env, cwd=ROOT, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0 and "stream layout ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_default_layout_is_the_delta_stream(hip_lib):
+    code = ("import sys; sys.path.insert(0, %r); import numpy as np; from yacht_amd.engine import RefDB; "
+            "db = RefDB(np.arange(1, 9, dtype=np.uint64), np.array([0, 8], dtype=np.uint64)); "
+            "print('layout', db.info()['stream_layout'])") % ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("YH_STREAM", "YH_WIDE_KEYS")}
+    r = subprocess.run([sys.executable, "-c", code], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "layout 1" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

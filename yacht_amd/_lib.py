@@ -57,6 +57,9 @@ class DbInfo(C.Structure):
         ("device_bytes", C.c_uint64),
         ("device_id", C.c_int32),
         ("flags", C.c_uint32),
+        ("stream_layout", C.c_uint32),
+        ("stream_shift", C.c_uint32),
+        ("stream_bytes", C.c_uint64),
     ]
 
 
@@ -157,7 +160,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError here = the .so does not match the header
         fn.restype = res
         fn.argtypes = args
-    if lib.yh_abi_version() != 1:
+    if lib.yh_abi_version() != 2:
         raise YachtHipError(YH_ERR_INVALID_ARG, f"ABI version mismatch in {path}")
     _lib = lib
     return lib

@@ -364,6 +364,17 @@ int yh_db_get_info(yh_db* db, yh_db_info* info) {
     info->device_bytes = db->device_bytes;
     info->device_id = db->device;
     info->flags = db->flags;
+    if (db->d_sdelta) {
+        info->stream_layout = YH_STREAM_DELTA;
+        info->stream_shift = db->sshift;
+        info->stream_bytes = db->slen + (db->slen / STREAM_BLOCK + 1) * sizeof(u64);
+    } else if (db->d_pkeys) {
+        info->stream_layout = YH_STREAM_KEYS24;
+        info->stream_bytes = db->pvals_len * 3;
+    } else if (db->d_pvals) {
+        info->stream_layout = YH_STREAM_WIDE;
+        info->stream_bytes = db->pvals_len * sizeof(u64);
+    }
     return YH_OK;
 }
 

@@ -559,9 +559,11 @@ int yh_build_partitions(yh_db* db, const u64* d_values, const u64* d_offsets, u3
 
 bool yh_use_delta_stream() {
     static const bool on = [] {
-        const char* s = getenv("YH_STREAM");  // "delta": the hash-sorted delta stream instead of the packed 24-bit keys
+        // default: the hash-sorted delta stream.  YH_STREAM=keys: partition-major packed 24-bit keys;
+        // YH_WIDE_KEYS=1: partition-major 64-bit hashes (both kept for A/B and as cross-checks)
+        const char* s = getenv("YH_STREAM");
         const char* w = getenv("YH_WIDE_KEYS");
-        return s && strcmp(s, "delta") == 0 && !(w && w[0] == '1');
+        return !(s && strcmp(s, "keys") == 0) && !(w && w[0] == '1');
     }();
     return on;
 }

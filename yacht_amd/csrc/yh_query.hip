@@ -844,10 +844,33 @@ struct StreamHit {
         u32 r;
         if (confirm(pos, sidx, r)) atomicAdd(&reps[(u64)(wg & rep_mask) * n_refs + r], 1u);
     }
+    // the same with the four reads issued together (one memory latency instead of three)
+    __device__ __forceinline__ void count_parallel(u32 wg, u64 pos, u32 sidx) const {
+        const u64 hv = svals[pos], sv = sample[sidx];
+        const u32 ref = sref[pos];
+        const u32 g = hitflag ? sgidx[pos] : STREAM_NONE;
+        if (hv != sv || ref == STREAM_NONE) return;
+        if (g != STREAM_NONE) hitflag[g] = 1;
+        atomicAdd(&reps[(u64)(wg & rep_mask) * n_refs + ref], 1u);
+    }
 };
-__device__ __forceinline__ void push_hit(const StreamHit& hit, const HitCtx32& c, u64 pos, u32 sidx) {
-    const u32 slot = atomicAdd(c.q_fill, 1u);
-    if (slot < (u32)TILE_QCAP) {
+// Candidates are queued PER WAVE (STREAM_WQ entries of LDS each): a wave that finds its queue half full
+// copies it to the workgroup's HBM segment by itself (wave_flush) -- no workgroup barrier anywhere in
+// the streaming loop, so the waves of a workgroup drift apart and one wave's probing overlaps the
+// others' loads (with a barrier every other round the kernel took loads + probing, not their maximum).
+#ifndef YH_STREAM_INPLACE
+#define YH_STREAM_INPLACE 1   // 1: the streaming kernel confirms and counts its candidates itself; 0: HBM queue + k_resolve_stream
+#endif
+constexpr u32 STREAM_WQ = (u32)TILE_QCAP / (TILE_THREADS / 64);
+struct WaveQ {
+    u32* fill;     // LDS: entries claimed in this wave's queue
+    u64x2* q;      // LDS: this wave's STREAM_WQ entries
+    u32* g_fill;   // LDS: entries claimed in the workgroup's HBM segment
+    u32 wg;
+};
+__device__ __forceinline__ void push_hit(const StreamHit& hit, const WaveQ& c, u64 pos, u32 sidx) {
+    const u32 slot = atomicAdd(c.fill, 1u);
+    if (slot < STREAM_WQ) {
         u64x2 e;
         e.x = pos;
         e.y = sidx;
@@ -855,6 +878,44 @@ __device__ __forceinline__ void push_hit(const StreamHit& hit, const HitCtx32& c
     } else {
         hit.count(c.wg, pos, sidx);
     }
+}
+// Candidates are confirmed and counted by the wave that found them, a queue-full at a time: four
+// independent reads per candidate (64-bit hash and reference of the stream position, the sample
+// hash, the shared-hash index), then one atomic.  A stream in hash order spreads a workgroup's ~250
+// hits over as many references, so there is nothing to pre-aggregate; the separate confirmation
+// kernel (k_resolve_stream over an HBM queue) was 19 us of pure latency per query.  (Requesting the
+// reads in one flush and counting in the next, every super-block, measured slower: 0.114 vs 0.104 ms.)
+#ifndef YH_STREAM_FLUSH_AT
+#define YH_STREAM_FLUSH_AT (STREAM_WQ / 2)
+#endif
+// wave-uniform call: take the wave's queue when it holds at least min_fill entries
+__device__ __forceinline__ void wave_flush(const StreamHit& hit, const WaveQ& c, u32 min_fill) {
+    const u32 lane = threadIdx.x & 63u;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    u32 f = (u32)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(c.fill, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT));
+    if (f < min_fill) return;
+    f = min(f, STREAM_WQ);
+#if YH_STREAM_INPLACE
+    for (u32 e = lane; e < f; e += 64) {
+        const u64x2 x = c.q[e];
+        hit.count_parallel(c.wg, x.x, (u32)x.y);
+    }
+#else
+    u32 g0 = 0;
+    if (lane == 0) g0 = atomicAdd(c.g_fill, f);
+    g0 = (u32)__builtin_amdgcn_readfirstlane((int)g0);
+    for (u32 e = lane; e < f; e += 64) {
+        const u64x2 x = c.q[e];
+        if (g0 + e < hit.qcap) hit.queue[(u64)c.wg * hit.qcap + g0 + e] = x;
+        else hit.count(c.wg, x.x, (u32)x.y);
+    }
+#endif
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) __hip_atomic_store(c.fill, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 }
 
 // one workgroup per queue segment: confirm, sum per reference in LDS, one global atomic per (workgroup, reference)
@@ -942,48 +1003,47 @@ __global__ void __launch_bounds__(256) k_prep_stream(const u64* __restrict__ sam
 constexpr int STREAM_PF = YH_STREAM_PF;
 static_assert(STREAM_PF >= 1 && STREAM_PF <= 15, "headers of a super-block live in lanes 0..PF");
 
+__device__ __forceinline__ u64 uniform_u64(u64 v) {  // a value every lane holds, moved to scalar registers
+    return ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(v >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)(u32)v);
+}
 __device__ __forceinline__ u64 readlane_u64(u64 v, int l) {
     return ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(v >> 32), l) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)v, l);
 }
 
-template <class Flush>
+#ifndef YH_STREAM_LATE
+#define YH_STREAM_LATE 0   // 1: request the next super-block after this one has been probed (no second register set)
+#endif
+#ifndef YH_STREAM_PULL
+#define YH_STREAM_PULL 1   // 1: a probe pulls its 16 delta bytes out of the wave's registers; 0: re-reads them (L2)
+#endif
+// loads of super-block sb of the block range [bl0, bl1) (blocks bl0 + sb*PF + i, clamped into the
+// range: harmless re-reads at the end); lanes 0..PF of h hold the PF + 1 block headers
+__device__ __forceinline__ void load_super(const u32x4* __restrict__ deltas, const u64* __restrict__ hdr, u64 bl0, u64 bl1,
+                                           u64 sb, u32x4 (&d)[STREAM_PF], u64& h) {
+    const u32 lane = threadIdx.x & 63u;
+    const u64 b0 = bl0 + sb * STREAM_PF;
+#pragma unroll
+    for (int i = 0; i < STREAM_PF; ++i) d[i] = deltas[min(b0 + i, bl1 - 1) * 64 + lane];
+    h = hdr[min(b0 + min((u64)lane, (u64)STREAM_PF), bl1)];
+}
+
+// cur / hcur: the wave's first super-block, already requested by the caller when `preloaded`
 __device__ __forceinline__ void stream_blocks(const u32x4* __restrict__ deltas, const u64* __restrict__ hdr, u64 bl0,
                                               u64 bl1, u32 sub, u32 n, u64 Klo, u64 Khi, u32 dsh, const u64* S,
                                               const u16* E, u32* INCw, u32* HBw, const StreamHit& hit,
-                                              const HitCtx32& ctx, const Flush& flush) {
+                                              const WaveQ& ctx, bool preloaded, u32x4 (&cur)[STREAM_PF], u64& hcur) {
     constexpr u32 WAVES = TILE_THREADS / 64;
-#ifndef YH_STREAM_FLUSH
-#define YH_STREAM_FLUSH 2
-#endif
-    constexpr u32 FLUSH_ROUNDS = YH_STREAM_FLUSH;  // super-steps between two looks at the candidate queue
     constexpr int PF = STREAM_PF;
     const u32 lane = threadIdx.x & 63u;
-    const u64 last_blk = bl1 - 1;
-
-    // loads of super-block sb (blocks sb*PF + i, clamped into the range: harmless re-reads at the end)
-    auto load_super = [&](u64 sb, u32x4 (&d)[PF], u64& h) {
-        const u64 b0 = bl0 + sb * PF;
-#pragma unroll
-        for (int i = 0; i < PF; ++i) d[i] = deltas[min(b0 + i, last_blk) * 64 + lane];
-        h = hdr[min(b0 + min((u64)lane, (u64)PF), bl1)];  // lanes 0..PF hold the PF + 1 headers
-    };
     const u64 n_super = (bl1 - bl0 + PF - 1) / PF;
-    u64 sb = threadIdx.x >> 6;
-    u32 round = 0;
-    u32x4 cur[PF];
-    u64 hcur = 0;
-    if (sb < n_super) load_super(sb, cur, hcur);
-    for (u64 it = 0; it < n_super; it += WAVES, sb += WAVES) {  // the same trip count in every wave
-        if ((++round % FLUSH_ROUNDS) == 0) {
-            __syncthreads();
-            const u32 fill = *ctx.q_fill;
-            __syncthreads();  // nobody queues before everybody has read: the decision is uniform
-            if (fill >= (u32)TILE_QCAP / 2) flush();
-        }
-        if (sb >= n_super) continue;
+    u64 sb = (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform, and the compiler knows it
+    if (sb < n_super && !preloaded) load_super(deltas, hdr, bl0, bl1, sb, cur, hcur);
+    for (; sb < n_super; sb += WAVES) {
+#if !YH_STREAM_LATE
         u32x4 nxt[PF];
         u64 hnxt;
-        load_super(min(sb + WAVES, n_super - 1), nxt, hnxt);
+        load_super(deltas, hdr, bl0, bl1, min(sb + WAVES, n_super - 1), nxt, hnxt);
+#endif
         const u64 b0 = bl0 + sb * PF;
         const int nvalid = (int)min((u64)PF, bl1 - b0);
         const u64 base0 = readlane_u64(hcur, 0);
@@ -1001,32 +1061,37 @@ __device__ __forceinline__ void stream_blocks(const u32x4* __restrict__ deltas, 
             if (lane <= (u32)PF) HBw[lane] = ((int)lane < nvalid) ? (u32)(hcur - base0) : 0xffffffffu;
             u32 hl[PF];  // last key of block i relative to base0 (scalar); invalid blocks: ~0
             u32 last_rel = 0;
+            // Lane sums of all PF blocks (v_sad_u8), then the PF inclusive wave scans step by step side
+            // by side (DPP only -- gfx9: row_shr 1/2/4/8 inside the rows of 16, then row_bcast:15 into
+            // rows 1 and 3, row_bcast:31 into rows 2 and 3): a DPP add needs two wait states after the
+            // write of its source, which the other blocks' adds fill.
+            int v[PF];
 #pragma unroll
             for (int i = 0; i < PF; ++i) {
                 const u32x4 d = cur[i];
                 const u32 w0 = lane ? d.x : (d.x & 0xffffff00u);  // (a block's first delta byte is not used)
-                const u32 tot = __builtin_amdgcn_sad_u8(w0, 0u, 0u) + __builtin_amdgcn_sad_u8(d.y, 0u, 0u) +
-                                __builtin_amdgcn_sad_u8(d.z, 0u, 0u) + __builtin_amdgcn_sad_u8(d.w, 0u, 0u);
-                // inclusive wave scan, DPP only (gfx9: row_shr 1/2/4/8 inside the rows of 16, then
-                // row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3)
-                int v = (int)tot;
-                v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
-                v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
-                v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
-                v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
-                v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
-                v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
-                INCw[i * 64 + lane] = (u32)v;
-                const u32 hb = (u32)(readlane_u64(hcur, i) - base0);
-                hl[i] = (i < nvalid) ? hb + (u32)__builtin_amdgcn_readlane(v, 63) : 0xffffffffu;
-                if (i < nvalid) last_rel = hl[i];
+                v[i] = (int)(__builtin_amdgcn_sad_u8(w0, 0u, 0u) + __builtin_amdgcn_sad_u8(d.y, 0u, 0u) +
+                             __builtin_amdgcn_sad_u8(d.z, 0u, 0u) + __builtin_amdgcn_sad_u8(d.w, 0u, 0u));
+            }
+#define YH_SCAN_STEP(ctrl, rmask)                                                                      \
+    _Pragma("unroll") for (int i = 0; i < PF; ++i) v[i] += __builtin_amdgcn_update_dpp(0, v[i], ctrl, rmask, 0xf, false);
+            YH_SCAN_STEP(0x111, 0xf)
+            YH_SCAN_STEP(0x112, 0xf)
+            YH_SCAN_STEP(0x114, 0xf)
+            YH_SCAN_STEP(0x118, 0xf)
+            YH_SCAN_STEP(0x142, 0xa)
+            YH_SCAN_STEP(0x143, 0xc)
+#undef YH_SCAN_STEP
+#pragma unroll
+            for (int i = 0; i < PF; ++i) {
+                INCw[i * 64 + lane] = (u32)v[i];
+                const u32 end_rel = (u32)(readlane_u64(hcur, i) - base0) + (u32)__builtin_amdgcn_readlane(v[i], 63);
+                hl[i] = (i < nvalid) ? end_rel : 0xffffffffu;
+                last_rel = (i < nvalid) ? end_rel : last_rel;
             }
             const u64 sb_last = base0 + last_rel;
             u32 k = (base0 <= Klo) ? 0u : (u32)E[(base0 - Klo) >> dsh];  // a slot at or before the first key >= base0
-#if defined(YH_STREAM_ABLATE) && YH_STREAM_ABLATE == 2  // timing-only: + lane spans
-            if (k == 0x12345678u && sb_last == 77 && INCw[lane] == 5) push_hit(hit, ctx, b0, sub);
-            if (true) {} else
-#endif
+            k = (u32)__builtin_amdgcn_readfirstlane((int)k);
             for (;;) {  // 64 sample slots at a time; the keys inside the super-block are a run of lanes
                 const u64 sk = S[k + lane];  // (ST_PAD sentinels ~0 behind the last key keep this in bounds)
                 const u64 ge = __ballot(sk >= base0);
@@ -1036,48 +1101,73 @@ __device__ __forceinline__ void stream_blocks(const u32x4* __restrict__ deltas, 
                 const u32 np = (u32)__popcll(__ballot(in));
 #if defined(YH_STREAM_ABLATE) && YH_STREAM_ABLATE == 3  // timing-only: + finding the probes
                 if (in && sk == 0x1234567812345678ull) push_hit(hit, ctx, b0, sub);
-                if (true) {} else
+                if (true) { if (c + np < 64) break; k += 64; continue; }
 #endif
-                if (in) {  // one probe per lane
-                    const u32 rel = (u32)(sk - base0);
-                    u32 f = 0;  // first block whose last key is >= the probe
+                // One probe per lane.  The probe's block f and lane t are found in LDS (HB, INC); lane t's
+                // 16 delta bytes are PULLED out of the registers of the wave with ds_bpermute -- a global
+                // re-read would have to wait (vmcnt is in order) for the whole next super-block in flight.
+                const u32 rel = (u32)(sk - base0);
+                u32 f = 0;  // first block whose last key is >= the probe
 #pragma unroll
-                    for (int i = 0; i < PF; ++i) f += (hl[i] < rel) ? 1u : 0u;
-                    while (f < (u32)PF) {  // (a run of equal keys may continue into the next block)
-                        const u32 hb = HBw[f];
-                        if (hb > rel) break;
-                        const u32 r = rel - hb;
-                        const u32* inc = INCw + f * 64;
-                        u32 t = 0;  // first lane whose last key is >= r  (inc[63] = the block's last key >= r)
+                for (int i = 0; i < PF; ++i) f += (hl[i] < rel) ? 1u : 0u;
+                bool act = in && f < (u32)PF;
+                u32 r = 0, t = 0;
+                auto locate = [&]() {  // r, t of the probe inside block f; a block that starts behind the probe ends it
+                    const u32 hb = HBw[f];
+                    if (hb > rel) { act = false; return; }
+                    r = rel - hb;
+                    const u32* inc = INCw + f * 64;
+                    t = 0;  // first lane whose last key is >= r  (inc[63] = the block's last key >= r)
 #pragma unroll
-                        for (int st = 32; st >= 1; st >>= 1) t += (inc[t + st - 1] < r) ? (u32)st : 0u;
-                        for (;;) {  // that lane's 16 elements, then the following lanes while the run of equal keys lasts
-                            const u32x4 w = deltas[(b0 + f) * 64 + t];
-                            const u32 W[4] = {t ? w.x : (w.x & 0xffffff00u), w.y, w.z, w.w};
-                            u32 cs = t ? inc[t - 1] : 0u, match = 0;
+                    for (int st = 32; st >= 1; st >>= 1) t += (inc[t + st - 1] < r) ? (u32)st : 0u;
+                };
+                if (act) locate();
+                while (__ballot(act)) {  // (more than one trip only for runs of equal keys that leave a lane)
+                    u32x4 w = {0u, 0u, 0u, 0u};
+#if YH_STREAM_PULL
+                    const int src = (int)(t << 2);
 #pragma unroll
-                            for (int j = 0; j < 16; ++j) {
-                                cs += (W[j >> 2] >> (8 * (j & 3))) & 0xffu;
-                                match |= (cs == r ? 1u : 0u) << j;
-                            }
-                            while (match) {
-                                const u32 j = (u32)__ffs((int)match) - 1u;
-                                match &= match - 1u;
-                                push_hit(hit, ctx, ((b0 + f) << 10) + 16u * t + j, sub + k + lane);
-                            }
-                            if (cs != r || t == 63) break;
-                            ++t;
+                    for (int i = 0; i < PF; ++i) {  // (unguarded: ~3 probes per block, a block without one is rare)
+                        const u32 x0 = (u32)__builtin_amdgcn_ds_bpermute(src, (int)cur[i].x);
+                        const u32 x1 = (u32)__builtin_amdgcn_ds_bpermute(src, (int)cur[i].y);
+                        const u32 x2 = (u32)__builtin_amdgcn_ds_bpermute(src, (int)cur[i].z);
+                        const u32 x3 = (u32)__builtin_amdgcn_ds_bpermute(src, (int)cur[i].w);
+                        if (f == (u32)i) { w.x = x0; w.y = x1; w.z = x2; w.w = x3; }
+                    }
+#else
+                    if (act) w = deltas[(b0 + f) * 64 + t];  // (hits L2: the wave has just read this block)
+#endif
+                    if (act) {
+                        const u32 W[4] = {t ? w.x : (w.x & 0xffffff00u), w.y, w.z, w.w};
+                        u32 cs = t ? INCw[f * 64 + t - 1] : 0u, match = 0;
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) {
+                            cs += (W[j >> 2] >> (8 * (j & 3))) & 0xffu;
+                            match |= (cs == r ? 1u : 0u) << j;
                         }
-                        ++f;
+                        while (match) {
+                            const u32 j = (u32)__ffs((int)match) - 1u;
+                            match &= match - 1u;
+                            push_hit(hit, ctx, ((b0 + f) << 10) + 16u * t + j, sub + k + lane);
+                        }
+                        if (cs != r) act = false;       // the lane's last key is above the probe: the run ended
+                        else if (t < 63) ++t;           // the run of equal keys may go on in the next lane
+                        else if (++f < (u32)PF) locate();  // ... or in the next block
+                        else act = false;
                     }
                 }
+                wave_flush(hit, ctx, YH_STREAM_FLUSH_AT);
                 if (c + np < 64) break;  // the run of inside keys ended within these 64 slots
                 k += 64;
             }
         }
+#if YH_STREAM_LATE
+        load_super(deltas, hdr, bl0, bl1, min(sb + WAVES, n_super - 1), cur, hcur);
+#else
 #pragma unroll
         for (int i = 0; i < PF; ++i) cur[i] = nxt[i];
         hcur = hnxt;
+#endif
     }
 }
 
@@ -1085,50 +1175,42 @@ __global__ void __launch_bounds__(TILE_THREADS, YH_TILE_WAVES_PER_SIMD)
 k_stream_lookup(const u32x4* __restrict__ deltas, const u64* __restrict__ hdr, u64 nblk,
                 const u64* __restrict__ sample, const u32* __restrict__ wg_sb, u32 sshift,
                 u32* __restrict__ qcount, StreamHit hit) {
+    constexpr u32 WAVES = TILE_THREADS / 64;
     __shared__ __attribute__((aligned(16))) u64 S[ST_SLOTS];
     __shared__ u16 E[TILE_NB];
-    __shared__ u64x2 Q[TILE_QCAP];
-    __shared__ u32 INC[TILE_THREADS / 64][STREAM_PF * 64];  // per wave: the lane-inclusive key sums of a super-block
-    __shared__ u32 HB[TILE_THREADS / 64][16];               // per wave: first key of each of its blocks, relative
-    __shared__ u32 q_fill;
+    __shared__ u64x2 Q[WAVES][STREAM_WQ];
+    __shared__ u32 INC[WAVES][STREAM_PF * 64];  // per wave: the lane-inclusive key sums of a super-block
+    __shared__ u32 HB[WAVES][16];               // per wave: first key of each of its blocks, relative
+    __shared__ u32 q_fill[WAVES];
     __shared__ u32 g_fill;
 
     const u32 tid = threadIdx.x;
+    const u32 wv = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const u32 lid = xcd_remap(blockIdx.x, gridDim.x);
     const u64 per = (nblk + gridDim.x - 1) / gridDim.x;
     const u64 B0 = min((u64)lid * per, nblk), B1 = min(nblk, B0 + per);
-    const HitCtx32 ctx{&q_fill, Q, lid};
-    if (tid == 0) { q_fill = 0; g_fill = 0; }
+    const WaveQ ctx{&q_fill[wv], Q[wv], &g_fill, lid};
     const u32 s0 = wg_sb[2 * lid], s1 = wg_sb[2 * lid + 1];
     if (B0 >= B1 || s0 >= s1) {  // no blocks, or no sample hash in this range of t: nothing to read
         if (tid == 0) qcount[lid] = 0;
         return;
     }
-    auto flush = [&]() {
-        __syncthreads();
-        const u32 f = min(q_fill, (u32)TILE_QCAP);
-        const u32 g0 = g_fill;
-        for (u32 e = tid; e < f; e += TILE_THREADS) {
-            const u64x2 x = Q[e];
-            if (g0 + e < hit.qcap) hit.queue[(u64)lid * hit.qcap + g0 + e] = x;
-            else hit.count(lid, x.x, (u32)x.y);
-        }
-        __syncthreads();
-        if (tid == 0) { q_fill = 0; g_fill = g0 + f; }
-        __syncthreads();
-    };
+    // one tile (the usual case): the wave's first super-block is requested before the tile is staged
+    const bool single = s1 - s0 <= (u32)ST_CAP;
+    u32x4 cur[STREAM_PF];
+    u64 hcur = 0;
+    if (single && (u64)wv * STREAM_PF < B1 - B0) load_super(deltas, hdr, B0, B1, wv, cur, hcur);
+    if (tid < WAVES) q_fill[tid] = 0;
+    if (tid == 0) g_fill = 0;
     bool first = true;
     for (u32 sub = s0; sub < s1; sub += ST_CAP) {
         const u32 n = min((u32)ST_CAP, s1 - sub);
-        if (!first) {
-            flush();
-            __syncthreads();
-        }
+        if (!first) __syncthreads();  // every wave is done with the previous tile
         first = false;
         for (u32 k = tid; k < n; k += TILE_THREADS) S[k] = sample[sub + k] >> sshift;
         for (u32 k = n + tid; k < n + ST_PAD; k += TILE_THREADS) S[k] = ~0ull;
         __syncthreads();
-        const u64 Klo = S[0], Khi = S[n - 1];
+        const u64 Klo = uniform_u64(S[0]), Khi = uniform_u64(S[n - 1]);
         const u64 span = Khi - Klo;
         const u32 dsh = (span >> TILE_LGNB) ? (u32)(64 - __builtin_clzll(span)) - TILE_LGNB : 0u;  // (span >> dsh) < TILE_NB
         for (u32 k = tid; k < n; k += TILE_THREADS) {
@@ -1140,7 +1222,7 @@ k_stream_lookup(const u32x4* __restrict__ deltas, const u64* __restrict__ hdr, u
         }
         __syncthreads();
         u64 bl0 = B0, bl1 = B1;
-        if (s1 - s0 > (u32)ST_CAP) {  // several tiles: each covers a contiguous sub-range of the blocks
+        if (!single) {  // several tiles: each covers a contiguous sub-range of the blocks
             u64 lo = B0, hi = B1;     // first block whose NEXT header is >= Klo
             while (lo < hi) { const u64 mid = (lo + hi) >> 1; if (hdr[mid + 1] < Klo) lo = mid + 1; else hi = mid; }
             bl0 = lo;
@@ -1148,10 +1230,14 @@ k_stream_lookup(const u32x4* __restrict__ deltas, const u64* __restrict__ hdr, u
             while (lo < hi) { const u64 mid = (lo + hi) >> 1; if (hdr[mid] <= Khi) lo = mid + 1; else hi = mid; }
             bl1 = lo;
         }
-        stream_blocks(deltas, hdr, bl0, bl1, sub, n, Klo, Khi, dsh, S, E, INC[tid >> 6], HB[tid >> 6], hit, ctx, flush);
+        if (bl0 < bl1)
+            stream_blocks(deltas, hdr, bl0, bl1, sub, n, Klo, Khi, dsh, S, E, INC[wv], HB[wv], hit, ctx, single, cur, hcur);
     }
-    flush();
+    wave_flush(hit, ctx, 1);
+#if !YH_STREAM_INPLACE
+    __syncthreads();
     if (tid == 0) qcount[lid] = min(g_fill, hit.qcap);
+#endif
 }
 
 // ---- cross-check kernel: one wave per reference over the plain CSR -------------------------------
@@ -1565,7 +1651,9 @@ static int yh_q_overlap_stream(yh_db* db, const u64* d_sample, u64 n_sample, u32
     k_stream_lookup<<<wgs, TILE_THREADS, 0, st>>>(reinterpret_cast<const u32x4*>(db->d_sdelta), db->d_shdr, nblk, d_sample,
                                                   db->d_wg_sb, db->sshift, db->d_hitq_cnt, sh);
     yh_ring_record_end(db, db->ev_overlap);
+#if !YH_STREAM_INPLACE
     k_resolve_stream<<<wgs, 256, 0, st>>>(db->d_hitq_cnt, sh);
+#endif
     k_reduce_replicas<<<(u32)((N + 255) / 256), 256, 0, st>>>(db->d_reps, R, N, d_overlap, make_mask ? db->d_mask : nullptr,
                                                              make_mask ? db->d_maskbits : nullptr);
     YH_HIP(hipGetLastError());
