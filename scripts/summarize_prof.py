@@ -51,12 +51,14 @@ if trace:
     rows = list(csv.DictReader(open(trace[0])))
     rows = [r for r in rows if any(t in r["Kernel_Name"] for t in OURS) or "Memset" in r["Kernel_Name"] or "fill" in r["Kernel_Name"].lower()]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    idx = [i for i, r in enumerate(rows) if "k_prep" in r["Kernel_Name"]]
-    if len(idx) >= 3:
+    for tag, title in (("k_prep_stream", "streaming step"), ("k_prep(", "indexed step (k_index_lookup)")):
+        idx = [i for i, r in enumerate(rows) if tag in r["Kernel_Name"].replace("(anonymous namespace)::", "") + "("]
+        if len(idx) < 3:
+            continue
         a, b = idx[-2], idx[-1]
         t0 = int(rows[a]["Start_Timestamp"])
         prev_end = t0
-        print("== timeline of one step (us) ==")
+        print(f"== timeline of one {title} (us) ==")
         for r in rows[a:b]:
             s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
             print(f"  +{(s - t0)/1e3:8.2f}  dur {(e - s)/1e3:8.2f}  gap {(s - prev_end)/1e3:7.2f}  {short(r['Kernel_Name'])}")

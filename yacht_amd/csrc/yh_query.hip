@@ -858,10 +858,20 @@ struct StreamHit {
 // copies it to the workgroup's HBM segment by itself (wave_flush) -- no workgroup barrier anywhere in
 // the streaming loop, so the waves of a workgroup drift apart and one wave's probing overlaps the
 // others' loads (with a barrier every other round the kernel took loads + probing, not their maximum).
+// Geometry of k_stream_lookup: 768 threads = 12 waves per workgroup, two workgroups per CU (67 KB of
+// LDS each) = 6 waves per SIMD, which needs <= 80 VGPRs: with the next super-block requested AFTER
+// this one is probed (YH_STREAM_LATE) there is one register set of deltas, 76 VGPRs, no scratch.
+#ifndef YH_STREAM_THREADS
+#define YH_STREAM_THREADS 768
+#endif
+#ifndef YH_STREAM_WAVES_PER_SIMD
+#define YH_STREAM_WAVES_PER_SIMD 6
+#endif
+constexpr int STREAM_THREADS = YH_STREAM_THREADS;
 #ifndef YH_STREAM_INPLACE
 #define YH_STREAM_INPLACE 1   // 1: the streaming kernel confirms and counts its candidates itself; 0: HBM queue + k_resolve_stream
 #endif
-constexpr u32 STREAM_WQ = (u32)TILE_QCAP / (TILE_THREADS / 64);
+constexpr u32 STREAM_WQ = (u32)TILE_QCAP / (STREAM_THREADS / 64);
 struct WaveQ {
     u32* fill;     // LDS: entries claimed in this wave's queue
     u64x2* q;      // LDS: this wave's STREAM_WQ entries
@@ -1011,10 +1021,10 @@ __device__ __forceinline__ u64 readlane_u64(u64 v, int l) {
 }
 
 #ifndef YH_STREAM_LATE
-#define YH_STREAM_LATE 0   // 1: request the next super-block after this one has been probed (no second register set)
+#define YH_STREAM_LATE 1   // 1: request the next super-block after this one has been probed (no second register set)
 #endif
 #ifndef YH_STREAM_PULL
-#define YH_STREAM_PULL 1   // 1: a probe pulls its 16 delta bytes out of the wave's registers; 0: re-reads them (L2)
+#define YH_STREAM_PULL 0   // 1: a probe pulls its 16 delta bytes out of the wave's registers; 0: re-reads them (L2)
 #endif
 // loads of super-block sb of the block range [bl0, bl1) (blocks bl0 + sb*PF + i, clamped into the
 // range: harmless re-reads at the end); lanes 0..PF of h hold the PF + 1 block headers
@@ -1032,7 +1042,7 @@ __device__ __forceinline__ void stream_blocks(const u32x4* __restrict__ deltas, 
                                               u64 bl1, u32 sub, u32 n, u64 Klo, u64 Khi, u32 dsh, const u64* S,
                                               const u16* E, u32* INCw, u32* HBw, const StreamHit& hit,
                                               const WaveQ& ctx, bool preloaded, u32x4 (&cur)[STREAM_PF], u64& hcur) {
-    constexpr u32 WAVES = TILE_THREADS / 64;
+    constexpr u32 WAVES = STREAM_THREADS / 64;
     constexpr int PF = STREAM_PF;
     const u32 lane = threadIdx.x & 63u;
     const u64 n_super = (bl1 - bl0 + PF - 1) / PF;
@@ -1171,11 +1181,11 @@ __device__ __forceinline__ void stream_blocks(const u32x4* __restrict__ deltas, 
     }
 }
 
-__global__ void __launch_bounds__(TILE_THREADS, YH_TILE_WAVES_PER_SIMD)
+__global__ void __launch_bounds__(STREAM_THREADS, YH_STREAM_WAVES_PER_SIMD)
 k_stream_lookup(const u32x4* __restrict__ deltas, const u64* __restrict__ hdr, u64 nblk,
                 const u64* __restrict__ sample, const u32* __restrict__ wg_sb, u32 sshift,
                 u32* __restrict__ qcount, StreamHit hit) {
-    constexpr u32 WAVES = TILE_THREADS / 64;
+    constexpr u32 WAVES = STREAM_THREADS / 64;
     __shared__ __attribute__((aligned(16))) u64 S[ST_SLOTS];
     __shared__ u16 E[TILE_NB];
     __shared__ u64x2 Q[WAVES][STREAM_WQ];
@@ -1207,13 +1217,13 @@ k_stream_lookup(const u32x4* __restrict__ deltas, const u64* __restrict__ hdr, u
         const u32 n = min((u32)ST_CAP, s1 - sub);
         if (!first) __syncthreads();  // every wave is done with the previous tile
         first = false;
-        for (u32 k = tid; k < n; k += TILE_THREADS) S[k] = sample[sub + k] >> sshift;
-        for (u32 k = n + tid; k < n + ST_PAD; k += TILE_THREADS) S[k] = ~0ull;
+        for (u32 k = tid; k < n; k += STREAM_THREADS) S[k] = sample[sub + k] >> sshift;
+        for (u32 k = n + tid; k < n + ST_PAD; k += STREAM_THREADS) S[k] = ~0ull;
         __syncthreads();
         const u64 Klo = uniform_u64(S[0]), Khi = uniform_u64(S[n - 1]);
         const u64 span = Khi - Klo;
         const u32 dsh = (span >> TILE_LGNB) ? (u32)(64 - __builtin_clzll(span)) - TILE_LGNB : 0u;  // (span >> dsh) < TILE_NB
-        for (u32 k = tid; k < n; k += TILE_THREADS) {
+        for (u32 k = tid; k < n; k += STREAM_THREADS) {
             const u32 bk = (u32)((S[k] - Klo) >> dsh);
             const int bp = (k == 0) ? -1 : (int)((S[k - 1] - Klo) >> dsh);
             for (int x = bp + 1; x <= (int)bk; ++x) E[x] = (u16)k;
@@ -1648,7 +1658,7 @@ static int yh_q_overlap_stream(yh_db* db, const u64* d_sample, u64 n_sample, u32
     StreamHit sh{(u32)N, db->d_reps, R - 1, reinterpret_cast<u64x2*>(db->d_hitq), db->hitq_cap, db->d_svals, db->d_sref,
                  db->d_sgidx, flags_too ? db->d_hit : nullptr, d_sample};
     yh_ring_record_begin(db, db->ev_overlap);
-    k_stream_lookup<<<wgs, TILE_THREADS, 0, st>>>(reinterpret_cast<const u32x4*>(db->d_sdelta), db->d_shdr, nblk, d_sample,
+    k_stream_lookup<<<wgs, STREAM_THREADS, 0, st>>>(reinterpret_cast<const u32x4*>(db->d_sdelta), db->d_shdr, nblk, d_sample,
                                                   db->d_wg_sb, db->sshift, db->d_hitq_cnt, sh);
     yh_ring_record_end(db, db->ev_overlap);
 #if !YH_STREAM_INPLACE
