@@ -186,7 +186,6 @@ struct yh_db {
     u64 slen = 0;              // multiple of STREAM_BLOCK
     u32 sshift = 0;
     u64* d_wg_key = nullptr;   // [wgs + 1] first t of each workgroup's block range (sample-independent)
-    u32* d_wg_sb = nullptr;    // [2 * wgs] per query: the sample range [lo, hi) of each workgroup
     u32 wg_key_n = 0;
     u32* d_pkeys = nullptr;    // packed KEY_BITS-bit keys of d_pvals, (hash >> kshift) & KEY_MASK: the stream K1 reads
     u32* d_pref = nullptr;     // [pvals_len] reference id of every stream position
@@ -203,6 +202,7 @@ struct yh_db {
     u8* d_mask = nullptr;      // [N]
     u32* d_maskbits = nullptr; // [ceil(N/64)*2] the same mask as bits
     u8* d_hit = nullptr;       // [G]
+    bool hit_clean = false;    // d_hit is all zero once everything queued on the stream has run
     u32* d_excl_e = nullptr;   // [N] shared hashes that are subset-exclusive   } one allocation of 3N words,
     u32* d_excl_m = nullptr;   // [N] ... and in the sample                      } zeroed together
     u32* d_ovsh = nullptr;     // [N] overlap restricted to shared hashes        }
@@ -214,7 +214,7 @@ struct yh_db {
     u32* d_hitq_cnt = nullptr; // [hitq_wgs]
     u32 hitq_wgs = 0, hitq_cap = 0;
     u32* d_wg_first = nullptr; // [hitq_wgs] first partition of each workgroup's slice of the key stream
-    u32* d_reps = nullptr;     // [R][N] replicated overlap counters
+    u32* d_reps = nullptr;     // [R][N] replicated overlap counters; ZERO AT REST: k_reduce_replicas clears what it sums
     u64 reps_cap = 0;
     void* d_batch = nullptr;   // scratch of the batched run: hit words, mask words, shared overlaps
     u64 batch_cap = 0;
@@ -307,7 +307,7 @@ int yh_q_exclusive_partial(yh_db* db, const u8* d_mask, const u64* d_sample, u64
                            u32* d_ovsh, bool own_bounds, bool hit_ready, const u32* d_maskbits);
 int yh_q_exclusive_final(yh_db* db, u64 n, const u8* d_mask, const u32* d_sizes, const u32* d_nshared,
                          const u32* d_overlap, const u32* d_ex_e, const u32* d_ex_m, const u32* d_ovsh, u32* d_excl,
-                         u32* d_match);
+                         u32* d_match, bool clean_hit = false);
 int yh_q_pairwise(yh_db* db, double c_thresh, u64 r0, u64 r1);
 int yh_q_check_sorted_host(const u64* v, u64 n);
 

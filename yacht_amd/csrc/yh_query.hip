@@ -121,17 +121,23 @@ __global__ void __launch_bounds__(256) k_resolve_hits(const u32* __restrict__ qc
     }
 }
 
-// overlap[j] = sum of the replicas; optionally also the subset mask "overlap > 0" as bytes and as
-// bits (one ballot per wave: references 64w .. 64w+63 -> two words)
-__global__ void __launch_bounds__(256) k_reduce_replicas(const u32* __restrict__ reps, u32 R, u64 n,
+// overlap[j] = sum of the replicas, which are CLEARED as they are read (d_reps is zero at rest: no
+// zeroing pass in front of the next query); optionally also the subset mask "overlap > 0" as bytes
+// and as bits (one ballot per wave: references 64w .. 64w+63 -> two words), and the zeroing of the
+// three exclusive accumulators [3][n] the kernels behind this one add into.
+__global__ void __launch_bounds__(256) k_reduce_replicas(u32* __restrict__ reps, u32 R, u64 n,
                                                          u32* __restrict__ out, u8* __restrict__ mask,
-                                                         u32* __restrict__ maskbits) {
+                                                         u32* __restrict__ maskbits, u32* __restrict__ excl3) {
     const u64 j = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     u32 acc = 0;
     if (j < n) {
-        for (u32 r = 0; r < R; ++r) acc += reps[(u64)r * n + j];
+        for (u32 r = 0; r < R; ++r) {
+            acc += reps[(u64)r * n + j];
+            reps[(u64)r * n + j] = 0;
+        }
         out[j] = acc;
         if (mask) mask[j] = acc ? 1 : 0;
+        if (excl3) { excl3[j] = 0; excl3[n + j] = 0; excl3[2 * n + j] = 0; }
     }
     if (maskbits) {
         const u64 bal = __ballot(acc != 0);
@@ -964,39 +970,27 @@ __global__ void k_wg_key(const u64* __restrict__ hdr, u64 nblk, u32 wgs, u64* __
     wg_key[w] = hdr[min((u64)w * per, nblk)];
 }
 
-// per query: each workgroup's sample range [lo, hi) = sample hashes with wg_key[w] <= t <= wg_key[w + 1]
-// (inclusive on both sides: equal keys may sit on either side of a range boundary), + the zeroing.
-// One WAVE per bound, 64-ary search: 3 dependent rounds of 64 parallel probes + a final one instead
-// of 20 dependent reads (11 -> 5 us at 2 x 512 bounds over a 10^6-hash sample).
-__global__ void __launch_bounds__(256) k_prep_stream(const u64* __restrict__ sample, u32 n, const u64* __restrict__ wg_key,
-                                                     u32 wgs, u32 sshift, u32* __restrict__ wg_sb, ZeroList z) {
-    const u64 t = blockIdx.x * (u64)blockDim.x + threadIdx.x;
-    const u64 nt = (u64)gridDim.x * blockDim.x;
-    const u64 gw = t >> 6;
+// A workgroup's sample range [lo, hi) = the sample hashes with wg_key[w] <= t <= wg_key[w + 1]
+// (inclusive on both sides: equal keys may sit on either side of a range boundary).  One WAVE per
+// bound, 64-ary search: 3 dependent rounds of 64 parallel probes + a final one instead of 20
+// dependent reads.  Lower bound: first t >= key; upper bound: first t > key.  Wave-uniform result.
+__device__ __forceinline__ u32 wave_bound(const u64* __restrict__ sample, u32 n, u32 sshift, u64 key, bool upper) {
     const u32 lane = threadIdx.x & 63u;
-    if (gw < 2ull * wgs) {
-        const bool upper = (gw & 1) != 0;  // lower bound: first trunc >= key; upper bound: first trunc > key
-        const u64 key = wg_key[(gw >> 1) + (upper ? 1 : 0)];
-        auto pred = [&](u32 i) { const u64 v = sample[i] >> sshift; return upper ? (v <= key) : (v < key); };
-        u32 lo = 0, hi = n;  // the answer (first index whose pred is false) lies in [lo, hi]
-        while (hi - lo > 64) {
-            const u32 step = (hi - lo + 63) / 64;
-            const u64 q = (u64)lo + (u64)(lane + 1) * step - 1;  // probe positions, ascending
-            const bool p = q < hi && pred((u32)q);
-            const u32 cnt = (u32)__popcll(__ballot(p));  // pred is monotone: the true lanes are 0..cnt-1
-            const u64 nlo = (u64)lo + (u64)cnt * step;
-            const u64 nhi = (u64)lo + (u64)(cnt + 1) * step - 1;  // pred is false there (or it is past hi)
-            hi = (u32)min((u64)hi, nhi);
-            lo = (u32)min(nlo, (u64)hi);
-        }
-        const u32 i = lo + lane;
-        const bool p = i < hi && pred(i);
-        const u32 ans = lo + (u32)__popcll(__ballot(p));
-        if (lane == 0) wg_sb[gw] = ans;
+    auto pred = [&](u32 i) { const u64 v = sample[i] >> sshift; return upper ? (v <= key) : (v < key); };
+    u32 lo = 0, hi = n;  // the answer (first index whose pred is false) lies in [lo, hi]
+    while (hi - lo > 64) {
+        const u32 step = (hi - lo + 63) / 64;
+        const u64 q = (u64)lo + (u64)(lane + 1) * step - 1;  // probe positions, ascending
+        const bool p = q < hi && pred((u32)q);
+        const u32 cnt = (u32)__popcll(__ballot(p));  // pred is monotone: the true lanes are 0..cnt-1
+        const u64 nlo = (u64)lo + (u64)cnt * step;
+        const u64 nhi = (u64)lo + (u64)(cnt + 1) * step - 1;  // pred is false there (or it is past hi)
+        hi = (u32)min((u64)hi, nhi);
+        lo = (u32)min(nlo, (u64)hi);
     }
-#pragma unroll
-    for (int b = 0; b < 4; ++b)
-        for (u64 i = t; i < z.n16[b]; i += nt) z.p[b][i] = make_uint4(0, 0, 0, 0);
+    const u32 i = lo + lane;
+    const bool p = i < hi && pred(i);
+    return lo + (u32)__popcll(__ballot(p));
 }
 
 // A wave reads the stream in super-blocks of STREAM_PF consecutive blocks (8 KB of delta bytes per
@@ -1183,7 +1177,7 @@ __device__ __forceinline__ void stream_blocks(const u32x4* __restrict__ deltas, 
 
 __global__ void __launch_bounds__(STREAM_THREADS, YH_STREAM_WAVES_PER_SIMD)
 k_stream_lookup(const u32x4* __restrict__ deltas, const u64* __restrict__ hdr, u64 nblk,
-                const u64* __restrict__ sample, const u32* __restrict__ wg_sb, u32 sshift,
+                const u64* __restrict__ sample, u32 n_sample, const u64* __restrict__ wg_key, u32 sshift,
                 u32* __restrict__ qcount, StreamHit hit) {
     constexpr u32 WAVES = STREAM_THREADS / 64;
     __shared__ __attribute__((aligned(16))) u64 S[ST_SLOTS];
@@ -1200,18 +1194,30 @@ k_stream_lookup(const u32x4* __restrict__ deltas, const u64* __restrict__ hdr, u
     const u64 per = (nblk + gridDim.x - 1) / gridDim.x;
     const u64 B0 = min((u64)lid * per, nblk), B1 = min(nblk, B0 + per);
     const WaveQ ctx{&q_fill[wv], Q[wv], &g_fill, lid};
-    const u32 s0 = wg_sb[2 * lid], s1 = wg_sb[2 * lid + 1];
-    if (B0 >= B1 || s0 >= s1) {  // no blocks, or no sample hash in this range of t: nothing to read
-        if (tid == 0) qcount[lid] = 0;
+    __shared__ u32 sbound[2];
+    if (B0 >= B1) {  // no blocks
+        if (tid == 0 && qcount) qcount[lid] = 0;
         return;
     }
-    // one tile (the usual case): the wave's first super-block is requested before the tile is staged
-    const bool single = s1 - s0 <= (u32)ST_CAP;
+    // The wave's first super-block is requested before anything else; while it is in flight, waves 0
+    // and 1 find the workgroup's range of the sample and the tile is staged.  (With several tiles --
+    // a sample slice above ST_CAP hashes -- the request is wasted and made again per tile.)
     u32x4 cur[STREAM_PF];
     u64 hcur = 0;
-    if (single && (u64)wv * STREAM_PF < B1 - B0) load_super(deltas, hdr, B0, B1, wv, cur, hcur);
+    if ((u64)wv * STREAM_PF < B1 - B0) load_super(deltas, hdr, B0, B1, wv, cur, hcur);
+    if (wv < 2) {
+        const u32 bnd = wave_bound(sample, n_sample, sshift, wg_key[lid + wv], wv == 1);
+        if ((tid & 63u) == 0) sbound[wv] = bnd;
+    }
     if (tid < WAVES) q_fill[tid] = 0;
     if (tid == 0) g_fill = 0;
+    __syncthreads();
+    const u32 s0 = (u32)__builtin_amdgcn_readfirstlane((int)sbound[0]), s1 = (u32)__builtin_amdgcn_readfirstlane((int)sbound[1]);
+    if (s0 >= s1) {  // no sample hash in this range of t: nothing to look up
+        if (tid == 0 && qcount) qcount[lid] = 0;
+        return;
+    }
+    const bool single = s1 - s0 <= (u32)ST_CAP;
     bool first = true;
     for (u32 sub = s0; sub < s1; sub += ST_CAP) {
         const u32 n = min((u32)ST_CAP, s1 - sub);
@@ -1450,8 +1456,11 @@ __global__ void __launch_bounds__(256) k_excl_chunks(u32 n_chunks, const uint2* 
 __global__ void k_excl_final(u64 n, const u8* __restrict__ mask, const u32* __restrict__ sizes,
                              const u32* __restrict__ nshared, const u32* __restrict__ overlap,
                              const u32* __restrict__ ex_e, const u32* __restrict__ ex_m,
-                             const u32* __restrict__ ovsh, u32* __restrict__ out_e, u32* __restrict__ out_m) {
+                             const u32* __restrict__ ovsh, u32* __restrict__ out_e, u32* __restrict__ out_m,
+                             uint4* __restrict__ hit16, u64 n_hit16) {
     const u64 j = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    // the shared-hash flags have been consumed by the kernels in front of this one: zero at rest
+    for (u64 i = j; i < n_hit16; i += (u64)gridDim.x * blockDim.x) hit16[i] = make_uint4(0, 0, 0, 0);
     if (j >= n) return;
     u32 e = 0, m = 0;
     if (mask[j]) {
@@ -1609,6 +1618,29 @@ int yh_q_check_sorted_host(const u64* v, u64 n) {
     return YH_OK;
 }
 
+// replicated counters: R * N * 4 bytes, at most ~8 MiB; zero at rest (k_reduce_replicas clears them)
+static int ensure_reps(yh_db* db, u32& R) {
+    const u64 N = db->n_refs;
+    R = 32;
+    while (R > 1 && (u64)R * N > (2u << 20)) R >>= 1;
+    if (db->reps_cap < (u64)R * N) {
+        YH_HIP(hipStreamSynchronize(db->stream));
+        if (db->d_reps) { (void)hipFree(db->d_reps); db->d_reps = nullptr; db->reps_cap = 0; }
+        YH_HIP(hipMalloc((void**)&db->d_reps, (u64)R * N * sizeof(u32) + 16));
+        YH_HIP(hipMemsetAsync(db->d_reps, 0, (u64)R * N * sizeof(u32) + 16, db->stream));
+        db->reps_cap = (u64)R * N;
+    }
+    return YH_OK;
+}
+// the shared-hash flags are zero at rest too (k_excl_final clears them behind their last reader);
+// a query that was not followed by its exclusive pass leaves them set, and the next one clears them
+static int claim_hit_flags(yh_db* db) {
+    if (!db->hit_clean && db->d_hit && db->n_shared)
+        YH_HIP(hipMemsetAsync(db->d_hit, 0, db->n_shared + 15, db->stream));
+    db->hit_clean = false;  // the kernels queued next set flags
+    return YH_OK;
+}
+
 // flag_shared: also flag which database-shared hashes are in the sample (db->d_hit), fused into the
 // same launch; yh_q_exclusive_partial(..., hit_ready = true) then skips its own membership pass.
 // overlap through the hash-sorted delta stream (the default layout)
@@ -1619,6 +1651,7 @@ static int yh_q_overlap_stream(yh_db* db, const u64* d_sample, u64 n_sample, u32
     const u64 nblk = db->slen / STREAM_BLOCK;
     u32 wgs = tile_grid(db->slen);
     if ((u64)wgs > nblk) wgs = (u32)std::max<u64>(nblk, 1);
+#if !YH_STREAM_INPLACE  // (A/B build: candidates through an HBM queue and k_resolve_stream)
     const u64 per_wg = (db->slen + wgs - 1) / wgs;
     const u32 qcap = (u32)std::min<u64>(std::max<u64>(4096, per_wg / 16), 1u << 24);
     if (db->hitq_wgs < wgs || db->hitq_cap < qcap) {
@@ -1631,41 +1664,33 @@ static int yh_q_overlap_stream(yh_db* db, const u64* d_sample, u64 n_sample, u32
         db->hitq_wgs = wgs;
         db->hitq_cap = qcap;
     }
+#endif
     if (db->wg_key_n != wgs) {  // the first t of every workgroup's block range: once per handle
         YH_HIP(hipStreamSynchronize(st));
         if (db->d_wg_key) { (void)hipFree(db->d_wg_key); db->d_wg_key = nullptr; }
-        if (db->d_wg_sb) { (void)hipFree(db->d_wg_sb); db->d_wg_sb = nullptr; }
         YH_HIP(hipMalloc((void**)&db->d_wg_key, ((u64)wgs + 2) * sizeof(u64)));
-        YH_HIP(hipMalloc((void**)&db->d_wg_sb, 2ull * wgs * sizeof(u32) + 16));
         k_wg_key<<<(wgs + 256) / 256, 256, 0, st>>>(db->d_shdr, nblk, wgs, db->d_wg_key);
         db->wg_key_n = wgs;
     }
-    u32 R = 32;
-    while (R > 1 && (u64)R * N > (2u << 20)) R >>= 1;
-    if (db->reps_cap < (u64)R * N) {
-        YH_HIP(hipStreamSynchronize(st));
-        if (db->d_reps) { (void)hipFree(db->d_reps); db->d_reps = nullptr; db->reps_cap = 0; }
-        YH_HIP(hipMalloc((void**)&db->d_reps, (u64)R * N * sizeof(u32) + 16));
-        db->reps_cap = (u64)R * N;
-    }
-    ZeroList z{};
-    z.p[0] = reinterpret_cast<uint4*>(db->d_reps);
-    z.n16[0] = ((u64)R * N * sizeof(u32) + 15) / 16;
-    if (flag_shared) { z.p[1] = reinterpret_cast<uint4*>(db->d_hit); z.n16[1] = (db->n_shared + 15) / 16; }
-    if (with_index) { z.p[2] = reinterpret_cast<uint4*>(db->d_excl_e); z.n16[2] = (3 * N * sizeof(u32) + 15) / 16; }
-    k_prep_stream<<<1024, 256, 0, st>>>(d_sample, (u32)n_sample, db->d_wg_key, wgs, db->sshift, db->d_wg_sb, z);
+    u32 R;
+    YH_TRY(ensure_reps(db, R));
     const bool flags_too = flag_shared && db->d_sgidx;
+    if (flags_too) YH_TRY(claim_hit_flags(db));
+    // No kernel in front of the streaming one: the counters it adds into are zero at rest, and every
+    // workgroup finds its own range of the sample (two 64-ary wave searches while its first
+    // super-block is in flight).
     StreamHit sh{(u32)N, db->d_reps, R - 1, reinterpret_cast<u64x2*>(db->d_hitq), db->hitq_cap, db->d_svals, db->d_sref,
                  db->d_sgidx, flags_too ? db->d_hit : nullptr, d_sample};
     yh_ring_record_begin(db, db->ev_overlap);
     k_stream_lookup<<<wgs, STREAM_THREADS, 0, st>>>(reinterpret_cast<const u32x4*>(db->d_sdelta), db->d_shdr, nblk, d_sample,
-                                                  db->d_wg_sb, db->sshift, db->d_hitq_cnt, sh);
+                                                    (u32)n_sample, db->d_wg_key, db->sshift, db->d_hitq_cnt, sh);
     yh_ring_record_end(db, db->ev_overlap);
 #if !YH_STREAM_INPLACE
     k_resolve_stream<<<wgs, 256, 0, st>>>(db->d_hitq_cnt, sh);
 #endif
     k_reduce_replicas<<<(u32)((N + 255) / 256), 256, 0, st>>>(db->d_reps, R, N, d_overlap, make_mask ? db->d_mask : nullptr,
-                                                             make_mask ? db->d_maskbits : nullptr);
+                                                             make_mask ? db->d_maskbits : nullptr,
+                                                             with_index ? db->d_excl_e : nullptr);
     YH_HIP(hipGetLastError());
     return YH_OK;
 }
@@ -1679,7 +1704,7 @@ int yh_q_overlap(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap, b
     flag_shared = with_index && db->n_shared > 0;
     if (N == 0 || db->n_hashes == 0 || n_sample == 0) {  // nothing can match: all-zero results
         YH_HIP(hipMemsetAsync(d_overlap, 0, std::max<u64>(N, 1) * sizeof(u32), st));
-        if (flag_shared) YH_HIP(hipMemsetAsync(db->d_hit, 0, db->n_shared, st));
+        if (flag_shared) { YH_HIP(hipMemsetAsync(db->d_hit, 0, db->n_shared + 15, st)); db->hit_clean = true; }
         if (with_index && N) YH_HIP(hipMemsetAsync(db->d_excl_e, 0, 3 * N * sizeof(u32), st));
         if (make_mask && N) {
             YH_HIP(hipMemsetAsync(db->d_mask, 0, N, st));
@@ -1707,23 +1732,12 @@ int yh_q_overlap(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap, b
         YH_HIP(hipMalloc((void**)&db->d_wg_first, (u64)wgs * sizeof(u32)));
         k_wg_first<<<(wgs + 255) / 256, 256, 0, st>>>(db->d_pbeg, db->n_parts, db->pvals_len, wgs, db->d_wg_first);
     }
-    // replicated counters: R * N * 4 bytes, at most ~8 MiB
-    u32 R = 32;
-    while (R > 1 && (u64)R * N > (2u << 20)) R >>= 1;
-    if (db->reps_cap < (u64)R * N) {
-        YH_HIP(hipStreamSynchronize(st));
-        if (db->d_reps) { (void)hipFree(db->d_reps); db->d_reps = nullptr; db->reps_cap = 0; }
-        YH_HIP(hipMalloc((void**)&db->d_reps, (u64)R * N * sizeof(u32) + 16));
-        db->reps_cap = (u64)R * N;
-    }
-    // one launch: sample slice bounds + zero the replicas, the shared-hash flags and the exclusive sums
-    ZeroList z{};
-    z.p[0] = reinterpret_cast<uint4*>(db->d_reps);
-    z.n16[0] = ((u64)R * N * sizeof(u32) + 15) / 16;
-    if (flag_shared) { z.p[1] = reinterpret_cast<uint4*>(db->d_hit); z.n16[1] = (db->n_shared + 15) / 16; }
-    if (with_index) { z.p[2] = reinterpret_cast<uint4*>(db->d_excl_e); z.n16[2] = (3 * N * sizeof(u32) + 15) / 16; }
-    k_prep<<<1024, 256, 0, st>>>(d_sample, (u32)n_sample, P, db->pshift, db->d_sbounds, z);
-    if (db->d_pkeys) {  // the 32-bit key stream (default); YH_WIDE_KEYS=1 at creation keeps the 64-bit kernel
+    u32 R;
+    YH_TRY(ensure_reps(db, R));
+    if (flag_shared) YH_TRY(claim_hit_flags(db));
+    // one launch in front: the sample's slice bounds per partition (the counters are zero at rest)
+    k_prep<<<(P + 1 + 255) / 256, 256, 0, st>>>(d_sample, (u32)n_sample, P, db->pshift, db->d_sbounds, ZeroList{});
+    if (db->d_pkeys) {  // the packed key stream (YH_STREAM=keys); YH_WIDE_KEYS=1 at creation keeps the 64-bit kernel
         const bool side = flag_shared && db->d_gkeys;
         NarrowHit nh{(u32)N, db->d_reps, R - 1, reinterpret_cast<u64x2*>(db->d_hitq), db->hitq_cap, db->d_pvals, db->d_pref,
                      side ? db->d_g : nullptr, db->d_hit, d_sample, (u32)n_sample, db->kshift == 0 ? 1u : 0u};
@@ -1734,7 +1748,8 @@ int yh_q_overlap(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap, b
         yh_ring_record_end(db, db->ev_overlap);
         k_resolve_hits32<<<wgs, 256, 0, st>>>(db->d_hitq_cnt, nh);
         k_reduce_replicas<<<(u32)((N + 255) / 256), 256, 0, st>>>(db->d_reps, R, N, d_overlap, make_mask ? db->d_mask : nullptr,
-                                                                 make_mask ? db->d_maskbits : nullptr);
+                                                                 make_mask ? db->d_maskbits : nullptr,
+                                                                 with_index ? db->d_excl_e : nullptr);
         YH_HIP(hipGetLastError());
         return YH_OK;
     }
@@ -1748,7 +1763,8 @@ int yh_q_overlap(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap, b
     yh_ring_record_end(db, db->ev_overlap);
     k_resolve_hits<<<wgs, 256, 0, st>>>(db->d_hitq_cnt, hit);
     k_reduce_replicas<<<(u32)((N + 255) / 256), 256, 0, st>>>(db->d_reps, R, N, d_overlap, make_mask ? db->d_mask : nullptr,
-                                                             make_mask ? db->d_maskbits : nullptr);
+                                                             make_mask ? db->d_maskbits : nullptr,
+                                                             with_index ? db->d_excl_e : nullptr);
     YH_HIP(hipGetLastError());
     return YH_OK;
 }
@@ -1763,20 +1779,10 @@ int yh_q_overlap_indexed(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_ov
     hipStream_t st = db->stream;
     const u64 N = db->n_refs;
     if (N == 0) return YH_OK;
-    u32 R = 32;
-    while (R > 1 && (u64)R * N > (2u << 20)) R >>= 1;
-    if (db->reps_cap < (u64)R * N) {
-        YH_HIP(hipStreamSynchronize(st));
-        if (db->d_reps) { (void)hipFree(db->d_reps); db->d_reps = nullptr; db->reps_cap = 0; }
-        YH_HIP(hipMalloc((void**)&db->d_reps, (u64)R * N * sizeof(u32) + 16));
-        db->reps_cap = (u64)R * N;
-    }
-    ZeroList z{};
-    z.p[0] = reinterpret_cast<uint4*>(db->d_reps);
-    z.n16[0] = ((u64)R * N * sizeof(u32) + 15) / 16;
-    if (for_exclusive && db->n_shared) { z.p[1] = reinterpret_cast<uint4*>(db->d_hit); z.n16[1] = (db->n_shared + 15) / 16; }
-    if (for_exclusive) { z.p[2] = reinterpret_cast<uint4*>(db->d_excl_e); z.n16[2] = (3 * N * sizeof(u32) + 15) / 16; }
-    k_prep<<<1024, 256, 0, st>>>(d_sample, (u32)0, 0u, db->pshift, db->d_sbounds, z);
+    u32 R;
+    YH_TRY(ensure_reps(db, R));
+    if (for_exclusive && db->n_shared) YH_TRY(claim_hit_flags(db));
+    // (no kernel in front of the lookup: the counters are zero at rest)
     yh_ring_record_begin(db, db->ev_overlap);
     if (n_sample && db->n_distinct)
         k_index_lookup<<<grid_for(n_sample, 256, 4096), 256, 0, st>>>(d_sample, n_sample, yh_dir_view(db), db->d_po, db->d_pr,
@@ -1785,7 +1791,8 @@ int yh_q_overlap_indexed(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_ov
     yh_ring_record_end(db, db->ev_overlap);
     k_reduce_replicas<<<(u32)((N + 255) / 256), 256, 0, st>>>(db->d_reps, R, N, d_overlap,
                                                              for_exclusive ? db->d_mask : nullptr,
-                                                             for_exclusive ? db->d_maskbits : nullptr);
+                                                             for_exclusive ? db->d_maskbits : nullptr,
+                                                             for_exclusive ? db->d_excl_e : nullptr);
     YH_HIP(hipGetLastError());
     return YH_OK;
 }
@@ -1824,8 +1831,9 @@ int yh_q_exclusive_partial(yh_db* db, const u8* d_mask, const u64* d_sample, u64
         d_maskbits = db->d_maskbits;
     }
     if (G) {
-        if (!hit_ready) YH_HIP(hipMemsetAsync(db->d_hit, 0, G, st));
+        if (!hit_ready && !db->hit_clean) { YH_HIP(hipMemsetAsync(db->d_hit, 0, G + 15, st)); db->hit_clean = true; }
         if (n_sample && !hit_ready) {
+            db->hit_clean = false;
             const u32 P = db->n_parts;
             if (own_bounds)
                 k_prep<<<(P + 1 + 255) / 256, 256, 0, st>>>(d_sample, (u32)n_sample, P, db->pshift, db->d_sbounds, ZeroList{});
@@ -1856,11 +1864,14 @@ int yh_q_exclusive_partial(yh_db* db, const u8* d_mask, const u64* d_sample, u64
 
 int yh_q_exclusive_final(yh_db* db, u64 n, const u8* d_mask, const u32* d_sizes, const u32* d_nshared,
                          const u32* d_overlap, const u32* d_ex_e, const u32* d_ex_m, const u32* d_ovsh, u32* d_excl,
-                         u32* d_match) {
+                         u32* d_match, bool clean_hit) {
     if (n == 0) return YH_OK;
-    k_excl_final<<<grid_for(n, 256, 1u << 22), 256, 0, db->stream>>>(n, d_mask, d_sizes, d_nshared, d_overlap, d_ex_e,
-                                                                      d_ex_m, d_ovsh, d_excl, d_match);
+    clean_hit = clean_hit && db->d_hit && db->n_shared;
+    k_excl_final<<<grid_for(n, 256, 1u << 22), 256, 0, db->stream>>>(
+        n, d_mask, d_sizes, d_nshared, d_overlap, d_ex_e, d_ex_m, d_ovsh, d_excl, d_match,
+        clean_hit ? reinterpret_cast<uint4*>(db->d_hit) : nullptr, clean_hit ? (db->n_shared + 15) / 16 : 0);
     YH_HIP(hipGetLastError());
+    if (clean_hit) db->hit_clean = true;
     return YH_OK;
 }
 
@@ -1875,7 +1886,7 @@ int yh_q_exclusive(yh_db* db, const u8* d_mask, const u64* d_sample, u64 n_sampl
     YH_TRY(yh_q_exclusive_partial(db, d_mask, d_sample, n_sample, db->d_excl_e, db->d_excl_m, db->d_ovsh, false,
                                   hit_ready, d_maskbits));
     YH_TRY(yh_q_exclusive_final(db, db->n_refs, d_mask, db->d_sizes, db->d_nshared, d_overlap, db->d_excl_e,
-                                db->d_excl_m, db->d_ovsh, d_excl, d_match));
+                                db->d_excl_m, db->d_ovsh, d_excl, d_match, true));
     yh_ring_record_end(db, db->ev_excl);
     return YH_OK;
 }
