@@ -305,15 +305,14 @@ struct StreamCount {
 };
 __global__ void k_stream_scatter(const u64* __restrict__ sk, const u32* __restrict__ sv, const u32* __restrict__ elem_g,
                                  u64 n, u32 sshift, const u64* __restrict__ pos1 /* position + 1 */,
-                                 u8* __restrict__ sdelta, u64* __restrict__ svals, u32* __restrict__ sref,
-                                 u32* __restrict__ sgidx, u64* __restrict__ hdr) {
+                                 u8* __restrict__ sdelta, uint4* __restrict__ srec, u64* __restrict__ hdr) {
     for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
         const u64 h = sk[i], t = h >> sshift, pos = pos1[i] - 1;
         u32 own = 0;
         if (i) {
             const u64 tp = sk[i - 1] >> sshift, ppos = pos1[i - 1] - 1;
             const u64 nfill = pos - ppos - 1;
-            for (u64 f = 1; f <= nfill; ++f) {  // (arrays are pre-set: hash 0, no reference)
+            for (u64 f = 1; f <= nfill; ++f) {  // (records are pre-set: no reference)
                 const u64 q = ppos + f;
                 sdelta[q] = 255;
                 if ((q & (STREAM_BLOCK - 1)) == 0) hdr[q >> 10] = tp + 255 * f;
@@ -321,9 +320,7 @@ __global__ void k_stream_scatter(const u64* __restrict__ sk, const u32* __restri
             own = (u32)(t - tp - 255 * nfill);
         }
         sdelta[pos] = (u8)own;
-        svals[pos] = h;
-        sref[pos] = sv[i];
-        if (sgidx) sgidx[pos] = elem_g ? elem_g[i] : STREAM_NONE;
+        srec[pos] = make_uint4((u32)h, (u32)(h >> 32), sv[i], elem_g ? elem_g[i] : STREAM_NONE);
         if ((pos & (STREAM_BLOCK - 1)) == 0) hdr[pos >> 10] = t;
     }
 }
@@ -600,17 +597,13 @@ static int build_stream(yh_db* db, const u64* d_sk, const u32* d_sv, const u32* 
         const u64 nblk = db->slen / STREAM_BLOCK;
         rc = yh_dmalloc(db, (void**)&db->d_sdelta, db->slen + 64);
         if (rc == YH_OK) rc = yh_dmalloc(db, (void**)&db->d_shdr, (nblk + 2) * sizeof(u64));
-        if (rc == YH_OK) rc = yh_dmalloc(db, (void**)&db->d_svals, db->slen * sizeof(u64));
-        if (rc == YH_OK) rc = yh_dmalloc(db, (void**)&db->d_sref, db->slen * sizeof(u32));
-        if (rc == YH_OK && d_elem_g) rc = yh_dmalloc(db, (void**)&db->d_sgidx, db->slen * sizeof(u32));
+        if (rc == YH_OK) rc = yh_dmalloc(db, (void**)&db->d_srec, db->slen * sizeof(uint4));
         ST_HIP(hipMemsetAsync(db->d_sdelta, 0, db->slen + 64, st));
         ST_HIP(hipMemsetAsync(db->d_shdr, 0xff, (nblk + 2) * sizeof(u64), st));
-        ST_HIP(hipMemsetAsync(db->d_svals, 0, db->slen * sizeof(u64), st));
-        ST_HIP(hipMemsetAsync(db->d_sref, 0xff, db->slen * sizeof(u32), st));
-        if (db->d_sgidx) ST_HIP(hipMemsetAsync(db->d_sgidx, 0xff, db->slen * sizeof(u32), st));
+        ST_HIP(hipMemsetAsync(db->d_srec, 0xff, db->slen * sizeof(uint4), st));
         if (rc == YH_OK)
-            k_stream_scatter<<<grid_for(H, 256), 256, 0, st>>>(d_sk, d_sv, d_elem_g, H, s, d_pos, db->d_sdelta, db->d_svals,
-                                                              db->d_sref, db->d_sgidx, db->d_shdr);
+            k_stream_scatter<<<grid_for(H, 256), 256, 0, st>>>(d_sk, d_sv, d_elem_g, H, s, d_pos, db->d_sdelta, db->d_srec,
+                                                              db->d_shdr);
         ST_HIP(hipGetLastError());
         ST_HIP(hipStreamSynchronize(st));
     }

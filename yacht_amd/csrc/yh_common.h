@@ -180,9 +180,8 @@ struct yh_db {
     // STREAM_BLOCK elements; s_hdr[b] = t of block b's first element (its own delta byte is unused).
     u8* d_sdelta = nullptr;    // [slen]
     u64* d_shdr = nullptr;     // [slen / STREAM_BLOCK + 1], last = ~0
-    u64* d_svals = nullptr;    // [slen] the 64-bit hash of every position (0 for fillers): read at candidates only
-    u32* d_sref = nullptr;     // [slen] its reference (STREAM_NONE for fillers)
-    u32* d_sgidx = nullptr;    // [slen] index into d_g when the hash is shared, else STREAM_NONE (with the index)
+    uint4* d_srec = nullptr;   // [slen] per position {hash lo, hash hi, reference, index into d_g or STREAM_NONE}
+                               // (fillers / padding: all ones): ONE 16-byte read per candidate
     u64 slen = 0;              // multiple of STREAM_BLOCK
     u32 sshift = 0;
     u64* d_wg_key = nullptr;   // [wgs + 1] first t of each workgroup's block range (sample-independent)

@@ -828,62 +828,67 @@ struct StreamHit {
     u32 n_refs;
     u32* reps;
     u32 rep_mask;
-    u64x2* queue;      // [wgs][qcap]: x = stream position, y = sample index
-    u32 qcap;
-    const u64* svals;
-    const u32* sref;
-    const u32* sgidx;  // may be null (handle without index)
-    u8* hitflag;       // may be null (overlap only)
+    const uint4* srec;  // per stream position: {hash lo, hash hi, reference, shared-hash index}
+    u8* hitflag;        // may be null (overlap only)
     const u64* sample;
-
-    __device__ __forceinline__ bool confirm(u64 pos, u32 sidx, u32& ref) const {
-        if (svals[pos] != sample[sidx]) return false;
-        ref = sref[pos];
-        if (ref == STREAM_NONE) return false;
-        if (hitflag) {
-            const u32 g = sgidx[pos];
-            if (g != STREAM_NONE) hitflag[g] = 1;
-        }
-        return true;
-    }
-    __device__ __forceinline__ void count(u32 wg, u64 pos, u32 sidx) const {
-        u32 r;
-        if (confirm(pos, sidx, r)) atomicAdd(&reps[(u64)(wg & rep_mask) * n_refs + r], 1u);
-    }
-    // the same with the four reads issued together (one memory latency instead of three)
-    __device__ __forceinline__ void count_parallel(u32 wg, u64 pos, u32 sidx) const {
-        const u64 hv = svals[pos], sv = sample[sidx];
-        const u32 ref = sref[pos];
-        const u32 g = hitflag ? sgidx[pos] : STREAM_NONE;
-        if (hv != sv || ref == STREAM_NONE) return;
-        if (g != STREAM_NONE) hitflag[g] = 1;
-        atomicAdd(&reps[(u64)(wg & rep_mask) * n_refs + ref], 1u);
-    }
 };
-// Candidates are queued PER WAVE (STREAM_WQ entries of LDS each): a wave that finds its queue half full
-// copies it to the workgroup's HBM segment by itself (wave_flush) -- no workgroup barrier anywhere in
-// the streaming loop, so the waves of a workgroup drift apart and one wave's probing overlaps the
-// others' loads (with a barrier every other round the kernel took loads + probing, not their maximum).
-// Geometry of k_stream_lookup: 768 threads = 12 waves per workgroup, two workgroups per CU (67 KB of
-// LDS each) = 6 waves per SIMD, which needs <= 80 VGPRs: with the next super-block requested AFTER
-// this one is probed (YH_STREAM_LATE) there is one register set of deltas, 76 VGPRs, no scratch.
+
+// Geometry of k_stream_lookup: 512 threads = 8 waves per workgroup, two workgroups per CU (~65 KB of
+// LDS each) = 4 waves per SIMD and up to 128 VGPRs (no scratch).  768 threads / 6 waves per SIMD
+// (<= 80 VGPRs) spills with 16-block super-blocks and measured slower (0.113 vs 0.100 ms).
 #ifndef YH_STREAM_THREADS
-#define YH_STREAM_THREADS 768
+#define YH_STREAM_THREADS 512
 #endif
 #ifndef YH_STREAM_WAVES_PER_SIMD
-#define YH_STREAM_WAVES_PER_SIMD 6
+#define YH_STREAM_WAVES_PER_SIMD 4
 #endif
 constexpr int STREAM_THREADS = YH_STREAM_THREADS;
-#ifndef YH_STREAM_INPLACE
-#define YH_STREAM_INPLACE 1   // 1: the streaming kernel confirms and counts its candidates itself; 0: HBM queue + k_resolve_stream
-#endif
-constexpr u32 STREAM_WQ = (u32)TILE_QCAP / (STREAM_THREADS / 64);
+// Candidates (a probe equal to an element's truncated key) are queued PER WAVE in LDS and confirmed
+// by the wave that found them -- no workgroup barrier anywhere in the streaming loop.  Confirmation
+// needs four independent random reads per candidate (the 64-bit hash and the reference of the stream
+// position, the sample hash, the shared-hash index); they are SPLIT IN TWO PHASES: a flush requests
+// them, one candidate per lane, into registers, and the NEXT flush, one super-block later, compares
+// and counts.  By then the wave has waited for two groups of the stream requested after them (vmcnt
+// is in order), so the reads cost no stall of their own; waiting for them in place was 16 us of the
+// kernel's 98 (timing-only builds: probes without queueing 74, queueing 80, + reads 96, + counting 98).
+constexpr u32 STREAM_WQ = 64;  // LDS queue entries per wave
 struct WaveQ {
     u32* fill;     // LDS: entries claimed in this wave's queue
-    u64x2* q;      // LDS: this wave's STREAM_WQ entries
-    u32* g_fill;   // LDS: entries claimed in the workgroup's HBM segment
+    u64x2* q;      // LDS: this wave's STREAM_WQ entries (x = stream position, y = sample index)
     u32 wg;
+    u32* tkey;     // LDS: the workgroup's per-reference hit sums, STREAM_TSLOTS slots (reference + 1, 0 = empty)
+    u32* tcnt;
 };
+// Confirmed hits are summed per reference in an LDS table of the workgroup and leave as ONE global
+// atomic per (workgroup, reference) when the workgroup ends: in hash order a reference's hits are
+// spread evenly over the workgroups, and same-address atomics are serialized in L2.
+constexpr u32 STREAM_TSLOTS = 512;
+static_assert(STREAM_TSLOTS == 1u << 9, "table_add hashes into 9 bits");
+__device__ __forceinline__ void table_add(const StreamHit& hit, const WaveQ& c, u32 ref) {
+    u32 slot = (ref * 2654435761u) >> (32 - 9);
+#pragma unroll 1
+    for (int probe = 0; probe < 8; ++probe, slot = (slot + 1) & (STREAM_TSLOTS - 1)) {
+        const u32 old = atomicCAS(&c.tkey[slot], 0u, ref + 1);
+        if (old == 0 || old == ref + 1) { atomicAdd(&c.tcnt[slot], 1u); return; }
+    }
+    atomicAdd(&hit.reps[(u64)(c.wg & hit.rep_mask) * hit.n_refs + ref], 1u);  // crowded table: count directly
+}
+struct Pending {  // one requested confirmation per lane
+    uint4 rec = make_uint4(0u, 0u, STREAM_NONE, STREAM_NONE);
+    u64 sv = 0;
+};
+__device__ __forceinline__ void pending_request(const StreamHit& hit, Pending& p, u64 pos, u32 sidx) {
+    p.rec = hit.srec[pos];
+    p.sv = hit.sample[sidx];
+}
+__device__ __forceinline__ void pending_count(const StreamHit& hit, const WaveQ& c, Pending& p) {
+    const u64 hv = ((u64)p.rec.y << 32) | p.rec.x;
+    if (hv == p.sv && p.rec.z != STREAM_NONE) {  // (fillers have no reference)
+        if (hit.hitflag && p.rec.w != STREAM_NONE) hit.hitflag[p.rec.w] = 1;
+        table_add(hit, c, p.rec.z);
+    }
+    p.rec.z = STREAM_NONE;
+}
 __device__ __forceinline__ void push_hit(const StreamHit& hit, const WaveQ& c, u64 pos, u32 sidx) {
     const u32 slot = atomicAdd(c.fill, 1u);
     if (slot < STREAM_WQ) {
@@ -891,75 +896,29 @@ __device__ __forceinline__ void push_hit(const StreamHit& hit, const WaveQ& c, u
         e.x = pos;
         e.y = sidx;
         c.q[slot] = e;
-    } else {
-        hit.count(c.wg, pos, sidx);
+    } else {  // queue full (a round with more than STREAM_WQ matches): confirm in place
+        Pending p;
+        pending_request(hit, p, pos, sidx);
+        pending_count(hit, c, p);
     }
 }
-// Candidates are confirmed and counted by the wave that found them, a queue-full at a time: four
-// independent reads per candidate (64-bit hash and reference of the stream position, the sample
-// hash, the shared-hash index), then one atomic.  A stream in hash order spreads a workgroup's ~250
-// hits over as many references, so there is nothing to pre-aggregate; the separate confirmation
-// kernel (k_resolve_stream over an HBM queue) was 19 us of pure latency per query.  (Requesting the
-// reads in one flush and counting in the next, every super-block, measured slower: 0.114 vs 0.104 ms.)
-#ifndef YH_STREAM_FLUSH_AT
-#define YH_STREAM_FLUSH_AT (STREAM_WQ / 2)
-#endif
-// wave-uniform call: take the wave's queue when it holds at least min_fill entries
-__device__ __forceinline__ void wave_flush(const StreamHit& hit, const WaveQ& c, u32 min_fill) {
+// wave-uniform call, once per round of probes: count the previous batch, request this one
+__device__ __forceinline__ void wave_flush(const StreamHit& hit, const WaveQ& c, Pending& pend) {
     const u32 lane = threadIdx.x & 63u;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    u32 f = (u32)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(c.fill, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT));
-    if (f < min_fill) return;
-    f = min(f, STREAM_WQ);
-#if YH_STREAM_INPLACE
-    for (u32 e = lane; e < f; e += 64) {
-        const u64x2 x = c.q[e];
-        hit.count_parallel(c.wg, x.x, (u32)x.y);
+    const u32 f = min((u32)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(c.fill, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT)), STREAM_WQ);
+    if (f == 0) return;  // (a batch in flight stays in flight)
+    pending_count(hit, c, pend);
+    if (lane < f) {
+        const u64x2 x = c.q[lane];
+        pending_request(hit, pend, x.x, (u32)x.y);
     }
-#else
-    u32 g0 = 0;
-    if (lane == 0) g0 = atomicAdd(c.g_fill, f);
-    g0 = (u32)__builtin_amdgcn_readfirstlane((int)g0);
-    for (u32 e = lane; e < f; e += 64) {
-        const u64x2 x = c.q[e];
-        if (g0 + e < hit.qcap) hit.queue[(u64)c.wg * hit.qcap + g0 + e] = x;
-        else hit.count(c.wg, x.x, (u32)x.y);
-    }
-#endif
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (lane == 0) __hip_atomic_store(c.fill, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-}
-
-// one workgroup per queue segment: confirm, sum per reference in LDS, one global atomic per (workgroup, reference)
-__global__ void __launch_bounds__(256) k_resolve_stream(const u32* __restrict__ qcount, StreamHit hit) {
-    __shared__ u32 tkey[RES_SLOTS];  // reference + 1, 0 = empty
-    __shared__ u32 tcnt[RES_SLOTS];
-    const u32 wg = blockIdx.x;
-    const u32 cnt = qcount[wg];
-    if (cnt == 0) return;
-    for (u32 k = threadIdx.x; k < RES_SLOTS; k += blockDim.x) { tkey[k] = 0; tcnt[k] = 0; }
-    __syncthreads();
-    const u64x2* q = hit.queue + (u64)wg * hit.qcap;
-    u32* my = hit.reps + (u64)(wg & hit.rep_mask) * hit.n_refs;
-    for (u32 e = threadIdx.x; e < cnt; e += blockDim.x) {
-        const u64x2 x = q[e];
-        u32 r;
-        if (!hit.confirm(x.x, (u32)x.y, r)) continue;
-        u32 slot = (r * 2654435761u) >> (32 - 10);
-        bool done = false;
-        for (int probe = 0; probe < 8 && !done; ++probe, slot = (slot + 1) & (RES_SLOTS - 1)) {
-            const u32 old = atomicCAS(&tkey[slot], 0u, r + 1);
-            if (old == 0 || old == r + 1) { atomicAdd(&tcnt[slot], 1u); done = true; }
-        }
-        if (!done) atomicAdd(&my[r], 1u);
-    }
-    __syncthreads();
-    for (u32 k = threadIdx.x; k < RES_SLOTS; k += blockDim.x)
-        if (tkey[k]) atomicAdd(&my[tkey[k] - 1], tcnt[k]);
 }
 
 // wg_key[w] = t of the first element of workgroup w's block range (~0 past the end): sample-independent
@@ -993,19 +952,29 @@ __device__ __forceinline__ u32 wave_bound(const u64* __restrict__ sample, u32 n,
     return lo + (u32)__popcll(__ballot(p));
 }
 
-// A wave reads the stream in super-blocks of STREAM_PF consecutive blocks (8 KB of delta bytes per
-// wave and request, the next super-block in flight while this one is probed).  Per super-block:
-//   1. every block's lane spans: byte sums (v_sad_u8) + a DPP wave scan, written to LDS (INC);
-//   2. the sample keys inside the super-block's key range, ONE PER LANE: which block (8 scalar
-//      compares), which lane of it (6-step binary search in INC), that lane's 16 delta bytes again
-//      (a 16-byte read that hits L2) and a 16-step compare.
-// Probing lane-parallel over 8192 elements instead of once per 1024 is what takes the kernel from
-// 0.19 instructions per element (one probe at a time, three lanes busy) to ~0.04.
+// A wave takes the stream in super-blocks of STREAM_NB = STREAM_PF x STREAM_GROUPS consecutive blocks
+// (16 KB of delta bytes).  Per super-block:
+//   1. group by group (STREAM_PF blocks = one register set of 16-byte vectors, 8 KB per request):
+//      every block's lane spans -- byte sums (v_sad_u8) + the PF wave scans side by side (DPP) --
+//      written to LDS (INC), the blocks' first and last keys to HB / scalar registers;
+//   2. the sample keys inside the super-block's key range, ONE PER LANE (~49 of 64 lanes busy for a
+//      10^6-hash sample against 3.3 x 10^8 hashes): which block (scalar compares), which lane of it
+//      (6-step binary search in INC), that lane's 16 delta bytes again (a 16-byte read that hits L2)
+//      and a 16-step compare.
+// The next group is requested only when the registers are free again (no second register set: 76
+// VGPRs, 6 waves per SIMD hide the latency), so the probes' L2 reads never queue behind a prefetch
+// (vmcnt is in order).  The kernel is bound by instruction issue, not by HBM: what counts is
+// instructions per element -- one probe at a time: 0.19; lane-parallel over 8 blocks: 0.063; over 16: see DESIGN.md.
 #ifndef YH_STREAM_PF
 #define YH_STREAM_PF 8
 #endif
+#ifndef YH_STREAM_GROUPS
+#define YH_STREAM_GROUPS 2
+#endif
 constexpr int STREAM_PF = YH_STREAM_PF;
-static_assert(STREAM_PF >= 1 && STREAM_PF <= 15, "headers of a super-block live in lanes 0..PF");
+constexpr int STREAM_NB = YH_STREAM_PF * YH_STREAM_GROUPS;
+static_assert(STREAM_PF >= 1 && STREAM_PF <= 15, "headers of a group live in lanes 0..PF");
+static_assert(STREAM_NB <= 16, "HB holds 16 block keys per wave");
 
 __device__ __forceinline__ u64 uniform_u64(u64 v) {  // a value every lane holds, moved to scalar registers
     return ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(v >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)(u32)v);
@@ -1014,107 +983,95 @@ __device__ __forceinline__ u64 readlane_u64(u64 v, int l) {
     return ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(v >> 32), l) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)v, l);
 }
 
-#ifndef YH_STREAM_LATE
-#define YH_STREAM_LATE 1   // 1: request the next super-block after this one has been probed (no second register set)
-#endif
-#ifndef YH_STREAM_PULL
-#define YH_STREAM_PULL 0   // 1: a probe pulls its 16 delta bytes out of the wave's registers; 0: re-reads them (L2)
-#endif
-// loads of super-block sb of the block range [bl0, bl1) (blocks bl0 + sb*PF + i, clamped into the
-// range: harmless re-reads at the end); lanes 0..PF of h hold the PF + 1 block headers
-__device__ __forceinline__ void load_super(const u32x4* __restrict__ deltas, const u64* __restrict__ hdr, u64 bl0, u64 bl1,
-                                           u64 sb, u32x4 (&d)[STREAM_PF], u64& h) {
+// loads of the STREAM_PF blocks from block bf on (clamped into [.., bl1): harmless re-reads at the
+// end); lanes 0..PF of h hold the PF + 1 block headers hdr[bf .. bf + PF]
+__device__ __forceinline__ void load_group(const u32x4* __restrict__ deltas, const u64* __restrict__ hdr, u64 bl1, u64 bf,
+                                           u32x4 (&d)[STREAM_PF], u64& h) {
     const u32 lane = threadIdx.x & 63u;
-    const u64 b0 = bl0 + sb * STREAM_PF;
 #pragma unroll
-    for (int i = 0; i < STREAM_PF; ++i) d[i] = deltas[min(b0 + i, bl1 - 1) * 64 + lane];
-    h = hdr[min(b0 + min((u64)lane, (u64)STREAM_PF), bl1)];
+    for (int i = 0; i < STREAM_PF; ++i) d[i] = deltas[min(bf + i, bl1 - 1) * 64 + lane];
+    h = hdr[min(bf + min((u64)lane, (u64)STREAM_PF), bl1)];
 }
 
-// cur / hcur: the wave's first super-block, already requested by the caller when `preloaded`
+// S: the tile's sample keys relative to Klo (32 bits, ~0 = sentinel); cur / hcur: the wave's first
+// group, already requested by the caller when `preloaded`
 __device__ __forceinline__ void stream_blocks(const u32x4* __restrict__ deltas, const u64* __restrict__ hdr, u64 bl0,
-                                              u64 bl1, u32 sub, u32 n, u64 Klo, u64 Khi, u32 dsh, const u64* S,
+                                              u64 bl1, u32 sub, u32 n, u64 Klo, u64 Khi, u32 dsh, const u32* S,
                                               const u16* E, u32* INCw, u32* HBw, const StreamHit& hit,
-                                              const WaveQ& ctx, bool preloaded, u32x4 (&cur)[STREAM_PF], u64& hcur) {
+                                              const WaveQ& ctx, Pending& pend, bool preloaded, u32x4 (&cur)[STREAM_PF], u64& hcur) {
     constexpr u32 WAVES = STREAM_THREADS / 64;
-    constexpr int PF = STREAM_PF;
+    constexpr int PF = STREAM_PF, NB = STREAM_NB;
     const u32 lane = threadIdx.x & 63u;
-    const u64 n_super = (bl1 - bl0 + PF - 1) / PF;
+    const u64 n_super = (bl1 - bl0 + NB - 1) / NB;
     u64 sb = (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform, and the compiler knows it
-    if (sb < n_super && !preloaded) load_super(deltas, hdr, bl0, bl1, sb, cur, hcur);
     for (; sb < n_super; sb += WAVES) {
-#if !YH_STREAM_LATE
-        u32x4 nxt[PF];
-        u64 hnxt;
-        load_super(deltas, hdr, bl0, bl1, min(sb + WAVES, n_super - 1), nxt, hnxt);
-#endif
-        const u64 b0 = bl0 + sb * PF;
-        const int nvalid = (int)min((u64)PF, bl1 - b0);
-        const u64 base0 = readlane_u64(hcur, 0);
-        const u64 endkey = readlane_u64(hcur, nvalid);  // first key behind the super-block
-#if defined(YH_STREAM_ABLATE) && YH_STREAM_ABLATE == 1  // timing-only: loads, nothing else
-        {
-            u32 acc = 0;
+        const u64 b0 = bl0 + sb * NB;
+        const int nvalid = (int)min((u64)NB, bl1 - b0);
+        u32 hl[NB];  // last key of block i relative to base0 (scalar); invalid blocks: ~0
+        u64 base0 = 0;
+        u32 last_rel = 0;
 #pragma unroll
-            for (int i = 0; i < PF; ++i) acc ^= cur[i].x ^ cur[i].y ^ cur[i].z ^ cur[i].w;
-            if (acc == 0x12345678u && base0 == 77) push_hit(hit, ctx, b0, sub);
-        }
-        if (true) {} else
-#endif
-        if (!(endkey < Klo || base0 > Khi)) {           // some sample key of the tile can lie inside
-            if (lane <= (u32)PF) HBw[lane] = ((int)lane < nvalid) ? (u32)(hcur - base0) : 0xffffffffu;
-            u32 hl[PF];  // last key of block i relative to base0 (scalar); invalid blocks: ~0
-            u32 last_rel = 0;
-            // Lane sums of all PF blocks (v_sad_u8), then the PF inclusive wave scans step by step side
-            // by side (DPP only -- gfx9: row_shr 1/2/4/8 inside the rows of 16, then row_bcast:15 into
-            // rows 1 and 3, row_bcast:31 into rows 2 and 3): a DPP add needs two wait states after the
-            // write of its source, which the other blocks' adds fill.
-            int v[PF];
+        for (int g = 0; g < NB / PF; ++g) {
+            const int nv = min(PF, nvalid - g * PF);  // valid blocks of this group
+            if (nv > 0) {
+                if (!(g == 0 && preloaded)) load_group(deltas, hdr, bl1, b0 + g * PF, cur, hcur);
+                if (g == 0) base0 = readlane_u64(hcur, 0);
+                if (lane < (u32)PF) HBw[g * PF + lane] = ((int)lane < nv) ? (u32)(hcur - base0) : 0xffffffffu;
+                // Lane sums of the PF blocks (v_sad_u8), then the PF inclusive wave scans step by step side
+                // by side (DPP only -- gfx9: row_shr 1/2/4/8 inside the rows of 16, then row_bcast:15 into
+                // rows 1 and 3, row_bcast:31 into rows 2 and 3): a DPP add needs two wait states after the
+                // write of its source, which the other blocks' adds fill.
+                int v[PF];
 #pragma unroll
-            for (int i = 0; i < PF; ++i) {
-                const u32x4 d = cur[i];
-                const u32 w0 = lane ? d.x : (d.x & 0xffffff00u);  // (a block's first delta byte is not used)
-                v[i] = (int)(__builtin_amdgcn_sad_u8(w0, 0u, 0u) + __builtin_amdgcn_sad_u8(d.y, 0u, 0u) +
-                             __builtin_amdgcn_sad_u8(d.z, 0u, 0u) + __builtin_amdgcn_sad_u8(d.w, 0u, 0u));
-            }
+                for (int i = 0; i < PF; ++i) {
+                    const u32x4 d = cur[i];
+                    const u32 w0 = lane ? d.x : (d.x & 0xffffff00u);  // (a block's first delta byte is not used)
+                    v[i] = (int)(__builtin_amdgcn_sad_u8(w0, 0u, 0u) + __builtin_amdgcn_sad_u8(d.y, 0u, 0u) +
+                                 __builtin_amdgcn_sad_u8(d.z, 0u, 0u) + __builtin_amdgcn_sad_u8(d.w, 0u, 0u));
+                }
 #define YH_SCAN_STEP(ctrl, rmask)                                                                      \
     _Pragma("unroll") for (int i = 0; i < PF; ++i) v[i] += __builtin_amdgcn_update_dpp(0, v[i], ctrl, rmask, 0xf, false);
-            YH_SCAN_STEP(0x111, 0xf)
-            YH_SCAN_STEP(0x112, 0xf)
-            YH_SCAN_STEP(0x114, 0xf)
-            YH_SCAN_STEP(0x118, 0xf)
-            YH_SCAN_STEP(0x142, 0xa)
-            YH_SCAN_STEP(0x143, 0xc)
+                YH_SCAN_STEP(0x111, 0xf)
+                YH_SCAN_STEP(0x112, 0xf)
+                YH_SCAN_STEP(0x114, 0xf)
+                YH_SCAN_STEP(0x118, 0xf)
+                YH_SCAN_STEP(0x142, 0xa)
+                YH_SCAN_STEP(0x143, 0xc)
 #undef YH_SCAN_STEP
 #pragma unroll
-            for (int i = 0; i < PF; ++i) {
-                INCw[i * 64 + lane] = (u32)v[i];
-                const u32 end_rel = (u32)(readlane_u64(hcur, i) - base0) + (u32)__builtin_amdgcn_readlane(v[i], 63);
-                hl[i] = (i < nvalid) ? end_rel : 0xffffffffu;
-                last_rel = (i < nvalid) ? end_rel : last_rel;
+                for (int i = 0; i < PF; ++i) {
+                    INCw[(g * PF + i) * 64 + lane] = (u32)v[i];
+                    const u32 end_rel = (u32)(readlane_u64(hcur, i) - base0) + (u32)__builtin_amdgcn_readlane(v[i], 63);
+                    hl[g * PF + i] = (i < nv) ? end_rel : 0xffffffffu;
+                    last_rel = (i < nv) ? end_rel : last_rel;
+                }
+            } else {
+                if (lane < (u32)PF) HBw[g * PF + lane] = 0xffffffffu;
+#pragma unroll
+                for (int i = 0; i < PF; ++i) hl[g * PF + i] = 0xffffffffu;
             }
-            const u64 sb_last = base0 + last_rel;
+        }
+        preloaded = false;
+        const u64 sb_last = base0 + last_rel;
+        if (base0 <= Khi && sb_last >= Klo)
+        {  // some sample key of the tile can lie inside
             u32 k = (base0 <= Klo) ? 0u : (u32)E[(base0 - Klo) >> dsh];  // a slot at or before the first key >= base0
             k = (u32)__builtin_amdgcn_readfirstlane((int)k);
             for (;;) {  // 64 sample slots at a time; the keys inside the super-block are a run of lanes
-                const u64 sk = S[k + lane];  // (ST_PAD sentinels ~0 behind the last key keep this in bounds)
+                const u32 s32 = S[k + lane];  // (ST_PAD sentinels ~0 behind the last key keep this in bounds)
+                const u64 sk = (s32 == 0xffffffffu) ? ~0ull : Klo + s32;
                 const u64 ge = __ballot(sk >= base0);
                 if (!ge) { k += 64; continue; }
                 const bool in = sk >= base0 && sk <= sb_last && k + lane < n;
                 const u32 c = (u32)__builtin_ctzll(ge);
                 const u32 np = (u32)__popcll(__ballot(in));
-#if defined(YH_STREAM_ABLATE) && YH_STREAM_ABLATE == 3  // timing-only: + finding the probes
-                if (in && sk == 0x1234567812345678ull) push_hit(hit, ctx, b0, sub);
-                if (true) { if (c + np < 64) break; k += 64; continue; }
-#endif
-                // One probe per lane.  The probe's block f and lane t are found in LDS (HB, INC); lane t's
-                // 16 delta bytes are PULLED out of the registers of the wave with ds_bpermute -- a global
-                // re-read would have to wait (vmcnt is in order) for the whole next super-block in flight.
+                // One probe per lane: its block f and lane t are found in LDS (HB, INC); lane t's 16 delta
+                // bytes are read again (they hit L2: the wave has just streamed them).
                 const u32 rel = (u32)(sk - base0);
                 u32 f = 0;  // first block whose last key is >= the probe
 #pragma unroll
-                for (int i = 0; i < PF; ++i) f += (hl[i] < rel) ? 1u : 0u;
-                bool act = in && f < (u32)PF;
+                for (int i = 0; i < NB; ++i) f += (hl[i] < rel) ? 1u : 0u;
+                bool act = in && f < (u32)NB;
                 u32 r = 0, t = 0;
                 auto locate = [&]() {  // r, t of the probe inside block f; a block that starts behind the probe ends it
                     const u32 hb = HBw[f];
@@ -1127,21 +1084,8 @@ __device__ __forceinline__ void stream_blocks(const u32x4* __restrict__ deltas, 
                 };
                 if (act) locate();
                 while (__ballot(act)) {  // (more than one trip only for runs of equal keys that leave a lane)
-                    u32x4 w = {0u, 0u, 0u, 0u};
-#if YH_STREAM_PULL
-                    const int src = (int)(t << 2);
-#pragma unroll
-                    for (int i = 0; i < PF; ++i) {  // (unguarded: ~3 probes per block, a block without one is rare)
-                        const u32 x0 = (u32)__builtin_amdgcn_ds_bpermute(src, (int)cur[i].x);
-                        const u32 x1 = (u32)__builtin_amdgcn_ds_bpermute(src, (int)cur[i].y);
-                        const u32 x2 = (u32)__builtin_amdgcn_ds_bpermute(src, (int)cur[i].z);
-                        const u32 x3 = (u32)__builtin_amdgcn_ds_bpermute(src, (int)cur[i].w);
-                        if (f == (u32)i) { w.x = x0; w.y = x1; w.z = x2; w.w = x3; }
-                    }
-#else
-                    if (act) w = deltas[(b0 + f) * 64 + t];  // (hits L2: the wave has just read this block)
-#endif
                     if (act) {
+                        const u32x4 w = deltas[(b0 + f) * 64 + t];
                         const u32 W[4] = {t ? w.x : (w.x & 0xffffff00u), w.y, w.z, w.w};
                         u32 cs = t ? INCw[f * 64 + t - 1] : 0u, match = 0;
 #pragma unroll
@@ -1154,89 +1098,90 @@ __device__ __forceinline__ void stream_blocks(const u32x4* __restrict__ deltas, 
                             match &= match - 1u;
                             push_hit(hit, ctx, ((b0 + f) << 10) + 16u * t + j, sub + k + lane);
                         }
-                        if (cs != r) act = false;       // the lane's last key is above the probe: the run ended
-                        else if (t < 63) ++t;           // the run of equal keys may go on in the next lane
-                        else if (++f < (u32)PF) locate();  // ... or in the next block
-                        else act = false;
+                        if (cs != r) act = false;          // the lane's last key is above the probe: the run ended
+                        else if (t < 63) ++t;              // the run of equal keys may go on in the next lane
+                        else if (++f < (u32)NB) locate();  // ... or in the next block
+                        else act = false;                  // ... or in the next super-block, which finds it itself
                     }
                 }
-                wave_flush(hit, ctx, YH_STREAM_FLUSH_AT);
+                wave_flush(hit, ctx, pend);
                 if (c + np < 64) break;  // the run of inside keys ended within these 64 slots
                 k += 64;
             }
         }
-#if YH_STREAM_LATE
-        load_super(deltas, hdr, bl0, bl1, min(sb + WAVES, n_super - 1), cur, hcur);
-#else
-#pragma unroll
-        for (int i = 0; i < PF; ++i) cur[i] = nxt[i];
-        hcur = hnxt;
-#endif
     }
 }
+
+constexpr int ST_LGNB = 11;             // buckets of the tile's directory E
+constexpr int ST_NB = 1 << ST_LGNB;
 
 __global__ void __launch_bounds__(STREAM_THREADS, YH_STREAM_WAVES_PER_SIMD)
 k_stream_lookup(const u32x4* __restrict__ deltas, const u64* __restrict__ hdr, u64 nblk,
                 const u64* __restrict__ sample, u32 n_sample, const u64* __restrict__ wg_key, u32 sshift,
-                u32* __restrict__ qcount, StreamHit hit) {
+                StreamHit hit) {
     constexpr u32 WAVES = STREAM_THREADS / 64;
-    __shared__ __attribute__((aligned(16))) u64 S[ST_SLOTS];
-    __shared__ u16 E[TILE_NB];
+    __shared__ u32 S[ST_SLOTS];                 // the tile's sample keys, relative to its first one
+    __shared__ u16 E[ST_NB];
     __shared__ u64x2 Q[WAVES][STREAM_WQ];
-    __shared__ u32 INC[WAVES][STREAM_PF * 64];  // per wave: the lane-inclusive key sums of a super-block
+    __shared__ u32 INC[WAVES][STREAM_NB * 64];  // per wave: the lane-inclusive key sums of a super-block
     __shared__ u32 HB[WAVES][16];               // per wave: first key of each of its blocks, relative
     __shared__ u32 q_fill[WAVES];
-    __shared__ u32 g_fill;
+    __shared__ u32 sbound[2];
+    __shared__ u32 n_fit;
+    __shared__ u32 tkey[STREAM_TSLOTS];
+    __shared__ u32 tcnt[STREAM_TSLOTS];
 
     const u32 tid = threadIdx.x;
     const u32 wv = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const u32 lid = xcd_remap(blockIdx.x, gridDim.x);
     const u64 per = (nblk + gridDim.x - 1) / gridDim.x;
     const u64 B0 = min((u64)lid * per, nblk), B1 = min(nblk, B0 + per);
-    const WaveQ ctx{&q_fill[wv], Q[wv], &g_fill, lid};
-    __shared__ u32 sbound[2];
-    if (B0 >= B1) {  // no blocks
-        if (tid == 0 && qcount) qcount[lid] = 0;
-        return;
-    }
-    // The wave's first super-block is requested before anything else; while it is in flight, waves 0
-    // and 1 find the workgroup's range of the sample and the tile is staged.  (With several tiles --
-    // a sample slice above ST_CAP hashes -- the request is wasted and made again per tile.)
+    const WaveQ ctx{&q_fill[wv], Q[wv], lid, tkey, tcnt};
+    if (B0 >= B1) return;  // no blocks
+    // The wave's first group is requested before anything else; while it is in flight, waves 0 and 1
+    // find the workgroup's range of the sample and the tile is staged.  (With several tiles -- a
+    // sample slice above ST_CAP hashes -- the request is wasted and made again per tile.)
     u32x4 cur[STREAM_PF];
     u64 hcur = 0;
-    if ((u64)wv * STREAM_PF < B1 - B0) load_super(deltas, hdr, B0, B1, wv, cur, hcur);
+    if ((u64)wv * STREAM_NB < B1 - B0) load_group(deltas, hdr, B1, B0 + (u64)wv * STREAM_NB, cur, hcur);
     if (wv < 2) {
         const u32 bnd = wave_bound(sample, n_sample, sshift, wg_key[lid + wv], wv == 1);
         if ((tid & 63u) == 0) sbound[wv] = bnd;
     }
     if (tid < WAVES) q_fill[tid] = 0;
-    if (tid == 0) g_fill = 0;
+    for (u32 k = tid; k < STREAM_TSLOTS; k += STREAM_THREADS) { tkey[k] = 0; tcnt[k] = 0; }
     __syncthreads();
     const u32 s0 = (u32)__builtin_amdgcn_readfirstlane((int)sbound[0]), s1 = (u32)__builtin_amdgcn_readfirstlane((int)sbound[1]);
-    if (s0 >= s1) {  // no sample hash in this range of t: nothing to look up
-        if (tid == 0 && qcount) qcount[lid] = 0;
-        return;
-    }
-    const bool single = s1 - s0 <= (u32)ST_CAP;
-    bool first = true;
-    for (u32 sub = s0; sub < s1; sub += ST_CAP) {
-        const u32 n = min((u32)ST_CAP, s1 - sub);
-        if (!first) __syncthreads();  // every wave is done with the previous tile
-        first = false;
-        for (u32 k = tid; k < n; k += STREAM_THREADS) S[k] = sample[sub + k] >> sshift;
-        for (u32 k = n + tid; k < n + ST_PAD; k += STREAM_THREADS) S[k] = ~0ull;
+    if (s0 >= s1) return;  // no sample hash in this range of t: nothing to look up
+    Pending pend;
+    for (u32 sub = s0; sub < s1;) {
+        u32 n = min((u32)ST_CAP, s1 - sub);
+        if (sub != s0) __syncthreads();  // every wave is done with the previous tile
+        // keys are staged relative to the tile's first one, in 32 bits; a tile ends early where that overflows
+        const u64 Klo = uniform_u64(sample[sub] >> sshift);
+        if (tid == 0) n_fit = n;
         __syncthreads();
-        const u64 Klo = uniform_u64(S[0]), Khi = uniform_u64(S[n - 1]);
-        const u64 span = Khi - Klo;
-        const u32 dsh = (span >> TILE_LGNB) ? (u32)(64 - __builtin_clzll(span)) - TILE_LGNB : 0u;  // (span >> dsh) < TILE_NB
         for (u32 k = tid; k < n; k += STREAM_THREADS) {
-            const u32 bk = (u32)((S[k] - Klo) >> dsh);
-            const int bp = (k == 0) ? -1 : (int)((S[k - 1] - Klo) >> dsh);
-            for (int x = bp + 1; x <= (int)bk; ++x) E[x] = (u16)k;
-            if (k == n - 1)
-                for (u32 x = bk + 1; x < (u32)TILE_NB; ++x) E[x] = (u16)n;
+            const u64 d = (sample[sub + k] >> sshift) - Klo;
+            if (d > 0xfffffffeull) atomicMin(&n_fit, k);
+            else S[k] = (u32)d;
         }
         __syncthreads();
+        n = (u32)__builtin_amdgcn_readfirstlane((int)n_fit);  // >= 1: key 0 is Klo itself
+        for (u32 k = n + tid; k < n + ST_PAD; k += STREAM_THREADS) S[k] = 0xffffffffu;
+        __syncthreads();
+        const u32 span = (u32)__builtin_amdgcn_readfirstlane((int)S[n - 1]);
+        const u64 Khi = Klo + span;
+        const u32 dsh = (span >> ST_LGNB) ? (u32)(32 - __builtin_clz(span)) - ST_LGNB : 0u;  // (span >> dsh) < ST_NB
+        for (u32 k = tid; k < n; k += STREAM_THREADS) {
+            const u32 bk = S[k] >> dsh;
+            const int bp = (k == 0) ? -1 : (int)(S[k - 1] >> dsh);
+            for (int x = bp + 1; x <= (int)bk; ++x) E[x] = (u16)k;
+            if (k == n - 1)
+                for (u32 x = bk + 1; x < (u32)ST_NB; ++x) E[x] = (u16)n;
+        }
+        __syncthreads();
+        const bool single = sub == s0 && n == s1 - s0;  // one tile (the usual case): the first request was right
         u64 bl0 = B0, bl1 = B1;
         if (!single) {  // several tiles: each covers a contiguous sub-range of the blocks
             u64 lo = B0, hi = B1;     // first block whose NEXT header is >= Klo
@@ -1247,13 +1192,16 @@ k_stream_lookup(const u32x4* __restrict__ deltas, const u64* __restrict__ hdr, u
             bl1 = lo;
         }
         if (bl0 < bl1)
-            stream_blocks(deltas, hdr, bl0, bl1, sub, n, Klo, Khi, dsh, S, E, INC[wv], HB[wv], hit, ctx, single, cur, hcur);
+            stream_blocks(deltas, hdr, bl0, bl1, sub, n, Klo, Khi, dsh, S, E, INC[wv], HB[wv], hit, ctx, pend,
+                          single && (u64)wv * STREAM_NB < B1 - B0, cur, hcur);
+        sub += n;
     }
-    wave_flush(hit, ctx, 1);
-#if !YH_STREAM_INPLACE
+    wave_flush(hit, ctx, pend);
+    pending_count(hit, ctx, pend);  // the last batch: the one wait for confirmation reads the wave cannot hide
     __syncthreads();
-    if (tid == 0) qcount[lid] = min(g_fill, hit.qcap);
-#endif
+    u32* my = hit.reps + (u64)(lid & hit.rep_mask) * hit.n_refs;
+    for (u32 k = tid; k < STREAM_TSLOTS; k += STREAM_THREADS)
+        if (tkey[k]) atomicAdd(&my[tkey[k] - 1], tcnt[k]);
 }
 
 // ---- cross-check kernel: one wave per reference over the plain CSR -------------------------------
@@ -1402,6 +1350,10 @@ __global__ void __launch_bounds__(EXCL_BLOCK) k_excl_apply(const u32* __restrict
 // on one posting: holder lists four at a time, ballots, three sums per chunk.  A heavy reference's
 // chunks are spread over as many waves.  (With most references masked the streaming pair above is
 // ~3x faster: its reads are coalesced.)
+#ifndef YH_EXCL_U
+#define YH_EXCL_U 4
+#endif
+constexpr int EXCL_U = YH_EXCL_U;
 __global__ void __launch_bounds__(256) k_excl_chunks(u32 n_chunks, const uint2* __restrict__ chunks,
                                                      const u32* __restrict__ rpo, const u32* __restrict__ rg,
                                                      const u64* __restrict__ po, const u32* __restrict__ pr,
@@ -1416,37 +1368,72 @@ __global__ void __launch_bounds__(256) k_excl_chunks(u32 n_chunks, const uint2* 
         mine = chunks[c];
         want = (maskbits[mine.x >> 5] >> (mine.x & 31u)) & 1u;
     }
+    // The masked chunks of the wave's 64 records, EXCL_U at a time: a chunk is a chain of dependent
+    // reads (posting -> shared hash -> holder list -> mask words), so the chunks of a step are walked
+    // side by side, branch-free (clamped addresses), and their reads overlap.
+    constexpr int U = EXCL_U;
     u64 todo = __ballot(want);
     while (todo) {
-        const int src = __ffsll((long long)todo) - 1;
-        todo &= todo - 1;
-        const u32 r = (u32)__shfl((int)mine.x, src);
-        const u32 k = (u32)__shfl((int)mine.y, src) + lane;
-        bool e = false, m = false, o = false;
-        if (k < rpo[r + 1]) {
-            const u32 gi = rg[k];
-            const u64 q0 = po[gi], q1 = po[gi + 1];
-            const bool in_sample = hit[gi] != 0;
-            u32 cnt = 0;
-            for (u64 q = q0; q < q1; q += 4) {  // holders four at a time: the loads of a step are independent
-                u32 h[4];
+        u32 r[U], k[U], lim[U];
+        bool on[U];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) h[t] = pr[min(q + t, q1 - 1)];
-                u32 mw[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) mw[t] = maskbits[h[t] >> 5];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) cnt += (q + t < q1) ? ((mw[t] >> (h[t] & 31u)) & 1u) : 0u;
-            }
-            e = (cnt == 1);
-            m = e && in_sample;
-            o = in_sample;
+        for (int u = 0; u < U; ++u) {
+            on[u] = todo != 0;
+            const int src = on[u] ? __ffsll((long long)todo) - 1 : 0;
+            todo &= todo - 1;  // (0 stays 0)
+            r[u] = (u32)__shfl((int)mine.x, src);
+            k[u] = (u32)__shfl((int)mine.y, src) + lane;
         }
-        const u32 ne = (u32)__popcll(__ballot(e)), nm = (u32)__popcll(__ballot(m)), no = (u32)__popcll(__ballot(o));
-        if (lane == 0) {
-            if (ne) atomicAdd(&ex_e[r], ne);
-            if (nm) atomicAdd(&ex_m[r], nm);
-            if (no) atomicAdd(&ovsh[r], no);
+#pragma unroll
+        for (int u = 0; u < U; ++u) lim[u] = on[u] ? rpo[r[u] + 1] : 0u;
+        bool valid[U];
+        u32 gi[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            valid[u] = k[u] < lim[u];
+            gi[u] = valid[u] ? rg[k[u]] : 0u;
+        }
+        u64 q[U], q1[U];
+        bool in_sample[U];
+        u32 cnt[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            q[u] = po[gi[u]];
+            q1[u] = valid[u] ? po[gi[u] + 1] : q[u];  // an invalid lane has an empty holder list
+            in_sample[u] = valid[u] && hit[gi[u]] != 0;
+            cnt[u] = 0;
+        }
+        for (;;) {  // holders four at a time per chunk: 4 * U independent reads a step
+            bool more = false;
+#pragma unroll
+            for (int u = 0; u < U; ++u) more |= q[u] < q1[u];
+            if (!__ballot(more)) break;
+            u32 h[U][4], mw[U][4];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) h[u][t] = (q[u] < q1[u]) ? pr[min(q[u] + t, q1[u] - 1)] : 0u;
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) mw[u][t] = maskbits[h[u][t] >> 5];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) cnt[u] += (q[u] + t < q1[u]) ? ((mw[u][t] >> (h[u][t] & 31u)) & 1u) : 0u;
+                q[u] = min(q[u] + 4, q1[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool e = valid[u] && cnt[u] == 1;
+            const u32 ne = (u32)__popcll(__ballot(e)), nm = (u32)__popcll(__ballot(e && in_sample[u])),
+                      no = (u32)__popcll(__ballot(in_sample[u]));
+            if (lane == 0 && on[u]) {
+                if (ne) atomicAdd(&ex_e[r[u]], ne);
+                if (nm) atomicAdd(&ex_m[r[u]], nm);
+                if (no) atomicAdd(&ovsh[r[u]], no);
+            }
         }
     }
 }
@@ -1651,20 +1638,6 @@ static int yh_q_overlap_stream(yh_db* db, const u64* d_sample, u64 n_sample, u32
     const u64 nblk = db->slen / STREAM_BLOCK;
     u32 wgs = tile_grid(db->slen);
     if ((u64)wgs > nblk) wgs = (u32)std::max<u64>(nblk, 1);
-#if !YH_STREAM_INPLACE  // (A/B build: candidates through an HBM queue and k_resolve_stream)
-    const u64 per_wg = (db->slen + wgs - 1) / wgs;
-    const u32 qcap = (u32)std::min<u64>(std::max<u64>(4096, per_wg / 16), 1u << 24);
-    if (db->hitq_wgs < wgs || db->hitq_cap < qcap) {
-        YH_HIP(hipStreamSynchronize(st));
-        if (db->d_hitq) { (void)hipFree(db->d_hitq); db->d_hitq = nullptr; }
-        if (db->d_hitq_cnt) { (void)hipFree(db->d_hitq_cnt); db->d_hitq_cnt = nullptr; }
-        db->hitq_wgs = db->hitq_cap = 0;
-        YH_HIP(hipMalloc((void**)&db->d_hitq, (u64)wgs * qcap * 2 * sizeof(u64)));
-        YH_HIP(hipMalloc((void**)&db->d_hitq_cnt, (u64)wgs * sizeof(u32)));
-        db->hitq_wgs = wgs;
-        db->hitq_cap = qcap;
-    }
-#endif
     if (db->wg_key_n != wgs) {  // the first t of every workgroup's block range: once per handle
         YH_HIP(hipStreamSynchronize(st));
         if (db->d_wg_key) { (void)hipFree(db->d_wg_key); db->d_wg_key = nullptr; }
@@ -1674,20 +1647,16 @@ static int yh_q_overlap_stream(yh_db* db, const u64* d_sample, u64 n_sample, u32
     }
     u32 R;
     YH_TRY(ensure_reps(db, R));
-    const bool flags_too = flag_shared && db->d_sgidx;
+    const bool flags_too = flag_shared && db->has_index;
     if (flags_too) YH_TRY(claim_hit_flags(db));
     // No kernel in front of the streaming one: the counters it adds into are zero at rest, and every
     // workgroup finds its own range of the sample (two 64-ary wave searches while its first
     // super-block is in flight).
-    StreamHit sh{(u32)N, db->d_reps, R - 1, reinterpret_cast<u64x2*>(db->d_hitq), db->hitq_cap, db->d_svals, db->d_sref,
-                 db->d_sgidx, flags_too ? db->d_hit : nullptr, d_sample};
+    StreamHit sh{(u32)N, db->d_reps, R - 1, db->d_srec, flags_too ? db->d_hit : nullptr, d_sample};
     yh_ring_record_begin(db, db->ev_overlap);
     k_stream_lookup<<<wgs, STREAM_THREADS, 0, st>>>(reinterpret_cast<const u32x4*>(db->d_sdelta), db->d_shdr, nblk, d_sample,
-                                                    (u32)n_sample, db->d_wg_key, db->sshift, db->d_hitq_cnt, sh);
+                                                    (u32)n_sample, db->d_wg_key, db->sshift, sh);
     yh_ring_record_end(db, db->ev_overlap);
-#if !YH_STREAM_INPLACE
-    k_resolve_stream<<<wgs, 256, 0, st>>>(db->d_hitq_cnt, sh);
-#endif
     k_reduce_replicas<<<(u32)((N + 255) / 256), 256, 0, st>>>(db->d_reps, R, N, d_overlap, make_mask ? db->d_mask : nullptr,
                                                              make_mask ? db->d_maskbits : nullptr,
                                                              with_index ? db->d_excl_e : nullptr);
