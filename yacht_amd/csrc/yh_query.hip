@@ -994,19 +994,20 @@ __device__ __forceinline__ void load_group(const u32x4* __restrict__ deltas, con
 }
 
 // S: the tile's sample keys relative to Klo (32 bits, ~0 = sentinel); cur / hcur: the wave's first
-// group, already requested by the caller when `preloaded`
+// group, already requested by the caller when `preloaded`.  nb = blocks per super-block in this call
+// (STREAM_NB, or fewer whole groups when the range is short).
 __device__ __forceinline__ void stream_blocks(const u32x4* __restrict__ deltas, const u64* __restrict__ hdr, u64 bl0,
                                               u64 bl1, u32 sub, u32 n, u64 Klo, u64 Khi, u32 dsh, const u32* S,
                                               const u16* E, u32* INCw, u32* HBw, const StreamHit& hit,
-                                              const WaveQ& ctx, Pending& pend, bool preloaded, u32x4 (&cur)[STREAM_PF], u64& hcur) {
+                                              const WaveQ& ctx, Pending& pend, bool preloaded, u32 nb, u32x4 (&cur)[STREAM_PF], u64& hcur) {
     constexpr u32 WAVES = STREAM_THREADS / 64;
     constexpr int PF = STREAM_PF, NB = STREAM_NB;
     const u32 lane = threadIdx.x & 63u;
-    const u64 n_super = (bl1 - bl0 + NB - 1) / NB;
+    const u64 n_super = (bl1 - bl0 + nb - 1) / nb;
     u64 sb = (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform, and the compiler knows it
     for (; sb < n_super; sb += WAVES) {
-        const u64 b0 = bl0 + sb * NB;
-        const int nvalid = (int)min((u64)NB, bl1 - b0);
+        const u64 b0 = bl0 + sb * nb;
+        const int nvalid = (int)min((u64)nb, bl1 - b0);
         u32 hl[NB];  // last key of block i relative to base0 (scalar); invalid blocks: ~0
         u64 base0 = 0;
         u32 last_rel = 0;
@@ -1191,9 +1192,12 @@ k_stream_lookup(const u32x4* __restrict__ deltas, const u64* __restrict__ hdr, u
             while (lo < hi) { const u64 mid = (lo + hi) >> 1; if (hdr[mid] <= Khi) lo = mid + 1; else hi = mid; }
             bl1 = lo;
         }
+        // full super-blocks when every wave gets at least two of them, single groups otherwise (a tile of
+        // a multi-tile sample covers few blocks: with 16-block super-blocks half the waves would idle)
+        const u32 nb = (bl1 - bl0 >= 2ull * WAVES * STREAM_NB) ? (u32)STREAM_NB : (u32)STREAM_PF;
         if (bl0 < bl1)
             stream_blocks(deltas, hdr, bl0, bl1, sub, n, Klo, Khi, dsh, S, E, INC[wv], HB[wv], hit, ctx, pend,
-                          single && (u64)wv * STREAM_NB < B1 - B0, cur, hcur);
+                          single && nb == (u32)STREAM_NB && (u64)wv * STREAM_NB < B1 - B0, nb, cur, hcur);
         sub += n;
     }
     wave_flush(hit, ctx, pend);
