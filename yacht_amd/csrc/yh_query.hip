@@ -1651,6 +1651,9 @@ static int yh_q_overlap_stream(yh_db* db, const u64* d_sample, u64 n_sample, u32
     }
     u32 R;
     YH_TRY(ensure_reps(db, R));
+    // hits leave a workgroup pre-summed (one atomic per workgroup and reference), so few replicas do
+    static const u32 r_env = [] { const char* e = getenv("YH_STREAM_REPS"); return e ? (u32)atoi(e) : 4u; }();
+    while (R > 1 && R > r_env) R >>= 1;
     const bool flags_too = flag_shared && db->has_index;
     if (flags_too) YH_TRY(claim_hit_flags(db));
     // No kernel in front of the streaming one: the counters it adds into are zero at rest, and every
