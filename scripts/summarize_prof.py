@@ -51,7 +51,7 @@ if trace:
     rows = list(csv.DictReader(open(trace[0])))
     rows = [r for r in rows if any(t in r["Kernel_Name"] for t in OURS) or "Memset" in r["Kernel_Name"] or "fill" in r["Kernel_Name"].lower()]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    for tag, title in (("k_prep_stream", "streaming step"), ("k_prep(", "indexed step (k_index_lookup)")):
+    for tag, title in (("k_stream_lookup(", "streaming step"), ("k_index_lookup(", "indexed step (k_index_lookup)")):
         idx = [i for i, r in enumerate(rows) if tag in r["Kernel_Name"].replace("(anonymous namespace)::", "") + "("]
         if len(idx) < 3:
             continue
