@@ -6,7 +6,7 @@ every array) against a 10^7-hash sample.  Not a bench line: a maximum-size parit
     python scripts/scale_probe.py [--refs 50000] [--median 33000] [--sample 10000000] [--oracle auto|yes|no]
 
 Checks, all bit-exact:
-  * overlap from the key-stream kernel == overlap from k_overlap_bsearch (independent kernel over
+  * overlap from the streaming kernel == overlap from k_overlap_bsearch (independent kernel over
     the plain CSR) == a torch searchsorted count of the same thing;
   * overlap / exclusive counts == the CPU oracle, when the host has the memory for it (--oracle).
 Prints one JSON line with sizes, timings and the verdicts.
@@ -121,12 +121,12 @@ def main() -> int:
         got = out.cpu().numpy().view(np.uint32)
         oracle_ok = bool(np.array_equal(got[0], w_ov) and np.array_equal(got[1], w_e) and np.array_equal(got[2], w_m))
 
-    key_bytes = 3 * H + 8 * sample.numel()
+    key_bytes = int(info.get("stream_bytes", 3 * H)) + 8 * sample.numel()  # what the streaming kernel has to read
     k_ms = float(tm["ms_overlap_kernel"])
     res = {
         "workload": f"one GPU's shard of configs[4]: {n} references, {H} hashes (scaled=100), sample {sample.numel()} hashes",
         "positions_exceed_2^31": H > (1 << 31),
-        "partitions": info["n_partitions"], "db_hbm_bytes": info["device_bytes"],
+        "stream_layout": info.get("stream_layout"), "stream_bytes": info.get("stream_bytes"), "db_hbm_bytes": info["device_bytes"],
         "seconds": {"generate": round(t_gen, 2), "build": round(t_build, 3)},
         "ms_per_step": round(ms_step, 3), "queries_per_s": round(n / (ms_step / 1e3), 1),
         "k1_ms": round(k_ms, 4), "k1_GBps": round(key_bytes / 1e9 / (k_ms / 1e3), 1) if k_ms else None,
