@@ -70,3 +70,44 @@ def test_default_layout_is_the_delta_stream(hip_lib):
     env = {k: v for k, v in os.environ.items() if k not in ("YH_STREAM", "YH_WIDE_KEYS")}
     r = subprocess.run([sys.executable, "-c", code], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "layout 1" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+CHILD_WIDE_TILE = r"""
+import sys
+import numpy as np
+sys.path.insert(0, %r)
+from oracle import oracle
+from yacht_amd.engine import RefDB
+
+# One workgroup (YH_TILE_WGS=1) over a database whose truncated-key range exceeds 2^32: the sample keys
+# of a tile are staged as 32-bit offsets from its first key, so a tile must end where the offset would
+# overflow -- a sample of a few hashes at the two ends and in the middle of the range forces that.
+rng = np.random.default_rng(11)
+H = 70_000_000                       # the range of truncated keys is 32..64 x H: 4.4e9 needs ~62 x H
+top = int(4.4e9) << 31               # hashes uniform below this -> stream_shift 31, key range 4.4e9 > 2^32
+vals = np.unique(rng.integers(0, top, size=H, dtype=np.uint64))
+refs = [vals[0::2].copy(), vals[1::2].copy()]                 # two interleaved references
+values = np.concatenate(refs)
+offsets = np.array([0, refs[0].size, refs[0].size + refs[1].size], dtype=np.uint64)
+picks = np.concatenate([vals[:3], vals[vals.size // 2 - 1: vals.size // 2 + 2], vals[-3:]])
+sample = np.unique(np.concatenate([picks, np.array([5, top // 2 + 12345, top - 2, 2**64 - 2], dtype=np.uint64)]))
+with RefDB(values, offsets, flags=1) as db:                    # overlap only: no inverted index needed
+    info = db.info()
+    assert info["stream_layout"] == 1
+    span = int(vals[-1] >> info["stream_shift"]) - int(vals[0] >> info["stream_shift"])
+    assert span > 2**32, (span, info["stream_shift"])
+    got = db.overlap(sample)
+want = oracle.overlap(values, offsets, sample)
+assert np.array_equal(got, want), (got, want)
+assert int(want.sum()) >= 7
+print("wide tile ok", span, got.tolist())
+"""
+
+
+def test_tile_ends_where_32_bit_key_offsets_would_overflow(hip_lib):
+    env = dict(os.environ, YH_TILE_WGS="1")
+    env.pop("YH_STREAM", None)
+    env.pop("YH_WIDE_KEYS", None)
+    r = subprocess.run([sys.executable, "-c", CHILD_WIDE_TILE % ROOT], env=env, cwd=ROOT, capture_output=True,
+                       text=True, timeout=1200)
+    assert r.returncode == 0 and "wide tile ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
