@@ -173,7 +173,7 @@ struct yh_db {
     u32 n_chunks = 0;
     bool posting_only = false;        // yh_db_create_from_pairs: posting lists of a hash range, no sketches
     bool excl_prefer_stream = false;  // set by the host-mask entry point when most references are masked
-    // hash-sorted delta stream (YH_STREAM=delta; DESIGN.md "K1"): every (hash, reference)
+    // hash-sorted delta stream (the default layout; DESIGN.md "K1"): every (hash, reference)
     // pair of the database in ascending hash order, the hash truncated to t = hash >> sshift so that
     // consecutive t differ by ~50 on average, one BYTE per element = t minus its predecessor's t.
     // A gap above 255 is bridged by filler elements (delta 255, no reference).  Blocks of

@@ -1,13 +1,17 @@
 // yh_query.hip — the per-query kernels of libyacht_hip.so (gfx950 / CDNA4, wave64).
 //
-//   k_prep               sample slice bounds per partition + zeroing of every accumulator of a step
-//   k_tile_lookup_keys   the streaming membership kernel (HBM-bound; DESIGN.md "K1"): each workgroup
-//                        stages one hash-range slice of the SAMPLE in LDS (Bloom-filter bitmap +
-//                        sorted keys + bucket directory) and streams the packed 24-bit keys of the
-//                        reference hashes of that range past it; key matches are queued as candidates
-//   k_resolve_hits32     candidates -> confirmed against the 64-bit hashes -> summed per reference
-//                        in LDS -> replicated counters
-//   k_reduce_replicas    overlap counts (+ the subset mask as bytes and bits)
+//   k_stream_lookup      the streaming membership kernel of the default layout (DESIGN.md "K1"): all
+//                        (hash, reference) pairs in hash order, one delta byte each; a workgroup stages
+//                        the sample hashes of its key range in LDS, rebuilds the lanes' key spans of
+//                        16-block super-blocks (v_sad_u8 + DPP scans) and lets the sample keys probe
+//                        them, one per lane; candidates are confirmed against the 64-bit hash of
+//                        their position in the same kernel and summed per reference in LDS
+//   k_prep, k_tile_lookup_keys, k_resolve_hits32
+//                        the partition-major packed 24-bit key layout (YH_STREAM=keys): sample slice
+//                        bounds per partition; every stream key tested against a Bloom filter of the
+//                        sample slice in LDS; candidates confirmed and counted by a second kernel
+//   k_reduce_replicas    overlap counts from the replicated counters, which it clears (zero at rest);
+//                        + the subset mask as bytes and bits, + zeroed exclusive accumulators
 //   k_tile_lookup<Hit>   the same tile kernel over the 64-bit hashes (YH_WIDE_KEYS=1, and the
 //                        stand-alone shared-hash membership pass of posting-only handles)
 //   k_index_lookup       sample-driven alternative (YH_DB_FULL_INDEX): one lane per sample hash
