@@ -85,6 +85,19 @@ def test_every_hash_hits_and_subtiles(hip_lib):
         _check_all(refs, sample, partitions_hint=hint)
 
 
+def test_one_hash_in_hundreds_of_references(hip_lib):
+    """200 identical sketches + 50 that share half of it: one probe of the sample matches a run of up
+    to 250 equal stream elements -- more than a wave's candidate queue holds -- and the runs cross
+    lane, block and super-block boundaries."""
+    rng = np.random.default_rng(21)
+    core = synth.random_sketch(rng, 300, synth.max_hash_for_scaled(1000))
+    refs = [core.copy() for _ in range(200)] + [np.unique(np.concatenate([core[::2], synth.random_sketch(
+        rng, 150, synth.max_hash_for_scaled(1000))])) for _ in range(50)]
+    sample = np.unique(np.concatenate([core, synth.random_sketch(rng, 5000, synth.max_hash_for_scaled(1000))]))
+    _check_all(refs, sample)
+    _check_all(refs, core[::3].copy())
+
+
 def test_hash_extremes(hip_lib):
     """Hashes near 0 and 2**64-1 (scaled=1 sketches), sample hashes outside the database range."""
     rng = np.random.default_rng(4)
