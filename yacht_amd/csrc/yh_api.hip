@@ -567,6 +567,10 @@ int yh_run_device(yh_db* db, const uint64_t* d_sample, uint64_t n_sample, uint32
     if (!d_overlap || (n_sample && !d_sample)) { yh_set_error("null device pointer"); return YH_ERR_INVALID_ARG; }
     if ((d_n_excl == nullptr) != (d_n_match == nullptr)) { yh_set_error("pass both d_n_excl and d_n_match or neither"); return YH_ERR_INVALID_ARG; }
     YH_TRY(db_select(db));
+    if (d_n_excl) {  // three launches when the handle holds the hash-sorted stream
+        const int rc = yh_q_run_fused(db, (const u64*)d_sample, n_sample, d_overlap, d_n_excl, d_n_match);
+        if (rc != 1) return rc;
+    }
     YH_TRY(yh_q_overlap(db, (const u64*)d_sample, n_sample, d_overlap, d_n_excl != nullptr, d_n_excl != nullptr));
     if (!d_n_excl) return YH_OK;
     return yh_q_exclusive(db, db->d_mask, (const u64*)d_sample, n_sample, d_overlap, d_n_excl, d_n_match, true,

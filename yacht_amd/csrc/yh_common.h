@@ -241,6 +241,7 @@ bool yh_use_delta_stream();  // YH_STREAM=delta at handle creation (default: par
 
 // ---- implemented in yh_query.hip -------------------------------------------------------------
 int yh_q_overlap(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap, bool flag_shared, bool make_mask);
+int yh_q_run_fused(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap, u32* d_excl, u32* d_match);  // 1 = not applicable
 int yh_q_overlap_bsearch(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap);
 // ---- the distinct-hash directory as the lookup kernels see it -------------------------------------
 // Primary structure: a table of 64-byte buckets, bucket(h) = floor(h * bkt_nb / 2^bits(max_hash))

@@ -129,9 +129,23 @@ __global__ void __launch_bounds__(256) k_resolve_hits(const u32* __restrict__ qc
 // zeroing pass in front of the next query); optionally also the subset mask "overlap > 0" as bytes
 // and as bits (one ballot per wave: references 64w .. 64w+63 -> two words), and the zeroing of the
 // three exclusive accumulators [3][n] the kernels behind this one add into.
+// With `fused` (the `yacht run` step on the hash-sorted stream, where the subset is "overlap > 0"):
+// also the second replica set (hits on shared hashes), and the exclusive counts up to the part that
+// needs the posting lists: n_match[j] = overlap - hits on shared hashes (final: a shared hash found
+// in the sample has all its holders in the subset, so it is exclusive to none of them), n_excl[j] =
+// |R_j| - nshared_j for the subset (k_excl_chunks adds the shared hashes whose other holders are all
+// outside the subset).
+struct FusedRun {
+    u32* reps2;
+    const u32* sizes;
+    const u32* nshared;
+    u32* n_excl;
+    u32* n_match;
+};
 __global__ void __launch_bounds__(256) k_reduce_replicas(u32* __restrict__ reps, u32 R, u64 n,
                                                          u32* __restrict__ out, u8* __restrict__ mask,
-                                                         u32* __restrict__ maskbits, u32* __restrict__ excl3) {
+                                                         u32* __restrict__ maskbits, u32* __restrict__ excl3,
+                                                         FusedRun fused) {
     const u64 j = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     u32 acc = 0;
     if (j < n) {
@@ -142,6 +156,15 @@ __global__ void __launch_bounds__(256) k_reduce_replicas(u32* __restrict__ reps,
         out[j] = acc;
         if (mask) mask[j] = acc ? 1 : 0;
         if (excl3) { excl3[j] = 0; excl3[n + j] = 0; excl3[2 * n + j] = 0; }
+        if (fused.reps2) {
+            u32 acc2 = 0;
+            for (u32 r = 0; r < R; ++r) {
+                acc2 += fused.reps2[(u64)r * n + j];
+                fused.reps2[(u64)r * n + j] = 0;
+            }
+            fused.n_match[j] = acc - acc2;
+            fused.n_excl[j] = acc ? fused.sizes[j] - fused.nshared[j] : 0u;
+        }
     }
     if (maskbits) {
         const u64 bal = __ballot(acc != 0);
@@ -833,7 +856,8 @@ struct StreamHit {
     u32* reps;
     u32 rep_mask;
     const uint4* srec;  // per stream position: {hash lo, hash hi, reference, shared-hash index}
-    u8* hitflag;        // may be null (overlap only)
+    u8* hitflag;        // may be null: hit[g] = 1 for every shared hash g found in the sample
+    u32* reps2;         // may be null: a second set of replicas counting the hits ON SHARED HASHES only
     const u64* sample;
 };
 
@@ -861,21 +885,28 @@ struct WaveQ {
     u64x2* q;      // LDS: this wave's STREAM_WQ entries (x = stream position, y = sample index)
     u32 wg;
     u32* tkey;     // LDS: the workgroup's per-reference hit sums, STREAM_TSLOTS slots (reference + 1, 0 = empty)
-    u32* tcnt;
+    u32* tcnt;     // hits: low 16 bits of the slot's increments count all hits ...
+    u32* tcnt2;    // ... and this one the hits on shared hashes
 };
 // Confirmed hits are summed per reference in an LDS table of the workgroup and leave as ONE global
 // atomic per (workgroup, reference) when the workgroup ends: in hash order a reference's hits are
 // spread evenly over the workgroups, and same-address atomics are serialized in L2.
 constexpr u32 STREAM_TSLOTS = 512;
 static_assert(STREAM_TSLOTS == 1u << 9, "table_add hashes into 9 bits");
-__device__ __forceinline__ void table_add(const StreamHit& hit, const WaveQ& c, u32 ref) {
+__device__ __forceinline__ void table_add(const StreamHit& hit, const WaveQ& c, u32 ref, bool shared) {
     u32 slot = (ref * 2654435761u) >> (32 - 9);
 #pragma unroll 1
     for (int probe = 0; probe < 8; ++probe, slot = (slot + 1) & (STREAM_TSLOTS - 1)) {
         const u32 old = atomicCAS(&c.tkey[slot], 0u, ref + 1);
-        if (old == 0 || old == ref + 1) { atomicAdd(&c.tcnt[slot], 1u); return; }
+        if (old == 0 || old == ref + 1) {
+            atomicAdd(&c.tcnt[slot], 1u);
+            if (shared && hit.reps2) atomicAdd(&c.tcnt2[slot], 1u);
+            return;
+        }
     }
-    atomicAdd(&hit.reps[(u64)(c.wg & hit.rep_mask) * hit.n_refs + ref], 1u);  // crowded table: count directly
+    const u64 at = (u64)(c.wg & hit.rep_mask) * hit.n_refs + ref;  // crowded table: count directly
+    atomicAdd(&hit.reps[at], 1u);
+    if (shared && hit.reps2) atomicAdd(&hit.reps2[at], 1u);
 }
 struct Pending {  // one requested confirmation per lane
     uint4 rec = make_uint4(0u, 0u, STREAM_NONE, STREAM_NONE);
@@ -889,7 +920,7 @@ __device__ __forceinline__ void pending_count(const StreamHit& hit, const WaveQ&
     const u64 hv = ((u64)p.rec.y << 32) | p.rec.x;
     if (hv == p.sv && p.rec.z != STREAM_NONE) {  // (fillers have no reference)
         if (hit.hitflag && p.rec.w != STREAM_NONE) hit.hitflag[p.rec.w] = 1;
-        table_add(hit, c, p.rec.z);
+        table_add(hit, c, p.rec.z, p.rec.w != STREAM_NONE);
     }
     p.rec.z = STREAM_NONE;
 }
@@ -1135,13 +1166,14 @@ k_stream_lookup(const u32x4* __restrict__ deltas, const u64* __restrict__ hdr, u
     __shared__ u32 n_fit;
     __shared__ u32 tkey[STREAM_TSLOTS];
     __shared__ u32 tcnt[STREAM_TSLOTS];
+    __shared__ u32 tcnt2[STREAM_TSLOTS];
 
     const u32 tid = threadIdx.x;
     const u32 wv = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const u32 lid = xcd_remap(blockIdx.x, gridDim.x);
     const u64 per = (nblk + gridDim.x - 1) / gridDim.x;
     const u64 B0 = min((u64)lid * per, nblk), B1 = min(nblk, B0 + per);
-    const WaveQ ctx{&q_fill[wv], Q[wv], lid, tkey, tcnt};
+    const WaveQ ctx{&q_fill[wv], Q[wv], lid, tkey, tcnt, tcnt2};
     if (B0 >= B1) return;  // no blocks
     // The wave's first group is requested before anything else; while it is in flight, waves 0 and 1
     // find the workgroup's range of the sample and the tile is staged.  (With several tiles -- a
@@ -1154,7 +1186,7 @@ k_stream_lookup(const u32x4* __restrict__ deltas, const u64* __restrict__ hdr, u
         if ((tid & 63u) == 0) sbound[wv] = bnd;
     }
     if (tid < WAVES) q_fill[tid] = 0;
-    for (u32 k = tid; k < STREAM_TSLOTS; k += STREAM_THREADS) { tkey[k] = 0; tcnt[k] = 0; }
+    for (u32 k = tid; k < STREAM_TSLOTS; k += STREAM_THREADS) { tkey[k] = 0; tcnt[k] = 0; tcnt2[k] = 0; }
     __syncthreads();
     const u32 s0 = (u32)__builtin_amdgcn_readfirstlane((int)sbound[0]), s1 = (u32)__builtin_amdgcn_readfirstlane((int)sbound[1]);
     if (s0 >= s1) return;  // no sample hash in this range of t: nothing to look up
@@ -1207,9 +1239,12 @@ k_stream_lookup(const u32x4* __restrict__ deltas, const u64* __restrict__ hdr, u
     wave_flush(hit, ctx, pend);
     pending_count(hit, ctx, pend);  // the last batch: the one wait for confirmation reads the wave cannot hide
     __syncthreads();
-    u32* my = hit.reps + (u64)(lid & hit.rep_mask) * hit.n_refs;
+    const u64 my = (u64)(lid & hit.rep_mask) * hit.n_refs;
     for (u32 k = tid; k < STREAM_TSLOTS; k += STREAM_THREADS)
-        if (tkey[k]) atomicAdd(&my[tkey[k] - 1], tcnt[k]);
+        if (tkey[k]) {
+            atomicAdd(&hit.reps[my + tkey[k] - 1], tcnt[k]);
+            if (hit.reps2 && tcnt2[k]) atomicAdd(&hit.reps2[my + tkey[k] - 1], tcnt2[k]);
+        }
 }
 
 // ---- cross-check kernel: one wave per reference over the plain CSR -------------------------------
@@ -1408,7 +1443,7 @@ __global__ void __launch_bounds__(256) k_excl_chunks(u32 n_chunks, const uint2* 
         for (int u = 0; u < U; ++u) {
             q[u] = po[gi[u]];
             q1[u] = valid[u] ? po[gi[u] + 1] : q[u];  // an invalid lane has an empty holder list
-            in_sample[u] = valid[u] && hit[gi[u]] != 0;
+            in_sample[u] = hit && valid[u] && hit[gi[u]] != 0;  // (no flags: only the exclusive sums are wanted)
             cnt[u] = 0;
         }
         for (;;) {  // holders four at a time per chunk: 4 * U independent reads a step
@@ -1621,8 +1656,9 @@ static int ensure_reps(yh_db* db, u32& R) {
     if (db->reps_cap < (u64)R * N) {
         YH_HIP(hipStreamSynchronize(db->stream));
         if (db->d_reps) { (void)hipFree(db->d_reps); db->d_reps = nullptr; db->reps_cap = 0; }
-        YH_HIP(hipMalloc((void**)&db->d_reps, (u64)R * N * sizeof(u32) + 16));
-        YH_HIP(hipMemsetAsync(db->d_reps, 0, (u64)R * N * sizeof(u32) + 16, db->stream));
+        // (two sets back to back: the second one counts hits on shared hashes in the fused run step)
+        YH_HIP(hipMalloc((void**)&db->d_reps, 2 * (u64)R * N * sizeof(u32) + 16));
+        YH_HIP(hipMemsetAsync(db->d_reps, 0, 2 * (u64)R * N * sizeof(u32) + 16, db->stream));
         db->reps_cap = (u64)R * N;
     }
     return YH_OK;
@@ -1639,8 +1675,11 @@ static int claim_hit_flags(yh_db* db) {
 // flag_shared: also flag which database-shared hashes are in the sample (db->d_hit), fused into the
 // same launch; yh_q_exclusive_partial(..., hit_ready = true) then skips its own membership pass.
 // overlap through the hash-sorted delta stream (the default layout)
+// d_fused_excl / d_fused_match non-null: the whole `yacht run` step (subset = overlap > 0) in three
+// launches -- no shared-hash flags, no exclusive accumulators, no finalize kernel (k_reduce_replicas).
 static int yh_q_overlap_stream(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap, bool flag_shared,
-                               bool with_index, bool make_mask) {
+                               bool with_index, bool make_mask, u32* d_fused_excl = nullptr,
+                               u32* d_fused_match = nullptr) {
     hipStream_t st = db->stream;
     const u64 N = db->n_refs;
     const u64 nblk = db->slen / STREAM_BLOCK;
@@ -1658,19 +1697,22 @@ static int yh_q_overlap_stream(yh_db* db, const u64* d_sample, u64 n_sample, u32
     // hits leave a workgroup pre-summed (one atomic per workgroup and reference), so few replicas do
     static const u32 r_env = [] { const char* e = getenv("YH_STREAM_REPS"); return e ? (u32)atoi(e) : 4u; }();
     while (R > 1 && R > r_env) R >>= 1;
-    const bool flags_too = flag_shared && db->has_index;
+    const bool fused = d_fused_excl != nullptr;
+    const bool flags_too = flag_shared && db->has_index && !fused;
     if (flags_too) YH_TRY(claim_hit_flags(db));
     // No kernel in front of the streaming one: the counters it adds into are zero at rest, and every
     // workgroup finds its own range of the sample (two 64-ary wave searches while its first
     // super-block is in flight).
-    StreamHit sh{(u32)N, db->d_reps, R - 1, db->d_srec, flags_too ? db->d_hit : nullptr, d_sample};
+    u32* const reps2 = db->d_reps + db->reps_cap;
+    StreamHit sh{(u32)N, db->d_reps, R - 1, db->d_srec, flags_too ? db->d_hit : nullptr, fused ? reps2 : nullptr, d_sample};
     yh_ring_record_begin(db, db->ev_overlap);
     k_stream_lookup<<<wgs, STREAM_THREADS, 0, st>>>(reinterpret_cast<const u32x4*>(db->d_sdelta), db->d_shdr, nblk, d_sample,
                                                     (u32)n_sample, db->d_wg_key, db->sshift, sh);
     yh_ring_record_end(db, db->ev_overlap);
-    k_reduce_replicas<<<(u32)((N + 255) / 256), 256, 0, st>>>(db->d_reps, R, N, d_overlap, make_mask ? db->d_mask : nullptr,
-                                                             make_mask ? db->d_maskbits : nullptr,
-                                                             with_index ? db->d_excl_e : nullptr);
+    k_reduce_replicas<<<(u32)((N + 255) / 256), 256, 0, st>>>(
+        db->d_reps, R, N, d_overlap, (make_mask && !fused) ? db->d_mask : nullptr, make_mask ? db->d_maskbits : nullptr,
+        (with_index && !fused) ? db->d_excl_e : nullptr,
+        fused ? FusedRun{reps2, db->d_sizes, db->d_nshared, d_fused_excl, d_fused_match} : FusedRun{});
     YH_HIP(hipGetLastError());
     return YH_OK;
 }
@@ -1729,7 +1771,7 @@ int yh_q_overlap(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap, b
         k_resolve_hits32<<<wgs, 256, 0, st>>>(db->d_hitq_cnt, nh);
         k_reduce_replicas<<<(u32)((N + 255) / 256), 256, 0, st>>>(db->d_reps, R, N, d_overlap, make_mask ? db->d_mask : nullptr,
                                                                  make_mask ? db->d_maskbits : nullptr,
-                                                                 with_index ? db->d_excl_e : nullptr);
+                                                                 with_index ? db->d_excl_e : nullptr, FusedRun{});
         YH_HIP(hipGetLastError());
         return YH_OK;
     }
@@ -1744,7 +1786,25 @@ int yh_q_overlap(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap, b
     k_resolve_hits<<<wgs, 256, 0, st>>>(db->d_hitq_cnt, hit);
     k_reduce_replicas<<<(u32)((N + 255) / 256), 256, 0, st>>>(db->d_reps, R, N, d_overlap, make_mask ? db->d_mask : nullptr,
                                                              make_mask ? db->d_maskbits : nullptr,
-                                                             with_index ? db->d_excl_e : nullptr);
+                                                             with_index ? db->d_excl_e : nullptr, FusedRun{});
+    YH_HIP(hipGetLastError());
+    return YH_OK;
+}
+
+// The `yacht run` step on the hash-sorted stream: overlap, subset = overlap > 0, exclusive counts.
+// Returns 1 when this handle cannot take the fused path (the caller then runs the general one).
+int yh_q_run_fused(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap, u32* d_excl, u32* d_match) {
+    static const bool off = [] { const char* e = getenv("YH_NO_FUSED_RUN"); return e && e[0] == '1'; }();
+    if (off || !db->d_sdelta || !db->has_index || db->posting_only || !db->d_chunks || db->n_refs == 0 ||
+        db->n_hashes == 0 || n_sample == 0 || n_sample > 0xfffffff0ull)
+        return 1;
+    hipStream_t st = db->stream;
+    YH_TRY(yh_q_overlap_stream(db, d_sample, n_sample, d_overlap, true, true, true, d_excl, d_match));
+    yh_ring_record_begin(db, db->ev_excl);
+    if (db->n_chunks)  // + the shared hashes of the subset's references whose other holders are all outside it
+        k_excl_chunks<<<(db->n_chunks + 255) / 256, 256, 0, st>>>(db->n_chunks, db->d_chunks, db->d_rpo, db->d_rg, db->d_po,
+                                                             db->d_pr, db->d_maskbits, nullptr, d_excl, nullptr, nullptr);
+    yh_ring_record_end(db, db->ev_excl);
     YH_HIP(hipGetLastError());
     return YH_OK;
 }
@@ -1772,7 +1832,7 @@ int yh_q_overlap_indexed(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_ov
     k_reduce_replicas<<<(u32)((N + 255) / 256), 256, 0, st>>>(db->d_reps, R, N, d_overlap,
                                                              for_exclusive ? db->d_mask : nullptr,
                                                              for_exclusive ? db->d_maskbits : nullptr,
-                                                             for_exclusive ? db->d_excl_e : nullptr);
+                                                             for_exclusive ? db->d_excl_e : nullptr, FusedRun{});
     YH_HIP(hipGetLastError());
     return YH_OK;
 }
