@@ -368,11 +368,29 @@ __global__ void k_chunk_counts(const u32* __restrict__ nshared, u64 n, u32* __re
     const u64 r = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     if (r < n) cc[r] = (nshared[r] + 63u) >> 6;
 }
-__global__ void k_fill_rg(u64 n_post, const u32* __restrict__ pr, const u32* __restrict__ pg,
-                          const u32* __restrict__ rpo, u32* __restrict__ cursor, u32* __restrict__ rg) {
+// rrec (layout: yh_common.h): the OTHER holders of the posting's hash next to it, so that the fused
+// run step reaches them in one read instead of three dependent ones (rg -> po -> pr).
+__global__ void k_fill_rg(u64 n_post, const u32* __restrict__ pr, const u32* __restrict__ pg, const u64* __restrict__ po,
+                          const u32* __restrict__ rpo, u32* __restrict__ cursor, u32* __restrict__ rg,
+                          uint4* __restrict__ rrec) {
     for (u64 k = blockIdx.x * (u64)blockDim.x + threadIdx.x; k < n_post; k += (u64)gridDim.x * blockDim.x) {
-        const u32 r = pr[k];
-        rg[rpo[r] + atomicAdd(&cursor[r], 1u)] = pg[k];  // order inside a reference is irrelevant (sums)
+        const u32 r = pr[k], g = pg[k];
+        const u32 dst = rpo[r] + atomicAdd(&cursor[r], 1u);  // order inside a reference is irrelevant (sums)
+        rg[dst] = g;
+        if (rrec) {
+            const u64 q0 = po[g], q1 = po[g + 1];
+            uint4 rec = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0u);
+            if (q1 - q0 <= 4) {  // up to three other holders: inline
+                u32 o[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};
+                u32 n = 0;
+                for (u64 q = q0; q < q1; ++q)
+                    if (q != k) o[n++] = pr[q];
+                rec = make_uint4(o[0], o[1], o[2], n);
+            } else {             // a longer list: where it is
+                rec = make_uint4((u32)q0, (u32)(q1 - q0), 0u, 0xffffffffu);
+            }
+            rrec[dst] = rec;
+        }
     }
 }
 // record = reference | first posting << 32; key = (the chunk's number inside its reference, a hash of
@@ -755,6 +773,7 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, const u
             size_t st_bytes = 0;
             rc = yh_dmalloc(db, (void**)&db->d_rpo, (N + 1) * sizeof(u32));
             if (rc == YH_OK) rc = yh_dmalloc(db, (void**)&db->d_rg, db->n_postings * sizeof(u32));
+            if (rc == YH_OK && want_stream) rc = yh_dmalloc(db, (void**)&db->d_rrec, (db->n_postings + 1) * sizeof(uint4));
             IDX_HIP(hipMalloc((void**)&d_cc, N * sizeof(u32)));
             IDX_HIP(hipMalloc((void**)&d_cpo, (N + 1) * sizeof(u32)));
             IDX_HIP(hipMalloc((void**)&d_cur, N * sizeof(u32)));
@@ -779,8 +798,8 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, const u
             IDX_HIP(hipMalloc((void**)&d_ck, std::max<u64>(n_chunks, 1) * sizeof(u64)));
             IDX_HIP(hipMalloc((void**)&d_ck2, std::max<u64>(n_chunks, 1) * sizeof(u64)));
             if (rc == YH_OK) {
-                k_fill_rg<<<grid_for(db->n_postings, 256), 256, 0, st>>>(db->n_postings, db->d_pr, db->d_pg, db->d_rpo, d_cur,
-                                                                         db->d_rg);
+                k_fill_rg<<<grid_for(db->n_postings, 256), 256, 0, st>>>(db->n_postings, db->d_pr, db->d_pg, db->d_po, db->d_rpo,
+                                                                         d_cur, db->d_rg, db->d_rrec);
                 k_fill_chunks<<<(u32)((N + 255) / 256), 256, 0, st>>>(N, db->d_rpo, d_cpo, d_crec, d_ck);
             }
             IDX_HIP(hipGetLastError());

@@ -170,6 +170,8 @@ struct yh_db {
     u32* d_rpo = nullptr;      // [N + 1] first posting of reference r in d_rg
     u32* d_rg = nullptr;       // [n_postings] shared-hash index, grouped by reference
     uint2* d_chunks = nullptr; // [n_chunks] (reference, first posting in d_rg)
+    uint4* d_rrec = nullptr;   // [n_postings] beside d_rg (stream layout): the other holders of the posting's hash,
+                               // {o0, o1, o2, count <= 3} or {first index in d_pr, holders, 0, ~0} for longer lists
     u32 n_chunks = 0;
     bool posting_only = false;        // yh_db_create_from_pairs: posting lists of a hash range, no sketches
     bool excl_prefer_stream = false;  // set by the host-mask entry point when most references are masked

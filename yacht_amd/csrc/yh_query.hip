@@ -1481,6 +1481,66 @@ __global__ void __launch_bounds__(256) k_excl_chunks(u32 n_chunks, const uint2* 
     }
 }
 
+// The fused run step's form: only the exclusive sums (no sample membership), through d_rrec -- the
+// other holders of a posting's hash sit next to it, so a chunk is chunk record -> own mask bit ->
+// {limit, holder record} -> the holders' mask words -> one atomic: five dependent reads instead of
+// eight.  ex_e[r] += shared hashes of r none of whose other holders is in the subset.
+__global__ void __launch_bounds__(256) k_excl_chunks_e(u32 n_chunks, const uint2* __restrict__ chunks,
+                                                       const u32* __restrict__ rpo, const uint4* __restrict__ rrec,
+                                                       u32 n_post, const u32* __restrict__ pr,
+                                                       const u32* __restrict__ maskbits, u32* __restrict__ ex_e) {
+    const u32 lane = threadIdx.x & 63u;
+    const u32 c = (u32)((blockIdx.x * (u64)blockDim.x + threadIdx.x));  // this lane's record
+    uint2 mine = make_uint2(0u, 0u);
+    bool want = false;
+    if (c < n_chunks) {
+        mine = chunks[c];
+        want = (maskbits[mine.x >> 5] >> (mine.x & 31u)) & 1u;
+    }
+    constexpr int U = EXCL_U;
+    u64 todo = __ballot(want);
+    while (todo) {
+        u32 r[U], k[U], lim[U];
+        bool on[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            on[u] = todo != 0;
+            const int src = on[u] ? __ffsll((long long)todo) - 1 : 0;
+            todo &= todo - 1;  // (0 stays 0)
+            r[u] = (u32)__shfl((int)mine.x, src);
+            k[u] = (u32)__shfl((int)mine.y, src) + lane;
+        }
+        uint4 rec[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            lim[u] = on[u] ? rpo[r[u] + 1] : 0u;
+            rec[u] = rrec[min(k[u], n_post - 1)];  // (read before the limit is known: clamped)
+        }
+        u32 others[U];  // holders other than r that are in the subset
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool valid = k[u] < lim[u];
+            const bool inl = rec[u].w != 0xffffffffu;
+            const u32 h0 = rec[u].x, h1 = rec[u].y, h2 = rec[u].z;
+            const u32 n = (valid && inl) ? rec[u].w : 0u;
+            const u32 m0 = n > 0 ? maskbits[h0 >> 5] : 0u, m1 = n > 1 ? maskbits[h1 >> 5] : 0u,
+                      m2 = n > 2 ? maskbits[h2 >> 5] : 0u;
+            others[u] = ((m0 >> (h0 & 31u)) & 1u) + ((m1 >> (h1 & 31u)) & 1u) + ((m2 >> (h2 & 31u)) & 1u);
+            if (valid && !inl) {  // a long holder list (rare): walk it, r itself included
+                u32 cnt = 0;
+                const u64 q0 = rec[u].x, q1 = q0 + rec[u].y;
+                for (u64 q = q0; q < q1; ++q) {
+                    const u32 h = pr[q];
+                    cnt += (maskbits[h >> 5] >> (h & 31u)) & 1u;
+                }
+                others[u] = cnt - 1;
+            }
+            const u32 ne = (u32)__popcll(__ballot(valid && others[u] == 0));
+            if (lane == 0 && on[u] && ne) atomicAdd(&ex_e[r[u]], ne);
+        }
+    }
+}
+
 // e_j = (hashes of j that no other reference of the whole database has) + ex_e[j]
 // m_j = (overlap_j - overlap restricted to database-shared hashes)      + ex_m[j]
 __global__ void k_excl_final(u64 n, const u8* __restrict__ mask, const u32* __restrict__ sizes,
@@ -1795,15 +1855,15 @@ int yh_q_overlap(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap, b
 // Returns 1 when this handle cannot take the fused path (the caller then runs the general one).
 int yh_q_run_fused(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap, u32* d_excl, u32* d_match) {
     static const bool off = [] { const char* e = getenv("YH_NO_FUSED_RUN"); return e && e[0] == '1'; }();
-    if (off || !db->d_sdelta || !db->has_index || db->posting_only || !db->d_chunks || db->n_refs == 0 ||
+    if (off || !db->d_sdelta || !db->has_index || db->posting_only || !db->d_chunks || !db->d_rrec || db->n_refs == 0 ||
         db->n_hashes == 0 || n_sample == 0 || n_sample > 0xfffffff0ull)
         return 1;
     hipStream_t st = db->stream;
     YH_TRY(yh_q_overlap_stream(db, d_sample, n_sample, d_overlap, true, true, true, d_excl, d_match));
     yh_ring_record_begin(db, db->ev_excl);
     if (db->n_chunks)  // + the shared hashes of the subset's references whose other holders are all outside it
-        k_excl_chunks<<<(db->n_chunks + 255) / 256, 256, 0, st>>>(db->n_chunks, db->d_chunks, db->d_rpo, db->d_rg, db->d_po,
-                                                             db->d_pr, db->d_maskbits, nullptr, d_excl, nullptr, nullptr);
+        k_excl_chunks_e<<<(db->n_chunks + 255) / 256, 256, 0, st>>>(db->n_chunks, db->d_chunks, db->d_rpo, db->d_rrec,
+                                                               (u32)db->n_postings, db->d_pr, db->d_maskbits, d_excl);
     yh_ring_record_end(db, db->ev_excl);
     YH_HIP(hipGetLastError());
     return YH_OK;
