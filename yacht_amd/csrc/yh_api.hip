@@ -425,7 +425,8 @@ int yh_run_indexed_device(yh_db* db, const uint64_t* d_sample, uint64_t n_sample
     if (!db_ok(db)) return YH_ERR_INVALID_ARG;
     if (!d_overlap || !d_n_excl || !d_n_match || (n_sample && !d_sample)) { yh_set_error("null device pointer"); return YH_ERR_INVALID_ARG; }
     YH_TRY(db_select(db));
-    YH_TRY(yh_q_overlap_indexed(db, (const u64*)d_sample, n_sample, d_overlap, true));
+    const int rc = yh_q_overlap_indexed(db, (const u64*)d_sample, n_sample, d_overlap, true, d_n_excl, d_n_match);
+    if (rc != YH_OK) return rc == 2 ? YH_OK : rc;
     return yh_q_exclusive(db, db->d_mask, (const u64*)d_sample, n_sample, d_overlap, d_n_excl, d_n_match, true,
                           db->d_maskbits);
 }

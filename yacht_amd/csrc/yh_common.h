@@ -300,7 +300,8 @@ inline YhDirView yh_dir_view(const yh_db* db) {
 }
 #endif
 
-int yh_q_overlap_indexed(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap, bool for_exclusive);
+int yh_q_overlap_indexed(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap, bool for_exclusive,
+                         u32* d_fused_excl = nullptr, u32* d_fused_match = nullptr);  // returns 2 when it did the exclusive counts too
 int yh_q_run_batch(yh_db* db, const u64* d_samples, const u64* d_soff, u32 n_samples, u64 total_hashes,
                    u32* d_overlap, u32* d_excl, u32* d_match);
 int yh_q_exclusive(yh_db* db, const u8* d_mask, const u64* d_sample, u64 n_sample,

@@ -1284,8 +1284,9 @@ __global__ void __launch_bounds__(256) k_overlap_bsearch(const u64* __restrict__
 __global__ void __launch_bounds__(256) k_index_lookup(const u64* __restrict__ sample, u64 n, const YhDirView dv,
                                                       const u64* __restrict__ po, const u32* __restrict__ pr,
                                                       u32* __restrict__ reps, u32 rep_mask, u64 n_refs,
-                                                      u8* __restrict__ hit) {
+                                                      u8* __restrict__ hit, u32* __restrict__ reps2) {
     u32* my = reps + (u64)(blockIdx.x & rep_mask) * n_refs;
+    u32* my2 = reps2 ? reps2 + (u64)(blockIdx.x & rep_mask) * n_refs : nullptr;  // hits on shared hashes (fused run)
     for (u64 t = blockIdx.x * (u64)blockDim.x + threadIdx.x; t < n; t += (u64)gridDim.x * blockDim.x) {
         const u32 r = dv.find(sample[t]);
         if (r == YH_DIR_NONE) continue;
@@ -1294,7 +1295,11 @@ __global__ void __launch_bounds__(256) k_index_lookup(const u64* __restrict__ sa
         } else {
             const u32 gi = r & 0x7fffffffu;
             if (hit) hit[gi] = 1;
-            for (u64 q = po[gi], qe = po[gi + 1]; q < qe; ++q) atomicAdd(&my[pr[q]], 1u);
+            for (u64 q = po[gi], qe = po[gi + 1]; q < qe; ++q) {
+                const u32 h = pr[q];
+                atomicAdd(&my[h], 1u);
+                if (my2) atomicAdd(&my2[h], 1u);
+            }
         }
     }
 }
@@ -1871,7 +1876,9 @@ int yh_q_run_fused(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap,
 
 // overlap (and, with for_exclusive, the shared-hash flags, the subset mask and zeroed exclusive
 // accumulators) through the directory; same outputs as yh_q_overlap(..., flag_shared, make_mask)
-int yh_q_overlap_indexed(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap, bool for_exclusive) {
+// d_fused_excl / d_fused_match non-null: the whole run step in three launches (see yh_q_run_fused)
+int yh_q_overlap_indexed(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap, bool for_exclusive,
+                         u32* d_fused_excl, u32* d_fused_match) {
     if (!(db->flags & YH_DB_FULL_INDEX) || !db->has_index) {
         yh_set_error("this handle was created without YH_DB_FULL_INDEX");
         return YH_ERR_UNSUPPORTED;
@@ -1881,20 +1888,32 @@ int yh_q_overlap_indexed(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_ov
     if (N == 0) return YH_OK;
     u32 R;
     YH_TRY(ensure_reps(db, R));
-    if (for_exclusive && db->n_shared) YH_TRY(claim_hit_flags(db));
+    static const bool fused_off = [] { const char* e = getenv("YH_NO_FUSED_RUN"); return e && e[0] == '1'; }();
+    const bool fused = d_fused_excl && for_exclusive && db->d_chunks && db->d_rrec && !fused_off;
+    if (for_exclusive && db->n_shared && !fused) YH_TRY(claim_hit_flags(db));
+    u32* const reps2 = db->d_reps + db->reps_cap;
     // (no kernel in front of the lookup: the counters are zero at rest)
     yh_ring_record_begin(db, db->ev_overlap);
     if (n_sample && db->n_distinct)
         k_index_lookup<<<grid_for(n_sample, 256, 4096), 256, 0, st>>>(d_sample, n_sample, yh_dir_view(db), db->d_po, db->d_pr,
                                                                       db->d_reps, R - 1, N,
-                                                                      (for_exclusive && db->n_shared) ? db->d_hit : nullptr);
+                                                                      (for_exclusive && db->n_shared && !fused) ? db->d_hit : nullptr,
+                                                                      fused ? reps2 : nullptr);
     yh_ring_record_end(db, db->ev_overlap);
-    k_reduce_replicas<<<(u32)((N + 255) / 256), 256, 0, st>>>(db->d_reps, R, N, d_overlap,
-                                                             for_exclusive ? db->d_mask : nullptr,
-                                                             for_exclusive ? db->d_maskbits : nullptr,
-                                                             for_exclusive ? db->d_excl_e : nullptr, FusedRun{});
+    k_reduce_replicas<<<(u32)((N + 255) / 256), 256, 0, st>>>(
+        db->d_reps, R, N, d_overlap, (for_exclusive && !fused) ? db->d_mask : nullptr,
+        for_exclusive ? db->d_maskbits : nullptr, (for_exclusive && !fused) ? db->d_excl_e : nullptr,
+        fused ? FusedRun{reps2, db->d_sizes, db->d_nshared, d_fused_excl, d_fused_match} : FusedRun{});
+    if (fused) {
+        yh_ring_record_begin(db, db->ev_excl);
+        if (db->n_chunks)
+            k_excl_chunks_e<<<(db->n_chunks + 255) / 256, 256, 0, st>>>(db->n_chunks, db->d_chunks, db->d_rpo, db->d_rrec,
+                                                                   (u32)db->n_postings, db->d_pr, db->d_maskbits,
+                                                                   d_fused_excl);
+        yh_ring_record_end(db, db->ev_excl);
+    }
     YH_HIP(hipGetLastError());
-    return YH_OK;
+    return fused ? 2 : YH_OK;  // 2: the exclusive counts are done too
 }
 
 int yh_q_overlap_bsearch(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap) {
