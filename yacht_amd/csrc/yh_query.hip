@@ -1230,7 +1230,10 @@ k_stream_lookup(const u32x4* __restrict__ deltas, const u64* __restrict__ hdr, u
         }
         // full super-blocks when every wave gets at least two of them, single groups otherwise (a tile of
         // a multi-tile sample covers few blocks: with 16-block super-blocks half the waves would idle)
-        const u32 nb = (bl1 - bl0 >= 2ull * WAVES * STREAM_NB) ? (u32)STREAM_NB : (u32)STREAM_PF;
+        // ... and fewer blocks still when the range is so short that whole groups would leave waves idle
+        // (a small database against a big sample: the probes, not the stream, are the work to spread)
+        const u32 nb = (bl1 - bl0 >= 2ull * WAVES * STREAM_NB) ? (u32)STREAM_NB
+                       : (u32)min((u64)STREAM_PF, max((bl1 - bl0) / WAVES, (u64)1));
         if (bl0 < bl1)
             stream_blocks(deltas, hdr, bl0, bl1, sub, n, Klo, Khi, dsh, S, E, INC[wv], HB[wv], hit, ctx, pend,
                           single && nb == (u32)STREAM_NB && (u64)wv * STREAM_NB < B1 - B0, nb, cur, hcur);
@@ -1748,8 +1751,8 @@ static int yh_q_overlap_stream(yh_db* db, const u64* d_sample, u64 n_sample, u32
     hipStream_t st = db->stream;
     const u64 N = db->n_refs;
     const u64 nblk = db->slen / STREAM_BLOCK;
-    u32 wgs = tile_grid(db->slen);
-    if ((u64)wgs > nblk) wgs = (u32)std::max<u64>(nblk, 1);
+    // (a workgroup's set-up is two wave searches and a few KB of LDS: two blocks are enough to pay for it)
+    u32 wgs = (u32)std::min<u64>(tile_grid(~0ull), std::max<u64>(nblk / 2, 1));
     if (db->wg_key_n != wgs) {  // the first t of every workgroup's block range: once per handle
         YH_HIP(hipStreamSynchronize(st));
         if (db->d_wg_key) { (void)hipFree(db->d_wg_key); db->d_wg_key = nullptr; }
