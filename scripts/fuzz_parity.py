@@ -1,0 +1,110 @@
+#!/usr/bin/env python3
+"""Randomized parity run on the GPU box: HIP path vs the CPU oracle over many shapes.
+
+    python scripts/fuzz_parity.py [--seconds 300] [--seed 0]
+
+Every round draws a database shape (number of references, sketch sizes, clusters that share
+hashes, hash range from a few thousand values to the full 64 bits, duplicates of whole sketches,
+empty sketches) and a sample (noise, hits, the union of everything, nothing), and compares
+overlap, the run step's exclusive counts (fused path), exclusive counts for an arbitrary subset
+(general path), the independent bsearch kernel and -- on small rounds -- the pairwise list with
+the oracle, bit for bit.  Prints one JSON line; exit code 1 on the first difference.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from oracle import oracle  # noqa: E402  (the checker)
+from yacht_amd import synth  # noqa: E402
+from yacht_amd.engine import RefDB, YH_DB_KEEP_CSR  # noqa: E402
+
+
+def draw(rng):
+    n_refs = int(rng.choice([1, 2, 7, 64, 300, 1500, 6000]))
+    top_bits = int(rng.choice([13, 20, 34, 54, 64]))
+    top = (1 << top_bits) - 1
+    median = float(rng.choice([3, 40, 400, 3000]))
+    median = min(median, max(1.0, top / 4))
+    refs = []
+    while len(refs) < n_refs:
+        kind = rng.random()
+        size = int(np.clip(rng.lognormal(np.log(median), 0.7), 0, min(20000, top // 2)))
+        base = np.unique(rng.integers(0, top, size=size, dtype=np.uint64, endpoint=True))
+        refs.append(base)
+        if kind < 0.25 and base.size:  # a cluster around it
+            for _ in range(int(rng.integers(1, 6))):
+                keep = base[rng.random(base.size) < rng.choice([1.0, 0.9, 0.5, 0.1])]
+                extra = np.unique(rng.integers(0, top, size=int(rng.integers(0, max(2, size // 3))), dtype=np.uint64,
+                                               endpoint=True))
+                refs.append(np.unique(np.concatenate([keep, extra])))
+        elif kind < 0.30:
+            refs.append(np.zeros(0, np.uint64))
+    refs = refs[:n_refs]
+    values, offsets = synth.pack(refs)
+    allh = np.unique(values) if values.size else values
+    mode = rng.random()
+    noise = np.unique(rng.integers(0, top, size=int(rng.choice([0, 10, 1000, 50000])), dtype=np.uint64, endpoint=True))
+    if mode < 0.15 or allh.size == 0:
+        sample = noise
+    elif mode < 0.3:
+        sample = np.unique(np.concatenate([allh, noise]))
+    else:
+        present = rng.random(len(refs)) < rng.choice([0.01, 0.1, 0.5])
+        parts = [r[rng.random(r.size) < rng.choice([0.05, 0.5, 1.0])] for r, p in zip(refs, present) if p and r.size]
+        sample = np.unique(np.concatenate(parts + [noise])) if parts else noise
+    return refs, values, offsets, sample, top_bits
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=300.0)
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args()
+    rng = np.random.default_rng(args.seed)
+    t_end = time.time() + args.seconds
+    rounds = 0
+    hashes = 0
+    c = 0.95 ** 31
+    while time.time() < t_end:
+        refs, values, offsets, sample, top_bits = draw(rng)
+        n = len(refs)
+        sizes = np.diff(offsets).astype(np.uint32)
+        tag = {"round": rounds, "n_refs": n, "n_hashes": int(values.size), "n_sample": int(sample.size), "top_bits": top_bits}
+        try:
+            with RefDB(values, offsets, flags=YH_DB_KEEP_CSR) as db:
+                want = oracle.overlap(values, offsets, sample)
+                assert np.array_equal(db.overlap(sample), want), "overlap"
+                assert np.array_equal(db.overlap(sample, method="bsearch"), want), "bsearch overlap"
+                we, wm = oracle.exclusive(values, offsets, want > 0, sample)
+                ov, e, m = db.run_counts(sample)
+                assert np.array_equal(ov, want) and np.array_equal(e, we) and np.array_equal(m, wm), "run counts"
+                mask = rng.random(n) < 0.5
+                we, wm = oracle.exclusive(values, offsets, mask, sample)
+                ge, gm = db.exclusive(mask, sample)
+                assert np.array_equal(ge, we) and np.array_equal(gm, wm), "exclusive for a subset"
+                if values.size < 400_000:
+                    wi, wj, wc, wstats = oracle.train_pairs(values, offsets, c, threads=4)
+                    gi, gj, gc = db.pairwise(c)
+                    assert np.array_equal(gi, wi) and np.array_equal(gj, wj) and np.array_equal(gc, wc), "pairs"
+                    assert db.index_stats() == wstats, "index stats"
+        except AssertionError as ex:
+            print(json.dumps({"fuzz": "FAILED", "what": str(ex), **tag, "seed": args.seed}), flush=True)
+            np.savez("gpurun_out/fuzz_failure.npz", values=values, offsets=offsets, sample=sample)
+            return 1
+        rounds += 1
+        hashes += int(values.size)
+    print(json.dumps({"fuzz": "ok", "rounds": rounds, "reference_hashes_checked": hashes, "seconds": args.seconds,
+                      "seed": args.seed}), flush=True)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
