@@ -1,4 +1,4 @@
-# usage (GPU box): bash scripts/sweep_delta.sh "<variants>" "<YH_TILE_WGS values>"  -- the default (delta stream) layout, whole step
+# usage (GPU box): bash scripts/sweep_step.sh "<variants>" "<YH_TILE_WGS values>"  -- the default (delta stream) layout, whole step
 for v in ${1:-base}; do
   if [ "$v" = base ]; then L=$PWD/yacht_amd/lib/libyacht_hip.so; else L=$PWD/yacht_amd/lib/libyacht_hip_$v.so; fi
   for w in ${2:-512}; do
