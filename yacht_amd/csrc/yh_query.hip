@@ -987,29 +987,31 @@ __device__ __forceinline__ u32 wave_bound(const u64* __restrict__ sample, u32 n,
     return lo + (u32)__popcll(__ballot(p));
 }
 
-// A wave takes the stream in super-blocks of STREAM_NB = STREAM_PF x STREAM_GROUPS consecutive blocks
-// (16 KB of delta bytes).  Per super-block:
-//   1. group by group (STREAM_PF blocks = one register set of 16-byte vectors, 8 KB per request):
-//      every block's lane spans -- byte sums (v_sad_u8) + the PF wave scans side by side (DPP) --
-//      written to LDS (INC), the blocks' first and last keys to HB / scalar registers;
+// A wave takes the stream in super-blocks of STREAM_NB = STREAM_PF x STREAM_GROUPS = 16 consecutive
+// blocks (16 KB of delta bytes).  Per super-block:
+//   1. four groups of 4 blocks through two register sets of 16-byte vectors (groups 0 and 1 requested
+//      together, group g + 2 when group g's registers have been summed): every block's lane spans
+//      -- byte sums (v_sad_u8) + the group's wave scans side by side (DPP) -- written to LDS (INC),
+//      the blocks' first and last keys to HB / scalar registers;
 //   2. the sample keys inside the super-block's key range, ONE PER LANE (~49 of 64 lanes busy for a
 //      10^6-hash sample against 3.3 x 10^8 hashes): which block (scalar compares), which lane of it
 //      (6-step binary search in INC), that lane's 16 delta bytes again (a 16-byte read that hits L2)
 //      and a 16-step compare.
-// The next group is requested only when the registers are free again (no second register set: 76
-// VGPRs, 6 waves per SIMD hide the latency), so the probes' L2 reads never queue behind a prefetch
-// (vmcnt is in order).  The kernel is bound by instruction issue, not by HBM: what counts is
-// instructions per element -- one probe at a time: 0.19; lane-parallel over 8 blocks: 0.063; over 16: see DESIGN.md.
+// Nothing of the NEXT super-block is requested before this one is probed, so the probes' L2 reads
+// never queue behind a prefetch (vmcnt is in order).  89 VGPRs.  The kernel is bound by the latency
+// of this chain at 4 waves per SIMD, not by instruction issue and not by HBM.
 #ifndef YH_STREAM_PF
-#define YH_STREAM_PF 8
+#define YH_STREAM_PF 4
 #endif
 #ifndef YH_STREAM_GROUPS
-#define YH_STREAM_GROUPS 2
+#define YH_STREAM_GROUPS 4
 #endif
+
 constexpr int STREAM_PF = YH_STREAM_PF;
 constexpr int STREAM_NB = YH_STREAM_PF * YH_STREAM_GROUPS;
 static_assert(STREAM_PF >= 1 && STREAM_PF <= 15, "headers of a group live in lanes 0..PF");
 static_assert(STREAM_NB <= 16, "HB holds 16 block keys per wave");
+static_assert(YH_STREAM_GROUPS == 4, "stream_blocks is written out for four groups over two register sets");
 
 __device__ __forceinline__ u64 uniform_u64(u64 v) {  // a value every lane holds, moved to scalar registers
     return ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(v >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)(u32)v);
@@ -1034,25 +1036,33 @@ __device__ __forceinline__ void load_group(const u32x4* __restrict__ deltas, con
 __device__ __forceinline__ void stream_blocks(const u32x4* __restrict__ deltas, const u64* __restrict__ hdr, u64 bl0,
                                               u64 bl1, u32 sub, u32 n, u64 Klo, u64 Khi, u32 dsh, const u32* S,
                                               const u16* E, u32* INCw, u32* HBw, const StreamHit& hit,
-                                              const WaveQ& ctx, Pending& pend, bool preloaded, u32 nb, u32x4 (&cur)[STREAM_PF], u64& hcur) {
+                                              const WaveQ& ctx, Pending& pend, bool preloaded, u32 nb, u32x4 (&bufA)[STREAM_PF], u64& hdrA,
+                                              u32x4 (&bufB)[STREAM_PF], u64& hdrB) {
     constexpr u32 WAVES = STREAM_THREADS / 64;
     constexpr int PF = STREAM_PF, NB = STREAM_NB;
     const u32 lane = threadIdx.x & 63u;
     const u64 n_super = (bl1 - bl0 + nb - 1) / nb;
-    u64 sb = (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform, and the compiler knows it
+    const u32 wvi = (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform, and the compiler knows it
+    u64 sb = wvi;
     for (; sb < n_super; sb += WAVES) {
         const u64 b0 = bl0 + sb * nb;
         const int nvalid = (int)min((u64)nb, bl1 - b0);
         u32 hl[NB];  // last key of block i relative to base0 (scalar); invalid blocks: ~0
         u64 base0 = 0;
         u32 last_rel = 0;
-#pragma unroll
-        for (int g = 0; g < NB / PF; ++g) {
+        // Four groups of PF blocks through TWO register sets: groups 0 and 1 are requested together,
+        // group g + 2 as soon as group g's registers have been summed, so that a request is in flight
+        // while the previous group's spans are computed (a super-block costs ~one memory latency, not
+        // one per group).  Nothing of the NEXT super-block is requested before this one is probed: the
+        // probes' own reads must not queue behind it (vmcnt is in order).
+        auto issue = [&](u32x4 (&d)[PF], u64& h, int g) {
+            if (g * PF < nvalid) load_group(deltas, hdr, bl1, b0 + g * PF, d, h);
+        };
+        auto spans = [&](const u32x4 (&d)[PF], const u64 h, int g) {
             const int nv = min(PF, nvalid - g * PF);  // valid blocks of this group
             if (nv > 0) {
-                if (!(g == 0 && preloaded)) load_group(deltas, hdr, bl1, b0 + g * PF, cur, hcur);
-                if (g == 0) base0 = readlane_u64(hcur, 0);
-                if (lane < (u32)PF) HBw[g * PF + lane] = ((int)lane < nv) ? (u32)(hcur - base0) : 0xffffffffu;
+                if (g == 0) base0 = readlane_u64(h, 0);
+                if (lane < (u32)PF) HBw[g * PF + lane] = ((int)lane < nv) ? (u32)(h - base0) : 0xffffffffu;
                 // Lane sums of the PF blocks (v_sad_u8), then the PF inclusive wave scans step by step side
                 // by side (DPP only -- gfx9: row_shr 1/2/4/8 inside the rows of 16, then row_bcast:15 into
                 // rows 1 and 3, row_bcast:31 into rows 2 and 3): a DPP add needs two wait states after the
@@ -1060,10 +1070,9 @@ __device__ __forceinline__ void stream_blocks(const u32x4* __restrict__ deltas, 
                 int v[PF];
 #pragma unroll
                 for (int i = 0; i < PF; ++i) {
-                    const u32x4 d = cur[i];
-                    const u32 w0 = lane ? d.x : (d.x & 0xffffff00u);  // (a block's first delta byte is not used)
-                    v[i] = (int)(__builtin_amdgcn_sad_u8(w0, 0u, 0u) + __builtin_amdgcn_sad_u8(d.y, 0u, 0u) +
-                                 __builtin_amdgcn_sad_u8(d.z, 0u, 0u) + __builtin_amdgcn_sad_u8(d.w, 0u, 0u));
+                    const u32 w0 = lane ? d[i].x : (d[i].x & 0xffffff00u);  // (a block's first delta byte is not used)
+                    v[i] = (int)(__builtin_amdgcn_sad_u8(w0, 0u, 0u) + __builtin_amdgcn_sad_u8(d[i].y, 0u, 0u) +
+                                 __builtin_amdgcn_sad_u8(d[i].z, 0u, 0u) + __builtin_amdgcn_sad_u8(d[i].w, 0u, 0u));
                 }
 #define YH_SCAN_STEP(ctrl, rmask)                                                                      \
     _Pragma("unroll") for (int i = 0; i < PF; ++i) v[i] += __builtin_amdgcn_update_dpp(0, v[i], ctrl, rmask, 0xf, false);
@@ -1077,7 +1086,7 @@ __device__ __forceinline__ void stream_blocks(const u32x4* __restrict__ deltas, 
 #pragma unroll
                 for (int i = 0; i < PF; ++i) {
                     INCw[(g * PF + i) * 64 + lane] = (u32)v[i];
-                    const u32 end_rel = (u32)(readlane_u64(hcur, i) - base0) + (u32)__builtin_amdgcn_readlane(v[i], 63);
+                    const u32 end_rel = (u32)(readlane_u64(h, i) - base0) + (u32)__builtin_amdgcn_readlane(v[i], 63);
                     hl[g * PF + i] = (i < nv) ? end_rel : 0xffffffffu;
                     last_rel = (i < nv) ? end_rel : last_rel;
                 }
@@ -1086,7 +1095,17 @@ __device__ __forceinline__ void stream_blocks(const u32x4* __restrict__ deltas, 
 #pragma unroll
                 for (int i = 0; i < PF; ++i) hl[g * PF + i] = 0xffffffffu;
             }
+        };
+        if (!preloaded) {
+            issue(bufA, hdrA, 0);
+            issue(bufB, hdrB, 1);
         }
+        spans(bufA, hdrA, 0);
+        issue(bufA, hdrA, 2);
+        spans(bufB, hdrB, 1);
+        issue(bufB, hdrB, 3);
+        spans(bufA, hdrA, 2);
+        spans(bufB, hdrB, 3);
         preloaded = false;
         const u64 sb_last = base0 + last_rel;
         if (base0 <= Khi && sb_last >= Klo)
@@ -1178,9 +1197,11 @@ k_stream_lookup(const u32x4* __restrict__ deltas, const u64* __restrict__ hdr, u
     // The wave's first group is requested before anything else; while it is in flight, waves 0 and 1
     // find the workgroup's range of the sample and the tile is staged.  (With several tiles -- a
     // sample slice above ST_CAP hashes -- the request is wasted and made again per tile.)
-    u32x4 cur[STREAM_PF];
-    u64 hcur = 0;
-    if ((u64)wv * STREAM_NB < B1 - B0) load_group(deltas, hdr, B1, B0 + (u64)wv * STREAM_NB, cur, hcur);
+    u32x4 bufA[STREAM_PF], bufB[STREAM_PF];
+    u64 hdrA = 0, hdrB = 0;
+    const u64 first_sb = wv;
+    if (first_sb * STREAM_NB < B1 - B0) load_group(deltas, hdr, B1, B0 + first_sb * STREAM_NB, bufA, hdrA);
+    if (first_sb * STREAM_NB + STREAM_PF < B1 - B0) load_group(deltas, hdr, B1, B0 + first_sb * STREAM_NB + STREAM_PF, bufB, hdrB);
     if (wv < 2) {
         const u32 bnd = wave_bound(sample, n_sample, sshift, wg_key[lid + wv], wv == 1);
         if ((tid & 63u) == 0) sbound[wv] = bnd;
@@ -1236,7 +1257,7 @@ k_stream_lookup(const u32x4* __restrict__ deltas, const u64* __restrict__ hdr, u
                        : (u32)min((u64)STREAM_PF, max((bl1 - bl0) / WAVES, (u64)1));
         if (bl0 < bl1)
             stream_blocks(deltas, hdr, bl0, bl1, sub, n, Klo, Khi, dsh, S, E, INC[wv], HB[wv], hit, ctx, pend,
-                          single && nb == (u32)STREAM_NB && (u64)wv * STREAM_NB < B1 - B0, nb, cur, hcur);
+                          single && nb == (u32)STREAM_NB && first_sb * STREAM_NB < B1 - B0, nb, bufA, hdrA, bufB, hdrB);
         sub += n;
     }
     wave_flush(hit, ctx, pend);
