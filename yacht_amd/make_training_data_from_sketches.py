@@ -20,61 +20,80 @@ from . import utils
 from .utils import logger
 
 
+# (flag, keyword arguments of add_argument): the reference's argument set (:20-50) + --device
+ARGUMENTS = (
+    ("--ref_file", dict(required=True,
+                        help="Sourmash signature database (.zip with SOURMASH-MANIFEST.csv and signatures/*.sig.gz).")),
+    ("--ksize", dict(type=int, required=True, help="k-mer size of the sketches to use.")),
+    ("--num_threads", dict(type=int, default=16, help="Host threads for file handling.")),
+    ("--ani_thresh", dict(type=float, default=0.95,
+                          help='Organisms with this ANI or greater between them are considered "equivalent".')),
+    ("--prefix", dict(default="yacht", help="Prefix name to identify this experiment.")),
+    ("--outdir", dict(type=str, default=os.getcwd(), help="Path to output directory.")),
+    ("--force", dict(action="store_true", help="Overwrite the output directory if it exists.")),
+    ("--device", dict(type=int, default=0, help="GPU to run the comparison on.")),
+)
+
+# messages the reference raises with (callers and its tests match on them)
+MSG_NOT_ZIP = "Reference database file {0} is not a zip file. Please a Sourmash signature database file with Zipfile format."
+MSG_NO_ZIP = "Reference database zip file {0} does not exist."
+MSG_TMP_EXISTS = ("Temporary directory {0} already exists. Please remove it, use '--force', or given a new prefix name "
+                  "using parameter '--prefix'.")
+MSG_SCALES = "Not all signatures have the same scaled. Please check your input."
+
+
 def add_arguments(parser: argparse.ArgumentParser) -> None:
-    parser.add_argument("--ref_file", required=True,
-                        help="Sourmash signature database (.zip with SOURMASH-MANIFEST.csv and signatures/*.sig.gz).")
-    parser.add_argument("--ksize", type=int, required=True, help="k-mer size of the sketches to use.")
-    parser.add_argument("--num_threads", type=int, default=16, help="Host threads for file handling.")
-    parser.add_argument("--ani_thresh", type=float, default=0.95,
-                        help='Organisms with this ANI or greater between them are considered "equivalent".')
-    parser.add_argument("--prefix", default="yacht", help="Prefix name to identify this experiment.")
-    parser.add_argument("--outdir", type=str, default=os.getcwd(), help="Path to output directory.")
-    parser.add_argument("--force", action="store_true", help="Overwrite the output directory if it exists.")
-    parser.add_argument("--device", type=int, default=0, help="GPU to run the comparison on.")
+    for flag, kw in ARGUMENTS:
+        parser.add_argument(flag, **kw)
+
+
+def _fresh_workdir(workdir: str, force: bool) -> None:
+    if os.path.exists(workdir):
+        if not force:
+            raise ValueError(MSG_TMP_EXISTS.format(workdir))
+        logger.warning(f"Temporary directory {workdir} already exists. Removing it.")
+        shutil.rmtree(workdir)
+    os.makedirs(workdir, exist_ok=True)
+
+
+def _unpack_database(zip_path: str, workdir: str, threads: int) -> None:
+    logger.info("Unzipping the sourmash signature file to the temporary directory")
+    with zipfile.ZipFile(zip_path, "r") as archive:
+        archive.extractall(workdir)
+    packed = glob.glob(f"{workdir}/signatures/*.sig.gz")
+    logger.info(f"Decompressing {len(packed)} .sig.gz files using {threads} threads.")
+    utils.decompress_all_sig_files(packed, threads)
 
 
 def main(args) -> None:
-    ref_file = str(Path(args.ref_file).absolute())
+    zip_path = str(Path(args.ref_file).absolute())
     outdir = str(Path(args.outdir).absolute())
-    ksize, num_threads, ani_thresh, prefix = args.ksize, args.num_threads, args.ani_thresh, args.prefix
+    workdir = os.path.join(outdir, args.prefix + "_intermediate_files")
 
     logger.info("Checking reference database file")
-    if os.path.splitext(ref_file)[1] != ".zip":
-        raise ValueError(f"Reference database file {ref_file} is not a zip file. Please a Sourmash signature database file with Zipfile format.")
-    utils.check_file_existence(ref_file, f"Reference database zip file {ref_file} does not exist.")
-
-    path_to_temp_dir = os.path.join(outdir, prefix + "_intermediate_files")
-    if os.path.exists(path_to_temp_dir):
-        if not args.force:
-            raise ValueError(f"Temporary directory {path_to_temp_dir} already exists. Please remove it, use '--force', or given a new prefix name using parameter '--prefix'.")
-        logger.warning(f"Temporary directory {path_to_temp_dir} already exists. Removing it.")
-        shutil.rmtree(path_to_temp_dir)
-    os.makedirs(path_to_temp_dir, exist_ok=True)
-
-    logger.info("Unzipping the sourmash signature file to the temporary directory")
-    with zipfile.ZipFile(ref_file, "r") as z:
-        z.extractall(path_to_temp_dir)
-    gz = glob.glob(f"{path_to_temp_dir}/signatures/*.sig.gz")
-    logger.info(f"Decompressing {len(gz)} .sig.gz files using {num_threads} threads.")
-    utils.decompress_all_sig_files(gz, num_threads)
+    if os.path.splitext(zip_path)[1] != ".zip":
+        raise ValueError(MSG_NOT_ZIP.format(zip_path))
+    utils.check_file_existence(zip_path, MSG_NO_ZIP.format(zip_path))
+    _fresh_workdir(workdir, args.force)
+    _unpack_database(zip_path, workdir, args.num_threads)
 
     logger.info("Extracting signature information")
-    sig_info_dict = utils.collect_signature_info(num_threads, ksize, path_to_temp_dir)
-    scales = {v[-2] for v in sig_info_dict.values()}
-    if len(scales) != 1:
-        raise ValueError("Not all signatures have the same scaled. Please check your input.")
-    scale = scales.pop()
+    sig_info = utils.collect_signature_info(args.num_threads, args.ksize, workdir)
+    scaled_values = {record[-2] for record in sig_info.values()}
+    if len(scaled_values) != 1:
+        raise ValueError(MSG_SCALES)
 
     logger.info("Finding the closely related genomes with ANI > ani_thresh and removing them.")
-    manifest_df = utils.run_yacht_train_core(num_threads, ani_thresh, ksize, path_to_temp_dir, sig_info_dict,
-                                             device=getattr(args, "device", 0))
+    kept = utils.run_yacht_train_core(args.num_threads, args.ani_thresh, args.ksize, workdir, sig_info,
+                                      device=getattr(args, "device", 0))
 
-    manifest_file_path = os.path.join(outdir, f"{prefix}_processed_manifest.tsv")
-    manifest_df.to_csv(manifest_file_path, sep="\t", index=None)
-    with open(os.path.join(outdir, f"{prefix}_config.json"), "w") as f:
-        json.dump({"manifest_file_path": manifest_file_path, "intermediate_files_dir": path_to_temp_dir,
-                   "scale": scale, "ksize": ksize, "ani_thresh": ani_thresh}, f, indent=4)
-    logger.info(f"{len(manifest_df)} of {len(sig_info_dict)} references kept; config written to {outdir}")
+    manifest_path = os.path.join(outdir, f"{args.prefix}_processed_manifest.tsv")
+    kept.to_csv(manifest_path, sep="\t", index=None)
+    config = {"manifest_file_path": manifest_path, "intermediate_files_dir": workdir, "scale": scaled_values.pop(),
+              "ksize": args.ksize, "ani_thresh": args.ani_thresh}
+    with open(os.path.join(outdir, f"{args.prefix}_config.json"), "w") as out:
+        json.dump(config, out, indent=4)
+    logger.info(f"{len(kept)} of {len(sig_info)} references kept; config written to {outdir}")
 
 
 if __name__ == "__main__":

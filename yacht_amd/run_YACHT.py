@@ -31,16 +31,35 @@ RAW_RENAMES = {
 }
 
 
+# (flag, keyword arguments of add_argument): the reference's argument set (run_YACHT.py:24-72)
+ARGUMENTS = (
+    ("--json", dict(type=str, required=True, help="Config json written by `yacht train`.")),
+    ("--sample_file", dict(required=True, help="Metagenomic sample in .sig.zip format")),
+    ("--significance", dict(type=float, default=0.99, help="Minimum probability of individual true negative.")),
+    ("--num_threads", dict(type=int, default=16, help="Host threads for file handling.")),
+    ("--keep_raw", dict(action="store_true", help="Keep raw results in output file.")),
+    ("--show_all", dict(action="store_true", help="Show all organisms (no matter if present) in output file.")),
+    ("--min_coverage_list", dict(nargs="+", type=float, default=[1, 0.5, 0.1, 0.05, 0.01],
+                                 help="Fractions of a genome's unique k-mers assumed covered by the sample, each in [0, 1].")),
+    ("--outdir", dict(type=str, default=os.getcwd(), help="Where the 'results' folder is created.")),
+)
+
+# messages the reference raises with (callers and its tests match on them)
+MSG_NO_CONFIG = "Config file {0} does not exist. Please run make_training_data_from_sketches.py first."
+MSG_BAD_COVERAGE = ("One of values in the min_coverage_list you provided {0} is not between 0 and 1. "
+                    "Please check your input.")
+MSG_NO_MANIFEST = ("The manifest file {0} does not exist. Please check if you are using the correct json file as input.")
+MSG_ZIP_WITHOUT_MANIFEST = ("The input file {0} appears to be missing a manifest associated with it. "
+                            "Try running: sourmash sig merge {0} -o <new signature with the manifest present>. "
+                            "And then run YACHT using the output of that command.")
+MSG_NOT_ONE_SKETCH = ("Expected exactly one signature with ksize {1} in {0}, found {2}. "
+                      "Likely you will need to do something like: sourmash sig merge {0} -o <new signature with just one sketch in it>.")
+MSG_SCALE_MISMATCH = "Sample scale factor does not equal genome scale factor. Please check your input."
+
+
 def add_arguments(parser: argparse.ArgumentParser) -> None:
-    parser.add_argument("--json", type=str, required=True, help="Config json written by `yacht train`.")
-    parser.add_argument("--sample_file", required=True, help="Metagenomic sample in .sig.zip format")
-    parser.add_argument("--significance", type=float, default=0.99, help="Minimum probability of individual true negative.")
-    parser.add_argument("--num_threads", type=int, default=16, help="Host threads for file handling.")
-    parser.add_argument("--keep_raw", action="store_true", help="Keep raw results in output file.")
-    parser.add_argument("--show_all", action="store_true", help="Show all organisms (no matter if present) in output file.")
-    parser.add_argument("--min_coverage_list", nargs="+", type=float, default=[1, 0.5, 0.1, 0.05, 0.01],
-                        help="Fractions of a genome's unique k-mers assumed covered by the sample, each in [0, 1].")
-    parser.add_argument("--outdir", type=str, default=os.getcwd(), help="Where the 'results' folder is created.")
+    for flag, kw in ARGUMENTS:
+        parser.add_argument(flag, **kw)
 
 
 def coverage_plan(min_coverage_list):
@@ -75,8 +94,7 @@ def main(args) -> None:
     results_folder = os.path.join(outdir, "results")
     os.makedirs(results_folder, exist_ok=True)
 
-    utils.check_file_existence(json_file_path, f"Config file {json_file_path} does not exist. "
-                                               f"Please run make_training_data_from_sketches.py first.")
+    utils.check_file_existence(json_file_path, MSG_NO_CONFIG.format(json_file_path))
     with open(json_file_path) as f:
         config = json.load(f)
     manifest_file_path, genome_dir = config["manifest_file_path"], config["intermediate_files_dir"]
@@ -88,29 +106,25 @@ def main(args) -> None:
         sys.exit(1)
     for x in args.min_coverage_list:
         if not (0 <= x <= 1):
-            raise ValueError(f"One of values in the min_coverage_list you provided {x} is not between 0 and 1. Please check your input.")
-    utils.check_file_existence(manifest_file_path, f"The manifest file {manifest_file_path} does not exist. "
-                                                   f"Please check if you are using the correct json file as input.")
+            raise ValueError(MSG_BAD_COVERAGE.format(x))
+    utils.check_file_existence(manifest_file_path, MSG_NO_MANIFEST.format(manifest_file_path))
 
     logger.info("Loading the manifest file generated from the training data.")
     manifest = pd.read_csv(manifest_file_path, sep="\t", header=0)
     with zipfile.ZipFile(sample_file, "r") as z:
         if "SOURMASH-MANIFEST.csv" not in z.namelist():
-            raise FileNotFoundError(f"The input file {sample_file} appears to be missing a manifest associated with it. "
-                                    f"Try running: sourmash sig merge {sample_file} -o <new signature with the manifest present>. "
-                                    f"And then run YACHT using the output of that command.")
+            raise FileNotFoundError(MSG_ZIP_WITHOUT_MANIFEST.format(sample_file))
     try:
         sample_sig = utils.load_signature_with_ksize(sample_file, ksize)
     except ValueError:
-        raise ValueError(f"Expected exactly one signature with ksize {ksize} in {sample_file}, found {len(sample_file)}. "
-                         f"Likely you will need to do something like: sourmash sig merge {sample_file} -o <new signature with just one sketch in it>.")
+        raise ValueError(MSG_NOT_ONE_SKETCH.format(sample_file, ksize, len(sample_file)))
     info = utils.get_info_from_single_sig(sample_file, ksize)
     manifest["num_exclusive_kmers_in_sample_sketch"] = info[3]
     manifest["num_total_kmers_in_sample_sketch"] = utils.get_num_kmers(info[3], info[4], info[5], scale=False)
     manifest["sample_scale_factor"] = info[5]
     manifest["min_coverage"] = 1.0
     if scale != info[5]:
-        raise ValueError("Sample scale factor does not equal genome scale factor. Please check your input.")
+        raise ValueError(MSG_SCALE_MISMATCH)
 
     covs, has_raw = coverage_plan(args.min_coverage_list)
 
