@@ -122,11 +122,6 @@ def main() -> int:
     torch.cuda.synchronize()
     db.set_stream(stream.cuda_stream)
     assert stream.cuda_stream != 0
-    # largest per-partition slice of the sample (one LDS tile holds 4094 hashes; larger slices
-    # make the kernel re-stream that partition once per extra tile)
-    part_of = (sample >> info["partition_shift"]) if info["partition_shift"] < 63 else torch.zeros_like(sample)
-    max_slice = int(torch.bincount(part_of.clamp_(0, info["n_partitions"])).max().item()) if n_sample else 0
-
     # Two sets of count buffers: the all-gather of sample k (async, on RCCL's stream, ordered after
     # sample k's kernels) overlaps the kernels of sample k+1; a buffer set is reused only after the
     # collective that reads it has completed (work.wait() = stream-level wait, no host block on RCCL).
@@ -322,8 +317,8 @@ def main() -> int:
                 "refs_per_gpu": n_refs,
                 "ref_hashes_per_gpu": H,
                 "sample_hashes": n_sample,
-                "partitions": info["n_partitions"],
-                "max_sample_slice": max_slice,
+                "stream_layout": {1: "hash-sorted delta stream", 2: "packed 24-bit keys", 3: "64-bit hashes"}.get(layout, "none"),
+                "stream_bytes": int(info.get("stream_bytes", 0)),
                 "shared_hashes": info["n_shared_distinct"],
                 "db_build_ms": round(float(timing["ms_db_build"]), 2),
                 "db_hbm_bytes": info["device_bytes"],
