@@ -891,12 +891,17 @@ struct WaveQ {
 // Confirmed hits are summed per reference in an LDS table of the workgroup and leave as ONE global
 // atomic per (workgroup, reference) when the workgroup ends: in hash order a reference's hits are
 // spread evenly over the workgroups, and same-address atomics are serialized in L2.
-constexpr u32 STREAM_TSLOTS = 512;
-static_assert(STREAM_TSLOTS == 1u << 9, "table_add hashes into 9 bits");
+#ifndef YH_STREAM_TPROBES
+#define YH_STREAM_TPROBES 2   // (8 probes: a sample holding 2 000+ genomes overflows the table, and the failing CAS chains cost 7-15 %)
+#endif
+#ifndef YH_STREAM_TBITS
+#define YH_STREAM_TBITS 9
+#endif
+constexpr u32 STREAM_TSLOTS = 1u << YH_STREAM_TBITS;
 __device__ __forceinline__ void table_add(const StreamHit& hit, const WaveQ& c, u32 ref, bool shared) {
-    u32 slot = (ref * 2654435761u) >> (32 - 9);
+    u32 slot = (ref * 2654435761u) >> (32 - YH_STREAM_TBITS);
 #pragma unroll 1
-    for (int probe = 0; probe < 8; ++probe, slot = (slot + 1) & (STREAM_TSLOTS - 1)) {
+    for (int probe = 0; probe < YH_STREAM_TPROBES; ++probe, slot = (slot + 1) & (STREAM_TSLOTS - 1)) {
         const u32 old = atomicCAS(&c.tkey[slot], 0u, ref + 1);
         if (old == 0 || old == ref + 1) {
             atomicAdd(&c.tcnt[slot], 1u);
