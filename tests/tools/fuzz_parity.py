@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomized parity run on the GPU box: HIP path vs the CPU oracle over many shapes.
 
-    python scripts/fuzz_parity.py [--seconds 300] [--seed 0]
+    python tests/tools/fuzz_parity.py [--seconds 300] [--seed 0]
 
 Every round draws a database shape (number of references, sketch sizes, clusters that share
 hashes, hash range from a few thousand values to the full 64 bits, duplicates of whole sketches,
@@ -20,7 +20,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 
 from oracle import oracle  # noqa: E402  (the checker)
 from yacht_amd import synth  # noqa: E402

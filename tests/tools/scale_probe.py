@@ -3,7 +3,7 @@
 over 8 GPUs): ~50 000 references x ~39 000 hashes = ~2 x 10^9 reference hashes (> 2^31 positions in
 every array) against a 10^7-hash sample.  Not a bench line: a maximum-size parity case.
 
-    python scripts/scale_probe.py [--refs 50000] [--median 33000] [--sample 10000000] [--oracle auto|yes|no]
+    python tests/tools/scale_probe.py [--refs 50000] [--median 33000] [--sample 10000000] [--oracle auto|yes|no]
 
 Checks, all bit-exact:
   * overlap from the streaming kernel == overlap from k_overlap_bsearch (independent kernel over
@@ -21,7 +21,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 
 
 def host_free_gib() -> float:
