@@ -211,6 +211,20 @@ int yh_train_select(const uint32_t* sizes, uint64_t n_refs,
                     const uint32_t* pair_i, const uint32_t* pair_j, uint64_t n_pairs,
                     uint32_t* selected, uint64_t* n_selected);
 
+/* ---- ingest: the sketches of many .sig files (in front of yh_db_create) ------------------------------
+ * What the reference's train core does before anything else (src/cpp/main.cpp:62-124,
+ * read_min_hashes / read_sketches_one_chunk / read_sketches): every path is a sourmash JSON file,
+ * of which record 0, signature 0, "mins" is taken (ksize is not checked there either); a file
+ * that cannot be opened or parsed is an EMPTY sketch.  Read and parsed by `threads` host threads.
+ * Two-step hand-over into caller-owned arrays: sizes first (offsets[n_paths + 1], offsets[0] = 0),
+ * then values[offsets[n_paths]] -- exactly the CSR yh_db_create takes.  Mins come out ascending and
+ * unique (sourmash writes them so; other writers are sorted and de-duplicated).                    */
+typedef struct yh_sig_batch yh_sig_batch;
+int yh_sig_batch_read(const char* const* paths, uint64_t n_paths, int threads, yh_sig_batch** out);
+int yh_sig_batch_sizes(const yh_sig_batch* batch, uint64_t* offsets);
+int yh_sig_batch_values(const yh_sig_batch* batch, uint64_t* values);
+int yh_sig_batch_destroy(yh_sig_batch* batch);
+
 /* ---- sketching (next to the path: SURVEY.md §8f N2) --------------------------------------------
  * DNA FracMinHash as `sourmash sketch dna -p k=K,scaled=S,abund` defines it (the reference shells
  * out to it: sketch_ref_genomes.py:25,61, sketch_sample.py:32,49): every length-`ksize` window of

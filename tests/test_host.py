@@ -173,3 +173,37 @@ def test_cli_parsers_and_error_paths(tmp_path):
                             "--outdir", str(tmp_path)])
     with pytest.raises(ValueError, match="does not exist"):
         missing.func(missing)
+
+
+def test_sig_batch_reader_matches_the_python_reader(tmp_path):
+    """yh_sig_batch_* (host threads, no GPU needed): record 0 / signature 0 / "mins" of every file, an
+    unreadable or malformed file is an empty sketch, unsorted writers are sorted and de-duplicated --
+    the same sketches as the json-module reader."""
+    import json
+
+    from yacht_amd import train_core
+
+    rng = np.random.default_rng(5)
+    paths, want = [], []
+    for i in range(200):
+        m = np.unique(rng.integers(0, 2 ** 64 - 1, size=int(rng.integers(0, 400)), dtype=np.uint64))
+        p = tmp_path / f"s{i}.sig"
+        rec = [{"class": "sourmash_signature", "name": f"g{i}", "signatures": [
+            {"num": 0, "ksize": 31, "seed": 42, "max_hash": 18446744073709552, "mins": [int(x) for x in m],
+             "abundances": [1] * len(m), "molecule": "dna"}], "version": 0.4}]
+        p.write_text(json.dumps(rec) if i % 2 else json.dumps(rec, indent=2))
+        paths.append(str(p))
+        want.append(m)
+    (tmp_path / "unsorted.sig").write_text('[{"signatures":[{"mins":[5, 3, 3, 9]}]}]')
+    paths.append(str(tmp_path / "unsorted.sig"))
+    want.append(np.array([3, 5, 9], dtype=np.uint64))
+    (tmp_path / "broken.sig").write_text('[{"signatures":[{"mins":[1, 2,')
+    paths.append(str(tmp_path / "broken.sig"))
+    paths.append(str(tmp_path / "missing.sig"))
+    values, offsets = train_core.read_sketches_csr(paths, threads=3)
+    assert offsets.size == len(paths) + 1 and int(offsets[-1]) == values.size
+    for i, m in enumerate(want):
+        assert np.array_equal(values[int(offsets[i]):int(offsets[i + 1])], m)
+    py = train_core.read_sketches(paths[:len(want) - 1], 1)
+    assert all(np.array_equal(a, b) for a, b in zip(py, want))
+    assert int(offsets[-1]) - int(offsets[-2]) == 0  # missing file: empty sketch

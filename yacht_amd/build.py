@@ -17,9 +17,9 @@ LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libyacht_hip.so")
 EXE_PATH = os.path.join(LIB_DIR, "run_yacht_train_core")
 
-LIB_SOURCES = ["yh_api.hip", "yh_build.hip", "yh_query.hip", "yh_sketch.hip"]
+LIB_SOURCES = ["yh_api.hip", "yh_build.hip", "yh_query.hip", "yh_sketch.hip", "yh_sigread.hip"]
 EXE_SOURCES = ["train_core_main.cpp"]
-HEADERS = ["yh_common.h", os.path.join(REPO_DIR, "include", "yacht_hip.h")]
+HEADERS = ["yh_common.h", "yh_sigread.h", os.path.join(REPO_DIR, "include", "yacht_hip.h")]
 ARCH = "gfx950"
 
 
@@ -83,8 +83,8 @@ def build_exe(force: bool = False, verbose: bool = False) -> str:
     """run_yacht_train_core: same argv / files contract as the reference executable."""
     build_lib(force=force, verbose=verbose)
     srcs = [os.path.join(CSRC, s) for s in EXE_SOURCES]
-    if force or _stale(EXE_PATH, srcs + [LIB_PATH]):
-        _run([_hipcc(), "-O2", "-std=c++17", f"-I{os.path.join(REPO_DIR, 'include')}", *srcs, "-o", EXE_PATH,
+    if force or _stale(EXE_PATH, srcs + [LIB_PATH, os.path.join(CSRC, "yh_sigread.h")]):
+        _run([_hipcc(), "-O2", "-std=c++17", f"-I{os.path.join(REPO_DIR, 'include')}", f"-I{CSRC}", *srcs, "-o", EXE_PATH,
               f"-L{LIB_DIR}", "-lyacht_hip", "-Wl,-rpath,$ORIGIN", "-lpthread"])
     return EXE_PATH
 

@@ -11,6 +11,7 @@
 // with the `i,j,jaccard,Cij,Cji` lines of each (pass, thread) row block (main.cpp:264-308,318-349).
 // The intersections, the threshold filter and the selection are done by the library
 // (yh_db_create / yh_pairwise / yh_train_select); this file only parses and prints.
+#include "yh_sigread.h"
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -97,84 +98,8 @@ int parse_args(int argc, char** argv, Args& a) {
     return 0;
 }
 
-// ---- just enough JSON to reach [0]["signatures"][0]["mins"] ---------------------------------------------
-struct Scanner {
-    const char* p;
-    const char* e;
-    void ws() { while (p < e && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) ++p; }
-    bool lit(char c) { ws(); if (p < e && *p == c) { ++p; return true; } return false; }
-    bool string(std::string* out) {
-        ws();
-        if (p >= e || *p != '"') return false;
-        ++p;
-        if (out) out->clear();
-        while (p < e && *p != '"') {
-            if (*p == '\\' && p + 1 < e) { if (out) out->push_back(p[1]); p += 2; }
-            else { if (out) out->push_back(*p); ++p; }
-        }
-        if (p >= e) return false;
-        ++p;
-        return true;
-    }
-    bool skip() {  // any value
-        ws();
-        if (p >= e) return false;
-        if (*p == '"') return string(nullptr);
-        if (*p == '{') {
-            ++p;
-            if (lit('}')) return true;
-            do { if (!string(nullptr) || !lit(':') || !skip()) return false; } while (lit(','));
-            return lit('}');
-        }
-        if (*p == '[') {
-            ++p;
-            if (lit(']')) return true;
-            do { if (!skip()) return false; } while (lit(','));
-            return lit(']');
-        }
-        while (p < e && *p != ',' && *p != '}' && *p != ']' && *p != ' ' && *p != '\n' && *p != '\t' && *p != '\r') ++p;
-        return true;
-    }
-    // positioned at an object: find `key`, leave the cursor on its value
-    bool find_key(const char* key) {
-        if (!lit('{')) return false;
-        if (lit('}')) return false;
-        std::string k;
-        do {
-            if (!string(&k) || !lit(':')) return false;
-            if (k == key) return true;
-            if (!skip()) return false;
-        } while (lit(','));
-        return false;
-    }
-};
-
-std::vector<uint64_t> read_mins(const std::string& path) {
-    std::vector<uint64_t> mins;
-    std::ifstream f(path, std::ios::binary);
-    if (!f.is_open()) { std::cerr << "Could not open the file!" << std::endl; return mins; }
-    std::stringstream ss;
-    ss << f.rdbuf();
-    const std::string text = ss.str();
-    Scanner s{text.data(), text.data() + text.size()};
-    if (!s.lit('[') || !s.find_key("signatures") || !s.lit('[') || !s.find_key("mins") || !s.lit('[')) return mins;
-    if (s.lit(']')) return mins;
-    do {
-        s.ws();
-        char* end = nullptr;
-        const unsigned long long v = strtoull(s.p, &end, 10);
-        if (end == s.p) { mins.clear(); return mins; }
-        s.p = end;
-        mins.push_back(v);
-    } while (s.lit(','));
-    bool ascending = true;
-    for (size_t i = 1; i < mins.size() && ascending; ++i) ascending = mins[i - 1] < mins[i];
-    if (!ascending) {  // sourmash writes ascending unique mins; tolerate other writers
-        std::sort(mins.begin(), mins.end());
-        mins.erase(std::unique(mins.begin(), mins.end()), mins.end());
-    }
-    return mins;
-}
+// (the .sig reader: yh_sigread.h)
+using yh_sig::read_mins;
 
 long ms_since(std::chrono::high_resolution_clock::time_point t0) {
     return (long)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::high_resolution_clock::now() - t0).count();

@@ -65,10 +65,32 @@ def _read_one(path: str) -> np.ndarray:
 
 
 def read_sketches(paths: Sequence[str], threads: int = 1) -> List[np.ndarray]:
+    """The sketches as a list (python reader: json per file).  `run` uses read_sketches_csr."""
     if threads > 1 and len(paths) > 256:
         with Pool(min(threads, os.cpu_count() or 1)) as p:
             return p.map(_read_one, paths, chunksize=64)
     return [_read_one(p) for p in paths]
+
+
+def read_sketches_csr(paths: Sequence[str], threads: int = 1):
+    """(values, offsets) of all files through the library's threaded reader (yh_sig_batch_*: the
+    counterpart of src/cpp/main.cpp:89-124); an unreadable file is an empty sketch there too."""
+    import ctypes as C
+
+    from . import _lib
+
+    lib = _lib.load()
+    arr = (C.c_char_p * len(paths))(*[os.fsencode(p) for p in paths])
+    h = C.c_void_p()
+    _lib.check(lib.yh_sig_batch_read(arr, len(paths), max(1, int(threads)), C.byref(h)))
+    try:
+        offsets = np.zeros(len(paths) + 1, dtype=np.uint64)
+        _lib.check(lib.yh_sig_batch_sizes(h, offsets.ctypes.data_as(C.c_void_p)))
+        values = np.zeros(int(offsets[-1]), dtype=np.uint64)
+        _lib.check(lib.yh_sig_batch_values(h, values.ctypes.data_as(C.c_void_p)))
+    finally:
+        lib.yh_sig_batch_destroy(h)
+    return values, offsets
 
 
 def run(file_list: str, working_directory: str, output_filename: str, threads: int = 1, passes: int = 1,
@@ -80,11 +102,10 @@ def run(file_list: str, working_directory: str, output_filename: str, threads: i
     if containment_threshold < 0.0 or containment_threshold > 1.0:
         raise ValueError("containment threshold must be between 0.0 and 1.0")
     paths = read_sketch_list(file_list)
-    sketches = read_sketches(paths, threads)
-    n = len(sketches)
-    empty = [i for i, s in enumerate(sketches) if s.size == 0]
-    values, offsets = pack_csr(sketches)
+    values, offsets = read_sketches_csr(paths, threads)
+    n = len(paths)
     sizes = np.diff(offsets).astype(np.uint32)
+    empty = [int(i) for i in np.flatnonzero(sizes == 0)]
     with RefDB(values, offsets, device=device, flags=YH_DB_PAIRWISE_ONLY) as db:
         stats = db.index_stats()
         pi, pj, pc = db.pairwise(float(containment_threshold))
