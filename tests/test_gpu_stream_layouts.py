@@ -54,9 +54,12 @@ print("stream layout ok")
 """
 
 
-@pytest.mark.parametrize("name,layout", [("delta", 1), ("keys", 2)])
-def test_stream_layout_matches_oracle(hip_lib, name, layout):
-    env = dict(os.environ, YH_STREAM=name)
+@pytest.mark.parametrize("name,layout,extra", [("delta", 1, {}), ("keys", 2, {}), ("delta", 1, {"YH_NO_FUSED_RUN": "1"})],
+                         ids=["delta", "keys", "delta-general-run"])
+def test_stream_layout_matches_oracle(hip_lib, name, layout, extra):
+    """(third case: the run step through the general exclusive pass -- shared-hash flags, k_excl_chunks,
+    k_excl_final -- instead of the fused three-launch form)"""
+    env = dict(os.environ, YH_STREAM=name, **extra)
     env.pop("YH_WIDE_KEYS", None)
     r = subprocess.run([sys.executable, "-c", CHILD % ROOT, str(layout)], env=env, cwd=ROOT, capture_output=True,
                        text=True, timeout=900)
