@@ -58,6 +58,11 @@ def parse_args():
 
 def main() -> int:
     args = parse_args()
+    # stdout carries the ONE JSON line and nothing else: libraries that print banners at start-up
+    # (RCCL prints its version block to stdout when a communicator is created) are sent to stderr.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
 
@@ -330,7 +335,8 @@ def main() -> int:
             "parity_bit_exact": parity,
             "indexed_path": indexed,
         }
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     db.close()
     if world > 1:
         dist.barrier()
