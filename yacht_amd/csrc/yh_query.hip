@@ -847,7 +847,10 @@ k_tile_lookup_keys(const u32x4* __restrict__ keys,  // packed key stream, groupe
 // position, so truncation collisions (~|S|/48 per query) and filler elements never count.
 // A workgroup owns a contiguous range of blocks = a range of t; the sample hashes of that range are
 // staged in LDS (sorted t values + a bucket directory) -- if there are none the range is not read.
-constexpr int ST_SLOTS = 4096;          // sample keys per tile
+#ifndef YH_ST_SLOTS
+#define YH_ST_SLOTS 6144
+#endif
+constexpr int ST_SLOTS = YH_ST_SLOTS;   // sample keys per tile
 constexpr int ST_PAD = 64 + 2;          // readable sentinels behind the last key (a wave reads 64 slots at once)
 constexpr int ST_CAP = ST_SLOTS - ST_PAD;
 
