@@ -864,7 +864,7 @@ struct StreamHit {
     const u64* sample;
 };
 
-// Geometry of k_stream_lookup: 512 threads = 8 waves per workgroup, two workgroups per CU (~65 KB of
+// Geometry of k_stream_lookup: 512 threads = 8 waves per workgroup, two workgroups per CU (~75 KB of
 // LDS each) = 4 waves per SIMD and up to 128 VGPRs (no scratch).  768 threads / 6 waves per SIMD
 // (<= 80 VGPRs) spills with 16-block super-blocks and measured slower (0.113 vs 0.100 ms).
 #ifndef YH_STREAM_THREADS
