@@ -208,6 +208,7 @@ struct yh_db {
     u32* d_excl_m = nullptr;   // [N] ... and in the sample                      } zeroed together
     u32* d_ovsh = nullptr;     // [N] overlap restricted to shared hashes        }
     u32* d_overlap_tmp = nullptr;  // [N]
+    u32* d_out_tmp = nullptr;      // [2][N] exclusive counts of the host-pointer entry points (allocated on first use)
     u64* d_sample_tmp = nullptr;   // grows on demand (host-pointer entry points)
     u64 sample_tmp_cap = 0;
     u32* d_flag = nullptr;     // [1] generic error/flag word
