@@ -63,6 +63,7 @@ def main() -> int:
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs between the ranks on this pool
     import torch
     import torch.distributed as dist
 
