@@ -4,25 +4,35 @@
     python bench.py --gpus N --steps K --warmup W
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-A "step" is one pass of the device-side `yacht run` counts over one sample sketch:
-overlap of the sample with every reference of the rank's shard (streaming lookup kernel, R1),
-mask = overlap > 0, subset-exclusive hash counts (R2), and — for N > 1 — one RCCL all-gather of
-the per-reference counts.  Inputs are resident in HBM before the timed region.
+A "step" is one pass of the device-side `yacht run` counts over ONE sample sketch: overlap of the
+sample with every reference (R1), subset = overlap > 0, subset-exclusive hash counts (R2).  Inputs are
+resident in HBM before the timed region; consecutive steps take DIFFERENT samples (--samples, default
+8, rotated), so no step finds the previous one's candidates warm in cache.
 
-Workload (config.workload): BASELINE.json configs[2] — GTDB-rs214-representatives scale,
-85 205 synthetic reference sketches (k=31, scaled=1000, sizes LogNormal(ln 3300, 0.6) in
-[300, 15000]) per GPU against one ~1 M-hash sample; the metric "ref-sketch containment
-queries/sec" counts one (sample, reference) intersection as one query.  N > 1 is weak scaling:
-every rank holds its own 85 205-reference shard of an N x 85 205 database, the sample is
-replicated, and no collective sits on the data path except the final gather of counts.
+Workload (config.workload): BASELINE.json configs[2] -- GTDB-rs214-representatives scale: ONE synthetic
+database of 85 205 reference sketches per GPU (k=31, scaled=1000, sizes LogNormal(ln 3300, 0.6) in
+[300, 15000], ~10 % of the genomes in clusters of 2-8 sharing 10-95 %) against ~1 M-hash samples; the
+metric "ref-sketch containment queries/sec" counts one (sample, reference) intersection as one query.
 
-Rank 0 prints ONE JSON line (contract in the task statement) carrying `roofline` for the
-dominant kernel (k_stream_lookup) and `cpu_baseline` (the oracle's C++ restatement,
-all host cores, same workload, also used as the full-size bit-exact parity check).
+N > 1: the references of ONE database are cut into contiguous shards balanced by hash count
+(dist.shard_plan; clusters straddle the cuts), one shard per GPU.  --scaling weak (default): the
+database grows with N (85 205 references per GPU); --scaling strong: the 85 205-reference database is
+cut N ways.  Either way the counts are the exact global ones (dist.ShardedRefDB: rank-local lookup, one
+all-gather of the subset bits inside the step, one all-gather of the count rows behind it, overlapped
+with the next sample), and rank 0 checks them against the CPU oracle on the WHOLE database.
+
+Rank 0 prints ONE JSON line (contract in the task statement).  Beside the contract's keys:
+  device_resident   median / p10 / p90 of per-step HIP-event intervals (a separate pass)
+  host_inclusive    SURVEY.md 8d's metric: pinned sample -> H2D -> kernels -> counts D2H, pipelined
+                    (yh_run_submit / yh_run_wait), + the latency of one synchronous yh_run call
+  real_shape        the hit shape of real runs (~29 % of the references overlap an 83 k-hash sample)
+  roofline          the dominant kernel, bytes_basis says which byte count `achieved` uses
+  cpu_baseline      the oracle's C++ restatement on the host cores (also the full-size parity check)
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -34,7 +44,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+REFS_PER_GPU = 85_205
 
 
 def parse_args():
@@ -43,17 +54,41 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="gtdb_rs214_scale", choices=["gtdb_rs214_scale", "config2_1000refs"])
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N>1: weak = 85 205 refs per GPU (database grows), strong = one 85 205-ref database cut N ways")
     ap.add_argument("--refs", type=int, default=0, help="override references per GPU (testing only)")
     ap.add_argument("--sample-hashes", type=int, default=1_000_000)
+    ap.add_argument("--samples", type=int, default=8, help="distinct samples rotated through the steps")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg (and its parity check)")
-    ap.add_argument("--overlap-only", action="store_true", help="time R1 only (diagnostic; not the reported metric)")
+    ap.add_argument("--parity-samples", type=int, default=2, help="how many of the samples the oracle re-computes")
     ap.add_argument("--seed", type=int, default=1002)
-    ap.add_argument("--present", type=int, default=200, help="genomes present in the sample (diagnostic)")
+    ap.add_argument("--present", type=int, default=200, help="genomes present in a sample (diagnostic)")
     ap.add_argument("--no-indexed", action="store_true", help="skip the extra measurement of the sample-driven path")
-    ap.add_argument("--sync-gather", action="store_true", help="N>1: blocking all-gather inside every step (no overlap)")
+    ap.add_argument("--no-host-inclusive", action="store_true")
+    ap.add_argument("--no-real-shape", action="store_true")
+    ap.add_argument("--percentile-steps", type=int, default=200)
+    ap.add_argument("--sync-gather", action="store_true", help="N>1: blocking gather of the count rows inside every step")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to test the N>1 logic)")
     ap.add_argument("--share-gpu", action="store_true", help="testing: all ranks use cuda:0 (1-GPU box, gloo backend)")
     return ap.parse_args()
+
+
+def pct(xs, q):
+    return float(np.percentile(np.asarray(xs, dtype=np.float64), q)) if len(xs) else 0.0
+
+
+def stats_ms(xs):
+    return {"median_ms": round(pct(xs, 50), 4), "p10_ms": round(pct(xs, 10), 4), "p90_ms": round(pct(xs, 90), 4),
+            "mean_ms": round(float(np.mean(xs)) if len(xs) else 0.0, 4), "n": len(xs)}
+
+
+def source_tag() -> str:
+    """What the PMC traffic figure is keyed on: the kernels' source."""
+    h = hashlib.sha256()
+    for f in ("yh_query.hip", "yh_common.h"):
+        with open(os.path.join(ROOT, "yacht_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def main() -> int:
@@ -90,70 +125,98 @@ def main() -> int:
             dist.init_process_group(args.backend)
 
     from yacht_amd import build, synth
-    from yacht_amd.engine import RefDB, YH_DB_DEFAULT, YH_DB_FULL_INDEX
+    from yacht_amd import dist as ydist
+    from yacht_amd.engine import PinnedArray, RefDB, YH_DB_DEFAULT, YH_DB_FULL_INDEX
 
     if not os.path.exists(build.LIB_PATH):
         build.build_lib()
 
-    # ---- synthetic workload, generated in HBM ---------------------------------------------------------
+    # ---- synthetic workload, generated in HBM: this rank's shard of ONE global database -----------------
     if args.workload == "gtdb_rs214_scale":
-        n_refs = args.refs or 85_205
-        values, offsets, sample = synth.config3_device(seed=args.seed + 7919 * rank, n_refs=n_refs,
-                                                       n_sample=args.sample_hashes, device=str(dev),
-                                                       n_present=args.present)
-        workload = f"GTDB-rs214-scale synthetic: {n_refs} refs/GPU k=31 scaled=1000 vs 1 sample"
+        per_gpu = args.refs or REFS_PER_GPU
+        gen = dict(cluster_frac=0.10, median=3300.0, sigma=0.6, lo=300, hi=15000)
+        n_present = args.present
+        wl_name = "GTDB-rs214-scale synthetic"
     else:
-        n_refs = args.refs or 1000
-        values, offsets, sample = synth.config3_device(seed=args.seed + 7919 * rank, n_refs=n_refs,
-                                                       n_sample=args.sample_hashes, device=str(dev), median=5000.0,
-                                                       sigma=0.35, lo=500, hi=20000, cluster_frac=0.0, n_present=50)
-        workload = f"configs[1]: {n_refs} refs/GPU (~5000 hashes) vs 1 sample"
-    if world > 1:  # the sample is replicated: every rank queries rank 0's sample
-        n_s = torch.tensor([sample.numel()], device=dev, dtype=torch.int64)
-        dist.broadcast(n_s, 0)
-        if rank != 0:
-            sample = torch.empty(int(n_s.item()), device=dev, dtype=torch.int64)
-        dist.broadcast(sample, 0)
+        per_gpu = args.refs or 1000
+        gen = dict(cluster_frac=0.0, median=5000.0, sigma=0.35, lo=500, hi=20000)
+        n_present = 50
+        wl_name = "configs[1] synthetic (~5000-hash refs)"
+    n_total = per_gpu * world if args.scaling == "weak" else per_gpu
+    plan = synth.global_db_plan(args.seed, n_total, **gen)
+    shards = ydist.shard_plan(plan["offsets"].astype(np.uint64), world)
+    r_beg, r_end = shards[rank]
+    n_local = r_end - r_beg
+    values, offsets = synth.global_db_refs_device(plan, np.arange(r_beg, r_end), device=str(dev))
     H = int(values.numel())
-    n_sample = int(sample.numel())
+    K = max(args.samples, 1)
+    samples = [synth.global_db_sample_device(plan, args.seed + 1000 + i, n_sample=args.sample_hashes, n_present=n_present,
+                                             device=str(dev)) for i in range(K)]
+    if world > 1:  # the samples are replicated: every rank queries rank 0's (deterministic, but make it certain)
+        def bcast(t):
+            c = ydist._stage(t, None)
+            dist.broadcast(c, 0)
+            return c.to(dev)
+
+        for i in range(K):
+            n_i = int(bcast(torch.tensor([samples[i].numel()], device=dev, dtype=torch.int64)).item())
+            samples[i] = bcast(samples[i] if rank == 0 else torch.empty(n_i, device=dev, dtype=torch.int64))
+    n_sample = int(np.mean([int(s.numel()) for s in samples]))
+    workload = (f"{wl_name}: one database of {n_total} refs, {per_gpu if args.scaling == 'weak' else n_total // world} refs/GPU, "
+                f"k=31 scaled=1000, {K} rotating ~{args.sample_hashes}-hash samples")
     torch.cuda.synchronize()
 
-    db = RefDB.from_device(values.data_ptr(), offsets.data_ptr(), n_refs, device=local_rank,
-                           flags=YH_DB_DEFAULT if args.no_indexed else YH_DB_FULL_INDEX)
-    info = db.info()
-    # Everything of the timed region runs on ONE explicit stream: the library's kernels are queued
-    # on it (a null handle — torch's default stream — would mean "the library's own stream"), and
-    # RCCL orders the all-gather after whatever is on torch's current stream.
+    # Everything of the timed region runs on ONE explicit stream: the library's kernels are queued on it
+    # and RCCL orders its collectives after whatever is on torch's current stream.
     stream = torch.cuda.Stream(device=dev)
+    sdb = None
+    with torch.cuda.stream(stream):
+        if world > 1:
+            sdb = ydist.ShardedRefDB(values, offsets, ydist.HipLocalBackend(local_rank))
+            db = sdb.local.handle
+            n_rows = torch.tensor([sdb.n_rows], device=dev, dtype=torch.int64)
+            n_rows_c = ydist._stage(n_rows, None)
+            dist.all_reduce(n_rows_c, op=dist.ReduceOp.MAX)
+            row_stride = int(n_rows_c.item())
+        else:
+            db = RefDB.from_device(values.data_ptr(), offsets.data_ptr(), n_local, device=local_rank,
+                                   flags=YH_DB_DEFAULT if args.no_indexed else YH_DB_FULL_INDEX)
+            row_stride = n_local
     torch.cuda.synchronize()
     db.set_stream(stream.cuda_stream)
     assert stream.cuda_stream != 0
-    # Two sets of count buffers: the all-gather of sample k (async, on RCCL's stream, ordered after
-    # sample k's kernels) overlaps the kernels of sample k+1; a buffer set is reused only after the
-    # collective that reads it has completed (work.wait() = stream-level wait, no host block on RCCL).
-    NBUF = 2 if world > 1 and not args.sync_gather else 1
-    counts_b = [torch.zeros((3, n_refs), device=dev, dtype=torch.int32) for _ in range(NBUF)]  # overlap, n_excl, n_match
-    gathered_b = [torch.zeros((world * 3, n_refs), device=dev, dtype=torch.int32) if world > 1 else None
-                  for _ in range(NBUF)]  # concatenation layout
+    info = db.info()
+
+    # Two sets of count buffers: the gather of sample k's rows (async, ordered after sample k's kernels)
+    # overlaps the kernels of sample k+1; a set is reused only after the collective reading it completed.
+    NBUF = 2
+    counts_b = [torch.zeros((3, row_stride), device=dev, dtype=torch.int32) for _ in range(NBUF)]
+    gathered_b = [torch.zeros((world, 3, row_stride), device=dev, dtype=torch.int32) if world > 1 else None
+                  for _ in range(NBUF)]
     pending = [None] * NBUF
-    p_sample = sample.data_ptr()
+    staged_gather = world > 1 and args.backend != "nccl"
     state = {"i": 0}
 
     def step():
-        b = state["i"] % NBUF
+        i = state["i"]
         state["i"] += 1
+        b = i % NBUF
+        s = samples[i % K]
         c = counts_b[b]
         with torch.cuda.stream(stream):
             if pending[b] is not None:
                 pending[b].wait()
                 pending[b] = None
-            db.run_device(p_sample, n_sample, c[0].data_ptr(), 0 if args.overlap_only else c[1].data_ptr(),
-                          0 if args.overlap_only else c[2].data_ptr())
-            if world > 1:
-                if NBUF > 1:
-                    pending[b] = dist.all_gather_into_tensor(gathered_b[b], c, async_op=True)
-                else:
+            if sdb is None:
+                db.run_device(s.data_ptr(), s.numel(), c[0].data_ptr(), c[1].data_ptr(), c[2].data_ptr())
+            else:
+                sdb.run(s, c)
+                if staged_gather:
+                    ydist.all_gather_into(gathered_b[b].view(-1), c.view(-1))
+                elif args.sync_gather:
                     dist.all_gather_into_tensor(gathered_b[b], c)
+                else:
+                    pending[b] = dist.all_gather_into_tensor(gathered_b[b], c, async_op=True)
 
     def drain():
         with torch.cuda.stream(stream):
@@ -180,69 +243,182 @@ def main() -> int:
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = ydist._stage(torch.tensor([elapsed], device=dev, dtype=torch.float64), None)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    timing = db.timing()  # mean over the (up to 256) most recent launches of the timed region
-    last = (state["i"] - 1) % NBUF
-    counts, gathered = counts_b[last], gathered_b[last]
-    if world > 1:  # every buffer set: the gathered block of this rank must be this rank's counts
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = n_total / (elapsed / args.steps)
+
+    # ---- per-step percentiles: a separate pass with one HIP event between steps -------------------------
+    n_pct = max(args.percentile_steps, args.steps)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_pct + 1)]
+    with torch.cuda.stream(stream):
+        evs[0].record(stream)
+    for k in range(n_pct):
+        step()
+        evs[k + 1].record(stream)
+    drain()
+    fence()
+    step_ms = [evs[k].elapsed_time(evs[k + 1]) for k in range(n_pct)]
+    device_resident = dict(stats_ms(step_ms), how="HIP-event interval per step, separate pass of rotating samples; "
+                                                   "`value`/`ms_per_step` come from the un-instrumented timed loop")
+    timing = db.timing()  # kernel-duration ring: every 8th launch of the timed region + percentile pass
+
+    # last step's counts of every sample (for parity): run each sample once more into its own buffer
+    results = []
+    for i in range(K):
+        c = torch.zeros((3, row_stride), device=dev, dtype=torch.int32)
+        with torch.cuda.stream(stream):
+            if sdb is None:
+                db.run_device(samples[i].data_ptr(), samples[i].numel(), c[0].data_ptr(), c[1].data_ptr(), c[2].data_ptr())
+                results.append(c)
+            else:
+                sdb.run(samples[i], c)
+                results.append(sdb.gather(c))
+    torch.cuda.synchronize()
+    if world > 1:  # the step's own gather must carry this rank's rows
         for b in range(NBUF):
-            assert bool(torch.equal(gathered_b[b].view(world, 3, n_refs)[rank], counts_b[b])), \
-                "all-gather ran ahead of the kernels"
+            assert bool(torch.equal(gathered_b[b][rank], counts_b[b])), "gather ran ahead of the kernels"
 
-    # ---- extra: the same step through the sample-driven path (work ~ |S| instead of streaming the
-    # database).  Not the reported `value` this round: the headline stays on the streaming kernel
-    # the north star describes; both are exact and both are checked against the oracle below.
-    indexed = None
-    counts_idx = None
-    if not args.no_indexed and not args.overlap_only:
-        counts_idx = torch.zeros((3, n_refs), device=dev, dtype=torch.int32)
-        pi0, pi1, pi2 = (counts_idx[k].data_ptr() for k in range(3))
+    # ---- N = 1 extras ------------------------------------------------------------------------------------
+    indexed = host_inclusive = real_shape = None
+    if world == 1 and not args.no_indexed:
+        cidx = torch.zeros((3, n_local), device=dev, dtype=torch.int32)
 
-        def step_idx():
+        def step_idx(i):
+            s = samples[i % K]
             with torch.cuda.stream(stream):
-                db.run_indexed_device(p_sample, n_sample, pi0, pi1, pi2)
-                if world > 1:
-                    dist.all_gather_into_tensor(gathered, counts_idx)  # (this extra measurement keeps the blocking form)
+                db.run_indexed_device(s.data_ptr(), s.numel(), cidx[0].data_ptr(), cidx[1].data_ptr(), cidx[2].data_ptr())
 
-        for _ in range(args.warmup):
-            step_idx()
+        for i in range(args.warmup):
+            step_idx(i)
         fence()
         db.timing()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step_idx()
+        for i in range(args.steps):
+            step_idx(i)
         fence()
         el = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([el], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el = float(t.item())
         tm_idx = db.timing()
-        indexed = {"ms_per_step": round(1e3 * el / args.steps, 4),
-                   "value": round(n_refs * world / (el / args.steps), 1), "unit": "queries/s",
-                   "lookup_kernel_ms_avg": round(float(tm_idx["ms_overlap_kernel"]), 4),
+        same = True
+        for i in range(K):
+            step_idx(i)
+            torch.cuda.synchronize()
+            same = same and bool(torch.equal(cidx, results[i]))
+        indexed = {"ms_per_step": round(1e3 * el / args.steps, 4), "value": round(n_local / (el / args.steps), 1),
+                   "unit": "queries/s", "lookup_kernel_ms_avg": round(float(tm_idx["ms_overlap_kernel"]), 4),
                    "exclusive_kernels_ms_avg": round(float(tm_idx["ms_exclusive_kernels"]), 4),
-                   "note": "k_index_lookup: one lane per sample hash through the distinct-hash directory "
-                           "(YH_DB_FULL_INDEX); equals the streaming path bit for bit"}
-        indexed["equals_streaming_path"] = bool(torch.equal(counts_idx, counts))
+                   "note": "yh_run_indexed_device: one lane per sample hash through the distinct-hash directory (YH_DB_FULL_INDEX)",
+                   "equals_default_path": same}
 
-    ms_per_step = 1e3 * elapsed / args.steps
-    total_refs = n_refs * world
-    value = total_refs / (elapsed / args.steps)
+    if world == 1 and not args.no_host_inclusive:
+        # SURVEY.md 8d's metric: wall time of the steady-state call INCLUDING sample H2D and counts D2H.
+        # Page-locked host buffers, yh_run_submit / yh_run_wait, DEPTH calls in flight.
+        DEPTH = 2
+        h_samples = []
+        for s in samples:
+            pa = PinnedArray(int(s.numel()), np.uint64)
+            pa.array[:] = s.cpu().numpy().view(np.uint64)
+            h_samples.append(pa)
+        h_out = [[PinnedArray(n_local, np.uint32) for _ in range(3)] for _ in range(DEPTH)]
+        done_t = []
+
+        def host_loop(n_steps, record):
+            for i in range(n_steps + DEPTH):
+                slot = i % DEPTH
+                if i >= DEPTH:
+                    db.run_wait(slot)
+                    if record:
+                        done_t.append(time.perf_counter())
+                if i < n_steps:
+                    o = h_out[slot]
+                    db.run_submit(slot, h_samples[i % K].array, o[0].array, o[1].array, o[2].array)
+
+        host_loop(args.warmup, False)
+        n_host = max(args.steps, args.percentile_steps)
+        t0 = time.perf_counter()
+        host_loop(n_host, True)
+        el = time.perf_counter() - t0
+        gaps = (np.diff(np.asarray([t0] + done_t)) * 1e3).tolist()[DEPTH:]
+        # the last DEPTH results are still in the buffers: check them against the device-resident counts
+        ok = True
+        for i in range(n_host - DEPTH, n_host):
+            o = h_out[i % DEPTH]
+            want = results[i % K].cpu().numpy().view(np.uint32)
+            ok = ok and all(np.array_equal(o[k].array, want[k]) for k in range(3))
+        # latency of ONE synchronous host-pointer call (what the CLI pays per sample)
+        lat = []
+        hs = h_samples[0].array
+        for i in range(30):
+            t1 = time.perf_counter()
+            db.run_counts(h_samples[i % K].array)
+            lat.append((time.perf_counter() - t1) * 1e3)
+        host_inclusive = dict(stats_ms(gaps), value=round(n_local / (el / n_host), 1), unit="queries/s",
+                              ms_per_step=round(1e3 * el / n_host, 4), pipeline_depth=DEPTH,
+                              h2d_bytes_per_step=8 * n_sample, d2h_bytes_per_step=12 * n_local,
+                              h2d_GBps=round(8 * n_sample / (el / n_host) / 1e9, 1),
+                              equals_device_resident=ok,
+                              sync_call_ms_median=round(pct(lat[5:], 50), 4),
+                              how="pinned sample -> H2D -> ordering check + kernels -> counts D2H per step "
+                                  "(yh_run_submit/yh_run_wait, copy streams beside the compute stream); "
+                                  "percentiles over the intervals between completed steps; "
+                                  "sync_call = one blocking yh_run from pageable numpy arrays")
+        del hs
+        for pa in h_samples:
+            pa.close()
+        for o in h_out:
+            for pa in o:
+                pa.close()
+
+    real_samples = []
+    if world == 1 and not args.no_real_shape and args.workload == "gtdb_rs214_scale":
+        # the hit shape of the reference's shipped results: ~29 % of the references overlap
+        real_samples = [synth.global_db_sample_device(plan, args.seed + 5000 + i, n_sample=83_000, device=str(dev),
+                                                      shape="real") for i in range(4)]
+        creal = torch.zeros((3, n_local), device=dev, dtype=torch.int32)
+
+        def step_real(i):
+            s = real_samples[i % len(real_samples)]
+            with torch.cuda.stream(stream):
+                db.run_device(s.data_ptr(), s.numel(), creal[0].data_ptr(), creal[1].data_ptr(), creal[2].data_ptr())
+
+        for i in range(args.warmup):
+            step_real(i)
+        fence()
+        db.timing()
+        ev2 = [torch.cuda.Event(enable_timing=True) for _ in range(n_pct + 1)]
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step_real(i)
+        fence()
+        el = time.perf_counter() - t0
+        ev2[0].record(stream)
+        for k in range(n_pct):
+            step_real(k)
+            ev2[k + 1].record(stream)
+        fence()
+        tm = db.timing()
+        step_real(0)
+        torch.cuda.synchronize()
+        real_counts0 = creal.clone()
+        real_shape = dict(stats_ms([ev2[k].elapsed_time(ev2[k + 1]) for k in range(n_pct)]),
+                          ms_per_step=round(1e3 * el / args.steps, 4), value=round(n_local / (el / args.steps), 1),
+                          unit="queries/s", sample_hashes=int(real_samples[0].numel()),
+                          refs_overlapping=int((real_counts0[0] != 0).sum().item()),
+                          lookup_kernel_ms_avg=round(float(tm["ms_overlap_kernel"]), 4),
+                          exclusive_kernels_ms_avg=round(float(tm["ms_exclusive_kernels"]), 4))
 
     # ---- roofline of the dominant kernel (the streaming lookup) ------------------------------------------
-    # Bytes one launch HAS to move in the layout the kernel reads (yh_db_info.stream_bytes: one delta
-    # byte per (hash, reference) pair + an 8-byte header per 1024 for the default hash-sorted delta
-    # stream; 3 bytes per pair for YH_STREAM=keys; 8 for YH_WIDE_KEYS=1) plus the 8-byte sample hashes
-    # staged once.  `achieved` is that figure over the measured duration: the physical HBM rate the
-    # kernel sustains, comparable with `peak` and with `traffic` (PMC).  SURVEY.md 8d's one-touch
-    # formula (8 B per reference hash: 8(H+|S|) + 8(N+1) + 4N) is reported beside it; it exceeds the
-    # peak because the kernel does not read 8 bytes per hash any more.
+    # `achieved` = bytes one launch HAS to move in the layout the kernel reads (yh_db_info.stream_bytes: one
+    # delta byte per (hash, reference) pair + an 8-byte header per 1024, plus the 8-byte sample hashes staged
+    # once) over the measured launch duration: a physical HBM rate comparable with `peak` and `traffic`.
+    # SURVEY.md 8d's one-touch formula (8 B per reference hash) is reported beside it (`survey_formula`); it
+    # exceeds the peak because the kernel does not read 8 bytes per hash.
     layout = int(info.get("stream_layout", 0))
     kernel_name = {1: "k_stream_lookup", 2: "k_tile_lookup_keys", 3: "k_tile_lookup<OverlapHit>"}.get(layout, "?")
-    survey_bytes = 8 * (H + n_sample) + 8 * (n_refs + 1) + 4 * n_refs
+    Hh = int(info["n_hashes"])
+    Nh = int(info["n_refs"])
+    survey_bytes = 8 * (Hh + n_sample) + 8 * (Nh + 1) + 4 * Nh
     alg_bytes = int(info.get("stream_bytes", 0)) + 8 * n_sample
     k_ms = float(timing["ms_overlap_kernel"])
     achieved = (alg_bytes / 1e9) / (k_ms / 1e3) if k_ms > 0 else 0.0
@@ -255,56 +431,90 @@ def main() -> int:
         "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4),
         "traffic": None,
+        "bytes_basis": "layout: the delta stream the kernel reads (1 B per reference hash + 8 B per 1024) + 8 B per sample hash",
         "algorithmic_bytes_per_launch": alg_bytes,
-        "bytes_per_ref_hash": round(int(info.get("stream_bytes", 0)) / max(H, 1), 4),
+        "bytes_per_ref_hash": round(int(info.get("stream_bytes", 0)) / max(Hh, 1), 4),
         "kernel_ms_avg": round(k_ms, 4),
         "exclusive_kernels_ms_avg": round(float(timing["ms_exclusive_kernels"]), 4),
         "survey_formula": {"bytes_per_launch": survey_bytes, "GBps": round(survey_rate, 1),
                            "frac": round(survey_rate / HBM_PEAK_GBS, 4),
                            "note": "8 B per reference hash as SURVEY.md 8d counts; the kernel streams "
-                                   f"{round(int(info.get('stream_bytes', 0)) / max(H, 1), 3)} B per hash"},
+                                   f"{round(int(info.get('stream_bytes', 0)) / max(Hh, 1), 3)} B per hash"},
     }
-    traffic_file = os.path.join(ROOT, "profiles", "traffic_r01.json")  # written by scripts/make_traffic_json.py
-    if os.path.exists(traffic_file):  # HBM bytes per launch from the rocprofv3 --pmc passes (profiles/README.md)
+    # HBM bytes per launch from the rocprofv3 --pmc passes (profiles/README.md), attached only when they
+    # were taken from THIS source of the kernels on THIS workload; otherwise null.
+    tag = source_tag()
+    for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+        if not (name.startswith("traffic_") and name.endswith(".json")):
+            continue
         try:
-            with open(traffic_file) as f:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
                 tr = json.load(f)
-            if tr.get("n_hashes") == H and tr.get("kernel") == roofline["kernel"]:
+            if tr.get("source_tag") == tag and tr.get("n_hashes") == Hh and tr.get("kernel") == roofline["kernel"]:
                 roofline["traffic"] = tr.get("hbm_bytes_per_launch")
+                roofline["traffic_provenance"] = {"file": "profiles/" + name, "source_tag": tag,
+                                                  "taken": tr.get("taken"), "commit": tr.get("commit")}
+                break
         except Exception:
             pass
 
-    # ---- CPU baseline + full-size parity (rank 0, its own shard) ---------------------------------------
+    # ---- CPU baseline + full-size parity (rank 0, the WHOLE database) -----------------------------------
     cpu_baseline = None
     parity = None
     if rank == 0 and not args.no_cpu_baseline:
         from oracle import oracle  # the checker; never the thing measured as `value`
 
-        h_values = values.cpu().numpy().view(np.uint64)
-        h_offsets = offsets.cpu().numpy().view(np.uint64)
-        h_sample = sample.cpu().numpy().view(np.uint64)
+        if world == 1:
+            h_values = values.cpu().numpy().view(np.uint64)
+            h_offsets = offsets.cpu().numpy().view(np.uint64)
+        else:  # regenerate the other shards here, one at a time (the generator is a pure function of the plan)
+            parts = []
+            for (b, e) in shards:
+                v, _ = synth.global_db_refs_device(plan, np.arange(b, e), device=str(dev))
+                parts.append(v.cpu().numpy().view(np.uint64))
+                del v
+            h_values = np.concatenate(parts)
+            h_offsets = plan["offsets"].astype(np.uint64)
+            del parts
         cores = oracle.hardware_threads()
-        t0 = time.perf_counter()
-        want_ov = oracle.overlap(h_values, h_offsets, h_sample, threads=cores)
-        t_ov = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        want_e, want_m = oracle.exclusive(h_values, h_offsets, want_ov > 0, h_sample)
-        t_ex = time.perf_counter() - t0
-        got = counts.cpu().numpy().view(np.uint32)
-        parity = bool(np.array_equal(got[0], want_ov))
-        if not args.overlap_only:
-            parity = parity and bool(np.array_equal(got[1], want_e)) and bool(np.array_equal(got[2], want_m))
-        t_cpu = t_ov if args.overlap_only else t_ov + t_ex
-        cpu_baseline = {
-            "value": round(n_refs / t_cpu, 1),
-            "unit": "queries/s",
-            "cores": cores,
-            "kind": "port",
-            "sample": f"whole rank-0 workload once ({n_refs} refs, {H} hashes): overlap {t_ov:.2f} s on {cores} "
-                      f"threads + exclusive {t_ex:.2f} s on 1 thread",
-        }
+        t_ov = t_ex = 0.0
+        parity = True
+        n_par = min(max(args.parity_samples, 1), K)
+        for i in range(n_par):
+            h_sample = samples[i].cpu().numpy().view(np.uint64)
+            t0 = time.perf_counter()
+            want_ov = oracle.overlap(h_values, h_offsets, h_sample, threads=cores)
+            t_ov += time.perf_counter() - t0
+            t0 = time.perf_counter()
+            want_e, want_m = oracle.exclusive(h_values, h_offsets, want_ov > 0, h_sample)
+            t_ex += time.perf_counter() - t0
+            got = results[i].cpu().numpy().view(np.uint32)[:, :n_total]
+            parity = parity and bool(np.array_equal(got[0], want_ov)) and bool(np.array_equal(got[1], want_e)) \
+                and bool(np.array_equal(got[2], want_m))
+        if real_shape is not None:
+            h_sample = real_samples[0].cpu().numpy().view(np.uint64)
+            want_ov = oracle.overlap(h_values, h_offsets, h_sample, threads=cores)
+            want_e, want_m = oracle.exclusive(h_values, h_offsets, want_ov > 0, h_sample)
+            got = real_counts0.cpu().numpy().view(np.uint32)
+            real_shape["parity_bit_exact"] = bool(np.array_equal(got[0], want_ov) and np.array_equal(got[1], want_e)
+                                                  and np.array_equal(got[2], want_m))
+            parity = parity and real_shape["parity_bit_exact"]
+        if world == 1:
+            cpu_baseline = {
+                "value": round(n_par * n_total / (t_ov + t_ex), 1),
+                "unit": "queries/s",
+                "cores": cores,
+                "kind": "port",
+                "sample": f"{n_par} of the {K} samples against the whole database ({n_total} refs, {Hh} hashes): "
+                          f"overlap {t_ov:.2f} s on {cores} threads + exclusive {t_ex:.2f} s on 1 thread",
+            }
 
     if rank == 0:
+        try:
+            import scipy
+            scipy_version = scipy.__version__
+        except Exception:
+            scipy_version = None
         out = {
             "metric": "ref-sketch containment queries/sec (yacht run)",
             "value": round(value, 1),
@@ -314,36 +524,50 @@ def main() -> int:
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "u64",
             "data": "synthetic",
             "config": {
                 "workload": workload,
-                "refs_per_gpu": n_refs,
-                "ref_hashes_per_gpu": H,
+                "refs_total": n_total,
+                "refs_per_gpu": n_local,
+                "ref_hashes_per_gpu": Hh,
                 "sample_hashes": n_sample,
+                "distinct_samples": K,
                 "stream_layout": {1: "hash-sorted delta stream", 2: "packed 24-bit keys", 3: "64-bit hashes"}.get(layout, "none"),
                 "stream_bytes": int(info.get("stream_bytes", 0)),
                 "shared_hashes": info["n_shared_distinct"],
+                "ghost_refs_rank0": (sdb.n_ghost if sdb is not None else 0),
                 "db_build_ms": round(float(timing["ms_db_build"]), 2),
                 "db_hbm_bytes": info["device_bytes"],
-                "step": "overlap" if args.overlap_only else "overlap + exclusive counts" + ((" + all_gather" + ("" if args.sync_gather else " (overlapped with the next sample)")) if world > 1 else ""),
-                "parallelism": f"refs sharded x{world}",
+                "step": "overlap + exclusive counts" + ((" (subset bits all-gathered inside the step) + all_gather of the count rows"
+                                                       + ("" if args.sync_gather else " (overlapped with the next sample)")) if world > 1 else ""),
+                "parallelism": f"one database, references sharded x{world} by hash count",
+                "scipy": scipy_version,
             },
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
             "parity_bit_exact": parity,
+            "device_resident": device_resident,
+            "host_inclusive": host_inclusive,
+            "real_shape": real_shape,
             "indexed_path": indexed,
         }
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
-    db.close()
+    if sdb is not None:
+        sdb.close()
+    else:
+        db.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    if rank == 0 and indexed is not None and not indexed["equals_streaming_path"]:
-        print("bench.py: indexed path differs from the streaming path", file=sys.stderr)
+    if rank == 0 and indexed is not None and not indexed["equals_default_path"]:
+        print("bench.py: indexed path differs from the default path", file=sys.stderr)
+        return 1
+    if rank == 0 and host_inclusive is not None and not host_inclusive["equals_device_resident"]:
+        print("bench.py: host-buffer path differs from the device-resident path", file=sys.stderr)
         return 1
     if rank == 0 and parity is False:
         print("bench.py: GPU counts differ from the CPU oracle", file=sys.stderr)

@@ -170,6 +170,45 @@ int yh_run(yh_db* db, const uint64_t* sample, uint64_t n_sample,
 int yh_run_device(yh_db* db, const uint64_t* d_sample, uint64_t n_sample,
                   uint32_t* d_overlap, uint32_t* d_n_excl, uint32_t* d_n_match);
 
+/* ---- references spread over several GPUs, the `yacht run` subset (overlap > 0) ------------------------
+ * North star: "references shard across the GPUs with only a final gather of per-reference counts".
+ * Overlap is rank-local.  Exclusivity is not -- the other holder of a hash may live on another rank --
+ * so every rank's handle is built over its own references PLUS ghosts: for every hash one of its
+ * references shares with a reference of another rank, that foreign reference appears as an extra
+ * reference holding (only) such hashes, behind the local ones, from a multiple of 64 on (pad with empty
+ * references).  The handle's index then knows every holder of every local hash, and a step needs one
+ * exchange: which references overlap the sample AT ALL, one bit each (N/8 bytes, latency-bound):
+ *   yh_run_local_device   lookup + reduce on this rank: d_overlap, d_n_match final; d_n_excl = the part
+ *                         that needs no posting list; the subset bits of the handle's references to
+ *                         d_bits_out (ceil(n_refs / 64) * 2 words; the ghosts' bits there are NOT valid)
+ *   -- all-gather of the local references' bits (torch.distributed / RCCL, yacht_amd/dist.py) --
+ *   yh_run_finish_device  ghost g takes bit ghost_src[g] of d_global_bits; then the posting-list part
+ *                         of d_n_excl is added.  Rows of ghosts and padding in the outputs are garbage.
+ * yh_db_set_ghosts registers the ghost range and their bit positions once per handle.            */
+int yh_db_set_ghosts(yh_db* db, uint64_t ghost_begin, uint64_t n_ghost, const uint32_t* d_ghost_src);
+int yh_run_local_device(yh_db* db, const uint64_t* d_sample, uint64_t n_sample, uint32_t* d_overlap,
+                        uint32_t* d_n_excl, uint32_t* d_n_match, uint32_t* d_bits_out);
+int yh_run_finish_device(yh_db* db, const uint32_t* d_global_bits, uint32_t* d_n_excl);
+
+/* Pipelined host-buffer form of yh_run: SURVEY.md 8d's steady-state call -- sample H2D, kernels,
+ * counts D2H -- split in two so that consecutive samples overlap.  yh_run_submit queues, on three
+ * streams of the handle, the upload of `sample`, an ordering check ON THE DEVICE (a sample that fails
+ * it is not looked up), the fused run kernels and the download of the three count rows into the
+ * caller's buffers, and returns without waiting; yh_run_wait(slot) blocks until that call's counts
+ * have landed and returns YH_ERR_UNSORTED when the check failed (the buffers are then all zero).
+ * `slot` in [0, YH_RUN_SLOTS): a slot holds one call in flight and must be waited for before it is
+ * submitted again; calls complete in submission order.  Copies overlap the kernels only when the host
+ * buffers are page-locked (yh_host_alloc, hipHostMalloc, torch pin_memory); pageable memory works,
+ * synchronously.  Buffers must stay valid until yh_run_wait returns.  Needs the default (delta
+ * stream) layout and the index.                                                               */
+#define YH_RUN_SLOTS 4
+int yh_run_submit(yh_db* db, int slot, const uint64_t* sample, uint64_t n_sample,
+                  uint32_t* overlap, uint32_t* n_excl, uint32_t* n_match);
+int yh_run_wait(yh_db* db, int slot);
+/* Page-locked host memory for the buffers above (hipHostMalloc / hipHostFree).                */
+int yh_host_alloc(void** out, uint64_t bytes);
+int yh_host_free(void* p);
+
 /* ---- references spread over several GPUs: exact exclusive counts --------------------------------
  * Each rank holds (a) a handle over its shard of the REFERENCES for the overlap kernel and (b) a
  * posting-list handle over its range of the HASH space, built from the (hash, global reference

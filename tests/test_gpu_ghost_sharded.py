@@ -1,0 +1,117 @@
+"""GPU: dist.ShardedRefDB on the HIP backend -- the `yacht run` step over ranks (ghost references,
+yh_run_local_device / yh_run_finish_device) -- with TWO PROCESSES sharing the one GPU of the test box
+(gloo moves the collectives through the host; RCCL refuses two ranks on one device), checked against
+the CPU oracle on the WHOLE database.  Plus bench.py's own N = 2 path on the same arrangement."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, os.environ["YH_ROOT"])
+import torch
+import torch.distributed as dist
+from oracle import oracle
+from yacht_amd import dist as ydist, synth
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("gloo")
+n_total = int(os.environ["YH_NREFS"])
+plan = synth.global_db_plan(31, n_total, cluster_frac=0.6)   # many clusters: the cuts go through some
+shards = ydist.shard_plan(plan["offsets"].astype(np.uint64), world)
+b, e = shards[rank]
+values, offsets = synth.global_db_refs_device(plan, np.arange(b, e), device="cuda:0")
+sdb = ydist.ShardedRefDB(values, offsets, ydist.HipLocalBackend(0))
+all_v, all_o = synth.global_db_refs_device(plan, np.arange(n_total), device="cuda:0")
+hv, ho = all_v.cpu().numpy().view(np.uint64), all_o.cpu().numpy().astype(np.uint64)
+ok = True
+for i, (shape, n_s) in enumerate((("present", 200000), ("real", 5000), ("present", 0))):
+    s = synth.global_db_sample_device(plan, 77 + i, n_sample=max(n_s, 1), n_present=60, device="cuda:0", shape=shape)
+    if n_s == 0:
+        s = s[:0]
+    c = sdb.run(s)
+    torch.cuda.synchronize()
+    full = sdb.gather(c).cpu().numpy().view(np.uint32)
+    hs = s.cpu().numpy().view(np.uint64)
+    want_ov = oracle.overlap(hv, ho, hs, threads=4)
+    want_e, want_m = oracle.exclusive(hv, ho, want_ov > 0, hs)
+    for name, got, want in (("overlap", full[0], want_ov), ("n_excl", full[1], want_e), ("n_match", full[2], want_m)):
+        if not np.array_equal(got, want):
+            ok = False
+            bad = np.flatnonzero(got != want)
+            print(f"rank {rank} sample {i} {name}: {bad.size} differ, first {bad[:5]} got {got[bad[:5]]} want {want[bad[:5]]}", flush=True)
+print(f"rank {rank}: ghosts {sdb.n_ghost}, rows {sdb.n_rows}, ok {ok}", flush=True)
+if world > 1 and sdb.n_ghost == 0:
+    ok = False
+    print("no ghost references: the cut did not go through a cluster", flush=True)
+sdb.close()
+dist.barrier()
+dist.destroy_process_group()
+sys.exit(0 if ok else 1)
+'''
+
+
+def _launch(world: int, n_refs: int, tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), YH_ROOT=ROOT, YH_NREFS=str(n_refs), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            out, _ = p.communicate()
+        outs.append(out)
+    return [p.returncode for p in procs], outs
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_sharded_refdb_hip_processes_share_gpu(hip_lib, tmp_path, world):
+    rcs, outs = _launch(world, 3000, tmp_path)
+    assert all(rc == 0 for rc in rcs), "\n".join(outs)
+
+
+def test_bench_two_ranks_share_gpu_strong_and_weak(hip_lib, tmp_path):
+    """bench.py --gpus 2 over gloo on one GPU: the driver-run N > 1 path, bit-exact against the oracle."""
+    for scaling in ("strong", "weak"):
+        port = _free_port()
+        procs = []
+        for r in range(2):
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+            procs.append(subprocess.Popen(
+                [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
+                 "--backend", "gloo", "--share-gpu", "--scaling", scaling, "--refs", "4000", "--sample-hashes", "100000",
+                 "--samples", "3", "--percentile-steps", "8", "--present", "50"],
+                env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+        res = [p.communicate(timeout=900) for p in procs]
+        assert all(p.returncode == 0 for p in procs), "\n".join(o + e for o, e in res)
+        line = json.loads(res[0][0].strip().splitlines()[-1])
+        assert line["parity_bit_exact"] is True and line["n_gpus"] == 2 and line["scaling"] == scaling
+        assert line["config"]["refs_total"] == (4000 if scaling == "strong" else 8000)

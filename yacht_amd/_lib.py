@@ -26,6 +26,7 @@ YH_DB_NO_INDEX = 1
 YH_DB_KEEP_CSR = 2
 YH_DB_FULL_INDEX = 4
 YH_DB_PAIRWISE_ONLY = 8
+YH_RUN_SLOTS = 4
 
 _ERR_NAMES = {
     YH_ERR_INVALID_ARG: "YH_ERR_INVALID_ARG",
@@ -100,6 +101,13 @@ SIGNATURES = {
     "yh_exclusive": (C.c_int, [_vp, _vp, _vp, C.c_uint64, _vp, _vp]),
     "yh_run": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp, _vp]),
     "yh_run_device": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp, _vp]),
+    "yh_db_set_ghosts": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _vp]),
+    "yh_run_local_device": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp, _vp, _vp]),
+    "yh_run_finish_device": (C.c_int, [_vp, _vp, _vp]),
+    "yh_run_submit": (C.c_int, [_vp, C.c_int, _vp, C.c_uint64, _vp, _vp, _vp]),
+    "yh_run_wait": (C.c_int, [_vp, C.c_int]),
+    "yh_host_alloc": (C.c_int, [C.POINTER(_vp), C.c_uint64]),
+    "yh_host_free": (C.c_int, [_vp]),
     "yh_db_create_from_pairs": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64, C.c_int, C.c_uint32, C.c_uint64,
                                           C.POINTER(_vp)]),
     "yh_exclusive_partial_device": (C.c_int, [_vp, _vp, _vp, C.c_uint64, _vp, _vp, _vp]),

@@ -335,12 +335,25 @@ int yh_db_destroy(yh_db* db) {
                     db->d_g, db->d_po, db->d_pr, db->d_pg, db->d_gbeg, db->d_gcnt, db->d_nshared, db->d_pq, db->d_pq_count, db->d_dh, db->d_dref, db->d_dir, db->d_bkt, db->d_pkeys, db->d_pref, db->d_gkeys, db->d_rpo, db->d_rg, db->d_rrec, db->d_chunks, db->d_sbounds,
                     db->d_mask, db->d_maskbits, db->d_hit, db->d_excl_e, db->d_overlap_tmp,
                     db->d_sample_tmp, db->d_out_tmp, db->d_flag, db->d_hitq, db->d_hitq_cnt, db->d_wg_first, db->d_reps, db->d_batch,
-                    db->d_sdelta, db->d_shdr, db->d_srec, db->d_wg_key};
+                    db->d_sdelta, db->d_shdr, db->d_srec, db->d_wg_key, db->d_ghost_src};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     ring_destroy(db->ev_overlap);
     ring_destroy(db->ev_excl);
     ring_destroy(db->ev_pair);
+    if (db->st_in) (void)hipStreamSynchronize(db->st_in);
+    if (db->st_out) (void)hipStreamSynchronize(db->st_out);
+    for (RunSlot& s : db->slots) {
+        if (s.d_sample) (void)hipFree(s.d_sample);
+        if (s.d_out) (void)hipFree(s.d_out);
+        if (s.d_bad) (void)hipFree(s.d_bad);
+        if (s.h_bad) (void)hipHostFree(s.h_bad);
+        if (s.ev_up) (void)hipEventDestroy(s.ev_up);
+        if (s.ev_done) (void)hipEventDestroy(s.ev_done);
+        if (s.ev_out) (void)hipEventDestroy(s.ev_out);
+    }
+    if (db->st_in) (void)hipStreamDestroy(db->st_in);
+    if (db->st_out) (void)hipStreamDestroy(db->st_out);
     if (db->own_stream) (void)hipStreamDestroy(db->own_stream);
     free(db->h_pw_i);
     free(db->h_pw_j);
@@ -504,9 +517,10 @@ __global__ void k_check_ascending(const u64* __restrict__ a, u64 n, u32* __restr
 // Host sample -> d_sample_tmp, and the ordering check ON THE DEVICE (a 10^6-hash sample is 8 MB: the
 // host loop over it was ~0.4 ms of the ~0.55 ms a host-pointer query took).  The query kernels assume
 // an ascending sample, so the verdict is awaited before they are queued.
-static int upload_sample(yh_db* db, const uint64_t* sample, uint64_t n_sample) {
+static int upload_sample(yh_db* db, const uint64_t* sample, uint64_t n_sample, bool defer_verdict = false) {
     if (n_sample && !sample) { yh_set_error("sample is null"); return YH_ERR_INVALID_ARG; }
     YH_TRY(ensure_sample_tmp(db, n_sample));
+    if (defer_verdict) YH_HIP(hipMemsetAsync(db->d_flag, 0, sizeof(u32), db->stream));
     if (n_sample < 2) {
         if (n_sample)
             YH_HIP(hipMemcpyAsync(db->d_sample_tmp, sample, n_sample * sizeof(u64), hipMemcpyHostToDevice, db->stream));
@@ -514,9 +528,12 @@ static int upload_sample(yh_db* db, const uint64_t* sample, uint64_t n_sample) {
     }
     u32 verdict = 0;
     YH_HIP(hipMemcpyAsync(db->d_sample_tmp, sample, n_sample * sizeof(u64), hipMemcpyHostToDevice, db->stream));
-    YH_HIP(hipMemsetAsync(db->d_flag, 0, sizeof(u32), db->stream));
+    if (!defer_verdict) YH_HIP(hipMemsetAsync(db->d_flag, 0, sizeof(u32), db->stream));
     k_check_ascending<<<(unsigned)std::min<u64>((n_sample + 255) / 256, 2048), 256, 0, db->stream>>>(db->d_sample_tmp, n_sample,
                                                                                                   db->d_flag);
+    // defer_verdict: the kernels queued next read d_flag themselves (StreamHit::bad) and look nothing up
+    // when it is set; the caller downloads the flag with the counts -- one host sync per call, not two
+    if (defer_verdict) return YH_OK;
     YH_HIP(hipMemcpyAsync(&verdict, db->d_flag, sizeof(u32), hipMemcpyDeviceToHost, db->stream));
     YH_HIP(hipStreamSynchronize(db->stream));
     if (verdict) {
@@ -612,21 +629,161 @@ int yh_run(yh_db* db, const uint64_t* sample, uint64_t n_sample, uint32_t* overl
     if (N && (!overlap || !n_excl || !n_match)) { yh_set_error("null argument"); return YH_ERR_INVALID_ARG; }
     if (!db->has_index) { yh_set_error("this handle was created with YH_DB_NO_INDEX"); return YH_ERR_UNSUPPORTED; }
     YH_TRY(db_select(db));
-    YH_TRY(upload_sample(db, sample, n_sample));
-    if (N == 0) return YH_OK;
+    const bool defer = db->d_sdelta != nullptr && db->d_flag != nullptr;  // the stream kernel honours the device-side verdict
+    YH_TRY(upload_sample(db, sample, n_sample, defer));
+    if (N == 0) {
+        if (defer) YH_HIP(hipStreamSynchronize(db->stream));
+        return YH_OK;
+    }
     u32 *d_e = nullptr, *d_m = nullptr;
     YH_TRY(ensure_out_tmp(db, &d_e, &d_m));
+    if (defer) db->d_bad = db->d_flag;
     int rc = yh_run_device(db, (const uint64_t*)db->d_sample_tmp, n_sample, db->d_overlap_tmp, d_e, d_m);
+    db->d_bad = nullptr;
+    u32 verdict = 0;
     if (rc == YH_OK) {
         if (hipMemcpyAsync(overlap, db->d_overlap_tmp, N * sizeof(u32), hipMemcpyDeviceToHost, db->stream) != hipSuccess ||
             hipMemcpyAsync(n_excl, d_e, N * sizeof(u32), hipMemcpyDeviceToHost, db->stream) != hipSuccess ||
             hipMemcpyAsync(n_match, d_m, N * sizeof(u32), hipMemcpyDeviceToHost, db->stream) != hipSuccess ||
+            (defer && hipMemcpyAsync(&verdict, db->d_flag, sizeof(u32), hipMemcpyDeviceToHost, db->stream) != hipSuccess) ||
             hipStreamSynchronize(db->stream) != hipSuccess) {
             yh_set_error("run download failed: %s", hipGetErrorString(hipGetLastError()));
             rc = YH_ERR_HIP;
         }
     }
+    if (rc == YH_OK && verdict) {
+        yh_set_error("the sample sketch is not strictly ascending");
+        rc = YH_ERR_UNSORTED;
+    }
     return rc;
+}
+
+// ---- sharded run: the step in two halves around the exchange of the subset bits -----------------------
+int yh_db_set_ghosts(yh_db* db, uint64_t ghost_begin, uint64_t n_ghost, const uint32_t* d_ghost_src) {
+    if (!db_ok(db)) return YH_ERR_INVALID_ARG;
+    if ((ghost_begin & 63u) || ghost_begin + n_ghost > db->n_refs || (n_ghost && !d_ghost_src)) {
+        yh_set_error("ghost range must start at a multiple of 64 and lie inside the handle's references");
+        return YH_ERR_INVALID_ARG;
+    }
+    YH_TRY(db_select(db));
+    YH_HIP(hipStreamSynchronize(db->stream));
+    if (db->d_ghost_src) { (void)hipFree(db->d_ghost_src); db->d_ghost_src = nullptr; }
+    db->ghost_begin = ghost_begin;
+    db->n_ghost = n_ghost;
+    if (n_ghost) {
+        YH_TRY(yh_dmalloc(db, (void**)&db->d_ghost_src, n_ghost * sizeof(u32)));
+        YH_HIP(hipMemcpyAsync(db->d_ghost_src, d_ghost_src, n_ghost * sizeof(u32), hipMemcpyDeviceToDevice, db->stream));
+        YH_HIP(hipStreamSynchronize(db->stream));
+    }
+    return YH_OK;
+}
+
+int yh_run_local_device(yh_db* db, const uint64_t* d_sample, uint64_t n_sample, uint32_t* d_overlap, uint32_t* d_n_excl,
+                        uint32_t* d_n_match, uint32_t* d_bits_out) {
+    if (!db_ok(db)) return YH_ERR_INVALID_ARG;
+    if (!d_overlap || !d_n_excl || !d_n_match || (n_sample && !d_sample)) { yh_set_error("null device pointer"); return YH_ERR_INVALID_ARG; }
+    YH_TRY(db_select(db));
+    const int rc = yh_q_run_fused(db, (const u64*)d_sample, n_sample, d_overlap, d_n_excl, d_n_match, 1, d_bits_out, nullptr);
+    if (rc == 1) { yh_set_error("yh_run_local_device needs a non-empty handle in the default layout with its index"); return YH_ERR_UNSUPPORTED; }
+    return rc;
+}
+
+int yh_run_finish_device(yh_db* db, const uint32_t* d_global_bits, uint32_t* d_n_excl) {
+    if (!db_ok(db)) return YH_ERR_INVALID_ARG;
+    if (!d_n_excl || (db->n_ghost && !d_global_bits)) { yh_set_error("null device pointer"); return YH_ERR_INVALID_ARG; }
+    YH_TRY(db_select(db));
+    const int rc = yh_q_run_fused(db, nullptr, 1, nullptr, d_n_excl, nullptr, 2, nullptr, d_global_bits);
+    if (rc == 1) { yh_set_error("yh_run_finish_device needs a non-empty handle in the default layout with its index"); return YH_ERR_UNSUPPORTED; }
+    return rc;
+}
+
+// ---- pipelined host-buffer run calls ---------------------------------------------------------------
+static int slot_prepare(yh_db* db, RunSlot& s, u64 n_sample) {
+    const u64 N = std::max<u64>(db->n_refs, 1);
+    if (!db->st_in) YH_HIP(hipStreamCreateWithFlags(&db->st_in, hipStreamNonBlocking));
+    if (!db->st_out) YH_HIP(hipStreamCreateWithFlags(&db->st_out, hipStreamNonBlocking));
+    if (!s.ev_up) {
+        YH_HIP(hipEventCreateWithFlags(&s.ev_up, hipEventDisableTiming));
+        YH_HIP(hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
+        YH_HIP(hipEventCreateWithFlags(&s.ev_out, hipEventDisableTiming));
+    }
+    if (!s.d_out) YH_TRY(yh_dmalloc(db, (void**)&s.d_out, 3 * N * sizeof(u32) + 16));
+    if (!s.d_bad) {
+        YH_TRY(yh_dmalloc(db, (void**)&s.d_bad, 16));
+        YH_HIP(hipHostMalloc((void**)&s.h_bad, 16, hipHostMallocDefault));
+    }
+    if (s.cap < n_sample) {
+        if (s.d_sample) { (void)hipFree(s.d_sample); s.d_sample = nullptr; s.cap = 0; }
+        const u64 cap = std::max<u64>(n_sample + n_sample / 8, 1024);
+        YH_HIP(hipMalloc((void**)&s.d_sample, cap * sizeof(u64)));
+        s.cap = cap;
+    }
+    return YH_OK;
+}
+
+int yh_run_submit(yh_db* db, int slot, const uint64_t* sample, uint64_t n_sample, uint32_t* overlap,
+                  uint32_t* n_excl, uint32_t* n_match) {
+    if (!db_ok(db)) return YH_ERR_INVALID_ARG;
+    if (slot < 0 || slot >= YH_RUN_SLOTS) { yh_set_error("slot %d out of range [0, %d)", slot, YH_RUN_SLOTS); return YH_ERR_INVALID_ARG; }
+    const u64 N = db->n_refs;
+    if ((N && (!overlap || !n_excl || !n_match)) || (n_sample && !sample)) { yh_set_error("null argument"); return YH_ERR_INVALID_ARG; }
+    if (!db->has_index || !db->d_sdelta) { yh_set_error("yh_run_submit needs the default layout with its index"); return YH_ERR_UNSUPPORTED; }
+    if (n_sample > 0xfffffff0ull) { yh_set_error("sample larger than 2^32-16 hashes"); return YH_ERR_INVALID_ARG; }
+    RunSlot& s = db->slots[slot];
+    if (s.busy) { yh_set_error("slot %d is in flight: yh_run_wait it first", slot); return YH_ERR_INVALID_ARG; }
+    YH_TRY(db_select(db));
+    YH_TRY(slot_prepare(db, s, n_sample));
+    // upload on the copy-in stream
+    if (n_sample) YH_HIP(hipMemcpyAsync(s.d_sample, sample, n_sample * sizeof(u64), hipMemcpyHostToDevice, db->st_in));
+    YH_HIP(hipEventRecord(s.ev_up, db->st_in));
+    // ordering check + kernels on the handle's stream, behind the upload
+    YH_HIP(hipStreamWaitEvent(db->stream, s.ev_up, 0));
+    YH_HIP(hipMemsetAsync(s.d_bad, 0, sizeof(u32), db->stream));
+    if (n_sample > 1)
+        k_check_ascending<<<(unsigned)std::min<u64>((n_sample + 255) / 256, 2048), 256, 0, db->stream>>>(s.d_sample, n_sample, s.d_bad);
+    int rc = YH_OK;
+    if (N) {
+        db->d_bad = s.d_bad;
+        rc = yh_run_device(db, (const uint64_t*)s.d_sample, n_sample, s.d_out, s.d_out + N, s.d_out + 2 * N);
+        db->d_bad = nullptr;
+    }
+    YH_HIP(hipEventRecord(s.ev_done, db->stream));
+    if (rc != YH_OK) return rc;
+    // download on the copy-out stream, behind the kernels
+    YH_HIP(hipStreamWaitEvent(db->st_out, s.ev_done, 0));
+    if (N) {
+        YH_HIP(hipMemcpyAsync(overlap, s.d_out, N * sizeof(u32), hipMemcpyDeviceToHost, db->st_out));
+        YH_HIP(hipMemcpyAsync(n_excl, s.d_out + N, N * sizeof(u32), hipMemcpyDeviceToHost, db->st_out));
+        YH_HIP(hipMemcpyAsync(n_match, s.d_out + 2 * N, N * sizeof(u32), hipMemcpyDeviceToHost, db->st_out));
+    }
+    YH_HIP(hipMemcpyAsync(s.h_bad, s.d_bad, sizeof(u32), hipMemcpyDeviceToHost, db->st_out));
+    YH_HIP(hipEventRecord(s.ev_out, db->st_out));
+    s.busy = true;
+    return YH_OK;
+}
+
+int yh_run_wait(yh_db* db, int slot) {
+    if (!db_ok(db)) return YH_ERR_INVALID_ARG;
+    if (slot < 0 || slot >= YH_RUN_SLOTS) { yh_set_error("slot %d out of range [0, %d)", slot, YH_RUN_SLOTS); return YH_ERR_INVALID_ARG; }
+    RunSlot& s = db->slots[slot];
+    if (!s.busy) { yh_set_error("slot %d has no call in flight", slot); return YH_ERR_INVALID_ARG; }
+    YH_TRY(db_select(db));
+    s.busy = false;
+    YH_HIP(hipEventSynchronize(s.ev_out));
+    if (*s.h_bad) { yh_set_error("the sample sketch is not strictly ascending"); return YH_ERR_UNSORTED; }
+    return YH_OK;
+}
+
+int yh_host_alloc(void** out, uint64_t bytes) {
+    if (!out) { yh_set_error("out is null"); return YH_ERR_INVALID_ARG; }
+    *out = nullptr;
+    hipError_t e = hipHostMalloc(out, std::max<uint64_t>(bytes, 16), hipHostMallocDefault);
+    if (e != hipSuccess) { yh_set_error("hipHostMalloc(%llu) failed: %s", (u64)bytes, hipGetErrorString(e)); return YH_ERR_OOM; }
+    return YH_OK;
+}
+int yh_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
+    return YH_OK;
 }
 
 // ---- pairwise --------------------------------------------------------------------------------------

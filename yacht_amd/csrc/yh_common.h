@@ -121,6 +121,18 @@ struct EventRing {
     bool created = false;
 };
 
+// One in-flight host-buffer run call (yh_run_submit / yh_run_wait): its own sample and count buffers
+// in HBM, so that the upload of call k+1 and the download of call k-1 overlap the kernels of call k.
+struct RunSlot {
+    u64* d_sample = nullptr;
+    u64 cap = 0;
+    u32* d_out = nullptr;     // [3][N] overlap, n_excl, n_match
+    u32* d_bad = nullptr;     // [1] set by the ordering check queued in front of the kernels
+    u32* h_bad = nullptr;     // pinned copy, read by yh_run_wait
+    hipEvent_t ev_up = nullptr, ev_done = nullptr, ev_out = nullptr;
+    bool busy = false;
+};
+
 struct yh_db {
     int device = -1;
     uint32_t flags = 0;
@@ -230,6 +242,16 @@ struct yh_db {
     u32* h_pw_j = nullptr;
     u32* h_pw_c = nullptr;
 
+    // sharded run (yh_db_set_ghosts): references [ghost_begin, ghost_begin + n_ghost) are copies of other
+    // ranks' references; their subset bits come from the owners (k_ghost_bits)
+    u32* d_ghost_src = nullptr;  // [n_ghost] bit index into the all-gathered subset bits
+    u64 ghost_begin = 0, n_ghost = 0;
+
+    // pipelined host-buffer calls
+    RunSlot slots[YH_RUN_SLOTS];
+    hipStream_t st_in = nullptr, st_out = nullptr;  // copy streams beside `stream`
+    const u32* d_bad = nullptr;  // non-null while a submitted call's kernels are being queued (see StreamHit::bad)
+
     // timing
     EventRing ev_overlap, ev_excl, ev_pair;
     float ms_db_build = 0.f;
@@ -244,7 +266,10 @@ bool yh_use_delta_stream();  // YH_STREAM=delta at handle creation (default: par
 
 // ---- implemented in yh_query.hip -------------------------------------------------------------
 int yh_q_overlap(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap, bool flag_shared, bool make_mask);
-int yh_q_run_fused(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap, u32* d_excl, u32* d_match);  // 1 = not applicable
+// phases: 1 = lookup + reduce (leaves the subset bits in d_maskbits and, optionally, d_bits_out), 2 = the
+// posting-list part of n_excl (ghost bits patched from d_global_bits first), 3 = both.  1 = not applicable.
+int yh_q_run_fused(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap, u32* d_excl, u32* d_match,
+                   int phases = 3, u32* d_bits_out = nullptr, const u32* d_global_bits = nullptr);
 int yh_q_overlap_bsearch(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap);
 // ---- the distinct-hash directory as the lookup kernels see it -------------------------------------
 // Primary structure: a table of 64-byte buckets, bucket(h) = floor(h * bkt_nb / 2^bits(max_hash))

@@ -141,6 +141,7 @@ struct FusedRun {
     const u32* nshared;
     u32* n_excl;
     u32* n_match;
+    u32* bits_out;  // may be null: a second copy of the subset bits (the sharded run hands them to the other ranks)
 };
 __global__ void __launch_bounds__(256) k_reduce_replicas(u32* __restrict__ reps, u32 R, u64 n,
                                                          u32* __restrict__ out, u8* __restrict__ mask,
@@ -171,7 +172,30 @@ __global__ void __launch_bounds__(256) k_reduce_replicas(u32* __restrict__ reps,
         if ((threadIdx.x & 63) == 0) {
             maskbits[(j >> 5)] = (u32)bal;
             maskbits[(j >> 5) + 1] = (u32)(bal >> 32);
+            if (fused.bits_out) {
+                fused.bits_out[(j >> 5)] = (u32)bal;
+                fused.bits_out[(j >> 5) + 1] = (u32)(bal >> 32);
+            }
         }
+    }
+}
+
+// Sharded run: the subset bits of the GHOST references (copies of other ranks' references that share a
+// hash with one of ours, appended behind the local ones from a multiple of 64 on) come from the
+// all-gathered bits of their owners: ghost k's bit is bit src[k] of `global_bits`.
+__global__ void __launch_bounds__(256) k_ghost_bits(const u32* __restrict__ global_bits, const u32* __restrict__ src,
+                                                    u64 ghost_begin, u64 n_ghost, u32* __restrict__ maskbits) {
+    const u64 k = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    bool on = false;
+    if (k < n_ghost) {
+        const u32 b = src[k];
+        on = (global_bits[b >> 5] >> (b & 31u)) & 1u;
+    }
+    const u64 bal = __ballot(on);
+    if ((threadIdx.x & 63) == 0 && (k & ~63ull) < n_ghost) {
+        const u64 w = (ghost_begin + k) >> 5;  // ghost_begin is a multiple of 64
+        maskbits[w] = (u32)bal;
+        maskbits[w + 1] = (u32)(bal >> 32);
     }
 }
 
@@ -862,6 +886,8 @@ struct StreamHit {
     u8* hitflag;        // may be null: hit[g] = 1 for every shared hash g found in the sample
     u32* reps2;         // may be null: a second set of replicas counting the hits ON SHARED HASHES only
     const u64* sample;
+    const u32* bad;     // may be null: *bad != 0 = the sample failed the ordering check queued in front of
+                        // this kernel (pipelined host-buffer calls): nothing is looked up, counts stay zero
 };
 
 // Geometry of k_stream_lookup: 512 threads = 8 waves per workgroup, two workgroups per CU (~75 KB of
@@ -1196,6 +1222,7 @@ k_stream_lookup(const u32x4* __restrict__ deltas, const u64* __restrict__ hdr, u
     __shared__ u32 tcnt2[STREAM_TSLOTS];
 
     const u32 tid = threadIdx.x;
+    if (hit.bad && *hit.bad) return;  // (wave-uniform scalar load)
     const u32 wv = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const u32 lid = xcd_remap(blockIdx.x, gridDim.x);
     const u64 per = (nblk + gridDim.x - 1) / gridDim.x;
@@ -1776,7 +1803,7 @@ static int claim_hit_flags(yh_db* db) {
 // launches -- no shared-hash flags, no exclusive accumulators, no finalize kernel (k_reduce_replicas).
 static int yh_q_overlap_stream(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap, bool flag_shared,
                                bool with_index, bool make_mask, u32* d_fused_excl = nullptr,
-                               u32* d_fused_match = nullptr) {
+                               u32* d_fused_match = nullptr, u32* d_bits_out = nullptr) {
     hipStream_t st = db->stream;
     const u64 N = db->n_refs;
     const u64 nblk = db->slen / STREAM_BLOCK;
@@ -1801,7 +1828,7 @@ static int yh_q_overlap_stream(yh_db* db, const u64* d_sample, u64 n_sample, u32
     // workgroup finds its own range of the sample (two 64-ary wave searches while its first
     // super-block is in flight).
     u32* const reps2 = db->d_reps + db->reps_cap;
-    StreamHit sh{(u32)N, db->d_reps, R - 1, db->d_srec, flags_too ? db->d_hit : nullptr, fused ? reps2 : nullptr, d_sample};
+    StreamHit sh{(u32)N, db->d_reps, R - 1, db->d_srec, flags_too ? db->d_hit : nullptr, fused ? reps2 : nullptr, d_sample, db->d_bad};
     yh_ring_record_begin(db, db->ev_overlap);
     k_stream_lookup<<<wgs, STREAM_THREADS, 0, st>>>(reinterpret_cast<const u32x4*>(db->d_sdelta), db->d_shdr, nblk, d_sample,
                                                     (u32)n_sample, db->d_wg_key, db->sshift, sh);
@@ -1809,7 +1836,7 @@ static int yh_q_overlap_stream(yh_db* db, const u64* d_sample, u64 n_sample, u32
     k_reduce_replicas<<<(u32)((N + 255) / 256), 256, 0, st>>>(
         db->d_reps, R, N, d_overlap, (make_mask && !fused) ? db->d_mask : nullptr, make_mask ? db->d_maskbits : nullptr,
         (with_index && !fused) ? db->d_excl_e : nullptr,
-        fused ? FusedRun{reps2, db->d_sizes, db->d_nshared, d_fused_excl, d_fused_match} : FusedRun{});
+        fused ? FusedRun{reps2, db->d_sizes, db->d_nshared, d_fused_excl, d_fused_match, d_bits_out} : FusedRun{});
     YH_HIP(hipGetLastError());
     return YH_OK;
 }
@@ -1890,18 +1917,36 @@ int yh_q_overlap(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap, b
 
 // The `yacht run` step on the hash-sorted stream: overlap, subset = overlap > 0, exclusive counts.
 // Returns 1 when this handle cannot take the fused path (the caller then runs the general one).
-int yh_q_run_fused(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap, u32* d_excl, u32* d_match) {
+int yh_q_run_fused(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap, u32* d_excl, u32* d_match, int phases,
+                   u32* d_bits_out, const u32* d_global_bits) {
     static const bool off = [] { const char* e = getenv("YH_NO_FUSED_RUN"); return e && e[0] == '1'; }();
-    if (off || !db->d_sdelta || !db->has_index || db->posting_only || !db->d_chunks || !db->d_rrec || db->n_refs == 0 ||
-        db->n_hashes == 0 || n_sample == 0 || n_sample > 0xfffffff0ull)
+    if (!db->d_sdelta || !db->has_index || db->posting_only || db->n_refs == 0 || db->n_hashes == 0 ||
+        (db->n_postings && (!db->d_rrec || !db->d_chunks)) || n_sample > 0xfffffff0ull)
         return 1;
+    if (phases == 3 && (off || n_sample == 0)) return 1;
     hipStream_t st = db->stream;
-    YH_TRY(yh_q_overlap_stream(db, d_sample, n_sample, d_overlap, true, true, true, d_excl, d_match));
-    yh_ring_record_begin(db, db->ev_excl);
-    if (db->n_chunks)  // + the shared hashes of the subset's references whose other holders are all outside it
-        k_excl_chunks_e<<<(db->n_chunks + 255) / 256, 256, 0, st>>>(db->n_chunks, db->d_chunks, db->d_rpo, db->d_rrec,
-                                                               (u32)db->n_postings, db->d_pr, db->d_maskbits, d_excl);
-    yh_ring_record_end(db, db->ev_excl);
+    if (phases & 1) {  // lookup + reduce: overlap, n_match, the singleton part of n_excl, the subset bits
+        if (n_sample == 0) {  // (sharded callers only: the one-call form takes the general path)
+            const u64 N = db->n_refs;
+            YH_HIP(hipMemsetAsync(d_overlap, 0, N * sizeof(u32), st));
+            YH_HIP(hipMemsetAsync(d_excl, 0, N * sizeof(u32), st));
+            YH_HIP(hipMemsetAsync(d_match, 0, N * sizeof(u32), st));
+            YH_HIP(hipMemsetAsync(db->d_maskbits, 0, ((N + 255) / 256) * 32, st));
+            if (d_bits_out) YH_HIP(hipMemsetAsync(d_bits_out, 0, ((N + 63) / 64) * 8, st));
+        } else {
+            YH_TRY(yh_q_overlap_stream(db, d_sample, n_sample, d_overlap, true, true, true, d_excl, d_match, d_bits_out));
+        }
+    }
+    if (phases & 2) {
+        yh_ring_record_begin(db, db->ev_excl);
+        if (db->n_ghost && d_global_bits)
+            k_ghost_bits<<<(u32)((db->n_ghost + 255) / 256), 256, 0, st>>>(d_global_bits, db->d_ghost_src, db->ghost_begin,
+                                                                        db->n_ghost, db->d_maskbits);
+        if (db->n_chunks)  // + the shared hashes of the subset's references whose other holders are all outside it
+            k_excl_chunks_e<<<(db->n_chunks + 255) / 256, 256, 0, st>>>(db->n_chunks, db->d_chunks, db->d_rpo, db->d_rrec,
+                                                                   (u32)db->n_postings, db->d_pr, db->d_maskbits, d_excl);
+        yh_ring_record_end(db, db->ev_excl);
+    }
     YH_HIP(hipGetLastError());
     return YH_OK;
 }
@@ -1935,7 +1980,7 @@ int yh_q_overlap_indexed(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_ov
     k_reduce_replicas<<<(u32)((N + 255) / 256), 256, 0, st>>>(
         db->d_reps, R, N, d_overlap, (for_exclusive && !fused) ? db->d_mask : nullptr,
         for_exclusive ? db->d_maskbits : nullptr, (for_exclusive && !fused) ? db->d_excl_e : nullptr,
-        fused ? FusedRun{reps2, db->d_sizes, db->d_nshared, d_fused_excl, d_fused_match} : FusedRun{});
+        fused ? FusedRun{reps2, db->d_sizes, db->d_nshared, d_fused_excl, d_fused_match, nullptr} : FusedRun{});
     if (fused) {
         yh_ring_record_begin(db, db->ev_excl);
         if (db->n_chunks)

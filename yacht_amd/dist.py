@@ -280,3 +280,230 @@ class ShardedRun:
             h = part.get("handle")
             if h is not None:
                 h.close()
+
+
+# ======================================================================================================
+# The `yacht run` step over ranks with ONE small exchange: ghosts (include/yacht_hip.h, "references
+# spread over several GPUs, the `yacht run` subset")
+# ======================================================================================================
+# ShardedRun above answers exclusivity for an ARBITRARY subset and pays for it: an all-gather of the
+# counts and an all-reduce of [3, N_total] per sample.  `yacht run` only ever asks for the subset
+# "overlap > 0" (hypothesis_recovery_src.py:361-378), and for that subset a rank can finish its own
+# references alone once its index knows every holder of every hash it holds -- including holders on
+# other ranks -- and one bit per foreign holder: does it overlap the sample at all?  So, once per
+# database, the hash-range owners (same all_to_all as above) send back, for every hash with holders on
+# more than one rank, the foreign postings to each holder's rank; a rank appends those foreign
+# references as GHOSTS (extra references holding only such hashes) behind its own, and the library
+# builds the usual handle over the lot.  Per sample: local lookup + reduce -> all-gather of the subset
+# bits (N_total / 8 bytes; latency-bound over xGMI) -> ghosts' bits patched, posting-list part added.
+# The per-reference counts leave in one final gather, which the caller may overlap with the next sample.
+def _is_gloo(group) -> bool:
+    import torch.distributed as dist
+
+    return dist.get_backend(group) == "gloo"
+
+
+def _stage(t, group):
+    """gloo moves CPU tensors: device tensors are staged through the host there (CPU tests, and the
+    two-processes-on-one-GPU test); RCCL takes the device tensor as it is."""
+    return t.cpu() if (t.is_cuda and _is_gloo(group)) else t
+
+
+def all_gather_into(out_t, in_t, group=None):
+    """dist.all_gather_into_tensor on the current stream (staged through the host for gloo)."""
+    import torch.distributed as dist
+
+    if in_t.is_cuda and _is_gloo(group):
+        o = out_t.cpu()
+        dist.all_gather_into_tensor(o, in_t.cpu().contiguous(), group=group)
+        out_t.copy_(o)
+        return
+    dist.all_gather_into_tensor(out_t, in_t.contiguous(), group=group)
+
+
+def all_to_all_v(in_t, send_counts, group=None):
+    """Variable all-to-all of a 1-D tensor cut at `send_counts`: (received tensor, recv_counts)."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    src = _stage(in_t, group).contiguous()
+    send_t = torch.tensor(list(send_counts), dtype=torch.int64, device=src.device)
+    recv_t = torch.zeros(world, dtype=torch.int64, device=src.device)
+    dist.all_to_all_single(recv_t, send_t, group=group)
+    recv = [int(x) for x in recv_t.tolist()]
+    out = torch.empty(sum(recv), dtype=in_t.dtype, device=src.device)
+    dist.all_to_all_single(out, src, recv, list(send_counts), group=group)
+    return out.to(in_t.device), recv
+
+
+class HipLocalBackend:
+    """The compute side of ShardedRefDB on the HIP engine: one RefDB over local references + ghosts.
+    Everything is queued on torch's CURRENT stream (the handle is pointed at it), so the collectives
+    torch issues on that stream are ordered with the kernels without host synchronisation."""
+
+    def __init__(self, device_index: int):
+        self.device_index = device_index
+
+    def make_local_db(self, values_t, offsets_t, ghost_begin: int, ghost_src_t):
+        import torch
+
+        from .engine import RefDB
+
+        n = offsets_t.numel() - 1
+        torch.cuda.current_stream().synchronize()  # build-time: the CSR tensors are complete
+        db = RefDB.from_device(values_t.data_ptr(), offsets_t.data_ptr(), n, device=self.device_index)
+        n_ghost = int(ghost_src_t.numel())
+        if n_ghost:
+            db.set_ghosts(ghost_begin, n_ghost, ghost_src_t.data_ptr())
+        backend = self
+
+        class _Local:
+            handle = db
+
+            def bind_stream(self):
+                db.set_stream(torch.cuda.current_stream().cuda_stream)
+
+            def run_local(self, sample_t, counts_t, bits_t):
+                db.run_local_device(sample_t.data_ptr(), sample_t.numel(), counts_t[0].data_ptr(), counts_t[1].data_ptr(),
+                                    counts_t[2].data_ptr(), bits_t.data_ptr())
+
+            def run_finish(self, global_bits_t, counts_t):
+                db.run_finish_device(global_bits_t.data_ptr(), counts_t[1].data_ptr())
+
+            def close(self):
+                db.close()
+
+        loc = _Local()
+        loc.bind_stream()
+        return loc
+
+
+class ShardedRefDB:
+    """`yacht run` counts for references spread over the ranks of `group`, subset = overlap > 0.
+
+    values_t / offsets_t: this rank's references (CSR, offsets rebased to 0) as int64 tensors holding
+    the uint64 bit patterns, on this rank's device.  Results per rank: a [3, n_pad] int32 tensor whose
+    first n_local columns are overlap / n_exclusive / n_matches of ITS references; gather() assembles
+    the [3, N_total] table in reference order on every rank."""
+
+    def __init__(self, values_t, offsets_t, backend, group=None):
+        import torch
+        import torch.distributed as dist
+
+        self.group = group
+        self.world = world = dist.get_world_size(group)
+        self.rank = rank = dist.get_rank(group)
+        dev = values_t.device
+        self.dev = dev
+        n_local = int(offsets_t.numel() - 1)
+        self.n_local = n_local
+        sizes_local = (offsets_t[1:] - offsets_t[:-1])
+
+        lens_t = torch.zeros(world, dtype=torch.int64, device="cpu" if _is_gloo(group) else dev)
+        dist.all_gather_into_tensor(lens_t, torch.tensor([n_local], dtype=torch.int64, device=lens_t.device), group=group)
+        lens = [int(x) for x in lens_t.tolist()]
+        starts = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        self.plan = [(int(starts[r]), int(starts[r + 1])) for r in range(world)]
+        self.n_total = int(starts[-1])
+        # bit space of the exchange: rank r's reference i is bit r * BITS + i
+        self.words = 2 * ((max(lens + [1]) + 63) // 64)
+        BITS = self.words * 32
+        n_pad = ((n_local + 63) // 64) * 64
+
+        ghost_vals = torch.zeros(0, dtype=torch.int64, device=dev)
+        ghost_sizes = torch.zeros(0, dtype=torch.int64, device=dev)
+        ghost_src = torch.zeros(0, dtype=torch.int32, device=dev)
+        if world > 1:
+            # (hash, global bit id) pairs in hash order, cut at the owners' range bounds
+            key = values_t ^ _SIGN  # signed order == unsigned hash order
+            top = key.max().reshape(1).clone() if values_t.numel() else torch.tensor([_SIGN], dtype=torch.int64, device=dev)
+            top_c = _stage(top, group)
+            dist.all_reduce(top_c, op=dist.ReduceOp.MAX, group=group)
+            max_hash = int(top_c.item() ^ _SIGN) & (2 ** 64 - 1)
+            gid = torch.repeat_interleave(torch.arange(n_local, device=dev, dtype=torch.int64) + rank * BITS, sizes_local)
+            key, perm = torch.sort(key, stable=True)
+            gid = gid[perm]
+            del perm
+            bounds = [(((max_hash + 1) * d) // world) for d in range(1, world)]
+            bkeys = torch.tensor([(b - 2 ** 63) for b in bounds], dtype=torch.int64, device=dev)
+            cuts = [0] + [int(c) for c in torch.searchsorted(key, bkeys).tolist()] + [int(key.numel())]
+            send = [cuts[d + 1] - cuts[d] for d in range(world)]
+            h_in, _ = all_to_all_v(key, send, group)       # (still in signed-order form)
+            g_in, _ = all_to_all_v(gid, send, group)
+            del key, gid
+            # owner side: runs of equal hashes whose holders live on more than one rank
+            h_in, perm = torch.sort(h_in, stable=True)
+            g_in = g_in[perm]
+            del perm
+            n_in = int(h_in.numel())
+            if n_in:
+                head = torch.ones(n_in, dtype=torch.bool, device=dev)
+                head[1:] = h_in[1:] != h_in[:-1]
+                run = torch.cumsum(head.to(torch.int64), 0) - 1
+                n_runs = int(run[-1].item()) + 1
+                r_of = torch.div(g_in, BITS, rounding_mode="floor")
+                present = torch.zeros((n_runs, world), dtype=torch.bool, device=dev)
+                present[run, r_of] = True
+                multi = present.sum(dim=1) > 1
+            back_h, back_g, back_n = [], [], []
+            for d in range(world):
+                if n_in:
+                    sel = multi[run] & present[run, d] & (r_of != d)
+                    back_h.append(h_in[sel])
+                    back_g.append(g_in[sel])
+                else:
+                    back_h.append(h_in[:0])
+                    back_g.append(g_in[:0])
+                back_n.append(int(back_h[-1].numel()))
+            fh, _ = all_to_all_v(torch.cat(back_h), back_n, group)
+            fg, _ = all_to_all_v(torch.cat(back_g), back_n, group)
+            del h_in, g_in, back_h, back_g
+            if fh.numel():
+                # ghosts: foreign references ordered by global id, their hashes ascending
+                fh, perm = torch.sort(fh, stable=True)
+                fg = fg[perm]
+                fg, perm = torch.sort(fg, stable=True)
+                fh = fh[perm]
+                uniq, cnt = torch.unique_consecutive(fg, return_counts=True)
+                ghost_vals = fh ^ _SIGN
+                ghost_sizes = cnt
+                ghost_src = uniq.to(torch.int32)
+        self.n_ghost = int(ghost_src.numel())
+        pad = torch.zeros(n_pad - n_local, dtype=torch.int64, device=dev)
+        all_sizes = torch.cat([sizes_local, pad, ghost_sizes])
+        offs = torch.zeros(all_sizes.numel() + 1, dtype=torch.int64, device=dev)
+        offs[1:] = torch.cumsum(all_sizes, 0)
+        vals = torch.cat([values_t, ghost_vals]).contiguous()
+        self.n_rows = int(all_sizes.numel())
+        self.local = backend.make_local_db(vals, offs.contiguous(), n_pad, ghost_src.contiguous())
+        self._keep = (vals, offs, ghost_src)
+        words_local = max(self.words, 2 * ((self.n_rows + 255) // 256) * 4 + 2)
+        self.bits_local = torch.zeros(words_local, dtype=torch.int32, device=dev)
+        self.bits_global = torch.zeros(world * self.words, dtype=torch.int32, device=dev)
+
+    def new_counts(self):
+        import torch
+
+        return torch.zeros((3, self.n_rows), dtype=torch.int32, device=self.dev)
+
+    def run(self, sample_t, counts_t=None):
+        """One sample: this rank's [3, n_rows] counts (columns [0, n_local) are its references).
+        Stream-ordered on the current stream; no host synchronisation with RCCL."""
+        if counts_t is None:
+            counts_t = self.new_counts()
+        self.local.run_local(sample_t, counts_t, self.bits_local)
+        if self.world > 1:
+            all_gather_into(self.bits_global, self.bits_local[: self.words], group=self.group)
+            self.local.run_finish(self.bits_global, counts_t)
+        else:
+            self.local.run_finish(self.bits_local, counts_t)
+        return counts_t
+
+    def gather(self, counts_t):
+        """[3, N_total] on every rank from the per-rank rows (one collective, shards padded)."""
+        mine = _stage(counts_t[:, : self.n_local], self.group).contiguous()
+        return gather_counts(mine, self.plan, group=self.group).to(self.dev)
+
+    def close(self):
+        self.local.close()

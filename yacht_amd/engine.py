@@ -182,6 +182,32 @@ class RefDB:
         _lib.check(self._lib.yh_run(self._h, _ptr(sample), sample.size, _ptr(ov), _ptr(e), _ptr(m)))
         return ov, e, m
 
+    # sharded run (dist.ShardedRefDB): the step in two halves around the exchange of the subset bits
+    def set_ghosts(self, ghost_begin: int, n_ghost: int, d_ghost_src: int) -> None:
+        _lib.check(self._lib.yh_db_set_ghosts(self._h, ghost_begin, n_ghost, C.c_void_p(d_ghost_src)))
+
+    def run_local_device(self, d_sample: int, n_sample: int, d_overlap: int, d_excl: int, d_match: int,
+                         d_bits_out: int) -> None:
+        _lib.check(self._lib.yh_run_local_device(self._h, C.c_void_p(d_sample), n_sample, C.c_void_p(d_overlap),
+                                                 C.c_void_p(d_excl), C.c_void_p(d_match), C.c_void_p(d_bits_out)))
+
+    def run_finish_device(self, d_global_bits: int, d_excl: int) -> None:
+        _lib.check(self._lib.yh_run_finish_device(self._h, C.c_void_p(d_global_bits), C.c_void_p(d_excl)))
+
+    def run_submit(self, slot: int, sample: np.ndarray, overlap: np.ndarray, n_excl: np.ndarray,
+                   n_match: np.ndarray) -> None:
+        """Queue one `yacht run` count call (upload, ordering check, kernels, download) without waiting;
+        run_wait(slot) completes it.  Arrays must stay alive (and unchanged) until then; page-locked
+        arrays (pinned_empty) make the copies overlap the kernels of the neighbouring calls."""
+        assert sample.dtype == np.uint64 and sample.flags.c_contiguous
+        for a in (overlap, n_excl, n_match):
+            assert a.dtype == np.uint32 and a.flags.c_contiguous and a.size >= self.n_refs
+        _lib.check(self._lib.yh_run_submit(self._h, slot, _ptr(sample), sample.size, _ptr(overlap), _ptr(n_excl),
+                                           _ptr(n_match)))
+
+    def run_wait(self, slot: int) -> None:
+        _lib.check(self._lib.yh_run_wait(self._h, slot))
+
     def run_batch(self, samples: Sequence[np.ndarray]) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
         """run_counts for up to 64 samples in one pass (needs YH_DB_FULL_INDEX): three uint32
         arrays of shape [len(samples), n_refs]."""
@@ -231,6 +257,32 @@ class RefDB:
                                          C.byref(n)))
         k = int(n.value)
         return pi[:k], pj[:k], pc[:k]
+
+
+class PinnedArray:
+    """A page-locked host array (yh_host_alloc) viewed as numpy; freed with the object."""
+
+    def __init__(self, n: int, dtype):
+        lib = _lib.load()
+        self._lib = lib
+        dt = np.dtype(dtype)
+        p = C.c_void_p(0)
+        _lib.check(lib.yh_host_alloc(C.byref(p), max(int(n) * dt.itemsize, 16)))
+        self._p = p
+        buf = (C.c_uint8 * (int(n) * dt.itemsize)).from_address(p.value)
+        self.array = np.frombuffer(buf, dtype=dt, count=int(n))
+
+    def close(self) -> None:
+        if self._p is not None and self._p.value:
+            self.array = None
+            self._lib.yh_host_free(self._p)
+            self._p = C.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def train_select(sizes, pair_i, pair_j) -> np.ndarray:
