@@ -66,6 +66,7 @@ def parse_args():
     ap.add_argument("--no-indexed", action="store_true", help="skip the extra measurement of the sample-driven path")
     ap.add_argument("--no-host-inclusive", action="store_true")
     ap.add_argument("--no-real-shape", action="store_true")
+    ap.add_argument("--host-depth", type=int, default=2, help="host-inclusive leg: calls in flight (1..4)")
     ap.add_argument("--percentile-steps", type=int, default=200)
     ap.add_argument("--sync-gather", action="store_true", help="N>1: blocking gather of the count rows inside every step")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to test the N>1 logic)")
@@ -314,7 +315,7 @@ def main() -> int:
     if world == 1 and not args.no_host_inclusive:
         # SURVEY.md 8d's metric: wall time of the steady-state call INCLUDING sample H2D and counts D2H.
         # Page-locked host buffers, yh_run_submit / yh_run_wait, DEPTH calls in flight.
-        DEPTH = 2
+        DEPTH = max(1, min(args.host_depth, 4))
         h_samples = []
         for s in samples:
             pa = PinnedArray(int(s.numel()), np.uint64)
@@ -322,17 +323,24 @@ def main() -> int:
             h_samples.append(pa)
         h_out = [[PinnedArray(n_local, np.uint32) for _ in range(3)] for _ in range(DEPTH)]
         done_t = []
+        host_t = {"submit": 0.0, "wait": 0.0}
 
         def host_loop(n_steps, record):
             for i in range(n_steps + DEPTH):
                 slot = i % DEPTH
                 if i >= DEPTH:
+                    ta = time.perf_counter()
                     db.run_wait(slot)
+                    tb = time.perf_counter()
                     if record:
-                        done_t.append(time.perf_counter())
+                        done_t.append(tb)
+                        host_t["wait"] += tb - ta
                 if i < n_steps:
                     o = h_out[slot]
+                    ta = time.perf_counter()
                     db.run_submit(slot, h_samples[i % K].array, o[0].array, o[1].array, o[2].array)
+                    if record:
+                        host_t["submit"] += time.perf_counter() - ta
 
         host_loop(args.warmup, False)
         n_host = max(args.steps, args.percentile_steps)
@@ -358,6 +366,8 @@ def main() -> int:
                               h2d_bytes_per_step=8 * n_sample, d2h_bytes_per_step=12 * n_local,
                               h2d_GBps=round(8 * n_sample / (el / n_host) / 1e9, 1),
                               equals_device_resident=ok,
+                              host_ms_in_submit=round(1e3 * host_t["submit"] / n_host, 4),
+                              host_ms_in_wait=round(1e3 * host_t["wait"] / n_host, 4),
                               sync_call_ms_median=round(pct(lat[5:], 50), 4),
                               how="pinned sample -> H2D -> ordering check + kernels -> counts D2H per step "
                                   "(yh_run_submit/yh_run_wait, copy streams beside the compute stream); "
@@ -538,6 +548,7 @@ def main() -> int:
                 "stream_layout": {1: "hash-sorted delta stream", 2: "packed 24-bit keys", 3: "64-bit hashes"}.get(layout, "none"),
                 "stream_bytes": int(info.get("stream_bytes", 0)),
                 "shared_hashes": info["n_shared_distinct"],
+                "shared_postings": info["n_shared_postings"],
                 "ghost_refs_rank0": (sdb.n_ghost if sdb is not None else 0),
                 "db_build_ms": round(float(timing["ms_db_build"]), 2),
                 "db_hbm_bytes": info["device_bytes"],

@@ -1,0 +1,171 @@
+// gather_probe.hip -- how fast can gfx950 answer N independent random 64-byte bucket reads (the shape of
+// the sample-driven lookup), by access form?  Also PCIe H2D rates for the host-inclusive step.
+//   hipcc --offload-arch=gfx950 -O3 -o gather_probe gather_probe.hip && ./gather_probe
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include <algorithm>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+typedef unsigned long long u64;
+typedef uint32_t u32;
+
+__device__ __forceinline__ u64 mix(u64 z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+// sorted-ish keys like a sample: key i = (i * stride + jitter); bucket = key * nb >> 64
+__global__ void k_keys(u64* keys, u64 n, u64 seed) {
+    u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (i < n) {
+        const u64 step = (~0ull) / n;
+        keys[i] = i * step + mix(i + seed) % step;
+    }
+}
+__global__ void k_fill(uint4* t, u64 n16) {
+    for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < n16; i += (u64)gridDim.x * blockDim.x)
+        t[i] = make_uint4((u32)mix(i), (u32)mix(i + 1), (u32)mix(i + 2), (u32)i);
+}
+// V1: one lane per lookup, four 16-byte loads of the same 64-byte bucket
+__global__ void __launch_bounds__(256) k_v1(const u64* __restrict__ keys, u64 n, const uint4* __restrict__ tab, u64 nb, u32* __restrict__ out) {
+    u64 t = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const u64 h = keys[t];
+    const uint4* p = tab + 4 * __umul64hi(h, nb);
+    const uint4 a = p[0], b = p[1], c = p[2], d = p[3];
+    const u32 lo = (u32)h;
+    u32 r = 0;
+    if (a.x == lo) r = c.z; if (a.z == lo) r = c.w; if (b.x == lo) r = d.x; if (b.z == lo) r = d.y; if (c.x == lo) r = d.z;
+    if (r) atomicAdd(&out[r & 1023], 1u);
+}
+// V2: one lane per lookup, ONE 16-byte load (what a 16-byte bucket would cost)
+__global__ void __launch_bounds__(256) k_v2(const u64* __restrict__ keys, u64 n, const uint4* __restrict__ tab, u64 nb, u32* __restrict__ out) {
+    u64 t = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const u64 h = keys[t];
+    const uint4 a = tab[4 * __umul64hi(h, nb)];
+    if (a.x == (u32)h) atomicAdd(&out[a.y & 1023], 1u);
+}
+// V3: four lanes per lookup, 16 bytes each (a wave-instruction touches 16 buckets, fully used)
+__global__ void __launch_bounds__(256) k_v3(const u64* __restrict__ keys, u64 n, const uint4* __restrict__ tab, u64 nb, u32* __restrict__ out) {
+    const u64 gt = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    const u32 lane = threadIdx.x & 63u;
+    const u64 wave0 = (gt & ~63ull);  // 64 lookups per wave, in four rounds of 16
+    u64 hv = (wave0 + lane < n) ? keys[wave0 + lane] : 0;
+    uint4 v[4];
+#pragma unroll
+    for (int rd = 0; rd < 4; ++rd) {
+        const int src = rd * 16 + (int)(lane >> 2);
+        const u64 h = __shfl(hv, src);
+        v[rd] = tab[4 * __umul64hi(h, nb) + (lane & 3u)];
+    }
+    u32 hit = 0;
+#pragma unroll
+    for (int rd = 0; rd < 4; ++rd) {
+        const int src = rd * 16 + (int)(lane >> 2);
+        const u64 h = __shfl(hv, src);
+        if (wave0 + src < n && (v[rd].x == (u32)h || v[rd].z == (u32)h)) hit = v[rd].y | 1u;
+    }
+    if (hit) atomicAdd(&out[hit & 1023], 1u);
+}
+// V4: like V1 but each thread does TWO lookups (more loads in flight per wave)
+__global__ void __launch_bounds__(256) k_v4(const u64* __restrict__ keys, u64 n, const uint4* __restrict__ tab, u64 nb, u32* __restrict__ out) {
+    u64 t = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    const u64 half = (n + 1) / 2;
+    if (t >= half) return;
+    const u64 h0 = keys[t], h1 = (t + half < n) ? keys[t + half] : h0;
+    const uint4* p = tab + 4 * __umul64hi(h0, nb);
+    const uint4* q = tab + 4 * __umul64hi(h1, nb);
+    const uint4 a = p[0], b = p[1], c = p[2], d = p[3];
+    const uint4 a1 = q[0], b1 = q[1], c1 = q[2], d1 = q[3];
+    u32 r = 0;
+    if (a.x == (u32)h0 || b.x == (u32)h0 || c.x == (u32)h0) r = d.x;
+    if (a1.x == (u32)h1 || b1.x == (u32)h1 || c1.x == (u32)h1) r = d1.x;
+    if (r) atomicAdd(&out[r & 1023], 1u);
+}
+// V5: one lane per lookup, one 64-bit... two 32-byte halves as 2 x (2 x 16 B)?  -> 128-byte bucket (8 x 16 B) to see the line-size effect
+__global__ void __launch_bounds__(256) k_v5(const u64* __restrict__ keys, u64 n, const uint4* __restrict__ tab, u64 nb, u32* __restrict__ out) {
+    u64 t = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const u64 h = keys[t];
+    const uint4* p = tab + 8 * __umul64hi(h, nb >> 1);
+    u32 r = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { const uint4 a = p[i]; if (a.x == (u32)h) r = a.y; }
+    if (r) atomicAdd(&out[r & 1023], 1u);
+}
+
+int main(int argc, char** argv) {
+    const u64 table_bytes = 6ull << 30;
+    const u64 nb = table_bytes / 64;
+    uint4* tab; u32* out; u64* keys;
+    CK(hipMalloc(&tab, table_bytes));
+    CK(hipMalloc(&out, 4096));
+    CK(hipMemset(out, 0, 4096));
+    k_fill<<<4096, 256>>>(tab, table_bytes / 16);
+    CK(hipDeviceSynchronize());
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const u64 sizes[] = {83000, 250000, 1000000, 4000000, 16000000};
+    const int REP = 20;
+    for (u64 n : sizes) {
+        CK(hipMalloc(&keys, (u64)REP * n * 8));
+        for (int r = 0; r < REP; ++r) k_keys<<<(unsigned)((n + 255) / 256), 256>>>(keys + (u64)r * n, n, 1000 + r);
+        CK(hipDeviceSynchronize());
+        printf("n = %llu lookups, table %.1f GB:", n, table_bytes / 1e9);
+        for (int v = 1; v <= 5; ++v) {
+            float best = 1e9, sum = 0;
+            for (int r = 0; r < REP; ++r) {
+                const u64* k = keys + (u64)r * n;
+                CK(hipEventRecord(e0));
+                const unsigned g = (unsigned)((n + 255) / 256);
+                if (v == 1) k_v1<<<g, 256>>>(k, n, tab, nb, out);
+                if (v == 2) k_v2<<<g, 256>>>(k, n, tab, nb, out);
+                if (v == 3) k_v3<<<g, 256>>>(k, n, tab, nb, out);
+                if (v == 4) k_v4<<<(g + 1) / 2, 256>>>(k, n, tab, nb, out);
+                if (v == 5) k_v5<<<g, 256>>>(k, n, tab, nb, out);
+                CK(hipEventRecord(e1));
+                CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                if (r >= 2) { best = std::min(best, ms); sum += ms; }
+            }
+            printf("  V%d %.1f us (min %.1f)", v, 1e3 * sum / (REP - 2), 1e3 * best);
+        }
+        printf("\n");
+        CK(hipFree(keys));
+    }
+    // ---- PCIe: pinned host -> device -----------------------------------------------------------------
+    {
+        const u64 bytes = 64ull << 20;
+        void *h, *d;
+        CK(hipHostMalloc(&h, bytes, hipHostMallocDefault));
+        CK(hipMalloc(&d, bytes));
+        memset(h, 1, bytes);
+        hipStream_t s1, s2; CK(hipStreamCreate(&s1)); CK(hipStreamCreate(&s2));
+        for (u64 sz : {1ull << 20, 8ull << 20, 64ull << 20}) {
+            for (int streams = 1; streams <= 2; ++streams) {
+                float best = 1e9;
+                for (int r = 0; r < 6; ++r) {
+                    CK(hipDeviceSynchronize());
+                    CK(hipEventRecord(e0, s1));
+                    if (streams == 1) CK(hipMemcpyAsync(d, h, sz, hipMemcpyHostToDevice, s1));
+                    else {
+                        CK(hipMemcpyAsync(d, h, sz / 2, hipMemcpyHostToDevice, s1));
+                        CK(hipMemcpyAsync((char*)d + sz / 2, (char*)h + sz / 2, sz / 2, hipMemcpyHostToDevice, s2));
+                        CK(hipStreamSynchronize(s2));
+                    }
+                    CK(hipEventRecord(e1, s1));
+                    CK(hipEventSynchronize(e1));
+                    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                    best = std::min(best, ms);
+                }
+                printf("H2D pinned %llu MB, %d stream(s): %.1f us = %.1f GB/s\n", sz >> 20, streams, 1e3 * best, sz / (best * 1e6));
+            }
+        }
+        // device kernel reading the pinned host buffer directly (zero-copy): a copy kernel
+        // (k_fill-like read of host memory)
+    }
+    return 0;
+}

@@ -37,7 +37,16 @@ dev = torch.device("cuda", 0)
 dist.init_process_group("gloo")
 n_total = int(os.environ["YH_NREFS"])
 plan = synth.global_db_plan(31, n_total, cluster_frac=0.6)   # many clusters: the cuts go through some
-shards = ydist.shard_plan(plan["offsets"].astype(np.uint64), world)
+# cuts moved forward to the next cluster MEMBER (its founder stays on the left of the cut): every cut
+# goes through a cluster, so every rank has ghost references
+cuts = [0]
+for r in range(1, world):
+    j = (n_total * r) // world
+    while plan["parent"][j] == j:
+        j += 1
+    cuts.append(j)
+cuts.append(n_total)
+shards = [(cuts[r], cuts[r + 1]) for r in range(world)]
 b, e = shards[rank]
 values, offsets = synth.global_db_refs_device(plan, np.arange(b, e), device="cuda:0")
 sdb = ydist.ShardedRefDB(values, offsets, ydist.HipLocalBackend(0))

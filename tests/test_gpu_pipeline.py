@@ -1,0 +1,109 @@
+"""GPU: the pipelined host-buffer calls (yh_run_submit / yh_run_wait) and the deferred ordering verdict of
+yh_run: results equal the oracle whatever is in flight beside them; an unsorted sample is refused by
+the check queued ON THE DEVICE (nothing is looked up, the call returns YH_ERR_UNSORTED, the handle stays
+usable)."""
+import numpy as np
+import pytest
+
+from oracle import oracle
+from yacht_amd import _lib, synth
+from yacht_amd.engine import PinnedArray, RefDB
+
+pytestmark = pytest.mark.gpu
+
+
+def _db(seed=5, n_refs=1500):
+    values, offsets, _ = synth.config3_like(seed=seed, n_refs=n_refs, n_sample=1000, n_present=5)
+    return values, offsets
+
+
+def _samples(values, offsets, k, rng):
+    refs = [values[int(offsets[j]):int(offsets[j + 1])] for j in range(offsets.size - 1)]
+    out = []
+    for i in range(k):
+        present = rng.choice(len(refs), size=30, replace=False)
+        out.append(synth.sample_from_refs(rng, refs, present, 0.4, 20000 + 3000 * i))
+    return out
+
+
+@pytest.mark.parametrize("pinned", [True, False])
+def test_submit_wait_rotating_slots(hip_lib, pinned):
+    rng = np.random.default_rng(11)
+    values, offsets = _db()
+    n = offsets.size - 1
+    samples = _samples(values, offsets, 7, rng) + [np.zeros(0, np.uint64), np.array([5], np.uint64)]
+    want = []
+    for s in samples:
+        ov = oracle.overlap(values, offsets, s)
+        e, m = oracle.exclusive(values, offsets, ov > 0, s)
+        want.append((ov, e, m))
+    keep = []
+
+    def buf(k, dt):
+        if pinned:
+            pa = PinnedArray(k, dt)
+            keep.append(pa)
+            return pa.array
+        return np.zeros(k, dt)
+
+    with RefDB(values, offsets) as db:
+        depth = _lib.YH_RUN_SLOTS
+        ins = [None] * depth
+        outs = [[buf(n, np.uint32) for _ in range(3)] for _ in range(depth)]
+        order = [int(x) for x in rng.integers(0, len(samples), size=40)]
+        for i, si in enumerate(order + [None] * depth):
+            slot = i % depth
+            if i >= depth:
+                db.run_wait(slot)
+                w = want[order[i - depth]]
+                assert all(np.array_equal(outs[slot][k], w[k]) for k in range(3)), f"call {i - depth}"
+            if si is not None:
+                s = samples[si]
+                h = buf(max(s.size, 1), np.uint64)[: s.size]
+                h[:] = s
+                ins[slot] = h
+                db.run_submit(slot, h, *outs[slot])
+        # a slot in flight cannot be resubmitted; an idle one cannot be waited for
+        db.run_submit(0, ins[0] if ins[0] is not None else samples[0], *outs[0])
+        with pytest.raises(_lib.YachtHipError):
+            db.run_submit(0, samples[0], *outs[0])
+        db.run_wait(0)
+        with pytest.raises(_lib.YachtHipError):
+            db.run_wait(0)
+    for pa in keep:
+        pa.close()
+
+
+def test_unsorted_sample_is_refused_on_device(hip_lib):
+    rng = np.random.default_rng(3)
+    values, offsets = _db(seed=9)
+    n = offsets.size - 1
+    good = _samples(values, offsets, 2, rng)
+    bad = good[0].copy()
+    bad[[100, 5000]] = bad[[5000, 100]]
+    dup = np.concatenate([good[1][:50], good[1][49:]])  # one repeated hash: not STRICTLY ascending
+    ov0 = oracle.overlap(values, offsets, good[0])
+    e0, m0 = oracle.exclusive(values, offsets, ov0 > 0, good[0])
+    with RefDB(values, offsets) as db:
+        outs = [[np.full(n, 7, np.uint32) for _ in range(3)] for _ in range(3)]
+        db.run_submit(0, good[0], *outs[0])
+        db.run_submit(1, bad, *outs[1])
+        db.run_submit(2, good[0], *outs[2])
+        db.run_wait(0)
+        with pytest.raises(_lib.YachtHipError) as ei:
+            db.run_wait(1)
+        assert ei.value.code == _lib.YH_ERR_UNSORTED
+        db.run_wait(2)
+        for k, w in enumerate((ov0, e0, m0)):
+            assert np.array_equal(outs[0][k], w) and np.array_equal(outs[2][k], w)
+            assert not outs[1][k].any(), "a refused sample must leave all-zero counts"
+        # the synchronous call: same verdict, handle still fine afterwards
+        for s in (bad, dup):
+            with pytest.raises(_lib.YachtHipError) as ei:
+                db.run_counts(s)
+            assert ei.value.code == _lib.YH_ERR_UNSORTED
+        ov, e, m = db.run_counts(good[0])
+        assert np.array_equal(ov, ov0) and np.array_equal(e, e0) and np.array_equal(m, m0)
+        with pytest.raises(_lib.YachtHipError):
+            db.overlap(bad)
+        assert np.array_equal(db.overlap(good[0]), ov0)

@@ -366,48 +366,35 @@ __global__ void k_make_keys(const u64* __restrict__ v, u64 n, u32 kshift, u32* _
 // ---- reference-major chunk view of the postings ---------------------------------------------------
 __global__ void k_chunk_counts(const u32* __restrict__ nshared, u64 n, u32* __restrict__ cc) {
     const u64 r = blockIdx.x * (u64)blockDim.x + threadIdx.x;
-    if (r < n) cc[r] = (nshared[r] + 63u) >> 6;
+    if (r < n) cc[r] = (nshared[r] + (u32)(YH_EXCL_PIECE - 1)) / (u32)YH_EXCL_PIECE;
 }
-// rrec (layout: yh_common.h): the OTHER holders of the posting's hash next to it, so that the fused
-// run step reaches them in one read instead of three dependent ones (rg -> po -> pr).
+// rrec / rrecx (layout: yh_common.h): the OTHER holders of the posting's hash next to it, so that the
+// fused run step reaches them in one (coalesced) read instead of three dependent ones (rg -> po -> pr).
 __global__ void k_fill_rg(u64 n_post, const u32* __restrict__ pr, const u32* __restrict__ pg, const u64* __restrict__ po,
                           const u32* __restrict__ rpo, u32* __restrict__ cursor, u32* __restrict__ rg,
-                          uint4* __restrict__ rrec) {
+                          uint4* __restrict__ rrec, uint4* __restrict__ rrecx) {
     for (u64 k = blockIdx.x * (u64)blockDim.x + threadIdx.x; k < n_post; k += (u64)gridDim.x * blockDim.x) {
         const u32 r = pr[k], g = pg[k];
         const u32 dst = rpo[r] + atomicAdd(&cursor[r], 1u);  // order inside a reference is irrelevant (sums)
         rg[dst] = g;
         if (rrec) {
             const u64 q0 = po[g], q1 = po[g + 1];
-            uint4 rec = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0u);
-            if (q1 - q0 <= 4) {  // up to three other holders: inline
-                u32 o[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};
+            uint4 rec, recx = make_uint4(0u, 0u, 0u, 0u);
+            if (q1 - q0 <= 8) {  // up to seven other holders: inline, the first three in rrec, the rest in rrecx
+                u32 o[7] = {0u, 0u, 0u, 0u, 0u, 0u, 0u};
                 u32 n = 0;
                 for (u64 q = q0; q < q1; ++q)
                     if (q != k) o[n++] = pr[q];
                 rec = make_uint4(o[0], o[1], o[2], n);
+                recx = make_uint4(o[3], o[4], o[5], o[6]);
             } else {             // a longer list: where it is
                 rec = make_uint4((u32)q0, (u32)(q1 - q0), 0u, 0xffffffffu);
             }
             rrec[dst] = rec;
+            rrecx[dst] = recx;
         }
     }
 }
-// record = reference | first posting << 32; key = (the chunk's number inside its reference, a hash of
-// the reference).  The records are then sorted by that key: neighbours in the final order belong to
-// different references, and related references (adjacent ids, often masked together) are apart.
-__global__ void k_fill_chunks(u64 n, const u32* __restrict__ rpo, const u32* __restrict__ cpo, u64* __restrict__ chunks,
-                              u64* __restrict__ ckey) {
-    const u64 r = blockIdx.x * (u64)blockDim.x + threadIdx.x;
-    if (r >= n) return;
-    const u32 b = rpo[r], e = rpo[r + 1];
-    u32 c = cpo[r], i = 0;
-    for (u32 k = b; k < e; k += 64, ++c, ++i) {
-        chunks[c] = (u64)r | ((u64)k << 32);
-        ckey[c] = ((u64)i << 32) | (u64)((u32)r * 2654435761u);
-    }
-}
-
 __global__ void k_bounds_u64(const u64* __restrict__ a, u64 n, u32 P, u32 pshift, u64* __restrict__ beg,
                              u64* __restrict__ cnt) {
     const u32 p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -774,6 +761,7 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, const u
             rc = yh_dmalloc(db, (void**)&db->d_rpo, (N + 1) * sizeof(u32));
             if (rc == YH_OK) rc = yh_dmalloc(db, (void**)&db->d_rg, db->n_postings * sizeof(u32));
             if (rc == YH_OK && want_stream) rc = yh_dmalloc(db, (void**)&db->d_rrec, (db->n_postings + 1) * sizeof(uint4));
+            if (rc == YH_OK && want_stream) rc = yh_dmalloc(db, (void**)&db->d_rrecx, (db->n_postings + 1) * sizeof(uint4));
             IDX_HIP(hipMalloc((void**)&d_cc, N * sizeof(u32)));
             IDX_HIP(hipMalloc((void**)&d_cpo, (N + 1) * sizeof(u32)));
             IDX_HIP(hipMalloc((void**)&d_cur, N * sizeof(u32)));
@@ -789,31 +777,14 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, const u
             IDX_HIP(hipMemcpyAsync(&n_chunks, d_cpo + N, sizeof(u32), hipMemcpyDeviceToHost, st));
             IDX_HIP(hipStreamSynchronize(st));
             db->n_chunks = n_chunks;
-            if (rc == YH_OK) rc = yh_dmalloc(db, (void**)&db->d_chunks, ((u64)n_chunks + 64) * sizeof(uint2));
-            u64* d_crec = nullptr;
-            u64 *d_ck = nullptr, *d_ck2 = nullptr;
-            void* d_st2 = nullptr;
-            size_t st2_bytes = 0;
-            IDX_HIP(hipMalloc((void**)&d_crec, std::max<u64>(n_chunks, 1) * sizeof(u64)));
-            IDX_HIP(hipMalloc((void**)&d_ck, std::max<u64>(n_chunks, 1) * sizeof(u64)));
-            IDX_HIP(hipMalloc((void**)&d_ck2, std::max<u64>(n_chunks, 1) * sizeof(u64)));
-            if (rc == YH_OK) {
+            if (rc == YH_OK) rc = yh_dmalloc(db, (void**)&db->d_work, ((u64)n_chunks + 64) * sizeof(uint2));
+            if (rc == YH_OK) rc = yh_dmalloc(db, (void**)&db->d_work_count, 16);
+            IDX_HIP(hipMemsetAsync(db->d_work_count, 0, 16, st));
+            if (rc == YH_OK)
                 k_fill_rg<<<grid_for(db->n_postings, 256), 256, 0, st>>>(db->n_postings, db->d_pr, db->d_pg, db->d_po, db->d_rpo,
-                                                                         d_cur, db->d_rg, db->d_rrec);
-                k_fill_chunks<<<(u32)((N + 255) / 256), 256, 0, st>>>(N, db->d_rpo, d_cpo, d_crec, d_ck);
-            }
+                                                                         d_cur, db->d_rg, db->d_rrec, db->d_rrecx);
             IDX_HIP(hipGetLastError());
-            if (n_chunks) {
-                u64* out = reinterpret_cast<u64*>(db->d_chunks);
-                IDX_HIP(rocprim::radix_sort_pairs(nullptr, st2_bytes, d_ck, d_ck2, d_crec, out, n_chunks, 0, 64, st));
-                IDX_HIP(hipMalloc(&d_st2, st2_bytes + 256));
-                IDX_HIP(rocprim::radix_sort_pairs(d_st2, st2_bytes, d_ck, d_ck2, d_crec, out, n_chunks, 0, 64, st));
-            }
             IDX_HIP(hipStreamSynchronize(st));
-            (void)hipFree(d_crec);
-            (void)hipFree(d_ck);
-            (void)hipFree(d_ck2);
-            (void)hipFree(d_st2);
             (void)hipFree(d_cc);
             (void)hipFree(d_cpo);
             (void)hipFree(d_cur);

@@ -107,6 +107,13 @@ constexpr u32 STREAM_NONE = 0xffffffffu;
 constexpr int TILE_UNROLL32 = YH_TILE_UNROLL32;
 static_assert(TILE_UNROLL32 * 4 <= 32, "candidate masks are 32-bit");
 
+// postings per work record of the reference-major exclusive pass (k_excl_pieces: one wave per record)
+#ifndef YH_EXCL_PIECE
+#define YH_EXCL_PIECE 512
+#endif
+#ifndef YH_EXCL_PIECE_THREADS
+#define YH_EXCL_PIECE_THREADS 512
+#endif
 constexpr int EXCL_QBLOCKS = 4096;  // workgroups (= queue segments) of k_excl_collect / k_excl_apply
 
 constexpr int TIMING_RING = 256;
@@ -181,9 +188,14 @@ struct yh_db {
     // exclusive pass visits only the chunks of masked references instead of streaming pr[]
     u32* d_rpo = nullptr;      // [N + 1] first posting of reference r in d_rg
     u32* d_rg = nullptr;       // [n_postings] shared-hash index, grouped by reference
-    uint2* d_chunks = nullptr; // [n_chunks] (reference, first posting in d_rg)
+    // work list of the exclusive pass: (reference, first posting in d_rg) per piece of <= YH_EXCL_PIECE postings
+    // of a reference in the subset; appended per query (k_reduce_replicas / k_excl_worklist); n_chunks = capacity
+    uint2* d_work = nullptr;
+    u32* d_work_count = nullptr;
     uint4* d_rrec = nullptr;   // [n_postings] beside d_rg (stream layout): the other holders of the posting's hash,
-                               // {o0, o1, o2, count <= 3} or {first index in d_pr, holders, 0, ~0} for longer lists
+                               // {o0, o1, o2, count <= 7} (others 3..6 in d_rrecx) or, for nine holders and
+                               // more, {first index in d_pr, holders, 0, ~0}
+    uint4* d_rrecx = nullptr;  // [n_postings] {o3, o4, o5, o6}
     u32 n_chunks = 0;
     bool posting_only = false;        // yh_db_create_from_pairs: posting lists of a hash range, no sketches
     bool excl_prefer_stream = false;  // set by the host-mask entry point when most references are masked

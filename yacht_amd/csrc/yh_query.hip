@@ -39,6 +39,7 @@
 namespace {
 
 constexpr int WAVE = 64;
+constexpr int EXCL_PIECE_C = YH_EXCL_PIECE;  // postings per work record of the exclusive pass
 
 typedef u64 u64x2 __attribute__((ext_vector_type(2)));  // one 16-byte global load per lane
 
@@ -142,11 +143,46 @@ struct FusedRun {
     u32* n_excl;
     u32* n_match;
     u32* bits_out;  // may be null: a second copy of the subset bits (the sharded run hands them to the other ranks)
+    // work list of the exclusive pass behind this kernel: the posting pieces of the subset's references
+    const u32* rpo;
+    uint2* work;
+    u32* work_count;  // zero when this kernel starts (the lookup kernel in front of it clears it)
+    u32 work_refs;    // references below this number produce work (sharded run: the ghosts behind do not)
 };
+
+// Append the posting pieces of every reference in the subset to the work list: (reference, first posting)
+// per <= EXCL_PIECE postings.  One atomic per workgroup.  All 256 threads of the block must call it.
+__device__ __forceinline__ void append_pieces(bool in_subset, u32 j, const u32* __restrict__ nshared,
+                                              const u32* __restrict__ rpo, uint2* __restrict__ work,
+                                              u32* __restrict__ work_count, u32* lds /* [8] */) {
+    const u32 lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const u32 np = in_subset ? (nshared[j] + (u32)EXCL_PIECE_C - 1u) / (u32)EXCL_PIECE_C : 0u;
+    u32 v = np;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const u32 t = (u32)__shfl_up((int)v, off);
+        if (lane >= (u32)off) v += t;
+    }
+    if (lane == 63) lds[wv] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const u32 total = lds[0] + lds[1] + lds[2] + lds[3];
+        lds[4] = total ? atomicAdd(work_count, total) : 0u;
+    }
+    __syncthreads();
+    u32 at = lds[4] + v - np;
+    for (u32 q = 0; q < wv; ++q) at += lds[q];
+    if (np) {
+        const u32 first = rpo[j];
+        for (u32 i = 0; i < np; ++i) work[at + i] = make_uint2(j, first + i * (u32)EXCL_PIECE_C);
+    }
+}
+
 __global__ void __launch_bounds__(256) k_reduce_replicas(u32* __restrict__ reps, u32 R, u64 n,
                                                          u32* __restrict__ out, u8* __restrict__ mask,
                                                          u32* __restrict__ maskbits, u32* __restrict__ excl3,
                                                          FusedRun fused) {
+    __shared__ u32 lds[8];
     const u64 j = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     u32 acc = 0;
     if (j < n) {
@@ -178,6 +214,17 @@ __global__ void __launch_bounds__(256) k_reduce_replicas(u32* __restrict__ reps,
             }
         }
     }
+    if (fused.work) append_pieces(acc != 0 && j < fused.work_refs, (u32)j, fused.nshared, fused.rpo, fused.work, fused.work_count, lds);
+}
+
+// the same work list for a subset that arrives as bits (general path); work_count zeroed by the caller
+__global__ void __launch_bounds__(256) k_excl_worklist(u64 n, const u32* __restrict__ maskbits, const u32* __restrict__ nshared,
+                                                       const u32* __restrict__ rpo, uint2* __restrict__ work,
+                                                       u32* __restrict__ work_count) {
+    __shared__ u32 lds[8];
+    const u64 j = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    const bool in = j < n && ((maskbits[j >> 5] >> (j & 31u)) & 1u);
+    append_pieces(in, (u32)j, nshared, rpo, work, work_count, lds);
 }
 
 // Sharded run: the subset bits of the GHOST references (copies of other ranks' references that share a
@@ -888,6 +935,7 @@ struct StreamHit {
     const u64* sample;
     const u32* bad;     // may be null: *bad != 0 = the sample failed the ordering check queued in front of
                         // this kernel (pipelined host-buffer calls): nothing is looked up, counts stay zero
+    u32* work_count;    // may be null: cleared here for the kernels behind (k_reduce_replicas appends the exclusive pass's work)
 };
 
 // Geometry of k_stream_lookup: 512 threads = 8 waves per workgroup, two workgroups per CU (~75 KB of
@@ -1041,6 +1089,13 @@ __device__ __forceinline__ u32 wave_bound(const u64* __restrict__ sample, u32 n,
 #define YH_STREAM_GROUPS 4
 #endif
 
+// words per block row of INC: 65, not 64 -- the lanes of a probe round sit on different blocks f at
+// the same search step, i.e. at the same column: with rows of 64 words all of them hit ONE bank
+// (PMC round 1: 39 % of the LDS cycles were conflict cycles); an odd stride spreads them
+#ifndef YH_INC_STRIDE
+#define YH_INC_STRIDE 65
+#endif
+constexpr int INC_STRIDE = YH_INC_STRIDE;
 constexpr int STREAM_PF = YH_STREAM_PF;
 constexpr int STREAM_NB = YH_STREAM_PF * YH_STREAM_GROUPS;
 static_assert(STREAM_PF >= 1 && STREAM_PF <= 15, "headers of a group live in lanes 0..PF");
@@ -1119,7 +1174,7 @@ __device__ __forceinline__ void stream_blocks(const u32x4* __restrict__ deltas, 
 #undef YH_SCAN_STEP
 #pragma unroll
                 for (int i = 0; i < PF; ++i) {
-                    INCw[(g * PF + i) * 64 + lane] = (u32)v[i];
+                    INCw[(g * PF + i) * INC_STRIDE + lane] = (u32)v[i];
                     const u32 end_rel = (u32)(readlane_u64(h, i) - base0) + (u32)__builtin_amdgcn_readlane(v[i], 63);
                     hl[g * PF + i] = (i < nv) ? end_rel : 0xffffffffu;
                     last_rel = (i < nv) ? end_rel : last_rel;
@@ -1166,7 +1221,7 @@ __device__ __forceinline__ void stream_blocks(const u32x4* __restrict__ deltas, 
                     const u32 hb = HBw[f];
                     if (hb > rel) { act = false; return; }
                     r = rel - hb;
-                    const u32* inc = INCw + f * 64;
+                    const u32* inc = INCw + f * INC_STRIDE;
                     t = 0;  // first lane whose last key is >= r  (inc[63] = the block's last key >= r)
 #pragma unroll
                     for (int st = 32; st >= 1; st >>= 1) t += (inc[t + st - 1] < r) ? (u32)st : 0u;
@@ -1176,7 +1231,7 @@ __device__ __forceinline__ void stream_blocks(const u32x4* __restrict__ deltas, 
                     if (act) {
                         const u32x4 w = deltas[(b0 + f) * 64 + t];
                         const u32 W[4] = {t ? w.x : (w.x & 0xffffff00u), w.y, w.z, w.w};
-                        u32 cs = t ? INCw[f * 64 + t - 1] : 0u, match = 0;
+                        u32 cs = t ? INCw[f * INC_STRIDE + t - 1] : 0u, match = 0;
 #pragma unroll
                         for (int j = 0; j < 16; ++j) {
                             cs += (W[j >> 2] >> (8 * (j & 3))) & 0xffu;
@@ -1212,7 +1267,7 @@ k_stream_lookup(const u32x4* __restrict__ deltas, const u64* __restrict__ hdr, u
     __shared__ u32 S[ST_SLOTS];                 // the tile's sample keys, relative to its first one
     __shared__ u16 E[ST_NB];
     __shared__ u64x2 Q[WAVES][STREAM_WQ];
-    __shared__ u32 INC[WAVES][STREAM_NB * 64];  // per wave: the lane-inclusive key sums of a super-block
+    __shared__ u32 INC[WAVES][STREAM_NB * INC_STRIDE];  // per wave: the lane-inclusive key sums of a super-block
     __shared__ u32 HB[WAVES][16];               // per wave: first key of each of its blocks, relative
     __shared__ u32 q_fill[WAVES];
     __shared__ u32 sbound[2];
@@ -1222,6 +1277,7 @@ k_stream_lookup(const u32x4* __restrict__ deltas, const u64* __restrict__ hdr, u
     __shared__ u32 tcnt2[STREAM_TSLOTS];
 
     const u32 tid = threadIdx.x;
+    if (hit.work_count && blockIdx.x == 0 && tid == 0) *hit.work_count = 0;
     if (hit.bad && *hit.bad) return;  // (wave-uniform scalar load)
     const u32 wv = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const u32 lid = xcd_remap(blockIdx.x, gridDim.x);
@@ -1343,7 +1399,10 @@ __global__ void __launch_bounds__(256) k_overlap_bsearch(const u64* __restrict__
 __global__ void __launch_bounds__(256) k_index_lookup(const u64* __restrict__ sample, u64 n, const YhDirView dv,
                                                       const u64* __restrict__ po, const u32* __restrict__ pr,
                                                       u32* __restrict__ reps, u32 rep_mask, u64 n_refs,
-                                                      u8* __restrict__ hit, u32* __restrict__ reps2) {
+                                                      u8* __restrict__ hit, u32* __restrict__ reps2,
+                                                      u32* __restrict__ work_count, const u32* __restrict__ bad) {
+    if (work_count && blockIdx.x == 0 && threadIdx.x == 0) *work_count = 0;  // (for the kernels behind: see StreamHit)
+    if (bad && *bad) return;
     u32* my = reps + (u64)(blockIdx.x & rep_mask) * n_refs;
     u32* my2 = reps2 ? reps2 + (u64)(blockIdx.x & rep_mask) * n_refs : nullptr;  // hits on shared hashes (fused run)
     for (u64 t = blockIdx.x * (u64)blockDim.x + threadIdx.x; t < n; t += (u64)gridDim.x * blockDim.x) {
@@ -1451,156 +1510,130 @@ __global__ void __launch_bounds__(EXCL_BLOCK) k_excl_apply(const u32* __restrict
 }
 
 // The same sums without the pass over pr[]: the reference-major view of the postings is cut into
-// chunks of <= 64 (d_chunks), stored so that neighbouring records belong to DIFFERENT references
-// (sorted by the chunk's number inside its reference).  A wave tests 64 records at once (one
-// coalesced load, one mask bit each) and walks only the chunks of masked references, every lane
-// on one posting: holder lists four at a time, ballots, three sums per chunk.  A heavy reference's
-// chunks are spread over as many waves.  (With most references masked the streaming pair above is
-// ~3x faster: its reads are coalesced.)
+// PIECES of <= EXCL_PIECE postings (d_chunks: (reference, first posting); most references are one
+// piece), stored so that neighbouring records belong to unrelated references.  ONE WAVE PER PIECE: the
+// wave tests its reference's subset bit and, if set, sweeps the piece 64 x EXCL_U postings a step, every
+// lane summing for itself; one wave reduction and ONE atomic per sum and piece at the end.
+// (Earlier form: one lane per 64-posting chunk record, a ballot and an atomic per chunk.  With 29 % of
+// the references in the subset -- the hit shape of real runs -- 73 of its 80 us were those atomics:
+// the ~30 chunks of a reference, and of its cluster mates next to it in the SAME 64-byte line, are
+// device-scope atomics that the memory side serializes per line.  bench.py "real_shape".)
+constexpr u32 EXCL_PIECE = YH_EXCL_PIECE;
 #ifndef YH_EXCL_U
 #define YH_EXCL_U 4
 #endif
 constexpr int EXCL_U = YH_EXCL_U;
-__global__ void __launch_bounds__(256) k_excl_chunks(u32 n_chunks, const uint2* __restrict__ chunks,
-                                                     const u32* __restrict__ rpo, const u32* __restrict__ rg,
-                                                     const u64* __restrict__ po, const u32* __restrict__ pr,
-                                                     const u32* __restrict__ maskbits, const u8* __restrict__ hit,
-                                                     u32* __restrict__ ex_e, u32* __restrict__ ex_m,
-                                                     u32* __restrict__ ovsh) {
-    const u32 lane = threadIdx.x & 63u;
-    const u32 c = (u32)((blockIdx.x * (u64)blockDim.x + threadIdx.x));  // this lane's record
-    uint2 mine = make_uint2(0u, 0u);
-    bool want = false;
-    if (c < n_chunks) {
-        mine = chunks[c];
-        want = (maskbits[mine.x >> 5] >> (mine.x & 31u)) & 1u;
-    }
-    // The masked chunks of the wave's 64 records, EXCL_U at a time: a chunk is a chain of dependent
-    // reads (posting -> shared hash -> holder list -> mask words), so the chunks of a step are walked
-    // side by side, branch-free (clamped addresses), and their reads overlap.
-    constexpr int U = EXCL_U;
-    u64 todo = __ballot(want);
-    while (todo) {
-        u32 r[U], k[U], lim[U];
-        bool on[U];
+constexpr u32 EXCL_LDS_WORDS = 12288;  // 48 KiB of subset bits = 393 216 references
+
+__device__ __forceinline__ u32 wave_sum(u32 v) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            on[u] = todo != 0;
-            const int src = on[u] ? __ffsll((long long)todo) - 1 : 0;
-            todo &= todo - 1;  // (0 stays 0)
-            r[u] = (u32)__shfl((int)mine.x, src);
-            k[u] = (u32)__shfl((int)mine.y, src) + lane;
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) lim[u] = on[u] ? rpo[r[u] + 1] : 0u;
-        bool valid[U];
-        u32 gi[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            valid[u] = k[u] < lim[u];
-            gi[u] = valid[u] ? rg[k[u]] : 0u;
-        }
-        u64 q[U], q1[U];
-        bool in_sample[U];
-        u32 cnt[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            q[u] = po[gi[u]];
-            q1[u] = valid[u] ? po[gi[u] + 1] : q[u];  // an invalid lane has an empty holder list
-            in_sample[u] = hit && valid[u] && hit[gi[u]] != 0;  // (no flags: only the exclusive sums are wanted)
-            cnt[u] = 0;
-        }
-        for (;;) {  // holders four at a time per chunk: 4 * U independent reads a step
-            bool more = false;
-#pragma unroll
-            for (int u = 0; u < U; ++u) more |= q[u] < q1[u];
-            if (!__ballot(more)) break;
-            u32 h[U][4], mw[U][4];
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-#pragma unroll
-                for (int t = 0; t < 4; ++t) h[u][t] = (q[u] < q1[u]) ? pr[min(q[u] + t, q1[u] - 1)] : 0u;
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-#pragma unroll
-                for (int t = 0; t < 4; ++t) mw[u][t] = maskbits[h[u][t] >> 5];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) cnt[u] += (q[u] + t < q1[u]) ? ((mw[u][t] >> (h[u][t] & 31u)) & 1u) : 0u;
-                q[u] = min(q[u] + 4, q1[u]);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const bool e = valid[u] && cnt[u] == 1;
-            const u32 ne = (u32)__popcll(__ballot(e)), nm = (u32)__popcll(__ballot(e && in_sample[u])),
-                      no = (u32)__popcll(__ballot(in_sample[u]));
-            if (lane == 0 && on[u]) {
-                if (ne) atomicAdd(&ex_e[r[u]], ne);
-                if (nm) atomicAdd(&ex_m[r[u]], nm);
-                if (no) atomicAdd(&ovsh[r[u]], no);
-            }
-        }
-    }
+    for (int off = 32; off >= 1; off >>= 1) v += (u32)__shfl_xor((int)v, off);
+    return v;
 }
 
-// The fused run step's form: only the exclusive sums (no sample membership), through d_rrec -- the
-// other holders of a posting's hash sit next to it, so a chunk is chunk record -> own mask bit ->
-// {limit, holder record} -> the holders' mask words -> one atomic: five dependent reads instead of
-// eight.  ex_e[r] += shared hashes of r none of whose other holders is in the subset.
-__global__ void __launch_bounds__(256) k_excl_chunks_e(u32 n_chunks, const uint2* __restrict__ chunks,
-                                                       const u32* __restrict__ rpo, const uint4* __restrict__ rrec,
-                                                       u32 n_post, const u32* __restrict__ pr,
-                                                       const u32* __restrict__ maskbits, u32* __restrict__ ex_e) {
-    const u32 lane = threadIdx.x & 63u;
-    const u32 c = (u32)((blockIdx.x * (u64)blockDim.x + threadIdx.x));  // this lane's record
-    uint2 mine = make_uint2(0u, 0u);
-    bool want = false;
-    if (c < n_chunks) {
-        mine = chunks[c];
-        want = (maskbits[mine.x >> 5] >> (mine.x & 31u)) & 1u;
+// Which holders of a posting's hash are in the subset, r itself excluded.  Through rrec / rrecx when the
+// handle has them (up to seven other holders sit beside the posting: one coalesced read), else -- and
+// for nine holders and more -- by walking the posting list, eight holders a step.
+template <class MaskWord>
+__device__ __forceinline__ u32 others_in_subset(const uint4 rec, const uint4 recx, const u32* __restrict__ pr,
+                                                const MaskWord& mword) {
+    if (rec.w != 0xffffffffu) {
+        const u32 hid[7] = {rec.x, rec.y, rec.z, recx.x, recx.y, recx.z, recx.w};
+        u32 others = 0;
+#pragma unroll
+        for (int t = 0; t < 7; ++t) others += ((u32)t < rec.w) ? ((mword(hid[t] >> 5) >> (hid[t] & 31u)) & 1u) : 0u;
+        return others;
     }
+    u32 cnt = 0;
+    const u32 q0 = rec.x, len = rec.y;
+    for (u32 base = 0; base < len && cnt < 2; base += 8) {
+        u32 h[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) h[t] = pr[q0 + min(base + (u32)t, len - 1)];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) cnt += (base + (u32)t < len) ? ((mword(h[t] >> 5) >> (h[t] & 31u)) & 1u) : 0u;
+    }
+    return cnt - 1u;  // (r is in its own list and in the subset)
+}
+
+// General form (any subset): ex_e[r] += shared hashes of r with no other holder in the subset, ex_m[r] +=
+// those of them found in the sample (hit[]), ovsh[r] += shared hashes of r found in the sample.
+// rrec == nullptr (posting-only handles): holders through rg -> po -> pr.  hit == nullptr: ex_e only.
+#ifndef YH_EXCL_GRID
+#define YH_EXCL_GRID 2048
+#endif
+constexpr int EXCL_PIECE_THREADS = YH_EXCL_PIECE_THREADS;  // waves of a workgroup share the staging of the subset bits
+template <bool LDSMASK>
+__global__ void __launch_bounds__(EXCL_PIECE_THREADS) k_excl_pieces(const u32* __restrict__ work_count, const uint2* __restrict__ work,
+                                                     const u32* __restrict__ rpo, const u32* __restrict__ rg,
+                                                     const uint4* __restrict__ rrec, const uint4* __restrict__ rrecx,
+                                                     const u64* __restrict__ po, u32 n_post, const u32* __restrict__ pr,
+                                                     const u32* __restrict__ maskbits, u32 n_mask_words,
+                                                     const u8* __restrict__ hit, u32* __restrict__ ex_e,
+                                                     u32* __restrict__ ex_m, u32* __restrict__ ovsh) {
+    extern __shared__ u32 lmask[];
+    constexpr u32 WPB = EXCL_PIECE_THREADS / 64;
+    const u32 lane = threadIdx.x & 63u;
+    const u32 n_work = *work_count;
+    if (blockIdx.x * WPB >= n_work) return;  // (the grid is sized for every piece of the database)
+    if (LDSMASK) {  // the subset bits into LDS (16-byte reads)
+        const uint4* src = reinterpret_cast<const uint4*>(maskbits);
+        uint4* dst = reinterpret_cast<uint4*>(lmask);
+        for (u32 i = threadIdx.x; i < n_mask_words / 4; i += EXCL_PIECE_THREADS) dst[i] = src[i];  // (n_mask_words is a multiple of 8)
+        __syncthreads();
+    }
+    auto mword = [&](u32 i) -> u32 { return LDSMASK ? lmask[i] : maskbits[i]; };
     constexpr int U = EXCL_U;
-    u64 todo = __ballot(want);
-    while (todo) {
-        u32 r[U], k[U], lim[U];
-        bool on[U];
+    for (u32 w = blockIdx.x * WPB + (threadIdx.x >> 6); w < n_work; w += gridDim.x * WPB) {
+        const uint2 mine = work[w];
+        const u32 r = mine.x;
+        const u32 end = min(mine.y + EXCL_PIECE, rpo[r + 1]);
+        u32 acc_e = 0, acc_m = 0, acc_o = 0;
+        for (u32 k0 = mine.y; k0 < end; k0 += 64u * U) {
+            u32 k[U];
+            bool valid[U], in_s[U];
+            uint4 rec[U], recx[U];
+            u32 gi[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            on[u] = todo != 0;
-            const int src = on[u] ? __ffsll((long long)todo) - 1 : 0;
-            todo &= todo - 1;  // (0 stays 0)
-            r[u] = (u32)__shfl((int)mine.x, src);
-            k[u] = (u32)__shfl((int)mine.y, src) + lane;
-        }
-        uint4 rec[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            lim[u] = on[u] ? rpo[r[u] + 1] : 0u;
-            rec[u] = rrec[min(k[u], n_post - 1)];  // (read before the limit is known: clamped)
-        }
-        u32 others[U];  // holders other than r that are in the subset
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const bool valid = k[u] < lim[u];
-            const bool inl = rec[u].w != 0xffffffffu;
-            const u32 h0 = rec[u].x, h1 = rec[u].y, h2 = rec[u].z;
-            const u32 n = (valid && inl) ? rec[u].w : 0u;
-            const u32 m0 = n > 0 ? maskbits[h0 >> 5] : 0u, m1 = n > 1 ? maskbits[h1 >> 5] : 0u,
-                      m2 = n > 2 ? maskbits[h2 >> 5] : 0u;
-            others[u] = ((m0 >> (h0 & 31u)) & 1u) + ((m1 >> (h1 & 31u)) & 1u) + ((m2 >> (h2 & 31u)) & 1u);
-            if (valid && !inl) {  // a long holder list (rare): walk it, r itself included
-                u32 cnt = 0;
-                const u64 q0 = rec[u].x, q1 = q0 + rec[u].y;
-                for (u64 q = q0; q < q1; ++q) {
-                    const u32 h = pr[q];
-                    cnt += (maskbits[h >> 5] >> (h & 31u)) & 1u;
-                }
-                others[u] = cnt - 1;
+            for (int u = 0; u < U; ++u) {
+                k[u] = k0 + 64u * u + lane;
+                valid[u] = k[u] < end;
+                const u32 kc = min(k[u], n_post - 1);  // (clamped: branch-free reads)
+                gi[u] = (hit || !rrec) ? rg[kc] : 0u;
+                if (rrec) rec[u] = rrec[kc];
+                recx[u] = make_uint4(0u, 0u, 0u, 0u);
             }
-            const u32 ne = (u32)__popcll(__ballot(valid && others[u] == 0));
-            if (lane == 0 && on[u] && ne) atomicAdd(&ex_e[r[u]], ne);
+            if (rrec) {  // holders 3..6: read only by the waves that have a posting with more than three others
+                bool more = false;
+#pragma unroll
+                for (int u = 0; u < U; ++u) more |= valid[u] && rec[u].w > 3u && rec[u].w != 0xffffffffu;
+                if (__ballot(more)) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) recx[u] = rrecx[min(k[u], n_post - 1)];
+                }
+            } else {     // posting-only handles: holders through the posting lists
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const u64 q0 = po[gi[u]], q1 = po[gi[u] + 1];
+                    rec[u] = make_uint4((u32)q0, (u32)(q1 - q0), 0u, 0xffffffffu);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) in_s[u] = hit && valid[u] && hit[gi[u]] != 0;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool e = valid[u] && others_in_subset(rec[u], recx[u], pr, mword) == 0;
+                acc_e += e ? 1u : 0u;
+                acc_m += (e && in_s[u]) ? 1u : 0u;
+                acc_o += in_s[u] ? 1u : 0u;
+            }
+        }
+        acc_e = wave_sum(acc_e);
+        if (hit) { acc_m = wave_sum(acc_m); acc_o = wave_sum(acc_o); }
+        if (lane == 0) {
+            if (acc_e) atomicAdd(&ex_e[r], acc_e);
+            if (hit && acc_m) atomicAdd(&ex_m[r], acc_m);
+            if (hit && acc_o) atomicAdd(&ovsh[r], acc_o);
         }
     }
 }
@@ -1796,6 +1829,22 @@ static int claim_hit_flags(yh_db* db) {
     return YH_OK;
 }
 
+// hit == nullptr: only ex_e is summed (the fused run step).  One wave per work record; the work list
+// (db->d_work, db->d_work_count) was appended by k_reduce_replicas / k_excl_worklist on the same stream.
+static void launch_excl_pieces(yh_db* db, const u32* d_maskbits, const u8* d_hit, u32* d_ex_e, u32* d_ex_m, u32* d_ovsh) {
+    const u32 words = (u32)(((db->n_refs + 255) / 256) * 8);  // what k_reduce_replicas / k_mask_bits write: whole 256-reference blocks
+    const u32 per_wg = EXCL_PIECE_THREADS / 64;
+    const u32 grid = std::min<u32>((db->n_chunks + per_wg - 1) / per_wg, (u32)YH_EXCL_GRID);
+    if (words <= EXCL_LDS_WORDS)
+        k_excl_pieces<true><<<grid, EXCL_PIECE_THREADS, words * sizeof(u32), db->stream>>>(
+            db->d_work_count, db->d_work, db->d_rpo, db->d_rg, db->d_rrec, db->d_rrecx, db->d_po, (u32)db->n_postings, db->d_pr,
+            d_maskbits, words, d_hit, d_ex_e, d_ex_m, d_ovsh);
+    else
+        k_excl_pieces<false><<<grid, EXCL_PIECE_THREADS, 0, db->stream>>>(
+            db->d_work_count, db->d_work, db->d_rpo, db->d_rg, db->d_rrec, db->d_rrecx, db->d_po, (u32)db->n_postings, db->d_pr,
+            d_maskbits, words, d_hit, d_ex_e, d_ex_m, d_ovsh);
+}
+
 // flag_shared: also flag which database-shared hashes are in the sample (db->d_hit), fused into the
 // same launch; yh_q_exclusive_partial(..., hit_ready = true) then skips its own membership pass.
 // overlap through the hash-sorted delta stream (the default layout)
@@ -1828,7 +1877,7 @@ static int yh_q_overlap_stream(yh_db* db, const u64* d_sample, u64 n_sample, u32
     // workgroup finds its own range of the sample (two 64-ary wave searches while its first
     // super-block is in flight).
     u32* const reps2 = db->d_reps + db->reps_cap;
-    StreamHit sh{(u32)N, db->d_reps, R - 1, db->d_srec, flags_too ? db->d_hit : nullptr, fused ? reps2 : nullptr, d_sample, db->d_bad};
+    StreamHit sh{(u32)N, db->d_reps, R - 1, db->d_srec, flags_too ? db->d_hit : nullptr, fused ? reps2 : nullptr, d_sample, db->d_bad, db->d_work_count};
     yh_ring_record_begin(db, db->ev_overlap);
     k_stream_lookup<<<wgs, STREAM_THREADS, 0, st>>>(reinterpret_cast<const u32x4*>(db->d_sdelta), db->d_shdr, nblk, d_sample,
                                                     (u32)n_sample, db->d_wg_key, db->sshift, sh);
@@ -1836,7 +1885,9 @@ static int yh_q_overlap_stream(yh_db* db, const u64* d_sample, u64 n_sample, u32
     k_reduce_replicas<<<(u32)((N + 255) / 256), 256, 0, st>>>(
         db->d_reps, R, N, d_overlap, (make_mask && !fused) ? db->d_mask : nullptr, make_mask ? db->d_maskbits : nullptr,
         (with_index && !fused) ? db->d_excl_e : nullptr,
-        fused ? FusedRun{reps2, db->d_sizes, db->d_nshared, d_fused_excl, d_fused_match, d_bits_out} : FusedRun{});
+        fused ? FusedRun{reps2, db->d_sizes, db->d_nshared, d_fused_excl, d_fused_match, d_bits_out, db->d_rpo, db->d_work,
+                         db->d_work_count, (u32)(db->n_ghost ? db->ghost_begin : N)}
+              : FusedRun{});
     YH_HIP(hipGetLastError());
     return YH_OK;
 }
@@ -1921,7 +1972,7 @@ int yh_q_run_fused(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap,
                    u32* d_bits_out, const u32* d_global_bits) {
     static const bool off = [] { const char* e = getenv("YH_NO_FUSED_RUN"); return e && e[0] == '1'; }();
     if (!db->d_sdelta || !db->has_index || db->posting_only || db->n_refs == 0 || db->n_hashes == 0 ||
-        (db->n_postings && (!db->d_rrec || !db->d_chunks)) || n_sample > 0xfffffff0ull)
+        (db->n_postings && (!db->d_rrec || !db->d_rrecx || !db->d_work)) || n_sample > 0xfffffff0ull)
         return 1;
     if (phases == 3 && (off || n_sample == 0)) return 1;
     hipStream_t st = db->stream;
@@ -1933,6 +1984,7 @@ int yh_q_run_fused(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap,
             YH_HIP(hipMemsetAsync(d_match, 0, N * sizeof(u32), st));
             YH_HIP(hipMemsetAsync(db->d_maskbits, 0, ((N + 255) / 256) * 32, st));
             if (d_bits_out) YH_HIP(hipMemsetAsync(d_bits_out, 0, ((N + 63) / 64) * 8, st));
+            if (db->d_work_count) YH_HIP(hipMemsetAsync(db->d_work_count, 0, sizeof(u32), st));
         } else {
             YH_TRY(yh_q_overlap_stream(db, d_sample, n_sample, d_overlap, true, true, true, d_excl, d_match, d_bits_out));
         }
@@ -1943,8 +1995,7 @@ int yh_q_run_fused(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap,
             k_ghost_bits<<<(u32)((db->n_ghost + 255) / 256), 256, 0, st>>>(d_global_bits, db->d_ghost_src, db->ghost_begin,
                                                                         db->n_ghost, db->d_maskbits);
         if (db->n_chunks)  // + the shared hashes of the subset's references whose other holders are all outside it
-            k_excl_chunks_e<<<(db->n_chunks + 255) / 256, 256, 0, st>>>(db->n_chunks, db->d_chunks, db->d_rpo, db->d_rrec,
-                                                                   (u32)db->n_postings, db->d_pr, db->d_maskbits, d_excl);
+            launch_excl_pieces(db, db->d_maskbits, nullptr, d_excl, nullptr, nullptr);
         yh_ring_record_end(db, db->ev_excl);
     }
     YH_HIP(hipGetLastError());
@@ -1966,7 +2017,7 @@ int yh_q_overlap_indexed(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_ov
     u32 R;
     YH_TRY(ensure_reps(db, R));
     static const bool fused_off = [] { const char* e = getenv("YH_NO_FUSED_RUN"); return e && e[0] == '1'; }();
-    const bool fused = d_fused_excl && for_exclusive && db->d_chunks && db->d_rrec && !fused_off;
+    const bool fused = d_fused_excl && for_exclusive && db->d_work && db->d_rrec && db->d_rrecx && !fused_off;
     if (for_exclusive && db->n_shared && !fused) YH_TRY(claim_hit_flags(db));
     u32* const reps2 = db->d_reps + db->reps_cap;
     // (no kernel in front of the lookup: the counters are zero at rest)
@@ -1975,18 +2026,19 @@ int yh_q_overlap_indexed(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_ov
         k_index_lookup<<<grid_for(n_sample, 256, 4096), 256, 0, st>>>(d_sample, n_sample, yh_dir_view(db), db->d_po, db->d_pr,
                                                                       db->d_reps, R - 1, N,
                                                                       (for_exclusive && db->n_shared && !fused) ? db->d_hit : nullptr,
-                                                                      fused ? reps2 : nullptr);
+                                                                      fused ? reps2 : nullptr, db->d_work_count, db->d_bad);
+    else if (fused && db->d_work_count)
+        YH_HIP(hipMemsetAsync(db->d_work_count, 0, sizeof(u32), st));
     yh_ring_record_end(db, db->ev_overlap);
     k_reduce_replicas<<<(u32)((N + 255) / 256), 256, 0, st>>>(
         db->d_reps, R, N, d_overlap, (for_exclusive && !fused) ? db->d_mask : nullptr,
         for_exclusive ? db->d_maskbits : nullptr, (for_exclusive && !fused) ? db->d_excl_e : nullptr,
-        fused ? FusedRun{reps2, db->d_sizes, db->d_nshared, d_fused_excl, d_fused_match, nullptr} : FusedRun{});
+        fused ? FusedRun{reps2, db->d_sizes, db->d_nshared, d_fused_excl, d_fused_match, nullptr, db->d_rpo, db->d_work,
+                         db->d_work_count, (u32)N}
+              : FusedRun{});
     if (fused) {
         yh_ring_record_begin(db, db->ev_excl);
-        if (db->n_chunks)
-            k_excl_chunks_e<<<(db->n_chunks + 255) / 256, 256, 0, st>>>(db->n_chunks, db->d_chunks, db->d_rpo, db->d_rrec,
-                                                                   (u32)db->n_postings, db->d_pr, db->d_maskbits,
-                                                                   d_fused_excl);
+        if (db->n_chunks) launch_excl_pieces(db, db->d_maskbits, nullptr, d_fused_excl, nullptr, nullptr);
         yh_ring_record_end(db, db->ev_excl);
     }
     YH_HIP(hipGetLastError());
@@ -2040,10 +2092,13 @@ int yh_q_exclusive_partial(yh_db* db, const u8* d_mask, const u64* d_sample, u64
                 SideStream{nullptr, nullptr, nullptr, nullptr});
         }
         static const bool stream_env = [] { const char* e = getenv("YH_EXCL_STREAM"); return e && e[0] == '1'; }();
-        if (db->d_chunks && !stream_env && !db->excl_prefer_stream) {
-            if (db->n_chunks)
-                k_excl_chunks<<<(db->n_chunks + 255) / 256, 256, 0, st>>>(db->n_chunks, db->d_chunks, db->d_rpo, db->d_rg, db->d_po,
-                                                                     db->d_pr, d_maskbits, db->d_hit, d_ex_e, d_ex_m, d_ovsh);
+        if (db->d_work && !stream_env && !db->excl_prefer_stream) {
+            if (db->n_chunks) {
+                YH_HIP(hipMemsetAsync(db->d_work_count, 0, sizeof(u32), st));
+                k_excl_worklist<<<(u32)((N + 255) / 256), 256, 0, st>>>(N, d_maskbits, db->d_nshared, db->d_rpo, db->d_work,
+                                                                       db->d_work_count);
+                launch_excl_pieces(db, d_maskbits, db->d_hit, d_ex_e, d_ex_m, d_ovsh);
+            }
         } else {
             const u64 vecs = (db->n_postings >> 2) + 1;
             const u32 blocks = (u32)std::min<u64>(EXCL_QBLOCKS, (vecs + EXCL_BLOCK - 1) / EXCL_BLOCK);
