@@ -66,7 +66,7 @@ def parse_args():
     ap.add_argument("--no-indexed", action="store_true", help="skip the extra measurement of the sample-driven path")
     ap.add_argument("--no-host-inclusive", action="store_true")
     ap.add_argument("--no-real-shape", action="store_true")
-    ap.add_argument("--host-depth", type=int, default=2, help="host-inclusive leg: calls in flight (1..4)")
+    ap.add_argument("--host-depth", type=int, default=3, help="host-inclusive leg: calls in flight (1..4)")
     ap.add_argument("--percentile-steps", type=int, default=200)
     ap.add_argument("--sync-gather", action="store_true", help="N>1: blocking gather of the count rows inside every step")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to test the N>1 logic)")
@@ -321,7 +321,13 @@ def main() -> int:
             pa = PinnedArray(int(s.numel()), np.uint64)
             pa.array[:] = s.cpu().numpy().view(np.uint64)
             h_samples.append(pa)
-        h_out = [[PinnedArray(n_local, np.uint32) for _ in range(3)] for _ in range(DEPTH)]
+        h_blk = [PinnedArray(3 * n_local, np.uint32) for _ in range(DEPTH)]  # one contiguous [3][N] block per slot: one D2H copy
+
+        class _Row:
+            def __init__(self, a):
+                self.array = a
+
+        h_out = [[_Row(b.array[k * n_local:(k + 1) * n_local]) for k in range(3)] for b in h_blk]
         done_t = []
         host_t = {"submit": 0.0, "wait": 0.0}
 
@@ -376,9 +382,9 @@ def main() -> int:
         del hs
         for pa in h_samples:
             pa.close()
-        for o in h_out:
-            for pa in o:
-                pa.close()
+        h_out = None
+        for pa in h_blk:
+            pa.close()
 
     real_samples = []
     if world == 1 and not args.no_real_shape and args.workload == "gtdb_rs214_scale":

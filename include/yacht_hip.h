@@ -191,10 +191,11 @@ int yh_run_local_device(yh_db* db, const uint64_t* d_sample, uint64_t n_sample, 
 int yh_run_finish_device(yh_db* db, const uint32_t* d_global_bits, uint32_t* d_n_excl);
 
 /* Pipelined host-buffer form of yh_run: SURVEY.md 8d's steady-state call -- sample H2D, kernels,
- * counts D2H -- split in two so that consecutive samples overlap.  yh_run_submit queues, on three
+ * counts D2H -- split in two so that consecutive samples overlap.  yh_run_submit queues, on two
  * streams of the handle, the upload of `sample`, an ordering check ON THE DEVICE (a sample that fails
  * it is not looked up), the fused run kernels and the download of the three count rows into the
- * caller's buffers, and returns without waiting; yh_run_wait(slot) blocks until that call's counts
+ * caller's buffers (one copy when they are one contiguous [3][N] block: n_excl == overlap + N,
+ * n_match == n_excl + N), and returns without waiting; yh_run_wait(slot) blocks until that call's counts
  * have landed and returns YH_ERR_UNSORTED when the check failed (the buffers are then all zero).
  * `slot` in [0, YH_RUN_SLOTS): a slot holds one call in flight and must be waited for before it is
  * submitted again; calls complete in submission order.  Copies overlap the kernels only when the host

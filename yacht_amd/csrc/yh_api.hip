@@ -335,7 +335,7 @@ int yh_db_destroy(yh_db* db) {
                     db->d_g, db->d_po, db->d_pr, db->d_pg, db->d_gbeg, db->d_gcnt, db->d_nshared, db->d_pq, db->d_pq_count, db->d_dh, db->d_dref, db->d_dir, db->d_bkt, db->d_pkeys, db->d_pref, db->d_gkeys, db->d_rpo, db->d_rg, db->d_rrec, db->d_rrecx, db->d_work, db->d_work_count, db->d_sbounds,
                     db->d_mask, db->d_maskbits, db->d_hit, db->d_excl_e, db->d_overlap_tmp,
                     db->d_sample_tmp, db->d_out_tmp, db->d_flag, db->d_hitq, db->d_hitq_cnt, db->d_wg_first, db->d_reps, db->d_batch,
-                    db->d_sdelta, db->d_shdr, db->d_srec, db->d_wg_key, db->d_ghost_src};
+                    db->d_sdelta, db->d_shdr, db->d_srec, db->d_wg_key, db->d_ghost_src, db->d_bad_word};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     ring_destroy(db->ev_overlap);
@@ -514,13 +514,42 @@ __global__ void k_check_ascending(const u64* __restrict__ a, u64 n, u32* __restr
     if (bad) *flag = 1;
 }
 
+// Sets *flag (device) and *host_flag (page-locked host memory, written through PCIe: visible to the host once the kernel
+// has completed) when a[i - 1] >= a[i] somewhere.
+__global__ void k_check_ascending2(const u64* __restrict__ a, u64 n, u32* __restrict__ flag, u32 gen, u32* __restrict__ host_flag) {
+    bool bad = false;
+    for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x + 1; i < n; i += (u64)gridDim.x * blockDim.x)
+        bad |= !(a[i - 1] < a[i]);
+    if (bad) {
+        *flag = gen;
+        if (host_flag) *host_flag = 1;
+    }
+}
+// device -> page-locked host memory by stores through PCIe (16 bytes per lane), in the step's own stream:
+// HIP's own path for this direction is a blit kernel with ~25 us of gaps around it (traced)
+__global__ void __launch_bounds__(256) k_copy_out(const uint4* __restrict__ src, uint4* __restrict__ dst, u64 n16) {
+    for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < n16; i += (u64)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+static u32 next_gen(yh_db* db) {
+    if (++db->bad_gen == 0) ++db->bad_gen;  // (0 is what a fresh flag word holds)
+    return db->bad_gen;
+}
+// the device address of a host buffer the GPU can store to directly, or null (pageable memory)
+static void* device_view_of_host(void* p) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (at.type != hipMemoryTypeHost) return nullptr;
+    void* d = nullptr;
+    if (hipHostGetDevicePointer(&d, p, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return d;
+}
+
 // Host sample -> d_sample_tmp, and the ordering check ON THE DEVICE (a 10^6-hash sample is 8 MB: the
 // host loop over it was ~0.4 ms of the ~0.55 ms a host-pointer query took).  The query kernels assume
 // an ascending sample, so the verdict is awaited before they are queued.
 static int upload_sample(yh_db* db, const uint64_t* sample, uint64_t n_sample, bool defer_verdict = false) {
     if (n_sample && !sample) { yh_set_error("sample is null"); return YH_ERR_INVALID_ARG; }
     YH_TRY(ensure_sample_tmp(db, n_sample));
-    if (defer_verdict) YH_HIP(hipMemsetAsync(db->d_flag, 0, sizeof(u32), db->stream));
     if (n_sample < 2) {
         if (n_sample)
             YH_HIP(hipMemcpyAsync(db->d_sample_tmp, sample, n_sample * sizeof(u64), hipMemcpyHostToDevice, db->stream));
@@ -528,12 +557,16 @@ static int upload_sample(yh_db* db, const uint64_t* sample, uint64_t n_sample, b
     }
     u32 verdict = 0;
     YH_HIP(hipMemcpyAsync(db->d_sample_tmp, sample, n_sample * sizeof(u64), hipMemcpyHostToDevice, db->stream));
-    if (!defer_verdict) YH_HIP(hipMemsetAsync(db->d_flag, 0, sizeof(u32), db->stream));
+    if (defer_verdict) {
+        // the kernels queued next read the verdict themselves (StreamHit::bad) and look nothing up when the
+        // sample failed; the caller downloads it with the counts -- one host sync per call, not two
+        k_check_ascending2<<<(unsigned)std::min<u64>((n_sample + 255) / 256, 2048), 256, 0, db->stream>>>(
+            db->d_sample_tmp, n_sample, db->d_bad_word, db->bad_gen, nullptr);
+        return YH_OK;
+    }
+    YH_HIP(hipMemsetAsync(db->d_flag, 0, sizeof(u32), db->stream));
     k_check_ascending<<<(unsigned)std::min<u64>((n_sample + 255) / 256, 2048), 256, 0, db->stream>>>(db->d_sample_tmp, n_sample,
                                                                                                   db->d_flag);
-    // defer_verdict: the kernels queued next read d_flag themselves (StreamHit::bad) and look nothing up
-    // when it is set; the caller downloads the flag with the counts -- one host sync per call, not two
-    if (defer_verdict) return YH_OK;
     YH_HIP(hipMemcpyAsync(&verdict, db->d_flag, sizeof(u32), hipMemcpyDeviceToHost, db->stream));
     YH_HIP(hipStreamSynchronize(db->stream));
     if (verdict) {
@@ -629,7 +662,14 @@ int yh_run(yh_db* db, const uint64_t* sample, uint64_t n_sample, uint32_t* overl
     if (N && (!overlap || !n_excl || !n_match)) { yh_set_error("null argument"); return YH_ERR_INVALID_ARG; }
     if (!db->has_index) { yh_set_error("this handle was created with YH_DB_NO_INDEX"); return YH_ERR_UNSUPPORTED; }
     YH_TRY(db_select(db));
-    const bool defer = db->d_sdelta != nullptr && db->d_flag != nullptr;  // the stream kernel honours the device-side verdict
+    const bool defer = db->d_sdelta != nullptr;  // the stream kernel honours the device-side verdict
+    if (defer) {
+        if (!db->d_bad_word) {
+            YH_TRY(yh_dmalloc(db, (void**)&db->d_bad_word, 16));
+            YH_HIP(hipMemsetAsync(db->d_bad_word, 0, 16, db->stream));
+        }
+        next_gen(db);
+    }
     YH_TRY(upload_sample(db, sample, n_sample, defer));
     if (N == 0) {
         if (defer) YH_HIP(hipStreamSynchronize(db->stream));
@@ -637,7 +677,7 @@ int yh_run(yh_db* db, const uint64_t* sample, uint64_t n_sample, uint32_t* overl
     }
     u32 *d_e = nullptr, *d_m = nullptr;
     YH_TRY(ensure_out_tmp(db, &d_e, &d_m));
-    if (defer) db->d_bad = db->d_flag;
+    if (defer) db->d_bad = db->d_bad_word;
     int rc = yh_run_device(db, (const uint64_t*)db->d_sample_tmp, n_sample, db->d_overlap_tmp, d_e, d_m);
     db->d_bad = nullptr;
     u32 verdict = 0;
@@ -645,13 +685,13 @@ int yh_run(yh_db* db, const uint64_t* sample, uint64_t n_sample, uint32_t* overl
         if (hipMemcpyAsync(overlap, db->d_overlap_tmp, N * sizeof(u32), hipMemcpyDeviceToHost, db->stream) != hipSuccess ||
             hipMemcpyAsync(n_excl, d_e, N * sizeof(u32), hipMemcpyDeviceToHost, db->stream) != hipSuccess ||
             hipMemcpyAsync(n_match, d_m, N * sizeof(u32), hipMemcpyDeviceToHost, db->stream) != hipSuccess ||
-            (defer && hipMemcpyAsync(&verdict, db->d_flag, sizeof(u32), hipMemcpyDeviceToHost, db->stream) != hipSuccess) ||
+            (defer && hipMemcpyAsync(&verdict, db->d_bad_word, sizeof(u32), hipMemcpyDeviceToHost, db->stream) != hipSuccess) ||
             hipStreamSynchronize(db->stream) != hipSuccess) {
             yh_set_error("run download failed: %s", hipGetErrorString(hipGetLastError()));
             rc = YH_ERR_HIP;
         }
     }
-    if (rc == YH_OK && verdict) {
+    if (rc == YH_OK && defer && verdict == db->bad_gen) {
         yh_set_error("the sample sketch is not strictly ascending");
         rc = YH_ERR_UNSORTED;
     }
@@ -701,7 +741,6 @@ int yh_run_finish_device(yh_db* db, const uint32_t* d_global_bits, uint32_t* d_n
 static int slot_prepare(yh_db* db, RunSlot& s, u64 n_sample) {
     const u64 N = std::max<u64>(db->n_refs, 1);
     if (!db->st_in) YH_HIP(hipStreamCreateWithFlags(&db->st_in, hipStreamNonBlocking));
-    if (!db->st_out) YH_HIP(hipStreamCreateWithFlags(&db->st_out, hipStreamNonBlocking));
     if (!s.ev_up) {
         YH_HIP(hipEventCreateWithFlags(&s.ev_up, hipEventDisableTiming));
         YH_HIP(hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
@@ -710,7 +749,9 @@ static int slot_prepare(yh_db* db, RunSlot& s, u64 n_sample) {
     if (!s.d_out) YH_TRY(yh_dmalloc(db, (void**)&s.d_out, 3 * N * sizeof(u32) + 16));
     if (!s.d_bad) {
         YH_TRY(yh_dmalloc(db, (void**)&s.d_bad, 16));
+        YH_HIP(hipMemsetAsync(s.d_bad, 0, 16, db->stream));
         YH_HIP(hipHostMalloc((void**)&s.h_bad, 16, hipHostMallocDefault));
+        YH_HIP(hipHostGetDevicePointer((void**)&s.h_bad_dev, s.h_bad, 0));
     }
     if (s.cap < n_sample) {
         if (s.d_sample) { (void)hipFree(s.d_sample); s.d_sample = nullptr; s.cap = 0; }
@@ -733,31 +774,44 @@ int yh_run_submit(yh_db* db, int slot, const uint64_t* sample, uint64_t n_sample
     if (s.busy) { yh_set_error("slot %d is in flight: yh_run_wait it first", slot); return YH_ERR_INVALID_ARG; }
     YH_TRY(db_select(db));
     YH_TRY(slot_prepare(db, s, n_sample));
-    // upload on the copy-in stream
+    // upload on the copy-in stream (SDMA: overlaps the kernels of the call in front)
+    *s.h_bad = 0;
     if (n_sample) YH_HIP(hipMemcpyAsync(s.d_sample, sample, n_sample * sizeof(u64), hipMemcpyHostToDevice, db->st_in));
     YH_HIP(hipEventRecord(s.ev_up, db->st_in));
-    // ordering check + kernels on the handle's stream, behind the upload
+    // ordering check + kernels + download on the handle's stream, behind the upload.  (The download stays
+    // on this stream: HIP moves device -> pinned host with blit kernels, and a third stream only added
+    // cross-stream waits in front of every step -- traced, profiles/r02/host_pipeline_trace.txt.)
     YH_HIP(hipStreamWaitEvent(db->stream, s.ev_up, 0));
-    YH_HIP(hipMemsetAsync(s.d_bad, 0, sizeof(u32), db->stream));
+    const u32 gen = next_gen(db);
     if (n_sample > 1)
-        k_check_ascending<<<(unsigned)std::min<u64>((n_sample + 255) / 256, 2048), 256, 0, db->stream>>>(s.d_sample, n_sample, s.d_bad);
+        k_check_ascending2<<<(unsigned)std::min<u64>((n_sample + 255) / 256, 2048), 256, 0, db->stream>>>(s.d_sample, n_sample, s.d_bad,
+                                                                                                         gen, s.h_bad_dev);
     int rc = YH_OK;
     if (N) {
         db->d_bad = s.d_bad;
         rc = yh_run_device(db, (const uint64_t*)s.d_sample, n_sample, s.d_out, s.d_out + N, s.d_out + 2 * N);
         db->d_bad = nullptr;
     }
-    YH_HIP(hipEventRecord(s.ev_done, db->stream));
     if (rc != YH_OK) return rc;
-    // download on the copy-out stream, behind the kernels
-    YH_HIP(hipStreamWaitEvent(db->st_out, s.ev_done, 0));
     if (N) {
-        YH_HIP(hipMemcpyAsync(overlap, s.d_out, N * sizeof(u32), hipMemcpyDeviceToHost, db->st_out));
-        YH_HIP(hipMemcpyAsync(n_excl, s.d_out + N, N * sizeof(u32), hipMemcpyDeviceToHost, db->st_out));
-        YH_HIP(hipMemcpyAsync(n_match, s.d_out + 2 * N, N * sizeof(u32), hipMemcpyDeviceToHost, db->st_out));
+        const bool one_block = n_excl == overlap + N && n_match == n_excl + N;  // one contiguous [3][N] host buffer
+        void* dv = nullptr;
+        if (one_block && (3 * N) % 4 == 0 && ((uintptr_t)overlap & 15u) == 0) {
+            if (s.out_host != overlap) { s.out_host = overlap; s.out_dev = device_view_of_host(overlap); }
+            dv = s.out_dev;
+        }
+        if (dv) {
+            k_copy_out<<<(unsigned)std::min<u64>((3 * N / 4 + 255) / 256, 512), 256, 0, db->stream>>>(
+                reinterpret_cast<const uint4*>(s.d_out), reinterpret_cast<uint4*>(dv), 3 * N / 4);
+        } else if (one_block) {
+            YH_HIP(hipMemcpyAsync(overlap, s.d_out, 3 * N * sizeof(u32), hipMemcpyDeviceToHost, db->stream));
+        } else {
+            YH_HIP(hipMemcpyAsync(overlap, s.d_out, N * sizeof(u32), hipMemcpyDeviceToHost, db->stream));
+            YH_HIP(hipMemcpyAsync(n_excl, s.d_out + N, N * sizeof(u32), hipMemcpyDeviceToHost, db->stream));
+            YH_HIP(hipMemcpyAsync(n_match, s.d_out + 2 * N, N * sizeof(u32), hipMemcpyDeviceToHost, db->stream));
+        }
     }
-    YH_HIP(hipMemcpyAsync(s.h_bad, s.d_bad, sizeof(u32), hipMemcpyDeviceToHost, db->st_out));
-    YH_HIP(hipEventRecord(s.ev_out, db->st_out));
+    YH_HIP(hipEventRecord(s.ev_out, db->stream));
     s.busy = true;
     return YH_OK;
 }
@@ -770,7 +824,7 @@ int yh_run_wait(yh_db* db, int slot) {
     YH_TRY(db_select(db));
     s.busy = false;
     YH_HIP(hipEventSynchronize(s.ev_out));
-    if (*s.h_bad) { yh_set_error("the sample sketch is not strictly ascending"); return YH_ERR_UNSORTED; }
+    if (*(volatile u32*)s.h_bad) { yh_set_error("the sample sketch is not strictly ascending"); return YH_ERR_UNSORTED; }
     return YH_OK;
 }
 

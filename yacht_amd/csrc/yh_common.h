@@ -135,8 +135,11 @@ struct RunSlot {
     u64 cap = 0;
     u32* d_out = nullptr;     // [3][N] overlap, n_excl, n_match
     u32* d_bad = nullptr;     // [1] set by the ordering check queued in front of the kernels
-    u32* h_bad = nullptr;     // pinned copy, read by yh_run_wait
+    u32* h_bad = nullptr;     // page-locked host word the check kernel also writes (zero-copy), read by yh_run_wait
+    u32* h_bad_dev = nullptr; // its device address
     hipEvent_t ev_up = nullptr, ev_done = nullptr, ev_out = nullptr;
+    void* out_host = nullptr;  // the last [3][N] host block of this slot and its device view (null: pageable)
+    void* out_dev = nullptr;
     bool busy = false;
 };
 
@@ -236,6 +239,7 @@ struct yh_db {
     u64* d_sample_tmp = nullptr;   // grows on demand (host-pointer entry points)
     u64 sample_tmp_cap = 0;
     u32* d_flag = nullptr;     // [1] generic error/flag word
+    u32* d_bad_word = nullptr; // [1] deferred ordering verdict of yh_run (see bad_gen)
     u64* d_hitq = nullptr;     // [hitq_wgs][hitq_cap] deferred overlap hits (partition << 32 | position)
     u32* d_hitq_cnt = nullptr; // [hitq_wgs]
     u32 hitq_wgs = 0, hitq_cap = 0;
@@ -262,7 +266,9 @@ struct yh_db {
     // pipelined host-buffer calls
     RunSlot slots[YH_RUN_SLOTS];
     hipStream_t st_in = nullptr, st_out = nullptr;  // copy streams beside `stream`
-    const u32* d_bad = nullptr;  // non-null while a submitted call's kernels are being queued (see StreamHit::bad)
+    const u32* d_bad = nullptr;  // non-null while the kernels of a call with a deferred ordering verdict are being queued:
+    u32 bad_gen = 0;             // the check kernel in front of them stores bad_gen there when the sample is not ascending
+                                 // (generations are unique per handle, so the word never has to be cleared)
 
     // timing
     EventRing ev_overlap, ev_excl, ev_pair;

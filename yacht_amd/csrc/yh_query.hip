@@ -933,8 +933,8 @@ struct StreamHit {
     u8* hitflag;        // may be null: hit[g] = 1 for every shared hash g found in the sample
     u32* reps2;         // may be null: a second set of replicas counting the hits ON SHARED HASHES only
     const u64* sample;
-    const u32* bad;     // may be null: *bad != 0 = the sample failed the ordering check queued in front of
-                        // this kernel (pipelined host-buffer calls): nothing is looked up, counts stay zero
+    const u32* bad;     // may be null: *bad == bad_gen = the sample failed the ordering check queued in front of
+    u32 bad_gen;        // this kernel (deferred verdict of the host-buffer calls): nothing is looked up, counts stay zero
     u32* work_count;    // may be null: cleared here for the kernels behind (k_reduce_replicas appends the exclusive pass's work)
 };
 
@@ -1278,7 +1278,7 @@ k_stream_lookup(const u32x4* __restrict__ deltas, const u64* __restrict__ hdr, u
 
     const u32 tid = threadIdx.x;
     if (hit.work_count && blockIdx.x == 0 && tid == 0) *hit.work_count = 0;
-    if (hit.bad && *hit.bad) return;  // (wave-uniform scalar load)
+    if (hit.bad && *hit.bad == hit.bad_gen) return;  // (wave-uniform scalar load)
     const u32 wv = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const u32 lid = xcd_remap(blockIdx.x, gridDim.x);
     const u64 per = (nblk + gridDim.x - 1) / gridDim.x;
@@ -1400,9 +1400,9 @@ __global__ void __launch_bounds__(256) k_index_lookup(const u64* __restrict__ sa
                                                       const u64* __restrict__ po, const u32* __restrict__ pr,
                                                       u32* __restrict__ reps, u32 rep_mask, u64 n_refs,
                                                       u8* __restrict__ hit, u32* __restrict__ reps2,
-                                                      u32* __restrict__ work_count, const u32* __restrict__ bad) {
+                                                      u32* __restrict__ work_count, const u32* __restrict__ bad, u32 bad_gen) {
     if (work_count && blockIdx.x == 0 && threadIdx.x == 0) *work_count = 0;  // (for the kernels behind: see StreamHit)
-    if (bad && *bad) return;
+    if (bad && *bad == bad_gen) return;
     u32* my = reps + (u64)(blockIdx.x & rep_mask) * n_refs;
     u32* my2 = reps2 ? reps2 + (u64)(blockIdx.x & rep_mask) * n_refs : nullptr;  // hits on shared hashes (fused run)
     for (u64 t = blockIdx.x * (u64)blockDim.x + threadIdx.x; t < n; t += (u64)gridDim.x * blockDim.x) {
@@ -1877,7 +1877,7 @@ static int yh_q_overlap_stream(yh_db* db, const u64* d_sample, u64 n_sample, u32
     // workgroup finds its own range of the sample (two 64-ary wave searches while its first
     // super-block is in flight).
     u32* const reps2 = db->d_reps + db->reps_cap;
-    StreamHit sh{(u32)N, db->d_reps, R - 1, db->d_srec, flags_too ? db->d_hit : nullptr, fused ? reps2 : nullptr, d_sample, db->d_bad, db->d_work_count};
+    StreamHit sh{(u32)N, db->d_reps, R - 1, db->d_srec, flags_too ? db->d_hit : nullptr, fused ? reps2 : nullptr, d_sample, db->d_bad, db->bad_gen, db->d_work_count};
     yh_ring_record_begin(db, db->ev_overlap);
     k_stream_lookup<<<wgs, STREAM_THREADS, 0, st>>>(reinterpret_cast<const u32x4*>(db->d_sdelta), db->d_shdr, nblk, d_sample,
                                                     (u32)n_sample, db->d_wg_key, db->sshift, sh);
@@ -2026,7 +2026,7 @@ int yh_q_overlap_indexed(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_ov
         k_index_lookup<<<grid_for(n_sample, 256, 4096), 256, 0, st>>>(d_sample, n_sample, yh_dir_view(db), db->d_po, db->d_pr,
                                                                       db->d_reps, R - 1, N,
                                                                       (for_exclusive && db->n_shared && !fused) ? db->d_hit : nullptr,
-                                                                      fused ? reps2 : nullptr, db->d_work_count, db->d_bad);
+                                                                      fused ? reps2 : nullptr, db->d_work_count, db->d_bad, db->bad_gen);
     else if (fused && db->d_work_count)
         YH_HIP(hipMemsetAsync(db->d_work_count, 0, sizeof(u32), st));
     yh_ring_record_end(db, db->ev_overlap);
