@@ -127,7 +127,8 @@ def main() -> int:
 
     from yacht_amd import build, synth
     from yacht_amd import dist as ydist
-    from yacht_amd.engine import PinnedArray, RefDB, YH_DB_DEFAULT, YH_DB_FULL_INDEX
+    from yacht_amd import _lib as ylib
+    from yacht_amd.engine import PinnedArray, RefDB, YH_DB_DEFAULT, YH_DB_NO_DIRECTORY
 
     if not os.path.exists(build.LIB_PATH):
         build.build_lib()
@@ -181,7 +182,7 @@ def main() -> int:
             row_stride = int(n_rows_c.item())
         else:
             db = RefDB.from_device(values.data_ptr(), offsets.data_ptr(), n_local, device=local_rank,
-                                   flags=YH_DB_DEFAULT if args.no_indexed else YH_DB_FULL_INDEX)
+                                   flags=YH_DB_NO_DIRECTORY if args.no_indexed else YH_DB_DEFAULT)
             row_stride = n_local
     torch.cuda.synchronize()
     db.set_stream(stream.cuda_stream)
@@ -283,34 +284,43 @@ def main() -> int:
 
     # ---- N = 1 extras ------------------------------------------------------------------------------------
     indexed = host_inclusive = real_shape = None
-    if world == 1 and not args.no_indexed:
-        cidx = torch.zeros((3, n_local), device=dev, dtype=torch.int32)
+    paths = {}
+    default_choice = ylib.YH_LOOKUP_STREAM
+    if world == 1:
+        default_choice = db.lookup_choice(n_sample)
+        timing_default = timing
+        cpath = torch.zeros((3, n_local), device=dev, dtype=torch.int32)
 
-        def step_idx(i):
+        def step_path(i):
             s = samples[i % K]
             with torch.cuda.stream(stream):
-                db.run_indexed_device(s.data_ptr(), s.numel(), cidx[0].data_ptr(), cidx[1].data_ptr(), cidx[2].data_ptr())
+                db.run_device(s.data_ptr(), s.numel(), cpath[0].data_ptr(), cpath[1].data_ptr(), cpath[2].data_ptr())
 
-        for i in range(args.warmup):
-            step_idx(i)
-        fence()
-        db.timing()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            step_idx(i)
-        fence()
-        el = time.perf_counter() - t0
-        tm_idx = db.timing()
-        same = True
-        for i in range(K):
-            step_idx(i)
-            torch.cuda.synchronize()
-            same = same and bool(torch.equal(cidx, results[i]))
-        indexed = {"ms_per_step": round(1e3 * el / args.steps, 4), "value": round(n_local / (el / args.steps), 1),
-                   "unit": "queries/s", "lookup_kernel_ms_avg": round(float(tm_idx["ms_overlap_kernel"]), 4),
-                   "exclusive_kernels_ms_avg": round(float(tm_idx["ms_exclusive_kernels"]), 4),
-                   "note": "yh_run_indexed_device: one lane per sample hash through the distinct-hash directory (YH_DB_FULL_INDEX)",
-                   "equals_default_path": same}
+        for name, mode in (("stream", ylib.YH_LOOKUP_STREAM), ("indexed", ylib.YH_LOOKUP_INDEXED)):
+            if mode == ylib.YH_LOOKUP_INDEXED and args.no_indexed:
+                continue
+            db.set_lookup(mode)
+            for i in range(args.warmup):
+                step_path(i)
+            fence()
+            db.timing()
+            t0 = time.perf_counter()
+            for i in range(max(args.steps, 64)):
+                step_path(i)
+            fence()
+            el = (time.perf_counter() - t0) / max(args.steps, 64)
+            tm = db.timing()
+            same = True
+            for i in range(K):
+                step_path(i)
+                torch.cuda.synchronize()
+                same = same and bool(torch.equal(cpath, results[i]))
+            paths[name] = {"ms_per_step": round(1e3 * el, 4), "value": round(n_local / el, 1), "unit": "queries/s",
+                           "lookup_kernel_ms_avg": round(float(tm["ms_overlap_kernel"]), 4),
+                           "exclusive_kernels_ms_avg": round(float(tm["ms_exclusive_kernels"]), 4),
+                           "equals_default_path": same}
+        db.set_lookup(ylib.YH_LOOKUP_AUTO)
+        indexed = paths.get("indexed")
 
     if world == 1 and not args.no_host_inclusive:
         # SURVEY.md 8d's metric: wall time of the steady-state call INCLUDING sample H2D and counts D2H.
@@ -348,7 +358,7 @@ def main() -> int:
                     if record:
                         host_t["submit"] += time.perf_counter() - ta
 
-        host_loop(args.warmup, False)
+        host_loop(max(args.warmup, 4 * K), False)  # (the first copy out of every pinned buffer is slow: ~15 ms)
         n_host = max(args.steps, args.percentile_steps)
         t0 = time.perf_counter()
         host_loop(n_host, True)
@@ -417,46 +427,92 @@ def main() -> int:
         step_real(0)
         torch.cuda.synchronize()
         real_counts0 = creal.clone()
+        forced = {}
+        for name, mode in (("stream", ylib.YH_LOOKUP_STREAM), ("indexed", ylib.YH_LOOKUP_INDEXED)):
+            if mode == ylib.YH_LOOKUP_INDEXED and args.no_indexed:
+                continue
+            db.set_lookup(mode)
+            for i in range(args.warmup):
+                step_real(i)
+            fence()
+            t0 = time.perf_counter()
+            for i in range(max(args.steps, 64)):
+                step_real(i)
+            fence()
+            forced[name] = round(1e3 * (time.perf_counter() - t0) / max(args.steps, 64), 4)
+            step_real(0)
+            torch.cuda.synchronize()
+            forced[name + "_equals_default"] = bool(torch.equal(creal, real_counts0))
+        db.set_lookup(ylib.YH_LOOKUP_AUTO)
         real_shape = dict(stats_ms([ev2[k].elapsed_time(ev2[k + 1]) for k in range(n_pct)]),
+                          default_lookup="indexed" if db.lookup_choice(int(real_samples[0].numel())) == ylib.YH_LOOKUP_INDEXED else "stream",
+                          forced_ms_per_step=forced,
                           ms_per_step=round(1e3 * el / args.steps, 4), value=round(n_local / (el / args.steps), 1),
                           unit="queries/s", sample_hashes=int(real_samples[0].numel()),
                           refs_overlapping=int((real_counts0[0] != 0).sum().item()),
                           lookup_kernel_ms_avg=round(float(tm["ms_overlap_kernel"]), 4),
                           exclusive_kernels_ms_avg=round(float(tm["ms_exclusive_kernels"]), 4))
 
-    # ---- roofline of the dominant kernel (the streaming lookup) ------------------------------------------
-    # `achieved` = bytes one launch HAS to move in the layout the kernel reads (yh_db_info.stream_bytes: one
-    # delta byte per (hash, reference) pair + an 8-byte header per 1024, plus the 8-byte sample hashes staged
-    # once) over the measured launch duration: a physical HBM rate comparable with `peak` and `traffic`.
-    # SURVEY.md 8d's one-touch formula (8 B per reference hash) is reported beside it (`survey_formula`); it
-    # exceeds the peak because the kernel does not read 8 bytes per hash.
+    # ---- roofline of the dominant kernel of the DEFAULT step --------------------------------------------
+    # Streaming lookup (k_stream_lookup): `achieved` = bytes one launch HAS to move in the layout the kernel
+    # reads (yh_db_info.stream_bytes: one delta byte per (hash, reference) pair + an 8-byte header per 1024,
+    # plus the 8-byte sample hashes staged once) over the measured launch duration.  SURVEY.md 8d's one-touch
+    # formula (8 B per reference hash) is reported beside it (`survey_formula`); it exceeds the peak because
+    # the kernel does not read 8 bytes per hash.
+    # Sample-driven lookup (k_index_lookup): one 64-byte bucket per sample hash + the 8-byte sample hash:
+    # 72 B x |S|, random sectors -- the same HBM peak, a much lower practical ceiling.
     layout = int(info.get("stream_layout", 0))
-    kernel_name = {1: "k_stream_lookup", 2: "k_tile_lookup_keys", 3: "k_tile_lookup<OverlapHit>"}.get(layout, "?")
     Hh = int(info["n_hashes"])
     Nh = int(info["n_refs"])
     survey_bytes = 8 * (Hh + n_sample) + 8 * (Nh + 1) + 4 * Nh
-    alg_bytes = int(info.get("stream_bytes", 0)) + 8 * n_sample
+
+    def roofline_stream(k_ms, excl_ms):
+        alg_bytes = int(info.get("stream_bytes", 0)) + 8 * n_sample
+        achieved = (alg_bytes / 1e9) / (k_ms / 1e3) if k_ms > 0 else 0.0
+        survey_rate = (survey_bytes / 1e9) / (k_ms / 1e3) if k_ms > 0 else 0.0
+        return {
+            "bound": "hbm",
+            "kernel": {1: "k_stream_lookup", 2: "k_tile_lookup_keys", 3: "k_tile_lookup<OverlapHit>"}.get(layout, "?"),
+            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": None,
+            "bytes_basis": "layout: the delta stream the kernel reads (1 B per reference hash + 8 B per 1024) + 8 B per sample hash",
+            "algorithmic_bytes_per_launch": alg_bytes,
+            "bytes_per_ref_hash": round(int(info.get("stream_bytes", 0)) / max(Hh, 1), 4),
+            "kernel_ms_avg": round(k_ms, 4), "exclusive_kernels_ms_avg": round(excl_ms, 4),
+            "survey_formula": {"bytes_per_launch": survey_bytes, "GBps": round(survey_rate, 1),
+                               "frac": round(survey_rate / HBM_PEAK_GBS, 4),
+                               "note": "8 B per reference hash as SURVEY.md 8d counts; the kernel streams "
+                                       f"{round(int(info.get('stream_bytes', 0)) / max(Hh, 1), 3)} B per hash"},
+        }
+
+    def roofline_indexed(k_ms, excl_ms):
+        alg_bytes = 72 * n_sample
+        achieved = (alg_bytes / 1e9) / (k_ms / 1e3) if k_ms > 0 else 0.0
+        survey_rate = (survey_bytes / 1e9) / (k_ms / 1e3) if k_ms > 0 else 0.0
+        return {
+            "bound": "hbm", "kernel": "k_index_lookup",
+            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": None,
+            "bytes_basis": "layout: one 64-byte bucket (random sector) + the 8-byte hash per SAMPLE hash; no reference hash is streamed",
+            "algorithmic_bytes_per_launch": alg_bytes,
+            "random_sectors_per_s": round(n_sample / (k_ms / 1e3), 1) if k_ms > 0 else 0.0,
+            "random_sector_ceiling_per_s": 4.6e10,
+            "ceiling_note": "scripts/probes/gather_probe.hip on this GPU: 4.6e10 independent 64-byte reads/s (2.9 TB/s) whatever the access form",
+            "kernel_ms_avg": round(k_ms, 4), "exclusive_kernels_ms_avg": round(excl_ms, 4),
+            "survey_formula": {"bytes_per_launch": survey_bytes, "GBps": round(survey_rate, 1),
+                               "frac": round(survey_rate / HBM_PEAK_GBS, 4),
+                               "note": "8 B per reference hash as SURVEY.md 8d counts; this kernel reads none of them"},
+        }
+
     k_ms = float(timing["ms_overlap_kernel"])
-    achieved = (alg_bytes / 1e9) / (k_ms / 1e3) if k_ms > 0 else 0.0
-    survey_rate = (survey_bytes / 1e9) / (k_ms / 1e3) if k_ms > 0 else 0.0
-    roofline = {
-        "bound": "hbm",
-        "kernel": kernel_name,
-        "achieved": round(achieved, 1),
-        "peak": HBM_PEAK_GBS,
-        "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 4),
-        "traffic": None,
-        "bytes_basis": "layout: the delta stream the kernel reads (1 B per reference hash + 8 B per 1024) + 8 B per sample hash",
-        "algorithmic_bytes_per_launch": alg_bytes,
-        "bytes_per_ref_hash": round(int(info.get("stream_bytes", 0)) / max(Hh, 1), 4),
-        "kernel_ms_avg": round(k_ms, 4),
-        "exclusive_kernels_ms_avg": round(float(timing["ms_exclusive_kernels"]), 4),
-        "survey_formula": {"bytes_per_launch": survey_bytes, "GBps": round(survey_rate, 1),
-                           "frac": round(survey_rate / HBM_PEAK_GBS, 4),
-                           "note": "8 B per reference hash as SURVEY.md 8d counts; the kernel streams "
-                                   f"{round(int(info.get('stream_bytes', 0)) / max(Hh, 1), 3)} B per hash"},
-    }
+    x_ms = float(timing["ms_exclusive_kernels"])
+    roofline = (roofline_indexed if default_choice == ylib.YH_LOOKUP_INDEXED else roofline_stream)(k_ms, x_ms)
+    roofline["default_lookup"] = "indexed" if default_choice == ylib.YH_LOOKUP_INDEXED else "stream"
+    other = None
+    if "stream" in paths and default_choice == ylib.YH_LOOKUP_INDEXED:
+        other = roofline_stream(paths["stream"]["lookup_kernel_ms_avg"], paths["stream"]["exclusive_kernels_ms_avg"])
+    elif "indexed" in paths and default_choice == ylib.YH_LOOKUP_STREAM:
+        other = roofline_indexed(paths["indexed"]["lookup_kernel_ms_avg"], paths["indexed"]["exclusive_kernels_ms_avg"])
     # HBM bytes per launch from the rocprofv3 --pmc passes (profiles/README.md), attached only when they
     # were taken from THIS source of the kernels on THIS workload; otherwise null.
     tag = source_tag()
@@ -466,11 +522,12 @@ def main() -> int:
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 tr = json.load(f)
-            if tr.get("source_tag") == tag and tr.get("n_hashes") == Hh and tr.get("kernel") == roofline["kernel"]:
-                roofline["traffic"] = tr.get("hbm_bytes_per_launch")
-                roofline["traffic_provenance"] = {"file": "profiles/" + name, "source_tag": tag,
-                                                  "taken": tr.get("taken"), "commit": tr.get("commit")}
-                break
+            for rl in (roofline, other):
+                if rl is not None and rl["traffic"] is None and tr.get("source_tag") == tag and tr.get("n_hashes") == Hh \
+                        and tr.get("kernel") == rl["kernel"]:
+                    rl["traffic"] = tr.get("hbm_bytes_per_launch")
+                    rl["traffic_provenance"] = {"file": "profiles/" + name, "source_tag": tag,
+                                                "taken": tr.get("taken"), "commit": tr.get("commit")}
         except Exception:
             pass
 
@@ -569,7 +626,8 @@ def main() -> int:
             "device_resident": device_resident,
             "host_inclusive": host_inclusive,
             "real_shape": real_shape,
-            "indexed_path": indexed,
+            "paths": paths,
+            "roofline_other_path": other,
         }
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
@@ -580,8 +638,8 @@ def main() -> int:
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    if rank == 0 and indexed is not None and not indexed["equals_default_path"]:
-        print("bench.py: indexed path differs from the default path", file=sys.stderr)
+    if rank == 0 and any(not p_["equals_default_path"] for p_ in paths.values()):
+        print("bench.py: the two lookup paths differ", file=sys.stderr)
         return 1
     if rank == 0 and host_inclusive is not None and not host_inclusive["equals_device_resident"]:
         print("bench.py: host-buffer path differs from the device-resident path", file=sys.stderr)

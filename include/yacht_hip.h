@@ -59,11 +59,15 @@ enum {
 #define YH_DB_DEFAULT      0u
 #define YH_DB_NO_INDEX     1u  /* skip the shared-hash inverted index (overlap-only handle)     */
 #define YH_DB_KEEP_CSR     2u  /* keep the plain CSR resident too (needed by yh_overlap_bsearch) */
-#define YH_DB_FULL_INDEX   4u  /* also keep a directory of EVERY distinct hash (+12 B per distinct
-                                  hash): enables the sample-driven yh_*_indexed_device queries      */
+#define YH_DB_FULL_INDEX   4u  /* (accepted for compatibility: the directory below is built by default)      */
 #define YH_DB_PAIRWISE_ONLY 8u /* `yacht train` handle: validated sizes + the inverted index only
                                   (yh_pairwise, yh_index_stats); no streaming layout, so the
                                   overlap / exclusive / run queries return YH_ERR_UNSUPPORTED        */
+#define YH_DB_NO_DIRECTORY 16u /* do not build the bucket table over the distinct hashes (25.6 B per
+                                  distinct hash): the sample-driven (indexed) lookups -- yh_*_indexed_device,
+                                  yh_run_batch, and the automatic choice inside yh_run / yh_overlap for
+                                  samples much smaller than the database -- are then unavailable and every
+                                  query streams the database                                          */
 
 typedef struct yh_db yh_db;
 
@@ -124,6 +128,18 @@ int yh_db_synchronize(yh_db* db);
  * only every YH_TIMING_EVERY-th launch (environment, default 8; 1 = all, 0 = none) is recorded. */
 int yh_db_get_timing(yh_db* db, yh_timing* t);
 
+/* Which lookup kernel yh_overlap / yh_run (host and device forms) use.  Both are exact.
+ *   YH_LOOKUP_AUTO     (default) by cost: the sample-driven kernel (one 64-byte bucket read per sample
+ *                      hash) when the sample is small against the database, else the streaming kernel
+ *                      (every reference hash, one delta byte each)
+ *   YH_LOOKUP_STREAM   always stream;   YH_LOOKUP_INDEXED  always sample-driven (needs the directory) */
+#define YH_LOOKUP_AUTO    0
+#define YH_LOOKUP_STREAM  1
+#define YH_LOOKUP_INDEXED 2
+int yh_db_set_lookup(yh_db* db, int mode);
+/* What a query with a sample of n_sample hashes would take now: YH_LOOKUP_STREAM or YH_LOOKUP_INDEXED (< 0: error). */
+int yh_db_lookup_choice(yh_db* db, uint64_t n_sample);
+
 /* ---- yacht run, step 1: overlap of one sample with every reference ----------------------
  * overlap[j] = |S ∩ R_j| for j in [0, N).  Host-pointer form is synchronous and validates
  * that the sample is strictly ascending.                                                    */
@@ -136,15 +152,15 @@ int yh_overlap_device(yh_db* db, const uint64_t* d_sample, uint64_t n_sample, ui
 int yh_overlap_bsearch(yh_db* db, const uint64_t* sample, uint64_t n_sample, uint32_t* overlap);
 int yh_overlap_bsearch_device(yh_db* db, const uint64_t* d_sample, uint64_t n_sample, uint32_t* d_overlap);
 
-/* Sample-driven forms (need YH_DB_FULL_INDEX): one lane per SAMPLE hash looks it up in a directory
- * of the database's distinct hashes, so the work is proportional to |S| instead of streaming every
- * reference hash.  Same results as yh_overlap_device / yh_run_device.                          */
+/* Sample-driven forms, whatever yh_db_set_lookup says (fail on a YH_DB_NO_DIRECTORY handle): one lane per
+ * SAMPLE hash looks it up in the bucket table over the database's distinct hashes, so the work is
+ * proportional to |S| instead of streaming every reference hash.  Same results as the streaming kernel. */
 int yh_overlap_indexed_device(yh_db* db, const uint64_t* d_sample, uint64_t n_sample, uint32_t* d_overlap);
 int yh_run_indexed_device(yh_db* db, const uint64_t* d_sample, uint64_t n_sample,
                           uint32_t* d_overlap, uint32_t* d_n_excl, uint32_t* d_n_match);
 
 /* Many samples against one resident database in one pass (needs
- * YH_DB_FULL_INDEX; the reference runs one sample per process, run_YACHT.py:150).  `samples` holds
+ * the directory; the reference runs one sample per process, run_YACHT.py:150).  `samples` holds
  * n_samples (1..64) sketches back to back, each strictly ascending, delimited by
  * sample_offsets[n_samples + 1]; outputs are [n_samples][N] row-major.  For every sample the three
  * rows equal what yh_run returns for it alone.  total_hashes = sample_offsets[n_samples].       */

@@ -144,7 +144,8 @@ static void overlap_probe(uint4* tab, u32* out) {
 }
 
 int main(int argc, char** argv) {
-    const u64 table_bytes = 6ull << 30;
+    const u64 table_gb = argc > 2 ? strtoull(argv[2], nullptr, 10) : 6;
+    const u64 table_bytes = table_gb << 30;
     const u64 nb = table_bytes / 64;
     uint4* tab; u32* out; u64* keys;
     CK(hipMalloc(&tab, table_bytes));
@@ -153,9 +154,8 @@ int main(int argc, char** argv) {
     k_fill<<<4096, 256>>>(tab, table_bytes / 16);
     CK(hipDeviceSynchronize());
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    overlap_probe(tab, out);
-    if (argc > 1) return 0;
-    const u64 sizes[] = {83000, 250000, 1000000, 4000000, 16000000};
+    if (argc > 1 && argv[1][0] == 'x') { overlap_probe(tab, out); return 0; }
+    const u64 sizes[] = {83000, 1000000, 4000000};
     const int REP = 20;
     for (u64 n : sizes) {
         CK(hipMalloc(&keys, (u64)REP * n * 8));
@@ -181,8 +181,31 @@ int main(int argc, char** argv) {
             printf("  V%d %.1f us (min %.1f)", v, 1e3 * sum / (REP - 2), 1e3 * best);
         }
         printf("\n");
+        if (n == 1000000) {  // the same V1 lookups with OTHER kernels between them, as inside a query step
+            uint4* other; const u64 ob = 2ull << 30;
+            CK(hipMalloc(&other, ob));
+            k_fill<<<4096, 256>>>(other, ob / 16);
+            CK(hipDeviceSynchronize());
+            for (int mode = 0; mode < 3; ++mode) {  // 0: a 340 MB streaming kernel between, 1: a tiny kernel between, 2: 2 GB streamed between
+                float sum = 0;
+                for (int r = 0; r < REP; ++r) {
+                    if (mode == 0) k_busy<<<512, 512>>>(other, (340ull << 20) / 16, out, 1);
+                    if (mode == 1) k_busy<<<64, 512>>>(other, 4096, out, 1);
+                    if (mode == 2) k_busy<<<512, 512>>>(other, ob / 16, out, 1);
+                    CK(hipEventRecord(e0));
+                    k_v1<<<(unsigned)((n + 255) / 256), 256>>>(keys + (u64)r * n, n, tab, nb, out);
+                    CK(hipEventRecord(e1));
+                    CK(hipEventSynchronize(e1));
+                    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                    if (r >= 2) sum += ms;
+                }
+                printf("   V1 with another kernel in front (mode %d): %.1f us\n", mode, 1e3 * sum / (REP - 2));
+            }
+            CK(hipFree(other));
+        }
         CK(hipFree(keys));
     }
+    if (argc > 1 && argv[1][0] == 't') return 0;
     // ---- PCIe: pinned host -> device -----------------------------------------------------------------
     {
         const u64 bytes = 64ull << 20;

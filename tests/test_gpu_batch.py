@@ -71,7 +71,7 @@ def test_batch_same_sample_repeated(hip_lib):
 def test_batch_errors(hip_lib):
     values, offsets = synth.config4(seed=34, n_clusters=4, size=50)
     smp = np.unique(values)[:20]
-    with RefDB(values, offsets) as db:  # no directory
+    with RefDB(values, offsets, flags=16) as db:  # YH_DB_NO_DIRECTORY
         with pytest.raises(_lib.YachtHipError):
             db.run_batch([smp])
     with RefDB(values, offsets, flags=FULL) as db:

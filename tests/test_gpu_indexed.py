@@ -5,7 +5,8 @@ import pytest
 
 from oracle import oracle
 from yacht_amd import synth
-from yacht_amd.engine import RefDB, YH_DB_FULL_INDEX, YH_DB_KEEP_CSR
+from yacht_amd import _lib
+from yacht_amd.engine import RefDB, YH_DB_FULL_INDEX, YH_DB_KEEP_CSR, YH_DB_NO_DIRECTORY
 
 pytestmark = pytest.mark.gpu
 
@@ -38,6 +39,8 @@ def _check(refs, sample):
         assert np.array_equal(ov, want_ov)
         assert np.array_equal(e, want_e) and np.array_equal(m, want_m)
         # the streaming path of the same handle still agrees
+        db.set_lookup(_lib.YH_LOOKUP_STREAM)
+        assert db.lookup_choice(max(sample.size, 1)) == _lib.YH_LOOKUP_STREAM
         sov, se, sm = db.run_counts(sample)
         assert np.array_equal(sov, want_ov) and np.array_equal(se, want_e) and np.array_equal(sm, want_m)
 
@@ -60,10 +63,13 @@ def test_indexed_small_cases(hip_lib):
 def test_indexed_needs_flag(hip_lib):
     from yacht_amd._lib import YH_ERR_UNSUPPORTED, YachtHipError
 
-    with RefDB(np.array([1, 2, 3], np.uint64), np.array([0, 3], np.uint64)) as db:
+    with RefDB(np.array([1, 2, 3], np.uint64), np.array([0, 3], np.uint64), flags=YH_DB_NO_DIRECTORY) as db:
         with pytest.raises(YachtHipError) as ei:
             db.overlap_indexed_device(0, 0, 1)
         assert ei.value.code in (YH_ERR_UNSUPPORTED, -1)
+        with pytest.raises(YachtHipError):
+            db.set_lookup(_lib.YH_LOOKUP_INDEXED)
+        assert db.lookup_choice(10) == _lib.YH_LOOKUP_STREAM
 
 
 def test_indexed_equals_streaming_at_full_scale(hip_lib):
@@ -75,8 +81,11 @@ def test_indexed_equals_streaming_at_full_scale(hip_lib):
     try:
         outs = [torch.zeros((3, n), dtype=torch.int32, device="cuda:0") for _ in range(2)]
         torch.cuda.synchronize()
+        assert db.lookup_choice(sample.numel()) == _lib.YH_LOOKUP_INDEXED  # 3e5 hashes against 3.3e8: sample-driven by default
+        db.set_lookup(_lib.YH_LOOKUP_STREAM)
         db.run_device(sample.data_ptr(), sample.numel(), outs[0][0].data_ptr(), outs[0][1].data_ptr(),
                       outs[0][2].data_ptr())
+        db.set_lookup(_lib.YH_LOOKUP_AUTO)
         db.run_indexed_device(sample.data_ptr(), sample.numel(), outs[1][0].data_ptr(), outs[1][1].data_ptr(),
                               outs[1][2].data_ptr())
         db.synchronize()

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from oracle import oracle
-from yacht_amd import synth
+from yacht_amd import _lib, synth
 from yacht_amd.engine import RefDB, YH_DB_KEEP_CSR, train_select
 
 pytestmark = pytest.mark.gpu
@@ -19,22 +19,25 @@ def _check_all(refs, sample, c_thresh=C_DEFAULT, partitions_hint=0):
     values, offsets = synth.pack(refs)
     sizes = np.diff(offsets).astype(np.uint32)
     with RefDB(values, offsets, flags=YH_DB_KEEP_CSR, partitions_hint=partitions_hint) as db:
-        # R1
         want = oracle.overlap(values, offsets, sample)
-        got = db.overlap(sample)
-        assert np.array_equal(got, want)
-        assert np.array_equal(db.overlap(sample, method="bsearch"), want)
-        # R2 on the overlap>0 subset and on two arbitrary subsets
-        rng = np.random.default_rng(7)
-        masks = [want > 0, np.ones(len(refs), bool), rng.random(len(refs)) < 0.5]
-        for mask in masks:
-            we, wm = oracle.exclusive(values, offsets, mask, sample)
-            ge, gm = db.exclusive(mask, sample)
-            assert np.array_equal(ge, we)
-            assert np.array_equal(gm, wm)
-        ov, e, m = db.run_counts(sample)
-        we, wm = oracle.exclusive(values, offsets, want > 0, sample)
-        assert np.array_equal(ov, want) and np.array_equal(e, we) and np.array_equal(m, wm)
+        # every query through the streaming kernel, through the sample-driven one, and by the library's own choice
+        for mode in (_lib.YH_LOOKUP_STREAM, _lib.YH_LOOKUP_INDEXED, _lib.YH_LOOKUP_AUTO):
+            db.set_lookup(mode)
+            # R1
+            got = db.overlap(sample)
+            assert np.array_equal(got, want)
+            assert np.array_equal(db.overlap(sample, method="bsearch"), want)
+            # R2 on the overlap>0 subset and on two arbitrary subsets
+            rng = np.random.default_rng(7)
+            masks = [want > 0, np.ones(len(refs), bool), rng.random(len(refs)) < 0.5]
+            for mask in masks:
+                we, wm = oracle.exclusive(values, offsets, mask, sample)
+                ge, gm = db.exclusive(mask, sample)
+                assert np.array_equal(ge, we)
+                assert np.array_equal(gm, wm)
+            ov, e, m = db.run_counts(sample)
+            we, wm = oracle.exclusive(values, offsets, want > 0, sample)
+            assert np.array_equal(ov, want) and np.array_equal(e, we) and np.array_equal(m, wm)
         # T2-T5
         wi, wj, wc, wstats = oracle.train_pairs(values, offsets, c_thresh, threads=3)
         gi, gj, gc = db.pairwise(c_thresh)

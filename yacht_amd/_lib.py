@@ -26,7 +26,9 @@ YH_DB_NO_INDEX = 1
 YH_DB_KEEP_CSR = 2
 YH_DB_FULL_INDEX = 4
 YH_DB_PAIRWISE_ONLY = 8
+YH_DB_NO_DIRECTORY = 16
 YH_RUN_SLOTS = 4
+YH_LOOKUP_AUTO, YH_LOOKUP_STREAM, YH_LOOKUP_INDEXED = 0, 1, 2
 
 _ERR_NAMES = {
     YH_ERR_INVALID_ARG: "YH_ERR_INVALID_ARG",
@@ -89,6 +91,8 @@ SIGNATURES = {
     "yh_db_get_info": (C.c_int, [_vp, C.POINTER(DbInfo)]),
     "yh_db_set_stream": (C.c_int, [_vp, _vp]),
     "yh_db_synchronize": (C.c_int, [_vp]),
+    "yh_db_set_lookup": (C.c_int, [_vp, C.c_int]),
+    "yh_db_lookup_choice": (C.c_int, [_vp, C.c_uint64]),
     "yh_db_get_timing": (C.c_int, [_vp, C.POINTER(Timing)]),
     "yh_overlap": (C.c_int, [_vp, _vp, C.c_uint64, _vp]),
     "yh_overlap_device": (C.c_int, [_vp, _vp, C.c_uint64, _vp]),

@@ -332,7 +332,7 @@ int yh_db_destroy(yh_db* db) {
     if (db->device >= 0) (void)hipSetDevice(db->device);
     if (db->stream) (void)hipStreamSynchronize(db->stream);
     void* ptrs[] = {db->d_values, db->d_offsets, db->d_pvals, db->d_pbeg, db->d_pcnt, db->d_poffs, db->d_sizes,
-                    db->d_g, db->d_po, db->d_pr, db->d_pg, db->d_gbeg, db->d_gcnt, db->d_nshared, db->d_pq, db->d_pq_count, db->d_dh, db->d_dref, db->d_dir, db->d_bkt, db->d_pkeys, db->d_pref, db->d_gkeys, db->d_rpo, db->d_rg, db->d_rrec, db->d_rrecx, db->d_work, db->d_work_count, db->d_sbounds,
+                    db->d_g, db->d_po, db->d_pr, db->d_pg, db->d_gbeg, db->d_gcnt, db->d_nshared, db->d_pq, db->d_pq_count, db->d_dh, db->d_dref, db->d_dir, db->d_bkt, db->d_cbkt, db->d_ovf_keys, db->d_ovf_vals, db->d_pkeys, db->d_pref, db->d_gkeys, db->d_rpo, db->d_rg, db->d_rrec, db->d_rrecx, db->d_work, db->d_work_count, db->d_sbounds,
                     db->d_mask, db->d_maskbits, db->d_hit, db->d_excl_e, db->d_overlap_tmp,
                     db->d_sample_tmp, db->d_out_tmp, db->d_flag, db->d_hitq, db->d_hitq_cnt, db->d_wg_first, db->d_reps, db->d_batch,
                     db->d_sdelta, db->d_shdr, db->d_srec, db->d_wg_key, db->d_ghost_src, db->d_bad_word};
@@ -418,11 +418,46 @@ int yh_db_get_timing(yh_db* db, yh_timing* t) {
     return YH_OK;
 }
 
+// ---- which lookup answers a sample query ---------------------------------------------------------------
+// Both are exact.  The streaming kernel reads every reference hash (one delta byte each): its time is
+// ~12 us + 0.22 ns per reference hash whatever the sample.  The sample-driven kernel reads one 64-byte
+// bucket per SAMPLE hash: ~8 us + 30-45 ns per 1 000 sample hashes + its hits.  (Measured on MI355X at
+// 3.3e8 reference hashes: 85 us against 50-60 us for a 1e6-hash sample, 8 us for an 8e4-hash one;
+// DESIGN.md 3.)  YH_LOOKUP=stream|indexed in the environment, or yh_db_set_lookup, force one.
+static bool prefer_indexed(const yh_db* db, u64 n_sample) {
+    if (!db->has_dir || !db->has_index || n_sample == 0) return false;
+    if (db->lookup_mode == YH_LOOKUP_STREAM) return false;
+    if (db->lookup_mode == YH_LOOKUP_INDEXED) return true;
+    static const int env = [] {
+        const char* e = getenv("YH_LOOKUP");
+        return !e ? 0 : (strcmp(e, "stream") == 0 ? 1 : (strcmp(e, "indexed") == 0 ? 2 : 0));
+    }();
+    if (env) return env == 2;
+    if (!db->d_sdelta) return true;
+    const double t_stream = 12.0 + 0.22e-3 * (double)db->n_hashes;
+    const double t_index = 8.0 + 0.060e-3 * (double)n_sample;  // (with a margin for hit-dense samples)
+    return t_index < t_stream;
+}
+
+int yh_db_lookup_choice(yh_db* db, uint64_t n_sample) {
+    if (!db_ok(db)) return YH_ERR_INVALID_ARG;
+    return prefer_indexed(db, n_sample) ? YH_LOOKUP_INDEXED : YH_LOOKUP_STREAM;
+}
+
+int yh_db_set_lookup(yh_db* db, int mode) {
+    if (!db_ok(db)) return YH_ERR_INVALID_ARG;
+    if (mode < YH_LOOKUP_AUTO || mode > YH_LOOKUP_INDEXED) { yh_set_error("mode must be YH_LOOKUP_AUTO, _STREAM or _INDEXED"); return YH_ERR_INVALID_ARG; }
+    if (mode == YH_LOOKUP_INDEXED && !db->has_dir) { yh_set_error("this handle has no directory of its distinct hashes"); return YH_ERR_UNSUPPORTED; }
+    db->lookup_mode = mode;
+    return YH_OK;
+}
+
 // ---- overlap ---------------------------------------------------------------------------------------
 int yh_overlap_device(yh_db* db, const uint64_t* d_sample, uint64_t n_sample, uint32_t* d_overlap) {
     if (!db_ok(db)) return YH_ERR_INVALID_ARG;
     if (!d_overlap || (n_sample && !d_sample)) { yh_set_error("null device pointer"); return YH_ERR_INVALID_ARG; }
     YH_TRY(db_select(db));
+    if (prefer_indexed(db, n_sample)) return yh_q_overlap_indexed(db, (const u64*)d_sample, n_sample, d_overlap, false);
     return yh_q_overlap(db, (const u64*)d_sample, n_sample, d_overlap, false, false);
 }
 
@@ -591,7 +626,7 @@ static int overlap_host(yh_db* db, const uint64_t* sample, uint64_t n_sample, ui
     YH_TRY(db_select(db));
     YH_TRY(upload_sample(db, sample, n_sample));
     if (bsearch) YH_TRY(yh_q_overlap_bsearch(db, db->d_sample_tmp, n_sample, db->d_overlap_tmp));
-    else YH_TRY(yh_q_overlap(db, db->d_sample_tmp, n_sample, db->d_overlap_tmp, false, false));
+    else YH_TRY(yh_overlap_device(db, (const uint64_t*)db->d_sample_tmp, n_sample, db->d_overlap_tmp));
     if (db->n_refs)
         YH_HIP(hipMemcpyAsync(overlap, db->d_overlap_tmp, db->n_refs * sizeof(u32), hipMemcpyDeviceToHost, db->stream));
     YH_HIP(hipStreamSynchronize(db->stream));
@@ -645,6 +680,10 @@ int yh_run_device(yh_db* db, const uint64_t* d_sample, uint64_t n_sample, uint32
     if (!d_overlap || (n_sample && !d_sample)) { yh_set_error("null device pointer"); return YH_ERR_INVALID_ARG; }
     if ((d_n_excl == nullptr) != (d_n_match == nullptr)) { yh_set_error("pass both d_n_excl and d_n_match or neither"); return YH_ERR_INVALID_ARG; }
     YH_TRY(db_select(db));
+    if (prefer_indexed(db, n_sample)) {
+        if (!d_n_excl) return yh_q_overlap_indexed(db, (const u64*)d_sample, n_sample, d_overlap, false);
+        return yh_run_indexed_device(db, d_sample, n_sample, d_overlap, d_n_excl, d_n_match);
+    }
     if (d_n_excl) {  // three launches when the handle holds the hash-sorted stream
         const int rc = yh_q_run_fused(db, (const u64*)d_sample, n_sample, d_overlap, d_n_excl, d_n_match);
         if (rc != 1) return rc;

@@ -356,6 +356,41 @@ __global__ void k_bkt_build(const u64* __restrict__ dh, const u32* __restrict__ 
     }
 }
 
+// ---- compact bucket table (layout: YhDirView) -------------------------------------------------------------
+// rank of distinct hash i inside its bucket = predecessors with the same bucket (buckets are runs of the sorted array)
+__device__ __forceinline__ u32 bucket_rank(const u64* __restrict__ dh, u64 i, u64 b, u32 lsh, u64 nb) {
+    u32 r = 0;
+    while (r < 64 && i > r && yh_bucket_of(dh[i - 1 - r], lsh, nb) == b) ++r;
+    return r;
+}
+__global__ void k_cbkt_count_overflow(const u64* __restrict__ dh, u64 D, u32 lsh, u64 nb, u64* __restrict__ n_over) {
+    u32 mine = 0;
+    for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < D; i += (u64)gridDim.x * blockDim.x)
+        mine += bucket_rank(dh, i, yh_bucket_of(dh[i], lsh, nb), lsh, nb) >= 7 ? 1u : 0u;
+    if (mine) atomicAdd(n_over, (u64)mine);
+}
+// The table is zeroed first; the overflow table's values are pre-set to YH_DIR_NONE (empty).
+__global__ void k_cbkt_build(const u64* __restrict__ dh, const u32* __restrict__ dref, u64 D, u32 lsh, u64 nb,
+                             u32* __restrict__ bkt, u64* __restrict__ ovf_keys, u32* __restrict__ ovf_vals, u32 ovf_mask) {
+    for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < D; i += (u64)gridDim.x * blockDim.x) {
+        const u64 h = dh[i];
+        const u64 b = yh_bucket_of(h, lsh, nb);
+        const u32 r = bucket_rank(dh, i, b, lsh, nb);
+        u32* w = bkt + 16 * b;
+        if (r < 7) {
+            w[r] = (u32)h;
+            w[8 + r] = dref[i];
+        } else {  // claim an empty slot (all keys are distinct: nothing to compare), then publish the key
+            for (u32 s = (u32)yh_ovf_slot(h) & ovf_mask;; s = (s + 1) & ovf_mask)
+                if (atomicCAS(&ovf_vals[s], YH_DIR_NONE, dref[i]) == YH_DIR_NONE) {
+                    ovf_keys[s] = h;
+                    break;
+                }
+        }
+        if (i + 1 == D || yh_bucket_of(dh[i + 1], lsh, nb) != b) w[7] = (r + 1 > 7) ? (7u | YH_CBKT_OVERFLOW) : r + 1;
+    }
+}
+
 // 32-bit keys of a hash array: inside one hash-range partition the bits above pshift are constant,
 // so (u32)(h >> kshift) orders and (almost always) identifies the hashes of a partition.
 __global__ void k_make_keys(const u64* __restrict__ v, u64 n, u32 kshift, u32* __restrict__ keys) {
@@ -638,6 +673,8 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, const u
         YH_TRY(yh_dmalloc(db, (void**)&db->d_po, sizeof(u64)));
         YH_HIP(hipMemsetAsync(db->d_po, 0, sizeof(u64), st));
         db->has_index = !(db->flags & YH_DB_NO_INDEX);
+        // (an empty database answers the sample-driven queries too: nothing is ever found)
+        db->has_dir = db->has_index && !d_pair_ids && !(db->flags & (YH_DB_NO_DIRECTORY | YH_DB_PAIRWISE_ONLY));
         return YH_OK;
     }
     if (H > 0xfffffff0ull * 2) {
@@ -715,38 +752,95 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, const u
     if (rc == YH_OK) rc = yh_dmalloc(db, (void**)&db->d_pq_count, EXCL_QBLOCKS * sizeof(u32));
     if (rc == YH_OK) {
         IDX_HIP(hipMemsetAsync(db->d_g, 0, std::max<u64>(db->n_shared, 2) * sizeof(u64), st));
-        const bool full = (db->flags & YH_DB_FULL_INDEX) != 0;
+        // The bucket table over the distinct hashes (sample-driven lookups) is part of every handle that
+        // answers sample queries, unless YH_DB_NO_DIRECTORY / YH_NO_DIRECTORY=1 opts out.
+        static const bool dir_env_off = [] { const char* e = getenv("YH_NO_DIRECTORY"); return e && e[0] == '1'; }();
+        const bool full = !d_pair_ids && !(db->flags & (YH_DB_NO_DIRECTORY | YH_DB_PAIRWISE_ONLY)) && !dir_env_off && db->n_distinct > 0;
+        unsigned bits = 1;
+        while (bits < 64 && (db->max_hash >> bits) != 0) ++bits;
+        // compact form: ~2.5 distinct hashes per bucket, and a bucket must span less than 2^32 hash values
+        const u64 nb_c = std::max<u64>((db->n_distinct * 2 + 4) / 5, 1);
+        // bucket(h) = floor(h * mul / 2^bits) with mul = floor(nb * 2^bits / (max_hash + 1)): monotone, and the
+        // hashes [0, max_hash] cover ALL nb buckets (with mul = nb a database whose largest hash is just above a
+        // power of two would use half the table at twice the load)
+        auto mul_for = [&](u64 nbk) -> u64 {
+            const unsigned __int128 num = (unsigned __int128)nbk << bits;
+            const unsigned __int128 m = num / ((unsigned __int128)db->max_hash + 1);
+            return (u64)std::min<unsigned __int128>(m, ~(u64)0);
+        };
+        const u64 mul_c = mul_for(nb_c);
+        static const bool wide_env = [] { const char* e = getenv("YH_WIDE_BUCKETS"); return e && e[0] == '1'; }();
+        // a bucket spans ceil(2^bits / mul) hash values: the low 32 bits identify a hash inside it iff that is <= 2^32
+        const bool compact = full && !wide_env && db->n_distinct <= 0x7ffffff0ull && mul_c > 0 &&
+                             (bits <= 32 || (((unsigned __int128)1 << bits) + mul_c - 1) / mul_c <= ((unsigned __int128)1 << 32));
+        u64* d_dh_tmp = nullptr;   // compact: dh / dref are build-time temporaries
+        u32* d_dref_tmp = nullptr;
         if (full) {
             if (db->n_distinct > 0x7ffffff0ull) { yh_set_error("more than 2^31 distinct hashes"); rc = YH_ERR_UNSUPPORTED; }
-            // ~4 distinct hashes per directory bucket
-            u32 lg = 4;
-            while (lg < 30 && (4ull << lg) < db->n_distinct) ++lg;
-            unsigned bits = 1;
-            while (bits < 64 && (db->max_hash >> bits) != 0) ++bits;
-            db->dir_shift = bits > lg ? bits - lg : 0;
-            db->dir_nb = (u32)((db->max_hash >> db->dir_shift) + 1);
-            if (rc == YH_OK) rc = yh_dmalloc(db, (void**)&db->d_dh, std::max<u64>(db->n_distinct, 2) * sizeof(u64));
-            if (rc == YH_OK) rc = yh_dmalloc(db, (void**)&db->d_dref, std::max<u64>(db->n_distinct, 2) * sizeof(u32));
-            if (rc == YH_OK) rc = yh_dmalloc(db, (void**)&db->d_dir, ((u64)db->dir_nb + 2) * sizeof(u32));
-            const char* nob = getenv("YH_NO_BUCKETS");
-            if (rc == YH_OK && db->n_distinct && !(nob && nob[0] == '1')) {
-                db->bkt_nb = (db->n_distinct + 1) / 2;
-                db->bkt_lsh = 64 - bits;
-                rc = yh_dmalloc(db, (void**)&db->d_bkt, db->bkt_nb * 64);
-                if (rc == YH_OK) IDX_HIP(hipMemsetAsync(db->d_bkt, 0, db->bkt_nb * 64, st));
+            db->bkt_lsh = 64 - bits;
+            if (compact) {
+                IDX_HIP(hipMalloc((void**)&d_dh_tmp, std::max<u64>(db->n_distinct, 2) * sizeof(u64)));
+                IDX_HIP(hipMalloc((void**)&d_dref_tmp, std::max<u64>(db->n_distinct, 2) * sizeof(u32)));
+            } else {
+                // ~4 distinct hashes per directory bucket
+                u32 lg = 4;
+                while (lg < 30 && (4ull << lg) < db->n_distinct) ++lg;
+                db->dir_shift = bits > lg ? bits - lg : 0;
+                db->dir_nb = (u32)((db->max_hash >> db->dir_shift) + 1);
+                if (rc == YH_OK) rc = yh_dmalloc(db, (void**)&db->d_dh, std::max<u64>(db->n_distinct, 2) * sizeof(u64));
+                if (rc == YH_OK) rc = yh_dmalloc(db, (void**)&db->d_dref, std::max<u64>(db->n_distinct, 2) * sizeof(u32));
+                if (rc == YH_OK) rc = yh_dmalloc(db, (void**)&db->d_dir, ((u64)db->dir_nb + 2) * sizeof(u32));
+                const char* nob = getenv("YH_NO_BUCKETS");
+                if (rc == YH_OK && !(nob && nob[0] == '1')) {
+                    db->bkt_nb = (db->n_distinct + 1) / 2;
+                    db->bkt_mul = std::max<u64>(mul_for(db->bkt_nb), 1);
+                    rc = yh_dmalloc(db, (void**)&db->d_bkt, db->bkt_nb * 64);
+                    if (rc == YH_OK) IDX_HIP(hipMemsetAsync(db->d_bkt, 0, db->bkt_nb * 64, st));
+                }
             }
         }
+        u64* const dh_out = !full ? nullptr : compact ? d_dh_tmp : db->d_dh;
+        u32* const dref_out = !full ? nullptr : compact ? d_dref_tmp : db->d_dref;
         if (rc == YH_OK)
             k_idx_emit<<<(u32)nb, IDX_THREADS, 0, st>>>(d_sk, d_sv, H, d_bases, db->d_g, db->d_po, db->d_pr, db->d_pg,
-                                                        db->d_nshared, full ? db->d_dh : nullptr,
-                                                        full ? db->d_dref : nullptr, d_elem_g);
+                                                        db->d_nshared, dh_out, dref_out, d_elem_g);
         if (rc == YH_OK && want_stream) rc = build_stream(db, d_sk, d_sv, d_elem_g, H);
-        if (rc == YH_OK && full)
+        if (rc == YH_OK && full && !compact)
             k_dir_build<<<grid_for(db->n_distinct, 256), 256, 0, st>>>(db->d_dh, db->n_distinct, db->dir_shift, db->dir_nb,
                                                                        db->d_dir);
-        if (rc == YH_OK && full && db->d_bkt)
+        if (rc == YH_OK && full && !compact && db->d_bkt)
             k_bkt_build<<<grid_for(db->n_distinct, 256), 256, 0, st>>>(db->d_dh, db->d_dref, db->n_distinct, db->bkt_lsh,
-                                                                       db->bkt_nb, reinterpret_cast<u32*>(db->d_bkt));
+                                                                       db->bkt_mul, reinterpret_cast<u32*>(db->d_bkt));
+        if (rc == YH_OK && compact) {
+            db->cbkt_nb = nb_c;
+            db->bkt_mul = mul_c;
+            u64 n_over = 0;
+            u64* d_cnt = reinterpret_cast<u64*>(d_counts);  // (free again: the per-block counts were consumed by k_idx_emit)
+            IDX_HIP(hipMemsetAsync(d_cnt, 0, sizeof(u64), st));
+            if (rc == YH_OK)
+                k_cbkt_count_overflow<<<grid_for(db->n_distinct, 256), 256, 0, st>>>(d_dh_tmp, db->n_distinct, db->bkt_lsh, mul_c, d_cnt);
+            IDX_HIP(hipMemcpyAsync(&n_over, d_cnt, sizeof(u64), hipMemcpyDeviceToHost, st));
+            IDX_HIP(hipStreamSynchronize(st));
+            u64 cap = 1024;
+            while (cap < 2 * n_over + 16) cap <<= 1;
+            if (cap > (1ull << 31)) { yh_set_error("overflow table too large"); rc = YH_ERR_UNSUPPORTED; }
+            db->ovf_mask = (u32)(cap - 1);
+            if (rc == YH_OK) rc = yh_dmalloc(db, (void**)&db->d_cbkt, nb_c * 64);
+            if (rc == YH_OK) rc = yh_dmalloc(db, (void**)&db->d_ovf_keys, cap * sizeof(u64));
+            if (rc == YH_OK) rc = yh_dmalloc(db, (void**)&db->d_ovf_vals, cap * sizeof(u32));
+            IDX_HIP(hipMemsetAsync(db->d_cbkt, 0, nb_c * 64, st));
+            IDX_HIP(hipMemsetAsync(db->d_ovf_keys, 0, cap * sizeof(u64), st));
+            IDX_HIP(hipMemsetAsync(db->d_ovf_vals, 0xff, cap * sizeof(u32), st));
+            if (rc == YH_OK)
+                k_cbkt_build<<<grid_for(db->n_distinct, 256), 256, 0, st>>>(d_dh_tmp, d_dref_tmp, db->n_distinct, db->bkt_lsh, mul_c,
+                                                                            reinterpret_cast<u32*>(db->d_cbkt), db->d_ovf_keys,
+                                                                            db->d_ovf_vals, db->ovf_mask);
+            IDX_HIP(hipGetLastError());
+            IDX_HIP(hipStreamSynchronize(st));
+        }
+        (void)hipFree(d_dh_tmp);
+        (void)hipFree(d_dref_tmp);
+        if (rc == YH_OK && full) db->has_dir = true;
         IDX_HIP(hipGetLastError());
         IDX_HIP(hipMemcpyAsync(db->d_po + db->n_shared, &db->n_postings, sizeof(u64), hipMemcpyHostToDevice, st));
         if (db->n_shared && db->d_pkeys && rc == YH_OK) {

@@ -2007,8 +2007,8 @@ int yh_q_run_fused(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap,
 // d_fused_excl / d_fused_match non-null: the whole run step in three launches (see yh_q_run_fused)
 int yh_q_overlap_indexed(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap, bool for_exclusive,
                          u32* d_fused_excl, u32* d_fused_match) {
-    if (!(db->flags & YH_DB_FULL_INDEX) || !db->has_index) {
-        yh_set_error("this handle was created without YH_DB_FULL_INDEX");
+    if (!db->has_dir || !db->has_index) {
+        yh_set_error("this handle has no directory of its distinct hashes (YH_DB_NO_DIRECTORY, or no index)");
         return YH_ERR_UNSUPPORTED;
     }
     hipStream_t st = db->stream;
@@ -2385,8 +2385,8 @@ __global__ void __launch_bounds__(256) k_batch_final(u32 n_samples, u64 n_refs, 
 
 int yh_q_run_batch(yh_db* db, const u64* d_samples, const u64* d_soff, u32 n_samples, u64 total_hashes,
                    u32* d_overlap, u32* d_excl, u32* d_match) {
-    if (!(db->flags & YH_DB_FULL_INDEX) || !db->has_index) {
-        yh_set_error("yh_run_batch needs a handle created with YH_DB_FULL_INDEX");
+    if (!db->has_dir || !db->has_index) {
+        yh_set_error("yh_run_batch needs the directory of the distinct hashes (handle created with YH_DB_NO_DIRECTORY?)");
         return YH_ERR_UNSUPPORTED;
     }
     if (n_samples < 1 || n_samples > 64) { yh_set_error("1..64 samples per batch"); return YH_ERR_INVALID_ARG; }

@@ -17,7 +17,8 @@ from typing import Optional, Sequence, Tuple
 import numpy as np
 
 from . import _lib
-from ._lib import (YH_DB_DEFAULT, YH_DB_FULL_INDEX, YH_DB_KEEP_CSR, YH_DB_NO_INDEX, YH_DB_PAIRWISE_ONLY,  # noqa: F401
+from ._lib import (YH_DB_DEFAULT, YH_DB_FULL_INDEX, YH_DB_KEEP_CSR, YH_DB_NO_DIRECTORY, YH_DB_NO_INDEX,  # noqa: F401
+                   YH_DB_PAIRWISE_ONLY,
                    YachtHipError)
 
 
@@ -151,6 +152,16 @@ class RefDB:
 
     def set_stream(self, hip_stream: int) -> None:
         _lib.check(self._lib.yh_db_set_stream(self._h, C.c_void_p(hip_stream)))
+
+    def set_lookup(self, mode: int) -> None:
+        """_lib.YH_LOOKUP_AUTO (default: by cost), YH_LOOKUP_STREAM or YH_LOOKUP_INDEXED for overlap / run queries."""
+        _lib.check(self._lib.yh_db_set_lookup(self._h, mode))
+
+    def lookup_choice(self, n_sample: int) -> int:
+        rc = self._lib.yh_db_lookup_choice(self._h, n_sample)
+        if rc < 0:
+            _lib.check(rc)
+        return rc
 
     def synchronize(self) -> None:
         _lib.check(self._lib.yh_db_synchronize(self._h))
