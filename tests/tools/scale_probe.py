@@ -34,18 +34,18 @@ def host_free_gib() -> float:
     return 0.0
 
 
-def main() -> int:
+def main(argv=None) -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--refs", type=int, default=56_000)
     ap.add_argument("--median", type=float, default=33_000.0)
     ap.add_argument("--sample", type=int, default=10_000_000)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--oracle", choices=("auto", "yes", "no"), default="auto")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
 
     import torch
 
-    from yacht_amd import synth
+    from yacht_amd import _lib, synth
     from yacht_amd.engine import RefDB
 
     dev = torch.device("cuda:0")
@@ -73,6 +73,7 @@ def main() -> int:
     torch.cuda.synchronize()
     t_gen = time.perf_counter() - t0
     n, H = args.refs, int(vals.numel())
+    torch.cuda.empty_cache()  # the generator's sort buffers go back to the driver: the library allocates with hipMalloc
     t0 = time.perf_counter()
     db = RefDB.from_device(vals.data_ptr(), offsets.data_ptr(), n, flags=2)  # YH_DB_KEEP_CSR
     t_build = time.perf_counter() - t0
@@ -86,6 +87,20 @@ def main() -> int:
     def step():
         db.run_device(sample.data_ptr(), sample.numel(), out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr())
 
+    default_choice = db.lookup_choice(int(sample.numel()))
+    # the sample-driven lookup first (one bucket read per sample hash), then the streaming kernel: same counts
+    db.set_lookup(_lib.YH_LOOKUP_INDEXED)
+    step()
+    stream.synchronize()
+    db.timing()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    stream.synchronize()
+    ms_step_indexed = (time.perf_counter() - t0) / args.steps * 1e3
+    tm_idx = db.timing()
+    out_indexed = out.clone()
+    db.set_lookup(_lib.YH_LOOKUP_STREAM)
     step()
     stream.synchronize()
     db.timing()
@@ -95,6 +110,8 @@ def main() -> int:
     stream.synchronize()
     ms_step = (time.perf_counter() - t0) / args.steps * 1e3
     tm = db.timing()
+    same_paths = bool(torch.equal(out, out_indexed))
+    db.set_lookup(_lib.YH_LOOKUP_AUTO)
 
     db.overlap_bsearch_device(sample.data_ptr(), sample.numel(), chk.data_ptr())
     stream.synchronize()
@@ -129,6 +146,9 @@ def main() -> int:
         "stream_layout": info.get("stream_layout"), "stream_bytes": info.get("stream_bytes"), "db_hbm_bytes": info["device_bytes"],
         "seconds": {"generate": round(t_gen, 2), "build": round(t_build, 3)},
         "ms_per_step": round(ms_step, 3), "queries_per_s": round(n / (ms_step / 1e3), 1),
+        "ms_per_step_indexed": round(ms_step_indexed, 3), "index_lookup_ms": round(float(tm_idx["ms_overlap_kernel"]), 4),
+        "default_lookup": "indexed" if default_choice == _lib.YH_LOOKUP_INDEXED else "stream",
+        "indexed_equals_stream": same_paths,
         "k1_ms": round(k_ms, 4), "k1_GBps": round(key_bytes / 1e9 / (k_ms / 1e3), 1) if k_ms else None,
         "overlap_equals_bsearch_kernel": same_bsearch,
         "overlap_sum_equals_torch_count": same_total,
@@ -137,7 +157,7 @@ def main() -> int:
     }
     print(json.dumps(res), flush=True)
     db.close()
-    return 0 if (same_bsearch and same_total and oracle_ok in (None, True)) else 1
+    return 0 if (same_bsearch and same_total and same_paths and oracle_ok in (None, True)) else 1
 
 
 if __name__ == "__main__":

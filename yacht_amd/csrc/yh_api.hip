@@ -420,10 +420,10 @@ int yh_db_get_timing(yh_db* db, yh_timing* t) {
 
 // ---- which lookup answers a sample query ---------------------------------------------------------------
 // Both are exact.  The streaming kernel reads every reference hash (one delta byte each): its time is
-// ~12 us + 0.22 ns per reference hash whatever the sample.  The sample-driven kernel reads one 64-byte
-// bucket per SAMPLE hash: ~8 us + 30-45 ns per 1 000 sample hashes + its hits.  (Measured on MI355X at
-// 3.3e8 reference hashes: 85 us against 50-60 us for a 1e6-hash sample, 8 us for an 8e4-hash one;
-// DESIGN.md 3.)  YH_LOOKUP=stream|indexed in the environment, or yh_db_set_lookup, force one.
+// ~12 us + 0.24 ns per reference hash whatever the sample.  The sample-driven kernel reads one 64-byte
+// bucket per SAMPLE hash: ~8 us + 31-39 ns per 1 000 sample hashes, hits included.  (Measured on MI355X:
+// 3.3e8 reference hashes, 1e6-hash sample: 86 against 39 us; 8.3e4-hash sample: 82 against 16 us;
+// 2.2e9 reference hashes, 1e7-hash sample: 539 against ~300 us)  YH_LOOKUP=stream|indexed in the environment, or yh_db_set_lookup, force one.
 static bool prefer_indexed(const yh_db* db, u64 n_sample) {
     if (!db->has_dir || !db->has_index || n_sample == 0) return false;
     if (db->lookup_mode == YH_LOOKUP_STREAM) return false;
@@ -434,8 +434,8 @@ static bool prefer_indexed(const yh_db* db, u64 n_sample) {
     }();
     if (env) return env == 2;
     if (!db->d_sdelta) return true;
-    const double t_stream = 12.0 + 0.22e-3 * (double)db->n_hashes;
-    const double t_index = 8.0 + 0.060e-3 * (double)n_sample;  // (with a margin for hit-dense samples)
+    const double t_stream = 12.0 + 0.24e-3 * (double)db->n_hashes;
+    const double t_index = 8.0 + 0.045e-3 * (double)n_sample;  // (with a margin for hit-dense samples)
     return t_index < t_stream;
 }
 

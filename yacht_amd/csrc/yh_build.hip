@@ -713,6 +713,10 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, const u
         IDX_HIP(hipMalloc(&d_tmp, std::max<size_t>(tmp_bytes, 16)));
         IDX_HIP(rocprim::radix_sort_pairs(d_tmp, tmp_bytes, (const u64*)d_values, d_sk, ids_src, d_sv,
                                           (size_t)H, 0u, end_bit, st));
+        // (the sort's buffers are the build's largest temporaries: back to the pool before the next ones come)
+        IDX_HIP(hipStreamSynchronize(st));
+        (void)hipFree(d_tmp); d_tmp = nullptr;
+        (void)hipFree(d_ids); d_ids = nullptr;
     }
     const bool want_stream = !d_pair_ids && yh_use_delta_stream() && !(db->flags & YH_DB_PAIRWISE_ONLY);
     if (rc == YH_OK && (db->flags & YH_DB_NO_INDEX)) {  // overlap-only handle: the stream and nothing else
@@ -771,12 +775,15 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, const u
         const u64 mul_c = mul_for(nb_c);
         static const bool wide_env = [] { const char* e = getenv("YH_WIDE_BUCKETS"); return e && e[0] == '1'; }();
         // a bucket spans ceil(2^bits / mul) hash values: the low 32 bits identify a hash inside it iff that is <= 2^32
-        const bool compact = full && !wide_env && db->n_distinct <= 0x7ffffff0ull && mul_c > 0 &&
+        const bool compact = full && !wide_env && nb_c <= 0xfffffff0ull && mul_c > 0 &&
                              (bits <= 32 || (((unsigned __int128)1 << bits) + mul_c - 1) / mul_c <= ((unsigned __int128)1 << 32));
         u64* d_dh_tmp = nullptr;   // compact: dh / dref are build-time temporaries
         u32* d_dref_tmp = nullptr;
+        if (full && !compact && db->n_distinct > 0x7ffffff0ull) {  // (the five-entry form indexes the distinct hashes with 32 bits)
+            yh_set_error("more than 2^31 distinct hashes in a database too wide for compact buckets");
+            rc = YH_ERR_UNSUPPORTED;
+        }
         if (full) {
-            if (db->n_distinct > 0x7ffffff0ull) { yh_set_error("more than 2^31 distinct hashes"); rc = YH_ERR_UNSUPPORTED; }
             db->bkt_lsh = 64 - bits;
             if (compact) {
                 IDX_HIP(hipMalloc((void**)&d_dh_tmp, std::max<u64>(db->n_distinct, 2) * sizeof(u64)));
@@ -804,7 +811,6 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, const u
         if (rc == YH_OK)
             k_idx_emit<<<(u32)nb, IDX_THREADS, 0, st>>>(d_sk, d_sv, H, d_bases, db->d_g, db->d_po, db->d_pr, db->d_pg,
                                                         db->d_nshared, dh_out, dref_out, d_elem_g);
-        if (rc == YH_OK && want_stream) rc = build_stream(db, d_sk, d_sv, d_elem_g, H);
         if (rc == YH_OK && full && !compact)
             k_dir_build<<<grid_for(db->n_distinct, 256), 256, 0, st>>>(db->d_dh, db->n_distinct, db->dir_shift, db->dir_nb,
                                                                        db->d_dir);
@@ -838,9 +844,13 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, const u
             IDX_HIP(hipGetLastError());
             IDX_HIP(hipStreamSynchronize(st));
         }
+        IDX_HIP(hipStreamSynchronize(st));
         (void)hipFree(d_dh_tmp);
         (void)hipFree(d_dref_tmp);
         if (rc == YH_OK && full) db->has_dir = true;
+        if (rc == YH_OK && want_stream) rc = build_stream(db, d_sk, d_sv, d_elem_g, H);  // (behind the table: its temporaries are gone)
+        (void)hipFree(d_elem_g);
+        d_elem_g = nullptr;
         IDX_HIP(hipGetLastError());
         IDX_HIP(hipMemcpyAsync(db->d_po + db->n_shared, &db->n_postings, sizeof(u64), hipMemcpyHostToDevice, st));
         if (db->n_shared && db->d_pkeys && rc == YH_OK) {

@@ -53,6 +53,29 @@ __device__ __forceinline__ u32 xcd_remap(u32 bid, u32 nwg) {
     return base + (bid >> 3);
 }
 
+// XCD-local counting (YH_XCD_ATOMICS, experiment): replica = the XCD the wave runs on, adds at WORKGROUP scope.
+// A device-scope atomic bypasses the XCD's L2 (the eight L2s are not coherent with each other) and is
+// executed at the memory side; an add that only waves of ONE XCD ever make to its address can stay in that
+// XCD's L2 -- the kernel boundary writes the lines back before k_reduce_replicas sums the replicas.
+#ifndef YH_XCD_ATOMICS
+#define YH_XCD_ATOMICS 0
+#endif
+__device__ __forceinline__ u32 xcc_id() { return (u32)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u; }  // HW_REG_XCC_ID[3:0]
+__device__ __forceinline__ void count_add(u32* p, u32 v) {
+#if YH_XCD_ATOMICS
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+    atomicAdd(p, v);
+#endif
+}
+__device__ __forceinline__ u32 replica_of(u32 wg, u32 rep_mask) {
+#if YH_XCD_ATOMICS
+    return xcc_id() & rep_mask;
+#else
+    return wg & rep_mask;
+#endif
+}
+
 // ---- hit handlers -------------------------------------------------------------------------------
 // A hit is reported as (partition, position relative to the partition's first element).
 // Resolving a position to its reference is a 17-step dependent search through L2 (~3 us) during
@@ -986,9 +1009,9 @@ __device__ __forceinline__ void table_add(const StreamHit& hit, const WaveQ& c, 
             return;
         }
     }
-    const u64 at = (u64)(c.wg & hit.rep_mask) * hit.n_refs + ref;  // crowded table: count directly
-    atomicAdd(&hit.reps[at], 1u);
-    if (shared && hit.reps2) atomicAdd(&hit.reps2[at], 1u);
+    const u64 at = (u64)replica_of(c.wg, hit.rep_mask) * hit.n_refs + ref;  // crowded table: count directly
+    count_add(&hit.reps[at], 1u);
+    if (shared && hit.reps2) count_add(&hit.reps2[at], 1u);
 }
 struct Pending {  // one requested confirmation per lane
     uint4 rec = make_uint4(0u, 0u, STREAM_NONE, STREAM_NONE);
@@ -1354,11 +1377,11 @@ k_stream_lookup(const u32x4* __restrict__ deltas, const u64* __restrict__ hdr, u
     wave_flush(hit, ctx, pend);
     pending_count(hit, ctx, pend);  // the last batch: the one wait for confirmation reads the wave cannot hide
     __syncthreads();
-    const u64 my = (u64)(lid & hit.rep_mask) * hit.n_refs;
+    const u64 my = (u64)replica_of(lid, hit.rep_mask) * hit.n_refs;
     for (u32 k = tid; k < STREAM_TSLOTS; k += STREAM_THREADS)
         if (tkey[k]) {
-            atomicAdd(&hit.reps[my + tkey[k] - 1], tcnt[k]);
-            if (hit.reps2 && tcnt2[k]) atomicAdd(&hit.reps2[my + tkey[k] - 1], tcnt2[k]);
+            count_add(&hit.reps[my + tkey[k] - 1], tcnt[k]);
+            if (hit.reps2 && tcnt2[k]) count_add(&hit.reps2[my + tkey[k] - 1], tcnt2[k]);
         }
 }
 
@@ -1403,20 +1426,20 @@ __global__ void __launch_bounds__(256) k_index_lookup(const u64* __restrict__ sa
                                                       u32* __restrict__ work_count, const u32* __restrict__ bad, u32 bad_gen) {
     if (work_count && blockIdx.x == 0 && threadIdx.x == 0) *work_count = 0;  // (for the kernels behind: see StreamHit)
     if (bad && *bad == bad_gen) return;
-    u32* my = reps + (u64)(blockIdx.x & rep_mask) * n_refs;
-    u32* my2 = reps2 ? reps2 + (u64)(blockIdx.x & rep_mask) * n_refs : nullptr;  // hits on shared hashes (fused run)
+    u32* my = reps + (u64)replica_of(blockIdx.x, rep_mask) * n_refs;
+    u32* my2 = reps2 ? reps2 + (u64)replica_of(blockIdx.x, rep_mask) * n_refs : nullptr;  // hits on shared hashes (fused run)
     for (u64 t = blockIdx.x * (u64)blockDim.x + threadIdx.x; t < n; t += (u64)gridDim.x * blockDim.x) {
         const u32 r = dv.find(sample[t]);
         if (r == YH_DIR_NONE) continue;
         if (!(r & 0x80000000u)) {
-            atomicAdd(&my[r], 1u);
+            count_add(&my[r], 1u);
         } else {
             const u32 gi = r & 0x7fffffffu;
             if (hit) hit[gi] = 1;
             for (u64 q = po[gi], qe = po[gi + 1]; q < qe; ++q) {
                 const u32 h = pr[q];
-                atomicAdd(&my[h], 1u);
-                if (my2) atomicAdd(&my2[h], 1u);
+                count_add(&my[h], 1u);
+                if (my2) count_add(&my2[h], 1u);
             }
         }
     }
@@ -1868,7 +1891,7 @@ static int yh_q_overlap_stream(yh_db* db, const u64* d_sample, u64 n_sample, u32
     u32 R;
     YH_TRY(ensure_reps(db, R));
     // hits leave a workgroup pre-summed (one atomic per workgroup and reference), so few replicas do
-    static const u32 r_env = [] { const char* e = getenv("YH_STREAM_REPS"); return e ? (u32)atoi(e) : 4u; }();
+    static const u32 r_env = [] { const char* e = getenv("YH_STREAM_REPS"); return e ? (u32)atoi(e) : (YH_XCD_ATOMICS ? 8u : 4u); }();
     while (R > 1 && R > r_env) R >>= 1;
     const bool fused = d_fused_excl != nullptr;
     const bool flags_too = flag_shared && db->has_index && !fused;
@@ -2016,6 +2039,10 @@ int yh_q_overlap_indexed(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_ov
     if (N == 0) return YH_OK;
     u32 R;
     YH_TRY(ensure_reps(db, R));
+    // (k_reduce_replicas reads every replica of both sets: 16 -> 8 replicas took 4 us off the step, with no
+    // measurable change of the lookup kernel at 1.3e5 hits per sample)
+    static const u32 ri_env = [] { const char* e = getenv("YH_INDEX_REPS"); return e ? (u32)atoi(e) : 8u; }();
+    while (R > 1 && R > ri_env) R >>= 1;
     static const bool fused_off = [] { const char* e = getenv("YH_NO_FUSED_RUN"); return e && e[0] == '1'; }();
     const bool fused = d_fused_excl && for_exclusive && db->d_work && db->d_rrec && db->d_rrecx && !fused_off;
     if (for_exclusive && db->n_shared && !fused) YH_TRY(claim_hit_flags(db));
