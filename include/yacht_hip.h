@@ -270,13 +270,16 @@ int yh_train_select(const uint32_t* sizes, uint64_t n_refs,
 /* ---- ingest: the sketches of many .sig files (in front of yh_db_create) ------------------------------
  * What the reference's train core does before anything else (src/cpp/main.cpp:62-124,
  * read_min_hashes / read_sketches_one_chunk / read_sketches): every path is a sourmash JSON file,
- * of which record 0, signature 0, "mins" is taken (ksize is not checked there either); a file
- * that cannot be opened or parsed is an EMPTY sketch.  Read and parsed by `threads` host threads.
+ * of which record 0, signature 0, "mins" is taken (ksize is not checked there either).  A file that
+ * cannot be opened is an EMPTY sketch with status 1 (the reference prints "Could not open the file!" and
+ * goes on); a file that does not parse is empty with status 2 -- the reference's process dies there, so
+ * callers must fail (yh_sig_batch_status: one byte per path).  Read and parsed by `threads` host threads.
  * Two-step hand-over into caller-owned arrays: sizes first (offsets[n_paths + 1], offsets[0] = 0),
  * then values[offsets[n_paths]] -- exactly the CSR yh_db_create takes.  Mins come out ascending and
  * unique (sourmash writes them so; other writers are sorted and de-duplicated).                    */
 typedef struct yh_sig_batch yh_sig_batch;
 int yh_sig_batch_read(const char* const* paths, uint64_t n_paths, int threads, yh_sig_batch** out);
+int yh_sig_batch_status(const yh_sig_batch* batch, uint8_t* status);
 int yh_sig_batch_sizes(const yh_sig_batch* batch, uint64_t* offsets);
 int yh_sig_batch_values(const yh_sig_batch* batch, uint64_t* values);
 int yh_sig_batch_destroy(yh_sig_batch* batch);

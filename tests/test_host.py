@@ -177,7 +177,7 @@ def test_cli_parsers_and_error_paths(tmp_path):
 
 def test_sig_batch_reader_matches_the_python_reader(tmp_path):
     """yh_sig_batch_* (host threads, no GPU needed): record 0 / signature 0 / "mins" of every file, an
-    unreadable or malformed file is an empty sketch, unsorted writers are sorted and de-duplicated --
+    unreadable file is an empty sketch, unsorted writers are sorted and de-duplicated --
     the same sketches as the json-module reader."""
     import json
 
@@ -197,8 +197,6 @@ def test_sig_batch_reader_matches_the_python_reader(tmp_path):
     (tmp_path / "unsorted.sig").write_text('[{"signatures":[{"mins":[5, 3, 3, 9]}]}]')
     paths.append(str(tmp_path / "unsorted.sig"))
     want.append(np.array([3, 5, 9], dtype=np.uint64))
-    (tmp_path / "broken.sig").write_text('[{"signatures":[{"mins":[1, 2,')
-    paths.append(str(tmp_path / "broken.sig"))
     paths.append(str(tmp_path / "missing.sig"))
     values, offsets = train_core.read_sketches_csr(paths, threads=3)
     assert offsets.size == len(paths) + 1 and int(offsets[-1]) == values.size
@@ -207,3 +205,28 @@ def test_sig_batch_reader_matches_the_python_reader(tmp_path):
     py = train_core.read_sketches(paths[:len(want) - 1], 1)
     assert all(np.array_equal(a, b) for a, b in zip(py, want))
     assert int(offsets[-1]) - int(offsets[-2]) == 0  # missing file: empty sketch
+
+
+def test_batch_reader_reports_missing_and_malformed_files(tmp_path, capfd):
+    """The reference's train core goes on with an empty sketch (and a message) when a file cannot be opened
+    and dies when one does not parse (src/cpp/main.cpp:62-84); the threaded reader says which is which."""
+    from yacht_amd import sigio, train_core
+
+    good = tmp_path / "good.sig"
+    sigio.write_sig(sigio.make_signature(np.array([5, 9, 11], np.uint64), name="g"), str(good))
+    missing = tmp_path / "missing.sig"
+    values, offsets = train_core.read_sketches_csr([str(good), str(missing), str(good)], threads=2)
+    assert offsets.tolist() == [0, 3, 3, 6] and values.tolist() == [5, 9, 11, 5, 9, 11]
+    assert "Could not open the file!" in capfd.readouterr().err
+    bad = tmp_path / "bad.sig"
+    bad.write_text('[{"signatures": [{"mins": [1, 2, oops]}]}]')
+    with pytest.raises(ValueError, match="could not be parsed"):
+        train_core.read_sketches_csr([str(good), str(bad)], threads=1)
+    cut = tmp_path / "cut.sig"
+    cut.write_text('[{"signatures":[{"mins":[1, 2')
+    with pytest.raises(ValueError, match="could not be parsed"):
+        train_core.read_sketches_csr([str(cut)], threads=1)
+    nokey = tmp_path / "nokey.sig"
+    nokey.write_text('[{"signatures": [{"ksize": 31}]}]')
+    with pytest.raises(ValueError, match="could not be parsed"):
+        train_core.read_sketches_csr([str(nokey)], threads=1)

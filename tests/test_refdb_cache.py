@@ -26,6 +26,35 @@ def test_cache_roundtrip_and_keying(tmp_path):
     assert sv.tolist() == [3, 4, 5, 6, 7, 8, 9, 0, 1, 2] and so.tolist() == [0, 7, 10]
 
 
+def test_cache_rewrite_is_atomic_for_readers(tmp_path):
+    """A reader that mapped one generation keeps a complete copy of it while another process rewrites the
+    cache (many `yacht run` processes share one training directory); a truncated array or a
+    meta that does not match its arrays is refused, never half-read."""
+    md5s = ["a", "b"]
+    v1, o1 = np.arange(6, dtype=np.uint64), np.array([0, 2, 6], dtype=np.uint64)
+    assert refdb_cache.save(str(tmp_path), md5s, 31, v1, o1)
+    got_v, got_o = refdb_cache.load(str(tmp_path), md5s, 31)
+    v2, o2 = np.arange(100, 108, dtype=np.uint64), np.array([0, 5, 8], dtype=np.uint64)
+    assert refdb_cache.save(str(tmp_path), md5s, 31, v2, o2)      # second generation replaces the first
+    assert np.array_equal(got_v, v1) and np.array_equal(got_o, o1)  # the mapped first generation is still whole
+    new_v, new_o = refdb_cache.load(str(tmp_path), md5s, 31)
+    assert np.array_equal(new_v, v2) and np.array_equal(new_o, o2)
+    d = tmp_path / refdb_cache.DIR_NAME
+    files = sorted(os.listdir(d))
+    assert len(files) == 3 and not any(f.endswith(".part") for f in files), files  # old generation cleaned up
+    meta = json.load(open(d / "meta.json"))
+    # a values file cut short: refused
+    p = d / meta["files"]["values"]
+    raw = open(p, "rb").read()
+    open(p, "wb").write(raw[:-16])
+    assert refdb_cache.load(str(tmp_path), md5s, 31) is None
+    open(p, "wb").write(raw)
+    assert refdb_cache.load(str(tmp_path), md5s, 31) is not None
+    # offsets from another generation under this meta: refused by the digest
+    np.save(d / meta["files"]["offsets"], np.array([0, 4, 8], dtype=np.uint64))
+    assert refdb_cache.load(str(tmp_path), md5s, 31) is None
+
+
 @pytest.mark.gpu
 def test_run_uses_the_packed_db_not_the_sig_files(hip_lib, tmp_path):
     """After `yacht train`, `yacht run` works with the signature JSON files gone: it reads the
@@ -45,7 +74,7 @@ def test_run_uses_the_packed_db_not_the_sig_files(hip_lib, tmp_path):
     meta = json.load(open(work / refdb_cache.DIR_NAME / "meta.json"))
     man = pd.read_csv(out / "db_processed_manifest.tsv", sep="\t")
     assert meta["md5sums"] == man["md5sum"].to_list() and meta["ksize"] == 31
-    offsets = np.load(work / refdb_cache.DIR_NAME / "offsets.npy")
+    offsets = np.load(work / refdb_cache.DIR_NAME / meta["files"]["offsets"])
     assert np.diff(offsets).tolist() == man["num_unique_kmers_in_genome_sketch"].to_list()
     for f in glob.glob(str(work / "signatures" / "*.sig")):
         os.remove(f)

@@ -18,6 +18,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <fstream>
@@ -135,14 +136,25 @@ int main(int argc, char** argv) {
     const uint64_t n = names.size();
     std::cout << "Total number of sketches to read: " << n << std::endl;
     std::vector<std::vector<uint64_t>> sketches(n);
+    std::atomic<uint64_t> malformed{0};
     {
         std::vector<std::thread> pool;
         const uint64_t chunk = n / (uint64_t)a.threads;
         for (int t = 0; t < a.threads; ++t) {
             const uint64_t b = (uint64_t)t * chunk, e = (t == a.threads - 1) ? n : (uint64_t)(t + 1) * chunk;
-            pool.emplace_back([&, b, e] { for (uint64_t i = b; i < e; ++i) sketches[i] = read_mins(names[i]); });
+            pool.emplace_back([&, b, e] {
+                for (uint64_t i = b; i < e; ++i) {
+                    int st = 0;
+                    sketches[i] = read_mins(names[i], true, &st);
+                    if (st == yh_sig::READ_MALFORMED) malformed.fetch_add(1);
+                }
+            });
         }
         for (auto& th : pool) th.join();
+    }
+    if (malformed.load()) {  // the reference's json::parse throws here and the process dies (main.cpp:73)
+        std::cerr << "Error: " << malformed.load() << " signature file(s) could not be parsed" << std::endl;
+        return 1;
     }
     std::cout << "All sketches read" << std::endl;
     std::vector<uint64_t> offsets(n + 1, 0);

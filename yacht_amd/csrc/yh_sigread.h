@@ -67,11 +67,17 @@ struct Scanner {
     }
 };
 
-inline std::vector<uint64_t> read_mins(const std::string& path, bool report = true) {
+// status (optional): READ_OK, READ_CANNOT_OPEN (the reference prints "Could not open the file!" and goes on with an
+// empty sketch, main.cpp:66-71) or READ_MALFORMED (the reference's json::parse / operator[] throws and the program
+// dies, main.cpp:73-81: callers must treat it as fatal).
+enum { READ_OK = 0, READ_CANNOT_OPEN = 1, READ_MALFORMED = 2 };
+inline std::vector<uint64_t> read_mins(const std::string& path, bool report = true, int* status = nullptr) {
     std::vector<uint64_t> mins;
+    if (status) *status = READ_OK;
     FILE* f = fopen(path.c_str(), "rb");
     if (!f) {
         if (report) std::cerr << "Could not open the file!" << std::endl;
+        if (status) *status = READ_CANNOT_OPEN;
         return mins;
     }
     std::string text;
@@ -85,7 +91,10 @@ inline std::vector<uint64_t> read_mins(const std::string& path, bool report = tr
     for (char buf[1 << 16]; (got = fread(buf, 1, sizeof buf, f)) > 0;) text.append(buf, got);  // (unseekable input)
     fclose(f);
     Scanner s{text.data(), text.data() + text.size()};
-    if (!s.lit('[') || !s.find_key("signatures") || !s.lit('[') || !s.find_key("mins") || !s.lit('[')) return mins;
+    if (!s.lit('[') || !s.find_key("signatures") || !s.lit('[') || !s.find_key("mins") || !s.lit('[')) {
+        if (status) *status = READ_MALFORMED;
+        return mins;
+    }
     if (s.lit(']')) return mins;
     mins.reserve(4096);
     do {
@@ -93,10 +102,19 @@ inline std::vector<uint64_t> read_mins(const std::string& path, bool report = tr
         const char* q = s.p;
         uint64_t v = 0;
         while (q < s.e && *q >= '0' && *q <= '9') v = v * 10 + (uint64_t)(*q++ - '0');
-        if (q == s.p) { mins.clear(); return mins; }  // not a number: malformed, as unreadable
+        if (q == s.p) {  // not a number
+            mins.clear();
+            if (status) *status = READ_MALFORMED;
+            return mins;
+        }
         s.p = q;
         mins.push_back(v);
     } while (s.lit(','));
+    if (!s.lit(']')) {  // the array never closes: a truncated file
+        mins.clear();
+        if (status) *status = READ_MALFORMED;
+        return mins;
+    }
     bool ascending = true;
     for (size_t i = 1; i < mins.size() && ascending; ++i) ascending = mins[i - 1] < mins[i];
     if (!ascending) {  // sourmash writes ascending unique mins; tolerate other writers

@@ -11,6 +11,7 @@
 
 struct yh_sig_batch {
     std::vector<std::vector<uint64_t>> mins;
+    std::vector<uint8_t> status;  // yh_sig::READ_*
 };
 
 extern "C" {
@@ -21,13 +22,22 @@ int yh_sig_batch_read(const char* const* paths, uint64_t n_paths, int threads, y
     yh_sig_batch* b = new (std::nothrow) yh_sig_batch;
     if (!b) { yh_set_error("out of host memory"); return YH_ERR_OOM; }
     b->mins.resize(n_paths);
+    b->status.assign(n_paths, 0);
     std::atomic<uint64_t> next{0};
+    std::atomic<bool> oom{false};
     auto work = [&]() {
-        for (;;) {  // files vary in size: a shared cursor instead of the reference's fixed chunks
-            const uint64_t i = next.fetch_add(16);
-            if (i >= n_paths) break;
-            for (uint64_t k = i; k < std::min<uint64_t>(i + 16, n_paths); ++k)
-                b->mins[k] = yh_sig::read_mins(paths[k] ? paths[k] : "", false);
+        try {  // (an exception leaving a std::thread ends the host process)
+            for (;;) {  // files vary in size: a shared cursor instead of the reference's fixed chunks
+                const uint64_t i = next.fetch_add(16);
+                if (i >= n_paths || oom.load()) break;
+                for (uint64_t k = i; k < std::min<uint64_t>(i + 16, n_paths); ++k) {
+                    int st = 0;
+                    b->mins[k] = yh_sig::read_mins(paths[k] ? paths[k] : "", false, &st);
+                    b->status[k] = (uint8_t)st;
+                }
+            }
+        } catch (...) {
+            oom.store(true);
         }
     };
     const int nt = (int)std::min<uint64_t>((uint64_t)threads, std::max<uint64_t>(n_paths / 16, 1));
@@ -35,7 +45,18 @@ int yh_sig_batch_read(const char* const* paths, uint64_t n_paths, int threads, y
     for (int t = 1; t < nt; ++t) pool.emplace_back(work);
     work();
     for (auto& t : pool) t.join();
+    if (oom.load()) {
+        delete b;
+        yh_set_error("out of host memory while reading the signature files");
+        return YH_ERR_OOM;
+    }
     *out = b;
+    return YH_OK;
+}
+
+int yh_sig_batch_status(const yh_sig_batch* b, uint8_t* status) {
+    if (!b || (!status && !b->status.empty())) { yh_set_error("null argument"); return YH_ERR_INVALID_ARG; }
+    if (!b->status.empty()) memcpy(status, b->status.data(), b->status.size());
     return YH_OK;
 }
 

@@ -57,8 +57,14 @@ _DB_CACHE: Dict[Tuple[str, Tuple[str, ...]], RefDB] = {}
 _LAST_RUN: Dict[str, object] = {}
 
 
-def _read_mins(path: str) -> np.ndarray:
-    return sigio.read_mins_first_signature(path)
+def _read_mins(path_and_ksize) -> np.ndarray:
+    """The sketch `yacht run` uses for a reference: the ONE signature of the given k-mer size in the file
+    (reference: load_signature_with_ksize, utils.py:31-51 -- anything else is an error there too)."""
+    path, ksize = path_and_ksize
+    sigs = sigio.load_file_as_signatures(path, ksize=ksize)
+    if len(sigs) != 1:
+        raise ValueError(f"Expected exactly one signature with ksize {ksize} in {path}, found {len(sigs)}")
+    return np.asarray(sigs[0].minhash.mins, dtype=np.uint64)
 
 
 def load_reference_csr(md5sums: List[str], path_to_genome_temp_dir: str, ksize: int, num_threads: int = 1):
@@ -68,7 +74,7 @@ def load_reference_csr(md5sums: List[str], path_to_genome_temp_dir: str, ksize: 
     cached = refdb_cache.load(path_to_genome_temp_dir, md5sums, ksize)
     if cached is not None:
         return cached
-    paths = [os.path.join(path_to_genome_temp_dir, "signatures", m + SIG_SUFFIX) for m in md5sums]
+    paths = [(os.path.join(path_to_genome_temp_dir, "signatures", m + SIG_SUFFIX), ksize) for m in md5sums]
     if num_threads > 1 and len(paths) > 256:
         with Pool(min(num_threads, os.cpu_count() or 1)) as p:
             sketches = p.map(_read_mins, paths, chunksize=64)

@@ -3,9 +3,9 @@
 The reference re-opens every selected `.sig` (JSON) three times per `yacht run`
 (hypothesis_recovery_src.py:93,154,168).  `yacht train` here also leaves
 
-    {prefix}_intermediate_files/yacht_hip_db/values.npy    uint64[H]  all hashes, reference-major
-                                            offsets.npy   uint64[N+1]
-                                            meta.json     {"ksize", "md5sums": [...]}  (row order)
+    {prefix}_intermediate_files/yacht_hip_db/values-<token>.npy   uint64[H]  all hashes, reference-major
+                                            offsets-<token>.npy  uint64[N+1]
+                                            meta.json   {"ksize", "md5sums": [...] (row order), "files", sizes, digest}
 
 and `yacht run` memory-maps the two arrays and hands them straight to yh_db_create: no JSON
 parsing, and pages are only touched by the host-to-device copy.  The cache is keyed by the md5
@@ -14,8 +14,10 @@ rewrites the cache.
 """
 from __future__ import annotations
 
+import hashlib
 import json
 import os
+import secrets
 from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -27,29 +29,66 @@ def cache_dir(genome_dir: str) -> str:
     return os.path.join(genome_dir, DIR_NAME)
 
 
+def _offsets_digest(offsets: np.ndarray) -> str:
+    return hashlib.sha1(np.ascontiguousarray(offsets, dtype=np.uint64).tobytes()).hexdigest()
+
+
 def save(genome_dir: str, md5sums: Sequence[str], ksize: int, values: np.ndarray, offsets: np.ndarray) -> bool:
+    """Write the packed set so that a concurrent reader never sees a half-written one (many `yacht run`
+    processes against one training directory is the normal workflow): the two arrays go into files of their
+    own, named by a fresh token and complete before anything refers to them; meta.json -- written beside
+    and moved into place with os.replace -- names the token, the sizes and a digest of the offsets.  A
+    reader that opened the previous meta keeps reading the previous files (unlinked files stay readable)."""
     d = cache_dir(genome_dir)
+    token = f"{os.getpid():x}-{secrets.token_hex(6)}"
     try:
         os.makedirs(d, exist_ok=True)
-        np.save(os.path.join(d, "values.npy"), np.ascontiguousarray(values, dtype=np.uint64))
-        np.save(os.path.join(d, "offsets.npy"), np.ascontiguousarray(offsets, dtype=np.uint64))
-        with open(os.path.join(d, "meta.json"), "w") as f:
-            json.dump({"ksize": int(ksize), "md5sums": list(md5sums)}, f)
+        values = np.ascontiguousarray(values, dtype=np.uint64)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        names = {"values": f"values-{token}.npy", "offsets": f"offsets-{token}.npy"}
+        for key, arr in (("values", values), ("offsets", offsets)):
+            tmp = os.path.join(d, names[key] + ".part")
+            with open(tmp, "wb") as f:
+                np.save(f, arr)
+                f.flush()
+                os.fsync(f.fileno())
+            os.replace(tmp, os.path.join(d, names[key]))
+        meta = {"ksize": int(ksize), "md5sums": list(md5sums), "files": names, "n_refs": int(offsets.size - 1),
+                "n_hashes": int(values.size), "offsets_sha1": _offsets_digest(offsets)}
+        tmp = os.path.join(d, f"meta-{token}.json.part")
+        with open(tmp, "w") as f:
+            json.dump(meta, f)
+            f.flush()
+            os.fsync(f.fileno())
+        os.replace(tmp, os.path.join(d, "meta.json"))
+        for old in os.listdir(d):  # earlier generations (best effort; a reader that has them open keeps them)
+            if (old.startswith("values-") or old.startswith("offsets-") or old in ("values.npy", "offsets.npy")) \
+                    and old not in names.values() and not old.endswith(".part"):
+                try:
+                    os.remove(os.path.join(d, old))
+                except OSError:
+                    pass
         return True
     except OSError:
         return False  # read-only training directory: just do not cache
 
 
 def load(genome_dir: str, md5sums: Sequence[str], ksize: int) -> Optional[Tuple[np.ndarray, np.ndarray]]:
+    """(values, offsets) memory-mapped, or None when there is no packed set for exactly these references --
+    or when what is on disk does not agree with its own meta (sizes, digest of the offsets)."""
     d = cache_dir(genome_dir)
     try:
         with open(os.path.join(d, "meta.json")) as f:
             meta = json.load(f)
         if int(meta["ksize"]) != int(ksize) or list(meta["md5sums"]) != list(md5sums):
             return None
-        values = np.load(os.path.join(d, "values.npy"), mmap_mode="r")
-        offsets = np.load(os.path.join(d, "offsets.npy"), mmap_mode="r")
-        if offsets.size != len(md5sums) + 1 or int(offsets[-1]) != values.size:
+        files = meta.get("files") or {"values": "values.npy", "offsets": "offsets.npy"}
+        values = np.load(os.path.join(d, files["values"]), mmap_mode="r")
+        offsets = np.load(os.path.join(d, files["offsets"]), mmap_mode="r")
+        if offsets.size != len(md5sums) + 1 or int(offsets[-1]) != values.size or int(offsets[0]) != 0:
+            return None
+        if "n_hashes" in meta and (int(meta["n_hashes"]) != values.size or int(meta["n_refs"]) != offsets.size - 1
+                                   or meta.get("offsets_sha1") != _offsets_digest(np.asarray(offsets))):
             return None
         return values, offsets
     except (OSError, ValueError, KeyError):

@@ -19,6 +19,7 @@ from __future__ import annotations
 
 import math
 import os
+import sys
 from multiprocessing import Pool
 from typing import List, Sequence, Tuple
 
@@ -74,7 +75,9 @@ def read_sketches(paths: Sequence[str], threads: int = 1) -> List[np.ndarray]:
 
 def read_sketches_csr(paths: Sequence[str], threads: int = 1):
     """(values, offsets) of all files through the library's threaded reader (yh_sig_batch_*: the
-    counterpart of src/cpp/main.cpp:89-124); an unreadable file is an empty sketch there too."""
+    counterpart of src/cpp/main.cpp:89-124).  A file that cannot be opened is an empty sketch and the
+    reference's message is printed (main.cpp:66-71); a file that does not parse raises -- the reference's
+    process dies on it (json::parse throws, main.cpp:73) and its Python caller turns that into ValueError."""
     import ctypes as C
 
     from . import _lib
@@ -84,6 +87,13 @@ def read_sketches_csr(paths: Sequence[str], threads: int = 1):
     h = C.c_void_p()
     _lib.check(lib.yh_sig_batch_read(arr, len(paths), max(1, int(threads)), C.byref(h)))
     try:
+        status = np.zeros(max(len(paths), 1), dtype=np.uint8)
+        _lib.check(lib.yh_sig_batch_status(h, status.ctypes.data_as(C.c_void_p)))
+        for _ in np.flatnonzero(status[:len(paths)] == 1):
+            print("Could not open the file!", file=sys.stderr)
+        bad = np.flatnonzero(status[:len(paths)] == 2)
+        if bad.size:
+            raise ValueError(f"{bad.size} signature file(s) could not be parsed, first: {paths[int(bad[0])]}")
         offsets = np.zeros(len(paths) + 1, dtype=np.uint64)
         _lib.check(lib.yh_sig_batch_sizes(h, offsets.ctypes.data_as(C.c_void_p)))
         values = np.zeros(int(offsets[-1]), dtype=np.uint64)
