@@ -16,7 +16,7 @@ import shutil
 import zipfile
 from pathlib import Path
 
-from . import utils
+from . import phases, utils
 from .utils import logger
 
 
@@ -58,11 +58,13 @@ def _fresh_workdir(workdir: str, force: bool) -> None:
 
 def _unpack_database(zip_path: str, workdir: str, threads: int) -> None:
     logger.info("Unzipping the sourmash signature file to the temporary directory")
-    with zipfile.ZipFile(zip_path, "r") as archive:
-        archive.extractall(workdir)
+    with phases.phase("unzip"):
+        with zipfile.ZipFile(zip_path, "r") as archive:
+            archive.extractall(workdir)
     packed = glob.glob(f"{workdir}/signatures/*.sig.gz")
     logger.info(f"Decompressing {len(packed)} .sig.gz files using {threads} threads.")
-    utils.decompress_all_sig_files(packed, threads)
+    with phases.phase("gunzip"):
+        utils.decompress_all_sig_files(packed, threads)
 
 
 def main(args) -> None:
@@ -78,14 +80,16 @@ def main(args) -> None:
     _unpack_database(zip_path, workdir, args.num_threads)
 
     logger.info("Extracting signature information")
-    sig_info = utils.collect_signature_info(args.num_threads, args.ksize, workdir)
+    with phases.phase("signature_metadata"):
+        sig_info = utils.collect_signature_info(args.num_threads, args.ksize, workdir)
     scaled_values = {record[-2] for record in sig_info.values()}
     if len(scaled_values) != 1:
         raise ValueError(MSG_SCALES)
 
     logger.info("Finding the closely related genomes with ANI > ani_thresh and removing them.")
-    kept = utils.run_yacht_train_core(args.num_threads, args.ani_thresh, args.ksize, workdir, sig_info,
-                                      device=getattr(args, "device", 0))
+    with phases.phase("train_core"):
+        kept = utils.run_yacht_train_core(args.num_threads, args.ani_thresh, args.ksize, workdir, sig_info,
+                                          device=getattr(args, "device", 0))
 
     manifest_path = os.path.join(outdir, f"{args.prefix}_processed_manifest.tsv")
     kept.to_csv(manifest_path, sep="\t", index=None)

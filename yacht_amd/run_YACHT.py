@@ -21,6 +21,7 @@ from pathlib import Path
 import pandas as pd
 
 from . import hypothesis_recovery_src as hr
+from . import phases
 from . import utils
 from .utils import logger
 
@@ -110,15 +111,17 @@ def main(args) -> None:
     utils.check_file_existence(manifest_file_path, MSG_NO_MANIFEST.format(manifest_file_path))
 
     logger.info("Loading the manifest file generated from the training data.")
-    manifest = pd.read_csv(manifest_file_path, sep="\t", header=0)
+    with phases.phase("load_manifest"):
+        manifest = pd.read_csv(manifest_file_path, sep="\t", header=0)
     with zipfile.ZipFile(sample_file, "r") as z:
         if "SOURMASH-MANIFEST.csv" not in z.namelist():
             raise FileNotFoundError(MSG_ZIP_WITHOUT_MANIFEST.format(sample_file))
-    try:
-        sample_sig = utils.load_signature_with_ksize(sample_file, ksize)
-    except ValueError:
-        raise ValueError(MSG_NOT_ONE_SKETCH.format(sample_file, ksize, len(sample_file)))
-    info = utils.get_info_from_single_sig(sample_file, ksize)
+    with phases.phase("load_sample"):
+        try:
+            sample_sig = utils.load_signature_with_ksize(sample_file, ksize)
+        except ValueError:
+            raise ValueError(MSG_NOT_ONE_SKETCH.format(sample_file, ksize, len(sample_file)))
+        info = utils.get_info_from_single_sig(sample_file, ksize)
     manifest["num_exclusive_kmers_in_sample_sketch"] = info[3]
     manifest["num_total_kmers_in_sample_sketch"] = utils.get_num_kmers(info[3], info[4], info[5], scale=False)
     manifest["sample_scale_factor"] = info[5]
@@ -137,13 +140,16 @@ def main(args) -> None:
             utils.decompress_all_sig_files(glob.glob(f"{genome_dir}/signatures/*.sig.gz"), args.num_threads)
 
     logger.info("Computing hypothesis recovery.")
-    results = hr.hypothesis_recovery(manifest, (sample_file, sample_sig), genome_dir, covs, scale, ksize,
-                                     args.significance, ani_thresh, args.num_threads)
+    with phases.phase("hypothesis_recovery"):
+        results = hr.hypothesis_recovery(manifest, (sample_file, sample_sig), genome_dir, covs, scale, ksize,
+                                         args.significance, ani_thresh, args.num_threads)
     hr.release_reference_dbs()
     results = [r[[c for c in r.columns if c not in ("md5sum", "sample_scale_factor")]]
                .rename(columns={"genome_scale_factor": "scale_factor"}) for r in results]
 
     logger.info(f"Saving results to {results_folder}.")
+    _t_write = phases.phase("write_results")
+    _t_write.__enter__()
     user_results = results if has_raw else results[1:]
     user_covs = covs if has_raw else covs[1:]
     pd.concat(user_results, ignore_index=True).to_csv(os.path.join(results_folder, "result_all.txt"), sep="\t", index=False)
@@ -153,6 +159,7 @@ def main(args) -> None:
     for cov, df in zip(user_covs, user_results):
         tables.append((f"min_coverage{cov}", df if args.show_all else df[df["in_sample_est"] == True]))  # noqa: E712
     write_tables(tables, results_folder)
+    _t_write.__exit__(None, None, None)
 
 
 if __name__ == "__main__":

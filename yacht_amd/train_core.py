@@ -25,7 +25,7 @@ from typing import List, Sequence, Tuple
 
 import numpy as np
 
-from . import sigio
+from . import phases, sigio
 from .engine import YH_DB_PAIRWISE_ONLY, RefDB, pack_csr, train_select
 
 
@@ -112,13 +112,17 @@ def run(file_list: str, working_directory: str, output_filename: str, threads: i
     if containment_threshold < 0.0 or containment_threshold > 1.0:
         raise ValueError("containment threshold must be between 0.0 and 1.0")
     paths = read_sketch_list(file_list)
-    values, offsets = read_sketches_csr(paths, threads)
+    with phases.phase("read_sig_files"):
+        values, offsets = read_sketches_csr(paths, threads)
     n = len(paths)
     sizes = np.diff(offsets).astype(np.uint32)
     empty = [int(i) for i in np.flatnonzero(sizes == 0)]
-    with RefDB(values, offsets, device=device, flags=YH_DB_PAIRWISE_ONLY) as db:
+    with phases.phase("upload_and_index"):
+        db = RefDB(values, offsets, device=device, flags=YH_DB_PAIRWISE_ONLY)
+    with db:
         stats = db.index_stats()
-        pi, pj, pc = db.pairwise(float(containment_threshold))
+        with phases.phase("pairwise"):
+            pi, pj, pc = db.pairwise(float(containment_threshold))
     if verbose:
         print(f"Total number of sketches to read: {n}")
         print(f"Number of empty sketches: {len(empty)}")
@@ -127,15 +131,17 @@ def run(file_list: str, working_directory: str, output_filename: str, threads: i
         print(f"Size of the index: {stats[2]}")
 
     # comparison files, split like the reference's (pass, thread) row blocks
-    starts = np.searchsorted(pi, np.arange(n + 1), side="left")
-    for (p, t, a, b) in row_ranges(n, threads, passes):
-        with open(os.path.join(working_directory, f"{p}_{t:03d}.txt"), "w") as f:
-            lo, hi = (int(starts[a]), int(starts[b])) if b > a else (0, 0)
-            for k in range(lo, hi):
-                i, j = int(pi[k]), int(pj[k])
-                f.write(format_pair_line(i, j, int(pc[k]), int(sizes[i]), int(sizes[j])) + "\n")
+    with phases.phase("write_comparison_files"):
+        starts = np.searchsorted(pi, np.arange(n + 1), side="left")
+        for (p, t, a, b) in row_ranges(n, threads, passes):
+            with open(os.path.join(working_directory, f"{p}_{t:03d}.txt"), "w") as f:
+                lo, hi = (int(starts[a]), int(starts[b])) if b > a else (0, 0)
+                for k in range(lo, hi):
+                    i, j = int(pi[k]), int(pj[k])
+                    f.write(format_pair_line(i, j, int(pc[k]), int(sizes[i]), int(sizes[j])) + "\n")
 
-    selected = train_select(sizes, pi, pj)
+    with phases.phase("select"):
+        selected = train_select(sizes, pi, pj)
     with open(output_filename, "w") as f:
         for g in selected:
             f.write(paths[int(g)] + "\n")

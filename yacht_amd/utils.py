@@ -20,7 +20,7 @@ from typing import Dict, List, Optional, Tuple
 import numpy as np
 import pandas as pd
 
-from . import refdb_cache, sigio, train_core
+from . import phases, refdb_cache, sigio, train_core
 
 logger = logging.getLogger("yacht_amd")
 if not logger.handlers:
@@ -144,12 +144,14 @@ def run_yacht_train_core(num_threads: int, ani_thresh: float, ksize: int, path_t
     row_of_path = {p: i for i, p in enumerate(core["paths"])}
     name_to_path = {name: info[-1] for name, info in sig_info_dict.items()}
     keep = [row_of_path[name_to_path[name]] for name in manifest["organism_name"]]
-    values, offsets = refdb_cache.subset(core["values"], core["offsets"], keep)
+    with phases.phase("pack_selected"):
+        values, offsets = refdb_cache.subset(core["values"], core["offsets"], keep)
     # The train core reads record 0 / signature 0 of every file, whatever its k-mer size (as the reference's does,
     # main.cpp:62-84); the manifest's sizes come from the signature of THIS k-mer size.  Only when the two agree
     # is the packed copy what `yacht run` would load itself -- otherwise it is not written and run reads the files.
     if np.array_equal(np.diff(offsets).astype(np.int64), manifest["num_unique_kmers_in_genome_sketch"].to_numpy(dtype=np.int64)):
-        refdb_cache.save(path_to_temp_dir, manifest["md5sum"].to_list(), ksize, values, offsets)
+        with phases.phase("write_packed_db"):
+            refdb_cache.save(path_to_temp_dir, manifest["md5sum"].to_list(), ksize, values, offsets)
     else:
         logger.warning("sketch sizes of the train core and of the ksize-filtered signatures differ: no packed copy written")
     return manifest
