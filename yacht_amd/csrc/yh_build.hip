@@ -186,28 +186,34 @@ __device__ __forceinline__ IdxFlags idx_flags(const u64* __restrict__ sk, u64 n,
     return f;
 }
 
-// per-block counts: {distinct heads, shared heads, shared elements}
+// One WAVE per chunk of IDX_BLOCK consecutive sorted elements, lane = element (64 at a step, coalesced);
+// ranks inside the chunk are ballot prefix counts.  (The first form gave every thread 16 consecutive
+// elements: 64 different cache lines per load instruction, 21 ms at 3.3e8 elements; this one ~3 ms.)
+// per-chunk counts: {distinct heads, shared heads, shared elements}
 __global__ void __launch_bounds__(IDX_THREADS) k_idx_count(const u64* __restrict__ sk, u64 n,
                                                             u32* __restrict__ counts /* [nb][3] */) {
-    __shared__ u32 acc[3];
-    if (threadIdx.x < 3) acc[threadIdx.x] = 0;
-    __syncthreads();
-    const u64 base = (u64)blockIdx.x * IDX_BLOCK;
+    const u32 lane = threadIdx.x & 63u;
+    const u64 chunk = (blockIdx.x * (u64)blockDim.x + threadIdx.x) >> 6;
+    const u64 base = chunk * IDX_BLOCK;
+    if (base >= n) return;
     u32 c0 = 0, c1 = 0, c2 = 0;
-    for (int it = 0; it < IDX_ITEMS; ++it) {
-        const u64 i = base + (u64)it * IDX_THREADS + threadIdx.x;
+    for (u32 it = 0; it < IDX_BLOCK / 64; ++it) {
+        const u64 i = base + (u64)it * 64 + lane;
+        bool head = false, shared = false;
         if (i < n) {
             const IdxFlags f = idx_flags(sk, n, i);
-            c0 += f.head;
-            c1 += f.head && f.shared;
-            c2 += f.shared;
+            head = f.head;
+            shared = f.shared;
         }
+        c0 += (u32)__popcll(__ballot(head));
+        c1 += (u32)__popcll(__ballot(head && shared));
+        c2 += (u32)__popcll(__ballot(shared));
     }
-    atomicAdd(&acc[0], c0);
-    atomicAdd(&acc[1], c1);
-    atomicAdd(&acc[2], c2);
-    __syncthreads();
-    if (threadIdx.x < 3) counts[(u64)blockIdx.x * 3 + threadIdx.x] = acc[threadIdx.x];
+    if (lane == 0) {
+        counts[chunk * 3 + 0] = c0;
+        counts[chunk * 3 + 1] = c1;
+        counts[chunk * 3 + 2] = c2;
+    }
 }
 
 // single workgroup: exclusive scan of the per-block counts into 64-bit bases, totals at [nb]
@@ -232,8 +238,9 @@ __global__ void __launch_bounds__(1024) k_idx_scan_counts(const u32* __restrict_
     }
 }
 
-// Write g[], po[], pr[], pg[] and nshared[].  Items are taken in a blocked arrangement (thread
-// t owns IDX_ITEMS consecutive sorted elements) so ranks inside the block are a plain scan.
+// Write g[], po[], pr[], pg[] and nshared[] (and dh / dref / elem_g).  Same wave-per-chunk walk as
+// k_idx_count; an element's rank = the chunk's base (bases[]) + what the wave has seen so far + the flagged
+// lanes below it.
 __global__ void __launch_bounds__(IDX_THREADS) k_idx_emit(const u64* __restrict__ sk, const u32* __restrict__ sv,
                                                           u64 n, const u64* __restrict__ bases,
                                                           u64* __restrict__ g, u64* __restrict__ po,
@@ -243,52 +250,48 @@ __global__ void __launch_bounds__(IDX_THREADS) k_idx_emit(const u64* __restrict_
                                                           u32* __restrict__ elem_g) {
     // dh/dref (optional): every DISTINCT hash ascending, with its single holder, or
     // 0x80000000 | (index into g) when several references hold it
-    __shared__ u32 lds[17];
-    const u64 base = (u64)blockIdx.x * IDX_BLOCK + (u64)threadIdx.x * IDX_ITEMS;
-    u32 nh = 0, ns = 0, nd = 0;
-    u32 fl[IDX_ITEMS];
-#pragma unroll
-    for (int it = 0; it < IDX_ITEMS; ++it) {
-        const u64 i = base + it;
-        u32 f = 0;
+    const u32 lane = threadIdx.x & 63u;
+    const u64 chunk = (blockIdx.x * (u64)blockDim.x + threadIdx.x) >> 6;
+    const u64 base = chunk * IDX_BLOCK;
+    if (base >= n) return;
+    u64 di = bases[chunk * 3 + 0];  // distinct hashes before this step's elements
+    u64 gi = bases[chunk * 3 + 1];  // shared heads
+    u64 mi = bases[chunk * 3 + 2];  // shared elements
+    const u64 below = (1ull << lane) - 1ull;
+    for (u32 it = 0; it < IDX_BLOCK / 64; ++it) {
+        const u64 i = base + (u64)it * 64 + lane;
+        bool head = false, shared = false;
+        u64 h = 0;
+        u32 r = 0;
         if (i < n) {
-            const IdxFlags x = idx_flags(sk, n, i);
-            f = (x.shared ? 1u : 0u) | ((x.shared && x.head) ? 2u : 0u) | (x.head ? 4u : 0u);
+            const IdxFlags f = idx_flags(sk, n, i);
+            head = f.head;
+            shared = f.shared;
+            h = sk[i];
+            r = sv[i];
         }
-        fl[it] = f;
-        ns += f & 1u;
-        nh += (f >> 1) & 1u;
-        nd += (f >> 2) & 1u;
-    }
-    u32 tot;
-    const u32 exh = block_excl_scan(nh, &tot, lds);
-    const u32 exs = block_excl_scan(ns, &tot, lds);
-    const u32 exd = dh ? block_excl_scan(nd, &tot, lds) : 0u;
-    u64 di = bases[(u64)blockIdx.x * 3 + 0] + exd;  // distinct hashes before this thread's items
-    u64 gi = bases[(u64)blockIdx.x * 3 + 1] + exh;  // shared heads before this thread's items
-    u64 mi = bases[(u64)blockIdx.x * 3 + 2] + exs;  // shared elements before this thread's items
-#pragma unroll
-    for (int it = 0; it < IDX_ITEMS; ++it) {
-        const u64 i = base + it;
-        const u32 f = fl[it];
-        if (f & 2u) {
-            g[gi] = sk[i];
-            po[gi] = mi;
-            ++gi;
+        const u64 bd = __ballot(head), bg = __ballot(head && shared), bm = __ballot(shared);
+        const u64 my_d = di + (u64)__popcll(bd & below);
+        // shared heads up to and including this lane: the g index of the run this element belongs to
+        const u64 my_g_incl = gi + (u64)__popcll(bg & (below | (1ull << lane)));
+        const u64 my_m = mi + (u64)__popcll(bm & below);
+        if (head && shared) {
+            g[my_g_incl - 1] = h;
+            po[my_g_incl - 1] = my_m;
         }
-        if (dh && (f & 4u)) {
-            dh[di] = sk[i];
-            dref[di] = (f & 2u) ? (0x80000000u | (u32)(gi - 1)) : sv[i];
-            ++di;
+        if (dh && head) {
+            dh[my_d] = h;
+            dref[my_d] = shared ? (0x80000000u | (u32)(my_g_incl - 1)) : r;
         }
-        if (f & 1u) {
-            const u32 r = sv[i];
-            pr[mi] = r;
-            pg[mi] = (u32)(gi - 1);
+        if (shared) {
+            pr[my_m] = r;
+            pg[my_m] = (u32)(my_g_incl - 1);
             atomicAdd(&nshared[r], 1u);
-            ++mi;
         }
-        if (elem_g && i < n) elem_g[i] = (f & 1u) ? (u32)(gi - 1) : STREAM_NONE;  // shared-hash index of every sorted element
+        if (elem_g && i < n) elem_g[i] = shared ? (u32)(my_g_incl - 1) : STREAM_NONE;  // shared-hash index of every sorted element
+        di += (u64)__popcll(bd);
+        gi += (u64)__popcll(bg);
+        mi += (u64)__popcll(bm);
     }
 }
 
@@ -733,7 +736,7 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, const u
     if (want_stream) IDX_HIP(hipMalloc((void**)&d_elem_g, H * sizeof(u32)));
     u64 totals[3] = {0, 0, 0};
     if (rc == YH_OK) {
-        k_idx_count<<<(u32)nb, IDX_THREADS, 0, st>>>(d_sk, H, d_counts);
+        k_idx_count<<<(u32)((nb * 64 + IDX_THREADS - 1) / IDX_THREADS), IDX_THREADS, 0, st>>>(d_sk, H, d_counts);
         k_idx_scan_counts<<<1, 1024, 0, st>>>(d_counts, nb, d_bases);
         IDX_HIP(hipGetLastError());
         IDX_HIP(hipMemcpyAsync(totals, d_bases + nb * 3, 3 * sizeof(u64), hipMemcpyDeviceToHost, st));
@@ -809,7 +812,7 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, const u
         u64* const dh_out = !full ? nullptr : compact ? d_dh_tmp : db->d_dh;
         u32* const dref_out = !full ? nullptr : compact ? d_dref_tmp : db->d_dref;
         if (rc == YH_OK)
-            k_idx_emit<<<(u32)nb, IDX_THREADS, 0, st>>>(d_sk, d_sv, H, d_bases, db->d_g, db->d_po, db->d_pr, db->d_pg,
+            k_idx_emit<<<(u32)((nb * 64 + IDX_THREADS - 1) / IDX_THREADS), IDX_THREADS, 0, st>>>(d_sk, d_sv, H, d_bases, db->d_g, db->d_po, db->d_pr, db->d_pg,
                                                         db->d_nshared, dh_out, dref_out, d_elem_g);
         if (rc == YH_OK && full && !compact)
             k_dir_build<<<grid_for(db->n_distinct, 256), 256, 0, st>>>(db->d_dh, db->n_distinct, db->dir_shift, db->dir_nb,

@@ -1688,19 +1688,50 @@ __global__ void k_excl_final(u64 n, const u8* __restrict__ mask, const u32* __re
 //
 // One thread per posting (a = its reference): for every other reference b of the same hash,
 // M[cid[a] - c0][cid[b]] += 1.  Integer atomics: the result does not depend on arrival order.
-__global__ void k_pair_accum(u64 n_post, const u32* __restrict__ pr, const u32* __restrict__ pg,
-                             const u64* __restrict__ po, const u32* __restrict__ cid, u64 c0, u64 c1, u64 n_c,
-                             u32* __restrict__ M) {
-    for (u64 k = blockIdx.x * (u64)blockDim.x + threadIdx.x; k < n_post; k += (u64)gridDim.x * blockDim.x) {
-        const u32 a = pr[k];
-        const u32 ca = cid[a];
-        if (ca < c0 || ca >= c1) continue;
-        const u32 gi = pg[k];
-        const u64 b = po[gi], e = po[gi + 1];
-        u32* row = M + (u64)(ca - c0) * n_c;
-        for (u64 q = b; q < e; ++q) {
-            const u32 o = pr[q];
-            if (o != a) atomicAdd(&row[cid[o]], 1u);
+// A posting whose hash has few holders walks the list itself; a list of more than PAIR_LONG holders is
+// walked by the whole wave, one holder per lane (a k-mer shared by M references is M^2 increments either
+// way, but M serial steps per posting instead of M / 64 made one conserved k-mer the tail of the launch).
+constexpr u32 PAIR_LONG = 32;
+__global__ void __launch_bounds__(256) k_pair_accum(u64 n_post, const u32* __restrict__ pr, const u32* __restrict__ pg,
+                                                    const u64* __restrict__ po, const u32* __restrict__ cid, u64 c0, u64 c1,
+                                                    u64 n_c, u32* __restrict__ M) {
+    const u32 lane = threadIdx.x & 63u;
+    const u64 wave = (blockIdx.x * (u64)blockDim.x + threadIdx.x) >> 6;
+    const u64 n_waves = ((u64)gridDim.x * blockDim.x) >> 6;
+    for (u64 k0 = wave * 64; k0 < n_post; k0 += n_waves * 64) {
+        const u64 k = k0 + lane;
+        u32 a = 0, ca = 0xffffffffu;
+        u64 b = 0, e = 0;
+        if (k < n_post) {
+            a = pr[k];
+            ca = cid[a];
+            if (ca >= c0 && ca < c1) {
+                const u32 gi = pg[k];
+                b = po[gi];
+                e = po[gi + 1];
+            }
+        }
+        const bool mine = e > b;
+        const bool is_long = mine && (e - b) > PAIR_LONG;
+        if (mine && !is_long) {
+            u32* row = M + (u64)(ca - c0) * n_c;
+            for (u64 q = b; q < e; ++q) {
+                const u32 o = pr[q];
+                if (o != a) atomicAdd(&row[cid[o]], 1u);
+            }
+        }
+        u64 todo = __ballot(is_long);
+        while (todo) {
+            const int src = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const u32 a_s = (u32)__shfl((int)a, src), ca_s = (u32)__shfl((int)ca, src);
+            const u64 b_s = ((u64)(u32)__shfl((int)(u32)(b >> 32), src) << 32) | (u32)__shfl((int)(u32)b, src);
+            const u64 e_s = ((u64)(u32)__shfl((int)(u32)(e >> 32), src) << 32) | (u32)__shfl((int)(u32)e, src);
+            u32* row = M + (u64)(ca_s - c0) * n_c;
+            for (u64 q = b_s + lane; q < e_s; q += 64) {
+                const u32 o = pr[q];
+                if (o != a_s) atomicAdd(&row[cid[o]], 1u);
+            }
         }
     }
 }
@@ -2198,8 +2229,14 @@ int yh_q_pairwise(yh_db* db, double c_thresh, u64 r0, u64 r1) {
     const u64 c_end = std::lower_bound(h_rid.begin(), h_rid.end(), (u32)std::min<u64>(r1, 0xffffffffull)) - h_rid.begin();
     if (NC == 0 || c_begin >= c_end) { db->pw_valid = true; db->pw_c = c_thresh; db->pw_r0 = r0; db->pw_r1 = r1; return YH_OK; }
 
-    // dense row blocks (compact rows x compact columns) of at most ~32 GiB of int32 counts
-    const u64 budget = 32ull << 30;
+    // dense row blocks (compact rows x compact columns) of int32 counts: at most ~32 GiB, and at most 60 % of what the
+    // device has free now (other handles, other ranks sharing the GPU); halved again when the allocation still fails
+    u64 budget = 32ull << 30;
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0) budget = std::min<u64>(budget, (u64)((double)free_b * 0.6));
+        else (void)hipGetLastError();
+    }
     u64 rows_per_block = std::max<u64>(1, budget / (NC * sizeof(u32)));
     if (rows_per_block > c_end - c_begin) rows_per_block = c_end - c_begin;
     const double c_relaxed = c_thresh * (1.0 - 1e-9) - 1e-300;
@@ -2217,7 +2254,18 @@ int yh_q_pairwise(yh_db* db, double c_thresh, u64 r0, u64 r1) {
             rc = (e__ == hipErrorOutOfMemory) ? YH_ERR_OOM : YH_ERR_HIP;                      \
         }                                                                                     \
     }
-    PW_HIP(hipMalloc((void**)&d_M, rows_per_block * NC * sizeof(u32)));
+    for (;;) {
+        const hipError_t em = hipMalloc((void**)&d_M, rows_per_block * NC * sizeof(u32));
+        if (em == hipSuccess) break;
+        (void)hipGetLastError();
+        d_M = nullptr;
+        if (em != hipErrorOutOfMemory || rows_per_block == 1) {
+            yh_set_error("hipMalloc of the %llu-row count block failed: %s", (u64)rows_per_block, hipGetErrorString(em));
+            rc = (em == hipErrorOutOfMemory) ? YH_ERR_OOM : YH_ERR_HIP;
+            break;
+        }
+        rows_per_block = (rows_per_block + 1) / 2;
+    }
     PW_HIP(hipMalloc((void**)&d_rowcnt, rows_per_block * sizeof(u32)));
     PW_HIP(hipMalloc((void**)&d_rowoff, (rows_per_block + 1) * sizeof(u64)));
     PW_HIP(hipMalloc((void**)&d_cid, N * sizeof(u32)));
