@@ -285,9 +285,8 @@ def main() -> int:
     # ---- N = 1 extras ------------------------------------------------------------------------------------
     indexed = host_inclusive = real_shape = None
     paths = {}
-    default_choice = ylib.YH_LOOKUP_STREAM
+    default_choice = db.lookup_choice(n_sample)  # (the sharded step asks the same question inside yh_run_local_device)
     if world == 1:
-        default_choice = db.lookup_choice(n_sample)
         timing_default = timing
         cpath = torch.zeros((3, n_local), device=dev, dtype=torch.int32)
 

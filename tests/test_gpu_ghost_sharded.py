@@ -79,7 +79,7 @@ sys.exit(0 if ok else 1)
 '''
 
 
-def _launch(world: int, n_refs: int, tmp_path):
+def _launch(world: int, n_refs: int, tmp_path, lookup: str = "auto"):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     port = _free_port()
@@ -87,6 +87,8 @@ def _launch(world: int, n_refs: int, tmp_path):
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), YH_ROOT=ROOT, YH_NREFS=str(n_refs), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        if lookup != "auto":
+            env["YH_LOOKUP"] = lookup  # force the streaming / the sample-driven lookup inside yh_run_local_device
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, text=True))
     outs = []
@@ -100,9 +102,9 @@ def _launch(world: int, n_refs: int, tmp_path):
     return [p.returncode for p in procs], outs
 
 
-@pytest.mark.parametrize("world", [1, 2, 3])
-def test_sharded_refdb_hip_processes_share_gpu(hip_lib, tmp_path, world):
-    rcs, outs = _launch(world, 3000, tmp_path)
+@pytest.mark.parametrize("world,lookup", [(1, "auto"), (2, "stream"), (2, "indexed"), (3, "auto")])
+def test_sharded_refdb_hip_processes_share_gpu(hip_lib, tmp_path, world, lookup):
+    rcs, outs = _launch(world, 3000, tmp_path, lookup)
     assert all(rc == 0 for rc in rcs), "\n".join(outs)
 
 

@@ -762,7 +762,8 @@ int yh_run_local_device(yh_db* db, const uint64_t* d_sample, uint64_t n_sample, 
     if (!db_ok(db)) return YH_ERR_INVALID_ARG;
     if (!d_overlap || !d_n_excl || !d_n_match || (n_sample && !d_sample)) { yh_set_error("null device pointer"); return YH_ERR_INVALID_ARG; }
     YH_TRY(db_select(db));
-    const int rc = yh_q_run_fused(db, (const u64*)d_sample, n_sample, d_overlap, d_n_excl, d_n_match, 1, d_bits_out, nullptr);
+    const int rc = yh_q_run_fused(db, (const u64*)d_sample, n_sample, d_overlap, d_n_excl, d_n_match, 1, d_bits_out, nullptr,
+                                  prefer_indexed(db, n_sample));
     if (rc == 1) { yh_set_error("yh_run_local_device needs a non-empty handle in the default layout with its index"); return YH_ERR_UNSUPPORTED; }
     return rc;
 }

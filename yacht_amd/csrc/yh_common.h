@@ -295,7 +295,7 @@ int yh_q_overlap(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap, b
 // phases: 1 = lookup + reduce (leaves the subset bits in d_maskbits and, optionally, d_bits_out), 2 = the
 // posting-list part of n_excl (ghost bits patched from d_global_bits first), 3 = both.  1 = not applicable.
 int yh_q_run_fused(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap, u32* d_excl, u32* d_match,
-                   int phases = 3, u32* d_bits_out = nullptr, const u32* d_global_bits = nullptr);
+                   int phases = 3, u32* d_bits_out = nullptr, const u32* d_global_bits = nullptr, bool use_indexed = false);
 int yh_q_overlap_bsearch(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap);
 // ---- the distinct-hash directory as the lookup kernels see it -------------------------------------
 // Primary structure: a table of 64-byte buckets, bucket(h) = floor(h * bkt_nb / 2^bits(max_hash))
@@ -403,8 +403,10 @@ inline YhDirView yh_dir_view(const yh_db* db) {
 }
 #endif
 
+// returns 2 when it did the exclusive counts too (lookup_half_only: everything but the posting-list pass)
 int yh_q_overlap_indexed(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap, bool for_exclusive,
-                         u32* d_fused_excl = nullptr, u32* d_fused_match = nullptr);  // returns 2 when it did the exclusive counts too
+                         u32* d_fused_excl = nullptr, u32* d_fused_match = nullptr, u32* d_bits_out = nullptr,
+                         bool lookup_half_only = false);
 int yh_q_run_batch(yh_db* db, const u64* d_samples, const u64* d_soff, u32 n_samples, u64 total_hashes,
                    u32* d_overlap, u32* d_excl, u32* d_match);
 int yh_q_exclusive(yh_db* db, const u8* d_mask, const u64* d_sample, u64 n_sample,

@@ -2023,7 +2023,7 @@ int yh_q_overlap(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap, b
 // The `yacht run` step on the hash-sorted stream: overlap, subset = overlap > 0, exclusive counts.
 // Returns 1 when this handle cannot take the fused path (the caller then runs the general one).
 int yh_q_run_fused(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap, u32* d_excl, u32* d_match, int phases,
-                   u32* d_bits_out, const u32* d_global_bits) {
+                   u32* d_bits_out, const u32* d_global_bits, bool use_indexed) {
     static const bool off = [] { const char* e = getenv("YH_NO_FUSED_RUN"); return e && e[0] == '1'; }();
     if (!db->d_sdelta || !db->has_index || db->posting_only || db->n_refs == 0 || db->n_hashes == 0 ||
         (db->n_postings && (!db->d_rrec || !db->d_rrecx || !db->d_work)) || n_sample > 0xfffffff0ull)
@@ -2039,6 +2039,9 @@ int yh_q_run_fused(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap,
             YH_HIP(hipMemsetAsync(db->d_maskbits, 0, ((N + 255) / 256) * 32, st));
             if (d_bits_out) YH_HIP(hipMemsetAsync(d_bits_out, 0, ((N + 63) / 64) * 8, st));
             if (db->d_work_count) YH_HIP(hipMemsetAsync(db->d_work_count, 0, sizeof(u32), st));
+        } else if (use_indexed && db->has_dir && db->d_work && db->d_rrec && db->d_rrecx) {
+            const int rc = yh_q_overlap_indexed(db, d_sample, n_sample, d_overlap, true, d_excl, d_match, d_bits_out, true);
+            if (rc != 2) return rc == YH_OK ? YH_ERR_UNSUPPORTED : rc;
         } else {
             YH_TRY(yh_q_overlap_stream(db, d_sample, n_sample, d_overlap, true, true, true, d_excl, d_match, d_bits_out));
         }
@@ -2060,7 +2063,7 @@ int yh_q_run_fused(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap,
 // accumulators) through the directory; same outputs as yh_q_overlap(..., flag_shared, make_mask)
 // d_fused_excl / d_fused_match non-null: the whole run step in three launches (see yh_q_run_fused)
 int yh_q_overlap_indexed(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap, bool for_exclusive,
-                         u32* d_fused_excl, u32* d_fused_match) {
+                         u32* d_fused_excl, u32* d_fused_match, u32* d_bits_out, bool lookup_half_only) {
     if (!db->has_dir || !db->has_index) {
         yh_set_error("this handle has no directory of its distinct hashes (YH_DB_NO_DIRECTORY, or no index)");
         return YH_ERR_UNSUPPORTED;
@@ -2091,10 +2094,10 @@ int yh_q_overlap_indexed(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_ov
     k_reduce_replicas<<<(u32)((N + 255) / 256), 256, 0, st>>>(
         db->d_reps, R, N, d_overlap, (for_exclusive && !fused) ? db->d_mask : nullptr,
         for_exclusive ? db->d_maskbits : nullptr, (for_exclusive && !fused) ? db->d_excl_e : nullptr,
-        fused ? FusedRun{reps2, db->d_sizes, db->d_nshared, d_fused_excl, d_fused_match, nullptr, db->d_rpo, db->d_work,
-                         db->d_work_count, (u32)N}
+        fused ? FusedRun{reps2, db->d_sizes, db->d_nshared, d_fused_excl, d_fused_match, d_bits_out, db->d_rpo, db->d_work,
+                         db->d_work_count, (u32)(db->n_ghost ? db->ghost_begin : N)}
               : FusedRun{});
-    if (fused) {
+    if (fused && !lookup_half_only) {  // (sharded run: the posting-list half follows the exchange of the subset bits)
         yh_ring_record_begin(db, db->ev_excl);
         if (db->n_chunks) launch_excl_pieces(db, db->d_maskbits, nullptr, d_fused_excl, nullptr, nullptr);
         yh_ring_record_end(db, db->ev_excl);
