@@ -127,7 +127,7 @@ static int db_create_common(const u64* values, const u64* offsets, bool on_devic
     if (!out) { yh_set_error("out is null"); return YH_ERR_INVALID_ARG; }
     *out = nullptr;
     if (!offsets) { yh_set_error("offsets is null"); return YH_ERR_INVALID_ARG; }
-    if (n_refs > 0xfffffff0ull) { yh_set_error("too many references"); return YH_ERR_INVALID_ARG; }
+    if (n_refs > 0x7ffffff0ull) { yh_set_error("too many references (at most 2^31 - 16: the top bit of a reference id is a flag)"); return YH_ERR_INVALID_ARG; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
         yh_set_error("no HIP device available (libyacht_hip has no CPU fallback)");

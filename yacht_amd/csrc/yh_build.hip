@@ -308,7 +308,7 @@ struct StreamCount {
 };
 __global__ void k_stream_scatter(const u64* __restrict__ sk, const u32* __restrict__ sv, const u32* __restrict__ elem_g,
                                  u64 n, u32 sshift, const u64* __restrict__ pos1 /* position + 1 */,
-                                 u8* __restrict__ sdelta, uint4* __restrict__ srec, u64* __restrict__ hdr) {
+                                 u8* __restrict__ sdelta, uint2* __restrict__ srec, u64* __restrict__ hdr) {
     for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
         const u64 h = sk[i], t = h >> sshift, pos = pos1[i] - 1;
         u32 own = 0;
@@ -323,7 +323,9 @@ __global__ void k_stream_scatter(const u64* __restrict__ sk, const u32* __restri
             own = (u32)(t - tp - 255 * nfill);
         }
         sdelta[pos] = (u8)own;
-        srec[pos] = make_uint4((u32)h, (u32)(h >> 32), sv[i], elem_g ? elem_g[i] : STREAM_NONE);
+        // the hash's low 32 bits (the stream key carries the bits from sshift <= 32 up) and its reference, top bit = the
+        // hash is one of the database-shared ones
+        srec[pos] = make_uint2((u32)h, sv[i] | ((elem_g && elem_g[i] != STREAM_NONE) ? 0x80000000u : 0u));
         if ((pos & (STREAM_BLOCK - 1)) == 0) hdr[pos >> 10] = t;
     }
 }
@@ -612,8 +614,12 @@ bool yh_use_delta_stream() {
 static int build_stream(yh_db* db, const u64* d_sk, const u32* d_sv, const u32* d_elem_g, u64 H) {
     hipStream_t st = db->stream;
     if (H == 0) return YH_OK;
-    u32 s = 0;  // mean truncated gap in [32, 64): ~1 % fillers, ~|S|/48 key-only candidates per query
-    while (s < 63 && ((db->max_hash >> (s + 1)) / H) >= 32) ++s;
+    // mean truncated gap in [32, 64): ~1 % fillers, ~|S|/48 key-only candidates per query.  At most 32 bits are
+    // dropped: a candidate is confirmed by the LOW 32 BITS of the hash (the 8-byte record of its position), which
+    // together with the key are the whole hash only then.  (A small database of wide hashes gets a stream that is
+    // mostly fillers: at most 2^32 / 255 = 16.8 M elements.)
+    u32 s = 0;
+    while (s < 32 && ((db->max_hash >> (s + 1)) / H) >= 32) ++s;
     db->sshift = s;
     u64* d_pos = nullptr;
     void* d_tmp = nullptr;
@@ -640,10 +646,10 @@ static int build_stream(yh_db* db, const u64* d_sk, const u32* d_sv, const u32* 
         const u64 nblk = db->slen / STREAM_BLOCK;
         rc = yh_dmalloc(db, (void**)&db->d_sdelta, db->slen + 64);
         if (rc == YH_OK) rc = yh_dmalloc(db, (void**)&db->d_shdr, (nblk + 2) * sizeof(u64));
-        if (rc == YH_OK) rc = yh_dmalloc(db, (void**)&db->d_srec, db->slen * sizeof(uint4));
+        if (rc == YH_OK) rc = yh_dmalloc(db, (void**)&db->d_srec, db->slen * sizeof(uint2));
         ST_HIP(hipMemsetAsync(db->d_sdelta, 0, db->slen + 64, st));
         ST_HIP(hipMemsetAsync(db->d_shdr, 0xff, (nblk + 2) * sizeof(u64), st));
-        ST_HIP(hipMemsetAsync(db->d_srec, 0xff, db->slen * sizeof(uint4), st));
+        ST_HIP(hipMemsetAsync(db->d_srec, 0xff, db->slen * sizeof(uint2), st));
         if (rc == YH_OK)
             k_stream_scatter<<<grid_for(H, 256), 256, 0, st>>>(d_sk, d_sv, d_elem_g, H, s, d_pos, db->d_sdelta, db->d_srec,
                                                               db->d_shdr);

@@ -209,8 +209,8 @@ struct yh_db {
     // STREAM_BLOCK elements; s_hdr[b] = t of block b's first element (its own delta byte is unused).
     u8* d_sdelta = nullptr;    // [slen]
     u64* d_shdr = nullptr;     // [slen / STREAM_BLOCK + 1], last = ~0
-    uint4* d_srec = nullptr;   // [slen] per position {hash lo, hash hi, reference, index into d_g or STREAM_NONE}
-                               // (fillers / padding: all ones): ONE 16-byte read per candidate
+    uint2* d_srec = nullptr;   // [slen] per position {low 32 bits of the hash, reference | 0x80000000 when the hash is a
+                               // database-shared one} (fillers / padding: all ones): ONE 8-byte read per candidate
     u64 slen = 0;              // multiple of STREAM_BLOCK
     u32 sshift = 0;
     u64* d_wg_key = nullptr;   // [wgs + 1] first t of each workgroup's block range (sample-independent)

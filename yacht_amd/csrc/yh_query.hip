@@ -952,8 +952,10 @@ struct StreamHit {
     u32 n_refs;
     u32* reps;
     u32 rep_mask;
-    const uint4* srec;  // per stream position: {hash lo, hash hi, reference, shared-hash index}
-    u8* hitflag;        // may be null: hit[g] = 1 for every shared hash g found in the sample
+    const uint2* srec;  // per stream position: {hash low word, reference | shared bit}
+    u8* hitflag;        // may be null: hit[g] = 1 for every shared hash g found in the sample (g by search in gsh)
+    const u64* gsh;     // the shared hashes ascending, and their number (only read when hitflag is set)
+    u32 n_gsh;
     u32* reps2;         // may be null: a second set of replicas counting the hits ON SHARED HASHES only
     const u64* sample;
     const u32* bad;     // may be null: *bad == bad_gen = the sample failed the ordering check queued in front of
@@ -1014,7 +1016,7 @@ __device__ __forceinline__ void table_add(const StreamHit& hit, const WaveQ& c, 
     if (shared && hit.reps2) count_add(&hit.reps2[at], 1u);
 }
 struct Pending {  // one requested confirmation per lane
-    uint4 rec = make_uint4(0u, 0u, STREAM_NONE, STREAM_NONE);
+    uint2 rec = make_uint2(0u, STREAM_NONE);
     u64 sv = 0;
 };
 __device__ __forceinline__ void pending_request(const StreamHit& hit, Pending& p, u64 pos, u32 sidx) {
@@ -1022,12 +1024,20 @@ __device__ __forceinline__ void pending_request(const StreamHit& hit, Pending& p
     p.sv = hit.sample[sidx];
 }
 __device__ __forceinline__ void pending_count(const StreamHit& hit, const WaveQ& c, Pending& p) {
-    const u64 hv = ((u64)p.rec.y << 32) | p.rec.x;
-    if (hv == p.sv && p.rec.z != STREAM_NONE) {  // (fillers have no reference)
-        if (hit.hitflag && p.rec.w != STREAM_NONE) hit.hitflag[p.rec.w] = 1;
-        table_add(hit, c, p.rec.z, p.rec.w != STREAM_NONE);
+    // the candidate's key equals the element's (bits sshift.. of the hash, sshift <= 32): the low words decide
+    if (p.rec.x == (u32)p.sv && p.rec.y != STREAM_NONE) {  // (fillers have no reference)
+        const bool shared = (p.rec.y & 0x80000000u) != 0;
+        if (hit.hitflag && shared) {  // which shared hash: a search (general exclusive path only; shared hits are few)
+            u32 lo = 0, hi = hit.n_gsh;
+            while (lo < hi) {
+                const u32 mid = (lo + hi) >> 1;
+                if (hit.gsh[mid] < p.sv) lo = mid + 1; else hi = mid;
+            }
+            hit.hitflag[lo] = 1;
+        }
+        table_add(hit, c, p.rec.y & 0x7fffffffu, shared);
     }
-    p.rec.z = STREAM_NONE;
+    p.rec.y = STREAM_NONE;
 }
 __device__ __forceinline__ void push_hit(const StreamHit& hit, const WaveQ& c, u64 pos, u32 sidx) {
     const u32 slot = atomicAdd(c.fill, 1u);
@@ -1931,7 +1941,8 @@ static int yh_q_overlap_stream(yh_db* db, const u64* d_sample, u64 n_sample, u32
     // workgroup finds its own range of the sample (two 64-ary wave searches while its first
     // super-block is in flight).
     u32* const reps2 = db->d_reps + db->reps_cap;
-    StreamHit sh{(u32)N, db->d_reps, R - 1, db->d_srec, flags_too ? db->d_hit : nullptr, fused ? reps2 : nullptr, d_sample, db->d_bad, db->bad_gen, db->d_work_count};
+    StreamHit sh{(u32)N, db->d_reps, R - 1, db->d_srec, flags_too ? db->d_hit : nullptr, db->d_g, (u32)db->n_shared,
+                 fused ? reps2 : nullptr, d_sample, db->d_bad, db->bad_gen, db->d_work_count};
     yh_ring_record_begin(db, db->ev_overlap);
     k_stream_lookup<<<wgs, STREAM_THREADS, 0, st>>>(reinterpret_cast<const u32x4*>(db->d_sdelta), db->d_shdr, nblk, d_sample,
                                                     (u32)n_sample, db->d_wg_key, db->sshift, sh);
