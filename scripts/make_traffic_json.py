@@ -1,43 +1,69 @@
 #!/usr/bin/env python3
-"""HBM traffic per launch of the dominant kernel (default k_stream_lookup) from the rocprofv3 --pmc passes.
+"""HBM traffic per launch of the two lookup kernels from the rocprofv3 --pmc passes of scripts/profile_bench.sh.
 
-    python scripts/make_traffic_json.py gpurun_out profiles/traffic_r01.json <n_hashes> [kernel]
+    python scripts/make_traffic_json.py gpurun_out profiles <round tag, e.g. r02>
 
-MI355X_MICROARCH.md (HBM section): FETCH_SIZE and WRITE_SIZE are in KiB per dispatch; on gfx950
-FETCH_SIZE reports exactly HALF of the bytes of a wide coalesced streaming read (16 B per lane),
-which is what this kernel's stream is, so it is doubled; WRITE_SIZE is exact.  The two counters
-do not fit one pass (TCC slots), hence two runs of the same command.
+Writes profiles/traffic_<tag>_stream.json (k_stream_lookup) and profiles/traffic_<tag>_index.json
+(k_index_lookup).  bench.py attaches `hbm_bytes_per_launch` to its roofline block only when the file's
+`source_tag` (sha256 of csrc/yh_query.hip + yh_common.h) and `n_hashes` match the run.
+
+MI355X_MICROARCH.md (HBM section): FETCH_SIZE / WRITE_SIZE are in KiB per dispatch; on gfx950 FETCH_SIZE
+reports exactly HALF of the bytes of a wide coalesced streaming read (16 B per lane) -- what k_stream_lookup's
+stream is -- so it is doubled there; WRITE_SIZE is exact.  k_index_lookup reads isolated 64-byte buckets: its
+requests are 64-byte ones and are counted as such (checked: TCC_MISS x 64 B agrees with FETCH_SIZE x 1 within
+a few per cent in profiles/<tag>/summary.txt), so no doubling.  The two counters do not fit one pass.
 """
 import collections
 import csv
+import datetime
 import glob
+import hashlib
 import json
 import os
+import subprocess
 import sys
 
-root, out, n_hashes = sys.argv[1], sys.argv[2], int(sys.argv[3])
-KERNEL = sys.argv[4] if len(sys.argv) > 4 else "k_stream_lookup"
+root, out_dir, tag = sys.argv[1], sys.argv[2], sys.argv[3]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def source_tag() -> str:
+    h = hashlib.sha256()
+    for f in ("yh_query.hip", "yh_common.h"):
+        with open(os.path.join(ROOT, "yacht_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def mean_counter(d, counter, kernel_tag):
     files = glob.glob(os.path.join(root, d, "*", "*_counter_collection.csv"))
     files.sort(key=os.path.getmtime)
+    if not files:  # the slimmed per-pass file scripts/profile_bench.sh leaves behind
+        files = [os.path.join(root, d + ".csv")]
     vals = []
     for r in csv.DictReader(open(files[-1])):
         if r["Counter_Name"] == counter and kernel_tag in r["Kernel_Name"]:
             vals.append(float(r["Counter_Value"]))
-    return sum(vals) / len(vals), len(vals)
+    return (sum(vals) / len(vals), len(vals)) if vals else (0.0, 0)
 
 
-fetch_kib, nf = mean_counter("pmc_fetch", "FETCH_SIZE", KERNEL)
-write_kib, nw = mean_counter("pmc_write", "WRITE_SIZE", KERNEL)
-hbm = 2.0 * fetch_kib * 1024.0 + write_kib * 1024.0
-json.dump({
-    "kernel": KERNEL,
-    "n_hashes": n_hashes,
-    "FETCH_SIZE_KiB_mean": fetch_kib, "launches_fetch": nf,
-    "WRITE_SIZE_KiB_mean": write_kib, "launches_write": nw,
-    "correction": "read bytes = 2 x FETCH_SIZE (gfx950, 16-B/lane coalesced stream); write bytes = WRITE_SIZE",
-    "hbm_bytes_per_launch": int(hbm),
-}, open(out, "w"), indent=1)
-print(open(out).read())
+try:
+    commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+except Exception:
+    commit = ""
+bench = json.load(open(os.path.join(root, "bench_for_traffic.json")))
+n_hashes = int(bench["config"]["ref_hashes_per_gpu"])
+for kernel, name, factor, why in (
+        ("k_stream_lookup", "stream", 2.0, "read bytes = 2 x FETCH_SIZE (gfx950, 16-B/lane coalesced stream); write bytes = WRITE_SIZE"),
+        ("k_index_lookup", "index", 1.0, "read bytes = FETCH_SIZE (isolated 64-byte bucket reads: 64-byte requests); write bytes = WRITE_SIZE")):
+    fetch_kib, nf = mean_counter("pmc_fetch", "FETCH_SIZE", kernel)
+    write_kib, nw = mean_counter("pmc_write", "WRITE_SIZE", kernel)
+    if not nf:
+        continue
+    rec = {"kernel": kernel, "n_hashes": n_hashes, "source_tag": source_tag(), "commit": commit,
+           "taken": datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%MZ"),
+           "FETCH_SIZE_KiB_mean": fetch_kib, "launches_fetch": nf, "WRITE_SIZE_KiB_mean": write_kib, "launches_write": nw,
+           "correction": why, "hbm_bytes_per_launch": int(factor * fetch_kib * 1024.0 + write_kib * 1024.0)}
+    path = os.path.join(out_dir, f"traffic_{tag}_{name}.json")
+    json.dump(rec, open(path, "w"), indent=1)
+    print(path, rec["hbm_bytes_per_launch"])

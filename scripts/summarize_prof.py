@@ -36,7 +36,7 @@ for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     files.sort(key=os.path.getmtime)
     for r in csv.DictReader(open(files[-1])):
-        if any(t in r["Kernel_Name"] for t in ("k_tile_lookup", "k_stream_lookup", "k_resolve_stream", "k_resolve_hits", "k_excl_chunks")):
+        if any(t in r["Kernel_Name"] for t in ("k_tile_lookup", "k_stream_lookup", "k_index_lookup", "k_reduce_replicas", "k_excl_pieces")):
             acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
     print(f"== {os.path.basename(d)} (mean per launch) ==")
     for k, v in acc.items():
@@ -51,11 +51,13 @@ if trace:
     rows = list(csv.DictReader(open(trace[0])))
     rows = [r for r in rows if any(t in r["Kernel_Name"] for t in OURS) or "Memset" in r["Kernel_Name"] or "fill" in r["Kernel_Name"].lower()]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    for tag, title in (("k_stream_lookup(", "streaming step"), ("k_index_lookup(", "indexed step (k_index_lookup)")):
+    for tag, title in (("k_stream_lookup(", "streaming step"), ("k_index_lookup(", "sample-driven step (k_index_lookup)")):
         idx = [i for i, r in enumerate(rows) if tag in r["Kernel_Name"].replace("(anonymous namespace)::", "") + "("]
-        if len(idx) < 3:
+        # two consecutive launches of the same lookup kernel with only step kernels between them
+        pairs = [(a, b) for a, b in zip(idx, idx[1:]) if b - a <= 4]
+        if not pairs:
             continue
-        a, b = idx[-2], idx[-1]
+        a, b = pairs[len(pairs) // 2]
         t0 = int(rows[a]["Start_Timestamp"])
         prev_end = t0
         print(f"== timeline of one {title} (us) ==")

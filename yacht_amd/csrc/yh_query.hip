@@ -175,11 +175,10 @@ struct FusedRun {
 
 // Append the posting pieces of every reference in the subset to the work list: (reference, first posting)
 // per <= EXCL_PIECE postings.  One atomic per workgroup.  All 256 threads of the block must call it.
-__device__ __forceinline__ void append_pieces(bool in_subset, u32 j, const u32* __restrict__ nshared,
-                                              const u32* __restrict__ rpo, uint2* __restrict__ work,
+__device__ __forceinline__ void append_pieces(bool in_subset, u32 j, u32 nshared_j, u32 rpo_j, uint2* __restrict__ work,
                                               u32* __restrict__ work_count, u32* lds /* [8] */) {
     const u32 lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    const u32 np = in_subset ? (nshared[j] + (u32)EXCL_PIECE_C - 1u) / (u32)EXCL_PIECE_C : 0u;
+    const u32 np = in_subset ? (nshared_j + (u32)EXCL_PIECE_C - 1u) / (u32)EXCL_PIECE_C : 0u;
     u32 v = np;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -195,10 +194,7 @@ __device__ __forceinline__ void append_pieces(bool in_subset, u32 j, const u32* 
     __syncthreads();
     u32 at = lds[4] + v - np;
     for (u32 q = 0; q < wv; ++q) at += lds[q];
-    if (np) {
-        const u32 first = rpo[j];
-        for (u32 i = 0; i < np; ++i) work[at + i] = make_uint2(j, first + i * (u32)EXCL_PIECE_C);
-    }
+    for (u32 i = 0; i < np; ++i) work[at + i] = make_uint2(j, rpo_j + i * (u32)EXCL_PIECE_C);
 }
 
 __global__ void __launch_bounds__(256) k_reduce_replicas(u32* __restrict__ reps, u32 R, u64 n,
@@ -208,6 +204,13 @@ __global__ void __launch_bounds__(256) k_reduce_replicas(u32* __restrict__ reps,
     __shared__ u32 lds[8];
     const u64 j = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     u32 acc = 0;
+    // everything this thread reads is requested up front (one memory round trip, not one per dependent use)
+    u32 size_j = 0, nshared_j = 0, rpo_j = 0;
+    if (j < n && fused.reps2) {
+        size_j = fused.sizes[j];
+        nshared_j = fused.nshared[j];
+        if (fused.work) rpo_j = fused.rpo[j];
+    }
     if (j < n) {
         for (u32 r = 0; r < R; ++r) {
             acc += reps[(u64)r * n + j];
@@ -223,7 +226,7 @@ __global__ void __launch_bounds__(256) k_reduce_replicas(u32* __restrict__ reps,
                 fused.reps2[(u64)r * n + j] = 0;
             }
             fused.n_match[j] = acc - acc2;
-            fused.n_excl[j] = acc ? fused.sizes[j] - fused.nshared[j] : 0u;
+            fused.n_excl[j] = acc ? size_j - nshared_j : 0u;
         }
     }
     if (maskbits) {
@@ -237,7 +240,7 @@ __global__ void __launch_bounds__(256) k_reduce_replicas(u32* __restrict__ reps,
             }
         }
     }
-    if (fused.work) append_pieces(acc != 0 && j < fused.work_refs, (u32)j, fused.nshared, fused.rpo, fused.work, fused.work_count, lds);
+    if (fused.work) append_pieces(acc != 0 && j < fused.work_refs, (u32)j, nshared_j, rpo_j, fused.work, fused.work_count, lds);
 }
 
 // the same work list for a subset that arrives as bits (general path); work_count zeroed by the caller
@@ -247,7 +250,7 @@ __global__ void __launch_bounds__(256) k_excl_worklist(u64 n, const u32* __restr
     __shared__ u32 lds[8];
     const u64 j = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     const bool in = j < n && ((maskbits[j >> 5] >> (j & 31u)) & 1u);
-    append_pieces(in, (u32)j, nshared, rpo, work, work_count, lds);
+    append_pieces(in, (u32)j, in ? nshared[j] : 0u, in ? rpo[j] : 0u, work, work_count, lds);
 }
 
 // Sharded run: the subset bits of the GHOST references (copies of other ranks' references that share a

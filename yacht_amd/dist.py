@@ -133,7 +133,9 @@ _SIGN = -(2 ** 63)  # int64 bit pattern 0x8000...: x ^ _SIGN turns unsigned orde
 
 
 class HipBackend:
-    """The compute side of ShardedRun on the HIP engine (the only one the product uses)."""
+    """The compute side of ShardedRun on the HIP engine.  Both handles are pointed at torch's CURRENT stream
+    when they are made, so the library's kernels, torch's fills and the collectives torch issues on that
+    stream are ordered by the stream itself: no host synchronisation per sample."""
 
     def __init__(self, device_index: int):
         self.device_index = device_index
@@ -143,17 +145,16 @@ class HipBackend:
 
         from .engine import RefDB, YH_DB_NO_INDEX
 
-        torch.cuda.current_stream().synchronize()
+        torch.cuda.current_stream().synchronize()  # build-time only: the CSR tensors are complete
         n = offsets_t.numel() - 1
         db = RefDB.from_device(values_t.data_ptr(), offsets_t.data_ptr(), n, device=self.device_index,
                                flags=YH_DB_NO_INDEX)
+        db.set_stream(torch.cuda.current_stream().cuda_stream)
         info = db.info()
 
         def overlap(sample_t):
             out = torch.zeros(n, dtype=torch.int32, device=sample_t.device)
-            torch.cuda.current_stream().synchronize()
             db.overlap_device(sample_t.data_ptr(), sample_t.numel(), out.data_ptr())
-            db.synchronize()
             return out
 
         return {"overlap": overlap, "partition_shift": info["partition_shift"], "handle": db}
@@ -163,33 +164,29 @@ class HipBackend:
 
         from .engine import RefDB
 
-        torch.cuda.current_stream().synchronize()
+        torch.cuda.current_stream().synchronize()  # build-time only
         db = RefDB.from_pairs(hashes_t.data_ptr(), refs_t.data_ptr(), hashes_t.numel(), n_total, partition_shift,
                               max_hash, device=self.device_index)
+        db.set_stream(torch.cuda.current_stream().cuda_stream)
         dev = hashes_t.device
 
         def partial(mask_t, sample_t):
             out = torch.zeros((3, n_total), dtype=torch.int32, device=dev)
-            torch.cuda.current_stream().synchronize()
             db.exclusive_partial_device(mask_t.data_ptr(), sample_t.data_ptr(), sample_t.numel(), out[0].data_ptr(),
                                         out[1].data_ptr(), out[2].data_ptr())
-            db.synchronize()
             return out
 
         def nshared():
             out = torch.zeros(n_total, dtype=torch.int32, device=dev)
             db.nshared_device(out.data_ptr())
-            db.synchronize()
             return out
 
         def finalize(mask_t, sizes_t, nshared_t, overlap_t, sums_t):
             e = torch.zeros(n_total, dtype=torch.int32, device=dev)
             m = torch.zeros(n_total, dtype=torch.int32, device=dev)
-            torch.cuda.current_stream().synchronize()
             db.exclusive_finalize_device(n_total, mask_t.data_ptr(), sizes_t.data_ptr(), nshared_t.data_ptr(),
                                          overlap_t.data_ptr(), sums_t[0].data_ptr(), sums_t[1].data_ptr(),
                                          sums_t[2].data_ptr(), e.data_ptr(), m.data_ptr())
-            db.synchronize()
             return e, m
 
         return {"partial": partial, "nshared": nshared, "finalize": finalize, "handle": db}
