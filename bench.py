@@ -71,6 +71,7 @@ def parse_args():
     ap.add_argument("--sync-gather", action="store_true", help="N>1: blocking gather of the count rows inside every step")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to test the N>1 logic)")
     ap.add_argument("--share-gpu", action="store_true", help="testing: all ranks use cuda:0 (1-GPU box, gloo backend)")
+    ap.add_argument("--force-dist", action="store_true", help="testing: take the N > 1 code path (process group, ShardedRefDB, gathers) with one rank")
     return ap.parse_args()
 
 
@@ -118,8 +119,10 @@ def main() -> int:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    multi = world > 1 or args.force_dist  # the N > 1 code path
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -154,7 +157,7 @@ def main() -> int:
     K = max(args.samples, 1)
     samples = [synth.global_db_sample_device(plan, args.seed + 1000 + i, n_sample=args.sample_hashes, n_present=n_present,
                                              device=str(dev)) for i in range(K)]
-    if world > 1:  # the samples are replicated: every rank queries rank 0's (deterministic, but make it certain)
+    if multi:  # the samples are replicated: every rank queries rank 0's (deterministic, but make it certain)
         def bcast(t):
             c = ydist._stage(t, None)
             dist.broadcast(c, 0)
@@ -173,7 +176,7 @@ def main() -> int:
     stream = torch.cuda.Stream(device=dev)
     sdb = None
     with torch.cuda.stream(stream):
-        if world > 1:
+        if multi:
             sdb = ydist.ShardedRefDB(values, offsets, ydist.HipLocalBackend(local_rank))
             db = sdb.local.handle
             n_rows = torch.tensor([sdb.n_rows], device=dev, dtype=torch.int64)
@@ -193,10 +196,10 @@ def main() -> int:
     # overlaps the kernels of sample k+1; a set is reused only after the collective reading it completed.
     NBUF = 2
     counts_b = [torch.zeros((3, row_stride), device=dev, dtype=torch.int32) for _ in range(NBUF)]
-    gathered_b = [torch.zeros((world, 3, row_stride), device=dev, dtype=torch.int32) if world > 1 else None
+    gathered_b = [torch.zeros((world, 3, row_stride), device=dev, dtype=torch.int32) if multi else None
                   for _ in range(NBUF)]
     pending = [None] * NBUF
-    staged_gather = world > 1 and args.backend != "nccl"
+    staged_gather = multi and args.backend != "nccl"
     state = {"i": 0}
 
     def step():
@@ -229,7 +232,7 @@ def main() -> int:
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -244,7 +247,7 @@ def main() -> int:
     drain()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = ydist._stage(torch.tensor([elapsed], device=dev, dtype=torch.float64), None)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -278,7 +281,7 @@ def main() -> int:
                 sdb.run(samples[i], c)
                 results.append(sdb.gather(c))
     torch.cuda.synchronize()
-    if world > 1:  # the step's own gather must carry this rank's rows
+    if multi:  # the step's own gather must carry this rank's rows
         for b in range(NBUF):
             assert bool(torch.equal(gathered_b[b][rank], counts_b[b])), "gather ran ahead of the kernels"
 
@@ -286,7 +289,7 @@ def main() -> int:
     indexed = host_inclusive = real_shape = None
     paths = {}
     default_choice = db.lookup_choice(n_sample)  # (the sharded step asks the same question inside yh_run_local_device)
-    if world == 1:
+    if not multi:
         timing_default = timing
         cpath = torch.zeros((3, n_local), device=dev, dtype=torch.int32)
 
@@ -321,7 +324,7 @@ def main() -> int:
         db.set_lookup(ylib.YH_LOOKUP_AUTO)
         indexed = paths.get("indexed")
 
-    if world == 1 and not args.no_host_inclusive:
+    if not multi and not args.no_host_inclusive:
         # SURVEY.md 8d's metric: wall time of the steady-state call INCLUDING sample H2D and counts D2H.
         # Page-locked host buffers, yh_run_submit / yh_run_wait, DEPTH calls in flight.
         DEPTH = max(1, min(args.host_depth, 4))
@@ -396,7 +399,7 @@ def main() -> int:
             pa.close()
 
     real_samples = []
-    if world == 1 and not args.no_real_shape and args.workload == "gtdb_rs214_scale":
+    if not multi and not args.no_real_shape and args.workload == "gtdb_rs214_scale":
         # the hit shape of the reference's shipped results: ~29 % of the references overlap
         real_samples = [synth.global_db_sample_device(plan, args.seed + 5000 + i, n_sample=83_000, device=str(dev),
                                                       shape="real") for i in range(4)]
@@ -536,7 +539,7 @@ def main() -> int:
     if rank == 0 and not args.no_cpu_baseline:
         from oracle import oracle  # the checker; never the thing measured as `value`
 
-        if world == 1:
+        if not multi:
             h_values = values.cpu().numpy().view(np.uint64)
             h_offsets = offsets.cpu().numpy().view(np.uint64)
         else:  # regenerate the other shards here, one at a time (the generator is a pure function of the plan)
@@ -571,7 +574,7 @@ def main() -> int:
             real_shape["parity_bit_exact"] = bool(np.array_equal(got[0], want_ov) and np.array_equal(got[1], want_e)
                                                   and np.array_equal(got[2], want_m))
             parity = parity and real_shape["parity_bit_exact"]
-        if world == 1:
+        if not multi:
             cpu_baseline = {
                 "value": round(n_par * n_total / (t_ov + t_ex), 1),
                 "unit": "queries/s",
@@ -615,7 +618,7 @@ def main() -> int:
                 "db_build_ms": round(float(timing["ms_db_build"]), 2),
                 "db_hbm_bytes": info["device_bytes"],
                 "step": "overlap + exclusive counts" + ((" (subset bits all-gathered inside the step) + all_gather of the count rows"
-                                                       + ("" if args.sync_gather else " (overlapped with the next sample)")) if world > 1 else ""),
+                                                       + ("" if args.sync_gather else " (overlapped with the next sample)")) if multi else ""),
                 "parallelism": f"one database, references sharded x{world} by hash count",
                 "scipy": scipy_version,
             },
@@ -634,7 +637,7 @@ def main() -> int:
         sdb.close()
     else:
         db.close()
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0 and any(not p_["equals_default_path"] for p_ in paths.values()):

@@ -108,6 +108,30 @@ def test_sharded_refdb_hip_processes_share_gpu(hip_lib, tmp_path, world, lookup)
     assert all(rc == 0 for rc in rcs), "\n".join(outs)
 
 
+def test_sharded_refdb_over_rccl_one_rank(hip_lib, tmp_path):
+    """The real backend: torch.distributed "nccl" (= RCCL) with one rank, every collective of the exchange and of the
+    step forced to run (YH_FORCE_EXCHANGE=1) -- what a 1-GPU box can check of the call shapes the 8-GPU run uses."""
+    script = tmp_path / "worker_rccl.py"
+    script.write_text(WORKER.replace('dist.init_process_group("gloo")',
+                                     'dist.init_process_group("nccl", device_id=dev)'))
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               YH_ROOT=ROOT, YH_NREFS="3000", HSA_ENABLE_IPC_MODE_LEGACY="0", YH_FORCE_EXCHANGE="1")
+    p = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
+
+
+def test_bench_over_rccl_one_rank(hip_lib):
+    """bench.py's N > 1 code path (ShardedRefDB step + async gather of the count rows) on RCCL with one rank."""
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               HSA_ENABLE_IPC_MODE_LEGACY="0", YH_FORCE_EXCHANGE="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "6", "--warmup", "2",
+                        "--refs", "4000", "--sample-hashes", "100000", "--samples", "3", "--percentile-steps", "8", "--present", "50"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout + p.stderr
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    assert line["parity_bit_exact"] is True and line["config"]["parallelism"].startswith("one database")
+
+
 def test_bench_two_ranks_share_gpu_strong_and_weak(hip_lib, tmp_path):
     """bench.py --gpus 2 over gloo on one GPU: the driver-run N > 1 path, bit-exact against the oracle."""
     for scaling in ("strong", "weak"):

@@ -11,6 +11,7 @@ Torch is plumbing here (process group + collectives); the compute callables are 
 """
 from __future__ import annotations
 
+import os
 from typing import Callable, List, Sequence, Tuple
 
 import numpy as np
@@ -411,7 +412,10 @@ class ShardedRefDB:
         ghost_vals = torch.zeros(0, dtype=torch.int64, device=dev)
         ghost_sizes = torch.zeros(0, dtype=torch.int64, device=dev)
         ghost_src = torch.zeros(0, dtype=torch.int32, device=dev)
-        if world > 1:
+        # (YH_FORCE_EXCHANGE=1: run every collective of the build and of the step with ONE rank too -- how the
+        # RCCL call shapes and dtypes are exercised on a 1-GPU box)
+        self.exchange = world > 1 or os.environ.get("YH_FORCE_EXCHANGE") == "1"
+        if self.exchange:
             # (hash, global bit id) pairs in hash order, cut at the owners' range bounds
             key = values_t ^ _SIGN  # signed order == unsigned hash order
             top = key.max().reshape(1).clone() if values_t.numel() else torch.tensor([_SIGN], dtype=torch.int64, device=dev)
@@ -424,7 +428,7 @@ class ShardedRefDB:
             del perm
             bounds = [(((max_hash + 1) * d) // world) for d in range(1, world)]
             bkeys = torch.tensor([(b - 2 ** 63) for b in bounds], dtype=torch.int64, device=dev)
-            cuts = [0] + [int(c) for c in torch.searchsorted(key, bkeys).tolist()] + [int(key.numel())]
+            cuts = [0] + ([int(c) for c in torch.searchsorted(key, bkeys).tolist()] if world > 1 else []) + [int(key.numel())]
             send = [cuts[d + 1] - cuts[d] for d in range(world)]
             h_in, _ = all_to_all_v(key, send, group)       # (still in signed-order form)
             g_in, _ = all_to_all_v(gid, send, group)
@@ -490,7 +494,7 @@ class ShardedRefDB:
         if counts_t is None:
             counts_t = self.new_counts()
         self.local.run_local(sample_t, counts_t, self.bits_local)
-        if self.world > 1:
+        if self.exchange:
             all_gather_into(self.bits_global, self.bits_local[: self.words], group=self.group)
             self.local.run_finish(self.bits_global, counts_t)
         else:
