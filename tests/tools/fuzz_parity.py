@@ -23,7 +23,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 
 from oracle import oracle  # noqa: E402  (the checker)
-from yacht_amd import synth  # noqa: E402
+from yacht_amd import _lib, synth  # noqa: E402
 from yacht_amd.engine import RefDB, YH_DB_KEEP_CSR  # noqa: E402
 
 
@@ -81,15 +81,18 @@ def main() -> int:
         try:
             with RefDB(values, offsets, flags=YH_DB_KEEP_CSR) as db:
                 want = oracle.overlap(values, offsets, sample)
-                assert np.array_equal(db.overlap(sample), want), "overlap"
                 assert np.array_equal(db.overlap(sample, method="bsearch"), want), "bsearch overlap"
                 we, wm = oracle.exclusive(values, offsets, want > 0, sample)
-                ov, e, m = db.run_counts(sample)
-                assert np.array_equal(ov, want) and np.array_equal(e, we) and np.array_equal(m, wm), "run counts"
                 mask = rng.random(n) < 0.5
-                we, wm = oracle.exclusive(values, offsets, mask, sample)
-                ge, gm = db.exclusive(mask, sample)
-                assert np.array_equal(ge, we) and np.array_equal(gm, wm), "exclusive for a subset"
+                xe, xm = oracle.exclusive(values, offsets, mask, sample)
+                # every query through the streaming kernel, the sample-driven kernel, and the library's choice
+                for mode, name in ((_lib.YH_LOOKUP_STREAM, "stream"), (_lib.YH_LOOKUP_INDEXED, "indexed"), (_lib.YH_LOOKUP_AUTO, "auto")):
+                    db.set_lookup(mode)
+                    assert np.array_equal(db.overlap(sample), want), "overlap " + name
+                    ov, e, m = db.run_counts(sample)
+                    assert np.array_equal(ov, want) and np.array_equal(e, we) and np.array_equal(m, wm), "run counts " + name
+                    ge, gm = db.exclusive(mask, sample)
+                    assert np.array_equal(ge, xe) and np.array_equal(gm, xm), "exclusive for a subset " + name
                 if values.size < 400_000:
                     wi, wj, wc, wstats = oracle.train_pairs(values, offsets, c, threads=4)
                     gi, gj, gc = db.pairwise(c)

@@ -890,7 +890,7 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, const u
             IDX_HIP(hipMemcpyAsync(&n_chunks, d_cpo + N, sizeof(u32), hipMemcpyDeviceToHost, st));
             IDX_HIP(hipStreamSynchronize(st));
             db->n_chunks = n_chunks;
-            if (rc == YH_OK) rc = yh_dmalloc(db, (void**)&db->d_work, ((u64)n_chunks + 64) * sizeof(uint2));
+            if (rc == YH_OK) rc = yh_dmalloc(db, (void**)&db->d_work, ((u64)n_chunks + 64) * sizeof(uint4));
             if (rc == YH_OK) rc = yh_dmalloc(db, (void**)&db->d_work_count, 16);
             IDX_HIP(hipMemsetAsync(db->d_work_count, 0, 16, st));
             if (rc == YH_OK)

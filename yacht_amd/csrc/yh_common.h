@@ -109,7 +109,7 @@ static_assert(TILE_UNROLL32 * 4 <= 32, "candidate masks are 32-bit");
 
 // postings per work record of the reference-major exclusive pass (k_excl_pieces: one wave per record)
 #ifndef YH_EXCL_PIECE
-#define YH_EXCL_PIECE 512
+#define YH_EXCL_PIECE 256
 #endif
 #ifndef YH_EXCL_PIECE_THREADS
 #define YH_EXCL_PIECE_THREADS 512
@@ -191,9 +191,9 @@ struct yh_db {
     // exclusive pass visits only the chunks of masked references instead of streaming pr[]
     u32* d_rpo = nullptr;      // [N + 1] first posting of reference r in d_rg
     u32* d_rg = nullptr;       // [n_postings] shared-hash index, grouped by reference
-    // work list of the exclusive pass: (reference, first posting in d_rg) per piece of <= YH_EXCL_PIECE postings
+    // work list of the exclusive pass: (reference, first posting in d_rg, end) per piece of <= YH_EXCL_PIECE postings
     // of a reference in the subset; appended per query (k_reduce_replicas / k_excl_worklist); n_chunks = capacity
-    uint2* d_work = nullptr;
+    uint4* d_work = nullptr;
     u32* d_work_count = nullptr;
     uint4* d_rrec = nullptr;   // [n_postings] beside d_rg (stream layout): the other holders of the posting's hash,
                                // {o0, o1, o2, count <= 7} (others 3..6 in d_rrecx) or, for nine holders and

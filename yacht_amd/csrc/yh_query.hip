@@ -168,14 +168,14 @@ struct FusedRun {
     u32* bits_out;  // may be null: a second copy of the subset bits (the sharded run hands them to the other ranks)
     // work list of the exclusive pass behind this kernel: the posting pieces of the subset's references
     const u32* rpo;
-    uint2* work;
+    uint4* work;
     u32* work_count;  // zero when this kernel starts (the lookup kernel in front of it clears it)
     u32 work_refs;    // references below this number produce work (sharded run: the ghosts behind do not)
 };
 
-// Append the posting pieces of every reference in the subset to the work list: (reference, first posting)
-// per <= EXCL_PIECE postings.  One atomic per workgroup.  All 256 threads of the block must call it.
-__device__ __forceinline__ void append_pieces(bool in_subset, u32 j, u32 nshared_j, u32 rpo_j, uint2* __restrict__ work,
+// Append the posting pieces of every reference in the subset to the work list: (reference, first posting,
+// end) per <= EXCL_PIECE postings.  One atomic per workgroup.  All 256 threads of the block must call it.
+__device__ __forceinline__ void append_pieces(bool in_subset, u32 j, u32 nshared_j, u32 rpo_j, uint4* __restrict__ work,
                                               u32* __restrict__ work_count, u32* lds /* [8] */) {
     const u32 lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const u32 np = in_subset ? (nshared_j + (u32)EXCL_PIECE_C - 1u) / (u32)EXCL_PIECE_C : 0u;
@@ -194,7 +194,11 @@ __device__ __forceinline__ void append_pieces(bool in_subset, u32 j, u32 nshared
     __syncthreads();
     u32 at = lds[4] + v - np;
     for (u32 q = 0; q < wv; ++q) at += lds[q];
-    for (u32 i = 0; i < np; ++i) work[at + i] = make_uint2(j, rpo_j + i * (u32)EXCL_PIECE_C);
+    const u32 last = rpo_j + nshared_j;  // (= rpo[j + 1]: the record carries its end, one read less per piece)
+    for (u32 i = 0; i < np; ++i) {
+        const u32 first = rpo_j + i * (u32)EXCL_PIECE_C;
+        work[at + i] = make_uint4(j, first, min(first + (u32)EXCL_PIECE_C, last), 0u);
+    }
 }
 
 __global__ void __launch_bounds__(256) k_reduce_replicas(u32* __restrict__ reps, u32 R, u64 n,
@@ -245,7 +249,7 @@ __global__ void __launch_bounds__(256) k_reduce_replicas(u32* __restrict__ reps,
 
 // the same work list for a subset that arrives as bits (general path); work_count zeroed by the caller
 __global__ void __launch_bounds__(256) k_excl_worklist(u64 n, const u32* __restrict__ maskbits, const u32* __restrict__ nshared,
-                                                       const u32* __restrict__ rpo, uint2* __restrict__ work,
+                                                       const u32* __restrict__ rpo, uint4* __restrict__ work,
                                                        u32* __restrict__ work_count) {
     __shared__ u32 lds[8];
     const u64 j = blockIdx.x * (u64)blockDim.x + threadIdx.x;
@@ -1598,9 +1602,12 @@ __device__ __forceinline__ u32 others_in_subset(const uint4 rec, const uint4 rec
 #ifndef YH_EXCL_GRID
 #define YH_EXCL_GRID 2048
 #endif
+#ifndef YH_EXCL_RECX_ALWAYS
+#define YH_EXCL_RECX_ALWAYS 0
+#endif
 constexpr int EXCL_PIECE_THREADS = YH_EXCL_PIECE_THREADS;  // waves of a workgroup share the staging of the subset bits
 template <bool LDSMASK>
-__global__ void __launch_bounds__(EXCL_PIECE_THREADS) k_excl_pieces(const u32* __restrict__ work_count, const uint2* __restrict__ work,
+__global__ void __launch_bounds__(EXCL_PIECE_THREADS) k_excl_pieces(const u32* __restrict__ work_count, const uint4* __restrict__ work,
                                                      const u32* __restrict__ rpo, const u32* __restrict__ rg,
                                                      const uint4* __restrict__ rrec, const uint4* __restrict__ rrecx,
                                                      const u64* __restrict__ po, u32 n_post, const u32* __restrict__ pr,
@@ -1612,6 +1619,10 @@ __global__ void __launch_bounds__(EXCL_PIECE_THREADS) k_excl_pieces(const u32* _
     const u32 lane = threadIdx.x & 63u;
     const u32 n_work = *work_count;
     if (blockIdx.x * WPB >= n_work) return;  // (the grid is sized for every piece of the database)
+    // this wave's first record is requested before the subset bits are staged: one round trip for both
+    const u32 w0 = blockIdx.x * WPB + (threadIdx.x >> 6);
+    uint4 first_rec = make_uint4(0u, 0u, 0u, 0u);
+    if (w0 < n_work) first_rec = work[w0];
     if (LDSMASK) {  // the subset bits into LDS (16-byte reads)
         const uint4* src = reinterpret_cast<const uint4*>(maskbits);
         uint4* dst = reinterpret_cast<uint4*>(lmask);
@@ -1620,10 +1631,10 @@ __global__ void __launch_bounds__(EXCL_PIECE_THREADS) k_excl_pieces(const u32* _
     }
     auto mword = [&](u32 i) -> u32 { return LDSMASK ? lmask[i] : maskbits[i]; };
     constexpr int U = EXCL_U;
-    for (u32 w = blockIdx.x * WPB + (threadIdx.x >> 6); w < n_work; w += gridDim.x * WPB) {
-        const uint2 mine = work[w];
+    for (u32 w = w0; w < n_work; w += gridDim.x * WPB) {
+        const uint4 mine = (w == w0) ? first_rec : work[w];
         const u32 r = mine.x;
-        const u32 end = min(mine.y + EXCL_PIECE, rpo[r + 1]);
+        const u32 end = mine.z;
         u32 acc_e = 0, acc_m = 0, acc_o = 0;
         for (u32 k0 = mine.y; k0 < end; k0 += 64u * U) {
             u32 k[U];
@@ -1640,7 +1651,7 @@ __global__ void __launch_bounds__(EXCL_PIECE_THREADS) k_excl_pieces(const u32* _
                 recx[u] = make_uint4(0u, 0u, 0u, 0u);
             }
             if (rrec) {  // holders 3..6: read only by the waves that have a posting with more than three others
-                bool more = false;
+                bool more = YH_EXCL_RECX_ALWAYS != 0;
 #pragma unroll
                 for (int u = 0; u < U; ++u) more |= valid[u] && rec[u].w > 3u && rec[u].w != 0xffffffffu;
                 if (__ballot(more)) {
