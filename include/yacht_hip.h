@@ -202,9 +202,11 @@ int yh_run_device(yh_db* db, const uint64_t* d_sample, uint64_t n_sample,
  *                         of d_n_excl is added.  Rows of ghosts and padding in the outputs are garbage.
  * yh_db_set_ghosts registers the ghost range and their bit positions once per handle.            */
 int yh_db_set_ghosts(yh_db* db, uint64_t ghost_begin, uint64_t n_ghost, const uint32_t* d_ghost_src);
-int yh_run_local_device(yh_db* db, const uint64_t* d_sample, uint64_t n_sample, uint32_t* d_overlap,
+/* `ctx` (0 or 1) names the step context the two halves share: with two contexts the lookup of sample k+1
+ * (ctx 1) can be queued while the exchange of sample k (ctx 0) is still in flight.                      */
+int yh_run_local_device(yh_db* db, int ctx, const uint64_t* d_sample, uint64_t n_sample, uint32_t* d_overlap,
                         uint32_t* d_n_excl, uint32_t* d_n_match, uint32_t* d_bits_out);
-int yh_run_finish_device(yh_db* db, const uint32_t* d_global_bits, uint32_t* d_n_excl);
+int yh_run_finish_device(yh_db* db, int ctx, const uint32_t* d_global_bits, uint32_t* d_n_excl);
 
 /* Pipelined host-buffer form of yh_run: SURVEY.md 8d's steady-state call -- sample H2D, kernels,
  * counts D2H -- split in two so that consecutive samples overlap.  yh_run_submit queues, on two

@@ -39,7 +39,7 @@ class SetLocalBackend:
         state = {}
 
         class L:
-            def run_local(self, sample_t, counts_t, bits_t):
+            def run_local(self, sample_t, counts_t, bits_t, ctx=0):
                 S = set(sample_t.numpy().view(np.uint64).tolist())
                 ov = np.array([len(S & r) for r in refs], dtype=np.int64)
                 sh = np.array([sum(1 for h in (S & r) if h in shared) for r in refs], dtype=np.int64)
@@ -50,11 +50,11 @@ class SetLocalBackend:
                 for j in np.flatnonzero(ov > 0):
                     bits[j >> 5] |= np.uint32(1 << (j & 31))
                 bits_t.copy_(torch.from_numpy(bits.view(np.int32)))
-                state["mask"] = ov > 0
+                state[ctx] = ov > 0
 
-            def run_finish(self, global_bits_t, counts_t):
+            def run_finish(self, global_bits_t, counts_t, ctx=0):
                 gb = global_bits_t.numpy().view(np.uint32)
-                mask = state["mask"].copy()
+                mask = state[ctx].copy()
                 for k, b in enumerate(gsrc.tolist()):
                     mask[ghost_begin + k] = bool((gb[b >> 5] >> (b & 31)) & 1)
                 e = counts_t[1].numpy().copy()
@@ -100,7 +100,17 @@ def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
                 np.unique(rng.integers(0, 2 ** 40, size=500, dtype=np.uint64))
             sample = np.union1d(sample, np.array(extra, dtype=np.uint64))
             st = torch.from_numpy(sample.view(np.int64).copy())
-            full = sdb.gather(sdb.run(st)).numpy().view(np.uint32)
+            if present and not extra:  # two steps in flight in the two contexts: begin(0), begin(1), end(0), end(1)
+                other = np.unique(rng.integers(0, 2 ** 40, size=300, dtype=np.uint64))
+                c0, c1 = sdb.new_counts(), sdb.new_counts()
+                sdb.run_begin(st, c0, 0)
+                sdb.run_begin(torch.from_numpy(other.view(np.int64).copy()), c1, 1)
+                sdb.run_end(c0, 0)
+                sdb.run_end(c1, 1)
+                full = sdb.gather(c0).numpy().view(np.uint32)
+                assert not sdb.gather(c1).numpy()[0].any()  # (the noise sample overlaps nothing)
+            else:
+                full = sdb.gather(sdb.run(st)).numpy().view(np.uint32)
             want_ov = oracle.overlap(values, offsets, sample)
             want_e, want_m = oracle.exclusive(values, offsets, want_ov > 0, sample)
             assert np.array_equal(full[0], want_ov), f"rank {rank}: overlap"

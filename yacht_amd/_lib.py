@@ -106,8 +106,8 @@ SIGNATURES = {
     "yh_run": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp, _vp]),
     "yh_run_device": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp, _vp]),
     "yh_db_set_ghosts": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _vp]),
-    "yh_run_local_device": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp, _vp, _vp]),
-    "yh_run_finish_device": (C.c_int, [_vp, _vp, _vp]),
+    "yh_run_local_device": (C.c_int, [_vp, C.c_int, _vp, C.c_uint64, _vp, _vp, _vp, _vp]),
+    "yh_run_finish_device": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "yh_run_submit": (C.c_int, [_vp, C.c_int, _vp, C.c_uint64, _vp, _vp, _vp]),
     "yh_run_wait": (C.c_int, [_vp, C.c_int]),
     "yh_host_alloc": (C.c_int, [C.POINTER(_vp), C.c_uint64]),

@@ -331,6 +331,14 @@ int yh_db_destroy(yh_db* db) {
     if (!db) return YH_OK;
     if (db->device >= 0) (void)hipSetDevice(db->device);
     if (db->stream) (void)hipStreamSynchronize(db->stream);
+    if (db->ctx_bits[0]) {  // the step contexts: back to the handle's own arrays, the second set freed here
+        db->d_maskbits = db->ctx_bits[0];
+        db->d_work = db->ctx_work[0];
+        db->d_work_count = db->ctx_count[0];
+        if (db->ctx_bits[1]) (void)hipFree(db->ctx_bits[1]);
+        if (db->ctx_work[1]) (void)hipFree(db->ctx_work[1]);
+        if (db->ctx_count[1]) (void)hipFree(db->ctx_count[1]);
+    }
     void* ptrs[] = {db->d_values, db->d_offsets, db->d_pvals, db->d_pbeg, db->d_pcnt, db->d_poffs, db->d_sizes,
                     db->d_g, db->d_po, db->d_pr, db->d_pg, db->d_gbeg, db->d_gcnt, db->d_nshared, db->d_pq, db->d_pq_count, db->d_dh, db->d_dref, db->d_dir, db->d_bkt, db->d_cbkt, db->d_ovf_keys, db->d_ovf_vals, db->d_pkeys, db->d_pref, db->d_gkeys, db->d_rpo, db->d_rg, db->d_rrec, db->d_rrecx, db->d_work, db->d_work_count, db->d_sbounds,
                     db->d_mask, db->d_maskbits, db->d_hit, db->d_excl_e, db->d_overlap_tmp,
@@ -757,21 +765,48 @@ int yh_db_set_ghosts(yh_db* db, uint64_t ghost_begin, uint64_t n_ghost, const ui
     return YH_OK;
 }
 
-int yh_run_local_device(yh_db* db, const uint64_t* d_sample, uint64_t n_sample, uint32_t* d_overlap, uint32_t* d_n_excl,
+// point the handle's step state (subset bits, work list) at context c
+static int use_ctx(yh_db* db, int c) {
+    if (c < 0 || c > 1) { yh_set_error("step context must be 0 or 1"); return YH_ERR_INVALID_ARG; }
+    if (!db->ctx_bits[0]) {  // first use: context 0 = the handle's own arrays
+        db->ctx_bits[0] = db->d_maskbits;
+        db->ctx_work[0] = db->d_work;
+        db->ctx_count[0] = db->d_work_count;
+    }
+    if (c == 1 && !db->ctx_bits[1]) {
+        const u64 N = db->n_refs;
+        YH_TRY(yh_dmalloc(db, (void**)&db->ctx_bits[1], ((N + 255) / 256) * 32 + 16));
+        YH_HIP(hipMemsetAsync(db->ctx_bits[1], 0, ((N + 255) / 256) * 32 + 16, db->stream));
+        if (db->d_work) {
+            YH_TRY(yh_dmalloc(db, (void**)&db->ctx_work[1], ((u64)db->n_chunks + 64) * sizeof(uint4)));
+            YH_TRY(yh_dmalloc(db, (void**)&db->ctx_count[1], 16));
+            YH_HIP(hipMemsetAsync(db->ctx_count[1], 0, 16, db->stream));
+        }
+    }
+    db->d_maskbits = db->ctx_bits[c];
+    db->d_work = db->ctx_work[c];
+    db->d_work_count = db->ctx_count[c];
+    db->ctx_now = c;
+    return YH_OK;
+}
+
+int yh_run_local_device(yh_db* db, int ctx, const uint64_t* d_sample, uint64_t n_sample, uint32_t* d_overlap, uint32_t* d_n_excl,
                         uint32_t* d_n_match, uint32_t* d_bits_out) {
     if (!db_ok(db)) return YH_ERR_INVALID_ARG;
     if (!d_overlap || !d_n_excl || !d_n_match || (n_sample && !d_sample)) { yh_set_error("null device pointer"); return YH_ERR_INVALID_ARG; }
     YH_TRY(db_select(db));
+    YH_TRY(use_ctx(db, ctx));
     const int rc = yh_q_run_fused(db, (const u64*)d_sample, n_sample, d_overlap, d_n_excl, d_n_match, 1, d_bits_out, nullptr,
                                   prefer_indexed(db, n_sample));
     if (rc == 1) { yh_set_error("yh_run_local_device needs a non-empty handle in the default layout with its index"); return YH_ERR_UNSUPPORTED; }
     return rc;
 }
 
-int yh_run_finish_device(yh_db* db, const uint32_t* d_global_bits, uint32_t* d_n_excl) {
+int yh_run_finish_device(yh_db* db, int ctx, const uint32_t* d_global_bits, uint32_t* d_n_excl) {
     if (!db_ok(db)) return YH_ERR_INVALID_ARG;
     if (!d_n_excl || (db->n_ghost && !d_global_bits)) { yh_set_error("null device pointer"); return YH_ERR_INVALID_ARG; }
     YH_TRY(db_select(db));
+    YH_TRY(use_ctx(db, ctx));
     const int rc = yh_q_run_fused(db, nullptr, 1, nullptr, d_n_excl, nullptr, 2, nullptr, d_global_bits);
     if (rc == 1) { yh_set_error("yh_run_finish_device needs a non-empty handle in the default layout with its index"); return YH_ERR_UNSUPPORTED; }
     return rc;

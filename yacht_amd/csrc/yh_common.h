@@ -266,6 +266,14 @@ struct yh_db {
     u32* h_pw_j = nullptr;
     u32* h_pw_c = nullptr;
 
+    // Two step contexts for the sharded run: what yh_run_local_device leaves for yh_run_finish_device (subset bits,
+    // work list).  With two of them the lookup of sample k+1 runs while the bit exchange of sample k is in flight.
+    // ctx_bits[0] / ctx_work[0] / ctx_count[0] are the handle's own arrays; [1] is allocated on first use.
+    u32* ctx_bits[2] = {nullptr, nullptr};
+    uint4* ctx_work[2] = {nullptr, nullptr};
+    u32* ctx_count[2] = {nullptr, nullptr};
+    int ctx_now = 0;
+
     // sharded run (yh_db_set_ghosts): references [ghost_begin, ghost_begin + n_ghost) are copies of other
     // ranks' references; their subset bits come from the owners (k_ghost_bits)
     u32* d_ghost_src = nullptr;  // [n_ghost] bit index into the all-gathered subset bits

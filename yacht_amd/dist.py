@@ -362,12 +362,12 @@ class HipLocalBackend:
             def bind_stream(self):
                 db.set_stream(torch.cuda.current_stream().cuda_stream)
 
-            def run_local(self, sample_t, counts_t, bits_t):
+            def run_local(self, sample_t, counts_t, bits_t, ctx=0):
                 db.run_local_device(sample_t.data_ptr(), sample_t.numel(), counts_t[0].data_ptr(), counts_t[1].data_ptr(),
-                                    counts_t[2].data_ptr(), bits_t.data_ptr())
+                                    counts_t[2].data_ptr(), bits_t.data_ptr(), ctx)
 
-            def run_finish(self, global_bits_t, counts_t):
-                db.run_finish_device(global_bits_t.data_ptr(), counts_t[1].data_ptr())
+            def run_finish(self, global_bits_t, counts_t, ctx=0):
+                db.run_finish_device(global_bits_t.data_ptr(), counts_t[1].data_ptr(), ctx)
 
             def close(self):
                 db.close()
@@ -480,26 +480,44 @@ class ShardedRefDB:
         self.local = backend.make_local_db(vals, offs.contiguous(), n_pad, ghost_src.contiguous())
         self._keep = (vals, offs, ghost_src)
         words_local = max(self.words, 2 * ((self.n_rows + 255) // 256) * 4 + 2)
-        self.bits_local = torch.zeros(words_local, dtype=torch.int32, device=dev)
-        self.bits_global = torch.zeros(world * self.words, dtype=torch.int32, device=dev)
+        # two step contexts: the lookup of sample k+1 is queued while the bit exchange of sample k is in flight
+        self.bits_local = [torch.zeros(words_local, dtype=torch.int32, device=dev) for _ in range(2)]
+        self.bits_global = [torch.zeros(world * self.words, dtype=torch.int32, device=dev) for _ in range(2)]
+        self._pending = [None, None]
 
     def new_counts(self):
         import torch
 
         return torch.zeros((3, self.n_rows), dtype=torch.int32, device=self.dev)
 
+    def run_begin(self, sample_t, counts_t, slot: int = 0):
+        """First half of a step in context `slot` (0 or 1): rank-local lookup + reduce, then the all-gather of
+        the subset bits is STARTED (RCCL: asynchronously, ordered behind the kernels).  run_end(slot) finishes."""
+        import torch.distributed as dist
+
+        self.local.run_local(sample_t, counts_t, self.bits_local[slot], slot)
+        if self.exchange:
+            mine = self.bits_local[slot][: self.words]
+            if mine.is_cuda and not _is_gloo(self.group):
+                self._pending[slot] = dist.all_gather_into_tensor(self.bits_global[slot], mine, group=self.group, async_op=True)
+            else:
+                all_gather_into(self.bits_global[slot], mine, group=self.group)
+
+    def run_end(self, counts_t, slot: int = 0):
+        """Second half: wait (on the stream) for the bits, ghosts take their owners' bits, posting-list pass."""
+        if self._pending[slot] is not None:
+            self._pending[slot].wait()
+            self._pending[slot] = None
+        self.local.run_finish(self.bits_global[slot] if self.exchange else self.bits_local[slot], counts_t, slot)
+        return counts_t
+
     def run(self, sample_t, counts_t=None):
         """One sample: this rank's [3, n_rows] counts (columns [0, n_local) are its references).
         Stream-ordered on the current stream; no host synchronisation with RCCL."""
         if counts_t is None:
             counts_t = self.new_counts()
-        self.local.run_local(sample_t, counts_t, self.bits_local)
-        if self.exchange:
-            all_gather_into(self.bits_global, self.bits_local[: self.words], group=self.group)
-            self.local.run_finish(self.bits_global, counts_t)
-        else:
-            self.local.run_finish(self.bits_local, counts_t)
-        return counts_t
+        self.run_begin(sample_t, counts_t, 0)
+        return self.run_end(counts_t, 0)
 
     def gather(self, counts_t):
         """[3, N_total] on every rank from the per-rank rows (one collective, shards padded)."""

@@ -198,12 +198,12 @@ class RefDB:
         _lib.check(self._lib.yh_db_set_ghosts(self._h, ghost_begin, n_ghost, C.c_void_p(d_ghost_src)))
 
     def run_local_device(self, d_sample: int, n_sample: int, d_overlap: int, d_excl: int, d_match: int,
-                         d_bits_out: int) -> None:
-        _lib.check(self._lib.yh_run_local_device(self._h, C.c_void_p(d_sample), n_sample, C.c_void_p(d_overlap),
+                         d_bits_out: int, ctx: int = 0) -> None:
+        _lib.check(self._lib.yh_run_local_device(self._h, ctx, C.c_void_p(d_sample), n_sample, C.c_void_p(d_overlap),
                                                  C.c_void_p(d_excl), C.c_void_p(d_match), C.c_void_p(d_bits_out)))
 
-    def run_finish_device(self, d_global_bits: int, d_excl: int) -> None:
-        _lib.check(self._lib.yh_run_finish_device(self._h, C.c_void_p(d_global_bits), C.c_void_p(d_excl)))
+    def run_finish_device(self, d_global_bits: int, d_excl: int, ctx: int = 0) -> None:
+        _lib.check(self._lib.yh_run_finish_device(self._h, ctx, C.c_void_p(d_global_bits), C.c_void_p(d_excl)))
 
     def run_submit(self, slot: int, sample: np.ndarray, overlap: np.ndarray, n_excl: np.ndarray,
                    n_match: np.ndarray) -> None:
