@@ -286,6 +286,24 @@ int yh_sig_batch_sizes(const yh_sig_batch* batch, uint64_t* offsets);
 int yh_sig_batch_values(const yh_sig_batch* batch, uint64_t* values);
 int yh_sig_batch_destroy(yh_sig_batch* batch);
 
+/* The two host passes `yacht train` makes over the signature files before the core (make_training_data_from_sketches.py
+ * :107-133, utils.py:201-221, :499-509), threaded:
+ *   yh_gunzip_files    every "x.sig.gz" -> "x.sig" next to it, the .gz removed (status[i]: 0 ok, 1 failed: left as it was)
+ *   yh_sig_meta_read   what get_info_from_single_sig takes from the ONE signature of k-mer size `ksize` in each file:
+ *                      record name, md5 of the sketch (md5 over str(ksize) + every hash in decimal), mean abundance,
+ *                      number of hashes, scaled = round(2^64 / max_hash).  status: 0 ok, 1 cannot open, 2 malformed,
+ *                      3 not exactly one signature of that k-mer size, 4 empty sketch, 5 a shape this reader leaves to
+ *                      the general (Python) one -- unsorted mins, non-integer fields.
+ *   yh_sig_meta_get    arrays of n entries; md5 as n x 33 bytes (NUL-terminated); name_offsets[n + 1] into the byte
+ *                      buffer yh_sig_meta_names fills (UTF-8, not terminated).                                       */
+typedef struct yh_sig_meta yh_sig_meta;
+int yh_gunzip_files(const char* const* paths, uint64_t n_paths, int threads, uint8_t* status);
+int yh_sig_meta_read(const char* const* paths, uint64_t n_paths, int ksize, int threads, yh_sig_meta** out);
+int yh_sig_meta_get(const yh_sig_meta* meta, uint8_t* status, uint64_t* n_hashes, uint64_t* scaled, double* mean_abundance,
+                    uint8_t* has_abundance, char* md5, uint64_t* name_offsets);
+int yh_sig_meta_names(const yh_sig_meta* meta, char* names);
+int yh_sig_meta_destroy(yh_sig_meta* meta);
+
 /* ---- sketching (next to the path: SURVEY.md §8f N2) --------------------------------------------
  * DNA FracMinHash as `sourmash sketch dna -p k=K,scaled=S,abund` defines it (the reference shells
  * out to it: sketch_ref_genomes.py:25,61, sketch_sample.py:32,49): every length-`ksize` window of

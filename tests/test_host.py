@@ -230,3 +230,67 @@ def test_batch_reader_reports_missing_and_malformed_files(tmp_path, capfd):
     nokey.write_text('[{"signatures": [{"ksize": 31}]}]')
     with pytest.raises(ValueError, match="could not be parsed"):
         train_core.read_sketches_csr([str(nokey)], threads=1)
+
+
+def test_native_metadata_pass_equals_reference_known_answers_and_python_reader(tmp_path):
+    """utils.collect_signature_info / decompress_all_sig_files on the library's threaded reader (yh_gunzip_files,
+    yh_sig_meta_*): the reference's own known answers for the 20 fixture genomes
+    (tests/unittests_data/test_collect_signature_info_data.json), and record-for-record the same as the Python
+    reader (get_info_from_single_sig) on files that exercise the scanner: escapes and non-ASCII in names, "name"
+    behind "signatures", several k-mer sizes in one file, no abundances, null abundances, an empty sketch, a file
+    without that k-mer size, a truncated file, unsorted mins (deferred to the Python reader), a .sig.gz left
+    compressed."""
+    import gzip as gz
+    import zipfile
+
+    work = tmp_path / "work"
+    (work / "signatures").mkdir(parents=True)
+    with zipfile.ZipFile(os.path.join(FX, "20_genomes_sketches.zip")) as z:
+        z.extractall(work)
+    packed = sorted(str(p) for p in (work / "signatures").glob("*.sig.gz"))
+    assert len(packed) == 20
+    utils.decompress_all_sig_files(packed, 4)
+    assert not list((work / "signatures").glob("*.gz")) and len(list((work / "signatures").glob("*.sig"))) == 20
+    want = json.load(open(os.path.join(FX, "test_collect_signature_info_data.json")))
+    info = utils.collect_signature_info(4, 31, str(work))
+    assert {k: [v[0], v[1], v[2], v[3]] for k, v in info.items()} == want
+    assert all(os.path.exists(v[4]) for v in info.values())
+
+    odd = tmp_path / "odd"
+    (odd / "signatures").mkdir(parents=True)
+
+    def sig(ksize, mins, ab="omit", max_hash=18446744073709552):
+        s = {"num": 0, "ksize": ksize, "seed": 42, "max_hash": max_hash, "mins": mins, "md5sum": "x", "molecule": "dna"}
+        if ab != "omit":
+            s["abundances"] = ab
+        return s
+
+    files = {
+        "escapes.sig": json.dumps([{"class": "sourmash_signature", "name": 'E. coli "K-12" \\ tab\there é中\U0001f9ec', "filename": "f",
+                                    "signatures": [sig(31, [3, 9, 27], [2, 3, 4])], "version": 0.4}]),
+        "name_last.sig": '[{"signatures":[' + json.dumps(sig(31, [5, 6])) + '],"filename":"x","name":"behind the signatures"}]',
+        "two_ksizes.sig": json.dumps([{"name": "two k", "signatures": [sig(21, [1, 2, 3], [1, 1, 1]), sig(31, [10, 20, 30, 40], [5, 1, 1, 1]),
+                                                                       sig(51, [7])]}]),
+        "null_ab.sig": json.dumps([{"name": "null abundances", "signatures": [sig(31, [11, 12, 13], None)]}]),
+        "scaled100.sig": json.dumps([{"name": "scaled 100", "signatures": [sig(31, [1, 2], [1, 2], 184467440737095520)]}]),
+        "empty.sig": json.dumps([{"name": "empty sketch", "signatures": [sig(31, [], [])]}]),
+        "other_k.sig": json.dumps([{"name": "no k31", "signatures": [sig(21, [1, 2])]}]),
+        "twice.sig": json.dumps([{"name": "two of k31", "signatures": [sig(31, [1]), sig(31, [2])]}]),
+        "cut.sig": '[{"name":"cut","signatures":[{"ksize":31,"mins":[1,2',
+        "unsorted.sig": json.dumps([{"name": "unsorted mins", "signatures": [sig(31, [9, 3, 3, 5], [1, 2, 2, 7])]}]),
+    }
+    for name, text in files.items():
+        (odd / "signatures" / name).write_text(text, encoding="utf-8")
+    with gz.open(odd / "signatures" / "still_packed.sig.gz", "wt", encoding="utf-8") as f:
+        f.write(json.dumps([{"name": "read through gzip", "signatures": [sig(31, [100, 200], [4, 6])]}]))
+    got = utils.collect_signature_info(3, 31, str(odd))
+    want = {}
+    for f in os.listdir(odd / "signatures"):
+        rec = utils.get_info_from_single_sig(str(odd / "signatures" / f), 31)
+        if rec:
+            want[rec[1]] = (rec[2], rec[3], rec[4], rec[5], rec[0])
+    assert got == want
+    assert set(got) == {'E. coli "K-12" \\ tab\there é中\U0001f9ec', "behind the signatures", "two k", "null abundances",
+                        "scaled 100", "unsorted mins", "read through gzip"}
+    assert got["two k"][1:4] == (2.0, 4, 1000) and got["null abundances"][1] is None and got["scaled 100"][3] == 100
+    assert got["unsorted mins"][2] == 3

@@ -125,3 +125,259 @@ inline std::vector<uint64_t> read_mins(const std::string& path, bool report = tr
 }
 
 }  // namespace yh_sig
+
+// ---- metadata of a signature file (the `yacht train` pass in front of the core: utils.py:89-110, :201-221) -----------
+// What get_info_from_single_sig takes from sourmash for the ONE signature of a given k-mer size in a file: the
+// record's name, the sketch's md5 (sourmash: md5 over str(ksize) followed by every hash in decimal, ascending),
+// the mean abundance, the number of hashes and `scaled` (= round(2^64 / max_hash)).
+namespace yh_sig {
+
+struct Md5 {  // RFC 1321, streaming
+    uint32_t a = 0x67452301u, b = 0xefcdab89u, c = 0x98badcfeu, d = 0x10325476u;
+    uint64_t len = 0;
+    unsigned char buf[64];
+    size_t fill = 0;
+    static uint32_t rol(uint32_t x, int s) { return (x << s) | (x >> (32 - s)); }
+    void block(const unsigned char* p) {
+        static const uint32_t K[64] = {
+            0xd76aa478, 0xe8c7b756, 0x242070db, 0xc1bdceee, 0xf57c0faf, 0x4787c62a, 0xa8304613, 0xfd469501, 0x698098d8, 0x8b44f7af,
+            0xffff5bb1, 0x895cd7be, 0x6b901122, 0xfd987193, 0xa679438e, 0x49b40821, 0xf61e2562, 0xc040b340, 0x265e5a51, 0xe9b6c7aa,
+            0xd62f105d, 0x02441453, 0xd8a1e681, 0xe7d3fbc8, 0x21e1cde6, 0xc33707d6, 0xf4d50d87, 0x455a14ed, 0xa9e3e905, 0xfcefa3f8,
+            0x676f02d9, 0x8d2a4c8a, 0xfffa3942, 0x8771f681, 0x6d9d6122, 0xfde5380c, 0xa4beea44, 0x4bdecfa9, 0xf6bb4b60, 0xbebfbc70,
+            0x289b7ec6, 0xeaa127fa, 0xd4ef3085, 0x04881d05, 0xd9d4d039, 0xe6db99e5, 0x1fa27cf8, 0xc4ac5665, 0xf4292244, 0x432aff97,
+            0xab9423a7, 0xfc93a039, 0x655b59c3, 0x8f0ccc92, 0xffeff47d, 0x85845dd1, 0x6fa87e4f, 0xfe2ce6e0, 0xa3014314, 0x4e0811a1,
+            0xf7537e82, 0xbd3af235, 0x2ad7d2bb, 0xeb86d391};
+        static const int S[64] = {7, 12, 17, 22, 7, 12, 17, 22, 7, 12, 17, 22, 7, 12, 17, 22, 5, 9, 14, 20, 5, 9, 14, 20, 5, 9, 14, 20, 5, 9, 14, 20,
+                                  4, 11, 16, 23, 4, 11, 16, 23, 4, 11, 16, 23, 4, 11, 16, 23, 6, 10, 15, 21, 6, 10, 15, 21, 6, 10, 15, 21, 6, 10, 15, 21};
+        uint32_t m[16];
+        for (int i = 0; i < 16; ++i) m[i] = (uint32_t)p[4 * i] | ((uint32_t)p[4 * i + 1] << 8) | ((uint32_t)p[4 * i + 2] << 16) | ((uint32_t)p[4 * i + 3] << 24);
+        uint32_t A = a, B = b, C = c, D = d;
+        for (int i = 0; i < 64; ++i) {
+            uint32_t f;
+            int g;
+            if (i < 16) { f = (B & C) | (~B & D); g = i; }
+            else if (i < 32) { f = (D & B) | (~D & C); g = (5 * i + 1) & 15; }
+            else if (i < 48) { f = B ^ C ^ D; g = (3 * i + 5) & 15; }
+            else { f = C ^ (B | ~D); g = (7 * i) & 15; }
+            const uint32_t t = D;
+            D = C;
+            C = B;
+            B = B + rol(A + f + K[i] + m[g], S[i]);
+            A = t;
+        }
+        a += A; b += B; c += C; d += D;
+    }
+    void update(const char* p, size_t n) {
+        len += n;
+        while (n) {
+            const size_t k = std::min(n, sizeof buf - fill);
+            std::copy(p, p + k, buf + fill);
+            fill += k; p += k; n -= k;
+            if (fill == 64) { block(buf); fill = 0; }
+        }
+    }
+    std::string hex() {
+        const uint64_t bits = len * 8;
+        const char pad = (char)0x80;
+        update(&pad, 1);
+        const char zero = 0;
+        while (fill != 56) update(&zero, 1);
+        unsigned char l[8];
+        for (int i = 0; i < 8; ++i) l[i] = (unsigned char)(bits >> (8 * i));
+        update((const char*)l, 8);
+        const uint32_t w[4] = {a, b, c, d};
+        static const char* H = "0123456789abcdef";
+        std::string out;
+        for (int i = 0; i < 4; ++i)
+            for (int k = 0; k < 4; ++k) { const unsigned v = (w[i] >> (8 * k)) & 0xff; out.push_back(H[v >> 4]); out.push_back(H[v & 15]); }
+        return out;
+    }
+};
+
+enum { META_OK = 0, META_CANNOT_OPEN = 1, META_MALFORMED = 2, META_NOT_ONE = 3, META_EMPTY = 4, META_NEEDS_GENERAL_READER = 5 };
+struct Meta {
+    int status = META_OK;
+    int n_matching = 0;  // signatures of the requested k-mer size in the file
+    std::string name, md5;
+    double mean_abundance = 0.0;
+    bool has_abundance = false;
+    uint64_t n_hashes = 0, scaled = 0;
+};
+
+// a JSON string with the escapes sourmash's writer (Rust serde / Python json) produces, as UTF-8
+inline bool json_string(Scanner& s, std::string* out) {
+    s.ws();
+    if (s.p >= s.e || *s.p != '"') return false;
+    ++s.p;
+    out->clear();
+    auto put_utf8 = [&](uint32_t cp) {
+        if (cp < 0x80) out->push_back((char)cp);
+        else if (cp < 0x800) { out->push_back((char)(0xc0 | (cp >> 6))); out->push_back((char)(0x80 | (cp & 0x3f))); }
+        else if (cp < 0x10000) { out->push_back((char)(0xe0 | (cp >> 12))); out->push_back((char)(0x80 | ((cp >> 6) & 0x3f))); out->push_back((char)(0x80 | (cp & 0x3f))); }
+        else { out->push_back((char)(0xf0 | (cp >> 18))); out->push_back((char)(0x80 | ((cp >> 12) & 0x3f))); out->push_back((char)(0x80 | ((cp >> 6) & 0x3f))); out->push_back((char)(0x80 | (cp & 0x3f))); }
+    };
+    auto hex4 = [&](uint32_t* v) {
+        if (s.e - s.p < 4) return false;
+        uint32_t x = 0;
+        for (int i = 0; i < 4; ++i) {
+            const char ch = s.p[i];
+            x = x * 16 + (uint32_t)(ch >= '0' && ch <= '9' ? ch - '0' : ch >= 'a' && ch <= 'f' ? ch - 'a' + 10 : ch >= 'A' && ch <= 'F' ? ch - 'A' + 10 : 99);
+            if (x > 0xffffff) return false;
+        }
+        s.p += 4;
+        *v = x;
+        return true;
+    };
+    while (s.p < s.e && *s.p != '"') {
+        if (*s.p != '\\') { out->push_back(*s.p++); continue; }
+        if (++s.p >= s.e) return false;
+        const char esc = *s.p++;
+        switch (esc) {
+            case 'n': out->push_back('\n'); break;
+            case 't': out->push_back('\t'); break;
+            case 'r': out->push_back('\r'); break;
+            case 'b': out->push_back('\b'); break;
+            case 'f': out->push_back('\f'); break;
+            case 'u': {
+                uint32_t cp;
+                if (!hex4(&cp)) return false;
+                if (cp >= 0xd800 && cp < 0xdc00 && s.e - s.p >= 6 && s.p[0] == '\\' && s.p[1] == 'u') {  // surrogate pair
+                    s.p += 2;
+                    uint32_t lo;
+                    if (!hex4(&lo)) return false;
+                    cp = 0x10000 + ((cp - 0xd800) << 10) + (lo - 0xdc00);
+                }
+                put_utf8(cp);
+                break;
+            }
+            default: out->push_back(esc);  // \" \\ \/
+        }
+    }
+    if (s.p >= s.e) return false;
+    ++s.p;
+    return true;
+}
+
+inline bool json_uint(Scanner& s, uint64_t* v) {
+    s.ws();
+    const char* q = s.p;
+    uint64_t x = 0;
+    while (q < s.e && *q >= '0' && *q <= '9') x = x * 10 + (uint64_t)(*q++ - '0');
+    if (q == s.p) return false;
+    if (q < s.e && (*q == '.' || *q == 'e' || *q == 'E')) return false;  // not an integer: leave it to the general reader
+    s.p = q;
+    *v = x;
+    return true;
+}
+
+// `text` = the content of a .sig file.  The one signature of k-mer size `ksize` in it.
+inline Meta parse_meta(const std::string& text, int ksize) {
+    Meta m;
+    Scanner s{text.data(), text.data() + text.size()};
+    auto bad = [&](int st) { m.status = st; return m; };
+    if (!s.lit('[')) return bad(META_MALFORMED);
+    if (s.lit(']')) return bad(META_NOT_ONE);
+    do {  // records
+        if (!s.lit('{')) return bad(META_MALFORMED);
+        std::string rec_name;
+        std::vector<Meta> found;
+        if (!s.lit('}')) {
+            std::string key;
+            do {
+                if (!s.string(&key) || !s.lit(':')) return bad(META_MALFORMED);
+                if (key == "name") {
+                    s.ws();
+                    if (s.p < s.e && *s.p == '"') { if (!json_string(s, &rec_name)) return bad(META_MALFORMED); }
+                    else if (!s.skip()) return bad(META_MALFORMED);
+                } else if (key == "signatures") {
+                    if (!s.lit('[')) return bad(META_MALFORMED);
+                    if (!s.lit(']')) {
+                        do {  // signatures
+                            if (!s.lit('{')) return bad(META_MALFORMED);
+                            uint64_t k = 0, max_hash = 0, n = 0, n_ab = 0;
+                            bool have_k = false, have_ab = false, ascending = true;
+                            uint64_t ab_sum = 0;  // (exact; numpy's mean of an int64 array is this sum in float64 over the count)
+                            uint64_t prev = 0;
+                            Md5 md;
+                            std::vector<uint64_t> mins;
+                            if (!s.lit('}')) {
+                                std::string sk;
+                                do {
+                                    if (!s.string(&sk) || !s.lit(':')) return bad(META_MALFORMED);
+                                    if (sk == "ksize") { if (!json_uint(s, &k)) return bad(META_NEEDS_GENERAL_READER); have_k = true; }
+                                    else if (sk == "max_hash") { if (!json_uint(s, &max_hash)) return bad(META_NEEDS_GENERAL_READER); }
+                                    else if (sk == "mins") {
+                                        if (!s.lit('[')) return bad(META_MALFORMED);
+                                        if (!s.lit(']')) {
+                                            do {
+                                                uint64_t v;
+                                                if (!json_uint(s, &v)) return bad(META_MALFORMED);
+                                                if (n && v <= prev) ascending = false;
+                                                prev = v;
+                                                mins.push_back(v);
+                                                ++n;
+                                            } while (s.lit(','));
+                                            if (!s.lit(']')) return bad(META_MALFORMED);
+                                        }
+                                    } else if (sk == "abundances") {
+                                        s.ws();
+                                        if (s.p < s.e && *s.p == '[') {
+                                            ++s.p;
+                                            have_ab = true;
+                                            if (!s.lit(']')) {
+                                                do {
+                                                    uint64_t v;
+                                                    if (!json_uint(s, &v)) return bad(META_NEEDS_GENERAL_READER);
+                                                    ab_sum += v;
+                                                    ++n_ab;
+                                                } while (s.lit(','));
+                                                if (!s.lit(']')) return bad(META_MALFORMED);
+                                            }
+                                        } else if (!s.skip()) return bad(META_MALFORMED);  // null
+                                    } else if (!s.skip()) return bad(META_MALFORMED);
+                                } while (s.lit(','));
+                                if (!s.lit('}')) return bad(META_MALFORMED);
+                            }
+                            if (!have_k) return bad(META_MALFORMED);
+                            if ((int)k == ksize) {
+                                if (!ascending || (have_ab && n_ab != n)) return bad(META_NEEDS_GENERAL_READER);  // (re-ordered / de-duplicated there)
+                                Meta one;
+                                one.n_hashes = n;
+                                one.has_abundance = have_ab;
+                                one.mean_abundance = (have_ab && n) ? (double)ab_sum / (double)n : 0.0;
+                                one.scaled = max_hash ? (uint64_t)__builtin_nearbyintl(18446744073709551616.0L / (long double)max_hash) : 0;  // sourmash: round(2^64 / max_hash)
+                                char tmp[24];
+                                int len = snprintf(tmp, sizeof tmp, "%llu", (unsigned long long)k);
+                                md.update(tmp, (size_t)len);
+                                for (uint64_t v : mins) {
+                                    char* q = tmp + sizeof tmp;
+                                    do { *--q = (char)('0' + v % 10); v /= 10; } while (v);
+                                    md.update(q, (size_t)(tmp + sizeof tmp - q));
+                                }
+                                one.md5 = md.hex();
+                                found.push_back(std::move(one));
+                            }
+                        } while (s.lit(','));
+                        if (!s.lit(']')) return bad(META_MALFORMED);
+                    }
+                } else if (!s.skip()) return bad(META_MALFORMED);
+            } while (s.lit(','));
+            if (!s.lit('}')) return bad(META_MALFORMED);
+        }
+        for (Meta& f : found) {  // ("name" may come behind "signatures" in the record)
+            ++m.n_matching;
+            if (m.n_matching == 1) {
+                const int keep = m.n_matching;
+                m = std::move(f);
+                m.n_matching = keep;
+                m.name = rec_name;
+            }
+        }
+    } while (s.lit(','));
+    if (!s.lit(']')) return bad(META_MALFORMED);
+    if (m.n_matching != 1) m.status = META_NOT_ONE;
+    else if (m.n_hashes == 0) m.status = META_EMPTY;
+    return m;
+}
+
+}  // namespace yh_sig

@@ -56,11 +56,30 @@ def _fresh_workdir(workdir: str, force: bool) -> None:
     os.makedirs(workdir, exist_ok=True)
 
 
+def _extract_members(job) -> int:
+    zip_path, workdir, names = job
+    with zipfile.ZipFile(zip_path, "r") as archive:
+        for n in names:
+            archive.extract(n, workdir)
+    return len(names)
+
+
 def _unpack_database(zip_path: str, workdir: str, threads: int) -> None:
     logger.info("Unzipping the sourmash signature file to the temporary directory")
     with phases.phase("unzip"):
         with zipfile.ZipFile(zip_path, "r") as archive:
-            archive.extractall(workdir)
+            names = archive.namelist()
+            if threads > 1 and len(names) > 2000:  # tens of thousands of small members: several readers of the one archive
+                from multiprocessing import Pool
+
+                workers = min(threads, 16)
+                per = (len(names) + 4 * workers - 1) // (4 * workers)
+                jobs = [(zip_path, workdir, names[i:i + per]) for i in range(0, len(names), per)]
+                with Pool(workers) as pool:
+                    done = sum(pool.imap_unordered(_extract_members, jobs))
+                assert done == len(names)
+            else:
+                archive.extractall(workdir)
     packed = glob.glob(f"{workdir}/signatures/*.sig.gz")
     logger.info(f"Decompressing {len(packed)} .sig.gz files using {threads} threads.")
     with phases.phase("gunzip"):

@@ -74,17 +74,59 @@ def get_info_from_single_sig(sig_file: str, ksize: int):
         return None
 
 
+def _sig_meta_native(paths: List[str], ksize: int, num_threads: int):
+    """(status, n_hashes, scaled, mean_abundance, has_abundance, md5s, names) of every file through the library's
+    threaded reader (yh_sig_meta_*: a JSON scan + md5 in C++ instead of a Python object per hash)."""
+    import ctypes as C
+
+    from . import _lib
+
+    lib = _lib.load()
+    n = len(paths)
+    arr = (C.c_char_p * n)(*[os.fsencode(p) for p in paths])
+    h = C.c_void_p()
+    _lib.check(lib.yh_sig_meta_read(arr, n, int(ksize), max(1, int(num_threads)), C.byref(h)))
+    try:
+        status = np.zeros(max(n, 1), np.uint8)
+        n_hashes = np.zeros(max(n, 1), np.uint64)
+        scaled = np.zeros(max(n, 1), np.uint64)
+        mean_ab = np.zeros(max(n, 1), np.float64)
+        has_ab = np.zeros(max(n, 1), np.uint8)
+        md5 = np.zeros(max(n, 1) * 33, np.uint8)
+        name_off = np.zeros(n + 1, np.uint64)
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        _lib.check(lib.yh_sig_meta_get(h, vp(status), vp(n_hashes), vp(scaled), vp(mean_ab), vp(has_ab), vp(md5), vp(name_off)))
+        names_buf = np.zeros(max(int(name_off[-1]), 1), np.uint8)
+        _lib.check(lib.yh_sig_meta_names(h, vp(names_buf)))
+    finally:
+        lib.yh_sig_meta_destroy(h)
+    raw = names_buf.tobytes()
+    names = [raw[int(name_off[i]):int(name_off[i + 1])].decode("utf-8", "replace") for i in range(n)]
+    md5s = [md5[33 * i:33 * i + 32].tobytes().decode("ascii") for i in range(n)]
+    return status[:n], n_hashes[:n], scaled[:n], mean_ab[:n], has_ab[:n], md5s, names
+
+
 def collect_signature_info(num_threads: int, ksize: int, path_to_temp_dir: str) -> Dict[str, Tuple]:
     """name -> (md5sum, mean abundance, sketch size, scaled, path) for every file under
-    {path_to_temp_dir}/signatures, in os.listdir order (reference utils.py:201-221)."""
+    {path_to_temp_dir}/signatures, in os.listdir order (reference utils.py:201-221).  Same records and the same
+    warning for a file without exactly one non-empty signature of this k-mer size as get_info_from_single_sig;
+    the files are read by the library's threaded scanner, and the few it defers (unsorted mins, non-integer
+    fields) by get_info_from_single_sig itself."""
     sig_dir = os.path.join(path_to_temp_dir, "signatures")
-    jobs = [(os.path.join(sig_dir, f), ksize) for f in os.listdir(sig_dir)]
-    if num_threads > 1 and len(jobs) > 64:
-        with Pool(num_threads) as p:
-            signatures = p.starmap(get_info_from_single_sig, jobs)
-    else:
-        signatures = [get_info_from_single_sig(*j) for j in jobs]
-    return {sig[1]: (sig[2], sig[3], sig[4], sig[5], sig[0]) for sig in signatures if sig}
+    paths = [os.path.join(sig_dir, f) for f in os.listdir(sig_dir)]
+    status, n_hashes, scaled, mean_ab, has_ab, md5s, names = _sig_meta_native(paths, ksize, num_threads)
+    out: Dict[str, Tuple] = {}
+    for i, path in enumerate(paths):
+        st = int(status[i])
+        if st == 0:
+            out[names[i]] = (md5s[i], float(mean_ab[i]) if has_ab[i] else None, int(n_hashes[i]), int(scaled[i]), path)
+        elif st == 5:  # a shape the scanner leaves to the general reader
+            rec = get_info_from_single_sig(path, ksize)
+            if rec:
+                out[rec[1]] = (rec[2], rec[3], rec[4], rec[5], rec[0])
+        else:
+            logger.warning(f"CANNOT extract the relevant info from the signature file: {path}")
+    return out
 
 
 def _gunzip_one(path: str) -> None:
@@ -94,13 +136,21 @@ def _gunzip_one(path: str) -> None:
 
 
 def decompress_all_sig_files(sig_files: List[str], num_threads: int) -> None:
-    """gunzip every *.sig.gz next to itself and delete the .gz (reference utils.py:499-509)."""
-    if num_threads > 1 and len(sig_files) > 64:
-        with Pool(num_threads) as p:
-            p.map(_gunzip_one, sig_files)
-    else:
-        for f in sig_files:
-            _gunzip_one(f)
+    """gunzip every *.sig.gz next to itself and delete the .gz (reference utils.py:499-509): the library's
+    threaded zlib pass; a file it could not handle goes through Python's gzip, which raises as the reference does."""
+    if not sig_files:
+        return
+    import ctypes as C
+
+    from . import _lib
+
+    lib = _lib.load()
+    n = len(sig_files)
+    arr = (C.c_char_p * n)(*[os.fsencode(p) for p in sig_files])
+    status = np.ones(n, np.uint8)
+    _lib.check(lib.yh_gunzip_files(arr, n, max(1, int(num_threads)), status.ctypes.data_as(C.c_void_p)))
+    for i in np.flatnonzero(status):
+        _gunzip_one(sig_files[int(i)])
 
 
 def run_yacht_train_core(num_threads: int, ani_thresh: float, ksize: int, path_to_temp_dir: str,
