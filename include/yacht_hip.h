@@ -119,7 +119,11 @@ int yh_db_create_device(const uint64_t* d_values, const uint64_t* d_offsets, uin
                         int device_id, uint32_t flags, uint32_t partitions_hint, yh_db** out);
 int yh_db_destroy(yh_db* db);
 int yh_db_get_info(yh_db* db, yh_db_info* info);
-/* Run all of the handle's work on this hipStream_t (NULL = the library's own stream).      */
+/* Run all of the handle's work on this hipStream_t (NULL = the library's own stream).
+ * The library's own stream is a blocking stream: device buffers the caller fills on the legacy default
+ * stream (what torch uses unless told otherwise) are complete before the handle's kernels read them, and
+ * a copy queued there after a *_device call sees its results.  A stream given here is the caller's: work
+ * on OTHER streams that writes the inputs or reads the outputs is the caller's to order.               */
 int yh_db_set_stream(yh_db* db, void* hip_stream);
 /* Block until everything queued on the handle's stream has finished.                       */
 int yh_db_synchronize(yh_db* db);

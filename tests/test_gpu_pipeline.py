@@ -107,3 +107,28 @@ def test_unsorted_sample_is_refused_on_device(hip_lib):
         with pytest.raises(_lib.YachtHipError):
             db.overlap(bad)
         assert np.array_equal(db.overlap(good[0]), ov0)
+
+
+def test_own_stream_is_ordered_with_the_default_stream(hip_lib):
+    """A caller that fills the output buffers with torch (default stream) and reads them back with torch
+    needs no synchronize of its own around the *_device calls on the handle's own stream: a long fill
+    queued just before the call must not land on top of the results, and the copy queued just after the
+    call must see them (include/yacht_hip.h, yh_db_set_stream)."""
+    import torch
+
+    rng = np.random.default_rng(77)
+    refs = synth.clustered_refs(rng, 400, (1.0, 0.9, 0.5, 0.25, 0.1), 800)
+    values, offsets = synth.pack(refs)
+    sample = synth.sample_from_refs(rng, refs, list(range(0, len(refs), 7)), 0.5, 20000)
+    want_ov = oracle.overlap(values, offsets, sample)
+    want_e, want_m = oracle.exclusive(values, offsets, want_ov > 0, sample)
+    n = len(refs)
+    s = torch.from_numpy(np.ascontiguousarray(sample).view(np.int64).copy()).cuda()
+    big = torch.empty(3, 32 << 20, dtype=torch.int32, device="cuda")  # (a fill of 384 MB takes far longer than the step)
+    with RefDB(values, offsets) as db:
+        for _ in range(20):
+            big.fill_(7)
+            db.run_device(s.data_ptr(), s.numel(), big[0].data_ptr(), big[1].data_ptr(), big[2].data_ptr())
+            got = big[:, :n].cpu().numpy().view(np.uint32)  # no db.synchronize(): the copy is ordered behind the step
+            assert np.array_equal(got[0], want_ov) and np.array_equal(got[1], want_e) and np.array_equal(got[2], want_m)
+            assert int(big[0, n]) == 7

@@ -149,7 +149,9 @@ static int db_create_common(const u64* values, const u64* offsets, bool on_devic
     bool own_inputs = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     do {
-        if (hipStreamCreateWithFlags(&db->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        // a BLOCKING stream: ordered with the legacy default stream, where a caller that never heard of streams
+        // (and torch, by default) fills the device buffers it hands over and reads the results back
+        if (hipStreamCreateWithFlags(&db->own_stream, hipStreamDefault) != hipSuccess) {
             yh_set_error("hipStreamCreate failed"); rc = YH_ERR_HIP; break;
         }
         db->stream = db->own_stream;
@@ -214,8 +216,10 @@ static int db_create_common(const u64* values, const u64* offsets, bool on_devic
             } else {
                 if ((rc = yh_dmalloc(db, (void**)&db->d_values, std::max<u64>(H, 2) * sizeof(u64))) != YH_OK) break;
                 if ((rc = yh_dmalloc(db, (void**)&db->d_offsets, (n_refs + 1) * sizeof(u64))) != YH_OK) break;
-                if ((H && hipMemcpy(db->d_values, values, H * sizeof(u64), hipMemcpyDeviceToDevice) != hipSuccess) ||
-                    hipMemcpy(db->d_offsets, offsets, (n_refs + 1) * sizeof(u64), hipMemcpyDeviceToDevice) != hipSuccess) {
+                // (on the handle's stream and waited for: a device-to-device hipMemcpy may return before it is done)
+                if ((H && hipMemcpyAsync(db->d_values, values, H * sizeof(u64), hipMemcpyDeviceToDevice, db->stream) != hipSuccess) ||
+                    hipMemcpyAsync(db->d_offsets, offsets, (n_refs + 1) * sizeof(u64), hipMemcpyDeviceToDevice, db->stream) != hipSuccess ||
+                    hipStreamSynchronize(db->stream) != hipSuccess) {
                     yh_set_error("CSR copy failed"); rc = YH_ERR_HIP; break;
                 }
             }
@@ -280,7 +284,7 @@ int yh_db_create_from_pairs(const uint64_t* d_hashes, const uint32_t* d_refs, ui
     db->n_parts = (u32)nparts;
     int rc = YH_OK;
     do {
-        if (hipStreamCreateWithFlags(&db->own_stream, hipStreamNonBlocking) != hipSuccess) { yh_set_error("hipStreamCreate failed"); rc = YH_ERR_HIP; break; }
+        if (hipStreamCreateWithFlags(&db->own_stream, hipStreamDefault) != hipSuccess) { yh_set_error("hipStreamCreate failed"); rc = YH_ERR_HIP; break; }
         db->stream = db->own_stream;
         if ((rc = yh_dmalloc(db, (void**)&db->d_sbounds, (u64)(db->n_parts + 1) * sizeof(u32))) != YH_OK) break;
         if ((rc = yh_dmalloc(db, (void**)&db->d_flag, 16)) != YH_OK) break;
@@ -340,7 +344,7 @@ int yh_db_destroy(yh_db* db) {
         if (db->ctx_count[1]) (void)hipFree(db->ctx_count[1]);
     }
     void* ptrs[] = {db->d_values, db->d_offsets, db->d_pvals, db->d_pbeg, db->d_pcnt, db->d_poffs, db->d_sizes,
-                    db->d_g, db->d_po, db->d_pr, db->d_pg, db->d_gbeg, db->d_gcnt, db->d_nshared, db->d_pq, db->d_pq_count, db->d_dh, db->d_dref, db->d_dir, db->d_bkt, db->d_cbkt, db->d_ovf_keys, db->d_ovf_vals, db->d_pkeys, db->d_pref, db->d_gkeys, db->d_rpo, db->d_rg, db->d_rrec, db->d_rrecx, db->d_work, db->d_work_count, db->d_sbounds,
+                    db->d_g, db->d_po, db->d_pr, db->d_pg, db->d_gbeg, db->d_gcnt, db->d_nshared, db->d_pq, db->d_pq_count, db->d_dh, db->d_dref, db->d_dir, db->d_bkt, db->d_cbkt, db->d_ovf_keys, db->d_ovf_vals, db->d_pkeys, db->d_pref, db->d_gkeys, db->d_rpo, db->d_rg, db->d_rrec, db->d_rrecx, db->d_hrec, db->d_hrecx, db->d_hmult, db->d_hpo, db->d_work, db->d_work_count, db->d_sbounds,
                     db->d_mask, db->d_maskbits, db->d_hit, db->d_excl_e, db->d_overlap_tmp,
                     db->d_sample_tmp, db->d_out_tmp, db->d_flag, db->d_hitq, db->d_hitq_cnt, db->d_wg_first, db->d_reps, db->d_batch,
                     db->d_sdelta, db->d_shdr, db->d_srec, db->d_wg_key, db->d_ghost_src, db->d_bad_word};

@@ -396,6 +396,60 @@ __global__ void k_cbkt_build(const u64* __restrict__ dh, const u32* __restrict__
     }
 }
 
+// ---- holder sets (layout: yh_common.h, d_hrec) -----------------------------------------------------------
+// Many shared hashes of a reference have the SAME other holders (a cluster of genomes: at most 2^(k-1) different
+// sets, thousands of hashes), and "none of the other holders is in the subset" has the same answer for all of them.
+// So the fused run step does not walk a reference's postings but its DISTINCT holder sets with their
+// multiplicities.  Built by sorting the reference-major postings by (reference, 64-bit hash of the holder record)
+// and cutting runs where the full 32-byte records differ -- a hash collision only splits a run, never merges two.
+__device__ __forceinline__ u64 set_mix(u64 z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__global__ void k_set_keys(u64 n_post, const uint4* __restrict__ rrec, const uint4* __restrict__ rrecx,
+                           u64* __restrict__ key, u32* __restrict__ idx) {
+    for (u64 p = blockIdx.x * (u64)blockDim.x + threadIdx.x; p < n_post; p += (u64)gridDim.x * blockDim.x) {
+        const uint4 a = rrec[p], b = rrecx[p];
+        u64 h = set_mix(((u64)a.x << 32) | a.y);
+        h = set_mix(h ^ (((u64)a.z << 32) | a.w));
+        h = set_mix(h ^ (((u64)b.x << 32) | b.y));
+        h = set_mix(h ^ (((u64)b.z << 32) | b.w));
+        key[p] = h;
+        idx[p] = (u32)p;
+    }
+}
+__global__ void k_gather_u32(u64 n, const u32* __restrict__ src, const u32* __restrict__ idx, u32* __restrict__ out) {
+    for (u64 s = blockIdx.x * (u64)blockDim.x + threadIdx.x; s < n; s += (u64)gridDim.x * blockDim.x) out[s] = src[idx[s]];
+}
+__device__ __forceinline__ bool same16(const uint4 a, const uint4 b) { return a.x == b.x && a.y == b.y && a.z == b.z && a.w == b.w; }
+// head[s] = 1 when sorted posting s starts a new (reference, holder set) run
+__global__ void k_set_heads(u64 n_post, const u32* __restrict__ idx, const u32* __restrict__ pref,
+                            const uint4* __restrict__ rrec, const uint4* __restrict__ rrecx, u32* __restrict__ head) {
+    for (u64 s = blockIdx.x * (u64)blockDim.x + threadIdx.x; s < n_post; s += (u64)gridDim.x * blockDim.x) {
+        bool h = s == 0;
+        if (!h) {
+            const u32 p = idx[s], q = idx[s - 1];
+            h = pref[p] != pref[q] || !same16(rrec[p], rrec[q]) || !same16(rrecx[p], rrecx[q]);
+        }
+        head[s] = h ? 1u : 0u;
+    }
+}
+// run[s] = inclusive scan of head (1-based run number of sorted posting s)
+__global__ void k_set_emit(u64 n_post, const u32* __restrict__ idx, const u32* __restrict__ pref, const u32* __restrict__ head,
+                           const u32* __restrict__ run, const uint4* __restrict__ rrec, const uint4* __restrict__ rrecx,
+                           uint4* __restrict__ hrec, uint4* __restrict__ hrecx, u32* __restrict__ hmult, u32* __restrict__ hcnt) {
+    for (u64 s = blockIdx.x * (u64)blockDim.x + threadIdx.x; s < n_post; s += (u64)gridDim.x * blockDim.x) {
+        const u32 r = run[s] - 1u, p = idx[s];
+        atomicAdd(&hmult[r], 1u);
+        if (head[s]) {
+            hrec[r] = rrec[p];
+            hrecx[r] = rrecx[p];
+            atomicAdd(&hcnt[pref[p]], 1u);
+        }
+    }
+}
+
 // 32-bit keys of a hash array: inside one hash-range partition the bits above pshift are constant,
 // so (u32)(h >> kshift) orders and (almost always) identifies the hashes of a partition.
 __global__ void k_make_keys(const u64* __restrict__ v, u64 n, u32 kshift, u32* __restrict__ keys) {
@@ -412,11 +466,12 @@ __global__ void k_chunk_counts(const u32* __restrict__ nshared, u64 n, u32* __re
 // fused run step reaches them in one (coalesced) read instead of three dependent ones (rg -> po -> pr).
 __global__ void k_fill_rg(u64 n_post, const u32* __restrict__ pr, const u32* __restrict__ pg, const u64* __restrict__ po,
                           const u32* __restrict__ rpo, u32* __restrict__ cursor, u32* __restrict__ rg,
-                          uint4* __restrict__ rrec, uint4* __restrict__ rrecx) {
+                          uint4* __restrict__ rrec, uint4* __restrict__ rrecx, u32* __restrict__ pref) {
     for (u64 k = blockIdx.x * (u64)blockDim.x + threadIdx.x; k < n_post; k += (u64)gridDim.x * blockDim.x) {
         const u32 r = pr[k], g = pg[k];
         const u32 dst = rpo[r] + atomicAdd(&cursor[r], 1u);  // order inside a reference is irrelevant (sums)
         rg[dst] = g;
+        if (pref) pref[dst] = r;
         if (rrec) {
             const u64 q0 = po[g], q1 = po[g + 1];
             uint4 rec, recx = make_uint4(0u, 0u, 0u, 0u);
@@ -893,11 +948,59 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, const u
             if (rc == YH_OK) rc = yh_dmalloc(db, (void**)&db->d_work, ((u64)n_chunks + 64) * sizeof(uint4));
             if (rc == YH_OK) rc = yh_dmalloc(db, (void**)&db->d_work_count, 16);
             IDX_HIP(hipMemsetAsync(db->d_work_count, 0, 16, st));
+            u32* d_pref = nullptr;  // reference of every reference-major posting position (for the holder sets)
+            if (want_stream) IDX_HIP(hipMalloc((void**)&d_pref, db->n_postings * sizeof(u32)));
             if (rc == YH_OK)
                 k_fill_rg<<<grid_for(db->n_postings, 256), 256, 0, st>>>(db->n_postings, db->d_pr, db->d_pg, db->d_po, db->d_rpo,
-                                                                         d_cur, db->d_rg, db->d_rrec, db->d_rrecx);
+                                                                         d_cur, db->d_rg, db->d_rrec, db->d_rrecx, d_pref);
             IDX_HIP(hipGetLastError());
+            if (rc == YH_OK && want_stream) {  // distinct holder sets per reference (k_set_*)
+                const u64 P = db->n_postings;
+                u64 *d_k = nullptr, *d_k2 = nullptr;
+                u32 *d_i = nullptr, *d_i2 = nullptr, *d_kr = nullptr, *d_kr2 = nullptr, *d_head = nullptr, *d_run = nullptr;
+                void* d_t = nullptr;
+                size_t tb1 = 0, tb2 = 0, tb3 = 0;
+                IDX_HIP(hipMalloc((void**)&d_k, P * sizeof(u64)));
+                IDX_HIP(hipMalloc((void**)&d_k2, P * sizeof(u64)));
+                IDX_HIP(hipMalloc((void**)&d_i, P * sizeof(u32)));
+                IDX_HIP(hipMalloc((void**)&d_i2, P * sizeof(u32)));
+                IDX_HIP(hipMalloc((void**)&d_kr, P * sizeof(u32)));
+                IDX_HIP(hipMalloc((void**)&d_kr2, P * sizeof(u32)));
+                unsigned ref_bits = 1;
+                while (ref_bits < 32 && (N >> ref_bits) != 0) ++ref_bits;
+                IDX_HIP(rocprim::radix_sort_pairs(nullptr, tb1, d_k, d_k2, d_i, d_i2, (size_t)P, 0u, 64u, st));
+                IDX_HIP(rocprim::radix_sort_pairs(nullptr, tb2, d_kr, d_kr2, d_i2, d_i, (size_t)P, 0u, ref_bits, st));
+                IDX_HIP(rocprim::inclusive_scan(nullptr, tb3, d_kr, d_kr2, (size_t)P, rocprim::plus<u32>(), st));
+                IDX_HIP(hipMalloc(&d_t, std::max(std::max(tb1, tb2), tb3) + 256));
+                if (rc == YH_OK) k_set_keys<<<grid_for(P, 256), 256, 0, st>>>(P, db->d_rrec, db->d_rrecx, d_k, d_i);
+                IDX_HIP(rocprim::radix_sort_pairs(d_t, tb1, d_k, d_k2, d_i, d_i2, (size_t)P, 0u, 64u, st));  // by holder-set hash
+                if (rc == YH_OK) k_gather_u32<<<grid_for(P, 256), 256, 0, st>>>(P, d_pref, d_i2, d_kr);
+                IDX_HIP(rocprim::radix_sort_pairs(d_t, tb2, d_kr, d_kr2, d_i2, d_i, (size_t)P, 0u, ref_bits, st));  // then, stably, by reference
+                d_head = d_kr;   // (the reference keys are spent)
+                d_run = d_kr2;
+                if (rc == YH_OK) k_set_heads<<<grid_for(P, 256), 256, 0, st>>>(P, d_i, d_pref, db->d_rrec, db->d_rrecx, d_head);
+                IDX_HIP(rocprim::inclusive_scan(d_t, tb3, d_head, d_run, (size_t)P, rocprim::plus<u32>(), st));
+                u32 n_sets = 0;
+                IDX_HIP(hipMemcpyAsync(&n_sets, d_run + (P - 1), sizeof(u32), hipMemcpyDeviceToHost, st));
+                IDX_HIP(hipStreamSynchronize(st));
+                db->n_sets = n_sets;
+                if (rc == YH_OK) rc = yh_dmalloc(db, (void**)&db->d_hrec, ((u64)n_sets + 1) * sizeof(uint4));
+                if (rc == YH_OK) rc = yh_dmalloc(db, (void**)&db->d_hrecx, ((u64)n_sets + 1) * sizeof(uint4));
+                if (rc == YH_OK) rc = yh_dmalloc(db, (void**)&db->d_hmult, ((u64)n_sets + 1) * sizeof(u32));
+                if (rc == YH_OK) rc = yh_dmalloc(db, (void**)&db->d_hpo, (N + 2) * sizeof(u32));
+                IDX_HIP(hipMemsetAsync(db->d_hmult, 0, ((u64)n_sets + 1) * sizeof(u32), st));
+                IDX_HIP(hipMemsetAsync(db->d_hpo, 0, (N + 2) * sizeof(u32), st));
+                if (rc == YH_OK)  // per-reference counts go to hpo[1..N], then an inclusive scan in place makes them offsets
+                    k_set_emit<<<grid_for(P, 256), 256, 0, st>>>(P, d_i, d_pref, d_head, d_run, db->d_rrec, db->d_rrecx, db->d_hrec,
+                                                                db->d_hrecx, db->d_hmult, db->d_hpo + 1);
+                IDX_HIP(rocprim::inclusive_scan(d_st, st_bytes, db->d_hpo + 1, db->d_hpo + 1, N, rocprim::plus<u32>(), st));
+                IDX_HIP(hipGetLastError());
+                IDX_HIP(hipStreamSynchronize(st));
+                (void)hipFree(d_k); (void)hipFree(d_k2); (void)hipFree(d_i); (void)hipFree(d_i2);
+                (void)hipFree(d_kr); (void)hipFree(d_kr2); (void)hipFree(d_t);
+            }
             IDX_HIP(hipStreamSynchronize(st));
+            (void)hipFree(d_pref);
             (void)hipFree(d_cc);
             (void)hipFree(d_cpo);
             (void)hipFree(d_cur);

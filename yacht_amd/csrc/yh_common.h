@@ -199,6 +199,13 @@ struct yh_db {
                                // {o0, o1, o2, count <= 7} (others 3..6 in d_rrecx) or, for nine holders and
                                // more, {first index in d_pr, holders, 0, ~0}
     uint4* d_rrecx = nullptr;  // [n_postings] {o3, o4, o5, o6}
+    // the DISTINCT holder sets of every reference with their multiplicities (what the fused run step walks instead of
+    // the postings): records as d_rrec / d_rrecx, reference-major, reference r owns [d_hpo[r], d_hpo[r + 1])
+    uint4* d_hrec = nullptr;   // [n_sets]
+    uint4* d_hrecx = nullptr;  // [n_sets]
+    u32* d_hmult = nullptr;    // [n_sets] shared hashes of the reference with exactly these other holders
+    u32* d_hpo = nullptr;      // [N + 1]
+    u32 n_sets = 0;
     u32 n_chunks = 0;
     bool posting_only = false;        // yh_db_create_from_pairs: posting lists of a hash range, no sketches
     bool excl_prefer_stream = false;  // set by the host-mask entry point when most references are masked

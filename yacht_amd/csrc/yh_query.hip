@@ -166,7 +166,8 @@ struct FusedRun {
     u32* n_excl;
     u32* n_match;
     u32* bits_out;  // may be null: a second copy of the subset bits (the sharded run hands them to the other ranks)
-    // work list of the exclusive pass behind this kernel: the posting pieces of the subset's references
+    // work list of the exclusive pass behind this kernel: pieces of the subset's references' holder-set records
+    // (reference j owns records [rpo[j], rpo[j + 1]) -- yh_db::d_hpo)
     const u32* rpo;
     uint4* work;
     u32* work_count;  // zero when this kernel starts (the lookup kernel in front of it clears it)
@@ -209,11 +210,11 @@ __global__ void __launch_bounds__(256) k_reduce_replicas(u32* __restrict__ reps,
     const u64 j = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     u32 acc = 0;
     // everything this thread reads is requested up front (one memory round trip, not one per dependent use)
-    u32 size_j = 0, nshared_j = 0, rpo_j = 0;
+    u32 size_j = 0, nshared_j = 0, rpo_j = 0, rpo_end = 0;
     if (j < n && fused.reps2) {
         size_j = fused.sizes[j];
         nshared_j = fused.nshared[j];
-        if (fused.work) rpo_j = fused.rpo[j];
+        if (fused.work) { rpo_j = fused.rpo[j]; rpo_end = fused.rpo[j + 1]; }
     }
     if (j < n) {
         for (u32 r = 0; r < R; ++r) {
@@ -244,7 +245,7 @@ __global__ void __launch_bounds__(256) k_reduce_replicas(u32* __restrict__ reps,
             }
         }
     }
-    if (fused.work) append_pieces(acc != 0 && j < fused.work_refs, (u32)j, nshared_j, rpo_j, fused.work, fused.work_count, lds);
+    if (fused.work) append_pieces(acc != 0 && j < fused.work_refs, (u32)j, rpo_end - rpo_j, rpo_j, fused.work, fused.work_count, lds);
 }
 
 // the same work list for a subset that arrives as bits (general path); work_count zeroed by the caller
@@ -1599,6 +1600,8 @@ __device__ __forceinline__ u32 others_in_subset(const uint4 rec, const uint4 rec
 // General form (any subset): ex_e[r] += shared hashes of r with no other holder in the subset, ex_m[r] +=
 // those of them found in the sample (hit[]), ovsh[r] += shared hashes of r found in the sample.
 // rrec == nullptr (posting-only handles): holders through rg -> po -> pr.  hit == nullptr: ex_e only.
+// mult != nullptr (the fused run step): the records are a reference's DISTINCT holder sets and mult[k] the number
+// of its shared hashes with that set (yh_db::d_hrec); n_post is then the number of set records.
 #ifndef YH_EXCL_GRID
 #define YH_EXCL_GRID 2048
 #endif
@@ -1610,6 +1613,7 @@ template <bool LDSMASK>
 __global__ void __launch_bounds__(EXCL_PIECE_THREADS) k_excl_pieces(const u32* __restrict__ work_count, const uint4* __restrict__ work,
                                                      const u32* __restrict__ rpo, const u32* __restrict__ rg,
                                                      const uint4* __restrict__ rrec, const uint4* __restrict__ rrecx,
+                                                     const u32* __restrict__ mult,
                                                      const u64* __restrict__ po, u32 n_post, const u32* __restrict__ pr,
                                                      const u32* __restrict__ maskbits, u32 n_mask_words,
                                                      const u8* __restrict__ hit, u32* __restrict__ ex_e,
@@ -1640,13 +1644,14 @@ __global__ void __launch_bounds__(EXCL_PIECE_THREADS) k_excl_pieces(const u32* _
             u32 k[U];
             bool valid[U], in_s[U];
             uint4 rec[U], recx[U];
-            u32 gi[U];
+            u32 gi[U], mu[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 k[u] = k0 + 64u * u + lane;
                 valid[u] = k[u] < end;
                 const u32 kc = min(k[u], n_post - 1);  // (clamped: branch-free reads)
                 gi[u] = (hit || !rrec) ? rg[kc] : 0u;
+                mu[u] = mult ? mult[kc] : 1u;
                 if (rrec) rec[u] = rrec[kc];
                 recx[u] = make_uint4(0u, 0u, 0u, 0u);
             }
@@ -1670,7 +1675,7 @@ __global__ void __launch_bounds__(EXCL_PIECE_THREADS) k_excl_pieces(const u32* _
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const bool e = valid[u] && others_in_subset(rec[u], recx[u], pr, mword) == 0;
-                acc_e += e ? 1u : 0u;
+                acc_e += e ? mu[u] : 0u;
                 acc_m += (e && in_s[u]) ? 1u : 0u;
                 acc_o += in_s[u] ? 1u : 0u;
             }
@@ -1909,17 +1914,23 @@ static int claim_hit_flags(yh_db* db) {
 
 // hit == nullptr: only ex_e is summed (the fused run step).  One wave per work record; the work list
 // (db->d_work, db->d_work_count) was appended by k_reduce_replicas / k_excl_worklist on the same stream.
-static void launch_excl_pieces(yh_db* db, const u32* d_maskbits, const u8* d_hit, u32* d_ex_e, u32* d_ex_m, u32* d_ovsh) {
+static void launch_excl_pieces(yh_db* db, const u32* d_maskbits, const u8* d_hit, u32* d_ex_e, u32* d_ex_m, u32* d_ovsh,
+                               bool sets = false) {
+    // sets: the work list holds pieces of holder-set records (appended by k_reduce_replicas), not of postings
+    const uint4* rec = sets ? db->d_hrec : db->d_rrec;
+    const uint4* recx = sets ? db->d_hrecx : db->d_rrecx;
+    const u32* mult = sets ? db->d_hmult : nullptr;
+    const u32 n_rec = sets ? db->n_sets : (u32)db->n_postings;
     const u32 words = (u32)(((db->n_refs + 255) / 256) * 8);  // what k_reduce_replicas / k_mask_bits write: whole 256-reference blocks
     const u32 per_wg = EXCL_PIECE_THREADS / 64;
     const u32 grid = std::min<u32>((db->n_chunks + per_wg - 1) / per_wg, (u32)YH_EXCL_GRID);
     if (words <= EXCL_LDS_WORDS)
         k_excl_pieces<true><<<grid, EXCL_PIECE_THREADS, words * sizeof(u32), db->stream>>>(
-            db->d_work_count, db->d_work, db->d_rpo, db->d_rg, db->d_rrec, db->d_rrecx, db->d_po, (u32)db->n_postings, db->d_pr,
+            db->d_work_count, db->d_work, db->d_rpo, db->d_rg, rec, recx, mult, db->d_po, n_rec, db->d_pr,
             d_maskbits, words, d_hit, d_ex_e, d_ex_m, d_ovsh);
     else
         k_excl_pieces<false><<<grid, EXCL_PIECE_THREADS, 0, db->stream>>>(
-            db->d_work_count, db->d_work, db->d_rpo, db->d_rg, db->d_rrec, db->d_rrecx, db->d_po, (u32)db->n_postings, db->d_pr,
+            db->d_work_count, db->d_work, db->d_rpo, db->d_rg, rec, recx, mult, db->d_po, n_rec, db->d_pr,
             d_maskbits, words, d_hit, d_ex_e, d_ex_m, d_ovsh);
 }
 
@@ -1964,7 +1975,7 @@ static int yh_q_overlap_stream(yh_db* db, const u64* d_sample, u64 n_sample, u32
     k_reduce_replicas<<<(u32)((N + 255) / 256), 256, 0, st>>>(
         db->d_reps, R, N, d_overlap, (make_mask && !fused) ? db->d_mask : nullptr, make_mask ? db->d_maskbits : nullptr,
         (with_index && !fused) ? db->d_excl_e : nullptr,
-        fused ? FusedRun{reps2, db->d_sizes, db->d_nshared, d_fused_excl, d_fused_match, d_bits_out, db->d_rpo, db->d_work,
+        fused ? FusedRun{reps2, db->d_sizes, db->d_nshared, d_fused_excl, d_fused_match, d_bits_out, db->d_hpo, db->d_work,
                          db->d_work_count, (u32)(db->n_ghost ? db->ghost_begin : N)}
               : FusedRun{});
     YH_HIP(hipGetLastError());
@@ -2051,7 +2062,7 @@ int yh_q_run_fused(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap,
                    u32* d_bits_out, const u32* d_global_bits, bool use_indexed) {
     static const bool off = [] { const char* e = getenv("YH_NO_FUSED_RUN"); return e && e[0] == '1'; }();
     if (!db->d_sdelta || !db->has_index || db->posting_only || db->n_refs == 0 || db->n_hashes == 0 ||
-        (db->n_postings && (!db->d_rrec || !db->d_rrecx || !db->d_work)) || n_sample > 0xfffffff0ull)
+        (db->n_postings && (!db->d_hrec || !db->d_hpo || !db->d_work)) || n_sample > 0xfffffff0ull)
         return 1;
     if (phases == 3 && (off || n_sample == 0)) return 1;
     hipStream_t st = db->stream;
@@ -2064,7 +2075,7 @@ int yh_q_run_fused(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap,
             YH_HIP(hipMemsetAsync(db->d_maskbits, 0, ((N + 255) / 256) * 32, st));
             if (d_bits_out) YH_HIP(hipMemsetAsync(d_bits_out, 0, ((N + 63) / 64) * 8, st));
             if (db->d_work_count) YH_HIP(hipMemsetAsync(db->d_work_count, 0, sizeof(u32), st));
-        } else if (use_indexed && db->has_dir && db->d_work && db->d_rrec && db->d_rrecx) {
+        } else if (use_indexed && db->has_dir && db->d_work && db->d_hrec && db->d_hpo) {
             const int rc = yh_q_overlap_indexed(db, d_sample, n_sample, d_overlap, true, d_excl, d_match, d_bits_out, true);
             if (rc != 2) return rc == YH_OK ? YH_ERR_UNSUPPORTED : rc;
         } else {
@@ -2077,7 +2088,7 @@ int yh_q_run_fused(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap,
             k_ghost_bits<<<(u32)((db->n_ghost + 255) / 256), 256, 0, st>>>(d_global_bits, db->d_ghost_src, db->ghost_begin,
                                                                         db->n_ghost, db->d_maskbits);
         if (db->n_chunks)  // + the shared hashes of the subset's references whose other holders are all outside it
-            launch_excl_pieces(db, db->d_maskbits, nullptr, d_excl, nullptr, nullptr);
+            launch_excl_pieces(db, db->d_maskbits, nullptr, d_excl, nullptr, nullptr, true);
         yh_ring_record_end(db, db->ev_excl);
     }
     YH_HIP(hipGetLastError());
@@ -2103,7 +2114,7 @@ int yh_q_overlap_indexed(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_ov
     static const u32 ri_env = [] { const char* e = getenv("YH_INDEX_REPS"); return e ? (u32)atoi(e) : 8u; }();
     while (R > 1 && R > ri_env) R >>= 1;
     static const bool fused_off = [] { const char* e = getenv("YH_NO_FUSED_RUN"); return e && e[0] == '1'; }();
-    const bool fused = d_fused_excl && for_exclusive && db->d_work && db->d_rrec && db->d_rrecx && !fused_off;
+    const bool fused = d_fused_excl && for_exclusive && db->d_work && db->d_hrec && db->d_hpo && !fused_off;
     if (for_exclusive && db->n_shared && !fused) YH_TRY(claim_hit_flags(db));
     u32* const reps2 = db->d_reps + db->reps_cap;
     // (no kernel in front of the lookup: the counters are zero at rest)
@@ -2119,12 +2130,12 @@ int yh_q_overlap_indexed(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_ov
     k_reduce_replicas<<<(u32)((N + 255) / 256), 256, 0, st>>>(
         db->d_reps, R, N, d_overlap, (for_exclusive && !fused) ? db->d_mask : nullptr,
         for_exclusive ? db->d_maskbits : nullptr, (for_exclusive && !fused) ? db->d_excl_e : nullptr,
-        fused ? FusedRun{reps2, db->d_sizes, db->d_nshared, d_fused_excl, d_fused_match, d_bits_out, db->d_rpo, db->d_work,
+        fused ? FusedRun{reps2, db->d_sizes, db->d_nshared, d_fused_excl, d_fused_match, d_bits_out, db->d_hpo, db->d_work,
                          db->d_work_count, (u32)(db->n_ghost ? db->ghost_begin : N)}
               : FusedRun{});
     if (fused && !lookup_half_only) {  // (sharded run: the posting-list half follows the exchange of the subset bits)
         yh_ring_record_begin(db, db->ev_excl);
-        if (db->n_chunks) launch_excl_pieces(db, db->d_maskbits, nullptr, d_fused_excl, nullptr, nullptr);
+        if (db->n_chunks) launch_excl_pieces(db, db->d_maskbits, nullptr, d_fused_excl, nullptr, nullptr, true);
         yh_ring_record_end(db, db->ev_excl);
     }
     YH_HIP(hipGetLastError());
