@@ -144,8 +144,8 @@ static void overlap_probe(uint4* tab, u32* out) {
 }
 
 int main(int argc, char** argv) {
-    const u64 table_gb = argc > 2 ? strtoull(argv[2], nullptr, 10) : 6;
-    const u64 table_bytes = table_gb << 30;
+    const u64 table_mb = argc > 2 ? strtoull(argv[2], nullptr, 10) : 6144;  // table size in MiB
+    const u64 table_bytes = table_mb << 20;
     const u64 nb = table_bytes / 64;
     uint4* tab; u32* out; u64* keys;
     CK(hipMalloc(&tab, table_bytes));

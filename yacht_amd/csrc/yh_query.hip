@@ -1437,6 +1437,21 @@ __global__ void __launch_bounds__(256) k_overlap_bsearch(const u64* __restrict__
 // its holder (or the posting list of a shared hash) -> replicated counters.  Work is proportional
 // to |S|, not to the database: ~3 dependent memory round trips per sample hash instead of
 // streaming every reference hash.  Also flags the shared hashes found (hit[], for R2).
+// The posting list of a shared hash found in the sample: every holder counts one hit.  The holders are requested
+// four at a time (a list of 8 was 8 dependent round trips: the tail of the launch for a sample of cluster members).
+template <typename Add>
+__device__ __forceinline__ void walk_holders(const u64* __restrict__ po, const u32* __restrict__ pr, u32 gi, Add add) {
+    const u64 q0 = po[gi], qe = po[gi + 1];
+    for (u64 q = q0; q < qe; q += 4) {
+        u32 h[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) h[i] = pr[min(q + (u64)i, qe - 1)];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (q + (u64)i < qe) add(h[i]);
+    }
+}
+
 __global__ void __launch_bounds__(256) k_index_lookup(const u64* __restrict__ sample, u64 n, const YhDirView dv,
                                                       const u64* __restrict__ po, const u32* __restrict__ pr,
                                                       u32* __restrict__ reps, u32 rep_mask, u64 n_refs,
@@ -1454,13 +1469,96 @@ __global__ void __launch_bounds__(256) k_index_lookup(const u64* __restrict__ sa
         } else {
             const u32 gi = r & 0x7fffffffu;
             if (hit) hit[gi] = 1;
-            for (u64 q = po[gi], qe = po[gi + 1]; q < qe; ++q) {
-                const u32 h = pr[q];
+            walk_holders(po, pr, gi, [&](u32 h) {
                 count_add(&my[h], 1u);
                 if (my2) count_add(&my2[h], 1u);
-            }
+            });
         }
     }
+}
+
+// The same lookup for LARGE samples: a workgroup of IDX_THREADS lanes takes a tile of IDX_THREADS x U consecutive
+// sample hashes, every lane has its U bucket reads in flight together, and the hits are summed per reference in an
+// LDS table that leaves as ONE global atomic per (workgroup, reference) at the end.  In hash order the hits of a
+// genome that is really in the sample (thousands of them) are spread evenly over the workgroups, and same-address
+// atomics are serialized memory-side: with one atomic per hit the hottest counter is the tail of the launch (one
+// 10^6-hash sample repeated, so that its buckets stay in the Infinity Cache: 1.9e5 hits on 284 references 35.1 us, no
+// hit at all 25.1 us, tiles 29.8 us; rotating samples, buckets from HBM: 38-40 -> 36 us, no hit 32).
+#ifndef YH_IDX_THREADS
+#define YH_IDX_THREADS 1024
+#endif
+#ifndef YH_IDX_TBITS
+#define YH_IDX_TBITS 10
+#endif
+constexpr int IDX_THREADS = YH_IDX_THREADS;
+constexpr u32 IDX_TSLOTS = 1u << YH_IDX_TBITS;
+template <int U>
+__global__ void __launch_bounds__(IDX_THREADS) k_index_lookup_tile(const u64* __restrict__ sample, u64 n, const YhDirView dv,
+                                                                   const u64* __restrict__ po, const u32* __restrict__ pr,
+                                                                   u32* __restrict__ reps, u32 rep_mask, u64 n_refs,
+                                                                   u8* __restrict__ hit, u32* __restrict__ reps2,
+                                                                   u32* __restrict__ work_count, const u32* __restrict__ bad,
+                                                                   u32 bad_gen) {
+    __shared__ u32 tkey[IDX_TSLOTS];   // reference + 1, 0 = empty
+    __shared__ u32 tcnt[IDX_TSLOTS];   // hits
+    __shared__ u32 tcnt2[IDX_TSLOTS];  // hits on shared hashes
+    if (work_count && blockIdx.x == 0 && threadIdx.x == 0) *work_count = 0;
+    if (bad && *bad == bad_gen) return;
+    u32* my = reps + (u64)replica_of(blockIdx.x, rep_mask) * n_refs;
+    u32* my2 = reps2 ? reps2 + (u64)replica_of(blockIdx.x, rep_mask) * n_refs : nullptr;
+    const u64 base = blockIdx.x * (u64)(IDX_THREADS * U);
+    u64 h[U];
+    bool ok[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const u64 t = base + (u64)u * IDX_THREADS + threadIdx.x;
+        h[u] = sample[min(t, n - 1)];
+        ok[u] = t < n && h[u] <= dv.max_hash;
+        if (!ok[u]) h[u] = 0;  // (still a valid bucket to read)
+    }
+    for (u32 k = threadIdx.x; k < IDX_TSLOTS; k += IDX_THREADS) { tkey[k] = 0; tcnt[k] = 0; tcnt2[k] = 0; }
+    YhDirView::v4u a[U], b[U], c[U], d[U];
+    u32 r[U];
+    if (dv.cbkt) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) dv.cbkt_request(h[u], a[u], b[u], c[u], d[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) asm volatile("" : "+v"(a[u]), "+v"(b[u]), "+v"(c[u]), "+v"(d[u]));  // (see YhDirView::find)
+    }
+    __syncthreads();  // the table is clear
+    auto add = [&](u32 ref, bool shared) {
+        u32 slot = (ref * 2654435761u) >> (32 - YH_IDX_TBITS);
+#pragma unroll 1
+        for (int probe = 0; probe < 2; ++probe, slot = (slot + 1) & (IDX_TSLOTS - 1)) {
+            const u32 old = atomicCAS(&tkey[slot], 0u, ref + 1);
+            if (old == 0 || old == ref + 1) {
+                atomicAdd(&tcnt[slot], 1u);
+                if (shared && my2) atomicAdd(&tcnt2[slot], 1u);
+                return;
+            }
+        }
+        count_add(&my[ref], 1u);  // crowded table: count directly
+        if (shared && my2) count_add(&my2[ref], 1u);
+    };
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        r[u] = YH_DIR_NONE;
+        if (ok[u]) r[u] = dv.cbkt ? dv.cbkt_resolve(h[u], a[u], b[u], c[u], d[u]) : dv.find(h[u]);
+        if (r[u] == YH_DIR_NONE) continue;
+        if (!(r[u] & 0x80000000u)) {
+            add(r[u], false);
+        } else {
+            const u32 gi = r[u] & 0x7fffffffu;
+            if (hit) hit[gi] = 1;
+            walk_holders(po, pr, gi, [&](u32 holder) { add(holder, true); });
+        }
+    }
+    __syncthreads();
+    for (u32 k = threadIdx.x; k < IDX_TSLOTS; k += IDX_THREADS)
+        if (tkey[k]) {
+            count_add(&my[tkey[k] - 1], tcnt[k]);
+            if (my2 && tcnt2[k]) count_add(&my2[tkey[k] - 1], tcnt2[k]);
+        }
 }
 
 // ---- exclusive counts -----------------------------------------------------------------------------
@@ -2111,19 +2209,37 @@ int yh_q_overlap_indexed(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_ov
     YH_TRY(ensure_reps(db, R));
     // (k_reduce_replicas reads every replica of both sets: 16 -> 8 replicas took 4 us off the step, with no
     // measurable change of the lookup kernel at 1.3e5 hits per sample)
-    static const u32 ri_env = [] { const char* e = getenv("YH_INDEX_REPS"); return e ? (u32)atoi(e) : 8u; }();
-    while (R > 1 && R > ri_env) R >>= 1;
+    static const u32 ri_env = [] { const char* e = getenv("YH_INDEX_REPS"); return e ? (u32)atoi(e) : 0u; }();
+    // tiles of IDX_THREADS x U hashes once there are enough of them for every CU (k_index_lookup_tile)
+    // (measured, 10^6-hash rotating samples with 1.6e5 hits: one hash per lane in 256-lane workgroups 38-40 us, tiles of U = 2
+    // 35.7-36.3, U = 4 slower; no hits at all 32.5 / 31.5; an 83 k-hash sample 13 / 23)
+    static const long tile_env = [] { const char* e = getenv("YH_INDEX_TILE"); return e ? atol(e) : -1L; }();  // 0 = never, 1/2/4 = U
+    int U = n_sample >= 192ull * IDX_THREADS * 2 ? 2 : 0;
+    if (tile_env >= 0) U = (int)tile_env;
+    // the tiles leave one atomic per (workgroup, reference): four replicas are enough there (step 49.9 -> 48.4 us; two: 51.7)
+    const u32 r_want = ri_env ? ri_env : (U ? 4u : 8u);
+    while (R > 1 && R > r_want) R >>= 1;
     static const bool fused_off = [] { const char* e = getenv("YH_NO_FUSED_RUN"); return e && e[0] == '1'; }();
     const bool fused = d_fused_excl && for_exclusive && db->d_work && db->d_hrec && db->d_hpo && !fused_off;
     if (for_exclusive && db->n_shared && !fused) YH_TRY(claim_hit_flags(db));
     u32* const reps2 = db->d_reps + db->reps_cap;
     // (no kernel in front of the lookup: the counters are zero at rest)
     yh_ring_record_begin(db, db->ev_overlap);
-    if (n_sample && db->n_distinct)
+    u8* const d_hitflags = (for_exclusive && db->n_shared && !fused) ? db->d_hit : nullptr;
+    u32* const d_reps2 = fused ? reps2 : nullptr;
+    if (n_sample && db->n_distinct && U) {
+        const u32 grid = (u32)((n_sample + (u64)IDX_THREADS * U - 1) / ((u64)IDX_THREADS * U));
+#define YH_TILE_LAUNCH(UU)                                                                                                       \
+    k_index_lookup_tile<UU><<<grid, IDX_THREADS, 0, st>>>(d_sample, n_sample, yh_dir_view(db), db->d_po, db->d_pr, db->d_reps,  \
+                                                          R - 1, N, d_hitflags, d_reps2, db->d_work_count, db->d_bad, db->bad_gen)
+        if (U == 4) YH_TILE_LAUNCH(4);
+        else if (U == 2) YH_TILE_LAUNCH(2);
+        else YH_TILE_LAUNCH(1);
+#undef YH_TILE_LAUNCH
+    } else if (n_sample && db->n_distinct)
         k_index_lookup<<<grid_for(n_sample, 256, 4096), 256, 0, st>>>(d_sample, n_sample, yh_dir_view(db), db->d_po, db->d_pr,
-                                                                      db->d_reps, R - 1, N,
-                                                                      (for_exclusive && db->n_shared && !fused) ? db->d_hit : nullptr,
-                                                                      fused ? reps2 : nullptr, db->d_work_count, db->d_bad, db->bad_gen);
+                                                                      db->d_reps, R - 1, N, d_hitflags, d_reps2, db->d_work_count,
+                                                                      db->d_bad, db->bad_gen);
     else if (fused && db->d_work_count)
         YH_HIP(hipMemsetAsync(db->d_work_count, 0, sizeof(u32), st));
     yh_ring_record_end(db, db->ev_overlap);
