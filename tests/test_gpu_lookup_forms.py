@@ -1,0 +1,30 @@
+"""GPU: the forms of the sample-driven lookup that only large inputs reach by themselves -- the tiled kernel with
+its LDS hit table (samples of 4e5+ hashes) and the presence filter in front of the buckets (databases of 1e6+
+distinct hashes) -- forced onto the small randomized cases of tests/tools/fuzz_parity.py, where the CPU oracle
+checks every count.  The knobs are read once per process, hence the subprocess."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("env", [
+    {"YH_INDEX_TILE": "2", "YH_FILTER_MIN": "1", "YH_FILTER_BPH": "2"},   # crowded filter: many false positives
+    {"YH_INDEX_TILE": "1", "YH_FILTER_MIN": "1", "YH_FILTER_BPH": "16"},
+    {"YH_INDEX_TILE": "4", "YH_NO_FILTER": "1"},
+], ids=["tile2-filter2", "tile1-filter16", "tile4-nofilter"])
+def test_forced_lookup_forms_against_oracle(hip_lib, env):
+    e = dict(os.environ)
+    e.update(env)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "fuzz_parity.py"), "--seconds", "25", "--seed", "31"],
+                       env=e, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
+    res = json.loads(line)
+    assert p.returncode == 0 and res["fuzz"] == "ok", line + p.stderr[-2000:]
+    assert res["rounds"] >= 10

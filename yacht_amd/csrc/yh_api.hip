@@ -344,7 +344,7 @@ int yh_db_destroy(yh_db* db) {
         if (db->ctx_count[1]) (void)hipFree(db->ctx_count[1]);
     }
     void* ptrs[] = {db->d_values, db->d_offsets, db->d_pvals, db->d_pbeg, db->d_pcnt, db->d_poffs, db->d_sizes,
-                    db->d_g, db->d_po, db->d_pr, db->d_pg, db->d_gbeg, db->d_gcnt, db->d_nshared, db->d_pq, db->d_pq_count, db->d_dh, db->d_dref, db->d_dir, db->d_bkt, db->d_cbkt, db->d_ovf_keys, db->d_ovf_vals, db->d_pkeys, db->d_pref, db->d_gkeys, db->d_rpo, db->d_rg, db->d_rrec, db->d_rrecx, db->d_hrec, db->d_hrecx, db->d_hmult, db->d_hpo, db->d_work, db->d_work_count, db->d_sbounds,
+                    db->d_g, db->d_po, db->d_pr, db->d_pg, db->d_gbeg, db->d_gcnt, db->d_nshared, db->d_pq, db->d_pq_count, db->d_dh, db->d_dref, db->d_dir, db->d_bkt, db->d_cbkt, db->d_ovf_keys, db->d_ovf_vals, db->d_pkeys, db->d_pref, db->d_gkeys, db->d_rpo, db->d_rg, db->d_rrec, db->d_rrecx, db->d_filter, db->d_hrec, db->d_hrecx, db->d_hmult, db->d_hpo, db->d_work, db->d_work_count, db->d_sbounds,
                     db->d_mask, db->d_maskbits, db->d_hit, db->d_excl_e, db->d_overlap_tmp,
                     db->d_sample_tmp, db->d_out_tmp, db->d_flag, db->d_hitq, db->d_hitq_cnt, db->d_wg_first, db->d_reps, db->d_batch,
                     db->d_sdelta, db->d_shdr, db->d_srec, db->d_wg_key, db->d_ghost_src, db->d_bad_word};

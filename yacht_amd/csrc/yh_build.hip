@@ -490,6 +490,13 @@ __global__ void k_fill_rg(u64 n_post, const u32* __restrict__ pr, const u32* __r
         }
     }
 }
+// presence filter of the distinct hashes (yh_db::d_filter): bit floor(h * n_bits / (max_hash + 1))
+__global__ void k_filter_build(const u64* __restrict__ dh, u64 n, u32 lsh, u64 fmul, u32* __restrict__ filter) {
+    for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+        const u64 bit = __umul64hi(dh[i] << lsh, fmul);
+        atomicOr(&filter[bit >> 5], 1u << (bit & 31u));
+    }
+}
 __global__ void k_bounds_u64(const u64* __restrict__ a, u64 n, u32 P, u32 pshift, u64* __restrict__ beg,
                              u64* __restrict__ cnt) {
     const u32 p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -906,6 +913,24 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, const u
                                                                             reinterpret_cast<u32*>(db->d_cbkt), db->d_ovf_keys,
                                                                             db->d_ovf_vals, db->ovf_mask);
             IDX_HIP(hipGetLastError());
+            // Presence filter in front of the buckets (k_index_lookup_tile): one bit per 1 / YH_FILTER_BPH of a hash's
+            // share of the range, indexed monotonically like the buckets, so that a sorted sample walks it front to back.
+            // A sample hash whose bit is clear is not in the database and its bucket is never read.
+            static const u32 fbph = [] { const char* e = getenv("YH_FILTER_BPH"); return e ? (u32)atoi(e) : 4u; }();
+            // (below ~10^6 distinct hashes the whole table is cache resident and the filter only adds a dependent read;
+            // YH_FILTER_MIN lowers the bar for tests)
+            static const u64 fmin = [] { const char* e = getenv("YH_FILTER_MIN"); return e ? (u64)atoll(e) : (u64)(1u << 20); }();
+            if (rc == YH_OK && fbph && db->n_distinct >= fmin) {
+                const u64 fbits = ((db->n_distinct * fbph + 511) / 512) * 512;
+                db->filter_mul = mul_for(fbits);
+                db->filter_bits = fbits;
+                rc = yh_dmalloc(db, (void**)&db->d_filter, fbits / 8 + 64);
+                IDX_HIP(hipMemsetAsync(db->d_filter, 0, fbits / 8 + 64, st));
+                if (rc == YH_OK && db->filter_mul)
+                    k_filter_build<<<grid_for(db->n_distinct, 256), 256, 0, st>>>(d_dh_tmp, db->n_distinct, db->bkt_lsh, db->filter_mul,
+                                                                                  db->d_filter);
+                IDX_HIP(hipGetLastError());
+            }
             IDX_HIP(hipStreamSynchronize(st));
         }
         IDX_HIP(hipStreamSynchronize(st));

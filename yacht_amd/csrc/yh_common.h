@@ -199,6 +199,9 @@ struct yh_db {
                                // {o0, o1, o2, count <= 7} (others 3..6 in d_rrecx) or, for nine holders and
                                // more, {first index in d_pr, holders, 0, ~0}
     uint4* d_rrecx = nullptr;  // [n_postings] {o3, o4, o5, o6}
+    // presence filter of the distinct hashes in front of the compact buckets: bit umulhi(h << bkt_lsh, filter_mul)
+    u32* d_filter = nullptr;
+    u64 filter_mul = 0, filter_bits = 0;
     // the DISTINCT holder sets of every reference with their multiplicities (what the fused run step walks instead of
     // the postings): records as d_rrec / d_rrecx, reference-major, reference r owns [d_hpo[r], d_hpo[r + 1])
     uint4* d_hrec = nullptr;   // [n_sets]

@@ -1494,6 +1494,7 @@ constexpr int IDX_THREADS = YH_IDX_THREADS;
 constexpr u32 IDX_TSLOTS = 1u << YH_IDX_TBITS;
 template <int U>
 __global__ void __launch_bounds__(IDX_THREADS) k_index_lookup_tile(const u64* __restrict__ sample, u64 n, const YhDirView dv,
+                                                                   const u32* __restrict__ filter, u64 filter_mul,
                                                                    const u64* __restrict__ po, const u32* __restrict__ pr,
                                                                    u32* __restrict__ reps, u32 rep_mask, u64 n_refs,
                                                                    u8* __restrict__ hit, u32* __restrict__ reps2,
@@ -1519,9 +1520,23 @@ __global__ void __launch_bounds__(IDX_THREADS) k_index_lookup_tile(const u64* __
     for (u32 k = threadIdx.x; k < IDX_TSLOTS; k += IDX_THREADS) { tkey[k] = 0; tcnt[k] = 0; tcnt2[k] = 0; }
     YhDirView::v4u a[U], b[U], c[U], d[U];
     u32 r[U];
+    if (filter) {  // the presence bits first: a hash whose bit is clear is not in the database (yh_db::d_filter)
+        u64 bit[U];
+        u32 w[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            bit[u] = yh_bucket_of(h[u], dv.bkt_lsh, filter_mul);
+            w[u] = filter[bit[u] >> 5];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) ok[u] = ok[u] && ((w[u] >> (bit[u] & 31u)) & 1u);
+    }
     if (dv.cbkt) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) dv.cbkt_request(h[u], a[u], b[u], c[u], d[u]);
+        for (int u = 0; u < U; ++u) {
+            a[u] = b[u] = c[u] = d[u] = YhDirView::v4u{0u, 0u, 0u, 0u};
+            if (ok[u]) dv.cbkt_request(h[u], a[u], b[u], c[u], d[u]);
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u) asm volatile("" : "+v"(a[u]), "+v"(b[u]), "+v"(c[u]), "+v"(d[u]));  // (see YhDirView::find)
     }
@@ -2227,10 +2242,12 @@ int yh_q_overlap_indexed(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_ov
     yh_ring_record_begin(db, db->ev_overlap);
     u8* const d_hitflags = (for_exclusive && db->n_shared && !fused) ? db->d_hit : nullptr;
     u32* const d_reps2 = fused ? reps2 : nullptr;
+    static const bool filter_off = [] { const char* e = getenv("YH_NO_FILTER"); return e && e[0] == '1'; }();
+    const u32* const d_filter = (db->d_cbkt && !filter_off) ? db->d_filter : nullptr;
     if (n_sample && db->n_distinct && U) {
         const u32 grid = (u32)((n_sample + (u64)IDX_THREADS * U - 1) / ((u64)IDX_THREADS * U));
 #define YH_TILE_LAUNCH(UU)                                                                                                       \
-    k_index_lookup_tile<UU><<<grid, IDX_THREADS, 0, st>>>(d_sample, n_sample, yh_dir_view(db), db->d_po, db->d_pr, db->d_reps,  \
+    k_index_lookup_tile<UU><<<grid, IDX_THREADS, 0, st>>>(d_sample, n_sample, yh_dir_view(db), d_filter, db->filter_mul, db->d_po, db->d_pr, db->d_reps,  \
                                                           R - 1, N, d_hitflags, d_reps2, db->d_work_count, db->d_bad, db->bad_gen)
         if (U == 4) YH_TILE_LAUNCH(4);
         else if (U == 2) YH_TILE_LAUNCH(2);
