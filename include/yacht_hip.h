@@ -86,6 +86,9 @@ typedef struct yh_db_info {
     uint32_t stream_layout;      /* what the streaming overlap kernel reads: YH_STREAM_*      */
     uint32_t stream_shift;       /* delta stream: stream key = hash >> stream_shift           */
     uint64_t stream_bytes;       /* bytes of that array = HBM bytes one query has to stream   */
+    uint64_t n_holder_sets;      /* distinct (reference, set of other holders) records the run step's
+                                    exclusive pass walks instead of the n_shared_postings postings  */
+    uint64_t filter_bytes;       /* presence filter in front of the bucket table (0: none)    */
 } yh_db_info;
 
 /* yh_db_info.stream_layout */

@@ -60,6 +60,8 @@ for kernel, name, factor, why in (
     write_kib, nw = mean_counter("pmc_write", "WRITE_SIZE", kernel)
     if not nf:
         continue
+    if name == "index" and mean_counter("pmc_fetch", "FETCH_SIZE", "k_index_lookup_tile")[1]:
+        kernel = "k_index_lookup_tile"  # (the form large samples take; bench.py names the same one)
     rec = {"kernel": kernel, "n_hashes": n_hashes, "source_tag": source_tag(), "commit": commit,
            "taken": datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%MZ"),
            "FETCH_SIZE_KiB_mean": fetch_kib, "launches_fetch": nf, "WRITE_SIZE_KiB_mean": write_kib, "launches_write": nw,

@@ -51,8 +51,8 @@ if trace:
     rows = list(csv.DictReader(open(trace[0])))
     rows = [r for r in rows if any(t in r["Kernel_Name"] for t in OURS) or "Memset" in r["Kernel_Name"] or "fill" in r["Kernel_Name"].lower()]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    for tag, title in (("k_stream_lookup(", "streaming step"), ("k_index_lookup(", "sample-driven step (k_index_lookup)")):
-        idx = [i for i, r in enumerate(rows) if tag in r["Kernel_Name"].replace("(anonymous namespace)::", "") + "("]
+    for tag, title in (("k_stream_lookup", "streaming step"), ("k_index_lookup", "sample-driven step (k_index_lookup / k_index_lookup_tile)")):
+        idx = [i for i, r in enumerate(rows) if tag in r["Kernel_Name"]]
         # two consecutive launches of the same lookup kernel with only step kernels between them
         pairs = [(a, b) for a, b in zip(idx, idx[1:]) if b - a <= 4]
         if not pairs:

@@ -63,6 +63,8 @@ class DbInfo(C.Structure):
         ("stream_layout", C.c_uint32),
         ("stream_shift", C.c_uint32),
         ("stream_bytes", C.c_uint64),
+        ("n_holder_sets", C.c_uint64),
+        ("filter_bytes", C.c_uint64),
     ]
 
 

@@ -389,6 +389,8 @@ int yh_db_get_info(yh_db* db, yh_db_info* info) {
     info->device_bytes = db->device_bytes;
     info->device_id = db->device;
     info->flags = db->flags;
+    info->n_holder_sets = db->d_hrec ? db->n_sets : 0;
+    info->filter_bytes = db->d_filter ? db->filter_bits / 8 : 0;
     if (db->d_sdelta) {
         info->stream_layout = YH_STREAM_DELTA;
         info->stream_shift = db->sshift;
