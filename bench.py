@@ -67,6 +67,8 @@ def parse_args():
     ap.add_argument("--no-indexed", action="store_true", help="skip the extra measurement of the sample-driven path")
     ap.add_argument("--no-host-inclusive", action="store_true")
     ap.add_argument("--no-real-shape", action="store_true")
+    ap.add_argument("--no-batched", action="store_true")
+    ap.add_argument("--batch-samples", type=int, default=32, help="samples per yh_run_batch_device call of the `batched` leg (<= 64)")
     ap.add_argument("--host-depth", type=int, default=3, help="host-inclusive leg: calls in flight (1..4)")
     ap.add_argument("--percentile-steps", type=int, default=200)
     ap.add_argument("--sync-gather", action="store_true", help="N>1: blocking gather of the count rows inside every step")
@@ -493,6 +495,47 @@ def main() -> int:
                           lookup_kernel_ms_avg=round(float(tm["ms_overlap_kernel"]), 4),
                           exclusive_kernels_ms_avg=round(float(tm["ms_exclusive_kernels"]), 4))
 
+    # ---- batched run: many samples against the resident database in ONE call -----------
+    # Not `value` (a step there is one sample, as the reference runs them): the throughput a caller gets who has
+    # the samples of a whole plate in hand.  Distinct samples, so that none finds its buckets cached.
+    batched = None
+    if not multi and not args.no_batched and args.workload == "gtdb_rs214_scale" and not args.no_indexed:
+        Bn = max(1, min(int(args.batch_samples), 64))
+        bs = [samples[i] if i < K else synth.global_db_sample_device(plan, args.seed + 7000 + i, n_sample=args.sample_hashes,
+                                                                     n_present=n_present, device=str(dev)) for i in range(Bn)]
+        cat = torch.cat(bs).contiguous()
+        soff = torch.zeros(Bn + 1, dtype=torch.int64, device=dev)
+        soff[1:] = torch.cumsum(torch.tensor([int(b.numel()) for b in bs], device=dev, dtype=torch.int64), 0)
+        bout = torch.zeros((3, Bn, n_local), device=dev, dtype=torch.int32)
+        single = torch.zeros((3, n_local), device=dev, dtype=torch.int32)
+        torch.cuda.synchronize()
+
+        def step_batch():
+            with torch.cuda.stream(stream):
+                db.run_batch_device(cat.data_ptr(), soff.data_ptr(), Bn, int(cat.numel()), bout[0].data_ptr(), bout[1].data_ptr(),
+                                    bout[2].data_ptr())
+
+        for _ in range(2):
+            step_batch()
+        fence()
+        reps_b = max(3, min(20, args.steps // Bn + 1))
+        t0 = time.perf_counter()
+        for _ in range(reps_b):
+            step_batch()
+        fence()
+        el_b = (time.perf_counter() - t0) / reps_b
+        same = True
+        for i in (0, Bn // 2, Bn - 1):  # the same counts as the single-sample step
+            with torch.cuda.stream(stream):
+                db.run_device(bs[i].data_ptr(), bs[i].numel(), single[0].data_ptr(), single[1].data_ptr(), single[2].data_ptr())
+            fence()
+            same = same and bool(torch.equal(single, bout[:, i, :]))
+        batched = {"samples_per_call": Bn, "ms_per_call": round(1e3 * el_b, 4), "ms_per_sample": round(1e3 * el_b / Bn, 4),
+                   "value": round(n_local * Bn / el_b, 1), "unit": "queries/s", "equals_single_sample_step": same,
+                   "how": "yh_run_batch_device: one lookup pass over the hashes of all samples + one exclusive pass with "
+                          "64-bit per-sample words; device-resident, distinct samples"}
+        del cat, bout, bs
+
     # ---- roofline of the dominant kernel of the DEFAULT step --------------------------------------------
     # Streaming lookup (k_stream_lookup): `achieved` = bytes one launch HAS to move in the layout the kernel
     # reads (yh_db_info.stream_bytes: one delta byte per (hash, reference) pair + an 8-byte header per 1024,
@@ -671,6 +714,7 @@ def main() -> int:
             "device_resident": device_resident,
             "host_inclusive": host_inclusive,
             "real_shape": real_shape,
+            "batched": batched,
             "paths": paths,
             "roofline_other_path": other,
         }
@@ -685,6 +729,9 @@ def main() -> int:
         dist.destroy_process_group()
     if rank == 0 and any(not p_["equals_default_path"] for p_ in paths.values()):
         print("bench.py: the two lookup paths differ", file=sys.stderr)
+        return 1
+    if rank == 0 and batched is not None and not batched["equals_single_sample_step"]:
+        print("bench.py: the batched run differs from the single-sample step", file=sys.stderr)
         return 1
     if rank == 0 and host_inclusive is not None and not host_inclusive["equals_device_resident"]:
         print("bench.py: host-buffer path differs from the device-resident path", file=sys.stderr)

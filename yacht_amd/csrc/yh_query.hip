@@ -68,6 +68,11 @@ __device__ __forceinline__ void count_add(u32* p, u32 v) {
     atomicAdd(p, v);
 #endif
 }
+// the presence filter a lookup may read in front of the compact buckets (null: none, or YH_NO_FILTER=1)
+static const u32* yh_filter_of(const yh_db* db) {
+    static const bool filter_off = [] { const char* e = getenv("YH_NO_FILTER"); return e && e[0] == '1'; }();
+    return (db->d_cbkt && db->d_filter && db->filter_mul && !filter_off) ? db->d_filter : nullptr;
+}
 __device__ __forceinline__ u32 replica_of(u32 wg, u32 rep_mask) {
 #if YH_XCD_ATOMICS
     return xcc_id() & rep_mask;
@@ -2242,8 +2247,7 @@ int yh_q_overlap_indexed(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_ov
     yh_ring_record_begin(db, db->ev_overlap);
     u8* const d_hitflags = (for_exclusive && db->n_shared && !fused) ? db->d_hit : nullptr;
     u32* const d_reps2 = fused ? reps2 : nullptr;
-    static const bool filter_off = [] { const char* e = getenv("YH_NO_FILTER"); return e && e[0] == '1'; }();
-    const u32* const d_filter = (db->d_cbkt && !filter_off) ? db->d_filter : nullptr;
+    const u32* const d_filter = yh_filter_of(db);
     if (n_sample && db->n_distinct && U) {
         const u32 grid = (u32)((n_sample + (u64)IDX_THREADS * U - 1) / ((u64)IDX_THREADS * U));
 #define YH_TILE_LAUNCH(UU)                                                                                                       \
@@ -2527,7 +2531,8 @@ __global__ void __launch_bounds__(256) k_batch_lookup(const u64* __restrict__ sa
                                                       u32 n_samples, const YhDirView dv, const u64* __restrict__ po,
                                                       const u32* __restrict__ pr, u64 n_refs,
                                                       u32* __restrict__ overlap /* [B][N] */, u64* __restrict__ hitword,
-                                                      u64 n_chunks, u64 chunk_mul) {
+                                                      u64 n_chunks, u64 chunk_mul, const u32* __restrict__ filter,
+                                                      u64 filter_mul) {
     __shared__ u64 off[65];
     if (threadIdx.x <= n_samples) off[threadIdx.x] = soff[threadIdx.x];
     __syncthreads();
@@ -2544,7 +2549,12 @@ __global__ void __launch_bounds__(256) k_batch_lookup(const u64* __restrict__ sa
             if (off[mid] <= t) lo = mid; else hi = mid;
         }
         const u32 s = lo;
-        const u32 r = dv.find(samples[t]);
+        const u64 h = samples[t];
+        if (filter && h <= dv.max_hash) {  // presence bit first (yh_db::d_filter): clear = not in the database
+            const u64 bit = yh_bucket_of(h, dv.bkt_lsh, filter_mul);
+            if (!((filter[bit >> 5] >> (bit & 31u)) & 1u)) continue;
+        }
+        const u32 r = dv.find(h);
         if (r == YH_DIR_NONE) continue;
         u32* row = overlap + (u64)s * n_refs;
         if (!(r & 0x80000000u)) {
@@ -2666,7 +2676,7 @@ int yh_q_run_batch(yh_db* db, const u64* d_samples, const u64* d_soff, u32 n_sam
         while (gcd(mul, n_chunks) != 1) mul += 2;
         k_batch_lookup<<<(u32)std::min<u64>(n_chunks, 8192), 256, 0, st>>>(d_samples, d_soff, n_samples, yh_dir_view(db),
                                                                            db->d_po, db->d_pr, N, d_overlap, d_hitword,
-                                                                           n_chunks, mul);
+                                                                           n_chunks, mul, yh_filter_of(db), db->filter_mul);
     }
     yh_ring_record_end(db, db->ev_overlap);
     yh_ring_record_begin(db, db->ev_excl);
