@@ -100,3 +100,30 @@ def test_real_hit_shape_against_oracle(hip_lib, n_refs):
         we, wm = oracle.exclusive(values, offsets, half, sample)
         e3, m3 = db.exclusive(half, sample)
         assert np.array_equal(e3, we) and np.array_equal(m3, wm)
+
+
+def test_holder_sets_are_the_distinct_ones(hip_lib):
+    """yh_db_info.n_holder_sets: the run step's exclusive pass walks one record per DISTINCT (reference, set of other
+    holders of a shared hash) -- counted here with Python sets from the CSR -- and the counts it produces from
+    them equal the oracle's (clusters, a hash held by every reference, duplicates of whole sketches)."""
+    rng = np.random.default_rng(99)
+    refs = synth.clustered_refs(rng, 120, (1.0, 0.9, 0.5, 0.25, 0.1), 600)
+    everywhere = np.array([7, 9], np.uint64)  # held by all: holder lists longer than the seven inline slots
+    refs = [np.unique(np.concatenate([r, everywhere])) for r in refs] + [refs[3].copy(), np.zeros(0, np.uint64)]
+    values, offsets = synth.pack(refs)
+    holders = {}
+    for j, r in enumerate(refs):
+        for h in r.tolist():
+            holders.setdefault(h, []).append(j)
+    want_sets = 0
+    for j, r in enumerate(refs):  # (a list of more than seven others is kept by reference to its postings: one record per hash)
+        want_sets += len({(tuple(o for o in holders[h] if o != j) if len(holders[h]) <= 8 else ("long", h))
+                          for h in r.tolist() if len(holders[h]) > 1})
+    sample = synth.sample_from_refs(rng, refs, list(range(0, len(refs), 5)), 0.6, 5000)
+    want_ov = oracle.overlap(values, offsets, sample)
+    want_e, want_m = oracle.exclusive(values, offsets, want_ov > 0, sample)
+    with RefDB(values, offsets) as db:
+        info = db.info()
+        assert info["n_holder_sets"] == want_sets and want_sets < info["n_shared_postings"]
+        ov, e, m = db.run_counts(sample)
+        assert np.array_equal(ov, want_ov) and np.array_equal(e, want_e) and np.array_equal(m, want_m)
