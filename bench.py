@@ -182,7 +182,7 @@ def main() -> int:
     sdb = None
     with torch.cuda.stream(stream):
         if multi:
-            sdb = ydist.ShardedRefDB(values, offsets, ydist.HipLocalBackend(local_rank))
+            sdb = ydist.ShardedRefDB(values, offsets, ydist.HipLocalBackend(local_rank), block=max(1, min(args.gather_every, 8)))
             db = sdb.local.handle
             n_rows = torch.tensor([sdb.n_rows], device=dev, dtype=torch.int64)
             n_rows_c = ydist._stage(n_rows, None)
@@ -197,15 +197,16 @@ def main() -> int:
     assert stream.cuda_stream != 0
     info = db.info()
 
-    # Count rows: N = 1 alternates two buffers.  N > 1: the rows of GB = --gather-every consecutive samples (default 8)
-    # fill one block [GB, 3, row_stride] and leave in ONE all-gather per block -- the north star's "final gather of
-    # the per-reference counts", amortised: a torch collective costs the host ~30 us per call, and two of them per
-    # step made the N > 1 loop host-bound (0.09 ms per step issued).  Two blocks alternate: a block is refilled only
-    # after the collective reading it has completed (work.wait() = a stream-level wait).  The subset-bit exchange
-    # INSIDE a step stays per sample (dist.ShardedRefDB), and with two step contexts it is in flight while the next
-    # sample's lookup runs.
+    # Count rows: N = 1 alternates two buffers.  N > 1: the samples go in BLOCKS of GB = --gather-every (default 8, at
+    # most 8): every sample's rank-local half (lookup + reduce) runs in its own step context of the library, the subset
+    # bits of the whole block leave in ONE all-gather, then the second halves follow and the block's count rows
+    # [GB, 3, row_stride] leave in ONE all-gather -- the north star's "final gather of the per-reference counts".
+    # A torch collective costs the host ~30 us per call and the device two cross-queue hand-overs: per sample that
+    # made the N > 1 loop host-bound (0.06-0.09 ms per step issued); per block it is an eighth of that.  Two blocks
+    # alternate: while the bits of block b travel, the local halves of block b+1 are queued; a block's buffers are
+    # refilled only after the collectives reading them have completed (work.wait() = a stream-level wait).
     NBUF = 2
-    GB = max(1, args.gather_every) if multi else 1
+    GB = max(1, min(args.gather_every, 8)) if multi else 1  # (two blocks in flight use 2 * GB of the library's 16 step contexts)
     counts_blk = [torch.zeros((GB, 3, row_stride), device=dev, dtype=torch.int32) for _ in range(NBUF)]
     gathered_blk = [torch.zeros((world, GB, 3, row_stride), device=dev, dtype=torch.int32) if multi else None
                     for _ in range(NBUF)]
@@ -226,10 +227,20 @@ def main() -> int:
         else:
             pending[blk] = dist.all_gather_into_tensor(gathered_blk[blk], counts_blk[blk], async_op=True)
 
-    def finish(i):  # second half of sample i (context i % 2); its block leaves when it was the last one in it
-        sdb.run_end(rows_of(i), i % 2)
-        if i % GB == GB - 1:
-            gather_block(i)
+    def finish_block(blk, i0, n_in):  # second halves of the n_in samples of block `blk` (first sample i0); then its rows leave
+        for g in range(n_in):
+            sdb.end(rows_of(i0 + g), blk, g)
+        gather_block(i0)
+
+    def close_block(blk, i0, n_in):  # all local halves of the block are queued: its subset bits leave in ONE all-gather
+        sdb.exchange(blk)
+        if pipelined:
+            # ... and while they travel, the second halves of the PREVIOUS block (whose bits have arrived meanwhile)
+            if state["open"] is not None:
+                finish_block(*state["open"])
+            state["open"] = (blk, i0, n_in)
+        else:
+            finish_block(blk, i0, n_in)
 
     def step():
         i = state["i"]
@@ -239,31 +250,22 @@ def main() -> int:
         if sdb is None:
             db.run_device(s.data_ptr(), s.numel(), c[0].data_ptr(), c[1].data_ptr(), c[2].data_ptr())
             return
-        blk = (i // GB) % NBUF
-        if i % GB == 0 and pending[blk] is not None:  # first sample of a block: the block's previous gather must be done
+        blk, g = (i // GB) % NBUF, i % GB
+        if g == 0 and pending[blk] is not None:  # first sample of a block: the block's previous gather must be done
             pending[blk].wait()
             pending[blk] = None
-        if pipelined:
-            # lookup + reduce of THIS sample and the start of its bit exchange, then the second half of the PREVIOUS
-            # sample (whose bits have arrived meanwhile): the collective's latency is off the critical path
-            sdb.run_begin(s, c, i % 2)
-            if state["open"] is not None:
-                finish(state["open"])
-            state["open"] = i
-        else:
-            sdb.run_begin(s, c, 0)
-            finish_now = i
-            sdb.run_end(c, 0)
-            if finish_now % GB == GB - 1:
-                gather_block(finish_now)
+        sdb.begin(s, c, blk, g)  # lookup + reduce of this sample in its own step context
+        if g == GB - 1:
+            close_block(blk, i - g, GB)
 
     def drain():
+        i = state["i"]
+        if multi and i % GB != 0:  # a partly filled block at the end of a loop leaves too
+            close_block((i // GB) % NBUF, i - i % GB, i % GB)
+            state["i"] += GB - i % GB  # (the next loop starts a fresh block)
         if state["open"] is not None:
-            finish(state["open"])
+            finish_block(*state["open"])
             state["open"] = None
-        if multi and state["i"] % GB != 0:  # a partly filled block at the end of a loop leaves too
-            gather_block(state["i"] - 1)
-            state["i"] += GB - state["i"] % GB  # (the next loop starts a fresh block)
         for b in range(NBUF):
             if pending[b] is not None:
                 pending[b].wait()
@@ -703,7 +705,7 @@ def main() -> int:
                 "ghost_refs_rank0": (sdb.n_ghost if sdb is not None else 0),
                 "db_build_ms": round(float(timing["ms_db_build"]), 2),
                 "db_hbm_bytes": info["device_bytes"],
-                "step": "overlap + exclusive counts" + ((" (subset bits all-gathered inside the step" + (", two samples in flight" if pipelined else "") + f") + one all_gather of the count rows per {GB} samples"
+                "step": "overlap + exclusive counts" + ((f" (blocks of {GB} samples: one all_gather of their subset bits" + (", two blocks in flight" if pipelined else "") + f") + one all_gather of the count rows per {GB} samples"
                                                        + ("" if args.sync_gather else " (overlapped with the next sample)")) if multi else ""),
                 "parallelism": f"one database, references sharded x{world} by hash count",
                 "scipy": scipy_version,

@@ -207,7 +207,11 @@ int yh_run_device(yh_db* db, const uint64_t* d_sample, uint64_t n_sample,
  *   -- all-gather of the local references' bits (torch.distributed / RCCL, yacht_amd/dist.py) --
  *   yh_run_finish_device  ghost g takes bit ghost_src[g] of d_global_bits; then the posting-list part
  *                         of d_n_excl is added.  Rows of ghosts and padding in the outputs are garbage.
- * yh_db_set_ghosts registers the ghost range and their bit positions once per handle.            */
+ * yh_db_set_ghosts registers the ghost range and their bit positions once per handle.
+ * A step runs in one of YH_RUN_CONTEXTS contexts (its own subset bits and work list): the local halves of a
+ * whole block of samples can be queued, their bits exchanged in ONE collective, and the second halves follow
+ * (d_global_bits then points at that sample's row of the gathered block; ghost_src indexes from there). */
+#define YH_RUN_CONTEXTS 16
 int yh_db_set_ghosts(yh_db* db, uint64_t ghost_begin, uint64_t n_ghost, const uint32_t* d_ghost_src);
 /* `ctx` (0 or 1) names the step context the two halves share: with two contexts the lookup of sample k+1
  * (ctx 1) can be queued while the exchange of sample k (ctx 0) is still in flight.                      */

@@ -118,6 +118,33 @@ def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
             assert np.array_equal(full[1], want_e), f"rank {rank}: n_excl"
         if world > 1:
             assert sdb.n_ghost > 0, "the cut was meant to go through a cluster"
+        # blocks of 3 samples per bit exchange, two blocks in flight (what bench.py --gpus N drives): the local halves of
+        # block 1 are queued before the second halves of block 0; a partly filled block at the end
+        sdb3 = ydist.ShardedRefDB(torch.from_numpy(v.view(np.int64).copy()), torch.from_numpy(o.astype(np.int64)),
+                                  SetLocalBackend(), block=3)
+        samples = []
+        for k in range(5):
+            present = [int(x) for x in rng.choice(len(refs), size=4 + k, replace=False)]
+            smp = synth.sample_from_refs(rng, refs, present, 0.5, 2000)
+            samples.append(np.union1d(smp, [everywhere]) if k % 2 else smp)
+        cs = [sdb3.new_counts() for _ in samples]
+        ts = [torch.from_numpy(x.view(np.int64).copy()) for x in samples]
+        for g in range(3):
+            sdb3.begin(ts[g], cs[g], 0, g)
+        sdb3.exchange(0)
+        for g in range(2):
+            sdb3.begin(ts[3 + g], cs[3 + g], 1, g)
+        sdb3.exchange(1)
+        for g in range(3):
+            sdb3.end(cs[g], 0, g)
+        for g in range(2):
+            sdb3.end(cs[3 + g], 1, g)
+        for smp, c in zip(samples, cs):
+            full = sdb3.gather(c).numpy().view(np.uint32)
+            want_ov = oracle.overlap(values, offsets, smp)
+            want_e, want_m = oracle.exclusive(values, offsets, want_ov > 0, smp)
+            assert np.array_equal(full[0], want_ov) and np.array_equal(full[2], want_m) and np.array_equal(full[1], want_e), \
+                f"rank {rank}: blocked exchange"
         open(os.path.join(out_dir, f"ok{rank}"), "w").close()
     finally:
         dist.destroy_process_group()

@@ -339,9 +339,11 @@ int yh_db_destroy(yh_db* db) {
         db->d_maskbits = db->ctx_bits[0];
         db->d_work = db->ctx_work[0];
         db->d_work_count = db->ctx_count[0];
-        if (db->ctx_bits[1]) (void)hipFree(db->ctx_bits[1]);
-        if (db->ctx_work[1]) (void)hipFree(db->ctx_work[1]);
-        if (db->ctx_count[1]) (void)hipFree(db->ctx_count[1]);
+        for (int c = 1; c < YH_RUN_CONTEXTS; ++c) {
+            if (db->ctx_bits[c]) (void)hipFree(db->ctx_bits[c]);
+            if (db->ctx_work[c]) (void)hipFree(db->ctx_work[c]);
+            if (db->ctx_count[c]) (void)hipFree(db->ctx_count[c]);
+        }
     }
     void* ptrs[] = {db->d_values, db->d_offsets, db->d_pvals, db->d_pbeg, db->d_pcnt, db->d_poffs, db->d_sizes,
                     db->d_g, db->d_po, db->d_pr, db->d_pg, db->d_gbeg, db->d_gcnt, db->d_nshared, db->d_pq, db->d_pq_count, db->d_dh, db->d_dref, db->d_dir, db->d_bkt, db->d_cbkt, db->d_ovf_keys, db->d_ovf_vals, db->d_pkeys, db->d_pref, db->d_gkeys, db->d_rpo, db->d_rg, db->d_rrec, db->d_rrecx, db->d_filter, db->d_hrec, db->d_hrecx, db->d_hmult, db->d_hpo, db->d_work, db->d_work_count, db->d_sbounds,
@@ -773,20 +775,20 @@ int yh_db_set_ghosts(yh_db* db, uint64_t ghost_begin, uint64_t n_ghost, const ui
 
 // point the handle's step state (subset bits, work list) at context c
 static int use_ctx(yh_db* db, int c) {
-    if (c < 0 || c > 1) { yh_set_error("step context must be 0 or 1"); return YH_ERR_INVALID_ARG; }
+    if (c < 0 || c >= YH_RUN_CONTEXTS) { yh_set_error("step context must be in [0, %d)", YH_RUN_CONTEXTS); return YH_ERR_INVALID_ARG; }
     if (!db->ctx_bits[0]) {  // first use: context 0 = the handle's own arrays
         db->ctx_bits[0] = db->d_maskbits;
         db->ctx_work[0] = db->d_work;
         db->ctx_count[0] = db->d_work_count;
     }
-    if (c == 1 && !db->ctx_bits[1]) {
+    if (c > 0 && !db->ctx_bits[c]) {
         const u64 N = db->n_refs;
-        YH_TRY(yh_dmalloc(db, (void**)&db->ctx_bits[1], ((N + 255) / 256) * 32 + 16));
-        YH_HIP(hipMemsetAsync(db->ctx_bits[1], 0, ((N + 255) / 256) * 32 + 16, db->stream));
-        if (db->d_work) {
-            YH_TRY(yh_dmalloc(db, (void**)&db->ctx_work[1], ((u64)db->n_chunks + 64) * sizeof(uint4)));
-            YH_TRY(yh_dmalloc(db, (void**)&db->ctx_count[1], 16));
-            YH_HIP(hipMemsetAsync(db->ctx_count[1], 0, 16, db->stream));
+        YH_TRY(yh_dmalloc(db, (void**)&db->ctx_bits[c], ((N + 255) / 256) * 32 + 16));
+        YH_HIP(hipMemsetAsync(db->ctx_bits[c], 0, ((N + 255) / 256) * 32 + 16, db->stream));
+        if (db->ctx_work[0]) {
+            YH_TRY(yh_dmalloc(db, (void**)&db->ctx_work[c], ((u64)db->n_chunks + 64) * sizeof(uint4)));
+            YH_TRY(yh_dmalloc(db, (void**)&db->ctx_count[c], 16));
+            YH_HIP(hipMemsetAsync(db->ctx_count[c], 0, 16, db->stream));
         }
     }
     db->d_maskbits = db->ctx_bits[c];

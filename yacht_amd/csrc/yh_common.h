@@ -278,10 +278,10 @@ struct yh_db {
 
     // Two step contexts for the sharded run: what yh_run_local_device leaves for yh_run_finish_device (subset bits,
     // work list).  With two of them the lookup of sample k+1 runs while the bit exchange of sample k is in flight.
-    // ctx_bits[0] / ctx_work[0] / ctx_count[0] are the handle's own arrays; [1] is allocated on first use.
-    u32* ctx_bits[2] = {nullptr, nullptr};
-    uint4* ctx_work[2] = {nullptr, nullptr};
-    u32* ctx_count[2] = {nullptr, nullptr};
+    // ctx_bits[0] / ctx_work[0] / ctx_count[0] are the handle's own arrays; the others are allocated on first use.
+    u32* ctx_bits[YH_RUN_CONTEXTS] = {};
+    uint4* ctx_work[YH_RUN_CONTEXTS] = {};
+    u32* ctx_count[YH_RUN_CONTEXTS] = {};
     int ctx_now = 0;
 
     // sharded run (yh_db_set_ghosts): references [ghost_begin, ghost_begin + n_ghost) are copies of other

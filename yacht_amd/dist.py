@@ -385,10 +385,15 @@ class ShardedRefDB:
     first n_local columns are overlap / n_exclusive / n_matches of ITS references; gather() assembles
     the [3, N_total] table in reference order on every rank."""
 
-    def __init__(self, values_t, offsets_t, backend, group=None):
+    def __init__(self, values_t, offsets_t, backend, group=None, block: int = 1):
+        """block: samples whose subset bits travel in ONE all-gather (begin / exchange / end below).  A torch
+        collective costs the host tens of microseconds and the device two cross-queue hand-overs, more than a
+        whole step's kernels are worth; with block = 8 a sample pays an eighth of that.  Two blocks are in flight."""
         import torch
         import torch.distributed as dist
 
+        assert 1 <= block <= 8, "two blocks of `block` samples use 2 * block of the library's 16 step contexts"
+        self.block = GB = int(block)
         self.group = group
         self.world = world = dist.get_world_size(group)
         self.rank = rank = dist.get_rank(group)
@@ -414,8 +419,8 @@ class ShardedRefDB:
         ghost_src = torch.zeros(0, dtype=torch.int32, device=dev)
         # (YH_FORCE_EXCHANGE=1: run every collective of the build and of the step with ONE rank too -- how the
         # RCCL call shapes and dtypes are exercised on a 1-GPU box)
-        self.exchange = world > 1 or os.environ.get("YH_FORCE_EXCHANGE") == "1"
-        if self.exchange:
+        self.has_exchange = world > 1 or os.environ.get("YH_FORCE_EXCHANGE") == "1"
+        if self.has_exchange:
             # (hash, global bit id) pairs in hash order, cut at the owners' range bounds
             key = values_t ^ _SIGN  # signed order == unsigned hash order
             top = key.max().reshape(1).clone() if values_t.numel() else torch.tensor([_SIGN], dtype=torch.int64, device=dev)
@@ -469,7 +474,7 @@ class ShardedRefDB:
                 uniq, cnt = torch.unique_consecutive(fg, return_counts=True)
                 ghost_vals = fh ^ _SIGN
                 ghost_sizes = cnt
-                ghost_src = uniq.to(torch.int32)
+                ghost_src = uniq  # (global ids rank * BITS + i for now: the gathered layout is fixed below)
         self.n_ghost = int(ghost_src.numel())
         pad = torch.zeros(n_pad - n_local, dtype=torch.int64, device=dev)
         all_sizes = torch.cat([sizes_local, pad, ghost_sizes])
@@ -477,12 +482,25 @@ class ShardedRefDB:
         offs[1:] = torch.cumsum(all_sizes, 0)
         vals = torch.cat([values_t, ghost_vals]).contiguous()
         self.n_rows = int(all_sizes.numel())
+        # One row of subset bits per sample: W words, the same on every rank (the reducer writes whole 256-reference
+        # blocks of this rank's rows, ghosts included).  A block leaves as [GB, W] and arrives as [world, GB, W]:
+        # sample g's bit of reference i of rank r is bit (r * GB * W * 32 + i) counted from ITS row g of rank 0.
+        w_t = torch.tensor([max(self.words, 2 * ((self.n_rows + 255) // 256) * 4 + 2)], dtype=torch.int64, device=dev)
+        w_c = _stage(w_t, group)
+        if self.has_exchange:
+            dist.all_reduce(w_c, op=dist.ReduceOp.MAX, group=group)
+        self.W = W = int(w_c.item())
+        if self.n_ghost:
+            r_of = torch.div(ghost_src, BITS, rounding_mode="floor")
+            ghost_src = (r_of * (GB * W * 32) + (ghost_src - r_of * BITS)).to(torch.int32)
+        else:
+            ghost_src = ghost_src.to(torch.int32)
         self.local = backend.make_local_db(vals, offs.contiguous(), n_pad, ghost_src.contiguous())
         self._keep = (vals, offs, ghost_src)
-        words_local = max(self.words, 2 * ((self.n_rows + 255) // 256) * 4 + 2)
-        # two step contexts: the lookup of sample k+1 is queued while the bit exchange of sample k is in flight
-        self.bits_local = [torch.zeros(words_local, dtype=torch.int32, device=dev) for _ in range(2)]
-        self.bits_global = [torch.zeros(world * self.words, dtype=torch.int32, device=dev) for _ in range(2)]
+        # two blocks of step contexts: the lookups of block b+1 are queued while the bit exchange of block b is in flight
+        self.bits_local = [torch.zeros((GB, W), dtype=torch.int32, device=dev) for _ in range(2)]
+        self.bits_global = [torch.zeros((world, GB, W), dtype=torch.int32, device=dev) for _ in range(2)]
+        self._global_rows = [[self.bits_global[s].view(-1)[g * W:] for g in range(GB)] for s in range(2)]
         self._pending = [None, None]
 
     def new_counts(self):
@@ -490,34 +508,49 @@ class ShardedRefDB:
 
         return torch.zeros((3, self.n_rows), dtype=torch.int32, device=self.dev)
 
-    def run_begin(self, sample_t, counts_t, slot: int = 0):
-        """First half of a step in context `slot` (0 or 1): rank-local lookup + reduce, then the all-gather of
-        the subset bits is STARTED (RCCL: asynchronously, ordered behind the kernels).  run_end(slot) finishes."""
+    def begin(self, sample_t, counts_t, slot: int = 0, g: int = 0):
+        """Rank-local half of sample g of block `slot` (0 or 1): lookup + reduce; its subset bits land in row g."""
+        self.local.run_local(sample_t, counts_t, self.bits_local[slot][g], slot * self.block + g)
+
+    def exchange(self, slot: int = 0):
+        """All-gather of the block's subset bits, STARTED (RCCL: asynchronously, ordered behind the kernels)."""
         import torch.distributed as dist
 
-        self.local.run_local(sample_t, counts_t, self.bits_local[slot], slot)
-        if self.exchange:
-            mine = self.bits_local[slot][: self.words]
-            if mine.is_cuda and not _is_gloo(self.group):
-                self._pending[slot] = dist.all_gather_into_tensor(self.bits_global[slot], mine, group=self.group, async_op=True)
-            else:
-                all_gather_into(self.bits_global[slot], mine, group=self.group)
+        if not self.has_exchange:
+            return
+        mine = self.bits_local[slot]
+        if mine.is_cuda and not _is_gloo(self.group):
+            self._pending[slot] = dist.all_gather_into_tensor(self.bits_global[slot], mine, group=self.group, async_op=True)
+        else:
+            all_gather_into(self.bits_global[slot].view(-1), mine.view(-1), group=self.group)
 
-    def run_end(self, counts_t, slot: int = 0):
-        """Second half: wait (on the stream) for the bits, ghosts take their owners' bits, posting-list pass."""
+    def end(self, counts_t, slot: int = 0, g: int = 0):
+        """Second half of sample g of block `slot`: wait (on the stream) for the block's bits, ghosts take their owners'
+        bits, posting-list pass."""
         if self._pending[slot] is not None:
             self._pending[slot].wait()
             self._pending[slot] = None
-        self.local.run_finish(self.bits_global[slot] if self.exchange else self.bits_local[slot], counts_t, slot)
+        self.local.run_finish(self._global_rows[slot][g] if self.has_exchange else self.bits_local[slot][g], counts_t,
+                              slot * self.block + g)
         return counts_t
+
+    def run_begin(self, sample_t, counts_t, slot: int = 0):
+        """One sample per exchange (block = 1): first half + the start of its bit exchange.  run_end(slot) finishes."""
+        assert self.block == 1, "a ShardedRefDB made with block > 1 is driven with begin / exchange / end"
+        self.begin(sample_t, counts_t, slot, 0)
+        self.exchange(slot)
+
+    def run_end(self, counts_t, slot: int = 0):
+        return self.end(counts_t, slot, 0)
 
     def run(self, sample_t, counts_t=None):
         """One sample: this rank's [3, n_rows] counts (columns [0, n_local) are its references).
         Stream-ordered on the current stream; no host synchronisation with RCCL."""
         if counts_t is None:
             counts_t = self.new_counts()
-        self.run_begin(sample_t, counts_t, 0)
-        return self.run_end(counts_t, 0)
+        self.begin(sample_t, counts_t, 0, 0)
+        self.exchange(0)  # (block > 1: the other rows of the block travel along, unused)
+        return self.end(counts_t, 0, 0)
 
     def gather(self, counts_t):
         """[3, N_total] on every rank from the per-rank rows (one collective, shards padded)."""
