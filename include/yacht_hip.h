@@ -213,8 +213,8 @@ int yh_run_device(yh_db* db, const uint64_t* d_sample, uint64_t n_sample,
  * (d_global_bits then points at that sample's row of the gathered block; ghost_src indexes from there). */
 #define YH_RUN_CONTEXTS 16
 int yh_db_set_ghosts(yh_db* db, uint64_t ghost_begin, uint64_t n_ghost, const uint32_t* d_ghost_src);
-/* `ctx` (0 or 1) names the step context the two halves share: with two contexts the lookup of sample k+1
- * (ctx 1) can be queued while the exchange of sample k (ctx 0) is still in flight.                      */
+/* `ctx` (0 .. YH_RUN_CONTEXTS - 1) names the step context the two halves share: the lookup of sample k+1
+ * (another context) can be queued while the exchange of sample k is still in flight.                    */
 int yh_run_local_device(yh_db* db, int ctx, const uint64_t* d_sample, uint64_t n_sample, uint32_t* d_overlap,
                         uint32_t* d_n_excl, uint32_t* d_n_match, uint32_t* d_bits_out);
 int yh_run_finish_device(yh_db* db, int ctx, const uint32_t* d_global_bits, uint32_t* d_n_excl);
