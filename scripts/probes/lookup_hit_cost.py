@@ -36,6 +36,9 @@ for i, s_ in enumerate(kinds["bench"]):
     keep = s_[~torch.isin(s_, shared)]
     fill = kinds["noise"][i][: s_.numel() - keep.numel()]
     kinds["bench_noshared"].append(torch.unique(torch.cat([keep, fill])).contiguous())
+# the real-shape samples: without their shared hashes, and noise of the same size
+kinds["real_noshared"] = [s_[~torch.isin(s_, shared)].contiguous() for s_ in kinds["real"]]
+kinds["noise_83k"] = [x[:: 12][:83_000].contiguous() for x in kinds["noise"]]
 del shared
 db = RefDB.from_device(values.data_ptr(), offsets.data_ptr(), n)
 out = torch.zeros(3, n, dtype=torch.int32, device="cuda:0")

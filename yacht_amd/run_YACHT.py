@@ -121,7 +121,9 @@ def main(args) -> None:
             sample_sig = utils.load_signature_with_ksize(sample_file, ksize)
         except ValueError:
             raise ValueError(MSG_NOT_ONE_SKETCH.format(sample_file, ksize, len(sample_file)))
-        info = utils.get_info_from_single_sig(sample_file, ksize)
+        # (the reference parses the file a second time here, run_YACHT.py:150-152 -> utils.py:89-110; same tuple)
+        info = (sample_file, sample_sig.name, sample_sig.md5sum(), sample_sig.minhash.mean_abundance,
+                len(sample_sig.minhash), sample_sig.minhash.scaled)
     manifest["num_exclusive_kmers_in_sample_sketch"] = info[3]
     manifest["num_total_kmers_in_sample_sketch"] = utils.get_num_kmers(info[3], info[4], info[5], scale=False)
     manifest["sample_scale_factor"] = info[5]
