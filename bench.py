@@ -72,6 +72,8 @@ def parse_args():
     ap.add_argument("--host-depth", type=int, default=3, help="host-inclusive leg: calls in flight (1..4)")
     ap.add_argument("--percentile-steps", type=int, default=200)
     ap.add_argument("--sync-gather", action="store_true", help="N>1: blocking gather of the count rows inside every step")
+    ap.add_argument("--count-gather", choices=("root", "all"), default="root",
+                    help="N>1 over RCCL: the count rows of a block go to rank 0 (where results are consumed; default) or to every rank")
     ap.add_argument("--gather-every", type=int, default=8, help="N>1: samples per all-gather of the count rows")
     ap.add_argument("--no-pipeline", action="store_true", help="N>1: finish every sample before the next one's lookup is queued")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to test the N>1 logic)")
@@ -212,6 +214,9 @@ def main() -> int:
                     for _ in range(NBUF)]
     pending = [None] * NBUF
     staged_gather = multi and args.backend != "nccl"
+    # all-gathering the rows hands every rank world x 8 MB per block it never reads; results are consumed on rank 0
+    to_root = multi and not staged_gather and args.count_gather == "root"
+    root_lists = [([gathered_blk[b][r] for r in range(world)] if rank == 0 else None) for b in range(NBUF)] if to_root else None
     pipelined = multi and not staged_gather and not args.sync_gather and not args.no_pipeline
     state = {"i": 0, "open": None}
 
@@ -222,6 +227,9 @@ def main() -> int:
         blk = (i // GB) % NBUF
         if staged_gather:
             ydist.all_gather_into(gathered_blk[blk].view(-1), counts_blk[blk].view(-1))
+        elif to_root:  # rank 0 receives [world, GB, 3, row_stride]; the others only send their 8 MB
+            w = dist.gather(counts_blk[blk], gather_list=root_lists[blk], dst=0, async_op=not args.sync_gather)
+            pending[blk] = None if args.sync_gather else w
         elif args.sync_gather:
             dist.all_gather_into_tensor(gathered_blk[blk], counts_blk[blk])
         else:
@@ -325,7 +333,8 @@ def main() -> int:
     torch.cuda.synchronize()
     if multi:  # the steps' own gathers must carry this rank's rows
         for b in range(NBUF):
-            assert bool(torch.equal(gathered_blk[b][rank], counts_blk[b])), "gather ran ahead of the kernels"
+            if not to_root or rank == 0:
+                assert bool(torch.equal(gathered_blk[b][rank], counts_blk[b])), "gather ran ahead of the kernels"
 
     # ---- N = 1 extras ------------------------------------------------------------------------------------
     indexed = host_inclusive = real_shape = None
@@ -705,7 +714,7 @@ def main() -> int:
                 "ghost_refs_rank0": (sdb.n_ghost if sdb is not None else 0),
                 "db_build_ms": round(float(timing["ms_db_build"]), 2),
                 "db_hbm_bytes": info["device_bytes"],
-                "step": "overlap + exclusive counts" + ((f" (blocks of {GB} samples: one all_gather of their subset bits" + (", two blocks in flight" if pipelined else "") + f") + one all_gather of the count rows per {GB} samples"
+                "step": "overlap + exclusive counts" + ((f" (blocks of {GB} samples: one all_gather of their subset bits" + (", two blocks in flight" if pipelined else "") + f") + one {'gather to rank 0' if to_root else 'all_gather'} of the count rows per {GB} samples"
                                                        + ("" if args.sync_gather else " (overlapped with the next sample)")) if multi else ""),
                 "parallelism": f"one database, references sharded x{world} by hash count",
                 "scipy": scipy_version,
