@@ -82,6 +82,8 @@ def test_indexed_equals_streaming_at_full_scale(hip_lib):
         outs = [torch.zeros((3, n), dtype=torch.int32, device="cuda:0") for _ in range(2)]
         torch.cuda.synchronize()
         assert db.lookup_choice(sample.numel()) == _lib.YH_LOOKUP_INDEXED  # 3e5 hashes against 3.3e8: sample-driven by default
+        # ... and still for a sample a tenth of the database (measured: 308 us against 533, scripts/probes/crossover.py)
+        assert db.lookup_choice(32_000_000) == _lib.YH_LOOKUP_INDEXED
         db.set_lookup(_lib.YH_LOOKUP_STREAM)
         db.run_device(sample.data_ptr(), sample.numel(), outs[0][0].data_ptr(), outs[0][1].data_ptr(),
                       outs[0][2].data_ptr())

@@ -435,11 +435,15 @@ int yh_db_get_timing(yh_db* db, yh_timing* t) {
 }
 
 // ---- which lookup answers a sample query ---------------------------------------------------------------
-// Both are exact.  The streaming kernel reads every reference hash (one delta byte each): its time is
-// ~12 us + 0.24 ns per reference hash whatever the sample.  The sample-driven kernel reads one 64-byte
-// bucket per SAMPLE hash: ~8 us + 31-39 ns per 1 000 sample hashes, hits included.  (Measured on MI355X:
-// 3.3e8 reference hashes, 1e6-hash sample: 86 against 39 us; 8.3e4-hash sample: 82 against 16 us;
-// 2.2e9 reference hashes, 1e7-hash sample: 539 against ~300 us)  YH_LOOKUP=stream|indexed in the environment, or yh_db_set_lookup, force one.
+// Both are exact.  The streaming kernel reads every reference hash (one delta byte each) and stages the sample:
+// ~12 us + 0.24 ns per reference hash + 14 ns per 1 000 sample hashes.  The sample-driven kernel reads a presence
+// bit and (mostly for hashes that are there) one 64-byte bucket per SAMPLE hash: ~8 us + 30 ns per 1 000 sample
+// hashes up to 2e6 of them, 9 ns per 1 000 beyond (a sorted sample that dense finds neighbouring buckets cached).
+// Measured on MI355X, whole step, 3.3e8 reference hashes (scripts/probes/crossover.py): samples of 1e6 / 4e6 / 3.2e7
+// hashes: 47 / 77 / 308 us sample-driven against 99 / 152 / 533 us streaming; 8.3e4 hashes: 30 against 104;
+// 2.2e9 reference hashes, 1e7-hash sample: 313 against 568 us.  The streaming kernel wins where the
+// database is small against the sample (a shard of a strongly scaled run).  YH_LOOKUP=stream|indexed in the
+// environment, or yh_db_set_lookup, force one.
 static bool prefer_indexed(const yh_db* db, u64 n_sample) {
     if (!db->has_dir || !db->has_index || n_sample == 0) return false;
     if (db->lookup_mode == YH_LOOKUP_STREAM) return false;
@@ -450,9 +454,10 @@ static bool prefer_indexed(const yh_db* db, u64 n_sample) {
     }();
     if (env) return env == 2;
     if (!db->d_sdelta) return true;
-    const double t_stream = 12.0 + 0.24e-3 * (double)db->n_hashes;
-    const double t_index = 8.0 + 0.045e-3 * (double)n_sample;  // (with a margin for hit-dense samples)
-    return t_index < t_stream;
+    const double ns = (double)n_sample;
+    const double t_stream = 12.0 + 0.24e-3 * (double)db->n_hashes + 0.014e-3 * ns;
+    const double t_index = 8.0 + 0.030e-3 * std::min(ns, 2e6) + 0.009e-3 * std::max(ns - 2e6, 0.0);
+    return t_index < 0.9 * t_stream;  // (a margin for hit-dense samples, where the sample-driven kernel loses most)
 }
 
 int yh_db_lookup_choice(yh_db* db, uint64_t n_sample) {
