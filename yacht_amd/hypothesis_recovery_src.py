@@ -119,7 +119,7 @@ def _sample_mins(sample_sig) -> np.ndarray:
 
 def get_organisms_with_nonzero_overlap(manifest: pd.DataFrame, sample_file: str, scale: int, ksize: int,
                                        num_threads: int, path_to_genome_temp_dir: str,
-                                       path_to_sample_temp_dir: str) -> List[str]:
+                                       path_to_sample_temp_dir: str, parsed_sample=None) -> List[str]:
     """Names of the manifest's organisms that share at least one hash with the sample
     (reference :30-113; there: `sourmash scripts multisearch ... -t 0`, `match_name` column)."""
     logger.info("Unzipping the sample signature zip file")
@@ -138,9 +138,14 @@ def get_organisms_with_nonzero_overlap(manifest: pd.DataFrame, sample_file: str,
     pd.DataFrame(organism_sigs).to_csv(os.path.join(path_to_sample_temp_dir, "organism_sig_file.txt"), header=False,
                                        index=False)
 
-    sigs = []
-    for path in sample_sigs:
-        sigs += sigio.load_file_as_signatures(path, ksize=ksize)
+    # parsed_sample: the caller's already-parsed signature of this very file (hypothesis_recovery holds it); a
+    # 10^6-hash sketch takes 0.2-0.3 s to parse and the archive has been read once already
+    if parsed_sample is not None and len(sample_sigs) == 1:
+        sigs = [parsed_sample]
+    else:
+        sigs = []
+        for path in sample_sigs:
+            sigs += sigio.load_file_as_signatures(path, ksize=ksize)
     result_csv = os.path.join(path_to_sample_temp_dir, "sample_multisearch_result.csv")
     rows = []
     if sigs and len(manifest):
@@ -249,7 +254,8 @@ def hypothesis_recovery(manifest: pd.DataFrame, sample_info_set, path_to_genome_
     os.makedirs(path_to_sample_temp_dir)
 
     names = get_organisms_with_nonzero_overlap(manifest, sample_file, scale, ksize, num_threads,
-                                               path_to_genome_temp_dir, path_to_sample_temp_dir)
+                                               path_to_genome_temp_dir, path_to_sample_temp_dir,
+                                               parsed_sample=sample_sig if hasattr(sample_sig, "minhash") else None)
     info, manifest = get_exclusive_hashes(manifest, names, sample_sig, ksize, path_to_genome_temp_dir)
     n_excl = np.array([x[0] for x in info], dtype=np.int64)
     n_match = np.array([x[1] for x in info], dtype=np.int64)
