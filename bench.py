@@ -317,7 +317,7 @@ def main() -> int:
     step_ms = [evs[k].elapsed_time(evs[k + 1]) for k in range(n_pct)]
     device_resident = dict(stats_ms(step_ms), how="HIP-event interval per step, separate pass of rotating samples; "
                                                    "`value`/`ms_per_step` come from the un-instrumented timed loop")
-    timing = db.timing()  # kernel-duration ring: every 8th launch of the timed region + percentile pass
+    timing = db.timing()  # kernel-duration ring: every 32nd launch of the timed region + percentile pass
 
     # last step's counts of every sample (for parity): run each sample once more into its own buffer
     results = []
@@ -605,6 +605,23 @@ def main() -> int:
     x_ms = float(timing["ms_exclusive_kernels"])
     roofline = (roofline_indexed if default_choice == ylib.YH_LOOKUP_INDEXED else roofline_stream)(k_ms, x_ms)
     roofline["default_lookup"] = "indexed" if default_choice == ylib.YH_LOOKUP_INDEXED else "stream"
+    # What a HIP-event pair measures with NOTHING between its two records, on the busy stream of the step loop: the
+    # part of `kernel_ms_avg` that is marker processing and dispatch, not kernel (rocprofv3's kernel durations in
+    # profiles/ do not contain it).  `achieved` / `frac` stay on the raw interval: never flattered.
+    if not multi:
+        pairs = []
+        for _ in range(64):
+            step()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            e1.record(stream)
+            pairs.append((e0, e1))
+        drain()
+        fence()
+        gaps = sorted(a.elapsed_time(b) for a, b in pairs)
+        empty_ms = float(gaps[len(gaps) // 2])
+        roofline["event_pair_overhead_ms"] = round(empty_ms, 4)
+        roofline["kernel_ms_avg_net_of_event_overhead"] = round(max(k_ms - empty_ms, 0.0), 4)
     other = None
     if "stream" in paths and default_choice == ylib.YH_LOOKUP_INDEXED:
         other = roofline_stream(paths["stream"]["lookup_kernel_ms_avg"], paths["stream"]["exclusive_kernels_ms_avg"])

@@ -132,7 +132,8 @@ int yh_db_set_stream(yh_db* db, void* hip_stream);
 int yh_db_synchronize(yh_db* db);
 /* Mean kernel durations (HIP events on the handle's stream) over the launches recorded since the
  * previous call; synchronizes the stream.  Event records are barrier packets inside the step, so
- * only every YH_TIMING_EVERY-th launch (environment, default 8; 1 = all, 0 = none) is recorded. */
+ * only every YH_TIMING_EVERY-th launch (environment, default 32; 1 = all, 0 = none) and the first one after
+ * each yh_db_get_timing is recorded: an event pair costs the stream about 5 us. */
 int yh_db_get_timing(yh_db* db, yh_timing* t);
 
 /* Which lookup kernel yh_overlap / yh_run (host and device forms) use.  Both are exact.
