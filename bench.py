@@ -640,6 +640,12 @@ def main() -> int:
                 if rl is not None and rl["traffic"] is None and tr.get("source_tag") == tag and tr.get("n_hashes") == Hh \
                         and tr.get("kernel") == rl["kernel"]:
                     rl["traffic"] = tr.get("hbm_bytes_per_launch")
+                    if tr.get("l2_requests_per_launch") and rl.get("kernel_ms_avg"):
+                        # isolated reads are bound by the NUMBER of L2 requests (TCC_REQ, same PMC passes): the rate over
+                        # this run's kernel interval, next to scripts/probes/gather_probe.hip's ceiling for launches of
+                        # 1e6 independent 64-byte reads (3.7e10/s; 4.6e10/s at 1.6e7)
+                        rl["l2_requests_per_launch"] = tr["l2_requests_per_launch"]
+                        rl["l2_requests_per_s"] = round(tr["l2_requests_per_launch"] / (rl["kernel_ms_avg"] / 1e3), 1)
                     rl["traffic_provenance"] = {"file": "profiles/" + name, "source_tag": tag,
                                                 "taken": tr.get("taken"), "commit": tr.get("commit")}
         except Exception:

@@ -51,7 +51,10 @@ try:
     commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
 except Exception:
     commit = ""
-bench = json.load(open(os.path.join(root, "bench_for_traffic.json")))
+bench_path = os.path.join(root, "bench_for_traffic.json")
+if not os.path.exists(bench_path):
+    bench_path = os.path.join(root, "bench_n1.json")  # (re-deriving from the slim files kept under profiles/<tag>/)
+bench = json.load(open(bench_path))
 n_hashes = int(bench["config"]["ref_hashes_per_gpu"])
 for kernel, name, factor, why in (
         ("k_stream_lookup", "stream", 2.0, "read bytes = 2 x FETCH_SIZE (gfx950, 16-B/lane coalesced stream); write bytes = WRITE_SIZE"),
@@ -66,6 +69,11 @@ for kernel, name, factor, why in (
            "taken": datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%MZ"),
            "FETCH_SIZE_KiB_mean": fetch_kib, "launches_fetch": nf, "WRITE_SIZE_KiB_mean": write_kib, "launches_write": nw,
            "correction": why, "hbm_bytes_per_launch": int(factor * fetch_kib * 1024.0 + write_kib * 1024.0)}
+    req, nr = mean_counter("pmc_tcc", "TCC_REQ_sum", kernel)
+    miss, _ = mean_counter("pmc_tcc", "TCC_MISS_sum", kernel)
+    if nr:  # L2 requests per launch: what a kernel of isolated reads is bound by
+        rec["l2_requests_per_launch"] = int(req)
+        rec["l2_misses_per_launch"] = int(miss)
     path = os.path.join(out_dir, f"traffic_{tag}_{name}.json")
     json.dump(rec, open(path, "w"), indent=1)
     print(path, rec["hbm_bytes_per_launch"])
