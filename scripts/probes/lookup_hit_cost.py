@@ -39,6 +39,14 @@ for i, s_ in enumerate(kinds["bench"]):
 # the real-shape samples: without their shared hashes, and noise of the same size
 kinds["real_noshared"] = [s_[~torch.isin(s_, shared)].contiguous() for s_ in kinds["real"]]
 kinds["noise_83k"] = [x[:: 12][:83_000].contiguous() for x in kinds["noise"]]
+# isolate-like samples: two whole genomes (every hash hits one of two counters) + a little noise
+sizes_all = (offsets[1:] - offsets[:-1])
+big = torch.argsort(sizes_all, descending=True)[:64].tolist()
+kinds["isolate"] = []
+for i in range(ROT):
+    a_, b_ = big[2 * i], big[2 * i + 1]
+    parts = [values[int(offsets[a_]):int(offsets[a_ + 1])], values[int(offsets[b_]):int(offsets[b_ + 1])], kinds["noise"][i][:2000]]
+    kinds["isolate"].append(torch.unique(torch.cat(parts)).contiguous())
 del shared
 db = RefDB.from_device(values.data_ptr(), offsets.data_ptr(), n)
 out = torch.zeros(3, n, dtype=torch.int32, device="cuda:0")

@@ -1496,33 +1496,36 @@ __global__ void __launch_bounds__(256) k_index_lookup(const u64* __restrict__ sa
 #define YH_IDX_TBITS 10
 #endif
 constexpr int IDX_THREADS = YH_IDX_THREADS;
-constexpr u32 IDX_TSLOTS = 1u << YH_IDX_TBITS;
-template <int U>
-__global__ void __launch_bounds__(IDX_THREADS) k_index_lookup_tile(const u64* __restrict__ sample, u64 n, const YhDirView dv,
+// (THREADS lanes x U hashes per workgroup, 2^TBITS slots in the hit table: <2, 1024, 10> for large samples; <1, 256, 8>
+// for small ones, where the table keeps a sample that is mostly ONE genome -- an isolate -- from sending thousands of
+// atomics to one counter)
+template <int U, int THREADS, int TBITS>
+__global__ void __launch_bounds__(THREADS) k_index_lookup_tile(const u64* __restrict__ sample, u64 n, const YhDirView dv,
                                                                    const u32* __restrict__ filter, u64 filter_mul,
                                                                    const u64* __restrict__ po, const u32* __restrict__ pr,
                                                                    u32* __restrict__ reps, u32 rep_mask, u64 n_refs,
                                                                    u8* __restrict__ hit, u32* __restrict__ reps2,
                                                                    u32* __restrict__ work_count, const u32* __restrict__ bad,
                                                                    u32 bad_gen) {
-    __shared__ u32 tkey[IDX_TSLOTS];   // reference + 1, 0 = empty
-    __shared__ u32 tcnt[IDX_TSLOTS];   // hits
-    __shared__ u32 tcnt2[IDX_TSLOTS];  // hits on shared hashes
+    constexpr u32 TSLOTS = 1u << TBITS;
+    __shared__ u32 tkey[TSLOTS];   // reference + 1, 0 = empty
+    __shared__ u32 tcnt[TSLOTS];   // hits
+    __shared__ u32 tcnt2[TSLOTS];  // hits on shared hashes
     if (work_count && blockIdx.x == 0 && threadIdx.x == 0) *work_count = 0;
     if (bad && *bad == bad_gen) return;
     u32* my = reps + (u64)replica_of(blockIdx.x, rep_mask) * n_refs;
     u32* my2 = reps2 ? reps2 + (u64)replica_of(blockIdx.x, rep_mask) * n_refs : nullptr;
-    const u64 base = blockIdx.x * (u64)(IDX_THREADS * U);
+    const u64 base = blockIdx.x * (u64)(THREADS * U);
     u64 h[U];
     bool ok[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        const u64 t = base + (u64)u * IDX_THREADS + threadIdx.x;
+        const u64 t = base + (u64)u * THREADS + threadIdx.x;
         h[u] = sample[min(t, n - 1)];
         ok[u] = t < n && h[u] <= dv.max_hash;
         if (!ok[u]) h[u] = 0;  // (still a valid bucket to read)
     }
-    for (u32 k = threadIdx.x; k < IDX_TSLOTS; k += IDX_THREADS) { tkey[k] = 0; tcnt[k] = 0; tcnt2[k] = 0; }
+    for (u32 k = threadIdx.x; k < TSLOTS; k += THREADS) { tkey[k] = 0; tcnt[k] = 0; tcnt2[k] = 0; }
     YhDirView::v4u a[U], b[U], c[U], d[U];
     u32 r[U];
     if (filter) {  // the presence bits first: a hash whose bit is clear is not in the database (yh_db::d_filter)
@@ -1547,9 +1550,9 @@ __global__ void __launch_bounds__(IDX_THREADS) k_index_lookup_tile(const u64* __
     }
     __syncthreads();  // the table is clear
     auto add = [&](u32 ref, bool shared) {
-        u32 slot = (ref * 2654435761u) >> (32 - YH_IDX_TBITS);
+        u32 slot = (ref * 2654435761u) >> (32 - TBITS);
 #pragma unroll 1
-        for (int probe = 0; probe < 2; ++probe, slot = (slot + 1) & (IDX_TSLOTS - 1)) {
+        for (int probe = 0; probe < 2; ++probe, slot = (slot + 1) & (TSLOTS - 1)) {
             const u32 old = atomicCAS(&tkey[slot], 0u, ref + 1);
             if (old == 0 || old == ref + 1) {
                 atomicAdd(&tcnt[slot], 1u);
@@ -1574,7 +1577,7 @@ __global__ void __launch_bounds__(IDX_THREADS) k_index_lookup_tile(const u64* __
         }
     }
     __syncthreads();
-    for (u32 k = threadIdx.x; k < IDX_TSLOTS; k += IDX_THREADS)
+    for (u32 k = threadIdx.x; k < TSLOTS; k += THREADS)
         if (tkey[k]) {
             count_add(&my[tkey[k] - 1], tcnt[k]);
             if (my2 && tcnt2[k]) count_add(&my2[tkey[k] - 1], tcnt2[k]);
@@ -2233,10 +2236,12 @@ int yh_q_overlap_indexed(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_ov
     // tiles of IDX_THREADS x U hashes once there are enough of them for every CU (k_index_lookup_tile)
     // (measured, 10^6-hash rotating samples with 1.6e5 hits: one hash per lane in 256-lane workgroups 38-40 us, tiles of U = 2
     // 35.7-36.3, U = 4 slower; no hits at all 32.5 / 31.5; an 83 k-hash sample 13 / 23)
-    static const long tile_env = [] { const char* e = getenv("YH_INDEX_TILE"); return e ? atol(e) : -1L; }();  // 0 = never, 1/2/4 = U
-    int U = n_sample >= 192ull * IDX_THREADS * 2 ? 2 : 0;
+    // YH_INDEX_TILE: 0 = k_index_lookup (one atomic per hit), 256 = the small aggregating form, 1/2/4 = 1024-lane tiles of U
+    static const long tile_env = [] { const char* e = getenv("YH_INDEX_TILE"); return e ? atol(e) : -1L; }();
+    int U = n_sample >= 192ull * IDX_THREADS * 2 ? 2 : 256;
     if (tile_env >= 0) U = (int)tile_env;
-    // the tiles leave one atomic per (workgroup, reference): four replicas are enough there (step 49.9 -> 48.4 us; two: 51.7)
+    // the aggregating forms leave one atomic per (workgroup, reference): four replicas are enough there (10^6-hash sample:
+    // step 49.9 -> 48.4 us; two: 51.7; 83 k-hash real-shape sample: 28.8 / 26.3 / 25.4 us with 8 / 4 / 2)
     const u32 r_want = ri_env ? ri_env : (U ? 4u : 8u);
     while (R > 1 && R > r_want) R >>= 1;
     static const bool fused_off = [] { const char* e = getenv("YH_NO_FUSED_RUN"); return e && e[0] == '1'; }();
@@ -2248,16 +2253,18 @@ int yh_q_overlap_indexed(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_ov
     u8* const d_hitflags = (for_exclusive && db->n_shared && !fused) ? db->d_hit : nullptr;
     u32* const d_reps2 = fused ? reps2 : nullptr;
     const u32* const d_filter = yh_filter_of(db);
-    if (n_sample && db->n_distinct && U) {
-        const u32 grid = (u32)((n_sample + (u64)IDX_THREADS * U - 1) / ((u64)IDX_THREADS * U));
-#define YH_TILE_LAUNCH(UU)                                                                                                       \
-    k_index_lookup_tile<UU><<<grid, IDX_THREADS, 0, st>>>(d_sample, n_sample, yh_dir_view(db), d_filter, db->filter_mul, db->d_po, db->d_pr, db->d_reps,  \
-                                                          R - 1, N, d_hitflags, d_reps2, db->d_work_count, db->d_bad, db->bad_gen)
-        if (U == 4) YH_TILE_LAUNCH(4);
-        else if (U == 2) YH_TILE_LAUNCH(2);
-        else YH_TILE_LAUNCH(1);
+#define YH_TILE_LAUNCH(UU, TT, BB, FILTER)                                                                                        \
+    k_index_lookup_tile<UU, TT, BB><<<(u32)((n_sample + (u64)(TT) * (UU) - 1) / ((u64)(TT) * (UU))), TT, 0, st>>>(                 \
+        d_sample, n_sample, yh_dir_view(db), FILTER, db->filter_mul, db->d_po, db->d_pr, db->d_reps, R - 1, N, d_hitflags, d_reps2, \
+        db->d_work_count, db->d_bad, db->bad_gen)
+    if (n_sample && db->n_distinct && U == 256)
+        // small samples: latency-bound, so no filter read in front of the bucket; 256-lane workgroups keep every CU busy
+        YH_TILE_LAUNCH(1, 256, 8, nullptr);
+    else if (n_sample && db->n_distinct && U == 4) YH_TILE_LAUNCH(4, IDX_THREADS, YH_IDX_TBITS, d_filter);
+    else if (n_sample && db->n_distinct && U == 2) YH_TILE_LAUNCH(2, IDX_THREADS, YH_IDX_TBITS, d_filter);
+    else if (n_sample && db->n_distinct && U == 1) YH_TILE_LAUNCH(1, IDX_THREADS, YH_IDX_TBITS, d_filter);
 #undef YH_TILE_LAUNCH
-    } else if (n_sample && db->n_distinct)
+    else if (n_sample && db->n_distinct)
         k_index_lookup<<<grid_for(n_sample, 256, 4096), 256, 0, st>>>(d_sample, n_sample, yh_dir_view(db), db->d_po, db->d_pr,
                                                                       db->d_reps, R - 1, N, d_hitflags, d_reps2, db->d_work_count,
                                                                       db->d_bad, db->bad_gen);
