@@ -16,8 +16,16 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 values, offsets, s0 = synth.config3_device(seed=1002, n_refs=85_205, n_sample=1_000_000, device="cuda:0")
 n = offsets.numel() - 1
 shape = sys.argv[2] if len(sys.argv) > 2 else "present"
-ns = 1_000_000 if shape == "present" else 83_000
-samples = [synth.sample_device(values, offsets, seed=3000 + i, n_sample=ns, n_present=200, shape=shape) for i in range(B)]
+ns = 1_000_000 if shape == "present" else 83_000  # (isolate: set below)
+if shape == "isolate":  # every sample = two whole genomes: all hits of a sample land on two counters
+    sizes_all = offsets[1:] - offsets[:-1]
+    big = torch.argsort(sizes_all, descending=True)[: 2 * B].tolist()
+    samples = [torch.unique(torch.cat([values[int(offsets[big[2 * i]]):int(offsets[big[2 * i] + 1])],
+                                       values[int(offsets[big[2 * i + 1]]):int(offsets[big[2 * i + 1] + 1])]])).contiguous()
+               for i in range(B)]
+    ns = int(samples[0].numel())
+else:
+    samples = [synth.sample_device(values, offsets, seed=3000 + i, n_sample=ns, n_present=200, shape=shape) for i in range(B)]
 cat = torch.cat(samples).contiguous()
 soff = torch.zeros(B + 1, dtype=torch.int64, device="cuda:0")
 soff[1:] = torch.cumsum(torch.tensor([s.numel() for s in samples], device="cuda:0"), 0)
