@@ -2541,69 +2541,36 @@ __global__ void __launch_bounds__(256) k_batch_lookup(const u64* __restrict__ sa
                                                       u64 n_chunks, u64 chunk_mul, const u32* __restrict__ filter,
                                                       u64 filter_mul) {
     __shared__ u64 off[65];
-    // hits of the chunk's (first) sample are summed per reference in LDS and leave as one atomic per (chunk, reference):
-    // a sample that is mostly one genome would otherwise send every hit to the same counter (32 such samples of
-    // 30 000 hashes: 0.49 ms per call, all of it same-address atomics)
-    constexpr u32 BT = 256;
-    __shared__ u32 tkey[BT];  // reference + 1, 0 = empty
-    __shared__ u32 tcnt[BT];
     if (threadIdx.x <= n_samples) off[threadIdx.x] = soff[threadIdx.x];
-    tkey[threadIdx.x] = 0;
-    tcnt[threadIdx.x] = 0;
     __syncthreads();
     const u64 total = off[n_samples];
     // 256-hash chunks are visited in a multiplicative permutation (chunk_mul coprime to n_chunks), so
-    // that the workgroups resident at any moment work on ALL samples
+    // that the workgroups resident at any moment work on ALL samples: a sample's hits land on its few
+    // hundred present references, and same-address atomics serialize (~11 ns each on this part)
     for (u64 c = blockIdx.x; c < n_chunks; c += gridDim.x) {
-        const u64 t0 = ((c * chunk_mul) % n_chunks) * 256;
-        const u64 t = t0 + threadIdx.x;
-        auto sample_of = [&](u64 pos) -> u32 {  // last s with off[s] <= pos
-            u32 lo = 0, hi = n_samples;
-            while (hi - lo > 1) {
-                const u32 mid = (lo + hi) >> 1;
-                if (off[mid] <= pos) lo = mid; else hi = mid;
-            }
-            return lo;
-        };
-        const u32 s0 = sample_of(t0);
-        if (t < total) {
-            const u32 s = sample_of(t);
-            const u64 h = samples[t];
-            bool present = true;
-            if (filter && h <= dv.max_hash) {  // presence bit first (yh_db::d_filter): clear = not in the database
-                const u64 bit = yh_bucket_of(h, dv.bkt_lsh, filter_mul);
-                present = (filter[bit >> 5] >> (bit & 31u)) & 1u;
-            }
-            const u32 r = present ? dv.find(h) : YH_DIR_NONE;
-            if (r != YH_DIR_NONE) {
-                u32* row = overlap + (u64)s * n_refs;
-                auto add = [&](u32 ref) {
-                    if (s == s0) {
-                        u32 slot = (ref * 2654435761u) >> 24;
-#pragma unroll 1
-                        for (int probe = 0; probe < 2; ++probe, slot = (slot + 1) & (BT - 1)) {
-                            const u32 old = atomicCAS(&tkey[slot], 0u, ref + 1);
-                            if (old == 0 || old == ref + 1) { atomicAdd(&tcnt[slot], 1u); return; }
-                        }
-                    }
-                    atomicAdd(&row[ref], 1u);  // (another sample of a chunk that straddles two, or a crowded table)
-                };
-                if (!(r & 0x80000000u)) {
-                    add(r);
-                } else {
-                    const u32 gi = r & 0x7fffffffu;
-                    atomicOr((unsigned long long*)&hitword[gi], 1ull << s);
-                    for (u64 q = po[gi], qe = po[gi + 1]; q < qe; ++q) add(pr[q]);
-                }
-            }
+        const u64 t = ((c * chunk_mul) % n_chunks) * 256 + threadIdx.x;
+        if (t >= total) continue;
+        u32 lo = 0, hi = n_samples;  // sample of position t: last s with off[s] <= t
+        while (hi - lo > 1) {
+            const u32 mid = (lo + hi) >> 1;
+            if (off[mid] <= t) lo = mid; else hi = mid;
         }
-        __syncthreads();
-        if (tkey[threadIdx.x]) {
-            atomicAdd(&overlap[(u64)s0 * n_refs + tkey[threadIdx.x] - 1], tcnt[threadIdx.x]);
-            tkey[threadIdx.x] = 0;
-            tcnt[threadIdx.x] = 0;
+        const u32 s = lo;
+        const u64 h = samples[t];
+        if (filter && h <= dv.max_hash) {  // presence bit first (yh_db::d_filter): clear = not in the database
+            const u64 bit = yh_bucket_of(h, dv.bkt_lsh, filter_mul);
+            if (!((filter[bit >> 5] >> (bit & 31u)) & 1u)) continue;
         }
-        __syncthreads();
+        const u32 r = dv.find(h);
+        if (r == YH_DIR_NONE) continue;
+        u32* row = overlap + (u64)s * n_refs;
+        if (!(r & 0x80000000u)) {
+            atomicAdd(&row[r], 1u);
+        } else {
+            const u32 gi = r & 0x7fffffffu;
+            atomicOr((unsigned long long*)&hitword[gi], 1ull << s);
+            for (u64 q = po[gi], qe = po[gi + 1]; q < qe; ++q) atomicAdd(&row[pr[q]], 1u);
+        }
     }
 }
 
