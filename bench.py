@@ -584,8 +584,8 @@ def main() -> int:
         achieved = (alg_bytes / 1e9) / (k_ms / 1e3) if k_ms > 0 else 0.0
         survey_rate = (survey_bytes / 1e9) / (k_ms / 1e3) if k_ms > 0 else 0.0
         return {
-            # (samples of 393 216+ hashes take the tiled form of the kernel: yh_q_overlap_indexed)
-            "bound": "hbm", "kernel": "k_index_lookup_tile" if n_sample >= 192 * 1024 * 2 else "k_index_lookup",
+            # (every sample size takes a form of k_index_lookup_tile: yh_q_overlap_indexed)
+            "bound": "hbm", "kernel": "k_index_lookup_tile",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": None,
             "bytes_basis": "layout: one 64-byte bucket (random sector) + the 8-byte hash per SAMPLE hash; no reference hash is streamed. "

@@ -2238,7 +2238,10 @@ int yh_q_overlap_indexed(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_ov
     // 35.7-36.3, U = 4 slower; no hits at all 32.5 / 31.5; an 83 k-hash sample 13 / 23)
     // YH_INDEX_TILE: 0 = k_index_lookup (one atomic per hit), 256 = the small aggregating form, 1/2/4 = 1024-lane tiles of U
     static const long tile_env = [] { const char* e = getenv("YH_INDEX_TILE"); return e ? atol(e) : -1L; }();
-    int U = n_sample >= 192ull * IDX_THREADS * 2 ? 2 : 256;
+    // (step time on the bench database, us, by sample size 1e5 / 2e5 / 3e5 / 4e5 / 5e5 / 7e5: small form 27.5 / 29.9 / 34.7 /
+    // 37.9 / 40.5 / 43.5; 1024-lane tiles of one hash 29.3 / 30.0 / 33.5 / 33.7 / 36.4 / 41.7; of two 35.1 / 34.9 / 35.0 / 36.0 /
+    // 36.9 / 41.1)
+    int U = n_sample >= 512ull * IDX_THREADS ? 2 : n_sample >= 256ull * IDX_THREADS ? 1 : 256;
     if (tile_env >= 0) U = (int)tile_env;
     // the aggregating forms leave one atomic per (workgroup, reference): four replicas are enough there (10^6-hash sample:
     // step 49.9 -> 48.4 us; two: 51.7; 83 k-hash real-shape sample: 28.8 / 26.3 / 25.4 us with 8 / 4 / 2)
