@@ -307,10 +307,15 @@ int yh_sig_batch_destroy(yh_sig_batch* batch);
  *                      3 not exactly one signature of that k-mer size, 4 empty sketch, 5 a shape this reader leaves to
  *                      the general (Python) one -- unsorted mins, non-integer fields.
  *   yh_sig_meta_get    arrays of n entries; md5 as n x 33 bytes (NUL-terminated); name_offsets[n + 1] into the byte
- *                      buffer yh_sig_meta_names fills (UTF-8, not terminated).                                       */
+ *                      buffer yh_sig_meta_names fills (UTF-8, not terminated).
+ *   yh_sig_meta_read_keep / yh_sig_meta_take_batch   the same pass also keeps what the train core reads from each file
+ *                      (yh_sig_batch_read's sketches and statuses, taken from the text while it is in memory), and hands
+ *                      it over as a yh_sig_batch: the 85 205 files of a GTDB training set are read once, not twice.     */
 typedef struct yh_sig_meta yh_sig_meta;
 int yh_gunzip_files(const char* const* paths, uint64_t n_paths, int threads, uint8_t* status);
 int yh_sig_meta_read(const char* const* paths, uint64_t n_paths, int ksize, int threads, yh_sig_meta** out);
+int yh_sig_meta_read_keep(const char* const* paths, uint64_t n_paths, int ksize, int threads, yh_sig_meta** out);
+int yh_sig_meta_take_batch(yh_sig_meta* meta, yh_sig_batch** out);
 int yh_sig_meta_get(const yh_sig_meta* meta, uint8_t* status, uint64_t* n_hashes, uint64_t* scaled, double* mean_abundance,
                     uint8_t* has_abundance, char* md5, uint64_t* name_offsets);
 int yh_sig_meta_names(const yh_sig_meta* meta, char* names);

@@ -294,3 +294,35 @@ def test_native_metadata_pass_equals_reference_known_answers_and_python_reader(t
                         "scaled 100", "unsorted mins", "read through gzip"}
     assert got["two k"][1:4] == (2.0, 4, 1000) and got["null abundances"][1] is None and got["scaled 100"][3] == 100
     assert got["unsorted mins"][2] == 3
+
+
+def test_metadata_pass_hands_its_sketches_to_the_core(tmp_path):
+    """`yacht train` reads its signature files once: utils.collect_signature_info keeps what the train core reads from
+    each file (yh_sig_meta_read_keep / yh_sig_meta_take_batch) and train_core.read_sketches_csr over the SAME path
+    list takes it -- equal to reading the files, statuses included; any other list reads the files."""
+    import zipfile
+
+    from yacht_amd import train_core
+
+    work = tmp_path / "work"
+    (work / "signatures").mkdir(parents=True)
+    with zipfile.ZipFile(os.path.join(FX, "20_genomes_sketches.zip")) as z:
+        z.extractall(work)
+    utils.decompress_all_sig_files(sorted(str(p) for p in (work / "signatures").glob("*.sig.gz")), 2)
+    (work / "signatures" / "zz_two_ksizes.sig").write_text(json.dumps([{"name": "two", "signatures": [
+        {"num": 0, "ksize": 21, "seed": 42, "max_hash": 18446744073709552, "mins": [5, 7, 9], "molecule": "dna"},
+        {"num": 0, "ksize": 31, "seed": 42, "max_hash": 18446744073709552, "mins": [1, 2], "molecule": "dna"}]}]))
+    paths = [os.path.join(str(work), "signatures", f) for f in os.listdir(work / "signatures")]
+    train_core.drop_parsed_sketches()
+    want_v, want_o = train_core.read_sketches_csr(paths, threads=2)  # from the files
+    info = utils.collect_signature_info(3, 31, str(work))
+    assert len(info) == 21 and train_core._PARSED.get("paths") == paths
+    got_v, got_o = train_core.read_sketches_csr(paths, threads=2)     # from the metadata pass
+    assert not train_core._PARSED and np.array_equal(got_o, want_o) and np.array_equal(got_v, want_v)
+    j = paths.index(os.path.join(str(work), "signatures", "zz_two_ksizes.sig"))
+    assert got_v[int(got_o[j]):int(got_o[j + 1])].tolist() == [5, 7, 9]  # the core takes signature 0 whatever its k-mer size
+    # another list (here: reversed) is read from the files, and the offer is dropped
+    utils.collect_signature_info(3, 31, str(work))
+    rev_v, rev_o = train_core.read_sketches_csr(paths[::-1], threads=2)
+    assert not train_core._PARSED and int(rev_o[-1]) == int(want_o[-1])
+    assert np.array_equal(rev_v[: int(rev_o[1])], want_v[int(want_o[-2]):])

@@ -132,6 +132,8 @@ SIGNATURES = {
     "yh_sig_batch_destroy": (C.c_int, [_vp]),
     "yh_gunzip_files": (C.c_int, [C.POINTER(C.c_char_p), C.c_uint64, C.c_int, _vp]),
     "yh_sig_meta_read": (C.c_int, [C.POINTER(C.c_char_p), C.c_uint64, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "yh_sig_meta_read_keep": (C.c_int, [C.POINTER(C.c_char_p), C.c_uint64, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "yh_sig_meta_take_batch": (C.c_int, [_vp, C.POINTER(_vp)]),
     "yh_sig_meta_get": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "yh_sig_meta_names": (C.c_int, [_vp, _vp]),
     "yh_sig_meta_destroy": (C.c_int, [_vp]),

@@ -71,25 +71,10 @@ struct Scanner {
 // empty sketch, main.cpp:66-71) or READ_MALFORMED (the reference's json::parse / operator[] throws and the program
 // dies, main.cpp:73-81: callers must treat it as fatal).
 enum { READ_OK = 0, READ_CANNOT_OPEN = 1, READ_MALFORMED = 2 };
-inline std::vector<uint64_t> read_mins(const std::string& path, bool report = true, int* status = nullptr) {
+// the mins of record 0, signature 0 of a signature file's text (what read_mins returns for the file)
+inline std::vector<uint64_t> mins_from_text(const std::string& text, int* status = nullptr) {
     std::vector<uint64_t> mins;
     if (status) *status = READ_OK;
-    FILE* f = fopen(path.c_str(), "rb");
-    if (!f) {
-        if (report) std::cerr << "Could not open the file!" << std::endl;
-        if (status) *status = READ_CANNOT_OPEN;
-        return mins;
-    }
-    std::string text;
-    if (fseek(f, 0, SEEK_END) == 0) {
-        const long len = ftell(f);
-        if (len > 0) text.resize((size_t)len);
-        rewind(f);
-    }
-    size_t got = text.empty() ? 0 : fread(&text[0], 1, text.size(), f);
-    if (got < text.size()) text.resize(got);
-    for (char buf[1 << 16]; (got = fread(buf, 1, sizeof buf, f)) > 0;) text.append(buf, got);  // (unseekable input)
-    fclose(f);
     Scanner s{text.data(), text.data() + text.size()};
     if (!s.lit('[') || !s.find_key("signatures") || !s.lit('[') || !s.find_key("mins") || !s.lit('[')) {
         if (status) *status = READ_MALFORMED;
@@ -122,6 +107,27 @@ inline std::vector<uint64_t> read_mins(const std::string& path, bool report = tr
         mins.erase(std::unique(mins.begin(), mins.end()), mins.end());
     }
     return mins;
+}
+
+inline std::vector<uint64_t> read_mins(const std::string& path, bool report = true, int* status = nullptr) {
+    if (status) *status = READ_OK;
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) {
+        if (report) std::cerr << "Could not open the file!" << std::endl;
+        if (status) *status = READ_CANNOT_OPEN;
+        return {};
+    }
+    std::string text;
+    if (fseek(f, 0, SEEK_END) == 0) {
+        const long len = ftell(f);
+        if (len > 0) text.resize((size_t)len);
+        rewind(f);
+    }
+    size_t got = text.empty() ? 0 : fread(&text[0], 1, text.size(), f);
+    if (got < text.size()) text.resize(got);
+    for (char buf[1 << 16]; (got = fread(buf, 1, sizeof buf, f)) > 0;) text.append(buf, got);  // (unseekable input)
+    fclose(f);
+    return mins_from_text(text, status);
 }
 
 }  // namespace yh_sig

@@ -147,6 +147,11 @@ int yh_sig_batch_destroy(yh_sig_batch* b) {
 
 struct yh_sig_meta {
     std::vector<yh_sig::Meta> m;
+    // yh_sig_meta_read_keep: what the train core would read from the same files (record 0, signature 0, no ksize check),
+    // taken from the text while it is in memory -- yh_sig_meta_take_batch hands it on
+    bool kept = false;
+    std::vector<std::vector<uint64_t>> mins;
+    std::vector<uint8_t> mins_status;
 };
 
 int yh_gunzip_files(const char* const* paths, uint64_t n_paths, int threads, uint8_t* status) {
@@ -174,16 +179,26 @@ int yh_gunzip_files(const char* const* paths, uint64_t n_paths, int threads, uin
     return YH_OK;
 }
 
-int yh_sig_meta_read(const char* const* paths, uint64_t n_paths, int ksize, int threads, yh_sig_meta** out) {
+static int sig_meta_read(const char* const* paths, uint64_t n_paths, int ksize, int threads, bool keep, yh_sig_meta** out) {
     if (!out || (n_paths && !paths)) { yh_set_error("null argument"); return YH_ERR_INVALID_ARG; }
     yh_sig_meta* b = new (std::nothrow) yh_sig_meta;
     if (!b) { yh_set_error("out of host memory"); return YH_ERR_OOM; }
     b->m.resize(n_paths);
+    b->kept = keep;
+    if (keep) {
+        b->mins.resize(n_paths);
+        b->mins_status.assign(n_paths, (uint8_t)yh_sig::READ_CANNOT_OPEN);
+    }
     std::atomic<bool> oom{false};
     for_each_threaded(n_paths, threads, [&](uint64_t k) {
         try {
             std::string text;
             if (!read_whole(paths[k] ? paths[k] : "", &text)) { b->m[k].status = yh_sig::META_CANNOT_OPEN; return; }
+            if (keep) {  // (the train core reads the file as it is: a gzipped one does not parse there)
+                int st = 0;
+                b->mins[k] = yh_sig::mins_from_text(text, &st);
+                b->mins_status[k] = (uint8_t)st;
+            }
             if (text.size() >= 2 && (unsigned char)text[0] == 0x1f && (unsigned char)text[1] == 0x8b) {
                 std::string plain;
                 if (!gunzip_buffer(text, &plain)) { b->m[k].status = yh_sig::META_MALFORMED; return; }
@@ -196,6 +211,26 @@ int yh_sig_meta_read(const char* const* paths, uint64_t n_paths, int ksize, int 
     });
     if (oom.load()) { delete b; yh_set_error("out of host memory while reading signature metadata"); return YH_ERR_OOM; }
     *out = b;
+    return YH_OK;
+}
+
+int yh_sig_meta_read(const char* const* paths, uint64_t n_paths, int ksize, int threads, yh_sig_meta** out) {
+    return sig_meta_read(paths, n_paths, ksize, threads, false, out);
+}
+
+int yh_sig_meta_read_keep(const char* const* paths, uint64_t n_paths, int ksize, int threads, yh_sig_meta** out) {
+    return sig_meta_read(paths, n_paths, ksize, threads, true, out);
+}
+
+int yh_sig_meta_take_batch(yh_sig_meta* b, yh_sig_batch** out) {
+    if (!b || !out) { yh_set_error("null argument"); return YH_ERR_INVALID_ARG; }
+    if (!b->kept) { yh_set_error("this metadata set was not read with yh_sig_meta_read_keep (or its sketches were taken already)"); return YH_ERR_UNSUPPORTED; }
+    yh_sig_batch* r = new (std::nothrow) yh_sig_batch;
+    if (!r) { yh_set_error("out of host memory"); return YH_ERR_OOM; }
+    r->mins.swap(b->mins);
+    r->status.swap(b->mins_status);
+    b->kept = false;
+    *out = r;
     return YH_OK;
 }
 

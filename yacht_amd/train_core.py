@@ -73,6 +73,26 @@ def read_sketches(paths: Sequence[str], threads: int = 1) -> List[np.ndarray]:
     return [_read_one(p) for p in paths]
 
 
+# Sketches the metadata pass in front of the core has parsed already (utils.collect_signature_info ->
+# yh_sig_meta_read_keep): the path list they belong to and the library's batch handle.  Used once, by the next
+# read_sketches_csr over exactly that list; anything else reads the files.
+_PARSED = {}
+
+
+def offer_parsed_sketches(paths: List[str], batch_handle) -> None:
+    drop_parsed_sketches()
+    _PARSED.update(paths=paths, handle=batch_handle)
+
+
+def drop_parsed_sketches() -> None:
+    h = _PARSED.pop("handle", None)
+    _PARSED.clear()
+    if h is not None:
+        from . import _lib
+
+        _lib.load().yh_sig_batch_destroy(h)
+
+
 def read_sketches_csr(paths: Sequence[str], threads: int = 1):
     """(values, offsets) of all files through the library's threaded reader (yh_sig_batch_*: the
     counterpart of src/cpp/main.cpp:89-124).  A file that cannot be opened is an empty sketch and the
@@ -83,9 +103,14 @@ def read_sketches_csr(paths: Sequence[str], threads: int = 1):
     from . import _lib
 
     lib = _lib.load()
-    arr = (C.c_char_p * len(paths))(*[os.fsencode(p) for p in paths])
-    h = C.c_void_p()
-    _lib.check(lib.yh_sig_batch_read(arr, len(paths), max(1, int(threads)), C.byref(h)))
+    if _PARSED.get("handle") is not None and _PARSED.get("paths") == list(paths):
+        h = _PARSED.pop("handle")  # the very files, parsed a moment ago by the metadata pass
+        _PARSED.clear()
+    else:
+        drop_parsed_sketches()
+        arr = (C.c_char_p * len(paths))(*[os.fsencode(p) for p in paths])
+        h = C.c_void_p()
+        _lib.check(lib.yh_sig_batch_read(arr, len(paths), max(1, int(threads)), C.byref(h)))
     try:
         status = np.zeros(max(len(paths), 1), dtype=np.uint8)
         _lib.check(lib.yh_sig_batch_status(h, status.ctypes.data_as(C.c_void_p)))

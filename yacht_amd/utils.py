@@ -74,9 +74,11 @@ def get_info_from_single_sig(sig_file: str, ksize: int):
         return None
 
 
-def _sig_meta_native(paths: List[str], ksize: int, num_threads: int):
+def _sig_meta_native(paths: List[str], ksize: int, num_threads: int, keep_sketches: bool = False):
     """(status, n_hashes, scaled, mean_abundance, has_abundance, md5s, names) of every file through the library's
-    threaded reader (yh_sig_meta_*: a JSON scan + md5 in C++ instead of a Python object per hash)."""
+    threaded reader (yh_sig_meta_*: a JSON scan + md5 in C++ instead of a Python object per hash).
+    keep_sketches: the pass also keeps what the train core reads from the same files and leaves it with
+    train_core.offer_parsed_sketches, so that `yacht train` reads its 85 205 files once, not twice."""
     import ctypes as C
 
     from . import _lib
@@ -85,8 +87,15 @@ def _sig_meta_native(paths: List[str], ksize: int, num_threads: int):
     n = len(paths)
     arr = (C.c_char_p * n)(*[os.fsencode(p) for p in paths])
     h = C.c_void_p()
-    _lib.check(lib.yh_sig_meta_read(arr, n, int(ksize), max(1, int(num_threads)), C.byref(h)))
+    read = lib.yh_sig_meta_read_keep if keep_sketches else lib.yh_sig_meta_read
+    _lib.check(read(arr, n, int(ksize), max(1, int(num_threads)), C.byref(h)))
     try:
+        if keep_sketches:
+            from . import train_core
+
+            hb = C.c_void_p()
+            _lib.check(lib.yh_sig_meta_take_batch(h, C.byref(hb)))
+            train_core.offer_parsed_sketches(list(paths), hb)  # (owns the batch handle from here on)
         status = np.zeros(max(n, 1), np.uint8)
         n_hashes = np.zeros(max(n, 1), np.uint64)
         scaled = np.zeros(max(n, 1), np.uint64)
@@ -114,7 +123,7 @@ def collect_signature_info(num_threads: int, ksize: int, path_to_temp_dir: str) 
     fields) by get_info_from_single_sig itself."""
     sig_dir = os.path.join(path_to_temp_dir, "signatures")
     paths = [os.path.join(sig_dir, f) for f in os.listdir(sig_dir)]
-    status, n_hashes, scaled, mean_ab, has_ab, md5s, names = _sig_meta_native(paths, ksize, num_threads)
+    status, n_hashes, scaled, mean_ab, has_ab, md5s, names = _sig_meta_native(paths, ksize, num_threads, keep_sketches=True)
     out: Dict[str, Tuple] = {}
     for i, path in enumerate(paths):
         st = int(status[i])
