@@ -15,6 +15,7 @@
  *   yh_pairwise         replaces  compute_intersection_matrix(_by_sketches) (src/cpp/main.cpp:249-366)
  *   yh_index_stats      replaces  the three statistics printed at src/cpp/main.cpp:242-244
  *   yh_train_select     replaces  do_yacht_train (src/cpp/main.cpp:371-407)
+ *   yh_hyp_test         replaces  single_hyp_test / get_alt_mut_rate (hypothesis_recovery_src.py:209-306; scipy there)
  *
  * Conventions
  *   - every function returns 0 on success, a negative YH_ERR_* code on failure;
@@ -280,6 +281,22 @@ int yh_index_stats(yh_db* db, uint64_t* n_distinct, uint64_t* n_singletons, uint
 int yh_train_select(const uint32_t* sizes, uint64_t n_refs,
                     const uint32_t* pair_i, const uint32_t* pair_j, uint64_t n_pairs,
                     uint32_t* selected, uint64_t* n_selected);
+
+/* ---- yacht run, step 3: the binomial presence test (host; no device, no scipy) ----------------------------
+ * single_hyp_test + get_alt_mut_rate (hypothesis_recovery_src.py:209-306) for n organisms at once, the eight
+ * result columns of hypothesis_recovery (:377-391) -- n_excl and n_match are the caller's own inputs:
+ *   n_excl_cov[i]    = int(n_excl[i] * min_coverage)                 ("num_exclusive_kmers_to_genome_coverage")
+ *   threshold[i]     = binom.ppf(1 - significance, n_excl_cov, ani_thresh ** ksize)   ("acceptance_threshold_with_coverage")
+ *   confidence[i]    = 1 - binom.cdf(threshold, n_excl_cov, p)        ("actual_confidence_with_coverage")
+ *   alt_mut_rate[i]  = 1 - (1 - betaincinv(n_excl_cov - threshold, 1 + threshold, significance)) ** (1 / ksize), NaN -> -1
+ *   p_val[i]         = binom.cdf(n_match, n_excl_cov, p) if n_match <= n_excl_cov else 1
+ *   in_sample_est[i] = n_match >= threshold and n_match != 0
+ * Exact log-space binomial tails (Loader's point probabilities) and a Newton solve of the regularized incomplete
+ * beta: integer columns and decisions equal scipy's, floating columns to ~1e-13 relative (tests/test_hyp_native.py
+ * against the reference's own outputs).  Needs no GPU and no handle.                                          */
+int yh_hyp_test(uint64_t n, const uint32_t* n_excl, const uint32_t* n_match, int ksize, double significance,
+                double ani_thresh, double min_coverage, uint8_t* in_sample_est, double* p_val,
+                uint32_t* n_excl_cov, double* threshold, double* confidence, double* alt_mut_rate);
 
 /* ---- ingest: the sketches of many .sig files (in front of yh_db_create) ------------------------------
  * What the reference's train core does before anything else (src/cpp/main.cpp:62-124,

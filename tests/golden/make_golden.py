@@ -2,6 +2,8 @@
 """Generate tests/golden/*.json|npz from the GENUINE reference, in the build container.
 
     python tests/golden/make_golden.py            (needs /root/reference and `make -C oracle ref`)
+    python tests/golden/make_golden.py cfg3       (only golden_train_cfg3.json: configs[3] at full size; `all` = everything)
+    python tests/golden/make_golden.py hypreal    (only golden_hyp_real.*: the hypothesis test on the (e, m) of real runs)
 
 Two sources, both the reference's own code, neither of which travels to the GPU box:
 
@@ -197,6 +199,85 @@ def golden_train() -> tuple:
     return arrays, cases
 
 
+def xlsx_columns(path: str, sheet: str, columns) -> dict:
+    """Numeric columns of one sheet of an .xlsx (a zip of XML; openpyxl is not in this image): {header: [values]}."""
+    import re
+    import zipfile
+
+    z = zipfile.ZipFile(path)
+    wb = z.read("xl/workbook.xml").decode()
+    names = re.findall(r'<sheet name="([^"]+)" sheetId="(\d+)"', wb)
+    sid = {n: i for n, i in names}[sheet]
+    xml = z.read(f"xl/worksheets/sheet{sid}.xml").decode()
+    rows = re.findall(r"<row [^>]*>(.*?)</row>", xml, flags=re.S)
+    cell = re.compile(r'<c r="([A-Z]+)\d+"[^>]*?(?:/>|>(?:<is><t>(.*?)</t></is>|<v>(.*?)</v>)</c>)', flags=re.S)
+    header = {col: (txt if txt is not None else val) for col, txt, val in cell.findall(rows[0])}
+    want = {col: name for col, name in header.items() if name in columns}
+    out = {name: [] for name in want.values()}
+    for r in rows[1:]:
+        got = {col: val for col, _txt, val in cell.findall(r) if col in want}
+        for col, name in want.items():
+            out[name].append(float(got[col]))
+    return out
+
+
+def golden_hyp_real(hr) -> dict:
+    """(n_exclusive, n_matches) pairs of REAL runs -- the raw_result sheets of the reference's shipped
+    use_case_examples/**/result_*.xlsx -- through the reference's single_hyp_test at three coverages each, with the
+    parameters those workbooks were made with.  Every 12th row: ~17 000 tuples."""
+    files = [("use_case_examples/low_abundance_samples/result_k31_ani0.90.xlsx", 31, 0.90, 0.90),
+             ("use_case_examples/low_abundance_samples/result_k51_ani0.95.xlsx", 51, 0.95, 0.95),
+             ("use_case_examples/MAG_fishing/result_k51_ani0.95_SRR32008482.xlsx", 51, 0.95, 0.95)]
+    cols = {k: [] for k in ("file", "e", "m", "cov", "present", "p_val", "n_cov", "thr", "conf", "alt")}
+    params = []
+    for fi, (rel, k, sig, ani) in enumerate(files):
+        tab = xlsx_columns(os.path.join(REF, rel), "raw_result", ("num_exclusive_kmers_to_genome", "num_matches"))
+        e_all = [int(x) for x in tab["num_exclusive_kmers_to_genome"]]
+        m_all = [int(x) for x in tab["num_matches"]]
+        params.append({"file": rel, "ksize": k, "significance": sig, "ani_thresh": ani, "rows_in_sheet": len(e_all)})
+        for e, m in list(zip(e_all, m_all))[fi::12]:
+            for cov in (1.0, 0.1, 0.01):
+                r = hr.single_hyp_test((e, m), k, sig, ani, cov)
+                for name, v in zip(("file", "e", "m", "cov", "present", "p_val", "n_cov", "thr", "conf", "alt"),
+                                   (fi, e, m, cov, bool(r[0]), float(r[1]), int(r[3]), float(r[5]), float(r[6]), float(r[7]))):
+                    cols[name].append(v)
+    arrays = {"file_index": np.asarray(cols["file"], np.uint8), "e": np.asarray(cols["e"], np.uint32),
+              "m": np.asarray(cols["m"], np.uint32), "cov": np.asarray(cols["cov"], np.float64),
+              "present": np.asarray(cols["present"], np.bool_), "p_val": np.asarray(cols["p_val"], np.float64),
+              "n_cov": np.asarray(cols["n_cov"], np.uint32), "thr": np.asarray(cols["thr"], np.float64),
+              "conf": np.asarray(cols["conf"], np.float64), "alt": np.asarray(cols["alt"], np.float64)}
+    return arrays, params
+
+
+def golden_train_cfg3() -> dict:
+    """BASELINE.json configs[3] at its REAL size (synth.config4(): 10 000 sketches of ~5 000 hashes) through the
+    genuine reference executable, `-t 8 -c 0.95**31 -p 1` (src/cpp/main.cpp:215-420 end to end).  The input is
+    regenerated from its seed by the test (a digest of it is stored); stored outputs: the selected ids in walk
+    order, the three printed statistics, and a sha256 over the sorted pair lines (the lines themselves: 1.4 MB)."""
+    import hashlib
+
+    values, offsets = synth.config4()
+    refs = [values[int(offsets[i]):int(offsets[i + 1])] for i in range(offsets.size - 1)]
+    c = 0.95 ** 31
+    with tempfile.TemporaryDirectory(dir=os.environ.get("YACHT_GOLDEN_TMP")) as d:
+        selected, lines, stdout = oracle.run_ref_exe(refs, c, d, threads=8)
+    stats = {}
+    for ln in stdout.splitlines():
+        if ln.startswith("Total number of distinct hashes:"):
+            stats["distinct"] = int(ln.split(":")[1])
+        elif "appear in only one sketch" in ln:
+            stats["singletons"] = int(ln.split(":")[1])
+        elif ln.startswith("Size of the index:"):
+            stats["index"] = int(ln.split(":")[1])
+        elif ln.startswith("Number of empty sketches:"):
+            stats["empty"] = int(ln.split(":")[1])
+    return {"generator": "yacht_amd.synth.config4()", "n_refs": int(offsets.size - 1), "n_hashes": int(values.size),
+            "input_sha256": hashlib.sha256(values.tobytes() + offsets.tobytes()).hexdigest(),
+            "c": c, "threads": 8, "selected": selected, "n_pair_lines": len(lines),
+            "pair_lines_sha256": hashlib.sha256("\n".join(lines).encode()).hexdigest(),
+            "first_pair_lines": lines[:5], "stats": stats}
+
+
 def golden_fixture(hr) -> dict:
     """The reference's end-to-end known answer (tests/test_workflow.py:62-66) reproduced from the
     raw fixture JSON: which genomes overlap the sample, their (n_exclusive, n_matches), and the
@@ -242,8 +323,24 @@ def main() -> None:
     assert os.path.isdir(REF), f"{REF} not found"
     oracle.build(with_ref=True)
     assert oracle.have_ref_exe()
+    if "cfg3" in sys.argv[1:] or "all" in sys.argv[1:]:  # minutes of the reference exe on 10 000 files: on request
+        with open(os.path.join(HERE, "golden_train_cfg3.json"), "w") as f:
+            json.dump(golden_train_cfg3(), f)
+        print("golden_train_cfg3.json written")
+        if "cfg3" in sys.argv[1:]:
+            return
     copy_fixtures()
     hr, _utils = import_reference()
+    if "hypreal" in sys.argv[1:] or "all" in sys.argv[1:]:
+        import scipy
+
+        arrays, params = golden_hyp_real(hr)
+        np.savez_compressed(os.path.join(HERE, "golden_hyp_real.npz"), **arrays)
+        with open(os.path.join(HERE, "golden_hyp_real.json"), "w") as f:
+            json.dump({"files": params, "n": int(arrays["e"].size), "scipy": scipy.__version__}, f)
+        print("golden_hyp_real written:", int(arrays["e"].size), "tuples")
+        if "hypreal" in sys.argv[1:]:
+            return
     with open(os.path.join(HERE, "golden_hyp.json"), "w") as f:
         json.dump(golden_hyp(hr), f)
     arrays, cases = golden_exclusive(hr)

@@ -1521,7 +1521,11 @@ __global__ void __launch_bounds__(THREADS) k_index_lookup_tile(const u64* __rest
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const u64 t = base + (u64)u * THREADS + threadIdx.x;
+#if YH_NT_BUCKETS
+        h[u] = __builtin_nontemporal_load(sample + min(t, n - 1));
+#else
         h[u] = sample[min(t, n - 1)];
+#endif
         ok[u] = t < n && h[u] <= dv.max_hash;
         if (!ok[u]) h[u] = 0;  // (still a valid bucket to read)
     }

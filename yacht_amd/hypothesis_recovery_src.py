@@ -223,6 +223,30 @@ def hyp_test_batch(n_excl, n_match, ksize: int, significance: float = 0.99, ani_
     return present, p_val, e, n_cov, m, thr, conf, alt
 
 
+def hyp_test_native(n_excl, n_match, ksize: int, significance: float = 0.99, ani_thresh: float = 0.95,
+                    min_coverage: float = 1):
+    """hyp_test_batch without scipy: yh_hyp_test of the C ABI (host C++: exact log-space binomial tails and a Newton
+    solve of the regularized incomplete beta).  Same eight columns; decisions, integer columns and thresholds equal
+    scipy's, floating columns to ~1e-13 relative (tests/test_hyp_native.py).  What a non-Python caller binds, and what
+    makes in_sample_est independent of the scipy build of the machine; YACHT_HYP_NATIVE=1 makes hypothesis_recovery
+    use it."""
+    import ctypes as C
+
+    from . import _lib
+
+    lib = _lib.load()
+    e = np.ascontiguousarray(n_excl, dtype=np.uint32)
+    m = np.ascontiguousarray(n_match, dtype=np.uint32)
+    n = int(e.size)
+    present = np.zeros(n, dtype=np.uint8)
+    p_val, thr, conf, alt = (np.zeros(n, dtype=np.float64) for _ in range(4))
+    n_cov = np.zeros(n, dtype=np.uint32)
+    ptr = lambda a: C.c_void_p(a.ctypes.data)  # noqa: E731
+    _lib.check(lib.yh_hyp_test(n, ptr(e), ptr(m), int(ksize), float(significance), float(ani_thresh), float(min_coverage),
+                               ptr(present), ptr(p_val), ptr(n_cov), ptr(thr), ptr(conf), ptr(alt)))
+    return present.astype(bool), p_val, e.astype(np.int64), n_cov.astype(np.int64), m.astype(np.int64), thr, conf, alt
+
+
 def single_hyp_test(exclusive_hashes_info_org: Tuple[int, int], ksize: int, significance: float = 0.99,
                     ani_thresh: float = 0.95, min_coverage: int = 1):
     """Binomial presence test for one organism (reference :233-306); returns the same 8-tuple:
@@ -264,7 +288,8 @@ def hypothesis_recovery(manifest: pd.DataFrame, sample_info_set, path_to_genome_
     for min_coverage in min_coverage_list:
         logger.info(f"Computing hypothesis recovery for min_coverage={min_coverage}")
         with phases.phase("hypothesis_tests"):
-            cols = hyp_test_batch(n_excl, n_match, ksize, significance, ani_thresh, min_coverage)
+            test = hyp_test_native if os.environ.get("YACHT_HYP_NATIVE") == "1" else hyp_test_batch
+            cols = test(n_excl, n_match, ksize, significance, ani_thresh, min_coverage)
         results = pd.DataFrame({name: col for name, col in zip(GIVEN_COLUMNS, cols)}, columns=GIVEN_COLUMNS)
         results["in_sample_est"] = results["in_sample_est"].astype(bool)
         manifest["min_coverage"] = min_coverage
