@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define YH_ABI_VERSION 2
+#define YH_ABI_VERSION 3
 
 enum {
     YH_OK               = 0,
@@ -62,7 +62,7 @@ enum {
 #define YH_DB_KEEP_CSR     2u  /* keep the plain CSR resident too (needed by yh_overlap_bsearch) */
 #define YH_DB_FULL_INDEX   4u  /* (accepted for compatibility: the directory below is built by default)      */
 #define YH_DB_PAIRWISE_ONLY 8u /* `yacht train` handle: validated sizes + the inverted index only
-                                  (yh_pairwise, yh_index_stats); no streaming layout, so the
+                                  (yh_pairwise, yh_index_stats); no lookup structures, so the
                                   overlap / exclusive / run queries return YH_ERR_UNSUPPORTED        */
 #define YH_DB_NO_DIRECTORY 16u /* do not build the bucket table over the distinct hashes (25.6 B per
                                   distinct hash): the sample-driven (indexed) lookups -- yh_*_indexed_device,
@@ -76,8 +76,8 @@ typedef struct yh_db_info {
     uint64_t n_refs;             /* N                                                         */
     uint64_t n_hashes;           /* H = offsets[N]                                            */
     uint64_t max_hash;           /* largest hash in the database (0 if H == 0)                */
-    uint32_t n_partitions;       /* P hash-range partitions of the partitioned CSR            */
-    uint32_t partition_shift;    /* partition of hash h = h >> partition_shift                */
+    uint32_t reserved0;          /* (was n_partitions: the partitioned layouts are gone; always 0) */
+    uint32_t reserved1;
     uint64_t n_distinct;         /* distinct hashes over all references (index built only)    */
     uint64_t n_shared_distinct;  /* distinct hashes present in >= 2 references ("index size") */
     uint64_t n_shared_postings;  /* sum over shared hashes of their reference counts          */
@@ -96,8 +96,6 @@ typedef struct yh_db_info {
 #define YH_STREAM_NONE   0u  /* posting-only / pairwise-only handle                              */
 #define YH_STREAM_DELTA  1u  /* default: all (hash, reference) pairs in hash order, one delta BYTE
                                 per pair (+ an 8-byte header per 1024) -- k_stream_lookup            */
-#define YH_STREAM_KEYS24 2u  /* YH_STREAM=keys: partition-major packed 24-bit keys -- k_tile_lookup_keys */
-#define YH_STREAM_WIDE   3u  /* YH_WIDE_KEYS=1: partition-major 64-bit hashes -- k_tile_lookup     */
 
 typedef struct yh_timing {
     float ms_overlap_kernel;     /* last overlap tile kernel (HIP events on the handle's stream) */
@@ -112,9 +110,9 @@ int yh_abi_version(void);
 int yh_device_count(int* n_devices);
 
 /* ---- database handle ------------------------------------------------------------------ */
-/* Upload a CSR reference database to `device_id`, validate ordering, build the hash-range
- * partitioned CSR and (unless YH_DB_NO_INDEX) the shared-hash inverted index.
- * partitions_hint = 0 chooses P from the mean sketch size.                                 */
+/* Upload a CSR reference database to `device_id`, validate ordering, and build what the queries read: the
+ * hash-sorted delta stream, the bucket table + presence filter over the distinct hashes and (unless
+ * YH_DB_NO_INDEX) the shared-hash inverted index.  partitions_hint is ignored (kept for ABI compatibility). */
 int yh_db_create(const uint64_t* values, const uint64_t* offsets, uint64_t n_refs,
                  int device_id, uint32_t flags, uint32_t partitions_hint, yh_db** out);
 /* Same, but `d_values`/`d_offsets` already live in the HBM of `device_id` (not modified,
@@ -205,14 +203,18 @@ int yh_run_device(yh_db* db, const uint64_t* d_sample, uint64_t n_sample,
  * exchange: which references overlap the sample AT ALL, one bit each (N/8 bytes, latency-bound):
  *   yh_run_local_device   lookup + reduce on this rank: d_overlap, d_n_match final; d_n_excl = the part
  *                         that needs no posting list; the subset bits of the handle's references to
- *                         d_bits_out (ceil(n_refs / 64) * 2 words; the ghosts' bits there are NOT valid)
+ *                         d_bits_out: ceil(n_refs / 256) * 8 words are written (whole 256-reference
+ *                         blocks; bits behind n_refs are 0; the ghosts' bits there are NOT valid)
  *   -- all-gather of the local references' bits (torch.distributed / RCCL, yacht_amd/dist.py) --
  *   yh_run_finish_device  ghost g takes bit ghost_src[g] of d_global_bits; then the posting-list part
  *                         of d_n_excl is added.  Rows of ghosts and padding in the outputs are garbage.
  * yh_db_set_ghosts registers the ghost range and their bit positions once per handle.
  * A step runs in one of YH_RUN_CONTEXTS contexts (its own subset bits and work list): the local halves of a
  * whole block of samples can be queued, their bits exchanged in ONE collective, and the second halves follow
- * (d_global_bits then points at that sample's row of the gathered block; ghost_src indexes from there). */
+ * (d_global_bits then points at that sample's row of the gathered block; ghost_src indexes from there).
+ * Between the two halves of a context no OTHER query may run on the handle in that context's place: a
+ * yh_overlap* / yh_exclusive / yh_run* call re-uses the current context's work list (the library returns
+ * YH_ERR_INVALID_ARG from yh_run_finish_device when it sees that this happened).                        */
 #define YH_RUN_CONTEXTS 16
 int yh_db_set_ghosts(yh_db* db, uint64_t ghost_begin, uint64_t n_ghost, const uint32_t* d_ghost_src);
 /* `ctx` (0 .. YH_RUN_CONTEXTS - 1) names the step context the two halves share: the lookup of sample k+1
@@ -241,31 +243,6 @@ int yh_run_wait(yh_db* db, int slot);
 int yh_host_alloc(void** out, uint64_t bytes);
 int yh_host_free(void* p);
 
-/* ---- references spread over several GPUs: exact exclusive counts --------------------------------
- * Each rank holds (a) a handle over its shard of the REFERENCES for the overlap kernel and (b) a
- * posting-list handle over its range of the HASH space, built from the (hash, global reference
- * id) pairs every rank sent it (yacht_amd/dist.py does the exchange with torch.distributed).
- *   yh_db_create_from_pairs       (b): pairs already in HBM; partition_shift/max_hash as reported
- *                                 by the reference shards' yh_db_get_info (use the global maximum)
- *   yh_exclusive_partial_device   partial sums over this handle's posting lists for a mask over
- *                                 ALL references: ex_e (hashes with exactly one masked holder),
- *                                 ex_m (those also in the sample), ovsh (sample hashes among the
- *                                 database-shared hashes, per masked holder); summed over ranks
- *   yh_db_nshared_device          per-reference count of hashes of this handle's range that
- *                                 another reference also holds; summed over ranks
- *   yh_exclusive_finalize_device  n_excl = size - nshared + ex_e, n_match = overlap - ovsh + ex_m
- *                                 for masked references, 0 otherwise (all arrays of length n)   */
-int yh_db_create_from_pairs(const uint64_t* d_hashes, const uint32_t* d_refs, uint64_t n_pairs,
-                            uint64_t n_refs_total, int device_id, uint32_t partition_shift, uint64_t max_hash,
-                            yh_db** out);
-int yh_exclusive_partial_device(yh_db* db, const uint8_t* d_mask, const uint64_t* d_sample, uint64_t n_sample,
-                                uint32_t* d_ex_e, uint32_t* d_ex_m, uint32_t* d_ovsh);
-int yh_db_nshared_device(yh_db* db, uint32_t* d_out);
-int yh_exclusive_finalize_device(yh_db* db, uint64_t n, const uint8_t* d_mask, const uint32_t* d_sizes,
-                                 const uint32_t* d_nshared, const uint32_t* d_overlap, const uint32_t* d_ex_e,
-                                 const uint32_t* d_ex_m, const uint32_t* d_ovsh, uint32_t* d_n_excl,
-                                 uint32_t* d_n_match);
-
 /* ---- yacht train: pairwise intersections ---------------------------------------------------
  * Emits every ORDERED pair (i, j), i != j, row_begin <= i < row_end, both sketches non-empty,
  * count = |R_i ∩ R_j| > 0 and !(1.0*count/|R_i| < c_thresh), sorted by (i, j).
@@ -273,6 +250,9 @@ int yh_exclusive_finalize_device(yh_db* db, uint64_t n, const uint8_t* d_mask, c
  * YH_ERR_CAPACITY when cap != 0 is too small, YH_OK when cap == 0.                            */
 int yh_pairwise(yh_db* db, double c_thresh, uint64_t row_begin, uint64_t row_end, uint64_t cap,
                 uint32_t* pair_i, uint32_t* pair_j, uint32_t* pair_count, uint64_t* n_out);
+/* d_out[j] (device, N words) = number of hashes of reference j that another reference holds too: the work of row j
+ * of the pairwise pass (yacht_amd/dist.py cuts `yacht train`'s row blocks by it).  Enqueued on the handle's stream. */
+int yh_db_nshared_device(yh_db* db, uint32_t* d_out);
 /* distinct hashes, hashes seen in exactly one reference, hashes kept in the index.           */
 int yh_index_stats(yh_db* db, uint64_t* n_distinct, uint64_t* n_singletons, uint64_t* n_index);
 

@@ -1,7 +1,8 @@
-"""The tile kernel streams 32-bit keys (hash >> kshift) and confirms key matches against the 64-bit
-hashes afterwards.  These cases are built to make keys collide: sample and database hashes that
-differ only in the bits a key drops, runs of equal keys that straddle a tile boundary, and the same
-inputs through the 64-bit kernel (YH_WIDE_KEYS=1) as a cross-check.  Everything against the oracle."""
+"""Both lookups work on pieces of a hash and confirm against the rest: the streaming kernel compares truncated keys
+(hash >> stream_shift) and confirms a candidate by the low 32 bits of its position's record, the sample-driven one
+picks a bucket by the high bits and compares low words.  These cases are built to make the pieces collide: sample and
+database hashes that differ only in low bits, runs of equal truncated keys, full-range (scaled = 1) hashes.  Every case
+through BOTH kernels, forced (the library's own choice would take one of them), against the oracle."""
 import os
 import subprocess
 import sys
@@ -10,6 +11,7 @@ import numpy as np
 import pytest
 
 from oracle import oracle
+from yacht_amd import _lib
 from yacht_amd.engine import RefDB, pack_csr
 
 pytestmark = pytest.mark.gpu
@@ -55,33 +57,32 @@ def _colliding_case(seed=7):
     return values, offsets, sample
 
 
-def _check(values, offsets, sample, hint):
-    with RefDB(values, offsets, partitions_hint=hint) as db:
-        info = db.info()
-        ov, e, m = db.run_counts(sample)
+def _check(values, offsets, sample):
     w_ov = oracle.overlap(values, offsets, sample)
     mask = (w_ov > 0).astype(np.uint8)
     w_e, w_m = oracle.exclusive(values, offsets, mask, sample)
-    assert np.array_equal(ov, w_ov)
-    assert np.array_equal(e, np.where(mask, w_e, 0))
-    assert np.array_equal(m, np.where(mask, w_m, 0))
+    with RefDB(values, offsets) as db:
+        info = db.info()
+        for mode in (_lib.YH_LOOKUP_STREAM, _lib.YH_LOOKUP_INDEXED):
+            db.set_lookup(mode)
+            assert db.lookup_choice(sample.size) == mode  # the kernel this pass is named for really runs
+            ov, e, m = db.run_counts(sample)
+            assert np.array_equal(ov, w_ov), mode
+            assert np.array_equal(e, np.where(mask, w_e, 0)), mode
+            assert np.array_equal(m, np.where(mask, w_m, 0)), mode
+            assert np.array_equal(db.overlap(sample), w_ov), mode
     return info
 
 
 def test_key_collisions_are_not_hits(hip_lib):
-    values, offsets, sample = _colliding_case()
-    info = _check(values, offsets, sample, hint=512)
-    assert info["n_partitions"] >= 256  # the case really runs with kshift > 0
+    for seed in (7, 8):
+        values, offsets, sample = _colliding_case(seed=seed)
+        info = _check(values, offsets, sample)
+        assert info["stream_shift"] > 0  # the stream really drops low bits of these hashes
 
 
-def test_key_collisions_other_partitionings(hip_lib):
-    values, offsets, sample = _colliding_case(seed=8)
-    for hint in (1, 16, 4096):
-        _check(values, offsets, sample, hint=hint)
-
-
-def test_full_range_hashes_single_partition(hip_lib):
-    """scaled = 1 sketches: hashes up to 2**64 - 1, few partitions, keys drop up to 31 bits."""
+def test_full_range_hashes(hip_lib):
+    """scaled = 1 sketches: hashes up to 2**64 - 1; the stream keeps bits 32.. only."""
     rng = np.random.default_rng(3)
     refs = [np.unique(rng.integers(0, 2**64 - 1, size=800, dtype=np.uint64, endpoint=True)) for _ in range(40)]
     refs.append(np.array([0, 1, 2**32, 2**32 + 1, 2**63, 2**64 - 2, 2**64 - 1], dtype=np.uint64))
@@ -89,28 +90,4 @@ def test_full_range_hashes_single_partition(hip_lib):
     sample = np.unique(np.concatenate([rng.choice(flat, 3000), rng.choice(flat, 3000) ^ np.uint64(1 << 5),
                                        np.array([0, 2**32 + 1, 2**64 - 1], dtype=np.uint64)]))
     values, offsets = pack_csr(refs)
-    for hint in (1, 2, 64):
-        _check(values, offsets, sample, hint=hint)
-
-
-def test_wide_key_build_gives_the_same_counts(hip_lib):
-    """The 64-bit tile kernel (YH_WIDE_KEYS=1 at creation) on the collision case, in a child process."""
-    code = (
-        "import sys, numpy as np; sys.path.insert(0, %r)\n"
-        "from tests.test_gpu_keys import _colliding_case\n"
-        "from yacht_amd.engine import RefDB\n"
-        "v, o, s = _colliding_case()\n"
-        "db = RefDB(v, o, partitions_hint=512); ov, e, m = db.run_counts(s)\n"
-        "np.savez(sys.argv[1], ov=ov, e=e, m=m)\n" % ROOT
-    )
-    import tempfile
-
-    with tempfile.TemporaryDirectory() as d:
-        out = os.path.join(d, "wide.npz")
-        env = dict(os.environ, YH_WIDE_KEYS="1")
-        subprocess.run([sys.executable, "-c", code, out], check=True, env=env, cwd=ROOT, timeout=600)
-        wide = np.load(out)
-        values, offsets, sample = _colliding_case()
-        with RefDB(values, offsets, partitions_hint=512) as db:
-            ov, e, m = db.run_counts(sample)
-        assert np.array_equal(ov, wide["ov"]) and np.array_equal(e, wide["e"]) and np.array_equal(m, wide["m"])
+    _check(values, offsets, sample)

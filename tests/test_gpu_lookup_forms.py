@@ -1,8 +1,8 @@
 """GPU: the forms of the sample-driven lookup that the small randomized cases of tests/tools/fuzz_parity.py do not
 reach by themselves -- the 1024-lane tiles (samples of 4e5+ hashes), the presence filter in front of the buckets
-(databases of 1e6+ distinct hashes), the plain one-atomic-per-hit kernel (A/B only) -- forced onto them, where the
-CPU oracle checks every count.  (Their default is the 256-lane aggregating form.)  The knobs are read once per
-process, hence the subprocess."""
+(databases of 1e6+ distinct hashes) -- forced onto them, where the CPU oracle checks every count.  (Their default is
+the 256-lane aggregating form.)  The knobs are tuning switches behind YH_DEBUG_TUNING=1, read once per process, hence
+the subprocess."""
 import json
 import os
 import subprocess
@@ -19,10 +19,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     {"YH_INDEX_TILE": "2", "YH_FILTER_MIN": "1", "YH_FILTER_BPH": "2"},   # crowded filter: many false positives
     {"YH_INDEX_TILE": "1", "YH_FILTER_MIN": "1", "YH_FILTER_BPH": "16"},
     {"YH_INDEX_TILE": "4", "YH_NO_FILTER": "1"},
-    {"YH_INDEX_TILE": "0"},                                              # one atomic per hit (no LDS hit table)
-], ids=["tile2-filter2", "tile1-filter16", "tile4-nofilter", "plain"])
+], ids=["tile2-filter2", "tile1-filter16", "tile4-nofilter"])
 def test_forced_lookup_forms_against_oracle(hip_lib, env):
-    e = dict(os.environ)
+    e = dict(os.environ, YH_DEBUG_TUNING="1")
     e.update(env)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "fuzz_parity.py"), "--seconds", "25", "--seed", "31"],
                        env=e, capture_output=True, text=True, timeout=600, cwd=ROOT)

@@ -15,10 +15,10 @@ pytestmark = pytest.mark.gpu
 C_DEFAULT = 0.95 ** 31
 
 
-def _check_all(refs, sample, c_thresh=C_DEFAULT, partitions_hint=0):
+def _check_all(refs, sample, c_thresh=C_DEFAULT):
     values, offsets = synth.pack(refs)
     sizes = np.diff(offsets).astype(np.uint32)
-    with RefDB(values, offsets, flags=YH_DB_KEEP_CSR, partitions_hint=partitions_hint) as db:
+    with RefDB(values, offsets, flags=YH_DB_KEEP_CSR) as db:
         want = oracle.overlap(values, offsets, sample)
         # every query through the streaming kernel, through the sample-driven one, and by the library's own choice
         for mode in (_lib.YH_LOOKUP_STREAM, _lib.YH_LOOKUP_INDEXED, _lib.YH_LOOKUP_AUTO):
@@ -79,13 +79,12 @@ def test_micro_golden_layout(hip_lib):
 
 
 def test_every_hash_hits_and_subtiles(hip_lib):
-    """Sample = union of all references (every lookup is a hit); one partition, so the sample
-    slice is far larger than one LDS tile and the kernel must loop over sub-tiles."""
+    """Sample = union of all references (every lookup is a hit): a streaming workgroup's slice of the sample is far
+    larger than one LDS tile and the kernel must loop over sub-tiles."""
     rng = np.random.default_rng(3)
     refs = synth.independent_refs(rng, 60, 900, 0.5, 50, 5000)
     sample = np.unique(np.concatenate(refs + [synth.random_sketch(rng, 40000, synth.max_hash_for_scaled(1000))]))
-    for hint in (0, 1, 4096):
-        _check_all(refs, sample, partitions_hint=hint)
+    _check_all(refs, sample)
 
 
 def test_one_hash_in_hundreds_of_references(hip_lib):

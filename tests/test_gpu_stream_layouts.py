@@ -1,6 +1,6 @@
-"""Both streaming layouts -- the hash-sorted delta stream (default) and the partition-major packed
-24-bit keys (YH_STREAM=keys at handle creation) -- must give the oracle's counts on the same edge cases.
-The layout is chosen per process, so the cases run in a child."""
+"""The streaming lookup (k_stream_lookup over the hash-sorted delta stream) on edge cases against the oracle -- FORCED:
+the library's own choice for databases this small is the sample-driven kernel.  Second pass: the run step through the
+general exclusive pass (YH_NO_FUSED_RUN behind the YH_DEBUG_TUNING gate, read once per process, hence the child)."""
 import os
 import subprocess
 import sys
@@ -17,15 +17,15 @@ import sys
 import numpy as np
 sys.path.insert(0, %r)
 from oracle import oracle
-from yacht_amd import synth
+from yacht_amd import _lib, synth
 from yacht_amd.engine import RefDB
 from tests.test_gpu_keys import _colliding_case
 
-WANT_LAYOUT = int(sys.argv[1])
-
 def check(values, offsets, sample, **kw):
     with RefDB(values, offsets, **kw) as db:
-        assert db.info()["stream_layout"] == WANT_LAYOUT, db.info()
+        assert db.info()["stream_layout"] == 1, db.info()
+        db.set_lookup(_lib.YH_LOOKUP_STREAM)
+        assert db.lookup_choice(max(sample.size, 1)) == _lib.YH_LOOKUP_STREAM
         ov, e, m = db.run_counts(sample)
         ov_only = db.overlap(sample)
     w_ov = oracle.overlap(values, offsets, sample)
@@ -54,25 +54,14 @@ print("stream layout ok")
 """
 
 
-@pytest.mark.parametrize("name,layout,extra", [("delta", 1, {}), ("keys", 2, {}), ("delta", 1, {"YH_NO_FUSED_RUN": "1"})],
-                         ids=["delta", "keys", "delta-general-run"])
-def test_stream_layout_matches_oracle(hip_lib, name, layout, extra):
-    """(third case: the run step through the general exclusive pass -- shared-hash flags, k_excl_chunks,
-    k_excl_final -- instead of the fused three-launch form)"""
-    env = dict(os.environ, YH_STREAM=name, **extra)
-    env.pop("YH_WIDE_KEYS", None)
-    r = subprocess.run([sys.executable, "-c", CHILD % ROOT, str(layout)], env=env, cwd=ROOT, capture_output=True,
+@pytest.mark.parametrize("extra", [{}, {"YH_DEBUG_TUNING": "1", "YH_NO_FUSED_RUN": "1"}], ids=["fused-run", "general-run"])
+def test_stream_lookup_matches_oracle(hip_lib, extra):
+    """(second case: the run step through the general exclusive pass -- shared-hash flags, k_excl_worklist,
+    k_excl_pieces over the postings, k_excl_final -- instead of the fused three-launch form)"""
+    env = dict(os.environ, **extra)
+    r = subprocess.run([sys.executable, "-c", CHILD % ROOT], env=env, cwd=ROOT, capture_output=True,
                        text=True, timeout=900)
     assert r.returncode == 0 and "stream layout ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
-
-
-def test_default_layout_is_the_delta_stream(hip_lib):
-    code = ("import sys; sys.path.insert(0, %r); import numpy as np; from yacht_amd.engine import RefDB; "
-            "db = RefDB(np.arange(1, 9, dtype=np.uint64), np.array([0, 8], dtype=np.uint64)); "
-            "print('layout', db.info()['stream_layout'])") % ROOT
-    env = {k: v for k, v in os.environ.items() if k not in ("YH_STREAM", "YH_WIDE_KEYS")}
-    r = subprocess.run([sys.executable, "-c", code], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "layout 1" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
 CHILD_WIDE_TILE = r"""
@@ -82,7 +71,7 @@ sys.path.insert(0, %r)
 from oracle import oracle
 from yacht_amd.engine import RefDB
 
-# One workgroup (YH_TILE_WGS=1) over a database whose truncated-key range exceeds 2^32: the sample keys
+# One workgroup (YH_STREAM_WGS=1, a tuning switch behind YH_DEBUG_TUNING) over a database whose truncated-key range exceeds 2^32: the sample keys
 # of a tile are staged as 32-bit offsets from its first key, so a tile must end where the offset would
 # overflow -- a sample of a few hashes at the two ends and in the middle of the range forces that.
 rng = np.random.default_rng(11)
@@ -94,7 +83,7 @@ values = np.concatenate(refs)
 offsets = np.array([0, refs[0].size, refs[0].size + refs[1].size], dtype=np.uint64)
 picks = np.concatenate([vals[:3], vals[vals.size // 2 - 1: vals.size // 2 + 2], vals[-3:]])
 sample = np.unique(np.concatenate([picks, np.array([5, top // 2 + 12345, top - 2, 2**64 - 2], dtype=np.uint64)]))
-with RefDB(values, offsets, flags=1) as db:                    # overlap only: no inverted index needed
+with RefDB(values, offsets, flags=1 | 16) as db:               # overlap only, no bucket table: every query streams
     info = db.info()
     assert info["stream_layout"] == 1
     span = int(vals[-1] >> info["stream_shift"]) - int(vals[0] >> info["stream_shift"])
@@ -108,9 +97,7 @@ print("wide tile ok", span, got.tolist())
 
 
 def test_tile_ends_where_32_bit_key_offsets_would_overflow(hip_lib):
-    env = dict(os.environ, YH_TILE_WGS="1")
-    env.pop("YH_STREAM", None)
-    env.pop("YH_WIDE_KEYS", None)
+    env = dict(os.environ, YH_DEBUG_TUNING="1", YH_STREAM_WGS="1")
     r = subprocess.run([sys.executable, "-c", CHILD_WIDE_TILE % ROOT], env=env, cwd=ROOT, capture_output=True,
                        text=True, timeout=1200)
     assert r.returncode == 0 and "wide tile ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

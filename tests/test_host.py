@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/yacht_hip.h but not exported"
     assert sorted(_lib.SIGNATURES) == names, "ctypes table and header disagree"
-    assert _lib.load().yh_abi_version() == 2
+    assert _lib.load().yh_abi_version() == 3
 
 
 def test_no_device_fails_loudly():
@@ -326,3 +326,28 @@ def test_metadata_pass_hands_its_sketches_to_the_core(tmp_path):
     rev_v, rev_o = train_core.read_sketches_csr(paths[::-1], threads=2)
     assert not train_core._PARSED and int(rev_o[-1]) == int(want_o[-1])
     assert np.array_equal(rev_v[: int(rev_o[1])], want_v[int(want_o[-2]):])
+
+
+def test_extract_members_concatenated_gzip_and_traversal(tmp_path):
+    """A .sig.gz of several gzip members inflates whole (as gzip / yh_gunzip_files read it); a member -- file OR
+    directory entry -- that would land outside the working directory is refused."""
+    import gzip
+    import zipfile
+
+    from yacht_amd.make_training_data_from_sketches import _extract_members
+
+    z = tmp_path / "a.zip"
+    work = tmp_path / "work"
+    work.mkdir()
+    with zipfile.ZipFile(z, "w") as a:
+        a.writestr("signatures/", b"")
+        a.writestr("signatures/x.sig.gz", gzip.compress(b"[1,") + gzip.compress(b"2]"))
+        a.writestr("signatures/broken.sig.gz", b"not gzip")
+    assert _extract_members((str(z), str(work), ["signatures/", "signatures/x.sig.gz", "signatures/broken.sig.gz"])) == 3
+    assert (work / "signatures" / "x.sig").read_bytes() == b"[1,2]"
+    assert (work / "signatures" / "broken.sig.gz").read_bytes() == b"not gzip"  # left for the gunzip pass to complain about
+    for bad in ("../../evil/", "../evil.sig"):
+        with zipfile.ZipFile(z, "w") as a:
+            a.writestr(bad, b"")
+        with pytest.raises(ValueError, match="outside the working directory"):
+            _extract_members((str(z), str(work), [bad]))

@@ -52,8 +52,8 @@ class DbInfo(C.Structure):
         ("n_refs", C.c_uint64),
         ("n_hashes", C.c_uint64),
         ("max_hash", C.c_uint64),
-        ("n_partitions", C.c_uint32),
-        ("partition_shift", C.c_uint32),
+        ("reserved0", C.c_uint32),
+        ("reserved1", C.c_uint32),
         ("n_distinct", C.c_uint64),
         ("n_shared_distinct", C.c_uint64),
         ("n_shared_postings", C.c_uint64),
@@ -114,11 +114,7 @@ SIGNATURES = {
     "yh_run_wait": (C.c_int, [_vp, C.c_int]),
     "yh_host_alloc": (C.c_int, [C.POINTER(_vp), C.c_uint64]),
     "yh_host_free": (C.c_int, [_vp]),
-    "yh_db_create_from_pairs": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64, C.c_int, C.c_uint32, C.c_uint64,
-                                          C.POINTER(_vp)]),
-    "yh_exclusive_partial_device": (C.c_int, [_vp, _vp, _vp, C.c_uint64, _vp, _vp, _vp]),
     "yh_db_nshared_device": (C.c_int, [_vp, _vp]),
-    "yh_exclusive_finalize_device": (C.c_int, [_vp, C.c_uint64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "yh_pairwise": (C.c_int, [_vp, C.c_double, C.c_uint64, C.c_uint64, C.c_uint64, _vp, _vp, _vp,
                               C.POINTER(C.c_uint64)]),
     "yh_index_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
@@ -187,7 +183,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError here = the .so does not match the header
         fn.restype = res
         fn.argtypes = args
-    if lib.yh_abi_version() != 2:
+    if lib.yh_abi_version() != 3:
         raise YachtHipError(YH_ERR_INVALID_ARG, f"ABI version mismatch in {path}")
     _lib = lib
     return lib

@@ -18,6 +18,11 @@ void yh_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+const char* yh_tune_env(const char* name) {
+    static const bool open_gate = [] { const char* e = getenv("YH_DEBUG_TUNING"); return e && e[0] == '1'; }();
+    return open_gate ? getenv(name) : nullptr;
+}
+
 int yh_dmalloc(yh_db* db, void** p, size_t bytes) {
     if (bytes == 0) bytes = 16;
     hipError_t e = hipMalloc(p, bytes);
@@ -52,7 +57,7 @@ static void ring_destroy(EventRing& r) {
 static int timing_every() {
     static int every = -1;
     if (every < 0) {
-        const char* e = getenv("YH_TIMING_EVERY");
+        const char* e = yh_tune_env("YH_TIMING_EVERY");
         every = e ? atoi(e) : 32;  // (an event pair costs the stream ~5 us: every 8th launch was 1.2 us of a 45 us step)
         if (every < 0) every = 0;
     }
@@ -85,6 +90,12 @@ static float ring_read(EventRing& r) {
     }
     r.pending = 0;
     return n ? (float)(acc / n) : 0.f;
+}
+
+// A query that is not one of the two halves of a step context re-uses the current context's subset bits and work
+// list: a context whose first half is queued loses them (yh_run_finish_device reports it).
+static void note_other_query(yh_db* db) {
+    if (db->ctx_open[db->ctx_now]) db->ctx_clobbered[db->ctx_now] = true;
 }
 
 static bool db_ok(yh_db* db) {
@@ -190,12 +201,11 @@ static int db_create_common(const u64* values, const u64* offsets, bool on_devic
         }
 
         (void)hipEventRecord(ev0, db->stream);
-        rc = yh_build_partitions(db, d_values_in, d_offsets_in, partitions_hint);
+        (void)partitions_hint;  // (accepted for ABI compatibility: the layouts it tuned are gone)
+        rc = yh_build_validate(db, d_values_in, d_offsets_in);
         if (rc != YH_OK) break;
-        if (!(flags & YH_DB_NO_INDEX) || yh_use_delta_stream()) {  // (the delta stream comes out of the same sort)
-            rc = yh_build_index(db, d_values_in, d_offsets_in, nullptr);
-            if (rc != YH_OK) break;
-        }
+        rc = yh_build_index(db, d_values_in, d_offsets_in);  // (overlap-only handles too: the delta stream comes out of the same sort)
+        if (rc != YH_OK) break;
         (void)hipEventRecord(ev1, db->stream);
         (void)hipEventSynchronize(ev1);
         (void)hipEventElapsedTime(&db->ms_db_build, ev0, ev1);
@@ -255,83 +265,6 @@ int yh_db_create_device(const uint64_t* d_values, const uint64_t* d_offsets, uin
                             partitions_hint, out);
 }
 
-// Posting-list-only handle from ready-made (hash, reference id) pairs that already live in HBM:
-// the hash-range shard of a database whose references are spread over several GPUs
-// (yacht_amd/dist.py).  It answers yh_exclusive_partial_device / yh_db_nshared_device only.
-int yh_db_create_from_pairs(const uint64_t* d_hashes, const uint32_t* d_refs, uint64_t n_pairs,
-                            uint64_t n_refs_total, int device_id, uint32_t partition_shift, uint64_t max_hash,
-                            yh_db** out) {
-    if (!out) { yh_set_error("out is null"); return YH_ERR_INVALID_ARG; }
-    *out = nullptr;
-    if (n_pairs && (!d_hashes || !d_refs)) { yh_set_error("null pair arrays"); return YH_ERR_INVALID_ARG; }
-    if (n_refs_total > 0xfffffff0ull || partition_shift > 63) { yh_set_error("bad size"); return YH_ERR_INVALID_ARG; }
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
-        yh_set_error("no HIP device available (libyacht_hip has no CPU fallback)");
-        return YH_ERR_NO_DEVICE;
-    }
-    if (device_id < 0 || device_id >= ndev) { yh_set_error("device_id %d out of range", device_id); return YH_ERR_NO_DEVICE; }
-    YH_HIP(hipSetDevice(device_id));
-    const u64 nparts = (max_hash >> partition_shift) + 1;
-    if (nparts > (1ull << 24)) { yh_set_error("partition_shift too small for max_hash"); return YH_ERR_INVALID_ARG; }
-    yh_db* db = new yh_db();
-    db->device = device_id;
-    db->flags = 0;
-    db->posting_only = true;
-    db->n_refs = n_refs_total;
-    db->n_hashes = n_pairs;
-    db->max_hash = max_hash;
-    db->pshift = partition_shift;
-    db->n_parts = (u32)nparts;
-    int rc = YH_OK;
-    do {
-        if (hipStreamCreateWithFlags(&db->own_stream, hipStreamDefault) != hipSuccess) { yh_set_error("hipStreamCreate failed"); rc = YH_ERR_HIP; break; }
-        db->stream = db->own_stream;
-        if ((rc = yh_dmalloc(db, (void**)&db->d_sbounds, (u64)(db->n_parts + 1) * sizeof(u32))) != YH_OK) break;
-        if ((rc = yh_dmalloc(db, (void**)&db->d_flag, 16)) != YH_OK) break;
-        if ((rc = yh_dmalloc(db, (void**)&db->d_maskbits, ((n_refs_total + 255) / 256) * 32 + 16)) != YH_OK) break;
-        if ((rc = yh_build_index(db, (const u64*)d_hashes, nullptr, d_refs)) != YH_OK) break;
-        ring_create(db->ev_excl);
-    } while (0);
-    if (rc != YH_OK) { yh_db_destroy(db); return rc; }
-    *out = db;
-    return YH_OK;
-}
-
-int yh_exclusive_partial_device(yh_db* db, const uint8_t* d_mask, const uint64_t* d_sample, uint64_t n_sample,
-                                uint32_t* d_ex_e, uint32_t* d_ex_m, uint32_t* d_ovsh) {
-    if (!db_ok(db)) return YH_ERR_INVALID_ARG;
-    if (db->n_refs && (!d_mask || !d_ex_e || !d_ex_m || !d_ovsh)) { yh_set_error("null device pointer"); return YH_ERR_INVALID_ARG; }
-    YH_TRY(db_select(db));
-    yh_ring_record_begin(db, db->ev_excl);
-    YH_TRY(yh_q_exclusive_partial(db, d_mask, (const u64*)d_sample, n_sample, d_ex_e, d_ex_m, d_ovsh, true, false,
-                                  nullptr));
-    yh_ring_record_end(db, db->ev_excl);
-    return YH_OK;
-}
-
-int yh_db_nshared_device(yh_db* db, uint32_t* d_out) {
-    if (!db_ok(db)) return YH_ERR_INVALID_ARG;
-    if (!db->has_index) { yh_set_error("this handle was created with YH_DB_NO_INDEX"); return YH_ERR_UNSUPPORTED; }
-    YH_TRY(db_select(db));
-    if (db->n_refs)
-        YH_HIP(hipMemcpyAsync(d_out, db->d_nshared, db->n_refs * sizeof(u32), hipMemcpyDeviceToDevice, db->stream));
-    return YH_OK;
-}
-
-int yh_exclusive_finalize_device(yh_db* db, uint64_t n, const uint8_t* d_mask, const uint32_t* d_sizes,
-                                 const uint32_t* d_nshared, const uint32_t* d_overlap, const uint32_t* d_ex_e,
-                                 const uint32_t* d_ex_m, const uint32_t* d_ovsh, uint32_t* d_n_excl,
-                                 uint32_t* d_n_match) {
-    if (!db_ok(db)) return YH_ERR_INVALID_ARG;
-    if (n && (!d_mask || !d_sizes || !d_nshared || !d_overlap || !d_ex_e || !d_ex_m || !d_ovsh || !d_n_excl || !d_n_match)) {
-        yh_set_error("null device pointer");
-        return YH_ERR_INVALID_ARG;
-    }
-    YH_TRY(db_select(db));
-    return yh_q_exclusive_final(db, n, d_mask, d_sizes, d_nshared, d_overlap, d_ex_e, d_ex_m, d_ovsh, d_n_excl, d_n_match);
-}
-
 int yh_db_destroy(yh_db* db) {
     if (!db) return YH_OK;
     if (db->device >= 0) (void)hipSetDevice(db->device);
@@ -346,29 +279,27 @@ int yh_db_destroy(yh_db* db) {
             if (db->ctx_count[c]) (void)hipFree(db->ctx_count[c]);
         }
     }
-    void* ptrs[] = {db->d_values, db->d_offsets, db->d_pvals, db->d_pbeg, db->d_pcnt, db->d_poffs, db->d_sizes,
-                    db->d_g, db->d_po, db->d_pr, db->d_pg, db->d_gbeg, db->d_gcnt, db->d_nshared, db->d_pq, db->d_pq_count, db->d_dh, db->d_dref, db->d_dir, db->d_bkt, db->d_cbkt, db->d_ovf_keys, db->d_ovf_vals, db->d_pkeys, db->d_pref, db->d_gkeys, db->d_rpo, db->d_rg, db->d_rrec, db->d_rrecx, db->d_filter, db->d_hrec, db->d_hrecx, db->d_hmult, db->d_hpo, db->d_work, db->d_work_count, db->d_sbounds,
-                    db->d_mask, db->d_maskbits, db->d_hit, db->d_excl_e, db->d_overlap_tmp,
-                    db->d_sample_tmp, db->d_out_tmp, db->d_flag, db->d_hitq, db->d_hitq_cnt, db->d_wg_first, db->d_reps, db->d_batch,
-                    db->d_sdelta, db->d_shdr, db->d_srec, db->d_wg_key, db->d_ghost_src, db->d_bad_word};
+    void* ptrs[] = {db->d_values, db->d_offsets, db->d_sizes, db->d_g, db->d_po, db->d_pr, db->d_pg, db->d_nshared, db->d_pq,
+                    db->d_pq_count, db->d_dh, db->d_dref, db->d_dir, db->d_bkt, db->d_cbkt, db->d_ovf_keys, db->d_ovf_vals,
+                    db->d_rpo, db->d_rg, db->d_rrec, db->d_rrecx, db->d_filter, db->d_hrec, db->d_hrecx, db->d_hmult, db->d_hpo,
+                    db->d_work, db->d_work_count, db->d_mask, db->d_maskbits, db->d_hit, db->d_excl_e, db->d_overlap_tmp,
+                    db->d_sample_tmp, db->d_out_tmp, db->d_flag, db->d_reps, db->d_batch, db->d_sdelta, db->d_shdr, db->d_srec,
+                    db->d_wg_key, db->d_ghost_src, db->d_bad_word};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     ring_destroy(db->ev_overlap);
     ring_destroy(db->ev_excl);
     ring_destroy(db->ev_pair);
     if (db->st_in) (void)hipStreamSynchronize(db->st_in);
-    if (db->st_out) (void)hipStreamSynchronize(db->st_out);
     for (RunSlot& s : db->slots) {
         if (s.d_sample) (void)hipFree(s.d_sample);
         if (s.d_out) (void)hipFree(s.d_out);
         if (s.d_bad) (void)hipFree(s.d_bad);
         if (s.h_bad) (void)hipHostFree(s.h_bad);
         if (s.ev_up) (void)hipEventDestroy(s.ev_up);
-        if (s.ev_done) (void)hipEventDestroy(s.ev_done);
         if (s.ev_out) (void)hipEventDestroy(s.ev_out);
     }
     if (db->st_in) (void)hipStreamDestroy(db->st_in);
-    if (db->st_out) (void)hipStreamDestroy(db->st_out);
     if (db->own_stream) (void)hipStreamDestroy(db->own_stream);
     free(db->h_pw_i);
     free(db->h_pw_j);
@@ -384,8 +315,6 @@ int yh_db_get_info(yh_db* db, yh_db_info* info) {
     info->n_refs = db->n_refs;
     info->n_hashes = db->n_hashes;
     info->max_hash = db->max_hash;
-    info->n_partitions = db->n_parts;
-    info->partition_shift = db->pshift;
     info->n_distinct = db->n_distinct;
     info->n_shared_distinct = db->n_shared;
     info->n_shared_postings = db->n_postings;
@@ -398,12 +327,6 @@ int yh_db_get_info(yh_db* db, yh_db_info* info) {
         info->stream_layout = YH_STREAM_DELTA;
         info->stream_shift = db->sshift;
         info->stream_bytes = db->slen + (db->slen / STREAM_BLOCK + 1) * sizeof(u64);
-    } else if (db->d_pkeys) {
-        info->stream_layout = YH_STREAM_KEYS24;
-        info->stream_bytes = db->pvals_len * 3;
-    } else if (db->d_pvals) {
-        info->stream_layout = YH_STREAM_WIDE;
-        info->stream_bytes = db->pvals_len * sizeof(u64);
     }
     return YH_OK;
 }
@@ -450,7 +373,7 @@ static bool prefer_indexed(const yh_db* db, u64 n_sample) {
     if (db->lookup_mode == YH_LOOKUP_STREAM) return false;
     if (db->lookup_mode == YH_LOOKUP_INDEXED) return true;
     static const int env = [] {
-        const char* e = getenv("YH_LOOKUP");
+        const char* e = yh_tune_env("YH_LOOKUP");
         return !e ? 0 : (strcmp(e, "stream") == 0 ? 1 : (strcmp(e, "indexed") == 0 ? 2 : 0));
     }();
     if (env) return env == 2;
@@ -479,6 +402,7 @@ int yh_overlap_device(yh_db* db, const uint64_t* d_sample, uint64_t n_sample, ui
     if (!db_ok(db)) return YH_ERR_INVALID_ARG;
     if (!d_overlap || (n_sample && !d_sample)) { yh_set_error("null device pointer"); return YH_ERR_INVALID_ARG; }
     YH_TRY(db_select(db));
+    note_other_query(db);
     if (prefer_indexed(db, n_sample)) return yh_q_overlap_indexed(db, (const u64*)d_sample, n_sample, d_overlap, false);
     return yh_q_overlap(db, (const u64*)d_sample, n_sample, d_overlap, false, false);
 }
@@ -487,6 +411,7 @@ int yh_overlap_indexed_device(yh_db* db, const uint64_t* d_sample, uint64_t n_sa
     if (!db_ok(db)) return YH_ERR_INVALID_ARG;
     if (!d_overlap || (n_sample && !d_sample)) { yh_set_error("null device pointer"); return YH_ERR_INVALID_ARG; }
     YH_TRY(db_select(db));
+    note_other_query(db);
     return yh_q_overlap_indexed(db, (const u64*)d_sample, n_sample, d_overlap, false);
 }
 
@@ -495,10 +420,10 @@ int yh_run_indexed_device(yh_db* db, const uint64_t* d_sample, uint64_t n_sample
     if (!db_ok(db)) return YH_ERR_INVALID_ARG;
     if (!d_overlap || !d_n_excl || !d_n_match || (n_sample && !d_sample)) { yh_set_error("null device pointer"); return YH_ERR_INVALID_ARG; }
     YH_TRY(db_select(db));
+    note_other_query(db);
     const int rc = yh_q_overlap_indexed(db, (const u64*)d_sample, n_sample, d_overlap, true, d_n_excl, d_n_match);
     if (rc != YH_OK) return rc == 2 ? YH_OK : rc;
-    return yh_q_exclusive(db, db->d_mask, (const u64*)d_sample, n_sample, d_overlap, d_n_excl, d_n_match, true,
-                          db->d_maskbits);
+    return yh_q_exclusive(db, db->d_mask, (const u64*)d_sample, n_sample, d_overlap, d_n_excl, d_n_match, db->d_maskbits);
 }
 
 int yh_run_batch_device(yh_db* db, const uint64_t* d_samples, const uint64_t* d_sample_offsets, uint32_t n_samples,
@@ -509,6 +434,7 @@ int yh_run_batch_device(yh_db* db, const uint64_t* d_samples, const uint64_t* d_
         return YH_ERR_INVALID_ARG;
     }
     YH_TRY(db_select(db));
+    note_other_query(db);
     return yh_q_run_batch(db, (const u64*)d_samples, (const u64*)d_sample_offsets, n_samples, total_hashes, d_overlap,
                           d_n_excl, d_n_match);
 }
@@ -670,6 +596,7 @@ int yh_exclusive(yh_db* db, const uint8_t* subset_mask, const uint64_t* sample, 
     if (N && (!subset_mask || !n_excl || !n_match)) { yh_set_error("null argument"); return YH_ERR_INVALID_ARG; }
     if (!db->has_index) { yh_set_error("this handle was created with YH_DB_NO_INDEX"); return YH_ERR_UNSUPPORTED; }
     YH_TRY(db_select(db));
+    note_other_query(db);
     YH_TRY(upload_sample(db, sample, n_sample));
     if (N == 0) return YH_OK;
     u32 *d_e = nullptr, *d_m = nullptr;
@@ -678,13 +605,7 @@ int yh_exclusive(yh_db* db, const uint8_t* subset_mask, const uint64_t* sample, 
     do {
         if (hipMemcpyAsync(db->d_mask, subset_mask, N, hipMemcpyHostToDevice, db->stream) != hipSuccess) { yh_set_error("mask upload failed"); rc = YH_ERR_HIP; break; }
         if ((rc = yh_q_overlap(db, db->d_sample_tmp, n_sample, db->d_overlap_tmp, true, false)) != YH_OK) break;
-        {   // most references masked: the coalesced pass over all postings beats the per-chunk walk
-            u64 masked = 0;
-            for (u64 j = 0; j < N; ++j) masked += subset_mask[j] != 0;
-            db->excl_prefer_stream = masked * 8 > N;
-        }
-        rc = yh_q_exclusive(db, db->d_mask, db->d_sample_tmp, n_sample, db->d_overlap_tmp, d_e, d_m, true, nullptr);
-        db->excl_prefer_stream = false;
+        rc = yh_q_exclusive(db, db->d_mask, db->d_sample_tmp, n_sample, db->d_overlap_tmp, d_e, d_m, nullptr);
         if (rc != YH_OK) break;
         if (hipMemcpyAsync(n_excl, d_e, N * sizeof(u32), hipMemcpyDeviceToHost, db->stream) != hipSuccess ||
             hipMemcpyAsync(n_match, d_m, N * sizeof(u32), hipMemcpyDeviceToHost, db->stream) != hipSuccess ||
@@ -702,6 +623,7 @@ int yh_run_device(yh_db* db, const uint64_t* d_sample, uint64_t n_sample, uint32
     if (!d_overlap || (n_sample && !d_sample)) { yh_set_error("null device pointer"); return YH_ERR_INVALID_ARG; }
     if ((d_n_excl == nullptr) != (d_n_match == nullptr)) { yh_set_error("pass both d_n_excl and d_n_match or neither"); return YH_ERR_INVALID_ARG; }
     YH_TRY(db_select(db));
+    note_other_query(db);
     if (prefer_indexed(db, n_sample)) {
         if (!d_n_excl) return yh_q_overlap_indexed(db, (const u64*)d_sample, n_sample, d_overlap, false);
         return yh_run_indexed_device(db, d_sample, n_sample, d_overlap, d_n_excl, d_n_match);
@@ -712,8 +634,7 @@ int yh_run_device(yh_db* db, const uint64_t* d_sample, uint64_t n_sample, uint32
     }
     YH_TRY(yh_q_overlap(db, (const u64*)d_sample, n_sample, d_overlap, d_n_excl != nullptr, d_n_excl != nullptr));
     if (!d_n_excl) return YH_OK;
-    return yh_q_exclusive(db, db->d_mask, (const u64*)d_sample, n_sample, d_overlap, d_n_excl, d_n_match, true,
-                          db->d_maskbits);
+    return yh_q_exclusive(db, db->d_mask, (const u64*)d_sample, n_sample, d_overlap, d_n_excl, d_n_match, db->d_maskbits);
 }
 
 int yh_run(yh_db* db, const uint64_t* sample, uint64_t n_sample, uint32_t* overlap, uint32_t* n_excl,
@@ -810,6 +731,8 @@ int yh_run_local_device(yh_db* db, int ctx, const uint64_t* d_sample, uint64_t n
     if (!d_overlap || !d_n_excl || !d_n_match || (n_sample && !d_sample)) { yh_set_error("null device pointer"); return YH_ERR_INVALID_ARG; }
     YH_TRY(db_select(db));
     YH_TRY(use_ctx(db, ctx));
+    db->ctx_open[ctx] = true;
+    db->ctx_clobbered[ctx] = false;
     const int rc = yh_q_run_fused(db, (const u64*)d_sample, n_sample, d_overlap, d_n_excl, d_n_match, 1, d_bits_out, nullptr,
                                   prefer_indexed(db, n_sample));
     if (rc == 1) { yh_set_error("yh_run_local_device needs a non-empty handle in the default layout with its index"); return YH_ERR_UNSUPPORTED; }
@@ -821,6 +744,13 @@ int yh_run_finish_device(yh_db* db, int ctx, const uint32_t* d_global_bits, uint
     if (!d_n_excl || (db->n_ghost && !d_global_bits)) { yh_set_error("null device pointer"); return YH_ERR_INVALID_ARG; }
     YH_TRY(db_select(db));
     YH_TRY(use_ctx(db, ctx));
+    const bool clobbered = db->ctx_open[ctx] && db->ctx_clobbered[ctx];
+    db->ctx_open[ctx] = false;
+    db->ctx_clobbered[ctx] = false;
+    if (clobbered) {
+        yh_set_error("another query ran on the handle between yh_run_local_device and yh_run_finish_device of context %d: its work list is gone", ctx);
+        return YH_ERR_INVALID_ARG;
+    }
     const int rc = yh_q_run_fused(db, nullptr, 1, nullptr, d_n_excl, nullptr, 2, nullptr, d_global_bits);
     if (rc == 1) { yh_set_error("yh_run_finish_device needs a non-empty handle in the default layout with its index"); return YH_ERR_UNSUPPORTED; }
     return rc;
@@ -832,7 +762,6 @@ static int slot_prepare(yh_db* db, RunSlot& s, u64 n_sample) {
     if (!db->st_in) YH_HIP(hipStreamCreateWithFlags(&db->st_in, hipStreamNonBlocking));
     if (!s.ev_up) {
         YH_HIP(hipEventCreateWithFlags(&s.ev_up, hipEventDisableTiming));
-        YH_HIP(hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
         YH_HIP(hipEventCreateWithFlags(&s.ev_out, hipEventDisableTiming));
     }
     if (!s.d_out) YH_TRY(yh_dmalloc(db, (void**)&s.d_out, 3 * N * sizeof(u32) + 16));
@@ -886,8 +815,7 @@ int yh_run_submit(yh_db* db, int slot, const uint64_t* sample, uint64_t n_sample
         const bool one_block = n_excl == overlap + N && n_match == n_excl + N;  // one contiguous [3][N] host buffer
         void* dv = nullptr;
         if (one_block && (3 * N) % 4 == 0 && ((uintptr_t)overlap & 15u) == 0) {
-            if (s.out_host != overlap) { s.out_host = overlap; s.out_dev = device_view_of_host(overlap); }
-            dv = s.out_dev;
+            dv = device_view_of_host(overlap);  // asked on every call: the same address may be pageable memory by now
         }
         if (dv) {
             k_copy_out<<<(unsigned)std::min<u64>((3 * N / 4 + 255) / 256, 512), 256, 0, db->stream>>>(
@@ -946,6 +874,16 @@ int yh_pairwise(yh_db* db, double c_thresh, uint64_t row_begin, uint64_t row_end
     memcpy(pair_i, db->h_pw_i, db->pw_n * sizeof(u32));
     memcpy(pair_j, db->h_pw_j, db->pw_n * sizeof(u32));
     memcpy(pair_count, db->h_pw_c, db->pw_n * sizeof(u32));
+    return YH_OK;
+}
+
+int yh_db_nshared_device(yh_db* db, uint32_t* d_out) {
+    if (!db_ok(db)) return YH_ERR_INVALID_ARG;
+    if (!db->has_index) { yh_set_error("this handle was created with YH_DB_NO_INDEX"); return YH_ERR_UNSUPPORTED; }
+    if (db->n_refs && !d_out) { yh_set_error("null device pointer"); return YH_ERR_INVALID_ARG; }
+    YH_TRY(db_select(db));
+    if (db->n_refs)
+        YH_HIP(hipMemcpyAsync(d_out, db->d_nshared, db->n_refs * sizeof(u32), hipMemcpyDeviceToDevice, db->stream));
     return YH_OK;
 }
 

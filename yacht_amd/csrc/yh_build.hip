@@ -1,10 +1,12 @@
 // yh_build.hip — one-time database construction on the device.
 //
-//   (1) hash-range partitioned CSR: the layout the streaming overlap kernel reads.
+//   (1) validation of the CSR (every reference strictly ascending), sketch sizes, the largest hash;
+//   (2) ONE stable radix sort of all (hash, reference) pairs, from which everything a query reads is cut:
+//       the hash-sorted delta stream (streaming lookup), the bucket table + presence filter over the distinct
+//       hashes (sample-driven lookup), and the shared-hash inverted index -- distinct hashes that occur in >= 2
+//       references with their posting lists: the content of the reference's `hash_index` after singletons are
+//       erased (src/cpp/main.cpp:215-246) -- with its reference-major views and holder sets.
 //       Replaces the per-run re-reading of N .sig files (hypothesis_recovery_src.py:93,154,168).
-//   (2) shared-hash inverted index: distinct hashes that occur in >= 2 references, with their
-//       posting lists.  Same content as the reference's `hash_index` after singletons are
-//       erased (src/cpp/main.cpp:215-246), built by a stable radix sort instead of a node map.
 #include "yh_common.h"
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -18,15 +20,6 @@
 namespace {
 
 constexpr int WAVE = 64;
-
-__device__ __forceinline__ u32 lower_bound_u64(const u64* a, u32 n, u64 key) {
-    u32 lo = 0, hi = n;
-    while (lo < hi) {
-        u32 mid = (lo + hi) >> 1;
-        if (a[mid] < key) lo = mid + 1; else hi = mid;
-    }
-    return lo;
-}
 
 // ---- validation + extent ----------------------------------------------------------------------
 // One wave per reference: flag[0] |= 1 if the slice is not strictly ascending; atomicMax of the
@@ -52,24 +45,6 @@ __global__ void k_scan_refs(const u64* __restrict__ values, const u64* __restric
             if (n > 0xffffffffull) atomicOr(flag, 2u);
             if (n) atomicMax(maxv, values[e - 1]);
         }
-    }
-}
-
-// ---- partition split points --------------------------------------------------------------------
-// split[j*(P+1)+p] = number of hashes of reference j below p << pshift.
-__global__ void k_split(const u64* __restrict__ values, const u64* __restrict__ offsets, u64 n_refs, u32 P,
-                        u32 pshift, u32* __restrict__ split) {
-    const u64 total = n_refs * (u64)(P + 1);
-    for (u64 t = blockIdx.x * (u64)blockDim.x + threadIdx.x; t < total; t += (u64)gridDim.x * blockDim.x) {
-        const u64 j = t / (P + 1);
-        const u32 p = (u32)(t % (P + 1));
-        const u64 b = offsets[j];
-        const u32 n = (u32)(offsets[j + 1] - b);
-        u32 r;
-        if (p == 0) r = 0;
-        else if (p == P) r = n;
-        else r = lower_bound_u64(values + b, n, (u64)p << pshift);
-        split[t] = r;
     }
 }
 
@@ -102,59 +77,6 @@ __device__ __forceinline__ u32 block_excl_scan(u32 v, u32* total_out, u32* lds /
     *total_out = lds[16];
     __syncthreads();
     return res;
-}
-
-// One workgroup per partition: poffs[p][j] = sum_{j' < j} (split[j'][p+1] - split[j'][p]).
-__global__ void __launch_bounds__(1024) k_part_scan(const u32* __restrict__ split, u64 n_refs, u32 P,
-                                                    u32* __restrict__ poffs, u64* __restrict__ pcnt,
-                                                    u32* __restrict__ flag) {
-    __shared__ u32 lds[17];
-    const u32 p = blockIdx.x;
-    u32* out = poffs + (u64)p * (n_refs + 1);
-    u64 carry = 0;
-    for (u64 base = 0; base < n_refs; base += blockDim.x) {
-        const u64 j = base + threadIdx.x;
-        u32 c = 0;
-        if (j < n_refs) c = split[j * (P + 1) + p + 1] - split[j * (P + 1) + p];
-        u32 tot;
-        const u32 ex = block_excl_scan(c, &tot, lds);
-        if (j < n_refs) out[j] = (u32)(carry + ex);
-        carry += tot;
-    }
-    if (threadIdx.x == 0) {
-        out[n_refs] = (u32)carry;
-        pcnt[p] = carry;
-        if (carry > 0xffffffffull) atomicOr(flag, 4u);
-    }
-}
-
-// One wave per reference: copy each hash to its partition-major slot.
-__global__ void k_scatter(const u64* __restrict__ values, const u64* __restrict__ offsets, u64 n_refs, u32 P,
-                          u32 pshift, const u32* __restrict__ split, const u64* __restrict__ pbeg,
-                          const u32* __restrict__ poffs, u64* __restrict__ pvals, u32 kshift,
-                          u32* __restrict__ pkeys, u32* __restrict__ pref) {
-    const u64 wave = (blockIdx.x * (u64)blockDim.x + threadIdx.x) / WAVE;
-    const u64 n_waves = ((u64)gridDim.x * blockDim.x) / WAVE;
-    const int lane = threadIdx.x & (WAVE - 1);
-    for (u64 j = wave; j < n_refs; j += n_waves) {
-        const u64 b = offsets[j];
-        const u32 n = (u32)(offsets[j + 1] - b);
-        const u32* sp = split + j * (P + 1);
-        for (u32 k = lane; k < n; k += WAVE) {
-            const u64 h = values[b + k];
-            const u32 p = (u32)(h >> pshift);
-            const u64 dst = pbeg[p] + poffs[(u64)p * (n_refs + 1) + j] + (k - sp[p]);
-            pvals[dst] = h;
-            if (pkeys) {
-                const u32 key = (u32)(h >> kshift) & KEY_MASK;
-                u8* kb = reinterpret_cast<u8*>(pkeys);
-                kb[yh_key_byte_addr(dst, 0)] = (u8)key;
-                kb[yh_key_byte_addr(dst, 1)] = (u8)(key >> 8);
-                kb[yh_key_byte_addr(dst, 2)] = (u8)(key >> 16);
-                pref[dst] = (u32)j;
-            }
-        }
-    }
 }
 
 // ---- index build ---------------------------------------------------------------------------------
@@ -450,13 +372,6 @@ __global__ void k_set_emit(u64 n_post, const u32* __restrict__ idx, const u32* _
     }
 }
 
-// 32-bit keys of a hash array: inside one hash-range partition the bits above pshift are constant,
-// so (u32)(h >> kshift) orders and (almost always) identifies the hashes of a partition.
-__global__ void k_make_keys(const u64* __restrict__ v, u64 n, u32 kshift, u32* __restrict__ keys) {
-    for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x)
-        keys[i] = (u32)(v[i] >> kshift) & KEY_MASK;
-}
-
 // ---- reference-major chunk view of the postings ---------------------------------------------------
 __global__ void k_chunk_counts(const u32* __restrict__ nshared, u64 n, u32* __restrict__ cc) {
     const u64 r = blockIdx.x * (u64)blockDim.x + threadIdx.x;
@@ -497,24 +412,6 @@ __global__ void k_filter_build(const u64* __restrict__ dh, u64 n, u32 lsh, u64 f
         atomicOr(&filter[bit >> 5], 1u << (bit & 31u));
     }
 }
-__global__ void k_bounds_u64(const u64* __restrict__ a, u64 n, u32 P, u32 pshift, u64* __restrict__ beg,
-                             u64* __restrict__ cnt) {
-    const u32 p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= P) return;
-    // n can exceed 2^32 in principle; use a 64-bit search
-    auto lb = [&](u64 key) {
-        u64 lo = 0, hi = n;
-        while (lo < hi) {
-            u64 mid = (lo + hi) >> 1;
-            if (a[mid] < key) lo = mid + 1; else hi = mid;
-        }
-        return lo;
-    };
-    const u64 b = (p == 0) ? 0 : lb((u64)p << pshift);
-    const u64 e = (p + 1 == P) ? n : lb((u64)(p + 1) << pshift);
-    beg[p] = b;
-    cnt[p] = e - b;
-}
 
 inline u32 grid_for(u64 work_items, u32 block, u32 max_blocks = 16384) {
     u64 g = (work_items + block - 1) / block;
@@ -526,7 +423,7 @@ inline u32 grid_for(u64 work_items, u32 block, u32 max_blocks = 16384) {
 }  // namespace
 
 // =================================================================================================
-int yh_build_partitions(yh_db* db, const u64* d_values, const u64* d_offsets, u32 parts_hint) {
+int yh_build_validate(yh_db* db, const u64* d_values, const u64* d_offsets) {
     const u64 N = db->n_refs;
     hipStream_t st = db->stream;
 
@@ -554,122 +451,7 @@ int yh_build_partitions(yh_db* db, const u64* d_values, const u64* d_offsets, u3
     u64 maxv;
     memcpy(&maxv, &hflag[2], 8);
     db->max_hash = maxv;
-
-    // ---- choose the partitioning: P ~ mean sketch size / YH_PIECE_TARGET, rounded down to 2^k,
-    // then the largest shift that still yields at least that many partitions.  Sketch size is the
-    // stand-in for the sample size the database will see (both follow `scaled`): a 1 M-hash sample
-    // puts ~950 keys into each 4094-slot LDS tile of a GTDB-like database (mean sketch ~4 000
-    // hashes -> 1 049 partitions); fewer keys per tile = fewer candidates, and a slice that does
-    // not fit one tile makes the kernel stream that partition again.  The other side: every
-    // (workgroup, partition) pair costs a tile set-up of a few microseconds, so a partition must
-    // hold at least 2^18 keys (a small database of large sketches would otherwise spend its time
-    // staging tiles: 6 000 sketches of 39 000 hashes ran at 1.8 TB/s with 20 972 partitions).
-    const u64 H = db->n_hashes;
-    u32 target = parts_hint;
-    if (target == 0) {
-        const u64 mean = N ? H / N : 0;
-        u64 t = std::min<u64>(mean / YH_PIECE_TARGET, std::max<u64>(H >> 18, 64));  // (64: room for large samples on small databases)
-        if (t < 1) t = 1;
-        if (t > 16384) t = 16384;
-        u32 pw = 1;
-        while ((u64)pw * 2 <= t) pw *= 2;
-        target = pw;
-    }
-    if (target > 65536) target = 65536;
-    u32 pshift = 0;
-    u32 P = 1;
-    if (H > 0 && target > 1) {
-        int s = 63;
-        while (s > 0 && ((maxv >> s) + 1) < target) --s;
-        pshift = (u32)s;
-        P = (u32)((maxv >> pshift) + 1);
-        if (P > 131072) {  // tiny hash ranges: fall back to fewer partitions
-            while (((maxv >> pshift) + 1) > 131072) ++pshift;
-            P = (u32)((maxv >> pshift) + 1);
-        }
-    } else {
-        pshift = 63;
-        // P = 1 requires every hash >> pshift == 0; with pshift = 63 a hash >= 2^63 would map to
-        // partition 1, so use two partitions in that case.
-        P = (H > 0) ? (u32)((maxv >> pshift) + 1) : 1;
-    }
-    db->pshift = pshift;
-    db->n_parts = P;
-
-    YH_TRY(yh_dmalloc(db, (void**)&db->d_sbounds, (u64)(P + 1) * sizeof(u32)));
-    if (db->flags & YH_DB_PAIRWISE_ONLY) return YH_OK;  // `yacht train` handle: validated sizes + the index, no streaming layout
-    if (yh_use_delta_stream()) return YH_OK;  // the streaming layout is the hash-sorted delta stream (yh_build_index)
-    YH_TRY(yh_dmalloc(db, (void**)&db->d_pbeg, (u64)P * sizeof(u64)));
-    YH_TRY(yh_dmalloc(db, (void**)&db->d_pcnt, (u64)P * sizeof(u64)));
-    YH_TRY(yh_dmalloc(db, (void**)&db->d_poffs, (u64)P * (N + 1) * sizeof(u32)));
-
-    u32* d_split = nullptr;
-    const u64 split_bytes = std::max<u64>(N, 1) * (u64)(P + 1) * sizeof(u32);
-    YH_HIP(hipMalloc((void**)&d_split, split_bytes));
-    int rc = YH_OK;
-    std::vector<u64> h_pcnt(P), h_pbeg(P);
-    do {
-        if (N) {
-            k_split<<<grid_for(N * (u64)(P + 1), 256), 256, 0, st>>>(d_values, d_offsets, N, P, pshift, d_split);
-        }
-        k_part_scan<<<P, 1024, 0, st>>>(d_split, N, P, db->d_poffs, db->d_pcnt, db->d_flag);
-        if (hipGetLastError() != hipSuccess) { yh_set_error("partition kernels failed to launch"); rc = YH_ERR_HIP; break; }
-        if (hipMemcpyAsync(h_pcnt.data(), db->d_pcnt, (u64)P * sizeof(u64), hipMemcpyDeviceToHost, st) != hipSuccess ||
-            hipMemcpyAsync(hflag, db->d_flag, 16, hipMemcpyDeviceToHost, st) != hipSuccess ||
-            hipStreamSynchronize(st) != hipSuccess) {
-            yh_set_error("partition scan failed: %s", hipGetErrorString(hipGetLastError()));
-            rc = YH_ERR_HIP;
-            break;
-        }
-        if (hflag[0] & 4u) { yh_set_error("a partition holds more than 2^32-1 hashes; raise partitions_hint"); rc = YH_ERR_INVALID_ARG; break; }
-        u64 pos = 0;
-        for (u32 p = 0; p < P; ++p) {
-            h_pbeg[p] = pos;
-            pos += h_pcnt[p];
-            pos = (pos + (KEY_BLOCK - 1)) & ~(u64)(KEY_BLOCK - 1);  // every partition starts on a key-block boundary
-        }
-        db->pvals_len = pos;
-        rc = yh_dmalloc(db, (void**)&db->d_pvals, std::max<u64>(pos, 2) * sizeof(u64));
-        if (rc != YH_OK) break;
-        if (hipMemsetAsync(db->d_pvals, 0, std::max<u64>(pos, 2) * sizeof(u64), st) != hipSuccess ||
-            hipMemcpyAsync(db->d_pbeg, h_pbeg.data(), (u64)P * sizeof(u64), hipMemcpyHostToDevice, st) != hipSuccess) {
-            yh_set_error("partition upload failed");
-            rc = YH_ERR_HIP;
-            break;
-        }
-        db->kshift = pshift > (u32)KEY_BITS ? pshift - KEY_BITS : 0;
-        const char* wide = getenv("YH_WIDE_KEYS");
-        if (!(wide && wide[0] == '1')) {
-            const u64 key_bytes = (pos / KEY_BLOCK) * KEY_BLOCK_BYTES + 256;
-            rc = yh_dmalloc(db, (void**)&db->d_pkeys, key_bytes);
-            if (rc == YH_OK) rc = yh_dmalloc(db, (void**)&db->d_pref, (pos + 8) * sizeof(u32));
-            if (rc != YH_OK) break;
-            if (hipMemsetAsync(db->d_pkeys, 0, key_bytes, st) != hipSuccess ||
-                hipMemsetAsync(db->d_pref, 0, (pos + 8) * sizeof(u32), st) != hipSuccess) { yh_set_error("memset failed"); rc = YH_ERR_HIP; break; }
-        }
-        if (N) {
-            k_scatter<<<grid_for(N * WAVE, 256), 256, 0, st>>>(d_values, d_offsets, N, P, pshift, d_split, db->d_pbeg,
-                                                               db->d_poffs, db->d_pvals, db->kshift, db->d_pkeys, db->d_pref);
-        }
-        if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) {
-            yh_set_error("partition scatter failed");
-            rc = YH_ERR_HIP;
-            break;
-        }
-    } while (0);
-    (void)hipFree(d_split);
-    return rc;
-}
-
-bool yh_use_delta_stream() {
-    static const bool on = [] {
-        // default: the hash-sorted delta stream.  YH_STREAM=keys: partition-major packed 24-bit keys;
-        // YH_WIDE_KEYS=1: partition-major 64-bit hashes (both kept for A/B and as cross-checks)
-        const char* s = getenv("YH_STREAM");
-        const char* w = getenv("YH_WIDE_KEYS");
-        return !(s && strcmp(s, "keys") == 0) && !(w && w[0] == '1');
-    }();
-    return on;
+    return YH_OK;
 }
 
 // The hash-sorted delta stream from the sorted (hash, reference) pairs (layout: yh_common.h).
@@ -725,17 +507,13 @@ static int build_stream(yh_db* db, const u64* d_sk, const u32* d_sv, const u32* 
 }
 
 // =================================================================================================
-int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, const u32* d_pair_ids) {
+int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets) {
     const u64 N = db->n_refs;
     const u64 H = db->n_hashes;
     hipStream_t st = db->stream;
 
     YH_TRY(yh_dmalloc(db, (void**)&db->d_nshared, std::max<u64>(N, 1) * sizeof(u32)));
     YH_HIP(hipMemsetAsync(db->d_nshared, 0, std::max<u64>(N, 1) * sizeof(u32), st));
-    YH_TRY(yh_dmalloc(db, (void**)&db->d_gbeg, (u64)db->n_parts * sizeof(u64)));
-    YH_TRY(yh_dmalloc(db, (void**)&db->d_gcnt, (u64)db->n_parts * sizeof(u64)));
-    YH_HIP(hipMemsetAsync(db->d_gbeg, 0, (u64)db->n_parts * sizeof(u64), st));
-    YH_HIP(hipMemsetAsync(db->d_gcnt, 0, (u64)db->n_parts * sizeof(u64), st));
 
     db->n_distinct = 0;
     db->n_shared = 0;
@@ -745,7 +523,7 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, const u
         YH_HIP(hipMemsetAsync(db->d_po, 0, sizeof(u64), st));
         db->has_index = !(db->flags & YH_DB_NO_INDEX);
         // (an empty database answers the sample-driven queries too: nothing is ever found)
-        db->has_dir = db->has_index && !d_pair_ids && !(db->flags & (YH_DB_NO_DIRECTORY | YH_DB_PAIRWISE_ONLY));
+        db->has_dir = db->has_index && !(db->flags & (YH_DB_NO_DIRECTORY | YH_DB_PAIRWISE_ONLY));
         return YH_OK;
     }
     if (H > 0xfffffff0ull * 2) {
@@ -766,14 +544,14 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, const u
             rc = (e__ == hipErrorOutOfMemory) ? YH_ERR_OOM : YH_ERR_HIP;                      \
         }                                                                                     \
     }
-    if (!d_pair_ids) IDX_HIP(hipMalloc((void**)&d_ids, H * sizeof(u32)));
+    IDX_HIP(hipMalloc((void**)&d_ids, H * sizeof(u32)));
     IDX_HIP(hipMalloc((void**)&d_sv, H * sizeof(u32)));
     IDX_HIP(hipMalloc((void**)&d_sk, H * sizeof(u64)));
     IDX_HIP(hipMalloc((void**)&d_counts, nb * 3 * sizeof(u32)));
     IDX_HIP(hipMalloc((void**)&d_bases, (nb + 1) * 3 * sizeof(u64)));
     if (rc == YH_OK) {
-        if (!d_pair_ids) k_fill_ref_ids<<<grid_for(N * WAVE, 256), 256, 0, st>>>(d_offsets, N, d_ids);
-        const u32* ids_src = d_pair_ids ? d_pair_ids : d_ids;
+        k_fill_ref_ids<<<grid_for(N * WAVE, 256), 256, 0, st>>>(d_offsets, N, d_ids);
+        const u32* ids_src = d_ids;
         // stable LSD radix sort of (hash, reference id): equal hashes keep their input order
         // (ascending reference for CSR input)
         unsigned end_bit = 1;
@@ -789,7 +567,7 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, const u
         (void)hipFree(d_tmp); d_tmp = nullptr;
         (void)hipFree(d_ids); d_ids = nullptr;
     }
-    const bool want_stream = !d_pair_ids && yh_use_delta_stream() && !(db->flags & YH_DB_PAIRWISE_ONLY);
+    const bool want_stream = !(db->flags & YH_DB_PAIRWISE_ONLY);
     if (rc == YH_OK && (db->flags & YH_DB_NO_INDEX)) {  // overlap-only handle: the stream and nothing else
         if (want_stream) rc = build_stream(db, d_sk, d_sv, nullptr, H);
         (void)hipFree(d_ids);
@@ -829,8 +607,8 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, const u
         IDX_HIP(hipMemsetAsync(db->d_g, 0, std::max<u64>(db->n_shared, 2) * sizeof(u64), st));
         // The bucket table over the distinct hashes (sample-driven lookups) is part of every handle that
         // answers sample queries, unless YH_DB_NO_DIRECTORY / YH_NO_DIRECTORY=1 opts out.
-        static const bool dir_env_off = [] { const char* e = getenv("YH_NO_DIRECTORY"); return e && e[0] == '1'; }();
-        const bool full = !d_pair_ids && !(db->flags & (YH_DB_NO_DIRECTORY | YH_DB_PAIRWISE_ONLY)) && !dir_env_off && db->n_distinct > 0;
+        static const bool dir_env_off = [] { const char* e = yh_tune_env("YH_NO_DIRECTORY"); return e && e[0] == '1'; }();
+        const bool full = !(db->flags & (YH_DB_NO_DIRECTORY | YH_DB_PAIRWISE_ONLY)) && !dir_env_off && db->n_distinct > 0;
         unsigned bits = 1;
         while (bits < 64 && (db->max_hash >> bits) != 0) ++bits;
         // compact form: ~2.5 distinct hashes per bucket, and a bucket must span less than 2^32 hash values
@@ -844,7 +622,7 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, const u
             return (u64)std::min<unsigned __int128>(m, ~(u64)0);
         };
         const u64 mul_c = mul_for(nb_c);
-        static const bool wide_env = [] { const char* e = getenv("YH_WIDE_BUCKETS"); return e && e[0] == '1'; }();
+        static const bool wide_env = [] { const char* e = yh_tune_env("YH_WIDE_BUCKETS"); return e && e[0] == '1'; }();
         // a bucket spans ceil(2^bits / mul) hash values: the low 32 bits identify a hash inside it iff that is <= 2^32
         const bool compact = full && !wide_env && nb_c <= 0xfffffff0ull && mul_c > 0 &&
                              (bits <= 32 || (((unsigned __int128)1 << bits) + mul_c - 1) / mul_c <= ((unsigned __int128)1 << 32));
@@ -868,7 +646,7 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, const u
                 if (rc == YH_OK) rc = yh_dmalloc(db, (void**)&db->d_dh, std::max<u64>(db->n_distinct, 2) * sizeof(u64));
                 if (rc == YH_OK) rc = yh_dmalloc(db, (void**)&db->d_dref, std::max<u64>(db->n_distinct, 2) * sizeof(u32));
                 if (rc == YH_OK) rc = yh_dmalloc(db, (void**)&db->d_dir, ((u64)db->dir_nb + 2) * sizeof(u32));
-                const char* nob = getenv("YH_NO_BUCKETS");
+                const char* nob = yh_tune_env("YH_NO_BUCKETS");
                 if (rc == YH_OK && !(nob && nob[0] == '1')) {
                     db->bkt_nb = (db->n_distinct + 1) / 2;
                     db->bkt_mul = std::max<u64>(mul_for(db->bkt_nb), 1);
@@ -916,10 +694,10 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, const u
             // Presence filter in front of the buckets (k_index_lookup_tile): one bit per 1 / YH_FILTER_BPH of a hash's
             // share of the range, indexed monotonically like the buckets, so that a sorted sample walks it front to back.
             // A sample hash whose bit is clear is not in the database and its bucket is never read.
-            static const u32 fbph = [] { const char* e = getenv("YH_FILTER_BPH"); return e ? (u32)atoi(e) : 4u; }();
+            static const u32 fbph = [] { const char* e = yh_tune_env("YH_FILTER_BPH"); return e ? (u32)atoi(e) : 4u; }();
             // (below ~10^6 distinct hashes the whole table is cache resident and the filter only adds a dependent read;
             // YH_FILTER_MIN lowers the bar for tests)
-            static const u64 fmin = [] { const char* e = getenv("YH_FILTER_MIN"); return e ? (u64)atoll(e) : (u64)(1u << 20); }();
+            static const u64 fmin = [] { const char* e = yh_tune_env("YH_FILTER_MIN"); return e ? (u64)atoll(e) : (u64)(1u << 20); }();
             if (rc == YH_OK && fbph && db->n_distinct >= fmin) {
                 const u64 fbits = ((db->n_distinct * fbph + 511) / 512) * 512;
                 db->filter_mul = mul_for(fbits);
@@ -942,11 +720,6 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, const u
         d_elem_g = nullptr;
         IDX_HIP(hipGetLastError());
         IDX_HIP(hipMemcpyAsync(db->d_po + db->n_shared, &db->n_postings, sizeof(u64), hipMemcpyHostToDevice, st));
-        if (db->n_shared && db->d_pkeys && rc == YH_OK) {
-            rc = yh_dmalloc(db, (void**)&db->d_gkeys, (db->n_shared + 8) * sizeof(u32));
-            if (rc == YH_OK)
-                k_make_keys<<<grid_for(db->n_shared, 256), 256, 0, st>>>(db->d_g, db->n_shared, db->kshift, db->d_gkeys);
-        }
         if (rc == YH_OK && db->n_postings && N && !(db->flags & YH_DB_PAIRWISE_ONLY)) {
             u32 *d_cc = nullptr, *d_cpo = nullptr, *d_cur = nullptr;
             void* d_st = nullptr;
@@ -1030,11 +803,6 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, const u
             (void)hipFree(d_cpo);
             (void)hipFree(d_cur);
             (void)hipFree(d_st);
-        }
-        if (db->n_shared) {
-            k_bounds_u64<<<(db->n_parts + 255) / 256, 256, 0, st>>>(db->d_g, db->n_shared, db->n_parts, db->pshift,
-                                                                    db->d_gbeg, db->d_gcnt);
-            IDX_HIP(hipGetLastError());
         }
         IDX_HIP(hipStreamSynchronize(st));
     }

@@ -35,77 +35,13 @@ void yh_set_error(const char* fmt, ...);
         if (rc__ != YH_OK) return rc__; \
     } while (0)
 
-// ---- tile-lookup geometry (the roofline kernel, k_tile_lookup in yh_query.hip) -----------------
-// One workgroup stages one hash-range partition's slice of the SAMPLE in LDS:
-//   BM : 2^TILE_LGBM-bit membership bitmap              (32,768 B)
-//   S  : TILE_SLOTS uint64 sorted hashes + 2 sentinels  (32,768 B)
-//   E  : TILE_NB uint16 bucket directory                ( 8,192 B)
-// 73,728 B per workgroup -> two workgroups fit the CU's 160 KiB.
-// (the YH_* macros exist so tuning variants can be built side by side: build.py build_variant)
-#ifndef YH_TILE_SLOTS
-#define YH_TILE_SLOTS 4096
-#endif
-#ifndef YH_TILE_LGNB
-#define YH_TILE_LGNB 12
-#endif
-#ifndef YH_TILE_LGBM
-#define YH_TILE_LGBM 18
-#endif
-#ifndef YH_TILE_THREADS
-#define YH_TILE_THREADS 512
-#endif
-#ifndef YH_TILE_UNROLL
-#define YH_TILE_UNROLL 4
-#endif
-// the same for the 32-bit key kernel (4 keys per vector): 2 measured 3-5 % faster than 4, 1 slower
-#ifndef YH_TILE_UNROLL32
-#define YH_TILE_UNROLL32 2
-#endif
-#ifndef YH_TILE_WAVES_PER_SIMD
-#define YH_TILE_WAVES_PER_SIMD 4
-#endif
-// mean sketch size / YH_PIECE_TARGET = number of hash-range partitions aimed for at build time
-// (2 -> P = 1049 at rs214 scale: ~950 sample hashes per tile; measured K1 0.182 ms against 0.192 ms
-// at 4 / P = 525 and 0.253 ms at 8 / P = 263: fewer sample keys per tile = fewer candidates)
-#ifndef YH_PIECE_TARGET
-#define YH_PIECE_TARGET 2
-#endif
-constexpr int TILE_SLOTS = YH_TILE_SLOTS;
-constexpr int TILE_CAP = TILE_SLOTS - 2;  // sample hashes per tile
-constexpr int TILE_LGNB = YH_TILE_LGNB;
-constexpr int TILE_NB = 1 << TILE_LGNB;
-constexpr int TILE_LGBM = YH_TILE_LGBM;
-constexpr int TILE_BM_WORDS = (1 << TILE_LGBM) / 32;
-constexpr int TILE_THREADS = YH_TILE_THREADS;
-constexpr int TILE_UNROLL = YH_TILE_UNROLL;  // 16-byte vectors in flight per lane
-static_assert(TILE_SLOTS <= 65536, "directory entries are uint16 slot numbers");
-// hits parked in LDS until the next tile switch (8 B each); 960 keeps two workgroups per CU
-#ifndef YH_TILE_QCAP
-#define YH_TILE_QCAP 960
-#endif
-constexpr int TILE_QCAP = YH_TILE_QCAP;
-static_assert(TILE_UNROLL * 2 <= 32, "candidate masks are 32-bit");
-// The key stream K1 reads: KEY_BITS-bit keys, bit-packed, in blocks of KEY_BLOCK keys laid out so
-// that a wave reads one block with three fully coalesced 16-byte loads per lane:
-//   lane l holds keys 16l .. 16l+15 of the block = 48 bytes = pieces 0..2,
-//   piece u of lane l lives at byte  block*3072 + (u*64 + l)*16.
-// Partitions start on block boundaries (pvals / pref use the same, unswizzled, positions).
-constexpr int KEY_BITS = 24;
-constexpr u32 KEY_MASK = (1u << KEY_BITS) - 1u;
-constexpr int KEY_BLOCK = 1024;
-constexpr int KEY_BLOCK_BYTES = KEY_BLOCK * KEY_BITS / 8;  // 3072
-#if defined(__HIPCC__)
-__host__ __device__ inline u64 yh_key_byte_addr(u64 pos, u32 byte_of_key) {
-    const u64 blk = pos >> 10;
-    const u32 within = (u32)(pos & 1023u), lane = within >> 4, k = within & 15u;
-    const u32 j = 3u * k + byte_of_key;  // byte inside the lane's 48
-    return blk * (u64)KEY_BLOCK_BYTES + ((u64)(j >> 4) * 64u + lane) * 16u + (j & 15u);
-}
-#endif
+// Tuning switches (YH_FILTER_BPH, YH_INDEX_TILE, YH_TIMING_EVERY, ...) are read from the environment only when
+// YH_DEBUG_TUNING=1: one gate, so that a production process never changes behaviour because of a stray variable.
+// Returns the variable's value, or nullptr (gate closed or variable unset).
+const char* yh_tune_env(const char* name);
+
 constexpr int STREAM_BLOCK = 1024;          // elements per block of the delta stream = 16 per lane
 constexpr u32 STREAM_NONE = 0xffffffffu;
-constexpr int TILE_UNROLL32 = YH_TILE_UNROLL32;
-static_assert(TILE_UNROLL32 * 4 <= 32, "candidate masks are 32-bit");
 
 // postings per work record of the reference-major exclusive pass (k_excl_pieces: one wave per record)
 #ifndef YH_EXCL_PIECE
@@ -137,9 +73,7 @@ struct RunSlot {
     u32* d_bad = nullptr;     // [1] set by the ordering check queued in front of the kernels
     u32* h_bad = nullptr;     // page-locked host word the check kernel also writes (zero-copy), read by yh_run_wait
     u32* h_bad_dev = nullptr; // its device address
-    hipEvent_t ev_up = nullptr, ev_done = nullptr, ev_out = nullptr;
-    void* out_host = nullptr;  // the last [3][N] host block of this slot and its device view (null: pageable)
-    void* out_dev = nullptr;
+    hipEvent_t ev_up = nullptr, ev_out = nullptr;
     bool busy = false;
 };
 
@@ -153,20 +87,12 @@ struct yh_db {
     u64 n_refs = 0;
     u64 n_hashes = 0;
     u64 max_hash = 0;
-    u32 n_parts = 1;
-    u32 pshift = 0;
     u64 device_bytes = 0;
 
     // plain CSR (only with YH_DB_KEEP_CSR)
     u64* d_values = nullptr;
     u64* d_offsets = nullptr;
 
-    // partitioned CSR: partition-major, reference-major inside a partition
-    u64* d_pvals = nullptr;  // [pvals_len]
-    u64 pvals_len = 0;
-    u64* d_pbeg = nullptr;   // [P]   first element of partition p in d_pvals (even)
-    u64* d_pcnt = nullptr;   // [P]   element count of partition p
-    u32* d_poffs = nullptr;  // [P*(N+1)] start of reference j inside partition p (relative)
     u32* d_sizes = nullptr;  // [N]   |R_j|
 
     // shared-hash inverted index (hashes present in >= 2 references)
@@ -178,8 +104,6 @@ struct yh_db {
     u64* d_po = nullptr;     // [G+1] posting-list offsets
     u32* d_pr = nullptr;     // [postings] reference ids, ascending inside a list
     u32* d_pg = nullptr;     // [postings] index of the hash each posting belongs to
-    u64* d_gbeg = nullptr;   // [P]   first shared hash of partition p in d_g
-    u64* d_gcnt = nullptr;   // [P]
     u32* d_nshared = nullptr;  // [N] number of shared hashes in reference j
 
     // full distinct-hash directory (only with YH_DB_FULL_INDEX): the sample-driven overlap path
@@ -210,8 +134,6 @@ struct yh_db {
     u32* d_hpo = nullptr;      // [N + 1]
     u32 n_sets = 0;
     u32 n_chunks = 0;
-    bool posting_only = false;        // yh_db_create_from_pairs: posting lists of a hash range, no sketches
-    bool excl_prefer_stream = false;  // set by the host-mask entry point when most references are masked
     // hash-sorted delta stream (the default layout; DESIGN.md "K1"): every (hash, reference)
     // pair of the database in ascending hash order, the hash truncated to t = hash >> sshift so that
     // consecutive t differ by ~50 on average, one BYTE per element = t minus its predecessor's t.
@@ -225,10 +147,6 @@ struct yh_db {
     u32 sshift = 0;
     u64* d_wg_key = nullptr;   // [wgs + 1] first t of each workgroup's block range (sample-independent)
     u32 wg_key_n = 0;
-    u32* d_pkeys = nullptr;    // packed KEY_BITS-bit keys of d_pvals, (hash >> kshift) & KEY_MASK: the stream K1 reads
-    u32* d_pref = nullptr;     // [pvals_len] reference id of every stream position
-    u32* d_gkeys = nullptr;    // [n_shared] the same keys of d_g, one per 32-bit word
-    u32 kshift = 0;            // pshift - KEY_BITS when pshift > KEY_BITS, else 0 (keys then carry every in-partition bit)
     uint4* d_bkt = nullptr;    // [bkt_nb] 64-byte buckets over the distinct hashes (YhDirView below)
     u64 bkt_nb = 0;
     u32 bkt_lsh = 0;
@@ -240,11 +158,10 @@ struct yh_db {
     u64* d_ovf_keys = nullptr; // [ovf_mask + 1] open-addressing table of the hashes that did not fit their bucket
     u32* d_ovf_vals = nullptr; //                 their dref words (YH_DIR_NONE = empty slot)
     u32 ovf_mask = 0;
-    u32* d_pq = nullptr;       // [postings] queue of postings that belong to masked references (per query)
+    u32* d_pq = nullptr;       // [postings] queue of postings that belong to masked references (batched run)
     u32* d_pq_count = nullptr; // [EXCL_QBLOCKS] fill of each workgroup's queue segment
 
     // per-query scratch (allocated once)
-    u32* d_sbounds = nullptr;  // [P+1] sample slice bounds per partition
     u8* d_mask = nullptr;      // [N]
     u32* d_maskbits = nullptr; // [ceil(N/64)*2] the same mask as bits
     u8* d_hit = nullptr;       // [G]
@@ -258,10 +175,6 @@ struct yh_db {
     u64 sample_tmp_cap = 0;
     u32* d_flag = nullptr;     // [1] generic error/flag word
     u32* d_bad_word = nullptr; // [1] deferred ordering verdict of yh_run (see bad_gen)
-    u64* d_hitq = nullptr;     // [hitq_wgs][hitq_cap] deferred overlap hits (partition << 32 | position)
-    u32* d_hitq_cnt = nullptr; // [hitq_wgs]
-    u32 hitq_wgs = 0, hitq_cap = 0;
-    u32* d_wg_first = nullptr; // [hitq_wgs] first partition of each workgroup's slice of the key stream
     u32* d_reps = nullptr;     // [R][N] replicated overlap counters; ZERO AT REST: k_reduce_replicas clears what it sums
     u64 reps_cap = 0;
     void* d_batch = nullptr;   // scratch of the batched run: hit words, mask words, shared overlaps
@@ -283,6 +196,8 @@ struct yh_db {
     uint4* ctx_work[YH_RUN_CONTEXTS] = {};
     u32* ctx_count[YH_RUN_CONTEXTS] = {};
     int ctx_now = 0;
+    bool ctx_open[YH_RUN_CONTEXTS] = {};       // yh_run_local_device queued, yh_run_finish_device not yet
+    bool ctx_clobbered[YH_RUN_CONTEXTS] = {};  // another query ran in the context's place meanwhile: its work list is gone
 
     // sharded run (yh_db_set_ghosts): references [ghost_begin, ghost_begin + n_ghost) are copies of other
     // ranks' references; their subset bits come from the owners (k_ghost_bits)
@@ -291,7 +206,7 @@ struct yh_db {
 
     // pipelined host-buffer calls
     RunSlot slots[YH_RUN_SLOTS];
-    hipStream_t st_in = nullptr, st_out = nullptr;  // copy streams beside `stream`
+    hipStream_t st_in = nullptr;  // the upload stream beside `stream`
     const u32* d_bad = nullptr;  // non-null while the kernels of a call with a deferred ordering verdict are being queued:
     u32 bad_gen = 0;             // the check kernel in front of them stores bad_gen there when the sample is not ascending
                                  // (generations are unique per handle, so the word never has to be cleared)
@@ -302,11 +217,8 @@ struct yh_db {
 };
 
 // ---- implemented in yh_build.hip -------------------------------------------------------------
-int yh_build_partitions(yh_db* db, const u64* d_values, const u64* d_offsets, u32 parts_hint);
-// d_pair_ids == nullptr: reference ids come from d_offsets (CSR); otherwise (d_values[i], d_pair_ids[i]) are
-// ready-made (hash, reference) pairs and d_offsets is unused.
-int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, const u32* d_pair_ids);
-bool yh_use_delta_stream();  // YH_STREAM=delta at handle creation (default: partition-major packed 24-bit keys)
+int yh_build_validate(yh_db* db, const u64* d_values, const u64* d_offsets);  // ordering check, sizes, largest hash
+int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets);
 
 // ---- implemented in yh_query.hip -------------------------------------------------------------
 int yh_q_overlap(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap, bool flag_shared, bool make_mask);
@@ -446,12 +358,7 @@ int yh_q_overlap_indexed(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_ov
 int yh_q_run_batch(yh_db* db, const u64* d_samples, const u64* d_soff, u32 n_samples, u64 total_hashes,
                    u32* d_overlap, u32* d_excl, u32* d_match);
 int yh_q_exclusive(yh_db* db, const u8* d_mask, const u64* d_sample, u64 n_sample,
-                   const u32* d_overlap, u32* d_excl, u32* d_match, bool hit_ready, const u32* d_maskbits);
-int yh_q_exclusive_partial(yh_db* db, const u8* d_mask, const u64* d_sample, u64 n_sample, u32* d_ex_e, u32* d_ex_m,
-                           u32* d_ovsh, bool own_bounds, bool hit_ready, const u32* d_maskbits);
-int yh_q_exclusive_final(yh_db* db, u64 n, const u8* d_mask, const u32* d_sizes, const u32* d_nshared,
-                         const u32* d_overlap, const u32* d_ex_e, const u32* d_ex_m, const u32* d_ovsh, u32* d_excl,
-                         u32* d_match, bool clean_hit = false);
+                   const u32* d_overlap, u32* d_excl, u32* d_match, const u32* d_maskbits);
 int yh_q_pairwise(yh_db* db, double c_thresh, u64 r0, u64 r1);
 int yh_q_check_sorted_host(const u64* v, u64 n);
 

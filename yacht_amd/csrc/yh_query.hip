@@ -1,33 +1,23 @@
 // yh_query.hip — the per-query kernels of libyacht_hip.so (gfx950 / CDNA4, wave64).
 //
-//   k_stream_lookup      the streaming membership kernel of the default layout (DESIGN.md "K1"): all
-//                        (hash, reference) pairs in hash order, one delta byte each; a workgroup stages
-//                        the sample hashes of its key range in LDS, rebuilds the lanes' key spans of
-//                        16-block super-blocks (v_sad_u8 + DPP scans) and lets the sample keys probe
-//                        them, one per lane; candidates are confirmed against the 64-bit hash of
-//                        their position in the same kernel and summed per reference in LDS
-//   k_prep, k_tile_lookup_keys, k_resolve_hits32
-//                        the partition-major packed 24-bit key layout (YH_STREAM=keys): sample slice
-//                        bounds per partition; every stream key tested against a Bloom filter of the
-//                        sample slice in LDS; candidates confirmed and counted by a second kernel
-//   k_reduce_replicas    overlap counts from the replicated counters, which it clears (zero at rest);
-//                        + the subset mask as bytes and bits, + zeroed exclusive accumulators
-//   k_tile_lookup<Hit>   the same tile kernel over the 64-bit hashes (YH_WIDE_KEYS=1, and the
-//                        stand-alone shared-hash membership pass of posting-only handles)
-//   k_index_lookup       sample-driven alternative (YH_DB_FULL_INDEX): one lane per sample hash
-//                        through the 64-byte bucket table / distinct-hash directory
-//   k_batch_*            up to 64 samples per pass through the same directory; exclusivity for all
-//                        samples at once by bit-sliced counting over 64-bit sample masks
-//   k_overlap_bsearch    one wave per reference, lanes binary-search the sample in L2: independent
-//                        cross-check and A/B baseline
-//   k_excl_chunks        subset-exclusive hash counts from the reference-major chunk view of the
-//   k_excl_collect/apply shared-hash posting lists (or from a pass over all postings), k_excl_final
-//                        (the arithmetic of hypothesis_recovery_src.py:165-204)
-//   k_pair_*             pairwise intersection counts from the posting lists into a dense row block,
-//                        threshold filter and ordered compaction (src/cpp/main.cpp:249-308)
-//
-// Timing-only ablation builds (-DYH_ABLATE=1|2|3, see build.py build_variant) compile parts of
-// the 64-bit k_tile_lookup out; their results are wrong by construction and they are never shipped.
+//   k_index_lookup_tile  the sample-driven lookup (default): one lane per SAMPLE hash -- presence bit, then one
+//                        64-byte bucket of the table over the database's distinct hashes -- hits summed per
+//                        reference in an LDS table, one global atomic per (workgroup, reference)
+//   k_stream_lookup      the streaming lookup (databases small against the sample): all (hash, reference) pairs
+//                        in hash order, one delta byte each; a workgroup stages the sample hashes of its key range
+//                        in LDS, rebuilds the lanes' key spans of 16-block super-blocks (v_sad_u8 + DPP scans) and
+//                        lets the sample keys probe them; candidates are confirmed against the full hash
+//   k_reduce_replicas    overlap counts from the replicated counters, which it clears (zero at rest); the subset
+//                        "overlap > 0" as bits; in the run step also n_match, the singleton part of n_excl and the
+//                        work list of the exclusive pass
+//   k_excl_pieces        subset-exclusive hash counts, one wave per work record: over a reference's DISTINCT holder
+//                        sets (run step) or its postings with hit flags (arbitrary subsets); k_excl_worklist,
+//                        k_excl_final (the arithmetic of hypothesis_recovery_src.py:165-204)
+//   k_batch_*            up to 64 samples per pass through the same bucket table; exclusivity for all samples at
+//                        once by bit-sliced counting over 64-bit sample masks (k_excl_collect gathers the postings)
+//   k_overlap_bsearch    one wave per reference, lanes binary-search the sample: the independent cross-check
+//   k_pair_*             pairwise intersection counts from the posting lists into a dense row block, threshold
+//                        filter and ordered compaction (src/cpp/main.cpp:249-308)
 #include "yh_common.h"
 
 #include <stdlib.h>
@@ -70,7 +60,7 @@ __device__ __forceinline__ void count_add(u32* p, u32 v) {
 }
 // the presence filter a lookup may read in front of the compact buckets (null: none, or YH_NO_FILTER=1)
 static const u32* yh_filter_of(const yh_db* db) {
-    static const bool filter_off = [] { const char* e = getenv("YH_NO_FILTER"); return e && e[0] == '1'; }();
+    static const bool filter_off = [] { const char* e = yh_tune_env("YH_NO_FILTER"); return e && e[0] == '1'; }();
     return (db->d_cbkt && db->d_filter && db->filter_mul && !filter_off) ? db->d_filter : nullptr;
 }
 __device__ __forceinline__ u32 replica_of(u32 wg, u32 rep_mask) {
@@ -79,79 +69,6 @@ __device__ __forceinline__ u32 replica_of(u32 wg, u32 rep_mask) {
 #else
     return wg & rep_mask;
 #endif
-}
-
-// ---- hit handlers -------------------------------------------------------------------------------
-// A hit is reported as (partition, position relative to the partition's first element).
-// Resolving a position to its reference is a 17-step dependent search through L2 (~3 us) during
-// which the rest of the wave idles, and even a single global store per hit delays the wave's next
-// `s_waitcnt vmcnt(0)` by a memory round trip.  So the streaming kernel only appends the hit to a
-// small queue in LDS; the queue is copied to the workgroup's segment of a queue in HBM at tile
-// switches and at the end, and k_resolve_hits turns that queue into counts with every lane busy.
-// Counts go to R replicas (workgroup id mod R) that k_reduce_replicas sums: a present genome
-// collects hundreds of hits and same-address atomics serialize in L2.  A hit is resolved in place
-// only when a queue overflows (samples made almost entirely of database hashes).
-struct HitCtx {
-    u32* q_fill;  // LDS: entries in the workgroup's LDS queue
-    u64* q;       // LDS queue
-    u32 wg;       // logical workgroup id
-};
-
-__device__ __forceinline__ u32 resolve_ref(const u32* __restrict__ po, u32 n_refs, u32 rel) {
-    u32 lo = 0, hi = n_refs;  // first j with po[j+1] > rel
-    while (lo < hi) {
-        const u32 mid = (lo + hi) >> 1;
-        if (po[mid + 1] <= rel) lo = mid + 1; else hi = mid;
-    }
-    return lo;
-}
-
-struct OverlapHit {
-    static constexpr bool kQueued = true;
-    const u32* poffs;  // [P][N+1]
-    u32 n_refs;
-    u32* reps;         // [R][N] replicated counters
-    u32 rep_mask;      // R - 1 (R a power of two)
-    u64* queue;        // [wgs][qcap]  (partition << 32 | rel)
-    u32 qcap;
-    __device__ __forceinline__ void count(u32 wg, u32 p, u32 rel) const {
-        const u32 j = resolve_ref(poffs + (u64)p * (n_refs + 1), n_refs, rel);
-        atomicAdd(&reps[(u64)(wg & rep_mask) * n_refs + j], 1u);
-    }
-    __device__ __forceinline__ void operator()(const HitCtx& c, u32 p, u64 rel) const {
-        const u32 slot = atomicAdd(c.q_fill, 1u);
-        if (slot < (u32)TILE_QCAP) c.q[slot] = ((u64)p << 32) | (u64)(u32)rel;
-        else count(c.wg, p, (u32)rel);
-    }
-};
-struct FlagHit {
-    static constexpr bool kQueued = false;
-    const u64* gbeg;  // [P]
-    u8* hit;          // [G]
-    __device__ __forceinline__ void operator()(const HitCtx&, u32 p, u64 rel) const { hit[gbeg[p] + rel] = 1; }
-    __device__ __forceinline__ void count(u32, u32, u32) const {}
-};
-
-// Optional second stream of the tile kernel: the database-shared hashes `g` (grouped by the same
-// partitions).  A workgroup that has partition p's tile staged also tests its proportional share
-// of g's partition-p slice and flags the members (`hit[]`, read by the exclusive-count kernels):
-// no extra launch and no extra tile set-ups for R2's membership pass.
-struct SideStream {
-    const u64* g;     // nullptr: no side stream
-    const u64* gbeg;  // [P]
-    const u64* gcnt;  // [P]
-    u8* hit;          // [G]
-};
-
-// one workgroup per queue segment: position -> reference -> replicated count
-__global__ void __launch_bounds__(256) k_resolve_hits(const u32* __restrict__ qcount, OverlapHit hit) {
-    const u32 wg = blockIdx.x;
-    const u32 cnt = qcount[wg];
-    const u64* q = hit.queue + (u64)wg * hit.qcap;
-    for (u32 e = threadIdx.x; e < cnt; e += blockDim.x) {
-        const u64 x = q[e];
-        hit.count(wg, (u32)(x >> 32), (u32)x);
-    }
 }
 
 // overlap[j] = sum of the replicas, which are CLEARED as they are read (d_reps is zero at rest: no
@@ -291,656 +208,7 @@ __global__ void __launch_bounds__(256) k_mask_bits(const u8* __restrict__ mask, 
     }
 }
 
-// One launch in front of the streaming kernel: the sample's slice bounds per partition, and the
-// zeroing of every buffer the step accumulates into (instead of one fill kernel per buffer).
-struct ZeroList {
-    uint4* p[4];
-    u64 n16[4];  // 16-byte units
-};
-__global__ void __launch_bounds__(256) k_prep(const u64* __restrict__ sample, u32 n, u32 P, u32 pshift,
-                                              u32* __restrict__ sb, ZeroList z) {
-    const u64 t = blockIdx.x * (u64)blockDim.x + threadIdx.x;
-    const u64 nt = (u64)gridDim.x * blockDim.x;
-    if (t <= P) {
-        const u32 p = (u32)t;
-        const bool wraps = (pshift > 0) && (((u64)p >> (64 - pshift)) != 0);  // p << pshift >= 2^64
-        u32 r;
-        if (p == 0) r = 0;
-        else if (wraps) r = n;
-        else {
-            const u64 key = (u64)p << pshift;
-            u32 lo = 0, hi = n;
-            while (lo < hi) {
-                const u32 mid = (lo + hi) >> 1;
-                if (sample[mid] < key) lo = mid + 1; else hi = mid;
-            }
-            r = lo;
-        }
-        sb[p] = r;
-    }
-#pragma unroll
-    for (int b = 0; b < 4; ++b)
-        for (u64 i = t; i < z.n16[b]; i += nt) z.p[b][i] = make_uint4(0, 0, 0, 0);
-}
-
-// ---- K1: streaming tile lookup -------------------------------------------------------------------
-// The hash stream `vals` is grouped by hash-range partition.  The grid is sized to the machine
-// (two resident workgroups per CU), every workgroup takes an equal contiguous slice [w0, w1) of
-// the whole stream and, for each partition that slice touches, stages that partition's slice of
-// the SAMPLE in LDS as three structures:
-//   BM : bitmap of 2^TILE_LGBM bits, bit (h mod 2^TILE_LGBM) set for every sample hash h
-//   S  : the sorted sample hashes of the partition + 2 sentinels (~0)
-//   E  : bucket directory, E[b] = first slot of S whose bucket is >= b
-// It then streams its reference hashes past them: 16-byte coalesced non-temporal loads, software
-// pipelined one batch ahead.  Every hash costs ONE LDS read (its bitmap word; all reads of a
-// batch in flight together).  With <= 4094 sample hashes per tile ~1.5 % of the misses survive
-// the bitmap; survivors and true members are then looked up exactly (directory -> slot -> next
-// slots) by the few lanes that hold one.  LDS 73,728 B -> two workgroups (16 waves) per CU.
-template <bool HI>
-__device__ __forceinline__ u32 bucket_of(u64 h, u32 bsh) {
-    // HI: the bucket bits lie entirely in the upper dword (bsh >= 32): one v_bfe_u32
-    if (HI) return ((u32)(h >> 32) >> (bsh - 32)) & (TILE_NB - 1);
-    return (u32)(h >> bsh) & (TILE_NB - 1);
-}
-__device__ __forceinline__ u32 bm_index(u64 h) { return (u32)h & ((1u << TILE_LGBM) - 1u); }
-
-template <bool HI, class Hit>
-__device__ __forceinline__ void tile_stream(const u64* __restrict__ vals, u64 start, u64 end, u64 e0, u32 p, u32 n,
-                                            u32 bsh, const u64* S, const u16* E, const u32* BM, const Hit& hit,
-                                            const HitCtx& ctx) {
-    constexpr int U = TILE_UNROLL;
-    constexpr int B = 2 * U;
-    const u32 tid = threadIdx.x;
-
-    // exact membership through the directory; reports a hit at stream position `pos`
-    auto lookup1 = [&](u64 h, u64 pos) {
-        u32 k = E[bucket_of<HI>(h, bsh)];
-        u64 v = S[k];
-        while (v < h) v = S[++k];  // sentinel ~0 stops the scan
-#if defined(YH_ABLATE) && YH_ABLATE == 3  // timing-only build: hits found but not recorded
-        if (v == h && k < n && pos == 0x7fffffffffffffffull) hit(ctx, p, pos - e0);
-        return;
-#endif
-        if (v == h && k < n) hit(ctx, p, pos - e0);
-    };
-
-    u64 i = start;
-    if (i & 1ull) {  // unaligned head (streams whose partitions are not padded to 16 bytes)
-        if (tid == 0) lookup1(vals[i], i);
-        ++i;
-    }
-    const u64 nvec = (end - i) >> 1;
-    if (nvec) {
-        const u64x2* __restrict__ vp = reinterpret_cast<const u64x2*>(vals + i);
-        const u64 last = nvec - 1;
-        u64x2 cur[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) cur[u] = __builtin_nontemporal_load(&vp[min((u64)tid + (u64)u * TILE_THREADS, last)]);
-        for (u64 v = tid; v < nvec; v += (u64)U * TILE_THREADS) {
-            // ---- prefetch the next batch (clamped indices: a few harmless re-reads at the very end)
-            u64x2 nxt[U];
-            const u64 vn = v + (u64)U * TILE_THREADS;
-#pragma unroll
-            for (int u = 0; u < U; ++u) nxt[u] = __builtin_nontemporal_load(&vp[min(vn + (u64)u * TILE_THREADS, last)]);
-
-            u64 h[B];
-            u32 valid = 0;
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                h[2 * u] = cur[u].x;
-                h[2 * u + 1] = cur[u].y;
-                if (v + (u64)u * TILE_THREADS < nvec) valid |= 3u << (2 * u);
-            }
-#if defined(YH_ABLATE) && YH_ABLATE == 1  // timing-only build: stream, no lookups (results are wrong)
-            {
-                u64 acc = 0;
-#pragma unroll
-                for (int b = 0; b < B; ++b) acc ^= h[b];
-                if (acc == 0x0123456789abcdefull && valid) hit(ctx, p, 0);
-#pragma unroll
-                for (int u = 0; u < U; ++u) cur[u] = nxt[u];
-                continue;
-            }
-#endif
-            // ---- one bitmap word per hash, all B reads in flight together
-            u32 w[B];
-#pragma unroll
-            for (int b = 0; b < B; ++b) w[b] = BM[bm_index(h[b]) >> 5];
-            u32 cand = 0;
-#pragma unroll
-            for (int b = 0; b < B; ++b) cand |= ((w[b] >> (bm_index(h[b]) & 31u)) & 1u) << b;
-            cand &= valid;
-#if defined(YH_ABLATE) && YH_ABLATE == 2  // timing-only build: bitmap only (results are wrong)
-            if (cand == 0xffffffffu) hit(ctx, p, 0);
-            cand = 0;
-#endif
-            // ---- rare: exact lookup of the candidates this lane holds (usually none or one)
-            while (cand) {
-                const u32 b = (u32)__ffs((int)cand) - 1u;
-                cand &= cand - 1u;
-                u64 hb = h[0];
-#pragma unroll
-                for (int j = 1; j < B; ++j) hb = (b == (u32)j) ? h[j] : hb;
-                const u64 pos = i + 2 * (v + (u64)(b >> 1) * TILE_THREADS) + (b & 1u);
-                lookup1(hb, pos);
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) cur[u] = nxt[u];
-        }
-    }
-    if (((end - i) & 1ull) && tid == 0) lookup1(vals[end - 1], end - 1);
-}
-
-template <class Hit>
-__global__ void __launch_bounds__(TILE_THREADS, YH_TILE_WAVES_PER_SIMD)
-k_tile_lookup(const u64* __restrict__ vals,     // hash stream, grouped by partition
-              const u64* __restrict__ pbeg,     // [P] first element of partition p (ascending)
-              const u64* __restrict__ pcnt,     // [P] elements in partition p
-              u32 P, u64 total_len,             // stream length including inter-partition padding
-              const u64* __restrict__ sample,   // sorted sample hashes
-              const u32* __restrict__ sbounds,  // [P+1] sample slice of partition p
-              u32 pshift, u32* __restrict__ qcount, Hit hit, SideStream side) {
-    __shared__ __attribute__((aligned(16))) u64 S[TILE_SLOTS];
-    __shared__ __attribute__((aligned(16))) u32 BM[TILE_BM_WORDS];
-    __shared__ u16 E[TILE_NB];
-    __shared__ u64 Q[Hit::kQueued ? TILE_QCAP : 1];  // hits waiting to be flushed to HBM
-    __shared__ u32 q_fill;                            // entries in Q (may exceed TILE_QCAP: overflow)
-    __shared__ u32 g_fill;                            // entries already flushed to this workgroup's segment
-
-    const u32 tid = threadIdx.x;
-    const u32 lid = xcd_remap(blockIdx.x, gridDim.x);
-    u64 per = (total_len + gridDim.x - 1) / gridDim.x;
-    per = (per + 1) & ~1ull;  // even: slices of an even-based stream stay 16-byte aligned
-    const u64 w0 = (u64)lid * per;
-    const u64 w1 = min(total_len, w0 + per);
-    const HitCtx ctx{&q_fill, Q, lid};
-    if (threadIdx.x == 0) { q_fill = 0; g_fill = 0; }  // visible to all after the first barrier
-    if (w0 >= w1) {
-        if (Hit::kQueued && threadIdx.x == 0) qcount[lid] = 0;
-        return;
-    }
-    // copy the LDS queue to this workgroup's HBM segment (entries past its capacity are resolved
-    // here); called by all threads, between streaming phases
-    auto flush = [&]() {
-        if (!Hit::kQueued) return;
-        __syncthreads();
-        const u32 f = min(q_fill, (u32)TILE_QCAP);
-        const u32 g0 = g_fill;
-        if constexpr (Hit::kQueued) {
-            for (u32 e = threadIdx.x; e < f; e += TILE_THREADS) {
-                const u64 x = Q[e];
-                if (g0 + e < hit.qcap) hit.queue[(u64)lid * hit.qcap + g0 + e] = x;
-                else hit.count(lid, (u32)(x >> 32), (u32)x);
-            }
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) { q_fill = 0; g_fill = g0 + f; }
-        __syncthreads();
-    };
-
-    // last partition that starts at or before w0
-    u32 p;
-    {
-        u32 lo = 0, hi = P;
-        while (lo < hi) {
-            const u32 mid = (lo + hi) >> 1;
-            if (pbeg[mid] <= w0) lo = mid + 1; else hi = mid;
-        }
-        p = lo ? lo - 1 : 0;
-    }
-    const u32 bsh = (pshift > (u32)TILE_LGNB) ? pshift - TILE_LGNB : 0u;
-    bool first = true;
-    for (; p < P; ++p) {
-        const u64 e0 = pbeg[p];
-        if (e0 >= w1) break;
-        const u64 start = max(w0, e0), end = min(w1, e0 + pcnt[p]);
-        if (start >= end) continue;
-        const u32 s0 = sbounds[p], s1 = sbounds[p + 1];
-        for (u32 sub = s0; sub < s1; sub += TILE_CAP) {
-            const u32 n = min((u32)TILE_CAP, s1 - sub);
-            if (!first) {
-                flush();          // drains the hit queue; its barriers also guarantee that the previous
-                __syncthreads();  // tile is fully consumed before it is overwritten
-            }
-            first = false;
-            // ---- clear the bitmap, stage the sample slice and its two sentinels
-            {
-                uint4* bm4 = reinterpret_cast<uint4*>(BM);
-                for (u32 k = tid; k < TILE_BM_WORDS / 4; k += TILE_THREADS) bm4[k] = make_uint4(0, 0, 0, 0);
-            }
-            for (u32 k = tid; k < n; k += TILE_THREADS) S[k] = sample[sub + k];
-            if (tid < 2) S[n + tid] = ~0ull;
-            __syncthreads();
-            // ---- bitmap bits and bucket directory (buckets are monotone in the hash inside one
-            // partition, so the slots of a bucket are contiguous)
-            for (u32 k = tid; k < n; k += TILE_THREADS) {
-                const u64 hk = S[k];
-                const u32 bi = bm_index(hk);
-                atomicOr(&BM[bi >> 5], 1u << (bi & 31u));
-                const u32 b = (u32)(hk >> bsh) & (TILE_NB - 1);
-                const int bp = (k == 0) ? -1 : (int)((u32)(S[k - 1] >> bsh) & (TILE_NB - 1));
-                for (int x = bp + 1; x <= (int)b; ++x) E[x] = (u16)k;
-                if (k == n - 1)
-                    for (u32 x = b + 1; x < (u32)TILE_NB; ++x) E[x] = (u16)n;
-            }
-            __syncthreads();
-            if (bsh >= 32) tile_stream<true>(vals, start, end, e0, p, n, bsh, S, E, BM, hit, ctx);
-            else tile_stream<false>(vals, start, end, e0, p, n, bsh, S, E, BM, hit, ctx);
-            if (side.g) {  // this workgroup's share of the shared hashes of partition p
-                const u64 cnt = pcnt[p], gc = side.gcnt[p], g0 = side.gbeg[p];
-                const u64 gs = g0 + gc * (start - e0) / cnt, ge = g0 + gc * (end - e0) / cnt;
-                if (gs < ge) {
-                    const FlagHit fh{side.gbeg, side.hit};
-                    if (bsh >= 32) tile_stream<true>(side.g, gs, ge, g0, p, n, bsh, S, E, BM, fh, ctx);
-                    else tile_stream<false>(side.g, gs, ge, g0, p, n, bsh, S, E, BM, fh, ctx);
-                }
-            }
-        }
-    }
-    flush();
-    if constexpr (Hit::kQueued) {
-        if (tid == 0) qcount[lid] = min(g_fill, hit.qcap);
-    }
-}
-
-// ---- K1 over packed keys ----------------------------------------------------------------------------
-// Inside a partition the bits above pshift are constant, so the stream only needs the KEY_BITS (24)
-// bits below them: key = (h >> kshift) & KEY_MASK, kshift = max(pshift, 24) - 24.  k_tile_lookup_keys
-// is the tile kernel over the packed key stream (d_pkeys): 3 bytes per reference hash instead of 8.
-// Keys order the hashes of a partition, so the tile structures work unchanged (S holds the sample's
-// keys); what a key cannot do when kshift > 0 is tell apart two hashes that differ only in their
-// low kshift bits.  So a key match is a CANDIDATE (at rs214 scale ~40 000 per launch are false,
-// against ~130 000 true hits): it is queued like a hit and k_resolve_hits32 confirms it against the
-// full 64-bit arrays (d_pvals / d_g, read at the queued positions only) and the sample before
-// counting.  (Confirming at the end of each workgroup instead of in a second launch was tried: the
-// step time stayed the same, the streaming kernel just absorbed the 20 us.)
-// The kernel is bound by HBM alone: running its filter stage twice per key changed its time by < 3 %
-// (timing-only build), which is why fewer bytes per key pay even at more instructions per key.
-//   * one wave reads a 1024-key block with three coalesced 16-byte loads per lane (layout:
-//     yh_common.h), the next block's loads in flight while this one is tested;
-//   * the bitmap is a blocked Bloom filter, two bits of one word per key (word from key bits 2..14,
-//     bits from 15..19 and 19..23): one LDS read per key, ~0.04 % of the misses survive it;
-//   * the side stream (shared hashes, d_gkeys, one key per 32-bit word, 1.6 % of the bytes) goes
-//     through tile_stream32; its hits are queued too (tagged): flagging needs the confirmation.
-// Tiles of one partition may split a run of equal keys; a match at slot 0 of a tile whose
-// predecessor ended with the same key was already reported there and is skipped (skip0).
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
-
-// A queued candidate: x = side << 63 | position in the stream (d_pkeys / d_gkeys index),
-// y = index of the first sample hash with the same key.  Confirming it takes the 64-bit hash at
-// that position, the sample from y on (equal keys are consecutive; almost always one read) and,
-// for the main stream, the reference id stored per stream position (d_pref): three independent
-// reads, no search.
-struct NarrowHit {
-    u32 n_refs;
-    u32* reps;
-    u32 rep_mask;
-    u64x2* queue;      // [wgs][qcap]
-    u32 qcap;
-    const u64* vals;   // d_pvals
-    const u32* pref;   // d_pref: reference of every stream position
-    const u64* g;      // d_g (side stream), may be null
-    u8* hitflag;       // [G]
-    const u64* sample;
-    u32 n_sample;
-    u32 exact;         // kshift == 0: a key match is a hash match
-
-    // true when candidate x is a real member of the sample (the 64-bit hashes agree)
-    __device__ __forceinline__ bool confirm(u64 x, u32 sidx) const {
-        if (exact) return true;
-        const u64 pos = x & 0x7fffffffffffffffull;
-        const u64 h = (x >> 63) ? g[pos] : vals[pos];
-        u32 i = sidx;
-        u64 s = sample[i];
-        while (s < h && ++i < n_sample) s = sample[i];
-        return s == h;
-    }
-    __device__ __forceinline__ void count(u32 wg, u64 x, u32 sidx) const {
-        if (!confirm(x, sidx)) return;
-        const u64 pos = x & 0x7fffffffffffffffull;
-        if (x >> 63) hitflag[pos] = 1;
-        else atomicAdd(&reps[(u64)(wg & rep_mask) * n_refs + pref[pos]], 1u);
-    }
-};
-struct HitCtx32 {
-    u32* q_fill;
-    u64x2* q;
-    u32 wg;
-};
-__device__ __forceinline__ void push_hit(const NarrowHit& hit, const HitCtx32& c, u64 x, u32 sidx) {
-    const u32 slot = atomicAdd(c.q_fill, 1u);
-    if (slot < (u32)TILE_QCAP) {
-        u64x2 e;
-        e.x = x;
-        e.y = sidx;
-        c.q[slot] = e;
-    } else {
-        hit.count(c.wg, x, sidx);
-    }
-}
-
-// One workgroup per queue segment: confirm, then count (or flag) with every lane busy.  A
-// workgroup's candidates come from one contiguous slice of the partition-major, reference-major
-// stream, i.e. from few references with several hits each; they are summed in a small LDS table
-// first and leave as one global atomic per (workgroup, reference).
-constexpr int RES_SLOTS = 1024;
-__global__ void __launch_bounds__(256) k_resolve_hits32(const u32* __restrict__ qcount, NarrowHit hit) {
-    __shared__ u32 tkey[RES_SLOTS];  // reference + 1, 0 = empty
-    __shared__ u32 tcnt[RES_SLOTS];
-    const u32 wg = blockIdx.x;
-    const u32 cnt = qcount[wg];
-    if (cnt == 0) return;
-    for (u32 k = threadIdx.x; k < RES_SLOTS; k += blockDim.x) { tkey[k] = 0; tcnt[k] = 0; }
-    __syncthreads();
-    const u64x2* q = hit.queue + (u64)wg * hit.qcap;
-    u32* my = hit.reps + (u64)(wg & hit.rep_mask) * hit.n_refs;
-    for (u32 e = threadIdx.x; e < cnt; e += blockDim.x) {
-        const u64x2 x = q[e];
-        if (!hit.confirm(x.x, (u32)x.y)) continue;
-        const u64 pos = x.x & 0x7fffffffffffffffull;
-        if (x.x >> 63) { hit.hitflag[pos] = 1; continue; }
-        const u32 r = hit.pref[pos];
-        u32 slot = (r * 2654435761u) >> (32 - 10);
-        bool done = false;
-        for (int probe = 0; probe < 8 && !done; ++probe, slot = (slot + 1) & (RES_SLOTS - 1)) {
-            const u32 old = atomicCAS(&tkey[slot], 0u, r + 1);
-            if (old == 0 || old == r + 1) { atomicAdd(&tcnt[slot], 1u); done = true; }
-        }
-        if (!done) atomicAdd(&my[r], 1u);  // crowded table: count directly
-    }
-    __syncthreads();
-    for (u32 k = threadIdx.x; k < RES_SLOTS; k += blockDim.x)
-        if (tkey[k]) atomicAdd(&my[tkey[k] - 1], tcnt[k]);
-}
-
-#ifndef YH_BLOOM_BITS
-#define YH_BLOOM_BITS 2
-#endif
-// Filter word = key bits 2..14 (so that the LDS byte address is one AND of the key), bit positions
-// inside the word = key bits 15..19 and 19..23 (shift amounts: the hardware reads 5 bits).  With
-// YH_BLOOM_LOWWORD=0: word = bits 5..17, bits 0..4 and 18..22 (one more instruction per key).
-#ifndef YH_BLOOM_LOWWORD
-#define YH_BLOOM_LOWWORD 1
-#endif
-__device__ __forceinline__ u32 bloom_s1(u32 key) { return YH_BLOOM_LOWWORD ? key >> 15 : key; }
-__device__ __forceinline__ u32 bloom_s2(u32 key) { return YH_BLOOM_LOWWORD ? key >> 19 : key >> 18; }
-__device__ __forceinline__ u32 bloom_b3(u32 key) { return ((key << 8) * 0x9e3779b1u) >> 27; }
-__device__ __forceinline__ u32 bloom_mask(u32 key) {
-    u32 m = 1u << (bloom_s1(key) & 31u);
-    if (YH_BLOOM_BITS >= 2) m |= 1u << (bloom_s2(key) & 31u);
-    if (YH_BLOOM_BITS >= 3) m |= 1u << bloom_b3(key);
-    return m;
-}
-__device__ __forceinline__ u32 bloom_test(u32 w, u32 key) {
-    u32 t = w >> (bloom_s1(key) & 31u);
-    if (YH_BLOOM_BITS >= 2) t &= w >> (bloom_s2(key) & 31u);
-    if (YH_BLOOM_BITS >= 3) t &= w >> bloom_b3(key);
-    return t & 1u;
-}
-__device__ __forceinline__ u32 bloom_word(u32 key) {
-    return YH_BLOOM_LOWWORD ? (key >> 2) & (u32)(TILE_BM_WORDS - 1) : (key >> 5) & (u32)(TILE_BM_WORDS - 1);
-}
-
-__device__ __forceinline__ void tile_stream32(const u32* __restrict__ keys, u64 start, u64 end, u64 tag, u32 sub, u32 n,
-                                              u32 ksh, bool skip0, const u32* S, const u16* E, const u32* BM,
-                                              const NarrowHit& hit, const HitCtx32& ctx) {
-    constexpr int U = TILE_UNROLL32;
-    constexpr int B = 4 * U;
-    const u32 tid = threadIdx.x;
-
-    auto lookup1 = [&](u32 key, u64 pos) {
-        u32 k = E[(key >> ksh) & (TILE_NB - 1)];
-        u32 v = S[k];
-        while (v < key) v = S[++k];  // sentinel 0xffffffff stops the scan
-        if (v == key && k < n && !(skip0 && k == 0)) push_hit(hit, ctx, tag | pos, sub + k);
-    };
-
-    u64 i = start;
-    {  // unaligned head
-        const u64 head = min((u64)((4 - (i & 3ull)) & 3ull), end - i);
-        if (tid < head) lookup1(keys[i + tid], i + tid);
-        i += head;
-    }
-    const u64 nvec = (end - i) >> 2;
-    if (nvec) {
-        const u32x4* __restrict__ vp = reinterpret_cast<const u32x4*>(keys + i);
-        const u64 last = nvec - 1;
-        u32x4 cur[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) cur[u] = __builtin_nontemporal_load(&vp[min((u64)tid + (u64)u * TILE_THREADS, last)]);
-        for (u64 v = tid; v < nvec; v += (u64)U * TILE_THREADS) {
-            u32x4 nxt[U];
-            const u64 vn = v + (u64)U * TILE_THREADS;
-#pragma unroll
-            for (int u = 0; u < U; ++u) nxt[u] = __builtin_nontemporal_load(&vp[min(vn + (u64)u * TILE_THREADS, last)]);
-
-            u32 h[B];
-            u32 valid = 0;
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                h[4 * u] = cur[u].x;
-                h[4 * u + 1] = cur[u].y;
-                h[4 * u + 2] = cur[u].z;
-                h[4 * u + 3] = cur[u].w;
-                if (v + (u64)u * TILE_THREADS < nvec) valid |= 15u << (4 * u);
-            }
-            u32 w[B];
-#pragma unroll
-            for (int b = 0; b < B; ++b) w[b] = BM[bloom_word(h[b])];
-            u32 cand = 0;
-#pragma unroll
-            for (int b = 0; b < B; ++b) cand |= bloom_test(w[b], h[b]) << b;
-            cand &= valid;
-            while (cand) {  // rare: exact lookup of the candidates this lane holds
-                const u32 b = (u32)__ffs((int)cand) - 1u;
-                cand &= cand - 1u;
-                u32 hb = h[0];
-#pragma unroll
-                for (int j = 1; j < B; ++j) hb = (b == (u32)j) ? h[j] : hb;
-                const u64 pos = i + 4 * (v + (u64)(b >> 2) * TILE_THREADS) + (b & 3u);
-                lookup1(hb, pos);
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) cur[u] = nxt[u];
-        }
-    }
-    {  // tail
-        const u64 tail = (end - i) & 3ull;
-        if (tid < tail) lookup1(keys[end - tail + tid], end - tail + tid);
-    }
-}
-
-// first[lid] = last partition that starts at or before workgroup lid's slice (sample-independent:
-// computed once per handle instead of a 10-step dependent search at the start of every workgroup)
-__global__ void k_wg_first(const u64* __restrict__ pbeg, u32 P, u64 total_len, u32 wgs, u32* __restrict__ first) {
-    const u32 lid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (lid >= wgs) return;
-    u64 per = (total_len + wgs - 1) / wgs;
-    per = (per + (KEY_BLOCK - 1)) & ~(u64)(KEY_BLOCK - 1);
-    const u64 w0 = (u64)lid * per;
-    u32 lo = 0, hi = P;
-    while (lo < hi) {
-        const u32 mid = (lo + hi) >> 1;
-        if (pbeg[mid] <= w0) lo = mid + 1; else hi = mid;
-    }
-    first[lid] = lo ? lo - 1 : 0;
-}
-
-// The main stream: packed 24-bit keys, one 1024-key block per wave and step (layout: yh_common.h).
-// `start` is a block boundary (partition starts and slice starts are); keys at positions >= end of
-// the last block are masked out.
-// Every FLUSH_ROUNDS rounds (one round = one block per wave) the workgroup meets at a barrier and
-// drains the candidate queue if it is half full: a sample made mostly of database hashes queues
-// several candidates per thousand keys, and a full queue means resolving them in place.
-template <class Flush>
-__device__ __forceinline__ void tile_stream24(const u32x4* __restrict__ pk, u64 start, u64 end, u32 sub, u32 n, u32 ksh,
-                                              bool skip0, const u32* S, const u16* E, const u32* BM, const NarrowHit& hit,
-                                              const HitCtx32& ctx, u32x4 c0, u32x4 c1, u32x4 c2, const Flush& flush) {
-    constexpr u32 WAVES = TILE_THREADS / 64;
-#ifndef YH_FLUSH_ROUNDS
-#define YH_FLUSH_ROUNDS 8
-#endif
-    constexpr u32 FLUSH_ROUNDS = YH_FLUSH_ROUNDS;
-    constexpr int B = 16;
-    const u32 lane = threadIdx.x & 63u;
-    const u64 b1 = (end + (KEY_BLOCK - 1)) >> 10;
-    u64 blk = (start >> 10) + (threadIdx.x >> 6);
-    u32 round = 0;
-
-    auto lookup1 = [&](u32 key, u64 pos) {
-        u32 k = E[(key >> ksh) & (TILE_NB - 1)];
-        u32 v = S[k];
-        while (v < key) v = S[++k];  // sentinel 0xffffffff stops the scan
-        if (v == key && k < n && !(skip0 && k == 0)) push_hit(hit, ctx, pos, sub + k);
-    };
-
-    // one block ahead (two blocks ahead measured the same: the kernel is not latency-bound)
-    // (c0..c2 = this wave's first block, loaded by the caller BEFORE it staged the tile)
-    auto addr = [&](u64 bk) { return pk + min(bk, b1 - 1) * 192 + lane; };  // clamped: a harmless re-read at the end
-    for (u64 base = start >> 10; base < b1; base += WAVES, blk += WAVES) {  // the same trip count in every wave
-        if ((++round % FLUSH_ROUNDS) == 0) {
-            __syncthreads();
-            const u32 fill = *ctx.q_fill;
-            __syncthreads();  // nobody queues before everybody has read: the decision is uniform
-            if (fill >= (u32)TILE_QCAP / 2) flush();
-        }
-        if (blk >= b1) continue;
-        const u32x4* pn = addr(blk + WAVES);
-        const u32x4 n0 = __builtin_nontemporal_load(pn), n1 = __builtin_nontemporal_load(pn + 64),
-                    n2 = __builtin_nontemporal_load(pn + 128);
-        const u32 W[12] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y, c2.z, c2.w};
-        u32 h[B];  // bits >= 24 of h[] may hold the next key's low byte: the filter only reads bits 0..22
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            h[4 * q] = W[3 * q];
-            h[4 * q + 1] = __builtin_amdgcn_alignbit(W[3 * q + 1], W[3 * q], 24);
-            h[4 * q + 2] = __builtin_amdgcn_alignbit(W[3 * q + 2], W[3 * q + 1], 16);
-            h[4 * q + 3] = W[3 * q + 2] >> 8;
-        }
-        const u64 pos0 = (blk << 10) + 16u * lane;
-        const u32 valid = pos0 >= end ? 0u : (end - pos0 >= 16 ? 0xffffu : (1u << (u32)(end - pos0)) - 1u);
-        u32 w[B];
-#pragma unroll
-        for (int b = 0; b < B; ++b) w[b] = BM[bloom_word(h[b])];
-        u32 cand = 0;
-#pragma unroll
-        for (int b = 0; b < B; ++b) cand |= bloom_test(w[b], h[b]) << b;
-        cand &= valid;
-        while (cand) {  // rare: exact lookup of the candidates this lane holds
-            const u32 b = (u32)__ffs((int)cand) - 1u;
-            cand &= cand - 1u;
-            // key b of this lane: its group of four keys = three words, then one funnel shift
-            const u32 q = b >> 2, k = b & 3u;
-            const u32 g0 = q == 0 ? W[0] : q == 1 ? W[3] : q == 2 ? W[6] : W[9];
-            const u32 g1 = q == 0 ? W[1] : q == 1 ? W[4] : q == 2 ? W[7] : W[10];
-            const u32 g2 = q == 0 ? W[2] : q == 1 ? W[5] : q == 2 ? W[8] : W[11];
-            const u32 lo = k < 2 ? g0 : (k == 2 ? g1 : g2);
-            const u32 hi = k < 2 ? g1 : (k == 2 ? g2 : 0u);
-            const u32 hb = __builtin_amdgcn_alignbit(hi, lo, (24u * k) & 31u);
-            lookup1(hb & KEY_MASK, pos0 + b);
-        }
-        c0 = n0;
-        c1 = n1;
-        c2 = n2;
-    }
-}
-
-__global__ void __launch_bounds__(TILE_THREADS, YH_TILE_WAVES_PER_SIMD)
-k_tile_lookup_keys(const u32x4* __restrict__ keys,  // packed key stream, grouped by partition (d_pkeys)
-                const u64* __restrict__ pbeg, const u64* __restrict__ pcnt, u32 P, u64 total_len,
-                const u64* __restrict__ sample, const u32* __restrict__ sbounds, u32 pshift, u32 kshift,
-                u32* __restrict__ qcount, NarrowHit hit,
-                const u32* __restrict__ gkeys,    // side stream (keys of d_g) or nullptr
-                const u64* __restrict__ gbeg, const u64* __restrict__ gcnt, const u32* __restrict__ wg_first) {
-    __shared__ __attribute__((aligned(16))) u32 S[TILE_SLOTS];
-    __shared__ __attribute__((aligned(16))) u32 BM[TILE_BM_WORDS];
-    __shared__ u16 E[TILE_NB];
-    __shared__ u64x2 Q[TILE_QCAP];
-    __shared__ u32 q_fill;
-    __shared__ u32 g_fill;
-
-    const u32 tid = threadIdx.x;
-    const u32 lid = xcd_remap(blockIdx.x, gridDim.x);
-    u64 per = (total_len + gridDim.x - 1) / gridDim.x;
-    per = (per + (KEY_BLOCK - 1)) & ~(u64)(KEY_BLOCK - 1);  // slices are whole key blocks
-    const u64 w0 = (u64)lid * per;
-    const u64 w1 = min(total_len, w0 + per);
-    const HitCtx32 ctx{&q_fill, Q, lid};
-    if (tid == 0) { q_fill = 0; g_fill = 0; }
-    if (w0 >= w1) {
-        if (tid == 0) qcount[lid] = 0;
-        return;
-    }
-    auto flush = [&]() {
-        __syncthreads();
-        const u32 f = min(q_fill, (u32)TILE_QCAP);
-        const u32 g0 = g_fill;
-        for (u32 e = tid; e < f; e += TILE_THREADS) {
-            const u64x2 x = Q[e];
-            if (g0 + e < hit.qcap) hit.queue[(u64)lid * hit.qcap + g0 + e] = x;
-            else hit.count(lid, x.x, (u32)x.y);
-        }
-        __syncthreads();
-        if (tid == 0) { q_fill = 0; g_fill = g0 + f; }
-        __syncthreads();
-    };
-
-    u32 p = wg_first[lid];
-    // bucket bits: the TILE_LGNB bits just below pshift, seen from the key
-    const u32 bsh = (pshift > (u32)TILE_LGNB) ? pshift - TILE_LGNB : 0u;
-    const u32 ksh = bsh - min(bsh, kshift);
-    bool first = true;
-    for (; p < P; ++p) {
-        const u64 e0 = pbeg[p];
-        if (e0 >= w1) break;
-        const u64 start = max(w0, e0), end = min(w1, e0 + pcnt[p]);
-        if (start >= end) continue;
-        const u32 s0 = sbounds[p], s1 = sbounds[p + 1];
-        for (u32 sub = s0; sub < s1; sub += TILE_CAP) {
-            const u32 n = min((u32)TILE_CAP, s1 - sub);
-            // this wave's first block of the stream: in flight while the tile is staged
-            u32x4 c0, c1, c2;
-            {
-                const u64 bl = min((start >> 10) + (tid >> 6), ((end + (KEY_BLOCK - 1)) >> 10) - 1);
-                const u32x4* pb = keys + bl * 192 + (tid & 63u);
-                c0 = __builtin_nontemporal_load(pb);
-                c1 = __builtin_nontemporal_load(pb + 64);
-                c2 = __builtin_nontemporal_load(pb + 128);
-            }
-            if (!first) {
-                flush();
-                __syncthreads();
-            }
-            first = false;
-            {
-                uint4* bm4 = reinterpret_cast<uint4*>(BM);
-                for (u32 k = tid; k < TILE_BM_WORDS / 4; k += TILE_THREADS) bm4[k] = make_uint4(0, 0, 0, 0);
-            }
-            for (u32 k = tid; k < n; k += TILE_THREADS) S[k] = (u32)(sample[sub + k] >> kshift) & KEY_MASK;
-            if (tid < 2) S[n + tid] = 0xffffffffu;
-            const bool skip0 = (sub > s0) && (((u32)(sample[sub - 1] >> kshift) & KEY_MASK) == ((u32)(sample[sub] >> kshift) & KEY_MASK));
-            __syncthreads();
-            for (u32 k = tid; k < n; k += TILE_THREADS) {
-                const u32 key = S[k];
-                atomicOr(&BM[bloom_word(key)], bloom_mask(key));
-                const u32 b = (key >> ksh) & (TILE_NB - 1);
-                const int bp = (k == 0) ? -1 : (int)((S[k - 1] >> ksh) & (TILE_NB - 1));
-                for (int x = bp + 1; x <= (int)b; ++x) E[x] = (u16)k;
-                if (k == n - 1)
-                    for (u32 x = b + 1; x < (u32)TILE_NB; ++x) E[x] = (u16)n;
-            }
-            __syncthreads();
-            tile_stream24(keys, start, end, sub, n, ksh, skip0, S, E, BM, hit, ctx, c0, c1, c2, flush);
-            if (gkeys) {  // this workgroup's share of the shared hashes of partition p
-                const u64 cnt = pcnt[p], gc = gcnt[p], g0 = gbeg[p];
-                const u64 gs = g0 + gc * (start - e0) / cnt, ge = g0 + gc * (end - e0) / cnt;
-                if (gs < ge) tile_stream32(gkeys, gs, ge, 1ull << 63, sub, n, ksh, skip0, S, E, BM, hit, ctx);
-            }
-        }
-    }
-    flush();
-    if (tid == 0) qcount[lid] = min(g_fill, hit.qcap);
-}
 
 // ---- K1 over the hash-sorted delta stream ------------------------------------------------------------
 // The stream (yh_common.h) is every (hash, reference) pair in ascending hash order, the hashes
@@ -1457,31 +725,6 @@ __device__ __forceinline__ void walk_holders(const u64* __restrict__ po, const u
     }
 }
 
-__global__ void __launch_bounds__(256) k_index_lookup(const u64* __restrict__ sample, u64 n, const YhDirView dv,
-                                                      const u64* __restrict__ po, const u32* __restrict__ pr,
-                                                      u32* __restrict__ reps, u32 rep_mask, u64 n_refs,
-                                                      u8* __restrict__ hit, u32* __restrict__ reps2,
-                                                      u32* __restrict__ work_count, const u32* __restrict__ bad, u32 bad_gen) {
-    if (work_count && blockIdx.x == 0 && threadIdx.x == 0) *work_count = 0;  // (for the kernels behind: see StreamHit)
-    if (bad && *bad == bad_gen) return;
-    u32* my = reps + (u64)replica_of(blockIdx.x, rep_mask) * n_refs;
-    u32* my2 = reps2 ? reps2 + (u64)replica_of(blockIdx.x, rep_mask) * n_refs : nullptr;  // hits on shared hashes (fused run)
-    for (u64 t = blockIdx.x * (u64)blockDim.x + threadIdx.x; t < n; t += (u64)gridDim.x * blockDim.x) {
-        const u32 r = dv.find(sample[t]);
-        if (r == YH_DIR_NONE) continue;
-        if (!(r & 0x80000000u)) {
-            count_add(&my[r], 1u);
-        } else {
-            const u32 gi = r & 0x7fffffffu;
-            if (hit) hit[gi] = 1;
-            walk_holders(po, pr, gi, [&](u32 h) {
-                count_add(&my[h], 1u);
-                if (my2) count_add(&my2[h], 1u);
-            });
-        }
-    }
-}
-
 // The same lookup for LARGE samples: a workgroup of IDX_THREADS lanes takes a tile of IDX_THREADS x U consecutive
 // sample hashes, every lane has its U bucket reads in flight together, and the hits are summed per reference in an
 // LDS table that leaves as ONE global atomic per (workgroup, reference) at the end.  In hash order the hits of a
@@ -1647,32 +890,6 @@ __global__ void __launch_bounds__(EXCL_BLOCK) k_excl_collect(u64 n_post, u64 chu
         __syncthreads();
     }
     if (threadIdx.x == 0) qcount[blockIdx.x] = done;
-}
-
-__global__ void __launch_bounds__(EXCL_BLOCK) k_excl_apply(const u32* __restrict__ queue, const u32* __restrict__ qcount,
-                                                           u64 chunk, const u64* __restrict__ po,
-                                                           const u32* __restrict__ pr, const u32* __restrict__ pg,
-                                                           const u32* __restrict__ maskbits, const u8* __restrict__ hit,
-                                                           u32* __restrict__ ex_e, u32* __restrict__ ex_m,
-                                                           u32* __restrict__ ovsh) {
-    const u32 n = qcount[blockIdx.x];
-    const u32* seg = queue + 4 * (u64)blockIdx.x * chunk;
-    for (u32 e = threadIdx.x; e < n; e += EXCL_BLOCK) {
-        const u32 k = seg[e];
-        const u32 r = pr[k];
-        const u32 gi = pg[k];
-        const bool in_sample = hit[gi] != 0;
-        u32 c = 0;
-        for (u64 q = po[gi], qe = po[gi + 1]; q < qe; ++q) {
-            const u32 o = pr[q];
-            c += (maskbits[o >> 5] >> (o & 31u)) & 1u;
-        }
-        if (c == 1) {
-            atomicAdd(&ex_e[r], 1u);
-            if (in_sample) atomicAdd(&ex_m[r], 1u);
-        }
-        if (in_sample) atomicAdd(&ovsh[r], 1u);
-    }
 }
 
 // The same sums without the pass over pr[]: the reference-major view of the postings is cut into
@@ -1988,22 +1205,6 @@ inline u32 grid_for(u64 work_items, u32 block, u32 max_blocks = 16384) {
     return (u32)g;
 }
 
-// Workgroups for the tile kernel: YH_TILE_WGS (default 512 = the two resident workgroups of each
-// of the 256 CUs, one round: with the 4-byte key stream the tile set-ups of further rounds cost
-// more than the tail they even out; measured 0.236 ms at 256-512, 0.246-0.253 ms at 1024-2048),
-// never so many that a workgroup gets less than 128 KiB of stream per tile it has to stage.
-inline u32 tile_grid(u64 stream_len) {
-    static int wgs_env = -1;
-    if (wgs_env < 0) {
-        const char* e = getenv("YH_TILE_WGS");
-        wgs_env = (e && atoi(e) > 0) ? atoi(e) : 512;
-    }
-    u64 g = (u64)wgs_env;
-    const u64 max_g = std::max<u64>(1, stream_len / 32768);  // a tile set-up must pay for itself
-    if (g > max_g) g = max_g;
-    return (u32)g;
-}
-
 }  // namespace
 
 // =================================================================================================
@@ -2071,7 +1272,9 @@ static int yh_q_overlap_stream(yh_db* db, const u64* d_sample, u64 n_sample, u32
     const u64 N = db->n_refs;
     const u64 nblk = db->slen / STREAM_BLOCK;
     // (a workgroup's set-up is two wave searches and a few KB of LDS: two blocks are enough to pay for it)
-    u32 wgs = (u32)std::min<u64>(tile_grid(~0ull), std::max<u64>(nblk / 2, 1));
+    // 512 workgroups = the two resident ones of each of the 256 CUs, one round (YH_STREAM_WGS: tests force one)
+    static const u32 wgs_env = [] { const char* e = yh_tune_env("YH_STREAM_WGS"); return (e && atoi(e) > 0) ? (u32)atoi(e) : 512u; }();
+    u32 wgs = (u32)std::min<u64>(wgs_env, std::max<u64>(nblk / 2, 1));
     if (db->wg_key_n != wgs) {  // the first t of every workgroup's block range: once per handle
         YH_HIP(hipStreamSynchronize(st));
         if (db->d_wg_key) { (void)hipFree(db->d_wg_key); db->d_wg_key = nullptr; }
@@ -2082,7 +1285,7 @@ static int yh_q_overlap_stream(yh_db* db, const u64* d_sample, u64 n_sample, u32
     u32 R;
     YH_TRY(ensure_reps(db, R));
     // hits leave a workgroup pre-summed (one atomic per workgroup and reference), so few replicas do
-    static const u32 r_env = [] { const char* e = getenv("YH_STREAM_REPS"); return e ? (u32)atoi(e) : (YH_XCD_ATOMICS ? 8u : 4u); }();
+    static const u32 r_env = [] { const char* e = yh_tune_env("YH_STREAM_REPS"); return e ? (u32)atoi(e) : (YH_XCD_ATOMICS ? 8u : 4u); }();
     while (R > 1 && R > r_env) R >>= 1;
     const bool fused = d_fused_excl != nullptr;
     const bool flags_too = flag_shared && db->has_index && !fused;
@@ -2108,7 +1311,7 @@ static int yh_q_overlap_stream(yh_db* db, const u64* d_sample, u64 n_sample, u32
 }
 
 int yh_q_overlap(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap, bool flag_shared, bool make_mask) {
-    if (db->posting_only || (db->flags & YH_DB_PAIRWISE_ONLY)) { yh_set_error("this handle has no streaming layout (yh_db_create_from_pairs or YH_DB_PAIRWISE_ONLY)"); return YH_ERR_UNSUPPORTED; }
+    if (!db->d_sdelta && db->n_hashes) { yh_set_error("this handle has no streaming layout (YH_DB_PAIRWISE_ONLY)"); return YH_ERR_UNSUPPORTED; }
     hipStream_t st = db->stream;
     const u64 N = db->n_refs;
     if (n_sample > 0xfffffff0ull) { yh_set_error("sample larger than 2^32-16 hashes"); return YH_ERR_INVALID_ARG; }
@@ -2124,69 +1327,15 @@ int yh_q_overlap(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap, b
         }
         return YH_OK;
     }
-    if (db->d_sdelta) return yh_q_overlap_stream(db, d_sample, n_sample, d_overlap, flag_shared, with_index, make_mask);
-    const u32 P = db->n_parts;
-    // hit queue: one segment per workgroup, 1/16 of its stream slice (at least 4096 entries)
-    const u32 wgs = tile_grid(db->pvals_len);
-    const u64 per_wg = (db->pvals_len + wgs - 1) / wgs;
-    const u64 qcap64 = std::min<u64>(std::max<u64>(4096, per_wg / 16), 1u << 24);
-    const u32 qcap = (u32)qcap64;
-    if (db->hitq_wgs < wgs || db->hitq_cap < qcap) {
-        YH_HIP(hipStreamSynchronize(st));
-        if (db->d_hitq) { (void)hipFree(db->d_hitq); db->d_hitq = nullptr; }
-        if (db->d_hitq_cnt) { (void)hipFree(db->d_hitq_cnt); db->d_hitq_cnt = nullptr; }
-        db->hitq_wgs = db->hitq_cap = 0;
-        YH_HIP(hipMalloc((void**)&db->d_hitq, (u64)wgs * qcap * 2 * sizeof(u64)));  // 16-byte entries (key stream)
-        YH_HIP(hipMalloc((void**)&db->d_hitq_cnt, (u64)wgs * sizeof(u32)));
-        db->hitq_wgs = wgs;
-        db->hitq_cap = qcap;
-        if (db->d_wg_first) { (void)hipFree(db->d_wg_first); db->d_wg_first = nullptr; }
-        YH_HIP(hipMalloc((void**)&db->d_wg_first, (u64)wgs * sizeof(u32)));
-        k_wg_first<<<(wgs + 255) / 256, 256, 0, st>>>(db->d_pbeg, db->n_parts, db->pvals_len, wgs, db->d_wg_first);
-    }
-    u32 R;
-    YH_TRY(ensure_reps(db, R));
-    if (flag_shared) YH_TRY(claim_hit_flags(db));
-    // one launch in front: the sample's slice bounds per partition (the counters are zero at rest)
-    k_prep<<<(P + 1 + 255) / 256, 256, 0, st>>>(d_sample, (u32)n_sample, P, db->pshift, db->d_sbounds, ZeroList{});
-    if (db->d_pkeys) {  // the packed key stream (YH_STREAM=keys); YH_WIDE_KEYS=1 at creation keeps the 64-bit kernel
-        const bool side = flag_shared && db->d_gkeys;
-        NarrowHit nh{(u32)N, db->d_reps, R - 1, reinterpret_cast<u64x2*>(db->d_hitq), db->hitq_cap, db->d_pvals, db->d_pref,
-                     side ? db->d_g : nullptr, db->d_hit, d_sample, (u32)n_sample, db->kshift == 0 ? 1u : 0u};
-        yh_ring_record_begin(db, db->ev_overlap);
-        k_tile_lookup_keys<<<wgs, TILE_THREADS, 0, st>>>(reinterpret_cast<const u32x4*>(db->d_pkeys), db->d_pbeg, db->d_pcnt, P, db->pvals_len, d_sample,
-                                                      db->d_sbounds, db->pshift, db->kshift, db->d_hitq_cnt, nh,
-                                                      side ? db->d_gkeys : nullptr, db->d_gbeg, db->d_gcnt, db->d_wg_first);
-        yh_ring_record_end(db, db->ev_overlap);
-        k_resolve_hits32<<<wgs, 256, 0, st>>>(db->d_hitq_cnt, nh);
-        k_reduce_replicas<<<(u32)((N + 255) / 256), 256, 0, st>>>(db->d_reps, R, N, d_overlap, make_mask ? db->d_mask : nullptr,
-                                                                 make_mask ? db->d_maskbits : nullptr,
-                                                                 with_index ? db->d_excl_e : nullptr, FusedRun{});
-        YH_HIP(hipGetLastError());
-        return YH_OK;
-    }
-    OverlapHit hit{db->d_poffs, (u32)N, db->d_reps, R - 1, db->d_hitq, db->hitq_cap};
-    yh_ring_record_begin(db, db->ev_overlap);
-    const SideStream side = flag_shared ? SideStream{db->d_g, db->d_gbeg, db->d_gcnt, db->d_hit}
-                                        : SideStream{nullptr, nullptr, nullptr, nullptr};
-    k_tile_lookup<OverlapHit><<<wgs, TILE_THREADS, 0, st>>>(db->d_pvals, db->d_pbeg, db->d_pcnt, P, db->pvals_len,
-                                                            d_sample, db->d_sbounds, db->pshift, db->d_hitq_cnt, hit,
-                                                            side);
-    yh_ring_record_end(db, db->ev_overlap);
-    k_resolve_hits<<<wgs, 256, 0, st>>>(db->d_hitq_cnt, hit);
-    k_reduce_replicas<<<(u32)((N + 255) / 256), 256, 0, st>>>(db->d_reps, R, N, d_overlap, make_mask ? db->d_mask : nullptr,
-                                                             make_mask ? db->d_maskbits : nullptr,
-                                                             with_index ? db->d_excl_e : nullptr, FusedRun{});
-    YH_HIP(hipGetLastError());
-    return YH_OK;
+    return yh_q_overlap_stream(db, d_sample, n_sample, d_overlap, flag_shared, with_index, make_mask);
 }
 
 // The `yacht run` step on the hash-sorted stream: overlap, subset = overlap > 0, exclusive counts.
 // Returns 1 when this handle cannot take the fused path (the caller then runs the general one).
 int yh_q_run_fused(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap, u32* d_excl, u32* d_match, int phases,
                    u32* d_bits_out, const u32* d_global_bits, bool use_indexed) {
-    static const bool off = [] { const char* e = getenv("YH_NO_FUSED_RUN"); return e && e[0] == '1'; }();
-    if (!db->d_sdelta || !db->has_index || db->posting_only || db->n_refs == 0 || db->n_hashes == 0 ||
+    static const bool off = [] { const char* e = yh_tune_env("YH_NO_FUSED_RUN"); return e && e[0] == '1'; }();
+    if (!db->d_sdelta || !db->has_index || db->n_refs == 0 || db->n_hashes == 0 ||
         (db->n_postings && (!db->d_hrec || !db->d_hpo || !db->d_work)) || n_sample > 0xfffffff0ull)
         return 1;
     if (phases == 3 && (off || n_sample == 0)) return 1;
@@ -2198,7 +1347,7 @@ int yh_q_run_fused(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap,
             YH_HIP(hipMemsetAsync(d_excl, 0, N * sizeof(u32), st));
             YH_HIP(hipMemsetAsync(d_match, 0, N * sizeof(u32), st));
             YH_HIP(hipMemsetAsync(db->d_maskbits, 0, ((N + 255) / 256) * 32, st));
-            if (d_bits_out) YH_HIP(hipMemsetAsync(d_bits_out, 0, ((N + 63) / 64) * 8, st));
+            if (d_bits_out) YH_HIP(hipMemsetAsync(d_bits_out, 0, ((N + 255) / 256) * 32, st));  // (the extent the reducer writes)
             if (db->d_work_count) YH_HIP(hipMemsetAsync(db->d_work_count, 0, sizeof(u32), st));
         } else if (use_indexed && db->has_dir && db->d_work && db->d_hrec && db->d_hpo) {
             const int rc = yh_q_overlap_indexed(db, d_sample, n_sample, d_overlap, true, d_excl, d_match, d_bits_out, true);
@@ -2236,22 +1385,22 @@ int yh_q_overlap_indexed(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_ov
     YH_TRY(ensure_reps(db, R));
     // (k_reduce_replicas reads every replica of both sets: 16 -> 8 replicas took 4 us off the step, with no
     // measurable change of the lookup kernel at 1.3e5 hits per sample)
-    static const u32 ri_env = [] { const char* e = getenv("YH_INDEX_REPS"); return e ? (u32)atoi(e) : 0u; }();
+    static const u32 ri_env = [] { const char* e = yh_tune_env("YH_INDEX_REPS"); return e ? (u32)atoi(e) : 0u; }();
     // tiles of IDX_THREADS x U hashes once there are enough of them for every CU (k_index_lookup_tile)
     // (measured, 10^6-hash rotating samples with 1.6e5 hits: one hash per lane in 256-lane workgroups 38-40 us, tiles of U = 2
     // 35.7-36.3, U = 4 slower; no hits at all 32.5 / 31.5; an 83 k-hash sample 13 / 23)
-    // YH_INDEX_TILE: 0 = k_index_lookup (one atomic per hit), 256 = the small aggregating form, 1/2/4 = 1024-lane tiles of U
-    static const long tile_env = [] { const char* e = getenv("YH_INDEX_TILE"); return e ? atol(e) : -1L; }();
+    // YH_INDEX_TILE (debug gate): 256 = the small aggregating form, 1/2/4 = 1024-lane tiles of U
+    static const long tile_env = [] { const char* e = yh_tune_env("YH_INDEX_TILE"); return e ? atol(e) : -1L; }();
     // (step time on the bench database, us, by sample size 1e5 / 2e5 / 3e5 / 4e5 / 5e5 / 7e5: small form 27.5 / 29.9 / 34.7 /
     // 37.9 / 40.5 / 43.5; 1024-lane tiles of one hash 29.3 / 30.0 / 33.5 / 33.7 / 36.4 / 41.7; of two 35.1 / 34.9 / 35.0 / 36.0 /
     // 36.9 / 41.1)
     int U = n_sample >= 512ull * IDX_THREADS ? 2 : n_sample >= 256ull * IDX_THREADS ? 1 : 256;
-    if (tile_env >= 0) U = (int)tile_env;
+    if (tile_env == 1 || tile_env == 2 || tile_env == 4 || tile_env == 256) U = (int)tile_env;
     // the aggregating forms leave one atomic per (workgroup, reference): four replicas are enough there (10^6-hash sample:
     // step 49.9 -> 48.4 us; two: 51.7; 83 k-hash real-shape sample: 28.8 / 26.3 / 25.4 us with 8 / 4 / 2)
-    const u32 r_want = ri_env ? ri_env : (U ? 4u : 8u);
+    const u32 r_want = ri_env ? ri_env : 4u;
     while (R > 1 && R > r_want) R >>= 1;
-    static const bool fused_off = [] { const char* e = getenv("YH_NO_FUSED_RUN"); return e && e[0] == '1'; }();
+    static const bool fused_off = [] { const char* e = yh_tune_env("YH_NO_FUSED_RUN"); return e && e[0] == '1'; }();
     const bool fused = d_fused_excl && for_exclusive && db->d_work && db->d_hrec && db->d_hpo && !fused_off;
     if (for_exclusive && db->n_shared && !fused) YH_TRY(claim_hit_flags(db));
     u32* const reps2 = db->d_reps + db->reps_cap;
@@ -2271,10 +1420,6 @@ int yh_q_overlap_indexed(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_ov
     else if (n_sample && db->n_distinct && U == 2) YH_TILE_LAUNCH(2, IDX_THREADS, YH_IDX_TBITS, d_filter);
     else if (n_sample && db->n_distinct && U == 1) YH_TILE_LAUNCH(1, IDX_THREADS, YH_IDX_TBITS, d_filter);
 #undef YH_TILE_LAUNCH
-    else if (n_sample && db->n_distinct)
-        k_index_lookup<<<grid_for(n_sample, 256, 4096), 256, 0, st>>>(d_sample, n_sample, yh_dir_view(db), db->d_po, db->d_pr,
-                                                                      db->d_reps, R - 1, N, d_hitflags, d_reps2, db->d_work_count,
-                                                                      db->d_bad, db->bad_gen);
     else if (fused && db->d_work_count)
         YH_HIP(hipMemsetAsync(db->d_work_count, 0, sizeof(u32), st));
     yh_ring_record_end(db, db->ev_overlap);
@@ -2305,98 +1450,41 @@ int yh_q_overlap_bsearch(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_ov
     return YH_OK;
 }
 
-// d_overlap must hold the overlap of the SAME sample (yh_q_overlap output).
-// Partial exclusive sums of this handle's posting lists for an arbitrary mask over ITS reference
-// numbering: ex_e / ex_m / ovsh (see k_excl_postings).  `own_bounds`: compute the sample's slice
-// bounds here (a handle whose overlap kernel did not just run on the same sample).
-int yh_q_exclusive_partial(yh_db* db, const u8* d_mask, const u64* d_sample, u64 n_sample, u32* d_ex_e, u32* d_ex_m,
-                           u32* d_ovsh, bool own_bounds, bool hit_ready, const u32* d_maskbits) {
+// Exclusive counts for an arbitrary subset (yh_exclusive; yh_run on handles without holder sets).  The caller has run
+// yh_q_overlap / yh_q_overlap_indexed on the SAME sample with flag_shared / for_exclusive: d_overlap holds its counts,
+// db->d_hit the shared hashes found in the sample, and the three accumulators db->d_excl_e/_m/d_ovsh are zero
+// (k_reduce_replicas).  d_maskbits == nullptr: the subset comes as bytes (d_mask) and is turned into bits here.
+int yh_q_exclusive(yh_db* db, const u8* d_mask, const u64* d_sample, u64 n_sample, const u32* d_overlap,
+                   u32* d_excl, u32* d_match, const u32* d_maskbits) {
+    (void)d_sample; (void)n_sample;
     if (!db->has_index) { yh_set_error("this handle was created with YH_DB_NO_INDEX"); return YH_ERR_UNSUPPORTED; }
+    if (db->flags & YH_DB_PAIRWISE_ONLY) { yh_set_error("this handle holds posting lists only"); return YH_ERR_UNSUPPORTED; }
     hipStream_t st = db->stream;
     const u64 N = db->n_refs;
     if (N == 0) return YH_OK;
-    if (n_sample > 0xfffffff0ull) { yh_set_error("sample larger than 2^32-16 hashes"); return YH_ERR_INVALID_ARG; }
-    const u64 G = db->n_shared;
-    if (!hit_ready) {  // (the fused path zeroed these in k_prep)
-        YH_HIP(hipMemsetAsync(d_ex_e, 0, N * sizeof(u32), st));
-        YH_HIP(hipMemsetAsync(d_ex_m, 0, N * sizeof(u32), st));
-        YH_HIP(hipMemsetAsync(d_ovsh, 0, N * sizeof(u32), st));
-    }
-    if (!d_maskbits) {  // mask supplied as bytes by the caller
+    yh_ring_record_begin(db, db->ev_excl);
+    if (!d_maskbits) {
         k_mask_bits<<<(u32)((N + 255) / 256), 256, 0, st>>>(d_mask, N, db->d_maskbits);
         d_maskbits = db->d_maskbits;
     }
-    if (G) {
-        if (!hit_ready && !db->hit_clean) { YH_HIP(hipMemsetAsync(db->d_hit, 0, G + 15, st)); db->hit_clean = true; }
-        if (n_sample && !hit_ready) {
-            db->hit_clean = false;
-            const u32 P = db->n_parts;
-            if (own_bounds)
-                k_prep<<<(P + 1 + 255) / 256, 256, 0, st>>>(d_sample, (u32)n_sample, P, db->pshift, db->d_sbounds, ZeroList{});
-            // membership of every shared hash in the sample: the same tile kernel over d_g
-            FlagHit fh{db->d_gbeg, db->d_hit};
-            k_tile_lookup<FlagHit><<<tile_grid(G), TILE_THREADS, 0, st>>>(
-                db->d_g, db->d_gbeg, db->d_gcnt, P, G, d_sample, db->d_sbounds, db->pshift, nullptr, fh,
-                SideStream{nullptr, nullptr, nullptr, nullptr});
-        }
-        static const bool stream_env = [] { const char* e = getenv("YH_EXCL_STREAM"); return e && e[0] == '1'; }();
-        if (db->d_work && !stream_env && !db->excl_prefer_stream) {
-            if (db->n_chunks) {
-                YH_HIP(hipMemsetAsync(db->d_work_count, 0, sizeof(u32), st));
-                k_excl_worklist<<<(u32)((N + 255) / 256), 256, 0, st>>>(N, d_maskbits, db->d_nshared, db->d_rpo, db->d_work,
-                                                                       db->d_work_count);
-                launch_excl_pieces(db, d_maskbits, db->d_hit, d_ex_e, d_ex_m, d_ovsh);
-            }
-        } else {
-            const u64 vecs = (db->n_postings >> 2) + 1;
-            const u32 blocks = (u32)std::min<u64>(EXCL_QBLOCKS, (vecs + EXCL_BLOCK - 1) / EXCL_BLOCK);
-            const u64 chunk = (vecs + blocks - 1) / blocks;
-            k_excl_collect<<<blocks, EXCL_BLOCK, 0, st>>>(db->n_postings, chunk, db->d_pr, d_maskbits, db->d_pq,
-                                                          db->d_pq_count);
-            k_excl_apply<<<blocks, EXCL_BLOCK, 0, st>>>(db->d_pq, db->d_pq_count, chunk, db->d_po, db->d_pr, db->d_pg,
-                                                        d_maskbits, db->d_hit, d_ex_e, d_ex_m, d_ovsh);
-        }
+    if (db->n_shared && db->n_chunks) {  // the shared hashes of the subset's references, by the reference-major postings
+        YH_HIP(hipMemsetAsync(db->d_work_count, 0, sizeof(u32), st));
+        k_excl_worklist<<<(u32)((N + 255) / 256), 256, 0, st>>>(N, d_maskbits, db->d_nshared, db->d_rpo, db->d_work, db->d_work_count);
+        launch_excl_pieces(db, d_maskbits, db->d_hit, db->d_excl_e, db->d_excl_m, db->d_ovsh);
     }
-    YH_HIP(hipGetLastError());
-    return YH_OK;
-}
-
-int yh_q_exclusive_final(yh_db* db, u64 n, const u8* d_mask, const u32* d_sizes, const u32* d_nshared,
-                         const u32* d_overlap, const u32* d_ex_e, const u32* d_ex_m, const u32* d_ovsh, u32* d_excl,
-                         u32* d_match, bool clean_hit) {
-    if (n == 0) return YH_OK;
-    clean_hit = clean_hit && db->d_hit && db->n_shared;
-    k_excl_final<<<grid_for(n, 256, 1u << 22), 256, 0, db->stream>>>(
-        n, d_mask, d_sizes, d_nshared, d_overlap, d_ex_e, d_ex_m, d_ovsh, d_excl, d_match,
+    const bool clean_hit = db->d_hit && db->n_shared;
+    k_excl_final<<<grid_for(N, 256, 1u << 22), 256, 0, st>>>(
+        N, d_mask, db->d_sizes, db->d_nshared, d_overlap, db->d_excl_e, db->d_excl_m, db->d_ovsh, d_excl, d_match,
         clean_hit ? reinterpret_cast<uint4*>(db->d_hit) : nullptr, clean_hit ? (db->n_shared + 15) / 16 : 0);
-    YH_HIP(hipGetLastError());
     if (clean_hit) db->hit_clean = true;
-    return YH_OK;
-}
-
-// d_overlap must hold the overlap of the SAME sample (yh_q_overlap output on this handle, which
-// also left the sample's slice bounds in d_sbounds).
-int yh_q_exclusive(yh_db* db, const u8* d_mask, const u64* d_sample, u64 n_sample, const u32* d_overlap,
-                   u32* d_excl, u32* d_match, bool hit_ready, const u32* d_maskbits) {
-    if (!db->has_index) { yh_set_error("this handle was created with YH_DB_NO_INDEX"); return YH_ERR_UNSUPPORTED; }
-    if (db->posting_only || (db->flags & YH_DB_PAIRWISE_ONLY)) { yh_set_error("this handle holds posting lists only"); return YH_ERR_UNSUPPORTED; }
-    if (db->n_refs == 0) return YH_OK;
-    yh_ring_record_begin(db, db->ev_excl);
-    YH_TRY(yh_q_exclusive_partial(db, d_mask, d_sample, n_sample, db->d_excl_e, db->d_excl_m, db->d_ovsh, false,
-                                  hit_ready, d_maskbits));
-    YH_TRY(yh_q_exclusive_final(db, db->n_refs, d_mask, db->d_sizes, db->d_nshared, d_overlap, db->d_excl_e,
-                                db->d_excl_m, db->d_ovsh, d_excl, d_match, true));
     yh_ring_record_end(db, db->ev_excl);
+    YH_HIP(hipGetLastError());
     return YH_OK;
 }
 
 // Fills the handle's host-side pair cache (h_pw_*) for rows [r0, r1).
 int yh_q_pairwise(yh_db* db, double c_thresh, u64 r0, u64 r1) {
     if (!db->has_index) { yh_set_error("this handle was created with YH_DB_NO_INDEX"); return YH_ERR_UNSUPPORTED; }
-    if (db->posting_only) {  // (from_pairs handles carry no sketch sizes)
-        yh_set_error("this handle holds posting lists only");
-        return YH_ERR_UNSUPPORTED;
-    }
     hipStream_t st = db->stream;
     const u64 N = db->n_refs;
     free(db->h_pw_i); free(db->h_pw_j); free(db->h_pw_c);

@@ -120,176 +120,20 @@ def sharded_pairwise(compute_rows: Callable[[int, int], Tuple[np.ndarray, np.nda
     return allp[0].astype(np.uint32), allp[1].astype(np.uint32), allp[2].astype(np.uint32)
 
 
-# ======================================================================================================
-# Exact `yacht run` counts when the references are spread over ranks (option B)
-# ======================================================================================================
-# overlap_j needs only rank-local data, but "hash h of R_j is held by no other overlapping
-# reference" is a global statement: the other holder may live on another rank.  So, once per
-# database, every rank sends each (hash, global reference id) pair to the rank that owns the hash's
-# RANGE (equal-width ranges of [0, max hash]; all_to_all), and the owner builds the posting lists of
-# its range.  Per sample: local overlap kernel -> all-gather of counts -> global mask -> each rank
-# sums its posting lists' contributions for ALL references -> one all-reduce of [3, N] -> finalize.
-# Every collective carries <= a few MB: latency-bound over xGMI.
 _SIGN = -(2 ** 63)  # int64 bit pattern 0x8000...: x ^ _SIGN turns unsigned order into signed order
-
-
-class HipBackend:
-    """The compute side of ShardedRun on the HIP engine.  Both handles are pointed at torch's CURRENT stream
-    when they are made, so the library's kernels, torch's fills and the collectives torch issues on that
-    stream are ordered by the stream itself: no host synchronisation per sample."""
-
-    def __init__(self, device_index: int):
-        self.device_index = device_index
-
-    def make_ref_db(self, values_t, offsets_t):
-        import torch
-
-        from .engine import RefDB, YH_DB_NO_INDEX
-
-        torch.cuda.current_stream().synchronize()  # build-time only: the CSR tensors are complete
-        n = offsets_t.numel() - 1
-        db = RefDB.from_device(values_t.data_ptr(), offsets_t.data_ptr(), n, device=self.device_index,
-                               flags=YH_DB_NO_INDEX)
-        db.set_stream(torch.cuda.current_stream().cuda_stream)
-        info = db.info()
-
-        def overlap(sample_t):
-            out = torch.zeros(n, dtype=torch.int32, device=sample_t.device)
-            db.overlap_device(sample_t.data_ptr(), sample_t.numel(), out.data_ptr())
-            return out
-
-        return {"overlap": overlap, "partition_shift": info["partition_shift"], "handle": db}
-
-    def make_posting_db(self, hashes_t, refs_t, n_total: int, partition_shift: int, max_hash: int):
-        import torch
-
-        from .engine import RefDB
-
-        torch.cuda.current_stream().synchronize()  # build-time only
-        db = RefDB.from_pairs(hashes_t.data_ptr(), refs_t.data_ptr(), hashes_t.numel(), n_total, partition_shift,
-                              max_hash, device=self.device_index)
-        db.set_stream(torch.cuda.current_stream().cuda_stream)
-        dev = hashes_t.device
-
-        def partial(mask_t, sample_t):
-            out = torch.zeros((3, n_total), dtype=torch.int32, device=dev)
-            db.exclusive_partial_device(mask_t.data_ptr(), sample_t.data_ptr(), sample_t.numel(), out[0].data_ptr(),
-                                        out[1].data_ptr(), out[2].data_ptr())
-            return out
-
-        def nshared():
-            out = torch.zeros(n_total, dtype=torch.int32, device=dev)
-            db.nshared_device(out.data_ptr())
-            return out
-
-        def finalize(mask_t, sizes_t, nshared_t, overlap_t, sums_t):
-            e = torch.zeros(n_total, dtype=torch.int32, device=dev)
-            m = torch.zeros(n_total, dtype=torch.int32, device=dev)
-            db.exclusive_finalize_device(n_total, mask_t.data_ptr(), sizes_t.data_ptr(), nshared_t.data_ptr(),
-                                         overlap_t.data_ptr(), sums_t[0].data_ptr(), sums_t[1].data_ptr(),
-                                         sums_t[2].data_ptr(), e.data_ptr(), m.data_ptr())
-            return e, m
-
-        return {"partial": partial, "nshared": nshared, "finalize": finalize, "handle": db}
-
-
-class ShardedRun:
-    """overlap + exact exclusive counts for references spread over the ranks of `group`.
-
-    values_t / offsets_t: this rank's references as int64 tensors holding the uint64 bit patterns
-    (CSR, offsets rebased to 0) on this rank's device.  `backend` supplies the compute (HipBackend;
-    the CPU test passes an oracle-based stand-in to exercise the plumbing with gloo)."""
-
-    def __init__(self, values_t, offsets_t, backend, group=None):
-        import torch
-        import torch.distributed as dist
-
-        self.group = group
-        self.world = dist.get_world_size(group)
-        self.rank = dist.get_rank(group)
-        dev = values_t.device
-        n_local = offsets_t.numel() - 1
-        sizes_local = (offsets_t[1:] - offsets_t[:-1]).to(torch.int32)
-
-        # reference numbering: rank r's references follow rank r-1's
-        counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(self.world)]
-        dist.all_gather(counts, torch.tensor([n_local], dtype=torch.int64, device=dev), group=group)
-        lens = [int(c.item()) for c in counts]
-        starts = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
-        self.plan = [(int(starts[r]), int(starts[r + 1])) for r in range(self.world)]
-        self.n_total = int(starts[-1])
-        ref_base = int(starts[self.rank])
-        self.sizes = gather_counts(sizes_local.unsqueeze(0), self.plan, group=group)[0].contiguous()
-
-        self.ref = backend.make_ref_db(values_t, offsets_t)
-
-        # global hash extent and the finest partition shift any shard chose
-        key = values_t ^ _SIGN  # signed order == unsigned hash order
-        top = key.max() if values_t.numel() else torch.tensor(_SIGN, dtype=torch.int64, device=dev)
-        top = top.reshape(1).clone()
-        dist.all_reduce(top, op=dist.ReduceOp.MAX, group=group)
-        self.max_hash = int(top.item() ^ _SIGN) & (2 ** 64 - 1)
-        ps = torch.tensor([self.ref["partition_shift"]], dtype=torch.int64, device=dev)
-        dist.all_reduce(ps, op=dist.ReduceOp.MIN, group=group)
-        pshift = int(ps.item())
-
-        # (hash, global reference id) pairs in hash order, cut at the owners' range bounds
-        refs = torch.repeat_interleave(torch.arange(n_local, device=dev, dtype=torch.int32) + ref_base,
-                                       sizes_local.long())
-        key, perm = torch.sort(key, stable=True)
-        refs = refs[perm]
-        bounds = [(((self.max_hash + 1) * d) // self.world) for d in range(1, self.world)]
-        bkeys = torch.tensor([(b - 2 ** 63) for b in bounds], dtype=torch.int64, device=dev)  # b ^ SIGN as signed
-        cuts = torch.searchsorted(key, bkeys).tolist() if self.world > 1 else []
-        cuts = [0] + [int(c) for c in cuts] + [key.numel()]
-        send = [cuts[d + 1] - cuts[d] for d in range(self.world)]
-        send_t = torch.tensor(send, dtype=torch.int64, device=dev)
-        recv_t = torch.zeros(self.world, dtype=torch.int64, device=dev)
-        dist.all_to_all_single(recv_t, send_t, group=group)
-        recv = [int(x) for x in recv_t.tolist()]
-        hashes_in = torch.empty(sum(recv), dtype=torch.int64, device=dev)
-        refs_in = torch.empty(sum(recv), dtype=torch.int32, device=dev)
-        dist.all_to_all_single(hashes_in, (key ^ _SIGN).contiguous(), recv, send, group=group)
-        dist.all_to_all_single(refs_in, refs.contiguous(), recv, send, group=group)
-        del key, perm, refs
-
-        self.post = backend.make_posting_db(hashes_in, refs_in, self.n_total, pshift, self.max_hash)
-        self._pairs = (hashes_in, refs_in)  # keep alive until the handle has consumed them
-        nshared = self.post["nshared"]()
-        dist.all_reduce(nshared, op=dist.ReduceOp.SUM, group=group)
-        self.nshared = nshared
-
-    def run(self, sample_t):
-        """(overlap, n_exclusive, n_matches) for ALL references, identical on every rank;
-        exclusivity is relative to the references with overlap > 0, wherever they live."""
-        import torch
-        import torch.distributed as dist
-
-        ov_local = self.ref["overlap"](sample_t)
-        overlap = gather_counts(ov_local.unsqueeze(0), self.plan, group=self.group)[0].contiguous()
-        mask = (overlap != 0).to(torch.uint8).contiguous()
-        sums = self.post["partial"](mask, sample_t)
-        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=self.group)
-        e, m = self.post["finalize"](mask, self.sizes, self.nshared, overlap, sums)
-        return overlap, e, m
-
-    def close(self):
-        for part in (self.ref, self.post):
-            h = part.get("handle")
-            if h is not None:
-                h.close()
 
 
 # ======================================================================================================
 # The `yacht run` step over ranks with ONE small exchange: ghosts (include/yacht_hip.h, "references
 # spread over several GPUs, the `yacht run` subset")
 # ======================================================================================================
-# ShardedRun above answers exclusivity for an ARBITRARY subset and pays for it: an all-gather of the
-# counts and an all-reduce of [3, N_total] per sample.  `yacht run` only ever asks for the subset
+# overlap_j needs only rank-local data, but "hash h of R_j is held by no other overlapping reference" is a
+# global statement: the other holder may live on another rank.  `yacht run` only ever asks for the subset
 # "overlap > 0" (hypothesis_recovery_src.py:361-378), and for that subset a rank can finish its own
 # references alone once its index knows every holder of every hash it holds -- including holders on
 # other ranks -- and one bit per foreign holder: does it overlap the sample at all?  So, once per
-# database, the hash-range owners (same all_to_all as above) send back, for every hash with holders on
+# database, every rank sends its (hash, reference) pairs to the owner of the hash's range (all_to_all), and the
+# owners send back, for every hash with holders on
 # more than one rank, the foreign postings to each holder's rank; a rank appends those foreign
 # references as GHOSTS (extra references holding only such hashes) behind its own, and the library
 # builds the usual handle over the lot.  Per sample: local lookup + reduce -> all-gather of the subset

@@ -43,7 +43,7 @@ def _ptr(a: Optional[np.ndarray]) -> C.c_void_p:
 
 
 class RefDB:
-    """Reference sketches in HBM: hash-range partitioned CSR + shared-hash inverted index."""
+    """Reference sketches in HBM: delta stream, bucket table + presence filter, shared-hash inverted index."""
 
     def __init__(self, values, offsets, device: int = 0, flags: int = YH_DB_DEFAULT, partitions_hint: int = 0):
         self._h = C.c_void_p(0)
@@ -82,37 +82,6 @@ class RefDB:
         self.n_refs = n_refs
         self.sizes = sizes
         return self
-
-    @classmethod
-    def from_pairs(cls, d_hashes: int, d_refs: int, n_pairs: int, n_refs_total: int, partition_shift: int,
-                   max_hash: int, device: int = 0) -> "RefDB":
-        """Posting-list-only handle over (hash, global reference id) pairs already in HBM: one
-        hash-range shard of a database whose references are spread over several GPUs.  Supports
-        exclusive_partial_device / nshared_device / exclusive_finalize_device only."""
-        self = cls.__new__(cls)
-        self._h = C.c_void_p(0)
-        lib = _lib.load()
-        h = C.c_void_p(0)
-        _lib.check(lib.yh_db_create_from_pairs(C.c_void_p(d_hashes), C.c_void_p(d_refs), n_pairs, n_refs_total,
-                                               device, partition_shift, max_hash, C.byref(h)))
-        self._h = h
-        self._lib = lib
-        self.n_refs = n_refs_total
-        self.sizes = None
-        return self
-
-    def exclusive_partial_device(self, d_mask: int, d_sample: int, n_sample: int, d_ex_e: int, d_ex_m: int,
-                                 d_ovsh: int) -> None:
-        _lib.check(self._lib.yh_exclusive_partial_device(self._h, C.c_void_p(d_mask), C.c_void_p(d_sample), n_sample,
-                                                         C.c_void_p(d_ex_e), C.c_void_p(d_ex_m), C.c_void_p(d_ovsh)))
-
-    def nshared_device(self, d_out: int) -> None:
-        _lib.check(self._lib.yh_db_nshared_device(self._h, C.c_void_p(d_out)))
-
-    def exclusive_finalize_device(self, n: int, d_mask: int, d_sizes: int, d_nshared: int, d_overlap: int,
-                                  d_ex_e: int, d_ex_m: int, d_ovsh: int, d_e: int, d_m: int) -> None:
-        _lib.check(self._lib.yh_exclusive_finalize_device(self._h, n, *(C.c_void_p(x) for x in (
-            d_mask, d_sizes, d_nshared, d_overlap, d_ex_e, d_ex_m, d_ovsh, d_e, d_m))))
 
     # ---- lifetime ---------------------------------------------------------------------------
     def close(self) -> None:
@@ -254,6 +223,10 @@ class RefDB:
                                            C.c_void_p(d_excl), C.c_void_p(d_match)))
 
     # ---- yacht train -------------------------------------------------------------------------
+    def nshared_device(self, d_out: int) -> None:
+        """d_out[j] = shared hashes of reference j (device array of n_refs uint32): the row weights of the pairwise pass."""
+        _lib.check(self._lib.yh_db_nshared_device(self._h, C.c_void_p(d_out)))
+
     def pairwise(self, c_thresh: float, row_begin: int = 0, row_end: Optional[int] = None):
         """Ordered pairs (i, j, |R_i ∩ R_j|) with !(count/|R_i| < c_thresh), sorted by (i, j)."""
         if row_end is None:

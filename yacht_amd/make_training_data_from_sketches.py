@@ -65,22 +65,39 @@ def _extract_members(job) -> int:
 
     zip_path, workdir, names = job
     made = set()
+    root = os.path.normpath(workdir)
+
+    def inside(member: str) -> str:  # the member's path, which must stay inside the working directory (directories too)
+        path = os.path.normpath(os.path.join(workdir, member))
+        if path != root and not path.startswith(root + os.sep):
+            raise ValueError(f"archive member outside the working directory: {member}")
+        return path
+
+    def inflate(data: bytes):  # every member of a (possibly concatenated) gzip stream, as gzip / yh_gunzip_files read it
+        out = []
+        while data:
+            d = zlib.decompressobj(31)
+            out.append(d.decompress(data))
+            out.append(d.flush())
+            if not d.eof:
+                raise zlib.error("truncated gzip member")
+            data = d.unused_data
+        return b"".join(out)
+
     with zipfile.ZipFile(zip_path, "r") as archive:
         for n in names:
             if n.endswith("/"):
-                os.makedirs(os.path.join(workdir, n), exist_ok=True)
+                os.makedirs(inside(n), exist_ok=True)
                 continue
             data = archive.read(n)
             out = n
             if n.endswith(".sig.gz"):
                 try:
-                    data = zlib.decompress(data, 31)
+                    data = inflate(data)
                     out = n[:-3]
                 except zlib.error:
                     pass
-            path = os.path.normpath(os.path.join(workdir, out))
-            if not path.startswith(os.path.normpath(workdir) + os.sep):
-                raise ValueError(f"archive member outside the working directory: {n}")
+            path = inside(out)
             d = os.path.dirname(path)
             if d not in made:
                 os.makedirs(d, exist_ok=True)
