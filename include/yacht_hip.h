@@ -239,6 +239,33 @@ int yh_run_finish_device(yh_db* db, int ctx, const uint32_t* d_global_bits, uint
 int yh_run_submit(yh_db* db, int slot, const uint64_t* sample, uint64_t n_sample,
                   uint32_t* overlap, uint32_t* n_excl, uint32_t* n_match);
 int yh_run_wait(yh_db* db, int slot);
+/* The same call with less on the wire (SURVEY.md 8d counts sample H2D + kernels + counts D2H; at 10^6-hash samples the
+ * step is bound by the 8 MB of PCIe upload, not by its 45 us of kernels):
+ *   packed sample   yh_sample_pack turns a strictly ascending sketch into ~4.7 bytes per hash (blocks of 256: first hash +
+ *                   255 bit-packed gaps at the width of the block's largest); done ONCE where the sketch is parsed
+ *                   (run_YACHT.py:150-165 loads a sample once), any thread, no device.  yh_run_submit_packed uploads
+ *                   that and expands it in HBM in front of the lookup; the expansion also checks the ordering, so a
+ *                   forged buffer ends in YH_ERR_UNSORTED (structure errors: YH_ERR_INVALID_ARG at submit).
+ *                   yh_sample_pack_bound(n) bytes always suffice; two-call sizing with packed = NULL, cap = 0.
+ *                   yh_sample_unpack is the host-side inverse (tools, tests).
+ *   compact rows    instead of three dense rows of N counts: one yh_run_row per reference with overlap > 0, ascending by
+ *                   reference -- what hypothesis_recovery consumes (hypothesis_recovery_src.py:361-378).  yh_run_wait_rows
+ *                   returns their number; YH_ERR_CAPACITY (with *n_rows = the number needed, rows[0, cap) valid) when the
+ *                   buffer was too small.  A page-locked row buffer is written by the kernel itself through PCIe.
+ * yh_run_submit_rows = unpacked upload, compact rows back.  All three submit forms share the slots and complete in
+ * submission order; yh_run_wait works for every form (it drops the row count).
+ * yh_run_rows_device: the compact rows of the step that has just been queued on the handle (yh_run_device and its
+ * relatives) from its three device count rows, on the handle's stream; d_n_rows receives their number (which may
+ * exceed cap_rows: rows beyond the capacity are not written).                                                   */
+typedef struct yh_run_row { uint32_t ref, overlap, n_excl, n_match; } yh_run_row;
+uint64_t yh_sample_pack_bound(uint64_t n_sample);
+int yh_sample_pack(const uint64_t* sample, uint64_t n_sample, void* packed, uint64_t cap_bytes, uint64_t* packed_bytes);
+int yh_sample_unpack(const void* packed, uint64_t packed_bytes, uint64_t* sample_out, uint64_t cap, uint64_t* n_sample);
+int yh_run_submit_packed(yh_db* db, int slot, const void* packed, uint64_t packed_bytes, yh_run_row* rows, uint64_t cap_rows);
+int yh_run_submit_rows(yh_db* db, int slot, const uint64_t* sample, uint64_t n_sample, yh_run_row* rows, uint64_t cap_rows);
+int yh_run_wait_rows(yh_db* db, int slot, uint64_t* n_rows);
+int yh_run_rows_device(yh_db* db, const uint32_t* d_overlap, const uint32_t* d_n_excl, const uint32_t* d_n_match,
+                       yh_run_row* d_rows, uint64_t cap_rows, uint32_t* d_n_rows);
 /* Page-locked host memory for the buffers above (hipHostMalloc / hipHostFree).                */
 int yh_host_alloc(void** out, uint64_t bytes);
 int yh_host_free(void* p);

@@ -132,3 +132,150 @@ def test_own_stream_is_ordered_with_the_default_stream(hip_lib):
             got = big[:, :n].cpu().numpy().view(np.uint32)  # no db.synchronize(): the copy is ordered behind the step
             assert np.array_equal(got[0], want_ov) and np.array_equal(got[1], want_e) and np.array_equal(got[2], want_m)
             assert int(big[0, n]) == 7
+
+
+def _rows_of(ov, e, m):
+    keep = np.flatnonzero(ov)
+    return keep.astype(np.uint32), ov[keep], e[keep], m[keep]
+
+
+@pytest.mark.parametrize("pinned", [True, False])
+def test_packed_upload_and_compact_rows(hip_lib, pinned):
+    """yh_run_submit_packed / yh_run_submit_rows / yh_run_wait_rows mixed with the dense form over all slots: the rows
+    are exactly the references with overlap > 0, ascending, with the oracle's three counts; the packed sample is expanded
+    on the device to the hashes it was made from."""
+    from yacht_amd.engine import ROW_DTYPE, pack_sample
+
+    rng = np.random.default_rng(21)
+    values, offsets = _db(seed=6, n_refs=5000)
+    n = offsets.size - 1
+    samples = _samples(values, offsets, 5, rng) + [np.zeros(0, np.uint64), np.array([5], np.uint64),
+                                                   np.unique(np.concatenate([values[::3], np.array([0, 2**64 - 1], np.uint64)]))]
+    want = []
+    for s in samples:
+        ov = oracle.overlap(values, offsets, s)
+        e, m = oracle.exclusive(values, offsets, ov > 0, s)
+        want.append((ov, e, m))
+    keep = []
+
+    def buf(k, dt):
+        if pinned:
+            pa = PinnedArray(k, dt)
+            keep.append(pa)
+            return pa.array
+        return np.zeros(k, dt)
+
+    with RefDB(values, offsets) as db:
+        depth = _lib.YH_RUN_SLOTS
+        rows = [buf(n, ROW_DTYPE) for _ in range(depth)]
+        dense = [[buf(n, np.uint32) for _ in range(3)] for _ in range(depth)]
+        held = [None] * depth
+        order = [(int(rng.integers(0, len(samples))), int(rng.integers(0, 3))) for _ in range(60)]
+        for i, job in enumerate(order + [None] * depth):
+            slot = i % depth
+            if i >= depth:
+                si, form = order[i - depth]
+                w = want[si]
+                if form == 2:
+                    db.run_wait(slot)
+                    assert all(np.array_equal(dense[slot][k], w[k]) for k in range(3)), f"call {i - depth}"
+                else:
+                    k = db.run_wait_rows(slot)
+                    ref, ov, e, m = _rows_of(*w)
+                    got = rows[slot][:k]
+                    assert k == ref.size and np.array_equal(got["ref"], ref) and np.array_equal(got["overlap"], ov), f"call {i - depth}"
+                    assert np.array_equal(got["n_excl"], e) and np.array_equal(got["n_match"], m), f"call {i - depth}"
+            if job is not None:
+                si, form = job
+                s = samples[si]
+                if form == 0:    # packed up, rows back
+                    p = pack_sample(s)
+                    h = buf(max(p.size, 1), np.uint8)[: p.size]
+                    h[:] = p
+                    held[slot] = h
+                    db.run_submit_packed(slot, h, rows[slot])
+                elif form == 1:  # raw up, rows back
+                    h = buf(max(s.size, 1), np.uint64)[: s.size]
+                    h[:] = s
+                    held[slot] = h
+                    db.run_submit_rows(slot, h, rows[slot])
+                else:            # raw up, dense rows back
+                    h = buf(max(s.size, 1), np.uint64)[: s.size]
+                    h[:] = s
+                    held[slot] = h
+                    db.run_submit(slot, h, *dense[slot])
+        # the synchronous convenience form, both uploads
+        for packed in (True, False):
+            got = db.run_rows(samples[1], packed=packed)
+            ref, ov, e, m = _rows_of(*want[1])
+            assert np.array_equal(got["ref"], ref) and np.array_equal(got["overlap"], ov)
+            assert np.array_equal(got["n_excl"], e) and np.array_equal(got["n_match"], m)
+        # a row buffer that is too small: the number needed comes back with YH_ERR_CAPACITY, the first rows are valid
+        small = buf(3, ROW_DTYPE)
+        db.run_submit_packed(0, pack_sample(samples[0]), small)
+        with pytest.raises(_lib.YachtHipError) as ei:
+            db.run_wait_rows(0)
+        assert ei.value.code == _lib.YH_ERR_CAPACITY
+        ref, ov, e, m = _rows_of(*want[0])
+        assert np.array_equal(small["ref"], ref[:3]) and np.array_equal(small["overlap"], ov[:3])
+    for pa in keep:
+        pa.close()
+
+
+def test_forged_packed_samples_are_refused(hip_lib):
+    """Structure errors are caught at submit (YH_ERR_INVALID_ARG); an ordering the format cannot promise -- blocks that do
+    not ascend, a gap that wraps past 2^64 -- by the expansion kernel (YH_ERR_UNSORTED at wait, nothing looked up)."""
+    from yacht_amd.engine import ROW_DTYPE, pack_sample
+
+    rng = np.random.default_rng(4)
+    values, offsets = _db(seed=9)
+    good = _samples(values, offsets, 1, rng)[0]
+    p = pack_sample(good)
+    n = offsets.size - 1
+    with RefDB(values, offsets) as db:
+        rows = np.zeros(n, dtype=ROW_DTYPE)
+        for bad in (p[:-8], p[:16]):
+            with pytest.raises(_lib.YachtHipError) as ei:
+                db.run_submit_packed(0, np.ascontiguousarray(bad), rows)
+            assert ei.value.code == _lib.YH_ERR_INVALID_ARG
+        forged = p.copy()
+        forged[32 + 16: 32 + 24] = 0          # first hash of block 1 = 0: not above block 0's last
+        db.run_submit_packed(0, forged, rows)
+        with pytest.raises(_lib.YachtHipError) as ei:
+            db.run_wait_rows(0)
+        assert ei.value.code == _lib.YH_ERR_UNSORTED
+        wrap = pack_sample(np.array([2**64 - 10, 2**64 - 5, 2**64 - 1], dtype=np.uint64)).copy()
+        wrap[32: 32 + 8] = np.frombuffer(np.uint64(2**64 - 3).tobytes(), dtype=np.uint8)   # base so high that the gaps wrap
+        db.run_submit_packed(1, wrap, rows)
+        with pytest.raises(_lib.YachtHipError) as ei:
+            db.run_wait_rows(1)
+        assert ei.value.code == _lib.YH_ERR_UNSORTED
+        got = db.run_rows(good)               # the handle is fine afterwards
+        ov = oracle.overlap(values, offsets, good)
+        assert np.array_equal(got["ref"], np.flatnonzero(ov)) and np.array_equal(got["overlap"], ov[ov > 0])
+
+
+def test_rows_of_a_device_resident_step(hip_lib):
+    import torch
+
+    from yacht_amd.engine import ROW_DTYPE
+
+    rng = np.random.default_rng(8)
+    values, offsets = _db(seed=12, n_refs=3000)
+    n = offsets.size - 1
+    s_h = _samples(values, offsets, 1, rng)[0]
+    ov = oracle.overlap(values, offsets, s_h)
+    e, m = oracle.exclusive(values, offsets, ov > 0, s_h)
+    s = torch.from_numpy(s_h.view(np.int64).copy()).cuda()
+    c = torch.zeros(3, n, dtype=torch.int32, device="cuda")
+    rows = torch.zeros(n, 4, dtype=torch.int32, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    with RefDB(values, offsets) as db:
+        db.run_device(s.data_ptr(), s.numel(), c[0].data_ptr(), c[1].data_ptr(), c[2].data_ptr())
+        db.run_rows_device(c[0].data_ptr(), c[1].data_ptr(), c[2].data_ptr(), rows.data_ptr(), n, cnt.data_ptr())
+        db.synchronize()
+        k = int(cnt.item())
+        got = rows[:k].cpu().numpy().view(np.uint32)
+        ref = np.flatnonzero(ov)
+        assert k == ref.size and np.array_equal(got[:, 0], ref) and np.array_equal(got[:, 1], ov[ref])
+        assert np.array_equal(got[:, 2], e[ref]) and np.array_equal(got[:, 3], m[ref])

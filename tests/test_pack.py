@@ -1,0 +1,66 @@
+"""The packed sample format (yh_sample_pack / yh_sample_unpack, host code of the C ABI): round trips, sizes, refusals.
+No GPU needed.  The device-side expansion and the compact rows are checked in tests/test_gpu_pipeline.py."""
+import numpy as np
+import pytest
+
+from yacht_amd import _lib, synth
+from yacht_amd.engine import pack_sample, unpack_sample
+
+
+def _roundtrip(a):
+    a = np.asarray(a, dtype=np.uint64)
+    p = pack_sample(a)
+    assert np.array_equal(unpack_sample(p), a)
+    return p
+
+
+def test_roundtrip_shapes():
+    rng = np.random.default_rng(1)
+    mh = synth.max_hash_for_scaled(1000)
+    for n in (0, 1, 2, 255, 256, 257, 511, 512, 513, 100_000):
+        _roundtrip(np.unique(rng.integers(0, mh, size=n, dtype=np.uint64))[:n])
+    _roundtrip([0, 1, 2, 3])                                          # gaps of 0 bits
+    _roundtrip(np.arange(1000, dtype=np.uint64) * np.uint64(7))       # constant gaps
+    _roundtrip([0, 2**64 - 1])                                        # a 64-bit gap
+    _roundtrip([5, 2**63, 2**63 + 1, 2**64 - 2, 2**64 - 1])
+    big = np.concatenate([np.arange(300, dtype=np.uint64), np.array([2**64 - 1], dtype=np.uint64)])
+    _roundtrip(big)                                                   # one block of tiny gaps, then a huge one
+
+
+def test_size_of_a_metagenome_sketch():
+    """10^6 uniform hashes at scaled = 1000: ~37 bits per gap + 16 bytes per 256 -> under 4.8 bytes per hash."""
+    rng = np.random.default_rng(2)
+    a = np.unique(rng.integers(0, synth.max_hash_for_scaled(1000), size=1_000_000, dtype=np.uint64))
+    p = _roundtrip(a)
+    assert p.size < 4.8 * a.size, p.size / a.size
+    assert p.size <= _lib.load().yh_sample_pack_bound(a.size)
+
+
+def test_refusals():
+    with pytest.raises(_lib.YachtHipError) as e:
+        pack_sample([3, 3])
+    assert e.value.code == _lib.YH_ERR_UNSORTED
+    with pytest.raises(_lib.YachtHipError):
+        pack_sample(np.concatenate([np.arange(300, dtype=np.uint64), np.array([10], dtype=np.uint64)]))  # descent across blocks
+    good = pack_sample(np.arange(0, 5000, 3, dtype=np.uint64))
+    for bad in (good[:-8], good[:20], np.concatenate([good, np.zeros(8, np.uint8)])):
+        with pytest.raises(_lib.YachtHipError) as e:
+            unpack_sample(bad)
+        assert e.value.code == _lib.YH_ERR_INVALID_ARG
+    forged = good.copy()
+    forged[0] ^= 1                                                    # magic
+    with pytest.raises(_lib.YachtHipError):
+        unpack_sample(forged)
+    forged = good.copy()
+    forged[32 + 12] = 99                                              # width of block 0 > 64
+    with pytest.raises(_lib.YachtHipError):
+        unpack_sample(forged)
+    forged = good.copy()
+    forged[32 + 16: 32 + 24] = 0                                      # base of block 1 = 0: blocks not ascending
+    with pytest.raises(_lib.YachtHipError) as e:
+        unpack_sample(forged)
+    assert e.value.code == _lib.YH_ERR_UNSORTED
+    small = np.zeros(8, dtype=np.uint8)
+    with pytest.raises(_lib.YachtHipError) as e:
+        pack_sample(np.arange(100, dtype=np.uint64), out=small)
+    assert e.value.code == _lib.YH_ERR_CAPACITY

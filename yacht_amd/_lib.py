@@ -112,6 +112,13 @@ SIGNATURES = {
     "yh_run_finish_device": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "yh_run_submit": (C.c_int, [_vp, C.c_int, _vp, C.c_uint64, _vp, _vp, _vp]),
     "yh_run_wait": (C.c_int, [_vp, C.c_int]),
+    "yh_sample_pack_bound": (C.c_uint64, [C.c_uint64]),
+    "yh_sample_pack": (C.c_int, [_vp, C.c_uint64, _vp, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "yh_sample_unpack": (C.c_int, [_vp, C.c_uint64, _vp, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "yh_run_submit_packed": (C.c_int, [_vp, C.c_int, _vp, C.c_uint64, _vp, C.c_uint64]),
+    "yh_run_submit_rows": (C.c_int, [_vp, C.c_int, _vp, C.c_uint64, _vp, C.c_uint64]),
+    "yh_run_wait_rows": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_uint64)]),
+    "yh_run_rows_device": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_uint64, _vp]),
     "yh_host_alloc": (C.c_int, [C.POINTER(_vp), C.c_uint64]),
     "yh_host_free": (C.c_int, [_vp]),
     "yh_db_nshared_device": (C.c_int, [_vp, _vp]),

@@ -293,6 +293,8 @@ int yh_db_destroy(yh_db* db) {
     if (db->st_in) (void)hipStreamSynchronize(db->st_in);
     for (RunSlot& s : db->slots) {
         if (s.d_sample) (void)hipFree(s.d_sample);
+        if (s.d_packed) (void)hipFree(s.d_packed);
+        if (s.d_rows) (void)hipFree(s.d_rows);
         if (s.d_out) (void)hipFree(s.d_out);
         if (s.d_bad) (void)hipFree(s.d_bad);
         if (s.h_bad) (void)hipHostFree(s.h_bad);
@@ -757,7 +759,7 @@ int yh_run_finish_device(yh_db* db, int ctx, const uint32_t* d_global_bits, uint
 }
 
 // ---- pipelined host-buffer run calls ---------------------------------------------------------------
-static int slot_prepare(yh_db* db, RunSlot& s, u64 n_sample) {
+static int slot_prepare(yh_db* db, RunSlot& s, u64 n_sample, u64 packed_bytes, bool rows_staging) {
     const u64 N = std::max<u64>(db->n_refs, 1);
     if (!db->st_in) YH_HIP(hipStreamCreateWithFlags(&db->st_in, hipStreamNonBlocking));
     if (!s.ev_up) {
@@ -768,6 +770,7 @@ static int slot_prepare(yh_db* db, RunSlot& s, u64 n_sample) {
     if (!s.d_bad) {
         YH_TRY(yh_dmalloc(db, (void**)&s.d_bad, 16));
         YH_HIP(hipMemsetAsync(s.d_bad, 0, 16, db->stream));
+        // two page-locked words the kernels write through PCIe: [0] the ordering verdict, [1] the number of rows
         YH_HIP(hipHostMalloc((void**)&s.h_bad, 16, hipHostMallocDefault));
         YH_HIP(hipHostGetDevicePointer((void**)&s.h_bad_dev, s.h_bad, 0));
     }
@@ -777,31 +780,57 @@ static int slot_prepare(yh_db* db, RunSlot& s, u64 n_sample) {
         YH_HIP(hipMalloc((void**)&s.d_sample, cap * sizeof(u64)));
         s.cap = cap;
     }
+    if (s.packed_cap < packed_bytes) {
+        if (s.d_packed) { (void)hipFree(s.d_packed); s.d_packed = nullptr; s.packed_cap = 0; }
+        const u64 cap = packed_bytes + packed_bytes / 8 + 4096;
+        YH_HIP(hipMalloc(&s.d_packed, cap));
+        s.packed_cap = cap;
+    }
+    if (rows_staging && !s.d_rows) YH_TRY(yh_dmalloc(db, (void**)&s.d_rows, N * sizeof(uint4)));
     return YH_OK;
 }
 
-int yh_run_submit(yh_db* db, int slot, const uint64_t* sample, uint64_t n_sample, uint32_t* overlap,
-                  uint32_t* n_excl, uint32_t* n_match) {
+// One call in flight: upload (raw u64 hashes, or a packed sample that is expanded in HBM) on the copy-in stream; ordering
+// check + kernels + the way back (three dense count rows, or the compact rows of the references with overlap > 0) on the
+// handle's stream.
+static int submit_common(yh_db* db, int slot, const void* sample, u64 n_or_bytes, bool packed, bool want_rows,
+                         uint32_t* overlap, uint32_t* n_excl, uint32_t* n_match, yh_run_row* rows, u64 cap_rows) {
     if (!db_ok(db)) return YH_ERR_INVALID_ARG;
     if (slot < 0 || slot >= YH_RUN_SLOTS) { yh_set_error("slot %d out of range [0, %d)", slot, YH_RUN_SLOTS); return YH_ERR_INVALID_ARG; }
     const u64 N = db->n_refs;
-    if ((N && (!overlap || !n_excl || !n_match)) || (n_sample && !sample)) { yh_set_error("null argument"); return YH_ERR_INVALID_ARG; }
-    if (!db->has_index || !db->d_sdelta) { yh_set_error("yh_run_submit needs the default layout with its index"); return YH_ERR_UNSUPPORTED; }
+    if (!want_rows && N && (!overlap || !n_excl || !n_match)) { yh_set_error("null argument"); return YH_ERR_INVALID_ARG; }
+    if (want_rows && cap_rows && !rows) { yh_set_error("null row buffer"); return YH_ERR_INVALID_ARG; }
+    if (n_or_bytes && !sample) { yh_set_error("null argument"); return YH_ERR_INVALID_ARG; }
+    if (!db->has_index || !db->d_sdelta) { yh_set_error("the pipelined run calls need a non-empty handle in the default layout with its index"); return YH_ERR_UNSUPPORTED; }
+    u64 n_sample = n_or_bytes, packed_bytes = 0;
+    if (packed) {
+        packed_bytes = n_or_bytes;
+        YH_TRY(yh_pack_validate(sample, packed_bytes, &n_sample));
+    }
     if (n_sample > 0xfffffff0ull) { yh_set_error("sample larger than 2^32-16 hashes"); return YH_ERR_INVALID_ARG; }
     RunSlot& s = db->slots[slot];
     if (s.busy) { yh_set_error("slot %d is in flight: yh_run_wait it first", slot); return YH_ERR_INVALID_ARG; }
     YH_TRY(db_select(db));
-    YH_TRY(slot_prepare(db, s, n_sample));
-    // upload on the copy-in stream (SDMA: overlaps the kernels of the call in front)
-    *s.h_bad = 0;
-    if (n_sample) YH_HIP(hipMemcpyAsync(s.d_sample, sample, n_sample * sizeof(u64), hipMemcpyHostToDevice, db->st_in));
+    note_other_query(db);
+    void* rows_dev = nullptr;  // where k_compact_rows stores: the caller's page-locked buffer, or the slot's staging rows
+    if (want_rows && cap_rows) rows_dev = device_view_of_host(rows);
+    const bool rows_staged = want_rows && cap_rows && !rows_dev;
+    YH_TRY(slot_prepare(db, s, n_sample, packed_bytes, rows_staged));
+    s.h_bad[0] = 0;
+    s.h_bad[1] = 0;
+    if (packed) {
+        if (packed_bytes) YH_HIP(hipMemcpyAsync(s.d_packed, sample, packed_bytes, hipMemcpyHostToDevice, db->st_in));
+    } else if (n_sample) {
+        YH_HIP(hipMemcpyAsync(s.d_sample, sample, n_sample * sizeof(u64), hipMemcpyHostToDevice, db->st_in));
+    }
     YH_HIP(hipEventRecord(s.ev_up, db->st_in));
-    // ordering check + kernels + download on the handle's stream, behind the upload.  (The download stays
-    // on this stream: HIP moves device -> pinned host with blit kernels, and a third stream only added
-    // cross-stream waits in front of every step -- traced, profiles/r02/host_pipeline_trace.txt.)
+    // (The way back stays on the handle's stream: HIP moves device -> pinned host with blit kernels, and a third stream
+    // only added cross-stream waits in front of every step -- traced in round 2.)
     YH_HIP(hipStreamWaitEvent(db->stream, s.ev_up, 0));
     const u32 gen = next_gen(db);
-    if (n_sample > 1)
+    if (packed)
+        YH_TRY(yh_pack_expand_device(db, s.d_packed, n_sample, s.d_sample, s.d_bad, gen, s.h_bad_dev));
+    else if (n_sample > 1)
         k_check_ascending2<<<(unsigned)std::min<u64>((n_sample + 255) / 256, 2048), 256, 0, db->stream>>>(s.d_sample, n_sample, s.d_bad,
                                                                                                          gen, s.h_bad_dev);
     int rc = YH_OK;
@@ -811,12 +840,18 @@ int yh_run_submit(yh_db* db, int slot, const uint64_t* sample, uint64_t n_sample
         db->d_bad = nullptr;
     }
     if (rc != YH_OK) return rc;
-    if (N) {
+    s.rows_cap = cap_rows;
+    s.rows_mode = want_rows;
+    if (want_rows) {
+        YH_TRY(yh_rows_compact_device(db, s.d_out, s.d_out + N, s.d_out + 2 * N, rows_staged ? (void*)s.d_rows : rows_dev,
+                                      cap_rows, nullptr, s.h_bad_dev + 1));
+        if (rows_staged && N)  // pageable row buffer: as many rows as it holds (their number is not known on the host yet)
+            YH_HIP(hipMemcpyAsync(rows, s.d_rows, std::min<u64>(cap_rows, N) * sizeof(uint4), hipMemcpyDeviceToHost, db->stream));
+    } else if (N) {
         const bool one_block = n_excl == overlap + N && n_match == n_excl + N;  // one contiguous [3][N] host buffer
         void* dv = nullptr;
-        if (one_block && (3 * N) % 4 == 0 && ((uintptr_t)overlap & 15u) == 0) {
+        if (one_block && (3 * N) % 4 == 0 && ((uintptr_t)overlap & 15u) == 0)
             dv = device_view_of_host(overlap);  // asked on every call: the same address may be pageable memory by now
-        }
         if (dv) {
             k_copy_out<<<(unsigned)std::min<u64>((3 * N / 4 + 255) / 256, 512), 256, 0, db->stream>>>(
                 reinterpret_cast<const uint4*>(s.d_out), reinterpret_cast<uint4*>(dv), 3 * N / 4);
@@ -833,7 +868,18 @@ int yh_run_submit(yh_db* db, int slot, const uint64_t* sample, uint64_t n_sample
     return YH_OK;
 }
 
-int yh_run_wait(yh_db* db, int slot) {
+int yh_run_submit(yh_db* db, int slot, const uint64_t* sample, uint64_t n_sample, uint32_t* overlap,
+                  uint32_t* n_excl, uint32_t* n_match) {
+    return submit_common(db, slot, sample, n_sample, false, false, overlap, n_excl, n_match, nullptr, 0);
+}
+int yh_run_submit_rows(yh_db* db, int slot, const uint64_t* sample, uint64_t n_sample, yh_run_row* rows, uint64_t cap_rows) {
+    return submit_common(db, slot, sample, n_sample, false, true, nullptr, nullptr, nullptr, rows, cap_rows);
+}
+int yh_run_submit_packed(yh_db* db, int slot, const void* packed, uint64_t packed_bytes, yh_run_row* rows, uint64_t cap_rows) {
+    return submit_common(db, slot, packed, packed_bytes, true, true, nullptr, nullptr, nullptr, rows, cap_rows);
+}
+
+static int wait_common(yh_db* db, int slot, uint64_t* n_rows) {
     if (!db_ok(db)) return YH_ERR_INVALID_ARG;
     if (slot < 0 || slot >= YH_RUN_SLOTS) { yh_set_error("slot %d out of range [0, %d)", slot, YH_RUN_SLOTS); return YH_ERR_INVALID_ARG; }
     RunSlot& s = db->slots[slot];
@@ -841,8 +887,31 @@ int yh_run_wait(yh_db* db, int slot) {
     YH_TRY(db_select(db));
     s.busy = false;
     YH_HIP(hipEventSynchronize(s.ev_out));
-    if (*(volatile u32*)s.h_bad) { yh_set_error("the sample sketch is not strictly ascending"); return YH_ERR_UNSORTED; }
+    if (n_rows) *n_rows = 0;
+    if (((volatile u32*)s.h_bad)[0]) { yh_set_error("the sample sketch is not strictly ascending"); return YH_ERR_UNSORTED; }
+    if (s.rows_mode) {
+        const u64 n = ((volatile u32*)s.h_bad)[1];
+        if (n_rows) *n_rows = n;
+        if (n > s.rows_cap) {
+            yh_set_error("row buffer holds %llu rows, %llu references overlap the sample", (u64)s.rows_cap, n);
+            return YH_ERR_CAPACITY;
+        }
+    }
     return YH_OK;
+}
+int yh_run_wait(yh_db* db, int slot) { return wait_common(db, slot, nullptr); }
+int yh_run_wait_rows(yh_db* db, int slot, uint64_t* n_rows) {
+    if (!n_rows) { yh_set_error("n_rows is null"); return YH_ERR_INVALID_ARG; }
+    return wait_common(db, slot, n_rows);
+}
+
+// the compact rows of the step that just ran on the handle (yh_run_device and its relatives): device-resident form
+int yh_run_rows_device(yh_db* db, const uint32_t* d_overlap, const uint32_t* d_n_excl, const uint32_t* d_n_match,
+                       yh_run_row* d_rows, uint64_t cap_rows, uint32_t* d_n_rows) {
+    if (!db_ok(db)) return YH_ERR_INVALID_ARG;
+    if (!d_n_rows || (db->n_refs && (!d_overlap || !d_n_excl || !d_n_match)) || (cap_rows && !d_rows)) { yh_set_error("null device pointer"); return YH_ERR_INVALID_ARG; }
+    YH_TRY(db_select(db));
+    return yh_rows_compact_device(db, d_overlap, d_n_excl, d_n_match, d_rows, cap_rows, d_n_rows, nullptr);
 }
 
 int yh_host_alloc(void** out, uint64_t bytes) {

@@ -69,9 +69,14 @@ struct EventRing {
 struct RunSlot {
     u64* d_sample = nullptr;
     u64 cap = 0;
+    void* d_packed = nullptr; // a packed sample as uploaded (yh_run_submit_packed), expanded into d_sample
+    u64 packed_cap = 0;
+    uint4* d_rows = nullptr;  // [N] staging of the compact rows when the caller's row buffer is pageable
+    u64 rows_cap = 0;         // capacity of the caller's row buffer of the call in flight
+    bool rows_mode = false;   // the call in flight returns compact rows
     u32* d_out = nullptr;     // [3][N] overlap, n_excl, n_match
     u32* d_bad = nullptr;     // [1] set by the ordering check queued in front of the kernels
-    u32* h_bad = nullptr;     // page-locked host word the check kernel also writes (zero-copy), read by yh_run_wait
+    u32* h_bad = nullptr;     // page-locked host words the kernels write through PCIe: [0] ordering verdict, [1] number of rows
     u32* h_bad_dev = nullptr; // its device address
     hipEvent_t ev_up = nullptr, ev_out = nullptr;
     bool busy = false;
@@ -219,6 +224,12 @@ struct yh_db {
 // ---- implemented in yh_build.hip -------------------------------------------------------------
 int yh_build_validate(yh_db* db, const u64* d_values, const u64* d_offsets);  // ordering check, sizes, largest hash
 int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets);
+
+// ---- implemented in yh_pack.hip ----------------------------------------------------------------
+int yh_pack_validate(const void* packed, u64 bytes, u64* n_out);
+int yh_pack_expand_device(yh_db* db, const void* d_packed, u64 n, u64* d_out, u32* d_bad, u32 gen, u32* h_bad_dev);
+int yh_rows_compact_device(yh_db* db, const u32* d_overlap, const u32* d_excl, const u32* d_match, void* rows_dev, u64 cap,
+                           u32* count_dev, u32* count_host_dev);
 
 // ---- implemented in yh_query.hip -------------------------------------------------------------
 int yh_q_overlap(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap, bool flag_shared, bool make_mask);

@@ -1,0 +1,322 @@
+// yh_pack.hip — the two ends of the host-buffer `yacht run` step that cross PCIe (sample H2D + kernels +
+// counts D2H), made small:
+//
+//   packed sample    a sorted sketch of n hashes in ~4.7 bytes per hash instead of 8.  Blocks of 256 hashes; a block is
+//                    its first hash (8 bytes) and 255 gaps (h[i] - h[i-1] - 1, so "strictly ascending" is structural)
+//                    bit-packed at the width of the block's largest gap.  FracMinHash hashes are uniform, so a gap is
+//                    geometric around range / n: 2^34.1 for 10^6 hashes at scaled = 1000, the largest of 255 of them
+//                    ~2^36.6 -> 37 bits.  (The entropy of the gaps is 35.5 bits; Elias-Fano would take 36.1.)
+//                    yh_sample_pack runs where the sketch is parsed (once per sample, next to a JSON parse that costs
+//                    a hundred times more); k_unpack_sample expands it in HBM in front of the lookup -- one workgroup
+//                    per block, one lane per hash, a block scan -- and checks what the format cannot promise: no
+//                    wrap-around inside a block, blocks ascending.
+//   compact rows     the run step's three count rows are ~99 % zeros (a sample overlaps ~1 % of GTDB): k_compact_rows
+//                    writes one 16-byte row (reference, overlap, n_exclusive, n_matches) per reference with overlap > 0,
+//                    in reference order, straight into the caller's page-locked buffer, and the number of rows.
+//                    1 MB of D2H per step becomes ~14 KB.
+#include "yh_common.h"
+
+#include <string.h>
+
+#include <algorithm>
+#include <thread>
+#include <vector>
+
+namespace {
+
+constexpr u32 PACK_MAGIC = 0x31504859u;  // "YHP1"
+constexpr u32 PACK_BLOCK = 256;
+
+struct PackHeader {   // 32 bytes
+    u32 magic, block;
+    u64 n;            // hashes
+    u64 payload_words;  // u64 words behind the block table (incl. one spare word: two-word reads never overrun)
+    u64 reserved;
+};
+struct PackBlock {    // 16 bytes
+    u64 base;         // the block's first hash
+    u32 word_off;     // first payload word of the block
+    u32 width;        // bits per gap, 0..64
+};
+static_assert(sizeof(PackHeader) == 32 && sizeof(PackBlock) == 16, "packed sample layout");
+
+inline u64 n_blocks(u64 n) { return (n + PACK_BLOCK - 1) / PACK_BLOCK; }
+inline u32 bits_of(u64 v) { return v ? 64u - (u32)__builtin_clzll(v) : 0u; }
+inline u64 block_words(u32 cnt, u32 width) { return ((u64)(cnt - 1) * width + 63) / 64; }
+
+// one workgroup per block, lane i = hash i of the block
+__global__ void __launch_bounds__(PACK_BLOCK) k_unpack_sample(const PackBlock* __restrict__ tab, const u64* __restrict__ payload,
+                                                              u64 n, u64* __restrict__ out, u32* __restrict__ bad, u32 gen,
+                                                              u32* __restrict__ host_bad) {
+    __shared__ u64 wave_sum[PACK_BLOCK / 64];
+    __shared__ u64 wave_last[PACK_BLOCK / 64];
+    const u64 b = blockIdx.x;
+    const u32 i = threadIdx.x, lane = i & 63u, wv = i >> 6;
+    const PackBlock blk = tab[b];
+    const u64 first = b * PACK_BLOCK;
+    const u32 cnt = (u32)min((u64)PACK_BLOCK, n - first);
+    u64 step = 0;  // h[i] - h[i-1]; 0 for lane 0 and for lanes behind the block's end
+    if (i >= 1 && i < cnt) {
+        const u64 bit = (u64)(i - 1) * blk.width;
+        const u64* p = payload + blk.word_off + (bit >> 6);
+        const u32 sh = (u32)(bit & 63u);
+        u64 v = 0;
+        if (blk.width) {
+            v = p[0] >> sh;
+            if (sh + blk.width > 64) v |= p[1] << (64 - sh);
+            if (blk.width < 64) v &= (1ull << blk.width) - 1ull;
+        }
+        step = v + 1ull;
+    }
+    // inclusive scan of the steps: inside the wave, then across the four waves
+    u64 acc = step;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const u64 t = ((u64)(u32)__shfl_up((int)(u32)(acc >> 32), off) << 32) | (u32)__shfl_up((int)(u32)acc, off);
+        if (lane >= (u32)off) acc += t;
+    }
+    if (lane == 63) wave_sum[wv] = acc;
+    __syncthreads();
+    u64 before = 0;
+    for (u32 w = 0; w < wv; ++w) before += wave_sum[w];
+    const u64 h = blk.base + before + acc;
+    // strictly ascending: every lane against its predecessor (a wrap-around past 2^64 shows as a descent somewhere),
+    // the block's last hash against the next block's first
+    const u64 prev_in_wave = ((u64)(u32)__shfl_up((int)(u32)(h >> 32), 1) << 32) | (u32)__shfl_up((int)(u32)h, 1);
+    if (lane == 63) wave_last[wv] = h;
+    __syncthreads();
+    bool wrong = false;
+    if (i >= 1 && i < cnt) {
+        const u64 prev = lane ? prev_in_wave : wave_last[wv - 1];
+        wrong = !(prev < h) || step == 0;  // (step == 0: v + 1 wrapped, a gap of 2^64)
+    }
+    if (i == cnt - 1 && first + cnt < n) wrong = wrong || !(h < tab[b + 1].base);
+    if (i < cnt) out[first + i] = h;
+    if (wrong) {
+        *bad = gen;
+        if (host_bad) *host_bad = 1;
+    }
+}
+
+// Rows of the references with overlap > 0, in reference order.  One workgroup per 2048 references (64 words of subset
+// bits); its first row number is the popcount of all the words in front, which every workgroup sums for itself (N / 32
+// words: 10 KB at 85 205 references, L2-resident).
+struct RowsOut {
+    uint4* rows;      // device view of the caller's buffer (page-locked host memory or HBM)
+    u64 cap;
+    u32* count_dev;   // may be null: number of rows (device word)
+    u32* count_host;  // may be null: the same, in page-locked host memory
+};
+__global__ void __launch_bounds__(1024) k_compact_rows(u64 n, const u32* __restrict__ maskbits, const u32* __restrict__ overlap,
+                                                       const u32* __restrict__ n_excl, const u32* __restrict__ n_match,
+                                                       RowsOut o) {
+    __shared__ u32 wsum[16];
+    __shared__ u32 wcnt[64];   // popcounts of this workgroup's 64 words
+    __shared__ u32 wpre[65];   // their exclusive prefix
+    const u32 tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    const u64 word0 = (u64)blockIdx.x * 64;          // first mask word of this workgroup
+    const u64 n_words = (n + 31) / 32;
+    // rows in front of this workgroup
+    u32 part = 0;
+    for (u64 w = tid; w < word0; w += 1024) part += (u32)__popc(maskbits[w]);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) part += (u32)__shfl_xor((int)part, off);
+    if (lane == 0) wsum[wv] = part;
+    if (tid < 64) wcnt[tid] = (word0 + tid < n_words) ? (u32)__popc(maskbits[word0 + tid]) : 0u;
+    __syncthreads();
+    if (tid == 0) {
+        u32 run = 0;
+        for (int w = 0; w < 64; ++w) { wpre[w] = run; run += wcnt[w]; }
+        wpre[64] = run;
+    }
+    __syncthreads();
+    u32 base = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) base += wsum[w];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const u32 t = tid + 1024u * k;             // reference inside the workgroup's 2048
+        const u64 j = word0 * 32 + t;
+        if (j < n) {
+            const u32 word = maskbits[word0 + (t >> 5)];
+            if ((word >> (t & 31u)) & 1u) {
+                const u64 row = (u64)base + wpre[t >> 5] + (u32)__popc(word & ((1u << (t & 31u)) - 1u));
+                if (row < o.cap) o.rows[row] = make_uint4((u32)j, overlap[j], n_excl[j], n_match[j]);
+            }
+        }
+    }
+    if (blockIdx.x == gridDim.x - 1 && tid == 0) {
+        const u32 total = base + wpre[64];
+        if (o.count_dev) *o.count_dev = total;
+        if (o.count_host) *o.count_host = total;
+    }
+}
+
+}  // namespace
+
+// ---- internal (yh_api.hip) ------------------------------------------------------------------------------------------
+// structure of a packed sample held in HOST memory: sizes, widths, payload offsets in bounds.  *n_out = its hash count.
+int yh_pack_validate(const void* packed, u64 bytes, u64* n_out) {
+    if (!packed || bytes < sizeof(PackHeader)) { yh_set_error("packed sample: shorter than its header"); return YH_ERR_INVALID_ARG; }
+    PackHeader hd;
+    memcpy(&hd, packed, sizeof(hd));
+    if (hd.magic != PACK_MAGIC || hd.block != PACK_BLOCK) { yh_set_error("packed sample: bad magic / block size"); return YH_ERR_INVALID_ARG; }
+    if (hd.n > 0xfffffff0ull) { yh_set_error("packed sample: more than 2^32-16 hashes"); return YH_ERR_INVALID_ARG; }
+    const u64 nb = n_blocks(hd.n);
+    if (hd.payload_words > (1ull << 33) || bytes != sizeof(PackHeader) + nb * sizeof(PackBlock) + hd.payload_words * 8) {
+        yh_set_error("packed sample: size does not match its header");
+        return YH_ERR_INVALID_ARG;
+    }
+    const PackBlock* tab = reinterpret_cast<const PackBlock*>((const char*)packed + sizeof(PackHeader));
+    for (u64 b = 0; b < nb; ++b) {
+        PackBlock blk;
+        memcpy(&blk, tab + b, sizeof(blk));
+        const u32 cnt = (u32)std::min<u64>(PACK_BLOCK, hd.n - b * PACK_BLOCK);
+        // (+1: the kernel may read the word behind a gap that ends on a word boundary)
+        if (blk.width > 64 || (u64)blk.word_off + block_words(cnt, blk.width) + 1 > hd.payload_words) {
+            yh_set_error("packed sample: block %llu points outside the payload", b);
+            return YH_ERR_INVALID_ARG;
+        }
+    }
+    *n_out = hd.n;
+    return YH_OK;
+}
+
+// d_packed: the same bytes in HBM (8-byte aligned); expands into d_out[n] and stores `gen` into *d_bad (and 1 into
+// *h_bad_dev, page-locked host memory, when given) if the hashes do not come out strictly ascending
+int yh_pack_expand_device(yh_db* db, const void* d_packed, u64 n, u64* d_out, u32* d_bad, u32 gen, u32* h_bad_dev) {
+    if (n == 0) return YH_OK;
+    const u64 nb = n_blocks(n);
+    const PackBlock* tab = reinterpret_cast<const PackBlock*>((const char*)d_packed + sizeof(PackHeader));
+    const u64* payload = reinterpret_cast<const u64*>(tab + nb);
+    k_unpack_sample<<<(u32)nb, PACK_BLOCK, 0, db->stream>>>(tab, payload, n, d_out, d_bad, gen, h_bad_dev);
+    YH_HIP(hipGetLastError());
+    return YH_OK;
+}
+
+// rows of the references with overlap > 0 from the three count rows of the step that just ran on the handle's stream
+// (its subset bits are db->d_maskbits)
+int yh_rows_compact_device(yh_db* db, const u32* d_overlap, const u32* d_excl, const u32* d_match, void* rows_dev, u64 cap,
+                           u32* count_dev, u32* count_host_dev) {
+    const u64 N = db->n_refs;
+    if (N == 0) {
+        if (count_dev) YH_HIP(hipMemsetAsync(count_dev, 0, sizeof(u32), db->stream));
+        return YH_OK;
+    }
+    RowsOut o{reinterpret_cast<uint4*>(rows_dev), cap, count_dev, count_host_dev};
+    k_compact_rows<<<(u32)((N + 2047) / 2048), 1024, 0, db->stream>>>(N, db->d_maskbits, d_overlap, d_excl, d_match, o);
+    YH_HIP(hipGetLastError());
+    return YH_OK;
+}
+
+// ---- C ABI: packing on the host -------------------------------------------------------------------------------------
+extern "C" {
+
+uint64_t yh_sample_pack_bound(uint64_t n_sample) {
+    const u64 nb = n_blocks(n_sample);
+    return sizeof(PackHeader) + nb * sizeof(PackBlock) + (n_sample + nb + 2) * 8;
+}
+
+int yh_sample_pack(const uint64_t* sample, uint64_t n_sample, void* packed, uint64_t cap_bytes, uint64_t* packed_bytes) {
+    if (!packed_bytes || (n_sample && !sample)) { yh_set_error("yh_sample_pack: null argument"); return YH_ERR_INVALID_ARG; }
+    if (n_sample > 0xfffffff0ull) { yh_set_error("sample larger than 2^32-16 hashes"); return YH_ERR_INVALID_ARG; }
+    const u64 n = n_sample, nb = n_blocks(n);
+    const u64* h = (const u64*)sample;
+    // pass 1: ordering, widths, offsets
+    std::vector<PackBlock> tab(nb);
+    u64 words = 0;
+    for (u64 b = 0; b < nb; ++b) {
+        const u64 first = b * PACK_BLOCK;
+        const u32 cnt = (u32)std::min<u64>(PACK_BLOCK, n - first);
+        if (b && !(h[first - 1] < h[first])) { yh_set_error("the sample sketch is not strictly ascending"); return YH_ERR_UNSORTED; }
+        u64 widest = 0;
+        for (u32 i = 1; i < cnt; ++i) {
+            if (!(h[first + i - 1] < h[first + i])) { yh_set_error("the sample sketch is not strictly ascending"); return YH_ERR_UNSORTED; }
+            widest |= h[first + i] - h[first + i - 1] - 1ull;
+        }
+        if (words > 0xfffffff0ull) { yh_set_error("packed sample too large"); return YH_ERR_INVALID_ARG; }
+        tab[b] = PackBlock{h[first], (u32)words, bits_of(widest)};
+        words += block_words(cnt, tab[b].width);
+    }
+    words += 1;  // the spare word
+    const u64 need = sizeof(PackHeader) + nb * sizeof(PackBlock) + words * 8;
+    *packed_bytes = need;
+    if (!packed || cap_bytes < need) {
+        if (!packed && cap_bytes == 0) return YH_OK;  // sizing call
+        yh_set_error("yh_sample_pack: buffer of %llu bytes, %llu needed", (u64)cap_bytes, need);
+        return YH_ERR_CAPACITY;
+    }
+    PackHeader hd{PACK_MAGIC, PACK_BLOCK, n, words, 0};
+    memcpy(packed, &hd, sizeof(hd));
+    if (nb) memcpy((char*)packed + sizeof(hd), tab.data(), nb * sizeof(PackBlock));
+    u64* payload = reinterpret_cast<u64*>((char*)packed + sizeof(hd) + nb * sizeof(PackBlock));
+    // pass 2: the gaps, block by block (blocks own disjoint words: threads need no coordination)
+    auto pack_range = [&](u64 b0, u64 b1) {
+        for (u64 b = b0; b < b1; ++b) {
+            const u64 first = b * PACK_BLOCK;
+            const u32 cnt = (u32)std::min<u64>(PACK_BLOCK, n - first);
+            const u32 w = tab[b].width;
+            u64* out = payload + tab[b].word_off;
+            const u64 nw = block_words(cnt, w);
+            for (u64 k = 0; k < nw; ++k) out[k] = 0;
+            if (!w) continue;
+            u64 bit = 0;
+            for (u32 i = 1; i < cnt; ++i, bit += w) {
+                const u64 v = h[first + i] - h[first + i - 1] - 1ull;
+                const u32 sh = (u32)(bit & 63u);
+                out[bit >> 6] |= v << sh;
+                if (sh + w > 64) out[(bit >> 6) + 1] |= v >> (64 - sh);
+            }
+        }
+    };
+    const unsigned hw = std::thread::hardware_concurrency();
+    const unsigned T = (unsigned)std::min<u64>(std::min<unsigned>(hw ? hw : 1, 8), nb / 512 + 1);
+    if (T <= 1) pack_range(0, nb);
+    else {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < T; ++t) th.emplace_back(pack_range, nb * t / T, nb * (t + 1) / T);
+        for (auto& x : th) x.join();
+    }
+    payload[words - 1] = 0;
+    return YH_OK;
+}
+
+int yh_sample_unpack(const void* packed, uint64_t packed_bytes, uint64_t* sample_out, uint64_t cap, uint64_t* n_sample) {
+    if (!n_sample) { yh_set_error("yh_sample_unpack: null argument"); return YH_ERR_INVALID_ARG; }
+    u64 n = 0;
+    YH_TRY(yh_pack_validate(packed, packed_bytes, &n));
+    *n_sample = n;
+    if (!sample_out && cap == 0) return YH_OK;  // sizing call
+    if (cap < n || !sample_out) { yh_set_error("yh_sample_unpack: room for %llu hashes, %llu needed", (u64)cap, n); return YH_ERR_CAPACITY; }
+    const u64 nb = n_blocks(n);
+    const PackBlock* tab = reinterpret_cast<const PackBlock*>((const char*)packed + sizeof(PackHeader));
+    const u64* payload = reinterpret_cast<const u64*>(tab + nb);
+    u64 prev = 0;
+    for (u64 b = 0; b < nb; ++b) {
+        PackBlock blk;
+        memcpy(&blk, tab + b, sizeof(blk));
+        const u64 first = b * PACK_BLOCK;
+        const u32 cnt = (u32)std::min<u64>(PACK_BLOCK, n - first);
+        u64 cur = blk.base;
+        if (b && !(prev < cur)) { yh_set_error("packed sample: blocks are not ascending"); return YH_ERR_UNSORTED; }
+        sample_out[first] = cur;
+        u64 bit = 0;
+        for (u32 i = 1; i < cnt; ++i, bit += blk.width) {
+            u64 v = 0;
+            if (blk.width) {
+                const u32 sh = (u32)(bit & 63u);
+                v = payload[blk.word_off + (bit >> 6)] >> sh;
+                if (sh + blk.width > 64) v |= payload[blk.word_off + (bit >> 6) + 1] << (64 - sh);
+                if (blk.width < 64) v &= (1ull << blk.width) - 1ull;
+            }
+            const u64 next = cur + v + 1ull;
+            if (!(cur < next)) { yh_set_error("packed sample: a gap wraps around 2^64"); return YH_ERR_UNSORTED; }
+            cur = next;
+            sample_out[first + i] = cur;
+        }
+        prev = cur;
+    }
+    return YH_OK;
+}
+
+}  // extern "C"

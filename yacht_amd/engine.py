@@ -34,6 +34,36 @@ def pack_csr(sketches: Sequence[np.ndarray]) -> Tuple[np.ndarray, np.ndarray]:
     return np.ascontiguousarray(values, dtype=np.uint64), offsets
 
 
+# one row of the compact result of a run step: a reference with overlap > 0 and its three counts (yh_run_row)
+ROW_DTYPE = np.dtype([("ref", np.uint32), ("overlap", np.uint32), ("n_excl", np.uint32), ("n_match", np.uint32)])
+
+
+def pack_sample(sample, out: Optional[np.ndarray] = None) -> np.ndarray:
+    """A strictly ascending uint64 sketch as the packed bytes yh_run_submit_packed uploads (~4.7 bytes per hash;
+    include/yacht_hip.h).  Host only: no device, any thread.  `out`: a uint8 buffer to pack into (e.g. a
+    PinnedArray's array, so that the upload overlaps the kernels); the returned array is the used part of it."""
+    lib = _lib.load()
+    sample = _as_u64(sample)
+    need = int(lib.yh_sample_pack_bound(sample.size))
+    if out is None:
+        out = np.empty(need, dtype=np.uint8)
+    assert out.dtype == np.uint8 and out.flags.c_contiguous
+    n = C.c_uint64(0)
+    _lib.check(lib.yh_sample_pack(_ptr(sample), sample.size, _ptr(out), out.size, C.byref(n)))
+    return out[: int(n.value)]
+
+
+def unpack_sample(packed: np.ndarray) -> np.ndarray:
+    """The sketch a packed sample holds (host-side inverse of pack_sample)."""
+    lib = _lib.load()
+    packed = np.ascontiguousarray(packed, dtype=np.uint8)
+    n = C.c_uint64(0)
+    _lib.check(lib.yh_sample_unpack(_ptr(packed), packed.size, None, 0, C.byref(n)))
+    out = np.zeros(int(n.value), dtype=np.uint64)
+    _lib.check(lib.yh_sample_unpack(_ptr(packed), packed.size, _ptr(out), out.size, C.byref(n)))
+    return out
+
+
 def _as_u64(a) -> np.ndarray:
     return np.ascontiguousarray(a, dtype=np.uint64)
 
@@ -187,6 +217,45 @@ class RefDB:
 
     def run_wait(self, slot: int) -> None:
         _lib.check(self._lib.yh_run_wait(self._h, slot))
+
+    def run_submit_packed(self, slot: int, packed: np.ndarray, rows: np.ndarray) -> None:
+        """Queue one run step from a packed sample (pack_sample); its result comes back as compact rows -- one
+        ROW_DTYPE record per reference with overlap > 0 -- in `rows`; run_wait_rows(slot) returns how many."""
+        assert packed.dtype == np.uint8 and packed.flags.c_contiguous
+        assert rows.dtype == ROW_DTYPE and rows.flags.c_contiguous
+        _lib.check(self._lib.yh_run_submit_packed(self._h, slot, _ptr(packed), packed.size, _ptr(rows), rows.size))
+
+    def run_submit_rows(self, slot: int, sample: np.ndarray, rows: np.ndarray) -> None:
+        assert sample.dtype == np.uint64 and sample.flags.c_contiguous
+        assert rows.dtype == ROW_DTYPE and rows.flags.c_contiguous
+        _lib.check(self._lib.yh_run_submit_rows(self._h, slot, _ptr(sample), sample.size, _ptr(rows), rows.size))
+
+    def run_wait_rows(self, slot: int) -> int:
+        n = C.c_uint64(0)
+        _lib.check(self._lib.yh_run_wait_rows(self._h, slot, C.byref(n)))
+        return int(n.value)
+
+    def run_rows(self, sample, packed: bool = True) -> np.ndarray:
+        """run_counts as compact rows (ROW_DTYPE, ascending by reference): only the references with overlap > 0."""
+        sample = _as_u64(sample)
+        cap = max(1024, self.n_refs // 16)
+        while True:
+            rows = np.zeros(cap, dtype=ROW_DTYPE)
+            if packed:
+                self.run_submit_packed(0, pack_sample(sample), rows)
+            else:
+                self.run_submit_rows(0, sample, rows)
+            n = C.c_uint64(0)
+            rc = self._lib.yh_run_wait_rows(self._h, 0, C.byref(n))
+            if rc == _lib.YH_ERR_CAPACITY:
+                cap = int(n.value)
+                continue
+            _lib.check(rc)
+            return rows[: int(n.value)]
+
+    def run_rows_device(self, d_overlap: int, d_excl: int, d_match: int, d_rows: int, cap_rows: int, d_n_rows: int) -> None:
+        _lib.check(self._lib.yh_run_rows_device(self._h, C.c_void_p(d_overlap), C.c_void_p(d_excl), C.c_void_p(d_match),
+                                                C.c_void_p(d_rows), cap_rows, C.c_void_p(d_n_rows)))
 
     def run_batch(self, samples: Sequence[np.ndarray]) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
         """run_counts for up to 64 samples in one pass (needs YH_DB_FULL_INDEX): three uint32
