@@ -2,7 +2,8 @@
 """bench.py — containment queries/sec of the `yacht run` hot path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1: as above -- bench.py then spawns its N ranks itself as child processes, before anything touches the GPU --
+     or under a launcher: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 A "step" is one pass of the device-side `yacht run` counts over ONE sample sketch: overlap of the
 sample with every reference (R1), subset = overlap > 0, subset-exclusive hash counts (R2).  Inputs are
@@ -66,10 +67,13 @@ def parse_args():
     ap.add_argument("--present", type=int, default=200, help="genomes present in a sample (diagnostic)")
     ap.add_argument("--no-indexed", action="store_true", help="skip the extra measurement of the sample-driven path")
     ap.add_argument("--no-host-inclusive", action="store_true")
+    ap.add_argument("--pipelined-tail", action="store_true",
+                    help="N=1: yh_run_device_pipelined instead of yh_run_device in the timed loop (the tail of a step on a second "
+                         "stream beside the next step's lookup; measured slower than the plain step: DESIGN.md 3)")
     ap.add_argument("--no-real-shape", action="store_true")
     ap.add_argument("--no-batched", action="store_true")
     ap.add_argument("--batch-samples", type=int, default=32, help="samples per yh_run_batch_device call of the `batched` leg (<= 64)")
-    ap.add_argument("--host-depth", type=int, default=3, help="host-inclusive leg: calls in flight (1..4)")
+    ap.add_argument("--host-depth", type=int, default=4, help="host-inclusive leg: calls in flight (1..4)")
     ap.add_argument("--percentile-steps", type=int, default=200)
     ap.add_argument("--sync-gather", action="store_true", help="N>1: blocking gather of the count rows inside every step")
     ap.add_argument("--count-gather", choices=("root", "all"), default="root",
@@ -100,8 +104,49 @@ def source_tag() -> str:
     return h.hexdigest()[:16]
 
 
+def _free_port() -> int:
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(args) -> int:
+    """--gpus N > 1 started the way --gpus 1 is started (no launcher, WORLD_SIZE unset): spawn the N ranks as CHILD
+    processes through torch.distributed.run and relay rank 0's JSON line and the exit code.  Nothing in this process
+    has touched the GPU (torch is not even imported yet), and nothing is exec'ed: the children are ordinary
+    subprocesses."""
+    import subprocess
+
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    if lines:
+        print(lines[-1], flush=True)
+    return proc.returncode if proc.returncode != 0 or lines else 1
+
+
+def cpu_model() -> str:
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.lower().startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+
+    return platform.processor() or platform.machine()
+
+
 def main() -> int:
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.force_dist:
+        return launch_ranks(args)
     # stdout carries the ONE JSON line and nothing else: libraries that print banners at start-up
     # (RCCL prints its version block to stdout when a communicator is created) are sent to stderr.
     sys.stdout.flush()
@@ -116,7 +161,7 @@ def main() -> int:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (a launcher started a different number of ranks)",
                   file=sys.stderr)
         return 2
     if not torch.cuda.is_available():
@@ -256,7 +301,9 @@ def main() -> int:
         s = samples[i % K]
         c = rows_of(i)
         if sdb is None:
-            db.run_device(s.data_ptr(), s.numel(), c[0].data_ptr(), c[1].data_ptr(), c[2].data_ptr())
+            # (two count buffers alternate; with --no-pipelined-tail every step's tail is waited for by the next lookup)
+            (db.run_device if not args.pipelined_tail else db.run_device_pipelined)(
+                s.data_ptr(), s.numel(), c[0].data_ptr(), c[1].data_ptr(), c[2].data_ptr())
             return
         blk, g = (i // GB) % NBUF, i % GB
         if g == 0 and pending[blk] is not None:  # first sample of a block: the block's previous gather must be done
@@ -267,6 +314,8 @@ def main() -> int:
             close_block(blk, i - g, GB)
 
     def drain():
+        if sdb is None:
+            db.run_device_join()  # the last tails: the stream's end is the end of every step
         i = state["i"]
         if multi and i % GB != 0:  # a partly filled block at the end of a loop leaves too
             close_block((i // GB) % NBUF, i - i % GB, i % GB)
@@ -331,6 +380,10 @@ def main() -> int:
                 sdb.run(samples[i], c)
                 results.append(sdb.gather(c))
     torch.cuda.synchronize()
+    pipelined_ok = None
+    if sdb is None and args.pipelined_tail:  # the timed loop's own (pipelined) outputs: its last two steps are still in the buffers
+        last = state["i"] - 1
+        pipelined_ok = all(bool(torch.equal(rows_of(last - d), results[(last - d) % K])) for d in range(min(2, NBUF)))
     if multi:  # the steps' own gathers must carry this rank's rows
         for b in range(NBUF):
             if not to_root or rank == 0:
@@ -342,12 +395,15 @@ def main() -> int:
     default_choice = db.lookup_choice(n_sample)  # (the sharded step asks the same question inside yh_run_local_device)
     if not multi:
         timing_default = timing
-        cpath = torch.zeros((3, n_local), device=dev, dtype=torch.int32)
+        cpath2 = [torch.zeros((3, n_local), device=dev, dtype=torch.int32) for _ in range(2)]
+        cpath = cpath2[0]
 
-        def step_path(i):
+        def step_path(i, plain=False):
             s = samples[i % K]
+            c = cpath if plain else cpath2[i % 2]
             with torch.cuda.stream(stream):
-                db.run_device(s.data_ptr(), s.numel(), cpath[0].data_ptr(), cpath[1].data_ptr(), cpath[2].data_ptr())
+                (db.run_device if (plain or not args.pipelined_tail) else db.run_device_pipelined)(
+                    s.data_ptr(), s.numel(), c[0].data_ptr(), c[1].data_ptr(), c[2].data_ptr())
 
         for name, mode in (("stream", ylib.YH_LOOKUP_STREAM), ("indexed", ylib.YH_LOOKUP_INDEXED)):
             if mode == ylib.YH_LOOKUP_INDEXED and args.no_indexed:
@@ -355,17 +411,19 @@ def main() -> int:
             db.set_lookup(mode)
             for i in range(args.warmup):
                 step_path(i)
+            db.run_device_join()
             fence()
             db.timing()
             t0 = time.perf_counter()
             for i in range(max(args.steps, 64)):
                 step_path(i)
+            db.run_device_join()
             fence()
             el = (time.perf_counter() - t0) / max(args.steps, 64)
             tm = db.timing()
             same = True
             for i in range(K):
-                step_path(i)
+                step_path(i, plain=True)
                 torch.cuda.synchronize()
                 same = same and bool(torch.equal(cpath, results[i]))
             paths[name] = {"ms_per_step": round(1e3 * el, 4), "value": round(n_local / el, 1), "unit": "queries/s",
@@ -377,107 +435,147 @@ def main() -> int:
 
     if not multi and not args.no_host_inclusive:
         # SURVEY.md 8d's metric: wall time of the steady-state call INCLUDING sample H2D and counts D2H.
-        # Page-locked host buffers, yh_run_submit / yh_run_wait, DEPTH calls in flight.
+        # Page-locked host buffers, DEPTH calls in flight.  Two wire formats:
+        #   packed_rows  the sample travels packed (yh_sample_pack: ~4.7 B per hash, made ONCE where the sketch is parsed;
+        #                its cost per sample is reported, it is not inside the step) and is expanded + order-checked on the
+        #                device; the result comes back as compact rows (references with overlap > 0 only)
+        #   raw_dense    round 2's form: 8 B per hash up, three dense count rows down
+        from yacht_amd.engine import ROW_DTYPE, pack_sample
+
         DEPTH = max(1, min(args.host_depth, 4))
-        h_samples = []
-        for s in samples:
-            pa = PinnedArray(int(s.numel()), np.uint64)
-            pa.array[:] = s.cpu().numpy().view(np.uint64)
+        h_samples, h_packed, pack_ms = [], [], []
+        for s_ in samples:
+            pa = PinnedArray(int(s_.numel()), np.uint64)
+            pa.array[:] = s_.cpu().numpy().view(np.uint64)
             h_samples.append(pa)
+            pp = PinnedArray(int(ylib.load().yh_sample_pack_bound(int(s_.numel()))), np.uint8)
+            t1 = time.perf_counter()
+            used = pack_sample(pa.array, out=pp.array)
+            pack_ms.append((time.perf_counter() - t1) * 1e3)
+            h_packed.append((pp, used))
         h_blk = [PinnedArray(3 * n_local, np.uint32) for _ in range(DEPTH)]  # one contiguous [3][N] block per slot: one D2H copy
+        h_rows = [PinnedArray(n_local, ROW_DTYPE) for _ in range(DEPTH)]
+        h_out = [[b.array[k * n_local:(k + 1) * n_local] for k in range(3)] for b in h_blk]
 
-        class _Row:
-            def __init__(self, a):
-                self.array = a
+        def submit_raw(slot, i):
+            o = h_out[slot]
+            db.run_submit(slot, h_samples[i % K].array, o[0], o[1], o[2])
 
-        h_out = [[_Row(b.array[k * n_local:(k + 1) * n_local]) for k in range(3)] for b in h_blk]
-        done_t = []
-        host_t = {"submit": 0.0, "wait": 0.0}
+        def submit_packed(slot, i):
+            db.run_submit_packed(slot, h_packed[i % K][1], h_rows[slot].array)
 
-        def host_loop(n_steps, record):
-            for i in range(n_steps + DEPTH):
-                slot = i % DEPTH
-                if i >= DEPTH:
-                    ta = time.perf_counter()
-                    db.run_wait(slot)
-                    tb = time.perf_counter()
-                    if record:
-                        done_t.append(tb)
-                        host_t["wait"] += tb - ta
-                if i < n_steps:
-                    o = h_out[slot]
-                    ta = time.perf_counter()
-                    db.run_submit(slot, h_samples[i % K].array, o[0].array, o[1].array, o[2].array)
-                    if record:
-                        host_t["submit"] += time.perf_counter() - ta
+        n_rows_seen = {}
 
-        host_loop(max(args.warmup, 4 * K), False)  # (the first copy out of every pinned buffer is slow: ~15 ms)
-        n_host = max(args.steps, args.percentile_steps)
-        t0 = time.perf_counter()
-        host_loop(n_host, True)
-        el = time.perf_counter() - t0
-        gaps = (np.diff(np.asarray([t0] + done_t)) * 1e3).tolist()[DEPTH:]
-        # the last DEPTH results are still in the buffers: check them against the device-resident counts
-        ok = True
-        for i in range(n_host - DEPTH, n_host):
-            o = h_out[i % DEPTH]
-            want = results[i % K].cpu().numpy().view(np.uint32)
-            ok = ok and all(np.array_equal(o[k].array, want[k]) for k in range(3))
+        def wait_rows(slot):
+            n_rows_seen[slot] = db.run_wait_rows(slot)
+
+        def host_leg(submit, wait, check):
+            done_t = []
+            host_t = {"submit": 0.0, "wait": 0.0}
+
+            def loop(n_steps, record):
+                for i in range(n_steps + DEPTH):
+                    slot = i % DEPTH
+                    if i >= DEPTH:
+                        ta = time.perf_counter()
+                        wait(slot)
+                        tb = time.perf_counter()
+                        if record:
+                            done_t.append(tb)
+                            host_t["wait"] += tb - ta
+                    if i < n_steps:
+                        ta = time.perf_counter()
+                        submit(slot, i)
+                        if record:
+                            host_t["submit"] += time.perf_counter() - ta
+
+            loop(max(args.warmup, 4 * K), False)  # (the first copy out of every pinned buffer is slow: ~15 ms)
+            n_host = max(args.steps, args.percentile_steps)
+            t0 = time.perf_counter()
+            loop(n_host, True)
+            el = time.perf_counter() - t0
+            gaps = (np.diff(np.asarray([t0] + done_t)) * 1e3).tolist()[DEPTH:]
+            ok = all(check(i % DEPTH, i % K) for i in range(n_host - DEPTH, n_host))  # the last DEPTH results are still in the buffers
+            return dict(stats_ms(gaps), value=round(n_local / (el / n_host), 1), unit="queries/s",
+                        ms_per_step=round(1e3 * el / n_host, 4), equals_device_resident=ok,
+                        host_ms_in_submit=round(1e3 * host_t["submit"] / n_host, 4),
+                        host_ms_in_wait=round(1e3 * host_t["wait"] / n_host, 4))
+
+        def check_dense(slot, k):
+            want = results[k].cpu().numpy().view(np.uint32)
+            return all(np.array_equal(h_out[slot][r], want[r]) for r in range(3))
+
+        def check_rows(slot, k):
+            want = results[k].cpu().numpy().view(np.uint32)
+            ref = np.flatnonzero(want[0])
+            got = h_rows[slot].array[: n_rows_seen.get(slot, 0)]
+            return bool(got.size == ref.size and np.array_equal(got["ref"], ref) and np.array_equal(got["overlap"], want[0][ref])
+                        and np.array_equal(got["n_excl"], want[1][ref]) and np.array_equal(got["n_match"], want[2][ref]))
+
+        leg_packed = host_leg(submit_packed, wait_rows, check_rows)
+        leg_raw = host_leg(submit_raw, db.run_wait, check_dense)
+        packed_bytes = int(np.mean([int(u.size) for _, u in h_packed]))
+        rows_per_step = int(np.mean([int((r[0] != 0).sum().item()) for r in results]))
+        leg_packed.update(h2d_bytes_per_step=packed_bytes, d2h_bytes_per_step=16 * rows_per_step + 4,
+                          h2d_GBps=round(packed_bytes / (leg_packed["ms_per_step"] / 1e3) / 1e9, 1),
+                          bytes_per_sample_hash=round(packed_bytes / max(n_sample, 1), 3),
+                          pack_ms_per_sample_on_host=round(float(np.median(pack_ms)), 3),
+                          pack_note="yh_sample_pack runs once per sample where the sketch is parsed (not inside the step)")
+        leg_raw.update(h2d_bytes_per_step=8 * n_sample, d2h_bytes_per_step=12 * n_local,
+                       h2d_GBps=round(8 * n_sample / (leg_raw["ms_per_step"] / 1e3) / 1e9, 1))
         # latency of ONE synchronous host-pointer call (what the CLI pays per sample)
         lat = []
-        hs = h_samples[0].array
         for i in range(30):
             t1 = time.perf_counter()
             db.run_counts(h_samples[i % K].array)
             lat.append((time.perf_counter() - t1) * 1e3)
-        host_inclusive = dict(stats_ms(gaps), value=round(n_local / (el / n_host), 1), unit="queries/s",
-                              ms_per_step=round(1e3 * el / n_host, 4), pipeline_depth=DEPTH,
-                              h2d_bytes_per_step=8 * n_sample, d2h_bytes_per_step=12 * n_local,
-                              h2d_GBps=round(8 * n_sample / (el / n_host) / 1e9, 1),
-                              equals_device_resident=ok,
-                              host_ms_in_submit=round(1e3 * host_t["submit"] / n_host, 4),
-                              host_ms_in_wait=round(1e3 * host_t["wait"] / n_host, 4),
+        host_inclusive = dict(leg_packed, form="packed_rows", pipeline_depth=DEPTH, raw_dense=leg_raw,
+                              equals_device_resident=bool(leg_packed["equals_device_resident"] and leg_raw["equals_device_resident"]),
                               sync_call_ms_median=round(pct(lat[5:], 50), 4),
-                              how="pinned sample -> H2D -> ordering check + kernels -> counts D2H per step "
-                                  "(yh_run_submit/yh_run_wait, copy streams beside the compute stream); "
-                                  "percentiles over the intervals between completed steps; "
-                                  "sync_call = one blocking yh_run from pageable numpy arrays")
-        del hs
-        for pa in h_samples:
+                              how="page-locked host buffers; per step: sample H2D on a copy stream -> expansion / ordering "
+                                  "check + kernels -> result D2H written by the step's own kernels (yh_run_submit_packed / "
+                                  "yh_run_wait_rows; raw_dense: yh_run_submit / yh_run_wait); percentiles over the intervals "
+                                  "between completed steps; sync_call = one blocking yh_run from pageable numpy arrays")
+        for pa in h_samples + [pp for pp, _ in h_packed] + h_blk + h_rows:
             pa.close()
         h_out = None
-        for pa in h_blk:
-            pa.close()
 
     real_samples = []
     if not multi and not args.no_real_shape and args.workload == "gtdb_rs214_scale":
         # the hit shape of the reference's shipped results: ~29 % of the references overlap
         real_samples = [synth.global_db_sample_device(plan, args.seed + 5000 + i, n_sample=83_000, device=str(dev),
                                                       shape="real") for i in range(4)]
-        creal = torch.zeros((3, n_local), device=dev, dtype=torch.int32)
+        creal2 = [torch.zeros((3, n_local), device=dev, dtype=torch.int32) for _ in range(2)]
+        creal = creal2[0]
+        run_step = db.run_device if not args.pipelined_tail else db.run_device_pipelined
 
-        def step_real(i):
+        def step_real(i, plain=False):
             s = real_samples[i % len(real_samples)]
+            c = creal if plain else creal2[i % 2]
             with torch.cuda.stream(stream):
-                db.run_device(s.data_ptr(), s.numel(), creal[0].data_ptr(), creal[1].data_ptr(), creal[2].data_ptr())
+                (db.run_device if plain else run_step)(s.data_ptr(), s.numel(), c[0].data_ptr(), c[1].data_ptr(), c[2].data_ptr())
+
+        def fence_real():
+            db.run_device_join()
+            fence()
 
         for i in range(args.warmup):
             step_real(i)
-        fence()
+        fence_real()
         db.timing()
         ev2 = [torch.cuda.Event(enable_timing=True) for _ in range(n_pct + 1)]
         t0 = time.perf_counter()
         for i in range(args.steps):
             step_real(i)
-        fence()
+        fence_real()
         el = time.perf_counter() - t0
         ev2[0].record(stream)
         for k in range(n_pct):
             step_real(k)
             ev2[k + 1].record(stream)
-        fence()
+        fence_real()
         tm = db.timing()
-        step_real(0)
+        step_real(0, plain=True)
         torch.cuda.synchronize()
         real_counts0 = creal.clone()
         forced = {}
@@ -487,13 +585,13 @@ def main() -> int:
             db.set_lookup(mode)
             for i in range(args.warmup):
                 step_real(i)
-            fence()
+            fence_real()
             t0 = time.perf_counter()
             for i in range(max(args.steps, 64)):
                 step_real(i)
-            fence()
+            fence_real()
             forced[name] = round(1e3 * (time.perf_counter() - t0) / max(args.steps, 64), 4)
-            step_real(0)
+            step_real(0, plain=True)
             torch.cuda.synchronize()
             forced[name + "_equals_default"] = bool(torch.equal(creal, real_counts0))
         db.set_lookup(ylib.YH_LOOKUP_AUTO)
@@ -697,6 +795,7 @@ def main() -> int:
                 "value": round(n_par * n_total / (t_ov + t_ex), 1),
                 "unit": "queries/s",
                 "cores": cores,
+                "cpu_model": cpu_model(),
                 "kind": "port",
                 "sample": f"{n_par} of the {K} samples against the whole database ({n_total} refs, {Hh} hashes): "
                           f"overlap {t_ov:.2f} s on {cores} threads + exclusive {t_ex:.2f} s on 1 thread",
@@ -716,6 +815,10 @@ def main() -> int:
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
+            # SURVEY.md 8d's wall-clock form of the same metric (sample H2D + kernels + result D2H per step, pipelined):
+            # `value` above has the samples resident in HBM, as the bench contract asks
+            "value_host_inclusive": (host_inclusive or {}).get("value"),
+            "ms_per_step_host_inclusive": (host_inclusive or {}).get("ms_per_step"),
             "host_issue_ms_per_step": round(1e3 * t_issued / args.steps, 4),
             "higher_is_better": True,
             "scaling": args.scaling,
@@ -737,6 +840,7 @@ def main() -> int:
                 "ghost_refs_rank0": (sdb.n_ghost if sdb is not None else 0),
                 "db_build_ms": round(float(timing["ms_db_build"]), 2),
                 "db_hbm_bytes": info["device_bytes"],
+                "pipelined_tail": bool(not multi and args.pipelined_tail),
                 "step": "overlap + exclusive counts" + ((f" (blocks of {GB} samples: one all_gather of their subset bits" + (", two blocks in flight" if pipelined else "") + f") + one {'gather to rank 0' if to_root else 'all_gather'} of the count rows per {GB} samples"
                                                        + ("" if args.sync_gather else " (overlapped with the next sample)")) if multi else ""),
                 "parallelism": f"one database, references sharded x{world} by hash count",
@@ -745,6 +849,7 @@ def main() -> int:
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
             "parity_bit_exact": parity,
+            "pipelined_steps_equal_plain_steps": pipelined_ok,
             "device_resident": device_resident,
             "host_inclusive": host_inclusive,
             "real_shape": real_shape,
@@ -769,6 +874,9 @@ def main() -> int:
         return 1
     if rank == 0 and host_inclusive is not None and not host_inclusive["equals_device_resident"]:
         print("bench.py: host-buffer path differs from the device-resident path", file=sys.stderr)
+        return 1
+    if rank == 0 and pipelined_ok is False:
+        print("bench.py: the pipelined steps differ from the plain ones", file=sys.stderr)
         return 1
     if rank == 0 and parity is False:
         print("bench.py: GPU counts differ from the CPU oracle", file=sys.stderr)

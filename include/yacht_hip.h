@@ -193,6 +193,18 @@ int yh_run(yh_db* db, const uint64_t* sample, uint64_t n_sample,
 int yh_run_device(yh_db* db, const uint64_t* d_sample, uint64_t n_sample,
                   uint32_t* d_overlap, uint32_t* d_n_excl, uint32_t* d_n_match);
 
+/* Throughput form for a caller with many samples already in HBM: the same step, but its tail (reduce + exclusive
+ * pass: ~11 us of launch and round-trip latency for almost no work) is queued on a second stream of the handle, so
+ * that the NEXT call's lookup runs beside it; consecutive calls alternate between two sets of counters and the step
+ * contexts 0 and 1.  The three output rows of a pipelined call are complete -- in the order of the handle's stream --
+ * only after yh_run_device_join (a stream-level wait; the host does not block), which every other query entry point,
+ * yh_db_synchronize and yh_db_set_stream perform first by themselves.  Consecutive calls must write different output
+ * buffers (two that alternate are enough).  Handles the split does not apply to (streaming lookup chosen, ghosts)
+ * run the call as yh_run_device does.                                                                          */
+int yh_run_device_pipelined(yh_db* db, const uint64_t* d_sample, uint64_t n_sample,
+                            uint32_t* d_overlap, uint32_t* d_n_excl, uint32_t* d_n_match);
+int yh_run_device_join(yh_db* db);
+
 /* ---- references spread over several GPUs, the `yacht run` subset (overlap > 0) ------------------------
  * North star: "references shard across the GPUs with only a final gather of per-reference counts".
  * Overlap is rank-local.  Exclusivity is not -- the other holder of a hash may live on another rank --

@@ -150,3 +150,18 @@ def test_bench_two_ranks_share_gpu_strong_and_weak(hip_lib, tmp_path):
         line = json.loads(res[0][0].strip().splitlines()[-1])
         assert line["parity_bit_exact"] is True and line["n_gpus"] == 2 and line["scaling"] == scaling
         assert line["config"]["refs_total"] == (4000 if scaling == "strong" else 8000)
+
+
+def test_bench_starts_its_own_ranks(hip_lib):
+    """`python bench.py --gpus 2 ...` with NO launcher and no WORLD_SIZE, the way the driver starts `--gpus 1`: bench.py
+    spawns its two ranks as child processes (before anything touches the GPU) and relays rank 0's line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--backend", "gloo",
+                        "--steps", "6", "--warmup", "2", "--refs", "4000", "--sample-hashes", "100000", "--samples", "3",
+                        "--percentile-steps", "8", "--present", "50"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    line = json.loads(lines[0])
+    assert line["parity_bit_exact"] is True and line["n_gpus"] == 2

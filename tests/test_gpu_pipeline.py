@@ -279,3 +279,45 @@ def test_rows_of_a_device_resident_step(hip_lib):
         ref = np.flatnonzero(ov)
         assert k == ref.size and np.array_equal(got[:, 0], ref) and np.array_equal(got[:, 1], ov[ref])
         assert np.array_equal(got[:, 2], e[ref]) and np.array_equal(got[:, 3], m[ref])
+
+
+def test_pipelined_device_steps(hip_lib):
+    """yh_run_device_pipelined: the tail of a step runs on a second stream beside the next step's lookup, over two
+    alternating sets of counters and step contexts.  Rotating samples of different hit shapes, two and three output
+    buffers, other queries in between (which join first), small samples that take other lookup forms."""
+    import torch
+
+    rng = np.random.default_rng(31)
+    values, offsets = _db(seed=14, n_refs=4000)
+    n = offsets.size - 1
+    hs = _samples(values, offsets, 5, rng) + [np.zeros(0, np.uint64), np.array([7], np.uint64), values[::2].copy()]
+    hs[-1] = np.unique(hs[-1])
+    want = []
+    for s in hs:
+        ov = oracle.overlap(values, offsets, s)
+        e, m = oracle.exclusive(values, offsets, ov > 0, s)
+        want.append(np.stack([ov, e, m]))
+    ds = [torch.from_numpy(s.view(np.int64).copy()).cuda() for s in hs]
+    with RefDB(values, offsets) as db:
+        for lookup in (_lib.YH_LOOKUP_AUTO, _lib.YH_LOOKUP_INDEXED, _lib.YH_LOOKUP_STREAM):
+            db.set_lookup(lookup)
+            for nbuf in (2, 3):
+                bufs = [torch.zeros(3, n, dtype=torch.int32, device="cuda") for _ in range(nbuf)]
+                order = [int(x) for x in rng.integers(0, len(hs), size=50)]
+                for i, si in enumerate(order):
+                    b = bufs[i % nbuf]
+                    db.run_device_pipelined(ds[si].data_ptr(), ds[si].numel(), b[0].data_ptr(), b[1].data_ptr(), b[2].data_ptr())
+                    if i >= nbuf - 1 and i % 7 == 3:   # read an older buffer back in the middle of the pipeline
+                        db.run_device_join()
+                        db.synchronize()
+                        j = i - (nbuf - 1)
+                        assert np.array_equal(bufs[j % nbuf].cpu().numpy().view(np.uint32), want[order[j]]), (lookup, nbuf, j)
+                    if i % 11 == 5:                    # another query in between: joins by itself
+                        assert np.array_equal(db.overlap(hs[1]), want[1][0])
+                db.synchronize()
+                for d in range(nbuf):
+                    j = len(order) - 1 - d
+                    assert np.array_equal(bufs[j % nbuf].cpu().numpy().view(np.uint32), want[order[j]]), (lookup, nbuf, j)
+        db.set_lookup(_lib.YH_LOOKUP_AUTO)
+        ov, e, m = db.run_counts(hs[0])              # the plain forms still answer afterwards
+        assert np.array_equal(np.stack([ov, e, m]), want[0])

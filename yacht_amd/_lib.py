@@ -107,6 +107,8 @@ SIGNATURES = {
     "yh_exclusive": (C.c_int, [_vp, _vp, _vp, C.c_uint64, _vp, _vp]),
     "yh_run": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp, _vp]),
     "yh_run_device": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp, _vp]),
+    "yh_run_device_pipelined": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp, _vp]),
+    "yh_run_device_join": (C.c_int, [_vp]),
     "yh_db_set_ghosts": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _vp]),
     "yh_run_local_device": (C.c_int, [_vp, C.c_int, _vp, C.c_uint64, _vp, _vp, _vp, _vp]),
     "yh_run_finish_device": (C.c_int, [_vp, C.c_int, _vp, _vp]),

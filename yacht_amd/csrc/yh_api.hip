@@ -92,9 +92,21 @@ static float ring_read(EventRing& r) {
     return n ? (float)(acc / n) : 0.f;
 }
 
+// Tails of pipelined steps still running on the tail stream: the handle's stream waits for them (a stream-level wait,
+// the host does not block), so that whatever is queued next sees their results and may re-use their counters.
+static int pipe_join(yh_db* db, int parity = -1) {
+    for (int p = 0; p < 2; ++p)
+        if ((parity < 0 || parity == p) && db->tail_pending[p]) {
+            YH_HIP(hipStreamWaitEvent(db->stream, db->ev_tail[p], 0));
+            db->tail_pending[p] = false;
+        }
+    return YH_OK;
+}
+
 // A query that is not one of the two halves of a step context re-uses the current context's subset bits and work
 // list: a context whose first half is queued loses them (yh_run_finish_device reports it).
 static void note_other_query(yh_db* db) {
+    (void)pipe_join(db);
     if (db->ctx_open[db->ctx_now]) db->ctx_clobbered[db->ctx_now] = true;
 }
 
@@ -268,7 +280,13 @@ int yh_db_create_device(const uint64_t* d_values, const uint64_t* d_offsets, uin
 int yh_db_destroy(yh_db* db) {
     if (!db) return YH_OK;
     if (db->device >= 0) (void)hipSetDevice(db->device);
+    if (db->st_tail) (void)hipStreamSynchronize(db->st_tail);
     if (db->stream) (void)hipStreamSynchronize(db->stream);
+    if (db->st_tail) (void)hipStreamDestroy(db->st_tail);
+    for (int p = 0; p < 2; ++p) {
+        if (db->ev_lookup[p]) (void)hipEventDestroy(db->ev_lookup[p]);
+        if (db->ev_tail[p]) (void)hipEventDestroy(db->ev_tail[p]);
+    }
     if (db->ctx_bits[0]) {  // the step contexts: back to the handle's own arrays, the second set freed here
         db->d_maskbits = db->ctx_bits[0];
         db->d_work = db->ctx_work[0];
@@ -290,7 +308,7 @@ int yh_db_destroy(yh_db* db) {
     ring_destroy(db->ev_overlap);
     ring_destroy(db->ev_excl);
     ring_destroy(db->ev_pair);
-    if (db->st_in) (void)hipStreamSynchronize(db->st_in);
+    for (hipStream_t q : db->st_in) if (q) (void)hipStreamSynchronize(q);
     for (RunSlot& s : db->slots) {
         if (s.d_sample) (void)hipFree(s.d_sample);
         if (s.d_packed) (void)hipFree(s.d_packed);
@@ -301,7 +319,7 @@ int yh_db_destroy(yh_db* db) {
         if (s.ev_up) (void)hipEventDestroy(s.ev_up);
         if (s.ev_out) (void)hipEventDestroy(s.ev_out);
     }
-    if (db->st_in) (void)hipStreamDestroy(db->st_in);
+    for (hipStream_t q : db->st_in) if (q) (void)hipStreamDestroy(q);
     if (db->own_stream) (void)hipStreamDestroy(db->own_stream);
     free(db->h_pw_i);
     free(db->h_pw_j);
@@ -336,6 +354,7 @@ int yh_db_get_info(yh_db* db, yh_db_info* info) {
 int yh_db_set_stream(yh_db* db, void* hip_stream) {
     if (!db_ok(db)) return YH_ERR_INVALID_ARG;
     YH_TRY(db_select(db));
+    YH_TRY(pipe_join(db));
     YH_HIP(hipStreamSynchronize(db->stream));
     db->stream = hip_stream ? (hipStream_t)hip_stream : db->own_stream;
     return YH_OK;
@@ -344,6 +363,7 @@ int yh_db_set_stream(yh_db* db, void* hip_stream) {
 int yh_db_synchronize(yh_db* db) {
     if (!db_ok(db)) return YH_ERR_INVALID_ARG;
     YH_TRY(db_select(db));
+    YH_TRY(pipe_join(db));
     YH_HIP(hipStreamSynchronize(db->stream));
     return YH_OK;
 }
@@ -352,6 +372,7 @@ int yh_db_get_timing(yh_db* db, yh_timing* t) {
     if (!db_ok(db)) return YH_ERR_INVALID_ARG;
     if (!t) { yh_set_error("t is null"); return YH_ERR_INVALID_ARG; }
     YH_TRY(db_select(db));
+    YH_TRY(pipe_join(db));
     YH_HIP(hipStreamSynchronize(db->stream));
     t->ms_overlap_kernel = ring_read(db->ev_overlap);
     t->ms_exclusive_kernels = ring_read(db->ev_excl);
@@ -639,6 +660,45 @@ int yh_run_device(yh_db* db, const uint64_t* d_sample, uint64_t n_sample, uint32
     return yh_q_exclusive(db, db->d_mask, (const u64*)d_sample, n_sample, d_overlap, d_n_excl, d_n_match, db->d_maskbits);
 }
 
+static int use_ctx(yh_db* db, int c);
+
+// Throughput form of yh_run_device for a caller with many samples in HBM: the step's tail (reduce + exclusive pass)
+// is queued on a second stream of the handle, so the NEXT call's lookup runs beside it.  The outputs of a pipelined
+// call are complete, in the order of the handle's stream, only after yh_run_device_join (or any other query, or
+// yh_db_synchronize, all of which join first); consecutive calls must use different output buffers.
+int yh_run_device_pipelined(yh_db* db, const uint64_t* d_sample, uint64_t n_sample, uint32_t* d_overlap,
+                            uint32_t* d_n_excl, uint32_t* d_n_match) {
+    if (!db_ok(db)) return YH_ERR_INVALID_ARG;
+    if (!d_overlap || !d_n_excl || !d_n_match || (n_sample && !d_sample)) { yh_set_error("null device pointer"); return YH_ERR_INVALID_ARG; }
+    YH_TRY(db_select(db));
+    // only the sample-driven fused step splits; everything else runs as yh_run_device does
+    if (!prefer_indexed(db, n_sample) || db->n_ghost) return yh_run_device(db, d_sample, n_sample, d_overlap, d_n_excl, d_n_match);
+    if (!db->st_tail) {
+        YH_HIP(hipStreamCreateWithFlags(&db->st_tail, hipStreamNonBlocking));
+        for (int p = 0; p < 2; ++p) {
+            YH_HIP(hipEventCreateWithFlags(&db->ev_lookup[p], hipEventDisableTiming));
+            YH_HIP(hipEventCreateWithFlags(&db->ev_tail[p], hipEventDisableTiming));
+        }
+    }
+    const int p = db->pipe_parity ^= 1;
+    YH_TRY(pipe_join(db, p));  // the step before the previous one used these counters and this context: its tail must be done
+    if (db->ctx_open[p]) db->ctx_clobbered[p] = true;
+    YH_TRY(use_ctx(db, p));
+    db->pipe_on = true;
+    const int rc = yh_q_overlap_indexed(db, (const u64*)d_sample, n_sample, d_overlap, true, d_n_excl, d_n_match);
+    db->pipe_on = false;
+    if (rc == 2) return YH_OK;
+    if (rc != YH_OK) return rc;
+    // (a handle without holder sets: the general exclusive pass, on the handle's stream)
+    return yh_q_exclusive(db, db->d_mask, (const u64*)d_sample, n_sample, d_overlap, d_n_excl, d_n_match, db->d_maskbits);
+}
+
+int yh_run_device_join(yh_db* db) {
+    if (!db_ok(db)) return YH_ERR_INVALID_ARG;
+    YH_TRY(db_select(db));
+    return pipe_join(db);
+}
+
 int yh_run(yh_db* db, const uint64_t* sample, uint64_t n_sample, uint32_t* overlap, uint32_t* n_excl,
            uint32_t* n_match) {
     if (!db_ok(db)) return YH_ERR_INVALID_ARG;
@@ -761,7 +821,7 @@ int yh_run_finish_device(yh_db* db, int ctx, const uint32_t* d_global_bits, uint
 // ---- pipelined host-buffer run calls ---------------------------------------------------------------
 static int slot_prepare(yh_db* db, RunSlot& s, u64 n_sample, u64 packed_bytes, bool rows_staging) {
     const u64 N = std::max<u64>(db->n_refs, 1);
-    if (!db->st_in) YH_HIP(hipStreamCreateWithFlags(&db->st_in, hipStreamNonBlocking));
+    for (hipStream_t& q : db->st_in) if (!q) YH_HIP(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
     if (!s.ev_up) {
         YH_HIP(hipEventCreateWithFlags(&s.ev_up, hipEventDisableTiming));
         YH_HIP(hipEventCreateWithFlags(&s.ev_out, hipEventDisableTiming));
@@ -818,12 +878,14 @@ static int submit_common(yh_db* db, int slot, const void* sample, u64 n_or_bytes
     YH_TRY(slot_prepare(db, s, n_sample, packed_bytes, rows_staged));
     s.h_bad[0] = 0;
     s.h_bad[1] = 0;
+    static const bool one_up = [] { const char* e = yh_tune_env("YH_ONE_UPLOAD_STREAM"); return e && e[0] == '1'; }();
+    hipStream_t up = db->st_in[one_up ? 0 : (slot & 1)];
     if (packed) {
-        if (packed_bytes) YH_HIP(hipMemcpyAsync(s.d_packed, sample, packed_bytes, hipMemcpyHostToDevice, db->st_in));
+        if (packed_bytes) YH_HIP(hipMemcpyAsync(s.d_packed, sample, packed_bytes, hipMemcpyHostToDevice, up));
     } else if (n_sample) {
-        YH_HIP(hipMemcpyAsync(s.d_sample, sample, n_sample * sizeof(u64), hipMemcpyHostToDevice, db->st_in));
+        YH_HIP(hipMemcpyAsync(s.d_sample, sample, n_sample * sizeof(u64), hipMemcpyHostToDevice, up));
     }
-    YH_HIP(hipEventRecord(s.ev_up, db->st_in));
+    YH_HIP(hipEventRecord(s.ev_up, up));
     // (The way back stays on the handle's stream: HIP moves device -> pinned host with blit kernels, and a third stream
     // only added cross-stream waits in front of every step -- traced in round 2.)
     YH_HIP(hipStreamWaitEvent(db->stream, s.ev_up, 0));

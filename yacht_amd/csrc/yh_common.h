@@ -209,9 +209,16 @@ struct yh_db {
     u32* d_ghost_src = nullptr;  // [n_ghost] bit index into the all-gathered subset bits
     u64 ghost_begin = 0, n_ghost = 0;
 
+    // pipelined device-resident steps (yh_run_device_pipelined): the tail of step k beside the lookup of step k + 1
+    hipStream_t st_tail = nullptr;
+    hipEvent_t ev_lookup[2] = {nullptr, nullptr}, ev_tail[2] = {nullptr, nullptr};
+    bool tail_pending[2] = {false, false};  // a tail recorded in ev_tail[p] the handle's stream has not been made to wait for
+    bool pipe_on = false;                   // set around the one call that may split its step
+    int pipe_parity = 0;
+
     // pipelined host-buffer calls
     RunSlot slots[YH_RUN_SLOTS];
-    hipStream_t st_in = nullptr;  // the upload stream beside `stream`
+    hipStream_t st_in[2] = {nullptr, nullptr};  // upload streams beside `stream` (slots alternate: two copy engines, the fixed cost of one copy hidden behind the other)
     const u32* d_bad = nullptr;  // non-null while the kernels of a call with a deferred ordering verdict are being queued:
     u32 bad_gen = 0;             // the check kernel in front of them stores bad_gen there when the sample is not ascending
                                  // (generations are unique per handle, so the word never has to be cleared)

@@ -1222,9 +1222,10 @@ static int ensure_reps(yh_db* db, u32& R) {
     if (db->reps_cap < (u64)R * N) {
         YH_HIP(hipStreamSynchronize(db->stream));
         if (db->d_reps) { (void)hipFree(db->d_reps); db->d_reps = nullptr; db->reps_cap = 0; }
-        // (two sets back to back: the second one counts hits on shared hashes in the fused run step)
-        YH_HIP(hipMalloc((void**)&db->d_reps, 2 * (u64)R * N * sizeof(u32) + 16));
-        YH_HIP(hipMemsetAsync(db->d_reps, 0, 2 * (u64)R * N * sizeof(u32) + 16, db->stream));
+        // (two sets back to back: the second one counts hits on shared hashes in the fused run step; and all of
+        // that twice: the pipelined step alternates between the two pairs, see yh_q_overlap_indexed)
+        YH_HIP(hipMalloc((void**)&db->d_reps, 4 * (u64)R * N * sizeof(u32) + 16));
+        YH_HIP(hipMemsetAsync(db->d_reps, 0, 4 * (u64)R * N * sizeof(u32) + 16, db->stream));
         db->reps_cap = (u64)R * N;
     }
     return YH_OK;
@@ -1241,7 +1242,8 @@ static int claim_hit_flags(yh_db* db) {
 // hit == nullptr: only ex_e is summed (the fused run step).  One wave per work record; the work list
 // (db->d_work, db->d_work_count) was appended by k_reduce_replicas / k_excl_worklist on the same stream.
 static void launch_excl_pieces(yh_db* db, const u32* d_maskbits, const u8* d_hit, u32* d_ex_e, u32* d_ex_m, u32* d_ovsh,
-                               bool sets = false) {
+                               bool sets = false, hipStream_t on = nullptr) {
+    const hipStream_t st = on ? on : db->stream;
     // sets: the work list holds pieces of holder-set records (appended by k_reduce_replicas), not of postings
     const uint4* rec = sets ? db->d_hrec : db->d_rrec;
     const uint4* recx = sets ? db->d_hrecx : db->d_rrecx;
@@ -1251,11 +1253,11 @@ static void launch_excl_pieces(yh_db* db, const u32* d_maskbits, const u8* d_hit
     const u32 per_wg = EXCL_PIECE_THREADS / 64;
     const u32 grid = std::min<u32>((db->n_chunks + per_wg - 1) / per_wg, (u32)YH_EXCL_GRID);
     if (words <= EXCL_LDS_WORDS)
-        k_excl_pieces<true><<<grid, EXCL_PIECE_THREADS, words * sizeof(u32), db->stream>>>(
+        k_excl_pieces<true><<<grid, EXCL_PIECE_THREADS, words * sizeof(u32), st>>>(
             db->d_work_count, db->d_work, db->d_rpo, db->d_rg, rec, recx, mult, db->d_po, n_rec, db->d_pr,
             d_maskbits, words, d_hit, d_ex_e, d_ex_m, d_ovsh);
     else
-        k_excl_pieces<false><<<grid, EXCL_PIECE_THREADS, 0, db->stream>>>(
+        k_excl_pieces<false><<<grid, EXCL_PIECE_THREADS, 0, st>>>(
             db->d_work_count, db->d_work, db->d_rpo, db->d_rg, rec, recx, mult, db->d_po, n_rec, db->d_pr,
             d_maskbits, words, d_hit, d_ex_e, d_ex_m, d_ovsh);
 }
@@ -1369,6 +1371,11 @@ int yh_q_run_fused(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap,
     return YH_OK;
 }
 
+static bool fused_possible(const yh_db* db, const u32* d_fused_excl, bool for_exclusive) {
+    static const bool fused_off = [] { const char* e = yh_tune_env("YH_NO_FUSED_RUN"); return e && e[0] == '1'; }();
+    return d_fused_excl && for_exclusive && db->d_work && db->d_hrec && db->d_hpo && !fused_off;
+}
+
 // overlap (and, with for_exclusive, the shared-hash flags, the subset mask and zeroed exclusive
 // accumulators) through the directory; same outputs as yh_q_overlap(..., flag_shared, make_mask)
 // d_fused_excl / d_fused_match non-null: the whole run step in three launches (see yh_q_run_fused)
@@ -1400,10 +1407,16 @@ int yh_q_overlap_indexed(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_ov
     // step 49.9 -> 48.4 us; two: 51.7; 83 k-hash real-shape sample: 28.8 / 26.3 / 25.4 us with 8 / 4 / 2)
     const u32 r_want = ri_env ? ri_env : 4u;
     while (R > 1 && R > r_want) R >>= 1;
-    static const bool fused_off = [] { const char* e = yh_tune_env("YH_NO_FUSED_RUN"); return e && e[0] == '1'; }();
-    const bool fused = d_fused_excl && for_exclusive && db->d_work && db->d_hrec && db->d_hpo && !fused_off;
+    const bool fused = fused_possible(db, d_fused_excl, for_exclusive);
     if (for_exclusive && db->n_shared && !fused) YH_TRY(claim_hit_flags(db));
-    u32* const reps2 = db->d_reps + db->reps_cap;
+    // Pipelined steps (yh_run_device_pipelined): the lookup stays on the handle's stream, reduce + exclusive pass go to
+    // the tail stream behind an event, and consecutive steps alternate between two sets of counters and two step
+    // contexts -- the lookup of step k + 1 runs while the tail of step k does (~11 us of launch and round-trip
+    // latency for almost no work).
+    const bool piped = db->pipe_on && fused_possible(db, d_fused_excl, for_exclusive) && !lookup_half_only;
+    u32* const reps1 = db->d_reps + (piped ? (u64)db->pipe_parity * 2 * db->reps_cap : 0);
+    u32* const reps2 = reps1 + db->reps_cap;
+    hipStream_t st_tail = piped ? db->st_tail : st;
     // (no kernel in front of the lookup: the counters are zero at rest)
     yh_ring_record_begin(db, db->ev_overlap);
     u8* const d_hitflags = (for_exclusive && db->n_shared && !fused) ? db->d_hit : nullptr;
@@ -1411,7 +1424,7 @@ int yh_q_overlap_indexed(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_ov
     const u32* const d_filter = yh_filter_of(db);
 #define YH_TILE_LAUNCH(UU, TT, BB, FILTER)                                                                                        \
     k_index_lookup_tile<UU, TT, BB><<<(u32)((n_sample + (u64)(TT) * (UU) - 1) / ((u64)(TT) * (UU))), TT, 0, st>>>(                 \
-        d_sample, n_sample, yh_dir_view(db), FILTER, db->filter_mul, db->d_po, db->d_pr, db->d_reps, R - 1, N, d_hitflags, d_reps2, \
+        d_sample, n_sample, yh_dir_view(db), FILTER, db->filter_mul, db->d_po, db->d_pr, reps1, R - 1, N, d_hitflags, d_reps2, \
         db->d_work_count, db->d_bad, db->bad_gen)
     if (n_sample && db->n_distinct && U == 256)
         // small samples: latency-bound, so no filter read in front of the bucket; 256-lane workgroups keep every CU busy
@@ -1423,16 +1436,24 @@ int yh_q_overlap_indexed(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_ov
     else if (fused && db->d_work_count)
         YH_HIP(hipMemsetAsync(db->d_work_count, 0, sizeof(u32), st));
     yh_ring_record_end(db, db->ev_overlap);
-    k_reduce_replicas<<<(u32)((N + 255) / 256), 256, 0, st>>>(
-        db->d_reps, R, N, d_overlap, (for_exclusive && !fused) ? db->d_mask : nullptr,
+    if (piped) {
+        YH_HIP(hipEventRecord(db->ev_lookup[db->pipe_parity], st));
+        YH_HIP(hipStreamWaitEvent(st_tail, db->ev_lookup[db->pipe_parity], 0));
+    }
+    k_reduce_replicas<<<(u32)((N + 255) / 256), 256, 0, st_tail>>>(
+        reps1, R, N, d_overlap, (for_exclusive && !fused) ? db->d_mask : nullptr,
         for_exclusive ? db->d_maskbits : nullptr, (for_exclusive && !fused) ? db->d_excl_e : nullptr,
         fused ? FusedRun{reps2, db->d_sizes, db->d_nshared, d_fused_excl, d_fused_match, d_bits_out, db->d_hpo, db->d_work,
                          db->d_work_count, (u32)(db->n_ghost ? db->ghost_begin : N)}
               : FusedRun{});
     if (fused && !lookup_half_only) {  // (sharded run: the posting-list half follows the exchange of the subset bits)
-        yh_ring_record_begin(db, db->ev_excl);
-        if (db->n_chunks) launch_excl_pieces(db, db->d_maskbits, nullptr, d_fused_excl, nullptr, nullptr, true);
-        yh_ring_record_end(db, db->ev_excl);
+        if (!piped) yh_ring_record_begin(db, db->ev_excl);
+        if (db->n_chunks) launch_excl_pieces(db, db->d_maskbits, nullptr, d_fused_excl, nullptr, nullptr, true, st_tail);
+        if (!piped) yh_ring_record_end(db, db->ev_excl);
+    }
+    if (piped) {
+        YH_HIP(hipEventRecord(db->ev_tail[db->pipe_parity], st_tail));
+        db->tail_pending[db->pipe_parity] = true;
     }
     YH_HIP(hipGetLastError());
     return fused ? 2 : YH_OK;  // 2: the exclusive counts are done too

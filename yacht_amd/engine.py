@@ -291,6 +291,15 @@ class RefDB:
         _lib.check(self._lib.yh_run_device(self._h, C.c_void_p(d_sample), n_sample, C.c_void_p(d_overlap),
                                            C.c_void_p(d_excl), C.c_void_p(d_match)))
 
+    def run_device_pipelined(self, d_sample: int, n_sample: int, d_overlap: int, d_excl: int, d_match: int) -> None:
+        """run_device whose tail runs beside the next call's lookup; outputs are complete after run_device_join()
+        (or any other query / synchronize on the handle).  Alternate at least two output buffers."""
+        _lib.check(self._lib.yh_run_device_pipelined(self._h, C.c_void_p(d_sample), n_sample, C.c_void_p(d_overlap),
+                                                     C.c_void_p(d_excl), C.c_void_p(d_match)))
+
+    def run_device_join(self) -> None:
+        _lib.check(self._lib.yh_run_device_join(self._h))
+
     # ---- yacht train -------------------------------------------------------------------------
     def nshared_device(self, d_out: int) -> None:
         """d_out[j] = shared hashes of reference j (device array of n_refs uint32): the row weights of the pairwise pass."""
