@@ -56,8 +56,15 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="gtdb_rs214_scale", choices=["gtdb_rs214_scale", "config2_1000refs"])
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="N>1: weak = 85 205 refs per GPU (database grows), strong = one 85 205-ref database cut N ways")
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
+                    help="N>1: strong (default) = BASELINE configs[2], ONE 85 205-reference database over the N GPUs; "
+                         "weak = 85 205 references per GPU (the database grows with N)")
+    ap.add_argument("--shard", default="hash", choices=["hash", "refs"],
+                    help="N>1: hash (default) = every GPU holds one HASH RANGE of all references and looks up the sample's hashes "
+                         "in it (dist.HashRangeRefDB: table AND lookups divide by N; counts are summed); refs = every GPU holds a "
+                         "range of the REFERENCES + ghosts and looks up the whole sample (dist.ShardedRefDB: the capacity mode)")
+    ap.add_argument("--no-scaling-model", action="store_true",
+                    help="N=1: skip the measurement of one rank's share of a G-way hash-range step (G = 2, 4, 8)")
     ap.add_argument("--refs", type=int, default=0, help="override references per GPU (testing only)")
     ap.add_argument("--sample-hashes", type=int, default=1_000_000)
     ap.add_argument("--samples", type=int, default=8, help="distinct samples rotated through the steps")
@@ -145,6 +152,8 @@ def cpu_model() -> str:
 
 def main() -> int:
     args = parse_args()
+    if args.scaling is None:
+        args.scaling = "strong" if args.gpus > 1 else "weak"  # (the same thing at N = 1)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.force_dist:
         return launch_ranks(args)
     # stdout carries the ONE JSON line and nothing else: libraries that print banners at start-up
@@ -201,10 +210,28 @@ def main() -> int:
         wl_name = "configs[1] synthetic (~5000-hash refs)"
     n_total = per_gpu * world if args.scaling == "weak" else per_gpu
     plan = synth.global_db_plan(args.seed, n_total, **gen)
+    by_hash = multi and args.shard == "hash"
     shards = ydist.shard_plan(plan["offsets"].astype(np.uint64), world)
-    r_beg, r_end = shards[rank]
-    n_local = r_end - r_beg
-    values, offsets = synth.global_db_refs_device(plan, np.arange(r_beg, r_end), device=str(dev))
+    max_hash_db = synth.max_hash_for_scaled(1000)
+    bounds = ydist.hash_range_bounds(max_hash_db, world)
+    if by_hash:
+        # this rank's HASH RANGE of every reference, generated in chunks of references (any rank generates any reference)
+        r_beg, r_end = 0, n_total
+        n_local = n_total
+        vs, sizes_l = [], []
+        for c0 in range(0, n_total, 16384):
+            v_c, o_c = synth.global_db_refs_device(plan, np.arange(c0, min(n_total, c0 + 16384)), device=str(dev))
+            v_c, o_c = ydist.slice_to_hash_range(v_c, o_c, bounds[rank], bounds[rank + 1])
+            vs.append(v_c)
+            sizes_l.append(o_c[1:] - o_c[:-1])
+        values = torch.cat(vs).contiguous()
+        offsets = torch.zeros(n_total + 1, dtype=torch.int64, device=dev)
+        offsets[1:] = torch.cumsum(torch.cat(sizes_l), 0)
+        del vs, sizes_l
+    else:
+        r_beg, r_end = shards[rank]
+        n_local = r_end - r_beg
+        values, offsets = synth.global_db_refs_device(plan, np.arange(r_beg, r_end), device=str(dev))
     H = int(values.numel())
     K = max(args.samples, 1)
     samples = [synth.global_db_sample_device(plan, args.seed + 1000 + i, n_sample=args.sample_hashes, n_present=n_present,
@@ -228,7 +255,12 @@ def main() -> int:
     stream = torch.cuda.Stream(device=dev)
     sdb = None
     with torch.cuda.stream(stream):
-        if multi:
+        if by_hash:
+            sdb = ydist.HashRangeRefDB(values, offsets, bounds, ydist.HipRangeBackend(local_rank),
+                                       block=max(1, min(args.gather_every, 8)))
+            db = sdb.local.handle
+            row_stride = n_total
+        elif multi:
             sdb = ydist.ShardedRefDB(values, offsets, ydist.HipLocalBackend(local_rank), block=max(1, min(args.gather_every, 8)))
             db = sdb.local.handle
             n_rows = torch.tensor([sdb.n_rows], device=dev, dtype=torch.int64)
@@ -259,6 +291,8 @@ def main() -> int:
                     for _ in range(NBUF)]
     pending = [None] * NBUF
     staged_gather = multi and args.backend != "nccl"
+    if by_hash:  # the block's rows are SUMMED over the ranks (to rank 0), not gathered
+        gathered_blk = [None] * NBUF
     # all-gathering the rows hands every rank world x 8 MB per block it never reads; results are consumed on rank 0
     to_root = multi and not staged_gather and args.count_gather == "root"
     root_lists = [([gathered_blk[b][r] for r in range(world)] if rank == 0 else None) for b in range(NBUF)] if to_root else None
@@ -270,6 +304,13 @@ def main() -> int:
 
     def gather_block(i):  # sample i was the last of its block: the block leaves
         blk = (i // GB) % NBUF
+        if by_hash:  # one reduce of [GB, 3, N] per block; rank 0 holds the sums (its buffer is overwritten by them)
+            if staged_gather:
+                counts_blk[blk].copy_(sdb.reduce(counts_blk[blk], dst=0))
+            else:
+                w = dist.reduce(counts_blk[blk], dst=0, op=dist.ReduceOp.SUM, async_op=not args.sync_gather)
+                pending[blk] = None if args.sync_gather else w
+            return
         if staged_gather:
             ydist.all_gather_into(gathered_blk[blk].view(-1), counts_blk[blk].view(-1))
         elif to_root:  # rank 0 receives [world, GB, 3, row_stride]; the others only send their 8 MB
@@ -384,7 +425,7 @@ def main() -> int:
     if sdb is None and args.pipelined_tail:  # the timed loop's own (pipelined) outputs: its last two steps are still in the buffers
         last = state["i"] - 1
         pipelined_ok = all(bool(torch.equal(rows_of(last - d), results[(last - d) % K])) for d in range(min(2, NBUF)))
-    if multi:  # the steps' own gathers must carry this rank's rows
+    if multi and not by_hash:  # the steps' own gathers must carry this rank's rows
         for b in range(NBUF):
             if not to_root or rank == 0:
                 assert bool(torch.equal(gathered_blk[b][rank], counts_blk[b])), "gather ran ahead of the kernels"
@@ -645,6 +686,52 @@ def main() -> int:
                           "64-bit per-sample words; device-resident, distinct samples"}
         del cat, bout, bs
 
+    # ---- what ONE rank of a G-way hash-range run computes per step, measured here (N = 1 only) ------------------
+    # The first multi-GPU run has a prediction to be compared with: rank 0's range of the database (1 / G of the hashes
+    # of every reference) is built on this GPU and the two halves of its step (yh_run_local_range_device,
+    # yh_run_finish_range_device) are timed on its slice of the rotating samples -- everything but the collectives.
+    scaling_model = None
+    if not multi and not args.no_scaling_model and args.workload == "gtdb_rs214_scale" and not args.no_indexed:
+        per_g = {}
+        for G in (2, 4, 8):
+            bg = ydist.hash_range_bounds(max_hash_db, G)
+            v_g, o_g = ydist.slice_to_hash_range(values, offsets, bg[0], bg[1])
+            with torch.cuda.stream(stream):
+                hr = ydist.HashRangeRefDB(v_g, o_g, [bg[0], bg[1]], ydist.HipRangeBackend(local_rank), block=1)
+            torch.cuda.synchronize()
+            hr.local.handle.set_stream(stream.cuda_stream)
+            cg = [hr.new_counts() for _ in range(2)]
+
+            def step_g(i):
+                with torch.cuda.stream(stream):
+                    hr.begin(samples[i % K], cg[i % 2], 0, 0)
+                    hr.end(cg[i % 2], 0, 0)
+
+            for i in range(max(args.warmup, K)):
+                step_g(i)
+            fence()
+            n_g = max(args.steps, 100)
+            t0 = time.perf_counter()
+            for i in range(n_g):
+                step_g(i)
+            fence()
+            el = (time.perf_counter() - t0) / n_g
+            a_, b_ = hr._slice_of(samples[0])
+            per_g[str(G)] = {"rank0_compute_ms_per_step": round(1e3 * el, 4), "sample_hashes_in_range": int(b_ - a_),
+                             "ref_hashes_in_range": int(v_g.numel()),
+                             "lookup_choice": "indexed" if hr.local.handle.lookup_choice(int(b_ - a_)) == ylib.YH_LOOKUP_INDEXED else "stream"}
+            hr.close()
+            del v_g, o_g, cg, hr
+        coll = 0.010  # ms per step: round 2's forced-exchange measurement of the N > 1 code path with one rank (0.0534 - 0.0438)
+        scaling_model = {
+            "per_G": per_g,
+            "collectives_ms_per_step_assumed": coll,
+            "predicted_ms_per_step": {g: round(v["rank0_compute_ms_per_step"] + coll, 4) for g, v in per_g.items()},
+            "predicted_speedup_vs_1gpu": {g: round(ms_per_step / (v["rank0_compute_ms_per_step"] + coll), 2) for g, v in per_g.items()},
+            "how": "rank 0's hash range of the whole database built on THIS GPU, both halves of its step timed on its slice of the "
+                   "rotating samples (no collectives); + the assumed cost of the two collectives per block of 8 samples",
+        }
+
     # ---- roofline of the dominant kernel of the DEFAULT step --------------------------------------------
     # Streaming lookup (k_stream_lookup): `achieved` = bytes one launch HAS to move in the layout the kernel
     # reads (yh_db_info.stream_bytes: one delta byte per (hash, reference) pair + an 8-byte header per 1024,
@@ -843,7 +930,10 @@ def main() -> int:
                 "pipelined_tail": bool(not multi and args.pipelined_tail),
                 "step": "overlap + exclusive counts" + ((f" (blocks of {GB} samples: one all_gather of their subset bits" + (", two blocks in flight" if pipelined else "") + f") + one {'gather to rank 0' if to_root else 'all_gather'} of the count rows per {GB} samples"
                                                        + ("" if args.sync_gather else " (overlapped with the next sample)")) if multi else ""),
-                "parallelism": f"one database, references sharded x{world} by hash count",
+                "parallelism": (f"one database, hash space cut x{world}: every GPU holds one hash range of all references, looks up "
+                                f"the sample's hashes in it; counts summed" if by_hash else
+                                f"one database, references sharded x{world} by hash count"),
+                "shard": ("hash" if by_hash else "refs") if multi else None,
                 "scipy": scipy_version,
             },
             "roofline": roofline,
@@ -852,6 +942,7 @@ def main() -> int:
             "pipelined_steps_equal_plain_steps": pipelined_ok,
             "device_resident": device_resident,
             "host_inclusive": host_inclusive,
+            "scaling_model": scaling_model,
             "real_shape": real_shape,
             "batched": batched,
             "paths": paths,

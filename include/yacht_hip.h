@@ -235,6 +235,25 @@ int yh_run_local_device(yh_db* db, int ctx, const uint64_t* d_sample, uint64_t n
                         uint32_t* d_n_excl, uint32_t* d_n_match, uint32_t* d_bits_out);
 int yh_run_finish_device(yh_db* db, int ctx, const uint32_t* d_global_bits, uint32_t* d_n_excl);
 
+/* ---- the run step over several GPUs by HASH RANGE (option B) ----------------------------------------
+ * Rank g's handle is built over ALL N references, each cut down to its hashes in [lo_g, hi_g) (a contiguous piece of
+ * every sorted sketch; yacht_amd/dist.py: HashRangeRefDB), and looks up only the sample's hashes in that range -- so
+ * both the table a lookup reads and the number of lookups shrink with the number of ranks, which sharding by
+ * reference does not give (there every rank looks up the whole sample).  A hash's holders all sit on one rank:
+ * multiplicity, sharedness and exclusivity are rank-local -- no ghosts -- and every count is a SUM over the ranks
+ * once the subset is the global one, "some rank saw an overlap":
+ *   yh_run_local_range_device   lookup + reduce of the sample's hashes in this range: d_overlap and d_n_match hold
+ *                               this rank's share; its subset bits go to d_bits_out (ceil(n_refs / 256) * 8 words)
+ *   -- all-gather of the ranks' bits (torch.distributed / RCCL) --
+ *   yh_run_finish_range_device  global subset = OR of the n_ranks gathered rows (row r starts r * stride_words words
+ *                               behind d_gathered_bits); d_n_excl = this rank's share of n_exclusive for it
+ *   -- sum of the three rows over the ranks (one reduce per block of samples) --
+ * Same step contexts and the same rule about other queries in between as the reference-sharded pair above.        */
+int yh_run_local_range_device(yh_db* db, int ctx, const uint64_t* d_sample, uint64_t n_sample, uint32_t* d_overlap,
+                              uint32_t* d_n_match, uint32_t* d_bits_out);
+int yh_run_finish_range_device(yh_db* db, int ctx, const uint32_t* d_gathered_bits, uint32_t n_ranks, uint64_t stride_words,
+                               uint32_t* d_n_excl);
+
 /* Pipelined host-buffer form of yh_run: SURVEY.md 8d's steady-state call -- sample H2D, kernels,
  * counts D2H -- split in two so that consecutive samples overlap.  yh_run_submit queues, on two
  * streams of the handle, the upload of `sample`, an ordering check ON THE DEVICE (a sample that fails

@@ -1,0 +1,171 @@
+"""HashRangeRefDB (yacht_amd/dist.py: the run step with the HASH SPACE spread over the ranks) on CPU: world_size 2 and 3,
+gloo.  The plumbing -- range bounds, cutting every reference and every sample to a range, the bit rows of a block of
+samples through one all-gather, the OR over the ranks, the sum of the shares -- is the code under test; the per-rank
+arithmetic is stood in by a set-based restatement of the two library calls (test infrastructure).  The reduced result
+must equal the oracle on the WHOLE database."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from yacht_amd import dist as ydist
+from yacht_amd import synth
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+class SetRangeBackend:
+    """yh_run_local_range_device / yh_run_finish_range_device restated with Python sets."""
+
+    def make_range_db(self, values_t, offsets_t):
+        import torch
+
+        v = values_t.numpy().view(np.uint64)
+        o = offsets_t.numpy()
+        refs = [set(v[o[j]:o[j + 1]].tolist()) for j in range(o.size - 1)]
+        holders = {}
+        for j, r in enumerate(refs):
+            for h in r:
+                holders.setdefault(h, []).append(j)
+        shared = {h: js for h, js in holders.items() if len(js) > 1}
+        nshared = [sum(1 for h in r if h in shared) for r in refs]
+
+        class L:
+            handle = None
+
+            def run_local(self, sample_t, a, b, counts_t, bits_t, ctx=0):
+                S = set(sample_t.numpy().view(np.uint64)[a:b].tolist())
+                ov = np.array([len(S & r) for r in refs], dtype=np.int64)
+                sh = np.array([sum(1 for h in (S & r) if h in shared) for r in refs], dtype=np.int64)
+                counts_t[0] = torch.from_numpy(ov.astype(np.int32))
+                counts_t[2] = torch.from_numpy((ov - sh).astype(np.int32))
+                bits = np.zeros(bits_t.numel(), dtype=np.uint32)
+                for j in np.flatnonzero(ov > 0):
+                    bits[j >> 5] |= np.uint32(1 << (j & 31))
+                bits_t.copy_(torch.from_numpy(bits.view(np.int32)))
+
+            def run_finish(self, gathered_t, n_ranks, stride_words, counts_t, ctx=0):
+                g = gathered_t.numpy().view(np.uint32)
+                words = (len(refs) + 31) // 32
+                acc = np.zeros(words, dtype=np.uint32)
+                for r in range(n_ranks):
+                    acc |= g[r * stride_words: r * stride_words + words]
+                mask = [bool((acc[j >> 5] >> (j & 31)) & 1) for j in range(len(refs))]
+                e = np.zeros(len(refs), dtype=np.int32)
+                for j, r in enumerate(refs):
+                    if mask[j]:
+                        e[j] = len(r) - nshared[j] + sum(1 for h in r if h in shared and not any(mask[x] for x in shared[h] if x != j))
+                counts_t[1] = torch.from_numpy(e)
+
+            def close(self):
+                pass
+
+        return L()
+
+
+def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
+    import torch
+    import torch.distributed as dist
+
+    from oracle import oracle
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(7)
+        refs = synth.clustered_refs(rng, 23, (1.0, 0.9, 0.5, 0.25, 0.1), 300)
+        refs[9] = np.zeros(0, np.uint64)
+        big = np.unique(rng.integers(2 ** 63, 2 ** 64 - 1, size=200, dtype=np.uint64))  # hashes above 2^63 (scaled = 1)
+        refs[3] = np.union1d(refs[3], big)
+        refs[len(refs) - 2] = np.union1d(refs[len(refs) - 2], big[:120])
+        values, offsets = synth.pack(refs)
+        vt = torch.from_numpy(values.view(np.int64).copy())
+        ot = torch.from_numpy(offsets.astype(np.int64))
+        bounds = ydist.hash_range_bounds(int(values.max()), world)
+        v, o = ydist.slice_to_hash_range(vt, ot, bounds[rank], bounds[rank + 1])
+        hr = ydist.HashRangeRefDB(v, o, bounds, SetRangeBackend())
+
+        def check(full, sample, what):
+            full = full.numpy().view(np.uint32)
+            want_ov = oracle.overlap(values, offsets, sample)
+            want_e, want_m = oracle.exclusive(values, offsets, want_ov > 0, sample)
+            assert np.array_equal(full[0], want_ov), f"rank {rank}: overlap ({what})"
+            assert np.array_equal(full[2], want_m), f"rank {rank}: n_match ({what})"
+            assert np.array_equal(full[1], want_e), f"rank {rank}: n_excl ({what})"
+
+        cases = [synth.sample_from_refs(rng, refs, [0, 3, 57, 58, 100], 0.6, 4000),
+                 synth.sample_from_refs(rng, refs, list(range(0, len(refs), 2)), 0.5, 3000),
+                 np.unique(rng.integers(0, 2 ** 40, size=500, dtype=np.uint64)),     # all of it in the first range
+                 np.zeros(0, np.uint64),
+                 np.union1d(big[::3], refs[0][:5])]                                # the two ends of the hash space
+        for k, sample in enumerate(cases):
+            st = torch.from_numpy(sample.view(np.int64).copy())
+            check(hr.gather(hr.run(st)), sample, f"case {k}")
+        # a reference whose ONLY overlap lies in another rank's range still joins this rank's subset: its exclusive
+        # count here must see it -- case 4 above (hashes at the two ends) is that situation for the middle rank.
+        # blocks of 3 samples per exchange, two blocks in flight, a partly filled block, one reduce per block
+        hr3 = ydist.HashRangeRefDB(v, o, bounds, SetRangeBackend(), block=3)
+        samples = [synth.sample_from_refs(rng, refs, [int(x) for x in rng.choice(len(refs), size=4 + k, replace=False)], 0.5, 2000)
+                   for k in range(5)]
+        ts = [torch.from_numpy(x.view(np.int64).copy()) for x in samples]
+        blk = [torch.zeros((3, 3, hr3.n_total), dtype=torch.int32) for _ in range(2)]
+        for g in range(3):
+            hr3.begin(ts[g], blk[0][g], 0, g)
+        hr3.exchange(0)
+        for g in range(2):
+            hr3.begin(ts[3 + g], blk[1][g], 1, g)
+        hr3.exchange(1)
+        for g in range(3):
+            hr3.end(blk[0][g], 0, g)
+        for g in range(2):
+            hr3.end(blk[1][g], 1, g)
+        tot = [hr3.reduce(b.clone(), dst=0) for b in blk]  # the block's rows in ONE collective, to rank 0
+        if rank == 0:
+            for k, smp in enumerate(samples):
+                check(tot[k // 3][k % 3], smp, f"blocked {k}")
+        open(os.path.join(out_dir, f"ok{rank}"), "w").close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_hash_range_refdb_gloo(tmp_path, world):
+    import torch.multiprocessing as mp
+
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(world))
+
+
+def test_bounds_and_slices():
+    import torch
+
+    rng = np.random.default_rng(0)
+    refs = [np.unique(rng.integers(0, 2 ** 64 - 1, size=200, dtype=np.uint64)) for _ in range(7)]
+    refs[3] = np.zeros(0, np.uint64)
+    values, offsets = synth.pack(refs)
+    vt = torch.from_numpy(values.view(np.int64).copy())
+    ot = torch.from_numpy(offsets.astype(np.int64))
+    for world in (1, 2, 3, 8):
+        b = ydist.hash_range_bounds(int(values.max()), world)
+        assert b[0] == 0 and b[-1] == 2 ** 64 and all(b[i] < b[i + 1] for i in range(world))
+        total = 0
+        sample = np.unique(rng.integers(0, 2 ** 64 - 1, size=1000, dtype=np.uint64))
+        st = torch.from_numpy(sample.view(np.int64).copy())
+        covered = 0
+        for g in range(world):
+            v, o = ydist.slice_to_hash_range(vt, ot, b[g], b[g + 1])
+            v, o = v.numpy().view(np.uint64), o.numpy()
+            for j, r in enumerate(refs):
+                inr = (r >= np.uint64(b[g])) & ((r < np.uint64(b[g + 1])) if b[g + 1] < 2 ** 64 else np.ones(r.size, bool))
+                assert np.array_equal(v[o[j]:o[j + 1]], r[inr])
+            total += v.size
+            a, e = ydist.sample_slice(st, b[g], b[g + 1])
+            assert a == covered
+            covered = e
+        assert total == values.size and covered == sample.size

@@ -79,16 +79,17 @@ sys.exit(0 if ok else 1)
 '''
 
 
-def _launch(world: int, n_refs: int, tmp_path, lookup: str = "auto"):
+def _launch(world: int, n_refs: int, tmp_path, lookup: str = "auto", worker: str = None):
     script = tmp_path / "worker.py"
-    script.write_text(WORKER)
+    script.write_text(worker or WORKER)
     port = _free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), YH_ROOT=ROOT, YH_NREFS=str(n_refs), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        if lookup != "auto":
-            env["YH_LOOKUP"] = lookup  # force the streaming / the sample-driven lookup inside yh_run_local_device
+        if lookup != "auto":  # force the streaming / the sample-driven lookup inside yh_run_local_device (a tuning switch)
+            env["YH_DEBUG_TUNING"] = "1"
+            env["YH_LOOKUP"] = lookup
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, text=True))
     outs = []
@@ -120,11 +121,12 @@ def test_sharded_refdb_over_rccl_one_rank(hip_lib, tmp_path):
     assert p.returncode == 0, p.stdout + p.stderr
 
 
-def test_bench_over_rccl_one_rank(hip_lib):
-    """bench.py's N > 1 code path (ShardedRefDB step + async gather of the count rows) on RCCL with one rank."""
+@pytest.mark.parametrize("shard", ["hash", "refs"])
+def test_bench_over_rccl_one_rank(hip_lib, shard):
+    """bench.py's N > 1 code path (sharded step + async collectives of the bits and the count rows) on RCCL with one rank."""
     env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
                HSA_ENABLE_IPC_MODE_LEGACY="0", YH_FORCE_EXCHANGE="1")
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "6", "--warmup", "2",
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--shard", shard, "--steps", "6", "--warmup", "2",
                         "--refs", "4000", "--sample-hashes", "100000", "--samples", "3", "--percentile-steps", "8", "--present", "50"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout + p.stderr
@@ -132,8 +134,10 @@ def test_bench_over_rccl_one_rank(hip_lib):
     assert line["parity_bit_exact"] is True and line["config"]["parallelism"].startswith("one database")
 
 
-def test_bench_two_ranks_share_gpu_strong_and_weak(hip_lib, tmp_path):
-    """bench.py --gpus 2 over gloo on one GPU: the driver-run N > 1 path, bit-exact against the oracle."""
+@pytest.mark.parametrize("shard", ["hash", "refs"])
+def test_bench_two_ranks_share_gpu_strong_and_weak(hip_lib, tmp_path, shard):
+    """bench.py --gpus 2 over gloo on one GPU: the driver-run N > 1 path (hash-range shards by default, reference shards
+    + ghosts with --shard refs), bit-exact against the oracle."""
     for scaling in ("strong", "weak"):
         port = _free_port()
         procs = []
@@ -142,14 +146,14 @@ def test_bench_two_ranks_share_gpu_strong_and_weak(hip_lib, tmp_path):
                        MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
             procs.append(subprocess.Popen(
                 [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
-                 "--backend", "gloo", "--share-gpu", "--scaling", scaling, "--refs", "4000", "--sample-hashes", "100000",
+                 "--backend", "gloo", "--share-gpu", "--scaling", scaling, "--shard", shard, "--refs", "4000", "--sample-hashes", "100000",
                  "--samples", "3", "--percentile-steps", "8", "--present", "50"],
                 env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
         res = [p.communicate(timeout=900) for p in procs]
         assert all(p.returncode == 0 for p in procs), "\n".join(o + e for o, e in res)
         line = json.loads(res[0][0].strip().splitlines()[-1])
         assert line["parity_bit_exact"] is True and line["n_gpus"] == 2 and line["scaling"] == scaling
-        assert line["config"]["refs_total"] == (4000 if scaling == "strong" else 8000)
+        assert line["config"]["refs_total"] == (4000 if scaling == "strong" else 8000) and line["config"]["shard"] == shard
 
 
 def test_bench_starts_its_own_ranks(hip_lib):
@@ -165,3 +169,75 @@ def test_bench_starts_its_own_ranks(hip_lib):
     assert len(lines) == 1, p.stdout
     line = json.loads(lines[0])
     assert line["parity_bit_exact"] is True and line["n_gpus"] == 2
+
+
+RANGE_WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, os.environ["YH_ROOT"])
+import torch
+import torch.distributed as dist
+from oracle import oracle
+from yacht_amd import dist as ydist, synth
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("gloo")
+n_total = int(os.environ["YH_NREFS"])
+plan = synth.global_db_plan(31, n_total, cluster_frac=0.6)
+all_v, all_o = synth.global_db_refs_device(plan, np.arange(n_total), device="cuda:0")
+hv, ho = all_v.cpu().numpy().view(np.uint64), all_o.cpu().numpy().astype(np.uint64)
+bounds = ydist.hash_range_bounds(int(hv.max()), world)
+v, o = ydist.slice_to_hash_range(all_v, all_o, bounds[rank], bounds[rank + 1])
+hr = ydist.HashRangeRefDB(v, o, bounds, ydist.HipRangeBackend(0), block=2)
+ok = True
+def check(full, s, what):
+    global ok
+    full = full.cpu().numpy().view(np.uint32)
+    hs = s.cpu().numpy().view(np.uint64)
+    want_ov = oracle.overlap(hv, ho, hs, threads=4)
+    want_e, want_m = oracle.exclusive(hv, ho, want_ov > 0, hs)
+    for name, got, want in (("overlap", full[0], want_ov), ("n_excl", full[1], want_e), ("n_match", full[2], want_m)):
+        if not np.array_equal(got, want):
+            ok = False
+            bad = np.flatnonzero(got != want)
+            print(f"rank {rank} {what} {name}: {bad.size} differ, first {bad[:5]} got {got[bad[:5]]} want {want[bad[:5]]}", flush=True)
+ss = []
+for i, (shape, n_s) in enumerate((("present", 200000), ("real", 5000), ("present", 0), ("present", 30000))):
+    s = synth.global_db_sample_device(plan, 77 + i, n_sample=max(n_s, 1), n_present=60, device="cuda:0", shape=shape)
+    ss.append(s[:0] if n_s == 0 else s)
+for i, s in enumerate(ss):
+    c = hr.run(s)
+    torch.cuda.synchronize()
+    check(hr.gather(c), s, f"sample {i}")
+# blocks of two samples per exchange, two blocks in flight, one reduce per block (what bench.py --gpus N drives)
+blk = [torch.zeros((2, 3, hr.n_total), dtype=torch.int32, device=dev) for _ in range(2)]
+for g in range(2):
+    hr.begin(ss[g], blk[0][g], 0, g)
+hr.exchange(0)
+for g in range(2):
+    hr.begin(ss[2 + g], blk[1][g], 1, g)
+hr.exchange(1)
+for g in range(2):
+    hr.end(blk[0][g], 0, g)
+for g in range(2):
+    hr.end(blk[1][g], 1, g)
+torch.cuda.synchronize()
+tot = [hr.reduce(b.clone()) for b in blk]
+for k, s in enumerate(ss):
+    check(tot[k // 2][k % 2], s, f"blocked {k}")
+print(f"rank {rank}: range [{bounds[rank]}, {bounds[rank + 1]}), {int(v.numel())} of {int(all_v.numel())} hashes, ok {ok}", flush=True)
+hr.close()
+dist.barrier()
+dist.destroy_process_group()
+sys.exit(0 if ok else 1)
+'''
+
+
+@pytest.mark.parametrize("world,lookup", [(1, "auto"), (2, "auto"), (2, "stream"), (2, "indexed"), (3, "auto")])
+def test_hash_range_refdb_hip_processes_share_gpu(hip_lib, tmp_path, world, lookup):
+    """dist.HashRangeRefDB on the HIP backend: every rank holds one hash range of ALL references; the reduced counts
+    equal the oracle on the whole database (1, 2 and 3 processes sharing the GPU over gloo)."""
+    rcs, outs = _launch(world, 3000, tmp_path, lookup, worker=RANGE_WORKER)
+    assert all(rc == 0 for rc in rcs), "\n".join(outs)

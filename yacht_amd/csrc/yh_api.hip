@@ -818,6 +818,42 @@ int yh_run_finish_device(yh_db* db, int ctx, const uint32_t* d_global_bits, uint
     return rc;
 }
 
+// ---- hash-range shards: the step in two halves around ONE exchange, no ghosts ------------------------------------
+int yh_run_local_range_device(yh_db* db, int ctx, const uint64_t* d_sample, uint64_t n_sample, uint32_t* d_overlap,
+                              uint32_t* d_n_match, uint32_t* d_bits_out) {
+    if (!db_ok(db)) return YH_ERR_INVALID_ARG;
+    if (!d_overlap || !d_n_match || !d_bits_out || (n_sample && !d_sample)) { yh_set_error("null device pointer"); return YH_ERR_INVALID_ARG; }
+    if (db->n_ghost) { yh_set_error("a handle with ghosts is a reference shard, not a hash-range shard"); return YH_ERR_INVALID_ARG; }
+    YH_TRY(db_select(db));
+    YH_TRY(pipe_join(db));
+    YH_TRY(use_ctx(db, ctx));
+    db->ctx_open[ctx] = true;
+    db->ctx_clobbered[ctx] = false;
+    db->range_local = true;
+    // (d_n_match doubles as the non-null "fused" marker; with range_local nothing is written through the n_excl slot)
+    const int rc = yh_q_run_fused(db, (const u64*)d_sample, n_sample, d_overlap, d_n_match, d_n_match, 1, d_bits_out, nullptr,
+                                  prefer_indexed(db, n_sample));
+    db->range_local = false;
+    if (rc == 1) { yh_set_error("yh_run_local_range_device needs a non-empty handle in the default layout with its index"); return YH_ERR_UNSUPPORTED; }
+    return rc;
+}
+
+int yh_run_finish_range_device(yh_db* db, int ctx, const uint32_t* d_gathered_bits, uint32_t n_ranks, uint64_t stride_words,
+                               uint32_t* d_n_excl) {
+    if (!db_ok(db)) return YH_ERR_INVALID_ARG;
+    if (!d_n_excl || !d_gathered_bits || n_ranks < 1) { yh_set_error("null device pointer / no ranks"); return YH_ERR_INVALID_ARG; }
+    YH_TRY(db_select(db));
+    YH_TRY(use_ctx(db, ctx));
+    const bool clobbered = db->ctx_open[ctx] && db->ctx_clobbered[ctx];
+    db->ctx_open[ctx] = false;
+    db->ctx_clobbered[ctx] = false;
+    if (clobbered) {
+        yh_set_error("another query ran on the handle between the two halves of context %d: its work list is gone", ctx);
+        return YH_ERR_INVALID_ARG;
+    }
+    return yh_q_range_finish(db, d_gathered_bits, n_ranks, stride_words, d_n_excl);
+}
+
 // ---- pipelined host-buffer run calls ---------------------------------------------------------------
 static int slot_prepare(yh_db* db, RunSlot& s, u64 n_sample, u64 packed_bytes, bool rows_staging) {
     const u64 N = std::max<u64>(db->n_refs, 1);

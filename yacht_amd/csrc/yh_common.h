@@ -201,6 +201,7 @@ struct yh_db {
     uint4* ctx_work[YH_RUN_CONTEXTS] = {};
     u32* ctx_count[YH_RUN_CONTEXTS] = {};
     int ctx_now = 0;
+    bool range_local = false;  // set around the first half of a hash-range shard's step (yh_run_local_range_device)
     bool ctx_open[YH_RUN_CONTEXTS] = {};       // yh_run_local_device queued, yh_run_finish_device not yet
     bool ctx_clobbered[YH_RUN_CONTEXTS] = {};  // another query ran in the context's place meanwhile: its work list is gone
 
@@ -245,6 +246,7 @@ int yh_q_overlap(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap, b
 int yh_q_run_fused(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap, u32* d_excl, u32* d_match,
                    int phases = 3, u32* d_bits_out = nullptr, const u32* d_global_bits = nullptr, bool use_indexed = false);
 int yh_q_overlap_bsearch(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap);
+int yh_q_range_finish(yh_db* db, const u32* d_gathered, u32 n_ranks, u64 stride_words, u32* d_excl);
 // ---- the distinct-hash directory as the lookup kernels see it -------------------------------------
 // Primary structure: a table of 64-byte buckets, bucket(h) = floor(h * bkt_nb / 2^bits(max_hash))
 // (monotone in h, ~2 distinct hashes per bucket).  A bucket is 16 words = one HBM sector:

@@ -153,7 +153,7 @@ __global__ void __launch_bounds__(256) k_reduce_replicas(u32* __restrict__ reps,
                 fused.reps2[(u64)r * n + j] = 0;
             }
             fused.n_match[j] = acc - acc2;
-            fused.n_excl[j] = acc ? size_j - nshared_j : 0u;
+            if (fused.n_excl) fused.n_excl[j] = acc ? size_j - nshared_j : 0u;
         }
     }
     if (maskbits) {
@@ -197,6 +197,37 @@ __global__ void __launch_bounds__(256) k_ghost_bits(const u32* __restrict__ glob
         maskbits[w] = (u32)bal;
         maskbits[w + 1] = (u32)(bal >> 32);
     }
+}
+
+// Hash-range sharding (yh_run_finish_range_device): every rank holds the hashes of ONE range of every reference, so
+// "reference j overlaps the sample" is the OR over the ranks of their local subset bits.  From the gathered rows
+// (rank r's row starts r * stride words in) this kernel makes the global subset bits, the part of n_excl that needs
+// no posting list -- |R_j| - nshared_j of THIS rank's range, for the references of the global subset -- and the work
+// list of the exclusive pass over them.  work_count is zero when it starts (the lookup kernel cleared it).
+__global__ void __launch_bounds__(256) k_range_mask(const u32* __restrict__ gathered, u32 n_ranks, u64 stride, u64 n,
+                                                    const u32* __restrict__ sizes, const u32* __restrict__ nshared,
+                                                    const u32* __restrict__ rpo, u32* __restrict__ maskbits,
+                                                    u32* __restrict__ n_excl, uint4* __restrict__ work,
+                                                    u32* __restrict__ work_count) {
+    __shared__ u32 lds[8];
+    const u64 j = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    bool in = false;
+    u32 size_j = 0, nshared_j = 0, rpo_j = 0, rpo_end = 0;
+    if (j < n) {
+        u32 w = 0;
+        for (u32 r = 0; r < n_ranks; ++r) w |= gathered[(u64)r * stride + (j >> 5)];
+        in = (w >> (j & 31u)) & 1u;
+        size_j = sizes[j];
+        nshared_j = nshared[j];
+        if (work) { rpo_j = rpo[j]; rpo_end = rpo[j + 1]; }
+        n_excl[j] = in ? size_j - nshared_j : 0u;
+    }
+    const u64 bal = __ballot(in);
+    if ((threadIdx.x & 63) == 0) {
+        maskbits[(j >> 5)] = (u32)bal;
+        maskbits[(j >> 5) + 1] = (u32)(bal >> 32);
+    }
+    if (work) append_pieces(in, (u32)j, rpo_end - rpo_j, rpo_j, work, work_count, lds);
 }
 
 __global__ void __launch_bounds__(256) k_mask_bits(const u8* __restrict__ mask, u64 n, u32* __restrict__ maskbits) {
@@ -1305,8 +1336,10 @@ static int yh_q_overlap_stream(yh_db* db, const u64* d_sample, u64 n_sample, u32
     k_reduce_replicas<<<(u32)((N + 255) / 256), 256, 0, st>>>(
         db->d_reps, R, N, d_overlap, (make_mask && !fused) ? db->d_mask : nullptr, make_mask ? db->d_maskbits : nullptr,
         (with_index && !fused) ? db->d_excl_e : nullptr,
-        fused ? FusedRun{reps2, db->d_sizes, db->d_nshared, d_fused_excl, d_fused_match, d_bits_out, db->d_hpo, db->d_work,
-                         db->d_work_count, (u32)(db->n_ghost ? db->ghost_begin : N)}
+        // (range_local -- a hash-range shard's first half: n_excl and the work list wait for the global subset)
+        fused ? FusedRun{reps2, db->d_sizes, db->d_nshared, db->range_local ? nullptr : d_fused_excl, d_fused_match, d_bits_out,
+                         db->d_hpo, db->range_local ? nullptr : db->d_work, db->d_work_count,
+                         (u32)(db->n_ghost ? db->ghost_begin : N)}
               : FusedRun{});
     YH_HIP(hipGetLastError());
     return YH_OK;
@@ -1376,6 +1409,22 @@ static bool fused_possible(const yh_db* db, const u32* d_fused_excl, bool for_ex
     return d_fused_excl && for_exclusive && db->d_work && db->d_hrec && db->d_hpo && !fused_off;
 }
 
+// Second half of a step on a hash-range shard: global subset = OR of the ranks' gathered bits, then the exclusive pass.
+int yh_q_range_finish(yh_db* db, const u32* d_gathered, u32 n_ranks, u64 stride_words, u32* d_excl) {
+    if (!db->has_index || db->n_refs == 0) return YH_OK;
+    hipStream_t st = db->stream;
+    const u64 N = db->n_refs;
+    const bool sets = db->n_postings && db->d_hrec && db->d_hpo && db->d_work;
+    yh_ring_record_begin(db, db->ev_excl);
+    k_range_mask<<<(u32)((N + 255) / 256), 256, 0, st>>>(d_gathered, n_ranks, stride_words, N, db->d_sizes, db->d_nshared,
+                                                          sets ? db->d_hpo : nullptr, db->d_maskbits, d_excl,
+                                                          sets ? db->d_work : nullptr, db->d_work_count);
+    if (sets && db->n_chunks) launch_excl_pieces(db, db->d_maskbits, nullptr, d_excl, nullptr, nullptr, true);
+    yh_ring_record_end(db, db->ev_excl);
+    YH_HIP(hipGetLastError());
+    return YH_OK;
+}
+
 // overlap (and, with for_exclusive, the shared-hash flags, the subset mask and zeroed exclusive
 // accumulators) through the directory; same outputs as yh_q_overlap(..., flag_shared, make_mask)
 // d_fused_excl / d_fused_match non-null: the whole run step in three launches (see yh_q_run_fused)
@@ -1443,8 +1492,10 @@ int yh_q_overlap_indexed(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_ov
     k_reduce_replicas<<<(u32)((N + 255) / 256), 256, 0, st_tail>>>(
         reps1, R, N, d_overlap, (for_exclusive && !fused) ? db->d_mask : nullptr,
         for_exclusive ? db->d_maskbits : nullptr, (for_exclusive && !fused) ? db->d_excl_e : nullptr,
-        fused ? FusedRun{reps2, db->d_sizes, db->d_nshared, d_fused_excl, d_fused_match, d_bits_out, db->d_hpo, db->d_work,
-                         db->d_work_count, (u32)(db->n_ghost ? db->ghost_begin : N)}
+        // (range_local -- a hash-range shard's first half: n_excl and the work list wait for the global subset)
+        fused ? FusedRun{reps2, db->d_sizes, db->d_nshared, db->range_local ? nullptr : d_fused_excl, d_fused_match, d_bits_out,
+                         db->d_hpo, db->range_local ? nullptr : db->d_work, db->d_work_count,
+                         (u32)(db->n_ghost ? db->ghost_begin : N)}
               : FusedRun{});
     if (fused && !lookup_half_only) {  // (sharded run: the posting-list half follows the exchange of the subset bits)
         if (!piped) yh_ring_record_begin(db, db->ev_excl);

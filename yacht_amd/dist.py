@@ -403,3 +403,199 @@ class ShardedRefDB:
 
     def close(self):
         self.local.close()
+
+
+# ======================================================================================================
+# The `yacht run` step over ranks by HASH RANGE (option B; include/yacht_hip.h)
+# ======================================================================================================
+# Sharding by reference (ShardedRefDB above) divides the DATABASE but not the work of the default lookup: that one
+# costs per SAMPLE hash, and every rank looks up the whole sample.  Here rank g owns the hashes in [lo_g, hi_g):
+# its handle holds all N references, each cut down to that range (a contiguous piece of every sorted sketch), and
+# it looks up only the sample's hashes in the range (a contiguous slice of the sorted sample).  Tables and lookups
+# shrink by the number of ranks.  All holders of a hash sit on its rank, so multiplicity and exclusivity are
+# rank-local -- no ghosts -- and every count is a sum over the ranks once the subset is the global one:
+#   begin     yh_run_local_range_device: this rank's share of overlap and n_match, its local subset bits
+#   exchange  ONE all-gather of the bits of a block of samples (N/8 bytes per sample and rank)
+#   end       yh_run_finish_range_device: subset = OR of the ranks' bits; this rank's share of n_exclusive
+#   reduce    ONE sum of the block's [block, 3, N] count rows over the ranks (to rank 0, where results are consumed)
+# ShardedRefDB stays the CAPACITY mode (a database that does not fit one GPU's HBM N times over in pieces of all
+# references is still cut by reference there); this is the THROUGHPUT mode.
+def hash_range_bounds(max_hash: int, world: int) -> List[int]:
+    """world + 1 cut points of [0, max_hash]: equal-width ranges (FracMinHash hashes are uniform below max_hash);
+    the last bound is 2**64 (exclusive upper end of the last range)."""
+    return [((int(max_hash) + 1) * r) // world for r in range(world)] + [2 ** 64]
+
+
+def _u64_key(x: int) -> int:
+    """The int64 whose signed order equals the unsigned order of x (x ^ 2**63 as a signed number)."""
+    return (int(x) ^ (2 ** 63)) - (2 ** 64 if (int(x) ^ (2 ** 63)) >= 2 ** 63 else 0)
+
+
+def slice_to_hash_range(values_t, offsets_t, lo: int, hi: int):
+    """The CSR of the same references holding only their hashes in [lo, hi) (hi = 2**64: no upper bound).  int64
+    tensors holding uint64 bit patterns, any device; every reference's hashes ascending (unsigned)."""
+    import torch
+
+    key = values_t ^ _SIGN  # signed order == unsigned order
+    keep = key >= _u64_key(lo)
+    if hi < 2 ** 64:
+        keep &= key < _u64_key(hi)
+    csum = torch.zeros(values_t.numel() + 1, dtype=torch.int64, device=values_t.device)
+    csum[1:] = torch.cumsum(keep.to(torch.int64), 0)
+    return values_t[keep].contiguous(), csum[offsets_t].contiguous()
+
+
+def sample_slice(sample_t, lo: int, hi: int) -> Tuple[int, int]:
+    """[a, b): the positions of the sorted sample's hashes in [lo, hi)."""
+    import torch
+
+    key = sample_t ^ _SIGN
+    b = [_u64_key(lo)] + ([_u64_key(hi)] if hi < 2 ** 64 else [])
+    cut = torch.searchsorted(key, torch.tensor(b, dtype=torch.int64, device=sample_t.device)).tolist()
+    return int(cut[0]), (int(cut[1]) if hi < 2 ** 64 else int(sample_t.numel()))
+
+
+class HipRangeBackend:
+    """The compute side of HashRangeRefDB on the HIP engine (everything on torch's CURRENT stream)."""
+
+    def __init__(self, device_index: int):
+        self.device_index = device_index
+
+    def make_range_db(self, values_t, offsets_t):
+        import torch
+
+        from .engine import RefDB
+
+        n = offsets_t.numel() - 1
+        torch.cuda.current_stream().synchronize()  # build-time: the CSR tensors are complete
+        db = RefDB.from_device(values_t.data_ptr(), offsets_t.data_ptr(), n, device=self.device_index)
+        empty = int(values_t.numel()) == 0
+
+        class _Range:
+            handle = db
+
+            def bind_stream(self):
+                db.set_stream(torch.cuda.current_stream().cuda_stream)
+
+            def run_local(self, sample_t, a, b, counts_t, bits_t, ctx=0):
+                if empty:  # a range that holds no reference hash: nothing can match
+                    counts_t.zero_()
+                    bits_t.zero_()
+                    return
+                db.run_local_range_device(sample_t.data_ptr() + 8 * a, b - a, counts_t[0].data_ptr(), counts_t[2].data_ptr(),
+                                          bits_t.data_ptr(), ctx)
+
+            def run_finish(self, gathered_t, n_ranks, stride_words, counts_t, ctx=0):
+                if empty:
+                    return
+                db.run_finish_range_device(gathered_t.data_ptr(), n_ranks, stride_words, counts_t[1].data_ptr(), ctx)
+
+            def close(self):
+                db.close()
+
+        r = _Range()
+        r.bind_stream()
+        return r
+
+
+class HashRangeRefDB:
+    """`yacht run` counts with the HASH SPACE spread over the ranks of `group`, subset = overlap > 0.
+
+    values_t / offsets_t: ALL references (CSR, int64 tensors holding uint64 bit patterns, this rank's device) already
+    cut down to this rank's range [bounds[rank], bounds[rank + 1]) -- slice_to_hash_range does that -- so offsets_t has
+    N_total + 1 entries on every rank.  Per rank a step leaves its SHARE of the three count rows ([3, N_total] int32);
+    reduce() sums the shares."""
+
+    def __init__(self, values_t, offsets_t, bounds: Sequence[int], backend, group=None, block: int = 1):
+        import torch
+        import torch.distributed as dist
+
+        assert 1 <= block <= 8, "two blocks of `block` samples use 2 * block of the library's 16 step contexts"
+        self.block = GB = int(block)
+        self.group = group
+        self.world = world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = rank = dist.get_rank(group) if dist.is_initialized() else 0
+        assert len(bounds) == world + 1
+        self.lo, self.hi = int(bounds[rank]), int(bounds[rank + 1])
+        self.dev = dev = values_t.device
+        self.n_total = self.n_rows = self.n_local = int(offsets_t.numel() - 1)
+        self.n_ghost = 0
+        self.has_exchange = world > 1 or os.environ.get("YH_FORCE_EXCHANGE") == "1"
+        # one row of subset bits per sample: whole 256-reference blocks (what the reducer writes), the same on every rank
+        self.W = W = ((self.n_total + 255) // 256) * 8
+        self.local = backend.make_range_db(values_t, offsets_t)
+        self._keep = (values_t, offsets_t)
+        self.bits_local = [torch.zeros((GB, W), dtype=torch.int32, device=dev) for _ in range(2)]
+        self.bits_global = [torch.zeros((world, GB, W), dtype=torch.int32, device=dev) for _ in range(2)]
+        self._pending = [None, None]
+        self._slices = {}
+
+    def new_counts(self):
+        import torch
+
+        return torch.zeros((3, self.n_total), dtype=torch.int32, device=self.dev)
+
+    def _slice_of(self, sample_t) -> Tuple[int, int]:
+        key = (sample_t.data_ptr(), int(sample_t.numel()))
+        if key not in self._slices:  # (one small device search + host sync per NEW sample tensor; resident samples: once)
+            if len(self._slices) > 4096:
+                self._slices.clear()
+            self._slices[key] = sample_slice(sample_t, self.lo, self.hi) if sample_t.numel() else (0, 0)
+        return self._slices[key]
+
+    def begin(self, sample_t, counts_t, slot: int = 0, g: int = 0):
+        """Rank-local half of sample g of block `slot`: lookup + reduce of the sample's hashes in this rank's range."""
+        a, b = self._slice_of(sample_t)
+        self.local.run_local(sample_t, a, b, counts_t, self.bits_local[slot][g], slot * self.block + g)
+
+    def exchange(self, slot: int = 0):
+        """All-gather of the block's local subset bits, STARTED (RCCL: asynchronously, ordered behind the kernels)."""
+        import torch.distributed as dist
+
+        if not self.has_exchange:
+            return
+        mine = self.bits_local[slot]
+        if mine.is_cuda and not _is_gloo(self.group):
+            self._pending[slot] = dist.all_gather_into_tensor(self.bits_global[slot], mine, group=self.group, async_op=True)
+        else:
+            all_gather_into(self.bits_global[slot].view(-1), mine.view(-1), group=self.group)
+
+    def end(self, counts_t, slot: int = 0, g: int = 0):
+        """Second half of sample g of block `slot`: global subset = OR of the ranks' bits, exclusive pass."""
+        if self._pending[slot] is not None:
+            self._pending[slot].wait()
+            self._pending[slot] = None
+        if self.has_exchange:  # rank r's row of sample g starts (r * block + g) * W words in
+            rows = self.bits_global[slot].view(-1)[g * self.W:]
+            self.local.run_finish(rows, self.world, self.block * self.W, counts_t, slot * self.block + g)
+        else:
+            self.local.run_finish(self.bits_local[slot][g], 1, self.W, counts_t, slot * self.block + g)
+        return counts_t
+
+    def run(self, sample_t, counts_t=None):
+        """One sample: this rank's share of the [3, N_total] counts.  Stream-ordered; no host synchronisation with RCCL."""
+        if counts_t is None:
+            counts_t = self.new_counts()
+        self.begin(sample_t, counts_t, 0, 0)
+        self.exchange(0)  # (block > 1: the other rows of the block travel along, unused)
+        return self.end(counts_t, 0, 0)
+
+    def reduce(self, counts_t, dst=None):
+        """Sum of the ranks' shares: the [.., 3, N_total] counts of the whole database (on `dst`, or on every rank)."""
+        import torch.distributed as dist
+
+        if self.world == 1 and not self.has_exchange:
+            return counts_t
+        c = _stage(counts_t, self.group).contiguous()
+        if dst is None:
+            dist.all_reduce(c, op=dist.ReduceOp.SUM, group=self.group)
+        else:
+            dist.reduce(c, dst=dst, op=dist.ReduceOp.SUM, group=self.group)
+        return c.to(self.dev)
+
+    def gather(self, counts_t):
+        """(the name ShardedRefDB uses for 'the whole table on every rank')"""
+        return self.reduce(counts_t.clone())
+
+    def close(self):
+        self.local.close()

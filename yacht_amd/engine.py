@@ -204,6 +204,16 @@ class RefDB:
     def run_finish_device(self, d_global_bits: int, d_excl: int, ctx: int = 0) -> None:
         _lib.check(self._lib.yh_run_finish_device(self._h, ctx, C.c_void_p(d_global_bits), C.c_void_p(d_excl)))
 
+    # hash-range shards (dist.HashRangeRefDB): the step in two halves around the all-gather of the ranks' subset bits
+    def run_local_range_device(self, d_sample: int, n_sample: int, d_overlap: int, d_match: int, d_bits_out: int,
+                               ctx: int = 0) -> None:
+        _lib.check(self._lib.yh_run_local_range_device(self._h, ctx, C.c_void_p(d_sample), n_sample, C.c_void_p(d_overlap),
+                                                       C.c_void_p(d_match), C.c_void_p(d_bits_out)))
+
+    def run_finish_range_device(self, d_gathered_bits: int, n_ranks: int, stride_words: int, d_excl: int, ctx: int = 0) -> None:
+        _lib.check(self._lib.yh_run_finish_range_device(self._h, ctx, C.c_void_p(d_gathered_bits), n_ranks, stride_words,
+                                                        C.c_void_p(d_excl)))
+
     def run_submit(self, slot: int, sample: np.ndarray, overlap: np.ndarray, n_excl: np.ndarray,
                    n_match: np.ndarray) -> None:
         """Queue one `yacht run` count call (upload, ordering check, kernels, download) without waiting;
