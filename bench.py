@@ -63,6 +63,7 @@ def parse_args():
                     help="N>1: hash (default) = every GPU holds one HASH RANGE of all references and looks up the sample's hashes "
                          "in it (dist.HashRangeRefDB: table AND lookups divide by N; counts are summed); refs = every GPU holds a "
                          "range of the REFERENCES + ghosts and looks up the whole sample (dist.ShardedRefDB: the capacity mode)")
+    ap.add_argument("--no-train", action="store_true", help="N=1: skip the `yacht train` block (configs[3], bench_train.py as a child process)")
     ap.add_argument("--no-scaling-model", action="store_true",
                     help="N=1: skip the measurement of one rank's share of a G-way hash-range step (G = 2, 4, 8)")
     ap.add_argument("--refs", type=int, default=0, help="override references per GPU (testing only)")
@@ -294,7 +295,7 @@ def main() -> int:
     if by_hash:  # the block's rows are SUMMED over the ranks (to rank 0), not gathered
         gathered_blk = [None] * NBUF
     # all-gathering the rows hands every rank world x 8 MB per block it never reads; results are consumed on rank 0
-    to_root = multi and not staged_gather and args.count_gather == "root"
+    to_root = multi and not by_hash and not staged_gather and args.count_gather == "root"
     root_lists = [([gathered_blk[b][r] for r in range(world)] if rank == 0 else None) for b in range(NBUF)] if to_root else None
     pipelined = multi and not staged_gather and not args.sync_gather and not args.no_pipeline
     state = {"i": 0, "open": None}
@@ -888,6 +889,28 @@ def main() -> int:
                           f"overlap {t_ov:.2f} s on {cores} threads + exclusive {t_ex:.2f} s on 1 thread",
             }
 
+    # ---- the `yacht train` side of the path (BASELINE configs[3]) in the same driver-timed run: bench_train.py as a CHILD
+    # process (its own handle, its own JSON line), after this process has released its database
+    train = None
+    if rank == 0 and not multi and not args.no_train:
+        import subprocess
+
+        if sdb is None:
+            db.close()
+        del values, offsets
+        torch.cuda.empty_cache()
+        t0 = time.perf_counter()
+        try:
+            tp = subprocess.run([sys.executable, os.path.join(ROOT, "bench_train.py"), "--steps", "5"]
+                                + (["--no-oracle"] if args.no_cpu_baseline else []),
+                                stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+            tl = [ln for ln in tp.stdout.splitlines() if ln.startswith("{")]
+            train = json.loads(tl[-1]) if tl else {"error": (tp.stderr or "")[-500:]}
+            train["returncode"] = tp.returncode
+        except Exception as ex:  # noqa: BLE001
+            train = {"error": repr(ex)}
+        train["wall_s_of_the_child"] = round(time.perf_counter() - t0, 1)
+
     if rank == 0:
         try:
             import scipy
@@ -943,6 +966,7 @@ def main() -> int:
             "device_resident": device_resident,
             "host_inclusive": host_inclusive,
             "scaling_model": scaling_model,
+            "train": train,
             "real_shape": real_shape,
             "batched": batched,
             "paths": paths,
@@ -953,7 +977,7 @@ def main() -> int:
     if sdb is not None:
         sdb.close()
     else:
-        db.close()
+        db.close()  # (a second close is a no-op)
     if multi:
         dist.barrier()
         dist.destroy_process_group()
@@ -965,6 +989,9 @@ def main() -> int:
         return 1
     if rank == 0 and host_inclusive is not None and not host_inclusive["equals_device_resident"]:
         print("bench.py: host-buffer path differs from the device-resident path", file=sys.stderr)
+        return 1
+    if rank == 0 and train is not None and (train.get("returncode", 1) != 0 or train.get("parity_bit_exact") is False):
+        print("bench.py: the train block failed or differs from its references: " + json.dumps(train)[:600], file=sys.stderr)
         return 1
     if rank == 0 and pipelined_ok is False:
         print("bench.py: the pipelined steps differ from the plain ones", file=sys.stderr)

@@ -28,6 +28,17 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
+def _cpu_model() -> str:
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.lower().startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return ""
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--clusters", type=int, default=2000)
@@ -136,6 +147,7 @@ def main() -> int:
         parity = bool(np.array_equal(gi, wi) and np.array_equal(gj, wj) and np.array_equal(gc, wc)
                       and gstats == wstats and np.array_equal(gsel, wsel))
         cpu = {"value": round(k * (k - 1) / 2 / t_cpu, 1), "unit": "pair-queries/s", "cores": cores, "kind": "port",
+               "cpu_model": _cpu_model(),
                "sample": f"first {k} sketches ({int(o2[-1])} hashes): index build on 1 thread + scatter on {cores} "
                          f"threads + selection, {t_cpu:.2f} s"}
         # the GENUINE reference executable (oracle/_ref, built from /root/reference/src/cpp/main.cpp in the
@@ -158,13 +170,37 @@ def main() -> int:
             same = bool(rsel == gsel.tolist() and rlines == glines)
             parity = parity and same
             cpu = {"value": round(k * (k - 1) / 2 / core_s, 1), "unit": "pair-queries/s", "cores": min(cores, 64),
-                   "kind": "reference",
+                   "kind": "reference", "cpu_model": _cpu_model(),
                    "sample": f"reference run_yacht_train_core -t {min(cores, 64)} on the first {k} sketches: index "
                              f"{phases.get('build index', 0)} ms + matrix {phases.get('compute intersection matrix', 0)} ms "
                              f"+ selection {phases.get('do yacht train', 0)} ms (file reading {phases.get('read all sketches', 0)} ms "
                              f"not counted; whole process incl. writing the JSON inputs {t_ref:.1f} s)",
                    "outputs_equal_hip_path": same,
                    "port_value": round(k * (k - 1) / 2 / t_cpu, 1)}
+
+    # configs[3] at its REAL size against the genuine reference: tests/golden/golden_train_cfg3.json holds what
+    # oracle/_ref/run_yacht_train_core wrote for this very input (selected ids in walk order, the three index statistics,
+    # a sha256 over the sorted pair lines) -- made once in the build container by tests/golden/make_golden.py cfg3
+    golden = None
+    gpath = os.path.join(ROOT, "tests", "golden", "golden_train_cfg3.json")
+    if rank == 0 and args.clusters == 2000 and args.size == 5000 and os.path.exists(gpath):
+        import hashlib
+
+        from yacht_amd.train_core import format_pair_line
+
+        with open(gpath) as f:
+            g = json.load(f)
+        same_input = hashlib.sha256(values.tobytes() + offsets.tobytes()).hexdigest() == g["input_sha256"]
+        lines = [format_pair_line(int(i), int(j), int(cc), int(sizes[i]), int(sizes[j])) for i, j, cc in zip(pi, pj, pc)]
+        golden = {"same_input": same_input,
+                  "selected_equal": sel.tolist() == g["selected"],
+                  "pair_lines_equal": len(lines) == g["n_pair_lines"] and hashlib.sha256("\n".join(lines).encode()).hexdigest() == g["pair_lines_sha256"],
+                  "stats_equal": list(stats) == [g["stats"]["distinct"], g["stats"]["singletons"], g["stats"]["index"]]}
+        golden["all_equal"] = all(golden.values())
+        if parity is not False and not golden["all_equal"]:
+            parity = False
+        elif parity is None:
+            parity = golden["all_equal"]
 
     # algorithmic bytes: every reference hash once + one (i, j, count) per emitted pair
     alg = 8 * int(offsets[-1]) + 12 * int(pi.size)
@@ -183,6 +219,7 @@ def main() -> int:
         "algorithmic_GBps_over_total": round(alg / total / 1e9, 2),
         "cpu_baseline": cpu,
         "parity_bit_exact": parity,
+        "full_size_vs_genuine_reference": golden,
     }
     # roofline-style figure of the kernels alone (B = 8 H + 12 P_out), HBM peak 8 TB/s
     k_ms = float(tm["ms_db_build"]) + k_pair_ms

@@ -266,3 +266,27 @@ def test_cli_train_then_run_end_to_end(hip_lib, tmp_path):
     # the reference's quirk: this column carries the sample's mean abundance
     assert float(r["num_exclusive_kmers_in_sample_sketch"]) == pytest.approx(2.4032636839886794)
     assert int(r["num_total_kmers_in_sample_sketch"]) == int(np.round(2.4032636839886794 * 49821))
+
+
+def test_train_config3_at_full_size_equals_the_genuine_reference(hip_lib):
+    """BASELINE configs[3] at its real size -- 10 000 sketches, 5e7 hashes -- through yh_db_create / yh_pairwise /
+    yh_train_select against what the genuine reference executable (oracle/_ref, `-t 8 -c 0.95**31`) wrote for the same
+    input in the build container (tests/golden/make_golden.py cfg3): the selected ids in walk order, the three index
+    statistics of main.cpp:242-244, and every one of the 20 000 pair lines (by digest)."""
+    import hashlib
+
+    from yacht_amd import synth
+    from yacht_amd.engine import YH_DB_PAIRWISE_ONLY
+
+    g = _load("golden_train_cfg3.json")
+    values, offsets = synth.config4()
+    assert hashlib.sha256(values.tobytes() + offsets.tobytes()).hexdigest() == g["input_sha256"], "the generator drifted"
+    sizes = np.diff(offsets).astype(np.uint32)
+    with RefDB(values, offsets, flags=YH_DB_PAIRWISE_ONLY) as db:
+        pi, pj, pc = db.pairwise(g["c"])
+        stats = db.index_stats()
+    lines = [format_pair_line(int(i), int(j), int(k), int(sizes[i]), int(sizes[j])) for i, j, k in zip(pi, pj, pc)]
+    assert len(lines) == g["n_pair_lines"] and lines[:5] == g["first_pair_lines"]
+    assert hashlib.sha256("\n".join(lines).encode()).hexdigest() == g["pair_lines_sha256"]
+    assert stats == (g["stats"]["distinct"], g["stats"]["singletons"], g["stats"]["index"])
+    assert train_select(sizes, pi, pj).tolist() == g["selected"]

@@ -128,3 +128,27 @@ def test_fixture_known_answer():
     r = oracle.single_hyp_test((3741, 2), 31, 0.99, 0.95, 0.001)
     assert bool(r[0]) is True and r[5] == 0.0 and r[3] == 3
     assert r[1] == pytest.approx(row["hyp_cov_0.001"][1], rel=1e-12)
+
+
+def test_oracle_train_core_at_config3_full_size_equals_the_genuine_reference():
+    """The oracle's restatement of main.cpp:215-407 on BASELINE configs[3] at its real size (10 000 sketches, 5e7 hashes)
+    against what the genuine reference executable wrote for the same input (tests/golden/golden_train_cfg3.json, made by
+    make_golden.py cfg3 in the build container): 20 000 pair lines by digest, the three statistics, the selection order.
+    (~1 minute on 8 cores: the reference's own index build is single-threaded.)"""
+    import hashlib
+    import json
+
+    from yacht_amd import synth
+    from yacht_amd.train_core import format_pair_line
+
+    with open(os.path.join(GOLD, "golden_train_cfg3.json")) as f:
+        g = json.load(f)
+    values, offsets = synth.config4()
+    assert hashlib.sha256(values.tobytes() + offsets.tobytes()).hexdigest() == g["input_sha256"], "the generator drifted"
+    sizes = np.diff(offsets).astype(np.uint32)
+    wi, wj, wc, wstats = oracle.train_pairs(values, offsets, g["c"], threads=8)
+    lines = [format_pair_line(int(i), int(j), int(k), int(sizes[i]), int(sizes[j])) for i, j, k in zip(wi, wj, wc)]
+    assert len(lines) == g["n_pair_lines"]
+    assert hashlib.sha256("\n".join(lines).encode()).hexdigest() == g["pair_lines_sha256"]
+    assert tuple(wstats) == (g["stats"]["distinct"], g["stats"]["singletons"], g["stats"]["index"])
+    assert oracle.train_select(sizes, wi, wj).tolist() == g["selected"]
