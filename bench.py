@@ -64,6 +64,11 @@ def parse_args():
                          "in it (dist.HashRangeRefDB: table AND lookups divide by N; counts are summed); refs = every GPU holds a "
                          "range of the REFERENCES + ghosts and looks up the whole sample (dist.ShardedRefDB: the capacity mode)")
     ap.add_argument("--no-train", action="store_true", help="N=1: skip the `yacht train` block (configs[3], bench_train.py as a child process)")
+    ap.add_argument("--block-mode", default="batched", choices=["batched", "steps"],
+                    help="N>1 with --shard hash: batched (default) = the samples of a block go through the batched kernels in ONE "
+                         "pass per rank (a rank's share of one sample is too few lookups to fill a launch) around one exchange of "
+                         "their subset words; steps = every sample is its own pair of half-steps, eight per bit exchange")
+    ap.add_argument("--batch-block", type=int, default=32, help="--block-mode batched: samples per block (<= 64)")
     ap.add_argument("--no-scaling-model", action="store_true",
                     help="N=1: skip the measurement of one rank's share of a G-way hash-range step (G = 2, 4, 8)")
     ap.add_argument("--refs", type=int, default=0, help="override references per GPU (testing only)")
@@ -235,6 +240,10 @@ def main() -> int:
         values, offsets = synth.global_db_refs_device(plan, np.arange(r_beg, r_end), device=str(dev))
     H = int(values.numel())
     K = max(args.samples, 1)
+    hash_batched = by_hash and args.block_mode == "batched"
+    BB = max(1, min(int(args.batch_block), 64))
+    if hash_batched:
+        K = max(K, BB)  # a block holds DISTINCT samples: a sample repeated inside one pass would find its own buckets cached
     samples = [synth.global_db_sample_device(plan, args.seed + 1000 + i, n_sample=args.sample_hashes, n_present=n_present,
                                              device=str(dev)) for i in range(K)]
     if multi:  # the samples are replicated: every rank queries rank 0's (deterministic, but make it certain)
@@ -337,9 +346,38 @@ def main() -> int:
         else:
             finish_block(blk, i0, n_in)
 
+    # --block-mode batched: block j = samples [j * BB, (j + 1) * BB) mod K in one pass of the batched kernels; its three
+    # count rows [3, BB, N] are this rank's shares and leave in one reduce (sum) to rank 0
+    if hash_batched:
+        bcounts = [torch.zeros((3, BB, n_total), device=dev, dtype=torch.int32) for _ in range(NBUF)]
+        bwords = torch.zeros(n_total, device=dev, dtype=torch.int64)
+        bgath = torch.zeros((world, n_total), device=dev, dtype=torch.int64)
+        packed_blocks = {}
+        bpending = [None] * NBUF
+
+        def run_block(j, n_in):
+            key = (j * BB) % K
+            if (key, n_in) not in packed_blocks:  # (resident samples: their slices are concatenated once)
+                packed_blocks[(key, n_in)] = sdb.pack_batch([samples[(key + t) % K] for t in range(n_in)])
+            b = j % NBUF
+            if bpending[b] is not None:  # the reduce that read this buffer two blocks ago
+                bpending[b].wait()
+                bpending[b] = None
+            sdb.batch_begin(packed_blocks[(key, n_in)], bcounts[b], bwords)
+            w = sdb.batch_exchange(bwords, bgath, async_op=False)
+            sdb.batch_end(n_in, bgath, bcounts[b])
+            if staged_gather:
+                bcounts[b].copy_(sdb.reduce(bcounts[b], dst=0))
+            else:
+                bpending[b] = dist.reduce(bcounts[b], dst=0, op=dist.ReduceOp.SUM, async_op=True)
+
     def step():
         i = state["i"]
         state["i"] += 1
+        if hash_batched:
+            if i % BB == BB - 1:
+                run_block(i // BB, BB)
+            return
         s = samples[i % K]
         c = rows_of(i)
         if sdb is None:
@@ -359,6 +397,15 @@ def main() -> int:
         if sdb is None:
             db.run_device_join()  # the last tails: the stream's end is the end of every step
         i = state["i"]
+        if hash_batched:
+            if i % BB != 0:  # a partly filled block at the end of a loop
+                run_block(i // BB, i % BB)
+                state["i"] += BB - i % BB
+            for b in range(NBUF):
+                if bpending[b] is not None:
+                    bpending[b].wait()
+                    bpending[b] = None
+            return
         if multi and i % GB != 0:  # a partly filled block at the end of a loop leaves too
             close_block((i // GB) % NBUF, i - i % GB, i % GB)
             state["i"] += GB - i % GB  # (the next loop starts a fresh block)
@@ -422,6 +469,11 @@ def main() -> int:
                 sdb.run(samples[i], c)
                 results.append(sdb.gather(c))
     torch.cuda.synchronize()
+    blocks_ok = None
+    if hash_batched and rank == 0:  # the timed loop's own outputs: the sums of its last block are on rank 0
+        jl = state["i"] // BB - 1
+        got = bcounts[jl % NBUF]
+        blocks_ok = all(bool(torch.equal(got[:, t, :], results[((jl * BB) % K + t) % K])) for t in range(BB))
     pipelined_ok = None
     if sdb is None and args.pipelined_tail:  # the timed loop's own (pipelined) outputs: its last two steps are still in the buffers
         last = state["i"] - 1
@@ -717,8 +769,34 @@ def main() -> int:
                 step_g(i)
             fence()
             el = (time.perf_counter() - t0) / n_g
+            # the throughput form: rank 0's share of a batch of 32 distinct samples in one pass (no exchange: its own words)
+            bsamp = [samples[i] if i < K else synth.global_db_sample_device(plan, args.seed + 7000 + i, n_sample=args.sample_hashes,
+                                                                           n_present=n_present, device=str(dev)) for i in range(32)]
+            with torch.cuda.stream(stream):
+                packed_b = hr.pack_batch(bsamp)
+            cb = torch.zeros((3, 32, n_local), device=dev, dtype=torch.int32)
+            wb = torch.zeros(n_local, device=dev, dtype=torch.int64)
+            gb = torch.zeros((1, n_local), device=dev, dtype=torch.int64)
+
+            def batch_g():
+                with torch.cuda.stream(stream):
+                    hr.batch_begin(packed_b, cb, wb)
+                    hr.batch_exchange(wb, gb)
+                    hr.batch_end(32, gb, cb)
+
+            for _ in range(2):
+                batch_g()
+            fence()
+            nb_ = max(3, min(20, args.steps // 32 + 1))
+            t0 = time.perf_counter()
+            for _ in range(nb_):
+                batch_g()
+            fence()
+            el_b = (time.perf_counter() - t0) / nb_
+            del bsamp, packed_b, cb, wb, gb
             a_, b_ = hr._slice_of(samples[0])
             per_g[str(G)] = {"rank0_compute_ms_per_step": round(1e3 * el, 4), "sample_hashes_in_range": int(b_ - a_),
+                             "batched32_rank0_ms_per_sample": round(1e3 * el_b / 32, 4),
                              "ref_hashes_in_range": int(v_g.numel()),
                              "lookup_choice": "indexed" if hr.local.handle.lookup_choice(int(b_ - a_)) == ylib.YH_LOOKUP_INDEXED else "stream"}
             hr.close()
@@ -729,6 +807,11 @@ def main() -> int:
             "collectives_ms_per_step_assumed": coll,
             "predicted_ms_per_step": {g: round(v["rank0_compute_ms_per_step"] + coll, 4) for g, v in per_g.items()},
             "predicted_speedup_vs_1gpu": {g: round(ms_per_step / (v["rank0_compute_ms_per_step"] + coll), 2) for g, v in per_g.items()},
+            # --block-mode batched (the N > 1 default): + one all-gather of N * 8 bytes per rank and one reduce of 3 * 32 * N * 4
+            # bytes per block of 32 samples, assumed at 0.06 ms per block on top (not overlapped)
+            "batched_predicted_ms_per_sample": {g: round(v["batched32_rank0_ms_per_sample"] + 0.06 / 32, 4) for g, v in per_g.items()},
+            "batched_predicted_speedup_vs_1gpu_single_steps": {g: round(ms_per_step / (v["batched32_rank0_ms_per_sample"] + 0.06 / 32), 2)
+                                                               for g, v in per_g.items()},
             "how": "rank 0's hash range of the whole database built on THIS GPU, both halves of its step timed on its slice of the "
                    "rotating samples (no collectives); + the assumed cost of the two collectives per block of 8 samples",
         }
@@ -957,12 +1040,15 @@ def main() -> int:
                                 f"the sample's hashes in it; counts summed" if by_hash else
                                 f"one database, references sharded x{world} by hash count"),
                 "shard": ("hash" if by_hash else "refs") if multi else None,
+                "block_mode": (args.block_mode if by_hash else "steps") if multi else None,
+                "samples_per_block": (BB if hash_batched else GB) if multi else None,
                 "scipy": scipy_version,
             },
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
             "parity_bit_exact": parity,
             "pipelined_steps_equal_plain_steps": pipelined_ok,
+            "batched_blocks_equal_single_steps": blocks_ok,
             "device_resident": device_resident,
             "host_inclusive": host_inclusive,
             "scaling_model": scaling_model,
@@ -992,6 +1078,9 @@ def main() -> int:
         return 1
     if rank == 0 and train is not None and (train.get("returncode", 1) != 0 or train.get("parity_bit_exact") is False):
         print("bench.py: the train block failed or differs from its references: " + json.dumps(train)[:600], file=sys.stderr)
+        return 1
+    if rank == 0 and blocks_ok is False:
+        print("bench.py: the batched blocks differ from the single-sample steps", file=sys.stderr)
         return 1
     if rank == 0 and pipelined_ok is False:
         print("bench.py: the pipelined steps differ from the plain ones", file=sys.stderr)

@@ -254,6 +254,20 @@ int yh_run_local_range_device(yh_db* db, int ctx, const uint64_t* d_sample, uint
 int yh_run_finish_range_device(yh_db* db, int ctx, const uint32_t* d_gathered_bits, uint32_t n_ranks, uint64_t stride_words,
                                uint32_t* d_n_excl);
 
+/* The same for MANY samples per call (yh_run_batch on a hash-range shard): a rank's share of one sample is only
+ * |S| / n_ranks lookups -- a launch of that size is bound by launch and round-trip latencies, not by the lookups -- so the
+ * throughput form takes up to 64 samples' slices at once, exchanges their subset words (one uint64 per reference: bit s =
+ * sample s overlaps it) in ONE all-gather, and leaves one [n_samples, N] share per count row to be summed over the ranks:
+ *   yh_run_batch_local_range_device    lookups of the concatenated slices (d_sample_offsets[n_samples + 1] delimits them);
+ *                                      d_overlap [n_samples][N] = this rank's share; d_maskwords_out [N] its subset words
+ *   yh_run_batch_finish_range_device   subset = OR of the n_ranks gathered word arrays ([n_ranks][N]); d_n_excl, d_n_match
+ *                                      [n_samples][N] = this rank's shares (d_overlap: what the first half left)
+ * No other batched call may run on the handle between the two halves (they share the handle's batch scratch).      */
+int yh_run_batch_local_range_device(yh_db* db, const uint64_t* d_samples, const uint64_t* d_sample_offsets, uint32_t n_samples,
+                                    uint64_t total_hashes, uint32_t* d_overlap, uint64_t* d_maskwords_out);
+int yh_run_batch_finish_range_device(yh_db* db, uint32_t n_samples, const uint64_t* d_gathered_maskwords, uint32_t n_ranks,
+                                     const uint32_t* d_overlap, uint32_t* d_n_excl, uint32_t* d_n_match);
+
 /* Pipelined host-buffer form of yh_run: SURVEY.md 8d's steady-state call -- sample H2D, kernels,
  * counts D2H -- split in two so that consecutive samples overlap.  yh_run_submit queues, on two
  * streams of the handle, the upload of `sample`, an ordering check ON THE DEVICE (a sample that fails

@@ -62,6 +62,34 @@ class SetRangeBackend:
                         e[j] = len(r) - nshared[j] + sum(1 for h in r if h in shared and not any(mask[x] for x in shared[h] if x != j))
                 counts_t[1] = torch.from_numpy(e)
 
+            def batch_local(self, cat_t, soff_t, n_samples, total, ov_t, words_t):
+                cat = cat_t.numpy().view(np.uint64)
+                off = soff_t.numpy()
+                words = np.zeros(len(refs), dtype=np.uint64)
+                self._hit = []
+                for s in range(n_samples):
+                    S = set(cat[off[s]:off[s + 1]].tolist())
+                    self._hit.append(S)
+                    ov = np.array([len(S & r) for r in refs], dtype=np.int32)
+                    ov_t[s] = torch.from_numpy(ov)
+                    words |= (ov > 0).astype(np.uint64) << np.uint64(s)
+                words_t.copy_(torch.from_numpy(words.view(np.int64)))
+
+            def batch_finish(self, n_samples, gathered_t, n_ranks, ov_t, e_t, m_t):
+                words = np.bitwise_or.reduce(gathered_t.numpy().view(np.uint64)[:n_ranks], axis=0)
+                for s in range(n_samples):
+                    mask = ((words >> np.uint64(s)) & np.uint64(1)).astype(bool)
+                    S = self._hit[s]
+                    e = np.zeros(len(refs), dtype=np.int32)
+                    m = np.zeros(len(refs), dtype=np.int32)
+                    for j, r in enumerate(refs):
+                        if mask[j]:
+                            excl = [h for h in r if h not in shared or not any(mask[x] for x in shared[h] if x != j)]
+                            e[j] = len(excl)
+                            m[j] = sum(1 for h in excl if h in S)
+                    e_t[s] = torch.from_numpy(e)
+                    m_t[s] = torch.from_numpy(m)
+
             def close(self):
                 pass
 
@@ -129,6 +157,12 @@ def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
         if rank == 0:
             for k, smp in enumerate(samples):
                 check(tot[k // 3][k % 3], smp, f"blocked {k}")
+        # the batched form: all five samples (+ an empty one) in ONE pass around one exchange of their subset words
+        batch = samples + [np.zeros(0, np.uint64)]
+        cb = hr.run_batch([torch.from_numpy(x.view(np.int64).copy()) for x in batch])
+        full = hr.reduce(cb.clone())
+        for k, smp in enumerate(batch):
+            check(full[:, k, :], smp, f"batched {k}")
         open(os.path.join(out_dir, f"ok{rank}"), "w").close()
     finally:
         dist.destroy_process_group()

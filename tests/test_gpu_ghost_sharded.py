@@ -147,13 +147,25 @@ def test_bench_two_ranks_share_gpu_strong_and_weak(hip_lib, tmp_path, shard):
             procs.append(subprocess.Popen(
                 [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
                  "--backend", "gloo", "--share-gpu", "--scaling", scaling, "--shard", shard, "--refs", "4000", "--sample-hashes", "100000",
-                 "--samples", "3", "--percentile-steps", "8", "--present", "50"],
+                 "--samples", "3", "--percentile-steps", "8", "--present", "50", "--batch-block", "4"],
                 env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
         res = [p.communicate(timeout=900) for p in procs]
         assert all(p.returncode == 0 for p in procs), "\n".join(o + e for o, e in res)
         line = json.loads(res[0][0].strip().splitlines()[-1])
         assert line["parity_bit_exact"] is True and line["n_gpus"] == 2 and line["scaling"] == scaling
         assert line["config"]["refs_total"] == (4000 if scaling == "strong" else 8000) and line["config"]["shard"] == shard
+
+
+def test_bench_two_ranks_hash_range_single_steps(hip_lib, tmp_path):
+    """--block-mode steps: the per-sample half-steps of the hash-range shards (the batched blocks are the default)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--backend", "gloo",
+                        "--block-mode", "steps", "--steps", "6", "--warmup", "2", "--refs", "4000", "--sample-hashes", "100000",
+                        "--samples", "3", "--percentile-steps", "8", "--present", "50"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["parity_bit_exact"] is True and line["config"]["block_mode"] == "steps" and line["config"]["shard"] == "hash"
 
 
 def test_bench_starts_its_own_ranks(hip_lib):
@@ -227,6 +239,12 @@ torch.cuda.synchronize()
 tot = [hr.reduce(b.clone()) for b in blk]
 for k, s in enumerate(ss):
     check(tot[k // 2][k % 2], s, f"blocked {k}")
+# the batched form: all four samples in ONE pass around one exchange of their subset words
+cb = hr.run_batch(ss)
+torch.cuda.synchronize()
+full = hr.reduce(cb.clone())
+for k, s in enumerate(ss):
+    check(full[:, k, :], s, f"batched {k}")
 print(f"rank {rank}: range [{bounds[rank]}, {bounds[rank + 1]}), {int(v.numel())} of {int(all_v.numel())} hashes, ok {ok}", flush=True)
 hr.close()
 dist.barrier()

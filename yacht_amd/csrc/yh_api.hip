@@ -854,6 +854,26 @@ int yh_run_finish_range_device(yh_db* db, int ctx, const uint32_t* d_gathered_bi
     return yh_q_range_finish(db, d_gathered_bits, n_ranks, stride_words, d_n_excl);
 }
 
+// the batched run on a hash-range shard: up to 64 samples per call around ONE exchange of their subset words
+int yh_run_batch_local_range_device(yh_db* db, const uint64_t* d_samples, const uint64_t* d_sample_offsets, uint32_t n_samples,
+                                    uint64_t total_hashes, uint32_t* d_overlap, uint64_t* d_maskwords_out) {
+    if (!db_ok(db)) return YH_ERR_INVALID_ARG;
+    if (!d_sample_offsets || !d_overlap || !d_maskwords_out || (total_hashes && !d_samples)) { yh_set_error("null device pointer"); return YH_ERR_INVALID_ARG; }
+    YH_TRY(db_select(db));
+    note_other_query(db);
+    return yh_q_run_batch(db, (const u64*)d_samples, (const u64*)d_sample_offsets, n_samples, total_hashes, d_overlap, nullptr,
+                          nullptr, 1, (u64*)d_maskwords_out);
+}
+
+int yh_run_batch_finish_range_device(yh_db* db, uint32_t n_samples, const uint64_t* d_gathered_maskwords, uint32_t n_ranks,
+                                     const uint32_t* d_overlap, uint32_t* d_n_excl, uint32_t* d_n_match) {
+    if (!db_ok(db)) return YH_ERR_INVALID_ARG;
+    if (!d_gathered_maskwords || n_ranks < 1 || !d_overlap || !d_n_excl || !d_n_match) { yh_set_error("null device pointer / no ranks"); return YH_ERR_INVALID_ARG; }
+    YH_TRY(db_select(db));
+    return yh_q_run_batch(db, nullptr, nullptr, n_samples, 0, const_cast<uint32_t*>(d_overlap), d_n_excl, d_n_match, 2, nullptr,
+                          (const u64*)d_gathered_maskwords, n_ranks);
+}
+
 // ---- pipelined host-buffer run calls ---------------------------------------------------------------
 static int slot_prepare(yh_db* db, RunSlot& s, u64 n_sample, u64 packed_bytes, bool rows_staging) {
     const u64 N = std::max<u64>(db->n_refs, 1);

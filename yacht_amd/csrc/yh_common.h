@@ -376,7 +376,8 @@ int yh_q_overlap_indexed(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_ov
                          u32* d_fused_excl = nullptr, u32* d_fused_match = nullptr, u32* d_bits_out = nullptr,
                          bool lookup_half_only = false);
 int yh_q_run_batch(yh_db* db, const u64* d_samples, const u64* d_soff, u32 n_samples, u64 total_hashes,
-                   u32* d_overlap, u32* d_excl, u32* d_match);
+                   u32* d_overlap, u32* d_excl, u32* d_match, int phases = 3, u64* d_maskword_out = nullptr,
+                   const u64* d_gathered = nullptr, u32 n_ranks = 0);
 int yh_q_exclusive(yh_db* db, const u8* d_mask, const u64* d_sample, u64 n_sample,
                    const u32* d_overlap, u32* d_excl, u32* d_match, const u32* d_maskbits);
 int yh_q_pairwise(yh_db* db, double c_thresh, u64 r0, u64 r1);

@@ -1793,16 +1793,34 @@ __global__ void __launch_bounds__(EXCL_BLOCK) k_batch_apply(const u32* __restric
     }
 }
 
+// hash-range shards: maskword[r] = OR over the ranks' gathered words; anybits as k_batch_maskwords makes them
+__global__ void __launch_bounds__(256) k_batch_or_maskwords(const u64* __restrict__ gathered, u32 n_ranks, u64 n_refs,
+                                                            u64* __restrict__ maskword, u32* __restrict__ anybits) {
+    const u64 r = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    u64 w = 0;
+    if (r < n_refs)
+        for (u32 k = 0; k < n_ranks; ++k) w |= gathered[(u64)k * n_refs + r];
+    if (r < n_refs) maskword[r] = w;
+    const u64 bal = __ballot(w != 0);
+    if ((threadIdx.x & 63) == 0) {
+        anybits[(r >> 5)] = (u32)bal;
+        anybits[(r >> 5) + 1] = (u32)(bal >> 32);
+    }
+}
+
 // in place: ex_e -> n_excl, ex_m -> n_match for every (sample, reference)
+// (maskword != nullptr -- a hash-range shard: the subset is the global one, a reference may be in it without an overlap
+// in THIS rank's range)
 __global__ void __launch_bounds__(256) k_batch_final(u32 n_samples, u64 n_refs, const u32* __restrict__ sizes,
                                                      const u32* __restrict__ nshared, const u32* __restrict__ overlap,
                                                      const u32* __restrict__ ovsh, u32* __restrict__ ex_e,
-                                                     u32* __restrict__ ex_m) {
+                                                     u32* __restrict__ ex_m, const u64* __restrict__ maskword) {
     const u64 total = (u64)n_samples * n_refs;
     for (u64 t = blockIdx.x * (u64)blockDim.x + threadIdx.x; t < total; t += (u64)gridDim.x * blockDim.x) {
         const u64 r = t % n_refs;
         const u32 ov = overlap[t];
-        if (ov) {
+        const bool in = maskword ? ((maskword[r] >> (t / n_refs)) & 1ull) != 0 : ov != 0;
+        if (in) {
             ex_e[t] = sizes[r] - nshared[r] + ex_e[t];
             ex_m[t] = ov - ovsh[t] + ex_m[t];
         } else {
@@ -1814,8 +1832,11 @@ __global__ void __launch_bounds__(256) k_batch_final(u32 n_samples, u64 n_refs, 
 
 }  // namespace
 
+// phases: 1 = lookup + the samples' subset words (copied to d_maskword_out when given), 2 = exclusive pass + final
+// (d_gathered: the words of n_ranks hash-range shards, OR-ed into the subset first), 3 = both (one device, one call)
 int yh_q_run_batch(yh_db* db, const u64* d_samples, const u64* d_soff, u32 n_samples, u64 total_hashes,
-                   u32* d_overlap, u32* d_excl, u32* d_match) {
+                   u32* d_overlap, u32* d_excl, u32* d_match, int phases, u64* d_maskword_out, const u64* d_gathered,
+                   u32 n_ranks) {
     if (!db->has_dir || !db->has_index) {
         yh_set_error("yh_run_batch needs the directory of the distinct hashes (handle created with YH_DB_NO_DIRECTORY?)");
         return YH_ERR_UNSUPPORTED;
@@ -1837,9 +1858,8 @@ int yh_q_run_batch(yh_db* db, const u64* d_samples, const u64* d_soff, u32 n_sam
     u64* d_hitword = reinterpret_cast<u64*>(db->d_batch);
     u64* d_maskword = d_hitword + G + 1;
     u32* d_ovsh = reinterpret_cast<u32*>(d_maskword + N + 1);
+    if (phases & 1) {
     YH_HIP(hipMemsetAsync(d_overlap, 0, BN * sizeof(u32), st));
-    YH_HIP(hipMemsetAsync(d_excl, 0, BN * sizeof(u32), st));
-    YH_HIP(hipMemsetAsync(d_match, 0, BN * sizeof(u32), st));
     YH_HIP(hipMemsetAsync(db->d_batch, 0, need, st));
     yh_ring_record_begin(db, db->ev_overlap);
     if (total_hashes && db->n_distinct) {
@@ -1853,8 +1873,15 @@ int yh_q_run_batch(yh_db* db, const u64* d_samples, const u64* d_soff, u32 n_sam
                                                                            n_chunks, mul, yh_filter_of(db), db->filter_mul);
     }
     yh_ring_record_end(db, db->ev_overlap);
-    yh_ring_record_begin(db, db->ev_excl);
     k_batch_maskwords<<<(u32)((N + 255) / 256), 256, 0, st>>>(d_overlap, n_samples, N, d_maskword, db->d_maskbits);
+    if (d_maskword_out) YH_HIP(hipMemcpyAsync(d_maskword_out, d_maskword, N * sizeof(u64), hipMemcpyDeviceToDevice, st));
+    }
+    if (!(phases & 2)) { YH_HIP(hipGetLastError()); return YH_OK; }
+    YH_HIP(hipMemsetAsync(d_excl, 0, BN * sizeof(u32), st));
+    YH_HIP(hipMemsetAsync(d_match, 0, BN * sizeof(u32), st));
+    yh_ring_record_begin(db, db->ev_excl);
+    if (d_gathered)
+        k_batch_or_maskwords<<<(u32)((N + 255) / 256), 256, 0, st>>>(d_gathered, n_ranks, N, d_maskword, db->d_maskbits);
     if (G && db->n_postings) {
         const u64 vecs = (db->n_postings >> 2) + 1;
         const u32 blocks = (u32)std::min<u64>(EXCL_QBLOCKS, (vecs + EXCL_BLOCK - 1) / EXCL_BLOCK);
@@ -1865,7 +1892,7 @@ int yh_q_run_batch(yh_db* db, const u64* d_samples, const u64* d_soff, u32 n_sam
                                                      d_maskword, d_hitword, N, d_excl, d_match, d_ovsh);
     }
     k_batch_final<<<grid_for(BN, 256, 8192), 256, 0, st>>>(n_samples, N, db->d_sizes, db->d_nshared, d_overlap, d_ovsh,
-                                                           d_excl, d_match);
+                                                           d_excl, d_match, d_gathered ? d_maskword : nullptr);
     yh_ring_record_end(db, db->ev_excl);
     YH_HIP(hipGetLastError());
     return YH_OK;

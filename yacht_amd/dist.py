@@ -490,6 +490,20 @@ class HipRangeBackend:
                     return
                 db.run_finish_range_device(gathered_t.data_ptr(), n_ranks, stride_words, counts_t[1].data_ptr(), ctx)
 
+            def batch_local(self, cat_t, soff_t, n_samples, total, ov_t, words_t):
+                if empty:
+                    ov_t.zero_()
+                    words_t.zero_()
+                    return
+                db.run_batch_local_range_device(cat_t.data_ptr(), soff_t.data_ptr(), n_samples, total, ov_t.data_ptr(), words_t.data_ptr())
+
+            def batch_finish(self, n_samples, gathered_t, n_ranks, ov_t, e_t, m_t):
+                if empty:
+                    e_t.zero_()
+                    m_t.zero_()
+                    return
+                db.run_batch_finish_range_device(n_samples, gathered_t.data_ptr(), n_ranks, ov_t.data_ptr(), e_t.data_ptr(), m_t.data_ptr())
+
             def close(self):
                 db.close()
 
@@ -579,6 +593,58 @@ class HashRangeRefDB:
         self.begin(sample_t, counts_t, 0, 0)
         self.exchange(0)  # (block > 1: the other rows of the block travel along, unused)
         return self.end(counts_t, 0, 0)
+
+    # ---- many samples per call: the throughput form (include/yacht_hip.h, yh_run_batch_*_range_device) ----
+    def pack_batch(self, samples):
+        """This rank's slices of up to 64 samples, concatenated: (hashes, offsets[len + 1], total) -- made once for
+        samples that stay resident."""
+        import torch
+
+        parts, lens = [], []
+        for s_ in samples:
+            a, b = self._slice_of(s_)
+            parts.append(s_[a:b])
+            lens.append(b - a)
+        cat = torch.cat(parts).contiguous() if sum(lens) else torch.zeros(1, dtype=torch.int64, device=self.dev)[:0]
+        soff = torch.zeros(len(samples) + 1, dtype=torch.int64, device=self.dev)
+        soff[1:] = torch.cumsum(torch.tensor(lens, dtype=torch.int64, device=self.dev), 0)
+        return cat, soff, int(sum(lens))
+
+    def batch_begin(self, batch, counts_t, words_t):
+        """First half for a whole batch: counts_t [3, B, N] (row 0 = this rank's share of the overlaps), words_t [N] int64
+        = this rank's subset words (bit s: sample s overlaps the reference in this range)."""
+        cat, soff, total = batch
+        self.local.batch_local(cat, soff, int(soff.numel()) - 1, total, counts_t[0], words_t)
+
+    def batch_exchange(self, words_t, gathered_t, async_op: bool = False):
+        """All-gather of the ranks' subset words into gathered_t [world, N]."""
+        import torch.distributed as dist
+
+        if not self.has_exchange:
+            gathered_t[0].copy_(words_t)
+            return None
+        if words_t.is_cuda and not _is_gloo(self.group):
+            return dist.all_gather_into_tensor(gathered_t, words_t, group=self.group, async_op=async_op)
+        all_gather_into(gathered_t.view(-1), words_t.view(-1), group=self.group)
+        return None
+
+    def batch_end(self, n_samples, gathered_t, counts_t):
+        self.local.batch_finish(n_samples, gathered_t, self.world, counts_t[0], counts_t[1], counts_t[2])
+        return counts_t
+
+    def run_batch(self, samples, counts_t=None):
+        """Up to 64 samples in one pass: this rank's share of the [3, B, N_total] counts (sum them with reduce())."""
+        import torch
+
+        B = len(samples)
+        assert 1 <= B <= 64
+        if counts_t is None:
+            counts_t = torch.zeros((3, B, self.n_total), dtype=torch.int32, device=self.dev)
+        words = torch.zeros(self.n_total, dtype=torch.int64, device=self.dev)
+        gathered = torch.zeros((self.world, self.n_total), dtype=torch.int64, device=self.dev)
+        self.batch_begin(self.pack_batch(samples), counts_t, words)
+        self.batch_exchange(words, gathered)
+        return self.batch_end(B, gathered, counts_t)
 
     def reduce(self, counts_t, dst=None):
         """Sum of the ranks' shares: the [.., 3, N_total] counts of the whole database (on `dst`, or on every rank)."""

@@ -214,6 +214,16 @@ class RefDB:
         _lib.check(self._lib.yh_run_finish_range_device(self._h, ctx, C.c_void_p(d_gathered_bits), n_ranks, stride_words,
                                                         C.c_void_p(d_excl)))
 
+    def run_batch_local_range_device(self, d_samples: int, d_offsets: int, n_samples: int, total_hashes: int, d_overlap: int,
+                                     d_maskwords_out: int) -> None:
+        _lib.check(self._lib.yh_run_batch_local_range_device(self._h, C.c_void_p(d_samples), C.c_void_p(d_offsets), n_samples,
+                                                             total_hashes, C.c_void_p(d_overlap), C.c_void_p(d_maskwords_out)))
+
+    def run_batch_finish_range_device(self, n_samples: int, d_gathered: int, n_ranks: int, d_overlap: int, d_excl: int,
+                                      d_match: int) -> None:
+        _lib.check(self._lib.yh_run_batch_finish_range_device(self._h, n_samples, C.c_void_p(d_gathered), n_ranks,
+                                                              C.c_void_p(d_overlap), C.c_void_p(d_excl), C.c_void_p(d_match)))
+
     def run_submit(self, slot: int, sample: np.ndarray, overlap: np.ndarray, n_excl: np.ndarray,
                    n_match: np.ndarray) -> None:
         """Queue one `yacht run` count call (upload, ordering check, kernels, download) without waiting;
