@@ -356,6 +356,7 @@ def main() -> int:
         bpending = [None] * NBUF
 
         def run_block(j, n_in):
+            state["last_block"] = (j, n_in)
             key = (j * BB) % K
             if (key, n_in) not in packed_blocks:  # (resident samples: their slices are concatenated once)
                 packed_blocks[(key, n_in)] = sdb.pack_batch([samples[(key + t) % K] for t in range(n_in)])
@@ -471,9 +472,9 @@ def main() -> int:
     torch.cuda.synchronize()
     blocks_ok = None
     if hash_batched and rank == 0:  # the timed loop's own outputs: the sums of its last block are on rank 0
-        jl = state["i"] // BB - 1
+        jl, n_last = state["last_block"]
         got = bcounts[jl % NBUF]
-        blocks_ok = all(bool(torch.equal(got[:, t, :], results[((jl * BB) % K + t) % K])) for t in range(BB))
+        blocks_ok = all(bool(torch.equal(got[:, t, :], results[((jl * BB) % K + t) % K])) for t in range(n_last))
     pipelined_ok = None
     if sdb is None and args.pipelined_tail:  # the timed loop's own (pipelined) outputs: its last two steps are still in the buffers
         last = state["i"] - 1
