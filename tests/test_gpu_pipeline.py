@@ -321,3 +321,54 @@ def test_pipelined_device_steps(hip_lib):
         db.set_lookup(_lib.YH_LOOKUP_AUTO)
         ov, e, m = db.run_counts(hs[0])              # the plain forms still answer afterwards
         assert np.array_equal(np.stack([ov, e, m]), want[0])
+
+
+def test_pipelined_device_steps_fused_launches(hip_lib):
+    """Samples of 262 144+ hashes take the fused form of yh_run_device_pipelined: ONE launch per call that looks up sample k,
+    reduces sample k - 1 and runs the exclusive pass of sample k - 2 (k_step_fused, one and two hashes per lane), over two
+    counter sets and three step contexts.  Outputs are complete after two further calls or after a join; small samples
+    and other queries in between fall back / drain correctly."""
+    import torch
+
+    rng = np.random.default_rng(41)
+    values, offsets = _db(seed=15, n_refs=4000)
+    n = offsets.size - 1
+    refs = [values[int(offsets[j]):int(offsets[j + 1])] for j in range(n)]
+    mh = synth.max_hash_for_scaled(1000)
+    hs = []
+    for i, size in enumerate((300_000, 600_000, 280_000, 700_000, 540_000)):
+        present = rng.choice(n, size=40 + 10 * i, replace=False)
+        hs.append(synth.sample_from_refs(rng, refs, present, 0.5, size))
+    hs.append(synth.sample_from_refs(rng, refs, rng.choice(n, size=10, replace=False), 0.5, 30_000))  # small: the plain step
+    hs.append(np.unique(rng.integers(0, mh, size=400_000, dtype=np.uint64)))                         # large, overlaps (almost) nothing
+    want = []
+    for s in hs:
+        ov = oracle.overlap(values, offsets, s, threads=4)
+        e, m = oracle.exclusive(values, offsets, ov > 0, s)
+        want.append(np.stack([ov, e, m]))
+    ds = [torch.from_numpy(s.view(np.int64).copy()).cuda() for s in hs]
+    with RefDB(values, offsets) as db:
+        assert db.lookup_choice(hs[0].size) == _lib.YH_LOOKUP_INDEXED
+        nbuf = 3  # a call's rows are touched by the two launches behind it: three buffers rotate
+        bufs = [torch.zeros(3, n, dtype=torch.int32, device="cuda") for _ in range(nbuf)]
+        order = [int(x) for x in rng.integers(0, len(hs), size=60)]
+        for i, si in enumerate(order):
+            b = bufs[i % nbuf]
+            db.run_device_pipelined(ds[si].data_ptr(), ds[si].numel(), b[0].data_ptr(), b[1].data_ptr(), b[2].data_ptr())
+            if i >= 2 and i % 9 == 4:   # complete after two further calls: read step i - 2 without a join
+                torch.cuda.synchronize()
+                j = i - 2
+                if hs[order[i]].size >= 262144 and hs[order[i - 1]].size >= 262144 and hs[order[j]].size >= 262144:
+                    assert np.array_equal(bufs[j % nbuf].cpu().numpy().view(np.uint32), want[order[j]]), ("two calls later", j)
+            if i % 13 == 6:             # another query in between: drains the pipeline by itself
+                assert np.array_equal(db.overlap(hs[5]), want[5][0])
+                for d in range(min(i + 1, nbuf)):
+                    j = i - d
+                    assert np.array_equal(bufs[j % nbuf].cpu().numpy().view(np.uint32), want[order[j]]), ("after another query", j)
+        db.run_device_join()
+        db.synchronize()
+        for d in range(nbuf):
+            j = len(order) - 1 - d
+            assert np.array_equal(bufs[j % nbuf].cpu().numpy().view(np.uint32), want[order[j]]), ("after join", j)
+        ov, e, m = db.run_counts(hs[1])
+        assert np.array_equal(np.stack([ov, e, m]), want[1])

@@ -92,14 +92,10 @@ static float ring_read(EventRing& r) {
     return n ? (float)(acc / n) : 0.f;
 }
 
-// Tails of pipelined steps still running on the tail stream: the handle's stream waits for them (a stream-level wait,
-// the host does not block), so that whatever is queued next sees their results and may re-use their counters.
-static int pipe_join(yh_db* db, int parity = -1) {
-    for (int p = 0; p < 2; ++p)
-        if ((parity < 0 || parity == p) && db->tail_pending[p]) {
-            YH_HIP(hipStreamWaitEvent(db->stream, db->ev_tail[p], 0));
-            db->tail_pending[p] = false;
-        }
+// Stages of pipelined steps (yh_run_device_pipelined) that have not run yet: one or two draining launches on the
+// handle's stream, behind which every output of every step queued so far is complete.
+static int pipe_join(yh_db* db) {
+    while (db->pend_red >= 0 || db->pend_excl >= 0) YH_TRY(yh_q_step_fused(db, nullptr, 0, nullptr, nullptr, nullptr));
     return YH_OK;
 }
 
@@ -280,13 +276,7 @@ int yh_db_create_device(const uint64_t* d_values, const uint64_t* d_offsets, uin
 int yh_db_destroy(yh_db* db) {
     if (!db) return YH_OK;
     if (db->device >= 0) (void)hipSetDevice(db->device);
-    if (db->st_tail) (void)hipStreamSynchronize(db->st_tail);
     if (db->stream) (void)hipStreamSynchronize(db->stream);
-    if (db->st_tail) (void)hipStreamDestroy(db->st_tail);
-    for (int p = 0; p < 2; ++p) {
-        if (db->ev_lookup[p]) (void)hipEventDestroy(db->ev_lookup[p]);
-        if (db->ev_tail[p]) (void)hipEventDestroy(db->ev_tail[p]);
-    }
     if (db->ctx_bits[0]) {  // the step contexts: back to the handle's own arrays, the second set freed here
         db->d_maskbits = db->ctx_bits[0];
         db->d_work = db->ctx_work[0];
@@ -662,35 +652,26 @@ int yh_run_device(yh_db* db, const uint64_t* d_sample, uint64_t n_sample, uint32
 
 static int use_ctx(yh_db* db, int c);
 
-// Throughput form of yh_run_device for a caller with many samples in HBM: the step's tail (reduce + exclusive pass)
-// is queued on a second stream of the handle, so the NEXT call's lookup runs beside it.  The outputs of a pipelined
-// call are complete, in the order of the handle's stream, only after yh_run_device_join (or any other query, or
-// yh_db_synchronize, all of which join first); consecutive calls must use different output buffers.
+// Throughput form of yh_run_device for a caller with many samples in HBM: every call is ONE launch (k_step_fused) that
+// looks up this sample, reduces the previous one and runs the exclusive pass of the one before.  A call's three output
+// rows are complete, in the order of the handle's stream, after two further pipelined calls or after
+// yh_run_device_join (which every other query, yh_db_synchronize and yh_db_set_stream perform first by themselves).
 int yh_run_device_pipelined(yh_db* db, const uint64_t* d_sample, uint64_t n_sample, uint32_t* d_overlap,
                             uint32_t* d_n_excl, uint32_t* d_n_match) {
     if (!db_ok(db)) return YH_ERR_INVALID_ARG;
     if (!d_overlap || !d_n_excl || !d_n_match || (n_sample && !d_sample)) { yh_set_error("null device pointer"); return YH_ERR_INVALID_ARG; }
     YH_TRY(db_select(db));
-    // only the sample-driven fused step splits; everything else runs as yh_run_device does
-    if (!prefer_indexed(db, n_sample) || db->n_ghost) return yh_run_device(db, d_sample, n_sample, d_overlap, d_n_excl, d_n_match);
-    if (!db->st_tail) {
-        YH_HIP(hipStreamCreateWithFlags(&db->st_tail, hipStreamNonBlocking));
-        for (int p = 0; p < 2; ++p) {
-            YH_HIP(hipEventCreateWithFlags(&db->ev_lookup[p], hipEventDisableTiming));
-            YH_HIP(hipEventCreateWithFlags(&db->ev_tail[p], hipEventDisableTiming));
-        }
+    // only the large-sample form of the sample-driven step is fused; everything else runs as yh_run_device does
+    if (!prefer_indexed(db, n_sample) || !yh_q_step_fused_ok(db, n_sample))
+        return yh_run_device(db, d_sample, n_sample, d_overlap, d_n_excl, d_n_match);
+    if (!db->ctx_bits[2]) {  // the three step contexts the stages rotate through
+        const int now = db->ctx_now;
+        for (int c = 0; c < 3; ++c) YH_TRY(use_ctx(db, c));
+        YH_TRY(use_ctx(db, now));
     }
-    const int p = db->pipe_parity ^= 1;
-    YH_TRY(pipe_join(db, p));  // the step before the previous one used these counters and this context: its tail must be done
-    if (db->ctx_open[p]) db->ctx_clobbered[p] = true;
-    YH_TRY(use_ctx(db, p));
-    db->pipe_on = true;
-    const int rc = yh_q_overlap_indexed(db, (const u64*)d_sample, n_sample, d_overlap, true, d_n_excl, d_n_match);
-    db->pipe_on = false;
-    if (rc == 2) return YH_OK;
-    if (rc != YH_OK) return rc;
-    // (a handle without holder sets: the general exclusive pass, on the handle's stream)
-    return yh_q_exclusive(db, db->d_mask, (const u64*)d_sample, n_sample, d_overlap, d_n_excl, d_n_match, db->d_maskbits);
+    for (int c = 0; c < 3; ++c)
+        if (db->ctx_open[c]) db->ctx_clobbered[c] = true;
+    return yh_q_step_fused(db, (const u64*)d_sample, n_sample, d_overlap, d_n_excl, d_n_match);
 }
 
 int yh_run_device_join(yh_db* db) {

@@ -210,12 +210,13 @@ struct yh_db {
     u32* d_ghost_src = nullptr;  // [n_ghost] bit index into the all-gathered subset bits
     u64 ghost_begin = 0, n_ghost = 0;
 
-    // pipelined device-resident steps (yh_run_device_pipelined): the tail of step k beside the lookup of step k + 1
-    hipStream_t st_tail = nullptr;
-    hipEvent_t ev_lookup[2] = {nullptr, nullptr}, ev_tail[2] = {nullptr, nullptr};
-    bool tail_pending[2] = {false, false};  // a tail recorded in ev_tail[p] the handle's stream has not been made to wait for
-    bool pipe_on = false;                   // set around the one call that may split its step
-    int pipe_parity = 0;
+    // pipelined device-resident steps (yh_run_device_pipelined): three stages of three consecutive samples per launch
+    // (k_step_fused).  pend_red: step context of the sample whose lookup ran in the last launch (-1: none), with the
+    // parity of its counter set and its three output rows; pend_excl: context of the sample reduced by the last launch
+    u64 pipe_k = 0;
+    int pend_red = -1, pend_red_parity = 0, pend_excl = -1;
+    u32* pend_red_out[3] = {nullptr, nullptr, nullptr};
+    u32* pend_excl_out = nullptr;
 
     // pipelined host-buffer calls
     RunSlot slots[YH_RUN_SLOTS];
@@ -246,6 +247,8 @@ int yh_q_overlap(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap, b
 int yh_q_run_fused(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap, u32* d_excl, u32* d_match,
                    int phases = 3, u32* d_bits_out = nullptr, const u32* d_global_bits = nullptr, bool use_indexed = false);
 int yh_q_overlap_bsearch(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap);
+bool yh_q_step_fused_ok(const yh_db* db, u64 n_sample);
+int yh_q_step_fused(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap, u32* d_excl, u32* d_match);
 int yh_q_range_finish(yh_db* db, const u32* d_gathered, u32 n_ranks, u64 stride_words, u32* d_excl);
 // ---- the distinct-hash directory as the lookup kernels see it -------------------------------------
 // Primary structure: a table of 64-byte buckets, bucket(h) = floor(h * bkt_nb / 2^bits(max_hash))

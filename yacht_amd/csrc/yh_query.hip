@@ -99,8 +99,8 @@ struct FusedRun {
 // Append the posting pieces of every reference in the subset to the work list: (reference, first posting,
 // end) per <= EXCL_PIECE postings.  One atomic per workgroup.  All 256 threads of the block must call it.
 __device__ __forceinline__ void append_pieces(bool in_subset, u32 j, u32 nshared_j, u32 rpo_j, uint4* __restrict__ work,
-                                              u32* __restrict__ work_count, u32* lds /* [8] */) {
-    const u32 lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+                                              u32* __restrict__ work_count, u32* lds /* [waves + 1] */) {
+    const u32 lane = threadIdx.x & 63u, wv = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
     const u32 np = in_subset ? (nshared_j + (u32)EXCL_PIECE_C - 1u) / (u32)EXCL_PIECE_C : 0u;
     u32 v = np;
 #pragma unroll
@@ -111,11 +111,12 @@ __device__ __forceinline__ void append_pieces(bool in_subset, u32 j, u32 nshared
     if (lane == 63) lds[wv] = v;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const u32 total = lds[0] + lds[1] + lds[2] + lds[3];
-        lds[4] = total ? atomicAdd(work_count, total) : 0u;
+        u32 total = 0;
+        for (u32 q = 0; q < n_waves; ++q) total += lds[q];
+        lds[n_waves] = total ? atomicAdd(work_count, total) : 0u;
     }
     __syncthreads();
-    u32 at = lds[4] + v - np;
+    u32 at = lds[n_waves] + v - np;
     for (u32 q = 0; q < wv; ++q) at += lds[q];
     const u32 last = rpo_j + nshared_j;  // (= rpo[j + 1]: the record carries its end, one read less per piece)
     for (u32 i = 0; i < np; ++i) {
@@ -124,12 +125,12 @@ __device__ __forceinline__ void append_pieces(bool in_subset, u32 j, u32 nshared
     }
 }
 
-__global__ void __launch_bounds__(256) k_reduce_replicas(u32* __restrict__ reps, u32 R, u64 n,
-                                                         u32* __restrict__ out, u8* __restrict__ mask,
-                                                         u32* __restrict__ maskbits, u32* __restrict__ excl3,
-                                                         FusedRun fused) {
-    __shared__ u32 lds[8];
-    const u64 j = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+// (body: any workgroup size that is a multiple of 64; `wg` = the workgroup's index among the reducing ones; lds: waves + 1 words)
+__device__ __forceinline__ void reduce_replicas_body(u32 wg, u32* lds, u32* __restrict__ reps, u32 R, u64 n,
+                                                     u32* __restrict__ out, u8* __restrict__ mask,
+                                                     u32* __restrict__ maskbits, u32* __restrict__ excl3,
+                                                     const FusedRun& fused) {
+    const u64 j = wg * (u64)blockDim.x + threadIdx.x;
     u32 acc = 0;
     // everything this thread reads is requested up front (one memory round trip, not one per dependent use)
     u32 size_j = 0, nshared_j = 0, rpo_j = 0, rpo_end = 0;
@@ -158,7 +159,8 @@ __global__ void __launch_bounds__(256) k_reduce_replicas(u32* __restrict__ reps,
     }
     if (maskbits) {
         const u64 bal = __ballot(acc != 0);
-        if ((threadIdx.x & 63) == 0) {
+        // (whole 256-reference blocks are written, whatever the workgroup size: what the arrays are sized for)
+        if ((threadIdx.x & 63) == 0 && (j >> 5) < ((n + 255) / 256) * 8) {
             maskbits[(j >> 5)] = (u32)bal;
             maskbits[(j >> 5) + 1] = (u32)(bal >> 32);
             if (fused.bits_out) {
@@ -170,11 +172,19 @@ __global__ void __launch_bounds__(256) k_reduce_replicas(u32* __restrict__ reps,
     if (fused.work) append_pieces(acc != 0 && j < fused.work_refs, (u32)j, rpo_end - rpo_j, rpo_j, fused.work, fused.work_count, lds);
 }
 
+__global__ void __launch_bounds__(256) k_reduce_replicas(u32* __restrict__ reps, u32 R, u64 n,
+                                                         u32* __restrict__ out, u8* __restrict__ mask,
+                                                         u32* __restrict__ maskbits, u32* __restrict__ excl3,
+                                                         FusedRun fused) {
+    __shared__ u32 lds[17];
+    reduce_replicas_body(blockIdx.x, lds, reps, R, n, out, mask, maskbits, excl3, fused);
+}
+
 // the same work list for a subset that arrives as bits (general path); work_count zeroed by the caller
 __global__ void __launch_bounds__(256) k_excl_worklist(u64 n, const u32* __restrict__ maskbits, const u32* __restrict__ nshared,
                                                        const u32* __restrict__ rpo, uint4* __restrict__ work,
                                                        u32* __restrict__ work_count) {
-    __shared__ u32 lds[8];
+    __shared__ u32 lds[17];
     const u64 j = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     const bool in = j < n && ((maskbits[j >> 5] >> (j & 31u)) & 1u);
     append_pieces(in, (u32)j, in ? nshared[j] : 0u, in ? rpo[j] : 0u, work, work_count, lds);
@@ -209,7 +219,7 @@ __global__ void __launch_bounds__(256) k_range_mask(const u32* __restrict__ gath
                                                     const u32* __restrict__ rpo, u32* __restrict__ maskbits,
                                                     u32* __restrict__ n_excl, uint4* __restrict__ work,
                                                     u32* __restrict__ work_count) {
-    __shared__ u32 lds[8];
+    __shared__ u32 lds[17];
     const u64 j = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     bool in = false;
     u32 size_j = 0, nshared_j = 0, rpo_j = 0, rpo_end = 0;
@@ -773,33 +783,42 @@ constexpr int IDX_THREADS = YH_IDX_THREADS;
 // (THREADS lanes x U hashes per workgroup, 2^TBITS slots in the hit table: <2, 1024, 10> for large samples; <1, 256, 8>
 // for small ones, where the table keeps a sample that is mostly ONE genome -- an isolate -- from sending thousands of
 // atomics to one counter)
+struct TileLookup {
+    const u64* sample;
+    u64 n;
+    YhDirView dv;
+    const u32* filter;
+    u64 filter_mul;
+    const u64* po;
+    const u32* pr;
+    u32* reps;
+    u32 rep_mask;
+    u64 n_refs;
+    u8* hit;
+    u32* reps2;
+    u32* work_count;
+    const u32* bad;
+    u32 bad_gen;
+};
+// (body: `wg` = the workgroup's index among the looking-up ones; tkey / tcnt / tcnt2: 2^TBITS words of LDS each)
 template <int U, int THREADS, int TBITS>
-__global__ void __launch_bounds__(THREADS) k_index_lookup_tile(const u64* __restrict__ sample, u64 n, const YhDirView dv,
-                                                                   const u32* __restrict__ filter, u64 filter_mul,
-                                                                   const u64* __restrict__ po, const u32* __restrict__ pr,
-                                                                   u32* __restrict__ reps, u32 rep_mask, u64 n_refs,
-                                                                   u8* __restrict__ hit, u32* __restrict__ reps2,
-                                                                   u32* __restrict__ work_count, const u32* __restrict__ bad,
-                                                                   u32 bad_gen) {
+__device__ __forceinline__ void lookup_tile_body(u32 wg, u32* tkey, u32* tcnt, u32* tcnt2, const TileLookup& q) {
     constexpr u32 TSLOTS = 1u << TBITS;
-    __shared__ u32 tkey[TSLOTS];   // reference + 1, 0 = empty
-    __shared__ u32 tcnt[TSLOTS];   // hits
-    __shared__ u32 tcnt2[TSLOTS];  // hits on shared hashes
-    if (work_count && blockIdx.x == 0 && threadIdx.x == 0) *work_count = 0;
-    if (bad && *bad == bad_gen) return;
-    u32* my = reps + (u64)replica_of(blockIdx.x, rep_mask) * n_refs;
-    u32* my2 = reps2 ? reps2 + (u64)replica_of(blockIdx.x, rep_mask) * n_refs : nullptr;
-    const u64 base = blockIdx.x * (u64)(THREADS * U);
+    const u64* __restrict__ sample = q.sample;
+    const u64 n = q.n;
+    const YhDirView& dv = q.dv;
+    const u32* __restrict__ filter = q.filter;
+    if (q.work_count && wg == 0 && threadIdx.x == 0) *q.work_count = 0;
+    if (q.bad && *q.bad == q.bad_gen) return;
+    u32* my = q.reps + (u64)replica_of(wg, q.rep_mask) * q.n_refs;
+    u32* my2 = q.reps2 ? q.reps2 + (u64)replica_of(wg, q.rep_mask) * q.n_refs : nullptr;
+    const u64 base = wg * (u64)(THREADS * U);
     u64 h[U];
     bool ok[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const u64 t = base + (u64)u * THREADS + threadIdx.x;
-#if YH_NT_BUCKETS
-        h[u] = __builtin_nontemporal_load(sample + min(t, n - 1));
-#else
         h[u] = sample[min(t, n - 1)];
-#endif
         ok[u] = t < n && h[u] <= dv.max_hash;
         if (!ok[u]) h[u] = 0;  // (still a valid bucket to read)
     }
@@ -811,7 +830,7 @@ __global__ void __launch_bounds__(THREADS) k_index_lookup_tile(const u64* __rest
         u32 w[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            bit[u] = yh_bucket_of(h[u], dv.bkt_lsh, filter_mul);
+            bit[u] = yh_bucket_of(h[u], dv.bkt_lsh, q.filter_mul);
             w[u] = filter[bit[u] >> 5];
         }
 #pragma unroll
@@ -850,8 +869,8 @@ __global__ void __launch_bounds__(THREADS) k_index_lookup_tile(const u64* __rest
             add(r[u], false);
         } else {
             const u32 gi = r[u] & 0x7fffffffu;
-            if (hit) hit[gi] = 1;
-            walk_holders(po, pr, gi, [&](u32 holder) { add(holder, true); });
+            if (q.hit) q.hit[gi] = 1;
+            walk_holders(q.po, q.pr, gi, [&](u32 holder) { add(holder, true); });
         }
     }
     __syncthreads();
@@ -860,6 +879,15 @@ __global__ void __launch_bounds__(THREADS) k_index_lookup_tile(const u64* __rest
             count_add(&my[tkey[k] - 1], tcnt[k]);
             if (my2 && tcnt2[k]) count_add(&my2[tkey[k] - 1], tcnt2[k]);
         }
+}
+
+template <int U, int THREADS, int TBITS>
+__global__ void __launch_bounds__(THREADS) k_index_lookup_tile(const TileLookup q) {
+    constexpr u32 TSLOTS = 1u << TBITS;
+    __shared__ u32 tkey[TSLOTS];   // reference + 1, 0 = empty
+    __shared__ u32 tcnt[TSLOTS];   // hits
+    __shared__ u32 tcnt2[TSLOTS];  // hits on shared hashes
+    lookup_tile_body<U, THREADS, TBITS>(blockIdx.x, tkey, tcnt, tcnt2, q);
 }
 
 // ---- exclusive counts -----------------------------------------------------------------------------
@@ -982,34 +1010,52 @@ __device__ __forceinline__ u32 others_in_subset(const uint4 rec, const uint4 rec
 #define YH_EXCL_RECX_ALWAYS 0
 #endif
 constexpr int EXCL_PIECE_THREADS = YH_EXCL_PIECE_THREADS;  // waves of a workgroup share the staging of the subset bits
-template <bool LDSMASK>
-__global__ void __launch_bounds__(EXCL_PIECE_THREADS) k_excl_pieces(const u32* __restrict__ work_count, const uint4* __restrict__ work,
-                                                     const u32* __restrict__ rpo, const u32* __restrict__ rg,
-                                                     const uint4* __restrict__ rrec, const uint4* __restrict__ rrecx,
-                                                     const u32* __restrict__ mult,
-                                                     const u64* __restrict__ po, u32 n_post, const u32* __restrict__ pr,
-                                                     const u32* __restrict__ maskbits, u32 n_mask_words,
-                                                     const u8* __restrict__ hit, u32* __restrict__ ex_e,
-                                                     u32* __restrict__ ex_m, u32* __restrict__ ovsh) {
-    extern __shared__ u32 lmask[];
-    constexpr u32 WPB = EXCL_PIECE_THREADS / 64;
+struct ExclPieces {
+    const u32* work_count;
+    const uint4* work;
+    const u32* rpo;
+    const u32* rg;
+    const uint4* rrec;
+    const uint4* rrecx;
+    const u32* mult;
+    const u64* po;
+    u32 n_post;
+    const u32* pr;
+    const u32* maskbits;
+    u32 n_mask_words;
+    const u8* hit;
+    u32* ex_e;
+    u32* ex_m;
+    u32* ovsh;
+};
+// (body: any workgroup size that is a multiple of 64; `wg` of `n_wgs` workgroups walk the work list; lmask: n_mask_words of LDS
+// when LDSMASK)
+template <bool LDSMASK, int U = EXCL_U>
+__device__ __forceinline__ void excl_pieces_body(u32 wg, u32 n_wgs, u32* lmask, const ExclPieces& q) {
+    const u32 WPB = blockDim.x >> 6;
     const u32 lane = threadIdx.x & 63u;
-    const u32 n_work = *work_count;
-    if (blockIdx.x * WPB >= n_work) return;  // (the grid is sized for every piece of the database)
+    const u32* __restrict__ rg = q.rg;
+    const uint4* __restrict__ rrec = q.rrec;
+    const uint4* __restrict__ rrecx = q.rrecx;
+    const u32* __restrict__ mult = q.mult;
+    const u32* __restrict__ pr = q.pr;
+    const u8* __restrict__ hit = q.hit;
+    const u32 n_post = q.n_post;
+    const u32 n_work = *q.work_count;
+    if (wg * WPB >= n_work) return;  // (the grid is sized for every piece of the database)
     // this wave's first record is requested before the subset bits are staged: one round trip for both
-    const u32 w0 = blockIdx.x * WPB + (threadIdx.x >> 6);
+    const u32 w0 = wg * WPB + (threadIdx.x >> 6);
     uint4 first_rec = make_uint4(0u, 0u, 0u, 0u);
-    if (w0 < n_work) first_rec = work[w0];
+    if (w0 < n_work) first_rec = q.work[w0];
     if (LDSMASK) {  // the subset bits into LDS (16-byte reads)
-        const uint4* src = reinterpret_cast<const uint4*>(maskbits);
+        const uint4* src = reinterpret_cast<const uint4*>(q.maskbits);
         uint4* dst = reinterpret_cast<uint4*>(lmask);
-        for (u32 i = threadIdx.x; i < n_mask_words / 4; i += EXCL_PIECE_THREADS) dst[i] = src[i];  // (n_mask_words is a multiple of 8)
+        for (u32 i = threadIdx.x; i < q.n_mask_words / 4; i += blockDim.x) dst[i] = src[i];  // (n_mask_words is a multiple of 8)
         __syncthreads();
     }
-    auto mword = [&](u32 i) -> u32 { return LDSMASK ? lmask[i] : maskbits[i]; };
-    constexpr int U = EXCL_U;
-    for (u32 w = w0; w < n_work; w += gridDim.x * WPB) {
-        const uint4 mine = (w == w0) ? first_rec : work[w];
+    auto mword = [&](u32 i) -> u32 { return LDSMASK ? lmask[i] : q.maskbits[i]; };
+    for (u32 w = w0; w < n_work; w += n_wgs * WPB) {
+        const uint4 mine = (w == w0) ? first_rec : q.work[w];
         const u32 r = mine.x;
         const u32 end = mine.z;
         u32 acc_e = 0, acc_m = 0, acc_o = 0;
@@ -1036,10 +1082,10 @@ __global__ void __launch_bounds__(EXCL_PIECE_THREADS) k_excl_pieces(const u32* _
 #pragma unroll
                     for (int u = 0; u < U; ++u) recx[u] = rrecx[min(k[u], n_post - 1)];
                 }
-            } else {     // posting-only handles: holders through the posting lists
+            } else {     // handles without the inline holder records: holders through the posting lists
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    const u64 q0 = po[gi[u]], q1 = po[gi[u] + 1];
+                    const u64 q0 = q.po[gi[u]], q1 = q.po[gi[u] + 1];
                     rec[u] = make_uint4((u32)q0, (u32)(q1 - q0), 0u, 0xffffffffu);
                 }
             }
@@ -1056,11 +1102,49 @@ __global__ void __launch_bounds__(EXCL_PIECE_THREADS) k_excl_pieces(const u32* _
         acc_e = wave_sum(acc_e);
         if (hit) { acc_m = wave_sum(acc_m); acc_o = wave_sum(acc_o); }
         if (lane == 0) {
-            if (acc_e) atomicAdd(&ex_e[r], acc_e);
-            if (hit && acc_m) atomicAdd(&ex_m[r], acc_m);
-            if (hit && acc_o) atomicAdd(&ovsh[r], acc_o);
+            if (acc_e) atomicAdd(&q.ex_e[r], acc_e);
+            if (hit && acc_m) atomicAdd(&q.ex_m[r], acc_m);
+            if (hit && acc_o) atomicAdd(&q.ovsh[r], acc_o);
         }
     }
+}
+
+template <bool LDSMASK>
+__global__ void __launch_bounds__(EXCL_PIECE_THREADS) k_excl_pieces(const ExclPieces q) {
+    extern __shared__ u32 lmask[];
+    excl_pieces_body<LDSMASK>(blockIdx.x, gridDim.x, lmask, q);
+}
+
+// ---- the whole step as ONE launch of three independent roles (yh_run_device_pipelined) ---------------------------
+// reduce + exclusive pass are ~11 us of launch and round-trip latency for almost no work.  Queued behind the lookup they
+// are 25 % of the step; on a second stream they do not overlap the next lookup either (its 488 workgroups of 1024 lanes
+// hold every wave slot of the chip until they end: measured slower than the plain step).  So the three stages of three
+// CONSECUTIVE samples share one launch: workgroups [0, E) run the exclusive pass of sample k - 2, the next R the reducer
+// of sample k - 1, the rest the lookup of sample k -- no workgroup depends on another of the same launch: consecutive
+// samples alternate between two sets of replica counters and rotate through three step contexts (subset bits + work
+// list).  The short roles come first in dispatch order, and a step costs one launch: the lookup's.
+struct StepFused {
+    TileLookup look;   u32 look_wgs;
+    u32* r_reps; u32 r_R; u64 r_n; u32* r_out; u32* r_maskbits; FusedRun r_fused; u32 red_wgs;
+    ExclPieces excl;   u32 excl_wgs; u32 excl_lds;  // excl_lds: the subset bits fit the launch's LDS
+};
+// (8 waves per SIMD = two workgroups per CU, as the stand-alone lookup has: 64 VGPRs; the exclusive role unrolls by 2)
+template <int U>
+__global__ void __launch_bounds__(1024, 8) k_step_fused(const StepFused s) {
+    extern __shared__ u32 smem[];
+    u32 b = blockIdx.x;
+    if (b < s.excl_wgs) {
+        if (s.excl_lds) excl_pieces_body<true, 2>(b, s.excl_wgs, smem, s.excl);
+        else excl_pieces_body<false, 2>(b, s.excl_wgs, smem, s.excl);
+        return;
+    }
+    b -= s.excl_wgs;
+    if (b < s.red_wgs) {
+        reduce_replicas_body(b, smem, s.r_reps, s.r_R, s.r_n, s.r_out, nullptr, s.r_maskbits, nullptr, s.r_fused);
+        return;
+    }
+    b -= s.red_wgs;
+    lookup_tile_body<U, 1024, 10>(b, smem, smem + 1024, smem + 2048, s.look);
 }
 
 // e_j = (hashes of j that no other reference of the whole database has) + ex_e[j]
@@ -1272,25 +1356,23 @@ static int claim_hit_flags(yh_db* db) {
 
 // hit == nullptr: only ex_e is summed (the fused run step).  One wave per work record; the work list
 // (db->d_work, db->d_work_count) was appended by k_reduce_replicas / k_excl_worklist on the same stream.
-static void launch_excl_pieces(yh_db* db, const u32* d_maskbits, const u8* d_hit, u32* d_ex_e, u32* d_ex_m, u32* d_ovsh,
-                               bool sets = false, hipStream_t on = nullptr) {
-    const hipStream_t st = on ? on : db->stream;
+static ExclPieces excl_args(yh_db* db, const u32* work_count, const uint4* work, const u32* d_maskbits, const u8* d_hit,
+                            u32* d_ex_e, u32* d_ex_m, u32* d_ovsh, bool sets) {
     // sets: the work list holds pieces of holder-set records (appended by k_reduce_replicas), not of postings
-    const uint4* rec = sets ? db->d_hrec : db->d_rrec;
-    const uint4* recx = sets ? db->d_hrecx : db->d_rrecx;
-    const u32* mult = sets ? db->d_hmult : nullptr;
-    const u32 n_rec = sets ? db->n_sets : (u32)db->n_postings;
     const u32 words = (u32)(((db->n_refs + 255) / 256) * 8);  // what k_reduce_replicas / k_mask_bits write: whole 256-reference blocks
+    return ExclPieces{work_count, work, db->d_rpo, db->d_rg, sets ? db->d_hrec : db->d_rrec, sets ? db->d_hrecx : db->d_rrecx,
+                      sets ? db->d_hmult : nullptr, db->d_po, sets ? db->n_sets : (u32)db->n_postings, db->d_pr, d_maskbits,
+                      words, d_hit, d_ex_e, d_ex_m, d_ovsh};
+}
+static void launch_excl_pieces(yh_db* db, const u32* d_maskbits, const u8* d_hit, u32* d_ex_e, u32* d_ex_m, u32* d_ovsh,
+                               bool sets = false) {
+    const ExclPieces q = excl_args(db, db->d_work_count, db->d_work, d_maskbits, d_hit, d_ex_e, d_ex_m, d_ovsh, sets);
     const u32 per_wg = EXCL_PIECE_THREADS / 64;
     const u32 grid = std::min<u32>((db->n_chunks + per_wg - 1) / per_wg, (u32)YH_EXCL_GRID);
-    if (words <= EXCL_LDS_WORDS)
-        k_excl_pieces<true><<<grid, EXCL_PIECE_THREADS, words * sizeof(u32), st>>>(
-            db->d_work_count, db->d_work, db->d_rpo, db->d_rg, rec, recx, mult, db->d_po, n_rec, db->d_pr,
-            d_maskbits, words, d_hit, d_ex_e, d_ex_m, d_ovsh);
+    if (q.n_mask_words <= EXCL_LDS_WORDS)
+        k_excl_pieces<true><<<grid, EXCL_PIECE_THREADS, q.n_mask_words * sizeof(u32), db->stream>>>(q);
     else
-        k_excl_pieces<false><<<grid, EXCL_PIECE_THREADS, 0, st>>>(
-            db->d_work_count, db->d_work, db->d_rpo, db->d_rg, rec, recx, mult, db->d_po, n_rec, db->d_pr,
-            d_maskbits, words, d_hit, d_ex_e, d_ex_m, d_ovsh);
+        k_excl_pieces<false><<<grid, EXCL_PIECE_THREADS, 0, db->stream>>>(q);
 }
 
 // flag_shared: also flag which database-shared hashes are in the sample (db->d_hit), fused into the
@@ -1458,14 +1540,8 @@ int yh_q_overlap_indexed(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_ov
     while (R > 1 && R > r_want) R >>= 1;
     const bool fused = fused_possible(db, d_fused_excl, for_exclusive);
     if (for_exclusive && db->n_shared && !fused) YH_TRY(claim_hit_flags(db));
-    // Pipelined steps (yh_run_device_pipelined): the lookup stays on the handle's stream, reduce + exclusive pass go to
-    // the tail stream behind an event, and consecutive steps alternate between two sets of counters and two step
-    // contexts -- the lookup of step k + 1 runs while the tail of step k does (~11 us of launch and round-trip
-    // latency for almost no work).
-    const bool piped = db->pipe_on && fused_possible(db, d_fused_excl, for_exclusive) && !lookup_half_only;
-    u32* const reps1 = db->d_reps + (piped ? (u64)db->pipe_parity * 2 * db->reps_cap : 0);
+    u32* const reps1 = db->d_reps;
     u32* const reps2 = reps1 + db->reps_cap;
-    hipStream_t st_tail = piped ? db->st_tail : st;
     // (no kernel in front of the lookup: the counters are zero at rest)
     yh_ring_record_begin(db, db->ev_overlap);
     u8* const d_hitflags = (for_exclusive && db->n_shared && !fused) ? db->d_hit : nullptr;
@@ -1473,8 +1549,8 @@ int yh_q_overlap_indexed(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_ov
     const u32* const d_filter = yh_filter_of(db);
 #define YH_TILE_LAUNCH(UU, TT, BB, FILTER)                                                                                        \
     k_index_lookup_tile<UU, TT, BB><<<(u32)((n_sample + (u64)(TT) * (UU) - 1) / ((u64)(TT) * (UU))), TT, 0, st>>>(                 \
-        d_sample, n_sample, yh_dir_view(db), FILTER, db->filter_mul, db->d_po, db->d_pr, reps1, R - 1, N, d_hitflags, d_reps2, \
-        db->d_work_count, db->d_bad, db->bad_gen)
+        TileLookup{d_sample, n_sample, yh_dir_view(db), FILTER, db->filter_mul, db->d_po, db->d_pr, reps1, R - 1, N, d_hitflags,    \
+                   d_reps2, db->d_work_count, db->d_bad, db->bad_gen})
     if (n_sample && db->n_distinct && U == 256)
         // small samples: latency-bound, so no filter read in front of the bucket; 256-lane workgroups keep every CU busy
         YH_TILE_LAUNCH(1, 256, 8, nullptr);
@@ -1485,11 +1561,7 @@ int yh_q_overlap_indexed(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_ov
     else if (fused && db->d_work_count)
         YH_HIP(hipMemsetAsync(db->d_work_count, 0, sizeof(u32), st));
     yh_ring_record_end(db, db->ev_overlap);
-    if (piped) {
-        YH_HIP(hipEventRecord(db->ev_lookup[db->pipe_parity], st));
-        YH_HIP(hipStreamWaitEvent(st_tail, db->ev_lookup[db->pipe_parity], 0));
-    }
-    k_reduce_replicas<<<(u32)((N + 255) / 256), 256, 0, st_tail>>>(
+    k_reduce_replicas<<<(u32)((N + 255) / 256), 256, 0, st>>>(
         reps1, R, N, d_overlap, (for_exclusive && !fused) ? db->d_mask : nullptr,
         for_exclusive ? db->d_maskbits : nullptr, (for_exclusive && !fused) ? db->d_excl_e : nullptr,
         // (range_local -- a hash-range shard's first half: n_excl and the work list wait for the global subset)
@@ -1498,16 +1570,79 @@ int yh_q_overlap_indexed(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_ov
                          (u32)(db->n_ghost ? db->ghost_begin : N)}
               : FusedRun{});
     if (fused && !lookup_half_only) {  // (sharded run: the posting-list half follows the exchange of the subset bits)
-        if (!piped) yh_ring_record_begin(db, db->ev_excl);
-        if (db->n_chunks) launch_excl_pieces(db, db->d_maskbits, nullptr, d_fused_excl, nullptr, nullptr, true, st_tail);
-        if (!piped) yh_ring_record_end(db, db->ev_excl);
-    }
-    if (piped) {
-        YH_HIP(hipEventRecord(db->ev_tail[db->pipe_parity], st_tail));
-        db->tail_pending[db->pipe_parity] = true;
+        yh_ring_record_begin(db, db->ev_excl);
+        if (db->n_chunks) launch_excl_pieces(db, db->d_maskbits, nullptr, d_fused_excl, nullptr, nullptr, true);
+        yh_ring_record_end(db, db->ev_excl);
     }
     YH_HIP(hipGetLastError());
     return fused ? 2 : YH_OK;  // 2: the exclusive counts are done too
+}
+
+// One launch of k_step_fused: the exclusive pass of the step before the previous one, the reducer of the previous
+// one, and (d_sample != nullptr) the lookup of a new one.  d_sample == nullptr: a draining launch (yh_run_device_join).
+// The caller has checked yh_q_step_fused_ok and allocated the step contexts 0..2.
+bool yh_q_step_fused_ok(const yh_db* db, u64 n_sample) {
+    return db->has_dir && db->has_index && db->d_cbkt && fused_possible(db, reinterpret_cast<const u32*>(db), true) &&
+           db->n_chunks && !db->n_ghost && n_sample >= 256ull * 1024 && n_sample <= 0xfffffff0ull;
+}
+int yh_q_step_fused(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap, u32* d_excl, u32* d_match) {
+    hipStream_t st = db->stream;
+    const u64 N = db->n_refs;
+    u32 R;
+    YH_TRY(ensure_reps(db, R));
+    while (R > 1 && R > 4u) R >>= 1;
+    StepFused s{};
+    u32 lds_words = 3 * 1024;  // the lookup role's hit table
+    if (db->pend_excl >= 0) {   // exclusive pass of the step reduced by the previous launch
+        const int c = db->pend_excl;
+        s.excl = excl_args(db, db->ctx_count[c], db->ctx_work[c], db->ctx_bits[c], nullptr, db->pend_excl_out, nullptr, nullptr, true);
+        s.excl_wgs = std::min<u32>((db->n_chunks + 15) / 16, 256u);
+        s.excl_lds = s.excl.n_mask_words <= EXCL_LDS_WORDS ? 1u : 0u;
+        if (s.excl_lds) lds_words = std::max(lds_words, s.excl.n_mask_words);
+    }
+    if (db->pend_red >= 0) {    // reducer of the step looked up by the previous launch
+        const int c = db->pend_red;
+        u32* const reps1 = db->d_reps + (u64)db->pend_red_parity * 2 * db->reps_cap;
+        s.r_reps = reps1;
+        s.r_R = R;
+        s.r_n = N;
+        s.r_out = db->pend_red_out[0];
+        s.r_maskbits = db->ctx_bits[c];
+        s.r_fused = FusedRun{reps1 + db->reps_cap, db->d_sizes, db->d_nshared, db->pend_red_out[1], db->pend_red_out[2], nullptr,
+                             db->d_hpo, db->ctx_work[c], db->ctx_count[c], (u32)N};
+        s.red_wgs = (u32)((N + 1023) / 1024);
+    }
+    int U = 2;
+    int c_new = -1;
+    if (d_sample) {
+        c_new = (int)(db->pipe_k % 3);
+        const int parity = (int)(db->pipe_k & 1);
+        u32* const reps1 = db->d_reps + (u64)parity * 2 * db->reps_cap;
+        U = n_sample >= 512ull * 1024 ? 2 : 1;
+        s.look = TileLookup{d_sample, n_sample, yh_dir_view(db), yh_filter_of(db), db->filter_mul, db->d_po, db->d_pr, reps1, R - 1, N,
+                            nullptr, reps1 + db->reps_cap, db->ctx_count[c_new], nullptr, 0u};
+        s.look_wgs = (u32)((n_sample + 1024ull * U - 1) / (1024ull * U));
+    }
+    const u32 total = s.excl_wgs + s.red_wgs + s.look_wgs;
+    if (total) {
+        if (d_sample) yh_ring_record_begin(db, db->ev_overlap);
+        if (U == 2) k_step_fused<2><<<total, 1024, lds_words * sizeof(u32), st>>>(s);
+        else k_step_fused<1><<<total, 1024, lds_words * sizeof(u32), st>>>(s);
+        if (d_sample) yh_ring_record_end(db, db->ev_overlap);
+        YH_HIP(hipGetLastError());
+    }
+    // the pipeline moves on
+    db->pend_excl = db->pend_red;
+    db->pend_excl_out = db->pend_red >= 0 ? db->pend_red_out[1] : nullptr;
+    db->pend_red = c_new;
+    if (d_sample) {
+        db->pend_red_parity = (int)(db->pipe_k & 1);
+        db->pend_red_out[0] = d_overlap;
+        db->pend_red_out[1] = d_excl;
+        db->pend_red_out[2] = d_match;
+        ++db->pipe_k;
+    }
+    return YH_OK;
 }
 
 int yh_q_overlap_bsearch(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap) {
