@@ -80,9 +80,10 @@ def parse_args():
     ap.add_argument("--present", type=int, default=200, help="genomes present in a sample (diagnostic)")
     ap.add_argument("--no-indexed", action="store_true", help="skip the extra measurement of the sample-driven path")
     ap.add_argument("--no-host-inclusive", action="store_true")
-    ap.add_argument("--pipelined-tail", action="store_true",
-                    help="N=1: yh_run_device_pipelined instead of yh_run_device in the timed loop (the tail of a step on a second "
-                         "stream beside the next step's lookup; measured slower than the plain step: DESIGN.md 3)")
+    ap.add_argument("--plain-steps", action="store_true",
+                    help="N=1: yh_run_device (three launches per sample: lookup, reduce, exclusive pass) instead of "
+                         "yh_run_device_pipelined (ONE launch per sample: its lookup beside the reducer of the previous sample and "
+                         "the exclusive pass of the one before) in the timed loop")
     ap.add_argument("--no-real-shape", action="store_true")
     ap.add_argument("--no-batched", action="store_true")
     ap.add_argument("--batch-samples", type=int, default=32, help="samples per yh_run_batch_device call of the `batched` leg (<= 64)")
@@ -158,6 +159,7 @@ def cpu_model() -> str:
 
 def main() -> int:
     args = parse_args()
+    args.pipelined_tail = not args.plain_steps
     if args.scaling is None:
         args.scaling = "strong" if args.gpus > 1 else "weak"  # (the same thing at N = 1)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.force_dist:
@@ -497,8 +499,7 @@ def main() -> int:
             s = samples[i % K]
             c = cpath if plain else cpath2[i % 2]
             with torch.cuda.stream(stream):
-                (db.run_device if (plain or not args.pipelined_tail) else db.run_device_pipelined)(
-                    s.data_ptr(), s.numel(), c[0].data_ptr(), c[1].data_ptr(), c[2].data_ptr())
+                db.run_device(s.data_ptr(), s.numel(), c[0].data_ptr(), c[1].data_ptr(), c[2].data_ptr())  # (plain steps: the kernels apart)
 
         for name, mode in (("stream", ylib.YH_LOOKUP_STREAM), ("indexed", ylib.YH_LOOKUP_INDEXED)):
             if mode == ylib.YH_LOOKUP_INDEXED and args.no_indexed:
@@ -830,6 +831,8 @@ def main() -> int:
     Nh = int(info["n_refs"])
     survey_bytes = 8 * (Hh + n_sample) + 8 * (Nh + 1) + 4 * Nh
 
+    rl_main = [False]  # (set while the roofline of the timed loop's own step is made: that one may be the fused launch)
+
     def roofline_stream(k_ms, excl_ms):
         alg_bytes = int(info.get("stream_bytes", 0)) + 8 * n_sample
         achieved = (alg_bytes / 1e9) / (k_ms / 1e3) if k_ms > 0 else 0.0
@@ -855,7 +858,7 @@ def main() -> int:
         survey_rate = (survey_bytes / 1e9) / (k_ms / 1e3) if k_ms > 0 else 0.0
         return {
             # (every sample size takes a form of k_index_lookup_tile: yh_q_overlap_indexed)
-            "bound": "hbm", "kernel": "k_index_lookup_tile",
+            "bound": "hbm", "kernel": "k_step_fused" if (args.pipelined_tail and not multi and rl_main[0]) else "k_index_lookup_tile",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": None,
             "bytes_basis": "layout: one 64-byte bucket (random sector) + the 8-byte hash per SAMPLE hash; no reference hash is streamed. "
@@ -873,7 +876,12 @@ def main() -> int:
 
     k_ms = float(timing["ms_overlap_kernel"])
     x_ms = float(timing["ms_exclusive_kernels"])
+    rl_main[0] = True
     roofline = (roofline_indexed if default_choice == ylib.YH_LOOKUP_INDEXED else roofline_stream)(k_ms, x_ms)
+    rl_main[0] = False
+    if roofline["kernel"] == "k_step_fused":
+        roofline["kernel_note"] = ("one launch per step: the lookup of this sample (the role the bytes are counted for: "
+                                   "k_index_lookup_tile's body) + the reducer of the previous sample + the exclusive pass of the one before")
     roofline["default_lookup"] = "indexed" if default_choice == ylib.YH_LOOKUP_INDEXED else "stream"
     # What a HIP-event pair measures with NOTHING between its two records, on the busy stream of the step loop: the
     # part of `kernel_ms_avg` that is marker processing and dispatch, not kernel (rocprofv3's kernel durations in

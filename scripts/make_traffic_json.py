@@ -58,7 +58,8 @@ bench = json.load(open(bench_path))
 n_hashes = int(bench["config"]["ref_hashes_per_gpu"])
 for kernel, name, factor, why in (
         ("k_stream_lookup", "stream", 2.0, "read bytes = 2 x FETCH_SIZE (gfx950, 16-B/lane coalesced stream); write bytes = WRITE_SIZE"),
-        ("k_index_lookup", "index", 1.0, "read bytes = FETCH_SIZE (isolated 64-byte bucket reads: 64-byte requests); write bytes = WRITE_SIZE")):
+        ("k_index_lookup", "index", 1.0, "read bytes = FETCH_SIZE (isolated 64-byte bucket reads: 64-byte requests); write bytes = WRITE_SIZE"),
+        ("k_step_fused", "fused", 1.0, "read bytes = FETCH_SIZE (isolated 64-byte reads of the lookup role + the two small tail roles); write bytes = WRITE_SIZE")):
     fetch_kib, nf = mean_counter("pmc_fetch", "FETCH_SIZE", kernel)
     write_kib, nw = mean_counter("pmc_write", "WRITE_SIZE", kernel)
     if not nf:

@@ -4,7 +4,7 @@
 MODE=${1:-stats}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT" || exit 1
-B="python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-host-inclusive --no-real-shape --no-batched"
+B="python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-host-inclusive --no-real-shape --no-batched --no-train --no-scaling-model"
 if [ "$MODE" = stats ] || [ "$MODE" = all ]; then
   rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_stats -- $B > gpurun_out/prof_stats.log 2>&1
 fi
@@ -19,7 +19,7 @@ python3 scripts/summarize_prof.py gpurun_out
 # keep what is judged (per-kernel stats, per-dispatch counter rows of OUR query kernels), drop the bulk
 python3 - <<'PY'
 import csv, glob, os
-keep = ("k_stream_lookup", "k_index_lookup", "k_reduce_replicas", "k_excl_pieces")
+keep = ("k_step_fused", "k_stream_lookup", "k_index_lookup", "k_reduce_replicas", "k_excl_pieces")
 for f in glob.glob("gpurun_out/pmc_*/*/*_counter_collection.csv"):
     rows = list(csv.DictReader(open(f)))
     out = os.path.join("gpurun_out", os.path.basename(os.path.dirname(os.path.dirname(f))) + ".csv")

@@ -7,7 +7,7 @@ import os
 import sys
 
 root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out"
-OURS = ("k_tile_lookup", "k_stream_lookup", "k_resolve_stream", "k_wg_", "k_batch", "k_index_lookup", "k_resolve_hits", "k_excl", "k_prep", "k_mask_bits", "k_reduce_replicas", "k_sample_bounds", "k_mask_from", "k_pair", "k_overlap_bsearch",
+OURS = ("k_step_fused", "k_unpack_sample", "k_compact_rows", "k_range_mask", "k_tile_lookup", "k_stream_lookup", "k_resolve_stream", "k_wg_", "k_batch", "k_index_lookup", "k_resolve_hits", "k_excl", "k_prep", "k_mask_bits", "k_reduce_replicas", "k_sample_bounds", "k_mask_from", "k_pair", "k_overlap_bsearch",
         "k_scan_u32", "k_idx", "k_split", "k_part_scan", "k_scatter", "k_scan_refs", "k_fill", "k_bounds")
 
 
@@ -36,7 +36,7 @@ for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     files.sort(key=os.path.getmtime)
     for r in csv.DictReader(open(files[-1])):
-        if any(t in r["Kernel_Name"] for t in ("k_tile_lookup", "k_stream_lookup", "k_index_lookup", "k_reduce_replicas", "k_excl_pieces")):
+        if any(t in r["Kernel_Name"] for t in ("k_step_fused", "k_tile_lookup", "k_stream_lookup", "k_index_lookup", "k_reduce_replicas", "k_excl_pieces")):
             acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
     print(f"== {os.path.basename(d)} (mean per launch) ==")
     for k, v in acc.items():
@@ -51,7 +51,8 @@ if trace:
     rows = list(csv.DictReader(open(trace[0])))
     rows = [r for r in rows if any(t in r["Kernel_Name"] for t in OURS) or "Memset" in r["Kernel_Name"] or "fill" in r["Kernel_Name"].lower()]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    for tag, title in (("k_stream_lookup", "streaming step"), ("k_index_lookup", "sample-driven step (k_index_lookup / k_index_lookup_tile)")):
+    for tag, title in (("k_step_fused", "fused step (k_step_fused: lookup k + reduce k-1 + exclusive pass k-2 in one launch)"),
+                       ("k_stream_lookup", "streaming step"), ("k_index_lookup", "sample-driven step, three launches (k_index_lookup_tile)")):
         idx = [i for i, r in enumerate(rows) if tag in r["Kernel_Name"]]
         # two consecutive launches of the same lookup kernel with only step kernels between them
         pairs = [(a, b) for a, b in zip(idx, idx[1:]) if b - a <= 4]
