@@ -46,7 +46,12 @@ def main() -> int:
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--oracle-clusters", type=int, default=400)
     ap.add_argument("--no-oracle", action="store_true")
-    ap.add_argument("--gpus", type=int, default=1, help="N > 1: rows of the pair matrix split over ranks (launch with torch.distributed.run)")
+    ap.add_argument("--gpus", type=int, default=1, help="N > 1: the work split over ranks (launch with torch.distributed.run)")
+    ap.add_argument("--shard", default="hash", choices=["hash", "rows"],
+                    help="N > 1: hash (default) = every rank uploads, indexes and intersects ONE HASH RANGE of all sketches, the "
+                         "partial pair counts are summed (dist.hash_range_pairwise); rows = every rank holds everything and computes a "
+                         "block of rows of the pair matrix (dist.sharded_pairwise)")
+    ap.add_argument("--no-scaling-model", action="store_true", help="N = 1: skip the measurement of one rank's share of a G-way hash-range run")
     ap.add_argument("--backend", default="nccl")
     ap.add_argument("--share-gpu", action="store_true", help="testing: all ranks on cuda:0 (gloo)")
     args = ap.parse_args()
@@ -81,6 +86,12 @@ def main() -> int:
     n = offsets.size - 1
     sizes = np.diff(offsets).astype(np.uint32)
 
+    range_slice = None
+    if world > 1 and args.shard == "hash":
+        from yacht_amd import dist as ydist
+
+        bnd = ydist.hash_range_bounds(int(values.max()), world)
+        range_slice = ydist.slice_csr_to_hash_range(values, offsets, bnd[rank], bnd[rank + 1])
     t_build, t_pair, t_sel = [], [], []
     k_pair_ms = []
     pi = pj = pc = None
@@ -88,6 +99,27 @@ def main() -> int:
         if world > 1:
             dist.barrier()
         t0 = time.perf_counter()
+        if world > 1 and args.shard == "hash":
+            # this rank's hash range of every sketch: uploaded, sorted, indexed and intersected here; partial counts summed
+            from yacht_amd import dist as ydist
+
+            v_r, o_r = range_slice  # (cut on the host once, outside the timed passes: `yacht train` has the sketches on the host)
+            db = RefDB(v_r, o_r, device=local_rank, flags=YH_DB_PAIRWISE_ONLY)
+            t1 = time.perf_counter()
+            pi, pj, pc, stats_sum = ydist.hash_range_pairwise(lambda: (*db.pairwise(0.0), db.index_stats()), n, sizes, c,
+                                                             device="cpu" if args.backend != "nccl" else f"cuda:{local_rank}")
+            t2 = time.perf_counter()
+            sel = train_select(sizes, pi, pj)
+            t3 = time.perf_counter()
+            tm = db.timing()
+            info = db.info()
+            stats = stats_sum
+            db.close()
+            t_build.append(t1 - t0)
+            t_pair.append(t2 - t1)
+            t_sel.append(t3 - t2)
+            k_pair_ms.append(tm["ms_pairwise_kernels"])
+            continue
         db = RefDB(values, offsets, device=local_rank, flags=YH_DB_PAIRWISE_ONLY)  # what `yacht train` creates (train_core.py)
         t1 = time.perf_counter()
         if world == 1:
@@ -146,6 +178,9 @@ def main() -> int:
         gsel = train_select(s2, gi, gj)
         parity = bool(np.array_equal(gi, wi) and np.array_equal(gj, wj) and np.array_equal(gc, wc)
                       and gstats == wstats and np.array_equal(gsel, wsel))
+        if k == n:  # the oracle saw everything: the timed passes' own results (sharded over the ranks when N > 1) against it
+            parity = parity and bool(np.array_equal(pi, wi) and np.array_equal(pj, wj) and np.array_equal(pc, wc)
+                                     and tuple(int(x) for x in stats) == tuple(wstats) and np.array_equal(sel, wsel))
         cpu = {"value": round(k * (k - 1) / 2 / t_cpu, 1), "unit": "pair-queries/s", "cores": cores, "kind": "port",
                "cpu_model": _cpu_model(),
                "sample": f"first {k} sketches ({int(o2[-1])} hashes): index build on 1 thread + scatter on {cores} "
@@ -202,13 +237,45 @@ def main() -> int:
         elif parity is None:
             parity = golden["all_equal"]
 
+    # what ONE rank of a G-way hash-range run does (N = 1 only): rank 0's range of every sketch through upload + index +
+    # pairwise(0.0) on this GPU; the merge of the partial lists is measured on this host with G copies of that list
+    scaling_model = None
+    if world == 1 and not args.no_scaling_model:
+        from yacht_amd import dist as ydist
+
+        per_g = {}
+        for G in (2, 4, 8):
+            bnd = ydist.hash_range_bounds(int(values.max()), G)
+            v_r, o_r = ydist.slice_csr_to_hash_range(values, offsets, bnd[0], bnd[1])
+            ts = []
+            for _ in range(4):
+                t0 = time.perf_counter()
+                with RefDB(v_r, o_r, device=local_rank, flags=YH_DB_PAIRWISE_ONLY) as dbg:
+                    gi_, gj_, gc_ = dbg.pairwise(0.0)
+                ts.append(time.perf_counter() - t0)
+            t0 = time.perf_counter()
+            ydist.merge_partial_pairs(n, [(gi_, gj_, gc_)] * G, sizes, c)
+            t_merge = time.perf_counter() - t0
+            per_g[str(G)] = {"rank0_upload_index_pairwise_s": round(float(np.median(ts[1:])), 5), "hashes_in_range": int(v_r.size),
+                             "partial_pairs": int(gi_.size), "host_merge_of_G_lists_s": round(t_merge, 5)}
+        scaling_model = {"per_G": per_g,
+                         "predicted_total_s": {g: round(v["rank0_upload_index_pairwise_s"] + v["host_merge_of_G_lists_s"] + t_sel + 0.0003, 5)
+                                               for g, v in per_g.items()},
+                         "predicted_speedup_vs_1gpu": {g: round(total / (v["rank0_upload_index_pairwise_s"] + v["host_merge_of_G_lists_s"] + t_sel + 0.0003), 2)
+                                                       for g, v in per_g.items()},
+                         "how": "rank 0's hash range of every sketch: yh_db_create(PAIRWISE_ONLY) + yh_pairwise(c = 0) timed on this GPU; + "
+                                "the sum-per-pair of G such lists on this host (on the device over RCCL) + selection + 0.3 ms assumed for "
+                                "the two small all-gathers"}
+
     # algorithmic bytes: every reference hash once + one (i, j, count) per emitted pair
     alg = 8 * int(offsets[-1]) + 12 * int(pi.size)
     out = {
         "metric": "ref x ref containment pair-queries/sec (yacht train)",
         "value": round(n_pairs_unordered / total, 1),
         "unit": "pair-queries/s",
-        "n_gpus": world, "scaling": "strong (rows of one pair matrix over ranks; every rank builds the whole index)",
+        "n_gpus": world,
+        "scaling": ("strong (one hash range of every sketch per rank: upload, index and pairwise all divide; partial counts summed)"
+                    if args.shard == "hash" else "strong (rows of one pair matrix over ranks; every rank builds the whole index)"),
         "config": {"workload": f"configs[3]: {args.clusters} clusters x 5 sketches of ~{args.size} hashes, C=0.95**31",
                    "n_refs": int(n), "n_hashes": int(offsets[-1]), "pairs_emitted": int(pi.size),
                    "selected": int(sel.size), "shared_hashes": int(stats[2]), "postings": int(info["n_shared_postings"])},
@@ -220,6 +287,7 @@ def main() -> int:
         "cpu_baseline": cpu,
         "parity_bit_exact": parity,
         "full_size_vs_genuine_reference": golden,
+        "scaling_model": scaling_model,
     }
     # roofline-style figure of the kernels alone (B = 8 H + 12 P_out), HBM peak 8 TB/s
     k_ms = float(tm["ms_db_build"]) + k_pair_ms

@@ -123,6 +123,82 @@ def sharded_pairwise(compute_rows: Callable[[int, int], Tuple[np.ndarray, np.nda
 _SIGN = -(2 ** 63)  # int64 bit pattern 0x8000...: x ^ _SIGN turns unsigned order into signed order
 
 
+# ---- `yacht train` by HASH RANGE: the index build divides too --------------------------------------------------------
+# With row blocks every rank still uploads, sorts and indexes the WHOLE reference set (13 of configs[3]'s 17 ms) and only
+# the 3.6 ms pairwise pass shrinks.  By hash range, rank g holds every reference cut down to [lo_g, hi_g): it uploads,
+# sorts and indexes 1/G of the (hash, reference) pairs, and its pairwise pass gives every pair's intersection count
+# RESTRICTED to the range -- |R_i n R_j| is the sum of those over the ranges.  Only pairs that share a hash at all
+# exist (a few per reference), so the partial lists are small: one all-gather of (i, j, partial count), a sum per pair,
+# then the reference's filter `!(1.0 * count / |R_i| < C)` (src/cpp/main.cpp:297-303) on the TOTAL count with the
+# WHOLE sketch's size.  The three index statistics (main.cpp:242-244) are sums over the ranges too.
+def slice_csr_to_hash_range(values: np.ndarray, offsets: np.ndarray, lo: int, hi: int) -> Tuple[np.ndarray, np.ndarray]:
+    """Host form of slice_to_hash_range: every reference's hashes in [lo, hi) (hi = 2**64: no upper bound)."""
+    values = np.asarray(values, dtype=np.uint64)
+    offsets = np.asarray(offsets, dtype=np.uint64)
+    keep = values >= np.uint64(lo)
+    if hi < 2 ** 64:
+        keep &= values < np.uint64(hi)
+    csum = np.concatenate([[0], np.cumsum(keep, dtype=np.uint64)])
+    return np.ascontiguousarray(values[keep]), csum[offsets.astype(np.int64)].astype(np.uint64)
+
+
+def merge_partial_pairs(n_refs: int, parts: Sequence[Tuple[np.ndarray, np.ndarray, np.ndarray]], sizes: np.ndarray,
+                        c_thresh: float):
+    """Sum the per-range (i, j, count) lists by pair and keep a pair iff !(1.0 * count / |R_i| < c_thresh): the pairs
+    RefDB.pairwise(c_thresh) gives on the whole sketches, sorted by (i, j)."""
+    if not parts or not sum(int(p[0].size) for p in parts):
+        z = np.zeros(0, dtype=np.uint32)
+        return z, z.copy(), z.copy()
+    key = np.concatenate([p[0].astype(np.int64) * n_refs + p[1].astype(np.int64) for p in parts])
+    cnt = np.concatenate([p[2].astype(np.int64) for p in parts])
+    uk, inv = np.unique(key, return_inverse=True)
+    tot = np.bincount(inv, weights=cnt.astype(np.float64), minlength=uk.size).astype(np.int64)  # (exact: counts << 2^53)
+    pi, pj = (uk // n_refs), (uk % n_refs)
+    keep = ~((1.0 * tot / np.asarray(sizes, dtype=np.float64)[pi]) < c_thresh)
+    return pi[keep].astype(np.uint32), pj[keep].astype(np.uint32), tot[keep].astype(np.uint32)
+
+
+def hash_range_pairwise(compute_range: Callable[[], Tuple[np.ndarray, np.ndarray, np.ndarray, Tuple[int, int, int]]],
+                        n_refs: int, sizes: np.ndarray, c_thresh: float, device="cpu", group=None):
+    """All pairs of the database from per-rank HASH RANGES.  `compute_range()` returns this rank's (i, j, partial count)
+    of every pair sharing a hash in its range (RefDB.pairwise(0.0) on the handle over the range slices) and its
+    (distinct, singletons, index) statistics.  Two collectives: the list lengths (+ the statistics), then the lists.
+    Returns (pair_i, pair_j, count, (distinct, singletons, index)) of the WHOLE database, identical on every rank."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    pi, pj, pc, stats = compute_range()
+    if world == 1:
+        gi, gj, gc = merge_partial_pairs(n_refs, [(pi, pj, pc)], sizes, c_thresh)
+        return gi, gj, gc, tuple(int(x) for x in stats)
+    mine = torch.from_numpy(np.stack([np.asarray(x, dtype=np.int64) for x in (pi, pj, pc)], axis=0)).to(device)
+    head = torch.tensor([mine.shape[1], *[int(x) for x in stats]], dtype=torch.int64, device=device)
+    heads = [torch.zeros_like(head) for _ in range(world)]
+    dist.all_gather(heads, head, group=group)
+    lens = [int(h[0].item()) for h in heads]
+    tot_stats = tuple(int(sum(int(h[k].item()) for h in heads)) for k in (1, 2, 3))
+    padded = torch.zeros((3, max(max(lens), 1)), dtype=torch.int64, device=device)
+    padded[:, : mine.shape[1]] = mine
+    out = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(out, padded, group=group)
+    if out[0].is_cuda:  # sum per pair and threshold on the device (a few 10^5 entries: a sort there, not on the host)
+        allp = torch.cat([out[r][:, : lens[r]] for r in range(world)], dim=1)
+        if allp.shape[1] == 0:
+            z = np.zeros(0, dtype=np.uint32)
+            return z, z.copy(), z.copy(), tot_stats
+        uk, inv = torch.unique(allp[0] * n_refs + allp[1], return_inverse=True)
+        tot = torch.zeros(uk.numel(), dtype=torch.int64, device=allp.device).scatter_add_(0, inv, allp[2])
+        pi_t = torch.div(uk, n_refs, rounding_mode="floor")
+        sz = torch.from_numpy(np.asarray(sizes, dtype=np.float64)).to(allp.device)
+        keep = ~((1.0 * tot.to(torch.float64) / sz[pi_t]) < c_thresh)
+        res = torch.stack([pi_t[keep], (uk - pi_t * n_refs)[keep], tot[keep]]).cpu().numpy()
+        return res[0].astype(np.uint32), res[1].astype(np.uint32), res[2].astype(np.uint32), tot_stats
+    parts = [tuple(out[r][k, : lens[r]].cpu().numpy() for k in range(3)) for r in range(world)]
+    gi, gj, gc = merge_partial_pairs(n_refs, parts, sizes, c_thresh)
+    return gi, gj, gc, tot_stats
+
+
 # ======================================================================================================
 # The `yacht run` step over ranks with ONE small exchange: ghosts (include/yacht_hip.h, "references
 # spread over several GPUs, the `yacht run` subset")
