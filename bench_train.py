@@ -248,23 +248,32 @@ def main() -> int:
             bnd = ydist.hash_range_bounds(int(values.max()), G)
             v_r, o_r = ydist.slice_csr_to_hash_range(values, offsets, bnd[0], bnd[1])
             ts = []
-            for _ in range(4):
+            for _ in range(5):
                 t0 = time.perf_counter()
-                with RefDB(v_r, o_r, device=local_rank, flags=YH_DB_PAIRWISE_ONLY) as dbg:
-                    gi_, gj_, gc_ = dbg.pairwise(0.0)
+                dbg = RefDB(v_r, o_r, device=local_rank, flags=YH_DB_PAIRWISE_ONLY)
+                gi_, gj_, gc_ = dbg.pairwise(0.0)
                 ts.append(time.perf_counter() - t0)
-            t0 = time.perf_counter()
-            ydist.merge_partial_pairs(n, [(gi_, gj_, gc_)] * G, sizes, c)
-            t_merge = time.perf_counter() - t0
+                dbg.close()  # (as in the timed passes above: the handle is released behind the results)
+            # the sum per pair of G such lists, on the device as the RCCL path does it (the lists arrive there)
+            import torch
+
+            one = torch.from_numpy(np.stack([x.astype(np.int64) for x in (gi_, gj_, gc_)])).to(f"cuda:{local_rank}")
+            tm_ = []
+            for _ in range(4):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                ydist.merge_partial_pairs_device(n, torch.cat([one] * G, dim=1), sizes, c)
+                tm_.append(time.perf_counter() - t0)
+            t_merge = float(np.median(tm_[1:]))
             per_g[str(G)] = {"rank0_upload_index_pairwise_s": round(float(np.median(ts[1:])), 5), "hashes_in_range": int(v_r.size),
-                             "partial_pairs": int(gi_.size), "host_merge_of_G_lists_s": round(t_merge, 5)}
+                             "partial_pairs": int(gi_.size), "device_merge_of_G_lists_s": round(t_merge, 5)}
         scaling_model = {"per_G": per_g,
-                         "predicted_total_s": {g: round(v["rank0_upload_index_pairwise_s"] + v["host_merge_of_G_lists_s"] + t_sel + 0.0003, 5)
+                         "predicted_total_s": {g: round(v["rank0_upload_index_pairwise_s"] + v["device_merge_of_G_lists_s"] + t_sel + 0.0003, 5)
                                                for g, v in per_g.items()},
-                         "predicted_speedup_vs_1gpu": {g: round(total / (v["rank0_upload_index_pairwise_s"] + v["host_merge_of_G_lists_s"] + t_sel + 0.0003), 2)
+                         "predicted_speedup_vs_1gpu": {g: round(total / (v["rank0_upload_index_pairwise_s"] + v["device_merge_of_G_lists_s"] + t_sel + 0.0003), 2)
                                                        for g, v in per_g.items()},
                          "how": "rank 0's hash range of every sketch: yh_db_create(PAIRWISE_ONLY) + yh_pairwise(c = 0) timed on this GPU; + "
-                                "the sum-per-pair of G such lists on this host (on the device over RCCL) + selection + 0.3 ms assumed for "
+                                "the sum-per-pair of G such lists on the device (torch.unique + scatter_add, as over RCCL) + selection + 0.3 ms assumed for "
                                 "the two small all-gathers"}
 
     # algorithmic bytes: every reference hash once + one (i, j, count) per emitted pair

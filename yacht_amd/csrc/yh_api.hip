@@ -64,7 +64,10 @@ static int timing_every() {
     return every;
 }
 void yh_ring_record_begin(yh_db* db, EventRing& r) {
-    if (!r.created) return;
+    if (!r.created) {
+        if (!r.wanted || timing_every() <= 0) return;
+        ring_create(r);  // lazily: 2 x TIMING_RING hipEventCreate calls were ~1.5 ms of every yh_db_create with three eager rings of 256
+    }
     const int every = timing_every();
     // every n-th launch, and always the first one after the ring was read (a short measurement still gets a sample)
     r.armed = every > 0 && ((r.calls++ % (unsigned)every) == 0 || r.pending == 0);
@@ -243,9 +246,7 @@ static int db_create_common(const u64* values, const u64* offsets, bool on_devic
                 }
             }
         }
-        ring_create(db->ev_overlap);
-        ring_create(db->ev_excl);
-        ring_create(db->ev_pair);
+        db->ev_overlap.wanted = db->ev_excl.wanted = db->ev_pair.wanted = true;
     } while (0);
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);

@@ -52,7 +52,7 @@ constexpr u32 STREAM_NONE = 0xffffffffu;
 #endif
 constexpr int EXCL_QBLOCKS = 4096;  // workgroups (= queue segments) of k_excl_collect / k_excl_apply
 
-constexpr int TIMING_RING = 256;
+constexpr int TIMING_RING = 32;  // (events are created when a ring records for the first time: a handle that is never timed pays nothing)
 
 struct EventRing {
     hipEvent_t beg[TIMING_RING];
@@ -62,6 +62,7 @@ struct EventRing {
     unsigned calls = 0;  // launches seen (the ring samples every n-th, see yh_ring_record_begin)
     bool armed = false;  // the current begin/end pair is being recorded
     bool created = false;
+    bool wanted = false;  // the handle records into this ring (created on first use)
 };
 
 // One in-flight host-buffer run call (yh_run_submit / yh_run_wait): its own sample and count buffers

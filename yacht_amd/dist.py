@@ -158,6 +158,22 @@ def merge_partial_pairs(n_refs: int, parts: Sequence[Tuple[np.ndarray, np.ndarra
     return pi[keep].astype(np.uint32), pj[keep].astype(np.uint32), tot[keep].astype(np.uint32)
 
 
+def merge_partial_pairs_device(n_refs: int, allp, sizes: np.ndarray, c_thresh: float):
+    """merge_partial_pairs on the device: allp = [3, total] int64 tensor (i, j, partial count) of all ranks' lists."""
+    import torch
+
+    if allp.shape[1] == 0:
+        z = np.zeros(0, dtype=np.uint32)
+        return z, z.copy(), z.copy()
+    uk, inv = torch.unique(allp[0] * n_refs + allp[1], return_inverse=True)
+    tot = torch.zeros(uk.numel(), dtype=torch.int64, device=allp.device).scatter_add_(0, inv, allp[2])
+    pi_t = torch.div(uk, n_refs, rounding_mode="floor")
+    sz = torch.from_numpy(np.asarray(sizes, dtype=np.float64)).to(allp.device)
+    keep = ~((1.0 * tot.to(torch.float64) / sz[pi_t]) < c_thresh)
+    res = torch.stack([pi_t[keep], (uk - pi_t * n_refs)[keep], tot[keep]]).cpu().numpy()
+    return res[0].astype(np.uint32), res[1].astype(np.uint32), res[2].astype(np.uint32)
+
+
 def hash_range_pairwise(compute_range: Callable[[], Tuple[np.ndarray, np.ndarray, np.ndarray, Tuple[int, int, int]]],
                         n_refs: int, sizes: np.ndarray, c_thresh: float, device="cpu", group=None):
     """All pairs of the database from per-rank HASH RANGES.  `compute_range()` returns this rank's (i, j, partial count)
@@ -183,17 +199,8 @@ def hash_range_pairwise(compute_range: Callable[[], Tuple[np.ndarray, np.ndarray
     out = [torch.empty_like(padded) for _ in range(world)]
     dist.all_gather(out, padded, group=group)
     if out[0].is_cuda:  # sum per pair and threshold on the device (a few 10^5 entries: a sort there, not on the host)
-        allp = torch.cat([out[r][:, : lens[r]] for r in range(world)], dim=1)
-        if allp.shape[1] == 0:
-            z = np.zeros(0, dtype=np.uint32)
-            return z, z.copy(), z.copy(), tot_stats
-        uk, inv = torch.unique(allp[0] * n_refs + allp[1], return_inverse=True)
-        tot = torch.zeros(uk.numel(), dtype=torch.int64, device=allp.device).scatter_add_(0, inv, allp[2])
-        pi_t = torch.div(uk, n_refs, rounding_mode="floor")
-        sz = torch.from_numpy(np.asarray(sizes, dtype=np.float64)).to(allp.device)
-        keep = ~((1.0 * tot.to(torch.float64) / sz[pi_t]) < c_thresh)
-        res = torch.stack([pi_t[keep], (uk - pi_t * n_refs)[keep], tot[keep]]).cpu().numpy()
-        return res[0].astype(np.uint32), res[1].astype(np.uint32), res[2].astype(np.uint32), tot_stats
+        gi, gj, gc = merge_partial_pairs_device(n_refs, torch.cat([out[r][:, : lens[r]] for r in range(world)], dim=1), sizes, c_thresh)
+        return gi, gj, gc, tot_stats
     parts = [tuple(out[r][k, : lens[r]].cpu().numpy() for k in range(3)) for r in range(world)]
     gi, gj, gc = merge_partial_pairs(n_refs, parts, sizes, c_thresh)
     return gi, gj, gc, tot_stats
