@@ -259,9 +259,6 @@ int yh_q_range_finish(yh_db* db, const u32* d_gathered, u32 n_ranks, u64 stride_
 // One random sector read answers a lookup; overflowing buckets fall back to the two-level
 // directory (dir -> dh -> dref, three dependent reads), which is also the whole path when the
 // table is absent (YH_NO_BUCKETS=1 at creation, for A/B timing).
-#ifndef YH_NT_BUCKETS
-#define YH_NT_BUCKETS 0
-#endif
 #define YH_BKT_OVERFLOW 0xffffffffu
 #define YH_DIR_NONE 0xffffffffu
 #if defined(__HIPCC__)
@@ -319,13 +316,9 @@ struct YhDirView {
     typedef u32 v4u __attribute__((ext_vector_type(4)));
     __device__ __forceinline__ void cbkt_request(u64 h, v4u& a, v4u& b, v4u& c, v4u& d) const {
         const v4u* p = reinterpret_cast<const v4u*>(cbkt) + 4 * yh_bucket_of(h, bkt_lsh, bkt_mul);
-#if YH_NT_BUCKETS
-        // read-once lines: kept out of the Infinity Cache, whose 256 MB then hold the presence filter across samples
-        a = __builtin_nontemporal_load(p); b = __builtin_nontemporal_load(p + 1);
-        c = __builtin_nontemporal_load(p + 2); d = __builtin_nontemporal_load(p + 3);
-#else
+        // (non-temporal loads here -- read-once lines kept out of the Infinity Cache in favour of the presence filter --
+        // measured 3-10 us SLOWER per launch: profiles/r03/filter_sweep.txt)
         a = p[0]; b = p[1]; c = p[2]; d = p[3];
-#endif
     }
     // ... and look at them
     __device__ __forceinline__ u32 cbkt_resolve(u64 h, const v4u a, const v4u b, const v4u c, const v4u d) const {
