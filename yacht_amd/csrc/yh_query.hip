@@ -180,6 +180,82 @@ __global__ void __launch_bounds__(256) k_reduce_replicas(u32* __restrict__ reps,
     reduce_replicas_body(blockIdx.x, lds, reps, R, n, out, mask, maskbits, excl3, fused);
 }
 
+// The reducer of the fused launch: RPT references per thread, all their reads in flight together, ONE scan and ONE
+// atomic per workgroup for the work list -- a workgroup covers RPT x blockDim references in one pass (the launch has
+// only the lookup's spare wave slots for this role: looping over 1024-reference blocks serialized five round trips).
+template <int RPT>
+__device__ __forceinline__ void reduce_replicas_multi(u32 blk, u32* lds, u32* __restrict__ reps, u32 R, u64 n, u32* __restrict__ out,
+                                                      u32* __restrict__ maskbits, const FusedRun& f) {
+    const u32 lane = threadIdx.x & 63u, wv = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    u64 j[RPT];
+    u32 acc[RPT], acc2[RPT], size_j[RPT], nsh[RPT], rpo0[RPT], rpo1[RPT];
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+        j[r] = ((u64)blk * RPT + r) * blockDim.x + threadIdx.x;
+        acc[r] = acc2[r] = size_j[r] = nsh[r] = rpo0[r] = rpo1[r] = 0;
+        if (j[r] < n) {
+            size_j[r] = f.sizes[j[r]];
+            nsh[r] = f.nshared[j[r]];
+            if (f.work) { rpo0[r] = f.rpo[j[r]]; rpo1[r] = f.rpo[j[r] + 1]; }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < RPT; ++r)
+        if (j[r] < n)
+            for (u32 k = 0; k < R; ++k) {
+                acc[r] += reps[(u64)k * n + j[r]];
+                acc2[r] += f.reps2[(u64)k * n + j[r]];
+            }
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+        if (j[r] < n) {
+            for (u32 k = 0; k < R; ++k) { reps[(u64)k * n + j[r]] = 0; f.reps2[(u64)k * n + j[r]] = 0; }
+            out[j[r]] = acc[r];
+            f.n_match[j[r]] = acc[r] - acc2[r];
+            if (f.n_excl) f.n_excl[j[r]] = acc[r] ? size_j[r] - nsh[r] : 0u;
+        }
+        const u64 bal = __ballot(acc[r] != 0);
+        if (lane == 0 && (j[r] >> 5) < ((n + 255) / 256) * 8) {  // (whole 256-reference blocks: what the arrays are sized for)
+            maskbits[(j[r] >> 5)] = (u32)bal;
+            maskbits[(j[r] >> 5) + 1] = (u32)(bal >> 32);
+            if (f.bits_out) { f.bits_out[(j[r] >> 5)] = (u32)bal; f.bits_out[(j[r] >> 5) + 1] = (u32)(bal >> 32); }
+        }
+    }
+    if (!f.work) return;
+    u32 np[RPT], mine = 0;
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+        const bool in = acc[r] != 0 && j[r] < f.work_refs;
+        np[r] = in ? (rpo1[r] - rpo0[r] + (u32)EXCL_PIECE_C - 1u) / (u32)EXCL_PIECE_C : 0u;
+        mine += np[r];
+    }
+    u32 v = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const u32 t = (u32)__shfl_up((int)v, off);
+        if (lane >= (u32)off) v += t;
+    }
+    if (lane == 63) lds[wv] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 total = 0;
+        for (u32 q = 0; q < n_waves; ++q) total += lds[q];
+        lds[n_waves] = total ? atomicAdd(f.work_count, total) : 0u;
+    }
+    __syncthreads();
+    u32 at = lds[n_waves] + v - mine;
+    for (u32 q = 0; q < wv; ++q) at += lds[q];
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+        const u32 last = rpo1[r];
+        for (u32 i = 0; i < np[r]; ++i) {
+            const u32 first = rpo0[r] + i * (u32)EXCL_PIECE_C;
+            f.work[at + i] = make_uint4((u32)j[r], first, min(first + (u32)EXCL_PIECE_C, last), 0u);
+        }
+        at += np[r];
+    }
+}
+
 // the same work list for a subset that arrives as bits (general path); work_count zeroed by the caller
 __global__ void __launch_bounds__(256) k_excl_worklist(u64 n, const u32* __restrict__ maskbits, const u32* __restrict__ nshared,
                                                        const u32* __restrict__ rpo, uint4* __restrict__ work,
@@ -870,10 +946,16 @@ __device__ __forceinline__ void lookup_tile_body(u32 wg, u32* tkey, u32* tcnt, u
         } else {
             const u32 gi = r[u] & 0x7fffffffu;
             if (q.hit) q.hit[gi] = 1;
+#if !(defined(YH_ABLATE_LOOKUP) && (YH_ABLATE_LOOKUP & 1))  // timing-only builds (build.py build_variant): results are wrong
             walk_holders(q.po, q.pr, gi, [&](u32 holder) { add(holder, true); });
+#endif
         }
     }
     __syncthreads();
+#if defined(YH_ABLATE_LOOKUP) && (YH_ABLATE_LOOKUP & 2)
+    if (n == 1) return;  // (never true: keeps the table alive)
+    return;
+#endif
     for (u32 k = threadIdx.x; k < TSLOTS; k += THREADS)
         if (tkey[k]) {
             count_add(&my[tkey[k] - 1], tcnt[k]);
@@ -1030,9 +1112,9 @@ struct ExclPieces {
 };
 // (body: any workgroup size that is a multiple of 64; `wg` of `n_wgs` workgroups walk the work list; lmask: n_mask_words of LDS
 // when LDSMASK)
-template <bool LDSMASK, int U = EXCL_U>
-__device__ __forceinline__ void excl_pieces_body(u32 wg, u32 n_wgs, u32* lmask, const ExclPieces& q) {
-    const u32 WPB = blockDim.x >> 6;
+// one work record (a piece of a reference's records) by one wave
+template <bool LDSMASK, int U>
+__device__ __forceinline__ void excl_one_piece(const uint4 mine, const u32* lmask, const ExclPieces& q) {
     const u32 lane = threadIdx.x & 63u;
     const u32* __restrict__ rg = q.rg;
     const uint4* __restrict__ rrec = q.rrec;
@@ -1041,72 +1123,79 @@ __device__ __forceinline__ void excl_pieces_body(u32 wg, u32 n_wgs, u32* lmask, 
     const u32* __restrict__ pr = q.pr;
     const u8* __restrict__ hit = q.hit;
     const u32 n_post = q.n_post;
+    auto mword = [&](u32 i) -> u32 { return LDSMASK ? lmask[i] : q.maskbits[i]; };
+    const u32 r = mine.x;
+    const u32 end = mine.z;
+    u32 acc_e = 0, acc_m = 0, acc_o = 0;
+    for (u32 k0 = mine.y; k0 < end; k0 += 64u * U) {
+        u32 k[U];
+        bool valid[U], in_s[U];
+        uint4 rec[U], recx[U];
+        u32 gi[U], mu[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            k[u] = k0 + 64u * u + lane;
+            valid[u] = k[u] < end;
+            const u32 kc = min(k[u], n_post - 1);  // (clamped: branch-free reads)
+            gi[u] = (hit || !rrec) ? rg[kc] : 0u;
+            mu[u] = mult ? mult[kc] : 1u;
+            if (rrec) rec[u] = rrec[kc];
+            recx[u] = make_uint4(0u, 0u, 0u, 0u);
+        }
+        if (rrec) {  // holders 3..6: read only by the waves that have a posting with more than three others
+            bool more = YH_EXCL_RECX_ALWAYS != 0;
+#pragma unroll
+            for (int u = 0; u < U; ++u) more |= valid[u] && rec[u].w > 3u && rec[u].w != 0xffffffffu;
+            if (__ballot(more)) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) recx[u] = rrecx[min(k[u], n_post - 1)];
+            }
+        } else {     // handles without the inline holder records: holders through the posting lists
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const u64 q0 = q.po[gi[u]], q1 = q.po[gi[u] + 1];
+                rec[u] = make_uint4((u32)q0, (u32)(q1 - q0), 0u, 0xffffffffu);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) in_s[u] = hit && valid[u] && hit[gi[u]] != 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool e = valid[u] && others_in_subset(rec[u], recx[u], pr, mword) == 0;
+            acc_e += e ? mu[u] : 0u;
+            acc_m += (e && in_s[u]) ? 1u : 0u;
+            acc_o += in_s[u] ? 1u : 0u;
+        }
+    }
+    acc_e = wave_sum(acc_e);
+    if (hit) { acc_m = wave_sum(acc_m); acc_o = wave_sum(acc_o); }
+    if (lane == 0) {
+        if (acc_e) atomicAdd(&q.ex_e[r], acc_e);
+        if (hit && acc_m) atomicAdd(&q.ex_m[r], acc_m);
+        if (hit && acc_o) atomicAdd(&q.ovsh[r], acc_o);
+    }
+}
+__device__ __forceinline__ void stage_subset_bits(u32* lmask, const ExclPieces& q) {  // (16-byte reads; n_mask_words is a multiple of 8)
+    const uint4* src = reinterpret_cast<const uint4*>(q.maskbits);
+    uint4* dst = reinterpret_cast<uint4*>(lmask);
+    for (u32 i = threadIdx.x; i < q.n_mask_words / 4; i += blockDim.x) dst[i] = src[i];
+    __syncthreads();
+}
+
+// (body: any workgroup size that is a multiple of 64; `wg` of `n_wgs` workgroups walk the work list, a fixed share each;
+// lmask: n_mask_words of LDS when LDSMASK)
+template <bool LDSMASK, int U = EXCL_U>
+__device__ __forceinline__ void excl_pieces_body(u32 wg, u32 n_wgs, u32* lmask, const ExclPieces& q) {
+    const u32 WPB = blockDim.x >> 6;
     const u32 n_work = *q.work_count;
     if (wg * WPB >= n_work) return;  // (the grid is sized for every piece of the database)
     // this wave's first record is requested before the subset bits are staged: one round trip for both
     const u32 w0 = wg * WPB + (threadIdx.x >> 6);
     uint4 first_rec = make_uint4(0u, 0u, 0u, 0u);
     if (w0 < n_work) first_rec = q.work[w0];
-    if (LDSMASK) {  // the subset bits into LDS (16-byte reads)
-        const uint4* src = reinterpret_cast<const uint4*>(q.maskbits);
-        uint4* dst = reinterpret_cast<uint4*>(lmask);
-        for (u32 i = threadIdx.x; i < q.n_mask_words / 4; i += blockDim.x) dst[i] = src[i];  // (n_mask_words is a multiple of 8)
-        __syncthreads();
-    }
-    auto mword = [&](u32 i) -> u32 { return LDSMASK ? lmask[i] : q.maskbits[i]; };
-    for (u32 w = w0; w < n_work; w += n_wgs * WPB) {
-        const uint4 mine = (w == w0) ? first_rec : q.work[w];
-        const u32 r = mine.x;
-        const u32 end = mine.z;
-        u32 acc_e = 0, acc_m = 0, acc_o = 0;
-        for (u32 k0 = mine.y; k0 < end; k0 += 64u * U) {
-            u32 k[U];
-            bool valid[U], in_s[U];
-            uint4 rec[U], recx[U];
-            u32 gi[U], mu[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                k[u] = k0 + 64u * u + lane;
-                valid[u] = k[u] < end;
-                const u32 kc = min(k[u], n_post - 1);  // (clamped: branch-free reads)
-                gi[u] = (hit || !rrec) ? rg[kc] : 0u;
-                mu[u] = mult ? mult[kc] : 1u;
-                if (rrec) rec[u] = rrec[kc];
-                recx[u] = make_uint4(0u, 0u, 0u, 0u);
-            }
-            if (rrec) {  // holders 3..6: read only by the waves that have a posting with more than three others
-                bool more = YH_EXCL_RECX_ALWAYS != 0;
-#pragma unroll
-                for (int u = 0; u < U; ++u) more |= valid[u] && rec[u].w > 3u && rec[u].w != 0xffffffffu;
-                if (__ballot(more)) {
-#pragma unroll
-                    for (int u = 0; u < U; ++u) recx[u] = rrecx[min(k[u], n_post - 1)];
-                }
-            } else {     // handles without the inline holder records: holders through the posting lists
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const u64 q0 = q.po[gi[u]], q1 = q.po[gi[u] + 1];
-                    rec[u] = make_uint4((u32)q0, (u32)(q1 - q0), 0u, 0xffffffffu);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) in_s[u] = hit && valid[u] && hit[gi[u]] != 0;
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const bool e = valid[u] && others_in_subset(rec[u], recx[u], pr, mword) == 0;
-                acc_e += e ? mu[u] : 0u;
-                acc_m += (e && in_s[u]) ? 1u : 0u;
-                acc_o += in_s[u] ? 1u : 0u;
-            }
-        }
-        acc_e = wave_sum(acc_e);
-        if (hit) { acc_m = wave_sum(acc_m); acc_o = wave_sum(acc_o); }
-        if (lane == 0) {
-            if (acc_e) atomicAdd(&q.ex_e[r], acc_e);
-            if (hit && acc_m) atomicAdd(&q.ex_m[r], acc_m);
-            if (hit && acc_o) atomicAdd(&q.ovsh[r], acc_o);
-        }
-    }
+    if (LDSMASK) stage_subset_bits(lmask, q);
+    for (u32 w = w0; w < n_work; w += n_wgs * WPB)
+        excl_one_piece<LDSMASK, U>((w == w0) ? first_rec : q.work[w], lmask, q);
 }
 
 template <bool LDSMASK>
@@ -1128,7 +1217,13 @@ struct StepFused {
     u32* r_reps; u32 r_R; u64 r_n; u32* r_out; u32* r_maskbits; FusedRun r_fused; u32 red_wgs;
     ExclPieces excl;   u32 excl_wgs; u32 excl_lds;  // excl_lds: the subset bits fit the launch's LDS
 };
-// (8 waves per SIMD = two workgroups per CU, as the stand-alone lookup has: 64 VGPRs; the exclusive role unrolls by 2)
+// (8 waves per SIMD = two workgroups per CU, as the stand-alone lookup has: 64 VGPRs; the exclusive role unrolls by 2.)
+// Dispatch order = block order: the exclusive role's workgroups come first (most of them find nothing beyond the work
+// list's end and are gone after one read), then the reducer's -- 4 references per thread, 21 workgroups for 85 205
+// references: it fits the wave slots the 488 lookup workgroups of a 10^6-hash sample leave free -- then the lookup's.
+// (Tried and dropped: no dedicated exclusive workgroups, every workgroup walking its share of the work list BEHIND its own
+// job -- the pass then starts when the lookups end instead of beside them: 49.8 us per launch against 33; and claiming
+// records from a shared cursor, which hung the device on a non-uniform early exit before a barrier.)
 template <int U>
 __global__ void __launch_bounds__(1024, 8) k_step_fused(const StepFused s) {
     extern __shared__ u32 smem[];
@@ -1140,7 +1235,11 @@ __global__ void __launch_bounds__(1024, 8) k_step_fused(const StepFused s) {
     }
     b -= s.excl_wgs;
     if (b < s.red_wgs) {
-        reduce_replicas_body(b, smem, s.r_reps, s.r_R, s.r_n, s.r_out, nullptr, s.r_maskbits, nullptr, s.r_fused);
+        const u32 blocks = (u32)((s.r_n + 4095) / 4096);
+        for (u32 blk = b; blk < blocks; blk += s.red_wgs) {
+            reduce_replicas_multi<4>(blk, smem, s.r_reps, s.r_R, s.r_n, s.r_out, s.r_maskbits, s.r_fused);
+            __syncthreads();  // (the scan words in LDS are re-used by the next block)
+        }
         return;
     }
     b -= s.red_wgs;
@@ -1610,7 +1709,7 @@ int yh_q_step_fused(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap
         s.r_maskbits = db->ctx_bits[c];
         s.r_fused = FusedRun{reps1 + db->reps_cap, db->d_sizes, db->d_nshared, db->pend_red_out[1], db->pend_red_out[2], nullptr,
                              db->d_hpo, db->ctx_work[c], db->ctx_count[c], (u32)N};
-        s.red_wgs = (u32)((N + 1023) / 1024);
+        s.red_wgs = (u32)((N + 4095) / 4096);  // (4 references per thread; cut down below to the slots the lookup leaves free)
     }
     int U = 2;
     int c_new = -1;
