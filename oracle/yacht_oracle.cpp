@@ -58,11 +58,20 @@ void oracle_overlap(const u64* values, const u64* offsets, u64 n_refs, const u64
             overlap[j] = intersect_sorted(values + offsets[j], offsets[j + 1] - offsets[j], sample, n_sample);
     };
     if (threads == 1 || n_refs < (u64)threads * 4) { work(0, n_refs); return; }
+    // contiguous reference ranges cut by HASH count (the cost of a reference is its size, not 1): thread t ends at
+    // the first reference boundary at or past t + 1 shares of the hashes
     std::vector<std::thread> pool;
-    const u64 per = (n_refs + threads - 1) / threads;
-    for (int t = 0; t < threads; ++t) {
-        const u64 a = std::min<u64>(n_refs, (u64)t * per), b = std::min<u64>(n_refs, a + per);
-        if (a < b) pool.emplace_back(work, a, b);
+    const u64 total = offsets[n_refs];
+    u64 a = 0;
+    for (int t = 0; t < threads && a < n_refs; ++t) {
+        u64 b = n_refs;
+        if (t + 1 < threads) {
+            const u64 target = total / (u64)threads * (u64)(t + 1);
+            b = (u64)(std::lower_bound(offsets + a, offsets + n_refs + 1, target) - offsets);
+            b = std::min<u64>(std::max<u64>(b, a + 1), n_refs);
+        }
+        pool.emplace_back(work, a, b);
+        a = b;
     }
     for (auto& th : pool) th.join();
 }

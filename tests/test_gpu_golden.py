@@ -173,7 +173,7 @@ def test_reference_workflow_known_answer(hip_lib, trained_fixture, tmp_path):
 
 
 def test_full_scale_properties(hip_lib):
-    """BASELINE.json configs[2] scale (85 205 references, ~3.3e8 hashes), no oracle needed:
+    """BASELINE.json configs[2] scale (85 205 references, ~3.3e8 hashes).  Properties that need no oracle:
     two independent kernels agree bit for bit; a reference queried as the sample overlaps itself
     completely; overlap counts are bounded by sketch sizes; the sum of overlaps equals the number
     of (sample hash, reference) incidences counted through the inverted index."""
@@ -215,6 +215,29 @@ def test_full_scale_properties(hip_lib):
         assert np.array_equal(ov2, ov)
         assert (e <= sizes).all() and (m <= e).all() and (m <= ov).all()
         assert not e[ov == 0].any() and not m[ov == 0].any()
+        # ... and the same sample against the CPU oracle on the WHOLE database (all host threads: ~2 s on the GPU box),
+        # through the plain step, the one-launch pipelined step and the packed upload + compact rows
+        from oracle import oracle
+
+        h_values = values.cpu().numpy().view(np.uint64)
+        h_offsets = offsets.cpu().numpy().view(np.uint64)
+        h_sample = sample.cpu().numpy().view(np.uint64)
+        want_ov = oracle.overlap(h_values, h_offsets, h_sample, threads=oracle.hardware_threads())
+        want_e, want_m = oracle.exclusive(h_values, h_offsets, want_ov > 0, h_sample)
+        assert np.array_equal(ov, want_ov) and np.array_equal(e, want_e) and np.array_equal(m, want_m)
+        bufs = [torch.zeros(3, n, dtype=torch.int32, device="cuda:0") for _ in range(3)]
+        for k in range(5):
+            c = bufs[k % 3]
+            db.run_device_pipelined(sample.data_ptr(), sample.numel(), c[0].data_ptr(), c[1].data_ptr(), c[2].data_ptr())
+        db.run_device_join()
+        db.synchronize()
+        for c in bufs:
+            got = c.cpu().numpy().view(np.uint32)
+            assert np.array_equal(got[0], want_ov) and np.array_equal(got[1], want_e) and np.array_equal(got[2], want_m)
+        rows = db.run_rows(h_sample)  # (packs the sample itself)
+        keep = np.flatnonzero(want_ov)
+        assert np.array_equal(rows["ref"], keep) and np.array_equal(rows["overlap"], want_ov[keep])
+        assert np.array_equal(rows["n_excl"], want_e[keep]) and np.array_equal(rows["n_match"], want_m[keep])
     finally:
         db.close()
 

@@ -147,10 +147,10 @@ def test_packed_upload_and_compact_rows(hip_lib, pinned):
     from yacht_amd.engine import ROW_DTYPE, pack_sample
 
     rng = np.random.default_rng(21)
-    values, offsets = _db(seed=6, n_refs=5000)
+    values, offsets = _db(seed=6, n_refs=2500)
     n = offsets.size - 1
     samples = _samples(values, offsets, 5, rng) + [np.zeros(0, np.uint64), np.array([5], np.uint64),
-                                                   np.unique(np.concatenate([values[::3], np.array([0, 2**64 - 1], np.uint64)]))]
+                                                   np.unique(np.concatenate([values[::5], np.array([0, 2**64 - 1], np.uint64)]))]
     want = []
     for s in samples:
         ov = oracle.overlap(values, offsets, s)
