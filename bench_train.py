@@ -73,6 +73,8 @@ def main() -> int:
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
+            if args.backend == "gloo":
+                os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # (no host-name look-ups: they stall on some boxes)
             dist.init_process_group(args.backend)
 
     from yacht_amd import _lib, synth

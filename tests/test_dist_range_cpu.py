@@ -104,6 +104,7 @@ def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # (no host-name look-ups: they stall on some boxes)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         rng = np.random.default_rng(7)

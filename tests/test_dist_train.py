@@ -29,6 +29,7 @@ def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # (no host-name look-ups: they stall on some boxes)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         values, offsets, c = _case()
@@ -58,6 +59,7 @@ def _range_worker(rank: int, world: int, port: int, out_dir: str) -> None:
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # (no host-name look-ups: they stall on some boxes)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         values, offsets, c = _case()
@@ -132,10 +134,12 @@ def test_row_blocks_on_the_hip_engine(hip_lib):
             parts = [db.pairwise(c, b, e) for b, e in plan]
             gi, gj, gc = (np.concatenate([p[k] for p in parts]) for k in range(3))
             assert np.array_equal(gi, wi) and np.array_equal(gj, wj) and np.array_equal(gc, wc)
-        # and through the collective with one rank
-        os.environ["MASTER_ADDR"] = "127.0.0.1"
-        os.environ["MASTER_PORT"] = str(_free_port())
-        dist.init_process_group("gloo", rank=0, world_size=1)
+        # and through the collective with one rank (a file store and the loopback interface: no TCP store, no host-name
+        # look-ups -- on one GPU box the env:// rendezvous of this single rank took 14 minutes)
+        import tempfile
+
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+        dist.init_process_group("gloo", init_method="file://" + tempfile.mktemp(prefix="yh_gloo_"), rank=0, world_size=1)
         try:
             gi, gj, gc = ydist.sharded_pairwise(lambda b, e: db.pairwise(c, b, e), ydist.pair_row_plan(nshared, 1))
         finally:

@@ -34,6 +34,7 @@ from yacht_amd import dist as ydist, synth
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 torch.cuda.set_device(0)
 dev = torch.device("cuda", 0)
+os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
 dist.init_process_group("gloo")
 n_total = int(os.environ["YH_NREFS"])
 plan = synth.global_db_plan(31, n_total, cluster_frac=0.6)   # many clusters: the cuts go through some
@@ -195,6 +196,7 @@ from yacht_amd import dist as ydist, synth
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 torch.cuda.set_device(0)
 dev = torch.device("cuda", 0)
+os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
 dist.init_process_group("gloo")
 n_total = int(os.environ["YH_NREFS"])
 plan = synth.global_db_plan(31, n_total, cluster_frac=0.6)
