@@ -1224,9 +1224,10 @@ struct StepFused {
 // (Tried and dropped: no dedicated exclusive workgroups, every workgroup walking its share of the work list BEHIND its own
 // job -- the pass then starts when the lookups end instead of beside them: 49.8 us per launch against 33; and claiming
 // records from a shared cursor, which hung the device on a non-uniform early exit before a barrier.)
-template <int U>
-__global__ void __launch_bounds__(1024, 8) k_step_fused(const StepFused s) {
+template <int U, int THREADS, int TBITS>
+__global__ void __launch_bounds__(THREADS, THREADS == 1024 ? 8 : 4) k_step_fused(const StepFused s) {
     extern __shared__ u32 smem[];
+    constexpr u32 TSLOTS = 1u << TBITS;
     u32 b = blockIdx.x;
     if (b < s.excl_wgs) {
         if (s.excl_lds) excl_pieces_body<true, 2>(b, s.excl_wgs, smem, s.excl);
@@ -1235,7 +1236,7 @@ __global__ void __launch_bounds__(1024, 8) k_step_fused(const StepFused s) {
     }
     b -= s.excl_wgs;
     if (b < s.red_wgs) {
-        const u32 blocks = (u32)((s.r_n + 4095) / 4096);
+        const u32 blocks = (u32)((s.r_n + 4ull * THREADS - 1) / (4ull * THREADS));
         for (u32 blk = b; blk < blocks; blk += s.red_wgs) {
             reduce_replicas_multi<4>(blk, smem, s.r_reps, s.r_R, s.r_n, s.r_out, s.r_maskbits, s.r_fused);
             __syncthreads();  // (the scan words in LDS are re-used by the next block)
@@ -1243,7 +1244,7 @@ __global__ void __launch_bounds__(1024, 8) k_step_fused(const StepFused s) {
         return;
     }
     b -= s.red_wgs;
-    lookup_tile_body<U, 1024, 10>(b, smem, smem + 1024, smem + 2048, s.look);
+    lookup_tile_body<U, THREADS, TBITS>(b, smem, smem + TSLOTS, smem + 2 * TSLOTS, s.look);
 }
 
 // e_j = (hashes of j that no other reference of the whole database has) + ex_e[j]
@@ -1682,7 +1683,7 @@ int yh_q_overlap_indexed(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_ov
 // The caller has checked yh_q_step_fused_ok and allocated the step contexts 0..2.
 bool yh_q_step_fused_ok(const yh_db* db, u64 n_sample) {
     return db->has_dir && db->has_index && db->d_cbkt && fused_possible(db, reinterpret_cast<const u32*>(db), true) &&
-           db->n_chunks && !db->n_ghost && n_sample >= 256ull * 1024 && n_sample <= 0xfffffff0ull;
+           db->n_chunks && !db->n_ghost && n_sample >= 1 && n_sample <= 0xfffffff0ull;
 }
 int yh_q_step_fused(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap, u32* d_excl, u32* d_match) {
     hipStream_t st = db->stream;
@@ -1690,12 +1691,16 @@ int yh_q_step_fused(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap
     u32 R;
     YH_TRY(ensure_reps(db, R));
     while (R > 1 && R > 4u) R >>= 1;
+    // One geometry per launch: the sample's size picks it (as for the stand-alone lookup: 256-lane workgroups below 262 144
+    // hashes, 1024-lane tiles of one or two hashes per lane above); a draining launch takes the small one.
+    const int form = !d_sample ? 0 : n_sample >= 512ull * 1024 ? 2 : n_sample >= 256ull * 1024 ? 1 : 0;
+    const u32 threads = form ? 1024u : 256u, waves = threads / 64, tslots = form ? 1024u : 256u;
     StepFused s{};
-    u32 lds_words = 3 * 1024;  // the lookup role's hit table
+    u32 lds_words = 3 * tslots;  // the lookup role's hit table
     if (db->pend_excl >= 0) {   // exclusive pass of the step reduced by the previous launch
         const int c = db->pend_excl;
         s.excl = excl_args(db, db->ctx_count[c], db->ctx_work[c], db->ctx_bits[c], nullptr, db->pend_excl_out, nullptr, nullptr, true);
-        s.excl_wgs = std::min<u32>((db->n_chunks + 15) / 16, 256u);
+        s.excl_wgs = std::min<u32>((db->n_chunks + waves - 1) / waves, 4096u / waves);  // (most find nothing and leave after one read)
         s.excl_lds = s.excl.n_mask_words <= EXCL_LDS_WORDS ? 1u : 0u;
         if (s.excl_lds) lds_words = std::max(lds_words, s.excl.n_mask_words);
     }
@@ -1709,24 +1714,25 @@ int yh_q_step_fused(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap
         s.r_maskbits = db->ctx_bits[c];
         s.r_fused = FusedRun{reps1 + db->reps_cap, db->d_sizes, db->d_nshared, db->pend_red_out[1], db->pend_red_out[2], nullptr,
                              db->d_hpo, db->ctx_work[c], db->ctx_count[c], (u32)N};
-        s.red_wgs = (u32)((N + 4095) / 4096);  // (4 references per thread; cut down below to the slots the lookup leaves free)
+        s.red_wgs = (u32)((N + 4ull * threads - 1) / (4ull * threads));  // (4 references per thread)
     }
-    int U = 2;
     int c_new = -1;
     if (d_sample) {
         c_new = (int)(db->pipe_k % 3);
         const int parity = (int)(db->pipe_k & 1);
         u32* const reps1 = db->d_reps + (u64)parity * 2 * db->reps_cap;
-        U = n_sample >= 512ull * 1024 ? 2 : 1;
-        s.look = TileLookup{d_sample, n_sample, yh_dir_view(db), yh_filter_of(db), db->filter_mul, db->d_po, db->d_pr, reps1, R - 1, N,
-                            nullptr, reps1 + db->reps_cap, db->ctx_count[c_new], nullptr, 0u};
-        s.look_wgs = (u32)((n_sample + 1024ull * U - 1) / (1024ull * U));
+        const u32 per_wg = threads * (form == 2 ? 2u : 1u);
+        // (the small form reads no presence filter: such a launch is latency-bound)
+        s.look = TileLookup{d_sample, n_sample, yh_dir_view(db), form ? yh_filter_of(db) : nullptr, db->filter_mul, db->d_po, db->d_pr,
+                            reps1, R - 1, N, nullptr, reps1 + db->reps_cap, db->ctx_count[c_new], nullptr, 0u};
+        s.look_wgs = (u32)((n_sample + per_wg - 1) / per_wg);
     }
     const u32 total = s.excl_wgs + s.red_wgs + s.look_wgs;
     if (total) {
         if (d_sample) yh_ring_record_begin(db, db->ev_overlap);
-        if (U == 2) k_step_fused<2><<<total, 1024, lds_words * sizeof(u32), st>>>(s);
-        else k_step_fused<1><<<total, 1024, lds_words * sizeof(u32), st>>>(s);
+        if (form == 2) k_step_fused<2, 1024, 10><<<total, 1024, lds_words * sizeof(u32), st>>>(s);
+        else if (form == 1) k_step_fused<1, 1024, 10><<<total, 1024, lds_words * sizeof(u32), st>>>(s);
+        else k_step_fused<1, 256, 8><<<total, 256, lds_words * sizeof(u32), st>>>(s);
         if (d_sample) yh_ring_record_end(db, db->ev_overlap);
         YH_HIP(hipGetLastError());
     }
