@@ -193,14 +193,15 @@ int yh_run(yh_db* db, const uint64_t* sample, uint64_t n_sample,
 int yh_run_device(yh_db* db, const uint64_t* d_sample, uint64_t n_sample,
                   uint32_t* d_overlap, uint32_t* d_n_excl, uint32_t* d_n_match);
 
-/* Throughput form for a caller with many samples already in HBM: the same step, but its tail (reduce + exclusive
- * pass: ~11 us of launch and round-trip latency for almost no work) is queued on a second stream of the handle, so
- * that the NEXT call's lookup runs beside it; consecutive calls alternate between two sets of counters and the step
- * contexts 0 and 1.  The three output rows of a pipelined call are complete -- in the order of the handle's stream --
- * only after yh_run_device_join (a stream-level wait; the host does not block), which every other query entry point,
- * yh_db_synchronize and yh_db_set_stream perform first by themselves.  Consecutive calls must write different output
- * buffers (two that alternate are enough).  Handles the split does not apply to (streaming lookup chosen, ghosts)
- * run the call as yh_run_device does.                                                                          */
+/* Throughput form for a caller with many samples already in HBM: every call is ONE kernel launch that looks up this
+ * sample, reduces the previous call's sample and runs the exclusive pass of the one before (three independent roles of
+ * one grid: consecutive calls alternate between two sets of counters and rotate through the step contexts 0..2), so the
+ * step's tail -- ~11 us of launch and round-trip latency for almost no work when queued behind the lookup -- costs
+ * nothing.  The three output rows of a call are complete, in the order of the handle's stream, after TWO further
+ * pipelined calls or after yh_run_device_join (one or two draining launches; the host does not block), which every
+ * other query entry point, yh_db_synchronize and yh_db_set_stream perform first by themselves.  A call's output buffers
+ * must stay untouched until then (three buffers that rotate are enough).  Where the split does not apply (streaming
+ * lookup chosen, ghosts, a handle without holder sets) the call runs as yh_run_device does.                     */
 int yh_run_device_pipelined(yh_db* db, const uint64_t* d_sample, uint64_t n_sample,
                             uint32_t* d_overlap, uint32_t* d_n_excl, uint32_t* d_n_match);
 int yh_run_device_join(yh_db* db);
