@@ -371,3 +371,23 @@ def test_pipelined_device_steps_fused_launches(hip_lib):
             assert np.array_equal(bufs[j % nbuf].cpu().numpy().view(np.uint32), want[order[j]]), ("after join", j)
         ov, e, m = db.run_counts(hs[1])
         assert np.array_equal(np.stack([ov, e, m]), want[1])
+
+
+def test_submit_forms_on_a_database_without_hashes(hip_lib):
+    """Three empty sketches: every count is zero through every submit form, as through yh_run (found by the fuzzer)."""
+    from yacht_amd.engine import ROW_DTYPE, pack_sample
+
+    offsets = np.zeros(4, dtype=np.uint64)
+    values = np.zeros(0, dtype=np.uint64)
+    sample = np.array([3, 9, 27], dtype=np.uint64)
+    with RefDB(values, offsets) as db:
+        ov, e, m = db.run_counts(sample)
+        assert not ov.any() and not e.any() and not m.any()
+        assert db.run_rows(sample).size == 0 and db.run_rows(sample, packed=False).size == 0
+        outs = [np.full(3, 7, np.uint32) for _ in range(3)]
+        db.run_submit(1, sample, *outs)
+        db.run_wait(1)
+        assert not any(o.any() for o in outs)
+        rows = np.zeros(3, dtype=ROW_DTYPE)
+        db.run_submit_packed(2, pack_sample(np.array([5, 4], dtype=np.uint64)[::-1].copy()), rows)
+        assert db.run_wait_rows(2) == 0

@@ -24,6 +24,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 
 from oracle import oracle  # noqa: E402  (the checker)
 from yacht_amd import _lib, synth  # noqa: E402
+import torch  # noqa: E402
+
 from yacht_amd.engine import RefDB, YH_DB_KEEP_CSR  # noqa: E402
 
 
@@ -93,6 +95,26 @@ def main() -> int:
                     assert np.array_equal(ov, want) and np.array_equal(e, we) and np.array_equal(m, wm), "run counts " + name
                     ge, gm = db.exclusive(mask, sample)
                     assert np.array_equal(ge, xe) and np.array_equal(gm, xm), "exclusive for a subset " + name
+                    # the same step through the packed upload + compact rows, and as one-launch pipelined device steps
+                    # (three of them: the sample's own three stages ride in three consecutive launches)
+                    keep = np.flatnonzero(want)
+                    for packed in (True, False):
+                        rows = db.run_rows(sample, packed=packed)
+                        assert np.array_equal(rows["ref"], keep) and np.array_equal(rows["overlap"], want[keep]) and \
+                            np.array_equal(rows["n_excl"], we[keep]) and np.array_equal(rows["n_match"], wm[keep]), \
+                            f"rows (packed={packed}) " + name
+                    if n:
+                        d_s = torch.from_numpy(np.ascontiguousarray(sample).view(np.int64).copy()).cuda() if sample.size else \
+                            torch.zeros(1, dtype=torch.int64, device="cuda")
+                        bufs = [torch.zeros(3, n, dtype=torch.int32, device="cuda") for _ in range(3)]
+                        for b in bufs:
+                            db.run_device_pipelined(d_s.data_ptr(), int(sample.size), b[0].data_ptr(), b[1].data_ptr(), b[2].data_ptr())
+                        db.run_device_join()
+                        db.synchronize()
+                        for b in bufs:
+                            g = b.cpu().numpy().view(np.uint32)
+                            assert np.array_equal(g[0], want) and np.array_equal(g[1], we) and np.array_equal(g[2], wm), \
+                                "pipelined steps " + name
                 if values.size < 400_000:
                     wi, wj, wc, wstats = oracle.train_pairs(values, offsets, c, threads=4)
                     gi, gj, gc = db.pairwise(c)

@@ -899,7 +899,8 @@ static int submit_common(yh_db* db, int slot, const void* sample, u64 n_or_bytes
     if (!want_rows && N && (!overlap || !n_excl || !n_match)) { yh_set_error("null argument"); return YH_ERR_INVALID_ARG; }
     if (want_rows && cap_rows && !rows) { yh_set_error("null row buffer"); return YH_ERR_INVALID_ARG; }
     if (n_or_bytes && !sample) { yh_set_error("null argument"); return YH_ERR_INVALID_ARG; }
-    if (!db->has_index || !db->d_sdelta) { yh_set_error("the pipelined run calls need a non-empty handle in the default layout with its index"); return YH_ERR_UNSUPPORTED; }
+    // (a database without a single hash has no stream either: every count is zero, as yh_run gives it)
+    if (!db->has_index || (!db->d_sdelta && db->n_hashes)) { yh_set_error("the pipelined run calls need a handle in the default layout with its index"); return YH_ERR_UNSUPPORTED; }
     u64 n_sample = n_or_bytes, packed_bytes = 0;
     if (packed) {
         packed_bytes = n_or_bytes;
