@@ -378,6 +378,11 @@ int yh_q_run_batch(yh_db* db, const u64* d_samples, const u64* d_soff, u32 n_sam
 int yh_q_exclusive(yh_db* db, const u8* d_mask, const u64* d_sample, u64 n_sample,
                    const u32* d_overlap, u32* d_excl, u32* d_match, const u32* d_maskbits);
 int yh_q_pairwise(yh_db* db, double c_thresh, u64 r0, u64 r1);
+// the presence filter a lookup may read in front of the compact buckets (null: none, or YH_NO_FILTER=1)
+inline const u32* yh_filter_of(const yh_db* db) {
+    static const bool filter_off = [] { const char* e = yh_tune_env("YH_NO_FILTER"); return e && e[0] == '1'; }();
+    return (db->d_cbkt && db->d_filter && db->filter_mul && !filter_off) ? db->d_filter : nullptr;
+}
 int yh_q_check_sorted_host(const u64* v, u64 n);
 
 // helpers (yh_api.hip)

@@ -13,11 +13,8 @@
 //   k_excl_pieces        subset-exclusive hash counts, one wave per work record: over a reference's DISTINCT holder
 //                        sets (run step) or its postings with hit flags (arbitrary subsets); k_excl_worklist,
 //                        k_excl_final (the arithmetic of hypothesis_recovery_src.py:165-204)
-//   k_batch_*            up to 64 samples per pass through the same bucket table; exclusivity for all samples at
-//                        once by bit-sliced counting over 64-bit sample masks (k_excl_collect gathers the postings)
 //   k_overlap_bsearch    one wave per reference, lanes binary-search the sample: the independent cross-check
-//   k_pair_*             pairwise intersection counts from the posting lists into a dense row block, threshold
-//                        filter and ordered compaction (src/cpp/main.cpp:249-308)
+// (the batched run is yh_batch.hip, `yacht train`'s pairwise counts yh_pairwise.hip)
 #include "yh_common.h"
 
 #include <stdlib.h>
@@ -57,11 +54,6 @@ __device__ __forceinline__ void count_add(u32* p, u32 v) {
 #else
     atomicAdd(p, v);
 #endif
-}
-// the presence filter a lookup may read in front of the compact buckets (null: none, or YH_NO_FILTER=1)
-static const u32* yh_filter_of(const yh_db* db) {
-    static const bool filter_off = [] { const char* e = yh_tune_env("YH_NO_FILTER"); return e && e[0] == '1'; }();
-    return (db->d_cbkt && db->d_filter && db->filter_mul && !filter_off) ? db->d_filter : nullptr;
 }
 __device__ __forceinline__ u32 replica_of(u32 wg, u32 rep_mask) {
 #if YH_XCD_ATOMICS
@@ -973,66 +965,6 @@ __global__ void __launch_bounds__(THREADS) k_index_lookup_tile(const TileLookup 
 }
 
 // ---- exclusive counts -----------------------------------------------------------------------------
-// Exclusive sums from the posting lists, in two launches.
-//
-// k_excl_collect: one coalesced pass over pr[] (four postings per lane per step, mask probes as
-// BITS: N/8 bytes stay resident in every CU's L1, while random byte reads of an N-byte mask pulled
-// one cache line per posting through L2).  Postings of masked references are only COLLECTED:
-// appended to a per-workgroup LDS list and flushed to a queue in HBM with one atomic per workgroup.
-// (~1 % of the postings belong to masked references, which is about every second wave; walking the
-// dependent chain below right there left 1-2 lanes per wave busy for several microseconds.)
-//
-// k_excl_apply: one lane per collected posting (r holds shared hash g), all lanes busy:
-//   c = masked holders of g;  c == 1 -> g is exclusive to r inside the subset (ex_e, and ex_m
-//   when g is in the sample);  g in the sample -> r's "shared overlap" grows by one (ovsh).
-constexpr int EXCL_BLOCK = 256;
-// Workgroup b owns the contiguous vectors [b*chunk, (b+1)*chunk) of pr[] (a vector = 4 postings)
-// and the queue segment that starts at posting index 4*b*chunk: even if every posting of its range
-// is collected the segment cannot overflow, so there is no global counter (10^4 atomics on one word
-// cost ~120 us) and no zeroing; qcount[b] is written by every workgroup.
-__global__ void __launch_bounds__(EXCL_BLOCK) k_excl_collect(u64 n_post, u64 chunk, const u32* __restrict__ pr,
-                                                             const u32* __restrict__ maskbits,
-                                                             u32* __restrict__ queue, u32* __restrict__ qcount) {
-    __shared__ u32 lq[EXCL_BLOCK * 4];
-    __shared__ u32 lfill;
-    if (threadIdx.x == 0) lfill = 0;
-    __syncthreads();
-    auto masked = [&](u32 r) -> bool { return (maskbits[r >> 5] >> (r & 31u)) & 1u; };
-    const u64 n4 = n_post >> 2;
-    const uint4* __restrict__ pr4 = reinterpret_cast<const uint4*>(pr);
-    const u64 v_begin = (u64)blockIdx.x * chunk;
-    const u64 v_end = min(n4 + 1, v_begin + chunk);  // vector n4 stands for the 0-3 trailing postings
-    u32* seg = queue + 4 * v_begin;
-    u32 done = 0;  // entries already flushed to seg (same value in every thread)
-    for (u64 v0 = v_begin; v0 < v_end; v0 += EXCL_BLOCK) {
-        const u64 v = v0 + threadIdx.x;
-        if (v < v_end && v < n4) {
-            const uint4 r = pr4[v];
-            const bool m0 = masked(r.x), m1 = masked(r.y), m2 = masked(r.z), m3 = masked(r.w);
-            const u32 cnt = (u32)m0 + (u32)m1 + (u32)m2 + (u32)m3;
-            if (cnt) {
-                u32 slot = atomicAdd(&lfill, cnt);
-                const u32 k = (u32)(4 * v);
-                if (m0) lq[slot++] = k;
-                if (m1) lq[slot++] = k + 1;
-                if (m2) lq[slot++] = k + 2;
-                if (m3) lq[slot++] = k + 3;
-            }
-        } else if (v < v_end && v == n4) {
-            for (u64 k = n4 << 2; k < n_post; ++k)
-                if (masked(pr[k])) lq[atomicAdd(&lfill, 1u)] = (u32)k;
-        }
-        __syncthreads();
-        const u32 f = lfill;
-        for (u32 e = threadIdx.x; e < f; e += EXCL_BLOCK) seg[done + e] = lq[e];
-        done += f;
-        __syncthreads();
-        if (threadIdx.x == 0) lfill = 0;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) qcount[blockIdx.x] = done;
-}
-
 // The same sums without the pass over pr[]: the reference-major view of the postings is cut into
 // PIECES of <= EXCL_PIECE postings (d_chunks: (reference, first posting); most references are one
 // piece), stored so that neighbouring records belong to unrelated references.  ONE WAVE PER PIECE: the
@@ -1265,152 +1197,6 @@ __global__ void k_excl_final(u64 n, const u8* __restrict__ mask, const u32* __re
     }
     out_e[j] = e;
     out_m[j] = m;
-}
-
-// ---- pairwise -------------------------------------------------------------------------------------
-// Only references that hold at least one shared hash can be in a pair, so the dense count block is
-// indexed by COMPACT ids (cid[ref], ascending with the reference id; rid[] maps back): a
-// dereplicated database of 85 205 genomes has ~8 000 such references (0.3 GB instead of 29 GB).
-//
-// One thread per posting (a = its reference): for every other reference b of the same hash,
-// M[cid[a] - c0][cid[b]] += 1.  Integer atomics: the result does not depend on arrival order.
-// A posting whose hash has few holders walks the list itself; a list of more than PAIR_LONG holders is
-// walked by the whole wave, one holder per lane (a k-mer shared by M references is M^2 increments either
-// way, but M serial steps per posting instead of M / 64 made one conserved k-mer the tail of the launch).
-constexpr u32 PAIR_LONG = 32;
-__global__ void __launch_bounds__(256) k_pair_accum(u64 n_post, const u32* __restrict__ pr, const u32* __restrict__ pg,
-                                                    const u64* __restrict__ po, const u32* __restrict__ cid, u64 c0, u64 c1,
-                                                    u64 n_c, u32* __restrict__ M) {
-    const u32 lane = threadIdx.x & 63u;
-    const u64 wave = (blockIdx.x * (u64)blockDim.x + threadIdx.x) >> 6;
-    const u64 n_waves = ((u64)gridDim.x * blockDim.x) >> 6;
-    for (u64 k0 = wave * 64; k0 < n_post; k0 += n_waves * 64) {
-        const u64 k = k0 + lane;
-        u32 a = 0, ca = 0xffffffffu;
-        u64 b = 0, e = 0;
-        if (k < n_post) {
-            a = pr[k];
-            ca = cid[a];
-            if (ca >= c0 && ca < c1) {
-                const u32 gi = pg[k];
-                b = po[gi];
-                e = po[gi + 1];
-            }
-        }
-        const bool mine = e > b;
-        const bool is_long = mine && (e - b) > PAIR_LONG;
-        if (mine && !is_long) {
-            u32* row = M + (u64)(ca - c0) * n_c;
-            for (u64 q = b; q < e; ++q) {
-                const u32 o = pr[q];
-                if (o != a) atomicAdd(&row[cid[o]], 1u);
-            }
-        }
-        u64 todo = __ballot(is_long);
-        while (todo) {
-            const int src = __ffsll((long long)todo) - 1;
-            todo &= todo - 1;
-            const u32 a_s = (u32)__shfl((int)a, src), ca_s = (u32)__shfl((int)ca, src);
-            const u64 b_s = ((u64)(u32)__shfl((int)(u32)(b >> 32), src) << 32) | (u32)__shfl((int)(u32)b, src);
-            const u64 e_s = ((u64)(u32)__shfl((int)(u32)(e >> 32), src) << 32) | (u32)__shfl((int)(u32)e, src);
-            u32* row = M + (u64)(ca_s - c0) * n_c;
-            for (u64 q = b_s + lane; q < e_s; q += 64) {
-                const u32 o = pr[q];
-                if (o != a_s) atomicAdd(&row[cid[o]], 1u);
-            }
-        }
-    }
-}
-
-__device__ __forceinline__ bool pair_keep(u32 cnt, u32 i, u32 j, const u32* __restrict__ sizes, double c_relaxed) {
-    if (cnt == 0 || i == j) return false;
-    const u32 si = sizes[i], sj = sizes[j];
-    if (si == 0 || sj == 0) return false;
-    // relaxed device-side filter; the exact `!(1.0*cnt/|R_i| < C)` of main.cpp:297-303 is applied
-    // on the host to the survivors, so no decision depends on device floating point
-    return !((double)cnt / (double)si < c_relaxed);
-}
-
-// one wave per row: count survivors
-__global__ void __launch_bounds__(256) k_pair_count(const u32* __restrict__ M, u64 r0, u64 r1, u64 n_refs,
-                                                    const u32* __restrict__ rid, const u32* __restrict__ sizes,
-                                                    double c_relaxed, u32* __restrict__ rowcnt) {
-    const u64 wave = (blockIdx.x * (u64)blockDim.x + threadIdx.x) / WAVE;
-    const u64 n_waves = ((u64)gridDim.x * blockDim.x) / WAVE;
-    const int lane = threadIdx.x & (WAVE - 1);
-    for (u64 i = r0 + wave; i < r1; i += n_waves) {
-        const u32* row = M + (i - r0) * n_refs;
-        u32 c = 0;
-        for (u64 j0 = 0; j0 < n_refs; j0 += WAVE) {
-            const u64 j = j0 + lane;
-            const bool keep = (j < n_refs) && pair_keep(row[j], rid[i], rid[j], sizes, c_relaxed);
-            c += (u32)__popcll(__ballot(keep));
-        }
-        if (lane == 0) rowcnt[i - r0] = c;
-    }
-}
-
-__global__ void __launch_bounds__(1024) k_scan_u32_to_u64(const u32* __restrict__ in, u64 n, u64* __restrict__ out) {
-    // single workgroup; out[n] = total
-    __shared__ u64 wsum[17];
-    const int lane = threadIdx.x & (WAVE - 1);
-    const int wid = threadIdx.x / WAVE;
-    const int nw = blockDim.x / WAVE;
-    u64 carry = 0;
-    for (u64 base = 0; base < n; base += blockDim.x) {
-        const u64 i = base + threadIdx.x;
-        const u64 v = (i < n) ? in[i] : 0;
-        u64 inc = v;
-#pragma unroll
-        for (int d = 1; d < WAVE; d <<= 1) {
-            const u64 t = __shfl_up(inc, d, WAVE);
-            if (lane >= d) inc += t;
-        }
-        if (lane == WAVE - 1) wsum[wid] = inc;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            u64 acc = 0;
-            for (int w = 0; w < nw; ++w) { const u64 t = wsum[w]; wsum[w] = acc; acc += t; }
-            wsum[16] = acc;
-        }
-        __syncthreads();
-        if (i < n) out[i] = carry + wsum[wid] + inc - v;
-        carry += wsum[16];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) out[n] = carry;
-}
-
-// one wave per row: ordered compaction (j ascending inside a row, rows ascending)
-__global__ void __launch_bounds__(256) k_pair_emit(const u32* __restrict__ M, u64 r0, u64 r1, u64 n_refs,
-                                                   const u32* __restrict__ rid, const u32* __restrict__ sizes,
-                                                   double c_relaxed,
-                                                   const u64* __restrict__ rowoff, u32* __restrict__ out_i,
-                                                   u32* __restrict__ out_j, u32* __restrict__ out_c) {
-    const u64 wave = (blockIdx.x * (u64)blockDim.x + threadIdx.x) / WAVE;
-    const u64 n_waves = ((u64)gridDim.x * blockDim.x) / WAVE;
-    const int lane = threadIdx.x & (WAVE - 1);
-    for (u64 i = r0 + wave; i < r1; i += n_waves) {
-        const u32* row = M + (i - r0) * n_refs;
-        u64 w = rowoff[i - r0];
-        for (u64 j0 = 0; j0 < n_refs; j0 += WAVE) {
-            const u64 j = j0 + lane;
-            u32 cnt = 0;
-            bool keep = false;
-            if (j < n_refs) {
-                cnt = row[j];
-                keep = pair_keep(cnt, rid[i], rid[j], sizes, c_relaxed);
-            }
-            const u64 bal = __ballot(keep);
-            if (keep) {
-                const u64 dst = w + __popcll(bal & ((1ull << lane) - 1ull));
-                out_i[dst] = rid[i];
-                out_j[dst] = rid[j];
-                out_c[dst] = cnt;
-            }
-            w += __popcll(bal);
-        }
-    }
 }
 
 inline u32 grid_for(u64 work_items, u32 block, u32 max_blocks = 16384) {
@@ -1789,350 +1575,6 @@ int yh_q_exclusive(yh_db* db, const u8* d_mask, const u64* d_sample, u64 n_sampl
         N, d_mask, db->d_sizes, db->d_nshared, d_overlap, db->d_excl_e, db->d_excl_m, db->d_ovsh, d_excl, d_match,
         clean_hit ? reinterpret_cast<uint4*>(db->d_hit) : nullptr, clean_hit ? (db->n_shared + 15) / 16 : 0);
     if (clean_hit) db->hit_clean = true;
-    yh_ring_record_end(db, db->ev_excl);
-    YH_HIP(hipGetLastError());
-    return YH_OK;
-}
-
-// Fills the handle's host-side pair cache (h_pw_*) for rows [r0, r1).
-int yh_q_pairwise(yh_db* db, double c_thresh, u64 r0, u64 r1) {
-    if (!db->has_index) { yh_set_error("this handle was created with YH_DB_NO_INDEX"); return YH_ERR_UNSUPPORTED; }
-    hipStream_t st = db->stream;
-    const u64 N = db->n_refs;
-    free(db->h_pw_i); free(db->h_pw_j); free(db->h_pw_c);
-    db->h_pw_i = db->h_pw_j = db->h_pw_c = nullptr;
-    db->pw_n = 0;
-    db->pw_valid = false;
-    if (r1 > N) r1 = N;
-    if (r0 >= r1) { db->pw_valid = true; db->pw_c = c_thresh; db->pw_r0 = r0; db->pw_r1 = r1; return YH_OK; }
-
-    // compact ids of the references that hold a shared hash (ascending with the reference id)
-    std::vector<u32> h_nsh(N), h_cid(N), h_rid;
-    YH_HIP(hipMemcpyAsync(h_nsh.data(), db->d_nshared, N * sizeof(u32), hipMemcpyDeviceToHost, st));
-    YH_HIP(hipStreamSynchronize(st));
-    for (u64 j = 0; j < N; ++j) {
-        if (h_nsh[j]) { h_cid[j] = (u32)h_rid.size(); h_rid.push_back((u32)j); }
-        else h_cid[j] = 0xffffffffu;
-    }
-    const u64 NC = h_rid.size();
-    const u64 c_begin = std::lower_bound(h_rid.begin(), h_rid.end(), (u32)r0) - h_rid.begin();
-    const u64 c_end = std::lower_bound(h_rid.begin(), h_rid.end(), (u32)std::min<u64>(r1, 0xffffffffull)) - h_rid.begin();
-    if (NC == 0 || c_begin >= c_end) { db->pw_valid = true; db->pw_c = c_thresh; db->pw_r0 = r0; db->pw_r1 = r1; return YH_OK; }
-
-    // dense row blocks (compact rows x compact columns) of int32 counts: at most ~32 GiB, and at most 60 % of what the
-    // device has free now (other handles, other ranks sharing the GPU); halved again when the allocation still fails
-    u64 budget = 32ull << 30;
-    {
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0) budget = std::min<u64>(budget, (u64)((double)free_b * 0.6));
-        else (void)hipGetLastError();
-    }
-    u64 rows_per_block = std::max<u64>(1, budget / (NC * sizeof(u32)));
-    if (rows_per_block > c_end - c_begin) rows_per_block = c_end - c_begin;
-    const double c_relaxed = c_thresh * (1.0 - 1e-9) - 1e-300;
-
-    u32 *d_M = nullptr, *d_rowcnt = nullptr, *d_oi = nullptr, *d_oj = nullptr, *d_oc = nullptr;
-    u32 *d_cid = nullptr, *d_rid = nullptr;
-    u64* d_rowoff = nullptr;
-    std::vector<u32> hi, hj, hc;
-    int rc = YH_OK;
-#define PW_HIP(call)                                                                          \
-    if (rc == YH_OK) {                                                                        \
-        hipError_t e__ = (call);                                                              \
-        if (e__ != hipSuccess) {                                                              \
-            yh_set_error("%s failed: %s", #call, hipGetErrorString(e__));                     \
-            rc = (e__ == hipErrorOutOfMemory) ? YH_ERR_OOM : YH_ERR_HIP;                      \
-        }                                                                                     \
-    }
-    for (;;) {
-        const hipError_t em = hipMalloc((void**)&d_M, rows_per_block * NC * sizeof(u32));
-        if (em == hipSuccess) break;
-        (void)hipGetLastError();
-        d_M = nullptr;
-        if (em != hipErrorOutOfMemory || rows_per_block == 1) {
-            yh_set_error("hipMalloc of the %llu-row count block failed: %s", (u64)rows_per_block, hipGetErrorString(em));
-            rc = (em == hipErrorOutOfMemory) ? YH_ERR_OOM : YH_ERR_HIP;
-            break;
-        }
-        rows_per_block = (rows_per_block + 1) / 2;
-    }
-    PW_HIP(hipMalloc((void**)&d_rowcnt, rows_per_block * sizeof(u32)));
-    PW_HIP(hipMalloc((void**)&d_rowoff, (rows_per_block + 1) * sizeof(u64)));
-    PW_HIP(hipMalloc((void**)&d_cid, N * sizeof(u32)));
-    PW_HIP(hipMalloc((void**)&d_rid, NC * sizeof(u32)));
-    PW_HIP(hipMemcpyAsync(d_cid, h_cid.data(), N * sizeof(u32), hipMemcpyHostToDevice, st));
-    PW_HIP(hipMemcpyAsync(d_rid, h_rid.data(), NC * sizeof(u32), hipMemcpyHostToDevice, st));
-    yh_ring_record_begin(db, db->ev_pair);
-    for (u64 b0 = c_begin; b0 < c_end && rc == YH_OK; b0 += rows_per_block) {
-        const u64 b1 = std::min(c_end, b0 + rows_per_block);
-        const u64 rows = b1 - b0;
-        PW_HIP(hipMemsetAsync(d_M, 0, rows * NC * sizeof(u32), st));
-        if (rc == YH_OK && db->n_postings) {
-            k_pair_accum<<<grid_for(db->n_postings, 256, 1u << 20), 256, 0, st>>>(db->n_postings, db->d_pr, db->d_pg,
-                                                                                  db->d_po, d_cid, b0, b1, NC, d_M);
-        }
-        if (rc == YH_OK) {
-            k_pair_count<<<grid_for(rows * WAVE, 256, 8192), 256, 0, st>>>(d_M, b0, b1, NC, d_rid, db->d_sizes, c_relaxed,
-                                                                           d_rowcnt);
-            k_scan_u32_to_u64<<<1, 1024, 0, st>>>(d_rowcnt, rows, d_rowoff);
-        }
-        PW_HIP(hipGetLastError());
-        u64 n_out = 0;
-        PW_HIP(hipMemcpyAsync(&n_out, d_rowoff + rows, sizeof(u64), hipMemcpyDeviceToHost, st));
-        PW_HIP(hipStreamSynchronize(st));
-        if (rc == YH_OK && n_out) {
-            PW_HIP(hipMalloc((void**)&d_oi, n_out * sizeof(u32)));
-            PW_HIP(hipMalloc((void**)&d_oj, n_out * sizeof(u32)));
-            PW_HIP(hipMalloc((void**)&d_oc, n_out * sizeof(u32)));
-            if (rc == YH_OK) {
-                k_pair_emit<<<grid_for(rows * WAVE, 256, 8192), 256, 0, st>>>(d_M, b0, b1, NC, d_rid, db->d_sizes,
-                                                                              c_relaxed, d_rowoff, d_oi, d_oj, d_oc);
-            }
-            PW_HIP(hipGetLastError());
-            const size_t base = hi.size();
-            hi.resize(base + n_out); hj.resize(base + n_out); hc.resize(base + n_out);
-            PW_HIP(hipMemcpyAsync(hi.data() + base, d_oi, n_out * sizeof(u32), hipMemcpyDeviceToHost, st));
-            PW_HIP(hipMemcpyAsync(hj.data() + base, d_oj, n_out * sizeof(u32), hipMemcpyDeviceToHost, st));
-            PW_HIP(hipMemcpyAsync(hc.data() + base, d_oc, n_out * sizeof(u32), hipMemcpyDeviceToHost, st));
-            PW_HIP(hipStreamSynchronize(st));
-            (void)hipFree(d_oi); (void)hipFree(d_oj); (void)hipFree(d_oc);
-            d_oi = d_oj = d_oc = nullptr;
-        }
-    }
-    yh_ring_record_end(db, db->ev_pair);
-#undef PW_HIP
-    (void)hipFree(d_M); (void)hipFree(d_rowcnt); (void)hipFree(d_rowoff);
-    (void)hipFree(d_oi); (void)hipFree(d_oj); (void)hipFree(d_oc);
-    (void)hipFree(d_cid); (void)hipFree(d_rid);
-    if (rc != YH_OK) return rc;
-
-    // exact host-side filter (main.cpp:297-303): keep iff !(1.0*count/|R_i| < C)
-    std::vector<u32> hsizes(N);
-    YH_HIP(hipMemcpy(hsizes.data(), db->d_sizes, N * sizeof(u32), hipMemcpyDeviceToHost));
-    size_t w = 0;
-    for (size_t k = 0; k < hi.size(); ++k) {
-        const double cij = 1.0 * hc[k] / hsizes[hi[k]];
-        if (cij < c_thresh) continue;
-        hi[w] = hi[k]; hj[w] = hj[k]; hc[w] = hc[k];
-        ++w;
-    }
-    db->pw_n = w;
-    db->h_pw_i = (u32*)malloc(std::max<size_t>(w, 1) * sizeof(u32));
-    db->h_pw_j = (u32*)malloc(std::max<size_t>(w, 1) * sizeof(u32));
-    db->h_pw_c = (u32*)malloc(std::max<size_t>(w, 1) * sizeof(u32));
-    if (!db->h_pw_i || !db->h_pw_j || !db->h_pw_c) { yh_set_error("host allocation failed"); return YH_ERR_OOM; }
-    memcpy(db->h_pw_i, hi.data(), w * sizeof(u32));
-    memcpy(db->h_pw_j, hj.data(), w * sizeof(u32));
-    memcpy(db->h_pw_c, hc.data(), w * sizeof(u32));
-    db->pw_valid = true;
-    db->pw_c = c_thresh;
-    db->pw_r0 = r0;
-    db->pw_r1 = r1;
-    return YH_OK;
-}
-
-// =================================================================================================
-// Batched `yacht run`: up to 64 samples against the resident database in one pass
-// =================================================================================================
-// Samples are looked up through the distinct-hash directory (k_index_lookup's scheme), one lane per
-// sample hash of ANY sample.  Per-sample state is carried as 64-bit words: hitword[g] = samples that
-// contain shared hash g, maskword[r] = samples that overlap reference r.  Exclusivity of a shared
-// hash for all samples at once is bit-sliced counting over its holders' mask words:
-//     ones ^= w, twos |= (ones_before & w)   ->   held by exactly one masked reference = ones & ~twos.
-namespace {
-
-__global__ void __launch_bounds__(256) k_batch_lookup(const u64* __restrict__ samples, const u64* __restrict__ soff,
-                                                      u32 n_samples, const YhDirView dv, const u64* __restrict__ po,
-                                                      const u32* __restrict__ pr, u64 n_refs,
-                                                      u32* __restrict__ overlap /* [B][N] */, u64* __restrict__ hitword,
-                                                      u64 n_chunks, u64 chunk_mul, const u32* __restrict__ filter,
-                                                      u64 filter_mul) {
-    __shared__ u64 off[65];
-    if (threadIdx.x <= n_samples) off[threadIdx.x] = soff[threadIdx.x];
-    __syncthreads();
-    const u64 total = off[n_samples];
-    // 256-hash chunks are visited in a multiplicative permutation (chunk_mul coprime to n_chunks), so
-    // that the workgroups resident at any moment work on ALL samples: a sample's hits land on its few
-    // hundred present references, and same-address atomics serialize (~11 ns each on this part)
-    for (u64 c = blockIdx.x; c < n_chunks; c += gridDim.x) {
-        const u64 t = ((c * chunk_mul) % n_chunks) * 256 + threadIdx.x;
-        if (t >= total) continue;
-        u32 lo = 0, hi = n_samples;  // sample of position t: last s with off[s] <= t
-        while (hi - lo > 1) {
-            const u32 mid = (lo + hi) >> 1;
-            if (off[mid] <= t) lo = mid; else hi = mid;
-        }
-        const u32 s = lo;
-        const u64 h = samples[t];
-        if (filter && h <= dv.max_hash) {  // presence bit first (yh_db::d_filter): clear = not in the database
-            const u64 bit = yh_bucket_of(h, dv.bkt_lsh, filter_mul);
-            if (!((filter[bit >> 5] >> (bit & 31u)) & 1u)) continue;
-        }
-        const u32 r = dv.find(h);
-        if (r == YH_DIR_NONE) continue;
-        u32* row = overlap + (u64)s * n_refs;
-        if (!(r & 0x80000000u)) {
-            atomicAdd(&row[r], 1u);
-        } else {
-            const u32 gi = r & 0x7fffffffu;
-            atomicOr((unsigned long long*)&hitword[gi], 1ull << s);
-            for (u64 q = po[gi], qe = po[gi + 1]; q < qe; ++q) atomicAdd(&row[pr[q]], 1u);
-        }
-    }
-}
-
-// maskword[r] = samples with overlap > 0; anybits = "some sample overlaps r" (for k_excl_collect)
-__global__ void __launch_bounds__(256) k_batch_maskwords(const u32* __restrict__ overlap, u32 n_samples, u64 n_refs,
-                                                         u64* __restrict__ maskword, u32* __restrict__ anybits) {
-    const u64 r = blockIdx.x * (u64)blockDim.x + threadIdx.x;
-    u64 w = 0;
-    if (r < n_refs)
-        for (u32 s = 0; s < n_samples; ++s) w |= (u64)(overlap[(u64)s * n_refs + r] != 0) << s;
-    if (r < n_refs) maskword[r] = w;
-    const u64 bal = __ballot(w != 0);
-    if ((threadIdx.x & 63) == 0) {
-        anybits[(r >> 5)] = (u32)bal;
-        anybits[(r >> 5) + 1] = (u32)(bal >> 32);
-    }
-}
-
-__global__ void __launch_bounds__(EXCL_BLOCK) k_batch_apply(const u32* __restrict__ queue, const u32* __restrict__ qcount,
-                                                            u64 chunk, const u64* __restrict__ po,
-                                                            const u32* __restrict__ pr, const u32* __restrict__ pg,
-                                                            const u64* __restrict__ maskword,
-                                                            const u64* __restrict__ hitword, u64 n_refs,
-                                                            u32* __restrict__ ex_e, u32* __restrict__ ex_m,
-                                                            u32* __restrict__ ovsh /* each [B][N] */) {
-    const u32 n = qcount[blockIdx.x];
-    const u32* seg = queue + 4 * (u64)blockIdx.x * chunk;
-    for (u32 e = threadIdx.x; e < n; e += EXCL_BLOCK) {
-        const u32 k = seg[e];
-        const u32 r = pr[k];
-        const u32 gi = pg[k];
-        const u64 wr = maskword[r];
-        const u64 hw = hitword[gi];
-        u64 ones = 0, twos = 0;
-        for (u64 q = po[gi], qe = po[gi + 1]; q < qe; ++q) {
-            const u64 w = maskword[pr[q]];
-            twos |= ones & w;
-            ones ^= w;
-        }
-        u64 excl = ones & ~twos & wr;  // samples in which r is the only masked holder of g
-        while (excl) {
-            const u32 s = (u32)__ffsll((long long)excl) - 1u;
-            excl &= excl - 1;
-            atomicAdd(&ex_e[(u64)s * n_refs + r], 1u);
-            if ((hw >> s) & 1ull) atomicAdd(&ex_m[(u64)s * n_refs + r], 1u);
-        }
-        u64 sh = wr & hw;  // samples that contain g and overlap r
-        while (sh) {
-            const u32 s = (u32)__ffsll((long long)sh) - 1u;
-            sh &= sh - 1;
-            atomicAdd(&ovsh[(u64)s * n_refs + r], 1u);
-        }
-    }
-}
-
-// hash-range shards: maskword[r] = OR over the ranks' gathered words; anybits as k_batch_maskwords makes them
-__global__ void __launch_bounds__(256) k_batch_or_maskwords(const u64* __restrict__ gathered, u32 n_ranks, u64 n_refs,
-                                                            u64* __restrict__ maskword, u32* __restrict__ anybits) {
-    const u64 r = blockIdx.x * (u64)blockDim.x + threadIdx.x;
-    u64 w = 0;
-    if (r < n_refs)
-        for (u32 k = 0; k < n_ranks; ++k) w |= gathered[(u64)k * n_refs + r];
-    if (r < n_refs) maskword[r] = w;
-    const u64 bal = __ballot(w != 0);
-    if ((threadIdx.x & 63) == 0) {
-        anybits[(r >> 5)] = (u32)bal;
-        anybits[(r >> 5) + 1] = (u32)(bal >> 32);
-    }
-}
-
-// in place: ex_e -> n_excl, ex_m -> n_match for every (sample, reference)
-// (maskword != nullptr -- a hash-range shard: the subset is the global one, a reference may be in it without an overlap
-// in THIS rank's range)
-__global__ void __launch_bounds__(256) k_batch_final(u32 n_samples, u64 n_refs, const u32* __restrict__ sizes,
-                                                     const u32* __restrict__ nshared, const u32* __restrict__ overlap,
-                                                     const u32* __restrict__ ovsh, u32* __restrict__ ex_e,
-                                                     u32* __restrict__ ex_m, const u64* __restrict__ maskword) {
-    const u64 total = (u64)n_samples * n_refs;
-    for (u64 t = blockIdx.x * (u64)blockDim.x + threadIdx.x; t < total; t += (u64)gridDim.x * blockDim.x) {
-        const u64 r = t % n_refs;
-        const u32 ov = overlap[t];
-        const bool in = maskword ? ((maskword[r] >> (t / n_refs)) & 1ull) != 0 : ov != 0;
-        if (in) {
-            ex_e[t] = sizes[r] - nshared[r] + ex_e[t];
-            ex_m[t] = ov - ovsh[t] + ex_m[t];
-        } else {
-            ex_e[t] = 0;
-            ex_m[t] = 0;
-        }
-    }
-}
-
-}  // namespace
-
-// phases: 1 = lookup + the samples' subset words (copied to d_maskword_out when given), 2 = exclusive pass + final
-// (d_gathered: the words of n_ranks hash-range shards, OR-ed into the subset first), 3 = both (one device, one call)
-int yh_q_run_batch(yh_db* db, const u64* d_samples, const u64* d_soff, u32 n_samples, u64 total_hashes,
-                   u32* d_overlap, u32* d_excl, u32* d_match, int phases, u64* d_maskword_out, const u64* d_gathered,
-                   u32 n_ranks) {
-    if (!db->has_dir || !db->has_index) {
-        yh_set_error("yh_run_batch needs the directory of the distinct hashes (handle created with YH_DB_NO_DIRECTORY?)");
-        return YH_ERR_UNSUPPORTED;
-    }
-    if (n_samples < 1 || n_samples > 64) { yh_set_error("1..64 samples per batch"); return YH_ERR_INVALID_ARG; }
-    hipStream_t st = db->stream;
-    const u64 N = db->n_refs;
-    if (N == 0) return YH_OK;
-    const u64 BN = (u64)n_samples * N;
-    const u64 G = db->n_shared;
-    // scratch: ovsh [B][N] u32, hitword [G] u64, maskword [N] u64 (kept on the handle, grown on demand)
-    const u64 need = BN * sizeof(u32) + (G + N + 2) * sizeof(u64) + 64;
-    if (db->batch_cap < need) {
-        YH_HIP(hipStreamSynchronize(st));
-        if (db->d_batch) { (void)hipFree(db->d_batch); db->d_batch = nullptr; db->batch_cap = 0; }
-        YH_HIP(hipMalloc((void**)&db->d_batch, need));
-        db->batch_cap = need;
-    }
-    u64* d_hitword = reinterpret_cast<u64*>(db->d_batch);
-    u64* d_maskword = d_hitword + G + 1;
-    u32* d_ovsh = reinterpret_cast<u32*>(d_maskword + N + 1);
-    if (phases & 1) {
-    YH_HIP(hipMemsetAsync(d_overlap, 0, BN * sizeof(u32), st));
-    YH_HIP(hipMemsetAsync(db->d_batch, 0, need, st));
-    yh_ring_record_begin(db, db->ev_overlap);
-    if (total_hashes && db->n_distinct) {
-        const u64 n_chunks = (total_hashes + 255) / 256;
-        if (n_chunks >> 32) { yh_set_error("batch too large"); return YH_ERR_INVALID_ARG; }
-        u64 mul = (u64)((double)n_chunks * 0.6180339887) | 1;  // golden-ratio stride, made coprime
-        auto gcd = [](u64 a, u64 b) { while (b) { const u64 t = a % b; a = b; b = t; } return a; };
-        while (gcd(mul, n_chunks) != 1) mul += 2;
-        k_batch_lookup<<<(u32)std::min<u64>(n_chunks, 8192), 256, 0, st>>>(d_samples, d_soff, n_samples, yh_dir_view(db),
-                                                                           db->d_po, db->d_pr, N, d_overlap, d_hitword,
-                                                                           n_chunks, mul, yh_filter_of(db), db->filter_mul);
-    }
-    yh_ring_record_end(db, db->ev_overlap);
-    k_batch_maskwords<<<(u32)((N + 255) / 256), 256, 0, st>>>(d_overlap, n_samples, N, d_maskword, db->d_maskbits);
-    if (d_maskword_out) YH_HIP(hipMemcpyAsync(d_maskword_out, d_maskword, N * sizeof(u64), hipMemcpyDeviceToDevice, st));
-    }
-    if (!(phases & 2)) { YH_HIP(hipGetLastError()); return YH_OK; }
-    YH_HIP(hipMemsetAsync(d_excl, 0, BN * sizeof(u32), st));
-    YH_HIP(hipMemsetAsync(d_match, 0, BN * sizeof(u32), st));
-    yh_ring_record_begin(db, db->ev_excl);
-    if (d_gathered)
-        k_batch_or_maskwords<<<(u32)((N + 255) / 256), 256, 0, st>>>(d_gathered, n_ranks, N, d_maskword, db->d_maskbits);
-    if (G && db->n_postings) {
-        const u64 vecs = (db->n_postings >> 2) + 1;
-        const u32 blocks = (u32)std::min<u64>(EXCL_QBLOCKS, (vecs + EXCL_BLOCK - 1) / EXCL_BLOCK);
-        const u64 chunk = (vecs + blocks - 1) / blocks;
-        k_excl_collect<<<blocks, EXCL_BLOCK, 0, st>>>(db->n_postings, chunk, db->d_pr, db->d_maskbits, db->d_pq,
-                                                      db->d_pq_count);
-        k_batch_apply<<<blocks, EXCL_BLOCK, 0, st>>>(db->d_pq, db->d_pq_count, chunk, db->d_po, db->d_pr, db->d_pg,
-                                                     d_maskword, d_hitword, N, d_excl, d_match, d_ovsh);
-    }
-    k_batch_final<<<grid_for(BN, 256, 8192), 256, 0, st>>>(n_samples, N, db->d_sizes, db->d_nshared, d_overlap, d_ovsh,
-                                                           d_excl, d_match, d_gathered ? d_maskword : nullptr);
     yh_ring_record_end(db, db->ev_excl);
     YH_HIP(hipGetLastError());
     return YH_OK;
