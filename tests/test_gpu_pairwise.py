@@ -1,0 +1,98 @@
+"""`yacht train`'s pairwise counts (yh_pairwise.hip: reference-major records, one row in LDS per workgroup) against the
+oracle: short, inline and whole-wave posting lists, several column blocks, handles with and without posting ranks,
+row ranges, and more survivors than the first output buffer holds.
+
+The column-block cases need a tuning variable (YH_DEBUG_TUNING=1 YH_PAIR_COLS=...), read when the library is first
+used, so they run in a child process.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r"""
+import json, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from oracle import oracle
+from yacht_amd import synth
+from yacht_amd.engine import RefDB, YH_DB_PAIRWISE_ONLY, train_select
+
+rng = np.random.default_rng(int(sys.argv[2]))
+mh = synth.max_hash_for_scaled(1000)
+refs = synth.clustered_refs(rng, 60, (1.0, 0.9, 0.5, 0.25, 0.1), 300)
+n0 = len(refs)
+# posting lists of every kind: a hash in 5..32 sketches (walked by its lane), in 33..300 (by the wave), and in all
+extra = [[] for _ in range(n0)]
+for m in (5, 8, 9, 31, 32, 33, 64, 65, 200, n0):
+    for _ in range(3):
+        h = int(rng.integers(1, mh))
+        for r in rng.choice(n0, size=m, replace=False):
+            extra[int(r)].append(h)
+refs = [np.unique(np.concatenate([r, np.array(e, np.uint64)])) for r, e in zip(refs, extra)]
+refs.insert(7, np.zeros(0, np.uint64))
+refs.append(np.array([3], np.uint64))
+values, offsets = synth.pack(refs)
+sizes = np.diff(offsets).astype(np.uint32)
+n = len(refs)
+out = {"n": n}
+for c in (0.0, 0.95 ** 31, 0.9):
+    wi, wj, wc, wstats = oracle.train_pairs(values, offsets, c, threads=4)
+    for flags in (0, YH_DB_PAIRWISE_ONLY):
+        with RefDB(values, offsets, flags=flags) as db:
+            gi, gj, gc = db.pairwise(c)
+            ok = bool(np.array_equal(gi, wi) and np.array_equal(gj, wj) and np.array_equal(gc, wc) and db.index_stats() == wstats)
+            cuts = sorted(set([0, n] + [int(x) for x in rng.integers(0, n, 3)]))
+            parts = [db.pairwise(c, a, b) for a, b in zip(cuts, cuts[1:])]
+            ok_rows = all(np.array_equal(np.concatenate([p[k] for p in parts]), w) for k, w in ((0, wi), (1, wj), (2, wc)))
+            ok_sel = bool(np.array_equal(train_select(sizes, gi, gj), oracle.train_select(sizes, wi, wj)))
+        out[f"c{c:.3f}_flags{flags}"] = [ok, bool(ok_rows), ok_sel, int(wi.size)]
+print(json.dumps(out))
+"""
+
+
+def _run(seed, env_extra):
+    env = dict(os.environ)
+    env.update(env_extra)
+    r = subprocess.run([sys.executable, "-c", WORKER, ROOT, str(seed)], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+@pytest.mark.parametrize("cols", [None, 64, 128])
+def test_pairwise_rows_against_the_oracle(hip_lib, cols):
+    env = {} if cols is None else {"YH_DEBUG_TUNING": "1", "YH_PAIR_COLS": str(cols)}
+    out = _run(5 if cols is None else cols, env)
+    assert out["n"] > 300
+    checks = {k: v for k, v in out.items() if k != "n"}
+    assert len(checks) == 6
+    for k, v in checks.items():
+        assert v[:3] == [True, True, True], (k, v)
+    assert any(v[3] > 1000 for v in checks.values())  # (the lists shared by all sketches: a dense corner)
+
+
+def test_more_survivors_than_the_first_buffer(hip_lib):
+    """1 500 sketches that all hold one common hash: 1 500 x 1 499 ordered pairs at C = 0 -- more than the million
+    entries the output starts with, so the row pass is repeated with the size it counted."""
+    from oracle import oracle
+    from yacht_amd import synth
+    from yacht_amd.engine import RefDB, YH_DB_PAIRWISE_ONLY
+
+    rng = np.random.default_rng(77)
+    mh = synth.max_hash_for_scaled(1000)
+    common = np.array([int(rng.integers(1, mh))], np.uint64)
+    refs = [np.unique(np.concatenate([common, synth.random_sketch(rng, 20, mh)])) for _ in range(1500)]
+    values, offsets = synth.pack(refs)
+    wi, wj, wc, wstats = oracle.train_pairs(values, offsets, 0.0, threads=4)
+    assert wi.size == 1500 * 1499
+    with RefDB(values, offsets, flags=YH_DB_PAIRWISE_ONLY) as db:
+        gi, gj, gc = db.pairwise(0.0)
+        assert np.array_equal(gi, wi) and np.array_equal(gj, wj) and np.array_equal(gc, wc)
+        assert db.index_stats() == wstats

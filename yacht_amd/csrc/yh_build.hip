@@ -169,7 +169,7 @@ __global__ void __launch_bounds__(IDX_THREADS) k_idx_emit(const u64* __restrict_
                                                           u32* __restrict__ pr, u32* __restrict__ pg,
                                                           u32* __restrict__ nshared,
                                                           u64* __restrict__ dh, u32* __restrict__ dref,
-                                                          u32* __restrict__ elem_g) {
+                                                          u32* __restrict__ elem_g, u32* __restrict__ prank) {
     // dh/dref (optional): every DISTINCT hash ascending, with its single holder, or
     // 0x80000000 | (index into g) when several references hold it
     const u32 lane = threadIdx.x & 63u;
@@ -208,7 +208,8 @@ __global__ void __launch_bounds__(IDX_THREADS) k_idx_emit(const u64* __restrict_
         if (shared) {
             pr[my_m] = r;
             pg[my_m] = (u32)(my_g_incl - 1);
-            atomicAdd(&nshared[r], 1u);
+            const u32 rank = atomicAdd(&nshared[r], 1u);
+            if (prank) prank[my_m] = rank;  // (any order inside the reference: the pairwise pass only sums)
         }
         if (elem_g && i < n) elem_g[i] = shared ? (u32)(my_g_incl - 1) : STREAM_NONE;  // shared-hash index of every sorted element
         di += (u64)__popcll(bd);
@@ -598,6 +599,8 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets) {
     if (rc == YH_OK) rc = yh_dmalloc(db, (void**)&db->d_po, (db->n_shared + 1) * sizeof(u64));
     if (rc == YH_OK) rc = yh_dmalloc(db, (void**)&db->d_pr, std::max<u64>(db->n_postings, 1) * sizeof(u32));
     if (rc == YH_OK) rc = yh_dmalloc(db, (void**)&db->d_pg, std::max<u64>(db->n_postings, 1) * sizeof(u32));
+    if (rc == YH_OK && (db->flags & YH_DB_PAIRWISE_ONLY))
+        rc = yh_dmalloc(db, (void**)&db->d_prank, std::max<u64>(db->n_postings, 1) * sizeof(u32));
     if (rc == YH_OK) rc = yh_dmalloc(db, (void**)&db->d_hit, db->n_shared + 16);  // zeroed in 16-byte units
     if (rc == YH_OK && db->n_postings > 0xfffffff0ull) { yh_set_error("more than 2^32 postings"); rc = YH_ERR_UNSUPPORTED; }
     // (+ slack: the last workgroup's segment may start up to 4*EXCL_QBLOCKS entries late)
@@ -659,7 +662,7 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets) {
         u32* const dref_out = !full ? nullptr : compact ? d_dref_tmp : db->d_dref;
         if (rc == YH_OK)
             k_idx_emit<<<(u32)((nb * 64 + IDX_THREADS - 1) / IDX_THREADS), IDX_THREADS, 0, st>>>(d_sk, d_sv, H, d_bases, db->d_g, db->d_po, db->d_pr, db->d_pg,
-                                                        db->d_nshared, dh_out, dref_out, d_elem_g);
+                                                        db->d_nshared, dh_out, dref_out, d_elem_g, db->d_prank);
         if (rc == YH_OK && full && !compact)
             k_dir_build<<<grid_for(db->n_distinct, 256), 256, 0, st>>>(db->d_dh, db->n_distinct, db->dir_shift, db->dir_nb,
                                                                        db->d_dir);

@@ -110,6 +110,7 @@ struct yh_db {
     u64* d_po = nullptr;     // [G+1] posting-list offsets
     u32* d_pr = nullptr;     // [postings] reference ids, ascending inside a list
     u32* d_pg = nullptr;     // [postings] index of the hash each posting belongs to
+    u32* d_prank = nullptr;  // [postings] YH_DB_PAIRWISE_ONLY: the posting's rank among its reference's shared hashes (yh_pairwise.hip)
     u32* d_nshared = nullptr;  // [N] number of shared hashes in reference j
 
     // full distinct-hash directory (only with YH_DB_FULL_INDEX): the sample-driven overlap path

@@ -1,4 +1,18 @@
 // yh_pairwise.hip -- `yacht train`: pairwise intersection counts from the posting lists (src/cpp/main.cpp:249-308)
+//
+// |R_i ∩ R_j| for every pair with a common hash = for every shared hash, one count for every ordered pair of its
+// holders.  The counts of ONE reference a (a row of the reference's intersection matrix) only come from a's own
+// postings, so the row is summed where atomics are cheap -- in the LDS of one workgroup -- and only its survivors
+// (main.cpp:297-303: !(count / |R_i| < C)) ever reach HBM.  No dense count matrix: 16 bytes per posting of scratch.
+//
+//   k_pair_transpose   the hash-major postings (pr / pg / po) into a reference-major array of 16-byte records
+//                      "the OTHER holders of this posting's hash" -- three inline, or where the list is in pr[];
+//                      the slot inside the reference's run is the posting's rank among the reference's shared hashes
+//                      (k_idx_emit's counting atomic returns it: yh_db::d_prank), or a cursor atomic where the handle
+//                      has no ranks
+//   k_pair_rows        one workgroup per reference (and block of columns): its records, one LDS add per other holder;
+//                      then the row's survivors, in column order, into a segment of the output claimed with ONE atomic
+// The host puts the segments in row order and applies the exact threshold (no decision depends on device floating point).
 #include "yh_common.h"
 
 #include <stdlib.h>
@@ -10,59 +24,37 @@
 namespace {
 
 constexpr int WAVE = 64;
-
-// ---- pairwise -------------------------------------------------------------------------------------
-// Only references that hold at least one shared hash can be in a pair, so the dense count block is
-// indexed by COMPACT ids (cid[ref], ascending with the reference id; rid[] maps back): a
-// dereplicated database of 85 205 genomes has ~8 000 such references (0.3 GB instead of 29 GB).
-//
-// One thread per posting (a = its reference): for every other reference b of the same hash,
-// M[cid[a] - c0][cid[b]] += 1.  Integer atomics: the result does not depend on arrival order.
-// A posting whose hash has few holders walks the list itself; a list of more than PAIR_LONG holders is
-// walked by the whole wave, one holder per lane (a k-mer shared by M references is M^2 increments either
-// way, but M serial steps per posting instead of M / 64 made one conserved k-mer the tail of the launch).
+constexpr int ROW_THREADS = 256;
+constexpr int ROW_WAVES = ROW_THREADS / WAVE;
+// holders of a hash up to which a posting's record names the others inline (three others)
+constexpr u32 PAIR_INLINE = 4;
+// a list of more than PAIR_LONG holders is walked by the whole wave, one holder per lane (a k-mer shared by M
+// references is M^2 increments either way, but M serial steps per posting instead of M / 64 made one conserved k-mer
+// the tail of the launch)
 constexpr u32 PAIR_LONG = 32;
-__global__ void __launch_bounds__(256) k_pair_accum(u64 n_post, const u32* __restrict__ pr, const u32* __restrict__ pg,
-                                                    const u64* __restrict__ po, const u32* __restrict__ cid, u64 c0, u64 c1,
-                                                    u64 n_c, u32* __restrict__ M) {
-    const u32 lane = threadIdx.x & 63u;
-    const u64 wave = (blockIdx.x * (u64)blockDim.x + threadIdx.x) >> 6;
-    const u64 n_waves = ((u64)gridDim.x * blockDim.x) >> 6;
-    for (u64 k0 = wave * 64; k0 < n_post; k0 += n_waves * 64) {
-        const u64 k = k0 + lane;
-        u32 a = 0, ca = 0xffffffffu;
-        u64 b = 0, e = 0;
-        if (k < n_post) {
-            a = pr[k];
-            ca = cid[a];
-            if (ca >= c0 && ca < c1) {
-                const u32 gi = pg[k];
-                b = po[gi];
-                e = po[gi + 1];
-            }
+// columns (u32 counts) of a row block in LDS: with the attribute below 36 864 (144 KiB), else what fits 64 KiB
+constexpr u32 PAIR_COLS_BIG = 36864;
+constexpr u32 PAIR_COLS_SMALL = 15360;
+
+__global__ void __launch_bounds__(256) k_pair_transpose(u64 n_post, const u32* __restrict__ pr, const u32* __restrict__ pg,
+                                                        const u64* __restrict__ po, const u32* __restrict__ rowptr,
+                                                        const u32* __restrict__ prank, u32* __restrict__ cursor,
+                                                        uint4* __restrict__ rrec) {
+    for (u64 k = blockIdx.x * (u64)blockDim.x + threadIdx.x; k < n_post; k += (u64)gridDim.x * blockDim.x) {
+        const u32 a = pr[k], g = pg[k];
+        const u64 q0 = po[g], q1 = po[g + 1];
+        const u32 slot = prank ? prank[k] : atomicAdd(&cursor[a], 1u);  // order inside a reference is irrelevant (sums)
+        uint4 rec;
+        if (q1 - q0 <= PAIR_INLINE) {
+            u32 o[3] = {0u, 0u, 0u};
+            u32 n = 0;
+            for (u64 q = q0; q < q1; ++q)
+                if (q != k) o[n++] = pr[q];
+            rec = make_uint4(o[0], o[1], o[2], n);
+        } else {
+            rec = make_uint4((u32)q0, (u32)(q1 - q0), 0u, 0xffffffffu);
         }
-        const bool mine = e > b;
-        const bool is_long = mine && (e - b) > PAIR_LONG;
-        if (mine && !is_long) {
-            u32* row = M + (u64)(ca - c0) * n_c;
-            for (u64 q = b; q < e; ++q) {
-                const u32 o = pr[q];
-                if (o != a) atomicAdd(&row[cid[o]], 1u);
-            }
-        }
-        u64 todo = __ballot(is_long);
-        while (todo) {
-            const int src = __ffsll((long long)todo) - 1;
-            todo &= todo - 1;
-            const u32 a_s = (u32)__shfl((int)a, src), ca_s = (u32)__shfl((int)ca, src);
-            const u64 b_s = ((u64)(u32)__shfl((int)(u32)(b >> 32), src) << 32) | (u32)__shfl((int)(u32)b, src);
-            const u64 e_s = ((u64)(u32)__shfl((int)(u32)(e >> 32), src) << 32) | (u32)__shfl((int)(u32)e, src);
-            u32* row = M + (u64)(ca_s - c0) * n_c;
-            for (u64 q = b_s + lane; q < e_s; q += 64) {
-                const u32 o = pr[q];
-                if (o != a_s) atomicAdd(&row[cid[o]], 1u);
-            }
-        }
+        rrec[(u64)rowptr[a] + slot] = rec;
     }
 }
 
@@ -75,87 +67,117 @@ __device__ __forceinline__ bool pair_keep(u32 cnt, u32 i, u32 j, const u32* __re
     return !((double)cnt / (double)si < c_relaxed);
 }
 
-// one wave per row: count survivors
-__global__ void __launch_bounds__(256) k_pair_count(const u32* __restrict__ M, u64 r0, u64 r1, u64 n_refs,
-                                                    const u32* __restrict__ rid, const u32* __restrict__ sizes,
-                                                    double c_relaxed, u32* __restrict__ rowcnt) {
-    const u64 wave = (blockIdx.x * (u64)blockDim.x + threadIdx.x) / WAVE;
-    const u64 n_waves = ((u64)gridDim.x * blockDim.x) / WAVE;
-    const int lane = threadIdx.x & (WAVE - 1);
-    for (u64 i = r0 + wave; i < r1; i += n_waves) {
-        const u32* row = M + (i - r0) * n_refs;
-        u32 c = 0;
-        for (u64 j0 = 0; j0 < n_refs; j0 += WAVE) {
-            const u64 j = j0 + lane;
-            const bool keep = (j < n_refs) && pair_keep(row[j], rid[i], rid[j], sizes, c_relaxed);
-            c += (u32)__popcll(__ballot(keep));
+struct PairRows {
+    const uint4* rrec;    // [postings] reference-major records
+    const u32* rowptr;    // [N + 1]
+    const u32* pr;        // hash-major holders (the long lists)
+    const u32* cid;       // [N] compact id of a reference that holds a shared hash
+    const u32* rid;       // [NC] back
+    const u32* sizes;     // [N]
+    u64 a0;               // first reference of the launch (blockIdx.x = a - a0)
+    u64 seg0;             // its first segment
+    u32 NC, cols;         // compact references; columns per block (blockIdx.y)
+    double c_relaxed;
+    u32* segcnt;          // [rows * column blocks] survivors of the segment
+    u64* segoff;          // ... and where they start in out_j / out_c
+    unsigned long long* cursor;
+    u64 cap;              // entries of out_j / out_c (a segment that does not fit is counted, not written)
+    u32* out_j;
+    u32* out_c;
+};
+
+__global__ void __launch_bounds__(ROW_THREADS) k_pair_rows(const PairRows p) {
+    extern __shared__ u32 row[];  // p.cols counts
+    __shared__ u32 wtot[ROW_WAVES];
+    __shared__ u64 s_base;
+    __shared__ u32 s_write;
+    const u32 tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
+    const u64 a = p.a0 + blockIdx.x;
+    const u32 c0 = blockIdx.y * p.cols;
+    const u32 w = min(p.NC - c0, p.cols);
+    const u64 seg = p.seg0 + (u64)blockIdx.x * gridDim.y + blockIdx.y;
+    const u32 t0 = p.rowptr[a], t1 = p.rowptr[a + 1];
+    if (t0 == t1) {  // (uniform) no shared hash: no pair
+        if (tid == 0) { p.segcnt[seg] = 0; p.segoff[seg] = 0; }
+        return;
+    }
+    for (u32 j = tid; j < w; j += ROW_THREADS) row[j] = 0;
+    __syncthreads();
+    auto add = [&](u32 o) {
+        const u32 c = p.cid[o] - c0;
+        if (c < w) atomicAdd(&row[c], 1u);
+    };
+    for (u32 tb = t0 + wid * 64u; tb < t1; tb += ROW_THREADS) {  // (wave-uniform bounds: the ballot below)
+        const u32 t = tb + lane;
+        uint4 rec = make_uint4(0u, 0u, 0u, 0u);
+        if (t < t1) rec = p.rrec[t];
+        const bool is_list = rec.w == 0xffffffffu;
+        if (!is_list) {
+            if (rec.w > 0) add(rec.x);
+            if (rec.w > 1) add(rec.y);
+            if (rec.w > 2) add(rec.z);
+        } else if (rec.y <= PAIR_LONG) {
+            for (u32 q = rec.x, qe = rec.x + rec.y; q < qe; ++q) {
+                const u32 o = p.pr[q];
+                if (o != (u32)a) add(o);
+            }
         }
-        if (lane == 0) rowcnt[i - r0] = c;
+        u64 todo = __ballot(is_list && rec.y > PAIR_LONG);
+        while (todo) {
+            const int src = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const u32 q0 = (u32)__shfl((int)rec.x, src), m = (u32)__shfl((int)rec.y, src);
+            for (u32 q = lane; q < m; q += 64u) {
+                const u32 o = p.pr[q0 + q];
+                if (o != (u32)a) add(o);
+            }
+        }
+    }
+    __syncthreads();
+    // survivors in column order: wave v owns the columns [v*per, (v+1)*per)
+    const u32 per = ((w + ROW_WAVES * 64u - 1) / (ROW_WAVES * 64u)) * 64u;
+    const u32 jb = min(w, wid * per), je = min(w, jb + per);
+    u32 mine = 0;
+    for (u32 j0 = jb; j0 < je; j0 += 64u) {
+        const u32 j = j0 + lane;
+        const u32 cnt = j < je ? row[j] : 0u;  // (rows are sparse: rid / sizes only behind a count)
+        const bool keep = cnt != 0 && pair_keep(cnt, (u32)a, p.rid[c0 + j], p.sizes, p.c_relaxed);
+        mine += (u32)__popcll(__ballot(keep));
+    }
+    if (lane == 0) wtot[wid] = mine;
+    __syncthreads();
+    if (tid == 0) {
+        u32 total = 0;
+        for (int v = 0; v < ROW_WAVES; ++v) total += wtot[v];
+        const u64 base = total ? atomicAdd(p.cursor, (unsigned long long)total) : 0;
+        p.segcnt[seg] = total;
+        p.segoff[seg] = base;
+        s_base = base;
+        s_write = (total && base + total <= p.cap) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_write) return;
+    u64 dst = s_base;
+    for (u32 v = 0; v < wid; ++v) dst += wtot[v];
+    for (u32 j0 = jb; j0 < je; j0 += 64u) {
+        const u32 j = j0 + lane;
+        const u32 cnt = j < je ? row[j] : 0u;
+        u32 rj = 0;
+        bool keep = false;
+        if (cnt != 0) {
+            rj = p.rid[c0 + j];
+            keep = pair_keep(cnt, (u32)a, rj, p.sizes, p.c_relaxed);
+        }
+        const u64 bal = __ballot(keep);
+        if (keep) {
+            const u64 d = dst + (u64)__popcll(bal & ((1ull << lane) - 1ull));
+            p.out_j[d] = rj;
+            p.out_c[d] = cnt;
+        }
+        dst += (u64)__popcll(bal);
     }
 }
 
-__global__ void __launch_bounds__(1024) k_scan_u32_to_u64(const u32* __restrict__ in, u64 n, u64* __restrict__ out) {
-    // single workgroup; out[n] = total
-    __shared__ u64 wsum[17];
-    const int lane = threadIdx.x & (WAVE - 1);
-    const int wid = threadIdx.x / WAVE;
-    const int nw = blockDim.x / WAVE;
-    u64 carry = 0;
-    for (u64 base = 0; base < n; base += blockDim.x) {
-        const u64 i = base + threadIdx.x;
-        const u64 v = (i < n) ? in[i] : 0;
-        u64 inc = v;
-#pragma unroll
-        for (int d = 1; d < WAVE; d <<= 1) {
-            const u64 t = __shfl_up(inc, d, WAVE);
-            if (lane >= d) inc += t;
-        }
-        if (lane == WAVE - 1) wsum[wid] = inc;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            u64 acc = 0;
-            for (int w = 0; w < nw; ++w) { const u64 t = wsum[w]; wsum[w] = acc; acc += t; }
-            wsum[16] = acc;
-        }
-        __syncthreads();
-        if (i < n) out[i] = carry + wsum[wid] + inc - v;
-        carry += wsum[16];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) out[n] = carry;
-}
-
-// one wave per row: ordered compaction (j ascending inside a row, rows ascending)
-__global__ void __launch_bounds__(256) k_pair_emit(const u32* __restrict__ M, u64 r0, u64 r1, u64 n_refs,
-                                                   const u32* __restrict__ rid, const u32* __restrict__ sizes,
-                                                   double c_relaxed,
-                                                   const u64* __restrict__ rowoff, u32* __restrict__ out_i,
-                                                   u32* __restrict__ out_j, u32* __restrict__ out_c) {
-    const u64 wave = (blockIdx.x * (u64)blockDim.x + threadIdx.x) / WAVE;
-    const u64 n_waves = ((u64)gridDim.x * blockDim.x) / WAVE;
-    const int lane = threadIdx.x & (WAVE - 1);
-    for (u64 i = r0 + wave; i < r1; i += n_waves) {
-        const u32* row = M + (i - r0) * n_refs;
-        u64 w = rowoff[i - r0];
-        for (u64 j0 = 0; j0 < n_refs; j0 += WAVE) {
-            const u64 j = j0 + lane;
-            u32 cnt = 0;
-            bool keep = false;
-            if (j < n_refs) {
-                cnt = row[j];
-                keep = pair_keep(cnt, rid[i], rid[j], sizes, c_relaxed);
-            }
-            const u64 bal = __ballot(keep);
-            if (keep) {
-                const u64 dst = w + __popcll(bal & ((1ull << lane) - 1ull));
-                out_i[dst] = rid[i];
-                out_j[dst] = rid[j];
-                out_c[dst] = cnt;
-            }
-            w += __popcll(bal);
-        }
-    }
-}
 inline u32 grid_for(u64 work_items, u32 block, u32 max_blocks = 16384) {
     u64 g = (work_items + block - 1) / block;
     if (g < 1) g = 1;
@@ -170,42 +192,56 @@ int yh_q_pairwise(yh_db* db, double c_thresh, u64 r0, u64 r1) {
     if (!db->has_index) { yh_set_error("this handle was created with YH_DB_NO_INDEX"); return YH_ERR_UNSUPPORTED; }
     hipStream_t st = db->stream;
     const u64 N = db->n_refs;
+    const u64 P = db->n_postings;
     free(db->h_pw_i); free(db->h_pw_j); free(db->h_pw_c);
     db->h_pw_i = db->h_pw_j = db->h_pw_c = nullptr;
     db->pw_n = 0;
     db->pw_valid = false;
     if (r1 > N) r1 = N;
-    if (r0 >= r1) { db->pw_valid = true; db->pw_c = c_thresh; db->pw_r0 = r0; db->pw_r1 = r1; return YH_OK; }
+    auto done_empty = [&]() { db->pw_valid = true; db->pw_c = c_thresh; db->pw_r0 = r0; db->pw_r1 = r1; return YH_OK; };
+    if (r0 >= r1 || P == 0) return done_empty();
 
-    // compact ids of the references that hold a shared hash (ascending with the reference id)
-    std::vector<u32> h_nsh(N), h_cid(N), h_rid;
+    // compact ids of the references that hold a shared hash (ascending with the reference id), and where a reference's
+    // records start: one staging buffer [rowptr (N + 1) | cid (N) | rid (NC)], one copy up
+    std::vector<u32> h_nsh(N);
     YH_HIP(hipMemcpyAsync(h_nsh.data(), db->d_nshared, N * sizeof(u32), hipMemcpyDeviceToHost, st));
     YH_HIP(hipStreamSynchronize(st));
+    std::vector<u32> h_tab(2 * N + 1 + N);
+    u32* h_rowptr = h_tab.data();
+    u32* h_cid = h_tab.data() + N + 1;
+    u32* h_rid = h_tab.data() + 2 * N + 1;
+    u64 NC = 0, acc = 0;
     for (u64 j = 0; j < N; ++j) {
-        if (h_nsh[j]) { h_cid[j] = (u32)h_rid.size(); h_rid.push_back((u32)j); }
+        h_rowptr[j] = (u32)acc;
+        acc += h_nsh[j];
+        if (h_nsh[j]) { h_cid[j] = (u32)NC; h_rid[NC++] = (u32)j; }
         else h_cid[j] = 0xffffffffu;
     }
-    const u64 NC = h_rid.size();
-    const u64 c_begin = std::lower_bound(h_rid.begin(), h_rid.end(), (u32)r0) - h_rid.begin();
-    const u64 c_end = std::lower_bound(h_rid.begin(), h_rid.end(), (u32)std::min<u64>(r1, 0xffffffffull)) - h_rid.begin();
-    if (NC == 0 || c_begin >= c_end) { db->pw_valid = true; db->pw_c = c_thresh; db->pw_r0 = r0; db->pw_r1 = r1; return YH_OK; }
+    h_rowptr[N] = (u32)acc;
+    if (acc != P) { yh_set_error("posting counts do not add up (%llu of %llu)", (u64)acc, (u64)P); return YH_ERR_HIP; }
+    if (NC == 0) return done_empty();
 
-    // dense row blocks (compact rows x compact columns) of int32 counts: at most ~32 GiB, and at most 60 % of what the
-    // device has free now (other handles, other ranks sharing the GPU); halved again when the allocation still fails
-    u64 budget = 32ull << 30;
-    {
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0) budget = std::min<u64>(budget, (u64)((double)free_b * 0.6));
-        else (void)hipGetLastError();
-    }
-    u64 rows_per_block = std::max<u64>(1, budget / (NC * sizeof(u32)));
-    if (rows_per_block > c_end - c_begin) rows_per_block = c_end - c_begin;
-    const double c_relaxed = c_thresh * (1.0 - 1e-9) - 1e-300;
+    // columns per row block: what the LDS holds
+    static const bool big_lds = [] {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pair_rows), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 (int)(PAIR_COLS_BIG * sizeof(u32)));
+        if (e != hipSuccess) (void)hipGetLastError();
+        return e == hipSuccess;
+    }();
+    u32 cols = big_lds ? PAIR_COLS_BIG : PAIR_COLS_SMALL;
+    if (const char* e = yh_tune_env("YH_PAIR_COLS")) cols = std::max(64, atoi(e));  // (tests: several column blocks)
+    cols = (u32)std::min<u64>(cols, (NC + 63) / 64 * 64);
+    const u32 ncb = (u32)((NC + cols - 1) / cols);
+    if (ncb > 65535) { yh_set_error("too many column blocks"); return YH_ERR_UNSUPPORTED; }
+    const u64 rows = r1 - r0;
+    const u64 nseg = rows * ncb;
 
-    u32 *d_M = nullptr, *d_rowcnt = nullptr, *d_oi = nullptr, *d_oj = nullptr, *d_oc = nullptr;
-    u32 *d_cid = nullptr, *d_rid = nullptr;
-    u64* d_rowoff = nullptr;
-    std::vector<u32> hi, hj, hc;
+    // scratch: [records 16 P | segoff 8 nseg | cursor 8 | tab 4 (2N + 1 + NC) | segcnt 4 nseg | cursors 4 N]
+    const bool ranks = db->d_prank != nullptr;
+    const u64 b_rec = P * sizeof(uint4), b_off = nseg * sizeof(u64), b_tab = (2 * N + 1 + NC) * sizeof(u32);
+    const u64 b_cnt = nseg * sizeof(u32), b_cur = ranks ? 0 : N * sizeof(u32);
+    char* d_scr = nullptr;
+    u32 *d_oj = nullptr, *d_oc = nullptr;
     int rc = YH_OK;
 #define PW_HIP(call)                                                                          \
     if (rc == YH_OK) {                                                                        \
@@ -215,86 +251,91 @@ int yh_q_pairwise(yh_db* db, double c_thresh, u64 r0, u64 r1) {
             rc = (e__ == hipErrorOutOfMemory) ? YH_ERR_OOM : YH_ERR_HIP;                      \
         }                                                                                     \
     }
-    for (;;) {
-        const hipError_t em = hipMalloc((void**)&d_M, rows_per_block * NC * sizeof(u32));
-        if (em == hipSuccess) break;
-        (void)hipGetLastError();
-        d_M = nullptr;
-        if (em != hipErrorOutOfMemory || rows_per_block == 1) {
-            yh_set_error("hipMalloc of the %llu-row count block failed: %s", (u64)rows_per_block, hipGetErrorString(em));
-            rc = (em == hipErrorOutOfMemory) ? YH_ERR_OOM : YH_ERR_HIP;
-            break;
-        }
-        rows_per_block = (rows_per_block + 1) / 2;
-    }
-    PW_HIP(hipMalloc((void**)&d_rowcnt, rows_per_block * sizeof(u32)));
-    PW_HIP(hipMalloc((void**)&d_rowoff, (rows_per_block + 1) * sizeof(u64)));
-    PW_HIP(hipMalloc((void**)&d_cid, N * sizeof(u32)));
-    PW_HIP(hipMalloc((void**)&d_rid, NC * sizeof(u32)));
-    PW_HIP(hipMemcpyAsync(d_cid, h_cid.data(), N * sizeof(u32), hipMemcpyHostToDevice, st));
-    PW_HIP(hipMemcpyAsync(d_rid, h_rid.data(), NC * sizeof(u32), hipMemcpyHostToDevice, st));
+    PW_HIP(hipMalloc((void**)&d_scr, b_rec + b_off + 8 + b_tab + b_cnt + b_cur + 64));
+    uint4* d_rrec = reinterpret_cast<uint4*>(d_scr);
+    u64* d_segoff = reinterpret_cast<u64*>(d_scr + b_rec);
+    unsigned long long* d_cursor = reinterpret_cast<unsigned long long*>(d_scr + b_rec + b_off);
+    u32* d_tab = reinterpret_cast<u32*>(d_scr + b_rec + b_off + 8);
+    u32* d_rowptr = d_tab;
+    u32* d_cid = d_tab + N + 1;
+    u32* d_rid = d_tab + 2 * N + 1;
+    u32* d_segcnt = d_tab + (2 * N + 1 + NC);
+    u32* d_cur = d_segcnt + nseg;
+    PW_HIP(hipMemcpyAsync(d_tab, h_tab.data(), b_tab, hipMemcpyHostToDevice, st));
+    if (!ranks) PW_HIP(hipMemsetAsync(d_cur, 0, b_cur, st));
+    // the survivors: room for a million to begin with; a run that finds more is repeated with what it counted
+    u64 cap = std::min<u64>(NC * (NC - 1), 1u << 20);
+    cap = std::max<u64>(cap, 1);
+    PW_HIP(hipMalloc((void**)&d_oj, cap * sizeof(u32)));
+    PW_HIP(hipMalloc((void**)&d_oc, cap * sizeof(u32)));
+    const double c_relaxed = c_thresh * (1.0 - 1e-9) - 1e-300;
+    std::vector<u32> h_segcnt(nseg);
+    std::vector<u64> h_segoff(nseg);
+    unsigned long long n_out = 0;
     yh_ring_record_begin(db, db->ev_pair);
-    for (u64 b0 = c_begin; b0 < c_end && rc == YH_OK; b0 += rows_per_block) {
-        const u64 b1 = std::min(c_end, b0 + rows_per_block);
-        const u64 rows = b1 - b0;
-        PW_HIP(hipMemsetAsync(d_M, 0, rows * NC * sizeof(u32), st));
-        if (rc == YH_OK && db->n_postings) {
-            k_pair_accum<<<grid_for(db->n_postings, 256, 1u << 20), 256, 0, st>>>(db->n_postings, db->d_pr, db->d_pg,
-                                                                                  db->d_po, d_cid, b0, b1, NC, d_M);
-        }
-        if (rc == YH_OK) {
-            k_pair_count<<<grid_for(rows * WAVE, 256, 8192), 256, 0, st>>>(d_M, b0, b1, NC, d_rid, db->d_sizes, c_relaxed,
-                                                                           d_rowcnt);
-            k_scan_u32_to_u64<<<1, 1024, 0, st>>>(d_rowcnt, rows, d_rowoff);
+    if (rc == YH_OK)
+        k_pair_transpose<<<grid_for(P, 256, 1u << 20), 256, 0, st>>>(P, db->d_pr, db->d_pg, db->d_po, d_rowptr, db->d_prank, d_cur,
+                                                                     d_rrec);
+    for (int attempt = 0; attempt < 2 && rc == YH_OK; ++attempt) {
+        PW_HIP(hipMemsetAsync(d_cursor, 0, 8, st));
+        PairRows q{d_rrec, d_rowptr, db->d_pr, d_cid, d_rid, db->d_sizes, 0, 0, (u32)NC, cols, c_relaxed,
+                   d_segcnt, d_segoff, d_cursor, cap, d_oj, d_oc};
+        for (u64 b0 = 0; b0 < rows && rc == YH_OK; b0 += 1u << 23) {  // (2^31 threads per grid dimension)
+            const u64 nb = std::min<u64>(rows - b0, 1u << 23);
+            q.a0 = r0 + b0;
+            q.seg0 = b0 * ncb;
+            k_pair_rows<<<dim3((u32)nb, ncb), ROW_THREADS, cols * sizeof(u32), st>>>(q);
         }
         PW_HIP(hipGetLastError());
-        u64 n_out = 0;
-        PW_HIP(hipMemcpyAsync(&n_out, d_rowoff + rows, sizeof(u64), hipMemcpyDeviceToHost, st));
+        if (attempt == 0) yh_ring_record_end(db, db->ev_pair);
+        PW_HIP(hipMemcpyAsync(&n_out, d_cursor, 8, hipMemcpyDeviceToHost, st));
+        PW_HIP(hipMemcpyAsync(h_segcnt.data(), d_segcnt, b_cnt, hipMemcpyDeviceToHost, st));
+        PW_HIP(hipMemcpyAsync(h_segoff.data(), d_segoff, b_off, hipMemcpyDeviceToHost, st));
         PW_HIP(hipStreamSynchronize(st));
-        if (rc == YH_OK && n_out) {
-            PW_HIP(hipMalloc((void**)&d_oi, n_out * sizeof(u32)));
-            PW_HIP(hipMalloc((void**)&d_oj, n_out * sizeof(u32)));
-            PW_HIP(hipMalloc((void**)&d_oc, n_out * sizeof(u32)));
-            if (rc == YH_OK) {
-                k_pair_emit<<<grid_for(rows * WAVE, 256, 8192), 256, 0, st>>>(d_M, b0, b1, NC, d_rid, db->d_sizes,
-                                                                              c_relaxed, d_rowoff, d_oi, d_oj, d_oc);
-            }
-            PW_HIP(hipGetLastError());
-            const size_t base = hi.size();
-            hi.resize(base + n_out); hj.resize(base + n_out); hc.resize(base + n_out);
-            PW_HIP(hipMemcpyAsync(hi.data() + base, d_oi, n_out * sizeof(u32), hipMemcpyDeviceToHost, st));
-            PW_HIP(hipMemcpyAsync(hj.data() + base, d_oj, n_out * sizeof(u32), hipMemcpyDeviceToHost, st));
-            PW_HIP(hipMemcpyAsync(hc.data() + base, d_oc, n_out * sizeof(u32), hipMemcpyDeviceToHost, st));
-            PW_HIP(hipStreamSynchronize(st));
-            (void)hipFree(d_oi); (void)hipFree(d_oj); (void)hipFree(d_oc);
-            d_oi = d_oj = d_oc = nullptr;
-        }
+        if (rc != YH_OK || n_out <= cap) break;
+        if (attempt == 1) { yh_set_error("pairwise: the second pass found more survivors than the first"); rc = YH_ERR_HIP; break; }
+        (void)hipFree(d_oj); (void)hipFree(d_oc);
+        d_oj = d_oc = nullptr;
+        cap = n_out;
+        PW_HIP(hipMalloc((void**)&d_oj, cap * sizeof(u32)));
+        PW_HIP(hipMalloc((void**)&d_oc, cap * sizeof(u32)));
     }
-    yh_ring_record_end(db, db->ev_pair);
+    std::vector<u32> oj(n_out), oc(n_out);
+    if (n_out) {
+        PW_HIP(hipMemcpyAsync(oj.data(), d_oj, n_out * sizeof(u32), hipMemcpyDeviceToHost, st));
+        PW_HIP(hipMemcpyAsync(oc.data(), d_oc, n_out * sizeof(u32), hipMemcpyDeviceToHost, st));
+    }
+    std::vector<u32> hsizes(N);
+    PW_HIP(hipMemcpyAsync(hsizes.data(), db->d_sizes, N * sizeof(u32), hipMemcpyDeviceToHost, st));
+    PW_HIP(hipStreamSynchronize(st));
 #undef PW_HIP
-    (void)hipFree(d_M); (void)hipFree(d_rowcnt); (void)hipFree(d_rowoff);
-    (void)hipFree(d_oi); (void)hipFree(d_oj); (void)hipFree(d_oc);
-    (void)hipFree(d_cid); (void)hipFree(d_rid);
+    (void)hipFree(d_scr); (void)hipFree(d_oj); (void)hipFree(d_oc);
     if (rc != YH_OK) return rc;
 
-    // exact host-side filter (main.cpp:297-303): keep iff !(1.0*count/|R_i| < C)
-    std::vector<u32> hsizes(N);
-    YH_HIP(hipMemcpy(hsizes.data(), db->d_sizes, N * sizeof(u32), hipMemcpyDeviceToHost));
+    // segments in row order (columns ascend inside a segment, column blocks inside a row), through the exact host-side
+    // filter (main.cpp:297-303): keep iff !(1.0*count/|R_i| < C)
+    u32* hi = (u32*)malloc(std::max<size_t>(n_out, 1) * sizeof(u32));
+    u32* hj = (u32*)malloc(std::max<size_t>(n_out, 1) * sizeof(u32));
+    u32* hc = (u32*)malloc(std::max<size_t>(n_out, 1) * sizeof(u32));
+    if (!hi || !hj || !hc) { free(hi); free(hj); free(hc); yh_set_error("host allocation failed"); return YH_ERR_OOM; }
     size_t w = 0;
-    for (size_t k = 0; k < hi.size(); ++k) {
-        const double cij = 1.0 * hc[k] / hsizes[hi[k]];
-        if (cij < c_thresh) continue;
-        hi[w] = hi[k]; hj[w] = hj[k]; hc[w] = hc[k];
-        ++w;
+    for (u64 s = 0; s < nseg; ++s) {
+        const u32 n = h_segcnt[s];
+        if (!n) continue;
+        const u32 i = (u32)(r0 + s / ncb);
+        const u64 off = h_segoff[s];
+        if (off + n > n_out) { free(hi); free(hj); free(hc); yh_set_error("pairwise: a segment outside the output"); return YH_ERR_HIP; }
+        for (u32 e = 0; e < n; ++e) {
+            const double cij = 1.0 * oc[off + e] / hsizes[i];
+            if (cij < c_thresh) continue;
+            hi[w] = i; hj[w] = oj[off + e]; hc[w] = oc[off + e];
+            ++w;
+        }
     }
     db->pw_n = w;
-    db->h_pw_i = (u32*)malloc(std::max<size_t>(w, 1) * sizeof(u32));
-    db->h_pw_j = (u32*)malloc(std::max<size_t>(w, 1) * sizeof(u32));
-    db->h_pw_c = (u32*)malloc(std::max<size_t>(w, 1) * sizeof(u32));
-    if (!db->h_pw_i || !db->h_pw_j || !db->h_pw_c) { yh_set_error("host allocation failed"); return YH_ERR_OOM; }
-    memcpy(db->h_pw_i, hi.data(), w * sizeof(u32));
-    memcpy(db->h_pw_j, hj.data(), w * sizeof(u32));
-    memcpy(db->h_pw_c, hc.data(), w * sizeof(u32));
+    db->h_pw_i = hi;
+    db->h_pw_j = hj;
+    db->h_pw_c = hc;
     db->pw_valid = true;
     db->pw_c = c_thresh;
     db->pw_r0 = r0;
