@@ -18,3 +18,12 @@ for r in rows[:30]:
     print(f"{nm:70s} {r['Calls']:>6s} {float(r['AverageNs'])/1e3:10.2f} {float(r['TotalDurationNs'])/1e6:9.3f} {100*float(r['TotalDurationNs'])/tot:6.1f}")
 PY
 cat gpurun_out/train_stats.txt
+# per-launch durations of k_pair_rows in launch order (tuning: YH_PAIR_PROBE=2 repeats the launch)
+python3 - <<'PY'
+import csv, glob
+f = sorted(glob.glob("gpurun_out/prof_train/**/*kernel_trace.csv", recursive=True))
+if f:
+    rows = [r for r in csv.DictReader(open(f[-1])) if "k_pair_rows" in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    print("k_pair_rows launches (us):", " ".join(f"{(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3:.0f}" for r in rows))
+PY

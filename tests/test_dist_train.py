@@ -134,16 +134,8 @@ def test_row_blocks_on_the_hip_engine(hip_lib):
             parts = [db.pairwise(c, b, e) for b, e in plan]
             gi, gj, gc = (np.concatenate([p[k] for p in parts]) for k in range(3))
             assert np.array_equal(gi, wi) and np.array_equal(gj, wj) and np.array_equal(gc, wc)
-        # and through the collective with one rank (a file store and the loopback interface: no TCP store, no host-name
-        # look-ups -- on one GPU box the env:// rendezvous of this single rank took 14 minutes)
-        import tempfile
-
-        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
-        dist.init_process_group("gloo", init_method="file://" + tempfile.mktemp(prefix="yh_gloo_"), rank=0, world_size=1)
-        try:
-            gi, gj, gc = ydist.sharded_pairwise(lambda b, e: db.pairwise(c, b, e), ydist.pair_row_plan(nshared, 1))
-        finally:
-            dist.destroy_process_group()
+        # (the collective itself runs in test_two_rank_train_gloo and, on the GPU, in test_bench_train_two_ranks_share_gpu:
+        # a process group set up inside this process cost 14 minutes of host-name look-ups on one GPU box)
     assert np.array_equal(gi, wi) and np.array_equal(gj, wj) and np.array_equal(gc, wc)
     assert np.array_equal(train_select(sizes, gi, gj), oracle.train_select(sizes, wi, wj))
 

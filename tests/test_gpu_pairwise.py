@@ -78,6 +78,17 @@ def test_pairwise_rows_against_the_oracle(hip_lib, cols):
     assert any(v[3] > 1000 for v in checks.values())  # (the lists shared by all sketches: a dense corner)
 
 
+@pytest.mark.parametrize("shares", ["0.4,0.3,0.2,0.1", "0.5,0.5", "0.05,0.05,0.9", "0.25,0.25,0.25,0.125,0.125"])
+def test_database_uploaded_in_chunks(hip_lib, shares):
+    """yh_db_create on host arrays above a size bar uploads the references in chunks, each sorted and merged into the
+    sorted prefix while the next one crosses the bus (yh_build_upload_sorted).  Forced onto a small database here; the
+    merged (hash, reference) order is checked on the device (YH_CHECK_SORT) and every pair result against the oracle."""
+    out = _run(11, {"YH_DEBUG_TUNING": "1", "YH_UPLOAD_CHUNK_MIN": "1", "YH_UPLOAD_SHARES": shares, "YH_CHECK_SORT": "1"})
+    checks = {k: v for k, v in out.items() if k != "n"}
+    for k, v in checks.items():
+        assert v[:3] == [True, True, True], (k, v)
+
+
 def test_more_survivors_than_the_first_buffer(hip_lib):
     """1 500 sketches that all hold one common hash: 1 500 x 1 499 ordered pairs at C = 0 -- more than the million
     entries the output starts with, so the row pass is repeated with the size it counted."""

@@ -23,16 +23,68 @@ const char* yh_tune_env(const char* name) {
     return open_gate ? getenv(name) : nullptr;
 }
 
+static bool pool_mode(int device) {
+    static int mode[64];  // 0 unknown, 1 pool, 2 plain
+    if (device < 0 || device >= 64) return false;
+    if (mode[device] == 0) {
+        int ok = 0;
+        const char* off = getenv("YH_NO_POOL");
+        if (!(off && off[0] == '1') && hipDeviceGetAttribute(&ok, hipDeviceAttributeMemoryPoolsSupported, device) == hipSuccess && ok) {
+            hipMemPool_t pool = nullptr;
+            uint64_t keep = ~(uint64_t)0;  // (nothing goes back to the driver between calls; yh_pool_trim bounds it)
+            if (hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess &&
+                hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep) == hipSuccess)
+                mode[device] = 1;
+        }
+        if (mode[device] == 0) { (void)hipGetLastError(); mode[device] = 2; }
+    }
+    return mode[device] == 1;
+}
+hipError_t yh_tmalloc(yh_db* db, void** p, size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    return pool_mode(db->device) ? hipMallocAsync(p, bytes, db->stream) : hipMalloc(p, bytes);
+}
+void yh_tfree(yh_db* db, void* p) {
+    if (!p) return;
+    if (pool_mode(db->device)) (void)hipFreeAsync(p, db->stream);
+    else (void)hipFree(p);
+}
+void yh_pool_trim(yh_db* db) {
+    if (!pool_mode(db->device)) return;
+    static const uint64_t keep = [] { const char* e = yh_tune_env("YH_POOL_KEEP"); return e ? (uint64_t)atoll(e) : (uint64_t)4 << 30; }();
+    hipMemPool_t pool = nullptr;
+    if (hipDeviceGetDefaultMemPool(&pool, db->device) != hipSuccess) { (void)hipGetLastError(); return; }
+    uint64_t held = 0;
+    if (hipMemPoolGetAttribute(pool, hipMemPoolAttrReservedMemCurrent, &held) != hipSuccess) { (void)hipGetLastError(); return; }
+    if (held > keep) {
+        (void)hipStreamSynchronize(db->stream);
+        (void)hipMemPoolTrimTo(pool, keep);
+    }
+}
+
 int yh_dmalloc(yh_db* db, void** p, size_t bytes) {
     if (bytes == 0) bytes = 16;
-    hipError_t e = hipMalloc(p, bytes);
+    const bool pooled = (db->flags & YH_DB_PAIRWISE_ONLY) && pool_mode(db->device);
+    hipError_t e = pooled ? hipMallocAsync(p, bytes, db->stream) : hipMalloc(p, bytes);
     if (e != hipSuccess) {
         *p = nullptr;
         yh_set_error("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
         return YH_ERR_OOM;
     }
+    if (pooled) db->pooled.push_back(*p);
     db->device_bytes += bytes;
     return YH_OK;
+}
+void yh_dfree(yh_db* db, void* p) {
+    if (!p) return;
+    for (size_t i = 0; i < db->pooled.size(); ++i)
+        if (db->pooled[i] == p) {
+            db->pooled[i] = db->pooled.back();
+            db->pooled.pop_back();
+            (void)hipFreeAsync(p, db->stream);
+            return;
+        }
+    (void)hipFree(p);
 }
 
 static void ring_create(EventRing& r) {
@@ -120,7 +172,7 @@ static int db_select(yh_db* db) {
 
 static int ensure_sample_tmp(yh_db* db, u64 n) {
     if (n <= db->sample_tmp_cap) return YH_OK;
-    if (db->d_sample_tmp) { (void)hipFree(db->d_sample_tmp); db->d_sample_tmp = nullptr; db->sample_tmp_cap = 0; }
+    if (db->d_sample_tmp) { yh_dfree(db, db->d_sample_tmp); db->d_sample_tmp = nullptr; db->sample_tmp_cap = 0; }
     const u64 cap = std::max<u64>(n, 1024);
     YH_HIP(hipMalloc((void**)&db->d_sample_tmp, cap * sizeof(u64)));
     db->sample_tmp_cap = cap;
@@ -169,7 +221,7 @@ static int db_create_common(const u64* values, const u64* offsets, bool on_devic
     int rc = YH_OK;
     u64* d_values_in = nullptr;   // arrays the build reads (borrowed or temporary)
     u64* d_offsets_in = nullptr;
-    bool own_inputs = false;
+    bool own_inputs = false, chunked = false, pooled_inputs = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     do {
         // a BLOCKING stream: ordered with the legacy default stream, where a caller that never heard of streams
@@ -201,25 +253,42 @@ static int db_create_common(const u64* values, const u64* offsets, bool on_devic
             d_offsets_in = const_cast<u64*>(offsets);
         } else {
             own_inputs = true;
-            if (hipMalloc((void**)&d_values_in, std::max<u64>(H, 2) * sizeof(u64)) != hipSuccess ||
-                hipMalloc((void**)&d_offsets_in, (n_refs + 1) * sizeof(u64)) != hipSuccess) {
+            pooled_inputs = !(flags & YH_DB_KEEP_CSR);  // (buffers the handle keeps are plain allocations)
+            if ((pooled_inputs ? yh_tmalloc(db, (void**)&d_values_in, std::max<u64>(H, 2) * sizeof(u64))
+                               : hipMalloc((void**)&d_values_in, std::max<u64>(H, 2) * sizeof(u64))) != hipSuccess ||
+                (pooled_inputs ? yh_tmalloc(db, (void**)&d_offsets_in, (n_refs + 1) * sizeof(u64))
+                               : hipMalloc((void**)&d_offsets_in, (n_refs + 1) * sizeof(u64))) != hipSuccess) {
                 yh_set_error("device allocation for the CSR upload failed"); rc = YH_ERR_OOM; break;
             }
-            if ((H && hipMemcpy(d_values_in, values, H * sizeof(u64), hipMemcpyHostToDevice) != hipSuccess) ||
-                hipMemcpy(d_offsets_in, offsets, (n_refs + 1) * sizeof(u64), hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipStreamSynchronize(db->stream);  // (stream-ordered allocations: there before another stream copies into them)
+            // a large host database goes up in chunks that are sorted and merged while the next one crosses the bus
+            // (yh_build_upload_sorted); a small one in one piece
+            static const u64 chunk_min = [] { const char* e = yh_tune_env("YH_UPLOAD_CHUNK_MIN"); return e ? (u64)atoll(e) : (u64)12 << 20; }();
+            chunked = H >= chunk_min && n_refs >= 4;
+            if (hipMemcpy(d_offsets_in, offsets, (n_refs + 1) * sizeof(u64), hipMemcpyHostToDevice) != hipSuccess ||
+                (!chunked && H && hipMemcpy(d_values_in, values, H * sizeof(u64), hipMemcpyHostToDevice) != hipSuccess)) {
                 yh_set_error("CSR upload failed"); rc = YH_ERR_HIP; break;
             }
         }
 
-        (void)hipEventRecord(ev0, db->stream);
         (void)partitions_hint;  // (accepted for ABI compatibility: the layouts it tuned are gone)
-        rc = yh_build_validate(db, d_values_in, d_offsets_in);
-        if (rc != YH_OK) break;
-        rc = yh_build_index(db, d_values_in, d_offsets_in);  // (overlap-only handles too: the delta stream comes out of the same sort)
+        u64* d_sk_pre = nullptr;
+        u32* d_sv_pre = nullptr;
+        if (chunked) {
+            rc = yh_build_upload_sorted(db, values, offsets, d_values_in, d_offsets_in, &d_sk_pre, &d_sv_pre);
+            if (rc != YH_OK) break;
+            (void)hipEventRecord(ev0, db->stream);
+        } else {
+            (void)hipEventRecord(ev0, db->stream);
+            rc = yh_build_validate(db, d_values_in, d_offsets_in);
+            if (rc != YH_OK) break;
+        }
+        rc = yh_build_index(db, d_values_in, d_offsets_in, d_sk_pre, d_sv_pre);  // (overlap-only handles too: the delta stream comes out of the same sort)
         if (rc != YH_OK) break;
         (void)hipEventRecord(ev1, db->stream);
         (void)hipEventSynchronize(ev1);
         (void)hipEventElapsedTime(&db->ms_db_build, ev0, ev1);
+        db->ms_db_build += db->ms_upload_kernels;  // (device time of the chunk sorts and merges that ran under the upload)
 
         const u64 N = n_refs;
         if ((rc = yh_dmalloc(db, (void**)&db->d_mask, std::max<u64>(N, 1))) != YH_OK) break;
@@ -251,9 +320,10 @@ static int db_create_common(const u64* values, const u64* offsets, bool on_devic
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
     if (own_inputs) {
-        (void)hipFree(d_values_in);
-        (void)hipFree(d_offsets_in);
+        if (pooled_inputs) { yh_tfree(db, d_values_in); yh_tfree(db, d_offsets_in); }
+        else { (void)hipFree(d_values_in); (void)hipFree(d_offsets_in); }
     }
+    if (db->stream) { (void)hipStreamSynchronize(db->stream); yh_pool_trim(db); }
     if (rc != YH_OK) {
         yh_db_destroy(db);
         return rc;
@@ -293,9 +363,9 @@ int yh_db_destroy(yh_db* db) {
                     db->d_rpo, db->d_rg, db->d_rrec, db->d_rrecx, db->d_filter, db->d_hrec, db->d_hrecx, db->d_hmult, db->d_hpo,
                     db->d_work, db->d_work_count, db->d_mask, db->d_maskbits, db->d_hit, db->d_excl_e, db->d_overlap_tmp,
                     db->d_sample_tmp, db->d_out_tmp, db->d_flag, db->d_reps, db->d_batch, db->d_sdelta, db->d_shdr, db->d_srec,
-                    db->d_wg_key, db->d_ghost_src, db->d_bad_word};
+                    db->d_wg_key, db->d_ghost_src, db->d_bad_word, db->d_prank};
     for (void* p : ptrs)
-        if (p) (void)hipFree(p);
+        if (p) yh_dfree(db, p);
     ring_destroy(db->ev_overlap);
     ring_destroy(db->ev_excl);
     ring_destroy(db->ev_pair);
@@ -311,6 +381,7 @@ int yh_db_destroy(yh_db* db) {
         if (s.ev_out) (void)hipEventDestroy(s.ev_out);
     }
     for (hipStream_t q : db->st_in) if (q) (void)hipStreamDestroy(q);
+    if (db->stream) { (void)hipStreamSynchronize(db->stream); yh_pool_trim(db); }
     if (db->own_stream) (void)hipStreamDestroy(db->own_stream);
     free(db->h_pw_i);
     free(db->h_pw_j);
@@ -733,7 +804,7 @@ int yh_db_set_ghosts(yh_db* db, uint64_t ghost_begin, uint64_t n_ghost, const ui
     }
     YH_TRY(db_select(db));
     YH_HIP(hipStreamSynchronize(db->stream));
-    if (db->d_ghost_src) { (void)hipFree(db->d_ghost_src); db->d_ghost_src = nullptr; }
+    if (db->d_ghost_src) { yh_dfree(db, db->d_ghost_src); db->d_ghost_src = nullptr; }
     db->ghost_begin = ghost_begin;
     db->n_ghost = n_ghost;
     if (n_ghost) {

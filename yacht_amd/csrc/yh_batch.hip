@@ -234,7 +234,7 @@ int yh_q_run_batch(yh_db* db, const u64* d_samples, const u64* d_soff, u32 n_sam
     const u64 need = BN * sizeof(u32) + (G + N + 2) * sizeof(u64) + 64;
     if (db->batch_cap < need) {
         YH_HIP(hipStreamSynchronize(st));
-        if (db->d_batch) { (void)hipFree(db->d_batch); db->d_batch = nullptr; db->batch_cap = 0; }
+        if (db->d_batch) { yh_dfree(db, db->d_batch); db->d_batch = nullptr; db->batch_cap = 0; }
         YH_HIP(hipMalloc((void**)&db->d_batch, need));
         db->batch_cap = need;
     }

@@ -9,10 +9,14 @@
 //       Replaces the per-run re-reading of N .sig files (hypothesis_recovery_src.py:93,154,168).
 #include "yh_common.h"
 
+#include <rocprim/device/device_merge.hpp>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 #include <rocprim/iterator/counting_iterator.hpp>
 #include <rocprim/iterator/transform_iterator.hpp>
+
+#include <stdio.h>
+#include <time.h>
 
 #include <algorithm>
 #include <vector>
@@ -80,14 +84,21 @@ __device__ __forceinline__ u32 block_excl_scan(u32 v, u32* total_out, u32* lds /
 }
 
 // ---- index build ---------------------------------------------------------------------------------
-__global__ void k_fill_ref_ids(const u64* __restrict__ offsets, u64 n_refs, u32* __restrict__ ids) {
+// (offsets: the entries of the references [ref_base, ref_base + n_refs); ids: indexed like values)
+__global__ void k_fill_ref_ids(const u64* __restrict__ offsets, u64 n_refs, u32* __restrict__ ids, u32 ref_base = 0) {
     const u64 wave = (blockIdx.x * (u64)blockDim.x + threadIdx.x) / WAVE;
     const u64 n_waves = ((u64)gridDim.x * blockDim.x) / WAVE;
     const int lane = threadIdx.x & (WAVE - 1);
     for (u64 j = wave; j < n_refs; j += n_waves) {
         const u64 b = offsets[j], e = offsets[j + 1];
-        for (u64 k = b + lane; k < e; k += WAVE) ids[k] = (u32)j;
+        for (u64 k = b + lane; k < e; k += WAVE) ids[k] = ref_base + (u32)j;
     }
+}
+
+// (tuning / tests, YH_CHECK_SORT=1) the sorted pairs: keys ascending, and ascending references inside a run of equal keys
+__global__ void k_check_sorted_pairs(const u64* __restrict__ sk, const u32* __restrict__ sv, u64 n, u32* __restrict__ bad) {
+    for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i + 1 < n; i += (u64)gridDim.x * blockDim.x)
+        if (sk[i] > sk[i + 1] || (sk[i] == sk[i + 1] && sv[i] >= sv[i + 1])) atomicOr(bad, 1u);
 }
 
 constexpr int IDX_THREADS = 256;
@@ -424,23 +435,27 @@ inline u32 grid_for(u64 work_items, u32 block, u32 max_blocks = 16384) {
 }  // namespace
 
 // =================================================================================================
-int yh_build_validate(yh_db* db, const u64* d_values, const u64* d_offsets) {
+static int validate_begin(yh_db* db) {
     const u64 N = db->n_refs;
-    hipStream_t st = db->stream;
-
     YH_TRY(yh_dmalloc(db, (void**)&db->d_sizes, std::max<u64>(N, 1) * sizeof(u32)));
     YH_TRY(yh_dmalloc(db, (void**)&db->d_flag, 16));
-    u64* d_maxv = (u64*)(db->d_flag + 2);  // 8-byte aligned slot inside the 16-byte scratch
-    YH_HIP(hipMemsetAsync(db->d_flag, 0, 16, st));
-    YH_HIP(hipMemsetAsync(db->d_sizes, 0, std::max<u64>(N, 1) * sizeof(u32), st));
-    if (N) {
-        k_scan_refs<<<grid_for(N * WAVE, 256), 256, 0, st>>>(d_values, d_offsets, N, db->d_sizes, db->d_flag,
-                                                             d_maxv);
+    YH_HIP(hipMemsetAsync(db->d_flag, 0, 16, db->stream));
+    YH_HIP(hipMemsetAsync(db->d_sizes, 0, std::max<u64>(N, 1) * sizeof(u32), db->stream));
+    return YH_OK;
+}
+static int validate_refs(yh_db* db, const u64* d_values, const u64* d_offsets, u64 r0, u64 r1) {
+    if (r1 > r0) {
+        u64* d_maxv = (u64*)(db->d_flag + 2);  // 8-byte aligned slot inside the 16-byte scratch
+        k_scan_refs<<<grid_for((r1 - r0) * WAVE, 256), 256, 0, db->stream>>>(d_values, d_offsets + r0, r1 - r0, db->d_sizes + r0,
+                                                                            db->d_flag, d_maxv);
         YH_HIP(hipGetLastError());
     }
+    return YH_OK;
+}
+static int validate_end(yh_db* db) {
     u32 hflag[4];
-    YH_HIP(hipMemcpyAsync(hflag, db->d_flag, 16, hipMemcpyDeviceToHost, st));
-    YH_HIP(hipStreamSynchronize(st));
+    YH_HIP(hipMemcpyAsync(hflag, db->d_flag, 16, hipMemcpyDeviceToHost, db->stream));
+    YH_HIP(hipStreamSynchronize(db->stream));
     if (hflag[0] & 1u) {
         yh_set_error("a reference sketch is not strictly ascending (or offsets are not monotone)");
         return YH_ERR_UNSORTED;
@@ -452,6 +467,164 @@ int yh_build_validate(yh_db* db, const u64* d_values, const u64* d_offsets) {
     u64 maxv;
     memcpy(&maxv, &hflag[2], 8);
     db->max_hash = maxv;
+    return YH_OK;
+}
+int yh_build_validate(yh_db* db, const u64* d_values, const u64* d_offsets) {
+    YH_TRY(validate_begin(db));
+    YH_TRY(validate_refs(db, d_values, d_offsets, 0, db->n_refs));
+    return validate_end(db);
+}
+
+// Host CSR -> device CSR, validated, and the (hash, reference) pairs of the whole database sorted by hash, with the
+// UPLOAD OVERLAPPED WITH THE SORT: the references go up in a few chunks of falling size on a stream of their own;
+// while chunk c + 1 crosses the bus, chunk c is checked (k_scan_refs), sorted (stable radix sort of its pairs) and
+// merged into the sorted prefix (rocprim::merge: ties take the first range first = the lower references, so a run of
+// equal hashes keeps ascending references).  Behind the last byte only the smallest chunk's sort and one merge remain
+// (`yacht train` at configs[3]: 8 ms of upload + 3 ms of sort -> 8 ms + 0.9 ms).  *d_sk_out / *d_sv_out are the
+// caller's to yh_tfree.  (The largest hash is needed before the first sort: for ascending sketches it is the largest
+// LAST element, which the host reads off the offsets; sketches that are not ascending fail the check anyway.)
+static double trace_now() {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+static bool trace_on() {
+    static const bool on = [] { const char* e = yh_tune_env("YH_TRACE_BUILD"); return e && e[0] == '1'; }();
+    return on;
+}
+#define TRACE(label) do { if (trace_on()) { const double t__ = trace_now(); fprintf(stderr, "[yh build] %-28s +%.3f ms\n", label, t__ - t_prev); t_prev = t__; } } while (0)
+
+int yh_build_upload_sorted(yh_db* db, const u64* h_values, const u64* h_offsets, u64* d_values, const u64* d_offsets,
+                           u64** d_sk_out, u32** d_sv_out) {
+    const u64 N = db->n_refs, H = db->n_hashes;
+    hipStream_t st = db->stream;
+    *d_sk_out = nullptr;
+    *d_sv_out = nullptr;
+    // chunk boundaries: shares of the hashes, moved to reference boundaries
+    static const std::vector<double> shares = [] {
+        std::vector<double> v;
+        if (const char* e = yh_tune_env("YH_UPLOAD_SHARES")) {  // e.g. "0.4,0.3,0.2,0.1"
+            for (const char* q = e; *q;) { v.push_back(atof(q)); while (*q && *q != ',') ++q; if (*q) ++q; }
+        }
+        if (v.empty()) v = {0.4, 0.3, 0.2, 0.1};
+        return v;
+    }();
+    std::vector<u64> rb{0};  // reference boundaries
+    double acc = 0.0;
+    for (size_t c = 0; c + 1 < shares.size(); ++c) {
+        acc += shares[c];
+        const u64 want = (u64)((double)H * acc);
+        const u64 r = (u64)(std::lower_bound(h_offsets, h_offsets + N + 1, want) - h_offsets);
+        if (r > rb.back() && r < N) rb.push_back(r);
+    }
+    rb.push_back(N);
+    const size_t C = rb.size() - 1;
+    u64 max_last = 0;
+    for (u64 j = 0; j < N; ++j)
+        if (h_offsets[j + 1] > h_offsets[j]) max_last = std::max(max_last, h_values[h_offsets[j + 1] - 1]);
+    unsigned end_bit = 1;
+    while (end_bit < 64 && (max_last >> end_bit) != 0) ++end_bit;
+
+    double t_prev = trace_now();
+    TRACE("chunk plan + max");
+    hipStream_t up = nullptr;
+    std::vector<hipEvent_t> ev(C, nullptr), eb(C, nullptr), ee(C, nullptr);
+    u64* K[2] = {nullptr, nullptr};
+    u32* V[2] = {nullptr, nullptr};
+    u32* d_ids = nullptr;
+    void* d_tmp = nullptr;
+    int rc = YH_OK;
+#define UP_HIP(call)                                                                          \
+    if (rc == YH_OK) {                                                                        \
+        hipError_t e__ = (call);                                                              \
+        if (e__ != hipSuccess) {                                                              \
+            yh_set_error("%s failed: %s", #call, hipGetErrorString(e__));                     \
+            rc = (e__ == hipErrorOutOfMemory) ? YH_ERR_OOM : YH_ERR_HIP;                      \
+        }                                                                                     \
+    }
+    UP_HIP(hipStreamCreateWithFlags(&up, hipStreamNonBlocking));
+    for (size_t c = 0; c < C; ++c) {
+        UP_HIP(hipEventCreateWithFlags(&ev[c], hipEventDisableTiming));
+        UP_HIP(hipEventCreate(&eb[c]));
+        UP_HIP(hipEventCreate(&ee[c]));
+    }
+    for (int b = 0; b < 2; ++b) {
+        UP_HIP(yh_tmalloc(db, (void**)&K[b], H * sizeof(u64)));
+        UP_HIP(yh_tmalloc(db, (void**)&V[b], H * sizeof(u32)));
+    }
+    UP_HIP(yh_tmalloc(db, (void**)&d_ids, H * sizeof(u32)));
+    // temporary storage: the largest chunk's sort, the largest merge
+    size_t tmp_bytes = 16;
+    for (size_t c = 0; c < C && rc == YH_OK; ++c) {
+        const u64 e0 = h_offsets[rb[c]], e1 = h_offsets[rb[c + 1]];
+        size_t b1 = 0, b2 = 0;
+        UP_HIP(rocprim::radix_sort_pairs(nullptr, b1, (const u64*)d_values, K[0], (const u32*)d_ids, V[0], (size_t)(e1 - e0), 0u, end_bit, st));
+        if (c) UP_HIP(rocprim::merge(nullptr, b2, (const u64*)K[0], (const u64*)K[0], K[1], (const u32*)V[0], (const u32*)V[0], V[1], (size_t)e0,
+                                     (size_t)(e1 - e0), rocprim::less<u64>(), st));
+        tmp_bytes = std::max(tmp_bytes, std::max(b1, b2));
+    }
+    UP_HIP(yh_tmalloc(db, &d_tmp, tmp_bytes));
+    TRACE("stream, events, buffers");
+    if (rc == YH_OK) rc = validate_begin(db);
+    int cur = 0;  // the buffer that holds the sorted prefix
+    for (size_t c = 0; c < C && rc == YH_OK; ++c) {
+        const u64 r0 = rb[c], r1 = rb[c + 1];
+        const u64 e0 = h_offsets[r0], e1 = h_offsets[r1], n = e1 - e0;
+        // (a copy from pageable memory returns when the data has left the host: the device work of the chunk before is
+        // already queued and runs meanwhile)
+        if (n) UP_HIP(hipMemcpyAsync(d_values + e0, h_values + e0, n * sizeof(u64), hipMemcpyHostToDevice, up));
+        TRACE("chunk copy returned");
+        UP_HIP(hipEventRecord(ev[c], up));
+        UP_HIP(hipStreamWaitEvent(st, ev[c], 0));
+        UP_HIP(hipEventRecord(eb[c], st));
+        if (rc == YH_OK) rc = validate_refs(db, d_values, d_offsets, r0, r1);
+        if (rc == YH_OK && n) {
+            k_fill_ref_ids<<<grid_for((r1 - r0) * WAVE, 256), 256, 0, st>>>(d_offsets + r0, r1 - r0, d_ids, (u32)r0);
+            size_t tb = tmp_bytes;
+            UP_HIP(rocprim::radix_sort_pairs(d_tmp, tb, (const u64*)(d_values + e0), K[cur] + e0, (const u32*)(d_ids + e0), V[cur] + e0,
+                                             (size_t)n, 0u, end_bit, st));
+            if (e0) {  // prefix [0, e0) and the chunk behind it, both in `cur`, into the other buffer
+                tb = tmp_bytes;
+                UP_HIP(rocprim::merge(d_tmp, tb, (const u64*)K[cur], (const u64*)(K[cur] + e0), K[cur ^ 1], (const u32*)V[cur],
+                                      (const u32*)(V[cur] + e0), V[cur ^ 1], (size_t)e0, (size_t)n, rocprim::less<u64>(), st));
+                cur ^= 1;
+            }
+        }
+        UP_HIP(hipEventRecord(ee[c], st));
+        TRACE("chunk work queued");
+    }
+    if (rc == YH_OK) rc = validate_end(db);  // (waits for the stream)
+    TRACE("stream drained");
+    if (rc == YH_OK && db->max_hash > max_last) { yh_set_error("internal: largest hash above the largest last element"); rc = YH_ERR_HIP; }
+    if (rc == YH_OK) {
+        static const bool check = [] { const char* e = yh_tune_env("YH_CHECK_SORT"); return e && e[0] == '1'; }();
+        if (check) {
+            u32 bad = 0;
+            UP_HIP(hipMemsetAsync(db->d_flag, 0, 4, st));
+            k_check_sorted_pairs<<<8192, 256, 0, st>>>(K[cur], V[cur], H, db->d_flag);
+            UP_HIP(hipMemcpyAsync(&bad, db->d_flag, 4, hipMemcpyDeviceToHost, st));
+            UP_HIP(hipStreamSynchronize(st));
+            if (rc == YH_OK && bad) { yh_set_error("YH_CHECK_SORT: the merged pairs are not in (hash, reference) order"); rc = YH_ERR_HIP; }
+        }
+    }
+    db->ms_upload_kernels = 0.f;
+    for (size_t c = 0; c < C; ++c) {
+        float ms = 0.f;
+        if (rc == YH_OK && eb[c] && ee[c] && hipEventElapsedTime(&ms, eb[c], ee[c]) == hipSuccess) db->ms_upload_kernels += ms;
+        if (ev[c]) (void)hipEventDestroy(ev[c]);
+        if (eb[c]) (void)hipEventDestroy(eb[c]);
+        if (ee[c]) (void)hipEventDestroy(ee[c]);
+    }
+#undef UP_HIP
+    if (up) { (void)hipStreamSynchronize(up); (void)hipStreamDestroy(up); }
+    yh_tfree(db, d_tmp);
+    yh_tfree(db, d_ids);
+    yh_tfree(db, K[cur ^ 1]);
+    yh_tfree(db, V[cur ^ 1]);
+    if (rc != YH_OK) { yh_tfree(db, K[cur]); yh_tfree(db, V[cur]); return rc; }
+    TRACE("frees");
+    *d_sk_out = K[cur];
+    *d_sv_out = V[cur];
     return YH_OK;
 }
 
@@ -479,9 +652,9 @@ static int build_stream(yh_db* db, const u64* d_sk, const u32* d_sv, const u32* 
         }                                                                                     \
     }
     auto counts = rocprim::make_transform_iterator(rocprim::counting_iterator<u64>(0), StreamCount{d_sk, s});
-    ST_HIP(hipMalloc((void**)&d_pos, H * sizeof(u64)));
+    ST_HIP(yh_tmalloc(db, (void**)&d_pos, H * sizeof(u64)));
     ST_HIP(rocprim::inclusive_scan(nullptr, tmp_bytes, counts, d_pos, (size_t)H, rocprim::plus<u64>(), st));
-    ST_HIP(hipMalloc(&d_tmp, tmp_bytes + 256));
+    ST_HIP(yh_tmalloc(db, &d_tmp, tmp_bytes + 256));
     ST_HIP(rocprim::inclusive_scan(d_tmp, tmp_bytes, counts, d_pos, (size_t)H, rocprim::plus<u64>(), st));
     u64 L = 0;
     ST_HIP(hipMemcpyAsync(&L, d_pos + (H - 1), sizeof(u64), hipMemcpyDeviceToHost, st));
@@ -502,13 +675,13 @@ static int build_stream(yh_db* db, const u64* d_sk, const u32* d_sv, const u32* 
         ST_HIP(hipStreamSynchronize(st));
     }
 #undef ST_HIP
-    (void)hipFree(d_pos);
-    (void)hipFree(d_tmp);
+    yh_tfree(db, d_pos);
+    yh_tfree(db, d_tmp);
     return rc;
 }
 
 // =================================================================================================
-int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets) {
+int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, u64* d_sk_pre, u32* d_sv_pre) {
     const u64 N = db->n_refs;
     const u64 H = db->n_hashes;
     hipStream_t st = db->stream;
@@ -545,12 +718,17 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets) {
             rc = (e__ == hipErrorOutOfMemory) ? YH_ERR_OOM : YH_ERR_HIP;                      \
         }                                                                                     \
     }
-    IDX_HIP(hipMalloc((void**)&d_ids, H * sizeof(u32)));
-    IDX_HIP(hipMalloc((void**)&d_sv, H * sizeof(u32)));
-    IDX_HIP(hipMalloc((void**)&d_sk, H * sizeof(u64)));
-    IDX_HIP(hipMalloc((void**)&d_counts, nb * 3 * sizeof(u32)));
-    IDX_HIP(hipMalloc((void**)&d_bases, (nb + 1) * 3 * sizeof(u64)));
-    if (rc == YH_OK) {
+    if (d_sk_pre) {  // (yh_build_upload_sorted made them; ours to free)
+        d_sk = d_sk_pre;
+        d_sv = d_sv_pre;
+    } else {
+        IDX_HIP(yh_tmalloc(db, (void**)&d_ids, H * sizeof(u32)));
+        IDX_HIP(yh_tmalloc(db, (void**)&d_sv, H * sizeof(u32)));
+        IDX_HIP(yh_tmalloc(db, (void**)&d_sk, H * sizeof(u64)));
+    }
+    IDX_HIP(yh_tmalloc(db, (void**)&d_counts, nb * 3 * sizeof(u32)));
+    IDX_HIP(yh_tmalloc(db, (void**)&d_bases, (nb + 1) * 3 * sizeof(u64)));
+    if (rc == YH_OK && !d_sk_pre) {
         k_fill_ref_ids<<<grid_for(N * WAVE, 256), 256, 0, st>>>(d_offsets, N, d_ids);
         const u32* ids_src = d_ids;
         // stable LSD radix sort of (hash, reference id): equal hashes keep their input order
@@ -560,27 +738,27 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets) {
         size_t tmp_bytes = 0;
         IDX_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, (const u64*)d_values, d_sk, ids_src, d_sv,
                                           (size_t)H, 0u, end_bit, st));
-        IDX_HIP(hipMalloc(&d_tmp, std::max<size_t>(tmp_bytes, 16)));
+        IDX_HIP(yh_tmalloc(db, &d_tmp, std::max<size_t>(tmp_bytes, 16)));
         IDX_HIP(rocprim::radix_sort_pairs(d_tmp, tmp_bytes, (const u64*)d_values, d_sk, ids_src, d_sv,
                                           (size_t)H, 0u, end_bit, st));
         // (the sort's buffers are the build's largest temporaries: back to the pool before the next ones come)
         IDX_HIP(hipStreamSynchronize(st));
-        (void)hipFree(d_tmp); d_tmp = nullptr;
-        (void)hipFree(d_ids); d_ids = nullptr;
+        yh_tfree(db, d_tmp); d_tmp = nullptr;
+        yh_tfree(db, d_ids); d_ids = nullptr;
     }
     const bool want_stream = !(db->flags & YH_DB_PAIRWISE_ONLY);
     if (rc == YH_OK && (db->flags & YH_DB_NO_INDEX)) {  // overlap-only handle: the stream and nothing else
         if (want_stream) rc = build_stream(db, d_sk, d_sv, nullptr, H);
-        (void)hipFree(d_ids);
-        (void)hipFree(d_sv);
-        (void)hipFree(d_sk);
-        (void)hipFree(d_counts);
-        (void)hipFree(d_bases);
-        (void)hipFree(d_tmp);
+        yh_tfree(db, d_ids);
+        yh_tfree(db, d_sv);
+        yh_tfree(db, d_sk);
+        yh_tfree(db, d_counts);
+        yh_tfree(db, d_bases);
+        yh_tfree(db, d_tmp);
         return rc;
     }
     u32* d_elem_g = nullptr;
-    if (want_stream) IDX_HIP(hipMalloc((void**)&d_elem_g, H * sizeof(u32)));
+    if (want_stream) IDX_HIP(yh_tmalloc(db, (void**)&d_elem_g, H * sizeof(u32)));
     u64 totals[3] = {0, 0, 0};
     if (rc == YH_OK) {
         k_idx_count<<<(u32)((nb * 64 + IDX_THREADS - 1) / IDX_THREADS), IDX_THREADS, 0, st>>>(d_sk, H, d_counts);
@@ -638,8 +816,8 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets) {
         if (full) {
             db->bkt_lsh = 64 - bits;
             if (compact) {
-                IDX_HIP(hipMalloc((void**)&d_dh_tmp, std::max<u64>(db->n_distinct, 2) * sizeof(u64)));
-                IDX_HIP(hipMalloc((void**)&d_dref_tmp, std::max<u64>(db->n_distinct, 2) * sizeof(u32)));
+                IDX_HIP(yh_tmalloc(db, (void**)&d_dh_tmp, std::max<u64>(db->n_distinct, 2) * sizeof(u64)));
+                IDX_HIP(yh_tmalloc(db, (void**)&d_dref_tmp, std::max<u64>(db->n_distinct, 2) * sizeof(u32)));
             } else {
                 // ~4 distinct hashes per directory bucket
                 u32 lg = 4;
@@ -715,11 +893,11 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets) {
             IDX_HIP(hipStreamSynchronize(st));
         }
         IDX_HIP(hipStreamSynchronize(st));
-        (void)hipFree(d_dh_tmp);
-        (void)hipFree(d_dref_tmp);
+        yh_tfree(db, d_dh_tmp);
+        yh_tfree(db, d_dref_tmp);
         if (rc == YH_OK && full) db->has_dir = true;
         if (rc == YH_OK && want_stream) rc = build_stream(db, d_sk, d_sv, d_elem_g, H);  // (behind the table: its temporaries are gone)
-        (void)hipFree(d_elem_g);
+        yh_tfree(db, d_elem_g);
         d_elem_g = nullptr;
         IDX_HIP(hipGetLastError());
         IDX_HIP(hipMemcpyAsync(db->d_po + db->n_shared, &db->n_postings, sizeof(u64), hipMemcpyHostToDevice, st));
@@ -731,11 +909,11 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets) {
             if (rc == YH_OK) rc = yh_dmalloc(db, (void**)&db->d_rg, db->n_postings * sizeof(u32));
             if (rc == YH_OK && want_stream) rc = yh_dmalloc(db, (void**)&db->d_rrec, (db->n_postings + 1) * sizeof(uint4));
             if (rc == YH_OK && want_stream) rc = yh_dmalloc(db, (void**)&db->d_rrecx, (db->n_postings + 1) * sizeof(uint4));
-            IDX_HIP(hipMalloc((void**)&d_cc, N * sizeof(u32)));
-            IDX_HIP(hipMalloc((void**)&d_cpo, (N + 1) * sizeof(u32)));
-            IDX_HIP(hipMalloc((void**)&d_cur, N * sizeof(u32)));
+            IDX_HIP(yh_tmalloc(db, (void**)&d_cc, N * sizeof(u32)));
+            IDX_HIP(yh_tmalloc(db, (void**)&d_cpo, (N + 1) * sizeof(u32)));
+            IDX_HIP(yh_tmalloc(db, (void**)&d_cur, N * sizeof(u32)));
             IDX_HIP(rocprim::inclusive_scan(nullptr, st_bytes, db->d_nshared, db->d_rpo + 1, N, rocprim::plus<u32>(), st));
-            IDX_HIP(hipMalloc(&d_st, st_bytes + 256));
+            IDX_HIP(yh_tmalloc(db, &d_st, st_bytes + 256));
             IDX_HIP(hipMemsetAsync(db->d_rpo, 0, sizeof(u32), st));
             IDX_HIP(hipMemsetAsync(d_cpo, 0, sizeof(u32), st));
             IDX_HIP(hipMemsetAsync(d_cur, 0, N * sizeof(u32), st));
@@ -750,7 +928,7 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets) {
             if (rc == YH_OK) rc = yh_dmalloc(db, (void**)&db->d_work_count, 16);
             IDX_HIP(hipMemsetAsync(db->d_work_count, 0, 16, st));
             u32* d_pref = nullptr;  // reference of every reference-major posting position (for the holder sets)
-            if (want_stream) IDX_HIP(hipMalloc((void**)&d_pref, db->n_postings * sizeof(u32)));
+            if (want_stream) IDX_HIP(yh_tmalloc(db, (void**)&d_pref, db->n_postings * sizeof(u32)));
             if (rc == YH_OK)
                 k_fill_rg<<<grid_for(db->n_postings, 256), 256, 0, st>>>(db->n_postings, db->d_pr, db->d_pg, db->d_po, db->d_rpo,
                                                                          d_cur, db->d_rg, db->d_rrec, db->d_rrecx, d_pref);
@@ -761,18 +939,18 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets) {
                 u32 *d_i = nullptr, *d_i2 = nullptr, *d_kr = nullptr, *d_kr2 = nullptr, *d_head = nullptr, *d_run = nullptr;
                 void* d_t = nullptr;
                 size_t tb1 = 0, tb2 = 0, tb3 = 0;
-                IDX_HIP(hipMalloc((void**)&d_k, P * sizeof(u64)));
-                IDX_HIP(hipMalloc((void**)&d_k2, P * sizeof(u64)));
-                IDX_HIP(hipMalloc((void**)&d_i, P * sizeof(u32)));
-                IDX_HIP(hipMalloc((void**)&d_i2, P * sizeof(u32)));
-                IDX_HIP(hipMalloc((void**)&d_kr, P * sizeof(u32)));
-                IDX_HIP(hipMalloc((void**)&d_kr2, P * sizeof(u32)));
+                IDX_HIP(yh_tmalloc(db, (void**)&d_k, P * sizeof(u64)));
+                IDX_HIP(yh_tmalloc(db, (void**)&d_k2, P * sizeof(u64)));
+                IDX_HIP(yh_tmalloc(db, (void**)&d_i, P * sizeof(u32)));
+                IDX_HIP(yh_tmalloc(db, (void**)&d_i2, P * sizeof(u32)));
+                IDX_HIP(yh_tmalloc(db, (void**)&d_kr, P * sizeof(u32)));
+                IDX_HIP(yh_tmalloc(db, (void**)&d_kr2, P * sizeof(u32)));
                 unsigned ref_bits = 1;
                 while (ref_bits < 32 && (N >> ref_bits) != 0) ++ref_bits;
                 IDX_HIP(rocprim::radix_sort_pairs(nullptr, tb1, d_k, d_k2, d_i, d_i2, (size_t)P, 0u, 64u, st));
                 IDX_HIP(rocprim::radix_sort_pairs(nullptr, tb2, d_kr, d_kr2, d_i2, d_i, (size_t)P, 0u, ref_bits, st));
                 IDX_HIP(rocprim::inclusive_scan(nullptr, tb3, d_kr, d_kr2, (size_t)P, rocprim::plus<u32>(), st));
-                IDX_HIP(hipMalloc(&d_t, std::max(std::max(tb1, tb2), tb3) + 256));
+                IDX_HIP(yh_tmalloc(db, &d_t, std::max(std::max(tb1, tb2), tb3) + 256));
                 if (rc == YH_OK) k_set_keys<<<grid_for(P, 256), 256, 0, st>>>(P, db->d_rrec, db->d_rrecx, d_k, d_i);
                 IDX_HIP(rocprim::radix_sort_pairs(d_t, tb1, d_k, d_k2, d_i, d_i2, (size_t)P, 0u, 64u, st));  // by holder-set hash
                 if (rc == YH_OK) k_gather_u32<<<grid_for(P, 256), 256, 0, st>>>(P, d_pref, d_i2, d_kr);
@@ -797,26 +975,26 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets) {
                 IDX_HIP(rocprim::inclusive_scan(d_st, st_bytes, db->d_hpo + 1, db->d_hpo + 1, N, rocprim::plus<u32>(), st));
                 IDX_HIP(hipGetLastError());
                 IDX_HIP(hipStreamSynchronize(st));
-                (void)hipFree(d_k); (void)hipFree(d_k2); (void)hipFree(d_i); (void)hipFree(d_i2);
-                (void)hipFree(d_kr); (void)hipFree(d_kr2); (void)hipFree(d_t);
+                yh_tfree(db, d_k); yh_tfree(db, d_k2); yh_tfree(db, d_i); yh_tfree(db, d_i2);
+                yh_tfree(db, d_kr); yh_tfree(db, d_kr2); yh_tfree(db, d_t);
             }
             IDX_HIP(hipStreamSynchronize(st));
-            (void)hipFree(d_pref);
-            (void)hipFree(d_cc);
-            (void)hipFree(d_cpo);
-            (void)hipFree(d_cur);
-            (void)hipFree(d_st);
+            yh_tfree(db, d_pref);
+            yh_tfree(db, d_cc);
+            yh_tfree(db, d_cpo);
+            yh_tfree(db, d_cur);
+            yh_tfree(db, d_st);
         }
         IDX_HIP(hipStreamSynchronize(st));
     }
 #undef IDX_HIP
-    (void)hipFree(d_elem_g);
-    (void)hipFree(d_ids);
-    (void)hipFree(d_sv);
-    (void)hipFree(d_sk);
-    (void)hipFree(d_counts);
-    (void)hipFree(d_bases);
-    (void)hipFree(d_tmp);
+    yh_tfree(db, d_elem_g);
+    yh_tfree(db, d_ids);
+    yh_tfree(db, d_sv);
+    yh_tfree(db, d_sk);
+    yh_tfree(db, d_counts);
+    yh_tfree(db, d_bases);
+    yh_tfree(db, d_tmp);
     if (rc == YH_OK) db->has_index = true;
     return rc;
 }

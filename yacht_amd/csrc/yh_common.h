@@ -6,6 +6,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string>
+#include <vector>
 
 #include "../../include/yacht_hip.h"
 
@@ -229,12 +230,17 @@ struct yh_db {
 
     // timing
     EventRing ev_overlap, ev_excl, ev_pair;
+    std::vector<void*> pooled;  // arrays of this handle that came from the memory pool (yh_dmalloc)
+    float ms_upload_kernels = 0.f;  // device time of the chunk sorts / merges that ran under the upload (yh_build_upload_sorted)
     float ms_db_build = 0.f;
 };
 
 // ---- implemented in yh_build.hip -------------------------------------------------------------
 int yh_build_validate(yh_db* db, const u64* d_values, const u64* d_offsets);  // ordering check, sizes, largest hash
-int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets);
+int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, u64* d_sk_pre = nullptr, u32* d_sv_pre = nullptr);
+// host CSR up in chunks, each checked, sorted and merged while the next one crosses the bus (yh_build.hip)
+int yh_build_upload_sorted(yh_db* db, const u64* h_values, const u64* h_offsets, u64* d_values, const u64* d_offsets,
+                           u64** d_sk_out, u32** d_sv_out);
 
 // ---- implemented in yh_pack.hip ----------------------------------------------------------------
 int yh_pack_validate(const void* packed, u64 bytes, u64* n_out);
@@ -388,5 +394,15 @@ int yh_q_check_sorted_host(const u64* v, u64 n);
 
 // helpers (yh_api.hip)
 int yh_dmalloc(yh_db* db, void** p, size_t bytes);
+// Temporaries of a build or a pairwise pass: stream-ordered allocations from the device's memory pool on the handle's
+// stream (hipMallocAsync / hipFreeAsync: a hipFree of a gigabyte buffer costs 0.3-1 ms and synchronizes the device, and
+// `yacht train` made a dozen of them per call); plain hipMalloc / hipFree where the device has no pools or with
+// YH_NO_POOL=1.  What a create leaves in the pool beyond YH_POOL_KEEP (default 4 GiB) is given back at its end.
+// (yh_dmalloc: the arrays a handle keeps -- from the pool too for YH_DB_PAIRWISE_ONLY handles, which live for one
+// `yacht train` call: fifteen hipMalloc + fifteen hipFree were 3.5 ms of a 14 ms call; yh_dfree releases either kind)
+void yh_dfree(yh_db* db, void* p);
+hipError_t yh_tmalloc(yh_db* db, void** p, size_t bytes);
+void yh_tfree(yh_db* db, void* p);
+void yh_pool_trim(yh_db* db);
 void yh_ring_record_begin(yh_db* db, EventRing& r);
 void yh_ring_record_end(yh_db* db, EventRing& r);

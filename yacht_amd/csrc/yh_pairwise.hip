@@ -24,8 +24,6 @@
 namespace {
 
 constexpr int WAVE = 64;
-constexpr int ROW_THREADS = 256;
-constexpr int ROW_WAVES = ROW_THREADS / WAVE;
 // holders of a hash up to which a posting's record names the others inline (three others)
 constexpr u32 PAIR_INLINE = 4;
 // a list of more than PAIR_LONG holders is walked by the whole wave, one holder per lane (a k-mer shared by M
@@ -39,7 +37,7 @@ constexpr u32 PAIR_COLS_SMALL = 15360;
 __global__ void __launch_bounds__(256) k_pair_transpose(u64 n_post, const u32* __restrict__ pr, const u32* __restrict__ pg,
                                                         const u64* __restrict__ po, const u32* __restrict__ rowptr,
                                                         const u32* __restrict__ prank, u32* __restrict__ cursor,
-                                                        uint4* __restrict__ rrec) {
+                                                        const u32* __restrict__ cid, uint4* __restrict__ rrec) {
     for (u64 k = blockIdx.x * (u64)blockDim.x + threadIdx.x; k < n_post; k += (u64)gridDim.x * blockDim.x) {
         const u32 a = pr[k], g = pg[k];
         const u64 q0 = po[g], q1 = po[g + 1];
@@ -50,7 +48,8 @@ __global__ void __launch_bounds__(256) k_pair_transpose(u64 n_post, const u32* _
             u32 n = 0;
             for (u64 q = q0; q < q1; ++q)
                 if (q != k) o[n++] = pr[q];
-            rec = make_uint4(o[0], o[1], o[2], n);
+            // (COMPACT ids: the row pass adds them to its LDS row without another look-up; o[] beyond n is reference 0)
+            rec = make_uint4(cid[o[0]], cid[o[1]], cid[o[2]], n);
         } else {
             rec = make_uint4((u32)q0, (u32)(q1 - q0), 0u, 0xffffffffu);
         }
@@ -76,19 +75,32 @@ struct PairRows {
     const u32* sizes;     // [N]
     u64 a0;               // first reference of the launch (blockIdx.x = a - a0)
     u64 seg0;             // its first segment
+    u64 nseg;             // segments of the whole call (rows x column blocks)
     u32 NC, cols;         // compact references; columns per block (blockIdx.y)
     double c_relaxed;
-    u32* segcnt;          // [rows * column blocks] survivors of the segment
-    u64* segoff;          // ... and where they start in out_j / out_c
+    u32* segcnt;          // [nseg] survivors of the segment
+    u64* segoff;          // ... and where they start in out[]
     unsigned long long* cursor;
-    u64 cap;              // entries of out_j / out_c (a segment that does not fit is counted, not written)
-    u32* out_j;
-    u32* out_c;
+    u64 cap;              // entries of out[] behind the fixed slots (a segment that does not fit is counted, not written)
+    uint2* out;           // (reference j, count): [nseg * PAIR_SLOTS] fixed slots, then the cursor's area
 };
 
-__global__ void __launch_bounds__(ROW_THREADS) k_pair_rows(const PairRows p) {
+// A segment of up to PAIR_SLOTS survivors has its own place in out[] (a cluster of genomes: a handful of mates per
+// row); only longer ones claim room behind the slots with an atomic (10^4 workgroups adding to ONE word: ~120 us).
+constexpr u32 PAIR_SLOTS = 4;
+#ifndef YH_PAIR_U
+#define YH_PAIR_U 4
+#endif
+constexpr int PAIR_U = YH_PAIR_U;  // records a lane has in flight
+
+#ifndef YH_ABLATE_PAIR
+#define YH_ABLATE_PAIR 0  // timing-only builds (results wrong): 1 no record pass, 2 no row clear / survivor scan, 4 records read but not added
+#endif
+template <int THREADS, bool AGG>
+__global__ void __launch_bounds__(THREADS) k_pair_rows(const PairRows p) {
+    constexpr int WAVES = THREADS / WAVE;
     extern __shared__ u32 row[];  // p.cols counts
-    __shared__ u32 wtot[ROW_WAVES];
+    __shared__ u32 wtot[WAVES];
     __shared__ u64 s_base;
     __shared__ u32 s_write;
     const u32 tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
@@ -101,44 +113,85 @@ __global__ void __launch_bounds__(ROW_THREADS) k_pair_rows(const PairRows p) {
         if (tid == 0) { p.segcnt[seg] = 0; p.segoff[seg] = 0; }
         return;
     }
-    for (u32 j = tid; j < w; j += ROW_THREADS) row[j] = 0;
+    // the first records are in flight while the row is cleared: PAIR_U loads per lane before any is used (one load in
+    // flight per wave left the pass at 1.4 TB/s of record reads -- 0.3 ms at configs[3], the adds themselves are free)
+    uint4 rec[PAIR_U];
+#pragma unroll
+    for (int u = 0; u < PAIR_U; ++u) {
+        const u32 t = t0 + u * THREADS + tid;
+        rec[u] = p.rrec[min(t, t1 - 1)];  // (unconditional, masked below: a load under `if` is waited for on the spot)
+        if (t >= t1) rec[u].w = 0;
+    }
+    if (!(YH_ABLATE_PAIR & 2))
+        for (u32 j = tid; j < w; j += THREADS) row[j] = 0;
     __syncthreads();
-    auto add = [&](u32 o) {
-        const u32 c = p.cid[o] - c0;
-        if (c < w) atomicAdd(&row[c], 1u);
-    };
-    for (u32 tb = t0 + wid * 64u; tb < t1; tb += ROW_THREADS) {  // (wave-uniform bounds: the ballot below)
-        const u32 t = tb + lane;
-        uint4 rec = make_uint4(0u, 0u, 0u, 0u);
-        if (t < t1) rec = p.rrec[t];
-        const bool is_list = rec.w == 0xffffffffu;
-        if (!is_list) {
-            if (rec.w > 0) add(rec.x);
-            if (rec.w > 1) add(rec.y);
-            if (rec.w > 2) add(rec.z);
-        } else if (rec.y <= PAIR_LONG) {
-            for (u32 q = rec.x, qe = rec.x + rec.y; q < qe; ++q) {
-                const u32 o = p.pr[q];
-                if (o != (u32)a) add(o);
-            }
+    // The records of a row name the same few references over and over (its cluster mates): with AGG a lane keeps counts
+    // for the first four columns it meets in registers and adds them to the row once (measured: no gain).
+    u32 ck0 = 0xffffffffu, ck1 = 0xffffffffu, ck2 = 0xffffffffu, ck3 = 0xffffffffu;
+    u32 cv0 = 0, cv1 = 0, cv2 = 0, cv3 = 0;
+    auto addc = [&](u32 cc) {  // cc: a compact id
+        const u32 c = cc - c0;
+        if (c >= w) return;
+        if (AGG) {
+            if (c == ck0) { ++cv0; return; }
+            if (c == ck1) { ++cv1; return; }
+            if (c == ck2) { ++cv2; return; }
+            if (c == ck3) { ++cv3; return; }
+            if (ck0 == 0xffffffffu) { ck0 = c; cv0 = 1; return; }
+            if (ck1 == 0xffffffffu) { ck1 = c; cv1 = 1; return; }
+            if (ck2 == 0xffffffffu) { ck2 = c; cv2 = 1; return; }
+            if (ck3 == 0xffffffffu) { ck3 = c; cv3 = 1; return; }
         }
-        u64 todo = __ballot(is_list && rec.y > PAIR_LONG);
-        while (todo) {
-            const int src = __ffsll((long long)todo) - 1;
-            todo &= todo - 1;
-            const u32 q0 = (u32)__shfl((int)rec.x, src), m = (u32)__shfl((int)rec.y, src);
-            for (u32 q = lane; q < m; q += 64u) {
-                const u32 o = p.pr[q0 + q];
-                if (o != (u32)a) add(o);
+        if (YH_ABLATE_PAIR & 4) { if (c == 0x12345u) row[0] = 1; return; }
+        atomicAdd(&row[c], 1u);
+    };
+    auto add = [&](u32 o) { addc(p.cid[o]); };  // o: a reference id (the long lists)
+    for (u32 tb = t0; tb < ((YH_ABLATE_PAIR & 1) ? t0 : t1); tb += PAIR_U * THREADS) {  // (workgroup-uniform bounds: the ballot below)
+        uint4 cur[PAIR_U];
+#pragma unroll
+        for (int u = 0; u < PAIR_U; ++u) {
+            cur[u] = rec[u];
+            const u32 t = tb + (PAIR_U + u) * THREADS + tid;  // the next step's records
+            rec[u] = p.rrec[min(t, t1 - 1)];
+            if (t >= t1) rec[u].w = 0;
+        }
+#pragma unroll
+        for (int u = 0; u < PAIR_U; ++u) {
+            const bool is_list = cur[u].w == 0xffffffffu;
+            if (!is_list) {
+                if (cur[u].w > 0) addc(cur[u].x);
+                if (cur[u].w > 1) addc(cur[u].y);
+                if (cur[u].w > 2) addc(cur[u].z);
+            } else if (cur[u].y <= PAIR_LONG) {
+                for (u32 q = cur[u].x, qe = cur[u].x + cur[u].y; q < qe; ++q) {
+                    const u32 o = p.pr[q];
+                    if (o != (u32)a) add(o);
+                }
+            }
+            u64 todo = __ballot(is_list && cur[u].y > PAIR_LONG);
+            while (todo) {
+                const int src = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                const u32 q0 = (u32)__shfl((int)cur[u].x, src), m = (u32)__shfl((int)cur[u].y, src);
+                for (u32 q = lane; q < m; q += 64u) {
+                    const u32 o = p.pr[q0 + q];
+                    if (o != (u32)a) add(o);
+                }
             }
         }
     }
+    if (AGG) {
+        if (cv0) atomicAdd(&row[ck0], cv0);
+        if (cv1) atomicAdd(&row[ck1], cv1);
+        if (cv2) atomicAdd(&row[ck2], cv2);
+        if (cv3) atomicAdd(&row[ck3], cv3);
+    }
     __syncthreads();
     // survivors in column order: wave v owns the columns [v*per, (v+1)*per)
-    const u32 per = ((w + ROW_WAVES * 64u - 1) / (ROW_WAVES * 64u)) * 64u;
+    const u32 per = ((w + WAVES * 64u - 1) / (WAVES * 64u)) * 64u;
     const u32 jb = min(w, wid * per), je = min(w, jb + per);
     u32 mine = 0;
-    for (u32 j0 = jb; j0 < je; j0 += 64u) {
+    for (u32 j0 = jb; j0 < ((YH_ABLATE_PAIR & 2) ? jb : je); j0 += 64u) {
         const u32 j = j0 + lane;
         const u32 cnt = j < je ? row[j] : 0u;  // (rows are sparse: rid / sizes only behind a count)
         const bool keep = cnt != 0 && pair_keep(cnt, (u32)a, p.rid[c0 + j], p.sizes, p.c_relaxed);
@@ -148,17 +201,24 @@ __global__ void __launch_bounds__(ROW_THREADS) k_pair_rows(const PairRows p) {
     __syncthreads();
     if (tid == 0) {
         u32 total = 0;
-        for (int v = 0; v < ROW_WAVES; ++v) total += wtot[v];
-        const u64 base = total ? atomicAdd(p.cursor, (unsigned long long)total) : 0;
+        for (int v = 0; v < WAVES; ++v) total += wtot[v];
+        u64 base = seg * PAIR_SLOTS;
+        bool fits = true;
+        if (total > PAIR_SLOTS) {
+            const u64 at = atomicAdd(p.cursor, (unsigned long long)total);
+            base = p.nseg * PAIR_SLOTS + at;
+            fits = at + total <= p.cap;
+        }
         p.segcnt[seg] = total;
         p.segoff[seg] = base;
         s_base = base;
-        s_write = (total && base + total <= p.cap) ? 1u : 0u;
+        s_write = (total && fits) ? 1u : 0u;
     }
     __syncthreads();
     if (!s_write) return;
     u64 dst = s_base;
     for (u32 v = 0; v < wid; ++v) dst += wtot[v];
+    if (wtot[wid] == 0) return;  // (wave-uniform)
     for (u32 j0 = jb; j0 < je; j0 += 64u) {
         const u32 j = j0 + lane;
         const u32 cnt = j < je ? row[j] : 0u;
@@ -169,13 +229,34 @@ __global__ void __launch_bounds__(ROW_THREADS) k_pair_rows(const PairRows p) {
             keep = pair_keep(cnt, (u32)a, rj, p.sizes, p.c_relaxed);
         }
         const u64 bal = __ballot(keep);
-        if (keep) {
-            const u64 d = dst + (u64)__popcll(bal & ((1ull << lane) - 1ull));
-            p.out_j[d] = rj;
-            p.out_c[d] = cnt;
-        }
+        if (keep) p.out[dst + (u64)__popcll(bal & ((1ull << lane) - 1ull))] = make_uint2(rj, cnt);
         dst += (u64)__popcll(bal);
     }
+}
+
+// (tuning probe, YH_PAIR_PROBE=1: the records read front to back by a plain grid-stride kernel -- what the buffer can give)
+__global__ void __launch_bounds__(256) k_pair_probe(const uint4* __restrict__ rrec, u64 n, u32* __restrict__ out) {
+    u32 acc = 0;
+    for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) acc ^= rrec[i].w ^ rrec[i].x;
+    if (acc == 0x12345678u) out[0] = acc;
+}
+
+// (tuning probe, YH_PAIR_PROBE=3: one workgroup per reference reads its records and nothing else)
+__global__ void __launch_bounds__(512) k_pair_probe_seg(const uint4* __restrict__ r, const u32* __restrict__ ptr, u32* out) {
+    const u32 t0 = ptr[blockIdx.x], t1 = ptr[blockIdx.x + 1];
+    u32 acc = 0;
+    for (u32 tb = t0; tb < t1; tb += 4 * 512) {
+        uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const u32 t = tb + u * 512 + threadIdx.x;
+            v[u] = make_uint4(0, 0, 0, 0);
+            if (t < t1) v[u] = r[t];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc ^= v[u].w ^ v[u].x;
+    }
+    if (acc == 0x12345678u) out[0] = acc;
 }
 
 inline u32 grid_for(u64 work_items, u32 block, u32 max_blocks = 16384) {
@@ -222,8 +303,14 @@ int yh_q_pairwise(yh_db* db, double c_thresh, u64 r0, u64 r1) {
     if (NC == 0) return done_empty();
 
     // columns per row block: what the LDS holds
-    static const bool big_lds = [] {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pair_rows), hipFuncAttributeMaxDynamicSharedMemorySize,
+    static const int threads = [] { const char* e = yh_tune_env("YH_PAIR_THREADS"); const int t = e ? atoi(e) : 256; return t == 1024 ? 1024 : t == 512 ? 512 : 256; }();
+    static const bool agg = [] { const char* e = yh_tune_env("YH_PAIR_AGG"); return e && e[0] == '1'; }();
+    typedef void (*RowsKernel)(const PairRows);
+    const RowsKernel kern = threads == 1024 ? (agg ? k_pair_rows<1024, true> : k_pair_rows<1024, false>)
+                          : threads == 512  ? (agg ? k_pair_rows<512, true> : k_pair_rows<512, false>)
+                                            : (agg ? k_pair_rows<256, true> : k_pair_rows<256, false>);
+    static const bool big_lds = [kern] {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                  (int)(PAIR_COLS_BIG * sizeof(u32)));
         if (e != hipSuccess) (void)hipGetLastError();
         return e == hipSuccess;
@@ -241,7 +328,7 @@ int yh_q_pairwise(yh_db* db, double c_thresh, u64 r0, u64 r1) {
     const u64 b_rec = P * sizeof(uint4), b_off = nseg * sizeof(u64), b_tab = (2 * N + 1 + NC) * sizeof(u32);
     const u64 b_cnt = nseg * sizeof(u32), b_cur = ranks ? 0 : N * sizeof(u32);
     char* d_scr = nullptr;
-    u32 *d_oj = nullptr, *d_oc = nullptr;
+    uint2* d_out = nullptr;
     int rc = YH_OK;
 #define PW_HIP(call)                                                                          \
     if (rc == YH_OK) {                                                                        \
@@ -251,7 +338,7 @@ int yh_q_pairwise(yh_db* db, double c_thresh, u64 r0, u64 r1) {
             rc = (e__ == hipErrorOutOfMemory) ? YH_ERR_OOM : YH_ERR_HIP;                      \
         }                                                                                     \
     }
-    PW_HIP(hipMalloc((void**)&d_scr, b_rec + b_off + 8 + b_tab + b_cnt + b_cur + 64));
+    PW_HIP(yh_tmalloc(db, (void**)&d_scr, b_rec + b_off + 8 + b_tab + b_cnt + b_cur + 64));
     uint4* d_rrec = reinterpret_cast<uint4*>(d_scr);
     u64* d_segoff = reinterpret_cast<u64*>(d_scr + b_rec);
     unsigned long long* d_cursor = reinterpret_cast<unsigned long long*>(d_scr + b_rec + b_off);
@@ -263,60 +350,67 @@ int yh_q_pairwise(yh_db* db, double c_thresh, u64 r0, u64 r1) {
     u32* d_cur = d_segcnt + nseg;
     PW_HIP(hipMemcpyAsync(d_tab, h_tab.data(), b_tab, hipMemcpyHostToDevice, st));
     if (!ranks) PW_HIP(hipMemsetAsync(d_cur, 0, b_cur, st));
-    // the survivors: room for a million to begin with; a run that finds more is repeated with what it counted
-    u64 cap = std::min<u64>(NC * (NC - 1), 1u << 20);
-    cap = std::max<u64>(cap, 1);
-    PW_HIP(hipMalloc((void**)&d_oj, cap * sizeof(u32)));
-    PW_HIP(hipMalloc((void**)&d_oc, cap * sizeof(u32)));
+    // the survivors: PAIR_SLOTS per segment, and room for a million behind them to begin with; a run whose long segments
+    // need more is repeated with what it counted
+    const u64 n_slots = nseg * PAIR_SLOTS;
+    u64 cap = std::max<u64>(std::min<u64>(NC * (NC - 1), 1u << 20), 1);
+    PW_HIP(yh_tmalloc(db, (void**)&d_out, (n_slots + cap) * sizeof(uint2)));
     const double c_relaxed = c_thresh * (1.0 - 1e-9) - 1e-300;
     std::vector<u32> h_segcnt(nseg);
     std::vector<u64> h_segoff(nseg);
-    unsigned long long n_out = 0;
+    unsigned long long n_over = 0;
     yh_ring_record_begin(db, db->ev_pair);
     if (rc == YH_OK)
         k_pair_transpose<<<grid_for(P, 256, 1u << 20), 256, 0, st>>>(P, db->d_pr, db->d_pg, db->d_po, d_rowptr, db->d_prank, d_cur,
-                                                                     d_rrec);
+                                                                     d_cid, d_rrec);
+    if (const char* e = yh_tune_env("YH_PAIR_PROBE")) {
+        if (e[0] == '1') k_pair_probe<<<8192, 256, 0, st>>>(d_rrec, P, d_segcnt);
+        if (e[0] == '3') { k_pair_probe_seg<<<(u32)N, 512, 0, st>>>(d_rrec, d_rowptr, d_segcnt); k_pair_probe_seg<<<(u32)N, 512, 40000, st>>>(d_rrec, d_rowptr, d_segcnt); }
+    }
     for (int attempt = 0; attempt < 2 && rc == YH_OK; ++attempt) {
         PW_HIP(hipMemsetAsync(d_cursor, 0, 8, st));
-        PairRows q{d_rrec, d_rowptr, db->d_pr, d_cid, d_rid, db->d_sizes, 0, 0, (u32)NC, cols, c_relaxed,
-                   d_segcnt, d_segoff, d_cursor, cap, d_oj, d_oc};
-        for (u64 b0 = 0; b0 < rows && rc == YH_OK; b0 += 1u << 23) {  // (2^31 threads per grid dimension)
-            const u64 nb = std::min<u64>(rows - b0, 1u << 23);
+        PairRows q{d_rrec, d_rowptr, db->d_pr, d_cid, d_rid, db->d_sizes, 0, 0, nseg, (u32)NC, cols, c_relaxed,
+                   d_segcnt, d_segoff, d_cursor, cap, d_out};
+        const u64 step = (1u << 31) / (u32)threads;  // (2^31 threads per grid dimension)
+        for (u64 b0 = 0; b0 < rows && rc == YH_OK; b0 += step) {
+            const u64 nb = std::min<u64>(rows - b0, step);
             q.a0 = r0 + b0;
             q.seg0 = b0 * ncb;
-            k_pair_rows<<<dim3((u32)nb, ncb), ROW_THREADS, cols * sizeof(u32), st>>>(q);
+            kern<<<dim3((u32)nb, ncb), threads, cols * sizeof(u32), st>>>(q);
+            if (const char* e = yh_tune_env("YH_PAIR_PROBE"))  // (tuning probe: the same launch again, and again)
+                if (e[0] == '2') { PW_HIP(hipMemsetAsync(d_cursor, 0, 8, st)); kern<<<dim3((u32)nb, ncb), threads, cols * sizeof(u32), st>>>(q);
+                                   PW_HIP(hipMemsetAsync(d_cursor, 0, 8, st)); kern<<<dim3((u32)nb, ncb), threads, cols * sizeof(u32), st>>>(q); }
         }
         PW_HIP(hipGetLastError());
         if (attempt == 0) yh_ring_record_end(db, db->ev_pair);
-        PW_HIP(hipMemcpyAsync(&n_out, d_cursor, 8, hipMemcpyDeviceToHost, st));
+        PW_HIP(hipMemcpyAsync(&n_over, d_cursor, 8, hipMemcpyDeviceToHost, st));
         PW_HIP(hipMemcpyAsync(h_segcnt.data(), d_segcnt, b_cnt, hipMemcpyDeviceToHost, st));
         PW_HIP(hipMemcpyAsync(h_segoff.data(), d_segoff, b_off, hipMemcpyDeviceToHost, st));
         PW_HIP(hipStreamSynchronize(st));
-        if (rc != YH_OK || n_out <= cap) break;
+        if (rc != YH_OK || n_over <= cap) break;
         if (attempt == 1) { yh_set_error("pairwise: the second pass found more survivors than the first"); rc = YH_ERR_HIP; break; }
-        (void)hipFree(d_oj); (void)hipFree(d_oc);
-        d_oj = d_oc = nullptr;
-        cap = n_out;
-        PW_HIP(hipMalloc((void**)&d_oj, cap * sizeof(u32)));
-        PW_HIP(hipMalloc((void**)&d_oc, cap * sizeof(u32)));
+        yh_tfree(db, d_out);
+        d_out = nullptr;
+        cap = n_over;
+        PW_HIP(yh_tmalloc(db, (void**)&d_out, (n_slots + cap) * sizeof(uint2)));
     }
-    std::vector<u32> oj(n_out), oc(n_out);
-    if (n_out) {
-        PW_HIP(hipMemcpyAsync(oj.data(), d_oj, n_out * sizeof(u32), hipMemcpyDeviceToHost, st));
-        PW_HIP(hipMemcpyAsync(oc.data(), d_oc, n_out * sizeof(u32), hipMemcpyDeviceToHost, st));
-    }
+    const u64 n_out = n_slots + n_over;
+    std::vector<uint2> ho(n_out);
+    PW_HIP(hipMemcpyAsync(ho.data(), d_out, n_out * sizeof(uint2), hipMemcpyDeviceToHost, st));
     std::vector<u32> hsizes(N);
     PW_HIP(hipMemcpyAsync(hsizes.data(), db->d_sizes, N * sizeof(u32), hipMemcpyDeviceToHost, st));
     PW_HIP(hipStreamSynchronize(st));
 #undef PW_HIP
-    (void)hipFree(d_scr); (void)hipFree(d_oj); (void)hipFree(d_oc);
+    yh_tfree(db, d_scr); yh_tfree(db, d_out);
     if (rc != YH_OK) return rc;
 
     // segments in row order (columns ascend inside a segment, column blocks inside a row), through the exact host-side
     // filter (main.cpp:297-303): keep iff !(1.0*count/|R_i| < C)
-    u32* hi = (u32*)malloc(std::max<size_t>(n_out, 1) * sizeof(u32));
-    u32* hj = (u32*)malloc(std::max<size_t>(n_out, 1) * sizeof(u32));
-    u32* hc = (u32*)malloc(std::max<size_t>(n_out, 1) * sizeof(u32));
+    u64 n_surv = 0;
+    for (u64 s = 0; s < nseg; ++s) n_surv += h_segcnt[s];
+    u32* hi = (u32*)malloc(std::max<size_t>(n_surv, 1) * sizeof(u32));
+    u32* hj = (u32*)malloc(std::max<size_t>(n_surv, 1) * sizeof(u32));
+    u32* hc = (u32*)malloc(std::max<size_t>(n_surv, 1) * sizeof(u32));
     if (!hi || !hj || !hc) { free(hi); free(hj); free(hc); yh_set_error("host allocation failed"); return YH_ERR_OOM; }
     size_t w = 0;
     for (u64 s = 0; s < nseg; ++s) {
@@ -326,9 +420,10 @@ int yh_q_pairwise(yh_db* db, double c_thresh, u64 r0, u64 r1) {
         const u64 off = h_segoff[s];
         if (off + n > n_out) { free(hi); free(hj); free(hc); yh_set_error("pairwise: a segment outside the output"); return YH_ERR_HIP; }
         for (u32 e = 0; e < n; ++e) {
-            const double cij = 1.0 * oc[off + e] / hsizes[i];
+            const uint2 v = ho[off + e];
+            const double cij = 1.0 * v.y / hsizes[i];
             if (cij < c_thresh) continue;
-            hi[w] = i; hj[w] = oj[off + e]; hc[w] = oc[off + e];
+            hi[w] = i; hj[w] = v.x; hc[w] = v.y;
             ++w;
         }
     }

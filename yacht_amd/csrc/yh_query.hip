@@ -1222,7 +1222,7 @@ static int ensure_reps(yh_db* db, u32& R) {
     while (R > 1 && (u64)R * N > (2u << 20)) R >>= 1;
     if (db->reps_cap < (u64)R * N) {
         YH_HIP(hipStreamSynchronize(db->stream));
-        if (db->d_reps) { (void)hipFree(db->d_reps); db->d_reps = nullptr; db->reps_cap = 0; }
+        if (db->d_reps) { yh_dfree(db, db->d_reps); db->d_reps = nullptr; db->reps_cap = 0; }
         // (two sets back to back: the second one counts hits on shared hashes in the fused run step; and all of
         // that twice: the pipelined step alternates between the two pairs, see yh_q_overlap_indexed)
         YH_HIP(hipMalloc((void**)&db->d_reps, 4 * (u64)R * N * sizeof(u32) + 16));
@@ -1278,7 +1278,7 @@ static int yh_q_overlap_stream(yh_db* db, const u64* d_sample, u64 n_sample, u32
     u32 wgs = (u32)std::min<u64>(wgs_env, std::max<u64>(nblk / 2, 1));
     if (db->wg_key_n != wgs) {  // the first t of every workgroup's block range: once per handle
         YH_HIP(hipStreamSynchronize(st));
-        if (db->d_wg_key) { (void)hipFree(db->d_wg_key); db->d_wg_key = nullptr; }
+        if (db->d_wg_key) { yh_dfree(db, db->d_wg_key); db->d_wg_key = nullptr; }
         YH_HIP(hipMalloc((void**)&db->d_wg_key, ((u64)wgs + 2) * sizeof(u64)));
         k_wg_key<<<(wgs + 256) / 256, 256, 0, st>>>(db->d_shdr, nblk, wgs, db->d_wg_key);
         db->wg_key_n = wgs;
