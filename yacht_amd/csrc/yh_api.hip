@@ -1,6 +1,9 @@
 // yh_api.hip — the extern "C" boundary of libyacht_hip.so (declared in include/yacht_hip.h).
 #include "yh_common.h"
 
+#include <mutex>
+#include <unordered_map>
+
 #include <stdarg.h>
 #include <string.h>
 
@@ -23,69 +26,106 @@ const char* yh_tune_env(const char* name) {
     return open_gate ? getenv(name) : nullptr;
 }
 
-static bool pool_mode(int device) {
-    static int mode[64];  // 0 unknown, 1 pool, 2 plain
-    if (device < 0 || device >= 64) return false;
-    if (mode[device] == 0) {
-        int ok = 0;
-        const char* off = getenv("YH_NO_POOL");
-        if (!(off && off[0] == '1') && hipDeviceGetAttribute(&ok, hipDeviceAttributeMemoryPoolsSupported, device) == hipSuccess && ok) {
-            hipMemPool_t pool = nullptr;
-            uint64_t keep = ~(uint64_t)0;  // (nothing goes back to the driver between calls; yh_pool_trim bounds it)
-            if (hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess &&
-                hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep) == hipSuccess)
-                mode[device] = 1;
-        }
-        if (mode[device] == 0) { (void)hipGetLastError(); mode[device] = 2; }
-    }
-    return mode[device] == 1;
+// ---- a cache of device buffers -----------------------------------------------------------------------------------
+// The temporaries of a build or a pairwise pass, and the arrays of a YH_DB_PAIRWISE_ONLY handle (which lives for one
+// `yacht train` call), are taken from and returned to a per-process cache instead of the driver: a hipFree of a gigabyte
+// buffer costs 0.3-1 ms and synchronizes the device, `yacht train` made thirty of them per call (3.5 of 14 ms), and
+// hipFreeAsync into the device's memory pool was no cheaper (0.35 ms a call).  A cached block remembers the stream that
+// last used it: the same stream may have it back at once (stream order), another one after that stream has drained.
+// What the cache holds beyond YH_POOL_KEEP (default 4 GiB) goes back to the driver at the end of a create / destroy.
+namespace {
+struct CacheBlock { void* p; size_t bytes; int device; hipStream_t owner; };
+std::mutex g_cache_mu;
+std::vector<CacheBlock> g_cache;                      // free blocks
+std::unordered_map<void*, size_t> g_cache_live;       // blocks handed out: their sizes
+bool cache_on() {
+    static const bool on = [] { const char* off = getenv("YH_NO_POOL"); return !(off && off[0] == '1'); }();
+    return on;
 }
+}  // namespace
 hipError_t yh_tmalloc(yh_db* db, void** p, size_t bytes) {
     if (bytes == 0) bytes = 16;
-    return pool_mode(db->device) ? hipMallocAsync(p, bytes, db->stream) : hipMalloc(p, bytes);
+    if (!cache_on()) return hipMalloc(p, bytes);
+    bytes = (bytes + 255) & ~(size_t)255;
+    hipStream_t wait_for = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        int best = -1;
+        for (size_t i = 0; i < g_cache.size(); ++i) {
+            const CacheBlock& b = g_cache[i];
+            if (b.device != db->device || b.bytes < bytes || b.bytes > bytes + bytes / 4 + (1u << 20)) continue;
+            if (best < 0 || b.bytes < g_cache[best].bytes || (b.bytes == g_cache[best].bytes && b.owner == db->stream)) best = (int)i;
+        }
+        if (best >= 0) {
+            const CacheBlock b = g_cache[best];
+            g_cache[best] = g_cache.back();
+            g_cache.pop_back();
+            g_cache_live[b.p] = b.bytes;
+            *p = b.p;
+            if (b.owner && b.owner != db->stream) wait_for = b.owner;
+            else return hipSuccess;
+        }
+    }
+    if (wait_for) return hipStreamSynchronize(wait_for);  // (a live handle's stream: owners are cleared when a handle goes)
+    const hipError_t e = hipMalloc(p, bytes);
+    if (e == hipSuccess) {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        g_cache_live[*p] = bytes;
+    }
+    return e;
 }
 void yh_tfree(yh_db* db, void* p) {
     if (!p) return;
-    if (pool_mode(db->device)) (void)hipFreeAsync(p, db->stream);
-    else (void)hipFree(p);
-}
-void yh_pool_trim(yh_db* db) {
-    if (!pool_mode(db->device)) return;
-    static const uint64_t keep = [] { const char* e = yh_tune_env("YH_POOL_KEEP"); return e ? (uint64_t)atoll(e) : (uint64_t)4 << 30; }();
-    hipMemPool_t pool = nullptr;
-    if (hipDeviceGetDefaultMemPool(&pool, db->device) != hipSuccess) { (void)hipGetLastError(); return; }
-    uint64_t held = 0;
-    if (hipMemPoolGetAttribute(pool, hipMemPoolAttrReservedMemCurrent, &held) != hipSuccess) { (void)hipGetLastError(); return; }
-    if (held > keep) {
-        (void)hipStreamSynchronize(db->stream);
-        (void)hipMemPoolTrimTo(pool, keep);
+    if (cache_on()) {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        auto it = g_cache_live.find(p);
+        if (it != g_cache_live.end()) {
+            g_cache.push_back(CacheBlock{p, it->second, db->device, db->stream});
+            g_cache_live.erase(it);
+            return;
+        }
     }
+    (void)hipFree(p);
+}
+// (the handle's stream has drained) blocks it used last are anyone's now; the excess over the bar goes back to the driver
+void yh_pool_trim(yh_db* db) {
+    if (!cache_on()) return;
+    static const size_t keep = [] { const char* e = yh_tune_env("YH_POOL_KEEP"); return e ? (size_t)atoll(e) : (size_t)4 << 30; }();
+    std::vector<void*> drop;
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        size_t held = 0;
+        for (CacheBlock& b : g_cache) {
+            if (b.owner == db->stream) b.owner = nullptr;
+            held += b.bytes;
+        }
+        while (held > keep) {  // largest idle block first
+            int big = -1;
+            for (size_t i = 0; i < g_cache.size(); ++i)
+                if (!g_cache[i].owner && (big < 0 || g_cache[i].bytes > g_cache[big].bytes)) big = (int)i;
+            if (big < 0) break;
+            held -= g_cache[big].bytes;
+            drop.push_back(g_cache[big].p);
+            g_cache[big] = g_cache.back();
+            g_cache.pop_back();
+        }
+    }
+    for (void* q : drop) (void)hipFree(q);
 }
 
 int yh_dmalloc(yh_db* db, void** p, size_t bytes) {
     if (bytes == 0) bytes = 16;
-    const bool pooled = (db->flags & YH_DB_PAIRWISE_ONLY) && pool_mode(db->device);
-    hipError_t e = pooled ? hipMallocAsync(p, bytes, db->stream) : hipMalloc(p, bytes);
+    const bool cached = (db->flags & YH_DB_PAIRWISE_ONLY) != 0;
+    hipError_t e = cached ? yh_tmalloc(db, p, bytes) : hipMalloc(p, bytes);
     if (e != hipSuccess) {
         *p = nullptr;
         yh_set_error("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
         return YH_ERR_OOM;
     }
-    if (pooled) db->pooled.push_back(*p);
     db->device_bytes += bytes;
     return YH_OK;
 }
-void yh_dfree(yh_db* db, void* p) {
-    if (!p) return;
-    for (size_t i = 0; i < db->pooled.size(); ++i)
-        if (db->pooled[i] == p) {
-            db->pooled[i] = db->pooled.back();
-            db->pooled.pop_back();
-            (void)hipFreeAsync(p, db->stream);
-            return;
-        }
-    (void)hipFree(p);
-}
+void yh_dfree(yh_db* db, void* p) { yh_tfree(db, p); }  // (a block the cache did not hand out goes to hipFree)
 
 static void ring_create(EventRing& r) {
     if (r.created) return;

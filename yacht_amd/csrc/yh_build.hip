@@ -19,6 +19,9 @@
 #include <time.h>
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
+#include <mutex>
 #include <vector>
 
 namespace {
@@ -527,8 +530,15 @@ int yh_build_upload_sorted(yh_db* db, const u64* h_values, const u64* h_offsets,
 
     double t_prev = trace_now();
     TRACE("chunk plan + max");
-    hipStream_t up = nullptr;
-    std::vector<hipEvent_t> ev(C, nullptr), eb(C, nullptr), ee(C, nullptr);
+    // (the upload stream and the chunk events are made once per device and kept: a dozen creates and destroys were
+    // 0.4 ms of every call)
+    struct UpCtx { hipStream_t up = nullptr; std::vector<hipEvent_t> ev, eb, ee; };
+    static std::mutex up_mu;
+    static UpCtx up_ctx[64];
+    std::lock_guard<std::mutex> up_lock(up_mu);  // (one chunked upload per process at a time: they would share the bus anyway)
+    UpCtx& uc = up_ctx[db->device & 63];
+    hipStream_t& up = uc.up;
+    std::vector<hipEvent_t>&ev = uc.ev, &eb = uc.eb, &ee = uc.ee;
     u64* K[2] = {nullptr, nullptr};
     u32* V[2] = {nullptr, nullptr};
     u32* d_ids = nullptr;
@@ -542,11 +552,13 @@ int yh_build_upload_sorted(yh_db* db, const u64* h_values, const u64* h_offsets,
             rc = (e__ == hipErrorOutOfMemory) ? YH_ERR_OOM : YH_ERR_HIP;                      \
         }                                                                                     \
     }
-    UP_HIP(hipStreamCreateWithFlags(&up, hipStreamNonBlocking));
-    for (size_t c = 0; c < C; ++c) {
-        UP_HIP(hipEventCreateWithFlags(&ev[c], hipEventDisableTiming));
-        UP_HIP(hipEventCreate(&eb[c]));
-        UP_HIP(hipEventCreate(&ee[c]));
+    if (!up) UP_HIP(hipStreamCreateWithFlags(&up, hipStreamNonBlocking));
+    while (ev.size() < C && rc == YH_OK) {
+        hipEvent_t a = nullptr, b = nullptr, c2 = nullptr;
+        UP_HIP(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+        UP_HIP(hipEventCreate(&b));
+        UP_HIP(hipEventCreate(&c2));
+        if (rc == YH_OK) { ev.push_back(a); eb.push_back(b); ee.push_back(c2); }
     }
     for (int b = 0; b < 2; ++b) {
         UP_HIP(yh_tmalloc(db, (void**)&K[b], H * sizeof(u64)));
@@ -567,14 +579,31 @@ int yh_build_upload_sorted(yh_db* db, const u64* h_values, const u64* h_offsets,
     TRACE("stream, events, buffers");
     if (rc == YH_OK) rc = validate_begin(db);
     int cur = 0;  // the buffer that holds the sorted prefix
+    // The copies are issued back to back by a thread of their own (a copy from pageable memory returns when the data has
+    // left the host, and queueing a chunk's sort and merge takes the host ~0.1 ms: with one thread doing both, the bus
+    // idled that long behind every chunk); this thread queues chunk c's device work as soon as its event is recorded.
+    std::atomic<int> copied{0};        // chunks whose copy has been issued and event recorded
+    std::atomic<int> copy_failed{0};
+    const int device = db->device;
+    std::thread copier;
+    if (rc == YH_OK) {
+        copier = std::thread([&, device]() {
+            if (hipSetDevice(device) != hipSuccess) { copy_failed.store(1); copied.store((int)C); return; }
+            for (size_t c = 0; c < C; ++c) {
+                const u64 e0 = h_offsets[rb[c]], e1 = h_offsets[rb[c + 1]];
+                if (e1 > e0 && hipMemcpyAsync(d_values + e0, h_values + e0, (e1 - e0) * sizeof(u64), hipMemcpyHostToDevice, up) != hipSuccess)
+                    copy_failed.store(1);
+                if (hipEventRecord(ev[c], up) != hipSuccess) copy_failed.store(1);
+                copied.store((int)c + 1, std::memory_order_release);
+            }
+        });
+    }
     for (size_t c = 0; c < C && rc == YH_OK; ++c) {
         const u64 r0 = rb[c], r1 = rb[c + 1];
         const u64 e0 = h_offsets[r0], e1 = h_offsets[r1], n = e1 - e0;
-        // (a copy from pageable memory returns when the data has left the host: the device work of the chunk before is
-        // already queued and runs meanwhile)
-        if (n) UP_HIP(hipMemcpyAsync(d_values + e0, h_values + e0, n * sizeof(u64), hipMemcpyHostToDevice, up));
-        TRACE("chunk copy returned");
-        UP_HIP(hipEventRecord(ev[c], up));
+        while (copied.load(std::memory_order_acquire) <= (int)c) std::this_thread::yield();
+        TRACE("chunk copy issued");
+        if (copy_failed.load()) { yh_set_error("CSR upload failed"); rc = YH_ERR_HIP; break; }
         UP_HIP(hipStreamWaitEvent(st, ev[c], 0));
         UP_HIP(hipEventRecord(eb[c], st));
         if (rc == YH_OK) rc = validate_refs(db, d_values, d_offsets, r0, r1);
@@ -593,6 +622,9 @@ int yh_build_upload_sorted(yh_db* db, const u64* h_values, const u64* h_offsets,
         UP_HIP(hipEventRecord(ee[c], st));
         TRACE("chunk work queued");
     }
+    if (copier.joinable()) copier.join();
+    if (rc == YH_OK && copy_failed.load()) { yh_set_error("CSR upload failed"); rc = YH_ERR_HIP; }
+    if (rc != YH_OK) (void)hipStreamSynchronize(up);
     if (rc == YH_OK) rc = validate_end(db);  // (waits for the stream)
     TRACE("stream drained");
     if (rc == YH_OK && db->max_hash > max_last) { yh_set_error("internal: largest hash above the largest last element"); rc = YH_ERR_HIP; }
@@ -610,13 +642,10 @@ int yh_build_upload_sorted(yh_db* db, const u64* h_values, const u64* h_offsets,
     db->ms_upload_kernels = 0.f;
     for (size_t c = 0; c < C; ++c) {
         float ms = 0.f;
-        if (rc == YH_OK && eb[c] && ee[c] && hipEventElapsedTime(&ms, eb[c], ee[c]) == hipSuccess) db->ms_upload_kernels += ms;
-        if (ev[c]) (void)hipEventDestroy(ev[c]);
-        if (eb[c]) (void)hipEventDestroy(eb[c]);
-        if (ee[c]) (void)hipEventDestroy(ee[c]);
+        if (rc == YH_OK && c < eb.size() && hipEventElapsedTime(&ms, eb[c], ee[c]) == hipSuccess) db->ms_upload_kernels += ms;
     }
 #undef UP_HIP
-    if (up) { (void)hipStreamSynchronize(up); (void)hipStreamDestroy(up); }
+    if (up) (void)hipStreamSynchronize(up);
     yh_tfree(db, d_tmp);
     yh_tfree(db, d_ids);
     yh_tfree(db, K[cur ^ 1]);
@@ -685,6 +714,7 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, u64* d_
     const u64 N = db->n_refs;
     const u64 H = db->n_hashes;
     hipStream_t st = db->stream;
+    double t_prev = trace_now();
 
     YH_TRY(yh_dmalloc(db, (void**)&db->d_nshared, std::max<u64>(N, 1) * sizeof(u32)));
     YH_HIP(hipMemsetAsync(db->d_nshared, 0, std::max<u64>(N, 1) * sizeof(u32), st));
@@ -746,6 +776,7 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, u64* d_
         yh_tfree(db, d_tmp); d_tmp = nullptr;
         yh_tfree(db, d_ids); d_ids = nullptr;
     }
+    TRACE("index: sorted pairs ready");
     const bool want_stream = !(db->flags & YH_DB_PAIRWISE_ONLY);
     if (rc == YH_OK && (db->flags & YH_DB_NO_INDEX)) {  // overlap-only handle: the stream and nothing else
         if (want_stream) rc = build_stream(db, d_sk, d_sv, nullptr, H);
@@ -767,6 +798,7 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, u64* d_
         IDX_HIP(hipMemcpyAsync(totals, d_bases + nb * 3, 3 * sizeof(u64), hipMemcpyDeviceToHost, st));
         IDX_HIP(hipStreamSynchronize(st));
     }
+    TRACE("index: counted");
     if (rc == YH_OK) {
         db->n_distinct = totals[0];
         db->n_shared = totals[1];
@@ -784,6 +816,7 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, u64* d_
     // (+ slack: the last workgroup's segment may start up to 4*EXCL_QBLOCKS entries late)
     if (rc == YH_OK) rc = yh_dmalloc(db, (void**)&db->d_pq, (db->n_postings + 8ull * EXCL_QBLOCKS + 16) * sizeof(u32));
     if (rc == YH_OK) rc = yh_dmalloc(db, (void**)&db->d_pq_count, EXCL_QBLOCKS * sizeof(u32));
+    TRACE("index: arrays allocated");
     if (rc == YH_OK) {
         IDX_HIP(hipMemsetAsync(db->d_g, 0, std::max<u64>(db->n_shared, 2) * sizeof(u64), st));
         // The bucket table over the distinct hashes (sample-driven lookups) is part of every handle that
@@ -987,6 +1020,7 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, u64* d_
         }
         IDX_HIP(hipStreamSynchronize(st));
     }
+    TRACE("index: emitted + drained");
 #undef IDX_HIP
     yh_tfree(db, d_elem_g);
     yh_tfree(db, d_ids);
@@ -995,6 +1029,7 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, u64* d_
     yh_tfree(db, d_counts);
     yh_tfree(db, d_bases);
     yh_tfree(db, d_tmp);
+    TRACE("index: frees");
     if (rc == YH_OK) db->has_index = true;
     return rc;
 }

@@ -230,7 +230,6 @@ struct yh_db {
 
     // timing
     EventRing ev_overlap, ev_excl, ev_pair;
-    std::vector<void*> pooled;  // arrays of this handle that came from the memory pool (yh_dmalloc)
     float ms_upload_kernels = 0.f;  // device time of the chunk sorts / merges that ran under the upload (yh_build_upload_sorted)
     float ms_db_build = 0.f;
 };
@@ -394,12 +393,8 @@ int yh_q_check_sorted_host(const u64* v, u64 n);
 
 // helpers (yh_api.hip)
 int yh_dmalloc(yh_db* db, void** p, size_t bytes);
-// Temporaries of a build or a pairwise pass: stream-ordered allocations from the device's memory pool on the handle's
-// stream (hipMallocAsync / hipFreeAsync: a hipFree of a gigabyte buffer costs 0.3-1 ms and synchronizes the device, and
-// `yacht train` made a dozen of them per call); plain hipMalloc / hipFree where the device has no pools or with
-// YH_NO_POOL=1.  What a create leaves in the pool beyond YH_POOL_KEEP (default 4 GiB) is given back at its end.
-// (yh_dmalloc: the arrays a handle keeps -- from the pool too for YH_DB_PAIRWISE_ONLY handles, which live for one
-// `yacht train` call: fifteen hipMalloc + fifteen hipFree were 3.5 ms of a 14 ms call; yh_dfree releases either kind)
+// Temporaries of a build or a pairwise pass (and, through yh_dmalloc, the arrays of a YH_DB_PAIRWISE_ONLY handle) come from
+// a per-process cache of device buffers (yh_api.hip); yh_dfree / yh_tfree release either kind of block.
 void yh_dfree(yh_db* db, void* p);
 hipError_t yh_tmalloc(yh_db* db, void** p, size_t bytes);
 void yh_tfree(yh_db* db, void* p);
