@@ -6,12 +6,15 @@
 // (main.cpp:297-303: !(count / |R_i| < C)) ever reach HBM.  No dense count matrix: 16 bytes per posting of scratch.
 //
 //   k_pair_transpose   the hash-major postings (pr / pg / po) into a reference-major array of 16-byte records
-//                      "the OTHER holders of this posting's hash" -- three inline, or where the list is in pr[];
-//                      the slot inside the reference's run is the posting's rank among the reference's shared hashes
-//                      (k_idx_emit's counting atomic returns it: yh_db::d_prank), or a cursor atomic where the handle
-//                      has no ranks
-//   k_pair_rows        one workgroup per reference (and block of columns): its records, one LDS add per other holder;
-//                      then the row's survivors, in column order, into a segment of the output claimed with ONE atomic
+//                      "the OTHER holders of this posting's hash" -- three inline as COMPACT ids, or where the list is
+//                      in pr[]; the slot inside the reference's run is the posting's rank among the reference's shared
+//                      hashes (k_idx_emit's counting atomic returns it: yh_db::d_prank), or a cursor atomic where the
+//                      handle has no ranks
+//   k_pair_rows        one workgroup per reference (and block of columns): its records, four loads in flight per lane,
+//                      one LDS add per other holder; then the row's survivors, in column order, into the segment's own
+//                      four slots of the output, or -- a longer segment -- into room claimed behind them with one atomic
+// configs[3] (27 M postings, 10 000 rows): 0.59 + 0.28 ms, where the dense count matrix with one global atomic per
+// (posting, other holder) took 2.66 + 0.53 ms.
 // The host puts the segments in row order and applies the exact threshold (no decision depends on device floating point).
 #include "yh_common.h"
 
@@ -96,7 +99,7 @@ constexpr int PAIR_U = YH_PAIR_U;  // records a lane has in flight
 #ifndef YH_ABLATE_PAIR
 #define YH_ABLATE_PAIR 0  // timing-only builds (results wrong): 1 no record pass, 2 no row clear / survivor scan, 4 records read but not added
 #endif
-template <int THREADS, bool AGG>
+template <int THREADS>
 __global__ void __launch_bounds__(THREADS) k_pair_rows(const PairRows p) {
     constexpr int WAVES = THREADS / WAVE;
     extern __shared__ u32 row[];  // p.cols counts
@@ -125,23 +128,11 @@ __global__ void __launch_bounds__(THREADS) k_pair_rows(const PairRows p) {
     if (!(YH_ABLATE_PAIR & 2))
         for (u32 j = tid; j < w; j += THREADS) row[j] = 0;
     __syncthreads();
-    // The records of a row name the same few references over and over (its cluster mates): with AGG a lane keeps counts
-    // for the first four columns it meets in registers and adds them to the row once (measured: no gain).
-    u32 ck0 = 0xffffffffu, ck1 = 0xffffffffu, ck2 = 0xffffffffu, ck3 = 0xffffffffu;
-    u32 cv0 = 0, cv1 = 0, cv2 = 0, cv3 = 0;
+    // (Same-address LDS adds are not what the pass waits for: counting a lane's first four columns in registers and
+    // adding them once made it slower; without any add it is 15 % shorter.)
     auto addc = [&](u32 cc) {  // cc: a compact id
         const u32 c = cc - c0;
         if (c >= w) return;
-        if (AGG) {
-            if (c == ck0) { ++cv0; return; }
-            if (c == ck1) { ++cv1; return; }
-            if (c == ck2) { ++cv2; return; }
-            if (c == ck3) { ++cv3; return; }
-            if (ck0 == 0xffffffffu) { ck0 = c; cv0 = 1; return; }
-            if (ck1 == 0xffffffffu) { ck1 = c; cv1 = 1; return; }
-            if (ck2 == 0xffffffffu) { ck2 = c; cv2 = 1; return; }
-            if (ck3 == 0xffffffffu) { ck3 = c; cv3 = 1; return; }
-        }
         if (YH_ABLATE_PAIR & 4) { if (c == 0x12345u) row[0] = 1; return; }
         atomicAdd(&row[c], 1u);
     };
@@ -179,12 +170,6 @@ __global__ void __launch_bounds__(THREADS) k_pair_rows(const PairRows p) {
                 }
             }
         }
-    }
-    if (AGG) {
-        if (cv0) atomicAdd(&row[ck0], cv0);
-        if (cv1) atomicAdd(&row[ck1], cv1);
-        if (cv2) atomicAdd(&row[ck2], cv2);
-        if (cv3) atomicAdd(&row[ck3], cv3);
     }
     __syncthreads();
     // survivors in column order: wave v owns the columns [v*per, (v+1)*per)
@@ -234,31 +219,6 @@ __global__ void __launch_bounds__(THREADS) k_pair_rows(const PairRows p) {
     }
 }
 
-// (tuning probe, YH_PAIR_PROBE=1: the records read front to back by a plain grid-stride kernel -- what the buffer can give)
-__global__ void __launch_bounds__(256) k_pair_probe(const uint4* __restrict__ rrec, u64 n, u32* __restrict__ out) {
-    u32 acc = 0;
-    for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) acc ^= rrec[i].w ^ rrec[i].x;
-    if (acc == 0x12345678u) out[0] = acc;
-}
-
-// (tuning probe, YH_PAIR_PROBE=3: one workgroup per reference reads its records and nothing else)
-__global__ void __launch_bounds__(512) k_pair_probe_seg(const uint4* __restrict__ r, const u32* __restrict__ ptr, u32* out) {
-    const u32 t0 = ptr[blockIdx.x], t1 = ptr[blockIdx.x + 1];
-    u32 acc = 0;
-    for (u32 tb = t0; tb < t1; tb += 4 * 512) {
-        uint4 v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const u32 t = tb + u * 512 + threadIdx.x;
-            v[u] = make_uint4(0, 0, 0, 0);
-            if (t < t1) v[u] = r[t];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) acc ^= v[u].w ^ v[u].x;
-    }
-    if (acc == 0x12345678u) out[0] = acc;
-}
-
 inline u32 grid_for(u64 work_items, u32 block, u32 max_blocks = 16384) {
     u64 g = (work_items + block - 1) / block;
     if (g < 1) g = 1;
@@ -303,12 +263,10 @@ int yh_q_pairwise(yh_db* db, double c_thresh, u64 r0, u64 r1) {
     if (NC == 0) return done_empty();
 
     // columns per row block: what the LDS holds
-    static const int threads = [] { const char* e = yh_tune_env("YH_PAIR_THREADS"); const int t = e ? atoi(e) : 256; return t == 1024 ? 1024 : t == 512 ? 512 : 256; }();
-    static const bool agg = [] { const char* e = yh_tune_env("YH_PAIR_AGG"); return e && e[0] == '1'; }();
+    static const int threads = [] { const char* e = yh_tune_env("YH_PAIR_THREADS"); const int t = e ? atoi(e) : 512; return t == 1024 ? 1024 : t == 256 ? 256 : 512; }();
     typedef void (*RowsKernel)(const PairRows);
-    const RowsKernel kern = threads == 1024 ? (agg ? k_pair_rows<1024, true> : k_pair_rows<1024, false>)
-                          : threads == 512  ? (agg ? k_pair_rows<512, true> : k_pair_rows<512, false>)
-                                            : (agg ? k_pair_rows<256, true> : k_pair_rows<256, false>);
+    // (512 lanes: configs[3]'s rows of ~2 700 records in 0.28 ms, against 0.37 with 256 lanes and 0.33 with 1 024)
+    const RowsKernel kern = threads == 1024 ? k_pair_rows<1024> : threads == 256 ? k_pair_rows<256> : k_pair_rows<512>;
     static const bool big_lds = [kern] {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                  (int)(PAIR_COLS_BIG * sizeof(u32)));
@@ -363,10 +321,6 @@ int yh_q_pairwise(yh_db* db, double c_thresh, u64 r0, u64 r1) {
     if (rc == YH_OK)
         k_pair_transpose<<<grid_for(P, 256, 1u << 20), 256, 0, st>>>(P, db->d_pr, db->d_pg, db->d_po, d_rowptr, db->d_prank, d_cur,
                                                                      d_cid, d_rrec);
-    if (const char* e = yh_tune_env("YH_PAIR_PROBE")) {
-        if (e[0] == '1') k_pair_probe<<<8192, 256, 0, st>>>(d_rrec, P, d_segcnt);
-        if (e[0] == '3') { k_pair_probe_seg<<<(u32)N, 512, 0, st>>>(d_rrec, d_rowptr, d_segcnt); k_pair_probe_seg<<<(u32)N, 512, 40000, st>>>(d_rrec, d_rowptr, d_segcnt); }
-    }
     for (int attempt = 0; attempt < 2 && rc == YH_OK; ++attempt) {
         PW_HIP(hipMemsetAsync(d_cursor, 0, 8, st));
         PairRows q{d_rrec, d_rowptr, db->d_pr, d_cid, d_rid, db->d_sizes, 0, 0, nseg, (u32)NC, cols, c_relaxed,
@@ -377,9 +331,6 @@ int yh_q_pairwise(yh_db* db, double c_thresh, u64 r0, u64 r1) {
             q.a0 = r0 + b0;
             q.seg0 = b0 * ncb;
             kern<<<dim3((u32)nb, ncb), threads, cols * sizeof(u32), st>>>(q);
-            if (const char* e = yh_tune_env("YH_PAIR_PROBE"))  // (tuning probe: the same launch again, and again)
-                if (e[0] == '2') { PW_HIP(hipMemsetAsync(d_cursor, 0, 8, st)); kern<<<dim3((u32)nb, ncb), threads, cols * sizeof(u32), st>>>(q);
-                                   PW_HIP(hipMemsetAsync(d_cursor, 0, 8, st)); kern<<<dim3((u32)nb, ncb), threads, cols * sizeof(u32), st>>>(q); }
         }
         PW_HIP(hipGetLastError());
         if (attempt == 0) yh_ring_record_end(db, db->ev_pair);
