@@ -39,7 +39,7 @@ std::mutex g_cache_mu;
 std::vector<CacheBlock> g_cache;                      // free blocks
 std::unordered_map<void*, size_t> g_cache_live;       // blocks handed out: their sizes
 bool cache_on() {
-    static const bool on = [] { const char* off = getenv("YH_NO_POOL"); return !(off && off[0] == '1'); }();
+    static const bool on = [] { const char* off = yh_tune_env("YH_NO_POOL"); return !(off && off[0] == '1'); }();
     return on;
 }
 }  // namespace
@@ -67,7 +67,19 @@ hipError_t yh_tmalloc(yh_db* db, void** p, size_t bytes) {
         }
     }
     if (wait_for) return hipStreamSynchronize(wait_for);  // (a live handle's stream: owners are cleared when a handle goes)
-    const hipError_t e = hipMalloc(p, bytes);
+    hipError_t e = hipMalloc(p, bytes);
+    if (e == hipErrorOutOfMemory) {  // give the driver back what the cache holds, and once more
+        (void)hipGetLastError();
+        (void)hipDeviceSynchronize();
+        std::vector<void*> drop;
+        {
+            std::lock_guard<std::mutex> lk(g_cache_mu);
+            for (const CacheBlock& b : g_cache) drop.push_back(b.p);
+            g_cache.clear();
+        }
+        for (void* q : drop) (void)hipFree(q);
+        e = hipMalloc(p, bytes);
+    }
     if (e == hipSuccess) {
         std::lock_guard<std::mutex> lk(g_cache_mu);
         g_cache_live[*p] = bytes;
