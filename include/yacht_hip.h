@@ -401,6 +401,11 @@ int yh_sig_meta_destroy(yh_sig_meta* meta);
  * YH_ERR_CAPACITY (with *n_out set) when cap is too small, cap = 0 only counts.               */
 int yh_sketch_dna(const uint8_t* seq, uint64_t n_bytes, int ksize, uint64_t seed, uint64_t max_hash,
                   int device_id, uint64_t cap, uint64_t* hashes_out, uint64_t* n_out);
+/* The same on device buffers (a sequence that is already in HBM), enqueued on `stream` (a hipStream_t, NULL = the
+ * default stream) without synchronizing: *d_count is zeroed first and receives the number of kept hashes, which may
+ * exceed cap -- then only the first cap were stored. */
+int yh_sketch_dna_device(const uint8_t* d_seq, uint64_t n_bytes, int ksize, uint64_t seed, uint64_t max_hash,
+                         uint64_t cap, uint64_t* d_hashes_out, uint64_t* d_count, void* stream);
 
 #ifdef __cplusplus
 }

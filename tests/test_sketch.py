@@ -39,7 +39,8 @@ def test_hip_sketch_equals_oracle(hip_lib):
     from yacht_amd import sketch
 
     path = os.path.join(FX, "GCF_018918235.1_genomic.fna.gz")
-    for k, scaled in ((31, 1000), (21, 100), (51, 1000)):
+    # (k <= 32: the 2-bit kernel, every shape of the MurmurHash3 tail; k = 51: the byte-wise kernel)
+    for k, scaled in ((31, 1000), (21, 100), (51, 1000), (32, 1000), (16, 100), (15, 100), (17, 200), (8, 20), (24, 100), (25, 100)):
         want_m, want_a = so.sketch_fasta(path, k, scaled)
         sig = sketch.sketch_file(path, k, scaled)
         assert np.array_equal(sig.minhash.mins, want_m)
@@ -51,6 +52,43 @@ def test_hip_sketch_equals_oracle(hip_lib):
     recs = [b"ACGTNACGTTGCAAGGCTTAACCGGATATCGCGATTACGG", b"acgtacgtacgtacgtacgtacgtaaa", b"ACG", b""]
     got = np.sort(sketch.hash_kmers(recs, 11, 1))
     want = np.sort(np.concatenate([so.kmer_hashes(r, 11) for r in recs]))
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.gpu
+def test_host_call_hashes_the_sequence_while_it_arrives(hip_lib):
+    """yh_sketch_dna uploads a long sequence in 32 MiB pieces and hashes the windows that are complete while the next piece
+    is on the bus: the same multiset of kept hashes as ONE launch over the resident sequence (yh_sketch_dna_device), and as
+    the oracle on a stretch across the first piece boundary."""
+    import ctypes as C
+
+    import torch
+
+    from yacht_amd import _lib, sketch
+
+    rng = np.random.default_rng(3)
+    n = 68_000_000
+    seq = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=n, dtype=np.uint8)]
+    seq[rng.integers(0, n, size=500)] = ord("N")
+    seq[(32 << 20) - 40:(32 << 20) - 35] = ord("n")     # bad bases right at a piece boundary
+    seq[(64 << 20) + 3] = ord("-")
+    for k, scaled in ((31, 1000), (51, 2000)):
+        host = np.sort(sketch.hash_kmers([seq], k, scaled))
+        lib = _lib.load()
+        mh = sketch.max_hash_for_scaled(scaled)
+        d_seq = torch.from_numpy(seq).cuda()
+        d_out = torch.zeros(host.size + 1000, dtype=torch.int64, device="cuda")
+        d_cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+        _lib.check(lib.yh_sketch_dna_device(C.c_void_p(d_seq.data_ptr()), n, k, sketch.DEFAULT_SEED, mh, d_out.numel(),
+                                            C.c_void_p(d_out.data_ptr()), C.c_void_p(d_cnt.data_ptr()),
+                                            C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        torch.cuda.synchronize()
+        dev = np.sort(d_out[: int(d_cnt.item())].cpu().numpy().view(np.uint64))
+        assert np.array_equal(host, dev), (k, scaled, host.size, dev.size)
+    lo, hi = (32 << 20) - 300_000, (32 << 20) + 300_000
+    want = so.kmer_hashes(seq[lo:hi].tobytes(), 31)
+    want = np.sort(want[want <= np.uint64(sketch.max_hash_for_scaled(1000))])
+    got = np.sort(sketch.hash_kmers([seq[lo:hi]], 31, 1000))
     assert np.array_equal(got, want)
 
 

@@ -133,6 +133,7 @@ SIGNATURES = {
     "yh_index_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "yh_sketch_dna": (C.c_int, [_vp, C.c_uint64, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_uint64, _vp,
                                 C.POINTER(C.c_uint64)]),
+    "yh_sketch_dna_device": (C.c_int, [_vp, C.c_uint64, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, _vp, _vp, _vp]),
     "yh_hyp_test": (C.c_int, [C.c_uint64, _vp, _vp, C.c_int, C.c_double, C.c_double, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp]),
     "yh_train_select": (C.c_int, [_vp, C.c_uint64, _vp, _vp, C.c_uint64, _vp, C.POINTER(C.c_uint64)]),
     "yh_sig_batch_read": (C.c_int, [C.POINTER(C.c_char_p), C.c_uint64, C.c_int, C.POINTER(_vp)]),

@@ -59,14 +59,19 @@ def hash_kmers(sequences: Iterable[bytes], ksize: int, scaled: int, seed: int = 
     """Kept hashes (unsorted, with duplicates) of all windows of all sequences: one device call on
     the sequences joined by a separator byte (a non-ACGT byte breaks every window that spans it)."""
     lib = _lib.load()
-    buf = np.frombuffer(b"\n".join(sequences), dtype=np.uint8)
+    seqs = list(sequences)
+    if len(seqs) == 1:  # (no copy: a genome of one record, or a caller that joined the records itself)
+        buf = seqs[0] if isinstance(seqs[0], np.ndarray) else np.frombuffer(seqs[0], dtype=np.uint8)
+        buf = np.ascontiguousarray(buf, dtype=np.uint8)
+    else:
+        buf = np.frombuffer(b"\n".join(bytes(s) for s in seqs), dtype=np.uint8)
     if buf.size < ksize:
         return np.zeros(0, dtype=np.uint64)
     mh = max_hash_for_scaled(scaled)
     cap = max(int(buf.size / max(scaled, 1) * 1.5) + 4096, 4096)
     n = C.c_uint64(0)
     while True:
-        out = np.zeros(cap, dtype=np.uint64)
+        out = np.empty(cap, dtype=np.uint64)
         rc = lib.yh_sketch_dna(C.c_void_p(buf.ctypes.data), buf.size, ksize, seed, mh, device, cap,
                                C.c_void_p(out.ctypes.data), C.byref(n))
         if rc == _lib.YH_ERR_CAPACITY:
