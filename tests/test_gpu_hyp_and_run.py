@@ -80,7 +80,7 @@ def test_run_path_uses_one_fused_call(hip_lib, monkeypatch):
         hr._LAST_RUN.clear()
 
 
-@pytest.mark.parametrize("n_refs", [3000, 20000])
+@pytest.mark.parametrize("n_refs", [3000, 12000])
 def test_real_hit_shape_against_oracle(hip_lib, n_refs):
     """~29 % of the references overlap an (almost all hits) sample: the hit-table overflow of the
     lookup kernel and the dense regime of the exclusive pass."""

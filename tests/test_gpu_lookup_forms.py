@@ -23,9 +23,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_forced_lookup_forms_against_oracle(hip_lib, env):
     e = dict(os.environ, YH_DEBUG_TUNING="1")
     e.update(env)
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "fuzz_parity.py"), "--seconds", "9", "--seed", "31"],
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "fuzz_parity.py"), "--seconds", "6", "--seed", "31"],
                        env=e, capture_output=True, text=True, timeout=600, cwd=ROOT)
     line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
     res = json.loads(line)
     assert p.returncode == 0 and res["fuzz"] == "ok", line + p.stderr[-2000:]
-    assert res["rounds"] >= 4
+    assert res["rounds"] >= 3

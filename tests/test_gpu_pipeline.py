@@ -303,7 +303,7 @@ def test_pipelined_device_steps(hip_lib):
             db.set_lookup(lookup)
             for nbuf in (2, 3):
                 bufs = [torch.zeros(3, n, dtype=torch.int32, device="cuda") for _ in range(nbuf)]
-                order = [int(x) for x in rng.integers(0, len(hs), size=36)]
+                order = [int(x) for x in rng.integers(0, len(hs), size=24)]
                 for i, si in enumerate(order):
                     b = bufs[i % nbuf]
                     db.run_device_pipelined(ds[si].data_ptr(), ds[si].numel(), b[0].data_ptr(), b[1].data_ptr(), b[2].data_ptr())
