@@ -39,8 +39,9 @@ def test_hip_sketch_equals_oracle(hip_lib):
     from yacht_amd import sketch
 
     path = os.path.join(FX, "GCF_018918235.1_genomic.fna.gz")
-    # (k <= 32: the 2-bit kernel, every shape of the MurmurHash3 tail; k = 51: the byte-wise kernel)
-    for k, scaled in ((31, 1000), (21, 100), (51, 1000), (32, 1000), (16, 100), (15, 100), (17, 200), (8, 20), (24, 100), (25, 100)):
+    # (k <= 32 / k <= 64: the 2-bit kernel on a 64- / 128-bit word, every shape of the MurmurHash3 tail; k = 70: the byte-wise kernel)
+    for k, scaled in ((31, 1000), (21, 100), (51, 1000), (32, 1000), (16, 100), (15, 100), (17, 200), (8, 20), (24, 100), (25, 100),
+                      (33, 500), (40, 500), (41, 500), (48, 500), (49, 500), (56, 500), (63, 500), (64, 500), (70, 500)):
         want_m, want_a = so.sketch_fasta(path, k, scaled)
         sig = sketch.sketch_file(path, k, scaled)
         assert np.array_equal(sig.minhash.mins, want_m)
@@ -72,7 +73,7 @@ def test_host_call_hashes_the_sequence_while_it_arrives(hip_lib):
     seq[rng.integers(0, n, size=500)] = ord("N")
     seq[(32 << 20) - 40:(32 << 20) - 35] = ord("n")     # bad bases right at a piece boundary
     seq[(32 << 20) + 3] = ord("-")
-    for k, scaled in ((31, 1000), (51, 2000)):
+    for k, scaled in ((31, 1000), (51, 2000), (70, 2000)):
         host = np.sort(sketch.hash_kmers([seq], k, scaled))
         lib = _lib.load()
         mh = sketch.max_hash_for_scaled(scaled)

@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(SK_THREADS) k_sketch_dna(const u8* __restrict_
     }
 }
 
-// ---- k <= 32: the k-mer as a 2-bit string in one register pair ---------------------------------------------------------
+// ---- k <= 64: the k-mer as a 2-bit string in one 64- or 128-bit word ---------------------------------------------------------
 // The first kernel above reads every window's k bytes three times through L1 (23 G bases/s at k = 31: below what PCIe
 // delivers).  Here a workgroup stages its 8 192 + k - 1 bases ONCE, coalesced, as 2-bit codes (16 bases per word, A C G T
 // = 0 1 2 3) with one "not a base" bit each; a lane owns RL_RUN = 32 consecutive windows = 64 staged bases in four
@@ -131,7 +131,7 @@ __global__ void __launch_bounds__(SK_THREADS) k_sketch_dna(const u8* __restrict_
 constexpr int RL_THREADS = 256;
 constexpr int RL_RUN = 32;                         // windows per lane
 constexpr int RL_WIN = RL_THREADS * RL_RUN;        // windows per workgroup
-constexpr int RL_UNITS = RL_WIN / 16 + 4;          // staged 16-base units (the last lane reads four from its first)
+constexpr int RL_UNITS = RL_WIN / 16 + 4;          // staged 16-base units (the last lane reads six from its first)
 
 // four bytes -> their 2-bit codes in the low bits of each byte, and bit 7 of a byte set when it is not A/C/G/T (either case)
 __device__ __forceinline__ void codes_of4(u32 w, u32& codes, u32& bad) {
@@ -154,9 +154,24 @@ __device__ __forceinline__ u64 ascii_of8(u32 v16) {
     return 0x4141414141414141ull + (lo & ~hi) * 2ull + (hi & ~lo) * 6ull + (lo & hi) * 0x13ull;
 }
 
+typedef unsigned __int128 u128;
+template <int KW> struct RollWord;
+template <> struct RollWord<1> { typedef u64 type; };
+template <> struct RollWord<2> { typedef u128 type; };
+__device__ __forceinline__ u32 top_bit_plus1(u64 x) { return x ? 64u - (u32)__clzll((long long)x) : 0u; }
+__device__ __forceinline__ u32 top_bit_plus1(u128 x) {
+    const u64 h = (u64)(x >> 64);
+    return h ? 64u + top_bit_plus1(h) : top_bit_plus1((u64)x);
+}
+
+// KW = 1: k <= 32, the k-mer in one 64-bit word; KW = 2: k <= 64, in a 128-bit one (the same code on a wider word)
+template <int KW>
 __global__ void __launch_bounds__(RL_THREADS) k_sketch_dna_roll(const u8* __restrict__ seq, u64 n, u32 k, u64 seed,
                                                                 u64 max_hash, u64 cap, u64* __restrict__ out,
                                                                 u64* __restrict__ out_count, u64 win0) {
+    typedef typename RollWord<KW>::type word;
+    constexpr u32 BITS = 64u * KW;      // of a word = 32 KW bases
+    constexpr int NW = 4 * KW;          // 8-byte ASCII words of a k-mer
     __shared__ u32 lcode[RL_UNITS];
     __shared__ u32 lbad[RL_UNITS];
     __shared__ u64 lbuf[SK_LCAP];
@@ -186,30 +201,41 @@ __global__ void __launch_bounds__(RL_THREADS) k_sketch_dna_roll(const u8* __rest
         lbad[u] = bad;
     }
     __syncthreads();
+    // the lane's 32 windows reach 32 + k - 1 <= 95 bases: units 2 l .. 2 l + 5 (six of sixteen bases; four when k <= 32)
     const u32 l2 = 2u * threadIdx.x;
-    const u64 lo = (u64)lcode[l2] | ((u64)lcode[l2 + 1] << 32), hi = (u64)lcode[l2 + 2] | ((u64)lcode[l2 + 3] << 32);
-    const u64 bad = (u64)lbad[l2] | ((u64)lbad[l2 + 1] << 16) | ((u64)lbad[l2 + 2] << 32) | ((u64)lbad[l2 + 3] << 48);
-    const u64 mask = (k == 32) ? ~0ull : ((1ull << (2 * k)) - 1ull);
+    word P0 = 0, P1 = 0, bad = 0;
+#pragma unroll
+    for (int q = 0; q < 2 * KW; ++q) {
+        P0 |= (word)lcode[l2 + q] << (32 * q);
+        bad |= (word)lbad[l2 + q] << (16 * q);
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        P1 |= (word)lcode[l2 + 2 * KW + q] << (32 * q);
+        bad |= (word)lbad[l2 + 2 * KW + q] << (16 * (2 * KW + q));
+    }
+    const word one = 1;
+    const word mask = (2 * k == BITS) ? ~(word)0 : ((one << (2 * k)) - one);
     const u64 w0 = B0 + (u64)threadIdx.x * RL_RUN;  // the lane's first window
-    // big-endian packing of the first k - 1 bases; the first window that no bad base among them reaches
-    u64 fbe = 0;
-    for (u32 j = 0; j + 1 < k; ++j) fbe = (fbe << 2) | ((lo >> (2 * j)) & 3ull);   // (k - 1 <= 31 bases: all in lo)
-    const u64 head_bad = (k > 1) ? (bad & ((1ull << (k - 1)) - 1ull)) : 0ull;
-    u32 first_ok = head_bad ? (64u - (u32)__clzll((long long)head_bad)) : 0u;
+    // big-endian packing of the first k - 1 bases (all in P0); the first window that no bad base among them reaches
+    word fbe = 0;
+    for (u32 j = 0; j + 1 < k; ++j) fbe = (fbe << 2) | ((P0 >> (2 * j)) & (word)3);
+    const word head_bad = (k > 1) ? (bad & ((one << (k - 1)) - one)) : (word)0;
+    u32 first_ok = top_bit_plus1(head_bad);
     const u64 c1 = 0x87c37b91114253d5ull, c2 = 0x4cf5ad432745937full;
     const u32 nblocks = k / 16, rem = k & 15u;
     for (u32 t = 0; t < (u32)RL_RUN; ++t) {
         const u32 p = t + k - 1;                       // the base this window adds
-        if ((bad >> p) & 1ull) first_ok = p + 1;
-        const u64 fle = (t ? ((lo >> (2 * t)) | (hi << (64 - 2 * t))) : lo) & mask;
-        fbe = ((fbe << 2) | ((fle >> (2 * (k - 1))) & 3ull)) & mask;
+        if ((u32)(bad >> p) & 1u) first_ok = p + 1;
+        const word fle = (t ? ((P0 >> (2 * t)) | (P1 << (BITS - 2 * t))) : P0) & mask;
+        fbe = ((fbe << 2) | ((fle >> (2 * (k - 1))) & (word)3)) & mask;
         if (t < first_ok || w0 + t >= n_win) continue;
-        const u64 rbe = ~fle & mask;                   // BE(reverse complement)
-        const u64 canon = (rbe < fbe) ? (~fbe & mask) : fle;   // LE packing of the canonical k-mer
+        const word rbe = ~fle & mask;                  // BE(reverse complement)
+        const word canon = (rbe < fbe) ? (~fbe & mask) : fle;   // LE packing of the canonical k-mer
         // its ASCII bytes, 8 per word, bytes from k on zero
-        u64 W[4];
+        u64 W[NW];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
+        for (int m = 0; m < NW; ++m) {
             const int cnt = (int)k - 8 * m;            // bytes of this word
             u64 a = ascii_of8((u32)(canon >> (16 * m)) & 0xffffu);
             if (cnt <= 0) a = 0;
@@ -217,28 +243,23 @@ __global__ void __launch_bounds__(RL_THREADS) k_sketch_dna_roll(const u8* __rest
             W[m] = a;
         }
         u64 h1 = seed, h2 = seed;
-        if (nblocks >= 1) {
-            u64 k1 = W[0], k2 = W[1];
-            k1 *= c1; k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1;
-            h1 = rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729ull;
-            k2 *= c2; k2 = rotl64(k2, 33); k2 *= c1; h2 ^= k2;
-            h2 = rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5ull;
+#pragma unroll
+        for (int blk = 0; blk < NW / 2; ++blk) {
+            if ((u32)blk < nblocks) {
+                u64 k1 = W[2 * blk], k2 = W[2 * blk + 1];
+                k1 *= c1; k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1;
+                h1 = rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729ull;
+                k2 *= c2; k2 = rotl64(k2, 33); k2 *= c1; h2 ^= k2;
+                h2 = rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5ull;
+            }
         }
-        if (nblocks >= 2) {
-            u64 k1 = W[2], k2 = W[3];
-            k1 *= c1; k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1;
-            h1 = rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729ull;
-            k2 *= c2; k2 = rotl64(k2, 33); k2 *= c1; h2 ^= k2;
-            h2 = rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5ull;
-        }
-        if (rem > 8) {
-            u64 k2 = (nblocks == 0) ? W[1] : W[3];
-            k2 *= c2; k2 = rotl64(k2, 33); k2 *= c1; h2 ^= k2;
-        }
-        if (rem > 0) {
-            u64 k1 = (nblocks == 0) ? W[0] : W[2];
-            k1 *= c1; k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1;
-        }
+        // the tail: the words behind the last whole block (zero when k is a multiple of 16)
+        u64 t1 = 0, t2 = 0;
+#pragma unroll
+        for (int blk = 0; blk < NW / 2; ++blk)
+            if ((u32)blk == nblocks) { t1 = W[2 * blk]; t2 = W[2 * blk + 1]; }
+        if (rem > 8) { t2 *= c2; t2 = rotl64(t2, 33); t2 *= c1; h2 ^= t2; }
+        if (rem > 0) { t1 *= c1; t1 = rotl64(t1, 31); t1 *= c2; h1 ^= t1; }
         h1 ^= (u64)k; h2 ^= (u64)k;
         h1 += h2; h2 += h1;
         h1 = fmix64(h1); h2 = fmix64(h2);
@@ -264,18 +285,19 @@ __global__ void __launch_bounds__(RL_THREADS) k_sketch_dna_roll(const u8* __rest
 }
 
 // The launch both entry points share: the windows [win0, win_end) of a sequence of which n_bytes are present (win0 a
-// multiple of SK_WIN_ALIGN); k <= 32 through the 2-bit kernel (YH_SKETCH_BYTES=1 behind the tuning gate: the first one).
+// multiple of SK_WIN_ALIGN); k <= 64 through the 2-bit kernel (YH_SKETCH_BYTES=1 behind the tuning gate: the first one).
 constexpr u64 SK_WIN_ALIGN = RL_WIN;  // (a multiple of both kernels' windows per workgroup)
 static_assert(RL_WIN % (SK_THREADS * SK_ITEMS) == 0, "one alignment for both kernels");
 static int launch_sketch(const u8* d_seq, u64 n_bytes, u32 k, u64 seed, u64 max_hash, u64 cap, u64* d_out, u64* d_cnt, hipStream_t st,
                          u64 win0, u64 win_end) {
     if (win_end <= win0) return YH_OK;
     static const bool bytes_only = [] { const char* e = yh_tune_env("YH_SKETCH_BYTES"); return e && e[0] == '1'; }();
-    const bool roll = k <= 32 && !bytes_only && (reinterpret_cast<uintptr_t>(d_seq) & 15u) == 0;
+    const bool roll = k <= 64 && !bytes_only && (reinterpret_cast<uintptr_t>(d_seq) & 15u) == 0;
     const u64 per_block = roll ? (u64)RL_WIN : (u64)SK_THREADS * SK_ITEMS;
     const u64 blocks = (win_end - win0 + per_block - 1) / per_block;
     if (blocks > 0x7fffffffull) { yh_set_error("sequence too long for one call"); return YH_ERR_INVALID_ARG; }
-    if (roll) k_sketch_dna_roll<<<(u32)blocks, RL_THREADS, 0, st>>>(d_seq, n_bytes, k, seed, max_hash, cap, d_out, d_cnt, win0);
+    if (roll && k <= 32) k_sketch_dna_roll<1><<<(u32)blocks, RL_THREADS, 0, st>>>(d_seq, n_bytes, k, seed, max_hash, cap, d_out, d_cnt, win0);
+    else if (roll) k_sketch_dna_roll<2><<<(u32)blocks, RL_THREADS, 0, st>>>(d_seq, n_bytes, k, seed, max_hash, cap, d_out, d_cnt, win0);
     else k_sketch_dna<<<(u32)blocks, SK_THREADS, 0, st>>>(d_seq, n_bytes, k, seed, max_hash, cap, d_out, d_cnt, win0);
     YH_HIP(hipGetLastError());
     return YH_OK;
