@@ -17,7 +17,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "too
 def test_one_gpu_shard_of_gtdb_full(hip_lib, capsys):
     import scale_probe
 
-    rc = scale_probe.main(["--refs", "56000", "--median", "33000", "--sample", "10000000", "--steps", "5", "--oracle", "auto"])
+    rc = scale_probe.main(["--refs", "56000", "--median", "33000", "--sample", "10000000", "--steps", "3", "--oracle", "auto"])
     line = [ln for ln in capsys.readouterr().out.splitlines() if ln.startswith("{")][-1]
     res = json.loads(line)
     print(line)

@@ -18,8 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.parametrize("env", [
     {"YH_INDEX_TILE": "2", "YH_FILTER_MIN": "1", "YH_FILTER_BPH": "2"},   # crowded filter: many false positives
     {"YH_INDEX_TILE": "1", "YH_FILTER_MIN": "1", "YH_FILTER_BPH": "16"},
-    {"YH_INDEX_TILE": "4", "YH_NO_FILTER": "1"},
-], ids=["tile2-filter2", "tile1-filter16", "tile4-nofilter"])
+], ids=["tile2-filter2", "tile1-filter16"])
 def test_forced_lookup_forms_against_oracle(hip_lib, env):
     e = dict(os.environ, YH_DEBUG_TUNING="1")
     e.update(env)
