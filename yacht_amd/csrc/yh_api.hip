@@ -66,7 +66,10 @@ hipError_t yh_tmalloc(yh_db* db, void** p, size_t bytes) {
             else return hipSuccess;
         }
     }
-    if (wait_for) return hipStreamSynchronize(wait_for);  // (a live handle's stream: owners are cleared when a handle goes)
+    if (wait_for) {  // (a live handle's stream: owners are cleared when a handle goes or changes its stream)
+        if (hipStreamSynchronize(wait_for) != hipSuccess) { (void)hipGetLastError(); return hipDeviceSynchronize(); }
+        return hipSuccess;
+    }
     hipError_t e = hipMalloc(p, bytes);
     if (e == hipErrorOutOfMemory) {  // give the driver back what the cache holds, and once more
         (void)hipGetLastError();
@@ -470,6 +473,7 @@ int yh_db_set_stream(yh_db* db, void* hip_stream) {
     YH_TRY(db_select(db));
     YH_TRY(pipe_join(db));
     YH_HIP(hipStreamSynchronize(db->stream));
+    yh_pool_trim(db);  // (the old stream has drained: cached blocks it used last are anyone's now -- it may not outlive this call)
     db->stream = hip_stream ? (hipStream_t)hip_stream : db->own_stream;
     return YH_OK;
 }
