@@ -169,6 +169,10 @@ def main() -> int:
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
+    if os.environ.get("YH_BENCH_TRACE_HANG"):  # diagnostics: every thread's stack to stderr after that many seconds
+        import faulthandler
+
+        faulthandler.dump_traceback_later(float(os.environ["YH_BENCH_TRACE_HANG"]), repeat=False, file=sys.stderr, exit=False)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs between the ranks on this pool
     import torch
     import torch.distributed as dist
