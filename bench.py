@@ -64,6 +64,7 @@ def parse_args():
                          "in it (dist.HashRangeRefDB: table AND lookups divide by N; counts are summed); refs = every GPU holds a "
                          "range of the REFERENCES + ghosts and looks up the whole sample (dist.ShardedRefDB: the capacity mode)")
     ap.add_argument("--no-train", action="store_true", help="N=1: skip the `yacht train` block (configs[3], bench_train.py as a child process)")
+    ap.add_argument("--no-sketch", action="store_true", help="N=1: skip the sketcher block (bench_sketch.py as a child process)")
     ap.add_argument("--block-mode", default="batched", choices=["batched", "steps"],
                     help="N>1 with --shard hash: batched (default) = the samples of a block go through the batched kernels in ONE "
                          "pass per rank (a rank's share of one sample is too few lookups to fill a launch) around one exchange of "
@@ -1009,6 +1010,22 @@ def main() -> int:
             train = {"error": repr(ex)}
         train["wall_s_of_the_child"] = round(time.perf_counter() - t0, 1)
 
+    # ---- the sketcher next to the path, likewise as a child process with its own JSON line
+    sketch_block = None
+    if rank == 0 and not multi and not args.no_sketch and not args.no_train:
+        import subprocess
+
+        t0 = time.perf_counter()
+        try:
+            sp = subprocess.run([sys.executable, os.path.join(ROOT, "bench_sketch.py"), "--steps", "6"],
+                                stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+            sl = [ln for ln in sp.stdout.splitlines() if ln.startswith("{")]
+            sketch_block = json.loads(sl[-1]) if sl else {"error": (sp.stderr or "")[-500:]}
+            sketch_block["returncode"] = sp.returncode
+        except Exception as ex:  # noqa: BLE001
+            sketch_block = {"error": repr(ex)}
+        sketch_block["wall_s_of_the_child"] = round(time.perf_counter() - t0, 1)
+
     if rank == 0:
         try:
             import scipy
@@ -1068,6 +1085,7 @@ def main() -> int:
             "host_inclusive": host_inclusive,
             "scaling_model": scaling_model,
             "train": train,
+            "sketch": sketch_block,
             "real_shape": real_shape,
             "batched": batched,
             "paths": paths,
