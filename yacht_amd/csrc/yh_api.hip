@@ -413,8 +413,8 @@ int yh_db_destroy(yh_db* db) {
             if (db->ctx_count[c]) (void)hipFree(db->ctx_count[c]);
         }
     }
-    void* ptrs[] = {db->d_values, db->d_offsets, db->d_sizes, db->d_g, db->d_po, db->d_pr, db->d_pg, db->d_nshared, db->d_pq,
-                    db->d_pq_count, db->d_dh, db->d_dref, db->d_dir, db->d_bkt, db->d_cbkt, db->d_ovf_keys, db->d_ovf_vals,
+    void* ptrs[] = {db->d_values, db->d_offsets, db->d_sizes, db->d_g, db->d_po, db->d_pr, db->d_pg, db->d_nshared,
+                    db->d_dh, db->d_dref, db->d_dir, db->d_bkt, db->d_cbkt, db->d_ovf_keys, db->d_ovf_vals,
                     db->d_rpo, db->d_rg, db->d_rrec, db->d_rrecx, db->d_filter, db->d_hrec, db->d_hrecx, db->d_hmult, db->d_hpo,
                     db->d_work, db->d_work_count, db->d_mask, db->d_maskbits, db->d_hit, db->d_excl_e, db->d_overlap_tmp,
                     db->d_sample_tmp, db->d_out_tmp, db->d_flag, db->d_reps, db->d_batch, db->d_sdelta, db->d_shdr, db->d_srec,

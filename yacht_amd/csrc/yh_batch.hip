@@ -11,72 +11,12 @@
 // Batched `yacht run`: up to 64 samples against the resident database in one pass
 // =================================================================================================
 // Samples are looked up through the distinct-hash directory (k_index_lookup's scheme), one lane per
-// sample hash of ANY sample.  Per-sample state is carried as 64-bit words: hitword[g] = samples that
-// contain shared hash g, maskword[r] = samples that overlap reference r.  Exclusivity of a shared
-// hash for all samples at once is bit-sliced counting over its holders' mask words:
-//     ones ^= w, twos |= (ones_before & w)   ->   held by exactly one masked reference = ones & ~twos.
+// sample hash of ANY sample.  Per-sample state is carried as 64-bit words: maskword[r] = samples that overlap
+// reference r.  Exclusivity for all samples at once, over a reference's DISTINCT holder sets (k_batch_sets):
+//     excl = maskword[r] & ~(OR of the other holders' words).
 namespace {
 
-// Exclusive sums from the posting lists, in two launches.
-//
-// k_excl_collect: one coalesced pass over pr[] (four postings per lane per step, mask probes as
-// BITS: N/8 bytes stay resident in every CU's L1, while random byte reads of an N-byte mask pulled
-// one cache line per posting through L2).  Postings of masked references are only COLLECTED:
-// appended to a per-workgroup LDS list and flushed to a queue in HBM with one atomic per workgroup.
-// (~1 % of the postings belong to masked references, which is about every second wave; walking the
-// dependent chain below right there left 1-2 lanes per wave busy for several microseconds.)
-//
-// k_excl_apply: one lane per collected posting (r holds shared hash g), all lanes busy:
-//   c = masked holders of g;  c == 1 -> g is exclusive to r inside the subset (ex_e, and ex_m
-//   when g is in the sample);  g in the sample -> r's "shared overlap" grows by one (ovsh).
 constexpr int EXCL_BLOCK = 256;
-// Workgroup b owns the contiguous vectors [b*chunk, (b+1)*chunk) of pr[] (a vector = 4 postings)
-// and the queue segment that starts at posting index 4*b*chunk: even if every posting of its range
-// is collected the segment cannot overflow, so there is no global counter (10^4 atomics on one word
-// cost ~120 us) and no zeroing; qcount[b] is written by every workgroup.
-__global__ void __launch_bounds__(EXCL_BLOCK) k_excl_collect(u64 n_post, u64 chunk, const u32* __restrict__ pr,
-                                                             const u32* __restrict__ maskbits,
-                                                             u32* __restrict__ queue, u32* __restrict__ qcount) {
-    __shared__ u32 lq[EXCL_BLOCK * 4];
-    __shared__ u32 lfill;
-    if (threadIdx.x == 0) lfill = 0;
-    __syncthreads();
-    auto masked = [&](u32 r) -> bool { return (maskbits[r >> 5] >> (r & 31u)) & 1u; };
-    const u64 n4 = n_post >> 2;
-    const uint4* __restrict__ pr4 = reinterpret_cast<const uint4*>(pr);
-    const u64 v_begin = (u64)blockIdx.x * chunk;
-    const u64 v_end = min(n4 + 1, v_begin + chunk);  // vector n4 stands for the 0-3 trailing postings
-    u32* seg = queue + 4 * v_begin;
-    u32 done = 0;  // entries already flushed to seg (same value in every thread)
-    for (u64 v0 = v_begin; v0 < v_end; v0 += EXCL_BLOCK) {
-        const u64 v = v0 + threadIdx.x;
-        if (v < v_end && v < n4) {
-            const uint4 r = pr4[v];
-            const bool m0 = masked(r.x), m1 = masked(r.y), m2 = masked(r.z), m3 = masked(r.w);
-            const u32 cnt = (u32)m0 + (u32)m1 + (u32)m2 + (u32)m3;
-            if (cnt) {
-                u32 slot = atomicAdd(&lfill, cnt);
-                const u32 k = (u32)(4 * v);
-                if (m0) lq[slot++] = k;
-                if (m1) lq[slot++] = k + 1;
-                if (m2) lq[slot++] = k + 2;
-                if (m3) lq[slot++] = k + 3;
-            }
-        } else if (v < v_end && v == n4) {
-            for (u64 k = n4 << 2; k < n_post; ++k)
-                if (masked(pr[k])) lq[atomicAdd(&lfill, 1u)] = (u32)k;
-        }
-        __syncthreads();
-        const u32 f = lfill;
-        for (u32 e = threadIdx.x; e < f; e += EXCL_BLOCK) seg[done + e] = lq[e];
-        done += f;
-        __syncthreads();
-        if (threadIdx.x == 0) lfill = 0;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) qcount[blockIdx.x] = done;
-}
-
 inline u32 grid_for(u64 work_items, u32 block, u32 max_blocks = 16384) {
     u64 g = (work_items + block - 1) / block;
     if (g < 1) g = 1;
@@ -87,7 +27,7 @@ inline u32 grid_for(u64 work_items, u32 block, u32 max_blocks = 16384) {
 __global__ void __launch_bounds__(256) k_batch_lookup(const u64* __restrict__ samples, const u64* __restrict__ soff,
                                                       u32 n_samples, const YhDirView dv, const u64* __restrict__ po,
                                                       const u32* __restrict__ pr, u64 n_refs,
-                                                      u32* __restrict__ overlap /* [B][N] */, u64* __restrict__ hitword,
+                                                      u32* __restrict__ overlap /* [B][N] */, u32* __restrict__ ovsh /* [B][N]: hits on shared hashes */,
                                                       u64 n_chunks, u64 chunk_mul, const u32* __restrict__ filter,
                                                       u64 filter_mul) {
     __shared__ u64 off[65];
@@ -118,13 +58,17 @@ __global__ void __launch_bounds__(256) k_batch_lookup(const u64* __restrict__ sa
             atomicAdd(&row[r], 1u);
         } else {
             const u32 gi = r & 0x7fffffffu;
-            atomicOr((unsigned long long*)&hitword[gi], 1ull << s);
-            for (u64 q = po[gi], qe = po[gi + 1]; q < qe; ++q) atomicAdd(&row[pr[q]], 1u);
+            u32* row2 = ovsh + (u64)s * n_refs;
+            for (u64 q = po[gi], qe = po[gi + 1]; q < qe; ++q) {
+                const u32 holder = pr[q];
+                atomicAdd(&row[holder], 1u);
+                atomicAdd(&row2[holder], 1u);
+            }
         }
     }
 }
 
-// maskword[r] = samples with overlap > 0; anybits = "some sample overlaps r" (for k_excl_collect)
+// maskword[r] = samples with overlap > 0; anybits = "some sample overlaps r" (for k_batch_worklist)
 __global__ void __launch_bounds__(256) k_batch_maskwords(const u32* __restrict__ overlap, u32 n_samples, u64 n_refs,
                                                          u64* __restrict__ maskword, u32* __restrict__ anybits) {
     const u64 r = blockIdx.x * (u64)blockDim.x + threadIdx.x;
@@ -139,39 +83,95 @@ __global__ void __launch_bounds__(256) k_batch_maskwords(const u32* __restrict__
     }
 }
 
-__global__ void __launch_bounds__(EXCL_BLOCK) k_batch_apply(const u32* __restrict__ queue, const u32* __restrict__ qcount,
-                                                            u64 chunk, const u64* __restrict__ po,
-                                                            const u32* __restrict__ pr, const u32* __restrict__ pg,
-                                                            const u64* __restrict__ maskword,
-                                                            const u64* __restrict__ hitword, u64 n_refs,
-                                                            u32* __restrict__ ex_e, u32* __restrict__ ex_m,
-                                                            u32* __restrict__ ovsh /* each [B][N] */) {
-    const u32 n = qcount[blockIdx.x];
-    const u32* seg = queue + 4 * (u64)blockIdx.x * chunk;
-    for (u32 e = threadIdx.x; e < n; e += EXCL_BLOCK) {
-        const u32 k = seg[e];
-        const u32 r = pr[k];
-        const u32 gi = pg[k];
+// The work list of the exclusive pass: every reference some sample overlaps appends pieces of <= BATCH_PIECE of its
+// DISTINCT holder-set records (yh_db::d_hrec, [hpo[r], hpo[r + 1])); work_count zeroed by the caller.
+constexpr u32 BATCH_PIECE = 256;
+__global__ void __launch_bounds__(256) k_batch_worklist(u64 n, const u32* __restrict__ anybits, const u32* __restrict__ hpo,
+                                                        uint4* __restrict__ work, u32* __restrict__ work_count) {
+    __shared__ u32 lds[5];
+    const u32 lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const u64 j = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    const bool in = j < n && ((anybits[j >> 5] >> (j & 31u)) & 1u);
+    const u32 first = in ? hpo[j] : 0u, last = in ? hpo[j + 1] : 0u;
+    const u32 np = (last - first + BATCH_PIECE - 1u) / BATCH_PIECE;
+    u32 v = np;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const u32 t = (u32)__shfl_up((int)v, off);
+        if (lane >= (u32)off) v += t;
+    }
+    if (lane == 63) lds[wv] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const u32 total = lds[0] + lds[1] + lds[2] + lds[3];
+        lds[4] = total ? atomicAdd(work_count, total) : 0u;
+    }
+    __syncthreads();
+    u32 at = lds[4] + v - np;
+    for (u32 q = 0; q < wv; ++q) at += lds[q];
+    for (u32 i = 0; i < np; ++i) {
+        const u32 f = first + i * BATCH_PIECE;
+        work[at + i] = make_uint4((u32)j, f, min(f + BATCH_PIECE, last), 0u);
+    }
+}
+
+// One wave per piece (reference r, <= 256 of its holder-set records).  For all samples at once: a shared hash of r is
+// exclusive to r in sample s iff r is in s's subset and none of the OTHER holders is --
+//     excl = maskword[r] & ~(OR of the other holders' mask words),
+// and every set bit s of it adds the record's multiplicity (shared hashes of r with exactly these other holders) to
+// ex_e[s][r]: one wave sum and one atomic per (piece, sample that overlaps r).  (Before: a pass over ALL postings to
+// collect those of masked references, then bit-sliced counting per posting: 149 us per 32-sample call against ~20.)
+__global__ void __launch_bounds__(256) k_batch_sets(const uint4* __restrict__ work, const u32* __restrict__ work_count,
+                                                    const uint4* __restrict__ hrec, const uint4* __restrict__ hrecx,
+                                                    const u32* __restrict__ hmult, const u32* __restrict__ pr,
+                                                    const u64* __restrict__ maskword, u64 n_refs, u32* __restrict__ ex_e) {
+    const u32 lane = threadIdx.x & 63u;
+    const u32 n_work = *work_count;
+    for (u32 w = blockIdx.x * 4u + (threadIdx.x >> 6); w < n_work; w += gridDim.x * 4u) {
+        const uint4 piece = work[w];
+        const u32 r = piece.x;
         const u64 wr = maskword[r];
-        const u64 hw = hitword[gi];
-        u64 ones = 0, twos = 0;
-        for (u64 q = po[gi], qe = po[gi + 1]; q < qe; ++q) {
-            const u64 w = maskword[pr[q]];
-            twos |= ones & w;
-            ones ^= w;
+        u64 excl[4];
+        u32 mu[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const u32 k = piece.y + 64u * u + lane;
+            excl[u] = 0;
+            mu[u] = 0;
+            if (k < piece.z) {
+                const uint4 rec = hrec[k];
+                u64 others = 0;
+                if (rec.w != 0xffffffffu) {  // up to seven other holders inline
+                    if (rec.w > 0) others |= maskword[rec.x];
+                    if (rec.w > 1) others |= maskword[rec.y];
+                    if (rec.w > 2) others |= maskword[rec.z];
+                    if (rec.w > 3) {
+                        const uint4 rx = hrecx[k];
+                        others |= maskword[rx.x];
+                        if (rec.w > 4) others |= maskword[rx.y];
+                        if (rec.w > 5) others |= maskword[rx.z];
+                        if (rec.w > 6) others |= maskword[rx.w];
+                    }
+                } else {                     // a longer list: {first index in pr, holders}
+                    for (u32 q = rec.x, qe = rec.x + rec.y; q < qe; ++q) {
+                        const u32 o = pr[q];
+                        if (o != r) others |= maskword[o];
+                    }
+                }
+                excl[u] = wr & ~others;
+                mu[u] = hmult[k];
+            }
         }
-        u64 excl = ones & ~twos & wr;  // samples in which r is the only masked holder of g
-        while (excl) {
-            const u32 s = (u32)__ffsll((long long)excl) - 1u;
-            excl &= excl - 1;
-            atomicAdd(&ex_e[(u64)s * n_refs + r], 1u);
-            if ((hw >> s) & 1ull) atomicAdd(&ex_m[(u64)s * n_refs + r], 1u);
-        }
-        u64 sh = wr & hw;  // samples that contain g and overlap r
-        while (sh) {
-            const u32 s = (u32)__ffsll((long long)sh) - 1u;
-            sh &= sh - 1;
-            atomicAdd(&ovsh[(u64)s * n_refs + r], 1u);
+        u64 todo = wr;  // (wave-uniform: the samples that overlap r)
+        while (todo) {
+            const u32 s = (u32)__ffsll((long long)todo) - 1u;
+            todo &= todo - 1;
+            u32 v = 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v += ((excl[u] >> s) & 1ull) ? mu[u] : 0u;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) v += (u32)__shfl_xor((int)v, off);
+            if (lane == 0 && v) atomicAdd(&ex_e[(u64)s * n_refs + r], v);
         }
     }
 }
@@ -191,7 +191,9 @@ __global__ void __launch_bounds__(256) k_batch_or_maskwords(const u64* __restric
     }
 }
 
-// in place: ex_e -> n_excl, ex_m -> n_match for every (sample, reference)
+// ex_e -> n_excl in place, n_match written, for every (sample, reference).  A shared hash found in sample s has ALL its
+// holders in s's subset (each of them overlaps s by that very hash), so it is exclusive to none of them: the matches are
+// the hits on unshared hashes, n_match = overlap - hits on shared hashes (what the single-sample step does too).
 // (maskword != nullptr -- a hash-range shard: the subset is the global one, a reference may be in it without an overlap
 // in THIS rank's range)
 __global__ void __launch_bounds__(256) k_batch_final(u32 n_samples, u64 n_refs, const u32* __restrict__ sizes,
@@ -205,7 +207,7 @@ __global__ void __launch_bounds__(256) k_batch_final(u32 n_samples, u64 n_refs, 
         const bool in = maskword ? ((maskword[r] >> (t / n_refs)) & 1ull) != 0 : ov != 0;
         if (in) {
             ex_e[t] = sizes[r] - nshared[r] + ex_e[t];
-            ex_m[t] = ov - ovsh[t] + ex_m[t];
+            ex_m[t] = ov - ovsh[t];
         } else {
             ex_e[t] = 0;
             ex_m[t] = 0;
@@ -230,16 +232,16 @@ int yh_q_run_batch(yh_db* db, const u64* d_samples, const u64* d_soff, u32 n_sam
     if (N == 0) return YH_OK;
     const u64 BN = (u64)n_samples * N;
     const u64 G = db->n_shared;
-    // scratch: ovsh [B][N] u32, hitword [G] u64, maskword [N] u64 (kept on the handle, grown on demand)
-    const u64 need = BN * sizeof(u32) + (G + N + 2) * sizeof(u64) + 64;
+    if (G && db->n_postings && !db->d_hrec) { yh_set_error("yh_run_batch needs the holder sets of the handle"); return YH_ERR_UNSUPPORTED; }
+    // scratch: maskword [N] u64, ovsh [B][N] u32 (kept on the handle, grown on demand)
+    const u64 need = BN * sizeof(u32) + (N + 2) * sizeof(u64) + 64;
     if (db->batch_cap < need) {
         YH_HIP(hipStreamSynchronize(st));
         if (db->d_batch) { yh_dfree(db, db->d_batch); db->d_batch = nullptr; db->batch_cap = 0; }
         YH_HIP(hipMalloc((void**)&db->d_batch, need));
         db->batch_cap = need;
     }
-    u64* d_hitword = reinterpret_cast<u64*>(db->d_batch);
-    u64* d_maskword = d_hitword + G + 1;
+    u64* d_maskword = reinterpret_cast<u64*>(db->d_batch);
     u32* d_ovsh = reinterpret_cast<u32*>(d_maskword + N + 1);
     if (phases & 1) {
     YH_HIP(hipMemsetAsync(d_overlap, 0, BN * sizeof(u32), st));
@@ -252,7 +254,7 @@ int yh_q_run_batch(yh_db* db, const u64* d_samples, const u64* d_soff, u32 n_sam
         auto gcd = [](u64 a, u64 b) { while (b) { const u64 t = a % b; a = b; b = t; } return a; };
         while (gcd(mul, n_chunks) != 1) mul += 2;
         k_batch_lookup<<<(u32)std::min<u64>(n_chunks, 8192), 256, 0, st>>>(d_samples, d_soff, n_samples, yh_dir_view(db),
-                                                                           db->d_po, db->d_pr, N, d_overlap, d_hitword,
+                                                                           db->d_po, db->d_pr, N, d_overlap, d_ovsh,
                                                                            n_chunks, mul, yh_filter_of(db), db->filter_mul);
     }
     yh_ring_record_end(db, db->ev_overlap);
@@ -261,18 +263,15 @@ int yh_q_run_batch(yh_db* db, const u64* d_samples, const u64* d_soff, u32 n_sam
     }
     if (!(phases & 2)) { YH_HIP(hipGetLastError()); return YH_OK; }
     YH_HIP(hipMemsetAsync(d_excl, 0, BN * sizeof(u32), st));
-    YH_HIP(hipMemsetAsync(d_match, 0, BN * sizeof(u32), st));
     yh_ring_record_begin(db, db->ev_excl);
     if (d_gathered)
         k_batch_or_maskwords<<<(u32)((N + 255) / 256), 256, 0, st>>>(d_gathered, n_ranks, N, d_maskword, db->d_maskbits);
     if (G && db->n_postings) {
-        const u64 vecs = (db->n_postings >> 2) + 1;
-        const u32 blocks = (u32)std::min<u64>(EXCL_QBLOCKS, (vecs + EXCL_BLOCK - 1) / EXCL_BLOCK);
-        const u64 chunk = (vecs + blocks - 1) / blocks;
-        k_excl_collect<<<blocks, EXCL_BLOCK, 0, st>>>(db->n_postings, chunk, db->d_pr, db->d_maskbits, db->d_pq,
-                                                      db->d_pq_count);
-        k_batch_apply<<<blocks, EXCL_BLOCK, 0, st>>>(db->d_pq, db->d_pq_count, chunk, db->d_po, db->d_pr, db->d_pg,
-                                                     d_maskword, d_hitword, N, d_excl, d_match, d_ovsh);
+        YH_HIP(hipMemsetAsync(db->d_work_count, 0, sizeof(u32), st));
+        k_batch_worklist<<<(u32)((N + 255) / 256), 256, 0, st>>>(N, db->d_maskbits, db->d_hpo, db->d_work, db->d_work_count);
+        const u32 sets_blocks = (u32)std::min<u64>(4096, ((u64)db->n_chunks + 3) / 4 + 1);
+        k_batch_sets<<<sets_blocks, 256, 0, st>>>(db->d_work, db->d_work_count, db->d_hrec, db->d_hrecx, db->d_hmult, db->d_pr,
+                                                   d_maskword, N, d_excl);
     }
     k_batch_final<<<grid_for(BN, 256, 8192), 256, 0, st>>>(n_samples, N, db->d_sizes, db->d_nshared, d_overlap, d_ovsh,
                                                            d_excl, d_match, d_gathered ? d_maskword : nullptr);

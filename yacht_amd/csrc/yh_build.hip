@@ -813,9 +813,6 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, u64* d_
         rc = yh_dmalloc(db, (void**)&db->d_prank, std::max<u64>(db->n_postings, 1) * sizeof(u32));
     if (rc == YH_OK) rc = yh_dmalloc(db, (void**)&db->d_hit, db->n_shared + 16);  // zeroed in 16-byte units
     if (rc == YH_OK && db->n_postings > 0xfffffff0ull) { yh_set_error("more than 2^32 postings"); rc = YH_ERR_UNSUPPORTED; }
-    // (+ slack: the last workgroup's segment may start up to 4*EXCL_QBLOCKS entries late)
-    if (rc == YH_OK) rc = yh_dmalloc(db, (void**)&db->d_pq, (db->n_postings + 8ull * EXCL_QBLOCKS + 16) * sizeof(u32));
-    if (rc == YH_OK) rc = yh_dmalloc(db, (void**)&db->d_pq_count, EXCL_QBLOCKS * sizeof(u32));
     TRACE("index: arrays allocated");
     if (rc == YH_OK) {
         IDX_HIP(hipMemsetAsync(db->d_g, 0, std::max<u64>(db->n_shared, 2) * sizeof(u64), st));

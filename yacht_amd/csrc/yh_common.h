@@ -51,7 +51,6 @@ constexpr u32 STREAM_NONE = 0xffffffffu;
 #ifndef YH_EXCL_PIECE_THREADS
 #define YH_EXCL_PIECE_THREADS 512
 #endif
-constexpr int EXCL_QBLOCKS = 4096;  // workgroups (= queue segments) of k_excl_collect / k_excl_apply
 
 constexpr int TIMING_RING = 32;  // (events are created when a ring records for the first time: a handle that is never timed pays nothing)
 
@@ -166,8 +165,6 @@ struct yh_db {
     u64* d_ovf_keys = nullptr; // [ovf_mask + 1] open-addressing table of the hashes that did not fit their bucket
     u32* d_ovf_vals = nullptr; //                 their dref words (YH_DIR_NONE = empty slot)
     u32 ovf_mask = 0;
-    u32* d_pq = nullptr;       // [postings] queue of postings that belong to masked references (batched run)
-    u32* d_pq_count = nullptr; // [EXCL_QBLOCKS] fill of each workgroup's queue segment
 
     // per-query scratch (allocated once)
     u8* d_mask = nullptr;      // [N]
