@@ -12,12 +12,12 @@ gen = dict(cluster_frac=0.10, median=3300.0, sigma=0.6, lo=300, hi=15000)
 plan = synth.global_db_plan(1, 85205, **gen)
 values, offsets = synth.global_db_refs_device(plan, np.arange(0, 85205), device=str(dev))
 n = 85205
-samples = [synth.global_db_sample_device(plan, 1001 + i, n_sample=1_000_000, n_present=200, device=str(dev)) for i in range(32)]
+samples = [synth.global_db_sample_device(plan, 1001 + i, n_sample=1_000_000, n_present=200, device=str(dev)) for i in range(64)]
 db = RefDB.from_device(values.data_ptr(), offsets.data_ptr(), n, device=0)
 st = torch.cuda.Stream()
 db.set_stream(st.cuda_stream)
-for B in (1, 2, 4, 8, 32):
-    reps = 32 // B
+for B in (1, 2, 4, 8, 16, 32, 64):
+    reps = 64 // B
     packs = []
     for g in range(reps):
         ss = samples[g * B:(g + 1) * B]
