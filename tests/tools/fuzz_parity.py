@@ -7,8 +7,8 @@ Every round draws a database shape (number of references, sketch sizes, clusters
 hashes, hash range from a few thousand values to the full 64 bits, duplicates of whole sketches,
 empty sketches) and a sample (noise, hits, the union of everything, nothing), and compares
 overlap, the run step's exclusive counts (fused path), exclusive counts for an arbitrary subset
-(general path), the independent bsearch kernel and -- on small rounds -- the pairwise list with
-the oracle, bit for bit.  Prints one JSON line; exit code 1 on the first difference.
+(general path), the independent bsearch kernel, the packed / rows / pipelined forms of the step, a batch of five
+samples through the batched run and -- on small rounds -- the pairwise list with the oracle, bit for bit.  Prints one JSON line; exit code 1 on the first difference.
 """
 from __future__ import annotations
 
@@ -115,6 +115,18 @@ def main() -> int:
                             g = b.cpu().numpy().view(np.uint32)
                             assert np.array_equal(g[0], want) and np.array_equal(g[1], we) and np.array_equal(g[2], wm), \
                                 "pipelined steps " + name
+                # a batch through the batched run (needs the bucket table: handles of a non-empty database have it):
+                # the sample, a random half of it, a sample of absent hashes, an empty one and the sample again
+                if n and values.size:
+                    half = sample[rng.random(sample.size) < 0.5]
+                    absent = np.unique(rng.integers(1, 2 ** 62, size=int(rng.integers(1, 2000)), dtype=np.uint64))
+                    batch = [sample, half, absent, np.zeros(0, np.uint64), sample]
+                    bo, be, bm = db.run_batch(batch)
+                    for k, s_k in enumerate(batch):
+                        w_ov = oracle.overlap(values, offsets, s_k)
+                        w_e, w_m = oracle.exclusive(values, offsets, w_ov > 0, s_k)
+                        assert np.array_equal(bo[k], w_ov) and np.array_equal(be[k], w_e) and np.array_equal(bm[k], w_m), \
+                            f"batched run, sample {k} of the batch"
                 if values.size < 400_000:
                     wi, wj, wc, wstats = oracle.train_pairs(values, offsets, c, threads=4)
                     gi, gj, gc = db.pairwise(c)
