@@ -24,47 +24,98 @@ inline u32 grid_for(u64 work_items, u32 block, u32 max_blocks = 16384) {
     return (u32)g;
 }
 
+// A workgroup's unit of work is a TILE of BATCH_TILE consecutive hashes of ONE sample; its hits are summed per reference in
+// an LDS table (two probes, overflow counts directly) and leave as one global atomic per (tile, reference hit) -- a
+// 2 048-hash tile of the bench samples has ~600 hits on ~190 references (timing-only build without any counting: 0.589
+// against 0.712 ms per 32-sample call).
+#ifndef YH_BATCH_TILE
+#define YH_BATCH_TILE 2048
+#endif
+constexpr u32 BATCH_TILE = YH_BATCH_TILE;
+constexpr u32 BATCH_TBITS = 10;
 __global__ void __launch_bounds__(256) k_batch_lookup(const u64* __restrict__ samples, const u64* __restrict__ soff,
                                                       u32 n_samples, const YhDirView dv, const u64* __restrict__ po,
                                                       const u32* __restrict__ pr, u64 n_refs,
                                                       u32* __restrict__ overlap /* [B][N] */, u32* __restrict__ ovsh /* [B][N]: hits on shared hashes */,
-                                                      u64 n_chunks, u64 chunk_mul, const u32* __restrict__ filter,
-                                                      u64 filter_mul) {
+                                                      const u32* __restrict__ filter, u64 filter_mul) {
+    constexpr u32 TSLOTS = 1u << BATCH_TBITS;
     __shared__ u64 off[65];
+    __shared__ u64 s_max_nt;
+    __shared__ u32 tkey[TSLOTS], tcnt[TSLOTS], tcnt2[TSLOTS];
     if (threadIdx.x <= n_samples) off[threadIdx.x] = soff[threadIdx.x];
     __syncthreads();
-    const u64 total = off[n_samples];
-    // 256-hash chunks are visited in a multiplicative permutation (chunk_mul coprime to n_chunks), so
-    // that the workgroups resident at any moment work on ALL samples: a sample's hits land on its few
-    // hundred present references, and same-address atomics serialize (~11 ns each on this part)
-    for (u64 c = blockIdx.x; c < n_chunks; c += gridDim.x) {
-        const u64 t = ((c * chunk_mul) % n_chunks) * 256 + threadIdx.x;
-        if (t >= total) continue;
-        u32 lo = 0, hi = n_samples;  // sample of position t: last s with off[s] <= t
-        while (hi - lo > 1) {
-            const u32 mid = (lo + hi) >> 1;
-            if (off[mid] <= t) lo = mid; else hi = mid;
-        }
-        const u32 s = lo;
-        const u64 h = samples[t];
-        if (filter && h <= dv.max_hash) {  // presence bit first (yh_db::d_filter): clear = not in the database
-            const u64 bit = yh_bucket_of(h, dv.bkt_lsh, filter_mul);
-            if (!((filter[bit >> 5] >> (bit & 31u)) & 1u)) continue;
-        }
-        const u32 r = dv.find(h);
-        if (r == YH_DIR_NONE) continue;
+    if (threadIdx.x == 0) {
+        u64 m = 0;
+        for (u32 q = 0; q < n_samples; ++q) m = max(m, (off[q + 1] - off[q] + BATCH_TILE - 1) / BATCH_TILE);
+        s_max_nt = m;
+    }
+    __syncthreads();
+    const u64 max_nt = s_max_nt;
+    // The tiles of ALL samples in the order of their place in the hash range: slot (v, s) is tile i = v * nt_s / max_nt of
+    // sample s (the sorted samples are uniform over the range: tile i of a sample sits at the i / nt_s quantile).  The
+    // workgroups resident at any moment then (i) work on all samples -- a sample's hits land on its few hundred present
+    // references, and same-address atomics serialize at ~11 ns each -- and (ii) read the SAME presence-filter lines for all
+    // of them; (iii) the slots of one quantile step sit on ONE XCD (workgroups b and b + 8 share an XCD: observed
+    // round-robin dispatch; speed only, never correctness), whose L2 then serves a filter line to all samples but the
+    // first: inside a group of 8 steps x n_samples slots, workgroup l takes step l % 8, sample l / 8.
+    // (A multiplicative permutation of 256-hash chunks, which gave (i) only: 21.0 us per 1e6 sample hashes; with (ii)
+    // 19.7, with (iii) 18.6.)
+    const u64 n_slots = max_nt * n_samples;
+    const u64 group = 8ull * n_samples;
+    for (u64 c = blockIdx.x; c < (n_slots + group - 1) / group * group; c += gridDim.x) {  // (workgroup-uniform)
+        const u64 l = c % group;
+        const u64 v = (c / group) * 8 + (l & 7u);
+        const u32 s = (u32)(l >> 3);
+        if (v >= max_nt) continue;
+        const u64 n_s = off[s + 1] - off[s], nt_s = (n_s + BATCH_TILE - 1) / BATCH_TILE;
+        if (nt_s == 0) continue;
+        const u64 i = v * nt_s / max_nt;
+        if (v > 0 && (v - 1) * nt_s / max_nt == i) continue;  // (a shorter sample: this tile had its slot already)
+        for (u32 k = threadIdx.x; k < TSLOTS; k += 256) { tkey[k] = 0; tcnt[k] = 0; tcnt2[k] = 0; }
+        __syncthreads();
         u32* row = overlap + (u64)s * n_refs;
-        if (!(r & 0x80000000u)) {
-            atomicAdd(&row[r], 1u);
-        } else {
-            const u32 gi = r & 0x7fffffffu;
-            u32* row2 = ovsh + (u64)s * n_refs;
-            for (u64 q = po[gi], qe = po[gi + 1]; q < qe; ++q) {
-                const u32 holder = pr[q];
-                atomicAdd(&row[holder], 1u);
-                atomicAdd(&row2[holder], 1u);
+        u32* row2 = ovsh + (u64)s * n_refs;
+        auto add = [&](u32 ref, bool shared) {
+#if defined(YH_ABLATE_BATCH) && YH_ABLATE_BATCH  // timing-only build (build.py build_variant): no counting, results wrong
+            if (ref == 0x7ffffff1u) row[0] = 1;
+            return;
+#endif
+            u32 slot = (ref * 2654435761u) >> (32 - BATCH_TBITS);
+#pragma unroll 1
+            for (int probe = 0; probe < 2; ++probe, slot = (slot + 1) & (TSLOTS - 1)) {
+                const u32 old = atomicCAS(&tkey[slot], 0u, ref + 1);
+                if (old == 0 || old == ref + 1) {
+                    atomicAdd(&tcnt[slot], 1u);
+                    if (shared) atomicAdd(&tcnt2[slot], 1u);
+                    return;
+                }
+            }
+            atomicAdd(&row[ref], 1u);  // crowded table: count directly
+            if (shared) atomicAdd(&row2[ref], 1u);
+        };
+        const u64 k_end = min(n_s, (i + 1) * BATCH_TILE);
+        for (u64 k = i * BATCH_TILE + threadIdx.x; k < k_end; k += 256) {
+            const u64 h = samples[off[s] + k];
+            if (filter && h <= dv.max_hash) {  // presence bit first (yh_db::d_filter): clear = not in the database
+                const u64 bit = yh_bucket_of(h, dv.bkt_lsh, filter_mul);
+                if (!((filter[bit >> 5] >> (bit & 31u)) & 1u)) continue;
+            }
+            const u32 r = dv.find(h);
+            if (r == YH_DIR_NONE) continue;
+            if (!(r & 0x80000000u)) {
+                add(r, false);
+            } else {
+                const u32 gi = r & 0x7fffffffu;
+                for (u64 q = po[gi], qe = po[gi + 1]; q < qe; ++q) add(pr[q], true);
             }
         }
+        __syncthreads();
+        for (u32 k = threadIdx.x; k < TSLOTS; k += 256)
+            if (tkey[k]) {
+                atomicAdd(&row[tkey[k] - 1], tcnt[k]);
+                if (tcnt2[k]) atomicAdd(&row2[tkey[k] - 1], tcnt2[k]);
+            }
+        __syncthreads();
     }
 }
 
@@ -248,14 +299,11 @@ int yh_q_run_batch(yh_db* db, const u64* d_samples, const u64* d_soff, u32 n_sam
     YH_HIP(hipMemsetAsync(db->d_batch, 0, need, st));
     yh_ring_record_begin(db, db->ev_overlap);
     if (total_hashes && db->n_distinct) {
-        const u64 n_chunks = (total_hashes + 255) / 256;
-        if (n_chunks >> 32) { yh_set_error("batch too large"); return YH_ERR_INVALID_ARG; }
-        u64 mul = (u64)((double)n_chunks * 0.6180339887) | 1;  // golden-ratio stride, made coprime
-        auto gcd = [](u64 a, u64 b) { while (b) { const u64 t = a % b; a = b; b = t; } return a; };
-        while (gcd(mul, n_chunks) != 1) mul += 2;
-        k_batch_lookup<<<(u32)std::min<u64>(n_chunks, 8192), 256, 0, st>>>(d_samples, d_soff, n_samples, yh_dir_view(db),
-                                                                           db->d_po, db->d_pr, N, d_overlap, d_ovsh,
-                                                                           n_chunks, mul, yh_filter_of(db), db->filter_mul);
+        const u64 n_tiles = (total_hashes + BATCH_TILE - 1) / BATCH_TILE + n_samples;  // (a ragged tile per sample)
+        if (n_tiles >> 31) { yh_set_error("batch too large"); return YH_ERR_INVALID_ARG; }
+        k_batch_lookup<<<(u32)std::min<u64>((n_tiles + 7) / 8 * 8, 16384), 256, 0, st>>>(d_samples, d_soff, n_samples, yh_dir_view(db),
+                                                                                       db->d_po, db->d_pr, N, d_overlap, d_ovsh,
+                                                                                       yh_filter_of(db), db->filter_mul);
     }
     yh_ring_record_end(db, db->ev_overlap);
     k_batch_maskwords<<<(u32)((N + 255) / 256), 256, 0, st>>>(d_overlap, n_samples, N, d_maskword, db->d_maskbits);
