@@ -69,7 +69,7 @@ def parse_args():
                     help="N>1 with --shard hash: batched (default) = the samples of a block go through the batched kernels in ONE "
                          "pass per rank (a rank's share of one sample is too few lookups to fill a launch) around one exchange of "
                          "their subset words; steps = every sample is its own pair of half-steps, eight per bit exchange")
-    ap.add_argument("--batch-block", type=int, default=32, help="--block-mode batched: samples per block (<= 64)")
+    ap.add_argument("--batch-block", type=int, default=64, help="--block-mode batched: samples per block (<= 64)")
     ap.add_argument("--no-scaling-model", action="store_true",
                     help="N=1: skip the measurement of one rank's share of a G-way hash-range step (G = 2, 4, 8)")
     ap.add_argument("--refs", type=int, default=0, help="override references per GPU (testing only)")
@@ -87,7 +87,7 @@ def parse_args():
                          "the exclusive pass of the one before) in the timed loop")
     ap.add_argument("--no-real-shape", action="store_true")
     ap.add_argument("--no-batched", action="store_true")
-    ap.add_argument("--batch-samples", type=int, default=32, help="samples per yh_run_batch_device call of the `batched` leg (<= 64)")
+    ap.add_argument("--batch-samples", type=int, default=64, help="samples per yh_run_batch_device call of the `batched` leg (<= 64)")
     ap.add_argument("--host-depth", type=int, default=4, help="host-inclusive leg: calls in flight (1..4)")
     ap.add_argument("--percentile-steps", type=int, default=200)
     ap.add_argument("--sync-gather", action="store_true", help="N>1: blocking gather of the count rows inside every step")
@@ -778,12 +778,13 @@ def main() -> int:
                 step_g(i)
             fence()
             el = (time.perf_counter() - t0) / n_g
-            # the throughput form: rank 0's share of a batch of 32 distinct samples in one pass (no exchange: its own words)
+            BM = max(1, min(int(args.batch_block), 64))
+            # the throughput form: rank 0's share of a batch of BM distinct samples (the block of --block-mode batched) in one pass (no exchange: its own words)
             bsamp = [samples[i] if i < K else synth.global_db_sample_device(plan, args.seed + 7000 + i, n_sample=args.sample_hashes,
-                                                                           n_present=n_present, device=str(dev)) for i in range(32)]
+                                                                           n_present=n_present, device=str(dev)) for i in range(BM)]
             with torch.cuda.stream(stream):
                 packed_b = hr.pack_batch(bsamp)
-            cb = torch.zeros((3, 32, n_local), device=dev, dtype=torch.int32)
+            cb = torch.zeros((3, BM, n_local), device=dev, dtype=torch.int32)
             wb = torch.zeros(n_local, device=dev, dtype=torch.int64)
             gb = torch.zeros((1, n_local), device=dev, dtype=torch.int64)
 
@@ -791,12 +792,12 @@ def main() -> int:
                 with torch.cuda.stream(stream):
                     hr.batch_begin(packed_b, cb, wb)
                     hr.batch_exchange(wb, gb)
-                    hr.batch_end(32, gb, cb)
+                    hr.batch_end(BM, gb, cb)
 
             for _ in range(2):
                 batch_g()
             fence()
-            nb_ = max(3, min(20, args.steps // 32 + 1))
+            nb_ = max(3, min(20, args.steps // BM + 1))
             t0 = time.perf_counter()
             for _ in range(nb_):
                 batch_g()
@@ -805,7 +806,7 @@ def main() -> int:
             del bsamp, packed_b, cb, wb, gb
             a_, b_ = hr._slice_of(samples[0])
             per_g[str(G)] = {"rank0_compute_ms_per_step": round(1e3 * el, 4), "sample_hashes_in_range": int(b_ - a_),
-                             "batched32_rank0_ms_per_sample": round(1e3 * el_b / 32, 4),
+                             "batched_rank0_ms_per_sample": round(1e3 * el_b / BM, 4), "samples_per_block": BM,
                              "ref_hashes_in_range": int(v_g.numel()),
                              "lookup_choice": "indexed" if hr.local.handle.lookup_choice(int(b_ - a_)) == ylib.YH_LOOKUP_INDEXED else "stream"}
             hr.close()
@@ -816,13 +817,13 @@ def main() -> int:
             "collectives_ms_per_step_assumed": coll,
             "predicted_ms_per_step": {g: round(v["rank0_compute_ms_per_step"] + coll, 4) for g, v in per_g.items()},
             "predicted_speedup_vs_1gpu": {g: round(ms_per_step / (v["rank0_compute_ms_per_step"] + coll), 2) for g, v in per_g.items()},
-            # --block-mode batched (the N > 1 default): + one all-gather of N * 8 bytes per rank and one reduce of 3 * 32 * N * 4
-            # bytes per block of 32 samples, assumed at 0.06 ms per block on top (not overlapped)
-            "batched_predicted_ms_per_sample": {g: round(v["batched32_rank0_ms_per_sample"] + 0.06 / 32, 4) for g, v in per_g.items()},
-            "batched_predicted_speedup_vs_1gpu_single_steps": {g: round(ms_per_step / (v["batched32_rank0_ms_per_sample"] + 0.06 / 32), 2)
+            # --block-mode batched (the N > 1 default): + one all-gather of N * 8 bytes per rank and one reduce of 3 * BM * N * 4
+            # bytes per block of BM samples, assumed at 0.06 ms per block on top (not overlapped)
+            "batched_predicted_ms_per_sample": {g: round(v["batched_rank0_ms_per_sample"] + 0.06 * (BM / 32) / BM, 4) for g, v in per_g.items()},
+            "batched_predicted_speedup_vs_1gpu_single_steps": {g: round(ms_per_step / (v["batched_rank0_ms_per_sample"] + 0.06 * (BM / 32) / BM), 2)
                                                                for g, v in per_g.items()},
             "how": "rank 0's hash range of the whole database built on THIS GPU, both halves of its step timed on its slice of the "
-                   "rotating samples (no collectives); + the assumed cost of the two collectives per block of 8 samples",
+                   "rotating samples (no collectives); + the assumed cost of the collectives (0.01 ms per sample-step; 0.06 ms per 32 samples of a batched block)",
         }
 
     # ---- roofline of the dominant kernel of the DEFAULT step --------------------------------------------
