@@ -22,7 +22,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_forced_lookup_forms_against_oracle(hip_lib, env):
     e = dict(os.environ, YH_DEBUG_TUNING="1")
     e.update(env)
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "fuzz_parity.py"), "--seconds", "6", "--seed", "31"],
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "fuzz_parity.py"), "--seconds", "6", "--seed", "31", "--no-batch"],
                        env=e, capture_output=True, text=True, timeout=600, cwd=ROOT)
     line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
     res = json.loads(line)

@@ -69,6 +69,7 @@ def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=300.0)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--no-batch", action="store_true", help="skip the batched-run check of every round")
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
     t_end = time.time() + args.seconds
@@ -117,14 +118,19 @@ def main() -> int:
                                 "pipelined steps " + name
                 # a batch through the batched run (needs the bucket table: handles of a non-empty database have it):
                 # the sample, a random half of it, a sample of absent hashes, an empty one and the sample again
-                if n and values.size:
+                if n and values.size and not args.no_batch:
                     half = sample[rng.random(sample.size) < 0.5]
                     absent = np.unique(rng.integers(1, 2 ** 62, size=int(rng.integers(1, 2000)), dtype=np.uint64))
                     batch = [sample, half, absent, np.zeros(0, np.uint64), sample]
                     bo, be, bm = db.run_batch(batch)
+                    zero = np.zeros(n, np.uint32)
+                    expect = {0: (want, we, wm), 3: (zero, zero, zero), 4: (want, we, wm)}  # (the oracle saw these already)
                     for k, s_k in enumerate(batch):
-                        w_ov = oracle.overlap(values, offsets, s_k)
-                        w_e, w_m = oracle.exclusive(values, offsets, w_ov > 0, s_k)
+                        if k in expect:
+                            w_ov, w_e, w_m = expect[k]
+                        else:
+                            w_ov = oracle.overlap(values, offsets, s_k)
+                            w_e, w_m = oracle.exclusive(values, offsets, w_ov > 0, s_k)
                         assert np.array_equal(bo[k], w_ov) and np.array_equal(be[k], w_e) and np.array_equal(bm[k], w_m), \
                             f"batched run, sample {k} of the batch"
                 if values.size < 400_000:
