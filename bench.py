@@ -294,6 +294,8 @@ def main() -> int:
     db.set_stream(stream.cuda_stream)
     assert stream.cuda_stream != 0
     info = db.info()
+    # the samples stay resident: each one's span in this rank's hash range is computed once (HashRangeRefDB remembers nothing)
+    spans = [sdb.slice_of(s_) for s_ in samples] if by_hash else None
 
     # Count rows: N = 1 alternates two buffers.  N > 1: the samples go in BLOCKS of GB = --gather-every (default 8, at
     # most 8): every sample's rank-local half (lookup + reduce) runs in its own step context of the library, the subset
@@ -368,7 +370,8 @@ def main() -> int:
             state["last_block"] = (j, n_in)
             key = (j * BB) % K
             if (key, n_in) not in packed_blocks:  # (resident samples: their slices are concatenated once)
-                packed_blocks[(key, n_in)] = sdb.pack_batch([samples[(key + t) % K] for t in range(n_in)])
+                packed_blocks[(key, n_in)] = sdb.pack_batch([samples[(key + t) % K] for t in range(n_in)],
+                                                             spans=[spans[(key + t) % K] for t in range(n_in)])
             b = j % NBUF
             if bpending[b] is not None:  # the reduce that read this buffer two blocks ago
                 bpending[b].wait()
@@ -399,7 +402,7 @@ def main() -> int:
         if g == 0 and pending[blk] is not None:  # first sample of a block: the block's previous gather must be done
             pending[blk].wait()
             pending[blk] = None
-        sdb.begin(s, c, blk, g)  # lookup + reduce of this sample in its own step context
+        sdb.begin(s, c, blk, g, **({"span": spans[i % K]} if spans is not None else {}))  # lookup + reduce of this sample in its own step context
         if g == GB - 1:
             close_block(blk, i - g, GB)
 
@@ -764,9 +767,11 @@ def main() -> int:
             hr.local.handle.set_stream(stream.cuda_stream)
             cg = [hr.new_counts() for _ in range(2)]
 
+            spans_g = [hr.slice_of(s_) for s_ in samples]  # (resident samples: their spans in this range, once)
+
             def step_g(i):
                 with torch.cuda.stream(stream):
-                    hr.begin(samples[i % K], cg[i % 2], 0, 0)
+                    hr.begin(samples[i % K], cg[i % 2], 0, 0, span=spans_g[i % K])
                     hr.end(cg[i % 2], 0, 0)
 
             for i in range(max(args.warmup, K)):
@@ -804,7 +809,7 @@ def main() -> int:
             fence()
             el_b = (time.perf_counter() - t0) / nb_
             del bsamp, packed_b, cb, wb, gb
-            a_, b_ = hr._slice_of(samples[0])
+            a_, b_ = spans_g[0]
             per_g[str(G)] = {"rank0_compute_ms_per_step": round(1e3 * el, 4), "sample_hashes_in_range": int(b_ - a_),
                              "batched_rank0_ms_per_sample": round(1e3 * el_b / BM, 4), "samples_per_block": BM,
                              "ref_hashes_in_range": int(v_g.numel()),

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define YH_ABI_VERSION 3
+#define YH_ABI_VERSION 4
 
 enum {
     YH_OK               = 0,
@@ -60,7 +60,6 @@ enum {
 #define YH_DB_DEFAULT      0u
 #define YH_DB_NO_INDEX     1u  /* skip the shared-hash inverted index (overlap-only handle)     */
 #define YH_DB_KEEP_CSR     2u  /* keep the plain CSR resident too (needed by yh_overlap_bsearch) */
-#define YH_DB_FULL_INDEX   4u  /* (accepted for compatibility: the directory below is built by default)      */
 #define YH_DB_PAIRWISE_ONLY 8u /* `yacht train` handle: validated sizes + the inverted index only
                                   (yh_pairwise, yh_index_stats); no lookup structures, so the
                                   overlap / exclusive / run queries return YH_ERR_UNSUPPORTED        */
@@ -76,8 +75,6 @@ typedef struct yh_db_info {
     uint64_t n_refs;             /* N                                                         */
     uint64_t n_hashes;           /* H = offsets[N]                                            */
     uint64_t max_hash;           /* largest hash in the database (0 if H == 0)                */
-    uint32_t reserved0;          /* (was n_partitions: the partitioned layouts are gone; always 0) */
-    uint32_t reserved1;
     uint64_t n_distinct;         /* distinct hashes over all references (index built only)    */
     uint64_t n_shared_distinct;  /* distinct hashes present in >= 2 references ("index size") */
     uint64_t n_shared_postings;  /* sum over shared hashes of their reference counts          */
@@ -98,10 +95,14 @@ typedef struct yh_db_info {
                                 per pair (+ an 8-byte header per 1024) -- k_stream_lookup            */
 
 typedef struct yh_timing {
-    float ms_overlap_kernel;     /* last overlap tile kernel (HIP events on the handle's stream) */
-    float ms_exclusive_kernels;  /* last shared-hit + postings + finalize kernels                 */
-    float ms_pairwise_kernels;   /* last accumulate + count + emit kernels                       */
-    float ms_db_build;           /* partition + (optional) index build at create time            */
+    float ms_overlap_kernel;     /* lookup kernel (HIP events on the handle's stream; mean over the sampled launches)   */
+    float ms_exclusive_kernels;  /* reducer / work list / exclusive-pass kernels behind it                               */
+    float ms_pairwise_kernels;   /* yh_pairwise: transpose + row kernels                                                 */
+    float ms_db_build;           /* yh_db_create: validation, sort, index, tables (device time, uploads excluded)        */
+    float ms_h2d;                /* host -> device copies: the CSR upload of yh_db_create until the first host-pointer
+                                    query, then the sample upload of the last synchronous host-pointer query (yh_overlap,
+                                    yh_exclusive, yh_run, yh_run_batch)                                                   */
+    float ms_d2h;                /* device -> host copies of that query's count rows (0 until one has run)              */
 } yh_timing;
 
 /* ---- library / device ---------------------------------------------------------------- */
@@ -112,13 +113,13 @@ int yh_device_count(int* n_devices);
 /* ---- database handle ------------------------------------------------------------------ */
 /* Upload a CSR reference database to `device_id`, validate ordering, and build what the queries read: the
  * hash-sorted delta stream, the bucket table + presence filter over the distinct hashes and (unless
- * YH_DB_NO_INDEX) the shared-hash inverted index.  partitions_hint is ignored (kept for ABI compatibility). */
+ * YH_DB_NO_INDEX) the shared-hash inverted index. */
 int yh_db_create(const uint64_t* values, const uint64_t* offsets, uint64_t n_refs,
-                 int device_id, uint32_t flags, uint32_t partitions_hint, yh_db** out);
+                 int device_id, uint32_t flags, yh_db** out);
 /* Same, but `d_values`/`d_offsets` already live in the HBM of `device_id` (not modified,
  * not retained after return unless YH_DB_KEEP_CSR is set, in which case they are COPIED). */
 int yh_db_create_device(const uint64_t* d_values, const uint64_t* d_offsets, uint64_t n_refs,
-                        int device_id, uint32_t flags, uint32_t partitions_hint, yh_db** out);
+                        int device_id, uint32_t flags, yh_db** out);
 int yh_db_destroy(yh_db* db);
 int yh_db_get_info(yh_db* db, yh_db_info* info);
 /* Run all of the handle's work on this hipStream_t (NULL = the library's own stream).
@@ -263,11 +264,34 @@ int yh_run_finish_range_device(yh_db* db, int ctx, const uint32_t* d_gathered_bi
  *                                      d_overlap [n_samples][N] = this rank's share; d_maskwords_out [N] its subset words
  *   yh_run_batch_finish_range_device   subset = OR of the n_ranks gathered word arrays ([n_ranks][N]); d_n_excl, d_n_match
  *                                      [n_samples][N] = this rank's shares (d_overlap: what the first half left)
- * No other batched call may run on the handle between the two halves (they share the handle's batch scratch).      */
-int yh_run_batch_local_range_device(yh_db* db, const uint64_t* d_samples, const uint64_t* d_sample_offsets, uint32_t n_samples,
-                                    uint64_t total_hashes, uint32_t* d_overlap, uint64_t* d_maskwords_out);
-int yh_run_batch_finish_range_device(yh_db* db, uint32_t n_samples, const uint64_t* d_gathered_maskwords, uint32_t n_ranks,
-                                     const uint32_t* d_overlap, uint32_t* d_n_excl, uint32_t* d_n_match);
+ * The two halves of a batch share one of YH_BATCH_SLOTS batch slots of the handle (the first half's hits on shared hashes
+ * wait there for the second): with two slots the subset words of block j travel while the lookups of block j + 1 run.  A
+ * second half without its first half in the slot, or with a different n_samples, or after yh_run_batch / yh_run_batch_device
+ * ran meanwhile (they use slot 0), fails with YH_ERR_INVALID_ARG.                                                        */
+#define YH_BATCH_SLOTS 2
+int yh_run_batch_local_range_device(yh_db* db, int slot, const uint64_t* d_samples, const uint64_t* d_sample_offsets,
+                                    uint32_t n_samples, uint64_t total_hashes, uint32_t* d_overlap, uint64_t* d_maskwords_out);
+int yh_run_batch_finish_range_device(yh_db* db, int slot, uint32_t n_samples, const uint64_t* d_gathered_maskwords,
+                                     uint32_t n_ranks, const uint32_t* d_overlap, uint32_t* d_n_excl, uint32_t* d_n_match);
+
+/* ---- the result of a batch in compact form: north star's "final gather of the per-reference counts" -------------------
+ * The three [n_samples][N] rows of a batch are almost all zero (a 10^6-hash metagenome overlaps a few hundred of 85 205
+ * references): what has to leave the GPU -- to the host, or to the rank that sums the shares of a hash-range run -- is
+ * one entry per (reference r, sample s) of the batch's subset, i.e. per set bit s of the slot's subset word of r, in
+ * (r, s) order.  On hash-range shards the subset is the GLOBAL one after the second half, so EVERY rank has the same
+ * entries in the same order and only the VALUES differ: a rank packs its three shares per entry, the value arrays are
+ * summed over the ranks as they are (12 bytes per entry and rank on the wire, no keys), and the consumer unpacks rows:
+ *   yh_run_batch_rows_pack_device    d_vals[3 * k + {0,1,2}] = overlap, n_excl, n_match of entry k (k < cap_rows);
+ *                                    *d_n_rows = the number of entries (may exceed cap_rows: then only the first
+ *                                    cap_rows were written and the caller falls back to the dense rows)
+ *   yh_run_batch_rows_unpack_device  d_rows[k] = {sample, ref, overlap, n_excl, n_match} from (summed) values
+ * Both read the subset words the last yh_run_batch_device (slot 0) or yh_run_batch_finish_range_device (its slot) left in
+ * the slot: YH_ERR_INVALID_ARG when the slot holds none.  Enqueued on the handle's stream, no host sync.          */
+typedef struct yh_batch_row { uint32_t sample, ref, overlap, n_excl, n_match; } yh_batch_row;
+int yh_run_batch_rows_pack_device(yh_db* db, int slot, const uint32_t* d_overlap, const uint32_t* d_n_excl,
+                                  const uint32_t* d_n_match, uint32_t* d_vals, uint64_t cap_rows, uint32_t* d_n_rows);
+int yh_run_batch_rows_unpack_device(yh_db* db, int slot, const uint32_t* d_vals, uint64_t cap_rows, yh_batch_row* d_rows,
+                                    uint32_t* d_n_rows);
 
 /* Pipelined host-buffer form of yh_run: SURVEY.md 8d's steady-state call -- sample H2D, kernels,
  * counts D2H -- split in two so that consecutive samples overlap.  yh_run_submit queues, on two

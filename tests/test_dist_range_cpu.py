@@ -62,11 +62,12 @@ class SetRangeBackend:
                         e[j] = len(r) - nshared[j] + sum(1 for h in r if h in shared and not any(mask[x] for x in shared[h] if x != j))
                 counts_t[1] = torch.from_numpy(e)
 
-            def batch_local(self, cat_t, soff_t, n_samples, total, ov_t, words_t):
+            def batch_local(self, cat_t, soff_t, n_samples, total, ov_t, words_t, slot=0):
                 cat = cat_t.numpy().view(np.uint64)
                 off = soff_t.numpy()
                 words = np.zeros(len(refs), dtype=np.uint64)
-                self._hit = []
+                self._slots = getattr(self, "_slots", {})
+                self._hit = self._slots.setdefault(slot, {})["hit"] = []
                 for s in range(n_samples):
                     S = set(cat[off[s]:off[s + 1]].tolist())
                     self._hit.append(S)
@@ -75,11 +76,14 @@ class SetRangeBackend:
                     words |= (ov > 0).astype(np.uint64) << np.uint64(s)
                 words_t.copy_(torch.from_numpy(words.view(np.int64)))
 
-            def batch_finish(self, n_samples, gathered_t, n_ranks, ov_t, e_t, m_t):
+            def batch_finish(self, n_samples, gathered_t, n_ranks, ov_t, e_t, m_t, slot=0):
                 words = np.bitwise_or.reduce(gathered_t.numpy().view(np.uint64)[:n_ranks], axis=0)
+                self._slots[slot]["words"] = words.copy()
+                self._slots[slot]["n"] = n_samples
+                hit = self._slots[slot]["hit"]
                 for s in range(n_samples):
                     mask = ((words >> np.uint64(s)) & np.uint64(1)).astype(bool)
-                    S = self._hit[s]
+                    S = hit[s]
                     e = np.zeros(len(refs), dtype=np.int32)
                     m = np.zeros(len(refs), dtype=np.int32)
                     for j, r in enumerate(refs):
@@ -89,6 +93,23 @@ class SetRangeBackend:
                             m[j] = sum(1 for h in excl if h in S)
                     e_t[s] = torch.from_numpy(e)
                     m_t[s] = torch.from_numpy(m)
+
+            def _entries(self, slot):  # (reference, sample) of every set bit of the slot's global words, in that order
+                words, n = self._slots[slot]["words"], self._slots[slot]["n"]
+                return [(r, s_) for r in range(len(refs)) for s_ in range(n) if (int(words[r]) >> s_) & 1]
+
+            def rows_pack(self, counts_t, vals_t, nrows_t, slot=0):
+                ent = self._entries(slot)
+                nrows_t[0] = len(ent)
+                for k, (r, s_) in enumerate(ent[: vals_t.shape[0]]):
+                    for c in range(3):
+                        vals_t[k, c] = counts_t[c, s_, r]
+
+            def rows_unpack(self, vals_t, rows_t, nrows_t, slot=0):
+                ent = self._entries(slot)
+                nrows_t[0] = len(ent)
+                for k, (r, s_) in enumerate(ent[: vals_t.shape[0]]):
+                    rows_t[k] = torch.tensor([s_, r, int(vals_t[k, 0]), int(vals_t[k, 1]), int(vals_t[k, 2])], dtype=torch.int32)
 
             def close(self):
                 pass
@@ -136,6 +157,13 @@ def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
         for k, sample in enumerate(cases):
             st = torch.from_numpy(sample.view(np.int64).copy())
             check(hr.gather(hr.run(st)), sample, f"case {k}")
+        # one staging tensor refilled IN PLACE with another sample of the same length (nothing may be
+        # remembered per tensor address -- the second sample's span in this rank's range differs from the first's)
+        n_st = min(cases[0].size, cases[1].size)
+        stage = torch.zeros(n_st, dtype=torch.int64)
+        for k in (0, 1, 0):
+            stage.copy_(torch.from_numpy(cases[k][:n_st].view(np.int64).copy()))
+            check(hr.gather(hr.run(stage)), cases[k][:n_st], f"refilled staging tensor, case {k}")
         # a reference whose ONLY overlap lies in another rank's range still joins this rank's subset: its exclusive
         # count here must see it -- case 4 above (hashes at the two ends) is that situation for the middle rank.
         # blocks of 3 samples per exchange, two blocks in flight, a partly filled block, one reduce per block
@@ -164,6 +192,49 @@ def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
         full = hr.reduce(cb.clone())
         for k, smp in enumerate(batch):
             check(full[:, k, :], smp, f"batched {k}")
+        # the result path in compact form (BatchRowsReducer): three blocks in flight in three batch slots, value triples
+        # summed to rank 0; the second reducer starts with a collective too small for its blocks -> the dense fallback
+        # for that block, a larger collective afterwards -- every block against the oracle on the whole database
+        blocks = [samples[:3], samples[3:] + [np.zeros(0, np.uint64)], samples[1:4], samples[:2]]
+        tb = [[torch.from_numpy(x.view(np.int64).copy()) for x in blk_] for blk_ in blocks]
+        for first_cap in (None, 4):
+            red = ydist.BatchRowsReducer(hr, batch=3, dst=0, nbuf=3, cap_rows=first_cap)
+            cnt = [torch.zeros((3, 3, hr.n_total), dtype=torch.int32) for _ in range(3)]
+            wrd = [torch.zeros(hr.n_total, dtype=torch.int64) for _ in range(3)]
+            gth = [torch.zeros((world, hr.n_total), dtype=torch.int64) for _ in range(3)]
+            got = {}
+
+            def finish(j):
+                rows, dense = red.finish(j % 3)
+                if rank == 0:
+                    nb = len(blocks[j])
+                    got[j] = dense[:, :nb] if rows is None else ydist.BatchRowsReducer.rows_to_dense(rows, nb, hr.n_total)
+
+            prev = None
+            for j, blk_ in enumerate(tb):
+                b = j % 3
+                if j >= 3:
+                    finish(j - 3)
+                hr.batch_begin(hr.pack_batch(blk_), cnt[b], wrd[b], slot=b)
+                hr.batch_exchange(wrd[b], gth[b])
+                if prev is not None:  # the previous block's second half behind this block's exchange
+                    pj, pb = prev
+                    hr.batch_end(len(tb[pj]), gth[pb], cnt[pb], slot=pb)
+                    red.send(pb, len(tb[pj]), cnt[pb], slot=pb)
+                prev = (j, b)
+            pj, pb = prev
+            hr.batch_end(len(tb[pj]), gth[pb], cnt[pb], slot=pb)
+            red.send(pb, len(tb[pj]), cnt[pb], slot=pb)
+            for j in range(max(0, len(tb) - 3), len(tb)):
+                finish(j)
+            if first_cap is not None:
+                assert red.n_overflow >= 1 and red.cap > first_cap, "the undersized collective must have been noticed"
+            else:
+                assert red.n_overflow == 0
+            if rank == 0:
+                for j, blk_ in enumerate(blocks):
+                    for k, smp in enumerate(blk_):
+                        check(got[j][:, k, :], smp, f"compact rows, first_cap {first_cap}, block {j} sample {k}")
         open(os.path.join(out_dir, f"ok{rank}"), "w").close()
     finally:
         dist.destroy_process_group()

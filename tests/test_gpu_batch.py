@@ -9,7 +9,7 @@ from yacht_amd.engine import RefDB
 
 pytestmark = pytest.mark.gpu
 
-FULL = 4  # YH_DB_FULL_INDEX
+FULL = 0  # YH_DB_DEFAULT: the directory is part of every handle unless YH_DB_NO_DIRECTORY
 
 
 def _samples(values, offsets, n_samples, seed, noise=400):
@@ -79,3 +79,52 @@ def test_batch_errors(hip_lib):
             db.run_batch([smp] * 65)
         with pytest.raises(_lib.YachtHipError):
             db.run_batch([smp[::-1].copy()])
+
+
+def test_batch_rs214_scale_against_oracle(hip_lib):
+    """yh_run_batch_device at the bench's own scale -- 85 205 references (3.3e8 hashes), 64 DISTINCT 1e6-hash samples in
+    one pass -- against the ORACLE on the whole database for three of them (first, middle, last), and the compact rows
+    of the batch against the dense rows for all 64 (the bench checked this only against the single step)."""
+    import torch
+
+    from yacht_amd.engine import YH_DB_DEFAULT
+
+    n_refs = 85_205
+    plan = synth.global_db_plan(1002, n_refs, cluster_frac=0.10, median=3300.0, sigma=0.6, lo=300, hi=15000)
+    values, offsets = synth.global_db_refs_device(plan, np.arange(n_refs), device="cuda:0")
+    samples = [synth.global_db_sample_device(plan, 5000 + i, n_sample=1_000_000, n_present=200, device="cuda:0") for i in range(64)]
+    cat = torch.cat(samples).contiguous()
+    soff = torch.zeros(65, dtype=torch.int64, device="cuda:0")
+    soff[1:] = torch.cumsum(torch.tensor([int(x.numel()) for x in samples], dtype=torch.int64, device="cuda:0"), 0)
+    out = torch.zeros((3, 64, n_refs), dtype=torch.int32, device="cuda:0")
+    torch.cuda.synchronize()
+    db = RefDB.from_device(values.data_ptr(), offsets.data_ptr(), n_refs, flags=YH_DB_DEFAULT)
+    try:
+        db.run_batch_device(cat.data_ptr(), soff.data_ptr(), 64, int(cat.numel()), out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr())
+        cap = 64 * 2048
+        vals = torch.zeros((cap, 3), dtype=torch.int32, device="cuda:0")
+        rows = torch.zeros((cap, 5), dtype=torch.int32, device="cuda:0")
+        n1 = torch.zeros(1, dtype=torch.int32, device="cuda:0")
+        n2 = torch.zeros(1, dtype=torch.int32, device="cuda:0")
+        db.run_batch_rows_pack_device(out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), vals.data_ptr(), cap, n1.data_ptr())
+        db.run_batch_rows_unpack_device(vals.data_ptr(), cap, rows.data_ptr(), n2.data_ptr())
+        db.synchronize()
+        got = out.cpu().numpy().view(np.uint32)
+        hv, ho = values.cpu().numpy().view(np.uint64), offsets.cpu().numpy().astype(np.uint64)
+        for s in (0, 31, 63):
+            hs = samples[s].cpu().numpy().view(np.uint64)
+            w_ov = oracle.overlap(hv, ho, hs, threads=8)
+            w_e, w_m = oracle.exclusive(hv, ho, w_ov > 0, hs)
+            assert np.array_equal(got[0][s], w_ov), f"overlap differs for sample {s}"
+            assert np.array_equal(got[1][s], w_e), f"n_excl differs for sample {s}"
+            assert np.array_equal(got[2][s], w_m), f"n_match differs for sample {s}"
+        k = int(n1.item())
+        assert k == int(n2.item()) == int((got[0] > 0).sum()) and k <= cap
+        r = rows[:k].cpu().numpy().view(np.uint32)
+        dense = np.zeros((3, 64, n_refs), dtype=np.uint32)
+        for c in range(3):
+            dense[c, r[:, 0], r[:, 1]] = r[:, 2 + c]
+        assert np.array_equal(dense, got), "the compact rows of the batch do not reproduce its dense rows"
+        assert np.array_equal(np.lexsort((r[:, 0], r[:, 1])), np.arange(k)), "(reference, sample) order"
+    finally:
+        db.close()

@@ -249,6 +249,55 @@ torch.cuda.synchronize()
 full = hr.reduce(cb.clone())
 for k, s in enumerate(ss):
     check(full[:, k, :], s, f"batched {k}")
+# the result path in compact form: blocks of two samples rotate through three batch slots, their value triples are summed
+# to rank 0 in ONE collective per block (BatchRowsReducer); an undersized first collective takes the dense fallback
+blocks = [[ss[0], ss[1]], [ss[2], ss[3]], [ss[3], ss[0]], [ss[1]]]
+for first_cap in (None, 8):
+    red = ydist.BatchRowsReducer(hr, batch=2, dst=0, nbuf=3, cap_rows=first_cap)
+    cnt = [torch.zeros((3, 2, hr.n_total), dtype=torch.int32, device=dev) for _ in range(3)]
+    wrd = [torch.zeros(hr.n_total, dtype=torch.int64, device=dev) for _ in range(3)]
+    gth = [torch.zeros((world, hr.n_total), dtype=torch.int64, device=dev) for _ in range(3)]
+    got = {}
+    def finish(j):
+        rows, dense = red.finish(j % 3)
+        if rank == 0:
+            nb = len(blocks[j])
+            got[j] = (dense[:, :nb] if rows is None else ydist.BatchRowsReducer.rows_to_dense(rows, nb, hr.n_total)).clone()
+    def second_half(j):
+        b = j % 3
+        hr.batch_end(len(blocks[j]), gth[b], cnt[b], slot=b)
+        red.send(b, len(blocks[j]), cnt[b], slot=b)
+    for j, blk_ in enumerate(blocks):
+        b = j % 3
+        if j >= 3:
+            finish(j - 3)
+        hr.batch_begin(hr.pack_batch(blk_), cnt[b], wrd[b], slot=b)
+        hr.batch_exchange(wrd[b], gth[b])
+        if j:
+            second_half(j - 1)
+    second_half(len(blocks) - 1)
+    for j in range(max(0, len(blocks) - 3), len(blocks)):
+        finish(j)
+    torch.cuda.synchronize()
+    if first_cap is not None and not (red.n_overflow >= 1 and red.cap > first_cap):
+        ok = False
+        print(f"rank {rank}: the undersized collective went unnoticed", flush=True)
+    if first_cap is None and red.n_overflow:
+        ok = False
+        print(f"rank {rank}: unexpected overflow of the default collective", flush=True)
+    if rank == 0:
+        for j, blk_ in enumerate(blocks):
+            for k, s in enumerate(blk_):
+                check(got[j][:, k, :], s, f"compact rows (first cap {first_cap}) block {j} sample {k}")
+# a second half without its first half in the slot is refused
+if int(v.numel()):
+    try:
+        hr.batch_end(2, gth[0], cnt[0], slot=1)
+        ok = False
+        print(f"rank {rank}: a second half without a first half was accepted", flush=True)
+    except Exception as e:
+        if "YH_ERR_INVALID_ARG" not in str(e):
+            raise
 print(f"rank {rank}: range [{bounds[rank]}, {bounds[rank + 1]}), {int(v.numel())} of {int(all_v.numel())} hashes, ok {ok}", flush=True)
 hr.close()
 dist.barrier()

@@ -289,6 +289,22 @@ def test_cli_train_then_run_end_to_end(hip_lib, tmp_path):
     # the reference's quirk: this column carries the sample's mean abundance
     assert float(r["num_exclusive_kmers_in_sample_sketch"]) == pytest.approx(2.4032636839886794)
     assert int(r["num_total_kmers_in_sample_sketch"]) == int(np.round(2.4032636839886794 * 49821))
+    # results/result.xlsx, read back as the reference's test_workflow.py:52-66 does (first sheet = the user's coverage
+    # unless --keep_raw put raw_result in front; here by name), without openpyxl: the three look-ups of that test
+    from yacht_amd import xlsx
+
+    book = xlsx.read_xlsx(str(res / "result.xlsx"))
+    assert list(book) == ["raw_result", "min_coverage0.001"]
+    df = book["min_coverage0.001"]
+    assert list(df.columns) == want_cols and len(df) == len(sheet)
+    rx = df[df["organism_name"] == "CP032507.1 Ectothiorhodospiraceae bacterium BW-2 chromosome, complete genome"]
+    assert str(rx["in_sample_est"].values[0]) == "True"
+    assert rx["num_matches"].values[0] == 2
+    assert rx["acceptance_threshold_with_coverage"].values[0] == 0
+    for c in want_cols:  # the workbook and the TSV sheet carry the same table
+        a, b = df[c].tolist(), sheet[c].tolist()
+        assert all((x == y) or (isinstance(x, float) and isinstance(y, float) and (np.isnan(x) and np.isnan(y) or abs(x - y) <= 1e-15 * abs(y)))
+                   for x, y in zip(a, b)), c
 
 
 def test_train_config3_at_full_size_equals_the_genuine_reference(hip_lib):

@@ -29,6 +29,17 @@ def test_hyp_grid_on_this_box(hip_lib):
     test_host.test_single_hyp_test_return_types()
 
 
+def test_native_hyp_test_on_this_box(hip_lib):
+    """yh_hyp_test -- the long-double arithmetic that decides in_sample_est for a C caller -- on the GPU box's own host
+    (libm, CPU): the reference's 1 512-tuple grid and its 16 344 real (n_exclusive, n_matches) pairs."""
+    import test_hyp_native
+
+    test_hyp_native.test_reference_grid()
+    test_hyp_native.test_real_run_tuples()
+    test_hyp_native.test_equals_scipy_path_on_random_tuples()
+    test_hyp_native.test_edges_and_errors()
+
+
 class _Sig:
     class _MH:
         def __init__(self, mins):

@@ -1,4 +1,4 @@
-"""GPU: the sample-driven (directory) overlap path, YH_DB_FULL_INDEX — same results as the
+"""GPU: the sample-driven (directory) overlap path, the default handle — same results as the
 streaming kernel and the oracle."""
 import numpy as np
 import pytest
@@ -6,7 +6,7 @@ import pytest
 from oracle import oracle
 from yacht_amd import synth
 from yacht_amd import _lib
-from yacht_amd.engine import RefDB, YH_DB_FULL_INDEX, YH_DB_KEEP_CSR, YH_DB_NO_DIRECTORY
+from yacht_amd.engine import RefDB, YH_DB_DEFAULT, YH_DB_KEEP_CSR, YH_DB_NO_DIRECTORY
 
 pytestmark = pytest.mark.gpu
 
@@ -34,7 +34,7 @@ def _check(refs, sample):
     values, offsets = synth.pack(refs)
     want_ov = oracle.overlap(values, offsets, sample)
     want_e, want_m = oracle.exclusive(values, offsets, want_ov > 0, sample)
-    with RefDB(values, offsets, flags=YH_DB_FULL_INDEX) as db:
+    with RefDB(values, offsets, flags=YH_DB_DEFAULT) as db:
         ov, e, m = _run_indexed(db, sample)
         assert np.array_equal(ov, want_ov)
         assert np.array_equal(e, want_e) and np.array_equal(m, want_m)
@@ -77,7 +77,7 @@ def test_indexed_equals_streaming_at_full_scale(hip_lib):
 
     values, offsets, sample = synth.config3_device(seed=77, n_refs=85_205, n_sample=300_000, device="cuda:0")
     n = offsets.numel() - 1
-    db = RefDB.from_device(values.data_ptr(), offsets.data_ptr(), n, flags=YH_DB_FULL_INDEX | YH_DB_KEEP_CSR)
+    db = RefDB.from_device(values.data_ptr(), offsets.data_ptr(), n, flags=YH_DB_DEFAULT | YH_DB_KEEP_CSR)
     try:
         outs = [torch.zeros((3, n), dtype=torch.int32, device="cuda:0") for _ in range(2)]
         torch.cuda.synchronize()

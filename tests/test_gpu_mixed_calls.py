@@ -14,6 +14,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_mixed_calls_on_one_handle(hip_lib):
     env = dict(os.environ)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "mix_calls.py"), "30", "7"], env=env, cwd=ROOT,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "mix_calls.py"), "60", "7"], env=env, cwd=ROOT,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "mixed calls ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

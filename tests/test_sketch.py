@@ -11,7 +11,8 @@ FX = os.path.join(os.path.dirname(__file__), "golden", "fixtures")
 # (distinct hashes, total k-mers) of demo/ref_genomes sketched by the reference's own pipeline
 # (k=31, scaled=1000, abund): columns num_unique_kmers_in_genome_sketch / num_total_kmers_in_genome_sketch
 # of tests/testdata/standardize_output_testdata/results/result.xlsx in the reference tree
-KAT = {"GCF_018918235.1": (2319, 2323), "GCF_018918045.1": (2452, 2453)}
+KAT = {"GCF_018918235.1": (2319, 2323), "GCF_018918045.1": (2452, 2453),
+       "GCF_018918095.1": (3009, 3035), "GCF_018918185.1": (2832, 2844)}
 
 
 def test_sketch_oracle_reference_known_answers():
@@ -20,6 +21,11 @@ def test_sketch_oracle_reference_known_answers():
         assert (len(mins), int(ab.sum())) == (distinct, total)
         assert bool(np.all(mins[1:] > mins[:-1])) and int(mins[-1]) <= 18446744073709552
     assert so.max_hash_for_scaled(1000) == 18446744073709552   # the max_hash in the reference's .sig fixtures
+    # a hash VALUE, not only counts: sourmash's own published known answer for its k-mer hash (tests/test_minhash.py
+    # there: hash_murmur("ACG") == 1731421407650554201; seed 42, first 64 bits of MurmurHash3_x64_128) -- the
+    # third-party definition the reference's sketches come from (sketch_ref_genomes.py:25,61)
+    assert int(so.murmur3_x64_128_h1(np.frombuffer(b"ACG", dtype=np.uint8).reshape(1, 3), 42)[0]) == 1731421407650554201
+    assert so.kmer_hashes(b"ACG", 3).tolist() == [1731421407650554201] and so.kmer_hashes(b"CGT", 3).tolist() == [1731421407650554201]
 
 
 def test_sketch_oracle_small_properties():
@@ -46,6 +52,10 @@ def test_hip_sketch_equals_oracle(hip_lib):
         sig = sketch.sketch_file(path, k, scaled)
         assert np.array_equal(sig.minhash.mins, want_m)
         assert np.array_equal(sig.minhash.abundances, want_a)
+    for g, kat in KAT.items():  # the four known answers of the reference's own sketches through the HIP kernel
+        sg = sketch.sketch_file(os.path.join(FX, f"{g}_genomic.fna.gz"), 31, 1000)
+        assert (len(sg.minhash), int(sg.minhash.abundances.sum())) == kat
+    assert sketch.hash_kmers([b"ACG"], 3, 1).tolist() == [1731421407650554201]  # sourmash's published hash value
     sig = sketch.sketch_file(path, 31, 1000)
     assert (len(sig.minhash), int(sig.minhash.abundances.sum())) == KAT["GCF_018918235.1"]
     assert sig.minhash.scaled == 1000 and sig.name.startswith("NZ_JAHLQE010000140.1")

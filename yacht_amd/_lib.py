@@ -24,10 +24,10 @@ YH_ERR_UNSUPPORTED = -7
 YH_DB_DEFAULT = 0
 YH_DB_NO_INDEX = 1
 YH_DB_KEEP_CSR = 2
-YH_DB_FULL_INDEX = 4
 YH_DB_PAIRWISE_ONLY = 8
 YH_DB_NO_DIRECTORY = 16
 YH_RUN_SLOTS = 4
+YH_BATCH_SLOTS = 2
 YH_LOOKUP_AUTO, YH_LOOKUP_STREAM, YH_LOOKUP_INDEXED = 0, 1, 2
 
 _ERR_NAMES = {
@@ -52,8 +52,6 @@ class DbInfo(C.Structure):
         ("n_refs", C.c_uint64),
         ("n_hashes", C.c_uint64),
         ("max_hash", C.c_uint64),
-        ("reserved0", C.c_uint32),
-        ("reserved1", C.c_uint32),
         ("n_distinct", C.c_uint64),
         ("n_shared_distinct", C.c_uint64),
         ("n_shared_postings", C.c_uint64),
@@ -74,6 +72,8 @@ class Timing(C.Structure):
         ("ms_exclusive_kernels", C.c_float),
         ("ms_pairwise_kernels", C.c_float),
         ("ms_db_build", C.c_float),
+        ("ms_h2d", C.c_float),
+        ("ms_d2h", C.c_float),
     ]
 
 
@@ -87,8 +87,8 @@ SIGNATURES = {
     "yh_last_error": (C.c_char_p, []),
     "yh_abi_version": (C.c_int, []),
     "yh_device_count": (C.c_int, [C.POINTER(C.c_int)]),
-    "yh_db_create": (C.c_int, [_vp, _vp, C.c_uint64, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(_vp)]),
-    "yh_db_create_device": (C.c_int, [_vp, _vp, C.c_uint64, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(_vp)]),
+    "yh_db_create": (C.c_int, [_vp, _vp, C.c_uint64, C.c_int, C.c_uint32, C.POINTER(_vp)]),
+    "yh_db_create_device": (C.c_int, [_vp, _vp, C.c_uint64, C.c_int, C.c_uint32, C.POINTER(_vp)]),
     "yh_db_destroy": (C.c_int, [_vp]),
     "yh_db_get_info": (C.c_int, [_vp, C.POINTER(DbInfo)]),
     "yh_db_set_stream": (C.c_int, [_vp, _vp]),
@@ -114,8 +114,10 @@ SIGNATURES = {
     "yh_run_finish_device": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "yh_run_local_range_device": (C.c_int, [_vp, C.c_int, _vp, C.c_uint64, _vp, _vp, _vp]),
     "yh_run_finish_range_device": (C.c_int, [_vp, C.c_int, _vp, C.c_uint32, C.c_uint64, _vp]),
-    "yh_run_batch_local_range_device": (C.c_int, [_vp, _vp, _vp, C.c_uint32, C.c_uint64, _vp, _vp]),
-    "yh_run_batch_finish_range_device": (C.c_int, [_vp, C.c_uint32, _vp, C.c_uint32, _vp, _vp, _vp]),
+    "yh_run_batch_local_range_device": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_uint32, C.c_uint64, _vp, _vp]),
+    "yh_run_batch_finish_range_device": (C.c_int, [_vp, C.c_int, C.c_uint32, _vp, C.c_uint32, _vp, _vp, _vp]),
+    "yh_run_batch_rows_pack_device": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, C.c_uint64, _vp]),
+    "yh_run_batch_rows_unpack_device": (C.c_int, [_vp, C.c_int, _vp, C.c_uint64, _vp, _vp]),
     "yh_run_submit": (C.c_int, [_vp, C.c_int, _vp, C.c_uint64, _vp, _vp, _vp]),
     "yh_run_wait": (C.c_int, [_vp, C.c_int]),
     "yh_sample_pack_bound": (C.c_uint64, [C.c_uint64]),
@@ -197,7 +199,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError here = the .so does not match the header
         fn.restype = res
         fn.argtypes = args
-    if lib.yh_abi_version() != 3:
+    if lib.yh_abi_version() != 4:
         raise YachtHipError(YH_ERR_INVALID_ARG, f"ABI version mismatch in {path}")
     _lib = lib
     return lib

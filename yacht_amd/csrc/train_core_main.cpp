@@ -181,7 +181,7 @@ int main(int argc, char** argv) {
     t0 = std::chrono::high_resolution_clock::now();
     std::cout << "Building index from sketches..." << std::endl;
     yh_db* db = nullptr;
-    int rc = yh_db_create(values.data(), offsets.data(), n, 0, YH_DB_PAIRWISE_ONLY, 0, &db);
+    int rc = yh_db_create(values.data(), offsets.data(), n, 0, YH_DB_PAIRWISE_ONLY, &db);
     if (rc != YH_OK) { std::cerr << "yh_db_create failed: " << yh_last_error() << std::endl; return 1; }
     uint64_t n_distinct = 0, n_single = 0, n_index = 0;
     yh_index_stats(db, &n_distinct, &n_single, &n_index);

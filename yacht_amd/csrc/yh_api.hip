@@ -6,6 +6,7 @@
 
 #include <stdarg.h>
 #include <string.h>
+#include <time.h>
 
 #include <algorithm>
 #include <utility>
@@ -30,24 +31,52 @@ const char* yh_tune_env(const char* name) {
 // The temporaries of a build or a pairwise pass, and the arrays of a YH_DB_PAIRWISE_ONLY handle (which lives for one
 // `yacht train` call), are taken from and returned to a per-process cache instead of the driver: a hipFree of a gigabyte
 // buffer costs 0.3-1 ms and synchronizes the device, `yacht train` made thirty of them per call (3.5 of 14 ms), and
-// hipFreeAsync into the device's memory pool was no cheaper (0.35 ms a call).  A cached block remembers the stream that
-// last used it: the same stream may have it back at once (stream order), another one after that stream has drained.
-// What the cache holds beyond YH_POOL_KEEP (default 4 GiB) goes back to the driver at the end of a create / destroy.
+// hipFreeAsync into the device's memory pool was no cheaper (0.35 ms a call).  A block is returned with an EVENT recorded
+// on the stream that used it last (events are the library's own, pooled: the stream itself may be a caller's and gone by
+// the time the block is reused): the same stream may have the block back at once (stream order), any other user waits
+// for the event.  What the cache holds beyond YH_POOL_KEEP (default 4 GiB) goes back to the driver at the end of a
+// create / destroy.
 namespace {
-struct CacheBlock { void* p; size_t bytes; int device; hipStream_t owner; };
+struct CacheBlock { void* p; size_t bytes; int device; hipStream_t owner; hipEvent_t freed; };
 std::mutex g_cache_mu;
 std::vector<CacheBlock> g_cache;                      // free blocks
 std::unordered_map<void*, size_t> g_cache_live;       // blocks handed out: their sizes
+std::vector<std::pair<int, hipEvent_t>> g_cache_events;  // idle events, by device
 bool cache_on() {
     static const bool on = [] { const char* off = yh_tune_env("YH_NO_POOL"); return !(off && off[0] == '1'); }();
     return on;
 }
+hipEvent_t cache_event_take(int device) {  // (g_cache_mu held)
+    for (size_t i = 0; i < g_cache_events.size(); ++i)
+        if (g_cache_events[i].first == device) {
+            hipEvent_t e = g_cache_events[i].second;
+            g_cache_events[i] = g_cache_events.back();
+            g_cache_events.pop_back();
+            return e;
+        }
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return e;
+}
+void cache_event_give(int device, hipEvent_t e) {  // (g_cache_mu held)
+    if (e) g_cache_events.emplace_back(device, e);
+}
 }  // namespace
+// (YH_TRACE_BUILD=1 behind the tuning gate: every device allocation that took the host more than 0.5 ms, to stderr)
+static bool alloc_trace_on() {
+    static const bool on = [] { const char* e = yh_tune_env("YH_TRACE_BUILD"); return e && e[0] == '1'; }();
+    return on;
+}
+static double alloc_now_ms() {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
 hipError_t yh_tmalloc(yh_db* db, void** p, size_t bytes) {
     if (bytes == 0) bytes = 16;
     if (!cache_on()) return hipMalloc(p, bytes);
     bytes = (bytes + 255) & ~(size_t)255;
-    hipStream_t wait_for = nullptr;
+    hipEvent_t wait_for = nullptr;
     {
         std::lock_guard<std::mutex> lk(g_cache_mu);
         int best = -1;
@@ -62,22 +91,29 @@ hipError_t yh_tmalloc(yh_db* db, void** p, size_t bytes) {
             g_cache.pop_back();
             g_cache_live[b.p] = b.bytes;
             *p = b.p;
-            if (b.owner && b.owner != db->stream) wait_for = b.owner;
-            else return hipSuccess;
+            if (b.freed && b.owner != db->stream) wait_for = b.freed;  // (another stream used it last: its work up to the free)
+            else { cache_event_give(b.device, b.freed); return hipSuccess; }
         }
     }
-    if (wait_for) {  // (a live handle's stream: owners are cleared when a handle goes or changes its stream)
-        if (hipStreamSynchronize(wait_for) != hipSuccess) { (void)hipGetLastError(); return hipDeviceSynchronize(); }
+    if (wait_for) {
+        const hipError_t we = hipEventSynchronize(wait_for);
+        {
+            std::lock_guard<std::mutex> lk(g_cache_mu);
+            cache_event_give(db->device, wait_for);
+        }
+        if (we != hipSuccess) { (void)hipGetLastError(); return hipDeviceSynchronize(); }
         return hipSuccess;
     }
+    const double t0 = alloc_trace_on() ? alloc_now_ms() : 0.0;
     hipError_t e = hipMalloc(p, bytes);
+    if (alloc_trace_on() && alloc_now_ms() - t0 > 0.5) fprintf(stderr, "[yh alloc] cache miss: hipMalloc(%.1f MB) took %.3f ms\n", bytes / 1e6, alloc_now_ms() - t0);
     if (e == hipErrorOutOfMemory) {  // give the driver back what the cache holds, and once more
         (void)hipGetLastError();
         (void)hipDeviceSynchronize();
         std::vector<void*> drop;
         {
             std::lock_guard<std::mutex> lk(g_cache_mu);
-            for (const CacheBlock& b : g_cache) drop.push_back(b.p);
+            for (const CacheBlock& b : g_cache) { drop.push_back(b.p); cache_event_give(b.device, b.freed); }
             g_cache.clear();
         }
         for (void* q : drop) (void)hipFree(q);
@@ -95,7 +131,16 @@ void yh_tfree(yh_db* db, void* p) {
         std::lock_guard<std::mutex> lk(g_cache_mu);
         auto it = g_cache_live.find(p);
         if (it != g_cache_live.end()) {
-            g_cache.push_back(CacheBlock{p, it->second, db->device, db->stream});
+            hipEvent_t ev = cache_event_take(db->device);
+            if (ev && hipEventRecord(ev, db->stream) != hipSuccess) {  // (cannot mark the point: wait for the stream now instead)
+                (void)hipGetLastError();
+                (void)hipStreamSynchronize(db->stream);
+                cache_event_give(db->device, ev);
+                ev = nullptr;
+            } else if (!ev) {
+                (void)hipStreamSynchronize(db->stream);
+            }
+            g_cache.push_back(CacheBlock{p, it->second, db->device, db->stream, ev});
             g_cache_live.erase(it);
             return;
         }
@@ -111,7 +156,11 @@ void yh_pool_trim(yh_db* db) {
         std::lock_guard<std::mutex> lk(g_cache_mu);
         size_t held = 0;
         for (CacheBlock& b : g_cache) {
-            if (b.owner == db->stream) b.owner = nullptr;
+            if (b.owner == db->stream) {  // (drained: nothing to wait for any more)
+                b.owner = nullptr;
+                cache_event_give(b.device, b.freed);
+                b.freed = nullptr;
+            }
             held += b.bytes;
         }
         while (held > keep) {  // largest idle block first
@@ -131,7 +180,10 @@ void yh_pool_trim(yh_db* db) {
 int yh_dmalloc(yh_db* db, void** p, size_t bytes) {
     if (bytes == 0) bytes = 16;
     const bool cached = (db->flags & YH_DB_PAIRWISE_ONLY) != 0;
+    const double t0 = alloc_trace_on() ? alloc_now_ms() : 0.0;
     hipError_t e = cached ? yh_tmalloc(db, p, bytes) : hipMalloc(p, bytes);
+    if (alloc_trace_on() && alloc_now_ms() - t0 > 0.5)
+        fprintf(stderr, "[yh alloc] %s(%.1f MB) took %.3f ms\n", cached ? "yh_tmalloc" : "hipMalloc", bytes / 1e6, alloc_now_ms() - t0);
     if (e != hipSuccess) {
         *p = nullptr;
         yh_set_error("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
@@ -211,9 +263,27 @@ static int pipe_join(yh_db* db) {
 
 // A query that is not one of the two halves of a step context re-uses the current context's subset bits and work
 // list: a context whose first half is queued loses them (yh_run_finish_device reports it).
+// the pending stages run, and the step queued last is no longer a pipelined one
+static int pipe_leave(yh_db* db) {
+    YH_TRY(pipe_join(db));
+    db->pipe_last_ctx = -1;
+    return YH_OK;
+}
 static void note_other_query(yh_db* db) {
-    (void)pipe_join(db);
+    (void)pipe_leave(db);
     if (db->ctx_open[db->ctx_now]) db->ctx_clobbered[db->ctx_now] = true;
+}
+
+// HIP events around the copies of the synchronous host-pointer queries (yh_timing.ms_h2d / ms_d2h); dir 0 = up, 1 = down
+static void xfer_mark(yh_db* db, int dir, int end) {
+    if (!db->ev_xfer[dir][0]) {
+        if (hipEventCreate(&db->ev_xfer[dir][0]) != hipSuccess || hipEventCreate(&db->ev_xfer[dir][1]) != hipSuccess) {
+            (void)hipGetLastError();
+            return;
+        }
+    }
+    (void)hipEventRecord(db->ev_xfer[dir][end], db->stream);
+    if (end) db->xfer_recorded[dir] = true;
 }
 
 static bool db_ok(yh_db* db) {
@@ -253,7 +323,7 @@ int yh_device_count(int* n_devices) {
 }
 
 static int db_create_common(const u64* values, const u64* offsets, bool on_device, u64 n_refs, int device_id,
-                            uint32_t flags, uint32_t partitions_hint, yh_db** out) {
+                            uint32_t flags, yh_db** out) {
     if (!out) { yh_set_error("out is null"); return YH_ERR_INVALID_ARG; }
     *out = nullptr;
     if (!offsets) { yh_set_error("offsets is null"); return YH_ERR_INVALID_ARG; }
@@ -320,13 +390,14 @@ static int db_create_common(const u64* values, const u64* offsets, bool on_devic
             // (yh_build_upload_sorted); a small one in one piece
             static const u64 chunk_min = [] { const char* e = yh_tune_env("YH_UPLOAD_CHUNK_MIN"); return e ? (u64)atoll(e) : (u64)12 << 20; }();
             chunked = H >= chunk_min && n_refs >= 4;
+            const double t_up = alloc_now_ms();
             if (hipMemcpy(d_offsets_in, offsets, (n_refs + 1) * sizeof(u64), hipMemcpyHostToDevice) != hipSuccess ||
                 (!chunked && H && hipMemcpy(d_values_in, values, H * sizeof(u64), hipMemcpyHostToDevice) != hipSuccess)) {
                 yh_set_error("CSR upload failed"); rc = YH_ERR_HIP; break;
             }
+            db->ms_h2d_create = (float)(alloc_now_ms() - t_up);  // (a chunked upload adds its own time: yh_build_upload_sorted)
         }
 
-        (void)partitions_hint;  // (accepted for ABI compatibility: the layouts it tuned are gone)
         u64* d_sk_pre = nullptr;
         u32* d_sv_pre = nullptr;
         if (chunked) {
@@ -388,15 +459,13 @@ static int db_create_common(const u64* values, const u64* offsets, bool on_devic
 }
 
 int yh_db_create(const uint64_t* values, const uint64_t* offsets, uint64_t n_refs, int device_id, uint32_t flags,
-                 uint32_t partitions_hint, yh_db** out) {
-    return db_create_common((const u64*)values, (const u64*)offsets, false, n_refs, device_id, flags,
-                            partitions_hint, out);
+                 yh_db** out) {
+    return db_create_common((const u64*)values, (const u64*)offsets, false, n_refs, device_id, flags, out);
 }
 
 int yh_db_create_device(const uint64_t* d_values, const uint64_t* d_offsets, uint64_t n_refs, int device_id,
-                        uint32_t flags, uint32_t partitions_hint, yh_db** out) {
-    return db_create_common((const u64*)d_values, (const u64*)d_offsets, true, n_refs, device_id, flags,
-                            partitions_hint, out);
+                        uint32_t flags, yh_db** out) {
+    return db_create_common((const u64*)d_values, (const u64*)d_offsets, true, n_refs, device_id, flags, out);
 }
 
 int yh_db_destroy(yh_db* db) {
@@ -417,10 +486,12 @@ int yh_db_destroy(yh_db* db) {
                     db->d_dh, db->d_dref, db->d_dir, db->d_bkt, db->d_cbkt, db->d_ovf_keys, db->d_ovf_vals,
                     db->d_rpo, db->d_rg, db->d_rrec, db->d_rrecx, db->d_filter, db->d_hrec, db->d_hrecx, db->d_hmult, db->d_hpo,
                     db->d_work, db->d_work_count, db->d_mask, db->d_maskbits, db->d_hit, db->d_excl_e, db->d_overlap_tmp,
-                    db->d_sample_tmp, db->d_out_tmp, db->d_flag, db->d_reps, db->d_batch, db->d_sdelta, db->d_shdr, db->d_srec,
+                    db->d_sample_tmp, db->d_out_tmp, db->d_flag, db->d_reps, db->batch[0].d_scratch, db->batch[1].d_scratch, db->d_sdelta, db->d_shdr, db->d_srec,
                     db->d_wg_key, db->d_ghost_src, db->d_bad_word, db->d_prank};
     for (void* p : ptrs)
         if (p) yh_dfree(db, p);
+    for (auto& pair : db->ev_xfer)
+        for (hipEvent_t e : pair) if (e) (void)hipEventDestroy(e);
     ring_destroy(db->ev_overlap);
     ring_destroy(db->ev_excl);
     ring_destroy(db->ev_pair);
@@ -496,6 +567,15 @@ int yh_db_get_timing(yh_db* db, yh_timing* t) {
     t->ms_exclusive_kernels = ring_read(db->ev_excl);
     t->ms_pairwise_kernels = ring_read(db->ev_pair);
     t->ms_db_build = db->ms_db_build;
+    t->ms_h2d = db->ms_h2d_create;
+    t->ms_d2h = 0.f;
+    for (int dir = 0; dir < 2; ++dir) {
+        float ms = 0.f;
+        if (db->xfer_recorded[dir] && hipEventElapsedTime(&ms, db->ev_xfer[dir][0], db->ev_xfer[dir][1]) == hipSuccess)
+            (dir ? t->ms_d2h : t->ms_h2d) = ms;
+        else
+            (void)hipGetLastError();
+    }
     return YH_OK;
 }
 
@@ -576,6 +656,7 @@ int yh_run_batch_device(yh_db* db, const uint64_t* d_samples, const uint64_t* d_
     }
     YH_TRY(db_select(db));
     note_other_query(db);
+    if (db->batch[0].open) db->batch[0].clobbered = true;  // (whole-batch calls run in slot 0)
     return yh_q_run_batch(db, (const u64*)d_samples, (const u64*)d_sample_offsets, n_samples, total_hashes, d_overlap,
                           d_n_excl, d_n_match);
 }
@@ -607,15 +688,20 @@ int yh_run_batch(yh_db* db, const uint64_t* samples, const uint64_t* sample_offs
         if (hipMalloc((void**)&d_s, std::max<u64>(total, 2) * sizeof(u64)) != hipSuccess ||
             hipMalloc((void**)&d_o, (u64)(n_samples + 1) * sizeof(u64)) != hipSuccess ||
             hipMalloc((void**)&d_out, 3 * BN * sizeof(u32)) != hipSuccess) { yh_set_error("hipMalloc failed"); rc = YH_ERR_OOM; break; }
-        if ((total && hipMemcpyAsync(d_s, samples, total * sizeof(u64), hipMemcpyHostToDevice, db->stream) != hipSuccess) ||
-            hipMemcpyAsync(d_o, sample_offsets, (u64)(n_samples + 1) * sizeof(u64), hipMemcpyHostToDevice, db->stream) != hipSuccess) {
-            yh_set_error("sample upload failed"); rc = YH_ERR_HIP; break;
-        }
+        xfer_mark(db, 0, 0);
+        const bool up_ok = (!total || hipMemcpyAsync(d_s, samples, total * sizeof(u64), hipMemcpyHostToDevice, db->stream) == hipSuccess) &&
+                           hipMemcpyAsync(d_o, sample_offsets, (u64)(n_samples + 1) * sizeof(u64), hipMemcpyHostToDevice, db->stream) == hipSuccess;
+        xfer_mark(db, 0, 1);
+        if (!up_ok) { yh_set_error("sample upload failed"); rc = YH_ERR_HIP; break; }
+        note_other_query(db);
+        if (db->batch[0].open) db->batch[0].clobbered = true;
         if ((rc = yh_q_run_batch(db, d_s, d_o, n_samples, total, d_out, d_out + BN, d_out + 2 * BN)) != YH_OK) break;
-        if (hipMemcpyAsync(overlap, d_out, BN * sizeof(u32), hipMemcpyDeviceToHost, db->stream) != hipSuccess ||
-            hipMemcpyAsync(n_excl, d_out + BN, BN * sizeof(u32), hipMemcpyDeviceToHost, db->stream) != hipSuccess ||
-            hipMemcpyAsync(n_match, d_out + 2 * BN, BN * sizeof(u32), hipMemcpyDeviceToHost, db->stream) != hipSuccess ||
-            hipStreamSynchronize(db->stream) != hipSuccess) {
+        xfer_mark(db, 1, 0);
+        const bool down_ok = hipMemcpyAsync(overlap, d_out, BN * sizeof(u32), hipMemcpyDeviceToHost, db->stream) == hipSuccess &&
+                             hipMemcpyAsync(n_excl, d_out + BN, BN * sizeof(u32), hipMemcpyDeviceToHost, db->stream) == hipSuccess &&
+                             hipMemcpyAsync(n_match, d_out + 2 * BN, BN * sizeof(u32), hipMemcpyDeviceToHost, db->stream) == hipSuccess;
+        xfer_mark(db, 1, 1);
+        if (!down_ok || hipStreamSynchronize(db->stream) != hipSuccess) {
             yh_set_error("batch download failed: %s", hipGetErrorString(hipGetLastError())); rc = YH_ERR_HIP;
         }
     } while (0);
@@ -680,7 +766,9 @@ static int upload_sample(yh_db* db, const uint64_t* sample, uint64_t n_sample, b
         return YH_OK;
     }
     u32 verdict = 0;
+    xfer_mark(db, 0, 0);
     YH_HIP(hipMemcpyAsync(db->d_sample_tmp, sample, n_sample * sizeof(u64), hipMemcpyHostToDevice, db->stream));
+    xfer_mark(db, 0, 1);
     if (defer_verdict) {
         // the kernels queued next read the verdict themselves (StreamHit::bad) and look nothing up when the
         // sample failed; the caller downloads it with the counts -- one host sync per call, not two
@@ -716,8 +804,10 @@ static int overlap_host(yh_db* db, const uint64_t* sample, uint64_t n_sample, ui
     YH_TRY(upload_sample(db, sample, n_sample));
     if (bsearch) YH_TRY(yh_q_overlap_bsearch(db, db->d_sample_tmp, n_sample, db->d_overlap_tmp));
     else YH_TRY(yh_overlap_device(db, (const uint64_t*)db->d_sample_tmp, n_sample, db->d_overlap_tmp));
+    xfer_mark(db, 1, 0);
     if (db->n_refs)
         YH_HIP(hipMemcpyAsync(overlap, db->d_overlap_tmp, db->n_refs * sizeof(u32), hipMemcpyDeviceToHost, db->stream));
+    xfer_mark(db, 1, 1);
     YH_HIP(hipStreamSynchronize(db->stream));
     return YH_OK;
 }
@@ -748,9 +838,11 @@ int yh_exclusive(yh_db* db, const uint8_t* subset_mask, const uint64_t* sample, 
         if ((rc = yh_q_overlap(db, db->d_sample_tmp, n_sample, db->d_overlap_tmp, true, false)) != YH_OK) break;
         rc = yh_q_exclusive(db, db->d_mask, db->d_sample_tmp, n_sample, db->d_overlap_tmp, d_e, d_m, nullptr);
         if (rc != YH_OK) break;
-        if (hipMemcpyAsync(n_excl, d_e, N * sizeof(u32), hipMemcpyDeviceToHost, db->stream) != hipSuccess ||
-            hipMemcpyAsync(n_match, d_m, N * sizeof(u32), hipMemcpyDeviceToHost, db->stream) != hipSuccess ||
-            hipStreamSynchronize(db->stream) != hipSuccess) {
+        xfer_mark(db, 1, 0);
+        const bool down_ok = hipMemcpyAsync(n_excl, d_e, N * sizeof(u32), hipMemcpyDeviceToHost, db->stream) == hipSuccess &&
+                             hipMemcpyAsync(n_match, d_m, N * sizeof(u32), hipMemcpyDeviceToHost, db->stream) == hipSuccess;
+        xfer_mark(db, 1, 1);
+        if (!down_ok || hipStreamSynchronize(db->stream) != hipSuccess) {
             yh_set_error("exclusive download failed: %s", hipGetErrorString(hipGetLastError()));
             rc = YH_ERR_HIP;
         }
@@ -835,11 +927,13 @@ int yh_run(yh_db* db, const uint64_t* sample, uint64_t n_sample, uint32_t* overl
     db->d_bad = nullptr;
     u32 verdict = 0;
     if (rc == YH_OK) {
-        if (hipMemcpyAsync(overlap, db->d_overlap_tmp, N * sizeof(u32), hipMemcpyDeviceToHost, db->stream) != hipSuccess ||
-            hipMemcpyAsync(n_excl, d_e, N * sizeof(u32), hipMemcpyDeviceToHost, db->stream) != hipSuccess ||
-            hipMemcpyAsync(n_match, d_m, N * sizeof(u32), hipMemcpyDeviceToHost, db->stream) != hipSuccess ||
-            (defer && hipMemcpyAsync(&verdict, db->d_bad_word, sizeof(u32), hipMemcpyDeviceToHost, db->stream) != hipSuccess) ||
-            hipStreamSynchronize(db->stream) != hipSuccess) {
+        xfer_mark(db, 1, 0);
+        const bool down_ok = hipMemcpyAsync(overlap, db->d_overlap_tmp, N * sizeof(u32), hipMemcpyDeviceToHost, db->stream) == hipSuccess &&
+                             hipMemcpyAsync(n_excl, d_e, N * sizeof(u32), hipMemcpyDeviceToHost, db->stream) == hipSuccess &&
+                             hipMemcpyAsync(n_match, d_m, N * sizeof(u32), hipMemcpyDeviceToHost, db->stream) == hipSuccess &&
+                             (!defer || hipMemcpyAsync(&verdict, db->d_bad_word, sizeof(u32), hipMemcpyDeviceToHost, db->stream) == hipSuccess);
+        xfer_mark(db, 1, 1);
+        if (!down_ok || hipStreamSynchronize(db->stream) != hipSuccess) {
             yh_set_error("run download failed: %s", hipGetErrorString(hipGetLastError()));
             rc = YH_ERR_HIP;
         }
@@ -901,6 +995,7 @@ int yh_run_local_device(yh_db* db, int ctx, const uint64_t* d_sample, uint64_t n
     if (!db_ok(db)) return YH_ERR_INVALID_ARG;
     if (!d_overlap || !d_n_excl || !d_n_match || (n_sample && !d_sample)) { yh_set_error("null device pointer"); return YH_ERR_INVALID_ARG; }
     YH_TRY(db_select(db));
+    YH_TRY(pipe_leave(db));  // (pending stages of pipelined steps read the step contexts 0..2 this call may write)
     YH_TRY(use_ctx(db, ctx));
     db->ctx_open[ctx] = true;
     db->ctx_clobbered[ctx] = false;
@@ -914,6 +1009,7 @@ int yh_run_finish_device(yh_db* db, int ctx, const uint32_t* d_global_bits, uint
     if (!db_ok(db)) return YH_ERR_INVALID_ARG;
     if (!d_n_excl || (db->n_ghost && !d_global_bits)) { yh_set_error("null device pointer"); return YH_ERR_INVALID_ARG; }
     YH_TRY(db_select(db));
+    YH_TRY(pipe_leave(db));
     YH_TRY(use_ctx(db, ctx));
     const bool clobbered = db->ctx_open[ctx] && db->ctx_clobbered[ctx];
     db->ctx_open[ctx] = false;
@@ -934,7 +1030,7 @@ int yh_run_local_range_device(yh_db* db, int ctx, const uint64_t* d_sample, uint
     if (!d_overlap || !d_n_match || !d_bits_out || (n_sample && !d_sample)) { yh_set_error("null device pointer"); return YH_ERR_INVALID_ARG; }
     if (db->n_ghost) { yh_set_error("a handle with ghosts is a reference shard, not a hash-range shard"); return YH_ERR_INVALID_ARG; }
     YH_TRY(db_select(db));
-    YH_TRY(pipe_join(db));
+    YH_TRY(pipe_leave(db));
     YH_TRY(use_ctx(db, ctx));
     db->ctx_open[ctx] = true;
     db->ctx_clobbered[ctx] = false;
@@ -952,6 +1048,7 @@ int yh_run_finish_range_device(yh_db* db, int ctx, const uint32_t* d_gathered_bi
     if (!db_ok(db)) return YH_ERR_INVALID_ARG;
     if (!d_n_excl || !d_gathered_bits || n_ranks < 1) { yh_set_error("null device pointer / no ranks"); return YH_ERR_INVALID_ARG; }
     YH_TRY(db_select(db));
+    YH_TRY(pipe_leave(db));
     YH_TRY(use_ctx(db, ctx));
     const bool clobbered = db->ctx_open[ctx] && db->ctx_clobbered[ctx];
     db->ctx_open[ctx] = false;
@@ -964,23 +1061,68 @@ int yh_run_finish_range_device(yh_db* db, int ctx, const uint32_t* d_gathered_bi
 }
 
 // the batched run on a hash-range shard: up to 64 samples per call around ONE exchange of their subset words
-int yh_run_batch_local_range_device(yh_db* db, const uint64_t* d_samples, const uint64_t* d_sample_offsets, uint32_t n_samples,
+static bool batch_slot_ok(int slot) {
+    if (slot >= 0 && slot < YH_BATCH_SLOTS) return true;
+    yh_set_error("batch slot must be in [0, %d)", YH_BATCH_SLOTS);
+    return false;
+}
+int yh_run_batch_local_range_device(yh_db* db, int slot, const uint64_t* d_samples, const uint64_t* d_sample_offsets, uint32_t n_samples,
                                     uint64_t total_hashes, uint32_t* d_overlap, uint64_t* d_maskwords_out) {
     if (!db_ok(db)) return YH_ERR_INVALID_ARG;
+    if (!batch_slot_ok(slot)) return YH_ERR_INVALID_ARG;
     if (!d_sample_offsets || !d_overlap || !d_maskwords_out || (total_hashes && !d_samples)) { yh_set_error("null device pointer"); return YH_ERR_INVALID_ARG; }
     YH_TRY(db_select(db));
     note_other_query(db);
-    return yh_q_run_batch(db, (const u64*)d_samples, (const u64*)d_sample_offsets, n_samples, total_hashes, d_overlap, nullptr,
-                          nullptr, 1, (u64*)d_maskwords_out);
+    const int rc = yh_q_run_batch(db, (const u64*)d_samples, (const u64*)d_sample_offsets, n_samples, total_hashes, d_overlap, nullptr,
+                                  nullptr, 1, (u64*)d_maskwords_out, nullptr, 0, slot);
+    yh_db::BatchSlot& bs = db->batch[slot];
+    bs.open = rc == YH_OK;
+    bs.clobbered = false;
+    return rc;
 }
 
-int yh_run_batch_finish_range_device(yh_db* db, uint32_t n_samples, const uint64_t* d_gathered_maskwords, uint32_t n_ranks,
+int yh_run_batch_finish_range_device(yh_db* db, int slot, uint32_t n_samples, const uint64_t* d_gathered_maskwords, uint32_t n_ranks,
                                      const uint32_t* d_overlap, uint32_t* d_n_excl, uint32_t* d_n_match) {
     if (!db_ok(db)) return YH_ERR_INVALID_ARG;
+    if (!batch_slot_ok(slot)) return YH_ERR_INVALID_ARG;
     if (!d_gathered_maskwords || n_ranks < 1 || !d_overlap || !d_n_excl || !d_n_match) { yh_set_error("null device pointer / no ranks"); return YH_ERR_INVALID_ARG; }
+    yh_db::BatchSlot& bs = db->batch[slot];
+    const bool was_open = bs.open, clobbered = bs.clobbered;
+    bs.open = false;
+    bs.clobbered = false;
+    if (db->n_refs && (!was_open || clobbered || bs.n_samples != n_samples)) {
+        yh_set_error(!was_open ? "batch slot %d holds no first half (yh_run_batch_local_range_device)"
+                     : clobbered ? "another batched call ran in batch slot %d between the two halves: the first half's state is gone"
+                                 : "batch slot %d: the second half names a different number of samples than the first", slot);
+        return YH_ERR_INVALID_ARG;
+    }
     YH_TRY(db_select(db));
+    note_other_query(db);  // (the second half rewrites the current step context's subset bits and work list)
     return yh_q_run_batch(db, nullptr, nullptr, n_samples, 0, const_cast<uint32_t*>(d_overlap), d_n_excl, d_n_match, 2, nullptr,
-                          (const u64*)d_gathered_maskwords, n_ranks);
+                          (const u64*)d_gathered_maskwords, n_ranks, slot);
+}
+
+// the compact form of a batch's result: one entry per set bit of the slot's subset words (yh_batch.hip)
+static int batch_rows_check(yh_db* db, int slot) {
+    if (!db_ok(db)) return YH_ERR_INVALID_ARG;
+    if (!batch_slot_ok(slot)) return YH_ERR_INVALID_ARG;
+    if (db->n_refs && (!db->batch[slot].words_valid || db->batch[slot].open)) {
+        yh_set_error("batch slot %d holds no completed batch (yh_run_batch_device / yh_run_batch_finish_range_device first)", slot);
+        return YH_ERR_INVALID_ARG;
+    }
+    return db_select(db);
+}
+int yh_run_batch_rows_pack_device(yh_db* db, int slot, const uint32_t* d_overlap, const uint32_t* d_n_excl, const uint32_t* d_n_match,
+                                  uint32_t* d_vals, uint64_t cap_rows, uint32_t* d_n_rows) {
+    YH_TRY(batch_rows_check(db, slot));
+    if (!d_n_rows || (db->n_refs && (!d_overlap || !d_n_excl || !d_n_match)) || (cap_rows && !d_vals)) { yh_set_error("null device pointer"); return YH_ERR_INVALID_ARG; }
+    return yh_q_batch_rows_pack(db, slot, d_overlap, d_n_excl, d_n_match, d_vals, cap_rows, d_n_rows);
+}
+int yh_run_batch_rows_unpack_device(yh_db* db, int slot, const uint32_t* d_vals, uint64_t cap_rows, yh_batch_row* d_rows,
+                                    uint32_t* d_n_rows) {
+    YH_TRY(batch_rows_check(db, slot));
+    if (!d_n_rows || (cap_rows && (!d_vals || !d_rows))) { yh_set_error("null device pointer"); return YH_ERR_INVALID_ARG; }
+    return yh_q_batch_rows_unpack(db, slot, d_vals, cap_rows, d_rows, d_n_rows);
 }
 
 // ---- pipelined host-buffer run calls ---------------------------------------------------------------
@@ -1140,6 +1282,9 @@ int yh_run_rows_device(yh_db* db, const uint32_t* d_overlap, const uint32_t* d_n
     if (!db_ok(db)) return YH_ERR_INVALID_ARG;
     if (!d_n_rows || (db->n_refs && (!d_overlap || !d_n_excl || !d_n_match)) || (cap_rows && !d_rows)) { yh_set_error("null device pointer"); return YH_ERR_INVALID_ARG; }
     YH_TRY(db_select(db));
+    // (the rows of a pipelined step are complete only behind its reducer and exclusive stages: run them first, so that
+    // the count rows AND the subset bits the compaction reads are those of the step queued last)
+    YH_TRY(pipe_join(db));
     return yh_rows_compact_device(db, d_overlap, d_n_excl, d_n_match, d_rows, cap_rows, d_n_rows, nullptr);
 }
 

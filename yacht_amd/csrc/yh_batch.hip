@@ -135,8 +135,10 @@ __global__ void __launch_bounds__(256) k_batch_maskwords(const u32* __restrict__
 }
 
 // The work list of the exclusive pass: every reference some sample overlaps appends pieces of <= BATCH_PIECE of its
-// DISTINCT holder-set records (yh_db::d_hrec, [hpo[r], hpo[r + 1])); work_count zeroed by the caller.
-constexpr u32 BATCH_PIECE = 256;
+// DISTINCT holder-set records (yh_db::d_hrec, [hpo[r], hpo[r + 1])); work_count zeroed by the caller.  The piece size is
+// the one yh_db::d_work was sized for at build time (k_chunk_counts: ceil(nshared[r] / YH_EXCL_PIECE) pieces per reference,
+// and a reference has no more holder-set records than shared hashes), whatever a build variant sets it to.
+constexpr u32 BATCH_PIECE = YH_EXCL_PIECE;
 __global__ void __launch_bounds__(256) k_batch_worklist(u64 n, const u32* __restrict__ anybits, const u32* __restrict__ hpo,
                                                         uint4* __restrict__ work, u32* __restrict__ work_count) {
     __shared__ u32 lds[5];
@@ -182,11 +184,12 @@ __global__ void __launch_bounds__(256) k_batch_sets(const uint4* __restrict__ wo
         const uint4 piece = work[w];
         const u32 r = piece.x;
         const u64 wr = maskword[r];
+        for (u32 first = piece.y; first < piece.z; first += 256u) {  // (wave-uniform; one round unless YH_EXCL_PIECE > 256)
         u64 excl[4];
         u32 mu[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const u32 k = piece.y + 64u * u + lane;
+            const u32 k = first + 64u * u + lane;
             excl[u] = 0;
             mu[u] = 0;
             if (k < piece.z) {
@@ -223,6 +226,7 @@ __global__ void __launch_bounds__(256) k_batch_sets(const uint4* __restrict__ wo
 #pragma unroll
             for (int off = 32; off >= 1; off >>= 1) v += (u32)__shfl_xor((int)v, off);
             if (lane == 0 && v) atomicAdd(&ex_e[(u64)s * n_refs + r], v);
+        }
         }
     }
 }
@@ -266,13 +270,137 @@ __global__ void __launch_bounds__(256) k_batch_final(u32 n_samples, u64 n_refs, 
     }
 }
 
+// ---- the batch's result in compact form (include/yacht_hip.h: yh_run_batch_rows_*) --------------------------------------
+// One entry per set bit s of maskword[r], in (r, s) order.  ROWS_BLOCK references per workgroup: k_batch_rows_count leaves
+// each block's number of entries, k_batch_rows_emit sums the counts of the blocks in front of its own (N / 2048 words),
+// scans its own references' popcounts and writes -- PACK: the three values of every entry from the dense rows; else the
+// rows themselves from the (summed) values.
+constexpr u32 ROWS_BLOCK = 2048;
+__global__ void __launch_bounds__(256) k_batch_rows_count(const u64* __restrict__ maskword, u64 n_refs, u32* __restrict__ blk_count) {
+    __shared__ u32 part[4];
+    const u64 r0 = (u64)blockIdx.x * ROWS_BLOCK;
+    u32 c = 0;
+    for (u32 k = threadIdx.x; k < ROWS_BLOCK; k += 256)
+        if (r0 + k < n_refs) c += (u32)__popcll(maskword[r0 + k]);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) c += (u32)__shfl_xor((int)c, off);
+    if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) blk_count[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+template <bool PACK>
+__global__ void __launch_bounds__(256) k_batch_rows_emit(const u64* __restrict__ maskword, u64 n_refs, u32 n_samples,
+                                                         const u32* __restrict__ blk_count, u32 n_blocks,
+                                                         const u32* __restrict__ overlap, const u32* __restrict__ excl,
+                                                         const u32* __restrict__ match, u32* __restrict__ vals /* PACK: out, else in */,
+                                                         yh_batch_row* __restrict__ rows, u64 cap, u32* __restrict__ n_rows) {
+    __shared__ u32 part[4];
+    __shared__ u32 wave_base[5];
+    const u32 lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    u32 before = 0;  // entries of the blocks in front of this one
+    for (u32 b = threadIdx.x; b < blockIdx.x; b += 256) before += blk_count[b];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) before += (u32)__shfl_xor((int)before, off);
+    if (lane == 0) part[wv] = before;
+    __syncthreads();
+    u32 base = part[0] + part[1] + part[2] + part[3];
+    if (blockIdx.x == n_blocks - 1 && threadIdx.x == 0) *n_rows = base + blk_count[blockIdx.x];
+    const u64 r0 = (u64)blockIdx.x * ROWS_BLOCK;
+    for (u32 k0 = 0; k0 < ROWS_BLOCK; k0 += 256) {  // (workgroup-uniform)
+        const u64 r = r0 + k0 + threadIdx.x;
+        u64 w = r < n_refs ? maskword[r] : 0ull;
+        const u32 c = (u32)__popcll(w);
+        u32 inc = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const u32 t = (u32)__shfl_up((int)inc, off);
+            if (lane >= (u32)off) inc += t;
+        }
+        __syncthreads();
+        if (lane == 63) wave_base[wv] = inc;
+        __syncthreads();
+        u32 at = base + inc - c;
+        for (u32 q = 0; q < wv; ++q) at += wave_base[q];
+        base += wave_base[0] + wave_base[1] + wave_base[2] + wave_base[3];
+        while (w) {
+            const u32 s = (u32)__ffsll((long long)w) - 1u;
+            w &= w - 1;
+            if (at < cap && s < n_samples) {
+                if (PACK) {
+                    const u64 t = (u64)s * n_refs + r;
+                    vals[3ull * at + 0] = overlap[t];
+                    vals[3ull * at + 1] = excl[t];
+                    vals[3ull * at + 2] = match[t];
+                } else {
+                    yh_batch_row row;
+                    row.sample = s;
+                    row.ref = (u32)r;
+                    row.overlap = vals[3ull * at + 0];
+                    row.n_excl = vals[3ull * at + 1];
+                    row.n_match = vals[3ull * at + 2];
+                    rows[at] = row;
+                }
+            }
+            ++at;
+        }
+    }
+}
+
 }  // namespace
+
+// a slot's scratch: maskword [N + 2] u64 | block counts of the compact rows [ceil(N / 2048) + 1, padded] u32 | ovsh [B][N] u32
+static u64 batch_blk_words(const yh_db* db) { return (((db->n_refs + ROWS_BLOCK - 1) / ROWS_BLOCK + 1) + 3) & ~(u64)3; }
+static u32* batch_slot_blk_counts(yh_db* db, int slot) {
+    return reinterpret_cast<u32*>(reinterpret_cast<u64*>(db->batch[slot].d_scratch) + db->n_refs + 2);
+}
+static int batch_slot_scratch(yh_db* db, int slot, u32 n_samples, u64** d_maskword, u32** d_ovsh, u64* need_out) {
+    const u64 N = db->n_refs;
+    const u64 BN = (u64)n_samples * N;
+    yh_db::BatchSlot& bs = db->batch[slot];
+    const u64 need = (N + 2) * sizeof(u64) + batch_blk_words(db) * sizeof(u32) + BN * sizeof(u32) + 64;  // (kept per slot, grown on demand)
+    if (bs.cap < need) {
+        YH_HIP(hipStreamSynchronize(db->stream));
+        if (bs.d_scratch) { yh_dfree(db, bs.d_scratch); bs.d_scratch = nullptr; bs.cap = 0; }
+        YH_HIP(hipMalloc((void**)&bs.d_scratch, need));
+        bs.cap = need;
+    }
+    *d_maskword = reinterpret_cast<u64*>(bs.d_scratch);
+    *d_ovsh = batch_slot_blk_counts(db, slot) + batch_blk_words(db);
+    if (need_out) *need_out = need;
+    return YH_OK;
+}
+
+int yh_q_batch_rows_pack(yh_db* db, int slot, const u32* d_overlap, const u32* d_excl, const u32* d_match, u32* d_vals, u64 cap_rows,
+                         u32* d_n_rows) {
+    const u64 N = db->n_refs;
+    if (N == 0) { YH_HIP(hipMemsetAsync(d_n_rows, 0, sizeof(u32), db->stream)); return YH_OK; }
+    const u64* d_maskword = reinterpret_cast<const u64*>(db->batch[slot].d_scratch);
+    u32* blk = batch_slot_blk_counts(db, slot);
+    const u32 nblk = (u32)((N + ROWS_BLOCK - 1) / ROWS_BLOCK);
+    k_batch_rows_count<<<nblk, 256, 0, db->stream>>>(d_maskword, N, blk);
+    k_batch_rows_emit<true><<<nblk, 256, 0, db->stream>>>(d_maskword, N, db->batch[slot].n_samples, blk, nblk, d_overlap, d_excl, d_match,
+                                                        d_vals, nullptr, cap_rows, d_n_rows);
+    YH_HIP(hipGetLastError());
+    return YH_OK;
+}
+int yh_q_batch_rows_unpack(yh_db* db, int slot, const u32* d_vals, u64 cap_rows, void* d_rows, u32* d_n_rows) {
+    const u64 N = db->n_refs;
+    if (N == 0) { YH_HIP(hipMemsetAsync(d_n_rows, 0, sizeof(u32), db->stream)); return YH_OK; }
+    const u64* d_maskword = reinterpret_cast<const u64*>(db->batch[slot].d_scratch);
+    u32* blk = batch_slot_blk_counts(db, slot);
+    const u32 nblk = (u32)((N + ROWS_BLOCK - 1) / ROWS_BLOCK);
+    k_batch_rows_count<<<nblk, 256, 0, db->stream>>>(d_maskword, N, blk);
+    k_batch_rows_emit<false><<<nblk, 256, 0, db->stream>>>(d_maskword, N, db->batch[slot].n_samples, blk, nblk, nullptr, nullptr, nullptr,
+                                                         const_cast<u32*>(d_vals), reinterpret_cast<yh_batch_row*>(d_rows), cap_rows, d_n_rows);
+    YH_HIP(hipGetLastError());
+    return YH_OK;
+}
 
 // phases: 1 = lookup + the samples' subset words (copied to d_maskword_out when given), 2 = exclusive pass + final
 // (d_gathered: the words of n_ranks hash-range shards, OR-ed into the subset first), 3 = both (one device, one call)
 int yh_q_run_batch(yh_db* db, const u64* d_samples, const u64* d_soff, u32 n_samples, u64 total_hashes,
                    u32* d_overlap, u32* d_excl, u32* d_match, int phases, u64* d_maskword_out, const u64* d_gathered,
-                   u32 n_ranks) {
+                   u32 n_ranks, int slot) {
     if (!db->has_dir || !db->has_index) {
         yh_set_error("yh_run_batch needs the directory of the distinct hashes (handle created with YH_DB_NO_DIRECTORY?)");
         return YH_ERR_UNSUPPORTED;
@@ -284,19 +412,15 @@ int yh_q_run_batch(yh_db* db, const u64* d_samples, const u64* d_soff, u32 n_sam
     const u64 BN = (u64)n_samples * N;
     const u64 G = db->n_shared;
     if (G && db->n_postings && !db->d_hrec) { yh_set_error("yh_run_batch needs the holder sets of the handle"); return YH_ERR_UNSUPPORTED; }
-    // scratch: maskword [N] u64, ovsh [B][N] u32 (kept on the handle, grown on demand)
-    const u64 need = BN * sizeof(u32) + (N + 2) * sizeof(u64) + 64;
-    if (db->batch_cap < need) {
-        YH_HIP(hipStreamSynchronize(st));
-        if (db->d_batch) { yh_dfree(db, db->d_batch); db->d_batch = nullptr; db->batch_cap = 0; }
-        YH_HIP(hipMalloc((void**)&db->d_batch, need));
-        db->batch_cap = need;
-    }
-    u64* d_maskword = reinterpret_cast<u64*>(db->d_batch);
-    u32* d_ovsh = reinterpret_cast<u32*>(d_maskword + N + 1);
+    yh_db::BatchSlot& bs = db->batch[slot];
+    u64* d_maskword = nullptr;
+    u32* d_ovsh = nullptr;
+    u64 need = 0;
+    YH_TRY(batch_slot_scratch(db, slot, (phases & 1) ? n_samples : std::max(n_samples, bs.n_samples), &d_maskword, &d_ovsh, &need));
+    if (phases & 1) { bs.n_samples = n_samples; bs.words_valid = false; }
     if (phases & 1) {
     YH_HIP(hipMemsetAsync(d_overlap, 0, BN * sizeof(u32), st));
-    YH_HIP(hipMemsetAsync(db->d_batch, 0, need, st));
+    YH_HIP(hipMemsetAsync(bs.d_scratch, 0, need, st));
     yh_ring_record_begin(db, db->ev_overlap);
     if (total_hashes && db->n_distinct) {
         const u64 n_tiles = (total_hashes + BATCH_TILE - 1) / BATCH_TILE + n_samples;  // (a ragged tile per sample)
@@ -325,5 +449,6 @@ int yh_q_run_batch(yh_db* db, const u64* d_samples, const u64* d_soff, u32 n_sam
                                                            d_excl, d_match, d_gathered ? d_maskword : nullptr);
     yh_ring_record_end(db, db->ev_excl);
     YH_HIP(hipGetLastError());
+    bs.words_valid = true;  // (the slot's words are the batch's subset -- on hash-range shards the global one)
     return YH_OK;
 }

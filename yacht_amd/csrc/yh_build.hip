@@ -589,6 +589,8 @@ int yh_build_upload_sorted(yh_db* db, const u64* h_values, const u64* h_offsets,
     if (rc == YH_OK) {
         copier = std::thread([&, device]() {
             if (hipSetDevice(device) != hipSuccess) { copy_failed.store(1); copied.store((int)C); return; }
+            const double t_up = trace_now();
+            struct UpClock { yh_db* db; double t0; ~UpClock() { db->ms_h2d_create += (float)(trace_now() - t0); } } up_clock{db, t_up};  // (yh_timing.ms_h2d)
             for (size_t c = 0; c < C; ++c) {
                 const u64 e0 = h_offsets[rb[c]], e1 = h_offsets[rb[c + 1]];
                 if (e1 > e0 && hipMemcpyAsync(d_values + e0, h_values + e0, (e1 - e0) * sizeof(u64), hipMemcpyHostToDevice, up) != hipSuccess)
@@ -596,6 +598,7 @@ int yh_build_upload_sorted(yh_db* db, const u64* h_values, const u64* h_offsets,
                 if (hipEventRecord(ev[c], up) != hipSuccess) copy_failed.store(1);
                 copied.store((int)c + 1, std::memory_order_release);
             }
+            if (C) (void)hipEventSynchronize(ev[C - 1]);  // (the clock stops when the last byte is up)
         });
     }
     for (size_t c = 0; c < C && rc == YH_OK; ++c) {
@@ -923,10 +926,12 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, u64* d_
             IDX_HIP(hipStreamSynchronize(st));
         }
         IDX_HIP(hipStreamSynchronize(st));
+        TRACE("index: emit + table + filter");
         yh_tfree(db, d_dh_tmp);
         yh_tfree(db, d_dref_tmp);
         if (rc == YH_OK && full) db->has_dir = true;
         if (rc == YH_OK && want_stream) rc = build_stream(db, d_sk, d_sv, d_elem_g, H);  // (behind the table: its temporaries are gone)
+        TRACE("index: delta stream");
         yh_tfree(db, d_elem_g);
         d_elem_g = nullptr;
         IDX_HIP(hipGetLastError());
@@ -963,6 +968,7 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, u64* d_
                 k_fill_rg<<<grid_for(db->n_postings, 256), 256, 0, st>>>(db->n_postings, db->d_pr, db->d_pg, db->d_po, db->d_rpo,
                                                                          d_cur, db->d_rg, db->d_rrec, db->d_rrecx, d_pref);
             IDX_HIP(hipGetLastError());
+            if (trace_on()) { IDX_HIP(hipStreamSynchronize(st)); TRACE("index: reference-major view"); }
             if (rc == YH_OK && want_stream) {  // distinct holder sets per reference (k_set_*)
                 const u64 P = db->n_postings;
                 u64 *d_k = nullptr, *d_k2 = nullptr;
@@ -1007,6 +1013,7 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, u64* d_
                 IDX_HIP(hipStreamSynchronize(st));
                 yh_tfree(db, d_k); yh_tfree(db, d_k2); yh_tfree(db, d_i); yh_tfree(db, d_i2);
                 yh_tfree(db, d_kr); yh_tfree(db, d_kr2); yh_tfree(db, d_t);
+                TRACE("index: holder sets");
             }
             IDX_HIP(hipStreamSynchronize(st));
             yh_tfree(db, d_pref);

@@ -182,8 +182,17 @@ struct yh_db {
     u32* d_bad_word = nullptr; // [1] deferred ordering verdict of yh_run (see bad_gen)
     u32* d_reps = nullptr;     // [R][N] replicated overlap counters; ZERO AT REST: k_reduce_replicas clears what it sums
     u64 reps_cap = 0;
-    void* d_batch = nullptr;   // scratch of the batched run: hit words, mask words, shared overlaps
-    u64 batch_cap = 0;
+    // scratch of the batched run, per batch slot: the samples' subset words [N + 1] u64 and the hits on shared hashes
+    // [B][N] u32 -- what the first half of a hash-range batch leaves for the second (two slots: the exchange of one
+    // block's words travels while the next block's lookups run)
+    struct BatchSlot {
+        void* d_scratch = nullptr;
+        u64 cap = 0;
+        u32 n_samples = 0;
+        bool open = false;       // first half queued, second not yet
+        bool clobbered = false;  // a whole-batch call ran in the slot meanwhile
+        bool words_valid = false;  // the slot holds the GLOBAL subset words of its last batch (yh_run_batch_rows_*)
+    } batch[YH_BATCH_SLOTS];
 
     // pairwise result cache (two-call sizing)
     bool pw_valid = false;
@@ -217,6 +226,7 @@ struct yh_db {
     int pend_red = -1, pend_red_parity = 0, pend_excl = -1;
     u32* pend_red_out[3] = {nullptr, nullptr, nullptr};
     u32* pend_excl_out = nullptr;
+    int pipe_last_ctx = -1;  // step context of the LAST step queued when that was a pipelined one (its subset bits: yh_run_rows_device); -1 otherwise
 
     // pipelined host-buffer calls
     RunSlot slots[YH_RUN_SLOTS];
@@ -229,6 +239,11 @@ struct yh_db {
     EventRing ev_overlap, ev_excl, ev_pair;
     float ms_upload_kernels = 0.f;  // device time of the chunk sorts / merges that ran under the upload (yh_build_upload_sorted)
     float ms_db_build = 0.f;
+    // host <-> device copies (yh_timing.ms_h2d / ms_d2h): the CSR upload of yh_db_create (host clock), then HIP events
+    // around the sample upload / count download of the last synchronous host-pointer query
+    float ms_h2d_create = 0.f;
+    hipEvent_t ev_xfer[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [h2d | d2h][begin | end], created on first use
+    bool xfer_recorded[2] = {false, false};
 };
 
 // ---- implemented in yh_build.hip -------------------------------------------------------------
@@ -377,7 +392,11 @@ int yh_q_overlap_indexed(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_ov
                          bool lookup_half_only = false);
 int yh_q_run_batch(yh_db* db, const u64* d_samples, const u64* d_soff, u32 n_samples, u64 total_hashes,
                    u32* d_overlap, u32* d_excl, u32* d_match, int phases = 3, u64* d_maskword_out = nullptr,
-                   const u64* d_gathered = nullptr, u32 n_ranks = 0);
+                   const u64* d_gathered = nullptr, u32 n_ranks = 0, int slot = 0);
+// the compact form of a batch's result (yh_batch.hip): pack = this rank's value triples, unpack = the rows themselves
+int yh_q_batch_rows_pack(yh_db* db, int slot, const u32* d_overlap, const u32* d_excl, const u32* d_match, u32* d_vals, u64 cap_rows,
+                         u32* d_n_rows);
+int yh_q_batch_rows_unpack(yh_db* db, int slot, const u32* d_vals, u64 cap_rows, void* d_rows, u32* d_n_rows);
 int yh_q_exclusive(yh_db* db, const u8* d_mask, const u64* d_sample, u64 n_sample,
                    const u32* d_overlap, u32* d_excl, u32* d_match, const u32* d_maskbits);
 int yh_q_pairwise(yh_db* db, double c_thresh, u64 r0, u64 r1);

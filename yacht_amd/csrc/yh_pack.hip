@@ -195,16 +195,17 @@ int yh_pack_expand_device(yh_db* db, const void* d_packed, u64 n, u64* d_out, u3
 }
 
 // rows of the references with overlap > 0 from the three count rows of the step that just ran on the handle's stream
-// (its subset bits are db->d_maskbits)
+// (its subset bits: db->d_maskbits, or -- the step was a pipelined one -- those of the step context it ran in)
 int yh_rows_compact_device(yh_db* db, const u32* d_overlap, const u32* d_excl, const u32* d_match, void* rows_dev, u64 cap,
                            u32* count_dev, u32* count_host_dev) {
+    const u32* maskbits = (db->pipe_last_ctx >= 0 && db->ctx_bits[db->pipe_last_ctx]) ? db->ctx_bits[db->pipe_last_ctx] : db->d_maskbits;
     const u64 N = db->n_refs;
     if (N == 0) {
         if (count_dev) YH_HIP(hipMemsetAsync(count_dev, 0, sizeof(u32), db->stream));
         return YH_OK;
     }
     RowsOut o{reinterpret_cast<uint4*>(rows_dev), cap, count_dev, count_host_dev};
-    k_compact_rows<<<(u32)((N + 2047) / 2048), 1024, 0, db->stream>>>(N, db->d_maskbits, d_overlap, d_excl, d_match, o);
+    k_compact_rows<<<(u32)((N + 2047) / 2048), 1024, 0, db->stream>>>(N, maskbits, d_overlap, d_excl, d_match, o);
     YH_HIP(hipGetLastError());
     return YH_OK;
 }

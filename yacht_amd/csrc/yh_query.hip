@@ -1531,6 +1531,7 @@ int yh_q_step_fused(yh_db* db, const u64* d_sample, u64 n_sample, u32* d_overlap
         db->pend_red_out[0] = d_overlap;
         db->pend_red_out[1] = d_excl;
         db->pend_red_out[2] = d_match;
+        db->pipe_last_ctx = c_new;
         ++db->pipe_k;
     }
     return YH_OK;

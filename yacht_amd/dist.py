@@ -12,7 +12,7 @@ Torch is plumbing here (process group + collectives); the compute callables are 
 from __future__ import annotations
 
 import os
-from typing import Callable, List, Sequence, Tuple
+from typing import Callable, List, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -573,19 +573,37 @@ class HipRangeBackend:
                     return
                 db.run_finish_range_device(gathered_t.data_ptr(), n_ranks, stride_words, counts_t[1].data_ptr(), ctx)
 
-            def batch_local(self, cat_t, soff_t, n_samples, total, ov_t, words_t):
-                if empty:
+            def batch_local(self, cat_t, soff_t, n_samples, total, ov_t, words_t, slot=0):
+                if empty:  # (a range without a single reference hash still takes part: its words are zero, its shares too)
                     ov_t.zero_()
                     words_t.zero_()
                     return
-                db.run_batch_local_range_device(cat_t.data_ptr(), soff_t.data_ptr(), n_samples, total, ov_t.data_ptr(), words_t.data_ptr())
+                db.run_batch_local_range_device(cat_t.data_ptr(), soff_t.data_ptr(), n_samples, total, ov_t.data_ptr(), words_t.data_ptr(), slot)
 
-            def batch_finish(self, n_samples, gathered_t, n_ranks, ov_t, e_t, m_t):
+            def batch_finish(self, n_samples, gathered_t, n_ranks, ov_t, e_t, m_t, slot=0):
                 if empty:
                     e_t.zero_()
                     m_t.zero_()
+                    self._empty_gathered = (gathered_t, n_ranks, n_samples)
                     return
-                db.run_batch_finish_range_device(n_samples, gathered_t.data_ptr(), n_ranks, ov_t.data_ptr(), e_t.data_ptr(), m_t.data_ptr())
+                db.run_batch_finish_range_device(n_samples, gathered_t.data_ptr(), n_ranks, ov_t.data_ptr(), e_t.data_ptr(), m_t.data_ptr(), slot)
+
+            def rows_pack(self, counts_t, vals_t, nrows_t, slot=0):
+                """vals_t [cap, 3] int32 = this rank's shares of every entry of the slot's batch; nrows_t [1] their number."""
+                if empty:  # every share is zero; the entries are those of the global subset all the same
+                    g, nr, ns = self._empty_gathered  # (rare: tests; through the host)
+                    w = np.bitwise_or.reduce(g[:nr].cpu().numpy().view(np.uint64), axis=0)
+                    n = int(np.unpackbits(w.view(np.uint8)).sum())
+                    nrows_t.copy_(torch.tensor([n], dtype=torch.int32))
+                    vals_t.zero_()
+                    return
+                db.run_batch_rows_pack_device(counts_t[0].data_ptr(), counts_t[1].data_ptr(), counts_t[2].data_ptr(), vals_t.data_ptr(),
+                                              int(vals_t.shape[0]), nrows_t.data_ptr(), slot)
+
+            def rows_unpack(self, vals_t, rows_t, nrows_t, slot=0):
+                """rows_t [cap, 5] int32 = (sample, ref, overlap, n_excl, n_match) from (summed) values."""
+                assert not empty, "the consumer of the rows needs a rank whose range holds reference hashes"
+                db.run_batch_rows_unpack_device(vals_t.data_ptr(), int(vals_t.shape[0]), rows_t.data_ptr(), nrows_t.data_ptr(), slot)
 
             def close(self):
                 db.close()
@@ -625,24 +643,23 @@ class HashRangeRefDB:
         self.bits_local = [torch.zeros((GB, W), dtype=torch.int32, device=dev) for _ in range(2)]
         self.bits_global = [torch.zeros((world, GB, W), dtype=torch.int32, device=dev) for _ in range(2)]
         self._pending = [None, None]
-        self._slices = {}
 
     def new_counts(self):
         import torch
 
         return torch.zeros((3, self.n_total), dtype=torch.int32, device=self.dev)
 
-    def _slice_of(self, sample_t) -> Tuple[int, int]:
-        key = (sample_t.data_ptr(), int(sample_t.numel()))
-        if key not in self._slices:  # (one small device search + host sync per NEW sample tensor; resident samples: once)
-            if len(self._slices) > 4096:
-                self._slices.clear()
-            self._slices[key] = sample_slice(sample_t, self.lo, self.hi) if sample_t.numel() else (0, 0)
-        return self._slices[key]
+    def slice_of(self, sample_t) -> Tuple[int, int]:
+        """[a, b): the positions of the sorted sample's hashes in this rank's range -- one small device search and a host
+        sync, computed on EVERY call (nothing is remembered about a tensor: an address says nothing about the hashes
+        behind it once a staging buffer is refilled or the allocator hands the address out again).  A caller whose
+        samples stay resident computes the spans once and passes them to begin() / pack_batch()."""
+        return sample_slice(sample_t, self.lo, self.hi) if sample_t.numel() else (0, 0)
 
-    def begin(self, sample_t, counts_t, slot: int = 0, g: int = 0):
-        """Rank-local half of sample g of block `slot`: lookup + reduce of the sample's hashes in this rank's range."""
-        a, b = self._slice_of(sample_t)
+    def begin(self, sample_t, counts_t, slot: int = 0, g: int = 0, span: Optional[Tuple[int, int]] = None):
+        """Rank-local half of sample g of block `slot`: lookup + reduce of the sample's hashes in this rank's range
+        (`span` = slice_of(sample_t) when the caller already has it)."""
+        a, b = self.slice_of(sample_t) if span is None else span
         self.local.run_local(sample_t, a, b, counts_t, self.bits_local[slot][g], slot * self.block + g)
 
     def exchange(self, slot: int = 0):
@@ -678,14 +695,14 @@ class HashRangeRefDB:
         return self.end(counts_t, 0, 0)
 
     # ---- many samples per call: the throughput form (include/yacht_hip.h, yh_run_batch_*_range_device) ----
-    def pack_batch(self, samples):
+    def pack_batch(self, samples, spans=None):
         """This rank's slices of up to 64 samples, concatenated: (hashes, offsets[len + 1], total) -- made once for
-        samples that stay resident."""
+        samples that stay resident (`spans`: their slice_of() results, when the caller has them)."""
         import torch
 
         parts, lens = [], []
-        for s_ in samples:
-            a, b = self._slice_of(s_)
+        for k_, s_ in enumerate(samples):
+            a, b = self.slice_of(s_) if spans is None else spans[k_]
             parts.append(s_[a:b])
             lens.append(b - a)
         cat = torch.cat(parts).contiguous() if sum(lens) else torch.zeros(1, dtype=torch.int64, device=self.dev)[:0]
@@ -693,11 +710,13 @@ class HashRangeRefDB:
         soff[1:] = torch.cumsum(torch.tensor(lens, dtype=torch.int64, device=self.dev), 0)
         return cat, soff, int(sum(lens))
 
-    def batch_begin(self, batch, counts_t, words_t):
+    def batch_begin(self, batch, counts_t, words_t, slot: int = 0):
         """First half for a whole batch: counts_t [3, B, N] (row 0 = this rank's share of the overlaps), words_t [N] int64
-        = this rank's subset words (bit s: sample s overlaps the reference in this range)."""
+        = this rank's subset words (bit s: sample s overlaps the reference in this range).  `slot` (0 .. YH_BATCH_SLOTS - 1)
+        names the batch slot of the library the two halves share: the words of one block travel while the next block's first
+        half runs in another slot."""
         cat, soff, total = batch
-        self.local.batch_local(cat, soff, int(soff.numel()) - 1, total, counts_t[0], words_t)
+        self.local.batch_local(cat, soff, int(soff.numel()) - 1, total, counts_t[0], words_t, slot)
 
     def batch_exchange(self, words_t, gathered_t, async_op: bool = False):
         """All-gather of the ranks' subset words into gathered_t [world, N]."""
@@ -711,8 +730,8 @@ class HashRangeRefDB:
         all_gather_into(gathered_t.view(-1), words_t.view(-1), group=self.group)
         return None
 
-    def batch_end(self, n_samples, gathered_t, counts_t):
-        self.local.batch_finish(n_samples, gathered_t, self.world, counts_t[0], counts_t[1], counts_t[2])
+    def batch_end(self, n_samples, gathered_t, counts_t, slot: int = 0):
+        self.local.batch_finish(n_samples, gathered_t, self.world, counts_t[0], counts_t[1], counts_t[2], slot)
         return counts_t
 
     def run_batch(self, samples, counts_t=None):
@@ -748,3 +767,131 @@ class HashRangeRefDB:
 
     def close(self):
         self.local.close()
+
+
+# ======================================================================================================
+# The result path of the batched hash-range run: compact rows instead of dense [3, B, N] shares
+# ======================================================================================================
+# north_star: "only a final RCCL gather of per-reference overlap counts".  A block of B samples leaves every rank with
+# three dense [B, N] shares, almost all zero (a 10^6-hash sample overlaps a few hundred of 85 205 references): summing
+# them as they are moves 3 * B * N * 4 bytes per rank and block (65.4 MB at B = 64, rs214 scale) -- more than the
+# rank's compute for the block takes.  After the second half every rank knows the GLOBAL subset (the OR of the gathered
+# words), so every rank has the SAME entries -- one per set bit s of word r, in (r, s) order -- and only the values
+# differ: a rank packs its (overlap, n_excl, n_match) share per entry (yh_run_batch_rows_pack_device), ONE sum-reduce of
+# the first `cap` value triples (12 bytes per entry: no keys on the wire) gives the totals, and the consumer unpacks the
+# rows (sample, ref, overlap, n_excl, n_match).  `cap` -- the size of the collective -- must be the same on every rank
+# and known on the host before the collective is queued, while the number of entries is only known on the device: the
+# collective of a block takes the current cap; when the block's entry count (the same number on every rank, read back
+# behind the block -- finish() -- at the same point of the program on every rank) exceeds it, all ranks fall back to
+# the dense reduce for THAT block (its dense shares are still in place) and raise the cap for the following ones.
+class BatchRowsReducer:
+    """Sum of the ranks' shares of a batch, as compact rows.  One object per HashRangeRefDB; `nbuf` blocks in flight.
+
+    send(b, n_samples, counts_t, slot)   behind hr.batch_end(.., slot): pack + ONE reduce of cap * 12 bytes (asynchronous
+                                         on RCCL)
+    finish(b) -> (rows, dense)           rows: [n, 5] int32 tensor (sample, ref, overlap, n_excl, n_match) on `dst` (on
+                                         every rank when dst is None), None elsewhere; dense: the summed [3, B, N] block
+                                         instead, when the block had more entries than the collective carried
+    Call finish(b) before the batch slot and the counts of block b are used again."""
+
+    def __init__(self, hr: "HashRangeRefDB", batch: int, dst: Optional[int] = 0, nbuf: int = 3, cap_rows: Optional[int] = None):
+        import torch
+
+        self.hr, self.dst, self.nbuf = hr, dst, int(nbuf)
+        self.B = int(batch)
+        self.cap = int(cap_rows) if cap_rows else min(512 * self.B, self.B * hr.n_total)  # (B * N entries at most)
+        self.dev = hr.dev
+        self._alloc = 0
+        self.vals = [None] * self.nbuf
+        self.rows = None
+        self.nrows_dev = [torch.zeros(1, dtype=torch.int32, device=self.dev) for _ in range(self.nbuf)]
+        pin = self.dev.type == "cuda"
+        self.nrows_host = [torch.zeros(1, dtype=torch.int32).pin_memory() if pin else torch.zeros(1, dtype=torch.int32)
+                           for _ in range(self.nbuf)]
+        self.ev = [torch.cuda.Event() if pin else None for _ in range(self.nbuf)]
+        self.state = [None] * self.nbuf  # (n_samples, counts_t, slot, cap used, pending work)
+        self.bytes_sent = 0       # what this rank put into the result collectives so far
+        self.bytes_dense = 0      # ... what the dense form would have been
+        self.n_overflow = 0
+        self._grow()
+
+    def _grow(self):
+        import torch
+
+        if self._alloc >= self.cap:
+            return
+        self._alloc = self.cap
+        for b in range(self.nbuf):
+            if self.state[b] is None:
+                self.vals[b] = torch.zeros((self._alloc, 3), dtype=torch.int32, device=self.dev)
+        self.rows = torch.zeros((self._alloc, 5), dtype=torch.int32, device=self.dev)
+        self._nrows_unpack = torch.zeros(1, dtype=torch.int32, device=self.dev)
+
+    def _is_dst(self) -> bool:
+        return self.dst is None or self.hr.rank == self.dst
+
+    def send(self, b: int, n_samples: int, counts_t, slot: int = 0):
+        import torch.distributed as dist
+
+        hr = self.hr
+        assert self.state[b] is None, "finish(b) first"
+        if self.vals[b] is None or self.vals[b].shape[0] < self.cap:
+            self._grow()
+            import torch
+
+            self.vals[b] = torch.zeros((self._alloc, 3), dtype=torch.int32, device=self.dev)
+        cap = self.cap
+        vals = self.vals[b][:cap]
+        hr.local.rows_pack(counts_t, vals, self.nrows_dev[b], slot)
+        self.nrows_host[b].copy_(self.nrows_dev[b], non_blocking=True)
+        if self.ev[b] is not None:
+            self.ev[b].record()
+        work = None
+        if hr.has_exchange:
+            if vals.is_cuda and not _is_gloo(hr.group):
+                work = (dist.all_reduce(vals, op=dist.ReduceOp.SUM, group=hr.group, async_op=True) if self.dst is None else
+                        dist.reduce(vals, dst=self.dst, op=dist.ReduceOp.SUM, group=hr.group, async_op=True))
+            else:
+                c = _stage(vals, hr.group).contiguous()
+                if self.dst is None:
+                    dist.all_reduce(c, op=dist.ReduceOp.SUM, group=hr.group)
+                else:
+                    dist.reduce(c, dst=self.dst, op=dist.ReduceOp.SUM, group=hr.group)
+                vals.copy_(c)
+        self.bytes_sent += cap * 12
+        self.bytes_dense += 3 * n_samples * hr.n_total * 4
+        self.state[b] = (n_samples, counts_t, slot, cap, work)
+
+    def finish(self, b: int):
+        n_samples, counts_t, slot, cap, work = self.state[b]
+        self.state[b] = None
+        if work is not None:
+            work.wait()
+        if self.ev[b] is not None:
+            self.ev[b].synchronize()
+        n = int(self.nrows_host[b].item())  # (the same number on every rank: the global subset's size)
+        self.last_n_rows = n
+        if n > cap:  # the collective was too small for this block: its dense shares are still there -- all ranks take this branch
+            self.n_overflow += 1
+            self.cap = min(((n + n // 4 + 4095) // 4096) * 4096, max(self.B * self.hr.n_total, n))
+            dense = self.hr.reduce(counts_t, dst=self.dst)
+            self.bytes_sent += 3 * n_samples * self.hr.n_total * 4
+            return None, (dense if self._is_dst() else None)
+        if not self._is_dst():
+            return None, None
+        if self.rows.shape[0] < cap:
+            self._grow()
+        self.hr.local.rows_unpack(self.vals[b][:cap], self.rows[:cap], self._nrows_unpack, slot)
+        return self.rows[:n], None
+
+    @staticmethod
+    def rows_to_dense(rows_t, n_samples: int, n_refs: int):
+        """[3, B, N] int32 from the compact rows (tests, parity checks)."""
+        import torch
+
+        out = torch.zeros((3, n_samples, n_refs), dtype=torch.int32, device=rows_t.device)
+        if rows_t.shape[0]:
+            s_, r_ = rows_t[:, 0].long(), rows_t[:, 1].long()
+            for k in range(3):
+                out[k, s_, r_] = rows_t[:, 2 + k]
+        return out

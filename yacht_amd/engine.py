@@ -17,7 +17,7 @@ from typing import Optional, Sequence, Tuple
 import numpy as np
 
 from . import _lib
-from ._lib import (YH_DB_DEFAULT, YH_DB_FULL_INDEX, YH_DB_KEEP_CSR, YH_DB_NO_DIRECTORY, YH_DB_NO_INDEX,  # noqa: F401
+from ._lib import (YH_DB_DEFAULT, YH_DB_KEEP_CSR, YH_DB_NO_DIRECTORY, YH_DB_NO_INDEX,  # noqa: F401
                    YH_DB_PAIRWISE_ONLY,
                    YachtHipError)
 
@@ -36,6 +36,9 @@ def pack_csr(sketches: Sequence[np.ndarray]) -> Tuple[np.ndarray, np.ndarray]:
 
 # one row of the compact result of a run step: a reference with overlap > 0 and its three counts (yh_run_row)
 ROW_DTYPE = np.dtype([("ref", np.uint32), ("overlap", np.uint32), ("n_excl", np.uint32), ("n_match", np.uint32)])
+# one row of the compact result of a BATCH (yh_batch_row): which sample, which reference, the three counts
+BATCH_ROW_DTYPE = np.dtype([("sample", np.uint32), ("ref", np.uint32), ("overlap", np.uint32), ("n_excl", np.uint32),
+                            ("n_match", np.uint32)])
 
 
 def pack_sample(sample, out: Optional[np.ndarray] = None) -> np.ndarray:
@@ -75,7 +78,7 @@ def _ptr(a: Optional[np.ndarray]) -> C.c_void_p:
 class RefDB:
     """Reference sketches in HBM: delta stream, bucket table + presence filter, shared-hash inverted index."""
 
-    def __init__(self, values, offsets, device: int = 0, flags: int = YH_DB_DEFAULT, partitions_hint: int = 0):
+    def __init__(self, values, offsets, device: int = 0, flags: int = YH_DB_DEFAULT):
         self._h = C.c_void_p(0)
         lib = _lib.load()
         values = _as_u64(values)
@@ -85,8 +88,7 @@ class RefDB:
         if int(offsets[-1]) != values.size:
             raise ValueError("offsets[-1] must equal len(values)")
         h = C.c_void_p(0)
-        _lib.check(lib.yh_db_create(_ptr(values), _ptr(offsets), offsets.size - 1, device, flags, partitions_hint,
-                                    C.byref(h)))
+        _lib.check(lib.yh_db_create(_ptr(values), _ptr(offsets), offsets.size - 1, device, flags, C.byref(h)))
         self._h = h
         self._lib = lib
         self.n_refs = offsets.size - 1
@@ -99,14 +101,13 @@ class RefDB:
 
     @classmethod
     def from_device(cls, d_values: int, d_offsets: int, n_refs: int, sizes: Optional[np.ndarray] = None,
-                    device: int = 0, flags: int = YH_DB_DEFAULT, partitions_hint: int = 0) -> "RefDB":
+                    device: int = 0, flags: int = YH_DB_DEFAULT) -> "RefDB":
         """Build from CSR arrays that already live in this device's HBM (raw device addresses)."""
         self = cls.__new__(cls)
         self._h = C.c_void_p(0)
         lib = _lib.load()
         h = C.c_void_p(0)
-        _lib.check(lib.yh_db_create_device(C.c_void_p(d_values), C.c_void_p(d_offsets), n_refs, device, flags,
-                                           partitions_hint, C.byref(h)))
+        _lib.check(lib.yh_db_create_device(C.c_void_p(d_values), C.c_void_p(d_offsets), n_refs, device, flags, C.byref(h)))
         self._h = h
         self._lib = lib
         self.n_refs = n_refs
@@ -215,14 +216,26 @@ class RefDB:
                                                         C.c_void_p(d_excl)))
 
     def run_batch_local_range_device(self, d_samples: int, d_offsets: int, n_samples: int, total_hashes: int, d_overlap: int,
-                                     d_maskwords_out: int) -> None:
-        _lib.check(self._lib.yh_run_batch_local_range_device(self._h, C.c_void_p(d_samples), C.c_void_p(d_offsets), n_samples,
+                                     d_maskwords_out: int, slot: int = 0) -> None:
+        _lib.check(self._lib.yh_run_batch_local_range_device(self._h, slot, C.c_void_p(d_samples), C.c_void_p(d_offsets), n_samples,
                                                              total_hashes, C.c_void_p(d_overlap), C.c_void_p(d_maskwords_out)))
 
     def run_batch_finish_range_device(self, n_samples: int, d_gathered: int, n_ranks: int, d_overlap: int, d_excl: int,
-                                      d_match: int) -> None:
-        _lib.check(self._lib.yh_run_batch_finish_range_device(self._h, n_samples, C.c_void_p(d_gathered), n_ranks,
+                                      d_match: int, slot: int = 0) -> None:
+        _lib.check(self._lib.yh_run_batch_finish_range_device(self._h, slot, n_samples, C.c_void_p(d_gathered), n_ranks,
                                                               C.c_void_p(d_overlap), C.c_void_p(d_excl), C.c_void_p(d_match)))
+
+    # the compact form of a batch's result: one entry per (reference, sample) of the batch's subset, in (reference, sample) order
+    def run_batch_rows_pack_device(self, d_overlap: int, d_excl: int, d_match: int, d_vals: int, cap_rows: int, d_n_rows: int,
+                                   slot: int = 0) -> None:
+        """d_vals [cap_rows][3] uint32 = this handle's (overlap, n_excl, n_match) of every entry; d_n_rows: their number."""
+        _lib.check(self._lib.yh_run_batch_rows_pack_device(self._h, slot, C.c_void_p(d_overlap), C.c_void_p(d_excl), C.c_void_p(d_match),
+                                                           C.c_void_p(d_vals), cap_rows, C.c_void_p(d_n_rows)))
+
+    def run_batch_rows_unpack_device(self, d_vals: int, cap_rows: int, d_rows: int, d_n_rows: int, slot: int = 0) -> None:
+        """d_rows [cap_rows] BATCH_ROW_DTYPE = (sample, ref, overlap, n_excl, n_match) from (summed) values."""
+        _lib.check(self._lib.yh_run_batch_rows_unpack_device(self._h, slot, C.c_void_p(d_vals), cap_rows, C.c_void_p(d_rows),
+                                                             C.c_void_p(d_n_rows)))
 
     def run_submit(self, slot: int, sample: np.ndarray, overlap: np.ndarray, n_excl: np.ndarray,
                    n_match: np.ndarray) -> None:
@@ -278,7 +291,7 @@ class RefDB:
                                                 C.c_void_p(d_rows), cap_rows, C.c_void_p(d_n_rows)))
 
     def run_batch(self, samples: Sequence[np.ndarray]) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
-        """run_counts for up to 64 samples in one pass (needs YH_DB_FULL_INDEX): three uint32
+        """run_counts for up to 64 samples in one pass (needs the directory: not YH_DB_NO_DIRECTORY): three uint32
         arrays of shape [len(samples), n_refs]."""
         values, offsets = pack_csr(samples)
         b = len(samples)

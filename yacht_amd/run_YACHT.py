@@ -4,7 +4,7 @@ Same arguments, checks, coverage-list handling and result layout as the referenc
 src/yacht/run_YACHT.py (:24-254): `results/result_all.txt` (tab-separated, every user coverage,
 unfiltered) and one table per coverage named `min_coverage{c}` (only organisms with
 in_sample_est unless --show_all), plus `raw_result` with --keep_raw.  The tables go to
-`results/result.xlsx` when openpyxl is importable, and always to `results/sheets/<name>.tsv`.
+`results/result.xlsx` (yacht_amd.xlsx: no openpyxl needed) and to `results/sheets/<name>.tsv`.
 Kept on purpose: the reference fills the column "num_exclusive_kmers_in_sample_sketch" with the
 sample's MEAN ABUNDANCE (run_YACHT.py:159) — downstream tools read it that way.
 """
@@ -74,18 +74,16 @@ def coverage_plan(min_coverage_list):
 
 
 def write_tables(tables, results_folder: str) -> None:
+    """`results/result.xlsx` -- one sheet per table, the reference's sheet names (run_YACHT.py:231-254) -- written by
+    yacht_amd.xlsx (zipfile + XML: no openpyxl needed to WRITE; `pd.read_excel` reads it where openpyxl exists,
+    yacht_amd.xlsx.read_xlsx anywhere), and the same tables as `results/sheets/<name>.tsv`."""
+    from . import xlsx
+
     sheets = os.path.join(results_folder, "sheets")
     os.makedirs(sheets, exist_ok=True)
     for name, df in tables:
         df.to_csv(os.path.join(sheets, f"{name}.tsv"), sep="\t", index=False)
-    try:
-        import openpyxl  # noqa: F401
-    except ImportError:
-        logger.warning("openpyxl is not installed: result.xlsx not written, tables are in results/sheets/*.tsv")
-        return
-    with pd.ExcelWriter(os.path.join(results_folder, "result.xlsx"), engine="openpyxl", mode="w") as w:
-        for name, df in tables:
-            df.to_excel(w, sheet_name=name, index=False)
+    xlsx.write_xlsx(os.path.join(results_folder, "result.xlsx"), tables)
 
 
 def main(args) -> None:
