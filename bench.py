@@ -34,6 +34,7 @@ Rank 0 prints ONE JSON line (contract in the task statement).  Beside the contra
 from __future__ import annotations
 
 import argparse
+import math
 import hashlib
 import json
 import os
@@ -90,6 +91,14 @@ def parse_args():
     ap.add_argument("--batch-samples", type=int, default=64, help="samples per yh_run_batch_device call of the `batched` leg (<= 64)")
     ap.add_argument("--host-depth", type=int, default=4, help="host-inclusive leg: calls in flight (1..4)")
     ap.add_argument("--percentile-steps", type=int, default=200)
+    ap.add_argument("--dense-reduce", action="store_true",
+                    help="N>1, --block-mode batched: sum the dense [3, B, N] shares of a block (round 3's result path: 65 MB per rank "
+                         "and block at rs214 scale) instead of its compact rows")
+    ap.add_argument("--min-timed-steps", type=int, default=2000,
+                    help="the timed loop runs max(--steps, this) steps, and more until it lasts --min-timed-ms (SURVEY.md 8d: >= 1000 "
+                         "iterations on launch-bound configurations; 20 steps are 0.75 ms of timed region)")
+    ap.add_argument("--min-timed-ms", type=float, default=50.0)
+    ap.add_argument("--pack-threads", default="2,4,8,16,24,32", help="host-inclusive leg with yh_sample_pack INSIDE the step: packing threads to try")
     ap.add_argument("--sync-gather", action="store_true", help="N>1: blocking gather of the count rows inside every step")
     ap.add_argument("--count-gather", choices=("root", "all"), default="root",
                     help="N>1 over RCCL: the count rows of a block go to rank 0 (where results are consumed; default) or to every rank")
@@ -357,32 +366,63 @@ def main() -> int:
         else:
             finish_block(blk, i0, n_in)
 
-    # --block-mode batched: block j = samples [j * BB, (j + 1) * BB) mod K in one pass of the batched kernels; its three
-    # count rows [3, BB, N] are this rank's shares and leave in one reduce (sum) to rank 0
+    # --block-mode batched: block j = samples [j * BB, (j + 1) * BB) mod K in one pass of the batched kernels.  Three blocks
+    # rotate through three batch slots of the library: while the subset words of block j travel (ONE all-gather of N * 8
+    # bytes per rank), the second half of block j - 1 runs, and its result leaves as COMPACT ROWS (dist.BatchRowsReducer:
+    # one sum-reduce of cap * 12 bytes to rank 0 -- north_star's "final gather of the per-reference counts"; round 3 summed
+    # the dense [3, BB, N] shares: 65 MB per rank and block); block j - 3's row count is read back before its slot is reused.
+    NB3 = 3
+    rowsx = None
     if hash_batched:
-        bcounts = [torch.zeros((3, BB, n_total), device=dev, dtype=torch.int32) for _ in range(NBUF)]
-        bwords = torch.zeros(n_total, device=dev, dtype=torch.int64)
-        bgath = torch.zeros((world, n_total), device=dev, dtype=torch.int64)
+        bcounts = [torch.zeros((3, BB, n_total), device=dev, dtype=torch.int32) for _ in range(NB3)]
+        bwords = [torch.zeros(n_total, device=dev, dtype=torch.int64) for _ in range(NB3)]
+        bgath = [torch.zeros((world, n_total), device=dev, dtype=torch.int64) for _ in range(NB3)]
         packed_blocks = {}
-        bpending = [None] * NBUF
+        bpending = [None] * NB3   # --dense-reduce: the reduce that reads the buffer
+        inflight = [None] * NB3   # (j, n_in): result on its way
+        state["prev"] = None      # (j, n_in, work): first half queued, words travelling
+        if not args.dense_reduce:
+            rowsx = ydist.BatchRowsReducer(sdb, batch=BB, dst=0, nbuf=NB3)
+
+        def second_half(j, n_in, w):
+            b = j % NB3
+            if w is not None:
+                w.wait()
+            sdb.batch_end(n_in, bgath[b], bcounts[b], slot=b)
+            if rowsx is not None:
+                rowsx.send(b, n_in, bcounts[b], slot=b)
+            elif staged_gather:
+                bcounts[b].copy_(sdb.reduce(bcounts[b], dst=0))
+            else:
+                bpending[b] = dist.reduce(bcounts[b], dst=0, op=dist.ReduceOp.SUM, async_op=True)
+            inflight[b] = (j, n_in)
+
+        def finish_block(b):
+            if inflight[b] is None:
+                return
+            j, n_in = inflight[b]
+            inflight[b] = None
+            if rowsx is not None:
+                rows, dense = rowsx.finish(b)  # (rows: a view that lasts until the next finish)
+                state["last_result"] = (j, n_in, rows, dense)
+            else:
+                if bpending[b] is not None:
+                    bpending[b].wait()
+                    bpending[b] = None
+                state["last_result"] = (j, n_in, None, bcounts[b])
 
         def run_block(j, n_in):
-            state["last_block"] = (j, n_in)
+            b = j % NB3
+            finish_block(b)  # block j - 3: its slot, its counts and its value buffer are free again
             key = (j * BB) % K
             if (key, n_in) not in packed_blocks:  # (resident samples: their slices are concatenated once)
                 packed_blocks[(key, n_in)] = sdb.pack_batch([samples[(key + t) % K] for t in range(n_in)],
                                                              spans=[spans[(key + t) % K] for t in range(n_in)])
-            b = j % NBUF
-            if bpending[b] is not None:  # the reduce that read this buffer two blocks ago
-                bpending[b].wait()
-                bpending[b] = None
-            sdb.batch_begin(packed_blocks[(key, n_in)], bcounts[b], bwords)
-            w = sdb.batch_exchange(bwords, bgath, async_op=False)
-            sdb.batch_end(n_in, bgath, bcounts[b])
-            if staged_gather:
-                bcounts[b].copy_(sdb.reduce(bcounts[b], dst=0))
-            else:
-                bpending[b] = dist.reduce(bcounts[b], dst=0, op=dist.ReduceOp.SUM, async_op=True)
+            sdb.batch_begin(packed_blocks[(key, n_in)], bcounts[b], bwords[b], slot=b)
+            w = sdb.batch_exchange(bwords[b], bgath[b], async_op=not staged_gather and not args.sync_gather)
+            if state["prev"] is not None:  # ... and behind this block's first half: the second half of the previous one
+                second_half(*state["prev"])
+            state["prev"] = (j, n_in, w)
 
     def step():
         i = state["i"]
@@ -414,10 +454,11 @@ def main() -> int:
             if i % BB != 0:  # a partly filled block at the end of a loop
                 run_block(i // BB, i % BB)
                 state["i"] += BB - i % BB
-            for b in range(NBUF):
-                if bpending[b] is not None:
-                    bpending[b].wait()
-                    bpending[b] = None
+            if state["prev"] is not None:
+                second_half(*state["prev"])
+                state["prev"] = None
+            for b in sorted(range(NB3), key=lambda q: inflight[q][0] if inflight[q] is not None else -1):
+                finish_block(b)  # (oldest block first: the same order on every rank)
             return
         if multi and i % GB != 0:  # a partly filled block at the end of a loop leaves too
             close_block((i // GB) % NBUF, i - i % GB, i % GB)
@@ -442,8 +483,26 @@ def main() -> int:
     drain()
     fence()
     db.timing()  # drop the warm-up launches from the kernel-duration ring
+    # How many steps the timed region holds: --steps as the driver passes it is a handful (20 steps = 0.75 ms of timed region:
+    # +-7 % from run to run), so the loop runs max(--steps, --min-timed-steps) steps -- and, should that still be shorter
+    # than --min-timed-ms, as many as a short calibration pass says it takes (the same number on every rank).
+    n_timed = max(args.steps, args.min_timed_steps)
+    n_cal = max(min(n_timed, 256), BB if hash_batched else 1)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(n_cal):
+        step()
+    drain()
+    fence()
+    cal = torch.tensor([(time.perf_counter() - t0) / n_cal], device=dev, dtype=torch.float64)
+    if multi:
+        cal = ydist._stage(cal, None)
+        dist.all_reduce(cal, op=dist.ReduceOp.MAX)
+    n_timed = max(n_timed, int(math.ceil(args.min_timed_ms * 1e-3 / max(float(cal.item()), 1e-9))))
+    if hash_batched:
+        n_timed = ((n_timed + BB - 1) // BB) * BB  # whole blocks
+    db.timing()
+    t0 = time.perf_counter()
+    for _ in range(n_timed):
         step()
     t_issued = time.perf_counter() - t0  # host time to QUEUE the steps (no waiting): host-bound when it equals `elapsed`
     drain()
@@ -453,8 +512,8 @@ def main() -> int:
         t = ydist._stage(torch.tensor([elapsed], device=dev, dtype=torch.float64), None)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    ms_per_step = 1e3 * elapsed / args.steps
-    value = n_total / (elapsed / args.steps)
+    ms_per_step = 1e3 * elapsed / n_timed
+    value = n_total / (elapsed / n_timed)
 
     # ---- per-step percentiles: a separate pass with one HIP event between steps -------------------------
     n_pct = max(args.percentile_steps, args.steps)
@@ -483,9 +542,9 @@ def main() -> int:
                 results.append(sdb.gather(c))
     torch.cuda.synchronize()
     blocks_ok = None
-    if hash_batched and rank == 0:  # the timed loop's own outputs: the sums of its last block are on rank 0
-        jl, n_last = state["last_block"]
-        got = bcounts[jl % NBUF]
+    if hash_batched and rank == 0:  # the timed loop's own outputs: the totals of the block finished last are on rank 0
+        jl, n_last, rows_l, dense_l = state["last_result"]
+        got = dense_l if rows_l is None else ydist.BatchRowsReducer.rows_to_dense(rows_l, n_last, n_total)
         blocks_ok = all(bool(torch.equal(got[:, t, :], results[((jl * BB) % K + t) % K])) for t in range(n_last))
     pipelined_ok = None
     if sdb is None and args.pipelined_tail:  # the timed loop's own (pipelined) outputs: its last two steps are still in the buffers
@@ -620,13 +679,52 @@ def main() -> int:
 
         leg_packed = host_leg(submit_packed, wait_rows, check_rows)
         leg_raw = host_leg(submit_raw, db.run_wait, check_dense)
+        # the packed form with yh_sample_pack INSIDE the step: T host threads pack the samples to come into a ring of
+        # page-locked buffers (the C call releases the GIL) while the main thread submits and waits as before -- which T
+        # keeps the step where the pre-packed form has it?  (One core packs a 1e6-hash sample in ~0.7 ms.)
+        from concurrent.futures import ThreadPoolExecutor
+
+        pack_legs = {}
+        bound = int(ylib.load().yh_sample_pack_bound(int(max(int(s_.numel()) for s_ in samples))))
+        for T in [int(x) for x in str(args.pack_threads).split(",") if x.strip()]:
+            LOOK = 2 * T + 2
+            R = DEPTH + LOOK + 1
+            ring = [PinnedArray(bound, np.uint8) for _ in range(R)]
+            used = [None] * R
+            n_host = max(args.steps, args.percentile_steps)
+            n_all = max(args.warmup, 2 * K) + n_host
+            with ThreadPoolExecutor(max_workers=T) as pool:
+                def job(j):
+                    used[j % R] = pack_sample(h_samples[j % K].array, out=ring[j % R].array, threads=1)  # (one core per sample)
+                futs = {j: pool.submit(job, j) for j in range(min(LOOK, n_all))}
+                t0 = None
+                for i in range(n_all + DEPTH):
+                    slot = i % DEPTH
+                    if i == n_all - n_host:
+                        t0 = time.perf_counter()
+                    if i >= DEPTH:
+                        wait_rows(slot)
+                    if i + LOOK < n_all:  # (its ring buffer belonged to call i + LOOK - R = i - DEPTH - 1: waited for above)
+                        futs[i + LOOK] = pool.submit(job, i + LOOK)
+                    if i < n_all:
+                        futs.pop(i).result()
+                        db.run_submit_packed(slot, used[i % R], h_rows[slot].array)
+                el = time.perf_counter() - t0
+            ok = all(check_rows(i % DEPTH, i % K) for i in range(n_all - DEPTH, n_all))
+            pack_legs[str(T)] = {"ms_per_step": round(1e3 * el / n_host, 4), "equals_device_resident": bool(ok)}
+            for pa in ring:
+                pa.close()
         packed_bytes = int(np.mean([int(u.size) for _, u in h_packed]))
         rows_per_step = int(np.mean([int((r[0] != 0).sum().item()) for r in results]))
         leg_packed.update(h2d_bytes_per_step=packed_bytes, d2h_bytes_per_step=16 * rows_per_step + 4,
                           h2d_GBps=round(packed_bytes / (leg_packed["ms_per_step"] / 1e3) / 1e9, 1),
                           bytes_per_sample_hash=round(packed_bytes / max(n_sample, 1), 3),
                           pack_ms_per_sample_on_host=round(float(np.median(pack_ms)), 3),
-                          pack_note="yh_sample_pack runs once per sample where the sketch is parsed (not inside the step)")
+                          pack_note="yh_sample_pack runs once per sample where the sketch is parsed (not inside the step); "
+                                    "pack_inside_the_step: the same leg with T host threads packing inside the timed loop",
+                          pack_inside_the_step=pack_legs,
+                          pack_threads_to_keep_the_step=next((int(t_) for t_, v_ in sorted(pack_legs.items(), key=lambda kv: int(kv[0]))
+                                                              if v_["ms_per_step"] <= 1.1 * leg_packed["ms_per_step"]), None))
         leg_raw.update(h2d_bytes_per_step=8 * n_sample, d2h_bytes_per_step=12 * n_local,
                        h2d_GBps=round(8 * n_sample / (leg_raw["ms_per_step"] / 1e3) / 1e9, 1))
         # latency of ONE synchronous host-pointer call (what the CLI pays per sample)
@@ -636,7 +734,8 @@ def main() -> int:
             db.run_counts(h_samples[i % K].array)
             lat.append((time.perf_counter() - t1) * 1e3)
         host_inclusive = dict(leg_packed, form="packed_rows", pipeline_depth=DEPTH, raw_dense=leg_raw,
-                              equals_device_resident=bool(leg_packed["equals_device_resident"] and leg_raw["equals_device_resident"]),
+                              equals_device_resident=bool(leg_packed["equals_device_resident"] and leg_raw["equals_device_resident"]
+                                                          and all(v_["equals_device_resident"] for v_ in pack_legs.values())),
                               sync_call_ms_median=round(pct(lat[5:], 50), 4),
                               how="page-locked host buffers; per step: sample H2D on a copy stream -> expansion / ordering "
                                   "check + kernels -> result D2H written by the step's own kernels (yh_run_submit_packed / "
@@ -670,8 +769,9 @@ def main() -> int:
         fence_real()
         db.timing()
         ev2 = [torch.cuda.Event(enable_timing=True) for _ in range(n_pct + 1)]
+        n_real = max(args.steps, args.min_timed_steps)  # (a 20-step loop is 0.3 ms: anything the host does is in it)
         t0 = time.perf_counter()
-        for i in range(args.steps):
+        for i in range(n_real):
             step_real(i)
         fence_real()
         el = time.perf_counter() - t0
@@ -704,7 +804,7 @@ def main() -> int:
         real_shape = dict(stats_ms([ev2[k].elapsed_time(ev2[k + 1]) for k in range(n_pct)]),
                           default_lookup="indexed" if db.lookup_choice(int(real_samples[0].numel())) == ylib.YH_LOOKUP_INDEXED else "stream",
                           forced_ms_per_step=forced,
-                          ms_per_step=round(1e3 * el / args.steps, 4), value=round(n_local / (el / args.steps), 1),
+                          ms_per_step=round(1e3 * el / n_real, 4), value=round(n_local / (el / n_real), 1), steps_timed=n_real,
                           unit="queries/s", sample_hashes=int(real_samples[0].numel()),
                           refs_overlapping=int((real_counts0[0] != 0).sum().item()),
                           lookup_kernel_ms_avg=round(float(tm["ms_overlap_kernel"]), 4),
@@ -793,11 +893,15 @@ def main() -> int:
             wb = torch.zeros(n_local, device=dev, dtype=torch.int64)
             gb = torch.zeros((1, n_local), device=dev, dtype=torch.int64)
 
+            vb = torch.zeros((BM * 2048, 3), device=dev, dtype=torch.int32)
+            nb_rows = torch.zeros(1, device=dev, dtype=torch.int32)
+
             def batch_g():
                 with torch.cuda.stream(stream):
                     hr.batch_begin(packed_b, cb, wb)
                     hr.batch_exchange(wb, gb)
                     hr.batch_end(BM, gb, cb)
+                    hr.local.rows_pack(cb, vb, nb_rows, 0)  # (the result leaves as compact rows: their packing is part of the block)
 
             for _ in range(2):
                 batch_g()
@@ -808,27 +912,65 @@ def main() -> int:
                 batch_g()
             fence()
             el_b = (time.perf_counter() - t0) / nb_
-            del bsamp, packed_b, cb, wb, gb
+            rows_in_block = int(nb_rows.item())
+            del bsamp, packed_b, cb, wb, gb, vb
             a_, b_ = spans_g[0]
             per_g[str(G)] = {"rank0_compute_ms_per_step": round(1e3 * el, 4), "sample_hashes_in_range": int(b_ - a_),
-                             "batched_rank0_ms_per_sample": round(1e3 * el_b / BM, 4), "samples_per_block": BM,
+                             "batched_rank0_ms_per_sample": round(1e3 * el_b / BM, 4), "batched_rank0_ms_per_block": round(1e3 * el_b, 4),
+                             "samples_per_block": BM, "rows_in_block": rows_in_block,
                              "ref_hashes_in_range": int(v_g.numel()),
                              "lookup_choice": "indexed" if hr.local.handle.lookup_choice(int(b_ - a_)) == ylib.YH_LOOKUP_INDEXED else "stream"}
             hr.close()
             del v_g, o_g, cg, hr
-        coll = 0.010  # ms per step: round 2's forced-exchange measurement of the N > 1 code path with one rank (0.0534 - 0.0438)
+        # The collectives of a block, from their BYTES (nothing here is measured: this box has one GPU).  Stated constants:
+        #   link   64 GB/s per direction and xGMI link (7 links x ~153 GB/s bidirectional per GPU, ~83 % of the wire rate as payload)
+        #   lat    30 us per collective (RCCL launch, synchronisation and the first hop of a small message between 8 ranks)
+        # On the fully connected xGMI mesh a rank reaches each peer over a link of its own: an all-gather moves the rank's
+        # message once per link (`direct`); a ring moves (G - 1) messages over one link (`ring`, the pessimistic bound).
+        LINK_GBPS, LAT_MS = 64.0, 0.030
+        words_bytes = 8 * n_local                      # all-gather of the block's subset words: one uint64 per reference and rank
+        cap_rows = min(512 * BM, BM * n_local)         # dist.BatchRowsReducer's collective: cap x (overlap, n_excl, n_match)
+        rows_bytes = 12 * cap_rows
+        dense_bytes = 3 * BM * n_local * 4             # round 3's result path: the dense shares
+        def t_coll(nbytes, G, ring):
+            return LAT_MS + (nbytes * ((G - 1) if ring else 1)) / (LINK_GBPS * 1e9) * 1e3
+        model = {}
+        for g, v in per_g.items():
+            G = int(g)
+            comp = v["batched_rank0_ms_per_block"]
+            c_dir = t_coll(words_bytes, G, False) + t_coll(rows_bytes, G, False)
+            c_ring = t_coll(words_bytes, G, True) + t_coll(rows_bytes, G, True)
+            c_dense_ring = t_coll(words_bytes, G, True) + t_coll(dense_bytes, G, True)
+            model[g] = {
+                "compute_ms_per_block": comp,
+                "collectives_ms_per_block_direct": round(c_dir, 4), "collectives_ms_per_block_ring": round(c_ring, 4),
+                "collectives_ms_per_block_dense_rows_ring": round(c_dense_ring, 4),
+                # three blocks in flight: the words of block j travel under the second half of block j - 1, the rows of block
+                # j - 1 under the first half of block j + 1 -- a block costs the longer of its compute and its collectives;
+                # `serial` = nothing overlaps (the pessimistic bound)
+                "ms_per_sample_overlapped": round(max(comp, c_ring) / BM, 4),
+                "ms_per_sample_serial": round((comp + c_ring) / BM, 4),
+                "ms_per_sample_serial_dense_rows": round((comp + c_dense_ring) / BM, 4),
+                "speedup_vs_1gpu_single_steps_overlapped": round(ms_per_step / (max(comp, c_ring) / BM), 2),
+                "speedup_vs_1gpu_single_steps_serial": round(ms_per_step / ((comp + c_ring) / BM), 2),
+                "speedup_vs_1gpu_single_steps_serial_dense_rows": round(ms_per_step / ((comp + c_dense_ring) / BM), 2),
+            }
         scaling_model = {
             "per_G": per_g,
-            "collectives_ms_per_step_assumed": coll,
-            "predicted_ms_per_step": {g: round(v["rank0_compute_ms_per_step"] + coll, 4) for g, v in per_g.items()},
-            "predicted_speedup_vs_1gpu": {g: round(ms_per_step / (v["rank0_compute_ms_per_step"] + coll), 2) for g, v in per_g.items()},
-            # --block-mode batched (the N > 1 default): + one all-gather of N * 8 bytes per rank and one reduce of 3 * BM * N * 4
-            # bytes per block of BM samples, assumed at 0.06 ms per block on top (not overlapped)
-            "batched_predicted_ms_per_sample": {g: round(v["batched_rank0_ms_per_sample"] + 0.06 * (BM / 32) / BM, 4) for g, v in per_g.items()},
-            "batched_predicted_speedup_vs_1gpu_single_steps": {g: round(ms_per_step / (v["batched_rank0_ms_per_sample"] + 0.06 * (BM / 32) / BM), 2)
-                                                               for g, v in per_g.items()},
-            "how": "rank 0's hash range of the whole database built on THIS GPU, both halves of its step timed on its slice of the "
-                   "rotating samples (no collectives); + the assumed cost of the collectives (0.01 ms per sample-step; 0.06 ms per 32 samples of a batched block)",
+            "collective_bytes_per_block_and_rank": {
+                "subset_words_all_gather": words_bytes, "compact_rows_reduce": rows_bytes,
+                "compact_rows_capacity": cap_rows, "rows_in_a_block_measured": {g: v["rows_in_block"] for g, v in per_g.items()},
+                "dense_rows_reduce_round3": dense_bytes,
+            },
+            "assumed": {"xgmi_link_GBps_per_direction": LINK_GBPS, "collective_latency_ms": LAT_MS,
+                        "note": "bytes are exact; the link rate and the per-collective latency are stated constants, not measurements (1-GPU box)"},
+            "batched": model,
+            # the per-sample half-steps (--block-mode steps): four launches of latency per sample, one exchange per block of 8
+            "single_steps_predicted_ms_per_step": {g: round(v["rank0_compute_ms_per_step"] + (t_coll(8 * ((n_local + 255) // 256) * 32, int(g), True)
+                                                                                            + t_coll(8 * 3 * n_local * 4, int(g), True)) / 8, 4)
+                                                   for g, v in per_g.items()},
+            "how": "rank 0's hash range of the whole database built on THIS GPU; both halves of a block of samples_per_block distinct "
+                   "samples + the packing of its compact rows timed on its slice (no collectives); the collectives from their bytes",
         }
 
     # ---- roofline of the dominant kernel of the DEFAULT step --------------------------------------------
@@ -896,6 +1038,10 @@ def main() -> int:
         roofline["kernel_note"] = ("one launch per step: the lookup of this sample (the role the bytes are counted for: "
                                    "k_index_lookup_tile's body) + the reducer of the previous sample + the exclusive pass of the one before")
     roofline["default_lookup"] = "indexed" if default_choice == ylib.YH_LOOKUP_INDEXED else "stream"
+    # (scalar copies of the nested survey_formula block: parsers that keep only scalars keep these)
+    roofline["bytes_survey_formula"] = roofline["survey_formula"]["bytes_per_launch"]
+    roofline["GBps_survey_formula"] = roofline["survey_formula"]["GBps"]
+    roofline["frac_survey_formula"] = roofline["survey_formula"]["frac"]
     # What a HIP-event pair measures with NOTHING between its two records, on the busy stream of the step loop: the
     # part of `kernel_ms_avg` that is marker processing and dispatch, not kernel (rocprofv3's kernel durations in
     # profiles/ do not contain it).  `achieved` / `frac` stay on the raw interval: never flattered.
@@ -941,6 +1087,15 @@ def main() -> int:
                                                 "taken": tr.get("taken"), "commit": tr.get("commit")}
         except Exception:
             pass
+
+    # ---- the database built a second time in this process (its arrays now come out of the library's buffer cache) ----
+    db_rebuild_ms = None
+    if not multi and not args.no_scaling_model:
+        with torch.cuda.stream(stream):
+            db2 = RefDB.from_device(values.data_ptr(), offsets.data_ptr(), n_local, device=local_rank,
+                                    flags=YH_DB_NO_DIRECTORY if args.no_indexed else YH_DB_DEFAULT)
+        db_rebuild_ms = round(float(db2.timing()["ms_db_build"]), 2)
+        db2.close()
 
     # ---- CPU baseline + full-size parity (rank 0, the WHOLE database) -----------------------------------
     cpu_baseline = None
@@ -1050,7 +1205,10 @@ def main() -> int:
             # `value` above has the samples resident in HBM, as the bench contract asks
             "value_host_inclusive": (host_inclusive or {}).get("value"),
             "ms_per_step_host_inclusive": (host_inclusive or {}).get("ms_per_step"),
-            "host_issue_ms_per_step": round(1e3 * t_issued / args.steps, 4),
+            "host_issue_ms_per_step": round(1e3 * t_issued / n_timed, 4),
+            # the timed region itself: `steps` is what the caller asked for, `steps_timed` what the loop ran (see --min-timed-steps)
+            "steps_timed": n_timed,
+            "timed_region_s": round(elapsed, 6),
             "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None,
@@ -1070,6 +1228,10 @@ def main() -> int:
                 "filter_bytes": info.get("filter_bytes"),
                 "ghost_refs_rank0": (sdb.n_ghost if sdb is not None else 0),
                 "db_build_ms": round(float(timing["ms_db_build"]), 2),
+                "db_rebuild_ms": db_rebuild_ms,
+                "db_build_note": "device input; HIP events around validation + sort + index + tables, host stalls included: a hipMalloc of a "
+                                 "multi-GB block sporadically takes 0.7-4 s on this pool (profiles/r04/malloc_probe.txt, a plain HIP program) -- "
+                                 "round 3's 705-815 ms; db_rebuild_ms = the same build again with the arrays out of the library's buffer cache",
                 "db_hbm_bytes": info["device_bytes"],
                 "pipelined_tail": bool(not multi and args.pipelined_tail),
                 "step": "overlap + exclusive counts" + ((f" (blocks of {GB} samples: one all_gather of their subset bits" + (", two blocks in flight" if pipelined else "") + f") + one {'gather to rank 0' if to_root else 'all_gather'} of the count rows per {GB} samples"
@@ -1080,6 +1242,14 @@ def main() -> int:
                 "shard": ("hash" if by_hash else "refs") if multi else None,
                 "block_mode": (args.block_mode if by_hash else "steps") if multi else None,
                 "samples_per_block": (BB if hash_batched else GB) if multi else None,
+                "result_path": (("dense [3, B, N] shares summed" if rowsx is None else "compact rows: value triples summed (dist.BatchRowsReducer)")
+                                if hash_batched else None),
+                "collective_bytes_per_block_and_rank": ({"subset_words_all_gather": 8 * n_total,
+                                                         "result": (12 * rowsx.cap if rowsx is not None else 3 * BB * n_total * 4),
+                                                         "result_dense_form": 3 * BB * n_total * 4,
+                                                         "rows_in_last_block": getattr(rowsx, "last_n_rows", None) if rowsx is not None else None,
+                                                         "dense_fallbacks": rowsx.n_overflow if rowsx is not None else None}
+                                                        if hash_batched else None),
                 "scipy": scipy_version,
             },
             "roofline": roofline,

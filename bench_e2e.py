@@ -136,28 +136,34 @@ def main() -> int:
     del values, offsets
 
     lines = {}
-    # ---- yacht train -------------------------------------------------------------------------------------
-    out_dir = os.path.join(args.work, "out")
-    os.makedirs(out_dir)
-    phases.reset()
-    t0 = time.perf_counter()
-    rc = cli.main(["train", "--ref_file", ref_zip, "--ksize", "31", "--ani_thresh", "0.95", "--prefix", "db", "--outdir", out_dir,
-                   "--num_threads", str(args.threads), "--force"])
-    wall = time.perf_counter() - t0
-    ph = phases.snapshot()
-    top = {k: v for k, v in ph.items() if "/" not in k}
-    rss_self, rss_kids = peak_rss_gb()
-    n_kept = sum(1 for _ in open(os.path.join(out_dir, "db_processed_manifest.tsv"))) - 1
-    lines["train"] = {
-        "command": "yacht train (python -m yacht_amd train): zip -> manifest + packed DB",
-        "workload": f"{args.refs} synthetic sketches k=31 scaled=1000 (rs214 shape), sourmash-style zip of {zip_gb:.2f} GB",
-        "rc": rc, "wall_s": round(wall, 2), "phases_s": ph,
-        "slowest_phase": max(top, key=top.get) if top else None,
-        "unaccounted_s": round(wall - sum(top.values()), 2),
-        "references_kept": n_kept, "threads": args.threads,
-        "peak_rss_gb": {"process": rss_self, "largest_pool_worker": rss_kids},
-        "reference_published": "README.md:276: 85 205 GTDB genomes, ~12 minutes, 52 GB (whole command, CPU)",
-    }
+    # ---- yacht train: the default (one native pass over the archive, the unzipped .sig files left behind as the reference
+    # leaves them), the same without the files, and rounds 1-3's three Python passes -----------------------------------
+    variants = [("default", []), ("no_sig_files", ["--no_sig_files"]), ("python_ingest", ["--python_ingest"])]
+    train_lines = {}
+    for tag, extra in variants:
+        out_dir = os.path.join(args.work, "out_" + tag)
+        os.makedirs(out_dir)
+        phases.reset()
+        t0 = time.perf_counter()
+        rc = cli.main(["train", "--ref_file", ref_zip, "--ksize", "31", "--ani_thresh", "0.95", "--prefix", "db", "--outdir", out_dir,
+                       "--num_threads", str(args.threads), "--force"] + extra)
+        wall = time.perf_counter() - t0
+        ph = phases.snapshot()
+        top = {k: v for k, v in ph.items() if "/" not in k}
+        rss_self, rss_kids = peak_rss_gb()
+        n_kept = sum(1 for _ in open(os.path.join(out_dir, "db_processed_manifest.tsv"))) - 1
+        train_lines[tag] = {"rc": rc, "wall_s": round(wall, 2), "phases_s": ph, "slowest_phase": max(top, key=top.get) if top else None,
+                            "unaccounted_s": round(wall - sum(top.values()), 2), "references_kept": n_kept,
+                            "peak_rss_gb": {"process": rss_self, "largest_pool_worker": rss_kids}}
+        if tag != "default" and not args.keep:
+            shutil.rmtree(out_dir, ignore_errors=True)
+    out_dir = os.path.join(args.work, "out_default")
+    n_kept = train_lines["default"]["references_kept"]
+    lines["train"] = dict(train_lines["default"],
+                          command="yacht train (python -m yacht_amd train): zip -> manifest + packed DB",
+                          workload=f"{args.refs} synthetic sketches k=31 scaled=1000 (rs214 shape), sourmash-style zip of {zip_gb:.2f} GB",
+                          threads=args.threads, variants={k: v for k, v in train_lines.items() if k != "default"},
+                          reference_published="README.md:276: 85 205 GTDB genomes, ~12 minutes, 52 GB (whole command, CPU)")
     print(json.dumps(lines["train"]), flush=True)
 
     # ---- yacht run ---------------------------------------------------------------------------------------

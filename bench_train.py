@@ -52,6 +52,9 @@ def main() -> int:
                          "partial pair counts are summed (dist.hash_range_pairwise); rows = every rank holds everything and computes a "
                          "block of rows of the pair matrix (dist.sharded_pairwise)")
     ap.add_argument("--no-scaling-model", action="store_true", help="N = 1: skip the measurement of one rank's share of a G-way hash-range run")
+    ap.add_argument("--no-device-input", action="store_true",
+                    help="N = 1: skip the extra passes with the sketches already in HBM (yh_db_create_device): the kernels' own rate, no PCIe")
+    ap.add_argument("--device-input", action="store_true", help="N = 1: ONLY the device-input passes (for profiling the kernels)")
     ap.add_argument("--backend", default="nccl")
     ap.add_argument("--share-gpu", action="store_true", help="testing: all ranks on cuda:0 (gloo)")
     args = ap.parse_args()
@@ -94,10 +97,50 @@ def main() -> int:
 
         bnd = ydist.hash_range_bounds(int(values.max()), world)
         range_slice = ydist.slice_csr_to_hash_range(values, offsets, bnd[rank], bnd[rank + 1])
+    # ---- the sketches already in HBM (the `yacht run` -> re-train case; every rank of a multi-GPU train behind the first
+    # broadcast): yh_db_create_device + yh_pairwise + selection -- no PCIe in the call, the kernels' own rate
+    device_input = None
+    if world == 1 and not args.no_device_input:
+        import torch
+
+        d_values = torch.from_numpy(values.view(np.int64)).to(f"cuda:{local_rank}")
+        d_offsets = torch.from_numpy(offsets.astype(np.int64)).to(f"cuda:{local_rank}")
+        torch.cuda.synchronize()
+        td_b, td_p, td_s, kb, kp = [], [], [], [], []
+        for _ in range(args.steps + 2):
+            t0 = time.perf_counter()
+            dbd = RefDB.from_device(d_values.data_ptr(), d_offsets.data_ptr(), n, sizes=sizes, device=local_rank, flags=YH_DB_PAIRWISE_ONLY)
+            t1 = time.perf_counter()
+            di, dj, dc = dbd.pairwise(c)
+            t2 = time.perf_counter()
+            dsel = train_select(sizes, di, dj)
+            t3 = time.perf_counter()
+            tmd = dbd.timing()
+            dstats = dbd.index_stats()
+            dbd.close()
+            td_b.append(t1 - t0); td_p.append(t2 - t1); td_s.append(t3 - t2)
+            kb.append(tmd["ms_db_build"]); kp.append(tmd["ms_pairwise_kernels"])
+        med = lambda x: float(np.median(x[2:]))  # noqa: E731
+        d_total = med(td_b) + med(td_p) + med(td_s)
+        alg_d = 8 * int(offsets[-1]) + 12 * int(di.size)
+        k_ms_d = med(kb) + med(kp)
+        device_input = {
+            "value": round(n * (n - 1) / 2 / d_total, 1), "unit": "pair-queries/s",
+            "seconds": {"create_device": round(med(td_b), 5), "pairwise": round(med(td_p), 5), "select": round(med(td_s), 5), "total": round(d_total, 5),
+                        "db_build_kernels_ms": round(med(kb), 3), "pairwise_kernels_ms": round(med(kp), 3)},
+            "roofline": {"bound": "hbm", "achieved": round(alg_d / 1e9 / (k_ms_d / 1e3), 1), "peak": 8000.0, "unit": "GB/s",
+                         "frac": round(alg_d / 1e9 / (k_ms_d / 1e3) / 8000.0, 4), "algorithmic_bytes": alg_d,
+                         "device_ms": round(k_ms_d, 3),
+                         "note": "one-touch bytes (8 H + 12 P_out, SURVEY.md 8d) over the device time of build + pairwise (HIP events around "
+                                 "validation, the distribution sort, the index kernels, transpose and rows)"},
+            "how": "sketches resident in HBM: yh_db_create_device(PAIRWISE_ONLY) + yh_pairwise + yh_train_select; medians of the passes behind two warm-ups",
+            "_results": (di, dj, dc, dsel, dstats),
+        }
+        del d_values, d_offsets
     t_build, t_pair, t_sel = [], [], []
     k_pair_ms = []
     pi = pj = pc = None
-    for _ in range(args.steps + 1):  # first pass is warm-up
+    for _ in range(0 if (args.device_input and device_input is not None) else args.steps + 1):  # first pass is warm-up
         if world > 1:
             dist.barrier()
         t0 = time.perf_counter()
@@ -152,6 +195,14 @@ def main() -> int:
         t_pair.append(t2 - t1)
         t_sel.append(t3 - t2)
         k_pair_ms.append(tm["ms_pairwise_kernels"])
+    if not t_build:  # --device-input: only those passes ran; the line's main figures are theirs
+        pi, pj, pc, sel, stats = device_input["_results"]
+        t_build = [0.0, device_input["seconds"]["create_device"]]
+        t_pair = [0.0, device_input["seconds"]["pairwise"]]
+        t_sel = [0.0, device_input["seconds"]["select"]]
+        k_pair_ms = [0.0, device_input["seconds"]["pairwise_kernels_ms"]]
+        tm = {"ms_db_build": device_input["seconds"]["db_build_kernels_ms"]}
+        info = {"n_shared_postings": -1}
     t_build, t_pair, t_sel, k_pair_ms = (float(np.median(x[1:])) for x in (t_build, t_pair, t_sel, k_pair_ms))
     total = t_build + t_pair + t_sel
     if world > 1:  # the slowest rank
@@ -300,15 +351,23 @@ def main() -> int:
         "full_size_vs_genuine_reference": golden,
         "scaling_model": scaling_model,
     }
+    if device_input is not None:
+        di, dj, dc, dsel, dstats = device_input.pop("_results")
+        device_input["equals_host_input"] = bool(np.array_equal(di, pi) and np.array_equal(dj, pj) and np.array_equal(dc, pc)
+                                                 and np.array_equal(dsel, sel) and tuple(int(x) for x in dstats) == tuple(int(x) for x in stats))
+        if not device_input["equals_host_input"]:
+            parity = False
+            out["parity_bit_exact"] = False
+        out["device_input"] = device_input
     # roofline-style figure of the kernels alone (B = 8 H + 12 P_out), HBM peak 8 TB/s
     k_ms = float(tm["ms_db_build"]) + k_pair_ms
     alg_upload_s = 8 * int(offsets[-1]) / 56e9  # what the bus needs for the sketches alone (measured: 56 GB/s from pageable memory)
-    out["roofline"] = {"bound": "hbm", "kernels": "chunk sorts + merges (rocPRIM, under the upload), k_idx_count/emit, k_pair_transpose, k_pair_rows",
+    out["roofline"] = {"bound": "hbm", "kernels": "k_part<1> per chunk (under the upload), k_part<2>, k_bucket_sort (yh_sort.hip), k_idx_count/emit, k_pair_transpose, k_pair_rows",
                        "achieved": round(alg / 1e9 / (k_ms / 1e3), 1) if k_ms > 0 else None, "peak": 8000.0, "unit": "GB/s",
                        "frac": round(alg / 1e9 / (k_ms / 1e3) / 8000.0, 4) if k_ms > 0 else None,
                        "exposed_device_ms": round(1e3 * total - 1e3 * alg_upload_s, 3),
-                       "note": "one-touch bytes over the SUM of the device time of all build + pairwise kernels; most of it (the chunk sorts and all "
-                               "merges but the last) runs while the database crosses PCIe -- exposed_device_ms = the call minus 8 H bytes at 56 GB/s"}
+                       "note": "one-touch bytes over the SUM of the device time of all build + pairwise kernels; the first-level distribution of "
+                               "the chunks runs while the database crosses PCIe -- exposed_device_ms = the call minus 8 H bytes at 56 GB/s"}
     if world > 1:
         if rank == 0:
             os.write(json_fd, (json.dumps(out) + "\n").encode())

@@ -265,10 +265,11 @@ int yh_run_finish_range_device(yh_db* db, int ctx, const uint32_t* d_gathered_bi
  *   yh_run_batch_finish_range_device   subset = OR of the n_ranks gathered word arrays ([n_ranks][N]); d_n_excl, d_n_match
  *                                      [n_samples][N] = this rank's shares (d_overlap: what the first half left)
  * The two halves of a batch share one of YH_BATCH_SLOTS batch slots of the handle (the first half's hits on shared hashes
- * wait there for the second): with two slots the subset words of block j travel while the lookups of block j + 1 run.  A
+ * wait there for the second): with several slots the subset words of block j travel while the lookups of block j + 1 run,
+ * and block j - 1's compact rows are still being read (yacht_amd/dist.py: BatchRowsReducer keeps three blocks in flight).  A
  * second half without its first half in the slot, or with a different n_samples, or after yh_run_batch / yh_run_batch_device
  * ran meanwhile (they use slot 0), fails with YH_ERR_INVALID_ARG.                                                        */
-#define YH_BATCH_SLOTS 2
+#define YH_BATCH_SLOTS 3
 int yh_run_batch_local_range_device(yh_db* db, int slot, const uint64_t* d_samples, const uint64_t* d_sample_offsets,
                                     uint32_t n_samples, uint64_t total_hashes, uint32_t* d_overlap, uint64_t* d_maskwords_out);
 int yh_run_batch_finish_range_device(yh_db* db, int slot, uint32_t n_samples, const uint64_t* d_gathered_maskwords,
@@ -330,6 +331,10 @@ int yh_run_wait(yh_db* db, int slot);
 typedef struct yh_run_row { uint32_t ref, overlap, n_excl, n_match; } yh_run_row;
 uint64_t yh_sample_pack_bound(uint64_t n_sample);
 int yh_sample_pack(const uint64_t* sample, uint64_t n_sample, void* packed, uint64_t cap_bytes, uint64_t* packed_bytes);
+/* The same with the number of host threads stated: <= 0 as yh_sample_pack (up to 8 for a large sample), 1 = everything on the
+ * calling thread -- for a caller that packs many samples at once, one thread each.                                      */
+int yh_sample_pack_threads(const uint64_t* sample, uint64_t n_sample, void* packed, uint64_t cap_bytes, uint64_t* packed_bytes,
+                           int threads);
 int yh_sample_unpack(const void* packed, uint64_t packed_bytes, uint64_t* sample_out, uint64_t cap, uint64_t* n_sample);
 int yh_run_submit_packed(yh_db* db, int slot, const void* packed, uint64_t packed_bytes, yh_run_row* rows, uint64_t cap_rows);
 int yh_run_submit_rows(yh_db* db, int slot, const uint64_t* sample, uint64_t n_sample, yh_run_row* rows, uint64_t cap_rows);
@@ -414,6 +419,18 @@ int yh_sig_meta_get(const yh_sig_meta* meta, uint8_t* status, uint64_t* n_hashes
                     uint8_t* has_abundance, char* md5, uint64_t* name_offsets);
 int yh_sig_meta_names(const yh_sig_meta* meta, char* names);
 int yh_sig_meta_destroy(yh_sig_meta* meta);
+/* The three passes in ONE over the archive itself (`yacht train` on a sourmash .zip database: unzip + gunzip + metadata,
+ * make_training_data_from_sketches.py:107-133, utils.py:201-221, :499-509): the central directory is read once (zip64
+ * too: a GTDB database has more than 65 535 members), then `threads` host threads pread and inflate the members and feed
+ * every "signatures/<x>.sig[.gz]" straight into the metadata scanner and the train core's sketch reader -- as
+ * yh_sig_meta_read_keep does for files -- in central-directory order.  out_dir != NULL: every member is also written
+ * below out_dir as the reference's passes leave it (a .sig.gz member as the .sig it inflates to; members may not leave
+ * out_dir); out_dir == NULL: nothing is written.
+ *   yh_sig_meta_count   signature members found
+ *   yh_sig_meta_paths   their paths relative to out_dir (path_offsets[n + 1]; paths == NULL: sizes only)            */
+int yh_zip_sig_ingest(const char* zip_path, const char* out_dir, int ksize, int threads, yh_sig_meta** out);
+int yh_sig_meta_count(const yh_sig_meta* meta, uint64_t* n);
+int yh_sig_meta_paths(const yh_sig_meta* meta, uint64_t* path_offsets, char* paths);
 
 /* ---- sketching (next to the path: SURVEY.md §8f N2) --------------------------------------------
  * DNA FracMinHash as `sourmash sketch dna -p k=K,scaled=S,abund` defines it (the reference shells

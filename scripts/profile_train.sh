@@ -5,7 +5,7 @@ set -u
 ROOT=$(pwd)
 export TMPDIR=/tmp
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/gpurun_out/prof_train" -o train -- python3 "$ROOT/bench_train.py" --no-oracle --no-scaling-model --steps 3 > "$ROOT/gpurun_out/train_prof_bench.json" 2> "$ROOT/gpurun_out/train_prof.err"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/gpurun_out/prof_train" -o train -- python3 "$ROOT/bench_train.py" --no-oracle --no-scaling-model --steps 3 ${TRAIN_PROF_ARGS:-} > "$ROOT/gpurun_out/train_prof_bench.json" 2> "$ROOT/gpurun_out/train_prof.err"
 cd "$ROOT"
 python3 - <<'PY' > gpurun_out/train_stats.txt
 import csv, glob

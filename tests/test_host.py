@@ -351,3 +351,79 @@ def test_extract_members_concatenated_gzip_and_traversal(tmp_path):
             a.writestr(bad, b"")
         with pytest.raises(ValueError, match="outside the working directory"):
             _extract_members((str(z), str(work), [bad]))
+
+
+def test_zip_ingest_one_pass_equals_the_three_passes(tmp_path):
+    """utils.ingest_zip_database (yh_zip_sig_ingest: central directory -> host threads pread, inflate, parse and write the
+    members) against the reference's three passes as this build had them (unzip, gunzip, metadata): the reference's own
+    known answers for the 20 fixture genomes, the same files on disk byte for byte, the sketches the train core reads from
+    them, the archive's member order -- on the fixture (stored members) and on a re-packed archive with DEFLATED members,
+    zip64 records (more than 65 535 members), a member that is not a signature and one that does not inflate."""
+    import gzip as gz
+    import zipfile
+
+    from yacht_amd import train_core
+
+    want = json.load(open(os.path.join(FX, "test_collect_signature_info_data.json")))
+    src = os.path.join(FX, "20_genomes_sketches.zip")
+    # the three passes, into `ref`
+    ref = tmp_path / "ref"
+    with zipfile.ZipFile(src) as z:
+        z.extractall(ref)
+        order = [n for n in z.namelist() if n.startswith("signatures/") and n.endswith(".sig.gz")]
+    utils.decompress_all_sig_files(sorted(str(p) for p in (ref / "signatures").glob("*.sig.gz")), 4)
+    one = tmp_path / "one"
+    info = utils.ingest_zip_database(src, str(one), 31, 4)
+    assert {k: [v[0], v[1], v[2], v[3]] for k, v in info.items()} == want
+    assert [os.path.relpath(v[4], one) for v in info.values()] == [n[:-3] for n in order]  # the archive's order
+    for p in sorted((ref / "signatures").glob("*.sig")):
+        assert (one / "signatures" / p.name).read_bytes() == p.read_bytes()
+    assert (one / "SOURMASH-MANIFEST.csv").read_bytes() == (ref / "SOURMASH-MANIFEST.csv").read_bytes()
+    # the sketches were kept for the core: the next read of exactly these paths takes them (no file is opened)
+    paths = train_core.parsed_paths()
+    assert paths == [v[4] for v in info.values()]
+    values, offsets = train_core.read_sketches_csr(paths, threads=2)
+    assert train_core.parsed_paths() is None
+    v2, o2 = train_core.read_sketches_csr(paths, threads=2)  # (from the files this time)
+    assert np.array_equal(values, v2) and np.array_equal(offsets, o2) and offsets.size == 21
+    # nothing written: the same records, no directory
+    lean = tmp_path / "lean"
+    info2 = utils.ingest_zip_database(src, str(lean), 31, 4, write_files=False)
+    train_core.drop_parsed_sketches()
+    assert {k: v[:4] for k, v in info2.items()} == {k: v[:4] for k, v in info.items()} and not lean.exists()
+
+    # a harder archive: deflated members, > 65 535 entries (zip64 end records), zip64 extra fields, odd members
+    big = tmp_path / "big.zip"
+    with zipfile.ZipFile(src) as z, zipfile.ZipFile(big, "w", compression=zipfile.ZIP_DEFLATED) as out:
+        out.writestr("SOURMASH-MANIFEST.csv", z.read("SOURMASH-MANIFEST.csv"))
+        for i, n in enumerate(order):
+            data = z.read(n)
+            if i % 3 == 0:   # stored, as sourmash writes them
+                out.writestr(zipfile.ZipInfo(n), data, compress_type=zipfile.ZIP_STORED)
+            elif i % 3 == 1:  # deflated on top of the gzip
+                out.writestr(n, data)
+            else:             # a plain .sig member, deflated, written through the zip64 code path
+                with out.open(zipfile.ZipInfo(n[:-3]), "w", force_zip64=True) as f:
+                    f.write(gz.decompress(data))
+        out.writestr("signatures/broken.sig.gz", b"\x1f\x8bnot gzip at all")
+        out.writestr("notes/readme.txt", "not a signature")
+        for i in range(66_000):
+            out.writestr(zipfile.ZipInfo(f"filler/{i}"), b"")
+    two = tmp_path / "two"
+    info3 = utils.ingest_zip_database(str(big), str(two), 31, 4)
+    train_core.drop_parsed_sketches()
+    assert {k: [v[0], v[1], v[2], v[3]] for k, v in info3.items()} == want
+    assert (two / "notes" / "readme.txt").read_text() == "not a signature"
+    assert (two / "signatures" / "broken.sig.gz").exists()  # (does not inflate: left as it is, and reported, not fatal)
+    assert len(list((two / "filler").iterdir())) == 66_000
+    for p in sorted((ref / "signatures").glob("*.sig")):
+        assert (two / "signatures" / p.name).read_bytes() == p.read_bytes()
+    # members may not leave the working directory
+    evil = tmp_path / "evil.zip"
+    with zipfile.ZipFile(evil, "w") as out:
+        out.writestr("../outside.sig", "[]")
+    with pytest.raises(_lib.YachtHipError, match="outside the working directory"):
+        utils.ingest_zip_database(str(evil), str(tmp_path / "w3"), 31, 2)
+    assert not (tmp_path / "outside.sig").exists()
+    with pytest.raises(_lib.YachtHipError):
+        utils.ingest_zip_database(os.path.join(FX, "test_collect_signature_info_data.json"), str(tmp_path / "w4"), 31, 2)

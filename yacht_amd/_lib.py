@@ -27,7 +27,7 @@ YH_DB_KEEP_CSR = 2
 YH_DB_PAIRWISE_ONLY = 8
 YH_DB_NO_DIRECTORY = 16
 YH_RUN_SLOTS = 4
-YH_BATCH_SLOTS = 2
+YH_BATCH_SLOTS = 3
 YH_LOOKUP_AUTO, YH_LOOKUP_STREAM, YH_LOOKUP_INDEXED = 0, 1, 2
 
 _ERR_NAMES = {
@@ -122,6 +122,7 @@ SIGNATURES = {
     "yh_run_wait": (C.c_int, [_vp, C.c_int]),
     "yh_sample_pack_bound": (C.c_uint64, [C.c_uint64]),
     "yh_sample_pack": (C.c_int, [_vp, C.c_uint64, _vp, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "yh_sample_pack_threads": (C.c_int, [_vp, C.c_uint64, _vp, C.c_uint64, C.POINTER(C.c_uint64), C.c_int]),
     "yh_sample_unpack": (C.c_int, [_vp, C.c_uint64, _vp, C.c_uint64, C.POINTER(C.c_uint64)]),
     "yh_run_submit_packed": (C.c_int, [_vp, C.c_int, _vp, C.c_uint64, _vp, C.c_uint64]),
     "yh_run_submit_rows": (C.c_int, [_vp, C.c_int, _vp, C.c_uint64, _vp, C.c_uint64]),
@@ -150,6 +151,9 @@ SIGNATURES = {
     "yh_sig_meta_get": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "yh_sig_meta_names": (C.c_int, [_vp, _vp]),
     "yh_sig_meta_destroy": (C.c_int, [_vp]),
+    "yh_zip_sig_ingest": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "yh_sig_meta_count": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
+    "yh_sig_meta_paths": (C.c_int, [_vp, _vp, _vp]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -17,9 +17,9 @@ LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libyacht_hip.so")
 EXE_PATH = os.path.join(LIB_DIR, "run_yacht_train_core")
 
-LIB_SOURCES = ["yh_api.hip", "yh_build.hip", "yh_query.hip", "yh_batch.hip", "yh_pairwise.hip", "yh_sketch.hip", "yh_sigread.hip", "yh_pack.hip", "yh_hyp.cpp"]
+LIB_SOURCES = ["yh_api.hip", "yh_build.hip", "yh_sort.hip", "yh_query.hip", "yh_batch.hip", "yh_pairwise.hip", "yh_sketch.hip", "yh_sigread.hip", "yh_pack.hip", "yh_hyp.cpp"]
 EXE_SOURCES = ["train_core_main.cpp"]
-HEADERS = ["yh_common.h", "yh_sigread.h", os.path.join(REPO_DIR, "include", "yacht_hip.h")]
+HEADERS = ["yh_common.h", "yh_sigread.h", "yh_sort.h", os.path.join(REPO_DIR, "include", "yacht_hip.h")]
 ARCH = "gfx950"
 
 

@@ -150,7 +150,7 @@ void yh_tfree(yh_db* db, void* p) {
 // (the handle's stream has drained) blocks it used last are anyone's now; the excess over the bar goes back to the driver
 void yh_pool_trim(yh_db* db) {
     if (!cache_on()) return;
-    static const size_t keep = [] { const char* e = yh_tune_env("YH_POOL_KEEP"); return e ? (size_t)atoll(e) : (size_t)4 << 30; }();
+    static const size_t keep = [] { const char* e = yh_tune_env("YH_POOL_KEEP"); return e ? (size_t)atoll(e) : (size_t)16 << 30; }();
     std::vector<void*> drop;
     {
         std::lock_guard<std::mutex> lk(g_cache_mu);
@@ -179,7 +179,12 @@ void yh_pool_trim(yh_db* db) {
 
 int yh_dmalloc(yh_db* db, void** p, size_t bytes) {
     if (bytes == 0) bytes = 16;
-    const bool cached = (db->flags & YH_DB_PAIRWISE_ONLY) != 0;
+    // Every array of a handle comes from the cache too (round 4; before: only those of YH_DB_PAIRWISE_ONLY handles): a
+    // process that creates handle after handle -- tests, the shares of a scaling model, `yacht train` -- then stops asking
+    // the driver for gigabytes it has just given back.  The driver's hipMalloc of a multi-GB block now and then takes
+    // SECONDS on this pool right after such frees (profiles/r04/malloc_probe.txt: 0.2 ms, 0.2 ms, 3 951 ms for the same
+    // call in a plain HIP program; build_trace.txt: one create of six at 3.5 s, all of it inside one allocation).
+    const bool cached = true;
     const double t0 = alloc_trace_on() ? alloc_now_ms() : 0.0;
     hipError_t e = cached ? yh_tmalloc(db, p, bytes) : hipMalloc(p, bytes);
     if (alloc_trace_on() && alloc_now_ms() - t0 > 0.5)
@@ -477,16 +482,16 @@ int yh_db_destroy(yh_db* db) {
         db->d_work = db->ctx_work[0];
         db->d_work_count = db->ctx_count[0];
         for (int c = 1; c < YH_RUN_CONTEXTS; ++c) {
-            if (db->ctx_bits[c]) (void)hipFree(db->ctx_bits[c]);
-            if (db->ctx_work[c]) (void)hipFree(db->ctx_work[c]);
-            if (db->ctx_count[c]) (void)hipFree(db->ctx_count[c]);
+            yh_dfree(db, db->ctx_bits[c]);
+            yh_dfree(db, db->ctx_work[c]);
+            yh_dfree(db, db->ctx_count[c]);
         }
     }
     void* ptrs[] = {db->d_values, db->d_offsets, db->d_sizes, db->d_g, db->d_po, db->d_pr, db->d_pg, db->d_nshared,
                     db->d_dh, db->d_dref, db->d_dir, db->d_bkt, db->d_cbkt, db->d_ovf_keys, db->d_ovf_vals,
                     db->d_rpo, db->d_rg, db->d_rrec, db->d_rrecx, db->d_filter, db->d_hrec, db->d_hrecx, db->d_hmult, db->d_hpo,
                     db->d_work, db->d_work_count, db->d_mask, db->d_maskbits, db->d_hit, db->d_excl_e, db->d_overlap_tmp,
-                    db->d_sample_tmp, db->d_out_tmp, db->d_flag, db->d_reps, db->batch[0].d_scratch, db->batch[1].d_scratch, db->d_sdelta, db->d_shdr, db->d_srec,
+                    db->d_sample_tmp, db->d_out_tmp, db->d_flag, db->d_reps, db->batch[0].d_scratch, db->batch[1].d_scratch, db->batch[2].d_scratch, db->d_sdelta, db->d_shdr, db->d_srec,
                     db->d_wg_key, db->d_ghost_src, db->d_bad_word, db->d_prank};
     for (void* p : ptrs)
         if (p) yh_dfree(db, p);
@@ -497,11 +502,11 @@ int yh_db_destroy(yh_db* db) {
     ring_destroy(db->ev_pair);
     for (hipStream_t q : db->st_in) if (q) (void)hipStreamSynchronize(q);
     for (RunSlot& s : db->slots) {
-        if (s.d_sample) (void)hipFree(s.d_sample);
-        if (s.d_packed) (void)hipFree(s.d_packed);
-        if (s.d_rows) (void)hipFree(s.d_rows);
-        if (s.d_out) (void)hipFree(s.d_out);
-        if (s.d_bad) (void)hipFree(s.d_bad);
+        yh_dfree(db, s.d_sample);  // (yh_dfree: cache blocks back to the cache, plain allocations to hipFree)
+        yh_dfree(db, s.d_packed);
+        yh_dfree(db, s.d_rows);
+        yh_dfree(db, s.d_out);
+        yh_dfree(db, s.d_bad);
         if (s.h_bad) (void)hipHostFree(s.h_bad);
         if (s.ev_up) (void)hipEventDestroy(s.ev_up);
         if (s.ev_out) (void)hipEventDestroy(s.ev_out);
@@ -1061,6 +1066,7 @@ int yh_run_finish_range_device(yh_db* db, int ctx, const uint32_t* d_gathered_bi
 }
 
 // the batched run on a hash-range shard: up to 64 samples per call around ONE exchange of their subset words
+static_assert(YH_BATCH_SLOTS == 3, "yh_db_destroy frees the scratch of three batch slots");
 static bool batch_slot_ok(int slot) {
     if (slot >= 0 && slot < YH_BATCH_SLOTS) return true;
     yh_set_error("batch slot must be in [0, %d)", YH_BATCH_SLOTS);

@@ -8,6 +8,7 @@
 //       erased (src/cpp/main.cpp:215-246) -- with its reference-major views and holder sets.
 //       Replaces the per-run re-reading of N .sig files (hypothesis_recovery_src.py:93,154,168).
 #include "yh_common.h"
+#include "yh_sort.h"
 
 #include <rocprim/device/device_merge.hpp>
 #include <rocprim/device/device_radix_sort.hpp>
@@ -479,13 +480,15 @@ int yh_build_validate(yh_db* db, const u64* d_values, const u64* d_offsets) {
 }
 
 // Host CSR -> device CSR, validated, and the (hash, reference) pairs of the whole database sorted by hash, with the
-// UPLOAD OVERLAPPED WITH THE SORT: the references go up in a few chunks of falling size on a stream of their own;
-// while chunk c + 1 crosses the bus, chunk c is checked (k_scan_refs), sorted (stable radix sort of its pairs) and
-// merged into the sorted prefix (rocprim::merge: ties take the first range first = the lower references, so a run of
-// equal hashes keeps ascending references).  Behind the last byte only the smallest chunk's sort and one merge remain
-// (`yacht train` at configs[3]: 8 ms of upload + 3 ms of sort -> 8 ms + 0.9 ms).  *d_sk_out / *d_sv_out are the
-// caller's to yh_tfree.  (The largest hash is needed before the first sort: for ascending sketches it is the largest
-// LAST element, which the host reads off the offsets; sketches that are not ascending fail the check anyway.)
+// UPLOAD OVERLAPPED WITH THE SORT: the references go up in a few chunks on a stream of their own; while chunk c + 1
+// crosses the bus, chunk c is checked (k_scan_refs) and DISTRIBUTED over the first-level regions of the sort
+// (yh_sort.hip: yh_psort_add -- the regions are filled by atomically reserved runs, so pieces can arrive in any number of
+// calls).  Behind the last byte remain the last chunk's distribution, the second level and the bucket sorts.  (Rounds 2-3
+// sorted every chunk with rocPRIM and merged it into the sorted prefix with rocprim::merge.)  Keys that are not uniform
+// enough for the distribution sort (a capacity is exceeded on the device) are sorted by rocPRIM behind the upload instead.
+// *d_sk_out / *d_sv_out are the caller's to yh_tfree.  (The largest hash is needed before the first chunk is distributed:
+// for ascending sketches it is the largest LAST element, which the host reads off the offsets; sketches that are not
+// ascending fail the check anyway.)
 static double trace_now() {
     struct timespec ts;
     clock_gettime(CLOCK_MONOTONIC, &ts);
@@ -525,9 +528,6 @@ int yh_build_upload_sorted(yh_db* db, const u64* h_values, const u64* h_offsets,
     u64 max_last = 0;
     for (u64 j = 0; j < N; ++j)
         if (h_offsets[j + 1] > h_offsets[j]) max_last = std::max(max_last, h_values[h_offsets[j + 1] - 1]);
-    unsigned end_bit = 1;
-    while (end_bit < 64 && (max_last >> end_bit) != 0) ++end_bit;
-
     double t_prev = trace_now();
     TRACE("chunk plan + max");
     // (the upload stream and the chunk events are made once per device and kept: a dozen creates and destroys were
@@ -543,6 +543,7 @@ int yh_build_upload_sorted(yh_db* db, const u64* h_values, const u64* h_offsets,
     u32* V[2] = {nullptr, nullptr};
     u32* d_ids = nullptr;
     void* d_tmp = nullptr;
+    yh_psort* ps = nullptr;
     int rc = YH_OK;
 #define UP_HIP(call)                                                                          \
     if (rc == YH_OK) {                                                                        \
@@ -560,25 +561,14 @@ int yh_build_upload_sorted(yh_db* db, const u64* h_values, const u64* h_offsets,
         UP_HIP(hipEventCreate(&c2));
         if (rc == YH_OK) { ev.push_back(a); eb.push_back(b); ee.push_back(c2); }
     }
-    for (int b = 0; b < 2; ++b) {
-        UP_HIP(yh_tmalloc(db, (void**)&K[b], H * sizeof(u64)));
-        UP_HIP(yh_tmalloc(db, (void**)&V[b], H * sizeof(u32)));
-    }
+    UP_HIP(yh_tmalloc(db, (void**)&K[0], H * sizeof(u64)));
+    UP_HIP(yh_tmalloc(db, (void**)&V[0], H * sizeof(u32)));
     UP_HIP(yh_tmalloc(db, (void**)&d_ids, H * sizeof(u32)));
-    // temporary storage: the largest chunk's sort, the largest merge
-    size_t tmp_bytes = 16;
-    for (size_t c = 0; c < C && rc == YH_OK; ++c) {
-        const u64 e0 = h_offsets[rb[c]], e1 = h_offsets[rb[c + 1]];
-        size_t b1 = 0, b2 = 0;
-        UP_HIP(rocprim::radix_sort_pairs(nullptr, b1, (const u64*)d_values, K[0], (const u32*)d_ids, V[0], (size_t)(e1 - e0), 0u, end_bit, st));
-        if (c) UP_HIP(rocprim::merge(nullptr, b2, (const u64*)K[0], (const u64*)K[0], K[1], (const u32*)V[0], (const u32*)V[0], V[1], (size_t)e0,
-                                     (size_t)(e1 - e0), rocprim::less<u64>(), st));
-        tmp_bytes = std::max(tmp_bytes, std::max(b1, b2));
-    }
-    UP_HIP(yh_tmalloc(db, &d_tmp, tmp_bytes));
+    const bool dist_sort = yh_psort_applicable(H, max_last);
+    if (rc == YH_OK && dist_sort) rc = yh_psort_begin(db, H, max_last, &ps);
     TRACE("stream, events, buffers");
     if (rc == YH_OK) rc = validate_begin(db);
-    int cur = 0;  // the buffer that holds the sorted prefix
+    const int cur = 0;  // (the buffer the sorted pairs land in)
     // The copies are issued back to back by a thread of their own (a copy from pageable memory returns when the data has
     // left the host, and queueing a chunk's sort and merge takes the host ~0.1 ms: with one thread doing both, the bus
     // idled that long behind every chunk); this thread queues chunk c's device work as soon as its event is recorded.
@@ -612,15 +602,7 @@ int yh_build_upload_sorted(yh_db* db, const u64* h_values, const u64* h_offsets,
         if (rc == YH_OK) rc = validate_refs(db, d_values, d_offsets, r0, r1);
         if (rc == YH_OK && n) {
             k_fill_ref_ids<<<grid_for((r1 - r0) * WAVE, 256), 256, 0, st>>>(d_offsets + r0, r1 - r0, d_ids, (u32)r0);
-            size_t tb = tmp_bytes;
-            UP_HIP(rocprim::radix_sort_pairs(d_tmp, tb, (const u64*)(d_values + e0), K[cur] + e0, (const u32*)(d_ids + e0), V[cur] + e0,
-                                             (size_t)n, 0u, end_bit, st));
-            if (e0) {  // prefix [0, e0) and the chunk behind it, both in `cur`, into the other buffer
-                tb = tmp_bytes;
-                UP_HIP(rocprim::merge(d_tmp, tb, (const u64*)K[cur], (const u64*)(K[cur] + e0), K[cur ^ 1], (const u32*)V[cur],
-                                      (const u32*)(V[cur] + e0), V[cur ^ 1], (size_t)e0, (size_t)n, rocprim::less<u64>(), st));
-                cur ^= 1;
-            }
+            if (ps) rc = yh_psort_add(db, ps, d_values + e0, d_ids + e0, n);  // this chunk's pairs into the first-level regions
         }
         UP_HIP(hipEventRecord(ee[c], st));
         TRACE("chunk work queued");
@@ -630,6 +612,34 @@ int yh_build_upload_sorted(yh_db* db, const u64* h_values, const u64* h_offsets,
     if (rc != YH_OK) (void)hipStreamSynchronize(up);
     if (rc == YH_OK) rc = validate_end(db);  // (waits for the stream)
     TRACE("stream drained");
+    float ms_chunks = 0.f;  // device time of the chunks' checks and distribution passes (they ran under the upload)
+    for (size_t c = 0; c < C && rc == YH_OK; ++c) {
+        float ms = 0.f;
+        if (c < eb.size() && hipEventElapsedTime(&ms, eb[c], ee[c]) == hipSuccess) ms_chunks += ms;
+        else (void)hipGetLastError();
+    }
+    bool sorted = false;
+    const bool timed_tail = rc == YH_OK && !eb.empty();
+    if (timed_tail) UP_HIP(hipEventRecord(eb[0], st));  // (pair 0 again: the device time of the tail behind the last byte)
+    if (rc == YH_OK && ps) rc = yh_psort_finish(db, ps, K[0], V[0], &sorted);  // second level + bucket sorts
+    if (rc == YH_OK && !sorted) {  // not this sort's keys: one rocPRIM sort of everything, behind the upload
+        unsigned end_bit2 = 1;
+        while (end_bit2 < 64 && (db->max_hash >> end_bit2) != 0) ++end_bit2;
+        size_t tb = 0;
+        UP_HIP(rocprim::radix_sort_pairs(nullptr, tb, (const u64*)d_values, K[0], (const u32*)d_ids, V[0], (size_t)H, 0u, end_bit2, st));
+        UP_HIP(yh_tmalloc(db, &d_tmp, std::max<size_t>(tb, 16)));
+        UP_HIP(rocprim::radix_sort_pairs(d_tmp, tb, (const u64*)d_values, K[0], (const u32*)d_ids, V[0], (size_t)H, 0u, end_bit2, st));
+        UP_HIP(hipStreamSynchronize(st));
+    }
+    float ms_tail = 0.f;
+    if (timed_tail) {
+        UP_HIP(hipEventRecord(ee[0], st));
+        UP_HIP(hipEventSynchronize(ee[0]));
+        if (rc == YH_OK) (void)hipEventElapsedTime(&ms_tail, eb[0], ee[0]);
+    }
+    yh_psort_destroy(db, ps);
+    ps = nullptr;
+    TRACE("sorted");
     if (rc == YH_OK && db->max_hash > max_last) { yh_set_error("internal: largest hash above the largest last element"); rc = YH_ERR_HIP; }
     if (rc == YH_OK) {
         static const bool check = [] { const char* e = yh_tune_env("YH_CHECK_SORT"); return e && e[0] == '1'; }();
@@ -642,17 +652,12 @@ int yh_build_upload_sorted(yh_db* db, const u64* h_values, const u64* h_offsets,
             if (rc == YH_OK && bad) { yh_set_error("YH_CHECK_SORT: the merged pairs are not in (hash, reference) order"); rc = YH_ERR_HIP; }
         }
     }
-    db->ms_upload_kernels = 0.f;
-    for (size_t c = 0; c < C; ++c) {
-        float ms = 0.f;
-        if (rc == YH_OK && c < eb.size() && hipEventElapsedTime(&ms, eb[c], ee[c]) == hipSuccess) db->ms_upload_kernels += ms;
-    }
+    db->ms_upload_kernels = ms_tail + ms_chunks;
 #undef UP_HIP
     if (up) (void)hipStreamSynchronize(up);
+    yh_psort_destroy(db, ps);
     yh_tfree(db, d_tmp);
     yh_tfree(db, d_ids);
-    yh_tfree(db, K[cur ^ 1]);
-    yh_tfree(db, V[cur ^ 1]);
     if (rc != YH_OK) { yh_tfree(db, K[cur]); yh_tfree(db, V[cur]); return rc; }
     TRACE("frees");
     *d_sk_out = K[cur];
@@ -764,16 +769,35 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, u64* d_
     if (rc == YH_OK && !d_sk_pre) {
         k_fill_ref_ids<<<grid_for(N * WAVE, 256), 256, 0, st>>>(d_offsets, N, d_ids);
         const u32* ids_src = d_ids;
-        // stable LSD radix sort of (hash, reference id): equal hashes keep their input order
-        // (ascending reference for CSR input)
-        unsigned end_bit = 1;
-        while (end_bit < 64 && (db->max_hash >> end_bit) != 0) ++end_bit;
-        size_t tmp_bytes = 0;
-        IDX_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, (const u64*)d_values, d_sk, ids_src, d_sv,
-                                          (size_t)H, 0u, end_bit, st));
-        IDX_HIP(yh_tmalloc(db, &d_tmp, std::max<size_t>(tmp_bytes, 16)));
-        IDX_HIP(rocprim::radix_sort_pairs(d_tmp, tmp_bytes, (const u64*)d_values, d_sk, ids_src, d_sv,
-                                          (size_t)H, 0u, end_bit, st));
+        // the pairs in (hash, reference) order: the distribution sort of yh_sort.hip for uniform keys (FracMinHash hashes
+        // are), rocPRIM's LSD radix sort -- stable: equal hashes keep ascending references -- for anything else
+        bool sorted = false;
+        if (rc == YH_OK && yh_psort_applicable(H, db->max_hash)) {
+            yh_psort* ps = nullptr;
+            rc = yh_psort_begin(db, H, db->max_hash, &ps);
+            if (rc == YH_OK) rc = yh_psort_add(db, ps, d_values, ids_src, H);
+            if (rc == YH_OK) rc = yh_psort_finish(db, ps, d_sk, d_sv, &sorted);
+            yh_psort_destroy(db, ps);
+        }
+        if (rc == YH_OK && !sorted) {
+            unsigned end_bit = 1;
+            while (end_bit < 64 && (db->max_hash >> end_bit) != 0) ++end_bit;
+            size_t tmp_bytes = 0;
+            IDX_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, (const u64*)d_values, d_sk, ids_src, d_sv,
+                                              (size_t)H, 0u, end_bit, st));
+            IDX_HIP(yh_tmalloc(db, &d_tmp, std::max<size_t>(tmp_bytes, 16)));
+            IDX_HIP(rocprim::radix_sort_pairs(d_tmp, tmp_bytes, (const u64*)d_values, d_sk, ids_src, d_sv,
+                                              (size_t)H, 0u, end_bit, st));
+        }
+        static const bool check_sorted = [] { const char* e = yh_tune_env("YH_CHECK_SORT"); return e && e[0] == '1'; }();
+        if (rc == YH_OK && check_sorted) {  // (tests / fuzzer: the order on the device, whichever sort made it)
+            u32 bad = 0;
+            IDX_HIP(hipMemsetAsync(db->d_flag, 0, 4, st));
+            k_check_sorted_pairs<<<8192, 256, 0, st>>>(d_sk, d_sv, H, db->d_flag);
+            IDX_HIP(hipMemcpyAsync(&bad, db->d_flag, 4, hipMemcpyDeviceToHost, st));
+            IDX_HIP(hipStreamSynchronize(st));
+            if (rc == YH_OK && bad) { yh_set_error("YH_CHECK_SORT: the sorted pairs are not in (hash, reference) order"); rc = YH_ERR_HIP; }
+        }
         // (the sort's buffers are the build's largest temporaries: back to the pool before the next ones come)
         IDX_HIP(hipStreamSynchronize(st));
         yh_tfree(db, d_tmp); d_tmp = nullptr;

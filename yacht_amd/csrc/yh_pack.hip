@@ -19,6 +19,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <thread>
 #include <vector>
 
@@ -218,26 +219,47 @@ uint64_t yh_sample_pack_bound(uint64_t n_sample) {
     return sizeof(PackHeader) + nb * sizeof(PackBlock) + (n_sample + nb + 2) * 8;
 }
 
-int yh_sample_pack(const uint64_t* sample, uint64_t n_sample, void* packed, uint64_t cap_bytes, uint64_t* packed_bytes) {
+// threads <= 0: as many as the sample is worth (at most 8); 1: everything on the calling thread (a caller that packs many
+// samples at once gives every sample a thread of its own: bench.py's host-inclusive leg with the packing inside the step)
+int yh_sample_pack_threads(const uint64_t* sample, uint64_t n_sample, void* packed, uint64_t cap_bytes, uint64_t* packed_bytes,
+                           int threads) {
     if (!packed_bytes || (n_sample && !sample)) { yh_set_error("yh_sample_pack: null argument"); return YH_ERR_INVALID_ARG; }
     if (n_sample > 0xfffffff0ull) { yh_set_error("sample larger than 2^32-16 hashes"); return YH_ERR_INVALID_ARG; }
     const u64 n = n_sample, nb = n_blocks(n);
     const u64* h = (const u64*)sample;
-    // pass 1: ordering, widths, offsets
+    const unsigned hw = std::thread::hardware_concurrency();
+    const unsigned T = threads > 0 ? (unsigned)std::min<u64>((u64)threads, nb / 64 + 1)
+                                   : (unsigned)std::min<u64>(std::min<unsigned>(hw ? hw : 1, 8), nb / 512 + 1);
+    // pass 1: ordering and the width of every block (blocks are independent), then their word offsets (a prefix sum)
     std::vector<PackBlock> tab(nb);
+    std::atomic<int> unsorted{0};
+    auto width_range = [&](u64 b0, u64 b1) {
+        for (u64 b = b0; b < b1; ++b) {
+            const u64 first = b * PACK_BLOCK;
+            const u32 cnt = (u32)std::min<u64>(PACK_BLOCK, n - first);
+            bool bad = b && !(h[first - 1] < h[first]);
+            u64 widest = 0;
+            for (u32 i = 1; i < cnt; ++i) {
+                bad |= !(h[first + i - 1] < h[first + i]);
+                widest |= h[first + i] - h[first + i - 1] - 1ull;
+            }
+            if (bad) unsorted.store(1, std::memory_order_relaxed);
+            tab[b] = PackBlock{h[first], 0u, bits_of(widest)};
+        }
+    };
+    auto run_ranges = [&](auto&& fn) {
+        if (T <= 1) { fn((u64)0, nb); return; }
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < T; ++t) th.emplace_back(fn, nb * t / T, nb * (t + 1) / T);
+        for (auto& x : th) x.join();
+    };
+    run_ranges(width_range);
+    if (unsorted.load()) { yh_set_error("the sample sketch is not strictly ascending"); return YH_ERR_UNSORTED; }
     u64 words = 0;
     for (u64 b = 0; b < nb; ++b) {
-        const u64 first = b * PACK_BLOCK;
-        const u32 cnt = (u32)std::min<u64>(PACK_BLOCK, n - first);
-        if (b && !(h[first - 1] < h[first])) { yh_set_error("the sample sketch is not strictly ascending"); return YH_ERR_UNSORTED; }
-        u64 widest = 0;
-        for (u32 i = 1; i < cnt; ++i) {
-            if (!(h[first + i - 1] < h[first + i])) { yh_set_error("the sample sketch is not strictly ascending"); return YH_ERR_UNSORTED; }
-            widest |= h[first + i] - h[first + i - 1] - 1ull;
-        }
         if (words > 0xfffffff0ull) { yh_set_error("packed sample too large"); return YH_ERR_INVALID_ARG; }
-        tab[b] = PackBlock{h[first], (u32)words, bits_of(widest)};
-        words += block_words(cnt, tab[b].width);
+        tab[b].word_off = (u32)words;
+        words += block_words((u32)std::min<u64>(PACK_BLOCK, n - b * PACK_BLOCK), tab[b].width);
     }
     words += 1;  // the spare word
     const u64 need = sizeof(PackHeader) + nb * sizeof(PackBlock) + words * 8;
@@ -270,16 +292,12 @@ int yh_sample_pack(const uint64_t* sample, uint64_t n_sample, void* packed, uint
             }
         }
     };
-    const unsigned hw = std::thread::hardware_concurrency();
-    const unsigned T = (unsigned)std::min<u64>(std::min<unsigned>(hw ? hw : 1, 8), nb / 512 + 1);
-    if (T <= 1) pack_range(0, nb);
-    else {
-        std::vector<std::thread> th;
-        for (unsigned t = 0; t < T; ++t) th.emplace_back(pack_range, nb * t / T, nb * (t + 1) / T);
-        for (auto& x : th) x.join();
-    }
+    run_ranges(pack_range);
     payload[words - 1] = 0;
     return YH_OK;
+}
+int yh_sample_pack(const uint64_t* sample, uint64_t n_sample, void* packed, uint64_t cap_bytes, uint64_t* packed_bytes) {
+    return yh_sample_pack_threads(sample, n_sample, packed, cap_bytes, packed_bytes, 0);
 }
 
 int yh_sample_unpack(const void* packed, uint64_t packed_bytes, uint64_t* sample_out, uint64_t cap, uint64_t* n_sample) {

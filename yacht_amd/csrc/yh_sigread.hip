@@ -9,6 +9,8 @@
 #include <atomic>
 #include <thread>
 
+#include <fcntl.h>
+#include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
 
@@ -147,6 +149,7 @@ int yh_sig_batch_destroy(yh_sig_batch* b) {
 
 struct yh_sig_meta {
     std::vector<yh_sig::Meta> m;
+    std::vector<std::string> rel_paths;  // yh_zip_sig_ingest: where (under out_dir) every signature member was / would be written
     // yh_sig_meta_read_keep: what the train core would read from the same files (record 0, signature 0, no ksize check),
     // taken from the text while it is in memory -- yh_sig_meta_take_batch hands it on
     bool kept = false;
@@ -269,6 +272,229 @@ int yh_sig_meta_names(const yh_sig_meta* b, char* names) {
 
 int yh_sig_meta_destroy(yh_sig_meta* b) {
     delete b;
+    return YH_OK;
+}
+
+int yh_sig_meta_count(const yh_sig_meta* b, uint64_t* n) {
+    if (!b || !n) { yh_set_error("null argument"); return YH_ERR_INVALID_ARG; }
+    *n = b->m.size();
+    return YH_OK;
+}
+
+int yh_sig_meta_paths(const yh_sig_meta* b, uint64_t* path_offsets, char* paths) {
+    if (!b || !path_offsets) { yh_set_error("null argument"); return YH_ERR_INVALID_ARG; }
+    uint64_t at = 0;
+    for (size_t i = 0; i < b->m.size(); ++i) {
+        const std::string& r = i < b->rel_paths.size() ? b->rel_paths[i] : std::string();
+        path_offsets[i] = at;
+        if (paths) memcpy(paths + at, r.data(), r.size());
+        at += r.size();
+    }
+    path_offsets[b->m.size()] = at;
+    return YH_OK;
+}
+
+// ---- a sourmash .zip database in ONE pass (`yacht train`: make_training_data_from_sketches.py:107-133, utils.py:201-221, :499-509) ----
+namespace {
+
+struct ZipEntry {
+    std::string name;
+    uint16_t method = 0;
+    uint64_t comp = 0, uncomp = 0, lho = 0;
+};
+inline uint16_t rd16(const unsigned char* p) { return (uint16_t)(p[0] | (p[1] << 8)); }
+inline uint32_t rd32(const unsigned char* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+inline uint64_t rd64(const unsigned char* p) { return (uint64_t)rd32(p) | ((uint64_t)rd32(p + 4) << 32); }
+
+bool pread_all(int fd, void* buf, size_t n, uint64_t off) {
+    char* q = (char*)buf;
+    while (n) {
+        const ssize_t got = pread(fd, q, n, (off_t)off);
+        if (got <= 0) return false;
+        q += got; off += (uint64_t)got; n -= (size_t)got;
+    }
+    return true;
+}
+
+// the central directory (zip64 too: a GTDB database has more than 65 535 members)
+bool zip_directory(int fd, uint64_t fsize, std::vector<ZipEntry>* out, std::string* err) {
+    const uint64_t tail = std::min<uint64_t>(fsize, 65557 + 20);
+    std::vector<unsigned char> buf(tail);
+    if (tail < 22 || !pread_all(fd, buf.data(), tail, fsize - tail)) { *err = "not a zip archive (too short)"; return false; }
+    long at = -1;
+    for (long i = (long)tail - 22; i >= 0; --i)
+        if (rd32(&buf[i]) == 0x06054b50u) { at = i; break; }
+    if (at < 0) { *err = "not a zip archive (no end-of-central-directory record)"; return false; }
+    uint64_t n = rd16(&buf[at + 10]), cd_size = rd32(&buf[at + 12]), cd_off = rd32(&buf[at + 16]);
+    if (n == 0xffffu || cd_size == 0xffffffffu || cd_off == 0xffffffffu) {
+        if (at < 20 || rd32(&buf[at - 20]) != 0x07064b50u) { *err = "zip64 locator missing"; return false; }
+        const uint64_t z64 = rd64(&buf[at - 20 + 8]);
+        unsigned char rec[56];
+        if (z64 + 56 > fsize || !pread_all(fd, rec, 56, z64) || rd32(rec) != 0x06064b50u) { *err = "bad zip64 end-of-central-directory record"; return false; }
+        n = rd64(rec + 32);
+        cd_size = rd64(rec + 40);
+        cd_off = rd64(rec + 48);
+    }
+    if (cd_off + cd_size > fsize) { *err = "central directory outside the file"; return false; }
+    std::vector<unsigned char> cd(cd_size);
+    if (cd_size && !pread_all(fd, cd.data(), cd_size, cd_off)) { *err = "cannot read the central directory"; return false; }
+    out->clear();
+    out->reserve(n);
+    uint64_t p = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        if (p + 46 > cd_size || rd32(&cd[p]) != 0x02014b50u) { *err = "bad central directory entry"; return false; }
+        ZipEntry e;
+        e.method = rd16(&cd[p + 10]);
+        e.comp = rd32(&cd[p + 20]);
+        e.uncomp = rd32(&cd[p + 24]);
+        const uint16_t nlen = rd16(&cd[p + 28]), xlen = rd16(&cd[p + 30]), clen = rd16(&cd[p + 32]);
+        e.lho = rd32(&cd[p + 42]);
+        if (p + 46 + nlen + xlen + clen > cd_size) { *err = "bad central directory entry"; return false; }
+        e.name.assign((const char*)&cd[p + 46], nlen);
+        // zip64 extra field: the 8-byte forms of the fields that read 0xffffffff, in this order
+        for (uint64_t x = p + 46 + nlen, xe = x + xlen; x + 4 <= xe;) {
+            const uint16_t id = rd16(&cd[x]), sz = rd16(&cd[x + 2]);
+            if (id == 0x0001u) {
+                uint64_t q = x + 4;
+                if (e.uncomp == 0xffffffffu && q + 8 <= xe) { e.uncomp = rd64(&cd[q]); q += 8; }
+                if (e.comp == 0xffffffffu && q + 8 <= xe) { e.comp = rd64(&cd[q]); q += 8; }
+                if (e.lho == 0xffffffffu && q + 8 <= xe) { e.lho = rd64(&cd[q]); q += 8; }
+            }
+            x += 4 + (uint64_t)sz;
+        }
+        out->push_back(std::move(e));
+        p += 46 + (uint64_t)nlen + xlen + clen;
+    }
+    return true;
+}
+
+// the bytes of one member (stored or deflated)
+bool zip_member(int fd, uint64_t fsize, const ZipEntry& e, std::string* out) {
+    unsigned char lh[30];
+    if (e.lho + 30 > fsize || !pread_all(fd, lh, 30, e.lho) || rd32(lh) != 0x04034b50u) return false;
+    const uint64_t data = e.lho + 30 + rd16(lh + 26) + rd16(lh + 28);
+    if (data + e.comp > fsize) return false;
+    if (e.method == 0) {
+        out->resize(e.comp);
+        return e.comp == 0 || pread_all(fd, &(*out)[0], e.comp, data);
+    }
+    if (e.method != 8) return false;
+    std::string packed(e.comp, '\0');
+    if (e.comp && !pread_all(fd, &packed[0], e.comp, data)) return false;
+    out->resize(e.uncomp);
+    z_stream z;
+    memset(&z, 0, sizeof z);
+    if (inflateInit2(&z, -15) != Z_OK) return false;
+    z.next_in = (Bytef*)packed.data();
+    z.avail_in = (uInt)packed.size();
+    z.next_out = (Bytef*)(out->empty() ? nullptr : &(*out)[0]);
+    z.avail_out = (uInt)out->size();
+    const int rc = inflate(&z, Z_FINISH);
+    const bool ok = rc == Z_STREAM_END && z.avail_out == 0;
+    inflateEnd(&z);
+    return ok;
+}
+
+// a member's path must stay inside the working directory
+bool safe_member_name(const std::string& n) {
+    if (n.empty() || n[0] == '/' || n.find('\\') != std::string::npos) return false;
+    size_t i = 0;
+    while (i <= n.size()) {
+        const size_t j = std::min(n.find('/', i), n.size());
+        if (j - i == 2 && n[i] == '.' && n[i + 1] == '.') return false;
+        i = j + 1;
+    }
+    return true;
+}
+bool ends_with(const std::string& s, const char* suf) {
+    const size_t k = strlen(suf);
+    return s.size() >= k && s.compare(s.size() - k, k, suf) == 0;
+}
+void mkdirs(const std::string& dir) {
+    for (size_t i = 1; i <= dir.size(); ++i)
+        if (i == dir.size() || dir[i] == '/') (void)mkdir(dir.substr(0, i).c_str(), 0777);
+}
+
+}  // namespace
+
+int yh_zip_sig_ingest(const char* zip_path, const char* out_dir, int ksize, int threads, yh_sig_meta** out) {
+    if (!zip_path || !out) { yh_set_error("null argument"); return YH_ERR_INVALID_ARG; }
+    *out = nullptr;
+    const int fd = open(zip_path, O_RDONLY);
+    if (fd < 0) { yh_set_error("cannot open %s", zip_path); return YH_ERR_INVALID_ARG; }
+    struct stat sb;
+    if (fstat(fd, &sb) != 0) { close(fd); yh_set_error("cannot stat %s", zip_path); return YH_ERR_INVALID_ARG; }
+    const uint64_t fsize = (uint64_t)sb.st_size;
+    std::vector<ZipEntry> dir;
+    std::string err;
+    if (!zip_directory(fd, fsize, &dir, &err)) { close(fd); yh_set_error("%s: %s", zip_path, err.c_str()); return YH_ERR_INVALID_ARG; }
+    for (const ZipEntry& e : dir)
+        if (!safe_member_name(e.name)) { close(fd); yh_set_error("archive member outside the working directory: %s", e.name.c_str()); return YH_ERR_INVALID_ARG; }
+    // the signature members, in central-directory order: "signatures/<x>.sig[.gz]"
+    std::vector<uint64_t> sig_of(dir.size(), ~(uint64_t)0);
+    uint64_t n_sig = 0;
+    for (size_t i = 0; i < dir.size(); ++i) {
+        const std::string& n = dir[i].name;
+        if (n.compare(0, 11, "signatures/") == 0 && (ends_with(n, ".sig") || ends_with(n, ".sig.gz"))) sig_of[i] = n_sig++;
+    }
+    yh_sig_meta* b = new (std::nothrow) yh_sig_meta;
+    if (!b) { close(fd); yh_set_error("out of host memory"); return YH_ERR_OOM; }
+    b->m.resize(n_sig);
+    b->rel_paths.resize(n_sig);
+    b->kept = true;
+    b->mins.resize(n_sig);
+    b->mins_status.assign(n_sig, (uint8_t)yh_sig::READ_CANNOT_OPEN);
+    const std::string root = out_dir ? std::string(out_dir) : std::string();
+    if (out_dir) {  // every directory once, before the threads start (directory entries and the parents of the members)
+        mkdirs(root);
+        std::string last;
+        for (const ZipEntry& e : dir) {
+            const size_t slash = e.name.rfind('/');
+            const std::string d = slash == std::string::npos ? std::string() : e.name.substr(0, slash);
+            if (!d.empty() && d != last) { mkdirs(root + "/" + d); last = d; }
+        }
+    }
+    std::atomic<bool> oom{false};
+    std::atomic<int> io_failed{0};
+    for_each_threaded(dir.size(), threads, [&](uint64_t i) {
+        try {
+            const ZipEntry& e = dir[i];
+            if (ends_with(e.name, "/")) return;
+            const uint64_t k = sig_of[i];
+            if (k == ~(uint64_t)0 && !out_dir) return;  // (not a signature, nothing to write: not read at all)
+            std::string bytes, plain;
+            if (!zip_member(fd, fsize, e, &bytes)) {
+                io_failed.store(1);
+                if (k != ~(uint64_t)0) b->m[k].status = yh_sig::META_CANNOT_OPEN;
+                return;
+            }
+            std::string out_name = e.name;
+            const std::string* text = &bytes;
+            if (ends_with(e.name, ".sig.gz") && gunzip_buffer(bytes, &plain)) {  // (one that does not inflate stays as it is)
+                out_name.resize(out_name.size() - 3);
+                text = &plain;
+            }
+            if (out_dir) {
+                const std::string path = root + "/" + out_name;
+                FILE* f = fopen(path.c_str(), "wb");
+                const bool ok = f && fwrite(text->data(), 1, text->size(), f) == text->size();
+                if (f && fclose(f) != 0) io_failed.store(1);
+                if (!ok) io_failed.store(1);
+            }
+            if (k == ~(uint64_t)0) return;
+            b->rel_paths[k] = out_name;
+            int st = 0;
+            b->mins[k] = yh_sig::mins_from_text(*text, &st);  // what the train core reads from the file (record 0, signature 0)
+            b->mins_status[k] = (uint8_t)st;
+            b->m[k] = yh_sig::parse_meta(*text, ksize);
+        } catch (...) {
+            oom.store(true);
+        }
+    });
+    close(fd);
+    if (oom.load()) { delete b; yh_set_error("out of host memory while reading %s", zip_path); return YH_ERR_OOM; }
+    if (io_failed.load()) { delete b; yh_set_error("%s: a member could not be read, inflated or written", zip_path); return YH_ERR_INVALID_ARG; }
+    *out = b;
     return YH_OK;
 }
 

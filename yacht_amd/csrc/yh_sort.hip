@@ -1,0 +1,472 @@
+// yh_sort.hip — the sort under T2 (compute_index_from_sketches, src/cpp/main.cpp:215-246), hand-written for gfx950.
+//
+// The reference builds `hash_index[h] = [ids containing h]` by inserting every hash of every sketch into a node-based
+// hash map, one thread (12.1 of 16.6 s in SURVEY.md's probe).  Here: all (hash, reference) pairs of the database sorted by
+// (hash, reference), from which the index is cut by run detection (yh_build.hip: k_idx_*).  Rounds 1-3 called
+// rocprim::radix_sort_pairs for it: an LSD radix sort that does not know anything about the keys -- 6-7 passes over the
+// 12-byte pairs, 62 % of `yacht train`'s device time.  FracMinHash hashes are UNIFORM below max_hash, so a linear function
+// of the key is a perfect splitter and the sort becomes distribution + a sort in LDS:
+//
+//   bucket(h) = floor(h * NB / (max_hash + 1))     monotone; NB = P1 * P2 buckets of ~FILL pairs each
+//   k_part<1>   every tile of 4 096 pairs: LDS histogram over the P1 first-level bins (bucket / P2), ONE global atomic per
+//               (tile, bin) reserves the tile's run in the bin's region, the tile is put in bin order in LDS and leaves as
+//               runs of consecutive addresses (coalesced stores; without the staging: one isolated 12-byte store per pair)
+//   k_part<2>   the same over every first-level region, bin = bucket % P2
+//   k_bucket_sort   one workgroup per bucket (<= CAP pairs, in LDS): a counting sort over S fine slots of the bucket's key
+//               range (again linear in the key: ~0.6 pairs per slot), then every pair ranks itself among the few pairs
+//               of its slot by (hash, reference) -- equal hashes end up in ascending reference order, what a stable sort
+//               of the CSR would give -- and the bucket leaves in order, coalesced, at its exact place of the output
+//
+// Three passes over the pairs (read 12 B + write 12 B each) instead of 6-7, no global merge.  Every capacity is checked on
+// the device: keys that are not uniform enough (a region or a bucket overflows, a slot holds hundreds of pairs: a hash held
+// by hundreds of references) raise a flag and the caller sorts with rocPRIM instead -- slower, equally exact.
+// The first level can be fed in pieces (yh_psort_add): the chunks of a host database are distributed while the next
+// chunk crosses PCIe, and only levels two and three remain behind the last byte (yh_build_upload_sorted).
+#include "yh_common.h"
+#include "yh_sort.h"
+
+#include <algorithm>
+
+namespace {
+
+constexpr u32 PART_TILE = 4096;      // pairs per workgroup of the distribution passes
+constexpr u32 PART_THREADS = 512;
+constexpr u32 PART_ITEMS = PART_TILE / PART_THREADS;
+constexpr u32 PART_MAX_BINS = 1024;  // bins per level (LDS histogram)
+constexpr u32 BKT_CAP = 4096;        // pairs a final bucket may hold
+constexpr u32 BKT_FILL = 2560;       // ... and holds on average (uniform keys: sd ~51; clustered references ~3x that)
+constexpr u32 BKT_THREADS = 1024;
+constexpr u32 BKT_ITEMS = BKT_CAP / BKT_THREADS;
+constexpr u32 BKT_SLOTS = 4096;      // fine slots of the counting sort inside a bucket (= 1 << BKT_SLOT_BITS)
+constexpr u32 SLOT_MAX = 256;        // pairs of one slot a pair ranks itself against; more: not this sort's input
+
+constexpr u32 BKT_SLOT_BITS = 12;
+// The FINE slot of a hash -- floor(h * NB * S / (max_hash + 1)), S = 2^BKT_SLOT_BITS slots per bucket -- is the one linear
+// function everything is cut from: bucket = fine >> BKT_SLOT_BITS, slot inside the bucket = fine & (S - 1).  (A multiplier for
+// the BUCKET index alone has too few significant bits at a few thousand buckets -- 38 281 for configs[3] -- and disagrees
+// with the fine index at the buckets' edges: 6 % of the pairs landed in a neighbour's slot range.)
+__device__ __forceinline__ u32 fine_of(u64 h, u32 lsh, u64 mul_fine) { return (u32)__umul64hi(h << lsh, mul_fine); }
+__device__ __forceinline__ u32 bucket_of(u64 h, u32 lsh, u64 mul_fine) { return fine_of(h, lsh, mul_fine) >> BKT_SLOT_BITS; }
+
+// block-wide exclusive scan over `n` (<= 2 * blockDim.x ... any multiple handled by the caller) LDS words, in place;
+// returns nothing: arr[i] = sum of arr[0..i).  blockDim.x threads, n <= ITEMS * blockDim.x with ITEMS consecutive words per thread.
+template <u32 ITEMS>
+__device__ __forceinline__ void block_scan_inplace(u32* arr, u32 n, u32* wave_tot /* >= 17 words */) {
+    const u32 tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6, nw = blockDim.x >> 6;
+    u32 v[ITEMS];
+    u32 sum = 0;
+#pragma unroll
+    for (u32 k = 0; k < ITEMS; ++k) {
+        const u32 i = tid * ITEMS + k;
+        v[k] = i < n ? arr[i] : 0u;
+        sum += v[k];
+    }
+    u32 inc = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const u32 t = (u32)__shfl_up((int)inc, d);
+        if (lane >= (u32)d) inc += t;
+    }
+    if (lane == 63) wave_tot[wv] = inc;
+    __syncthreads();
+    if (wv == 0) {
+        const u32 w = lane < nw ? wave_tot[lane] : 0u;
+        u32 winc = w;
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) {
+            const u32 t = (u32)__shfl_up((int)winc, d);
+            if (lane >= (u32)d) winc += t;
+        }
+        if (lane < nw) wave_tot[lane] = winc - w;
+    }
+    __syncthreads();
+    u32 run = wave_tot[wv] + inc - sum;
+#pragma unroll
+    for (u32 k = 0; k < ITEMS; ++k) {
+        const u32 i = tid * ITEMS + k;
+        if (i < n) arr[i] = run;
+        run += v[k];
+    }
+    __syncthreads();
+}
+
+struct PartArgs {
+    const u64* in_k;
+    const u32* in_v;
+    u64 n_in;             // pairs of this call's input (level 1; level 2 without in_cnt: ONE input segment of n_in pairs)
+    u64 cap_in;           // level 2: capacity of an input region
+    const u32* in_cnt;    // level 2: pairs in every input region
+    u32 tiles_per_seg;    // level 2: workgroups per input region
+    u64 mul;              // fine slot of h = umulhi(h << lsh, mul); bucket = fine >> BKT_SLOT_BITS
+    u32 lsh, P2, nbins;
+    u64* out_k;
+    u32* out_v;
+    u64 cap_out;
+    u32* out_cnt;
+    u32* flags;           // [0] |= 1: a region overflowed
+};
+
+template <int LEVEL>
+__global__ void __launch_bounds__(PART_THREADS) k_part(const PartArgs a) {
+    __shared__ u64 skey[PART_TILE];
+    __shared__ u32 sval[PART_TILE];
+    __shared__ u16 sbin[PART_TILE];
+    __shared__ u32 hist[PART_MAX_BINS], loc[PART_MAX_BINS], gbase[PART_MAX_BINS];
+    __shared__ u32 wtot[17];
+    const u32 tid = threadIdx.x;
+    u64 seg_n, in_base;
+    u32 seg = 0, t;
+    if (LEVEL == 1) {
+        seg_n = a.n_in;
+        in_base = 0;
+        t = blockIdx.x;
+    } else {
+        seg = blockIdx.x / a.tiles_per_seg;
+        t = blockIdx.x % a.tiles_per_seg;
+        seg_n = a.in_cnt ? min((u64)a.in_cnt[seg], a.cap_in) : a.n_in;
+        in_base = (u64)seg * a.cap_in;
+    }
+    const u64 t0 = (u64)t * PART_TILE;
+    if (t0 >= seg_n) return;  // (workgroup-uniform)
+    const u32 tile_n = (u32)min((u64)PART_TILE, seg_n - t0);
+    for (u32 b = tid; b < a.nbins; b += PART_THREADS) hist[b] = 0;
+    __syncthreads();
+    u64 key[PART_ITEMS];
+    u32 val[PART_ITEMS], bin[PART_ITEMS], rank[PART_ITEMS];
+#pragma unroll
+    for (u32 k = 0; k < PART_ITEMS; ++k) {
+        const u32 i = k * PART_THREADS + tid;
+        bin[k] = 0xffffffffu;
+        if (i < tile_n) {
+            key[k] = a.in_k[in_base + t0 + i];
+            val[k] = a.in_v[in_base + t0 + i];
+            const u32 b = bucket_of(key[k], a.lsh, a.mul);
+            bin[k] = LEVEL == 1 ? b / a.P2 : b % a.P2;
+            if (bin[k] >= a.nbins) bin[k] = a.nbins - 1;  // (keys above max_hash: cannot happen after validation; stay in range)
+            rank[k] = atomicAdd(&hist[bin[k]], 1u);
+        }
+    }
+    __syncthreads();
+    // reserve the tile's run in every bin's region, then turn the histogram into offsets inside the tile
+    for (u32 b = tid; b < a.nbins; b += PART_THREADS) {
+        const u32 c = hist[b];
+        u32 g = 0;
+        if (c) {
+            const u32 region = LEVEL == 1 ? b : seg * a.P2 + b;
+            g = atomicAdd(&a.out_cnt[region], c);
+            if ((u64)g + c > a.cap_out) atomicOr(a.flags, 1u);
+        }
+        gbase[b] = g;
+        loc[b] = c;
+    }
+    __syncthreads();
+    block_scan_inplace<(PART_MAX_BINS + PART_THREADS - 1) / PART_THREADS>(loc, a.nbins, wtot);
+#pragma unroll
+    for (u32 k = 0; k < PART_ITEMS; ++k)
+        if (bin[k] != 0xffffffffu) {
+            const u32 s = loc[bin[k]] + rank[k];
+            skey[s] = key[k];
+            sval[s] = val[k];
+            sbin[s] = (u16)bin[k];
+        }
+    __syncthreads();
+#pragma unroll
+    for (u32 k = 0; k < PART_ITEMS; ++k) {
+        const u32 s = k * PART_THREADS + tid;
+        if (s < tile_n) {
+            const u32 b = sbin[s];
+            const u64 at = (u64)gbase[b] + (s - loc[b]);
+            if (at < a.cap_out) {
+                const u64 region = LEVEL == 1 ? b : (u64)seg * a.P2 + b;
+                a.out_k[region * a.cap_out + at] = skey[s];
+                a.out_v[region * a.cap_out + at] = sval[s];
+            }
+        }
+    }
+}
+
+// exclusive scan of min(cnt[b], cap) over the buckets into 64-bit offsets (single workgroup); flags |= 2 when a bucket is over
+__global__ void __launch_bounds__(1024) k_bucket_offsets(const u32* __restrict__ cnt, u64 nb, u32 cap, u64* __restrict__ off,
+                                                         u32* __restrict__ flags) {
+    __shared__ u32 lds[1024];
+    __shared__ u32 wtot[17];
+    u64 carry = 0;
+    for (u64 base = 0; base < nb; base += 1024) {
+        const u64 b = base + threadIdx.x;
+        u32 c = b < nb ? cnt[b] : 0u;
+        if (c > cap) { atomicOr(flags, 2u); c = cap; }
+        lds[threadIdx.x] = c;
+        __syncthreads();
+        block_scan_inplace<1>(lds, 1024, wtot);
+        if (b < nb) off[b] = carry + lds[threadIdx.x];
+        __syncthreads();
+        // the block's total: last exclusive value + last count
+        if (threadIdx.x == 1023) wtot[16] = lds[1023] + c;
+        __syncthreads();
+        carry += wtot[16];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) off[nb] = carry;
+}
+
+struct BucketArgs {
+    const u64* in_k;
+    const u32* in_v;
+    const u32* cnt;
+    const u64* off;
+    u64 cap_in;
+    u64 mul_fine;  // fine slot of h = umulhi(h << lsh, mul_fine); the low BKT_SLOT_BITS bits = the slot inside the bucket
+    u32 lsh;
+    u64* out_k;
+    u32* out_v;
+    u32* flags;    // [0] |= 4: a slot held more than SLOT_MAX pairs
+};
+
+__global__ void __launch_bounds__(BKT_THREADS) k_bucket_sort(const BucketArgs a) {
+    __shared__ u64 skey[BKT_CAP];
+    __shared__ u32 sval[BKT_CAP];
+    __shared__ u32 start[BKT_SLOTS];  // counts, then offsets
+    __shared__ u32 wtot[17];
+    const u32 tid = threadIdx.x;
+    const u64 b = blockIdx.x;
+    const u32 n = min(a.cnt[b], BKT_CAP);
+    if (n == 0) return;
+    for (u32 i = tid; i < BKT_SLOTS; i += BKT_THREADS) start[i] = 0;
+    __syncthreads();
+    u64 key[BKT_ITEMS];
+    u32 val[BKT_ITEMS], slot[BKT_ITEMS], rank[BKT_ITEMS];
+    const u64 in_base = b * a.cap_in;
+#pragma unroll
+    for (u32 k = 0; k < BKT_ITEMS; ++k) {
+        const u32 i = k * BKT_THREADS + tid;
+        slot[k] = 0xffffffffu;
+        if (i < n) {
+            key[k] = a.in_k[in_base + i];
+            val[k] = a.in_v[in_base + i];
+            slot[k] = fine_of(key[k], a.lsh, a.mul_fine) & (BKT_SLOTS - 1u);
+            rank[k] = atomicAdd(&start[slot[k]], 1u);
+        }
+    }
+    __syncthreads();
+    // a crowded slot = many pairs with (nearly) the same hash: the quadratic ranking below is not made for that
+    u32 cnt_mine[BKT_ITEMS];
+#pragma unroll
+    for (u32 k = 0; k < BKT_ITEMS; ++k) cnt_mine[k] = slot[k] != 0xffffffffu ? start[slot[k]] : 0u;
+    __syncthreads();
+    block_scan_inplace<BKT_SLOTS / BKT_THREADS>(start, BKT_SLOTS, wtot);
+    u32 pos[BKT_ITEMS];
+#pragma unroll
+    for (u32 k = 0; k < BKT_ITEMS; ++k)
+        if (slot[k] != 0xffffffffu) {
+            pos[k] = start[slot[k]] + rank[k];
+            skey[pos[k]] = key[k];
+            sval[pos[k]] = val[k];
+        }
+    __syncthreads();
+    bool crowded = false;
+#pragma unroll
+    for (u32 k = 0; k < BKT_ITEMS; ++k)
+        if (slot[k] != 0xffffffffu) {
+            const u32 s0 = start[slot[k]], c = cnt_mine[k];
+            u32 less = 0;
+            if (c > SLOT_MAX) {
+                crowded = true;
+            } else {
+                for (u32 q = s0; q < s0 + c; ++q) {
+                    const u64 kq = skey[q];
+                    less += (kq < key[k] || (kq == key[k] && sval[q] < val[k])) ? 1u : 0u;
+                }
+            }
+            pos[k] = s0 + less;
+        }
+    if (crowded) atomicOr(a.flags, 4u);
+    __syncthreads();
+#pragma unroll
+    for (u32 k = 0; k < BKT_ITEMS; ++k)
+        if (slot[k] != 0xffffffffu) {
+            skey[pos[k]] = key[k];
+            sval[pos[k]] = val[k];
+        }
+    __syncthreads();
+    const u64 out_base = a.off[b];
+    for (u32 i = tid; i < n; i += BKT_THREADS) {
+        a.out_k[out_base + i] = skey[i];
+        a.out_v[out_base + i] = sval[i];
+    }
+}
+
+static_assert(BKT_SLOTS == (1u << BKT_SLOT_BITS), "slots per bucket");
+u64 mul_for(u64 slots, u64 max_hash, unsigned bits) {
+    const unsigned __int128 num = (unsigned __int128)slots << bits;
+    const unsigned __int128 m = num / ((unsigned __int128)max_hash + 1);
+    return (u64)std::min<unsigned __int128>(m, ~(u64)0);
+}
+
+}  // namespace
+
+struct yh_psort {
+    u64 H = 0, max_hash = 0;
+    u64 NB = 0;
+    u32 P1 = 0, P2 = 0, lsh = 0;
+    u64 mul = 0, mul_fine = 0;
+    u64 cap1 = 0;
+    u64 fed = 0;
+    u64* k1 = nullptr;  // [P1][cap1] first-level regions
+    u32* v1 = nullptr;
+    u64* k2 = nullptr;  // [NB][BKT_CAP] buckets
+    u32* v2 = nullptr;
+    u32* cnt = nullptr;  // [P1] + [NB] + flags[4]
+    u64* off = nullptr;  // [NB + 1]
+};
+
+// Is this input one the distribution sort takes?  (A database of a few thousand hashes is one bucket; a key range narrower
+// than the number of fine slots cannot be spread: rocPRIM sorts those.)
+bool yh_psort_applicable(u64 H, u64 max_hash) {
+    static const bool off = [] { const char* e = yh_tune_env("YH_NO_PSORT"); return e && e[0] == '1'; }();
+    if (off || H == 0 || H > 0xfffffff0ull) return false;
+    const u64 NB = (H + BKT_FILL - 1) / BKT_FILL;
+    if (NB > (u64)PART_MAX_BINS * PART_MAX_BINS) return false;
+    // every bucket needs a key range of at least BKT_SLOTS values, or equal "slots" would pile up whatever the keys are
+    return max_hash / NB >= BKT_SLOTS || NB == 1;
+}
+
+void yh_psort_destroy(yh_db* db, yh_psort* s) {
+    if (!s) return;
+    yh_tfree(db, s->k1); yh_tfree(db, s->v1); yh_tfree(db, s->k2); yh_tfree(db, s->v2);
+    yh_tfree(db, s->cnt); yh_tfree(db, s->off);
+    delete s;
+}
+
+int yh_psort_begin(yh_db* db, u64 H, u64 max_hash, yh_psort** out) {
+    *out = nullptr;
+    yh_psort* s = new yh_psort();
+    s->H = H;
+    s->max_hash = max_hash;
+    const u64 nb = std::max<u64>((H + BKT_FILL - 1) / BKT_FILL, 1);
+    u32 p2 = 1;
+    while ((u64)p2 * p2 < nb) ++p2;
+    s->P2 = p2;
+    s->P1 = (u32)((nb + p2 - 1) / p2);
+    s->NB = (u64)s->P1 * s->P2;
+    unsigned bits = 1;
+    while (bits < 64 && (max_hash >> bits) != 0) ++bits;
+    s->lsh = 64 - bits;
+    s->mul_fine = mul_for(s->NB * BKT_SLOTS, max_hash, bits);
+    s->mul = s->mul_fine;  // (the distribution passes cut their bins from the same fine index)
+    // a first-level region: its share of uniform keys + 3 % + a tile (skewed keys overflow it and are sorted by rocPRIM instead)
+    s->cap1 = ((H / s->P1 + H / s->P1 / 32 + 2 * PART_TILE + 255) / 256) * 256;
+    hipError_t e = hipSuccess;
+    if (s->P1 > 1) {
+        if (e == hipSuccess) e = yh_tmalloc(db, (void**)&s->k1, s->P1 * s->cap1 * sizeof(u64));
+        if (e == hipSuccess) e = yh_tmalloc(db, (void**)&s->v1, s->P1 * s->cap1 * sizeof(u32));
+    }
+    if (e == hipSuccess) e = yh_tmalloc(db, (void**)&s->k2, s->NB * BKT_CAP * sizeof(u64));
+    if (e == hipSuccess) e = yh_tmalloc(db, (void**)&s->v2, s->NB * BKT_CAP * sizeof(u32));
+    if (e == hipSuccess) e = yh_tmalloc(db, (void**)&s->cnt, (s->P1 + s->NB + 4) * sizeof(u32));
+    if (e == hipSuccess) e = yh_tmalloc(db, (void**)&s->off, (s->NB + 1) * sizeof(u64));
+    if (e == hipSuccess) e = hipMemsetAsync(s->cnt, 0, (s->P1 + s->NB + 4) * sizeof(u32), db->stream);
+    if (e != hipSuccess) {
+        yh_set_error("distribution sort: allocation failed: %s", hipGetErrorString(e));
+        yh_psort_destroy(db, s);
+        return e == hipErrorOutOfMemory ? YH_ERR_OOM : YH_ERR_HIP;
+    }
+    *out = s;
+    return YH_OK;
+}
+
+// first level for n more pairs (any order of calls; on the handle's stream)
+int yh_psort_add(yh_db* db, yh_psort* s, const u64* d_keys, const u32* d_vals, u64 n) {
+    if (n == 0) return YH_OK;
+    s->fed += n;
+    u32* cnt1 = s->cnt;
+    u32* cnt2 = s->cnt + s->P1;
+    u32* flags = s->cnt + s->P1 + s->NB;
+    PartArgs a{};
+    a.in_k = d_keys;
+    a.in_v = d_vals;
+    a.n_in = n;
+    a.mul = s->mul;
+    a.lsh = s->lsh;
+    a.flags = flags;
+    const u32 tiles = (u32)((n + PART_TILE - 1) / PART_TILE);
+    if (s->P1 > 1) {
+        a.P2 = s->P2;
+        a.nbins = s->P1;
+        a.out_k = s->k1;
+        a.out_v = s->v1;
+        a.cap_out = s->cap1;
+        a.out_cnt = cnt1;
+        k_part<1><<<tiles, PART_THREADS, 0, db->stream>>>(a);
+    } else {  // one first-level bin: straight into the buckets (bin = bucket % P2 = bucket)
+        a.P2 = s->P2;
+        a.nbins = s->P2;
+        a.out_k = s->k2;
+        a.out_v = s->v2;
+        a.cap_out = BKT_CAP;
+        a.out_cnt = cnt2;
+        a.in_cnt = nullptr;  // (one input segment of n_in pairs)
+        a.cap_in = n;
+        a.tiles_per_seg = tiles;
+        k_part<2><<<tiles, PART_THREADS, 0, db->stream>>>(a);
+    }
+    YH_HIP(hipGetLastError());
+    return YH_OK;
+}
+
+// second level + the sort of every bucket; the sorted pairs land in d_keys_out / d_vals_out (H entries).  *took_it = false:
+// the keys were not this sort's input (a capacity was exceeded) -- nothing usable was written, sort another way.
+int yh_psort_finish(yh_db* db, yh_psort* s, u64* d_keys_out, u32* d_vals_out, bool* took_it) {
+    *took_it = false;
+    u32* cnt1 = s->cnt;
+    u32* cnt2 = s->cnt + s->P1;
+    u32* flags = s->cnt + s->P1 + s->NB;
+    if (s->P1 > 1) {
+        PartArgs a{};
+        a.in_k = s->k1;
+        a.in_v = s->v1;
+        a.cap_in = s->cap1;
+        a.in_cnt = cnt1;
+        a.tiles_per_seg = (u32)((s->cap1 + PART_TILE - 1) / PART_TILE);
+        a.mul = s->mul;
+        a.lsh = s->lsh;
+        a.P2 = s->P2;
+        a.nbins = s->P2;
+        a.out_k = s->k2;
+        a.out_v = s->v2;
+        a.cap_out = BKT_CAP;
+        a.out_cnt = cnt2;
+        a.flags = flags;
+        const u64 grid = (u64)s->P1 * a.tiles_per_seg;
+        if (grid >> 31) { yh_set_error("distribution sort: grid too large"); return YH_ERR_UNSUPPORTED; }
+        k_part<2><<<(u32)grid, PART_THREADS, 0, db->stream>>>(a);
+    }
+    k_bucket_offsets<<<1, 1024, 0, db->stream>>>(cnt2, s->NB, BKT_CAP, s->off, flags);
+    BucketArgs b{};
+    b.in_k = s->k2;
+    b.in_v = s->v2;
+    b.cnt = cnt2;
+    b.off = s->off;
+    b.cap_in = BKT_CAP;
+    b.mul_fine = s->mul_fine;
+    b.lsh = s->lsh;
+    b.out_k = d_keys_out;
+    b.out_v = d_vals_out;
+    b.flags = flags;
+    k_bucket_sort<<<(u32)s->NB, BKT_THREADS, 0, db->stream>>>(b);
+    YH_HIP(hipGetLastError());
+    u32 hflags[4] = {0, 0, 0, 0};
+    u64 total = 0;
+    YH_HIP(hipMemcpyAsync(hflags, flags, 3 * sizeof(u32), hipMemcpyDeviceToHost, db->stream));
+    YH_HIP(hipMemcpyAsync(&total, s->off + s->NB, sizeof(u64), hipMemcpyDeviceToHost, db->stream));
+    YH_HIP(hipStreamSynchronize(db->stream));
+    *took_it = hflags[0] == 0 && total == s->fed;
+    static const bool trace = [] { const char* e = yh_tune_env("YH_TRACE_BUILD"); return e && e[0] == '1'; }();
+    if (trace || !*took_it) {
+        // (a refusal is worth a line even without the trace switch: the caller falls back to a sort three times as slow)
+        static const bool say = [] { const char* e = yh_tune_env("YH_TRACE_SORT"); return e && e[0] == '1'; }();
+        if (trace || say)
+            fprintf(stderr, "[yh sort] H %llu  P1 %u x P2 %u = %llu buckets  cap1 %llu  flags %u (1 region, 2 bucket, 4 slot)  sorted %llu of %llu -> %s\n",
+                    (u64)s->H, s->P1, s->P2, (u64)s->NB, (u64)s->cap1, hflags[0], total, (u64)s->fed, *took_it ? "taken" : "REFUSED");
+    }
+    return YH_OK;
+}

@@ -41,10 +41,12 @@ BATCH_ROW_DTYPE = np.dtype([("sample", np.uint32), ("ref", np.uint32), ("overlap
                             ("n_match", np.uint32)])
 
 
-def pack_sample(sample, out: Optional[np.ndarray] = None) -> np.ndarray:
+def pack_sample(sample, out: Optional[np.ndarray] = None, threads: int = 0) -> np.ndarray:
     """A strictly ascending uint64 sketch as the packed bytes yh_run_submit_packed uploads (~4.7 bytes per hash;
     include/yacht_hip.h).  Host only: no device, any thread.  `out`: a uint8 buffer to pack into (e.g. a
-    PinnedArray's array, so that the upload overlaps the kernels); the returned array is the used part of it."""
+    PinnedArray's array, so that the upload overlaps the kernels); the returned array is the used part of it.
+    `threads`: host threads of this one call (0: up to 8 for a large sample; 1: the calling thread only -- for callers
+    that pack many samples at once from threads of their own: the C call releases the GIL)."""
     lib = _lib.load()
     sample = _as_u64(sample)
     need = int(lib.yh_sample_pack_bound(sample.size))
@@ -52,7 +54,7 @@ def pack_sample(sample, out: Optional[np.ndarray] = None) -> np.ndarray:
         out = np.empty(need, dtype=np.uint8)
     assert out.dtype == np.uint8 and out.flags.c_contiguous
     n = C.c_uint64(0)
-    _lib.check(lib.yh_sample_pack(_ptr(sample), sample.size, _ptr(out), out.size, C.byref(n)))
+    _lib.check(lib.yh_sample_pack_threads(_ptr(sample), sample.size, _ptr(out), out.size, C.byref(n), int(threads)))
     return out[: int(n.value)]
 
 

@@ -123,20 +123,22 @@ def get_organisms_with_nonzero_overlap(manifest: pd.DataFrame, sample_file: str,
     """Names of the manifest's organisms that share at least one hash with the sample
     (reference :30-113; there: `sourmash scripts multisearch ... -t 0`, `match_name` column)."""
     logger.info("Unzipping the sample signature zip file")
-    with zipfile.ZipFile(sample_file, "r") as z:
-        z.extractall(path_to_sample_temp_dir)
-    gz = glob.glob(f"{path_to_sample_temp_dir}/signatures/*.sig.gz")
-    logger.info(f"Decompressing {len(gz)} .sig.gz files using {num_threads} threads.")
-    decompress_all_sig_files(gz, num_threads)
+    with phases.phase("unpack_sample"):
+        with zipfile.ZipFile(sample_file, "r") as z:
+            z.extractall(path_to_sample_temp_dir)
+        gz = glob.glob(f"{path_to_sample_temp_dir}/signatures/*.sig.gz")
+        logger.info(f"Decompressing {len(gz)} .sig.gz files using {num_threads} threads.")
+        decompress_all_sig_files(gz, num_threads)
 
     # the same two list files the reference hands to multisearch (kept for tooling that reads them)
-    sample_sigs = [os.path.join(path_to_sample_temp_dir, "signatures", f)
-                   for f in os.listdir(os.path.join(path_to_sample_temp_dir, "signatures"))]
-    pd.DataFrame(sample_sigs).to_csv(os.path.join(path_to_sample_temp_dir, "sample_sig_file.txt"), header=False,
-                                     index=False)
-    organism_sigs = [os.path.join(path_to_genome_temp_dir, "signatures", m + SIG_SUFFIX) for m in manifest["md5sum"]]
-    pd.DataFrame(organism_sigs).to_csv(os.path.join(path_to_sample_temp_dir, "organism_sig_file.txt"), header=False,
-                                       index=False)
+    with phases.phase("write_list_files"):
+        sample_sigs = [os.path.join(path_to_sample_temp_dir, "signatures", f)
+                       for f in os.listdir(os.path.join(path_to_sample_temp_dir, "signatures"))]
+        pd.DataFrame(sample_sigs).to_csv(os.path.join(path_to_sample_temp_dir, "sample_sig_file.txt"), header=False,
+                                         index=False)
+        organism_sigs = [os.path.join(path_to_genome_temp_dir, "signatures", m + SIG_SUFFIX) for m in manifest["md5sum"]]
+        pd.DataFrame(organism_sigs).to_csv(os.path.join(path_to_sample_temp_dir, "organism_sig_file.txt"), header=False,
+                                           index=False)
 
     # parsed_sample: the caller's already-parsed signature of this very file (hypothesis_recovery holds it); a
     # 10^6-hash sketch takes 0.2-0.3 s to parse and the archive has been read once already
@@ -159,24 +161,26 @@ def get_organisms_with_nonzero_overlap(manifest: pd.DataFrame, sample_file: str,
                 overlap, n_excl, n_match = db.run_counts(mins)  # the fused step: R1 + R2 for the subset overlap > 0
             _LAST_RUN.clear()
             _LAST_RUN.update(db=db, mins=mins, overlap=overlap, n_excl=n_excl, n_match=n_match)
-            nq = len(q.minhash)
-            q_name, q_md5 = q.name, q.md5sum()  # (the md5 of a 10^6-hash sketch takes ~30 ms: once, not once per row)
-            hit = np.flatnonzero(overlap)
-            ov = overlap[hit].astype(np.float64)
-            sz = np.asarray(sizes, dtype=np.float64)[hit]
-            cont = ov / nq if nq else np.zeros_like(ov)
-            for k, j in enumerate(hit.tolist()):
-                rows.append((q_name, q_md5, names[j], md5s[j], float(cont[k]), float(max(cont[k], ov[k] / sz[k])),
-                             float(ov[k] / (nq + sz[k] - ov[k])), int(ov[k])))
+            with phases.phase("multisearch_rows"):
+                nq = len(q.minhash)
+                q_name, q_md5 = q.name, q.md5sum()  # (the md5 of a 10^6-hash sketch takes ~30 ms: once, not once per row)
+                hit = np.flatnonzero(overlap)
+                ov = overlap[hit].astype(np.float64)
+                sz = np.asarray(sizes, dtype=np.float64)[hit]
+                cont = ov / nq if nq else np.zeros_like(ov)
+                for k, j in enumerate(hit.tolist()):
+                    rows.append((q_name, q_md5, names[j], md5s[j], float(cont[k]), float(max(cont[k], ov[k] / sz[k])),
+                                 float(ov[k] / (nq + sz[k] - ov[k])), int(ov[k])))
     if not rows:
         open(result_csv, "w").close()
         print("ERROR: Multisearch file is empty. Likely there are no microorganisms in your sample, or something went wrong",
               flush=True)
         sys.exit(0)
-    res = pd.DataFrame(rows, columns=["query_name", "query_md5", "match_name", "match_md5", "containment",
-                                      "max_containment", "jaccard", "intersect_hashes"])
-    res.to_csv(result_csv, index=False)
-    return res.drop_duplicates().reset_index(drop=True)["match_name"].to_list()
+    with phases.phase("write_multisearch_csv"):
+        res = pd.DataFrame(rows, columns=["query_name", "query_md5", "match_name", "match_md5", "containment",
+                                          "max_containment", "jaccard", "intersect_hashes"])
+        res.to_csv(result_csv, index=False)
+        return res.drop_duplicates().reset_index(drop=True)["match_name"].to_list()
 
 
 def get_exclusive_hashes(manifest: pd.DataFrame, nontrivial_organism_names: List[str], sample_sig, ksize: int,
@@ -272,17 +276,19 @@ def hypothesis_recovery(manifest: pd.DataFrame, sample_info_set, path_to_genome_
     sample_dir = os.path.dirname(sample_file)
     sample_name = os.path.basename(sample_file).replace(".sig.zip", "")
     path_to_sample_temp_dir = os.path.join(sample_dir, f"sample_{sample_name}_intermediate_files")
-    if os.path.exists(path_to_sample_temp_dir):
-        logger.info(f"Removing existing temporary directory: {path_to_sample_temp_dir}")
-        shutil.rmtree(path_to_sample_temp_dir)
-    os.makedirs(path_to_sample_temp_dir)
+    with phases.phase("sample_temp_dir"):
+        if os.path.exists(path_to_sample_temp_dir):
+            logger.info(f"Removing existing temporary directory: {path_to_sample_temp_dir}")
+            shutil.rmtree(path_to_sample_temp_dir)
+        os.makedirs(path_to_sample_temp_dir)
 
     names = get_organisms_with_nonzero_overlap(manifest, sample_file, scale, ksize, num_threads,
                                                path_to_genome_temp_dir, path_to_sample_temp_dir,
                                                parsed_sample=sample_sig if hasattr(sample_sig, "minhash") else None)
-    info, manifest = get_exclusive_hashes(manifest, names, sample_sig, ksize, path_to_genome_temp_dir)
-    n_excl = np.array([x[0] for x in info], dtype=np.int64)
-    n_match = np.array([x[1] for x in info], dtype=np.int64)
+    with phases.phase("exclusive_hashes_bookkeeping"):
+        info, manifest = get_exclusive_hashes(manifest, names, sample_sig, ksize, path_to_genome_temp_dir)
+        n_excl = np.array([x[0] for x in info], dtype=np.int64)
+        n_match = np.array([x[1] for x in info], dtype=np.int64)
 
     out = []
     for min_coverage in min_coverage_list:
@@ -290,8 +296,9 @@ def hypothesis_recovery(manifest: pd.DataFrame, sample_info_set, path_to_genome_
         with phases.phase("hypothesis_tests"):
             test = hyp_test_native if os.environ.get("YACHT_HYP_NATIVE") == "1" else hyp_test_batch
             cols = test(n_excl, n_match, ksize, significance, ani_thresh, min_coverage)
-        results = pd.DataFrame({name: col for name, col in zip(GIVEN_COLUMNS, cols)}, columns=GIVEN_COLUMNS)
-        results["in_sample_est"] = results["in_sample_est"].astype(bool)
-        manifest["min_coverage"] = min_coverage
-        out.append(pd.concat([manifest, results], axis=1))
+        with phases.phase("assemble_frames"):
+            results = pd.DataFrame({name: col for name, col in zip(GIVEN_COLUMNS, cols)}, columns=GIVEN_COLUMNS)
+            results["in_sample_est"] = results["in_sample_est"].astype(bool)
+            manifest["min_coverage"] = min_coverage
+            out.append(pd.concat([manifest, results], axis=1))
     return out

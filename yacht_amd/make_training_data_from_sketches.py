@@ -32,6 +32,12 @@ ARGUMENTS = (
     ("--outdir", dict(type=str, default=os.getcwd(), help="Path to output directory.")),
     ("--force", dict(action="store_true", help="Overwrite the output directory if it exists.")),
     ("--device", dict(type=int, default=0, help="GPU to run the comparison on.")),
+    ("--no_sig_files", dict(action="store_true",
+                            help="Do not leave the unzipped signatures/*.sig files in the working directory (the reference does; "
+                                 "`yacht run` of this build reads the packed database written next to them instead).")),
+    ("--python_ingest", dict(action="store_true",
+                             help="Unzip, gunzip and read the signature files in separate passes, as rounds 1-3 did "
+                                  "(default: one native pass over the archive).")),
 )
 
 # messages the reference raises with (callers and its tests match on them)
@@ -139,11 +145,19 @@ def main(args) -> None:
         raise ValueError(MSG_NOT_ZIP.format(zip_path))
     utils.check_file_existence(zip_path, MSG_NO_ZIP.format(zip_path))
     _fresh_workdir(workdir, args.force)
-    _unpack_database(zip_path, workdir, args.num_threads)
-
-    logger.info("Extracting signature information")
-    with phases.phase("signature_metadata"):
-        sig_info = utils.collect_signature_info(args.num_threads, args.ksize, workdir)
+    if not zipfile.is_zipfile(zip_path):
+        raise zipfile.BadZipFile(f"File is not a zip file: {zip_path}")
+    if getattr(args, "python_ingest", False):
+        _unpack_database(zip_path, workdir, args.num_threads)
+        logger.info("Extracting signature information")
+        with phases.phase("signature_metadata"):
+            sig_info = utils.collect_signature_info(args.num_threads, args.ksize, workdir)
+    else:
+        # one pass over the archive: members inflated, parsed and (unless --no_sig_files) written by native threads
+        logger.info("Reading the sourmash signature database")
+        with phases.phase("ingest"):
+            sig_info = utils.ingest_zip_database(zip_path, workdir, args.ksize, args.num_threads,
+                                                 write_files=not getattr(args, "no_sig_files", False))
     scaled_values = {record[-2] for record in sig_info.values()}
     if len(scaled_values) != 1:
         raise ValueError(MSG_SCALES)

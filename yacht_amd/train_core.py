@@ -84,6 +84,11 @@ def offer_parsed_sketches(paths: List[str], batch_handle) -> None:
     _PARSED.update(paths=paths, handle=batch_handle)
 
 
+def parsed_paths():
+    """The path list of the sketches an ingest pass left here (None: nothing offered)."""
+    return list(_PARSED["paths"]) if _PARSED.get("handle") is not None else None
+
+
 def drop_parsed_sketches() -> None:
     h = _PARSED.pop("handle", None)
     _PARSED.clear()

@@ -138,6 +138,66 @@ def collect_signature_info(num_threads: int, ksize: int, path_to_temp_dir: str) 
     return out
 
 
+def ingest_zip_database(zip_path: str, path_to_temp_dir: str, ksize: int, num_threads: int, write_files: bool = True) -> Dict[str, Tuple]:
+    """`yacht train`'s unzip + gunzip + metadata passes in ONE pass over the archive (yh_zip_sig_ingest; reference
+    make_training_data_from_sketches.py:107-133, utils.py:201-221, :499-509): the same dictionary collect_signature_info
+    returns -- name -> (md5sum, mean abundance, sketch size, scaled, path) -- with the signature members in the archive's
+    own order, and (write_files) the same files left in the working directory: every member as the reference's passes
+    leave it, a `.sig.gz` as the `.sig` it inflates to.  The sketches the train core needs are kept from the same pass
+    (train_core.offer_parsed_sketches).  Shapes the native scanner defers (status 5) go through the general reader, which
+    needs the file: with write_files=False such a member is an error."""
+    import ctypes as C
+
+    from . import _lib, train_core
+
+    lib = _lib.load()
+    h = C.c_void_p()
+    _lib.check(lib.yh_zip_sig_ingest(os.fsencode(zip_path), os.fsencode(path_to_temp_dir) if write_files else None, int(ksize),
+                                     max(1, int(num_threads)), C.byref(h)))
+    try:
+        cnt = C.c_uint64(0)
+        _lib.check(lib.yh_sig_meta_count(h, C.byref(cnt)))
+        n = int(cnt.value)
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        p_off = np.zeros(n + 1, np.uint64)
+        _lib.check(lib.yh_sig_meta_paths(h, vp(p_off), None))
+        p_buf = np.zeros(max(int(p_off[-1]), 1), np.uint8)
+        _lib.check(lib.yh_sig_meta_paths(h, vp(p_off), vp(p_buf)))
+        raw_p = p_buf.tobytes()
+        paths = [os.path.join(path_to_temp_dir, os.fsdecode(raw_p[int(p_off[i]):int(p_off[i + 1])])) for i in range(n)]
+        hb = C.c_void_p()
+        _lib.check(lib.yh_sig_meta_take_batch(h, C.byref(hb)))
+        train_core.offer_parsed_sketches(list(paths), hb)  # (owns the batch handle from here on)
+        status = np.zeros(max(n, 1), np.uint8)
+        n_hashes = np.zeros(max(n, 1), np.uint64)
+        scaled = np.zeros(max(n, 1), np.uint64)
+        mean_ab = np.zeros(max(n, 1), np.float64)
+        has_ab = np.zeros(max(n, 1), np.uint8)
+        md5 = np.zeros(max(n, 1) * 33, np.uint8)
+        name_off = np.zeros(n + 1, np.uint64)
+        _lib.check(lib.yh_sig_meta_get(h, vp(status), vp(n_hashes), vp(scaled), vp(mean_ab), vp(has_ab), vp(md5), vp(name_off)))
+        names_buf = np.zeros(max(int(name_off[-1]), 1), np.uint8)
+        _lib.check(lib.yh_sig_meta_names(h, vp(names_buf)))
+    finally:
+        lib.yh_sig_meta_destroy(h)
+    raw = names_buf.tobytes()
+    md5_raw = md5.tobytes()
+    out: Dict[str, Tuple] = {}
+    for i, path in enumerate(paths):
+        st = int(status[i])
+        if st == 0:
+            name = raw[int(name_off[i]):int(name_off[i + 1])].decode("utf-8", "replace")
+            out[name] = (md5_raw[33 * i:33 * i + 32].decode("ascii"), float(mean_ab[i]) if has_ab[i] else None, int(n_hashes[i]),
+                         int(scaled[i]), path)
+        elif st == 5 and write_files:
+            rec = get_info_from_single_sig(path, ksize)
+            if rec:
+                out[rec[1]] = (rec[2], rec[3], rec[4], rec[5], rec[0])
+        else:
+            logger.warning(f"CANNOT extract the relevant info from the signature file: {path}")
+    return out
+
+
 def _gunzip_one(path: str) -> None:
     with gzip.open(path, "rb") as f_in, open(path[: -len(".gz")], "wb") as f_out:
         shutil.copyfileobj(f_in, f_out)
@@ -169,7 +229,12 @@ def run_yacht_train_core(num_threads: int, ani_thresh: float, ksize: int, path_t
     (reference utils.py:112-197).  Same files are left behind: training_sig_files.tsv,
     selected_result.tsv, comparison_files/<pass>_<thread>.txt; same manifest columns returned."""
     sig_dir = os.path.join(path_to_temp_dir, "signatures")
-    sig_files = [os.path.join(sig_dir, f) for f in os.listdir(sig_dir)]
+    sig_files = [os.path.join(sig_dir, f) for f in os.listdir(sig_dir)] if os.path.isdir(sig_dir) else []
+    # (the reference's file list is os.listdir's order -- whatever the file system gives.  When the ingest pass has the
+    # sketches of exactly these files in hand, the list takes ITS order -- the archive's -- and nothing is read twice.)
+    offered = train_core.parsed_paths()
+    if offered is not None and (not sig_files or set(offered) == set(sig_files)):
+        sig_files = list(offered)
     sig_files_path = os.path.join(path_to_temp_dir, "training_sig_files.tsv")
     pd.DataFrame(sig_files).to_csv(sig_files_path, header=False, index=False)
 
