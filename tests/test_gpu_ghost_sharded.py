@@ -129,7 +129,7 @@ def test_bench_over_rccl_one_rank(hip_lib, shard):
     """bench.py's N > 1 code path (sharded step + async collectives of the bits and the count rows) on RCCL with one rank."""
     env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
                HSA_ENABLE_IPC_MODE_LEGACY="0", YH_FORCE_EXCHANGE="1")
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--shard", shard, "--steps", "6", "--warmup", "2",
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--shard", shard, "--steps", "6", "--min-timed-steps", "0", "--min-timed-ms", "0", "--warmup", "2",
                         "--refs", "4000", "--sample-hashes", "100000", "--samples", "3", "--percentile-steps", "8", "--present", "50"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout + p.stderr
@@ -148,7 +148,7 @@ def test_bench_two_ranks_share_gpu_strong_and_weak(hip_lib, tmp_path, shard):
             env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
                        MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
             procs.append(subprocess.Popen(
-                [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
+                [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--min-timed-steps", "0", "--min-timed-ms", "0", "--warmup", "2",
                  "--backend", "gloo", "--share-gpu", "--scaling", scaling, "--shard", shard, "--refs", "4000", "--sample-hashes", "100000",
                  "--samples", "3", "--percentile-steps", "8", "--present", "50", "--batch-block", "4"],
                 env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
@@ -163,7 +163,7 @@ def test_bench_two_ranks_hash_range_single_steps(hip_lib, tmp_path):
     """--block-mode steps: the per-sample half-steps of the hash-range shards (the batched blocks are the default)."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--backend", "gloo",
-                        "--block-mode", "steps", "--steps", "6", "--warmup", "2", "--refs", "4000", "--sample-hashes", "100000",
+                        "--block-mode", "steps", "--steps", "6", "--min-timed-steps", "0", "--min-timed-ms", "0", "--warmup", "2", "--refs", "4000", "--sample-hashes", "100000",
                         "--samples", "3", "--percentile-steps", "8", "--present", "50"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
@@ -176,7 +176,7 @@ def test_bench_starts_its_own_ranks(hip_lib):
     spawns its two ranks as child processes (before anything touches the GPU) and relays rank 0's line."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--backend", "gloo",
-                        "--steps", "6", "--warmup", "2", "--refs", "4000", "--sample-hashes", "100000", "--samples", "3",
+                        "--steps", "6", "--min-timed-steps", "0", "--min-timed-ms", "0", "--warmup", "2", "--refs", "4000", "--sample-hashes", "100000", "--samples", "3",
                         "--percentile-steps", "8", "--present", "50"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
