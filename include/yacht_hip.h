@@ -228,7 +228,26 @@ int yh_run_device_join(yh_db* db);
  * (d_global_bits then points at that sample's row of the gathered block; ghost_src indexes from there).
  * Between the two halves of a context no OTHER query may run on the handle in that context's place: a
  * yh_overlap* / yh_exclusive / yh_run* call re-uses the current context's work list (the library returns
- * YH_ERR_INVALID_ARG from yh_run_finish_device when it sees that this happened).                        */
+ * YH_ERR_INVALID_ARG from yh_run_finish_device when it sees that this happened).
+ *
+ * What may run on a handle between the two halves of an OPEN step context or batch slot (one handle, one thread at a time):
+ *
+ *   entry point                                            | an open step context (ctx)            | an open batch slot
+ *   -------------------------------------------------------+---------------------------------------+--------------------------------
+ *   yh_run_local*_device / yh_run_finish*_device, OTHER ctx | yes: contexts are independent         | yes
+ *   yh_run_batch_local_range / _finish_range, OTHER slot    | clobbers the CURRENT context (*)      | yes: slots are independent
+ *   yh_run_batch_rows_pack / _unpack_device                 | yes                                   | yes (they read a COMPLETED slot)
+ *   yh_overlap* / yh_exclusive / yh_run / yh_run_device /    | clobbers the CURRENT context (*): the  | yes, except yh_run_batch /
+ *     yh_run_indexed_device / yh_run_submit* / yh_run_batch* |   finish half of that context then     |   yh_run_batch_device, which run in
+ *                                                            |   returns YH_ERR_INVALID_ARG           |   slot 0 and clobber a first half there
+ *   yh_run_device_pipelined                                  | clobbers contexts 0..2 (it rotates     | yes
+ *                                                            |   through them); others untouched      |
+ *   yh_run_rows_device, yh_run_device_join,                  | yes (they only complete pending        | yes
+ *     yh_db_synchronize, yh_db_get_timing, yh_db_get_info    |   pipelined stages)                    |
+ *   yh_pairwise, yh_index_stats, yh_db_nshared_device        | yes                                   | yes
+ *   yh_db_set_stream                                         | yes (drains the old stream first)      | yes
+ *   (*) the CURRENT context = the one named by the last yh_run_local*_device / yh_run_finish*_device call (0 at start).
+ * Every query entry point first completes the pending stages of pipelined steps (yh_run_device_join) by itself.          */
 #define YH_RUN_CONTEXTS 16
 int yh_db_set_ghosts(yh_db* db, uint64_t ghost_begin, uint64_t n_ghost, const uint32_t* d_ghost_src);
 /* `ctx` (0 .. YH_RUN_CONTEXTS - 1) names the step context the two halves share: the lookup of sample k+1

@@ -5,8 +5,9 @@ S=${1:-120}
 cd "$GRAFT_REPO_ROOT" || exit 1
 run() { echo "== $*"; env "$@" timeout $((S + 200)) python tests/tools/fuzz_parity.py --seconds "$S" --seed "$SEED" 2>&1 | tail -1; }
 SEED=9101 run YH_DEBUG_TUNING=0
+SEED=9107 run YH_DEBUG_TUNING=1 YH_CHECK_SORT=1
 SEED=9102 run YH_DEBUG_TUNING=1 YH_UPLOAD_CHUNK_MIN=1 YH_CHECK_SORT=1 YH_UPLOAD_SHARES=0.3,0.3,0.2,0.1,0.1
-SEED=9103 run YH_DEBUG_TUNING=1 YH_PAIR_COLS=64 YH_PAIR_THREADS=256
+SEED=9103 run YH_DEBUG_TUNING=1 YH_PAIR_COLS=64 YH_PAIR_THREADS=256 YH_NO_PSORT=1
 SEED=9104 run YH_DEBUG_TUNING=1 YH_INDEX_TILE=2 YH_FILTER_MIN=1 YH_FILTER_BPH=2 YH_PAIR_THREADS=1024
 SEED=9105 run YH_DEBUG_TUNING=1 YH_NO_POOL=1 YH_UPLOAD_CHUNK_MIN=1000
 echo "== mix_calls 150 rounds"; timeout 900 python tests/tools/mix_calls.py 150 9106 2>&1 | tail -1

@@ -4,7 +4,7 @@
 MODE=${1:-stats}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT" || exit 1
-B="python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-host-inclusive --no-real-shape --no-batched --no-train --no-scaling-model"
+B="python3 bench.py --steps 20 --warmup 3 --min-timed-steps 300 --min-timed-ms 0 --no-cpu-baseline --no-host-inclusive --no-real-shape --no-batched --no-train --no-scaling-model"
 if [ "$MODE" = stats ] || [ "$MODE" = all ]; then
   rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_stats -- $B > gpurun_out/prof_stats.log 2>&1
 fi

@@ -1,5 +1,6 @@
 // yh_api.hip — the extern "C" boundary of libyacht_hip.so (declared in include/yacht_hip.h).
 #include "yh_common.h"
+#include "yh_sort.h"
 
 #include <mutex>
 #include <unordered_map>
@@ -411,7 +412,9 @@ static int db_create_common(const u64* values, const u64* offsets, bool on_devic
             (void)hipEventRecord(ev0, db->stream);
         } else {
             (void)hipEventRecord(ev0, db->stream);
-            rc = yh_build_validate(db, d_values_in, d_offsets_in);
+            // sizes + largest hash now; every sketch's ordering is checked by the sort's first level on its way through
+            // (yh_build_index), or by a pass of its own where that sort does not apply
+            rc = yh_build_validate_extents(db, d_values_in, d_offsets_in);
             if (rc != YH_OK) break;
         }
         rc = yh_build_index(db, d_values_in, d_offsets_in, d_sk_pre, d_sv_pre);  // (overlap-only handles too: the delta stream comes out of the same sort)
@@ -477,6 +480,7 @@ int yh_db_destroy(yh_db* db) {
     if (!db) return YH_OK;
     if (db->device >= 0) (void)hipSetDevice(db->device);
     if (db->stream) (void)hipStreamSynchronize(db->stream);
+    if (db->tmp_psort) { yh_psort_destroy(db, db->tmp_psort); db->tmp_psort = nullptr; }  // (a create that failed half way)
     if (db->ctx_bits[0]) {  // the step contexts: back to the handle's own arrays, the second set freed here
         db->d_maskbits = db->ctx_bits[0];
         db->d_work = db->ctx_work[0];

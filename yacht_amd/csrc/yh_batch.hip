@@ -98,7 +98,8 @@ __global__ void __launch_bounds__(256) k_batch_lookup(const u64* __restrict__ sa
             const u64 h = samples[off[s] + k];
             if (filter && h <= dv.max_hash) {  // presence bit first (yh_db::d_filter): clear = not in the database
                 const u64 bit = yh_bucket_of(h, dv.bkt_lsh, filter_mul);
-                if (!((filter[bit >> 5] >> (bit & 31u)) & 1u)) continue;
+                const u32 m = yh_filter_mask(h, bit);
+                if ((filter[bit >> 5] & m) != m) continue;
             }
             const u32 r = dv.find(h);
             if (r == YH_DIR_NONE) continue;

@@ -184,23 +184,34 @@ __global__ void __launch_bounds__(IDX_THREADS) k_idx_emit(const u64* __restrict_
                                                           u32* __restrict__ pr, u32* __restrict__ pg,
                                                           u32* __restrict__ nshared,
                                                           u64* __restrict__ dh, u32* __restrict__ dref,
-                                                          u32* __restrict__ elem_g, u32* __restrict__ prank) {
+                                                          u32* __restrict__ elem_g, u32* __restrict__ prank,
+                                                          const u64* __restrict__ chunk_off, u64 n_chunks) {
     // dh/dref (optional): every DISTINCT hash ascending, with its single holder, or
     // 0x80000000 | (index into g) when several references hold it
+    // chunk_off (optional): the chunks are the buckets of the distribution sort, [chunk_off[c], chunk_off[c + 1]), whose
+    // three counts the sort made itself; else chunks of IDX_BLOCK elements counted by k_idx_count
     const u32 lane = threadIdx.x & 63u;
     const u64 chunk = (blockIdx.x * (u64)blockDim.x + threadIdx.x) >> 6;
-    const u64 base = chunk * IDX_BLOCK;
-    if (base >= n) return;
+    u64 base, end;
+    if (chunk_off) {
+        if (chunk >= n_chunks) return;
+        base = chunk_off[chunk];
+        end = chunk_off[chunk + 1];
+    } else {
+        base = chunk * IDX_BLOCK;
+        if (base >= n) return;
+        end = min(n, base + (u64)IDX_BLOCK);
+    }
     u64 di = bases[chunk * 3 + 0];  // distinct hashes before this step's elements
     u64 gi = bases[chunk * 3 + 1];  // shared heads
     u64 mi = bases[chunk * 3 + 2];  // shared elements
     const u64 below = (1ull << lane) - 1ull;
-    for (u32 it = 0; it < IDX_BLOCK / 64; ++it) {
-        const u64 i = base + (u64)it * 64 + lane;
+    for (u64 i0 = base; i0 < end; i0 += 64) {  // (wave-uniform)
+        const u64 i = i0 + lane;
         bool head = false, shared = false;
         u64 h = 0;
         u32 r = 0;
-        if (i < n) {
+        if (i < end) {
             const IdxFlags f = idx_flags(sk, n, i);
             head = f.head;
             shared = f.shared;
@@ -226,7 +237,7 @@ __global__ void __launch_bounds__(IDX_THREADS) k_idx_emit(const u64* __restrict_
             const u32 rank = atomicAdd(&nshared[r], 1u);
             if (prank) prank[my_m] = rank;  // (any order inside the reference: the pairwise pass only sums)
         }
-        if (elem_g && i < n) elem_g[i] = shared ? (u32)(my_g_incl - 1) : STREAM_NONE;  // shared-hash index of every sorted element
+        if (elem_g && i < end) elem_g[i] = shared ? (u32)(my_g_incl - 1) : STREAM_NONE;  // shared-hash index of every sorted element
         di += (u64)__popcll(bd);
         gi += (u64)__popcll(bg);
         mi += (u64)__popcll(bm);
@@ -425,7 +436,7 @@ __global__ void k_fill_rg(u64 n_post, const u32* __restrict__ pr, const u32* __r
 __global__ void k_filter_build(const u64* __restrict__ dh, u64 n, u32 lsh, u64 fmul, u32* __restrict__ filter) {
     for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
         const u64 bit = __umul64hi(dh[i] << lsh, fmul);
-        atomicOr(&filter[bit >> 5], 1u << (bit & 31u));
+        atomicOr(&filter[bit >> 5], yh_filter_mask(dh[i], bit));
     }
 }
 
@@ -476,7 +487,48 @@ static int validate_end(yh_db* db) {
 int yh_build_validate(yh_db* db, const u64* d_values, const u64* d_offsets) {
     YH_TRY(validate_begin(db));
     YH_TRY(validate_refs(db, d_values, d_offsets, 0, db->n_refs));
-    return validate_end(db);
+    YH_TRY(validate_end(db));
+    db->order_checked = true;
+    return YH_OK;
+}
+// The same in two parts, for a database the distribution sort is going to read anyway: the sizes and the largest hash from
+// the offsets and every sketch's LAST element (N reads; the largest hash of ascending sketches is the largest last element,
+// and sketches that are not ascending fail the ordering check whatever this says) -- and the ordering check itself, which
+// the sort's first level does on its way through (yh_psort_check_order) or, without that sort, yh_build_check_order.
+__global__ void k_ref_extents(const u64* __restrict__ values, const u64* __restrict__ offsets, u64 n_refs, u32* __restrict__ sizes,
+                              u32* __restrict__ flag, u64* __restrict__ maxv) {
+    for (u64 j = blockIdx.x * (u64)blockDim.x + threadIdx.x; j < n_refs; j += (u64)gridDim.x * blockDim.x) {
+        const u64 b = offsets[j], e = offsets[j + 1];
+        if (e < b) { atomicOr(flag, 1u); continue; }
+        const u64 n = e - b;
+        sizes[j] = (u32)n;
+        if (n > 0xffffffffull) atomicOr(flag, 2u);
+        if (n) atomicMax(maxv, values[e - 1]);
+    }
+}
+int yh_build_validate_extents(yh_db* db, const u64* d_values, const u64* d_offsets) {
+    YH_TRY(validate_begin(db));
+    if (db->n_refs) {
+        u64* d_maxv = (u64*)(db->d_flag + 2);
+        k_ref_extents<<<grid_for(db->n_refs, 256), 256, 0, db->stream>>>(d_values, d_offsets, db->n_refs, db->d_sizes, db->d_flag, d_maxv);
+        YH_HIP(hipGetLastError());
+    }
+    YH_TRY(validate_end(db));
+    db->order_checked = false;
+    return YH_OK;
+}
+int yh_build_check_order(yh_db* db, const u64* d_values, const u64* d_offsets) {
+    // (k_scan_refs again: it rewrites the same sizes and can only raise the same maximum)
+    YH_HIP(hipMemsetAsync(db->d_flag, 0, 4, db->stream));
+    YH_TRY(validate_refs(db, d_values, d_offsets, 0, db->n_refs));
+    u32 hflag = 0;
+    YH_HIP(hipMemcpyAsync(&hflag, db->d_flag, 4, hipMemcpyDeviceToHost, db->stream));
+    YH_HIP(hipStreamSynchronize(db->stream));
+    if (hflag & 1u) {
+        yh_set_error("a reference sketch is not strictly ascending (or offsets are not monotone)");
+        return YH_ERR_UNSORTED;
+    }
+    return YH_OK;
 }
 
 // Host CSR -> device CSR, validated, and the (hash, reference) pairs of the whole database sorted by hash, with the
@@ -611,6 +663,7 @@ int yh_build_upload_sorted(yh_db* db, const u64* h_values, const u64* h_offsets,
     if (rc == YH_OK && copy_failed.load()) { yh_set_error("CSR upload failed"); rc = YH_ERR_HIP; }
     if (rc != YH_OK) (void)hipStreamSynchronize(up);
     if (rc == YH_OK) rc = validate_end(db);  // (waits for the stream)
+    db->order_checked = true;  // (k_scan_refs checked every chunk)
     TRACE("stream drained");
     float ms_chunks = 0.f;  // device time of the chunks' checks and distribution passes (they ran under the upload)
     for (size_t c = 0; c < C && rc == YH_OK; ++c) {
@@ -637,6 +690,7 @@ int yh_build_upload_sorted(yh_db* db, const u64* h_values, const u64* h_offsets,
         UP_HIP(hipEventSynchronize(ee[0]));
         if (rc == YH_OK) (void)hipEventElapsedTime(&ms_tail, eb[0], ee[0]);
     }
+    if (rc == YH_OK && sorted && ps) { db->tmp_psort = ps; ps = nullptr; }  // (its buckets are the chunks yh_build_index walks)
     yh_psort_destroy(db, ps);
     ps = nullptr;
     TRACE("sorted");
@@ -747,7 +801,13 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, u64* d_
     u64 *d_sk = nullptr, *d_bases = nullptr;
     void* d_tmp = nullptr;
     int rc = YH_OK;
-    const u64 nb = (H + IDX_BLOCK - 1) / IDX_BLOCK;
+    // The sorted pairs are walked in CHUNKS (count -> scan -> emit).  Sorted by the distribution sort, the chunks are its
+    // buckets -- it counted them itself, in LDS -- else fixed chunks of IDX_BLOCK pairs counted by k_idx_count.
+    yh_psort* ps = db->tmp_psort;  // (yh_build_upload_sorted's, when it sorted that way; ours to destroy)
+    db->tmp_psort = nullptr;
+    u64 nb = (H + IDX_BLOCK - 1) / IDX_BLOCK;
+    const u64* d_chunk_off = nullptr;
+    const u32* d_chunk_counts = nullptr;
 #define IDX_HIP(call)                                                                         \
     if (rc == YH_OK) {                                                                        \
         hipError_t e__ = (call);                                                              \
@@ -764,8 +824,8 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, u64* d_
         IDX_HIP(yh_tmalloc(db, (void**)&d_sv, H * sizeof(u32)));
         IDX_HIP(yh_tmalloc(db, (void**)&d_sk, H * sizeof(u64)));
     }
-    IDX_HIP(yh_tmalloc(db, (void**)&d_counts, nb * 3 * sizeof(u32)));
-    IDX_HIP(yh_tmalloc(db, (void**)&d_bases, (nb + 1) * 3 * sizeof(u64)));
+    if (ps) yh_psort_chunks(ps, &nb, &d_chunk_off, &d_chunk_counts);
+    bool order_checked = db->order_checked;
     if (rc == YH_OK && !d_sk_pre) {
         k_fill_ref_ids<<<grid_for(N * WAVE, 256), 256, 0, st>>>(d_offsets, N, d_ids);
         const u32* ids_src = d_ids;
@@ -773,11 +833,26 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, u64* d_
         // are), rocPRIM's LSD radix sort -- stable: equal hashes keep ascending references -- for anything else
         bool sorted = false;
         if (rc == YH_OK && yh_psort_applicable(H, db->max_hash)) {
-            yh_psort* ps = nullptr;
+            bool unsorted = false;
             rc = yh_psort_begin(db, H, db->max_hash, &ps);
+            if (rc == YH_OK) yh_psort_check_order(ps, !order_checked);  // (the first level reads every pair anyway)
             if (rc == YH_OK) rc = yh_psort_add(db, ps, d_values, ids_src, H);
-            if (rc == YH_OK) rc = yh_psort_finish(db, ps, d_sk, d_sv, &sorted);
-            yh_psort_destroy(db, ps);
+            if (rc == YH_OK) rc = yh_psort_finish(db, ps, d_sk, d_sv, &sorted, &unsorted);
+            if (rc == YH_OK && !order_checked && unsorted) {
+                yh_set_error("a reference sketch is not strictly ascending (or offsets are not monotone)");
+                rc = YH_ERR_UNSORTED;
+            }
+            if (rc == YH_OK && sorted) {
+                order_checked = true;
+                yh_psort_chunks(ps, &nb, &d_chunk_off, &d_chunk_counts);
+            } else {
+                yh_psort_destroy(db, ps);
+                ps = nullptr;
+            }
+        }
+        if (rc == YH_OK && !order_checked) {  // (no distribution sort, or refused: the ordering check as a pass of its own)
+            rc = yh_build_check_order(db, d_values, d_offsets);
+            order_checked = true;
         }
         if (rc == YH_OK && !sorted) {
             unsigned end_bit = 1;
@@ -807,6 +882,7 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, u64* d_
     const bool want_stream = !(db->flags & YH_DB_PAIRWISE_ONLY);
     if (rc == YH_OK && (db->flags & YH_DB_NO_INDEX)) {  // overlap-only handle: the stream and nothing else
         if (want_stream) rc = build_stream(db, d_sk, d_sv, nullptr, H);
+        yh_psort_destroy(db, ps);
         yh_tfree(db, d_ids);
         yh_tfree(db, d_sv);
         yh_tfree(db, d_sk);
@@ -818,9 +894,12 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, u64* d_
     u32* d_elem_g = nullptr;
     if (want_stream) IDX_HIP(yh_tmalloc(db, (void**)&d_elem_g, H * sizeof(u32)));
     u64 totals[3] = {0, 0, 0};
+    // (d_counts: the chunk counts when k_idx_count makes them; later a few words of scratch)
+    IDX_HIP(yh_tmalloc(db, (void**)&d_counts, std::max<u64>(d_chunk_counts ? 0 : nb * 3, 16) * sizeof(u32)));
+    IDX_HIP(yh_tmalloc(db, (void**)&d_bases, (nb + 1) * 3 * sizeof(u64)));
     if (rc == YH_OK) {
-        k_idx_count<<<(u32)((nb * 64 + IDX_THREADS - 1) / IDX_THREADS), IDX_THREADS, 0, st>>>(d_sk, H, d_counts);
-        k_idx_scan_counts<<<1, 1024, 0, st>>>(d_counts, nb, d_bases);
+        if (!d_chunk_counts) k_idx_count<<<(u32)((nb * 64 + IDX_THREADS - 1) / IDX_THREADS), IDX_THREADS, 0, st>>>(d_sk, H, d_counts);
+        k_idx_scan_counts<<<1, 1024, 0, st>>>(d_chunk_counts ? d_chunk_counts : d_counts, nb, d_bases);
         IDX_HIP(hipGetLastError());
         IDX_HIP(hipMemcpyAsync(totals, d_bases + nb * 3, 3 * sizeof(u64), hipMemcpyDeviceToHost, st));
         IDX_HIP(hipStreamSynchronize(st));
@@ -897,7 +976,7 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, u64* d_
         u32* const dref_out = !full ? nullptr : compact ? d_dref_tmp : db->d_dref;
         if (rc == YH_OK)
             k_idx_emit<<<(u32)((nb * 64 + IDX_THREADS - 1) / IDX_THREADS), IDX_THREADS, 0, st>>>(d_sk, d_sv, H, d_bases, db->d_g, db->d_po, db->d_pr, db->d_pg,
-                                                        db->d_nshared, dh_out, dref_out, d_elem_g, db->d_prank);
+                                                        db->d_nshared, dh_out, dref_out, d_elem_g, db->d_prank, d_chunk_off, nb);
         if (rc == YH_OK && full && !compact)
             k_dir_build<<<grid_for(db->n_distinct, 256), 256, 0, st>>>(db->d_dh, db->n_distinct, db->dir_shift, db->dir_nb,
                                                                        db->d_dir);
@@ -1050,6 +1129,7 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, u64* d_
     }
     TRACE("index: emitted + drained");
 #undef IDX_HIP
+    yh_psort_destroy(db, ps);
     yh_tfree(db, d_elem_g);
     yh_tfree(db, d_ids);
     yh_tfree(db, d_sv);

@@ -237,6 +237,8 @@ struct yh_db {
 
     // timing
     EventRing ev_overlap, ev_excl, ev_pair;
+    struct yh_psort* tmp_psort = nullptr;  // build time: the distribution sort that made the sorted pairs (its buckets are walked as chunks)
+    bool order_checked = false;            // build time: every sketch's ordering has been verified
     float ms_upload_kernels = 0.f;  // device time of the chunk sorts / merges that ran under the upload (yh_build_upload_sorted)
     float ms_db_build = 0.f;
     // host <-> device copies (yh_timing.ms_h2d / ms_d2h): the CSR upload of yh_db_create (host clock), then HIP events
@@ -248,6 +250,8 @@ struct yh_db {
 
 // ---- implemented in yh_build.hip -------------------------------------------------------------
 int yh_build_validate(yh_db* db, const u64* d_values, const u64* d_offsets);  // ordering check, sizes, largest hash
+int yh_build_validate_extents(yh_db* db, const u64* d_values, const u64* d_offsets);  // sizes + largest hash only (N reads); order: later
+int yh_build_check_order(yh_db* db, const u64* d_values, const u64* d_offsets);
 int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, u64* d_sk_pre = nullptr, u32* d_sv_pre = nullptr);
 // host CSR up in chunks, each checked, sorted and merged while the next one crosses the bus (yh_build.hip)
 int yh_build_upload_sorted(yh_db* db, const u64* h_values, const u64* h_offsets, u64* d_values, const u64* d_offsets,
@@ -281,6 +285,27 @@ int yh_q_range_finish(yh_db* db, const u32* d_gathered, u32 n_ranks, u64 stride_
 #define YH_DIR_NONE 0xffffffffu
 #if defined(__HIPCC__)
 __device__ __forceinline__ u64 yh_bucket_of(u64 h, u32 lsh, u64 nb) { return __umul64hi(h << lsh, nb); }
+// The presence filter (yh_db::d_filter): the 32-bit WORD of a hash is a monotone function of it (a sorted sample walks the
+// filter front to back); inside the word a hash owns TWO bits picked by a multiplicative hash (round 4; before: the one bit
+// the monotone index named).  Same table, same single read per sample hash; at 4 bits per distinct hash a word holds ~8
+// hashes = ~13 of 32 bits set, so an absent hash finds both of its bits set with probability ~0.16 instead of ~0.22 for one
+// bit -- a fifth fewer bucket reads for nothing.  A hash that IS in the database always finds its bits: counts stay exact.
+#ifndef YH_FILTER_K
+#define YH_FILTER_K 2  // bits per hash inside its word (1 = round 3's filter: the bit the monotone index names; 3: tuning)
+#endif
+__host__ __device__ __forceinline__ u32 yh_filter_mask(u64 h, u64 bit) {
+#if YH_FILTER_K >= 2
+    const u32 m = (u32)((h * 0x9E3779B97F4A7C15ull) >> 49);  // 15 bits: three 5-bit positions
+    (void)bit;
+    u32 mask = (1u << (m & 31u)) | (1u << ((m >> 5) & 31u));
+#if YH_FILTER_K >= 3
+    mask |= 1u << ((m >> 10) & 31u);
+#endif
+    return mask;
+#else
+    return 1u << (u32)(bit & 31u);
+#endif
+}
 
 // Compact bucket (the form every database of realistic size gets): bucket(h) as above with ~2.5 distinct
 // hashes per bucket; inside a bucket the hashes span less than 2^32, so their LOW 32 BITS identify them:

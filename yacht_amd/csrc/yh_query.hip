@@ -902,7 +902,10 @@ __device__ __forceinline__ void lookup_tile_body(u32 wg, u32* tkey, u32* tcnt, u
             w[u] = filter[bit[u] >> 5];
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) ok[u] = ok[u] && ((w[u] >> (bit[u] & 31u)) & 1u);
+        for (int u = 0; u < U; ++u) {
+            const u32 m = yh_filter_mask(h[u], bit[u]);
+            ok[u] = ok[u] && (w[u] & m) == m;
+        }
     }
     if (dv.cbkt) {
 #pragma unroll

@@ -103,7 +103,8 @@ struct PartArgs {
     u32* out_v;
     u64 cap_out;
     u32* out_cnt;
-    u32* flags;           // [0] |= 1: a region overflowed
+    u32* flags;           // [0] |= 1: a region overflowed; |= 8: two neighbours with the same value (reference) not ascending
+    u32 check_order;      // level 1: the input is a CSR in reference order with the reference id as value -- check every sketch's order here
 };
 
 template <int LEVEL>
@@ -140,6 +141,14 @@ __global__ void __launch_bounds__(PART_THREADS) k_part(const PartArgs a) {
         if (i < tile_n) {
             key[k] = a.in_k[in_base + t0 + i];
             val[k] = a.in_v[in_base + t0 + i];
+            if (a.check_order && (LEVEL == 1 || !a.in_cnt)) {
+                // the element in front (lane - 1 has it; the wave's first lane reads it): same reference => strictly smaller hash
+                u64 pk = ((u64)(u32)__shfl_up((int)(u32)(key[k] >> 32), 1) << 32) | (u32)__shfl_up((int)(u32)key[k], 1);
+                u32 pv = (u32)__shfl_up((int)val[k], 1);
+                const u64 gi = t0 + i;
+                if ((tid & 63u) == 0 && gi > 0) { pk = a.in_k[in_base + gi - 1]; pv = a.in_v[in_base + gi - 1]; }
+                if (gi > 0 && pv == val[k] && !(pk < key[k])) atomicOr(a.flags, 8u);
+            }
             const u32 b = bucket_of(key[k], a.lsh, a.mul);
             bin[k] = LEVEL == 1 ? b / a.P2 : b % a.P2;
             if (bin[k] >= a.nbins) bin[k] = a.nbins - 1;  // (keys above max_hash: cannot happen after validation; stay in range)
@@ -220,6 +229,8 @@ struct BucketArgs {
     u64* out_k;
     u32* out_v;
     u32* flags;    // [0] |= 4: a slot held more than SLOT_MAX pairs
+    u32* counts;   // [buckets][3] {distinct hashes, hashes held by >= 2 references, pairs of those}: what k_idx_count counts per
+                   // chunk of the sorted pairs -- a run of equal hashes never leaves its bucket, so the bucket sees it whole
 };
 
 __global__ void __launch_bounds__(BKT_THREADS) k_bucket_sort(const BucketArgs a) {
@@ -227,10 +238,12 @@ __global__ void __launch_bounds__(BKT_THREADS) k_bucket_sort(const BucketArgs a)
     __shared__ u32 sval[BKT_CAP];
     __shared__ u32 start[BKT_SLOTS];  // counts, then offsets
     __shared__ u32 wtot[17];
+    __shared__ u32 tot3[3];
     const u32 tid = threadIdx.x;
     const u64 b = blockIdx.x;
     const u32 n = min(a.cnt[b], BKT_CAP);
-    if (n == 0) return;
+    if (n == 0) return;  // (its three counts stay zero: the array is cleared before the launch)
+    if (tid < 3) tot3[tid] = 0;
     for (u32 i = tid; i < BKT_SLOTS; i += BKT_THREADS) start[i] = 0;
     __syncthreads();
     u64 key[BKT_ITEMS];
@@ -289,9 +302,26 @@ __global__ void __launch_bounds__(BKT_THREADS) k_bucket_sort(const BucketArgs a)
         }
     __syncthreads();
     const u64 out_base = a.off[b];
-    for (u32 i = tid; i < n; i += BKT_THREADS) {
-        a.out_k[out_base + i] = skey[i];
-        a.out_v[out_base + i] = sval[i];
+    u32 c0 = 0, c1 = 0, c2 = 0;
+    for (u32 i0 = 0; i0 < n; i0 += BKT_THREADS) {  // (workgroup-uniform bound: the ballots)
+        const u32 i = i0 + tid;
+        bool head = false, shared = false;
+        if (i < n) {
+            const u64 h = skey[i];
+            a.out_k[out_base + i] = h;
+            a.out_v[out_base + i] = sval[i];
+            const bool eq_prev = i > 0 && skey[i - 1] == h, eq_next = i + 1 < n && skey[i + 1] == h;
+            head = !eq_prev;
+            shared = eq_prev || eq_next;
+        }
+        c0 += (u32)__popcll(__ballot(head));
+        c1 += (u32)__popcll(__ballot(head && shared));
+        c2 += (u32)__popcll(__ballot(shared));
+    }
+    if (a.counts) {
+        if ((tid & 63u) == 0) { atomicAdd(&tot3[0], c0); atomicAdd(&tot3[1], c1); atomicAdd(&tot3[2], c2); }
+        __syncthreads();
+        if (tid < 3) a.counts[b * 3 + tid] = tot3[tid];
     }
 }
 
@@ -317,6 +347,8 @@ struct yh_psort {
     u32* v2 = nullptr;
     u32* cnt = nullptr;  // [P1] + [NB] + flags[4]
     u64* off = nullptr;  // [NB + 1]
+    u32* counts = nullptr;  // [NB][3] run statistics of every bucket (k_bucket_sort)
+    bool check_order = false;
 };
 
 // Is this input one the distribution sort takes?  (A database of a few thousand hashes is one bucket; a key range narrower
@@ -330,10 +362,16 @@ bool yh_psort_applicable(u64 H, u64 max_hash) {
     return max_hash / NB >= BKT_SLOTS || NB == 1;
 }
 
+void yh_psort_check_order(yh_psort* s, bool on) { s->check_order = on; }
+void yh_psort_chunks(const yh_psort* s, u64* n_chunks, const u64** d_chunk_off, const u32** d_chunk_counts) {
+    *n_chunks = s->NB;
+    *d_chunk_off = s->off;
+    *d_chunk_counts = s->counts;
+}
 void yh_psort_destroy(yh_db* db, yh_psort* s) {
     if (!s) return;
     yh_tfree(db, s->k1); yh_tfree(db, s->v1); yh_tfree(db, s->k2); yh_tfree(db, s->v2);
-    yh_tfree(db, s->cnt); yh_tfree(db, s->off);
+    yh_tfree(db, s->cnt); yh_tfree(db, s->off); yh_tfree(db, s->counts);
     delete s;
 }
 
@@ -364,7 +402,9 @@ int yh_psort_begin(yh_db* db, u64 H, u64 max_hash, yh_psort** out) {
     if (e == hipSuccess) e = yh_tmalloc(db, (void**)&s->v2, s->NB * BKT_CAP * sizeof(u32));
     if (e == hipSuccess) e = yh_tmalloc(db, (void**)&s->cnt, (s->P1 + s->NB + 4) * sizeof(u32));
     if (e == hipSuccess) e = yh_tmalloc(db, (void**)&s->off, (s->NB + 1) * sizeof(u64));
+    if (e == hipSuccess) e = yh_tmalloc(db, (void**)&s->counts, s->NB * 3 * sizeof(u32));
     if (e == hipSuccess) e = hipMemsetAsync(s->cnt, 0, (s->P1 + s->NB + 4) * sizeof(u32), db->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(s->counts, 0, s->NB * 3 * sizeof(u32), db->stream);
     if (e != hipSuccess) {
         yh_set_error("distribution sort: allocation failed: %s", hipGetErrorString(e));
         yh_psort_destroy(db, s);
@@ -388,6 +428,7 @@ int yh_psort_add(yh_db* db, yh_psort* s, const u64* d_keys, const u32* d_vals, u
     a.mul = s->mul;
     a.lsh = s->lsh;
     a.flags = flags;
+    a.check_order = s->check_order ? 1u : 0u;
     const u32 tiles = (u32)((n + PART_TILE - 1) / PART_TILE);
     if (s->P1 > 1) {
         a.P2 = s->P2;
@@ -415,8 +456,9 @@ int yh_psort_add(yh_db* db, yh_psort* s, const u64* d_keys, const u32* d_vals, u
 
 // second level + the sort of every bucket; the sorted pairs land in d_keys_out / d_vals_out (H entries).  *took_it = false:
 // the keys were not this sort's input (a capacity was exceeded) -- nothing usable was written, sort another way.
-int yh_psort_finish(yh_db* db, yh_psort* s, u64* d_keys_out, u32* d_vals_out, bool* took_it) {
+int yh_psort_finish(yh_db* db, yh_psort* s, u64* d_keys_out, u32* d_vals_out, bool* took_it, bool* unsorted) {
     *took_it = false;
+    if (unsorted) *unsorted = false;
     u32* cnt1 = s->cnt;
     u32* cnt2 = s->cnt + s->P1;
     u32* flags = s->cnt + s->P1 + s->NB;
@@ -452,6 +494,7 @@ int yh_psort_finish(yh_db* db, yh_psort* s, u64* d_keys_out, u32* d_vals_out, bo
     b.out_k = d_keys_out;
     b.out_v = d_vals_out;
     b.flags = flags;
+    b.counts = s->counts;
     k_bucket_sort<<<(u32)s->NB, BKT_THREADS, 0, db->stream>>>(b);
     YH_HIP(hipGetLastError());
     u32 hflags[4] = {0, 0, 0, 0};
@@ -459,7 +502,8 @@ int yh_psort_finish(yh_db* db, yh_psort* s, u64* d_keys_out, u32* d_vals_out, bo
     YH_HIP(hipMemcpyAsync(hflags, flags, 3 * sizeof(u32), hipMemcpyDeviceToHost, db->stream));
     YH_HIP(hipMemcpyAsync(&total, s->off + s->NB, sizeof(u64), hipMemcpyDeviceToHost, db->stream));
     YH_HIP(hipStreamSynchronize(db->stream));
-    *took_it = hflags[0] == 0 && total == s->fed;
+    *took_it = (hflags[0] & 7u) == 0 && total == s->fed;
+    if (unsorted) *unsorted = (hflags[0] & 8u) != 0;
     static const bool trace = [] { const char* e = yh_tune_env("YH_TRACE_BUILD"); return e && e[0] == '1'; }();
     if (trace || !*took_it) {
         // (a refusal is worth a line even without the trace switch: the caller falls back to a sort three times as slow)
