@@ -1088,15 +1088,6 @@ def main() -> int:
         except Exception:
             pass
 
-    # ---- the database built a second time in this process (its arrays now come out of the library's buffer cache) ----
-    db_rebuild_ms = None
-    if not multi and not args.no_scaling_model:
-        with torch.cuda.stream(stream):
-            db2 = RefDB.from_device(values.data_ptr(), offsets.data_ptr(), n_local, device=local_rank,
-                                    flags=YH_DB_NO_DIRECTORY if args.no_indexed else YH_DB_DEFAULT)
-        db_rebuild_ms = round(float(db2.timing()["ms_db_build"]), 2)
-        db2.close()
-
     # ---- CPU baseline + full-size parity (rank 0, the WHOLE database) -----------------------------------
     cpu_baseline = None
     parity = None
@@ -1152,11 +1143,20 @@ def main() -> int:
     # ---- the `yacht train` side of the path (BASELINE configs[3]) in the same driver-timed run: bench_train.py as a CHILD
     # process (its own handle, its own JSON line), after this process has released its database
     train = None
+    db_rebuild_ms = None
     if rank == 0 and not multi and not args.no_train:
         import subprocess
 
         if sdb is None:
             db.close()
+            # ---- the database built again in this process: its arrays now come out of the library's buffer cache (the
+            # handle above has just returned them), so the driver is not asked for memory at all
+            if not args.no_scaling_model:
+                with torch.cuda.stream(stream):
+                    db2 = RefDB.from_device(values.data_ptr(), offsets.data_ptr(), n_local, device=local_rank,
+                                            flags=YH_DB_NO_DIRECTORY if args.no_indexed else YH_DB_DEFAULT)
+                db_rebuild_ms = round(float(db2.timing()["ms_db_build"]), 2)
+                db2.close()
         del values, offsets
         torch.cuda.empty_cache()
         t0 = time.perf_counter()
@@ -1231,7 +1231,8 @@ def main() -> int:
                 "db_rebuild_ms": db_rebuild_ms,
                 "db_build_note": "device input; HIP events around validation + sort + index + tables, host stalls included: a hipMalloc of a "
                                  "multi-GB block sporadically takes 0.7-4 s on this pool (profiles/r04/malloc_probe.txt, a plain HIP program) -- "
-                                 "round 3's 705-815 ms; db_rebuild_ms = the same build again with the arrays out of the library's buffer cache",
+                                 "round 3's 705-815 ms; db_rebuild_ms = the same build again behind the first handle's destroy, its arrays out of "
+                                 "the library's buffer cache (no driver allocation)",
                 "db_hbm_bytes": info["device_bytes"],
                 "pipelined_tail": bool(not multi and args.pipelined_tail),
                 "step": "overlap + exclusive counts" + ((f" (blocks of {GB} samples: one all_gather of their subset bits" + (", two blocks in flight" if pipelined else "") + f") + one {'gather to rank 0' if to_root else 'all_gather'} of the count rows per {GB} samples"

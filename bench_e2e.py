@@ -95,6 +95,7 @@ def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--refs", type=int, default=85_205)
     ap.add_argument("--threads", type=int, default=min(os.cpu_count() or 8, 64))
+    ap.add_argument("--more-threads", type=int, default=0, help="also run the default and the --no_sig_files train with this many host threads")
     ap.add_argument("--work", default="/tmp/yacht_e2e")
     ap.add_argument("--out", default="")
     ap.add_argument("--seed", type=int, default=1002)
@@ -138,21 +139,25 @@ def main() -> int:
     lines = {}
     # ---- yacht train: the default (one native pass over the archive, the unzipped .sig files left behind as the reference
     # leaves them), the same without the files, and rounds 1-3's three Python passes -----------------------------------
-    variants = [("default", []), ("no_sig_files", ["--no_sig_files"]), ("python_ingest", ["--python_ingest"])]
+    variants = [("default", [], args.threads), ("no_sig_files", ["--no_sig_files"], args.threads),
+                ("python_ingest", ["--python_ingest"], args.threads)]
+    if args.more_threads:
+        variants += [(f"default_{args.more_threads}_threads", [], args.more_threads),
+                     (f"no_sig_files_{args.more_threads}_threads", ["--no_sig_files"], args.more_threads)]
     train_lines = {}
-    for tag, extra in variants:
+    for tag, extra, n_threads in variants:
         out_dir = os.path.join(args.work, "out_" + tag)
         os.makedirs(out_dir)
         phases.reset()
         t0 = time.perf_counter()
         rc = cli.main(["train", "--ref_file", ref_zip, "--ksize", "31", "--ani_thresh", "0.95", "--prefix", "db", "--outdir", out_dir,
-                       "--num_threads", str(args.threads), "--force"] + extra)
+                       "--num_threads", str(n_threads), "--force"] + extra)
         wall = time.perf_counter() - t0
         ph = phases.snapshot()
         top = {k: v for k, v in ph.items() if "/" not in k}
         rss_self, rss_kids = peak_rss_gb()
         n_kept = sum(1 for _ in open(os.path.join(out_dir, "db_processed_manifest.tsv"))) - 1
-        train_lines[tag] = {"rc": rc, "wall_s": round(wall, 2), "phases_s": ph, "slowest_phase": max(top, key=top.get) if top else None,
+        train_lines[tag] = {"rc": rc, "threads": n_threads, "wall_s": round(wall, 2), "phases_s": ph, "slowest_phase": max(top, key=top.get) if top else None,
                             "unaccounted_s": round(wall - sum(top.values()), 2), "references_kept": n_kept,
                             "peak_rss_gb": {"process": rss_self, "largest_pool_worker": rss_kids}}
         if tag != "default" and not args.keep:

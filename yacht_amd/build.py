@@ -60,7 +60,7 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
                 print("hipcc -c", os.path.basename(s), flush=True)
             _run([hipcc, *common, "-c", s, "-o", o])
     if force or _stale(LIB_PATH, objs):
-        _run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", LIB_PATH, "-lz"])
+        _run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", LIB_PATH, "-lz", "-ldl"])
     return LIB_PATH
 
 
@@ -75,7 +75,7 @@ def build_variant(name: str, defines: dict, verbose: bool = False) -> str:
     if verbose:
         print("hipcc variant", name, " ".join(flags), flush=True)
     _run([hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result",
-          f"-I{os.path.join(REPO_DIR, 'include')}", *flags, *srcs, "-o", out, "-lz"])
+          f"-I{os.path.join(REPO_DIR, 'include')}", *flags, *srcs, "-o", out, "-lz", "-ldl"])
     return out
 
 

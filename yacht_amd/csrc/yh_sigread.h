@@ -72,10 +72,10 @@ struct Scanner {
 // dies, main.cpp:73-81: callers must treat it as fatal).
 enum { READ_OK = 0, READ_CANNOT_OPEN = 1, READ_MALFORMED = 2 };
 // the mins of record 0, signature 0 of a signature file's text (what read_mins returns for the file)
-inline std::vector<uint64_t> mins_from_text(const std::string& text, int* status = nullptr) {
+inline std::vector<uint64_t> mins_from_text(const char* text_p, size_t text_n, int* status = nullptr) {
     std::vector<uint64_t> mins;
     if (status) *status = READ_OK;
-    Scanner s{text.data(), text.data() + text.size()};
+    Scanner s{text_p, text_p + text_n};
     if (!s.lit('[') || !s.find_key("signatures") || !s.lit('[') || !s.find_key("mins") || !s.lit('[')) {
         if (status) *status = READ_MALFORMED;
         return mins;
@@ -107,6 +107,10 @@ inline std::vector<uint64_t> mins_from_text(const std::string& text, int* status
         mins.erase(std::unique(mins.begin(), mins.end()), mins.end());
     }
     return mins;
+}
+
+inline std::vector<uint64_t> mins_from_text(const std::string& text, int* status = nullptr) {
+    return mins_from_text(text.data(), text.size(), status);
 }
 
 inline std::vector<uint64_t> read_mins(const std::string& path, bool report = true, int* status = nullptr) {
@@ -175,6 +179,8 @@ struct Md5 {  // RFC 1321, streaming
     }
     void update(const char* p, size_t n) {
         len += n;
+        if (fill == 0)
+            while (n >= 64) { block((const unsigned char*)p); p += 64; n -= 64; }
         while (n) {
             const size_t k = std::min(n, sizeof buf - fill);
             std::copy(p, p + k, buf + fill);
@@ -277,9 +283,14 @@ inline bool json_uint(Scanner& s, uint64_t* v) {
 }
 
 // `text` = the content of a .sig file.  The one signature of k-mer size `ksize` in it.
-inline Meta parse_meta(const std::string& text, int ksize) {
+// first_mins / have_first (optional): the "mins" of record 0, signature 0 -- what the train core reads from the same file
+// (mins_from_text) -- captured on the way when that array was there and strictly ascending; the caller may use it INSTEAD of a
+// second scan only when the whole file parsed (status META_OK, META_NOT_ONE or META_EMPTY) and *have_first is set.
+inline Meta parse_meta(const char* text_p, size_t text_n, int ksize, std::vector<uint64_t>* first_mins = nullptr, bool* have_first = nullptr) {
     Meta m;
-    Scanner s{text.data(), text.data() + text.size()};
+    if (have_first) *have_first = false;
+    uint64_t rec_idx = 0;
+    Scanner s{text_p, text_p + text_n};
     auto bad = [&](int st) { m.status = st; return m; };
     if (!s.lit('[')) return bad(META_MALFORMED);
     if (s.lit(']')) return bad(META_NOT_ONE);
@@ -287,6 +298,7 @@ inline Meta parse_meta(const std::string& text, int ksize) {
         if (!s.lit('{')) return bad(META_MALFORMED);
         std::string rec_name;
         std::vector<Meta> found;
+        uint64_t sig_idx = 0;
         if (!s.lit('}')) {
             std::string key;
             do {
@@ -301,7 +313,7 @@ inline Meta parse_meta(const std::string& text, int ksize) {
                         do {  // signatures
                             if (!s.lit('{')) return bad(META_MALFORMED);
                             uint64_t k = 0, max_hash = 0, n = 0, n_ab = 0;
-                            bool have_k = false, have_ab = false, ascending = true;
+                            bool have_k = false, have_ab = false, ascending = true, have_mins = false, md_streamed = false;
                             uint64_t ab_sum = 0;  // (exact; numpy's mean of an int64 array is this sum in float64 over the count)
                             uint64_t prev = 0;
                             Md5 md;
@@ -313,11 +325,26 @@ inline Meta parse_meta(const std::string& text, int ksize) {
                                     if (sk == "ksize") { if (!json_uint(s, &k)) return bad(META_NEEDS_GENERAL_READER); have_k = true; }
                                     else if (sk == "max_hash") { if (!json_uint(s, &max_hash)) return bad(META_NEEDS_GENERAL_READER); }
                                     else if (sk == "mins") {
+                                        have_mins = true;
                                         if (!s.lit('[')) return bad(META_MALFORMED);
+                                        // the sketch's md5 is over str(ksize) + every hash in decimal: when the k-mer size is known
+                                        // by now (sourmash writes it first) the digits go into the md5 straight from the text
+                                        md_streamed = have_k && (int)k == ksize;
+                                        if (md_streamed) {
+                                            char tmp[24];
+                                            const int len = snprintf(tmp, sizeof tmp, "%llu", (unsigned long long)k);
+                                            md.update(tmp, (size_t)len);
+                                        }
                                         if (!s.lit(']')) {
                                             do {
                                                 uint64_t v;
+                                                s.ws();
+                                                const char* t0 = s.p;
                                                 if (!json_uint(s, &v)) return bad(META_MALFORMED);
+                                                if (md_streamed) {
+                                                    if (s.p - t0 > 1 && *t0 == '0') md_streamed = false;  // (not str(int): formatted below)
+                                                    else md.update(t0, (size_t)(s.p - t0));
+                                                }
                                                 if (n && v <= prev) ascending = false;
                                                 prev = v;
                                                 mins.push_back(v);
@@ -345,6 +372,11 @@ inline Meta parse_meta(const std::string& text, int ksize) {
                                 if (!s.lit('}')) return bad(META_MALFORMED);
                             }
                             if (!have_k) return bad(META_MALFORMED);
+                            if (first_mins && have_first && rec_idx == 0 && sig_idx == 0 && have_mins && ascending) {
+                                *first_mins = mins;  // (a copy: the md5 below still walks them)
+                                *have_first = true;
+                            }
+                            ++sig_idx;
                             if ((int)k == ksize) {
                                 if (!ascending || (have_ab && n_ab != n)) return bad(META_NEEDS_GENERAL_READER);  // (re-ordered / de-duplicated there)
                                 Meta one;
@@ -352,13 +384,16 @@ inline Meta parse_meta(const std::string& text, int ksize) {
                                 one.has_abundance = have_ab;
                                 one.mean_abundance = (have_ab && n) ? (double)ab_sum / (double)n : 0.0;
                                 one.scaled = max_hash ? (uint64_t)__builtin_nearbyintl(18446744073709551616.0L / (long double)max_hash) : 0;  // sourmash: round(2^64 / max_hash)
-                                char tmp[24];
-                                int len = snprintf(tmp, sizeof tmp, "%llu", (unsigned long long)k);
-                                md.update(tmp, (size_t)len);
-                                for (uint64_t v : mins) {
-                                    char* q = tmp + sizeof tmp;
-                                    do { *--q = (char)('0' + v % 10); v /= 10; } while (v);
-                                    md.update(q, (size_t)(tmp + sizeof tmp - q));
+                                if (!md_streamed) {  // (ksize behind mins in the object, or a number not written as str(int))
+                                    md = Md5();
+                                    char tmp[24];
+                                    int len = snprintf(tmp, sizeof tmp, "%llu", (unsigned long long)k);
+                                    md.update(tmp, (size_t)len);
+                                    for (uint64_t v : mins) {
+                                        char* q = tmp + sizeof tmp;
+                                        do { *--q = (char)('0' + v % 10); v /= 10; } while (v);
+                                        md.update(q, (size_t)(tmp + sizeof tmp - q));
+                                    }
                                 }
                                 one.md5 = md.hex();
                                 found.push_back(std::move(one));
@@ -370,6 +405,7 @@ inline Meta parse_meta(const std::string& text, int ksize) {
             } while (s.lit(','));
             if (!s.lit('}')) return bad(META_MALFORMED);
         }
+        ++rec_idx;
         for (Meta& f : found) {  // ("name" may come behind "signatures" in the record)
             ++m.n_matching;
             if (m.n_matching == 1) {
@@ -385,5 +421,6 @@ inline Meta parse_meta(const std::string& text, int ksize) {
     else if (m.n_hashes == 0) m.status = META_EMPTY;
     return m;
 }
+inline Meta parse_meta(const std::string& text, int ksize) { return parse_meta(text.data(), text.size(), ksize); }
 
 }  // namespace yh_sig

@@ -9,8 +9,10 @@
 #include <atomic>
 #include <thread>
 
+#include <dlfcn.h>
 #include <fcntl.h>
 #include <sys/stat.h>
+#include <time.h>
 #include <unistd.h>
 #include <zlib.h>
 
@@ -134,11 +136,14 @@ int yh_sig_batch_sizes(const yh_sig_batch* b, uint64_t* offsets) {
 
 int yh_sig_batch_values(const yh_sig_batch* b, uint64_t* values) {
     if (!b || (!values && !b->mins.empty())) { yh_set_error("null argument"); return YH_ERR_INVALID_ARG; }
-    uint64_t at = 0;
-    for (const auto& m : b->mins) {
-        if (!m.empty()) memcpy(values + at, m.data(), m.size() * sizeof(uint64_t));
-        at += m.size();
-    }
+    std::vector<uint64_t> at(b->mins.size() + 1, 0);
+    for (size_t i = 0; i < b->mins.size(); ++i) at[i + 1] = at[i] + b->mins[i].size();
+    // (3.3e8 hashes at GTDB scale: 2.7 GB into fresh pages -- a few threads instead of one)
+    const int threads = at.back() > (1u << 22) ? (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u) : 1;
+    for_each_threaded(b->mins.size(), threads, [&](uint64_t i) {
+        const auto& m = b->mins[i];
+        if (!m.empty()) memcpy(values + at[i], m.data(), m.size() * sizeof(uint64_t));
+    });
     return YH_OK;
 }
 
@@ -368,6 +373,109 @@ bool zip_directory(int fd, uint64_t fsize, std::vector<ZipEntry>* out, std::stri
     return true;
 }
 
+// A per-thread byte buffer that grows without being zero-filled (std::string::resize clears what inflate is about to
+// overwrite: 8 GB of memset over a GTDB database).
+struct RawBuf {
+    char* p = nullptr;
+    size_t cap = 0, n = 0;
+    ~RawBuf() { free(p); }
+    bool room(size_t want) {
+        if (want <= cap) return true;
+        size_t c = cap ? cap : (size_t)1 << 16;
+        while (c < want) c *= 2;
+        char* q = (char*)realloc(p, c);
+        if (!q) return false;
+        p = q;
+        cap = c;
+        return true;
+    }
+};
+// libdeflate, when the machine has it (no header needed for three functions; zlib otherwise): 2-3 x zlib's inflate rate on
+// whole buffers, which is what a zip member is.  Looked up once.
+struct Deflate {
+    void* (*alloc)(void) = nullptr;
+    void (*release)(void*) = nullptr;
+    int (*gzip)(void*, const void*, size_t, void*, size_t, size_t*) = nullptr;
+    int (*raw)(void*, const void*, size_t, void*, size_t, size_t*) = nullptr;
+    Deflate() {
+        static const bool off = [] { const char* e = yh_tune_env("YH_NO_LIBDEFLATE"); return e && e[0] == '1'; }();
+        if (off) return;
+        void* h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+        if (!h) return;
+        alloc = (void* (*)(void))dlsym(h, "libdeflate_alloc_decompressor");
+        release = (void (*)(void*))dlsym(h, "libdeflate_free_decompressor");
+        gzip = (int (*)(void*, const void*, size_t, void*, size_t, size_t*))dlsym(h, "libdeflate_gzip_decompress");
+        raw = (int (*)(void*, const void*, size_t, void*, size_t, size_t*))dlsym(h, "libdeflate_deflate_decompress");
+        if (!alloc || !release || !gzip || !raw) alloc = nullptr;
+    }
+    bool ok() const { return alloc != nullptr; }
+};
+const Deflate& deflate_lib() { static const Deflate d; return d; }
+struct Decompressor {  // one per thread
+    void* d = nullptr;
+    Decompressor() { if (deflate_lib().ok()) d = deflate_lib().alloc(); }
+    ~Decompressor() { if (d) deflate_lib().release(d); }
+};
+
+// ONE gzip member whose trailer names its size (what sourmash writes): a single inflate call straight into `out`.
+// false: not that shape (several members, a size that does not fit, a corrupt stream) -- the caller takes the general route.
+bool gunzip_oneshot(const char* in, size_t n_in, RawBuf* out) {
+    if (n_in < 18 || (unsigned char)in[0] != 0x1f || (unsigned char)in[1] != 0x8b) return false;
+    const uint32_t isize = rd32((const unsigned char*)in + n_in - 4);
+    if (isize > (1u << 30)) return false;
+    if (!out->room((size_t)isize + 1)) return false;
+    static thread_local Decompressor dec;
+    if (dec.d) {  // (LIBDEFLATE_SUCCESS = 0; anything else -- several members, a bad stream -- takes zlib's opinion below)
+        size_t got = 0;
+        if (deflate_lib().gzip(dec.d, in, n_in, out->p, (size_t)isize, &got) == 0 && got == isize) { out->n = isize; return true; }
+    }
+    z_stream z;
+    memset(&z, 0, sizeof z);
+    if (inflateInit2(&z, 15 + 16) != Z_OK) return false;
+    z.next_in = (Bytef*)in;
+    z.avail_in = (uInt)n_in;
+    z.next_out = (Bytef*)out->p;
+    z.avail_out = (uInt)isize + 1;
+    const int rc = inflate(&z, Z_FINISH);
+    const bool ok = rc == Z_STREAM_END && z.avail_in == 0 && z.total_out == isize;
+    inflateEnd(&z);
+    out->n = ok ? isize : 0;
+    return ok;
+}
+
+// the bytes of one member (stored or deflated), into a raw buffer
+bool zip_member_raw(int fd, uint64_t fsize, const ZipEntry& e, RawBuf* scratch, RawBuf* out) {
+    unsigned char lh[30];
+    if (e.lho + 30 > fsize || !pread_all(fd, lh, 30, e.lho) || rd32(lh) != 0x04034b50u) return false;
+    const uint64_t data = e.lho + 30 + rd16(lh + 26) + rd16(lh + 28);
+    if (data + e.comp > fsize) return false;
+    if (e.method == 0) {
+        if (!out->room(e.comp + 1)) return false;
+        out->n = e.comp;
+        return e.comp == 0 || pread_all(fd, out->p, e.comp, data);
+    }
+    if (e.method != 8) return false;
+    if (!scratch->room(e.comp + 1) || !out->room(e.uncomp + 1)) return false;
+    if (e.comp && !pread_all(fd, scratch->p, e.comp, data)) return false;
+    static thread_local Decompressor dec;
+    if (dec.d) {
+        size_t got = 0;
+        if (deflate_lib().raw(dec.d, scratch->p, e.comp, out->p, e.uncomp, &got) == 0 && got == e.uncomp) { out->n = e.uncomp; return true; }
+    }
+    z_stream z;
+    memset(&z, 0, sizeof z);
+    if (inflateInit2(&z, -15) != Z_OK) return false;
+    z.next_in = (Bytef*)scratch->p;
+    z.avail_in = (uInt)e.comp;
+    z.next_out = (Bytef*)out->p;
+    z.avail_out = (uInt)e.uncomp;
+    const int rc = inflate(&z, Z_FINISH);
+    const bool ok = rc == Z_STREAM_END && z.avail_out == 0;
+    inflateEnd(&z);
+    out->n = ok ? e.uncomp : 0;
+    return ok;
+}
+
 // the bytes of one member (stored or deflated)
 bool zip_member(int fd, uint64_t fsize, const ZipEntry& e, std::string* out) {
     unsigned char lh[30];
@@ -456,41 +564,78 @@ int yh_zip_sig_ingest(const char* zip_path, const char* out_dir, int ksize, int 
     }
     std::atomic<bool> oom{false};
     std::atomic<int> io_failed{0};
+    // (YH_TRACE_BUILD=1 behind the tuning gate: where the threads' time went, summed over the threads)
+    static const bool trace = [] { const char* e = yh_tune_env("YH_TRACE_BUILD"); return e && e[0] == '1'; }();
+    std::atomic<uint64_t> ns_read{0}, ns_gunzip{0}, ns_parse{0}, ns_write{0};
+    auto now_ns = [] { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec; };
+    const uint64_t t_begin = now_ns();
     for_each_threaded(dir.size(), threads, [&](uint64_t i) {
         try {
+            static thread_local RawBuf scratch, bytes, plain;
             const ZipEntry& e = dir[i];
             if (ends_with(e.name, "/")) return;
             const uint64_t k = sig_of[i];
             if (k == ~(uint64_t)0 && !out_dir) return;  // (not a signature, nothing to write: not read at all)
-            std::string bytes, plain;
-            if (!zip_member(fd, fsize, e, &bytes)) {
+            uint64_t t0 = trace ? now_ns() : 0;
+            if (!zip_member_raw(fd, fsize, e, &scratch, &bytes)) {
                 io_failed.store(1);
                 if (k != ~(uint64_t)0) b->m[k].status = yh_sig::META_CANNOT_OPEN;
                 return;
             }
+            if (trace) { const uint64_t t1 = now_ns(); ns_read += t1 - t0; t0 = t1; }
             std::string out_name = e.name;
-            const std::string* text = &bytes;
-            if (ends_with(e.name, ".sig.gz") && gunzip_buffer(bytes, &plain)) {  // (one that does not inflate stays as it is)
-                out_name.resize(out_name.size() - 3);
-                text = &plain;
+            const char* text = bytes.p;
+            size_t text_n = bytes.n;
+            std::string general;  // (only for streams the one-shot form does not take)
+            if (ends_with(e.name, ".sig.gz")) {
+                if (gunzip_oneshot(bytes.p, bytes.n, &plain)) {
+                    out_name.resize(out_name.size() - 3);
+                    text = plain.p;
+                    text_n = plain.n;
+                } else if (gunzip_buffer(std::string(bytes.p, bytes.n), &general)) {  // several members, an odd trailer
+                    out_name.resize(out_name.size() - 3);
+                    text = general.data();
+                    text_n = general.size();
+                }  // (one that does not inflate stays as it is)
             }
+            if (trace) { const uint64_t t1 = now_ns(); ns_gunzip += t1 - t0; t0 = t1; }
             if (out_dir) {
                 const std::string path = root + "/" + out_name;
-                FILE* f = fopen(path.c_str(), "wb");
-                const bool ok = f && fwrite(text->data(), 1, text->size(), f) == text->size();
-                if (f && fclose(f) != 0) io_failed.store(1);
+                const int ofd = open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
+                bool ok = ofd >= 0;
+                for (size_t off = 0; ok && off < text_n;) {
+                    const ssize_t w = write(ofd, text + off, text_n - off);
+                    if (w <= 0) ok = false; else off += (size_t)w;
+                }
+                if (ofd >= 0 && close(ofd) != 0) ok = false;
                 if (!ok) io_failed.store(1);
+                if (trace) { const uint64_t t1 = now_ns(); ns_write += t1 - t0; t0 = t1; }
             }
             if (k == ~(uint64_t)0) return;
             b->rel_paths[k] = out_name;
-            int st = 0;
-            b->mins[k] = yh_sig::mins_from_text(*text, &st);  // what the train core reads from the file (record 0, signature 0)
-            b->mins_status[k] = (uint8_t)st;
-            b->m[k] = yh_sig::parse_meta(*text, ksize);
+            // one scan for both readers: the metadata of the signature of this k-mer size, and -- what the train core reads from
+            // the file -- the mins of record 0 / signature 0, captured on the way when the whole file parses
+            std::vector<uint64_t> first;
+            bool have_first = false;
+            b->m[k] = yh_sig::parse_meta(text, text_n, ksize, &first, &have_first);
+            const int st_meta = b->m[k].status;
+            if (have_first && (st_meta == yh_sig::META_OK || st_meta == yh_sig::META_NOT_ONE || st_meta == yh_sig::META_EMPTY)) {
+                b->mins[k] = std::move(first);
+                b->mins_status[k] = (uint8_t)yh_sig::READ_OK;
+            } else {
+                int st = 0;
+                b->mins[k] = yh_sig::mins_from_text(text, text_n, &st);
+                b->mins_status[k] = (uint8_t)st;
+            }
+            if (trace) ns_parse += now_ns() - t0;
         } catch (...) {
             oom.store(true);
         }
     });
+    if (trace)
+        fprintf(stderr, "[yh ingest] %zu members, %llu signatures, %d threads: wall %.3f s; thread-seconds: read+inflate %.2f, gunzip %.2f, write %.2f, parse+md5 %.2f\n",
+                dir.size(), (unsigned long long)n_sig, threads, (now_ns() - t_begin) * 1e-9, ns_read.load() * 1e-9, ns_gunzip.load() * 1e-9,
+                ns_write.load() * 1e-9, ns_parse.load() * 1e-9);
     close(fd);
     if (oom.load()) { delete b; yh_set_error("out of host memory while reading %s", zip_path); return YH_ERR_OOM; }
     if (io_failed.load()) { delete b; yh_set_error("%s: a member could not be read, inflated or written", zip_path); return YH_ERR_INVALID_ARG; }

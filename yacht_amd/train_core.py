@@ -126,7 +126,7 @@ def read_sketches_csr(paths: Sequence[str], threads: int = 1):
             raise ValueError(f"{bad.size} signature file(s) could not be parsed, first: {paths[int(bad[0])]}")
         offsets = np.zeros(len(paths) + 1, dtype=np.uint64)
         _lib.check(lib.yh_sig_batch_sizes(h, offsets.ctypes.data_as(C.c_void_p)))
-        values = np.zeros(int(offsets[-1]), dtype=np.uint64)
+        values = np.empty(int(offsets[-1]), dtype=np.uint64)  # (every element is written by the library)
         _lib.check(lib.yh_sig_batch_values(h, values.ctypes.data_as(C.c_void_p)))
     finally:
         lib.yh_sig_batch_destroy(h)
