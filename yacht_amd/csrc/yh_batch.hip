@@ -32,6 +32,14 @@ inline u32 grid_for(u64 work_items, u32 block, u32 max_blocks = 16384) {
 #define YH_BATCH_TILE 2048
 #endif
 constexpr u32 BATCH_TILE = YH_BATCH_TILE;
+#ifndef YH_BATCH_U
+#define YH_BATCH_U 1
+#endif
+// hashes a lane has in flight.  ONE: measured (scripts/sweep_batch_u.sh, profiles/r04/batch_u.txt) 0.0154 ms per sample at 1,
+// 0.0168 at 2, 0.0233 at 4, 0.0371 at 8 -- unlike the single-sample lookup (two per lane), this pass has its parallelism
+// from eight resident workgroups per CU working on the SAME presence-filter lines for different samples; more hashes per
+// lane cost registers, i.e. resident waves, and spread a workgroup's reads in time.
+constexpr int BATCH_U = YH_BATCH_U;
 constexpr u32 BATCH_TBITS = 10;
 __global__ void __launch_bounds__(256) k_batch_lookup(const u64* __restrict__ samples, const u64* __restrict__ soff,
                                                       u32 n_samples, const YhDirView dv, const u64* __restrict__ po,
@@ -94,20 +102,57 @@ __global__ void __launch_bounds__(256) k_batch_lookup(const u64* __restrict__ sa
             if (shared) atomicAdd(&row2[ref], 1u);
         };
         const u64 k_end = min(n_s, (i + 1) * BATCH_TILE);
-        for (u64 k = i * BATCH_TILE + threadIdx.x; k < k_end; k += 256) {
-            const u64 h = samples[off[s] + k];
-            if (filter && h <= dv.max_hash) {  // presence bit first (yh_db::d_filter): clear = not in the database
-                const u64 bit = yh_bucket_of(h, dv.bkt_lsh, filter_mul);
-                const u32 m = yh_filter_mask(h, bit);
-                if ((filter[bit >> 5] & m) != m) continue;
+        // BATCH_U hashes of a lane at a time: all presence words are requested, then the buckets of the hashes that passed,
+        // then they are looked at (BATCH_U = 1: word, bucket, counts, next hash)
+        for (u64 k0 = i * BATCH_TILE; k0 < k_end; k0 += 256u * BATCH_U) {  // (workgroup-uniform)
+            u64 h[BATCH_U];
+            bool ok[BATCH_U];
+            u32 w[BATCH_U];
+            u64 bit[BATCH_U];
+            YhDirView::v4u a[BATCH_U], b[BATCH_U], c[BATCH_U], d[BATCH_U];
+#pragma unroll
+            for (int u = 0; u < BATCH_U; ++u) {
+                const u64 k = k0 + (u64)u * 256u + threadIdx.x;
+                h[u] = samples[off[s] + min(k, k_end - 1)];
+                ok[u] = k < k_end && h[u] <= dv.max_hash;
+                if (!ok[u]) h[u] = 0;  // (still a valid word / bucket to read)
             }
-            const u32 r = dv.find(h);
-            if (r == YH_DIR_NONE) continue;
-            if (!(r & 0x80000000u)) {
-                add(r, false);
-            } else {
-                const u32 gi = r & 0x7fffffffu;
-                for (u64 q = po[gi], qe = po[gi + 1]; q < qe; ++q) add(pr[q], true);
+            if (filter) {
+#pragma unroll
+                for (int u = 0; u < BATCH_U; ++u) {
+                    bit[u] = yh_bucket_of(h[u], dv.bkt_lsh, filter_mul);
+                    w[u] = filter[bit[u] >> 5];
+                }
+#pragma unroll
+                for (int u = 0; u < BATCH_U; ++u) {
+                    const u32 m = yh_filter_mask(h[u], bit[u]);
+                    ok[u] = ok[u] && (w[u] & m) == m;
+                }
+            }
+            if (dv.cbkt) {
+#pragma unroll
+                for (int u = 0; u < BATCH_U; ++u) {
+                    a[u] = b[u] = c[u] = d[u] = YhDirView::v4u{0u, 0u, 0u, 0u};
+#if defined(YH_BATCH_NT) && YH_BATCH_NT
+                    if (ok[u]) dv.cbkt_request_nt(h[u], a[u], b[u], c[u], d[u]);
+#else
+                    if (ok[u]) dv.cbkt_request(h[u], a[u], b[u], c[u], d[u]);
+#endif
+                }
+#pragma unroll
+                for (int u = 0; u < BATCH_U; ++u) asm volatile("" : "+v"(a[u]), "+v"(b[u]), "+v"(c[u]), "+v"(d[u]));  // (see YhDirView::find)
+            }
+#pragma unroll
+            for (int u = 0; u < BATCH_U; ++u) {
+                if (!ok[u]) continue;
+                const u32 r = dv.cbkt ? dv.cbkt_resolve(h[u], a[u], b[u], c[u], d[u]) : dv.find(h[u]);
+                if (r == YH_DIR_NONE) continue;
+                if (!(r & 0x80000000u)) {
+                    add(r, false);
+                } else {
+                    const u32 gi = r & 0x7fffffffu;
+                    for (u64 q = po[gi], qe = po[gi + 1]; q < qe; ++q) add(pr[q], true);
+                }
             }
         }
         __syncthreads();

@@ -363,6 +363,15 @@ struct YhDirView {
         // measured 3-10 us SLOWER per launch: profiles/r03/filter_sweep.txt)
         a = p[0]; b = p[1]; c = p[2]; d = p[3];
     }
+    // the same with non-temporal loads: the bucket is read once and should not push re-used lines (the presence filter of a
+    // batched pass) out of the XCD's L2
+    __device__ __forceinline__ void cbkt_request_nt(u64 h, v4u& a, v4u& b, v4u& c, v4u& d) const {
+        const v4u* p = reinterpret_cast<const v4u*>(cbkt) + 4 * yh_bucket_of(h, bkt_lsh, bkt_mul);
+        a = __builtin_nontemporal_load(p);
+        b = __builtin_nontemporal_load(p + 1);
+        c = __builtin_nontemporal_load(p + 2);
+        d = __builtin_nontemporal_load(p + 3);
+    }
     // ... and look at them
     __device__ __forceinline__ u32 cbkt_resolve(u64 h, const v4u a, const v4u b, const v4u c, const v4u d) const {
         const u32 lo = (u32)h, n = b.w & 0xfu;
