@@ -448,6 +448,13 @@ int yh_sig_meta_destroy(yh_sig_meta* meta);
  *   yh_sig_meta_count   signature members found
  *   yh_sig_meta_paths   their paths relative to out_dir (path_offsets[n + 1]; paths == NULL: sizes only)            */
 int yh_zip_sig_ingest(const char* zip_path, const char* out_dir, int ksize, int threads, yh_sig_meta** out);
+/* The same files WITHOUT the metadata, written in the background: creating 85 205 files in one directory is mostly the
+ * directory's lock, so `yacht train` reads the archive with out_dir == NULL above and lets threads of their own leave the
+ * unzipped members behind while it does the rest.  yh_zip_extract_start returns at once; yh_zip_extract_wait joins, frees
+ * the job and reports a member that could not be read, inflated or written (YH_ERR_INVALID_ARG).                    */
+typedef struct yh_zip_job yh_zip_job;
+int yh_zip_extract_start(const char* zip_path, const char* out_dir, int threads, yh_zip_job** out);
+int yh_zip_extract_wait(yh_zip_job* job, uint64_t* n_members);
 int yh_sig_meta_count(const yh_sig_meta* meta, uint64_t* n);
 int yh_sig_meta_paths(const yh_sig_meta* meta, uint64_t* path_offsets, char* paths);
 

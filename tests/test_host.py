@@ -386,6 +386,18 @@ def test_zip_ingest_one_pass_equals_the_three_passes(tmp_path):
     assert train_core.parsed_paths() is None
     v2, o2 = train_core.read_sketches_csr(paths, threads=2)  # (from the files this time)
     assert np.array_equal(values, v2) and np.array_equal(offsets, o2) and offsets.size == 21
+    # the files written in the BACKGROUND while the archive is read without writing (what `yacht train` does)
+    bg_dir = tmp_path / "bg"
+    bg = utils.BackgroundExtraction(src, str(bg_dir), 3)
+    info_bg = utils.ingest_zip_database(src, str(bg_dir), 31, 4, write_files=False, background=bg)
+    train_core.drop_parsed_sketches()
+    assert bg.wait() == 21 and bg.wait() == 0  # (20 signatures + the manifest; a second wait is a no-op)
+    assert {k: v[:4] for k, v in info_bg.items()} == {k: v[:4] for k, v in info.items()}
+    for p_ in sorted((ref / "signatures").glob("*.sig")):
+        assert (bg_dir / "signatures" / p_.name).read_bytes() == p_.read_bytes()
+    assert (bg_dir / "SOURMASH-MANIFEST.csv").read_bytes() == (ref / "SOURMASH-MANIFEST.csv").read_bytes()
+    with pytest.raises(_lib.YachtHipError):
+        utils.BackgroundExtraction(str(tmp_path / "missing.zip"), str(tmp_path / "w5"), 2)
     # nothing written: the same records, no directory
     lean = tmp_path / "lean"
     info2 = utils.ingest_zip_database(src, str(lean), 31, 4, write_files=False)

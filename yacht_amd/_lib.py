@@ -152,6 +152,8 @@ SIGNATURES = {
     "yh_sig_meta_names": (C.c_int, [_vp, _vp]),
     "yh_sig_meta_destroy": (C.c_int, [_vp]),
     "yh_zip_sig_ingest": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "yh_zip_extract_start": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(_vp)]),
+    "yh_zip_extract_wait": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "yh_sig_meta_count": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "yh_sig_meta_paths": (C.c_int, [_vp, _vp, _vp]),
 }

@@ -145,6 +145,7 @@ def main(args) -> None:
         raise ValueError(MSG_NOT_ZIP.format(zip_path))
     utils.check_file_existence(zip_path, MSG_NO_ZIP.format(zip_path))
     _fresh_workdir(workdir, args.force)
+    extraction = None
     if not zipfile.is_zipfile(zip_path):
         raise zipfile.BadZipFile(f"File is not a zip file: {zip_path}")
     if getattr(args, "python_ingest", False):
@@ -153,11 +154,15 @@ def main(args) -> None:
         with phases.phase("signature_metadata"):
             sig_info = utils.collect_signature_info(args.num_threads, args.ksize, workdir)
     else:
-        # one pass over the archive: members inflated, parsed and (unless --no_sig_files) written by native threads
+        # one pass over the archive: members inflated and parsed by native threads; unless --no_sig_files, the unzipped
+        # members are left in the working directory by threads of their own WHILE the comparison runs (85 205 file
+        # creations are the directory's lock, not CPU), waited for before the command returns
         logger.info("Reading the sourmash signature database")
+        if not getattr(args, "no_sig_files", False):
+            extraction = utils.BackgroundExtraction(zip_path, workdir, max(2, min(int(args.num_threads), 16)))
         with phases.phase("ingest"):
-            sig_info = utils.ingest_zip_database(zip_path, workdir, args.ksize, args.num_threads,
-                                                 write_files=not getattr(args, "no_sig_files", False))
+            sig_info = utils.ingest_zip_database(zip_path, workdir, args.ksize, args.num_threads, write_files=False,
+                                                 background=extraction)
     scaled_values = {record[-2] for record in sig_info.values()}
     if len(scaled_values) != 1:
         raise ValueError(MSG_SCALES)
@@ -173,6 +178,9 @@ def main(args) -> None:
               "ksize": args.ksize, "ani_thresh": args.ani_thresh}
     with open(os.path.join(outdir, f"{args.prefix}_config.json"), "w") as out:
         json.dump(config, out, indent=4)
+    if extraction is not None:
+        with phases.phase("wait_for_sig_files"):
+            extraction.wait()
     logger.info(f"{len(kept)} of {len(sig_info)} references kept; config written to {outdir}")
 
 

@@ -138,7 +138,41 @@ def collect_signature_info(num_threads: int, ksize: int, path_to_temp_dir: str) 
     return out
 
 
-def ingest_zip_database(zip_path: str, path_to_temp_dir: str, ksize: int, num_threads: int, write_files: bool = True) -> Dict[str, Tuple]:
+class BackgroundExtraction:
+    """The members of a .zip database being written to a directory by native threads (yh_zip_extract_start); wait()
+    joins and raises what failed.  `yacht train` starts one, reads the archive without writing anything, runs the
+    comparison, and waits at the end: the 85 205 file creations of a GTDB database are the directory's lock, not CPU."""
+
+    def __init__(self, zip_path: str, out_dir: str, threads: int):
+        import ctypes as C
+
+        from . import _lib
+
+        self._lib = _lib.load()
+        self._h = C.c_void_p()
+        _lib.check(self._lib.yh_zip_extract_start(os.fsencode(zip_path), os.fsencode(out_dir), max(1, int(threads)), C.byref(self._h)))
+
+    def wait(self) -> int:
+        import ctypes as C
+
+        from . import _lib
+
+        if self._h is None or not self._h.value:
+            return 0
+        n = C.c_uint64(0)
+        h, self._h = self._h, None
+        _lib.check(self._lib.yh_zip_extract_wait(h, C.byref(n)))
+        return int(n.value)
+
+    def __del__(self):
+        try:
+            self.wait()
+        except Exception:
+            pass
+
+
+def ingest_zip_database(zip_path: str, path_to_temp_dir: str, ksize: int, num_threads: int, write_files: bool = True,
+                        background: Optional[BackgroundExtraction] = None) -> Dict[str, Tuple]:
     """`yacht train`'s unzip + gunzip + metadata passes in ONE pass over the archive (yh_zip_sig_ingest; reference
     make_training_data_from_sketches.py:107-133, utils.py:201-221, :499-509): the same dictionary collect_signature_info
     returns -- name -> (md5sum, mean abundance, sketch size, scaled, path) -- with the signature members in the archive's
@@ -189,7 +223,9 @@ def ingest_zip_database(zip_path: str, path_to_temp_dir: str, ksize: int, num_th
             name = raw[int(name_off[i]):int(name_off[i + 1])].decode("utf-8", "replace")
             out[name] = (md5_raw[33 * i:33 * i + 32].decode("ascii"), float(mean_ab[i]) if has_ab[i] else None, int(n_hashes[i]),
                          int(scaled[i]), path)
-        elif st == 5 and write_files:
+        elif st == 5 and (write_files or background is not None):
+            if background is not None:
+                background.wait()  # (the general reader opens the file)
             rec = get_info_from_single_sig(path, ksize)
             if rec:
                 out[rec[1]] = (rec[2], rec[3], rec[4], rec[5], rec[0])
@@ -229,12 +265,14 @@ def run_yacht_train_core(num_threads: int, ani_thresh: float, ksize: int, path_t
     (reference utils.py:112-197).  Same files are left behind: training_sig_files.tsv,
     selected_result.tsv, comparison_files/<pass>_<thread>.txt; same manifest columns returned."""
     sig_dir = os.path.join(path_to_temp_dir, "signatures")
-    sig_files = [os.path.join(sig_dir, f) for f in os.listdir(sig_dir)] if os.path.isdir(sig_dir) else []
     # (the reference's file list is os.listdir's order -- whatever the file system gives.  When the ingest pass has the
-    # sketches of exactly these files in hand, the list takes ITS order -- the archive's -- and nothing is read twice.)
+    # database's sketches in hand, the list is ITS list in its order -- the archive's -- and nothing is read twice; the
+    # files themselves may still be on their way to the directory: utils.BackgroundExtraction.)
     offered = train_core.parsed_paths()
-    if offered is not None and (not sig_files or set(offered) == set(sig_files)):
+    if offered is not None:
         sig_files = list(offered)
+    else:
+        sig_files = [os.path.join(sig_dir, f) for f in os.listdir(sig_dir)]
     sig_files_path = os.path.join(path_to_temp_dir, "training_sig_files.tsv")
     pd.DataFrame(sig_files).to_csv(sig_files_path, header=False, index=False)
 
