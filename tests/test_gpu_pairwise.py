@@ -107,3 +107,48 @@ def test_more_survivors_than_the_first_buffer(hip_lib):
         gi, gj, gc = db.pairwise(0.0)
         assert np.array_equal(gi, wi) and np.array_equal(gj, wj) and np.array_equal(gc, wc)
         assert db.index_stats() == wstats
+
+
+SORT_WORKER = r"""
+import json, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from oracle import oracle
+from yacht_amd import synth
+from yacht_amd.engine import RefDB, YH_DB_PAIRWISE_ONLY
+
+rng = np.random.default_rng(3)
+mh = synth.max_hash_for_scaled(1000)
+base = [synth.random_sketch(rng, 400, mh) for _ in range(2000)]
+for a in range(0, 2000, 5):           # clusters: neighbours share half of a sketch
+    base[a + 1] = np.unique(np.concatenate([base[a + 1], base[a][::2]]))
+heavy = int(sys.argv[2])              # one hash held by this many references
+if heavy:
+    h = np.array([int(rng.integers(1, mh))], np.uint64)
+    for r in rng.choice(2000, size=heavy, replace=False):
+        base[int(r)] = np.unique(np.concatenate([base[int(r)], h]))
+values, offsets = synth.pack(base)
+wi, wj, wc, wstats = oracle.train_pairs(values, offsets, 0.2, threads=4)
+ok = True
+for flags in (YH_DB_PAIRWISE_ONLY, 0):
+    with RefDB(values, offsets, flags=flags) as db:
+        gi, gj, gc = db.pairwise(0.2)
+        ok = ok and bool(np.array_equal(gi, wi) and np.array_equal(gj, wj) and np.array_equal(gc, wc) and db.index_stats() == wstats)
+print(json.dumps({"ok": ok, "pairs": int(wi.size)}))
+"""
+
+
+@pytest.mark.parametrize("heavy,verdict", [(0, "taken"), (800, "taken"), (2000, "REFUSED")])
+def test_distribution_sort_takes_uniform_keys_and_refuses_the_rest(hip_lib, heavy, verdict):
+    """yh_sort.hip on 2 000 sketches (8e5 hashes, ~310 buckets): uniform keys and a hash held by 800 references are sorted by
+    it; a hash held by all 2 000 overflows its bucket, is refused on the device and sorted by rocPRIM -- the verdict line
+    says which ([yh sort] ... taken / REFUSED), the order is checked on the device either way (YH_CHECK_SORT) and pairs
+    and statistics equal the oracle's."""
+    env = dict(os.environ)
+    env.update({"YH_DEBUG_TUNING": "1", "YH_TRACE_BUILD": "1", "YH_CHECK_SORT": "1"})
+    r = subprocess.run([sys.executable, "-c", SORT_WORKER, ROOT, str(heavy)], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["ok"] and out["pairs"] > 300
+    lines = [ln for ln in r.stderr.splitlines() if ln.startswith("[yh sort]")]
+    assert len(lines) == 2 and all(ln.rstrip().endswith(verdict) for ln in lines), lines

@@ -38,7 +38,7 @@ constexpr u32 BKT_FILL = 2560;       // ... and holds on average (uniform keys: 
 constexpr u32 BKT_THREADS = 1024;
 constexpr u32 BKT_ITEMS = BKT_CAP / BKT_THREADS;
 constexpr u32 BKT_SLOTS = 4096;      // fine slots of the counting sort inside a bucket (= 1 << BKT_SLOT_BITS)
-constexpr u32 SLOT_MAX = 256;        // pairs of one slot a pair ranks itself against; more: not this sort's input
+constexpr u32 SLOT_MAX = 1024;       // pairs of one slot a pair ranks itself against (a hash held by that many references: 10^6 LDS reads); more: not this sort's input
 
 constexpr u32 BKT_SLOT_BITS = 12;
 // The FINE slot of a hash -- floor(h * NB * S / (max_hash + 1)), S = 2^BKT_SLOT_BITS slots per bucket -- is the one linear
