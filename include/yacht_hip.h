@@ -425,7 +425,9 @@ int yh_sig_batch_destroy(yh_sig_batch* batch);
  *                      3 not exactly one signature of that k-mer size, 4 empty sketch, 5 a shape this reader leaves to
  *                      the general (Python) one -- unsorted mins, non-integer fields.
  *   yh_sig_meta_get    arrays of n entries; md5 as n x 33 bytes (NUL-terminated); name_offsets[n + 1] into the byte
- *                      buffer yh_sig_meta_names fills (UTF-8, not terminated).
+ *                      buffer yh_sig_meta_names fills (UTF-8, not terminated).  has_abundance: bit 0 = the signature has
+ *                      abundances; bit 1 = it is record 0 / signature 0 of its file, i.e. its mins are the sketch
+ *                      yh_sig_meta_take_batch hands over for this file.
  *   yh_sig_meta_read_keep / yh_sig_meta_take_batch   the same pass also keeps what the train core reads from each file
  *                      (yh_sig_batch_read's sketches and statuses, taken from the text while it is in memory), and hands
  *                      it over as a yh_sig_batch: the 85 205 files of a GTDB training set are read once, not twice.     */

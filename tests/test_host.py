@@ -439,3 +439,44 @@ def test_zip_ingest_one_pass_equals_the_three_passes(tmp_path):
     assert not (tmp_path / "outside.sig").exists()
     with pytest.raises(_lib.YachtHipError):
         utils.ingest_zip_database(os.path.join(FX, "test_collect_signature_info_data.json"), str(tmp_path / "w4"), 31, 2)
+
+
+def test_sample_archive_through_the_native_scanner_equals_the_python_reader(tmp_path):
+    """utils.load_signature_with_ksize reads a one-signature archive -- a sample -- through the library's scanner
+    (yh_zip_sig_ingest): the same name, md5, sizes, mins, mean abundance and (lazily) abundances as the general reader,
+    which still handles every other shape: several signature files, several k-mer sizes with the wanted one not first,
+    no signature of that size, an empty one (the reference's messages)."""
+    import json as js
+
+    from yacht_amd import sigio
+
+    f = os.path.join(FX, "sample.sig.zip")
+    a = utils.load_signature_with_ksize(f, 31)
+    b = sigio.load_file_as_signatures(f, ksize=31)[0]
+    assert type(a.minhash).__name__ == "_NativeMinHash"
+    assert a.name == b.name and a.md5sum() == b.md5sum() and len(a.minhash) == len(b.minhash) == 49821
+    assert a.minhash.scaled == b.minhash.scaled == 1000 and a.minhash.max_hash == b.minhash.max_hash
+    assert a.minhash.mean_abundance == b.minhash.mean_abundance and a.minhash.track_abundance
+    assert np.array_equal(a.minhash.mins, b.minhash.mins) and np.array_equal(a.minhash.abundances, b.minhash.abundances)
+    assert a.minhash.hashes == b.minhash.hashes
+    assert utils._load_single_signature_native(os.path.join(FX, "20_genomes_sketches.zip"), 31) is None   # 20 files
+    assert utils._load_single_signature_native(f, 21) is None                                              # no such k
+    with pytest.raises(ValueError, match="Expected exactly one signature with ksize 21"):
+        utils.load_signature_with_ksize(f, 21)
+    with pytest.raises(ValueError, match="Empty sketch"):
+        utils.load_signature_with_ksize(os.path.join(FX, "extract_empty_hash.sig.zip"), 31)
+    # two k-mer sizes in one file, the wanted one second: the core's "first signature" is another sketch -> general reader
+    two = [sigio.make_signature(np.array([1, 5, 9], np.uint64), ksize=21, scaled=1000, name="two"),
+           sigio.make_signature(np.array([2, 6, 10, 14], np.uint64), ksize=31, scaled=1000, name="two")]
+    rec = sigio.signature_record(two[0])
+    rec["signatures"].append(sigio.signature_record(two[1])["signatures"][0])
+    import zipfile
+    z = tmp_path / "two.sig.zip"
+    with zipfile.ZipFile(z, "w") as out:
+        out.writestr(sigio.MANIFEST_NAME, sigio.MANIFEST_HEADER + "\n")
+        out.writestr("signatures/x.sig", js.dumps([rec]))
+    assert utils._load_single_signature_native(str(z), 31) is None
+    got = utils.load_signature_with_ksize(str(z), 31)
+    assert got.minhash.mins.tolist() == [2, 6, 10, 14] and type(got.minhash).__name__ == "MinHash"
+    first = utils.load_signature_with_ksize(str(z), 21)     # the first signature IS the wanted one: native
+    assert first.minhash.mins.tolist() == [1, 5, 9] and type(first.minhash).__name__ == "_NativeMinHash" and first.minhash.mean_abundance is None

@@ -213,6 +213,7 @@ struct Meta {
     std::string name, md5;
     double mean_abundance = 0.0;
     bool has_abundance = false;
+    bool is_first = false;  // the signature is record 0 / signature 0 of its file: its mins are what the train core reads from it
     uint64_t n_hashes = 0, scaled = 0;
 };
 
@@ -380,6 +381,7 @@ inline Meta parse_meta(const char* text_p, size_t text_n, int ksize, std::vector
                             if ((int)k == ksize) {
                                 if (!ascending || (have_ab && n_ab != n)) return bad(META_NEEDS_GENERAL_READER);  // (re-ordered / de-duplicated there)
                                 Meta one;
+                                one.is_first = rec_idx == 0 && sig_idx == 1;  // (sig_idx counts this signature already)
                                 one.n_hashes = n;
                                 one.has_abundance = have_ab;
                                 one.mean_abundance = (have_ab && n) ? (double)ab_sum / (double)n : 0.0;

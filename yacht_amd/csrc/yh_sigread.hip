@@ -255,7 +255,7 @@ int yh_sig_meta_get(const yh_sig_meta* b, uint8_t* status, uint64_t* n_hashes, u
         n_hashes[i] = x.n_hashes;
         scaled[i] = x.scaled;
         mean_abundance[i] = x.mean_abundance;
-        has_abundance[i] = x.has_abundance ? 1 : 0;
+        has_abundance[i] = (uint8_t)((x.has_abundance ? 1 : 0) | (x.is_first ? 2 : 0));
         memset(md5 + 33 * i, 0, 33);
         memcpy(md5 + 33 * i, x.md5.data(), std::min<size_t>(x.md5.size(), 32));
         name_offsets[i] = at;

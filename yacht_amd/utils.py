@@ -35,9 +35,102 @@ FILE_LOCATION = os.path.dirname(os.path.realpath(__file__))
 __version__ = "1.4.0"  # the reference interface version mirrored here
 
 
+class _NativeMinHash(sigio.MinHash):
+    """The sketch of a one-signature archive as the library's scanner read it (yh_zip_sig_ingest): mins, md5, mean
+    abundance, scaled -- what `yacht run` uses of a sample (run_YACHT.py:150-165).  The per-hash abundances, which nothing on
+    this path reads, are parsed by the general reader only if somebody asks for them."""
+
+    def __init__(self, mins, ksize, scaled, mean_abundance, md5, filename):
+        self.mins = np.ascontiguousarray(mins, dtype=np.uint64)
+        self.ksize = int(ksize)
+        self._scaled = int(scaled)
+        self.max_hash = sigio.max_hash_for_scaled(self._scaled)
+        self.seed = 42
+        self.moltype = "DNA"
+        self.num = 0
+        self._mean_abundance = mean_abundance
+        self._md5 = md5
+        self._filename = filename
+        self._abundances = None
+
+    @property
+    def scaled(self) -> int:
+        return self._scaled
+
+    @property
+    def abundances(self):
+        if self._mean_abundance is None:
+            return None
+        if self._abundances is None:
+            self._abundances = sigio.load_file_as_signatures(self._filename, ksize=self.ksize)[0].minhash.abundances
+        return self._abundances
+
+    @property
+    def mean_abundance(self):
+        return self._mean_abundance
+
+    def md5sum(self) -> str:
+        return self._md5
+
+
+def _load_single_signature_native(filename: str, ksize: int):
+    """The signature of a sourmash .zip that holds exactly ONE signature file whose first signature is the one of this k-mer
+    size -- a sample -- through the library's scanner (a 10^6-hash sample: 0.03 s instead of 0.3 s of json.loads + an md5 over a
+    million decimal strings); None for every other shape, which the general reader below handles (and complains about)."""
+    import ctypes as C
+
+    from . import _lib
+
+    try:
+        if not str(filename).endswith(".zip"):
+            return None
+        lib = _lib.load()
+        h = C.c_void_p()
+        if lib.yh_zip_sig_ingest(os.fsencode(filename), None, int(ksize), 2, C.byref(h)) != _lib.YH_OK:
+            return None
+    except Exception:
+        return None
+    hb = C.c_void_p()
+    try:
+        cnt = C.c_uint64(0)
+        _lib.check(lib.yh_sig_meta_count(h, C.byref(cnt)))
+        if cnt.value != 1:
+            return None
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        status, n_hashes, scaled = np.zeros(1, np.uint8), np.zeros(1, np.uint64), np.zeros(1, np.uint64)
+        mean_ab, has_ab, md5, name_off = np.zeros(1, np.float64), np.zeros(1, np.uint8), np.zeros(33, np.uint8), np.zeros(2, np.uint64)
+        _lib.check(lib.yh_sig_meta_get(h, vp(status), vp(n_hashes), vp(scaled), vp(mean_ab), vp(has_ab), vp(md5), vp(name_off)))
+        if int(status[0]) != 0 or not (int(has_ab[0]) & 2):
+            return None
+        names_buf = np.zeros(max(int(name_off[1]), 1), np.uint8)
+        _lib.check(lib.yh_sig_meta_names(h, vp(names_buf)))
+        _lib.check(lib.yh_sig_meta_take_batch(h, C.byref(hb)))
+        st = np.zeros(1, np.uint8)
+        _lib.check(lib.yh_sig_batch_status(hb, vp(st)))
+        off = np.zeros(2, np.uint64)
+        _lib.check(lib.yh_sig_batch_sizes(hb, vp(off)))
+        if int(st[0]) != 0 or int(off[1]) != int(n_hashes[0]) or int(off[1]) == 0:
+            return None
+        mins = np.empty(int(off[1]), np.uint64)
+        _lib.check(lib.yh_sig_batch_values(hb, vp(mins)))
+        name = names_buf.tobytes()[: int(name_off[1])].decode("utf-8", "replace")
+        mh = _NativeMinHash(mins, ksize, int(scaled[0]), float(mean_ab[0]) if int(has_ab[0]) & 1 else None,
+                            md5.tobytes()[:32].decode("ascii"), filename)
+        return sigio.Signature(mh, name=name, filename="")
+    except Exception:
+        return None
+    finally:
+        if hb.value:
+            lib.yh_sig_batch_destroy(hb)
+        lib.yh_sig_meta_destroy(h)
+
+
 def load_signature_with_ksize(filename: str, ksize: int) -> sigio.Signature:
     """Exactly one non-empty signature of the given k-mer size, else ValueError
     (reference utils.py:31-51, same messages)."""
+    fast = _load_single_signature_native(filename, ksize)
+    if fast is not None:
+        return fast
     sketches = sigio.load_file_as_signatures(filename, ksize=ksize)
     if len(sketches) != 1:
         raise ValueError(f"Expected exactly one signature with ksize {ksize} in {filename}, found {len(sketches)}")
@@ -128,7 +221,7 @@ def collect_signature_info(num_threads: int, ksize: int, path_to_temp_dir: str) 
     for i, path in enumerate(paths):
         st = int(status[i])
         if st == 0:
-            out[names[i]] = (md5s[i], float(mean_ab[i]) if has_ab[i] else None, int(n_hashes[i]), int(scaled[i]), path)
+            out[names[i]] = (md5s[i], float(mean_ab[i]) if has_ab[i] & 1 else None, int(n_hashes[i]), int(scaled[i]), path)
         elif st == 5:  # a shape the scanner leaves to the general reader
             rec = get_info_from_single_sig(path, ksize)
             if rec:
@@ -221,7 +314,7 @@ def ingest_zip_database(zip_path: str, path_to_temp_dir: str, ksize: int, num_th
         st = int(status[i])
         if st == 0:
             name = raw[int(name_off[i]):int(name_off[i + 1])].decode("utf-8", "replace")
-            out[name] = (md5_raw[33 * i:33 * i + 32].decode("ascii"), float(mean_ab[i]) if has_ab[i] else None, int(n_hashes[i]),
+            out[name] = (md5_raw[33 * i:33 * i + 32].decode("ascii"), float(mean_ab[i]) if has_ab[i] & 1 else None, int(n_hashes[i]),
                          int(scaled[i]), path)
         elif st == 5 and (write_files or background is not None):
             if background is not None:
