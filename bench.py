@@ -170,6 +170,14 @@ def cpu_model() -> str:
 def main() -> int:
     args = parse_args()
     args.pipelined_tail = not args.plain_steps
+    wall = {}  # this process's wall-clock by section (seconds): a slow box or a driver stall shows up here
+    t_wall = [time.perf_counter()]
+
+    def stamp(name: str) -> None:
+        now = time.perf_counter()
+        wall[name] = round(wall.get(name, 0.0) + now - t_wall[0], 2)
+        t_wall[0] = now
+
     if args.scaling is None:
         args.scaling = "strong" if args.gpus > 1 else "weak"  # (the same thing at N = 1)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.force_dist:
@@ -221,6 +229,7 @@ def main() -> int:
     if not os.path.exists(build.LIB_PATH):
         build.build_lib()
 
+    stamp("imports_and_init")
     # ---- synthetic workload, generated in HBM: this rank's shard of ONE global database -----------------
     if args.workload == "gtdb_rs214_scale":
         per_gpu = args.refs or REFS_PER_GPU
@@ -515,6 +524,7 @@ def main() -> int:
     ms_per_step = 1e3 * elapsed / n_timed
     value = n_total / (elapsed / n_timed)
 
+    stamp("database_and_timed_region")
     # ---- per-step percentiles: a separate pass with one HIP event between steps -------------------------
     n_pct = max(args.percentile_steps, args.steps)
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_pct + 1)]
@@ -555,6 +565,7 @@ def main() -> int:
             if not to_root or rank == 0:
                 assert bool(torch.equal(gathered_blk[b][rank], counts_blk[b])), "gather ran ahead of the kernels"
 
+    stamp("percentiles")
     # ---- N = 1 extras ------------------------------------------------------------------------------------
     indexed = host_inclusive = real_shape = None
     paths = {}
@@ -810,6 +821,7 @@ def main() -> int:
                           lookup_kernel_ms_avg=round(float(tm["ms_overlap_kernel"]), 4),
                           exclusive_kernels_ms_avg=round(float(tm["ms_exclusive_kernels"]), 4))
 
+    stamp("n1_extras")
     # ---- batched run: many samples against the resident database in ONE call -----------
     # Not `value` (a step there is one sample, as the reference runs them): the throughput a caller gets who has
     # the samples of a whole plate in hand.  Distinct samples, so that none finds its buckets cached.
@@ -851,6 +863,7 @@ def main() -> int:
                           "64-bit per-sample words; device-resident, distinct samples"}
         del cat, bout, bs
 
+    stamp("batched")
     # ---- what ONE rank of a G-way hash-range run computes per step, measured here (N = 1 only) ------------------
     # The first multi-GPU run has a prediction to be compared with: rank 0's range of the database (1 / G of the hashes
     # of every reference) is built on this GPU and the two halves of its step (yh_run_local_range_device,
@@ -973,6 +986,7 @@ def main() -> int:
                    "samples + the packing of its compact rows timed on its slice (no collectives); the collectives from their bytes",
         }
 
+    stamp("scaling_model")
     # ---- roofline of the dominant kernel of the DEFAULT step --------------------------------------------
     # Streaming lookup (k_stream_lookup): `achieved` = bytes one launch HAS to move in the layout the kernel
     # reads (yh_db_info.stream_bytes: one delta byte per (hash, reference) pair + an 8-byte header per 1024,
@@ -1088,6 +1102,7 @@ def main() -> int:
         except Exception:
             pass
 
+    stamp("roofline")
     # ---- CPU baseline + full-size parity (rank 0, the WHOLE database) -----------------------------------
     cpu_baseline = None
     parity = None
@@ -1140,6 +1155,7 @@ def main() -> int:
                           f"overlap {t_ov:.2f} s on {cores} threads + exclusive {t_ex:.2f} s on 1 thread",
             }
 
+    stamp("cpu_baseline_and_parity")
     # ---- the `yacht train` side of the path (BASELINE configs[3]) in the same driver-timed run: bench_train.py as a CHILD
     # process (its own handle, its own JSON line), after this process has released its database
     train = None
@@ -1163,7 +1179,7 @@ def main() -> int:
         try:
             tp = subprocess.run([sys.executable, os.path.join(ROOT, "bench_train.py"), "--steps", "5"]
                                 + (["--no-oracle"] if args.no_cpu_baseline else []),
-                                stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+                                stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=420)
             tl = [ln for ln in tp.stdout.splitlines() if ln.startswith("{")]
             train = json.loads(tl[-1]) if tl else {"error": (tp.stderr or "")[-500:]}
             train["returncode"] = tp.returncode
@@ -1171,6 +1187,7 @@ def main() -> int:
             train = {"error": repr(ex)}
         train["wall_s_of_the_child"] = round(time.perf_counter() - t0, 1)
 
+    stamp("train_child")
     # ---- the sketcher next to the path, likewise as a child process with its own JSON line
     sketch_block = None
     if rank == 0 and not multi and not args.no_sketch and not args.no_train:
@@ -1179,7 +1196,7 @@ def main() -> int:
         t0 = time.perf_counter()
         try:
             sp = subprocess.run([sys.executable, os.path.join(ROOT, "bench_sketch.py"), "--steps", "6"],
-                                stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+                                stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240)
             sl = [ln for ln in sp.stdout.splitlines() if ln.startswith("{")]
             sketch_block = json.loads(sl[-1]) if sl else {"error": (sp.stderr or "")[-500:]}
             sketch_block["returncode"] = sp.returncode
@@ -1187,6 +1204,7 @@ def main() -> int:
             sketch_block = {"error": repr(ex)}
         sketch_block["wall_s_of_the_child"] = round(time.perf_counter() - t0, 1)
 
+    stamp("sketch_child")
     if rank == 0:
         try:
             import scipy
@@ -1229,6 +1247,8 @@ def main() -> int:
                 "ghost_refs_rank0": (sdb.n_ghost if sdb is not None else 0),
                 "db_build_ms": round(float(timing["ms_db_build"]), 2),
                 "db_rebuild_ms": db_rebuild_ms,
+                "device_memory": ylib.alloc_stats(),
+                "wall_s_by_section": wall,
                 "db_build_note": "device input; HIP events around validation + sort + index + tables, host stalls included: a hipMalloc of a "
                                  "multi-GB block sporadically takes 0.7-4 s on this pool (profiles/r04/malloc_probe.txt, a plain HIP program) -- "
                                  "round 3's 705-815 ms; db_rebuild_ms = the same build again behind the first handle's destroy, its arrays out of "

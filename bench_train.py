@@ -58,6 +58,14 @@ def main() -> int:
     ap.add_argument("--backend", default="nccl")
     ap.add_argument("--share-gpu", action="store_true", help="testing: all ranks on cuda:0 (gloo)")
     args = ap.parse_args()
+    wall = {}  # where this process's wall-clock went (seconds per section): a slow box shows up here, not in the medians
+    t_wall = [time.perf_counter()]
+
+    def stamp(name: str) -> None:
+        now = time.perf_counter()
+        wall[name] = round(wall.get(name, 0.0) + now - t_wall[0], 2)
+        t_wall[0] = now
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = 0 if args.share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
@@ -86,6 +94,7 @@ def main() -> int:
     if _lib.device_count() < 1:
         print("bench_train.py needs an MI355X (no CPU fallback)", file=sys.stderr)
         return 2
+    stamp("imports_and_device_count")
     c = 0.95 ** 31
     values, offsets = synth.config4(seed=1003, n_clusters=args.clusters, size=args.size)
     n = offsets.size - 1
@@ -99,6 +108,7 @@ def main() -> int:
         range_slice = ydist.slice_csr_to_hash_range(values, offsets, bnd[rank], bnd[rank + 1])
     # ---- the sketches already in HBM (the `yacht run` -> re-train case; every rank of a multi-GPU train behind the first
     # broadcast): yh_db_create_device + yh_pairwise + selection -- no PCIe in the call, the kernels' own rate
+    stamp("synthetic_sketches")
     device_input = None
     if world == 1 and not args.no_device_input:
         import torch
@@ -137,6 +147,7 @@ def main() -> int:
             "_results": (di, dj, dc, dsel, dstats),
         }
         del d_values, d_offsets
+        stamp("device_input_passes")
     t_build, t_pair, t_sel = [], [], []
     k_pair_ms = []
     pi = pj = pc = None
@@ -195,6 +206,7 @@ def main() -> int:
         t_pair.append(t2 - t1)
         t_sel.append(t3 - t2)
         k_pair_ms.append(tm["ms_pairwise_kernels"])
+    stamp("host_input_passes")
     if not t_build:  # --device-input: only those passes ran; the line's main figures are theirs
         pi, pj, pc, sel, stats = device_input["_results"]
         t_build = [0.0, device_input["seconds"]["create_device"]]
@@ -238,6 +250,7 @@ def main() -> int:
                "cpu_model": _cpu_model(),
                "sample": f"first {k} sketches ({int(o2[-1])} hashes): index build on 1 thread + scatter on {cores} "
                          f"threads + selection, {t_cpu:.2f} s"}
+        stamp("cpu_port_and_parity")
         # the GENUINE reference executable (oracle/_ref, built from /root/reference/src/cpp/main.cpp in the
         # build container and shipped as a binary): timed on the same sketches, and its files compared
         # with the HIP path's results
@@ -266,6 +279,7 @@ def main() -> int:
                    "outputs_equal_hip_path": same,
                    "port_value": round(k * (k - 1) / 2 / t_cpu, 1)}
 
+    stamp("genuine_reference_executable")
     # configs[3] at its REAL size against the genuine reference: tests/golden/golden_train_cfg3.json holds what
     # oracle/_ref/run_yacht_train_core wrote for this very input (selected ids in walk order, the three index statistics,
     # a sha256 over the sorted pair lines) -- made once in the build container by tests/golden/make_golden.py cfg3
@@ -290,6 +304,7 @@ def main() -> int:
         elif parity is None:
             parity = golden["all_equal"]
 
+    stamp("full_size_golden_compare")
     # what ONE rank of a G-way hash-range run does (N = 1 only): rank 0's range of every sketch through upload + index +
     # pairwise(0.0) on this GPU; the merge of the partial lists is measured on this host with G copies of that list
     scaling_model = None
@@ -329,6 +344,7 @@ def main() -> int:
                                 "the sum-per-pair of G such lists on the device (torch.unique + scatter_add, as over RCCL) + selection + 0.3 ms assumed for "
                                 "the two small all-gathers"}
 
+    stamp("scaling_model")
     # algorithmic bytes: every reference hash once + one (i, j, count) per emitted pair
     alg = 8 * int(offsets[-1]) + 12 * int(pi.size)
     out = {
@@ -350,6 +366,8 @@ def main() -> int:
         "parity_bit_exact": parity,
         "full_size_vs_genuine_reference": golden,
         "scaling_model": scaling_model,
+        "wall_s_by_section": wall,
+        "device_memory": _lib.alloc_stats(),
     }
     if device_input is not None:
         di, dj, dc, dsel, dstats = device_input.pop("_results")

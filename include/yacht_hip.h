@@ -109,6 +109,11 @@ typedef struct yh_timing {
 const char* yh_last_error(void);
 int yh_abi_version(void);
 int yh_device_count(int* n_devices);
+/* Process-wide counters of the device buffer cache behind every handle: how often the library had to go to the
+ * driver for memory (hipMalloc), the host milliseconds spent inside those calls (on this pool a multi-GB hipMalloc
+ * now and then takes seconds: profiles/r04/malloc_probe.txt), and the bytes the cache holds idle now.  Any pointer
+ * may be NULL.  No GPU needed. */
+int yh_alloc_stats(uint64_t* n_driver_allocs, double* ms_in_driver, uint64_t* bytes_idle);
 
 /* ---- database handle ------------------------------------------------------------------ */
 /* Upload a CSR reference database to `device_id`, validate ordering, and build what the queries read: the

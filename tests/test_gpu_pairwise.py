@@ -66,10 +66,19 @@ def _run(seed, env_extra):
     return json.loads(r.stdout.strip().splitlines()[-1])
 
 
-@pytest.mark.parametrize("cols", [None, 64, 128])
+@pytest.mark.parametrize("cols", [None, 64, 128, "unfused", "lists"])
 def test_pairwise_rows_against_the_oracle(hip_lib, cols):
-    env = {} if cols is None else {"YH_DEBUG_TUNING": "1", "YH_PAIR_COLS": str(cols)}
-    out = _run(5 if cols is None else cols, env)
+    """YH_DB_PAIRWISE_ONLY handles take the fused path (records written by the sort's last pass, yh_sort.hip), the others the
+    posting arrays + k_pair_transpose; "unfused": the train handle without the fused path (posting ranks); "lists": every fused
+    record in list form (what >= 2^21 - 1 references get)."""
+    env = {} if cols is None else {"YH_DEBUG_TUNING": "1"}
+    if cols == "unfused":
+        env["YH_NO_FUSED_TRAIN"] = "1"
+    elif cols == "lists":
+        env["YH_FZ_NO_INLINE"] = "1"
+    elif cols is not None:
+        env["YH_PAIR_COLS"] = str(cols)
+    out = _run(cols if isinstance(cols, int) else 5, env)
     assert out["n"] > 300
     checks = {k: v for k, v in out.items() if k != "n"}
     assert len(checks) == 6

@@ -87,6 +87,7 @@ SIGNATURES = {
     "yh_last_error": (C.c_char_p, []),
     "yh_abi_version": (C.c_int, []),
     "yh_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "yh_alloc_stats": (C.c_int, [C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "yh_db_create": (C.c_int, [_vp, _vp, C.c_uint64, C.c_int, C.c_uint32, C.POINTER(_vp)]),
     "yh_db_create_device": (C.c_int, [_vp, _vp, C.c_uint64, C.c_int, C.c_uint32, C.POINTER(_vp)]),
     "yh_db_destroy": (C.c_int, [_vp]),
@@ -221,3 +222,10 @@ def device_count() -> int:
     n = C.c_int(0)
     rc = load().yh_device_count(C.byref(n))
     return n.value if rc == YH_OK else 0
+
+
+def alloc_stats() -> dict:
+    """This process's trips to the driver for device memory (yh_alloc_stats): count, host ms inside hipMalloc, idle cached bytes."""
+    n, ms, idle = C.c_uint64(0), C.c_double(0.0), C.c_uint64(0)
+    check(load().yh_alloc_stats(C.byref(n), C.byref(ms), C.byref(idle)))
+    return {"driver_allocs": int(n.value), "ms_in_driver": round(float(ms.value), 1), "bytes_idle": int(idle.value)}

@@ -43,6 +43,8 @@ std::mutex g_cache_mu;
 std::vector<CacheBlock> g_cache;                      // free blocks
 std::unordered_map<void*, size_t> g_cache_live;       // blocks handed out: their sizes
 std::vector<std::pair<int, hipEvent_t>> g_cache_events;  // idle events, by device
+uint64_t g_driver_allocs = 0;                         // hipMalloc calls made for handles (yh_alloc_stats)
+double g_driver_alloc_ms = 0.0;                       // host time inside them
 bool cache_on() {
     static const bool on = [] { const char* off = yh_tune_env("YH_NO_POOL"); return !(off && off[0] == '1'); }();
     return on;
@@ -105,9 +107,15 @@ hipError_t yh_tmalloc(yh_db* db, void** p, size_t bytes) {
         if (we != hipSuccess) { (void)hipGetLastError(); return hipDeviceSynchronize(); }
         return hipSuccess;
     }
-    const double t0 = alloc_trace_on() ? alloc_now_ms() : 0.0;
+    const double t0 = alloc_now_ms();
     hipError_t e = hipMalloc(p, bytes);
-    if (alloc_trace_on() && alloc_now_ms() - t0 > 0.5) fprintf(stderr, "[yh alloc] cache miss: hipMalloc(%.1f MB) took %.3f ms\n", bytes / 1e6, alloc_now_ms() - t0);
+    const double took = alloc_now_ms() - t0;
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        ++g_driver_allocs;
+        g_driver_alloc_ms += took;
+    }
+    if (alloc_trace_on() && took > 0.5) fprintf(stderr, "[yh alloc] cache miss: hipMalloc(%.1f MB) took %.3f ms\n", bytes / 1e6, took);
     if (e == hipErrorOutOfMemory) {  // give the driver back what the cache holds, and once more
         (void)hipGetLastError();
         (void)hipDeviceSynchronize();
@@ -315,6 +323,17 @@ extern "C" {
 const char* yh_last_error(void) { return g_err; }
 int yh_abi_version(void) { return YH_ABI_VERSION; }
 
+int yh_alloc_stats(uint64_t* n_driver_allocs, double* ms_in_driver, uint64_t* bytes_idle) {
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    if (n_driver_allocs) *n_driver_allocs = g_driver_allocs;
+    if (ms_in_driver) *ms_in_driver = g_driver_alloc_ms;
+    if (bytes_idle) {
+        uint64_t b = 0;
+        for (const CacheBlock& c : g_cache) b += c.bytes;
+        *bytes_idle = b;
+    }
+    return YH_OK;
+}
 int yh_device_count(int* n_devices) {
     if (!n_devices) { yh_set_error("n_devices is null"); return YH_ERR_INVALID_ARG; }
     int n = 0;
@@ -496,7 +515,7 @@ int yh_db_destroy(yh_db* db) {
                     db->d_rpo, db->d_rg, db->d_rrec, db->d_rrecx, db->d_filter, db->d_hrec, db->d_hrecx, db->d_hmult, db->d_hpo,
                     db->d_work, db->d_work_count, db->d_mask, db->d_maskbits, db->d_hit, db->d_excl_e, db->d_overlap_tmp,
                     db->d_sample_tmp, db->d_out_tmp, db->d_flag, db->d_reps, db->batch[0].d_scratch, db->batch[1].d_scratch, db->batch[2].d_scratch, db->d_sdelta, db->d_shdr, db->d_srec,
-                    db->d_wg_key, db->d_ghost_src, db->d_bad_word, db->d_prank};
+                    db->d_wg_key, db->d_ghost_src, db->d_bad_word, db->d_prank, db->d_fz_rec, db->d_fz_list, db->d_fz_off, db->d_fz_tab};
     for (void* p : ptrs)
         if (p) yh_dfree(db, p);
     for (auto& pair : db->ev_xfer)
@@ -694,9 +713,10 @@ int yh_run_batch(yh_db* db, const uint64_t* samples, const uint64_t* sample_offs
     u32* d_out = nullptr;
     int rc = YH_OK;
     do {
-        if (hipMalloc((void**)&d_s, std::max<u64>(total, 2) * sizeof(u64)) != hipSuccess ||
-            hipMalloc((void**)&d_o, (u64)(n_samples + 1) * sizeof(u64)) != hipSuccess ||
-            hipMalloc((void**)&d_out, 3 * BN * sizeof(u32)) != hipSuccess) { yh_set_error("hipMalloc failed"); rc = YH_ERR_OOM; break; }
+        // (from the buffer cache: a caller that batches sample after sample does not go to the driver every time)
+        if (yh_tmalloc(db, (void**)&d_s, std::max<u64>(total, 2) * sizeof(u64)) != hipSuccess ||
+            yh_tmalloc(db, (void**)&d_o, (u64)(n_samples + 1) * sizeof(u64)) != hipSuccess ||
+            yh_tmalloc(db, (void**)&d_out, 3 * BN * sizeof(u32)) != hipSuccess) { yh_set_error("device allocation failed"); rc = YH_ERR_OOM; break; }
         xfer_mark(db, 0, 0);
         const bool up_ok = (!total || hipMemcpyAsync(d_s, samples, total * sizeof(u64), hipMemcpyHostToDevice, db->stream) == hipSuccess) &&
                            hipMemcpyAsync(d_o, sample_offsets, (u64)(n_samples + 1) * sizeof(u64), hipMemcpyHostToDevice, db->stream) == hipSuccess;
@@ -714,7 +734,7 @@ int yh_run_batch(yh_db* db, const uint64_t* samples, const uint64_t* sample_offs
             yh_set_error("batch download failed: %s", hipGetErrorString(hipGetLastError())); rc = YH_ERR_HIP;
         }
     } while (0);
-    (void)hipFree(d_s); (void)hipFree(d_o); (void)hipFree(d_out);
+    yh_tfree(db, d_s); yh_tfree(db, d_o); yh_tfree(db, d_out);
     return rc;
 }
 
@@ -1335,6 +1355,7 @@ int yh_db_nshared_device(yh_db* db, uint32_t* d_out) {
     if (!db->has_index) { yh_set_error("this handle was created with YH_DB_NO_INDEX"); return YH_ERR_UNSUPPORTED; }
     if (db->n_refs && !d_out) { yh_set_error("null device pointer"); return YH_ERR_INVALID_ARG; }
     YH_TRY(db_select(db));
+    YH_TRY(yh_q_fz_nshared(db));  // (a fused YH_DB_PAIRWISE_ONLY handle counts them now, once)
     if (db->n_refs)
         YH_HIP(hipMemcpyAsync(d_out, db->d_nshared, db->n_refs * sizeof(u32), hipMemcpyDeviceToDevice, db->stream));
     return YH_OK;

@@ -552,6 +552,58 @@ static bool trace_on() {
 }
 #define TRACE(label) do { if (trace_on()) { const double t__ = trace_now(); fprintf(stderr, "[yh build] %-28s +%.3f ms\n", label, t__ - t_prev); t_prev = t__; } } while (0)
 
+// ---- the fused path of a YH_DB_PAIRWISE_ONLY handle (yh_db::fz; yh_sort.hip: k_bucket_sort<true>) ---------------------
+// `yacht train` wants nothing of the index but the pairwise pass's input.  Where the distribution sort takes the pairs,
+// they carry their CSR POSITION instead of the reference id, and the sort's last pass -- which has every run of equal
+// hashes whole and in order in LDS -- writes the 8-byte record "the other holders of this element's hash" straight to the
+// element's position: a reference's records are the extent of its sketch.  Gone: the sorted pairs themselves (12 B written
+// and read again), k_idx_emit with its counting atomic per posting, k_pair_transpose with its isolated store per posting,
+// the posting arrays, and the host's prefix sum over nshared[] in yh_pairwise.
+static bool fz_wanted(const yh_db* db) {
+    static const bool off = [] { const char* e = yh_tune_env("YH_NO_FUSED_TRAIN"); return e && e[0] == '1'; }();
+    return !off && (db->flags & YH_DB_PAIRWISE_ONLY) && !(db->flags & YH_DB_NO_INDEX) && db->n_refs > 0 && db->n_hashes > 0;
+}
+static void fz_drop(yh_db* db) {
+    const u64 N = db->n_refs, H = db->n_hashes;
+    if (db->d_fz_off) db->device_bytes -= (N + 1) * sizeof(u64);
+    if (db->d_fz_tab) db->device_bytes -= ((H >> YH_REF_TAB_SH) + 2) * sizeof(u32);
+    if (db->d_fz_rec) db->device_bytes -= H * sizeof(u64);
+    yh_dfree(db, db->d_fz_off); yh_dfree(db, db->d_fz_tab); yh_dfree(db, db->d_fz_rec);
+    db->d_fz_off = nullptr; db->d_fz_tab = nullptr; db->d_fz_rec = nullptr;
+}
+// the handle's copy of the offsets, the position -> reference look-up and the (still unwritten) records; then the sort in
+// position mode
+static int fz_begin(yh_db* db, const u64* d_offsets, u64 max_hash, yh_psort** ps) {
+    const u64 N = db->n_refs, H = db->n_hashes;
+    *ps = nullptr;
+    int rc = yh_dmalloc(db, (void**)&db->d_fz_off, (N + 1) * sizeof(u64));
+    if (rc == YH_OK) rc = yh_dmalloc(db, (void**)&db->d_fz_tab, ((H >> YH_REF_TAB_SH) + 2) * sizeof(u32));
+    if (rc == YH_OK) rc = yh_dmalloc(db, (void**)&db->d_fz_rec, H * sizeof(u64));
+    if (rc == YH_OK && hipMemcpyAsync(db->d_fz_off, d_offsets, (N + 1) * sizeof(u64), hipMemcpyDeviceToDevice, db->stream) != hipSuccess) {
+        yh_set_error("copy of the offsets failed");
+        rc = YH_ERR_HIP;
+    }
+    if (rc == YH_OK) rc = yh_ref_table_build(db, db->d_fz_off, N, H, db->d_fz_tab);
+    if (rc == YH_OK) rc = yh_psort_begin(db, H, max_hash, ps);
+    if (rc == YH_OK) yh_psort_positions(*ps, db->d_fz_tab, db->d_fz_off);
+    if (rc != YH_OK) { yh_psort_destroy(db, *ps); *ps = nullptr; fz_drop(db); }
+    return rc;
+}
+// the sort's second level + fused last pass; *took = false: not this sort's keys, everything of the attempt is released
+static int fz_finish(yh_db* db, yh_psort* ps, bool* took, bool* unsorted) {
+    u64 totals[3] = {0, 0, 0};
+    u32* d_list = nullptr;
+    int rc = yh_psort_finish_emit(db, ps, db->d_fz_rec, db->n_refs, totals, &d_list, took, unsorted);
+    yh_psort_destroy(db, ps);
+    if (rc != YH_OK || !*took) { fz_drop(db); return rc; }
+    db->d_fz_list = d_list;
+    db->n_distinct = totals[0];
+    db->n_shared = totals[1];
+    db->n_postings = totals[2];
+    db->fz = true;
+    return YH_OK;
+}
+
 int yh_build_upload_sorted(yh_db* db, const u64* h_values, const u64* h_offsets, u64* d_values, const u64* d_offsets,
                            u64** d_sk_out, u32** d_sv_out) {
     const u64 N = db->n_refs, H = db->n_hashes;
@@ -613,11 +665,15 @@ int yh_build_upload_sorted(yh_db* db, const u64* h_values, const u64* h_offsets,
         UP_HIP(hipEventCreate(&c2));
         if (rc == YH_OK) { ev.push_back(a); eb.push_back(b); ee.push_back(c2); }
     }
-    UP_HIP(yh_tmalloc(db, (void**)&K[0], H * sizeof(u64)));
-    UP_HIP(yh_tmalloc(db, (void**)&V[0], H * sizeof(u32)));
-    UP_HIP(yh_tmalloc(db, (void**)&d_ids, H * sizeof(u32)));
     const bool dist_sort = yh_psort_applicable(H, max_last);
-    if (rc == YH_OK && dist_sort) rc = yh_psort_begin(db, H, max_last, &ps);
+    bool fused = dist_sort && fz_wanted(db);  // (a YH_DB_PAIRWISE_ONLY handle: positions as values, no sorted pairs at all)
+    if (!fused) {
+        UP_HIP(yh_tmalloc(db, (void**)&K[0], H * sizeof(u64)));
+        UP_HIP(yh_tmalloc(db, (void**)&V[0], H * sizeof(u32)));
+        UP_HIP(yh_tmalloc(db, (void**)&d_ids, H * sizeof(u32)));
+    }
+    if (rc == YH_OK && fused) rc = fz_begin(db, d_offsets, max_last, &ps);
+    else if (rc == YH_OK && dist_sort) rc = yh_psort_begin(db, H, max_last, &ps);
     TRACE("stream, events, buffers");
     if (rc == YH_OK) rc = validate_begin(db);
     const int cur = 0;  // (the buffer the sorted pairs land in)
@@ -652,7 +708,9 @@ int yh_build_upload_sorted(yh_db* db, const u64* h_values, const u64* h_offsets,
         UP_HIP(hipStreamWaitEvent(st, ev[c], 0));
         UP_HIP(hipEventRecord(eb[c], st));
         if (rc == YH_OK) rc = validate_refs(db, d_values, d_offsets, r0, r1);
-        if (rc == YH_OK && n) {
+        if (rc == YH_OK && n && fused) {
+            rc = yh_psort_add(db, ps, d_values + e0, nullptr, n, e0);  // (the value of a pair is its position)
+        } else if (rc == YH_OK && n) {
             k_fill_ref_ids<<<grid_for((r1 - r0) * WAVE, 256), 256, 0, st>>>(d_offsets + r0, r1 - r0, d_ids, (u32)r0);
             if (ps) rc = yh_psort_add(db, ps, d_values + e0, d_ids + e0, n);  // this chunk's pairs into the first-level regions
         }
@@ -674,8 +732,20 @@ int yh_build_upload_sorted(yh_db* db, const u64* h_values, const u64* h_offsets,
     bool sorted = false;
     const bool timed_tail = rc == YH_OK && !eb.empty();
     if (timed_tail) UP_HIP(hipEventRecord(eb[0], st));  // (pair 0 again: the device time of the tail behind the last byte)
+    if (rc == YH_OK && fused) {  // second level + the fused last pass: the handle is complete behind it (yh_build_index sees db->fz)
+        bool took = false;
+        rc = fz_finish(db, ps, &took, nullptr);
+        ps = nullptr;
+        if (rc == YH_OK && !took) {  // not this sort's keys after all: the plain way, everything behind the upload
+            fused = false;
+            UP_HIP(yh_tmalloc(db, (void**)&K[0], H * sizeof(u64)));
+            UP_HIP(yh_tmalloc(db, (void**)&V[0], H * sizeof(u32)));
+            UP_HIP(yh_tmalloc(db, (void**)&d_ids, H * sizeof(u32)));
+            if (rc == YH_OK) k_fill_ref_ids<<<grid_for(N * WAVE, 256), 256, 0, st>>>(d_offsets, N, d_ids);
+        }
+    }
     if (rc == YH_OK && ps) rc = yh_psort_finish(db, ps, K[0], V[0], &sorted);  // second level + bucket sorts
-    if (rc == YH_OK && !sorted) {  // not this sort's keys: one rocPRIM sort of everything, behind the upload
+    if (rc == YH_OK && !sorted && !fused) {  // not this sort's keys: one rocPRIM sort of everything, behind the upload
         unsigned end_bit2 = 1;
         while (end_bit2 < 64 && (db->max_hash >> end_bit2) != 0) ++end_bit2;
         size_t tb = 0;
@@ -695,7 +765,7 @@ int yh_build_upload_sorted(yh_db* db, const u64* h_values, const u64* h_offsets,
     ps = nullptr;
     TRACE("sorted");
     if (rc == YH_OK && db->max_hash > max_last) { yh_set_error("internal: largest hash above the largest last element"); rc = YH_ERR_HIP; }
-    if (rc == YH_OK) {
+    if (rc == YH_OK && !fused) {
         static const bool check = [] { const char* e = yh_tune_env("YH_CHECK_SORT"); return e && e[0] == '1'; }();
         if (check) {
             u32 bad = 0;
@@ -781,6 +851,10 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, u64* d_
     YH_TRY(yh_dmalloc(db, (void**)&db->d_nshared, std::max<u64>(N, 1) * sizeof(u32)));
     YH_HIP(hipMemsetAsync(db->d_nshared, 0, std::max<u64>(N, 1) * sizeof(u32), st));
 
+    if (db->fz) {  // (yh_build_upload_sorted went the fused way: the records are there, nothing else is wanted)
+        db->has_index = true;
+        return YH_OK;
+    }
     db->n_distinct = 0;
     db->n_shared = 0;
     db->n_postings = 0;
@@ -795,6 +869,28 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, u64* d_
     if (H > 0xfffffff0ull * 2) {
         yh_set_error("index build supports at most 2^33 hashes per device");
         return YH_ERR_UNSUPPORTED;
+    }
+
+    bool try_psort = yh_psort_applicable(H, db->max_hash);
+    if (!d_sk_pre && try_psort && fz_wanted(db)) {  // the fused path from device memory (see fz_wanted above)
+        yh_psort* fps = nullptr;
+        bool took = false, unsorted = false;
+        YH_TRY(fz_begin(db, d_offsets, db->max_hash, &fps));
+        yh_psort_check_order(fps, !db->order_checked);  // (the first level reads every pair anyway)
+        int frc = yh_psort_add(db, fps, d_values, nullptr, H, 0);
+        if (frc != YH_OK) { yh_psort_destroy(db, fps); fz_drop(db); return frc; }
+        YH_TRY(fz_finish(db, fps, &took, &unsorted));
+        if (!db->order_checked && unsorted) {
+            yh_set_error("a reference sketch is not strictly ascending (or offsets are not monotone)");
+            return YH_ERR_UNSORTED;
+        }
+        if (took) {
+            db->order_checked = true;
+            db->has_index = true;
+            TRACE("index: fused records");
+            return YH_OK;
+        }
+        try_psort = false;  // (a capacity was exceeded: the plain distribution sort would refuse the same keys)
     }
 
     u32 *d_ids = nullptr, *d_sv = nullptr, *d_counts = nullptr;
@@ -832,7 +928,7 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, u64* d_
         // the pairs in (hash, reference) order: the distribution sort of yh_sort.hip for uniform keys (FracMinHash hashes
         // are), rocPRIM's LSD radix sort -- stable: equal hashes keep ascending references -- for anything else
         bool sorted = false;
-        if (rc == YH_OK && yh_psort_applicable(H, db->max_hash)) {
+        if (rc == YH_OK && try_psort) {
             bool unsorted = false;
             rc = yh_psort_begin(db, H, db->max_hash, &ps);
             if (rc == YH_OK) yh_psort_check_order(ps, !order_checked);  // (the first level reads every pair anyway)

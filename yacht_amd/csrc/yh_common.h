@@ -112,6 +112,16 @@ struct yh_db {
     u32* d_pg = nullptr;     // [postings] index of the hash each posting belongs to
     u32* d_prank = nullptr;  // [postings] YH_DB_PAIRWISE_ONLY: the posting's rank among its reference's shared hashes (yh_pairwise.hip)
     u32* d_nshared = nullptr;  // [N] number of shared hashes in reference j
+    // YH_DB_PAIRWISE_ONLY handles whose pairs the distribution sort took (yh_sort.hip, k_bucket_sort<true>): the sort's
+    // last pass writes what the pairwise pass reads, and none of g / po / pr / pg / prank exists -- ONE 8-byte record per
+    // CSR position, "the other holders of this element's hash" (0: no other holder), so a reference's records are the
+    // extent of its sketch and nothing is counted, ranked or transposed (yh_pairwise.hip: k_pair_rows<.., true>)
+    bool fz = false;
+    u64* d_fz_rec = nullptr;   // [H] bit 63 clear: up to three holders as 21-bit fields (reference + 1); set: {holders << 40 | first entry of d_fz_list}
+    u32* d_fz_list = nullptr;  // [buckets x 4096] the holders of every hash with more than four of them, at the hash's place in its bucket
+    u64* d_fz_off = nullptr;   // [N + 1] the CSR offsets = the rows of d_fz_rec
+    u32* d_fz_tab = nullptr;   // [H / 256 + 2] reference of every 256th CSR position (position -> reference look-ups)
+    bool fz_nshared = false;   // d_nshared has been counted from the records (on demand: yh_db_nshared_device)
 
     // full distinct-hash directory (only with YH_DB_FULL_INDEX): the sample-driven overlap path
     u64* d_dh = nullptr;       // [D] every distinct hash, ascending
@@ -434,6 +444,7 @@ int yh_q_batch_rows_unpack(yh_db* db, int slot, const u32* d_vals, u64 cap_rows,
 int yh_q_exclusive(yh_db* db, const u8* d_mask, const u64* d_sample, u64 n_sample,
                    const u32* d_overlap, u32* d_excl, u32* d_match, const u32* d_maskbits);
 int yh_q_pairwise(yh_db* db, double c_thresh, u64 r0, u64 r1);
+int yh_q_fz_nshared(yh_db* db);  // (yh_pairwise.hip) d_nshared of a fused handle, counted on first use
 // the presence filter a lookup may read in front of the compact buckets (null: none, or YH_NO_FILTER=1)
 inline const u32* yh_filter_of(const yh_db* db) {
     static const bool filter_off = [] { const char* e = yh_tune_env("YH_NO_FILTER"); return e && e[0] == '1'; }();

@@ -72,6 +72,8 @@ __device__ __forceinline__ bool pair_keep(u32 cnt, u32 i, u32 j, const u32* __re
 struct PairRows {
     const uint4* rrec;    // [postings] reference-major records
     const u32* rowptr;    // [N + 1]
+    const u64* frec;      // FUSED (yh_db::fz): 8-byte records, one per CSR position (yh_db::d_fz_rec) ...
+    const u64* foff;      // ... the rows = the sketches' extents (yh_db::d_fz_off); pr = yh_db::d_fz_list; cid / rid unused (identity)
     const u32* pr;        // hash-major holders (the long lists)
     const u32* cid;       // [N] compact id of a reference that holds a shared hash
     const u32* rid;       // [NC] back
@@ -99,9 +101,17 @@ constexpr int PAIR_U = YH_PAIR_U;  // records a lane has in flight
 #ifndef YH_ABLATE_PAIR
 #define YH_ABLATE_PAIR 0  // timing-only builds (results wrong): 1 no record pass, 2 no row clear / survivor scan, 4 records read but not added
 #endif
-template <int THREADS>
+// FUSED: the records are yh_db::d_fz_rec's (8 bytes per CSR position, written by the sort's last pass: yh_sort.hip) and a
+// row is the extent of the reference's sketch -- entries of hashes nobody else holds are 0 and add nothing.
+template <bool FUSED> struct PairRec { typedef uint4 T; };
+template <> struct PairRec<true> { typedef u64 T; };
+constexpr u64 FZ_LIST = 1ull << 63;
+constexpr u32 FZ_FIELD = (1u << 21) - 1u;
+
+template <int THREADS, bool FUSED>
 __global__ void __launch_bounds__(THREADS) k_pair_rows(const PairRows p) {
     constexpr int WAVES = THREADS / WAVE;
+    typedef typename PairRec<FUSED>::T Rec;
     extern __shared__ u32 row[];  // p.cols counts
     __shared__ u32 wtot[WAVES];
     __shared__ u64 s_base;
@@ -111,19 +121,31 @@ __global__ void __launch_bounds__(THREADS) k_pair_rows(const PairRows p) {
     const u32 c0 = blockIdx.y * p.cols;
     const u32 w = min(p.NC - c0, p.cols);
     const u64 seg = p.seg0 + (u64)blockIdx.x * gridDim.y + blockIdx.y;
-    const u32 t0 = p.rowptr[a], t1 = p.rowptr[a + 1];
+    const Rec* recs;
+    u32 t1;  // records of the row: recs[0 .. t1)
+    if constexpr (FUSED) {
+        const u64 b = p.foff[a];
+        recs = p.frec + b;
+        t1 = (u32)(p.foff[a + 1] - b);
+    } else {
+        const u32 b = p.rowptr[a];
+        recs = p.rrec + b;
+        t1 = p.rowptr[a + 1] - b;
+    }
+    const u32 t0 = 0;
     if (t0 == t1) {  // (uniform) no shared hash: no pair
         if (tid == 0) { p.segcnt[seg] = 0; p.segoff[seg] = 0; }
         return;
     }
+    auto mask_off = [](Rec& r) { if constexpr (FUSED) r = 0; else r.w = 0; };
     // the first records are in flight while the row is cleared: PAIR_U loads per lane before any is used (one load in
     // flight per wave left the pass at 1.4 TB/s of record reads -- 0.3 ms at configs[3], the adds themselves are free)
-    uint4 rec[PAIR_U];
+    Rec rec[PAIR_U];
 #pragma unroll
     for (int u = 0; u < PAIR_U; ++u) {
         const u32 t = t0 + u * THREADS + tid;
-        rec[u] = p.rrec[min(t, t1 - 1)];  // (unconditional, masked below: a load under `if` is waited for on the spot)
-        if (t >= t1) rec[u].w = 0;
+        rec[u] = recs[min(t, t1 - 1)];  // (unconditional, masked below: a load under `if` is waited for on the spot)
+        if (t >= t1) mask_off(rec[u]);
     }
     if (!(YH_ABLATE_PAIR & 2))
         for (u32 j = tid; j < w; j += THREADS) row[j] = 0;
@@ -136,34 +158,56 @@ __global__ void __launch_bounds__(THREADS) k_pair_rows(const PairRows p) {
         if (YH_ABLATE_PAIR & 4) { if (c == 0x12345u) row[0] = 1; return; }
         atomicAdd(&row[c], 1u);
     };
-    auto add = [&](u32 o) { addc(p.cid[o]); };  // o: a reference id (the long lists)
+    auto add = [&](u32 o) { if constexpr (FUSED) addc(o); else addc(p.cid[o]); };  // o: a reference id (the long lists)
     for (u32 tb = t0; tb < ((YH_ABLATE_PAIR & 1) ? t0 : t1); tb += PAIR_U * THREADS) {  // (workgroup-uniform bounds: the ballot below)
-        uint4 cur[PAIR_U];
+        Rec cur[PAIR_U];
 #pragma unroll
         for (int u = 0; u < PAIR_U; ++u) {
             cur[u] = rec[u];
             const u32 t = tb + (PAIR_U + u) * THREADS + tid;  // the next step's records
-            rec[u] = p.rrec[min(t, t1 - 1)];
-            if (t >= t1) rec[u].w = 0;
+            rec[u] = recs[min(t, t1 - 1)];
+            if (t >= t1) mask_off(rec[u]);
         }
 #pragma unroll
         for (int u = 0; u < PAIR_U; ++u) {
-            const bool is_list = cur[u].w == 0xffffffffu;
-            if (!is_list) {
-                if (cur[u].w > 0) addc(cur[u].x);
-                if (cur[u].w > 1) addc(cur[u].y);
-                if (cur[u].w > 2) addc(cur[u].z);
-            } else if (cur[u].y <= PAIR_LONG) {
-                for (u32 q = cur[u].x, qe = cur[u].x + cur[u].y; q < qe; ++q) {
+            bool is_list;
+            u64 lq0 = 0;   // a list: its first entry in pr[] ...
+            u32 lm = 0;    // ... and its length (this reference included)
+            if constexpr (FUSED) {
+                const u64 r = cur[u];
+                is_list = (r & FZ_LIST) != 0;
+                if (!is_list) {  // three 21-bit fields: reference + 1, 0 = none
+                    const u32 f0 = (u32)r & FZ_FIELD, f1 = (u32)(r >> 21) & FZ_FIELD, f2 = (u32)(r >> 42) & FZ_FIELD;
+                    if (f0) addc(f0 - 1u);
+                    if (f1) addc(f1 - 1u);
+                    if (f2) addc(f2 - 1u);
+                } else {
+                    lq0 = r & ((1ull << 40) - 1ull);
+                    lm = (u32)(r >> 40) & ((1u << 22) - 1u);
+                }
+            } else {
+                is_list = cur[u].w == 0xffffffffu;
+                if (!is_list) {
+                    if (cur[u].w > 0) addc(cur[u].x);
+                    if (cur[u].w > 1) addc(cur[u].y);
+                    if (cur[u].w > 2) addc(cur[u].z);
+                } else {
+                    lq0 = cur[u].x;
+                    lm = cur[u].y;
+                }
+            }
+            if (is_list && lm <= PAIR_LONG) {
+                for (u64 q = lq0, qe = lq0 + lm; q < qe; ++q) {
                     const u32 o = p.pr[q];
                     if (o != (u32)a) add(o);
                 }
             }
-            u64 todo = __ballot(is_list && cur[u].y > PAIR_LONG);
+            u64 todo = __ballot(is_list && lm > PAIR_LONG);
             while (todo) {
                 const int src = __ffsll((long long)todo) - 1;
                 todo &= todo - 1;
-                const u32 q0 = (u32)__shfl((int)cur[u].x, src), m = (u32)__shfl((int)cur[u].y, src);
+                const u64 q0 = ((u64)(u32)__shfl((int)(u32)(lq0 >> 32), src) << 32) | (u32)__shfl((int)(u32)lq0, src);
+                const u32 m = (u32)__shfl((int)lm, src);
                 for (u32 q = lane; q < m; q += 64u) {
                     const u32 o = p.pr[q0 + q];
                     if (o != (u32)a) add(o);
@@ -179,7 +223,7 @@ __global__ void __launch_bounds__(THREADS) k_pair_rows(const PairRows p) {
     for (u32 j0 = jb; j0 < ((YH_ABLATE_PAIR & 2) ? jb : je); j0 += 64u) {
         const u32 j = j0 + lane;
         const u32 cnt = j < je ? row[j] : 0u;  // (rows are sparse: rid / sizes only behind a count)
-        const bool keep = cnt != 0 && pair_keep(cnt, (u32)a, p.rid[c0 + j], p.sizes, p.c_relaxed);
+        const bool keep = cnt != 0 && pair_keep(cnt, (u32)a, FUSED ? c0 + j : p.rid[c0 + j], p.sizes, p.c_relaxed);
         mine += (u32)__popcll(__ballot(keep));
     }
     if (lane == 0) wtot[wid] = mine;
@@ -210,13 +254,24 @@ __global__ void __launch_bounds__(THREADS) k_pair_rows(const PairRows p) {
         u32 rj = 0;
         bool keep = false;
         if (cnt != 0) {
-            rj = p.rid[c0 + j];
+            rj = FUSED ? c0 + j : p.rid[c0 + j];
             keep = pair_keep(cnt, (u32)a, rj, p.sizes, p.c_relaxed);
         }
         const u64 bal = __ballot(keep);
         if (keep) p.out[dst + (u64)__popcll(bal & ((1ull << lane) - 1ull))] = make_uint2(rj, cnt);
         dst += (u64)__popcll(bal);
     }
+}
+
+// a fused handle counts a reference's shared hashes only when asked (yh_db_nshared_device): its non-zero records, a wave per row
+__global__ void __launch_bounds__(256) k_fz_nshared(const u64* __restrict__ rec, const u64* __restrict__ off, u64 n_refs, u32* __restrict__ nshared) {
+    const u64 a = (blockIdx.x * (u64)blockDim.x + threadIdx.x) >> 6;
+    const u32 lane = threadIdx.x & 63u;
+    if (a >= n_refs) return;
+    u32 c = 0;
+    for (u64 i = off[a] + lane, e = off[a + 1]; i < e; i += 64) c += rec[i] != 0 ? 1u : 0u;
+    for (int d = 32; d > 0; d >>= 1) c += (u32)__shfl_down((int)c, d);
+    if (lane == 0) nshared[a] = c;
 }
 
 inline u32 grid_for(u64 work_items, u32 block, u32 max_blocks = 16384) {
@@ -227,6 +282,14 @@ inline u32 grid_for(u64 work_items, u32 block, u32 max_blocks = 16384) {
 }
 
 }  // namespace
+
+int yh_q_fz_nshared(yh_db* db) {
+    if (!db->fz || db->fz_nshared || db->n_refs == 0) return YH_OK;
+    k_fz_nshared<<<(u32)((db->n_refs * 64 + 255) / 256), 256, 0, db->stream>>>(db->d_fz_rec, db->d_fz_off, db->n_refs, db->d_nshared);
+    YH_HIP(hipGetLastError());
+    db->fz_nshared = true;
+    return YH_OK;
+}
 
 // Fills the handle's host-side pair cache (h_pw_*) for rows [r0, r1).
 int yh_q_pairwise(yh_db* db, double c_thresh, u64 r0, u64 r1) {
@@ -244,34 +307,48 @@ int yh_q_pairwise(yh_db* db, double c_thresh, u64 r0, u64 r1) {
 
     // compact ids of the references that hold a shared hash (ascending with the reference id), and where a reference's
     // records start: one staging buffer [rowptr (N + 1) | cid (N) | rid (NC)], one copy up
-    std::vector<u32> h_nsh(N);
-    YH_HIP(hipMemcpyAsync(h_nsh.data(), db->d_nshared, N * sizeof(u32), hipMemcpyDeviceToHost, st));
-    YH_HIP(hipStreamSynchronize(st));
-    std::vector<u32> h_tab(2 * N + 1 + N);
-    u32* h_rowptr = h_tab.data();
-    u32* h_cid = h_tab.data() + N + 1;
-    u32* h_rid = h_tab.data() + 2 * N + 1;
-    u64 NC = 0, acc = 0;
-    for (u64 j = 0; j < N; ++j) {
-        h_rowptr[j] = (u32)acc;
-        acc += h_nsh[j];
-        if (h_nsh[j]) { h_cid[j] = (u32)NC; h_rid[NC++] = (u32)j; }
-        else h_cid[j] = 0xffffffffu;
+    // (a fused handle -- yh_db::fz -- has its records in place, one per CSR position: the rows are the sketches' extents, the
+    // columns the reference ids themselves, and neither a count per reference nor a table is needed)
+    const bool fz = db->fz;
+    std::vector<u32> h_tab;
+    u64 NC = 0;
+    if (!fz) {
+        std::vector<u32> h_nsh(N);
+        YH_HIP(hipMemcpyAsync(h_nsh.data(), db->d_nshared, N * sizeof(u32), hipMemcpyDeviceToHost, st));
+        YH_HIP(hipStreamSynchronize(st));
+        h_tab.resize(2 * N + 1 + N);
+        u32* h_rowptr = h_tab.data();
+        u32* h_cid = h_tab.data() + N + 1;
+        u32* h_rid = h_tab.data() + 2 * N + 1;
+        u64 acc = 0;
+        for (u64 j = 0; j < N; ++j) {
+            h_rowptr[j] = (u32)acc;
+            acc += h_nsh[j];
+            if (h_nsh[j]) { h_cid[j] = (u32)NC; h_rid[NC++] = (u32)j; }
+            else h_cid[j] = 0xffffffffu;
+        }
+        h_rowptr[N] = (u32)acc;
+        if (acc != P) { yh_set_error("posting counts do not add up (%llu of %llu)", (u64)acc, (u64)P); return YH_ERR_HIP; }
+    } else {
+        NC = N;
     }
-    h_rowptr[N] = (u32)acc;
-    if (acc != P) { yh_set_error("posting counts do not add up (%llu of %llu)", (u64)acc, (u64)P); return YH_ERR_HIP; }
     if (NC == 0) return done_empty();
 
     // columns per row block: what the LDS holds
     static const int threads = [] { const char* e = yh_tune_env("YH_PAIR_THREADS"); const int t = e ? atoi(e) : 512; return t == 1024 ? 1024 : t == 256 ? 256 : 512; }();
     typedef void (*RowsKernel)(const PairRows);
     // (512 lanes: configs[3]'s rows of ~2 700 records in 0.28 ms, against 0.37 with 256 lanes and 0.33 with 1 024)
-    const RowsKernel kern = threads == 1024 ? k_pair_rows<1024> : threads == 256 ? k_pair_rows<256> : k_pair_rows<512>;
-    static const bool big_lds = [kern] {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                 (int)(PAIR_COLS_BIG * sizeof(u32)));
-        if (e != hipSuccess) (void)hipGetLastError();
-        return e == hipSuccess;
+    const RowsKernel kern_plain = threads == 1024 ? k_pair_rows<1024, false> : threads == 256 ? k_pair_rows<256, false> : k_pair_rows<512, false>;
+    const RowsKernel kern_fused = threads == 1024 ? k_pair_rows<1024, true> : threads == 256 ? k_pair_rows<256, true> : k_pair_rows<512, true>;
+    const RowsKernel kern = fz ? kern_fused : kern_plain;
+    static const bool big_lds = [kern_plain, kern_fused] {
+        bool ok = true;
+        for (const RowsKernel k : {kern_plain, kern_fused}) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                     (int)(PAIR_COLS_BIG * sizeof(u32)));
+            if (e != hipSuccess) { (void)hipGetLastError(); ok = false; }
+        }
+        return ok;
     }();
     u32 cols = big_lds ? PAIR_COLS_BIG : PAIR_COLS_SMALL;
     if (const char* e = yh_tune_env("YH_PAIR_COLS")) cols = std::max(64, atoi(e));  // (tests: several column blocks)
@@ -282,8 +359,8 @@ int yh_q_pairwise(yh_db* db, double c_thresh, u64 r0, u64 r1) {
     const u64 nseg = rows * ncb;
 
     // scratch: [records 16 P | segoff 8 nseg | cursor 8 | tab 4 (2N + 1 + NC) | segcnt 4 nseg | cursors 4 N]
-    const bool ranks = db->d_prank != nullptr;
-    const u64 b_rec = P * sizeof(uint4), b_off = nseg * sizeof(u64), b_tab = (2 * N + 1 + NC) * sizeof(u32);
+    const bool ranks = db->d_prank != nullptr || fz;
+    const u64 b_rec = fz ? 0 : P * sizeof(uint4), b_off = nseg * sizeof(u64), b_tab = fz ? 0 : (2 * N + 1 + NC) * sizeof(u32);
     const u64 b_cnt = nseg * sizeof(u32), b_cur = ranks ? 0 : N * sizeof(u32);
     char* d_scr = nullptr;
     uint2* d_out = nullptr;
@@ -304,9 +381,9 @@ int yh_q_pairwise(yh_db* db, double c_thresh, u64 r0, u64 r1) {
     u32* d_rowptr = d_tab;
     u32* d_cid = d_tab + N + 1;
     u32* d_rid = d_tab + 2 * N + 1;
-    u32* d_segcnt = d_tab + (2 * N + 1 + NC);
+    u32* d_segcnt = d_tab + b_tab / sizeof(u32);
     u32* d_cur = d_segcnt + nseg;
-    PW_HIP(hipMemcpyAsync(d_tab, h_tab.data(), b_tab, hipMemcpyHostToDevice, st));
+    if (!fz) PW_HIP(hipMemcpyAsync(d_tab, h_tab.data(), b_tab, hipMemcpyHostToDevice, st));
     if (!ranks) PW_HIP(hipMemsetAsync(d_cur, 0, b_cur, st));
     // the survivors: PAIR_SLOTS per segment, and room for a million behind them to begin with; a run whose long segments
     // need more is repeated with what it counted
@@ -318,13 +395,13 @@ int yh_q_pairwise(yh_db* db, double c_thresh, u64 r0, u64 r1) {
     std::vector<u64> h_segoff(nseg);
     unsigned long long n_over = 0;
     yh_ring_record_begin(db, db->ev_pair);
-    if (rc == YH_OK)
+    if (rc == YH_OK && !fz)
         k_pair_transpose<<<grid_for(P, 256, 1u << 20), 256, 0, st>>>(P, db->d_pr, db->d_pg, db->d_po, d_rowptr, db->d_prank, d_cur,
                                                                      d_cid, d_rrec);
     for (int attempt = 0; attempt < 2 && rc == YH_OK; ++attempt) {
         PW_HIP(hipMemsetAsync(d_cursor, 0, 8, st));
-        PairRows q{d_rrec, d_rowptr, db->d_pr, d_cid, d_rid, db->d_sizes, 0, 0, nseg, (u32)NC, cols, c_relaxed,
-                   d_segcnt, d_segoff, d_cursor, cap, d_out};
+        PairRows q{d_rrec, d_rowptr, db->d_fz_rec, db->d_fz_off, fz ? db->d_fz_list : db->d_pr, d_cid, d_rid, db->d_sizes, 0, 0, nseg,
+                   (u32)NC, cols, c_relaxed, d_segcnt, d_segoff, d_cursor, cap, d_out};
         const u64 step = (1u << 31) / (u32)threads;  // (2^31 threads per grid dimension)
         for (u64 b0 = 0; b0 < rows && rc == YH_OK; b0 += step) {
             const u64 nb = std::min<u64>(rows - b0, step);

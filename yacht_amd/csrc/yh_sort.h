@@ -8,7 +8,8 @@ bool yh_psort_applicable(u64 H, u64 max_hash);
 // regions and counters for H pairs (temporaries from the handle's buffer cache)
 int yh_psort_begin(yh_db* db, u64 H, u64 max_hash, yh_psort** out);
 // first level for n more pairs, on the handle's stream (the pieces of a database may arrive in any number of calls)
-int yh_psort_add(yh_db* db, yh_psort* s, const u64* d_keys, const u32* d_vals, u64 n);
+// d_vals = NULL (after yh_psort_positions): the value of pair i is its CSR position pos_base + i
+int yh_psort_add(yh_db* db, yh_psort* s, const u64* d_keys, const u32* d_vals, u64 n, u64 pos_base = 0);
 // second level + the sort of every bucket: d_keys_out / d_vals_out receive all pairs in (hash, reference) order.
 // *took_it = false when a capacity was exceeded on the device (keys not uniform enough): nothing usable was written.
 // Synchronizes the handle's stream.
@@ -21,3 +22,12 @@ void yh_psort_check_order(yh_psort* s, bool on);
 // [d_chunk_off[c], d_chunk_off[c + 1]); d_chunk_counts[3 c ..] = its {distinct hashes, shared hashes, pairs of shared hashes}
 void yh_psort_chunks(const yh_psort* s, u64* n_chunks, const u64** d_chunk_off, const u32** d_chunk_counts);
 void yh_psort_destroy(yh_db* db, yh_psort* s);
+
+// ---- position mode: the fused last pass of a YH_DB_PAIRWISE_ONLY handle (yh_db::fz) ----------------------------------
+constexpr unsigned YH_REF_TAB_SH = 8;  // one look-up entry per 256 CSR positions
+// d_tab[j] = the reference that owns CSR position j << YH_REF_TAB_SH, for j in [0, (H >> YH_REF_TAB_SH) + 2)
+int yh_ref_table_build(yh_db* db, const u64* d_offsets, u64 n_refs, u64 H, u32* d_tab);
+// the pairs carry CSR positions instead of reference ids (equal hashes still end up in ascending reference order)
+void yh_psort_positions(yh_psort* s, const u32* d_ref_tab, const u64* d_offsets);
+// second level + every bucket sorted in LDS and turned into the pairwise pass's records on the spot (see yh_sort.hip)
+int yh_psort_finish_emit(yh_db* db, yh_psort* s, u64* d_rec, u64 n_refs, u64 totals[3], u32** d_list_out, bool* took_it, bool* unsorted = nullptr);

@@ -33,14 +33,20 @@ constexpr u32 PART_TILE = 4096;      // pairs per workgroup of the distribution 
 constexpr u32 PART_THREADS = 512;
 constexpr u32 PART_ITEMS = PART_TILE / PART_THREADS;
 constexpr u32 PART_MAX_BINS = 1024;  // bins per level (LDS histogram)
-constexpr u32 BKT_CAP = 4096;        // pairs a final bucket may hold
-constexpr u32 BKT_FILL = 2560;       // ... and holds on average (uniform keys: sd ~51; clustered references ~3x that)
-constexpr u32 BKT_THREADS = 1024;
+#ifndef YH_BKT_BITS
+#define YH_BKT_BITS 12  // log2 of the pairs a final bucket may hold (tuning builds: yacht_amd.build.build_variant)
+#endif
+#ifndef YH_BKT_THREADS
+#define YH_BKT_THREADS 1024
+#endif
+constexpr u32 BKT_SLOT_BITS = YH_BKT_BITS;
+constexpr u32 BKT_CAP = 1u << BKT_SLOT_BITS;   // pairs a final bucket may hold
+constexpr u32 BKT_FILL = BKT_CAP / 8 * 5;      // ... and holds on average (2 560 of 4 096; uniform keys: sd ~51; clustered references ~3x that)
+constexpr u32 BKT_THREADS = YH_BKT_THREADS;
 constexpr u32 BKT_ITEMS = BKT_CAP / BKT_THREADS;
-constexpr u32 BKT_SLOTS = 4096;      // fine slots of the counting sort inside a bucket (= 1 << BKT_SLOT_BITS)
+constexpr u32 BKT_SLOTS = BKT_CAP;   // fine slots of the counting sort inside a bucket (= 1 << BKT_SLOT_BITS)
 constexpr u32 SLOT_MAX = 1024;       // pairs of one slot a pair ranks itself against (a hash held by that many references: 10^6 LDS reads); more: not this sort's input
 
-constexpr u32 BKT_SLOT_BITS = 12;
 // The FINE slot of a hash -- floor(h * NB * S / (max_hash + 1)), S = 2^BKT_SLOT_BITS slots per bucket -- is the one linear
 // function everything is cut from: bucket = fine >> BKT_SLOT_BITS, slot inside the bucket = fine & (S - 1).  (A multiplier for
 // the BUCKET index alone has too few significant bits at a few thousand buckets -- 38 281 for configs[3] -- and disagrees
@@ -90,9 +96,35 @@ __device__ __forceinline__ void block_scan_inplace(u32* arr, u32 n, u32* wave_to
     __syncthreads();
 }
 
+// Which reference owns CSR position p?  tab[j] = the reference of position j << YH_REF_TAB_SH (k_ref_table below); the
+// answer lies in [tab[j], tab[j + 1]] -- one entry for all but the blocks a sketch boundary crosses.
+__device__ __forceinline__ u32 ref_of(u64 p, const u32* __restrict__ tab, const u64* __restrict__ off) {
+    const u64 j = p >> YH_REF_TAB_SH;
+    u32 lo = tab[j], hi = tab[j + 1];
+    while (lo < hi) {  // the largest r in [lo, hi] with off[r] <= p
+        const u32 mid = lo + (hi - lo + 1) / 2;
+        if (off[mid] <= p) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+__global__ void k_ref_table(const u64* __restrict__ off, u64 n_refs, u64 n_tab, u32* __restrict__ tab) {
+    const u64 j = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (j >= n_tab) return;
+    const u64 p = j << YH_REF_TAB_SH;
+    u64 lo = 0, hi = n_refs - 1;  // the largest r with off[r] <= p (off[0] = 0: there is one)
+    while (lo < hi) {
+        const u64 mid = lo + (hi - lo + 1) / 2;
+        if (off[mid] <= p) lo = mid; else hi = mid - 1;
+    }
+    tab[j] = (u32)lo;
+}
+
 struct PartArgs {
     const u64* in_k;
-    const u32* in_v;
+    const u32* in_v;      // values; NULL (level 1): the value of a pair is its CSR POSITION, val_base + its index
+    u64 val_base;
+    const u32* ref_tab;   // position mode: the look-up of ref_of() (the ordering check)
+    const u64* ref_off;
     u64 n_in;             // pairs of this call's input (level 1; level 2 without in_cnt: ONE input segment of n_in pairs)
     u64 cap_in;           // level 2: capacity of an input region
     const u32* in_cnt;    // level 2: pairs in every input region
@@ -140,14 +172,17 @@ __global__ void __launch_bounds__(PART_THREADS) k_part(const PartArgs a) {
         bin[k] = 0xffffffffu;
         if (i < tile_n) {
             key[k] = a.in_k[in_base + t0 + i];
-            val[k] = a.in_v[in_base + t0 + i];
+            const bool positions = (LEVEL == 1 || !a.in_cnt) && !a.in_v;
+            val[k] = positions ? (u32)(a.val_base + t0 + i) : a.in_v[in_base + t0 + i];
             if (a.check_order && (LEVEL == 1 || !a.in_cnt)) {
                 // the element in front (lane - 1 has it; the wave's first lane reads it): same reference => strictly smaller hash
                 u64 pk = ((u64)(u32)__shfl_up((int)(u32)(key[k] >> 32), 1) << 32) | (u32)__shfl_up((int)(u32)key[k], 1);
                 u32 pv = (u32)__shfl_up((int)val[k], 1);
                 const u64 gi = t0 + i;
-                if ((tid & 63u) == 0 && gi > 0) { pk = a.in_k[in_base + gi - 1]; pv = a.in_v[in_base + gi - 1]; }
-                if (gi > 0 && pv == val[k] && !(pk < key[k])) atomicOr(a.flags, 8u);
+                if ((tid & 63u) == 0 && gi > 0) { pk = a.in_k[in_base + gi - 1]; if (!positions) pv = a.in_v[in_base + gi - 1]; }
+                // (positions: the element in front is of the same reference unless this one is the first of its sketch)
+                const bool same = positions ? (u64)val[k] > a.ref_off[ref_of(val[k], a.ref_tab, a.ref_off)] : pv == val[k];
+                if (gi > 0 && same && !(pk < key[k])) atomicOr(a.flags, 8u);
             }
             const u32 b = bucket_of(key[k], a.lsh, a.mul);
             bin[k] = LEVEL == 1 ? b / a.P2 : b % a.P2;
@@ -231,16 +266,38 @@ struct BucketArgs {
     u32* flags;    // [0] |= 4: a slot held more than SLOT_MAX pairs
     u32* counts;   // [buckets][3] {distinct hashes, hashes held by >= 2 references, pairs of those}: what k_idx_count counts per
                    // chunk of the sorted pairs -- a run of equal hashes never leaves its bucket, so the bucket sees it whole
+    // EMIT (the values are CSR positions): the bucket does not leave as sorted pairs at all -- every element whose hash
+    // another reference holds too gets its record of the pairwise pass, stored at its own CSR position
+    u64 nb;                      // buckets
+    u64 n_pos;                   // CSR positions (H)
+    u32 per_xcd;                 // ... of one XCD (see the kernel)
+    u64* rec;                    // [H] yh_db::d_fz_rec
+    u32* list;                   // [buckets][BKT_CAP] yh_db::d_fz_list -- the SAME memory as in_v: a bucket's values are in registers before anything is stored
+    const u32* ref_tab;
+    const u64* ref_off;
+    u32 inline_ok;               // reference ids fit the 21-bit fields of an inline record
+    unsigned long long* totals;  // [4] {distinct hashes, shared hashes, their pairs, pairs seen}
 };
 
+// EMIT: the workgroups of one XCD (blockIdx % 8 on this chip) walk ONE EIGHTH of the hash space front to back.  A sketch's
+// elements inside a first-level region of the sort are ~36 consecutive CSR positions, and that region's ~140 buckets are
+// then all sorted on the same XCD within a short time of each other: its L2 sees the stores of the whole run and merges
+// them (scripts/probes/scatter_probe.hip: 27 M 8-byte records in 0.30 ms this way, 0.39 ms with bucket = blockIdx, 0.69 ms
+// at isolated positions -- and the counting atomic + the store of k_idx_emit / k_pair_transpose before: 0.76 + 0.56 ms).
+template <bool EMIT>
 __global__ void __launch_bounds__(BKT_THREADS) k_bucket_sort(const BucketArgs a) {
     __shared__ u64 skey[BKT_CAP];
     __shared__ u32 sval[BKT_CAP];
-    __shared__ u32 start[BKT_SLOTS];  // counts, then offsets
+    __shared__ u32 start[BKT_SLOTS];  // counts, then offsets; EMIT: then the reference of every shared element
     __shared__ u32 wtot[17];
     __shared__ u32 tot3[3];
     const u32 tid = threadIdx.x;
-    const u64 b = blockIdx.x;
+    u64 b = blockIdx.x;
+    if (EMIT) {
+        b = (u64)(blockIdx.x & 7u) * a.per_xcd + (blockIdx.x >> 3);
+        if ((blockIdx.x >> 3) >= a.per_xcd || b >= a.nb) return;
+        if (a.cnt[b] > BKT_CAP && tid == 0) atomicOr(a.flags, 2u);
+    }
     const u32 n = min(a.cnt[b], BKT_CAP);
     if (n == 0) return;  // (its three counts stay zero: the array is cleared before the launch)
     if (tid < 3) tot3[tid] = 0;
@@ -301,6 +358,48 @@ __global__ void __launch_bounds__(BKT_THREADS) k_bucket_sort(const BucketArgs a)
             sval[pos[k]] = val[k];
         }
     __syncthreads();
+    if (EMIT) {
+        static_assert(BKT_SLOTS >= BKT_CAP, "start[] doubles as the references of a bucket");
+        u32 c0 = 0, c1 = 0, c2 = 0;  // (start[] is free: its last reads were in front of the barrier above)
+        for (u32 i0 = 0; i0 < n; i0 += BKT_THREADS) {  // (workgroup-uniform bound: the ballots)
+            const u32 i = i0 + tid;
+            bool head = false, shared = false;
+            if (i < n) {
+                const u64 h = skey[i];
+                const bool eq_prev = i > 0 && skey[i - 1] == h, eq_next = i + 1 < n && skey[i + 1] == h;
+                head = !eq_prev;
+                shared = eq_prev || eq_next;
+                if (shared) start[i] = ref_of(sval[i], a.ref_tab, a.ref_off);
+            }
+            c0 += (u32)__popcll(__ballot(head));
+            c1 += (u32)__popcll(__ballot(head && shared));
+            c2 += (u32)__popcll(__ballot(shared));
+        }
+        if ((tid & 63u) == 0) { atomicAdd(&tot3[0], c0); atomicAdd(&tot3[1], c1); atomicAdd(&tot3[2], c2); }
+        __syncthreads();
+        if (tid < 3 && tot3[tid]) atomicAdd(&a.totals[tid], (unsigned long long)tot3[tid]);
+        if (tid == 3) atomicAdd(&a.totals[3], (unsigned long long)n);
+        for (u32 i = tid; i < n; i += BKT_THREADS) {
+            const u64 h = skey[i];
+            u32 s = i, e = i + 1;
+            while (s > 0 && skey[s - 1] == h) --s;
+            while (e < n && skey[e] == h) ++e;
+            const u32 len = e - s;
+            if (len < 2) continue;  // (its record stays 0: the array is cleared before the launch)
+            u64 r;
+            if (len <= 4 && a.inline_ok) {
+                r = 0;
+                u32 sh = 0;
+                for (u32 q = s; q < e; ++q)
+                    if (q != i) { r |= (u64)(start[q] + 1u) << sh; sh += 21; }
+            } else {
+                a.list[b * BKT_CAP + i] = start[i];
+                r = (1ull << 63) | ((u64)len << 40) | (b * BKT_CAP + s);
+            }
+            if (sval[i] < a.n_pos) a.rec[sval[i]] = r;  // (always, unless a refused sort left the bucket in disorder)
+        }
+        return;
+    }
     const u64 out_base = a.off[b];
     u32 c0 = 0, c1 = 0, c2 = 0;
     for (u32 i0 = 0; i0 < n; i0 += BKT_THREADS) {  // (workgroup-uniform bound: the ballots)
@@ -349,6 +448,9 @@ struct yh_psort {
     u64* off = nullptr;  // [NB + 1]
     u32* counts = nullptr;  // [NB][3] run statistics of every bucket (k_bucket_sort)
     bool check_order = false;
+    const u32* ref_tab = nullptr;  // position mode (yh_psort_positions): the values are CSR positions
+    const u64* ref_off = nullptr;
+    unsigned long long* totals = nullptr;  // [4] position mode: what the fused last pass counted
 };
 
 // Is this input one the distribution sort takes?  (A database of a few thousand hashes is one bucket; a key range narrower
@@ -363,6 +465,14 @@ bool yh_psort_applicable(u64 H, u64 max_hash) {
 }
 
 void yh_psort_check_order(yh_psort* s, bool on) { s->check_order = on; }
+void yh_psort_positions(yh_psort* s, const u32* d_ref_tab, const u64* d_offsets) { s->ref_tab = d_ref_tab; s->ref_off = d_offsets; }
+int yh_ref_table_build(yh_db* db, const u64* d_offsets, u64 n_refs, u64 H, u32* d_tab) {
+    const u64 n_tab = (H >> YH_REF_TAB_SH) + 2;
+    if (n_refs == 0) return YH_OK;
+    k_ref_table<<<(u32)((n_tab + 255) / 256), 256, 0, db->stream>>>(d_offsets, n_refs, n_tab, d_tab);
+    YH_HIP(hipGetLastError());
+    return YH_OK;
+}
 void yh_psort_chunks(const yh_psort* s, u64* n_chunks, const u64** d_chunk_off, const u32** d_chunk_counts) {
     *n_chunks = s->NB;
     *d_chunk_off = s->off;
@@ -371,7 +481,7 @@ void yh_psort_chunks(const yh_psort* s, u64* n_chunks, const u64** d_chunk_off, 
 void yh_psort_destroy(yh_db* db, yh_psort* s) {
     if (!s) return;
     yh_tfree(db, s->k1); yh_tfree(db, s->v1); yh_tfree(db, s->k2); yh_tfree(db, s->v2);
-    yh_tfree(db, s->cnt); yh_tfree(db, s->off); yh_tfree(db, s->counts);
+    yh_tfree(db, s->cnt); yh_tfree(db, s->off); yh_tfree(db, s->counts); yh_tfree(db, s->totals);
     delete s;
 }
 
@@ -415,8 +525,9 @@ int yh_psort_begin(yh_db* db, u64 H, u64 max_hash, yh_psort** out) {
 }
 
 // first level for n more pairs (any order of calls; on the handle's stream)
-int yh_psort_add(yh_db* db, yh_psort* s, const u64* d_keys, const u32* d_vals, u64 n) {
+int yh_psort_add(yh_db* db, yh_psort* s, const u64* d_keys, const u32* d_vals, u64 n, u64 pos_base) {
     if (n == 0) return YH_OK;
+    if (!d_vals && !s->ref_tab) { yh_set_error("internal: positions as values without yh_psort_positions"); return YH_ERR_INVALID_ARG; }
     s->fed += n;
     u32* cnt1 = s->cnt;
     u32* cnt2 = s->cnt + s->P1;
@@ -424,6 +535,9 @@ int yh_psort_add(yh_db* db, yh_psort* s, const u64* d_keys, const u32* d_vals, u
     PartArgs a{};
     a.in_k = d_keys;
     a.in_v = d_vals;
+    a.val_base = pos_base;
+    a.ref_tab = s->ref_tab;
+    a.ref_off = s->ref_off;
     a.n_in = n;
     a.mul = s->mul;
     a.lsh = s->lsh;
@@ -456,9 +570,7 @@ int yh_psort_add(yh_db* db, yh_psort* s, const u64* d_keys, const u32* d_vals, u
 
 // second level + the sort of every bucket; the sorted pairs land in d_keys_out / d_vals_out (H entries).  *took_it = false:
 // the keys were not this sort's input (a capacity was exceeded) -- nothing usable was written, sort another way.
-int yh_psort_finish(yh_db* db, yh_psort* s, u64* d_keys_out, u32* d_vals_out, bool* took_it, bool* unsorted) {
-    *took_it = false;
-    if (unsorted) *unsorted = false;
+static int second_level(yh_db* db, yh_psort* s) {
     u32* cnt1 = s->cnt;
     u32* cnt2 = s->cnt + s->P1;
     u32* flags = s->cnt + s->P1 + s->NB;
@@ -482,6 +594,26 @@ int yh_psort_finish(yh_db* db, yh_psort* s, u64* d_keys_out, u32* d_vals_out, bo
         if (grid >> 31) { yh_set_error("distribution sort: grid too large"); return YH_ERR_UNSUPPORTED; }
         k_part<2><<<(u32)grid, PART_THREADS, 0, db->stream>>>(a);
     }
+    YH_HIP(hipGetLastError());
+    return YH_OK;
+}
+static void say_verdict(const yh_psort* s, u32 flags, u64 total, bool took, const char* what) {
+    static const bool trace = [] { const char* e = yh_tune_env("YH_TRACE_BUILD"); return e && e[0] == '1'; }();
+    if (trace || !took) {
+        // (a refusal is worth a line even without the trace switch: the caller falls back to a sort three times as slow)
+        static const bool say = [] { const char* e = yh_tune_env("YH_TRACE_SORT"); return e && e[0] == '1'; }();
+        if (trace || say)
+            fprintf(stderr, "[yh sort] H %llu  P1 %u x P2 %u = %llu buckets  cap1 %llu  flags %u (1 region, 2 bucket, 4 slot)  %s %llu of %llu -> %s\n",
+                    (u64)s->H, s->P1, s->P2, (u64)s->NB, (u64)s->cap1, flags, what, total, (u64)s->fed, took ? "taken" : "REFUSED");
+    }
+}
+
+int yh_psort_finish(yh_db* db, yh_psort* s, u64* d_keys_out, u32* d_vals_out, bool* took_it, bool* unsorted) {
+    *took_it = false;
+    if (unsorted) *unsorted = false;
+    u32* cnt2 = s->cnt + s->P1;
+    u32* flags = s->cnt + s->P1 + s->NB;
+    YH_TRY(second_level(db, s));
     k_bucket_offsets<<<1, 1024, 0, db->stream>>>(cnt2, s->NB, BKT_CAP, s->off, flags);
     BucketArgs b{};
     b.in_k = s->k2;
@@ -495,7 +627,7 @@ int yh_psort_finish(yh_db* db, yh_psort* s, u64* d_keys_out, u32* d_vals_out, bo
     b.out_v = d_vals_out;
     b.flags = flags;
     b.counts = s->counts;
-    k_bucket_sort<<<(u32)s->NB, BKT_THREADS, 0, db->stream>>>(b);
+    k_bucket_sort<false><<<(u32)s->NB, BKT_THREADS, 0, db->stream>>>(b);
     YH_HIP(hipGetLastError());
     u32 hflags[4] = {0, 0, 0, 0};
     u64 total = 0;
@@ -504,13 +636,60 @@ int yh_psort_finish(yh_db* db, yh_psort* s, u64* d_keys_out, u32* d_vals_out, bo
     YH_HIP(hipStreamSynchronize(db->stream));
     *took_it = (hflags[0] & 7u) == 0 && total == s->fed;
     if (unsorted) *unsorted = (hflags[0] & 8u) != 0;
-    static const bool trace = [] { const char* e = yh_tune_env("YH_TRACE_BUILD"); return e && e[0] == '1'; }();
-    if (trace || !*took_it) {
-        // (a refusal is worth a line even without the trace switch: the caller falls back to a sort three times as slow)
-        static const bool say = [] { const char* e = yh_tune_env("YH_TRACE_SORT"); return e && e[0] == '1'; }();
-        if (trace || say)
-            fprintf(stderr, "[yh sort] H %llu  P1 %u x P2 %u = %llu buckets  cap1 %llu  flags %u (1 region, 2 bucket, 4 slot)  sorted %llu of %llu -> %s\n",
-                    (u64)s->H, s->P1, s->P2, (u64)s->NB, (u64)s->cap1, hflags[0], total, (u64)s->fed, *took_it ? "taken" : "REFUSED");
+    say_verdict(s, hflags[0], total, *took_it, "sorted");
+    return YH_OK;
+}
+
+// Position mode: second level + the FUSED last pass (k_bucket_sort<true>): every bucket is sorted in LDS and leaves as the
+// records of the pairwise pass (yh_db::d_fz_rec, cleared here; H entries) instead of as sorted pairs.  totals[3] = {distinct
+// hashes, hashes with >= 2 holders, their pairs}.  *d_list_out: the holders of the hashes with more than four of them
+// (yh_db::d_fz_list) -- the sort's own bucket array, which is the caller's from here on (free it with yh_tfree).
+// *took_it = false: a capacity was exceeded, nothing usable was written.  Synchronizes the handle's stream.
+int yh_psort_finish_emit(yh_db* db, yh_psort* s, u64* d_rec, u64 n_refs, u64 totals[3], u32** d_list_out, bool* took_it, bool* unsorted) {
+    *took_it = false;
+    *d_list_out = nullptr;
+    if (unsorted) *unsorted = false;
+    if (!s->ref_tab) { yh_set_error("internal: the fused pass needs positions as values"); return YH_ERR_INVALID_ARG; }
+    u32* cnt2 = s->cnt + s->P1;
+    u32* flags = s->cnt + s->P1 + s->NB;
+    hipError_t e = yh_tmalloc(db, (void**)&s->totals, 4 * sizeof(unsigned long long));
+    if (e != hipSuccess) { yh_set_error("distribution sort: allocation failed: %s", hipGetErrorString(e)); return YH_ERR_OOM; }
+    YH_HIP(hipMemsetAsync(s->totals, 0, 4 * sizeof(unsigned long long), db->stream));
+    YH_HIP(hipMemsetAsync(d_rec, 0, s->H * sizeof(u64), db->stream));
+    YH_TRY(second_level(db, s));
+    BucketArgs b{};
+    b.in_k = s->k2;
+    b.in_v = s->v2;
+    b.cnt = cnt2;
+    b.cap_in = BKT_CAP;
+    b.mul_fine = s->mul_fine;
+    b.lsh = s->lsh;
+    b.flags = flags;
+    b.nb = s->NB;
+    b.n_pos = s->H;
+    b.per_xcd = (u32)((s->NB + 7) / 8);
+    b.rec = d_rec;
+    b.list = s->v2;
+    b.ref_tab = s->ref_tab;
+    b.ref_off = s->ref_off;
+    // (reference + 1 in 21 bits; YH_FZ_NO_INLINE=1 behind the tuning gate: every record in list form, as with >= 2^21 - 1 references)
+    static const bool no_inline = [] { const char* e = yh_tune_env("YH_FZ_NO_INLINE"); return e && e[0] == '1'; }();
+    b.inline_ok = (n_refs < (1u << 21) - 1 && !no_inline) ? 1u : 0u;
+    b.totals = s->totals;
+    k_bucket_sort<true><<<8u * b.per_xcd, BKT_THREADS, 0, db->stream>>>(b);
+    YH_HIP(hipGetLastError());
+    u32 hflags[4] = {0, 0, 0, 0};
+    unsigned long long ht[4] = {0, 0, 0, 0};
+    YH_HIP(hipMemcpyAsync(hflags, flags, 3 * sizeof(u32), hipMemcpyDeviceToHost, db->stream));
+    YH_HIP(hipMemcpyAsync(ht, s->totals, sizeof(ht), hipMemcpyDeviceToHost, db->stream));
+    YH_HIP(hipStreamSynchronize(db->stream));
+    *took_it = (hflags[0] & 7u) == 0 && ht[3] == s->fed;
+    if (unsorted) *unsorted = (hflags[0] & 8u) != 0;
+    say_verdict(s, hflags[0], ht[3], *took_it, "fused: records of");
+    if (*took_it) {
+        totals[0] = ht[0]; totals[1] = ht[1]; totals[2] = ht[2];
+        *d_list_out = s->v2;
+        s->v2 = nullptr;
     }
     return YH_OK;
 }
