@@ -29,8 +29,14 @@
 
 namespace {
 
-constexpr u32 PART_TILE = 4096;      // pairs per workgroup of the distribution passes
-constexpr u32 PART_THREADS = 512;
+#ifndef YH_PART_TILE
+#define YH_PART_TILE 4096
+#endif
+#ifndef YH_PART_THREADS
+#define YH_PART_THREADS 1024
+#endif
+constexpr u32 PART_TILE = YH_PART_TILE;      // pairs per workgroup of the distribution passes
+constexpr u32 PART_THREADS = YH_PART_THREADS;
 constexpr u32 PART_ITEMS = PART_TILE / PART_THREADS;
 constexpr u32 PART_MAX_BINS = 1024;  // bins per level (LDS histogram)
 #ifndef YH_BKT_BITS
@@ -191,20 +197,29 @@ __global__ void __launch_bounds__(PART_THREADS) k_part(const PartArgs a) {
         }
     }
     __syncthreads();
-    // reserve the tile's run in every bin's region, then turn the histogram into offsets inside the tile
-    for (u32 b = tid; b < a.nbins; b += PART_THREADS) {
-        const u32 c = hist[b];
-        u32 g = 0;
-        if (c) {
-            const u32 region = LEVEL == 1 ? b : seg * a.P2 + b;
-            g = atomicAdd(&a.out_cnt[region], c);
-            if ((u64)g + c > a.cap_out) atomicOr(a.flags, 1u);
+    // reserve the tile's run in every bin's region, then turn the histogram into offsets inside the tile.  The atomics'
+    // answers are not needed before the pairs leave: they stay in registers while the tile is put in bin order (the wait
+    // for a contended L2 atomic -- every tile of the launch adds to the same few hundred counters -- was in the chain of
+    // every tile)
+    constexpr u32 BINS_PER_THREAD = (PART_MAX_BINS + PART_THREADS - 1) / PART_THREADS;
+    u32 g_mine[BINS_PER_THREAD], c_mine[BINS_PER_THREAD];
+#pragma unroll
+    for (u32 q = 0; q < BINS_PER_THREAD; ++q) {
+        const u32 b = q * PART_THREADS + tid;
+        g_mine[q] = 0;
+        c_mine[q] = 0;
+        if (b < a.nbins) {
+            const u32 c = hist[b];
+            c_mine[q] = c;
+            if (c) {
+                const u32 region = LEVEL == 1 ? b : seg * a.P2 + b;
+                g_mine[q] = atomicAdd(&a.out_cnt[region], c);
+            }
+            loc[b] = c;
         }
-        gbase[b] = g;
-        loc[b] = c;
     }
     __syncthreads();
-    block_scan_inplace<(PART_MAX_BINS + PART_THREADS - 1) / PART_THREADS>(loc, a.nbins, wtot);
+    block_scan_inplace<BINS_PER_THREAD>(loc, a.nbins, wtot);
 #pragma unroll
     for (u32 k = 0; k < PART_ITEMS; ++k)
         if (bin[k] != 0xffffffffu) {
@@ -213,6 +228,14 @@ __global__ void __launch_bounds__(PART_THREADS) k_part(const PartArgs a) {
             sval[s] = val[k];
             sbin[s] = (u16)bin[k];
         }
+#pragma unroll
+    for (u32 q = 0; q < BINS_PER_THREAD; ++q) {
+        const u32 b = q * PART_THREADS + tid;
+        if (b < a.nbins) {
+            gbase[b] = g_mine[q];
+            if (c_mine[q] && (u64)g_mine[q] + c_mine[q] > a.cap_out) atomicOr(a.flags, 1u);
+        }
+    }
     __syncthreads();
 #pragma unroll
     for (u32 k = 0; k < PART_ITEMS; ++k) {
@@ -279,148 +302,211 @@ struct BucketArgs {
     unsigned long long* totals;  // [4] {distinct hashes, shared hashes, their pairs, pairs seen}
 };
 
-// EMIT: the workgroups of one XCD (blockIdx % 8 on this chip) walk ONE EIGHTH of the hash space front to back.  A sketch's
-// elements inside a first-level region of the sort are ~36 consecutive CSR positions, and that region's ~140 buckets are
-// then all sorted on the same XCD within a short time of each other: its L2 sees the stores of the whole run and merges
-// them (scripts/probes/scatter_probe.hip: 27 M 8-byte records in 0.30 ms this way, 0.39 ms with bucket = blockIdx, 0.69 ms
-// at isolated positions -- and the counting atomic + the store of k_idx_emit / k_pair_transpose before: 0.76 + 0.56 ms).
+// exclusive scan of arr[0 .. ITEMS * blockDim.x) in place, ITEMS consecutive words per thread; two barriers (the second one
+// behind the last store).  Every wave sums the totals of the waves below it itself instead of waiting for one wave to scan them.
+template <u32 ITEMS>
+__device__ __forceinline__ void block_scan_inplace2(u32* arr, u32* wave_tot /* >= 16 words */) {
+    const u32 tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6, nw = blockDim.x >> 6;
+    u32 v[ITEMS];
+    u32 sum = 0;
+    if constexpr (ITEMS == 4) {  // (one 16-byte LDS read: arr is 16-byte aligned -- a __shared__ array of the kernel)
+        const uint4 q = reinterpret_cast<const uint4*>(arr)[tid];
+        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        sum = q.x + q.y + q.z + q.w;
+    } else {
+#pragma unroll
+        for (u32 k = 0; k < ITEMS; ++k) {
+            v[k] = arr[tid * ITEMS + k];
+            sum += v[k];
+        }
+    }
+    u32 inc = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const u32 t = (u32)__shfl_up((int)inc, d);
+        if (lane >= (u32)d) inc += t;
+    }
+    if (lane == 63) wave_tot[wv] = inc;
+    __syncthreads();
+    u32 below = (lane < nw && lane < wv) ? wave_tot[lane] : 0u;  // (nw <= 16)
+#pragma unroll
+    for (int d = 8; d > 0; d >>= 1) below += (u32)__shfl_xor((int)below, d);
+    below = (u32)__shfl((int)below, 0);
+    u32 run = below + inc - sum;
+    if constexpr (ITEMS == 4) {
+        reinterpret_cast<uint4*>(arr)[tid] = make_uint4(run, run + v[0], run + v[0] + v[1], run + v[0] + v[1] + v[2]);
+    } else {
+#pragma unroll
+        for (u32 k = 0; k < ITEMS; ++k) {
+            arr[tid * ITEMS + k] = run;
+            run += v[k];
+        }
+    }
+    __syncthreads();
+}
+
+// The last pass: every bucket (<= BKT_CAP pairs) sorted in LDS, one workgroup per bucket.  XCD x (blockIdx % 8 on this chip)
+// takes the x-th EIGHTH of the buckets, front to back.  EMIT: that walk is what lets the L2s merge the record stores -- a
+// sketch's elements inside a first-level region of the sort are ~36 consecutive CSR positions, and the region's ~140
+// buckets are then all sorted on the same XCD within a short time of each other (scripts/probes/scatter_probe.hip: 27 M
+// 8-byte records in 0.30 ms this way, 0.39 ms with bucket = blockIdx, 0.69 ms at isolated positions -- and the counting
+// atomic + the store of k_idx_emit / k_pair_transpose before: 0.76 + 0.56 ms).
+// (Measured and dropped: PERSISTENT workgroups that fetch the next bucket into registers while they sort the current one --
+// 86 registers, one workgroup per CU; held to 64 it spills and takes 1.02 ms for configs[3] against 0.72 ms.)
+#ifndef YH_ABLATE_FZ
+#define YH_ABLATE_FZ 0  // timing-only builds (results wrong): 1 no record stores, 2 no position -> reference look-ups, 4 no ranking inside the slots, 8 no run scan
+#endif
 template <bool EMIT>
 __global__ void __launch_bounds__(BKT_THREADS) k_bucket_sort(const BucketArgs a) {
     __shared__ u64 skey[BKT_CAP];
     __shared__ u32 sval[BKT_CAP];
-    __shared__ u32 start[BKT_SLOTS];  // counts, then offsets; EMIT: then the reference of every shared element
-    __shared__ u32 wtot[17];
+    __shared__ __attribute__((aligned(16))) u32 start[BKT_SLOTS];  // counts, then offsets; EMIT: then the reference of every pair, in sorted order
+    __shared__ u32 wtot[16];
     __shared__ u32 tot3[3];
+    static_assert(BKT_SLOTS >= BKT_CAP, "start[] doubles as the references of a bucket");
+    static_assert(BKT_THREADS <= 1024, "block_scan_inplace2 sums at most 16 wave totals");
     const u32 tid = threadIdx.x;
-    u64 b = blockIdx.x;
-    if (EMIT) {
-        b = (u64)(blockIdx.x & 7u) * a.per_xcd + (blockIdx.x >> 3);
-        if ((blockIdx.x >> 3) >= a.per_xcd || b >= a.nb) return;
-        if (a.cnt[b] > BKT_CAP && tid == 0) atomicOr(a.flags, 2u);
-    }
+    const u64 b = (u64)(blockIdx.x & 7u) * a.per_xcd + (blockIdx.x >> 3);
+    if ((blockIdx.x >> 3) >= a.per_xcd || b >= a.nb) return;
+    if (a.cnt[b] > BKT_CAP && tid == 0) atomicOr(a.flags, 2u);
     const u32 n = min(a.cnt[b], BKT_CAP);
-    if (n == 0) return;  // (its three counts stay zero: the array is cleared before the launch)
-    if (tid < 3) tot3[tid] = 0;
-    for (u32 i = tid; i < BKT_SLOTS; i += BKT_THREADS) start[i] = 0;
-    __syncthreads();
-    u64 key[BKT_ITEMS];
-    u32 val[BKT_ITEMS], slot[BKT_ITEMS], rank[BKT_ITEMS];
-    const u64 in_base = b * a.cap_in;
+    {
+        u64 key[BKT_ITEMS];
+        u32 val[BKT_ITEMS], slot[BKT_ITEMS], rank[BKT_ITEMS];
+        u32 rf[BKT_ITEMS];  // EMIT: the reference that owns the pair's position -- looked up now (two reads the L2s serve), needed
+                            // when the bucket is in order: the look-ups of all pairs are in flight under the sort
+        if (n == 0) return;  // (workgroup-uniform; its three counts stay zero: the array is cleared before the launch)
 #pragma unroll
-    for (u32 k = 0; k < BKT_ITEMS; ++k) {
-        const u32 i = k * BKT_THREADS + tid;
-        slot[k] = 0xffffffffu;
-        if (i < n) {
-            key[k] = a.in_k[in_base + i];
-            val[k] = a.in_v[in_base + i];
-            slot[k] = fine_of(key[k], a.lsh, a.mul_fine) & (BKT_SLOTS - 1u);
-            rank[k] = atomicAdd(&start[slot[k]], 1u);
+        for (u32 k = 0; k < BKT_ITEMS; ++k) {
+            const u32 i = k * BKT_THREADS + tid;
+            if (i < n) { key[k] = a.in_k[b * a.cap_in + i]; val[k] = a.in_v[b * a.cap_in + i]; }
         }
-    }
-    __syncthreads();
-    // a crowded slot = many pairs with (nearly) the same hash: the quadratic ranking below is not made for that
-    u32 cnt_mine[BKT_ITEMS];
-#pragma unroll
-    for (u32 k = 0; k < BKT_ITEMS; ++k) cnt_mine[k] = slot[k] != 0xffffffffu ? start[slot[k]] : 0u;
-    __syncthreads();
-    block_scan_inplace<BKT_SLOTS / BKT_THREADS>(start, BKT_SLOTS, wtot);
-    u32 pos[BKT_ITEMS];
-#pragma unroll
-    for (u32 k = 0; k < BKT_ITEMS; ++k)
-        if (slot[k] != 0xffffffffu) {
-            pos[k] = start[slot[k]] + rank[k];
-            skey[pos[k]] = key[k];
-            sval[pos[k]] = val[k];
+        if (tid < 3) tot3[tid] = 0;
+        // (the LDS pipe of a CU is what this kernel keeps busy -- ~20 operations per pair: wide clears and scans, no store
+        // that would put back what is there already, and every pair emitted by the lane that holds it in registers)
+        static_assert(BKT_SLOTS % (4 * BKT_THREADS) == 0 || BKT_SLOTS / BKT_THREADS < 4, "16-byte clears");
+        if (BKT_SLOTS / BKT_THREADS >= 4) {
+            for (u32 i = tid; i < BKT_SLOTS / 4; i += BKT_THREADS) reinterpret_cast<uint4*>(start)[i] = make_uint4(0u, 0u, 0u, 0u);
+        } else {
+            for (u32 i = tid; i < BKT_SLOTS; i += BKT_THREADS) start[i] = 0;
         }
-    __syncthreads();
-    bool crowded = false;
+        __syncthreads();
 #pragma unroll
-    for (u32 k = 0; k < BKT_ITEMS; ++k)
-        if (slot[k] != 0xffffffffu) {
-            const u32 s0 = start[slot[k]], c = cnt_mine[k];
-            u32 less = 0;
-            if (c > SLOT_MAX) {
-                crowded = true;
-            } else {
-                for (u32 q = s0; q < s0 + c; ++q) {
-                    const u64 kq = skey[q];
-                    less += (kq < key[k] || (kq == key[k] && sval[q] < val[k])) ? 1u : 0u;
-                }
-            }
-            pos[k] = s0 + less;
-        }
-    if (crowded) atomicOr(a.flags, 4u);
-    __syncthreads();
-#pragma unroll
-    for (u32 k = 0; k < BKT_ITEMS; ++k)
-        if (slot[k] != 0xffffffffu) {
-            skey[pos[k]] = key[k];
-            sval[pos[k]] = val[k];
-        }
-    __syncthreads();
-    if (EMIT) {
-        static_assert(BKT_SLOTS >= BKT_CAP, "start[] doubles as the references of a bucket");
-        u32 c0 = 0, c1 = 0, c2 = 0;  // (start[] is free: its last reads were in front of the barrier above)
-        for (u32 i0 = 0; i0 < n; i0 += BKT_THREADS) {  // (workgroup-uniform bound: the ballots)
-            const u32 i = i0 + tid;
-            bool head = false, shared = false;
+        for (u32 k = 0; k < BKT_ITEMS; ++k) {
+            const u32 i = k * BKT_THREADS + tid;
+            slot[k] = 0xffffffffu;
             if (i < n) {
-                const u64 h = skey[i];
-                const bool eq_prev = i > 0 && skey[i - 1] == h, eq_next = i + 1 < n && skey[i + 1] == h;
-                head = !eq_prev;
-                shared = eq_prev || eq_next;
-                if (shared) start[i] = ref_of(sval[i], a.ref_tab, a.ref_off);
+                if (EMIT) rf[k] = (YH_ABLATE_FZ & 2) ? val[k] >> 12 : ref_of(val[k], a.ref_tab, a.ref_off);
+                slot[k] = fine_of(key[k], a.lsh, a.mul_fine) & (BKT_SLOTS - 1u);
+                rank[k] = atomicAdd(&start[slot[k]], 1u);
             }
-            c0 += (u32)__popcll(__ballot(head));
-            c1 += (u32)__popcll(__ballot(head && shared));
-            c2 += (u32)__popcll(__ballot(shared));
+        }
+        __syncthreads();
+        block_scan_inplace2<BKT_SLOTS / BKT_THREADS>(start, wtot);
+#pragma unroll
+        for (u32 k = 0; k < BKT_ITEMS; ++k)
+            if (slot[k] != 0xffffffffu) {
+                const u32 at = start[slot[k]] + rank[k];
+                skey[at] = key[k];
+                sval[at] = val[k];
+            }
+        __syncthreads();
+        // every pair ranks itself among the pairs of its slot; a crowded slot = many pairs with (nearly) the same hash, which
+        // this quadratic step is not made for
+        bool crowded = false;
+        u32 pos[BKT_ITEMS];
+        bool moved[BKT_ITEMS];
+#pragma unroll
+        for (u32 k = 0; k < BKT_ITEMS; ++k) {
+            moved[k] = false;
+            if (slot[k] != 0xffffffffu) {
+                const u32 s0 = start[slot[k]];
+                const u32 c = (slot[k] + 1u < BKT_SLOTS ? start[slot[k] + 1u] : n) - s0;  // pairs of the slot
+                u32 less = 0;
+                if (c > SLOT_MAX) {
+                    crowded = true;
+                } else if (!(YH_ABLATE_FZ & 4)) {
+                    for (u32 q = s0; q < s0 + c; ++q) {
+                        const u64 kq = skey[q];
+                        less += (kq < key[k] || (kq == key[k] && sval[q] < val[k])) ? 1u : 0u;
+                    }
+                }
+                pos[k] = s0 + less;
+                moved[k] = less != rank[k];  // (the one pair of a slot -- most of them -- is where it belongs already)
+            }
+        }
+        if (crowded) atomicOr(a.flags, 4u);
+        __syncthreads();
+#pragma unroll
+        for (u32 k = 0; k < BKT_ITEMS; ++k)
+            if (slot[k] != 0xffffffffu) {
+                if (moved[k]) {
+                    skey[pos[k]] = key[k];
+                    if (!EMIT) sval[pos[k]] = val[k];  // (EMIT: the lane that holds a pair emits it -- nobody reads sval[] again)
+                }
+                if (EMIT) start[pos[k]] = rf[k];  // (start[] is free: its last reads were in front of the barrier above)
+            }
+        __syncthreads();
+        u32 c0 = 0, c1 = 0, c2 = 0;
+        if (EMIT) {
+#pragma unroll
+            for (u32 k = 0; k < BKT_ITEMS; ++k) {  // (every lane takes every turn: the ballots)
+                const u32 i = pos[k];
+                bool head = false, shared = false;
+                if (slot[k] != 0xffffffffu) {
+                    const u64 h = key[k];
+                    u32 s = i, e = i + 1;  // the run of this hash: [s, e)
+                    if (!(YH_ABLATE_FZ & 8)) {
+                        while (s > 0 && skey[s - 1] == h) --s;
+                        while (e < n && skey[e] == h) ++e;
+                    } else if ((h & 1) && i + 1 < n) e = i + 2;
+                    const u32 len = e - s;
+                    head = s == i;
+                    shared = len >= 2;
+                    if (shared) {  // (else its record stays 0: the array is cleared before the launch)
+                        u64 r;
+                        if (len <= 4 && a.inline_ok) {
+                            r = 0;
+                            u32 sh = 0;
+                            for (u32 q = s; q < e; ++q)
+                                if (q != i) { r |= (u64)(start[q] + 1u) << sh; sh += 21; }
+                        } else {
+                            a.list[b * BKT_CAP + i] = rf[k];
+                            r = (1ull << 63) | ((u64)len << 40) | (b * BKT_CAP + s);
+                        }
+                        if ((YH_ABLATE_FZ & 1) ? r == 0x1234567ull : val[k] < a.n_pos) a.rec[val[k]] = r;
+                    }
+                }
+                c0 += (u32)__popcll(__ballot(head));
+                c1 += (u32)__popcll(__ballot(head && shared));
+                c2 += (u32)__popcll(__ballot(shared));
+            }
+        } else {
+            const u64 out_base = a.off[b];
+            for (u32 i0 = 0; i0 < n; i0 += BKT_THREADS) {  // (workgroup-uniform bound: the ballots)
+                const u32 i = i0 + tid;
+                bool head = false, shared = false;
+                if (i < n) {
+                    const u64 h = skey[i];
+                    a.out_k[out_base + i] = h;
+                    a.out_v[out_base + i] = sval[i];
+                    const bool eq_prev = i > 0 && skey[i - 1] == h, eq_next = i + 1 < n && skey[i + 1] == h;
+                    head = !eq_prev;
+                    shared = eq_prev || eq_next;
+                }
+                c0 += (u32)__popcll(__ballot(head));
+                c1 += (u32)__popcll(__ballot(head && shared));
+                c2 += (u32)__popcll(__ballot(shared));
+            }
         }
         if ((tid & 63u) == 0) { atomicAdd(&tot3[0], c0); atomicAdd(&tot3[1], c1); atomicAdd(&tot3[2], c2); }
-        __syncthreads();
-        if (tid < 3 && tot3[tid]) atomicAdd(&a.totals[tid], (unsigned long long)tot3[tid]);
-        if (tid == 3) atomicAdd(&a.totals[3], (unsigned long long)n);
-        for (u32 i = tid; i < n; i += BKT_THREADS) {
-            const u64 h = skey[i];
-            u32 s = i, e = i + 1;
-            while (s > 0 && skey[s - 1] == h) --s;
-            while (e < n && skey[e] == h) ++e;
-            const u32 len = e - s;
-            if (len < 2) continue;  // (its record stays 0: the array is cleared before the launch)
-            u64 r;
-            if (len <= 4 && a.inline_ok) {
-                r = 0;
-                u32 sh = 0;
-                for (u32 q = s; q < e; ++q)
-                    if (q != i) { r |= (u64)(start[q] + 1u) << sh; sh += 21; }
-            } else {
-                a.list[b * BKT_CAP + i] = start[i];
-                r = (1ull << 63) | ((u64)len << 40) | (b * BKT_CAP + s);
-            }
-            if (sval[i] < a.n_pos) a.rec[sval[i]] = r;  // (always, unless a refused sort left the bucket in disorder)
+        __syncthreads();  // (also: every read of this bucket's LDS is behind us)
+        if (EMIT) {
+            if (tid < 3 && tot3[tid]) atomicAdd(&a.totals[tid], (unsigned long long)tot3[tid]);
+            if (tid == 3) atomicAdd(&a.totals[3], (unsigned long long)n);
+        } else if (a.counts && tid < 3) {
+            a.counts[b * 3 + tid] = tot3[tid];
         }
-        return;
-    }
-    const u64 out_base = a.off[b];
-    u32 c0 = 0, c1 = 0, c2 = 0;
-    for (u32 i0 = 0; i0 < n; i0 += BKT_THREADS) {  // (workgroup-uniform bound: the ballots)
-        const u32 i = i0 + tid;
-        bool head = false, shared = false;
-        if (i < n) {
-            const u64 h = skey[i];
-            a.out_k[out_base + i] = h;
-            a.out_v[out_base + i] = sval[i];
-            const bool eq_prev = i > 0 && skey[i - 1] == h, eq_next = i + 1 < n && skey[i + 1] == h;
-            head = !eq_prev;
-            shared = eq_prev || eq_next;
-        }
-        c0 += (u32)__popcll(__ballot(head));
-        c1 += (u32)__popcll(__ballot(head && shared));
-        c2 += (u32)__popcll(__ballot(shared));
-    }
-    if (a.counts) {
-        if ((tid & 63u) == 0) { atomicAdd(&tot3[0], c0); atomicAdd(&tot3[1], c1); atomicAdd(&tot3[2], c2); }
-        __syncthreads();
-        if (tid < 3) a.counts[b * 3 + tid] = tot3[tid];
     }
 }
 
@@ -627,7 +713,9 @@ int yh_psort_finish(yh_db* db, yh_psort* s, u64* d_keys_out, u32* d_vals_out, bo
     b.out_v = d_vals_out;
     b.flags = flags;
     b.counts = s->counts;
-    k_bucket_sort<false><<<(u32)s->NB, BKT_THREADS, 0, db->stream>>>(b);
+    b.nb = s->NB;
+    b.per_xcd = (u32)((s->NB + 7) / 8);
+    k_bucket_sort<false><<<8u * b.per_xcd, BKT_THREADS, 0, db->stream>>>(b);
     YH_HIP(hipGetLastError());
     u32 hflags[4] = {0, 0, 0, 0};
     u64 total = 0;
