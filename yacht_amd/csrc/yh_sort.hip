@@ -131,6 +131,8 @@ struct PartArgs {
     u64 val_base;
     const u32* ref_tab;   // position mode: the look-up of ref_of() (the ordering check)
     const u64* ref_off;
+    u64* rec_clear;       // position mode: yh_db::d_fz_rec -- every pair clears the record of its position on the way through
+                          // (400 MB of streaming stores under a pass that waits for LDS and atomics, instead of a memset of their own)
     u64 n_in;             // pairs of this call's input (level 1; level 2 without in_cnt: ONE input segment of n_in pairs)
     u64 cap_in;           // level 2: capacity of an input region
     const u32* in_cnt;    // level 2: pairs in every input region
@@ -149,8 +151,7 @@ template <int LEVEL>
 __global__ void __launch_bounds__(PART_THREADS) k_part(const PartArgs a) {
     __shared__ u64 skey[PART_TILE];
     __shared__ u32 sval[PART_TILE];
-    __shared__ u16 sbin[PART_TILE];
-    __shared__ u32 hist[PART_MAX_BINS], loc[PART_MAX_BINS], gbase[PART_MAX_BINS];
+    __shared__ u32 hist[PART_MAX_BINS], loc[PART_MAX_BINS], gbase[PART_MAX_BINS];  // (gbase: where the bin's run starts in its region MINUS where it starts in the tile)
     __shared__ u32 wtot[17];
     const u32 tid = threadIdx.x;
     u64 seg_n, in_base;
@@ -170,6 +171,13 @@ __global__ void __launch_bounds__(PART_THREADS) k_part(const PartArgs a) {
     const u32 tile_n = (u32)min((u64)PART_TILE, seg_n - t0);
     for (u32 b = tid; b < a.nbins; b += PART_THREADS) hist[b] = 0;
     __syncthreads();
+    // (the bin is computed twice -- when the pair is counted and when it leaves -- rather than kept in LDS beside it: the
+    // LDS pipe, ~7 operations per pair now, is what these passes keep busy, a multiplication is free)
+    auto bin_of = [&](u64 h) -> u32 {
+        const u32 b = bucket_of(h, a.lsh, a.mul);
+        const u32 x = LEVEL == 1 ? b / a.P2 : b % a.P2;
+        return x >= a.nbins ? a.nbins - 1 : x;  // (keys above max_hash: cannot happen after validation; stay in range)
+    };
     u64 key[PART_ITEMS];
     u32 val[PART_ITEMS], bin[PART_ITEMS], rank[PART_ITEMS];
 #pragma unroll
@@ -180,19 +188,30 @@ __global__ void __launch_bounds__(PART_THREADS) k_part(const PartArgs a) {
             key[k] = a.in_k[in_base + t0 + i];
             const bool positions = (LEVEL == 1 || !a.in_cnt) && !a.in_v;
             val[k] = positions ? (u32)(a.val_base + t0 + i) : a.in_v[in_base + t0 + i];
+            if (positions && a.rec_clear) a.rec_clear[val[k]] = 0;
             if (a.check_order && (LEVEL == 1 || !a.in_cnt)) {
                 // the element in front (lane - 1 has it; the wave's first lane reads it): same reference => strictly smaller hash
                 u64 pk = ((u64)(u32)__shfl_up((int)(u32)(key[k] >> 32), 1) << 32) | (u32)__shfl_up((int)(u32)key[k], 1);
                 u32 pv = (u32)__shfl_up((int)val[k], 1);
                 const u64 gi = t0 + i;
                 if ((tid & 63u) == 0 && gi > 0) { pk = a.in_k[in_base + gi - 1]; if (!positions) pv = a.in_v[in_base + gi - 1]; }
-                // (positions: the element in front is of the same reference unless this one is the first of its sketch)
-                const bool same = positions ? (u64)val[k] > a.ref_off[ref_of(val[k], a.ref_tab, a.ref_off)] : pv == val[k];
+                bool same = pv == val[k];
+                if (positions) {
+                    // the element in front is of the same reference unless this one is the first of its sketch.  The wave's
+                    // pairs are consecutive positions: where its first and its last active lane are of one reference (all but
+                    // the waves a sketch boundary crosses) that is everybody's, and two lanes have looked it up, not 64
+                    const u64 act = __ballot(true);
+                    const int l0 = __ffsll((long long)act) - 1, l1 = 63 - __clzll((long long)act);
+                    const u32 lane = tid & 63u;
+                    u32 r = (lane == (u32)l0 || lane == (u32)l1) ? ref_of(val[k], a.ref_tab, a.ref_off) : 0u;
+                    const u32 r0 = (u32)__shfl((int)r, l0), r1 = (u32)__shfl((int)r, l1);
+                    if (r0 != r1) r = ref_of(val[k], a.ref_tab, a.ref_off);
+                    else r = r0;
+                    same = (u64)val[k] > a.ref_off[r];
+                }
                 if (gi > 0 && same && !(pk < key[k])) atomicOr(a.flags, 8u);
             }
-            const u32 b = bucket_of(key[k], a.lsh, a.mul);
-            bin[k] = LEVEL == 1 ? b / a.P2 : b % a.P2;
-            if (bin[k] >= a.nbins) bin[k] = a.nbins - 1;  // (keys above max_hash: cannot happen after validation; stay in range)
+            bin[k] = bin_of(key[k]);
             rank[k] = atomicAdd(&hist[bin[k]], 1u);
         }
     }
@@ -226,13 +245,12 @@ __global__ void __launch_bounds__(PART_THREADS) k_part(const PartArgs a) {
             const u32 s = loc[bin[k]] + rank[k];
             skey[s] = key[k];
             sval[s] = val[k];
-            sbin[s] = (u16)bin[k];
         }
 #pragma unroll
     for (u32 q = 0; q < BINS_PER_THREAD; ++q) {
         const u32 b = q * PART_THREADS + tid;
         if (b < a.nbins) {
-            gbase[b] = g_mine[q];
+            gbase[b] = g_mine[q] - loc[b];
             if (c_mine[q] && (u64)g_mine[q] + c_mine[q] > a.cap_out) atomicOr(a.flags, 1u);
         }
     }
@@ -241,11 +259,12 @@ __global__ void __launch_bounds__(PART_THREADS) k_part(const PartArgs a) {
     for (u32 k = 0; k < PART_ITEMS; ++k) {
         const u32 s = k * PART_THREADS + tid;
         if (s < tile_n) {
-            const u32 b = sbin[s];
-            const u64 at = (u64)gbase[b] + (s - loc[b]);
+            const u64 h = skey[s];
+            const u32 b = bin_of(h);
+            const u64 at = (u32)(gbase[b] + s);
             if (at < a.cap_out) {
                 const u64 region = LEVEL == 1 ? b : (u64)seg * a.P2 + b;
-                a.out_k[region * a.cap_out + at] = skey[s];
+                a.out_k[region * a.cap_out + at] = h;
                 a.out_v[region * a.cap_out + at] = sval[s];
             }
         }
@@ -536,6 +555,7 @@ struct yh_psort {
     bool check_order = false;
     const u32* ref_tab = nullptr;  // position mode (yh_psort_positions): the values are CSR positions
     const u64* ref_off = nullptr;
+    u64* rec_clear = nullptr;      // position mode: the records the first level clears on its way through
     unsigned long long* totals = nullptr;  // [4] position mode: what the fused last pass counted
 };
 
@@ -551,7 +571,11 @@ bool yh_psort_applicable(u64 H, u64 max_hash) {
 }
 
 void yh_psort_check_order(yh_psort* s, bool on) { s->check_order = on; }
-void yh_psort_positions(yh_psort* s, const u32* d_ref_tab, const u64* d_offsets) { s->ref_tab = d_ref_tab; s->ref_off = d_offsets; }
+void yh_psort_positions(yh_psort* s, const u32* d_ref_tab, const u64* d_offsets, u64* d_rec) {
+    s->ref_tab = d_ref_tab;
+    s->ref_off = d_offsets;
+    s->rec_clear = d_rec;
+}
 int yh_ref_table_build(yh_db* db, const u64* d_offsets, u64 n_refs, u64 H, u32* d_tab) {
     const u64 n_tab = (H >> YH_REF_TAB_SH) + 2;
     if (n_refs == 0) return YH_OK;
@@ -624,6 +648,7 @@ int yh_psort_add(yh_db* db, yh_psort* s, const u64* d_keys, const u32* d_vals, u
     a.val_base = pos_base;
     a.ref_tab = s->ref_tab;
     a.ref_off = s->ref_off;
+    a.rec_clear = d_vals ? nullptr : s->rec_clear;
     a.n_in = n;
     a.mul = s->mul;
     a.lsh = s->lsh;
@@ -729,7 +754,7 @@ int yh_psort_finish(yh_db* db, yh_psort* s, u64* d_keys_out, u32* d_vals_out, bo
 }
 
 // Position mode: second level + the FUSED last pass (k_bucket_sort<true>): every bucket is sorted in LDS and leaves as the
-// records of the pairwise pass (yh_db::d_fz_rec, cleared here; H entries) instead of as sorted pairs.  totals[3] = {distinct
+// records of the pairwise pass (yh_db::d_fz_rec, H entries, cleared by the first level) instead of as sorted pairs.  totals[3] = {distinct
 // hashes, hashes with >= 2 holders, their pairs}.  *d_list_out: the holders of the hashes with more than four of them
 // (yh_db::d_fz_list) -- the sort's own bucket array, which is the caller's from here on (free it with yh_tfree).
 // *took_it = false: a capacity was exceeded, nothing usable was written.  Synchronizes the handle's stream.
@@ -743,7 +768,7 @@ int yh_psort_finish_emit(yh_db* db, yh_psort* s, u64* d_rec, u64 n_refs, u64 tot
     hipError_t e = yh_tmalloc(db, (void**)&s->totals, 4 * sizeof(unsigned long long));
     if (e != hipSuccess) { yh_set_error("distribution sort: allocation failed: %s", hipGetErrorString(e)); return YH_ERR_OOM; }
     YH_HIP(hipMemsetAsync(s->totals, 0, 4 * sizeof(unsigned long long), db->stream));
-    YH_HIP(hipMemsetAsync(d_rec, 0, s->H * sizeof(u64), db->stream));
+    if (d_rec != s->rec_clear) { yh_set_error("internal: the records were not cleared by the first level"); return YH_ERR_INVALID_ARG; }
     YH_TRY(second_level(db, s));
     BucketArgs b{};
     b.in_k = s->k2;
