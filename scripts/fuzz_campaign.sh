@@ -1,6 +1,7 @@
 #!/bin/bash
 # A longer randomized parity campaign (GPU box): tests/tools/fuzz_parity.py under several tuning configurations and
 # tests/tools/mix_calls.py, each against the CPU oracle.  usage: bash scripts/fuzz_campaign.sh [seconds per leg, default 120]
+# (the train handle of every small round takes the fused path of yh_sort.hip; two legs force its list-only records and the posting arrays)
 S=${1:-120}
 cd "$GRAFT_REPO_ROOT" || exit 1
 run() { echo "== $*"; env "$@" timeout $((S + 200)) python tests/tools/fuzz_parity.py --seconds "$S" --seed "$SEED" 2>&1 | tail -1; }
@@ -10,4 +11,6 @@ SEED=9102 run YH_DEBUG_TUNING=1 YH_UPLOAD_CHUNK_MIN=1 YH_CHECK_SORT=1 YH_UPLOAD_
 SEED=9103 run YH_DEBUG_TUNING=1 YH_PAIR_COLS=64 YH_PAIR_THREADS=256 YH_NO_PSORT=1
 SEED=9104 run YH_DEBUG_TUNING=1 YH_INDEX_TILE=2 YH_FILTER_MIN=1 YH_FILTER_BPH=2 YH_PAIR_THREADS=1024
 SEED=9105 run YH_DEBUG_TUNING=1 YH_NO_POOL=1 YH_UPLOAD_CHUNK_MIN=1000
+SEED=9108 run YH_DEBUG_TUNING=1 YH_FZ_NO_INLINE=1 YH_UPLOAD_CHUNK_MIN=1
+SEED=9109 run YH_DEBUG_TUNING=1 YH_NO_FUSED_TRAIN=1 YH_PAIR_COLS=128
 echo "== mix_calls 150 rounds"; timeout 900 python tests/tools/mix_calls.py 150 9106 2>&1 | tail -1

@@ -161,3 +161,36 @@ def test_distribution_sort_takes_uniform_keys_and_refuses_the_rest(hip_lib, heav
     assert out["ok"] and out["pairs"] > 300
     lines = [ln for ln in r.stderr.splitlines() if ln.startswith("[yh sort]")]
     assert len(lines) == 2 and all(ln.rstrip().endswith(verdict) for ln in lines), lines
+
+
+def test_tiny_sketches_and_shared_counts_on_the_train_handle(hip_lib):
+    """6 000 sketches of 0..6 hashes drawn from a small pool (many share): every block of the position -> reference look-up
+    of the fused path (one entry per 256 CSR positions) spans dozens of references, some of them empty.  Pairs, statistics and
+    the per-reference shared-hash counts (counted from the records on demand) against the oracle / the full handle."""
+    import torch
+
+    from oracle import oracle
+    from yacht_amd import synth
+    from yacht_amd.engine import RefDB, YH_DB_PAIRWISE_ONLY
+
+    rng = np.random.default_rng(91)
+    mh = synth.max_hash_for_scaled(1000)
+    pool = np.unique(rng.integers(1, mh, size=9000, dtype=np.uint64))
+    refs = [np.unique(rng.choice(pool, size=int(rng.integers(0, 7)), replace=False)) if rng.random() < 0.9 else np.zeros(0, np.uint64)
+            for _ in range(6000)]
+    values, offsets = synth.pack(refs)
+    n = len(refs)
+    wi, wj, wc, wstats = oracle.train_pairs(values, offsets, 0.3, threads=4)
+    assert wi.size > 1000
+    with RefDB(values, offsets, flags=YH_DB_PAIRWISE_ONLY) as tdb, RefDB(values, offsets) as db:
+        gi, gj, gc = tdb.pairwise(0.3)
+        assert np.array_equal(gi, wi) and np.array_equal(gj, wj) and np.array_equal(gc, wc)
+        assert tdb.index_stats() == wstats
+        ns_t = torch.zeros(n, dtype=torch.int32, device="cuda:0")
+        ns_d = torch.zeros(n, dtype=torch.int32, device="cuda:0")
+        torch.cuda.synchronize()
+        tdb.nshared_device(ns_t.data_ptr())
+        tdb.synchronize()
+        db.nshared_device(ns_d.data_ptr())
+        db.synchronize()
+        assert torch.equal(ns_t, ns_d) and int(ns_d.sum()) > 0

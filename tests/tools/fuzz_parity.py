@@ -26,7 +26,7 @@ from oracle import oracle  # noqa: E402  (the checker)
 from yacht_amd import _lib, synth  # noqa: E402
 import torch  # noqa: E402
 
-from yacht_amd.engine import RefDB, YH_DB_KEEP_CSR  # noqa: E402
+from yacht_amd.engine import RefDB, YH_DB_KEEP_CSR, YH_DB_PAIRWISE_ONLY  # noqa: E402
 
 
 def draw(rng):
@@ -138,6 +138,24 @@ def main() -> int:
                     gi, gj, gc = db.pairwise(c)
                     assert np.array_equal(gi, wi) and np.array_equal(gj, wj) and np.array_equal(gc, wc), "pairs"
                     assert db.index_stats() == wstats, "index stats"
+                    # `yacht train`'s own handle: the fused path (the sort's last pass writes the records), a row range of it,
+                    # and its shared-hash counts per reference against the full handle's
+                    with RefDB(values, offsets, flags=YH_DB_PAIRWISE_ONLY) as tdb:
+                        ti, tj, tc = tdb.pairwise(c)
+                        assert np.array_equal(ti, wi) and np.array_equal(tj, wj) and np.array_equal(tc, wc), "pairs (train handle)"
+                        assert tdb.index_stats() == wstats, "index stats (train handle)"
+                        if n > 2:
+                            cut = int(rng.integers(1, n))
+                            parts = [tdb.pairwise(c, 0, cut), tdb.pairwise(c, cut, n)]
+                            for k, w_k in ((0, wi), (1, wj), (2, wc)):
+                                assert np.array_equal(np.concatenate([q[k] for q in parts]), w_k), "pairs (train handle, row ranges)"
+                        if n:
+                            ns_t = torch.zeros(n, dtype=torch.int32, device="cuda:0")
+                            ns_d = torch.zeros(n, dtype=torch.int32, device="cuda:0")
+                            torch.cuda.synchronize()
+                            tdb.nshared_device(ns_t.data_ptr()); tdb.synchronize()
+                            db.nshared_device(ns_d.data_ptr()); db.synchronize()
+                            assert torch.equal(ns_t, ns_d), "shared hashes per reference (train handle)"
         except AssertionError as ex:
             print(json.dumps({"fuzz": "FAILED", "what": str(ex), **tag, "seed": args.seed}), flush=True)
             np.savez("gpurun_out/fuzz_failure.npz", values=values, offsets=offsets, sample=sample)
