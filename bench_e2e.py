@@ -162,6 +162,22 @@ def main() -> int:
                             "peak_rss_gb": {"process": rss_self, "largest_pool_worker": rss_kids}}
         if tag != "default" and not args.keep:
             shutil.rmtree(out_dir, ignore_errors=True)
+    # ---- the same command as a user starts it: a FRESH process (the in-process calls above find numpy / pandas / torch imported
+    # and the library and the HIP context up already)
+    import subprocess
+
+    cold = {}
+    for cmd_tag, extra in (("default", []), ("no_sig_files", ["--no_sig_files"])):
+        out_dir_c = os.path.join(args.work, f"out_cold_{cmd_tag}")
+        os.makedirs(out_dir_c)
+        env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        t0 = time.perf_counter()
+        rc = subprocess.run([sys.executable, "-m", "yacht_amd", "train", "--ref_file", ref_zip, "--ksize", "31", "--ani_thresh", "0.95",
+                             "--prefix", "db", "--outdir", out_dir_c, "--num_threads", str(args.threads), "--force"] + extra,
+                            env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL).returncode
+        cold[cmd_tag] = {"rc": rc, "wall_s": round(time.perf_counter() - t0, 2)}
+        shutil.rmtree(out_dir_c, ignore_errors=True)
+    train_lines["default"]["fresh_process_wall_s"] = cold
     out_dir = os.path.join(args.work, "out_default")
     n_kept = train_lines["default"]["references_kept"]
     lines["train"] = dict(train_lines["default"],
@@ -189,7 +205,17 @@ def main() -> int:
                      "slowest_phase": max(top, key=top.get) if top else None,
                      "slowest_leaf_phase": max((k for k in ph if not any(o.startswith(k + "/") for o in ph)), key=ph.get),
                      "result_rows": rows, "peak_rss_gb": {"process": rss_self, "largest_pool_worker": rss_kids}})
+    res_dir = os.path.join(args.work, "res_cold")
+    os.makedirs(res_dir)
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    t0 = time.perf_counter()
+    rc = subprocess.run([sys.executable, "-m", "yacht_amd", "run", "--json", os.path.join(out_dir, "db_config.json"), "--sample_file",
+                         os.path.join(args.work, "sample_1M.sig.zip"), "--min_coverage_list", "1", "0.5", "0.1", "0.05", "0.01",
+                         "--outdir", res_dir, "--num_threads", str(args.threads)],
+                        env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL).returncode
+    cold_run = {"rc": rc, "wall_s": round(time.perf_counter() - t0, 2)}
     lines["run"] = {
+        "fresh_process_wall_s_sample_1M": cold_run,
         "command": "yacht run (python -m yacht_amd run): config + sample zip -> result_all.txt (+ xlsx when openpyxl exists), 5 coverages",
         "workload": f"the {n_kept} references `yacht train` kept, packed DB memory-mapped from disk",
         "runs": runs,

@@ -141,7 +141,8 @@ def run(file_list: str, working_directory: str, output_filename: str, threads: i
         raise ValueError("number of passes must be at least 1")
     if containment_threshold < 0.0 or containment_threshold > 1.0:
         raise ValueError("containment threshold must be between 0.0 and 1.0")
-    paths = read_sketch_list(file_list)
+    with phases.phase("read_file_list"):
+        paths = read_sketch_list(file_list)
     with phases.phase("read_sig_files"):
         values, offsets = read_sketches_csr(paths, threads)
     n = len(paths)
@@ -153,6 +154,8 @@ def run(file_list: str, working_directory: str, output_filename: str, threads: i
         stats = db.index_stats()
         with phases.phase("pairwise"):
             pi, pj, pc = db.pairwise(float(containment_threshold))
+        with phases.phase("release_device_db"):
+            db.close()
     if verbose:
         print(f"Total number of sketches to read: {n}")
         print(f"Number of empty sketches: {len(empty)}")
@@ -172,8 +175,9 @@ def run(file_list: str, working_directory: str, output_filename: str, threads: i
 
     with phases.phase("select"):
         selected = train_select(sizes, pi, pj)
-    with open(output_filename, "w") as f:
-        for g in selected:
-            f.write(paths[int(g)] + "\n")
+    with phases.phase("write_selected_list"):
+        with open(output_filename, "w") as f:
+            for g in selected:
+                f.write(paths[int(g)] + "\n")
     return {"n": n, "empty": empty, "stats": stats, "n_pairs": int(pi.size), "selected": selected.tolist(),
             "paths": paths, "values": values, "offsets": offsets}

@@ -367,7 +367,8 @@ def run_yacht_train_core(num_threads: int, ani_thresh: float, ksize: int, path_t
     else:
         sig_files = [os.path.join(sig_dir, f) for f in os.listdir(sig_dir)]
     sig_files_path = os.path.join(path_to_temp_dir, "training_sig_files.tsv")
-    pd.DataFrame(sig_files).to_csv(sig_files_path, header=False, index=False)
+    with phases.phase("write_file_list"):
+        pd.DataFrame(sig_files).to_csv(sig_files_path, header=False, index=False)
 
     containment_thresh = ani_thresh ** ksize
     total = len(sig_files)
@@ -381,24 +382,25 @@ def run_yacht_train_core(num_threads: int, ani_thresh: float, ksize: int, path_t
     except Exception as exc:  # the reference raises ValueError on a non-zero exit code
         raise ValueError(f"Error running comparison algorithm: {exc}") from exc
 
-    os.makedirs(os.path.join(path_to_temp_dir, "comparison_files"), exist_ok=True)
-    for file in glob(os.path.join(path_to_temp_dir, "*.txt")):
-        shutil.move(file, os.path.join(path_to_temp_dir, "comparison_files"))
+    with phases.phase("manifest_of_the_selected"):
+        os.makedirs(os.path.join(path_to_temp_dir, "comparison_files"), exist_ok=True)
+        for file in glob(os.path.join(path_to_temp_dir, "*.txt")):
+            shutil.move(file, os.path.join(path_to_temp_dir, "comparison_files"))
 
-    selected_sig_files = pd.read_csv(selected_path, sep="\t", header=None)[0].to_list()
-    path_to_name = {sig_info_dict[name][-1]: name for name in sig_info_dict}
-    selected_names = set(path_to_name[p] for p in selected_sig_files)
+        selected_sig_files = pd.read_csv(selected_path, sep="\t", header=None)[0].to_list()
+        path_to_name = {sig_info_dict[name][-1]: name for name in sig_info_dict}
+        selected_names = set(path_to_name[p] for p in selected_sig_files)
 
-    rows = []
-    for name, (md5sum, mean_abund, n_hashes, scaled, _path) in sig_info_dict.items():
-        if name in selected_names:
-            rows.append((name, md5sum, n_hashes, get_num_kmers(mean_abund, n_hashes, scaled, False), scaled))
-    manifest = pd.DataFrame(rows, columns=["organism_name", "md5sum", "num_unique_kmers_in_genome_sketch",
-                                           "num_total_kmers_in_genome_sketch", "genome_scale_factor"])
-    # the selected sketches, packed in manifest order, for `yacht run` (refdb_cache)
-    row_of_path = {p: i for i, p in enumerate(core["paths"])}
-    name_to_path = {name: info[-1] for name, info in sig_info_dict.items()}
-    keep = [row_of_path[name_to_path[name]] for name in manifest["organism_name"]]
+        rows = []
+        for name, (md5sum, mean_abund, n_hashes, scaled, _path) in sig_info_dict.items():
+            if name in selected_names:
+                rows.append((name, md5sum, n_hashes, get_num_kmers(mean_abund, n_hashes, scaled, False), scaled))
+        manifest = pd.DataFrame(rows, columns=["organism_name", "md5sum", "num_unique_kmers_in_genome_sketch",
+                                               "num_total_kmers_in_genome_sketch", "genome_scale_factor"])
+        # the selected sketches, packed in manifest order, for `yacht run` (refdb_cache)
+        row_of_path = {p: i for i, p in enumerate(core["paths"])}
+        name_to_path = {name: info[-1] for name, info in sig_info_dict.items()}
+        keep = [row_of_path[name_to_path[name]] for name in manifest["organism_name"]]
     with phases.phase("pack_selected"):
         values, offsets = refdb_cache.subset(core["values"], core["offsets"], keep)
     # The train core reads record 0 / signature 0 of every file, whatever its k-mer size (as the reference's does,
