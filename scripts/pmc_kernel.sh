@@ -1,5 +1,5 @@
-# usage (GPU box): bash scripts/pmc_kernel.sh <kernel substring> <out tag> -- <program and args>
-# SQ and L2 counters of one kernel (means per launch), each group in a pass of its own.
+# usage (GPU box): bash scripts/pmc_kernel.sh <kernel substring[,substring...]> <out tag> -- <program and args>
+# SQ and L2 counters of the kernels (means per launch), each group in a pass of its own.
 K="$1"; TAG="$2"; shift 3
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT" || exit 1
@@ -15,16 +15,18 @@ done
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pmck_${TAG}_trace -- "$@" > /dev/null 2>&1
 python3 - "$K" "$TAG" <<'PY'
 import csv, glob, collections, sys
-K, TAG = sys.argv[1], sys.argv[2]
-for d in sorted(glob.glob(f"gpurun_out/pmck_{TAG}_[0-9]*")):
-    fs = sorted(glob.glob(d + "/*/*_counter_collection.csv"))
-    if not fs: print(d, "no output"); continue
-    acc = collections.defaultdict(list)
-    for r in csv.DictReader(open(fs[-1])):
-        if K in r["Kernel_Name"]:
-            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
-    for c, v in sorted(acc.items()):
-        print(f"{c:40s} {sum(v) / len(v):14.6g}   (n={len(v)})")
+KS, TAG = sys.argv[1].split(","), sys.argv[2]
+for K in KS:
+    print("==", K)
+    for d in sorted(glob.glob(f"gpurun_out/pmck_{TAG}_[0-9]*")):
+        fs = sorted(glob.glob(d + "/*/*_counter_collection.csv"))
+        if not fs: print(d, "no output"); continue
+        acc = collections.defaultdict(list)
+        for r in csv.DictReader(open(fs[-1])):
+            if K in r["Kernel_Name"]:
+                acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for c, v in sorted(acc.items()):
+            print(f"{c:40s} {sum(v) / len(v):14.6g}   (n={len(v)})")
 for f in glob.glob(f"gpurun_out/pmck_{TAG}_trace/*/*_kernel_stats.csv"):
     for r in csv.DictReader(open(f)):
         if "yh" in r["Name"] or "k_" in r["Name"]:
