@@ -26,6 +26,29 @@ def test_cache_roundtrip_and_keying(tmp_path):
     assert sv.tolist() == [3, 4, 5, 6, 7, 8, 9, 0, 1, 2] and so.tolist() == [0, 7, 10]
 
 
+def test_subset_written_from_the_source_slices(tmp_path):
+    """save_subset_async (what `yacht train` uses): the rows' slices straight from the source arrays, runs of consecutive rows
+    as one write, published only on request -- same files as subset() + save(); discard() leaves nothing behind."""
+    rng = np.random.default_rng(5)
+    sizes = rng.integers(0, 9, size=40)
+    offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+    values = rng.integers(1, 2 ** 60, size=int(offsets[-1]), dtype=np.uint64)
+    rows = [0, 1, 2, 5, 6, 9, 17, 18, 19, 39]
+    md5s = [f"m{r}" for r in rows]
+    pend = refdb_cache.save_subset_async(str(tmp_path), 31, values, offsets, rows)
+    assert refdb_cache.load(str(tmp_path), md5s, 31) is None  # (nothing refers to the files yet)
+    assert pend.publish(md5s)
+    v, o = refdb_cache.load(str(tmp_path), md5s, 31)
+    wv, wo = refdb_cache.subset(values, offsets, rows)
+    assert np.array_equal(v, wv) and np.array_equal(o, wo) and np.array_equal(pend.out_offsets, wo)
+    other = tmp_path / "other"
+    pend = refdb_cache.save_subset_async(str(other), 31, values, offsets, [3, 4])
+    pend.discard()
+    assert os.listdir(other / refdb_cache.DIR_NAME) == []
+    empty = refdb_cache.save_subset_async(str(tmp_path / "none"), 31, values, offsets, [])
+    assert empty.publish([]) and refdb_cache.load(str(tmp_path / "none"), [], 31)[0].size == 0
+
+
 def test_cache_rewrite_is_atomic_for_readers(tmp_path):
     """A reader that mapped one generation keeps a complete copy of it while another process rewrites the
     cache (many `yacht run` processes share one training directory); a truncated array or a

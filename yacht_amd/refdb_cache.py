@@ -61,16 +61,105 @@ def save(genome_dir: str, md5sums: Sequence[str], ksize: int, values: np.ndarray
             f.flush()
             os.fsync(f.fileno())
         os.replace(tmp, os.path.join(d, "meta.json"))
-        for old in os.listdir(d):  # earlier generations (best effort; a reader that has them open keeps them)
-            if (old.startswith("values-") or old.startswith("offsets-") or old in ("values.npy", "offsets.npy")) \
-                    and old not in names.values() and not old.endswith(".part"):
-                try:
-                    os.remove(os.path.join(d, old))
-                except OSError:
-                    pass
+        _remove_older_generations(d, names)
         return True
     except OSError:
         return False  # read-only training directory: just do not cache
+
+
+class PendingSubsetSave:
+    """The packed copy of SOME rows of a CSR on its way to disk in a thread of its own (save_subset_async): the rows'
+    slices are written straight from the source arrays -- no packed copy in memory first -- while the caller does other
+    work (file writes release the GIL).  Nothing refers to the files until publish(); discard() removes them."""
+
+    def __init__(self, genome_dir: str, ksize: int, values: np.ndarray, offsets: np.ndarray, rows: Sequence[int]):
+        import threading
+
+        self.dir = cache_dir(genome_dir)
+        self.ksize = int(ksize)
+        token = f"{os.getpid():x}-{secrets.token_hex(6)}"
+        self.token = token
+        self.names = {"values": f"values-{token}.npy", "offsets": f"offsets-{token}.npy"}
+        rows = np.asarray(rows, dtype=np.int64)
+        sizes = (offsets[rows + 1] - offsets[rows]).astype(np.uint64) if rows.size else np.zeros(0, np.uint64)
+        self.out_offsets = np.zeros(rows.size + 1, dtype=np.uint64)
+        if rows.size:
+            self.out_offsets[1:] = np.cumsum(sizes, dtype=np.uint64)
+        self.ok = False
+        self._thread = threading.Thread(target=self._write, args=(values, offsets, rows), name="yacht-hip-packed-db", daemon=True)
+        self._thread.start()
+
+    def _write(self, values: np.ndarray, offsets: np.ndarray, rows: np.ndarray) -> None:
+        try:
+            os.makedirs(self.dir, exist_ok=True)
+            values = np.ascontiguousarray(values, dtype=np.uint64)
+            n_out = int(self.out_offsets[-1])
+            tmp = os.path.join(self.dir, self.names["values"] + ".part")
+            with open(tmp, "wb") as f:
+                np.lib.format.write_array_header_1_0(f, {"descr": "<u8", "fortran_order": False, "shape": (n_out,)})
+                # runs of consecutive rows are one slice of the source
+                k = 0
+                while k < rows.size:
+                    e = k + 1
+                    while e < rows.size and rows[e] == rows[e - 1] + 1:
+                        e += 1
+                    f.write(memoryview(values[int(offsets[rows[k]]):int(offsets[rows[e - 1] + 1])]))
+                    k = e
+                f.flush()
+                os.fsync(f.fileno())
+            os.replace(tmp, os.path.join(self.dir, self.names["values"]))
+            tmp = os.path.join(self.dir, self.names["offsets"] + ".part")
+            with open(tmp, "wb") as f:
+                np.save(f, self.out_offsets)
+                f.flush()
+                os.fsync(f.fileno())
+            os.replace(tmp, os.path.join(self.dir, self.names["offsets"]))
+            self.ok = True
+        except OSError:
+            self.ok = False  # read-only training directory: just do not cache
+
+    def publish(self, md5sums: Sequence[str]) -> bool:
+        """Wait for the files and make them the directory's packed copy (meta.json moved into place)."""
+        self._thread.join()
+        if not self.ok:
+            return False
+        try:
+            meta = {"ksize": self.ksize, "md5sums": list(md5sums), "files": self.names, "n_refs": int(self.out_offsets.size - 1),
+                    "n_hashes": int(self.out_offsets[-1]), "offsets_sha1": _offsets_digest(self.out_offsets)}
+            tmp = os.path.join(self.dir, f"meta-{self.token}.json.part")
+            with open(tmp, "w") as f:
+                json.dump(meta, f)
+                f.flush()
+                os.fsync(f.fileno())
+            os.replace(tmp, os.path.join(self.dir, "meta.json"))
+            _remove_older_generations(self.dir, self.names)
+            return True
+        except OSError:
+            return False
+
+    def discard(self) -> None:
+        self._thread.join()
+        for name in self.names.values():
+            for path in (os.path.join(self.dir, name), os.path.join(self.dir, name + ".part")):
+                try:
+                    os.remove(path)
+                except OSError:
+                    pass
+
+
+def save_subset_async(genome_dir: str, ksize: int, values: np.ndarray, offsets: np.ndarray, rows: Sequence[int]) -> PendingSubsetSave:
+    """Start writing the packed copy of `rows` (in that order) of the CSR; see PendingSubsetSave."""
+    return PendingSubsetSave(genome_dir, ksize, values, offsets, rows)
+
+
+def _remove_older_generations(d: str, names) -> None:
+    for old in os.listdir(d):  # earlier generations (best effort; a reader that has them open keeps them)
+        if (old.startswith("values-") or old.startswith("offsets-") or old in ("values.npy", "offsets.npy")) \
+                and old not in names.values() and not old.endswith(".part"):
+            try:
+                os.remove(os.path.join(d, old))
+            except OSError:
+                pass
 
 
 def load(genome_dir: str, md5sums: Sequence[str], ksize: int) -> Optional[Tuple[np.ndarray, np.ndarray]]:

@@ -382,33 +382,32 @@ def run_yacht_train_core(num_threads: int, ani_thresh: float, ksize: int, path_t
     except Exception as exc:  # the reference raises ValueError on a non-zero exit code
         raise ValueError(f"Error running comparison algorithm: {exc}") from exc
 
+    # The selected sketches, packed in manifest order (= the order of sig_info_dict, the archive's) for `yacht run`
+    # (refdb_cache): their slices go to disk in a thread of their own, straight from the core's arrays, while the manifest is
+    # put together here; nothing refers to the files until the sizes below have been checked.
+    os.makedirs(os.path.join(path_to_temp_dir, "comparison_files"), exist_ok=True)
+    for file in glob(os.path.join(path_to_temp_dir, "*.txt")):
+        shutil.move(file, os.path.join(path_to_temp_dir, "comparison_files"))
+    with phases.phase("rows_of_the_selected"):
+        selected_paths = set(core["paths"][int(g)] for g in core["selected"])
+        row_of_path = {p: i for i, p in enumerate(core["paths"])}
+        kept_names = [name for name, info in sig_info_dict.items() if info[-1] in selected_paths]
+        keep = [row_of_path[sig_info_dict[name][-1]] for name in kept_names]
+    pending = refdb_cache.save_subset_async(path_to_temp_dir, ksize, core["values"], core["offsets"], keep)
     with phases.phase("manifest_of_the_selected"):
-        os.makedirs(os.path.join(path_to_temp_dir, "comparison_files"), exist_ok=True)
-        for file in glob(os.path.join(path_to_temp_dir, "*.txt")):
-            shutil.move(file, os.path.join(path_to_temp_dir, "comparison_files"))
-
-        selected_sig_files = pd.read_csv(selected_path, sep="\t", header=None)[0].to_list()
-        path_to_name = {sig_info_dict[name][-1]: name for name in sig_info_dict}
-        selected_names = set(path_to_name[p] for p in selected_sig_files)
-
         rows = []
-        for name, (md5sum, mean_abund, n_hashes, scaled, _path) in sig_info_dict.items():
-            if name in selected_names:
-                rows.append((name, md5sum, n_hashes, get_num_kmers(mean_abund, n_hashes, scaled, False), scaled))
+        for name in kept_names:
+            md5sum, mean_abund, n_hashes, scaled, _path = sig_info_dict[name]
+            rows.append((name, md5sum, n_hashes, get_num_kmers(mean_abund, n_hashes, scaled, False), scaled))
         manifest = pd.DataFrame(rows, columns=["organism_name", "md5sum", "num_unique_kmers_in_genome_sketch",
                                                "num_total_kmers_in_genome_sketch", "genome_scale_factor"])
-        # the selected sketches, packed in manifest order, for `yacht run` (refdb_cache)
-        row_of_path = {p: i for i, p in enumerate(core["paths"])}
-        name_to_path = {name: info[-1] for name, info in sig_info_dict.items()}
-        keep = [row_of_path[name_to_path[name]] for name in manifest["organism_name"]]
-    with phases.phase("pack_selected"):
-        values, offsets = refdb_cache.subset(core["values"], core["offsets"], keep)
     # The train core reads record 0 / signature 0 of every file, whatever its k-mer size (as the reference's does,
     # main.cpp:62-84); the manifest's sizes come from the signature of THIS k-mer size.  Only when the two agree
-    # is the packed copy what `yacht run` would load itself -- otherwise it is not written and run reads the files.
-    if np.array_equal(np.diff(offsets).astype(np.int64), manifest["num_unique_kmers_in_genome_sketch"].to_numpy(dtype=np.int64)):
-        with phases.phase("write_packed_db"):
-            refdb_cache.save(path_to_temp_dir, manifest["md5sum"].to_list(), ksize, values, offsets)
-    else:
-        logger.warning("sketch sizes of the train core and of the ksize-filtered signatures differ: no packed copy written")
+    # is the packed copy what `yacht run` would load itself -- otherwise it is dropped and run reads the files.
+    with phases.phase("write_packed_db"):
+        if np.array_equal(np.diff(pending.out_offsets).astype(np.int64), manifest["num_unique_kmers_in_genome_sketch"].to_numpy(dtype=np.int64)):
+            pending.publish(manifest["md5sum"].to_list())
+        else:
+            pending.discard()
+            logger.warning("sketch sizes of the train core and of the ksize-filtered signatures differ: no packed copy written")
     return manifest
