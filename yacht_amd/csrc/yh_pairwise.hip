@@ -15,6 +15,9 @@
 //                      four slots of the output, or -- a longer segment -- into room claimed behind them with one atomic
 // configs[3] (27 M postings, 10 000 rows): 0.59 + 0.28 ms, where the dense count matrix with one global atomic per
 // (posting, other holder) took 2.66 + 0.53 ms.
+// `yacht train`'s own handle (YH_DB_PAIRWISE_ONLY, uniform keys: yh_db::fz) skips the transposition altogether: the last
+// pass of the sort has written an 8-byte record per CSR position (yh_sort.hip), a reference's records are the extent of
+// its sketch, and k_pair_rows<.., true> reads them as they lie -- 0.28 ms for the whole pairwise call's device side.
 // The host puts the segments in row order and applies the exact threshold (no decision depends on device floating point).
 #include "yh_common.h"
 

@@ -18,10 +18,16 @@
 //               of the CSR would give -- and the bucket leaves in order, coalesced, at its exact place of the output
 //
 // Three passes over the pairs (read 12 B + write 12 B each) instead of 6-7, no global merge.  Every capacity is checked on
-// the device: keys that are not uniform enough (a region or a bucket overflows, a slot holds hundreds of pairs: a hash held
-// by hundreds of references) raise a flag and the caller sorts with rocPRIM instead -- slower, equally exact.
+// the device: keys that are not uniform enough (a region or a bucket overflows, a slot holds more than SLOT_MAX pairs: a
+// hash held by a thousand references) raise a flag and the caller sorts with rocPRIM instead -- slower, equally exact.
 // The first level can be fed in pieces (yh_psort_add): the chunks of a host database are distributed while the next
 // chunk crosses PCIe, and only levels two and three remain behind the last byte (yh_build_upload_sorted).
+//
+// POSITION MODE (`yacht train`'s handle, yh_db::fz): the value of a pair is its CSR position, not its reference -- the
+// order is the same -- and the last pass (k_bucket_sort<true>) does not write sorted pairs at all: with every run of equal
+// hashes whole and in order in LDS it stores, at the position of every element whose hash another reference holds too,
+// the 8-byte record the pairwise pass reads ("the other holders").  No posting arrays, no rank per posting, no
+// transposition: see yh_build.hip (fz_*) and yh_pairwise.hip (k_pair_rows<.., true>).
 #include "yh_common.h"
 #include "yh_sort.h"
 
