@@ -291,6 +291,7 @@ def main() -> int:
     # and RCCL orders its collectives after whatever is on torch's current stream.
     stream = torch.cuda.Stream(device=dev)
     sdb = None
+    db_build_driver = None
     with torch.cuda.stream(stream):
         if by_hash:
             sdb = ydist.HashRangeRefDB(values, offsets, bounds, ydist.HipRangeBackend(local_rank),
@@ -305,8 +306,12 @@ def main() -> int:
             dist.all_reduce(n_rows_c, op=dist.ReduceOp.MAX)
             row_stride = int(n_rows_c.item())
         else:
+            mem0 = ylib.alloc_stats()
             db = RefDB.from_device(values.data_ptr(), offsets.data_ptr(), n_local, device=local_rank,
                                    flags=YH_DB_NO_DIRECTORY if args.no_indexed else YH_DB_DEFAULT)
+            mem1 = ylib.alloc_stats()
+            db_build_driver = {"allocations": mem1["driver_allocs"] - mem0["driver_allocs"],
+                               "ms_inside_hipMalloc": round(mem1["ms_in_driver"] - mem0["ms_in_driver"], 1)}
             row_stride = n_local
     torch.cuda.synchronize()
     db.set_stream(stream.cuda_stream)
@@ -1160,6 +1165,7 @@ def main() -> int:
     # process (its own handle, its own JSON line), after this process has released its database
     train = None
     db_rebuild_ms = None
+    db_rebuild_driver = None
     if rank == 0 and not multi and not args.no_train:
         import subprocess
 
@@ -1169,9 +1175,13 @@ def main() -> int:
             # handle above has just returned them), so the driver is not asked for memory at all
             if not args.no_scaling_model:
                 with torch.cuda.stream(stream):
+                    mem0 = ylib.alloc_stats()
                     db2 = RefDB.from_device(values.data_ptr(), offsets.data_ptr(), n_local, device=local_rank,
                                             flags=YH_DB_NO_DIRECTORY if args.no_indexed else YH_DB_DEFAULT)
+                    mem1 = ylib.alloc_stats()
                 db_rebuild_ms = round(float(db2.timing()["ms_db_build"]), 2)
+                db_rebuild_driver = {"allocations": mem1["driver_allocs"] - mem0["driver_allocs"],
+                                     "ms_inside_hipMalloc": round(mem1["ms_in_driver"] - mem0["ms_in_driver"], 1)}
                 db2.close()
         del values, offsets
         torch.cuda.empty_cache()
@@ -1247,12 +1257,14 @@ def main() -> int:
                 "ghost_refs_rank0": (sdb.n_ghost if sdb is not None else 0),
                 "db_build_ms": round(float(timing["ms_db_build"]), 2),
                 "db_rebuild_ms": db_rebuild_ms,
+                "db_build_driver": db_build_driver, "db_rebuild_driver": db_rebuild_driver,
                 "device_memory": ylib.alloc_stats(),
                 "wall_s_by_section": wall,
                 "db_build_note": "device input; HIP events around validation + sort + index + tables, host stalls included: a hipMalloc of a "
                                  "multi-GB block sporadically takes 0.7-4 s on this pool (profiles/r04/malloc_probe.txt, a plain HIP program) -- "
                                  "round 3's 705-815 ms; db_rebuild_ms = the same build again behind the first handle's destroy, its arrays out of "
-                                 "the library's buffer cache (no driver allocation)",
+                                 "the library's buffer cache; db_build_driver / db_rebuild_driver = the trips to the driver inside the two calls "
+                                 "and the host time inside them (yh_alloc_stats): what a build above ~60 ms is made of",
                 "db_hbm_bytes": info["device_bytes"],
                 "pipelined_tail": bool(not multi and args.pipelined_tail),
                 "step": "overlap + exclusive counts" + ((f" (blocks of {GB} samples: one all_gather of their subset bits" + (", two blocks in flight" if pipelined else "") + f") + one {'gather to rank 0' if to_root else 'all_gather'} of the count rows per {GB} samples"
