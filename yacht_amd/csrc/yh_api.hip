@@ -35,7 +35,7 @@ const char* yh_tune_env(const char* name) {
 // hipFreeAsync into the device's memory pool was no cheaper (0.35 ms a call).  A block is returned with an EVENT recorded
 // on the stream that used it last (events are the library's own, pooled: the stream itself may be a caller's and gone by
 // the time the block is reused): the same stream may have the block back at once (stream order), any other user waits
-// for the event.  What the cache holds beyond YH_POOL_KEEP (default 4 GiB) goes back to the driver at the end of a
+// for the event.  What the cache holds beyond YH_POOL_KEEP (default 48 GiB) goes back to the driver at the end of a
 // create / destroy.
 namespace {
 struct CacheBlock { void* p; size_t bytes; int device; hipStream_t owner; hipEvent_t freed; };
@@ -159,7 +159,7 @@ void yh_tfree(yh_db* db, void* p) {
 // (the handle's stream has drained) blocks it used last are anyone's now; the excess over the bar goes back to the driver
 void yh_pool_trim(yh_db* db) {
     if (!cache_on()) return;
-    static const size_t keep = [] { const char* e = yh_tune_env("YH_POOL_KEEP"); return e ? (size_t)atoll(e) : (size_t)16 << 30; }();
+    static const size_t keep = [] { const char* e = yh_tune_env("YH_POOL_KEEP"); return e ? (size_t)atoll(e) : (size_t)48 << 30; }();  // (a sixth of this GPU's HBM: what a handle at GTDB scale and its build's temporaries leave behind -- 28 GB -- comes back without the driver)
     std::vector<void*> drop;
     {
         std::lock_guard<std::mutex> lk(g_cache_mu);
