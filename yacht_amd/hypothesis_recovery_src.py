@@ -57,6 +57,15 @@ _DB_CACHE: Dict[Tuple[str, Tuple[str, ...]], RefDB] = {}
 _LAST_RUN: Dict[str, object] = {}
 
 
+def _write_path_list(path: str, paths) -> None:
+    """One path per line, quoted where a CSV reader needs it: byte for byte what `pd.DataFrame(paths).to_csv(path, header=False,
+    index=False)` writes (the reference's call), without building a frame of 80 000 rows for it (0.1 s of a 0.57 s `yacht run`)."""
+    import csv
+
+    with open(path, "w", newline="") as f:
+        csv.writer(f, lineterminator="\n").writerows([p] for p in paths)
+
+
 def _read_mins(path_and_ksize) -> np.ndarray:
     """The sketch `yacht run` uses for a reference: the ONE signature of the given k-mer size in the file
     (reference: load_signature_with_ksize, utils.py:31-51 -- anything else is an error there too)."""
@@ -134,11 +143,9 @@ def get_organisms_with_nonzero_overlap(manifest: pd.DataFrame, sample_file: str,
     with phases.phase("write_list_files"):
         sample_sigs = [os.path.join(path_to_sample_temp_dir, "signatures", f)
                        for f in os.listdir(os.path.join(path_to_sample_temp_dir, "signatures"))]
-        pd.DataFrame(sample_sigs).to_csv(os.path.join(path_to_sample_temp_dir, "sample_sig_file.txt"), header=False,
-                                         index=False)
+        _write_path_list(os.path.join(path_to_sample_temp_dir, "sample_sig_file.txt"), sample_sigs)
         organism_sigs = [os.path.join(path_to_genome_temp_dir, "signatures", m + SIG_SUFFIX) for m in manifest["md5sum"]]
-        pd.DataFrame(organism_sigs).to_csv(os.path.join(path_to_sample_temp_dir, "organism_sig_file.txt"), header=False,
-                                           index=False)
+        _write_path_list(os.path.join(path_to_sample_temp_dir, "organism_sig_file.txt"), organism_sigs)
 
     # parsed_sample: the caller's already-parsed signature of this very file (hypothesis_recovery holds it); a
     # 10^6-hash sketch takes 0.2-0.3 s to parse and the archive has been read once already

@@ -368,7 +368,10 @@ def run_yacht_train_core(num_threads: int, ani_thresh: float, ksize: int, path_t
         sig_files = [os.path.join(sig_dir, f) for f in os.listdir(sig_dir)]
     sig_files_path = os.path.join(path_to_temp_dir, "training_sig_files.tsv")
     with phases.phase("write_file_list"):
-        pd.DataFrame(sig_files).to_csv(sig_files_path, header=False, index=False)
+        import csv
+
+        with open(sig_files_path, "w", newline="") as f:  # (what pd.DataFrame(sig_files).to_csv(..., header=False, index=False) writes)
+            csv.writer(f, lineterminator="\n").writerows([p] for p in sig_files)
 
     containment_thresh = ani_thresh ** ksize
     total = len(sig_files)
