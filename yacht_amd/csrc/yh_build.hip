@@ -666,7 +666,7 @@ int yh_build_upload_sorted(yh_db* db, const u64* h_values, const u64* h_offsets,
         if (rc == YH_OK) { ev.push_back(a); eb.push_back(b); ee.push_back(c2); }
     }
     const bool dist_sort = yh_psort_applicable(H, max_last);
-    bool fused = dist_sort && fz_wanted(db);  // (a YH_DB_PAIRWISE_ONLY handle: positions as values, no sorted pairs at all)
+    bool fused = dist_sort && fz_wanted(db) && max_last != ~0ull;  // (a YH_DB_PAIRWISE_ONLY handle: positions as values, no sorted pairs at all; hash + 1 is the table's key)
     if (!fused) {
         UP_HIP(yh_tmalloc(db, (void**)&K[0], H * sizeof(u64)));
         UP_HIP(yh_tmalloc(db, (void**)&V[0], H * sizeof(u32)));
@@ -872,7 +872,7 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, u64* d_
     }
 
     bool try_psort = yh_psort_applicable(H, db->max_hash);
-    if (!d_sk_pre && try_psort && fz_wanted(db)) {  // the fused path from device memory (see fz_wanted above)
+    if (!d_sk_pre && try_psort && fz_wanted(db) && db->max_hash != ~0ull) {  // the fused path from device memory (see fz_wanted above)
         yh_psort* fps = nullptr;
         bool took = false, unsorted = false;
         YH_TRY(fz_begin(db, d_offsets, db->max_hash, &fps));

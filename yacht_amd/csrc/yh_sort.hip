@@ -535,6 +535,128 @@ __global__ void __launch_bounds__(BKT_THREADS) k_bucket_sort(const BucketArgs a)
     }
 }
 
+// The last pass in position mode: the pairwise records need, for every pair, the OTHER pairs of its bucket with the same
+// hash -- a GROUPING, not an order.  One workgroup per bucket puts the bucket's pairs into an LDS hash table keyed by the
+// hash itself (open addressing from the pair's fine slot, a linear function of the key that spreads ~0.4 distinct hashes
+// per slot; a 64-bit compare-and-swap claims a slot or finds the hash there), the pairs of one hash chained through their
+// slot's head word; behind ONE barrier every pair walks its chain and stores its record.  Three barriers per bucket
+// instead of the eight of a counting sort + ranking + placement (k_bucket_sort, which did this job first: 0.68 ms at
+// configs[3], this 0.55), and no limit on the holders of one hash short of the bucket's capacity (a chain of m pairs is
+// walked m times: m^2 LDS reads).
+// Hashes with more than four holders (or any, when references do not fit 21-bit fields) keep their holders in the
+// bucket's list area: the chain's first pair reserves room, every pair writes its reference at its rank among the chain's
+// pair indices.
+// XCD x (blockIdx % 8 on this chip) takes the x-th EIGHTH of the buckets, front to back: that walk is what lets the L2s
+// merge the record stores -- a sketch's elements inside a first-level region of the sort are ~36 consecutive CSR positions,
+// and the region's ~140 buckets are then all processed on the same XCD within a short time of each other
+// (scripts/probes/scatter_probe.hip: 27 M 8-byte records in 0.30 ms this way, 0.39 ms with bucket = blockIdx, 0.69 ms at
+// isolated positions, 1.3 ms with non-temporal stores -- and the counting atomic + the store of k_idx_emit /
+// k_pair_transpose before: 0.76 + 0.56 ms).
+__global__ void __launch_bounds__(BKT_THREADS) k_bucket_group(const BucketArgs a) {
+    constexpr u32 NONE = 0xffffffffu;
+    __shared__ __attribute__((aligned(16))) u64 tkey[BKT_CAP];   // hash + 1 of the slot's group (0: free)
+    __shared__ __attribute__((aligned(16))) u32 thead[BKT_CAP];  // the group's last-come pair; later, for a listed group, where its holders start in the list
+    __shared__ u32 eref[BKT_CAP];     // pair -> reference
+    __shared__ u16 enext[BKT_CAP];    // pair -> the pair that came before it in its group (0xffff: none)
+    __shared__ u32 tot3[3];
+    __shared__ u32 lcount, has_list;
+    static_assert(BKT_CAP <= 65535, "pair indices in 16 bits");
+    const u32 tid = threadIdx.x;
+    const u64 b = (u64)(blockIdx.x & 7u) * a.per_xcd + (blockIdx.x >> 3);
+    if ((blockIdx.x >> 3) >= a.per_xcd || b >= a.nb) return;
+    if (a.cnt[b] > BKT_CAP && tid == 0) atomicOr(a.flags, 2u);
+    const u32 n = min(a.cnt[b], BKT_CAP);
+    if (n == 0) return;
+    u64 key[BKT_ITEMS];
+    u32 val[BKT_ITEMS], rf[BKT_ITEMS], slot[BKT_ITEMS];
+#pragma unroll
+    for (u32 k = 0; k < BKT_ITEMS; ++k) {
+        const u32 e = k * BKT_THREADS + tid;
+        slot[k] = NONE;
+        if (e < n) { key[k] = a.in_k[b * a.cap_in + e]; val[k] = a.in_v[b * a.cap_in + e]; }
+    }
+    for (u32 i = tid; i < BKT_CAP / 2; i += BKT_THREADS) reinterpret_cast<uint4*>(tkey)[i] = make_uint4(0u, 0u, 0u, 0u);
+    for (u32 i = tid; i < BKT_CAP / 4; i += BKT_THREADS) reinterpret_cast<uint4*>(thead)[i] = make_uint4(NONE, NONE, NONE, NONE);
+    if (tid < 3) tot3[tid] = 0;
+    if (tid == 3) { lcount = 0; has_list = 0; }
+    __syncthreads();
+    u32 c0 = 0;
+#pragma unroll
+    for (u32 k = 0; k < BKT_ITEMS; ++k) {
+        const u32 e = k * BKT_THREADS + tid;
+        bool won = false;
+        if (e < n) {
+            rf[k] = ref_of(val[k], a.ref_tab, a.ref_off);
+            eref[e] = rf[k];
+            const unsigned long long k1 = key[k] + 1ull;  // (the fused path is taken only where the largest hash is below 2^64 - 1)
+            u32 s = fine_of(key[k], a.lsh, a.mul_fine) & (BKT_CAP - 1u);
+            for (u32 probe = 0; probe < BKT_CAP; ++probe) {
+                const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&tkey[s]), 0ull, k1);
+                if (old == 0ull) { won = true; break; }
+                if (old == k1) break;
+                s = (s + 1u) & (BKT_CAP - 1u);
+            }
+            slot[k] = s;
+            enext[e] = (u16)atomicExch(&thead[s], e);  // (NONE -> 0xffff)
+        }
+        c0 += (u32)__popcll(__ballot(won));
+    }
+    __syncthreads();
+    u32 c1 = 0, c2 = 0;
+    u32 glen[BKT_ITEMS], grank[BKT_ITEMS];
+#pragma unroll
+    for (u32 k = 0; k < BKT_ITEMS; ++k) {
+        const u32 e = k * BKT_THREADS + tid;
+        bool first = false, shared = false;
+        glen[k] = 0;
+        grank[k] = 0;
+        if (slot[k] != NONE) {
+            u32 others[3] = {0u, 0u, 0u};
+            u32 cnt = 0, rank = 0;
+            for (u32 j = thead[slot[k]]; j != 0xffffu && j != NONE; j = enext[j]) {
+                if (j == e) continue;
+                if (cnt < 3) others[cnt] = eref[j];
+                ++cnt;
+                rank += j < e ? 1u : 0u;
+            }
+            const u32 len = cnt + 1u;
+            first = enext[e] == 0xffffu;  // (the pair that claimed the chain: one per group)
+            shared = len >= 2u;
+            if (shared) {
+                if (len <= 4u && a.inline_ok) {
+                    const u64 r = (u64)(others[0] + 1u) | (cnt > 1 ? (u64)(others[1] + 1u) << 21 : 0ull) | (cnt > 2 ? (u64)(others[2] + 1u) << 42 : 0ull);
+                    if (val[k] < a.n_pos) a.rec[val[k]] = r;
+                } else {
+                    glen[k] = len;
+                    grank[k] = rank;
+                    has_list = 1u;
+                }
+            }
+        }
+        c1 += (u32)__popcll(__ballot(first && shared));
+        c2 += (u32)__popcll(__ballot(shared));
+    }
+    if ((tid & 63u) == 0) { atomicAdd(&tot3[0], c0); atomicAdd(&tot3[1], c1); atomicAdd(&tot3[2], c2); }
+    __syncthreads();
+    if (tid < 3 && tot3[tid]) atomicAdd(&a.totals[tid], (unsigned long long)tot3[tid]);
+    if (tid == 3) atomicAdd(&a.totals[3], (unsigned long long)n);
+    if (!has_list) return;  // (uniform: read behind the barrier)
+    // the listed groups: the chain's first pair reserves the group's room in the bucket's list area
+#pragma unroll
+    for (u32 k = 0; k < BKT_ITEMS; ++k) {
+        const u32 e = k * BKT_THREADS + tid;
+        if (slot[k] != NONE && glen[k] && enext[e] == 0xffffu) thead[slot[k]] = atomicAdd(&lcount, glen[k]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (u32 k = 0; k < BKT_ITEMS; ++k)
+        if (slot[k] != NONE && glen[k]) {
+            const u64 start = b * BKT_CAP + thead[slot[k]];
+            a.list[start + grank[k]] = rf[k];
+            if (val[k] < a.n_pos) a.rec[val[k]] = (1ull << 63) | ((u64)glen[k] << 40) | start;
+        }
+}
+
 static_assert(BKT_SLOTS == (1u << BKT_SLOT_BITS), "slots per bucket");
 u64 mul_for(u64 slots, u64 max_hash, unsigned bits) {
     const unsigned __int128 num = (unsigned __int128)slots << bits;
@@ -795,7 +917,7 @@ int yh_psort_finish_emit(yh_db* db, yh_psort* s, u64* d_rec, u64 n_refs, u64 tot
     static const bool no_inline = [] { const char* e = yh_tune_env("YH_FZ_NO_INLINE"); return e && e[0] == '1'; }();
     b.inline_ok = (n_refs < (1u << 21) - 1 && !no_inline) ? 1u : 0u;
     b.totals = s->totals;
-    k_bucket_sort<true><<<8u * b.per_xcd, BKT_THREADS, 0, db->stream>>>(b);
+    k_bucket_group<<<8u * b.per_xcd, BKT_THREADS, 0, db->stream>>>(b);
     YH_HIP(hipGetLastError());
     u32 hflags[4] = {0, 0, 0, 0};
     unsigned long long ht[4] = {0, 0, 0, 0};
