@@ -380,7 +380,7 @@ def main() -> int:
     # roofline-style figure of the kernels alone (B = 8 H + 12 P_out), HBM peak 8 TB/s
     k_ms = float(tm["ms_db_build"]) + k_pair_ms
     alg_upload_s = 8 * int(offsets[-1]) / 56e9  # what the bus needs for the sketches alone (measured: 56 GB/s from pageable memory)
-    out["roofline"] = {"bound": "hbm", "kernels": "k_part<1> per chunk (under the upload), k_part<2>, k_bucket_sort<true> (yh_sort.hip: its last pass writes the pairwise records), k_pair_rows",
+    out["roofline"] = {"bound": "hbm", "kernels": "k_part<1> per chunk (under the upload), k_part<2>, k_bucket_group (yh_sort.hip: the sort's last pass groups by hash in LDS and writes the pairwise records), k_pair_rows",
                        "achieved": round(alg / 1e9 / (k_ms / 1e3), 1) if k_ms > 0 else None, "peak": 8000.0, "unit": "GB/s",
                        "frac": round(alg / 1e9 / (k_ms / 1e3) / 8000.0, 4) if k_ms > 0 else None,
                        "exposed_device_ms": round(1e3 * total - 1e3 * alg_upload_s, 3),

@@ -552,7 +552,7 @@ static bool trace_on() {
 }
 #define TRACE(label) do { if (trace_on()) { const double t__ = trace_now(); fprintf(stderr, "[yh build] %-28s +%.3f ms\n", label, t__ - t_prev); t_prev = t__; } } while (0)
 
-// ---- the fused path of a YH_DB_PAIRWISE_ONLY handle (yh_db::fz; yh_sort.hip: k_bucket_sort<true>) ---------------------
+// ---- the fused path of a YH_DB_PAIRWISE_ONLY handle (yh_db::fz; yh_sort.hip: k_bucket_group) ---------------------
 // `yacht train` wants nothing of the index but the pairwise pass's input.  Where the distribution sort takes the pairs,
 // they carry their CSR POSITION instead of the reference id, and the sort's last pass -- which has every run of equal
 // hashes whole and in order in LDS -- writes the 8-byte record "the other holders of this element's hash" straight to the

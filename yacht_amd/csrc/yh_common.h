@@ -112,7 +112,7 @@ struct yh_db {
     u32* d_pg = nullptr;     // [postings] index of the hash each posting belongs to
     u32* d_prank = nullptr;  // [postings] YH_DB_PAIRWISE_ONLY: the posting's rank among its reference's shared hashes (yh_pairwise.hip)
     u32* d_nshared = nullptr;  // [N] number of shared hashes in reference j
-    // YH_DB_PAIRWISE_ONLY handles whose pairs the distribution sort took (yh_sort.hip, k_bucket_sort<true>): the sort's
+    // YH_DB_PAIRWISE_ONLY handles whose pairs the distribution sort took (yh_sort.hip, k_bucket_group): the sort's
     // last pass writes what the pairwise pass reads, and none of g / po / pr / pg / prank exists -- ONE 8-byte record per
     // CSR position, "the other holders of this element's hash" (0: no other holder), so a reference's records are the
     // extent of its sketch and nothing is counted, ranked or transposed (yh_pairwise.hip: k_pair_rows<.., true>)

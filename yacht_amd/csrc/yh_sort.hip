@@ -24,8 +24,8 @@
 // chunk crosses PCIe, and only levels two and three remain behind the last byte (yh_build_upload_sorted).
 //
 // POSITION MODE (`yacht train`'s handle, yh_db::fz): the value of a pair is its CSR position, not its reference -- the
-// order is the same -- and the last pass (k_bucket_sort<true>) does not write sorted pairs at all: with every run of equal
-// hashes whole and in order in LDS it stores, at the position of every element whose hash another reference holds too,
+// order is the same -- and the last pass (k_bucket_group) does not sort or write pairs at all: it groups the bucket's pairs
+// by hash in an LDS hash table and stores, at the position of every element whose hash another reference holds too,
 // the 8-byte record the pairwise pass reads ("the other holders").  No posting arrays, no rank per posting, no
 // transposition: see yh_build.hip (fz_*) and yh_pairwise.hip (k_pair_rows<.., true>).
 #include "yh_common.h"
@@ -314,8 +314,8 @@ struct BucketArgs {
     u32* flags;    // [0] |= 4: a slot held more than SLOT_MAX pairs
     u32* counts;   // [buckets][3] {distinct hashes, hashes held by >= 2 references, pairs of those}: what k_idx_count counts per
                    // chunk of the sorted pairs -- a run of equal hashes never leaves its bucket, so the bucket sees it whole
-    // EMIT (the values are CSR positions): the bucket does not leave as sorted pairs at all -- every element whose hash
-    // another reference holds too gets its record of the pairwise pass, stored at its own CSR position
+    // position mode (k_bucket_group): the bucket does not leave as sorted pairs at all -- every element whose hash another
+    // reference holds too gets its record of the pairwise pass, stored at its own CSR position
     u64 nb;                      // buckets
     u64 n_pos;                   // CSR positions (H)
     u32 per_xcd;                 // ... of one XCD (see the kernel)
@@ -370,168 +370,112 @@ __device__ __forceinline__ void block_scan_inplace2(u32* arr, u32* wave_tot /* >
     __syncthreads();
 }
 
-// The last pass: every bucket (<= BKT_CAP pairs) sorted in LDS, one workgroup per bucket.  XCD x (blockIdx % 8 on this chip)
-// takes the x-th EIGHTH of the buckets, front to back.  EMIT: that walk is what lets the L2s merge the record stores -- a
-// sketch's elements inside a first-level region of the sort are ~36 consecutive CSR positions, and the region's ~140
-// buckets are then all sorted on the same XCD within a short time of each other (scripts/probes/scatter_probe.hip: 27 M
-// 8-byte records in 0.30 ms this way, 0.39 ms with bucket = blockIdx, 0.69 ms at isolated positions -- and the counting
-// atomic + the store of k_idx_emit / k_pair_transpose before: 0.76 + 0.56 ms).
+// The last pass: every bucket (<= BKT_CAP pairs) sorted in LDS, one workgroup per bucket, and written out coalesced at its
+// exact place, with the run statistics k_idx_emit needs (the index build of every handle but `yacht train`'s own, whose
+// last pass is k_bucket_group below).  ~17 LDS operations per pair: 16-byte clears and scans, a scan in which every wave
+// sums the totals below it itself (two barriers), no store that would put back what is in place already.
 // (Measured and dropped: PERSISTENT workgroups that fetch the next bucket into registers while they sort the current one --
-// 86 registers, one workgroup per CU; held to 64 it spills and takes 1.02 ms for configs[3] against 0.72 ms.)
-#ifndef YH_ABLATE_FZ
-#define YH_ABLATE_FZ 0  // timing-only builds (results wrong): 1 no record stores, 2 no position -> reference look-ups, 4 no ranking inside the slots, 8 no run scan
-#endif
-template <bool EMIT>
+// 86 registers, one workgroup per CU; held to 64 it spills: 1.02 ms for configs[3] against 0.72 ms.)
 __global__ void __launch_bounds__(BKT_THREADS) k_bucket_sort(const BucketArgs a) {
     __shared__ u64 skey[BKT_CAP];
     __shared__ u32 sval[BKT_CAP];
-    __shared__ __attribute__((aligned(16))) u32 start[BKT_SLOTS];  // counts, then offsets; EMIT: then the reference of every pair, in sorted order
+    __shared__ __attribute__((aligned(16))) u32 start[BKT_SLOTS];  // counts, then offsets
     __shared__ u32 wtot[16];
     __shared__ u32 tot3[3];
-    static_assert(BKT_SLOTS >= BKT_CAP, "start[] doubles as the references of a bucket");
     static_assert(BKT_THREADS <= 1024, "block_scan_inplace2 sums at most 16 wave totals");
     const u32 tid = threadIdx.x;
-    const u64 b = (u64)(blockIdx.x & 7u) * a.per_xcd + (blockIdx.x >> 3);
-    if ((blockIdx.x >> 3) >= a.per_xcd || b >= a.nb) return;
-    if (a.cnt[b] > BKT_CAP && tid == 0) atomicOr(a.flags, 2u);
+    const u64 b = blockIdx.x;
+    if (b >= a.nb) return;
     const u32 n = min(a.cnt[b], BKT_CAP);
-    {
-        u64 key[BKT_ITEMS];
-        u32 val[BKT_ITEMS], slot[BKT_ITEMS], rank[BKT_ITEMS];
-        u32 rf[BKT_ITEMS];  // EMIT: the reference that owns the pair's position -- looked up now (two reads the L2s serve), needed
-                            // when the bucket is in order: the look-ups of all pairs are in flight under the sort
-        if (n == 0) return;  // (workgroup-uniform; its three counts stay zero: the array is cleared before the launch)
+    if (n == 0) return;  // (workgroup-uniform; its three counts stay zero: the array is cleared before the launch)
+    u64 key[BKT_ITEMS];
+    u32 val[BKT_ITEMS], slot[BKT_ITEMS], rank[BKT_ITEMS];
 #pragma unroll
-        for (u32 k = 0; k < BKT_ITEMS; ++k) {
-            const u32 i = k * BKT_THREADS + tid;
-            if (i < n) { key[k] = a.in_k[b * a.cap_in + i]; val[k] = a.in_v[b * a.cap_in + i]; }
+    for (u32 k = 0; k < BKT_ITEMS; ++k) {
+        const u32 i = k * BKT_THREADS + tid;
+        if (i < n) { key[k] = a.in_k[b * a.cap_in + i]; val[k] = a.in_v[b * a.cap_in + i]; }
+    }
+    if (tid < 3) tot3[tid] = 0;
+    static_assert(BKT_SLOTS % (4 * BKT_THREADS) == 0 || BKT_SLOTS / BKT_THREADS < 4, "16-byte clears");
+    if (BKT_SLOTS / BKT_THREADS >= 4) {
+        for (u32 i = tid; i < BKT_SLOTS / 4; i += BKT_THREADS) reinterpret_cast<uint4*>(start)[i] = make_uint4(0u, 0u, 0u, 0u);
+    } else {
+        for (u32 i = tid; i < BKT_SLOTS; i += BKT_THREADS) start[i] = 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (u32 k = 0; k < BKT_ITEMS; ++k) {
+        const u32 i = k * BKT_THREADS + tid;
+        slot[k] = 0xffffffffu;
+        if (i < n) {
+            slot[k] = fine_of(key[k], a.lsh, a.mul_fine) & (BKT_SLOTS - 1u);
+            rank[k] = atomicAdd(&start[slot[k]], 1u);
         }
-        if (tid < 3) tot3[tid] = 0;
-        // (the LDS pipe of a CU is what this kernel keeps busy -- ~20 operations per pair: wide clears and scans, no store
-        // that would put back what is there already, and every pair emitted by the lane that holds it in registers)
-        static_assert(BKT_SLOTS % (4 * BKT_THREADS) == 0 || BKT_SLOTS / BKT_THREADS < 4, "16-byte clears");
-        if (BKT_SLOTS / BKT_THREADS >= 4) {
-            for (u32 i = tid; i < BKT_SLOTS / 4; i += BKT_THREADS) reinterpret_cast<uint4*>(start)[i] = make_uint4(0u, 0u, 0u, 0u);
-        } else {
-            for (u32 i = tid; i < BKT_SLOTS; i += BKT_THREADS) start[i] = 0;
+    }
+    __syncthreads();
+    block_scan_inplace2<BKT_SLOTS / BKT_THREADS>(start, wtot);
+#pragma unroll
+    for (u32 k = 0; k < BKT_ITEMS; ++k)
+        if (slot[k] != 0xffffffffu) {
+            const u32 at = start[slot[k]] + rank[k];
+            skey[at] = key[k];
+            sval[at] = val[k];
         }
-        __syncthreads();
+    __syncthreads();
+    // every pair ranks itself among the pairs of its slot; a crowded slot = many pairs with (nearly) the same hash, which
+    // this quadratic step is not made for
+    bool crowded = false;
+    u32 pos[BKT_ITEMS];
+    bool moved[BKT_ITEMS];
 #pragma unroll
-        for (u32 k = 0; k < BKT_ITEMS; ++k) {
-            const u32 i = k * BKT_THREADS + tid;
-            slot[k] = 0xffffffffu;
-            if (i < n) {
-                if (EMIT) rf[k] = (YH_ABLATE_FZ & 2) ? val[k] >> 12 : ref_of(val[k], a.ref_tab, a.ref_off);
-                slot[k] = fine_of(key[k], a.lsh, a.mul_fine) & (BKT_SLOTS - 1u);
-                rank[k] = atomicAdd(&start[slot[k]], 1u);
-            }
-        }
-        __syncthreads();
-        block_scan_inplace2<BKT_SLOTS / BKT_THREADS>(start, wtot);
-#pragma unroll
-        for (u32 k = 0; k < BKT_ITEMS; ++k)
-            if (slot[k] != 0xffffffffu) {
-                const u32 at = start[slot[k]] + rank[k];
-                skey[at] = key[k];
-                sval[at] = val[k];
-            }
-        __syncthreads();
-        // every pair ranks itself among the pairs of its slot; a crowded slot = many pairs with (nearly) the same hash, which
-        // this quadratic step is not made for
-        bool crowded = false;
-        u32 pos[BKT_ITEMS];
-        bool moved[BKT_ITEMS];
-#pragma unroll
-        for (u32 k = 0; k < BKT_ITEMS; ++k) {
-            moved[k] = false;
-            if (slot[k] != 0xffffffffu) {
-                const u32 s0 = start[slot[k]];
-                const u32 c = (slot[k] + 1u < BKT_SLOTS ? start[slot[k] + 1u] : n) - s0;  // pairs of the slot
-                u32 less = 0;
-                if (c > SLOT_MAX) {
-                    crowded = true;
-                } else if (!(YH_ABLATE_FZ & 4)) {
-                    for (u32 q = s0; q < s0 + c; ++q) {
-                        const u64 kq = skey[q];
-                        less += (kq < key[k] || (kq == key[k] && sval[q] < val[k])) ? 1u : 0u;
-                    }
+    for (u32 k = 0; k < BKT_ITEMS; ++k) {
+        moved[k] = false;
+        if (slot[k] != 0xffffffffu) {
+            const u32 s0 = start[slot[k]];
+            const u32 c = (slot[k] + 1u < BKT_SLOTS ? start[slot[k] + 1u] : n) - s0;  // pairs of the slot
+            u32 less = 0;
+            if (c > SLOT_MAX) {
+                crowded = true;
+            } else {
+                for (u32 q = s0; q < s0 + c; ++q) {
+                    const u64 kq = skey[q];
+                    less += (kq < key[k] || (kq == key[k] && sval[q] < val[k])) ? 1u : 0u;
                 }
-                pos[k] = s0 + less;
-                moved[k] = less != rank[k];  // (the one pair of a slot -- most of them -- is where it belongs already)
             }
+            pos[k] = s0 + less;
+            moved[k] = less != rank[k];  // (the one pair of a slot -- most of them -- is where it belongs already)
         }
-        if (crowded) atomicOr(a.flags, 4u);
-        __syncthreads();
+    }
+    if (crowded) atomicOr(a.flags, 4u);
+    __syncthreads();
 #pragma unroll
-        for (u32 k = 0; k < BKT_ITEMS; ++k)
-            if (slot[k] != 0xffffffffu) {
-                if (moved[k]) {
-                    skey[pos[k]] = key[k];
-                    if (!EMIT) sval[pos[k]] = val[k];  // (EMIT: the lane that holds a pair emits it -- nobody reads sval[] again)
-                }
-                if (EMIT) start[pos[k]] = rf[k];  // (start[] is free: its last reads were in front of the barrier above)
-            }
-        __syncthreads();
-        u32 c0 = 0, c1 = 0, c2 = 0;
-        if (EMIT) {
-#pragma unroll
-            for (u32 k = 0; k < BKT_ITEMS; ++k) {  // (every lane takes every turn: the ballots)
-                const u32 i = pos[k];
-                bool head = false, shared = false;
-                if (slot[k] != 0xffffffffu) {
-                    const u64 h = key[k];
-                    u32 s = i, e = i + 1;  // the run of this hash: [s, e)
-                    if (!(YH_ABLATE_FZ & 8)) {
-                        while (s > 0 && skey[s - 1] == h) --s;
-                        while (e < n && skey[e] == h) ++e;
-                    } else if ((h & 1) && i + 1 < n) e = i + 2;
-                    const u32 len = e - s;
-                    head = s == i;
-                    shared = len >= 2;
-                    if (shared) {  // (else its record stays 0: the array is cleared before the launch)
-                        u64 r;
-                        if (len <= 4 && a.inline_ok) {
-                            r = 0;
-                            u32 sh = 0;
-                            for (u32 q = s; q < e; ++q)
-                                if (q != i) { r |= (u64)(start[q] + 1u) << sh; sh += 21; }
-                        } else {
-                            a.list[b * BKT_CAP + i] = rf[k];
-                            r = (1ull << 63) | ((u64)len << 40) | (b * BKT_CAP + s);
-                        }
-                        if ((YH_ABLATE_FZ & 1) ? r == 0x1234567ull : val[k] < a.n_pos) a.rec[val[k]] = r;
-                    }
-                }
-                c0 += (u32)__popcll(__ballot(head));
-                c1 += (u32)__popcll(__ballot(head && shared));
-                c2 += (u32)__popcll(__ballot(shared));
-            }
-        } else {
-            const u64 out_base = a.off[b];
-            for (u32 i0 = 0; i0 < n; i0 += BKT_THREADS) {  // (workgroup-uniform bound: the ballots)
-                const u32 i = i0 + tid;
-                bool head = false, shared = false;
-                if (i < n) {
-                    const u64 h = skey[i];
-                    a.out_k[out_base + i] = h;
-                    a.out_v[out_base + i] = sval[i];
-                    const bool eq_prev = i > 0 && skey[i - 1] == h, eq_next = i + 1 < n && skey[i + 1] == h;
-                    head = !eq_prev;
-                    shared = eq_prev || eq_next;
-                }
-                c0 += (u32)__popcll(__ballot(head));
-                c1 += (u32)__popcll(__ballot(head && shared));
-                c2 += (u32)__popcll(__ballot(shared));
-            }
+    for (u32 k = 0; k < BKT_ITEMS; ++k)
+        if (slot[k] != 0xffffffffu && moved[k]) {
+            skey[pos[k]] = key[k];
+            sval[pos[k]] = val[k];
         }
+    __syncthreads();
+    u32 c0 = 0, c1 = 0, c2 = 0;
+    const u64 out_base = a.off[b];
+    for (u32 i0 = 0; i0 < n; i0 += BKT_THREADS) {  // (workgroup-uniform bound: the ballots)
+        const u32 i = i0 + tid;
+        bool head = false, shared = false;
+        if (i < n) {
+            const u64 h = skey[i];
+            a.out_k[out_base + i] = h;
+            a.out_v[out_base + i] = sval[i];
+            const bool eq_prev = i > 0 && skey[i - 1] == h, eq_next = i + 1 < n && skey[i + 1] == h;
+            head = !eq_prev;
+            shared = eq_prev || eq_next;
+        }
+        c0 += (u32)__popcll(__ballot(head));
+        c1 += (u32)__popcll(__ballot(head && shared));
+        c2 += (u32)__popcll(__ballot(shared));
+    }
+    if (a.counts) {
         if ((tid & 63u) == 0) { atomicAdd(&tot3[0], c0); atomicAdd(&tot3[1], c1); atomicAdd(&tot3[2], c2); }
-        __syncthreads();  // (also: every read of this bucket's LDS is behind us)
-        if (EMIT) {
-            if (tid < 3 && tot3[tid]) atomicAdd(&a.totals[tid], (unsigned long long)tot3[tid]);
-            if (tid == 3) atomicAdd(&a.totals[3], (unsigned long long)n);
-        } else if (a.counts && tid < 3) {
-            a.counts[b * 3 + tid] = tot3[tid];
-        }
+        __syncthreads();
+        if (tid < 3) a.counts[b * 3 + tid] = tot3[tid];
     }
 }
 
@@ -867,8 +811,7 @@ int yh_psort_finish(yh_db* db, yh_psort* s, u64* d_keys_out, u32* d_vals_out, bo
     b.flags = flags;
     b.counts = s->counts;
     b.nb = s->NB;
-    b.per_xcd = (u32)((s->NB + 7) / 8);
-    k_bucket_sort<false><<<8u * b.per_xcd, BKT_THREADS, 0, db->stream>>>(b);
+    k_bucket_sort<<<(u32)s->NB, BKT_THREADS, 0, db->stream>>>(b);
     YH_HIP(hipGetLastError());
     u32 hflags[4] = {0, 0, 0, 0};
     u64 total = 0;
@@ -881,7 +824,7 @@ int yh_psort_finish(yh_db* db, yh_psort* s, u64* d_keys_out, u32* d_vals_out, bo
     return YH_OK;
 }
 
-// Position mode: second level + the FUSED last pass (k_bucket_sort<true>): every bucket is sorted in LDS and leaves as the
+// Position mode: second level + the FUSED last pass (k_bucket_group): every bucket is grouped by hash in LDS and leaves as the
 // records of the pairwise pass (yh_db::d_fz_rec, H entries, cleared by the first level) instead of as sorted pairs.  totals[3] = {distinct
 // hashes, hashes with >= 2 holders, their pairs}.  *d_list_out: the holders of the hashes with more than four of them
 // (yh_db::d_fz_list) -- the sort's own bucket array, which is the caller's from here on (free it with yh_tfree).
