@@ -194,3 +194,34 @@ def test_tiny_sketches_and_shared_counts_on_the_train_handle(hip_lib):
         db.nshared_device(ns_d.data_ptr())
         db.synchronize()
         assert torch.equal(ns_t, ns_d) and int(ns_d.sum()) > 0
+
+
+def test_neighbouring_hashes_crowd_one_slot_of_the_grouping_table(hip_lib):
+    """1 200 CONSECUTIVE hash values, each held by two of 2 000 sketches: all of them start at the same slot of their bucket's
+    hash table in the fused train path (k_bucket_group probes linearly from a linear function of the key) -- long probe
+    sequences, same answers.  Next to them one hash held by 1 100 sketches: more holders than the counting sort of the other
+    handles ranks (it refuses them and rocPRIM sorts), no limit for the grouping."""
+    from oracle import oracle
+    from yacht_amd import synth
+    from yacht_amd.engine import RefDB, YH_DB_PAIRWISE_ONLY
+
+    rng = np.random.default_rng(123)
+    mh = synth.max_hash_for_scaled(1000)
+    refs = [synth.random_sketch(rng, 400, mh) for _ in range(2000)]
+    h0 = int(rng.integers(mh // 4, mh // 2))
+    extra = [[] for _ in range(2000)]
+    for d in range(1200):
+        for r in rng.choice(2000, size=2, replace=False):
+            extra[int(r)].append(h0 + d)
+    heavy = int(rng.integers(mh // 2, mh - 1))
+    for r in rng.choice(2000, size=1100, replace=False):
+        extra[int(r)].append(heavy)
+    refs = [np.unique(np.concatenate([a, np.array(e, np.uint64)])) for a, e in zip(refs, extra)]
+    values, offsets = synth.pack(refs)
+    wi, wj, wc, wstats = oracle.train_pairs(values, offsets, 0.001, threads=4)
+    assert wi.size > 1100 * 1099
+    for flags in (YH_DB_PAIRWISE_ONLY, 0):
+        with RefDB(values, offsets, flags=flags) as db:
+            gi, gj, gc = db.pairwise(0.001)
+            assert np.array_equal(gi, wi) and np.array_equal(gj, wj) and np.array_equal(gc, wc), flags
+            assert db.index_stats() == wstats
