@@ -585,7 +585,7 @@ static int fz_begin(yh_db* db, const u64* d_offsets, u64 max_hash, yh_psort** ps
     }
     if (rc == YH_OK) rc = yh_ref_table_build(db, db->d_fz_off, N, H, db->d_fz_tab);
     if (rc == YH_OK) rc = yh_psort_begin(db, H, max_hash, ps);
-    if (rc == YH_OK) yh_psort_positions(*ps, db->d_fz_tab, db->d_fz_off, db->d_fz_rec);
+    if (rc == YH_OK) yh_psort_positions(*ps, db->d_fz_tab, db->d_fz_off, db->n_refs, db->d_fz_rec);
     if (rc != YH_OK) { yh_psort_destroy(db, *ps); *ps = nullptr; fz_drop(db); }
     return rc;
 }

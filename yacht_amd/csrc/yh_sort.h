@@ -29,6 +29,6 @@ constexpr unsigned YH_REF_TAB_SH = 8;  // one look-up entry per 256 CSR position
 int yh_ref_table_build(yh_db* db, const u64* d_offsets, u64 n_refs, u64 H, u32* d_tab);
 // the pairs carry CSR positions instead of reference ids (equal hashes still end up in ascending reference order)
 // (d_rec: the H records of yh_psort_finish_emit -- the first level clears each pair's on its way through)
-void yh_psort_positions(yh_psort* s, const u32* d_ref_tab, const u64* d_offsets, u64* d_rec);
+void yh_psort_positions(yh_psort* s, const u32* d_ref_tab, const u64* d_offsets, u64 n_refs, u64* d_rec);
 // second level + every bucket sorted in LDS and turned into the pairwise pass's records on the spot (see yh_sort.hip)
 int yh_psort_finish_emit(yh_db* db, yh_psort* s, u64* d_rec, u64 n_refs, u64 totals[3], u32** d_list_out, bool* took_it, bool* unsorted = nullptr);

@@ -119,6 +119,13 @@ __device__ __forceinline__ u32 ref_of(u64 p, const u32* __restrict__ tab, const 
     }
     return lo;
 }
+// bit p of `bits` (cleared before): CSR position p is the first of a (non-empty) sketch
+__global__ void k_first_bits(const u64* __restrict__ off, u64 n_refs, unsigned long long* __restrict__ bits) {
+    const u64 r = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (r >= n_refs) return;
+    const u64 b = off[r];
+    if (off[r + 1] > b) atomicOr(&bits[b >> 6], 1ull << (b & 63u));
+}
 __global__ void k_ref_table(const u64* __restrict__ off, u64 n_refs, u64 n_tab, u32* __restrict__ tab) {
     const u64 j = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     if (j >= n_tab) return;
@@ -135,8 +142,7 @@ struct PartArgs {
     const u64* in_k;
     const u32* in_v;      // values; NULL (level 1): the value of a pair is its CSR POSITION, val_base + its index
     u64 val_base;
-    const u32* ref_tab;   // position mode: the look-up of ref_of() (the ordering check)
-    const u64* ref_off;
+    const u64* first_bits;  // position mode + ordering check: bit p set = position p is the first of its sketch (k_first_bits)
     u64* rec_clear;       // position mode: yh_db::d_fz_rec -- every pair clears the record of its position on the way through
                           // (400 MB of streaming stores under a pass that waits for LDS and atomics, instead of a memset of their own)
     u64 n_in;             // pairs of this call's input (level 1; level 2 without in_cnt: ONE input segment of n_in pairs)
@@ -186,36 +192,59 @@ __global__ void __launch_bounds__(PART_THREADS) k_part(const PartArgs a) {
     };
     u64 key[PART_ITEMS];
     u32 val[PART_ITEMS], bin[PART_ITEMS], rank[PART_ITEMS];
+    const bool first_pass = LEVEL == 1 || !a.in_cnt;  // (the input is the CSR itself)
+    const bool positions = first_pass && !a.in_v;
+    const bool check = a.check_order && first_pass;
+    // Every load of the tile first, none of them depending on another.  What the ordering check needs beyond the pair is the
+    // same for a whole wave -- the pair in front of its first lane (the other lanes get their neighbour's by a shuffle) and,
+    // positions, the one or two words of the sketches' first positions its 64 pairs fall into -- and is read with SCALAR
+    // loads: a vector load costs the address unit its 16 cycles per wave whether or not the lanes agree (two more per pair
+    // were 0.05 ms of this pass).
+    const u32 wave0 = (u32)__builtin_amdgcn_readfirstlane((int)tid) & ~63u;  // (uniform: the wave's first lane)
+    u64 pkey[PART_ITEMS], fb0[PART_ITEMS], fb1[PART_ITEMS];
+    u32 pval[PART_ITEMS];
+#pragma unroll
+    for (u32 k = 0; k < PART_ITEMS; ++k) {
+        const u32 i = k * PART_THREADS + tid;
+        const u32 iw = k * PART_THREADS + wave0;  // (uniform)
+        pkey[k] = 0; fb0[k] = 0; fb1[k] = 0; pval[k] = 0;
+        if (i < tile_n) {
+            key[k] = a.in_k[in_base + t0 + i];
+            val[k] = positions ? (u32)(a.val_base + t0 + i) : a.in_v[in_base + t0 + i];
+        }
+        if (check && iw < tile_n) {
+            if (t0 + iw > 0) {
+                pkey[k] = a.in_k[in_base + t0 + iw - 1];
+                if (!positions) pval[k] = a.in_v[in_base + t0 + iw - 1];
+            }
+            if (positions) {
+                const u64 p0 = a.val_base + t0 + iw;
+                fb0[k] = a.first_bits[p0 >> 6];
+                fb1[k] = a.first_bits[(p0 >> 6) + 1];  // (the map has a word to spare)
+            }
+        }
+    }
+    if (check) {
+#pragma unroll
+        for (u32 k = 0; k < PART_ITEMS; ++k) {  // (every lane takes part: inactive ones hand on garbage nobody uses)
+            const u64 up = ((u64)(u32)__shfl_up((int)(u32)(key[k] >> 32), 1) << 32) | (u32)__shfl_up((int)(u32)key[k], 1);
+            const u32 upv = (u32)__shfl_up((int)val[k], 1);
+            if ((tid & 63u) != 0) { pkey[k] = up; pval[k] = upv; }
+        }
+    }
 #pragma unroll
     for (u32 k = 0; k < PART_ITEMS; ++k) {
         const u32 i = k * PART_THREADS + tid;
         bin[k] = 0xffffffffu;
         if (i < tile_n) {
-            key[k] = a.in_k[in_base + t0 + i];
-            const bool positions = (LEVEL == 1 || !a.in_cnt) && !a.in_v;
-            val[k] = positions ? (u32)(a.val_base + t0 + i) : a.in_v[in_base + t0 + i];
             if (positions && a.rec_clear) a.rec_clear[val[k]] = 0;
-            if (a.check_order && (LEVEL == 1 || !a.in_cnt)) {
-                // the element in front (lane - 1 has it; the wave's first lane reads it): same reference => strictly smaller hash
-                u64 pk = ((u64)(u32)__shfl_up((int)(u32)(key[k] >> 32), 1) << 32) | (u32)__shfl_up((int)(u32)key[k], 1);
-                u32 pv = (u32)__shfl_up((int)val[k], 1);
-                const u64 gi = t0 + i;
-                if ((tid & 63u) == 0 && gi > 0) { pk = a.in_k[in_base + gi - 1]; if (!positions) pv = a.in_v[in_base + gi - 1]; }
-                bool same = pv == val[k];
-                if (positions) {
-                    // the element in front is of the same reference unless this one is the first of its sketch.  The wave's
-                    // pairs are consecutive positions: where its first and its last active lane are of one reference (all but
-                    // the waves a sketch boundary crosses) that is everybody's, and two lanes have looked it up, not 64
-                    const u64 act = __ballot(true);
-                    const int l0 = __ffsll((long long)act) - 1, l1 = 63 - __clzll((long long)act);
-                    const u32 lane = tid & 63u;
-                    u32 r = (lane == (u32)l0 || lane == (u32)l1) ? ref_of(val[k], a.ref_tab, a.ref_off) : 0u;
-                    const u32 r0 = (u32)__shfl((int)r, l0), r1 = (u32)__shfl((int)r, l1);
-                    if (r0 != r1) r = ref_of(val[k], a.ref_tab, a.ref_off);
-                    else r = r0;
-                    same = (u64)val[k] > a.ref_off[r];
-                }
-                if (gi > 0 && same && !(pk < key[k])) atomicOr(a.flags, 8u);
+            if (check && t0 + i > 0) {
+                // same reference as the element in front => strictly larger hash (positions: the same reference unless this
+                // element is the first of its sketch)
+                const u64 p0 = a.val_base + t0 + k * PART_THREADS + wave0;  // the position of the wave's first lane
+                const u64 word = ((u64)val[k] >> 6) == (p0 >> 6) ? fb0[k] : fb1[k];
+                const bool same = positions ? ((word >> (val[k] & 63u)) & 1ull) == 0ull : pval[k] == val[k];
+                if (same && !(pkey[k] < key[k])) atomicOr(a.flags, 8u);
             }
             bin[k] = bin_of(key[k]);
             rank[k] = atomicAdd(&hist[bin[k]], 1u);
@@ -627,6 +656,8 @@ struct yh_psort {
     bool check_order = false;
     const u32* ref_tab = nullptr;  // position mode (yh_psort_positions): the values are CSR positions
     const u64* ref_off = nullptr;
+    u64 n_refs = 0;
+    unsigned long long* first_bits = nullptr;  // position mode + ordering check: the sketches' first positions as a bit map
     u64* rec_clear = nullptr;      // position mode: the records the first level clears on its way through
     unsigned long long* totals = nullptr;  // [4] position mode: what the fused last pass counted
 };
@@ -643,9 +674,10 @@ bool yh_psort_applicable(u64 H, u64 max_hash) {
 }
 
 void yh_psort_check_order(yh_psort* s, bool on) { s->check_order = on; }
-void yh_psort_positions(yh_psort* s, const u32* d_ref_tab, const u64* d_offsets, u64* d_rec) {
+void yh_psort_positions(yh_psort* s, const u32* d_ref_tab, const u64* d_offsets, u64 n_refs, u64* d_rec) {
     s->ref_tab = d_ref_tab;
     s->ref_off = d_offsets;
+    s->n_refs = n_refs;
     s->rec_clear = d_rec;
 }
 int yh_ref_table_build(yh_db* db, const u64* d_offsets, u64 n_refs, u64 H, u32* d_tab) {
@@ -663,7 +695,7 @@ void yh_psort_chunks(const yh_psort* s, u64* n_chunks, const u64** d_chunk_off, 
 void yh_psort_destroy(yh_db* db, yh_psort* s) {
     if (!s) return;
     yh_tfree(db, s->k1); yh_tfree(db, s->v1); yh_tfree(db, s->k2); yh_tfree(db, s->v2);
-    yh_tfree(db, s->cnt); yh_tfree(db, s->off); yh_tfree(db, s->counts); yh_tfree(db, s->totals);
+    yh_tfree(db, s->cnt); yh_tfree(db, s->off); yh_tfree(db, s->counts); yh_tfree(db, s->totals); yh_tfree(db, s->first_bits);
     delete s;
 }
 
@@ -718,8 +750,15 @@ int yh_psort_add(yh_db* db, yh_psort* s, const u64* d_keys, const u32* d_vals, u
     a.in_k = d_keys;
     a.in_v = d_vals;
     a.val_base = pos_base;
-    a.ref_tab = s->ref_tab;
-    a.ref_off = s->ref_off;
+    if (!d_vals && s->check_order && !s->first_bits) {  // the map of the sketches' first positions, once
+        const size_t words = (size_t)(s->H >> 6) + 2;
+        hipError_t e = yh_tmalloc(db, (void**)&s->first_bits, words * sizeof(unsigned long long));
+        if (e != hipSuccess) { yh_set_error("distribution sort: allocation failed: %s", hipGetErrorString(e)); return YH_ERR_OOM; }
+        YH_HIP(hipMemsetAsync(s->first_bits, 0, words * sizeof(unsigned long long), db->stream));
+        k_first_bits<<<(u32)((s->n_refs + 255) / 256), 256, 0, db->stream>>>(s->ref_off, s->n_refs, s->first_bits);
+        YH_HIP(hipGetLastError());
+    }
+    a.first_bits = d_vals ? nullptr : s->first_bits;
     a.rec_clear = d_vals ? nullptr : s->rec_clear;
     a.n_in = n;
     a.mul = s->mul;
