@@ -480,3 +480,16 @@ def test_sample_archive_through_the_native_scanner_equals_the_python_reader(tmp_
     assert got.minhash.mins.tolist() == [2, 6, 10, 14] and type(got.minhash).__name__ == "MinHash"
     first = utils.load_signature_with_ksize(str(z), 21)     # the first signature IS the wanted one: native
     assert first.minhash.mins.tolist() == [1, 5, 9] and type(first.minhash).__name__ == "_NativeMinHash" and first.minhash.mean_abundance is None
+
+
+def test_path_lists_are_what_the_reference_writes(tmp_path):
+    """hypothesis_recovery_src._write_path_list (and the list of run_yacht_train_core): byte for byte what the reference's
+    `pd.DataFrame(paths).to_csv(path, header=False, index=False)` writes, including the paths a CSV reader needs quoted."""
+    import pandas as pd
+
+    from yacht_amd.hypothesis_recovery_src import _write_path_list
+
+    paths = ["/a/b.sig", "/with,comma/x.sig", '/with"quote/y.sig', "/plain/z", "/sp ace/w.sig", "/uni\u00e9/q.sig"]
+    _write_path_list(str(tmp_path / "mine.txt"), paths)
+    pd.DataFrame(paths).to_csv(tmp_path / "theirs.txt", header=False, index=False)
+    assert (tmp_path / "mine.txt").read_bytes() == (tmp_path / "theirs.txt").read_bytes()
