@@ -60,9 +60,11 @@ enum {
 #define YH_DB_DEFAULT      0u
 #define YH_DB_NO_INDEX     1u  /* skip the shared-hash inverted index (overlap-only handle)     */
 #define YH_DB_KEEP_CSR     2u  /* keep the plain CSR resident too (needed by yh_overlap_bsearch) */
-#define YH_DB_PAIRWISE_ONLY 8u /* `yacht train` handle: validated sizes + the inverted index only
-                                  (yh_pairwise, yh_index_stats); no lookup structures, so the
-                                  overlap / exclusive / run queries return YH_ERR_UNSUPPORTED        */
+#define YH_DB_PAIRWISE_ONLY 8u /* `yacht train` handle: validated sizes + what yh_pairwise reads, nothing else
+                                  (yh_pairwise, yh_index_stats, yh_db_nshared_device); no lookup structures, so
+                                  the overlap / exclusive / run queries return YH_ERR_UNSUPPORTED.  For uniform
+                                  hashes (FracMinHash) that is one 8-byte record per CSR position, written by the
+                                  last pass of the sort itself; else the inverted index                          */
 #define YH_DB_NO_DIRECTORY 16u /* do not build the bucket table over the distinct hashes (25.6 B per
                                   distinct hash): the sample-driven (indexed) lookups -- yh_*_indexed_device,
                                   yh_run_batch, and the automatic choice inside yh_run / yh_overlap for
