@@ -27,6 +27,8 @@ _NS_PKG = "http://schemas.openxmlformats.org/package/2006/relationships"
 _BAD_SHEET_CHARS = re.compile(r"[\[\]:*?/\\]")
 # characters XML 1.0 cannot carry (control characters but tab / LF / CR)
 _BAD_XML = re.compile("[\x00-\x08\x0b\x0c\x0e-\x1f]")
+# anything that keeps a string from going into a cell as it is: markup characters, control characters, other white space at an end
+_NOT_PLAIN = re.compile("[&<>\x00-\x1f]|^\\s|\\s$")
 
 
 def _col(i: int) -> str:
@@ -69,13 +71,44 @@ def _cell(ref: str, v) -> str:
     return f'<c r="{ref}" t="inlineStr"><is><t{keep}>{escape(s)}</t></is></c>'
 
 
+def _column_cells(letters: str, values: list, dtype) -> List[str]:
+    """The cells of one column, row 2 on (one string per row; "" = no cell).  Columns of one numpy dtype -- what a result
+    table is made of -- are formatted without a type test per cell (a 20 000-row sheet: 0.3 s of `_cell` calls before)."""
+    n = len(values)
+    kind = getattr(dtype, "kind", "O")
+    if kind == "b":
+        return [f'<c r="{letters}{r}" t="b"><v>{1 if v else 0}</v></c>' for r, v in zip(range(2, n + 2), values)]
+    if kind in "iu":
+        return [f'<c r="{letters}{r}"><v>{v}</v></c>' for r, v in zip(range(2, n + 2), values)]
+    if kind == "f":
+        out = []
+        for r, v in zip(range(2, n + 2), values):
+            if v != v:  # NaN: pandas writes an empty cell too
+                out.append("")
+            elif v in (math.inf, -math.inf):
+                out.append(f'<c r="{letters}{r}" t="inlineStr"><is><t>{"inf" if v > 0 else "-inf"}</t></is></c>')
+            else:
+                out.append(f'<c r="{letters}{r}"><v>{v!r}</v></c>')
+        return out
+    out = []
+    for r, v in zip(range(2, n + 2), values):
+        if type(v) is str and not _NOT_PLAIN.search(v) and v[:1] != " " and v[-1:] != " ":
+            out.append(f'<c r="{letters}{r}" t="inlineStr"><is><t>{v}</t></is></c>')  # (nothing to escape, strip or drop)
+        else:
+            out.append(_cell(f"{letters}{r}", v))
+    return out
+
+
 def _sheet_xml(df: pd.DataFrame) -> str:
     out: List[str] = ['<?xml version="1.0" encoding="UTF-8" standalone="yes"?>\n',
                       f'<worksheet xmlns="{_NS}"><sheetData>']
     out.append('<row r="1">' + "".join(_cell(f"{_col(c)}1", str(name)) for c, name in enumerate(df.columns)) + "</row>")
-    cols = [df[c].tolist() for c in df.columns]  # (python scalars / numpy scalars, column by column)
-    for r in range(len(df)):
-        out.append(f'<row r="{r + 2}">' + "".join(_cell(f"{_col(c)}{r + 2}", col[r]) for c, col in enumerate(cols)) + "</row>")
+    # (python scalars, column by column: .tolist() turns numpy scalars into int / float / bool)
+    cols = [_column_cells(_col(c), df.iloc[:, c].tolist(), df.dtypes.iloc[c]) for c in range(df.shape[1])]
+    for r, cells in enumerate(zip(*cols) if cols else ()):
+        out.append(f'<row r="{r + 2}">' + "".join(cells) + "</row>")
+    if not cols:
+        out.extend(f'<row r="{r + 2}"></row>' for r in range(len(df)))
     out.append("</sheetData></worksheet>")
     return "".join(out)
 
@@ -114,7 +147,8 @@ def write_xlsx(path: str, tables: Sequence[Tuple[str, pd.DataFrame]]) -> List[st
               '<cellStyleXfs count="1"><xf numFmtId="0" fontId="0" fillId="0" borderId="0"/></cellStyleXfs>'
               '<cellXfs count="1"><xf numFmtId="0" fontId="0" fillId="0" borderId="0" xfId="0"/></cellXfs>'
               '<cellStyles count="1"><cellStyle name="Normal" xfId="0" builtinId="0"/></cellStyles></styleSheet>')
-    with zipfile.ZipFile(path, "w", compression=zipfile.ZIP_DEFLATED) as z:
+    # (deflate level 1: the sheets are 10 MB of XML per 20 000 rows and level 6 was two thirds of the call; the file is ~15 % larger)
+    with zipfile.ZipFile(path, "w", compression=zipfile.ZIP_DEFLATED, compresslevel=1) as z:
         z.writestr("[Content_Types].xml", content_types)
         z.writestr("_rels/.rels", root_rels)
         z.writestr("xl/workbook.xml", workbook)
