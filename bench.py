@@ -94,6 +94,11 @@ def parse_args():
     ap.add_argument("--dense-reduce", action="store_true",
                     help="N>1, --block-mode batched: sum the dense [3, B, N] shares of a block (round 3's result path: 65 MB per rank "
                          "and block at rs214 scale) instead of its compact rows")
+    ap.add_argument("--dense-words", action="store_true",
+                    help="N>1, --block-mode batched: all-gather the dense subset-word rows of a block (8 N bytes per rank: round 4's "
+                         "exchange) instead of the ranks' non-zero (word, reference) entries")
+    ap.add_argument("--no-same-form", action="store_true",
+                    help="N>1: skip rank 0's single-GPU pass of the same form on the same samples (value_1gpu_same_form, scaling_efficiency)")
     ap.add_argument("--min-timed-steps", type=int, default=2000,
                     help="the timed loop runs max(--steps, this) steps, and more until it lasts --min-timed-ms (SURVEY.md 8d: >= 1000 "
                          "iterations on launch-bound configurations; 20 steps are 0.75 ms of timed region)")
@@ -387,56 +392,24 @@ def main() -> int:
     # the dense [3, BB, N] shares: 65 MB per rank and block); block j - 3's row count is read back before its slot is reused.
     NB3 = 3
     rowsx = None
+    runner = None
     if hash_batched:
-        bcounts = [torch.zeros((3, BB, n_total), device=dev, dtype=torch.int32) for _ in range(NB3)]
-        bwords = [torch.zeros(n_total, device=dev, dtype=torch.int64) for _ in range(NB3)]
-        bgath = [torch.zeros((world, n_total), device=dev, dtype=torch.int64) for _ in range(NB3)]
         packed_blocks = {}
-        bpending = [None] * NB3   # --dense-reduce: the reduce that reads the buffer
-        inflight = [None] * NB3   # (j, n_in): result on its way
-        state["prev"] = None      # (j, n_in, work): first half queued, words travelling
-        if not args.dense_reduce:
-            rowsx = ydist.BatchRowsReducer(sdb, batch=BB, dst=0, nbuf=NB3)
 
-        def second_half(j, n_in, w):
-            b = j % NB3
-            if w is not None:
-                w.wait()
-            sdb.batch_end(n_in, bgath[b], bcounts[b], slot=b)
-            if rowsx is not None:
-                rowsx.send(b, n_in, bcounts[b], slot=b)
-            elif staged_gather:
-                bcounts[b].copy_(sdb.reduce(bcounts[b], dst=0))
-            else:
-                bpending[b] = dist.reduce(bcounts[b], dst=0, op=dist.ReduceOp.SUM, async_op=True)
-            inflight[b] = (j, n_in)
+        def on_block(tag, n_in, rows, dense):
+            state["last_result"] = (tag, n_in, rows, dense)
 
-        def finish_block(b):
-            if inflight[b] is None:
-                return
-            j, n_in = inflight[b]
-            inflight[b] = None
-            if rowsx is not None:
-                rows, dense = rowsx.finish(b)  # (rows: a view that lasts until the next finish)
-                state["last_result"] = (j, n_in, rows, dense)
-            else:
-                if bpending[b] is not None:
-                    bpending[b].wait()
-                    bpending[b] = None
-                state["last_result"] = (j, n_in, None, bcounts[b])
+        runner = ydist.BatchedRangeRunner(sdb, batch=BB, dst=0, nbuf=NB3, dense_rows=args.dense_reduce,
+                                          compact_words=not args.dense_words, on_result=on_block,
+                                          async_collectives=not staged_gather and not args.sync_gather)
+        rowsx = runner.red
 
         def run_block(j, n_in):
-            b = j % NB3
-            finish_block(b)  # block j - 3: its slot, its counts and its value buffer are free again
             key = (j * BB) % K
             if (key, n_in) not in packed_blocks:  # (resident samples: their slices are concatenated once)
                 packed_blocks[(key, n_in)] = sdb.pack_batch([samples[(key + t) % K] for t in range(n_in)],
                                                              spans=[spans[(key + t) % K] for t in range(n_in)])
-            sdb.batch_begin(packed_blocks[(key, n_in)], bcounts[b], bwords[b], slot=b)
-            w = sdb.batch_exchange(bwords[b], bgath[b], async_op=not staged_gather and not args.sync_gather)
-            if state["prev"] is not None:  # ... and behind this block's first half: the second half of the previous one
-                second_half(*state["prev"])
-            state["prev"] = (j, n_in, w)
+            runner.submit(packed_blocks[(key, n_in)], n_in, tag=j)
 
     def step():
         i = state["i"]
@@ -468,11 +441,7 @@ def main() -> int:
             if i % BB != 0:  # a partly filled block at the end of a loop
                 run_block(i // BB, i % BB)
                 state["i"] += BB - i % BB
-            if state["prev"] is not None:
-                second_half(*state["prev"])
-                state["prev"] = None
-            for b in sorted(range(NB3), key=lambda q: inflight[q][0] if inflight[q] is not None else -1):
-                finish_block(b)  # (oldest block first: the same order on every rank)
+            runner.drain()  # (the previous block's second half, then every block's rows, oldest first: the same order on every rank)
             return
         if multi and i % GB != 0:  # a partly filled block at the end of a loop leaves too
             close_block((i // GB) % NBUF, i - i % GB, i % GB)
@@ -874,18 +843,22 @@ def main() -> int:
     # of every reference) is built on this GPU and the two halves of its step (yh_run_local_range_device,
     # yh_run_finish_range_device) are timed on its slice of the rotating samples -- everything but the collectives.
     scaling_model = None
-    if not multi and not args.no_scaling_model and args.workload == "gtdb_rs214_scale" and not args.no_indexed:
-        per_g = {}
-        for G in (2, 4, 8):
-            bg = ydist.hash_range_bounds(max_hash_db, G)
-            v_g, o_g = ydist.slice_to_hash_range(values, offsets, bg[0], bg[1])
-            with torch.cuda.stream(stream):
-                hr = ydist.HashRangeRefDB(v_g, o_g, [bg[0], bg[1]], ydist.HipRangeBackend(local_rank), block=1)
-            torch.cuda.synchronize()
-            hr.local.handle.set_stream(stream.cuda_stream)
-            cg = [hr.new_counts() for _ in range(2)]
 
-            spans_g = [hr.slice_of(s_) for s_ in samples]  # (resident samples: their spans in this range, once)
+    def share_of(G, v_full, o_full, n_refs_, group=None, single_steps=True):
+        """Rank 0's share of a G-way hash-range run of the database (v_full, o_full), built and timed on THIS GPU: both halves
+        of a block of BM distinct samples through dist.BatchedRangeRunner -- the very object the N > 1 loop drives, here with a
+        one-rank exchange (its own words): packing and unpacking of the compact subset words and of the compact rows
+        included, the collectives themselves not.  G = 1 is the whole database: the single-GPU figure of the SAME FORM."""
+        bg = ydist.hash_range_bounds(max_hash_db, G)
+        v_g, o_g = (v_full, o_full) if G == 1 else ydist.slice_to_hash_range(v_full, o_full, bg[0], bg[1])
+        with torch.cuda.stream(stream):
+            hr = ydist.HashRangeRefDB(v_g, o_g, [bg[0], bg[1]], ydist.HipRangeBackend(local_rank), group=group, block=1)
+        torch.cuda.synchronize()
+        hr.local.handle.set_stream(stream.cuda_stream)
+        spans_g = [hr.slice_of(s_) for s_ in samples]  # (resident samples: their spans in this range, once)
+        el = None
+        if single_steps:
+            cg = [hr.new_counts() for _ in range(2)]
 
             def step_g(i):
                 with torch.cuda.stream(stream):
@@ -894,71 +867,79 @@ def main() -> int:
 
             for i in range(max(args.warmup, K)):
                 step_g(i)
-            fence()
+            torch.cuda.synchronize()
             n_g = max(args.steps, 100)
             t0 = time.perf_counter()
             for i in range(n_g):
                 step_g(i)
-            fence()
+            torch.cuda.synchronize()
             el = (time.perf_counter() - t0) / n_g
-            BM = max(1, min(int(args.batch_block), 64))
-            # the throughput form: rank 0's share of a batch of BM distinct samples (the block of --block-mode batched) in one pass (no exchange: its own words)
-            bsamp = [samples[i] if i < K else synth.global_db_sample_device(plan, args.seed + 7000 + i, n_sample=args.sample_hashes,
-                                                                           n_present=n_present, device=str(dev)) for i in range(BM)]
-            with torch.cuda.stream(stream):
-                packed_b = hr.pack_batch(bsamp)
-            cb = torch.zeros((3, BM, n_local), device=dev, dtype=torch.int32)
-            wb = torch.zeros(n_local, device=dev, dtype=torch.int64)
-            gb = torch.zeros((1, n_local), device=dev, dtype=torch.int64)
+            del cg
+        BM = max(1, min(int(args.batch_block), 64))
+        # the throughput form: BM distinct samples per block (the block of --block-mode batched), three blocks in flight
+        bsamp = [samples[i] if i < K else synth.global_db_sample_device(plan, args.seed + 7000 + i, n_sample=args.sample_hashes,
+                                                                       n_present=n_present, device=str(dev)) for i in range(BM)]
+        with torch.cuda.stream(stream):
+            packed_b = hr.pack_batch(bsamp)
+        seen = {}
 
-            vb = torch.zeros((BM * 2048, 3), device=dev, dtype=torch.int32)
-            nb_rows = torch.zeros(1, device=dev, dtype=torch.int32)
+        def on_res(tag, n_in, rows, dense):
+            seen["rows"] = int(rows.shape[0]) if rows is not None else -1
 
-            def batch_g():
-                with torch.cuda.stream(stream):
-                    hr.batch_begin(packed_b, cb, wb)
-                    hr.batch_exchange(wb, gb)
-                    hr.batch_end(BM, gb, cb)
-                    hr.local.rows_pack(cb, vb, nb_rows, 0)  # (the result leaves as compact rows: their packing is part of the block)
-
-            for _ in range(2):
-                batch_g()
-            fence()
-            nb_ = max(3, min(20, args.steps // BM + 1))
+        with torch.cuda.stream(stream):
+            run_g = ydist.BatchedRangeRunner(hr, batch=BM, dst=0, nbuf=3, on_result=on_res, compact_words=not args.dense_words,
+                                             dense_rows=args.dense_reduce)
+            for _ in range(3):
+                run_g.submit(packed_b, BM)
+            run_g.drain()
+            torch.cuda.synchronize()
+            nb_ = max(6, min(30, args.steps // BM + 1))
             t0 = time.perf_counter()
             for _ in range(nb_):
-                batch_g()
-            fence()
+                run_g.submit(packed_b, BM)
+            run_g.drain()
+            torch.cuda.synchronize()
             el_b = (time.perf_counter() - t0) / nb_
-            rows_in_block = int(nb_rows.item())
-            del bsamp, packed_b, cb, wb, gb, vb
-            a_, b_ = spans_g[0]
-            per_g[str(G)] = {"rank0_compute_ms_per_step": round(1e3 * el, 4), "sample_hashes_in_range": int(b_ - a_),
-                             "batched_rank0_ms_per_sample": round(1e3 * el_b / BM, 4), "batched_rank0_ms_per_block": round(1e3 * el_b, 4),
-                             "samples_per_block": BM, "rows_in_block": rows_in_block,
-                             "ref_hashes_in_range": int(v_g.numel()),
-                             "lookup_choice": "indexed" if hr.local.handle.lookup_choice(int(b_ - a_)) == ylib.YH_LOOKUP_INDEXED else "stream"}
-            hr.close()
-            del v_g, o_g, cg, hr
+        a_, b_ = spans_g[0]
+        res = {"rank0_compute_ms_per_step": round(1e3 * el, 4) if el is not None else None, "sample_hashes_in_range": int(b_ - a_),
+               "batched_rank0_ms_per_sample": round(1e3 * el_b / BM, 4), "batched_rank0_ms_per_block": round(1e3 * el_b, 4),
+               "samples_per_block": BM, "rows_in_block": seen.get("rows"), "blocks_timed": nb_,
+               "word_exchange_overflows": run_g.n_words_overflow, "rows_overflows": (run_g.red.n_overflow if run_g.red is not None else None),
+               "collective_bytes": run_g.collective_bytes(),
+               "ref_hashes_in_range": int(v_g.numel()),
+               "lookup_choice": "indexed" if hr.local.handle.lookup_choice(int(b_ - a_)) == ylib.YH_LOOKUP_INDEXED else "stream"}
+        hr.close()
+        del bsamp, packed_b, run_g, hr
+        return res
+
+    if not multi and not args.no_scaling_model and args.workload == "gtdb_rs214_scale" and not args.no_indexed:
+        per_g = {}
+        for G in (1, 2, 4, 8):
+            per_g[str(G)] = share_of(G, values, offsets, n_local, single_steps=G > 1)
+        BM = max(1, min(int(args.batch_block), 64))
         # The collectives of a block, from their BYTES (nothing here is measured: this box has one GPU).  Stated constants:
         #   link   64 GB/s per direction and xGMI link (7 links x ~153 GB/s bidirectional per GPU, ~83 % of the wire rate as payload)
         #   lat    30 us per collective (RCCL launch, synchronisation and the first hop of a small message between 8 ranks)
         # On the fully connected xGMI mesh a rank reaches each peer over a link of its own: an all-gather moves the rank's
         # message once per link (`direct`); a ring moves (G - 1) messages over one link (`ring`, the pessimistic bound).
         LINK_GBPS, LAT_MS = 64.0, 0.030
-        words_bytes = 8 * n_local                      # all-gather of the block's subset words: one uint64 per reference and rank
-        cap_rows = min(512 * BM, BM * n_local)         # dist.BatchRowsReducer's collective: cap x (overlap, n_excl, n_match)
-        rows_bytes = 12 * cap_rows
-        dense_bytes = 3 * BM * n_local * 4             # round 3's result path: the dense shares
+        cbytes = per_g["1"]["collective_bytes"]        # (the same capacities at every G: they depend on N and the block size only)
+        words_bytes = cbytes["subset_words_all_gather"]  # all-gather of the block's subset words, compact: 12 B per non-zero word's slot
+        words_dense_bytes = cbytes["subset_words_dense_form"]  # round 4's exchange: one uint64 per reference and rank
+        rows_bytes = cbytes["result"]                  # dist.BatchRowsReducer's collective: cap x (overlap, n_excl, n_match)
+        dense_bytes = cbytes["result_dense_form"]      # round 3's result path: the dense shares
         def t_coll(nbytes, G, ring):
             return LAT_MS + (nbytes * ((G - 1) if ring else 1)) / (LINK_GBPS * 1e9) * 1e3
+        one_gpu_same_form = per_g["1"]["batched_rank0_ms_per_sample"]  # the single-GPU figure of the SAME form (blocks of BM through the same runner)
         model = {}
         for g, v in per_g.items():
             G = int(g)
+            if G == 1:
+                continue
             comp = v["batched_rank0_ms_per_block"]
             c_dir = t_coll(words_bytes, G, False) + t_coll(rows_bytes, G, False)
             c_ring = t_coll(words_bytes, G, True) + t_coll(rows_bytes, G, True)
-            c_dense_ring = t_coll(words_bytes, G, True) + t_coll(dense_bytes, G, True)
+            c_dense_ring = t_coll(words_dense_bytes, G, True) + t_coll(dense_bytes, G, True)
             model[g] = {
                 "compute_ms_per_block": comp,
                 "collectives_ms_per_block_direct": round(c_dir, 4), "collectives_ms_per_block_ring": round(c_ring, 4),
@@ -969,15 +950,25 @@ def main() -> int:
                 "ms_per_sample_overlapped": round(max(comp, c_ring) / BM, 4),
                 "ms_per_sample_serial": round((comp + c_ring) / BM, 4),
                 "ms_per_sample_serial_dense_rows": round((comp + c_dense_ring) / BM, 4),
+                # LIKE FOR LIKE: against one GPU running the same batched blocks (what scaling efficiency is made of) ...
+                "speedup_vs_1gpu_batched_overlapped": round(one_gpu_same_form / (max(comp, c_ring) / BM), 2),
+                "speedup_vs_1gpu_batched_serial": round(one_gpu_same_form / ((comp + c_ring) / BM), 2),
+                "efficiency_vs_1gpu_batched_overlapped": round(one_gpu_same_form / (max(comp, c_ring) / BM) / G, 3),
+                "efficiency_vs_1gpu_batched_serial": round(one_gpu_same_form / ((comp + c_ring) / BM) / G, 3),
+                # ... and against `value` (one GPU, ONE sample per launch: a different form -- what the driver's own division of the
+                # per-N values will show, since N = 1 reports single steps and N > 1 batched blocks)
                 "speedup_vs_1gpu_single_steps_overlapped": round(ms_per_step / (max(comp, c_ring) / BM), 2),
                 "speedup_vs_1gpu_single_steps_serial": round(ms_per_step / ((comp + c_ring) / BM), 2),
                 "speedup_vs_1gpu_single_steps_serial_dense_rows": round(ms_per_step / ((comp + c_dense_ring) / BM), 2),
             }
         scaling_model = {
             "per_G": per_g,
+            "one_gpu_same_form_ms_per_sample": one_gpu_same_form,
             "collective_bytes_per_block_and_rank": {
-                "subset_words_all_gather": words_bytes, "compact_rows_reduce": rows_bytes,
-                "compact_rows_capacity": cap_rows, "rows_in_a_block_measured": {g: v["rows_in_block"] for g, v in per_g.items()},
+                "subset_words_all_gather": words_bytes, "subset_words_dense_form_round4": words_dense_bytes,
+                "compact_rows_reduce": rows_bytes, "total": words_bytes + rows_bytes,
+                "compact_rows_capacity": cbytes["result_capacity_rows"], "subset_words_capacity": cbytes["subset_words_capacity"],
+                "rows_in_a_block_measured": {g: v["rows_in_block"] for g, v in per_g.items()},
                 "dense_rows_reduce_round3": dense_bytes,
             },
             "assumed": {"xgmi_link_GBps_per_direction": LINK_GBPS, "collective_latency_ms": LAT_MS,
@@ -986,11 +977,52 @@ def main() -> int:
             # the per-sample half-steps (--block-mode steps): four launches of latency per sample, one exchange per block of 8
             "single_steps_predicted_ms_per_step": {g: round(v["rank0_compute_ms_per_step"] + (t_coll(8 * ((n_local + 255) // 256) * 32, int(g), True)
                                                                                             + t_coll(8 * 3 * n_local * 4, int(g), True)) / 8, 4)
-                                                   for g, v in per_g.items()},
-            "how": "rank 0's hash range of the whole database built on THIS GPU; both halves of a block of samples_per_block distinct "
-                   "samples + the packing of its compact rows timed on its slice (no collectives); the collectives from their bytes",
+                                                   for g, v in per_g.items() if v["rank0_compute_ms_per_step"] is not None},
+            "how": "rank 0's hash range of the whole database built on THIS GPU (G = 1: all of it); blocks of samples_per_block distinct "
+                   "samples through dist.BatchedRangeRunner -- both halves, compact words and compact rows packed and unpacked, three blocks "
+                   "in flight, no collectives -- timed on its slice; the collectives from their bytes",
         }
 
+    # ---- N > 1: what makes the scaling line like-for-like and self-proving ---------------------------------------------
+    #   form                    what a step of `value` is: batched blocks (default) or single steps
+    #   value_1gpu_same_form    rank 0 ALONE, after the timed region, on the WHOLE database and the same samples, through the very
+    #                           same runner (a one-rank group: no collectives) -- the other ranks wait at the barrier
+    #   scaling_efficiency      value / (N x value_1gpu_same_form)
+    #   rccl_world_size, ranks  what the process group itself reports after init_process_group, every rank's device identity
+    #                           (all-gathered) and a one-word all-reduce whose answer only N distinct ranks can produce
+    same_form = None
+    dist_proof = None
+    if multi:
+        ident = {"rank": rank, "local_rank": local_rank, "device_index": int(torch.cuda.current_device()), "pid": os.getpid()}
+        try:
+            pr_ = torch.cuda.get_device_properties(dev)
+            ident["device_name"] = pr_.name
+            ident["device_uuid"] = str(getattr(pr_, "uuid", None))
+            ident["pci_bus_id"] = getattr(pr_, "pci_bus_id", None)
+        except Exception as ex:  # noqa: BLE001
+            ident["error"] = repr(ex)
+        idents = [None] * world
+        dist.all_gather_object(idents, ident)
+        word = ydist._stage(torch.tensor([rank + 1], device=dev, dtype=torch.int64), None)
+        dist.all_reduce(word, op=dist.ReduceOp.SUM)
+        uu = [str(x.get("device_uuid")) + "/" + str(x.get("pci_bus_id")) + "/" + str(x.get("device_index")) for x in idents]
+        dist_proof = {"backend": dist.get_backend(), "rccl_world_size": dist.get_world_size(), "ranks": idents,
+                      "distinct_devices": len(set(uu)) if not args.share_gpu else 1,
+                      "all_reduce_of_rank_plus_1": int(word.item()), "all_reduce_expected": world * (world + 1) // 2,
+                      "all_reduce_ok": int(word.item()) == world * (world + 1) // 2}
+        g1 = dist.new_group([0])  # (every rank takes part in making it; only rank 0 uses it)
+        if hash_batched and not args.no_same_form and args.workload == "gtdb_rs214_scale":
+            if rank == 0:
+                vs_ = []
+                for c0 in range(0, n_total, 16384):
+                    v_c, _o = synth.global_db_refs_device(plan, np.arange(c0, min(n_total, c0 + 16384)), device=str(dev))
+                    vs_.append(v_c)
+                v_full = torch.cat(vs_).contiguous()
+                o_full = torch.from_numpy(plan["offsets"].astype(np.int64)).to(dev)
+                del vs_
+                same_form = share_of(1, v_full, o_full, n_total, group=g1, single_steps=False)
+                del v_full, o_full
+            fence()
     stamp("scaling_model")
     # ---- roofline of the dominant kernel of the DEFAULT step --------------------------------------------
     # Streaming lookup (k_stream_lookup): `achieved` = bytes one launch HAS to move in the layout the kernel
@@ -1215,6 +1247,19 @@ def main() -> int:
         sketch_block["wall_s_of_the_child"] = round(time.perf_counter() - t0, 1)
 
     stamp("sketch_child")
+    form = ("batched blocks of %d samples (dist.BatchedRangeRunner)" % BB) if hash_batched else "single steps (one sample per launch)"
+    value_batched = ms_per_sample_batched = value_1gpu_same_form = scaling_efficiency = None
+    if not multi:
+        if scaling_model is not None:  # the runner form on the whole database (scaling_model.per_G["1"])
+            ms_per_sample_batched = scaling_model["one_gpu_same_form_ms_per_sample"]
+        elif batched is not None:      # (--no-scaling-model: the one-call form, yh_run_batch_device)
+            ms_per_sample_batched = batched["ms_per_sample"]
+        if ms_per_sample_batched:
+            value_batched = round(n_total / (ms_per_sample_batched / 1e3), 1)
+    elif same_form is not None:
+        value_1gpu_same_form = round(n_total / (same_form["batched_rank0_ms_per_sample"] / 1e3), 1)
+        scaling_efficiency = round(value / (world * value_1gpu_same_form), 4)
+    train_di = ((train or {}).get("device_input") or {})
     if rank == 0:
         try:
             import scipy
@@ -1234,6 +1279,16 @@ def main() -> int:
             "value_host_inclusive": (host_inclusive or {}).get("value"),
             "ms_per_step_host_inclusive": (host_inclusive or {}).get("ms_per_step"),
             "host_issue_ms_per_step": round(1e3 * t_issued / n_timed, 4),
+            # what a step of `value` is.  N = 1: one sample per launch (as the reference runs them: run_YACHT.py:150); N > 1 (default):
+            # blocks of --batch-block distinct samples per pass.  The like-for-like single-GPU figure of the batched form is
+            # `value_batched` at N = 1 and `value_1gpu_same_form` at N > 1 (rank 0 alone, whole database, same samples, same runner).
+            "form": form,
+            "value_batched": value_batched, "ms_per_sample_batched": ms_per_sample_batched,
+            "value_1gpu_same_form": value_1gpu_same_form,
+            "ms_per_sample_1gpu_same_form": (same_form or {}).get("batched_rank0_ms_per_sample"),
+            "scaling_efficiency": scaling_efficiency,
+            "rccl_world_size": (dist_proof or {}).get("rccl_world_size"),
+            "distributed": dist_proof,
             # the timed region itself: `steps` is what the caller asked for, `steps_timed` what the loop ran (see --min-timed-steps)
             "steps_timed": n_timed,
             "timed_region_s": round(elapsed, 6),
@@ -1245,6 +1300,19 @@ def main() -> int:
             "config": {
                 "workload": workload,
                 "refs_total": n_total,
+                # the figures that decide credit, where the driver's record keeps them (VERDICT r04 "next" 2)
+                "ms_per_step_host_inclusive": (host_inclusive or {}).get("ms_per_step"),
+                "value_host_inclusive": (host_inclusive or {}).get("value"),
+                "sample_hash_lookups_per_s": round(n_sample / (ms_per_step / 1e3), 1),  # (the work rate: a step costs per SAMPLE hash, whatever N_refs is)
+                "value_batched": value_batched, "ms_per_sample_batched": ms_per_sample_batched,
+                "form": form, "value_1gpu_same_form": value_1gpu_same_form, "scaling_efficiency": scaling_efficiency,
+                "rccl_world_size": (dist_proof or {}).get("rccl_world_size"),
+                "train_device_input_ms": (round(1e3 * train_di["seconds"]["total"], 3) if train_di.get("seconds") else None),
+                "train_device_ms": ((train_di.get("roofline") or {}).get("device_ms")),
+                "train_frac": ((train_di.get("roofline") or {}).get("frac")),
+                "train_traffic_bytes": ((train_di.get("roofline") or {}).get("traffic")),
+                "train_host_input_ms": (round(1e3 * train["seconds"]["total"], 3) if (train or {}).get("seconds") else None),
+                "roofline_frac": roofline.get("frac"), "roofline_kernel_us": round(1e3 * float(roofline.get("kernel_ms_avg") or 0.0), 2),
                 "refs_per_gpu": n_local,
                 "ref_hashes_per_gpu": Hh,
                 "sample_hashes": n_sample,
@@ -1277,12 +1345,12 @@ def main() -> int:
                 "samples_per_block": (BB if hash_batched else GB) if multi else None,
                 "result_path": (("dense [3, B, N] shares summed" if rowsx is None else "compact rows: value triples summed (dist.BatchRowsReducer)")
                                 if hash_batched else None),
-                "collective_bytes_per_block_and_rank": ({"subset_words_all_gather": 8 * n_total,
-                                                         "result": (12 * rowsx.cap if rowsx is not None else 3 * BB * n_total * 4),
-                                                         "result_dense_form": 3 * BB * n_total * 4,
-                                                         "rows_in_last_block": getattr(rowsx, "last_n_rows", None) if rowsx is not None else None,
-                                                         "dense_fallbacks": rowsx.n_overflow if rowsx is not None else None}
+                "collective_bytes_per_block_and_rank": (dict(runner.collective_bytes(),
+                                                             rows_in_last_block=getattr(rowsx, "last_n_rows", None) if rowsx is not None else None,
+                                                             dense_fallbacks=rowsx.n_overflow if rowsx is not None else None,
+                                                             word_exchange_repeats=runner.n_words_overflow)
                                                         if hash_batched else None),
+                "one_gpu_same_form": same_form,
                 "scipy": scipy_version,
             },
             "roofline": roofline,
@@ -1320,6 +1388,9 @@ def main() -> int:
         return 1
     if rank == 0 and train is not None and (train.get("returncode", 1) != 0 or train.get("parity_bit_exact") is False):
         print("bench.py: the train block failed or differs from its references: " + json.dumps(train)[:600], file=sys.stderr)
+        return 1
+    if rank == 0 and dist_proof is not None and not dist_proof["all_reduce_ok"]:
+        print("bench.py: the one-word all-reduce over the ranks gave a wrong sum: " + json.dumps(dist_proof)[:400], file=sys.stderr)
         return 1
     if rank == 0 and blocks_ok is False:
         print("bench.py: the batched blocks differ from the single-sample steps", file=sys.stderr)

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define YH_ABI_VERSION 4
+#define YH_ABI_VERSION 5
 
 enum {
     YH_OK               = 0,
@@ -319,6 +319,28 @@ int yh_run_batch_rows_pack_device(yh_db* db, int slot, const uint32_t* d_overlap
                                   const uint32_t* d_n_match, uint32_t* d_vals, uint64_t cap_rows, uint32_t* d_n_rows);
 int yh_run_batch_rows_unpack_device(yh_db* db, int slot, const uint32_t* d_vals, uint64_t cap_rows, yh_batch_row* d_rows,
                                     uint32_t* d_n_rows);
+
+/* ---- the subset words of a block in compact form (ABI 5) ----------------------------------------------------------------
+ * Between the two halves of a batched hash-range run every rank needs the OR of all ranks' subset words.  The dense row
+ * (one uint64 per reference: 8 N bytes per rank and block, 682 KB at rs214 scale) is mostly zeros -- a block of 64 samples
+ * overlaps ~15 000 of 85 205 references -- so a rank all-gathers its NON-ZERO words instead:
+ *   yh_run_batch_words_packed_len    uint64 words a packed buffer of capacity cap_words takes: 1 + cap + ceil(cap / 2)
+ *                                    ([0] = the rank's number of non-zero words, then the words, then 32-bit reference ids)
+ *   yh_run_batch_words_pack_device   d_words [N] (what yh_run_batch_local_range_device left) -> d_packed; the count in
+ *                                    [0] is the true one even when it exceeds cap_words (then only cap_words entries
+ *                                    were written)
+ *   yh_run_batch_words_unpack_device d_gathered = n_ranks packed buffers back to back (an all-gather's output) ->
+ *                                    d_words_out [N] = their OR -- pass it to yh_run_batch_finish_range_device with
+ *                                    n_ranks = 1 --; *d_overflow = 1 when some rank had more words than cap_words (the
+ *                                    OR is then incomplete and the caller repeats the exchange with a larger capacity
+ *                                    or with the dense rows), else 0.  Reference ids >= N are ignored.
+ * No handle state is read or written but the stream and N: both are enqueued on the handle's stream, no host sync, and
+ * may run at any point of the interleaving table above.  (No reference counterpart: run_YACHT.py:150 runs one sample per
+ * process on one machine.)                                                                                              */
+uint64_t yh_run_batch_words_packed_len(uint64_t cap_words);
+int yh_run_batch_words_pack_device(yh_db* db, const uint64_t* d_words, uint64_t* d_packed, uint64_t cap_words);
+int yh_run_batch_words_unpack_device(yh_db* db, const uint64_t* d_gathered, uint32_t n_ranks, uint64_t cap_words,
+                                     uint64_t* d_words_out, uint32_t* d_overflow);
 
 /* Pipelined host-buffer form of yh_run: SURVEY.md 8d's steady-state call -- sample H2D, kernels,
  * counts D2H -- split in two so that consecutive samples overlap.  yh_run_submit queues, on two

@@ -94,6 +94,29 @@ class SetRangeBackend:
                     e_t[s] = torch.from_numpy(e)
                     m_t[s] = torch.from_numpy(m)
 
+            def words_pack(self, words_t, packed_t, cap):  # yh_run_batch_words_pack_device restated
+                w = words_t.numpy().view(np.uint64)
+                nz = np.flatnonzero(w)[::-1]  # (any order is allowed: take a different one than the kernel's)
+                out = np.zeros(packed_t.numel(), dtype=np.uint64)
+                out[0] = nz.size
+                k = min(int(nz.size), int(cap))
+                out[1:1 + k] = w[nz[:k]]
+                out[1 + cap:].view(np.uint32)[:k] = nz[:k].astype(np.uint32)
+                packed_t.copy_(torch.from_numpy(out.view(np.int64)))
+
+            def words_unpack(self, gathered_t, n_ranks, cap, words_out_t, overflow_t):
+                g = gathered_t.numpy().view(np.uint64).reshape(n_ranks, -1)
+                acc = np.zeros(len(refs), dtype=np.uint64)
+                ov = 0
+                for k in range(n_ranks):
+                    n = int(g[k, 0])
+                    ov |= int(n > cap)
+                    n = min(n, int(cap))
+                    ids = g[k, 1 + cap:].view(np.uint32)[:n]
+                    np.bitwise_or.at(acc, ids, g[k, 1:1 + n])
+                words_out_t.view(-1).copy_(torch.from_numpy(acc.view(np.int64)))
+                overflow_t[0] = ov
+
             def _entries(self, slot):  # (reference, sample) of every set bit of the slot's global words, in that order
                 words, n = self._slots[slot]["words"], self._slots[slot]["n"]
                 return [(r, s_) for r in range(len(refs)) for s_ in range(n) if (int(words[r]) >> s_) & 1]
@@ -235,6 +258,37 @@ def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
                 for j, blk_ in enumerate(blocks):
                     for k, smp in enumerate(blk_):
                         check(got[j][:, k, :], smp, f"compact rows, first_cap {first_cap}, block {j} sample {k}")
+        # the whole pipeline as the product drives it (BatchedRangeRunner): compact subset words + compact rows, three blocks
+        # in flight; undersized exchanges of either kind are noticed on every rank, the block repeated, the capacity raised
+        for kw, expect in ((dict(), "fits"), (dict(cap_words=2), "words"), (dict(cap_rows=4), "rows"),
+                           (dict(cap_words=3, cap_rows=5), "both"), (dict(compact_words=False), "fits"),
+                           (dict(dense_rows=True, cap_words=2), "words")):
+            got = {}
+
+            def on_result(tag, n_in, rows, dense):
+                if rank == 0:
+                    got[tag] = dense[:, :n_in].clone() if rows is None else ydist.BatchRowsReducer.rows_to_dense(rows, n_in, hr.n_total)
+                else:
+                    assert rows is None and dense is None
+
+            run = ydist.BatchedRangeRunner(hr, batch=3, dst=0, nbuf=3, on_result=on_result, **kw)
+            for rep in range(2):  # (the second round starts with the raised capacities)
+                for j, blk_ in enumerate(tb):
+                    run.submit(hr.pack_batch(blk_), len(blk_), tag=(rep, j))
+                run.drain()
+            if expect in ("words", "both"):
+                assert run.n_words_overflow >= 1 and run.cap_words > kw["cap_words"], "the undersized word exchange must have been noticed"
+            else:
+                assert run.n_words_overflow == 0
+            if expect in ("rows", "both"):
+                assert run.red.n_overflow >= 1
+            cb_ = run.collective_bytes()
+            assert cb_["total"] == cb_["subset_words_all_gather"] + cb_["result"]
+            if rank == 0:
+                assert sorted(got) == [(rep, j) for rep in range(2) for j in range(len(tb))]
+                for (rep, j), dense in got.items():
+                    for k, smp in enumerate(blocks[j]):
+                        check(dense[:, k, :], smp, f"runner {kw} round {rep} block {j} sample {k}")
         open(os.path.join(out_dir, f"ok{rank}"), "w").close()
     finally:
         dist.destroy_process_group()

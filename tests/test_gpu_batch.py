@@ -126,5 +126,66 @@ def test_batch_rs214_scale_against_oracle(hip_lib):
             dense[c, r[:, 0], r[:, 1]] = r[:, 2 + c]
         assert np.array_equal(dense, got), "the compact rows of the batch do not reproduce its dense rows"
         assert np.array_equal(np.lexsort((r[:, 0], r[:, 1])), np.arange(k)), "(reference, sample) order"
+        # the block's subset words in compact form (ABI 5): packed -> "gathered" (two ranks: the real words and a second,
+        # disjoint-ish set) -> OR; at the default capacity of dist.BatchedRangeRunner (320 per sample) and undersized
+        words = torch.from_numpy(np.bitwise_or.reduce((got[0] > 0).astype(np.uint64) << np.arange(64, dtype=np.uint64)[:, None], axis=0).view(np.int64)).to("cuda:0")
+        other = torch.roll(words, 12345) & 0x0F0F
+        want = (words | other).cpu().numpy()
+        nz = int((words != 0).sum().item())
+        for cap, expect_ovf in ((320 * 64, 0), (nz - 1, 1), (n_refs, 0)):
+            L = int(_lib.load().yh_run_batch_words_packed_len(cap))
+            assert L == 1 + cap + (cap + 1) // 2
+            gath = torch.full((2, L), -1, dtype=torch.int64, device="cuda:0")
+            ored = torch.full((n_refs,), -1, dtype=torch.int64, device="cuda:0")
+            ovf = torch.full((1,), 7, dtype=torch.int32, device="cuda:0")
+            db.synchronize()
+            torch.cuda.synchronize()
+            db.run_batch_words_pack_device(words.data_ptr(), gath[0].data_ptr(), cap)
+            db.run_batch_words_pack_device(other.data_ptr(), gath[1].data_ptr(), cap)
+            db.run_batch_words_unpack_device(gath.data_ptr(), 2, cap, ored.data_ptr(), ovf.data_ptr())
+            db.synchronize()
+            assert int(gath[0, 0].item()) == nz and int(gath[1, 0].item()) == int((other != 0).sum().item())
+            assert int(ovf.item()) == expect_ovf, (cap, nz)
+            if not expect_ovf:
+                assert np.array_equal(ored.cpu().numpy(), want), f"OR of the packed words differs (cap {cap})"
+        assert nz <= 320 * 64, f"{nz} non-zero subset words in a block of 64: the runner's default capacity is too small for the bench workload"
     finally:
         db.close()
+
+
+def test_batch_words_compact_small(hip_lib):
+    """yh_run_batch_words_pack_device / _unpack_device on small rows: empty, full, forged reference ids, one rank."""
+    import torch
+
+    values, offsets = synth.config4(seed=35, n_clusters=30, size=60)
+    n = offsets.size - 1
+    rng = np.random.default_rng(3)
+    with RefDB(values, offsets, flags=FULL) as db:
+        for density in (0.0, 0.07, 1.0):
+            w = rng.integers(1, 2 ** 63, size=n, dtype=np.int64) * (rng.random(n) < density)
+            wt = torch.from_numpy(w).to("cuda:0")
+            cap = n
+            L = 1 + cap + (cap + 1) // 2
+            g = torch.zeros((1, L), dtype=torch.int64, device="cuda:0")
+            out = torch.full((n,), 5, dtype=torch.int64, device="cuda:0")
+            ovf = torch.zeros(1, dtype=torch.int32, device="cuda:0")
+            torch.cuda.synchronize()
+            db.run_batch_words_pack_device(wt.data_ptr(), g.data_ptr(), cap)
+            db.run_batch_words_unpack_device(g.data_ptr(), 1, cap, out.data_ptr(), ovf.data_ptr())
+            db.synchronize()
+            assert np.array_equal(out.cpu().numpy(), w) and int(ovf.item()) == 0
+        # a forged buffer: count beyond the capacity, reference ids beyond N -> flagged / ignored, nothing written out of bounds
+        cap = 8
+        L = 1 + cap + (cap + 1) // 2
+        forged = np.zeros(L, dtype=np.int64)
+        forged[0] = 1000
+        forged[1:1 + cap] = 3
+        forged[1 + cap:].view(np.uint32)[:cap] = [0, n + 5, 2 ** 31, 1, n, 0xFFFFFFFF, 2, 3]
+        g = torch.from_numpy(forged).to("cuda:0")
+        out = torch.zeros(n, dtype=torch.int64, device="cuda:0")
+        ovf = torch.zeros(1, dtype=torch.int32, device="cuda:0")
+        torch.cuda.synchronize()
+        db.run_batch_words_unpack_device(g.data_ptr(), 1, cap, out.data_ptr(), ovf.data_ptr())
+        db.synchronize()
+        o = out.cpu().numpy()
+        assert int(ovf.item()) == 1 and o[:4].tolist() == [3, 3, 3, 3] and not o[4:].any()

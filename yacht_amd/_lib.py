@@ -119,6 +119,9 @@ SIGNATURES = {
     "yh_run_batch_finish_range_device": (C.c_int, [_vp, C.c_int, C.c_uint32, _vp, C.c_uint32, _vp, _vp, _vp]),
     "yh_run_batch_rows_pack_device": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, C.c_uint64, _vp]),
     "yh_run_batch_rows_unpack_device": (C.c_int, [_vp, C.c_int, _vp, C.c_uint64, _vp, _vp]),
+    "yh_run_batch_words_packed_len": (C.c_uint64, [C.c_uint64]),
+    "yh_run_batch_words_pack_device": (C.c_int, [_vp, _vp, _vp, C.c_uint64]),
+    "yh_run_batch_words_unpack_device": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint64, _vp, _vp]),
     "yh_run_submit": (C.c_int, [_vp, C.c_int, _vp, C.c_uint64, _vp, _vp, _vp]),
     "yh_run_wait": (C.c_int, [_vp, C.c_int]),
     "yh_sample_pack_bound": (C.c_uint64, [C.c_uint64]),
@@ -206,7 +209,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError here = the .so does not match the header
         fn.restype = res
         fn.argtypes = args
-    if lib.yh_abi_version() != 4:
+    if lib.yh_abi_version() != 5:
         raise YachtHipError(YH_ERR_INVALID_ARG, f"ABI version mismatch in {path}")
     _lib = lib
     return lib

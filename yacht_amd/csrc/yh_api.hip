@@ -1155,6 +1155,22 @@ int yh_run_batch_rows_unpack_device(yh_db* db, int slot, const uint32_t* d_vals,
     return yh_q_batch_rows_unpack(db, slot, d_vals, cap_rows, d_rows, d_n_rows);
 }
 
+uint64_t yh_run_batch_words_packed_len(uint64_t cap_words) { return yh_batch_words_packed_len(cap_words); }
+int yh_run_batch_words_pack_device(yh_db* db, const uint64_t* d_words, uint64_t* d_packed, uint64_t cap_words) {
+    if (!db_ok(db)) return YH_ERR_INVALID_ARG;
+    if (!d_packed || (db->n_refs && !d_words)) { yh_set_error("null device pointer"); return YH_ERR_INVALID_ARG; }
+    YH_TRY(db_select(db));
+    return yh_q_batch_words_pack(db, (const u64*)d_words, (u64*)d_packed, cap_words);
+}
+int yh_run_batch_words_unpack_device(yh_db* db, const uint64_t* d_gathered, uint32_t n_ranks, uint64_t cap_words,
+                                     uint64_t* d_words_out, uint32_t* d_overflow) {
+    if (!db_ok(db)) return YH_ERR_INVALID_ARG;
+    if (!d_gathered || !d_overflow || (db->n_refs && !d_words_out)) { yh_set_error("null device pointer"); return YH_ERR_INVALID_ARG; }
+    if (n_ranks < 1 || n_ranks > 65535) { yh_set_error("n_ranks out of range"); return YH_ERR_INVALID_ARG; }
+    YH_TRY(db_select(db));
+    return yh_q_batch_words_unpack(db, (const u64*)d_gathered, n_ranks, cap_words, (u64*)d_words_out, d_overflow);
+}
+
 // ---- pipelined host-buffer run calls ---------------------------------------------------------------
 static int slot_prepare(yh_db* db, RunSlot& s, u64 n_sample, u64 packed_bytes, bool rows_staging) {
     const u64 N = std::max<u64>(db->n_refs, 1);

@@ -392,6 +392,47 @@ __global__ void __launch_bounds__(256) k_batch_rows_emit(const u64* __restrict__
     }
 }
 
+// ---- the subset words of a block in compact form (include/yacht_hip.h: yh_run_batch_words_*) --------------------------
+// A block of 64 samples overlaps ~15 000 of 85 205 references: the dense word row a rank all-gathers (8 N bytes) is
+// five-sixths zeros.  PACK: the non-zero words of a rank as (word, reference) entries behind their count --
+//   packed[0] = number of non-zero words (the TRUE number, also when it exceeds cap: the reader sees the overflow),
+//   packed[1 .. cap] = the words, then cap 32-bit reference ids (two per 64-bit word) --
+// in no particular order (the reader ORs them into place).  UNPACK: the entries of all ranks OR-ed into one dense row
+// (zeroed by the caller), *overflow = some rank had more words than its buffer carried.
+__global__ void __launch_bounds__(256) k_batch_words_pack(const u64* __restrict__ words, u64 n_refs, u64* __restrict__ packed, u64 cap) {
+    const u64 r = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    const u64 w = r < n_refs ? words[r] : 0ull;
+    const u64 bal = __ballot(w != 0);
+    if (!bal) return;
+    const u32 lane = threadIdx.x & 63u;
+    u64 base = 0;
+    if (lane == (u32)__ffsll((long long)bal) - 1u) base = atomicAdd((unsigned long long*)packed, (unsigned long long)__popcll(bal));
+    base = __shfl(base, __ffsll((long long)bal) - 1);
+    if (w) {
+        const u64 at = base + __popcll(bal & ((1ull << lane) - 1ull));
+        if (at < cap) {
+            packed[1 + at] = w;
+            reinterpret_cast<u32*>(packed + 1 + cap)[at] = (u32)r;
+        }
+    }
+}
+__global__ void __launch_bounds__(256) k_batch_words_unpack(const u64* __restrict__ gathered, u32 n_ranks, u64 cap, u64 stride,
+                                                            u64 n_refs, u64* __restrict__ words, u32* __restrict__ overflow) {
+    const u32 k = blockIdx.y;
+    const u64* packed = gathered + (u64)k * stride;
+    const u64 n = packed[0];
+    if (blockIdx.x == 0 && k == 0 && threadIdx.x == 0) {
+        u32 ov = 0;
+        for (u32 q = 0; q < n_ranks; ++q) ov |= (u32)(gathered[(u64)q * stride] > cap);
+        *overflow = ov;
+    }
+    const u32* refs = reinterpret_cast<const u32*>(packed + 1 + cap);
+    for (u64 e = blockIdx.x * (u64)blockDim.x + threadIdx.x; e < min(n, cap); e += (u64)gridDim.x * blockDim.x) {
+        const u32 r = refs[e];
+        if (r < n_refs) atomicOr((unsigned long long*)&words[r], (unsigned long long)packed[1 + e]);  // (a forged id is dropped)
+    }
+}
+
 }  // namespace
 
 // a slot's scratch: maskword [N + 2] u64 | block counts of the compact rows [ceil(N / 2048) + 1, padded] u32 | ovsh [B][N] u32
@@ -496,5 +537,21 @@ int yh_q_run_batch(yh_db* db, const u64* d_samples, const u64* d_soff, u32 n_sam
     yh_ring_record_end(db, db->ev_excl);
     YH_HIP(hipGetLastError());
     bs.words_valid = true;  // (the slot's words are the batch's subset -- on hash-range shards the global one)
+    return YH_OK;
+}
+
+// the subset words of a block as (word, reference) entries (kernels above); both on the handle's stream, no host sync
+int yh_q_batch_words_pack(yh_db* db, const u64* d_words, u64* d_packed, u64 cap) {
+    YH_HIP(hipMemsetAsync(d_packed, 0, sizeof(u64), db->stream));
+    if (db->n_refs) k_batch_words_pack<<<(u32)((db->n_refs + 255) / 256), 256, 0, db->stream>>>(d_words, db->n_refs, d_packed, cap);
+    YH_HIP(hipGetLastError());
+    return YH_OK;
+}
+int yh_q_batch_words_unpack(yh_db* db, const u64* d_gathered, u32 n_ranks, u64 cap, u64* d_words_out, u32* d_overflow) {
+    const u64 stride = yh_batch_words_packed_len(cap);
+    if (db->n_refs) YH_HIP(hipMemsetAsync(d_words_out, 0, db->n_refs * sizeof(u64), db->stream));
+    const u32 gx = (u32)std::min<u64>(std::max<u64>((cap + 255) / 256, 1), 64);
+    k_batch_words_unpack<<<dim3(gx, n_ranks), 256, 0, db->stream>>>(d_gathered, n_ranks, cap, stride, db->n_refs, d_words_out, d_overflow);
+    YH_HIP(hipGetLastError());
     return YH_OK;
 }

@@ -580,18 +580,27 @@ class HipRangeBackend:
                     return
                 db.run_batch_local_range_device(cat_t.data_ptr(), soff_t.data_ptr(), n_samples, total, ov_t.data_ptr(), words_t.data_ptr(), slot)
 
+            def words_pack(self, words_t, packed_t, cap):
+                """packed_t [words_packed_len(cap)] int64 = count, this rank's non-zero subset words, their reference ids."""
+                db.run_batch_words_pack_device(words_t.data_ptr(), packed_t.data_ptr(), int(cap))
+
+            def words_unpack(self, gathered_t, n_ranks, cap, words_out_t, overflow_t):
+                """words_out_t [N] int64 = OR of the ranks' packed words; overflow_t [1] int32 = some rank had more than cap."""
+                db.run_batch_words_unpack_device(gathered_t.data_ptr(), int(n_ranks), int(cap), words_out_t.data_ptr(), overflow_t.data_ptr())
+
             def batch_finish(self, n_samples, gathered_t, n_ranks, ov_t, e_t, m_t, slot=0):
                 if empty:
                     e_t.zero_()
                     m_t.zero_()
-                    self._empty_gathered = (gathered_t, n_ranks, n_samples)
+                    self._empty_gathered = getattr(self, "_empty_gathered", {})
+                    self._empty_gathered[slot] = (gathered_t, n_ranks, n_samples)  # (per batch slot: ADVICE r04)
                     return
                 db.run_batch_finish_range_device(n_samples, gathered_t.data_ptr(), n_ranks, ov_t.data_ptr(), e_t.data_ptr(), m_t.data_ptr(), slot)
 
             def rows_pack(self, counts_t, vals_t, nrows_t, slot=0):
                 """vals_t [cap, 3] int32 = this rank's shares of every entry of the slot's batch; nrows_t [1] their number."""
                 if empty:  # every share is zero; the entries are those of the global subset all the same
-                    g, nr, ns = self._empty_gathered  # (rare: tests; through the host)
+                    g, nr, ns = self._empty_gathered[slot]  # (rare: tests; through the host)
                     w = np.bitwise_or.reduce(g[:nr].cpu().numpy().view(np.uint64), axis=0)
                     n = int(np.unpackbits(w.view(np.uint8)).sum())
                     nrows_t.copy_(torch.tensor([n], dtype=torch.int32))
@@ -730,9 +739,19 @@ class HashRangeRefDB:
         all_gather_into(gathered_t.view(-1), words_t.view(-1), group=self.group)
         return None
 
-    def batch_end(self, n_samples, gathered_t, counts_t, slot: int = 0):
-        self.local.batch_finish(n_samples, gathered_t, self.world, counts_t[0], counts_t[1], counts_t[2], slot)
+    def batch_end(self, n_samples, gathered_t, counts_t, slot: int = 0, n_ranks: Optional[int] = None):
+        """Second half: subset = OR of the n_ranks word rows of gathered_t (default: one per rank; 1 = a row that is already
+        the OR, what batch_words_unpack leaves)."""
+        self.local.batch_finish(n_samples, gathered_t, self.world if n_ranks is None else int(n_ranks), counts_t[0], counts_t[1],
+                                counts_t[2], slot)
         return counts_t
+
+    # the subset words of a block in compact form (include/yacht_hip.h: yh_run_batch_words_*)
+    def batch_words_pack(self, words_t, packed_t, cap: int):
+        self.local.words_pack(words_t, packed_t, cap)
+
+    def batch_words_unpack(self, gathered_t, cap: int, words_out_t, overflow_t):
+        self.local.words_unpack(gathered_t, self.world if self.has_exchange else 1, cap, words_out_t, overflow_t)
 
     def run_batch(self, samples, counts_t=None):
         """Up to 64 samples in one pass: this rank's share of the [3, B, N_total] counts (sum them with reduce())."""
@@ -790,8 +809,9 @@ class BatchRowsReducer:
     send(b, n_samples, counts_t, slot)   behind hr.batch_end(.., slot): pack + ONE reduce of cap * 12 bytes (asynchronous
                                          on RCCL)
     finish(b) -> (rows, dense)           rows: [n, 5] int32 tensor (sample, ref, overlap, n_excl, n_match) on `dst` (on
-                                         every rank when dst is None), None elsewhere; dense: the summed [3, B, N] block
-                                         instead, when the block had more entries than the collective carried
+                                         every rank when dst is None), None elsewhere -- a view of buffer b's own row
+                                         array, untouched until the next finish(b) of the same b; dense: the summed
+                                         [3, B, N] block instead, when the block had more entries than the collective carried
     Call finish(b) before the batch slot and the counts of block b are used again."""
 
     def __init__(self, hr: "HashRangeRefDB", batch: int, dst: Optional[int] = 0, nbuf: int = 3, cap_rows: Optional[int] = None):
@@ -799,11 +819,11 @@ class BatchRowsReducer:
 
         self.hr, self.dst, self.nbuf = hr, dst, int(nbuf)
         self.B = int(batch)
-        self.cap = int(cap_rows) if cap_rows else min(512 * self.B, self.B * hr.n_total)  # (B * N entries at most)
+        self.cap = int(cap_rows) if cap_rows else min(384 * self.B, self.B * hr.n_total)  # (B * N entries at most)
         self.dev = hr.dev
         self._alloc = 0
         self.vals = [None] * self.nbuf
-        self.rows = None
+        self.rows = [None] * self.nbuf
         self.nrows_dev = [torch.zeros(1, dtype=torch.int32, device=self.dev) for _ in range(self.nbuf)]
         pin = self.dev.type == "cuda"
         self.nrows_host = [torch.zeros(1, dtype=torch.int32).pin_memory() if pin else torch.zeros(1, dtype=torch.int32)
@@ -824,7 +844,11 @@ class BatchRowsReducer:
         for b in range(self.nbuf):
             if self.state[b] is None:
                 self.vals[b] = torch.zeros((self._alloc, 3), dtype=torch.int32, device=self.dev)
-        self.rows = torch.zeros((self._alloc, 5), dtype=torch.int32, device=self.dev)
+        # one row buffer per in-flight block (a caller may still be reading block b's rows -- e.g. through a
+        # non-blocking D2H copy -- when the next block is finished); a buffer in use keeps its old size until it is free
+        for b in range(self.nbuf):
+            if self.state[b] is None:
+                self.rows[b] = torch.zeros((self._alloc, 5), dtype=torch.int32, device=self.dev)
         self._nrows_unpack = torch.zeros(1, dtype=torch.int32, device=self.dev)
 
     def _is_dst(self) -> bool:
@@ -879,10 +903,12 @@ class BatchRowsReducer:
             return None, (dense if self._is_dst() else None)
         if not self._is_dst():
             return None, None
-        if self.rows.shape[0] < cap:
-            self._grow()
-        self.hr.local.rows_unpack(self.vals[b][:cap], self.rows[:cap], self._nrows_unpack, slot)
-        return self.rows[:n], None
+        if self.rows[b] is None or self.rows[b].shape[0] < cap:
+            import torch
+
+            self.rows[b] = torch.zeros((max(self._alloc, cap), 5), dtype=torch.int32, device=self.dev)
+        self.hr.local.rows_unpack(self.vals[b][:cap], self.rows[b][:cap], self._nrows_unpack, slot)
+        return self.rows[b][:n], None  # (block b's own buffer: valid until finish(b) of a LATER block in the same buffer)
 
     @staticmethod
     def rows_to_dense(rows_t, n_samples: int, n_refs: int):
@@ -895,3 +921,184 @@ class BatchRowsReducer:
             for k in range(3):
                 out[k, s_, r_] = rows_t[:, 2 + k]
         return out
+
+
+# ======================================================================================================
+# The batched hash-range run as ONE object: blocks of <= 64 samples through three batch slots
+# ======================================================================================================
+def words_packed_len(cap: int) -> int:
+    """int64 words of a packed subset-word buffer of capacity `cap` (include/yacht_hip.h: yh_run_batch_words_packed_len)."""
+    return 1 + int(cap) + (int(cap) + 1) // 2
+
+
+class BatchedRangeRunner:
+    """The throughput form of `yacht run` over hash-range shards, driven block by block.
+
+    Per block (<= 64 distinct samples, packed once with hr.pack_batch): first half (lookups of this rank's slices) -> the
+    block's subset words leave in ONE all-gather -- in compact form: a rank's NON-ZERO (word, reference) entries,
+    12 * cap_words + 8 bytes instead of 8 * N (a block of 64 samples overlaps ~15 000 of 85 205 references) -> second half
+    (subset = OR over the ranks, exclusive pass) -> the block's result leaves as compact rows (BatchRowsReducer: ONE
+    sum-reduce of 12 * cap_rows bytes).  `nbuf` blocks rotate through the library's batch slots: while the words of block
+    j travel, the second half of block j - 1 runs and its rows leave; block j - nbuf's entry count and overflow flag are
+    read back before its slot is reused -- the only host synchronisation, one block of queued work behind the GPU.
+
+    Both collectives have a FIXED size that every rank must know before the entry counts exist; a block that did not fit
+    (the same verdict on every rank: every rank sees every rank's count) is repeated synchronously -- words with capacity
+    N, rows through the dense reduce -- and the capacities grow for the blocks that follow.
+
+    submit(batch, n_samples, tag)  queue a block (batch = hr.pack_batch(..)); may deliver earlier blocks' results
+    drain()                        finish everything queued
+    Results arrive in submission order through on_result(tag, n_samples, rows, dense): on rank `dst` (every rank when
+    dst is None) rows = [n, 5] int32 (sample, ref, overlap, n_excl, n_match) or, after a rows overflow, dense = the
+    summed [3, B, N] block; (None, None) elsewhere.  No reference counterpart (run_YACHT.py:150: one sample per process)."""
+
+    def __init__(self, hr: "HashRangeRefDB", batch: int = 64, dst: Optional[int] = 0, nbuf: int = 3, cap_rows: Optional[int] = None,
+                 cap_words: Optional[int] = None, compact_words: bool = True, dense_rows: bool = False, on_result=None,
+                 async_collectives: bool = True):
+        import torch
+
+        assert 1 <= batch <= 64 and 1 <= nbuf <= 3, "the library has YH_BATCH_SLOTS = 3 batch slots of <= 64 samples"
+        self.hr, self.B, self.nbuf, self.dst = hr, int(batch), int(nbuf), dst
+        self.dev = dev = hr.dev
+        N = hr.n_total
+        self.compact_words = bool(compact_words)
+        self.dense_rows = bool(dense_rows)
+        self.cap_words = max(1, min(int(cap_words) if cap_words else 320 * self.B, max(N, 1)))
+        self.on_result = on_result
+        self.async_collectives = bool(async_collectives) and dev.type == "cuda" and hr.has_exchange and not _is_gloo(hr.group)
+        self.red = None if self.dense_rows else BatchRowsReducer(hr, batch=self.B, dst=dst, nbuf=self.nbuf, cap_rows=cap_rows)
+        self.counts = [torch.zeros((3, self.B, N), dtype=torch.int32, device=dev) for _ in range(self.nbuf)]
+        self.words = [torch.zeros(N, dtype=torch.int64, device=dev) for _ in range(self.nbuf)]
+        self.words_or = [torch.zeros((1, N), dtype=torch.int64, device=dev) for _ in range(self.nbuf)]
+        self.gath_dense = [None] * self.nbuf   # [world, N] int64, made on first use (dense exchange only)
+        self.packed = [None] * self.nbuf       # this rank's packed words / the all-gathered ones, sized for the cap in use
+        self.gath_packed = [None] * self.nbuf
+        self.ovf_dev = [torch.zeros(1, dtype=torch.int32, device=dev) for _ in range(self.nbuf)]
+        pin = dev.type == "cuda"
+        self.ovf_host = [torch.zeros(1, dtype=torch.int32).pin_memory() if pin else torch.zeros(1, dtype=torch.int32)
+                         for _ in range(self.nbuf)]
+        self.ev = [torch.cuda.Event() if pin else None for _ in range(self.nbuf)]
+        self.inflight = [None] * self.nbuf     # (seq, tag, n_samples, batch, pending dense reduce)
+        self.prev = None                       # first half queued, words travelling: (seq, tag, n_samples, batch, work, cap)
+        self.seq = 0
+        self.n_words_overflow = 0
+        self.bytes_words = 0                   # what this rank put into the word exchanges so far
+        self.last_result = None
+
+    # ---- what a block puts on the wire ----------------------------------------------------------------
+    def collective_bytes(self) -> dict:
+        N = self.hr.n_total
+        w = 8 * words_packed_len(self.cap_words) if self.compact_words else 8 * N
+        r = 3 * self.B * N * 4 if self.red is None else 12 * self.red.cap
+        return {"subset_words_all_gather": w, "subset_words_dense_form": 8 * N, "subset_words_capacity": self.cap_words if self.compact_words else None,
+                "result": r, "result_dense_form": 3 * self.B * N * 4, "result_capacity_rows": None if self.red is None else self.red.cap,
+                "total": w + r}
+
+    def _exchange(self, b: int, cap: int, sync: bool = False):
+        import torch
+
+        hr = self.hr
+        if not self.compact_words:
+            if self.gath_dense[b] is None:
+                self.gath_dense[b] = torch.zeros((hr.world, hr.n_total), dtype=torch.int64, device=self.dev)
+            self.bytes_words += 8 * hr.n_total
+            return hr.batch_exchange(self.words[b], self.gath_dense[b], async_op=self.async_collectives and not sync)
+        L = words_packed_len(cap)
+        if self.packed[b] is None or self.packed[b].numel() != L:
+            self.packed[b] = torch.zeros(L, dtype=torch.int64, device=self.dev)
+            self.gath_packed[b] = torch.zeros((hr.world, L), dtype=torch.int64, device=self.dev)
+        hr.batch_words_pack(self.words[b], self.packed[b], cap)
+        self.bytes_words += 8 * L
+        return hr.batch_exchange(self.packed[b], self.gath_packed[b], async_op=self.async_collectives and not sync)
+
+    def _second_half(self, seq, tag, n_in, batch, work, cap):
+        hr = self.hr
+        b = seq % self.nbuf
+        if work is not None:
+            work.wait()
+        if self.compact_words:
+            hr.batch_words_unpack(self.gath_packed[b], cap, self.words_or[b], self.ovf_dev[b])
+            hr.batch_end(n_in, self.words_or[b], self.counts[b], slot=b, n_ranks=1)
+            self.ovf_host[b].copy_(self.ovf_dev[b], non_blocking=True)
+        else:
+            hr.batch_end(n_in, self.gath_dense[b], self.counts[b], slot=b)
+        pend = None
+        if self.red is not None:
+            self.red.send(b, n_in, self.counts[b], slot=b)  # (its event, recorded behind the count's copy, covers the flag's copy too)
+        else:
+            import torch.distributed as dist
+
+            if self.ev[b] is not None:
+                self.ev[b].record()
+            if hr.has_exchange:
+                if self.async_collectives:
+                    pend = dist.reduce(self.counts[b], dst=self.dst, op=dist.ReduceOp.SUM, group=hr.group, async_op=True) if self.dst is not None \
+                        else dist.all_reduce(self.counts[b], op=dist.ReduceOp.SUM, group=hr.group, async_op=True)
+                else:
+                    self.counts[b].copy_(hr.reduce(self.counts[b], dst=self.dst))
+        self.inflight[b] = (seq, tag, n_in, batch, pend)
+
+    def _is_dst(self) -> bool:
+        return self.dst is None or self.hr.rank == self.dst
+
+    def _finish(self, b: int):
+        if self.inflight[b] is None:
+            return
+        seq, tag, n_in, batch, pend = self.inflight[b]
+        self.inflight[b] = None
+        rows = dense = None
+        if self.red is not None:
+            rows, dense = self.red.finish(b)  # (waits for the block's event: the overflow flag has landed too)
+        else:
+            if pend is not None:
+                pend.wait()
+            if self.ev[b] is not None:
+                self.ev[b].synchronize()
+            dense = self.counts[b] if self._is_dst() else None
+        if self.compact_words and int(self.ovf_host[b].item()) != 0:
+            # Some rank had more non-zero words than the exchange carried: the subset of this block was incomplete on every
+            # rank, and every rank knows (the flag is made from all ranks' counts).  Repeat the block here, synchronously,
+            # with a capacity nothing can exceed, and give the following blocks a larger one.
+            self.n_words_overflow += 1
+            N = max(self.hr.n_total, 1)
+            self.cap_words = min(N, max(2 * self.cap_words, 1024))
+            rows, dense = self._redo(b, n_in, batch, N)
+        self.last_result = (tag, n_in, rows, dense)
+        if self.on_result is not None:
+            self.on_result(tag, n_in, rows, dense)
+
+    def _redo(self, b: int, n_in: int, batch, cap: int):
+        hr = self.hr
+        hr.batch_begin(batch, self.counts[b], self.words[b], slot=b)
+        w = self._exchange(b, cap, sync=True)
+        if w is not None:
+            w.wait()
+        hr.batch_words_unpack(self.gath_packed[b], cap, self.words_or[b], self.ovf_dev[b])
+        hr.batch_end(n_in, self.words_or[b], self.counts[b], slot=b, n_ranks=1)
+        self.packed[b] = self.gath_packed[b] = None  # (sized for `cap`: the next block makes its own)
+        if self.red is not None:
+            self.red.send(b, n_in, self.counts[b], slot=b)
+            return self.red.finish(b)
+        dense = hr.reduce(self.counts[b], dst=self.dst)
+        return None, (dense if self._is_dst() else None)
+
+    def submit(self, batch, n_samples: int, tag=None):
+        assert 1 <= n_samples <= self.B
+        seq = self.seq
+        self.seq += 1
+        b = seq % self.nbuf
+        self._finish(b)  # block seq - nbuf: its slot, its counts and its buffers are free again
+        self.hr.batch_begin(batch, self.counts[b], self.words[b], slot=b)
+        cap = self.cap_words
+        work = self._exchange(b, cap)
+        if self.prev is not None:  # ... and behind this block's first half: the second half of the previous one
+            self._second_half(*self.prev)
+        self.prev = (seq, tag, n_samples, batch, work, cap)
+
+    def drain(self):
+        if self.prev is not None:
+            self._second_half(*self.prev)
+            self.prev = None
+        order = sorted((q for q in range(self.nbuf) if self.inflight[q] is not None), key=lambda q: self.inflight[q][0])
+        for b in order:  # (oldest block first: the same order on every rank)
+            self._finish(b)

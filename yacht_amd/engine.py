@@ -239,6 +239,16 @@ class RefDB:
         _lib.check(self._lib.yh_run_batch_rows_unpack_device(self._h, slot, C.c_void_p(d_vals), cap_rows, C.c_void_p(d_rows),
                                                              C.c_void_p(d_n_rows)))
 
+    # the subset words of a block in compact form: what a hash-range rank all-gathers between the two halves
+    def run_batch_words_pack_device(self, d_words: int, d_packed: int, cap_words: int) -> None:
+        """d_packed [words_packed_len(cap_words)] uint64 = count, the non-zero words of d_words [N], their reference ids."""
+        _lib.check(self._lib.yh_run_batch_words_pack_device(self._h, C.c_void_p(d_words), C.c_void_p(d_packed), cap_words))
+
+    def run_batch_words_unpack_device(self, d_gathered: int, n_ranks: int, cap_words: int, d_words_out: int, d_overflow: int) -> None:
+        """d_words_out [N] uint64 = OR of the n_ranks packed buffers at d_gathered; d_overflow [1] uint32 = some rank overflowed."""
+        _lib.check(self._lib.yh_run_batch_words_unpack_device(self._h, C.c_void_p(d_gathered), n_ranks, cap_words,
+                                                              C.c_void_p(d_words_out), C.c_void_p(d_overflow)))
+
     def run_submit(self, slot: int, sample: np.ndarray, overlap: np.ndarray, n_excl: np.ndarray,
                    n_match: np.ndarray) -> None:
         """Queue one `yacht run` count call (upload, ordering check, kernels, download) without waiting;
