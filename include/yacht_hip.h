@@ -116,6 +116,11 @@ int yh_device_count(int* n_devices);
  * now and then takes seconds: profiles/r04/malloc_probe.txt), and the bytes the cache holds idle now.  Any pointer
  * may be NULL.  No GPU needed. */
 int yh_alloc_stats(uint64_t* n_driver_allocs, double* ms_in_driver, uint64_t* bytes_idle);
+/* The cache keeps idle blocks up to a sixth of the device's memory, and never more than half of (free + cached) -- or
+ * YH_POOL_KEEP=<bytes> from the environment -- trimmed at the end of every create / destroy.  yh_pool_release gives ALL
+ * idle blocks back to the driver now (for a caller that is about to need the memory elsewhere: torch, RCCL, another
+ * process; e.g. on an out-of-memory error of its own); *bytes_released may be NULL.  Handles in use are not touched.   */
+int yh_pool_release(uint64_t* bytes_released);
 
 /* ---- database handle ------------------------------------------------------------------ */
 /* Upload a CSR reference database to `device_id`, validate ordering, and build what the queries read: the

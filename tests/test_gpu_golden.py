@@ -307,6 +307,27 @@ def test_cli_train_then_run_end_to_end(hip_lib, tmp_path):
                    for x, y in zip(a, b)), c
 
 
+def test_cli_train_reads_an_archive_the_native_reader_refuses(hip_lib, tmp_path, caplog):
+    """`yacht train` on an archive whose members use a compression method the one-pass native reader does not
+    know (bzip2) falls back to Python's zipfile by itself -- the same manifest as on the archive sourmash wrote."""
+    from yacht_amd import cli
+
+    src = os.path.join(FX, "20_genomes_sketches.zip")
+    odd = tmp_path / "bz.zip"
+    with zipfile.ZipFile(src) as z, zipfile.ZipFile(odd, "w") as out:
+        for i in z.infolist():
+            out.writestr(i.filename, z.read(i.filename), compress_type=zipfile.ZIP_BZIP2 if i.filename.endswith(".sig.gz") else zipfile.ZIP_STORED)
+    mans = []
+    for name, ref in (("plain", src), ("bz", str(odd))):
+        o = tmp_path / name
+        o.mkdir()
+        assert cli.main(["train", "--ref_file", ref, "--ksize", "31", "--prefix", "p", "--ani_thresh", "0.95", "--outdir", str(o),
+                         "--num_threads", "2", "--force"]) == 0
+        mans.append(pd.read_csv(o / "p_processed_manifest.tsv", sep="\t").sort_values("md5sum").reset_index(drop=True))
+        assert (o / "p_intermediate_files" / "signatures" / "04212e93c2172d4df49dc5d8c2973d8b.sig").stat().st_size > 291
+    assert len(mans[0]) == 20 and mans[0].equals(mans[1])
+
+
 def test_train_config3_at_full_size_equals_the_genuine_reference(hip_lib):
     """BASELINE configs[3] at its real size -- 10 000 sketches, 5e7 hashes -- through yh_db_create / yh_pairwise /
     yh_train_select against what the genuine reference executable (oracle/_ref, `-t 8 -c 0.95**31`) wrote for the same

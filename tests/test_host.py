@@ -4,6 +4,7 @@ import ctypes
 import json
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -441,6 +442,105 @@ def test_zip_ingest_one_pass_equals_the_three_passes(tmp_path):
         utils.ingest_zip_database(os.path.join(FX, "test_collect_signature_info_data.json"), str(tmp_path / "w4"), 31, 2)
 
 
+def test_zip_ingest_refuses_corrupt_archives_without_taking_the_process_down(tmp_path):
+    """ADVICE r04 on the native archive reader: (1) a member whose bytes no longer match the CRC-32 of the central directory
+    is refused (Python's zipfile raises BadZipFile there) although it still inflates; (2) end records that claim 2^60
+    entries / a central directory larger than the file come back as an error code -- no bad_alloc through extern "C", no
+    std::terminate in the extraction thread; (3) an archive with bytes put in front of it (every stated offset shifted) is
+    read like Python's zipfile reads it; (4) a compression method the reader does not know is an error code -- and
+    `yacht train` then reads the archive with Python's zipfile by itself."""
+    import struct
+    import subprocess
+    import zipfile
+
+    from yacht_amd import train_core
+
+    src = os.path.join(FX, "20_genomes_sketches.zip")
+    want = json.load(open(os.path.join(FX, "test_collect_signature_info_data.json")))
+    raw = bytearray(open(src, "rb").read())
+    with zipfile.ZipFile(src) as z:
+        infos = z.infolist()
+    victim = next(i for i in infos if i.filename.endswith(".sig.gz"))
+    # (1) one payload byte of a stored member flipped, inside the gzip stream's 8-byte trailer-free part: pick a byte of
+    # the deflate data whose change still inflates for SOME members -- whatever it does, the CRC of the zip member differs
+    data_off = victim.header_offset + 30 + len(victim.filename.encode()) + struct.unpack("<H", raw[victim.header_offset + 28: victim.header_offset + 30])[0]
+    bad = bytearray(raw)
+    bad[data_off + victim.compress_size // 2] ^= 0x01
+    p1 = tmp_path / "crc.zip"
+    p1.write_bytes(bad)
+    with pytest.raises(zipfile.BadZipFile):
+        with zipfile.ZipFile(p1) as z:
+            z.read(victim.filename)
+    with pytest.raises(_lib.YachtHipError):
+        utils.ingest_zip_database(str(p1), str(tmp_path / "w1"), 31, 3, write_files=False)
+    train_core.drop_parsed_sketches()
+    bg = utils.BackgroundExtraction(str(p1), str(tmp_path / "w1b"), 2)
+    with pytest.raises(_lib.YachtHipError):
+        bg.wait()
+    # (2) forged end records.  Plain end record: entry count / directory size / offset fields
+    eocd = raw.rfind(b"PK\x05\x06")
+    for field_off, value in ((12, 0x7fffffff), (16, 0x7ffffff0)):
+        f = bytearray(raw)
+        f[eocd + field_off: eocd + field_off + 4] = struct.pack("<I", value)
+        q = tmp_path / f"forged_{field_off}.zip"
+        q.write_bytes(f)
+        with pytest.raises(_lib.YachtHipError):
+            utils.ingest_zip_database(str(q), str(tmp_path / "wf"), 31, 2, write_files=False)
+        train_core.drop_parsed_sketches()
+    # ... and a zip64 pair that claims 2^60 entries in a 2^61-byte directory (built by hand behind the real directory)
+    cd_size, cd_off = struct.unpack("<II", raw[eocd + 12: eocd + 20])
+    z64 = struct.pack("<IQHHIIQQQQ", 0x06064b50, 44, 45, 45, 0, 0, 1 << 60, 1 << 60, 1 << 61, cd_off)
+    loc = struct.pack("<IIQI", 0x07064b50, 0, cd_off + cd_size, 1)
+    end = struct.pack("<IHHHHIIH", 0x06054b50, 0, 0, 0xffff, 0xffff, 0xffffffff, 0xffffffff, 0)
+    q = tmp_path / "forged_zip64.zip"
+    q.write_bytes(bytes(raw[:eocd]) + z64 + loc + end)
+    # (in a child process: what used to happen here was std::terminate -- the interpreter gone, not an exception)
+    code = ("import sys; sys.path.insert(0, %r)\nfrom yacht_amd import utils, _lib\n"
+            "for how in ('ingest', 'extract'):\n"
+            "    try:\n"
+            "        if how == 'ingest': utils.ingest_zip_database(%r, %r, 31, 2, write_files=False)\n"
+            "        else: utils.BackgroundExtraction(%r, %r, 2).wait()\n"
+            "        print(how, 'accepted')\n"
+            "    except _lib.YachtHipError as e:\n"
+            "        print(how, 'refused')\n" % (ROOT, str(q), str(tmp_path / "wz"), str(q), str(tmp_path / "wz2")))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.split() == ["ingest", "refused", "extract", "refused"], r.stdout + r.stderr[-2000:]
+    # (3) 1 000 bytes in front of the archive: Python reads it (offsets are taken relative to the directory's real place)
+    pre = tmp_path / "prefixed.zip"
+    pre.write_bytes(b"#!stub\n" + b"x" * 993 + bytes(raw))
+    with zipfile.ZipFile(pre) as z:
+        assert z.testzip() is None
+    info = utils.ingest_zip_database(str(pre), str(tmp_path / "w3"), 31, 3, write_files=False)
+    train_core.drop_parsed_sketches()
+    assert {k: [v[0], v[1], v[2], v[3]] for k, v in info.items()} == want
+    # (4) a method the native reader does not know (bzip2): an error code from the library ...
+    odd = tmp_path / "bz.zip"
+    with zipfile.ZipFile(src) as z, zipfile.ZipFile(odd, "w") as out:
+        for i in z.infolist():
+            out.writestr(i.filename, z.read(i.filename), compress_type=zipfile.ZIP_BZIP2 if i.filename.endswith(".sig.gz") else zipfile.ZIP_STORED)
+    with pytest.raises(_lib.YachtHipError):
+        utils.ingest_zip_database(str(odd), str(tmp_path / "w4"), 31, 2, write_files=False)
+    train_core.drop_parsed_sketches()
+    # ... and a stale offer of another working directory is not taken for this one's file list (ADVICE r04, utils.py:364)
+    utils.ingest_zip_database(src, str(tmp_path / "elsewhere"), 31, 2)
+    assert train_core.parsed_paths() is not None
+    wd = tmp_path / "here"
+    (wd / "signatures").mkdir(parents=True)
+    listed = []
+    orig_run = train_core.run
+    try:
+        def fake_run(file_list, *a, **k):
+            listed.extend(open(file_list).read().split())
+            raise RuntimeError("stop here")
+        train_core.run = fake_run
+        (wd / "signatures" / "only.sig").write_text("[]")
+        with pytest.raises(ValueError, match="stop here"):
+            utils.run_yacht_train_core(1, 0.95, 31, str(wd), {})
+    finally:
+        train_core.run = orig_run
+    assert listed == [str(wd / "signatures" / "only.sig")] and train_core.parsed_paths() is None
+
+
 def test_sample_archive_through_the_native_scanner_equals_the_python_reader(tmp_path):
     """utils.load_signature_with_ksize reads a one-signature archive -- a sample -- through the library's scanner
     (yh_zip_sig_ingest): the same name, md5, sizes, mins, mean abundance and (lazily) abundances as the general reader,
@@ -493,3 +593,10 @@ def test_path_lists_are_what_the_reference_writes(tmp_path):
     _write_path_list(str(tmp_path / "mine.txt"), paths)
     pd.DataFrame(paths).to_csv(tmp_path / "theirs.txt", header=False, index=False)
     assert (tmp_path / "mine.txt").read_bytes() == (tmp_path / "theirs.txt").read_bytes()
+
+
+def test_pool_release_is_exported_and_harmless_without_a_gpu():
+    """yh_pool_release exists (idle blocks of the device buffer cache back to the driver on demand); with nothing
+    cached -- and no GPU -- it releases zero bytes."""
+    assert _lib.pool_release() == 0
+    assert _lib.alloc_stats()["bytes_idle"] == 0

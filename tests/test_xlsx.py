@@ -88,3 +88,28 @@ def test_pandas_reads_it_when_openpyxl_is_there(tmp_path):
     df = pd.read_excel(path)  # first sheet, as the reference's test reads it
     assert list(df.columns) == list(tables[0][1].columns) and len(df) == 4
     assert str(df["in_sample_est"].values[0]) == "True" and df["num_matches"].values[0] == 2
+
+
+def test_nullable_extension_dtypes_with_missing_values(tmp_path):
+    """pandas' nullable Int64 / UInt64 / boolean / string columns report numpy-like kinds while their values
+    hold pd.NA: such a column must not take the per-dtype fast path (it wrote `<v><NA></v>` -- a workbook nobody can open).
+    NA = an empty cell, every part stays well-formed XML, the other values round-trip."""
+    df = pd.DataFrame({
+        "name": pd.array(["a", None, "c"], dtype="string"),
+        "count": pd.array([1, pd.NA, 3], dtype="Int64"),
+        "big": pd.array([2 ** 40 + 5, 7, pd.NA], dtype="UInt64"),
+        "flag": pd.array([True, pd.NA, False], dtype="boolean"),
+        "plain": np.array([10, 20, 30], dtype=np.int64),
+    })
+    path = str(tmp_path / "nullable.xlsx")
+    xlsx.write_xlsx(path, [("s", df)])
+    with zipfile.ZipFile(path) as z:
+        for n in z.namelist():
+            if n.endswith(".xml") or n.endswith(".rels"):
+                ET.fromstring(z.read(n))  # well-formed
+        assert b"NA" not in z.read("xl/worksheets/sheet1.xml")
+    got = xlsx.read_xlsx(path)["s"]
+    assert got["count"].tolist()[0] == 1 and np.isnan(got["count"].tolist()[1]) and got["count"].tolist()[2] == 3
+    assert int(got["big"].tolist()[0]) == 2 ** 40 + 5 and np.isnan(got["big"].tolist()[2])
+    assert got["flag"].tolist()[0] is True or got["flag"].tolist()[0] == True  # noqa: E712
+    assert got["plain"].tolist() == [10, 20, 30]

@@ -86,6 +86,7 @@ _vp = C.c_void_p
 SIGNATURES = {
     "yh_last_error": (C.c_char_p, []),
     "yh_abi_version": (C.c_int, []),
+    "yh_pool_release": (C.c_int, [C.POINTER(C.c_uint64)]),
     "yh_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "yh_alloc_stats": (C.c_int, [C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "yh_db_create": (C.c_int, [_vp, _vp, C.c_uint64, C.c_int, C.c_uint32, C.POINTER(_vp)]),
@@ -225,6 +226,13 @@ def device_count() -> int:
     n = C.c_int(0)
     rc = load().yh_device_count(C.byref(n))
     return n.value if rc == YH_OK else 0
+
+
+def pool_release() -> int:
+    """Give every idle block of the library's device buffer cache back to the driver (yh_pool_release): bytes released."""
+    b = C.c_uint64(0)
+    check(load().yh_pool_release(C.byref(b)))
+    return int(b.value)
 
 
 def alloc_stats() -> dict:

@@ -159,7 +159,25 @@ void yh_tfree(yh_db* db, void* p) {
 // (the handle's stream has drained) blocks it used last are anyone's now; the excess over the bar goes back to the driver
 void yh_pool_trim(yh_db* db) {
     if (!cache_on()) return;
-    static const size_t keep = [] { const char* e = yh_tune_env("YH_POOL_KEEP"); return e ? (size_t)atoll(e) : (size_t)48 << 30; }();  // (a sixth of this GPU's HBM: what a handle at GTDB scale and its build's temporaries leave behind -- 28 GB -- comes back without the driver)
+    // The bar: a SIXTH OF THE DEVICE'S MEMORY (48 GB of an MI355X's 288: what a handle at GTDB scale and its build's
+    // temporaries leave behind -- 28 GB -- comes back without the driver), never more than half of what is free right now
+    // plus what the cache already holds, so that torch / RCCL in the same process, or another process on the GPU, are not
+    // starved by blocks nobody uses; YH_POOL_KEEP=<bytes> overrides it (no tuning gate: a deployment knob),
+    // yh_pool_release() gives everything back on demand.
+    static const long long keep_env = [] { const char* e = getenv("YH_POOL_KEEP"); return e && e[0] ? atoll(e) : -1ll; }();
+    size_t keep = 0;
+    if (keep_env >= 0) {
+        keep = (size_t)keep_env;
+    } else {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); total_b = (size_t)288 << 30; free_b = total_b; }
+        size_t held_now = 0;
+        {
+            std::lock_guard<std::mutex> lk(g_cache_mu);
+            for (const CacheBlock& b : g_cache) held_now += b.bytes;
+        }
+        keep = std::min(total_b / 6, (free_b + held_now) / 2);
+    }
     std::vector<void*> drop;
     {
         std::lock_guard<std::mutex> lk(g_cache_mu);
@@ -184,6 +202,27 @@ void yh_pool_trim(yh_db* db) {
         }
     }
     for (void* q : drop) (void)hipFree(q);
+}
+
+// everything the cache holds idle goes back to the driver (blocks whose last user has not finished are waited for first)
+static uint64_t pool_release_all() {
+    std::vector<CacheBlock> drop;
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        drop.swap(g_cache);
+    }
+    uint64_t bytes = 0;
+    for (CacheBlock& b : drop) {
+        if (b.freed) {
+            (void)hipSetDevice(b.device);
+            if (hipEventSynchronize(b.freed) != hipSuccess) { (void)hipGetLastError(); (void)hipDeviceSynchronize(); }
+            std::lock_guard<std::mutex> lk(g_cache_mu);
+            cache_event_give(b.device, b.freed);
+        }
+        (void)hipFree(b.p);
+        bytes += b.bytes;
+    }
+    return bytes;
 }
 
 int yh_dmalloc(yh_db* db, void** p, size_t bytes) {
@@ -332,6 +371,11 @@ int yh_alloc_stats(uint64_t* n_driver_allocs, double* ms_in_driver, uint64_t* by
         for (const CacheBlock& c : g_cache) b += c.bytes;
         *bytes_idle = b;
     }
+    return YH_OK;
+}
+int yh_pool_release(uint64_t* bytes_released) {
+    const uint64_t b = cache_on() ? pool_release_all() : 0;
+    if (bytes_released) *bytes_released = b;
     return YH_OK;
 }
 int yh_device_count(int* n_devices) {

@@ -604,6 +604,35 @@ static int fz_finish(yh_db* db, yh_psort* ps, bool* took, bool* unsorted) {
     return YH_OK;
 }
 
+// The same through the distribution WITHOUT a first level (yh_sort.hip: k_piece_bounds / k_piece_part): no position ->
+// reference table (the pairs bring their reference), the bounds pass clears the records.
+static int fzp_begin(yh_db* db, const u64* d_offsets, u64 max_hash, yh_pieces** pc) {
+    const u64 N = db->n_refs, H = db->n_hashes;
+    *pc = nullptr;
+    int rc = yh_dmalloc(db, (void**)&db->d_fz_off, (N + 1) * sizeof(u64));
+    if (rc == YH_OK) rc = yh_dmalloc(db, (void**)&db->d_fz_rec, H * sizeof(u64));
+    if (rc == YH_OK && hipMemcpyAsync(db->d_fz_off, d_offsets, (N + 1) * sizeof(u64), hipMemcpyDeviceToDevice, db->stream) != hipSuccess) {
+        yh_set_error("copy of the offsets failed");
+        rc = YH_ERR_HIP;
+    }
+    if (rc == YH_OK) rc = yh_pc_begin(db, H, max_hash, N, db->d_fz_rec, pc);
+    if (rc != YH_OK) { yh_pc_destroy(db, *pc); *pc = nullptr; fz_drop(db); }
+    return rc;
+}
+static int fzp_finish(yh_db* db, yh_pieces* pc, const u64* d_values, bool* took, bool* unsorted) {
+    u64 totals[3] = {0, 0, 0};
+    u32* d_list = nullptr;
+    int rc = yh_pc_finish_emit(db, pc, d_values, db->d_fz_off, totals, &d_list, took, unsorted);
+    yh_pc_destroy(db, pc);
+    if (rc != YH_OK || !*took) { fz_drop(db); return rc; }
+    db->d_fz_list = d_list;
+    db->n_distinct = totals[0];
+    db->n_shared = totals[1];
+    db->n_postings = totals[2];
+    db->fz = true;
+    return YH_OK;
+}
+
 int yh_build_upload_sorted(yh_db* db, const u64* h_values, const u64* h_offsets, u64* d_values, const u64* d_offsets,
                            u64** d_sk_out, u32** d_sv_out) {
     const u64 N = db->n_refs, H = db->n_hashes;
@@ -672,7 +701,10 @@ int yh_build_upload_sorted(yh_db* db, const u64* h_values, const u64* h_offsets,
         UP_HIP(yh_tmalloc(db, (void**)&V[0], H * sizeof(u32)));
         UP_HIP(yh_tmalloc(db, (void**)&d_ids, H * sizeof(u32)));
     }
-    if (rc == YH_OK && fused) rc = fz_begin(db, d_offsets, max_last, &ps);
+    yh_pieces* pc = nullptr;
+    const bool pieces = fused && yh_pc_applicable(H, max_last, N);  // (no first level at all: the regions are read in place)
+    if (rc == YH_OK && pieces) rc = fzp_begin(db, d_offsets, max_last, &pc);
+    else if (rc == YH_OK && fused) rc = fz_begin(db, d_offsets, max_last, &ps);
     else if (rc == YH_OK && dist_sort) rc = yh_psort_begin(db, H, max_last, &ps);
     TRACE("stream, events, buffers");
     if (rc == YH_OK) rc = validate_begin(db);
@@ -708,7 +740,9 @@ int yh_build_upload_sorted(yh_db* db, const u64* h_values, const u64* h_offsets,
         UP_HIP(hipStreamWaitEvent(st, ev[c], 0));
         UP_HIP(hipEventRecord(eb[c], st));
         if (rc == YH_OK) rc = validate_refs(db, d_values, d_offsets, r0, r1);
-        if (rc == YH_OK && n && fused) {
+        if (rc == YH_OK && n && pc) {
+            rc = yh_pc_scan(db, pc, d_values, db->d_fz_off, r0, r1, n, false);  // (k_scan_refs above checked the order)
+        } else if (rc == YH_OK && n && fused) {
             rc = yh_psort_add(db, ps, d_values + e0, nullptr, n, e0);  // (the value of a pair is its position)
         } else if (rc == YH_OK && n) {
             k_fill_ref_ids<<<grid_for((r1 - r0) * WAVE, 256), 256, 0, st>>>(d_offsets + r0, r1 - r0, d_ids, (u32)r0);
@@ -734,8 +768,8 @@ int yh_build_upload_sorted(yh_db* db, const u64* h_values, const u64* h_offsets,
     if (timed_tail) UP_HIP(hipEventRecord(eb[0], st));  // (pair 0 again: the device time of the tail behind the last byte)
     if (rc == YH_OK && fused) {  // second level + the fused last pass: the handle is complete behind it (yh_build_index sees db->fz)
         bool took = false;
-        rc = fz_finish(db, ps, &took, nullptr);
-        ps = nullptr;
+        if (pc) { rc = fzp_finish(db, pc, d_values, &took, nullptr); pc = nullptr; }
+        else { rc = fz_finish(db, ps, &took, nullptr); ps = nullptr; }
         if (rc == YH_OK && !took) {  // not this sort's keys after all: the plain way, everything behind the upload
             fused = false;
             UP_HIP(yh_tmalloc(db, (void**)&K[0], H * sizeof(u64)));
@@ -780,6 +814,7 @@ int yh_build_upload_sorted(yh_db* db, const u64* h_values, const u64* h_offsets,
 #undef UP_HIP
     if (up) (void)hipStreamSynchronize(up);
     yh_psort_destroy(db, ps);
+    if (pc) { yh_pc_destroy(db, pc); pc = nullptr; if (!db->fz) fz_drop(db); }
     yh_tfree(db, d_tmp);
     yh_tfree(db, d_ids);
     if (rc != YH_OK) { yh_tfree(db, K[cur]); yh_tfree(db, V[cur]); return rc; }
@@ -872,6 +907,26 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, u64* d_
     }
 
     bool try_psort = yh_psort_applicable(H, db->max_hash);
+    if (!d_sk_pre && try_psort && fz_wanted(db) && db->max_hash != ~0ull && yh_pc_applicable(H, db->max_hash, N)) {
+        // the fused path from device memory WITHOUT a first level: bounds pass (ordering check, records cleared), the
+        // distribution of the pieces, the grouping pass
+        yh_pieces* pc = nullptr;
+        bool took = false, unsorted = false;
+        YH_TRY(fzp_begin(db, d_offsets, db->max_hash, &pc));
+        int prc = yh_pc_scan(db, pc, d_values, db->d_fz_off, 0, N, H, !db->order_checked);
+        if (prc != YH_OK) { yh_pc_destroy(db, pc); fz_drop(db); return prc; }
+        YH_TRY(fzp_finish(db, pc, d_values, &took, &unsorted));
+        if (!db->order_checked && unsorted) {
+            yh_set_error("a reference sketch is not strictly ascending (or offsets are not monotone)");
+            return YH_ERR_UNSORTED;
+        }
+        if (took) {
+            db->order_checked = true;
+            db->has_index = true;
+            TRACE("index: fused records (pieces)");
+            return YH_OK;
+        }
+    }
     if (!d_sk_pre && try_psort && fz_wanted(db) && db->max_hash != ~0ull) {  // the fused path from device memory (see fz_wanted above)
         yh_psort* fps = nullptr;
         bool took = false, unsorted = false;

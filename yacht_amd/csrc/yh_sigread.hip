@@ -305,6 +305,7 @@ namespace {
 struct ZipEntry {
     std::string name;
     uint16_t method = 0;
+    uint32_t crc = 0;
     uint64_t comp = 0, uncomp = 0, lho = 0;
 };
 inline uint16_t rd16(const unsigned char* p) { return (uint16_t)(p[0] | (p[1] << 8)); }
@@ -331,17 +332,28 @@ bool zip_directory(int fd, uint64_t fsize, std::vector<ZipEntry>* out, std::stri
         if (rd32(&buf[i]) == 0x06054b50u) { at = i; break; }
     if (at < 0) { *err = "not a zip archive (no end-of-central-directory record)"; return false; }
     uint64_t n = rd16(&buf[at + 10]), cd_size = rd32(&buf[at + 12]), cd_off = rd32(&buf[at + 16]);
+    const uint64_t eocd_pos = fsize - tail + (uint64_t)at;
+    uint64_t cd_end = eocd_pos;  // where the central directory ends: right in front of the end record (or of its zip64 pair)
     if (n == 0xffffu || cd_size == 0xffffffffu || cd_off == 0xffffffffu) {
         if (at < 20 || rd32(&buf[at - 20]) != 0x07064b50u) { *err = "zip64 locator missing"; return false; }
-        const uint64_t z64 = rd64(&buf[at - 20 + 8]);
+        // the zip64 end record sits right in front of its locator (as Python's zipfile takes it: an archive with data put in
+        // front of it has every stated offset shifted, this one too)
+        if (eocd_pos < 20 + 56) { *err = "bad zip64 end-of-central-directory record"; return false; }
+        const uint64_t z64 = eocd_pos - 20 - 56;
         unsigned char rec[56];
-        if (z64 + 56 > fsize || !pread_all(fd, rec, 56, z64) || rd32(rec) != 0x06064b50u) { *err = "bad zip64 end-of-central-directory record"; return false; }
+        if (!pread_all(fd, rec, 56, z64) || rd32(rec) != 0x06064b50u) { *err = "bad zip64 end-of-central-directory record"; return false; }
         n = rd64(rec + 32);
         cd_size = rd64(rec + 40);
         cd_off = rd64(rec + 48);
+        cd_end = z64;
     }
-    if (cd_off + cd_size > fsize) { *err = "central directory outside the file"; return false; }
-    std::vector<unsigned char> cd(cd_size);
+    // every value above is the archive's own claim: check it against the file before anything is sized by it
+    if (cd_size > cd_end || cd_off > cd_end - cd_size) { *err = "central directory outside the file"; return false; }
+    if (n > cd_size / 46) { *err = "central directory too small for its entry count"; return false; }
+    const uint64_t shift = cd_end - cd_size - cd_off;  // bytes put in front of the archive (a self-extracting stub): 0 normally
+    cd_off += shift;
+    std::vector<unsigned char> cd;
+    try { cd.resize(cd_size); } catch (...) { *err = "out of host memory for the central directory"; return false; }
     if (cd_size && !pread_all(fd, cd.data(), cd_size, cd_off)) { *err = "cannot read the central directory"; return false; }
     out->clear();
     out->reserve(n);
@@ -350,6 +362,7 @@ bool zip_directory(int fd, uint64_t fsize, std::vector<ZipEntry>* out, std::stri
         if (p + 46 > cd_size || rd32(&cd[p]) != 0x02014b50u) { *err = "bad central directory entry"; return false; }
         ZipEntry e;
         e.method = rd16(&cd[p + 10]);
+        e.crc = rd32(&cd[p + 16]);
         e.comp = rd32(&cd[p + 20]);
         e.uncomp = rd32(&cd[p + 24]);
         const uint16_t nlen = rd16(&cd[p + 28]), xlen = rd16(&cd[p + 30]), clen = rd16(&cd[p + 32]);
@@ -367,6 +380,8 @@ bool zip_directory(int fd, uint64_t fsize, std::vector<ZipEntry>* out, std::stri
             }
             x += 4 + (uint64_t)sz;
         }
+        if (e.lho > ~(uint64_t)0 - shift) { *err = "bad central directory entry"; return false; }
+        e.lho += shift;
         out->push_back(std::move(e));
         p += 46 + (uint64_t)nlen + xlen + clen;
     }
@@ -397,6 +412,7 @@ struct Deflate {
     void (*release)(void*) = nullptr;
     int (*gzip)(void*, const void*, size_t, void*, size_t, size_t*) = nullptr;
     int (*raw)(void*, const void*, size_t, void*, size_t, size_t*) = nullptr;
+    uint32_t (*crc)(uint32_t, const void*, size_t) = nullptr;
     Deflate() {
         static const bool off = [] { const char* e = yh_tune_env("YH_NO_LIBDEFLATE"); return e && e[0] == '1'; }();
         if (off) return;
@@ -406,11 +422,26 @@ struct Deflate {
         release = (void (*)(void*))dlsym(h, "libdeflate_free_decompressor");
         gzip = (int (*)(void*, const void*, size_t, void*, size_t, size_t*))dlsym(h, "libdeflate_gzip_decompress");
         raw = (int (*)(void*, const void*, size_t, void*, size_t, size_t*))dlsym(h, "libdeflate_deflate_decompress");
+        crc = (uint32_t (*)(uint32_t, const void*, size_t))dlsym(h, "libdeflate_crc32");
         if (!alloc || !release || !gzip || !raw) alloc = nullptr;
     }
     bool ok() const { return alloc != nullptr; }
 };
 const Deflate& deflate_lib() { static const Deflate d; return d; }
+// CRC-32 of a member's bytes (the central directory names it; Python's zipfile checks it on every read)
+uint32_t crc32_of(const void* p, size_t n) {
+    const Deflate& d = deflate_lib();
+    if (d.ok() && d.crc) return d.crc(0u, p, n);
+    uLong c = crc32(0L, Z_NULL, 0);
+    const unsigned char* q = (const unsigned char*)p;
+    while (n) {
+        const uInt step = (uInt)std::min<size_t>(n, (size_t)1 << 30);
+        c = crc32(c, q, step);
+        q += step;
+        n -= step;
+    }
+    return (uint32_t)c;
+}
 struct Decompressor {  // one per thread
     void* d = nullptr;
     Decompressor() { if (deflate_lib().ok()) d = deflate_lib().alloc(); }
@@ -444,15 +475,19 @@ bool gunzip_oneshot(const char* in, size_t n_in, RawBuf* out) {
 }
 
 // the bytes of one member (stored or deflated), into a raw buffer
+// (checked against the member's CRC-32 as the central directory states it: a corrupt member that still inflates is refused,
+// as Python's zipfile refuses it -- ADVICE r04)
 bool zip_member_raw(int fd, uint64_t fsize, const ZipEntry& e, RawBuf* scratch, RawBuf* out) {
     unsigned char lh[30];
-    if (e.lho + 30 > fsize || !pread_all(fd, lh, 30, e.lho) || rd32(lh) != 0x04034b50u) return false;
+    if (fsize < 30 || e.lho > fsize - 30 || !pread_all(fd, lh, 30, e.lho) || rd32(lh) != 0x04034b50u) return false;
     const uint64_t data = e.lho + 30 + rd16(lh + 26) + rd16(lh + 28);
-    if (data + e.comp > fsize) return false;
+    if (data > fsize || e.comp > fsize - data) return false;
+    if (e.comp >= ((uint64_t)1 << 32) || e.uncomp >= ((uint64_t)1 << 32)) return false;  // (a 4 GB signature: the Python route's business)
     if (e.method == 0) {
         if (!out->room(e.comp + 1)) return false;
         out->n = e.comp;
-        return e.comp == 0 || pread_all(fd, out->p, e.comp, data);
+        if (e.comp && !pread_all(fd, out->p, e.comp, data)) return false;
+        return crc32_of(out->p, out->n) == e.crc;
     }
     if (e.method != 8) return false;
     if (!scratch->room(e.comp + 1) || !out->room(e.uncomp + 1)) return false;
@@ -460,7 +495,10 @@ bool zip_member_raw(int fd, uint64_t fsize, const ZipEntry& e, RawBuf* scratch, 
     static thread_local Decompressor dec;
     if (dec.d) {
         size_t got = 0;
-        if (deflate_lib().raw(dec.d, scratch->p, e.comp, out->p, e.uncomp, &got) == 0 && got == e.uncomp) { out->n = e.uncomp; return true; }
+        if (deflate_lib().raw(dec.d, scratch->p, e.comp, out->p, e.uncomp, &got) == 0 && got == e.uncomp) {
+            out->n = e.uncomp;
+            return crc32_of(out->p, out->n) == e.crc;
+        }
     }
     z_stream z;
     memset(&z, 0, sizeof z);
@@ -473,34 +511,7 @@ bool zip_member_raw(int fd, uint64_t fsize, const ZipEntry& e, RawBuf* scratch, 
     const bool ok = rc == Z_STREAM_END && z.avail_out == 0;
     inflateEnd(&z);
     out->n = ok ? e.uncomp : 0;
-    return ok;
-}
-
-// the bytes of one member (stored or deflated)
-bool zip_member(int fd, uint64_t fsize, const ZipEntry& e, std::string* out) {
-    unsigned char lh[30];
-    if (e.lho + 30 > fsize || !pread_all(fd, lh, 30, e.lho) || rd32(lh) != 0x04034b50u) return false;
-    const uint64_t data = e.lho + 30 + rd16(lh + 26) + rd16(lh + 28);
-    if (data + e.comp > fsize) return false;
-    if (e.method == 0) {
-        out->resize(e.comp);
-        return e.comp == 0 || pread_all(fd, &(*out)[0], e.comp, data);
-    }
-    if (e.method != 8) return false;
-    std::string packed(e.comp, '\0');
-    if (e.comp && !pread_all(fd, &packed[0], e.comp, data)) return false;
-    out->resize(e.uncomp);
-    z_stream z;
-    memset(&z, 0, sizeof z);
-    if (inflateInit2(&z, -15) != Z_OK) return false;
-    z.next_in = (Bytef*)packed.data();
-    z.avail_in = (uInt)packed.size();
-    z.next_out = (Bytef*)(out->empty() ? nullptr : &(*out)[0]);
-    z.avail_out = (uInt)out->size();
-    const int rc = inflate(&z, Z_FINISH);
-    const bool ok = rc == Z_STREAM_END && z.avail_out == 0;
-    inflateEnd(&z);
-    return ok;
+    return ok && crc32_of(out->p, out->n) == e.crc;
 }
 
 // a member's path must stay inside the working directory
@@ -537,16 +548,30 @@ struct yh_zip_job {
     uint64_t n_members = 0;
 };
 
+static void zip_extract_run_impl(yh_zip_job* job, std::string zip_path, std::string root, int threads);
+// (nothing may leave a std::thread's function: an exception there is std::terminate -- the interpreter gone)
 static void zip_extract_run(yh_zip_job* job, std::string zip_path, std::string root, int threads) {
+    try {
+        zip_extract_run_impl(job, zip_path, root, threads);
+    } catch (const std::exception& ex) {
+        job->error = zip_path + ": " + ex.what();
+        job->failed.store(1);
+    } catch (...) {
+        job->error = zip_path + ": unexpected failure while extracting";
+        job->failed.store(1);
+    }
+}
+static void zip_extract_run_impl(yh_zip_job* job, std::string zip_path, std::string root, int threads) {
     const int fd = open(zip_path.c_str(), O_RDONLY);
     struct stat sb;
     if (fd < 0 || fstat(fd, &sb) != 0) { job->error = "cannot open " + zip_path; job->failed.store(1); if (fd >= 0) close(fd); return; }
+    struct FdGuard { int fd; ~FdGuard() { close(fd); } } fd_guard{fd};
     const uint64_t fsize = (uint64_t)sb.st_size;
     std::vector<ZipEntry> dir;
     std::string err;
-    if (!zip_directory(fd, fsize, &dir, &err)) { job->error = zip_path + ": " + err; job->failed.store(1); close(fd); return; }
+    if (!zip_directory(fd, fsize, &dir, &err)) { job->error = zip_path + ": " + err; job->failed.store(1); return; }
     for (const ZipEntry& e : dir)
-        if (!safe_member_name(e.name)) { job->error = "archive member outside the working directory: " + e.name; job->failed.store(1); close(fd); return; }
+        if (!safe_member_name(e.name)) { job->error = "archive member outside the working directory: " + e.name; job->failed.store(1); return; }
     job->n_members = dir.size();
     mkdirs(root);
     std::string last;
@@ -582,7 +607,6 @@ static void zip_extract_run(yh_zip_job* job, std::string zip_path, std::string r
             job->failed.store(1);
         }
     });
-    close(fd);
     if (job->failed.load() && job->error.empty()) job->error = zip_path + ": a member could not be read, inflated or written";
 }
 
@@ -613,19 +637,36 @@ int yh_zip_extract_wait(yh_zip_job* job, uint64_t* n_members) {
     return failed ? YH_ERR_INVALID_ARG : YH_OK;
 }
 
+static int zip_sig_ingest_impl(const char* zip_path, const char* out_dir, int ksize, int threads, yh_sig_meta** out);
+// (no exception crosses the C boundary: a corrupt archive that makes a vector throw is an error code, not std::terminate)
 int yh_zip_sig_ingest(const char* zip_path, const char* out_dir, int ksize, int threads, yh_sig_meta** out) {
     if (!zip_path || !out) { yh_set_error("null argument"); return YH_ERR_INVALID_ARG; }
     *out = nullptr;
+    try {
+        return zip_sig_ingest_impl(zip_path, out_dir, ksize, threads, out);
+    } catch (const std::bad_alloc&) {
+        yh_set_error("out of host memory while reading %s", zip_path);
+        return YH_ERR_OOM;
+    } catch (const std::exception& ex) {
+        yh_set_error("%s: %s", zip_path, ex.what());
+        return YH_ERR_INVALID_ARG;
+    } catch (...) {
+        yh_set_error("%s: unexpected failure", zip_path);
+        return YH_ERR_INVALID_ARG;
+    }
+}
+static int zip_sig_ingest_impl(const char* zip_path, const char* out_dir, int ksize, int threads, yh_sig_meta** out) {
     const int fd = open(zip_path, O_RDONLY);
     if (fd < 0) { yh_set_error("cannot open %s", zip_path); return YH_ERR_INVALID_ARG; }
+    struct FdGuard { int fd; ~FdGuard() { close(fd); } } fd_guard{fd};  // (closed on every way out, a thrown one included)
     struct stat sb;
-    if (fstat(fd, &sb) != 0) { close(fd); yh_set_error("cannot stat %s", zip_path); return YH_ERR_INVALID_ARG; }
+    if (fstat(fd, &sb) != 0) { yh_set_error("cannot stat %s", zip_path); return YH_ERR_INVALID_ARG; }
     const uint64_t fsize = (uint64_t)sb.st_size;
     std::vector<ZipEntry> dir;
     std::string err;
-    if (!zip_directory(fd, fsize, &dir, &err)) { close(fd); yh_set_error("%s: %s", zip_path, err.c_str()); return YH_ERR_INVALID_ARG; }
+    if (!zip_directory(fd, fsize, &dir, &err)) { yh_set_error("%s: %s", zip_path, err.c_str()); return YH_ERR_INVALID_ARG; }
     for (const ZipEntry& e : dir)
-        if (!safe_member_name(e.name)) { close(fd); yh_set_error("archive member outside the working directory: %s", e.name.c_str()); return YH_ERR_INVALID_ARG; }
+        if (!safe_member_name(e.name)) { yh_set_error("archive member outside the working directory: %s", e.name.c_str()); return YH_ERR_INVALID_ARG; }
     // the signature members, in central-directory order: "signatures/<x>.sig[.gz]"
     std::vector<uint64_t> sig_of(dir.size(), ~(uint64_t)0);
     uint64_t n_sig = 0;
@@ -634,7 +675,8 @@ int yh_zip_sig_ingest(const char* zip_path, const char* out_dir, int ksize, int 
         if (n.compare(0, 11, "signatures/") == 0 && (ends_with(n, ".sig") || ends_with(n, ".sig.gz"))) sig_of[i] = n_sig++;
     }
     yh_sig_meta* b = new (std::nothrow) yh_sig_meta;
-    if (!b) { close(fd); yh_set_error("out of host memory"); return YH_ERR_OOM; }
+    if (!b) { yh_set_error("out of host memory"); return YH_ERR_OOM; }
+    struct MetaGuard { yh_sig_meta* p; ~MetaGuard() { delete p; } } meta_guard{b};  // (released unless handed to the caller)
     b->m.resize(n_sig);
     b->rel_paths.resize(n_sig);
     b->kept = true;
@@ -724,9 +766,9 @@ int yh_zip_sig_ingest(const char* zip_path, const char* out_dir, int ksize, int 
         fprintf(stderr, "[yh ingest] %zu members, %llu signatures, %d threads: wall %.3f s; thread-seconds: read+inflate %.2f, gunzip %.2f, write %.2f, parse+md5 %.2f\n",
                 dir.size(), (unsigned long long)n_sig, threads, (now_ns() - t_begin) * 1e-9, ns_read.load() * 1e-9, ns_gunzip.load() * 1e-9,
                 ns_write.load() * 1e-9, ns_parse.load() * 1e-9);
-    close(fd);
-    if (oom.load()) { delete b; yh_set_error("out of host memory while reading %s", zip_path); return YH_ERR_OOM; }
-    if (io_failed.load()) { delete b; yh_set_error("%s: a member could not be read, inflated or written", zip_path); return YH_ERR_INVALID_ARG; }
+    if (oom.load()) { yh_set_error("out of host memory while reading %s", zip_path); return YH_ERR_OOM; }
+    if (io_failed.load()) { yh_set_error("%s: a member could not be read, inflated or written", zip_path); return YH_ERR_INVALID_ARG; }
+    meta_guard.p = nullptr;
     *out = b;
     return YH_OK;
 }

@@ -32,3 +32,16 @@ int yh_ref_table_build(yh_db* db, const u64* d_offsets, u64 n_refs, u64 H, u32* 
 void yh_psort_positions(yh_psort* s, const u32* d_ref_tab, const u64* d_offsets, u64 n_refs, u64* d_rec);
 // second level + every bucket sorted in LDS and turned into the pairwise pass's records on the spot (see yh_sort.hip)
 int yh_psort_finish_emit(yh_db* db, yh_psort* s, u64* d_rec, u64 n_refs, u64 totals[3], u32** d_list_out, bool* took_it, bool* unsorted = nullptr);
+
+// ---- the same without a first level (round 5): regions are read in place as contiguous PIECES of the ascending sketches ----
+struct yh_pieces;
+bool yh_pc_applicable(u64 H, u64 max_hash, u64 n_refs);
+// d_rec: the H records of the pairwise pass (cleared by the bounds pass on its way through)
+int yh_pc_begin(yh_db* db, u64 H, u64 max_hash, u64 n_refs, u64* d_rec, yh_pieces** out);
+// the bounds pass over the sketches [r0, r1) holding n_pairs hashes (the chunks of an upload as they arrive); check_order:
+// flag sketches that are not strictly ascending
+int yh_pc_scan(yh_db* db, yh_pieces* s, const u64* d_values, const u64* d_offsets, u64 r0, u64 r1, u64 n_pairs, bool check_order);
+// distribution into the buckets + the fused last pass; semantics of yh_psort_finish_emit.  Synchronizes the stream.
+int yh_pc_finish_emit(yh_db* db, yh_pieces* s, const u64* d_values, const u64* d_offsets, u64 totals[3], u32** d_list_out, bool* took_it,
+                      bool* unsorted = nullptr);
+void yh_pc_destroy(yh_db* db, yh_pieces* s);

@@ -31,7 +31,10 @@
 #include "yh_common.h"
 #include "yh_sort.h"
 
+#include <stdlib.h>
+
 #include <algorithm>
+#include <cmath>
 
 namespace {
 
@@ -57,6 +60,7 @@ constexpr u32 BKT_FILL = BKT_CAP / 8 * 5;      // ... and holds on average (2 56
 constexpr u32 BKT_THREADS = YH_BKT_THREADS;
 constexpr u32 BKT_ITEMS = BKT_CAP / BKT_THREADS;
 constexpr u32 BKT_SLOTS = BKT_CAP;   // fine slots of the counting sort inside a bucket (= 1 << BKT_SLOT_BITS)
+constexpr u32 TOT_LANES = 256;       // rows of the grouping pass's counters (k_bucket_group)
 constexpr u32 SLOT_MAX = 1024;       // pairs of one slot a pair ranks itself against (a hash held by that many references: 10^6 LDS reads); more: not this sort's input
 
 // The FINE slot of a hash -- floor(h * NB * S / (max_hash + 1)), S = 2^BKT_SLOT_BITS slots per bucket -- is the one linear
@@ -353,7 +357,12 @@ struct BucketArgs {
     const u32* ref_tab;
     const u64* ref_off;
     u32 inline_ok;               // reference ids fit the 21-bit fields of an inline record
-    unsigned long long* totals;  // [4] {distinct hashes, shared hashes, their pairs, pairs seen}
+    unsigned long long* totals;  // [TOT_LANES][8] {distinct hashes, shared hashes, their pairs, pairs seen, ...}: bucket b adds into row b % TOT_LANES
+                                 // (one row of four counters for all 19 600 workgroups: 78 000 atomics on ONE cache line, ~6 ns each --
+                                 // the whole 0.5 ms of this kernel at configs[3], whatever else it did: profiles/r05/ablate_group.txt)
+    u64 stride_v;                // packed pairs: elements between two buckets of in_v / list (in_k: cap_in)
+    u32 rem_bits;                // != 0: PACKED pairs (k_piece_part): in_k = low rem_bits bits of the hash | reference << rem_bits
+                                 // (inside a bucket the hashes span less than 2^rem_bits: the low bits identify them), in_v = position
 };
 
 // exclusive scan of arr[0 .. ITEMS * blockDim.x) in place, ITEMS consecutive words per thread; two barriers (the second one
@@ -537,17 +546,39 @@ __global__ void __launch_bounds__(BKT_THREADS) k_bucket_group(const BucketArgs a
     const u32 tid = threadIdx.x;
     const u64 b = (u64)(blockIdx.x & 7u) * a.per_xcd + (blockIdx.x >> 3);
     if ((blockIdx.x >> 3) >= a.per_xcd || b >= a.nb) return;
+    const u64 sv = a.stride_v ? a.stride_v : a.cap_in;
+    u64 key[BKT_ITEMS];
+    u32 val[BKT_ITEMS], rf[BKT_ITEMS], slot[BKT_ITEMS];
+#if defined(YH_GROUP_SPEC_LOADS) && YH_GROUP_SPEC_LOADS
+#pragma unroll
+    for (u32 k = 0; k < BKT_ITEMS; ++k) {
+        const u32 e = k * BKT_THREADS + tid;
+        key[k] = a.in_k[b * a.cap_in + e];
+        val[k] = a.in_v[b * sv + e];
+    }
+#endif
     if (a.cnt[b] > BKT_CAP && tid == 0) atomicOr(a.flags, 2u);
     const u32 n = min(a.cnt[b], BKT_CAP);
     if (n == 0) return;
-    u64 key[BKT_ITEMS];
-    u32 val[BKT_ITEMS], rf[BKT_ITEMS], slot[BKT_ITEMS];
 #pragma unroll
     for (u32 k = 0; k < BKT_ITEMS; ++k) {
         const u32 e = k * BKT_THREADS + tid;
         slot[k] = NONE;
-        if (e < n) { key[k] = a.in_k[b * a.cap_in + e]; val[k] = a.in_v[b * a.cap_in + e]; }
+#if defined(YH_ABLATE_GROUP) && (YH_ABLATE_GROUP & 16)  // timing-only build: not even the loads
+        if (e < n) { key[k] = b + e; val[k] = e; }
+#else
+#if !(defined(YH_GROUP_SPEC_LOADS) && YH_GROUP_SPEC_LOADS)  // (else: requested above, before the bucket's count was known)
+        if (e < n) { key[k] = a.in_k[b * a.cap_in + e]; val[k] = a.in_v[b * sv + e]; }
+#endif
+#endif
     }
+#if defined(YH_ABLATE_GROUP) && (YH_ABLATE_GROUP & 8)  // timing-only build: the loads and nothing else
+    { u64 x = 0;
+#pragma unroll
+      for (u32 k = 0; k < BKT_ITEMS; ++k) if (k * BKT_THREADS + tid < n) x += key[k] + val[k];
+      if (x == 0x123456789abcdefull) a.rec[0] = x;
+      return; }
+#endif
     for (u32 i = tid; i < BKT_CAP / 2; i += BKT_THREADS) reinterpret_cast<uint4*>(tkey)[i] = make_uint4(0u, 0u, 0u, 0u);
     for (u32 i = tid; i < BKT_CAP / 4; i += BKT_THREADS) reinterpret_cast<uint4*>(thead)[i] = make_uint4(NONE, NONE, NONE, NONE);
     if (tid < 3) tot3[tid] = 0;
@@ -559,10 +590,20 @@ __global__ void __launch_bounds__(BKT_THREADS) k_bucket_group(const BucketArgs a
         const u32 e = k * BKT_THREADS + tid;
         bool won = false;
         if (e < n) {
-            rf[k] = ref_of(val[k], a.ref_tab, a.ref_off);
+            u32 s;
+            if (a.rem_bits) {  // (uniform) the pair brings its reference; the table's key is the hash's low bits
+                rf[k] = (u32)(key[k] >> a.rem_bits);
+                key[k] &= (1ull << a.rem_bits) - 1ull;
+                s = (u32)((key[k] * 0x9E3779B97F4A7C15ull) >> (64 - BKT_SLOT_BITS));
+            } else {
+                rf[k] = ref_of(val[k], a.ref_tab, a.ref_off);
+                s = fine_of(key[k], a.lsh, a.mul_fine) & (BKT_CAP - 1u);
+            }
             eref[e] = rf[k];
             const unsigned long long k1 = key[k] + 1ull;  // (the fused path is taken only where the largest hash is below 2^64 - 1)
-            u32 s = fine_of(key[k], a.lsh, a.mul_fine) & (BKT_CAP - 1u);
+#if defined(YH_ABLATE_GROUP) && (YH_ABLATE_GROUP & 4)  // timing-only build: no table inserts
+            won = (k1 & 1ull) != 0; tkey[s] = k1; slot[k] = s; enext[e] = 0xffffu; thead[s] = e;
+#else
             for (u32 probe = 0; probe < BKT_CAP; ++probe) {
                 const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&tkey[s]), 0ull, k1);
                 if (old == 0ull) { won = true; break; }
@@ -571,6 +612,7 @@ __global__ void __launch_bounds__(BKT_THREADS) k_bucket_group(const BucketArgs a
             }
             slot[k] = s;
             enext[e] = (u16)atomicExch(&thead[s], e);  // (NONE -> 0xffff)
+#endif
         }
         c0 += (u32)__popcll(__ballot(won));
     }
@@ -586,19 +628,27 @@ __global__ void __launch_bounds__(BKT_THREADS) k_bucket_group(const BucketArgs a
         if (slot[k] != NONE) {
             u32 others[3] = {0u, 0u, 0u};
             u32 cnt = 0, rank = 0;
+#if defined(YH_ABLATE_GROUP) && (YH_ABLATE_GROUP & 2)  // timing-only build: the chain is not walked
+            cnt = enext[e] != 0xffffu ? 1u : 0u; others[0] = eref[e ^ 1u];
+#else
             for (u32 j = thead[slot[k]]; j != 0xffffu && j != NONE; j = enext[j]) {
                 if (j == e) continue;
                 if (cnt < 3) others[cnt] = eref[j];
                 ++cnt;
                 rank += j < e ? 1u : 0u;
             }
+#endif
             const u32 len = cnt + 1u;
             first = enext[e] == 0xffffu;  // (the pair that claimed the chain: one per group)
             shared = len >= 2u;
             if (shared) {
                 if (len <= 4u && a.inline_ok) {
                     const u64 r = (u64)(others[0] + 1u) | (cnt > 1 ? (u64)(others[1] + 1u) << 21 : 0ull) | (cnt > 2 ? (u64)(others[2] + 1u) << 42 : 0ull);
+#if defined(YH_ABLATE_GROUP) && (YH_ABLATE_GROUP & 1)  // timing-only build: no record stores (results wrong)
+                    if (r == 0x123456789abcdefull) a.rec[val[k]] = r;
+#else
                     if (val[k] < a.n_pos) a.rec[val[k]] = r;
+#endif
                 } else {
                     glen[k] = len;
                     grank[k] = rank;
@@ -611,8 +661,9 @@ __global__ void __launch_bounds__(BKT_THREADS) k_bucket_group(const BucketArgs a
     }
     if ((tid & 63u) == 0) { atomicAdd(&tot3[0], c0); atomicAdd(&tot3[1], c1); atomicAdd(&tot3[2], c2); }
     __syncthreads();
-    if (tid < 3 && tot3[tid]) atomicAdd(&a.totals[tid], (unsigned long long)tot3[tid]);
-    if (tid == 3) atomicAdd(&a.totals[3], (unsigned long long)n);
+    unsigned long long* trow = a.totals + (size_t)(b % TOT_LANES) * 8u;
+    if (tid < 3 && tot3[tid]) atomicAdd(&trow[tid], (unsigned long long)tot3[tid]);
+    if (tid == 3) atomicAdd(&trow[3], (unsigned long long)n);
     if (!has_list) return;  // (uniform: read behind the barrier)
     // the listed groups: the chain's first pair reserves the group's room in the bucket's list area
 #pragma unroll
@@ -624,10 +675,394 @@ __global__ void __launch_bounds__(BKT_THREADS) k_bucket_group(const BucketArgs a
 #pragma unroll
     for (u32 k = 0; k < BKT_ITEMS; ++k)
         if (slot[k] != NONE && glen[k]) {
-            const u64 start = b * BKT_CAP + thead[slot[k]];
+            const u64 start = b * sv + thead[slot[k]];
             a.list[start + grank[k]] = rf[k];
             if (val[k] < a.n_pos) a.rec[val[k]] = (1ull << 63) | ((u64)glen[k] << 40) | start;
         }
+}
+
+// The grouping pass for PACKED pairs (round 5): 32-bit table words, no chains.
+// What the chained table above costs was taken apart with timing-only builds (profiles/r05/ablate_group*.txt, sweep_spec*.txt,
+// ablate_g4*.txt): of ~500 us at configs[3], the pairs' loads WAITING FOR THE BUCKET'S COUNT ~300 (requested before the count
+// is known -- slots beyond it hold garbage nobody uses -- the kernel without any table work falls from 496 to 194 us); the
+// chain walk 155 (every pair follows its group's links: dependent LDS reads, a wave as slow as its longest chain); the
+// inserts 100; the record stores 57.  With either half gone the other still fills the time, so both change.  And what an
+// insert costs is the NUMBER OF RETURNING LDS ATOMICS A WAVE ISSUES, ~8-9 cycles each for 64-bit operands whatever the
+// active lanes (a first chain-free form kept the holders in a second 64-bit word per slot, joined by compare-and-swap: 869 us
+// -- 207 for those joins alone, 325 for the side table of its groups of more than four).  Here:
+//   ekey[e]  = the pair as it came (hash remainder | reference << rem_bits)          plain 8-byte store
+//   tidx[s]  = claimer's pair index + 1 | members that joined << 16                  32-bit: ONE compare-and-swap claims a
+//              slot or finds it taken -- then the claimer's ekey says whether it is this pair's hash (probe on if not) --
+//              and a member's rank is ONE 32-bit add
+//   tmem[s]  = the pair indices of the first three members                          plain 2-byte stores
+// Behind the barrier a pair reads its slot's word and members (independent reads), then the up to three other pairs' ekey:
+// no loop, no divergence beyond "shared or not".  Groups of more than four holders go to the bucket's list area: every
+// holder knows its rank (claimer 0, members in order of arrival), the claimer reserves the room.
+// Measured (profiles/r05/sweep_g5.txt, ablate_g5.txt): 472 us against 499 for the chained table on the same pairs; of them
+// the inserts 283 (with keys that never collide: ~100 -- the probing of a table at load 0.4-0.6, where a wave is as slow
+// as its unluckiest lane, is what is left), the reads behind the barrier 27, the record stores 24, loads + clears +
+// barriers 189.
+__global__ void __launch_bounds__(BKT_THREADS) k_bucket_group5(const BucketArgs a) {
+    __shared__ __attribute__((aligned(16))) u64 ekey[BKT_CAP];
+    __shared__ __attribute__((aligned(16))) u32 tidx[BKT_CAP];
+    __shared__ u16 tmem[BKT_CAP * 3];
+    __shared__ u32 tot3[3];
+    __shared__ u32 lcount, has_list;
+    const u32 tid = threadIdx.x;
+    const u64 b = (u64)(blockIdx.x & 7u) * a.per_xcd + (blockIdx.x >> 3);
+    if ((blockIdx.x >> 3) >= a.per_xcd || b >= a.nb) return;
+    u64 key[BKT_ITEMS];
+    u32 val[BKT_ITEMS], st[BKT_ITEMS];  // st: slot | rank << 12 (rank 0: claimed the slot; members: 1 + order of arrival)
+#pragma unroll
+    for (u32 k = 0; k < BKT_ITEMS; ++k) {  // (before the count is known: the capacity is allocated for every bucket)
+        const u32 e = k * BKT_THREADS + tid;
+#if defined(YH_ABLATE_GROUP) && (YH_ABLATE_GROUP & 16)  // timing-only build: not even the loads
+        key[k] = (b * 0x9E3779B97F4A7C15ull + e * 0x7F4A7C15ull) >> 3; val[k] = e;
+#else
+        key[k] = a.in_k[b * a.cap_in + e];
+        val[k] = a.in_v[b * a.stride_v + e];
+#endif
+    }
+    for (u32 i = tid; i < BKT_CAP / 4; i += BKT_THREADS) reinterpret_cast<uint4*>(tidx)[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (tid < 3) tot3[tid] = 0;
+    if (tid == 3) { lcount = 0; has_list = 0; }
+    const u32 c_raw = a.cnt[b];
+    if (c_raw > BKT_CAP && tid == 0) atomicOr(a.flags, 2u);
+    const u32 n = min(c_raw, BKT_CAP);
+#pragma unroll
+    for (u32 k = 0; k < BKT_ITEMS; ++k) {
+        const u32 e = k * BKT_THREADS + tid;
+        if (e < n) ekey[e] = key[k];
+    }
+    __syncthreads();
+    const u64 rmask = (1ull << a.rem_bits) - 1ull;
+    // (Measured and dropped, profiles/r05/sweep_g5q.txt: a QUEUE PER LANE -- every step a lane probes one slot for the first of
+    // its pairs that is not placed yet, so that a wave makes max-over-lanes(sum of the lane's probes) steps instead of
+    // sum-over-pairs(max-over-lanes(probes)) -- 491-499 us against 472 for the four loops below.)
+    u32 c0 = 0;
+#pragma unroll
+    for (u32 k = 0; k < BKT_ITEMS; ++k) {
+        const u32 e = k * BKT_THREADS + tid;
+        bool won = false;
+        st[k] = 0xffffffffu;
+        if (e < n) {
+            const u64 rem = key[k] & rmask;
+            u32 s = (u32)((rem * 0x9E3779B97F4A7C15ull) >> (64 - BKT_SLOT_BITS));
+            u32 rank = 0;
+#if defined(YH_ABLATE_GROUP) && (YH_ABLATE_GROUP & 4)  // timing-only build: no table inserts
+            tidx[s] = e + 1u; won = (rem & 1ull) != 0;
+            for (u32 probe = 0; probe < 0; ++probe) {
+#else
+            for (u32 probe = 0; probe < BKT_CAP; ++probe) {
+#endif
+                const u32 old = atomicCAS(&tidx[s], 0u, e + 1u);
+                if (old == 0u) { won = true; break; }
+                if ((ekey[(old & 0xffffu) - 1u] & rmask) == rem) {  // this pair's hash: join
+                    const u32 r = atomicAdd(&tidx[s], 1u << 16) >> 16;  // members in front of this one
+                    if (r < 3u) tmem[s * 3u + r] = (u16)e;
+                    rank = r + 1u;
+                    break;
+                }
+                s = (s + 1u) & (BKT_CAP - 1u);
+            }
+            st[k] = s | (rank << 12);
+        }
+        c0 += (u32)__popcll(__ballot(won));
+    }
+    __syncthreads();
+    u32 c1 = 0, c2 = 0;
+    u32 listed = 0;
+#pragma unroll
+    for (u32 k = 0; k < BKT_ITEMS; ++k) {
+        bool first = false, shared = false;
+        if (st[k] != 0xffffffffu) {
+            const u32 s = st[k] & 0xfffu, rank = st[k] >> 12;
+#if defined(YH_ABLATE_GROUP) && (YH_ABLATE_GROUP & 2)  // timing-only build: the slot is not read again
+            const u32 w = (u32)key[k] & 0x1ffffu;
+#else
+            const u32 w = tidx[s];
+#endif
+            const u32 members = w >> 16;
+            first = rank == 0u;
+            shared = members != 0u;
+            if (shared) {
+                if (members <= 3u && a.inline_ok) {
+                    // the other holders: the claimer (unless that is this pair) and the members but this one
+                    const u32 m0 = tmem[s * 3u], m1 = tmem[s * 3u + 1u], m2 = tmem[s * 3u + 2u];
+                    u32 o[3];
+                    u32 cnt = 0;
+                    if (rank != 0u) o[cnt++] = (w & 0xffffu) - 1u;
+                    if (rank != 1u) o[cnt++] = m0;
+                    if (members > 1u && rank != 2u) o[cnt++] = m1;
+                    if (members > 2u && rank != 3u) o[cnt++] = m2;
+                    // (cnt = members: one of the up to four is this pair)
+#if defined(YH_ABLATE_GROUP) && (YH_ABLATE_GROUP & 2)
+                    u64 r = m0 + m1 + m2 + o[0] + 1;
+#else
+                    u64 r = (u64)((u32)(ekey[o[0]] >> a.rem_bits) + 1u);
+                    if (cnt > 1u) r |= (u64)((u32)(ekey[o[1]] >> a.rem_bits) + 1u) << 21;
+                    if (cnt > 2u) r |= (u64)((u32)(ekey[o[2]] >> a.rem_bits) + 1u) << 42;
+#endif
+#if defined(YH_ABLATE_GROUP) && (YH_ABLATE_GROUP & 1)  // timing-only build: no record stores (results wrong)
+                    if (r == 0x123456789abcdefull) a.rec[val[k]] = r;
+#else
+                    if (val[k] < a.n_pos) a.rec[val[k]] = r;
+#endif
+                } else {
+                    listed |= 1u << k;
+                    has_list = 1u;
+                }
+            }
+        }
+        c1 += (u32)__popcll(__ballot(first && shared));
+        c2 += (u32)__popcll(__ballot(shared));
+    }
+    if ((tid & 63u) == 0) { atomicAdd(&tot3[0], c0); atomicAdd(&tot3[1], c1); atomicAdd(&tot3[2], c2); }
+    __syncthreads();
+    unsigned long long* trow = a.totals + (size_t)(b % TOT_LANES) * 8u;
+    if (tid < 3 && tot3[tid]) atomicAdd(&trow[tid], (unsigned long long)tot3[tid]);
+    if (tid == 3) atomicAdd(&trow[3], (unsigned long long)n);
+    if (!has_list) return;  // (uniform: read behind the barrier)
+    // groups of more than four holders (or any group, when references do not fit the inline fields): the claimer reserves the
+    // group's room in the bucket's list area and leaves its start where the members' indices were (nobody reads those now:
+    // every pair wrote its inline record, or found out that it has none, before the barrier above)
+#pragma unroll
+    for (u32 k = 0; k < BKT_ITEMS; ++k)
+        if (((listed >> k) & 1u) && (st[k] >> 12) == 0u) {
+            const u32 s = st[k] & 0xfffu;
+            const u32 start = atomicAdd(&lcount, 1u + (tidx[s] >> 16));
+            tmem[s * 3u] = (u16)start;  // (a bucket's list area = its capacity: 4 096 entries, 12 bits)
+        }
+    __syncthreads();
+#pragma unroll
+    for (u32 k = 0; k < BKT_ITEMS; ++k)
+        if ((listed >> k) & 1u) {
+            const u32 s = st[k] & 0xfffu, rank = st[k] >> 12, len = 1u + (tidx[s] >> 16);
+            const u64 start = b * a.stride_v + tmem[s * 3u];
+            a.list[start + rank] = (u32)(key[k] >> a.rem_bits);
+            if (val[k] < a.n_pos) a.rec[val[k]] = (1ull << 63) | ((u64)len << 40) | start;
+        }
+}
+
+// (Round 5, measured and dropped -- profiles/r05/sweep_group_w.txt: PERSISTENT workgroups, 64 per XCD, that request the next
+// bucket's pairs into registers before they group the current one, on the theory that a bucket's ~13 us are mostly the
+// latency of its loads and the drain of its stores: 667 us against 505 for one workgroup per bucket (32 per XCD: 945; 128:
+// 696) -- 64 registers with the prefetched pairs means spills, the table needs a fourth barrier before it is cleared, and
+// the hardware's own dispatch of the next workgroup into a freed slot was already hiding what there was to hide.)
+// =====================================================================================================================
+// The distribution WITHOUT a first level (round 5): `yacht train`'s handle, position mode.
+// Every sketch is ASCENDING and bucket(h) is monotone, so the hashes of sketch i that fall into first-level region r are a
+// contiguous PIECE [bnd[r][i], bnd[r + 1][i]) of the CSR: region r does not have to be written out and read again (12 B
+// out + 12 B in per pair: k_part<1> 0.45-0.53 ms + the input side of k_part<2> at configs[3]) -- it can be READ IN PLACE.
+//   k_piece_bounds   one streaming pass over the CSR (a wave per sketch, 8-byte coalesced loads): where every region starts
+//                    in every sketch (transposed through LDS into region-major rows), the ordering check, and the clearing
+//                    of the pairwise records -- 8 B read + 8 B written per pair, nothing scattered
+//   k_piece_part     a tile = (region r, a group of S sketches): their pieces of r (~36 hashes = 288 contiguous bytes each at
+//                    configs[3]) are read straight from the CSR and distributed over the region's P2 buckets exactly as
+//                    k_part<2> does it (LDS histogram, one reserving atomic per (tile, bin), staged, coalesced runs) -- as
+//                    PACKED pairs: the low rem_bits bits of the hash (inside a bucket the hashes span less than
+//                    2^rem_bits) with the REFERENCE id above them (the tile knows whose piece it reads: k_bucket_group's
+//                    position -> reference look-ups are gone), and the position.  Still 12 bytes.
+//                    All tiles of a region run on ONE XCD, consecutively (blockIdx % 8 = region % 8): the runs of a bucket
+//                    are completed in that XCD's L2 before they go to HBM.
+// Traffic per pair: 8 + 8 (bounds, clear) + 8 + 12 (distribution) against 8 + 12 + 8 and 12 + 12.
+constexpr u32 PC_MAX_S = 1023;   // sketches per tile (one thread each for the prefix of their piece lengths)
+#ifndef YH_PC_BOUND_THREADS
+#define YH_PC_BOUND_THREADS 512
+#endif
+constexpr u32 PC_BOUND_THREADS = YH_PC_BOUND_THREADS;  // (16 waves: with 4 per workgroup ~5 waves per CU had 10 KB of loads in flight each -- 1.3 TB/s)
+#ifndef YH_PC_BOUND_U
+#define YH_PC_BOUND_U 4
+#endif
+constexpr u32 PC_BOUND_U = YH_PC_BOUND_U;    // 512-byte loads a wave has in flight
+struct PieceArgs {
+    const u64* values;
+    const u64* off;      // CSR offsets [N + 1]
+    u64 n_refs;
+    u32* bnd;            // [(P1 + 1)][n_pad]: bnd[r][i] = first position of sketch i whose region is >= r (bnd[0][i] = off[i], bnd[P1][i] = off[i + 1])
+    u64 n_pad;
+    u32 P1, P2, S, Gn, SK;
+    u64 mul;
+    u32 lsh, rem_bits;
+    u32 inv_p2;          // ceil(2^32 / P2): bucket / P2 = (bucket * inv_p2) >> 32 for every bucket < NB
+    u64* rec_clear;
+    u64* out_a;          // [NB][stride_k] packed (hash remainder | reference << rem_bits)
+    u32* out_p;          // [NB][stride_v] positions
+    u64 stride_k, stride_v;  // elements between two buckets: BKT_CAP + a pad (see yh_pieces)
+    u32* out_cnt;        // [NB]
+    u32* flags;          // |= 8: a sketch is not ascending (bounds pass) or a piece holds a hash of another region
+    u32 check_order;
+};
+
+__global__ void __launch_bounds__(PC_BOUND_THREADS) k_piece_bounds(const PieceArgs a, u64 r0, u64 r1) {
+    extern __shared__ u32 bl[];  // [SK][P1 + 1]
+    const u32 lane = threadIdx.x & 63u, wv = threadIdx.x >> 6, nwv = PC_BOUND_THREADS / 64;
+    const u64 i0 = r0 + (u64)blockIdx.x * a.SK;
+    const u32 nsk = (u32)min((u64)a.SK, r1 - i0);
+    const u32 W = a.P1 + 1;
+    bool bad = false;
+    for (u32 s = wv; s < nsk; s += nwv) {  // (wave-uniform)
+        u32* row = bl + (size_t)s * W;
+        const u64 b = a.off[i0 + s], e = a.off[i0 + s + 1];
+        if (e < b) { bad = true; for (u32 r = lane; r < W; r += 64) row[r] = (u32)b; continue; }
+        u32 carry_reg = 0xffffffffu;  // region of the element in front (none yet: -1)
+        u64 carry_h = 0;
+        bool have = false;
+        for (u64 p0 = b; p0 < e; p0 += 64u * PC_BOUND_U) {
+            u64 h[PC_BOUND_U];
+#pragma unroll
+            for (u32 u = 0; u < PC_BOUND_U; ++u) {
+                const u64 p = p0 + u * 64u + lane;
+                h[u] = p < e ? a.values[p] : 0ull;
+            }
+#pragma unroll
+            for (u32 u = 0; u < PC_BOUND_U; ++u) {
+                const u64 pw = p0 + u * 64u;  // (uniform)
+                if (pw >= e) break;
+                const u64 p = pw + lane;
+                const bool in = p < e;
+                u32 reg = (u32)(((u64)bucket_of(h[u], a.lsh, a.mul) * a.inv_p2) >> 32);  // bucket / P2 (pc_geometry checks the reciprocal)
+                reg = reg >= a.P1 ? a.P1 - 1u : reg;
+                u32 up_reg = (u32)__shfl_up((int)reg, 1);
+                u64 up_h = ((u64)(u32)__shfl_up((int)(u32)(h[u] >> 32), 1) << 32) | (u32)__shfl_up((int)(u32)h[u], 1);
+                bool up_have = true;
+                if (lane == 0) { up_reg = carry_reg; up_h = carry_h; up_have = have; }
+                if (in) {
+                    if (a.rec_clear) a.rec_clear[p] = 0;
+                    if (up_have && !(up_h < h[u])) bad = true;
+                    // this element opens every region behind its predecessor's up to its own (none when the sketch is not
+                    // ascending here: flagged above)
+                    for (u32 r = up_reg + 1u; r <= reg; ++r) row[r] = (u32)p;
+                }
+                const u32 last = (u32)min((u64)63, e - pw - 1);  // (uniform) the wave's last element of this load
+                carry_reg = (u32)__shfl((int)reg, (int)last);
+                carry_h = ((u64)(u32)__shfl((int)(u32)(h[u] >> 32), (int)last) << 32) | (u32)__shfl((int)(u32)h[u], (int)last);
+                have = true;
+            }
+        }
+        for (u32 r = carry_reg + 1u + lane; r < W; r += 64) row[r] = (u32)e;  // the regions behind the last element (all of them: an empty sketch)
+    }
+    if (a.check_order && __ballot(bad) != 0ull && lane == 0) atomicOr(a.flags, 8u);
+    __syncthreads();
+    for (u32 idx = threadIdx.x; idx < W * nsk; idx += PC_BOUND_THREADS) {  // region-major rows: runs of nsk consecutive sketches
+        const u32 r = idx / nsk, s = idx % nsk;
+        a.bnd[(u64)r * a.n_pad + i0 + s] = bl[(size_t)s * W + r];
+    }
+}
+
+__global__ void __launch_bounds__(PART_THREADS) k_piece_part(const PieceArgs a) {
+    __shared__ u64 skey[PART_TILE];
+    __shared__ u32 sval[PART_TILE];
+    __shared__ u16 sbin[PART_TILE];
+    __shared__ u32 hist[PART_MAX_BINS], loc[PART_MAX_BINS], gbase[PART_MAX_BINS];
+    __shared__ u32 pre[PC_MAX_S + 1], pstart[PC_MAX_S + 1];
+    __shared__ u32 wtot[17];
+    const u32 tid = threadIdx.x;
+    const u32 k = blockIdx.x >> 3;
+    const u32 r = (blockIdx.x & 7u) + 8u * (k / a.Gn), g = k % a.Gn;  // XCD x takes the regions x, x + 8, ...: one after the other
+    if (r >= a.P1) return;
+    const u64 s0 = (u64)g * a.S;
+    const u32 ns = (u32)min((u64)a.S, a.n_refs - s0);
+    if (tid <= ns) {
+        u32 len = 0;
+        if (tid < ns) {
+            const u32 pa = a.bnd[(u64)r * a.n_pad + s0 + tid], pb = a.bnd[(u64)(r + 1) * a.n_pad + s0 + tid];
+            pstart[tid] = pa;
+            len = pb > pa ? pb - pa : 0u;
+        }
+        pre[tid] = len;
+    }
+    __syncthreads();
+    block_scan_inplace<1>(pre, ns + 1, wtot);  // pre[j] = elements of the pieces in front of j; pre[ns] = all of them
+    const u32 total = pre[ns];
+    const u64 rem_mask = (1ull << a.rem_bits) - 1ull;
+    constexpr u32 BINS_PER_THREAD = (PART_MAX_BINS + PART_THREADS - 1) / PART_THREADS;
+    bool bad = false;
+    for (u32 base = 0; base < total; base += PART_TILE) {  // (workgroup-uniform; one round unless the group's pieces outgrow a tile)
+        const u32 tile_n = min(PART_TILE, total - base);
+        for (u32 b = tid; b < a.P2; b += PART_THREADS) hist[b] = 0;
+        __syncthreads();
+        u64 key[PART_ITEMS];
+        u32 val[PART_ITEMS], bin[PART_ITEMS], rank[PART_ITEMS], pos[PART_ITEMS], who[PART_ITEMS];
+#pragma unroll
+        for (u32 q = 0; q < PART_ITEMS; ++q) {
+            const u32 e = base + q * PART_THREADS + tid;
+            pos[q] = 0xffffffffu;
+            if (e < total) {
+                u32 lo = 0, hi = ns;  // the piece of element e: the largest j with pre[j] <= e (pre[ns] = total > e)
+                while (hi - lo > 1u) {
+                    const u32 mid = (lo + hi) >> 1;
+                    if (pre[mid] <= e) lo = mid; else hi = mid;
+                }
+                who[q] = lo;
+                pos[q] = pstart[lo] + (e - pre[lo]);
+            }
+        }
+#pragma unroll
+        for (u32 q = 0; q < PART_ITEMS; ++q)
+            if (pos[q] != 0xffffffffu) key[q] = a.values[pos[q]];
+#pragma unroll
+        for (u32 q = 0; q < PART_ITEMS; ++q) {
+            bin[q] = 0xffffffffu;
+            if (pos[q] != 0xffffffffu) {
+                const u32 bk = bucket_of(key[q], a.lsh, a.mul);
+                u32 reg = (u32)(((u64)bk * a.inv_p2) >> 32);
+                reg = reg >= a.P1 ? a.P1 - 1u : reg;
+                u32 b = bk - reg * a.P2;
+                if (reg != r) { bad = true; b = 0; }  // (a sketch that is not ascending: the whole attempt is refused)
+                if (b >= a.P2) b = a.P2 - 1u;
+                bin[q] = b;
+                val[q] = pos[q];
+                key[q] = (key[q] & rem_mask) | ((u64)(s0 + who[q]) << a.rem_bits);
+                rank[q] = atomicAdd(&hist[b], 1u);
+            }
+        }
+        __syncthreads();
+        u32 g_mine[BINS_PER_THREAD], c_mine[BINS_PER_THREAD];
+#pragma unroll
+        for (u32 q = 0; q < BINS_PER_THREAD; ++q) {
+            const u32 b = q * PART_THREADS + tid;
+            g_mine[q] = 0;
+            c_mine[q] = 0;
+            if (b < a.P2) {
+                const u32 c = hist[b];
+                c_mine[q] = c;
+                if (c) g_mine[q] = atomicAdd(&a.out_cnt[(u64)r * a.P2 + b], c);
+                loc[b] = c;
+            }
+        }
+        __syncthreads();
+        block_scan_inplace<BINS_PER_THREAD>(loc, a.P2, wtot);
+#pragma unroll
+        for (u32 q = 0; q < PART_ITEMS; ++q)
+            if (bin[q] != 0xffffffffu) {
+                const u32 s = loc[bin[q]] + rank[q];
+                skey[s] = key[q];
+                sval[s] = val[q];
+                sbin[s] = (u16)bin[q];
+            }
+#pragma unroll
+        for (u32 q = 0; q < BINS_PER_THREAD; ++q) {
+            const u32 b = q * PART_THREADS + tid;
+            if (b < a.P2) gbase[b] = g_mine[q] - loc[b];
+        }
+        __syncthreads();
+#pragma unroll
+        for (u32 q = 0; q < PART_ITEMS; ++q) {
+            const u32 s = q * PART_THREADS + tid;
+            if (s < tile_n) {
+                const u32 b = sbin[s];
+                const u64 at = (u32)(gbase[b] + s);
+                if (at < BKT_CAP) {  // (an overflowing bucket is seen by k_bucket_group: its count exceeds the capacity)
+                    const u64 bkt = (u64)r * a.P2 + b;
+                    a.out_a[bkt * a.stride_k + at] = skey[s];
+                    a.out_p[bkt * a.stride_v + at] = sval[s];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (__ballot(bad) != 0ull && (tid & 63u) == 0) atomicOr(a.flags, 8u);
 }
 
 static_assert(BKT_SLOTS == (1u << BKT_SLOT_BITS), "slots per bucket");
@@ -875,9 +1310,9 @@ int yh_psort_finish_emit(yh_db* db, yh_psort* s, u64* d_rec, u64 n_refs, u64 tot
     if (!s->ref_tab) { yh_set_error("internal: the fused pass needs positions as values"); return YH_ERR_INVALID_ARG; }
     u32* cnt2 = s->cnt + s->P1;
     u32* flags = s->cnt + s->P1 + s->NB;
-    hipError_t e = yh_tmalloc(db, (void**)&s->totals, 4 * sizeof(unsigned long long));
+    hipError_t e = yh_tmalloc(db, (void**)&s->totals, TOT_LANES * 8 * sizeof(unsigned long long));
     if (e != hipSuccess) { yh_set_error("distribution sort: allocation failed: %s", hipGetErrorString(e)); return YH_ERR_OOM; }
-    YH_HIP(hipMemsetAsync(s->totals, 0, 4 * sizeof(unsigned long long), db->stream));
+    YH_HIP(hipMemsetAsync(s->totals, 0, TOT_LANES * 8 * sizeof(unsigned long long), db->stream));
     if (d_rec != s->rec_clear) { yh_set_error("internal: the records were not cleared by the first level"); return YH_ERR_INVALID_ARG; }
     YH_TRY(second_level(db, s));
     BucketArgs b{};
@@ -903,9 +1338,12 @@ int yh_psort_finish_emit(yh_db* db, yh_psort* s, u64* d_rec, u64 n_refs, u64 tot
     YH_HIP(hipGetLastError());
     u32 hflags[4] = {0, 0, 0, 0};
     unsigned long long ht[4] = {0, 0, 0, 0};
+    static thread_local unsigned long long hrows[TOT_LANES * 8];
     YH_HIP(hipMemcpyAsync(hflags, flags, 3 * sizeof(u32), hipMemcpyDeviceToHost, db->stream));
-    YH_HIP(hipMemcpyAsync(ht, s->totals, sizeof(ht), hipMemcpyDeviceToHost, db->stream));
+    YH_HIP(hipMemcpyAsync(hrows, s->totals, sizeof(hrows), hipMemcpyDeviceToHost, db->stream));
     YH_HIP(hipStreamSynchronize(db->stream));
+    for (u32 q = 0; q < TOT_LANES; ++q)
+        for (u32 t = 0; t < 4; ++t) ht[t] += hrows[q * 8 + t];
     *took_it = (hflags[0] & 7u) == 0 && ht[3] == s->fed;
     if (unsorted) *unsorted = (hflags[0] & 8u) != 0;
     say_verdict(s, hflags[0], ht[3], *took_it, "fused: records of");
@@ -913,6 +1351,182 @@ int yh_psort_finish_emit(yh_db* db, yh_psort* s, u64* d_rec, u64 n_refs, u64 tot
         totals[0] = ht[0]; totals[1] = ht[1]; totals[2] = ht[2];
         *d_list_out = s->v2;
         s->v2 = nullptr;
+    }
+    return YH_OK;
+}
+
+
+// =====================================================================================================================
+// The distribution without a first level (kernels: k_piece_bounds, k_piece_part above) -- driver
+// =====================================================================================================================
+struct yh_pieces {
+    u64 H = 0, max_hash = 0, n_refs = 0;
+    u64 NB = 0, n_pad = 0;
+    u32 P1 = 0, P2 = 0, lsh = 0, rem_bits = 0, S = 0, Gn = 0, SK = 0, inv_p2 = 0;
+    u64 mul_fine = 0;
+    // elements between two buckets of a2 / p2: the capacity + an optional pad (YH_PC_PAD; a stride of exactly 32 KB was
+    // suspected of putting every bucket's first byte on one HBM channel -- pads of 0 ... 4 352 bytes measure the same)
+    u64 stride_k = BKT_CAP, stride_v = BKT_CAP;
+    u32* bnd = nullptr;   // [(P1 + 1)][n_pad]
+    u64* a2 = nullptr;    // [NB][BKT_CAP] packed pairs
+    u32* p2 = nullptr;    // [NB][BKT_CAP] positions; afterwards the list area of the handle (yh_db::d_fz_list)
+    u32* cnt = nullptr;   // [NB] + flags[4]
+    unsigned long long* totals = nullptr;
+    u64* rec = nullptr;
+    u64 scanned = 0;      // pairs the bounds pass has seen
+};
+
+static unsigned bitlen64(u64 x) { unsigned b = 0; while (x) { ++b; x >>= 1; } return b; }
+
+// the geometry: NB buckets of ~BKT_FILL pairs = P1 regions x P2 buckets; false: not this path's input
+static bool pc_geometry(u64 H, u64 max_hash, u64 n_refs, yh_pieces* g) {
+    if (!yh_psort_applicable(H, max_hash) || n_refs == 0 || max_hash == ~0ull) return false;
+    static const double p2f = [] { const char* e = yh_tune_env("YH_PC_P2F"); return e ? atof(e) : 2.0; }();
+    static const u32 tile_elems = [] { const char* e = yh_tune_env("YH_PC_TILE_ELEMS"); return e ? (u32)atoi(e) : 3584u; }();
+    const u64 nb = std::max<u64>((H + BKT_FILL - 1) / BKT_FILL, 1);
+    u64 p2 = (u64)(p2f * std::sqrt((double)nb) + 0.5);
+    p2 = std::min<u64>(std::max<u64>(p2, 1), PART_MAX_BINS);
+    p2 = std::min<u64>(p2, nb);
+    g->P2 = (u32)p2;
+    g->P1 = (u32)((nb + p2 - 1) / p2);
+    if (g->P1 > PART_MAX_BINS) return false;
+    g->NB = (u64)g->P1 * g->P2;
+    g->inv_p2 = p2 == 1 ? 0xffffffffu : (u32)(((1ull << 32) + p2 - 1) / p2);
+    // floor(b * ceil(2^32 / P2) / 2^32) == b / P2 needs b * (P2 - 2^32 mod P2) < 2^32: true below 2^22 for P2 <= 1024; checked anyway
+    if (p2 > 1 && (g->NB - 1) * (u64)((u64)g->inv_p2 * p2 - (1ull << 32)) >= (1ull << 32)) return false;
+    if (p2 == 1) return false;  // (one bucket per region: a database this small goes the two-level way)
+    unsigned bits = 1;
+    while (bits < 64 && (max_hash >> bits) != 0) ++bits;
+    g->lsh = 64 - bits;
+    g->mul_fine = mul_for(g->NB * BKT_SLOTS, max_hash, bits);
+    if (g->mul_fine == 0) return false;
+    // the hashes of one bucket span at most ceil(BKT_SLOTS * 2^bits / mul) + 1 values: their low rem_bits bits tell them apart
+    const unsigned __int128 span = (((unsigned __int128)BKT_SLOTS << bits) + g->mul_fine - 1) / g->mul_fine + 2;
+    if (span >> 63) return false;
+    g->rem_bits = bitlen64((u64)span);
+    const unsigned ref_bits = std::max(1u, bitlen64(n_refs - 1));
+    if (g->rem_bits + ref_bits > 64 || g->rem_bits >= 63) return false;
+    // sketches per tile: their pieces of one region together ~tile_elems pairs
+    const double avg_piece = (double)H / ((double)n_refs * g->P1);
+    u64 S = (u64)(tile_elems / std::max(avg_piece, 1e-9));
+    S = std::min<u64>(std::max<u64>(S, 1), PC_MAX_S);
+    S = std::min<u64>(S, n_refs);
+    g->S = (u32)S;
+    g->Gn = (u32)((n_refs + S - 1) / S);
+    // sketches per workgroup of the bounds pass: their [SK][P1 + 1] block in LDS (<= 48 KB)
+    g->SK = (u32)std::min<u64>(32, std::max<u64>(4, 12288 / (g->P1 + 1)));
+    g->n_pad = (n_refs + 63) & ~(u64)63;
+    const u64 tiles = 8ull * ((g->P1 + 7) / 8) * g->Gn;
+    if (tiles >> 31) return false;
+    static const u32 pad = [] { const char* e = yh_tune_env("YH_PC_PAD"); return e ? (u32)atoi(e) : 0u; }();  // bytes (0, 128 ... 4 352 measured the same: profiles/r05/sweep_pad.txt)
+    g->stride_k = BKT_CAP + pad / 8;
+    g->stride_v = BKT_CAP + pad / 4;
+    g->H = H; g->max_hash = max_hash; g->n_refs = n_refs;
+    return true;
+}
+bool yh_pc_applicable(u64 H, u64 max_hash, u64 n_refs) {
+    static const bool off = [] { const char* e = yh_tune_env("YH_NO_PIECES"); return e && e[0] == '1'; }();
+    yh_pieces g;
+    return !off && pc_geometry(H, max_hash, n_refs, &g);
+}
+void yh_pc_destroy(yh_db* db, yh_pieces* s) {
+    if (!s) return;
+    yh_tfree(db, s->bnd); yh_tfree(db, s->a2); yh_tfree(db, s->p2); yh_tfree(db, s->cnt); yh_tfree(db, s->totals);
+    delete s;
+}
+int yh_pc_begin(yh_db* db, u64 H, u64 max_hash, u64 n_refs, u64* d_rec, yh_pieces** out) {
+    *out = nullptr;
+    yh_pieces* s = new yh_pieces();
+    if (!pc_geometry(H, max_hash, n_refs, s)) { delete s; yh_set_error("internal: not the input of the piece distribution"); return YH_ERR_INVALID_ARG; }
+    s->rec = d_rec;
+    hipError_t e = yh_tmalloc(db, (void**)&s->bnd, (u64)(s->P1 + 1) * s->n_pad * sizeof(u32));
+    if (e == hipSuccess) e = yh_tmalloc(db, (void**)&s->a2, s->NB * s->stride_k * sizeof(u64));
+    if (e == hipSuccess) e = yh_tmalloc(db, (void**)&s->p2, s->NB * s->stride_v * sizeof(u32));
+    if (e == hipSuccess) e = yh_tmalloc(db, (void**)&s->cnt, (s->NB + 4) * sizeof(u32));
+    if (e == hipSuccess) e = yh_tmalloc(db, (void**)&s->totals, TOT_LANES * 8 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemsetAsync(s->cnt, 0, (s->NB + 4) * sizeof(u32), db->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(s->totals, 0, TOT_LANES * 8 * sizeof(unsigned long long), db->stream);
+    if (e != hipSuccess) {
+        yh_set_error("piece distribution: allocation failed: %s", hipGetErrorString(e));
+        yh_pc_destroy(db, s);
+        return e == hipErrorOutOfMemory ? YH_ERR_OOM : YH_ERR_HIP;
+    }
+    *out = s;
+    return YH_OK;
+}
+static PieceArgs pc_args(const yh_pieces* s, const u64* d_values, const u64* d_offsets) {
+    PieceArgs a{};
+    a.values = d_values; a.off = d_offsets; a.n_refs = s->n_refs; a.bnd = s->bnd; a.n_pad = s->n_pad;
+    a.P1 = s->P1; a.P2 = s->P2; a.S = s->S; a.Gn = s->Gn; a.SK = s->SK;
+    a.mul = s->mul_fine; a.lsh = s->lsh; a.rem_bits = s->rem_bits; a.inv_p2 = s->inv_p2;
+    a.rec_clear = s->rec; a.out_a = s->a2; a.out_p = s->p2; a.out_cnt = s->cnt; a.flags = s->cnt + s->NB;
+    a.stride_k = s->stride_k; a.stride_v = s->stride_v;
+    return a;
+}
+// the bounds pass over the sketches [r0, r1) (any number of calls, any order: the chunks of an upload as they arrive)
+int yh_pc_scan(yh_db* db, yh_pieces* s, const u64* d_values, const u64* d_offsets, u64 r0, u64 r1, u64 n_pairs, bool check_order) {
+    if (r1 <= r0) return YH_OK;
+    PieceArgs a = pc_args(s, d_values, d_offsets);
+    a.check_order = check_order ? 1u : 0u;
+    const u64 wgs = (r1 - r0 + s->SK - 1) / s->SK;
+    if (wgs >> 31) { yh_set_error("piece distribution: grid too large"); return YH_ERR_UNSUPPORTED; }
+    const size_t lds = (size_t)s->SK * (s->P1 + 1) * sizeof(u32);
+    k_piece_bounds<<<(u32)wgs, PC_BOUND_THREADS, lds, db->stream>>>(a, r0, r1);
+    YH_HIP(hipGetLastError());
+    s->scanned += n_pairs;
+    return YH_OK;
+}
+// distribution + the fused last pass (k_bucket_group on packed pairs): as yh_psort_finish_emit
+int yh_pc_finish_emit(yh_db* db, yh_pieces* s, const u64* d_values, const u64* d_offsets, u64 totals[3], u32** d_list_out, bool* took_it,
+                      bool* unsorted) {
+    *took_it = false;
+    *d_list_out = nullptr;
+    if (unsorted) *unsorted = false;
+    PieceArgs a = pc_args(s, d_values, d_offsets);
+    k_piece_part<<<8u * ((s->P1 + 7) / 8) * s->Gn, PART_THREADS, 0, db->stream>>>(a);
+    YH_HIP(hipGetLastError());
+    u32* flags = s->cnt + s->NB;
+    BucketArgs b{};
+    b.in_k = s->a2;
+    b.in_v = s->p2;
+    b.cnt = s->cnt;
+    b.cap_in = s->stride_k;
+    b.stride_v = s->stride_v;
+    b.mul_fine = s->mul_fine;
+    b.lsh = s->lsh;
+    b.flags = flags;
+    b.nb = s->NB;
+    b.n_pos = s->H;
+    b.per_xcd = (u32)((s->NB + 7) / 8);
+    b.rec = s->rec;
+    b.list = s->p2;
+    b.rem_bits = s->rem_bits;
+    static const bool no_inline = [] { const char* e = yh_tune_env("YH_FZ_NO_INLINE"); return e && e[0] == '1'; }();
+    b.inline_ok = (s->n_refs < (1u << 21) - 1 && !no_inline) ? 1u : 0u;
+    b.totals = s->totals;
+    // (the chained table of the two-level path, k_bucket_group, takes packed pairs too: YH_GROUP_CHAINS=1 behind the tuning gate)
+    static const bool chains = [] { const char* e = yh_tune_env("YH_GROUP_CHAINS"); return e && e[0] == '1'; }();
+    if (!chains) k_bucket_group5<<<8u * b.per_xcd, BKT_THREADS, 0, db->stream>>>(b);
+    else k_bucket_group<<<8u * b.per_xcd, BKT_THREADS, 0, db->stream>>>(b);
+    YH_HIP(hipGetLastError());
+    u32 hflags[4] = {0, 0, 0, 0};
+    unsigned long long ht[4] = {0, 0, 0, 0};
+    static thread_local unsigned long long hrows[TOT_LANES * 8];
+    YH_HIP(hipMemcpyAsync(hflags, flags, 3 * sizeof(u32), hipMemcpyDeviceToHost, db->stream));
+    YH_HIP(hipMemcpyAsync(hrows, s->totals, sizeof(hrows), hipMemcpyDeviceToHost, db->stream));
+    YH_HIP(hipStreamSynchronize(db->stream));
+    for (u32 q = 0; q < TOT_LANES; ++q)
+        for (u32 t = 0; t < 4; ++t) ht[t] += hrows[q * 8 + t];
+    *took_it = (hflags[0] & 7u) == 0 && ht[3] == s->H && s->scanned == s->H && !(hflags[0] & 8u);
+    if (unsorted) *unsorted = (hflags[0] & 8u) != 0;
+    static const bool trace = [] { const char* e = yh_tune_env("YH_TRACE_BUILD"); const char* f = yh_tune_env("YH_TRACE_SORT"); return (e && e[0] == '1') || (f && f[0] == '1'); }();
+    if (trace)
+        fprintf(stderr, "[yh pieces] H %llu  P1 %u x P2 %u = %llu buckets  S %u x Gn %u  SK %u  rem_bits %u  flags %u  records of %llu of %llu -> %s\n",
+                (u64)s->H, s->P1, s->P2, (u64)s->NB, s->S, s->Gn, s->SK, s->rem_bits, hflags[0], (u64)ht[3], (u64)s->H, *took_it ? "taken" : "REFUSED");
+    if (*took_it) {
+        totals[0] = ht[0]; totals[1] = ht[1]; totals[2] = ht[2];
+        *d_list_out = s->p2;
+        s->p2 = nullptr;
     }
     return YH_OK;
 }

@@ -117,11 +117,16 @@ class RefDB:
         return self
 
     # ---- lifetime ---------------------------------------------------------------------------
-    def close(self) -> None:
+    def close(self, release_pool: bool = False) -> None:
+        """Destroy the handle.  Its arrays go to the library's buffer cache (the next handle of this process takes them without
+        the driver); release_pool=True hands the cache's idle blocks back to the driver as well (_lib.pool_release) -- for a
+        process that needs the memory elsewhere next (torch, RCCL)."""
         h = getattr(self, "_h", None)
         if h is not None and h.value:
             self._lib.yh_db_destroy(h)
             self._h = C.c_void_p(0)
+        if release_pool:
+            _lib.pool_release()
 
     def __del__(self):
         try:

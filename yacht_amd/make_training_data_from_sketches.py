@@ -16,7 +16,7 @@ import shutil
 import zipfile
 from pathlib import Path
 
-from . import phases, utils
+from . import phases, train_core, utils
 from .utils import logger
 
 
@@ -158,19 +158,43 @@ def main(args) -> None:
         # members are left in the working directory by threads of their own WHILE the comparison runs (85 205 file
         # creations are the directory's lock, not CPU), waited for before the command returns
         logger.info("Reading the sourmash signature database")
-        if not getattr(args, "no_sig_files", False):
-            extraction = utils.BackgroundExtraction(zip_path, workdir, max(2, min(int(args.num_threads), 16)))
-        with phases.phase("ingest"):
-            sig_info = utils.ingest_zip_database(zip_path, workdir, args.ksize, args.num_threads, write_files=False,
-                                                 background=extraction)
+        from ._lib import YachtHipError
+
+        try:
+            if not getattr(args, "no_sig_files", False):
+                extraction = utils.BackgroundExtraction(zip_path, workdir, max(2, min(int(args.num_threads), 16)))
+            with phases.phase("ingest"):
+                sig_info = utils.ingest_zip_database(zip_path, workdir, args.ksize, args.num_threads, write_files=False,
+                                                     background=extraction)
+        except YachtHipError as exc:
+            # The native reader takes what sourmash writes (stored / deflated members, zip64, CRC-checked); an archive it
+            # refuses -- another compression method, a layout it does not know -- gets Python's zipfile's opinion
+            # (ADVICE r04): the three-pass route of --python_ingest, which raises BadZipFile itself where the archive IS bad.
+            logger.warning(f"the native archive reader refused {zip_path} ({exc}); reading it with Python's zipfile instead")
+            train_core.drop_parsed_sketches()
+            if extraction is not None:
+                try:
+                    extraction.wait()
+                except Exception:  # noqa: BLE001 -- (it read the same archive: its verdict is the one above)
+                    pass
+                extraction = None
+            _fresh_workdir(workdir, True)
+            _unpack_database(zip_path, workdir, args.num_threads)
+            logger.info("Extracting signature information")
+            with phases.phase("signature_metadata"):
+                sig_info = utils.collect_signature_info(args.num_threads, args.ksize, workdir)
     scaled_values = {record[-2] for record in sig_info.values()}
     if len(scaled_values) != 1:
+        train_core.drop_parsed_sketches()  # (the ingest's offer must not outlive a run that stops here)
         raise ValueError(MSG_SCALES)
 
     logger.info("Finding the closely related genomes with ANI > ani_thresh and removing them.")
-    with phases.phase("train_core"):
-        kept = utils.run_yacht_train_core(args.num_threads, args.ani_thresh, args.ksize, workdir, sig_info,
-                                          device=getattr(args, "device", 0))
+    try:
+        with phases.phase("train_core"):
+            kept = utils.run_yacht_train_core(args.num_threads, args.ani_thresh, args.ksize, workdir, sig_info,
+                                              device=getattr(args, "device", 0))
+    finally:
+        train_core.drop_parsed_sketches()
 
     manifest_path = os.path.join(outdir, f"{args.prefix}_processed_manifest.tsv")
     kept.to_csv(manifest_path, sep="\t", index=None)

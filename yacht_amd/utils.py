@@ -362,9 +362,15 @@ def run_yacht_train_core(num_threads: int, ani_thresh: float, ksize: int, path_t
     # database's sketches in hand, the list is ITS list in its order -- the archive's -- and nothing is read twice; the
     # files themselves may still be on their way to the directory: utils.BackgroundExtraction.)
     offered = train_core.parsed_paths()
-    if offered is not None:
+    # (the offer is a process-wide leftover of the LAST ingest -- it is this call's list only when every path lies
+    # in THIS working directory's signatures/; anything else -- an ingest whose run aborted, a direct caller of this public
+    # function -- is dropped and the directory listed, as the reference does)
+    sig_root = os.path.join(os.path.abspath(sig_dir), "")
+    if offered is not None and offered and all(os.path.abspath(p_).startswith(sig_root) for p_ in offered):
         sig_files = list(offered)
     else:
+        if offered is not None:
+            train_core.drop_parsed_sketches()
         sig_files = [os.path.join(sig_dir, f) for f in os.listdir(sig_dir)]
     sig_files_path = os.path.join(path_to_temp_dir, "training_sig_files.tsv")
     with phases.phase("write_file_list"):

@@ -57,6 +57,8 @@ def _cell(ref: str, v) -> str:
         return ""
     if isinstance(v, (bool, np.bool_)):
         return f'<c r="{ref}" t="b"><v>{int(bool(v))}</v></c>'
+    if v is None or v is getattr(_pd_na(), "NA", None) or v is getattr(_pd_na(), "NaT", None):
+        return ""  # a missing value of a nullable column: an empty cell, as NaN is
     if isinstance(v, (int, np.integer)):
         return f'<c r="{ref}"><v>{int(v)}</v></c>'
     if isinstance(v, (float, np.floating)):
@@ -71,11 +73,22 @@ def _cell(ref: str, v) -> str:
     return f'<c r="{ref}" t="inlineStr"><is><t{keep}>{escape(s)}</t></is></c>'
 
 
+def _pd_na():
+    """pandas, when it is importable (the tables written here are DataFrames, so it is): its NA / NaT singletons."""
+    try:
+        import pandas as pd
+        return pd
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def _column_cells(letters: str, values: list, dtype) -> List[str]:
     """The cells of one column, row 2 on (one string per row; "" = no cell).  Columns of one numpy dtype -- what a result
     table is made of -- are formatted without a type test per cell (a 20 000-row sheet: 0.3 s of `_cell` calls before)."""
     n = len(values)
-    kind = getattr(dtype, "kind", "O")
+    # the fast paths are for plain numpy dtypes only: pandas' nullable Int64 / UInt64 / boolean report kind "i" / "u" / "b" too,
+    # but their .tolist() holds pd.NA (ADVICE r04: "<v><NA></v>" is not XML) -- those go cell by cell, NA as an empty cell
+    kind = dtype.kind if isinstance(dtype, np.dtype) else "O"
     if kind == "b":
         return [f'<c r="{letters}{r}" t="b"><v>{1 if v else 0}</v></c>' for r, v in zip(range(2, n + 2), values)]
     if kind in "iu":
