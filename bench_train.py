@@ -143,9 +143,35 @@ def main() -> int:
                          "device_ms": round(k_ms_d, 3),
                          "note": "one-touch bytes (8 H + 12 P_out, SURVEY.md 8d) over the device time of build + pairwise (HIP events around "
                                  "validation, the distribution sort with its fused last pass, and the row pass)"},
+            "kernels": "k_piece_bounds (regions of every sketch, ordering check, records cleared), k_piece_part (pieces read in place -> buckets), "
+                       "k_bucket_group5 (grouping by hash in LDS -> pairwise records), k_pair_rows",
             "how": "sketches resident in HBM: yh_db_create_device(PAIRWISE_ONLY) + yh_pairwise + yh_train_select; medians of the passes behind two warm-ups",
             "_results": (di, dj, dc, dsel, dstats),
         }
+        # HBM bytes actually moved, from the rocprofv3 --pmc passes of scripts/pmc_train.sh -- attached only when they were taken
+        # from THIS source of the kernels (profiles/traffic_<round>_train.json is keyed on its sha256)
+        try:
+            import hashlib
+
+            hsh = hashlib.sha256()
+            for f_ in ("yh_sort.hip", "yh_pairwise.hip", "yh_common.h"):
+                with open(os.path.join(ROOT, "yacht_amd", "csrc", f_), "rb") as fh:
+                    hsh.update(fh.read())
+            tag_ = hsh.hexdigest()[:16]
+            device_input["roofline"]["traffic"] = None
+            for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+                if name.startswith("traffic_") and name.endswith("_train.json"):
+                    with open(os.path.join(ROOT, "profiles", name)) as f:
+                        tr = json.load(f)
+                    if tr.get("source_tag") == tag_ and tr.get("n_hashes") == int(offsets[-1]):
+                        device_input["roofline"]["traffic"] = tr["hbm_bytes_per_call"]
+                        device_input["roofline"]["moved_over_algorithmic"] = tr["moved_over_algorithmic"]
+                        device_input["roofline"]["traffic_per_kernel"] = {k_: v_["hbm_bytes"] for k_, v_ in tr["per_kernel"].items()}
+                        device_input["roofline"]["traffic_provenance"] = {"file": "profiles/" + name, "source_tag": tag_, "taken": tr.get("taken"),
+                                                                           "commit": tr.get("commit"), "read_factor": tr.get("read_factor")}
+                        break
+        except Exception as ex:  # noqa: BLE001
+            device_input["roofline"]["traffic_error"] = repr(ex)
         del d_values, d_offsets
         stamp("device_input_passes")
     t_build, t_pair, t_sel = [], [], []
@@ -380,12 +406,14 @@ def main() -> int:
     # roofline-style figure of the kernels alone (B = 8 H + 12 P_out), HBM peak 8 TB/s
     k_ms = float(tm["ms_db_build"]) + k_pair_ms
     alg_upload_s = 8 * int(offsets[-1]) / 56e9  # what the bus needs for the sketches alone (measured: 56 GB/s from pageable memory)
-    out["roofline"] = {"bound": "hbm", "kernels": "k_part<1> per chunk (under the upload), k_part<2>, k_bucket_group (yh_sort.hip: the sort's last pass groups by hash in LDS and writes the pairwise records), k_pair_rows",
+    out["roofline"] = {"bound": "hbm", "kernels": "k_piece_bounds per chunk (under the upload), k_piece_part, k_bucket_group5 (yh_sort.hip: regions read in place as pieces of the ascending sketches, buckets grouped by hash in LDS into the pairwise records), k_pair_rows",
                        "achieved": round(alg / 1e9 / (k_ms / 1e3), 1) if k_ms > 0 else None, "peak": 8000.0, "unit": "GB/s",
                        "frac": round(alg / 1e9 / (k_ms / 1e3) / 8000.0, 4) if k_ms > 0 else None,
                        "exposed_device_ms": round(1e3 * total - 1e3 * alg_upload_s, 3),
-                       "note": "one-touch bytes over the SUM of the device time of all build + pairwise kernels; the first-level distribution of "
-                               "the chunks runs while the database crosses PCIe -- exposed_device_ms = the call minus 8 H bytes at 56 GB/s"}
+                       "traffic": (device_input or {}).get("roofline", {}).get("traffic"),
+                       "note": "one-touch bytes over the SUM of the device time of all build + pairwise kernels (k_scan_refs' ordering check of "
+                               "every chunk included); the bounds pass of the chunks runs while the database crosses PCIe -- "
+                               "exposed_device_ms = the call minus 8 H bytes at 56 GB/s; traffic = the device-input kernels' (the same kernels)"}
     if world > 1:
         if rank == 0:
             os.write(json_fd, (json.dumps(out) + "\n").encode())

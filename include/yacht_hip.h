@@ -89,7 +89,17 @@ typedef struct yh_db_info {
     uint64_t n_holder_sets;      /* distinct (reference, set of other holders) records the run step's
                                     exclusive pass walks instead of the n_shared_postings postings  */
     uint64_t filter_bytes;       /* presence filter in front of the bucket table (0: none)    */
+    uint32_t sort_path;          /* how the (hash, reference) pairs were put in order: YH_SORT_* (ABI 5)                 */
+    uint32_t reserved_;
+    uint64_t n_spilled_buckets;  /* buckets of the distribution that held more pairs than their capacity -- a k-mer that  */
+    uint64_t n_spilled_pairs;    /* thousands of references share -- and were grouped on the side; their pairs            */
 } yh_db_info;
+
+/* yh_db_info.sort_path */
+#define YH_SORT_NONE      0u  /* no index (YH_DB_NO_INDEX) or an empty database                                              */
+#define YH_SORT_RADIX     1u  /* rocPRIM's radix sort of all pairs: keys the distribution could not take                       */
+#define YH_SORT_TWO_LEVEL 2u  /* the hand-written two-level distribution sort (yh_sort.hip: k_part, k_bucket_sort / _group)   */
+#define YH_SORT_PIECES    3u  /* `yacht train`'s handle: regions read in place as pieces of the ascending sketches            */
 
 /* yh_db_info.stream_layout */
 #define YH_STREAM_NONE   0u  /* posting-only / pairwise-only handle                              */

@@ -91,3 +91,88 @@ def test_full_range_hashes(hip_lib):
                                        np.array([0, 2**32 + 1, 2**64 - 1], dtype=np.uint64)]))
     values, offsets = pack_csr(refs)
     _check(values, offsets, sample)
+
+
+def _hot_database(seed, n_refs, size, n_hot, hot_lo, hot_hi, n_clusters=300):
+    """n_refs sketches of ~size uniform hashes; the first 5 * n_clusters form clusters of five around the train threshold
+    (config4's retentions); n_hot "conserved k-mers", each put into hot_lo .. hot_hi randomly chosen sketches."""
+    from yacht_amd import synth
+
+    rng = np.random.default_rng(seed)
+    mh = synth.max_hash_for_scaled(1000)
+    refs = []
+    for _ in range(n_clusters):
+        parent = np.unique(rng.integers(1, mh, size=size, dtype=np.uint64))
+        for keep in (1.0, 0.9, 0.5, 0.25, 0.1):
+            kept = parent[rng.random(parent.size) < keep]
+            extra = np.unique(rng.integers(1, mh, size=max(size - kept.size, 0), dtype=np.uint64))
+            refs.append(np.union1d(kept, extra))
+    while len(refs) < n_refs:
+        refs.append(np.unique(rng.integers(1, mh, size=int(rng.integers(size // 2, size * 2)), dtype=np.uint64)))
+    hot = np.unique(rng.integers(1, mh, size=n_hot, dtype=np.uint64))
+    members = [[] for _ in range(n_refs)]
+    holders = []
+    for h in hot:
+        m = int(rng.integers(hot_lo, hot_hi + 1))
+        who = rng.choice(n_refs, size=m, replace=False)
+        holders.append(m)
+        for r in who:
+            members[int(r)].append(h)
+    refs = [np.union1d(r, np.asarray(m, dtype=np.uint64)) if m else r for r, m in zip(refs, members)]
+    return refs, hot, holders
+
+
+def test_hot_kmers_spill_their_buckets_and_nothing_else(hip_lib):
+    """VERDICT r04 "next" 5: hashes held by thousands of references (conserved rRNA k-mers) put more pairs into ONE bucket
+    of the distribution than it holds.  Until round 4 that sent the whole database to rocPRIM's radix sort and `yacht train`
+    off its fused path; now only those buckets go to a side list that is grouped on its own -- yh_db_info says so
+    (sort_path = pieces, n_spilled_buckets / n_spilled_pairs) -- and everything equals the oracle: the kept pairs and the
+    three statistics of the whole database, the shared-hash count of every reference, and the counts of rows whose pairs
+    come from the hot k-mers alone (a low threshold) against the full handle's generic path."""
+    import torch
+
+    from yacht_amd import synth
+    from yacht_amd.engine import YH_DB_PAIRWISE_ONLY
+
+    refs, hot, holders = _hot_database(77, 12_000, 400, 30, 5_000, 11_000)
+    values, offsets = synth.pack(refs)
+    n = len(refs)
+    c = 0.95 ** 31
+    wi, wj, wc, wstats = oracle.train_pairs(values, offsets, c, threads=oracle.hardware_threads())
+    assert wi.size > 500
+    with RefDB(values, offsets, flags=YH_DB_PAIRWISE_ONLY) as tdb, RefDB(values, offsets) as db:
+        info = tdb.info()
+        assert info["sort_path"] == 3, info  # YH_SORT_PIECES: not the radix fallback
+        assert info["n_spilled_buckets"] >= len(hot) * 0.9 and info["n_spilled_buckets"] <= 2 * len(hot) + 2, info
+        assert info["n_spilled_pairs"] >= sum(holders) and info["n_spilled_pairs"] <= sum(holders) + 2 * 4096 * info["n_spilled_buckets"], info
+        gi, gj, gc = tdb.pairwise(c)
+        assert np.array_equal(gi, wi) and np.array_equal(gj, wj) and np.array_equal(gc, wc)
+        assert tdb.index_stats() == wstats
+        ns_t = torch.zeros(n, dtype=torch.int32, device="cuda:0")
+        ns_d = torch.zeros(n, dtype=torch.int32, device="cuda:0")
+        torch.cuda.synchronize()
+        tdb.nshared_device(ns_t.data_ptr())
+        tdb.synchronize()
+        db.nshared_device(ns_d.data_ptr())
+        db.synchronize()
+        assert torch.equal(ns_t, ns_d)
+        # rows whose pairs are made by the hot k-mers (thousands of columns each): the fused records' list form through the second
+        # list array, against the generic handle
+        rows = [int(r) for r in np.flatnonzero(np.asarray([np.isin(hot, r).sum() for r in refs[2000:2400]]) >= 3)[:6] + 2000]
+        assert rows
+        for r0 in rows:
+            a = tdb.pairwise(0.004, r0, r0 + 1)
+            b = db.pairwise(0.004, r0, r0 + 1)
+            assert a[0].size > 1000 and all(np.array_equal(x, y) for x, y in zip(a, b)), r0
+    # the same database with the side list compiled out of the decision (YH_NO_SPILL=1): the old behaviour -- refused, radix sort
+    env = dict(os.environ, YH_DEBUG_TUNING="1", YH_NO_SPILL="1")
+    code = ("import sys, json, numpy as np\nsys.path.insert(0, %r)\nsys.path.insert(0, %r)\n"
+            "from test_gpu_keys import _hot_database\nfrom yacht_amd import synth\nfrom yacht_amd.engine import RefDB, YH_DB_PAIRWISE_ONLY\n"
+            "refs, hot, holders = _hot_database(77, 12000, 400, 30, 5000, 11000)\nv, o = synth.pack(refs)\n"
+            "with RefDB(v, o, flags=YH_DB_PAIRWISE_ONLY) as t:\n    print(json.dumps(t.info()))\n" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    import json
+
+    old = json.loads(r.stdout.strip().splitlines()[-1])
+    assert old["sort_path"] == 1 and old["n_spilled_pairs"] == 0, old  # YH_SORT_RADIX

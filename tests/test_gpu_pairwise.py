@@ -150,8 +150,9 @@ print(json.dumps({"ok": ok, "pairs": int(wi.size)}))
 @pytest.mark.parametrize("heavy,verdict", [(0, "taken"), (800, "taken"), (2000, "REFUSED")])
 def test_distribution_sort_takes_uniform_keys_and_refuses_the_rest(hip_lib, heavy, verdict):
     """yh_sort.hip on 2 000 sketches (8e5 hashes, ~310 buckets): uniform keys and a hash held by 800 references are sorted by
-    it; a hash held by all 2 000 overflows its bucket, is refused on the device and sorted by rocPRIM -- the verdict line
-    says which ([yh sort] ... taken / REFUSED), the order is checked on the device either way (YH_CHECK_SORT) and pairs
+    it; a hash held by all 2 000 overflows its bucket: the two-level sort of the full handle refuses it on the device and
+    rocPRIM sorts instead, the train handle's distribution sends that bucket to its side list -- the verdict lines say which
+    ([yh sort] / [yh pieces] ... taken / REFUSED), the order is checked on the device either way (YH_CHECK_SORT) and pairs
     and statistics equal the oracle's."""
     env = dict(os.environ)
     env.update({"YH_DEBUG_TUNING": "1", "YH_TRACE_BUILD": "1", "YH_CHECK_SORT": "1"})
@@ -159,11 +160,17 @@ def test_distribution_sort_takes_uniform_keys_and_refuses_the_rest(hip_lib, heav
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["ok"] and out["pairs"] > 300
-    # (the train handle goes through the distribution without a first level -- "[yh pieces]" -- and, refused there, through the
-    # two-level sort in position mode, which refuses the same keys; the full handle through the two-level sort)
-    lines = [ln for ln in r.stderr.splitlines() if ln.startswith("[yh sort]") or ln.startswith("[yh pieces]")]
-    assert len(lines) == (3 if verdict == "REFUSED" else 2) and all(ln.rstrip().endswith(verdict) for ln in lines), lines
-    assert sum(ln.startswith("[yh pieces]") for ln in lines) == 1, lines
+    # The train handle goes through the distribution without a first level ("[yh pieces]"), which takes ALL three inputs since
+    # round 5: the bucket a hash of 2 000 holders overflows goes to its side list; the full handle goes through the two-level
+    # sort ("[yh sort]"), which still refuses that one for rocPRIM.
+    verdicts = [ln for ln in r.stderr.splitlines() if (ln.startswith("[yh sort]") or ln.startswith("[yh pieces]")) and " -> " in ln]
+    assert len(verdicts) == 2, verdicts
+    pieces = [ln for ln in verdicts if ln.startswith("[yh pieces]")]
+    sorts = [ln for ln in verdicts if ln.startswith("[yh sort]")]
+    assert len(pieces) == 1 and pieces[0].rstrip().endswith("taken"), verdicts
+    assert len(sorts) == 1 and sorts[0].rstrip().endswith(verdict), verdicts
+    side = [ln for ln in r.stderr.splitlines() if ln.startswith("[yh pieces] side list:")]
+    assert (len(side) == 1) == (heavy == 2000), r.stderr[-1500:]
 
 
 def test_tiny_sketches_and_shared_counts_on_the_train_handle(hip_lib):

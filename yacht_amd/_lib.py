@@ -63,6 +63,10 @@ class DbInfo(C.Structure):
         ("stream_bytes", C.c_uint64),
         ("n_holder_sets", C.c_uint64),
         ("filter_bytes", C.c_uint64),
+        ("sort_path", C.c_uint32),
+        ("reserved_", C.c_uint32),
+        ("n_spilled_buckets", C.c_uint64),
+        ("n_spilled_pairs", C.c_uint64),
     ]
 
 

@@ -559,7 +559,7 @@ int yh_db_destroy(yh_db* db) {
                     db->d_rpo, db->d_rg, db->d_rrec, db->d_rrecx, db->d_filter, db->d_hrec, db->d_hrecx, db->d_hmult, db->d_hpo,
                     db->d_work, db->d_work_count, db->d_mask, db->d_maskbits, db->d_hit, db->d_excl_e, db->d_overlap_tmp,
                     db->d_sample_tmp, db->d_out_tmp, db->d_flag, db->d_reps, db->batch[0].d_scratch, db->batch[1].d_scratch, db->batch[2].d_scratch, db->d_sdelta, db->d_shdr, db->d_srec,
-                    db->d_wg_key, db->d_ghost_src, db->d_bad_word, db->d_prank, db->d_fz_rec, db->d_fz_list, db->d_fz_off, db->d_fz_tab};
+                    db->d_wg_key, db->d_ghost_src, db->d_bad_word, db->d_prank, db->d_fz_rec, db->d_fz_list, db->d_fz_list2, db->d_fz_off, db->d_fz_tab};
     for (void* p : ptrs)
         if (p) yh_dfree(db, p);
     for (auto& pair : db->ev_xfer)
@@ -603,6 +603,9 @@ int yh_db_get_info(yh_db* db, yh_db_info* info) {
     info->flags = db->flags;
     info->n_holder_sets = db->d_hrec ? db->n_sets : 0;
     info->filter_bytes = db->d_filter ? db->filter_bits / 8 : 0;
+    info->sort_path = db->sort_path;
+    info->n_spilled_buckets = db->n_spilled_buckets;
+    info->n_spilled_pairs = db->n_spilled_pairs;
     if (db->d_sdelta) {
         info->stream_layout = YH_STREAM_DELTA;
         info->stream_shift = db->sshift;

@@ -597,6 +597,8 @@ static int fz_finish(yh_db* db, yh_psort* ps, bool* took, bool* unsorted) {
     yh_psort_destroy(db, ps);
     if (rc != YH_OK || !*took) { fz_drop(db); return rc; }
     db->d_fz_list = d_list;
+    db->fz_list_split = ~(u64)0;
+    db->sort_path = YH_SORT_TWO_LEVEL;
     db->n_distinct = totals[0];
     db->n_shared = totals[1];
     db->n_postings = totals[2];
@@ -619,12 +621,30 @@ static int fzp_begin(yh_db* db, const u64* d_offsets, u64 max_hash, yh_pieces** 
     if (rc != YH_OK) { yh_pc_destroy(db, *pc); *pc = nullptr; fz_drop(db); }
     return rc;
 }
+int yh_radix_sort_pairs_u64_u32(yh_db* db, const u64* k_in, u64* k_out, const u32* v_in, u32* v_out, u64 n, unsigned end_bit) {
+    if (n == 0) return YH_OK;
+    size_t tb = 0;
+    void* d_tmp = nullptr;
+    end_bit = std::min(std::max(end_bit, 1u), 64u);
+    YH_HIP(rocprim::radix_sort_pairs(nullptr, tb, k_in, k_out, v_in, v_out, (size_t)n, 0u, end_bit, db->stream));
+    if (yh_tmalloc(db, &d_tmp, std::max<size_t>(tb, 16)) != hipSuccess) { yh_set_error("out of device memory"); return YH_ERR_OOM; }
+    const hipError_t e = rocprim::radix_sort_pairs(d_tmp, tb, k_in, k_out, v_in, v_out, (size_t)n, 0u, end_bit, db->stream);
+    yh_tfree(db, d_tmp);
+    if (e != hipSuccess) { yh_set_error("radix sort failed: %s", hipGetErrorString(e)); return YH_ERR_HIP; }
+    return YH_OK;
+}
 static int fzp_finish(yh_db* db, yh_pieces* pc, const u64* d_values, bool* took, bool* unsorted) {
     u64 totals[3] = {0, 0, 0};
     u32* d_list = nullptr;
-    int rc = yh_pc_finish_emit(db, pc, d_values, db->d_fz_off, totals, &d_list, took, unsorted);
+    yh_pc_spill spill;
+    int rc = yh_pc_finish_emit(db, pc, d_values, db->d_fz_off, totals, &d_list, took, unsorted, &spill);
     yh_pc_destroy(db, pc);
-    if (rc != YH_OK || !*took) { fz_drop(db); return rc; }
+    if (rc != YH_OK || !*took) { yh_tfree(db, spill.d_list2); fz_drop(db); return rc; }
+    db->d_fz_list2 = spill.d_list2;
+    db->fz_list_split = spill.d_list2 ? spill.list_split : ~(u64)0;
+    db->n_spilled_pairs = spill.n_pairs;
+    db->n_spilled_buckets = spill.n_buckets;
+    db->sort_path = YH_SORT_PIECES;
     db->d_fz_list = d_list;
     db->n_distinct = totals[0];
     db->n_shared = totals[1];
@@ -976,6 +996,7 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, u64* d_
         IDX_HIP(yh_tmalloc(db, (void**)&d_sk, H * sizeof(u64)));
     }
     if (ps) yh_psort_chunks(ps, &nb, &d_chunk_off, &d_chunk_counts);
+    db->sort_path = ps ? YH_SORT_TWO_LEVEL : YH_SORT_RADIX;  // (pairs sorted behind the upload: by whichever of the two took them)
     bool order_checked = db->order_checked;
     if (rc == YH_OK && !d_sk_pre) {
         k_fill_ref_ids<<<grid_for(N * WAVE, 256), 256, 0, st>>>(d_offsets, N, d_ids);
@@ -995,6 +1016,7 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, u64* d_
             }
             if (rc == YH_OK && sorted) {
                 order_checked = true;
+                db->sort_path = YH_SORT_TWO_LEVEL;
                 yh_psort_chunks(ps, &nb, &d_chunk_off, &d_chunk_counts);
             } else {
                 yh_psort_destroy(db, ps);

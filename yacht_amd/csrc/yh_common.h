@@ -119,6 +119,10 @@ struct yh_db {
     bool fz = false;
     u64* d_fz_rec = nullptr;   // [H] bit 63 clear: up to three holders as 21-bit fields (reference + 1); set: {holders << 40 | first entry of d_fz_list}
     u32* d_fz_list = nullptr;  // [buckets x 4096] the holders of every hash with more than four of them, at the hash's place in its bucket
+    u32* d_fz_list2 = nullptr; // the holders of the hashes of SPILLED buckets (more pairs than a bucket holds: a k-mer thousands of references
+    u64 fz_list_split = 0;     //   share), hash by hash; a list record whose start is >= fz_list_split names d_fz_list2[start - fz_list_split]
+    u64 n_spilled_pairs = 0, n_spilled_buckets = 0;  // (yh_db_info)
+    u32 sort_path = 0;         // how the pairs were put in order: YH_SORT_* (yh_db_info.sort_path)
     u64* d_fz_off = nullptr;   // [N + 1] the CSR offsets = the rows of d_fz_rec
     u32* d_fz_tab = nullptr;   // [H / 256 + 2] reference of every 256th CSR position (position -> reference look-ups)
     bool fz_nshared = false;   // d_nshared has been counted from the records (on demand: yh_db_nshared_device)

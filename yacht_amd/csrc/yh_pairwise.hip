@@ -78,6 +78,8 @@ struct PairRows {
     const u64* frec;      // FUSED (yh_db::fz): 8-byte records, one per CSR position (yh_db::d_fz_rec) ...
     const u64* foff;      // ... the rows = the sketches' extents (yh_db::d_fz_off); pr = yh_db::d_fz_list; cid / rid unused (identity)
     const u32* pr;        // hash-major holders (the long lists)
+    const u32* pr2;       // FUSED: the lists of the groups of spilled buckets (yh_db::d_fz_list2) ...
+    u64 pr_split;         // ... which list records name by a start >= pr_split (entry q of them: pr2[q - pr_split])
     const u32* cid;       // [N] compact id of a reference that holds a shared hash
     const u32* rid;       // [NC] back
     const u32* sizes;     // [N]
@@ -199,9 +201,13 @@ __global__ void __launch_bounds__(THREADS) k_pair_rows(const PairRows p) {
                     lm = cur[u].y;
                 }
             }
+            const u32* lp = p.pr;  // where this record's list lives
+            if constexpr (FUSED) {
+                if (is_list && lq0 >= p.pr_split) { lp = p.pr2; lq0 -= p.pr_split; }
+            }
             if (is_list && lm <= PAIR_LONG) {
                 for (u64 q = lq0, qe = lq0 + lm; q < qe; ++q) {
-                    const u32 o = p.pr[q];
+                    const u32 o = lp[q];
                     if (o != (u32)a) add(o);
                 }
             }
@@ -211,8 +217,9 @@ __global__ void __launch_bounds__(THREADS) k_pair_rows(const PairRows p) {
                 todo &= todo - 1;
                 const u64 q0 = ((u64)(u32)__shfl((int)(u32)(lq0 >> 32), src) << 32) | (u32)__shfl((int)(u32)lq0, src);
                 const u32 m = (u32)__shfl((int)lm, src);
+                const u32* lsrc = __shfl((int)(lp != p.pr), src) != 0 ? p.pr2 : p.pr;
                 for (u32 q = lane; q < m; q += 64u) {
-                    const u32 o = p.pr[q0 + q];
+                    const u32 o = lsrc[q0 + q];
                     if (o != (u32)a) add(o);
                 }
             }
@@ -403,7 +410,7 @@ int yh_q_pairwise(yh_db* db, double c_thresh, u64 r0, u64 r1) {
                                                                      d_cid, d_rrec);
     for (int attempt = 0; attempt < 2 && rc == YH_OK; ++attempt) {
         PW_HIP(hipMemsetAsync(d_cursor, 0, 8, st));
-        PairRows q{d_rrec, d_rowptr, db->d_fz_rec, db->d_fz_off, fz ? db->d_fz_list : db->d_pr, d_cid, d_rid, db->d_sizes, 0, 0, nseg,
+        PairRows q{d_rrec, d_rowptr, db->d_fz_rec, db->d_fz_off, fz ? db->d_fz_list : db->d_pr, db->d_fz_list2, fz ? db->fz_list_split : ~(u64)0, d_cid, d_rid, db->d_sizes, 0, 0, nseg,
                    (u32)NC, cols, c_relaxed, d_segcnt, d_segoff, d_cursor, cap, d_out};
         const u64 step = (1u << 31) / (u32)threads;  // (2^31 threads per grid dimension)
         for (u64 b0 = 0; b0 < rows && rc == YH_OK; b0 += step) {

@@ -877,7 +877,9 @@ __device__ __forceinline__ void lookup_tile_body(u32 wg, u32* tkey, u32* tcnt, u
     const YhDirView& dv = q.dv;
     const u32* __restrict__ filter = q.filter;
     if (q.work_count && wg == 0 && threadIdx.x == 0) *q.work_count = 0;
+#if !(defined(YH_LOOKUP_LATE_BAD) && YH_LOOKUP_LATE_BAD) && !(defined(YH_ABLATE_LOOKUP) && (YH_ABLATE_LOOKUP & 32))
     if (q.bad && *q.bad == q.bad_gen) return;
+#endif
     u32* my = q.reps + (u64)replica_of(wg, q.rep_mask) * q.n_refs;
     u32* my2 = q.reps2 ? q.reps2 + (u64)replica_of(wg, q.rep_mask) * q.n_refs : nullptr;
     const u64 base = wg * (u64)(THREADS * U);
@@ -890,10 +892,17 @@ __device__ __forceinline__ void lookup_tile_body(u32 wg, u32* tkey, u32* tcnt, u
         ok[u] = t < n && h[u] <= dv.max_hash;
         if (!ok[u]) h[u] = 0;  // (still a valid bucket to read)
     }
+#if defined(YH_LOOKUP_LATE_BAD) && YH_LOOKUP_LATE_BAD  // (the sample's loads are in flight before the verdict of its ordering check is asked for)
+    if (q.bad && *q.bad == q.bad_gen) return;
+#endif
     for (u32 k = threadIdx.x; k < TSLOTS; k += THREADS) { tkey[k] = 0; tcnt[k] = 0; tcnt2[k] = 0; }
     YhDirView::v4u a[U], b[U], c[U], d[U];
     u32 r[U];
+#if defined(YH_ABLATE_LOOKUP) && (YH_ABLATE_LOOKUP & 16)  // timing-only build: no presence filter read
+    if (false) {
+#else
     if (filter) {  // the presence bits first: a hash whose bit is clear is not in the database (yh_db::d_filter)
+#endif
         u64 bit[U];
         u32 w[U];
 #pragma unroll
@@ -911,6 +920,9 @@ __device__ __forceinline__ void lookup_tile_body(u32 wg, u32* tkey, u32* tcnt, u
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             a[u] = b[u] = c[u] = d[u] = YhDirView::v4u{0u, 0u, 0u, 0u};
+#if defined(YH_ABLATE_LOOKUP) && (YH_ABLATE_LOOKUP & 8)  // timing-only build: no bucket is read (every hash "absent" behind the filter)
+            ok[u] = ok[u] && h[u] == 0x123456789abcdefull;
+#endif
             if (ok[u]) dv.cbkt_request(h[u], a[u], b[u], c[u], d[u]);
         }
 #pragma unroll
@@ -918,6 +930,10 @@ __device__ __forceinline__ void lookup_tile_body(u32 wg, u32* tkey, u32* tcnt, u
     }
     __syncthreads();  // the table is clear
     auto add = [&](u32 ref, bool shared) {
+#if defined(YH_ABLATE_LOOKUP) && (YH_ABLATE_LOOKUP & 4)  // timing-only build: hits are not counted
+        if (ref == 0x7ffffff1u) my[0] = 1;
+        return;
+#endif
         u32 slot = (ref * 2654435761u) >> (32 - TBITS);
 #pragma unroll 1
         for (int probe = 0; probe < 2; ++probe, slot = (slot + 1) & (TSLOTS - 1)) {
@@ -1164,6 +1180,9 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? 8 : 4) k_step_fused
     extern __shared__ u32 smem[];
     constexpr u32 TSLOTS = 1u << TBITS;
     u32 b = blockIdx.x;
+#if defined(YH_ABLATE_LOOKUP) && (YH_ABLATE_LOOKUP & 64)  // timing-only build: the launch's exclusive and reducer roles do nothing
+    if (b < s.excl_wgs + s.red_wgs) return;
+#endif
     if (b < s.excl_wgs) {
         if (s.excl_lds) excl_pieces_body<true, 2>(b, s.excl_wgs, smem, s.excl);
         else excl_pieces_body<false, 2>(b, s.excl_wgs, smem, s.excl);

@@ -42,6 +42,11 @@ int yh_pc_begin(yh_db* db, u64 H, u64 max_hash, u64 n_refs, u64* d_rec, yh_piece
 // flag sketches that are not strictly ascending
 int yh_pc_scan(yh_db* db, yh_pieces* s, const u64* d_values, const u64* d_offsets, u64 r0, u64 r1, u64 n_pairs, bool check_order);
 // distribution into the buckets + the fused last pass; semantics of yh_psort_finish_emit.  Synchronizes the stream.
+// *spill (optional): what went through the side list of overflowed buckets -- their groups' holder lists (the caller's to
+// yh_tfree, nullptr when nothing spilled), the start value from which a list record names that array, and the counts
+struct yh_pc_spill { u32* d_list2 = nullptr; u64 list_split = 0, n_pairs = 0, n_buckets = 0; };
 int yh_pc_finish_emit(yh_db* db, yh_pieces* s, const u64* d_values, const u64* d_offsets, u64 totals[3], u32** d_list_out, bool* took_it,
-                      bool* unsorted = nullptr);
+                      bool* unsorted = nullptr, yh_pc_spill* spill = nullptr);
+// rocPRIM's radix sort of (u64 key, u32 value) pairs over the low end_bit bits (yh_build.hip, where rocPRIM lives)
+int yh_radix_sort_pairs_u64_u32(yh_db* db, const u64* k_in, u64* k_out, const u32* v_in, u32* v_out, u64 n, unsigned end_bit);
 void yh_pc_destroy(yh_db* db, yh_pieces* s);

@@ -361,6 +361,7 @@ struct BucketArgs {
                                  // (one row of four counters for all 19 600 workgroups: 78 000 atomics on ONE cache line, ~6 ns each --
                                  // the whole 0.5 ms of this kernel at configs[3], whatever else it did: profiles/r05/ablate_group.txt)
     u64 stride_v;                // packed pairs: elements between two buckets of in_v / list (in_k: cap_in)
+    u64* spill_a; u32* spill_p; u32* spill_b; u64 spill_cap;  // k_bucket_group5: the side list of the buckets that overflowed
     u32 rem_bits;                // != 0: PACKED pairs (k_piece_part): in_k = low rem_bits bits of the hash | reference << rem_bits
                                  // (inside a bucket the hashes span less than 2^rem_bits: the low bits identify them), in_v = position
 };
@@ -727,8 +728,20 @@ __global__ void __launch_bounds__(BKT_THREADS) k_bucket_group5(const BucketArgs 
     if (tid < 3) tot3[tid] = 0;
     if (tid == 3) { lcount = 0; has_list = 0; }
     const u32 c_raw = a.cnt[b];
-    if (c_raw > BKT_CAP && tid == 0) atomicOr(a.flags, 2u);
-    const u32 n = min(c_raw, BKT_CAP);
+    if (c_raw > BKT_CAP) {  // (uniform) more pairs than a bucket holds -- a hash thousands of references share: the pairs that
+        // arrived in time follow the late ones to the side list, where the whole bucket is grouped (yh_pc_spill_group)
+        if (!a.spill_a) { if (tid == 0) atomicOr(a.flags, 2u); return; }
+        if (tid == 0) { lcount = atomicAdd(&a.flags[1], BKT_CAP); atomicAdd(&a.flags[2], 1u); }
+        __syncthreads();
+        const u64 at0 = lcount;
+#pragma unroll
+        for (u32 k = 0; k < BKT_ITEMS; ++k) {
+            const u64 at2 = at0 + k * BKT_THREADS + tid;
+            if (at2 < a.spill_cap) { a.spill_a[at2] = key[k]; a.spill_p[at2] = val[k]; a.spill_b[at2] = (u32)b; }
+        }
+        return;
+    }
+    const u32 n = c_raw;
 #pragma unroll
     for (u32 k = 0; k < BKT_ITEMS; ++k) {
         const u32 e = k * BKT_THREADS + tid;
@@ -889,6 +902,8 @@ struct PieceArgs {
     u64* out_a;          // [NB][stride_k] packed (hash remainder | reference << rem_bits)
     u32* out_p;          // [NB][stride_v] positions
     u64 stride_k, stride_v;  // elements between two buckets: BKT_CAP + a pad (see yh_pieces)
+    // pairs that find their bucket full (a hash thousands of references hold) go to a side list; flags[1] counts them
+    u64* spill_a; u32* spill_p; u32* spill_b; u64 spill_cap;
     u32* out_cnt;        // [NB]
     u32* flags;          // |= 8: a sketch is not ascending (bounds pass) or a piece holds a hash of another region
     u32 check_order;
@@ -1053,16 +1068,62 @@ __global__ void __launch_bounds__(PART_THREADS) k_piece_part(const PieceArgs a) 
             if (s < tile_n) {
                 const u32 b = sbin[s];
                 const u64 at = (u32)(gbase[b] + s);
-                if (at < BKT_CAP) {  // (an overflowing bucket is seen by k_bucket_group: its count exceeds the capacity)
-                    const u64 bkt = (u64)r * a.P2 + b;
+                const u64 bkt = (u64)r * a.P2 + b;
+                if (at < BKT_CAP) {
                     a.out_a[bkt * a.stride_k + at] = skey[s];
                     a.out_p[bkt * a.stride_v + at] = sval[s];
+                } else if (a.spill_a) {  // the bucket is full: the side list (the grouping pass sends the bucket's other pairs after it)
+                    const u64 at2 = atomicAdd(&a.flags[1], 1u);
+                    if (at2 < a.spill_cap) { a.spill_a[at2] = skey[s]; a.spill_p[at2] = sval[s]; a.spill_b[at2] = (u32)bkt; }
                 }
             }
         }
         __syncthreads();
     }
     if (__ballot(bad) != 0ull && (tid & 63u) == 0) atomicOr(a.flags, 8u);
+}
+
+// ---- the side list of the overflowed buckets ------------------------------------------------------------------------------
+// A bucket holds 4 096 pairs; a k-mer that 40 000 references share (conserved rRNA 31-mers across GTDB) puts ten times
+// that into one.  Until round 4 ONE such bucket sent the whole database to rocPRIM's radix sort and `yacht train` off its
+// fused path.  Now the bucket's pairs go to a side list -- the late ones from k_piece_part, the rest from k_bucket_group5 --
+// which alone is sorted by (bucket, hash remainder) with rocPRIM and grouped by the two kernels below: every pair finds its
+// run of equal keys by binary search (the list is small), its rank is its place in the run, the run IS the group's holder
+// list (yh_db::d_fz_list2), the record names it.  Everything else stays where it was.
+__global__ void k_spill_keys(const u64* __restrict__ sa, const u32* __restrict__ sb, u64 n, u32 rem_bits, u64* __restrict__ key, u32* __restrict__ idx) {
+    const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    key[i] = ((u64)sb[i] << rem_bits) | (sa[i] & ((1ull << rem_bits) - 1ull));
+    idx[i] = (u32)i;
+}
+__global__ void __launch_bounds__(256) k_spill_group(const u64* __restrict__ key /* sorted */, const u32* __restrict__ idx, u64 n,
+                                                     const u64* __restrict__ sa, const u32* __restrict__ sp, u32 rem_bits, u64 n_pos,
+                                                     u64 list_base, u32* __restrict__ list2, u64* __restrict__ rec,
+                                                     unsigned long long* __restrict__ totals) {
+    __shared__ u32 tot3[3];
+    if (threadIdx.x < 3) tot3[threadIdx.x] = 0;
+    __syncthreads();
+    const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    bool head = false, shared = false;
+    if (i < n) {
+        const u64 k = key[i];
+        u64 lo = 0, hi = i;  // first entry of the run: the smallest j with key[j] == k (key[i] == k)
+        while (lo < hi) { const u64 mid = (lo + hi) >> 1; if (key[mid] < k) lo = mid + 1; else hi = mid; }
+        const u64 first = lo;
+        lo = i; hi = n;      // one past its last entry
+        while (lo < hi) { const u64 mid = (lo + hi) >> 1; if (key[mid] <= k) lo = mid + 1; else hi = mid; }
+        const u64 len = lo - first;
+        const u32 j = idx[i];
+        list2[i] = (u32)(sa[j] >> rem_bits);
+        head = i == first;
+        shared = len >= 2;
+        const u32 pos = sp[j];
+        if (shared && pos < n_pos) rec[pos] = (1ull << 63) | (len << 40) | (list_base + first);
+    }
+    const u32 c0 = (u32)__popcll(__ballot(head)), c1 = (u32)__popcll(__ballot(head && shared)), c2 = (u32)__popcll(__ballot(shared));
+    if ((threadIdx.x & 63u) == 0) { atomicAdd(&tot3[0], c0); atomicAdd(&tot3[1], c1); atomicAdd(&tot3[2], c2); }
+    __syncthreads();
+    if (threadIdx.x < 3 && tot3[threadIdx.x]) atomicAdd(&totals[threadIdx.x], (unsigned long long)tot3[threadIdx.x]);
 }
 
 static_assert(BKT_SLOTS == (1u << BKT_SLOT_BITS), "slots per bucket");
@@ -1374,6 +1435,11 @@ struct yh_pieces {
     unsigned long long* totals = nullptr;
     u64* rec = nullptr;
     u64 scanned = 0;      // pairs the bounds pass has seen
+    // the side list of overflowed buckets (k_piece_part / k_bucket_group5 -> yh_pc_finish_emit)
+    u64* spill_a = nullptr; u32* spill_p = nullptr; u32* spill_b = nullptr;
+    u64 spill_cap = 0;
+    u64 n_spilled = 0, n_spilled_buckets = 0;  // (what yh_pc_finish_emit found)
+    u32* list2 = nullptr;  // the holder lists of the spilled groups (handed to the handle)
 };
 
 static unsigned bitlen64(u64 x) { unsigned b = 0; while (x) { ++b; x >>= 1; } return b; }
@@ -1432,6 +1498,7 @@ bool yh_pc_applicable(u64 H, u64 max_hash, u64 n_refs) {
 void yh_pc_destroy(yh_db* db, yh_pieces* s) {
     if (!s) return;
     yh_tfree(db, s->bnd); yh_tfree(db, s->a2); yh_tfree(db, s->p2); yh_tfree(db, s->cnt); yh_tfree(db, s->totals);
+    yh_tfree(db, s->spill_a); yh_tfree(db, s->spill_p); yh_tfree(db, s->spill_b); yh_tfree(db, s->list2);
     delete s;
 }
 int yh_pc_begin(yh_db* db, u64 H, u64 max_hash, u64 n_refs, u64* d_rec, yh_pieces** out) {
@@ -1444,6 +1511,15 @@ int yh_pc_begin(yh_db* db, u64 H, u64 max_hash, u64 n_refs, u64* d_rec, yh_piece
     if (e == hipSuccess) e = yh_tmalloc(db, (void**)&s->p2, s->NB * s->stride_v * sizeof(u32));
     if (e == hipSuccess) e = yh_tmalloc(db, (void**)&s->cnt, (s->NB + 4) * sizeof(u32));
     if (e == hipSuccess) e = yh_tmalloc(db, (void**)&s->totals, TOT_LANES * 8 * sizeof(unsigned long long));
+    // room for the side list: a sixteenth of the pairs (at least a million) -- more than that overflowing is not a database with
+    // a few hot k-mers but keys this distribution is not made for (refused: flag 2)
+    static const bool no_spill = [] { const char* e_ = yh_tune_env("YH_NO_SPILL"); return e_ && e_[0] == '1'; }();
+    s->spill_cap = no_spill ? 0 : std::max<u64>(H / 16, (u64)1 << 20);
+    if (s->spill_cap) {
+        if (e == hipSuccess) e = yh_tmalloc(db, (void**)&s->spill_a, s->spill_cap * sizeof(u64));
+        if (e == hipSuccess) e = yh_tmalloc(db, (void**)&s->spill_p, s->spill_cap * sizeof(u32));
+        if (e == hipSuccess) e = yh_tmalloc(db, (void**)&s->spill_b, s->spill_cap * sizeof(u32));
+    }
     if (e == hipSuccess) e = hipMemsetAsync(s->cnt, 0, (s->NB + 4) * sizeof(u32), db->stream);
     if (e == hipSuccess) e = hipMemsetAsync(s->totals, 0, TOT_LANES * 8 * sizeof(unsigned long long), db->stream);
     if (e != hipSuccess) {
@@ -1461,6 +1537,7 @@ static PieceArgs pc_args(const yh_pieces* s, const u64* d_values, const u64* d_o
     a.mul = s->mul_fine; a.lsh = s->lsh; a.rem_bits = s->rem_bits; a.inv_p2 = s->inv_p2;
     a.rec_clear = s->rec; a.out_a = s->a2; a.out_p = s->p2; a.out_cnt = s->cnt; a.flags = s->cnt + s->NB;
     a.stride_k = s->stride_k; a.stride_v = s->stride_v;
+    a.spill_a = s->spill_a; a.spill_p = s->spill_p; a.spill_b = s->spill_b; a.spill_cap = s->spill_cap;
     return a;
 }
 // the bounds pass over the sketches [r0, r1) (any number of calls, any order: the chunks of an upload as they arrive)
@@ -1478,7 +1555,7 @@ int yh_pc_scan(yh_db* db, yh_pieces* s, const u64* d_values, const u64* d_offset
 }
 // distribution + the fused last pass (k_bucket_group on packed pairs): as yh_psort_finish_emit
 int yh_pc_finish_emit(yh_db* db, yh_pieces* s, const u64* d_values, const u64* d_offsets, u64 totals[3], u32** d_list_out, bool* took_it,
-                      bool* unsorted) {
+                      bool* unsorted, yh_pc_spill* spill) {
     *took_it = false;
     *d_list_out = nullptr;
     if (unsorted) *unsorted = false;
@@ -1501,6 +1578,7 @@ int yh_pc_finish_emit(yh_db* db, yh_pieces* s, const u64* d_values, const u64* d
     b.rec = s->rec;
     b.list = s->p2;
     b.rem_bits = s->rem_bits;
+    b.spill_a = s->spill_a; b.spill_p = s->spill_p; b.spill_b = s->spill_b; b.spill_cap = s->spill_cap;
     static const bool no_inline = [] { const char* e = yh_tune_env("YH_FZ_NO_INLINE"); return e && e[0] == '1'; }();
     b.inline_ok = (s->n_refs < (1u << 21) - 1 && !no_inline) ? 1u : 0u;
     b.totals = s->totals;
@@ -1517,16 +1595,63 @@ int yh_pc_finish_emit(yh_db* db, yh_pieces* s, const u64* d_values, const u64* d
     YH_HIP(hipStreamSynchronize(db->stream));
     for (u32 q = 0; q < TOT_LANES; ++q)
         for (u32 t = 0; t < 4; ++t) ht[t] += hrows[q * 8 + t];
-    *took_it = (hflags[0] & 7u) == 0 && ht[3] == s->H && s->scanned == s->H && !(hflags[0] & 8u);
+    // the side list: hflags[1] pairs of hflags[2] overflowed buckets -- sorted by (bucket, hash remainder) and grouped on their own
+    const u64 n_spill = hflags[1];
+    bool spill_ok = true;
+    if (n_spill && (hflags[0] & 15u) == 0) {
+        unsigned nb_bits = 1;
+        while (nb_bits < 32 && (s->NB >> nb_bits) != 0) ++nb_bits;
+        if (n_spill > s->spill_cap || nb_bits + s->rem_bits > 64) {
+            spill_ok = false;
+        } else {
+            u64 *k_in = nullptr, *k_out = nullptr;
+            u32 *i_in = nullptr, *i_out = nullptr;
+            hipError_t e2 = yh_tmalloc(db, (void**)&k_in, n_spill * sizeof(u64));
+            if (e2 == hipSuccess) e2 = yh_tmalloc(db, (void**)&k_out, n_spill * sizeof(u64));
+            if (e2 == hipSuccess) e2 = yh_tmalloc(db, (void**)&i_in, n_spill * sizeof(u32));
+            if (e2 == hipSuccess) e2 = yh_tmalloc(db, (void**)&i_out, n_spill * sizeof(u32));
+            if (e2 == hipSuccess) e2 = yh_tmalloc(db, (void**)&s->list2, n_spill * sizeof(u32));
+            int rc2 = e2 == hipSuccess ? YH_OK : YH_ERR_OOM;
+            if (rc2 == YH_OK) {
+                k_spill_keys<<<(u32)((n_spill + 255) / 256), 256, 0, db->stream>>>(s->spill_a, s->spill_b, n_spill, s->rem_bits, k_in, i_in);
+                rc2 = yh_radix_sort_pairs_u64_u32(db, k_in, k_out, i_in, i_out, n_spill, nb_bits + s->rem_bits);
+            }
+            if (rc2 == YH_OK) {
+                const u64 list_base = s->NB * s->stride_v;  // (list records below it name the buckets' own list areas: yh_db::fz_list_split)
+                k_spill_group<<<(u32)((n_spill + 255) / 256), 256, 0, db->stream>>>(k_out, i_out, n_spill, s->spill_a, s->spill_p, s->rem_bits, s->H,
+                                                                                   list_base, s->list2, s->rec, s->totals);
+                if (hipGetLastError() != hipSuccess) rc2 = YH_ERR_HIP;
+                unsigned long long add3[3] = {0, 0, 0};
+                if (rc2 == YH_OK && hipMemcpyAsync(add3, s->totals, sizeof(add3), hipMemcpyDeviceToHost, db->stream) != hipSuccess) rc2 = YH_ERR_HIP;
+                if (rc2 == YH_OK && hipStreamSynchronize(db->stream) != hipSuccess) rc2 = YH_ERR_HIP;
+                // (row 0 of the counters held the grouping pass's share of buckets 0, 256, ...: already summed into ht[] above)
+                for (u32 t = 0; t < 3; ++t) ht[t] += add3[t] - hrows[t];
+                ht[3] += n_spill;
+            }
+            yh_tfree(db, k_in); yh_tfree(db, k_out); yh_tfree(db, i_in); yh_tfree(db, i_out);
+            if (rc2 != YH_OK) { yh_set_error("the side list of the overflowed buckets could not be grouped"); return rc2; }
+            s->n_spilled = n_spill;
+            s->n_spilled_buckets = hflags[2];
+        }
+    }
+    *took_it = spill_ok && (hflags[0] & 7u) == 0 && ht[3] == s->H && s->scanned == s->H && !(hflags[0] & 8u);
     if (unsorted) *unsorted = (hflags[0] & 8u) != 0;
     static const bool trace = [] { const char* e = yh_tune_env("YH_TRACE_BUILD"); const char* f = yh_tune_env("YH_TRACE_SORT"); return (e && e[0] == '1') || (f && f[0] == '1'); }();
     if (trace)
         fprintf(stderr, "[yh pieces] H %llu  P1 %u x P2 %u = %llu buckets  S %u x Gn %u  SK %u  rem_bits %u  flags %u  records of %llu of %llu -> %s\n",
                 (u64)s->H, s->P1, s->P2, (u64)s->NB, s->S, s->Gn, s->SK, s->rem_bits, hflags[0], (u64)ht[3], (u64)s->H, *took_it ? "taken" : "REFUSED");
+    if (trace && n_spill) fprintf(stderr, "[yh pieces] side list: %llu pairs of %u overflowed buckets (room for %llu)\n", (u64)n_spill, hflags[2], (u64)s->spill_cap);
     if (*took_it) {
         totals[0] = ht[0]; totals[1] = ht[1]; totals[2] = ht[2];
         *d_list_out = s->p2;
         s->p2 = nullptr;
+        if (spill) {
+            spill->d_list2 = s->list2;
+            s->list2 = nullptr;
+            spill->list_split = s->NB * s->stride_v;
+            spill->n_pairs = s->n_spilled;
+            spill->n_buckets = s->n_spilled_buckets;
+        }
     }
     return YH_OK;
 }
