@@ -147,30 +147,33 @@ print(json.dumps({"ok": ok, "pairs": int(wi.size)}))
 """
 
 
+@pytest.mark.parametrize("mode", ["pieces", "two_level"])
 @pytest.mark.parametrize("heavy,verdict", [(0, "taken"), (800, "taken"), (2000, "REFUSED")])
-def test_distribution_sort_takes_uniform_keys_and_refuses_the_rest(hip_lib, heavy, verdict):
-    """yh_sort.hip on 2 000 sketches (8e5 hashes, ~310 buckets): uniform keys and a hash held by 800 references are sorted by
-    it; a hash held by all 2 000 overflows its bucket: the two-level sort of the full handle refuses it on the device and
-    rocPRIM sorts instead, the train handle's distribution sends that bucket to its side list -- the verdict lines say which
-    ([yh sort] / [yh pieces] ... taken / REFUSED), the order is checked on the device either way (YH_CHECK_SORT) and pairs
-    and statistics equal the oracle's."""
+def test_distribution_sort_takes_uniform_keys_and_refuses_the_rest(hip_lib, heavy, verdict, mode):
+    """yh_sort.hip on 2 000 sketches (8e5 hashes, ~310 buckets), the train handle and the full handle: uniform keys, a hash
+    held by 800 references, a hash held by all 2 000 (it overflows its bucket).
+    mode "pieces" (the default since round 5: regions read in place, overflowed buckets through a side list): all three are
+    TAKEN by both handles -- the verdict lines "[yh pieces] ... -> taken", and "side list" says when it was used;
+    mode "two_level" (YH_NO_PIECES=1 YH_NO_PIECES_SORT=1: round 4's two-level sort, still the path of inputs the piece geometry
+    does not take): the overflowing one is REFUSED on the device and sorted by rocPRIM ("[yh sort] ... -> REFUSED").
+    Either way the order is checked on the device (YH_CHECK_SORT) and pairs and statistics equal the oracle's."""
     env = dict(os.environ)
     env.update({"YH_DEBUG_TUNING": "1", "YH_TRACE_BUILD": "1", "YH_CHECK_SORT": "1"})
+    if mode == "two_level":
+        env.update({"YH_NO_PIECES": "1", "YH_NO_PIECES_SORT": "1"})
     r = subprocess.run([sys.executable, "-c", SORT_WORKER, ROOT, str(heavy)], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["ok"] and out["pairs"] > 300
-    # The train handle goes through the distribution without a first level ("[yh pieces]"), which takes ALL three inputs since
-    # round 5: the bucket a hash of 2 000 holders overflows goes to its side list; the full handle goes through the two-level
-    # sort ("[yh sort]"), which still refuses that one for rocPRIM.
     verdicts = [ln for ln in r.stderr.splitlines() if (ln.startswith("[yh sort]") or ln.startswith("[yh pieces]")) and " -> " in ln]
-    assert len(verdicts) == 2, verdicts
     pieces = [ln for ln in verdicts if ln.startswith("[yh pieces]")]
     sorts = [ln for ln in verdicts if ln.startswith("[yh sort]")]
-    assert len(pieces) == 1 and pieces[0].rstrip().endswith("taken"), verdicts
-    assert len(sorts) == 1 and sorts[0].rstrip().endswith(verdict), verdicts
-    side = [ln for ln in r.stderr.splitlines() if ln.startswith("[yh pieces] side list:")]
-    assert (len(side) == 1) == (heavy == 2000), r.stderr[-1500:]
+    if mode == "pieces":
+        assert len(pieces) == 2 and not sorts and all(ln.rstrip().endswith("taken") for ln in pieces), verdicts
+        used_side_list = ["side list: " in ln or ("side list " in ln and " side list 0 pairs" not in ln) for ln in r.stderr.splitlines() if ln.startswith("[yh pieces]")]
+        assert any(used_side_list) == (heavy == 2000), r.stderr[-1500:]
+    else:
+        assert not pieces and len(sorts) == 2 and all(ln.rstrip().endswith(verdict) for ln in sorts), verdicts
 
 
 def test_tiny_sketches_and_shared_counts_on_the_train_handle(hip_lib):

@@ -999,12 +999,31 @@ int yh_build_index(yh_db* db, const u64* d_values, const u64* d_offsets, u64* d_
     db->sort_path = ps ? YH_SORT_TWO_LEVEL : YH_SORT_RADIX;  // (pairs sorted behind the upload: by whichever of the two took them)
     bool order_checked = db->order_checked;
     if (rc == YH_OK && !d_sk_pre) {
-        k_fill_ref_ids<<<grid_for(N * WAVE, 256), 256, 0, st>>>(d_offsets, N, d_ids);
         const u32* ids_src = d_ids;
-        // the pairs in (hash, reference) order: the distribution sort of yh_sort.hip for uniform keys (FracMinHash hashes
-        // are), rocPRIM's LSD radix sort -- stable: equal hashes keep ascending references -- for anything else
+        // the pairs in (hash, reference) order: the distribution of yh_sort.hip for uniform keys (FracMinHash hashes are) --
+        // without a first level where the geometry allows (round 5: regions read in place as pieces of the ascending sketches;
+        // buckets that overflow go through a side list) --, rocPRIM's LSD radix sort -- stable: equal hashes keep ascending
+        // references -- for anything else
         bool sorted = false;
-        if (rc == YH_OK && try_psort) {
+        static const bool no_pc_sort = [] { const char* e = yh_tune_env("YH_NO_PIECES_SORT"); return e && e[0] == '1'; }();
+        if (rc == YH_OK && try_psort && !no_pc_sort && db->max_hash != ~0ull && yh_pc_applicable(H, db->max_hash, N)) {
+            bool unsorted = false;
+            u64 sp_pairs = 0, sp_buckets = 0;
+            rc = yh_pc_sort(db, d_values, d_offsets, N, H, db->max_hash, !order_checked, d_sk, d_sv, &ps, &sorted, &unsorted, &sp_pairs, &sp_buckets);
+            if (rc == YH_OK && !order_checked && unsorted) {
+                yh_set_error("a reference sketch is not strictly ascending (or offsets are not monotone)");
+                rc = YH_ERR_UNSORTED;
+            }
+            if (rc == YH_OK && sorted) {
+                order_checked = true;
+                db->sort_path = YH_SORT_PIECES;
+                db->n_spilled_pairs = sp_pairs;
+                db->n_spilled_buckets = sp_buckets;
+                yh_psort_chunks(ps, &nb, &d_chunk_off, &d_chunk_counts);
+            }
+        }
+        if (rc == YH_OK && !sorted) k_fill_ref_ids<<<grid_for(N * WAVE, 256), 256, 0, st>>>(d_offsets, N, d_ids);
+        if (rc == YH_OK && try_psort && !sorted) {
             bool unsorted = false;
             rc = yh_psort_begin(db, H, db->max_hash, &ps);
             if (rc == YH_OK) yh_psort_check_order(ps, !order_checked);  // (the first level reads every pair anyway)

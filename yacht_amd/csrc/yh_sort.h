@@ -50,3 +50,8 @@ int yh_pc_finish_emit(yh_db* db, yh_pieces* s, const u64* d_values, const u64* d
 // rocPRIM's radix sort of (u64 key, u32 value) pairs over the low end_bit bits (yh_build.hip, where rocPRIM lives)
 int yh_radix_sort_pairs_u64_u32(yh_db* db, const u64* k_in, u64* k_out, const u32* v_in, u32* v_out, u64 n, unsigned end_bit);
 void yh_pc_destroy(yh_db* db, yh_pieces* s);
+// every OTHER handle through the same distribution: all pairs in (hash, reference) order in d_keys_out / d_vals_out (H entries each),
+// the buckets as chunks (*chunks_out: for yh_psort_chunks, the caller's to yh_psort_destroy); buckets that overflow go through
+// a side list sorted by rocPRIM and come back to their places.  *took_it = false: not this path's keys, nothing usable written.
+int yh_pc_sort(yh_db* db, const u64* d_values, const u64* d_offsets, u64 n_refs, u64 H, u64 max_hash, bool check_order,
+               u64* d_keys_out, u32* d_vals_out, yh_psort** chunks_out, bool* took_it, bool* unsorted, u64* n_spilled_pairs, u64* n_spilled_buckets);

@@ -311,6 +311,7 @@ __global__ void __launch_bounds__(PART_THREADS) k_part(const PartArgs a) {
 }
 
 // exclusive scan of min(cnt[b], cap) over the buckets into 64-bit offsets (single workgroup); flags |= 2 when a bucket is over
+// (cap = 0: the counts as they are -- the pairs beyond a bucket's capacity are on the side list and come back to their places)
 __global__ void __launch_bounds__(1024) k_bucket_offsets(const u32* __restrict__ cnt, u64 nb, u32 cap, u64* __restrict__ off,
                                                          u32* __restrict__ flags) {
     __shared__ u32 lds[1024];
@@ -319,7 +320,7 @@ __global__ void __launch_bounds__(1024) k_bucket_offsets(const u32* __restrict__
     for (u64 base = 0; base < nb; base += 1024) {
         const u64 b = base + threadIdx.x;
         u32 c = b < nb ? cnt[b] : 0u;
-        if (c > cap) { atomicOr(flags, 2u); c = cap; }
+        if (cap && c > cap) { atomicOr(flags, 2u); c = cap; }
         lds[threadIdx.x] = c;
         __syncthreads();
         block_scan_inplace<1>(lds, 1024, wtot);
@@ -361,7 +362,8 @@ struct BucketArgs {
                                  // (one row of four counters for all 19 600 workgroups: 78 000 atomics on ONE cache line, ~6 ns each --
                                  // the whole 0.5 ms of this kernel at configs[3], whatever else it did: profiles/r05/ablate_group.txt)
     u64 stride_v;                // packed pairs: elements between two buckets of in_v / list (in_k: cap_in)
-    u64* spill_a; u32* spill_p; u32* spill_b; u64 spill_cap;  // k_bucket_group5: the side list of the buckets that overflowed
+    u32* over_bits;              // != NULL: a bucket with more pairs than its capacity (k_bucket_sort: or with a crowded slot) is not an
+                                 // error: its bit is set, flags[2] counts it, and its pairs are grouped / sorted from a side list
     u32 rem_bits;                // != 0: PACKED pairs (k_piece_part): in_k = low rem_bits bits of the hash | reference << rem_bits
                                  // (inside a bucket the hashes span less than 2^rem_bits: the low bits identify them), in_v = position
 };
@@ -434,6 +436,12 @@ __global__ void __launch_bounds__(BKT_THREADS) k_bucket_sort(const BucketArgs a)
         const u32 i = k * BKT_THREADS + tid;
         if (i < n) { key[k] = a.in_k[b * a.cap_in + i]; val[k] = a.in_v[b * a.cap_in + i]; }
     }
+    // the whole bucket to the side list: it overflowed, or -- see below -- one of its slots is crowded; the list is sorted on its own
+    // and its pairs come back to this bucket's place in the output (k_spill_place)
+    auto spill_bucket = [&]() {
+        if (tid == 0) { atomicOr(&a.over_bits[b >> 5], 1u << (b & 31u)); atomicAdd(&a.flags[2], 1u); }
+    };
+    if (a.over_bits && a.cnt[b] > BKT_CAP) { spill_bucket(); return; }  // (uniform)
     if (tid < 3) tot3[tid] = 0;
     static_assert(BKT_SLOTS % (4 * BKT_THREADS) == 0 || BKT_SLOTS / BKT_THREADS < 4, "16-byte clears");
     if (BKT_SLOTS / BKT_THREADS >= 4) {
@@ -485,7 +493,18 @@ __global__ void __launch_bounds__(BKT_THREADS) k_bucket_sort(const BucketArgs a)
             moved[k] = less != rank[k];  // (the one pair of a slot -- most of them -- is where it belongs already)
         }
     }
-    if (crowded) atomicOr(a.flags, 4u);
+    if (a.over_bits) {  // (uniform) a crowded slot -- a hash a thousand references hold -- sends the bucket to the side list
+        if (tid == 0) tot3[0] = 0;
+        __syncthreads();
+        if (crowded) tot3[0] = 1u;
+        __syncthreads();
+        const bool any = tot3[0] != 0u;
+        __syncthreads();
+        if (tid == 0) tot3[0] = 0;
+        if (any) { spill_bucket(); return; }
+    } else if (crowded) {
+        atomicOr(a.flags, 4u);
+    }
     __syncthreads();
 #pragma unroll
     for (u32 k = 0; k < BKT_ITEMS; ++k)
@@ -728,16 +747,11 @@ __global__ void __launch_bounds__(BKT_THREADS) k_bucket_group5(const BucketArgs 
     if (tid < 3) tot3[tid] = 0;
     if (tid == 3) { lcount = 0; has_list = 0; }
     const u32 c_raw = a.cnt[b];
-    if (c_raw > BKT_CAP) {  // (uniform) more pairs than a bucket holds -- a hash thousands of references share: the pairs that
-        // arrived in time follow the late ones to the side list, where the whole bucket is grouped (yh_pc_spill_group)
-        if (!a.spill_a) { if (tid == 0) atomicOr(a.flags, 2u); return; }
-        if (tid == 0) { lcount = atomicAdd(&a.flags[1], BKT_CAP); atomicAdd(&a.flags[2], 1u); }
-        __syncthreads();
-        const u64 at0 = lcount;
-#pragma unroll
-        for (u32 k = 0; k < BKT_ITEMS; ++k) {
-            const u64 at2 = at0 + k * BKT_THREADS + tid;
-            if (at2 < a.spill_cap) { a.spill_a[at2] = key[k]; a.spill_p[at2] = val[k]; a.spill_b[at2] = (u32)b; }
+    if (c_raw > BKT_CAP) {  // (uniform) more pairs than a bucket holds -- a hash thousands of references share: the bucket is marked
+        // and ALL its pairs are grouped from the side list (k_spill_collect / k_spill_group)
+        if (tid == 0) {
+            if (a.over_bits) { atomicOr(&a.over_bits[b >> 5], 1u << (b & 31u)); atomicAdd(&a.flags[2], 1u); }
+            else atomicOr(a.flags, 2u);
         }
         return;
     }
@@ -902,11 +916,13 @@ struct PieceArgs {
     u64* out_a;          // [NB][stride_k] packed (hash remainder | reference << rem_bits)
     u32* out_p;          // [NB][stride_v] positions
     u64 stride_k, stride_v;  // elements between two buckets: BKT_CAP + a pad (see yh_pieces)
-    // pairs that find their bucket full (a hash thousands of references hold) go to a side list; flags[1] counts them
+    // the side list of the buckets that overflowed (k_spill_collect): all their pairs, fetched from the sketches once more
     u64* spill_a; u32* spill_p; u32* spill_b; u64 spill_cap;
+    const u32* over_bits;  // bit b: bucket b overflowed (set by the pass behind the distribution)
     u32* out_cnt;        // [NB]
     u32* flags;          // |= 8: a sketch is not ascending (bounds pass) or a piece holds a hash of another region
     u32 check_order;
+    u32 emit_ref;        // != 0: the pairs leave as (whole hash, reference) -- the input of k_bucket_sort (every handle but `yacht train`'s)
 };
 
 __global__ void __launch_bounds__(PC_BOUND_THREADS) k_piece_bounds(const PieceArgs a, u64 r0, u64 r1) {
@@ -965,6 +981,10 @@ __global__ void __launch_bounds__(PC_BOUND_THREADS) k_piece_bounds(const PieceAr
     }
 }
 
+// (EMIT_REF is a template parameter, and pairs that find their bucket full are NOT appended to the side list here: either one
+// as a run-time branch inside this kernel's loops cost it a third -- 480-500 us against 340, whatever form the branch took:
+// profiles/r05/sweep_part_branches.txt.  The rare case is k_spill_collect's.)
+template <bool EMIT_REF>
 __global__ void __launch_bounds__(PART_THREADS) k_piece_part(const PieceArgs a) {
     __shared__ u64 skey[PART_TILE];
     __shared__ u32 sval[PART_TILE];
@@ -1027,8 +1047,12 @@ __global__ void __launch_bounds__(PART_THREADS) k_piece_part(const PieceArgs a) 
                 if (reg != r) { bad = true; b = 0; }  // (a sketch that is not ascending: the whole attempt is refused)
                 if (b >= a.P2) b = a.P2 - 1u;
                 bin[q] = b;
-                val[q] = pos[q];
-                key[q] = (key[q] & rem_mask) | ((u64)(s0 + who[q]) << a.rem_bits);
+                if constexpr (EMIT_REF) {
+                    val[q] = (u32)(s0 + who[q]);
+                } else {
+                    val[q] = pos[q];
+                    key[q] = (key[q] & rem_mask) | ((u64)(s0 + who[q]) << a.rem_bits);
+                }
                 rank[q] = atomicAdd(&hist[b], 1u);
             }
         }
@@ -1068,13 +1092,11 @@ __global__ void __launch_bounds__(PART_THREADS) k_piece_part(const PieceArgs a) 
             if (s < tile_n) {
                 const u32 b = sbin[s];
                 const u64 at = (u32)(gbase[b] + s);
-                const u64 bkt = (u64)r * a.P2 + b;
-                if (at < BKT_CAP) {
+                if (at < BKT_CAP) {  // (a pair that finds its bucket full is dropped HERE: the bucket's count says so, the pass behind this
+                    // one marks the bucket, and k_spill_collect fetches ALL its pairs from the sketches again -- the rare case pays)
+                    const u64 bkt = (u64)r * a.P2 + b;
                     a.out_a[bkt * a.stride_k + at] = skey[s];
                     a.out_p[bkt * a.stride_v + at] = sval[s];
-                } else if (a.spill_a) {  // the bucket is full: the side list (the grouping pass sends the bucket's other pairs after it)
-                    const u64 at2 = atomicAdd(&a.flags[1], 1u);
-                    if (at2 < a.spill_cap) { a.spill_a[at2] = skey[s]; a.spill_p[at2] = sval[s]; a.spill_b[at2] = (u32)bkt; }
                 }
             }
         }
@@ -1090,11 +1112,50 @@ __global__ void __launch_bounds__(PART_THREADS) k_piece_part(const PieceArgs a) 
 // which alone is sorted by (bucket, hash remainder) with rocPRIM and grouped by the two kernels below: every pair finds its
 // run of equal keys by binary search (the list is small), its rank is its place in the run, the run IS the group's holder
 // list (yh_db::d_fz_list2), the record names it.  Everything else stays where it was.
+// every pair of the marked buckets, fetched from the sketches once more (a wave per sketch, as the bounds pass reads them):
+// 8 H bytes read again -- only when some bucket overflowed
+template <bool EMIT_REF>
+__global__ void __launch_bounds__(256) k_spill_collect(const PieceArgs a) {
+    const u32 lane = threadIdx.x & 63u;
+    const u64 sk = blockIdx.x * 4ull + (threadIdx.x >> 6);
+    if (sk >= a.n_refs) return;
+    const u64 b0 = a.off[sk], e0 = a.off[sk + 1];
+    const u64 rem_mask = (1ull << a.rem_bits) - 1ull;
+    for (u64 p0 = b0; p0 < e0; p0 += 64u * PC_BOUND_U) {
+        u64 h[PC_BOUND_U];
+#pragma unroll
+        for (u32 u = 0; u < PC_BOUND_U; ++u) {
+            const u64 p = p0 + u * 64u + lane;
+            h[u] = p < e0 ? a.values[p] : 0ull;
+        }
+#pragma unroll
+        for (u32 u = 0; u < PC_BOUND_U; ++u) {
+            const u64 p = p0 + u * 64u + lane;
+            if (p >= e0) continue;
+            const u32 bk = bucket_of(h[u], a.lsh, a.mul);
+            if (!((a.over_bits[bk >> 5] >> (bk & 31u)) & 1u)) continue;
+            const u64 at = atomicAdd(&a.flags[1], 1u);
+            if (at < a.spill_cap) {
+                a.spill_a[at] = EMIT_REF ? h[u] : ((h[u] & rem_mask) | (sk << a.rem_bits));
+                a.spill_p[at] = EMIT_REF ? (u32)sk : (u32)p;
+                a.spill_b[at] = bk;
+            }
+        }
+    }
+}
+// (sa = NULL: the key is sb[i] itself)
 __global__ void k_spill_keys(const u64* __restrict__ sa, const u32* __restrict__ sb, u64 n, u32 rem_bits, u64* __restrict__ key, u32* __restrict__ idx) {
     const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     if (i >= n) return;
-    key[i] = ((u64)sb[i] << rem_bits) | (sa[i] & ((1ull << rem_bits) - 1ull));
+    key[i] = sa ? (((u64)sb[i] << rem_bits) | (sa[i] & ((1ull << rem_bits) - 1ull))) : (u64)sb[i];
     idx[i] = (u32)i;
+}
+__global__ void k_spill_gather(const u32* __restrict__ idx, u64 n, const u64* __restrict__ sa, const u32* __restrict__ sp, u64* __restrict__ key, u32* __restrict__ ref) {
+    const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u32 j = idx[i];
+    key[i] = sa[j];
+    ref[i] = sp[j];
 }
 __global__ void __launch_bounds__(256) k_spill_group(const u64* __restrict__ key /* sorted */, const u32* __restrict__ idx, u64 n,
                                                      const u64* __restrict__ sa, const u32* __restrict__ sp, u32 rem_bits, u64 n_pos,
@@ -1124,6 +1185,25 @@ __global__ void __launch_bounds__(256) k_spill_group(const u64* __restrict__ key
     if ((threadIdx.x & 63u) == 0) { atomicAdd(&tot3[0], c0); atomicAdd(&tot3[1], c1); atomicAdd(&tot3[2], c2); }
     __syncthreads();
     if (threadIdx.x < 3 && tot3[threadIdx.x]) atomicAdd(&totals[threadIdx.x], (unsigned long long)tot3[threadIdx.x]);
+}
+
+// the side list of a SORTING handle, sorted by (hash, reference): every pair back to its bucket's place in the output, and the
+// bucket's run statistics (what k_bucket_sort leaves for the buckets it sorts itself)
+__global__ void __launch_bounds__(256) k_spill_place(const u64* __restrict__ key /* sorted */, const u32* __restrict__ ref, u64 n, u32 lsh, u64 mul_fine,
+                                                     const u64* __restrict__ off, u64* __restrict__ out_k, u32* __restrict__ out_v, u32* __restrict__ counts) {
+    const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u64 h = key[i];
+    const u32 b = bucket_of(h, lsh, mul_fine);
+    u64 lo = 0, hi = i;  // the first entry of bucket b (buckets are monotone in the hash)
+    while (lo < hi) { const u64 mid = (lo + hi) >> 1; if (bucket_of(key[mid], lsh, mul_fine) < b) lo = mid + 1; else hi = mid; }
+    const u64 dst = off[b] + (i - lo);
+    out_k[dst] = h;
+    out_v[dst] = ref[i];
+    const bool eq_prev = i > 0 && key[i - 1] == h, eq_next = i + 1 < n && key[i + 1] == h;
+    if (!eq_prev) atomicAdd(&counts[(u64)b * 3], 1u);
+    if (!eq_prev && eq_next) atomicAdd(&counts[(u64)b * 3 + 1], 1u);
+    if (eq_prev || eq_next) atomicAdd(&counts[(u64)b * 3 + 2], 1u);
 }
 
 static_assert(BKT_SLOTS == (1u << BKT_SLOT_BITS), "slots per bucket");
@@ -1509,18 +1589,13 @@ int yh_pc_begin(yh_db* db, u64 H, u64 max_hash, u64 n_refs, u64* d_rec, yh_piece
     hipError_t e = yh_tmalloc(db, (void**)&s->bnd, (u64)(s->P1 + 1) * s->n_pad * sizeof(u32));
     if (e == hipSuccess) e = yh_tmalloc(db, (void**)&s->a2, s->NB * s->stride_k * sizeof(u64));
     if (e == hipSuccess) e = yh_tmalloc(db, (void**)&s->p2, s->NB * s->stride_v * sizeof(u32));
-    if (e == hipSuccess) e = yh_tmalloc(db, (void**)&s->cnt, (s->NB + 4) * sizeof(u32));
+    if (e == hipSuccess) e = yh_tmalloc(db, (void**)&s->cnt, (s->NB + 4 + s->NB / 32 + 2) * sizeof(u32));  // counts | flags[4] | the overflowed buckets as bits
     if (e == hipSuccess) e = yh_tmalloc(db, (void**)&s->totals, TOT_LANES * 8 * sizeof(unsigned long long));
-    // room for the side list: a sixteenth of the pairs (at least a million) -- more than that overflowing is not a database with
-    // a few hot k-mers but keys this distribution is not made for (refused: flag 2)
+    // (the side list of overflowed buckets gets its room when a bucket HAS overflowed: a sixteenth of the pairs, at least a million --
+    // more than that is not a database with a few hot k-mers but keys this distribution is not made for: refused)
     static const bool no_spill = [] { const char* e_ = yh_tune_env("YH_NO_SPILL"); return e_ && e_[0] == '1'; }();
     s->spill_cap = no_spill ? 0 : std::max<u64>(H / 16, (u64)1 << 20);
-    if (s->spill_cap) {
-        if (e == hipSuccess) e = yh_tmalloc(db, (void**)&s->spill_a, s->spill_cap * sizeof(u64));
-        if (e == hipSuccess) e = yh_tmalloc(db, (void**)&s->spill_p, s->spill_cap * sizeof(u32));
-        if (e == hipSuccess) e = yh_tmalloc(db, (void**)&s->spill_b, s->spill_cap * sizeof(u32));
-    }
-    if (e == hipSuccess) e = hipMemsetAsync(s->cnt, 0, (s->NB + 4) * sizeof(u32), db->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(s->cnt, 0, (s->NB + 4 + s->NB / 32 + 2) * sizeof(u32), db->stream);
     if (e == hipSuccess) e = hipMemsetAsync(s->totals, 0, TOT_LANES * 8 * sizeof(unsigned long long), db->stream);
     if (e != hipSuccess) {
         yh_set_error("piece distribution: allocation failed: %s", hipGetErrorString(e));
@@ -1538,6 +1613,7 @@ static PieceArgs pc_args(const yh_pieces* s, const u64* d_values, const u64* d_o
     a.rec_clear = s->rec; a.out_a = s->a2; a.out_p = s->p2; a.out_cnt = s->cnt; a.flags = s->cnt + s->NB;
     a.stride_k = s->stride_k; a.stride_v = s->stride_v;
     a.spill_a = s->spill_a; a.spill_p = s->spill_p; a.spill_b = s->spill_b; a.spill_cap = s->spill_cap;
+    a.over_bits = s->cnt + s->NB + 4;
     return a;
 }
 // the bounds pass over the sketches [r0, r1) (any number of calls, any order: the chunks of an upload as they arrive)
@@ -1553,6 +1629,25 @@ int yh_pc_scan(yh_db* db, yh_pieces* s, const u64* d_values, const u64* d_offset
     s->scanned += n_pairs;
     return YH_OK;
 }
+// some bucket overflowed: room for the side list, then every pair of the marked buckets from the sketches again; *n_spill = their
+// number (more than the room: the caller refuses the attempt).  Synchronizes the stream.
+static int pc_collect_spill(yh_db* db, yh_pieces* s, const u64* d_values, const u64* d_offsets, bool emit_ref, u64* n_spill) {
+    hipError_t e = yh_tmalloc(db, (void**)&s->spill_a, s->spill_cap * sizeof(u64));
+    if (e == hipSuccess) e = yh_tmalloc(db, (void**)&s->spill_p, s->spill_cap * sizeof(u32));
+    if (e == hipSuccess) e = yh_tmalloc(db, (void**)&s->spill_b, s->spill_cap * sizeof(u32));
+    if (e != hipSuccess) { yh_set_error("piece distribution: no room for the side list: %s", hipGetErrorString(e)); return YH_ERR_OOM; }
+    PieceArgs a = pc_args(s, d_values, d_offsets);
+    const u32 grid = (u32)((s->n_refs + 3) / 4);
+    if (emit_ref) k_spill_collect<true><<<grid, 256, 0, db->stream>>>(a);
+    else k_spill_collect<false><<<grid, 256, 0, db->stream>>>(a);
+    YH_HIP(hipGetLastError());
+    u32 got = 0;
+    YH_HIP(hipMemcpyAsync(&got, s->cnt + s->NB + 1, sizeof(u32), hipMemcpyDeviceToHost, db->stream));
+    YH_HIP(hipStreamSynchronize(db->stream));
+    *n_spill = got;
+    return YH_OK;
+}
+
 // distribution + the fused last pass (k_bucket_group on packed pairs): as yh_psort_finish_emit
 int yh_pc_finish_emit(yh_db* db, yh_pieces* s, const u64* d_values, const u64* d_offsets, u64 totals[3], u32** d_list_out, bool* took_it,
                       bool* unsorted, yh_pc_spill* spill) {
@@ -1560,7 +1655,7 @@ int yh_pc_finish_emit(yh_db* db, yh_pieces* s, const u64* d_values, const u64* d
     *d_list_out = nullptr;
     if (unsorted) *unsorted = false;
     PieceArgs a = pc_args(s, d_values, d_offsets);
-    k_piece_part<<<8u * ((s->P1 + 7) / 8) * s->Gn, PART_THREADS, 0, db->stream>>>(a);
+    k_piece_part<false><<<8u * ((s->P1 + 7) / 8) * s->Gn, PART_THREADS, 0, db->stream>>>(a);
     YH_HIP(hipGetLastError());
     u32* flags = s->cnt + s->NB;
     BucketArgs b{};
@@ -1578,7 +1673,7 @@ int yh_pc_finish_emit(yh_db* db, yh_pieces* s, const u64* d_values, const u64* d
     b.rec = s->rec;
     b.list = s->p2;
     b.rem_bits = s->rem_bits;
-    b.spill_a = s->spill_a; b.spill_p = s->spill_p; b.spill_b = s->spill_b; b.spill_cap = s->spill_cap;
+    b.over_bits = s->spill_cap ? s->cnt + s->NB + 4 : nullptr;
     static const bool no_inline = [] { const char* e = yh_tune_env("YH_FZ_NO_INLINE"); return e && e[0] == '1'; }();
     b.inline_ok = (s->n_refs < (1u << 21) - 1 && !no_inline) ? 1u : 0u;
     b.totals = s->totals;
@@ -1596,8 +1691,9 @@ int yh_pc_finish_emit(yh_db* db, yh_pieces* s, const u64* d_values, const u64* d
     for (u32 q = 0; q < TOT_LANES; ++q)
         for (u32 t = 0; t < 4; ++t) ht[t] += hrows[q * 8 + t];
     // the side list: hflags[1] pairs of hflags[2] overflowed buckets -- sorted by (bucket, hash remainder) and grouped on their own
-    const u64 n_spill = hflags[1];
+    u64 n_spill = 0;
     bool spill_ok = true;
+    if (hflags[2] && (hflags[0] & 15u) == 0) YH_TRY(pc_collect_spill(db, s, d_values, d_offsets, false, &n_spill));
     if (n_spill && (hflags[0] & 15u) == 0) {
         unsigned nb_bits = 1;
         while (nb_bits < 32 && (s->NB >> nb_bits) != 0) ++nb_bits;
@@ -1653,5 +1749,106 @@ int yh_pc_finish_emit(yh_db* db, yh_pieces* s, const u64* d_values, const u64* d
             spill->n_buckets = s->n_spilled_buckets;
         }
     }
+    return YH_OK;
+}
+
+
+// ---- the same distribution for every OTHER handle: sorted (hash, reference) pairs + the buckets as chunks (as yh_psort_finish) ----
+// Bounds pass (ordering check) -> pieces read in place, leaving as (whole hash, reference) pairs (no array of reference ids is
+// made and read: k_fill_ref_ids' 4 H bytes each way are gone with the first level's 12 + 12) -> k_bucket_sort.  Buckets that
+// overflow, or hold a slot too crowded for the sort's ranking step, go to the side list: sorted by rocPRIM on their own and put
+// back at their places (k_spill_place) -- the rest of the database never notices.  *chunks_out: a yh_psort that owns the bucket
+// offsets / statistics for yh_psort_chunks (the caller's to yh_psort_destroy).
+int yh_pc_sort(yh_db* db, const u64* d_values, const u64* d_offsets, u64 n_refs, u64 H, u64 max_hash, bool check_order,
+               u64* d_keys_out, u32* d_vals_out, yh_psort** chunks_out, bool* took_it, bool* unsorted, u64* n_spilled_pairs, u64* n_spilled_buckets) {
+    *took_it = false;
+    *chunks_out = nullptr;
+    if (unsorted) *unsorted = false;
+    yh_pieces* s = nullptr;
+    YH_TRY(yh_pc_begin(db, H, max_hash, n_refs, nullptr, &s));
+    struct Guard { yh_db* db; yh_pieces* s; ~Guard() { yh_pc_destroy(db, s); } } guard{db, s};
+    if (s->stride_k != BKT_CAP || s->stride_v != BKT_CAP) { yh_set_error("internal: padded bucket strides are for the grouping pass only"); return YH_ERR_INVALID_ARG; }
+    u64* off = nullptr;
+    u32* counts = nullptr;
+    hipError_t e = yh_tmalloc(db, (void**)&off, (s->NB + 1) * sizeof(u64));
+    if (e == hipSuccess) e = yh_tmalloc(db, (void**)&counts, s->NB * 3 * sizeof(u32));
+    if (e == hipSuccess) e = hipMemsetAsync(counts, 0, s->NB * 3 * sizeof(u32), db->stream);
+    if (e != hipSuccess) { yh_tfree(db, off); yh_tfree(db, counts); yh_set_error("piece distribution: allocation failed: %s", hipGetErrorString(e)); return YH_ERR_OOM; }
+    auto fail = [&](int rc) { yh_tfree(db, off); yh_tfree(db, counts); return rc; };
+    int rc = yh_pc_scan(db, s, d_values, d_offsets, 0, n_refs, H, check_order);
+    if (rc != YH_OK) return fail(rc);
+    PieceArgs a = pc_args(s, d_values, d_offsets);
+    a.emit_ref = 1u;
+    a.rec_clear = nullptr;
+    k_piece_part<true><<<8u * ((s->P1 + 7) / 8) * s->Gn, PART_THREADS, 0, db->stream>>>(a);
+    u32* flags = s->cnt + s->NB;
+    k_bucket_offsets<<<1, 1024, 0, db->stream>>>(s->cnt, s->NB, s->spill_cap ? 0u : BKT_CAP, off, flags);
+    BucketArgs b{};
+    b.in_k = s->a2; b.in_v = s->p2; b.cnt = s->cnt; b.off = off; b.cap_in = BKT_CAP;
+    b.mul_fine = s->mul_fine; b.lsh = s->lsh;
+    b.out_k = d_keys_out; b.out_v = d_vals_out;
+    b.flags = flags; b.counts = counts; b.nb = s->NB;
+    b.over_bits = s->spill_cap ? s->cnt + s->NB + 4 : nullptr;
+    k_bucket_sort<<<(u32)s->NB, BKT_THREADS, 0, db->stream>>>(b);
+    if (hipGetLastError() != hipSuccess) { yh_set_error("piece distribution: launch failed"); return fail(YH_ERR_HIP); }
+    u32 hflags[4] = {0, 0, 0, 0};
+    u64 total = 0;
+    if (hipMemcpyAsync(hflags, flags, 3 * sizeof(u32), hipMemcpyDeviceToHost, db->stream) != hipSuccess ||
+        hipMemcpyAsync(&total, off + s->NB, sizeof(u64), hipMemcpyDeviceToHost, db->stream) != hipSuccess ||
+        hipStreamSynchronize(db->stream) != hipSuccess) { yh_set_error("piece distribution: readback failed"); return fail(YH_ERR_HIP); }
+    u64 n_spill = 0;
+    bool ok = (hflags[0] & 15u) == 0 && total == H && s->scanned == H;
+    if (ok && hflags[2]) {
+        rc = pc_collect_spill(db, s, d_values, d_offsets, true, &n_spill);
+        if (rc != YH_OK) return fail(rc);
+    }
+    if (ok && n_spill) {
+        if (n_spill > s->spill_cap) {
+            ok = false;
+        } else {  // by reference, then (stably) by hash: (hash, reference) order; then every pair to its bucket's place
+            unsigned hbits = 1, rbits = 1;
+            while (hbits < 64 && (max_hash >> hbits) != 0) ++hbits;
+            while (rbits < 32 && ((n_refs - 1) >> rbits) != 0) ++rbits;
+            u64 *k1 = nullptr, *k2 = nullptr;
+            u32 *r1 = nullptr, *r2 = nullptr;
+            e = yh_tmalloc(db, (void**)&k1, n_spill * sizeof(u64));
+            if (e == hipSuccess) e = yh_tmalloc(db, (void**)&k2, n_spill * sizeof(u64));
+            if (e == hipSuccess) e = yh_tmalloc(db, (void**)&r1, n_spill * sizeof(u32));
+            if (e == hipSuccess) e = yh_tmalloc(db, (void**)&r2, n_spill * sizeof(u32));
+            rc = e == hipSuccess ? YH_OK : YH_ERR_OOM;
+            // (radix sort by the REFERENCE as key needs it as the key: sort (ref -> key u64) pairs with the hash as "value" is not what
+            // the helper takes; sort by the composite in two passes instead: pass 1 orders by reference -- key = reference, value =
+            // index -- pass 2 orders stably by hash)
+            u64* kr = k1;  // reference as a 64-bit key
+            if (rc == YH_OK) {
+                k_spill_keys<<<(u32)((n_spill + 255) / 256), 256, 0, db->stream>>>(nullptr, s->spill_p, n_spill, 0u, kr, r1);  // key = reference, idx = i
+                rc = yh_radix_sort_pairs_u64_u32(db, kr, k2, r1, r2, n_spill, rbits);  // r2 = indices in reference order
+            }
+            if (rc == YH_OK) {
+                k_spill_gather<<<(u32)((n_spill + 255) / 256), 256, 0, db->stream>>>(r2, n_spill, s->spill_a, s->spill_p, k1, r1);  // k1 = hash, r1 = reference, in that order
+                rc = yh_radix_sort_pairs_u64_u32(db, k1, k2, r1, r2, n_spill, hbits);  // stable: equal hashes keep ascending references
+            }
+            if (rc == YH_OK) {
+                k_spill_place<<<(u32)((n_spill + 255) / 256), 256, 0, db->stream>>>(k2, r2, n_spill, s->lsh, s->mul_fine, off, d_keys_out, d_vals_out, counts);
+                if (hipGetLastError() != hipSuccess || hipStreamSynchronize(db->stream) != hipSuccess) rc = YH_ERR_HIP;
+            }
+            yh_tfree(db, k1); yh_tfree(db, k2); yh_tfree(db, r1); yh_tfree(db, r2);
+            if (rc != YH_OK) { yh_set_error("the side list of the overflowed buckets could not be sorted"); return fail(rc); }
+        }
+    }
+    if (unsorted) *unsorted = (hflags[0] & 8u) != 0;
+    static const bool trace = [] { const char* e_ = yh_tune_env("YH_TRACE_BUILD"); const char* f = yh_tune_env("YH_TRACE_SORT"); return (e_ && e_[0] == '1') || (f && f[0] == '1'); }();
+    if (trace)
+        fprintf(stderr, "[yh pieces] H %llu  P1 %u x P2 %u = %llu buckets  S %u x Gn %u  flags %u  sorted %llu of %llu  side list %llu pairs of %u buckets -> %s\n",
+                (u64)H, s->P1, s->P2, (u64)s->NB, s->S, s->Gn, hflags[0], (u64)total, (u64)H, (u64)n_spill, hflags[2], ok ? "taken" : "REFUSED");
+    if (!ok) return fail(YH_OK);
+    yh_psort* ps = new yh_psort();  // (only what yh_psort_chunks / yh_psort_destroy look at)
+    ps->H = H; ps->max_hash = max_hash; ps->NB = s->NB; ps->P1 = s->P1; ps->P2 = s->P2;
+    ps->off = off;
+    ps->counts = counts;
+    *chunks_out = ps;
+    *took_it = true;
+    if (n_spilled_pairs) *n_spilled_pairs = n_spill;
+    if (n_spilled_buckets) *n_spilled_buckets = hflags[2];
     return YH_OK;
 }
