@@ -7,8 +7,9 @@ then creates ONE handle and reports the build's device time, its wall time and t
     plain      as bench.py does it
     settle     torch.cuda.empty_cache() + synchronize + 50 ms of sleep in front of the create (are torch's frees what the
                driver is still busy with?)
-    prealloc   YH_POOL_PREALLOC_MB blocks requested up front in <= 1 GiB pieces, freed into the library's cache (the create
-               then finds its memory there)
+    prewarmN   one N-GiB block allocated and handed back to the driver before anything else (default 48): if the stall is a
+               once-per-process cost of the first big allocation, it moves there -- where a helper thread could pay it while
+               the command still parses its inputs
 usage (GPU box):  python scripts/probes/fresh_build_probe.py [--runs 6]  -> one line per child + p50 / p90 per mode"""
 import argparse
 import json
@@ -31,6 +32,15 @@ values, offsets = synth.global_db_refs_device(plan, np.arange(85205), device="cu
 torch.cuda.synchronize()
 if mode == "settle":
     torch.cuda.empty_cache(); torch.cuda.synchronize(); time.sleep(0.05)
+t_pre = 0.0
+if mode.startswith("prewarm"):  # one big allocation made and given back to the driver first: is the cost once per process?
+    gb = int(mode[len("prewarm"):] or 48)
+    t0 = time.perf_counter()
+    blk = torch.empty(gb << 30, dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()
+    del blk
+    torch.cuda.empty_cache(); torch.cuda.synchronize()
+    t_pre = time.perf_counter() - t0
 m0 = _lib.alloc_stats()
 t0 = time.perf_counter()
 db = RefDB.from_device(values.data_ptr(), offsets.data_ptr(), 85205, flags=YH_DB_DEFAULT)
@@ -39,7 +49,7 @@ t1 = time.perf_counter()
 m1 = _lib.alloc_stats()
 print(json.dumps({"mode": mode, "db_build_ms": round(float(db.timing()["ms_db_build"]), 2), "create_wall_ms": round(1e3 * (t1 - t0), 2),
                   "driver_allocs": m1["driver_allocs"] - m0["driver_allocs"], "ms_in_hipMalloc": round(m1["ms_in_driver"] - m0["ms_in_driver"], 1),
-                  "process_s_before_create": round(t0 - t_start, 2)}))
+                  "process_s_before_create": round(t0 - t_start, 2), "prewarm_s": round(t_pre, 3)}))
 db.close()
 ''' % ROOT
 

@@ -877,9 +877,6 @@ __device__ __forceinline__ void lookup_tile_body(u32 wg, u32* tkey, u32* tcnt, u
     const YhDirView& dv = q.dv;
     const u32* __restrict__ filter = q.filter;
     if (q.work_count && wg == 0 && threadIdx.x == 0) *q.work_count = 0;
-#if !(defined(YH_LOOKUP_LATE_BAD) && YH_LOOKUP_LATE_BAD) && !(defined(YH_ABLATE_LOOKUP) && (YH_ABLATE_LOOKUP & 32))
-    if (q.bad && *q.bad == q.bad_gen) return;
-#endif
     u32* my = q.reps + (u64)replica_of(wg, q.rep_mask) * q.n_refs;
     u32* my2 = q.reps2 ? q.reps2 + (u64)replica_of(wg, q.rep_mask) * q.n_refs : nullptr;
     const u64 base = wg * (u64)(THREADS * U);
@@ -892,7 +889,9 @@ __device__ __forceinline__ void lookup_tile_body(u32 wg, u32* tkey, u32* tcnt, u
         ok[u] = t < n && h[u] <= dv.max_hash;
         if (!ok[u]) h[u] = 0;  // (still a valid bucket to read)
     }
-#if defined(YH_LOOKUP_LATE_BAD) && YH_LOOKUP_LATE_BAD  // (the sample's loads are in flight before the verdict of its ordering check is asked for)
+#if !(defined(YH_ABLATE_LOOKUP) && (YH_ABLATE_LOOKUP & 32))
+    // (the verdict of the sample's ordering check is asked for BEHIND the sample's own loads: in front of them every workgroup began
+    // with a dependent round trip -- profiles/r05/ablate_step.txt: 0.2 us of the step)
     if (q.bad && *q.bad == q.bad_gen) return;
 #endif
     for (u32 k = threadIdx.x; k < TSLOTS; k += THREADS) { tkey[k] = 0; tcnt[k] = 0; tcnt2[k] = 0; }

@@ -1131,10 +1131,17 @@ __global__ void __launch_bounds__(256) k_spill_collect(const PieceArgs a) {
 #pragma unroll
         for (u32 u = 0; u < PC_BOUND_U; ++u) {
             const u64 p = p0 + u * 64u + lane;
-            if (p >= e0) continue;
-            const u32 bk = bucket_of(h[u], a.lsh, a.mul);
-            if (!((a.over_bits[bk >> 5] >> (bk & 31u)) & 1u)) continue;
-            const u64 at = atomicAdd(&a.flags[1], 1u);
+            const u32 bk = p < e0 ? bucket_of(h[u], a.lsh, a.mul) : 0u;
+            const bool take = p < e0 && ((a.over_bits[bk >> 5] >> (bk & 31u)) & 1u);
+            // one reserving atomic per WAVE (every pair its own: 1.2e6 adds to ONE word were 10 ms of a hot database's build)
+            const u64 bal = __ballot(take);
+            if (!bal) continue;
+            u32 base = 0;
+            const int first = __ffsll((long long)bal) - 1;
+            if ((int)lane == first) base = atomicAdd(&a.flags[1], (u32)__popcll(bal));
+            base = (u32)__shfl((int)base, first);
+            if (!take) continue;
+            const u64 at = (u64)base + (u64)__popcll(bal & ((1ull << lane) - 1ull));
             if (at < a.spill_cap) {
                 a.spill_a[at] = EMIT_REF ? h[u] : ((h[u] & rem_mask) | (sk << a.rem_bits));
                 a.spill_p[at] = EMIT_REF ? (u32)sk : (u32)p;
