@@ -56,6 +56,9 @@ def inject(values, offsets, n_hot, lo, hi, seed):
 
 
 def time_create(values, offsets, n, flags, reps=5):
+    from yacht_amd import _lib
+
+    _lib.pool_release()  # (every series starts with an empty buffer cache: the first create of each is the warm-up)
     ts, info = [], None
     for _ in range(reps + 1):
         torch.cuda.synchronize()
@@ -66,7 +69,7 @@ def time_create(values, offsets, n, flags, reps=5):
         info = db.info()
         bms = db.timing()["ms_db_build"]
         db.close()
-    return float(np.median(ts[1:])) * 1e3, float(bms), info
+    return float(np.median(ts[1:])) * 1e3, float(bms), dict(info, ms_in_hipMalloc_of_the_series=_lib.alloc_stats()["ms_in_driver"])
 
 
 def main() -> int:

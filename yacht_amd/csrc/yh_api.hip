@@ -38,7 +38,8 @@ const char* yh_tune_env(const char* name) {
 // for the event.  What the cache holds beyond YH_POOL_KEEP (default 48 GiB) goes back to the driver at the end of a
 // create / destroy.
 namespace {
-struct CacheBlock { void* p; size_t bytes; int device; hipStream_t owner; hipEvent_t freed; };
+struct CacheBlock { void* p; size_t bytes; int device; hipStream_t owner; hipEvent_t freed; uint64_t tick; };  // tick: when it came back (trim: oldest first)
+uint64_t g_cache_tick = 0;
 std::mutex g_cache_mu;
 std::vector<CacheBlock> g_cache;                      // free blocks
 std::unordered_map<void*, size_t> g_cache_live;       // blocks handed out: their sizes
@@ -149,7 +150,7 @@ void yh_tfree(yh_db* db, void* p) {
             } else if (!ev) {
                 (void)hipStreamSynchronize(db->stream);
             }
-            g_cache.push_back(CacheBlock{p, it->second, db->device, db->stream, ev});
+            g_cache.push_back(CacheBlock{p, it->second, db->device, db->stream, ev, ++g_cache_tick});
             g_cache_live.erase(it);
             return;
         }
@@ -190,10 +191,12 @@ void yh_pool_trim(yh_db* db) {
             }
             held += b.bytes;
         }
-        while (held > keep) {  // largest idle block first
+        while (held > keep) {  // the idle block that came back longest ago first (round 4: the largest first -- a process that went from one
+            // database to another of a slightly different size then lost the NEW handle's big blocks at every destroy and asked the
+            // driver for them again at every create: 493 ms per build on a box whose hipMalloc stalls, profiles/r05/hot_kmers_first.json)
             int big = -1;
             for (size_t i = 0; i < g_cache.size(); ++i)
-                if (!g_cache[i].owner && (big < 0 || g_cache[i].bytes > g_cache[big].bytes)) big = (int)i;
+                if (!g_cache[i].owner && (big < 0 || g_cache[i].tick < g_cache[big].tick)) big = (int)i;
             if (big < 0) break;
             held -= g_cache[big].bytes;
             drop.push_back(g_cache[big].p);

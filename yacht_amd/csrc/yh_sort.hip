@@ -774,7 +774,16 @@ __global__ void __launch_bounds__(BKT_THREADS) k_bucket_group5(const BucketArgs 
         st[k] = 0xffffffffu;
         if (e < n) {
             const u64 rem = key[k] & rmask;
-            u32 s = (u32)((rem * 0x9E3779B97F4A7C15ull) >> (64 - BKT_SLOT_BITS));
+            const u64 mixed = rem * 0x9E3779B97F4A7C15ull;
+            u32 s = (u32)(mixed >> (64 - BKT_SLOT_BITS));
+#if defined(YH_GROUP_LINEAR) && YH_GROUP_LINEAR
+            const u32 step = 1u;
+#else
+            // DOUBLE HASHING: the probe step is a second (odd) function of the hash -- a wave makes max-over-lanes(probes) steps per
+            // pair, and two hashes that collide do not share the rest of their probe sequences as they do with step 1 (simulated at
+            // this load: 8.9 wave steps per four pairs against 11.6; the inserts are ~25 us per wave step at configs[3])
+            const u32 step = ((u32)(mixed >> 20) & (BKT_CAP - 1u)) | 1u;
+#endif
             u32 rank = 0;
 #if defined(YH_ABLATE_GROUP) && (YH_ABLATE_GROUP & 4)  // timing-only build: no table inserts
             tidx[s] = e + 1u; won = (rem & 1ull) != 0;
@@ -790,7 +799,7 @@ __global__ void __launch_bounds__(BKT_THREADS) k_bucket_group5(const BucketArgs 
                     rank = r + 1u;
                     break;
                 }
-                s = (s + 1u) & (BKT_CAP - 1u);
+                s = (s + step) & (BKT_CAP - 1u);
             }
             st[k] = s | (rank << 12);
         }
