@@ -15,13 +15,21 @@ database of 85 205 reference sketches per GPU (k=31, scaled=1000, sizes LogNorma
 [300, 15000], ~10 % of the genomes in clusters of 2-8 sharing 10-95 %) against ~1 M-hash samples; the
 metric "ref-sketch containment queries/sec" counts one (sample, reference) intersection as one query.
 
-N > 1: the references of ONE database are cut into contiguous shards balanced by hash count
-(dist.shard_plan; clusters straddle the cuts), one shard per GPU.  --scaling weak (default): the
-database grows with N (85 205 references per GPU); --scaling strong: the 85 205-reference database is
-cut N ways.  Either way the counts are the exact global ones (dist.ShardedRefDB: rank-local lookup, one
-all-gather of the subset bits inside the step -- in flight while the next sample's lookup runs -- and one
-all-gather of the count rows per --gather-every samples), and rank 0 checks them against the CPU oracle
-on the WHOLE database.
+N > 1 (default --shard hash, --block-mode batched, --scaling strong): the HASH SPACE of ONE 85 205-reference database is cut
+over the ranks (dist.HashRangeRefDB: every GPU holds one hash range of all references and looks up the sample's hashes in it;
+tables AND lookups divide) and the samples go in blocks of 64 through dist.BatchedRangeRunner: first halves, ONE all-gather
+of the ranks' non-zero subset words, second halves, ONE sum-reduce of compact count rows to rank 0 -- 0.54 MB per rank and
+block, three blocks in flight.  The counts are the exact global ones; rank 0 checks them against the CPU oracle on the WHOLE
+database.  --shard refs: contiguous reference shards + ghosts (dist.ShardedRefDB, the capacity mode); --block-mode steps: one
+sample per pair of half-steps; --scaling weak: 85 205 references per GPU.
+An N > 1 line proves itself and carries its own like-for-like baseline:
+  form, value_1gpu_same_form   what a step of `value` is (batched blocks), and rank 0 ALONE running the same blocks of the same
+                               samples on the whole database through the same runner, measured after the timed region
+  scaling_efficiency           value / (N x value_1gpu_same_form)
+  rccl_world_size, distributed what the process group reports after init, every rank's device identity (all-gathered), and a
+                               one-word all-reduce only N distinct ranks can get right (the line is refused if it is wrong)
+At N = 1 `value` is ONE sample per launch (as the reference runs samples: run_YACHT.py:150); `value_batched` is the same
+runner on the whole database -- what N > 1 values are to be divided by.
 
 Rank 0 prints ONE JSON line (contract in the task statement).  Beside the contract's keys:
   device_resident   median / p10 / p90 of per-step HIP-event intervals (a separate pass)

@@ -731,10 +731,20 @@ __global__ void __launch_bounds__(BKT_THREADS) k_bucket_group5(const BucketArgs 
     const u32 tid = threadIdx.x;
     const u64 b = (u64)(blockIdx.x & 7u) * a.per_xcd + (blockIdx.x >> 3);
     if ((blockIdx.x >> 3) >= a.per_xcd || b >= a.nb) return;
+    const u32 c_raw = a.cnt[b];  // (asked for first: it is back by the time the first half of the pairs is)
     u64 key[BKT_ITEMS];
     u32 val[BKT_ITEMS], st[BKT_ITEMS];  // st: slot | rank << 12 (rank 0: claimed the slot; members: 1 + order of arrival)
+    // The first half of the capacity is requested before the bucket's count is known (the capacity is allocated for every bucket;
+    // slots beyond the count hold garbage nobody uses) -- a bucket holds ~2 560 pairs, so these are nearly all real --, the second
+    // half behind the count, which has arrived meanwhile: only the pairs that exist.  (All four quarters up front: 0.96 GB read
+    // for 0.60 GB of pairs at configs[3].)
+#if defined(YH_GROUP_SPEC_ALL) && YH_GROUP_SPEC_ALL
+    constexpr u32 SPEC_ITEMS = BKT_ITEMS;
+#else
+    constexpr u32 SPEC_ITEMS = BKT_ITEMS / 2;
+#endif
 #pragma unroll
-    for (u32 k = 0; k < BKT_ITEMS; ++k) {  // (before the count is known: the capacity is allocated for every bucket)
+    for (u32 k = 0; k < SPEC_ITEMS; ++k) {
         const u32 e = k * BKT_THREADS + tid;
 #if defined(YH_ABLATE_GROUP) && (YH_ABLATE_GROUP & 16)  // timing-only build: not even the loads
         key[k] = (b * 0x9E3779B97F4A7C15ull + e * 0x7F4A7C15ull) >> 3; val[k] = e;
@@ -746,7 +756,6 @@ __global__ void __launch_bounds__(BKT_THREADS) k_bucket_group5(const BucketArgs 
     for (u32 i = tid; i < BKT_CAP / 4; i += BKT_THREADS) reinterpret_cast<uint4*>(tidx)[i] = make_uint4(0u, 0u, 0u, 0u);
     if (tid < 3) tot3[tid] = 0;
     if (tid == 3) { lcount = 0; has_list = 0; }
-    const u32 c_raw = a.cnt[b];
     if (c_raw > BKT_CAP) {  // (uniform) more pairs than a bucket holds -- a hash thousands of references share: the bucket is marked
         // and ALL its pairs are grouped from the side list (k_spill_collect / k_spill_group)
         if (tid == 0) {
@@ -756,6 +765,12 @@ __global__ void __launch_bounds__(BKT_THREADS) k_bucket_group5(const BucketArgs 
         return;
     }
     const u32 n = c_raw;
+#pragma unroll
+    for (u32 k = SPEC_ITEMS; k < BKT_ITEMS; ++k) {
+        const u32 e = k * BKT_THREADS + tid;
+        key[k] = 0; val[k] = 0;
+        if (e < n) { key[k] = a.in_k[b * a.cap_in + e]; val[k] = a.in_v[b * a.stride_v + e]; }
+    }
 #pragma unroll
     for (u32 k = 0; k < BKT_ITEMS; ++k) {
         const u32 e = k * BKT_THREADS + tid;
@@ -1044,7 +1059,11 @@ __global__ void __launch_bounds__(PART_THREADS) k_piece_part(const PieceArgs a) 
         }
 #pragma unroll
         for (u32 q = 0; q < PART_ITEMS; ++q)
+#if defined(YH_ABLATE_PART) && (YH_ABLATE_PART & 4)  // timing-only build: the pieces are not read (keys made up inside the region)
+            if (pos[q] != 0xffffffffu) key[q] = ((u64)r * a.P2 + (pos[q] * 2654435761u) % a.P2) * ((~0ull) / ((u64)a.P1 * a.P2 * 1000ull)) + pos[q];
+#else
             if (pos[q] != 0xffffffffu) key[q] = a.values[pos[q]];
+#endif
 #pragma unroll
         for (u32 q = 0; q < PART_ITEMS; ++q) {
             bin[q] = 0xffffffffu;
@@ -1075,7 +1094,11 @@ __global__ void __launch_bounds__(PART_THREADS) k_piece_part(const PieceArgs a) 
             if (b < a.P2) {
                 const u32 c = hist[b];
                 c_mine[q] = c;
+#if defined(YH_ABLATE_PART) && (YH_ABLATE_PART & 2)  // timing-only build: no reserving atomics (every tile writes at the bucket's start)
+                if (c) g_mine[q] = 0;
+#else
                 if (c) g_mine[q] = atomicAdd(&a.out_cnt[(u64)r * a.P2 + b], c);
+#endif
                 loc[b] = c;
             }
         }
@@ -1104,8 +1127,12 @@ __global__ void __launch_bounds__(PART_THREADS) k_piece_part(const PieceArgs a) 
                 if (at < BKT_CAP) {  // (a pair that finds its bucket full is dropped HERE: the bucket's count says so, the pass behind this
                     // one marks the bucket, and k_spill_collect fetches ALL its pairs from the sketches again -- the rare case pays)
                     const u64 bkt = (u64)r * a.P2 + b;
+#if defined(YH_ABLATE_PART) && (YH_ABLATE_PART & 1)  // timing-only build: the pairs are not stored
+                    if (skey[s] == 0x123456789abcdefull) a.out_a[bkt * a.stride_k + at] = skey[s] + sval[s];
+#else
                     a.out_a[bkt * a.stride_k + at] = skey[s];
                     a.out_p[bkt * a.stride_v + at] = sval[s];
+#endif
                 }
             }
         }
