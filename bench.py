@@ -1332,6 +1332,11 @@ def main() -> int:
                 "filter_bytes": info.get("filter_bytes"),
                 "ghost_refs_rank0": (sdb.n_ghost if sdb is not None else 0),
                 "db_build_ms": round(float(timing["ms_db_build"]), 2),
+                # ... without the host time inside hipMalloc (db_build_driver): on this pool a process that starts while the driver is
+                # still wiping tens of GB a PREVIOUS process freed waits for that inside its own first allocations
+                # (profiles/r05/malloc_modes_probe.txt, fresh_build_probe.txt) -- not the build's work
+                "db_build_ms_net_of_hipMalloc": (round(max(float(timing["ms_db_build"]) - db_build_driver["ms_inside_hipMalloc"], 0.0), 2)
+                                                 if db_build_driver else None),
                 "db_rebuild_ms": db_rebuild_ms,
                 "db_build_driver": db_build_driver, "db_rebuild_driver": db_rebuild_driver,
                 "device_memory": ylib.alloc_stats(),
