@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define YH_ABI_VERSION 5
+#define YH_ABI_VERSION 6
 
 enum {
     YH_OK               = 0,
@@ -315,6 +315,20 @@ int yh_run_batch_local_range_device(yh_db* db, int slot, const uint64_t* d_sampl
                                     uint32_t n_samples, uint64_t total_hashes, uint32_t* d_overlap, uint64_t* d_maskwords_out);
 int yh_run_batch_finish_range_device(yh_db* db, int slot, uint32_t n_samples, const uint64_t* d_gathered_maskwords,
                                      uint32_t n_ranks, const uint32_t* d_overlap, uint32_t* d_n_excl, uint32_t* d_n_match);
+/* A second stream for the second halves (ABI 6).  A block's second half is a dozen small launches (OR of the words, work
+ * list, exclusive pass, the dense final pass, the compact rows: ~100 us of launch floors at rs214 scale, whatever the
+ * rank's share of the lookups); on the handle's one stream they stand between the lookups of block j and those of block
+ * j + 1.  With a finish stream set, yh_run_batch_finish_range_device, yh_run_batch_words_unpack_device and
+ * yh_run_batch_rows_pack_device are enqueued THERE and run beside the next block's first half:
+ *   - the library orders a slot's second half behind its own first half (an event per slot), and every other query entry
+ *     point, yh_db_synchronize and yh_db_destroy behind the last second half queued;
+ *   - the CALLER orders what it adds between the halves (the exchange whose output yh_run_batch_words_unpack_device /
+ *     yh_run_batch_finish_range_device read must be visible to the finish stream), reads the second half's outputs on the
+ *     finish stream or behind it, and does not start a slot's next first half before that slot's second half and rows
+ *     have finished (BatchedRangeRunner reads the block's entry count back first: a host wait).
+ * yh_run_batch_rows_unpack_device and everything else stay on the handle's stream.  NULL = one stream again; the call
+ * drains the previous finish stream.  hip_stream must be a stream of the handle's device.                              */
+int yh_db_set_batch_finish_stream(yh_db* db, void* hip_stream);
 
 /* ---- the result of a batch in compact form: north star's "final gather of the per-reference counts" -------------------
  * The three [n_samples][N] rows of a batch are almost all zero (a 10^6-hash metagenome overlaps a few hundred of 85 205

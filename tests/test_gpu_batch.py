@@ -29,6 +29,14 @@ def _samples(values, offsets, n_samples, seed, noise=400):
     return out
 
 
+def _want(values, offsets, smp):
+    """The three count rows of one sample by the oracle, zero outside the sample's subset (what the batch calls leave)."""
+    w_ov = oracle.overlap(values, offsets, smp)
+    mask = (w_ov > 0).astype(np.uint8)
+    w_e, w_m = oracle.exclusive(values, offsets, mask, smp)
+    return w_ov, np.where(mask, w_e, 0), np.where(mask, w_m, 0)
+
+
 def _check(values, offsets, samples):
     n = offsets.size - 1
     with RefDB(values, offsets, flags=FULL) as db:
@@ -189,3 +197,57 @@ def test_batch_words_compact_small(hip_lib):
         db.synchronize()
         o = out.cpu().numpy()
         assert int(ovf.item()) == 1 and o[:4].tolist() == [3, 3, 3, 3] and not o[4:].any()
+
+
+@pytest.mark.parametrize("finish_stream", [True, False])
+def test_runner_second_halves_on_their_own_stream(hip_lib, finish_stream):
+    """dist.BatchedRangeRunner over one hash range (no process group): many blocks through the three batch slots with the second
+    halves on the finish stream (ABI 6: yh_db_set_batch_finish_stream) or on the handle's one stream -- every block against
+    the oracle, an undersized word exchange repeated on the way, and a single-sample query of the same handle afterwards
+    (which must come behind the last second half: it uses the same work list and subset bits)."""
+    import torch
+
+    from yacht_amd import dist as ydist
+
+    values, offsets = synth.config4(seed=41, n_clusters=60, size=90)
+    n = offsets.size - 1
+    dev = torch.device("cuda", 0)
+    vt = torch.from_numpy(values.view(np.int64).copy()).to(dev)
+    ot = torch.from_numpy(offsets.astype(np.int64)).to(dev)
+    blocks = [_samples(values, offsets, 1 + (7 * j) % 9, seed=500 + j) for j in range(14)]
+    hr = ydist.HashRangeRefDB(vt, ot, [0, 2 ** 64], ydist.HipRangeBackend(0))
+    try:
+        for kw in (dict(), dict(cap_words=2), dict(dense_rows=True), dict(compact_words=False)):
+            got = {}
+
+            def on_result(tag, n_in, rows, dense):
+                got[tag] = (dense[:, :n_in].clone() if rows is None else ydist.BatchRowsReducer.rows_to_dense(rows, n_in, n)).cpu().numpy()
+
+            run = ydist.BatchedRangeRunner(hr, batch=9, dst=0, nbuf=3, on_result=on_result, finish_stream=finish_stream, **kw)
+            assert (run.s2 is not None) == finish_stream
+            packed = [hr.pack_batch([torch.from_numpy(s.view(np.int64).copy()).to(dev) for s in blk]) for blk in blocks]
+            for rep in range(2):
+                for j, blk in enumerate(blocks):
+                    run.submit(packed[j], len(blk), tag=(rep, j))
+                run.drain()
+            if "cap_words" in kw:
+                assert run.n_words_overflow >= 1
+            # a single-sample query right behind the last block, no synchronisation in between
+            one = torch.from_numpy(blocks[3][0].view(np.int64).copy()).to(dev)
+            cnt = torch.zeros((3, n), dtype=torch.int32, device=dev)
+            run.submit(packed[5], len(blocks[5]), tag="last")
+            run.drain()
+            hr.local.handle.run_device(one.data_ptr(), one.numel(), cnt[0].data_ptr(), cnt[1].data_ptr(), cnt[2].data_ptr())
+            hr.local.handle.synchronize()
+            want = _want(values, offsets, blocks[3][0])
+            assert all(np.array_equal(cnt[k].cpu().numpy(), want[k]) for k in range(3)), f"single-sample query behind the runner ({kw})"
+            run.close()
+            assert sorted(k for k in got if k != "last") == [(rep, j) for rep in range(2) for j in range(len(blocks))]
+            for key, dense in got.items():
+                blk = blocks[5] if key == "last" else blocks[key[1]]
+                for k, smp in enumerate(blk):
+                    want = _want(values, offsets, smp)
+                    for row in range(3):
+                        assert np.array_equal(dense[row, k], want[row]), f"runner {kw} finish_stream={finish_stream} block {key} sample {k} row {row}"
+    finally:
+        hr.close()

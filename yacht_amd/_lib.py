@@ -98,6 +98,7 @@ SIGNATURES = {
     "yh_db_destroy": (C.c_int, [_vp]),
     "yh_db_get_info": (C.c_int, [_vp, C.POINTER(DbInfo)]),
     "yh_db_set_stream": (C.c_int, [_vp, _vp]),
+    "yh_db_set_batch_finish_stream": (C.c_int, [_vp, _vp]),
     "yh_db_synchronize": (C.c_int, [_vp]),
     "yh_db_set_lookup": (C.c_int, [_vp, C.c_int]),
     "yh_db_lookup_choice": (C.c_int, [_vp, C.c_uint64]),
@@ -214,7 +215,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError here = the .so does not match the header
         fn.restype = res
         fn.argtypes = args
-    if lib.yh_abi_version() != 5:
+    if lib.yh_abi_version() != 6:
         raise YachtHipError(YH_ERR_INVALID_ARG, f"ABI version mismatch in {path}")
     _lib = lib
     return lib

@@ -278,7 +278,7 @@ static int timing_every() {
     }
     return every;
 }
-void yh_ring_record_begin(yh_db* db, EventRing& r) {
+void yh_ring_record_begin(yh_db* db, EventRing& r, hipStream_t st) {
     if (!r.created) {
         if (!r.wanted || timing_every() <= 0) return;
         ring_create(r);  // lazily: 2 x TIMING_RING hipEventCreate calls were ~1.5 ms of every yh_db_create with three eager rings of 256
@@ -287,12 +287,12 @@ void yh_ring_record_begin(yh_db* db, EventRing& r) {
     // every n-th launch, and always the first one after the ring was read (a short measurement still gets a sample)
     r.armed = every > 0 && ((r.calls++ % (unsigned)every) == 0 || r.pending == 0);
     if (!r.armed) return;
-    (void)hipEventRecord(r.beg[r.head], db->stream);
+    (void)hipEventRecord(r.beg[r.head], st ? st : db->stream);
 }
-void yh_ring_record_end(yh_db* db, EventRing& r) {
+void yh_ring_record_end(yh_db* db, EventRing& r, hipStream_t st) {
     if (!r.created || !r.armed) return;
     r.armed = false;
-    (void)hipEventRecord(r.end[r.head], db->stream);
+    (void)hipEventRecord(r.end[r.head], st ? st : db->stream);
     r.head = (r.head + 1) % TIMING_RING;
     if (r.pending < TIMING_RING) ++r.pending;
 }
@@ -325,9 +325,17 @@ static int pipe_leave(yh_db* db) {
     db->pipe_last_ctx = -1;
     return YH_OK;
 }
-static void note_other_query(yh_db* db) {
+// the handle's stream behind the last second half queued on the finish stream (yh_db_set_batch_finish_stream): the second
+// halves use the work list and the subset bits every other query uses
+static void fin_join(yh_db* db) {
+    if (!db->fin_pending) return;
+    db->fin_pending = false;
+    if (db->ev_fin) (void)hipStreamWaitEvent(db->stream, db->ev_fin, 0);
+}
+static void note_other_query(yh_db* db, bool join_fin = true) {
     (void)pipe_leave(db);
     if (db->ctx_open[db->ctx_now]) db->ctx_clobbered[db->ctx_now] = true;
+    if (join_fin) fin_join(db);
 }
 
 // HIP events around the copies of the synchronous host-pointer queries (yh_timing.ms_h2d / ms_d2h); dir 0 = up, 1 = down
@@ -545,7 +553,10 @@ int yh_db_create_device(const uint64_t* d_values, const uint64_t* d_offsets, uin
 int yh_db_destroy(yh_db* db) {
     if (!db) return YH_OK;
     if (db->device >= 0) (void)hipSetDevice(db->device);
+    if (db->fin_stream) (void)hipStreamSynchronize(db->fin_stream);  // (the caller's: second halves may still be running there)
     if (db->stream) (void)hipStreamSynchronize(db->stream);
+    if (db->ev_fin) (void)hipEventDestroy(db->ev_fin);
+    for (yh_db::BatchSlot& bs : db->batch) if (bs.ev_first) (void)hipEventDestroy(bs.ev_first);
     if (db->tmp_psort) { yh_psort_destroy(db, db->tmp_psort); db->tmp_psort = nullptr; }  // (a create that failed half way)
     if (db->ctx_bits[0]) {  // the step contexts: back to the handle's own arrays, the second set freed here
         db->d_maskbits = db->ctx_bits[0];
@@ -627,10 +638,26 @@ int yh_db_set_stream(yh_db* db, void* hip_stream) {
     return YH_OK;
 }
 
+int yh_db_set_batch_finish_stream(yh_db* db, void* hip_stream) {
+    if (!db_ok(db)) return YH_ERR_INVALID_ARG;
+    YH_TRY(db_select(db));
+    if (db->fin_stream) YH_HIP(hipStreamSynchronize(db->fin_stream));
+    db->fin_pending = false;
+    db->fin_stream = (hipStream_t)hip_stream;
+    if (db->fin_stream) {
+        if (!db->ev_fin) YH_HIP(hipEventCreateWithFlags(&db->ev_fin, hipEventDisableTiming));
+        for (yh_db::BatchSlot& bs : db->batch)
+            if (!bs.ev_first) YH_HIP(hipEventCreateWithFlags(&bs.ev_first, hipEventDisableTiming));
+    }
+    return YH_OK;
+}
+
 int yh_db_synchronize(yh_db* db) {
     if (!db_ok(db)) return YH_ERR_INVALID_ARG;
     YH_TRY(db_select(db));
     YH_TRY(pipe_join(db));
+    if (db->fin_stream) YH_HIP(hipStreamSynchronize(db->fin_stream));
+    db->fin_pending = false;
     YH_HIP(hipStreamSynchronize(db->stream));
     return YH_OK;
 }
@@ -1152,7 +1179,7 @@ int yh_run_batch_local_range_device(yh_db* db, int slot, const uint64_t* d_sampl
     if (!batch_slot_ok(slot)) return YH_ERR_INVALID_ARG;
     if (!d_sample_offsets || !d_overlap || !d_maskwords_out || (total_hashes && !d_samples)) { yh_set_error("null device pointer"); return YH_ERR_INVALID_ARG; }
     YH_TRY(db_select(db));
-    note_other_query(db);
+    note_other_query(db, /*join_fin=*/false);  // (a first half touches nothing a second half on the finish stream uses)
     const int rc = yh_q_run_batch(db, (const u64*)d_samples, (const u64*)d_sample_offsets, n_samples, total_hashes, d_overlap, nullptr,
                                   nullptr, 1, (u64*)d_maskwords_out, nullptr, 0, slot);
     yh_db::BatchSlot& bs = db->batch[slot];
@@ -1177,7 +1204,7 @@ int yh_run_batch_finish_range_device(yh_db* db, int slot, uint32_t n_samples, co
         return YH_ERR_INVALID_ARG;
     }
     YH_TRY(db_select(db));
-    note_other_query(db);  // (the second half rewrites the current step context's subset bits and work list)
+    note_other_query(db, /*join_fin=*/false);  // (the second half rewrites the current step context's subset bits and work list)
     return yh_q_run_batch(db, nullptr, nullptr, n_samples, 0, const_cast<uint32_t*>(d_overlap), d_n_excl, d_n_match, 2, nullptr,
                           (const u64*)d_gathered_maskwords, n_ranks, slot);
 }

@@ -170,11 +170,22 @@ __global__ void __launch_bounds__(256) k_batch_maskwords(const u32* __restrict__
                                                          u64* __restrict__ maskword, u32* __restrict__ anybits) {
     const u64 r = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     u64 w = 0;
-    if (r < n_refs)
-        for (u32 s = 0; s < n_samples; ++s) w |= (u64)(overlap[(u64)s * n_refs + r] != 0) << s;
+    if (r < n_refs) {
+        // eight rows requested together (one row a step, each load waited for before the next was asked: 29.6 us for the 21.8 MB of a
+        // block of 64 -- 0.74 TB/s: profiles/r05/batch_share_kernels.txt)
+        u32 s = 0;
+        for (; s + 8 <= n_samples; s += 8) {
+            u32 v[8];
+#pragma unroll
+            for (u32 q = 0; q < 8; ++q) v[q] = overlap[(u64)(s + q) * n_refs + r];
+#pragma unroll
+            for (u32 q = 0; q < 8; ++q) w |= (u64)(v[q] != 0) << (s + q);
+        }
+        for (; s < n_samples; ++s) w |= (u64)(overlap[(u64)s * n_refs + r] != 0) << s;
+    }
     if (r < n_refs) maskword[r] = w;
     const u64 bal = __ballot(w != 0);
-    if ((threadIdx.x & 63) == 0) {
+    if (anybits && (threadIdx.x & 63) == 0) {  // (nullptr: a first half whose second half makes its own -- k_batch_or_maskwords)
         anybits[(r >> 5)] = (u32)bal;
         anybits[(r >> 5) + 1] = (u32)(bal >> 32);
     }
@@ -299,16 +310,20 @@ __global__ void __launch_bounds__(256) k_batch_or_maskwords(const u64* __restric
 // in THIS rank's range)
 __global__ void __launch_bounds__(256) k_batch_final(u32 n_samples, u64 n_refs, const u32* __restrict__ sizes,
                                                      const u32* __restrict__ nshared, const u32* __restrict__ overlap,
-                                                     const u32* __restrict__ ovsh, u32* __restrict__ ex_e,
+                                                     u32* __restrict__ ovsh, u32* __restrict__ ex_e,
                                                      u32* __restrict__ ex_m, const u64* __restrict__ maskword) {
     const u64 total = (u64)n_samples * n_refs;
     for (u64 t = blockIdx.x * (u64)blockDim.x + threadIdx.x; t < total; t += (u64)gridDim.x * blockDim.x) {
         const u64 r = t % n_refs;
         const u32 ov = overlap[t];
+        // the slot's hits on shared hashes are read once, here, and left zero for the slot's next first half (which then
+        // has 22 MB less to clear in front of its lookups: BatchSlot::ovsh_clean); only the few non-zero ones are written
+        const u32 sh = ovsh[t];
+        if (sh) ovsh[t] = 0;
         const bool in = maskword ? ((maskword[r] >> (t / n_refs)) & 1ull) != 0 : ov != 0;
         if (in) {
             ex_e[t] = sizes[r] - nshared[r] + ex_e[t];
-            ex_m[t] = ov - ovsh[t];
+            ex_m[t] = ov - sh;
         } else {
             ex_e[t] = 0;
             ex_m[t] = 0;
@@ -318,10 +333,10 @@ __global__ void __launch_bounds__(256) k_batch_final(u32 n_samples, u64 n_refs, 
 
 // ---- the batch's result in compact form (include/yacht_hip.h: yh_run_batch_rows_*) --------------------------------------
 // One entry per set bit s of maskword[r], in (r, s) order.  ROWS_BLOCK references per workgroup: k_batch_rows_count leaves
-// each block's number of entries, k_batch_rows_emit sums the counts of the blocks in front of its own (N / 2048 words),
+// each block's number of entries, k_batch_rows_emit sums the counts of the blocks in front of its own (N / 256 words),
 // scans its own references' popcounts and writes -- PACK: the three values of every entry from the dense rows; else the
 // rows themselves from the (summed) values.
-constexpr u32 ROWS_BLOCK = 2048;
+constexpr u32 ROWS_BLOCK = 256;  // references per workgroup of the row kernels (2 048: 42 workgroups for 85 205 references -- 13 us a pass; 256: 333)
 __global__ void __launch_bounds__(256) k_batch_rows_count(const u64* __restrict__ maskword, u64 n_refs, u32* __restrict__ blk_count) {
     __shared__ u32 part[4];
     const u64 r0 = (u64)blockIdx.x * ROWS_BLOCK;
@@ -399,17 +414,23 @@ __global__ void __launch_bounds__(256) k_batch_rows_emit(const u64* __restrict__
 //   packed[1 .. cap] = the words, then cap 32-bit reference ids (two per 64-bit word) --
 // in no particular order (the reader ORs them into place).  UNPACK: the entries of all ranks OR-ed into one dense row
 // (zeroed by the caller), *overflow = some rank had more words than its buffer carried.
-__global__ void __launch_bounds__(256) k_batch_words_pack(const u64* __restrict__ words, u64 n_refs, u64* __restrict__ packed, u64 cap) {
+// (one reserving atomic per WORKGROUP of 1 024 references: one per wave were 1 331 adds to ONE word -- 18 us of a kernel that reads 0.7 MB)
+__global__ void __launch_bounds__(1024) k_batch_words_pack(const u64* __restrict__ words, u64 n_refs, u64* __restrict__ packed, u64 cap) {
+    __shared__ u32 wcnt[16];
+    __shared__ unsigned long long s_base;
     const u64 r = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     const u64 w = r < n_refs ? words[r] : 0ull;
     const u64 bal = __ballot(w != 0);
-    if (!bal) return;
-    const u32 lane = threadIdx.x & 63u;
-    u64 base = 0;
-    if (lane == (u32)__ffsll((long long)bal) - 1u) base = atomicAdd((unsigned long long*)packed, (unsigned long long)__popcll(bal));
-    base = __shfl(base, __ffsll((long long)bal) - 1);
+    const u32 lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    if (lane == 0) wcnt[wv] = (u32)__popcll(bal);
+    __syncthreads();
+    u32 below = 0, total = 0;
+    for (u32 q = 0; q < 16; ++q) { const u32 c = wcnt[q]; total += c; below += q < wv ? c : 0u; }
+    if (total == 0) return;  // (uniform)
+    if (threadIdx.x == 0) s_base = atomicAdd((unsigned long long*)packed, (unsigned long long)total);
+    __syncthreads();
     if (w) {
-        const u64 at = base + __popcll(bal & ((1ull << lane) - 1ull));
+        const u64 at = s_base + below + __popcll(bal & ((1ull << lane) - 1ull));
         if (at < cap) {
             packed[1 + at] = w;
             reinterpret_cast<u32*>(packed + 1 + cap)[at] = (u32)r;
@@ -435,7 +456,7 @@ __global__ void __launch_bounds__(256) k_batch_words_unpack(const u64* __restric
 
 }  // namespace
 
-// a slot's scratch: maskword [N + 2] u64 | block counts of the compact rows [ceil(N / 2048) + 1, padded] u32 | ovsh [B][N] u32
+// a slot's scratch: maskword [N + 2] u64 | block counts of the compact rows [ceil(N / ROWS_BLOCK) + 1, padded] u32 | ovsh [B][N] u32
 static u64 batch_blk_words(const yh_db* db) { return (((db->n_refs + ROWS_BLOCK - 1) / ROWS_BLOCK + 1) + 3) & ~(u64)3; }
 static u32* batch_slot_blk_counts(yh_db* db, int slot) {
     return reinterpret_cast<u32*>(reinterpret_cast<u64*>(db->batch[slot].d_scratch) + db->n_refs + 2);
@@ -450,6 +471,7 @@ static int batch_slot_scratch(yh_db* db, int slot, u32 n_samples, u64** d_maskwo
         if (bs.d_scratch) { yh_dfree(db, bs.d_scratch); bs.d_scratch = nullptr; bs.cap = 0; }
         YH_HIP(hipMalloc((void**)&bs.d_scratch, need));
         bs.cap = need;
+        bs.ovsh_clean = false;
     }
     *d_maskword = reinterpret_cast<u64*>(bs.d_scratch);
     *d_ovsh = batch_slot_blk_counts(db, slot) + batch_blk_words(db);
@@ -460,14 +482,16 @@ static int batch_slot_scratch(yh_db* db, int slot, u32 n_samples, u64** d_maskwo
 int yh_q_batch_rows_pack(yh_db* db, int slot, const u32* d_overlap, const u32* d_excl, const u32* d_match, u32* d_vals, u64 cap_rows,
                          u32* d_n_rows) {
     const u64 N = db->n_refs;
-    if (N == 0) { YH_HIP(hipMemsetAsync(d_n_rows, 0, sizeof(u32), db->stream)); return YH_OK; }
+    if (N == 0) { YH_HIP(hipMemsetAsync(d_n_rows, 0, sizeof(u32), db->fin_stream ? db->fin_stream : db->stream)); return YH_OK; }
     const u64* d_maskword = reinterpret_cast<const u64*>(db->batch[slot].d_scratch);
     u32* blk = batch_slot_blk_counts(db, slot);
     const u32 nblk = (u32)((N + ROWS_BLOCK - 1) / ROWS_BLOCK);
-    k_batch_rows_count<<<nblk, 256, 0, db->stream>>>(d_maskword, N, blk);
-    k_batch_rows_emit<true><<<nblk, 256, 0, db->stream>>>(d_maskword, N, db->batch[slot].n_samples, blk, nblk, d_overlap, d_excl, d_match,
-                                                        d_vals, nullptr, cap_rows, d_n_rows);
+    hipStream_t st = db->fin_stream ? db->fin_stream : db->stream;  // (behind the second half that made the rows)
+    k_batch_rows_count<<<nblk, 256, 0, st>>>(d_maskword, N, blk);
+    k_batch_rows_emit<true><<<nblk, 256, 0, st>>>(d_maskword, N, db->batch[slot].n_samples, blk, nblk, d_overlap, d_excl, d_match,
+                                                d_vals, nullptr, cap_rows, d_n_rows);
     YH_HIP(hipGetLastError());
+    if (db->fin_stream) { YH_HIP(hipEventRecord(db->ev_fin, st)); db->fin_pending = true; }
     return YH_OK;
 }
 int yh_q_batch_rows_unpack(yh_db* db, int slot, const u32* d_vals, u64 cap_rows, void* d_rows, u32* d_n_rows) {
@@ -493,7 +517,10 @@ int yh_q_run_batch(yh_db* db, const u64* d_samples, const u64* d_soff, u32 n_sam
         return YH_ERR_UNSUPPORTED;
     }
     if (n_samples < 1 || n_samples > 64) { yh_set_error("1..64 samples per batch"); return YH_ERR_INVALID_ARG; }
-    hipStream_t st = db->stream;
+    // a second half alone goes to the finish stream when the handle has one (yh_db_set_batch_finish_stream), behind its slot's
+    // first half; a first half alone then leaves the handle's subset bits to the second halves
+    const bool split_streams = db->fin_stream && phases != 3;
+    hipStream_t st = (split_streams && phases == 2) ? db->fin_stream : db->stream;
     const u64 N = db->n_refs;
     if (N == 0) return YH_OK;
     const u64 BN = (u64)n_samples * N;
@@ -507,8 +534,11 @@ int yh_q_run_batch(yh_db* db, const u64* d_samples, const u64* d_soff, u32 n_sam
     if (phases & 1) { bs.n_samples = n_samples; bs.words_valid = false; }
     if (phases & 1) {
     YH_HIP(hipMemsetAsync(d_overlap, 0, BN * sizeof(u32), st));
-    YH_HIP(hipMemsetAsync(bs.d_scratch, 0, need, st));
-    yh_ring_record_begin(db, db->ev_overlap);
+    // (the words and block counts in front of ovsh are written whole by the kernels that make them; what lies behind them was
+    // cleared when the scratch was made and is only ever cleared again)
+    if (!bs.ovsh_clean) YH_HIP(hipMemsetAsync(bs.d_scratch, 0, bs.cap, st));  // (all of it: a first half without its second may have been a larger batch)
+    bs.ovsh_clean = false;
+    yh_ring_record_begin(db, db->ev_overlap, st);
     if (total_hashes && db->n_distinct) {
         const u64 n_tiles = (total_hashes + BATCH_TILE - 1) / BATCH_TILE + n_samples;  // (a ragged tile per sample)
         if (n_tiles >> 31) { yh_set_error("batch too large"); return YH_ERR_INVALID_ARG; }
@@ -516,13 +546,15 @@ int yh_q_run_batch(yh_db* db, const u64* d_samples, const u64* d_soff, u32 n_sam
                                                                                        db->d_po, db->d_pr, N, d_overlap, d_ovsh,
                                                                                        yh_filter_of(db), db->filter_mul);
     }
-    yh_ring_record_end(db, db->ev_overlap);
-    k_batch_maskwords<<<(u32)((N + 255) / 256), 256, 0, st>>>(d_overlap, n_samples, N, d_maskword, db->d_maskbits);
+    yh_ring_record_end(db, db->ev_overlap, st);
+    k_batch_maskwords<<<(u32)((N + 255) / 256), 256, 0, st>>>(d_overlap, n_samples, N, d_maskword, split_streams ? nullptr : db->d_maskbits);
     if (d_maskword_out) YH_HIP(hipMemcpyAsync(d_maskword_out, d_maskword, N * sizeof(u64), hipMemcpyDeviceToDevice, st));
+    if (split_streams) YH_HIP(hipEventRecord(bs.ev_first, st));
     }
     if (!(phases & 2)) { YH_HIP(hipGetLastError()); return YH_OK; }
+    if (split_streams) YH_HIP(hipStreamWaitEvent(st, bs.ev_first, 0));
     YH_HIP(hipMemsetAsync(d_excl, 0, BN * sizeof(u32), st));
-    yh_ring_record_begin(db, db->ev_excl);
+    yh_ring_record_begin(db, db->ev_excl, st);
     if (d_gathered)
         k_batch_or_maskwords<<<(u32)((N + 255) / 256), 256, 0, st>>>(d_gathered, n_ranks, N, d_maskword, db->d_maskbits);
     if (G && db->n_postings) {
@@ -534,8 +566,10 @@ int yh_q_run_batch(yh_db* db, const u64* d_samples, const u64* d_soff, u32 n_sam
     }
     k_batch_final<<<grid_for(BN, 256, 8192), 256, 0, st>>>(n_samples, N, db->d_sizes, db->d_nshared, d_overlap, d_ovsh,
                                                            d_excl, d_match, d_gathered ? d_maskword : nullptr);
-    yh_ring_record_end(db, db->ev_excl);
+    yh_ring_record_end(db, db->ev_excl, st);
     YH_HIP(hipGetLastError());
+    if (split_streams) { YH_HIP(hipEventRecord(db->ev_fin, st)); db->fin_pending = true; }
+    bs.ovsh_clean = true;  // (k_batch_final, over the same [n_samples][N] the lookups counted into)
     bs.words_valid = true;  // (the slot's words are the batch's subset -- on hash-range shards the global one)
     return YH_OK;
 }
@@ -543,15 +577,16 @@ int yh_q_run_batch(yh_db* db, const u64* d_samples, const u64* d_soff, u32 n_sam
 // the subset words of a block as (word, reference) entries (kernels above); both on the handle's stream, no host sync
 int yh_q_batch_words_pack(yh_db* db, const u64* d_words, u64* d_packed, u64 cap) {
     YH_HIP(hipMemsetAsync(d_packed, 0, sizeof(u64), db->stream));
-    if (db->n_refs) k_batch_words_pack<<<(u32)((db->n_refs + 255) / 256), 256, 0, db->stream>>>(d_words, db->n_refs, d_packed, cap);
+    if (db->n_refs) k_batch_words_pack<<<(u32)((db->n_refs + 1023) / 1024), 1024, 0, db->stream>>>(d_words, db->n_refs, d_packed, cap);
     YH_HIP(hipGetLastError());
     return YH_OK;
 }
 int yh_q_batch_words_unpack(yh_db* db, const u64* d_gathered, u32 n_ranks, u64 cap, u64* d_words_out, u32* d_overflow) {
     const u64 stride = yh_batch_words_packed_len(cap);
-    if (db->n_refs) YH_HIP(hipMemsetAsync(d_words_out, 0, db->n_refs * sizeof(u64), db->stream));
+    hipStream_t st = db->fin_stream ? db->fin_stream : db->stream;  // (the second half that reads d_words_out runs there)
+    if (db->n_refs) YH_HIP(hipMemsetAsync(d_words_out, 0, db->n_refs * sizeof(u64), st));
     const u32 gx = (u32)std::min<u64>(std::max<u64>((cap + 255) / 256, 1), 64);
-    k_batch_words_unpack<<<dim3(gx, n_ranks), 256, 0, db->stream>>>(d_gathered, n_ranks, cap, stride, db->n_refs, d_words_out, d_overflow);
+    k_batch_words_unpack<<<dim3(gx, n_ranks), 256, 0, st>>>(d_gathered, n_ranks, cap, stride, db->n_refs, d_words_out, d_overflow);
     YH_HIP(hipGetLastError());
     return YH_OK;
 }

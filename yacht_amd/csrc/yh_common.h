@@ -206,7 +206,13 @@ struct yh_db {
         bool open = false;       // first half queued, second not yet
         bool clobbered = false;  // a whole-batch call ran in the slot meanwhile
         bool words_valid = false;  // the slot holds the GLOBAL subset words of its last batch (yh_run_batch_rows_*)
+        bool ovsh_clean = false;   // the second half left the slot's hits-on-shared-hashes rows zero (k_batch_final)
+        hipEvent_t ev_first = nullptr;  // end of the slot's first half on the handle's stream (made when a finish stream is set)
     } batch[YH_BATCH_SLOTS];
+    // yh_db_set_batch_finish_stream: where the second halves of the batched hash-range calls run (nullptr: on `stream`)
+    hipStream_t fin_stream = nullptr;
+    hipEvent_t ev_fin = nullptr;   // behind the last launch queued on fin_stream
+    bool fin_pending = false;      // ... which the handle's stream has not waited for yet
 
     // pairwise result cache (two-call sizing)
     bool pw_valid = false;
@@ -468,5 +474,5 @@ void yh_dfree(yh_db* db, void* p);
 hipError_t yh_tmalloc(yh_db* db, void** p, size_t bytes);
 void yh_tfree(yh_db* db, void* p);
 void yh_pool_trim(yh_db* db);
-void yh_ring_record_begin(yh_db* db, EventRing& r);
-void yh_ring_record_end(yh_db* db, EventRing& r);
+void yh_ring_record_begin(yh_db* db, EventRing& r, hipStream_t st = nullptr);  // (st: nullptr = the handle's stream)
+void yh_ring_record_end(yh_db* db, EventRing& r, hipStream_t st = nullptr);

@@ -560,6 +560,11 @@ class HipRangeBackend:
             def bind_stream(self):
                 db.set_stream(torch.cuda.current_stream().cuda_stream)
 
+            def set_finish_stream(self, stream):
+                """torch.cuda.Stream (or None) for the second halves of the batched calls: what runs under
+                `with torch.cuda.stream(stream)` on the torch side runs there inside the library too."""
+                db.set_batch_finish_stream(None if stream is None else stream.cuda_stream)
+
             def run_local(self, sample_t, a, b, counts_t, bits_t, ctx=0):
                 if empty:  # a range that holds no reference hash: nothing can match
                     counts_t.zero_()
@@ -954,7 +959,7 @@ class BatchedRangeRunner:
 
     def __init__(self, hr: "HashRangeRefDB", batch: int = 64, dst: Optional[int] = 0, nbuf: int = 3, cap_rows: Optional[int] = None,
                  cap_words: Optional[int] = None, compact_words: bool = True, dense_rows: bool = False, on_result=None,
-                 async_collectives: bool = True):
+                 async_collectives: bool = True, finish_stream: bool = True):
         import torch
 
         assert 1 <= batch <= 64 and 1 <= nbuf <= 3, "the library has YH_BATCH_SLOTS = 3 batch slots of <= 64 samples"
@@ -978,6 +983,14 @@ class BatchedRangeRunner:
         self.ovf_host = [torch.zeros(1, dtype=torch.int32).pin_memory() if pin else torch.zeros(1, dtype=torch.int32)
                          for _ in range(self.nbuf)]
         self.ev = [torch.cuda.Event() if pin else None for _ in range(self.nbuf)]
+        # The second halves on a stream of their own (include/yacht_hip.h: yh_db_set_batch_finish_stream): a dozen launches at
+        # their launch floors (~100 us a block at rs214 scale, whatever the rank's share of the lookups) run beside the next
+        # block's lookups instead of between them.  ev_x[b]: block b's words are on their way (recorded on the first stream).
+        self.s2 = None
+        if finish_stream and pin and hasattr(hr.local, "set_finish_stream"):
+            self.s2 = torch.cuda.Stream(device=dev)
+            hr.local.set_finish_stream(self.s2)
+        self.ev_x = [torch.cuda.Event() if self.s2 is not None else None for _ in range(self.nbuf)]
         self.inflight = [None] * self.nbuf     # (seq, tag, n_samples, batch, pending dense reduce)
         self.prev = None                       # first half queued, words travelling: (seq, tag, n_samples, batch, work, cap)
         self.seq = 0
@@ -1002,16 +1015,39 @@ class BatchedRangeRunner:
             if self.gath_dense[b] is None:
                 self.gath_dense[b] = torch.zeros((hr.world, hr.n_total), dtype=torch.int64, device=self.dev)
             self.bytes_words += 8 * hr.n_total
-            return hr.batch_exchange(self.words[b], self.gath_dense[b], async_op=self.async_collectives and not sync)
+            work = hr.batch_exchange(self.words[b], self.gath_dense[b], async_op=self.async_collectives and not sync)
+            if self.s2 is not None:
+                self.ev_x[b].record()
+            return work
         L = words_packed_len(cap)
         if self.packed[b] is None or self.packed[b].numel() != L:
             self.packed[b] = torch.zeros(L, dtype=torch.int64, device=self.dev)
             self.gath_packed[b] = torch.zeros((hr.world, L), dtype=torch.int64, device=self.dev)
         hr.batch_words_pack(self.words[b], self.packed[b], cap)
         self.bytes_words += 8 * L
-        return hr.batch_exchange(self.packed[b], self.gath_packed[b], async_op=self.async_collectives and not sync)
+        work = hr.batch_exchange(self.packed[b], self.gath_packed[b], async_op=self.async_collectives and not sync)
+        if self.s2 is not None:
+            self.ev_x[b].record()  # (on the first stream: behind the pack, a copy that stands in for the exchange, a synchronous collective)
+        return work
+
+    def close(self):
+        """Everything queued finished, the handle back on one stream (the runner's second stream is not used after this)."""
+        self.drain()
+        if self.s2 is not None:
+            self.s2.synchronize()
+            self.hr.local.set_finish_stream(None)
+            self.s2 = None
 
     def _second_half(self, seq, tag, n_in, batch, work, cap):
+        if self.s2 is None:
+            return self._second_half_on(seq, tag, n_in, batch, work, cap)
+        import torch
+
+        with torch.cuda.stream(self.s2):  # (the library's side of these calls runs on s2 by itself; this is for torch's side)
+            self.s2.wait_event(self.ev_x[seq % self.nbuf])
+            return self._second_half_on(seq, tag, n_in, batch, work, cap)
+
+    def _second_half_on(self, seq, tag, n_in, batch, work, cap):
         hr = self.hr
         b = seq % self.nbuf
         if work is not None:
@@ -1071,13 +1107,26 @@ class BatchedRangeRunner:
         hr = self.hr
         hr.batch_begin(batch, self.counts[b], self.words[b], slot=b)
         w = self._exchange(b, cap, sync=True)
-        if w is not None:
-            w.wait()
-        hr.batch_words_unpack(self.gath_packed[b], cap, self.words_or[b], self.ovf_dev[b])
-        hr.batch_end(n_in, self.words_or[b], self.counts[b], slot=b, n_ranks=1)
+
+        def second():
+            if w is not None:
+                w.wait()
+            hr.batch_words_unpack(self.gath_packed[b], cap, self.words_or[b], self.ovf_dev[b])
+            hr.batch_end(n_in, self.words_or[b], self.counts[b], slot=b, n_ranks=1)
+            if self.red is not None:
+                self.red.send(b, n_in, self.counts[b], slot=b)
+
+        if self.s2 is None:
+            second()
+        else:
+            import torch
+
+            with torch.cuda.stream(self.s2):
+                self.s2.wait_event(self.ev_x[b])
+                second()
+            self.s2.synchronize()  # (the buffers dropped below and the dense reduce on the first stream)
         self.packed[b] = self.gath_packed[b] = None  # (sized for `cap`: the next block makes its own)
         if self.red is not None:
-            self.red.send(b, n_in, self.counts[b], slot=b)
             return self.red.finish(b)
         dense = hr.reduce(self.counts[b], dst=self.dst)
         return None, (dense if self._is_dst() else None)

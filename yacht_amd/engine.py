@@ -160,6 +160,11 @@ class RefDB:
     def set_stream(self, hip_stream: int) -> None:
         _lib.check(self._lib.yh_db_set_stream(self._h, C.c_void_p(hip_stream)))
 
+    def set_batch_finish_stream(self, hip_stream: Optional[int]) -> None:
+        """The second halves of the batched hash-range calls (run_batch_finish_range_device, words unpack, rows pack) on this
+        hipStream_t beside the next block's first half; None = on the handle's stream again (include/yacht_hip.h)."""
+        _lib.check(self._lib.yh_db_set_batch_finish_stream(self._h, C.c_void_p(hip_stream or 0)))
+
     def set_lookup(self, mode: int) -> None:
         """_lib.YH_LOOKUP_AUTO (default: by cost), YH_LOOKUP_STREAM or YH_LOOKUP_INDEXED for overlap / run queries."""
         _lib.check(self._lib.yh_db_set_lookup(self._h, mode))
