@@ -901,7 +901,7 @@ def main() -> int:
                 run_g.submit(packed_b, BM)
             run_g.drain()
             torch.cuda.synchronize()
-            nb_ = max(6, min(30, args.steps // BM + 1))
+            nb_ = max(30, min(60, args.steps // BM + 1))  # (steady state: six blocks were mostly the fill and the drain of three in flight)
             t0 = time.perf_counter()
             for _ in range(nb_):
                 run_g.submit(packed_b, BM)
