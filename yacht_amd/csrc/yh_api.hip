@@ -278,6 +278,45 @@ static int timing_every() {
     }
     return every;
 }
+// ---- page-locked staging buffers (yh_common.h: YhPin) -----------------------------------------------------------------
+namespace {
+struct PinBuf { void* p = nullptr; u64 cap = 0; bool busy = false; };
+std::mutex g_pin_mu;
+PinBuf g_pin[4];
+}
+void* yh_pin_acquire(u64 bytes) {
+    if (bytes == 0 || bytes > ((u64)64 << 20)) return nullptr;
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    for (PinBuf& b : g_pin)
+        if (!b.busy && b.p && b.cap >= bytes) { b.busy = true; return b.p; }
+    PinBuf* pick = nullptr;
+    for (PinBuf& b : g_pin)
+        if (!b.busy && !b.p) { pick = &b; break; }
+    if (!pick)
+        for (PinBuf& b : g_pin)
+            if (!b.busy) { pick = &b; break; }  // (too small for this caller: replaced)
+    if (!pick) return nullptr;
+    if (pick->p) { (void)hipHostFree(pick->p); pick->p = nullptr; pick->cap = 0; }
+    u64 cap = (u64)64 << 10;
+    while (cap < bytes) cap <<= 1;
+    void* p = nullptr;
+    if (hipHostMalloc(&p, cap, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    pick->p = p;
+    pick->cap = cap;
+    pick->busy = true;
+    return p;
+}
+void yh_pin_release(void* p) {
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    for (PinBuf& b : g_pin)
+        if (b.p == p) { b.busy = false; return; }
+}
+static void pin_release_idle() {  // (yh_pool_release: the idle ones back to the system)
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    for (PinBuf& b : g_pin)
+        if (b.p && !b.busy) { (void)hipHostFree(b.p); b.p = nullptr; b.cap = 0; }
+}
+
 void yh_ring_record_begin(yh_db* db, EventRing& r, hipStream_t st) {
     if (!r.created) {
         if (!r.wanted || timing_every() <= 0) return;
@@ -386,6 +425,7 @@ int yh_alloc_stats(uint64_t* n_driver_allocs, double* ms_in_driver, uint64_t* by
 }
 int yh_pool_release(uint64_t* bytes_released) {
     const uint64_t b = cache_on() ? pool_release_all() : 0;
+    pin_release_idle();  // (the page-locked staging buffers too; host memory, not counted in *bytes_released)
     if (bytes_released) *bytes_released = b;
     return YH_OK;
 }
@@ -439,7 +479,16 @@ static int db_create_common(const u64* values, const u64* offsets, bool on_devic
         (void)hipEventCreate(&ev1);
 
         u64 H = 0;
-        if (on_device) {
+        // (a device CSR with references: offsets[0] and offsets[n_refs] come back with the extents pass's verdict below --
+        // two blocking 8-byte copies here were ~50 us of a 1.1 ms create)
+        const bool ends_from_extents = on_device && n_refs > 0;
+        if (ends_from_extents) {
+            if (!values) {  // (null is only right for a database without a hash, which nothing here knows yet)
+                u64 last = 0;
+                if (hipMemcpy(&last, offsets + n_refs, sizeof(u64), hipMemcpyDeviceToHost) != hipSuccess) { yh_set_error("cannot read d_offsets[n_refs]"); rc = YH_ERR_HIP; break; }
+                if (last) { yh_set_error("values is null"); rc = YH_ERR_INVALID_ARG; break; }
+            }
+        } else if (on_device) {
             if (hipMemcpy(&H, offsets + n_refs, sizeof(u64), hipMemcpyDeviceToHost) != hipSuccess) {
                 yh_set_error("cannot read d_offsets[n_refs]"); rc = YH_ERR_HIP; break;
             }
@@ -488,8 +537,9 @@ static int db_create_common(const u64* values, const u64* offsets, bool on_devic
             (void)hipEventRecord(ev0, db->stream);
             // sizes + largest hash now; every sketch's ordering is checked by the sort's first level on its way through
             // (yh_build_index), or by a pass of its own where that sort does not apply
-            rc = yh_build_validate_extents(db, d_values_in, d_offsets_in);
+            rc = yh_build_validate_extents(db, d_values_in, d_offsets_in);  // (sets db->n_hashes of a device CSR: offsets[n_refs])
             if (rc != YH_OK) break;
+            H = db->n_hashes;
         }
         rc = yh_build_index(db, d_values_in, d_offsets_in, d_sk_pre, d_sv_pre);  // (overlap-only handles too: the delta stream comes out of the same sort)
         if (rc != YH_OK) break;

@@ -453,8 +453,8 @@ inline u32 grid_for(u64 work_items, u32 block, u32 max_blocks = 16384) {
 static int validate_begin(yh_db* db) {
     const u64 N = db->n_refs;
     YH_TRY(yh_dmalloc(db, (void**)&db->d_sizes, std::max<u64>(N, 1) * sizeof(u32)));
-    YH_TRY(yh_dmalloc(db, (void**)&db->d_flag, 16));
-    YH_HIP(hipMemsetAsync(db->d_flag, 0, 16, db->stream));
+    YH_TRY(yh_dmalloc(db, (void**)&db->d_flag, 32));  // flag | - | largest hash (8 B) | offsets[0] | offsets[n_refs] (k_ref_extents)
+    YH_HIP(hipMemsetAsync(db->d_flag, 0, 32, db->stream));
     YH_HIP(hipMemsetAsync(db->d_sizes, 0, std::max<u64>(N, 1) * sizeof(u32), db->stream));
     return YH_OK;
 }
@@ -467,10 +467,24 @@ static int validate_refs(yh_db* db, const u64* d_values, const u64* d_offsets, u
     }
     return YH_OK;
 }
-static int validate_end(yh_db* db) {
-    u32 hflag[4];
-    YH_HIP(hipMemcpyAsync(hflag, db->d_flag, 16, hipMemcpyDeviceToHost, db->stream));
+static int validate_end(yh_db* db, bool ends = false) {
+    u32 hstack[8];
+    // (a `yacht train` handle: the sketch sizes come along -- yh_pairwise's exact filter reads them on the host, and fetching
+    // them there was one more copy behind its kernel)
+    const bool want_sizes = (db->flags & YH_DB_PAIRWISE_ONLY) && db->n_refs && db->h_sizes.empty();
+    YhPin pin(32 + (want_sizes ? db->n_refs * sizeof(u32) : 0));
+    u32* hflag = pin.p ? static_cast<u32*>(pin.p) : hstack;
+    YH_HIP(hipMemcpyAsync(hflag, db->d_flag, 32, hipMemcpyDeviceToHost, db->stream));
+    if (want_sizes && pin.p) YH_HIP(hipMemcpyAsync(hflag + 8, db->d_sizes, db->n_refs * sizeof(u32), hipMemcpyDeviceToHost, db->stream));
     YH_HIP(hipStreamSynchronize(db->stream));
+    if (want_sizes && pin.p) db->h_sizes.assign(hflag + 8, hflag + 8 + db->n_refs);
+    if (ends) {  // the CSR's first and last offset, read by k_ref_extents (a device CSR: the host has not seen them)
+        u64 first, last;
+        memcpy(&first, &hflag[4], 8);
+        memcpy(&last, &hflag[6], 8);
+        if (first != 0) { yh_set_error("offsets[0] must be 0"); return YH_ERR_INVALID_ARG; }
+        if (!(hflag[0] & 1u)) db->n_hashes = last;
+    }
     if (hflag[0] & 1u) {
         yh_set_error("a reference sketch is not strictly ascending (or offsets are not monotone)");
         return YH_ERR_UNSORTED;
@@ -497,6 +511,7 @@ int yh_build_validate(yh_db* db, const u64* d_values, const u64* d_offsets) {
 // the sort's first level does on its way through (yh_psort_check_order) or, without that sort, yh_build_check_order.
 __global__ void k_ref_extents(const u64* __restrict__ values, const u64* __restrict__ offsets, u64 n_refs, u32* __restrict__ sizes,
                               u32* __restrict__ flag, u64* __restrict__ maxv) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) { maxv[1] = offsets[0]; maxv[2] = offsets[n_refs]; }
     for (u64 j = blockIdx.x * (u64)blockDim.x + threadIdx.x; j < n_refs; j += (u64)gridDim.x * blockDim.x) {
         const u64 b = offsets[j], e = offsets[j + 1];
         if (e < b) { atomicOr(flag, 1u); continue; }
@@ -513,7 +528,7 @@ int yh_build_validate_extents(yh_db* db, const u64* d_values, const u64* d_offse
         k_ref_extents<<<grid_for(db->n_refs, 256), 256, 0, db->stream>>>(d_values, d_offsets, db->n_refs, db->d_sizes, db->d_flag, d_maxv);
         YH_HIP(hipGetLastError());
     }
-    YH_TRY(validate_end(db));
+    YH_TRY(validate_end(db, /*ends=*/db->n_refs > 0));
     db->order_checked = false;
     return YH_OK;
 }

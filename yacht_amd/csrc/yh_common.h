@@ -193,6 +193,7 @@ struct yh_db {
     u64* d_sample_tmp = nullptr;   // grows on demand (host-pointer entry points)
     u64 sample_tmp_cap = 0;
     u32* d_flag = nullptr;     // [1] generic error/flag word
+    std::vector<u32> h_sizes;  // the sketch sizes on the host (YH_DB_PAIRWISE_ONLY handles: yh_pairwise's exact filter reads them)
     u32* d_bad_word = nullptr; // [1] deferred ordering verdict of yh_run (see bad_gen)
     u32* d_reps = nullptr;     // [R][N] replicated overlap counters; ZERO AT REST: k_reduce_replicas clears what it sums
     u64 reps_cap = 0;
@@ -474,5 +475,17 @@ void yh_dfree(yh_db* db, void* p);
 hipError_t yh_tmalloc(yh_db* db, void** p, size_t bytes);
 void yh_tfree(yh_db* db, void* p);
 void yh_pool_trim(yh_db* db);
+// A page-locked host staging buffer of >= `bytes` from a small process-wide cache (a read-back into pageable memory is a blocking,
+// staged copy of 20-40 us whatever its size; into page-locked memory it is queued in ~5 us and several wait for ONE synchronize).
+// p == nullptr when it cannot be had (more than 64 MB, four already in use, no memory): the caller reads into pageable memory.
+void* yh_pin_acquire(u64 bytes);
+void yh_pin_release(void* p);
+struct YhPin {
+    void* p;
+    explicit YhPin(u64 bytes) : p(yh_pin_acquire(bytes)) {}
+    ~YhPin() { if (p) yh_pin_release(p); }
+    YhPin(const YhPin&) = delete;
+    YhPin& operator=(const YhPin&) = delete;
+};
 void yh_ring_record_begin(yh_db* db, EventRing& r, hipStream_t st = nullptr);  // (st: nullptr = the handle's stream)
 void yh_ring_record_end(yh_db* db, EventRing& r, hipStream_t st = nullptr);

@@ -383,7 +383,17 @@ int yh_q_pairwise(yh_db* db, double c_thresh, u64 r0, u64 r1) {
             rc = (e__ == hipErrorOutOfMemory) ? YH_ERR_OOM : YH_ERR_HIP;                      \
         }                                                                                     \
     }
-    PW_HIP(yh_tmalloc(db, (void**)&d_scr, b_rec + b_off + 8 + b_tab + b_cnt + b_cur + 64));
+    // the survivors: PAIR_SLOTS per segment, and room for a million behind them to begin with; a run whose long segments
+    // need more is repeated with what it counted
+    const u64 n_slots = nseg * PAIR_SLOTS;
+    u64 cap = std::max<u64>(std::min<u64>(NC * (NC - 1), 1u << 20), 1);
+    // One block: [records | segoff | cursor | tab | segcnt | cursors | (pad) | survivors].  On a fused handle with ranks the
+    // tab and the cursors are empty, and everything the host reads -- offsets, the cursor, counts, the survivors' slots and the
+    // first `spec` survivors behind them -- is ONE contiguous piece: one copy into page-locked memory, one wait.  (Five copies
+    // into pageable vectors around two waits were ~0.14 of configs[3]'s 0.40 ms; five queued copies still ~13 us each.)
+    const u64 b_meta = b_off + 8 + b_tab + b_cnt + b_cur;
+    const u64 b_meta_pad = (b_meta + 15) & ~(u64)15;
+    PW_HIP(yh_tmalloc(db, (void**)&d_scr, b_rec + b_meta_pad + (n_slots + cap) * sizeof(uint2) + 64));
     uint4* d_rrec = reinterpret_cast<uint4*>(d_scr);
     u64* d_segoff = reinterpret_cast<u64*>(d_scr + b_rec);
     unsigned long long* d_cursor = reinterpret_cast<unsigned long long*>(d_scr + b_rec + b_off);
@@ -393,16 +403,27 @@ int yh_q_pairwise(yh_db* db, double c_thresh, u64 r0, u64 r1) {
     u32* d_rid = d_tab + 2 * N + 1;
     u32* d_segcnt = d_tab + b_tab / sizeof(u32);
     u32* d_cur = d_segcnt + nseg;
+    uint2* d_out_own = nullptr;  // (a second attempt's larger output)
+    d_out = reinterpret_cast<uint2*>(d_scr + b_rec + b_meta_pad);
     if (!fz) PW_HIP(hipMemcpyAsync(d_tab, h_tab.data(), b_tab, hipMemcpyHostToDevice, st));
     if (!ranks) PW_HIP(hipMemsetAsync(d_cur, 0, b_cur, st));
-    // the survivors: PAIR_SLOTS per segment, and room for a million behind them to begin with; a run whose long segments
-    // need more is repeated with what it counted
-    const u64 n_slots = nseg * PAIR_SLOTS;
-    u64 cap = std::max<u64>(std::min<u64>(NC * (NC - 1), 1u << 20), 1);
-    PW_HIP(yh_tmalloc(db, (void**)&d_out, (n_slots + cap) * sizeof(uint2)));
     const double c_relaxed = c_thresh * (1.0 - 1e-9) - 1e-300;
-    std::vector<u32> h_segcnt(nseg);
-    std::vector<u64> h_segoff(nseg);
+    const u64 spec = std::min<u64>(cap, 1u << 16);
+    const bool have_sizes = db->h_sizes.size() == N;  // (a YH_DB_PAIRWISE_ONLY handle fetched them when it was made)
+    bool one_piece = b_tab == 0 && b_cur == 0;
+    const u64 b_piece = b_meta_pad + (n_slots + spec) * sizeof(uint2);
+    YhPin pin(b_piece + (have_sizes ? 0 : N * sizeof(u32)) + 64);
+    char* const hp = static_cast<char*>(pin.p);
+    if (!hp) one_piece = false;
+    // host side: the same layout as the device's piece when it comes in one copy
+    std::vector<u32> v_segcnt(hp ? 0 : nseg);
+    std::vector<u64> v_segoff(hp ? 0 : nseg);
+    unsigned long long n_over_stack = 0;
+    u64* const h_segoff = hp ? reinterpret_cast<u64*>(hp) : v_segoff.data();
+    unsigned long long* const p_n_over = hp ? reinterpret_cast<unsigned long long*>(hp + b_off) : &n_over_stack;
+    u32* const h_segcnt = hp ? reinterpret_cast<u32*>(hp + b_off + 8 + b_tab) : v_segcnt.data();
+    uint2* const h_out_pin = hp ? reinterpret_cast<uint2*>(hp + b_meta_pad) : nullptr;
+    u32* const h_sizes_pin = (hp && !have_sizes) ? reinterpret_cast<u32*>(hp + b_piece) : nullptr;
     unsigned long long n_over = 0;
     yh_ring_record_begin(db, db->ev_pair);
     if (rc == YH_OK && !fz)
@@ -421,25 +442,41 @@ int yh_q_pairwise(yh_db* db, double c_thresh, u64 r0, u64 r1) {
         }
         PW_HIP(hipGetLastError());
         if (attempt == 0) yh_ring_record_end(db, db->ev_pair);
-        PW_HIP(hipMemcpyAsync(&n_over, d_cursor, 8, hipMemcpyDeviceToHost, st));
-        PW_HIP(hipMemcpyAsync(h_segcnt.data(), d_segcnt, b_cnt, hipMemcpyDeviceToHost, st));
-        PW_HIP(hipMemcpyAsync(h_segoff.data(), d_segoff, b_off, hipMemcpyDeviceToHost, st));
+        if (one_piece && attempt == 0) {
+            PW_HIP(hipMemcpyAsync(hp, d_segoff, b_piece, hipMemcpyDeviceToHost, st));
+        } else {
+            PW_HIP(hipMemcpyAsync(p_n_over, d_cursor, 8, hipMemcpyDeviceToHost, st));
+            PW_HIP(hipMemcpyAsync(h_segcnt, d_segcnt, b_cnt, hipMemcpyDeviceToHost, st));
+            PW_HIP(hipMemcpyAsync(h_segoff, d_segoff, b_off, hipMemcpyDeviceToHost, st));
+            if (hp) PW_HIP(hipMemcpyAsync(h_out_pin, d_out, (n_slots + std::min<u64>(spec, cap)) * sizeof(uint2), hipMemcpyDeviceToHost, st));
+        }
+        if (h_sizes_pin && attempt == 0) PW_HIP(hipMemcpyAsync(h_sizes_pin, db->d_sizes, N * sizeof(u32), hipMemcpyDeviceToHost, st));
         PW_HIP(hipStreamSynchronize(st));
+        n_over = *p_n_over;
         if (rc != YH_OK || n_over <= cap) break;
         if (attempt == 1) { yh_set_error("pairwise: the second pass found more survivors than the first"); rc = YH_ERR_HIP; break; }
-        yh_tfree(db, d_out);
-        d_out = nullptr;
         cap = n_over;
-        PW_HIP(yh_tmalloc(db, (void**)&d_out, (n_slots + cap) * sizeof(uint2)));
+        PW_HIP(yh_tmalloc(db, (void**)&d_out_own, (n_slots + cap) * sizeof(uint2)));
+        d_out = d_out_own;
     }
     const u64 n_out = n_slots + n_over;
-    std::vector<uint2> ho(n_out);
-    PW_HIP(hipMemcpyAsync(ho.data(), d_out, n_out * sizeof(uint2), hipMemcpyDeviceToHost, st));
-    std::vector<u32> hsizes(N);
-    PW_HIP(hipMemcpyAsync(hsizes.data(), db->d_sizes, N * sizeof(u32), hipMemcpyDeviceToHost, st));
-    PW_HIP(hipStreamSynchronize(st));
+    std::vector<uint2> v_out;
+    std::vector<u32> v_sizes;
+    const uint2* ho = h_out_pin;
+    const u32* hsizes = have_sizes ? db->h_sizes.data() : h_sizes_pin;
+    if (rc == YH_OK && (!hp || n_over > spec)) {  // the second round
+        v_out.resize(n_out);
+        PW_HIP(hipMemcpyAsync(v_out.data(), d_out, n_out * sizeof(uint2), hipMemcpyDeviceToHost, st));
+        if (!hsizes) {
+            v_sizes.resize(N);
+            PW_HIP(hipMemcpyAsync(v_sizes.data(), db->d_sizes, N * sizeof(u32), hipMemcpyDeviceToHost, st));
+            hsizes = v_sizes.data();
+        }
+        PW_HIP(hipStreamSynchronize(st));
+        ho = v_out.data();
+    }
 #undef PW_HIP
-    yh_tfree(db, d_scr); yh_tfree(db, d_out);
+    yh_tfree(db, d_scr); yh_tfree(db, d_out_own);
     if (rc != YH_OK) return rc;
 
     // segments in row order (columns ascend inside a segment, column blocks inside a row), through the exact host-side

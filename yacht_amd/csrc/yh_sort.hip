@@ -1751,11 +1751,15 @@ int yh_pc_finish_emit(yh_db* db, yh_pieces* s, const u64* d_values, const u64* d
     if (!chains) k_bucket_group5<<<8u * b.per_xcd, BKT_THREADS, 0, db->stream>>>(b);
     else k_bucket_group<<<8u * b.per_xcd, BKT_THREADS, 0, db->stream>>>(b);
     YH_HIP(hipGetLastError());
-    u32 hflags[4] = {0, 0, 0, 0};
     unsigned long long ht[4] = {0, 0, 0, 0};
-    static thread_local unsigned long long hrows[TOT_LANES * 8];
+    static thread_local unsigned long long hrows_pageable[TOT_LANES * 8 + 2];
+    constexpr size_t ROWS_BYTES = TOT_LANES * 8 * sizeof(unsigned long long);
+    YhPin pin(ROWS_BYTES + 16);  // (both read-backs queued into page-locked memory, one wait)
+    unsigned long long* hrows = pin.p ? static_cast<unsigned long long*>(pin.p) : hrows_pageable;
+    u32* hflags = reinterpret_cast<u32*>(hrows + TOT_LANES * 8);
+    hflags[0] = hflags[1] = hflags[2] = hflags[3] = 0;
     YH_HIP(hipMemcpyAsync(hflags, flags, 3 * sizeof(u32), hipMemcpyDeviceToHost, db->stream));
-    YH_HIP(hipMemcpyAsync(hrows, s->totals, sizeof(hrows), hipMemcpyDeviceToHost, db->stream));
+    YH_HIP(hipMemcpyAsync(hrows, s->totals, ROWS_BYTES, hipMemcpyDeviceToHost, db->stream));
     YH_HIP(hipStreamSynchronize(db->stream));
     for (u32 q = 0; q < TOT_LANES; ++q)
         for (u32 t = 0; t < 4; ++t) ht[t] += hrows[q * 8 + t];
