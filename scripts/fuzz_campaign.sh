@@ -18,4 +18,5 @@ SEED=9110 run YH_DEBUG_TUNING=1 YH_NO_PIECES=1 YH_NO_PIECES_SORT=1 YH_CHECK_SORT
 SEED=9111 run YH_DEBUG_TUNING=1 YH_GROUP_CHAINS=1 YH_PC_P2F=0.6 YH_PC_TILE_ELEMS=700 YH_CHECK_SORT=1
 SEED=9112 run YH_DEBUG_TUNING=1 YH_NO_SPILL=1 YH_PC_P2F=5 YH_CHECK_SORT=1
 SEED=9113 run YH_DEBUG_TUNING=1 YH_PC_PAD=640 YH_FZ_NO_INLINE=1 YH_CHECK_SORT=1 YH_UPLOAD_CHUNK_MIN=1
+SEED=9114 run YH_DEBUG_TUNING=1 YH_NO_PIN=1 YH_UPLOAD_CHUNK_MIN=100000
 echo "== mix_calls 150 rounds"; timeout 900 python tests/tools/mix_calls.py 150 9106 2>&1 | tail -1

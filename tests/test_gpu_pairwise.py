@@ -98,9 +98,11 @@ def test_database_uploaded_in_chunks(hip_lib, shares):
         assert v[:3] == [True, True, True], (k, v)
 
 
-def test_more_survivors_than_the_first_buffer(hip_lib):
-    """1 500 sketches that all hold one common hash: 1 500 x 1 499 ordered pairs at C = 0 -- more than the million
-    entries the output starts with, so the row pass is repeated with the size it counted."""
+@pytest.mark.parametrize("n", [1500, 400])
+def test_more_survivors_than_the_first_buffer(hip_lib, n):
+    """n sketches that all hold one common hash: n (n - 1) ordered pairs at C = 0, all behind the segments' fixed slots.
+    1 500: more than the million entries the output starts with, so the row pass is repeated with the size it counted;
+    400: more than the 65 536 that come back with the counts in the first copy, so the survivors take a second one."""
     from oracle import oracle
     from yacht_amd import synth
     from yacht_amd.engine import RefDB, YH_DB_PAIRWISE_ONLY
@@ -108,10 +110,10 @@ def test_more_survivors_than_the_first_buffer(hip_lib):
     rng = np.random.default_rng(77)
     mh = synth.max_hash_for_scaled(1000)
     common = np.array([int(rng.integers(1, mh))], np.uint64)
-    refs = [np.unique(np.concatenate([common, synth.random_sketch(rng, 20, mh)])) for _ in range(1500)]
+    refs = [np.unique(np.concatenate([common, synth.random_sketch(rng, 20, mh)])) for _ in range(n)]
     values, offsets = synth.pack(refs)
     wi, wj, wc, wstats = oracle.train_pairs(values, offsets, 0.0, threads=4)
-    assert wi.size == 1500 * 1499
+    assert wi.size == n * (n - 1)
     with RefDB(values, offsets, flags=YH_DB_PAIRWISE_ONLY) as db:
         gi, gj, gc = db.pairwise(0.0)
         assert np.array_equal(gi, wi) and np.array_equal(gj, wj) and np.array_equal(gc, wc)

@@ -285,7 +285,8 @@ std::mutex g_pin_mu;
 PinBuf g_pin[4];
 }
 void* yh_pin_acquire(u64 bytes) {
-    if (bytes == 0 || bytes > ((u64)64 << 20)) return nullptr;
+    static const bool off = [] { const char* e = yh_tune_env("YH_NO_PIN"); return e && e[0] == '1'; }();  // (tests: the pageable paths)
+    if (off || bytes == 0 || bytes > ((u64)64 << 20)) return nullptr;
     std::lock_guard<std::mutex> lk(g_pin_mu);
     for (PinBuf& b : g_pin)
         if (!b.busy && b.p && b.cap >= bytes) { b.busy = true; return b.p; }
