@@ -32,10 +32,6 @@ namespace {
 constexpr int WAVE = 64;
 // holders of a hash up to which a posting's record names the others inline (three others)
 constexpr u32 PAIR_INLINE = 4;
-// a list of more than PAIR_LONG holders is walked by the whole wave, one holder per lane (a k-mer shared by M
-// references is M^2 increments either way, but M serial steps per posting instead of M / 64 made one conserved k-mer
-// the tail of the launch)
-constexpr u32 PAIR_LONG = 32;
 // columns (u32 counts) of a row block in LDS: with the attribute below 36 864 (144 KiB), else what fits 64 KiB
 constexpr u32 PAIR_COLS_BIG = 36864;
 constexpr u32 PAIR_COLS_SMALL = 15360;
@@ -104,7 +100,7 @@ constexpr u32 PAIR_SLOTS = 4;
 constexpr int PAIR_U = YH_PAIR_U;  // records a lane has in flight
 
 #ifndef YH_ABLATE_PAIR
-#define YH_ABLATE_PAIR 0  // timing-only builds (results wrong): 1 no record pass, 2 no row clear / survivor scan, 4 records read but not added
+#define YH_ABLATE_PAIR 0  // timing-only builds (results wrong): 1 no record pass, 2 no row clear / survivor scan, 4 records read but not added, 8 records read but not decoded
 #endif
 // FUSED: the records are yh_db::d_fz_rec's (8 bytes per CSR position, written by the sort's last pass: yh_sort.hip) and a
 // row is the extent of the reference's sketch -- entries of hashes nobody else holds are 0 and add nothing.
@@ -119,6 +115,7 @@ __global__ void __launch_bounds__(THREADS) k_pair_rows(const PairRows p) {
     typedef typename PairRec<FUSED>::T Rec;
     extern __shared__ u32 row[];  // p.cols counts
     __shared__ u32 wtot[WAVES];
+    __shared__ u64 lqueue[WAVES][64];  // a wave's queue of list records (below)
     __shared__ u64 s_base;
     __shared__ u32 s_write;
     const u32 tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
@@ -164,6 +161,50 @@ __global__ void __launch_bounds__(THREADS) k_pair_rows(const PairRows p) {
         atomicAdd(&row[c], 1u);
     };
     auto add = [&](u32 o) { if constexpr (FUSED) addc(o); else addc(p.cid[o]); };  // o: a reference id (the long lists)
+    // LIST records -- "the other holders are entries [q0, q0 + m) of the holder array" -- are not walked where they are met:
+    // a load inside the record loop is waited for with everything in flight before it (vmcnt counts in order), i.e. with the
+    // next step's records, and half of configs[3]'s wave steps meet one (a hash all five genomes of a cluster hold).  A wave
+    // QUEUES them (64 descriptors of its own in LDS) and walks the queue when it is full and behind the row's last record:
+    // all queued lists flattened over the lanes -- entry t of the concatenation belongs to the list whose exclusive length
+    // prefix is the largest <= t (six ds_bpermute steps) -- so that 64 holders are requested per round whatever the lists'
+    // lengths: a cluster's five-entry lists a dozen to the round, a k-mer of 5 000 holders in 79 rounds (before: one holder
+    // after the other by the record's own lane up to 32 holders, one list per round above).
+    // (profiles/r05/ablate_pair.txt: the records read but not decoded 86 us, decoded with the lists walked in place 217.)
+    auto flush = [&](u32 nq) {
+        const u64 d = lane < nq ? lqueue[wid][lane] : 0ull;
+        const u32 m = (u32)(d >> 40);  // (24 bits)
+        u32 inc = m;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const u32 t_ = (u32)__shfl_up((int)inc, off);
+            if (lane >= (u32)off) inc += t_;
+        }
+        const u32 total = (u32)__shfl((int)inc, 63);
+        const u32 exc = lane < nq ? inc - m : 0xffffffffu;  // (behind the queue's end: above every t)
+        const u32 dlo = (u32)d, dhi = (u32)(d >> 32);
+        for (u32 t0_ = 0; t0_ < total; t0_ += 64u) {  // (wave-uniform)
+            const u32 t = t0_ + lane;
+            u32 e = 0;
+#pragma unroll
+            for (u32 step = 32; step >= 1; step >>= 1) {
+                const u32 cand = e + step;  // (<= 63)
+                const u32 v = (u32)__shfl((int)exc, (int)cand);
+                if (v <= t) e = cand;
+            }
+            const u32 e_exc = (u32)__shfl((int)exc, (int)e);
+            const u64 de = ((u64)(u32)__shfl((int)dhi, (int)e) << 32) | (u32)__shfl((int)dlo, (int)e);
+            if (t < total) {
+                u64 q0 = de & ((1ull << 40) - 1ull);
+                const u32* lsrc = p.pr;
+                if constexpr (FUSED) {
+                    if (q0 >= p.pr_split) { lsrc = p.pr2; q0 -= p.pr_split; }
+                }
+                const u32 o = lsrc[q0 + (t - e_exc)];
+                if (o != (u32)a) add(o);
+            }
+        }
+    };
+    u32 nq = 0;  // descriptors in this wave's queue (wave-uniform)
     for (u32 tb = t0; tb < ((YH_ABLATE_PAIR & 1) ? t0 : t1); tb += PAIR_U * THREADS) {  // (workgroup-uniform bounds: the ballot below)
         Rec cur[PAIR_U];
 #pragma unroll
@@ -175,6 +216,10 @@ __global__ void __launch_bounds__(THREADS) k_pair_rows(const PairRows p) {
         }
 #pragma unroll
         for (int u = 0; u < PAIR_U; ++u) {
+            if constexpr (FUSED && (YH_ABLATE_PAIR & 8) != 0) {  // (timing only: the records read, nothing decoded)
+                if (cur[u] == 0x123456789abcull) row[0] = 1;
+                continue;
+            }
             bool is_list;
             u64 lq0 = 0;   // a list: its first entry in pr[] ...
             u32 lm = 0;    // ... and its length (this reference included)
@@ -201,29 +246,30 @@ __global__ void __launch_bounds__(THREADS) k_pair_rows(const PairRows p) {
                     lm = cur[u].y;
                 }
             }
-            const u32* lp = p.pr;  // where this record's list lives
-            if constexpr (FUSED) {
-                if (is_list && lq0 >= p.pr_split) { lp = p.pr2; lq0 -= p.pr_split; }
-            }
-            if (is_list && lm <= PAIR_LONG) {
+            if (!FUSED && is_list && lm >= (1u << 24)) {  // (no room for its length in a descriptor: a hash 16 million references hold)
                 for (u64 q = lq0, qe = lq0 + lm; q < qe; ++q) {
-                    const u32 o = lp[q];
+                    const u32 o = p.pr[q];
                     if (o != (u32)a) add(o);
                 }
+                is_list = false;
             }
-            u64 todo = __ballot(is_list && lm > PAIR_LONG);
-            while (todo) {
-                const int src = __ffsll((long long)todo) - 1;
-                todo &= todo - 1;
-                const u64 q0 = ((u64)(u32)__shfl((int)(u32)(lq0 >> 32), src) << 32) | (u32)__shfl((int)(u32)lq0, src);
-                const u32 m = (u32)__shfl((int)lm, src);
-                const u32* lsrc = __shfl((int)(lp != p.pr), src) != 0 ? p.pr2 : p.pr;
-                for (u32 q = lane; q < m; q += 64u) {
-                    const u32 o = lsrc[q0 + q];
-                    if (o != (u32)a) add(o);
+            // a list: queued (the walk is the wave's, behind the records)
+            const u64 bal = __ballot(is_list);
+            if (bal) {  // (wave-uniform)
+                const u32 c = (u32)__popcll(bal);
+                if (nq + c > 64u) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    flush(nq);
+                    nq = 0;
                 }
+                if (is_list) lqueue[wid][nq + (u32)__popcll(bal & ((1ull << lane) - 1ull))] = (lq0 & ((1ull << 40) - 1ull)) | ((u64)lm << 40);
+                nq += c;
             }
         }
+    }
+    if (nq) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        flush(nq);
     }
     __syncthreads();
     // survivors in column order: wave v owns the columns [v*per, (v+1)*per)
