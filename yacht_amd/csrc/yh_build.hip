@@ -477,7 +477,12 @@ static int validate_end(yh_db* db, bool ends = false) {
     YH_HIP(hipMemcpyAsync(hflag, db->d_flag, 32, hipMemcpyDeviceToHost, db->stream));
     if (want_sizes && pin.p) YH_HIP(hipMemcpyAsync(hflag + 8, db->d_sizes, db->n_refs * sizeof(u32), hipMemcpyDeviceToHost, db->stream));
     YH_HIP(hipStreamSynchronize(db->stream));
-    if (want_sizes && pin.p) db->h_sizes.assign(hflag + 8, hflag + 8 + db->n_refs);
+    if (want_sizes && pin.p) {
+        db->h_sizes.assign(hflag + 8, hflag + 8 + db->n_refs);
+        u32 mx = 0;
+        for (const u32 v : db->h_sizes) mx = std::max(mx, v);
+        db->max_ref_size = mx;
+    }
     if (ends) {  // the CSR's first and last offset, read by k_ref_extents (a device CSR: the host has not seen them)
         u64 first, last;
         memcpy(&first, &hflag[4], 8);

@@ -194,6 +194,7 @@ struct yh_db {
     u64 sample_tmp_cap = 0;
     u32* d_flag = nullptr;     // [1] generic error/flag word
     std::vector<u32> h_sizes;  // the sketch sizes on the host (YH_DB_PAIRWISE_ONLY handles: yh_pairwise's exact filter reads them)
+    u32 max_ref_size = 0;      // ... and the largest of them (16-bit counts in k_pair_rows when it fits)
     u32* d_bad_word = nullptr; // [1] deferred ordering verdict of yh_run (see bad_gen)
     u32* d_reps = nullptr;     // [R][N] replicated overlap counters; ZERO AT REST: k_reduce_replicas clears what it sums
     u64 reps_cap = 0;

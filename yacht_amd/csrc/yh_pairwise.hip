@@ -109,11 +109,16 @@ template <> struct PairRec<true> { typedef u64 T; };
 constexpr u64 FZ_LIST = 1ull << 63;
 constexpr u32 FZ_FIELD = (1u << 21) - 1u;
 
-template <int THREADS, bool FUSED>
+// HALF: the row's counts are 16 bits wide, two columns to the LDS word (a count never exceeds the smaller of the two sketches:
+// the host asks for this form when no sketch has more than 65 535 hashes).  Half the LDS per row is twice the resident rows: a
+// row's phases -- clear, records, survivors -- come one after the other inside a workgroup and the workgroups of a CU start
+// together, so few large workgroups leave the memory pipe idle while they count and the ALUs idle while they read; at
+// configs[3] four 512-lane rows per CU with 40 KB each took 227 us, seven 256-lane rows with 20 KB each take 209 (profiles/r05/sweep_pair_half.txt).
+template <int THREADS, bool FUSED, bool HALF>
 __global__ void __launch_bounds__(THREADS) k_pair_rows(const PairRows p) {
     constexpr int WAVES = THREADS / WAVE;
     typedef typename PairRec<FUSED>::T Rec;
-    extern __shared__ u32 row[];  // p.cols counts
+    extern __shared__ u32 row[];  // p.cols counts (HALF: two to the word)
     __shared__ u32 wtot[WAVES];
     __shared__ u64 lqueue[WAVES][64];  // a wave's queue of list records (below)
     __shared__ u64 s_base;
@@ -150,7 +155,7 @@ __global__ void __launch_bounds__(THREADS) k_pair_rows(const PairRows p) {
         if (t >= t1) mask_off(rec[u]);
     }
     if (!(YH_ABLATE_PAIR & 2))
-        for (u32 j = tid; j < w; j += THREADS) row[j] = 0;
+        for (u32 j = tid; j < (HALF ? (w + 1u) >> 1 : w); j += THREADS) row[j] = 0;
     __syncthreads();
     // (Same-address LDS adds are not what the pass waits for: counting a lane's first four columns in registers and
     // adding them once made it slower; without any add it is 15 % shorter.)
@@ -158,7 +163,16 @@ __global__ void __launch_bounds__(THREADS) k_pair_rows(const PairRows p) {
         const u32 c = cc - c0;
         if (c >= w) return;
         if (YH_ABLATE_PAIR & 4) { if (c == 0x12345u) row[0] = 1; return; }
-        atomicAdd(&row[c], 1u);
+        if constexpr (HALF) atomicAdd(&row[c >> 1], 1u << ((c & 1u) * 16u));
+        else atomicAdd(&row[c], 1u);
+    };
+    // (Tried, round 5: the adds of a wave step combined per column first -- the first active lane's column by readlane, who
+    // else has it by ballot, one add of the population count; up to 2 / 4 / 8 distinct columns per step, the rest on their own --
+    // because without any add the pass is 110 us against 208: 323 / 447 / 443 us.  The LDS takes 64 adds to a handful of words
+    // far better than the wave takes the loop: profiles/r05/sweep_pair_agg.txt.)
+    auto count_of = [&](u32 j) -> u32 {  // column j's count
+        if constexpr (HALF) return (row[j >> 1] >> ((j & 1u) * 16u)) & 0xffffu;
+        else return row[j];
     };
     auto add = [&](u32 o) { if constexpr (FUSED) addc(o); else addc(p.cid[o]); };  // o: a reference id (the long lists)
     // LIST records -- "the other holders are entries [q0, q0 + m) of the holder array" -- are not walked where they are met:
@@ -278,7 +292,7 @@ __global__ void __launch_bounds__(THREADS) k_pair_rows(const PairRows p) {
     u32 mine = 0;
     for (u32 j0 = jb; j0 < ((YH_ABLATE_PAIR & 2) ? jb : je); j0 += 64u) {
         const u32 j = j0 + lane;
-        const u32 cnt = j < je ? row[j] : 0u;  // (rows are sparse: rid / sizes only behind a count)
+        const u32 cnt = j < je ? count_of(j) : 0u;  // (rows are sparse: rid / sizes only behind a count)
         const bool keep = cnt != 0 && pair_keep(cnt, (u32)a, FUSED ? c0 + j : p.rid[c0 + j], p.sizes, p.c_relaxed);
         mine += (u32)__popcll(__ballot(keep));
     }
@@ -306,7 +320,7 @@ __global__ void __launch_bounds__(THREADS) k_pair_rows(const PairRows p) {
     if (wtot[wid] == 0) return;  // (wave-uniform)
     for (u32 j0 = jb; j0 < je; j0 += 64u) {
         const u32 j = j0 + lane;
-        const u32 cnt = j < je ? row[j] : 0u;
+        const u32 cnt = j < je ? count_of(j) : 0u;
         u32 rj = 0;
         bool keep = false;
         if (cnt != 0) {
@@ -391,22 +405,30 @@ int yh_q_pairwise(yh_db* db, double c_thresh, u64 r0, u64 r1) {
     if (NC == 0) return done_empty();
 
     // columns per row block: what the LDS holds
-    static const int threads = [] { const char* e = yh_tune_env("YH_PAIR_THREADS"); const int t = e ? atoi(e) : 512; return t == 1024 ? 1024 : t == 256 ? 256 : 512; }();
     typedef void (*RowsKernel)(const PairRows);
-    // (512 lanes: configs[3]'s rows of ~2 700 records in 0.28 ms, against 0.37 with 256 lanes and 0.33 with 1 024)
-    const RowsKernel kern_plain = threads == 1024 ? k_pair_rows<1024, false> : threads == 256 ? k_pair_rows<256, false> : k_pair_rows<512, false>;
-    const RowsKernel kern_fused = threads == 1024 ? k_pair_rows<1024, true> : threads == 256 ? k_pair_rows<256, true> : k_pair_rows<512, true>;
-    const RowsKernel kern = fz ? kern_fused : kern_plain;
-    static const bool big_lds = [kern_plain, kern_fused] {
+    // 16-bit counts (k_pair_rows<.., HALF>): a fused handle that knows its sketch sizes and has none above 65 535 hashes
+    static const bool no_half = [] { const char* e = yh_tune_env("YH_PAIR_NO_HALF"); return e && e[0] == '1'; }();
+    const bool half = fz && !no_half && db->h_sizes.size() == N && db->max_ref_size <= 0xffffu;
+    // lanes per row: 512 for 32-bit rows (configs[3]'s rows of ~2 700 records in 0.28 ms, against 0.37 with 256 lanes and 0.33
+    // with 1 024); 256 for 16-bit rows (more rows resident per CU: profiles/r05/sweep_pair_half.txt)
+    static const int threads_env = [] { const char* e = yh_tune_env("YH_PAIR_THREADS"); const int t = e ? atoi(e) : 0; return (t == 1024 || t == 512 || t == 256) ? t : 0; }();
+    const int threads = threads_env ? threads_env : (half ? 256 : 512);
+    const RowsKernel kern_plain = threads == 1024 ? k_pair_rows<1024, false, false> : threads == 256 ? k_pair_rows<256, false, false> : k_pair_rows<512, false, false>;
+    const RowsKernel kern_fused = threads == 1024 ? k_pair_rows<1024, true, false> : threads == 256 ? k_pair_rows<256, true, false> : k_pair_rows<512, true, false>;
+    const RowsKernel kern_half = threads == 1024 ? k_pair_rows<1024, true, true> : threads == 256 ? k_pair_rows<256, true, true> : k_pair_rows<512, true, true>;
+    const RowsKernel kern = half ? kern_half : fz ? kern_fused : kern_plain;
+    static const bool big_lds = [] {
         bool ok = true;
-        for (const RowsKernel k : {kern_plain, kern_fused}) {
+        for (const RowsKernel k : {(RowsKernel)k_pair_rows<1024, false, false>, (RowsKernel)k_pair_rows<512, false, false>, (RowsKernel)k_pair_rows<256, false, false>,
+                                   (RowsKernel)k_pair_rows<1024, true, false>, (RowsKernel)k_pair_rows<512, true, false>, (RowsKernel)k_pair_rows<256, true, false>,
+                                   (RowsKernel)k_pair_rows<1024, true, true>, (RowsKernel)k_pair_rows<512, true, true>, (RowsKernel)k_pair_rows<256, true, true>}) {
             const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                      (int)(PAIR_COLS_BIG * sizeof(u32)));
             if (e != hipSuccess) { (void)hipGetLastError(); ok = false; }
         }
         return ok;
     }();
-    u32 cols = big_lds ? PAIR_COLS_BIG : PAIR_COLS_SMALL;
+    u32 cols = (big_lds ? PAIR_COLS_BIG : PAIR_COLS_SMALL) * (half ? 2u : 1u);  // (columns: what the LDS words hold)
     if (const char* e = yh_tune_env("YH_PAIR_COLS")) cols = std::max(64, atoi(e));  // (tests: several column blocks)
     cols = (u32)std::min<u64>(cols, (NC + 63) / 64 * 64);
     const u32 ncb = (u32)((NC + cols - 1) / cols);
@@ -484,7 +506,7 @@ int yh_q_pairwise(yh_db* db, double c_thresh, u64 r0, u64 r1) {
             const u64 nb = std::min<u64>(rows - b0, step);
             q.a0 = r0 + b0;
             q.seg0 = b0 * ncb;
-            kern<<<dim3((u32)nb, ncb), threads, cols * sizeof(u32), st>>>(q);
+            kern<<<dim3((u32)nb, ncb), threads, (half ? (cols + 1) / 2 : cols) * sizeof(u32), st>>>(q);
         }
         PW_HIP(hipGetLastError());
         if (attempt == 0) yh_ring_record_end(db, db->ev_pair);
