@@ -8,7 +8,7 @@ run() { echo "== $*"; env "$@" timeout $((S + 200)) python tests/tools/fuzz_pari
 SEED=9101 run YH_DEBUG_TUNING=0
 SEED=9107 run YH_DEBUG_TUNING=1 YH_CHECK_SORT=1
 SEED=9102 run YH_DEBUG_TUNING=1 YH_UPLOAD_CHUNK_MIN=1 YH_CHECK_SORT=1 YH_UPLOAD_SHARES=0.3,0.3,0.2,0.1,0.1
-SEED=9103 run YH_DEBUG_TUNING=1 YH_PAIR_COLS=64 YH_PAIR_THREADS=256 YH_NO_PSORT=1
+SEED=9103 run YH_DEBUG_TUNING=1 YH_PAIR_COLS=64 YH_PAIR_THREADS=256 YH_NO_PSORT=1 YH_PAIR_NO_HALF=1
 SEED=9104 run YH_DEBUG_TUNING=1 YH_INDEX_TILE=2 YH_FILTER_MIN=1 YH_FILTER_BPH=2 YH_PAIR_THREADS=1024
 SEED=9105 run YH_DEBUG_TUNING=1 YH_NO_POOL=1 YH_UPLOAD_CHUNK_MIN=1000
 SEED=9108 run YH_DEBUG_TUNING=1 YH_FZ_NO_INLINE=1 YH_UPLOAD_CHUNK_MIN=1

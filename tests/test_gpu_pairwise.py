@@ -240,3 +240,27 @@ def test_neighbouring_hashes_crowd_one_slot_of_the_grouping_table(hip_lib):
             gi, gj, gc = db.pairwise(0.001)
             assert np.array_equal(gi, wi) and np.array_equal(gj, wj) and np.array_equal(gc, wc), flags
             assert db.index_stats() == wstats
+
+
+@pytest.mark.parametrize("size", [65535, 65536])
+def test_sixteen_bit_row_counts_at_their_limit(hip_lib, size):
+    """Three identical sketches of 65 535 hashes: every count of the row pass is 65 535 -- the largest a 16-bit count holds, in
+    both halves of one LDS word (columns 0 and 1 of row 2), without a carry between them; with 65 536 hashes the handle
+    must take the 32-bit rows.  Two smaller relatives keep the threshold filter in play."""
+    from oracle import oracle
+    from yacht_amd import synth
+    from yacht_amd.engine import RefDB, YH_DB_PAIRWISE_ONLY
+
+    rng = np.random.default_rng(5)
+    mh = synth.max_hash_for_scaled(1000)
+    big = synth.random_sketch(rng, size + 64, mh)[:size]  # (exactly `size` distinct hashes)
+    assert big.size == size
+    refs = [big, big.copy(), big.copy(), big[::3].copy(), np.unique(np.concatenate([big[::7], synth.random_sketch(rng, 500, mh)]))]
+    values, offsets = synth.pack(refs)
+    for c in (0.0, 0.3):
+        wi, wj, wc, wstats = oracle.train_pairs(values, offsets, c, threads=4)
+        with RefDB(values, offsets, flags=YH_DB_PAIRWISE_ONLY) as db:
+            gi, gj, gc = db.pairwise(c)
+            assert np.array_equal(gi, wi) and np.array_equal(gj, wj) and np.array_equal(gc, wc), (size, c)
+            assert db.index_stats() == wstats
+    assert int(wc.max()) == big.size
