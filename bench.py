@@ -492,10 +492,15 @@ def main() -> int:
     if hash_batched:
         n_timed = ((n_timed + BB - 1) // BB) * BB  # whole blocks
     db.timing()
+    # (HIP events on the handle's stream around the launches of the timed region -- the roofline's launch duration when a
+    # step is ONE launch: see `duration_basis` below)
+    ev_region = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    ev_region[0].record(stream)
     t0 = time.perf_counter()
     for _ in range(n_timed):
         step()
     t_issued = time.perf_counter() - t0  # host time to QUEUE the steps (no waiting): host-bound when it equals `elapsed`
+    ev_region[1].record(stream)
     drain()
     fence()
     elapsed = time.perf_counter() - t0
@@ -1090,12 +1095,25 @@ def main() -> int:
 
     k_ms = float(timing["ms_overlap_kernel"])
     x_ms = float(timing["ms_exclusive_kernels"])
+    k_pairs_ms = k_ms
+    one_launch_per_step = bool(args.pipelined_tail and not multi and default_choice == ylib.YH_LOOKUP_INDEXED)
+    if one_launch_per_step:
+        # The step is ONE launch (k_step_fused), so the launches of the timed region are exactly n_timed and the interval between
+        # two HIP events on their stream, one before the first and one behind the last, divided by n_timed, is the kernel's
+        # average duration INCLUDING the dispatch gaps between consecutive launches -- an upper bound, never flattering -- and
+        # without the ~5 us a per-launch event pair adds to every sampled launch (`kernel_ms_avg_event_pairs`; rocprofv3's
+        # own figure for the kernel is in profiles/: 33.4 us).
+        k_ms = float(ev_region[0].elapsed_time(ev_region[1])) / n_timed
     rl_main[0] = True
     roofline = (roofline_indexed if default_choice == ylib.YH_LOOKUP_INDEXED else roofline_stream)(k_ms, x_ms)
     rl_main[0] = False
     if roofline["kernel"] == "k_step_fused":
         roofline["kernel_note"] = ("one launch per step: the lookup of this sample (the role the bytes are counted for: "
                                    "k_index_lookup_tile's body) + the reducer of the previous sample + the exclusive pass of the one before")
+    roofline["duration_basis"] = (f"HIP events on the handle's stream around the {n_timed} launches of the timed region / {n_timed} "
+                                  "(dispatch gaps included)" if one_launch_per_step else
+                                  "HIP event pairs around every 32nd launch of the dominant kernel in the timed region (the library's ring)")
+    roofline["kernel_ms_avg_event_pairs"] = round(k_pairs_ms, 4)
     roofline["default_lookup"] = "indexed" if default_choice == ylib.YH_LOOKUP_INDEXED else "stream"
     # (scalar copies of the nested survey_formula block: parsers that keep only scalars keep these)
     roofline["bytes_survey_formula"] = roofline["survey_formula"]["bytes_per_launch"]
@@ -1117,7 +1135,7 @@ def main() -> int:
         gaps = sorted(a.elapsed_time(b) for a, b in pairs)
         empty_ms = float(gaps[len(gaps) // 2])
         roofline["event_pair_overhead_ms"] = round(empty_ms, 4)
-        roofline["kernel_ms_avg_net_of_event_overhead"] = round(max(k_ms - empty_ms, 0.0), 4)
+        roofline["kernel_ms_avg_net_of_event_overhead"] = round(max(k_pairs_ms - empty_ms, 0.0), 4)  # (of the per-launch pairs)
     other = None
     if "stream" in paths and default_choice == ylib.YH_LOOKUP_INDEXED:
         other = roofline_stream(paths["stream"]["lookup_kernel_ms_avg"], paths["stream"]["exclusive_kernels_ms_avg"])

@@ -1,4 +1,4 @@
-# One measurement session on the GPU box (round 5): rocprofv3 kernel stats + PMC passes of bench.py, the bench lines, the train
+# One measurement session on the GPU box (round 5; afterwards, here: bash scripts/adopt_session.sh): rocprofv3 kernel stats + PMC passes of bench.py, the bench lines, the train
 # profile (host input and device input), the commands end to end.  usage: bash scripts/measure_session.sh  -> gpurun_out/
 set -u
 cd "$GRAFT_REPO_ROOT"

@@ -1,18 +1,13 @@
 #!/bin/bash
-# The batched lookup with non-temporal bucket loads (YH_BATCH_NT=1) against the default, two takes each.
+# k_batch_lookup with non-temporal loads for the read-once lines (YH_BATCH_NT build variants: 1 buckets, 2 sample hashes, 3 both):
+# do they leave the XCD's L2 to the presence-filter lines the 64 samples of a quantile step share?
 cd "$GRAFT_REPO_ROOT" || exit 1
 python3 - <<'PY'
 from yacht_amd import build
-build.build_variant("bnt0", {"YH_BATCH_NT": 0})
-build.build_variant("bnt1", {"YH_BATCH_NT": 1})
+for v in (1, 2, 3):
+    build.build_variant(f"nt{v}", {"YH_BATCH_NT": v})
 PY
-for v in 0 1; do for take in 1 2; do
-  YACHT_HIP_LIB="yacht_amd/lib/libyacht_hip_bnt$v.so" python3 bench.py --no-train --no-sketch --no-cpu-baseline --no-host-inclusive --no-real-shape 2>/dev/null | tail -1 > /tmp/line.json
-  python3 - "$v" <<'PY'
-import json, sys
-d = json.loads(open("/tmp/line.json").read())
-sm = d["scaling_model"]["per_G"]
-print(f"NT={sys.argv[1]}: batched {d['batched']['ms_per_sample']:.4f} ms/sample (equal {d['batched']['equals_single_sample_step']})  rank-0 share per block at G=2/4/8: "
-      + " / ".join(f"{sm[g]['batched_rank0_ms_per_block']:.3f}" for g in ('2', '4', '8')) + " ms", flush=True)
-PY
-done; done
+for v in 0 1 2 3; do
+  lib="yacht_amd/lib/libyacht_hip_nt$v.so"; [ $v = 0 ] && lib="yacht_amd/lib/libyacht_hip.so"
+  for g in 1 8; do echo -n "NT $v  "; YACHT_HIP_LIB=$lib python3 scripts/probes/batch_share_trace.py $g 60 2>&1 | grep "per block"; done
+done

@@ -600,3 +600,29 @@ def test_pool_release_is_exported_and_harmless_without_a_gpu():
     cached -- and no GPU -- it releases zero bytes."""
     assert _lib.pool_release() == 0
     assert _lib.alloc_stats()["bytes_idle"] == 0
+
+
+def test_traffic_files_were_taken_from_this_source_of_the_kernels():
+    """profiles/traffic_r05_*.json carry the sha256 of the kernel sources their PMC passes ran on; bench.py / bench_train.py attach
+    `roofline.traffic` only when it matches.  A mismatch is not an error of the code -- the kernels were edited since the last
+    measurement session -- so it skips, loudly, instead of failing: retake with scripts/measure_session.sh + adopt_session.sh."""
+    import hashlib
+    import json
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def src(files):
+        h = hashlib.sha256()
+        for f in files:
+            with open(os.path.join(root, "yacht_amd", "csrc", f), "rb") as fh:
+                h.update(fh.read())
+        return h.hexdigest()[:16]
+
+    want = {"fused": src(("yh_query.hip", "yh_common.h")), "train": src(("yh_sort.hip", "yh_pairwise.hip", "yh_common.h"))}
+    stale = []
+    for n, tag in want.items():
+        with open(os.path.join(root, "profiles", f"traffic_r05_{n}.json")) as f:
+            if json.load(f)["source_tag"] != tag:
+                stale.append(n)
+    if stale:
+        pytest.skip(f"PMC traffic files are older than the kernels they describe: {stale} (bench lines will carry traffic = null)")

@@ -113,7 +113,11 @@ __global__ void __launch_bounds__(256) k_batch_lookup(const u64* __restrict__ sa
 #pragma unroll
             for (int u = 0; u < BATCH_U; ++u) {
                 const u64 k = k0 + (u64)u * 256u + threadIdx.x;
+#if defined(YH_BATCH_NT) && (YH_BATCH_NT & 2)
+                h[u] = __builtin_nontemporal_load(&samples[off[s] + min(k, k_end - 1)]);
+#else
                 h[u] = samples[off[s] + min(k, k_end - 1)];
+#endif
                 ok[u] = k < k_end && h[u] <= dv.max_hash;
                 if (!ok[u]) h[u] = 0;  // (still a valid word / bucket to read)
             }
@@ -133,7 +137,7 @@ __global__ void __launch_bounds__(256) k_batch_lookup(const u64* __restrict__ sa
 #pragma unroll
                 for (int u = 0; u < BATCH_U; ++u) {
                     a[u] = b[u] = c[u] = d[u] = YhDirView::v4u{0u, 0u, 0u, 0u};
-#if defined(YH_BATCH_NT) && YH_BATCH_NT
+#if defined(YH_BATCH_NT) && (YH_BATCH_NT & 1)
                     if (ok[u]) dv.cbkt_request_nt(h[u], a[u], b[u], c[u], d[u]);
 #else
                     if (ok[u]) dv.cbkt_request(h[u], a[u], b[u], c[u], d[u]);
