@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define YH_ABI_VERSION 6
+#define YH_ABI_VERSION 7
 
 enum {
     YH_OK               = 0,
@@ -142,6 +142,22 @@ int yh_db_create(const uint64_t* values, const uint64_t* offsets, uint64_t n_ref
  * not retained after return unless YH_DB_KEEP_CSR is set, in which case they are COPIED). */
 int yh_db_create_device(const uint64_t* d_values, const uint64_t* d_offsets, uint64_t n_refs,
                         int device_id, uint32_t flags, yh_db** out);
+/* The same from a PACKED database (ABI 7): `packed` = what yh_csr_pack made of a host CSR -- every sketch in blocks of 256
+ * hashes, a block = its first hash + the gaps at the width of its widest gap; ~5.7 bytes per hash for sketches of ~5 000 at
+ * scaled = 1000 -- so that 0.7 of the bytes cross the bus; the blocks are expanded in HBM, chunk by chunk under the upload, in
+ * front of the same ordering check every database goes through.  `packed` must be 8-byte aligned and is not retained.
+ *   yh_csr_pack_bound   bytes that always suffice for n_hashes hashes in n_refs sketches
+ *   yh_csr_pack         values / offsets as yh_db_create takes them -> packed (two-call sizing: packed = NULL, cap_bytes = 0);
+ *                       YH_ERR_UNSORTED for a sketch that is not strictly ascending; threads <= 0: up to 16 host threads
+ *   yh_csr_unpack       the inverse, on the host (two-call sizing: all outputs NULL / 0 -> *n_hashes, *n_refs)
+ * (Where it is used: a database kept packed in host memory or on disk; `yacht train` parses .sig files into it.  No reference
+ * counterpart: main.cpp:62-124 reads JSON into vectors.)                                                                */
+uint64_t yh_csr_pack_bound(uint64_t n_hashes, uint64_t n_refs);
+int yh_csr_pack(const uint64_t* values, const uint64_t* offsets, uint64_t n_refs, void* packed, uint64_t cap_bytes,
+                uint64_t* packed_bytes, int threads);
+int yh_csr_unpack(const void* packed, uint64_t packed_bytes, uint64_t* values_out, uint64_t cap_hashes, uint64_t* offsets_out,
+                  uint64_t cap_refs, uint64_t* n_hashes, uint64_t* n_refs);
+int yh_db_create_packed(const void* packed, uint64_t packed_bytes, int device_id, uint32_t flags, yh_db** out);
 int yh_db_destroy(yh_db* db);
 int yh_db_get_info(yh_db* db, yh_db_info* info);
 /* Run all of the handle's work on this hipStream_t (NULL = the library's own stream).

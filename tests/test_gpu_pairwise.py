@@ -264,3 +264,42 @@ def test_sixteen_bit_row_counts_at_their_limit(hip_lib, size):
             assert np.array_equal(gi, wi) and np.array_equal(gj, wj) and np.array_equal(gc, wc), (size, c)
             assert db.index_stats() == wstats
     assert int(wc.max()) == big.size
+
+
+def test_database_created_from_its_packed_form(hip_lib):
+    """yh_db_create_packed (ABI 7): the chunks of a packed CSR expanded in HBM under the upload -- the train handle and the full
+    handle equal to those made from the plain arrays (pairs, statistics, run counts), a small database through the host-side
+    unpacking, forged blobs refused."""
+    from yacht_amd import _lib, synth
+    from yacht_amd.engine import RefDB, YH_DB_PAIRWISE_ONLY, csr_pack
+
+    values, offsets = synth.config4(seed=77, n_clusters=520, size=5000)  # 1.3e7 hashes: above the chunked upload's bar
+    assert values.size >= 12 << 20
+    blob = csr_pack(values, offsets)
+    c = 0.95 ** 31
+    with RefDB(values, offsets, flags=YH_DB_PAIRWISE_ONLY) as a, RefDB.from_packed(blob, flags=YH_DB_PAIRWISE_ONLY) as b:
+        pa, pb = a.pairwise(c), b.pairwise(c)
+        assert all(np.array_equal(x, y) for x, y in zip(pa, pb)) and pa[0].size > 1000
+        assert a.index_stats() == b.index_stats()
+        assert b.info()["n_hashes"] == values.size
+    rng = np.random.default_rng(3)
+    n = offsets.size - 1
+    parts = [values[int(offsets[j]):int(offsets[j + 1])][::3] for j in rng.choice(n, size=20, replace=False)]
+    sample = np.unique(np.concatenate(parts + [synth.random_sketch(rng, 20000, synth.max_hash_for_scaled(1000))]))
+    with RefDB(values, offsets) as a, RefDB.from_packed(blob) as b:
+        ra, rb = a.run_counts(sample), b.run_counts(sample)
+        assert all(np.array_equal(x, y) for x, y in zip(ra, rb)) and int(ra[0].max()) > 0
+    # forged: a block that points outside the payload; a block whose first hash lies below its predecessor's hashes
+    first_block = 8 + (n + 1)
+    bad = blob.copy()
+    bad[first_block + 3 * 5 + 1] = np.uint64(2 ** 41)
+    with pytest.raises(_lib.YachtHipError, match="packed CSR"):
+        RefDB.from_packed(bad, flags=YH_DB_PAIRWISE_ONLY)
+    bad = blob.copy()
+    bad[first_block + 3 * 7] = np.uint64(1)  # (block 7 is not the first block of its sketch: sketches have ~20)
+    with pytest.raises(_lib.YachtHipError, match="ascending"):
+        RefDB.from_packed(bad, flags=YH_DB_PAIRWISE_ONLY)
+    # a small database: unpacked on the host, created as ever
+    sv, so = synth.config4(seed=5, n_clusters=30, size=200)
+    with RefDB(sv, so, flags=YH_DB_PAIRWISE_ONLY) as a, RefDB.from_packed(csr_pack(sv, so), flags=YH_DB_PAIRWISE_ONLY) as b:
+        assert all(np.array_equal(x, y) for x, y in zip(a.pairwise(0.1), b.pairwise(0.1)))

@@ -64,3 +64,51 @@ def test_refusals():
     with pytest.raises(_lib.YachtHipError) as e:
         pack_sample(np.arange(100, dtype=np.uint64), out=small)
     assert e.value.code == _lib.YH_ERR_CAPACITY
+
+
+def test_csr_pack_roundtrip_and_refusals():
+    """yh_csr_pack / yh_csr_unpack (the input of yh_db_create_packed): sketches of every length around the block size, empty ones,
+    gaps of every width up to 64 bits; what is refused (unsorted sketches, truncated or forged blobs)."""
+    from yacht_amd.engine import csr_pack, csr_unpack
+
+    rng = np.random.default_rng(12)
+    mh = synth.max_hash_for_scaled(1000)
+    refs = [synth.random_sketch(rng, k, mh) for k in (0, 1, 2, 255, 256, 257, 511, 512, 513, 5000, 0, 3)]
+    refs.append(np.array([0, 1, 2**63, 2**64 - 1], dtype=np.uint64))          # a 63-bit gap and the largest hash
+    refs.append(np.arange(1000, dtype=np.uint64) * np.uint64(3))               # constant narrow gaps
+    refs.append(np.arange(300, dtype=np.uint64))                               # gaps of width 0
+    values, offsets = synth.pack(refs)
+    blob = csr_pack(values, offsets)
+    assert blob.dtype == np.uint64
+    v2, o2 = csr_unpack(blob)
+    assert np.array_equal(v2, values) and np.array_equal(o2, offsets.astype(np.uint64))
+    for t in (1, 3):
+        assert np.array_equal(csr_pack(values, offsets, threads=t), blob)     # the same bytes whatever the threads
+    # a database of uniform sketches of ~5 000 hashes: ~5.7 bytes per hash
+    big = [synth.random_sketch(rng, 5000, mh) for _ in range(40)]
+    bv, bo = synth.pack(big)
+    bb = csr_pack(bv, bo)
+    assert 5.3 < bb.nbytes / bv.size < 6.0, bb.nbytes / bv.size
+    assert np.array_equal(csr_unpack(bb)[0], bv)
+    # an empty database and one of empty sketches
+    for vals, offs in ((np.zeros(0, np.uint64), np.zeros(1, np.uint64)), (np.zeros(0, np.uint64), np.zeros(4, np.uint64))):
+        e = csr_pack(vals, offs)
+        ev, eo = csr_unpack(e)
+        assert ev.size == 0 and np.array_equal(eo, offs)
+    # refusals
+    bad = values.copy()
+    bad[int(offsets[9]) + 7] = bad[int(offsets[9]) + 6]                        # a repeated hash inside sketch 9
+    with pytest.raises(_lib.YachtHipError):
+        csr_pack(bad, offsets)
+    with pytest.raises(_lib.YachtHipError):
+        csr_unpack(blob[:-1])                                                  # truncated
+    forged = blob.copy()
+    forged[1] += np.uint64(1)                                                  # n_refs off by one
+    with pytest.raises(_lib.YachtHipError):
+        csr_unpack(forged)
+    forged = blob.copy()
+    n_refs = len(refs)
+    first_block_entry = 8 + (n_refs + 1)                                       # header (8 words) + offsets -> block 0: base, word_off, width
+    forged[first_block_entry + 3 + 1] = np.uint64(2**40)                       # block 1's word_off far outside the payload
+    with pytest.raises(_lib.YachtHipError):
+        csr_unpack(forged)

@@ -95,6 +95,10 @@ SIGNATURES = {
     "yh_alloc_stats": (C.c_int, [C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "yh_db_create": (C.c_int, [_vp, _vp, C.c_uint64, C.c_int, C.c_uint32, C.POINTER(_vp)]),
     "yh_db_create_device": (C.c_int, [_vp, _vp, C.c_uint64, C.c_int, C.c_uint32, C.POINTER(_vp)]),
+    "yh_csr_pack_bound": (C.c_uint64, [C.c_uint64, C.c_uint64]),
+    "yh_csr_pack": (C.c_int, [_vp, _vp, C.c_uint64, _vp, C.c_uint64, C.POINTER(C.c_uint64), C.c_int]),
+    "yh_csr_unpack": (C.c_int, [_vp, C.c_uint64, _vp, C.c_uint64, _vp, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "yh_db_create_packed": (C.c_int, [_vp, C.c_uint64, C.c_int, C.c_uint32, C.POINTER(_vp)]),
     "yh_db_destroy": (C.c_int, [_vp]),
     "yh_db_get_info": (C.c_int, [_vp, C.POINTER(DbInfo)]),
     "yh_db_set_stream": (C.c_int, [_vp, _vp]),
@@ -215,7 +219,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError here = the .so does not match the header
         fn.restype = res
         fn.argtypes = args
-    if lib.yh_abi_version() != 6:
+    if lib.yh_abi_version() != 7:
         raise YachtHipError(YH_ERR_INVALID_ARG, f"ABI version mismatch in {path}")
     _lib = lib
     return lib

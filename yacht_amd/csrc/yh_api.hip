@@ -1,6 +1,7 @@
 // yh_api.hip — the extern "C" boundary of libyacht_hip.so (declared in include/yacht_hip.h).
 #include "yh_common.h"
 #include "yh_sort.h"
+#include "yh_pack.h"
 
 #include <mutex>
 #include <unordered_map>
@@ -444,7 +445,7 @@ int yh_device_count(int* n_devices) {
 }
 
 static int db_create_common(const u64* values, const u64* offsets, bool on_device, u64 n_refs, int device_id,
-                            uint32_t flags, yh_db** out) {
+                            uint32_t flags, yh_db** out, const YhPackedCsr* pk = nullptr) {
     if (!out) { yh_set_error("out is null"); return YH_ERR_INVALID_ARG; }
     *out = nullptr;
     if (!offsets) { yh_set_error("offsets is null"); return YH_ERR_INVALID_ARG; }
@@ -500,7 +501,7 @@ static int db_create_common(const u64* values, const u64* offsets, bool on_devic
             if (offsets[0] != 0) { yh_set_error("offsets[0] must be 0"); rc = YH_ERR_INVALID_ARG; break; }
             H = offsets[n_refs];
         }
-        if (H && !values) { yh_set_error("values is null"); rc = YH_ERR_INVALID_ARG; break; }
+        if (H && !values && !pk) { yh_set_error("values is null"); rc = YH_ERR_INVALID_ARG; break; }
         db->n_hashes = H;
 
         if (on_device) {
@@ -519,7 +520,7 @@ static int db_create_common(const u64* values, const u64* offsets, bool on_devic
             // a large host database goes up in chunks that are sorted and merged while the next one crosses the bus
             // (yh_build_upload_sorted); a small one in one piece
             static const u64 chunk_min = [] { const char* e = yh_tune_env("YH_UPLOAD_CHUNK_MIN"); return e ? (u64)atoll(e) : (u64)12 << 20; }();
-            chunked = H >= chunk_min && n_refs >= 4;
+            chunked = pk ? true : (H >= chunk_min && n_refs >= 4);  // (a packed database always: yh_db_create_packed unpacks small ones on the host)
             const double t_up = alloc_now_ms();
             if (hipMemcpy(d_offsets_in, offsets, (n_refs + 1) * sizeof(u64), hipMemcpyHostToDevice) != hipSuccess ||
                 (!chunked && H && hipMemcpy(d_values_in, values, H * sizeof(u64), hipMemcpyHostToDevice) != hipSuccess)) {
@@ -531,7 +532,8 @@ static int db_create_common(const u64* values, const u64* offsets, bool on_devic
         u64* d_sk_pre = nullptr;
         u32* d_sv_pre = nullptr;
         if (chunked) {
-            rc = yh_build_upload_sorted(db, values, offsets, d_values_in, d_offsets_in, &d_sk_pre, &d_sv_pre);
+            rc = pk ? yh_build_upload_sorted_packed(db, pk, d_values_in, d_offsets_in, &d_sk_pre, &d_sv_pre)
+                    : yh_build_upload_sorted(db, values, offsets, d_values_in, d_offsets_in, &d_sk_pre, &d_sv_pre);
             if (rc != YH_OK) break;
             (void)hipEventRecord(ev0, db->stream);
         } else {
@@ -599,6 +601,23 @@ int yh_db_create(const uint64_t* values, const uint64_t* offsets, uint64_t n_ref
 int yh_db_create_device(const uint64_t* d_values, const uint64_t* d_offsets, uint64_t n_refs, int device_id,
                         uint32_t flags, yh_db** out) {
     return db_create_common((const u64*)d_values, (const u64*)d_offsets, true, n_refs, device_id, flags, out);
+}
+
+// A database that arrives packed (yh_csr_pack): ~5.7 instead of 8 bytes per hash cross the bus, the chunks are expanded in HBM in
+// front of their ordering checks (yh_build.hip).  Small ones (what yh_db_create uploads in one piece) are unpacked on the host.
+int yh_db_create_packed(const void* packed, uint64_t packed_bytes, int device_id, uint32_t flags, yh_db** out) {
+    if (!out) { yh_set_error("out is null"); return YH_ERR_INVALID_ARG; }
+    *out = nullptr;
+    YhPackedCsr v;
+    YH_TRY(yh_csr_view(packed, packed_bytes, &v));
+    static const u64 chunk_min = [] { const char* e = yh_tune_env("YH_UPLOAD_CHUNK_MIN"); return e ? (u64)atoll(e) : (u64)12 << 20; }();
+    if (!(v.n_hashes >= chunk_min && v.n_refs >= 4)) {
+        std::vector<uint64_t> values(std::max<u64>(v.n_hashes, 1)), offsets(v.n_refs + 1);
+        uint64_t h = 0, n = 0;
+        YH_TRY(yh_csr_unpack(packed, packed_bytes, values.data(), v.n_hashes, offsets.data(), v.n_refs, &h, &n));
+        return db_create_common((const u64*)values.data(), (const u64*)offsets.data(), false, v.n_refs, device_id, flags, out);
+    }
+    return db_create_common(nullptr, v.offsets, false, v.n_refs, device_id, flags, out, &v);
 }
 
 int yh_db_destroy(yh_db* db) {

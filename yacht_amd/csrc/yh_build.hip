@@ -9,6 +9,7 @@
 //       Replaces the per-run re-reading of N .sig files (hypothesis_recovery_src.py:93,154,168).
 #include "yh_common.h"
 #include "yh_sort.h"
+#include "yh_pack.h"
 
 #include <rocprim/device/device_merge.hpp>
 #include <rocprim/device/device_radix_sort.hpp>
@@ -490,6 +491,10 @@ static int validate_end(yh_db* db, bool ends = false) {
         if (first != 0) { yh_set_error("offsets[0] must be 0"); return YH_ERR_INVALID_ARG; }
         if (!(hflag[0] & 1u)) db->n_hashes = last;
     }
+    if (hflag[0] & 4u) {  // (first: what such a block should have written is whatever the buffer held)
+        yh_set_error("packed CSR: a block points outside the payload or does not fit the offsets");
+        return YH_ERR_INVALID_ARG;
+    }
     if (hflag[0] & 1u) {
         yh_set_error("a reference sketch is not strictly ascending (or offsets are not monotone)");
         return YH_ERR_UNSORTED;
@@ -498,6 +503,7 @@ static int validate_end(yh_db* db, bool ends = false) {
         yh_set_error("a reference sketch has more than 2^32-1 hashes");
         return YH_ERR_INVALID_ARG;
     }
+
     u64 maxv;
     memcpy(&maxv, &hflag[2], 8);
     db->max_hash = maxv;
@@ -673,8 +679,19 @@ static int fzp_finish(yh_db* db, yh_pieces* pc, const u64* d_values, bool* took,
     return YH_OK;
 }
 
+// (pk: the database arrives PACKED -- yh_csr_pack's blob, ~5.7 instead of 8 bytes per hash on the bus -- and every chunk is
+// expanded into d_values by k_unpack_csr in front of its ordering check; h_values is not read then)
+static int upload_sorted_impl(yh_db* db, const u64* h_values, const u64* h_offsets, const YhPackedCsr* pk, u64* d_values, const u64* d_offsets,
+                              u64** d_sk_out, u32** d_sv_out);
 int yh_build_upload_sorted(yh_db* db, const u64* h_values, const u64* h_offsets, u64* d_values, const u64* d_offsets,
                            u64** d_sk_out, u32** d_sv_out) {
+    return upload_sorted_impl(db, h_values, h_offsets, nullptr, d_values, d_offsets, d_sk_out, d_sv_out);
+}
+int yh_build_upload_sorted_packed(yh_db* db, const YhPackedCsr* pk, u64* d_values, const u64* d_offsets, u64** d_sk_out, u32** d_sv_out) {
+    return upload_sorted_impl(db, nullptr, pk->offsets, pk, d_values, d_offsets, d_sk_out, d_sv_out);
+}
+static int upload_sorted_impl(yh_db* db, const u64* h_values, const u64* h_offsets, const YhPackedCsr* pk, u64* d_values, const u64* d_offsets,
+                              u64** d_sk_out, u32** d_sv_out) {
     const u64 N = db->n_refs, H = db->n_hashes;
     hipStream_t st = db->stream;
     *d_sk_out = nullptr;
@@ -699,8 +716,10 @@ int yh_build_upload_sorted(yh_db* db, const u64* h_values, const u64* h_offsets,
     rb.push_back(N);
     const size_t C = rb.size() - 1;
     u64 max_last = 0;
-    for (u64 j = 0; j < N; ++j)
-        if (h_offsets[j + 1] > h_offsets[j]) max_last = std::max(max_last, h_values[h_offsets[j + 1] - 1]);
+    if (pk) max_last = pk->max_hash;  // (the packer's; a wrong one shows below: the largest hash the check finds must not exceed it)
+    else
+        for (u64 j = 0; j < N; ++j)
+            if (h_offsets[j + 1] > h_offsets[j]) max_last = std::max(max_last, h_values[h_offsets[j + 1] - 1]);
     double t_prev = trace_now();
     TRACE("chunk plan + max");
     // (the upload stream and the chunk events are made once per device and kept: a dozen creates and destroys were
@@ -716,6 +735,9 @@ int yh_build_upload_sorted(yh_db* db, const u64* h_values, const u64* h_offsets,
     u32* V[2] = {nullptr, nullptr};
     u32* d_ids = nullptr;
     void* d_tmp = nullptr;
+    char* d_pk_tab = nullptr;   // a packed database: its block table, payload and first_block[] in HBM
+    u64* d_pk_payload = nullptr;
+    u64* d_pk_fb = nullptr;
     yh_psort* ps = nullptr;
     int rc = YH_OK;
 #define UP_HIP(call)                                                                          \
@@ -746,6 +768,12 @@ int yh_build_upload_sorted(yh_db* db, const u64* h_values, const u64* h_offsets,
     if (rc == YH_OK && pieces) rc = fzp_begin(db, d_offsets, max_last, &pc);
     else if (rc == YH_OK && fused) rc = fz_begin(db, d_offsets, max_last, &ps);
     else if (rc == YH_OK && dist_sort) rc = yh_psort_begin(db, H, max_last, &ps);
+    if (pk) {
+        UP_HIP(yh_tmalloc(db, (void**)&d_pk_tab, std::max<u64>(pk->n_blocks * yh_csr_block_bytes(), 8)));
+        UP_HIP(yh_tmalloc(db, (void**)&d_pk_payload, pk->payload_words * sizeof(u64)));
+        UP_HIP(yh_tmalloc(db, (void**)&d_pk_fb, (N + 1) * sizeof(u64)));
+        UP_HIP(hipStreamSynchronize(st));  // (stream-ordered allocations: there before the upload stream copies into them)
+    }
     TRACE("stream, events, buffers");
     if (rc == YH_OK) rc = validate_begin(db);
     const int cur = 0;  // (the buffer the sorted pairs land in)
@@ -761,9 +789,19 @@ int yh_build_upload_sorted(yh_db* db, const u64* h_values, const u64* h_offsets,
             if (hipSetDevice(device) != hipSuccess) { copy_failed.store(1); copied.store((int)C); return; }
             const double t_up = trace_now();
             struct UpClock { yh_db* db; double t0; ~UpClock() { db->ms_h2d_create += (float)(trace_now() - t0); } } up_clock{db, t_up};  // (yh_timing.ms_h2d)
+            if (pk && hipMemcpyAsync(d_pk_fb, pk->first_block.data(), (N + 1) * sizeof(u64), hipMemcpyHostToDevice, up) != hipSuccess) copy_failed.store(1);
             for (size_t c = 0; c < C; ++c) {
                 const u64 e0 = h_offsets[rb[c]], e1 = h_offsets[rb[c + 1]];
-                if (e1 > e0 && hipMemcpyAsync(d_values + e0, h_values + e0, (e1 - e0) * sizeof(u64), hipMemcpyHostToDevice, up) != hipSuccess)
+                if (pk) {  // the chunk's blocks: their table entries and their payload words (the last chunk: the spare word too)
+                    const u64 b0 = pk->first_block[rb[c]], b1 = pk->first_block[rb[c + 1]];
+                    const u64 w0 = yh_csr_block_word_off(pk, b0), w1 = c + 1 == C ? pk->payload_words : yh_csr_block_word_off(pk, b1);
+                    const u64 bb = yh_csr_block_bytes();
+                    if (b1 > b0 && hipMemcpyAsync(d_pk_tab + b0 * bb, (const char*)pk->tab + b0 * bb, (b1 - b0) * bb, hipMemcpyHostToDevice, up) != hipSuccess)
+                        copy_failed.store(1);
+                    if (w1 > w0 && w1 <= pk->payload_words &&
+                        hipMemcpyAsync(d_pk_payload + w0, pk->payload + w0, (w1 - w0) * sizeof(u64), hipMemcpyHostToDevice, up) != hipSuccess)
+                        copy_failed.store(1);
+                } else if (e1 > e0 && hipMemcpyAsync(d_values + e0, h_values + e0, (e1 - e0) * sizeof(u64), hipMemcpyHostToDevice, up) != hipSuccess)
                     copy_failed.store(1);
                 if (hipEventRecord(ev[c], up) != hipSuccess) copy_failed.store(1);
                 copied.store((int)c + 1, std::memory_order_release);
@@ -779,6 +817,9 @@ int yh_build_upload_sorted(yh_db* db, const u64* h_values, const u64* h_offsets,
         if (copy_failed.load()) { yh_set_error("CSR upload failed"); rc = YH_ERR_HIP; break; }
         UP_HIP(hipStreamWaitEvent(st, ev[c], 0));
         UP_HIP(hipEventRecord(eb[c], st));
+        if (rc == YH_OK && pk)
+            rc = yh_csr_expand_device(db, d_pk_tab, d_pk_payload, pk->payload_words, d_pk_fb, d_offsets, N, pk->first_block[r0], pk->first_block[r1],
+                                      d_values, db->d_flag);
         if (rc == YH_OK) rc = validate_refs(db, d_values, d_offsets, r0, r1);
         if (rc == YH_OK && n && pc) {
             rc = yh_pc_scan(db, pc, d_values, db->d_fz_off, r0, r1, n, false);  // (k_scan_refs above checked the order)
@@ -857,6 +898,7 @@ int yh_build_upload_sorted(yh_db* db, const u64* h_values, const u64* h_offsets,
     if (pc) { yh_pc_destroy(db, pc); pc = nullptr; if (!db->fz) fz_drop(db); }
     yh_tfree(db, d_tmp);
     yh_tfree(db, d_ids);
+    yh_tfree(db, d_pk_tab); yh_tfree(db, d_pk_payload); yh_tfree(db, d_pk_fb);
     if (rc != YH_OK) { yh_tfree(db, K[cur]); yh_tfree(db, V[cur]); return rc; }
     TRACE("frees");
     *d_sk_out = K[cur];

@@ -15,6 +15,7 @@
 //                    in reference order, straight into the caller's page-locked buffer, and the number of rows.
 //                    1 MB of D2H per step becomes ~14 KB.
 #include "yh_common.h"
+#include "yh_pack.h"
 
 #include <string.h>
 
@@ -97,6 +98,76 @@ __global__ void __launch_bounds__(PACK_BLOCK) k_unpack_sample(const PackBlock* _
         *bad = gen;
         if (host_bad) *host_bad = 1;
     }
+}
+
+// ---- a whole CSR packed the same way (yh_csr_pack / yh_db_create_packed) ---------------------------------------------------
+// Every sketch on its own: blocks of 256 hashes, a block = its first hash + the gaps at the block's widest gap's width; sketches
+// of ~5 000 hashes at scaled = 1000 take ~5.7 bytes per hash.  The blob: CsrHeader | offsets [n_refs + 1] | CsrBlock [n_blocks]
+// (the blocks of sketch 0, of sketch 1, ...: ceil(size / 256) each) | payload words (one spare word at the end).
+constexpr u32 CSR_MAGIC = 0x31434859u;  // "YHC1"
+struct CsrHeader {   // 64 bytes
+    u32 magic, block;
+    u64 n_refs, n_hashes, n_blocks, payload_words, max_hash;
+    u64 reserved[2];
+};
+struct CsrBlock {    // 24 bytes
+    u64 base;        // the block's first hash
+    u64 word_off;    // first payload word of the block
+    u32 width;       // bits per gap, 0..64
+    u32 reserved;
+};
+static_assert(sizeof(CsrHeader) == 64 && sizeof(CsrBlock) == 24, "packed CSR layout");
+
+// one workgroup per block b0 + blockIdx.x: which sketch it belongs to from first_block[] (blocks in front of every sketch),
+// where its hashes go from the offsets; what the format cannot promise -- payload words inside the blob -- is checked
+// (flag |= 4), the ordering is the ordering check's business (k_scan_refs / k_piece_bounds read what is written here).
+__global__ void __launch_bounds__(PACK_BLOCK) k_unpack_csr(const CsrBlock* __restrict__ tab, const u64* __restrict__ payload, u64 payload_words,
+                                                           const u64* __restrict__ first_block, const u64* __restrict__ offsets, u64 n_refs,
+                                                           u64 b0, u64* __restrict__ out, u32* __restrict__ flag) {
+    __shared__ u64 wave_sum[PACK_BLOCK / 64];
+    const u64 b = b0 + blockIdx.x;
+    const u32 i = threadIdx.x, lane = i & 63u, wv = i >> 6;
+    // the sketch: the largest j with first_block[j] <= b (empty sketches share their successor's entry and are passed over)
+    u64 lo = 0, hi = n_refs;  // first_block[lo] <= b < first_block[hi] (first_block[n_refs] = all blocks)
+    while (hi - lo > 1) {
+        const u64 mid = (lo + hi) >> 1;
+        if (first_block[mid] <= b) lo = mid; else hi = mid;
+    }
+    const u64 j = lo;
+    const u64 k = b - first_block[j];
+    const u64 beg = offsets[j] + k * PACK_BLOCK, end = offsets[j + 1];
+    if (beg >= end) { if (i == 0) atomicOr(flag, 4u); return; }  // (a table that does not fit the offsets)
+    const u32 cnt = (u32)min((u64)PACK_BLOCK, end - beg);
+    const CsrBlock blk = tab[b];
+    const u64 nw = blk.width <= 64u ? ((u64)(cnt - 1) * blk.width + 63) / 64 : ~0ull;
+    if (blk.width > 64u || blk.word_off > payload_words || nw + 1 > payload_words - blk.word_off) {  // (+ 1: two-word reads)
+        if (i == 0) atomicOr(flag, 4u);
+        return;
+    }
+    u64 step = 0;  // h[i] - h[i-1]; 0 for lane 0 and for lanes behind the block's end
+    if (i >= 1 && i < cnt) {
+        const u64 bit = (u64)(i - 1) * blk.width;
+        const u64* p = payload + blk.word_off + (bit >> 6);
+        const u32 sh = (u32)(bit & 63u);
+        u64 v = 0;
+        if (blk.width) {
+            v = p[0] >> sh;
+            if (sh + blk.width > 64) v |= p[1] << (64 - sh);
+            if (blk.width < 64) v &= (1ull << blk.width) - 1ull;
+        }
+        step = v + 1ull;
+    }
+    u64 acc = step;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const u64 t = ((u64)(u32)__shfl_up((int)(u32)(acc >> 32), off) << 32) | (u32)__shfl_up((int)(u32)acc, off);
+        if (lane >= (u32)off) acc += t;
+    }
+    if (lane == 63) wave_sum[wv] = acc;
+    __syncthreads();
+    u64 before = 0;
+    for (u32 w = 0; w < wv; ++w) before += wave_sum[w];
+    if (i < cnt) out[beg + i] = blk.base + before + acc;
 }
 
 // Rows of the references with overlap > 0, in reference order.  One workgroup per 2048 references (64 words of subset
@@ -191,6 +262,63 @@ int yh_pack_expand_device(yh_db* db, const void* d_packed, u64 n, u64* d_out, u3
     const PackBlock* tab = reinterpret_cast<const PackBlock*>((const char*)d_packed + sizeof(PackHeader));
     const u64* payload = reinterpret_cast<const u64*>(tab + nb);
     k_unpack_sample<<<(u32)nb, PACK_BLOCK, 0, db->stream>>>(tab, payload, n, d_out, d_bad, gen, h_bad_dev);
+    YH_HIP(hipGetLastError());
+    return YH_OK;
+}
+
+// ---- the packed CSR (yh_csr_pack): a host view of a blob, and its blocks expanded on the device -------------------------
+// Sizes against the header, offsets ascending from 0 to n_hashes, as many blocks as the sketches need; v->first_block[j] =
+// blocks in front of sketch j.  (Block widths and payload offsets are the unpack kernel's to check: it reads them anyway.)
+int yh_csr_view(const void* packed, u64 bytes, YhPackedCsr* v) {
+    if (!packed || bytes < sizeof(CsrHeader)) { yh_set_error("packed CSR: shorter than its header"); return YH_ERR_INVALID_ARG; }
+    if (reinterpret_cast<uintptr_t>(packed) & 7u) { yh_set_error("packed CSR: the buffer must be 8-byte aligned"); return YH_ERR_INVALID_ARG; }
+    CsrHeader hd;
+    memcpy(&hd, packed, sizeof(hd));
+    if (hd.magic != CSR_MAGIC || hd.block != PACK_BLOCK) { yh_set_error("packed CSR: bad magic / block size"); return YH_ERR_INVALID_ARG; }
+    if (hd.n_refs > 0x7ffffff0ull || hd.n_hashes > (1ull << 48) || hd.n_blocks > (1ull << 41) || hd.payload_words > (1ull << 48) || hd.payload_words < 1) {
+        yh_set_error("packed CSR: implausible header");
+        return YH_ERR_INVALID_ARG;
+    }
+    const u64 need = sizeof(CsrHeader) + (hd.n_refs + 1) * 8 + hd.n_blocks * sizeof(CsrBlock) + hd.payload_words * 8;
+    if (bytes != need) { yh_set_error("packed CSR: %llu bytes, its header says %llu", (u64)bytes, need); return YH_ERR_INVALID_ARG; }
+    v->n_refs = hd.n_refs;
+    v->n_hashes = hd.n_hashes;
+    v->n_blocks = hd.n_blocks;
+    v->payload_words = hd.payload_words;
+    v->max_hash = hd.max_hash;
+    v->offsets = reinterpret_cast<const u64*>((const char*)packed + sizeof(CsrHeader));
+    v->tab = v->offsets + hd.n_refs + 1;
+    v->payload = reinterpret_cast<const u64*>((const char*)v->tab + hd.n_blocks * sizeof(CsrBlock));
+    v->first_block.assign(hd.n_refs + 1, 0);
+    if (v->offsets[0] != 0) { yh_set_error("offsets[0] must be 0"); return YH_ERR_INVALID_ARG; }
+    u64 nb = 0;
+    for (u64 j = 0; j < hd.n_refs; ++j) {
+        const u64 a = v->offsets[j], e = v->offsets[j + 1];
+        if (e < a || e > hd.n_hashes) { yh_set_error("packed CSR: offsets are not monotone"); return YH_ERR_UNSORTED; }
+        if (e - a > 0xffffffffull) { yh_set_error("a reference sketch has more than 2^32-1 hashes"); return YH_ERR_INVALID_ARG; }
+        v->first_block[j] = nb;
+        nb += (e - a + PACK_BLOCK - 1) / PACK_BLOCK;
+    }
+    v->first_block[hd.n_refs] = nb;
+    if (v->offsets[hd.n_refs] != hd.n_hashes || nb != hd.n_blocks) { yh_set_error("packed CSR: offsets and block count do not match the header"); return YH_ERR_INVALID_ARG; }
+    return YH_OK;
+}
+u64 yh_csr_block_bytes() { return sizeof(CsrBlock); }
+u64 yh_csr_block_word_off(const YhPackedCsr* v, u64 b) {  // first payload word of block b (b == n_blocks: the spare word's index)
+    if (b >= v->n_blocks) return v->payload_words - 1;
+    CsrBlock blk;
+    memcpy(&blk, (const char*)v->tab + b * sizeof(CsrBlock), sizeof(blk));
+    return blk.word_off;
+}
+// the blocks [b0, b1) of a packed CSR whose table, payload, first_block[] and offsets are in HBM -> d_values; *d_flag |= 4 when
+// a block points outside the payload or does not fit the offsets
+int yh_csr_expand_device(yh_db* db, const void* d_tab, const u64* d_payload, u64 payload_words, const u64* d_first_block, const u64* d_offsets,
+                         u64 n_refs, u64 b0, u64 b1, u64* d_values, u32* d_flag) {
+    for (u64 b = b0; b < b1; b += (u64)1 << 30) {  // (2^31 - 1 workgroups per launch)
+        const u64 n = std::min<u64>(b1 - b, (u64)1 << 30);
+        k_unpack_csr<<<(u32)n, PACK_BLOCK, 0, db->stream>>>(reinterpret_cast<const CsrBlock*>(d_tab), d_payload, payload_words, d_first_block,
+                                                           d_offsets, n_refs, b, d_values, d_flag);
+    }
     YH_HIP(hipGetLastError());
     return YH_OK;
 }
@@ -334,6 +462,160 @@ int yh_sample_unpack(const void* packed, uint64_t packed_bytes, uint64_t* sample
             sample_out[first + i] = cur;
         }
         prev = cur;
+    }
+    return YH_OK;
+}
+
+// ---- a whole CSR (yh_db_create_packed's input) ------------------------------------------------------------------------
+uint64_t yh_csr_pack_bound(uint64_t n_hashes, uint64_t n_refs) {
+    const u64 nb = n_hashes / PACK_BLOCK + n_refs + 1;  // (every sketch may end in a partial block)
+    return sizeof(CsrHeader) + (n_refs + 1) * 8 + nb * sizeof(CsrBlock) + (n_hashes + nb + 2) * 8;
+}
+
+int yh_csr_pack(const uint64_t* values, const uint64_t* offsets, uint64_t n_refs, void* packed, uint64_t cap_bytes, uint64_t* packed_bytes,
+                int threads) {
+    if (!packed_bytes || !offsets) { yh_set_error("yh_csr_pack: null argument"); return YH_ERR_INVALID_ARG; }
+    if (n_refs > 0x7ffffff0ull) { yh_set_error("too many references"); return YH_ERR_INVALID_ARG; }
+    if (offsets[0] != 0) { yh_set_error("offsets[0] must be 0"); return YH_ERR_INVALID_ARG; }
+    const u64 N = n_refs, H = offsets[N];
+    if (H && !values) { yh_set_error("values is null"); return YH_ERR_INVALID_ARG; }
+    const u64* h = (const u64*)values;
+    std::vector<u64> fb(N + 1);
+    u64 nb = 0;
+    for (u64 j = 0; j < N; ++j) {
+        if (offsets[j + 1] < offsets[j]) { yh_set_error("offsets are not monotone"); return YH_ERR_UNSORTED; }
+        fb[j] = nb;
+        nb += (offsets[j + 1] - offsets[j] + PACK_BLOCK - 1) / PACK_BLOCK;
+    }
+    fb[N] = nb;
+    const unsigned hw = std::thread::hardware_concurrency();
+    const unsigned T = (unsigned)std::max<u64>(1, std::min<u64>(threads > 0 ? (u64)threads : std::min<unsigned>(hw ? hw : 1, 16), N / 64 + 1));
+    std::vector<CsrBlock> tab(nb);
+    std::atomic<int> unsorted{0};
+    std::vector<u64> tmax(T, 0);
+    auto run_ranges = [&](auto&& fn) {  // sketches [j0, j1) per thread, cut by hash count
+        if (T <= 1) { fn(0u, (u64)0, N); return; }
+        std::vector<std::thread> th;
+        u64 j0 = 0;
+        for (unsigned t = 0; t < T; ++t) {
+            u64 j1 = j0;
+            const u64 target = H / T * (t + 1);
+            while (j1 < N && (t + 1 == T || offsets[j1 + 1] <= target)) ++j1;
+            th.emplace_back(fn, t, j0, j1);
+            j0 = j1;
+        }
+        for (auto& x : th) x.join();
+    };
+    // pass 1: ordering, the width of every block, the largest hash
+    run_ranges([&](unsigned t, u64 j0, u64 j1) {
+        u64 mx = 0;
+        bool bad = false;
+        for (u64 j = j0; j < j1; ++j) {
+            const u64 a = offsets[j], e = offsets[j + 1];
+            if (e > a) mx = std::max(mx, h[e - 1]);
+            for (u64 first = a, b = fb[j]; first < e; first += PACK_BLOCK, ++b) {
+                const u32 cnt = (u32)std::min<u64>(PACK_BLOCK, e - first);
+                bad |= first > a && !(h[first - 1] < h[first]);
+                u64 widest = 0;
+                for (u32 i = 1; i < cnt; ++i) {
+                    bad |= !(h[first + i - 1] < h[first + i]);
+                    widest |= h[first + i] - h[first + i - 1] - 1ull;
+                }
+                tab[b] = CsrBlock{h[first], 0ull, bits_of(widest), 0u};
+            }
+        }
+        tmax[t] = mx;
+        if (bad) unsorted.store(1, std::memory_order_relaxed);
+    });
+    if (unsorted.load()) { yh_set_error("a reference sketch is not strictly ascending"); return YH_ERR_UNSORTED; }
+    u64 words = 0;
+    for (u64 j = 0; j < N; ++j)
+        for (u64 first = offsets[j], b = fb[j]; first < offsets[j + 1]; first += PACK_BLOCK, ++b) {
+            tab[b].word_off = words;
+            words += block_words((u32)std::min<u64>(PACK_BLOCK, offsets[j + 1] - first), tab[b].width);
+        }
+    words += 1;  // the spare word
+    const u64 need = sizeof(CsrHeader) + (N + 1) * 8 + nb * sizeof(CsrBlock) + words * 8;
+    *packed_bytes = need;
+    if (!packed || cap_bytes < need) {
+        if (!packed && cap_bytes == 0) return YH_OK;  // sizing call
+        yh_set_error("yh_csr_pack: buffer of %llu bytes, %llu needed", (u64)cap_bytes, need);
+        return YH_ERR_CAPACITY;
+    }
+    if (reinterpret_cast<uintptr_t>(packed) & 7u) { yh_set_error("yh_csr_pack: the buffer must be 8-byte aligned"); return YH_ERR_INVALID_ARG; }
+    u64 mx = 0;
+    for (const u64 v : tmax) mx = std::max(mx, v);
+    CsrHeader hd{CSR_MAGIC, PACK_BLOCK, N, H, nb, words, mx, {0, 0}};
+    char* p = (char*)packed;
+    memcpy(p, &hd, sizeof(hd));
+    memcpy(p + sizeof(hd), offsets, (N + 1) * 8);
+    if (nb) memcpy(p + sizeof(hd) + (N + 1) * 8, tab.data(), nb * sizeof(CsrBlock));
+    u64* payload = reinterpret_cast<u64*>(p + sizeof(hd) + (N + 1) * 8 + nb * sizeof(CsrBlock));
+    // pass 2: the gaps (blocks own disjoint words)
+    run_ranges([&](unsigned, u64 j0, u64 j1) {
+        for (u64 j = j0; j < j1; ++j)
+            for (u64 first = offsets[j], b = fb[j]; first < offsets[j + 1]; first += PACK_BLOCK, ++b) {
+                const u32 cnt = (u32)std::min<u64>(PACK_BLOCK, offsets[j + 1] - first);
+                const u32 w = tab[b].width;
+                u64* out = payload + tab[b].word_off;
+                const u64 nw = block_words(cnt, w);
+                for (u64 k = 0; k < nw; ++k) out[k] = 0;
+                if (!w) continue;
+                u64 bit = 0;
+                for (u32 i = 1; i < cnt; ++i, bit += w) {
+                    const u64 v = h[first + i] - h[first + i - 1] - 1ull;
+                    const u32 sh = (u32)(bit & 63u);
+                    out[bit >> 6] |= v << sh;
+                    if (sh + w > 64) out[(bit >> 6) + 1] |= v >> (64 - sh);
+                }
+            }
+    });
+    payload[words - 1] = 0;
+    return YH_OK;
+}
+
+int yh_csr_unpack(const void* packed, uint64_t packed_bytes, uint64_t* values_out, uint64_t cap_hashes, uint64_t* offsets_out,
+                  uint64_t cap_refs, uint64_t* n_hashes, uint64_t* n_refs) {
+    if (!n_hashes || !n_refs) { yh_set_error("yh_csr_unpack: null argument"); return YH_ERR_INVALID_ARG; }
+    YhPackedCsr v;
+    YH_TRY(yh_csr_view(packed, packed_bytes, &v));
+    *n_hashes = v.n_hashes;
+    *n_refs = v.n_refs;
+    if (!values_out && !offsets_out && cap_hashes == 0 && cap_refs == 0) return YH_OK;  // sizing call
+    if (cap_hashes < v.n_hashes || cap_refs < v.n_refs || !offsets_out || (v.n_hashes && !values_out)) {
+        yh_set_error("yh_csr_unpack: room for %llu hashes of %llu references, %llu of %llu needed", (u64)cap_hashes, (u64)cap_refs, v.n_hashes, v.n_refs);
+        return YH_ERR_CAPACITY;
+    }
+    memcpy(offsets_out, v.offsets, (v.n_refs + 1) * 8);
+    for (u64 j = 0; j < v.n_refs; ++j) {
+        u64 prev = 0;
+        for (u64 first = v.offsets[j], b = v.first_block[j]; first < v.offsets[j + 1]; first += PACK_BLOCK, ++b) {
+            CsrBlock blk;
+            memcpy(&blk, (const char*)v.tab + b * sizeof(CsrBlock), sizeof(blk));
+            const u32 cnt = (u32)std::min<u64>(PACK_BLOCK, v.offsets[j + 1] - first);
+            if (blk.width > 64 || blk.word_off > v.payload_words || block_words(cnt, blk.width) + 1 > v.payload_words - blk.word_off) {
+                yh_set_error("packed CSR: block %llu points outside the payload", b);
+                return YH_ERR_INVALID_ARG;
+            }
+            u64 cur = blk.base;
+            if (first > v.offsets[j] && !(prev < cur)) { yh_set_error("packed CSR: blocks of a sketch are not ascending"); return YH_ERR_UNSORTED; }
+            values_out[first] = cur;
+            u64 bit = 0;
+            for (u32 i = 1; i < cnt; ++i, bit += blk.width) {
+                u64 g = 0;
+                if (blk.width) {
+                    const u32 sh = (u32)(bit & 63u);
+                    g = v.payload[blk.word_off + (bit >> 6)] >> sh;
+                    if (sh + blk.width > 64) g |= v.payload[blk.word_off + (bit >> 6) + 1] << (64 - sh);
+                    if (blk.width < 64) g &= (1ull << blk.width) - 1ull;
+                }
+                const u64 next = cur + g + 1ull;
+                if (!(cur < next)) { yh_set_error("packed CSR: a gap wraps around 2^64"); return YH_ERR_UNSORTED; }
+                cur = next;
+                values_out[first + i] = cur;
+            }
+            prev = cur;
+        }
     }
     return YH_OK;
 }

@@ -116,6 +116,21 @@ class RefDB:
         self.sizes = sizes
         return self
 
+    @classmethod
+    def from_packed(cls, packed: np.ndarray, sizes: Optional[np.ndarray] = None, device: int = 0, flags: int = YH_DB_DEFAULT) -> "RefDB":
+        """Build from a packed CSR (csr_pack's uint64 array): 0.7 of the bytes cross the bus, the sketches are expanded in HBM."""
+        assert packed.dtype == np.uint64 and packed.flags["C_CONTIGUOUS"], "csr_pack returns what this takes"
+        self = cls.__new__(cls)
+        self._h = C.c_void_p(0)
+        lib = _lib.load()
+        h = C.c_void_p(0)
+        _lib.check(lib.yh_db_create_packed(_ptr(packed), packed.nbytes, device, flags, C.byref(h)))
+        self._h = h
+        self._lib = lib
+        self.n_refs = int(self.info()["n_refs"])
+        self.sizes = sizes
+        return self
+
     # ---- lifetime ---------------------------------------------------------------------------
     def close(self, release_pool: bool = False) -> None:
         """Destroy the handle.  Its arrays go to the library's buffer cache (the next handle of this process takes them without
@@ -374,6 +389,33 @@ class RefDB:
                                          C.byref(n)))
         k = int(n.value)
         return pi[:k], pj[:k], pc[:k]
+
+
+def csr_pack(values: np.ndarray, offsets: np.ndarray, threads: int = 0) -> np.ndarray:
+    """A CSR of strictly ascending uint64 sketches -> the packed form yh_db_create_packed / RefDB.from_packed take (a uint64
+    array: 8-byte aligned); ~5.7 bytes per hash for sketches of ~5 000 hashes at scaled = 1000."""
+    lib = _lib.load()
+    values = np.ascontiguousarray(values, dtype=np.uint64)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    n = offsets.size - 1
+    need = C.c_uint64(0)
+    _lib.check(lib.yh_csr_pack(_ptr(values), _ptr(offsets), n, None, 0, C.byref(need), threads))
+    out = np.zeros((int(need.value) + 7) // 8, dtype=np.uint64)
+    _lib.check(lib.yh_csr_pack(_ptr(values), _ptr(offsets), n, _ptr(out), out.nbytes, C.byref(need), threads))
+    assert int(need.value) == out.nbytes
+    return out
+
+
+def csr_unpack(packed: np.ndarray):
+    """(values, offsets) of a packed CSR, on the host."""
+    lib = _lib.load()
+    packed = np.ascontiguousarray(packed, dtype=np.uint64)
+    h, n = C.c_uint64(0), C.c_uint64(0)
+    _lib.check(lib.yh_csr_unpack(_ptr(packed), packed.nbytes, None, 0, None, 0, C.byref(h), C.byref(n)))
+    values = np.zeros(max(int(h.value), 1), dtype=np.uint64)
+    offsets = np.zeros(int(n.value) + 1, dtype=np.uint64)
+    _lib.check(lib.yh_csr_unpack(_ptr(packed), packed.nbytes, _ptr(values), int(h.value), _ptr(offsets), int(n.value), C.byref(h), C.byref(n)))
+    return values[:int(h.value)], offsets
 
 
 class PinnedArray:
