@@ -70,19 +70,31 @@ def main() -> int:
     ap.add_argument("--seconds", type=float, default=300.0)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-batch", action="store_true", help="skip the batched-run check of every round")
+    ap.add_argument("--packed", action="store_true", help="every handle from the database's packed form (yh_csr_pack -> yh_db_create_packed; "
+                                                          "with YH_DEBUG_TUNING=1 YH_UPLOAD_CHUNK_MIN=1 the chunked expansion on the device)")
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
     t_end = time.time() + args.seconds
     rounds = 0
     hashes = 0
     c = 0.95 ** 31
+    def make_db(values, offsets, flags):
+        if not args.packed:
+            return RefDB(values, offsets, flags=flags)
+        from yacht_amd.engine import csr_pack, csr_unpack
+
+        blob = csr_pack(values, offsets, threads=int(rng.integers(1, 4)))
+        v2, o2 = csr_unpack(blob)
+        assert np.array_equal(v2, values) and np.array_equal(o2, offsets.astype(np.uint64)), "csr_pack / csr_unpack round trip"
+        return RefDB.from_packed(blob, sizes=np.diff(offsets).astype(np.uint32), flags=flags)
+
     while time.time() < t_end:
         refs, values, offsets, sample, top_bits = draw(rng)
         n = len(refs)
         sizes = np.diff(offsets).astype(np.uint32)
         tag = {"round": rounds, "n_refs": n, "n_hashes": int(values.size), "n_sample": int(sample.size), "top_bits": top_bits}
         try:
-            with RefDB(values, offsets, flags=YH_DB_KEEP_CSR) as db:
+            with make_db(values, offsets, YH_DB_KEEP_CSR) as db:
                 want = oracle.overlap(values, offsets, sample)
                 assert np.array_equal(db.overlap(sample, method="bsearch"), want), "bsearch overlap"
                 we, wm = oracle.exclusive(values, offsets, want > 0, sample)
@@ -140,7 +152,7 @@ def main() -> int:
                     assert db.index_stats() == wstats, "index stats"
                     # `yacht train`'s own handle: the fused path (the sort's last pass writes the records), a row range of it,
                     # and its shared-hash counts per reference against the full handle's
-                    with RefDB(values, offsets, flags=YH_DB_PAIRWISE_ONLY) as tdb:
+                    with make_db(values, offsets, YH_DB_PAIRWISE_ONLY) as tdb:
                         ti, tj, tc = tdb.pairwise(c)
                         assert np.array_equal(ti, wi) and np.array_equal(tj, wj) and np.array_equal(tc, wc), "pairs (train handle)"
                         assert tdb.index_stats() == wstats, "index stats (train handle)"
