@@ -409,14 +409,16 @@ int yh_q_pairwise(yh_db* db, double c_thresh, u64 r0, u64 r1) {
     // 16-bit counts (k_pair_rows<.., HALF>): a fused handle that knows its sketch sizes and has none above 65 535 hashes
     static const bool no_half = [] { const char* e = yh_tune_env("YH_PAIR_NO_HALF"); return e && e[0] == '1'; }();
     const bool half = fz && !no_half && db->h_sizes.size() == N && db->max_ref_size <= 0xffffu;
-    // lanes per row: 512 for 32-bit rows (configs[3]'s rows of ~2 700 records in 0.28 ms, against 0.37 with 256 lanes and 0.33
-    // with 1 024); 256 for 16-bit rows (more rows resident per CU: profiles/r05/sweep_pair_half.txt)
+    // Lanes per row and columns per block go by what a CU can hold: a row block's LDS is its columns (2 or 4 bytes each), and the
+    // WAVES resident per CU -- not the lanes of one row -- decide how well the phases of different rows overlap.  A row block is
+    // kept at <= 56 KB (two per CU) by cutting the columns into as many blocks as that takes, although every block reads the row's
+    // records again; and it gets the lanes that fill the CU's 32 waves at its size: 256 up to 24 KB (seven blocks per CU:
+    // configs[3]'s 10 000 16-bit columns, 209 us against 227 with 512), 512 up to 40 KB, 1 024 above.  At 85 205 references:
+    // three blocks of 28 416 columns, 1 024 lanes: 4.8 ms (512 lanes: 6.1); two blocks of 73 728 -- one per CU --: 19.9 / 10.8 /
+    // 7.1 ms at 256 / 512 / 1 024 lanes; round 4's 32-bit rows in three blocks of 36 864, 512 lanes: 11.5
+    // (profiles/r05/rs214_rows_sweep.txt, sweep_pair_half.txt).
     static const int threads_env = [] { const char* e = yh_tune_env("YH_PAIR_THREADS"); const int t = e ? atoi(e) : 0; return (t == 1024 || t == 512 || t == 256) ? t : 0; }();
-    const int threads = threads_env ? threads_env : (half ? 256 : 512);
-    const RowsKernel kern_plain = threads == 1024 ? k_pair_rows<1024, false, false> : threads == 256 ? k_pair_rows<256, false, false> : k_pair_rows<512, false, false>;
-    const RowsKernel kern_fused = threads == 1024 ? k_pair_rows<1024, true, false> : threads == 256 ? k_pair_rows<256, true, false> : k_pair_rows<512, true, false>;
-    const RowsKernel kern_half = threads == 1024 ? k_pair_rows<1024, true, true> : threads == 256 ? k_pair_rows<256, true, true> : k_pair_rows<512, true, true>;
-    const RowsKernel kern = half ? kern_half : fz ? kern_fused : kern_plain;
+    const u32 bytes_per_col = half ? 2u : 4u;
     static const bool big_lds = [] {
         bool ok = true;
         for (const RowsKernel k : {(RowsKernel)k_pair_rows<1024, false, false>, (RowsKernel)k_pair_rows<512, false, false>, (RowsKernel)k_pair_rows<256, false, false>,
@@ -428,9 +430,18 @@ int yh_q_pairwise(yh_db* db, double c_thresh, u64 r0, u64 r1) {
         }
         return ok;
     }();
-    u32 cols = (big_lds ? PAIR_COLS_BIG : PAIR_COLS_SMALL) * (half ? 2u : 1u);  // (columns: what the LDS words hold)
-    if (const char* e = yh_tune_env("YH_PAIR_COLS")) cols = std::max(64, atoi(e));  // (tests: several column blocks)
+    const u32 cols_cap = (big_lds ? PAIR_COLS_BIG : PAIR_COLS_SMALL) * (half ? 2u : 1u);  // (columns: what the LDS words can hold)
+    const u32 cols_target = std::min<u32>(cols_cap, 57344u / bytes_per_col);
+    const u64 nblk_want = (NC + cols_target - 1) / cols_target;
+    u32 cols = (u32)std::min<u64>(cols_cap, ((NC + nblk_want - 1) / nblk_want + 63) / 64 * 64);  // (the blocks of a row alike)
+    if (const char* e = yh_tune_env("YH_PAIR_COLS")) cols = (u32)std::min<u64>(cols_cap, std::max(64, atoi(e)));  // (tests: several column blocks)
     cols = (u32)std::min<u64>(cols, (NC + 63) / 64 * 64);
+    const u64 block_bytes = (u64)cols * bytes_per_col;
+    const int threads = threads_env ? threads_env : (block_bytes <= 24576u ? (half ? 256 : 512) : block_bytes <= 40960u ? 512 : 1024);
+    const RowsKernel kern_plain = threads == 1024 ? k_pair_rows<1024, false, false> : threads == 256 ? k_pair_rows<256, false, false> : k_pair_rows<512, false, false>;
+    const RowsKernel kern_fused = threads == 1024 ? k_pair_rows<1024, true, false> : threads == 256 ? k_pair_rows<256, true, false> : k_pair_rows<512, true, false>;
+    const RowsKernel kern_half = threads == 1024 ? k_pair_rows<1024, true, true> : threads == 256 ? k_pair_rows<256, true, true> : k_pair_rows<512, true, true>;
+    const RowsKernel kern = half ? kern_half : fz ? kern_fused : kern_plain;
     const u32 ncb = (u32)((NC + cols - 1) / cols);
     if (ncb > 65535) { yh_set_error("too many column blocks"); return YH_ERR_UNSUPPORTED; }
     const u64 rows = r1 - r0;
