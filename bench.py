@@ -1338,6 +1338,8 @@ def main() -> int:
                 "train_frac": ((train_di.get("roofline") or {}).get("frac")),
                 "train_traffic_bytes": ((train_di.get("roofline") or {}).get("traffic")),
                 "train_host_input_ms": (round(1e3 * train["seconds"]["total"], 3) if (train or {}).get("seconds") else None),
+                "train_packed_input_ms": (round(1e3 * train["packed_input"]["seconds"]["total"], 3)
+                                          if ((train or {}).get("packed_input") or {}).get("seconds") else None),
                 "roofline_frac": roofline.get("frac"), "roofline_kernel_us": round(1e3 * float(roofline.get("kernel_ms_avg") or 0.0), 2),
                 "refs_per_gpu": n_local,
                 "ref_hashes_per_gpu": Hh,
