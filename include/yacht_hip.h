@@ -334,13 +334,15 @@ int yh_run_batch_finish_range_device(yh_db* db, int slot, uint32_t n_samples, co
 /* A second stream for the second halves (ABI 6).  A block's second half is a dozen small launches (OR of the words, work
  * list, exclusive pass, the dense final pass, the compact rows: ~100 us of launch floors at rs214 scale, whatever the
  * rank's share of the lookups); on the handle's one stream they stand between the lookups of block j and those of block
- * j + 1.  With a finish stream set, yh_run_batch_finish_range_device, yh_run_batch_words_unpack_device and
- * yh_run_batch_rows_pack_device are enqueued THERE and run beside the next block's first half:
+ * j + 1.  With a finish stream set, yh_run_batch_finish_range_device, yh_run_batch_words_pack_device / _unpack_device and
+ * yh_run_batch_rows_pack_device are enqueued THERE and run beside the next block's first half -- and so is the tail of
+ * yh_run_batch_local_range_device: d_maskwords_out is written on the FINISH stream (behind the lookups, which stay on the
+ * handle's), so that the handle's stream carries nothing but clears and lookups:
  *   - the library orders a slot's second half behind its own first half (an event per slot), and every other query entry
  *     point, yh_db_synchronize and yh_db_destroy behind the last second half queued;
- *   - the CALLER orders what it adds between the halves (the exchange whose output yh_run_batch_words_unpack_device /
- *     yh_run_batch_finish_range_device read must be visible to the finish stream), reads the second half's outputs on the
- *     finish stream or behind it, and does not start a slot's next first half before that slot's second half and rows
+ *   - the CALLER issues what it adds between the halves on the finish stream or behind it (the exchange reads
+ *     d_maskwords_out / the packed words there, and its output must be visible to the finish stream before
+ *     yh_run_batch_words_unpack_device / yh_run_batch_finish_range_device), reads the second half's outputs there too, and does not start a slot's next first half before that slot's second half and rows
  *     have finished (BatchedRangeRunner reads the block's entry count back first: a host wait).
  * yh_run_batch_rows_unpack_device and everything else stay on the handle's stream.  NULL = one stream again; the call
  * drains the previous finish stream.  hip_stream must be a stream of the handle's device.                              */

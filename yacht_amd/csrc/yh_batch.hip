@@ -551,12 +551,21 @@ int yh_q_run_batch(yh_db* db, const u64* d_samples, const u64* d_soff, u32 n_sam
                                                                                        yh_filter_of(db), db->filter_mul);
     }
     yh_ring_record_end(db, db->ev_overlap, st);
-    k_batch_maskwords<<<(u32)((N + 255) / 256), 256, 0, st>>>(d_overlap, n_samples, N, d_maskword, split_streams ? nullptr : db->d_maskbits);
-    if (d_maskword_out) YH_HIP(hipMemcpyAsync(d_maskword_out, d_maskword, N * sizeof(u64), hipMemcpyDeviceToDevice, st));
-    if (split_streams) YH_HIP(hipEventRecord(bs.ev_first, st));
+    // With a finish stream the first stream carries nothing but the clears and the lookups: the samples' subset words (and their
+    // copy for the exchange) are made on the finish stream behind the lookups' event -- the exchange they are for, the words' pack
+    // and the second half all run there, and the next block's lookups start ~20 us of launch floors earlier.
+    hipStream_t sw = st;
+    if (split_streams) {
+        YH_HIP(hipEventRecord(bs.ev_first, st));
+        sw = db->fin_stream;
+        YH_HIP(hipStreamWaitEvent(sw, bs.ev_first, 0));
+    }
+    k_batch_maskwords<<<(u32)((N + 255) / 256), 256, 0, sw>>>(d_overlap, n_samples, N, d_maskword, split_streams ? nullptr : db->d_maskbits);
+    if (d_maskword_out) YH_HIP(hipMemcpyAsync(d_maskword_out, d_maskword, N * sizeof(u64), hipMemcpyDeviceToDevice, sw));
+    if (split_streams) { YH_HIP(hipEventRecord(db->ev_fin, sw)); db->fin_pending = true; }
     }
     if (!(phases & 2)) { YH_HIP(hipGetLastError()); return YH_OK; }
-    if (split_streams) YH_HIP(hipStreamWaitEvent(st, bs.ev_first, 0));
+    // (a second half alone is on the finish stream behind its slot's words, which waited for the slot's lookups)
     YH_HIP(hipMemsetAsync(d_excl, 0, BN * sizeof(u32), st));
     yh_ring_record_begin(db, db->ev_excl, st);
     if (d_gathered)
@@ -580,8 +589,9 @@ int yh_q_run_batch(yh_db* db, const u64* d_samples, const u64* d_soff, u32 n_sam
 
 // the subset words of a block as (word, reference) entries (kernels above); both on the handle's stream, no host sync
 int yh_q_batch_words_pack(yh_db* db, const u64* d_words, u64* d_packed, u64 cap) {
-    YH_HIP(hipMemsetAsync(d_packed, 0, sizeof(u64), db->stream));
-    if (db->n_refs) k_batch_words_pack<<<(u32)((db->n_refs + 1023) / 1024), 1024, 0, db->stream>>>(d_words, db->n_refs, d_packed, cap);
+    hipStream_t st = db->fin_stream ? db->fin_stream : db->stream;  // (where a first half leaves its words when there is a finish stream)
+    YH_HIP(hipMemsetAsync(d_packed, 0, sizeof(u64), st));
+    if (db->n_refs) k_batch_words_pack<<<(u32)((db->n_refs + 1023) / 1024), 1024, 0, st>>>(d_words, db->n_refs, d_packed, cap);
     YH_HIP(hipGetLastError());
     return YH_OK;
 }

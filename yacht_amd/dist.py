@@ -1008,6 +1008,16 @@ class BatchedRangeRunner:
                 "total": w + r}
 
     def _exchange(self, b: int, cap: int, sync: bool = False):
+        """The block's subset words on their way (their pack included).  With a finish stream the library leaves a first half's
+        words THERE (the first stream carries nothing but clears and lookups), so the pack and the collective are issued there."""
+        if self.s2 is None:
+            return self._exchange_on(b, cap, sync)
+        import torch
+
+        with torch.cuda.stream(self.s2):
+            return self._exchange_on(b, cap, sync)
+
+    def _exchange_on(self, b: int, cap: int, sync: bool = False):
         import torch
 
         hr = self.hr
@@ -1027,7 +1037,7 @@ class BatchedRangeRunner:
         self.bytes_words += 8 * L
         work = hr.batch_exchange(self.packed[b], self.gath_packed[b], async_op=self.async_collectives and not sync)
         if self.s2 is not None:
-            self.ev_x[b].record()  # (on the first stream: behind the pack, a copy that stands in for the exchange, a synchronous collective)
+            self.ev_x[b].record()  # (behind the pack, a copy that stands in for the exchange, a synchronous collective -- on the stream they were issued on)
         return work
 
     def close(self):
