@@ -381,8 +381,8 @@ int yh_run_batch_rows_unpack_device(yh_db* db, int slot, const uint32_t* d_vals,
  *                                    n_ranks = 1 --; *d_overflow = 1 when some rank had more words than cap_words (the
  *                                    OR is then incomplete and the caller repeats the exchange with a larger capacity
  *                                    or with the dense rows), else 0.  Reference ids >= N are ignored.
- * No handle state is read or written but the stream and N: both are enqueued on the handle's stream, no host sync, and
- * may run at any point of the interleaving table above.  (No reference counterpart: run_YACHT.py:150 runs one sample per
+ * No handle state is read or written but the stream and N: both are enqueued on the handle's stream (on the finish stream
+ * when one is set: yh_db_set_batch_finish_stream), no host sync, and may run at any point of the interleaving table above.  (No reference counterpart: run_YACHT.py:150 runs one sample per
  * process on one machine.)                                                                                              */
 uint64_t yh_run_batch_words_packed_len(uint64_t cap_words);
 int yh_run_batch_words_pack_device(yh_db* db, const uint64_t* d_words, uint64_t* d_packed, uint64_t cap_words);
