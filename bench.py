@@ -1401,8 +1401,16 @@ def main() -> int:
             "paths": paths,
             "roofline_other_path": other,
         }
+        # The ONE stdout line holds the contract keys + small config / roofline / cpu_baseline (bench_line.py: <= 4 kB, strict
+        # JSON); the whole result goes to gpurun_out/bench_extras.json and to stderr (a 20.7 kB line left the
+        # driver's record unparsed).
+        import bench_line
+
+        extras_path = bench_line.write_extras(out, ROOT)
+        sys.stderr.write("bench.py: full result (also in %s):\n%s\n" % (extras_path, json.dumps(out, indent=1, default=str)))
+        sys.stderr.flush()
         sys.stdout.flush()
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
+        os.write(json_fd, (bench_line.dumps(out, extras_path) + "\n").encode())
     if sdb is not None:
         sdb.close()
     else:
