@@ -262,7 +262,10 @@ def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
         # in flight; undersized exchanges of either kind are noticed on every rank, the block repeated, the capacity raised
         for kw, expect in ((dict(), "fits"), (dict(cap_words=2), "words"), (dict(cap_rows=4), "rows"),
                            (dict(cap_words=3, cap_rows=5), "both"), (dict(compact_words=False), "fits"),
-                           (dict(dense_rows=True, cap_words=2), "words")):
+                           (dict(dense_rows=True, cap_words=2), "words"),
+                           # fewer slots: one slot = the two halves of successive blocks in turn, no overlap
+                           (dict(nbuf=1), "fits"), (dict(nbuf=2), "fits"), (dict(nbuf=1, cap_words=2, cap_rows=4), "both"),
+                           (dict(nbuf=1, dense_rows=True), "fits")):
             got = {}
 
             def on_result(tag, n_in, rows, dense):
@@ -271,7 +274,7 @@ def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
                 else:
                     assert rows is None and dense is None
 
-            run = ydist.BatchedRangeRunner(hr, batch=3, dst=0, nbuf=3, on_result=on_result, **kw)
+            run = ydist.BatchedRangeRunner(hr, batch=3, dst=0, on_result=on_result, **dict(dict(nbuf=3), **kw))
             for rep in range(2):  # (the second round starts with the raised capacities)
                 for j, blk_ in enumerate(tb):
                     run.submit(hr.pack_batch(blk_), len(blk_), tag=(rep, j))

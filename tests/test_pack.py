@@ -112,3 +112,22 @@ def test_csr_pack_roundtrip_and_refusals():
     forged[first_block_entry + 3 + 1] = np.uint64(2**40)                       # block 1's word_off far outside the payload
     with pytest.raises(_lib.YachtHipError):
         csr_unpack(forged)
+    #  a block table whose word offsets are in bounds but NOT the running prefix -- two blocks swapped, one that
+    # points at an earlier block's words -- is refused by the view itself: the chunked upload copies payload ranges by these
+    # offsets, and a non-monotone table would leave blocks decoding words that were never copied
+    blocks = [first_block_entry + 3 * b for b in range(4)]
+    w = [int(blob[e + 1]) for e in blocks]
+    assert w[0] == 0 and w[1] <= w[2] <= w[3] and w[3] > w[2]
+    forged = blob.copy()
+    forged[blocks[3] + 1] = np.uint64(w[2])                                    # block 3 re-reads block 2's words
+    with pytest.raises(_lib.YachtHipError):
+        csr_unpack(forged)
+    forged = blob.copy()
+    forged[blocks[2] + 1], forged[blocks[3] + 1] = np.uint64(w[3]), np.uint64(w[2])   # swapped
+    with pytest.raises(_lib.YachtHipError):
+        csr_unpack(forged)
+    forged = blob.copy()
+    forged[blocks[0]] = np.uint64(2**64 - 1)                                   # block 0's base above the header's largest hash
+    forged[7 - 2] = np.uint64(2**63)                                           # (header word 5 = max_hash)
+    with pytest.raises(_lib.YachtHipError):
+        csr_unpack(forged)

@@ -608,16 +608,24 @@ int yh_db_create_device(const uint64_t* d_values, const uint64_t* d_offsets, uin
 int yh_db_create_packed(const void* packed, uint64_t packed_bytes, int device_id, uint32_t flags, yh_db** out) {
     if (!out) { yh_set_error("out is null"); return YH_ERR_INVALID_ARG; }
     *out = nullptr;
-    YhPackedCsr v;
-    YH_TRY(yh_csr_view(packed, packed_bytes, &v));
-    static const u64 chunk_min = [] { const char* e = yh_tune_env("YH_UPLOAD_CHUNK_MIN"); return e ? (u64)atoll(e) : (u64)12 << 20; }();
-    if (!(v.n_hashes >= chunk_min && v.n_refs >= 4)) {
-        std::vector<uint64_t> values(std::max<u64>(v.n_hashes, 1)), offsets(v.n_refs + 1);
-        uint64_t h = 0, n = 0;
-        YH_TRY(yh_csr_unpack(packed, packed_bytes, values.data(), v.n_hashes, offsets.data(), v.n_refs, &h, &n));
-        return db_create_common((const u64*)values.data(), (const u64*)offsets.data(), false, v.n_refs, device_id, flags, out);
+    try {  // (the view's and the host unpack's vectors are sized by the blob's header: no exception crosses the C boundary)
+        YhPackedCsr v;
+        YH_TRY(yh_csr_view(packed, packed_bytes, &v));
+        static const u64 chunk_min = [] { const char* e = yh_tune_env("YH_UPLOAD_CHUNK_MIN"); return e ? (u64)atoll(e) : (u64)12 << 20; }();
+        if (!(v.n_hashes >= chunk_min && v.n_refs >= 4)) {
+            std::vector<uint64_t> values(std::max<u64>(v.n_hashes, 1)), offsets(v.n_refs + 1);
+            uint64_t h = 0, n = 0;
+            YH_TRY(yh_csr_unpack(packed, packed_bytes, values.data(), v.n_hashes, offsets.data(), v.n_refs, &h, &n));
+            return db_create_common((const u64*)values.data(), (const u64*)offsets.data(), false, v.n_refs, device_id, flags, out);
+        }
+        return db_create_common(nullptr, v.offsets, false, v.n_refs, device_id, flags, out, &v);
+    } catch (const std::bad_alloc&) {
+        yh_set_error("yh_db_create_packed: out of host memory");
+        return YH_ERR_OOM;
+    } catch (const std::exception& ex) {
+        yh_set_error("yh_db_create_packed: %s", ex.what());
+        return YH_ERR_INVALID_ARG;
     }
-    return db_create_common(nullptr, v.offsets, false, v.n_refs, device_id, flags, out, &v);
 }
 
 int yh_db_destroy(yh_db* db) {
@@ -1299,6 +1307,9 @@ int yh_run_batch_rows_unpack_device(yh_db* db, int slot, const uint32_t* d_vals,
                                     uint32_t* d_n_rows) {
     YH_TRY(batch_rows_check(db, slot));
     if (!d_n_rows || (cap_rows && (!d_vals || !d_rows))) { yh_set_error("null device pointer"); return YH_ERR_INVALID_ARG; }
+    // (runs on the handle's stream and reads the slot's subset words + rewrites its block counts, both written on the finish
+    // stream by the second half and the rows pack: behind them -- ADVICE r05)
+    fin_join(db);
     return yh_q_batch_rows_unpack(db, slot, d_vals, cap_rows, d_rows, d_n_rows);
 }
 

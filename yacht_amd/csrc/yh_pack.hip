@@ -291,16 +291,36 @@ int yh_csr_view(const void* packed, u64 bytes, YhPackedCsr* v) {
     v->payload = reinterpret_cast<const u64*>((const char*)v->tab + hd.n_blocks * sizeof(CsrBlock));
     v->first_block.assign(hd.n_refs + 1, 0);
     if (v->offsets[0] != 0) { yh_set_error("offsets[0] must be 0"); return YH_ERR_INVALID_ARG; }
-    u64 nb = 0;
+    // The block table is untrusted input as well: every block's payload starts where the one before it ends --
+    // the only layout yh_csr_pack writes -- so the chunked upload's payload ranges [w0, w1) are monotone, cover what their
+    // blocks read, and nothing decodes words that were never copied.  width <= 64; the running prefix + the spare word is
+    // the payload's length; a block's base (its first hash) and the largest hash a block can reach stay below the header's
+    // max_hash check of the build only loosely, so the base is held to it here.
+    u64 nb = 0, words = 0;
     for (u64 j = 0; j < hd.n_refs; ++j) {
         const u64 a = v->offsets[j], e = v->offsets[j + 1];
         if (e < a || e > hd.n_hashes) { yh_set_error("packed CSR: offsets are not monotone"); return YH_ERR_UNSORTED; }
         if (e - a > 0xffffffffull) { yh_set_error("a reference sketch has more than 2^32-1 hashes"); return YH_ERR_INVALID_ARG; }
         v->first_block[j] = nb;
-        nb += (e - a + PACK_BLOCK - 1) / PACK_BLOCK;
+        const u64 nbj = (e - a + PACK_BLOCK - 1) / PACK_BLOCK;
+        if (nb + nbj > hd.n_blocks) { yh_set_error("packed CSR: offsets and block count do not match the header"); return YH_ERR_INVALID_ARG; }
+        for (u64 first = a, b = nb; first < e; first += PACK_BLOCK, ++b) {
+            CsrBlock blk;
+            memcpy(&blk, (const char*)v->tab + b * sizeof(CsrBlock), sizeof(blk));
+            const u32 cnt = (u32)std::min<u64>(PACK_BLOCK, e - first);
+            if (blk.width > 64u || blk.word_off != words) {
+                yh_set_error("packed CSR: block %llu is not where the blocks in front of it end (or its width is > 64)", b);
+                return YH_ERR_INVALID_ARG;
+            }
+            if (blk.base > hd.max_hash) { yh_set_error("packed CSR: block %llu starts above the header's largest hash", b); return YH_ERR_INVALID_ARG; }
+            words += block_words(cnt, blk.width);
+            if (words >= hd.payload_words) { yh_set_error("packed CSR: block %llu points outside the payload", b); return YH_ERR_INVALID_ARG; }
+        }
+        nb += nbj;
     }
     v->first_block[hd.n_refs] = nb;
     if (v->offsets[hd.n_refs] != hd.n_hashes || nb != hd.n_blocks) { yh_set_error("packed CSR: offsets and block count do not match the header"); return YH_ERR_INVALID_ARG; }
+    if (words + 1 != hd.payload_words) { yh_set_error("packed CSR: the payload is %llu words, its blocks take %llu + the spare word", hd.payload_words, words); return YH_ERR_INVALID_ARG; }
     return YH_OK;
 }
 u64 yh_csr_block_bytes() { return sizeof(CsrBlock); }

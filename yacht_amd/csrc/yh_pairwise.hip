@@ -32,9 +32,14 @@ namespace {
 constexpr int WAVE = 64;
 // holders of a hash up to which a posting's record names the others inline (three others)
 constexpr u32 PAIR_INLINE = 4;
-// columns (u32 counts) of a row block in LDS: with the attribute below 36 864 (144 KiB), else what fits 64 KiB
+// columns (u32 counts) of a row block in LDS: with the attribute below 36 864 (144 KiB), else what fits 64 KiB.  Both leave
+// room for k_pair_rows' STATIC LDS -- the waves' list queues, 8 KiB at 1 024 lanes, + the wave totals (15 360
+// columns + the queues was 65.6 KB of a 64 KB limit): 144 + 8.1 KiB of gfx950's 160, 54 + 8.1 KiB of 64.
 constexpr u32 PAIR_COLS_BIG = 36864;
-constexpr u32 PAIR_COLS_SMALL = 15360;
+constexpr u32 PAIR_COLS_SMALL = 13824;
+constexpr u32 PAIR_STATIC_LDS = 16u * 64u * 8u + 256u;  // (lqueue[WAVES][64] at 16 waves + wtot + s_base, rounded up)
+static_assert(PAIR_COLS_BIG * 4u + PAIR_STATIC_LDS <= 160u * 1024u, "a row block + the kernel's static LDS fit gfx950's 160 KiB");
+static_assert(PAIR_COLS_SMALL * 4u + PAIR_STATIC_LDS <= 64u * 1024u, "the fallback row block + the static LDS fit 64 KiB");
 
 __global__ void __launch_bounds__(256) k_pair_transpose(u64 n_post, const u32* __restrict__ pr, const u32* __restrict__ pg,
                                                         const u64* __restrict__ po, const u32* __restrict__ rowptr,

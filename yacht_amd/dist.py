@@ -1074,14 +1074,18 @@ class BatchedRangeRunner:
         else:
             import torch.distributed as dist
 
-            if self.ev[b] is not None:
-                self.ev[b].record()
             if hr.has_exchange:
                 if self.async_collectives:
                     pend = dist.reduce(self.counts[b], dst=self.dst, op=dist.ReduceOp.SUM, group=hr.group, async_op=True) if self.dst is not None \
                         else dist.all_reduce(self.counts[b], op=dist.ReduceOp.SUM, group=hr.group, async_op=True)
                 else:
                     self.counts[b].copy_(hr.reduce(self.counts[b], dst=self.dst))
+            # The block's event goes BEHIND the reduce: a synchronous reduce is queued on this stream (the finish stream when
+            # there is one), and _finish hands counts[b] to on_result -- and the slot's next first half clears it -- once this
+            # event has passed (recorded in front of the reduce, both raced with it).  An asynchronous reduce is
+            # ordered by pend.wait() in _finish.
+            if self.ev[b] is not None:
+                self.ev[b].record()
         self.inflight[b] = (seq, tag, n_in, batch, pend)
 
     def _is_dst(self) -> bool:
@@ -1146,6 +1150,11 @@ class BatchedRangeRunner:
         seq = self.seq
         self.seq += 1
         b = seq % self.nbuf
+        if self.nbuf == 1 and self.prev is not None:
+            # One slot: the previous block still owns it (first half, counts, gathered words) until its second half has run,
+            # so the two halves cannot overlap -- finish it here, in front of this block's first half.
+            self._second_half(*self.prev)
+            self.prev = None
         self._finish(b)  # block seq - nbuf: its slot, its counts and its buffers are free again
         self.hr.batch_begin(batch, self.counts[b], self.words[b], slot=b)
         cap = self.cap_words
