@@ -33,7 +33,8 @@ def host_free_gib() -> float:
 
 
 def main() -> int:
-    n_refs = int(sys.argv[1]) if len(sys.argv) > 1 else 85_205
+    pos = [a for a in sys.argv[1:] if not a.startswith("--")]
+    n_refs = int(pos[0]) if pos else 85_205
     c = 0.95 ** 31
     values, offsets, _sample = synth.config3_device(seed=1002, n_refs=n_refs, n_sample=1000, device="cuda:0")
     torch.cuda.synchronize()
@@ -83,6 +84,19 @@ def main() -> int:
     out["all_equal"] = all(eq.values())
     out["reference_published"] = "README.md:276: ~12 minutes, 52 GB, 64 threads for the whole `yacht train` command at this N"
     print(json.dumps(out), flush=True)
+    if "--write-golden" in sys.argv and n_refs == 85_205:
+        # the ORACLE's answers only (never the GPU's): what tests/test_gpu_train_rs214.py holds the shipped build to
+        g = {"what": "yacht train core at N = 85 205 (README.md:276's scale): the ORACLE PORT's answers (oracle/yacht_oracle.cpp) on "
+                     "synth.config3_device(seed=1002, n_refs=85205, n_sample=1000), as digests: sha256[:32] over the little-endian bytes "
+                     "of the (i, j, count) uint32 arrays of the kept pairs in (i, j) order, and of the selection (uint32 ids in walk order)",
+             "made_by": "scripts/train_rs214_parity.py --write-golden", "seed": 1002, "n_refs": n_refs, "n_hashes": int(h_values.size),
+             "c_thresh": c, "pairs_kept": int(wi.size), "selected": int(wsel.size),
+             "stats_distinct_singletons_index": [int(x) for x in wstats], "oracle_pairs_digest": digest(wi, wj, wc),
+             "oracle_selection_digest": digest(wsel), "input_digest": digest(values.cpu().numpy(), offsets.cpu().numpy()),
+             "oracle_train_pairs_s": round(t1 - t0, 1)}
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "golden_train_rs214.json"), "w") as f:
+            json.dump(g, f, indent=1)
     return 0 if out["all_equal"] else 1
 
 
