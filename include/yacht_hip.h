@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define YH_ABI_VERSION 7
+#define YH_ABI_VERSION 8
 
 enum {
     YH_OK               = 0,
@@ -452,6 +452,12 @@ int yh_pairwise(yh_db* db, double c_thresh, uint64_t row_begin, uint64_t row_end
 int yh_db_nshared_device(yh_db* db, uint32_t* d_out);
 /* distinct hashes, hashes seen in exactly one reference, hashes kept in the index.           */
 int yh_index_stats(yh_db* db, uint64_t* n_distinct, uint64_t* n_singletons, uint64_t* n_index);
+/* (ABI 8) How the last yh_pairwise of this handle summed its rows: a `yacht train` handle with more references than one
+ * dense row block holds (> 28 672) keeps a row's counts in a hash table over the columns the row touches
+ * (*sparse_rows); a row that touches more than 2 048 columns -- a k-mer thousands of genomes share -- takes the dense
+ * pass (*dense_rows).  Both 0: every row dense (small N, or a handle that is not `yacht train`'s).  Diagnostic; the
+ * pairs are the same either way (reference: the dense matrix of src/cpp/main.cpp:249-312).                        */
+int yh_pairwise_row_stats(yh_db* db, uint64_t* sparse_rows, uint64_t* dense_rows);
 
 /* Greedy size-ordered selection (host).  `pair_i/pair_j` are the pairs with C(i->j) >= C,
  * sorted by (i, j).  selected[] receives the kept reference ids in walk order.              */

@@ -53,6 +53,9 @@ for c in (0.0, 0.95 ** 31, 0.9):
             parts = [db.pairwise(c, a, b) for a, b in zip(cuts, cuts[1:])]
             ok_rows = all(np.array_equal(np.concatenate([p[k] for p in parts]), w) for k, w in ((0, wi), (1, wj), (2, wc)))
             ok_sel = bool(np.array_equal(train_select(sizes, gi, gj), oracle.train_select(sizes, wi, wj)))
+            if flags == YH_DB_PAIRWISE_ONLY:
+                db.pairwise(c)
+                out["sparse_rows"], out["dense_rows"] = db.pairwise_row_stats()
         out[f"c{c:.3f}_flags{flags}"] = [ok, bool(ok_rows), ok_sel, int(wi.size)]
 print(json.dumps(out))
 """
@@ -66,7 +69,7 @@ def _run(seed, env_extra):
     return json.loads(r.stdout.strip().splitlines()[-1])
 
 
-@pytest.mark.parametrize("cols", [None, 64, 128, "unfused", "lists"])
+@pytest.mark.parametrize("cols", [None, 64, 128, "unfused", "lists", "sparse", "sparse_lists"])
 def test_pairwise_rows_against_the_oracle(hip_lib, cols):
     """YH_DB_PAIRWISE_ONLY handles take the fused path (records written by the sort's last pass, yh_sort.hip), the others the
     posting arrays + k_pair_transpose; "unfused": the train handle without the fused path (posting ranks); "lists": every fused
@@ -76,11 +79,18 @@ def test_pairwise_rows_against_the_oracle(hip_lib, cols):
         env["YH_NO_FUSED_TRAIN"] = "1"
     elif cols == "lists":
         env["YH_FZ_NO_INLINE"] = "1"
+    elif cols == "sparse":         # round 6: the row pass of large N (k_pair_rows_sparse: a hash table over the touched columns) forced onto this one
+        env["YH_PAIR_SPARSE"] = "1"
+    elif cols == "sparse_lists":
+        env["YH_PAIR_SPARSE"] = "1"
+        env["YH_FZ_NO_INLINE"] = "1"
     elif cols is not None:
         env["YH_PAIR_COLS"] = str(cols)
     out = _run(cols if isinstance(cols, int) else 5, env)
+    if isinstance(cols, str) and cols.startswith("sparse"):
+        assert out["sparse_rows"] > 300 and out["dense_rows"] == 0, out
     assert out["n"] > 300
-    checks = {k: v for k, v in out.items() if k != "n"}
+    checks = {k: v for k, v in out.items() if k not in ("n", "sparse_rows", "dense_rows")}
     assert len(checks) == 6
     for k, v in checks.items():
         assert v[:3] == [True, True, True], (k, v)
@@ -93,7 +103,7 @@ def test_database_uploaded_in_chunks(hip_lib, shares):
     sorted prefix while the next one crosses the bus (yh_build_upload_sorted).  Forced onto a small database here; the
     merged (hash, reference) order is checked on the device (YH_CHECK_SORT) and every pair result against the oracle."""
     out = _run(11, {"YH_DEBUG_TUNING": "1", "YH_UPLOAD_CHUNK_MIN": "1", "YH_UPLOAD_SHARES": shares, "YH_CHECK_SORT": "1"})
-    checks = {k: v for k, v in out.items() if k != "n"}
+    checks = {k: v for k, v in out.items() if k not in ("n", "sparse_rows", "dense_rows")}
     for k, v in checks.items():
         assert v[:3] == [True, True, True], (k, v)
 
@@ -303,3 +313,56 @@ def test_database_created_from_its_packed_form(hip_lib):
     sv, so = synth.config4(seed=5, n_clusters=30, size=200)
     with RefDB(sv, so, flags=YH_DB_PAIRWISE_ONLY) as a, RefDB.from_packed(csr_pack(sv, so), flags=YH_DB_PAIRWISE_ONLY) as b:
         assert all(np.array_equal(x, y) for x, y in zip(a.pairwise(0.1), b.pairwise(0.1)))
+
+
+HOT_WORKER = r"""
+import json, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from oracle import oracle
+from yacht_amd import synth
+from yacht_amd.engine import RefDB, YH_DB_PAIRWISE_ONLY, train_select
+
+rng = np.random.default_rng(606)
+mh = synth.max_hash_for_scaled(1000)
+n_hot, n = 2400, 2600
+refs = [synth.random_sketch(rng, int(rng.integers(8, 30)), mh) for _ in range(n)]
+hot = [int(rng.integers(1, mh)) for _ in range(3)]          # three hashes that the first 2 400 sketches all hold
+for i in range(n_hot):
+    refs[i] = np.unique(np.concatenate([refs[i], np.array(hot, np.uint64)]))
+for i in range(n_hot, n - 1, 2):                             # ... and pairs of near-duplicates among the rest (sparse rows)
+    refs[i + 1] = np.unique(np.concatenate([refs[i][: refs[i].size * 3 // 4], refs[i + 1][:4]]))
+values, offsets = synth.pack(refs)
+sizes = np.diff(offsets).astype(np.uint32)
+out = {}
+for c in (0.0, 0.2):
+    wi, wj, wc, wstats = oracle.train_pairs(values, offsets, c, threads=8)
+    with RefDB(values, offsets, flags=YH_DB_PAIRWISE_ONLY) as db:
+        gi, gj, gc = db.pairwise(c)
+        sp, de = db.pairwise_row_stats()
+        part = db.pairwise(c, 100, 2500)
+        keep = (wi >= 100) & (wi < 2500)
+        ok_part = bool(np.array_equal(part[0], wi[keep]) and np.array_equal(part[1], wj[keep]) and np.array_equal(part[2], wc[keep]))
+    out[f"c{c}"] = [bool(np.array_equal(gi, wi) and np.array_equal(gj, wj) and np.array_equal(gc, wc)), ok_part, int(wi.size), int(sp), int(de),
+                    bool(np.array_equal(train_select(sizes, gi, gj), oracle.train_select(sizes, wi, wj)))]
+print(json.dumps(out))
+"""
+
+
+@pytest.mark.parametrize("cols", [None, 1024])
+def test_sparse_rows_hand_hot_rows_back_to_the_dense_pass(hip_lib, cols):
+    """k_pair_rows_sparse keeps a row's counts in a hash table over the columns it touches (2 048 at most); a row that touches
+    more -- here 2 400 sketches that all hold three common hashes: 2 399 columns each -- is handed back and takes the dense pass
+    (k_pair_rows with a row list; `cols`: in several column blocks), the other rows stay sparse.  Pairs, row ranges and the
+    selection against the oracle."""
+    env = dict(os.environ)
+    env.update({"YH_DEBUG_TUNING": "1", "YH_PAIR_SPARSE": "1"})
+    if cols:
+        env["YH_PAIR_COLS"] = str(cols)
+    r = subprocess.run([sys.executable, "-c", HOT_WORKER, ROOT], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    for k, v in out.items():
+        assert v[0] and v[1] and v[5], (k, v)
+        assert v[3] == 200 and v[4] == 2400, (k, v)   # (the last full-range call: 200 rows sparse, 2 400 handed back)
+    assert out["c0.0"][2] > 2400 * 2399

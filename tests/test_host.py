@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/yacht_hip.h but not exported"
     assert sorted(_lib.SIGNATURES) == names, "ctypes table and header disagree"
-    assert _lib.load().yh_abi_version() == 7
+    assert _lib.load().yh_abi_version() == 8
 
 
 def test_no_device_fails_loudly():

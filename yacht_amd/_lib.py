@@ -148,6 +148,7 @@ SIGNATURES = {
     "yh_pairwise": (C.c_int, [_vp, C.c_double, C.c_uint64, C.c_uint64, C.c_uint64, _vp, _vp, _vp,
                               C.POINTER(C.c_uint64)]),
     "yh_index_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "yh_pairwise_row_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "yh_sketch_dna": (C.c_int, [_vp, C.c_uint64, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_uint64, _vp,
                                 C.POINTER(C.c_uint64)]),
     "yh_sketch_dna_device": (C.c_int, [_vp, C.c_uint64, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, _vp, _vp, _vp]),
@@ -219,7 +220,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError here = the .so does not match the header
         fn.restype = res
         fn.argtypes = args
-    if lib.yh_abi_version() != 7:
+    if lib.yh_abi_version() != 8:
         raise YachtHipError(YH_ERR_INVALID_ARG, f"ABI version mismatch in {path}")
     _lib = lib
     return lib

@@ -1544,6 +1544,13 @@ int yh_index_stats(yh_db* db, uint64_t* n_distinct, uint64_t* n_singletons, uint
     return YH_OK;
 }
 
+int yh_pairwise_row_stats(yh_db* db, uint64_t* sparse_rows, uint64_t* dense_rows) {
+    if (!db_ok(db)) return YH_ERR_INVALID_ARG;
+    if (sparse_rows) *sparse_rows = db->pw_sparse_rows;
+    if (dense_rows) *dense_rows = db->pw_dense_rows;
+    return YH_OK;
+}
+
 // ---- greedy selection (host; src/cpp/main.cpp:371-407) ----------------------------------------------
 // Walk the references by ascending sketch size; drop one when a not-yet-dropped neighbour of at
 // least its size exists.  The size ordering comes from libstdc++'s std::sort with a size-only

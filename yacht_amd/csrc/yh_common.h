@@ -224,6 +224,7 @@ struct yh_db {
     u32* h_pw_i = nullptr;
     u32* h_pw_j = nullptr;
     u32* h_pw_c = nullptr;
+    u64 pw_sparse_rows = 0, pw_dense_rows = 0;  // the last sparse row pass (k_pair_rows_sparse): rows it kept / handed back to the dense pass
 
     // Two step contexts for the sharded run: what yh_run_local_device leaves for yh_run_finish_device (subset bits,
     // work list).  With two of them the lookup of sample k+1 runs while the bit exchange of sample k is in flight.

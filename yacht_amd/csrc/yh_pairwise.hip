@@ -94,6 +94,12 @@ struct PairRows {
     unsigned long long* cursor;
     u64 cap;              // entries of out[] behind the fixed slots (a segment that does not fit is counted, not written)
     uint2* out;           // (reference j, count): [nseg * PAIR_SLOTS] fixed slots, then the cursor's area
+    const u32* rowlist;   // != NULL: blockIdx.x names rowlist[blockIdx.x] (the rows k_pair_rows_sparse handed back), not a0 + blockIdx.x
+    // k_pair_rows_sparse:
+    u64 rows;             // rows of the call: a0 .. a0 + rows
+    u32 ncb;              // segments per row in segcnt / segoff (the dense geometry's column blocks: a row handed back fills them all)
+    u32* ovf_count;       // rows whose touched columns outgrew the table ...
+    u32* ovf_rows;        // ... and which (k_pair_rows takes them: rowlist)
 };
 
 // A segment of up to PAIR_SLOTS survivors has its own place in out[] (a cluster of genomes: a handful of mates per
@@ -129,10 +135,10 @@ __global__ void __launch_bounds__(THREADS) k_pair_rows(const PairRows p) {
     __shared__ u64 s_base;
     __shared__ u32 s_write;
     const u32 tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
-    const u64 a = p.a0 + blockIdx.x;
+    const u64 a = p.rowlist ? (u64)p.rowlist[blockIdx.x] : p.a0 + blockIdx.x;
     const u32 c0 = blockIdx.y * p.cols;
     const u32 w = min(p.NC - c0, p.cols);
-    const u64 seg = p.seg0 + (u64)blockIdx.x * gridDim.y + blockIdx.y;
+    const u64 seg = p.seg0 + (a - p.a0) * gridDim.y + blockIdx.y;
     const Rec* recs;
     u32 t1;  // records of the row: recs[0 .. t1)
     if constexpr (FUSED) {
@@ -338,6 +344,196 @@ __global__ void __launch_bounds__(THREADS) k_pair_rows(const PairRows p) {
     }
 }
 
+// ---- the row pass for MANY references: sparse rows (round 6) ---------------------------------------------------------------
+// k_pair_rows keeps a row's counts DENSE in LDS: at the scale the reference publishes (README.md:276: 85 205 genomes) that is
+// 170 KB of 16-bit columns per row -- three column blocks of 28 416, each clearing and scanning its 56 KB for the handful of
+// cluster mates a genome has, each reading the row's records again: 4.7 ms, nearly all of it clears and scans
+// (profiles/r05/rs214_rows_sweep.txt).  Here a row's counts live in a HASH TABLE over the columns it touches (SP_SLOTS slots:
+// key = column + 1, count beside it; linear probing) with a list of the slots claimed: nothing is cleared per row -- a
+// persistent workgroup resets exactly the slots its row claimed -- and nothing is scanned but that list.  What a row costs is
+// its records (8 bytes per CSR position, streamed once) and its adds; a row that touches nothing (nine in ten at rs214 scale)
+// costs its records alone.  A row whose touched columns outgrow the list (a hot k-mer: thousands of holders) is handed back
+// through ovf_rows and takes the dense pass (k_pair_rows with rowlist); the host sorts a sparse row's survivors by column
+// (they leave in the order the slots were claimed).  FUSED handles only (yh_db::fz -- `yacht train`'s).
+constexpr u32 SP_THREADS = 256;
+constexpr u32 SP_BITS = 12;
+constexpr u32 SP_SLOTS = 1u << SP_BITS;   // 32 KB of table (key + count)
+constexpr u32 SP_LIST = SP_SLOTS / 2;     // claimed slots a row may have: the table is never more than half full
+constexpr int SP_U = 8;                   // records a lane has in flight
+__global__ void __launch_bounds__(SP_THREADS) k_pair_rows_sparse(const PairRows p) {
+    constexpr int WAVES = SP_THREADS / WAVE;
+    __shared__ u32 tkey[SP_SLOTS], tcnt[SP_SLOTS];
+    __shared__ u16 tlist[SP_LIST];
+    __shared__ u64 lqueue[WAVES][64];
+    __shared__ u32 wtot[WAVES];
+    __shared__ u32 s_nt[2], s_ovf[2], s_write;  // (per row PARITY: a wave that is through with row k adds for row k + 1 while others still read row k's)
+    __shared__ u64 s_base;
+    const u32 tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
+    for (u32 k = tid; k < SP_SLOTS; k += SP_THREADS) { tkey[k] = 0; tcnt[k] = 0; }
+    if (tid < 2) { s_nt[tid] = 0; s_ovf[tid] = 0; }
+    __syncthreads();
+    u32 par = 1;
+    for (u64 rix = blockIdx.x; rix < p.rows; rix += gridDim.x) {  // (workgroup-uniform)
+        par ^= 1u;
+        const u64 a = p.a0 + rix;
+        const u64 seg = p.seg0 + rix * p.ncb;
+        const u64 fb = p.foff[a];
+        const u64* recs = p.frec + fb;
+        const u32 t1 = (u32)(p.foff[a + 1] - fb);
+        if (tid < p.ncb) { p.segcnt[seg + tid] = 0; p.segoff[seg + tid] = 0; }  // (ncb <= 65 535 / rows of >= 1 segment; see the host)
+        for (u32 k = SP_THREADS + tid; k < p.ncb; k += SP_THREADS) { p.segcnt[seg + k] = 0; p.segoff[seg + k] = 0; }
+        if (t1 == 0) continue;
+        auto add = [&](u32 col) {
+            if (col == (u32)a) return;
+            u32 sl = (col * 2654435761u) >> (32 - SP_BITS);
+            for (u32 probe = 0; probe < SP_SLOTS; ++probe, sl = (sl + 1u) & (SP_SLOTS - 1u)) {
+                const u32 old = atomicCAS(&tkey[sl], 0u, col + 1u);
+                if (old == 0u) {  // claimed: on the row's list (a list that is full hands the row back: the claim is undone by the full reset below)
+                    const u32 k = atomicAdd(&s_nt[par], 1u);
+                    if (k < SP_LIST) tlist[k] = (u16)sl; else s_ovf[par] = 1u;
+                    atomicAdd(&tcnt[sl], 1u);
+                    return;
+                }
+                if (old == col + 1u) { atomicAdd(&tcnt[sl], 1u); return; }
+                if (s_ovf[par]) return;  // (the row is lost already; and a table nobody reads may fill up)
+            }
+        };
+        auto flush = [&](u32 nq) {  // (k_pair_rows' walk of a wave's queued list records, flattened over the lanes)
+            const u64 d = lane < nq ? lqueue[wid][lane] : 0ull;
+            const u32 m = (u32)(d >> 40);
+            u32 inc = m;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const u32 t_ = (u32)__shfl_up((int)inc, off);
+                if (lane >= (u32)off) inc += t_;
+            }
+            const u32 total = (u32)__shfl((int)inc, 63);
+            const u32 exc = lane < nq ? inc - m : 0xffffffffu;
+            const u32 dlo = (u32)d, dhi = (u32)(d >> 32);
+            for (u32 t0_ = 0; t0_ < total; t0_ += 64u) {
+                const u32 t = t0_ + lane;
+                u32 e = 0;
+#pragma unroll
+                for (u32 step = 32; step >= 1; step >>= 1) {
+                    const u32 cand = e + step;
+                    const u32 v = (u32)__shfl((int)exc, (int)cand);
+                    if (v <= t) e = cand;
+                }
+                const u32 e_exc = (u32)__shfl((int)exc, (int)e);
+                const u64 de = ((u64)(u32)__shfl((int)dhi, (int)e) << 32) | (u32)__shfl((int)dlo, (int)e);
+                if (t < total) {
+                    u64 q0 = de & ((1ull << 40) - 1ull);
+                    const u32* lsrc = p.pr;
+                    if (q0 >= p.pr_split) { lsrc = p.pr2; q0 -= p.pr_split; }
+                    add(lsrc[q0 + (t - e_exc)]);
+                }
+            }
+        };
+        u64 rec[SP_U];
+#pragma unroll
+        for (int u = 0; u < SP_U; ++u) {
+            const u32 t = u * SP_THREADS + tid;
+            rec[u] = recs[min(t, t1 - 1)];
+            if (t >= t1) rec[u] = 0;
+        }
+        u32 nq = 0;
+        for (u32 tb = 0; tb < t1; tb += SP_U * SP_THREADS) {  // (workgroup-uniform bounds)
+            u64 cur[SP_U];
+#pragma unroll
+            for (int u = 0; u < SP_U; ++u) {
+                cur[u] = rec[u];
+                const u32 t = tb + (SP_U + u) * SP_THREADS + tid;
+                rec[u] = recs[min(t, t1 - 1)];
+                if (t >= t1) rec[u] = 0;
+            }
+#pragma unroll
+            for (int u = 0; u < SP_U; ++u) {
+                const u64 r = cur[u];
+                if (__ballot(r != 0) == 0ull) continue;  // (wave-uniform: most wave steps of most rows)
+                const bool is_list = (r & FZ_LIST) != 0;
+                if (!is_list) {
+                    const u32 f0 = (u32)r & FZ_FIELD, f1 = (u32)(r >> 21) & FZ_FIELD, f2 = (u32)(r >> 42) & FZ_FIELD;
+                    if (f0) add(f0 - 1u);
+                    if (f1) add(f1 - 1u);
+                    if (f2) add(f2 - 1u);
+                }
+                const u64 bal = __ballot(is_list);
+                if (bal) {
+                    const u32 c = (u32)__popcll(bal);
+                    if (nq + c > 64u) {
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        flush(nq);
+                        nq = 0;
+                    }
+                    if (is_list) lqueue[wid][nq + (u32)__popcll(bal & ((1ull << lane) - 1ull))] = r & ~FZ_LIST;  // {length << 40 | first entry}: the descriptor as it is
+                    nq += c;
+                }
+            }
+        }
+        if (nq) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            flush(nq);
+        }
+        __syncthreads();
+        const u32 nt = s_nt[par];
+        if (nt == 0) continue;  // (uniform) nothing touched: s_nt and the table are as they were
+        if (s_ovf[par]) {       // (uniform) handed back; the table is reset whole (rare)
+            __syncthreads();
+            for (u32 k = tid; k < SP_SLOTS; k += SP_THREADS) { tkey[k] = 0; tcnt[k] = 0; }
+            if (tid == 0) { p.ovf_rows[atomicAdd(p.ovf_count, 1u)] = (u32)a; s_nt[par] = 0; s_ovf[par] = 0; }
+            __syncthreads();
+            continue;
+        }
+        // survivors of the relaxed threshold among the touched columns (two walks over the list: count, then write)
+        u32 mine = 0;
+        for (u32 k0 = 0; k0 < nt; k0 += SP_THREADS) {
+            const u32 k = k0 + tid;
+            bool keep = false;
+            if (k < nt) { const u32 sl = tlist[k]; keep = pair_keep(tcnt[sl], (u32)a, tkey[sl] - 1u, p.sizes, p.c_relaxed); }
+            mine += (u32)__popcll(__ballot(keep));
+        }
+        if (lane == 0) wtot[wid] = mine;
+        __syncthreads();
+        if (tid == 0) {
+            u32 total = 0;
+            for (int v = 0; v < WAVES; ++v) total += wtot[v];
+            u64 base = seg * PAIR_SLOTS;
+            bool fits = true;
+            if (total > PAIR_SLOTS) {
+                const u64 at = atomicAdd(p.cursor, (unsigned long long)total);
+                base = p.nseg * PAIR_SLOTS + at;
+                fits = at + total <= p.cap;
+            }
+            p.segcnt[seg] = total;
+            p.segoff[seg] = base;
+            s_base = base;
+            s_write = (total && fits) ? 1u : 0u;
+            s_nt[par] = 0;
+        }
+        __syncthreads();
+        u64 dst = s_base;
+        for (u32 v = 0; v < wid; ++v) dst += wtot[v];
+        const bool wr = s_write != 0;
+        for (u32 k0 = 0; k0 < nt; k0 += SP_THREADS) {
+            const u32 k = k0 + tid;
+            bool keep = false;
+            u32 rj = 0, cnt = 0;
+            if (k < nt) {
+                const u32 sl = tlist[k];
+                rj = tkey[sl] - 1u;
+                cnt = tcnt[sl];
+                keep = pair_keep(cnt, (u32)a, rj, p.sizes, p.c_relaxed);
+                tkey[sl] = 0;  // the row's slots back to empty: nothing else is ever cleared
+                tcnt[sl] = 0;
+            }
+            const u64 bal = __ballot(keep);
+            if (keep && wr) p.out[dst + (u64)__popcll(bal & ((1ull << lane) - 1ull))] = make_uint2(rj, cnt);
+            dst += (u64)__popcll(bal);
+        }
+        __syncthreads();  // (the reset is complete before the next row's adds)
+    }
+}
+
 // a fused handle counts a reference's shared hashes only when asked (yh_db_nshared_device): its non-zero records, a wave per row
 __global__ void __launch_bounds__(256) k_fz_nshared(const u64* __restrict__ rec, const u64* __restrict__ off, u64 n_refs, u32* __restrict__ nshared) {
     const u64 a = (blockIdx.x * (u64)blockDim.x + threadIdx.x) >> 6;
@@ -451,6 +647,10 @@ int yh_q_pairwise(yh_db* db, double c_thresh, u64 r0, u64 r1) {
     if (ncb > 65535) { yh_set_error("too many column blocks"); return YH_ERR_UNSUPPORTED; }
     const u64 rows = r1 - r0;
     const u64 nseg = rows * ncb;
+    // Sparse rows (k_pair_rows_sparse) when a dense row takes more than one column block -- more than 28 672 references at 16-bit
+    // counts: the scale the reference publishes -- on a fused handle; YH_PAIR_SPARSE=0 / 1 forces either form (tests run both).
+    static const int sparse_env = [] { const char* e = yh_tune_env("YH_PAIR_SPARSE"); return e ? (e[0] == '1' ? 1 : e[0] == '0' ? 0 : -1) : -1; }();
+    const bool sparse = fz && (sparse_env < 0 ? ncb > 1 : sparse_env == 1);
 
     // scratch: [records 16 P | segoff 8 nseg | cursor 8 | tab 4 (2N + 1 + NC) | segcnt 4 nseg | cursors 4 N]
     const bool ranks = db->d_prank != nullptr || fz;
@@ -458,6 +658,7 @@ int yh_q_pairwise(yh_db* db, double c_thresh, u64 r0, u64 r1) {
     const u64 b_cnt = nseg * sizeof(u32), b_cur = ranks ? 0 : N * sizeof(u32);
     char* d_scr = nullptr;
     uint2* d_out = nullptr;
+    u32* d_ovf = nullptr;  // sparse rows: [count | the rows handed back to the dense pass]
     int rc = YH_OK;
 #define PW_HIP(call)                                                                          \
     if (rc == YH_OK) {                                                                        \
@@ -488,6 +689,7 @@ int yh_q_pairwise(yh_db* db, double c_thresh, u64 r0, u64 r1) {
     u32* d_segcnt = d_tab + b_tab / sizeof(u32);
     u32* d_cur = d_segcnt + nseg;
     uint2* d_out_own = nullptr;  // (a second attempt's larger output)
+    if (sparse) PW_HIP(yh_tmalloc(db, (void**)&d_ovf, (rows + 2) * sizeof(u32)));
     d_out = reinterpret_cast<uint2*>(d_scr + b_rec + b_meta_pad);
     if (!fz) PW_HIP(hipMemcpyAsync(d_tab, h_tab.data(), b_tab, hipMemcpyHostToDevice, st));
     if (!ranks) PW_HIP(hipMemsetAsync(d_cur, 0, b_cur, st));
@@ -518,11 +720,37 @@ int yh_q_pairwise(yh_db* db, double c_thresh, u64 r0, u64 r1) {
         PairRows q{d_rrec, d_rowptr, db->d_fz_rec, db->d_fz_off, fz ? db->d_fz_list : db->d_pr, db->d_fz_list2, fz ? db->fz_list_split : ~(u64)0, d_cid, d_rid, db->d_sizes, 0, 0, nseg,
                    (u32)NC, cols, c_relaxed, d_segcnt, d_segoff, d_cursor, cap, d_out};
         const u64 step = (1u << 31) / (u32)threads;  // (2^31 threads per grid dimension)
+        if (sparse) {
+            q.a0 = r0; q.seg0 = 0; q.rows = rows; q.ncb = ncb; q.ovf_count = d_ovf; q.ovf_rows = d_ovf + 1;
+            PW_HIP(hipMemsetAsync(d_ovf, 0, sizeof(u32), st));
+            // persistent workgroups, four to the CU (38 KB of LDS each); rows by stride
+            static const u32 sp_grid = [] { const char* e = yh_tune_env("YH_PAIR_SPARSE_GRID"); return e ? (u32)std::max(1, atoi(e)) : 0u; }();
+            static const u32 n_cus = [] { int dev = 0, v = 0; return (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? (u32)v : 256u; }();
+            const u32 grid = (u32)std::min<u64>(rows, sp_grid ? sp_grid : n_cus * 4u);
+            if (rc == YH_OK) k_pair_rows_sparse<<<grid, SP_THREADS, 0, st>>>(q);
+            u32 n_ovf = 0;
+            YhPin pin_ovf(64);
+            u32* h_ovf = pin_ovf.p ? static_cast<u32*>(pin_ovf.p) : &n_ovf;
+            PW_HIP(hipMemcpyAsync(h_ovf, d_ovf, sizeof(u32), hipMemcpyDeviceToHost, st));
+            PW_HIP(hipStreamSynchronize(st));
+            n_ovf = *h_ovf;
+            db->pw_sparse_rows = rows - n_ovf;
+            db->pw_dense_rows = n_ovf;
+            // the rows whose touched columns outgrew the table (hot k-mers): the dense pass, all their column blocks
+            q.rowlist = d_ovf + 1;
+            for (u64 b0 = 0; b0 < n_ovf && rc == YH_OK; b0 += step) {
+                const u64 nb = std::min<u64>(n_ovf - b0, step);
+                q.rowlist = d_ovf + 1 + b0;
+                kern<<<dim3((u32)nb, ncb), threads, (half ? (cols + 1) / 2 : cols) * sizeof(u32), st>>>(q);
+            }
+            q.rowlist = nullptr;
+        } else {
         for (u64 b0 = 0; b0 < rows && rc == YH_OK; b0 += step) {
             const u64 nb = std::min<u64>(rows - b0, step);
             q.a0 = r0 + b0;
             q.seg0 = b0 * ncb;
             kern<<<dim3((u32)nb, ncb), threads, (half ? (cols + 1) / 2 : cols) * sizeof(u32), st>>>(q);
+        }
         }
         PW_HIP(hipGetLastError());
         if (attempt == 0) yh_ring_record_end(db, db->ev_pair);
@@ -560,7 +788,7 @@ int yh_q_pairwise(yh_db* db, double c_thresh, u64 r0, u64 r1) {
         ho = v_out.data();
     }
 #undef PW_HIP
-    yh_tfree(db, d_scr); yh_tfree(db, d_out_own);
+    yh_tfree(db, d_scr); yh_tfree(db, d_out_own); yh_tfree(db, d_ovf);
     if (rc != YH_OK) return rc;
 
     // segments in row order (columns ascend inside a segment, column blocks inside a row), through the exact host-side
@@ -572,18 +800,28 @@ int yh_q_pairwise(yh_db* db, double c_thresh, u64 r0, u64 r1) {
     u32* hc = (u32*)malloc(std::max<size_t>(n_surv, 1) * sizeof(u32));
     if (!hi || !hj || !hc) { free(hi); free(hj); free(hc); yh_set_error("host allocation failed"); return YH_ERR_OOM; }
     size_t w = 0;
+    std::vector<u64> srt;
     for (u64 s = 0; s < nseg; ++s) {
         const u32 n = h_segcnt[s];
         if (!n) continue;
         const u32 i = (u32)(r0 + s / ncb);
         const u64 off = h_segoff[s];
         if (off + n > n_out) { free(hi); free(hj); free(hc); yh_set_error("pairwise: a segment outside the output"); return YH_ERR_HIP; }
+        const size_t w_row = w;
         for (u32 e = 0; e < n; ++e) {
             const uint2 v = ho[off + e];
             const double cij = 1.0 * v.y / hsizes[i];
             if (cij < c_thresh) continue;
             hi[w] = i; hj[w] = v.x; hc[w] = v.y;
             ++w;
+        }
+        if (sparse && w - w_row > 1) {  // a sparse row's survivors leave in the order its table's slots were claimed: by column here
+            srt.resize(w - w_row);
+            for (size_t e = 0; e < srt.size(); ++e) srt[e] = ((u64)hj[w_row + e] << 32) | hc[w_row + e];
+            if (!std::is_sorted(srt.begin(), srt.end())) {
+                std::sort(srt.begin(), srt.end());
+                for (size_t e = 0; e < srt.size(); ++e) { hj[w_row + e] = (u32)(srt[e] >> 32); hc[w_row + e] = (u32)srt[e]; }
+            }
         }
     }
     db->pw_n = w;

@@ -366,6 +366,8 @@ struct BucketArgs {
                                  // error: its bit is set, flags[2] counts it, and its pairs are grouped / sorted from a side list
     u32 rem_bits;                // != 0: PACKED pairs (k_piece_part): in_k = low rem_bits bits of the hash | reference << rem_bits
                                  // (inside a bucket the hashes span less than 2^rem_bits: the low bits identify them), in_v = position
+    u32 write_all;               // k_bucket_group5: EVERY pair stores the record of its position (0: nobody else holds its hash) --
+                                 // the records are not cleared in front of the distribution (round 6)
 };
 
 // exclusive scan of arr[0 .. ITEMS * blockDim.x) in place, ITEMS consecutive words per thread; two barriers (the second one
@@ -836,6 +838,11 @@ __global__ void __launch_bounds__(BKT_THREADS) k_bucket_group5(const BucketArgs 
             const u32 members = w >> 16;
             first = rank == 0u;
             shared = members != 0u;
+            // Round 6: a pair whose hash nobody else holds stores its (zero) record too -- every CSR position belongs to exactly one
+            // pair of exactly one bucket, so the records need no clearing pass in front of the distribution (0.40 GB of zeros at
+            // configs[3], written by k_piece_bounds until round 5), and a record line that this XCD's L2 collects from its buckets'
+            // pairs now leaves it WHOLE (2.7e7 records scattered over 5e7 positions cost 1.9 x their bytes in partly written lines).
+            if (!shared && a.write_all && val[k] < a.n_pos) a.rec[val[k]] = 0ull;
             if (shared) {
                 if (members <= 3u && a.inline_ok) {
                     // the other holders: the claimer (unless that is this pair) and the members but this one
@@ -1248,7 +1255,9 @@ __global__ void __launch_bounds__(256) k_spill_group(const u64* __restrict__ key
         head = i == first;
         shared = len >= 2;
         const u32 pos = sp[j];
-        if (shared && pos < n_pos) rec[pos] = (1ull << 63) | (len << 40) | (list_base + first);
+        // (every pair of a marked bucket stores its record -- zero when nobody else holds its hash: k_bucket_group5 left the whole
+        // bucket alone, and the records are not cleared beforehand)
+        if (pos < n_pos) rec[pos] = shared ? ((1ull << 63) | (len << 40) | (list_base + first)) : 0ull;
     }
     const u32 c0 = (u32)__popcll(__ballot(head)), c1 = (u32)__popcll(__ballot(head && shared)), c2 = (u32)__popcll(__ballot(shared));
     if ((threadIdx.x & 63u) == 0) { atomicAdd(&tot3[0], c0); atomicAdd(&tot3[1], c1); atomicAdd(&tot3[2], c2); }
@@ -1674,12 +1683,19 @@ int yh_pc_begin(yh_db* db, u64 H, u64 max_hash, u64 n_refs, u64* d_rec, yh_piece
     *out = s;
     return YH_OK;
 }
+// (the chained table of the two-level path, k_bucket_group, takes packed pairs too: YH_GROUP_CHAINS=1 behind the tuning gate; it
+// stores the records of shared hashes only, so with it the bounds pass clears them as it did until round 5)
+static bool pc_group_chains() {
+    static const bool chains = [] { const char* e = yh_tune_env("YH_GROUP_CHAINS"); return e && e[0] == '1'; }();
+    return chains;
+}
 static PieceArgs pc_args(const yh_pieces* s, const u64* d_values, const u64* d_offsets) {
     PieceArgs a{};
     a.values = d_values; a.off = d_offsets; a.n_refs = s->n_refs; a.bnd = s->bnd; a.n_pad = s->n_pad;
     a.P1 = s->P1; a.P2 = s->P2; a.S = s->S; a.Gn = s->Gn; a.SK = s->SK;
     a.mul = s->mul_fine; a.lsh = s->lsh; a.rem_bits = s->rem_bits; a.inv_p2 = s->inv_p2;
-    a.rec_clear = s->rec; a.out_a = s->a2; a.out_p = s->p2; a.out_cnt = s->cnt; a.flags = s->cnt + s->NB;
+    a.rec_clear = pc_group_chains() ? s->rec : nullptr;  // (k_bucket_group5 writes every position's record itself)
+    a.out_a = s->a2; a.out_p = s->p2; a.out_cnt = s->cnt; a.flags = s->cnt + s->NB;
     a.stride_k = s->stride_k; a.stride_v = s->stride_v;
     a.spill_a = s->spill_a; a.spill_p = s->spill_p; a.spill_b = s->spill_b; a.spill_cap = s->spill_cap;
     a.over_bits = s->cnt + s->NB + 4;
@@ -1746,8 +1762,8 @@ int yh_pc_finish_emit(yh_db* db, yh_pieces* s, const u64* d_values, const u64* d
     static const bool no_inline = [] { const char* e = yh_tune_env("YH_FZ_NO_INLINE"); return e && e[0] == '1'; }();
     b.inline_ok = (s->n_refs < (1u << 21) - 1 && !no_inline) ? 1u : 0u;
     b.totals = s->totals;
-    // (the chained table of the two-level path, k_bucket_group, takes packed pairs too: YH_GROUP_CHAINS=1 behind the tuning gate)
-    static const bool chains = [] { const char* e = yh_tune_env("YH_GROUP_CHAINS"); return e && e[0] == '1'; }();
+    const bool chains = pc_group_chains();
+    b.write_all = chains ? 0u : 1u;
     if (!chains) k_bucket_group5<<<8u * b.per_xcd, BKT_THREADS, 0, db->stream>>>(b);
     else k_bucket_group<<<8u * b.per_xcd, BKT_THREADS, 0, db->stream>>>(b);
     YH_HIP(hipGetLastError());

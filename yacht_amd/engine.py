@@ -172,6 +172,12 @@ class RefDB:
         _lib.check(self._lib.yh_index_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
 
+    def pairwise_row_stats(self) -> Tuple[int, int]:
+        """(rows the last pairwise() summed sparsely, rows it handed back to the dense pass) -- (0, 0): every row dense."""
+        a, b = C.c_uint64(), C.c_uint64()
+        _lib.check(self._lib.yh_pairwise_row_stats(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def set_stream(self, hip_stream: int) -> None:
         _lib.check(self._lib.yh_db_set_stream(self._h, C.c_void_p(hip_stream)))
 
