@@ -78,7 +78,7 @@ def parse_args():
                     help="N>1 with --shard hash: batched (default) = the samples of a block go through the batched kernels in ONE "
                          "pass per rank (a rank's share of one sample is too few lookups to fill a launch) around one exchange of "
                          "their subset words; steps = every sample is its own pair of half-steps, eight per bit exchange")
-    ap.add_argument("--batch-block", type=int, default=64, help="--block-mode batched: samples per block (<= 64)")
+    ap.add_argument("--batch-block", type=int, default=256, help="--block-mode batched: samples per block (<= 256: four word planes of 64 samples; 64 until round 5)")
     ap.add_argument("--no-scaling-model", action="store_true",
                     help="N=1: skip the measurement of one rank's share of a G-way hash-range step (G = 2, 4, 8)")
     ap.add_argument("--refs", type=int, default=0, help="override references per GPU (testing only)")
@@ -96,7 +96,7 @@ def parse_args():
                          "the exclusive pass of the one before) in the timed loop")
     ap.add_argument("--no-real-shape", action="store_true")
     ap.add_argument("--no-batched", action="store_true")
-    ap.add_argument("--batch-samples", type=int, default=64, help="samples per yh_run_batch_device call of the `batched` leg (<= 64)")
+    ap.add_argument("--batch-samples", type=int, default=64, help="samples per yh_run_batch_device call of the `batched` leg (<= 256)")
     ap.add_argument("--host-depth", type=int, default=4, help="host-inclusive leg: calls in flight (1..4)")
     ap.add_argument("--percentile-steps", type=int, default=200)
     ap.add_argument("--dense-reduce", action="store_true",
@@ -281,7 +281,7 @@ def main() -> int:
     H = int(values.numel())
     K = max(args.samples, 1)
     hash_batched = by_hash and args.block_mode == "batched"
-    BB = max(1, min(int(args.batch_block), 64))
+    BB = max(1, min(int(args.batch_block), 256))
     if hash_batched:
         K = max(K, BB)  # a block holds DISTINCT samples: a sample repeated inside one pass would find its own buckets cached
     samples = [synth.global_db_sample_device(plan, args.seed + 1000 + i, n_sample=args.sample_hashes, n_present=n_present,
@@ -814,7 +814,7 @@ def main() -> int:
     # the samples of a whole plate in hand.  Distinct samples, so that none finds its buckets cached.
     batched = None
     if not multi and not args.no_batched and args.workload == "gtdb_rs214_scale" and not args.no_indexed:
-        Bn = max(1, min(int(args.batch_samples), 64))
+        Bn = max(1, min(int(args.batch_samples), 256))
         bs = [samples[i] if i < K else synth.global_db_sample_device(plan, args.seed + 7000 + i, n_sample=args.sample_hashes,
                                                                      n_present=n_present, device=str(dev)) for i in range(Bn)]
         cat = torch.cat(bs).contiguous()
@@ -888,7 +888,7 @@ def main() -> int:
             torch.cuda.synchronize()
             el = (time.perf_counter() - t0) / n_g
             del cg
-        BM = max(1, min(int(args.batch_block), 64))
+        BM = max(1, min(int(args.batch_block), 256))
         # the throughput form: BM distinct samples per block (the block of --block-mode batched), three blocks in flight
         bsamp = [samples[i] if i < K else synth.global_db_sample_device(plan, args.seed + 7000 + i, n_sample=args.sample_hashes,
                                                                        n_present=n_present, device=str(dev)) for i in range(BM)]
@@ -929,7 +929,7 @@ def main() -> int:
         per_g = {}
         for G in (1, 2, 4, 8):
             per_g[str(G)] = share_of(G, values, offsets, n_local, single_steps=G > 1)
-        BM = max(1, min(int(args.batch_block), 64))
+        BM = max(1, min(int(args.batch_block), 256))
         # The collectives of a block, from their BYTES (nothing here is measured: this box has one GPU).  Stated constants:
         #   link   64 GB/s per direction and xGMI link (7 links x ~153 GB/s bidirectional per GPU, ~83 % of the wire rate as payload)
         #   lat    30 us per collective (RCCL launch, synchronisation and the first hop of a small message between 8 ranks)

@@ -207,9 +207,14 @@ int yh_run_indexed_device(yh_db* db, const uint64_t* d_sample, uint64_t n_sample
 
 /* Many samples against one resident database in one pass (needs
  * the directory; the reference runs one sample per process, run_YACHT.py:150).  `samples` holds
- * n_samples (1..64) sketches back to back, each strictly ascending, delimited by
+ * n_samples (1..YH_BATCH_MAX_SAMPLES) sketches back to back, each strictly ascending, delimited by
  * sample_offsets[n_samples + 1]; outputs are [n_samples][N] row-major.  For every sample the three
- * rows equal what yh_run returns for it alone.  total_hashes = sample_offsets[n_samples].       */
+ * rows equal what yh_run returns for it alone.  total_hashes = sample_offsets[n_samples].
+ * (ABI 8: 256 samples per call, 64 until ABI 7.  Per-sample state travels as 64-bit SUBSET WORDS in planes of 64
+ * samples: plane w = samples 64 w .. 64 w + 63, word [w * N + r], bit s - 64 w = sample s overlaps reference r;
+ * YH_BATCH_PLANES(n_samples) planes.  Up to 64 samples: the one array of N words of the earlier ABIs.)          */
+#define YH_BATCH_MAX_SAMPLES 256
+#define YH_BATCH_PLANES(n_samples) (((n_samples) + 63u) / 64u)
 int yh_run_batch(yh_db* db, const uint64_t* samples, const uint64_t* sample_offsets, uint32_t n_samples,
                  uint32_t* overlap, uint32_t* n_excl, uint32_t* n_match);
 int yh_run_batch_device(yh_db* db, const uint64_t* d_samples, const uint64_t* d_sample_offsets, uint32_t n_samples,
@@ -315,11 +320,12 @@ int yh_run_finish_range_device(yh_db* db, int ctx, const uint32_t* d_gathered_bi
 
 /* The same for MANY samples per call (yh_run_batch on a hash-range shard): a rank's share of one sample is only
  * |S| / n_ranks lookups -- a launch of that size is bound by launch and round-trip latencies, not by the lookups -- so the
- * throughput form takes up to 64 samples' slices at once, exchanges their subset words (one uint64 per reference: bit s =
- * sample s overlaps it) in ONE all-gather, and leaves one [n_samples, N] share per count row to be summed over the ranks:
+ * throughput form takes up to YH_BATCH_MAX_SAMPLES samples' slices at once, exchanges their subset words (one uint64 per
+ * reference and plane of 64 samples: bit s = sample s of the plane overlaps it) in ONE all-gather, and leaves one
+ * [n_samples, N] share per count row to be summed over the ranks (P = YH_BATCH_PLANES(n_samples)):
  *   yh_run_batch_local_range_device    lookups of the concatenated slices (d_sample_offsets[n_samples + 1] delimits them);
- *                                      d_overlap [n_samples][N] = this rank's share; d_maskwords_out [N] its subset words
- *   yh_run_batch_finish_range_device   subset = OR of the n_ranks gathered word arrays ([n_ranks][N]); d_n_excl, d_n_match
+ *                                      d_overlap [n_samples][N] = this rank's share; d_maskwords_out [P][N] its subset words
+ *   yh_run_batch_finish_range_device   subset = OR of the n_ranks gathered word arrays ([n_ranks][P][N]); d_n_excl, d_n_match
  *                                      [n_samples][N] = this rank's shares (d_overlap: what the first half left)
  * The two halves of a batch share one of YH_BATCH_SLOTS batch slots of the handle (the first half's hits on shared hashes
  * wait there for the second): with several slots the subset words of block j travel while the lookups of block j + 1 run,
@@ -351,7 +357,7 @@ int yh_db_set_batch_finish_stream(yh_db* db, void* hip_stream);
 /* ---- the result of a batch in compact form: north star's "final gather of the per-reference counts" -------------------
  * The three [n_samples][N] rows of a batch are almost all zero (a 10^6-hash metagenome overlaps a few hundred of 85 205
  * references): what has to leave the GPU -- to the host, or to the rank that sums the shares of a hash-range run -- is
- * one entry per (reference r, sample s) of the batch's subset, i.e. per set bit s of the slot's subset word of r, in
+ * one entry per (reference r, sample s) of the batch's subset, i.e. per set bit of the slot's subset words of r, in
  * (r, s) order.  On hash-range shards the subset is the GLOBAL one after the second half, so EVERY rank has the same
  * entries in the same order and only the VALUES differ: a rank packs its three shares per entry, the value arrays are
  * summed over the ranks as they are (12 bytes per entry and rank on the wire, no keys), and the consumer unpacks rows:
@@ -373,20 +379,21 @@ int yh_run_batch_rows_unpack_device(yh_db* db, int slot, const uint32_t* d_vals,
  * overlaps ~15 000 of 85 205 references -- so a rank all-gathers its NON-ZERO words instead:
  *   yh_run_batch_words_packed_len    uint64 words a packed buffer of capacity cap_words takes: 1 + cap + ceil(cap / 2)
  *                                    ([0] = the rank's number of non-zero words, then the words, then 32-bit reference ids)
- *   yh_run_batch_words_pack_device   d_words [N] (what yh_run_batch_local_range_device left) -> d_packed; the count in
- *                                    [0] is the true one even when it exceeds cap_words (then only cap_words entries
- *                                    were written)
+ *   yh_run_batch_words_pack_device   d_words [n_planes][N] (what yh_run_batch_local_range_device left; n_planes =
+ *                                    YH_BATCH_PLANES of the block's samples -- ABI 8) -> d_packed; an entry's 32-bit id is
+ *                                    its word's index in that array (plane * N + reference); the count in [0] is the true
+ *                                    one even when it exceeds cap_words (then only cap_words entries were written)
  *   yh_run_batch_words_unpack_device d_gathered = n_ranks packed buffers back to back (an all-gather's output) ->
- *                                    d_words_out [N] = their OR -- pass it to yh_run_batch_finish_range_device with
- *                                    n_ranks = 1 --; *d_overflow = 1 when some rank had more words than cap_words (the
+ *                                    d_words_out [n_planes][N] = their OR -- pass it to yh_run_batch_finish_range_device
+ *                                    with n_ranks = 1 --; *d_overflow = 1 when some rank had more words than cap_words (the
  *                                    OR is then incomplete and the caller repeats the exchange with a larger capacity
- *                                    or with the dense rows), else 0.  Reference ids >= N are ignored.
+ *                                    or with the dense rows), else 0.  Ids >= n_planes * N are ignored.
  * No handle state is read or written but the stream and N: both are enqueued on the handle's stream (on the finish stream
  * when one is set: yh_db_set_batch_finish_stream), no host sync, and may run at any point of the interleaving table above.  (No reference counterpart: run_YACHT.py:150 runs one sample per
  * process on one machine.)                                                                                              */
 uint64_t yh_run_batch_words_packed_len(uint64_t cap_words);
-int yh_run_batch_words_pack_device(yh_db* db, const uint64_t* d_words, uint64_t* d_packed, uint64_t cap_words);
-int yh_run_batch_words_unpack_device(yh_db* db, const uint64_t* d_gathered, uint32_t n_ranks, uint64_t cap_words,
+int yh_run_batch_words_pack_device(yh_db* db, const uint64_t* d_words, uint32_t n_planes, uint64_t* d_packed, uint64_t cap_words);
+int yh_run_batch_words_unpack_device(yh_db* db, const uint64_t* d_gathered, uint32_t n_ranks, uint32_t n_planes, uint64_t cap_words,
                                      uint64_t* d_words_out, uint32_t* d_overflow);
 
 /* Pipelined host-buffer form of yh_run: SURVEY.md 8d's steady-state call -- sample H2D, kernels,

@@ -65,7 +65,8 @@ class SetRangeBackend:
             def batch_local(self, cat_t, soff_t, n_samples, total, ov_t, words_t, slot=0):
                 cat = cat_t.numpy().view(np.uint64)
                 off = soff_t.numpy()
-                words = np.zeros(len(refs), dtype=np.uint64)
+                N_ = len(refs)
+                words = np.zeros(((n_samples + 63) // 64) * N_, dtype=np.uint64)  # planes of 64 samples: word [(s >> 6) * N + r], bit s & 63
                 self._slots = getattr(self, "_slots", {})
                 self._hit = self._slots.setdefault(slot, {})["hit"] = []
                 for s in range(n_samples):
@@ -73,16 +74,18 @@ class SetRangeBackend:
                     self._hit.append(S)
                     ov = np.array([len(S & r) for r in refs], dtype=np.int32)
                     ov_t[s] = torch.from_numpy(ov)
-                    words |= (ov > 0).astype(np.uint64) << np.uint64(s)
-                words_t.copy_(torch.from_numpy(words.view(np.int64)))
+                    words[(s >> 6) * N_: (s >> 6) * N_ + N_] |= (ov > 0).astype(np.uint64) << np.uint64(s & 63)
+                words_t.view(-1)[: words.size].copy_(torch.from_numpy(words.view(np.int64)))
 
             def batch_finish(self, n_samples, gathered_t, n_ranks, ov_t, e_t, m_t, slot=0):
-                words = np.bitwise_or.reduce(gathered_t.numpy().view(np.uint64)[:n_ranks], axis=0)
+                N_ = len(refs)
+                nw = ((n_samples + 63) // 64) * N_
+                words = np.bitwise_or.reduce(gathered_t.numpy().view(np.uint64).reshape(gathered_t.shape[0], -1)[:n_ranks, :nw], axis=0)
                 self._slots[slot]["words"] = words.copy()
                 self._slots[slot]["n"] = n_samples
                 hit = self._slots[slot]["hit"]
                 for s in range(n_samples):
-                    mask = ((words >> np.uint64(s)) & np.uint64(1)).astype(bool)
+                    mask = ((words[(s >> 6) * N_: (s >> 6) * N_ + N_] >> np.uint64(s & 63)) & np.uint64(1)).astype(bool)
                     S = hit[s]
                     e = np.zeros(len(refs), dtype=np.int32)
                     m = np.zeros(len(refs), dtype=np.int32)
@@ -106,7 +109,7 @@ class SetRangeBackend:
 
             def words_unpack(self, gathered_t, n_ranks, cap, words_out_t, overflow_t):
                 g = gathered_t.numpy().view(np.uint64).reshape(n_ranks, -1)
-                acc = np.zeros(len(refs), dtype=np.uint64)
+                acc = np.zeros(words_out_t.numel(), dtype=np.uint64)
                 ov = 0
                 for k in range(n_ranks):
                     n = int(g[k, 0])
@@ -119,7 +122,7 @@ class SetRangeBackend:
 
             def _entries(self, slot):  # (reference, sample) of every set bit of the slot's global words, in that order
                 words, n = self._slots[slot]["words"], self._slots[slot]["n"]
-                return [(r, s_) for r in range(len(refs)) for s_ in range(n) if (int(words[r]) >> s_) & 1]
+                return [(r, s_) for r in range(len(refs)) for s_ in range(n) if (int(words[(s_ >> 6) * len(refs) + r]) >> (s_ & 63)) & 1]
 
             def rows_pack(self, counts_t, vals_t, nrows_t, slot=0):
                 ent = self._entries(slot)
@@ -292,6 +295,29 @@ def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
                 for (rep, j), dense in got.items():
                     for k, smp in enumerate(blocks[j]):
                         check(dense[:, k, :], smp, f"runner {kw} round {rep} block {j} sample {k}")
+        # blocks of MORE than 64 samples (round 6: subset words in planes of 64 samples, up to 256 per block): 70, 130 and 5
+        # samples through a runner of batch 130 -- entries of planes 1 and 2, a partly filled last plane, an undersized exchange
+        big = [[samples[k % 5] for k in range(70)], [samples[(3 * k + 1) % 5] if k % 7 else np.zeros(0, np.uint64) for k in range(130)], samples]
+        tbig = [[torch.from_numpy(x.view(np.int64).copy()) for x in blk_] for blk_ in big]
+        for kw in (dict(), dict(cap_words=5, cap_rows=9), dict(compact_words=False, nbuf=2)):
+            got = {}
+
+            def on_big(tag, n_in, rows, dense):
+                if rank == 0:
+                    got[tag] = dense[:, :n_in].clone() if rows is None else ydist.BatchRowsReducer.rows_to_dense(rows, n_in, hr.n_total)
+
+            run = ydist.BatchedRangeRunner(hr, batch=130, dst=0, on_result=on_big, **kw)
+            assert run.planes == 3 and run.words[0].numel() == 3 * hr.n_total
+            for j, blk_ in enumerate(tbig):
+                run.submit(hr.pack_batch(blk_), len(blk_), tag=j)
+            run.drain()
+            if "cap_words" in kw:
+                assert run.n_words_overflow >= 1 and run.red.n_overflow >= 1
+            if rank == 0:
+                for j, blk_ in enumerate(big):
+                    for k in (0, 1, 63, 64, 65, 69, 127, 128, 129):
+                        if k < len(blk_):
+                            check(got[j][:, k, :], blk_[k], f"big blocks {kw} block {j} sample {k}")
         open(os.path.join(out_dir, f"ok{rank}"), "w").close()
     finally:
         dist.destroy_process_group()

@@ -65,6 +65,14 @@ def test_batch_matches_oracle_ragged(hip_lib):
         _check(values, offsets, _samples(values, offsets, b, seed=100 + b))
 
 
+@pytest.mark.parametrize("b", [65, 128, 200, 256])
+def test_batch_of_more_than_64_samples(hip_lib, b):
+    """Round 6 (ABI 8): up to 256 samples per pass -- the subset words in planes of 64 samples.  Related references (many shared
+    hashes: the exclusive pass works plane by plane), an empty sample, ragged lengths; every sample against the oracle."""
+    values, offsets = synth.config4(seed=36, n_clusters=30, size=200)
+    _check(values, offsets, _samples(values, offsets, b, seed=200 + b, noise=150))
+
+
 def test_batch_same_sample_repeated(hip_lib):
     """All 64 bit lanes carry the same sample: every row must be identical to the single run."""
     values, offsets = synth.config4(seed=33, n_clusters=20, size=300)
@@ -84,7 +92,7 @@ def test_batch_errors(hip_lib):
             db.run_batch([smp])
     with RefDB(values, offsets, flags=FULL) as db:
         with pytest.raises(_lib.YachtHipError):
-            db.run_batch([smp] * 65)
+            db.run_batch([smp] * 257)
         with pytest.raises(_lib.YachtHipError):
             db.run_batch([smp[::-1].copy()])
 
@@ -217,13 +225,18 @@ def test_runner_second_halves_on_their_own_stream(hip_lib, finish_stream):
     blocks = [_samples(values, offsets, 1 + (7 * j) % 9, seed=500 + j) for j in range(14)]
     hr = ydist.HashRangeRefDB(vt, ot, [0, 2 ** 64], ydist.HipRangeBackend(0))
     try:
-        for kw in (dict(), dict(cap_words=2), dict(dense_rows=True), dict(compact_words=False)):
+        for kw in (dict(), dict(cap_words=2), dict(dense_rows=True), dict(compact_words=False),
+                   # blocks of up to 200 samples: three word planes through the same three slots (round 6)
+                   dict(batch=200), dict(batch=200, cap_words=7, cap_rows=11), dict(batch=256, compact_words=False)):
+            if "batch" in kw:
+                blocks = [_samples(values, offsets, nb, seed=900 + j, noise=60) for j, nb in enumerate((200, 65, 3, 130, 64, 200, 1, 199))]
+            kw = dict(dict(batch=9), **kw)
             got = {}
 
             def on_result(tag, n_in, rows, dense):
                 got[tag] = (dense[:, :n_in].clone() if rows is None else ydist.BatchRowsReducer.rows_to_dense(rows, n_in, n)).cpu().numpy()
 
-            run = ydist.BatchedRangeRunner(hr, batch=9, dst=0, nbuf=3, on_result=on_result, finish_stream=finish_stream, **kw)
+            run = ydist.BatchedRangeRunner(hr, dst=0, nbuf=3, on_result=on_result, finish_stream=finish_stream, **kw)
             assert (run.s2 is not None) == finish_stream
             packed = [hr.pack_batch([torch.from_numpy(s.view(np.int64).copy()).to(dev) for s in blk]) for blk in blocks]
             for rep in range(2):

@@ -130,8 +130,8 @@ SIGNATURES = {
     "yh_run_batch_rows_pack_device": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, C.c_uint64, _vp]),
     "yh_run_batch_rows_unpack_device": (C.c_int, [_vp, C.c_int, _vp, C.c_uint64, _vp, _vp]),
     "yh_run_batch_words_packed_len": (C.c_uint64, [C.c_uint64]),
-    "yh_run_batch_words_pack_device": (C.c_int, [_vp, _vp, _vp, C.c_uint64]),
-    "yh_run_batch_words_unpack_device": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint64, _vp, _vp]),
+    "yh_run_batch_words_pack_device": (C.c_int, [_vp, _vp, C.c_uint32, _vp, C.c_uint64]),
+    "yh_run_batch_words_unpack_device": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.c_uint64, _vp, _vp]),
     "yh_run_submit": (C.c_int, [_vp, C.c_int, _vp, C.c_uint64, _vp, _vp, _vp]),
     "yh_run_wait": (C.c_int, [_vp, C.c_int]),
     "yh_sample_pack_bound": (C.c_uint64, [C.c_uint64]),

@@ -847,7 +847,7 @@ int yh_run_batch_device(yh_db* db, const uint64_t* d_samples, const uint64_t* d_
 int yh_run_batch(yh_db* db, const uint64_t* samples, const uint64_t* sample_offsets, uint32_t n_samples,
                  uint32_t* overlap, uint32_t* n_excl, uint32_t* n_match) {
     if (!db_ok(db)) return YH_ERR_INVALID_ARG;
-    if (!sample_offsets || n_samples < 1 || n_samples > 64) { yh_set_error("1..64 samples and their offsets"); return YH_ERR_INVALID_ARG; }
+    if (!sample_offsets || n_samples < 1 || n_samples > YH_BATCH_MAX_SAMPLES) { yh_set_error("1..%d samples and their offsets", YH_BATCH_MAX_SAMPLES); return YH_ERR_INVALID_ARG; }
     const u64 total = sample_offsets[n_samples];
     const u64 N = db->n_refs;
     if (sample_offsets[0] != 0 || (total && !samples) || (N && (!overlap || !n_excl || !n_match))) {
@@ -1244,7 +1244,7 @@ int yh_run_finish_range_device(yh_db* db, int ctx, const uint32_t* d_gathered_bi
     return yh_q_range_finish(db, d_gathered_bits, n_ranks, stride_words, d_n_excl);
 }
 
-// the batched run on a hash-range shard: up to 64 samples per call around ONE exchange of their subset words
+// the batched run on a hash-range shard: up to YH_BATCH_MAX_SAMPLES samples per call around ONE exchange of their subset words
 static_assert(YH_BATCH_SLOTS == 3, "yh_db_destroy frees the scratch of three batch slots");
 static bool batch_slot_ok(int slot) {
     if (slot >= 0 && slot < YH_BATCH_SLOTS) return true;
@@ -1314,19 +1314,26 @@ int yh_run_batch_rows_unpack_device(yh_db* db, int slot, const uint32_t* d_vals,
 }
 
 uint64_t yh_run_batch_words_packed_len(uint64_t cap_words) { return yh_batch_words_packed_len(cap_words); }
-int yh_run_batch_words_pack_device(yh_db* db, const uint64_t* d_words, uint64_t* d_packed, uint64_t cap_words) {
+static bool batch_planes_ok(const yh_db* db, uint32_t n_planes) {
+    if (n_planes >= 1 && n_planes <= YH_BATCH_PLANES(YH_BATCH_MAX_SAMPLES) && (u64)n_planes * db->n_refs < 0xffffffffull) return true;
+    yh_set_error("n_planes must be 1..%d (and n_planes * N below 2^32: an entry's id is 32 bits)", (int)YH_BATCH_PLANES(YH_BATCH_MAX_SAMPLES));
+    return false;
+}
+int yh_run_batch_words_pack_device(yh_db* db, const uint64_t* d_words, uint32_t n_planes, uint64_t* d_packed, uint64_t cap_words) {
     if (!db_ok(db)) return YH_ERR_INVALID_ARG;
     if (!d_packed || (db->n_refs && !d_words)) { yh_set_error("null device pointer"); return YH_ERR_INVALID_ARG; }
+    if (!batch_planes_ok(db, n_planes)) return YH_ERR_INVALID_ARG;
     YH_TRY(db_select(db));
-    return yh_q_batch_words_pack(db, (const u64*)d_words, (u64*)d_packed, cap_words);
+    return yh_q_batch_words_pack(db, (const u64*)d_words, n_planes, (u64*)d_packed, cap_words);
 }
-int yh_run_batch_words_unpack_device(yh_db* db, const uint64_t* d_gathered, uint32_t n_ranks, uint64_t cap_words,
+int yh_run_batch_words_unpack_device(yh_db* db, const uint64_t* d_gathered, uint32_t n_ranks, uint32_t n_planes, uint64_t cap_words,
                                      uint64_t* d_words_out, uint32_t* d_overflow) {
     if (!db_ok(db)) return YH_ERR_INVALID_ARG;
     if (!d_gathered || !d_overflow || (db->n_refs && !d_words_out)) { yh_set_error("null device pointer"); return YH_ERR_INVALID_ARG; }
     if (n_ranks < 1 || n_ranks > 65535) { yh_set_error("n_ranks out of range"); return YH_ERR_INVALID_ARG; }
+    if (!batch_planes_ok(db, n_planes)) return YH_ERR_INVALID_ARG;
     YH_TRY(db_select(db));
-    return yh_q_batch_words_unpack(db, (const u64*)d_gathered, n_ranks, cap_words, (u64*)d_words_out, d_overflow);
+    return yh_q_batch_words_unpack(db, (const u64*)d_gathered, n_ranks, n_planes, cap_words, (u64*)d_words_out, d_overflow);
 }
 
 // ---- pipelined host-buffer run calls ---------------------------------------------------------------

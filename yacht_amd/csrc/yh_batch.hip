@@ -1,4 +1,4 @@
-// yh_batch.hip -- batched `yacht run`: up to 64 samples against the resident database in one pass
+// yh_batch.hip -- batched `yacht run`: up to 256 samples against the resident database in one pass
 #include "yh_common.h"
 
 #include <stdlib.h>
@@ -14,7 +14,15 @@
 // sample hash of ANY sample.  Per-sample state is carried as 64-bit words: maskword[r] = samples that overlap
 // reference r.  Exclusivity for all samples at once, over a reference's DISTINCT holder sets (k_batch_sets):
 //     excl = maskword[r] & ~(OR of the other holders' words).
+// Round 6: up to YH_BATCH_MAX_SAMPLES = 256 samples per pass.  The words come in PLANES of 64 samples -- plane w = samples
+// 64 w .. 64 w + 63, maskword[w * N + r] -- so a batch of <= 64 samples is exactly the one-plane layout of rounds 3-5, and a
+// hash-range rank whose share of a block is an eighth of every sample gets four times the lookups per block for the same
+// dozen launches at their floors (<= 64 samples capped an eight-rank block at 8e6 lookups).
 namespace {
+
+constexpr u32 BATCH_MAX = 256;                    // samples per batch (include/yacht_hip.h: YH_BATCH_MAX_SAMPLES)
+constexpr u32 BATCH_MAX_PLANES = BATCH_MAX / 64;  // word planes a slot's scratch has room for
+inline u32 planes_of(u32 n_samples) { return (n_samples + 63u) / 64u; }
 
 constexpr int EXCL_BLOCK = 256;
 inline u32 grid_for(u64 work_items, u32 block, u32 max_blocks = 16384) {
@@ -47,15 +55,17 @@ __global__ void __launch_bounds__(256) k_batch_lookup(const u64* __restrict__ sa
                                                       u32* __restrict__ overlap /* [B][N] */, u32* __restrict__ ovsh /* [B][N]: hits on shared hashes */,
                                                       const u32* __restrict__ filter, u64 filter_mul) {
     constexpr u32 TSLOTS = 1u << BATCH_TBITS;
-    __shared__ u64 off[65];
+    __shared__ u64 off[BATCH_MAX + 1];
     __shared__ u64 s_max_nt;
     __shared__ u32 tkey[TSLOTS], tcnt[TSLOTS], tcnt2[TSLOTS];
-    if (threadIdx.x <= n_samples) off[threadIdx.x] = soff[threadIdx.x];
+    for (u32 q = threadIdx.x; q <= n_samples; q += 256) off[q] = soff[q];
+    if (threadIdx.x == 0) s_max_nt = 0;
     __syncthreads();
-    if (threadIdx.x == 0) {
+    {   // the longest sample's tiles (one wave: a maximum over <= 256 lengths)
         u64 m = 0;
-        for (u32 q = 0; q < n_samples; ++q) m = max(m, (off[q + 1] - off[q] + BATCH_TILE - 1) / BATCH_TILE);
-        s_max_nt = m;
+        if (threadIdx.x < 64)
+            for (u32 q = threadIdx.x; q < n_samples; q += 64) m = max(m, (off[q + 1] - off[q] + BATCH_TILE - 1) / BATCH_TILE);
+        if (threadIdx.x < 64 && m) atomicMax((unsigned long long*)&s_max_nt, (unsigned long long)m);
     }
     __syncthreads();
     const u64 max_nt = s_max_nt;
@@ -173,22 +183,27 @@ __global__ void __launch_bounds__(256) k_batch_lookup(const u64* __restrict__ sa
 __global__ void __launch_bounds__(256) k_batch_maskwords(const u32* __restrict__ overlap, u32 n_samples, u64 n_refs,
                                                          u64* __restrict__ maskword, u32* __restrict__ anybits) {
     const u64 r = blockIdx.x * (u64)blockDim.x + threadIdx.x;
-    u64 w = 0;
-    if (r < n_refs) {
-        // eight rows requested together (one row a step, each load waited for before the next was asked: 29.6 us for the 21.8 MB of a
-        // block of 64 -- 0.74 TB/s: profiles/r05/batch_share_kernels.txt)
-        u32 s = 0;
-        for (; s + 8 <= n_samples; s += 8) {
-            u32 v[8];
+    u64 any = 0;
+    for (u32 s0 = 0; s0 < n_samples; s0 += 64) {  // (uniform) one plane of 64 samples a round
+        const u32 ns = min(64u, n_samples - s0);
+        u64 w = 0;
+        if (r < n_refs) {
+            // eight rows requested together (one row a step, each load waited for before the next was asked: 29.6 us for the 21.8 MB of a
+            // block of 64 -- 0.74 TB/s: profiles/r05/batch_share_kernels.txt)
+            u32 s = 0;
+            for (; s + 8 <= ns; s += 8) {
+                u32 v[8];
 #pragma unroll
-            for (u32 q = 0; q < 8; ++q) v[q] = overlap[(u64)(s + q) * n_refs + r];
+                for (u32 q = 0; q < 8; ++q) v[q] = overlap[(u64)(s0 + s + q) * n_refs + r];
 #pragma unroll
-            for (u32 q = 0; q < 8; ++q) w |= (u64)(v[q] != 0) << (s + q);
+                for (u32 q = 0; q < 8; ++q) w |= (u64)(v[q] != 0) << (s + q);
+            }
+            for (; s < ns; ++s) w |= (u64)(overlap[(u64)(s0 + s) * n_refs + r] != 0) << s;
+            maskword[(u64)(s0 >> 6) * n_refs + r] = w;
         }
-        for (; s < n_samples; ++s) w |= (u64)(overlap[(u64)s * n_refs + r] != 0) << s;
+        any |= w;
     }
-    if (r < n_refs) maskword[r] = w;
-    const u64 bal = __ballot(w != 0);
+    const u64 bal = __ballot(any != 0);
     if (anybits && (threadIdx.x & 63) == 0) {  // (nullptr: a first half whose second half makes its own -- k_batch_or_maskwords)
         anybits[(r >> 5)] = (u32)bal;
         anybits[(r >> 5) + 1] = (u32)(bal >> 32);
@@ -238,13 +253,17 @@ __global__ void __launch_bounds__(256) k_batch_worklist(u64 n, const u32* __rest
 __global__ void __launch_bounds__(256) k_batch_sets(const uint4* __restrict__ work, const u32* __restrict__ work_count,
                                                     const uint4* __restrict__ hrec, const uint4* __restrict__ hrecx,
                                                     const u32* __restrict__ hmult, const u32* __restrict__ pr,
-                                                    const u64* __restrict__ maskword, u64 n_refs, u32* __restrict__ ex_e) {
+                                                    const u64* __restrict__ maskword_all, u64 n_refs, u32* __restrict__ ex_e_all, u32 n_planes) {
     const u32 lane = threadIdx.x & 63u;
     const u32 n_work = *work_count;
     for (u32 w = blockIdx.x * 4u + (threadIdx.x >> 6); w < n_work; w += gridDim.x * 4u) {
         const uint4 piece = work[w];
         const u32 r = piece.x;
+        for (u32 pl = 0; pl < n_planes; ++pl) {  // (wave-uniform) the planes of 64 samples, one after the other: the records come from the L2 again
+        const u64* maskword = maskword_all + (u64)pl * n_refs;
+        u32* ex_e = ex_e_all + (u64)pl * 64u * n_refs;
         const u64 wr = maskword[r];
+        if (wr == 0) continue;  // no sample of this plane overlaps r
         for (u32 first = piece.y; first < piece.z; first += 256u) {  // (wave-uniform; one round unless YH_EXCL_PIECE > 256)
         u64 excl[4];
         u32 mu[4];
@@ -289,18 +308,23 @@ __global__ void __launch_bounds__(256) k_batch_sets(const uint4* __restrict__ wo
             if (lane == 0 && v) atomicAdd(&ex_e[(u64)s * n_refs + r], v);
         }
         }
+        }
     }
 }
 
 // hash-range shards: maskword[r] = OR over the ranks' gathered words; anybits as k_batch_maskwords makes them
-__global__ void __launch_bounds__(256) k_batch_or_maskwords(const u64* __restrict__ gathered, u32 n_ranks, u64 n_refs,
-                                                            u64* __restrict__ maskword, u32* __restrict__ anybits) {
+__global__ void __launch_bounds__(256) k_batch_or_maskwords(const u64* __restrict__ gathered /* [n_ranks][n_planes][N] */, u32 n_ranks, u64 n_refs,
+                                                            u64* __restrict__ maskword, u32* __restrict__ anybits, u32 n_planes) {
     const u64 r = blockIdx.x * (u64)blockDim.x + threadIdx.x;
-    u64 w = 0;
+    u64 any = 0;
     if (r < n_refs)
-        for (u32 k = 0; k < n_ranks; ++k) w |= gathered[(u64)k * n_refs + r];
-    if (r < n_refs) maskword[r] = w;
-    const u64 bal = __ballot(w != 0);
+        for (u32 pl = 0; pl < n_planes; ++pl) {
+            u64 w = 0;
+            for (u32 k = 0; k < n_ranks; ++k) w |= gathered[((u64)k * n_planes + pl) * n_refs + r];
+            maskword[(u64)pl * n_refs + r] = w;
+            any |= w;
+        }
+    const u64 bal = __ballot(any != 0);
     if ((threadIdx.x & 63) == 0) {
         anybits[(r >> 5)] = (u32)bal;
         anybits[(r >> 5) + 1] = (u32)(bal >> 32);
@@ -324,7 +348,8 @@ __global__ void __launch_bounds__(256) k_batch_final(u32 n_samples, u64 n_refs, 
         // has 22 MB less to clear in front of its lookups: BatchSlot::ovsh_clean); only the few non-zero ones are written
         const u32 sh = ovsh[t];
         if (sh) ovsh[t] = 0;
-        const bool in = maskword ? ((maskword[r] >> (t / n_refs)) & 1ull) != 0 : ov != 0;
+        const u64 smp = t / n_refs;
+        const bool in = maskword ? ((maskword[(smp >> 6) * n_refs + r] >> (smp & 63u)) & 1ull) != 0 : ov != 0;
         if (in) {
             ex_e[t] = sizes[r] - nshared[r] + ex_e[t];
             ex_m[t] = ov - sh;
@@ -341,12 +366,13 @@ __global__ void __launch_bounds__(256) k_batch_final(u32 n_samples, u64 n_refs, 
 // scans its own references' popcounts and writes -- PACK: the three values of every entry from the dense rows; else the
 // rows themselves from the (summed) values.
 constexpr u32 ROWS_BLOCK = 256;  // references per workgroup of the row kernels (2 048: 42 workgroups for 85 205 references -- 13 us a pass; 256: 333)
-__global__ void __launch_bounds__(256) k_batch_rows_count(const u64* __restrict__ maskword, u64 n_refs, u32* __restrict__ blk_count) {
+__global__ void __launch_bounds__(256) k_batch_rows_count(const u64* __restrict__ maskword, u64 n_refs, u32 n_planes, u32* __restrict__ blk_count) {
     __shared__ u32 part[4];
     const u64 r0 = (u64)blockIdx.x * ROWS_BLOCK;
     u32 c = 0;
     for (u32 k = threadIdx.x; k < ROWS_BLOCK; k += 256)
-        if (r0 + k < n_refs) c += (u32)__popcll(maskword[r0 + k]);
+        if (r0 + k < n_refs)
+            for (u32 pl = 0; pl < n_planes; ++pl) c += (u32)__popcll(maskword[(u64)pl * n_refs + r0 + k]);
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) c += (u32)__shfl_xor((int)c, off);
     if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6] = c;
@@ -358,7 +384,7 @@ __global__ void __launch_bounds__(256) k_batch_rows_emit(const u64* __restrict__
                                                          const u32* __restrict__ blk_count, u32 n_blocks,
                                                          const u32* __restrict__ overlap, const u32* __restrict__ excl,
                                                          const u32* __restrict__ match, u32* __restrict__ vals /* PACK: out, else in */,
-                                                         yh_batch_row* __restrict__ rows, u64 cap, u32* __restrict__ n_rows) {
+                                                         yh_batch_row* __restrict__ rows, u64 cap, u32* __restrict__ n_rows, u32 n_planes) {
     __shared__ u32 part[4];
     __shared__ u32 wave_base[5];
     const u32 lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
@@ -373,8 +399,13 @@ __global__ void __launch_bounds__(256) k_batch_rows_emit(const u64* __restrict__
     const u64 r0 = (u64)blockIdx.x * ROWS_BLOCK;
     for (u32 k0 = 0; k0 < ROWS_BLOCK; k0 += 256) {  // (workgroup-uniform)
         const u64 r = r0 + k0 + threadIdx.x;
-        u64 w = r < n_refs ? maskword[r] : 0ull;
-        const u32 c = (u32)__popcll(w);
+        u64 wp[BATCH_MAX_PLANES];  // the reference's words, plane by plane: its entries in (reference, sample) order
+        u32 c = 0;
+#pragma unroll
+        for (u32 pl = 0; pl < BATCH_MAX_PLANES; ++pl) {
+            wp[pl] = (pl < n_planes && r < n_refs) ? maskword[(u64)pl * n_refs + r] : 0ull;
+            c += (u32)__popcll(wp[pl]);
+        }
         u32 inc = c;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -387,8 +418,11 @@ __global__ void __launch_bounds__(256) k_batch_rows_emit(const u64* __restrict__
         u32 at = base + inc - c;
         for (u32 q = 0; q < wv; ++q) at += wave_base[q];
         base += wave_base[0] + wave_base[1] + wave_base[2] + wave_base[3];
+#pragma unroll
+        for (u32 pl = 0; pl < BATCH_MAX_PLANES; ++pl) {
+        u64 w = wp[pl];
         while (w) {
-            const u32 s = (u32)__ffsll((long long)w) - 1u;
+            const u32 s = pl * 64u + (u32)__ffsll((long long)w) - 1u;
             w &= w - 1;
             if (at < cap && s < n_samples) {
                 if (PACK) {
@@ -408,6 +442,7 @@ __global__ void __launch_bounds__(256) k_batch_rows_emit(const u64* __restrict__
             }
             ++at;
         }
+        }
     }
 }
 
@@ -419,6 +454,7 @@ __global__ void __launch_bounds__(256) k_batch_rows_emit(const u64* __restrict__
 // in no particular order (the reader ORs them into place).  UNPACK: the entries of all ranks OR-ed into one dense row
 // (zeroed by the caller), *overflow = some rank had more words than its buffer carried.
 // (one reserving atomic per WORKGROUP of 1 024 references: one per wave were 1 331 adds to ONE word -- 18 us of a kernel that reads 0.7 MB)
+// (n_refs here = the words of ALL planes, n_planes * N: an entry's id is its index into the plane-major array)
 __global__ void __launch_bounds__(1024) k_batch_words_pack(const u64* __restrict__ words, u64 n_refs, u64* __restrict__ packed, u64 cap) {
     __shared__ u32 wcnt[16];
     __shared__ unsigned long long s_base;
@@ -460,16 +496,18 @@ __global__ void __launch_bounds__(256) k_batch_words_unpack(const u64* __restric
 
 }  // namespace
 
-// a slot's scratch: maskword [N + 2] u64 | block counts of the compact rows [ceil(N / ROWS_BLOCK) + 1, padded] u32 | ovsh [B][N] u32
+// a slot's scratch: maskword [4 planes][N] (+ 2) u64 | block counts of the compact rows [ceil(N / ROWS_BLOCK) + 1, padded] u32 | ovsh [B][N] u32
+// (room for all BATCH_MAX_PLANES planes whatever the batch: where the parts lie does not depend on the number of samples)
+static u64 batch_mask_words(const yh_db* db) { return (u64)BATCH_MAX_PLANES * db->n_refs + 2; }
 static u64 batch_blk_words(const yh_db* db) { return (((db->n_refs + ROWS_BLOCK - 1) / ROWS_BLOCK + 1) + 3) & ~(u64)3; }
 static u32* batch_slot_blk_counts(yh_db* db, int slot) {
-    return reinterpret_cast<u32*>(reinterpret_cast<u64*>(db->batch[slot].d_scratch) + db->n_refs + 2);
+    return reinterpret_cast<u32*>(reinterpret_cast<u64*>(db->batch[slot].d_scratch) + batch_mask_words(db));
 }
 static int batch_slot_scratch(yh_db* db, int slot, u32 n_samples, u64** d_maskword, u32** d_ovsh, u64* need_out) {
     const u64 N = db->n_refs;
     const u64 BN = (u64)n_samples * N;
     yh_db::BatchSlot& bs = db->batch[slot];
-    const u64 need = (N + 2) * sizeof(u64) + batch_blk_words(db) * sizeof(u32) + BN * sizeof(u32) + 64;  // (kept per slot, grown on demand)
+    const u64 need = batch_mask_words(db) * sizeof(u64) + batch_blk_words(db) * sizeof(u32) + BN * sizeof(u32) + 64;  // (kept per slot, grown on demand)
     if (bs.cap < need) {
         YH_HIP(hipStreamSynchronize(db->stream));
         if (bs.d_scratch) { yh_dfree(db, bs.d_scratch); bs.d_scratch = nullptr; bs.cap = 0; }
@@ -490,10 +528,11 @@ int yh_q_batch_rows_pack(yh_db* db, int slot, const u32* d_overlap, const u32* d
     const u64* d_maskword = reinterpret_cast<const u64*>(db->batch[slot].d_scratch);
     u32* blk = batch_slot_blk_counts(db, slot);
     const u32 nblk = (u32)((N + ROWS_BLOCK - 1) / ROWS_BLOCK);
+    const u32 npl = planes_of(db->batch[slot].n_samples);
     hipStream_t st = db->fin_stream ? db->fin_stream : db->stream;  // (behind the second half that made the rows)
-    k_batch_rows_count<<<nblk, 256, 0, st>>>(d_maskword, N, blk);
+    k_batch_rows_count<<<nblk, 256, 0, st>>>(d_maskword, N, npl, blk);
     k_batch_rows_emit<true><<<nblk, 256, 0, st>>>(d_maskword, N, db->batch[slot].n_samples, blk, nblk, d_overlap, d_excl, d_match,
-                                                d_vals, nullptr, cap_rows, d_n_rows);
+                                                d_vals, nullptr, cap_rows, d_n_rows, npl);
     YH_HIP(hipGetLastError());
     if (db->fin_stream) { YH_HIP(hipEventRecord(db->ev_fin, st)); db->fin_pending = true; }
     return YH_OK;
@@ -504,9 +543,10 @@ int yh_q_batch_rows_unpack(yh_db* db, int slot, const u32* d_vals, u64 cap_rows,
     const u64* d_maskword = reinterpret_cast<const u64*>(db->batch[slot].d_scratch);
     u32* blk = batch_slot_blk_counts(db, slot);
     const u32 nblk = (u32)((N + ROWS_BLOCK - 1) / ROWS_BLOCK);
-    k_batch_rows_count<<<nblk, 256, 0, db->stream>>>(d_maskword, N, blk);
+    const u32 npl = planes_of(db->batch[slot].n_samples);
+    k_batch_rows_count<<<nblk, 256, 0, db->stream>>>(d_maskword, N, npl, blk);
     k_batch_rows_emit<false><<<nblk, 256, 0, db->stream>>>(d_maskword, N, db->batch[slot].n_samples, blk, nblk, nullptr, nullptr, nullptr,
-                                                         const_cast<u32*>(d_vals), reinterpret_cast<yh_batch_row*>(d_rows), cap_rows, d_n_rows);
+                                                         const_cast<u32*>(d_vals), reinterpret_cast<yh_batch_row*>(d_rows), cap_rows, d_n_rows, npl);
     YH_HIP(hipGetLastError());
     return YH_OK;
 }
@@ -520,7 +560,8 @@ int yh_q_run_batch(yh_db* db, const u64* d_samples, const u64* d_soff, u32 n_sam
         yh_set_error("yh_run_batch needs the directory of the distinct hashes (handle created with YH_DB_NO_DIRECTORY?)");
         return YH_ERR_UNSUPPORTED;
     }
-    if (n_samples < 1 || n_samples > 64) { yh_set_error("1..64 samples per batch"); return YH_ERR_INVALID_ARG; }
+    if (n_samples < 1 || n_samples > BATCH_MAX) { yh_set_error("1..%u samples per batch", BATCH_MAX); return YH_ERR_INVALID_ARG; }
+    const u32 npl = planes_of(n_samples);  // word planes of 64 samples (d_maskword_out / d_gathered: [ranks][npl][N])
     // a second half alone goes to the finish stream when the handle has one (yh_db_set_batch_finish_stream), behind its slot's
     // first half; a first half alone then leaves the handle's subset bits to the second halves
     const bool split_streams = db->fin_stream && phases != 3;
@@ -561,7 +602,7 @@ int yh_q_run_batch(yh_db* db, const u64* d_samples, const u64* d_soff, u32 n_sam
         YH_HIP(hipStreamWaitEvent(sw, bs.ev_first, 0));
     }
     k_batch_maskwords<<<(u32)((N + 255) / 256), 256, 0, sw>>>(d_overlap, n_samples, N, d_maskword, split_streams ? nullptr : db->d_maskbits);
-    if (d_maskword_out) YH_HIP(hipMemcpyAsync(d_maskword_out, d_maskword, N * sizeof(u64), hipMemcpyDeviceToDevice, sw));
+    if (d_maskword_out) YH_HIP(hipMemcpyAsync(d_maskword_out, d_maskword, (u64)npl * N * sizeof(u64), hipMemcpyDeviceToDevice, sw));
     if (split_streams) { YH_HIP(hipEventRecord(db->ev_fin, sw)); db->fin_pending = true; }
     }
     if (!(phases & 2)) { YH_HIP(hipGetLastError()); return YH_OK; }
@@ -569,13 +610,13 @@ int yh_q_run_batch(yh_db* db, const u64* d_samples, const u64* d_soff, u32 n_sam
     YH_HIP(hipMemsetAsync(d_excl, 0, BN * sizeof(u32), st));
     yh_ring_record_begin(db, db->ev_excl, st);
     if (d_gathered)
-        k_batch_or_maskwords<<<(u32)((N + 255) / 256), 256, 0, st>>>(d_gathered, n_ranks, N, d_maskword, db->d_maskbits);
+        k_batch_or_maskwords<<<(u32)((N + 255) / 256), 256, 0, st>>>(d_gathered, n_ranks, N, d_maskword, db->d_maskbits, npl);
     if (G && db->n_postings) {
         YH_HIP(hipMemsetAsync(db->d_work_count, 0, sizeof(u32), st));
         k_batch_worklist<<<(u32)((N + 255) / 256), 256, 0, st>>>(N, db->d_maskbits, db->d_hpo, db->d_work, db->d_work_count);
         const u32 sets_blocks = (u32)std::min<u64>(4096, ((u64)db->n_chunks + 3) / 4 + 1);
         k_batch_sets<<<sets_blocks, 256, 0, st>>>(db->d_work, db->d_work_count, db->d_hrec, db->d_hrecx, db->d_hmult, db->d_pr,
-                                                   d_maskword, N, d_excl);
+                                                   d_maskword, N, d_excl, npl);
     }
     k_batch_final<<<grid_for(BN, 256, 8192), 256, 0, st>>>(n_samples, N, db->d_sizes, db->d_nshared, d_overlap, d_ovsh,
                                                            d_excl, d_match, d_gathered ? d_maskword : nullptr);
@@ -588,19 +629,21 @@ int yh_q_run_batch(yh_db* db, const u64* d_samples, const u64* d_soff, u32 n_sam
 }
 
 // the subset words of a block as (word, reference) entries (kernels above); both on the handle's stream, no host sync
-int yh_q_batch_words_pack(yh_db* db, const u64* d_words, u64* d_packed, u64 cap) {
+int yh_q_batch_words_pack(yh_db* db, const u64* d_words, u32 n_planes, u64* d_packed, u64 cap) {
     hipStream_t st = db->fin_stream ? db->fin_stream : db->stream;  // (where a first half leaves its words when there is a finish stream)
+    const u64 nw = (u64)n_planes * db->n_refs;  // the words of all planes: an entry names its word by its index here
     YH_HIP(hipMemsetAsync(d_packed, 0, sizeof(u64), st));
-    if (db->n_refs) k_batch_words_pack<<<(u32)((db->n_refs + 1023) / 1024), 1024, 0, st>>>(d_words, db->n_refs, d_packed, cap);
+    if (nw) k_batch_words_pack<<<(u32)((nw + 1023) / 1024), 1024, 0, st>>>(d_words, nw, d_packed, cap);
     YH_HIP(hipGetLastError());
     return YH_OK;
 }
-int yh_q_batch_words_unpack(yh_db* db, const u64* d_gathered, u32 n_ranks, u64 cap, u64* d_words_out, u32* d_overflow) {
+int yh_q_batch_words_unpack(yh_db* db, const u64* d_gathered, u32 n_ranks, u32 n_planes, u64 cap, u64* d_words_out, u32* d_overflow) {
     const u64 stride = yh_batch_words_packed_len(cap);
     hipStream_t st = db->fin_stream ? db->fin_stream : db->stream;  // (the second half that reads d_words_out runs there)
-    if (db->n_refs) YH_HIP(hipMemsetAsync(d_words_out, 0, db->n_refs * sizeof(u64), st));
+    const u64 nw = (u64)n_planes * db->n_refs;
+    if (nw) YH_HIP(hipMemsetAsync(d_words_out, 0, nw * sizeof(u64), st));
     const u32 gx = (u32)std::min<u64>(std::max<u64>((cap + 255) / 256, 1), 64);
-    k_batch_words_unpack<<<dim3(gx, n_ranks), 256, 0, st>>>(d_gathered, n_ranks, cap, stride, db->n_refs, d_words_out, d_overflow);
+    k_batch_words_unpack<<<dim3(gx, n_ranks), 256, 0, st>>>(d_gathered, n_ranks, cap, stride, nw, d_words_out, d_overflow);
     YH_HIP(hipGetLastError());
     return YH_OK;
 }

@@ -456,8 +456,8 @@ int yh_q_batch_rows_pack(yh_db* db, int slot, const u32* d_overlap, const u32* d
 int yh_q_batch_rows_unpack(yh_db* db, int slot, const u32* d_vals, u64 cap_rows, void* d_rows, u32* d_n_rows);
 // the subset words of a block as (word, reference) entries: what a hash-range rank all-gathers instead of its dense row
 inline u64 yh_batch_words_packed_len(u64 cap) { return 1 + cap + (cap + 1) / 2; }
-int yh_q_batch_words_pack(yh_db* db, const u64* d_words, u64* d_packed, u64 cap);
-int yh_q_batch_words_unpack(yh_db* db, const u64* d_gathered, u32 n_ranks, u64 cap, u64* d_words_out, u32* d_overflow);
+int yh_q_batch_words_pack(yh_db* db, const u64* d_words, u32 n_planes, u64* d_packed, u64 cap);
+int yh_q_batch_words_unpack(yh_db* db, const u64* d_gathered, u32 n_ranks, u32 n_planes, u64 cap, u64* d_words_out, u32* d_overflow);
 int yh_q_exclusive(yh_db* db, const u8* d_mask, const u64* d_sample, u64 n_sample,
                    const u32* d_overlap, u32* d_excl, u32* d_match, const u32* d_maskbits);
 int yh_q_pairwise(yh_db* db, double c_thresh, u64 r0, u64 r1);

@@ -271,13 +271,15 @@ class RefDB:
                                                              C.c_void_p(d_n_rows)))
 
     # the subset words of a block in compact form: what a hash-range rank all-gathers between the two halves
-    def run_batch_words_pack_device(self, d_words: int, d_packed: int, cap_words: int) -> None:
-        """d_packed [words_packed_len(cap_words)] uint64 = count, the non-zero words of d_words [N], their reference ids."""
-        _lib.check(self._lib.yh_run_batch_words_pack_device(self._h, C.c_void_p(d_words), C.c_void_p(d_packed), cap_words))
+    def run_batch_words_pack_device(self, d_words: int, d_packed: int, cap_words: int, n_planes: int = 1) -> None:
+        """d_packed [words_packed_len(cap_words)] uint64 = count, the non-zero words of d_words [n_planes][N], their ids
+        (plane * N + reference); n_planes = batch_planes(samples of the block)."""
+        _lib.check(self._lib.yh_run_batch_words_pack_device(self._h, C.c_void_p(d_words), n_planes, C.c_void_p(d_packed), cap_words))
 
-    def run_batch_words_unpack_device(self, d_gathered: int, n_ranks: int, cap_words: int, d_words_out: int, d_overflow: int) -> None:
-        """d_words_out [N] uint64 = OR of the n_ranks packed buffers at d_gathered; d_overflow [1] uint32 = some rank overflowed."""
-        _lib.check(self._lib.yh_run_batch_words_unpack_device(self._h, C.c_void_p(d_gathered), n_ranks, cap_words,
+    def run_batch_words_unpack_device(self, d_gathered: int, n_ranks: int, cap_words: int, d_words_out: int, d_overflow: int,
+                                      n_planes: int = 1) -> None:
+        """d_words_out [n_planes][N] uint64 = OR of the n_ranks packed buffers at d_gathered; d_overflow [1] uint32 = some rank overflowed."""
+        _lib.check(self._lib.yh_run_batch_words_unpack_device(self._h, C.c_void_p(d_gathered), n_ranks, n_planes, cap_words,
                                                               C.c_void_p(d_words_out), C.c_void_p(d_overflow)))
 
     def run_submit(self, slot: int, sample: np.ndarray, overlap: np.ndarray, n_excl: np.ndarray,
@@ -334,7 +336,7 @@ class RefDB:
                                                 C.c_void_p(d_rows), cap_rows, C.c_void_p(d_n_rows)))
 
     def run_batch(self, samples: Sequence[np.ndarray]) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
-        """run_counts for up to 64 samples in one pass (needs the directory: not YH_DB_NO_DIRECTORY): three uint32
+        """run_counts for up to BATCH_MAX_SAMPLES (256) samples in one pass (needs the directory: not YH_DB_NO_DIRECTORY): three uint32
         arrays of shape [len(samples), n_refs]."""
         values, offsets = pack_csr(samples)
         b = len(samples)
@@ -395,6 +397,14 @@ class RefDB:
                                          C.byref(n)))
         k = int(n.value)
         return pi[:k], pj[:k], pc[:k]
+
+
+BATCH_MAX_SAMPLES = 256  # include/yacht_hip.h: YH_BATCH_MAX_SAMPLES
+
+
+def batch_planes(n_samples: int) -> int:
+    """Planes of 64 samples the subset words of a batch take (include/yacht_hip.h: YH_BATCH_PLANES)."""
+    return (int(n_samples) + 63) // 64
 
 
 def csr_pack(values: np.ndarray, offsets: np.ndarray, threads: int = 0) -> np.ndarray:
