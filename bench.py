@@ -62,6 +62,8 @@ REFS_PER_GPU = 85_205
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--extras", default=None, help="where the WHOLE result goes (the stdout line carries the contract keys only and names "
+                                                   "this file as `extras`; default gpurun_out/bench_extras.json in the repository)")
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="gtdb_rs214_scale", choices=["gtdb_rs214_scale", "config2_1000refs"])
@@ -1406,7 +1408,7 @@ def main() -> int:
         # driver's record unparsed).
         import bench_line
 
-        extras_path = bench_line.write_extras(out, ROOT)
+        extras_path = bench_line.write_extras(out, ROOT, args.extras)
         sys.stderr.write("bench.py: full result (also in %s):\n%s\n" % (extras_path, json.dumps(out, indent=1, default=str)))
         sys.stderr.flush()
         sys.stdout.flush()

@@ -20,7 +20,7 @@ CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per
                  "vs_baseline", "dtype", "data", "parity_bit_exact")
 
 # scalars of the full result's `config` that stay in the line (<= 20 with the ones compact() adds)
-CONFIG_KEYS = ("workload", "refs_total", "ref_hashes_per_gpu", "sample_hashes", "form", "parallelism",
+CONFIG_KEYS = ("workload", "refs_total", "ref_hashes_per_gpu", "sample_hashes", "form", "shard", "samples_per_block",
                "ms_per_step_host_inclusive", "value_host_inclusive", "value_batched", "ms_per_sample_batched",
                "value_1gpu_same_form", "scaling_efficiency", "rccl_world_size", "sample_hash_lookups_per_s",
                "train_device_ms", "train_frac", "train_traffic_bytes", "db_build_ms", "db_hbm_bytes")
@@ -82,13 +82,22 @@ def dumps(full: dict, extras_path: str | None = None) -> str:
     return line
 
 
-def write_extras(full: dict, root: str) -> str | None:
-    """The whole result (train, scaling_model, host_inclusive, sketch, paths, ...) beside the line; returns its repo-relative path."""
-    rel = os.path.join("gpurun_out", "bench_extras.json")
+def write_extras(full: dict, root: str, path: str | None = None) -> str | None:
+    """The whole result (train, scaling_model, host_inclusive, sketch, paths, ...) beside the line; returns the path the line
+    names: `path` as given (bench.py --extras), else gpurun_out/bench_extras.json relative to the repository."""
+    rel = path or os.path.join("gpurun_out", "bench_extras.json")
+    dst = rel if os.path.isabs(rel) else os.path.join(root, rel)
     try:
-        os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
-        with open(os.path.join(root, rel), "w") as f:
+        os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
+        with open(dst, "w") as f:
             json.dump(full, f, indent=1, default=str)
         return rel
     except OSError:
         return None
+
+
+def read_extras(line: dict, root: str) -> dict:
+    """The whole result a line names (tests; anyone who wants `train`, `scaling_model`, ... of a run)."""
+    rel = line["extras"]
+    with open(rel if os.path.isabs(rel) else os.path.join(root, rel)) as f:
+        return json.load(f)

@@ -4,9 +4,12 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 mkdir -p gpurun_out
+B=${BS_B:-64}       # samples per block (round 6: up to 256)
+NBLK=${BS_BLOCKS:-40}
+SUF=$([ "$B" = 64 ] && echo "" || echo "_B$B")
 for g in ${@:-8 1}; do
   rm -rf /tmp/bs_$g
-  rocprofv3 --kernel-trace --output-format csv -d /tmp/bs_$g -- python3 scripts/probes/batch_share_trace.py $g 40 2> gpurun_out/batch_share_G$g.err
-  grep "per block" gpurun_out/batch_share_G$g.err > gpurun_out/batch_share_G$g.txt
-  python3 scripts/probes/batch_share_blocks.py /tmp/bs_$g 3 >> gpurun_out/batch_share_G$g.txt
+  rocprofv3 --kernel-trace --output-format csv -d /tmp/bs_$g -- python3 scripts/probes/batch_share_trace.py $g $NBLK $B 2> gpurun_out/batch_share_G$g$SUF.err
+  grep "per block" gpurun_out/batch_share_G$g$SUF.err > gpurun_out/batch_share_G$g$SUF.txt
+  python3 scripts/probes/batch_share_blocks.py /tmp/bs_$g 3 >> gpurun_out/batch_share_G$g$SUF.txt
 done

@@ -124,17 +124,34 @@ def test_sharded_refdb_over_rccl_one_rank(hip_lib, tmp_path):
     assert p.returncode == 0, p.stdout + p.stderr
 
 
+def _whole_result(line):
+    """bench.py's stdout line carries the contract keys only (bench_line.py); the whole result is in the file it names."""
+    import bench_line
+
+    full = bench_line.read_extras(line, ROOT)
+    for k in ("metric", "value", "n_gpus", "ms_per_step", "parity_bit_exact", "scaling"):
+        assert full[k] == line[k] or (isinstance(full[k], float) and abs(full[k] - line[k]) < 1e-9), k
+    return full
+
+
+def _extras_arg():
+    import tempfile
+
+    return ["--extras", os.path.join(tempfile.mkdtemp(prefix="yh_bench_"), "extras.json")]
+
+
 @pytest.mark.parametrize("shard", ["hash", "refs"])
 def test_bench_over_rccl_one_rank(hip_lib, shard):
     """bench.py's N > 1 code path (sharded step + async collectives of the bits and the count rows) on RCCL with one rank."""
     env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
                HSA_ENABLE_IPC_MODE_LEGACY="0", YH_FORCE_EXCHANGE="1")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--shard", shard, "--steps", "6", "--min-timed-steps", "0", "--min-timed-ms", "0", "--warmup", "2",
-                        "--refs", "4000", "--sample-hashes", "100000", "--samples", "3", "--percentile-steps", "8", "--present", "50"],
+                        "--refs", "4000", "--sample-hashes", "100000", "--samples", "3", "--percentile-steps", "8", "--present", "50"] + _extras_arg(),
                        env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout + p.stderr
     line = json.loads(p.stdout.strip().splitlines()[-1])
-    assert line["parity_bit_exact"] is True and line["config"]["parallelism"].startswith("one database")
+    assert len(p.stdout.strip().splitlines()[-1]) < 4096
+    assert line["parity_bit_exact"] is True and _whole_result(line)["config"]["parallelism"].startswith("one database")
 
 
 @pytest.mark.parametrize("shard", ["hash", "refs"])
@@ -150,11 +167,14 @@ def test_bench_two_ranks_share_gpu_strong_and_weak(hip_lib, tmp_path, shard):
             procs.append(subprocess.Popen(
                 [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--min-timed-steps", "0", "--min-timed-ms", "0", "--warmup", "2",
                  "--backend", "gloo", "--share-gpu", "--scaling", scaling, "--shard", shard, "--refs", "4000", "--sample-hashes", "100000",
-                 "--samples", "3", "--percentile-steps", "8", "--present", "50", "--batch-block", "4"],
+                 "--samples", "3", "--percentile-steps", "8", "--present", "50", "--batch-block", "4", "--extras", str(tmp_path / f"extras_{scaling}.json")],
                 env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
         res = [p.communicate(timeout=900) for p in procs]
         assert all(p.returncode == 0 for p in procs), "\n".join(o + e for o, e in res)
         line = json.loads(res[0][0].strip().splitlines()[-1])
+        assert line["config"]["shard"] == shard and (shard != "hash" or line["config"]["samples_per_block"] == 4)
+        assert line["config"]["rccl_world_size"] == 2 and (shard != "hash" or line["config"]["scaling_efficiency"] > 0)
+        line = _whole_result(line)
         assert line["parity_bit_exact"] is True and line["n_gpus"] == 2 and line["scaling"] == scaling
         assert line["config"]["refs_total"] == (4000 if scaling == "strong" else 8000) and line["config"]["shard"] == shard
         # the self-proving part of an N > 1 line (VERDICT r04 "next" 1)
@@ -176,10 +196,10 @@ def test_bench_two_ranks_hash_range_single_steps(hip_lib, tmp_path):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--backend", "gloo",
                         "--block-mode", "steps", "--steps", "6", "--min-timed-steps", "0", "--min-timed-ms", "0", "--warmup", "2", "--refs", "4000", "--sample-hashes", "100000",
-                        "--samples", "3", "--percentile-steps", "8", "--present", "50"],
+                        "--samples", "3", "--percentile-steps", "8", "--present", "50"] + _extras_arg(),
                        env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
-    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    line = _whole_result(json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]))
     assert line["parity_bit_exact"] is True and line["config"]["block_mode"] == "steps" and line["config"]["shard"] == "hash"
 
 
@@ -189,12 +209,12 @@ def test_bench_starts_its_own_ranks(hip_lib):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--backend", "gloo",
                         "--steps", "6", "--min-timed-steps", "0", "--min-timed-ms", "0", "--warmup", "2", "--refs", "4000", "--sample-hashes", "100000", "--samples", "3",
-                        "--percentile-steps", "8", "--present", "50"],
+                        "--percentile-steps", "8", "--present", "50"] + _extras_arg(),
                        env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, p.stdout
-    line = json.loads(lines[0])
+    assert len(lines) == 1 and len(lines[0]) < 4096, p.stdout
+    line = _whole_result(json.loads(lines[0]))
     assert line["parity_bit_exact"] is True and line["n_gpus"] == 2
     assert line["rccl_world_size"] == 2 and line["distributed"]["all_reduce_ok"] is True and line["scaling_efficiency"] > 0
 

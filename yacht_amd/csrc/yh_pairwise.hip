@@ -723,10 +723,10 @@ int yh_q_pairwise(yh_db* db, double c_thresh, u64 r0, u64 r1) {
         if (sparse) {
             q.a0 = r0; q.seg0 = 0; q.rows = rows; q.ncb = ncb; q.ovf_count = d_ovf; q.ovf_rows = d_ovf + 1;
             PW_HIP(hipMemsetAsync(d_ovf, 0, sizeof(u32), st));
-            // persistent workgroups, four to the CU (38 KB of LDS each); rows by stride
+            // persistent workgroups (38 KB of LDS each: four resident per CU); rows by stride
             static const u32 sp_grid = [] { const char* e = yh_tune_env("YH_PAIR_SPARSE_GRID"); return e ? (u32)std::max(1, atoi(e)) : 0u; }();
             static const u32 n_cus = [] { int dev = 0, v = 0; return (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? (u32)v : 256u; }();
-            const u32 grid = (u32)std::min<u64>(rows, sp_grid ? sp_grid : n_cus * 4u);
+            const u32 grid = (u32)std::min<u64>(rows, sp_grid ? sp_grid : n_cus * 16u);  // (four resident per CU; four times that for the balance: rows differ 50-fold in length -- 0.99 -> 0.87 ms at 85 205)
             if (rc == YH_OK) k_pair_rows_sparse<<<grid, SP_THREADS, 0, st>>>(q);
             u32 n_ovf = 0;
             YhPin pin_ovf(64);

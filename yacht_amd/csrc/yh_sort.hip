@@ -930,9 +930,13 @@ constexpr u32 PC_MAX_S = 1023;   // sketches per tile (one thread each for the p
 #endif
 constexpr u32 PC_BOUND_THREADS = YH_PC_BOUND_THREADS;  // (16 waves: with 4 per workgroup ~5 waves per CU had 10 KB of loads in flight each -- 1.3 TB/s)
 #ifndef YH_PC_BOUND_U
-#define YH_PC_BOUND_U 4
+#define YH_PC_BOUND_U 8
 #endif
-constexpr u32 PC_BOUND_U = YH_PC_BOUND_U;    // 512-byte loads a wave has in flight
+// 512-byte loads a wave has in flight.  Round 6 (scripts/sweep_bounds.sh, profiles/r06/sweep_bounds.txt): without its zero-fill the
+// pass read configs[3]'s 0.40 GB in ~165 us -- 2.4 TB/s: 313 workgroups of 16 waves on 256 CUs (a second, 22 %-full round of
+// workgroups) and two sketches of 20 dependent load rounds per wave.  One sketch per wave (SK = 8 sketches per 8-wave workgroup:
+// 1 250 workgroups) and eight loads in flight: build kernels 0.985 -> 0.920 ms.
+constexpr u32 PC_BOUND_U = YH_PC_BOUND_U;
 struct PieceArgs {
     const u64* values;
     const u64* off;      // CSR offsets [N + 1]
@@ -1638,7 +1642,8 @@ static bool pc_geometry(u64 H, u64 max_hash, u64 n_refs, yh_pieces* g) {
     g->S = (u32)S;
     g->Gn = (u32)((n_refs + S - 1) / S);
     // sketches per workgroup of the bounds pass: their [SK][P1 + 1] block in LDS (<= 48 KB)
-    g->SK = (u32)std::min<u64>(32, std::max<u64>(4, 12288 / (g->P1 + 1)));
+    static const u32 sk_env = [] { const char* e = yh_tune_env("YH_PC_SK"); return e ? (u32)std::max(1, atoi(e)) : 0u; }();
+    g->SK = (u32)std::min<u64>(sk_env ? sk_env : PC_BOUND_THREADS / 64, std::max<u64>(sk_env ? 1 : 4, 12288 / (g->P1 + 1)));  // (a sketch per wave)
     g->n_pad = (n_refs + 63) & ~(u64)63;
     const u64 tiles = 8ull * ((g->P1 + 7) / 8) * g->Gn;
     if (tiles >> 31) return false;
