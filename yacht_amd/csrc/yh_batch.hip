@@ -48,6 +48,9 @@ constexpr u32 BATCH_TILE = YH_BATCH_TILE;
 // from eight resident workgroups per CU working on the SAME presence-filter lines for different samples; more hashes per
 // lane cost registers, i.e. resident waves, and spread a workgroup's reads in time.
 constexpr int BATCH_U = YH_BATCH_U;
+#ifndef YH_BATCH_PIPE
+#define YH_BATCH_PIPE 1  // the rounds of a tile software-pipelined (k_batch_lookup); 0: round 5's loop
+#endif
 constexpr u32 BATCH_TBITS = 10;
 __global__ void __launch_bounds__(256) k_batch_lookup(const u64* __restrict__ samples, const u64* __restrict__ soff,
                                                       u32 n_samples, const YhDirView dv, const u64* __restrict__ po,
@@ -112,6 +115,51 @@ __global__ void __launch_bounds__(256) k_batch_lookup(const u64* __restrict__ sa
             if (shared) atomicAdd(&row2[ref], 1u);
         };
         const u64 k_end = min(n_s, (i + 1) * BATCH_TILE);
+        auto hits_of = [&](u32 r) {  // what a found hash adds: its holder, or the holders of a shared hash
+            if (r == YH_DIR_NONE) return;
+            if (!(r & 0x80000000u)) {
+                add(r, false);
+            } else {
+                const u32 gi = r & 0x7fffffffu;
+                for (u64 q = po[gi], qe = po[gi + 1]; q < qe; ++q) add(pr[q], true);
+            }
+        };
+#if YH_BATCH_U == 1 && YH_BATCH_PIPE
+        // Round 6: the rounds of a tile SOFTWARE-PIPELINED.  A round was: sample hash -> presence word (a dependent read) -> bucket
+        // (dependent again) -> hits; eight of them per tile, one after the other, each two memory latencies long, with one read in
+        // flight per lane (two whole hashes in flight per lane cost the registers of a second bucket and were slower: YH_BATCH_U).
+        // Now round j + 1's presence word -- one register -- is requested BEHIND round j's bucket and arrives under round j's
+        // wait and hits, and the sample hash of round j + 2 with it: a round is one latency long.  (vmcnt counts in order: the
+        // bucket, requested first, is waited for with the two younger reads still in flight.)
+        if (filter && dv.cbkt) {
+            const u64 t0 = i * BATCH_TILE;
+            auto ld = [&](u64 k) -> u64 { return samples[off[s] + min(k, k_end - 1)]; };
+            u64 hN = ld(t0 + threadIdx.x);
+            bool okN = t0 + threadIdx.x < k_end && hN <= dv.max_hash;
+            if (!okN) hN = 0;
+            u64 bitN = yh_bucket_of(hN, dv.bkt_lsh, filter_mul);
+            u32 wN = filter[bitN >> 5];
+            u64 hNN = ld(t0 + 256u + threadIdx.x);
+            for (u64 k0 = t0; k0 < k_end; k0 += 256u) {  // (workgroup-uniform)
+                const u64 h = hN, bit = bitN;
+                const u32 w = wN;
+                const u32 m = yh_filter_mask(h, bit);
+                const bool ok = okN && (w & m) == m;
+                YhDirView::v4u a = YhDirView::v4u{0u, 0u, 0u, 0u}, b = a, c = a, d = a;
+                if (ok) dv.cbkt_request(h, a, b, c, d);
+                // the next round's presence word and the hash of the round after it, behind this round's bucket
+                const u64 kn = k0 + 256u + threadIdx.x;
+                hN = hNN;
+                okN = kn < k_end && hN <= dv.max_hash;
+                if (!okN) hN = 0;
+                bitN = yh_bucket_of(hN, dv.bkt_lsh, filter_mul);
+                wN = filter[bitN >> 5];              // (unconditional -- behind the tile's last round: a valid word nobody uses --
+                hNN = ld(k0 + 512u + threadIdx.x);   // so that the wait below does not have to cover a branch)
+                asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));  // (see YhDirView::find)
+                if (ok) hits_of(dv.cbkt_resolve(h, a, b, c, d));
+            }
+        } else
+#endif
         // BATCH_U hashes of a lane at a time: all presence words are requested, then the buckets of the hashes that passed,
         // then they are looked at (BATCH_U = 1: word, bucket, counts, next hash)
         for (u64 k0 = i * BATCH_TILE; k0 < k_end; k0 += 256u * BATCH_U) {  // (workgroup-uniform)
@@ -159,14 +207,7 @@ __global__ void __launch_bounds__(256) k_batch_lookup(const u64* __restrict__ sa
 #pragma unroll
             for (int u = 0; u < BATCH_U; ++u) {
                 if (!ok[u]) continue;
-                const u32 r = dv.cbkt ? dv.cbkt_resolve(h[u], a[u], b[u], c[u], d[u]) : dv.find(h[u]);
-                if (r == YH_DIR_NONE) continue;
-                if (!(r & 0x80000000u)) {
-                    add(r, false);
-                } else {
-                    const u32 gi = r & 0x7fffffffu;
-                    for (u64 q = po[gi], qe = po[gi + 1]; q < qe; ++q) add(pr[q], true);
-                }
+                hits_of(dv.cbkt ? dv.cbkt_resolve(h[u], a[u], b[u], c[u], d[u]) : dv.find(h[u]));
             }
         }
         __syncthreads();

@@ -409,7 +409,11 @@ struct Pending {  // one requested confirmation per lane
     uint2 rec = make_uint2(0u, STREAM_NONE);
     u64 sv = 0;
 };
+#ifndef YH_ABLATE_STREAM
+#define YH_ABLATE_STREAM 0  // traffic-attribution builds (results wrong): 1 = candidates are not confirmed (no srec / sample read), 2 = the probes do not read their lane's delta bytes again
+#endif
 __device__ __forceinline__ void pending_request(const StreamHit& hit, Pending& p, u64 pos, u32 sidx) {
+    if (YH_ABLATE_STREAM & 1) { p.rec = make_uint2((u32)pos, STREAM_NONE); p.sv = sidx; return; }
     p.rec = hit.srec[pos];
     p.sv = hit.sample[sidx];
 }
@@ -652,7 +656,7 @@ __device__ __forceinline__ void stream_blocks(const u32x4* __restrict__ deltas, 
                 if (act) locate();
                 while (__ballot(act)) {  // (more than one trip only for runs of equal keys that leave a lane)
                     if (act) {
-                        const u32x4 w = deltas[(b0 + f) * 64 + t];
+                        const u32x4 w = (YH_ABLATE_STREAM & 2) ? u32x4{r, t, f, 1u} : deltas[(b0 + f) * 64 + t];
                         const u32 W[4] = {t ? w.x : (w.x & 0xffffff00u), w.y, w.z, w.w};
                         u32 cs = t ? INCw[f * INC_STRIDE + t - 1] : 0u, match = 0;
 #pragma unroll
