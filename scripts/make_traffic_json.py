@@ -47,6 +47,25 @@ def mean_counter(d, counter, kernel_tag):
     return (sum(vals) / len(vals), len(vals)) if vals else (0.0, 0)
 
 
+def stream_isolated_kib():
+    """FETCH_SIZE (KiB per launch) of k_stream_lookup's ISOLATED reads -- the probes' second look at their lane's 16 delta bytes and
+    the candidates' confirmation reads -- from the traffic-attribution builds of scripts/pmc_stream_ablate.sh (round 6): the shipped
+    kernel's FETCH_SIZE minus that of the build without either.  Those are 64-byte requests, counted as such (x 1); only the
+    coalesced stream under them is reported at half its bytes.  None when the ablation file is not there."""
+    for cand in (os.path.join(root, "r06", "pmc_stream_ablate.txt"), os.path.join(root, "pmc_stream_ablate.txt"),
+                 os.path.join(ROOT, "profiles", "r06", "pmc_stream_ablate.txt")):
+        if os.path.exists(cand):
+            fetch, v = {}, None
+            for ln in open(cand):
+                if ln.startswith("== YH_ABLATE_STREAM ="):
+                    v = int(ln.split("=")[-1])
+                elif ln.startswith("FETCH_SIZE") and v is not None:
+                    fetch[v] = float(ln.split()[1])
+            if 0 in fetch and 3 in fetch:
+                return max(fetch[0] - fetch[3], 0.0), cand
+    return None
+
+
 try:
     commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
 except Exception:
@@ -70,6 +89,15 @@ for kernel, name, factor, why in (
            "taken": datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%MZ"),
            "FETCH_SIZE_KiB_mean": fetch_kib, "launches_fetch": nf, "WRITE_SIZE_KiB_mean": write_kib, "launches_write": nw,
            "correction": why, "hbm_bytes_per_launch": int(factor * fetch_kib * 1024.0 + write_kib * 1024.0)}
+    iso = stream_isolated_kib() if name == "stream" else None
+    if iso is not None and iso[0] < fetch_kib:
+        # the blanket doubling also doubled the isolated 64-byte reads that are counted in full (rounds 2-5: 444.5 MB = 1.28 x the layout)
+        rec["hbm_bytes_per_launch_blanket_doubling"] = rec["hbm_bytes_per_launch"]
+        rec["isolated_FETCH_SIZE_KiB"] = iso[0]
+        rec["hbm_bytes_per_launch"] = int((2.0 * (fetch_kib - iso[0]) + iso[0] + write_kib) * 1024.0)
+        rec["correction"] = ("read bytes = 2 x (FETCH_SIZE - isolated) + isolated: the coalesced 16-B/lane stream is reported at half its bytes "
+                             "(gfx950), the isolated 64-byte reads (probe re-reads + candidate confirmations, from the ablation builds of "
+                             "scripts/pmc_stream_ablate.sh: %s) in full; write bytes = WRITE_SIZE" % os.path.relpath(iso[1], ROOT))
     req, nr = mean_counter("pmc_tcc", "TCC_REQ_sum", kernel)
     miss, _ = mean_counter("pmc_tcc", "TCC_MISS_sum", kernel)
     if nr:  # L2 requests per launch: what a kernel of isolated reads is bound by

@@ -48,9 +48,7 @@ constexpr u32 BATCH_TILE = YH_BATCH_TILE;
 // from eight resident workgroups per CU working on the SAME presence-filter lines for different samples; more hashes per
 // lane cost registers, i.e. resident waves, and spread a workgroup's reads in time.
 constexpr int BATCH_U = YH_BATCH_U;
-#ifndef YH_BATCH_PIPE
-#define YH_BATCH_PIPE 1  // the rounds of a tile software-pipelined (k_batch_lookup); 0: round 5's loop
-#endif
+
 constexpr u32 BATCH_TBITS = 10;
 __global__ void __launch_bounds__(256) k_batch_lookup(const u64* __restrict__ samples, const u64* __restrict__ soff,
                                                       u32 n_samples, const YhDirView dv, const u64* __restrict__ po,
@@ -124,42 +122,10 @@ __global__ void __launch_bounds__(256) k_batch_lookup(const u64* __restrict__ sa
                 for (u64 q = po[gi], qe = po[gi + 1]; q < qe; ++q) add(pr[q], true);
             }
         };
-#if YH_BATCH_U == 1 && YH_BATCH_PIPE
-        // Round 6: the rounds of a tile SOFTWARE-PIPELINED.  A round was: sample hash -> presence word (a dependent read) -> bucket
-        // (dependent again) -> hits; eight of them per tile, one after the other, each two memory latencies long, with one read in
-        // flight per lane (two whole hashes in flight per lane cost the registers of a second bucket and were slower: YH_BATCH_U).
-        // Now round j + 1's presence word -- one register -- is requested BEHIND round j's bucket and arrives under round j's
-        // wait and hits, and the sample hash of round j + 2 with it: a round is one latency long.  (vmcnt counts in order: the
-        // bucket, requested first, is waited for with the two younger reads still in flight.)
-        if (filter && dv.cbkt) {
-            const u64 t0 = i * BATCH_TILE;
-            auto ld = [&](u64 k) -> u64 { return samples[off[s] + min(k, k_end - 1)]; };
-            u64 hN = ld(t0 + threadIdx.x);
-            bool okN = t0 + threadIdx.x < k_end && hN <= dv.max_hash;
-            if (!okN) hN = 0;
-            u64 bitN = yh_bucket_of(hN, dv.bkt_lsh, filter_mul);
-            u32 wN = filter[bitN >> 5];
-            u64 hNN = ld(t0 + 256u + threadIdx.x);
-            for (u64 k0 = t0; k0 < k_end; k0 += 256u) {  // (workgroup-uniform)
-                const u64 h = hN, bit = bitN;
-                const u32 w = wN;
-                const u32 m = yh_filter_mask(h, bit);
-                const bool ok = okN && (w & m) == m;
-                YhDirView::v4u a = YhDirView::v4u{0u, 0u, 0u, 0u}, b = a, c = a, d = a;
-                if (ok) dv.cbkt_request(h, a, b, c, d);
-                // the next round's presence word and the hash of the round after it, behind this round's bucket
-                const u64 kn = k0 + 256u + threadIdx.x;
-                hN = hNN;
-                okN = kn < k_end && hN <= dv.max_hash;
-                if (!okN) hN = 0;
-                bitN = yh_bucket_of(hN, dv.bkt_lsh, filter_mul);
-                wN = filter[bitN >> 5];              // (unconditional -- behind the tile's last round: a valid word nobody uses --
-                hNN = ld(k0 + 512u + threadIdx.x);   // so that the wait below does not have to cover a branch)
-                asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));  // (see YhDirView::find)
-                if (ok) hits_of(dv.cbkt_resolve(h, a, b, c, d));
-            }
-        } else
-#endif
+        // (Round 6, measured and dropped -- profiles/r06/batch_share_G*_B256*.txt: the eight rounds of a tile SOFTWARE-PIPELINED -- round
+        // j + 1's presence word and round j + 2's sample hash requested behind round j's bucket, so that a round is one dependent
+        // latency long instead of two: k_batch_lookup 3 622 -> 3 693 us per block of 256 samples at G = 1, 496 -> 512 at G = 8 --
+        // nothing: with 32 resident waves per CU taking turns the pass is not waiting for its own chain.)
         // BATCH_U hashes of a lane at a time: all presence words are requested, then the buckets of the hashes that passed,
         // then they are looked at (BATCH_U = 1: word, bucket, counts, next hash)
         for (u64 k0 = i * BATCH_TILE; k0 < k_end; k0 += 256u * BATCH_U) {  // (workgroup-uniform)
@@ -397,6 +363,34 @@ __global__ void __launch_bounds__(256) k_batch_final(u32 n_samples, u64 n_refs, 
         } else {
             ex_e[t] = 0;
             ex_m[t] = 0;
+        }
+    }
+}
+
+// The same over the ENTRIES of the batch only -- the set bits of the subset words -- (round 6): the dense pass above reads three and
+// writes two [B][N] arrays, 0.44 GB and 100 us per block of 256 samples at rs214 scale whatever the rank's share of the lookups,
+// for ~60 000 cells that hold anything.  Cells outside the subset: ex_e is zero already (cleared in front of k_batch_sets, which
+// adds to subset cells only), ex_m is cleared by the caller (one fill), overlap / ovsh are zero there on every shard (a
+// reference outside the GLOBAL subset overlaps the sample in no range).  One lane per reference, its samples plane by plane.
+__global__ void __launch_bounds__(256) k_batch_final_sparse(u32 n_samples, u64 n_refs, u32 n_planes, const u32* __restrict__ sizes,
+                                                            const u32* __restrict__ nshared, const u32* __restrict__ overlap,
+                                                            u32* __restrict__ ovsh, u32* __restrict__ ex_e, u32* __restrict__ ex_m,
+                                                            const u64* __restrict__ maskword) {
+    const u64 r = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (r >= n_refs) return;
+    u32 base = 0xffffffffu;  // sizes[r] - nshared[r], fetched behind the first set bit (most references have none)
+    for (u32 pl = 0; pl < n_planes; ++pl) {
+        u64 w = maskword[(u64)pl * n_refs + r];
+        while (w) {
+            const u32 s = pl * 64u + (u32)__ffsll((long long)w) - 1u;
+            w &= w - 1;
+            if (s >= n_samples) continue;
+            if (base == 0xffffffffu) base = sizes[r] - nshared[r];
+            const u64 t = (u64)s * n_refs + r;
+            const u32 sh = ovsh[t];
+            if (sh) ovsh[t] = 0;  // (left zero for the slot's next first half: BatchSlot::ovsh_clean)
+            ex_e[t] += base;
+            ex_m[t] = overlap[t] - sh;
         }
     }
 }
@@ -659,8 +653,15 @@ int yh_q_run_batch(yh_db* db, const u64* d_samples, const u64* d_soff, u32 n_sam
         k_batch_sets<<<sets_blocks, 256, 0, st>>>(db->d_work, db->d_work_count, db->d_hrec, db->d_hrecx, db->d_hmult, db->d_pr,
                                                    d_maskword, N, d_excl, npl);
     }
-    k_batch_final<<<grid_for(BN, 256, 8192), 256, 0, st>>>(n_samples, N, db->d_sizes, db->d_nshared, d_overlap, d_ovsh,
-                                                           d_excl, d_match, d_gathered ? d_maskword : nullptr);
+    static const bool dense_final = [] { const char* e = yh_tune_env("YH_BATCH_DENSE_FINAL"); return e && e[0] == '1'; }();
+    if (dense_final) {
+        k_batch_final<<<grid_for(BN, 256, 8192), 256, 0, st>>>(n_samples, N, db->d_sizes, db->d_nshared, d_overlap, d_ovsh,
+                                                               d_excl, d_match, d_gathered ? d_maskword : nullptr);
+    } else {  // the entries only (the subset words are the batch's own when nothing was gathered: overlap != 0)
+        YH_HIP(hipMemsetAsync(d_match, 0, BN * sizeof(u32), st));
+        k_batch_final_sparse<<<(u32)((N + 255) / 256), 256, 0, st>>>(n_samples, N, npl, db->d_sizes, db->d_nshared, d_overlap, d_ovsh,
+                                                                   d_excl, d_match, d_maskword);
+    }
     yh_ring_record_end(db, db->ev_excl, st);
     YH_HIP(hipGetLastError());
     if (split_streams) { YH_HIP(hipEventRecord(db->ev_fin, st)); db->fin_pending = true; }

@@ -56,7 +56,10 @@ constexpr u32 PART_MAX_BINS = 1024;  // bins per level (LDS histogram)
 #endif
 constexpr u32 BKT_SLOT_BITS = YH_BKT_BITS;
 constexpr u32 BKT_CAP = 1u << BKT_SLOT_BITS;   // pairs a final bucket may hold
-constexpr u32 BKT_FILL = BKT_CAP / 8 * 5;      // ... and holds on average (2 560 of 4 096; uniform keys: sd ~51; clustered references ~3x that)
+#ifndef YH_BKT_FILL8
+#define YH_BKT_FILL8 5   // eighths of its capacity a bucket holds on average (tuning: scripts/sweep_fill.sh)
+#endif
+constexpr u32 BKT_FILL = BKT_CAP / 8 * YH_BKT_FILL8;  // ... and holds on average (2 560 of 4 096; uniform keys: sd ~51; clustered references ~3x that)
 constexpr u32 BKT_THREADS = YH_BKT_THREADS;
 constexpr u32 BKT_ITEMS = BKT_CAP / BKT_THREADS;
 constexpr u32 BKT_SLOTS = BKT_CAP;   // fine slots of the counting sort inside a bucket (= 1 << BKT_SLOT_BITS)
@@ -742,6 +745,8 @@ __global__ void __launch_bounds__(BKT_THREADS) k_bucket_group5(const BucketArgs 
     // for 0.60 GB of pairs at configs[3].)
 #if defined(YH_GROUP_SPEC_ALL) && YH_GROUP_SPEC_ALL
     constexpr u32 SPEC_ITEMS = BKT_ITEMS;
+#elif defined(YH_GROUP_SPEC_ITEMS)
+    constexpr u32 SPEC_ITEMS = YH_GROUP_SPEC_ITEMS;
 #else
     constexpr u32 SPEC_ITEMS = BKT_ITEMS / 2;
 #endif
