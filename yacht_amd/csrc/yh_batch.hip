@@ -326,7 +326,11 @@ __global__ void __launch_bounds__(256) k_batch_or_maskwords(const u64* __restric
     u64 any = 0;
     if (r < n_refs)
         for (u32 pl = 0; pl < n_planes; ++pl) {
-            u64 w = 0;
+            // ... and this rank's own words, which the slot still holds from its first half: they are part of every complete
+            // gather anyway, and with them the subset covers every cell this rank counted into even when the gathered words are
+            // INCOMPLETE (an exchange that overflowed its capacity: the block is repeated) -- k_batch_final_sparse clears the hits
+            // on shared hashes of the subset's cells only, and the slot's next first half relies on all of them being zero
+            u64 w = maskword[(u64)pl * n_refs + r];
             for (u32 k = 0; k < n_ranks; ++k) w |= gathered[((u64)k * n_planes + pl) * n_refs + r];
             maskword[(u64)pl * n_refs + r] = w;
             any |= w;
@@ -490,27 +494,41 @@ __global__ void __launch_bounds__(256) k_batch_rows_emit(const u64* __restrict__
 // (zeroed by the caller), *overflow = some rank had more words than its buffer carried.
 // (one reserving atomic per WORKGROUP of 1 024 references: one per wave were 1 331 adds to ONE word -- 18 us of a kernel that reads 0.7 MB)
 // (n_refs here = the words of ALL planes, n_planes * N: an entry's id is its index into the plane-major array)
-__global__ void __launch_bounds__(1024) k_batch_words_pack(const u64* __restrict__ words, u64 n_refs, u64* __restrict__ packed, u64 cap) {
+// (Round 6: 256 lanes, four words each -- still one reserving atomic per 1 024 words.  As a 1 024-lane workgroup the kernel, on the
+// finish stream beside the next block's lookups -- eight 256-lane workgroups resident on every CU --, waited for sixteen free wave
+// slots on one CU: 305 us per block of 256 samples at G = 1 for a pass over 2.7 MB, profiles/r06/batch_share_G1_B256_before_pipe.txt.)
+__global__ void __launch_bounds__(256) k_batch_words_pack(const u64* __restrict__ words, u64 n_refs, u64* __restrict__ packed, u64 cap) {
     __shared__ u32 wcnt[16];
     __shared__ unsigned long long s_base;
-    const u64 r = blockIdx.x * (u64)blockDim.x + threadIdx.x;
-    const u64 w = r < n_refs ? words[r] : 0ull;
-    const u64 bal = __ballot(w != 0);
     const u32 lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    if (lane == 0) wcnt[wv] = (u32)__popcll(bal);
+    u64 w[4], bal[4];
+#pragma unroll
+    for (u32 k = 0; k < 4; ++k) {
+        const u64 r = blockIdx.x * 1024ull + k * 256u + threadIdx.x;
+        w[k] = r < n_refs ? words[r] : 0ull;
+    }
+#pragma unroll
+    for (u32 k = 0; k < 4; ++k) {
+        bal[k] = __ballot(w[k] != 0);
+        if (lane == 0) wcnt[k * 4u + wv] = (u32)__popcll(bal[k]);
+    }
     __syncthreads();
-    u32 below = 0, total = 0;
-    for (u32 q = 0; q < 16; ++q) { const u32 c = wcnt[q]; total += c; below += q < wv ? c : 0u; }
+    u32 total = 0;
+    for (u32 q = 0; q < 16; ++q) total += wcnt[q];
     if (total == 0) return;  // (uniform)
     if (threadIdx.x == 0) s_base = atomicAdd((unsigned long long*)packed, (unsigned long long)total);
     __syncthreads();
-    if (w) {
-        const u64 at = s_base + below + __popcll(bal & ((1ull << lane) - 1ull));
-        if (at < cap) {
-            packed[1 + at] = w;
-            reinterpret_cast<u32*>(packed + 1 + cap)[at] = (u32)r;
+#pragma unroll
+    for (u32 k = 0; k < 4; ++k)
+        if (w[k]) {
+            u32 below = 0;
+            for (u32 q = 0; q < k * 4u + wv; ++q) below += wcnt[q];
+            const u64 at = s_base + below + __popcll(bal[k] & ((1ull << lane) - 1ull));
+            if (at < cap) {
+                packed[1 + at] = w[k];
+                reinterpret_cast<u32*>(packed + 1 + cap)[at] = (u32)(blockIdx.x * 1024ull + k * 256u + threadIdx.x);
+            }
         }
-    }
 }
 __global__ void __launch_bounds__(256) k_batch_words_unpack(const u64* __restrict__ gathered, u32 n_ranks, u64 cap, u64 stride,
                                                             u64 n_refs, u64* __restrict__ words, u32* __restrict__ overflow) {
@@ -675,7 +693,7 @@ int yh_q_batch_words_pack(yh_db* db, const u64* d_words, u32 n_planes, u64* d_pa
     hipStream_t st = db->fin_stream ? db->fin_stream : db->stream;  // (where a first half leaves its words when there is a finish stream)
     const u64 nw = (u64)n_planes * db->n_refs;  // the words of all planes: an entry names its word by its index here
     YH_HIP(hipMemsetAsync(d_packed, 0, sizeof(u64), st));
-    if (nw) k_batch_words_pack<<<(u32)((nw + 1023) / 1024), 1024, 0, st>>>(d_words, nw, d_packed, cap);
+    if (nw) k_batch_words_pack<<<(u32)((nw + 1023) / 1024), 256, 0, st>>>(d_words, nw, d_packed, cap);
     YH_HIP(hipGetLastError());
     return YH_OK;
 }
