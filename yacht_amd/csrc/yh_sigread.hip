@@ -3,6 +3,7 @@
 // read_sketches / read_sketches_one_chunk, src/cpp/main.cpp:89-124).  No device code.
 #include "yh_common.h"
 #include "yh_sigread.h"
+#include "yh_pack.h"
 
 #include <string.h>
 
@@ -145,6 +146,27 @@ int yh_sig_batch_values(const yh_sig_batch* b, uint64_t* values) {
         if (!m.empty()) memcpy(values + at[i], m.data(), m.size() * sizeof(uint64_t));
     });
     return YH_OK;
+}
+
+// The parsed sketches as a PACKED CSR (yh_db_create_packed's input), straight from the files' own vectors: no CSR of 8 bytes per
+// hash is made in between (round 6: `yacht train` uploads and writes the packed form).  Two-call sizing as yh_csr_pack;
+// YH_ERR_UNSORTED when a file's mins are not strictly ascending (the caller then takes the CSR path, whose reader tolerates that).
+int yh_sig_batch_pack(const yh_sig_batch* b, void* packed, uint64_t cap_bytes, uint64_t* packed_bytes, int threads) {
+    if (!b || !packed_bytes) { yh_set_error("null argument"); return YH_ERR_INVALID_ARG; }
+    try {
+        const size_t n = b->mins.size();
+        std::vector<uint64_t> offsets(n + 1, 0);
+        std::vector<const uint64_t*> parts(n, nullptr);
+        for (size_t i = 0; i < n; ++i) {
+            offsets[i + 1] = offsets[i] + b->mins[i].size();
+            parts[i] = b->mins[i].data();
+        }
+        return yh_csr_pack_parts(reinterpret_cast<const u64* const*>(parts.data()), reinterpret_cast<const u64*>(offsets.data()), n, packed, cap_bytes,
+                                 reinterpret_cast<u64*>(packed_bytes), threads);
+    } catch (const std::bad_alloc&) {
+        yh_set_error("yh_sig_batch_pack: out of host memory");
+        return YH_ERR_OOM;
+    }
 }
 
 int yh_sig_batch_destroy(yh_sig_batch* b) {

@@ -422,6 +422,24 @@ def csr_pack(values: np.ndarray, offsets: np.ndarray, threads: int = 0) -> np.nd
     return out
 
 
+def csr_subset(packed: np.ndarray, rows: Sequence[int]) -> np.ndarray:
+    """The listed sketches of a packed CSR, in that order, as a packed CSR of their own (yh_csr_subset: no hash is decoded)."""
+    lib = _lib.load()
+    assert packed.dtype == np.uint64 and packed.flags["C_CONTIGUOUS"]
+    rows = np.ascontiguousarray(rows, dtype=np.uint64)
+    need = C.c_uint64(0)
+    _lib.check(lib.yh_csr_subset(_ptr(packed), packed.nbytes, _ptr(rows), rows.size, None, 0, C.byref(need)))
+    out = np.zeros((int(need.value) + 7) // 8, dtype=np.uint64)
+    _lib.check(lib.yh_csr_subset(_ptr(packed), packed.nbytes, _ptr(rows), rows.size, _ptr(out), out.nbytes, C.byref(need)))
+    return out
+
+
+def packed_offsets(packed: np.ndarray) -> np.ndarray:
+    """The offsets[N + 1] a packed CSR carries behind its 64-byte header (a view: header word 1 = N)."""
+    n = int(packed[1])
+    return packed[8: 8 + n + 1]
+
+
 def csr_unpack(packed: np.ndarray):
     """(values, offsets) of a packed CSR, on the host."""
     lib = _lib.load()

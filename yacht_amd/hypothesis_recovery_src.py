@@ -102,9 +102,14 @@ def get_reference_db(manifest: pd.DataFrame, path_to_genome_temp_dir: str, ksize
     db = _DB_CACHE.get(key)
     if db is None:
         with phases.phase("load_reference_csr"):
-            values, offsets = load_reference_csr(list(md5s), path_to_genome_temp_dir, ksize, num_threads)
+            got = refdb_cache.load_any(path_to_genome_temp_dir, list(md5s), ksize)  # (round 6: `yacht train` leaves the packed form)
+            if got is None or "packed" not in got:
+                values, offsets = load_reference_csr(list(md5s), path_to_genome_temp_dir, ksize, num_threads)
         with phases.phase("upload_and_build_db"):
-            db = RefDB(values, offsets, device=device)
+            if got is not None and "packed" in got:
+                db = RefDB.from_packed(np.ascontiguousarray(got["packed"]), sizes=np.diff(got["offsets"]).astype(np.uint32), device=device)
+            else:
+                db = RefDB(values, offsets, device=device)
         _DB_CACHE.clear()  # one database resident at a time
         _DB_CACHE[key] = db
     return db

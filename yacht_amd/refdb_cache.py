@@ -11,6 +11,11 @@ and `yacht run` memory-maps the two arrays and hands them straight to yh_db_crea
 parsing, and pages are only touched by the host-to-device copy.  The cache is keyed by the md5
 list (manifest order) and the k-mer size; anything else falls back to reading the signatures and
 rewrites the cache.
+
+Round 6: `yacht train` writes the PACKED form instead (`packed-<token>.npy`: yh_csr_pack's blob, ~5.7 instead of 8 bytes
+per hash -- the selected sketches cut out of the blob the train core uploaded, yh_csr_subset, no hash decoded), `meta.json`
+names it under "files": {"packed": ..}, and `yacht run` hands the memory-mapped blob to yh_db_create_packed
+(load_any); directories written by earlier rounds (values / offsets) keep working.
 """
 from __future__ import annotations
 
@@ -72,22 +77,45 @@ class PendingSubsetSave:
     slices are written straight from the source arrays -- no packed copy in memory first -- while the caller does other
     work (file writes release the GIL).  Nothing refers to the files until publish(); discard() removes them."""
 
-    def __init__(self, genome_dir: str, ksize: int, values: np.ndarray, offsets: np.ndarray, rows: Sequence[int]):
+    def __init__(self, genome_dir: str, ksize: int, values: Optional[np.ndarray], offsets: np.ndarray, rows: Sequence[int],
+                 packed: Optional[np.ndarray] = None):
         import threading
 
         self.dir = cache_dir(genome_dir)
         self.ksize = int(ksize)
         token = f"{os.getpid():x}-{secrets.token_hex(6)}"
         self.token = token
-        self.names = {"values": f"values-{token}.npy", "offsets": f"offsets-{token}.npy"}
+        self.names = ({"packed": f"packed-{token}.npy"} if packed is not None else
+                      {"values": f"values-{token}.npy", "offsets": f"offsets-{token}.npy"})
         rows = np.asarray(rows, dtype=np.int64)
         sizes = (offsets[rows + 1] - offsets[rows]).astype(np.uint64) if rows.size else np.zeros(0, np.uint64)
         self.out_offsets = np.zeros(rows.size + 1, dtype=np.uint64)
         if rows.size:
             self.out_offsets[1:] = np.cumsum(sizes, dtype=np.uint64)
         self.ok = False
-        self._thread = threading.Thread(target=self._write, args=(values, offsets, rows), name="yacht-hip-packed-db", daemon=True)
+        if packed is not None:
+            self._thread = threading.Thread(target=self._write_packed, args=(packed, rows), name="yacht-hip-packed-db", daemon=True)
+        else:
+            self._thread = threading.Thread(target=self._write, args=(values, offsets, rows), name="yacht-hip-packed-db", daemon=True)
         self._thread.start()
+
+    def _write_packed(self, packed: np.ndarray, rows: np.ndarray) -> None:
+        """The rows cut out of the packed CSR the train core uploaded (yh_csr_subset: block entries re-based, payload words copied;
+        the C call releases the GIL) and written as ONE file."""
+        try:
+            from .engine import csr_subset
+
+            os.makedirs(self.dir, exist_ok=True)
+            sub = csr_subset(packed, rows)
+            tmp = os.path.join(self.dir, self.names["packed"] + ".part")
+            with open(tmp, "wb") as f:
+                np.save(f, sub)
+                f.flush()
+                os.fsync(f.fileno())
+            os.replace(tmp, os.path.join(self.dir, self.names["packed"]))
+            self.ok = True
+        except Exception:  # noqa: BLE001  (read-only directory, a blob the library refuses: just do not cache)
+            self.ok = False
 
     def _write(self, values: np.ndarray, offsets: np.ndarray, rows: np.ndarray) -> None:
         try:
@@ -147,14 +175,16 @@ class PendingSubsetSave:
                     pass
 
 
-def save_subset_async(genome_dir: str, ksize: int, values: np.ndarray, offsets: np.ndarray, rows: Sequence[int]) -> PendingSubsetSave:
-    """Start writing the packed copy of `rows` (in that order) of the CSR; see PendingSubsetSave."""
-    return PendingSubsetSave(genome_dir, ksize, values, offsets, rows)
+def save_subset_async(genome_dir: str, ksize: int, values: Optional[np.ndarray], offsets: np.ndarray, rows: Sequence[int],
+                      packed: Optional[np.ndarray] = None) -> PendingSubsetSave:
+    """Start writing the packed copy of `rows` (in that order) of the CSR -- or, given the train core's packed blob, of that; see
+    PendingSubsetSave."""
+    return PendingSubsetSave(genome_dir, ksize, values, offsets, rows, packed=packed)
 
 
 def _remove_older_generations(d: str, names) -> None:
     for old in os.listdir(d):  # earlier generations (best effort; a reader that has them open keeps them)
-        if (old.startswith("values-") or old.startswith("offsets-") or old in ("values.npy", "offsets.npy")) \
+        if (old.startswith("values-") or old.startswith("offsets-") or old.startswith("packed-") or old in ("values.npy", "offsets.npy")) \
                 and old not in names.values() and not old.endswith(".part"):
             try:
                 os.remove(os.path.join(d, old))
@@ -162,15 +192,50 @@ def _remove_older_generations(d: str, names) -> None:
                 pass
 
 
-def load(genome_dir: str, md5sums: Sequence[str], ksize: int) -> Optional[Tuple[np.ndarray, np.ndarray]]:
-    """(values, offsets) memory-mapped, or None when there is no packed set for exactly these references --
-    or when what is on disk does not agree with its own meta (sizes, digest of the offsets)."""
+def load_any(genome_dir: str, md5sums: Sequence[str], ksize: int):
+    """{"packed": blob} (round 6: what `yacht train` writes; memory-mapped, for RefDB.from_packed) or {"values", "offsets"}
+    (earlier rounds' directories, and what `yacht run` writes itself after parsing the signature files) -- or None when there is
+    no copy for exactly these references, or when what is on disk does not agree with its own meta."""
     d = cache_dir(genome_dir)
     try:
         with open(os.path.join(d, "meta.json")) as f:
             meta = json.load(f)
         if int(meta["ksize"]) != int(ksize) or list(meta["md5sums"]) != list(md5sums):
             return None
+        files = meta.get("files") or {}
+        if "packed" in files:
+            blob = np.load(os.path.join(d, files["packed"]), mmap_mode="r")
+            if blob.dtype != np.uint64 or blob.ndim != 1 or blob.size < 8 + len(md5sums) + 1:
+                return None
+            n_refs, n_hashes = int(blob[1]), int(blob[2])
+            offsets = np.asarray(blob[8: 8 + n_refs + 1])
+            if n_refs != len(md5sums) or int(meta.get("n_refs", -1)) != n_refs or int(meta.get("n_hashes", -1)) != n_hashes \
+                    or meta.get("offsets_sha1") != _offsets_digest(offsets):
+                return None
+            return {"packed": blob, "offsets": offsets}
+    except (OSError, ValueError, KeyError):
+        return None
+    got = load(genome_dir, md5sums, ksize)
+    return None if got is None else {"values": got[0], "offsets": got[1]}
+
+
+def load(genome_dir: str, md5sums: Sequence[str], ksize: int) -> Optional[Tuple[np.ndarray, np.ndarray]]:
+    """(values, offsets) memory-mapped, or None when there is no packed set for exactly these references --
+    or when what is on disk does not agree with its own meta (sizes, digest of the offsets).  (A directory that holds the
+    packed form is unpacked here: callers that want the CSR; `yacht run` itself takes load_any.)"""
+    d = cache_dir(genome_dir)
+    try:
+        with open(os.path.join(d, "meta.json")) as f:
+            meta = json.load(f)
+        if int(meta["ksize"]) != int(ksize) or list(meta["md5sums"]) != list(md5sums):
+            return None
+        if "packed" in (meta.get("files") or {}):
+            got = load_any(genome_dir, md5sums, ksize)
+            if got is None:
+                return None
+            from .engine import csr_unpack
+
+            return csr_unpack(np.ascontiguousarray(got["packed"]))
         files = meta.get("files") or {"values": "values.npy", "offsets": "offsets.npy"}
         values = np.load(os.path.join(d, files["values"]), mmap_mode="r")
         offsets = np.load(os.path.join(d, files["offsets"]), mmap_mode="r")

@@ -133,6 +133,45 @@ def read_sketches_csr(paths: Sequence[str], threads: int = 1):
     return values, offsets
 
 
+def read_sketches_packed(paths: Sequence[str], threads: int = 1):
+    """(packed, offsets) of all files: the library's threaded reader as read_sketches_csr uses it, and the sketches packed straight
+    from the parsed files (yh_sig_batch_pack: ~5.7 instead of 8 bytes per hash, no CSR in between) -- what RefDB.from_packed
+    uploads and refdb_cache writes for `yacht run`.  (None, None) when some file's mins are not strictly ascending: the caller
+    takes read_sketches_csr, which is the path that says what is wrong (or, for the Python reader, repairs it)."""
+    import ctypes as C
+
+    from . import _lib
+
+    lib = _lib.load()
+    if _PARSED.get("handle") is not None and _PARSED.get("paths") == list(paths):
+        h = _PARSED["handle"]  # (left in place: a fallback to read_sketches_csr takes it from there)
+        own = False
+    else:
+        drop_parsed_sketches()
+        arr = (C.c_char_p * len(paths))(*[os.fsencode(p) for p in paths])
+        h = C.c_void_p()
+        _lib.check(lib.yh_sig_batch_read(arr, len(paths), max(1, int(threads)), C.byref(h)))
+        offer_parsed_sketches(list(paths), h)  # (so that a fallback does not read the files again)
+        own = True
+    status = np.zeros(max(len(paths), 1), dtype=np.uint8)
+    _lib.check(lib.yh_sig_batch_status(h, status.ctypes.data_as(C.c_void_p)))
+    if np.any(status[:len(paths)] == 2):
+        return None, None  # (read_sketches_csr raises the reference's error for it)
+    need = C.c_uint64(0)
+    rc = lib.yh_sig_batch_pack(h, None, 0, C.byref(need), max(1, int(threads)))
+    if rc == _lib.YH_ERR_UNSORTED:
+        return None, None
+    _lib.check(rc)
+    packed = np.zeros((int(need.value) + 7) // 8, dtype=np.uint64)
+    _lib.check(lib.yh_sig_batch_pack(h, packed.ctypes.data_as(C.c_void_p), packed.nbytes, C.byref(need), max(1, int(threads))))
+    for _ in np.flatnonzero(status[:len(paths)] == 1):
+        print("Could not open the file!", file=sys.stderr)
+    drop_parsed_sketches()
+    from .engine import packed_offsets
+
+    return packed, np.array(packed_offsets(packed), dtype=np.uint64)
+
+
 def run(file_list: str, working_directory: str, output_filename: str, threads: int = 1, passes: int = 1,
         containment_threshold: float = 0.9, device: int = 0, verbose: bool = False) -> dict:
     if threads < 1:
@@ -143,13 +182,23 @@ def run(file_list: str, working_directory: str, output_filename: str, threads: i
         raise ValueError("containment threshold must be between 0.0 and 1.0")
     with phases.phase("read_file_list"):
         paths = read_sketch_list(file_list)
+    # Round 6: the sketches go from the parsed files into the PACKED form (5.7 bytes per hash), which is what is uploaded
+    # (yh_db_create_packed expands it in HBM under the upload) and what the caller writes for `yacht run`; the plain CSR only
+    # for inputs the packer refuses (YACHT_TRAIN_CSR=1 forces it: tests compare the two).
+    packed = values = None
     with phases.phase("read_sig_files"):
-        values, offsets = read_sketches_csr(paths, threads)
+        if os.environ.get("YACHT_TRAIN_CSR") != "1":
+            packed, offsets = read_sketches_packed(paths, threads)
+        if packed is None:
+            values, offsets = read_sketches_csr(paths, threads)
     n = len(paths)
     sizes = np.diff(offsets).astype(np.uint32)
     empty = [int(i) for i in np.flatnonzero(sizes == 0)]
     with phases.phase("upload_and_index"):
-        db = RefDB(values, offsets, device=device, flags=YH_DB_PAIRWISE_ONLY)
+        if packed is not None:
+            db = RefDB.from_packed(packed, sizes=sizes, device=device, flags=YH_DB_PAIRWISE_ONLY)
+        else:
+            db = RefDB(values, offsets, device=device, flags=YH_DB_PAIRWISE_ONLY)
     with db:
         stats = db.index_stats()
         with phases.phase("pairwise"):
@@ -180,4 +229,4 @@ def run(file_list: str, working_directory: str, output_filename: str, threads: i
             for g in selected:
                 f.write(paths[int(g)] + "\n")
     return {"n": n, "empty": empty, "stats": stats, "n_pairs": int(pi.size), "selected": selected.tolist(),
-            "paths": paths, "values": values, "offsets": offsets}
+            "paths": paths, "values": values, "offsets": offsets, "packed": packed}

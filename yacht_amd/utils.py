@@ -402,7 +402,7 @@ def run_yacht_train_core(num_threads: int, ani_thresh: float, ksize: int, path_t
         row_of_path = {p: i for i, p in enumerate(core["paths"])}
         kept_names = [name for name, info in sig_info_dict.items() if info[-1] in selected_paths]
         keep = [row_of_path[sig_info_dict[name][-1]] for name in kept_names]
-    pending = refdb_cache.save_subset_async(path_to_temp_dir, ksize, core["values"], core["offsets"], keep)
+    pending = refdb_cache.save_subset_async(path_to_temp_dir, ksize, core["values"], core["offsets"], keep, packed=core.get("packed"))
     with phases.phase("manifest_of_the_selected"):
         rows = []
         for name in kept_names:
