@@ -859,6 +859,8 @@ def main() -> int:
     # yh_run_finish_range_device) are timed on its slice of the rotating samples -- everything but the collectives.
     scaling_model = None
 
+    block_samples = []
+
     def share_of(G, v_full, o_full, n_refs_, group=None, single_steps=True):
         """Rank 0's share of a G-way hash-range run of the database (v_full, o_full), built and timed on THIS GPU: both halves
         of a block of BM distinct samples through dist.BatchedRangeRunner -- the very object the N > 1 loop drives, here with a
@@ -892,8 +894,11 @@ def main() -> int:
             del cg
         BM = max(1, min(int(args.batch_block), 256))
         # the throughput form: BM distinct samples per block (the block of --block-mode batched), three blocks in flight
-        bsamp = [samples[i] if i < K else synth.global_db_sample_device(plan, args.seed + 7000 + i, n_sample=args.sample_hashes,
-                                                                       n_present=n_present, device=str(dev)) for i in range(BM)]
+        if len(block_samples) < BM:  # (made once: the same BM distinct samples for every G -- 248 x ~1e6 hashes at BM = 256)
+            block_samples.extend(samples[i] if i < K else synth.global_db_sample_device(plan, args.seed + 7000 + i, n_sample=args.sample_hashes,
+                                                                                      n_present=n_present, device=str(dev))
+                                 for i in range(len(block_samples), BM))
+        bsamp = block_samples[:BM]
         with torch.cuda.stream(stream):
             packed_b = hr.pack_batch(bsamp)
         seen = {}
