@@ -1,8 +1,8 @@
 #!/bin/bash
 # HERE (not on the GPU box), after `gpurun -- bash scripts/measure_session.sh`: only gpurun_out/ travels back, so the traffic files
 # bench.py / bench_train.py attach (keyed on the kernels' source) and the evidence the documents cite are copied into profiles/.
-# usage: bash scripts/adopt_session.sh [round tag, default r05]
-TAG=${1:-r05}
+# usage: bash scripts/adopt_session.sh [round tag, default r06]
+TAG=${1:-r06}
 cd "$(dirname "$0")/.." || exit 1
 for n in fused index stream train; do
   [ -f gpurun_out/traffic_${TAG}_$n.json ] && cp gpurun_out/traffic_${TAG}_$n.json profiles/traffic_${TAG}_$n.json

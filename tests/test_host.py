@@ -614,7 +614,7 @@ def test_pool_release_is_exported_and_harmless_without_a_gpu():
 
 
 def test_traffic_files_were_taken_from_this_source_of_the_kernels():
-    """profiles/traffic_r05_*.json carry the sha256 of the kernel sources their PMC passes ran on; bench.py / bench_train.py attach
+    """profiles/traffic_r06_*.json carry the sha256 of the kernel sources their PMC passes ran on; bench.py / bench_train.py attach
     `roofline.traffic` only when it matches.  A mismatch is not an error of the code -- the kernels were edited since the last
     measurement session -- so it skips, loudly, instead of failing: retake with scripts/measure_session.sh + adopt_session.sh."""
     import hashlib
@@ -632,7 +632,7 @@ def test_traffic_files_were_taken_from_this_source_of_the_kernels():
     want = {"fused": src(("yh_query.hip", "yh_common.h")), "train": src(("yh_sort.hip", "yh_pairwise.hip", "yh_common.h"))}
     stale = []
     for n, tag in want.items():
-        with open(os.path.join(root, "profiles", f"traffic_r05_{n}.json")) as f:
+        with open(os.path.join(root, "profiles", f"traffic_r06_{n}.json")) as f:
             if json.load(f)["source_tag"] != tag:
                 stale.append(n)
     if stale:
