@@ -19,6 +19,10 @@ SEED=9111 run YH_DEBUG_TUNING=1 YH_GROUP_CHAINS=1 YH_PC_P2F=0.6 YH_PC_TILE_ELEMS
 SEED=9112 run YH_DEBUG_TUNING=1 YH_NO_SPILL=1 YH_PC_P2F=5 YH_CHECK_SORT=1
 SEED=9113 run YH_DEBUG_TUNING=1 YH_PC_PAD=640 YH_FZ_NO_INLINE=1 YH_CHECK_SORT=1 YH_UPLOAD_CHUNK_MIN=1
 SEED=9114 run YH_DEBUG_TUNING=1 YH_NO_PIN=1 YH_UPLOAD_CHUNK_MIN=100000
+# round 6: the sparse row pass forced onto every train handle (default only above 28 672 references), alone and with list-only records
+SEED=9117 run YH_DEBUG_TUNING=1 YH_PAIR_SPARSE=1
+SEED=9118 run YH_DEBUG_TUNING=1 YH_PAIR_SPARSE=1 YH_FZ_NO_INLINE=1 YH_PAIR_SPARSE_GRID=3 YH_UPLOAD_CHUNK_MIN=1
+SEED=9119 run YH_DEBUG_TUNING=1 YH_BATCH_DENSE_FINAL=1 YH_PC_SK=3
 echo "== --packed YH_UPLOAD_CHUNK_MIN=1"; YH_DEBUG_TUNING=1 YH_UPLOAD_CHUNK_MIN=1 YH_CHECK_SORT=1 timeout $((S + 200)) python tests/tools/fuzz_parity.py --seconds "$S" --seed 9115 --packed 2>&1 | tail -1
 echo "== --packed (host-side unpacking of small databases)"; timeout $((S + 200)) python tests/tools/fuzz_parity.py --seconds $((S / 3 + 5)) --seed 9116 --packed 2>&1 | tail -1
 echo "== mix_calls 150 rounds"; timeout 900 python tests/tools/mix_calls.py 150 9106 2>&1 | tail -1

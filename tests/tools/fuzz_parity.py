@@ -134,17 +134,20 @@ def main() -> int:
                     half = sample[rng.random(sample.size) < 0.5]
                     absent = np.unique(rng.integers(1, 2 ** 62, size=int(rng.integers(1, 2000)), dtype=np.uint64))
                     batch = [sample, half, absent, np.zeros(0, np.uint64), sample]
-                    bo, be, bm = db.run_batch(batch)
+                    # round 6: up to 256 samples per pass (subset words in planes of 64 samples) -- the five patterns repeated in a
+                    # random order to a random batch size; the oracle sees each pattern once
+                    n_b = int(rng.choice([5, 5, 64, 65, 130, 200, 256])) if n <= 2000 else 5
+                    pick = list(range(5)) + [int(x) for x in rng.integers(0, 5, size=n_b - 5)]
+                    bo, be, bm = db.run_batch([batch[k] for k in pick])
                     zero = np.zeros(n, np.uint32)
                     expect = {0: (want, we, wm), 3: (zero, zero, zero), 4: (want, we, wm)}  # (the oracle saw these already)
-                    for k, s_k in enumerate(batch):
-                        if k in expect:
-                            w_ov, w_e, w_m = expect[k]
-                        else:
-                            w_ov = oracle.overlap(values, offsets, s_k)
-                            w_e, w_m = oracle.exclusive(values, offsets, w_ov > 0, s_k)
-                        assert np.array_equal(bo[k], w_ov) and np.array_equal(be[k], w_e) and np.array_equal(bm[k], w_m), \
-                            f"batched run, sample {k} of the batch"
+                    for k in (1, 2):
+                        w_ov = oracle.overlap(values, offsets, batch[k])
+                        expect[k] = (w_ov,) + tuple(oracle.exclusive(values, offsets, w_ov > 0, batch[k]))
+                    for pos, k in enumerate(pick):
+                        w_ov, w_e, w_m = expect[k]
+                        assert np.array_equal(bo[pos], w_ov) and np.array_equal(be[pos], w_e) and np.array_equal(bm[pos], w_m), \
+                            f"batched run, sample {pos} (pattern {k}) of a batch of {n_b}"
                 if values.size < 400_000:
                     wi, wj, wc, wstats = oracle.train_pairs(values, offsets, c, threads=4)
                     gi, gj, gc = db.pairwise(c)
