@@ -56,6 +56,9 @@ constexpr u32 PART_MAX_BINS = 1024;  // bins per level (LDS histogram)
 #endif
 constexpr u32 BKT_SLOT_BITS = YH_BKT_BITS;
 constexpr u32 BKT_CAP = 1u << BKT_SLOT_BITS;   // pairs a final bucket may hold
+#ifndef YH_GROUP_NT
+#define YH_GROUP_NT 1  // 1: k_bucket_group5 reads its pairs with non-temporal loads (adopted); 2: k_piece_part stores them so (measured worse)
+#endif
 #ifndef YH_BKT_FILL8
 #define YH_BKT_FILL8 5   // eighths of its capacity a bucket holds on average (tuning: scripts/sweep_fill.sh)
 #endif
@@ -756,8 +759,14 @@ __global__ void __launch_bounds__(BKT_THREADS) k_bucket_group5(const BucketArgs 
 #if defined(YH_ABLATE_GROUP) && (YH_ABLATE_GROUP & 16)  // timing-only build: not even the loads
         key[k] = (b * 0x9E3779B97F4A7C15ull + e * 0x7F4A7C15ull) >> 3; val[k] = e;
 #else
+#if YH_GROUP_NT & 1  // the bucket's pairs are read once: non-temporal, so that they do not push the record lines the XCD's L2 is
+        key[k] = __builtin_nontemporal_load(&a.in_k[b * a.cap_in + e]);   // collecting out before they are whole (round 6: the pass
+        // wrote 0.71 GB for 0.40 GB of records; with these 0.61 -- profiles/r06/sweep_group_nt.txt; the time is the same)
+        val[k] = __builtin_nontemporal_load(&a.in_v[b * a.stride_v + e]);
+#else
         key[k] = a.in_k[b * a.cap_in + e];
         val[k] = a.in_v[b * a.stride_v + e];
+#endif
 #endif
     }
     for (u32 i = tid; i < BKT_CAP / 4; i += BKT_THREADS) reinterpret_cast<uint4*>(tidx)[i] = make_uint4(0u, 0u, 0u, 0u);
@@ -776,7 +785,11 @@ __global__ void __launch_bounds__(BKT_THREADS) k_bucket_group5(const BucketArgs 
     for (u32 k = SPEC_ITEMS; k < BKT_ITEMS; ++k) {
         const u32 e = k * BKT_THREADS + tid;
         key[k] = 0; val[k] = 0;
+#if YH_GROUP_NT & 1
+        if (e < n) { key[k] = __builtin_nontemporal_load(&a.in_k[b * a.cap_in + e]); val[k] = __builtin_nontemporal_load(&a.in_v[b * a.stride_v + e]); }
+#else
         if (e < n) { key[k] = a.in_k[b * a.cap_in + e]; val[k] = a.in_v[b * a.stride_v + e]; }
+#endif
     }
 #pragma unroll
     for (u32 k = 0; k < BKT_ITEMS; ++k) {
@@ -1146,8 +1159,13 @@ __global__ void __launch_bounds__(PART_THREADS) k_piece_part(const PieceArgs a) 
 #if defined(YH_ABLATE_PART) && (YH_ABLATE_PART & 1)  // timing-only build: the pairs are not stored
                     if (skey[s] == 0x123456789abcdefull) a.out_a[bkt * a.stride_k + at] = skey[s] + sval[s];
 #else
+#if YH_GROUP_NT & 2  // (measured: the runs' stores no longer merge in the L2 -- 0.62 -> 1.08 GB written, +55 us)
+                    __builtin_nontemporal_store(skey[s], &a.out_a[bkt * a.stride_k + at]);
+                    __builtin_nontemporal_store(sval[s], &a.out_p[bkt * a.stride_v + at]);
+#else
                     a.out_a[bkt * a.stride_k + at] = skey[s];
                     a.out_p[bkt * a.stride_v + at] = sval[s];
+#endif
 #endif
                 }
             }
