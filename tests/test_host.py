@@ -637,3 +637,22 @@ def test_traffic_files_were_taken_from_this_source_of_the_kernels():
                 stale.append(n)
     if stale:
         pytest.skip(f"PMC traffic files are older than the kernels they describe: {stale} (bench lines will carry traffic = null)")
+
+
+def test_native_md5_of_a_sketch_equals_hashlib(tmp_path):
+    """Round 6: the scanner's MD5 (RFC 1321, unrolled) over str(ksize) + every hash in decimal -- sourmash's md5sum of a sketch -- against
+    hashlib for sketches of many sizes (every alignment of the 64-byte block buffer; the digits arrive a number at a time)."""
+    import hashlib
+
+    from yacht_amd import sigio, utils
+
+    rng = np.random.default_rng(66)
+    d = tmp_path / "signatures"
+    d.mkdir()
+    want = {}
+    for i, n in enumerate([1, 2, 3, 4, 5, 7, 13, 64, 65, 127, 128, 129, 1000, 3900, 6000] + [int(x) for x in rng.integers(1, 300, size=25)]):
+        m = np.unique(rng.integers(0, 18446744073709552 if i % 3 else 2 ** 64 - 1, size=n, dtype=np.uint64))
+        want[f"g{i}"] = hashlib.md5(("31" + "".join(str(int(x)) for x in m)).encode()).hexdigest()
+        sigio.write_sig(sigio.make_signature(m, ksize=31, scaled=1000, name=f"g{i}", abundances=np.ones(m.size, np.int64)), str(d / f"s{i}.sig"))
+    info = utils.collect_signature_info(3, 31, str(tmp_path))
+    assert {k: v[0] for k, v in info.items()} == want

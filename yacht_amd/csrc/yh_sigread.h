@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <fstream>
 #include <iostream>
 #include <sstream>
@@ -148,33 +149,54 @@ struct Md5 {  // RFC 1321, streaming
     unsigned char buf[64];
     size_t fill = 0;
     static uint32_t rol(uint32_t x, int s) { return (x << s) | (x >> (32 - s)); }
+    // One 64-byte block, fully unrolled (round 6: the table-driven loop with a four-way branch per step ran at 316 MB/s -- 0.22 of the
+    // 0.38 ms a 3 900-hash signature took to scan, md5 included; the ingest of 85 205 such members is CPU-bound on exactly that).
     void block(const unsigned char* p) {
-        static const uint32_t K[64] = {
-            0xd76aa478, 0xe8c7b756, 0x242070db, 0xc1bdceee, 0xf57c0faf, 0x4787c62a, 0xa8304613, 0xfd469501, 0x698098d8, 0x8b44f7af,
-            0xffff5bb1, 0x895cd7be, 0x6b901122, 0xfd987193, 0xa679438e, 0x49b40821, 0xf61e2562, 0xc040b340, 0x265e5a51, 0xe9b6c7aa,
-            0xd62f105d, 0x02441453, 0xd8a1e681, 0xe7d3fbc8, 0x21e1cde6, 0xc33707d6, 0xf4d50d87, 0x455a14ed, 0xa9e3e905, 0xfcefa3f8,
-            0x676f02d9, 0x8d2a4c8a, 0xfffa3942, 0x8771f681, 0x6d9d6122, 0xfde5380c, 0xa4beea44, 0x4bdecfa9, 0xf6bb4b60, 0xbebfbc70,
-            0x289b7ec6, 0xeaa127fa, 0xd4ef3085, 0x04881d05, 0xd9d4d039, 0xe6db99e5, 0x1fa27cf8, 0xc4ac5665, 0xf4292244, 0x432aff97,
-            0xab9423a7, 0xfc93a039, 0x655b59c3, 0x8f0ccc92, 0xffeff47d, 0x85845dd1, 0x6fa87e4f, 0xfe2ce6e0, 0xa3014314, 0x4e0811a1,
-            0xf7537e82, 0xbd3af235, 0x2ad7d2bb, 0xeb86d391};
-        static const int S[64] = {7, 12, 17, 22, 7, 12, 17, 22, 7, 12, 17, 22, 7, 12, 17, 22, 5, 9, 14, 20, 5, 9, 14, 20, 5, 9, 14, 20, 5, 9, 14, 20,
-                                  4, 11, 16, 23, 4, 11, 16, 23, 4, 11, 16, 23, 4, 11, 16, 23, 6, 10, 15, 21, 6, 10, 15, 21, 6, 10, 15, 21, 6, 10, 15, 21};
         uint32_t m[16];
-        for (int i = 0; i < 16; ++i) m[i] = (uint32_t)p[4 * i] | ((uint32_t)p[4 * i + 1] << 8) | ((uint32_t)p[4 * i + 2] << 16) | ((uint32_t)p[4 * i + 3] << 24);
+        memcpy(m, p, 64);  // (little-endian hosts: x86-64, the only target of this build)
         uint32_t A = a, B = b, C = c, D = d;
-        for (int i = 0; i < 64; ++i) {
-            uint32_t f;
-            int g;
-            if (i < 16) { f = (B & C) | (~B & D); g = i; }
-            else if (i < 32) { f = (D & B) | (~D & C); g = (5 * i + 1) & 15; }
-            else if (i < 48) { f = B ^ C ^ D; g = (3 * i + 5) & 15; }
-            else { f = C ^ (B | ~D); g = (7 * i) & 15; }
-            const uint32_t t = D;
-            D = C;
-            C = B;
-            B = B + rol(A + f + K[i] + m[g], S[i]);
-            A = t;
-        }
+#define YH_MD5_F(x, y, z) ((z) ^ ((x) & ((y) ^ (z))))
+#define YH_MD5_G(x, y, z) ((y) ^ ((z) & ((x) ^ (y))))
+#define YH_MD5_H(x, y, z) ((x) ^ (y) ^ (z))
+#define YH_MD5_I(x, y, z) ((y) ^ ((x) | ~(z)))
+#define YH_MD5_STEP(f, w, x, y, z, data, k, sh) w += f(x, y, z) + (data) + (k); w = rol(w, sh) + x;
+        YH_MD5_STEP(YH_MD5_F, A, B, C, D, m[0], 0xd76aa478u, 7)   YH_MD5_STEP(YH_MD5_F, D, A, B, C, m[1], 0xe8c7b756u, 12)
+        YH_MD5_STEP(YH_MD5_F, C, D, A, B, m[2], 0x242070dbu, 17)  YH_MD5_STEP(YH_MD5_F, B, C, D, A, m[3], 0xc1bdceeeu, 22)
+        YH_MD5_STEP(YH_MD5_F, A, B, C, D, m[4], 0xf57c0fafu, 7)   YH_MD5_STEP(YH_MD5_F, D, A, B, C, m[5], 0x4787c62au, 12)
+        YH_MD5_STEP(YH_MD5_F, C, D, A, B, m[6], 0xa8304613u, 17)  YH_MD5_STEP(YH_MD5_F, B, C, D, A, m[7], 0xfd469501u, 22)
+        YH_MD5_STEP(YH_MD5_F, A, B, C, D, m[8], 0x698098d8u, 7)   YH_MD5_STEP(YH_MD5_F, D, A, B, C, m[9], 0x8b44f7afu, 12)
+        YH_MD5_STEP(YH_MD5_F, C, D, A, B, m[10], 0xffff5bb1u, 17) YH_MD5_STEP(YH_MD5_F, B, C, D, A, m[11], 0x895cd7beu, 22)
+        YH_MD5_STEP(YH_MD5_F, A, B, C, D, m[12], 0x6b901122u, 7)  YH_MD5_STEP(YH_MD5_F, D, A, B, C, m[13], 0xfd987193u, 12)
+        YH_MD5_STEP(YH_MD5_F, C, D, A, B, m[14], 0xa679438eu, 17) YH_MD5_STEP(YH_MD5_F, B, C, D, A, m[15], 0x49b40821u, 22)
+        YH_MD5_STEP(YH_MD5_G, A, B, C, D, m[1], 0xf61e2562u, 5)   YH_MD5_STEP(YH_MD5_G, D, A, B, C, m[6], 0xc040b340u, 9)
+        YH_MD5_STEP(YH_MD5_G, C, D, A, B, m[11], 0x265e5a51u, 14) YH_MD5_STEP(YH_MD5_G, B, C, D, A, m[0], 0xe9b6c7aau, 20)
+        YH_MD5_STEP(YH_MD5_G, A, B, C, D, m[5], 0xd62f105du, 5)   YH_MD5_STEP(YH_MD5_G, D, A, B, C, m[10], 0x02441453u, 9)
+        YH_MD5_STEP(YH_MD5_G, C, D, A, B, m[15], 0xd8a1e681u, 14) YH_MD5_STEP(YH_MD5_G, B, C, D, A, m[4], 0xe7d3fbc8u, 20)
+        YH_MD5_STEP(YH_MD5_G, A, B, C, D, m[9], 0x21e1cde6u, 5)   YH_MD5_STEP(YH_MD5_G, D, A, B, C, m[14], 0xc33707d6u, 9)
+        YH_MD5_STEP(YH_MD5_G, C, D, A, B, m[3], 0xf4d50d87u, 14)  YH_MD5_STEP(YH_MD5_G, B, C, D, A, m[8], 0x455a14edu, 20)
+        YH_MD5_STEP(YH_MD5_G, A, B, C, D, m[13], 0xa9e3e905u, 5)  YH_MD5_STEP(YH_MD5_G, D, A, B, C, m[2], 0xfcefa3f8u, 9)
+        YH_MD5_STEP(YH_MD5_G, C, D, A, B, m[7], 0x676f02d9u, 14)  YH_MD5_STEP(YH_MD5_G, B, C, D, A, m[12], 0x8d2a4c8au, 20)
+        YH_MD5_STEP(YH_MD5_H, A, B, C, D, m[5], 0xfffa3942u, 4)   YH_MD5_STEP(YH_MD5_H, D, A, B, C, m[8], 0x8771f681u, 11)
+        YH_MD5_STEP(YH_MD5_H, C, D, A, B, m[11], 0x6d9d6122u, 16) YH_MD5_STEP(YH_MD5_H, B, C, D, A, m[14], 0xfde5380cu, 23)
+        YH_MD5_STEP(YH_MD5_H, A, B, C, D, m[1], 0xa4beea44u, 4)   YH_MD5_STEP(YH_MD5_H, D, A, B, C, m[4], 0x4bdecfa9u, 11)
+        YH_MD5_STEP(YH_MD5_H, C, D, A, B, m[7], 0xf6bb4b60u, 16)  YH_MD5_STEP(YH_MD5_H, B, C, D, A, m[10], 0xbebfbc70u, 23)
+        YH_MD5_STEP(YH_MD5_H, A, B, C, D, m[13], 0x289b7ec6u, 4)  YH_MD5_STEP(YH_MD5_H, D, A, B, C, m[0], 0xeaa127fau, 11)
+        YH_MD5_STEP(YH_MD5_H, C, D, A, B, m[3], 0xd4ef3085u, 16)  YH_MD5_STEP(YH_MD5_H, B, C, D, A, m[6], 0x04881d05u, 23)
+        YH_MD5_STEP(YH_MD5_H, A, B, C, D, m[9], 0xd9d4d039u, 4)   YH_MD5_STEP(YH_MD5_H, D, A, B, C, m[12], 0xe6db99e5u, 11)
+        YH_MD5_STEP(YH_MD5_H, C, D, A, B, m[15], 0x1fa27cf8u, 16) YH_MD5_STEP(YH_MD5_H, B, C, D, A, m[2], 0xc4ac5665u, 23)
+        YH_MD5_STEP(YH_MD5_I, A, B, C, D, m[0], 0xf4292244u, 6)   YH_MD5_STEP(YH_MD5_I, D, A, B, C, m[7], 0x432aff97u, 10)
+        YH_MD5_STEP(YH_MD5_I, C, D, A, B, m[14], 0xab9423a7u, 15) YH_MD5_STEP(YH_MD5_I, B, C, D, A, m[5], 0xfc93a039u, 21)
+        YH_MD5_STEP(YH_MD5_I, A, B, C, D, m[12], 0x655b59c3u, 6)  YH_MD5_STEP(YH_MD5_I, D, A, B, C, m[3], 0x8f0ccc92u, 10)
+        YH_MD5_STEP(YH_MD5_I, C, D, A, B, m[10], 0xffeff47du, 15) YH_MD5_STEP(YH_MD5_I, B, C, D, A, m[1], 0x85845dd1u, 21)
+        YH_MD5_STEP(YH_MD5_I, A, B, C, D, m[8], 0x6fa87e4fu, 6)   YH_MD5_STEP(YH_MD5_I, D, A, B, C, m[15], 0xfe2ce6e0u, 10)
+        YH_MD5_STEP(YH_MD5_I, C, D, A, B, m[6], 0xa3014314u, 15)  YH_MD5_STEP(YH_MD5_I, B, C, D, A, m[13], 0x4e0811a1u, 21)
+        YH_MD5_STEP(YH_MD5_I, A, B, C, D, m[4], 0xf7537e82u, 6)   YH_MD5_STEP(YH_MD5_I, D, A, B, C, m[11], 0xbd3af235u, 10)
+        YH_MD5_STEP(YH_MD5_I, C, D, A, B, m[2], 0x2ad7d2bbu, 15)  YH_MD5_STEP(YH_MD5_I, B, C, D, A, m[9], 0xeb86d391u, 21)
+#undef YH_MD5_STEP
+#undef YH_MD5_F
+#undef YH_MD5_G
+#undef YH_MD5_H
+#undef YH_MD5_I
         a += A; b += B; c += C; d += D;
     }
     void update(const char* p, size_t n) {
@@ -183,9 +205,13 @@ struct Md5 {  // RFC 1321, streaming
             while (n >= 64) { block((const unsigned char*)p); p += 64; n -= 64; }
         while (n) {
             const size_t k = std::min(n, sizeof buf - fill);
-            std::copy(p, p + k, buf + fill);
+            memcpy(buf + fill, p, k);
             fill += k; p += k; n -= k;
-            if (fill == 64) { block(buf); fill = 0; }
+            if (fill == 64) {
+                block(buf);
+                fill = 0;
+                while (n >= 64) { block((const unsigned char*)p); p += 64; n -= 64; }  // (whole blocks straight from the caller's bytes)
+            }
         }
     }
     std::string hex() {
