@@ -640,7 +640,9 @@ int yh_q_run_batch(yh_db* db, const u64* d_samples, const u64* d_soff, u32 n_sam
     if (total_hashes && db->n_distinct) {
         const u64 n_tiles = (total_hashes + BATCH_TILE - 1) / BATCH_TILE + n_samples;  // (a ragged tile per sample)
         if (n_tiles >> 31) { yh_set_error("batch too large"); return YH_ERR_INVALID_ARG; }
-        k_batch_lookup<<<(u32)std::min<u64>((n_tiles + 7) / 8 * 8, 16384), 256, 0, st>>>(d_samples, d_soff, n_samples, yh_dir_view(db),
+        static const long grid_env = [] { const char* e = yh_tune_env("YH_BATCH_GRID"); return e ? atol(e) : -1L; }();
+        const u64 grid_cap = grid_env < 0 ? 16384ull : grid_env == 0 ? (u64)0x7fffff00 : (u64)grid_env;  // (0: one workgroup per slot)
+        k_batch_lookup<<<(u32)std::min<u64>((n_tiles + 7) / 8 * 8, grid_cap), 256, 0, st>>>(d_samples, d_soff, n_samples, yh_dir_view(db),
                                                                                        db->d_po, db->d_pr, N, d_overlap, d_ovsh,
                                                                                        yh_filter_of(db), db->filter_mul);
     }
