@@ -641,7 +641,9 @@ int yh_q_run_batch(yh_db* db, const u64* d_samples, const u64* d_soff, u32 n_sam
         const u64 n_tiles = (total_hashes + BATCH_TILE - 1) / BATCH_TILE + n_samples;  // (a ragged tile per sample)
         if (n_tiles >> 31) { yh_set_error("batch too large"); return YH_ERR_INVALID_ARG; }
         static const long grid_env = [] { const char* e = yh_tune_env("YH_BATCH_GRID"); return e ? atol(e) : -1L; }();
-        const u64 grid_cap = grid_env < 0 ? 16384ull : grid_env == 0 ? (u64)0x7fffff00 : (u64)grid_env;  // (0: one workgroup per slot)
+        // (workgroups of the launch, each looping over its slots: 2 048 -- the resident set -- 19.5 us per sample of a block of 256 at
+        // rs214 scale, 4 096 16.5, 8 192 15.5, 16 384 14.8 (rounds 3-5), 32 768 14.2, one per slot 14.5: profiles/r06/sweep_batch_grid.txt)
+        const u64 grid_cap = grid_env < 0 ? 32768ull : grid_env == 0 ? (u64)0x7fffff00 : (u64)grid_env;  // (0: one workgroup per slot)
         k_batch_lookup<<<(u32)std::min<u64>((n_tiles + 7) / 8 * 8, grid_cap), 256, 0, st>>>(d_samples, d_soff, n_samples, yh_dir_view(db),
                                                                                        db->d_po, db->d_pr, N, d_overlap, d_ovsh,
                                                                                        yh_filter_of(db), db->filter_mul);
