@@ -7,3 +7,6 @@ for v in 0 1 2 3; do
   if [ $v = 0 ]; then unset YACHT_HIP_LIB; else export YACHT_HIP_LIB=$(python3 -c "from yacht_amd import build; print(build.build_variant('abl_batch_$v', {'YH_ABLATE_BATCH_READS': $v}))"); fi
   echo -n "YH_ABLATE_BATCH_READS=$v  "; python3 scripts/probes/batch_share_trace.py 1 12 256 2>&1 | grep "per block"
 done
+# ... and what one global atomic per hit costs (no LDS table: results right) -- what a window-major order of the lookups would need
+export YACHT_HIP_LIB=$(python3 -c "from yacht_amd import build; print(build.build_variant('batch_direct', {'YH_BATCH_DIRECT_ATOMICS': 1}))")
+echo -n "YH_BATCH_DIRECT_ATOMICS=1  "; python3 scripts/probes/batch_share_trace.py 1 12 256 2>&1 | grep "per block"

@@ -100,6 +100,11 @@ __global__ void __launch_bounds__(256) k_batch_lookup(const u64* __restrict__ sa
             return;
 #endif
             u32 slot = (ref * 2654435761u) >> (32 - BATCH_TBITS);
+#if defined(YH_BATCH_DIRECT_ATOMICS) && YH_BATCH_DIRECT_ATOMICS  // measurement build: one global atomic per hit, no LDS table (results right)
+            atomicAdd(&row[ref], 1u);
+            if (shared) atomicAdd(&row2[ref], 1u);
+            return;
+#endif
 #pragma unroll 1
             for (int probe = 0; probe < 2; ++probe, slot = (slot + 1) & (TSLOTS - 1)) {
                 const u32 old = atomicCAS(&tkey[slot], 0u, ref + 1);
