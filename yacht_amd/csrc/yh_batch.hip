@@ -203,6 +203,107 @@ __global__ void __launch_bounds__(256) k_batch_lookup(const u64* __restrict__ sa
     }
 }
 
+// ---- the same lookups in WINDOW-MAJOR order (round 6) ------------------------------------------------------------------------
+// k_batch_lookup reads one presence-filter word per sample hash from the L2 -- 30 % of its time at 256 samples per pass
+// (profiles/r06/ablate_batch_reads.txt: the pass without the filter read and with the buckets a perfect filter would leave takes
+// 2.2 of 3.7 ms; with the filter read and no bucket 1.3).  The filter's word is a monotone function of the hash, so the hashes of
+// ALL samples that fall into a WINDOW of BW_WORDS consecutive filter words are a contiguous slice of each sorted sample: a
+// workgroup stages its window in LDS once -- the whole filter is then read once per pass, coalesced: 162 MB for 2.6e8 lookups --
+// and walks the samples' slices against it, a wave per sample: the slice's start is the previous window's end (a cursor per
+// sample in LDS; the first from one binary search per sample and workgroup, which owns BW_PER_WG consecutive windows), its end
+// is where the wave's ascending hashes leave the window.  A hit is ONE global atomic (a (window, sample) pair holds ~27 hits on
+// as many references: nothing to combine).  Needs the compact buckets and the filter (every database of realistic size).
+constexpr u32 BW_WORDS = 4096;   // filter words per window: 16 KB of LDS
+#ifndef YH_BATCH_WIN_PER_WG
+#define YH_BATCH_WIN_PER_WG 4
+#endif
+constexpr u32 BW_PER_WG = YH_BATCH_WIN_PER_WG;
+__global__ void __launch_bounds__(256) k_batch_lookup_win(const u64* __restrict__ samples, const u64* __restrict__ soff, u32 n_samples,
+                                                          const YhDirView dv, const u64* __restrict__ po, const u32* __restrict__ pr, u64 n_refs,
+                                                          u32* __restrict__ overlap, u32* __restrict__ ovsh, const u32* __restrict__ filter,
+                                                          u64 filter_mul, u64 n_fwords) {
+    __shared__ u32 fw[BW_WORDS];
+    __shared__ u64 off[BATCH_MAX + 1];
+    __shared__ u32 cur[BATCH_MAX], cend[BATCH_MAX];
+    __shared__ u32 s_any;
+    const u32 lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    for (u32 q = threadIdx.x; q <= n_samples; q += 256) off[q] = soff[q];
+    if (threadIdx.x == 0) s_any = 0;
+    __syncthreads();
+    const u64 word0 = (u64)blockIdx.x * BW_PER_WG * BW_WORDS, word1 = min(word0 + (u64)BW_PER_WG * BW_WORDS, n_fwords);
+    // the samples' cursors: first hash whose filter word is >= word0 / >= word1 (a lane per sample; hashes above max_hash lie behind every window)
+    for (u32 sI = threadIdx.x; sI < n_samples; sI += 256) {
+        const u64* smp = samples + off[sI];
+        const u64 n_s = off[sI + 1] - off[sI];
+        auto first_at = [&](u64 word) -> u32 {
+            u64 lo = 0, hi = n_s;
+            while (lo < hi) {
+                const u64 mid = (lo + hi) >> 1;
+                const u64 h = smp[mid];
+                const bool before = h <= dv.max_hash && (yh_bucket_of(h, dv.bkt_lsh, filter_mul) >> 5) < word;
+                if (before) lo = mid + 1; else hi = mid;
+            }
+            return (u32)lo;
+        };
+        const u32 c0 = first_at(word0), c1 = word1 >= n_fwords ? first_at(~0ull >> 6) : first_at(word1);
+        cur[sI] = c0;
+        cend[sI] = c1;
+        if (c1 > c0) s_any = 1u;
+    }
+    __syncthreads();
+    if (!s_any) return;  // (uniform) no sample has a hash in these windows (a hash-range shard: most of the filter's range is another rank's)
+    for (u32 wi = 0; wi < BW_PER_WG; ++wi) {
+        const u64 wbeg = word0 + (u64)wi * BW_WORDS;
+        if (wbeg >= n_fwords) break;  // (uniform)
+        const u64 wend = min(wbeg + BW_WORDS, n_fwords);
+        for (u32 k = threadIdx.x; k < BW_WORDS; k += 256) fw[k] = wbeg + k < n_fwords ? filter[wbeg + k] : 0u;
+        __syncthreads();
+        for (u32 sI = wv; sI < n_samples; sI += 4) {  // (wave-uniform) a wave per sample
+            const u64* smp = samples + off[sI];
+            const u32 stop = cend[sI];
+            u32 k = cur[sI];
+            u32* row = overlap + (u64)sI * n_refs;
+            u32* row2 = ovsh + (u64)sI * n_refs;
+            while (k < stop) {  // (wave-uniform)
+                const u32 idx = k + lane;
+                const bool valid = idx < stop;
+                const u64 h = smp[valid ? idx : stop - 1];
+                const u64 bit = yh_bucket_of(h, dv.bkt_lsh, filter_mul);
+                const u64 word = bit >> 5;
+                const bool inwin = valid && word < wend;  // (>= wbeg: the cursor; the in-window lanes are a prefix: the hashes ascend)
+                const u32 c = (u32)__popcll(__ballot(inwin));
+                bool ok = false;
+                if (inwin) {
+                    const u32 m = yh_filter_mask(h, bit);
+                    ok = (fw[word - wbeg] & m) == m;
+                }
+                YhDirView::v4u a = YhDirView::v4u{0u, 0u, 0u, 0u}, b = a, cc = a, d = a;
+                if (ok) dv.cbkt_request(h, a, b, cc, d);
+                asm volatile("" : "+v"(a), "+v"(b), "+v"(cc), "+v"(d));  // (see YhDirView::find)
+                if (ok) {
+                    const u32 r = dv.cbkt_resolve(h, a, b, cc, d);
+                    if (r != YH_DIR_NONE) {
+                        if (!(r & 0x80000000u)) {
+                            atomicAdd(&row[r], 1u);
+                        } else {
+                            const u32 gi = r & 0x7fffffffu;
+                            for (u64 q = po[gi], qe = po[gi + 1]; q < qe; ++q) {
+                                const u32 ref = pr[q];
+                                atomicAdd(&row[ref], 1u);
+                                atomicAdd(&row2[ref], 1u);
+                            }
+                        }
+                    }
+                }
+                k += c;
+                if (c < 64u) break;  // the window ended inside these 64 hashes
+            }
+            if (lane == 0) cur[sI] = k;
+        }
+        __syncthreads();
+    }
+}
+
 // maskword[r] = samples with overlap > 0; anybits = "some sample overlaps r" (for k_batch_worklist)
 __global__ void __launch_bounds__(256) k_batch_maskwords(const u32* __restrict__ overlap, u32 n_samples, u64 n_refs,
                                                          u64* __restrict__ maskword, u32* __restrict__ anybits) {
@@ -657,6 +758,15 @@ int yh_q_run_batch(yh_db* db, const u64* d_samples, const u64* d_soff, u32 n_sam
     if (total_hashes && db->n_distinct) {
         const u64 n_tiles = (total_hashes + BATCH_TILE - 1) / BATCH_TILE + n_samples;  // (a ragged tile per sample)
         if (n_tiles >> 31) { yh_set_error("batch too large"); return YH_ERR_INVALID_ARG; }
+        // window-major order (k_batch_lookup_win) behind YH_BATCH_WIN=1 until it has been measured
+        static const int win_env = [] { const char* e = yh_tune_env("YH_BATCH_WIN"); return e ? atoi(e) : 0; }();
+        const u32* filt = yh_filter_of(db);
+        const u64 n_fwords = db->filter_bits / 32;
+        if (win_env && filt && db->d_cbkt && n_fwords && n_samples >= (u32)win_env) {
+            const u64 n_wg = (n_fwords + (u64)BW_PER_WG * BW_WORDS - 1) / ((u64)BW_PER_WG * BW_WORDS);
+            k_batch_lookup_win<<<(u32)n_wg, 256, 0, st>>>(d_samples, d_soff, n_samples, yh_dir_view(db), db->d_po, db->d_pr, N, d_overlap, d_ovsh,
+                                                          filt, db->filter_mul, n_fwords);
+        } else {
         static const long grid_env = [] { const char* e = yh_tune_env("YH_BATCH_GRID"); return e ? atol(e) : -1L; }();
         // (workgroups of the launch, each looping over its slots: 2 048 -- the resident set -- 19.5 us per sample of a block of 256 at
         // rs214 scale, 4 096 16.5, 8 192 15.5, 16 384 14.8 (rounds 3-5), 32 768 14.2, one per slot 14.5: profiles/r06/sweep_batch_grid.txt)
@@ -664,6 +774,7 @@ int yh_q_run_batch(yh_db* db, const u64* d_samples, const u64* d_soff, u32 n_sam
         k_batch_lookup<<<(u32)std::min<u64>((n_tiles + 7) / 8 * 8, grid_cap), 256, 0, st>>>(d_samples, d_soff, n_samples, yh_dir_view(db),
                                                                                        db->d_po, db->d_pr, N, d_overlap, d_ovsh,
                                                                                        yh_filter_of(db), db->filter_mul);
+        }
     }
     yh_ring_record_end(db, db->ev_overlap, st);
     // With a finish stream the first stream carries nothing but the clears and the lookups: the samples' subset words (and their
