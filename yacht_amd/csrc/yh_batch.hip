@@ -203,161 +203,16 @@ __global__ void __launch_bounds__(256) k_batch_lookup(const u64* __restrict__ sa
     }
 }
 
-// ---- the same lookups in WINDOW-MAJOR order (round 6) ------------------------------------------------------------------------
-// k_batch_lookup reads one presence-filter word per sample hash from the L2 -- 30 % of its time at 256 samples per pass
-// (profiles/r06/ablate_batch_reads.txt: the pass without the filter read and with the buckets a perfect filter would leave takes
-// 2.2 of 3.7 ms; with the filter read and no bucket 1.3).  The filter's word is a monotone function of the hash, so the hashes of
-// ALL samples that fall into a WINDOW of BW_WORDS consecutive filter words are a contiguous slice of each sorted sample: a
-// workgroup stages its window in LDS once -- the whole filter is then read once per pass, coalesced: 162 MB for 2.6e8 lookups --
-// and walks the samples' slices against it, a wave per sample: the slice's start is the previous window's end (a cursor per
-// sample in LDS; the first from one binary search per sample and workgroup, which owns BW_PER_WG consecutive windows), its end
-// is where the wave's ascending hashes leave the window.  A hit is ONE global atomic (a (window, sample) pair holds ~27 hits on
-// as many references: nothing to combine).  Needs the compact buckets and the filter (every database of realistic size).
-#ifndef YH_BATCH_WIN_WORDS
-#define YH_BATCH_WIN_WORDS 2048
-#endif
-constexpr u32 BW_WORDS = YH_BATCH_WIN_WORDS;   // filter words per window (8 KB of LDS: ~50 hashes of a 1e6-hash sample -- one wave step)
-#ifndef YH_BATCH_WIN_PER_WG
-#define YH_BATCH_WIN_PER_WG 8
-#endif
-constexpr u32 BW_PER_WG = YH_BATCH_WIN_PER_WG;
-#ifndef YH_BATCH_WIN_U
-#define YH_BATCH_WIN_U 4
-#endif
-constexpr int BW_U = YH_BATCH_WIN_U;           // samples a wave has in flight (their hashes, then their buckets, requested together)
-// the hash range the block's samples cover, as filter words: [range[0], range[1]) -- workgroups outside it return at once (a
-// hash-range shard's samples are slices of ONE eighth of the hash space, the filter spans all of it)
-__global__ void __launch_bounds__(256) k_batch_win_range(const u64* __restrict__ samples, const u64* __restrict__ soff, u32 n_samples, u64 max_hash,
-                                                         u32 lsh, u64 filter_mul, u64 n_fwords, u64* __restrict__ range) {
-    __shared__ unsigned long long lo_s, hi_s;
-    if (threadIdx.x == 0) { lo_s = ~0ull; hi_s = 0ull; }
-    __syncthreads();
-    for (u32 sI = threadIdx.x; sI < n_samples; sI += 256) {
-        const u64 a = soff[sI], e = soff[sI + 1];
-        if (e > a) {
-            const u64 h0 = samples[a];
-            if (h0 <= max_hash) atomicMin(&lo_s, (unsigned long long)(yh_bucket_of(h0, lsh, filter_mul) >> 5));
-            const u64 h1 = samples[e - 1];  // (a last hash above max_hash: everything up to the filter's end may be needed)
-            atomicMax(&hi_s, (unsigned long long)(h1 <= max_hash ? (yh_bucket_of(h1, lsh, filter_mul) >> 5) + 1 : n_fwords));
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) { range[0] = lo_s; range[1] = hi_s; }
-}
-__global__ void __launch_bounds__(256) k_batch_lookup_win(const u64* __restrict__ samples, const u64* __restrict__ soff, u32 n_samples,
-                                                          const YhDirView dv, const u64* __restrict__ po, const u32* __restrict__ pr, u64 n_refs,
-                                                          u32* __restrict__ overlap, u32* __restrict__ ovsh, const u32* __restrict__ filter,
-                                                          u64 filter_mul, u64 n_fwords, const u64* __restrict__ range) {
-    __shared__ u32 fw[BW_WORDS];
-    __shared__ u64 off[BATCH_MAX + 1];
-    __shared__ u32 cur[BATCH_MAX], cend[BATCH_MAX];
-    const u32 lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    const u64 word0 = (u64)blockIdx.x * BW_PER_WG * BW_WORDS, word1 = min(word0 + (u64)BW_PER_WG * BW_WORDS, n_fwords);
-    if (word1 <= range[0] || word0 >= range[1]) return;  // (uniform scalar loads) no sample has a hash in these windows
-    for (u32 q = threadIdx.x; q <= n_samples; q += 256) off[q] = soff[q];
-    __syncthreads();
-    // the samples' cursors: first hash whose filter word is >= word0 / >= word1 (a lane per sample; hashes above max_hash lie behind every window)
-    for (u32 sI = threadIdx.x; sI < n_samples; sI += 256) {
-        const u64* smp = samples + off[sI];
-        const u64 n_s = off[sI + 1] - off[sI];
-        auto first_at = [&](u64 word) -> u32 {
-            u64 lo = 0, hi = n_s;
-            while (lo < hi) {
-                const u64 mid = (lo + hi) >> 1;
-                const u64 h = smp[mid];
-                const bool before = h <= dv.max_hash && (yh_bucket_of(h, dv.bkt_lsh, filter_mul) >> 5) < word;
-                if (before) lo = mid + 1; else hi = mid;
-            }
-            return (u32)lo;
-        };
-        cur[sI] = first_at(word0);
-        cend[sI] = word1 >= n_fwords ? first_at(~0ull >> 6) : first_at(word1);
-    }
-    __syncthreads();
-    auto hits_of = [&](u32 r, u32* row, u32* row2) {
-        if (r == YH_DIR_NONE) return;
-        if (!(r & 0x80000000u)) {
-            atomicAdd(&row[r], 1u);
-        } else {
-            const u32 gi = r & 0x7fffffffu;
-            for (u64 q = po[gi], qe = po[gi + 1]; q < qe; ++q) {
-                const u32 ref = pr[q];
-                atomicAdd(&row[ref], 1u);
-                atomicAdd(&row2[ref], 1u);
-            }
-        }
-    };
-    for (u32 wi = 0; wi < BW_PER_WG; ++wi) {
-        const u64 wbeg = word0 + (u64)wi * BW_WORDS;
-        if (wbeg >= n_fwords) break;  // (uniform)
-        const u64 wend = min(wbeg + BW_WORDS, n_fwords);
-        for (u32 k = threadIdx.x; k < BW_WORDS; k += 256) fw[k] = wbeg + k < n_fwords ? filter[wbeg + k] : 0u;
-        __syncthreads();
-        // a wave takes BW_U samples at a time: their next 64 hashes are requested together, then their buckets -- a step of the wave
-        // is two memory latencies for BW_U x 64 lookups (one sample at a time the pass was 4.2 ms per block of 256 against 3.7 for
-        // the tile order: 64 samples x 2 steps x 2 latencies per wave and window)
-        for (u32 s0 = wv * BW_U; s0 < n_samples; s0 += 4 * BW_U) {  // (wave-uniform)
-            u64 h[BW_U];
-            u32 kk[BW_U], st[BW_U], cnt[BW_U];
-            bool ok[BW_U];
-#pragma unroll
-            for (int u = 0; u < BW_U; ++u) {
-                const u32 sI = s0 + u;
-                kk[u] = sI < n_samples ? cur[sI] : 0u;
-                st[u] = sI < n_samples ? cend[sI] : 0u;
-                const u32 idx = kk[u] + lane;
-                h[u] = idx < st[u] ? samples[off[sI] + idx] : ~0ull;
-            }
-            YhDirView::v4u a[BW_U], b[BW_U], cc[BW_U], d[BW_U];
-#pragma unroll
-            for (int u = 0; u < BW_U; ++u) {
-                const bool valid = kk[u] + lane < st[u];
-                const u64 bit = yh_bucket_of(h[u], dv.bkt_lsh, filter_mul);
-                const u64 word = bit >> 5;
-                const bool inwin = valid && word < wend;  // (>= wbeg: the cursor; the in-window lanes are a prefix: the hashes ascend)
-                cnt[u] = (u32)__popcll(__ballot(inwin));
-                ok[u] = false;
-                if (inwin) {
-                    const u32 m = yh_filter_mask(h[u], bit);
-                    ok[u] = (fw[word - wbeg] & m) == m;
-                }
-                a[u] = b[u] = cc[u] = d[u] = YhDirView::v4u{0u, 0u, 0u, 0u};
-                if (ok[u]) dv.cbkt_request(h[u], a[u], b[u], cc[u], d[u]);
-            }
-#pragma unroll
-            for (int u = 0; u < BW_U; ++u) asm volatile("" : "+v"(a[u]), "+v"(b[u]), "+v"(cc[u]), "+v"(d[u]));  // (see YhDirView::find)
-#pragma unroll
-            for (int u = 0; u < BW_U; ++u) {
-                const u32 sI = s0 + u;
-                if (sI >= n_samples) continue;  // (wave-uniform)
-                u32* row = overlap + (u64)sI * n_refs;
-                u32* row2 = ovsh + (u64)sI * n_refs;
-                if (ok[u]) hits_of(dv.cbkt_resolve(h[u], a[u], b[u], cc[u], d[u]), row, row2);
-                u32 k = kk[u] + cnt[u];
-                // the rare sample with more than 64 hashes in this window: the rest one wave step at a time
-                while (cnt[u] == 64u && k < st[u]) {  // (wave-uniform)
-                    const u32 idx = k + lane;
-                    const bool valid = idx < st[u];
-                    const u64 hx = valid ? samples[off[sI] + idx] : ~0ull;
-                    const u64 bit = yh_bucket_of(hx, dv.bkt_lsh, filter_mul);
-                    const u64 word = bit >> 5;
-                    const bool inwin = valid && word < wend;
-                    cnt[u] = (u32)__popcll(__ballot(inwin));
-                    bool okx = false;
-                    if (inwin) {
-                        const u32 m = yh_filter_mask(hx, bit);
-                        okx = (fw[word - wbeg] & m) == m;
-                    }
-                    if (okx) hits_of(dv.find(hx), row, row2);
-                    k += cnt[u];
-                }
-                if (lane == 0) cur[sI] = k;
-            }
-        }
-        __syncthreads();
-    }
-}
-
+// (Round 6, measured and dropped: the same lookups in WINDOW-MAJOR order.  The filter's word is a monotone function of the hash, so the
+// hashes of all samples that fall into a window of 2 048 consecutive filter words are a contiguous slice of each sorted sample; a
+// workgroup staged its window in LDS -- the whole filter then read ONCE per pass, coalesced, instead of one L2 read per sample
+// hash, which is 30 % of this pass: profiles/r06/ablate_batch_reads.txt -- and walked the samples' slices against it, a wave per
+// sample (then four samples in flight per wave), cursors per sample in LDS, one global atomic per hit (a (window, sample) pair
+// holds ~27 hits on as many references: nothing to combine; one atomic per hit costs the tile order +0.4 ms).  Bit-exact
+// (test_gpu_batch.py with it forced) and SLOWER: 4.10-4.17 ms per block of 256 samples against 3.62-3.71, and 1.23 against 0.71
+// for an eighth of the hash space: ~50 hashes of a sample per window are 512-byte reads scattered over 256 arrays, every
+// workgroup starts with 512 binary searches, and the lookups of one tile no longer share an LDS hit table.  Git history:
+// "batch lookup in window-major order".)
 // maskword[r] = samples with overlap > 0; anybits = "some sample overlaps r" (for k_batch_worklist)
 __global__ void __launch_bounds__(256) k_batch_maskwords(const u32* __restrict__ overlap, u32 n_samples, u64 n_refs,
                                                          u64* __restrict__ maskword, u32* __restrict__ anybits) {
@@ -812,17 +667,6 @@ int yh_q_run_batch(yh_db* db, const u64* d_samples, const u64* d_soff, u32 n_sam
     if (total_hashes && db->n_distinct) {
         const u64 n_tiles = (total_hashes + BATCH_TILE - 1) / BATCH_TILE + n_samples;  // (a ragged tile per sample)
         if (n_tiles >> 31) { yh_set_error("batch too large"); return YH_ERR_INVALID_ARG; }
-        // window-major order (k_batch_lookup_win) behind YH_BATCH_WIN=1 until it has been measured
-        static const int win_env = [] { const char* e = yh_tune_env("YH_BATCH_WIN"); return e ? atoi(e) : 0; }();
-        const u32* filt = yh_filter_of(db);
-        const u64 n_fwords = db->filter_bits / 32;
-        if (win_env && filt && db->d_cbkt && n_fwords && n_samples >= (u32)win_env) {
-            const u64 n_wg = (n_fwords + (u64)BW_PER_WG * BW_WORDS - 1) / ((u64)BW_PER_WG * BW_WORDS);
-            u64* d_range = reinterpret_cast<u64*>(bs.d_scratch) + batch_mask_words(db) - 2;  // (the slot's two spare words behind its mask words)
-            k_batch_win_range<<<1, 256, 0, st>>>(d_samples, d_soff, n_samples, db->max_hash, db->bkt_lsh, db->filter_mul, n_fwords, d_range);
-            k_batch_lookup_win<<<(u32)n_wg, 256, 0, st>>>(d_samples, d_soff, n_samples, yh_dir_view(db), db->d_po, db->d_pr, N, d_overlap, d_ovsh,
-                                                          filt, db->filter_mul, n_fwords, d_range);
-        } else {
         static const long grid_env = [] { const char* e = yh_tune_env("YH_BATCH_GRID"); return e ? atol(e) : -1L; }();
         // (workgroups of the launch, each looping over its slots: 2 048 -- the resident set -- 19.5 us per sample of a block of 256 at
         // rs214 scale, 4 096 16.5, 8 192 15.5, 16 384 14.8 (rounds 3-5), 32 768 14.2, one per slot 14.5: profiles/r06/sweep_batch_grid.txt)
@@ -830,7 +674,6 @@ int yh_q_run_batch(yh_db* db, const u64* d_samples, const u64* d_soff, u32 n_sam
         k_batch_lookup<<<(u32)std::min<u64>((n_tiles + 7) / 8 * 8, grid_cap), 256, 0, st>>>(d_samples, d_soff, n_samples, yh_dir_view(db),
                                                                                        db->d_po, db->d_pr, N, d_overlap, d_ovsh,
                                                                                        yh_filter_of(db), db->filter_mul);
-        }
     }
     yh_ring_record_end(db, db->ev_overlap, st);
     // With a finish stream the first stream carries nothing but the clears and the lookups: the samples' subset words (and their
