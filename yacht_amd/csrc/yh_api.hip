@@ -1519,8 +1519,14 @@ int yh_pairwise(yh_db* db, double c_thresh, uint64_t row_begin, uint64_t row_end
     if (!(c_thresh >= 0.0 && c_thresh <= 1.0)) { yh_set_error("containment threshold must be between 0.0 and 1.0"); return YH_ERR_INVALID_ARG; }
     YH_TRY(db_select(db));
     if (row_end > db->n_refs) row_end = db->n_refs;
-    if (!(db->pw_valid && db->pw_c == c_thresh && db->pw_r0 == row_begin && db->pw_r1 == row_end))
-        YH_TRY(yh_q_pairwise(db, c_thresh, row_begin, row_end));
+    if (!(db->pw_valid && db->pw_c == c_thresh && db->pw_r0 == row_begin && db->pw_r1 == row_end)) {
+        try {  // (the pass sizes host vectors by N and by the survivors: no exception crosses the C boundary)
+            YH_TRY(yh_q_pairwise(db, c_thresh, row_begin, row_end));
+        } catch (const std::bad_alloc&) {
+            yh_set_error("yh_pairwise: out of host memory");
+            return YH_ERR_OOM;
+        }
+    }
     *n_out = db->pw_n;
     if (cap == 0) return YH_OK;
     if (cap < db->pw_n) { yh_set_error("pair buffers hold %llu entries, %llu needed", (u64)cap, db->pw_n); return YH_ERR_CAPACITY; }

@@ -572,6 +572,7 @@ int yh_q_pairwise(yh_db* db, double c_thresh, u64 r0, u64 r1) {
     db->h_pw_i = db->h_pw_j = db->h_pw_c = nullptr;
     db->pw_n = 0;
     db->pw_valid = false;
+    db->pw_sparse_rows = db->pw_dense_rows = 0;  // (yh_pairwise_row_stats: of THIS call)
     if (r1 > N) r1 = N;
     auto done_empty = [&]() { db->pw_valid = true; db->pw_c = c_thresh; db->pw_r0 = r0; db->pw_r1 = r1; return YH_OK; };
     if (r0 >= r1 || P == 0) return done_empty();
