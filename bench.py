@@ -1079,23 +1079,31 @@ def main() -> int:
         }
 
     def roofline_indexed(k_ms, excl_ms):
-        alg_bytes = 72 * n_sample
+        # N > 1, batched blocks (the default there): ONE launch of k_batch_lookup looks up this rank's slices of all BB samples of a
+        # block -- BB x |S| / world hashes --, so the launch's bytes are counted for those (round 6: the line counted one sample's
+        # bytes against a block's launch -- frac 0.002)
+        batched_launch = bool(multi and hash_batched and rl_main[0])
+        launch_hashes = (BB * n_sample) // world if batched_launch else n_sample
+        alg_bytes = 72 * launch_hashes
         achieved = (alg_bytes / 1e9) / (k_ms / 1e3) if k_ms > 0 else 0.0
-        survey_rate = (survey_bytes / 1e9) / (k_ms / 1e3) if k_ms > 0 else 0.0
+        sv_bytes = survey_bytes + 8 * (launch_hashes - n_sample)
+        survey_rate = (sv_bytes / 1e9) / (k_ms / 1e3) if k_ms > 0 else 0.0
         return {
             # (every sample size takes a form of k_index_lookup_tile: yh_q_overlap_indexed)
-            "bound": "hbm", "kernel": "k_step_fused" if (args.pipelined_tail and not multi and rl_main[0]) else "k_index_lookup_tile",
+            "bound": "hbm", "kernel": "k_batch_lookup" if batched_launch else
+                                      "k_step_fused" if (args.pipelined_tail and not multi and rl_main[0]) else "k_index_lookup_tile",
+            "hashes_per_launch": launch_hashes,
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": None,
             "bytes_basis": "layout: one 64-byte bucket (random sector) + the 8-byte hash per SAMPLE hash; no reference hash is streamed. "
                            "The presence filter in front of the buckets trades most bucket reads of absent hashes for one filter "
                            "line each, so the measured traffic differs from this figure in both directions",
             "algorithmic_bytes_per_launch": alg_bytes,
-            "random_sectors_per_s": round(n_sample / (k_ms / 1e3), 1) if k_ms > 0 else 0.0,
+            "random_sectors_per_s": round(launch_hashes / (k_ms / 1e3), 1) if k_ms > 0 else 0.0,
             "random_sector_ceiling_per_s": 4.6e10,
             "ceiling_note": "scripts/probes/gather_probe.hip on this GPU: 4.6e10 independent 64-byte reads/s (2.9 TB/s) whatever the access form",
             "kernel_ms_avg": round(k_ms, 4), "exclusive_kernels_ms_avg": round(excl_ms, 4),
-            "survey_formula": {"bytes_per_launch": survey_bytes, "GBps": round(survey_rate, 1),
+            "survey_formula": {"bytes_per_launch": sv_bytes, "GBps": round(survey_rate, 1),
                                "frac": round(survey_rate / HBM_PEAK_GBS, 4),
                                "note": "8 B per reference hash as SURVEY.md 8d counts; this kernel reads none of them"},
         }
