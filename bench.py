@@ -169,6 +169,28 @@ def launch_ranks(args) -> int:
     return proc.returncode if proc.returncode != 0 or lines else 1
 
 
+def cpu_quota():
+    """CPUs the container may use at once (cgroup v2 cpu.max / v1 cfs quota), or None: the GPU boxes of this pool show 256 hardware
+    threads and grant 16 CPUs of them (`1600000 100000`) -- threads beyond the quota only take turns (profiles/r06/ingest_trace.txt)."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, p_ = f.read().split()[:2]
+        if q != "max" and float(p_) > 0:
+            return float(q) / float(p_)
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            q = float(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            p_ = float(f.read())
+        if q > 0 and p_ > 0:
+            return q / p_
+    except (OSError, ValueError):
+        pass
+    return None
+
+
 def cpu_model() -> str:
     try:
         with open("/proc/cpuinfo") as f:
@@ -1199,7 +1221,10 @@ def main() -> int:
             h_values = np.concatenate(parts)
             h_offsets = plan["offsets"].astype(np.uint64)
             del parts
-        cores = oracle.hardware_threads()
+        hw_threads = oracle.hardware_threads()
+        quota = cpu_quota()
+        # (threads = what the container may actually run at once: the box shows 256 hardware threads and grants 16 CPUs)
+        cores = max(1, min(hw_threads, int(quota))) if quota else hw_threads
         t_ov = t_ex = 0.0
         parity = True
         n_par = min(max(args.parity_samples, 1), K)
@@ -1230,7 +1255,9 @@ def main() -> int:
                 "cpu_model": cpu_model(),
                 "kind": "port",
                 "sample": f"{n_par} of the {K} samples against the whole database ({n_total} refs, {Hh} hashes): "
-                          f"overlap {t_ov:.2f} s on {cores} threads + exclusive {t_ex:.2f} s on 1 thread",
+                          f"overlap {t_ov:.2f} s on {cores} threads + exclusive {t_ex:.2f} s on 1 thread"
+                          + (f" (cgroup quota {quota:g} CPUs of {hw_threads} hardware threads)" if quota else ""),
+                "hardware_threads": hw_threads, "cpu_quota": quota,
             }
 
     stamp("cpu_baseline_and_parity")

@@ -28,6 +28,27 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
+def _cpu_quota():
+    """CPUs the container may use at once (cgroup v2 cpu.max / v1 cfs quota), or None."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, p_ = f.read().split()[:2]
+        if q != "max" and float(p_) > 0:
+            return float(q) / float(p_)
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            q = float(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            p_ = float(f.read())
+        if q > 0 and p_ > 0:
+            return q / p_
+    except (OSError, ValueError):
+        pass
+    return None
+
+
 def _cpu_model() -> str:
     try:
         with open("/proc/cpuinfo") as f:
@@ -320,7 +341,9 @@ def main() -> int:
         k = min(args.oracle_clusters, args.clusters) * 5
         v2, o2 = values[: int(offsets[k])], offsets[: k + 1]
         s2 = sizes[:k]
-        cores = oracle.hardware_threads()
+        hw_threads = oracle.hardware_threads()
+        quota = _cpu_quota()  # (the GPU boxes of this pool show 256 hardware threads and grant 16 CPUs: threads beyond that only take turns)
+        cores = max(1, min(hw_threads, int(quota))) if quota else hw_threads
         t0 = time.perf_counter()
         wi, wj, wc, wstats = oracle.train_pairs(v2, o2, c, threads=cores)
         wsel = oracle.train_select(s2, wi, wj)
@@ -337,7 +360,7 @@ def main() -> int:
         cpu = {"value": round(k * (k - 1) / 2 / t_cpu, 1), "unit": "pair-queries/s", "cores": cores, "kind": "port",
                "cpu_model": _cpu_model(),
                "sample": f"first {k} sketches ({int(o2[-1])} hashes): index build on 1 thread + scatter on {cores} "
-                         f"threads + selection, {t_cpu:.2f} s"}
+                         f"threads + selection, {t_cpu:.2f} s", "hardware_threads": hw_threads, "cpu_quota": quota}
         stamp("cpu_port_and_parity")
         # the GENUINE reference executable (oracle/_ref, built from /root/reference/src/cpp/main.cpp in the
         # build container and shipped as a binary): timed on the same sketches, and its files compared
@@ -364,7 +387,7 @@ def main() -> int:
                              f"{phases.get('build index', 0)} ms + matrix {phases.get('compute intersection matrix', 0)} ms "
                              f"+ selection {phases.get('do yacht train', 0)} ms (file reading {phases.get('read all sketches', 0)} ms "
                              f"not counted; whole process incl. writing the JSON inputs {t_ref:.1f} s)",
-                   "outputs_equal_hip_path": same,
+                   "outputs_equal_hip_path": same, "hardware_threads": hw_threads, "cpu_quota": quota,
                    "port_value": round(k * (k - 1) / 2 / t_cpu, 1)}
 
     stamp("genuine_reference_executable")
