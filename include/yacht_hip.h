@@ -158,7 +158,9 @@ int yh_csr_pack(const uint64_t* values, const uint64_t* offsets, uint64_t n_refs
 int yh_csr_unpack(const void* packed, uint64_t packed_bytes, uint64_t* values_out, uint64_t cap_hashes, uint64_t* offsets_out,
                   uint64_t cap_refs, uint64_t* n_hashes, uint64_t* n_refs);
 /* (ABI 8) rows[0 .. n_rows) of a packed CSR, in that order, as a packed CSR of their own (block entries re-based, payload words
- * copied as they are: no hash is decoded but each row's last block, for the largest hash).  Two-call sizing as yh_csr_pack. */
+ * copied as they are: no hash is decoded but each row's last block, for the largest hash).  Two-call sizing as yh_csr_pack.
+ * (What the reference does with the selection: src/yacht/make_training_data_from_sketches.py:107-155 keeps the selected
+ * signatures' files for `yacht run`, which re-opens them -- hypothesis_recovery_src.py:93,154,168.)                       */
 int yh_csr_subset(const void* packed, uint64_t packed_bytes, const uint64_t* rows, uint64_t n_rows, void* out, uint64_t cap_bytes,
                   uint64_t* out_bytes);
 int yh_db_create_packed(const void* packed, uint64_t packed_bytes, int device_id, uint32_t flags, yh_db** out);
@@ -509,7 +511,8 @@ int yh_sig_batch_sizes(const yh_sig_batch* batch, uint64_t* offsets);
 int yh_sig_batch_values(const yh_sig_batch* batch, uint64_t* values);
 /* (ABI 8) The same sketches as a PACKED CSR -- yh_db_create_packed's input, ~5.7 instead of 8 bytes per hash -- made from the
  * parsed files directly (two-call sizing as yh_csr_pack; YH_ERR_UNSORTED when some file's mins are not strictly ascending: the
- * caller takes yh_sig_batch_values then).  `yacht train` uploads this blob and writes the selected sketches of it for `yacht run`. */
+ * caller takes yh_sig_batch_values then).  `yacht train` uploads this blob and writes the selected sketches of it for `yacht run`.
+ * (Replaces, with yh_sig_batch_read, the reference's file stage src/cpp/main.cpp:62-124 -- JSON into vector<vector<hash_t>>.)      */
 int yh_sig_batch_pack(const yh_sig_batch* batch, void* packed, uint64_t cap_bytes, uint64_t* packed_bytes, int threads);
 int yh_sig_batch_destroy(yh_sig_batch* batch);
 
